@@ -1,0 +1,398 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_linalg.hpp header).  PARITY UNPINNED.
+//
+// orc_capi.cpp: extern "C" surface of the CPU oracle, loaded with ctypes by tests/ and by
+// bench.py's cpu_baseline leg.  Nothing in simple-mpc_amd/ links or loads this library.
+#include "../include/smpc_robots_builtin.h"
+#include "orc_mpc.hpp"
+#include <chrono>
+#include <cstring>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace orc;
+
+namespace
+{
+  Mat mat_from(const double * p, int r, int c)
+  {
+    Mat m(r, c);
+    std::memcpy(m.a.data(), p, sizeof(double) * (size_t)r * c);
+    return m;
+  }
+  void mat_to(const Mat & m, double * p) { std::memcpy(p, m.a.data(), sizeof(double) * m.a.size()); }
+  void vec_to(const Vec & v, double * p) { std::memcpy(p, v.data(), sizeof(double) * v.size()); }
+
+  StageRef make_ref(const KinoModel & md, unsigned mask, const double * u_ref, const double * x_tgt, const double * foot_ref)
+  {
+    StageRef r;
+    r.mask = mask;
+    r.u_ref.assign(u_ref, u_ref + md.nu);
+    r.x_tgt.assign(x_tgt, x_tgt + md.nx);
+    r.foot_ref.resize(md.nf);
+    for (int f = 0; f < md.nf; f++)
+      r.foot_ref[f] = v3(foot_ref[3 * f], foot_ref[3 * f + 1], foot_ref[3 * f + 2]);
+    return r;
+  }
+} // namespace
+
+extern "C"
+{
+  const smpc_robot_model * orc_builtin_robot(const char * name)
+  {
+    if (!std::strcmp(name, "go2_like"))
+      return &SMPC_ROBOT_GO2_LIKE;
+    if (!std::strcmp(name, "biped_like"))
+      return &SMPC_ROBOT_BIPED_LIKE;
+    return nullptr;
+  }
+  int orc_robot_dims(const smpc_robot_model * m, int * out) // nq nv nfeet njoints
+  {
+    out[0] = m->nq;
+    out[1] = m->nv;
+    out[2] = m->nfeet;
+    out[3] = m->njoints;
+    return 0;
+  }
+  void orc_robot_info(const smpc_robot_model * m, double * q_ref, double * q_lo, double * q_hi, double * mass)
+  {
+    for (int i = 0; i < m->nq; i++)
+      q_ref[i] = m->q_ref[i];
+    for (int i = 0; i < m->nv - 6; i++)
+    {
+      q_lo[i] = m->q_lo[i];
+      q_hi[i] = m->q_hi[i];
+    }
+    *mass = m->total_mass;
+  }
+
+  // ---- Lie group helpers ----
+  void orc_x_integrate(const smpc_robot_model * m, const double * x, const double * dx, double * out)
+  {
+    x_integrate(m->nq, m->nv, x, dx, out);
+  }
+  void orc_x_difference(const smpc_robot_model * m, const double * x0, const double * x1, double * out)
+  {
+    x_difference(m->nq, m->nv, x0, x1, out);
+  }
+  void orc_exp6(const double * nu, double * R9, double * p3)
+  {
+    SE3 M = exp6(nu);
+    std::memcpy(R9, M.R.m, 9 * sizeof(double));
+    std::memcpy(p3, M.p.x, 3 * sizeof(double));
+  }
+  void orc_log6(const double * R9, const double * p3, double * nu)
+  {
+    SE3 M;
+    std::memcpy(M.R.m, R9, 9 * sizeof(double));
+    std::memcpy(M.p.x, p3, 3 * sizeof(double));
+    log6(M, nu);
+  }
+  void orc_Jexp6(const double * nu, double * J36) { mat_to(Jexp6(nu), J36); }
+  void orc_Jlog6_of_exp(const double * nu, double * J36) { mat_to(Jlog6(exp6(nu)), J36); }
+
+  // ---- kinodynamics model ----
+  void * orc_kino_create(
+    const smpc_robot_model * m, double dt, const double * w_x, const double * w_u, const double * w_frame,
+    const double * w_cent, const double * w_centder, const double * qmin, const double * qmax, const double * gravity,
+    int kinematics_limits)
+  {
+    KinoSettings s;
+    const int ndx = 2 * m->nv, nu = m->nv - 6 + 3 * m->nfeet;
+    s.timestep = dt;
+    s.w_x = mat_from(w_x, ndx, ndx);
+    s.w_u = mat_from(w_u, nu, nu);
+    s.w_frame = mat_from(w_frame, 3, 3);
+    s.w_cent = mat_from(w_cent, 6, 6);
+    s.w_centder = mat_from(w_centder, 6, 6);
+    s.qmin.assign(qmin, qmin + m->nv - 6);
+    s.qmax.assign(qmax, qmax + m->nv - 6);
+    for (int i = 0; i < 3; i++)
+      s.gravity[i] = gravity[i];
+    s.kinematics_limits = kinematics_limits != 0;
+    return new KinoModel(m, s);
+  }
+  void orc_kino_destroy(void * h) { delete (KinoModel *)h; }
+  void orc_kino_dims(void * h, int * out) // nx ndx nu nc nf
+  {
+    KinoModel * md = (KinoModel *)h;
+    out[0] = md->nx;
+    out[1] = md->ndx;
+    out[2] = md->nu;
+    out[3] = md->nc;
+    out[4] = md->nf;
+  }
+  void orc_kino_eval(
+    void * h, unsigned mask, const double * u_ref, const double * x_tgt, const double * foot_ref, const double * x,
+    const double * u, double * xnext, double * xdot, double * cost, double * c)
+  {
+    KinoModel * md = (KinoModel *)h;
+    Rigid R(md->M);
+    StageRef r = make_ref(*md, mask, u_ref, x_tgt, foot_ref);
+    StageEval o;
+    md->eval(R, r, x, u, o);
+    vec_to(o.xnext, xnext);
+    vec_to(o.xdot, xdot);
+    *cost = o.cost;
+    vec_to(o.c, c);
+  }
+  void orc_kino_deriv(
+    void * h, unsigned mask, const double * u_ref, const double * x_tgt, const double * foot_ref, const double * x,
+    const double * u, double * A, double * B, double * lx, double * lu, double * Lxx, double * Lxu, double * Luu,
+    double * Cx, double * Cu)
+  {
+    KinoModel * md = (KinoModel *)h;
+    Rigid R(md->M);
+    StageRef r = make_ref(*md, mask, u_ref, x_tgt, foot_ref);
+    StageDer o;
+    md->deriv(R, r, x, u, o);
+    mat_to(o.A, A);
+    mat_to(o.B, B);
+    vec_to(o.lx, lx);
+    vec_to(o.lu, lu);
+    mat_to(o.Lxx, Lxx);
+    mat_to(o.Lxu, Lxu);
+    mat_to(o.Luu, Luu);
+    mat_to(o.Cx, Cx);
+    mat_to(o.Cu, Cu);
+  }
+  void orc_kino_term(void * h, const double * x_tgt, const double * x, double * cost, double * lx, double * Lxx)
+  {
+    KinoModel * md = (KinoModel *)h;
+    Rigid R(md->M);
+    Vec xt(x_tgt, x_tgt + md->nx);
+    *cost = md->term_eval(R, xt, x);
+    Vec l;
+    Mat L;
+    md->term_deriv(R, xt, x, l, L);
+    vec_to(l, lx);
+    mat_to(L, Lxx);
+  }
+  // centroidal quantities for physics identities: hg(6), Ag(6 x nv), dAg*v (6), com(3), feet(nf*3)
+  void orc_centroidal(
+    const smpc_robot_model * m, const double * x, double * hg, double * Ag, double * dAgv, double * com, double * feet)
+  {
+    Rigid R(m);
+    R.fk(x);
+    R.velocities(x + m->nq);
+    R.forces(x + m->nq, nullptr);
+    vec_to(sv_vec(R.hg()), hg);
+    mat_to(R.Ag(), Ag);
+    vec_to(sv_vec(R.dAg_v()), dAgv);
+    for (int i = 0; i < 3; i++)
+      com[i] = R.com[i];
+    for (int f = 0; f < m->nfeet; f++)
+      for (int i = 0; i < 3; i++)
+        feet[3 * f + i] = R.foot_p[f][i];
+  }
+
+  // ---- proximal Riccati on packed knots (row-major, stage-major) ----
+  void orc_riccati(
+    int H, int ndx, int nu, int nc, double mu, const double * Q, const double * S, const double * Rm, const double * q,
+    const double * r, const double * A, const double * B, const double * f, const double * C, const double * D,
+    const double * d, const double * QN, const double * qN, double * dxs, double * dus, double * dvs, double * dlams,
+    double * Ks)
+  {
+    std::vector<Knot> kn(H);
+    for (int t = 0; t < H; t++)
+    {
+      kn[t].Q = mat_from(Q + (size_t)t * ndx * ndx, ndx, ndx);
+      kn[t].S = mat_from(S + (size_t)t * ndx * nu, ndx, nu);
+      kn[t].R = mat_from(Rm + (size_t)t * nu * nu, nu, nu);
+      kn[t].A = mat_from(A + (size_t)t * ndx * ndx, ndx, ndx);
+      kn[t].B = mat_from(B + (size_t)t * ndx * nu, ndx, nu);
+      kn[t].C = mat_from(C + (size_t)t * nc * ndx, nc, ndx);
+      kn[t].D = mat_from(D + (size_t)t * nc * nu, nc, nu);
+      kn[t].q.assign(q + (size_t)t * ndx, q + (size_t)(t + 1) * ndx);
+      kn[t].r.assign(r + (size_t)t * nu, r + (size_t)(t + 1) * nu);
+      kn[t].f.assign(f + (size_t)t * ndx, f + (size_t)(t + 1) * ndx);
+      kn[t].d.assign(d + (size_t)t * nc, d + (size_t)(t + 1) * nc);
+    }
+    Mat QNm = mat_from(QN, ndx, ndx);
+    Vec qNv(qN, qN + ndx);
+    std::vector<Vec> dx, du, dv, dl;
+    std::vector<Mat> K;
+    prox_riccati(kn, QNm, qNv, mu, dx, du, dv, dl, &K);
+    for (int t = 0; t <= H; t++)
+    {
+      vec_to(dx[t], dxs + (size_t)t * ndx);
+      vec_to(dl[t], dlams + (size_t)t * ndx);
+    }
+    for (int t = 0; t < H; t++)
+    {
+      vec_to(du[t], dus + (size_t)t * nu);
+      vec_to(dv[t], dvs + (size_t)t * nc);
+      mat_to(K[t], Ks + (size_t)t * nu * ndx);
+    }
+  }
+
+  // ---- gait timer (integer KATs of tests/mpc.cpp:78-90) ----
+  void * orc_timer_create(const unsigned char * cs, int n, int nf, int H)
+  {
+    CycleTimer * t = new CycleTimer();
+    std::vector<std::vector<char>> v(n, std::vector<char>(nf));
+    for (int i = 0; i < n; i++)
+      for (int f = 0; f < nf; f++)
+        v[i][f] = cs[i * nf + f];
+    t->generate(v, H, nf);
+    return t;
+  }
+  void orc_timer_destroy(void * h) { delete (CycleTimer *)h; }
+  void orc_timer_recede(void * h) { ((CycleTimer *)h)->recede_cycle(); }
+  int orc_timer_get(void * h, int foot, int which, int * out, int cap) // which 0 takeoff 1 land
+  {
+    CycleTimer * t = (CycleTimer *)h;
+    const std::vector<int> & v = which ? t->land[foot] : t->takeoff[foot];
+    for (int i = 0; i < (int)v.size() && i < cap; i++)
+      out[i] = v[i];
+    return (int)v.size();
+  }
+  void orc_bezier8(const double * p0, const double * p1, double apex, float t, double * out)
+  {
+    V3 r = bezier8(v3(p0[0], p0[1], p0[2]), v3(p1[0], p1[1], p1[2]), apex, t);
+    for (int i = 0; i < 3; i++)
+      out[i] = r[i];
+  }
+
+  // ---- batched MPC ----
+  struct orc_mpc_settings
+  {
+    double swing_apex, support_force, TOL, mu_init, timestep;
+    int max_iters, num_threads, T_fly, T_contact, T;
+  };
+  void * orc_mpc_create(void * kino, const orc_mpc_settings * s, int B, double gravity_arg)
+  {
+    KinoModel * md = (KinoModel *)kino;
+    MPCSettings ms;
+    ms.swing_apex = s->swing_apex;
+    ms.support_force = s->support_force;
+    ms.TOL = s->TOL;
+    ms.mu_init = s->mu_init;
+    ms.timestep = s->timestep;
+    ms.max_iters = s->max_iters;
+    ms.num_threads = s->num_threads;
+    ms.T_fly = s->T_fly;
+    ms.T_contact = s->T_contact;
+    ms.T = s->T;
+#ifdef _OPENMP
+    if (s->num_threads > 0)
+      omp_set_num_threads(s->num_threads);
+#endif
+    return new BatchMPC(md->M, md->s, ms, s->T, B, gravity_arg);
+  }
+  void orc_mpc_destroy(void * h) { delete (BatchMPC *)h; }
+  void orc_mpc_generate_cycle(void * h, const unsigned char * cs, int n)
+  {
+    BatchMPC * m = (BatchMPC *)h;
+    std::vector<std::vector<char>> v(n, std::vector<char>(m->nf));
+    for (int i = 0; i < n; i++)
+      for (int f = 0; f < m->nf; f++)
+        v[i][f] = cs[i * m->nf + f];
+    m->generateCycleHorizon(v);
+  }
+  void orc_mpc_switch_to_walk(void * h, const double * v6) { ((BatchMPC *)h)->switchToWalk(v6); }
+  void orc_mpc_switch_to_stand(void * h) { ((BatchMPC *)h)->switchToStand(); }
+  void orc_mpc_set_x_reference(void * h, const double * x)
+  {
+    BatchMPC * m = (BatchMPC *)h;
+    m->x_reference.assign(x, x + m->md.nx);
+  }
+  double orc_mpc_iterate(void * h, const double * X)
+  {
+    auto t0 = std::chrono::steady_clock::now();
+    ((BatchMPC *)h)->iterate(X);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  // what: 0 xs [B][H+1][nx], 1 us [B][H][nu], 2 K0 [B][nu][ndx], 3 vs [B][H][nc], 4 lams [B][H+1][ndx],
+  //       5 foot refs [B][H][nf][3], 6 info [B][12], 7 xdot [B][H][2nv], 8 Ks [B][H][nu][ndx]
+  void orc_mpc_get(void * h, int what, double * out)
+  {
+    BatchMPC * m = (BatchMPC *)h;
+    const KinoModel & md = m->md;
+    const int H = m->H;
+    for (int b = 0; b < m->B; b++)
+    {
+      const SolverState & S = m->sol[b];
+      switch (what)
+      {
+      case 0:
+        for (int t = 0; t <= H; t++)
+          vec_to(S.xs[t], out + ((size_t)b * (H + 1) + t) * md.nx);
+        break;
+      case 1:
+        for (int t = 0; t < H; t++)
+          vec_to(S.us[t], out + ((size_t)b * H + t) * md.nu);
+        break;
+      case 2:
+        if (!S.Ks.empty())
+          mat_to(S.Ks[0], out + (size_t)b * md.nu * md.ndx);
+        break;
+      case 3:
+        for (int t = 0; t < H; t++)
+          vec_to(S.vs[t], out + ((size_t)b * H + t) * md.nc);
+        break;
+      case 4:
+        for (int t = 0; t <= H; t++)
+          vec_to(S.lams[t], out + ((size_t)b * (H + 1) + t) * md.ndx);
+        break;
+      case 5:
+        for (int t = 0; t < H; t++)
+          for (int f = 0; f < md.nf; f++)
+            for (int i = 0; i < 3; i++)
+              out[(((size_t)b * H + t) * md.nf + f) * 3 + i] = m->ocp[b].stages[t].foot_ref[f][i];
+        break;
+      case 6: {
+        const IterInfo & I = m->last_info[b];
+        double * o = out + (size_t)b * 12;
+        o[0] = I.phi0;
+        o[1] = I.dphi0;
+        o[2] = I.alpha;
+        o[3] = I.phi_new;
+        o[4] = I.prim_infeas;
+        o[5] = I.dual_infeas;
+        o[6] = I.ls_failed;
+        o[7] = S.preg;
+        o[8] = I.prim_new;
+        o[9] = I.cost;
+        o[10] = I.cost_new;
+        o[11] = I.ls_index;
+        break;
+      }
+      case 7:
+        for (int t = 0; t < H && t < (int)S.xdot.size(); t++)
+          vec_to(S.xdot[t], out + ((size_t)b * H + t) * 2 * md.nv);
+        break;
+      case 8:
+        for (int t = 0; t < H && t < (int)S.Ks.size(); t++)
+          mat_to(S.Ks[t], out + ((size_t)b * H + t) * md.nu * md.ndx);
+        break;
+      }
+    }
+  }
+  int orc_mpc_cold_iters(void * h) { return (int)((BatchMPC *)h)->cold_trace.size(); }
+  void orc_mpc_cold_trace(void * h, double * out) // [n][4]: phi0, prim, dual, alpha
+  {
+    BatchMPC * m = (BatchMPC *)h;
+    for (size_t i = 0; i < m->cold_trace.size(); i++)
+    {
+      out[4 * i] = m->cold_trace[i].phi0;
+      out[4 * i + 1] = m->cold_trace[i].prim_infeas;
+      out[4 * i + 2] = m->cold_trace[i].dual_infeas;
+      out[4 * i + 3] = m->cold_trace[i].alpha;
+    }
+  }
+  int orc_mpc_timing(void * h, int foot, int which, int * out, int cap)
+  {
+    return orc_timer_get(&((BatchMPC *)h)->timer, foot, which, out, cap);
+  }
+  // single ProxDDP iteration on explicit inputs, for stage-by-stage GPU parity:
+  // returns the LQ knots of iteration 1 for instance b (packed like orc_riccati inputs)
+  int orc_num_threads()
+  {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+  }
+}

@@ -1,0 +1,489 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_linalg.hpp header).  PARITY UNPINNED.
+//
+// orc_kino.hpp: the kinodynamics stage of the reference, restated.
+//   composition  : src/kinodynamics.cpp:40-152 (createStage), :352-364 (createTerminalCost)
+//   dynamics     : Aligator KinodynamicsFwdDynamics + IntegratorSemiImplEuler
+//                  (constructed at src/kinodynamics.cpp:85-88)  [UPSTREAM-RECALL, SURVEY App. B.2]
+//   costs        : state / control / centroidal / centroidal_derivative / <foot>_pose
+//                  (src/kinodynamics.cpp:60-83)
+//   constraints  : joint box (src/kinodynamics.cpp:91-101), LOCAL frame velocity = 0 per contact
+//                  foot (src/kinodynamics.cpp:110-133)
+// force_size == 3 (point feet) only; force_cone / land_cstr rows are not restated yet.
+#pragma once
+#include "orc_rigid.hpp"
+
+namespace orc
+{
+  struct KinoSettings // mirrors KinodynamicsSettings (include/simple-mpc/kinodynamics.hpp:24-51)
+  {
+    double timestep = 0.01;
+    Mat w_x, w_u, w_frame, w_cent, w_centder;
+    Vec qmin, qmax;
+    double gravity[3] = {0, 0, -9.81};
+    double mu = 0.8, Lfoot = 0.01, Wfoot = 0.01;
+    int force_size = 3;
+    bool kinematics_limits = true, force_cone = false, land_cstr = false;
+  };
+
+  enum RowKind
+  {
+    ROW_ABSENT = 0,
+    ROW_EQ = 1,
+    ROW_BOX = 2,
+    ROW_NEG = 3
+  };
+
+  struct StageRef
+  {
+    unsigned mask = 0xF;      // contact bit per foot
+    Vec u_ref;                // nu   (control_cost target, src/kinodynamics.cpp:61,229-240)
+    Vec x_tgt;                // nx   (state_cost target)
+    std::vector<V3> foot_ref; // nf   (<foot>_pose_cost references)
+  };
+
+  struct StageEval
+  {
+    Vec xnext, xdot, c;
+    double cost = 0;
+  };
+  struct StageDer
+  {
+    Mat A, B, Lxx, Lxu, Luu, Cx, Cu;
+    Vec lx, lu;
+  };
+
+  struct KinoModel
+  {
+    const smpc_robot_model * M;
+    KinoSettings s;
+    int nq, nv, nx, ndx, nu, nf, nc;
+    std::vector<int> row_kind_base; // per-row kind when present
+    Vec row_lo, row_hi;
+
+    KinoModel(const smpc_robot_model * m, const KinoSettings & st) : M(m), s(st)
+    {
+      nq = m->nq;
+      nv = m->nv;
+      nx = nq + nv;
+      ndx = 2 * nv;
+      nf = m->nfeet;
+      nu = nv - 6 + 3 * nf;
+      nc = (nv - 6) + 3 * nf;
+    }
+    // fixed row layout: rows [0, nv-6) joint box, rows nv-6+3f.. frame velocity of foot f
+    int row_kind(const StageRef & r, int row) const
+    {
+      if (row < nv - 6)
+        return s.kinematics_limits ? ROW_BOX : ROW_ABSENT;
+      int f = (row - (nv - 6)) / 3;
+      return ((r.mask >> f) & 1u) ? ROW_EQ : ROW_ABSENT;
+    }
+    double row_lo_v(int row) const { return row < nv - 6 ? s.qmin[row] : 0.0; }
+    double row_hi_v(int row) const { return row < nv - 6 ? s.qmax[row] : 0.0; }
+
+    // ---- continuous dynamics  xdot = (v, a) ----
+    // hdot target from contact forces: [m g + sum f ; sum (p_f - c) x f]
+    SV hdot_target(const Rigid & R, const StageRef & r, const double * u) const
+    {
+      SV hd{v3(R.mass * s.gravity[0], R.mass * s.gravity[1], R.mass * s.gravity[2]), v3(0, 0, 0)};
+      for (int f = 0; f < nf; f++)
+        if ((r.mask >> f) & 1u)
+        {
+          V3 F = v3(u[3 * f], u[3 * f + 1], u[3 * f + 2]);
+          hd.l = hd.l + F;
+          hd.a = hd.a + cross(R.foot_p[f] - R.com, F);
+        }
+      return hd;
+    }
+
+    // forward: fills R (fk, velocities, forces with the solved acceleration), returns a (nv)
+    Vec forward(Rigid & R, const StageRef & r, const double * x, const double * u, Mat * Agb_inv_out = nullptr) const
+    {
+      const double * q = x;
+      const double * v = x + nq;
+      R.fk(q);
+      R.velocities(v);
+      R.forces(v, nullptr);
+      SV b = R.dAg_v();
+      Mat Ag = R.Ag();
+      SV hd = hdot_target(R, r, u);
+      Vec rhs = sv_vec(hd - b);
+      const double * aj = u + 3 * nf;
+      for (int i = 0; i < 6; i++)
+        for (int k = 6; k < nv; k++)
+          rhs[i] -= Ag(i, k) * aj[k - 6];
+      Mat Agb(6, 6);
+      for (int i = 0; i < 6; i++)
+        for (int k = 0; k < 6; k++)
+          Agb(i, k) = Ag(i, k);
+      Mat Agb_inv = inverse(Agb);
+      Vec ab = mul(Agb_inv, rhs);
+      Vec a(nv);
+      for (int i = 0; i < 6; i++)
+        a[i] = ab[i];
+      for (int k = 6; k < nv; k++)
+        a[k] = aj[k - 6];
+      if (Agb_inv_out)
+        *Agb_inv_out = Agb_inv;
+      return a;
+    }
+
+    // da/dq, da/dv (nv x nv), da/du (nv x nu).  R must hold forward() results; recomputes forces.
+    void dforward(Rigid & R, const StageRef & r, const double * x, const double * u, const Vec & a, const Mat & Agb_inv,
+                  Mat & da_dq, Mat & da_dv, Mat & da_du, Mat * dh_dq_out = nullptr) const
+    {
+      const double * v = x + nq;
+      R.forces(v, a.data());
+      R.compute_Bc();
+      Mat dh_dq, dhdot_dq, dhdot_dv;
+      R.centroidal_derivatives(dh_dq, dhdot_dq, dhdot_dv);
+      if (dh_dq_out)
+        *dh_dq_out = dh_dq;
+      Mat Ag = R.Ag();
+      // d hdot_target / dq
+      Mat dtgt(6, nv);
+      for (int f = 0; f < nf; f++)
+        if ((r.mask >> f) & 1u)
+        {
+          V3 F = v3(u[3 * f], u[3 * f + 1], u[3 * f + 2]);
+          for (int k = 0; k < nv; k++)
+          {
+            V3 dp = R.Jfoot_col(f, k) - R.Jcom_col(k);
+            V3 t = cross(dp, F);
+            for (int i = 0; i < 3; i++)
+              dtgt(3 + i, k) += t[i];
+          }
+        }
+      Mat rq = dtgt;
+      add_inplace(rq, dhdot_dq, -1.0);
+      Mat ab_dq = mul(Agb_inv, rq);
+      Mat ab_dv = mul(Agb_inv, dhdot_dv);
+      da_dq.resize(nv, nv);
+      da_dv.resize(nv, nv);
+      da_du.resize(nv, nu);
+      for (int i = 0; i < 6; i++)
+        for (int k = 0; k < nv; k++)
+        {
+          da_dq(i, k) = ab_dq(i, k);
+          da_dv(i, k) = -ab_dv(i, k);
+        }
+      // forces
+      for (int f = 0; f < nf; f++)
+        if ((r.mask >> f) & 1u)
+        {
+          M3 X = skew(R.foot_p[f] - R.com);
+          Mat G(6, 3);
+          for (int i = 0; i < 3; i++)
+          {
+            G(i, i) = 1.0;
+            for (int j = 0; j < 3; j++)
+              G(3 + i, j) = X(i, j);
+          }
+          Mat AG = mul(Agb_inv, G);
+          for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 3; j++)
+              da_du(i, 3 * f + j) = AG(i, j);
+        }
+      // joint accelerations
+      Mat Agj(6, nv - 6);
+      for (int i = 0; i < 6; i++)
+        for (int k = 6; k < nv; k++)
+          Agj(i, k - 6) = Ag(i, k);
+      Mat AA = mul(Agb_inv, Agj);
+      for (int i = 0; i < 6; i++)
+        for (int k = 0; k < nv - 6; k++)
+          da_du(i, 3 * nf + k) = -AA(i, k);
+      for (int k = 0; k < nv - 6; k++)
+        da_du(6 + k, 3 * nf + k) = 1.0;
+    }
+
+    // ---- cost pieces ----
+    static double quad(const Mat & W, const Vec & r)
+    {
+      Vec Wr = mul(W, r);
+      return 0.5 * dot(r, Wr);
+    }
+
+    // Evaluate dynamics + cost + constraints at (x,u).
+    void eval(Rigid & R, const StageRef & r, const double * x, const double * u, StageEval & o) const
+    {
+      const double dt = s.timestep;
+      Vec a = forward(R, r, x, u);
+      o.xdot.assign(2 * nv, 0.0);
+      for (int i = 0; i < nv; i++)
+      {
+        o.xdot[i] = x[nq + i];
+        o.xdot[nv + i] = a[i];
+      }
+      // semi-implicit Euler: v+ = v + dt a ; q+ = q (+) dt v+
+      Vec dx(ndx);
+      for (int i = 0; i < nv; i++)
+      {
+        dx[nv + i] = dt * a[i];
+        dx[i] = dt * (x[nq + i] + dx[nv + i]);
+      }
+      o.xnext.assign(nx, 0.0);
+      x_integrate(nq, nv, x, dx.data(), o.xnext.data());
+      // costs
+      double cost = 0;
+      Vec rx(ndx);
+      x_difference(nq, nv, r.x_tgt.data(), x, rx.data());
+      cost += quad(s.w_x, rx);
+      Vec ru(nu);
+      for (int i = 0; i < nu; i++)
+        ru[i] = u[i] - r.u_ref[i];
+      cost += quad(s.w_u, ru);
+      cost += quad(s.w_cent, sv_vec(R.hg()));
+      cost += quad(s.w_centder, sv_vec(hdot_target(R, r, u)));
+      for (int f = 0; f < nf; f++)
+      {
+        V3 e = R.foot_p[f] - r.foot_ref[f];
+        cost += quad(s.w_frame, Vec{e[0], e[1], e[2]});
+      }
+      o.cost = cost;
+      // constraints
+      o.c.assign(nc, 0.0);
+      if (s.kinematics_limits)
+        for (int i = 0; i < nv - 6; i++)
+          o.c[i] = x[7 + i]; // (x (-) neutral)[6+i]
+      for (int f = 0; f < nf; f++)
+        if ((r.mask >> f) & 1u)
+        {
+          const int l = M->foot_joint[f];
+          V3 vw = R.vel[l].l + cross(R.vel[l].a, R.foot_p[f]);
+          V3 c = tr(R.oMi[l].R) * vw;
+          for (int i = 0; i < 3; i++)
+            o.c[nv - 6 + 3 * f + i] = c[i];
+        }
+    }
+
+    // Derivatives at (x,u): A,B, cost gradient + Gauss-Newton Hessian, constraint Jacobians.
+    void deriv(Rigid & R, const StageRef & r, const double * x, const double * u, StageDer & o) const
+    {
+      const double dt = s.timestep;
+      Mat Agb_inv;
+      Vec a = forward(R, r, x, u, &Agb_inv);
+      Mat da_dq, da_dv, da_du, dh_dq;
+      dforward(R, r, x, u, a, Agb_inv, da_dq, da_dv, da_du, &dh_dq);
+      // d(dx)/dx and d(dx)/du, dx = [dt (v + dt a); dt a]
+      Mat Dx(ndx, ndx), Du(ndx, nu);
+      for (int i = 0; i < nv; i++)
+      {
+        for (int k = 0; k < nv; k++)
+        {
+          Dx(nv + i, k) = dt * da_dq(i, k);
+          Dx(nv + i, nv + k) = dt * da_dv(i, k);
+          Dx(i, k) = dt * dt * da_dq(i, k);
+          Dx(i, nv + k) = dt * dt * da_dv(i, k);
+        }
+        Dx(i, nv + i) += dt;
+        for (int k = 0; k < nu; k++)
+        {
+          Du(nv + i, k) = dt * da_du(i, k);
+          Du(i, k) = dt * dt * da_du(i, k);
+        }
+      }
+      double nu6[6];
+      for (int i = 0; i < 6; i++)
+        nu6[i] = dt * (x[nq + i] + dt * a[i]);
+      Mat Je = Jexp6(nu6);                       // d (x (+) dx) / d dx, SE3 block
+      Mat Jq = action_matrix(inv(exp6(nu6)));    // d (x (+) dx) / d x, SE3 block
+      // transport: first 6 rows of Dx, Du get multiplied by Je
+      o.A.resize(ndx, ndx);
+      o.B.resize(ndx, nu);
+      for (int i = 0; i < ndx; i++)
+      {
+        for (int k = 0; k < ndx; k++)
+        {
+          double sacc;
+          if (i < 6)
+          {
+            sacc = 0;
+            for (int m = 0; m < 6; m++)
+              sacc += Je(i, m) * Dx(m, k);
+          }
+          else
+            sacc = Dx(i, k);
+          o.A(i, k) = sacc;
+        }
+        for (int k = 0; k < nu; k++)
+        {
+          double sacc;
+          if (i < 6)
+          {
+            sacc = 0;
+            for (int m = 0; m < 6; m++)
+              sacc += Je(i, m) * Du(m, k);
+          }
+          else
+            sacc = Du(i, k);
+          o.B(i, k) = sacc;
+        }
+      }
+      for (int i = 0; i < 6; i++)
+        for (int k = 0; k < 6; k++)
+          o.A(i, k) += Jq(i, k);
+      for (int i = 6; i < ndx; i++)
+        o.A(i, i) += 1.0;
+
+      // ---- costs ----
+      o.lx.assign(ndx, 0.0);
+      o.lu.assign(nu, 0.0);
+      o.Lxx.resize(ndx, ndx);
+      o.Lxu.resize(ndx, nu);
+      o.Luu.resize(nu, nu);
+      auto add_cost = [&](const Mat & W, const Vec & res, const Mat & Jx, const Mat * Ju) {
+        Vec Wr = mul(W, res);
+        axpy(o.lx, mulT(Jx, Wr));
+        Mat WJx = mul(W, Jx);
+        add_inplace(o.Lxx, mulTN(Jx, WJx));
+        if (Ju)
+        {
+          axpy(o.lu, mulT(*Ju, Wr));
+          Mat WJu = mul(W, *Ju);
+          add_inplace(o.Lxu, mulTN(Jx, WJu));
+          add_inplace(o.Luu, mulTN(*Ju, WJu));
+        }
+      };
+      { // state cost: r = x (-) x_tgt, J = blockdiag(Jlog6(Mt^-1 M), I)
+        Vec rx(ndx);
+        x_difference(nq, nv, r.x_tgt.data(), x, rx.data());
+        SE3 Mt{quat_to_R(r.x_tgt.data() + 3), v3(r.x_tgt[0], r.x_tgt[1], r.x_tgt[2])};
+        SE3 Mx{quat_to_R(x + 3), v3(x[0], x[1], x[2])};
+        Mat Jl = Jlog6(inv(Mt) * Mx);
+        Mat Jx = Mat::identity(ndx);
+        for (int i = 0; i < 6; i++)
+          for (int k = 0; k < 6; k++)
+            Jx(i, k) = Jl(i, k);
+        add_cost(s.w_x, rx, Jx, nullptr);
+      }
+      { // control cost
+        Vec ru(nu);
+        for (int i = 0; i < nu; i++)
+          ru[i] = u[i] - r.u_ref[i];
+        Vec Wr = mul(s.w_u, ru);
+        axpy(o.lu, Wr);
+        add_inplace(o.Luu, s.w_u);
+      }
+      Mat Ag = R.Ag();
+      { // centroidal momentum cost: r = hg(q,v)
+        Mat Jx(6, ndx);
+        for (int i = 0; i < 6; i++)
+          for (int k = 0; k < nv; k++)
+          {
+            Jx(i, k) = dh_dq(i, k);
+            Jx(i, nv + k) = Ag(i, k);
+          }
+        add_cost(s.w_cent, sv_vec(R.hg()), Jx, nullptr);
+      }
+      { // centroidal momentum derivative cost: r = hdot_target(q,u)
+        Mat Jx(6, ndx), Ju(6, nu);
+        for (int f = 0; f < nf; f++)
+          if ((r.mask >> f) & 1u)
+          {
+            V3 F = v3(u[3 * f], u[3 * f + 1], u[3 * f + 2]);
+            for (int k = 0; k < nv; k++)
+            {
+              V3 t = cross(R.Jfoot_col(f, k) - R.Jcom_col(k), F);
+              for (int i = 0; i < 3; i++)
+                Jx(3 + i, k) += t[i];
+            }
+            M3 X = skew(R.foot_p[f] - R.com);
+            for (int i = 0; i < 3; i++)
+            {
+              Ju(i, 3 * f + i) = 1.0;
+              for (int j = 0; j < 3; j++)
+                Ju(3 + i, 3 * f + j) = X(i, j);
+            }
+          }
+        add_cost(s.w_centder, sv_vec(hdot_target(R, r, u)), Jx, &Ju);
+      }
+      for (int f = 0; f < nf; f++)
+      { // foot translation cost
+        Mat Jx(3, ndx);
+        for (int k = 0; k < nv; k++)
+        {
+          V3 c = R.Jfoot_col(f, k);
+          for (int i = 0; i < 3; i++)
+            Jx(i, k) = c[i];
+        }
+        V3 e = R.foot_p[f] - r.foot_ref[f];
+        add_cost(s.w_frame, Vec{e[0], e[1], e[2]}, Jx, nullptr);
+      }
+      // ---- constraints ----
+      o.Cx.resize(nc, ndx);
+      o.Cu.resize(nc, nu);
+      if (s.kinematics_limits)
+        for (int i = 0; i < nv - 6; i++)
+          o.Cx(i, 6 + i) = 1.0;
+      for (int f = 0; f < nf; f++)
+        if ((r.mask >> f) & 1u)
+        {
+          V3 c;
+          Mat dq, dv;
+          R.foot_local_velocity(f, c, dq, dv);
+          for (int i = 0; i < 3; i++)
+            for (int k = 0; k < nv; k++)
+            {
+              o.Cx(nv - 6 + 3 * f + i, k) = dq(i, k);
+              o.Cx(nv - 6 + 3 * f + i, nv + k) = dv(i, k);
+            }
+        }
+    }
+
+    // ---- terminal cost: state (target x_tgt) + centroidal with 10 w_cent ----
+    double term_eval(Rigid & R, const Vec & x_tgt, const double * x) const
+    {
+      R.fk(x);
+      R.velocities(x + nq);
+      Vec rx(ndx);
+      x_difference(nq, nv, x_tgt.data(), x, rx.data());
+      Mat W10 = s.w_cent;
+      for (auto & e : W10.a)
+        e *= 10.0;
+      return quad(s.w_x, rx) + quad(W10, sv_vec(R.hg()));
+    }
+    void term_deriv(Rigid & R, const Vec & x_tgt, const double * x, Vec & lx, Mat & Lxx) const
+    {
+      R.fk(x);
+      R.velocities(x + nq);
+      Vec zero(nv, 0.0);
+      R.forces(x + nq, zero.data());
+      R.compute_Bc();
+      Mat dh_dq, d1, d2;
+      R.centroidal_derivatives(dh_dq, d1, d2);
+      Mat Ag = R.Ag();
+      lx.assign(ndx, 0.0);
+      Lxx.resize(ndx, ndx);
+      {
+        Vec rx(ndx);
+        x_difference(nq, nv, x_tgt.data(), x, rx.data());
+        SE3 Mt{quat_to_R(x_tgt.data() + 3), v3(x_tgt[0], x_tgt[1], x_tgt[2])};
+        SE3 Mx{quat_to_R(x + 3), v3(x[0], x[1], x[2])};
+        Mat Jl = Jlog6(inv(Mt) * Mx);
+        Mat Jx = Mat::identity(ndx);
+        for (int i = 0; i < 6; i++)
+          for (int k = 0; k < 6; k++)
+            Jx(i, k) = Jl(i, k);
+        Vec Wr = mul(s.w_x, rx);
+        axpy(lx, mulT(Jx, Wr));
+        add_inplace(Lxx, mulTN(Jx, mul(s.w_x, Jx)));
+      }
+      {
+        Mat W10 = s.w_cent;
+        for (auto & e : W10.a)
+          e *= 10.0;
+        Mat Jx(6, ndx);
+        for (int i = 0; i < 6; i++)
+          for (int k = 0; k < nv; k++)
+          {
+            Jx(i, k) = dh_dq(i, k);
+            Jx(i, nv + k) = Ag(i, k);
+          }
+        Vec Wr = mul(W10, sv_vec(R.hg()));
+        axpy(lx, mulT(Jx, Wr));
+        add_inplace(Lxx, mulTN(Jx, mul(W10, Jx)));
+      }
+    }
+  };
+} // namespace orc

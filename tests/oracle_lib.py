@@ -1,0 +1,331 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORC_DIR, "liborc.so")
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_bp = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    srcs = [os.path.join(ORC_DIR, f) for f in os.listdir(ORC_DIR) if f.endswith((".hpp", ".cpp"))]
+    srcs += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORC_DIR, "-s"])
+    return LIB_PATH
+
+
+class MpcSettingsC(C.Structure):
+    _fields_ = [
+        ("swing_apex", C.c_double),
+        ("support_force", C.c_double),
+        ("TOL", C.c_double),
+        ("mu_init", C.c_double),
+        ("timestep", C.c_double),
+        ("max_iters", C.c_int),
+        ("num_threads", C.c_int),
+        ("T_fly", C.c_int),
+        ("T_contact", C.c_int),
+        ("T", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.orc_builtin_robot.restype = vp
+    L.orc_builtin_robot.argtypes = [C.c_char_p]
+    L.orc_robot_dims.argtypes = [vp, _ip]
+    L.orc_robot_info.argtypes = [vp, _dp, _dp, _dp, _dp]
+    L.orc_x_integrate.argtypes = [vp, _dp, _dp, _dp]
+    L.orc_x_difference.argtypes = [vp, _dp, _dp, _dp]
+    L.orc_exp6.argtypes = [_dp, _dp, _dp]
+    L.orc_log6.argtypes = [_dp, _dp, _dp]
+    L.orc_Jexp6.argtypes = [_dp, _dp]
+    L.orc_Jlog6_of_exp.argtypes = [_dp, _dp]
+    L.orc_kino_create.restype = vp
+    L.orc_kino_create.argtypes = [vp, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int]
+    L.orc_kino_destroy.argtypes = [vp]
+    L.orc_kino_dims.argtypes = [vp, _ip]
+    L.orc_kino_eval.argtypes = [vp, C.c_uint, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_kino_deriv.argtypes = [vp, C.c_uint] + [_dp] * 14
+    L.orc_kino_term.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_centroidal.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_riccati.argtypes = [C.c_int] * 4 + [C.c_double] + [_dp] * 18
+    L.orc_timer_create.restype = vp
+    L.orc_timer_create.argtypes = [_bp, C.c_int, C.c_int, C.c_int]
+    L.orc_timer_destroy.argtypes = [vp]
+    L.orc_timer_recede.argtypes = [vp]
+    L.orc_timer_get.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
+    L.orc_bezier8.argtypes = [_dp, _dp, C.c_double, C.c_float, _dp]
+    L.orc_mpc_create.restype = vp
+    L.orc_mpc_create.argtypes = [vp, C.POINTER(MpcSettingsC), C.c_int, C.c_double]
+    L.orc_mpc_destroy.argtypes = [vp]
+    L.orc_mpc_generate_cycle.argtypes = [vp, _bp, C.c_int]
+    L.orc_mpc_switch_to_walk.argtypes = [vp, _dp]
+    L.orc_mpc_switch_to_stand.argtypes = [vp]
+    L.orc_mpc_set_x_reference.argtypes = [vp, _dp]
+    L.orc_mpc_iterate.restype = C.c_double
+    L.orc_mpc_iterate.argtypes = [vp, _dp]
+    L.orc_mpc_get.argtypes = [vp, C.c_int, _dp]
+    L.orc_mpc_cold_iters.argtypes = [vp]
+    L.orc_mpc_cold_trace.argtypes = [vp, _dp]
+    L.orc_mpc_timing.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
+    L.orc_num_threads.restype = C.c_int
+    _lib = L
+    return L
+
+
+class Robot:
+    def __init__(self, name="go2_like"):
+        L = lib()
+        self.ptr = L.orc_builtin_robot(name.encode())
+        assert self.ptr, name
+        d = np.zeros(4, np.int32)
+        L.orc_robot_dims(self.ptr, d)
+        self.nq, self.nv, self.nf, self.nj = (int(v) for v in d)
+        self.nx = self.nq + self.nv
+        self.ndx = 2 * self.nv
+        self.q_ref = np.zeros(self.nq)
+        self.q_lo = np.zeros(self.nv - 6)
+        self.q_hi = np.zeros(self.nv - 6)
+        m = np.zeros(1)
+        L.orc_robot_info(self.ptr, self.q_ref, self.q_lo, self.q_hi, m)
+        self.mass = float(m[0])
+        self.x_ref = np.concatenate([self.q_ref, np.zeros(self.nv)])
+
+    def integrate(self, x, dx):
+        out = np.zeros(self.nx)
+        lib().orc_x_integrate(self.ptr, np.ascontiguousarray(x, float), np.ascontiguousarray(dx, float), out)
+        return out
+
+    def difference(self, x0, x1):
+        out = np.zeros(self.ndx)
+        lib().orc_x_difference(self.ptr, np.ascontiguousarray(x0, float), np.ascontiguousarray(x1, float), out)
+        return out
+
+    def centroidal(self, x):
+        hg, Ag, dAgv, com, feet = np.zeros(6), np.zeros((6, self.nv)), np.zeros(6), np.zeros(3), np.zeros((self.nf, 3))
+        lib().orc_centroidal(self.ptr, np.ascontiguousarray(x, float), hg, Ag, dAgv, com, feet)
+        return dict(hg=hg, Ag=Ag, dAgv=dAgv, com=com, feet=feet)
+
+
+def go2_kino_settings(robot):
+    """KinodynamicsSettings of record: reference examples/go2_kinodynamics.py:42-85."""
+    nv = robot.nv
+    w_basepos = [0, 0, 100, 10, 10, 0]
+    w_legpos = [1, 1, 1]
+    w_basevel = [10, 10, 10, 10, 10, 10]
+    w_legvel = [0.1, 0.1, 0.1]
+    w_x = np.diag(np.array(w_basepos + w_legpos * 4 + w_basevel + w_legvel * 4, float))
+    w_u = np.diag(np.concatenate([np.ones(12) * 0.01, np.ones(nv - 6) * 1e-5]))
+    w_cent = np.diag([0.0, 0.0, 1.0, 0.1, 0.1, 10.0])
+    w_centder = np.diag([0.0, 0.0, 0.0, 0.1, 0.1, 0.1])
+    return dict(
+        timestep=0.01,
+        w_x=w_x,
+        w_u=w_u,
+        w_cent=w_cent,
+        w_centder=w_centder,
+        gravity=np.array([0.0, 0.0, -9.81]),
+        force_size=3,
+        w_frame=np.eye(3) * 2000.0,
+        qmin=robot.q_lo.copy(),
+        qmax=robot.q_hi.copy(),
+        mu=0.8,
+        Lfoot=0.01,
+        Wfoot=0.01,
+        kinematics_limits=True,
+        force_cone=False,
+        land_cstr=False,
+    )
+
+
+def go2_mpc_settings(robot, max_iters=1, num_threads=0):
+    """MPC settings of record: reference examples/go2_kinodynamics.py:96-106."""
+    return dict(
+        support_force=robot.mass * 9.81,
+        TOL=1e-4,
+        mu_init=1e-8,
+        max_iters=max_iters,
+        num_threads=num_threads,
+        swing_apex=0.15,
+        T_fly=30,
+        T_contact=10,
+        timestep=0.01,
+        T=50,
+    )
+
+
+def trot_cycle(T_ds=10, T_ss=30):
+    """Contact cycle of examples/go2_kinodynamics.py:111-139, order FL FR RL RR."""
+    quad = [1, 1, 1, 1]
+    lift_fl = [0, 1, 1, 0]
+    lift_fr = [1, 0, 0, 1]
+    cs = [quad] * T_ds + [lift_fl] * T_ss + [quad] * T_ds + [lift_fr] * T_ss
+    return np.array(cs, np.uint8)
+
+
+class Kino:
+    def __init__(self, robot, s):
+        L = lib()
+        self.robot = robot
+        self.s = s
+        c = lambda a: np.ascontiguousarray(a, float)
+        self.h = L.orc_kino_create(
+            robot.ptr, s["timestep"], c(s["w_x"]), c(s["w_u"]), c(s["w_frame"]), c(s["w_cent"]), c(s["w_centder"]),
+            c(s["qmin"]), c(s["qmax"]), c(s["gravity"]), int(s["kinematics_limits"]),
+        )
+        d = np.zeros(5, np.int32)
+        L.orc_kino_dims(self.h, d)
+        self.nx, self.ndx, self.nu, self.nc, self.nf = (int(v) for v in d)
+        self.nv = robot.nv
+
+    def eval(self, mask, u_ref, x_tgt, foot_ref, x, u):
+        c = lambda a: np.ascontiguousarray(a, float)
+        xnext, xdot, cost, cc = np.zeros(self.nx), np.zeros(2 * self.nv), np.zeros(1), np.zeros(self.nc)
+        lib().orc_kino_eval(self.h, mask, c(u_ref), c(x_tgt), c(foot_ref), c(x), c(u), xnext, xdot, cost, cc)
+        return dict(xnext=xnext, xdot=xdot, cost=float(cost[0]), c=cc)
+
+    def deriv(self, mask, u_ref, x_tgt, foot_ref, x, u):
+        c = lambda a: np.ascontiguousarray(a, float)
+        n, m, k = self.ndx, self.nu, self.nc
+        o = dict(
+            A=np.zeros((n, n)), B=np.zeros((n, m)), lx=np.zeros(n), lu=np.zeros(m), Lxx=np.zeros((n, n)),
+            Lxu=np.zeros((n, m)), Luu=np.zeros((m, m)), Cx=np.zeros((k, n)), Cu=np.zeros((k, m)),
+        )
+        lib().orc_kino_deriv(
+            self.h, mask, c(u_ref), c(x_tgt), c(foot_ref), c(x), c(u), o["A"], o["B"], o["lx"], o["lu"], o["Lxx"],
+            o["Lxu"], o["Luu"], o["Cx"], o["Cu"],
+        )
+        return o
+
+    def term(self, x_tgt, x):
+        c = lambda a: np.ascontiguousarray(a, float)
+        cost, lx, Lxx = np.zeros(1), np.zeros(self.ndx), np.zeros((self.ndx, self.ndx))
+        lib().orc_kino_term(self.h, c(x_tgt), c(x), cost, lx, Lxx)
+        return float(cost[0]), lx, Lxx
+
+
+def riccati(Q, S, R, q, r, A, B, f, Cm, D, d, QN, qN, mu):
+    H, ndx, nu = B.shape
+    nc = Cm.shape[1]
+    c = lambda a: np.ascontiguousarray(a, float)
+    dxs, dus, dvs, dlams = np.zeros((H + 1, ndx)), np.zeros((H, nu)), np.zeros((H, nc)), np.zeros((H + 1, ndx))
+    Ks = np.zeros((H, nu, ndx))
+    lib().orc_riccati(
+        H, ndx, nu, nc, mu, c(Q), c(S), c(R), c(q), c(r), c(A), c(B), c(f), c(Cm), c(D), c(d), c(QN), c(qN), dxs, dus,
+        dvs, dlams, Ks,
+    )
+    return dxs, dus, dvs, dlams, Ks
+
+
+class Timer:
+    def __init__(self, cs, H):
+        cs = np.ascontiguousarray(cs, np.uint8)
+        self.nf = cs.shape[1]
+        self.h = lib().orc_timer_create(cs, cs.shape[0], cs.shape[1], H)
+
+    def get(self, foot, which):
+        out = np.zeros(64, np.int32)
+        n = lib().orc_timer_get(self.h, foot, which, out, 64)
+        return [int(v) for v in out[:n]]
+
+    def recede(self):
+        lib().orc_timer_recede(self.h)
+
+
+class OracleMPC:
+    """Batched restatement of simple_mpc.MPC (reference: include/simple-mpc/mpc.hpp:55-197)."""
+
+    def __init__(self, kino, mpc_settings, B, gravity_arg=-9.81):
+        self.kino = kino
+        self.B = B
+        self.H = mpc_settings["T"]
+        s = MpcSettingsC(
+            mpc_settings["swing_apex"], mpc_settings["support_force"], mpc_settings["TOL"], mpc_settings["mu_init"],
+            mpc_settings["timestep"], mpc_settings["max_iters"], mpc_settings.get("num_threads", 0),
+            mpc_settings["T_fly"], mpc_settings["T_contact"], mpc_settings["T"],
+        )
+        self.h = lib().orc_mpc_create(kino.h, C.byref(s), B, gravity_arg)
+
+    def generateCycleHorizon(self, cs):
+        cs = np.ascontiguousarray(cs, np.uint8)
+        lib().orc_mpc_generate_cycle(self.h, cs, cs.shape[0])
+
+    def switchToWalk(self, v6):
+        lib().orc_mpc_switch_to_walk(self.h, np.ascontiguousarray(v6, float))
+
+    def switchToStand(self):
+        lib().orc_mpc_switch_to_stand(self.h)
+
+    def iterate(self, X):
+        X = np.ascontiguousarray(X, float)
+        assert X.shape == (self.B, self.kino.nx)
+        return lib().orc_mpc_iterate(self.h, X)
+
+    def _get(self, what, shape):
+        out = np.zeros(shape)
+        lib().orc_mpc_get(self.h, what, out)
+        return out
+
+    @property
+    def xs(self):
+        return self._get(0, (self.B, self.H + 1, self.kino.nx))
+
+    @property
+    def us(self):
+        return self._get(1, (self.B, self.H, self.kino.nu))
+
+    @property
+    def K0(self):
+        return self._get(2, (self.B, self.kino.nu, self.kino.ndx))
+
+    @property
+    def vs(self):
+        return self._get(3, (self.B, self.H, self.kino.nc))
+
+    @property
+    def lams(self):
+        return self._get(4, (self.B, self.H + 1, self.kino.ndx))
+
+    @property
+    def foot_refs(self):
+        return self._get(5, (self.B, self.H, self.kino.nf, 3))
+
+    @property
+    def info(self):
+        return self._get(6, (self.B, 12))
+
+    @property
+    def xdot(self):
+        return self._get(7, (self.B, self.H, 2 * self.kino.nv))
+
+    def cold_trace(self):
+        n = lib().orc_mpc_cold_iters(self.h)
+        out = np.zeros((n, 4))
+        lib().orc_mpc_cold_trace(self.h, out)
+        return out
+
+    def timing(self, foot, which):
+        out = np.zeros(64, np.int32)
+        n = lib().orc_mpc_timing(self.h, foot, which, out, 64)
+        return [int(v) for v in out[:n]]
