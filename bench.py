@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC control-steps/sec at fixed ProxDDP iterations, Go2 kinodynamics, H=50 (BASELINE.json).
+
+A "step" is one batched MPC::iterate (reference src/mpc.cpp:189-218) of B instances per GPU with exactly
+k ProxDDP iterations each; value = (instances x steps) / wall time, whole job.  Inputs (measured states)
+are resident in HBM when the timed region starts: the closed loop feeds back xs[1] + N(0, 1e-3^2) noise
+generated on the device.  Multi-GPU: one process per GPU, batch sharded by instance, no
+collective on the solve path (weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 4096] [--iters 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "simple-mpc_amd", "python"))
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix dense peak (public spec)
+
+
+def f_ric(ndx, nu, nc):
+    """Algorithmic FLOPs of the proximal Riccati backward+forward per (instance, stage, iteration): SURVEY 8(d)."""
+    return (4 * ndx**3 + 4 * ndx**2 * nu + 2 * ndx * nu**2 + (nu + nc) ** 3 / 3 + 2 * (nu + nc) ** 2 * (ndx + 1)
+            + 2 * ndx**2 * (nu + nc) + 2 * ndx * (nu + nc))
+
+
+def cpu_baseline(iters, seconds_budget=20.0):
+    """Oracle (CPU restatement, not Aligator) on the host cores, bounded sample of the same workload."""
+    import numpy as np
+    import mpc_setup as S
+    import oracle_lib as O
+
+    threads = O.lib().orc_num_threads()
+    B = max(threads * 2, 8)
+    om, rb, _ = S.make_oracle(B, max_iters=iters)
+    om.generateCycleHorizon(O.trot_cycle())
+    om.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = S.random_states(rb, B)
+    om.iterate(X)  # warm-up
+    X = om.xs[:, 1, :].copy()
+    t0 = time.time()
+    n = 0
+    while True:
+        om.iterate(X)
+        X = om.xs[:, 1, :].copy()
+        n += 1
+        if time.time() - t0 > seconds_budget or n >= 50:
+            break
+    dt = time.time() - t0
+    return {
+        "value": B * n / dt,
+        "unit": "control-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "CPU restatement (oracle/, not Aligator): %d instances x %d steps, k=%d, OpenMP over instances" % (B, n, iters),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--iters", type=int, default=3, help="ProxDDP iterations per control step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MPC engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as g
+
+    if rank == 0:
+        g.build_hip()
+    if dist is not None:
+        dist.barrier()
+    import mpc_setup as S
+    import oracle_lib as O
+
+    B = args.batch
+    gm, rb, _, _ = S.make_product(B, max_iters=args.iters, device_id=local_rank)
+    gm.generateCycleHorizon(O.trot_cycle())
+    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+
+    dev = torch.device("cuda", local_rank)
+    X0 = S.random_states(rb, B, seed=20240529 + rank)
+    X = torch.from_numpy(X0).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20240529 + rank)
+
+    def step():
+        gm.iterate_device(X.data_ptr())
+        gm.get_x_device(1, X.data_ptr())  # x_meas <- xs[1] (same stream, ordered after the solve)
+        gm.wait()
+        noise = torch.randn(X.shape, generator=gen, device=dev, dtype=torch.float64) * 1e-3
+        X.add_(noise)
+        q = X[:, 3:7]
+        q.div_(q.norm(dim=1, keepdim=True))
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        gm.set_profiling(True)
+        gm.reset_kernel_times()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kt = gm.kernel_times() if not args.no_profile else {}
+    info = gm.info
+    ok = bool(np.all(np.isfinite(info)))
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        H, ndx, nu, nc = gm.H, gm.ndx, gm.nu, gm.nc
+        out = {
+            "metric": "MPC control-steps/sec at fixed ProxDDP iters, Go2 kinodyn H=50",
+            "value": value,
+            "unit": "control-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "Go2 kinodynamics (go2_like table), H=%d, %d ProxDDP iters/step, batch=%d per GPU, trot 10/30/10/30, "
+                "closed loop x_meas = xs[1] + N(0,1e-3^2)" % (H, args.iters, B),
+                "global_batch": world * B,
+                "parallelism": "instance-sharded x%d, no collective on the solve path" % world,
+                "finite": ok,
+            },
+        }
+        if kt:
+            dom = max(kt, key=lambda k: kt[k][0])
+            ms_dom, calls = kt[dom]
+            avg_ms = ms_dom / max(calls, 1)
+            flops = B * H * f_ric(ndx, nu, nc) if dom == "riccati" else None
+            out["kernel_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}
+            out["kernel_share"] = {k: round(v[0] / max(1e-9, sum(x[0] for x in kt.values())), 3) for k, v in kt.items()}
+            if flops is not None:
+                achieved = flops / (avg_ms * 1e-3) / 1e12
+                out["roofline"] = {
+                    "bound": "mfma",
+                    "kernel": "riccati_body (proximal Riccati backward sweep)",
+                    "achieved": achieved,
+                    "peak": FP64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s",
+                    "frac": achieved / FP64_PEAK_TFLOPS,
+                    "traffic": None,
+                    "note": "FP64 dense peak (vector = matrix on MI355X); algorithmic FLOPs = B*H*F_ric(36,24,24) per launch",
+                }
+            else:
+                out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.iters)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,148 @@
+/*
+ * smpc.h -- C ABI of the MI355X batched locomotion-MPC engine (libsmpc_hip.so).
+ *
+ * Drop-in boundary for the hot path of Simple-Robotics/simple-mpc: `MPC::iterate()` and what it drives
+ * (reference src/mpc.cpp:189-218).  Plain pointers and sizes only; all arrays are row-major,
+ * instance-major ([B][...]), IEEE double.  Host C++ (simple-mpc_amd/csrc/simple_mpc.hpp) and the
+ * Python module `simple_mpc` bind these symbols; INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Every function returns 0 on success and a negative code on failure; smpc_last_error() then holds the
+ * message (the reference throws std::runtime_error at the same places: src/kinodynamics.cpp:175,235,
+ * 279,299; src/ocp-handler.cpp:28,32,76).
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef SMPC_H
+#define SMPC_H
+#include "smpc_robot.h"
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMPC_OK 0
+#define SMPC_ERR_INVALID (-1)
+#define SMPC_ERR_RUNTIME (-2)
+#define SMPC_ERR_NO_DEVICE (-3)
+
+typedef struct smpc_handle smpc_handle;
+
+/* KinodynamicsSettings: reference include/simple-mpc/kinodynamics.hpp:24-51 (same field names).
+ * Matrices are dense row-major: w_x (ndx x ndx), w_u (nu x nu), w_frame (3x3), w_cent, w_centder (6x6). */
+typedef struct smpc_kinodynamics_settings
+{
+  double timestep;
+  const double * w_x;
+  const double * w_u;
+  const double * w_frame;
+  const double * w_cent;
+  const double * w_centder;
+  const double * qmin;
+  const double * qmax;
+  double gravity[3];
+  double mu;
+  double Lfoot;
+  double Wfoot;
+  int force_size;
+  int kinematics_limits;
+  int force_cone;
+  int land_cstr;
+} smpc_kinodynamics_settings;
+
+/* MPCSettings: reference include/simple-mpc/mpc.hpp:29-49 (same field names). */
+typedef struct smpc_mpc_settings
+{
+  double swing_apex;
+  double support_force;
+  double TOL;
+  double mu_init;
+  int max_iters;
+  int num_threads; /* accepted for API compatibility; the GPU path ignores it */
+  int T_fly;
+  int T_contact;
+  int T;
+  double timestep;
+} smpc_mpc_settings;
+
+/* Built-in robot tables ("go2_like", "biped_like"); NULL if unknown.
+ * Replaces RobotModelHandler(model, "standing", base) + addPointFoot
+ * (reference src/robot-handler.cpp:12-60; examples/go2_kinodynamics.py:23-27). */
+const smpc_robot_model * smpc_builtin_robot(const char * name);
+
+const char * smpc_last_error(void);
+/* number of HIP devices visible (0 => every compute entry point fails loudly) */
+int smpc_device_count(void);
+
+/* KinodynamicsOCP(settings, model) + createProblem(x_ref, T, force_size, gravity, false) + MPC(settings, ocp):
+ * reference src/kinodynamics.cpp:29-38, src/ocp-handler.cpp:96-137, src/mpc.cpp:19-99.
+ * `gravity_arg` is the 4th argument of createProblem (its sign convention differs between callers,
+ * SURVEY App. C.8).  Performs the cold solve (<= 100 ProxDDP iterations). */
+int smpc_create(
+  const smpc_robot_model * robot, const smpc_kinodynamics_settings * ocp, const smpc_mpc_settings * mpc, int batch,
+  double gravity_arg, int device_id, smpc_handle ** out);
+int smpc_destroy(smpc_handle * h);
+
+/* dims[0..7] = nq, nv, nx, ndx, nu, nc, nfeet, H */
+int smpc_get_dims(const smpc_handle * h, int * dims);
+
+/* MPC::generateCycleHorizon (reference src/mpc.cpp:101-187). contact_states: [n_states][nfeet], 0/1. */
+int smpc_generate_cycle_horizon(smpc_handle * h, const uint8_t * contact_states, int n_states);
+/* MPC::switchToWalk / switchToStand (reference src/mpc.cpp:382-392) */
+int smpc_switch_to_walk(smpc_handle * h, const double * velocity_base6);
+int smpc_switch_to_stand(smpc_handle * h);
+/* MPC::x_reference_ (public member, reference include/simple-mpc/mpc.hpp:191) */
+int smpc_set_x_reference(smpc_handle * h, const double * x_ref);
+
+/* MPC::iterate for the whole batch (reference src/mpc.cpp:189-218). X: [B][nx] measured states (host).
+ * Synchronous: returns when the solve is complete. */
+int smpc_iterate(smpc_handle * h, const double * X);
+/* Same with X already resident in HBM; asynchronous on the handle's stream (pair with smpc_wait). */
+int smpc_iterate_device(smpc_handle * h, const double * X_device);
+int smpc_wait(smpc_handle * h);
+/* xs_[t] of every instance into a dense device buffer [B][nx]; asynchronous on the handle's stream.
+ * Lets a closed loop keep the measured states resident in HBM (x_meas = xs[1] + noise). */
+int smpc_get_x_device(smpc_handle * h, int t, double * out_device);
+
+/* MPC::xs_ / us_ / Ks_ (reference include/simple-mpc/mpc.hpp:187-189; filled at src/mpc.cpp:215-217).
+ * out: xs [B][H+1][nx], us [B][H][nu], K0 [B][nu][ndx], Ks [B][H][nu][ndx] */
+int smpc_get_xs(smpc_handle * h, double * out);
+int smpc_get_us(smpc_handle * h, double * out);
+int smpc_get_K0(smpc_handle * h, double * out);
+int smpc_get_Ks(smpc_handle * h, double * out);
+/* solver multipliers (results_.vs / results_.lams): vs [B][H][nc], lams [B][H+1][ndx] (lams[0] = 0) */
+int smpc_get_vs(smpc_handle * h, double * out);
+int smpc_get_lams(smpc_handle * h, double * out);
+/* MPC::getStateDerivative(t) for t = 0,1 (reference src/mpc.cpp:346-352). out: [B][2][2 nv] */
+int smpc_get_state_derivative01(smpc_handle * h, double * out);
+/* MPC::getReferencePose(t, foot).translation() for all t, feet (reference src/mpc.cpp:336-339). out: [B][H][nfeet][3] */
+int smpc_get_reference_poses(smpc_handle * h, double * out);
+/* MPC::foot_takeoff_times_ / foot_land_times_ (reference include/simple-mpc/mpc.hpp:184-185). which: 0 takeoff, 1 land.
+ * Returns the number of entries (<= cap copied). */
+int smpc_get_foot_timing(smpc_handle * h, int foot, int which, int * out, int cap);
+/* per-instance solver scalars of the last iteration, [B][16]:
+ * phi0, dphi0, alpha, phi_new, prim_infeas, dual_infeas, ls_failed, preg, prim_new, cost, cost_new, ls_index */
+int smpc_get_info(smpc_handle * h, double * out);
+/* cold-solve trace of the constructor: returns n iterations; out [n][4] = phi0, prim, dual, alpha (cap rows) */
+int smpc_get_cold_trace(smpc_handle * h, double * out, int cap);
+
+/* test / debug access to one LQ knot (stage t of instance inst) as assembled by the stage kernel in the
+ * LAST iteration: out must hold smpc_lq_size() doubles, laid out A,B,Q,S,R,C,q,r,f,d,lx,lu,lpd,vpd */
+int smpc_lq_size(const smpc_handle * h);
+int smpc_debug_get_lq(smpc_handle * h, int inst, int t, double * out);
+/* last line-search steps: dxs [B][H+1][ndx], dus [B][H][nu] */
+int smpc_debug_get_steps(smpc_handle * h, double * dxs, double * dus);
+/* terminal node of the last iteration for one instance: QN [ndx][ndx], qN [ndx] */
+int smpc_debug_get_terminal(smpc_handle * h, int inst, double * QN, double * qN);
+
+/* profiling: when enabled every kernel launch is bracketed by HIP events on the handle's stream.
+ * smpc_get_kernel_times: ms[7], calls[7] for recede, deriv, riccati, forward, trial, select, apply. */
+int smpc_set_profiling(smpc_handle * h, int enabled);
+int smpc_get_kernel_times(smpc_handle * h, double * ms, long * calls);
+int smpc_reset_kernel_times(smpc_handle * h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -369,6 +369,32 @@ extern "C"
       }
     }
   }
+  void orc_mpc_keep_knots(void * h, int on)
+  {
+    BatchMPC * m = (BatchMPC *)h;
+    m->keep_knots = on != 0;
+    m->last_knots.assign(m->B, std::vector<Knot>());
+  }
+  // LQ knot (b, t) of the last iteration, packed A,B,Q,S,R,C,q,r,f,d (row-major)
+  int orc_mpc_get_knot(void * h, int b, int t, double * out)
+  {
+    BatchMPC * m = (BatchMPC *)h;
+    if (b < 0 || b >= m->B || t < 0 || t >= (int)m->last_knots[b].size())
+      return -1;
+    const Knot & k = m->last_knots[b][t];
+    double * o = out;
+    for (const Mat * M : {&k.A, &k.B, &k.Q, &k.S, &k.R, &k.C})
+    {
+      mat_to(*M, o);
+      o += M->a.size();
+    }
+    for (const Vec * v : {&k.q, &k.r, &k.f, &k.d})
+    {
+      vec_to(*v, o);
+      o += v->size();
+    }
+    return (int)(o - out);
+  }
   int orc_mpc_cold_iters(void * h) { return (int)((BatchMPC *)h)->cold_trace.size(); }
   void orc_mpc_cold_trace(void * h, double * out) // [n][4]: phi0, prim, dual, alpha
   {

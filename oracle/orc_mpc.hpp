@@ -135,6 +135,8 @@ namespace orc
     std::vector<SolverState> sol;
     std::vector<std::vector<FootTraj>> ftraj; // [b][f]
     std::vector<IterInfo> last_info;
+    bool keep_knots = false;
+    std::vector<std::vector<Knot>> last_knots; // [b][t], filled when keep_knots (tests only)
 
     BatchMPC(const smpc_robot_model * m, const KinoSettings & ks, const MPCSettings & ms, int H_, int B_, double gravity_arg)
     : M(m), md(m, ks), st(ms), H(H_), B(B_)
@@ -175,6 +177,10 @@ namespace orc
         IterInfo info = solver.iterate(R, o, s0, vs_e, lams_e);
         cold_trace.push_back(info);
         if (std::fmax(info.prim_infeas, info.dual_infeas) <= st.TOL)
+          break;
+        // stalled: the predicted merit decrease is below what FP64 can resolve (cf. Aligator's
+        // ls_params.dphi_thresh early exit) -- DESIGN.md "solver constants"
+        if (std::fabs(info.dphi0) <= SolverConsts::STALL_REL * std::fmax(1.0, std::fabs(info.phi0)))
           break;
         if (info.dual_infeas <= st.TOL)
         {
@@ -325,8 +331,9 @@ namespace orc
         S.us.push_back(S.us.back());
         // ---- solver run: max_iters iterations, centres = incoming multipliers ----
         std::vector<Vec> vs_e = S.vs, lams_e = S.lams;
+        S.preg = SolverConsts::REG_INIT; // regularisation restarts with every solver run
         for (int it = 0; it < st.max_iters; it++)
-          last_info[b] = solver.iterate(R, o, S, vs_e, lams_e);
+          last_info[b] = solver.iterate(R, o, S, vs_e, lams_e, keep_knots ? &last_knots[b] : nullptr);
       }
     }
   };

@@ -28,6 +28,7 @@ namespace orc
     static constexpr double ARMIJO_C1 = 1e-4;
     static constexpr double REG_INIT = 1e-9, REG_MIN = 1e-10, REG_MAX = 1e9;
     static constexpr double REG_INC = 10.0, REG_DEC = 1.0 / 3.0;
+    static constexpr double STALL_REL = 1e-9; // cold solve: stop when |dphi0| <= STALL_REL max(1,|phi0|)
   };
 
   struct Knot

@@ -1,0 +1,128 @@
+// smpc_backend.h -- HIP/gfx950 backend glue for the kernel bodies in smpc_kernels*.h.
+//
+// Kernel bodies are written in a "lane phase" style:
+//
+//     SMPC_LANES(NT)            // code executed by every lane of the workgroup, `lane` = threadIdx.x
+//       ...
+//     SMPC_LANES_END            // workgroup barrier
+//
+// Code between phases is workgroup-uniform.  Data crossing a phase boundary lives in LDS.  This
+// keeps every cross-lane dependency explicit (one barrier per phase end) and lets the test suite
+// re-compile the very same bodies with a sequential lane loop (tests/emu/, found first on the
+// include path there) to check them against the oracle without a GPU.  This header is the only
+// backend the shipped library is built with; it has no CPU path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+
+#define SMPC_HD __host__ __device__ __forceinline__
+#define SMPC_DEV __device__ __forceinline__
+#define SMPC_DEV_NOINLINE __device__ __noinline__
+#define SMPC_LDS(type, name, n) __shared__ type name[n]
+#define SMPC_LANES(NT)                                                                                                 \
+  {                                                                                                                    \
+    const int lane = (int)threadIdx.x;                                                                                 \
+    (void)lane;
+#define SMPC_LANES_END                                                                                                 \
+  }                                                                                                                    \
+  __syncthreads();
+// per-lane value that must survive a phase boundary (register on the GPU)
+#define SMPC_PL(type, name, NT) type name
+#define SMPC_PLA(type, name, NT, n) type name[n]
+#define SMPC_PLV(name) name
+
+namespace smpc
+{
+  inline void hip_check(hipError_t e, const char * what, const char * file, int line)
+  {
+    if (e != hipSuccess)
+    {
+      char buf[512];
+      std::snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+      throw std::runtime_error(buf);
+    }
+  }
+#define SMPC_HIP(x) ::smpc::hip_check((x), #x, __FILE__, __LINE__)
+
+  typedef hipStream_t stream_t;
+
+  inline void * dev_alloc(size_t bytes)
+  {
+    void * p = nullptr;
+    SMPC_HIP(hipMalloc(&p, bytes ? bytes : 8));
+    SMPC_HIP(hipMemset(p, 0, bytes ? bytes : 8));
+    return p;
+  }
+  inline void dev_free(void * p)
+  {
+    if (p)
+      (void)hipFree(p);
+  }
+  inline void h2d(void * dst, const void * src, size_t bytes, stream_t s)
+  {
+    SMPC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+  }
+  inline void d2h(void * dst, const void * src, size_t bytes, stream_t s)
+  {
+    SMPC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+  }
+  inline void d2d(void * dst, const void * src, size_t bytes, stream_t s)
+  {
+    SMPC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+  }
+  inline void dev_zero(void * dst, size_t bytes, stream_t s) { SMPC_HIP(hipMemsetAsync(dst, 0, bytes, s)); }
+  inline void stream_sync(stream_t s) { SMPC_HIP(hipStreamSynchronize(s)); }
+  inline stream_t stream_create()
+  {
+    stream_t s;
+    SMPC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+  }
+  inline void stream_destroy(stream_t s) { (void)hipStreamDestroy(s); }
+  inline void set_device(int id) { SMPC_HIP(hipSetDevice(id)); }
+  inline int device_count()
+  {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+      return 0;
+    return n;
+  }
+
+  struct event_t
+  {
+    hipEvent_t e;
+  };
+  inline event_t event_create()
+  {
+    event_t ev;
+    SMPC_HIP(hipEventCreate(&ev.e));
+    return ev;
+  }
+  inline void event_destroy(event_t ev) { (void)hipEventDestroy(ev.e); }
+  inline void event_record(event_t ev, stream_t s) { SMPC_HIP(hipEventRecord(ev.e, s)); }
+  inline float event_elapsed_ms(event_t a, event_t b)
+  {
+    float ms = 0;
+    SMPC_HIP(hipEventSynchronize(b.e));
+    SMPC_HIP(hipEventElapsedTime(&ms, a.e, b.e));
+    return ms;
+  }
+
+  template <class Args, void (*Body)(const Args &, int), int NT>
+  __global__ __launch_bounds__(NT) void kernel_entry(const Args a)
+  {
+    Body(a, (int)blockIdx.x);
+  }
+
+  template <class Args, void (*Body)(const Args &, int), int NT>
+  inline void launch(int grid, stream_t s, const Args & a)
+  {
+    if (grid <= 0)
+      return;
+    hipLaunchKernelGGL((kernel_entry<Args, Body, NT>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    SMPC_HIP(hipGetLastError());
+  }
+} // namespace smpc

@@ -1,0 +1,292 @@
+// smpc_capi.cpp -- extern "C" entry points of include/smpc.h over KinoEngine.  Compiled by hipcc for
+// gfx950 (kernels are instantiated here); there is no CPU implementation behind these symbols.
+#include "../../include/smpc.h"
+#include "../../include/smpc_robots_builtin.h"
+#include "smpc_engine.h"
+#include <cstring>
+#include <memory>
+#include <string>
+
+using namespace smpc;
+
+typedef Dims<13, 4> DimsGo2; // free-flyer + 12 revolute joints, 4 point feet
+
+struct smpc_handle
+{
+  std::unique_ptr<KinoEngine<DimsGo2>> eng;
+};
+
+namespace
+{
+  thread_local std::string g_err;
+  int fail(int code, const std::string & msg)
+  {
+    g_err = msg;
+    return code;
+  }
+  template <class F>
+  int guarded(F && f)
+  {
+    try
+    {
+      f();
+      return SMPC_OK;
+    }
+    catch (const std::exception & e)
+    {
+      return fail(SMPC_ERR_RUNTIME, e.what());
+    }
+  }
+} // namespace
+
+extern "C"
+{
+  const smpc_robot_model * smpc_builtin_robot(const char * name)
+  {
+    if (!name)
+      return nullptr;
+    if (!std::strcmp(name, "go2_like"))
+      return &SMPC_ROBOT_GO2_LIKE;
+    if (!std::strcmp(name, "biped_like"))
+      return &SMPC_ROBOT_BIPED_LIKE;
+    return nullptr;
+  }
+  const char * smpc_last_error(void) { return g_err.c_str(); }
+  int smpc_device_count(void) { return device_count(); }
+
+  int smpc_create(
+    const smpc_robot_model * robot, const smpc_kinodynamics_settings * ocp, const smpc_mpc_settings * mpc, int batch,
+    double gravity_arg, int device_id, smpc_handle ** out)
+  {
+    if (!robot || !ocp || !mpc || !out)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (device_count() <= 0)
+      return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the MPC engine has no CPU path");
+    if (ocp->force_size != 3)
+      return fail(SMPC_ERR_INVALID, "force size in settings does not match reference force size (only 3-D point feet are built)");
+    if (ocp->force_cone || ocp->land_cstr)
+      return fail(SMPC_ERR_INVALID, "force_cone / land_cstr constraint rows are not built yet");
+    if (mpc->T < 2)
+      return fail(SMPC_ERR_INVALID, "horizon must have at least 2 stages");
+    const int nv = robot->nv, ndx = 2 * nv, nu = nv - 6 + 3 * robot->nfeet;
+    HostKinoSettings ks;
+    ks.timestep = ocp->timestep;
+    ks.w_x.assign(ocp->w_x, ocp->w_x + (size_t)ndx * ndx);
+    ks.w_u.assign(ocp->w_u, ocp->w_u + (size_t)nu * nu);
+    ks.w_frame.assign(ocp->w_frame, ocp->w_frame + 9);
+    ks.w_cent.assign(ocp->w_cent, ocp->w_cent + 36);
+    ks.w_centder.assign(ocp->w_centder, ocp->w_centder + 36);
+    ks.qmin.assign(ocp->qmin, ocp->qmin + nv - 6);
+    ks.qmax.assign(ocp->qmax, ocp->qmax + nv - 6);
+    for (int i = 0; i < 3; i++)
+      ks.gravity[i] = ocp->gravity[i];
+    ks.kinematics_limits = ocp->kinematics_limits;
+    HostMpcSettings ms;
+    ms.swing_apex = mpc->swing_apex;
+    ms.support_force = mpc->support_force;
+    ms.TOL = mpc->TOL;
+    ms.mu_init = mpc->mu_init;
+    ms.timestep = mpc->timestep;
+    ms.max_iters = mpc->max_iters;
+    ms.num_threads = mpc->num_threads;
+    ms.T_fly = mpc->T_fly;
+    ms.T_contact = mpc->T_contact;
+    ms.T = mpc->T;
+    return guarded([&] {
+      std::unique_ptr<smpc_handle> h(new smpc_handle());
+      h->eng.reset(new KinoEngine<DimsGo2>(robot, ks, ms, batch, gravity_arg, device_id));
+      *out = h.release();
+    });
+  }
+  int smpc_destroy(smpc_handle * h)
+  {
+    delete h;
+    return SMPC_OK;
+  }
+  int smpc_get_dims(const smpc_handle * h, int * d)
+  {
+    if (!h || !d)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    d[0] = DimsGo2::NQ;
+    d[1] = DimsGo2::NV;
+    d[2] = DimsGo2::NX;
+    d[3] = DimsGo2::NDX;
+    d[4] = DimsGo2::NU;
+    d[5] = DimsGo2::NC;
+    d[6] = DimsGo2::NF;
+    d[7] = h->eng->H;
+    return SMPC_OK;
+  }
+  int smpc_generate_cycle_horizon(smpc_handle * h, const uint8_t * cs, int n)
+  {
+    if (!h || !cs)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { h->eng->generate_cycle_horizon(cs, n); });
+  }
+  int smpc_switch_to_walk(smpc_handle * h, const double * v6)
+  {
+    if (!h || !v6)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    h->eng->switch_to_walk(v6);
+    return SMPC_OK;
+  }
+  int smpc_switch_to_stand(smpc_handle * h)
+  {
+    if (!h)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    h->eng->switch_to_stand();
+    return SMPC_OK;
+  }
+  int smpc_set_x_reference(smpc_handle * h, const double * x)
+  {
+    if (!h || !x)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    h->eng->x_reference.assign(x, x + DimsGo2::NX);
+    return SMPC_OK;
+  }
+  int smpc_iterate(smpc_handle * h, const double * X)
+  {
+    if (!h || !X)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { h->eng->iterate_host(X); });
+  }
+  int smpc_iterate_device(smpc_handle * h, const double * Xd)
+  {
+    if (!h || !Xd)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { h->eng->iterate_device(Xd); });
+  }
+  int smpc_wait(smpc_handle * h)
+  {
+    if (!h)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { h->eng->sync(); });
+  }
+  int smpc_get_x_device(smpc_handle * h, int t, double * out_device)
+  {
+    if (!h || !out_device)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { h->eng->gather_x_device(t, out_device); });
+  }
+  int smpc_get_xs(smpc_handle * h, double * out)
+  {
+    return guarded([&] { h->eng->get_ring(h->eng->buf.xs, DimsGo2::NX, h->eng->H + 1, out); });
+  }
+  int smpc_get_us(smpc_handle * h, double * out)
+  {
+    return guarded([&] { h->eng->get_ring(h->eng->buf.us, DimsGo2::NU, h->eng->H, out); });
+  }
+  int smpc_get_vs(smpc_handle * h, double * out)
+  {
+    return guarded([&] { h->eng->get_ring(h->eng->buf.vs, DimsGo2::NC, h->eng->H, out); });
+  }
+  int smpc_get_lams(smpc_handle * h, double * out)
+  {
+    // device arrays hold lambda_{t+1} at stage t; the API returns lams[0..H] with lams[0] = 0
+    return guarded([&] {
+      auto & e = *h->eng;
+      std::vector<double> tmp((size_t)e.B * e.H * DimsGo2::NDX);
+      e.get_ring(e.buf.lams, DimsGo2::NDX, e.H, tmp.data());
+      for (int b = 0; b < e.B; b++)
+      {
+        double * o = out + (size_t)b * (e.H + 1) * DimsGo2::NDX;
+        std::memset(o, 0, DimsGo2::NDX * sizeof(double));
+        std::memcpy(o + DimsGo2::NDX, tmp.data() + (size_t)b * e.H * DimsGo2::NDX, (size_t)e.H * DimsGo2::NDX * sizeof(double));
+      }
+    });
+  }
+  int smpc_get_K0(smpc_handle * h, double * out)
+  {
+    return guarded([&] { h->eng->get_K(out, false); });
+  }
+  int smpc_get_Ks(smpc_handle * h, double * out)
+  {
+    return guarded([&] { h->eng->get_K(out, true); });
+  }
+  int smpc_get_state_derivative01(smpc_handle * h, double * out)
+  {
+    return guarded([&] { h->eng->get_linear(h->eng->buf.xdot01, (size_t)h->eng->B * 4 * DimsGo2::NV, out); });
+  }
+  int smpc_get_reference_poses(smpc_handle * h, double * out)
+  {
+    return guarded([&] { h->eng->get_linear(h->eng->buf.foot_ref, (size_t)h->eng->B * h->eng->H * DimsGo2::NF * 3, out); });
+  }
+  int smpc_get_foot_timing(smpc_handle * h, int foot, int which, int * out, int cap)
+  {
+    if (!h || foot < 0 || foot >= DimsGo2::NF || h->eng->timer.nf == 0)
+    {
+      fail(SMPC_ERR_INVALID, "invalid foot index or cycle horizon not generated");
+      return SMPC_ERR_INVALID;
+    }
+    const std::vector<int> & v = which ? h->eng->timer.land[foot] : h->eng->timer.takeoff[foot];
+    for (int i = 0; i < (int)v.size() && i < cap; i++)
+      out[i] = v[i];
+    return (int)v.size();
+  }
+  int smpc_get_info(smpc_handle * h, double * out)
+  {
+    return guarded([&] { h->eng->get_linear(h->eng->buf.scal, (size_t)h->eng->B * SC_N, out); });
+  }
+  int smpc_get_cold_trace(smpc_handle * h, double * out, int cap)
+  {
+    const int n = h->eng->cold_iters;
+    for (int i = 0; i < n && i < cap; i++)
+      for (int k = 0; k < 4; k++)
+        out[i * 4 + k] = h->eng->cold_trace[(size_t)i * 4 + k];
+    return n;
+  }
+  int smpc_lq_size(const smpc_handle *) { return DimsGo2::LQ_STRIDE; }
+  int smpc_debug_get_lq(smpc_handle * h, int inst, int t, double * out)
+  {
+    if (!h || inst < 0 || inst >= h->eng->B || t < 0 || t >= h->eng->H)
+      return fail(SMPC_ERR_INVALID, "Stage index exceeds stage vector size");
+    return guarded([&] {
+      h->eng->get_linear(h->eng->buf.lq + ((size_t)inst * h->eng->H + t) * DimsGo2::LQ_STRIDE, DimsGo2::LQ_STRIDE, out);
+    });
+  }
+  int smpc_debug_get_steps(smpc_handle * h, double * dxs, double * dus)
+  {
+    return guarded([&] {
+      auto & e = *h->eng;
+      e.get_linear(e.buf.dxs, (size_t)e.B * (e.H + 1) * DimsGo2::NDX, dxs);
+      e.get_linear(e.buf.dus, (size_t)e.B * e.H * DimsGo2::NU, dus);
+    });
+  }
+  int smpc_debug_get_terminal(smpc_handle * h, int inst, double * QN, double * qN)
+  {
+    if (!h || inst < 0 || inst >= h->eng->B)
+      return fail(SMPC_ERR_INVALID, "instance index out of range");
+    return guarded([&] {
+      auto & e = *h->eng;
+      e.get_linear(e.buf.QN + (size_t)inst * DimsGo2::NDX * DimsGo2::NDX, DimsGo2::NDX * DimsGo2::NDX, QN);
+      e.get_linear(e.buf.qN + (size_t)inst * DimsGo2::NDX, DimsGo2::NDX, qN);
+    });
+  }
+  int smpc_set_profiling(smpc_handle * h, int en)
+  {
+    h->eng->profiling = en != 0;
+    return SMPC_OK;
+  }
+  int smpc_get_kernel_times(smpc_handle * h, double * ms, long * calls)
+  {
+    return guarded([&] {
+      h->eng->collect_profile();
+      for (int i = 0; i < KID_N; i++)
+      {
+        ms[i] = h->eng->kernel_ms[i];
+        calls[i] = h->eng->kernel_calls[i];
+      }
+    });
+  }
+  int smpc_reset_kernel_times(smpc_handle * h)
+  {
+    return guarded([&] {
+      h->eng->collect_profile();
+      for (int i = 0; i < KID_N; i++)
+      {
+        h->eng->kernel_ms[i] = 0;
+        h->eng->kernel_calls[i] = 0;
+      }
+    });
+  }
+}

@@ -1,0 +1,586 @@
+// smpc_engine.h -- host side of the batched kinodynamics MPC engine: owns the device buffers, the
+// shared (phase-aligned) gait state machine and the launch sequence of one control step.
+//
+// Mirrors, for a batch of B instances, the reference's MPC class:
+//   MPC::MPC                   src/mpc.cpp:19-99      -> KinoEngine::KinoEngine (cold solve once, broadcast)
+//   MPC::generateCycleHorizon  src/mpc.cpp:101-187    -> generate_cycle_horizon
+//   MPC::iterate               src/mpc.cpp:189-218    -> iterate
+//   MPC::recedeWithCycle       src/mpc.cpp:220-254    -> recede_host (+ ring head increment)
+//   MPC::updateCycleTiming     src/mpc.cpp:256-276    -> GaitTimer::update_timing
+//   MPC::switchToWalk/Stand    src/mpc.cpp:382-392
+#pragma once
+#include "smpc_solver_kernels.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace smpc
+{
+  struct HostKinoSettings
+  {
+    double timestep;
+    std::vector<double> w_x, w_u, w_frame, w_cent, w_centder, qmin, qmax;
+    double gravity[3];
+    int kinematics_limits;
+  };
+  struct HostMpcSettings
+  {
+    double swing_apex, support_force, TOL, mu_init, timestep;
+    int max_iters, num_threads, T_fly, T_contact, T;
+  };
+
+  // integer gait bookkeeping (reference src/mpc.cpp:101-132, 220-276)
+  struct GaitTimer
+  {
+    int H = 0, nf = 0;
+    std::vector<std::vector<unsigned char>> states;
+    std::vector<std::vector<int>> takeoff, land;
+    void generate(const unsigned char * cs, int n, int nf_, int H_)
+    {
+      H = H_;
+      nf = nf_;
+      states.clear();
+      const int reps = 1 + H / n; // original + m copies, m = H / n (integer division)
+      for (int r = 0; r < reps; r++)
+        for (int i = 0; i < n; i++)
+          states.emplace_back(cs + (size_t)i * nf, cs + (size_t)(i + 1) * nf);
+      takeoff.assign(nf, {});
+      land.assign(nf, {});
+      const int N = (int)states.size();
+      for (int f = 0; f < nf; f++)
+      {
+        for (int i = 1; i < N; i++)
+        {
+          const bool now = states[i][f], prev = states[i - 1][f];
+          if (!now && prev)
+            takeoff[f].push_back(i + H);
+          if (now && !prev)
+            land[f].push_back(i + H);
+        }
+        if (states[N - 1][f] && !states[0][f])
+          takeoff[f].push_back(N - 1 + H);
+        if (!states[N - 1][f] && states[0][f])
+          land[f].push_back(N - 1 + H);
+      }
+    }
+    void update_timing(bool only_horizon)
+    {
+      for (int f = 0; f < nf; f++)
+      {
+        for (auto * v : {&land[f], &takeoff[f]})
+        {
+          for (int & t : *v)
+            if (!only_horizon || t < H)
+              t -= 1;
+          if (!v->empty() && (*v)[0] < 0)
+            v->erase(v->begin());
+        }
+      }
+    }
+    void recede_cycle()
+    {
+      std::rotate(states.begin(), states.begin() + 1, states.end());
+      const int N = (int)states.size();
+      for (int f = 0; f < nf; f++)
+      {
+        if (!states[N - 1][f] && states[N - 2][f])
+          takeoff[f].push_back(N + H);
+        if (states[N - 1][f] && !states[N - 2][f])
+          land[f].push_back(N + H);
+      }
+      update_timing(false);
+    }
+  };
+
+  enum KernelId
+  {
+    KID_RECEDE = 0,
+    KID_DERIV,
+    KID_RICCATI,
+    KID_FORWARD,
+    KID_TRIAL,
+    KID_SELECT,
+    KID_APPLY,
+    KID_N
+  };
+
+  template <class D>
+  class KinoEngine
+  {
+  public:
+    typedef Dims<D::NJ, D::NF> DD;
+    Buffers<D> buf;
+    int B, H, R, head = 0;
+    HostMpcSettings ms;
+    std::vector<StageShared<D>> horizon, cycle;
+    StageShared<D> standing;
+    GaitTimer timer;
+    bool walking = true;
+    double velocity_base[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<double> x_reference, x_model_ref;
+    stream_t stream;
+    double * X_dev = nullptr;
+    double * stage_out = nullptr; // staging for linearised outputs
+    size_t stage_out_bytes = 0;
+    int cold_iters = 0;
+    std::vector<double> cold_trace; // [n][4] phi0, prim, dual, alpha
+    // profiling
+    bool profiling = false;
+    double kernel_ms[KID_N] = {0};
+    long kernel_calls[KID_N] = {0};
+    std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
+    static constexpr double ARMIJO_C1 = 1e-4, REG_INIT = 1e-9, REG_MIN = 1e-10, REG_MAX = 1e9, REG_INC = 10.0, REG_DEC = 1.0 / 3.0, STALL_REL = 1e-9;
+
+    KinoEngine(const smpc_robot_model * rm, const HostKinoSettings & ks, const HostMpcSettings & ms_, int batch, double gravity_arg, int device)
+    : ms(ms_)
+    {
+      if (rm->njoints != D::NJ || rm->nfeet != D::NF)
+        throw std::runtime_error("robot shape (njoints, nfeet) does not match this kernel instantiation");
+      if (batch <= 0)
+        throw std::runtime_error("batch must be positive");
+      if ((int)ks.w_x.size() != D::NDX * D::NDX || (int)ks.w_u.size() != D::NU * D::NU || (int)ks.w_frame.size() != 9 || (int)ks.w_cent.size() != 36
+          || (int)ks.w_centder.size() != 36 || (int)ks.qmin.size() != D::NA || (int)ks.qmax.size() != D::NA)
+        throw std::runtime_error("kinodynamics settings: weight / limit sizes do not match the robot");
+      set_device(device);
+      stream = stream_create();
+      B = batch;
+      H = ms.T;
+      R = H + 1;
+      // ---- model table ----
+      std::vector<DevModel<D>> hm(1);
+      DevModel<D> & m = hm[0];
+      std::memset(&m, 0, sizeof(m));
+      int maxlev = 0;
+      for (int j = 0; j < D::NJ; j++)
+      {
+        m.parent[j] = rm->parent[j];
+        if (j > 0 && (rm->parent[j] < 0 || rm->parent[j] >= j))
+          throw std::runtime_error("robot joints must be topologically ordered");
+        m.jtype[j] = rm->jtype[j];
+        m.level[j] = j == 0 ? 0 : m.level[rm->parent[j]] + 1;
+        maxlev = std::max(maxlev, m.level[j]);
+        m.anc[j] = (j == 0 ? 0u : m.anc[rm->parent[j]]) | (1u << j);
+        for (int i = 0; i < 9; i++)
+          m.jpR[j][i] = rm->jp_R[j][i];
+        for (int i = 0; i < 3; i++)
+        {
+          m.jpp[j][i] = rm->jp_p[j][i];
+          m.com[j][i] = rm->com[j][i];
+        }
+        m.mass[j] = rm->mass[j];
+        for (int i = 0; i < 6; i++)
+          m.inertia[j][i] = rm->inertia[j][i];
+      }
+      m.nlevels = maxlev + 1;
+      for (int f = 0; f < D::NF; f++)
+      {
+        m.foot_joint[f] = rm->foot_joint[f];
+        for (int i = 0; i < 3; i++)
+        {
+          m.foot_p[f][i] = rm->foot_p[f][i];
+          m.foot_ref_p[f][i] = rm->foot_ref_p[f][i];
+        }
+      }
+      m.total_mass = rm->total_mass;
+      m.dt = ks.timestep;
+      for (int i = 0; i < 3; i++)
+        m.gravity[i] = ks.gravity[i];
+      std::copy(ks.w_x.begin(), ks.w_x.end(), m.w_x);
+      std::copy(ks.w_u.begin(), ks.w_u.end(), m.w_u);
+      std::copy(ks.w_frame.begin(), ks.w_frame.end(), m.w_frame);
+      std::copy(ks.w_cent.begin(), ks.w_cent.end(), m.w_cent);
+      std::copy(ks.w_centder.begin(), ks.w_centder.end(), m.w_centder);
+      std::copy(ks.qmin.begin(), ks.qmin.end(), m.qmin);
+      std::copy(ks.qmax.begin(), ks.qmax.end(), m.qmax);
+      m.kinematics_limits = ks.kinematics_limits;
+      m.mu = ms.mu_init;
+      x_model_ref.assign(D::NX, 0.0);
+      for (int i = 0; i < D::NQ; i++)
+        x_model_ref[i] = rm->q_ref[i];
+      x_reference = x_model_ref;
+      for (int i = 0; i < D::NX; i++)
+        m.x_term[i] = x_model_ref[i];
+      // ---- buffers ----
+      buf.B = B;
+      buf.H = H;
+      buf.R = R;
+      auto dalloc = [&](size_t n) { return (double *)dev_alloc(n * sizeof(double)); };
+      const size_t BR = (size_t)B * R, BH = (size_t)B * H;
+      buf.xs = dalloc(BR * D::NX);
+      buf.us = dalloc(BR * D::NU);
+      buf.vs = dalloc(BR * D::NC);
+      buf.lams = dalloc(BR * D::NDX);
+      buf.vs_e = dalloc(BR * D::NC);
+      buf.lams_e = dalloc(BR * D::NDX);
+      buf.dxs = dalloc((size_t)B * (H + 1) * D::NDX);
+      buf.dus = dalloc(BH * D::NU);
+      buf.dvs = dalloc(BH * D::NC);
+      buf.dlams = dalloc(BH * D::NDX);
+      buf.foot_ref = dalloc(BH * D::NF * 3);
+      buf.ftraj = dalloc((size_t)B * D::NF * 6);
+      buf.lq = dalloc(BH * D::LQ_STRIDE);
+      buf.gains = dalloc(BH * D::G_STRIDE);
+      buf.QN = dalloc((size_t)B * D::NDX * D::NDX);
+      buf.qN = dalloc((size_t)B * D::NDX);
+      buf.parts0 = dalloc((size_t)B * (H + 1) * 4);
+      buf.partsT = dalloc((size_t)B * D::LS_N * (H + 1) * 2);
+      buf.scal = dalloc((size_t)B * SC_N);
+      buf.xdotT = dalloc((size_t)B * D::LS_N * 4 * D::NV);
+      buf.xdot01 = dalloc((size_t)B * 4 * D::NV);
+      buf.ls_sel = (int *)dev_alloc((size_t)B * sizeof(int));
+      buf.stages = (StageShared<D> *)dev_alloc((size_t)H * sizeof(StageShared<D>));
+      buf.model = (DevModel<D> *)dev_alloc(sizeof(DevModel<D>));
+      X_dev = dalloc((size_t)B * D::NX);
+      h2d(buf.model, hm.data(), sizeof(DevModel<D>), stream);
+      stream_sync(stream);
+
+      // ---- default problem (OCPHandler::createProblem, src/ocp-handler.cpp:96-137) ----
+      StageShared<D> def;
+      std::memset(&def, 0, sizeof(def));
+      def.mask = (1u << D::NF) - 1u;
+      for (int f = 0; f < D::NF; f++)
+        def.u_ref[3 * f + 2] = -rm->total_mass * gravity_arg / (double)D::NF;
+      for (int i = 0; i < D::NX; i++)
+        def.x_tgt[i] = x_model_ref[i];
+      horizon.assign(H, def);
+      standing = def;
+      cold_solve(def);
+    }
+    ~KinoEngine()
+    {
+      for (double * p : {buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref, buf.ftraj, buf.lq,
+                         buf.gains, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, X_dev, stage_out})
+        dev_free(p);
+      dev_free(buf.ls_sel);
+      dev_free(buf.stages);
+      dev_free(buf.model);
+      stream_destroy(stream);
+    }
+    KinoEngine(const KinoEngine &) = delete;
+    KinoEngine & operator=(const KinoEngine &) = delete;
+
+    SolverArgs<D> solver_args(const Buffers<D> & b, int j0 = 0, int nj = 0) const
+    {
+      SolverArgs<D> a;
+      a.b = b;
+      a.head = head;
+      a.j0 = j0;
+      a.nj = nj;
+      a.armijo_c1 = ARMIJO_C1;
+      a.reg_min = REG_MIN;
+      a.reg_max = REG_MAX;
+      a.reg_inc = REG_INC;
+      a.reg_dec = REG_DEC;
+      return a;
+    }
+
+    template <class Args, void (*Body)(const Args &, int), int NT>
+    void timed_launch(int kid, int grid, const Args & a)
+    {
+      if (profiling)
+      {
+        event_t e0 = event_create(), e1 = event_create();
+        event_record(e0, stream);
+        launch<Args, Body, NT>(grid, stream, a);
+        event_record(e1, stream);
+        pending_events.push_back({kid, {e0, e1}});
+      }
+      else
+        launch<Args, Body, NT>(grid, stream, a);
+      kernel_calls[kid]++;
+    }
+    void collect_profile()
+    {
+      stream_sync(stream);
+      for (auto & pe : pending_events)
+      {
+        kernel_ms[pe.first] += event_elapsed_ms(pe.second.first, pe.second.second);
+        event_destroy(pe.second.first);
+        event_destroy(pe.second.second);
+      }
+      pending_events.clear();
+    }
+
+    // one ProxDDP iteration for the instances covered by b (b.B may be < B for the cold solve)
+    void run_iteration(const Buffers<D> & b)
+    {
+      StageKernelArgs<D> sk;
+      sk.b = b;
+      sk.head = head;
+      sk.j0 = 0;
+      sk.nj = 0;
+      timed_launch<StageKernelArgs<D>, deriv_body<D>, 64>(KID_DERIV, b.B * (H + 1), sk);
+      timed_launch<SolverArgs<D>, riccati_body<D>, 256>(KID_RICCATI, b.B, solver_args(b));
+      timed_launch<SolverArgs<D>, forward_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
+      const int groups[3][2] = {{0, 1}, {1, 3}, {4, D::LS_N - 4}};
+      for (auto & gq : groups)
+      {
+        sk.j0 = gq[0];
+        sk.nj = gq[1];
+        timed_launch<StageKernelArgs<D>, trial_body<D>, 64>(KID_TRIAL, b.B * (H + 1) * sk.nj, sk);
+        timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, gq[0], gq[1]));
+      }
+      timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B * (H + 1), solver_args(b));
+    }
+    void copy_centres(const Buffers<D> & b)
+    {
+      d2d(b.vs_e, b.vs, (size_t)b.B * R * D::NC * sizeof(double), stream);
+      d2d(b.lams_e, b.lams, (size_t)b.B * R * D::NDX * sizeof(double), stream);
+    }
+
+    void upload_stages()
+    {
+      h2d(buf.stages, horizon.data(), (size_t)H * sizeof(StageShared<D>), stream);
+    }
+
+    // reference: src/mpc.cpp:72-91.  All instances share x0 = reference state: solve instance 0, broadcast.
+    void cold_solve(const StageShared<D> & def)
+    {
+      std::vector<double> xs0((size_t)R * D::NX), us0((size_t)R * D::NU);
+      for (int t = 0; t < R; t++)
+      {
+        std::copy(x_model_ref.begin(), x_model_ref.end(), xs0.begin() + (size_t)t * D::NX);
+        std::copy(def.u_ref, def.u_ref + D::NU, us0.begin() + (size_t)t * D::NU);
+      }
+      head = 0;
+      h2d(buf.xs, xs0.data(), xs0.size() * sizeof(double), stream);
+      h2d(buf.us, us0.data(), us0.size() * sizeof(double), stream);
+      std::vector<double> sc0(SC_N, 0.0);
+      sc0[SC_PREG] = REG_INIT;
+      h2d(buf.scal, sc0.data(), SC_N * sizeof(double), stream);
+      upload_stages();
+      // foot refs of the default problem are the identity placements: translation 0 (src/ocp-handler.cpp:116)
+      dev_zero(buf.foot_ref, (size_t)H * D::NF * 3 * sizeof(double), stream);
+      Buffers<D> b1 = buf;
+      b1.B = 1;
+      copy_centres(b1);
+      std::vector<double> sc(SC_N);
+      cold_trace.clear();
+      for (int it = 0; it < 100; it++)
+      {
+        run_iteration(b1);
+        d2h(sc.data(), buf.scal, SC_N * sizeof(double), stream);
+        stream_sync(stream);
+        cold_iters = it + 1;
+        cold_trace.insert(cold_trace.end(), {sc[SC_PHI0], sc[SC_PRIM], sc[SC_DUAL], sc[SC_ALPHA]});
+        if (std::fmax(sc[SC_PRIM], sc[SC_DUAL]) <= ms.TOL)
+          break;
+        // stalled: predicted merit decrease below FP64 resolution (DESIGN.md "solver constants")
+        if (std::fabs(sc[SC_DPHI0]) <= STALL_REL * std::fmax(1.0, std::fabs(sc[SC_PHI0])))
+          break;
+        if (sc[SC_DUAL] <= ms.TOL)
+          copy_centres(b1);
+      }
+      // broadcast instance 0 to the whole batch
+      auto bc = [&](double * p, size_t per) {
+        for (size_t done = 1; done < (size_t)B;)
+        {
+          const size_t n = std::min(done, (size_t)B - done);
+          d2d(p + done * per, p, n * per * sizeof(double), stream);
+          done += n;
+        }
+      };
+      bc(buf.xs, (size_t)R * D::NX);
+      bc(buf.us, (size_t)R * D::NU);
+      bc(buf.vs, (size_t)R * D::NC);
+      bc(buf.lams, (size_t)R * D::NDX);
+      bc(buf.scal, SC_N);
+      // swing start/end = reference foot positions (FootTrajectory ctor, src/foot-trajectory.cpp:20-39):
+      // a reference-only recede call with land = -1 < T_fly keeps them, so initialise them here on the host
+      std::vector<double> ft((size_t)D::NF * 6);
+      host_foot_positions(x_model_ref.data(), ft.data());
+      h2d(buf.ftraj, ft.data(), ft.size() * sizeof(double), stream);
+      stream_sync(stream);
+      bc(buf.ftraj, (size_t)D::NF * 6);
+      stream_sync(stream);
+      for (int f = 0; f < D::NF; f++)
+        for (int i = 0; i < 3; i++)
+          ref_foot_pos[f][i] = ft[f * 6 + i];
+    }
+    double ref_foot_pos[D::NF][3];
+
+    // foot positions at the model reference state, [NF][6] = (start, end) both at the foot position.
+    // Host restatement of FK limited to what the constructor needs (src/mpc.cpp:24-39).
+    void host_foot_positions(const double * x, double * out)
+    {
+      std::vector<DevModel<D>> hm(1);
+      d2h(hm.data(), buf.model, sizeof(DevModel<D>), stream);
+      stream_sync(stream);
+      const DevModel<D> & m = hm[0];
+      M3 Rj[D::NJ];
+      V3 pj[D::NJ];
+      for (int j = 0; j < D::NJ; j++)
+      {
+        if (j == 0)
+        {
+          Rj[0] = quat_to_R(Quat{x[3], x[4], x[5], x[6]});
+          pj[0] = ld3(x);
+        }
+        else
+        {
+          const double ang = x[6 + j], s = std::sin(ang), c = std::cos(ang);
+          const int jt = m.jtype[j];
+          M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -s, 0, s, c} : (jt == 2 ? M3{c, 0, s, 0, 1, 0, -s, 0, c} : M3{c, -s, 0, s, c, 0, 0, 0, 1});
+          Rj[j] = Rj[m.parent[j]] * (ldm3(m.jpR[j]) * Rq);
+          pj[j] = pj[m.parent[j]] + Rj[m.parent[j]] * ld3(m.jpp[j]);
+        }
+      }
+      for (int f = 0; f < D::NF; f++)
+      {
+        const V3 p = Rj[m.foot_joint[f]] * ld3(m.foot_p[f]) + pj[m.foot_joint[f]];
+        st3(out + f * 6, p);
+        st3(out + f * 6 + 3, p);
+      }
+    }
+
+    void generate_cycle_horizon(const unsigned char * cs, int n)
+    {
+      if (n <= 0)
+        throw std::runtime_error("contact sequence must not be empty");
+      timer.generate(cs, n, D::NF, H);
+      cycle.clear();
+      for (auto & st : timer.states)
+      {
+        int active = 0;
+        for (int f = 0; f < D::NF; f++)
+          active += st[f] ? 1 : 0;
+        StageShared<D> s;
+        std::memset(&s, 0, sizeof(s));
+        for (int f = 0; f < D::NF; f++)
+          if (st[f])
+          {
+            s.mask |= 1u << f;
+            s.u_ref[3 * f + 2] = ms.support_force / (double)active;
+          }
+        for (int i = 0; i < D::NX; i++)
+          s.x_tgt[i] = x_model_ref[i];
+        cycle.push_back(s);
+      }
+    }
+    void switch_to_walk(const double * v6)
+    {
+      walking = true;
+      for (int i = 0; i < 6; i++)
+        velocity_base[i] = v6[i];
+    }
+    void switch_to_stand()
+    {
+      walking = false;
+      for (int i = 0; i < 6; i++)
+        velocity_base[i] = 0.0;
+    }
+
+    // One control step for the whole batch; Xd: device pointer [B][NX]
+    void iterate_device(const double * Xd)
+    {
+      if (cycle.empty())
+        throw std::runtime_error("generateCycleHorizon must be called before iterate");
+      // ---- recedeWithCycle (host, shared by the batch) ----
+      int last_support = 0;
+      for (int f = 0; f < D::NF; f++)
+        last_support += (horizon[H - 1].mask >> f) & 1u;
+      StageShared<D> incoming;
+      if (walking || last_support < D::NF)
+      {
+        incoming = cycle[0];
+        std::rotate(cycle.begin(), cycle.begin() + 1, cycle.end());
+        timer.recede_cycle();
+      }
+      else
+      {
+        incoming = standing;
+        timer.update_timing(true);
+      }
+      horizon.erase(horizon.begin());
+      horizon.push_back(incoming);
+      // setReferenceState(H-1, x_reference_) ; setVelocityBase(H-1, velocity_base_)  (src/mpc.cpp:311-312)
+      for (int i = 0; i < D::NX; i++)
+        horizon[H - 1].x_tgt[i] = x_reference[i];
+      for (int i = 0; i < 6; i++)
+        horizon[H - 1].x_tgt[D::NQ + i] = velocity_base[i];
+      upload_stages();
+      head = head + 1 == R ? 0 : head + 1; // replaceStageCircular + cycleProblem as a ring advance
+      RecedeArgs<D> ra;
+      ra.b = buf;
+      ra.head = head;
+      ra.X = Xd;
+      for (int f = 0; f < D::NF; f++)
+        ra.land[f] = timer.land[f].empty() ? -1 : timer.land[f][0];
+      ra.T_fly = ms.T_fly;
+      ra.T_contact = ms.T_contact;
+      ra.swing_apex = ms.swing_apex;
+      ra.timestep = ms.timestep;
+      for (int i = 0; i < 6; i++)
+        ra.vbase[i] = velocity_base[i];
+      ra.shift = 1;
+      ra.reg_init = REG_INIT;
+      timed_launch<RecedeArgs<D>, recede_body<D>, 64>(KID_RECEDE, B, ra);
+      copy_centres(buf);
+      for (int it = 0; it < ms.max_iters; it++)
+        run_iteration(buf);
+    }
+    void iterate_host(const double * X)
+    {
+      h2d(X_dev, X, (size_t)B * D::NX * sizeof(double), stream);
+      iterate_device(X_dev);
+      stream_sync(stream);
+    }
+    void sync() { stream_sync(stream); }
+    // xs[t] of every instance -> dense device buffer [B][NX], asynchronous on the engine's stream
+    void gather_x_device(int t, double * out_dev)
+    {
+      if (t < 0 || t > H)
+        throw std::runtime_error("Stage index exceeds stage vector size");
+      GatherArgs<D> ga;
+      ga.b = buf;
+      ga.head = head;
+      ga.t = t;
+      ga.out = out_dev;
+      launch<GatherArgs<D>, gather_x_body<D>, 256>((int)(((size_t)B * D::NX + 255) / 256), stream, ga);
+    }
+
+    double * staging(size_t bytes)
+    {
+      if (bytes > stage_out_bytes)
+      {
+        dev_free(stage_out);
+        stage_out = (double *)dev_alloc(bytes);
+        stage_out_bytes = bytes;
+      }
+      return stage_out;
+    }
+    // ring array [B][R][n] -> host linear [B][count][n] for t = 0..count-1
+    void get_ring(const double * src, int n, int count, double * out)
+    {
+      stream_sync(stream);
+      std::vector<double> tmp((size_t)B * R * n);
+      d2h(tmp.data(), src, tmp.size() * sizeof(double), stream);
+      stream_sync(stream);
+      for (int b = 0; b < B; b++)
+        for (int t = 0; t < count; t++)
+          std::memcpy(out + ((size_t)b * count + t) * n, tmp.data() + ((size_t)b * R + ring_slot(head, t, R)) * n, n * sizeof(double));
+    }
+    void get_linear(const double * src, size_t n, double * out)
+    {
+      stream_sync(stream);
+      d2h(out, src, n * sizeof(double), stream);
+      stream_sync(stream);
+    }
+    // K_t of every stage [B][H][NU][NDX] (strided out of the gains block) or only K_0 [B][NU][NDX]
+    void get_K(double * out, bool all)
+    {
+      stream_sync(stream);
+      const int nt = all ? H : 1;
+      std::vector<double> row(D::NU * (D::NDX + 1));
+      for (int b = 0; b < B; b++)
+        for (int t = 0; t < nt; t++)
+        {
+          d2h(row.data(), buf.gains + ((size_t)b * H + t) * D::G_STRIDE + D::G_K, row.size() * sizeof(double), stream);
+          stream_sync(stream);
+          for (int i = 0; i < D::NU; i++)
+            std::memcpy(out + (((size_t)b * nt + t) * D::NU + i) * D::NDX, row.data() + (size_t)i * (D::NDX + 1), D::NDX * sizeof(double));
+        }
+    }
+  };
+} // namespace smpc

@@ -1,0 +1,595 @@
+// smpc_kino_kernels.h -- kernel bodies that run one wavefront per (instance, stage):
+//   deriv_body : HOT(1)+(2)+(3) at the current iterate -> LQ knot in HBM + merit partials
+//   trial_body : HOT(6) one line-search candidate: LINEAR rollout point (reference src/mpc.cpp:44),
+//                re-evaluation, AL multipliers, merit partials
+// (reference call site: SolverProxDDP::run, src/mpc.cpp:212; stage composition src/kinodynamics.cpp:40-152)
+#pragma once
+#include "smpc_kino_stage.h"
+
+namespace smpc
+{
+  template <class D>
+  struct StageKernelArgs
+  {
+    Buffers<D> b;
+    int head;
+    int j0, nj; // trial kernel: candidate range
+  };
+
+  // x (+) alpha*dx into dst (NX); SE3 part by `se3lane`, vector part by lanes
+  template <class D>
+  SMPC_DEV void lanes_integrate(const double * x, const double * dx, double alpha, double * dst, int lane, int se3lane)
+  {
+    constexpr int NV = D::NV, NQ = D::NQ;
+    if (lane == se3lane)
+    {
+      const V3 dv = alpha * ld3(dx), dw = alpha * ld3(dx + 3);
+      const M3 R0 = quat_to_R(Quat{x[3], x[4], x[5], x[6]});
+      const SE3 E = exp6(dv, dw);
+      st3(dst, ld3(x) + R0 * E.p);
+      Quat qn = quat_mul(Quat{x[3], x[4], x[5], x[6]}, quat_exp(dw));
+      const double n = 1.0 / sqrt(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+      dst[3] = qn.x * n;
+      dst[4] = qn.y * n;
+      dst[5] = qn.z * n;
+      dst[6] = qn.w * n;
+    }
+    for (int i = 6 + lane; i < 2 * NV; i += 64)
+    {
+      if (i < NV)
+        dst[i + 1] = x[i + 1] + alpha * dx[i];
+      else
+        dst[NQ + i - NV] = x[NQ + i - NV] + alpha * dx[i];
+    }
+  }
+  // e = xa (-) xb  (tangent at xb): SE3 part by se3lane, rest by lanes
+  template <class D>
+  SMPC_DEV void lanes_difference(const double * xb, const double * xa, double * e, int lane, int se3lane)
+  {
+    constexpr int NV = D::NV, NQ = D::NQ;
+    if (lane == se3lane)
+    {
+      const SE3 Mb{quat_to_R(Quat{xb[3], xb[4], xb[5], xb[6]}), ld3(xb)};
+      const SE3 Ma{quat_to_R(Quat{xa[3], xa[4], xa[5], xa[6]}), ld3(xa)};
+      V3 v, w;
+      log6(se3_mul(se3_inv(Mb), Ma), v, w);
+      st3(e, v);
+      st3(e + 3, w);
+    }
+    for (int i = 6 + lane; i < 2 * NV; i += 64)
+    {
+      if (i < NV)
+        e[i] = xa[i + 1] - xb[i + 1];
+      else
+        e[i] = xa[NQ + i - NV] - xb[NQ + i - NV];
+    }
+  }
+
+  // =============================================================================================
+  // deriv_body: grid = B * (H+1); block (inst, t); t == H is the terminal node.
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void deriv_body(const StageKernelArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NV = D::NV, NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF, NA = D::NA;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H, R = b.R;
+    const int inst = block / (H + 1), t = block % (H + 1);
+    const bool term = t == H;
+    const DevModel<D> & md = *b.model;
+    SMPC_LDS(KinoScratch<D>, scs, 1);
+    KinoScratch<D> & sc = scs[0];
+    const int st = ring_slot(ka.head, t, R);
+    const size_t ib = (size_t)inst * R;
+    const double * xg = b.xs + (ib + st) * NX;
+    const double * xn_g = b.xs + (ib + ring_slot(ka.head, term ? t : t + 1, R)) * NX;
+    const int sprev = ring_slot(ka.head, t > 0 ? t - 1 : 0, R);
+    const double preg = b.scal[(size_t)inst * SC_N + SC_PREG];
+
+    StageIn<D> in;
+    in.md = &md;
+    in.terminal = term;
+    in.mask = term ? 0u : b.stages[t].mask;
+    in.u_ref = term ? nullptr : b.stages[t].u_ref;
+    in.x_tgt = term ? md.x_term : b.stages[t].x_tgt;
+    in.foot_ref = term ? nullptr : b.foot_ref + ((size_t)inst * H + t) * NF * 3;
+
+    SMPC_LANES(NT)
+    {
+      for (int i = lane; i < NX; i += NT)
+        sc.x[i] = xg[i];
+      for (int i = lane; i < NU; i += NT)
+        sc.u[i] = term ? 0.0 : b.us[(ib + st) * NU + i];
+      for (int i = lane; i < NDX; i += NT)
+      {
+        sc.lam_next[i] = term ? 0.0 : b.lams[(ib + st) * NDX + i];
+        sc.lam_prev[i] = t > 0 ? b.lams[(ib + sprev) * NDX + i] : 0.0;
+      }
+      for (int i = lane; i < NC; i += NT)
+        sc.nu[i] = term ? 0.0 : b.vs[(ib + st) * NC + i];
+    }
+    SMPC_LANES_END
+
+    kino_tree_phases<D, true>(sc, in);
+
+    if (!term)
+    {
+      SMPC_LANES(NT)
+      lanes_difference<D>(xn_g, sc.xnext, sc.e, lane, 61);
+      SMPC_LANES_END
+    }
+    kino_cost_constraints<D, true>(sc, in);
+
+    double * parts = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
+
+    if (term)
+    {
+      // ---- terminal node: Q_N = Lxx + preg I, q_N = lx - lambda_H ----
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NDX * 6; idx += NT)
+        {
+          const int a = idx / 6, k = idx % 6;
+          double s = 0.0;
+          for (int bb = 0; bb < 6; bb++)
+            s += md.w_x[a * NDX + bb] * sc.Jl[bb * 6 + k];
+          sc.WJl[idx] = s;
+        }
+        for (int idx = lane; idx < 6 * NDX; idx += NT)
+        {
+          const int a = idx / NDX, k = idx % NDX;
+          double s = 0.0;
+          for (int bb = 0; bb < 6; bb++)
+            s += 10.0 * md.w_cent[a * 6 + bb] * (k < NV ? sc.dh_dq[bb * NV + k] : sc.Ag[bb * NV + k - NV]);
+          sc.WJc[idx] = s;
+        }
+      }
+      SMPC_LANES_END
+      double * QN = b.QN + (size_t)inst * NDX * NDX;
+      double * qN = b.qN + (size_t)inst * NDX;
+      SMPC_LANES(NT)
+      if (lane < NDX)
+      {
+        const int k = lane;
+        double dual = 0.0;
+        // gradient
+        double g = 0.0;
+        if (k < 6)
+          for (int a = 0; a < 6; a++)
+            g += sc.Jl[a * 6 + k] * sc.Wrx[a];
+        else
+          g = sc.Wrx[k];
+        for (int a = 0; a < 6; a++)
+          g += (k < NV ? sc.dh_dq[a * NV + k] : sc.Ag[a * NV + k - NV]) * sc.Whg[a];
+        const double qn = g - sc.lam_prev[k];
+        qN[k] = qn;
+        dual = fabs(qn);
+        sc.lx[k] = dual;
+        for (int i = 0; i < NDX; i++)
+        {
+          double v;
+          if (i < 6)
+          {
+            v = 0.0;
+            for (int a = 0; a < 6; a++)
+              v += sc.Jl[a * 6 + i] * (k < 6 ? sc.WJl[a * 6 + k] : md.w_x[a * NDX + k]);
+          }
+          else
+            v = k < 6 ? sc.WJl[i * 6 + k] : md.w_x[i * NDX + k];
+          for (int a = 0; a < 6; a++)
+            v += (i < NV ? sc.dh_dq[a * NV + i] : sc.Ag[a * NV + i - NV]) * sc.WJc[a * NDX + k];
+          if (i == k)
+            v += preg;
+          QN[i * NDX + k] = v;
+        }
+      }
+      SMPC_LANES_END
+      SMPC_LANES(NT)
+      if (lane == 0)
+      {
+        double dual = 0.0;
+        for (int k = 0; k < NDX; k++)
+          dual = fmax(dual, sc.lx[k]);
+        parts[0] = sc.red[0];
+        parts[1] = sc.red[0];
+        parts[2] = 0.0;
+        parts[3] = dual;
+      }
+      SMPC_LANES_END
+      return;
+    }
+
+    // ---- multipliers, active set ----
+    kino_multipliers<D>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+
+    // ---- small weighted-Jacobian tables ----
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < NDX * 6; idx += NT)
+      {
+        const int a = idx / 6, k = idx % 6;
+        double s = 0.0;
+        for (int bb = 0; bb < 6; bb++)
+          s += md.w_x[a * NDX + bb] * sc.Jl[bb * 6 + k];
+        sc.WJl[idx] = s;
+      }
+      for (int idx = lane; idx < 6 * NDX; idx += NT)
+      {
+        const int a = idx / NDX, k = idx % NDX;
+        double s = 0.0;
+        for (int bb = 0; bb < 6; bb++)
+          s += md.w_cent[a * 6 + bb] * (k < NV ? sc.dh_dq[bb * NV + k] : sc.Ag[bb * NV + k - NV]);
+        sc.WJc[idx] = s;
+      }
+      for (int idx = lane; idx < 3 * NV; idx += NT)
+      {
+        const int a = idx / NV, k = idx % NV;
+        double s = 0.0;
+        for (int bb = 0; bb < 3; bb++)
+          s += md.w_centder[(3 + a) * 6 + 3 + bb] * sc.dtgt[bb * NV + k];
+        sc.WD[idx] = s;
+      }
+      for (int idx = lane; idx < 6 * 3 * NF; idx += NT)
+      {
+        const int a = idx / (3 * NF), k = idx % (3 * NF);
+        const int f = k / 3, j = k % 3;
+        double s = 0.0;
+        if ((in.mask >> f) & 1u)
+        {
+          const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
+          const V3 xc = cross(rr, mk3(j == 0, j == 1, j == 2)); // column j of [rr]x
+          s = md.w_centder[a * 6 + j] + md.w_centder[a * 6 + 3] * xc.x + md.w_centder[a * 6 + 4] * xc.y + md.w_centder[a * 6 + 5] * xc.z;
+        }
+        sc.WJu[idx] = s;
+      }
+      for (int idx = lane; idx < NF * 3 * NV; idx += NT)
+      {
+        const int fa = idx / NV, k = idx % NV;
+        const int f = fa / 3, a = fa % 3;
+        double s = 0.0;
+        for (int bb = 0; bb < 3; bb++)
+          s += md.w_frame[a * 3 + bb] * sc.Jfoot[(f * 3 + bb) * NV + k];
+        sc.WJf[idx] = s;
+      }
+    }
+    SMPC_LANES_END
+
+    double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
+    const double dt = md.dt;
+    const double mu = md.mu;
+
+    // ---- [A | B]: lane k < NDX owns column k of A, lane NDX+k owns column k of B ----
+    SMPC_LANES(NT)
+    if (lane < NDX + NU)
+    {
+      const bool isA = lane < NDX;
+      const int k = isA ? lane : lane - NDX;
+      // top block source column: Dtop[m] (m<6) = d(dx_q)[m]/d(col)
+      double Dtop[6], Dbot[6];
+      for (int m = 0; m < 6; m++)
+      {
+        if (isA)
+        {
+          if (k < NV)
+          {
+            Dbot[m] = dt * sc.ab_dq[m * NV + k];
+            Dtop[m] = dt * Dbot[m];
+          }
+          else
+          {
+            const int kk = k - NV;
+            Dbot[m] = dt * sc.ab_dv[m * NV + kk];
+            Dtop[m] = dt * Dbot[m] + (m == kk ? dt : 0.0);
+          }
+        }
+        else
+        {
+          Dbot[m] = dt * sc.ab_du[m * NU + k];
+          Dtop[m] = dt * Dbot[m];
+        }
+      }
+      double acc = 0.0; // (A^T lam_next)[k] or (B^T lam_next)[k]
+      double * dst = lq + (isA ? D::O_A : D::O_B);
+      const int ld = isA ? NDX : NU;
+      for (int i = 0; i < NDX; i++)
+      {
+        double v;
+        if (i < 6)
+        {
+          // Je row i = [J3 Q; 0 J3]
+          if (i < 3)
+            v = sc.Je3[i * 3 + 0] * Dtop[0] + sc.Je3[i * 3 + 1] * Dtop[1] + sc.Je3[i * 3 + 2] * Dtop[2] + sc.JeQ[i * 3 + 0] * Dtop[3]
+                + sc.JeQ[i * 3 + 1] * Dtop[4] + sc.JeQ[i * 3 + 2] * Dtop[5];
+          else
+            v = sc.Je3[(i - 3) * 3 + 0] * Dtop[3] + sc.Je3[(i - 3) * 3 + 1] * Dtop[4] + sc.Je3[(i - 3) * 3 + 2] * Dtop[5];
+          if (isA && k < 6)
+            v += sc.Jq[i * 6 + k];
+        }
+        else if (i < NV)
+        {
+          if (isA)
+            v = (k == i ? 1.0 : 0.0) + (k == NV + i ? dt : 0.0);
+          else
+            v = (k == 3 * NF + i - 6) ? dt * dt : 0.0;
+        }
+        else if (i < NV + 6)
+        {
+          v = Dbot[i - NV];
+          if (isA && k == i)
+            v += 1.0;
+        }
+        else
+        {
+          if (isA)
+            v = (k == i) ? 1.0 : 0.0;
+          else
+            v = (k == 3 * NF + i - NV - 6) ? dt : 0.0;
+        }
+        dst[i * ld + k] = v;
+        acc += v * sc.lam_next[i];
+      }
+      // Lagrangian gradient pieces: cost gradient + multipliers
+      if (isA)
+      {
+        double g;
+        if (k < 6)
+        {
+          g = 0.0;
+          for (int a = 0; a < 6; a++)
+            g += sc.Jl[a * 6 + k] * sc.Wrx[a];
+        }
+        else
+          g = sc.Wrx[k];
+        for (int a = 0; a < 6; a++)
+          g += (k < NV ? sc.dh_dq[a * NV + k] : sc.Ag[a * NV + k - NV]) * sc.Whg[a];
+        if (k < NV)
+        {
+          for (int a = 0; a < 3; a++)
+            g += sc.dtgt[a * NV + k] * sc.Whd[3 + a];
+          for (int fa = 0; fa < NF * 3; fa++)
+            g += sc.Jfoot[fa * NV + k] * sc.Wrf[fa];
+        }
+        sc.lx[k] = g;
+        // C_x^T nu (full Jacobian)
+        double cn = 0.0;
+        if (md.kinematics_limits && k >= 6 && k < NV)
+          cn += sc.nu[k - 6];
+        for (int f = 0; f < NF; f++)
+          if ((in.mask >> f) & 1u)
+            for (int r = 0; r < 3; r++)
+              cn += (k < NV ? sc.dcq[(f * 3 + r) * NV + k] : sc.dcv[(f * 3 + r) * NV + k - NV]) * sc.nu[NA + 3 * f + r];
+        double q = g + acc + cn - sc.lam_prev[k];
+        if (t == 0)
+          q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
+        lq[D::O_q + k] = q;
+        lq[D::O_lx + k] = g;
+        lq[D::O_f + k] = mu * (sc.lamp[k] - sc.lam_next[k]);
+        lq[D::O_lpd + k] = 2.0 * sc.lamp[k] - sc.lam_next[k];
+        sc.rx[k] = fabs(q); // reuse as dual-infeasibility scratch
+      }
+      else
+      {
+        double g = sc.Wru[k];
+        if (k < 3 * NF)
+        {
+          const int f = k / 3, j = k % 3;
+          if ((in.mask >> f) & 1u)
+          {
+            const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
+            const V3 xc = cross(rr, mk3(j == 0, j == 1, j == 2));
+            g += sc.Whd[j] + xc.x * sc.Whd[3] + xc.y * sc.Whd[4] + xc.z * sc.Whd[5];
+          }
+        }
+        sc.lu[k] = g;
+        const double r = g + acc;
+        lq[D::O_r + k] = r;
+        lq[D::O_lu + k] = g;
+        sc.ru[k] = fabs(r);
+      }
+    }
+    SMPC_LANES_END
+
+    // ---- [Q | S]: lane k < NDX owns column k of Q, lane NDX+k column k of S ----
+    SMPC_LANES(NT)
+    if (lane < NDX + NU)
+    {
+      const bool isQ = lane < NDX;
+      const int k = isQ ? lane : lane - NDX;
+      double * dst = lq + (isQ ? D::O_Q : D::O_S);
+      const int ld = isQ ? NDX : NU;
+      const bool fcol = !isQ && k < 3 * NF && ((in.mask >> (k / 3)) & 1u);
+      for (int i = 0; i < NDX; i++)
+      {
+        double v = 0.0;
+        if (isQ)
+        {
+          if (i < 6)
+            for (int a = 0; a < 6; a++)
+              v += sc.Jl[a * 6 + i] * (k < 6 ? sc.WJl[a * 6 + k] : md.w_x[a * NDX + k]);
+          else
+            v = k < 6 ? sc.WJl[i * 6 + k] : md.w_x[i * NDX + k];
+          for (int a = 0; a < 6; a++)
+            v += (i < NV ? sc.dh_dq[a * NV + i] : sc.Ag[a * NV + i - NV]) * sc.WJc[a * NDX + k];
+          if (i < NV && k < NV)
+          {
+            for (int a = 0; a < 3; a++)
+              v += sc.dtgt[a * NV + i] * sc.WD[a * NV + k];
+            for (int fa = 0; fa < NF * 3; fa++)
+              v += sc.Jfoot[fa * NV + i] * sc.WJf[fa * NV + k];
+          }
+          if (i == k)
+            v += preg;
+        }
+        else if (fcol && i < NV)
+        {
+          for (int a = 0; a < 3; a++)
+            v += sc.dtgt[a * NV + i] * sc.WJu[(3 + a) * 3 * NF + k];
+        }
+        dst[i * ld + k] = v;
+      }
+    }
+    SMPC_LANES_END
+
+    // ---- [C | R]: lane k < NDX owns column k of C (active rows), lane NDX+k column k of R ----
+    SMPC_LANES(NT)
+    if (lane < NDX + NU)
+    {
+      const bool isC = lane < NDX;
+      const int k = isC ? lane : lane - NDX;
+      if (isC)
+      {
+        double * dst = lq + D::O_C;
+        for (int i = 0; i < NC; i++)
+        {
+          double v = 0.0;
+          if (sc.act[i])
+          {
+            if (i < NA)
+              v = (k == 6 + i) ? 1.0 : 0.0;
+            else
+              v = k < NV ? sc.dcq[(i - NA) * NV + k] : sc.dcv[(i - NA) * NV + k - NV];
+          }
+          dst[i * NDX + k] = v;
+        }
+      }
+      else
+      {
+        double * dst = lq + D::O_R;
+        const bool fk = k < 3 * NF && ((in.mask >> (k / 3)) & 1u);
+        for (int i = 0; i < NU; i++)
+        {
+          double v = md.w_u[i * NU + k];
+          if (fk && i < 3 * NF && ((in.mask >> (i / 3)) & 1u))
+          {
+            // Ju[:, i]^T * WJu[:, k]
+            const int f = i / 3, j = i % 3;
+            const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
+            const V3 xc = cross(rr, mk3(j == 0, j == 1, j == 2));
+            v += sc.WJu[j * 3 * NF + k] + xc.x * sc.WJu[3 * 3 * NF + k] + xc.y * sc.WJu[4 * 3 * NF + k] + xc.z * sc.WJu[5 * 3 * NF + k];
+          }
+          if (i == k)
+            v += preg;
+          dst[i * NU + k] = v;
+        }
+      }
+      // vectors d, vpd
+      if (lane < NC)
+      {
+        lq[D::O_d + lane] = mu * (sc.vplus[lane] - sc.nu[lane]);
+        lq[D::O_vpd + lane] = sc.act[lane] ? 2.0 * sc.vplus[lane] - sc.nu[lane] : 0.0;
+      }
+    }
+    SMPC_LANES_END
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      double dual = 0.0;
+      for (int k = 0; k < NDX; k++)
+        dual = fmax(dual, sc.rx[k]);
+      for (int k = 0; k < NU; k++)
+        dual = fmax(dual, sc.ru[k]);
+      parts[0] = sc.red[0] + sc.red[1];
+      parts[1] = sc.red[0];
+      parts[2] = sc.red[2];
+      parts[3] = dual;
+    }
+    SMPC_LANES_END
+  }
+
+  // =============================================================================================
+  // trial_body: grid = B * (H+1) * nj; evaluates candidate j = j0 + jj for instances still undecided
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void trial_body(const StageKernelArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NV = D::NV, NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H, R = b.R;
+    const int per = (H + 1) * ka.nj;
+    const int inst = block / per;
+    const int rem = block % per;
+    const int jj = rem / (H + 1), t = rem % (H + 1);
+    const int j = ka.j0 + jj;
+    if (b.ls_sel[inst] >= 0)
+      return; // already accepted an earlier candidate (uniform across the workgroup)
+    const bool term = t == H;
+    const DevModel<D> & md = *b.model;
+    SMPC_LDS(KinoScratch<D>, scs, 1);
+    KinoScratch<D> & sc = scs[0];
+    const int st = ring_slot(ka.head, t, R);
+    const size_t ib = (size_t)inst * R;
+    double alpha = 1.0;
+    for (int i = 0; i < j; i++)
+      alpha *= 0.5;
+
+    StageIn<D> in;
+    in.md = &md;
+    in.terminal = term;
+    in.mask = term ? 0u : b.stages[t].mask;
+    in.u_ref = term ? nullptr : b.stages[t].u_ref;
+    in.x_tgt = term ? md.x_term : b.stages[t].x_tgt;
+    in.foot_ref = term ? nullptr : b.foot_ref + ((size_t)inst * H + t) * NF * 3;
+
+    const double * dx = b.dxs + ((size_t)inst * (H + 1) + t) * NDX;
+    SMPC_LANES(NT)
+    {
+      lanes_integrate<D>(b.xs + (ib + st) * NX, dx, alpha, sc.x, lane, 0);
+      if (!term)
+      {
+        // trial x_{t+1} goes to sc.rf/... no: keep it in sc.WJf (NX doubles fit) as scratch
+        const int sn = ring_slot(ka.head, t + 1, R);
+        lanes_integrate<D>(b.xs + (ib + sn) * NX, dx + NDX, alpha, sc.WJf, lane, 1);
+        const size_t lt = (size_t)inst * H + t;
+        for (int i = lane; i < NU; i += NT)
+          sc.u[i] = b.us[(ib + st) * NU + i] + alpha * b.dus[lt * NU + i];
+        for (int i = lane; i < NDX; i += NT)
+          sc.lam_next[i] = b.lams[(ib + st) * NDX + i] + alpha * b.dlams[lt * NDX + i];
+        for (int i = lane; i < NC; i += NT)
+          sc.nu[i] = b.vs[(ib + st) * NC + i] + alpha * b.dvs[lt * NC + i];
+      }
+      else
+        for (int i = lane; i < NU; i += NT)
+          sc.u[i] = 0.0;
+    }
+    SMPC_LANES_END
+
+    kino_tree_phases<D, false>(sc, in);
+    if (!term)
+    {
+      SMPC_LANES(NT)
+      lanes_difference<D>(sc.WJf, sc.xnext, sc.e, lane, 61);
+      SMPC_LANES_END
+    }
+    kino_cost_constraints<D, false>(sc, in);
+    double * parts = b.partsT + (((size_t)inst * D::LS_N + j) * (H + 1) + t) * 2;
+    if (term)
+    {
+      SMPC_LANES(NT)
+      if (lane == 0)
+      {
+        parts[0] = sc.red[0];
+        parts[1] = 0.0;
+      }
+      SMPC_LANES_END
+      return;
+    }
+    kino_multipliers<D>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+    SMPC_LANES(NT)
+    {
+      if (lane == 0)
+      {
+        parts[0] = sc.red[0] + sc.red[1];
+        parts[1] = sc.red[2];
+      }
+      if (t < 2 && lane < NV)
+      {
+        double * xd = b.xdotT + (((size_t)inst * D::LS_N + j) * 2 + t) * 2 * NV;
+        xd[lane] = sc.x[D::NQ + lane];
+        xd[NV + lane] = sc.a[lane];
+      }
+    }
+    SMPC_LANES_END
+  }
+} // namespace smpc

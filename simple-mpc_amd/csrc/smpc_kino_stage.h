@@ -1,0 +1,834 @@
+// smpc_kino_stage.h -- the per-(instance, stage) kinodynamics kernel body.
+//
+// One 64-lane wavefront owns one (instance, stage) pair.  The stage's state/control block and all
+// rigid-body intermediates are staged in LDS; the tree algorithms run level-synchronously with one
+// lane per joint / per dof column, the dense assembly (A, B, Gauss-Newton Hessians, constraint rows)
+// runs with all 64 lanes, and the LQ knot is written to HBM as contiguous coalesced runs.
+//
+// What it computes is what the reference obtains, per stage, from Aligator/Pinocchio inside
+// SolverProxDDP::run (reference src/mpc.cpp:212) for the stage built by
+// KinodynamicsOCP::createStage (reference src/kinodynamics.cpp:40-152):
+//   HOT(1) evaluate   : x+ = f(x,u) (KinodynamicsFwdDynamics + IntegratorSemiImplEuler), costs, constraints
+//   HOT(2) derivatives: A, B, cost gradient + Gauss-Newton Hessian, constraint Jacobians
+//   HOT(3) LQ assembly: AL multipliers / active set, knot (Q,S,R,q,r,A,B,f,C,d)
+// World-frame spatial formulation; derivation in DESIGN.md "Rigid-body derivatives".
+#pragma once
+#include "smpc_math.h"
+#include "smpc_model.h"
+
+namespace smpc
+{
+  template <class D>
+  struct KinoScratch
+  {
+    double x[D::NX], u[D::NU];
+    double oR[D::NJ * 9], op[D::NJ * 3];
+    double S[D::NV * 6];
+    double vel[D::NJ * 6], acc[D::NJ * 6];
+    double I[D::NJ * 10], Ic[D::NJ * 10];
+    double h[D::NJ * 6], hc[D::NJ * 6], Fc[D::NJ * 6];
+    double footp[D::NF * 3];
+    double com[3];
+    double Ag[6 * D::NV];
+    double b0[6], hd[6], hg[6];
+    double gjA[36], gjB[36], Agbi[36];
+    double a[D::NV];
+    double xnext[D::NX], e[D::NDX];
+    double cval[D::NC];
+    // residuals and weighted residuals
+    double rx[D::NDX], Wrx[D::NDX], ru[D::NU], Wru[D::NU], Whg[6], Whd[6], rf[D::NF * 3], Wrf[D::NF * 3];
+    // derivative-only section
+    double dh_dq[6 * D::NV], dhd_dq[6 * D::NV], dhd_dv[6 * D::NV];
+    double Jcom[3 * D::NV], Jfoot[D::NF * 3 * D::NV];
+    double dtgt[3 * D::NV];
+    double ab_dq[6 * D::NV], ab_dv[6 * D::NV], ab_du[6 * D::NU];
+    double Je3[9], JeQ[9], Jq[36], Jl[36];
+    double WJl[D::NDX * 6];           // w_x[:,0:6] * Jl
+    double WJc[6 * D::NDX];           // w_cent * [dh_dq | Ag]
+    double WD[3 * D::NV];             // w_centder[3:6,3:6] * dtgt
+    double WJu[6 * 3 * D::NF];        // w_centder * Ju (force columns)
+    double WJf[D::NF * 3 * D::NV];    // w_frame * Jfoot
+    double dcq[D::NF * 3 * D::NV], dcv[D::NF * 3 * D::NV];
+    double lx[D::NDX], lu[D::NU];
+    double vplus[D::NC], lamp[D::NDX], lam_next[D::NDX], lam_prev[D::NDX], nu[D::NC];
+    int act[D::NC];
+    double red[8];
+  };
+
+  // inputs describing one stage evaluation
+  template <class D>
+  struct StageIn
+  {
+    const DevModel<D> * md;
+    unsigned mask;
+    const double * u_ref;    // NU (global)
+    const double * x_tgt;    // NX (global)
+    const double * foot_ref; // NF*3 (global)
+    bool terminal;
+  };
+
+  // ---------------------------------------------------------------------------------------------
+  // Tree + dynamics phases.  On return (all lanes synchronised) the scratch holds: kinematics,
+  // composite quantities, Ag, hg, b0, hd, Agbi, a, xnext.  If DERIV, also acc/Fc for the solved
+  // acceleration and every derivative column.
+  // ---------------------------------------------------------------------------------------------
+  template <class D, bool DERIV>
+  SMPC_DEV void kino_tree_phases(KinoScratch<D> & sc, const StageIn<D> & in)
+  {
+    constexpr int NT = 64;
+    constexpr int NJ = D::NJ, NV = D::NV, NQ = D::NQ, NF = D::NF;
+    const DevModel<D> & md = *in.md;
+    const int nlev = md.nlevels;
+
+    // ---- FK, level by level ----
+    for (int lvl = 0; lvl < nlev; lvl++)
+    {
+      SMPC_LANES(NT)
+      if (lane < NJ && md.level[lane] == lvl)
+      {
+        const int j = lane;
+        M3 R;
+        V3 p;
+        if (j == 0)
+        {
+          R = quat_to_R(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]});
+          p = ld3(sc.x);
+        }
+        else
+        {
+          const int par = md.parent[j];
+          const double ang = sc.x[6 + j];
+          const double s = sin(ang), c = cos(ang);
+          const int jt = md.jtype[j];
+          M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -s, 0, s, c} : (jt == 2 ? M3{c, 0, s, 0, 1, 0, -s, 0, c} : M3{c, -s, 0, s, c, 0, 0, 0, 1});
+          const M3 Rp = ldm3(&sc.oR[par * 9]);
+          R = Rp * (ldm3(md.jpR[j]) * Rq);
+          p = ld3(&sc.op[par * 3]) + Rp * ld3(md.jpp[j]);
+        }
+        stm3(&sc.oR[j * 9], R);
+        st3(&sc.op[j * 3], p);
+      }
+      SMPC_LANES_END
+    }
+    // ---- S columns (lanes 0..NV-1), world inertias (lanes 32..32+NJ-1), feet (lanes 48..) ----
+    SMPC_LANES(NT)
+    if (lane < NV)
+    {
+      const int k = lane;
+      const int j = k < 6 ? 0 : k - 5;
+      const M3 R = ldm3(&sc.oR[j * 9]);
+      const V3 p = ld3(&sc.op[j * 3]);
+      int col;
+      if (k < 6)
+        col = k % 3;
+      else
+        col = md.jtype[j] - 1;
+      const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
+      SV s;
+      if (k < 3)
+        s = SV{ax, mk3(0, 0, 0)};
+      else
+        s = SV{cross(p, ax), ax};
+      stsv(&sc.S[k * 6], s);
+    }
+    else if (lane >= 32 && lane < 32 + NJ)
+    {
+      const int j = lane - 32;
+      const M3 R = ldm3(&sc.oR[j * 9]);
+      const V3 p = ld3(&sc.op[j * 3]);
+      const double m = md.mass[j];
+      const V3 c = R * ld3(md.com[j]) + p;
+      const double * il = md.inertia[j];
+      const M3 Il = M3{il[0], il[1], il[3], il[1], il[2], il[4], il[3], il[4], il[5]};
+      const M3 Iw = R * Il * transpose(R);
+      const double cc = dot(c, c);
+      SI I;
+      I.m = m;
+      I.mc = m * c;
+      I.jxx = Iw.a00 + m * (cc - c.x * c.x);
+      I.jxy = Iw.a01 - m * c.x * c.y;
+      I.jxz = Iw.a02 - m * c.x * c.z;
+      I.jyy = Iw.a11 + m * (cc - c.y * c.y);
+      I.jyz = Iw.a12 - m * c.y * c.z;
+      I.jzz = Iw.a22 + m * (cc - c.z * c.z);
+      stsi(&sc.I[j * 10], I);
+      stsi(&sc.Ic[j * 10], I);
+    }
+    else if (lane >= 48 && lane < 48 + NF)
+    {
+      const int f = lane - 48;
+      const int j = md.foot_joint[f];
+      st3(&sc.footp[f * 3], ldm3(&sc.oR[j * 9]) * ld3(md.foot_p[f]) + ld3(&sc.op[j * 3]));
+    }
+    SMPC_LANES_END
+    // ---- velocities and bias accelerations (a = 0), ascending ----
+    const double * vq = &sc.x[NQ];
+    for (int lvl = 0; lvl < nlev; lvl++)
+    {
+      SMPC_LANES(NT)
+      if (lane < NJ && md.level[lane] == lvl)
+      {
+        const int j = lane;
+        SV v, a;
+        if (j == 0)
+        {
+          v = sv0();
+          for (int k = 0; k < 6; k++)
+            v = v + vq[k] * ldsv(&sc.S[k * 6]);
+          a = sv0();
+        }
+        else
+        {
+          const int par = md.parent[j];
+          const SV vp = ldsv(&sc.vel[par * 6]);
+          const SV s = ldsv(&sc.S[(j + 5) * 6]);
+          v = vp + vq[j + 5] * s;
+          a = ldsv(&sc.acc[par * 6]) + vq[j + 5] * crm(vp, s);
+        }
+        stsv(&sc.vel[j * 6], v);
+        stsv(&sc.acc[j * 6], a);
+        const SI I = ldsi(&sc.I[j * 10]);
+        const SV h = I * v;
+        stsv(&sc.h[j * 6], h);
+        stsv(&sc.hc[j * 6], h);
+        stsv(&sc.Fc[j * 6], I * a + crf(v, h));
+      }
+      SMPC_LANES_END
+    }
+    // ---- composites, descending: parents gather their children ----
+    for (int lvl = nlev - 2; lvl >= 0; lvl--)
+    {
+      SMPC_LANES(NT)
+      if (lane < NJ && md.level[lane] == lvl)
+      {
+        const int j = lane;
+        SI Ic = ldsi(&sc.Ic[j * 10]);
+        SV hc = ldsv(&sc.hc[j * 6]);
+        SV Fc = ldsv(&sc.Fc[j * 6]);
+        for (int c = j + 1; c < NJ; c++)
+          if (md.parent[c] == j)
+          {
+            Ic = Ic + ldsi(&sc.Ic[c * 10]);
+            hc = hc + ldsv(&sc.hc[c * 6]);
+            Fc = Fc + ldsv(&sc.Fc[c * 6]);
+          }
+        stsi(&sc.Ic[j * 10], Ic);
+        stsv(&sc.hc[j * 6], hc);
+        stsv(&sc.Fc[j * 6], Fc);
+      }
+      SMPC_LANES_END
+    }
+    // ---- CoM, centroidal map columns, hg, b0, hdot target, 6x6 inertia for the base solve ----
+    SMPC_LANES(NT)
+    {
+      const SI I0 = ldsi(&sc.Ic[0]);
+      const V3 com = (1.0 / I0.m) * I0.mc;
+      if (lane < NV)
+      {
+        const int k = lane;
+        const int j = k < 6 ? 0 : k - 5;
+        const SV c = ldsi(&sc.Ic[j * 10]) * ldsv(&sc.S[k * 6]);
+        const V3 ang = c.a - cross(com, c.l);
+        sc.Ag[0 * NV + k] = c.l.x;
+        sc.Ag[1 * NV + k] = c.l.y;
+        sc.Ag[2 * NV + k] = c.l.z;
+        sc.Ag[3 * NV + k] = ang.x;
+        sc.Ag[4 * NV + k] = ang.y;
+        sc.Ag[5 * NV + k] = ang.z;
+      }
+      else if (lane == 32)
+      {
+        st3(sc.com, com);
+        const SV h0 = ldsv(&sc.hc[0]);
+        st3(&sc.hg[0], h0.l);
+        st3(&sc.hg[3], h0.a - cross(com, h0.l));
+        const SV f0 = ldsv(&sc.Fc[0]);
+        st3(&sc.b0[0], f0.l);
+        st3(&sc.b0[3], f0.a - cross(com, f0.l));
+      }
+      else if (lane == 33)
+      {
+        V3 fl = md.total_mass * ld3(md.gravity);
+        V3 fa = mk3(0, 0, 0);
+        for (int f = 0; f < NF; f++)
+          if ((in.mask >> f) & 1u)
+          {
+            const V3 F = ld3(&sc.u[3 * f]);
+            fl = fl + F;
+            fa = fa + cross(ld3(&sc.footp[f * 3]) - com, F);
+          }
+        st3(&sc.hd[0], fl);
+        st3(&sc.hd[3], fa);
+      }
+      else if (lane == 34)
+      {
+        // dense 6x6 of the composite inertia Ic0 (about the world origin), for Gauss-Jordan
+        const double m = I0.m;
+        const V3 c = I0.mc;
+        double * A = sc.gjA;
+        for (int i = 0; i < 36; i++)
+          A[i] = 0.0;
+        A[0] = A[7] = A[14] = m;
+        // top-right = -[mc]x ; bottom-left = [mc]x
+        A[0 * 6 + 4] = c.z;
+        A[0 * 6 + 5] = -c.y;
+        A[1 * 6 + 3] = -c.z;
+        A[1 * 6 + 5] = c.x;
+        A[2 * 6 + 3] = c.y;
+        A[2 * 6 + 4] = -c.x;
+        A[3 * 6 + 1] = -c.z;
+        A[3 * 6 + 2] = c.y;
+        A[4 * 6 + 0] = c.z;
+        A[4 * 6 + 2] = -c.x;
+        A[5 * 6 + 0] = -c.y;
+        A[5 * 6 + 1] = c.x;
+        A[3 * 6 + 3] = I0.jxx;
+        A[3 * 6 + 4] = A[4 * 6 + 3] = I0.jxy;
+        A[3 * 6 + 5] = A[5 * 6 + 3] = I0.jxz;
+        A[4 * 6 + 4] = I0.jyy;
+        A[4 * 6 + 5] = A[5 * 6 + 4] = I0.jyz;
+        A[5 * 6 + 5] = I0.jzz;
+      }
+    }
+    SMPC_LANES_END
+    // ---- in-place Gauss-Jordan inverse of the SPD 6x6 (36 lanes, ping-pong gjA <-> gjB) ----
+    for (int pv = 0; pv < 6; pv++)
+    {
+      const double * src = (pv & 1) ? sc.gjB : sc.gjA;
+      double * dst = (pv & 1) ? sc.gjA : sc.gjB;
+      SMPC_LANES(NT)
+      if (lane < 36)
+      {
+        const int r = lane / 6, c = lane % 6;
+        const double piv = 1.0 / src[pv * 6 + pv];
+        double val;
+        if (r == pv)
+          val = (c == pv) ? piv : src[pv * 6 + c] * piv;
+        else
+          val = (c == pv) ? -src[r * 6 + pv] * piv : src[r * 6 + c] - src[r * 6 + pv] * src[pv * 6 + c] * piv;
+        dst[lane] = val;
+      }
+      SMPC_LANES_END
+    }
+    // after 6 steps the inverse sits in gjA.  M1 = Ic0^-1 * T(c)^-1  with T^-1 = [[I,0],[[c]x, I]]
+    SMPC_LANES(NT)
+    if (lane < 36)
+    {
+      const int r = lane / 6, c = lane % 6;
+      const double * Ii = sc.gjA;
+      double val = Ii[r * 6 + c];
+      if (c < 3)
+      {
+        const V3 cm = ld3(sc.com);
+        // column c of [c]x : [c]x e_c = c x e_c
+        const V3 e = mk3(c == 0, c == 1, c == 2);
+        const V3 col = cross(cm, e);
+        val += Ii[r * 6 + 3] * col.x + Ii[r * 6 + 4] * col.y + Ii[r * 6 + 5] * col.z;
+      }
+      sc.gjB[lane] = val;
+    }
+    SMPC_LANES_END
+    // Agbi = X0^-1 * M1,  X0^-1 = [[R^T, -R^T [p]x],[0, R^T]]
+    SMPC_LANES(NT)
+    if (lane < 36)
+    {
+      const int r = lane / 6, c = lane % 6;
+      const M3 R = ldm3(&sc.oR[0]);
+      const V3 p = ld3(&sc.op[0]);
+      const V3 ml = mk3(sc.gjB[0 * 6 + c], sc.gjB[1 * 6 + c], sc.gjB[2 * 6 + c]);
+      const V3 ma = mk3(sc.gjB[3 * 6 + c], sc.gjB[4 * 6 + c], sc.gjB[5 * 6 + c]);
+      V3 out;
+      if (r < 3)
+        out = tmul(R, ml - cross(p, ma));
+      else
+        out = tmul(R, ma);
+      const int rr = r % 3;
+      sc.Agbi[lane] = rr == 0 ? out.x : (rr == 1 ? out.y : out.z);
+    }
+    SMPC_LANES_END
+    // ---- base acceleration ----
+    SMPC_LANES(NT)
+    if (lane < NV)
+    {
+      double val;
+      if (lane < 6)
+      {
+        val = 0.0;
+        for (int m = 0; m < 6; m++)
+        {
+          double rhs = sc.hd[m] - sc.b0[m];
+          for (int k = 6; k < NV; k++)
+            rhs -= sc.Ag[m * NV + k] * sc.u[3 * NF + k - 6];
+          val += sc.Agbi[lane * 6 + m] * rhs;
+        }
+      }
+      else
+        val = sc.u[3 * NF + lane - 6];
+      sc.a[lane] = val;
+    }
+    SMPC_LANES_END
+    if (in.terminal)
+    {
+      SMPC_LANES(NT)
+      if (lane < NV)
+        sc.a[lane] = 0.0;
+      SMPC_LANES_END
+    }
+    // ---- x+ = x (+) [dt (v + dt a); dt a] ----
+    SMPC_LANES(NT)
+    {
+      const double dt = md.dt;
+      if (lane == 0)
+      {
+        const V3 dv = mk3(dt * (vq[0] + dt * sc.a[0]), dt * (vq[1] + dt * sc.a[1]), dt * (vq[2] + dt * sc.a[2]));
+        const V3 dw = mk3(dt * (vq[3] + dt * sc.a[3]), dt * (vq[4] + dt * sc.a[4]), dt * (vq[5] + dt * sc.a[5]));
+        const SE3 E = exp6(dv, dw);
+        const M3 R0 = ldm3(&sc.oR[0]);
+        st3(&sc.xnext[0], ld3(&sc.op[0]) + R0 * E.p);
+        Quat qn = quat_mul(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]}, quat_exp(dw));
+        const double n = 1.0 / sqrt(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+        sc.xnext[3] = qn.x * n;
+        sc.xnext[4] = qn.y * n;
+        sc.xnext[5] = qn.z * n;
+        sc.xnext[6] = qn.w * n;
+      }
+      else if (lane >= 6 && lane < NV)
+        sc.xnext[lane + 1] = sc.x[lane + 1] + dt * (vq[lane] + dt * sc.a[lane]);
+      if (lane >= 32 && lane < 32 + NV)
+      {
+        const int i = lane - 32;
+        sc.xnext[NQ + i] = vq[i] + dt * sc.a[i];
+      }
+    }
+    SMPC_LANES_END
+
+    if (!DERIV)
+      return;
+
+    // ---- accelerations with the solved a, ascending, and net forces ----
+    for (int lvl = 0; lvl < nlev; lvl++)
+    {
+      SMPC_LANES(NT)
+      if (lane < NJ && md.level[lane] == lvl)
+      {
+        const int j = lane;
+        SV a;
+        if (j == 0)
+        {
+          a = sv0();
+          for (int k = 0; k < 6; k++)
+            a = a + sc.a[k] * ldsv(&sc.S[k * 6]);
+        }
+        else
+        {
+          const int par = md.parent[j];
+          const SV s = ldsv(&sc.S[(j + 5) * 6]);
+          a = ldsv(&sc.acc[par * 6]) + sc.a[j + 5] * s + vq[j + 5] * crm(ldsv(&sc.vel[par * 6]), s);
+        }
+        stsv(&sc.acc[j * 6], a);
+        stsv(&sc.Fc[j * 6], ldsi(&sc.I[j * 10]) * a + crf(ldsv(&sc.vel[j * 6]), ldsv(&sc.h[j * 6])));
+      }
+      SMPC_LANES_END
+    }
+    for (int lvl = nlev - 2; lvl >= 0; lvl--)
+    {
+      SMPC_LANES(NT)
+      if (lane < NJ && md.level[lane] == lvl)
+      {
+        const int j = lane;
+        SV Fc = ldsv(&sc.Fc[j * 6]);
+        for (int c = j + 1; c < NJ; c++)
+          if (md.parent[c] == j)
+            Fc = Fc + ldsv(&sc.Fc[c * 6]);
+        stsv(&sc.Fc[j * 6], Fc);
+      }
+      SMPC_LANES_END
+    }
+    // ---- derivative columns: lane k < NV ----
+    SMPC_LANES(NT)
+    if (lane < NV)
+    {
+      const int k = lane;
+      const int i = k < 6 ? 0 : k - 5;
+      const int lam = md.parent[i];
+      const SV s = ldsv(&sc.S[k * 6]);
+      const SI Ici = ldsi(&sc.Ic[i * 10]);
+      const SV vi = ldsv(&sc.vel[i * 6]);
+      SV d = sv0(), Ak = sv0();
+      if (lam >= 0)
+      {
+        const SV vl = ldsv(&sc.vel[lam * 6]);
+        d = crm(vl, s);
+        Ak = crm(ldsv(&sc.acc[lam * 6]), s) + crm(vl, d);
+      }
+      // sum over subtree bodies of  v_l x* (I_l y) - I_l (v_l x y)  for y = S_k and y = d_k
+      SV BS = sv0(), Bd = sv0();
+      for (int l = i; l < NJ; l++)
+        if ((md.anc[l] >> i) & 1u)
+        {
+          const SI Il = ldsi(&sc.I[l * 10]);
+          const SV vl = ldsv(&sc.vel[l * 6]);
+          BS = BS + crf(vl, Il * s) - Il * crm(vl, s);
+          if (lam >= 0)
+            Bd = Bd + crf(vl, Il * d) - Il * crm(vl, d);
+        }
+      const SV hci = ldsv(&sc.hc[i * 6]);
+      BS = BS + crf(s, hci);
+      Bd = Bd + crf(d, hci);
+      const SV dh = crf(s, hci) + Ici * d;
+      const SV dF = crf(s, ldsv(&sc.Fc[i * 6])) + Ici * Ak + Bd;
+      const SV dFv = BS + Ici * (crm(vi, s) + d);
+      const V3 com = ld3(sc.com);
+      const double im = 1.0 / md.total_mass;
+      const V3 jc = im * (Ici * s).l;
+      const SV h0 = ldsv(&sc.hc[0]);
+      const SV F0 = ldsv(&sc.Fc[0]);
+      const V3 dha = dh.a - cross(com, dh.l) - cross(jc, h0.l);
+      const V3 dFa = dF.a - cross(com, dF.l) - cross(jc, F0.l);
+      const V3 dFva = dFv.a - cross(com, dFv.l);
+      sc.dh_dq[0 * NV + k] = dh.l.x;
+      sc.dh_dq[1 * NV + k] = dh.l.y;
+      sc.dh_dq[2 * NV + k] = dh.l.z;
+      sc.dh_dq[3 * NV + k] = dha.x;
+      sc.dh_dq[4 * NV + k] = dha.y;
+      sc.dh_dq[5 * NV + k] = dha.z;
+      sc.dhd_dq[0 * NV + k] = dF.l.x;
+      sc.dhd_dq[1 * NV + k] = dF.l.y;
+      sc.dhd_dq[2 * NV + k] = dF.l.z;
+      sc.dhd_dq[3 * NV + k] = dFa.x;
+      sc.dhd_dq[4 * NV + k] = dFa.y;
+      sc.dhd_dq[5 * NV + k] = dFa.z;
+      sc.dhd_dv[0 * NV + k] = dFv.l.x;
+      sc.dhd_dv[1 * NV + k] = dFv.l.y;
+      sc.dhd_dv[2 * NV + k] = dFv.l.z;
+      sc.dhd_dv[3 * NV + k] = dFva.x;
+      sc.dhd_dv[4 * NV + k] = dFva.y;
+      sc.dhd_dv[5 * NV + k] = dFva.z;
+      sc.Jcom[0 * NV + k] = jc.x;
+      sc.Jcom[1 * NV + k] = jc.y;
+      sc.Jcom[2 * NV + k] = jc.z;
+      // feet: linear Jacobian columns, local-velocity constraint derivative columns, d hdot_tgt / dq
+      V3 dt_ang = mk3(0, 0, 0);
+      for (int f = 0; f < NF; f++)
+      {
+        const int lj = md.foot_joint[f];
+        const bool anc = (md.anc[lj] >> i) & 1u;
+        const V3 pf = ld3(&sc.footp[f * 3]);
+        V3 jf = mk3(0, 0, 0), cq = mk3(0, 0, 0), cv = mk3(0, 0, 0);
+        if (anc)
+        {
+          jf = s.l + cross(s.a, pf);
+          const M3 Rl = ldm3(&sc.oR[lj * 9]);
+          cv = tmul(Rl, jf);
+          if (lam >= 0)
+            cq = tmul(Rl, d.l + cross(d.a, pf));
+        }
+        sc.Jfoot[(f * 3 + 0) * NV + k] = jf.x;
+        sc.Jfoot[(f * 3 + 1) * NV + k] = jf.y;
+        sc.Jfoot[(f * 3 + 2) * NV + k] = jf.z;
+        sc.dcq[(f * 3 + 0) * NV + k] = cq.x;
+        sc.dcq[(f * 3 + 1) * NV + k] = cq.y;
+        sc.dcq[(f * 3 + 2) * NV + k] = cq.z;
+        sc.dcv[(f * 3 + 0) * NV + k] = cv.x;
+        sc.dcv[(f * 3 + 1) * NV + k] = cv.y;
+        sc.dcv[(f * 3 + 2) * NV + k] = cv.z;
+        if ((in.mask >> f) & 1u)
+          dt_ang = dt_ang + cross(jf - jc, ld3(&sc.u[3 * f]));
+      }
+      sc.dtgt[0 * NV + k] = dt_ang.x;
+      sc.dtgt[1 * NV + k] = dt_ang.y;
+      sc.dtgt[2 * NV + k] = dt_ang.z;
+    }
+    SMPC_LANES_END
+    // ---- base-acceleration derivatives: Agbi * [dtgt - dhd_dq | -dhd_dv | G_f | -Ag_j] ----
+    SMPC_LANES(NT)
+    {
+      constexpr int NCOL = 2 * NV + D::NU;
+      for (int idx = lane; idx < 6 * NCOL; idx += NT)
+      {
+        const int r = idx / NCOL, c = idx % NCOL;
+        double acc = 0.0;
+        if (c < NV)
+        {
+          for (int m = 0; m < 6; m++)
+          {
+            const double rq = (m >= 3 ? sc.dtgt[(m - 3) * NV + c] : 0.0) - sc.dhd_dq[m * NV + c];
+            acc += sc.Agbi[r * 6 + m] * rq;
+          }
+          sc.ab_dq[r * NV + c] = acc;
+        }
+        else if (c < 2 * NV)
+        {
+          const int k = c - NV;
+          for (int m = 0; m < 6; m++)
+            acc -= sc.Agbi[r * 6 + m] * sc.dhd_dv[m * NV + k];
+          sc.ab_dv[r * NV + k] = acc;
+        }
+        else
+        {
+          const int k = c - 2 * NV;
+          if (k < 3 * NF)
+          {
+            const int f = k / 3, jj = k % 3;
+            if ((in.mask >> f) & 1u)
+            {
+              const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
+              const V3 e = mk3(jj == 0, jj == 1, jj == 2);
+              const V3 xc = cross(rr, e); // column jj of [rr]x
+              acc = sc.Agbi[r * 6 + jj] + sc.Agbi[r * 6 + 3] * xc.x + sc.Agbi[r * 6 + 4] * xc.y + sc.Agbi[r * 6 + 5] * xc.z;
+            }
+          }
+          else
+          {
+            const int kk = k - 3 * NF + 6;
+            for (int m = 0; m < 6; m++)
+              acc -= sc.Agbi[r * 6 + m] * sc.Ag[m * NV + kk];
+          }
+          sc.ab_du[r * D::NU + k] = acc;
+        }
+      }
+      // integrator Jacobians on two spare lanes
+      if (lane == 62)
+      {
+        const double dt = md.dt;
+        const V3 dv = mk3(dt * (vq[0] + dt * sc.a[0]), dt * (vq[1] + dt * sc.a[1]), dt * (vq[2] + dt * sc.a[2]));
+        const V3 dw = mk3(dt * (vq[3] + dt * sc.a[3]), dt * (vq[4] + dt * sc.a[4]), dt * (vq[5] + dt * sc.a[5]));
+        M3 J3, Q;
+        Jexp6(dv, dw, J3, Q);
+        stm3(sc.Je3, J3);
+        stm3(sc.JeQ, Q);
+        // action matrix of exp6(nu)^-1 = [[R^T, -R^T [p]x],[0, R^T]]
+        const SE3 E = exp6(dv, dw);
+        const M3 Rt = transpose(E.R);
+        const M3 X = (-1.0) * (Rt * skew(E.p));
+        double * Jq = sc.Jq;
+        const double rt[9] = {Rt.a00, Rt.a01, Rt.a02, Rt.a10, Rt.a11, Rt.a12, Rt.a20, Rt.a21, Rt.a22};
+        const double xx[9] = {X.a00, X.a01, X.a02, X.a10, X.a11, X.a12, X.a20, X.a21, X.a22};
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++)
+          {
+            Jq[i * 6 + j] = rt[i * 3 + j];
+            Jq[(i + 3) * 6 + j + 3] = rt[i * 3 + j];
+            Jq[i * 6 + j + 3] = xx[i * 3 + j];
+            Jq[(i + 3) * 6 + j] = 0.0;
+          }
+      }
+    }
+    SMPC_LANES_END
+  }
+
+  // state residual rx = x (-) x_tgt and (optionally) Jlog6 of the base block, by one lane + vector part
+  template <class D, bool DERIV>
+  SMPC_DEV void kino_state_residual(KinoScratch<D> & sc, const double * xt, int lane)
+  {
+    constexpr int NV = D::NV, NQ = D::NQ;
+    if (lane == 63)
+    {
+      const SE3 Mt{quat_to_R(Quat{xt[3], xt[4], xt[5], xt[6]}), ld3(xt)};
+      const SE3 Mx{ldm3(&sc.oR[0]), ld3(&sc.op[0])};
+      V3 v, w;
+      log6(se3_mul(se3_inv(Mt), Mx), v, w);
+      st3(&sc.rx[0], v);
+      st3(&sc.rx[3], w);
+      if (DERIV)
+      {
+        M3 Ji, X;
+        Jlog6(v, w, Ji, X);
+        const double ji[9] = {Ji.a00, Ji.a01, Ji.a02, Ji.a10, Ji.a11, Ji.a12, Ji.a20, Ji.a21, Ji.a22};
+        const double xx[9] = {X.a00, X.a01, X.a02, X.a10, X.a11, X.a12, X.a20, X.a21, X.a22};
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++)
+          {
+            sc.Jl[i * 6 + j] = ji[i * 3 + j];
+            sc.Jl[(i + 3) * 6 + j + 3] = ji[i * 3 + j];
+            sc.Jl[i * 6 + j + 3] = xx[i * 3 + j];
+            sc.Jl[(i + 3) * 6 + j] = 0.0;
+          }
+      }
+    }
+    else if (lane >= 6 && lane < NV)
+      sc.rx[lane] = sc.x[lane + 1] - xt[lane + 1];
+    if (lane < NV)
+      sc.rx[NV + lane] = sc.x[NQ + lane] - xt[NQ + lane];
+  }
+
+  // Residuals, weighted residuals, cost value, constraint values.  Result: sc.red[0] = stage cost.
+  template <class D, bool DERIV>
+  SMPC_DEV void kino_cost_constraints(KinoScratch<D> & sc, const StageIn<D> & in)
+  {
+    constexpr int NT = 64;
+    constexpr int NV = D::NV, NF = D::NF, NU = D::NU, NDX = D::NDX, NA = D::NA, NC = D::NC;
+    static_assert(NV <= 20 && NF * 3 <= 12 && NU <= 24 && NF <= 8 && NDX <= 40, "lane map of this kernel assumes a Go2-sized robot");
+    const DevModel<D> & md = *in.md;
+    SMPC_LANES(NT)
+    {
+      kino_state_residual<D, DERIV>(sc, in.x_tgt, lane);
+      if (!in.terminal)
+      {
+        if (lane >= 32 && lane < 32 + NU)
+          sc.ru[lane - 32] = sc.u[lane - 32] - in.u_ref[lane - 32];
+        if (lane >= 20 && lane < 20 + NF * 3)
+        {
+          const int i = lane - 20;
+          sc.rf[i] = sc.footp[i] - in.foot_ref[i];
+        }
+        // constraint values
+        if (lane < NA)
+          sc.cval[lane] = md.kinematics_limits ? sc.x[7 + lane] : 0.0;
+        if (lane >= 56 && lane < 56 + NF)
+        {
+          const int f = lane - 56;
+          V3 c = mk3(0, 0, 0);
+          if ((in.mask >> f) & 1u)
+          {
+            const int l = md.foot_joint[f];
+            const SV vl = ldsv(&sc.vel[l * 6]);
+            c = tmul(ldm3(&sc.oR[l * 9]), vl.l + cross(vl.a, ld3(&sc.footp[f * 3])));
+          }
+          st3(&sc.cval[NA + 3 * f], c);
+        }
+      }
+    }
+    SMPC_LANES_END
+    SMPC_LANES(NT)
+    {
+      // weighted residuals
+      if (lane < NDX)
+      {
+        double s = 0.0;
+        for (int j = 0; j < NDX; j++)
+          s += md.w_x[lane * NDX + j] * sc.rx[j];
+        sc.Wrx[lane] = s;
+      }
+      if (lane >= 40 && lane < 46)
+      {
+        const int i = lane - 40;
+        double s = 0.0;
+        const double sc10 = in.terminal ? 10.0 : 1.0; // terminal: 10 * w_cent (src/kinodynamics.cpp:361)
+        for (int j = 0; j < 6; j++)
+          s += sc10 * md.w_cent[i * 6 + j] * sc.hg[j];
+        sc.Whg[i] = s;
+      }
+      if (!in.terminal)
+      {
+        if (lane >= 46 && lane < 52)
+        {
+          const int i = lane - 46;
+          double s = 0.0;
+          for (int j = 0; j < 6; j++)
+            s += md.w_centder[i * 6 + j] * sc.hd[j];
+          sc.Whd[i] = s;
+        }
+        if (lane >= 52 && lane < 52 + NF * 3)
+        {
+          const int i = lane - 52, f = i / 3, r = i % 3;
+          double s = 0.0;
+          for (int j = 0; j < 3; j++)
+            s += md.w_frame[r * 3 + j] * sc.rf[f * 3 + j];
+          sc.Wrf[i] = s;
+        }
+      }
+    }
+    SMPC_LANES_END
+    if (!in.terminal)
+    {
+      SMPC_LANES(NT)
+      if (lane < NU)
+      {
+        double s = 0.0;
+        for (int j = 0; j < NU; j++)
+          s += md.w_u[lane * NU + j] * sc.ru[j];
+        sc.Wru[lane] = s;
+      }
+      SMPC_LANES_END
+    }
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      double c = 0.0;
+      for (int i = 0; i < NDX; i++)
+        c += sc.rx[i] * sc.Wrx[i];
+      for (int i = 0; i < 6; i++)
+        c += sc.hg[i] * sc.Whg[i];
+      if (!in.terminal)
+      {
+        for (int i = 0; i < NU; i++)
+          c += sc.ru[i] * sc.Wru[i];
+        for (int i = 0; i < 6; i++)
+          c += sc.hd[i] * sc.Whd[i];
+        for (int i = 0; i < NF * 3; i++)
+          c += sc.rf[i] * sc.Wrf[i];
+      }
+      sc.red[0] = 0.5 * c;
+    }
+    SMPC_LANES_END
+    (void)NC;
+  }
+
+  // AL multipliers for this stage (reference: SolverProxDDP computeMultipliers).
+  // Inputs (LDS): sc.e, sc.cval, sc.lam_next (lambda_{t+1}), sc.nu.  Centres from global.
+  // Outputs: sc.lamp, sc.vplus, sc.act, sc.red[1] = penalty part of the merit, sc.red[2] = primal infeasibility
+  template <class D>
+  SMPC_DEV void kino_multipliers(KinoScratch<D> & sc, const StageIn<D> & in, const double * lam_e, const double * nu_e)
+  {
+    constexpr int NT = 64;
+    constexpr int NDX = D::NDX, NC = D::NC, NA = D::NA;
+    const DevModel<D> & md = *in.md;
+    const double mu = md.mu;
+    SMPC_LANES(NT)
+    {
+      if (lane < NDX)
+        sc.lamp[lane] = lam_e[lane] + sc.e[lane] / mu;
+      for (int i = lane; i < NC; i += NT)
+      {
+        int kind; // 0 absent 1 eq 2 box
+        if (i < NA)
+          kind = md.kinematics_limits ? 2 : 0;
+        else
+          kind = ((in.mask >> ((i - NA) / 3)) & 1u) ? 1 : 0;
+        double vp = 0.0;
+        int act = 0;
+        if (kind != 0)
+        {
+          const double z = sc.cval[i] + mu * nu_e[i];
+          double proj = 0.0;
+          if (kind == 2)
+            proj = fmin(fmax(z, md.qmin[i]), md.qmax[i]);
+          vp = (z - proj) / mu;
+          act = (z != proj) || kind == 1;
+        }
+        sc.vplus[i] = vp;
+        sc.act[i] = act;
+      }
+    }
+    SMPC_LANES_END
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      double pen = 0.0, prim = 0.0;
+      for (int i = 0; i < NDX; i++)
+      {
+        const double lp = sc.lamp[i], dl = lp - sc.lam_next[i];
+        pen += 0.5 * mu * (lp * lp + dl * dl);
+        prim = fmax(prim, fabs(sc.e[i]));
+      }
+      for (int i = 0; i < NC; i++)
+      {
+        const double vp = sc.vplus[i], dv = vp - sc.nu[i];
+        pen += 0.5 * mu * (vp * vp + dv * dv);
+        double viol = 0.0;
+        if (i < NA)
+        {
+          if (md.kinematics_limits)
+            viol = fmax(fmax(sc.cval[i] - md.qmax[i], md.qmin[i] - sc.cval[i]), 0.0);
+        }
+        else if ((in.mask >> ((i - NA) / 3)) & 1u)
+          viol = fabs(sc.cval[i]);
+        prim = fmax(prim, viol);
+      }
+      sc.red[1] = pen;
+      sc.red[2] = prim;
+    }
+    SMPC_LANES_END
+  }
+} // namespace smpc

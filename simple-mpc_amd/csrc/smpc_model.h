@@ -1,0 +1,143 @@
+// smpc_model.h -- compile-time problem dimensions, the device-resident model table and the HBM layout
+// of every per-instance buffer of the batched kinodynamics MPC engine.
+//
+// Batch layout: instance-major.  Every per-instance array is [B][...] with the instance's data
+// contiguous, so that the lanes of the workgroup that owns an (instance, stage) read and write
+// contiguous, coalesced runs.  Stage-indexed arrays are rings of R = H+1 slots addressed through
+// slot(t) = (head + t) % R: receding the horizon (reference: replaceStageCircular + cycleProblem,
+// src/mpc.cpp:225-226) is a head increment, not a memmove.
+#pragma once
+#include "../../include/smpc_robot.h"
+#include <smpc_backend.h>
+
+namespace smpc
+{
+  template <int NJ_, int NF_>
+  struct Dims
+  {
+    static constexpr int NJ = NJ_;         // joints incl. free-flyer
+    static constexpr int NF = NF_;         // feet (3-D point contacts)
+    static constexpr int NV = NJ_ + 5;     // 6 + (NJ-1)
+    static constexpr int NQ = NJ_ + 6;     // 7 + (NJ-1)
+    static constexpr int NX = NQ + NV;     // reference: nq + nv
+    static constexpr int NDX = 2 * NV;     // src/ocp-handler.cpp:17
+    static constexpr int NA = NV - 6;      // actuated joints
+    static constexpr int NU = NA + 3 * NF; // src/kinodynamics.cpp:34
+    static constexpr int NC = NA + 3 * NF; // joint box rows + 3 velocity rows per foot
+    // LQ knot block (doubles), one per (instance, stage)
+    static constexpr int O_A = 0;
+    static constexpr int O_B = O_A + NDX * NDX;
+    static constexpr int O_Q = O_B + NDX * NU;
+    static constexpr int O_S = O_Q + NDX * NDX;
+    static constexpr int O_R = O_S + NDX * NU;
+    static constexpr int O_C = O_R + NU * NU;
+    static constexpr int O_q = O_C + NC * NDX;
+    static constexpr int O_r = O_q + NDX;
+    static constexpr int O_f = O_r + NU;
+    static constexpr int O_d = O_f + NDX;
+    static constexpr int O_lx = O_d + NC;   // cost gradient without multipliers (for dphi)
+    static constexpr int O_lu = O_lx + NDX;
+    static constexpr int O_lpd = O_lu + NU; // 2 lam+ - lam of this stage's dynamics
+    static constexpr int O_vpd = O_lpd + NDX;
+    static constexpr int LQ_STRIDE = ((O_vpd + NC + 7) / 8) * 8;
+    // gains block per (instance, stage): Kk = [K k] (NU x (NDX+1)), Pt (NDX x NDX), pnext (NDX)
+    static constexpr int G_K = 0;
+    static constexpr int G_Pt = G_K + NU * (NDX + 1);
+    static constexpr int G_pn = G_Pt + NDX * NDX;
+    static constexpr int G_STRIDE = ((G_pn + NDX + 7) / 8) * 8;
+    static constexpr int LS_N = 10; // line-search candidates 2^0 .. 2^-9
+  };
+
+  // Model + settings, device resident (one copy per handle).
+  template <class D>
+  struct DevModel
+  {
+    int parent[D::NJ];
+    int jtype[D::NJ];
+    int level[D::NJ];
+    int nlevels;
+    unsigned anc[D::NJ]; // bit a set <=> joint a is an ancestor-or-self of joint j
+    double jpR[D::NJ][9];
+    double jpp[D::NJ][3];
+    double mass[D::NJ];
+    double com[D::NJ][3];
+    double inertia[D::NJ][6];
+    int foot_joint[D::NF];
+    double foot_p[D::NF][3];
+    double foot_ref_p[D::NF][3];
+    double total_mass;
+    // KinodynamicsSettings (include/simple-mpc/kinodynamics.hpp:24-51)
+    double dt;
+    double gravity[3];
+    double w_x[D::NDX * D::NDX];
+    double w_u[D::NU * D::NU];
+    double w_frame[9];
+    double w_cent[36];
+    double w_centder[36];
+    double qmin[D::NA];
+    double qmax[D::NA];
+    int kinematics_limits;
+    // solver
+    double mu;
+    // terminal state_cost target (model reference state)
+    double x_term[D::NX];
+  };
+
+  // stage descriptors shared by all instances (phase-aligned batch), uploaded per control step
+  template <class D>
+  struct StageShared
+  {
+    unsigned mask;
+    unsigned pad;
+    double u_ref[D::NU];
+    double x_tgt[D::NX];
+  };
+
+  template <class D>
+  struct Buffers
+  {
+    int B = 0, H = 0, R = 0; // batch, horizon, ring length H+1
+    // ring state, [B][R][.]
+    double *xs = nullptr, *us = nullptr, *vs = nullptr, *lams = nullptr; // lams[slot(t)] = lambda_{t+1}
+    double *vs_e = nullptr, *lams_e = nullptr;                           // AL centres
+    // steps, [B][H(+1)][.] (linear in t)
+    double *dxs = nullptr, *dus = nullptr, *dvs = nullptr, *dlams = nullptr;
+    // per-instance references, [B][H][NF*3]
+    double * foot_ref = nullptr;
+    double * ftraj = nullptr; // [B][NF][6] swing start / end
+    // LQ + gains
+    double *lq = nullptr, *gains = nullptr;
+    double *QN = nullptr, *qN = nullptr; // [B][NDX*NDX], [B][NDX]
+    // merit bookkeeping
+    double * parts0 = nullptr;   // [B][H+1][4] phi, cost, prim, dual at the current point
+    double * partsT = nullptr;   // [B][LS_N][H+1][2] phi, prim at trial points
+    double * scal = nullptr;     // [B][16] per-instance scalars, see SC_*
+    double * xdotT = nullptr;    // [B][LS_N][2][2NV] trial xdot for t = 0,1
+    double * xdot01 = nullptr;   // [B][2][2NV]
+    int * ls_sel = nullptr;      // [B] selected candidate, -1 = undecided
+    StageShared<D> * stages = nullptr; // [H] linear in t
+    DevModel<D> * model = nullptr;
+  };
+  enum
+  {
+    SC_PHI0 = 0,
+    SC_DPHI0 = 1,
+    SC_ALPHA = 2,
+    SC_PHI_NEW = 3,
+    SC_PRIM = 4,
+    SC_DUAL = 5,
+    SC_LS_FAILED = 6,
+    SC_PREG = 7,
+    SC_PRIM_NEW = 8,
+    SC_COST = 9,
+    SC_COST_NEW = 10,
+    SC_LS_INDEX = 11,
+    SC_N = 16
+  };
+
+  SMPC_HD int ring_slot(int head, int t, int R)
+  {
+    int s = head + t;
+    return s >= R ? s - R : s;
+  }
+} // namespace smpc

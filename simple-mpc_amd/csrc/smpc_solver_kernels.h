@@ -1,0 +1,736 @@
+// smpc_solver_kernels.h -- model-independent kernel bodies of the batched ProxDDP iteration:
+//   riccati_body : HOT(4) proximal Riccati backward sweep, one 256-lane workgroup per instance,
+//                  per-stage blocks staged in LDS (reference: gar::ProximalRiccatiSolver::backward
+//                  selected at src/mpc.cpp:52; derivation in DESIGN.md)
+//   forward_body : HOT(5) gains -> (dx, du, dnu, dlam) + directional derivative of the merit
+//   select_body  : HOT(6) Armijo test over the evaluated line-search candidates
+//   apply_body   : accept the step (LINEAR rollout x (+) alpha dx, reference src/mpc.cpp:44)
+//   recede_body  : per control step: ring advance, warm-start shift (src/mpc.cpp:201-207), FK of the
+//                  measured state, Raibert foothold + Bezier swing references
+//                  (src/mpc.cpp:278-324, src/foot-trajectory.cpp:41-96)
+#pragma once
+#include "smpc_kino_kernels.h"
+
+namespace smpc
+{
+  template <class D>
+  struct SolverArgs
+  {
+    Buffers<D> b;
+    int head;
+    int j0, nj;
+    double armijo_c1, reg_min, reg_max, reg_inc, reg_dec;
+  };
+
+  // out(i,j) = init(i,j) + sum_k X[k*ldx + i] * Y[k*ldy + j]  for an M x N output, register tiles TM x TN
+  template <int M, int N, int K, int TM, int TN, int NT, class Init, class Store>
+  SMPC_DEV void mm_tn(const double * X, int ldx, const double * Y, int ldy, int lane, Init init, Store store)
+  {
+    static_assert(M % TM == 0 && N % TN == 0, "tile must divide the output");
+    constexpr int TJ = N / TN, NTILES = (M / TM) * TJ;
+    for (int tile = lane; tile < NTILES; tile += NT)
+    {
+      const int i0 = (tile / TJ) * TM, j0 = (tile % TJ) * TN;
+      double acc[TM][TN];
+#pragma unroll
+      for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int c = 0; c < TN; c++)
+          acc[a][c] = init(i0 + a, j0 + c);
+      for (int k = 0; k < K; k++)
+      {
+        double xv[TM], yv[TN];
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+          xv[a] = X[k * ldx + i0 + a];
+#pragma unroll
+        for (int c = 0; c < TN; c++)
+          yv[c] = Y[k * ldy + j0 + c];
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+          for (int c = 0; c < TN; c++)
+            acc[a][c] += xv[a] * yv[c];
+      }
+#pragma unroll
+      for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int c = 0; c < TN; c++)
+          store(i0 + a, j0 + c, acc[a][c]);
+    }
+  }
+
+  // In-place lower Cholesky of the N x N matrix M (leading dimension ld) by the whole workgroup.
+  // Two phases per column: scaled column into `col`, then trailing update.
+  template <int N, int NT>
+  SMPC_DEV void wg_cholesky(double * Mx, int ld, double * col)
+  {
+    for (int k = 0; k < N; k++)
+    {
+      SMPC_LANES(NT)
+      if (lane >= k && lane < N)
+      {
+        const double d = sqrt(Mx[k * ld + k]);
+        col[lane] = lane == k ? d : Mx[lane * ld + k] / d;
+      }
+      SMPC_LANES_END
+      SMPC_LANES(NT)
+      {
+        const int n = N - k; // rows k..N-1
+        for (int idx = lane; idx < n * n; idx += NT)
+        {
+          const int i = k + idx / n, j = k + idx % n;
+          if (j == k)
+            Mx[i * ld + k] = col[i];
+          else if (j <= i && i > k)
+            Mx[i * ld + j] -= col[i] * col[j];
+        }
+      }
+      SMPC_LANES_END
+    }
+  }
+
+  // Solve (L L^T) X = RHS for NRHS columns held column-wise: lane c owns column c, kept in registers.
+  // get(i, c) reads RHS(i, c); put(i, c, v) stores the result.  fwd_only: stop after L y = rhs.
+  template <int N, int NT, class Get, class PutY, class PutX>
+  SMPC_DEV void lane_chol_solve(const double * L, int ld, int ncols, int lane, Get get, PutY puty, PutX putx)
+  {
+    if (lane < ncols)
+    {
+      double col[N];
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        col[i] = get(i, lane);
+#pragma unroll
+      for (int i = 0; i < N; i++)
+      {
+        double s = col[i];
+#pragma unroll
+        for (int k = 0; k < i; k++)
+          s -= L[i * ld + k] * col[k];
+        col[i] = s / L[i * ld + i];
+        puty(i, lane, col[i]);
+      }
+#pragma unroll
+      for (int i = N - 1; i >= 0; i--)
+      {
+        double s = col[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++)
+          s -= L[k * ld + i] * col[k];
+        col[i] = s / L[i * ld + i];
+        putx(i, lane, col[i]);
+      }
+    }
+  }
+
+  // =============================================================================================
+  // riccati_body: grid = B, 256 lanes.  Backward sweep t = H-1 .. 0 for one instance.
+  // =============================================================================================
+  template <class D>
+  struct RiccatiLds
+  {
+    static constexpr int NDX = D::NDX, NU = D::NU, NC = D::NC, NXU = D::NDX + D::NU;
+    double P[NDX * NDX];   // P_{t+1} -> P~ -> P_t
+    double MT[NDX * NXU];  // M = I + mu P (Cholesky factor), then [TA | TB]; later W = L_R^-1 [S^^T r^]
+    double AB[NDX * NXU];  // [A | B]; later C
+    double QS[NDX * NXU];  // [Q^ | S^]
+    double Rh[NU * NU];
+    double p[NDX], pt[NDX], qh[NDX], rh[NU], f[NDX], d[NC], col[NDX], wr[NU], kk[NU];
+  };
+
+  template <class D>
+  SMPC_DEV void riccati_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 256;
+    constexpr int NDX = D::NDX, NU = D::NU, NC = D::NC, NXU = NDX + NU;
+    static_assert(NDX % 3 == 0 && NXU % 3 == 0 && NU % 3 == 0, "register tiles of 3 must divide the dimensions");
+    const Buffers<D> & b = ka.b;
+    const int H = b.H;
+    const int inst = block;
+    const double mu = b.model->mu;
+    SMPC_LDS(RiccatiLds<D>, lds, 1);
+    RiccatiLds<D> & s = lds[0];
+
+    // terminal: P = Q_N, p = q_N
+    SMPC_LANES(NT)
+    {
+      for (int i = lane; i < NDX * NDX; i += NT)
+        s.P[i] = b.QN[(size_t)inst * NDX * NDX + i];
+      for (int i = lane; i < NDX; i += NT)
+        s.p[i] = b.qN[(size_t)inst * NDX + i];
+    }
+    SMPC_LANES_END
+
+    for (int t = H - 1; t >= 0; t--)
+    {
+      const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
+      double * g = b.gains + ((size_t)inst * H + t) * D::G_STRIDE;
+      // ---- load [A|B], f; M = I + mu P; save p_{t+1} ----
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NDX * NDX; idx += NT)
+        {
+          const int i = idx / NDX, j = idx % NDX;
+          s.AB[i * NXU + j] = lq[D::O_A + idx];
+          s.MT[i * NDX + j] = mu * s.P[idx] + (i == j ? 1.0 : 0.0);
+        }
+        for (int idx = lane; idx < NDX * NU; idx += NT)
+        {
+          const int i = idx / NU, j = idx % NU;
+          s.AB[i * NXU + NDX + j] = lq[D::O_B + idx];
+        }
+        for (int i = lane; i < NDX; i += NT)
+        {
+          s.f[i] = lq[D::O_f + i];
+          g[D::G_pn + i] = s.p[i];
+        }
+        for (int i = lane; i < NC; i += NT)
+          s.d[i] = lq[D::O_d + i];
+      }
+      SMPC_LANES_END
+      // pt = p + P f
+      SMPC_LANES(NT)
+      if (lane < NDX)
+      {
+        double acc = s.p[lane];
+        for (int j = 0; j < NDX; j++)
+          acc += s.P[lane * NDX + j] * s.f[j];
+        s.pt[lane] = acc;
+      }
+      SMPC_LANES_END
+      wg_cholesky<NDX, NT>(s.MT, NDX, s.col);
+      // P~ = M^-1 P (columns 0..NDX-1), p~ = M^-1 pt (column NDX)
+      SMPC_LANES(NT)
+      lane_chol_solve<NDX, NT>(
+        s.MT, NDX, NDX + 1, lane, [&](int i, int c) { return c < NDX ? s.P[i * NDX + c] : s.pt[i]; }, [&](int, int, double) {},
+        [&](int i, int c, double v) {
+          if (c < NDX)
+            s.P[i * NDX + c] = v;
+          else
+            s.pt[i] = v;
+        });
+      SMPC_LANES_END
+      // symmetrise P~ and store it for the forward pass
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < NDX * NDX; idx += NT)
+      {
+        const int i = idx / NDX, j = idx % NDX;
+        if (j < i)
+        {
+          const double v = 0.5 * (s.P[i * NDX + j] + s.P[j * NDX + i]);
+          s.P[i * NDX + j] = v;
+          s.P[j * NDX + i] = v;
+        }
+      }
+      SMPC_LANES_END
+      // [TA|TB] = P~ [A|B]  (P~ symmetric -> X^T Y form); also stream P~ out
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NDX * NDX; idx += NT)
+          g[D::G_Pt + idx] = s.P[idx];
+        mm_tn<NDX, NXU, NDX, 3, 3, NT>(
+          s.P, NDX, s.AB, NXU, lane, [](int, int) { return 0.0; }, [&](int i, int j, double v) { s.MT[i * NXU + j] = v; });
+      }
+      SMPC_LANES_END
+      // [Q^|S^] = [Q|S] + A^T [TA|TB];  R^ = R + B^T TB;  q^ = q + A^T p~;  r^ = r + B^T p~
+      SMPC_LANES(NT)
+      {
+        mm_tn<NDX, NXU, NDX, 3, 3, NT>(
+          s.AB, NXU, s.MT, NXU, lane, [&](int i, int j) { return j < NDX ? lq[D::O_Q + i * NDX + j] : lq[D::O_S + i * NU + j - NDX]; },
+          [&](int i, int j, double v) { s.QS[i * NXU + j] = v; });
+        mm_tn<NU, NU, NDX, 3, 3, NT>(
+          s.AB + NDX, NXU, s.MT + NDX, NXU, lane, [&](int i, int j) { return lq[D::O_R + i * NU + j]; },
+          [&](int i, int j, double v) { s.Rh[i * NU + j] = v; });
+        if (lane < NXU)
+        {
+          double acc = lane < NDX ? lq[D::O_q + lane] : lq[D::O_r + lane - NDX];
+          for (int k = 0; k < NDX; k++)
+            acc += s.AB[k * NXU + lane] * s.pt[k];
+          if (lane < NDX)
+            s.qh[lane] = acc;
+          else
+            s.rh[lane - NDX] = acc;
+        }
+      }
+      SMPC_LANES_END
+      wg_cholesky<NU, NT>(s.Rh, NU, s.col);
+      // W = L_R^-1 [S^^T r^] (kept, NU x (NDX+1), in MT);  [K k] = -R^^-1 [S^^T r^]
+      SMPC_LANES(NT)
+      lane_chol_solve<NU, NT>(
+        s.Rh, NU, NDX + 1, lane, [&](int i, int c) { return c < NDX ? s.QS[c * NXU + NDX + i] : s.rh[i]; },
+        [&](int i, int c, double v) { s.MT[i * (NDX + 1) + c] = v; },
+        [&](int i, int c, double v) {
+          g[D::G_K + i * (NDX + 1) + c] = -v;
+          if (c == NDX)
+            s.kk[i] = -v;
+        });
+      SMPC_LANES_END
+      // load C (active rows) over [A|B]
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < NC * NDX; idx += NT)
+        s.AB[idx] = lq[D::O_C + idx];
+      SMPC_LANES_END
+      // P_t = Q^ - W^T W + C^T C / mu ;  p_t = q^ - W^T w_r + C^T d / mu
+      SMPC_LANES(NT)
+      {
+        const double imu = 1.0 / mu;
+        mm_tn<NDX, NDX, NU, 3, 3, NT>(
+          s.MT, NDX + 1, s.MT, NDX + 1, lane, [](int, int) { return 0.0; },
+          [&](int i, int j, double v) { s.P[i * NDX + j] = s.QS[i * NXU + j] - v; });
+        if (lane >= 192 && lane < 192 + NDX)
+        {
+          const int i = lane - 192;
+          double acc = s.qh[i];
+          for (int m = 0; m < NU; m++)
+            acc -= s.MT[m * (NDX + 1) + i] * s.MT[m * (NDX + 1) + NDX];
+          double cd = 0.0;
+          for (int r = 0; r < NC; r++)
+            cd += s.AB[r * NDX + i] * s.d[r];
+          s.p[i] = acc + imu * cd;
+        }
+      }
+      SMPC_LANES_END
+      SMPC_LANES(NT)
+      {
+        const double imu = 1.0 / mu;
+        mm_tn<NDX, NDX, NC, 3, 3, NT>(
+          s.AB, NDX, s.AB, NDX, lane, [](int, int) { return 0.0; }, [&](int i, int j, double v) { s.P[i * NDX + j] += imu * v; });
+      }
+      SMPC_LANES_END
+      // symmetrise P_t
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < NDX * NDX; idx += NT)
+      {
+        const int i = idx / NDX, j = idx % NDX;
+        if (j < i)
+        {
+          const double v = 0.5 * (s.P[i * NDX + j] + s.P[j * NDX + i]);
+          s.P[i * NDX + j] = v;
+          s.P[j * NDX + i] = v;
+        }
+      }
+      SMPC_LANES_END
+    }
+  }
+
+  // =============================================================================================
+  // forward_body: grid = B, 64 lanes.  Forward sweep + merit directional derivative.
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void forward_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NDX = D::NDX, NU = D::NU, NC = D::NC;
+    static_assert(NDX <= 64 && NU + NC <= 64, "one lane per row");
+    const Buffers<D> & b = ka.b;
+    const int H = b.H, R = b.R;
+    const int inst = block;
+    const double mu = b.model->mu;
+    SMPC_LDS(double, dx, D::NDX);
+    SMPC_LDS(double, du, D::NU);
+    SMPC_LDS(double, y, D::NDX);
+    SMPC_LDS(double, part, 64);
+    SMPC_LDS(double, lpd_prev, D::NDX);
+    SMPC_LANES(NT)
+    {
+      if (lane < NDX)
+      {
+        dx[lane] = 0.0;
+        lpd_prev[lane] = 0.0;
+        b.dxs[((size_t)inst * (H + 1)) * NDX + lane] = 0.0;
+      }
+      part[lane] = 0.0;
+    }
+    SMPC_LANES_END
+    for (int t = 0; t < H; t++)
+    {
+      const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
+      const double * g = b.gains + ((size_t)inst * H + t) * D::G_STRIDE;
+      const size_t lt = (size_t)inst * H + t;
+      // du = k + K dx  (lanes 0..NU-1) ; dnu = (C dx + d)/mu (lanes NU..NU+NC-1)
+      SMPC_LANES(NT)
+      {
+        if (lane < NU)
+        {
+          const double * Kr = g + D::G_K + lane * (NDX + 1);
+          double acc = Kr[NDX];
+          for (int j = 0; j < NDX; j++)
+            acc += Kr[j] * dx[j];
+          du[lane] = acc;
+          b.dus[lt * NU + lane] = acc;
+          part[lane] += lq[D::O_lu + lane] * acc;
+        }
+        else if (lane < NU + NC)
+        {
+          const int r = lane - NU;
+          const double * Cr = lq + D::O_C + r * NDX;
+          double acc = lq[D::O_d + r];
+          for (int j = 0; j < NDX; j++)
+            acc += Cr[j] * dx[j];
+          const double dnu = acc / mu;
+          b.dvs[lt * NC + r] = dnu;
+          // vpd (mu dnu - d) - d dnu
+          part[lane] += lq[D::O_vpd + r] * (mu * dnu - lq[D::O_d + r]) - lq[D::O_d + r] * dnu;
+        }
+      }
+      SMPC_LANES_END
+      // y = A dx + B du + f - mu p_{t+1}
+      SMPC_LANES(NT)
+      if (lane < NDX)
+      {
+        const double * Ar = lq + D::O_A + lane * NDX;
+        const double * Br = lq + D::O_B + lane * NU;
+        double acc = 0.0;
+        for (int j = 0; j < NDX; j++)
+          acc += Ar[j] * dx[j];
+        for (int j = 0; j < NU; j++)
+          acc += Br[j] * du[j];
+        const double fi = lq[D::O_f + lane], pn = g[D::G_pn + lane];
+        // lx.dx - lpd_{t-1}.dx + lpd_t.(A dx + B du)
+        part[lane] += (lq[D::O_lx + lane] - lpd_prev[lane]) * dx[lane] + lq[D::O_lpd + lane] * acc;
+        y[lane] = acc + fi - mu * pn;
+      }
+      SMPC_LANES_END
+      // w = P~ y ; dx+ = y - mu w ; dlam+ = w + p_{t+1}
+      SMPC_LANES(NT)
+      if (lane < NDX)
+      {
+        const double * Pr = g + D::G_Pt + lane * NDX;
+        double w = 0.0;
+        for (int j = 0; j < NDX; j++)
+          w += Pr[j] * y[j];
+        const double dxn = y[lane] - mu * w;
+        const double dl = w + g[D::G_pn + lane];
+        b.dxs[((size_t)inst * (H + 1) + t + 1) * NDX + lane] = dxn;
+        b.dlams[lt * NDX + lane] = dl;
+        part[lane] -= lq[D::O_f + lane] * dl;
+        lpd_prev[lane] = lq[D::O_lpd + lane];
+        dx[lane] = dxn; // dx is not read in this phase (only y is), so it can be advanced in place
+      }
+      SMPC_LANES_END
+    }
+    // terminal gradient term (lxN - lpd_{H-1}) . dx_H with lxN = qN + lambda_H
+    SMPC_LANES(NT)
+    if (lane < NDX)
+    {
+      const int sl = ring_slot(ka.head, H - 1, R);
+      const double lamH = b.lams[((size_t)inst * R + sl) * NDX + lane];
+      const double lxN = b.qN[(size_t)inst * NDX + lane] + lamH;
+      part[lane] += (lxN - lpd_prev[lane]) * dx[lane];
+    }
+    SMPC_LANES_END
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      double sacc = 0.0;
+      for (int i = 0; i < 64; i++)
+        sacc += part[i];
+      b.scal[(size_t)inst * SC_N + SC_DPHI0] = sacc;
+      b.ls_sel[inst] = -1;
+    }
+    SMPC_LANES_END
+  }
+
+  // =============================================================================================
+  // select_body: grid = ceil(B/64), one lane per instance.
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void select_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H;
+    SMPC_LANES(NT)
+    {
+      const int inst = block * NT + lane;
+      if (inst < b.B)
+      {
+        double * sc = b.scal + (size_t)inst * SC_N;
+        if (ka.j0 == 0)
+        {
+          double phi = 0.0, cost = 0.0, prim = 0.0, dual = 0.0;
+          for (int t = 0; t <= H; t++)
+          {
+            const double * p = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
+            phi += p[0];
+            cost += p[1];
+            prim = fmax(prim, p[2]);
+            dual = fmax(dual, p[3]);
+          }
+          sc[SC_PHI0] = phi;
+          sc[SC_COST] = cost;
+          sc[SC_PRIM] = prim;
+          sc[SC_DUAL] = dual;
+        }
+        if (b.ls_sel[inst] < 0)
+        {
+          const double phi0 = sc[SC_PHI0], dphi0 = sc[SC_DPHI0];
+          double alpha = 1.0;
+          for (int i = 0; i < ka.j0; i++)
+            alpha *= 0.5;
+          int sel = -1;
+          double phi_sel = 0.0, prim_sel = 0.0;
+          for (int jj = 0; jj < ka.nj; jj++)
+          {
+            const int j = ka.j0 + jj;
+            double phi = 0.0, prim = 0.0;
+            for (int t = 0; t <= H; t++)
+            {
+              const double * p = b.partsT + (((size_t)inst * D::LS_N + j) * (H + 1) + t) * 2;
+              phi += p[0];
+              prim = fmax(prim, p[1]);
+            }
+            const bool ok = phi <= phi0 + ka.armijo_c1 * alpha * dphi0;
+            const bool last = j == D::LS_N - 1;
+            if (ok || last)
+            {
+              sel = j;
+              phi_sel = phi;
+              prim_sel = prim;
+              sc[SC_LS_FAILED] = ok ? 0.0 : 1.0;
+              break;
+            }
+            alpha *= 0.5;
+          }
+          if (sel >= 0)
+          {
+            b.ls_sel[inst] = sel;
+            sc[SC_ALPHA] = alpha;
+            sc[SC_PHI_NEW] = phi_sel;
+            sc[SC_PRIM_NEW] = prim_sel;
+            sc[SC_LS_INDEX] = (double)sel;
+            const double preg = sc[SC_PREG];
+            sc[SC_PREG] = sc[SC_LS_FAILED] != 0.0 ? fmin(preg * ka.reg_inc, ka.reg_max) : fmax(preg * ka.reg_dec, ka.reg_min);
+            for (int i = 0; i < 4 * D::NV; i++)
+              b.xdot01[(size_t)inst * 4 * D::NV + i] = b.xdotT[((size_t)inst * D::LS_N + sel) * 4 * D::NV + i];
+          }
+        }
+      }
+    }
+    SMPC_LANES_END
+  }
+
+  // =============================================================================================
+  // apply_body: grid = B * (H+1), 64 lanes: accept the step of size alpha for (inst, t)
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void apply_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H, R = b.R;
+    const int inst = block / (H + 1), t = block % (H + 1);
+    const double alpha = b.scal[(size_t)inst * SC_N + SC_ALPHA];
+    const int st = ring_slot(ka.head, t, R);
+    const size_t ib = (size_t)inst * R;
+    SMPC_LDS(double, xn, D::NX);
+    SMPC_LANES(NT)
+    lanes_integrate<D>(b.xs + (ib + st) * NX, b.dxs + ((size_t)inst * (H + 1) + t) * NDX, alpha, xn, lane, 0);
+    SMPC_LANES_END
+    SMPC_LANES(NT)
+    {
+      for (int i = lane; i < NX; i += NT)
+        b.xs[(ib + st) * NX + i] = xn[i];
+      if (t < H)
+      {
+        const size_t lt = (size_t)inst * H + t;
+        for (int i = lane; i < NU; i += NT)
+          b.us[(ib + st) * NU + i] += alpha * b.dus[lt * NU + i];
+        for (int i = lane; i < NC; i += NT)
+          b.vs[(ib + st) * NC + i] += alpha * b.dvs[lt * NC + i];
+        for (int i = lane; i < NDX; i += NT)
+          b.lams[(ib + st) * NDX + i] += alpha * b.dlams[lt * NDX + i];
+      }
+    }
+    SMPC_LANES_END
+  }
+
+  // =============================================================================================
+  // recede_body: grid = B, 64 lanes.  `head` is the NEW head (already advanced by the host).
+  // =============================================================================================
+  template <class D>
+  struct RecedeArgs
+  {
+    Buffers<D> b;
+    int head;
+    const double * X;   // [B][NX] measured states (device)
+    int land[D::NF];    // first landing time per foot or -1 (src/mpc.cpp:283-285)
+    int T_fly, T_contact;
+    double swing_apex, timestep;
+    double vbase[6];
+    int shift;          // 1: regular control step; 0: only (re)generate references
+    double reg_init;
+  };
+
+  SMPC_HD V3 bezier8(V3 p0, V3 p1, double apex, float tf)
+  {
+    V3 mid = 0.75 * p0 + 0.25 * p1;
+    mid.z += apex;
+    const double u = (double)tf, uo = 1.0 - u;
+    double bc = 1.0, tn = 1.0;
+    V3 tmp = uo * p0;
+    for (int i = 1; i < 8; i++)
+    {
+      tn = tn * u;
+      bc = bc * (double)(8 - i + 1) / (double)i;
+      const V3 cp = i < 4 ? p0 : (i == 4 ? mid : p1);
+      tmp = uo * (tmp + (tn * bc) * cp);
+    }
+    return tmp + (tn * u) * p1;
+  }
+
+  template <class D>
+  SMPC_DEV void recede_body(const RecedeArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF, NJ = D::NJ;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H, R = b.R;
+    const int inst = block;
+    const DevModel<D> & md = *b.model;
+    const size_t ib = (size_t)inst * R;
+    const double * xm = ka.X + (size_t)inst * NX;
+    SMPC_LDS(double, oR, D::NJ * 9);
+    SMPC_LDS(double, op, D::NJ * 3);
+    SMPC_LDS(double, fp, D::NF * 3);
+    SMPC_LDS(double, fse, D::NF * 6);
+    const int s0 = ring_slot(ka.head, 0, R), sHm1 = ring_slot(ka.head, H - 1, R), sH = ring_slot(ka.head, H, R);
+    const int sHm2 = ring_slot(ka.head, H - 2, R);
+    // ---- warm-start shift on the ring (head already advanced): x_0 := measured, duplicate the tail ----
+    SMPC_LANES(NT)
+    if (ka.shift)
+    {
+      for (int i = lane; i < NX; i += NT)
+      {
+        b.xs[(ib + s0) * NX + i] = xm[i];
+        b.xs[(ib + sH) * NX + i] = b.xs[(ib + sHm1) * NX + i];
+      }
+      for (int i = lane; i < NU; i += NT)
+        b.us[(ib + sHm1) * NU + i] = b.us[(ib + sHm2) * NU + i];
+      for (int i = lane; i < NC; i += NT)
+        b.vs[(ib + sHm1) * NC + i] = 0.0;
+      for (int i = lane; i < NDX; i += NT)
+        b.lams[(ib + sHm1) * NDX + i] = 0.0;
+      if (lane == 0)
+        b.scal[(size_t)inst * SC_N + SC_PREG] = ka.reg_init; // regularisation restarts with every solver run
+    }
+    SMPC_LANES_END
+    // ---- FK of the measured state (reference: RobotDataHandler::updateInternalData, src/robot-handler.cpp:114-127) ----
+    for (int lvl = 0; lvl < md.nlevels; lvl++)
+    {
+      SMPC_LANES(NT)
+      if (lane < NJ && md.level[lane] == lvl)
+      {
+        const int j = lane;
+        M3 Rm;
+        V3 p;
+        if (j == 0)
+        {
+          Rm = quat_to_R(Quat{xm[3], xm[4], xm[5], xm[6]});
+          p = ld3(xm);
+        }
+        else
+        {
+          const int par = md.parent[j];
+          const double ang = xm[6 + j];
+          const double sn = sin(ang), c = cos(ang);
+          const int jt = md.jtype[j];
+          M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -sn, 0, sn, c} : (jt == 2 ? M3{c, 0, sn, 0, 1, 0, -sn, 0, c} : M3{c, -sn, 0, sn, c, 0, 0, 0, 1});
+          const M3 Rp = ldm3(&oR[par * 9]);
+          Rm = Rp * (ldm3(md.jpR[j]) * Rq);
+          p = ld3(&op[par * 3]) + Rp * ld3(md.jpp[j]);
+        }
+        stm3(&oR[j * 9], Rm);
+        st3(&op[j * 3], p);
+      }
+      SMPC_LANES_END
+    }
+    // ---- Raibert foothold, swing start/end update (src/mpc.cpp:280-302) ----
+    SMPC_LANES(NT)
+    if (lane < NF)
+    {
+      const int f = lane;
+      const int j = md.foot_joint[f];
+      const V3 pf = ldm3(&oR[j * 9]) * ld3(md.foot_p[f]) + ld3(&op[j * 3]);
+      st3(&fp[f * 3], pf);
+      const V3 bp = ld3(&op[0]);
+      const V3 refp = ldm3(&oR[0]) * ld3(md.foot_ref_p[f]) + bp;
+      const double tw0 = -(refp.y - bp.y), tw1 = refp.x - bp.x;
+      const double span = (double)(ka.T_fly + ka.T_contact) * ka.timestep;
+      const V3 next = mk3(refp.x + (ka.vbase[0] + ka.vbase[5] * tw0) * span, refp.y + (ka.vbase[1] + ka.vbase[5] * tw1) * span, pf.z);
+      double * ft = b.ftraj + ((size_t)inst * NF + f) * 6;
+      const bool update = !(ka.land[f] < ka.T_fly);
+      if (update)
+      {
+        st3(ft, pf);
+        st3(ft + 3, next);
+      }
+      st3(&fse[f * 6], ld3(ft));
+      st3(&fse[f * 6 + 3], ld3(ft + 3));
+    }
+    SMPC_LANES_END
+    // ---- sample the references for every horizon stage (src/foot-trajectory.cpp:64-82) ----
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < H * NF; idx += NT)
+    {
+      const int k = idx / NF, f = idx % NF;
+      const int t = ka.land[f] - k;
+      const V3 p0 = ld3(&fse[f * 6]), p1 = ld3(&fse[f * 6 + 3]);
+      V3 p;
+      if (t < 0)
+        p = p1;
+      else if (t > ka.T_fly)
+        p = p0;
+      else
+        p = bezier8(p0, p1, ka.swing_apex, float(ka.T_fly - t) / float(ka.T_fly));
+      st3(b.foot_ref + (((size_t)inst * H + k) * NF + f) * 3, p);
+    }
+    SMPC_LANES_END
+  }
+
+  // gather one horizon node t of every instance out of the ring into a dense [B][NX] device buffer
+  template <class D>
+  struct GatherArgs
+  {
+    Buffers<D> b;
+    int head, t;
+    double * out;
+  };
+  template <class D>
+  SMPC_DEV void gather_x_body(const GatherArgs<D> & ka, int block)
+  {
+    constexpr int NT = 256;
+    const Buffers<D> & b = ka.b;
+    const int st = ring_slot(ka.head, ka.t, b.R);
+    SMPC_LANES(NT)
+    {
+      const size_t i = (size_t)block * NT + lane;
+      if (i < (size_t)b.B * D::NX)
+      {
+        const size_t inst = i / D::NX, k = i % D::NX;
+        ka.out[i] = b.xs[(inst * b.R + st) * D::NX + k];
+      }
+    }
+    SMPC_LANES_END
+  }
+
+  // copy current multipliers into the AL centres (start of SolverProxDDP::run: prev_vs / prev_lams)
+  template <class D>
+  SMPC_DEV void centres_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 256;
+    const Buffers<D> & b = ka.b;
+    const size_t n_v = (size_t)b.B * b.R * D::NC, n_l = (size_t)b.B * b.R * D::NDX;
+    SMPC_LANES(NT)
+    {
+      const size_t i = (size_t)block * NT + lane;
+      if (i < n_v)
+        b.vs_e[i] = b.vs[i];
+      if (i < n_l)
+        b.lams_e[i] = b.lams[i];
+    }
+    SMPC_LANES_END
+  }
+} // namespace smpc

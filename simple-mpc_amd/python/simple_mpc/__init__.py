@@ -1,0 +1,415 @@
+"""simple_mpc -- drop-in Python surface for the MPC hot path of Simple-Robotics/simple-mpc, backed by
+the MI355X HIP engine through the C ABI of include/smpc.h.
+
+Mirrors the reference's Python module (reference bindings/module.cpp:23-40, bindings/expose-mpc.cpp:28-107,
+bindings/expose-kinodynamics.cpp:9-129, bindings/expose-robot-handler.cpp:25-60): same class names, method
+names and dict keys for the classes on the `MPC.iterate` path.  Differences, all forced by the missing
+Pinocchio/Aligator Python modules:
+  * `RobotModelHandler` takes a robot table (`load_robot("go2_like")`) instead of a `pinocchio.Model`;
+  * `MPC.solver` / `getTrajOptProblem()` (Aligator objects) are not reproduced;
+  * `BatchedMPC` is an addition: same verbs, `iterate(X[B, nx])`, outputs `[B, ...]`.
+There is no CPU implementation: constructing an MPC without the HIP library or without a GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import KinodynamicsSettingsC, MpcSettingsC, SmpcLib, default_lib
+
+__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "MPC", "BatchedMPC"]
+
+
+def load_robot(name, lib=None):
+    """Built-in robot table (stands in for example_robot_data.load(name).model)."""
+    lib = lib or default_lib()
+    ptr = lib.L.smpc_builtin_robot(name.encode())
+    if not ptr:
+        raise RuntimeError("unknown robot %r" % name)
+    return ptr
+
+
+class RobotModelHandler:
+    """reference: include/simple-mpc/robot-handler.hpp:28-225, src/robot-handler.cpp:12-96."""
+
+    def __init__(self, model, reference_configuration_name="standing", base_frame_name="root_joint"):
+        self._ptr = model
+        self._m = model.contents
+        if reference_configuration_name != "standing":
+            raise RuntimeError("unknown reference configuration %r" % reference_configuration_name)
+        self._base = base_frame_name
+        self._feet = []
+
+    def _table_foot(self, name):
+        for f in range(self._m.nfeet):
+            if self._m.foot_name[f].value.decode() == name:
+                return f
+        raise RuntimeError("frame %r is not a foot of robot %r" % (name, self._m.name.decode()))
+
+    def addPointFoot(self, foot_name, reference_parent_frame_name):
+        f = self._table_foot(foot_name)
+        if f != len(self._feet):
+            raise RuntimeError("feet must be added in the order of the robot table")
+        self._feet.append(foot_name)
+        return f
+
+    def addQuadFoot(self, foot_name, reference_parent_frame_name, contact_points):
+        raise RuntimeError("6-D (quad) feet are not built yet")
+
+    def getFeetNb(self):
+        return len(self._feet)
+
+    def getFootFrameName(self, i):
+        return self._feet[i]
+
+    def getFeetFrameNames(self):
+        return list(self._feet)
+
+    def getFootNb(self, name):
+        return self._feet.index(name)
+
+    def getMass(self):
+        return float(self._m.total_mass)
+
+    def getReferenceState(self):
+        return np.concatenate([np.array(self._m.q_ref[: self._m.nq]), np.zeros(self._m.nv)])
+
+    def getModel(self):
+        return self
+
+    # minimal pinocchio.Model-like attributes used by the reference's example scripts
+    @property
+    def nq(self):
+        return int(self._m.nq)
+
+    @property
+    def nv(self):
+        return int(self._m.nv)
+
+    @property
+    def lowerPositionLimit(self):
+        return np.concatenate([np.full(7, -np.inf), np.array(self._m.q_lo[: self._m.nv - 6])])
+
+    @property
+    def upperPositionLimit(self):
+        return np.concatenate([np.full(7, np.inf), np.array(self._m.q_hi[: self._m.nv - 6])])
+
+
+class RobotDataHandler:
+    """Placeholder with the reference's name; the batched FK runs on the device inside iterate
+    (reference src/robot-handler.cpp:106-149)."""
+
+    def __init__(self, model_handler):
+        self.model_handler = model_handler
+
+
+_KINO_KEYS = [
+    "timestep", "w_x", "w_u", "w_frame", "w_cent", "w_centder", "qmin", "qmax", "gravity", "mu", "Lfoot", "Wfoot",
+    "force_size", "kinematics_limits", "force_cone", "land_cstr",
+]
+
+
+class KinodynamicsOCP:
+    """reference: src/kinodynamics.cpp:29-38 (ctor), bindings/expose-kinodynamics.cpp:9-34 (dict keys)."""
+
+    def __init__(self, settings, model_handler):
+        for k in _KINO_KEYS:
+            if k not in settings:
+                raise KeyError(k)  # boost.python raises KeyError on a missing key
+        self.settings = dict(settings)
+        self.model_handler = model_handler
+        self._problem = None
+        nv = model_handler.nv
+        self.nu = nv - 6 + int(settings["force_size"]) * model_handler.getFeetNb()
+
+    def getSettings(self):
+        return dict(self.settings)
+
+    def getModelHandler(self):
+        return self.model_handler
+
+    def getNu(self):
+        return self.nu
+
+    def createProblem(self, x0, horizon, force_size, gravity, terminal_constraint=False):
+        """reference src/ocp-handler.cpp:96-137"""
+        if force_size != self.settings["force_size"]:
+            raise RuntimeError("force size in settings does not match reference force size")
+        if terminal_constraint:
+            raise RuntimeError("terminal (DCM) constraint is not built yet")
+        self._problem = dict(x0=np.array(x0, float), horizon=int(horizon), gravity=float(gravity))
+
+    def getSize(self):
+        if self._problem is None:
+            raise RuntimeError("Create problem first!")
+        return self._problem["horizon"]
+
+
+_MPC_KEYS = ["support_force", "TOL", "mu_init", "max_iters", "num_threads", "swing_apex", "T_fly", "T_contact", "timestep"]
+
+
+class BatchedMPC:
+    """B phase-aligned instances of the reference's MPC (include/simple-mpc/mpc.hpp:55-197) solved together."""
+
+    def __init__(self, settings, ocp, batch, device_id=0, lib=None):
+        for k in _MPC_KEYS:
+            if k not in settings:
+                raise KeyError(k)
+        if ocp._problem is None:
+            raise RuntimeError("Create problem first!")
+        self._lib = lib or default_lib()
+        L = self._lib.L
+        self.settings = dict(settings)
+        self.ocp_handler = ocp
+        s = ocp.settings
+        c = lambda a: np.ascontiguousarray(np.asarray(a, float))
+        self._keep = [c(s[k]) for k in ("w_x", "w_u", "w_frame", "w_cent", "w_centder", "qmin", "qmax")]
+        mh = ocp.model_handler
+        ndx, nu = 2 * mh.nv, ocp.nu
+        shapes = [(ndx, ndx), (nu, nu), (3, 3), (6, 6), (6, 6), (mh.nv - 6,), (mh.nv - 6,)]
+        for a, sh, k in zip(self._keep, shapes, ("w_x", "w_u", "w_frame", "w_cent", "w_centder", "qmin", "qmax")):
+            if a.shape != sh:
+                raise RuntimeError("%s has shape %s, expected %s" % (k, a.shape, sh))
+        ks = KinodynamicsSettingsC()
+        ks.timestep = s["timestep"]
+        for name, arr in zip(("w_x", "w_u", "w_frame", "w_cent", "w_centder", "qmin", "qmax"), self._keep):
+            setattr(ks, name, arr.ctypes.data)
+        for i in range(3):
+            ks.gravity[i] = float(s["gravity"][i])
+        ks.mu, ks.Lfoot, ks.Wfoot = s["mu"], s["Lfoot"], s["Wfoot"]
+        ks.force_size = int(s["force_size"])
+        ks.kinematics_limits = int(bool(s["kinematics_limits"]))
+        ks.force_cone = int(bool(s["force_cone"]))
+        ks.land_cstr = int(bool(s["land_cstr"]))
+        ms = MpcSettingsC()
+        ms.swing_apex = settings["swing_apex"]
+        ms.support_force = settings["support_force"]
+        ms.TOL = settings["TOL"]
+        ms.mu_init = settings["mu_init"]
+        ms.max_iters = int(settings["max_iters"])
+        ms.num_threads = int(settings["num_threads"])
+        ms.T_fly = int(settings["T_fly"])
+        ms.T_contact = int(settings["T_contact"])
+        ms.T = int(ocp._problem["horizon"])
+        ms.timestep = settings["timestep"]
+        h = C.c_void_p()
+        self._lib.check(L.smpc_create(mh._ptr, C.byref(ks), C.byref(ms), int(batch), ocp._problem["gravity"], int(device_id), C.byref(h)))
+        self._h = h
+        d = np.zeros(8, np.int32)
+        L.smpc_get_dims(self._h, d)
+        self.nq, self.nv, self.nx, self.ndx, self.nu, self.nc, self.nf, self.H = (int(v) for v in d)
+        self.B = int(batch)
+        self._x_reference = mh.getReferenceState()
+        self._velocity_base = np.zeros(6)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.L.smpc_destroy(h)
+            self._h = None
+
+    # ---- reference verbs ----
+    def generateCycleHorizon(self, contact_states):
+        """contact_states: list of {foot_name: bool} (reference bindings/expose-mpc.cpp:78) or uint8 array [n][nfeet]."""
+        if len(contact_states) and isinstance(contact_states[0], dict):
+            names = self.ocp_handler.model_handler.getFeetFrameNames()
+            cs = np.array([[1 if st[n] else 0 for n in names] for st in contact_states], np.uint8)
+        else:
+            cs = np.ascontiguousarray(contact_states, np.uint8)
+        self._lib.check(self._lib.L.smpc_generate_cycle_horizon(self._h, cs, cs.shape[0]))
+
+    def switchToWalk(self, velocity_base):
+        v = np.ascontiguousarray(velocity_base, float)
+        if v.shape != (6,):
+            raise RuntimeError("velocity_base size should be 6")
+        self._velocity_base = v.copy()
+        self._lib.check(self._lib.L.smpc_switch_to_walk(self._h, v))
+
+    def switchToStand(self):
+        self._velocity_base = np.zeros(6)
+        self._lib.check(self._lib.L.smpc_switch_to_stand(self._h))
+
+    @property
+    def velocity_base(self):
+        return self._velocity_base
+
+    @velocity_base.setter
+    def velocity_base(self, v):
+        # reference: public member MPC::velocity_base_ (bindings/expose-mpc.cpp:86); walking state is unchanged
+        v = np.ascontiguousarray(v, float)
+        self._velocity_base = v.copy()
+        self._lib.check(self._lib.L.smpc_switch_to_walk(self._h, v))
+
+    @property
+    def x_reference(self):
+        return self._x_reference
+
+    @x_reference.setter
+    def x_reference(self, x):
+        x = np.ascontiguousarray(x, float)
+        if x.shape != (self.nx,):
+            raise RuntimeError("x_ref not of the right size")
+        self._x_reference = x.copy()
+        self._lib.check(self._lib.L.smpc_set_x_reference(self._h, x))
+
+    def iterate(self, X):
+        X = np.ascontiguousarray(X, float)
+        if X.shape != (self.B, self.nx):
+            raise RuntimeError("X must have shape (batch, nq+nv)")
+        self._lib.check(self._lib.L.smpc_iterate(self._h, X))
+
+    def iterate_device(self, device_ptr):
+        self._lib.check(self._lib.L.smpc_iterate_device(self._h, C.c_void_p(int(device_ptr))))
+
+    def wait(self):
+        self._lib.check(self._lib.L.smpc_wait(self._h))
+
+    def get_x_device(self, t, device_ptr):
+        """xs[t] of every instance into a device buffer [B][nx] (asynchronous on the engine's stream)."""
+        self._lib.check(self._lib.L.smpc_get_x_device(self._h, int(t), C.c_void_p(int(device_ptr))))
+
+    def _get(self, fn, shape):
+        out = np.zeros(shape)
+        self._lib.check(getattr(self._lib.L, fn)(self._h, out))
+        return out
+
+    @property
+    def xs(self):
+        return self._get("smpc_get_xs", (self.B, self.H + 1, self.nx))
+
+    @property
+    def us(self):
+        return self._get("smpc_get_us", (self.B, self.H, self.nu))
+
+    @property
+    def K0(self):
+        return self._get("smpc_get_K0", (self.B, self.nu, self.ndx))
+
+    @property
+    def Ks(self):
+        return self._get("smpc_get_Ks", (self.B, self.H, self.nu, self.ndx))
+
+    @property
+    def vs(self):
+        return self._get("smpc_get_vs", (self.B, self.H, self.nc))
+
+    @property
+    def lams(self):
+        return self._get("smpc_get_lams", (self.B, self.H + 1, self.ndx))
+
+    @property
+    def info(self):
+        return self._get("smpc_get_info", (self.B, 16))
+
+    def getStateDerivative(self, t):
+        if t not in (0, 1):
+            raise RuntimeError("state derivative is retained for t = 0, 1 only")
+        return self._get("smpc_get_state_derivative01", (self.B, 2, 2 * self.nv))[:, t, :]
+
+    def getReferencePoses(self):
+        return self._get("smpc_get_reference_poses", (self.B, self.H, self.nf, 3))
+
+    def _timing(self, which):
+        names = self.ocp_handler.model_handler.getFeetFrameNames()
+        out = {}
+        for f, n in enumerate(names):
+            buf = np.zeros(256, np.int32)
+            cnt = self._lib.check(self._lib.L.smpc_get_foot_timing(self._h, f, which, buf, 256))
+            out[n] = [int(v) for v in buf[:cnt]]
+        return out
+
+    @property
+    def foot_takeoff_times(self):
+        return self._timing(0)
+
+    @property
+    def foot_land_times(self):
+        return self._timing(1)
+
+    def getFootTakeoffCycle(self, name):
+        return self._timing(0)[name]
+
+    def getFootLandCycle(self, name):
+        return self._timing(1)[name]
+
+    def cold_trace(self):
+        out = np.zeros((100, 4))
+        n = self._lib.L.smpc_get_cold_trace(self._h, out, 100)
+        return out[:n]
+
+    def getSettings(self):
+        return dict(self.settings)
+
+    def getModelHandler(self):
+        return self.ocp_handler.model_handler
+
+    # ---- debug / profiling ----
+    def debug_lq(self, inst, t):
+        n = self._lib.L.smpc_lq_size(self._h)
+        out = np.zeros(n)
+        self._lib.check(self._lib.L.smpc_debug_get_lq(self._h, inst, t, out))
+        ndx, nu, nc = self.ndx, self.nu, self.nc
+        o = 0
+        res = {}
+        for name, shape in (
+            ("A", (ndx, ndx)), ("B", (ndx, nu)), ("Q", (ndx, ndx)), ("S", (ndx, nu)), ("R", (nu, nu)), ("C", (nc, ndx)),
+            ("q", (ndx,)), ("r", (nu,)), ("f", (ndx,)), ("d", (nc,)), ("lx", (ndx,)), ("lu", (nu,)), ("lpd", (ndx,)),
+            ("vpd", (nc,)),
+        ):
+            sz = int(np.prod(shape))
+            res[name] = out[o : o + sz].reshape(shape).copy()
+            o += sz
+        return res
+
+    def debug_steps(self):
+        dxs = np.zeros((self.B, self.H + 1, self.ndx))
+        dus = np.zeros((self.B, self.H, self.nu))
+        self._lib.check(self._lib.L.smpc_debug_get_steps(self._h, dxs, dus))
+        return dxs, dus
+
+    def debug_terminal(self, inst):
+        QN, qN = np.zeros((self.ndx, self.ndx)), np.zeros(self.ndx)
+        self._lib.check(self._lib.L.smpc_debug_get_terminal(self._h, inst, QN, qN))
+        return QN, qN
+
+    def set_profiling(self, on):
+        self._lib.L.smpc_set_profiling(self._h, int(on))
+
+    def kernel_times(self):
+        ms = np.zeros(7)
+        calls = np.zeros(7, np.int64)
+        self._lib.check(self._lib.L.smpc_get_kernel_times(self._h, ms, calls))
+        names = ["recede", "deriv", "riccati", "forward", "trial", "select", "apply"]
+        return {n: (float(m), int(c)) for n, m, c in zip(names, ms, calls)}
+
+    def reset_kernel_times(self):
+        self._lib.check(self._lib.L.smpc_reset_kernel_times(self._h))
+
+
+class MPC(BatchedMPC):
+    """Single-instance view with the reference's exact verbs: iterate(x), xs/us/Ks as lists of vectors
+    (reference bindings/expose-mpc.cpp:73-106)."""
+
+    def __init__(self, settings, ocp, device_id=0, lib=None):
+        super().__init__(settings, ocp, 1, device_id, lib)
+
+    def iterate(self, x):
+        x = np.ascontiguousarray(x, float)
+        if x.shape != (self.nx,):
+            raise RuntimeError("x must have size nq+nv")
+        super().iterate(x[None, :])
+
+    @property
+    def xs(self):
+        return list(super().xs[0])
+
+    @property
+    def us(self):
+        return list(super().us[0])
+
+    @property
+    def Ks(self):
+        return list(super().Ks[0])
+
+    def getStateDerivative(self, t):
+        return super().getStateDerivative(t)[0]

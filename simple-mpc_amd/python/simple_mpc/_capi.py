@@ -1,0 +1,154 @@
+"""ctypes binding of include/smpc.h (libsmpc_hip.so).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950).  There is
+no CPU implementation behind it: loading fails loudly if the library is missing, and every compute
+entry point fails if no HIP device is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libsmpc_hip.so"))
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_lp = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_bp = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+class KinodynamicsSettingsC(C.Structure):
+    _fields_ = [
+        ("timestep", C.c_double),
+        ("w_x", C.c_void_p),
+        ("w_u", C.c_void_p),
+        ("w_frame", C.c_void_p),
+        ("w_cent", C.c_void_p),
+        ("w_centder", C.c_void_p),
+        ("qmin", C.c_void_p),
+        ("qmax", C.c_void_p),
+        ("gravity", C.c_double * 3),
+        ("mu", C.c_double),
+        ("Lfoot", C.c_double),
+        ("Wfoot", C.c_double),
+        ("force_size", C.c_int),
+        ("kinematics_limits", C.c_int),
+        ("force_cone", C.c_int),
+        ("land_cstr", C.c_int),
+    ]
+
+
+class MpcSettingsC(C.Structure):
+    _fields_ = [
+        ("swing_apex", C.c_double),
+        ("support_force", C.c_double),
+        ("TOL", C.c_double),
+        ("mu_init", C.c_double),
+        ("max_iters", C.c_int),
+        ("num_threads", C.c_int),
+        ("T_fly", C.c_int),
+        ("T_contact", C.c_int),
+        ("T", C.c_int),
+        ("timestep", C.c_double),
+    ]
+
+
+MAXJ, MAXF, NAME = 32, 4, 32
+
+
+class RobotModelC(C.Structure):
+    """Mirror of smpc_robot_model (include/smpc_robot.h)."""
+
+    _fields_ = [
+        ("name", C.c_char * NAME),
+        ("njoints", C.c_int),
+        ("nq", C.c_int),
+        ("nv", C.c_int),
+        ("parent", C.c_int * MAXJ),
+        ("jtype", C.c_int * MAXJ),
+        ("jp_R", (C.c_double * 9) * MAXJ),
+        ("jp_p", (C.c_double * 3) * MAXJ),
+        ("mass", C.c_double * MAXJ),
+        ("com", (C.c_double * 3) * MAXJ),
+        ("inertia", (C.c_double * 6) * MAXJ),
+        ("nfeet", C.c_int),
+        ("foot_name", (C.c_char * NAME) * MAXF),
+        ("foot_joint", C.c_int * MAXF),
+        ("foot_p", (C.c_double * 3) * MAXF),
+        ("foot_ref_p", (C.c_double * 3) * MAXF),
+        ("q_ref", C.c_double * (MAXJ + 6)),
+        ("q_lo", C.c_double * MAXJ),
+        ("q_hi", C.c_double * MAXJ),
+        ("total_mass", C.c_double),
+    ]
+
+
+# every symbol declared in include/smpc.h
+SYMBOLS = [
+    "smpc_builtin_robot", "smpc_last_error", "smpc_device_count", "smpc_create", "smpc_destroy", "smpc_get_dims",
+    "smpc_generate_cycle_horizon", "smpc_switch_to_walk", "smpc_switch_to_stand", "smpc_set_x_reference",
+    "smpc_iterate", "smpc_iterate_device", "smpc_wait", "smpc_get_x_device", "smpc_get_xs", "smpc_get_us", "smpc_get_K0", "smpc_get_Ks",
+    "smpc_get_vs", "smpc_get_lams", "smpc_get_state_derivative01", "smpc_get_reference_poses",
+    "smpc_get_foot_timing", "smpc_get_info", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
+    "smpc_debug_get_steps", "smpc_debug_get_terminal", "smpc_set_profiling", "smpc_get_kernel_times", "smpc_reset_kernel_times",
+]
+
+
+class SmpcLib:
+    def __init__(self, path=None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "simple_mpc: native library %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950).  There is no CPU fallback." % path
+            )
+        self.path = path
+        L = C.CDLL(path)
+        self.L = L
+        vp = C.c_void_p
+        L.smpc_builtin_robot.restype = C.POINTER(RobotModelC)
+        L.smpc_builtin_robot.argtypes = [C.c_char_p]
+        L.smpc_last_error.restype = C.c_char_p
+        L.smpc_device_count.restype = C.c_int
+        L.smpc_create.argtypes = [
+            C.POINTER(RobotModelC), C.POINTER(KinodynamicsSettingsC), C.POINTER(MpcSettingsC), C.c_int, C.c_double,
+            C.c_int, C.POINTER(vp),
+        ]
+        L.smpc_destroy.argtypes = [vp]
+        L.smpc_get_dims.argtypes = [vp, _ip]
+        L.smpc_generate_cycle_horizon.argtypes = [vp, _bp, C.c_int]
+        L.smpc_switch_to_walk.argtypes = [vp, _dp]
+        L.smpc_switch_to_stand.argtypes = [vp]
+        L.smpc_set_x_reference.argtypes = [vp, _dp]
+        L.smpc_iterate.argtypes = [vp, _dp]
+        L.smpc_iterate_device.argtypes = [vp, vp]
+        L.smpc_wait.argtypes = [vp]
+        L.smpc_get_x_device.argtypes = [vp, C.c_int, vp]
+        for nm in ("xs", "us", "K0", "Ks", "vs", "lams", "state_derivative01", "reference_poses", "info"):
+            getattr(L, "smpc_get_" + nm).argtypes = [vp, _dp]
+        L.smpc_get_foot_timing.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
+        L.smpc_get_cold_trace.argtypes = [vp, _dp, C.c_int]
+        L.smpc_lq_size.argtypes = [vp]
+        L.smpc_debug_get_lq.argtypes = [vp, C.c_int, C.c_int, _dp]
+        L.smpc_debug_get_steps.argtypes = [vp, _dp, _dp]
+        L.smpc_debug_get_terminal.argtypes = [vp, C.c_int, _dp, _dp]
+        L.smpc_set_profiling.argtypes = [vp, C.c_int]
+        L.smpc_get_kernel_times.argtypes = [vp, _dp, _lp]
+        L.smpc_reset_kernel_times.argtypes = [vp]
+
+    def check(self, code):
+        if code < 0:
+            msg = self.L.smpc_last_error().decode()
+            raise RuntimeError(msg)  # the reference raises std::runtime_error -> Python RuntimeError
+        return code
+
+
+_default = None
+
+
+def default_lib():
+    global _default
+    if _default is None:
+        _default = SmpcLib()
+    return _default

@@ -1,0 +1,69 @@
+// TEST INFRASTRUCTURE ONLY -- sequential "lane loop" stand-in for simple-mpc_amd/csrc/smpc_backend.h.
+//
+// The test build puts tests/emu first on the include path, so the unmodified kernel bodies and host
+// logic of simple-mpc_amd/csrc are compiled by g++ with every SMPC_LANES phase executed as a loop
+// over lanes (in ascending or descending order, see smpc::emu_reverse: running both orders and
+// comparing results exposes missing phase barriers).  It exists so that the numerics of the HIP
+// kernel bodies can be checked against the oracle in the CPU-only CI tier and under sanitizers;
+// the shipped library is never built with it and has no CPU path.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#define SMPC_CPU_EMU_BUILD 1
+#define SMPC_HD inline
+#define SMPC_DEV inline
+#define SMPC_DEV_NOINLINE inline
+#define SMPC_LDS(type, name, n) static thread_local type name[n]
+#define SMPC_LANES(NT)                                                                                                 \
+  for (int _l = 0; _l < (NT); ++_l)                                                                                    \
+  {                                                                                                                    \
+    const int lane = ::smpc::emu_reverse ? ((NT)-1 - _l) : _l;                                                         \
+    (void)lane;
+#define SMPC_LANES_END }
+#define SMPC_PL(type, name, NT) type name[NT]
+#define SMPC_PLA(type, name, NT, n) type name[NT][n]
+#define SMPC_PLV(name) name[lane]
+
+namespace smpc
+{
+  inline bool emu_reverse = std::getenv("SMPC_EMU_REVERSE") != nullptr && std::getenv("SMPC_EMU_REVERSE")[0] == '1';
+  typedef int stream_t;
+  inline void * dev_alloc(size_t bytes)
+  {
+    void * p = std::calloc(bytes ? bytes : 8, 1);
+    if (!p)
+      throw std::runtime_error("emu: out of memory");
+    return p;
+  }
+  inline void dev_free(void * p) { std::free(p); }
+  inline void h2d(void * dst, const void * src, size_t bytes, stream_t) { std::memcpy(dst, src, bytes); }
+  inline void d2h(void * dst, const void * src, size_t bytes, stream_t) { std::memcpy(dst, src, bytes); }
+  inline void d2d(void * dst, const void * src, size_t bytes, stream_t) { std::memmove(dst, src, bytes); }
+  inline void dev_zero(void * dst, size_t bytes, stream_t) { std::memset(dst, 0, bytes); }
+  inline void stream_sync(stream_t) {}
+  inline stream_t stream_create() { return 0; }
+  inline void stream_destroy(stream_t) {}
+  inline void set_device(int) {}
+  inline int device_count() { return 1; }
+  struct event_t
+  {
+    int e;
+  };
+  inline event_t event_create() { return event_t{0}; }
+  inline void event_destroy(event_t) {}
+  inline void event_record(event_t, stream_t) {}
+  inline float event_elapsed_ms(event_t, event_t) { return 0.f; }
+
+  template <class Args, void (*Body)(const Args &, int), int NT>
+  inline void launch(int grid, stream_t, const Args & a)
+  {
+#pragma omp parallel for schedule(dynamic)
+    for (int b = 0; b < grid; b++)
+      Body(a, b);
+  }
+} // namespace smpc

@@ -1,0 +1,88 @@
+"""Shared construction of (oracle MPC, product MPC) pairs on the Go2 kinodynamics settings of record
+(reference examples/go2_kinodynamics.py:30-139).  TEST INFRASTRUCTURE."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "simple-mpc_amd", "python"))
+
+import oracle_lib as O  # noqa: E402
+import simple_mpc  # noqa: E402
+from simple_mpc._capi import SmpcLib  # noqa: E402
+
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libsmpc_emu.so")
+FEET = ["FL_foot", "FR_foot", "RL_foot", "RR_foot"]
+MPC_KEYS = ["support_force", "TOL", "mu_init", "max_iters", "num_threads", "swing_apex", "T_fly", "T_contact", "timestep"]
+SIGMA = np.concatenate([np.ones(3) * 0.02, np.ones(3) * 0.05, np.ones(12) * 0.1, np.ones(3) * 0.1, np.ones(3) * 0.2, np.ones(12) * 0.5])
+
+_emu = None
+
+
+def emu_lib():
+    """The test-only sequential-lane build of the kernel bodies (never used by the product path)."""
+    global _emu
+    if _emu is None:
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+
+        g.build_emu()
+        _emu = SmpcLib(EMU_LIB)
+    return _emu
+
+
+def make_product(batch, max_iters=1, lib=None, horizon=50, settings_override=None, mpc_override=None, device_id=0):
+    rb = O.Robot("go2_like")
+    s = O.go2_kino_settings(rb)
+    if settings_override:
+        s.update(settings_override)
+    ms = O.go2_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if mpc_override:
+        ms.update(mpc_override)
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+    for n in FEET:
+        mh.addPointFoot(n, "root_joint")
+    ocp = simple_mpc.KinodynamicsOCP(s, mh)
+    ocp.createProblem(mh.getReferenceState(), horizon, 3, -9.81, False)
+    conf = {k: ms[k] for k in MPC_KEYS}
+    gm = simple_mpc.BatchedMPC(conf, ocp, batch, device_id=device_id, lib=lib)
+    return gm, rb, s, ms
+
+
+def make_oracle(batch, max_iters=1, horizon=50, settings_override=None, mpc_override=None):
+    rb = O.Robot("go2_like")
+    s = O.go2_kino_settings(rb)
+    if settings_override:
+        s.update(settings_override)
+    ms = O.go2_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if mpc_override:
+        ms.update(mpc_override)
+    K = O.Kino(rb, s)
+    om = O.OracleMPC(K, ms, batch)
+    return om, rb, K
+
+
+def make_pair(batch, max_iters=1, lib=None, horizon=50, walk=(0.2, 0, 0, 0, 0, 0), **kw):
+    om, rb, _ = make_oracle(batch, max_iters, horizon, **kw)
+    gm, _, _, _ = make_product(batch, max_iters, lib, horizon, **kw)
+    cs = O.trot_cycle()
+    om.generateCycleHorizon(cs)
+    gm.generateCycleHorizon(cs)
+    v = np.array(walk, float)
+    om.switchToWalk(v)
+    gm.switchToWalk(v)
+    return om, gm, rb
+
+
+def random_states(rb, batch, seed=20240529, scale=1.0):
+    """Synthetic initial states of SURVEY 8(d): x_ref (+) N(0, diag(sigma^2))."""
+    rng = np.random.default_rng(seed)
+    return np.stack([rb.integrate(rb.x_ref, rng.normal(size=rb.ndx) * SIGMA * scale) for _ in range(batch)])
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(1.0, np.abs(a).max()))

@@ -319,6 +319,27 @@ class OracleMPC:
     def xdot(self):
         return self._get(7, (self.B, self.H, 2 * self.kino.nv))
 
+    def keep_knots(self, on=True):
+        lib().orc_mpc_keep_knots.argtypes = [C.c_void_p, C.c_int]
+        lib().orc_mpc_keep_knots(self.h, int(on))
+
+    def knot(self, b, t):
+        k = self.kino
+        ndx, nu, nc = k.ndx, k.nu, k.nc
+        lib().orc_mpc_get_knot.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+        out = np.zeros(2 * ndx * ndx + 2 * ndx * nu + nu * nu + nc * ndx + 2 * ndx + nu + nc)
+        n = lib().orc_mpc_get_knot(self.h, b, t, out)
+        assert n == out.size, n
+        res, o = {}, 0
+        for name, shape in (
+            ("A", (ndx, ndx)), ("B", (ndx, nu)), ("Q", (ndx, ndx)), ("S", (ndx, nu)), ("R", (nu, nu)), ("C", (nc, ndx)),
+            ("q", (ndx,)), ("r", (nu,)), ("f", (ndx,)), ("d", (nc,)),
+        ):
+            sz = int(np.prod(shape))
+            res[name] = out[o : o + sz].reshape(shape).copy()
+            o += sz
+        return res
+
     def cold_trace(self):
         n = lib().orc_mpc_cold_iters(self.h)
         out = np.zeros((n, 4))

@@ -1,0 +1,85 @@
+"""GPU parity tests: the HIP path (through the C ABI, libsmpc_hip.so) against the CPU oracle on the same
+seeded inputs.  Tolerance (north_star): <= 1e-4 relative state-trajectory error."""
+import numpy as np
+import pytest
+
+import mpc_setup as S
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _loaded_native():
+    with open("/proc/self/maps") as f:
+        return "libsmpc_hip.so" in f.read()
+
+
+def test_native_library_is_the_one_loaded(built):
+    gm, rb, _, _ = S.make_product(1)
+    assert _loaded_native(), "HIP extension not loaded"
+    assert gm._lib.L.smpc_device_count() >= 1
+
+
+def test_cold_solve_matches_oracle(built):
+    om, gm, rb = S.make_pair(batch=3)
+    assert len(om.cold_trace()) == len(gm.cold_trace())
+    assert S.rel_err(om.xs, gm.xs) < TOL
+    assert S.rel_err(om.us, gm.us) < TOL
+
+
+@pytest.mark.parametrize("iters", [1, 3])
+def test_closed_loop_parity(built, iters):
+    B = 16
+    om, gm, rb = S.make_pair(batch=B, max_iters=iters)
+    X = S.random_states(rb, B)
+    worst = 0.0
+    for step in range(12):
+        om.iterate(X)
+        gm.iterate(X)
+        worst = max(worst, S.rel_err(om.xs, gm.xs))
+        assert S.rel_err(om.xs, gm.xs) < TOL, (step, S.rel_err(om.xs, gm.xs))
+        assert S.rel_err(om.us, gm.us) < TOL * 10
+        assert np.array_equal(om.info[:, 2], gm.info[:, 2]), "line-search step sizes differ"
+        assert S.rel_err(om.foot_refs, gm.getReferencePoses()) < 1e-12
+        X = om.xs[:, 1, :].copy()
+    for f in range(4):
+        assert om.timing(f, 0) == gm.foot_takeoff_times[S.FEET[f]]
+        assert om.timing(f, 1) == gm.foot_land_times[S.FEET[f]]
+    print("worst relative xs error over the run: %.3e" % worst)
+
+
+def test_stage_knots_match_oracle(built):
+    om, gm, rb = S.make_pair(batch=2)
+    om.keep_knots()
+    X = S.random_states(rb, 2)
+    om.iterate(X)
+    gm.iterate(X)
+    for t in (0, 1, 17, 48, 49):
+        ko, kg = om.knot(1, t), gm.debug_lq(1, t)
+        for k in ("A", "B", "Q", "S", "R", "C", "q", "r", "f", "d"):
+            assert S.rel_err(ko[k], kg[k]) < 1e-8, (t, k)
+
+
+def test_full_size_properties(built):
+    """BASELINE size (B=4096, H=50, 3 iterations): size-independent properties instead of an oracle run:
+    identical instances give identical trajectories, dynamics defects and contact constraints are closed,
+    the step is a descent step for every instance."""
+    B = 4096
+    gm, rb, _, _ = S.make_product(B, max_iters=3)
+    import oracle_lib as O
+
+    gm.generateCycleHorizon(O.trot_cycle())
+    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = S.random_states(rb, 64)
+    X = np.tile(X, (B // 64, 1))  # 64 distinct states, each repeated 64 times
+    for _ in range(3):
+        gm.iterate(X)
+        xs = gm.xs
+        X = xs[:, 1, :].copy()
+    xs = xs.reshape(B // 64, 64, *xs.shape[1:])
+    assert np.abs(xs - xs[0:1]).max() == 0.0, "replicated instances must be bit-identical"
+    info = gm.info
+    assert np.all(np.isfinite(info))
+    assert np.all(info[:, 8] < 1e-2), "primal infeasibility after the step"
+    assert np.all(info[:, 1] < 0), "merit directional derivative must be negative"
+    assert np.all(info[:, 3] <= info[:, 0]), "merit must not increase"
