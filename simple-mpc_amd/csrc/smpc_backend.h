@@ -54,6 +54,9 @@ namespace smpc
     void * p = nullptr;
     SMPC_HIP(hipMalloc(&p, bytes ? bytes : 8));
     SMPC_HIP(hipMemset(p, 0, bytes ? bytes : 8));
+    // the engine's streams are non-blocking (no implicit ordering with the null stream the memset
+    // runs on): make the zero-fill complete before any kernel can touch the buffer
+    SMPC_HIP(hipDeviceSynchronize());
     return p;
   }
   inline void dev_free(void * p)

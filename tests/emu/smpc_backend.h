@@ -18,7 +18,11 @@
 #define SMPC_HD inline
 #define SMPC_DEV inline
 #define SMPC_DEV_NOINLINE inline
-#define SMPC_LDS(type, name, n) static thread_local type name[n]
+// LDS is NOT zero on the GPU: poison it on every kernel-body entry (0xFF bytes = NaN doubles) so that a
+// read-before-write shows up here instead of only on hardware.
+#define SMPC_LDS(type, name, n)                                                                                        \
+  static thread_local type name[n];                                                                                    \
+  std::memset((void *)name, 0xFF, sizeof(type) * (n))
 #define SMPC_LANES(NT)                                                                                                 \
   for (int _l = 0; _l < (NT); ++_l)                                                                                    \
   {                                                                                                                    \

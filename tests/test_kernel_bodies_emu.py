@@ -1,0 +1,150 @@
+"""CPU tier: the HIP kernel bodies of simple-mpc_amd/csrc, re-compiled with the sequential-lane test backend
+(tests/emu/smpc_backend.h), against the oracle.  This checks the numerics and the phase/barrier structure of
+the shipped kernels without a GPU; the same comparisons run on the real device in test_gpu_parity.py.
+The emulation library is test infrastructure: the product path never loads it."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mpc_setup as S
+import oracle_lib as O
+
+TOL = 1e-4  # north_star: relative state-trajectory error
+
+
+@pytest.fixture(scope="module")
+def lib(built):
+    return S.emu_lib()
+
+
+def test_cold_solve_matches_oracle(lib):
+    om, gm, rb = S.make_pair(2, lib=lib)
+    assert len(om.cold_trace()) == len(gm.cold_trace())
+    assert S.rel_err(om.cold_trace(), gm.cold_trace()) < 1e-6
+    assert S.rel_err(om.xs, gm.xs) < 1e-9
+    assert S.rel_err(om.us, gm.us) < 1e-9
+    # both instances are copies of the single cold solve
+    assert np.array_equal(gm.xs[0], gm.xs[1])
+
+
+@pytest.mark.parametrize("iters", [1, 3])
+def test_closed_loop_parity(lib, iters):
+    B = 3
+    om, gm, rb = S.make_pair(B, max_iters=iters, lib=lib)
+    X = S.random_states(rb, B)
+    for step in range(6):
+        om.iterate(X)
+        gm.iterate(X)
+        assert S.rel_err(om.xs, gm.xs) < 1e-7, step
+        assert S.rel_err(om.us, gm.us) < 1e-7
+        assert S.rel_err(om.K0, gm.K0) < 1e-6
+        assert np.array_equal(om.info[:, 2], gm.info[:, 2])
+        assert S.rel_err(om.info[:, :2], gm.info[:, :2]) < 1e-6  # phi0, dphi0
+        assert S.rel_err(om.foot_refs, gm.getReferencePoses()) < 1e-13
+        xd = np.stack([gm.getStateDerivative(0), gm.getStateDerivative(1)], 1)
+        assert S.rel_err(om.xdot[:, :2], xd) < 1e-6
+        X = om.xs[:, 1, :].copy()
+    for f in range(4):
+        assert om.timing(f, 0) == gm.foot_takeoff_times[S.FEET[f]]
+        assert om.timing(f, 1) == gm.foot_land_times[S.FEET[f]]
+
+
+def test_stage_knots_match_oracle(lib):
+    om, gm, rb = S.make_pair(2, lib=lib)
+    om.keep_knots()
+    X = S.random_states(rb, 2)
+    for _ in range(2):
+        om.iterate(X)
+        gm.iterate(X)
+        X = om.xs[:, 1, :].copy()
+    for t in (0, 1, 9, 10, 25, 48, 49):  # includes contact-switch stages of the trot
+        ko, kg = om.knot(1, t), gm.debug_lq(1, t)
+        for k in ("A", "B", "Q", "S", "R", "C", "q", "r", "f", "d"):
+            assert S.rel_err(ko[k], kg[k]) < 1e-8, (t, k)
+
+
+def test_walk_to_stand_and_swing_references(lib):
+    """Longer run through take-off / landing and switchToStand (reference src/mpc.cpp:220-254,382-392)."""
+    B = 2
+    om, gm, rb = S.make_pair(B, max_iters=1, lib=lib)
+    X = S.random_states(rb, B, scale=0.3)
+    for step in range(40):
+        if step == 30:
+            om.switchToStand()
+            gm.switchToStand()
+        om.iterate(X)
+        gm.iterate(X)
+        assert S.rel_err(om.foot_refs, gm.getReferencePoses()) < 1e-12
+        X = om.xs[:, 1, :].copy()
+    assert S.rel_err(om.xs, gm.xs) < TOL
+    # the swing references leave the ground once the landing time is inside the fly window
+    assert gm.getReferencePoses()[:, :, :, 2].max() > 0.05
+
+
+def test_joint_limit_rows_activate(lib):
+    """Box rows (reference src/kinodynamics.cpp:91-101): tighten the limits so the AL projection is active."""
+    rb = O.Robot("go2_like")
+    q = rb.q_ref[7:]
+    over = dict(qmin=q - 0.02, qmax=q + 0.02)
+    om, gm, rb = S.make_pair(2, lib=lib, settings_override=over)
+    X = S.random_states(rb, 2, scale=0.5)
+    for _ in range(3):
+        om.iterate(X)
+        gm.iterate(X)
+        X = om.xs[:, 1, :].copy()
+    assert np.abs(om.vs[:, :, :12]).max() > 1.0  # multipliers of the box rows are in play
+    assert S.rel_err(om.xs, gm.xs) < TOL
+    assert S.rel_err(om.vs, gm.vs) < 1e-4
+
+
+def test_batch_instances_are_independent(lib):
+    gm4, rb, _, _ = S.make_product(4, lib=lib)
+    gm1, _, _, _ = S.make_product(1, lib=lib)
+    for g in (gm4, gm1):
+        g.generateCycleHorizon(O.trot_cycle())
+        g.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = S.random_states(rb, 4)
+    gm4.iterate(X)
+    gm1.iterate(X[2:3])
+    assert np.array_equal(gm4.xs[2], gm1.xs[0])
+
+
+def test_lane_order_independence(built):
+    """Run the same closed loop with lanes executed in descending order: a missing phase barrier (a lane
+    reading what a later lane writes in the same phase) changes the result in one of the two orders."""
+    code = (
+        "import sys; sys.path.insert(0, %r); import numpy as np, mpc_setup as S\n"
+        "gm, rb, _, _ = S.make_product(2, max_iters=2, lib=S.emu_lib())\n"
+        "import oracle_lib as O\n"
+        "gm.generateCycleHorizon(O.trot_cycle()); gm.switchToWalk(np.array([0.2,0,0,0,0,0.]))\n"
+        "X = S.random_states(rb, 2)\n"
+        "for _ in range(3):\n"
+        "    gm.iterate(X); X = gm.xs[:,1,:].copy()\n"
+        "np.save(sys.argv[1], gm.xs)\n" % os.path.dirname(os.path.abspath(__file__))
+    )
+    outs = []
+    for rev in ("0", "1"):
+        path = "/tmp/smpc_emu_order_%s.npy" % rev
+        env = dict(os.environ, SMPC_EMU_REVERSE=rev)
+        subprocess.check_call([sys.executable, "-c", code, path], env=env)
+        outs.append(np.load(path))
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_reference_gait_kat_through_the_c_abi(lib):
+    """reference tests/mpc.cpp:78-90 on the product's own timer: feet 0/1 carry the left/right patterns of the
+    reference test (H = 100); 10 iterate() calls shift every entry by 10."""
+    cs = np.array([[1, 1, 1, 1]] * 10 + [[1, 0, 1, 0]] * 50 + [[1, 1, 1, 1]] * 10 + [[0, 1, 0, 1]] * 50, np.uint8)
+    gm, rb, _, _ = S.make_product(1, lib=lib, horizon=100, mpc_override=dict(T_fly=80, T_contact=20))
+    gm.generateCycleHorizon(cs)
+    to, ld = gm.foot_takeoff_times, gm.foot_land_times
+    assert (to["FL_foot"][0], to["FR_foot"][0], ld["FL_foot"][0], ld["FR_foot"][0]) == (170, 110, 219, 160)
+    assert len(gm.xs[0]) == 101 and len(gm.us[0]) == 100  # reference tests/mpc.cpp:43-44
+    x = rb.x_ref
+    for _ in range(10):
+        gm.iterate(x[None, :])
+    to, ld = gm.foot_takeoff_times, gm.foot_land_times
+    assert (to["FL_foot"][0], to["FR_foot"][0], ld["FL_foot"][0], ld["FR_foot"][0]) == (160, 100, 209, 150)

@@ -1,0 +1,64 @@
+"""N > 1 path on CPU: the batch shards by instance across ranks with no collective on the solve path
+(SURVEY 8e).  Two gloo ranks each solve their shard (emulated kernel bodies); the gathered outputs must be
+bit-identical to a single process solving the whole batch, and the timing reduction used by bench.py
+(MAX over ranks) must work."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import mpc_setup as S, oracle_lib as O
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+B = 2
+gm, rb, _, _ = S.make_product(B, lib=S.emu_lib())
+gm.generateCycleHorizon(O.trot_cycle()); gm.switchToWalk(np.array([0.2,0,0,0,0,0.]))
+Xall = S.random_states(rb, B * world)
+X = Xall[rank * B:(rank + 1) * B]          # contiguous block partition of the batch
+for _ in range(2):
+    gm.iterate(X); X = gm.xs[:, 1, :].copy()
+mine = torch.from_numpy(gm.xs.copy())
+parts = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(parts, mine)               # output gather only; nothing on the solve path
+t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+if rank == 0:
+    np.save(sys.argv[1], torch.cat(parts).numpy()); assert t.item() == world
+dist.barrier(); dist.destroy_process_group()
+""" % HERE
+
+
+def test_two_rank_sharding_matches_single_process(built, tmp_path):
+    import mpc_setup as S
+    import oracle_lib as O
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "gathered.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), str(script), out],
+        env=env, timeout=600,
+    )
+    gathered = np.load(out)
+    gm, rb, _, _ = S.make_product(4, lib=S.emu_lib())
+    gm.generateCycleHorizon(O.trot_cycle())
+    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = S.random_states(rb, 4)
+    for _ in range(2):
+        gm.iterate(X)
+        X = gm.xs[:, 1, :].copy()
+    assert np.array_equal(gathered, gm.xs)
