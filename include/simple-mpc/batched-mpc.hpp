@@ -1,0 +1,147 @@
+// simple-mpc/batched-mpc.hpp -- header-only C++ host mirror of the reference's MPC class over the C ABI
+// of smpc.h.  Same namespace, verb and settings-field names as the reference
+// (include/simple-mpc/mpc.hpp:29-49,55-197; include/simple-mpc/kinodynamics.hpp:24-51), Eigen types replaced by
+// std::vector<double> (Eigen is not available in this build).  Errors are rethrown as std::runtime_error, as in the
+// reference (src/kinodynamics.cpp:175,235,279; src/ocp-handler.cpp:28,32,76).
+#pragma once
+#include "../smpc.h"
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace simple_mpc
+{
+  struct KinodynamicsSettings // reference include/simple-mpc/kinodynamics.hpp:24-51
+  {
+    double timestep = 0.01;
+    std::vector<double> w_x, w_u, w_frame, w_cent, w_centder; // dense row-major matrices
+    std::vector<double> qmin, qmax;
+    double gravity[3] = {0, 0, -9.81};
+    double mu = 0.8, Lfoot = 0.01, Wfoot = 0.01;
+    int force_size = 3;
+    bool kinematics_limits = true, force_cone = false, land_cstr = false;
+  };
+
+  struct MPCSettings // reference include/simple-mpc/mpc.hpp:29-49
+  {
+    double swing_apex = 0.15;
+    double support_force = 1000;
+    double TOL = 1e-4;
+    double mu_init = 1e-8;
+    std::size_t max_iters = 1;
+    std::size_t num_threads = 2;
+    int T_fly = 80;
+    int T_contact = 20;
+    std::size_t T = 100;
+    double timestep = 0.01;
+  };
+
+  class BatchedMPC
+  {
+    smpc_handle * h_ = nullptr;
+    int dims_[8] = {0};
+    int batch_ = 0;
+    std::vector<std::string> ee_names_;
+    static void check(int code)
+    {
+      if (code < 0)
+        throw std::runtime_error(smpc_last_error());
+    }
+
+  public:
+    MPCSettings settings_;
+    std::vector<double> xs_, us_, K0_; // [B][H+1][nx], [B][H][nu], [B][nu][ndx] after iterate()
+
+    // KinodynamicsOCP(settings, model) + createProblem(x_ref, T, force_size, gravity, false) + MPC(settings, ocp)
+    BatchedMPC(const smpc_robot_model * robot, const KinodynamicsSettings & ocp, const MPCSettings & settings, int batch,
+               double gravity_arg = -9.81, int device_id = 0)
+    : batch_(batch), settings_(settings)
+    {
+      smpc_kinodynamics_settings ks{};
+      ks.timestep = ocp.timestep;
+      ks.w_x = ocp.w_x.data();
+      ks.w_u = ocp.w_u.data();
+      ks.w_frame = ocp.w_frame.data();
+      ks.w_cent = ocp.w_cent.data();
+      ks.w_centder = ocp.w_centder.data();
+      ks.qmin = ocp.qmin.data();
+      ks.qmax = ocp.qmax.data();
+      for (int i = 0; i < 3; i++)
+        ks.gravity[i] = ocp.gravity[i];
+      ks.mu = ocp.mu;
+      ks.Lfoot = ocp.Lfoot;
+      ks.Wfoot = ocp.Wfoot;
+      ks.force_size = ocp.force_size;
+      ks.kinematics_limits = ocp.kinematics_limits;
+      ks.force_cone = ocp.force_cone;
+      ks.land_cstr = ocp.land_cstr;
+      smpc_mpc_settings ms{};
+      ms.swing_apex = settings.swing_apex;
+      ms.support_force = settings.support_force;
+      ms.TOL = settings.TOL;
+      ms.mu_init = settings.mu_init;
+      ms.max_iters = (int)settings.max_iters;
+      ms.num_threads = (int)settings.num_threads;
+      ms.T_fly = settings.T_fly;
+      ms.T_contact = settings.T_contact;
+      ms.T = (int)settings.T;
+      ms.timestep = settings.timestep;
+      check(smpc_create(robot, &ks, &ms, batch, gravity_arg, device_id, &h_));
+      check(smpc_get_dims(h_, dims_));
+      for (int f = 0; f < robot->nfeet; f++)
+        ee_names_.push_back(robot->foot_name[f]);
+    }
+    ~BatchedMPC() { smpc_destroy(h_); }
+    BatchedMPC(const BatchedMPC &) = delete;
+    BatchedMPC & operator=(const BatchedMPC &) = delete;
+
+    int nx() const { return dims_[2]; }
+    int ndx() const { return dims_[3]; }
+    int nu() const { return dims_[4]; }
+    int horizon() const { return dims_[7]; }
+
+    // reference src/mpc.cpp:101-187
+    void generateCycleHorizon(const std::vector<std::map<std::string, bool>> & contact_states)
+    {
+      std::vector<uint8_t> cs;
+      for (auto & st : contact_states)
+        for (auto & n : ee_names_)
+          cs.push_back(st.at(n) ? 1 : 0);
+      check(smpc_generate_cycle_horizon(h_, cs.data(), (int)contact_states.size()));
+    }
+    // reference src/mpc.cpp:189-218; X is [B][nx]
+    void iterate(const std::vector<double> & X)
+    {
+      if ((int)X.size() != batch_ * nx())
+        throw std::runtime_error("X must hold batch * (nq + nv) values");
+      check(smpc_iterate(h_, X.data()));
+      xs_.resize((size_t)batch_ * (horizon() + 1) * nx());
+      us_.resize((size_t)batch_ * horizon() * nu());
+      K0_.resize((size_t)batch_ * nu() * ndx());
+      check(smpc_get_xs(h_, xs_.data()));
+      check(smpc_get_us(h_, us_.data()));
+      check(smpc_get_K0(h_, K0_.data()));
+    }
+    void switchToWalk(const double * velocity_base6) { check(smpc_switch_to_walk(h_, velocity_base6)); }
+    void switchToStand() { check(smpc_switch_to_stand(h_)); }
+    std::vector<int> getFootTakeoffCycle(const std::string & ee) { return timing(ee, 0); }
+    std::vector<int> getFootLandCycle(const std::string & ee) { return timing(ee, 1); }
+    smpc_handle * handle() { return h_; }
+
+  private:
+    std::vector<int> timing(const std::string & ee, int which)
+    {
+      for (size_t f = 0; f < ee_names_.size(); f++)
+        if (ee_names_[f] == ee)
+        {
+          std::vector<int> v(256);
+          const int n = smpc_get_foot_timing(h_, (int)f, which, v.data(), 256);
+          check(n);
+          v.resize(n);
+          return v;
+        }
+      throw std::runtime_error("unknown end effector " + ee);
+    }
+  };
+} // namespace simple_mpc
