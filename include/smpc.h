@@ -136,6 +136,10 @@ int smpc_debug_get_steps(smpc_handle * h, double * dxs, double * dus);
 /* terminal node of the last iteration for one instance: QN [ndx][ndx], qN [ndx] */
 int smpc_debug_get_terminal(smpc_handle * h, int inst, double * QN, double * qN);
 
+/* in-kernel phase timers of the Riccati sweep (shader cycles, block 0 only); needs SMPC_PHASE_PROFILE=1
+ * in the environment at smpc_create time. out: 64 doubles */
+int smpc_debug_get_phase_cycles(smpc_handle * h, double * out64);
+
 /* profiling: when enabled every kernel launch is bracketed by HIP events on the handle's stream.
  * smpc_get_kernel_times: ms[7], calls[7] for recede, deriv, riccati, forward, trial, select, apply. */
 int smpc_set_profiling(smpc_handle * h, int enabled);

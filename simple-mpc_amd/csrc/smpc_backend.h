@@ -29,13 +29,32 @@
 #define SMPC_LANES_END                                                                                                 \
   }                                                                                                                    \
   __syncthreads();
+// Phase end for kernels whose workgroup is exactly ONE wavefront: lanes run in lockstep and the LDS
+// serves one wave's requests in order, so no s_barrier and no vmcnt/lgkmcnt drain is needed -- only a
+// compiler-level ordering point.  Outstanding global loads (register prefetch) stay in flight.
+#define SMPC_LANES_END_WAVE                                                                                            \
+  }                                                                                                                    \
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                               \
+  __builtin_amdgcn_wave_barrier();                                                                                     \
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 // per-lane value that must survive a phase boundary (register on the GPU)
 #define SMPC_PL(type, name, NT) type name
 #define SMPC_PLA(type, name, NT, n) type name[n]
 #define SMPC_PLV(name) name
+#define SMPC_CLOCK() ((long long)__builtin_readcyclecounter())
+// 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps (full FP64 accuracy, no division)
+#define SMPC_RSQRT(x) ::smpc::rsqrt_nr(x)
 
 namespace smpc
 {
+  __device__ __forceinline__ double rsqrt_nr(double x)
+  {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+  }
+
   inline void hip_check(hipError_t e, const char * what, const char * file, int line)
   {
     if (e != hipSuccess)

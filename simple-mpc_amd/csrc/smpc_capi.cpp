@@ -262,6 +262,12 @@ extern "C"
       e.get_linear(e.buf.qN + (size_t)inst * DimsGo2::NDX, DimsGo2::NDX, qN);
     });
   }
+  int smpc_debug_get_phase_cycles(smpc_handle * h, double * out64)
+  {
+    if (!h || !h->eng->buf.dbg)
+      return fail(SMPC_ERR_INVALID, "phase timers are off (set SMPC_PHASE_PROFILE=1 before smpc_create)");
+    return guarded([&] { h->eng->get_linear(h->eng->buf.dbg, 64, out64); });
+  }
   int smpc_set_profiling(smpc_handle * h, int en)
   {
     h->eng->profiling = en != 0;

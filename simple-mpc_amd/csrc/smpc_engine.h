@@ -9,6 +9,7 @@
 //   MPC::updateCycleTiming     src/mpc.cpp:256-276    -> GaitTimer::update_timing
 //   MPC::switchToWalk/Stand    src/mpc.cpp:382-392
 #pragma once
+#include "smpc_riccati_kino.h"
 #include "smpc_solver_kernels.h"
 #include <algorithm>
 #include <cmath>
@@ -124,6 +125,9 @@ namespace smpc
     double * stage_out = nullptr; // staging for linearised outputs
     size_t stage_out_bytes = 0;
     int cold_iters = 0;
+    int riccati_nt = std::getenv("SMPC_RICCATI_NT") ? std::atoi(std::getenv("SMPC_RICCATI_NT")) : 128; // dense sweep: lanes per instance
+    // SMPC_RICCATI=dense selects the model-independent sweep (A/B comparison and cross-check in the tests)
+    bool structured_riccati = !(std::getenv("SMPC_RICCATI") && std::string(std::getenv("SMPC_RICCATI")) == "dense");
     std::vector<double> cold_trace; // [n][4] phi0, prim, dual, alpha
     // profiling
     bool profiling = false;
@@ -220,7 +224,7 @@ namespace smpc
       buf.foot_ref = dalloc(BH * D::NF * 3);
       buf.ftraj = dalloc((size_t)B * D::NF * 6);
       buf.lq = dalloc(BH * D::LQ_STRIDE);
-      buf.gains = dalloc(BH * D::G_STRIDE);
+      buf.gains = dalloc(BH * (size_t)std::max((int)D::G_STRIDE, (int)GainsK<D>::STRIDE));
       buf.QN = dalloc((size_t)B * D::NDX * D::NDX);
       buf.qN = dalloc((size_t)B * D::NDX);
       buf.parts0 = dalloc((size_t)B * (H + 1) * 4);
@@ -232,6 +236,8 @@ namespace smpc
       buf.stages = (StageShared<D> *)dev_alloc((size_t)H * sizeof(StageShared<D>));
       buf.model = (DevModel<D> *)dev_alloc(sizeof(DevModel<D>));
       X_dev = dalloc((size_t)B * D::NX);
+      if (std::getenv("SMPC_PHASE_PROFILE"))
+        buf.dbg = dalloc(64);
       h2d(buf.model, hm.data(), sizeof(DevModel<D>), stream);
       stream_sync(stream);
 
@@ -311,8 +317,28 @@ namespace smpc
       sk.j0 = 0;
       sk.nj = 0;
       timed_launch<StageKernelArgs<D>, deriv_body<D>, 64>(KID_DERIV, b.B * (H + 1), sk);
-      timed_launch<SolverArgs<D>, riccati_body<D>, 256>(KID_RICCATI, b.B, solver_args(b));
-      timed_launch<SolverArgs<D>, forward_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
+      if (structured_riccati)
+      {
+        // kinodynamics-structured sweep, one wavefront per instance, factored feedback
+        timed_launch<SolverArgs<D>, riccati_kino_body<D>, 64>(KID_RICCATI, b.B, solver_args(b));
+        timed_launch<SolverArgs<D>, forward_kino_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
+      }
+      else
+      {
+        // dense, model-independent sweep (kept for models without the semi-implicit row structure)
+        switch (riccati_nt)
+        {
+        case 64:
+          timed_launch<SolverArgs<D>, riccati_body<D, 64>, 64>(KID_RICCATI, b.B, solver_args(b));
+          break;
+        case 128:
+          timed_launch<SolverArgs<D>, riccati_body<D, 128>, 128>(KID_RICCATI, b.B, solver_args(b));
+          break;
+        default:
+          timed_launch<SolverArgs<D>, riccati_body<D, 256>, 256>(KID_RICCATI, b.B, solver_args(b));
+        }
+        timed_launch<SolverArgs<D>, forward_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
+      }
       const int groups[3][2] = {{0, 1}, {1, 3}, {4, D::LS_N - 4}};
       for (auto & gq : groups)
       {
@@ -572,6 +598,20 @@ namespace smpc
     {
       stream_sync(stream);
       const int nt = all ? H : 1;
+      if (structured_riccati)
+      {
+        // feedback is stored factored (W, L_R): K_t = -L_R^-T W_x, expanded on the device on request
+        const size_t n = (size_t)B * nt * D::NU * D::NDX;
+        double * dev = staging(n * sizeof(double));
+        GainOutArgs<D> ga;
+        ga.b = buf;
+        ga.nt = nt;
+        ga.out = dev;
+        launch<GainOutArgs<D>, gains_out_body<D>, 64>(B * nt, stream, ga);
+        d2h(out, dev, n * sizeof(double), stream);
+        stream_sync(stream);
+        return;
+      }
       std::vector<double> row(D::NU * (D::NDX + 1));
       for (int b = 0; b < B; b++)
         for (int t = 0; t < nt; t++)

@@ -1,0 +1,913 @@
+// smpc_riccati_kino.h -- structure-exploiting proximal Riccati sweep for the kinodynamics stage
+// (HOT(4)/(5) of SolverProxDDP::run, reference src/mpc.cpp:212; LQ solver choice src/mpc.cpp:52).
+//
+// One 64-lane wavefront per instance, per-stage blocks in LDS (33 KB), no workgroup-wide barriers on the
+// critical path.  Same KKT system as riccati_body (smpc_solver_kernels.h), reorganised:
+//
+//   * semi-implicit Euler structure (reference src/kinodynamics.cpp:88): with the tangent split
+//     [qb(6) | qj | vb(6) | vj], only the 12 rows G = qb u vb of A and B are dense; rows qj are
+//     e_i + dt e_{v(i)} (A) / dt^2 e_a (B), rows vj are e_i / dt e_a.  Products with A, B cost 12/36 of dense.
+//   * only forward substitutions:  L L^T = I + mu P,  Y = L^-1 [P | p + P f],
+//         P~ = P - mu Y^T Y   (= (I + mu P)^-1 P),   p~ = (I - mu P~)(p + P f)
+//         L_R L_R^T = R^,  W = L_R^-1 [S^^T | r^],  P_t = Q^ - W^T W + C^T C / mu,  p_t = q^ - W^T w + C^T d / mu
+//     The feedback is kept in factored form (W, L_R): du = -L_R^-T (W_x dx + w) in the forward sweep.
+//   * constraint rows: joint-box rows are unit selectors (diagonal contribution), contact rows are dense.
+#pragma once
+#include "smpc_solver_kernels.h"
+
+namespace smpc
+{
+  // gains block v2 per (instance, stage)
+  template <class D>
+  struct GainsK
+  {
+    static constexpr int NDX = D::NDX, NU = D::NU;
+    static constexpr int G_W = 0;                            // W = L_R^-1 [S^^T | r^]   NU x (NDX+1)
+    static constexpr int G_LR = G_W + NU * (NDX + 1);        // L_R (lower, row-major, full square) NU x NU
+    static constexpr int G_Pt = G_LR + NU * NU;              // P~ NDX x NDX
+    static constexpr int G_pn = G_Pt + NDX * NDX;            // p_{t+1}
+    static constexpr int STRIDE = ((G_pn + NDX + 7) / 8) * 8;
+  };
+
+  template <class D>
+  struct KinoIdx
+  {
+    static constexpr int NV = D::NV, NDX = D::NDX, NA = D::NA, NF = D::NF, NU = D::NU, NG = 12;
+    SMPC_HD static int G(int g) { return g < 6 ? g : NV + g - 6; }             // dense row index
+    SMPC_HD static bool isG(int i) { return i < 6 || (i >= NV && i < NV + 6); }
+    SMPC_HD static bool isQj(int i) { return i >= 6 && i < NV; }
+    SMPC_HD static bool isVj(int i) { return i >= NV + 6; }
+  };
+
+  // Cholesky by one wave with one matrix row per lane held in registers (no integer division, two phases
+  // per column).  On exit row k of Mx, entries i >= k, holds column k of L (L[i][k]) -- contiguous for the
+  // forward substitution -- and invd[k] = 1 / L[k][k].  dg: N doubles of LDS scratch.
+  template <int N, int NT>
+  SMPC_DEV void wave_cholesky_rows(double * Mx, int ld, double * dg, double * invd)
+  {
+    SMPC_PLA(double, row, NT, N);
+    SMPC_PL(double, lcur, NT);
+    SMPC_LANES(NT)
+    if (lane < N)
+    {
+#pragma unroll
+      for (int j = 0; j < N; j++)
+        SMPC_PLV(row)[j] = Mx[lane * ld + j];
+      if (lane == 0)
+        dg[0] = SMPC_PLV(row)[0];
+    }
+    SMPC_LANES_END_WAVE
+#pragma unroll
+    for (int k = 0; k < N; k++)
+    {
+      SMPC_LANES(NT)
+      if (lane >= k && lane < N)
+      {
+        const double d = dg[k];
+        const double rs = SMPC_RSQRT(d);
+        const double l = lane == k ? d * rs : SMPC_PLV(row)[k] * rs;
+        SMPC_PLV(lcur) = l;
+        Mx[k * ld + lane] = l;
+        if (lane == k)
+          invd[k] = rs;
+      }
+      SMPC_LANES_END_WAVE
+      if (k + 1 < N)
+      {
+        SMPC_LANES(NT)
+        if (lane > k && lane < N)
+        {
+          const double l = SMPC_PLV(lcur);
+#pragma unroll
+          for (int j = k + 1; j < N; j++)
+            SMPC_PLV(row)[j] -= l * Mx[k * ld + j];
+          if (lane == k + 1)
+            dg[k + 1] = SMPC_PLV(row)[k + 1];
+        }
+        SMPC_LANES_END_WAVE
+      }
+    }
+  }
+
+  // Forward substitution L y = b, one right-hand side per lane (lane c < ncols), right-looking and IN PLACE in
+  // LDS: Yc(i) is column c of the right-hand sides (conflict-free: consecutive lanes -> consecutive words),
+  // LT row k (entries >= k) = column k of L (broadcast reads).  Few registers, no unrolled register arrays.
+  template <int N>
+  SMPC_DEV void lane_forward_subst_lds(const double * LT, int ld, const double * invd, int ncols, int lane, double * Y, int ldy)
+  {
+    if (lane < ncols)
+    {
+      double * yc = Y + lane;
+      for (int k = 0; k < N; k++)
+      {
+        const double xk = yc[k * ldy] * invd[k];
+        yc[k * ldy] = xk;
+        const double * lt = LT + k * ld;
+        // chunks of 8 rows: batch the 16 LDS reads, then 8 FMAs, then 8 writes (one LDS latency per chunk)
+        int i = k + 1;
+        for (; i + 8 <= N; i += 8)
+        {
+          double yv[8], lv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+          {
+            yv[u] = yc[(i + u) * ldy];
+            lv[u] = lt[i + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            yc[(i + u) * ldy] = yv[u] - lv[u] * xk;
+        }
+        {
+          double yv[8], lv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+          {
+            const int ii = i + u < N ? i + u : N - 1;
+            yv[u] = yc[ii * ldy];
+            lv[u] = lt[ii];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (i + u < N)
+              yc[(i + u) * ldy] = yv[u] - lv[u] * xk;
+        }
+      }
+    }
+  }
+
+  // n-th tile (row-major over the lower triangle incl. diagonal) of a square tile grid: n -> (ti, tj), tj <= ti
+  SMPC_HD void lower_tile(int n, int & ti, int & tj)
+  {
+    int t = (int)((sqrtf(8.0f * (float)n + 1.0f) - 1.0f) * 0.5f);
+    if ((t + 1) * (t + 2) / 2 <= n)
+      t++;
+    if (t * (t + 1) / 2 > n)
+      t--;
+    ti = t;
+    tj = n - t * (t + 1) / 2;
+  }
+
+  // optional in-kernel phase timer: accumulates shader cycles since the previous tick into dbg[slot]
+  SMPC_DEV void prof_tick(double * dbg, int slot, long long & tprev)
+  {
+    if (!dbg)
+      return;
+    const long long now = SMPC_CLOCK();
+    SMPC_LANES(64)
+    if (lane == 0)
+      dbg[slot] += (double)(now - tprev);
+    SMPC_LANES_END_WAVE
+    tprev = SMPC_CLOCK();
+  }
+
+  template <class D>
+  struct RiccatiKinoLds
+  {
+    static constexpr int NDX = D::NDX, NU = D::NU, NXU = D::NDX + D::NU, NG = 12;
+    static constexpr int SCR = NDX * NDX + NDX * (NDX + 1);
+    double P[NDX * NDX]; // P_{t+1} -> P~ -> Q^ -> P_t
+    // scratch, by phase:  [L (NDX^2) | Y (NDX x (NDX+1))]  ->  [NAB | PEG | TG] (3 x NG x NXU)
+    //                     ->  [S^ (NDX x NU) | W (NU x (NDX+1)) | Cc (NG x NDX)]
+    double scr[SCR];
+    double Rh[NU * NU]; // R^ -> L_R (sym-stored)
+    double p[NDX], pt0[NDX], pt[NDX], qh[NDX], rh[NU], f[NDX], col[NDX], invd[NDX], invdR[NU];
+    double dc[NG], boxd[D::NA], boxact[D::NA];
+  };
+
+  // =============================================================================================
+  // riccati_kino_body: grid = B, NT = 64 lanes (one wavefront per instance)
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void riccati_kino_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64; // exactly one wavefront per workgroup: phases end with SMPC_LANES_END_WAVE
+    constexpr int NDX = D::NDX, NU = D::NU, NV = D::NV, NA = D::NA, NF = D::NF, NXU = NDX + NU, NG = 12;
+    typedef KinoIdx<D> IX;
+    typedef GainsK<D> GK;
+    static_assert(NDX % 3 == 0 && NU % 3 == 0 && NXU % 3 == 0 && NG % 3 == 0, "3x3 register tiles");
+    static_assert(NDX + 1 <= NT, "one lane per right-hand side");
+    static_assert(3 * NG * NXU <= RiccatiKinoLds<D>::SCR, "overlay of the small blocks");
+    static_assert(NDX * NU + NU * (NDX + 1) + NG * NDX <= RiccatiKinoLds<D>::SCR, "overlay of S^, W, Cc");
+    const Buffers<D> & b = ka.b;
+    const int H = b.H;
+    const int inst = block;
+    const double mu = b.model->mu, imu = 1.0 / mu, dt = b.model->dt;
+    SMPC_LDS(RiccatiKinoLds<D>, lds, 1);
+    RiccatiKinoLds<D> & s = lds[0];
+    double * Lm = s.scr;                       // [NDX][NDX]    phase 1-3
+    double * Ym = s.scr + NDX * NDX;           // [NDX][NDX+1]  phase 2-3
+    double * NAB = s.scr;                      // [NG][NXU]  dense rows of [A | B]           phase 4
+    double * PEG = s.scr + NG * NXU;           // [NG][NXU]  (P~ E)[G,:] | (P~ E_b)[G,:]
+    double * TG = s.scr + 2 * NG * NXU;        // [NG][NXU]  (P~ A)[G,:] | (P~ B)[G,:]
+    double * Sh = s.scr;                       // [NDX][NU]  S^ (written after the products)  phase 5
+    double * Wm = s.scr + NDX * NU;            // [NU][NDX+1]
+    double * Cc = s.scr + NDX * NU + NU * (NDX + 1); // [NG][NDX] contact rows                phase 6
+
+    SMPC_LANES(NT)
+    {
+      for (int i = lane; i < NDX * NDX; i += NT)
+        s.P[i] = b.QN[(size_t)inst * NDX * NDX + i];
+      for (int i = lane; i < NDX; i += NT)
+        s.p[i] = b.qN[(size_t)inst * NDX + i];
+    }
+    SMPC_LANES_END_WAVE
+
+    double * prof = (b.dbg != nullptr && block == 0) ? b.dbg : nullptr; // optional phase timers (block 0 only)
+    long long tprev = SMPC_CLOCK();
+    for (int t = H - 1; t >= 0; t--)
+    {
+      const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
+      double * g = b.gains + ((size_t)inst * H + t) * GK::STRIDE;
+      // per-lane prefetch registers (filled right after the first factorisation, consumed in phases 4-6)
+      SMPC_PLA(double, qs_acc, NT, 4 * 9); // [Q|S] entries of this lane's (up to 4) 3x3 tiles, later [Q^|S^]
+      SMPC_PLA(double, r_acc, NT, 9);      // R entries of this lane's tile, later R^
+      constexpr int NAB_PL = (NG * NXU + NT - 1) / NT, CC_PL = (NG * NDX + NT - 1) / NT;
+      SMPC_PLA(double, nab_pf, NT, NAB_PL);
+      SMPC_PLA(double, cc_pf, NT, CC_PL);
+      SMPC_PLA(double, vec_pf, NT, 4);
+      // ---- (1) M = I + mu P ; f ; save p_{t+1} ----
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NDX * NDX; idx += NT)
+          Lm[idx] = mu * s.P[idx] + ((idx / NDX) == (idx % NDX) ? 1.0 : 0.0);
+        if (lane < NDX)
+        {
+          s.f[lane] = lq[D::O_f + lane];
+          g[GK::G_pn + lane] = s.p[lane];
+        }
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 0, tprev);
+      SMPC_LANES(NT)
+      if (lane < NDX)
+      {
+        double acc = s.p[lane];
+#pragma unroll 4
+        for (int j = 0; j < NDX; j++)
+          acc += s.P[lane * NDX + j] * s.f[j];
+        s.pt0[lane] = acc;
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 1, tprev);
+      wave_cholesky_rows<NDX, NT>(Lm, NDX, s.col, s.invd);
+      prof_tick(prof, 2, tprev);
+      // ---- (1b) issue every remaining global load of this stage now (register prefetch): the HBM/L2 latency
+      //           overlaps with the substitution / P~ phases; values are consumed or staged to LDS later ----
+      SMPC_LANES(NT)
+      {
+        constexpr int TJ = NXU / 3, NTILES = (NDX / 3) * TJ;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+        {
+          const int tile = lane + rr * NT;
+          const int i0 = tile < NTILES ? (tile / TJ) * 3 : 0, j0 = tile < NTILES ? (tile % TJ) * 3 : 0;
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+            {
+              const int i = i0 + a, j = j0 + c;
+              SMPC_PLV(qs_acc)[rr * 9 + a * 3 + c] = j < NDX ? lq[D::O_Q + i * NDX + j] : lq[D::O_S + i * NU + j - NDX];
+            }
+        }
+        {
+          constexpr int TR = NU / 3;
+          const int tl = lane < TR * TR ? lane : 0;
+          const int i0 = (tl / TR) * 3, j0 = (tl % TR) * 3;
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              SMPC_PLV(r_acc)[a * 3 + c] = lq[D::O_R + (i0 + a) * NU + j0 + c];
+        }
+#pragma unroll
+        for (int n = 0; n < NAB_PL; n++)
+        {
+          const int idx = lane + n * NT;
+          const int gi = idx < NG * NXU ? idx / NXU : 0, j = idx % NXU;
+          SMPC_PLV(nab_pf)[n] = j < NDX ? lq[D::O_A + IX::G(gi) * NDX + j] : lq[D::O_B + IX::G(gi) * NU + j - NDX];
+        }
+#pragma unroll
+        for (int n = 0; n < CC_PL; n++)
+        {
+          const int idx = lane + n * NT;
+          const int r = idx < NG * NDX ? idx / NDX : 0;
+          SMPC_PLV(cc_pf)[n] = lq[D::O_C + (NA + r) * NDX + idx % NDX];
+        }
+        SMPC_PLV(vec_pf)[0] = lane < NDX ? lq[D::O_q + lane] : (lane < NXU ? lq[D::O_r + lane - NDX] : 0.0);
+        SMPC_PLV(vec_pf)[1] = lane < NG ? lq[D::O_d + NA + lane] : 0.0;
+        SMPC_PLV(vec_pf)[2] = lane < NA ? lq[D::O_C + lane * NDX + 6 + lane] : 0.0; // 1 if the box row is active
+        SMPC_PLV(vec_pf)[3] = lane < NA ? lq[D::O_d + lane] : 0.0;
+      }
+      SMPC_LANES_END_WAVE
+      // ---- (2) Y = L^-1 [P | pt0] ----
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NDX * NDX; idx += NT)
+          Ym[(idx / NDX) * (NDX + 1) + idx % NDX] = s.P[idx];
+        if (lane < NDX)
+          Ym[lane * (NDX + 1) + NDX] = s.pt0[lane];
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      lane_forward_subst_lds<NDX>(Lm, NDX, s.invd, NDX + 1, lane, Ym, NDX + 1);
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 3, tprev);
+      // ---- (3) P~ = P - mu Y^T Y (lower tiles, mirrored) ----
+      SMPC_LANES(NT)
+      {
+        constexpr int TJ = NDX / 3, NLOW = TJ * (TJ + 1) / 2;
+        for (int n = lane; n < NLOW; n += NT)
+        {
+          int ti, tj;
+          lower_tile(n, ti, tj);
+          const int i0 = ti * 3, j0 = tj * 3;
+          double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll 4
+          for (int k = 0; k < NDX; k++)
+          {
+            const double * yr = &Ym[k * (NDX + 1)];
+            const double x0 = yr[i0], x1 = yr[i0 + 1], x2 = yr[i0 + 2];
+            const double y0 = yr[j0], y1 = yr[j0 + 1], y2 = yr[j0 + 2];
+            acc[0][0] += x0 * y0;
+            acc[0][1] += x0 * y1;
+            acc[0][2] += x0 * y2;
+            acc[1][0] += x1 * y0;
+            acc[1][1] += x1 * y1;
+            acc[1][2] += x1 * y2;
+            acc[2][0] += x2 * y0;
+            acc[2][1] += x2 * y1;
+            acc[2][2] += x2 * y2;
+          }
+          // batch the symmetrising reads, then write (off-diagonal tiles: all 9 + mirror; diagonal: lower part)
+          double pv[3][3];
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              pv[a][c] = 0.5 * (s.P[(i0 + a) * NDX + j0 + c] + s.P[(j0 + c) * NDX + i0 + a]) - mu * acc[a][c];
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              if (ti != tj || c <= a)
+              {
+                s.P[(i0 + a) * NDX + j0 + c] = pv[a][c];
+                s.P[(j0 + c) * NDX + i0 + a] = pv[a][c];
+              }
+        }
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 4, tprev);
+      // p~ = pt0 - mu P~ pt0 ; stream P~ out ; load the dense rows of [A|B]
+      SMPC_LANES(NT)
+      {
+        if (lane < NDX)
+        {
+          double acc = 0.0;
+#pragma unroll 4
+          for (int j = 0; j < NDX; j++)
+            acc += s.P[lane * NDX + j] * s.pt0[j];
+          s.pt[lane] = s.pt0[lane] - mu * acc;
+        }
+        for (int idx = lane; idx < NDX * NDX; idx += NT)
+          g[GK::G_Pt + idx] = s.P[idx];
+#pragma unroll
+        for (int n = 0; n < NAB_PL; n++)
+        {
+          const int idx = lane + n * NT;
+          if (idx < NG * NXU)
+            NAB[idx] = SMPC_PLV(nab_pf)[n];
+        }
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 5, tprev);
+      // ---- (4a) column pass, in place:  P[:, vj] += dt P[:, qj]   (P now holds P~ E on its J columns) ----
+      // E_b = dt * E[:, vj], so every product with E_b is a scaled slice of the same matrix.
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < NDX * NA; idx += NT)
+      {
+        const int i = idx / NA, jp = idx % NA;
+        s.P[i * NDX + NV + 6 + jp] += dt * s.P[i * NDX + 6 + jp];
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 6, tprev);
+      // ---- (4b) PEG = [(P~ E)[G,:] | (P~ E_b)[G,:]]  (zero in the G / force columns) ----
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < NG * NXU; idx += NT)
+      {
+        const int gi = idx / NXU, j = idx % NXU;
+        const double * pg = &s.P[IX::G(gi) * NDX];
+        double v = 0.0;
+        if (j < NDX)
+        {
+          if (!IX::isG(j))
+            v = pg[j];
+        }
+        else if (j - NDX >= 3 * NF)
+          v = dt * pg[NV + 6 + j - NDX - 3 * NF];
+        PEG[idx] = v;
+      }
+      SMPC_LANES_END_WAVE
+      // ---- (4c) TG = P~[G,G] * NAB + PEG ;  row pass, in place: P[vj, :] += dt P[qj, :]  (P[J,J] = E^T P~ E) ----
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NG * NXU; idx += NT)
+        {
+          const int gi = idx / NXU, j = idx % NXU;
+          const double * pg = &s.P[IX::G(gi) * NDX];
+          double acc = PEG[idx];
+#pragma unroll
+          for (int h = 0; h < NG; h++)
+            acc += pg[IX::G(h)] * NAB[h * NXU + j];
+          TG[idx] = acc;
+        }
+        for (int idx = lane; idx < NA * NDX; idx += NT)
+        {
+          const int ip = idx / NDX, j = idx % NDX;
+          s.P[(NV + 6 + ip) * NDX + j] += dt * s.P[(6 + ip) * NDX + j];
+        }
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 7, tprev);
+      // ---- (4d) [Q^|S^] , R^ , q^ , r^ : products with K = 2 NG over X = [NA ; PEG_x], Y = [TG ; NAB] ----
+      // results stay in registers (all tiles of a lane) and are written back after the phase barrier
+      SMPC_LANES(NT)
+      {
+        constexpr int TJ = NXU / 3, NTILES = (NDX / 3) * TJ; // 12 x 20 = 240
+        static_assert(NTILES <= 4 * NT, "tile storage");
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+        {
+          const int tile = lane + rr * NT;
+          if (tile < NTILES)
+          {
+            const int i0 = (tile / TJ) * 3, j0 = (tile % TJ) * 3;
+            double acc[3][3];
+            // init: [Q|S] (prefetched) + E^T P~ [E|E_b]
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+              {
+                const int i = i0 + a, j = j0 + c;
+                // + (E^T P~ [E | E_b])[i][j]  = coef * P[i][col]  (coef 0 / 1 / dt; branch-free)
+                const int ac = j - NDX - 3 * NF; // joint-acceleration column index if >= 0
+                const int col = j < NDX ? j : (ac >= 0 ? NV + 6 + ac : 0);
+                const double coef = IX::isG(i) ? 0.0 : (j < NDX ? (IX::isG(j) ? 0.0 : 1.0) : (ac >= 0 ? dt : 0.0));
+                const double v = SMPC_PLV(qs_acc)[rr * 9 + a * 3 + c] + coef * s.P[i * NDX + col];
+                acc[a][c] = v;
+              }
+#pragma unroll 4
+            for (int k = 0; k < NG; k++)
+            {
+              double xv[3], yv[3], xu[3], yn[3];
+#pragma unroll
+              for (int a = 0; a < 3; a++)
+              {
+                xv[a] = NAB[k * NXU + i0 + a]; // NA[k][i]
+                xu[a] = PEG[k * NXU + i0 + a]; // (P~E)[G_k][i]
+              }
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+              {
+                yv[c] = TG[k * NXU + j0 + c];
+                yn[c] = NAB[k * NXU + j0 + c];
+              }
+#pragma unroll
+              for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                  acc[a][c] += xv[a] * yv[c] + xu[a] * yn[c];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+                SMPC_PLV(qs_acc)[rr * 9 + a * 3 + c] = acc[a][c];
+          }
+        }
+        // R^ tile (one per lane): R + E_b^T P~ E_b + NB^T TG_b + PEG_b^T NB
+        {
+          constexpr int TR = NU / 3;
+          static_assert(TR * TR <= NT, "one R tile per lane");
+          if (lane < TR * TR)
+          {
+            const int i0 = (lane / TR) * 3, j0 = (lane % TR) * 3;
+            double acc[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+              {
+                const int i = i0 + a, j = j0 + c;
+                double v = SMPC_PLV(r_acc)[a * 3 + c];
+                if (i >= 3 * NF && j >= 3 * NF)
+                  v += dt * dt * s.P[(NV + 6 + i - 3 * NF) * NDX + NV + 6 + j - 3 * NF];
+                acc[a][c] = v;
+              }
+#pragma unroll 4
+            for (int k = 0; k < NG; k++)
+            {
+              double xn[3], xp[3], yt[3], yn[3];
+#pragma unroll
+              for (int a = 0; a < 3; a++)
+              {
+                xn[a] = NAB[k * NXU + NDX + i0 + a];
+                xp[a] = PEG[k * NXU + NDX + i0 + a];
+              }
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+              {
+                yt[c] = TG[k * NXU + NDX + j0 + c];
+                yn[c] = NAB[k * NXU + NDX + j0 + c];
+              }
+#pragma unroll
+              for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                  acc[a][c] += xn[a] * yt[c] + xp[a] * yn[c];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+                SMPC_PLV(r_acc)[a * 3 + c] = acc[a][c];
+          }
+        }
+        // q^ = q + A^T p~ ; r^ = r + B^T p~
+        if (lane < NXU)
+        {
+          const int j = lane;
+          double acc = SMPC_PLV(vec_pf)[0];
+          if (j < NDX)
+          {
+            if (IX::isQj(j))
+              acc += s.pt[j];
+            else if (IX::isVj(j))
+              acc += dt * s.pt[j - NV] + s.pt[j];
+          }
+          else if (j - NDX >= 3 * NF)
+          {
+            const int ip = j - NDX - 3 * NF;
+            acc += dt * dt * s.pt[6 + ip] + dt * s.pt[NV + 6 + ip];
+          }
+#pragma unroll
+          for (int k = 0; k < NG; k++)
+            acc += NAB[k * NXU + j] * s.pt[IX::G(k)];
+          if (j < NDX)
+            s.qh[j] = acc;
+          else
+            s.rh[j - NDX] = acc;
+        }
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 8, tprev);
+      // write back: Q^ -> s.P (P~ is dead), S^ -> Sh, R^ -> s.Rh
+      SMPC_LANES(NT)
+      {
+        constexpr int TJ = NXU / 3, NTILES = (NDX / 3) * TJ;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+        {
+          const int tile = lane + rr * NT;
+          if (tile < NTILES)
+          {
+            const int i0 = (tile / TJ) * 3, j0 = (tile % TJ) * 3;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+              {
+                const int i = i0 + a, j = j0 + c;
+                const double v = SMPC_PLV(qs_acc)[rr * 9 + a * 3 + c];
+                if (j < NDX)
+                  s.P[i * NDX + j] = v;
+                else
+                  Sh[i * NU + j - NDX] = v;
+              }
+          }
+        }
+        constexpr int TR = NU / 3;
+        if (lane < TR * TR)
+        {
+          const int i0 = (lane / TR) * 3, j0 = (lane % TR) * 3;
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              s.Rh[(i0 + a) * NU + j0 + c] = SMPC_PLV(r_acc)[a * 3 + c];
+        }
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 9, tprev);
+      // ---- (5) L_R = chol(R^) ; W = L_R^-1 [S^^T | r^] ----
+      wave_cholesky_rows<NU, NT>(s.Rh, NU, s.col, s.invdR);
+      prof_tick(prof, 10, tprev);
+      // right-hand sides [S^^T | r^] into W (S^ lives in Sh, a different part of the scratch)
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NU * NDX; idx += NT)
+        {
+          const int i = idx / NDX, c = idx % NDX;
+          Wm[i * (NDX + 1) + c] = Sh[c * NU + i];
+        }
+        if (lane < NU)
+          Wm[lane * (NDX + 1) + NDX] = s.rh[lane];
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
+        lane_forward_subst_lds<NU>(s.Rh, NU, s.invdR, NDX + 1, lane, Wm, NDX + 1);
+        // L_R out (lower triangle incl. diagonal; the forward sweep reads only that part)
+        for (int idx = lane; idx < NU * NU; idx += NT)
+        {
+          const int r = idx / NU, c = idx % NU;
+          g[GK::G_LR + idx] = c <= r ? s.Rh[c * NU + r] : 0.0; // L_R[r][c] = LT[c][r]
+        }
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 11, tprev);
+      // contact rows of C, box activity, d  (S^ is dead: Cc overlays it)
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NU * (NDX + 1); idx += NT)
+          g[GK::G_W + idx] = Wm[idx];
+#pragma unroll
+        for (int n = 0; n < CC_PL; n++)
+        {
+          const int idx = lane + n * NT;
+          if (idx < NG * NDX)
+            Cc[idx] = SMPC_PLV(cc_pf)[n];
+        }
+        if (lane < NG)
+          s.dc[lane] = SMPC_PLV(vec_pf)[1];
+        if (lane < NA)
+        {
+          s.boxact[lane] = SMPC_PLV(vec_pf)[2];
+          s.boxd[lane] = SMPC_PLV(vec_pf)[3];
+        }
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 12, tprev);
+      // ---- (6) P_t = Q^ - W^T W + C^T C / mu (lower tiles, mirrored) ; p_t ----
+      SMPC_LANES(NT)
+      {
+        constexpr int TJ = NDX / 3, NLOW = TJ * (TJ + 1) / 2;
+        for (int n = lane; n < NLOW; n += NT)
+        {
+          int ti, tj;
+          lower_tile(n, ti, tj);
+          const int i0 = ti * 3, j0 = tj * 3;
+          double aw[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, ac[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll 4
+          for (int k = 0; k < NU; k++)
+          {
+            const double * wr = &Wm[k * (NDX + 1)];
+            const double x0 = wr[i0], x1 = wr[i0 + 1], x2 = wr[i0 + 2];
+            const double y0 = wr[j0], y1 = wr[j0 + 1], y2 = wr[j0 + 2];
+            aw[0][0] += x0 * y0;
+            aw[0][1] += x0 * y1;
+            aw[0][2] += x0 * y2;
+            aw[1][0] += x1 * y0;
+            aw[1][1] += x1 * y1;
+            aw[1][2] += x1 * y2;
+            aw[2][0] += x2 * y0;
+            aw[2][1] += x2 * y1;
+            aw[2][2] += x2 * y2;
+          }
+#pragma unroll 4
+          for (int k = 0; k < NG; k++)
+          {
+            const double * cr = &Cc[k * NDX];
+            const double x0 = cr[i0], x1 = cr[i0 + 1], x2 = cr[i0 + 2];
+            const double y0 = cr[j0], y1 = cr[j0 + 1], y2 = cr[j0 + 2];
+            ac[0][0] += x0 * y0;
+            ac[0][1] += x0 * y1;
+            ac[0][2] += x0 * y2;
+            ac[1][0] += x1 * y0;
+            ac[1][1] += x1 * y1;
+            ac[1][2] += x1 * y2;
+            ac[2][0] += x2 * y0;
+            ac[2][1] += x2 * y1;
+            ac[2][2] += x2 * y2;
+          }
+          double pv[3][3];
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+            {
+              const int i = i0 + a, j = j0 + c;
+              double v = 0.5 * (s.P[i * NDX + j] + s.P[j * NDX + i]) - aw[a][c] + imu * ac[a][c];
+              const double bx = s.boxact[IX::isQj(i) ? i - 6 : 0];
+              v += (i == j && IX::isQj(i)) ? imu * bx : 0.0;
+              pv[a][c] = v;
+            }
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              if (ti != tj || c <= a)
+              {
+                s.P[(i0 + a) * NDX + j0 + c] = pv[a][c];
+                s.P[(j0 + c) * NDX + i0 + a] = pv[a][c];
+              }
+        }
+        if (lane < NDX)
+        {
+          const int i = lane;
+          double acc = s.qh[i];
+#pragma unroll 4
+          for (int m = 0; m < NU; m++)
+            acc -= Wm[m * (NDX + 1) + i] * Wm[m * (NDX + 1) + NDX];
+          double cd = 0.0;
+#pragma unroll 4
+          for (int r = 0; r < NG; r++)
+            cd += Cc[r * NDX + i] * s.dc[r];
+          if (IX::isQj(i))
+            cd += s.boxact[i - 6] * s.boxd[i - 6];
+          s.p[i] = acc + imu * cd;
+        }
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 13, tprev);
+    }
+  }
+
+  // =============================================================================================
+  // forward_kino_body: grid = B, 64 lanes.  Forward sweep with the factored feedback + merit derivative.
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void forward_kino_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NDX = D::NDX, NU = D::NU, NC = D::NC;
+    typedef GainsK<D> GK;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H, R = b.R;
+    const int inst = block;
+    const double mu = b.model->mu;
+    SMPC_LDS(double, dx, D::NDX);
+    SMPC_LDS(double, du, D::NU);
+    SMPC_LDS(double, z, D::NU);
+    SMPC_LDS(double, y, D::NDX);
+    SMPC_LDS(double, part, 64);
+    SMPC_LDS(double, lpd_prev, D::NDX);
+    SMPC_LANES(NT)
+    {
+      if (lane < NDX)
+      {
+        dx[lane] = 0.0;
+        lpd_prev[lane] = 0.0;
+        b.dxs[((size_t)inst * (H + 1)) * NDX + lane] = 0.0;
+      }
+      part[lane] = 0.0;
+    }
+    SMPC_LANES_END_WAVE
+    for (int t = 0; t < H; t++)
+    {
+      const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
+      const double * g = b.gains + ((size_t)inst * H + t) * GK::STRIDE;
+      const size_t lt = (size_t)inst * H + t;
+      // z = W_x dx + w ; dnu = (C dx + d)/mu
+      SMPC_LANES(NT)
+      {
+        if (lane < NU)
+        {
+          const double * Wr = g + GK::G_W + lane * (NDX + 1);
+          double acc = Wr[NDX];
+#pragma unroll 4
+          for (int j = 0; j < NDX; j++)
+            acc += Wr[j] * dx[j];
+          z[lane] = acc;
+        }
+        else if (lane < NU + NC)
+        {
+          const int r = lane - NU;
+          const double * Cr = lq + D::O_C + r * NDX;
+          double acc = lq[D::O_d + r];
+#pragma unroll 4
+          for (int j = 0; j < NDX; j++)
+            acc += Cr[j] * dx[j];
+          const double dnu = acc / mu;
+          b.dvs[lt * NC + r] = dnu;
+          part[lane] += lq[D::O_vpd + r] * (mu * dnu - lq[D::O_d + r]) - lq[D::O_d + r] * dnu;
+        }
+      }
+      SMPC_LANES_END_WAVE
+      // du = -L_R^-T z : back substitution, lane i owns du_i; the wave resolves one unknown per step
+      for (int k = NU - 1; k >= 0; k--)
+      {
+        SMPC_LANES(NT)
+        if (lane == k)
+        {
+          const double * LRk = g + GK::G_LR + k * NU;
+          const double v = -z[k] / LRk[k];
+          du[k] = v;
+          b.dus[lt * NU + k] = v;
+          part[k] += lq[D::O_lu + k] * v;
+        }
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        if (lane < k)
+          z[lane] += g[GK::G_LR + k * NU + lane] * du[k]; // z_i -= L[k][i] * (-du_k) ... sign folded: L^T du = -z
+        SMPC_LANES_END_WAVE
+      }
+      // y = A dx + B du + f - mu p_{t+1}
+      SMPC_LANES(NT)
+      if (lane < NDX)
+      {
+        const double * Ar = lq + D::O_A + lane * NDX;
+        const double * Br = lq + D::O_B + lane * NU;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int j = 0; j < NDX; j++)
+          acc += Ar[j] * dx[j];
+#pragma unroll 4
+        for (int j = 0; j < NU; j++)
+          acc += Br[j] * du[j];
+        const double fi = lq[D::O_f + lane], pn = g[GK::G_pn + lane];
+        part[lane] += (lq[D::O_lx + lane] - lpd_prev[lane]) * dx[lane] + lq[D::O_lpd + lane] * acc;
+        y[lane] = acc + fi - mu * pn;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      if (lane < NDX)
+      {
+        const double * Pr = g + GK::G_Pt + lane * NDX;
+        double w = 0.0;
+#pragma unroll 4
+        for (int j = 0; j < NDX; j++)
+          w += Pr[j] * y[j];
+        const double dxn = y[lane] - mu * w;
+        const double dl = w + g[GK::G_pn + lane];
+        b.dxs[((size_t)inst * (H + 1) + t + 1) * NDX + lane] = dxn;
+        b.dlams[lt * NDX + lane] = dl;
+        part[lane] -= lq[D::O_f + lane] * dl;
+        lpd_prev[lane] = lq[D::O_lpd + lane];
+        dx[lane] = dxn;
+      }
+      SMPC_LANES_END_WAVE
+    }
+    SMPC_LANES(NT)
+    if (lane < NDX)
+    {
+      const int sl = ring_slot(ka.head, H - 1, R);
+      const double lamH = b.lams[((size_t)inst * R + sl) * NDX + lane];
+      const double lxN = b.qN[(size_t)inst * NDX + lane] + lamH;
+      part[lane] += (lxN - lpd_prev[lane]) * dx[lane];
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      double sacc = 0.0;
+      for (int i = 0; i < 64; i++)
+        sacc += part[i];
+      b.scal[(size_t)inst * SC_N + SC_DPHI0] = sacc;
+      b.ls_sel[inst] = -1;
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // K_t = -L_R^-T W_x for (instance, stage) blocks: grid = B * nt, 64 lanes (lane = column of K)
+  template <class D>
+  struct GainOutArgs
+  {
+    Buffers<D> b;
+    int nt;       // stages per instance to export (1 = K0 only, H = all)
+    double * out; // [B][nt][NU][NDX]
+  };
+  template <class D>
+  SMPC_DEV void gains_out_body(const GainOutArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NDX = D::NDX, NU = D::NU;
+    typedef GainsK<D> GK;
+    const Buffers<D> & b = ka.b;
+    const int inst = block / ka.nt, t = block % ka.nt;
+    const double * g = b.gains + ((size_t)inst * b.H + t) * GK::STRIDE;
+    double * out = ka.out + ((size_t)inst * ka.nt + t) * NU * NDX;
+    SMPC_LANES(NT)
+    if (lane < NDX)
+    {
+      double x[NU];
+#pragma unroll
+      for (int i = 0; i < NU; i++)
+        x[i] = g[GK::G_W + i * (NDX + 1) + lane];
+#pragma unroll
+      for (int i = NU - 1; i >= 0; i--)
+      {
+        double sacc = x[i];
+#pragma unroll
+        for (int k = i + 1; k < NU; k++)
+          sacc -= g[GK::G_LR + k * NU + i] * x[k];
+        x[i] = sacc / g[GK::G_LR + i * NU + i];
+        out[i * NDX + lane] = -x[i];
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
+} // namespace smpc

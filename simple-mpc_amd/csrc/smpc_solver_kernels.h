@@ -37,6 +37,7 @@ namespace smpc
 #pragma unroll
         for (int c = 0; c < TN; c++)
           acc[a][c] = init(i0 + a, j0 + c);
+#pragma unroll 4
       for (int k = 0; k < K; k++)
       {
         double xv[TM], yv[TN];
@@ -139,10 +140,10 @@ namespace smpc
     double p[NDX], pt[NDX], qh[NDX], rh[NU], f[NDX], d[NC], col[NDX], wr[NU], kk[NU];
   };
 
-  template <class D>
+  template <class D, int NT>
   SMPC_DEV void riccati_body(const SolverArgs<D> & ka, int block)
   {
-    constexpr int NT = 256;
+    static_assert(NT >= 64, "needs one lane per right-hand side column");
     constexpr int NDX = D::NDX, NU = D::NU, NC = D::NC, NXU = NDX + NU;
     static_assert(NDX % 3 == 0 && NXU % 3 == 0 && NU % 3 == 0, "register tiles of 3 must divide the dimensions");
     const Buffers<D> & b = ka.b;
@@ -194,6 +195,7 @@ namespace smpc
       if (lane < NDX)
       {
         double acc = s.p[lane];
+#pragma unroll 4
         for (int j = 0; j < NDX; j++)
           acc += s.P[lane * NDX + j] * s.f[j];
         s.pt[lane] = acc;
@@ -245,6 +247,7 @@ namespace smpc
         if (lane < NXU)
         {
           double acc = lane < NDX ? lq[D::O_q + lane] : lq[D::O_r + lane - NDX];
+#pragma unroll 4
           for (int k = 0; k < NDX; k++)
             acc += s.AB[k * NXU + lane] * s.pt[k];
           if (lane < NDX)
@@ -278,13 +281,15 @@ namespace smpc
         mm_tn<NDX, NDX, NU, 3, 3, NT>(
           s.MT, NDX + 1, s.MT, NDX + 1, lane, [](int, int) { return 0.0; },
           [&](int i, int j, double v) { s.P[i * NDX + j] = s.QS[i * NXU + j] - v; });
-        if (lane >= 192 && lane < 192 + NDX)
+        if (lane >= NT - 64 && lane < NT - 64 + NDX)
         {
-          const int i = lane - 192;
+          const int i = lane - (NT - 64);
           double acc = s.qh[i];
+#pragma unroll 4
           for (int m = 0; m < NU; m++)
             acc -= s.MT[m * (NDX + 1) + i] * s.MT[m * (NDX + 1) + NDX];
           double cd = 0.0;
+#pragma unroll 4
           for (int r = 0; r < NC; r++)
             cd += s.AB[r * NDX + i] * s.d[r];
           s.p[i] = acc + imu * cd;
@@ -355,6 +360,7 @@ namespace smpc
         {
           const double * Kr = g + D::G_K + lane * (NDX + 1);
           double acc = Kr[NDX];
+#pragma unroll 4
           for (int j = 0; j < NDX; j++)
             acc += Kr[j] * dx[j];
           du[lane] = acc;
@@ -366,6 +372,7 @@ namespace smpc
           const int r = lane - NU;
           const double * Cr = lq + D::O_C + r * NDX;
           double acc = lq[D::O_d + r];
+#pragma unroll 4
           for (int j = 0; j < NDX; j++)
             acc += Cr[j] * dx[j];
           const double dnu = acc / mu;
@@ -382,8 +389,10 @@ namespace smpc
         const double * Ar = lq + D::O_A + lane * NDX;
         const double * Br = lq + D::O_B + lane * NU;
         double acc = 0.0;
+#pragma unroll 4
         for (int j = 0; j < NDX; j++)
           acc += Ar[j] * dx[j];
+#pragma unroll 4
         for (int j = 0; j < NU; j++)
           acc += Br[j] * du[j];
         const double fi = lq[D::O_f + lane], pn = g[D::G_pn + lane];
@@ -398,6 +407,7 @@ namespace smpc
       {
         const double * Pr = g + D::G_Pt + lane * NDX;
         double w = 0.0;
+#pragma unroll 4
         for (int j = 0; j < NDX; j++)
           w += Pr[j] * y[j];
         const double dxn = y[lane] - mu * w;

@@ -91,7 +91,7 @@ SYMBOLS = [
     "smpc_iterate", "smpc_iterate_device", "smpc_wait", "smpc_get_x_device", "smpc_get_xs", "smpc_get_us", "smpc_get_K0", "smpc_get_Ks",
     "smpc_get_vs", "smpc_get_lams", "smpc_get_state_derivative01", "smpc_get_reference_poses",
     "smpc_get_foot_timing", "smpc_get_info", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
-    "smpc_debug_get_steps", "smpc_debug_get_terminal", "smpc_set_profiling", "smpc_get_kernel_times", "smpc_reset_kernel_times",
+    "smpc_debug_get_steps", "smpc_debug_get_terminal", "smpc_debug_get_phase_cycles", "smpc_set_profiling", "smpc_get_kernel_times", "smpc_reset_kernel_times",
 ]
 
 
@@ -133,6 +133,7 @@ class SmpcLib:
         L.smpc_debug_get_lq.argtypes = [vp, C.c_int, C.c_int, _dp]
         L.smpc_debug_get_steps.argtypes = [vp, _dp, _dp]
         L.smpc_debug_get_terminal.argtypes = [vp, C.c_int, _dp, _dp]
+        L.smpc_debug_get_phase_cycles.argtypes = [vp, _dp]
         L.smpc_set_profiling.argtypes = [vp, C.c_int]
         L.smpc_get_kernel_times.argtypes = [vp, _dp, _lp]
         L.smpc_reset_kernel_times.argtypes = [vp]

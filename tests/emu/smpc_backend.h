@@ -29,9 +29,12 @@
     const int lane = ::smpc::emu_reverse ? ((NT)-1 - _l) : _l;                                                         \
     (void)lane;
 #define SMPC_LANES_END }
+#define SMPC_LANES_END_WAVE }
 #define SMPC_PL(type, name, NT) type name[NT]
 #define SMPC_PLA(type, name, NT, n) type name[NT][n]
 #define SMPC_PLV(name) name[lane]
+#define SMPC_CLOCK() (0LL)
+#define SMPC_RSQRT(x) (1.0 / std::sqrt(x))
 
 namespace smpc
 {
