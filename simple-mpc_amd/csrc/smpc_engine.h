@@ -339,12 +339,13 @@ namespace smpc
         }
         timed_launch<SolverArgs<D>, forward_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
       }
-      const int groups[3][2] = {{0, 1}, {1, 3}, {4, D::LS_N - 4}};
+      // alpha = 1 for everybody; the backtracking candidates 2^-1 .. 2^-9 only for instances that rejected it
+      const int groups[2][2] = {{0, 1}, {1, D::LS_N - 1}};
       for (auto & gq : groups)
       {
         sk.j0 = gq[0];
         sk.nj = gq[1];
-        timed_launch<StageKernelArgs<D>, trial_body<D>, 64>(KID_TRIAL, b.B * (H + 1) * sk.nj, sk);
+        timed_launch<StageKernelArgs<D>, trial_body<D>, 64>(KID_TRIAL, b.B * (H + 1), sk);
         timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, gq[0], gq[1]));
       }
       timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B * (H + 1), solver_args(b));

@@ -94,6 +94,9 @@ namespace smpc
     in.u_ref = term ? nullptr : b.stages[t].u_ref;
     in.x_tgt = term ? md.x_term : b.stages[t].x_tgt;
     in.foot_ref = term ? nullptr : b.foot_ref + ((size_t)inst * H + t) * NF * 3;
+    long long tprev = SMPC_CLOCK();
+    in.prof = (b.dbg != nullptr && block == 17) ? b.dbg : nullptr; // optional phase timers: one mid-horizon block
+    in.tprev = &tprev;
 
     SMPC_LANES(NT)
     {
@@ -111,6 +114,7 @@ namespace smpc
     }
     SMPC_LANES_END
 
+    if (in.prof) prof_tick(in.prof, 15, tprev);
     kino_tree_phases<D, true>(sc, in);
 
     if (!term)
@@ -119,7 +123,9 @@ namespace smpc
       lanes_difference<D>(xn_g, sc.xnext, sc.e, lane, 61);
       SMPC_LANES_END
     }
+    if (in.prof) prof_tick(in.prof, 29, tprev);
     kino_cost_constraints<D, true>(sc, in);
+    if (in.prof) prof_tick(in.prof, 30, tprev);
 
     double * parts = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
 
@@ -202,6 +208,7 @@ namespace smpc
 
     // ---- multipliers, active set ----
     kino_multipliers<D>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+    if (in.prof) prof_tick(in.prof, 31, tprev);
 
     // ---- small weighted-Jacobian tables ----
     SMPC_LANES(NT)
@@ -255,6 +262,7 @@ namespace smpc
     }
     SMPC_LANES_END
 
+    if (in.prof) prof_tick(in.prof, 32, tprev);
     double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
     const double dt = md.dt;
     const double mu = md.mu;
@@ -390,6 +398,7 @@ namespace smpc
     }
     SMPC_LANES_END
 
+    if (in.prof) prof_tick(in.prof, 33, tprev);
     // ---- [Q | S]: lane k < NDX owns column k of Q, lane NDX+k column k of S ----
     SMPC_LANES(NT)
     if (lane < NDX + NU)
@@ -431,6 +440,7 @@ namespace smpc
     }
     SMPC_LANES_END
 
+    if (in.prof) prof_tick(in.prof, 34, tprev);
     // ---- [C | R]: lane k < NDX owns column k of C (active rows), lane NDX+k column k of R ----
     SMPC_LANES(NT)
     if (lane < NDX + NU)
@@ -481,6 +491,7 @@ namespace smpc
       }
     }
     SMPC_LANES_END
+    if (in.prof) prof_tick(in.prof, 35, tprev);
     SMPC_LANES(NT)
     if (lane == 0)
     {
@@ -498,22 +509,31 @@ namespace smpc
   }
 
   // =============================================================================================
-  // trial_body: grid = B * (H+1) * nj; evaluates candidate j = j0 + jj for instances still undecided
+  // trial_body: grid = B * (H+1); block (inst, t) evaluates the candidates j0 .. j0+nj-1 one after the other,
+  // but only while its instance is still undecided: the common case (alpha = 1 accepted) costs one early exit
+  // per block instead of nj idle blocks.
   // =============================================================================================
   template <class D>
+  SMPC_DEV void trial_one(const StageKernelArgs<D> & ka, int inst, int t, int j);
+
+  template <class D>
   SMPC_DEV void trial_body(const StageKernelArgs<D> & ka, int block)
+  {
+    const int H = ka.b.H;
+    const int inst = block / (H + 1), t = block % (H + 1);
+    if (ka.b.ls_sel[inst] >= 0)
+      return; // already accepted an earlier candidate (uniform across the workgroup)
+    for (int jj = 0; jj < ka.nj; jj++)
+      trial_one<D>(ka, inst, t, ka.j0 + jj);
+  }
+
+  template <class D>
+  SMPC_DEV void trial_one(const StageKernelArgs<D> & ka, int inst, int t, int j)
   {
     constexpr int NT = 64;
     constexpr int NV = D::NV, NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF;
     const Buffers<D> & b = ka.b;
     const int H = b.H, R = b.R;
-    const int per = (H + 1) * ka.nj;
-    const int inst = block / per;
-    const int rem = block % per;
-    const int jj = rem / (H + 1), t = rem % (H + 1);
-    const int j = ka.j0 + jj;
-    if (b.ls_sel[inst] >= 0)
-      return; // already accepted an earlier candidate (uniform across the workgroup)
     const bool term = t == H;
     const DevModel<D> & md = *b.model;
     SMPC_LDS(KinoScratch<D>, scs, 1);

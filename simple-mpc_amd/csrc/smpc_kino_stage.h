@@ -65,6 +65,8 @@ namespace smpc
     const double * x_tgt;    // NX (global)
     const double * foot_ref; // NF*3 (global)
     bool terminal;
+    double * prof = nullptr; // optional phase timers (null = off)
+    long long * tprev = nullptr;
   };
 
   // ---------------------------------------------------------------------------------------------
@@ -110,6 +112,7 @@ namespace smpc
       }
       SMPC_LANES_END
     }
+    if (in.prof) prof_tick(in.prof, 16, *in.tprev);
     // ---- S columns (lanes 0..NV-1), world inertias (lanes 32..32+NJ-1), feet (lanes 48..) ----
     SMPC_LANES(NT)
     if (lane < NV)
@@ -159,6 +162,7 @@ namespace smpc
       const int f = lane - 48;
       const int j = md.foot_joint[f];
       st3(&sc.footp[f * 3], ldm3(&sc.oR[j * 9]) * ld3(md.foot_p[f]) + ld3(&sc.op[j * 3]));
+    if (in.prof) prof_tick(in.prof, 17, *in.tprev);
     }
     SMPC_LANES_END
     // ---- velocities and bias accelerations (a = 0), ascending ----
@@ -195,6 +199,7 @@ namespace smpc
       }
       SMPC_LANES_END
     }
+    if (in.prof) prof_tick(in.prof, 18, *in.tprev);
     // ---- composites, descending: parents gather their children ----
     for (int lvl = nlev - 2; lvl >= 0; lvl--)
     {
@@ -218,6 +223,7 @@ namespace smpc
       }
       SMPC_LANES_END
     }
+    if (in.prof) prof_tick(in.prof, 19, *in.tprev);
     // ---- CoM, centroidal map columns, hg, b0, hdot target, 6x6 inertia for the base solve ----
     SMPC_LANES(NT)
     {
@@ -289,6 +295,7 @@ namespace smpc
         A[4 * 6 + 5] = A[5 * 6 + 4] = I0.jyz;
         A[5 * 6 + 5] = I0.jzz;
       }
+    if (in.prof) prof_tick(in.prof, 20, *in.tprev);
     }
     SMPC_LANES_END
     // ---- in-place Gauss-Jordan inverse of the SPD 6x6 (36 lanes, ping-pong gjA <-> gjB) ----
@@ -310,6 +317,7 @@ namespace smpc
       }
       SMPC_LANES_END
     }
+    if (in.prof) prof_tick(in.prof, 21, *in.tprev);
     // after 6 steps the inverse sits in gjA.  M1 = Ic0^-1 * T(c)^-1  with T^-1 = [[I,0],[[c]x, I]]
     SMPC_LANES(NT)
     if (lane < 36)
@@ -326,6 +334,7 @@ namespace smpc
         val += Ii[r * 6 + 3] * col.x + Ii[r * 6 + 4] * col.y + Ii[r * 6 + 5] * col.z;
       }
       sc.gjB[lane] = val;
+    if (in.prof) prof_tick(in.prof, 22, *in.tprev);
     }
     SMPC_LANES_END
     // Agbi = X0^-1 * M1,  X0^-1 = [[R^T, -R^T [p]x],[0, R^T]]
@@ -344,6 +353,7 @@ namespace smpc
         out = tmul(R, ma);
       const int rr = r % 3;
       sc.Agbi[lane] = rr == 0 ? out.x : (rr == 1 ? out.y : out.z);
+    if (in.prof) prof_tick(in.prof, 22, *in.tprev);
     }
     SMPC_LANES_END
     // ---- base acceleration ----
@@ -365,6 +375,7 @@ namespace smpc
       else
         val = sc.u[3 * NF + lane - 6];
       sc.a[lane] = val;
+    if (in.prof) prof_tick(in.prof, 23, *in.tprev);
     }
     SMPC_LANES_END
     if (in.terminal)
@@ -399,6 +410,7 @@ namespace smpc
         const int i = lane - 32;
         sc.xnext[NQ + i] = vq[i] + dt * sc.a[i];
       }
+    if (in.prof) prof_tick(in.prof, 24, *in.tprev);
     }
     SMPC_LANES_END
 
@@ -430,6 +442,7 @@ namespace smpc
       }
       SMPC_LANES_END
     }
+    if (in.prof) prof_tick(in.prof, 25, *in.tprev);
     for (int lvl = nlev - 2; lvl >= 0; lvl--)
     {
       SMPC_LANES(NT)
@@ -444,6 +457,7 @@ namespace smpc
       }
       SMPC_LANES_END
     }
+    if (in.prof) prof_tick(in.prof, 26, *in.tprev);
     // ---- derivative columns: lane k < NV ----
     SMPC_LANES(NT)
     if (lane < NV)
@@ -538,6 +552,7 @@ namespace smpc
       sc.dtgt[0 * NV + k] = dt_ang.x;
       sc.dtgt[1 * NV + k] = dt_ang.y;
       sc.dtgt[2 * NV + k] = dt_ang.z;
+    if (in.prof) prof_tick(in.prof, 27, *in.tprev);
     }
     SMPC_LANES_END
     // ---- base-acceleration derivatives: Agbi * [dtgt - dhd_dq | -dhd_dv | G_f | -Ag_j] ----
@@ -613,6 +628,7 @@ namespace smpc
             Jq[(i + 3) * 6 + j] = 0.0;
           }
       }
+    if (in.prof) prof_tick(in.prof, 28, *in.tprev);
     }
     SMPC_LANES_END
   }

@@ -136,6 +136,19 @@ namespace smpc
     SC_N = 16
   };
 
+  // optional in-kernel phase timer: accumulates shader cycles since the previous tick into dbg[slot]
+  SMPC_DEV void prof_tick(double * dbg, int slot, long long & tprev)
+  {
+    if (!dbg)
+      return;
+    const long long now = SMPC_CLOCK();
+    SMPC_LANES(64)
+    if (lane == 0)
+      dbg[slot] += (double)(now - tprev);
+    SMPC_LANES_END
+    tprev = SMPC_CLOCK();
+  }
+
   SMPC_HD int ring_slot(int head, int t, int R)
   {
     int s = head + t;

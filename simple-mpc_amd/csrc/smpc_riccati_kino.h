@@ -89,6 +89,42 @@ namespace smpc
     }
   }
 
+  // Forward substitution L y = b for one right-hand side per lane (lane c < ncols), right-looking, the whole
+  // column kept in registers (N doubles): N(N-1)/2 FMAs and as many broadcast LDS reads per lane.  Needs a
+  // register budget of its own: keep no other large per-lane state live across it.
+  template <int N, class Get, class Put>
+  SMPC_DEV void lane_forward_subst(const double * LT, int ld, const double * invd, int ncols, int lane, Get get, Put put)
+  {
+    if (lane < ncols)
+    {
+      double b[N], l0[N], l1[N];
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        b[i] = get(i, lane);
+#pragma unroll
+      for (int i = 1; i < N; i++)
+        l0[i] = LT[i];
+      // software pipeline: the L row of step k+1 is requested before the FMAs of step k
+#pragma unroll
+      for (int k = 0; k < N; k++)
+      {
+        double * cur = (k & 1) ? l1 : l0;
+        double * nxt = (k & 1) ? l0 : l1;
+        if (k + 1 < N)
+        {
+#pragma unroll
+          for (int i = k + 2; i < N; i++)
+            nxt[i] = LT[(k + 1) * ld + i];
+        }
+        const double xk = b[k] * invd[k];
+        put(k, lane, xk);
+#pragma unroll
+        for (int i = k + 1; i < N; i++)
+          b[i] -= cur[i] * xk;
+      }
+    }
+  }
+
   // Forward substitution L y = b, one right-hand side per lane (lane c < ncols), right-looking and IN PLACE in
   // LDS: Yc(i) is column c of the right-hand sides (conflict-free: consecutive lanes -> consecutive words),
   // LT row k (entries >= k) = column k of L (broadcast reads).  Few registers, no unrolled register arrays.
@@ -146,19 +182,6 @@ namespace smpc
       t--;
     ti = t;
     tj = n - t * (t + 1) / 2;
-  }
-
-  // optional in-kernel phase timer: accumulates shader cycles since the previous tick into dbg[slot]
-  SMPC_DEV void prof_tick(double * dbg, int slot, long long & tprev)
-  {
-    if (!dbg)
-      return;
-    const long long now = SMPC_CLOCK();
-    SMPC_LANES(64)
-    if (lane == 0)
-      dbg[slot] += (double)(now - tprev);
-    SMPC_LANES_END_WAVE
-    tprev = SMPC_CLOCK();
   }
 
   template <class D>
@@ -252,35 +275,24 @@ namespace smpc
       prof_tick(prof, 1, tprev);
       wave_cholesky_rows<NDX, NT>(Lm, NDX, s.col, s.invd);
       prof_tick(prof, 2, tprev);
-      // ---- (1b) issue every remaining global load of this stage now (register prefetch): the HBM/L2 latency
-      //           overlaps with the substitution / P~ phases; values are consumed or staged to LDS later ----
+      // ---- (2) Y = L^-1 [P | pt0] : right-hand sides copied into Y, then substituted in place (register column) ----
       SMPC_LANES(NT)
       {
-        constexpr int TJ = NXU / 3, NTILES = (NDX / 3) * TJ;
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-        {
-          const int tile = lane + rr * NT;
-          const int i0 = tile < NTILES ? (tile / TJ) * 3 : 0, j0 = tile < NTILES ? (tile % TJ) * 3 : 0;
-#pragma unroll
-          for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-            {
-              const int i = i0 + a, j = j0 + c;
-              SMPC_PLV(qs_acc)[rr * 9 + a * 3 + c] = j < NDX ? lq[D::O_Q + i * NDX + j] : lq[D::O_S + i * NU + j - NDX];
-            }
-        }
-        {
-          constexpr int TR = NU / 3;
-          const int tl = lane < TR * TR ? lane : 0;
-          const int i0 = (tl / TR) * 3, j0 = (tl % TR) * 3;
-#pragma unroll
-          for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-              SMPC_PLV(r_acc)[a * 3 + c] = lq[D::O_R + (i0 + a) * NU + j0 + c];
-        }
+        for (int idx = lane; idx < NDX * NDX; idx += NT)
+          Ym[(idx / NDX) * (NDX + 1) + idx % NDX] = s.P[idx];
+        if (lane < NDX)
+          Ym[lane * (NDX + 1) + NDX] = s.pt0[lane];
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      lane_forward_subst<NDX>(
+        Lm, NDX, s.invd, NDX + 1, lane, [&](int i, int c) { return Ym[i * (NDX + 1) + c]; },
+        [&](int i, int c, double v) { Ym[i * (NDX + 1) + c] = v; });
+      SMPC_LANES_END_WAVE
+      // ---- (2b) register prefetch of the dense rows of [A|B], the contact rows of C and the stage vectors;
+      //           the latency overlaps with the P~ product ----
+      SMPC_LANES(NT)
+      {
 #pragma unroll
         for (int n = 0; n < NAB_PL; n++)
         {
@@ -300,18 +312,6 @@ namespace smpc
         SMPC_PLV(vec_pf)[2] = lane < NA ? lq[D::O_C + lane * NDX + 6 + lane] : 0.0; // 1 if the box row is active
         SMPC_PLV(vec_pf)[3] = lane < NA ? lq[D::O_d + lane] : 0.0;
       }
-      SMPC_LANES_END_WAVE
-      // ---- (2) Y = L^-1 [P | pt0] ----
-      SMPC_LANES(NT)
-      {
-        for (int idx = lane; idx < NDX * NDX; idx += NT)
-          Ym[(idx / NDX) * (NDX + 1) + idx % NDX] = s.P[idx];
-        if (lane < NDX)
-          Ym[lane * (NDX + 1) + NDX] = s.pt0[lane];
-      }
-      SMPC_LANES_END_WAVE
-      SMPC_LANES(NT)
-      lane_forward_subst_lds<NDX>(Lm, NDX, s.invd, NDX + 1, lane, Ym, NDX + 1);
       SMPC_LANES_END_WAVE
       prof_tick(prof, 3, tprev);
       // ---- (3) P~ = P - mu Y^T Y (lower tiles, mirrored) ----
@@ -360,6 +360,37 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 4, tprev);
+      // ---- (3b) register prefetch of this lane's [Q|S] and R tile entries: the HBM/L2 latency overlaps with
+      //           the P~ E passes and the TG product below ----
+      SMPC_LANES(NT)
+      {
+        constexpr int TJ = NXU / 3, NTILES = (NDX / 3) * TJ;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+        {
+          const int tile = lane + rr * NT;
+          const int i0 = tile < NTILES ? (tile / TJ) * 3 : 0, j0 = tile < NTILES ? (tile % TJ) * 3 : 0;
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+            {
+              const int i = i0 + a, j = j0 + c;
+              SMPC_PLV(qs_acc)[rr * 9 + a * 3 + c] = j < NDX ? lq[D::O_Q + i * NDX + j] : lq[D::O_S + i * NU + j - NDX];
+            }
+        }
+        {
+          constexpr int TR = NU / 3;
+          const int tl = lane < TR * TR ? lane : 0;
+          const int i0 = (tl / TR) * 3, j0 = (tl % TR) * 3;
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              SMPC_PLV(r_acc)[a * 3 + c] = lq[D::O_R + (i0 + a) * NU + j0 + c];
+        }
+      }
+      SMPC_LANES_END_WAVE
       // p~ = pt0 - mu P~ pt0 ; stream P~ out ; load the dense rows of [A|B]
       SMPC_LANES(NT)
       {
@@ -619,7 +650,9 @@ namespace smpc
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
       {
-        lane_forward_subst_lds<NU>(s.Rh, NU, s.invdR, NDX + 1, lane, Wm, NDX + 1);
+        lane_forward_subst<NU>(
+          s.Rh, NU, s.invdR, NDX + 1, lane, [&](int i, int c) { return Wm[i * (NDX + 1) + c]; },
+          [&](int i, int c, double v) { Wm[i * (NDX + 1) + c] = v; });
         // L_R out (lower triangle incl. diagonal; the forward sweep reads only that part)
         for (int idx = lane; idx < NU * NU; idx += NT)
         {

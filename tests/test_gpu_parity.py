@@ -48,6 +48,20 @@ def test_closed_loop_parity(built, iters):
     print("worst relative xs error over the run: %.3e" % worst)
 
 
+def test_line_search_backtracking_matches(built):
+    om, gm, rb = S.make_pair(8, max_iters=2)
+    X = S.random_states(rb, 8, seed=3, scale=4.0)
+    seen = False
+    for _ in range(3):
+        om.iterate(X)
+        gm.iterate(X)
+        assert np.array_equal(om.info[:, 2], gm.info[:, 2])
+        seen |= bool((om.info[:, 2] < 1.0).any())
+        assert S.rel_err(om.xs, gm.xs) < TOL
+        X = om.xs[:, 1, :].copy()
+    assert seen
+
+
 def test_stage_knots_match_oracle(built):
     om, gm, rb = S.make_pair(batch=2)
     om.keep_knots()

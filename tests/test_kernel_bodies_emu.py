@@ -100,6 +100,45 @@ def test_joint_limit_rows_activate(lib):
     assert S.rel_err(om.vs, gm.vs) < 1e-4
 
 
+def test_line_search_backtracking_matches(lib):
+    """Large perturbations make some instances reject alpha = 1: the speculative line search (alpha = 1 for all,
+    then 2^-1..2^-9 only for the undecided ones) must pick the same step as sequential backtracking."""
+    om, gm, rb = S.make_pair(4, max_iters=2, lib=lib)
+    X = S.random_states(rb, 4, seed=3, scale=4.0)
+    seen_backtrack = False
+    for _ in range(3):
+        om.iterate(X)
+        gm.iterate(X)
+        assert np.array_equal(om.info[:, 2], gm.info[:, 2])
+        seen_backtrack |= bool((om.info[:, 2] < 1.0).any())
+        assert S.rel_err(om.xs, gm.xs) < 1e-7
+        X = om.xs[:, 1, :].copy()
+    assert seen_backtrack, "scenario no longer exercises backtracking"
+
+
+def test_dense_and_structured_riccati_agree(built):
+    """The model-independent dense sweep (SMPC_RICCATI=dense) and the kinodynamics-structured sweep solve the same
+    KKT system: identical trajectories up to round-off."""
+    code = (
+        "import sys; sys.path.insert(0, %r); import numpy as np, mpc_setup as S\n"
+        "gm, rb, _, _ = S.make_product(2, max_iters=2, lib=S.emu_lib())\n"
+        "import oracle_lib as O\n"
+        "gm.generateCycleHorizon(O.trot_cycle()); gm.switchToWalk(np.array([0.2,0,0,0,0,0.]))\n"
+        "X = S.random_states(rb, 2)\n"
+        "for _ in range(3):\n"
+        "    gm.iterate(X); X = gm.xs[:,1,:].copy()\n"
+        "np.savez(sys.argv[1], xs=gm.xs, K0=gm.K0)\n" % os.path.dirname(os.path.abspath(__file__))
+    )
+    outs = []
+    for mode in ("dense", "kino"):
+        path = "/tmp/smpc_emu_riccati_%s.npz" % mode
+        env = dict(os.environ, SMPC_RICCATI=mode)
+        subprocess.check_call([sys.executable, "-c", code, path], env=env)
+        outs.append(np.load(path))
+    assert S.rel_err(outs[0]["xs"], outs[1]["xs"]) < 1e-7
+    assert S.rel_err(outs[0]["K0"], outs[1]["K0"]) < 1e-6
+
+
 def test_batch_instances_are_independent(lib):
     gm4, rb, _, _ = S.make_product(4, lib=lib)
     gm1, _, _, _ = S.make_product(1, lib=lib)
