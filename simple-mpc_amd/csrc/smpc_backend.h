@@ -133,18 +133,19 @@ namespace smpc
     return ms;
   }
 
-  template <class Args, void (*Body)(const Args &, int), int NT>
-  __global__ __launch_bounds__(NT) void kernel_entry(const Args a)
+  // MINW = minimum waves per SIMD the register allocator must leave room for (caps VGPRs at 512 / MINW)
+  template <class Args, void (*Body)(const Args &, int), int NT, int MINW>
+  __global__ __launch_bounds__(NT, MINW) void kernel_entry(const Args a)
   {
     Body(a, (int)blockIdx.x);
   }
 
-  template <class Args, void (*Body)(const Args &, int), int NT>
+  template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1>
   inline void launch(int grid, stream_t s, const Args & a)
   {
     if (grid <= 0)
       return;
-    hipLaunchKernelGGL((kernel_entry<Args, Body, NT>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL((kernel_entry<Args, Body, NT, MINW>), dim3((unsigned)grid), dim3(NT), 0, s, a);
     SMPC_HIP(hipGetLastError());
   }
 } // namespace smpc

@@ -9,6 +9,9 @@
 //   MPC::updateCycleTiming     src/mpc.cpp:256-276    -> GaitTimer::update_timing
 //   MPC::switchToWalk/Stand    src/mpc.cpp:382-392
 #pragma once
+#ifndef SMPC_TRIAL_MINW
+#define SMPC_TRIAL_MINW 2
+#endif
 #include "smpc_riccati_kino.h"
 #include "smpc_solver_kernels.h"
 #include <algorithm>
@@ -134,6 +137,7 @@ namespace smpc
     double kernel_ms[KID_N] = {0};
     long kernel_calls[KID_N] = {0};
     std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
+    static constexpr int TRIAL_MINW = SMPC_TRIAL_MINW; // waves per SIMD the trial kernel's register budget allows
     static constexpr double ARMIJO_C1 = 1e-4, REG_INIT = 1e-9, REG_MIN = 1e-10, REG_MAX = 1e9, REG_INC = 10.0, REG_DEC = 1.0 / 3.0, STALL_REL = 1e-9;
 
     KinoEngine(const smpc_robot_model * rm, const HostKinoSettings & ks, const HostMpcSettings & ms_, int batch, double gravity_arg, int device)
@@ -281,19 +285,19 @@ namespace smpc
       return a;
     }
 
-    template <class Args, void (*Body)(const Args &, int), int NT>
+    template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1>
     void timed_launch(int kid, int grid, const Args & a)
     {
       if (profiling)
       {
         event_t e0 = event_create(), e1 = event_create();
         event_record(e0, stream);
-        launch<Args, Body, NT>(grid, stream, a);
+        launch<Args, Body, NT, MINW>(grid, stream, a);
         event_record(e1, stream);
         pending_events.push_back({kid, {e0, e1}});
       }
       else
-        launch<Args, Body, NT>(grid, stream, a);
+        launch<Args, Body, NT, MINW>(grid, stream, a);
       kernel_calls[kid]++;
     }
     void collect_profile()
@@ -345,7 +349,7 @@ namespace smpc
       {
         sk.j0 = gq[0];
         sk.nj = gq[1];
-        timed_launch<StageKernelArgs<D>, trial_body<D>, 64>(KID_TRIAL, b.B * (H + 1), sk);
+        timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_TRIAL, b.B * (H + 1), sk);
         timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, gq[0], gq[1]));
       }
       timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B * (H + 1), solver_args(b));

@@ -71,6 +71,7 @@ namespace smpc
   template <class D>
   SMPC_DEV void deriv_body(const StageKernelArgs<D> & ka, int block)
   {
+    typedef KinoScratch<D, true> KinoScratchT;
     constexpr int NT = 64;
     constexpr int NV = D::NV, NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF, NA = D::NA;
     const Buffers<D> & b = ka.b;
@@ -78,8 +79,8 @@ namespace smpc
     const int inst = block / (H + 1), t = block % (H + 1);
     const bool term = t == H;
     const DevModel<D> & md = *b.model;
-    SMPC_LDS(KinoScratch<D>, scs, 1);
-    KinoScratch<D> & sc = scs[0];
+    SMPC_LDS(KinoScratchT, scs, 1);
+    KinoScratchT & sc = scs[0];
     const int st = ring_slot(ka.head, t, R);
     const size_t ib = (size_t)inst * R;
     const double * xg = b.xs + (ib + st) * NX;
@@ -207,7 +208,7 @@ namespace smpc
     }
 
     // ---- multipliers, active set ----
-    kino_multipliers<D>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+    kino_multipliers<D, true>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
     if (in.prof) prof_tick(in.prof, 31, tprev);
 
     // ---- small weighted-Jacobian tables ----
@@ -228,6 +229,11 @@ namespace smpc
         for (int bb = 0; bb < 6; bb++)
           s += md.w_cent[a * 6 + bb] * (k < NV ? sc.dh_dq[bb * NV + k] : sc.Ag[bb * NV + k - NV]);
         sc.WJc[idx] = s;
+        // JtW[i][k] = sum_a Jl[a][i] w_x[a][k]  (rows of J_x^T w_x for the base block)
+        double t = 0.0;
+        for (int bb = 0; bb < 6; bb++)
+          t += sc.Jl[bb * 6 + a] * md.w_x[bb * NDX + k];
+        sc.JtW[idx] = t;
       }
       for (int idx = lane; idx < 3 * NV; idx += NT)
       {
@@ -258,6 +264,20 @@ namespace smpc
         for (int bb = 0; bb < 3; bb++)
           s += md.w_frame[a * 3 + bb] * sc.Jfoot[(f * 3 + bb) * NV + k];
         sc.WJf[idx] = s;
+      }
+      if (lane < 36)
+      {
+        // JWJ = Jl^T w_x[0:6,0:6] Jl (base block of the state Hessian)
+        const int i = lane / 6, j = lane % 6;
+        double s = 0.0;
+        for (int a = 0; a < 6; a++)
+        {
+          double t = 0.0;
+          for (int bb = 0; bb < 6; bb++)
+            t += md.w_x[a * NDX + bb] * sc.Jl[bb * 6 + j];
+          s += sc.Jl[a * 6 + i] * t;
+        }
+        sc.JWJ[lane] = s;
       }
     }
     SMPC_LANES_END
@@ -399,91 +419,152 @@ namespace smpc
     SMPC_LANES_END
 
     if (in.prof) prof_tick(in.prof, 33, tprev);
-    // ---- [Q | S]: lane k < NDX owns column k of Q, lane NDX+k column k of S ----
+    // ---- Q, S, R as 3x3 register tiles over the structured sum of J^T W J terms:
+    //      Q = state block (table look-ups) + Jc^T (Wc Jc) [K=6, all 36x36]
+    //          + dtgt^T (Wcd dtgt) [K=3] + Jfoot^T (Wf Jfoot) [K=3 NF]   on the q x q block only
+    //      S = dtgt^T (Wcd Ju)   on (q rows) x (force columns of feet in contact), zero elsewhere
+    //      R = w_u + Ju^T (Wcd Ju) on the force x force block ----
     SMPC_LANES(NT)
-    if (lane < NDX + NU)
     {
-      const bool isQ = lane < NDX;
-      const int k = isQ ? lane : lane - NDX;
-      double * dst = lq + (isQ ? D::O_Q : D::O_S);
-      const int ld = isQ ? NDX : NU;
-      const bool fcol = !isQ && k < 3 * NF && ((in.mask >> (k / 3)) & 1u);
-      for (int i = 0; i < NDX; i++)
+      constexpr int TQ = NDX / 3;
+      for (int tile = lane; tile < TQ * TQ; tile += NT)
       {
-        double v = 0.0;
-        if (isQ)
-        {
-          if (i < 6)
-            for (int a = 0; a < 6; a++)
-              v += sc.Jl[a * 6 + i] * (k < 6 ? sc.WJl[a * 6 + k] : md.w_x[a * NDX + k]);
-          else
-            v = k < 6 ? sc.WJl[i * 6 + k] : md.w_x[i * NDX + k];
-          for (int a = 0; a < 6; a++)
-            v += (i < NV ? sc.dh_dq[a * NV + i] : sc.Ag[a * NV + i - NV]) * sc.WJc[a * NDX + k];
-          if (i < NV && k < NV)
+        const int i0 = (tile / TQ) * 3, j0 = (tile % TQ) * 3;
+        double acc[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c = 0; c < 3; c++)
           {
-            for (int a = 0; a < 3; a++)
-              v += sc.dtgt[a * NV + i] * sc.WD[a * NV + k];
-            for (int fa = 0; fa < NF * 3; fa++)
-              v += sc.Jfoot[fa * NV + i] * sc.WJf[fa * NV + k];
-          }
-          if (i == k)
-            v += preg;
-        }
-        else if (fcol && i < NV)
-        {
-          for (int a = 0; a < 3; a++)
-            v += sc.dtgt[a * NV + i] * sc.WJu[(3 + a) * 3 * NF + k];
-        }
-        dst[i * ld + k] = v;
-      }
-    }
-    SMPC_LANES_END
-
-    if (in.prof) prof_tick(in.prof, 34, tprev);
-    // ---- [C | R]: lane k < NDX owns column k of C (active rows), lane NDX+k column k of R ----
-    SMPC_LANES(NT)
-    if (lane < NDX + NU)
-    {
-      const bool isC = lane < NDX;
-      const int k = isC ? lane : lane - NDX;
-      if (isC)
-      {
-        double * dst = lq + D::O_C;
-        for (int i = 0; i < NC; i++)
-        {
-          double v = 0.0;
-          if (sc.act[i])
-          {
-            if (i < NA)
-              v = (k == 6 + i) ? 1.0 : 0.0;
+            const int i = i0 + a, j = j0 + c;
+            // state block: J_x^T w_x J_x with J_x = blockdiag(Jlog6, I)
+            double v;
+            if (i < 6)
+              v = j < 6 ? sc.JWJ[i * 6 + j] : sc.JtW[i * NDX + j];
             else
-              v = k < NV ? sc.dcq[(i - NA) * NV + k] : sc.dcv[(i - NA) * NV + k - NV];
+              v = j < 6 ? sc.WJl[i * 6 + j] : md.w_x[i * NDX + j];
+            acc[a][c] = v + (i == j ? preg : 0.0);
           }
-          dst[i * NDX + k] = v;
-        }
-      }
-      else
-      {
-        double * dst = lq + D::O_R;
-        const bool fk = k < 3 * NF && ((in.mask >> (k / 3)) & 1u);
-        for (int i = 0; i < NU; i++)
+        const double * jc = i0 < NV ? &sc.dh_dq[i0] : &sc.Ag[i0 - NV];
+#pragma unroll
+        for (int k = 0; k < 6; k++)
         {
-          double v = md.w_u[i * NU + k];
-          if (fk && i < 3 * NF && ((in.mask >> (i / 3)) & 1u))
-          {
-            // Ju[:, i]^T * WJu[:, k]
-            const int f = i / 3, j = i % 3;
-            const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
-            const V3 xc = cross(rr, mk3(j == 0, j == 1, j == 2));
-            v += sc.WJu[j * 3 * NF + k] + xc.x * sc.WJu[3 * 3 * NF + k] + xc.y * sc.WJu[4 * 3 * NF + k] + xc.z * sc.WJu[5 * 3 * NF + k];
-          }
-          if (i == k)
-            v += preg;
-          dst[i * NU + k] = v;
+          const double x0 = jc[k * NV], x1 = jc[k * NV + 1], x2 = jc[k * NV + 2];
+          const double * wr = &sc.WJc[k * NDX + j0];
+          const double y0 = wr[0], y1 = wr[1], y2 = wr[2];
+          acc[0][0] += x0 * y0;
+          acc[0][1] += x0 * y1;
+          acc[0][2] += x0 * y2;
+          acc[1][0] += x1 * y0;
+          acc[1][1] += x1 * y1;
+          acc[1][2] += x1 * y2;
+          acc[2][0] += x2 * y0;
+          acc[2][1] += x2 * y1;
+          acc[2][2] += x2 * y2;
         }
+        if (i0 < NV && j0 < NV)
+        {
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+          {
+            const double * xr = &sc.dtgt[k * NV + i0];
+            const double * yr = &sc.WD[k * NV + j0];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+                acc[a][c] += xr[a] * yr[c];
+          }
+#pragma unroll 4
+          for (int k = 0; k < NF * 3; k++)
+          {
+            const double * xr = &sc.Jfoot[k * NV + i0];
+            const double * yr = &sc.WJf[k * NV + j0];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+                acc[a][c] += xr[a] * yr[c];
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            lq[D::O_Q + (i0 + a) * NDX + j0 + c] = acc[a][c];
       }
-      // vectors d, vpd
+      // S
+      constexpr int TS = NU / 3;
+      for (int tile = lane; tile < TQ * TS; tile += NT)
+      {
+        const int i0 = (tile / TS) * 3, j0 = (tile % TS) * 3;
+        double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        if (i0 < NV && j0 < 3 * NF && ((in.mask >> (j0 / 3)) & 1u))
+        {
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+          {
+            const double * xr = &sc.dtgt[k * NV + i0];
+            const double * yr = &sc.WJu[(3 + k) * 3 * NF + j0];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+                acc[a][c] += xr[a] * yr[c];
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            lq[D::O_S + (i0 + a) * NU + j0 + c] = acc[a][c];
+      }
+      // R
+      for (int tile = lane; tile < TS * TS; tile += NT)
+      {
+        const int i0 = (tile / TS) * 3, j0 = (tile % TS) * 3;
+        double acc[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            acc[a][c] = md.w_u[(i0 + a) * NU + j0 + c] + ((i0 + a) == (j0 + c) ? preg : 0.0);
+        if (i0 < 3 * NF && j0 < 3 * NF && ((in.mask >> (i0 / 3)) & 1u) && ((in.mask >> (j0 / 3)) & 1u))
+        {
+          // Ju[:, 3f+a] = [e_a ; (p_f - c) x e_a]
+          const V3 rr = ld3(&sc.footp[(i0 / 3) * 3]) - ld3(sc.com);
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+          {
+            const V3 xc = cross(rr, mk3(a == 0, a == 1, a == 2));
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+            {
+              const int k = j0 + c;
+              acc[a][c] += sc.WJu[a * 3 * NF + k] + xc.x * sc.WJu[3 * 3 * NF + k] + xc.y * sc.WJu[4 * 3 * NF + k] + xc.z * sc.WJu[5 * 3 * NF + k];
+            }
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            lq[D::O_R + (i0 + a) * NU + j0 + c] = acc[a][c];
+      }
+      // C (active rows; coalesced row runs), d, vpd
+      for (int idx = lane; idx < NC * NDX; idx += NT)
+      {
+        const int i = idx / NDX, k = idx % NDX;
+        double v = 0.0;
+        if (sc.act[i])
+        {
+          if (i < NA)
+            v = (k == 6 + i) ? 1.0 : 0.0;
+          else
+            v = k < NV ? sc.dcq[(i - NA) * NV + k] : sc.dcv[(i - NA) * NV + k - NV];
+        }
+        lq[D::O_C + idx] = v;
+      }
       if (lane < NC)
       {
         lq[D::O_d + lane] = mu * (sc.vplus[lane] - sc.nu[lane]);
@@ -530,14 +611,15 @@ namespace smpc
   template <class D>
   SMPC_DEV void trial_one(const StageKernelArgs<D> & ka, int inst, int t, int j)
   {
+    typedef KinoScratch<D, false> KinoScratchT;
     constexpr int NT = 64;
     constexpr int NV = D::NV, NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF;
     const Buffers<D> & b = ka.b;
     const int H = b.H, R = b.R;
     const bool term = t == H;
     const DevModel<D> & md = *b.model;
-    SMPC_LDS(KinoScratch<D>, scs, 1);
-    KinoScratch<D> & sc = scs[0];
+    SMPC_LDS(KinoScratchT, scs, 1);
+    KinoScratchT & sc = scs[0];
     const int st = ring_slot(ka.head, t, R);
     const size_t ib = (size_t)inst * R;
     double alpha = 1.0;
@@ -558,9 +640,8 @@ namespace smpc
       lanes_integrate<D>(b.xs + (ib + st) * NX, dx, alpha, sc.x, lane, 0);
       if (!term)
       {
-        // trial x_{t+1} goes to sc.rf/... no: keep it in sc.WJf (NX doubles fit) as scratch
         const int sn = ring_slot(ka.head, t + 1, R);
-        lanes_integrate<D>(b.xs + (ib + sn) * NX, dx + NDX, alpha, sc.WJf, lane, 1);
+        lanes_integrate<D>(b.xs + (ib + sn) * NX, dx + NDX, alpha, sc.xn1, lane, 1);
         const size_t lt = (size_t)inst * H + t;
         for (int i = lane; i < NU; i += NT)
           sc.u[i] = b.us[(ib + st) * NU + i] + alpha * b.dus[lt * NU + i];
@@ -579,7 +660,7 @@ namespace smpc
     if (!term)
     {
       SMPC_LANES(NT)
-      lanes_difference<D>(sc.WJf, sc.xnext, sc.e, lane, 61);
+      lanes_difference<D>(sc.xn1, sc.xnext, sc.e, lane, 61);
       SMPC_LANES_END
     }
     kino_cost_constraints<D, false>(sc, in);
@@ -595,7 +676,7 @@ namespace smpc
       SMPC_LANES_END
       return;
     }
-    kino_multipliers<D>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+    kino_multipliers<D, false>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
     SMPC_LANES(NT)
     {
       if (lane == 0)

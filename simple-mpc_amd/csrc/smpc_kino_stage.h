@@ -15,11 +15,14 @@
 #pragma once
 #include "smpc_math.h"
 #include "smpc_model.h"
+#include <type_traits>
 
 namespace smpc
 {
+  // LDS scratch of one (instance, stage) wavefront.  The evaluation-only part (trial points of the line
+  // search) is 13.6 KB; the derivative part adds 21 KB and is only instantiated by the derivative kernel.
   template <class D>
-  struct KinoScratch
+  struct KinoScratchEval
   {
     double x[D::NX], u[D::NU];
     double oR[D::NJ * 9], op[D::NJ * 3];
@@ -33,26 +36,38 @@ namespace smpc
     double b0[6], hd[6], hg[6];
     double gjA[36], gjB[36], Agbi[36];
     double a[D::NV];
-    double xnext[D::NX], e[D::NDX];
+    double xnext[D::NX], e[D::NDX], xn1[D::NX];
     double cval[D::NC];
     // residuals and weighted residuals
     double rx[D::NDX], Wrx[D::NDX], ru[D::NU], Wru[D::NU], Whg[6], Whd[6], rf[D::NF * 3], Wrf[D::NF * 3];
-    // derivative-only section
+    double vplus[D::NC], lamp[D::NDX], lam_next[D::NDX], lam_prev[D::NDX], nu[D::NC];
+    int act[D::NC];
+    double red[8];
+  };
+  template <class D>
+  struct KinoScratchDerivPart
+  {
     double dh_dq[6 * D::NV], dhd_dq[6 * D::NV], dhd_dv[6 * D::NV];
     double Jcom[3 * D::NV], Jfoot[D::NF * 3 * D::NV];
     double dtgt[3 * D::NV];
     double ab_dq[6 * D::NV], ab_dv[6 * D::NV], ab_du[6 * D::NU];
     double Je3[9], JeQ[9], Jq[36], Jl[36];
     double WJl[D::NDX * 6];           // w_x[:,0:6] * Jl
+    double JtW[6 * D::NDX];           // Jl^T w_x[0:6,:]
+    double JWJ[36];                   // Jl^T w_x[0:6,0:6] Jl
     double WJc[6 * D::NDX];           // w_cent * [dh_dq | Ag]
     double WD[3 * D::NV];             // w_centder[3:6,3:6] * dtgt
     double WJu[6 * 3 * D::NF];        // w_centder * Ju (force columns)
     double WJf[D::NF * 3 * D::NV];    // w_frame * Jfoot
     double dcq[D::NF * 3 * D::NV], dcv[D::NF * 3 * D::NV];
     double lx[D::NDX], lu[D::NU];
-    double vplus[D::NC], lamp[D::NDX], lam_next[D::NDX], lam_prev[D::NDX], nu[D::NC];
-    int act[D::NC];
-    double red[8];
+  };
+  struct KinoScratchNoDeriv
+  {
+  };
+  template <class D, bool DERIV>
+  struct KinoScratch : KinoScratchEval<D>, std::conditional<DERIV, KinoScratchDerivPart<D>, KinoScratchNoDeriv>::type
+  {
   };
 
   // inputs describing one stage evaluation
@@ -75,14 +90,26 @@ namespace smpc
   // acceleration and every derivative column.
   // ---------------------------------------------------------------------------------------------
   template <class D, bool DERIV>
-  SMPC_DEV void kino_tree_phases(KinoScratch<D> & sc, const StageIn<D> & in)
+  SMPC_DEV void kino_tree_phases(KinoScratch<D, DERIV> & sc, const StageIn<D> & in)
   {
     constexpr int NT = 64;
     constexpr int NJ = D::NJ, NV = D::NV, NQ = D::NQ, NF = D::NF;
     const DevModel<D> & md = *in.md;
     const int nlev = md.nlevels;
 
-    // ---- FK, level by level ----
+    // ---- root -> leaf pass, fused: per joint (one lane) placement, motion column(s), world inertia, velocity,
+    //      bias acceleration (a = 0), own momentum and net force; values stay in registers within the lane ----
+    const double * vq = &sc.x[NQ];
+    SMPC_PL(double, sn_j, NT);
+    SMPC_PL(double, cs_j, NT);
+    SMPC_LANES(NT)
+    if (lane > 0 && lane < NJ)
+    {
+      const double ang = sc.x[6 + lane];
+      SMPC_PLV(sn_j) = sin(ang);
+      SMPC_PLV(cs_j) = cos(ang);
+    }
+    SMPC_LANES_END
     for (int lvl = 0; lvl < nlev; lvl++)
     {
       SMPC_LANES(NT)
@@ -91,116 +118,73 @@ namespace smpc
         const int j = lane;
         M3 R;
         V3 p;
+        SV v, a;
         if (j == 0)
         {
           R = quat_to_R(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]});
           p = ld3(sc.x);
-        }
-        else
-        {
-          const int par = md.parent[j];
-          const double ang = sc.x[6 + j];
-          const double s = sin(ang), c = cos(ang);
-          const int jt = md.jtype[j];
-          M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -s, 0, s, c} : (jt == 2 ? M3{c, 0, s, 0, 1, 0, -s, 0, c} : M3{c, -s, 0, s, c, 0, 0, 0, 1});
-          const M3 Rp = ldm3(&sc.oR[par * 9]);
-          R = Rp * (ldm3(md.jpR[j]) * Rq);
-          p = ld3(&sc.op[par * 3]) + Rp * ld3(md.jpp[j]);
-        }
-        stm3(&sc.oR[j * 9], R);
-        st3(&sc.op[j * 3], p);
-      }
-      SMPC_LANES_END
-    }
-    if (in.prof) prof_tick(in.prof, 16, *in.tprev);
-    // ---- S columns (lanes 0..NV-1), world inertias (lanes 32..32+NJ-1), feet (lanes 48..) ----
-    SMPC_LANES(NT)
-    if (lane < NV)
-    {
-      const int k = lane;
-      const int j = k < 6 ? 0 : k - 5;
-      const M3 R = ldm3(&sc.oR[j * 9]);
-      const V3 p = ld3(&sc.op[j * 3]);
-      int col;
-      if (k < 6)
-        col = k % 3;
-      else
-        col = md.jtype[j] - 1;
-      const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
-      SV s;
-      if (k < 3)
-        s = SV{ax, mk3(0, 0, 0)};
-      else
-        s = SV{cross(p, ax), ax};
-      stsv(&sc.S[k * 6], s);
-    }
-    else if (lane >= 32 && lane < 32 + NJ)
-    {
-      const int j = lane - 32;
-      const M3 R = ldm3(&sc.oR[j * 9]);
-      const V3 p = ld3(&sc.op[j * 3]);
-      const double m = md.mass[j];
-      const V3 c = R * ld3(md.com[j]) + p;
-      const double * il = md.inertia[j];
-      const M3 Il = M3{il[0], il[1], il[3], il[1], il[2], il[4], il[3], il[4], il[5]};
-      const M3 Iw = R * Il * transpose(R);
-      const double cc = dot(c, c);
-      SI I;
-      I.m = m;
-      I.mc = m * c;
-      I.jxx = Iw.a00 + m * (cc - c.x * c.x);
-      I.jxy = Iw.a01 - m * c.x * c.y;
-      I.jxz = Iw.a02 - m * c.x * c.z;
-      I.jyy = Iw.a11 + m * (cc - c.y * c.y);
-      I.jyz = Iw.a12 - m * c.y * c.z;
-      I.jzz = Iw.a22 + m * (cc - c.z * c.z);
-      stsi(&sc.I[j * 10], I);
-      stsi(&sc.Ic[j * 10], I);
-    }
-    else if (lane >= 48 && lane < 48 + NF)
-    {
-      const int f = lane - 48;
-      const int j = md.foot_joint[f];
-      st3(&sc.footp[f * 3], ldm3(&sc.oR[j * 9]) * ld3(md.foot_p[f]) + ld3(&sc.op[j * 3]));
-    if (in.prof) prof_tick(in.prof, 17, *in.tprev);
-    }
-    SMPC_LANES_END
-    // ---- velocities and bias accelerations (a = 0), ascending ----
-    const double * vq = &sc.x[NQ];
-    for (int lvl = 0; lvl < nlev; lvl++)
-    {
-      SMPC_LANES(NT)
-      if (lane < NJ && md.level[lane] == lvl)
-      {
-        const int j = lane;
-        SV v, a;
-        if (j == 0)
-        {
           v = sv0();
           for (int k = 0; k < 6; k++)
-            v = v + vq[k] * ldsv(&sc.S[k * 6]);
+          {
+            const int col = k % 3;
+            const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
+            const SV sk = k < 3 ? SV{ax, mk3(0, 0, 0)} : SV{cross(p, ax), ax};
+            stsv(&sc.S[k * 6], sk);
+            v = v + vq[k] * sk;
+          }
           a = sv0();
         }
         else
         {
           const int par = md.parent[j];
+          const double s = SMPC_PLV(sn_j), c = SMPC_PLV(cs_j);
+          const int jt = md.jtype[j];
+          const M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -s, 0, s, c} : (jt == 2 ? M3{c, 0, s, 0, 1, 0, -s, 0, c} : M3{c, -s, 0, s, c, 0, 0, 0, 1});
+          const M3 Rp = ldm3(&sc.oR[par * 9]);
+          R = Rp * (ldm3(md.jpR[j]) * Rq);
+          p = ld3(&sc.op[par * 3]) + Rp * ld3(md.jpp[j]);
+          const int col = jt - 1;
+          const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
+          const SV sk = SV{cross(p, ax), ax};
+          stsv(&sc.S[(j + 5) * 6], sk);
           const SV vp = ldsv(&sc.vel[par * 6]);
-          const SV s = ldsv(&sc.S[(j + 5) * 6]);
-          v = vp + vq[j + 5] * s;
-          a = ldsv(&sc.acc[par * 6]) + vq[j + 5] * crm(vp, s);
+          v = vp + vq[j + 5] * sk;
+          a = ldsv(&sc.acc[par * 6]) + vq[j + 5] * crm(vp, sk);
         }
+        stm3(&sc.oR[j * 9], R);
+        st3(&sc.op[j * 3], p);
         stsv(&sc.vel[j * 6], v);
         stsv(&sc.acc[j * 6], a);
-        const SI I = ldsi(&sc.I[j * 10]);
+        // world inertia about the origin
+        const double m = md.mass[j];
+        const V3 c = R * ld3(md.com[j]) + p;
+        const double * il = md.inertia[j];
+        const M3 Il = M3{il[0], il[1], il[3], il[1], il[2], il[4], il[3], il[4], il[5]};
+        const M3 Iw = R * Il * transpose(R);
+        const double cc = dot(c, c);
+        SI I;
+        I.m = m;
+        I.mc = m * c;
+        I.jxx = Iw.a00 + m * (cc - c.x * c.x);
+        I.jxy = Iw.a01 - m * c.x * c.y;
+        I.jxz = Iw.a02 - m * c.x * c.z;
+        I.jyy = Iw.a11 + m * (cc - c.y * c.y);
+        I.jyz = Iw.a12 - m * c.y * c.z;
+        I.jzz = Iw.a22 + m * (cc - c.z * c.z);
+        stsi(&sc.I[j * 10], I);
+        stsi(&sc.Ic[j * 10], I);
         const SV h = I * v;
         stsv(&sc.h[j * 6], h);
         stsv(&sc.hc[j * 6], h);
         stsv(&sc.Fc[j * 6], I * a + crf(v, h));
+        for (int f = 0; f < NF; f++)
+          if (md.foot_joint[f] == j)
+            st3(&sc.footp[f * 3], R * ld3(md.foot_p[f]) + p);
       }
       SMPC_LANES_END
     }
-    if (in.prof) prof_tick(in.prof, 18, *in.tprev);
-    // ---- composites, descending: parents gather their children ----
+    if (in.prof) prof_tick(in.prof, 16, *in.tprev);
+    // ---- composites, leaf -> root: parents gather their children ----
     for (int lvl = nlev - 2; lvl >= 0; lvl--)
     {
       SMPC_LANES(NT)
@@ -414,49 +398,43 @@ namespace smpc
     }
     SMPC_LANES_END
 
-    if (!DERIV)
-      return;
-
-    // ---- accelerations with the solved a, ascending, and net forces ----
-    for (int lvl = 0; lvl < nlev; lvl++)
+    if constexpr (DERIV)
     {
-      SMPC_LANES(NT)
-      if (lane < NJ && md.level[lane] == lvl)
-      {
-        const int j = lane;
-        SV a;
-        if (j == 0)
-        {
-          a = sv0();
-          for (int k = 0; k < 6; k++)
-            a = a + sc.a[k] * ldsv(&sc.S[k * 6]);
-        }
-        else
-        {
-          const int par = md.parent[j];
-          const SV s = ldsv(&sc.S[(j + 5) * 6]);
-          a = ldsv(&sc.acc[par * 6]) + sc.a[j + 5] * s + vq[j + 5] * crm(ldsv(&sc.vel[par * 6]), s);
-        }
-        stsv(&sc.acc[j * 6], a);
-        stsv(&sc.Fc[j * 6], ldsi(&sc.I[j * 10]) * a + crf(ldsv(&sc.vel[j * 6]), ldsv(&sc.h[j * 6])));
-      }
-      SMPC_LANES_END
-    }
-    if (in.prof) prof_tick(in.prof, 25, *in.tprev);
-    for (int lvl = nlev - 2; lvl >= 0; lvl--)
+    // ---- accelerations and composite net forces for the solved a, without another tree sweep:
+    //      acc_i(a) = acc_i(0) + sum_{k <= i} a_k S_k
+    //      Fc_i(a)  = Fc_i(0) + sum_{k <= i} a_k Ic_i S_k + sum_{k strictly below i} a_k Ic_{j(k)} S_k ----
+    SMPC_LANES(NT)
     {
-      SMPC_LANES(NT)
-      if (lane < NJ && md.level[lane] == lvl)
+      if (lane < NJ)
       {
-        const int j = lane;
-        SV Fc = ldsv(&sc.Fc[j * 6]);
-        for (int c = j + 1; c < NJ; c++)
-          if (md.parent[c] == j)
-            Fc = Fc + ldsv(&sc.Fc[c * 6]);
-        stsv(&sc.Fc[j * 6], Fc);
+        const int i = lane;
+        SV acc = ldsv(&sc.acc[i * 6]);
+        for (int k = 0; k < NV; k++)
+        {
+          const int jk = k < 6 ? 0 : k - 5;
+          if ((md.anc[i] >> jk) & 1u)
+            acc = acc + sc.a[k] * ldsv(&sc.S[k * 6]);
+        }
+        stsv(&sc.acc[i * 6], acc);
       }
-      SMPC_LANES_END
+      else if (lane >= 32 && lane < 32 + NJ)
+      {
+        const int i = lane - 32;
+        SV F = ldsv(&sc.Fc[i * 6]);
+        const SI Ici = ldsi(&sc.Ic[i * 10]);
+        for (int k = 0; k < NV; k++)
+        {
+          const int jk = k < 6 ? 0 : k - 5;
+          const SV sk = ldsv(&sc.S[k * 6]);
+          if ((md.anc[i] >> jk) & 1u)
+            F = F + sc.a[k] * (Ici * sk);
+          else if ((md.anc[jk] >> i) & 1u)
+            F = F + sc.a[k] * (ldsi(&sc.Ic[jk * 10]) * sk);
+        }
+        stsv(&sc.Fc[i * 6], F); // each lane reads and writes only its own Fc_i: no cross-lane hazard
+      }
     }
+    SMPC_LANES_END
     if (in.prof) prof_tick(in.prof, 26, *in.tprev);
     // ---- derivative columns: lane k < NV ----
     SMPC_LANES(NT)
@@ -628,14 +606,15 @@ namespace smpc
             Jq[(i + 3) * 6 + j] = 0.0;
           }
       }
-    if (in.prof) prof_tick(in.prof, 28, *in.tprev);
     }
     SMPC_LANES_END
+    if (in.prof) prof_tick(in.prof, 28, *in.tprev);
+    } // if constexpr (DERIV)
   }
 
   // state residual rx = x (-) x_tgt and (optionally) Jlog6 of the base block, by one lane + vector part
   template <class D, bool DERIV>
-  SMPC_DEV void kino_state_residual(KinoScratch<D> & sc, const double * xt, int lane)
+  SMPC_DEV void kino_state_residual(KinoScratch<D, DERIV> & sc, const double * xt, int lane)
   {
     constexpr int NV = D::NV, NQ = D::NQ;
     if (lane == 63)
@@ -646,7 +625,7 @@ namespace smpc
       log6(se3_mul(se3_inv(Mt), Mx), v, w);
       st3(&sc.rx[0], v);
       st3(&sc.rx[3], w);
-      if (DERIV)
+      if constexpr (DERIV)
       {
         M3 Ji, X;
         Jlog6(v, w, Ji, X);
@@ -670,7 +649,7 @@ namespace smpc
 
   // Residuals, weighted residuals, cost value, constraint values.  Result: sc.red[0] = stage cost.
   template <class D, bool DERIV>
-  SMPC_DEV void kino_cost_constraints(KinoScratch<D> & sc, const StageIn<D> & in)
+  SMPC_DEV void kino_cost_constraints(KinoScratch<D, DERIV> & sc, const StageIn<D> & in)
   {
     constexpr int NT = 64;
     constexpr int NV = D::NV, NF = D::NF, NU = D::NU, NDX = D::NDX, NA = D::NA, NC = D::NC;
@@ -784,8 +763,8 @@ namespace smpc
   // AL multipliers for this stage (reference: SolverProxDDP computeMultipliers).
   // Inputs (LDS): sc.e, sc.cval, sc.lam_next (lambda_{t+1}), sc.nu.  Centres from global.
   // Outputs: sc.lamp, sc.vplus, sc.act, sc.red[1] = penalty part of the merit, sc.red[2] = primal infeasibility
-  template <class D>
-  SMPC_DEV void kino_multipliers(KinoScratch<D> & sc, const StageIn<D> & in, const double * lam_e, const double * nu_e)
+  template <class D, bool DERIV>
+  SMPC_DEV void kino_multipliers(KinoScratch<D, DERIV> & sc, const StageIn<D> & in, const double * lam_e, const double * nu_e)
   {
     constexpr int NT = 64;
     constexpr int NDX = D::NDX, NC = D::NC, NA = D::NA;
