@@ -172,6 +172,61 @@ namespace smpc
     }
   }
 
+  // acc(3x3) += sum_k x_k (3) * y_k (3)^T, software-pipelined by hand with two register sets: the operands
+  // of step k+1 are requested before the FMAs of step k.  The loop itself is NOT unrolled (K even), which
+  // keeps the register footprint at 12 operand doubles.  xp(k) / yp(k): pointers to 3 consecutive doubles.
+  template <int K, class XP, class YP>
+  SMPC_DEV void tile3x3_mac(double (&acc)[3][3], XP xp, YP yp)
+  {
+    static_assert(K % 2 == 0, "K must be even");
+    double xa[3], ya[3], xb[3], yb[3];
+    {
+      const double * x = xp(0);
+      const double * y = yp(0);
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+      {
+        xa[a] = x[a];
+        ya[a] = y[a];
+      }
+    }
+#pragma unroll 1
+    for (int k = 0; k < K; k += 2)
+    {
+      {
+        const double * x = xp(k + 1);
+        const double * y = yp(k + 1);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+        {
+          xb[a] = x[a];
+          yb[a] = y[a];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          acc[a][c] += xa[a] * ya[c];
+      {
+        const int kn = k + 2 < K ? k + 2 : k; // last iteration: harmless reload
+        const double * x = xp(kn);
+        const double * y = yp(kn);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+        {
+          xa[a] = x[a];
+          ya[a] = y[a];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          acc[a][c] += xb[a] * yb[c];
+    }
+  }
+
   // n-th tile (row-major over the lower triangle incl. diagonal) of a square tile grid: n -> (ti, tj), tj <= ti
   SMPC_HD void lower_tile(int n, int & ti, int & tj)
   {
@@ -324,22 +379,7 @@ namespace smpc
           lower_tile(n, ti, tj);
           const int i0 = ti * 3, j0 = tj * 3;
           double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#pragma unroll 4
-          for (int k = 0; k < NDX; k++)
-          {
-            const double * yr = &Ym[k * (NDX + 1)];
-            const double x0 = yr[i0], x1 = yr[i0 + 1], x2 = yr[i0 + 2];
-            const double y0 = yr[j0], y1 = yr[j0 + 1], y2 = yr[j0 + 2];
-            acc[0][0] += x0 * y0;
-            acc[0][1] += x0 * y1;
-            acc[0][2] += x0 * y2;
-            acc[1][0] += x1 * y0;
-            acc[1][1] += x1 * y1;
-            acc[1][2] += x1 * y2;
-            acc[2][0] += x2 * y0;
-            acc[2][1] += x2 * y1;
-            acc[2][2] += x2 * y2;
-          }
+          tile3x3_mac<NDX>(acc, [&](int k) { return &Ym[k * (NDX + 1) + i0]; }, [&](int k) { return &Ym[k * (NDX + 1) + j0]; });
           // batch the symmetrising reads, then write (off-diagonal tiles: all 9 + mirror; diagonal: lower part)
           double pv[3][3];
 #pragma unroll
@@ -490,28 +530,8 @@ namespace smpc
                 const double v = SMPC_PLV(qs_acc)[rr * 9 + a * 3 + c] + coef * s.P[i * NDX + col];
                 acc[a][c] = v;
               }
-#pragma unroll 4
-            for (int k = 0; k < NG; k++)
-            {
-              double xv[3], yv[3], xu[3], yn[3];
-#pragma unroll
-              for (int a = 0; a < 3; a++)
-              {
-                xv[a] = NAB[k * NXU + i0 + a]; // NA[k][i]
-                xu[a] = PEG[k * NXU + i0 + a]; // (P~E)[G_k][i]
-              }
-#pragma unroll
-              for (int c = 0; c < 3; c++)
-              {
-                yv[c] = TG[k * NXU + j0 + c];
-                yn[c] = NAB[k * NXU + j0 + c];
-              }
-#pragma unroll
-              for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-                  acc[a][c] += xv[a] * yv[c] + xu[a] * yn[c];
-            }
+            tile3x3_mac<NG>(acc, [&](int k) { return &NAB[k * NXU + i0]; }, [&](int k) { return &TG[k * NXU + j0]; });
+            tile3x3_mac<NG>(acc, [&](int k) { return &PEG[k * NXU + i0]; }, [&](int k) { return &NAB[k * NXU + j0]; });
 #pragma unroll
             for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -538,28 +558,8 @@ namespace smpc
                   v += dt * dt * s.P[(NV + 6 + i - 3 * NF) * NDX + NV + 6 + j - 3 * NF];
                 acc[a][c] = v;
               }
-#pragma unroll 4
-            for (int k = 0; k < NG; k++)
-            {
-              double xn[3], xp[3], yt[3], yn[3];
-#pragma unroll
-              for (int a = 0; a < 3; a++)
-              {
-                xn[a] = NAB[k * NXU + NDX + i0 + a];
-                xp[a] = PEG[k * NXU + NDX + i0 + a];
-              }
-#pragma unroll
-              for (int c = 0; c < 3; c++)
-              {
-                yt[c] = TG[k * NXU + NDX + j0 + c];
-                yn[c] = NAB[k * NXU + NDX + j0 + c];
-              }
-#pragma unroll
-              for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-                  acc[a][c] += xn[a] * yt[c] + xp[a] * yn[c];
-            }
+            tile3x3_mac<NG>(acc, [&](int k) { return &NAB[k * NXU + NDX + i0]; }, [&](int k) { return &TG[k * NXU + NDX + j0]; });
+            tile3x3_mac<NG>(acc, [&](int k) { return &PEG[k * NXU + NDX + i0]; }, [&](int k) { return &NAB[k * NXU + NDX + j0]; });
 #pragma unroll
             for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -694,38 +694,8 @@ namespace smpc
           lower_tile(n, ti, tj);
           const int i0 = ti * 3, j0 = tj * 3;
           double aw[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, ac[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#pragma unroll 4
-          for (int k = 0; k < NU; k++)
-          {
-            const double * wr = &Wm[k * (NDX + 1)];
-            const double x0 = wr[i0], x1 = wr[i0 + 1], x2 = wr[i0 + 2];
-            const double y0 = wr[j0], y1 = wr[j0 + 1], y2 = wr[j0 + 2];
-            aw[0][0] += x0 * y0;
-            aw[0][1] += x0 * y1;
-            aw[0][2] += x0 * y2;
-            aw[1][0] += x1 * y0;
-            aw[1][1] += x1 * y1;
-            aw[1][2] += x1 * y2;
-            aw[2][0] += x2 * y0;
-            aw[2][1] += x2 * y1;
-            aw[2][2] += x2 * y2;
-          }
-#pragma unroll 4
-          for (int k = 0; k < NG; k++)
-          {
-            const double * cr = &Cc[k * NDX];
-            const double x0 = cr[i0], x1 = cr[i0 + 1], x2 = cr[i0 + 2];
-            const double y0 = cr[j0], y1 = cr[j0 + 1], y2 = cr[j0 + 2];
-            ac[0][0] += x0 * y0;
-            ac[0][1] += x0 * y1;
-            ac[0][2] += x0 * y2;
-            ac[1][0] += x1 * y0;
-            ac[1][1] += x1 * y1;
-            ac[1][2] += x1 * y2;
-            ac[2][0] += x2 * y0;
-            ac[2][1] += x2 * y1;
-            ac[2][2] += x2 * y2;
-          }
+          tile3x3_mac<NU>(aw, [&](int k) { return &Wm[k * (NDX + 1) + i0]; }, [&](int k) { return &Wm[k * (NDX + 1) + j0]; });
+          tile3x3_mac<NG>(ac, [&](int k) { return &Cc[k * NDX + i0]; }, [&](int k) { return &Cc[k * NDX + j0]; });
           double pv[3][3];
 #pragma unroll
           for (int a = 0; a < 3; a++)
