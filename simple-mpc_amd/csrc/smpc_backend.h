@@ -41,12 +41,28 @@
 #define SMPC_PL(type, name, NT) type name
 #define SMPC_PLA(type, name, NT, n) type name[n]
 #define SMPC_PLV(name) name
+// value of a per-lane persistent variable / array element in lane `src` (wave-uniform src): v_readlane pairs, the
+// result lives in SGPRs and feeds VALU FMAs directly -- no LDS round trip, no barrier
+#define SMPC_XLANE(name, src) ::smpc::readlane_f64(name, src)
+#define SMPC_XLANE_A(name, idx, src) ::smpc::readlane_f64(name[idx], src)
 #define SMPC_CLOCK() ((long long)__builtin_readcyclecounter())
 // 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps (full FP64 accuracy, no division)
 #define SMPC_RSQRT(x) ::smpc::rsqrt_nr(x)
 
 namespace smpc
 {
+  __device__ __forceinline__ double readlane_f64(double v, int src)
+  {
+    union
+    {
+      double d;
+      int i[2];
+    } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+    return u.d;
+  }
   __device__ __forceinline__ double rsqrt_nr(double x)
   {
     double y = __builtin_amdgcn_rsq(x);

@@ -23,7 +23,7 @@ namespace smpc
   {
     static constexpr int NDX = D::NDX, NU = D::NU;
     static constexpr int G_W = 0;                            // W = L_R^-1 [S^^T | r^]   NU x (NDX+1)
-    static constexpr int G_LR = G_W + NU * (NDX + 1);        // L_R (lower, row-major, full square) NU x NU
+    static constexpr int G_LR = G_W + NU * (NDX + 1);        // L_R^-1 (lower, row-major, full square) NU x NU
     static constexpr int G_Pt = G_LR + NU * NU;              // P~ NDX x NDX
     static constexpr int G_pn = G_Pt + NDX * NDX;            // p_{t+1}
     static constexpr int STRIDE = ((G_pn + NDX + 7) / 8) * 8;
@@ -90,39 +90,116 @@ namespace smpc
   }
 
   // Forward substitution L y = b for one right-hand side per lane (lane c < ncols), right-looking, the whole
-  // column kept in registers (N doubles): N(N-1)/2 FMAs and as many broadcast LDS reads per lane.  Needs a
-  // register budget of its own: keep no other large per-lane state live across it.
+  // column kept in registers (N doubles): N(N-1)/2 FMAs and as many broadcast LDS reads per lane.  The L
+  // entries are consumed in one linear order (k, i > k); a ring of DPF registers holds the next DPF of them, so
+  // every LDS read is issued DPF FMAs before its use and the footprint stays at N + DPF doubles (VALU operands
+  // must live in the 256 arch VGPRs: anything above that is shuffled through AGPRs by the compiler).
   template <int N, class Get, class Put>
   SMPC_DEV void lane_forward_subst(const double * LT, int ld, const double * invd, int ncols, int lane, Get get, Put put)
   {
+    constexpr int DPF = 12, M = N * (N - 1) / 2;
+    static_assert(M >= DPF, "ring deeper than the work");
     if (lane < ncols)
     {
-      double b[N], l0[N], l1[N];
+      double b[N], ring[DPF];
 #pragma unroll
       for (int i = 0; i < N; i++)
         b[i] = get(i, lane);
+      int pk = 0, pi = 1; // prefetch cursor (compile-time after unrolling)
 #pragma unroll
-      for (int i = 1; i < N; i++)
-        l0[i] = LT[i];
-      // software pipeline: the L row of step k+1 is requested before the FMAs of step k
+      for (int m = 0; m < DPF; m++)
+      {
+        ring[m] = LT[pk * ld + pi];
+        if (++pi == N)
+        {
+          pk++;
+          pi = pk + 1;
+        }
+      }
+      int m = 0;
 #pragma unroll
       for (int k = 0; k < N; k++)
       {
-        double * cur = (k & 1) ? l1 : l0;
-        double * nxt = (k & 1) ? l0 : l1;
-        if (k + 1 < N)
-        {
-#pragma unroll
-          for (int i = k + 2; i < N; i++)
-            nxt[i] = LT[(k + 1) * ld + i];
-        }
         const double xk = b[k] * invd[k];
         put(k, lane, xk);
 #pragma unroll
         for (int i = k + 1; i < N; i++)
-          b[i] -= cur[i] * xk;
+        {
+          const double l = ring[m % DPF];
+          if (m + DPF < M)
+          {
+            ring[m % DPF] = LT[pk * ld + pi];
+            if (++pi == N)
+            {
+              pk++;
+              pi = pk + 1;
+            }
+          }
+          b[i] -= l * xk;
+          m++;
+        }
       }
     }
+  }
+
+  // Cholesky + forward substitution by ONE wave, entirely in registers: lane i keeps row i of the matrix
+  // (N doubles); entries of other lanes' rows are fetched with v_readlane (SMPC_XLANE), so neither the
+  // factorisation nor the substitution touches LDS for L (a broadcast ds_read costs a full LDS pass and the
+  // waves of a CU share one LDS pipe).  On exit of the factor part lane i holds L[i][k] in row[k] (k < i) and
+  // 1 / L[i][i] in row[i].  Then, one right-hand side per lane c < ncols:  y = L^-1 b,  b = get(i, c),  put(i, c, y_i).
+  // getm(i, j): matrix entry (only j <= i is used).
+  template <int N, int NT, class GetM, class Get, class Put>
+  SMPC_DEV void wave_chol_solve(GetM getm, int ncols, Get get, Put put)
+  {
+    SMPC_PLA(double, row, NT, N);
+    SMPC_PL(double, lcur, NT);
+    SMPC_PL(double, rcur, NT);
+    SMPC_LANES(NT)
+    {
+#pragma unroll
+      for (int j = 0; j < N; j++)
+        SMPC_PLV(row)[j] = lane < N ? getm(lane, j) : 0.0;
+    }
+    SMPC_LANES_END_WAVE
+#pragma unroll
+    for (int k = 0; k < N; k++)
+    {
+      SMPC_LANES(NT)
+      {
+        const double d = SMPC_XLANE_A(row, k, k);
+        const double rs = SMPC_RSQRT(d);
+        SMPC_PLV(rcur) = rs;
+        SMPC_PLV(lcur) = SMPC_PLV(row)[k] * rs;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
+        const double l = SMPC_PLV(lcur);
+        SMPC_PLV(row)[k] = lane == k ? SMPC_PLV(rcur) : l;
+#pragma unroll
+        for (int j = k + 1; j < N; j++)
+          SMPC_PLV(row)[j] -= l * SMPC_XLANE(lcur, j);
+      }
+      SMPC_LANES_END_WAVE
+    }
+    SMPC_LANES(NT)
+    if (lane < ncols)
+    {
+      double b[N];
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        b[i] = get(i, lane);
+#pragma unroll
+      for (int k = 0; k < N; k++)
+      {
+        const double xk = b[k] * SMPC_XLANE_A(row, k, k);
+        put(k, lane, xk);
+#pragma unroll
+        for (int i = k + 1; i < N; i++)
+          b[i] -= SMPC_XLANE_A(row, k, i) * xk;
+      }
+    }
+    SMPC_LANES_END_WAVE
   }
 
   // Forward substitution L y = b, one right-hand side per lane (lane c < ncols), right-looking and IN PLACE in
@@ -279,6 +356,7 @@ namespace smpc
     double * PEG = s.scr + NG * NXU;           // [NG][NXU]  (P~ E)[G,:] | (P~ E_b)[G,:]
     double * TG = s.scr + 2 * NG * NXU;        // [NG][NXU]  (P~ A)[G,:] | (P~ B)[G,:]
     double * Sh = s.scr;                       // [NDX][NU]  S^ (written after the products)  phase 5
+    double * Li = s.scr + NDX * NU + NU * (NDX + 1); // [NU][NU] L_R^-1 (streamed out before Cc is written)
     double * Wm = s.scr + NDX * NU;            // [NU][NDX+1]
     double * Cc = s.scr + NDX * NU + NU * (NDX + 1); // [NG][NDX] contact rows                phase 6
 
@@ -328,22 +406,13 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 1, tprev);
-      wave_cholesky_rows<NDX, NT>(Lm, NDX, s.col, s.invd);
-      prof_tick(prof, 2, tprev);
-      // ---- (2) Y = L^-1 [P | pt0] : right-hand sides copied into Y, then substituted in place (register column) ----
-      SMPC_LANES(NT)
-      {
-        for (int idx = lane; idx < NDX * NDX; idx += NT)
-          Ym[(idx / NDX) * (NDX + 1) + idx % NDX] = s.P[idx];
-        if (lane < NDX)
-          Ym[lane * (NDX + 1) + NDX] = s.pt0[lane];
-      }
-      SMPC_LANES_END_WAVE
-      SMPC_LANES(NT)
-      lane_forward_subst<NDX>(
-        Lm, NDX, s.invd, NDX + 1, lane, [&](int i, int c) { return Ym[i * (NDX + 1) + c]; },
+      // ---- (1)+(2) L = chol(I + mu P) ; Y = L^-1 [P | pt0]  (registers + cross-lane reads only) ----
+      wave_chol_solve<NDX, NT>(
+        [&](int i, int j) { return Lm[i * NDX + j]; }, NDX + 1,
+        [&](int i, int c) { return c < NDX ? s.P[i * NDX + c] : s.pt0[i]; },
         [&](int i, int c, double v) { Ym[i * (NDX + 1) + c] = v; });
-      SMPC_LANES_END_WAVE
+      prof_tick(prof, 2, tprev);
+      prof_tick(prof, 3, tprev);
       // ---- (2b) register prefetch of the dense rows of [A|B], the contact rows of C and the stage vectors;
       //           the latency overlaps with the P~ product ----
       SMPC_LANES(NT)
@@ -634,39 +703,33 @@ namespace smpc
       SMPC_LANES_END_WAVE
       prof_tick(prof, 9, tprev);
       // ---- (5) L_R = chol(R^) ; W = L_R^-1 [S^^T | r^] ----
-      wave_cholesky_rows<NU, NT>(s.Rh, NU, s.col, s.invdR);
+      // columns 0..NDX of the right-hand sides: [S^^T | r^] -> W ; columns NDX+1..NDX+NU: identity -> L_R^-1 on the
+      // otherwise idle lanes (the forward sweep then needs one product, not a 24-step back substitution).
+      // L_R^-1 lands in the block Cc takes over afterwards.  Loads / stores are address-selected, not branched.
+      wave_chol_solve<NU, NT>(
+        [&](int i, int j) { return s.Rh[i * NU + j]; }, NDX + 1 + NU,
+        [&](int i, int c) {
+          const double * src = c < NDX ? &Sh[c * NU + i] : &s.rh[i];
+          const double v = *src;
+          return c <= NDX ? v : (i == c - NDX - 1 ? 1.0 : 0.0);
+        },
+        [&](int i, int c, double v) {
+          double * dst = c <= NDX ? &Wm[i * (NDX + 1) + c] : &Li[i * NU + c - NDX - 1];
+          *dst = v;
+        });
       prof_tick(prof, 10, tprev);
-      // right-hand sides [S^^T | r^] into W (S^ lives in Sh, a different part of the scratch)
-      SMPC_LANES(NT)
-      {
-        for (int idx = lane; idx < NU * NDX; idx += NT)
-        {
-          const int i = idx / NDX, c = idx % NDX;
-          Wm[i * (NDX + 1) + c] = Sh[c * NU + i];
-        }
-        if (lane < NU)
-          Wm[lane * (NDX + 1) + NDX] = s.rh[lane];
-      }
-      SMPC_LANES_END_WAVE
-      SMPC_LANES(NT)
-      {
-        lane_forward_subst<NU>(
-          s.Rh, NU, s.invdR, NDX + 1, lane, [&](int i, int c) { return Wm[i * (NDX + 1) + c]; },
-          [&](int i, int c, double v) { Wm[i * (NDX + 1) + c] = v; });
-        // L_R out (lower triangle incl. diagonal; the forward sweep reads only that part)
-        for (int idx = lane; idx < NU * NU; idx += NT)
-        {
-          const int r = idx / NU, c = idx % NU;
-          g[GK::G_LR + idx] = c <= r ? s.Rh[c * NU + r] : 0.0; // L_R[r][c] = LT[c][r]
-        }
-      }
-      SMPC_LANES_END_WAVE
       prof_tick(prof, 11, tprev);
       // contact rows of C, box activity, d  (S^ is dead: Cc overlays it)
       SMPC_LANES(NT)
       {
         for (int idx = lane; idx < NU * (NDX + 1); idx += NT)
           g[GK::G_W + idx] = Wm[idx];
+        for (int idx = lane; idx < NU * NU; idx += NT)
+          g[GK::G_LR + idx] = Li[idx];
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
 #pragma unroll
         for (int n = 0; n < CC_PL; n++)
         {
@@ -741,116 +804,190 @@ namespace smpc
 
   // =============================================================================================
   // forward_kino_body: grid = B, 64 lanes.  Forward sweep with the factored feedback + merit derivative.
+  // The blocks a stage needs (W, L_R^-1, P~, p+, dense rows of [A|B], contact rows of C, vectors) are contiguous
+  // chunks of the gains / LQ blocks: they are fetched with coalesced loads into registers one stage AHEAD (the
+  // loads fly while the current stage computes from LDS) and committed to LDS at the stage boundary.
   // =============================================================================================
+  template <class D>
+  struct ForwardKinoLds
+  {
+    static constexpr int NDX = D::NDX, NU = D::NU, NG = 12;
+    static constexpr int N_G = GainsK<D>::G_pn + NDX;                        // W | L_R^-1 | P~ | p+
+    static constexpr int N_A = 6 * NDX, N_B = 6 * NU, N_C = NG * NDX;        // row groups qb / vb of A, B; contact rows of C
+    static constexpr int N_V = D::O_vpd + D::NC - D::O_f;                    // f d lx lu lpd vpd
+    static constexpr int O_A0 = N_G, O_A1 = O_A0 + N_A, O_B0 = O_A1 + N_A, O_B1 = O_B0 + N_B, O_Cc = O_B1 + N_B,
+                         O_V = O_Cc + N_C, O_box = O_V + N_V, N_STAGE = O_box + D::NA;
+    static constexpr int PER_LANE = (N_STAGE + 63) / 64;
+    double st[PER_LANE * 64];
+    double dx[NDX], du[NU], z[NU], y[NDX], part[64], lpd_prev[NDX];
+  };
+
   template <class D>
   SMPC_DEV void forward_kino_body(const SolverArgs<D> & ka, int block)
   {
     constexpr int NT = 64;
-    constexpr int NDX = D::NDX, NU = D::NU, NC = D::NC;
+    constexpr int NDX = D::NDX, NU = D::NU, NC = D::NC, NV = D::NV, NA = D::NA, NF = D::NF;
     typedef GainsK<D> GK;
+    typedef KinoIdx<D> IX;
+    typedef ForwardKinoLds<D> FL;
+    static_assert(GK::G_W == 0 && GK::G_pn + NDX == FL::N_G, "gains chunk must be contiguous");
+    static_assert(D::O_d == D::O_f + NDX && D::O_lx == D::O_d + NC && D::O_lu == D::O_lx + NDX && D::O_lpd == D::O_lu + NU &&
+                    D::O_vpd == D::O_lpd + NDX,
+                  "vector chunk must be contiguous");
+    constexpr int PER = FL::PER_LANE;
     const Buffers<D> & b = ka.b;
     const int H = b.H, R = b.R;
     const int inst = block;
-    const double mu = b.model->mu;
-    SMPC_LDS(double, dx, D::NDX);
-    SMPC_LDS(double, du, D::NU);
-    SMPC_LDS(double, z, D::NU);
-    SMPC_LDS(double, y, D::NDX);
-    SMPC_LDS(double, part, 64);
-    SMPC_LDS(double, lpd_prev, D::NDX);
+    const double mu = b.model->mu, dt = b.model->dt;
+    SMPC_LDS(FL, lds, 1);
+    FL & s = lds[0];
+    SMPC_PLA(double, pf, NT, PER);
+    // fetch stage t into the per-lane registers (flat staging index -> source chunk)
+    auto fetch = [&](int lane, double * r, int t) {
+      const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
+      const double * g = b.gains + ((size_t)inst * H + t) * GK::STRIDE;
+#pragma unroll
+      for (int n = 0; n < PER; n++)
+      {
+        const int idx = lane + n * NT;
+        const double * src;
+        if (idx < FL::O_A0)
+          src = g + idx;
+        else if (idx < FL::O_A1)
+          src = lq + D::O_A + (idx - FL::O_A0);
+        else if (idx < FL::O_B0)
+          src = lq + D::O_A + NV * NDX + (idx - FL::O_A1);
+        else if (idx < FL::O_B1)
+          src = lq + D::O_B + (idx - FL::O_B0);
+        else if (idx < FL::O_Cc)
+          src = lq + D::O_B + NV * NU + (idx - FL::O_B1);
+        else if (idx < FL::O_V)
+          src = lq + D::O_C + NA * NDX + (idx - FL::O_Cc);
+        else if (idx < FL::O_box)
+          src = lq + D::O_f + (idx - FL::O_V);
+        else
+          src = lq + D::O_C + (idx - FL::O_box) * (NDX + 1) + 6;
+        r[n] = idx < FL::N_STAGE ? *src : 0.0;
+      }
+    };
     SMPC_LANES(NT)
     {
       if (lane < NDX)
       {
-        dx[lane] = 0.0;
-        lpd_prev[lane] = 0.0;
+        s.dx[lane] = 0.0;
+        s.lpd_prev[lane] = 0.0;
         b.dxs[((size_t)inst * (H + 1)) * NDX + lane] = 0.0;
       }
-      part[lane] = 0.0;
+      s.part[lane] = 0.0;
+      fetch(lane, SMPC_PLV(pf), 0);
     }
     SMPC_LANES_END_WAVE
+    const double * W = s.st + GK::G_W;
+    const double * Li = s.st + GK::G_LR;
+    const double * Pt = s.st + GK::G_Pt;
+    const double * pn = s.st + GK::G_pn;
+    const double * vf = s.st + FL::O_V;
+    const double *vd = vf + NDX, *vlx = vd + NC, *vlu = vlx + NDX, *vlpd = vlu + NU, *vvpd = vlpd + NDX;
+    const double * boxact = s.st + FL::O_box;
     for (int t = 0; t < H; t++)
     {
-      const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
-      const double * g = b.gains + ((size_t)inst * H + t) * GK::STRIDE;
       const size_t lt = (size_t)inst * H + t;
-      // z = W_x dx + w ; dnu = (C dx + d)/mu
+      // commit stage t to LDS, start fetching stage t+1
+      SMPC_LANES(NT)
+      {
+#pragma unroll
+        for (int n = 0; n < PER; n++)
+          s.st[lane + n * NT] = SMPC_PLV(pf)[n];
+        if (t + 1 < H)
+          fetch(lane, SMPC_PLV(pf), t + 1);
+      }
+      SMPC_LANES_END_WAVE
+      // ---- z = W_x dx + w ; dnu = (C dx + d)/mu ----
       SMPC_LANES(NT)
       {
         if (lane < NU)
         {
-          const double * Wr = g + GK::G_W + lane * (NDX + 1);
+          const double * Wr = &W[lane * (NDX + 1)];
           double acc = Wr[NDX];
 #pragma unroll 4
           for (int j = 0; j < NDX; j++)
-            acc += Wr[j] * dx[j];
-          z[lane] = acc;
+            acc += Wr[j] * s.dx[j];
+          s.z[lane] = acc;
         }
         else if (lane < NU + NC)
         {
           const int r = lane - NU;
-          const double * Cr = lq + D::O_C + r * NDX;
-          double acc = lq[D::O_d + r];
+          double acc = vd[r];
+          if (r < NA)
+            acc += boxact[r] * s.dx[6 + r];
+          else
+          {
+            const double * Cr = &s.st[FL::O_Cc + (r - NA) * NDX];
 #pragma unroll 4
-          for (int j = 0; j < NDX; j++)
-            acc += Cr[j] * dx[j];
+            for (int j = 0; j < NDX; j++)
+              acc += Cr[j] * s.dx[j];
+          }
           const double dnu = acc / mu;
           b.dvs[lt * NC + r] = dnu;
-          part[lane] += lq[D::O_vpd + r] * (mu * dnu - lq[D::O_d + r]) - lq[D::O_d + r] * dnu;
+          s.part[lane] += vvpd[r] * (mu * dnu - vd[r]) - vd[r] * dnu;
         }
       }
       SMPC_LANES_END_WAVE
-      // du = -L_R^-T z : back substitution, lane i owns du_i; the wave resolves one unknown per step
-      for (int k = NU - 1; k >= 0; k--)
-      {
-        SMPC_LANES(NT)
-        if (lane == k)
-        {
-          const double * LRk = g + GK::G_LR + k * NU;
-          const double v = -z[k] / LRk[k];
-          du[k] = v;
-          b.dus[lt * NU + k] = v;
-          part[k] += lq[D::O_lu + k] * v;
-        }
-        SMPC_LANES_END_WAVE
-        SMPC_LANES(NT)
-        if (lane < k)
-          z[lane] += g[GK::G_LR + k * NU + lane] * du[k]; // z_i -= L[k][i] * (-du_k) ... sign folded: L^T du = -z
-        SMPC_LANES_END_WAVE
-      }
-      // y = A dx + B du + f - mu p_{t+1}
+      // ---- du = -(L_R^-1)^T z ----
       SMPC_LANES(NT)
-      if (lane < NDX)
+      if (lane < NU)
       {
-        const double * Ar = lq + D::O_A + lane * NDX;
-        const double * Br = lq + D::O_B + lane * NU;
         double acc = 0.0;
 #pragma unroll 4
-        for (int j = 0; j < NDX; j++)
-          acc += Ar[j] * dx[j];
-#pragma unroll 4
-        for (int j = 0; j < NU; j++)
-          acc += Br[j] * du[j];
-        const double fi = lq[D::O_f + lane], pn = g[GK::G_pn + lane];
-        part[lane] += (lq[D::O_lx + lane] - lpd_prev[lane]) * dx[lane] + lq[D::O_lpd + lane] * acc;
-        y[lane] = acc + fi - mu * pn;
+        for (int i = 0; i < NU; i++)
+          acc += Li[i * NU + lane] * s.z[i]; // upper part of L_R^-1 is stored as exact zeros
+        const double v = -acc;
+        s.du[lane] = v;
+        b.dus[lt * NU + lane] = v;
+        s.part[lane] += vlu[lane] * v;
       }
       SMPC_LANES_END_WAVE
+      // ---- y = A dx + B du + f - mu p_{t+1}  (dense rows G; unit rows by structure) ----
       SMPC_LANES(NT)
       if (lane < NDX)
       {
-        const double * Pr = g + GK::G_Pt + lane * NDX;
+        const int i = lane;
+        double acc;
+        if (IX::isG(i))
+        {
+          const double * Ar = &s.st[(i < 6 ? FL::O_A0 + i * NDX : FL::O_A1 + (i - NV) * NDX)];
+          const double * Br = &s.st[(i < 6 ? FL::O_B0 + i * NU : FL::O_B1 + (i - NV) * NU)];
+          acc = 0.0;
+#pragma unroll 4
+          for (int j = 0; j < NDX; j++)
+            acc += Ar[j] * s.dx[j];
+#pragma unroll 4
+          for (int j = 0; j < NU; j++)
+            acc += Br[j] * s.du[j];
+        }
+        else if (IX::isQj(i))
+          acc = s.dx[i] + dt * s.dx[i + NV] + dt * dt * s.du[3 * NF + i - 6];
+        else
+          acc = s.dx[i] + dt * s.du[3 * NF + i - NV - 6];
+        s.part[lane] += (vlx[lane] - s.lpd_prev[lane]) * s.dx[lane] + vlpd[lane] * acc;
+        s.y[lane] = acc + vf[lane] - mu * pn[lane];
+      }
+      SMPC_LANES_END_WAVE
+      // ---- w = P~ y (P~ symmetric: column reads are conflict-free) ; dx+ = y - mu w ; dlam+ = w + p_{t+1} ----
+      SMPC_LANES(NT)
+      if (lane < NDX)
+      {
         double w = 0.0;
 #pragma unroll 4
         for (int j = 0; j < NDX; j++)
-          w += Pr[j] * y[j];
-        const double dxn = y[lane] - mu * w;
-        const double dl = w + g[GK::G_pn + lane];
+          w += Pt[j * NDX + lane] * s.y[j];
+        const double dxn = s.y[lane] - mu * w;
+        const double dl = w + pn[lane];
         b.dxs[((size_t)inst * (H + 1) + t + 1) * NDX + lane] = dxn;
         b.dlams[lt * NDX + lane] = dl;
-        part[lane] -= lq[D::O_f + lane] * dl;
-        lpd_prev[lane] = lq[D::O_lpd + lane];
-        dx[lane] = dxn;
+        s.part[lane] -= vf[lane] * dl;
+        s.lpd_prev[lane] = vlpd[lane];
+        s.dx[lane] = dxn;
       }
       SMPC_LANES_END_WAVE
     }
@@ -860,7 +997,7 @@ namespace smpc
       const int sl = ring_slot(ka.head, H - 1, R);
       const double lamH = b.lams[((size_t)inst * R + sl) * NDX + lane];
       const double lxN = b.qN[(size_t)inst * NDX + lane] + lamH;
-      part[lane] += (lxN - lpd_prev[lane]) * dx[lane];
+      s.part[lane] += (lxN - s.lpd_prev[lane]) * s.dx[lane];
     }
     SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
@@ -868,14 +1005,14 @@ namespace smpc
     {
       double sacc = 0.0;
       for (int i = 0; i < 64; i++)
-        sacc += part[i];
+        sacc += s.part[i];
       b.scal[(size_t)inst * SC_N + SC_DPHI0] = sacc;
       b.ls_sel[inst] = -1;
     }
     SMPC_LANES_END_WAVE
   }
 
-  // K_t = -L_R^-T W_x for (instance, stage) blocks: grid = B * nt, 64 lanes (lane = column of K)
+  // K_t = -(L_R^-1)^T W_x for (instance, stage) blocks: grid = B * nt, 64 lanes (lane = column of K)
   template <class D>
   struct GainOutArgs
   {
@@ -900,15 +1037,13 @@ namespace smpc
 #pragma unroll
       for (int i = 0; i < NU; i++)
         x[i] = g[GK::G_W + i * (NDX + 1) + lane];
-#pragma unroll
-      for (int i = NU - 1; i >= 0; i--)
+      for (int i = 0; i < NU; i++)
       {
-        double sacc = x[i];
+        double sacc = 0.0; // K = -(L_R^-1)^T W_x
 #pragma unroll
-        for (int k = i + 1; k < NU; k++)
-          sacc -= g[GK::G_LR + k * NU + i] * x[k];
-        x[i] = sacc / g[GK::G_LR + i * NU + i];
-        out[i * NDX + lane] = -x[i];
+        for (int k = 0; k < NU; k++)
+          sacc += (k >= i) ? g[GK::G_LR + k * NU + i] * x[k] : 0.0;
+        out[i * NDX + lane] = -sacc;
       }
     }
     SMPC_LANES_END_WAVE
