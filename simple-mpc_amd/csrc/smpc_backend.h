@@ -22,9 +22,14 @@
 #define SMPC_DEV __device__ __forceinline__
 #define SMPC_DEV_NOINLINE __device__ __noinline__
 #define SMPC_LDS(type, name, n) __shared__ type name[n]
+// The lane index is re-materialised through an opaque asm in every phase: otherwise the compiler hoists the index
+// arithmetic of ALL phases out of the stage loops (hundreds of loop-invariant values), spills them to scratch,
+// and every scratch access then drains the outstanding global prefetches (shared vmcnt).
 #define SMPC_LANES(NT)                                                                                                 \
   {                                                                                                                    \
-    const int lane = (int)threadIdx.x;                                                                                 \
+    int _smpc_lane = (int)threadIdx.x;                                                                                 \
+    asm volatile("" : "+v"(_smpc_lane));                                                                               \
+    const int lane = _smpc_lane;                                                                                       \
     (void)lane;
 #define SMPC_LANES_END                                                                                                 \
   }                                                                                                                    \
@@ -45,12 +50,20 @@
 // result lives in SGPRs and feeds VALU FMAs directly -- no LDS round trip, no barrier
 #define SMPC_XLANE(name, src) ::smpc::readlane_f64(name, src)
 #define SMPC_XLANE_A(name, idx, src) ::smpc::readlane_f64(name[idx], src)
+// FP64 matrix cores (v_mfma_f64_16x16x4_f64), one wave:  D(16x16) += A(16x4) B(4x16).
+//   operands, one double per lane:   A[i][k] in lane i + 16 k ,  B[k][j] in lane j + 16 k
+//   accumulator tile t, 4 doubles per lane:   D[(lane >> 4) + 4 v][lane & 15]  in  SMPC_ACCV(acc, t, v)
+// (lane maps verified on hardware by tools/micro/mfma_f64_layout.hip).  av / bv are SMPC_PLA operand arrays.
+#define SMPC_ACC(name, NT, n) ::smpc::d4 name[n]
+#define SMPC_ACCV(name, t, v) name[t][v]
+#define SMPC_MFMA(acc, t, av, ia, bv, ib) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ia], bv[ib], acc[t], 0, 0, 0)
 #define SMPC_CLOCK() ((long long)__builtin_readcyclecounter())
 // 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps (full FP64 accuracy, no division)
 #define SMPC_RSQRT(x) ::smpc::rsqrt_nr(x)
 
 namespace smpc
 {
+  typedef double d4 __attribute__((ext_vector_type(4)));
   __device__ __forceinline__ double readlane_f64(double v, int src)
   {
     union

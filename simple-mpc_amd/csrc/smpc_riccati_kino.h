@@ -350,7 +350,6 @@ namespace smpc
     const double mu = b.model->mu, imu = 1.0 / mu, dt = b.model->dt;
     SMPC_LDS(RiccatiKinoLds<D>, lds, 1);
     RiccatiKinoLds<D> & s = lds[0];
-    double * Lm = s.scr;                       // [NDX][NDX]    phase 1-3
     double * Ym = s.scr + NDX * NDX;           // [NDX][NDX+1]  phase 2-3
     double * NAB = s.scr;                      // [NG][NXU]  dense rows of [A | B]           phase 4
     double * PEG = s.scr + NG * NXU;           // [NG][NXU]  (P~ E)[G,:] | (P~ E_b)[G,:]
@@ -375,23 +374,22 @@ namespace smpc
     {
       const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
       double * g = b.gains + ((size_t)inst * H + t) * GK::STRIDE;
-      // per-lane prefetch registers (filled right after the first factorisation, consumed in phases 4-6)
-      SMPC_PLA(double, qs_acc, NT, 4 * 9); // [Q|S] entries of this lane's (up to 4) 3x3 tiles, later [Q^|S^]
-      SMPC_PLA(double, r_acc, NT, 9);      // R entries of this lane's tile, later R^
+      // matrix-core tile bookkeeping: upper tiles (I <= J) of the 16-padded 48x48 (P) and 64x64 (H^) grids
+      constexpr int T3I[6] = {0, 0, 0, 1, 1, 2}, T3J[6] = {0, 1, 2, 1, 2, 2};
+      constexpr int T4I[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, T4J[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+      constexpr int QT[6] = {0, 1, 2, 4, 5, 7}; // the T4 tiles that hold Q^ (rows, cols < NDX)
+      // per-lane registers that live across phases
+      SMPC_ACC(hacc, NT, 10); // H^ = [Q S; S^T R] + [A|B]^T P~ [A|B], upper tiles; later P_t in the QT tiles
       constexpr int NAB_PL = (NG * NXU + NT - 1) / NT, CC_PL = (NG * NDX + NT - 1) / NT;
       SMPC_PLA(double, nab_pf, NT, NAB_PL);
       SMPC_PLA(double, cc_pf, NT, CC_PL);
       SMPC_PLA(double, vec_pf, NT, 4);
-      // ---- (1) M = I + mu P ; f ; save p_{t+1} ----
+      // ---- (1) f ; save p_{t+1} ; pt0 = p + P f ----
       SMPC_LANES(NT)
+      if (lane < NDX)
       {
-        for (int idx = lane; idx < NDX * NDX; idx += NT)
-          Lm[idx] = mu * s.P[idx] + ((idx / NDX) == (idx % NDX) ? 1.0 : 0.0);
-        if (lane < NDX)
-        {
-          s.f[lane] = lq[D::O_f + lane];
-          g[GK::G_pn + lane] = s.p[lane];
-        }
+        s.f[lane] = lq[D::O_f + lane];
+        g[GK::G_pn + lane] = s.p[lane];
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 0, tprev);
@@ -406,13 +404,12 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 1, tprev);
-      // ---- (1)+(2) L = chol(I + mu P) ; Y = L^-1 [P | pt0]  (registers + cross-lane reads only) ----
+      // ---- (2) L = chol(I + mu P) ; Y = L^-1 [P | pt0]  (registers + cross-lane reads only) ----
       wave_chol_solve<NDX, NT>(
-        [&](int i, int j) { return Lm[i * NDX + j]; }, NDX + 1,
+        [&](int i, int j) { return mu * s.P[i * NDX + j] + (i == j ? 1.0 : 0.0); }, NDX + 1,
         [&](int i, int c) { return c < NDX ? s.P[i * NDX + c] : s.pt0[i]; },
         [&](int i, int c, double v) { Ym[i * (NDX + 1) + c] = v; });
       prof_tick(prof, 2, tprev);
-      prof_tick(prof, 3, tprev);
       // ---- (2b) register prefetch of the dense rows of [A|B], the contact rows of C and the stage vectors;
       //           the latency overlaps with the P~ product ----
       SMPC_LANES(NT)
@@ -438,66 +435,76 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 3, tprev);
-      // ---- (3) P~ = P - mu Y^T Y (lower tiles, mirrored) ----
-      SMPC_LANES(NT)
+      // ---- (3) P~ = P - mu Y^T Y on the matrix cores: 6 upper tiles, K = NDX.  The A operand of tile row I and
+      //          the B operand of tile column I are the same value: Y[4 ks + (lane >> 4)][16 I + (lane & 15)] ----
       {
-        constexpr int TJ = NDX / 3, NLOW = TJ * (TJ + 1) / 2;
-        for (int n = lane; n < NLOW; n += NT)
+        constexpr int KS = NDX / 4;
+        SMPC_ACC(pacc, NT, 6);
+        SMPC_PLA(double, yv, NT, 3 * KS);
+        SMPC_LANES(NT)
         {
-          int ti, tj;
-          lower_tile(n, ti, tj);
-          const int i0 = ti * 3, j0 = tj * 3;
-          double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-          tile3x3_mac<NDX>(acc, [&](int k) { return &Ym[k * (NDX + 1) + i0]; }, [&](int k) { return &Ym[k * (NDX + 1) + j0]; });
-          // batch the symmetrising reads, then write (off-diagonal tiles: all 9 + mirror; diagonal: lower part)
-          double pv[3][3];
+          const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-          for (int a = 0; a < 3; a++)
+          for (int tt = 0; tt < 6; tt++)
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-              pv[a][c] = 0.5 * (s.P[(i0 + a) * NDX + j0 + c] + s.P[(j0 + c) * NDX + i0 + a]) - mu * acc[a][c];
+            for (int v = 0; v < 4; v++)
+              SMPC_ACCV(pacc, tt, v) = 0.0;
 #pragma unroll
-          for (int a = 0; a < 3; a++)
+          for (int ks = 0; ks < KS; ks++)
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-              if (ti != tj || c <= a)
-              {
-                s.P[(i0 + a) * NDX + j0 + c] = pv[a][c];
-                s.P[(j0 + c) * NDX + i0 + a] = pv[a][c];
-              }
-        }
-      }
-      SMPC_LANES_END_WAVE
-      prof_tick(prof, 4, tprev);
-      // ---- (3b) register prefetch of this lane's [Q|S] and R tile entries: the HBM/L2 latency overlaps with
-      //           the P~ E passes and the TG product below ----
-      SMPC_LANES(NT)
-      {
-        constexpr int TJ = NXU / 3, NTILES = (NDX / 3) * TJ;
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-        {
-          const int tile = lane + rr * NT;
-          const int i0 = tile < NTILES ? (tile / TJ) * 3 : 0, j0 = tile < NTILES ? (tile % TJ) * 3 : 0;
-#pragma unroll
-          for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int c = 0; c < 3; c++)
+            for (int I = 0; I < 3; I++)
             {
-              const int i = i0 + a, j = j0 + c;
-              SMPC_PLV(qs_acc)[rr * 9 + a * 3 + c] = j < NDX ? lq[D::O_Q + i * NDX + j] : lq[D::O_S + i * NU + j - NDX];
+              const int col = 16 * I + lc;
+              const double v = Ym[(4 * ks + lr) * (NDX + 1) + (col < NDX ? col : NDX)];
+              SMPC_PLV(yv)[ks * 3 + I] = col < NDX ? v : 0.0;
             }
         }
+        SMPC_LANES_END_WAVE
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+          for (int tt = 0; tt < 6; tt++)
+            SMPC_MFMA(pacc, tt, yv, ks * 3 + T3I[tt], yv, ks * 3 + T3J[tt]);
+        SMPC_LANES(NT)
         {
-          constexpr int TR = NU / 3;
-          const int tl = lane < TR * TR ? lane : 0;
-          const int i0 = (tl / TR) * 3, j0 = (tl % TR) * 3;
+          const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-          for (int a = 0; a < 3; a++)
+          for (int tt = 0; tt < 6; tt++)
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-              SMPC_PLV(r_acc)[a * 3 + c] = lq[D::O_R + (i0 + a) * NU + j0 + c];
+            for (int v = 0; v < 4; v++)
+            {
+              const int row = 16 * T3I[tt] + lr + 4 * v, col = 16 * T3J[tt] + lc;
+              if (col < NDX && row <= col) // row <= col < NDX ; diagonal tiles: upper part only
+              {
+                const double pv = 0.5 * (s.P[row * NDX + col] + s.P[col * NDX + row]) - mu * SMPC_ACCV(pacc, tt, v);
+                s.P[row * NDX + col] = pv;
+                s.P[col * NDX + row] = pv;
+              }
+            }
         }
+        SMPC_LANES_END_WAVE
+      }
+      prof_tick(prof, 4, tprev);
+      // ---- (3b) register prefetch of [Q S; S^T R] in accumulator-tile layout (element (row, col) of tile (I, J):
+      //           row = 16 I + (lane >> 4) + 4 v, col = 16 J + (lane & 15)); the HBM/L2 latency overlaps with the
+      //           P~ E passes and the TG product below ----
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int tt = 0; tt < 10; tt++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            const int row = 16 * T4I[tt] + lr + 4 * v, col = 16 * T4J[tt] + lc;
+            const int r0 = row < col ? row : col, c0 = row < col ? col : row;
+            const bool valid = c0 < NXU;
+            const int r = valid ? r0 : 0, c = valid ? c0 : 0;
+            const double * src = c < NDX ? lq + D::O_Q + r * NDX + c
+                                         : (r < NDX ? lq + D::O_S + r * NU + c - NDX : lq + D::O_R + (r - NDX) * NU + c - NDX);
+            const double val = *src;
+            SMPC_ACCV(hacc, tt, v) = valid ? val : 0.0;
+          }
       }
       SMPC_LANES_END_WAVE
       // p~ = pt0 - mu P~ pt0 ; stream P~ out ; load the dense rows of [A|B]
@@ -532,7 +539,6 @@ namespace smpc
         s.P[i * NDX + NV + 6 + jp] += dt * s.P[i * NDX + 6 + jp];
       }
       SMPC_LANES_END_WAVE
-      prof_tick(prof, 6, tprev);
       // ---- (4b) PEG = [(P~ E)[G,:] | (P~ E_b)[G,:]]  (zero in the G / force columns) ----
       SMPC_LANES(NT)
       for (int idx = lane; idx < NG * NXU; idx += NT)
@@ -550,155 +556,163 @@ namespace smpc
         PEG[idx] = v;
       }
       SMPC_LANES_END_WAVE
-      // ---- (4c) TG = P~[G,G] * NAB + PEG ;  row pass, in place: P[vj, :] += dt P[qj, :]  (P[J,J] = E^T P~ E) ----
-      SMPC_LANES(NT)
+      prof_tick(prof, 6, tprev);
+      // ---- (4c) TG = P~[G,G] * NAB + PEG on the matrix cores (M = NG padded to 16, N = NXU padded to 64, K = NG) ----
       {
-        for (int idx = lane; idx < NG * NXU; idx += NT)
+        constexpr int KS = NG / 4;
+        SMPC_ACC(tacc, NT, 4);
+        SMPC_PLA(double, pgv, NT, KS);
+        SMPC_PLA(double, nbv, NT, KS * 4);
+        SMPC_LANES(NT)
         {
-          const int gi = idx / NXU, j = idx % NXU;
-          const double * pg = &s.P[IX::G(gi) * NDX];
-          double acc = PEG[idx];
+          const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-          for (int h = 0; h < NG; h++)
-            acc += pg[IX::G(h)] * NAB[h * NXU + j];
-          TG[idx] = acc;
+          for (int J = 0; J < 4; J++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+            {
+              const int row = lr + 4 * v, col = 16 * J + lc;
+              const bool valid = row < NG && col < NXU;
+              const double pv = PEG[(valid ? row : 0) * NXU + (valid ? col : 0)];
+              SMPC_ACCV(tacc, J, v) = valid ? pv : 0.0;
+            }
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++)
+          {
+            const double pv = s.P[IX::G(lc < NG ? lc : 0) * NDX + IX::G(4 * ks + lr)];
+            SMPC_PLV(pgv)[ks] = lc < NG ? pv : 0.0;
+#pragma unroll
+            for (int J = 0; J < 4; J++)
+            {
+              const int col = 16 * J + lc;
+              const double nv = NAB[(4 * ks + lr) * NXU + (col < NXU ? col : 0)];
+              SMPC_PLV(nbv)[ks * 4 + J] = col < NXU ? nv : 0.0;
+            }
+          }
         }
-        for (int idx = lane; idx < NA * NDX; idx += NT)
+        SMPC_LANES_END_WAVE
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+          for (int J = 0; J < 4; J++)
+            SMPC_MFMA(tacc, J, pgv, ks, nbv, ks * 4 + J);
+        // TG out ; row pass, in place: P[vj, :] += dt P[qj, :]  (P[J,J] = E^T P~ E)
+        SMPC_LANES(NT)
         {
-          const int ip = idx / NDX, j = idx % NDX;
-          s.P[(NV + 6 + ip) * NDX + j] += dt * s.P[(6 + ip) * NDX + j];
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int J = 0; J < 4; J++)
+#pragma unroll
+            for (int v = 0; v < 3; v++) // rows lr + 4 v < NG = 12
+            {
+              const int row = lr + 4 * v, col = 16 * J + lc;
+              if (col < NXU)
+                TG[row * NXU + col] = SMPC_ACCV(tacc, J, v);
+            }
+          for (int idx = lane; idx < NA * NDX; idx += NT)
+          {
+            const int ip = idx / NDX, j = idx % NDX;
+            s.P[(NV + 6 + ip) * NDX + j] += dt * s.P[(6 + ip) * NDX + j];
+          }
         }
+        SMPC_LANES_END_WAVE
       }
-      SMPC_LANES_END_WAVE
       prof_tick(prof, 7, tprev);
-      // ---- (4d) [Q^|S^] , R^ , q^ , r^ : products with K = 2 NG over X = [NA ; PEG_x], Y = [TG ; NAB] ----
-      // results stay in registers (all tiles of a lane) and are written back after the phase barrier
-      SMPC_LANES(NT)
+      // ---- (4d) H^ += E^T P~ [E|E_b] (structured) + NAB^T TG + PEG^T NAB  (matrix cores, K = 2 NG) ; q^ , r^ ----
       {
-        constexpr int TJ = NXU / 3, NTILES = (NDX / 3) * TJ; // 12 x 20 = 240
-        static_assert(NTILES <= 4 * NT, "tile storage");
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++)
+        constexpr int KS = NG / 4;
+        SMPC_PLA(double, nav, NT, KS * 4);
+        SMPC_PLA(double, tgv, NT, KS * 4);
+        SMPC_PLA(double, pev, NT, KS * 4);
+        SMPC_LANES(NT)
         {
-          const int tile = lane + rr * NT;
-          if (tile < NTILES)
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+            for (int J = 0; J < 4; J++)
+            {
+              const int col = 16 * J + lc, off = (4 * ks + lr) * NXU + (col < NXU ? col : 0);
+              const double a0 = NAB[off], a1 = TG[off], a2 = PEG[off];
+              SMPC_PLV(nav)[ks * 4 + J] = col < NXU ? a0 : 0.0;
+              SMPC_PLV(tgv)[ks * 4 + J] = col < NXU ? a1 : 0.0;
+              SMPC_PLV(pev)[ks * 4 + J] = col < NXU ? a2 : 0.0;
+            }
+          // structured term: index m of [x | u] -> (column of P, scale): x: (m, 0 on G rows else 1); u: joint accelerations
+          // map to the vj columns with scale dt, forces to nothing
+#pragma unroll
+          for (int tt = 0; tt < 10; tt++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+            {
+              const int row = 16 * T4I[tt] + lr + 4 * v, col = 16 * T4J[tt] + lc;
+              const int r = row < col ? row : col, c = row < col ? col : row;
+              const int ar = r - NDX - 3 * NF, ac = c - NDX - 3 * NF;
+              const int pr = r < NDX ? r : (ar >= 0 && r < NXU ? NV + 6 + ar : 0);
+              const int pc = c < NDX ? c : (ac >= 0 && c < NXU ? NV + 6 + ac : 0);
+              const double sr = r < NDX ? (IX::isG(r) ? 0.0 : 1.0) : (ar >= 0 && r < NXU ? dt : 0.0);
+              const double sc = c < NDX ? (IX::isG(c) ? 0.0 : 1.0) : (ac >= 0 && c < NXU ? dt : 0.0);
+              SMPC_ACCV(hacc, tt, v) += sr * sc * s.P[pr * NDX + pc];
+            }
+          // q^ = q + A^T p~ ; r^ = r + B^T p~
+          if (lane < NXU)
           {
-            const int i0 = (tile / TJ) * 3, j0 = (tile % TJ) * 3;
-            double acc[3][3];
-            // init: [Q|S] (prefetched) + E^T P~ [E|E_b]
+            const int j = lane;
+            double acc = SMPC_PLV(vec_pf)[0];
+            if (j < NDX)
+            {
+              if (IX::isQj(j))
+                acc += s.pt[j];
+              else if (IX::isVj(j))
+                acc += dt * s.pt[j - NV] + s.pt[j];
+            }
+            else if (j - NDX >= 3 * NF)
+            {
+              const int ip = j - NDX - 3 * NF;
+              acc += dt * dt * s.pt[6 + ip] + dt * s.pt[NV + 6 + ip];
+            }
 #pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-              for (int c = 0; c < 3; c++)
-              {
-                const int i = i0 + a, j = j0 + c;
-                // + (E^T P~ [E | E_b])[i][j]  = coef * P[i][col]  (coef 0 / 1 / dt; branch-free)
-                const int ac = j - NDX - 3 * NF; // joint-acceleration column index if >= 0
-                const int col = j < NDX ? j : (ac >= 0 ? NV + 6 + ac : 0);
-                const double coef = IX::isG(i) ? 0.0 : (j < NDX ? (IX::isG(j) ? 0.0 : 1.0) : (ac >= 0 ? dt : 0.0));
-                const double v = SMPC_PLV(qs_acc)[rr * 9 + a * 3 + c] + coef * s.P[i * NDX + col];
-                acc[a][c] = v;
-              }
-            tile3x3_mac<NG>(acc, [&](int k) { return &NAB[k * NXU + i0]; }, [&](int k) { return &TG[k * NXU + j0]; });
-            tile3x3_mac<NG>(acc, [&](int k) { return &PEG[k * NXU + i0]; }, [&](int k) { return &NAB[k * NXU + j0]; });
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-              for (int c = 0; c < 3; c++)
-                SMPC_PLV(qs_acc)[rr * 9 + a * 3 + c] = acc[a][c];
+            for (int k = 0; k < NG; k++)
+              acc += NAB[k * NXU + j] * s.pt[IX::G(k)];
+            if (j < NDX)
+              s.qh[j] = acc;
+            else
+              s.rh[j - NDX] = acc;
           }
         }
-        // R^ tile (one per lane): R + E_b^T P~ E_b + NB^T TG_b + PEG_b^T NB
-        {
-          constexpr int TR = NU / 3;
-          static_assert(TR * TR <= NT, "one R tile per lane");
-          if (lane < TR * TR)
+        SMPC_LANES_END_WAVE
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+          for (int tt = 0; tt < 10; tt++)
           {
-            const int i0 = (lane / TR) * 3, j0 = (lane % TR) * 3;
-            double acc[3][3];
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-              for (int c = 0; c < 3; c++)
-              {
-                const int i = i0 + a, j = j0 + c;
-                double v = SMPC_PLV(r_acc)[a * 3 + c];
-                if (i >= 3 * NF && j >= 3 * NF)
-                  v += dt * dt * s.P[(NV + 6 + i - 3 * NF) * NDX + NV + 6 + j - 3 * NF];
-                acc[a][c] = v;
-              }
-            tile3x3_mac<NG>(acc, [&](int k) { return &NAB[k * NXU + NDX + i0]; }, [&](int k) { return &TG[k * NXU + NDX + j0]; });
-            tile3x3_mac<NG>(acc, [&](int k) { return &PEG[k * NXU + NDX + i0]; }, [&](int k) { return &NAB[k * NXU + NDX + j0]; });
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-              for (int c = 0; c < 3; c++)
-                SMPC_PLV(r_acc)[a * 3 + c] = acc[a][c];
+            SMPC_MFMA(hacc, tt, nav, ks * 4 + T4I[tt], tgv, ks * 4 + T4J[tt]);
+            SMPC_MFMA(hacc, tt, pev, ks * 4 + T4I[tt], nav, ks * 4 + T4J[tt]);
           }
-        }
-        // q^ = q + A^T p~ ; r^ = r + B^T p~
-        if (lane < NXU)
-        {
-          const int j = lane;
-          double acc = SMPC_PLV(vec_pf)[0];
-          if (j < NDX)
-          {
-            if (IX::isQj(j))
-              acc += s.pt[j];
-            else if (IX::isVj(j))
-              acc += dt * s.pt[j - NV] + s.pt[j];
-          }
-          else if (j - NDX >= 3 * NF)
-          {
-            const int ip = j - NDX - 3 * NF;
-            acc += dt * dt * s.pt[6 + ip] + dt * s.pt[NV + 6 + ip];
-          }
-#pragma unroll
-          for (int k = 0; k < NG; k++)
-            acc += NAB[k * NXU + j] * s.pt[IX::G(k)];
-          if (j < NDX)
-            s.qh[j] = acc;
-          else
-            s.rh[j - NDX] = acc;
-        }
       }
-      SMPC_LANES_END_WAVE
       prof_tick(prof, 8, tprev);
-      // write back: Q^ -> s.P (P~ is dead), S^ -> Sh, R^ -> s.Rh
+      // S^ -> Sh, R^ (upper triangle) -> s.Rh ; Q^ stays in the accumulators (tiles QT)
       SMPC_LANES(NT)
       {
-        constexpr int TJ = NXU / 3, NTILES = (NDX / 3) * TJ;
+        const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-        {
-          const int tile = lane + rr * NT;
-          if (tile < NTILES)
+        for (int tt = 0; tt < 10; tt++)
+          if (16 * T4J[tt] + 15 >= NDX)
           {
-            const int i0 = (tile / TJ) * 3, j0 = (tile % TJ) * 3;
 #pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-              for (int c = 0; c < 3; c++)
+            for (int v = 0; v < 4; v++)
+            {
+              const int row = 16 * T4I[tt] + lr + 4 * v, col = 16 * T4J[tt] + lc;
+              const double val = SMPC_ACCV(hacc, tt, v);
+              if (col >= NDX && col < NXU)
               {
-                const int i = i0 + a, j = j0 + c;
-                const double v = SMPC_PLV(qs_acc)[rr * 9 + a * 3 + c];
-                if (j < NDX)
-                  s.P[i * NDX + j] = v;
-                else
-                  Sh[i * NU + j - NDX] = v;
+                if (row < NDX)
+                  Sh[row * NU + col - NDX] = val;
+                else if (row <= col)
+                  s.Rh[(row - NDX) * NU + col - NDX] = val;
               }
+            }
           }
-        }
-        constexpr int TR = NU / 3;
-        if (lane < TR * TR)
-        {
-          const int i0 = (lane / TR) * 3, j0 = (lane % TR) * 3;
-#pragma unroll
-          for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-              s.Rh[(i0 + a) * NU + j0 + c] = SMPC_PLV(r_acc)[a * 3 + c];
-        }
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 9, tprev);
@@ -707,7 +721,7 @@ namespace smpc
       // otherwise idle lanes (the forward sweep then needs one product, not a 24-step back substitution).
       // L_R^-1 lands in the block Cc takes over afterwards.  Loads / stores are address-selected, not branched.
       wave_chol_solve<NU, NT>(
-        [&](int i, int j) { return s.Rh[i * NU + j]; }, NDX + 1 + NU,
+        [&](int i, int j) { return s.Rh[j * NU + i]; }, NDX + 1 + NU, // R^ is stored upper: (j, i), j <= i
         [&](int i, int c) {
           const double * src = c < NDX ? &Sh[c * NU + i] : &s.rh[i];
           const double v = *src;
@@ -718,8 +732,6 @@ namespace smpc
           *dst = v;
         });
       prof_tick(prof, 10, tprev);
-      prof_tick(prof, 11, tprev);
-      // contact rows of C, box activity, d  (S^ is dead: Cc overlays it)
       SMPC_LANES(NT)
       {
         for (int idx = lane; idx < NU * (NDX + 1); idx += NT)
@@ -728,6 +740,8 @@ namespace smpc
           g[GK::G_LR + idx] = Li[idx];
       }
       SMPC_LANES_END_WAVE
+      prof_tick(prof, 11, tprev);
+      // contact rows of C, box activity, d
       SMPC_LANES(NT)
       {
 #pragma unroll
@@ -747,57 +761,68 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 12, tprev);
-      // ---- (6) P_t = Q^ - W^T W + C^T C / mu (lower tiles, mirrored) ; p_t ----
-      SMPC_LANES(NT)
+      // ---- (6) P_t = Q^ - W_x^T W_x + C^T C / mu + box (matrix cores, K = NU + NG, accumulating onto Q^) ; p_t ----
       {
-        constexpr int TJ = NDX / 3, NLOW = TJ * (TJ + 1) / 2;
-        for (int n = lane; n < NLOW; n += NT)
+        constexpr int KW = NU / 4, KC = NG / 4;
+        SMPC_PLA(double, wpv, NT, (KW + KC) * 3); // B operands:  W_x | Cc
+        SMPC_PLA(double, wnv, NT, (KW + KC) * 3); // A operands: -W_x | Cc / mu
+        SMPC_LANES(NT)
         {
-          int ti, tj;
-          lower_tile(n, ti, tj);
-          const int i0 = ti * 3, j0 = tj * 3;
-          double aw[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, ac[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-          tile3x3_mac<NU>(aw, [&](int k) { return &Wm[k * (NDX + 1) + i0]; }, [&](int k) { return &Wm[k * (NDX + 1) + j0]; });
-          tile3x3_mac<NG>(ac, [&](int k) { return &Cc[k * NDX + i0]; }, [&](int k) { return &Cc[k * NDX + j0]; });
-          double pv[3][3];
+          const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-          for (int a = 0; a < 3; a++)
+          for (int ks = 0; ks < KW + KC; ks++)
 #pragma unroll
-            for (int c = 0; c < 3; c++)
+            for (int I = 0; I < 3; I++)
             {
-              const int i = i0 + a, j = j0 + c;
-              double v = 0.5 * (s.P[i * NDX + j] + s.P[j * NDX + i]) - aw[a][c] + imu * ac[a][c];
-              const double bx = s.boxact[IX::isQj(i) ? i - 6 : 0];
-              v += (i == j && IX::isQj(i)) ? imu * bx : 0.0;
-              pv[a][c] = v;
+              const int col = 16 * I + lc, cs = col < NDX ? col : 0;
+              const double raw = ks < KW ? Wm[(4 * ks + lr) * (NDX + 1) + cs] : Cc[(4 * (ks - KW) + lr) * NDX + cs];
+              const double val = col < NDX ? raw : 0.0;
+              SMPC_PLV(wpv)[ks * 3 + I] = val;
+              SMPC_PLV(wnv)[ks * 3 + I] = ks < KW ? -val : imu * val;
             }
-#pragma unroll
-          for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-              if (ti != tj || c <= a)
-              {
-                s.P[(i0 + a) * NDX + j0 + c] = pv[a][c];
-                s.P[(j0 + c) * NDX + i0 + a] = pv[a][c];
-              }
+          if (lane < NDX)
+          {
+            const int i = lane;
+            double acc = s.qh[i];
+#pragma unroll 4
+            for (int m = 0; m < NU; m++)
+              acc -= Wm[m * (NDX + 1) + i] * Wm[m * (NDX + 1) + NDX];
+            double cd = 0.0;
+#pragma unroll 4
+            for (int r = 0; r < NG; r++)
+              cd += Cc[r * NDX + i] * s.dc[r];
+            if (IX::isQj(i))
+              cd += s.boxact[i - 6] * s.boxd[i - 6];
+            s.p[i] = acc + imu * cd;
+          }
         }
-        if (lane < NDX)
+        SMPC_LANES_END_WAVE
+#pragma unroll
+        for (int ks = 0; ks < KW + KC; ks++)
+#pragma unroll
+          for (int tt = 0; tt < 6; tt++)
+            SMPC_MFMA(hacc, QT[tt], wnv, ks * 3 + T3I[tt], wpv, ks * 3 + T3J[tt]);
+        SMPC_LANES(NT)
         {
-          const int i = lane;
-          double acc = s.qh[i];
-#pragma unroll 4
-          for (int m = 0; m < NU; m++)
-            acc -= Wm[m * (NDX + 1) + i] * Wm[m * (NDX + 1) + NDX];
-          double cd = 0.0;
-#pragma unroll 4
-          for (int r = 0; r < NG; r++)
-            cd += Cc[r * NDX + i] * s.dc[r];
-          if (IX::isQj(i))
-            cd += s.boxact[i - 6] * s.boxd[i - 6];
-          s.p[i] = acc + imu * cd;
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int tt = 0; tt < 6; tt++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+            {
+              const int row = 16 * T3I[tt] + lr + 4 * v, col = 16 * T3J[tt] + lc;
+              if (col < NDX && row <= col)
+              {
+                double pv = SMPC_ACCV(hacc, QT[tt], v);
+                if (row == col && IX::isQj(row))
+                  pv += imu * s.boxact[row - 6];
+                s.P[row * NDX + col] = pv;
+                s.P[col * NDX + row] = pv;
+              }
+            }
         }
+        SMPC_LANES_END_WAVE
       }
-      SMPC_LANES_END_WAVE
       prof_tick(prof, 13, tprev);
     }
   }

@@ -35,11 +35,29 @@
 #define SMPC_PLV(name) name[lane]
 #define SMPC_XLANE(name, src) name[src]
 #define SMPC_XLANE_A(name, idx, src) name[src][idx]
+// wave-collective matrix-core step (see the HIP backend for the lane maps); called between lane phases
+#define SMPC_ACC(name, NT, n) double name[NT][n][4]
+#define SMPC_ACCV(name, t, v) name[lane][t][v]
+#define SMPC_MFMA(acc, t, av, ia, bv, ib) ::smpc::emu_mfma_f64_16x16x4(acc, t, av, ia, bv, ib)
 #define SMPC_CLOCK() (0LL)
 #define SMPC_RSQRT(x) (1.0 / std::sqrt(x))
 
 namespace smpc
 {
+  // D[(l>>4)+4v][l&15] += sum_k A[.][k] B[k][.], k ascending with fused multiply-adds (bitwise what the hardware does)
+  template <class Acc, class AV, class BV>
+  inline void emu_mfma_f64_16x16x4(Acc & acc, int t, const AV & av, int ia, const BV & bv, int ib)
+  {
+    for (int l = 0; l < 64; l++)
+      for (int v = 0; v < 4; v++)
+      {
+        const int row = (l >> 4) + 4 * v, col = l & 15;
+        double sacc = acc[l][t][v];
+        for (int k = 0; k < 4; k++)
+          sacc = std::fma(av[row + 16 * k][ia], bv[col + 16 * k][ib], sacc);
+        acc[l][t][v] = sacc;
+      }
+  }
   inline bool emu_reverse = std::getenv("SMPC_EMU_REVERSE") != nullptr && std::getenv("SMPC_EMU_REVERSE")[0] == '1';
   typedef int stream_t;
   inline void * dev_alloc(size_t bytes)
