@@ -134,6 +134,7 @@ namespace smpc
     std::vector<double> cold_trace; // [n][4] phi0, prim, dual, alpha
     // profiling
     bool profiling = false;
+    static constexpr int LS_SLOTS = 256; // instance slots of the backtracking trial launch
     double kernel_ms[KID_N] = {0};
     long kernel_calls[KID_N] = {0};
     std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
@@ -237,6 +238,7 @@ namespace smpc
       buf.xdotT = dalloc((size_t)B * D::LS_N * 4 * D::NV);
       buf.xdot01 = dalloc((size_t)B * 4 * D::NV);
       buf.ls_sel = (int *)dev_alloc((size_t)B * sizeof(int));
+      buf.und_list = (int *)dev_alloc((size_t)(B + 1) * sizeof(int));
       buf.stages = (StageShared<D> *)dev_alloc((size_t)H * sizeof(StageShared<D>));
       buf.model = (DevModel<D> *)dev_alloc(sizeof(DevModel<D>));
       X_dev = dalloc((size_t)B * D::NX);
@@ -263,6 +265,7 @@ namespace smpc
                          buf.gains, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, X_dev, stage_out})
         dev_free(p);
       dev_free(buf.ls_sel);
+      dev_free(buf.und_list);
       dev_free(buf.stages);
       dev_free(buf.model);
       stream_destroy(stream);
@@ -320,6 +323,7 @@ namespace smpc
       sk.head = head;
       sk.j0 = 0;
       sk.nj = 0;
+      sk.slots = 0;
       timed_launch<StageKernelArgs<D>, deriv_body<D>, 64>(KID_DERIV, b.B * (H + 1), sk);
       if (structured_riccati)
       {
@@ -349,7 +353,17 @@ namespace smpc
       {
         sk.j0 = gq[0];
         sk.nj = gq[1];
-        timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_TRIAL, b.B * (H + 1), sk);
+        if (gq[0] == 0)
+        {
+          sk.slots = 0;
+          timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_TRIAL, b.B * (H + 1), sk);
+        }
+        else
+        {
+          sk.slots = b.B < LS_SLOTS ? b.B : LS_SLOTS;
+          timed_launch<SolverArgs<D>, compact_body<D>, 64>(KID_SELECT, 1, solver_args(b));
+          timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_TRIAL, sk.slots * (H + 1), sk);
+        }
         timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, gq[0], gq[1]));
       }
       timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B * (H + 1), solver_args(b));

@@ -14,6 +14,7 @@ namespace smpc
     Buffers<D> b;
     int head;
     int j0, nj; // trial kernel: candidate range
+    int slots;  // trial kernel: 0 = block per (instance, stage); > 0 = `slots` instance slots walking und_list
   };
 
   // x (+) alpha*dx into dst (NX); SE3 part by `se3lane`, vector part by lanes
@@ -590,9 +591,9 @@ namespace smpc
   }
 
   // =============================================================================================
-  // trial_body: grid = B * (H+1); block (inst, t) evaluates the candidates j0 .. j0+nj-1 one after the other,
-  // but only while its instance is still undecided: the common case (alpha = 1 accepted) costs one early exit
-  // per block instead of nj idle blocks.
+  // trial_body: grid = B * (H+1); block (inst, t) evaluates the candidates j0 .. j0+nj-1 one after the other.
+  // The backtracking launch (slots > 0) has grid = slots * (H+1) and walks the compacted list of instances that
+  // rejected alpha = 1: the common case (everybody accepted) costs a few thousand empty blocks, not B * (H+1).
   // =============================================================================================
   template <class D>
   SMPC_DEV void trial_one(const StageKernelArgs<D> & ka, int inst, int t, int j);
@@ -601,6 +602,19 @@ namespace smpc
   SMPC_DEV void trial_body(const StageKernelArgs<D> & ka, int block)
   {
     const int H = ka.b.H;
+    if (ka.slots > 0)
+    {
+      // backtracking launch: only the instances that rejected alpha = 1 (compacted list), `slots` at a time
+      const int slot = block / (H + 1), t = block % (H + 1);
+      const int count = ka.b.und_list[ka.b.B];
+      for (int m = slot; m < count; m += ka.slots)
+      {
+        const int inst = ka.b.und_list[m];
+        for (int jj = 0; jj < ka.nj; jj++)
+          trial_one<D>(ka, inst, t, ka.j0 + jj);
+      }
+      return;
+    }
     const int inst = block / (H + 1), t = block % (H + 1);
     if (ka.b.ls_sel[inst] >= 0)
       return; // already accepted an earlier candidate (uniform across the workgroup)

@@ -115,6 +115,7 @@ namespace smpc
     double * xdotT = nullptr;    // [B][LS_N][2][2NV] trial xdot for t = 0,1
     double * xdot01 = nullptr;   // [B][2][2NV]
     int * ls_sel = nullptr;      // [B] selected candidate, -1 = undecided
+    int * und_list = nullptr;    // [B + 1] compacted indices of the undecided instances; und_list[B] = their count
     double * dbg = nullptr;      // [64] optional in-kernel phase timers (null = off)
     StageShared<D> * stages = nullptr; // [H] linear in t
     DevModel<D> * model = nullptr;

@@ -419,7 +419,8 @@ namespace smpc
         {
           const int idx = lane + n * NT;
           const int gi = idx < NG * NXU ? idx / NXU : 0, j = idx % NXU;
-          SMPC_PLV(nab_pf)[n] = j < NDX ? lq[D::O_A + IX::G(gi) * NDX + j] : lq[D::O_B + IX::G(gi) * NU + j - NDX];
+          // (address selects, one load each: a select on a loaded VALUE would make the wave wait for it here)
+          SMPC_PLV(nab_pf)[n] = lq[j < NDX ? D::O_A + IX::G(gi) * NDX + j : D::O_B + IX::G(gi) * NU + j - NDX];
         }
 #pragma unroll
         for (int n = 0; n < CC_PL; n++)
@@ -428,10 +429,11 @@ namespace smpc
           const int r = idx < NG * NDX ? idx / NDX : 0;
           SMPC_PLV(cc_pf)[n] = lq[D::O_C + (NA + r) * NDX + idx % NDX];
         }
-        SMPC_PLV(vec_pf)[0] = lane < NDX ? lq[D::O_q + lane] : (lane < NXU ? lq[D::O_r + lane - NDX] : 0.0);
-        SMPC_PLV(vec_pf)[1] = lane < NG ? lq[D::O_d + NA + lane] : 0.0;
-        SMPC_PLV(vec_pf)[2] = lane < NA ? lq[D::O_C + lane * NDX + 6 + lane] : 0.0; // 1 if the box row is active
-        SMPC_PLV(vec_pf)[3] = lane < NA ? lq[D::O_d + lane] : 0.0;
+        // (values of out-of-range lanes are never used: clamp the index instead of masking the value)
+        SMPC_PLV(vec_pf)[0] = lq[lane < NDX ? D::O_q + lane : (lane < NXU ? D::O_r + lane - NDX : D::O_q)];
+        SMPC_PLV(vec_pf)[1] = lq[D::O_d + NA + (lane < NG ? lane : 0)];
+        SMPC_PLV(vec_pf)[2] = lq[D::O_C + (lane < NA ? lane * NDX + 6 + lane : 0)]; // 1 if the box row is active
+        SMPC_PLV(vec_pf)[3] = lq[D::O_d + (lane < NA ? lane : 0)];
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 3, tprev);
@@ -500,10 +502,10 @@ namespace smpc
             const int r0 = row < col ? row : col, c0 = row < col ? col : row;
             const bool valid = c0 < NXU;
             const int r = valid ? r0 : 0, c = valid ? c0 : 0;
-            const double * src = c < NDX ? lq + D::O_Q + r * NDX + c
-                                         : (r < NDX ? lq + D::O_S + r * NU + c - NDX : lq + D::O_R + (r - NDX) * NU + c - NDX);
-            const double val = *src;
-            SMPC_ACCV(hacc, tt, v) = valid ? val : 0.0;
+            const int off = c < NDX ? D::O_Q + r * NDX + c : (r < NDX ? D::O_S + r * NU + c - NDX : D::O_R + (r - NDX) * NU + c - NDX);
+            // padding rows / cols (>= NXU) load Q[0][0]: an accumulator entry only ever feeds itself and those are never
+            // read back, so they need no masking (a select on the loaded value would stall the prefetch here)
+            SMPC_ACCV(hacc, tt, v) = lq[off];
           }
       }
       SMPC_LANES_END_WAVE
@@ -843,6 +845,19 @@ namespace smpc
     static constexpr int O_A0 = N_G, O_A1 = O_A0 + N_A, O_B0 = O_A1 + N_A, O_B1 = O_B0 + N_B, O_Cc = O_B1 + N_B,
                          O_V = O_Cc + N_C, O_box = O_V + N_V, N_STAGE = O_box + D::NA;
     static constexpr int PER_LANE = (N_STAGE + 63) / 64;
+    // staging chunks: 0 gains | 1,2 A rows qb, vb | 3,4 B rows qb, vb | 5 contact rows of C | 6 vectors | 7 box diag | 8 pad
+    SMPC_HD static constexpr int start(int c)
+    {
+      return c == 0 ? 0 : c == 1 ? O_A0 : c == 2 ? O_A1 : c == 3 ? O_B0 : c == 4 ? O_B1 : c == 5 ? O_Cc : c == 6 ? O_V : c == 7 ? O_box : N_STAGE;
+    }
+    SMPC_HD static constexpr int chunk(int idx)
+    {
+      return idx < O_A0 ? 0 : idx < O_A1 ? 1 : idx < O_B0 ? 2 : idx < O_B1 ? 3 : idx < O_Cc ? 4 : idx < O_V ? 5 : idx < O_box ? 6 : idx < N_STAGE ? 7 : 8;
+    }
+    SMPC_HD static constexpr int src(int c) // offset of the chunk's source in the LQ block (chunks 1..6)
+    {
+      return c == 1 ? D::O_A : c == 2 ? D::O_A + D::NV * NDX : c == 3 ? D::O_B : c == 4 ? D::O_B + D::NV * NU : c == 5 ? D::O_C + D::NA * NDX : D::O_f;
+    }
     double st[PER_LANE * 64];
     double dx[NDX], du[NU], z[NU], y[NDX], part[64], lpd_prev[NDX];
   };
@@ -867,32 +882,39 @@ namespace smpc
     SMPC_LDS(FL, lds, 1);
     FL & s = lds[0];
     SMPC_PLA(double, pf, NT, PER);
-    // fetch stage t into the per-lane registers (flat staging index -> source chunk)
+    // fetch stage t into the per-lane registers (flat staging index -> source chunk).  Chunk boundaries are
+    // compile-time: for most n all 64 lanes fall into one chunk (plain base + lane address); the few straddling
+    // ones use an integer select chain -- no divergent branches.
     auto fetch = [&](int lane, double * r, int t) {
       const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
       const double * g = b.gains + ((size_t)inst * H + t) * GK::STRIDE;
 #pragma unroll
       for (int n = 0; n < PER; n++)
       {
-        const int idx = lane + n * NT;
-        const double * src;
-        if (idx < FL::O_A0)
-          src = g + idx;
-        else if (idx < FL::O_A1)
-          src = lq + D::O_A + (idx - FL::O_A0);
-        else if (idx < FL::O_B0)
-          src = lq + D::O_A + NV * NDX + (idx - FL::O_A1);
-        else if (idx < FL::O_B1)
-          src = lq + D::O_B + (idx - FL::O_B0);
-        else if (idx < FL::O_Cc)
-          src = lq + D::O_B + NV * NU + (idx - FL::O_B1);
-        else if (idx < FL::O_V)
-          src = lq + D::O_C + NA * NDX + (idx - FL::O_Cc);
-        else if (idx < FL::O_box)
-          src = lq + D::O_f + (idx - FL::O_V);
+        const int lo = n * NT, hi = n * NT + NT - 1;
+        if (FL::chunk(lo) == FL::chunk(hi))
+        {
+          const int c = FL::chunk(lo);
+          if (c == 0)
+            r[n] = g[lo + lane];
+          else if (c < 7)
+            r[n] = lq[FL::src(c) + lo - FL::start(c) + lane];
+          else if (c == 7)
+            r[n] = lq[D::O_C + (lo + lane - FL::O_box) * (NDX + 1) + 6];
+          else
+            r[n] = 0.0;
+        }
         else
-          src = lq + D::O_C + (idx - FL::O_box) * (NDX + 1) + 6;
-        r[n] = idx < FL::N_STAGE ? *src : 0.0;
+        {
+          const int idx = lo + lane;
+          int off = 0; // offset into lq
+#pragma unroll
+          for (int c = 1; c < 7; c++)
+            off = (idx >= FL::start(c) && idx < FL::start(c + 1)) ? FL::src(c) + idx - FL::start(c) : off;
+          off = (idx >= FL::O_box && idx < FL::N_STAGE) ? D::O_C + (idx - FL::O_box) * (NDX + 1) + 6 : off;
+          const double * src = idx < FL::N_G ? g + idx : lq + off; // address select, ONE load, no wait on its value
+          r[n] = *src;                                             // (pad entries load lq[0]; never read back)
+        }
       }
     };
     SMPC_LANES(NT)

@@ -522,6 +522,49 @@ namespace smpc
   }
 
   // =============================================================================================
+  // compact_body: grid = 1, 64 lanes: ordered list of the instances whose line search is still undecided
+  // (deterministic: lane l scans a contiguous range, exclusive prefix over the 64 counts)
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void compact_body(const SolverArgs<D> & ka, int)
+  {
+    constexpr int NT = 64;
+    const Buffers<D> & b = ka.b;
+    SMPC_LDS(int, cnt, NT + 1);
+    const int per = (b.B + NT - 1) / NT;
+    SMPC_LANES(NT)
+    {
+      int c = 0;
+      for (int i = lane * per; i < (lane + 1) * per && i < b.B; i++)
+        c += b.ls_sel[i] < 0 ? 1 : 0;
+      cnt[lane] = c;
+    }
+    SMPC_LANES_END
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      int run = 0;
+      for (int l = 0; l < NT; l++)
+      {
+        const int c = cnt[l];
+        cnt[l] = run;
+        run += c;
+      }
+      cnt[NT] = run;
+      b.und_list[b.B] = run;
+    }
+    SMPC_LANES_END
+    SMPC_LANES(NT)
+    {
+      int pos = cnt[lane];
+      for (int i = lane * per; i < (lane + 1) * per && i < b.B; i++)
+        if (b.ls_sel[i] < 0)
+          b.und_list[pos++] = i;
+    }
+    SMPC_LANES_END
+  }
+
+  // =============================================================================================
   // apply_body: grid = B * (H+1), 64 lanes: accept the step of size alpha for (inst, t)
   // =============================================================================================
   template <class D>
