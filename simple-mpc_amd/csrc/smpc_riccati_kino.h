@@ -1,8 +1,8 @@
 // smpc_riccati_kino.h -- structure-exploiting proximal Riccati sweep for the kinodynamics stage
 // (HOT(4)/(5) of SolverProxDDP::run, reference src/mpc.cpp:212; LQ solver choice src/mpc.cpp:52).
 //
-// One 64-lane wavefront per instance, per-stage blocks in LDS (33 KB), no workgroup-wide barriers on the
-// critical path.  Same KKT system as riccati_body (smpc_solver_kernels.h), reorganised:
+// One 64-lane wavefront per instance, per-stage blocks in LDS (36 KB), no workgroup-wide barriers: phases are
+// separated by wave-level ordering points only.  Same KKT system as riccati_body (smpc_solver_kernels.h), reorganised:
 //
 //   * semi-implicit Euler structure (reference src/kinodynamics.cpp:88): with the tangent split
 //     [qb(6) | qj | vb(6) | vj], only the 12 rows G = qb u vb of A and B are dense; rows qj are
@@ -10,8 +10,13 @@
 //   * only forward substitutions:  L L^T = I + mu P,  Y = L^-1 [P | p + P f],
 //         P~ = P - mu Y^T Y   (= (I + mu P)^-1 P),   p~ = (I - mu P~)(p + P f)
 //         L_R L_R^T = R^,  W = L_R^-1 [S^^T | r^],  P_t = Q^ - W^T W + C^T C / mu,  p_t = q^ - W^T w + C^T d / mu
-//     The feedback is kept in factored form (W, L_R): du = -L_R^-T (W_x dx + w) in the forward sweep.
+//     The feedback is kept in factored form (W, L_R^-1): du = -(L_R^-1)^T (W_x dx + w) in the forward sweep.
 //   * constraint rows: joint-box rows are unit selectors (diagonal contribution), contact rows are dense.
+//   * where the FLOPs go:  the four GEMM-shaped products (Y^T Y, P~[G,G] NAB, [A|B]^T P~ [A|B], W^T W + C^T C) run on
+//     the FP64 matrix cores (v_mfma_f64_16x16x4_f64; 16-padded upper tiles, operands read once from LDS, symmetric
+//     results kept in accumulator registers between phases); the two Cholesky factorisations and their forward
+//     substitutions run in registers with one matrix row / right-hand side per lane and v_readlane broadcasts
+//     (a broadcast LDS read costs a full LDS pass per value; see tools/micro/xlane_bench.hip).
 #pragma once
 #include "smpc_solver_kernels.h"
 
@@ -38,109 +43,6 @@ namespace smpc
     SMPC_HD static bool isQj(int i) { return i >= 6 && i < NV; }
     SMPC_HD static bool isVj(int i) { return i >= NV + 6; }
   };
-
-  // Cholesky by one wave with one matrix row per lane held in registers (no integer division, two phases
-  // per column).  On exit row k of Mx, entries i >= k, holds column k of L (L[i][k]) -- contiguous for the
-  // forward substitution -- and invd[k] = 1 / L[k][k].  dg: N doubles of LDS scratch.
-  template <int N, int NT>
-  SMPC_DEV void wave_cholesky_rows(double * Mx, int ld, double * dg, double * invd)
-  {
-    SMPC_PLA(double, row, NT, N);
-    SMPC_PL(double, lcur, NT);
-    SMPC_LANES(NT)
-    if (lane < N)
-    {
-#pragma unroll
-      for (int j = 0; j < N; j++)
-        SMPC_PLV(row)[j] = Mx[lane * ld + j];
-      if (lane == 0)
-        dg[0] = SMPC_PLV(row)[0];
-    }
-    SMPC_LANES_END_WAVE
-#pragma unroll
-    for (int k = 0; k < N; k++)
-    {
-      SMPC_LANES(NT)
-      if (lane >= k && lane < N)
-      {
-        const double d = dg[k];
-        const double rs = SMPC_RSQRT(d);
-        const double l = lane == k ? d * rs : SMPC_PLV(row)[k] * rs;
-        SMPC_PLV(lcur) = l;
-        Mx[k * ld + lane] = l;
-        if (lane == k)
-          invd[k] = rs;
-      }
-      SMPC_LANES_END_WAVE
-      if (k + 1 < N)
-      {
-        SMPC_LANES(NT)
-        if (lane > k && lane < N)
-        {
-          const double l = SMPC_PLV(lcur);
-#pragma unroll
-          for (int j = k + 1; j < N; j++)
-            SMPC_PLV(row)[j] -= l * Mx[k * ld + j];
-          if (lane == k + 1)
-            dg[k + 1] = SMPC_PLV(row)[k + 1];
-        }
-        SMPC_LANES_END_WAVE
-      }
-    }
-  }
-
-  // Forward substitution L y = b for one right-hand side per lane (lane c < ncols), right-looking, the whole
-  // column kept in registers (N doubles): N(N-1)/2 FMAs and as many broadcast LDS reads per lane.  The L
-  // entries are consumed in one linear order (k, i > k); a ring of DPF registers holds the next DPF of them, so
-  // every LDS read is issued DPF FMAs before its use and the footprint stays at N + DPF doubles (VALU operands
-  // must live in the 256 arch VGPRs: anything above that is shuffled through AGPRs by the compiler).
-  template <int N, class Get, class Put>
-  SMPC_DEV void lane_forward_subst(const double * LT, int ld, const double * invd, int ncols, int lane, Get get, Put put)
-  {
-    constexpr int DPF = 12, M = N * (N - 1) / 2;
-    static_assert(M >= DPF, "ring deeper than the work");
-    if (lane < ncols)
-    {
-      double b[N], ring[DPF];
-#pragma unroll
-      for (int i = 0; i < N; i++)
-        b[i] = get(i, lane);
-      int pk = 0, pi = 1; // prefetch cursor (compile-time after unrolling)
-#pragma unroll
-      for (int m = 0; m < DPF; m++)
-      {
-        ring[m] = LT[pk * ld + pi];
-        if (++pi == N)
-        {
-          pk++;
-          pi = pk + 1;
-        }
-      }
-      int m = 0;
-#pragma unroll
-      for (int k = 0; k < N; k++)
-      {
-        const double xk = b[k] * invd[k];
-        put(k, lane, xk);
-#pragma unroll
-        for (int i = k + 1; i < N; i++)
-        {
-          const double l = ring[m % DPF];
-          if (m + DPF < M)
-          {
-            ring[m % DPF] = LT[pk * ld + pi];
-            if (++pi == N)
-            {
-              pk++;
-              pi = pk + 1;
-            }
-          }
-          b[i] -= l * xk;
-          m++;
-        }
-      }
-    }
-  }
 
   // Cholesky + forward substitution by ONE wave, entirely in registers: lane i keeps row i of the matrix
   // (N doubles); entries of other lanes' rows are fetched with v_readlane (SMPC_XLANE), so neither the
@@ -202,128 +104,15 @@ namespace smpc
     SMPC_LANES_END_WAVE
   }
 
-  // Forward substitution L y = b, one right-hand side per lane (lane c < ncols), right-looking and IN PLACE in
-  // LDS: Yc(i) is column c of the right-hand sides (conflict-free: consecutive lanes -> consecutive words),
-  // LT row k (entries >= k) = column k of L (broadcast reads).  Few registers, no unrolled register arrays.
-  template <int N>
-  SMPC_DEV void lane_forward_subst_lds(const double * LT, int ld, const double * invd, int ncols, int lane, double * Y, int ldy)
-  {
-    if (lane < ncols)
-    {
-      double * yc = Y + lane;
-      for (int k = 0; k < N; k++)
-      {
-        const double xk = yc[k * ldy] * invd[k];
-        yc[k * ldy] = xk;
-        const double * lt = LT + k * ld;
-        // chunks of 8 rows: batch the 16 LDS reads, then 8 FMAs, then 8 writes (one LDS latency per chunk)
-        int i = k + 1;
-        for (; i + 8 <= N; i += 8)
-        {
-          double yv[8], lv[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++)
-          {
-            yv[u] = yc[(i + u) * ldy];
-            lv[u] = lt[i + u];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; u++)
-            yc[(i + u) * ldy] = yv[u] - lv[u] * xk;
-        }
-        {
-          double yv[8], lv[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++)
-          {
-            const int ii = i + u < N ? i + u : N - 1;
-            yv[u] = yc[ii * ldy];
-            lv[u] = lt[ii];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; u++)
-            if (i + u < N)
-              yc[(i + u) * ldy] = yv[u] - lv[u] * xk;
-        }
-      }
-    }
-  }
-
-  // acc(3x3) += sum_k x_k (3) * y_k (3)^T, software-pipelined by hand with two register sets: the operands
-  // of step k+1 are requested before the FMAs of step k.  The loop itself is NOT unrolled (K even), which
-  // keeps the register footprint at 12 operand doubles.  xp(k) / yp(k): pointers to 3 consecutive doubles.
-  template <int K, class XP, class YP>
-  SMPC_DEV void tile3x3_mac(double (&acc)[3][3], XP xp, YP yp)
-  {
-    static_assert(K % 2 == 0, "K must be even");
-    double xa[3], ya[3], xb[3], yb[3];
-    {
-      const double * x = xp(0);
-      const double * y = yp(0);
-#pragma unroll
-      for (int a = 0; a < 3; a++)
-      {
-        xa[a] = x[a];
-        ya[a] = y[a];
-      }
-    }
-#pragma unroll 1
-    for (int k = 0; k < K; k += 2)
-    {
-      {
-        const double * x = xp(k + 1);
-        const double * y = yp(k + 1);
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-        {
-          xb[a] = x[a];
-          yb[a] = y[a];
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-          acc[a][c] += xa[a] * ya[c];
-      {
-        const int kn = k + 2 < K ? k + 2 : k; // last iteration: harmless reload
-        const double * x = xp(kn);
-        const double * y = yp(kn);
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-        {
-          xa[a] = x[a];
-          ya[a] = y[a];
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-          acc[a][c] += xb[a] * yb[c];
-    }
-  }
-
-  // n-th tile (row-major over the lower triangle incl. diagonal) of a square tile grid: n -> (ti, tj), tj <= ti
-  SMPC_HD void lower_tile(int n, int & ti, int & tj)
-  {
-    int t = (int)((sqrtf(8.0f * (float)n + 1.0f) - 1.0f) * 0.5f);
-    if ((t + 1) * (t + 2) / 2 <= n)
-      t++;
-    if (t * (t + 1) / 2 > n)
-      t--;
-    ti = t;
-    tj = n - t * (t + 1) / 2;
-  }
-
   template <class D>
   struct RiccatiKinoLds
   {
     static constexpr int NDX = D::NDX, NU = D::NU, NXU = D::NDX + D::NU, NG = 12;
-    static constexpr int SCR = NDX * NDX + NDX * (NDX + 1);
-    double P[NDX * NDX]; // P_{t+1} -> P~ -> Q^ -> P_t
-    // scratch, by phase:  [L (NDX^2) | Y (NDX x (NDX+1))]  ->  [NAB | PEG | TG] (3 x NG x NXU)
-    //                     ->  [S^ (NDX x NU) | W (NU x (NDX+1)) | Cc (NG x NDX)]
+    static constexpr int SCR_Y = NDX * (NDX + 1), SCR_G = 3 * NG * NXU, SCR_W = NDX * NU + NU * (NDX + 1) + NU * NU;
+    static constexpr int SCR = SCR_Y > SCR_G ? (SCR_Y > SCR_W ? SCR_Y : SCR_W) : (SCR_G > SCR_W ? SCR_G : SCR_W);
+    double P[NDX * NDX]; // P_{t+1} -> P~ (-> E^T P~ E in place) -> P_t
+    // scratch, by phase:  Y (NDX x (NDX+1))  ->  [NAB | PEG | TG] (3 x NG x NXU)
+    //                     ->  [S^ (NDX x NU) | W (NU x (NDX+1)) | L_R^-1 (NU x NU), then Cc (NG x NDX)]
     double scr[SCR];
     double Rh[NU * NU]; // R^ -> L_R (sym-stored)
     double p[NDX], pt0[NDX], pt[NDX], qh[NDX], rh[NU], f[NDX], col[NDX], invd[NDX], invdR[NU];
@@ -343,14 +132,14 @@ namespace smpc
     static_assert(NDX % 3 == 0 && NU % 3 == 0 && NXU % 3 == 0 && NG % 3 == 0, "3x3 register tiles");
     static_assert(NDX + 1 <= NT, "one lane per right-hand side");
     static_assert(3 * NG * NXU <= RiccatiKinoLds<D>::SCR, "overlay of the small blocks");
-    static_assert(NDX * NU + NU * (NDX + 1) + NG * NDX <= RiccatiKinoLds<D>::SCR, "overlay of S^, W, Cc");
+    static_assert(NG * NDX <= NU * NU, "Cc takes over the L_R^-1 block");
     const Buffers<D> & b = ka.b;
     const int H = b.H;
     const int inst = block;
     const double mu = b.model->mu, imu = 1.0 / mu, dt = b.model->dt;
     SMPC_LDS(RiccatiKinoLds<D>, lds, 1);
     RiccatiKinoLds<D> & s = lds[0];
-    double * Ym = s.scr + NDX * NDX;           // [NDX][NDX+1]  phase 2-3
+    double * Ym = s.scr;                       // [NDX][NDX+1]  phase 2-3
     double * NAB = s.scr;                      // [NG][NXU]  dense rows of [A | B]           phase 4
     double * PEG = s.scr + NG * NXU;           // [NG][NXU]  (P~ E)[G,:] | (P~ E_b)[G,:]
     double * TG = s.scr + 2 * NG * NXU;        // [NG][NXU]  (P~ A)[G,:] | (P~ B)[G,:]
