@@ -170,6 +170,8 @@ namespace smpc
         m.level[j] = j == 0 ? 0 : m.level[rm->parent[j]] + 1;
         maxlev = std::max(maxlev, m.level[j]);
         m.anc[j] = (j == 0 ? 0u : m.anc[rm->parent[j]]) | (1u << j);
+        if (j > 0)
+          m.children[rm->parent[j]] |= 1u << j;
         for (int i = 0; i < 9; i++)
           m.jpR[j][i] = rm->jp_R[j][i];
         for (int i = 0; i < 3; i++)

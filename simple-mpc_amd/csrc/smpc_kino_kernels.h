@@ -79,9 +79,10 @@ namespace smpc
     const int H = b.H, R = b.R;
     const int inst = block / (H + 1), t = block % (H + 1);
     const bool term = t == H;
-    const DevModel<D> & md = *b.model;
+    const DevModel<D> & mg = *b.model; // global: large weights only
     SMPC_LDS(KinoScratchT, scs, 1);
     KinoScratchT & sc = scs[0];
+    const DevModelSmall<D> & md = sc.ml; // LDS copy (filled in the load phase)
     const int st = ring_slot(ka.head, t, R);
     const size_t ib = (size_t)inst * R;
     const double * xg = b.xs + (ib + st) * NX;
@@ -90,11 +91,11 @@ namespace smpc
     const double preg = b.scal[(size_t)inst * SC_N + SC_PREG];
 
     StageIn<D> in;
-    in.md = &md;
+    in.md = &mg;
     in.terminal = term;
     in.mask = term ? 0u : b.stages[t].mask;
     in.u_ref = term ? nullptr : b.stages[t].u_ref;
-    in.x_tgt = term ? md.x_term : b.stages[t].x_tgt;
+    in.x_tgt = term ? mg.x_term : b.stages[t].x_tgt;
     in.foot_ref = term ? nullptr : b.foot_ref + ((size_t)inst * H + t) * NF * 3;
     long long tprev = SMPC_CLOCK();
     in.prof = (b.dbg != nullptr && block == 17) ? b.dbg : nullptr; // optional phase timers: one mid-horizon block
@@ -102,6 +103,7 @@ namespace smpc
 
     SMPC_LANES(NT)
     {
+      lanes_load_model<D, NT>(sc, &mg, lane);
       for (int i = lane; i < NX; i += NT)
         sc.x[i] = xg[i];
       for (int i = lane; i < NU; i += NT)
@@ -114,7 +116,7 @@ namespace smpc
       for (int i = lane; i < NC; i += NT)
         sc.nu[i] = term ? 0.0 : b.vs[(ib + st) * NC + i];
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
 
     if (in.prof) prof_tick(in.prof, 15, tprev);
     kino_tree_phases<D, true>(sc, in);
@@ -123,7 +125,7 @@ namespace smpc
     {
       SMPC_LANES(NT)
       lanes_difference<D>(xn_g, sc.xnext, sc.e, lane, 61);
-      SMPC_LANES_END
+      SMPC_LANES_END_WAVE
     }
     if (in.prof) prof_tick(in.prof, 29, tprev);
     kino_cost_constraints<D, true>(sc, in);
@@ -141,7 +143,7 @@ namespace smpc
           const int a = idx / 6, k = idx % 6;
           double s = 0.0;
           for (int bb = 0; bb < 6; bb++)
-            s += md.w_x[a * NDX + bb] * sc.Jl[bb * 6 + k];
+            s += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + k];
           sc.WJl[idx] = s;
         }
         for (int idx = lane; idx < 6 * NDX; idx += NT)
@@ -153,7 +155,7 @@ namespace smpc
           sc.WJc[idx] = s;
         }
       }
-      SMPC_LANES_END
+      SMPC_LANES_END_WAVE
       double * QN = b.QN + (size_t)inst * NDX * NDX;
       double * qN = b.qN + (size_t)inst * NDX;
       SMPC_LANES(NT)
@@ -181,10 +183,10 @@ namespace smpc
           {
             v = 0.0;
             for (int a = 0; a < 6; a++)
-              v += sc.Jl[a * 6 + i] * (k < 6 ? sc.WJl[a * 6 + k] : md.w_x[a * NDX + k]);
+              v += sc.Jl[a * 6 + i] * (k < 6 ? sc.WJl[a * 6 + k] : mg.w_x[a * NDX + k]);
           }
           else
-            v = k < 6 ? sc.WJl[i * 6 + k] : md.w_x[i * NDX + k];
+            v = k < 6 ? sc.WJl[i * 6 + k] : mg.w_x[i * NDX + k];
           for (int a = 0; a < 6; a++)
             v += (i < NV ? sc.dh_dq[a * NV + i] : sc.Ag[a * NV + i - NV]) * sc.WJc[a * NDX + k];
           if (i == k)
@@ -192,7 +194,7 @@ namespace smpc
           QN[i * NDX + k] = v;
         }
       }
-      SMPC_LANES_END
+      SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
       if (lane == 0)
       {
@@ -204,7 +206,7 @@ namespace smpc
         parts[2] = 0.0;
         parts[3] = dual;
       }
-      SMPC_LANES_END
+      SMPC_LANES_END_WAVE
       return;
     }
 
@@ -220,7 +222,7 @@ namespace smpc
         const int a = idx / 6, k = idx % 6;
         double s = 0.0;
         for (int bb = 0; bb < 6; bb++)
-          s += md.w_x[a * NDX + bb] * sc.Jl[bb * 6 + k];
+          s += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + k];
         sc.WJl[idx] = s;
       }
       for (int idx = lane; idx < 6 * NDX; idx += NT)
@@ -233,7 +235,7 @@ namespace smpc
         // JtW[i][k] = sum_a Jl[a][i] w_x[a][k]  (rows of J_x^T w_x for the base block)
         double t = 0.0;
         for (int bb = 0; bb < 6; bb++)
-          t += sc.Jl[bb * 6 + a] * md.w_x[bb * NDX + k];
+          t += sc.Jl[bb * 6 + a] * mg.w_x[bb * NDX + k];
         sc.JtW[idx] = t;
       }
       for (int idx = lane; idx < 3 * NV; idx += NT)
@@ -275,13 +277,13 @@ namespace smpc
         {
           double t = 0.0;
           for (int bb = 0; bb < 6; bb++)
-            t += md.w_x[a * NDX + bb] * sc.Jl[bb * 6 + j];
+            t += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + j];
           s += sc.Jl[a * 6 + i] * t;
         }
         sc.JWJ[lane] = s;
       }
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
 
     if (in.prof) prof_tick(in.prof, 32, tprev);
     double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
@@ -417,7 +419,7 @@ namespace smpc
         sc.ru[k] = fabs(r);
       }
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
 
     if (in.prof) prof_tick(in.prof, 33, tprev);
     // ---- Q, S, R as 3x3 register tiles over the structured sum of J^T W J terms:
@@ -443,7 +445,7 @@ namespace smpc
             if (i < 6)
               v = j < 6 ? sc.JWJ[i * 6 + j] : sc.JtW[i * NDX + j];
             else
-              v = j < 6 ? sc.WJl[i * 6 + j] : md.w_x[i * NDX + j];
+              v = j < 6 ? sc.WJl[i * 6 + j] : mg.w_x[i * NDX + j];
             acc[a][c] = v + (i == j ? preg : 0.0);
           }
         const double * jc = i0 < NV ? &sc.dh_dq[i0] : &sc.Ag[i0 - NV];
@@ -529,7 +531,7 @@ namespace smpc
         for (int a = 0; a < 3; a++)
 #pragma unroll
           for (int c = 0; c < 3; c++)
-            acc[a][c] = md.w_u[(i0 + a) * NU + j0 + c] + ((i0 + a) == (j0 + c) ? preg : 0.0);
+            acc[a][c] = mg.w_u[(i0 + a) * NU + j0 + c] + ((i0 + a) == (j0 + c) ? preg : 0.0);
         if (i0 < 3 * NF && j0 < 3 * NF && ((in.mask >> (i0 / 3)) & 1u) && ((in.mask >> (j0 / 3)) & 1u))
         {
           // Ju[:, 3f+a] = [e_a ; (p_f - c) x e_a]
@@ -572,7 +574,7 @@ namespace smpc
         lq[D::O_vpd + lane] = sc.act[lane] ? 2.0 * sc.vplus[lane] - sc.nu[lane] : 0.0;
       }
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     if (in.prof) prof_tick(in.prof, 35, tprev);
     SMPC_LANES(NT)
     if (lane == 0)
@@ -587,7 +589,7 @@ namespace smpc
       parts[2] = sc.red[2];
       parts[3] = dual;
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
   }
 
   // =============================================================================================
@@ -631,9 +633,10 @@ namespace smpc
     const Buffers<D> & b = ka.b;
     const int H = b.H, R = b.R;
     const bool term = t == H;
-    const DevModel<D> & md = *b.model;
+    const DevModel<D> & mg = *b.model; // global: large weights only
     SMPC_LDS(KinoScratchT, scs, 1);
     KinoScratchT & sc = scs[0];
+    const DevModelSmall<D> & md = sc.ml; // LDS copy (filled in the load phase)
     const int st = ring_slot(ka.head, t, R);
     const size_t ib = (size_t)inst * R;
     double alpha = 1.0;
@@ -641,16 +644,17 @@ namespace smpc
       alpha *= 0.5;
 
     StageIn<D> in;
-    in.md = &md;
+    in.md = &mg;
     in.terminal = term;
     in.mask = term ? 0u : b.stages[t].mask;
     in.u_ref = term ? nullptr : b.stages[t].u_ref;
-    in.x_tgt = term ? md.x_term : b.stages[t].x_tgt;
+    in.x_tgt = term ? mg.x_term : b.stages[t].x_tgt;
     in.foot_ref = term ? nullptr : b.foot_ref + ((size_t)inst * H + t) * NF * 3;
 
     const double * dx = b.dxs + ((size_t)inst * (H + 1) + t) * NDX;
     SMPC_LANES(NT)
     {
+      lanes_load_model<D, NT>(sc, &mg, lane);
       lanes_integrate<D>(b.xs + (ib + st) * NX, dx, alpha, sc.x, lane, 0);
       if (!term)
       {
@@ -668,14 +672,14 @@ namespace smpc
         for (int i = lane; i < NU; i += NT)
           sc.u[i] = 0.0;
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
 
     kino_tree_phases<D, false>(sc, in);
     if (!term)
     {
       SMPC_LANES(NT)
       lanes_difference<D>(sc.xn1, sc.xnext, sc.e, lane, 61);
-      SMPC_LANES_END
+      SMPC_LANES_END_WAVE
     }
     kino_cost_constraints<D, false>(sc, in);
     double * parts = b.partsT + (((size_t)inst * D::LS_N + j) * (H + 1) + t) * 2;
@@ -687,7 +691,7 @@ namespace smpc
         parts[0] = sc.red[0];
         parts[1] = 0.0;
       }
-      SMPC_LANES_END
+      SMPC_LANES_END_WAVE
       return;
     }
     kino_multipliers<D, false>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
@@ -705,6 +709,6 @@ namespace smpc
         xd[NV + lane] = sc.a[lane];
       }
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
   }
 } // namespace smpc

@@ -13,6 +13,7 @@
 //   HOT(3) LQ assembly: AL multipliers / active set, knot (Q,S,R,q,r,A,B,f,C,d)
 // World-frame spatial formulation; derivation in DESIGN.md "Rigid-body derivatives".
 #pragma once
+#include <cstddef>
 #include "smpc_math.h"
 #include "smpc_model.h"
 #include <type_traits>
@@ -24,6 +25,7 @@ namespace smpc
   template <class D>
   struct KinoScratchEval
   {
+    DevModelSmall<D> ml; // model constants (copied from global memory once per block)
     double x[D::NX], u[D::NU];
     double oR[D::NJ * 9], op[D::NJ * 3];
     double S[D::NV * 6];
@@ -84,6 +86,24 @@ namespace smpc
     long long * tprev = nullptr;
   };
 
+  // copy the small model block into the block's LDS scratch (call inside the block's load phase)
+  template <class D, int NT, class Scratch>
+  SMPC_DEV void lanes_load_model(Scratch & sc, const DevModel<D> * gm, int lane)
+  {
+    constexpr int N = (int)(sizeof(DevModelSmall<D>) / sizeof(double)), PER = (N + NT - 1) / NT;
+    static_assert(sizeof(DevModelSmall<D>) % sizeof(double) == 0, "LDS copy is done in doubles");
+    const double * src = reinterpret_cast<const double *>(static_cast<const DevModelSmall<D> *>(gm));
+    double * dst = reinterpret_cast<double *>(&sc.ml);
+    double r[PER]; // all loads in flight before the first store (a rolled loop would serialise the latencies)
+#pragma unroll
+    for (int n = 0; n < PER; n++)
+      r[n] = src[lane + n * NT < N ? lane + n * NT : 0];
+#pragma unroll
+    for (int n = 0; n < PER; n++)
+      if (lane + n * NT < N)
+        dst[lane + n * NT] = r[n];
+  }
+
   // ---------------------------------------------------------------------------------------------
   // Tree + dynamics phases.  On return (all lanes synchronised) the scratch holds: kinematics,
   // composite quantities, Ag, hg, b0, hd, Agbi, a, xnext.  If DERIV, also acc/Fc for the solved
@@ -94,119 +114,153 @@ namespace smpc
   {
     constexpr int NT = 64;
     constexpr int NJ = D::NJ, NV = D::NV, NQ = D::NQ, NF = D::NF;
-    const DevModel<D> & md = *in.md;
+    const DevModelSmall<D> & md = sc.ml;
+    const DevModel<D> & mg = *in.md;
+    (void)mg;
     const int nlev = md.nlevels;
 
-    // ---- root -> leaf pass, fused: per joint (one lane) placement, motion column(s), world inertia, velocity,
-    //      bias acceleration (a = 0), own momentum and net force; values stay in registers within the lane ----
+    // ---- root -> leaf pass.  A SIMD pass costs the same with 1 or 64 active lanes, so only what really depends on
+    //      the parent runs level by level (placement, motion column, velocity, bias acceleration: ~80 flops);
+    //      the joint-local part before and the inertia / momentum / force part after run once for all joints ----
     const double * vq = &sc.x[NQ];
-    SMPC_PL(double, sn_j, NT);
-    SMPC_PL(double, cs_j, NT);
+    SMPC_PLA(double, rl, NT, 9); // jpR * Rq of this lane's joint
     SMPC_LANES(NT)
-    if (lane > 0 && lane < NJ)
+    if (lane < NJ)
     {
-      const double ang = sc.x[6 + lane];
-      SMPC_PLV(sn_j) = sin(ang);
-      SMPC_PLV(cs_j) = cos(ang);
+      const int j = lane;
+      if (j == 0)
+      {
+        const M3 R = quat_to_R(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]});
+        const V3 p = ld3(sc.x);
+        SV v = sv0();
+        for (int k = 0; k < 6; k++)
+        {
+          const int col = k % 3;
+          const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
+          const SV sk = k < 3 ? SV{ax, mk3(0, 0, 0)} : SV{cross(p, ax), ax};
+          stsv(&sc.S[k * 6], sk);
+          v = v + vq[k] * sk;
+        }
+        stm3(&sc.oR[0], R);
+        st3(&sc.op[0], p);
+        stsv(&sc.vel[0], v);
+        stsv(&sc.acc[0], sv0());
+      }
+      else
+      {
+        const double ang = sc.x[6 + j];
+        const double s = sin(ang), c = cos(ang);
+        const int jt = md.jtype[j];
+        const M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -s, 0, s, c} : (jt == 2 ? M3{c, 0, s, 0, 1, 0, -s, 0, c} : M3{c, -s, 0, s, c, 0, 0, 0, 1});
+        const M3 Rl = ldm3(md.jpR[j]) * Rq;
+        stm3(SMPC_PLV(rl), Rl);
+      }
     }
-    SMPC_LANES_END
-    for (int lvl = 0; lvl < nlev; lvl++)
+    SMPC_LANES_END_WAVE
+    for (int lvl = 1; lvl < nlev; lvl++)
     {
       SMPC_LANES(NT)
-      if (lane < NJ && md.level[lane] == lvl)
+      if (lane > 0 && lane < NJ && md.level[lane] == lvl)
       {
         const int j = lane;
-        M3 R;
-        V3 p;
-        SV v, a;
-        if (j == 0)
-        {
-          R = quat_to_R(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]});
-          p = ld3(sc.x);
-          v = sv0();
-          for (int k = 0; k < 6; k++)
-          {
-            const int col = k % 3;
-            const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
-            const SV sk = k < 3 ? SV{ax, mk3(0, 0, 0)} : SV{cross(p, ax), ax};
-            stsv(&sc.S[k * 6], sk);
-            v = v + vq[k] * sk;
-          }
-          a = sv0();
-        }
-        else
-        {
-          const int par = md.parent[j];
-          const double s = SMPC_PLV(sn_j), c = SMPC_PLV(cs_j);
-          const int jt = md.jtype[j];
-          const M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -s, 0, s, c} : (jt == 2 ? M3{c, 0, s, 0, 1, 0, -s, 0, c} : M3{c, -s, 0, s, c, 0, 0, 0, 1});
-          const M3 Rp = ldm3(&sc.oR[par * 9]);
-          R = Rp * (ldm3(md.jpR[j]) * Rq);
-          p = ld3(&sc.op[par * 3]) + Rp * ld3(md.jpp[j]);
-          const int col = jt - 1;
-          const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
-          const SV sk = SV{cross(p, ax), ax};
-          stsv(&sc.S[(j + 5) * 6], sk);
-          const SV vp = ldsv(&sc.vel[par * 6]);
-          v = vp + vq[j + 5] * sk;
-          a = ldsv(&sc.acc[par * 6]) + vq[j + 5] * crm(vp, sk);
-        }
+        const int par = md.parent[j];
+        const M3 Rp = ldm3(&sc.oR[par * 9]);
+        const M3 R = Rp * ldm3(SMPC_PLV(rl));
+        const V3 p = ld3(&sc.op[par * 3]) + Rp * ld3(md.jpp[j]);
+        const int col = md.jtype[j] - 1;
+        const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
+        const SV sk = SV{cross(p, ax), ax};
+        const SV vp = ldsv(&sc.vel[par * 6]);
+        const double qd = vq[j + 5];
         stm3(&sc.oR[j * 9], R);
         st3(&sc.op[j * 3], p);
-        stsv(&sc.vel[j * 6], v);
-        stsv(&sc.acc[j * 6], a);
-        // world inertia about the origin
-        const double m = md.mass[j];
-        const V3 c = R * ld3(md.com[j]) + p;
-        const double * il = md.inertia[j];
-        const M3 Il = M3{il[0], il[1], il[3], il[1], il[2], il[4], il[3], il[4], il[5]};
-        const M3 Iw = R * Il * transpose(R);
-        const double cc = dot(c, c);
-        SI I;
-        I.m = m;
-        I.mc = m * c;
-        I.jxx = Iw.a00 + m * (cc - c.x * c.x);
-        I.jxy = Iw.a01 - m * c.x * c.y;
-        I.jxz = Iw.a02 - m * c.x * c.z;
-        I.jyy = Iw.a11 + m * (cc - c.y * c.y);
-        I.jyz = Iw.a12 - m * c.y * c.z;
-        I.jzz = Iw.a22 + m * (cc - c.z * c.z);
-        stsi(&sc.I[j * 10], I);
-        stsi(&sc.Ic[j * 10], I);
-        const SV h = I * v;
-        stsv(&sc.h[j * 6], h);
-        stsv(&sc.hc[j * 6], h);
-        stsv(&sc.Fc[j * 6], I * a + crf(v, h));
-        for (int f = 0; f < NF; f++)
-          if (md.foot_joint[f] == j)
-            st3(&sc.footp[f * 3], R * ld3(md.foot_p[f]) + p);
+        stsv(&sc.S[(j + 5) * 6], sk);
+        stsv(&sc.vel[j * 6], vp + qd * sk);
+        stsv(&sc.acc[j * 6], ldsv(&sc.acc[par * 6]) + qd * crm(vp, sk));
       }
-      SMPC_LANES_END
+      SMPC_LANES_END_WAVE
     }
-    if (in.prof) prof_tick(in.prof, 16, *in.tprev);
-    // ---- composites, leaf -> root: parents gather their children ----
-    for (int lvl = nlev - 2; lvl >= 0; lvl--)
+    SMPC_LANES(NT)
+    if (lane < NJ)
     {
-      SMPC_LANES(NT)
-      if (lane < NJ && md.level[lane] == lvl)
-      {
-        const int j = lane;
-        SI Ic = ldsi(&sc.Ic[j * 10]);
-        SV hc = ldsv(&sc.hc[j * 6]);
-        SV Fc = ldsv(&sc.Fc[j * 6]);
-        for (int c = j + 1; c < NJ; c++)
-          if (md.parent[c] == j)
-          {
-            Ic = Ic + ldsi(&sc.Ic[c * 10]);
-            hc = hc + ldsv(&sc.hc[c * 6]);
-            Fc = Fc + ldsv(&sc.Fc[c * 6]);
-          }
-        stsi(&sc.Ic[j * 10], Ic);
-        stsv(&sc.hc[j * 6], hc);
-        stsv(&sc.Fc[j * 6], Fc);
-      }
-      SMPC_LANES_END
+      const int j = lane;
+      const M3 R = ldm3(&sc.oR[j * 9]);
+      const V3 p = ld3(&sc.op[j * 3]);
+      const SV v = ldsv(&sc.vel[j * 6]), a = ldsv(&sc.acc[j * 6]);
+      // world inertia about the origin
+      const double m = md.mass[j];
+      const V3 c = R * ld3(md.com[j]) + p;
+      const double * il = md.inertia[j];
+      const M3 Il = M3{il[0], il[1], il[3], il[1], il[2], il[4], il[3], il[4], il[5]};
+      const M3 Iw = R * Il * transpose(R);
+      const double cc = dot(c, c);
+      SI I;
+      I.m = m;
+      I.mc = m * c;
+      I.jxx = Iw.a00 + m * (cc - c.x * c.x);
+      I.jxy = Iw.a01 - m * c.x * c.y;
+      I.jxz = Iw.a02 - m * c.x * c.z;
+      I.jyy = Iw.a11 + m * (cc - c.y * c.y);
+      I.jyz = Iw.a12 - m * c.y * c.z;
+      I.jzz = Iw.a22 + m * (cc - c.z * c.z);
+      stsi(&sc.I[j * 10], I);
+      stsi(&sc.Ic[j * 10], I);
+      const SV h = I * v;
+      stsv(&sc.h[j * 6], h);
+      stsv(&sc.hc[j * 6], h);
+      stsv(&sc.Fc[j * 6], I * a + crf(v, h));
     }
+    else if (lane >= 32 && lane < 32 + NF)
+    {
+      const int f = lane - 32, j = md.foot_joint[f];
+      st3(&sc.footp[f * 3], ldm3(&sc.oR[j * 9]) * ld3(md.foot_p[f]) + ld3(&sc.op[j * 3]));
+    }
+    SMPC_LANES_END_WAVE
+    if (in.prof) prof_tick(in.prof, 16, *in.tprev);
+    // ---- per-body "velocity product" matrices  B_l y = v_l x* (I_l y) - I_l (v_l x y)  (lane = (body, column));
+    //      their subtree sums give the sums over subtree bodies in the derivative columns as two 6x6 products.
+    //      They live in the block the weighted-Jacobian tables take over later. ----
+    double * Bm = nullptr;
+    if constexpr (DERIV)
+    {
+      static_assert(D::NDX * 6 + 6 * D::NDX + 36 + 6 * D::NDX >= NJ * 36, "B matrices overlay WJl | JtW | JWJ | WJc");
+      static_assert(offsetof(KinoScratchDerivPart<D>, WJc) - offsetof(KinoScratchDerivPart<D>, WJl) == (D::NDX * 12 + 36) * sizeof(double),
+                    "table block must be contiguous");
+      Bm = sc.WJl;
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < NJ * 6; idx += NT)
+      {
+        const int l = idx / 6, m = idx % 6;
+        const SI Il = ldsi(&sc.I[l * 10]);
+        const SV vl = ldsv(&sc.vel[l * 6]);
+        const V3 e = mk3(m % 3 == 0, m % 3 == 1, m % 3 == 2), z = mk3(0, 0, 0);
+        const SV y = m < 3 ? SV{e, z} : SV{z, e};
+        const SV col = crf(vl, Il * y) - Il * crm(vl, y);
+        double * dst = &Bm[l * 36 + m];
+        dst[0] = col.l.x;
+        dst[6] = col.l.y;
+        dst[12] = col.l.z;
+        dst[18] = col.a.x;
+        dst[24] = col.a.y;
+        dst[30] = col.a.z;
+      }
+      SMPC_LANES_END_WAVE
+    }
+    // ---- composites, leaf -> root: lane = one scalar of (Ic | hc | Fc | B), walking the joints in reverse
+    //      topological order (parent < child) ----
+    SMPC_LANES(NT)
+    if (lane < 22 + (DERIV ? 36 : 0))
+    {
+      double * base = lane < 10 ? sc.Ic : (lane < 16 ? sc.hc : (lane < 22 ? sc.Fc : Bm));
+      const int stride = lane < 10 ? 10 : (lane < 22 ? 6 : 36);
+      const int e = lane < 10 ? lane : (lane < 16 ? lane - 10 : (lane < 22 ? lane - 16 : lane - 22));
+      for (int j = NJ - 1; j >= 1; j--)
+      {
+        const int par = md.parent[j];
+        base[par * stride + e] += base[j * stride + e];
+      }
+    }
+    SMPC_LANES_END_WAVE
     if (in.prof) prof_tick(in.prof, 19, *in.tprev);
     // ---- CoM, centroidal map columns, hg, b0, hdot target, 6x6 inertia for the base solve ----
     SMPC_LANES(NT)
@@ -281,7 +335,7 @@ namespace smpc
       }
     if (in.prof) prof_tick(in.prof, 20, *in.tprev);
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     // ---- in-place Gauss-Jordan inverse of the SPD 6x6 (36 lanes, ping-pong gjA <-> gjB) ----
     for (int pv = 0; pv < 6; pv++)
     {
@@ -299,7 +353,7 @@ namespace smpc
           val = (c == pv) ? -src[r * 6 + pv] * piv : src[r * 6 + c] - src[r * 6 + pv] * src[pv * 6 + c] * piv;
         dst[lane] = val;
       }
-      SMPC_LANES_END
+      SMPC_LANES_END_WAVE
     }
     if (in.prof) prof_tick(in.prof, 21, *in.tprev);
     // after 6 steps the inverse sits in gjA.  M1 = Ic0^-1 * T(c)^-1  with T^-1 = [[I,0],[[c]x, I]]
@@ -320,7 +374,7 @@ namespace smpc
       sc.gjB[lane] = val;
     if (in.prof) prof_tick(in.prof, 22, *in.tprev);
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     // Agbi = X0^-1 * M1,  X0^-1 = [[R^T, -R^T [p]x],[0, R^T]]
     SMPC_LANES(NT)
     if (lane < 36)
@@ -339,7 +393,7 @@ namespace smpc
       sc.Agbi[lane] = rr == 0 ? out.x : (rr == 1 ? out.y : out.z);
     if (in.prof) prof_tick(in.prof, 22, *in.tprev);
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     // ---- base acceleration ----
     SMPC_LANES(NT)
     if (lane < NV)
@@ -361,13 +415,13 @@ namespace smpc
       sc.a[lane] = val;
     if (in.prof) prof_tick(in.prof, 23, *in.tprev);
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     if (in.terminal)
     {
       SMPC_LANES(NT)
       if (lane < NV)
         sc.a[lane] = 0.0;
-      SMPC_LANES_END
+      SMPC_LANES_END_WAVE
     }
     // ---- x+ = x (+) [dt (v + dt a); dt a] ----
     SMPC_LANES(NT)
@@ -396,45 +450,46 @@ namespace smpc
       }
     if (in.prof) prof_tick(in.prof, 24, *in.tprev);
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
 
     if constexpr (DERIV)
     {
     // ---- accelerations and composite net forces for the solved a, without another tree sweep:
     //      acc_i(a) = acc_i(0) + sum_{k <= i} a_k S_k
     //      Fc_i(a)  = Fc_i(0) + sum_{k <= i} a_k Ic_i S_k + sum_{k strictly below i} a_k Ic_{j(k)} S_k ----
+    //      With aS_k = a_k S_k and dacc_i = sum_{k <= i} aS_k the middle term is Ic_i dacc_i; the last one sums
+    //      the per-dof vectors Ic_{j(k)} aS_k.  Both per-dof vectors are formed once (lane = dof), then lane = joint
+    //      only adds (the scratch of the constraint derivatives, written later, holds them meanwhile).
+    double * aS = sc.dcq;  // [NV][6]
+    double * IaS = sc.dcv; // [NV][6]
+    static_assert(NF * 3 >= 6, "temporary storage");
     SMPC_LANES(NT)
+    if (lane < NV)
     {
-      if (lane < NJ)
-      {
-        const int i = lane;
-        SV acc = ldsv(&sc.acc[i * 6]);
-        for (int k = 0; k < NV; k++)
-        {
-          const int jk = k < 6 ? 0 : k - 5;
-          if ((md.anc[i] >> jk) & 1u)
-            acc = acc + sc.a[k] * ldsv(&sc.S[k * 6]);
-        }
-        stsv(&sc.acc[i * 6], acc);
-      }
-      else if (lane >= 32 && lane < 32 + NJ)
-      {
-        const int i = lane - 32;
-        SV F = ldsv(&sc.Fc[i * 6]);
-        const SI Ici = ldsi(&sc.Ic[i * 10]);
-        for (int k = 0; k < NV; k++)
-        {
-          const int jk = k < 6 ? 0 : k - 5;
-          const SV sk = ldsv(&sc.S[k * 6]);
-          if ((md.anc[i] >> jk) & 1u)
-            F = F + sc.a[k] * (Ici * sk);
-          else if ((md.anc[jk] >> i) & 1u)
-            F = F + sc.a[k] * (ldsi(&sc.Ic[jk * 10]) * sk);
-        }
-        stsv(&sc.Fc[i * 6], F); // each lane reads and writes only its own Fc_i: no cross-lane hazard
-      }
+      const int k = lane, jk = k < 6 ? 0 : k - 5;
+      const SV ask = sc.a[k] * ldsv(&sc.S[k * 6]);
+      stsv(&aS[k * 6], ask);
+      stsv(&IaS[k * 6], ldsi(&sc.Ic[jk * 10]) * ask);
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane < NJ)
+    {
+      const int i = lane;
+      const unsigned anci = md.anc[i];
+      SV dacc = sv0(), sub = sv0();
+      for (int k = 0; k < NV; k++)
+      {
+        const int jk = k < 6 ? 0 : k - 5;
+        if ((anci >> jk) & 1u)
+          dacc = dacc + ldsv(&aS[k * 6]);
+        else if ((md.anc[jk] >> i) & 1u)
+          sub = sub + ldsv(&IaS[k * 6]);
+      }
+      stsv(&sc.acc[i * 6], ldsv(&sc.acc[i * 6]) + dacc);
+      stsv(&sc.Fc[i * 6], ldsv(&sc.Fc[i * 6]) + ldsi(&sc.Ic[i * 10]) * dacc + sub);
+    }
+    SMPC_LANES_END_WAVE
     if (in.prof) prof_tick(in.prof, 26, *in.tprev);
     // ---- derivative columns: lane k < NV ----
     SMPC_LANES(NT)
@@ -453,17 +508,30 @@ namespace smpc
         d = crm(vl, s);
         Ak = crm(ldsv(&sc.acc[lam * 6]), s) + crm(vl, d);
       }
-      // sum over subtree bodies of  v_l x* (I_l y) - I_l (v_l x y)  for y = S_k and y = d_k
-      SV BS = sv0(), Bd = sv0();
-      for (int l = i; l < NJ; l++)
-        if ((md.anc[l] >> i) & 1u)
+      // sum over subtree bodies of  v_l x* (I_l y) - I_l (v_l x y)  for y = S_k and y = d_k: composite B_i y
+      SV BS, Bd;
+      {
+        const double * Bc = &Bm[i * 36];
+        const double sv[6] = {s.l.x, s.l.y, s.l.z, s.a.x, s.a.y, s.a.z};
+        const double dv[6] = {d.l.x, d.l.y, d.l.z, d.a.x, d.a.y, d.a.z};
+        double o1[6], o2[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
         {
-          const SI Il = ldsi(&sc.I[l * 10]);
-          const SV vl = ldsv(&sc.vel[l * 6]);
-          BS = BS + crf(vl, Il * s) - Il * crm(vl, s);
-          if (lam >= 0)
-            Bd = Bd + crf(vl, Il * d) - Il * crm(vl, d);
+          double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+          for (int m = 0; m < 6; m++)
+          {
+            const double bv = Bc[r * 6 + m];
+            a1 += bv * sv[m];
+            a2 += bv * dv[m];
+          }
+          o1[r] = a1;
+          o2[r] = a2;
         }
+        BS = SV{mk3(o1[0], o1[1], o1[2]), mk3(o1[3], o1[4], o1[5])};
+        Bd = SV{mk3(o2[0], o2[1], o2[2]), mk3(o2[3], o2[4], o2[5])};
+      }
       const SV hci = ldsv(&sc.hc[i * 6]);
       BS = BS + crf(s, hci);
       Bd = Bd + crf(d, hci);
@@ -532,7 +600,7 @@ namespace smpc
       sc.dtgt[2 * NV + k] = dt_ang.z;
     if (in.prof) prof_tick(in.prof, 27, *in.tprev);
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     // ---- base-acceleration derivatives: Agbi * [dtgt - dhd_dq | -dhd_dv | G_f | -Ag_j] ----
     SMPC_LANES(NT)
     {
@@ -607,7 +675,7 @@ namespace smpc
           }
       }
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     if (in.prof) prof_tick(in.prof, 28, *in.tprev);
     } // if constexpr (DERIV)
   }
@@ -654,7 +722,9 @@ namespace smpc
     constexpr int NT = 64;
     constexpr int NV = D::NV, NF = D::NF, NU = D::NU, NDX = D::NDX, NA = D::NA, NC = D::NC;
     static_assert(NV <= 20 && NF * 3 <= 12 && NU <= 24 && NF <= 8 && NDX <= 40, "lane map of this kernel assumes a Go2-sized robot");
-    const DevModel<D> & md = *in.md;
+    const DevModelSmall<D> & md = sc.ml;
+    const DevModel<D> & mg = *in.md;
+    (void)mg;
     SMPC_LANES(NT)
     {
       kino_state_residual<D, DERIV>(sc, in.x_tgt, lane);
@@ -684,7 +754,7 @@ namespace smpc
         }
       }
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
     {
       // weighted residuals
@@ -692,7 +762,7 @@ namespace smpc
       {
         double s = 0.0;
         for (int j = 0; j < NDX; j++)
-          s += md.w_x[lane * NDX + j] * sc.rx[j];
+          s += mg.w_x[lane * NDX + j] * sc.rx[j];
         sc.Wrx[lane] = s;
       }
       if (lane >= 40 && lane < 46)
@@ -724,7 +794,7 @@ namespace smpc
         }
       }
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     if (!in.terminal)
     {
       SMPC_LANES(NT)
@@ -732,10 +802,10 @@ namespace smpc
       {
         double s = 0.0;
         for (int j = 0; j < NU; j++)
-          s += md.w_u[lane * NU + j] * sc.ru[j];
+          s += mg.w_u[lane * NU + j] * sc.ru[j];
         sc.Wru[lane] = s;
       }
-      SMPC_LANES_END
+      SMPC_LANES_END_WAVE
     }
     SMPC_LANES(NT)
     if (lane == 0)
@@ -756,7 +826,7 @@ namespace smpc
       }
       sc.red[0] = 0.5 * c;
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     (void)NC;
   }
 
@@ -768,7 +838,9 @@ namespace smpc
   {
     constexpr int NT = 64;
     constexpr int NDX = D::NDX, NC = D::NC, NA = D::NA;
-    const DevModel<D> & md = *in.md;
+    const DevModelSmall<D> & md = sc.ml;
+    const DevModel<D> & mg = *in.md;
+    (void)mg;
     const double mu = md.mu;
     SMPC_LANES(NT)
     {
@@ -796,7 +868,7 @@ namespace smpc
         sc.act[i] = act;
       }
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
     if (lane == 0)
     {
@@ -824,6 +896,6 @@ namespace smpc
       sc.red[1] = pen;
       sc.red[2] = prim;
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
   }
 } // namespace smpc

@@ -49,36 +49,45 @@ namespace smpc
   };
 
   // Model + settings, device resident (one copy per handle).
+  // Model constants.  The "small" part (tree tables, small weights, scalars: 3.6 KB) is copied into LDS by every
+  // rigid-body kernel block at start, so that no phase of the tree algorithms waits on a global load; the large
+  // weight matrices stay in global memory (L2-resident, read in the assembly phases only).
   template <class D>
-  struct DevModel
+  struct DevModelSmall
   {
-    int parent[D::NJ];
-    int jtype[D::NJ];
-    int level[D::NJ];
-    int nlevels;
-    unsigned anc[D::NJ]; // bit a set <=> joint a is an ancestor-or-self of joint j
     double jpR[D::NJ][9];
     double jpp[D::NJ][3];
     double mass[D::NJ];
     double com[D::NJ][3];
     double inertia[D::NJ][6];
-    int foot_joint[D::NF];
     double foot_p[D::NF][3];
     double foot_ref_p[D::NF][3];
     double total_mass;
     // KinodynamicsSettings (include/simple-mpc/kinodynamics.hpp:24-51)
     double dt;
     double gravity[3];
-    double w_x[D::NDX * D::NDX];
-    double w_u[D::NU * D::NU];
     double w_frame[9];
     double w_cent[36];
     double w_centder[36];
     double qmin[D::NA];
     double qmax[D::NA];
-    int kinematics_limits;
     // solver
     double mu;
+    int parent[D::NJ];
+    int jtype[D::NJ];
+    int level[D::NJ];
+    unsigned anc[D::NJ];      // bit a set <=> joint a is an ancestor-or-self of joint j
+    unsigned children[D::NJ]; // bit c set <=> parent[c] == j
+    int foot_joint[D::NF];
+    int nlevels;
+    int kinematics_limits;
+    int pad_[2 + (5 * D::NJ + D::NF) % 2]; // keeps sizeof a multiple of 8
+  };
+  template <class D>
+  struct DevModel : DevModelSmall<D>
+  {
+    double w_x[D::NDX * D::NDX];
+    double w_u[D::NU * D::NU];
     // terminal state_cost target (model reference state)
     double x_term[D::NX];
   };
