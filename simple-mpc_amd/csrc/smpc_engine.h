@@ -199,6 +199,12 @@ namespace smpc
         m.gravity[i] = ks.gravity[i];
       std::copy(ks.w_x.begin(), ks.w_x.end(), m.w_x);
       std::copy(ks.w_u.begin(), ks.w_u.end(), m.w_u);
+      for (int i = 0; i < D::NDX; i++)
+        for (int j = 0; j < D::NDX; j++)
+          m.w_xT[j * D::NDX + i] = m.w_x[i * D::NDX + j];
+      for (int i = 0; i < D::NU; i++)
+        for (int j = 0; j < D::NU; j++)
+          m.w_uT[j * D::NU + i] = m.w_u[i * D::NU + j];
       std::copy(ks.w_frame.begin(), ks.w_frame.end(), m.w_frame);
       std::copy(ks.w_cent.begin(), ks.w_cent.end(), m.w_cent);
       std::copy(ks.w_centder.begin(), ks.w_centder.end(), m.w_centder);

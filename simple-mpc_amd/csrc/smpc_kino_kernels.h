@@ -103,18 +103,25 @@ namespace smpc
 
     SMPC_LANES(NT)
     {
+      // all global loads of the block are issued back to back (index clamped, one wait), then committed to LDS
+      static_assert(NX <= NT && NU <= NT && NDX <= NT && NC <= NT, "one element per lane");
+      const double vx = xg[lane < NX ? lane : 0];
+      const double vu = b.us[(ib + st) * NU + (lane < NU ? lane : 0)];
+      const double vl = b.lams[(ib + st) * NDX + (lane < NDX ? lane : 0)];
+      const double vlp = b.lams[(ib + sprev) * NDX + (lane < NDX ? lane : 0)];
+      const double vn = b.vs[(ib + st) * NC + (lane < NC ? lane : 0)];
       lanes_load_model<D, NT>(sc, &mg, lane);
-      for (int i = lane; i < NX; i += NT)
-        sc.x[i] = xg[i];
-      for (int i = lane; i < NU; i += NT)
-        sc.u[i] = term ? 0.0 : b.us[(ib + st) * NU + i];
-      for (int i = lane; i < NDX; i += NT)
+      if (lane < NX)
+        sc.x[lane] = vx;
+      if (lane < NU)
+        sc.u[lane] = term ? 0.0 : vu;
+      if (lane < NDX)
       {
-        sc.lam_next[i] = term ? 0.0 : b.lams[(ib + st) * NDX + i];
-        sc.lam_prev[i] = t > 0 ? b.lams[(ib + sprev) * NDX + i] : 0.0;
+        sc.lam_next[lane] = term ? 0.0 : vl;
+        sc.lam_prev[lane] = t > 0 ? vlp : 0.0;
       }
-      for (int i = lane; i < NC; i += NT)
-        sc.nu[i] = term ? 0.0 : b.vs[(ib + st) * NC + i];
+      if (lane < NC)
+        sc.nu[lane] = term ? 0.0 : vn;
     }
     SMPC_LANES_END_WAVE
 

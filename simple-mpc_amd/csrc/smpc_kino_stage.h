@@ -45,6 +45,7 @@ namespace smpc
     double vplus[D::NC], lamp[D::NDX], lam_next[D::NDX], lam_prev[D::NDX], nu[D::NC];
     int act[D::NC];
     double red[8];
+    double part[64], part2[64], part8[16]; // wave reductions: 64 partials -> 8 -> 1 (fixed order)
   };
   template <class D>
   struct KinoScratchDerivPart
@@ -601,29 +602,33 @@ namespace smpc
     if (in.prof) prof_tick(in.prof, 27, *in.tprev);
     }
     SMPC_LANES_END_WAVE
-    // ---- base-acceleration derivatives: Agbi * [dtgt - dhd_dq | -dhd_dv | G_f | -Ag_j] ----
+    // ---- base-acceleration derivatives: Agbi * [dtgt - dhd_dq | -dhd_dv | G_f | -Ag_j]; lane = column ----
     SMPC_LANES(NT)
     {
       constexpr int NCOL = 2 * NV + D::NU;
-      for (int idx = lane; idx < 6 * NCOL; idx += NT)
+      static_assert(NCOL <= NT - 2, "one lane per column, two spare lanes");
+      if (lane < NCOL)
       {
-        const int r = idx / NCOL, c = idx % NCOL;
-        double acc = 0.0;
+        const int c = lane;
+        double rhs[6] = {0, 0, 0, 0, 0, 0};
+        double * dst;
+        int ld;
         if (c < NV)
         {
+#pragma unroll
           for (int m = 0; m < 6; m++)
-          {
-            const double rq = (m >= 3 ? sc.dtgt[(m - 3) * NV + c] : 0.0) - sc.dhd_dq[m * NV + c];
-            acc += sc.Agbi[r * 6 + m] * rq;
-          }
-          sc.ab_dq[r * NV + c] = acc;
+            rhs[m] = (m >= 3 ? sc.dtgt[(m - 3) * NV + c] : 0.0) - sc.dhd_dq[m * NV + c];
+          dst = &sc.ab_dq[c];
+          ld = NV;
         }
         else if (c < 2 * NV)
         {
           const int k = c - NV;
+#pragma unroll
           for (int m = 0; m < 6; m++)
-            acc -= sc.Agbi[r * 6 + m] * sc.dhd_dv[m * NV + k];
-          sc.ab_dv[r * NV + k] = acc;
+            rhs[m] = -sc.dhd_dv[m * NV + k];
+          dst = &sc.ab_dv[k];
+          ld = NV;
         }
         else
         {
@@ -636,16 +641,32 @@ namespace smpc
               const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
               const V3 e = mk3(jj == 0, jj == 1, jj == 2);
               const V3 xc = cross(rr, e); // column jj of [rr]x
-              acc = sc.Agbi[r * 6 + jj] + sc.Agbi[r * 6 + 3] * xc.x + sc.Agbi[r * 6 + 4] * xc.y + sc.Agbi[r * 6 + 5] * xc.z;
+              rhs[0] = e.x;
+              rhs[1] = e.y;
+              rhs[2] = e.z;
+              rhs[3] = xc.x;
+              rhs[4] = xc.y;
+              rhs[5] = xc.z;
             }
           }
           else
           {
             const int kk = k - 3 * NF + 6;
+#pragma unroll
             for (int m = 0; m < 6; m++)
-              acc -= sc.Agbi[r * 6 + m] * sc.Ag[m * NV + kk];
+              rhs[m] = -sc.Ag[m * NV + kk];
           }
-          sc.ab_du[r * D::NU + k] = acc;
+          dst = &sc.ab_du[k];
+          ld = D::NU;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+        {
+          double acc = 0.0;
+#pragma unroll
+          for (int m = 0; m < 6; m++)
+            acc += sc.Agbi[r * 6 + m] * rhs[m];
+          dst[r * ld] = acc;
         }
       }
       // integrator Jacobians on two spare lanes
@@ -761,8 +782,9 @@ namespace smpc
       if (lane < NDX)
       {
         double s = 0.0;
+#pragma unroll 6
         for (int j = 0; j < NDX; j++)
-          s += mg.w_x[lane * NDX + j] * sc.rx[j];
+          s += mg.w_xT[j * NDX + lane] * sc.rx[j];
         sc.Wrx[lane] = s;
       }
       if (lane >= 40 && lane < 46)
@@ -801,32 +823,51 @@ namespace smpc
       if (lane < NU)
       {
         double s = 0.0;
+#pragma unroll 6
         for (int j = 0; j < NU; j++)
-          s += mg.w_u[lane * NU + j] * sc.ru[j];
+          s += mg.w_uT[j * NU + lane] * sc.ru[j];
         sc.Wru[lane] = s;
       }
       SMPC_LANES_END_WAVE
     }
+    // cost = 1/2 sum of r_i (W r)_i over all residual groups: one term pair per lane, then a fixed-order reduction
+    SMPC_LANES(NT)
+    {
+      double c = 0.0;
+      if (lane < NDX)
+        c = sc.rx[lane] * sc.Wrx[lane];
+      else if (lane < NDX + 6)
+        c = sc.hg[lane - NDX] * sc.Whg[lane - NDX];
+      else if (!in.terminal && lane < NDX + 12)
+        c = sc.hd[lane - NDX - 6] * sc.Whd[lane - NDX - 6];
+      else if (!in.terminal && lane < NDX + 12 + NF * 3)
+        c = sc.rf[lane - NDX - 12] * sc.Wrf[lane - NDX - 12];
+      if (!in.terminal && lane < NU)
+        c += sc.ru[lane] * sc.Wru[lane];
+      sc.part[lane] = c;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane < 8)
+    {
+      double c = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        c += sc.part[lane * 8 + i];
+      sc.part8[lane] = c;
+    }
+    SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
     if (lane == 0)
     {
       double c = 0.0;
-      for (int i = 0; i < NDX; i++)
-        c += sc.rx[i] * sc.Wrx[i];
-      for (int i = 0; i < 6; i++)
-        c += sc.hg[i] * sc.Whg[i];
-      if (!in.terminal)
-      {
-        for (int i = 0; i < NU; i++)
-          c += sc.ru[i] * sc.Wru[i];
-        for (int i = 0; i < 6; i++)
-          c += sc.hd[i] * sc.Whd[i];
-        for (int i = 0; i < NF * 3; i++)
-          c += sc.rf[i] * sc.Wrf[i];
-      }
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        c += sc.part8[i];
       sc.red[0] = 0.5 * c;
     }
     SMPC_LANES_END_WAVE
+    static_assert(NDX + 12 + NF * 3 <= NT, "one residual term per lane");
     (void)NC;
   }
 
@@ -869,29 +910,57 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
+    // merit penalty and primal infeasibility: lane i < NDX takes dynamics row i, lane NDX + i constraint row i
+    static_assert(NDX + NC <= NT, "one row per lane");
+    SMPC_LANES(NT)
+    {
+      double pen = 0.0, prim = 0.0;
+      if (lane < NDX)
+      {
+        const double lp = sc.lamp[lane], dl = lp - sc.lam_next[lane];
+        pen = 0.5 * mu * (lp * lp + dl * dl);
+        prim = fabs(sc.e[lane]);
+      }
+      else if (lane < NDX + NC)
+      {
+        const int i = lane - NDX;
+        const double vp = sc.vplus[i], dv = vp - sc.nu[i];
+        pen = 0.5 * mu * (vp * vp + dv * dv);
+        if (i < NA)
+        {
+          if (md.kinematics_limits)
+            prim = fmax(fmax(sc.cval[i] - md.qmax[i], md.qmin[i] - sc.cval[i]), 0.0);
+        }
+        else if ((in.mask >> ((i - NA) / 3)) & 1u)
+          prim = fabs(sc.cval[i]);
+      }
+      sc.part[lane] = pen;
+      sc.part2[lane] = prim;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane < 8)
+    {
+      double pen = 0.0, prim = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+      {
+        pen += sc.part[lane * 8 + i];
+        prim = fmax(prim, sc.part2[lane * 8 + i]);
+      }
+      sc.part8[lane] = pen;
+      sc.part8[8 + lane] = prim;
+    }
+    SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
     if (lane == 0)
     {
       double pen = 0.0, prim = 0.0;
-      for (int i = 0; i < NDX; i++)
+#pragma unroll
+      for (int i = 0; i < 8; i++)
       {
-        const double lp = sc.lamp[i], dl = lp - sc.lam_next[i];
-        pen += 0.5 * mu * (lp * lp + dl * dl);
-        prim = fmax(prim, fabs(sc.e[i]));
-      }
-      for (int i = 0; i < NC; i++)
-      {
-        const double vp = sc.vplus[i], dv = vp - sc.nu[i];
-        pen += 0.5 * mu * (vp * vp + dv * dv);
-        double viol = 0.0;
-        if (i < NA)
-        {
-          if (md.kinematics_limits)
-            viol = fmax(fmax(sc.cval[i] - md.qmax[i], md.qmin[i] - sc.cval[i]), 0.0);
-        }
-        else if ((in.mask >> ((i - NA) / 3)) & 1u)
-          viol = fabs(sc.cval[i]);
-        prim = fmax(prim, viol);
+        pen += sc.part8[i];
+        prim = fmax(prim, sc.part8[8 + i]);
       }
       sc.red[1] = pen;
       sc.red[2] = prim;

@@ -88,6 +88,8 @@ namespace smpc
   {
     double w_x[D::NDX * D::NDX];
     double w_u[D::NU * D::NU];
+    double w_xT[D::NDX * D::NDX]; // transposes: lane = row matvecs read them with coalesced loads
+    double w_uT[D::NU * D::NU];
     // terminal state_cost target (model reference state)
     double x_term[D::NX];
   };
