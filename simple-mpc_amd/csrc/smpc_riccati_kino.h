@@ -27,10 +27,9 @@ namespace smpc
   struct GainsK
   {
     static constexpr int NDX = D::NDX, NU = D::NU;
-    static constexpr int G_W = 0;                            // W = L_R^-1 [S^^T | r^]   NU x (NDX+1)
-    static constexpr int G_LR = G_W + NU * (NDX + 1);        // L_R^-1 (lower, row-major, full square) NU x NU
-    static constexpr int G_Pt = G_LR + NU * NU;              // P~ NDX x NDX
-    static constexpr int G_pn = G_Pt + NDX * NDX;            // p_{t+1}
+    static constexpr int G_W = 0;                     // [K | k] = -R^^-1 [S^^T | r^]   NU x (NDX+1)
+    static constexpr int G_Pt = G_W + NU * (NDX + 1); // P~ NDX x NDX
+    static constexpr int G_pn = G_Pt + NDX * NDX;     // p_{t+1}
     static constexpr int STRIDE = ((G_pn + NDX + 7) / 8) * 8;
   };
 
@@ -104,18 +103,148 @@ namespace smpc
     SMPC_LANES_END_WAVE
   }
 
+  // index of the upper tile (I <= J) of an NTI x NTI tile grid, row-major over the upper triangle
+  template <int NTI>
+  SMPC_HD constexpr int tix(int I, int J)
+  {
+    return I * NTI - I * (I - 1) / 2 + (J - I);
+  }
+
+  // Symmetric block sweep (block Gauss-Jordan without pivoting on an SPD pivot block) on the matrix cores, one wave.
+  // T is a symmetric (16 NTI)^2 matrix held as upper 16x16 accumulator tiles (SMPC_ACC, tile tix(I, J)).  The NP
+  // panels of 4 pivots  PIV0 + 4p .. PIV0 + 4p + 3  are swept one after the other:
+  //     P_m := the stored entries pairing index m with the 4 pivots,   D := pivot block,   U_m := D^-1 P_m,
+  //     T[i][j] -= U_i^T P_j   for every stored (i, j)          (one 16x16x4 MFMA per tile: a rank-4 update)
+  //     entries pairing (pivot, m) := U_m                       (ALL only)
+  // Every update is the symmetric bilinear form P_i^T D^-1 P_j, so upper storage needs no sign bookkeeping: after
+  // sweeping a pivot set S the stored entry pairing s in S with an unswept j holds (T_SS^-1 T_Sj)_s, and the unswept
+  // block holds the Schur complement T_jj' - T_jS T_SS^-1 T_Sj'.  ALL = false maintains only the tiles at or beyond
+  // the current pivot's tile row (Schur complement of leading pivots: what a Cholesky-based elimination would give).
+  // prow / urow: LDS, 4 x 16 NTI doubles each.  prof: optional phase timers (slots 36..39).
+  template <int NT, int NTI, bool ALL, int PIV0, int NP, class Acc>
+  SMPC_DEV void wave_block_sweep(Acc & acc, double * prow, double * urow, double * prof, long long & tprev)
+  {
+    constexpr int LDW = 16 * NTI;
+    static_assert(NT == 64 && PIV0 % 4 == 0 && PIV0 + 4 * NP <= LDW && LDW <= 2 * NT, "sweep geometry");
+    SMPC_PLA(double, aop, NT, NTI);
+    SMPC_PLA(double, bop, NT, NTI);
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+    {
+      const int kb = PIV0 + 4 * p, Ip = kb / 16, c0 = kb % 16, vp = c0 / 4;
+      // (a) pivot entries -> prow[k][m]
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int J = Ip; J < NTI; J++)
+          prow[lr * LDW + 16 * J + lc] = SMPC_ACCV(acc, tix<NTI>(Ip, J), vp);
+        if (ALL && lc >= c0 && lc < c0 + 4)
+        {
+#pragma unroll
+          for (int I = 0; I < Ip; I++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+              prow[(lc - c0) * LDW + 16 * I + lr + 4 * v] = SMPC_ACCV(acc, tix<NTI>(I, Ip), v);
+        }
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 36, tprev);
+      // (b) U_m = D^-1 P_m, lane = index m (every lane factors the 4x4 pivot block D = L diag(d) L^T itself)
+      SMPC_LANES(NT)
+      {
+        const double * d = prow + kb;
+        const double D00 = d[0], D01 = d[1], D02 = d[2], D03 = d[3];
+        const double D11 = d[LDW + 1], D12 = d[LDW + 2], D13 = d[LDW + 3];
+        const double D22 = d[2 * LDW + 2], D23 = d[2 * LDW + 3], D33 = d[3 * LDW + 3];
+        const double i0 = SMPC_RCP(D00);
+        const double l10 = D01 * i0, l20 = D02 * i0, l30 = D03 * i0;
+        const double i1 = SMPC_RCP(D11 - l10 * D01);
+        const double t21 = D12 - l20 * D01, t31 = D13 - l30 * D01;
+        const double l21 = t21 * i1, l31 = t31 * i1;
+        const double i2 = SMPC_RCP(D22 - l20 * D02 - l21 * t21);
+        const double t32 = D23 - l30 * D02 - l31 * t21;
+        const double l32 = t32 * i2;
+        const double i3 = SMPC_RCP(D33 - l30 * D03 - l31 * t31 - l32 * t32);
+#pragma unroll
+        for (int rr = 0; rr < (LDW + NT - 1) / NT; rr++)
+        {
+          const int m = lane + rr * NT;
+          if (m < LDW)
+          {
+            const double a0 = prow[m], a1 = prow[LDW + m], a2 = prow[2 * LDW + m], a3 = prow[3 * LDW + m];
+            const double y1 = a1 - l10 * a0;
+            const double y2 = a2 - l20 * a0 - l21 * y1;
+            const double y3 = a3 - l30 * a0 - l31 * y1 - l32 * y2;
+            const double u3 = y3 * i3;
+            const double u2 = y2 * i2 - l32 * u3;
+            const double u1 = y1 * i1 - l21 * u2 - l31 * u3;
+            const double u0 = a0 * i0 - l10 * u1 - l20 * u2 - l30 * u3;
+            urow[m] = u0;
+            urow[LDW + m] = u1;
+            urow[2 * LDW + m] = u2;
+            urow[3 * LDW + m] = u3;
+          }
+        }
+      }
+      SMPC_LANES_END_WAVE
+      prof_tick(prof, 37, tprev);
+      // (c) rank-4 update of every maintained tile
+      const int I0 = ALL ? 0 : Ip;
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int I = I0; I < NTI; I++)
+        {
+          SMPC_PLV(aop)[I] = -urow[lr * LDW + 16 * I + lc];
+          SMPC_PLV(bop)[I] = prow[lr * LDW + 16 * I + lc];
+        }
+      }
+      SMPC_LANES_END_WAVE
+#pragma unroll
+      for (int I = I0; I < NTI; I++)
+#pragma unroll
+        for (int J = I; J < NTI; J++)
+          SMPC_MFMA(acc, tix<NTI>(I, J), aop, I, bop, J);
+      prof_tick(prof, 38, tprev);
+      // (d) pivot entries := U
+      if (ALL)
+      {
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int J = Ip; J < NTI; J++)
+            SMPC_ACCV(acc, tix<NTI>(Ip, J), vp) = urow[lr * LDW + 16 * J + lc];
+          if (lc >= c0 && lc < c0 + 4)
+          {
+#pragma unroll
+            for (int I = 0; I <= Ip; I++)
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+                if (I < Ip || v != vp)
+                  SMPC_ACCV(acc, tix<NTI>(I, Ip), v) = urow[(lc - c0) * LDW + 16 * I + lr + 4 * v];
+          }
+        }
+        SMPC_LANES_END_WAVE
+        prof_tick(prof, 39, tprev);
+      }
+    }
+  }
+
   template <class D>
   struct RiccatiKinoLds
   {
     static constexpr int NDX = D::NDX, NU = D::NU, NXU = D::NDX + D::NU, NG = 12;
-    static constexpr int SCR_Y = NDX * (NDX + 1), SCR_G = 3 * NG * NXU, SCR_W = NDX * NU + NU * (NDX + 1) + NU * NU;
-    static constexpr int SCR = SCR_Y > SCR_G ? (SCR_Y > SCR_W ? SCR_Y : SCR_W) : (SCR_G > SCR_W ? SCR_G : SCR_W);
+    static constexpr int SWP = 4 * 16 * 5; // one operand block of the widest sweep (4 x 80)
+    static constexpr int SCR_G = 3 * NG * NXU, SCR_W = NG * NDX + NU * (NDX + 1) + 2 * SWP;
+    static constexpr int SCR = SCR_G > SCR_W ? SCR_G : SCR_W;
     double P[NDX * NDX]; // P_{t+1} -> P~ (-> E^T P~ E in place) -> P_t
-    // scratch, by phase:  Y (NDX x (NDX+1))  ->  [NAB | PEG | TG] (3 x NG x NXU)
-    //                     ->  [S^ (NDX x NU) | W (NU x (NDX+1)) | L_R^-1 (NU x NU), then Cc (NG x NDX)]
+    // scratch, by phase:  sweep operands (2 x 4 x 80)  ->  [NAB | PEG | TG] (3 x NG x NXU)
+    //                     ->  [Cc (NG x NDX) | K staging (NU x (NDX+1)) | sweep operands (2 x 4 x 64)]
     double scr[SCR];
-    double Rh[NU * NU]; // R^ -> L_R (sym-stored)
-    double p[NDX], pt0[NDX], pt[NDX], qh[NDX], rh[NU], f[NDX], col[NDX], invd[NDX], invdR[NU];
+    double p[NDX], pt0[NDX], pt[NDX], qh[NDX], rh[NU], f[NDX];
     double dc[NG], boxd[D::NA], boxact[D::NA];
   };
 
@@ -129,24 +258,22 @@ namespace smpc
     constexpr int NDX = D::NDX, NU = D::NU, NV = D::NV, NA = D::NA, NF = D::NF, NXU = NDX + NU, NG = 12;
     typedef KinoIdx<D> IX;
     typedef GainsK<D> GK;
-    static_assert(NDX % 3 == 0 && NU % 3 == 0 && NXU % 3 == 0 && NG % 3 == 0, "3x3 register tiles");
-    static_assert(NDX + 1 <= NT, "one lane per right-hand side");
+    static_assert(NDX % 4 == 0 && NU % 4 == 0 && NG % 4 == 0, "pivot panels and K steps of 4");
+    static_assert(2 * NDX + 1 <= 80 && NXU + 1 <= 64, "bordered matrices fit the 5x5 / 4x4 tile grids");
     static_assert(3 * NG * NXU <= RiccatiKinoLds<D>::SCR, "overlay of the small blocks");
-    static_assert(NG * NDX <= NU * NU, "Cc takes over the L_R^-1 block");
     const Buffers<D> & b = ka.b;
     const int H = b.H;
     const int inst = block;
-    const double mu = b.model->mu, imu = 1.0 / mu, dt = b.model->dt;
+    const double mu = b.model->mu, imu = 1.0 / mu, dt = b.model->dt, smu = sqrt(mu);
     SMPC_LDS(RiccatiKinoLds<D>, lds, 1);
     RiccatiKinoLds<D> & s = lds[0];
-    double * Ym = s.scr;                       // [NDX][NDX+1]  phase 2-3
     double * NAB = s.scr;                      // [NG][NXU]  dense rows of [A | B]           phase 4
     double * PEG = s.scr + NG * NXU;           // [NG][NXU]  (P~ E)[G,:] | (P~ E_b)[G,:]
     double * TG = s.scr + 2 * NG * NXU;        // [NG][NXU]  (P~ A)[G,:] | (P~ B)[G,:]
-    double * Sh = s.scr;                       // [NDX][NU]  S^ (written after the products)  phase 5
-    double * Li = s.scr + NDX * NU + NU * (NDX + 1); // [NU][NU] L_R^-1 (streamed out before Cc is written)
-    double * Wm = s.scr + NDX * NU;            // [NU][NDX+1]
-    double * Cc = s.scr + NDX * NU + NU * (NDX + 1); // [NG][NDX] contact rows                phase 6
+    double * Cc = s.scr;                       // [NG][NDX]  contact rows                     phase 5-6
+    double * Wm = s.scr + NG * NDX;            // [NU][NDX+1] staging of [K | k]
+    double * sw1 = s.scr;                      // sweep operands of the first (5x5 tiles) sweep: 2 x 4 x 80
+    double * sw2 = s.scr + NG * NDX + NU * (NDX + 1); // ... of the second (4x4 tiles): 2 x 4 x 64
 
     SMPC_LANES(NT)
     {
@@ -163,12 +290,13 @@ namespace smpc
     {
       const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
       double * g = b.gains + ((size_t)inst * H + t) * GK::STRIDE;
-      // matrix-core tile bookkeeping: upper tiles (I <= J) of the 16-padded 48x48 (P) and 64x64 (H^) grids
+      // matrix-core tile bookkeeping: upper tiles (I <= J) of 16-padded grids (3x3 for P, 4x4 for H^, 5x5 bordered)
       constexpr int T3I[6] = {0, 0, 0, 1, 1, 2}, T3J[6] = {0, 1, 2, 1, 2, 2};
       constexpr int T4I[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, T4J[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+      constexpr int T5I[15] = {0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 3, 3, 4}, T5J[15] = {0, 1, 2, 3, 4, 1, 2, 3, 4, 2, 3, 4, 3, 4, 4};
       constexpr int QT[6] = {0, 1, 2, 4, 5, 7}; // the T4 tiles that hold Q^ (rows, cols < NDX)
       // per-lane registers that live across phases
-      SMPC_ACC(hacc, NT, 10); // H^ = [Q S; S^T R] + [A|B]^T P~ [A|B], upper tiles; later P_t in the QT tiles
+      SMPC_ACC(hacc, NT, 10); // H^ = [Q S; S^T R] + [A|B]^T P~ [A|B], upper tiles; swept in place
       constexpr int NAB_PL = (NG * NXU + NT - 1) / NT, CC_PL = (NG * NDX + NT - 1) / NT;
       SMPC_PLA(double, nab_pf, NT, NAB_PL);
       SMPC_PLA(double, cc_pf, NT, CC_PL);
@@ -193,12 +321,6 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 1, tprev);
-      // ---- (2) L = chol(I + mu P) ; Y = L^-1 [P | pt0]  (registers + cross-lane reads only) ----
-      wave_chol_solve<NDX, NT>(
-        [&](int i, int j) { return mu * s.P[i * NDX + j] + (i == j ? 1.0 : 0.0); }, NDX + 1,
-        [&](int i, int c) { return c < NDX ? s.P[i * NDX + c] : s.pt0[i]; },
-        [&](int i, int c, double v) { Ym[i * (NDX + 1) + c] = v; });
-      prof_tick(prof, 2, tprev);
       // ---- (2b) register prefetch of the dense rows of [A|B], the contact rows of C and the stage vectors;
       //           the latency overlaps with the P~ product ----
       SMPC_LANES(NT)
@@ -225,51 +347,55 @@ namespace smpc
         SMPC_PLV(vec_pf)[3] = lq[D::O_d + (lane < NA ? lane : 0)];
       }
       SMPC_LANES_END_WAVE
-      prof_tick(prof, 3, tprev);
-      // ---- (3) P~ = P - mu Y^T Y on the matrix cores: 6 upper tiles, K = NDX.  The A operand of tile row I and
-      //          the B operand of tile column I are the same value: Y[4 ks + (lane >> 4)][16 I + (lane & 15)] ----
+      prof_tick(prof, 2, tprev);
+      // ---- (2) P~ and p~ as the Schur complement of the bordered matrix
+      //              [ I + mu P      sqrt(mu) P   sqrt(mu) pt0 ]
+      //              [ sqrt(mu) P    P            pt0          ]      (pivots: the first NDX rows, 9 panels of 4)
+      //          = P - mu P (I + mu P)^-1 P = (I + mu P)^-1 P   and   pt0 - mu P (I + mu P)^-1 pt0 = p~ ----
       {
-        constexpr int KS = NDX / 4;
-        SMPC_ACC(pacc, NT, 6);
-        SMPC_PLA(double, yv, NT, 3 * KS);
+        SMPC_ACC(t1, NT, 15);
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-          for (int tt = 0; tt < 6; tt++)
+          for (int tt = 0; tt < 15; tt++)
 #pragma unroll
             for (int v = 0; v < 4; v++)
-              SMPC_ACCV(pacc, tt, v) = 0.0;
-#pragma unroll
-          for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-            for (int I = 0; I < 3; I++)
             {
-              const int col = 16 * I + lc;
-              const double v = Ym[(4 * ks + lr) * (NDX + 1) + (col < NDX ? col : NDX)];
-              SMPC_PLV(yv)[ks * 3 + I] = col < NDX ? v : 0.0;
+              const int row = 16 * T5I[tt] + lr + 4 * v, col = 16 * T5J[tt] + lc;
+              const int r = row < col ? row : col, c = row < col ? col : row;
+              const int ri = r < NDX ? r : r - NDX, ci = c < NDX ? c : c - NDX; // indices into P / pt0
+              const bool isv = c == 2 * NDX && r < 2 * NDX, ism = c < 2 * NDX;
+              const double pv = s.P[(ism ? ri * NDX + ci : 0)];
+              const double tv = s.pt0[isv ? ri : 0];
+              double val = ism ? pv : (isv ? tv : 0.0);
+              const double scale = c < NDX ? mu : ((r < NDX && (ism || isv)) ? smu : 1.0);
+              val = val * scale + ((c < NDX && r == c) ? 1.0 : 0.0);
+              SMPC_ACCV(t1, tt, v) = val;
             }
         }
         SMPC_LANES_END_WAVE
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-          for (int tt = 0; tt < 6; tt++)
-            SMPC_MFMA(pacc, tt, yv, ks * 3 + T3I[tt], yv, ks * 3 + T3J[tt]);
+        prof_tick(prof, 3, tprev);
+        wave_block_sweep<NT, 5, false, 0, NDX / 4>(t1, sw1, sw1 + RiccatiKinoLds<D>::SWP, prof, tprev);
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-          for (int tt = 0; tt < 6; tt++)
+          for (int tt = 9; tt < 15; tt++) // tile rows >= 2 hold the Schur block (rows NDX .. 2 NDX)
 #pragma unroll
             for (int v = 0; v < 4; v++)
             {
-              const int row = 16 * T3I[tt] + lr + 4 * v, col = 16 * T3J[tt] + lc;
-              if (col < NDX && row <= col) // row <= col < NDX ; diagonal tiles: upper part only
+              const int row = 16 * T5I[tt] + lr + 4 * v, col = 16 * T5J[tt] + lc;
+              const double val = SMPC_ACCV(t1, tt, v);
+              if (row >= NDX && row < 2 * NDX && col >= row)
               {
-                const double pv = 0.5 * (s.P[row * NDX + col] + s.P[col * NDX + row]) - mu * SMPC_ACCV(pacc, tt, v);
-                s.P[row * NDX + col] = pv;
-                s.P[col * NDX + row] = pv;
+                if (col < 2 * NDX)
+                {
+                  s.P[(row - NDX) * NDX + col - NDX] = val;
+                  s.P[(col - NDX) * NDX + row - NDX] = val;
+                }
+                else if (col == 2 * NDX)
+                  s.pt[row - NDX] = val;
               }
             }
         }
@@ -298,17 +424,9 @@ namespace smpc
           }
       }
       SMPC_LANES_END_WAVE
-      // p~ = pt0 - mu P~ pt0 ; stream P~ out ; load the dense rows of [A|B]
+      // stream P~ out ; load the dense rows of [A|B]
       SMPC_LANES(NT)
       {
-        if (lane < NDX)
-        {
-          double acc = 0.0;
-#pragma unroll 4
-          for (int j = 0; j < NDX; j++)
-            acc += s.P[lane * NDX + j] * s.pt0[j];
-          s.pt[lane] = s.pt0[lane] - mu * acc;
-        }
         for (int idx = lane; idx < NDX * NDX; idx += NT)
           g[GK::G_Pt + idx] = s.P[idx];
 #pragma unroll
@@ -482,57 +600,8 @@ namespace smpc
           }
       }
       prof_tick(prof, 8, tprev);
-      // S^ -> Sh, R^ (upper triangle) -> s.Rh ; Q^ stays in the accumulators (tiles QT)
-      SMPC_LANES(NT)
-      {
-        const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-        for (int tt = 0; tt < 10; tt++)
-          if (16 * T4J[tt] + 15 >= NDX)
-          {
-#pragma unroll
-            for (int v = 0; v < 4; v++)
-            {
-              const int row = 16 * T4I[tt] + lr + 4 * v, col = 16 * T4J[tt] + lc;
-              const double val = SMPC_ACCV(hacc, tt, v);
-              if (col >= NDX && col < NXU)
-              {
-                if (row < NDX)
-                  Sh[row * NU + col - NDX] = val;
-                else if (row <= col)
-                  s.Rh[(row - NDX) * NU + col - NDX] = val;
-              }
-            }
-          }
-      }
-      SMPC_LANES_END_WAVE
-      prof_tick(prof, 9, tprev);
-      // ---- (5) L_R = chol(R^) ; W = L_R^-1 [S^^T | r^] ----
-      // columns 0..NDX of the right-hand sides: [S^^T | r^] -> W ; columns NDX+1..NDX+NU: identity -> L_R^-1 on the
-      // otherwise idle lanes (the forward sweep then needs one product, not a 24-step back substitution).
-      // L_R^-1 lands in the block Cc takes over afterwards.  Loads / stores are address-selected, not branched.
-      wave_chol_solve<NU, NT>(
-        [&](int i, int j) { return s.Rh[j * NU + i]; }, NDX + 1 + NU, // R^ is stored upper: (j, i), j <= i
-        [&](int i, int c) {
-          const double * src = c < NDX ? &Sh[c * NU + i] : &s.rh[i];
-          const double v = *src;
-          return c <= NDX ? v : (i == c - NDX - 1 ? 1.0 : 0.0);
-        },
-        [&](int i, int c, double v) {
-          double * dst = c <= NDX ? &Wm[i * (NDX + 1) + c] : &Li[i * NU + c - NDX - 1];
-          *dst = v;
-        });
-      prof_tick(prof, 10, tprev);
-      SMPC_LANES(NT)
-      {
-        for (int idx = lane; idx < NU * (NDX + 1); idx += NT)
-          g[GK::G_W + idx] = Wm[idx];
-        for (int idx = lane; idx < NU * NU; idx += NT)
-          g[GK::G_LR + idx] = Li[idx];
-      }
-      SMPC_LANES_END_WAVE
-      prof_tick(prof, 11, tprev);
-      // contact rows of C, box activity, d
+      // ---- (5) contact rows of C into LDS ; then  Q^ += C^T C / mu + box  (matrix cores, K = NG), the vector column
+      //          [q^ + C^T d / mu ; r^] goes into column NXU of the H^ grid ----
       SMPC_LANES(NT)
       {
 #pragma unroll
@@ -551,69 +620,114 @@ namespace smpc
         }
       }
       SMPC_LANES_END_WAVE
-      prof_tick(prof, 12, tprev);
-      // ---- (6) P_t = Q^ - W_x^T W_x + C^T C / mu + box (matrix cores, K = NU + NG, accumulating onto Q^) ; p_t ----
       {
-        constexpr int KW = NU / 4, KC = NG / 4;
-        SMPC_PLA(double, wpv, NT, (KW + KC) * 3); // B operands:  W_x | Cc
-        SMPC_PLA(double, wnv, NT, (KW + KC) * 3); // A operands: -W_x | Cc / mu
+        constexpr int KC = NG / 4;
+        SMPC_PLA(double, cpv, NT, KC * 3); // B operands: Cc
+        SMPC_PLA(double, cnv, NT, KC * 3); // A operands: Cc / mu
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-          for (int ks = 0; ks < KW + KC; ks++)
+          for (int ks = 0; ks < KC; ks++)
 #pragma unroll
             for (int I = 0; I < 3; I++)
             {
-              const int col = 16 * I + lc, cs = col < NDX ? col : 0;
-              const double raw = ks < KW ? Wm[(4 * ks + lr) * (NDX + 1) + cs] : Cc[(4 * (ks - KW) + lr) * NDX + cs];
+              const int col = 16 * I + lc;
+              const double raw = Cc[(4 * ks + lr) * NDX + (col < NDX ? col : 0)];
               const double val = col < NDX ? raw : 0.0;
-              SMPC_PLV(wpv)[ks * 3 + I] = val;
-              SMPC_PLV(wnv)[ks * 3 + I] = ks < KW ? -val : imu * val;
+              SMPC_PLV(cpv)[ks * 3 + I] = val;
+              SMPC_PLV(cnv)[ks * 3 + I] = imu * val;
             }
           if (lane < NDX)
           {
             const int i = lane;
-            double acc = s.qh[i];
-#pragma unroll 4
-            for (int m = 0; m < NU; m++)
-              acc -= Wm[m * (NDX + 1) + i] * Wm[m * (NDX + 1) + NDX];
             double cd = 0.0;
 #pragma unroll 4
             for (int r = 0; r < NG; r++)
               cd += Cc[r * NDX + i] * s.dc[r];
             if (IX::isQj(i))
               cd += s.boxact[i - 6] * s.boxd[i - 6];
-            s.p[i] = acc + imu * cd;
+            s.qh[i] += imu * cd;
           }
         }
         SMPC_LANES_END_WAVE
 #pragma unroll
-        for (int ks = 0; ks < KW + KC; ks++)
+        for (int ks = 0; ks < KC; ks++)
 #pragma unroll
           for (int tt = 0; tt < 6; tt++)
-            SMPC_MFMA(hacc, QT[tt], wnv, ks * 3 + T3I[tt], wpv, ks * 3 + T3J[tt]);
+            SMPC_MFMA(hacc, QT[tt], cnv, ks * 3 + T3I[tt], cpv, ks * 3 + T3J[tt]);
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
+          // box rows: unit selectors -> diagonal contribution on the qj entries
 #pragma unroll
-          for (int tt = 0; tt < 6; tt++)
+          for (int I = 0; I < 3; I++)
 #pragma unroll
             for (int v = 0; v < 4; v++)
             {
-              const int row = 16 * T3I[tt] + lr + 4 * v, col = 16 * T3J[tt] + lc;
-              if (col < NDX && row <= col)
-              {
-                double pv = SMPC_ACCV(hacc, QT[tt], v);
-                if (row == col && IX::isQj(row))
-                  pv += imu * s.boxact[row - 6];
-                s.P[row * NDX + col] = pv;
-                s.P[col * NDX + row] = pv;
-              }
+              const int row = 16 * I + lr + 4 * v;
+              if (lc == lr + 4 * v && IX::isQj(row))
+                SMPC_ACCV(hacc, tix<4>(I, I), v) += imu * s.boxact[row - 6];
             }
+          // vector column NXU (lanes with lc == NXU % 16 of the last tile column)
+          if (lc == NXU % 16)
+          {
+#pragma unroll
+            for (int I = 0; I < 4; I++)
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+              {
+                const int row = 16 * I + lr + 4 * v;
+                const double val = row < NDX ? s.qh[row] : s.rh[row < NXU ? row - NDX : 0];
+                SMPC_ACCV(hacc, tix<4>(I, 3), v) = row < NXU ? val : 0.0;
+              }
+          }
         }
         SMPC_LANES_END_WAVE
       }
+      static_assert(NXU / 16 == 3 && NXU % 16 != 0, "vector column lives in the last tile column of the 4x4 grid");
+      prof_tick(prof, 9, tprev);
+      // ---- (6) sweep the NU control pivots (rows NDX .. NXU) of
+      //              [ Q^ + C^T C/mu   S^    q^ + C^T d/mu ]
+      //              [ S^^T            R^    r^            ]
+      //          in place:  x-x block -> P_t,  x-vector -> p_t,  stored (x, u) entries -> R^^-1 S^^T = -K,
+      //          (u, vector) entries -> R^^-1 r^ = -k ----
+      wave_block_sweep<NT, 4, true, NDX, NU / 4>(hacc, sw2, sw2 + 4 * 64, prof, tprev);
+      prof_tick(prof, 10, tprev);
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int tt = 0; tt < 10; tt++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            const int row = 16 * T4I[tt] + lr + 4 * v, col = 16 * T4J[tt] + lc;
+            const double val = SMPC_ACCV(hacc, tt, v);
+            if (row < NDX)
+            {
+              if (col < NDX)
+              {
+                if (row <= col)
+                {
+                  s.P[row * NDX + col] = val;
+                  s.P[col * NDX + row] = val;
+                }
+              }
+              else if (col < NXU)
+                Wm[(col - NDX) * (NDX + 1) + row] = -val; // K
+              else if (col == NXU)
+                s.p[row] = val; // p_t
+            }
+            else if (row < NXU && col == NXU)
+              Wm[(row - NDX) * (NDX + 1) + NDX] = -val; // k
+          }
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < NU * (NDX + 1); idx += NT)
+        g[GK::G_W + idx] = Wm[idx];
+      SMPC_LANES_END_WAVE
       prof_tick(prof, 13, tprev);
     }
   }
@@ -628,7 +742,7 @@ namespace smpc
   struct ForwardKinoLds
   {
     static constexpr int NDX = D::NDX, NU = D::NU, NG = 12;
-    static constexpr int N_G = GainsK<D>::G_pn + NDX;                        // W | L_R^-1 | P~ | p+
+    static constexpr int N_G = GainsK<D>::G_pn + NDX;                        // [K | k] | P~ | p+
     static constexpr int N_A = 6 * NDX, N_B = 6 * NU, N_C = NG * NDX;        // row groups qb / vb of A, B; contact rows of C
     static constexpr int N_V = D::O_vpd + D::NC - D::O_f;                    // f d lx lu lpd vpd
     static constexpr int O_A0 = N_G, O_A1 = O_A0 + N_A, O_B0 = O_A1 + N_A, O_B1 = O_B0 + N_B, O_Cc = O_B1 + N_B,
@@ -648,7 +762,7 @@ namespace smpc
       return c == 1 ? D::O_A : c == 2 ? D::O_A + D::NV * NDX : c == 3 ? D::O_B : c == 4 ? D::O_B + D::NV * NU : c == 5 ? D::O_C + D::NA * NDX : D::O_f;
     }
     double st[PER_LANE * 64];
-    double dx[NDX], du[NU], z[NU], y[NDX], part[64], lpd_prev[NDX];
+    double dx[NDX], du[NU], y[NDX], part[64], lpd_prev[NDX];
   };
 
   template <class D>
@@ -719,7 +833,6 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     const double * W = s.st + GK::G_W;
-    const double * Li = s.st + GK::G_LR;
     const double * Pt = s.st + GK::G_Pt;
     const double * pn = s.st + GK::G_pn;
     const double * vf = s.st + FL::O_V;
@@ -738,7 +851,7 @@ namespace smpc
           fetch(lane, SMPC_PLV(pf), t + 1);
       }
       SMPC_LANES_END_WAVE
-      // ---- z = W_x dx + w ; dnu = (C dx + d)/mu ----
+      // ---- du = K dx + k ; dnu = (C dx + d)/mu ----
       SMPC_LANES(NT)
       {
         if (lane < NU)
@@ -748,7 +861,9 @@ namespace smpc
 #pragma unroll 4
           for (int j = 0; j < NDX; j++)
             acc += Wr[j] * s.dx[j];
-          s.z[lane] = acc;
+          s.du[lane] = acc;
+          b.dus[lt * NU + lane] = acc;
+          s.part[lane] += vlu[lane] * acc;
         }
         else if (lane < NU + NC)
         {
@@ -767,20 +882,6 @@ namespace smpc
           b.dvs[lt * NC + r] = dnu;
           s.part[lane] += vvpd[r] * (mu * dnu - vd[r]) - vd[r] * dnu;
         }
-      }
-      SMPC_LANES_END_WAVE
-      // ---- du = -(L_R^-1)^T z ----
-      SMPC_LANES(NT)
-      if (lane < NU)
-      {
-        double acc = 0.0;
-#pragma unroll 4
-        for (int i = 0; i < NU; i++)
-          acc += Li[i * NU + lane] * s.z[i]; // upper part of L_R^-1 is stored as exact zeros
-        const double v = -acc;
-        s.du[lane] = v;
-        b.dus[lt * NU + lane] = v;
-        s.part[lane] += vlu[lane] * v;
       }
       SMPC_LANES_END_WAVE
       // ---- y = A dx + B du + f - mu p_{t+1}  (dense rows G; unit rows by structure) ----
@@ -848,7 +949,7 @@ namespace smpc
     SMPC_LANES_END_WAVE
   }
 
-  // K_t = -(L_R^-1)^T W_x for (instance, stage) blocks: grid = B * nt, 64 lanes (lane = column of K)
+  // K_t for (instance, stage) blocks: grid = B * nt, 64 lanes (lane = column of K)
   template <class D>
   struct GainOutArgs
   {
@@ -869,18 +970,9 @@ namespace smpc
     SMPC_LANES(NT)
     if (lane < NDX)
     {
-      double x[NU];
-#pragma unroll
+#pragma unroll 4
       for (int i = 0; i < NU; i++)
-        x[i] = g[GK::G_W + i * (NDX + 1) + lane];
-      for (int i = 0; i < NU; i++)
-      {
-        double sacc = 0.0; // K = -(L_R^-1)^T W_x
-#pragma unroll
-        for (int k = 0; k < NU; k++)
-          sacc += (k >= i) ? g[GK::G_LR + k * NU + i] * x[k] : 0.0;
-        out[i * NDX + lane] = -sacc;
-      }
+        out[i * NDX + lane] = g[GK::G_W + i * (NDX + 1) + lane];
     }
     SMPC_LANES_END_WAVE
   }
