@@ -29,6 +29,7 @@
   {                                                                                                                    \
     int _smpc_lane = (int)threadIdx.x;                                                                                 \
     asm volatile("" : "+v"(_smpc_lane));                                                                               \
+    __builtin_assume(_smpc_lane >= 0 && _smpc_lane < (NT));                                                            \
     const int lane = _smpc_lane;                                                                                       \
     (void)lane;
 #define SMPC_LANES_END                                                                                                 \

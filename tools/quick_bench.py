@@ -23,6 +23,7 @@ if os.environ.get('SMPC_PHASE_PROFILE'):
     names = ['loadM','pt0','chol36','subst36','Ptilde','ptilde+io','PEG','TG','products','writeback','chol24','subst24','loadC','Pt']
     n = (steps+1)*iters*gm.H
     print('phase cycles per stage (block 0):', ' '.join('%s %.0f' % (nm, out[i]/n) for i,nm in enumerate(names)), '| total %.0f' % (out[:14].sum()/n))
+    print('  sweep parts per stage (15 panels): gather %.0f  invert+U %.0f  operands+mfma %.0f  fixup %.0f' % tuple(out[36:40]/n))
 if os.environ.get('SMPC_PHASE_PROFILE'):
     names2 = {15:'load',16:'FK',17:'S/I',18:'vel',19:'composite',20:'com/Ag',21:'GJ',22:'M1/Agbi',23:'a',24:'xnext',25:'acc',26:'Fc',27:'columns',28:'ab_d',29:'defect',30:'cost/cstr',31:'mult',32:'tables',33:'AB',34:'QS',35:'CR'}
     nd = (steps+1)*iters
