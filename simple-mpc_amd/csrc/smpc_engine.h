@@ -265,6 +265,13 @@ namespace smpc
         def.x_tgt[i] = x_model_ref[i];
       horizon.assign(H, def);
       standing = def;
+      {
+        StageKernelArgs<D> sk;
+        sk.b = buf;
+        sk.head = 0;
+        sk.j0 = sk.nj = sk.slots = 0;
+        launch<StageKernelArgs<D>, lq_init_body<D>, 64>(B * H, stream, sk);
+      }
       cold_solve(def);
     }
     ~KinoEngine()

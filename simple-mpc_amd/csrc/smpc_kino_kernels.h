@@ -330,10 +330,23 @@ namespace smpc
       double acc = 0.0; // (A^T lam_next)[k] or (B^T lam_next)[k]
       double * dst = lq + (isA ? D::O_A : D::O_B);
       const int ld = isA ? NDX : NU;
-      for (int i = 0; i < NDX; i++)
+      // only the 12 rows G = qb u vb are state dependent; rows qj / vj are the constant integrator pattern
+      // (e_i + dt e_{v(i)} | dt^2 e_a and e_i | dt e_a), written once by lq_init_body
+      // (the multiplier products are accumulated in row order, like a dense A^T lam)
+#pragma unroll
+      for (int gi = 0; gi < 12; gi++)
       {
+        const int i = gi < 6 ? gi : NV + gi - 6;
+        if (gi == 6)
+        {
+          // rows qj
+          if (isA)
+            acc += (k >= 6 && k < NV) ? sc.lam_next[k] : (k >= NV + 6 ? dt * sc.lam_next[k - NV] : 0.0);
+          else
+            acc += k >= 3 * NF ? dt * dt * sc.lam_next[6 + k - 3 * NF] : 0.0;
+        }
         double v;
-        if (i < 6)
+        if (gi < 6)
         {
           // Je row i = [J3 Q; 0 J3]
           if (i < 3)
@@ -344,29 +357,20 @@ namespace smpc
           if (isA && k < 6)
             v += sc.Jq[i * 6 + k];
         }
-        else if (i < NV)
-        {
-          if (isA)
-            v = (k == i ? 1.0 : 0.0) + (k == NV + i ? dt : 0.0);
-          else
-            v = (k == 3 * NF + i - 6) ? dt * dt : 0.0;
-        }
-        else if (i < NV + 6)
+        else
         {
           v = Dbot[i - NV];
           if (isA && k == i)
             v += 1.0;
         }
-        else
-        {
-          if (isA)
-            v = (k == i) ? 1.0 : 0.0;
-          else
-            v = (k == 3 * NF + i - NV - 6) ? dt : 0.0;
-        }
         dst[i * ld + k] = v;
         acc += v * sc.lam_next[i];
       }
+      // rows vj
+      if (isA)
+        acc += k >= NV + 6 ? sc.lam_next[k] : 0.0;
+      else
+        acc += k >= 3 * NF ? dt * sc.lam_next[NV + 6 + k - 3 * NF] : 0.0;
       // Lagrangian gradient pieces: cost gradient + multipliers
       if (isA)
       {
@@ -595,6 +599,38 @@ namespace smpc
       parts[1] = sc.red[0];
       parts[2] = sc.red[2];
       parts[3] = dual;
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // =============================================================================================
+  // lq_init_body: grid = B * H, run once: the state-independent rows (qj, vj) of A and B of every knot
+  // (semi-implicit Euler: q+ = q + dt (v + dt a), v+ = v + dt a, reference src/kinodynamics.cpp:88)
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void lq_init_body(const StageKernelArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NV = D::NV, NDX = D::NDX, NU = D::NU, NF = D::NF;
+    static_assert(NDX + NU <= NT, "one lane per column");
+    const double dt = ka.b.model->dt;
+    double * lq = ka.b.lq + (size_t)block * D::LQ_STRIDE;
+    SMPC_LANES(NT)
+    if (lane < NDX + NU)
+    {
+      const bool isA = lane < NDX;
+      const int k = isA ? lane : lane - NDX;
+      for (int i = 6; i < NDX; i++)
+      {
+        if (i >= NV && i < NV + 6)
+          continue;
+        double v;
+        if (i < NV)
+          v = isA ? (k == i ? 1.0 : 0.0) + (k == NV + i ? dt : 0.0) : ((k == 3 * NF + i - 6) ? dt * dt : 0.0);
+        else
+          v = isA ? ((k == i) ? 1.0 : 0.0) : ((k == 3 * NF + i - NV - 6) ? dt : 0.0);
+        lq[(isA ? D::O_A + i * NDX : D::O_B + i * NU) + k] = v;
+      }
     }
     SMPC_LANES_END_WAVE
   }
