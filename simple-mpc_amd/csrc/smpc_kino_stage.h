@@ -105,6 +105,94 @@ namespace smpc
         dst[lane + n * NT] = r[n];
   }
 
+  // SE(3) work of a stage on two lanes in lockstep.  Lane 0 integrates the base (exp side, nu = dt (v + dt a)): x+ and,
+  // with derivatives, Jexp6(nu) and the action matrix of exp6(nu)^-1.  Lane 1 forms the base block of the state
+  // residual (log side, nu = log6(M_tgt^-1 M)) and, with derivatives, Jlog6(nu).  Both need W = [w]x, W^2, the same
+  // coefficient functions of |w| and the Q block of the SE(3) Jacobian: those run once, as the same instructions,
+  // for the two lanes (on a SIMD machine two different single-lane branches cost the sum of both).
+  template <class D, bool DERIV>
+  SMPC_DEV void kino_se3_pair(KinoScratch<D, DERIV> & sc, const StageIn<D> & in, const double * vq, double dt, int lane)
+  {
+    const bool ex = lane == 0;
+    V3 vec, w; // vec: exp side dv ; log side translation of M_tgt^-1 M
+    if (ex)
+    {
+      vec = mk3(dt * (vq[0] + dt * sc.a[0]), dt * (vq[1] + dt * sc.a[1]), dt * (vq[2] + dt * sc.a[2]));
+      w = mk3(dt * (vq[3] + dt * sc.a[3]), dt * (vq[4] + dt * sc.a[4]), dt * (vq[5] + dt * sc.a[5]));
+    }
+    else
+    {
+      const double * xt = in.x_tgt;
+      const SE3 Mt{quat_to_R(Quat{xt[3], xt[4], xt[5], xt[6]}), ld3(xt)};
+      const SE3 M = se3_mul(se3_inv(Mt), SE3{ldm3(&sc.oR[0]), ld3(&sc.op[0])});
+      w = log3(M.R);
+      vec = M.p;
+    }
+    const double t = sqrt(dot(w, w));
+    const M3 W = skew(w);
+    const M3 W2 = W * W;
+    const double cB = cf_B(t), cC = cf_C(t), cD = cf_D(t);
+    // exp: E.p = (I + B W + C W^2) dv ;  log: v = (I - W/2 + D W^2) p
+    const double c1 = ex ? cB : -0.5, c2 = ex ? cC : cD;
+    const V3 out = vec + c1 * (W * vec) + c2 * (W2 * vec);
+    const V3 v = ex ? vec : out;
+    M3 J = m3_id(), Q = m3_id();
+    if constexpr (DERIV)
+    {
+      Q = se3_Q(-1.0 * v, -1.0 * w);
+      J = m3_id() + (ex ? -cB : 0.5) * W + c2 * W2; // Jexp3(w) | Jlog3(w)
+    }
+    if (ex)
+    {
+      const M3 R0 = ldm3(&sc.oR[0]);
+      st3(&sc.xnext[0], ld3(&sc.op[0]) + R0 * out);
+      Quat qn = quat_mul(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]}, quat_exp(w));
+      const double n = 1.0 / sqrt(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+      sc.xnext[3] = qn.x * n;
+      sc.xnext[4] = qn.y * n;
+      sc.xnext[5] = qn.z * n;
+      sc.xnext[6] = qn.w * n;
+      if constexpr (DERIV)
+      {
+        stm3(sc.Je3, J);
+        stm3(sc.JeQ, Q);
+        // action matrix of exp6(nu)^-1 = [[R^T, -R^T [p]x],[0, R^T]]
+        const M3 Rt = transpose(m3_id() + cf_sinc(t) * W + cB * W2);
+        const M3 X = (-1.0) * (Rt * skew(out));
+        double * Jq = sc.Jq;
+        const double rt[9] = {Rt.a00, Rt.a01, Rt.a02, Rt.a10, Rt.a11, Rt.a12, Rt.a20, Rt.a21, Rt.a22};
+        const double xx[9] = {X.a00, X.a01, X.a02, X.a10, X.a11, X.a12, X.a20, X.a21, X.a22};
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++)
+          {
+            Jq[i * 6 + j] = rt[i * 3 + j];
+            Jq[(i + 3) * 6 + j + 3] = rt[i * 3 + j];
+            Jq[i * 6 + j + 3] = xx[i * 3 + j];
+            Jq[(i + 3) * 6 + j] = 0.0;
+          }
+      }
+    }
+    else
+    {
+      st3(&sc.rx[0], out);
+      st3(&sc.rx[3], w);
+      if constexpr (DERIV)
+      {
+        const M3 X = (-1.0) * (J * Q * J);
+        const double ji[9] = {J.a00, J.a01, J.a02, J.a10, J.a11, J.a12, J.a20, J.a21, J.a22};
+        const double xx[9] = {X.a00, X.a01, X.a02, X.a10, X.a11, X.a12, X.a20, X.a21, X.a22};
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++)
+          {
+            sc.Jl[i * 6 + j] = ji[i * 3 + j];
+            sc.Jl[(i + 3) * 6 + j + 3] = ji[i * 3 + j];
+            sc.Jl[i * 6 + j + 3] = xx[i * 3 + j];
+            sc.Jl[(i + 3) * 6 + j] = 0.0;
+          }
+      }
+    }
+  }
+
   // ---------------------------------------------------------------------------------------------
   // Tree + dynamics phases.  On return (all lanes synchronised) the scratch holds: kinematics,
   // composite quantities, Ag, hg, b0, hd, Agbi, a, xnext.  If DERIV, also acc/Fc for the solved
@@ -428,20 +516,8 @@ namespace smpc
     SMPC_LANES(NT)
     {
       const double dt = md.dt;
-      if (lane == 0)
-      {
-        const V3 dv = mk3(dt * (vq[0] + dt * sc.a[0]), dt * (vq[1] + dt * sc.a[1]), dt * (vq[2] + dt * sc.a[2]));
-        const V3 dw = mk3(dt * (vq[3] + dt * sc.a[3]), dt * (vq[4] + dt * sc.a[4]), dt * (vq[5] + dt * sc.a[5]));
-        const SE3 E = exp6(dv, dw);
-        const M3 R0 = ldm3(&sc.oR[0]);
-        st3(&sc.xnext[0], ld3(&sc.op[0]) + R0 * E.p);
-        Quat qn = quat_mul(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]}, quat_exp(dw));
-        const double n = 1.0 / sqrt(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
-        sc.xnext[3] = qn.x * n;
-        sc.xnext[4] = qn.y * n;
-        sc.xnext[5] = qn.z * n;
-        sc.xnext[6] = qn.w * n;
-      }
+      if (lane < 2)
+        kino_se3_pair<D, DERIV>(sc, in, vq, dt, lane);
       else if (lane >= 6 && lane < NV)
         sc.xnext[lane + 1] = sc.x[lane + 1] + dt * (vq[lane] + dt * sc.a[lane]);
       if (lane >= 32 && lane < 32 + NV)
@@ -669,32 +745,6 @@ namespace smpc
           dst[r * ld] = acc;
         }
       }
-      // integrator Jacobians on two spare lanes
-      if (lane == 62)
-      {
-        const double dt = md.dt;
-        const V3 dv = mk3(dt * (vq[0] + dt * sc.a[0]), dt * (vq[1] + dt * sc.a[1]), dt * (vq[2] + dt * sc.a[2]));
-        const V3 dw = mk3(dt * (vq[3] + dt * sc.a[3]), dt * (vq[4] + dt * sc.a[4]), dt * (vq[5] + dt * sc.a[5]));
-        M3 J3, Q;
-        Jexp6(dv, dw, J3, Q);
-        stm3(sc.Je3, J3);
-        stm3(sc.JeQ, Q);
-        // action matrix of exp6(nu)^-1 = [[R^T, -R^T [p]x],[0, R^T]]
-        const SE3 E = exp6(dv, dw);
-        const M3 Rt = transpose(E.R);
-        const M3 X = (-1.0) * (Rt * skew(E.p));
-        double * Jq = sc.Jq;
-        const double rt[9] = {Rt.a00, Rt.a01, Rt.a02, Rt.a10, Rt.a11, Rt.a12, Rt.a20, Rt.a21, Rt.a22};
-        const double xx[9] = {X.a00, X.a01, X.a02, X.a10, X.a11, X.a12, X.a20, X.a21, X.a22};
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 3; j++)
-          {
-            Jq[i * 6 + j] = rt[i * 3 + j];
-            Jq[(i + 3) * 6 + j + 3] = rt[i * 3 + j];
-            Jq[i * 6 + j + 3] = xx[i * 3 + j];
-            Jq[(i + 3) * 6 + j] = 0.0;
-          }
-      }
     }
     SMPC_LANES_END_WAVE
     if (in.prof) prof_tick(in.prof, 28, *in.tprev);
@@ -706,32 +756,10 @@ namespace smpc
   SMPC_DEV void kino_state_residual(KinoScratch<D, DERIV> & sc, const double * xt, int lane)
   {
     constexpr int NV = D::NV, NQ = D::NQ;
-    if (lane == 63)
-    {
-      const SE3 Mt{quat_to_R(Quat{xt[3], xt[4], xt[5], xt[6]}), ld3(xt)};
-      const SE3 Mx{ldm3(&sc.oR[0]), ld3(&sc.op[0])};
-      V3 v, w;
-      log6(se3_mul(se3_inv(Mt), Mx), v, w);
-      st3(&sc.rx[0], v);
-      st3(&sc.rx[3], w);
-      if constexpr (DERIV)
-      {
-        M3 Ji, X;
-        Jlog6(v, w, Ji, X);
-        const double ji[9] = {Ji.a00, Ji.a01, Ji.a02, Ji.a10, Ji.a11, Ji.a12, Ji.a20, Ji.a21, Ji.a22};
-        const double xx[9] = {X.a00, X.a01, X.a02, X.a10, X.a11, X.a12, X.a20, X.a21, X.a22};
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 3; j++)
-          {
-            sc.Jl[i * 6 + j] = ji[i * 3 + j];
-            sc.Jl[(i + 3) * 6 + j + 3] = ji[i * 3 + j];
-            sc.Jl[i * 6 + j + 3] = xx[i * 3 + j];
-            sc.Jl[(i + 3) * 6 + j] = 0.0;
-          }
-      }
-    }
-    else if (lane >= 6 && lane < NV)
+    // (base block rx[0:6] and its Jlog6: kino_se3_pair, together with the base integration)
+    if (lane >= 6 && lane < NV)
       sc.rx[lane] = sc.x[lane + 1] - xt[lane + 1];
+
     if (lane < NV)
       sc.rx[NV + lane] = sc.x[NQ + lane] - xt[NQ + lane];
   }
