@@ -184,6 +184,20 @@ namespace smpc
   {
     if (grid <= 0)
       return;
+    static const bool dbg_occ = std::getenv("SMPC_DEBUG_OCCUPANCY") != nullptr;
+    if (dbg_occ)
+    {
+      static bool once = false;
+      if (!once)
+      {
+        once = true;
+        int nb = 0;
+        SMPC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel_entry<Args, Body, NT, MINW>, NT, 0));
+        hipFuncAttributes fa;
+        SMPC_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel_entry<Args, Body, NT, MINW>)));
+        std::fprintf(stderr, "[smpc] %s: %d blocks/CU (NT %d, LDS %zu B, %d regs)\n", __PRETTY_FUNCTION__, nb, NT, (size_t)fa.sharedSizeBytes, fa.numRegs);
+      }
+    }
     hipLaunchKernelGGL((kernel_entry<Args, Body, NT, MINW>), dim3((unsigned)grid), dim3(NT), 0, s, a);
     SMPC_HIP(hipGetLastError());
   }

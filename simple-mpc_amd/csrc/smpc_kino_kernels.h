@@ -159,7 +159,7 @@ namespace smpc
           double s = 0.0;
           for (int bb = 0; bb < 6; bb++)
             s += 10.0 * md.w_cent[a * 6 + bb] * (k < NV ? sc.dh_dq[bb * NV + k] : sc.Ag[bb * NV + k - NV]);
-          sc.WJc[idx] = s;
+          sc.WJc()[idx] = s;
         }
       }
       SMPC_LANES_END_WAVE
@@ -195,7 +195,7 @@ namespace smpc
           else
             v = k < 6 ? sc.WJl[i * 6 + k] : mg.w_x[i * NDX + k];
           for (int a = 0; a < 6; a++)
-            v += (i < NV ? sc.dh_dq[a * NV + i] : sc.Ag[a * NV + i - NV]) * sc.WJc[a * NDX + k];
+            v += (i < NV ? sc.dh_dq[a * NV + i] : sc.Ag[a * NV + i - NV]) * sc.WJc()[a * NDX + k];
           if (i == k)
             v += preg;
           QN[i * NDX + k] = v;
@@ -238,7 +238,7 @@ namespace smpc
         double s = 0.0;
         for (int bb = 0; bb < 6; bb++)
           s += md.w_cent[a * 6 + bb] * (k < NV ? sc.dh_dq[bb * NV + k] : sc.Ag[bb * NV + k - NV]);
-        sc.WJc[idx] = s;
+        sc.WJc()[idx] = s;
         // JtW[i][k] = sum_a Jl[a][i] w_x[a][k]  (rows of J_x^T w_x for the base block)
         double t = 0.0;
         for (int bb = 0; bb < 6; bb++)
@@ -251,7 +251,7 @@ namespace smpc
         double s = 0.0;
         for (int bb = 0; bb < 3; bb++)
           s += md.w_centder[(3 + a) * 6 + 3 + bb] * sc.dtgt[bb * NV + k];
-        sc.WD[idx] = s;
+        sc.WD()[idx] = s;
       }
       for (int idx = lane; idx < 6 * 3 * NF; idx += NT)
       {
@@ -264,7 +264,7 @@ namespace smpc
           const V3 xc = cross(rr, mk3(j == 0, j == 1, j == 2)); // column j of [rr]x
           s = md.w_centder[a * 6 + j] + md.w_centder[a * 6 + 3] * xc.x + md.w_centder[a * 6 + 4] * xc.y + md.w_centder[a * 6 + 5] * xc.z;
         }
-        sc.WJu[idx] = s;
+        sc.WJu()[idx] = s;
       }
       for (int idx = lane; idx < NF * 3 * NV; idx += NT)
       {
@@ -273,7 +273,7 @@ namespace smpc
         double s = 0.0;
         for (int bb = 0; bb < 3; bb++)
           s += md.w_frame[a * 3 + bb] * sc.Jfoot[(f * 3 + bb) * NV + k];
-        sc.WJf[idx] = s;
+        sc.WJf()[idx] = s;
       }
       if (lane < 36)
       {
@@ -400,7 +400,7 @@ namespace smpc
         for (int f = 0; f < NF; f++)
           if ((in.mask >> f) & 1u)
             for (int r = 0; r < 3; r++)
-              cn += (k < NV ? sc.dcq[(f * 3 + r) * NV + k] : sc.dcv[(f * 3 + r) * NV + k - NV]) * sc.nu[NA + 3 * f + r];
+              cn += (k < NV ? sc.dcq()[(f * 3 + r) * NV + k] : sc.dcv[(f * 3 + r) * NV + k - NV]) * sc.nu[NA + 3 * f + r];
         double q = g + acc + cn - sc.lam_prev[k];
         if (t == 0)
           q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
@@ -464,7 +464,7 @@ namespace smpc
         for (int k = 0; k < 6; k++)
         {
           const double x0 = jc[k * NV], x1 = jc[k * NV + 1], x2 = jc[k * NV + 2];
-          const double * wr = &sc.WJc[k * NDX + j0];
+          const double * wr = &sc.WJc()[k * NDX + j0];
           const double y0 = wr[0], y1 = wr[1], y2 = wr[2];
           acc[0][0] += x0 * y0;
           acc[0][1] += x0 * y1;
@@ -482,7 +482,7 @@ namespace smpc
           for (int k = 0; k < 3; k++)
           {
             const double * xr = &sc.dtgt[k * NV + i0];
-            const double * yr = &sc.WD[k * NV + j0];
+            const double * yr = &sc.WD()[k * NV + j0];
 #pragma unroll
             for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -493,7 +493,7 @@ namespace smpc
           for (int k = 0; k < NF * 3; k++)
           {
             const double * xr = &sc.Jfoot[k * NV + i0];
-            const double * yr = &sc.WJf[k * NV + j0];
+            const double * yr = &sc.WJf()[k * NV + j0];
 #pragma unroll
             for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -519,7 +519,7 @@ namespace smpc
           for (int k = 0; k < 3; k++)
           {
             const double * xr = &sc.dtgt[k * NV + i0];
-            const double * yr = &sc.WJu[(3 + k) * 3 * NF + j0];
+            const double * yr = &sc.WJu()[(3 + k) * 3 * NF + j0];
 #pragma unroll
             for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -555,7 +555,7 @@ namespace smpc
             for (int c = 0; c < 3; c++)
             {
               const int k = j0 + c;
-              acc[a][c] += sc.WJu[a * 3 * NF + k] + xc.x * sc.WJu[3 * 3 * NF + k] + xc.y * sc.WJu[4 * 3 * NF + k] + xc.z * sc.WJu[5 * 3 * NF + k];
+              acc[a][c] += sc.WJu()[a * 3 * NF + k] + xc.x * sc.WJu()[3 * 3 * NF + k] + xc.y * sc.WJu()[4 * 3 * NF + k] + xc.z * sc.WJu()[5 * 3 * NF + k];
             }
           }
         }
@@ -575,7 +575,7 @@ namespace smpc
           if (i < NA)
             v = (k == 6 + i) ? 1.0 : 0.0;
           else
-            v = k < NV ? sc.dcq[(i - NA) * NV + k] : sc.dcv[(i - NA) * NV + k - NV];
+            v = k < NV ? sc.dcq()[(i - NA) * NV + k] : sc.dcv[(i - NA) * NV + k - NV];
         }
         lq[D::O_C + idx] = v;
       }
@@ -647,24 +647,19 @@ namespace smpc
   SMPC_DEV void trial_body(const StageKernelArgs<D> & ka, int block)
   {
     const int H = ka.b.H;
-    if (ka.slots > 0)
+    const int slot = block / (H + 1), t = block % (H + 1);
+    // slots > 0: backtracking launch over the compacted list of instances that rejected alpha = 1, `slots` at a time;
+    // slots == 0: block per (instance, stage).  One loop (one inlined copy of the stage evaluation) serves both.
+    const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : slot + 1;
+    const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
+    for (int m = slot; m < count; m += stride)
     {
-      // backtracking launch: only the instances that rejected alpha = 1 (compacted list), `slots` at a time
-      const int slot = block / (H + 1), t = block % (H + 1);
-      const int count = ka.b.und_list[ka.b.B];
-      for (int m = slot; m < count; m += ka.slots)
-      {
-        const int inst = ka.b.und_list[m];
-        for (int jj = 0; jj < ka.nj; jj++)
-          trial_one<D>(ka, inst, t, ka.j0 + jj);
-      }
-      return;
+      const int inst = ka.slots > 0 ? ka.b.und_list[m] : m;
+      if (ka.slots == 0 && ka.b.ls_sel[inst] >= 0)
+        break; // already accepted an earlier candidate (uniform across the workgroup)
+      for (int jj = 0; jj < ka.nj; jj++)
+        trial_one<D>(ka, inst, t, ka.j0 + jj);
     }
-    const int inst = block / (H + 1), t = block % (H + 1);
-    if (ka.b.ls_sel[inst] >= 0)
-      return; // already accepted an earlier candidate (uniform across the workgroup)
-    for (int jj = 0; jj < ka.nj; jj++)
-      trial_one<D>(ka, inst, t, ka.j0 + jj);
   }
 
   template <class D>

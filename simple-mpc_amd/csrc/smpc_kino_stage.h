@@ -27,11 +27,16 @@ namespace smpc
   {
     DevModelSmall<D> ml; // model constants (copied from global memory once per block)
     double x[D::NX], u[D::NU];
-    double oR[D::NJ * 9], op[D::NJ * 3];
-    double S[D::NV * 6];
-    double vel[D::NJ * 6], acc[D::NJ * 6];
-    double I[D::NJ * 10], Ic[D::NJ * 10];
-    double h[D::NJ * 6], hc[D::NJ * 6], Fc[D::NJ * 6];
+    // tree block A (contiguous, 667 doubles): dead once the derivative columns and the constraint values are formed;
+    // reused -- in this order of time -- by the wave reductions of the cost / multiplier phases and by the
+    // weighted-Jacobian tables of the assembly phases (accessors below)
+    double oR[D::NJ * 9], S[D::NV * 6], vel[D::NJ * 6], acc[D::NJ * 6], Ic[D::NJ * 10], hc[D::NJ * 6], Fc[D::NJ * 6];
+    // tree block B (contiguous, 247 doubles): dead before the derivative columns; reused by the contact-constraint
+    // Jacobian dcq (and, before that, by a temporary of the net-force update)
+    double op[D::NJ * 3], I[D::NJ * 10], h[D::NJ * 6];
+    SMPC_HD double * part() { return oR; }        // [64]
+    SMPC_HD double * part2() { return oR + 64; }  // [64]
+    SMPC_HD double * part8() { return oR + 128; } // [16]
     double footp[D::NF * 3];
     double com[3];
     double Ag[6 * D::NV];
@@ -45,7 +50,6 @@ namespace smpc
     double vplus[D::NC], lamp[D::NDX], lam_next[D::NDX], lam_prev[D::NDX], nu[D::NC];
     int act[D::NC];
     double red[8];
-    double part[64], part2[64], part8[16]; // wave reductions: 64 partials -> 8 -> 1 (fixed order)
   };
   template <class D>
   struct KinoScratchDerivPart
@@ -58,11 +62,7 @@ namespace smpc
     double WJl[D::NDX * 6];           // w_x[:,0:6] * Jl
     double JtW[6 * D::NDX];           // Jl^T w_x[0:6,:]
     double JWJ[36];                   // Jl^T w_x[0:6,0:6] Jl
-    double WJc[6 * D::NDX];           // w_cent * [dh_dq | Ag]
-    double WD[3 * D::NV];             // w_centder[3:6,3:6] * dtgt
-    double WJu[6 * 3 * D::NF];        // w_centder * Ju (force columns)
-    double WJf[D::NF * 3 * D::NV];    // w_frame * Jfoot
-    double dcq[D::NF * 3 * D::NV], dcv[D::NF * 3 * D::NV];
+    double dcv[D::NF * 3 * D::NV];
     double lx[D::NDX], lu[D::NU];
   };
   struct KinoScratchNoDeriv
@@ -71,6 +71,15 @@ namespace smpc
   template <class D, bool DERIV>
   struct KinoScratch : KinoScratchEval<D>, std::conditional<DERIV, KinoScratchDerivPart<D>, KinoScratchNoDeriv>::type
   {
+    // tables living in tree block A (written by the table phase, after the last reader of the tree data)
+    SMPC_HD double * WJc() { return this->oR; }       // [6][NDX]     w_cent * [dh_dq | Ag]
+    SMPC_HD double * WD() { return this->oR + 216; }  // [3][NV]      w_centder[3:6,3:6] * dtgt
+    SMPC_HD double * WJu() { return this->oR + 270; } // [6][3 NF]    w_centder * Ju (force columns)
+    SMPC_HD double * WJf() { return this->oR + 342; } // [3 NF][NV]   w_frame * Jfoot
+    SMPC_HD double * dcq() { return this->op; }       // [3 NF][NV]   d(contact velocity)/dq, in tree block B
+    static_assert(6 * D::NDX == 216 && 3 * D::NV == 54 && 18 * D::NF == 72 && 342 + 3 * D::NF * D::NV <= D::NJ * 9 + D::NV * 6 + D::NJ * 40,
+                  "table layout inside tree block A");
+    static_assert(3 * D::NF * D::NV <= D::NJ * 19, "dcq inside tree block B");
   };
 
   // inputs describing one stage evaluation
@@ -131,7 +140,8 @@ namespace smpc
     const double t = sqrt(dot(w, w));
     const M3 W = skew(w);
     const M3 W2 = W * W;
-    const double cB = cf_B(t), cC = cf_C(t), cD = cf_D(t);
+    const SE3Coef kf = se3_coef(t);
+    const double cB = kf.B, cC = kf.C, cD = kf.D;
     // exp: E.p = (I + B W + C W^2) dv ;  log: v = (I - W/2 + D W^2) p
     const double c1 = ex ? cB : -0.5, c2 = ex ? cC : cD;
     const V3 out = vec + c1 * (W * vec) + c2 * (W2 * vec);
@@ -139,14 +149,15 @@ namespace smpc
     M3 J = m3_id(), Q = m3_id();
     if constexpr (DERIV)
     {
-      Q = se3_Q(-1.0 * v, -1.0 * w);
+      Q = se3_Q(-1.0 * v, -1.0 * w, kf);
       J = m3_id() + (ex ? -cB : 0.5) * W + c2 * W2; // Jexp3(w) | Jlog3(w)
     }
     if (ex)
     {
       const M3 R0 = ldm3(&sc.oR[0]);
       st3(&sc.xnext[0], ld3(&sc.op[0]) + R0 * out);
-      Quat qn = quat_mul(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]}, quat_exp(w));
+      const double qs = 0.5 * kf.sinch;
+      Quat qn = quat_mul(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]}, Quat{qs * w.x, qs * w.y, qs * w.z, kf.ch});
       const double n = 1.0 / sqrt(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
       sc.xnext[3] = qn.x * n;
       sc.xnext[4] = qn.y * n;
@@ -157,7 +168,7 @@ namespace smpc
         stm3(sc.Je3, J);
         stm3(sc.JeQ, Q);
         // action matrix of exp6(nu)^-1 = [[R^T, -R^T [p]x],[0, R^T]]
-        const M3 Rt = transpose(m3_id() + cf_sinc(t) * W + cB * W2);
+        const M3 Rt = transpose(m3_id() + kf.sinc * W + cB * W2);
         const M3 X = (-1.0) * (Rt * skew(out));
         double * Jq = sc.Jq;
         const double rt[9] = {Rt.a00, Rt.a01, Rt.a02, Rt.a10, Rt.a11, Rt.a12, Rt.a20, Rt.a21, Rt.a22};
@@ -312,8 +323,8 @@ namespace smpc
     double * Bm = nullptr;
     if constexpr (DERIV)
     {
-      static_assert(D::NDX * 6 + 6 * D::NDX + 36 + 6 * D::NDX >= NJ * 36, "B matrices overlay WJl | JtW | JWJ | WJc");
-      static_assert(offsetof(KinoScratchDerivPart<D>, WJc) - offsetof(KinoScratchDerivPart<D>, WJl) == (D::NDX * 12 + 36) * sizeof(double),
+      static_assert(D::NDX * 6 + 6 * D::NDX + 36 >= NJ * 36, "B matrices overlay WJl | JtW | JWJ");
+      static_assert(offsetof(KinoScratchDerivPart<D>, JWJ) - offsetof(KinoScratchDerivPart<D>, WJl) == D::NDX * 12 * sizeof(double),
                     "table block must be contiguous");
       Bm = sc.WJl;
       SMPC_LANES(NT)
@@ -537,7 +548,7 @@ namespace smpc
     //      With aS_k = a_k S_k and dacc_i = sum_{k <= i} aS_k the middle term is Ic_i dacc_i; the last one sums
     //      the per-dof vectors Ic_{j(k)} aS_k.  Both per-dof vectors are formed once (lane = dof), then lane = joint
     //      only adds (the scratch of the constraint derivatives, written later, holds them meanwhile).
-    double * aS = sc.dcq;  // [NV][6]
+    double * aS = sc.dcq();  // [NV][6]
     double * IaS = sc.dcv; // [NV][6]
     static_assert(NF * 3 >= 6, "temporary storage");
     SMPC_LANES(NT)
@@ -663,9 +674,9 @@ namespace smpc
         sc.Jfoot[(f * 3 + 0) * NV + k] = jf.x;
         sc.Jfoot[(f * 3 + 1) * NV + k] = jf.y;
         sc.Jfoot[(f * 3 + 2) * NV + k] = jf.z;
-        sc.dcq[(f * 3 + 0) * NV + k] = cq.x;
-        sc.dcq[(f * 3 + 1) * NV + k] = cq.y;
-        sc.dcq[(f * 3 + 2) * NV + k] = cq.z;
+        sc.dcq()[(f * 3 + 0) * NV + k] = cq.x;
+        sc.dcq()[(f * 3 + 1) * NV + k] = cq.y;
+        sc.dcq()[(f * 3 + 2) * NV + k] = cq.z;
         sc.dcv[(f * 3 + 0) * NV + k] = cv.x;
         sc.dcv[(f * 3 + 1) * NV + k] = cv.y;
         sc.dcv[(f * 3 + 2) * NV + k] = cv.z;
@@ -872,7 +883,7 @@ namespace smpc
         c = sc.rf[lane - NDX - 12] * sc.Wrf[lane - NDX - 12];
       if (!in.terminal && lane < NU)
         c += sc.ru[lane] * sc.Wru[lane];
-      sc.part[lane] = c;
+      sc.part()[lane] = c;
     }
     SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
@@ -881,8 +892,8 @@ namespace smpc
       double c = 0.0;
 #pragma unroll
       for (int i = 0; i < 8; i++)
-        c += sc.part[lane * 8 + i];
-      sc.part8[lane] = c;
+        c += sc.part()[lane * 8 + i];
+      sc.part8()[lane] = c;
     }
     SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
@@ -891,7 +902,7 @@ namespace smpc
       double c = 0.0;
 #pragma unroll
       for (int i = 0; i < 8; i++)
-        c += sc.part8[i];
+        c += sc.part8()[i];
       sc.red[0] = 0.5 * c;
     }
     SMPC_LANES_END_WAVE
@@ -962,8 +973,8 @@ namespace smpc
         else if ((in.mask >> ((i - NA) / 3)) & 1u)
           prim = fabs(sc.cval[i]);
       }
-      sc.part[lane] = pen;
-      sc.part2[lane] = prim;
+      sc.part()[lane] = pen;
+      sc.part2()[lane] = prim;
     }
     SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
@@ -973,11 +984,11 @@ namespace smpc
 #pragma unroll
       for (int i = 0; i < 8; i++)
       {
-        pen += sc.part[lane * 8 + i];
-        prim = fmax(prim, sc.part2[lane * 8 + i]);
+        pen += sc.part()[lane * 8 + i];
+        prim = fmax(prim, sc.part2()[lane * 8 + i]);
       }
-      sc.part8[lane] = pen;
-      sc.part8[8 + lane] = prim;
+      sc.part8()[lane] = pen;
+      sc.part8()[8 + lane] = prim;
     }
     SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
@@ -987,8 +998,8 @@ namespace smpc
 #pragma unroll
       for (int i = 0; i < 8; i++)
       {
-        pen += sc.part8[i];
-        prim = fmax(prim, sc.part8[8 + i]);
+        pen += sc.part8()[i];
+        prim = fmax(prim, sc.part8()[8 + i]);
       }
       sc.red[1] = pen;
       sc.red[2] = prim;

@@ -203,6 +203,48 @@ namespace smpc
     const M3 FPFF = FPF * F, FFPF = F * FPF;
     return 0.5 * P + cf_C(t) * (FP + PF + FPF) + cf_Q2(t) * (FFP + PFF + (-3.0) * FPF) + cf_Q3(t) * (FPFF + FFPF);
   }
+  // all coefficient functions of one angle from a single sincos(t/2) (sin t = 2 s c, cos t = 1 - 2 s^2)
+  struct SE3Coef
+  {
+    double sinc, sinch, ch, B, C, D, Q2, Q3; // sin t / t, sin(t/2)/(t/2), cos(t/2), cf_B .. cf_Q3
+  };
+  SMPC_HD SE3Coef se3_coef(double t)
+  {
+    SE3Coef k;
+    const double h = 0.5 * t, t2 = t * t;
+    double sh, ch;
+    sincos(h, &sh, &ch);
+    const double s1 = 2.0 * sh * ch, c1 = 1.0 - 2.0 * sh * sh;
+    k.ch = ch;
+    k.sinch = h < 1e-4 ? 1.0 - h * h / 6.0 : sh / h;
+    k.sinc = t < 1e-4 ? 1.0 - t2 / 6.0 : s1 / t;
+    k.B = 0.5 * k.sinch * k.sinch;
+    if (t < 0.05)
+    {
+      k.C = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0 - t2 * t2 * t2 / 362880.0;
+      k.D = 1.0 / 12.0 + t2 / 720.0 + t2 * t2 / 30240.0 + t2 * t2 * t2 / 1209600.0;
+      k.Q2 = 1.0 / 24.0 - t2 / 720.0 + t2 * t2 / 40320.0;
+      k.Q3 = 1.0 / 120.0 - t2 / 2520.0 + t2 * t2 / 120960.0;
+    }
+    else
+    {
+      k.C = (t - s1) / (t2 * t);
+      k.D = 1.0 / t2 - (1.0 + c1) / (2.0 * t * s1);
+      k.Q2 = (t2 + 2.0 * c1 - 2.0) / (2.0 * t2 * t2);
+      k.Q3 = (2.0 * t - 3.0 * s1 + t * c1) / (2.0 * t2 * t2 * t);
+    }
+    return k;
+  }
+  // se3_Q with precomputed coefficients
+  SMPC_HD M3 se3_Q(V3 rho, V3 phi, const SE3Coef & k)
+  {
+    const M3 P = skew(rho), F = skew(phi);
+    const M3 FP = F * P, PF = P * F;
+    const M3 FPF = FP * F;
+    const M3 FFP = F * FP, PFF = PF * F;
+    const M3 FPFF = FPF * F, FFPF = F * FPF;
+    return 0.5 * P + k.C * (FP + PF + FPF) + k.Q2 * (FFP + PFF + (-3.0) * FPF) + k.Q3 * (FPFF + FFPF);
+  }
   // right Jacobian of SE(3) at nu=[v;w]: J = [[J3, Q],[0, J3]]
   SMPC_HD void Jexp6(V3 v, V3 w, M3 & J3, M3 & Q)
   {
