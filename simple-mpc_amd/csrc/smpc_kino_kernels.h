@@ -245,12 +245,12 @@ namespace smpc
           t += sc.Jl[bb * 6 + a] * mg.w_x[bb * NDX + k];
         sc.JtW[idx] = t;
       }
-      for (int idx = lane; idx < 3 * NV; idx += NT)
+      for (int idx = lane; idx < 6 * NV; idx += NT)
       {
         const int a = idx / NV, k = idx % NV;
         double s = 0.0;
         for (int bb = 0; bb < 3; bb++)
-          s += md.w_centder[(3 + a) * 6 + 3 + bb] * sc.dtgt[bb * NV + k];
+          s += md.w_centder[a * 6 + 3 + bb] * sc.dtgt[bb * NV + k];
         sc.WD()[idx] = s;
       }
       for (int idx = lane; idx < 6 * 3 * NF; idx += NT)
@@ -433,138 +433,162 @@ namespace smpc
     SMPC_LANES_END_WAVE
 
     if (in.prof) prof_tick(in.prof, 33, tprev);
-    // ---- Q, S, R as 3x3 register tiles over the structured sum of J^T W J terms:
-    //      Q = state block (table look-ups) + Jc^T (Wc Jc) [K=6, all 36x36]
-    //          + dtgt^T (Wcd dtgt) [K=3] + Jfoot^T (Wf Jfoot) [K=3 NF]   on the q x q block only
-    //      S = dtgt^T (Wcd Ju)   on (q rows) x (force columns of feet in contact), zero elsewhere
-    //      R = w_u + Ju^T (Wcd Ju) on the force x force block ----
-    SMPC_LANES(NT)
+    // ---- Q, S, R on the matrix cores:  H = [Q S; S^T R] = H_0 + J^T (W J)  with the stacked Gauss-Newton Jacobian
+    //        rows  0.. 5  centroidal momentum      J = [dh_dq | Ag | 0]                    W J = WJc
+    //        rows  8..13  momentum derivative      J = [[0; dtgt] | 0 | Ju (contact) | 0]  W J = [WD | 0 | WJu | 0]
+    //        rows 16..27  foot positions           J = [Jfoot | 0 | 0]                     W J = WJf
+    //      (K = 28 with two zero rows after each 6-row group, 7 K-steps of 4),  H_0 = state / control weight blocks
+    //      + preg I.  Upper 16x16 tiles of the 64-padded (x, u) grid; tile column 3 (joint-acceleration columns of u)
+    //      has no Jacobian entries and is written from the weights directly. ----
     {
-      constexpr int TQ = NDX / 3;
-      for (int tile = lane; tile < TQ * TQ; tile += NT)
+      constexpr int T3I[6] = {0, 0, 0, 1, 1, 2}, T3J[6] = {0, 1, 2, 1, 2, 2};
+      SMPC_ACC(qacc, NT, 6);
+      SMPC_PLA(double, av, NT, 7 * 3);
+      SMPC_PLA(double, bv, NT, 7 * 3);
+      SMPC_LANES(NT)
       {
-        const int i0 = (tile / TQ) * 3, j0 = (tile % TQ) * 3;
-        double acc[3][3];
+        const int lr = lane >> 4, lc = lane & 15;
+        // H_0 in accumulator layout: the weight entries come from global memory -- all loads are issued first
+        // (one per accumulator entry, address-selected), the table look-ups and selects follow
+        double wv[24];
 #pragma unroll
-        for (int a = 0; a < 3; a++)
+        for (int tt = 0; tt < 6; tt++)
 #pragma unroll
-          for (int c = 0; c < 3; c++)
+          for (int v = 0; v < 4; v++)
           {
-            const int i = i0 + a, j = j0 + c;
-            // state block: J_x^T w_x J_x with J_x = blockdiag(Jlog6, I)
-            double v;
-            if (i < 6)
-              v = j < 6 ? sc.JWJ[i * 6 + j] : sc.JtW[i * NDX + j];
-            else
-              v = j < 6 ? sc.WJl[i * 6 + j] : mg.w_x[i * NDX + j];
-            acc[a][c] = v + (i == j ? preg : 0.0);
+            const int row = 16 * T3I[tt] + lr + 4 * v, col = 16 * T3J[tt] + lc;
+            const bool inx = row >= 6 && row < NDX && col >= 6 && col < NDX;
+            const bool inu = row >= NDX && row < NDX + NU && col >= NDX && col < NDX + NU;
+            const double * src = inx ? &mg.w_x[row * NDX + col] : (inu ? &mg.w_u[(row - NDX) * NU + col - NDX] : &mg.w_x[0]);
+            wv[tt * 4 + v] = *src;
           }
-        const double * jc = i0 < NV ? &sc.dh_dq[i0] : &sc.Ag[i0 - NV];
 #pragma unroll
-        for (int k = 0; k < 6; k++)
-        {
-          const double x0 = jc[k * NV], x1 = jc[k * NV + 1], x2 = jc[k * NV + 2];
-          const double * wr = &sc.WJc()[k * NDX + j0];
-          const double y0 = wr[0], y1 = wr[1], y2 = wr[2];
-          acc[0][0] += x0 * y0;
-          acc[0][1] += x0 * y1;
-          acc[0][2] += x0 * y2;
-          acc[1][0] += x1 * y0;
-          acc[1][1] += x1 * y1;
-          acc[1][2] += x1 * y2;
-          acc[2][0] += x2 * y0;
-          acc[2][1] += x2 * y1;
-          acc[2][2] += x2 * y2;
-        }
-        if (i0 < NV && j0 < NV)
-        {
+        for (int tt = 0; tt < 6; tt++)
 #pragma unroll
-          for (int k = 0; k < 3; k++)
+          for (int v = 0; v < 4; v++)
           {
-            const double * xr = &sc.dtgt[k * NV + i0];
-            const double * yr = &sc.WD()[k * NV + j0];
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-              for (int c = 0; c < 3; c++)
-                acc[a][c] += xr[a] * yr[c];
+            const int row = 16 * T3I[tt] + lr + 4 * v, col = 16 * T3J[tt] + lc;
+            const bool inx = row >= 6 && row < NDX && col >= 6 && col < NDX;
+            const bool inu = row >= NDX && row < NDX + NU && col >= NDX && col < NDX + NU;
+            double val = (inx || inu) ? wv[tt * 4 + v] : 0.0;
+            if (row < NDX && col < NDX && (row < 6 || col < 6))
+              val = row < 6 ? (col < 6 ? sc.JWJ[row * 6 + col] : sc.JtW[row * NDX + col]) : sc.WJl[row * 6 + col];
+            SMPC_ACCV(qacc, tt, v) = val + ((row == col && row < NDX + NU) ? preg : 0.0);
           }
-#pragma unroll 4
-          for (int k = 0; k < NF * 3; k++)
+        // operands
+#pragma unroll
+        for (int ks = 0; ks < 7; ks++)
+#pragma unroll
+          for (int I = 0; I < 3; I++)
           {
-            const double * xr = &sc.Jfoot[k * NV + i0];
-            const double * yr = &sc.WJf()[k * NV + j0];
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-              for (int c = 0; c < 3; c++)
-                acc[a][c] += xr[a] * yr[c];
-          }
-        }
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-          for (int c = 0; c < 3; c++)
-            lq[D::O_Q + (i0 + a) * NDX + j0 + c] = acc[a][c];
-      }
-      // S
-      constexpr int TS = NU / 3;
-      for (int tile = lane; tile < TQ * TS; tile += NT)
-      {
-        const int i0 = (tile / TS) * 3, j0 = (tile % TS) * 3;
-        double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        if (i0 < NV && j0 < 3 * NF && ((in.mask >> (j0 / 3)) & 1u))
-        {
-#pragma unroll
-          for (int k = 0; k < 3; k++)
-          {
-            const double * xr = &sc.dtgt[k * NV + i0];
-            const double * yr = &sc.WJu()[(3 + k) * 3 * NF + j0];
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-              for (int c = 0; c < 3; c++)
-                acc[a][c] += xr[a] * yr[c];
-          }
-        }
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-          for (int c = 0; c < 3; c++)
-            lq[D::O_S + (i0 + a) * NU + j0 + c] = acc[a][c];
-      }
-      // R
-      for (int tile = lane; tile < TS * TS; tile += NT)
-      {
-        const int i0 = (tile / TS) * 3, j0 = (tile % TS) * 3;
-        double acc[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-          for (int c = 0; c < 3; c++)
-            acc[a][c] = mg.w_u[(i0 + a) * NU + j0 + c] + ((i0 + a) == (j0 + c) ? preg : 0.0);
-        if (i0 < 3 * NF && j0 < 3 * NF && ((in.mask >> (i0 / 3)) & 1u) && ((in.mask >> (j0 / 3)) & 1u))
-        {
-          // Ju[:, 3f+a] = [e_a ; (p_f - c) x e_a]
-          const V3 rr = ld3(&sc.footp[(i0 / 3) * 3]) - ld3(sc.com);
-#pragma unroll
-          for (int a = 0; a < 3; a++)
-          {
-            const V3 xc = cross(rr, mk3(a == 0, a == 1, a == 2));
-#pragma unroll
-            for (int c = 0; c < 3; c++)
+            const int col = 16 * I + lc;
+            double a = 0.0, bq = 0.0;
+            if (ks < 2)
             {
-              const int k = j0 + c;
-              acc[a][c] += sc.WJu()[a * 3 * NF + k] + xc.x * sc.WJu()[3 * 3 * NF + k] + xc.y * sc.WJu()[4 * 3 * NF + k] + xc.z * sc.WJu()[5 * 3 * NF + k];
+              const int r = 4 * ks + lr;
+              if (r < 6 && col < NDX)
+              {
+                a = col < NV ? sc.dh_dq[r * NV + col] : sc.Ag[r * NV + col - NV];
+                bq = sc.WJc()[r * NDX + col];
+              }
+            }
+            else if (ks < 4)
+            {
+              const int r = 4 * (ks - 2) + lr;
+              if (r < 6)
+              {
+                if (col < NV)
+                {
+                  a = r >= 3 ? sc.dtgt[(r - 3) * NV + col] : 0.0;
+                  bq = sc.WD()[r * NV + col];
+                }
+                else if (col >= NDX && col < NDX + 3 * NF)
+                {
+                  const int k = col - NDX, f = k / 3, j = k % 3;
+                  if ((in.mask >> f) & 1u)
+                  {
+                    // Ju[:, 3f+j] = [e_j ; (p_f - c) x e_j]
+                    const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
+                    const V3 xc = cross(rr, mk3(j == 0, j == 1, j == 2));
+                    a = r < 3 ? (r == j ? 1.0 : 0.0) : (r == 3 ? xc.x : (r == 4 ? xc.y : xc.z));
+                    bq = sc.WJu()[r * 3 * NF + k];
+                  }
+                }
+              }
+            }
+            else
+            {
+              const int r = 4 * (ks - 4) + lr;
+              if (col < NV)
+              {
+                a = sc.Jfoot[r * NV + col];
+                bq = sc.WJf()[r * NV + col];
+              }
+            }
+            SMPC_PLV(av)[ks * 3 + I] = a;
+            SMPC_PLV(bv)[ks * 3 + I] = bq;
+          }
+      }
+      SMPC_LANES_END_WAVE
+#pragma unroll
+      for (int ks = 0; ks < 7; ks++)
+#pragma unroll
+        for (int tt = 0; tt < 6; tt++)
+          if (ks < 4 || T3J[tt] < 2) // the foot rows only reach the q columns (tile columns 0, 1)
+            SMPC_MFMA(qacc, tt, av, ks * 3 + T3I[tt], bv, ks * 3 + T3J[tt]);
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int tt = 0; tt < 6; tt++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            const int row = 16 * T3I[tt] + lr + 4 * v, col = 16 * T3J[tt] + lc;
+            const double val = SMPC_ACCV(qacc, tt, v);
+            if (col < NDX)
+            {
+              if (row < NDX)
+              {
+                lq[D::O_Q + row * NDX + col] = val;
+                if (T3I[tt] != T3J[tt])
+                  lq[D::O_Q + col * NDX + row] = val; // off-diagonal tiles: mirror
+              }
+            }
+            else if (col < NDX + 16 * 3 - NDX && col < NDX + NU)
+            {
+              if (row < NDX)
+                lq[D::O_S + row * NU + col - NDX] = val;
+              else
+                lq[D::O_R + (row - NDX) * NU + col - NDX] = val;
             }
           }
+        // columns / rows of the joint accelerations (u indices >= 16 * 3 - NDX): no Jacobian entries
+        constexpr int UC = 16 * 3 - NDX; // u columns covered by the tiles
+        for (int idx = lane; idx < NDX * (NU - UC); idx += NT)
+        {
+          const int i = idx / (NU - UC), j = UC + idx % (NU - UC);
+          lq[D::O_S + i * NU + j] = 0.0;
         }
+        {
+          constexpr int NR = (NU * NU + NT - 1) / NT;
+          double rv[NR]; // batched: a rolled load -> store loop would pay the global latency NR times
 #pragma unroll
-        for (int a = 0; a < 3; a++)
+          for (int n = 0; n < NR; n++)
+            rv[n] = mg.w_u[lane + n * NT < NU * NU ? lane + n * NT : 0];
 #pragma unroll
-          for (int c = 0; c < 3; c++)
-            lq[D::O_R + (i0 + a) * NU + j0 + c] = acc[a][c];
+          for (int n = 0; n < NR; n++)
+          {
+            const int idx = lane + n * NT, i = idx / NU, j = idx % NU;
+            if (idx < NU * NU && (i >= UC || j >= UC))
+              lq[D::O_R + idx] = rv[n] + (i == j ? preg : 0.0);
+          }
+        }
       }
+      SMPC_LANES_END_WAVE
+    }
+    SMPC_LANES(NT)
+    {
       // C (active rows; coalesced row runs), d, vpd
       for (int idx = lane; idx < NC * NDX; idx += NT)
       {

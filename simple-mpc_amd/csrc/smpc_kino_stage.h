@@ -73,11 +73,11 @@ namespace smpc
   {
     // tables living in tree block A (written by the table phase, after the last reader of the tree data)
     SMPC_HD double * WJc() { return this->oR; }       // [6][NDX]     w_cent * [dh_dq | Ag]
-    SMPC_HD double * WD() { return this->oR + 216; }  // [3][NV]      w_centder[3:6,3:6] * dtgt
-    SMPC_HD double * WJu() { return this->oR + 270; } // [6][3 NF]    w_centder * Ju (force columns)
-    SMPC_HD double * WJf() { return this->oR + 342; } // [3 NF][NV]   w_frame * Jfoot
+    SMPC_HD double * WD() { return this->oR + 216; }  // [6][NV]      w_centder[:,3:6] * dtgt
+    SMPC_HD double * WJu() { return this->oR + 324; } // [6][3 NF]    w_centder * Ju (force columns)
+    SMPC_HD double * WJf() { return this->oR + 396; } // [3 NF][NV]   w_frame * Jfoot
     SMPC_HD double * dcq() { return this->op; }       // [3 NF][NV]   d(contact velocity)/dq, in tree block B
-    static_assert(6 * D::NDX == 216 && 3 * D::NV == 54 && 18 * D::NF == 72 && 342 + 3 * D::NF * D::NV <= D::NJ * 9 + D::NV * 6 + D::NJ * 40,
+    static_assert(6 * D::NDX == 216 && 6 * D::NV == 108 && 18 * D::NF == 72 && 396 + 3 * D::NF * D::NV <= D::NJ * 9 + D::NV * 6 + D::NJ * 40,
                   "table layout inside tree block A");
     static_assert(3 * D::NF * D::NV <= D::NJ * 19, "dcq inside tree block B");
   };
