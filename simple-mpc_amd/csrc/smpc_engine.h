@@ -139,6 +139,7 @@ namespace smpc
     long kernel_calls[KID_N] = {0};
     std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
     static constexpr int TRIAL_MINW = SMPC_TRIAL_MINW; // waves per SIMD the trial kernel's register budget allows
+    static constexpr int RICCATI_MINW = 2;             // the Riccati sweep is latency bound: 2 waves per SIMD (8 per CU, 19.8 KB LDS each)
     static constexpr double ARMIJO_C1 = 1e-4, REG_INIT = 1e-9, REG_MIN = 1e-10, REG_MAX = 1e9, REG_INC = 10.0, REG_DEC = 1.0 / 3.0, STALL_REL = 1e-9;
 
     KinoEngine(const smpc_robot_model * rm, const HostKinoSettings & ks, const HostMpcSettings & ms_, int batch, double gravity_arg, int device)
@@ -343,7 +344,7 @@ namespace smpc
       if (structured_riccati)
       {
         // kinodynamics-structured sweep, one wavefront per instance, factored feedback
-        timed_launch<SolverArgs<D>, riccati_kino_body<D>, 64>(KID_RICCATI, b.B, solver_args(b));
+        timed_launch<SolverArgs<D>, riccati_kino_body<D>, 64, RICCATI_MINW>(KID_RICCATI, b.B, solver_args(b));
         timed_launch<SolverArgs<D>, forward_kino_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
       }
       else

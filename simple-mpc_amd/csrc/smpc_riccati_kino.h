@@ -238,11 +238,12 @@ namespace smpc
   {
     static constexpr int NDX = D::NDX, NU = D::NU, NXU = D::NDX + D::NU, NG = 12;
     static constexpr int SWP = 4 * 16 * 5; // one operand block of the widest sweep (4 x 80)
-    static constexpr int SCR_G = 3 * NG * NXU, SCR_W = NG * NDX + NU * (NDX + 1) + 2 * SWP;
-    static constexpr int SCR = SCR_G > SCR_W ? SCR_G : SCR_W;
+    static constexpr int SCR_1 = 2 * SWP, SCR_2 = NG * NXU, SCR_3 = NG * NDX + 2 * 4 * 64;
+    static constexpr int SCR = SCR_1 > SCR_2 ? (SCR_1 > SCR_3 ? SCR_1 : SCR_3) : (SCR_2 > SCR_3 ? SCR_2 : SCR_3);
+    static_assert(NU * (NDX + 1) <= SCR_3, "the [K | k] staging block takes over Cc and the sweep operands");
     double P[NDX * NDX]; // P_{t+1} -> P~ (-> E^T P~ E in place) -> P_t
-    // scratch, by phase:  sweep operands (2 x 4 x 80)  ->  [NAB | PEG | TG] (3 x NG x NXU)
-    //                     ->  [Cc (NG x NDX) | K staging (NU x (NDX+1)) | sweep operands (2 x 4 x 64)]
+    // scratch, by phase:  sweep operands (2 x 4 x 80)  ->  NAB (NG x NXU)
+    //                     ->  [Cc (NG x NDX) | sweep operands (2 x 4 x 64)]  ->  staging of [K | k] (NU x (NDX+1))
     double scr[SCR];
     double p[NDX], pt0[NDX], pt[NDX], qh[NDX], rh[NU], f[NDX];
     double dc[NG], boxd[D::NA], boxact[D::NA];
@@ -260,7 +261,6 @@ namespace smpc
     typedef GainsK<D> GK;
     static_assert(NDX % 4 == 0 && NU % 4 == 0 && NG % 4 == 0, "pivot panels and K steps of 4");
     static_assert(2 * NDX + 1 <= 80 && NXU + 1 <= 64, "bordered matrices fit the 5x5 / 4x4 tile grids");
-    static_assert(3 * NG * NXU <= RiccatiKinoLds<D>::SCR, "overlay of the small blocks");
     const Buffers<D> & b = ka.b;
     const int H = b.H;
     const int inst = block;
@@ -268,12 +268,10 @@ namespace smpc
     SMPC_LDS(RiccatiKinoLds<D>, lds, 1);
     RiccatiKinoLds<D> & s = lds[0];
     double * NAB = s.scr;                      // [NG][NXU]  dense rows of [A | B]           phase 4
-    double * PEG = s.scr + NG * NXU;           // [NG][NXU]  (P~ E)[G,:] | (P~ E_b)[G,:]
-    double * TG = s.scr + 2 * NG * NXU;        // [NG][NXU]  (P~ A)[G,:] | (P~ B)[G,:]
     double * Cc = s.scr;                       // [NG][NDX]  contact rows                     phase 5-6
-    double * Wm = s.scr + NG * NDX;            // [NU][NDX+1] staging of [K | k]
+    double * Wm = s.scr;                       // [NU][NDX+1] staging of [K | k]              epilogue
     double * sw1 = s.scr;                      // sweep operands of the first (5x5 tiles) sweep: 2 x 4 x 80
-    double * sw2 = s.scr + NG * NDX + NU * (NDX + 1); // ... of the second (4x4 tiles): 2 x 4 x 64
+    double * sw2 = s.scr + NG * NDX;           // ... of the second (4x4 tiles): 2 x 4 x 64
 
     SMPC_LANES(NT)
     {
@@ -442,34 +440,24 @@ namespace smpc
       // ---- (4a) column pass, in place:  P[:, vj] += dt P[:, qj]   (P now holds P~ E on its J columns) ----
       // E_b = dt * E[:, vj], so every product with E_b is a scaled slice of the same matrix.
       SMPC_LANES(NT)
-      for (int idx = lane; idx < NDX * NA; idx += NT)
       {
-        const int i = idx / NA, jp = idx % NA;
-        s.P[i * NDX + NV + 6 + jp] += dt * s.P[i * NDX + 6 + jp];
+        // lane -> (row group, column): NA columns x 5 row groups, no index division in the loop
+        const int jp = lane % NA, ib = lane / NA;
+        if (ib < 5)
+          for (int i = ib; i < NDX; i += 5)
+            s.P[i * NDX + NV + 6 + jp] += dt * s.P[i * NDX + 6 + jp];
       }
       SMPC_LANES_END_WAVE
-      // ---- (4b) PEG = [(P~ E)[G,:] | (P~ E_b)[G,:]]  (zero in the G / force columns) ----
-      SMPC_LANES(NT)
-      for (int idx = lane; idx < NG * NXU; idx += NT)
-      {
-        const int gi = idx / NXU, j = idx % NXU;
-        const double * pg = &s.P[IX::G(gi) * NDX];
-        double v = 0.0;
-        if (j < NDX)
-        {
-          if (!IX::isG(j))
-            v = pg[j];
-        }
-        else if (j - NDX >= 3 * NF)
-          v = dt * pg[NV + 6 + j - NDX - 3 * NF];
-        PEG[idx] = v;
-      }
-      SMPC_LANES_END_WAVE
+      static_assert(5 * NA <= NT, "lane map of the column pass");
       prof_tick(prof, 6, tprev);
-      // ---- (4c) TG = P~[G,G] * NAB + PEG on the matrix cores (M = NG padded to 16, N = NXU padded to 64, K = NG) ----
+      // ---- (4b, 4c) PEG = [(P~ E)[G,:] | (P~ E_b)[G,:]] (zero in the G / force columns), gathered from P straight
+      //      into accumulator layout;  TG = P~[G,G] * NAB + PEG on the matrix cores (M = NG -> 16, N = NXU -> 64, K = NG).
+      //      Both stay in registers: in accumulator layout a lane holds rows lr, lr + 4, lr + 8 of its column, which
+      //      are exactly the rows 4 ks + lr it must supply as an MFMA operand at K-step ks of the next product. ----
+      constexpr int KS = NG / 4;
+      SMPC_ACC(tacc, NT, 4);
+      SMPC_PLA(double, pegv, NT, 4 * KS);
       {
-        constexpr int KS = NG / 4;
-        SMPC_ACC(tacc, NT, 4);
         SMPC_PLA(double, pgv, NT, KS);
         SMPC_PLA(double, nbv, NT, KS * 4);
         SMPC_LANES(NT)
@@ -481,9 +469,13 @@ namespace smpc
             for (int v = 0; v < 4; v++)
             {
               const int row = lr + 4 * v, col = 16 * J + lc;
-              const bool valid = row < NG && col < NXU;
-              const double pv = PEG[(valid ? row : 0) * NXU + (valid ? col : 0)];
-              SMPC_ACCV(tacc, J, v) = valid ? pv : 0.0;
+              const int ac = col - NDX - 3 * NF; // joint-acceleration column if >= 0
+              const int pc = col < NDX ? col : (ac >= 0 && col < NXU ? NV + 6 + ac : 0);
+              const double scale = col < NDX ? (IX::isG(col) ? 0.0 : 1.0) : (ac >= 0 && col < NXU ? dt : 0.0);
+              const double pv = v < KS ? scale * s.P[IX::G(row < NG ? row : 0) * NDX + pc] : 0.0;
+              SMPC_ACCV(tacc, J, v) = pv;
+              if (v < KS)
+                SMPC_PLV(pegv)[J * KS + v] = pv;
             }
 #pragma unroll
           for (int ks = 0; ks < KS; ks++)
@@ -505,34 +497,18 @@ namespace smpc
 #pragma unroll
           for (int J = 0; J < 4; J++)
             SMPC_MFMA(tacc, J, pgv, ks, nbv, ks * 4 + J);
-        // TG out ; row pass, in place: P[vj, :] += dt P[qj, :]  (P[J,J] = E^T P~ E)
+        // row pass, in place: P[vj, :] += dt P[qj, :]  (P[J,J] = E^T P~ E)
         SMPC_LANES(NT)
-        {
-          const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-          for (int J = 0; J < 4; J++)
-#pragma unroll
-            for (int v = 0; v < 3; v++) // rows lr + 4 v < NG = 12
-            {
-              const int row = lr + 4 * v, col = 16 * J + lc;
-              if (col < NXU)
-                TG[row * NXU + col] = SMPC_ACCV(tacc, J, v);
-            }
-          for (int idx = lane; idx < NA * NDX; idx += NT)
-          {
-            const int ip = idx / NDX, j = idx % NDX;
-            s.P[(NV + 6 + ip) * NDX + j] += dt * s.P[(6 + ip) * NDX + j];
-          }
-        }
+        if (lane < NDX)
+          for (int ip = 0; ip < NA; ip++)
+            s.P[(NV + 6 + ip) * NDX + lane] += dt * s.P[(6 + ip) * NDX + lane];
         SMPC_LANES_END_WAVE
       }
       prof_tick(prof, 7, tprev);
       // ---- (4d) H^ += E^T P~ [E|E_b] (structured) + NAB^T TG + PEG^T NAB  (matrix cores, K = 2 NG) ; q^ , r^ ----
       {
-        constexpr int KS = NG / 4;
         SMPC_PLA(double, nav, NT, KS * 4);
         SMPC_PLA(double, tgv, NT, KS * 4);
-        SMPC_PLA(double, pev, NT, KS * 4);
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
@@ -541,11 +517,10 @@ namespace smpc
 #pragma unroll
             for (int J = 0; J < 4; J++)
             {
-              const int col = 16 * J + lc, off = (4 * ks + lr) * NXU + (col < NXU ? col : 0);
-              const double a0 = NAB[off], a1 = TG[off], a2 = PEG[off];
+              const int col = 16 * J + lc;
+              const double a0 = NAB[(4 * ks + lr) * NXU + (col < NXU ? col : 0)];
               SMPC_PLV(nav)[ks * 4 + J] = col < NXU ? a0 : 0.0;
-              SMPC_PLV(tgv)[ks * 4 + J] = col < NXU ? a1 : 0.0;
-              SMPC_PLV(pev)[ks * 4 + J] = col < NXU ? a2 : 0.0;
+              SMPC_PLV(tgv)[ks * 4 + J] = col < NXU ? SMPC_ACCV(tacc, J, ks) : 0.0;
             }
           // structured term: index m of [x | u] -> (column of P, scale): x: (m, 0 on G rows else 1); u: joint accelerations
           // map to the vj columns with scale dt, forces to nothing
@@ -596,7 +571,7 @@ namespace smpc
           for (int tt = 0; tt < 10; tt++)
           {
             SMPC_MFMA(hacc, tt, nav, ks * 4 + T4I[tt], tgv, ks * 4 + T4J[tt]);
-            SMPC_MFMA(hacc, tt, pev, ks * 4 + T4I[tt], nav, ks * 4 + T4J[tt]);
+            SMPC_MFMA(hacc, tt, pegv, T4I[tt] * KS + ks, nav, ks * 4 + T4J[tt]);
           }
       }
       prof_tick(prof, 8, tprev);
