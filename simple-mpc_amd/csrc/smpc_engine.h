@@ -206,6 +206,21 @@ namespace smpc
       for (int i = 0; i < D::NU; i++)
         for (int j = 0; j < D::NU; j++)
           m.w_uT[j * D::NU + i] = m.w_u[i * D::NU + j];
+      m.w_diag = 1;
+      for (int i = 0; i < D::NDX; i++)
+        for (int j = 0; j < D::NDX; j++)
+          if (i != j && m.w_x[i * D::NDX + j] != 0.0)
+            m.w_diag = 0;
+      for (int i = 0; i < D::NU; i++)
+        for (int j = 0; j < D::NU; j++)
+          if (i != j && m.w_u[i * D::NU + j] != 0.0)
+            m.w_diag = 0;
+      if (std::getenv("SMPC_FORCE_DENSE_WEIGHTS"))
+        m.w_diag = 0; // test hook: exercise the general path with diagonal data
+      for (int i = 0; i < D::NDX; i++)
+        m.wxd[i] = m.w_x[i * D::NDX + i];
+      for (int i = 0; i < D::NU; i++)
+        m.wud[i] = m.w_u[i * D::NU + i];
       std::copy(ks.w_frame.begin(), ks.w_frame.end(), m.w_frame);
       std::copy(ks.w_cent.begin(), ks.w_cent.end(), m.w_cent);
       std::copy(ks.w_centder.begin(), ks.w_centder.end(), m.w_centder);

@@ -224,12 +224,16 @@ namespace smpc
     // ---- small weighted-Jacobian tables ----
     SMPC_LANES(NT)
     {
+      const bool wdiag = md.w_diag != 0; // diagonal w_x, w_u: their entries come from the LDS model block
       for (int idx = lane; idx < NDX * 6; idx += NT)
       {
         const int a = idx / 6, k = idx % 6;
         double s = 0.0;
-        for (int bb = 0; bb < 6; bb++)
-          s += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + k];
+        if (wdiag)
+          s = a < 6 ? md.wxd[a] * sc.Jl[a * 6 + k] : 0.0;
+        else
+          for (int bb = 0; bb < 6; bb++)
+            s += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + k];
         sc.WJl[idx] = s;
       }
       for (int idx = lane; idx < 6 * NDX; idx += NT)
@@ -241,8 +245,11 @@ namespace smpc
         sc.WJc()[idx] = s;
         // JtW[i][k] = sum_a Jl[a][i] w_x[a][k]  (rows of J_x^T w_x for the base block)
         double t = 0.0;
-        for (int bb = 0; bb < 6; bb++)
-          t += sc.Jl[bb * 6 + a] * mg.w_x[bb * NDX + k];
+        if (wdiag)
+          t = k < 6 ? sc.Jl[k * 6 + a] * md.wxd[k] : 0.0;
+        else
+          for (int bb = 0; bb < 6; bb++)
+            t += sc.Jl[bb * 6 + a] * mg.w_x[bb * NDX + k];
         sc.JtW[idx] = t;
       }
       for (int idx = lane; idx < 6 * NV; idx += NT)
@@ -283,8 +290,11 @@ namespace smpc
         for (int a = 0; a < 6; a++)
         {
           double t = 0.0;
-          for (int bb = 0; bb < 6; bb++)
-            t += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + j];
+          if (wdiag)
+            t = md.wxd[a] * sc.Jl[a * 6 + j];
+          else
+            for (int bb = 0; bb < 6; bb++)
+              t += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + j];
           s += sc.Jl[a * 6 + i] * t;
         }
         sc.JWJ[lane] = s;
@@ -451,17 +461,33 @@ namespace smpc
         // H_0 in accumulator layout: the weight entries come from global memory -- all loads are issued first
         // (one per accumulator entry, address-selected), the table look-ups and selects follow
         double wv[24];
+        const bool wdiag = md.w_diag != 0;
+        if (wdiag)
+        {
 #pragma unroll
-        for (int tt = 0; tt < 6; tt++)
+          for (int tt = 0; tt < 6; tt++)
 #pragma unroll
-          for (int v = 0; v < 4; v++)
-          {
-            const int row = 16 * T3I[tt] + lr + 4 * v, col = 16 * T3J[tt] + lc;
-            const bool inx = row >= 6 && row < NDX && col >= 6 && col < NDX;
-            const bool inu = row >= NDX && row < NDX + NU && col >= NDX && col < NDX + NU;
-            const double * src = inx ? &mg.w_x[row * NDX + col] : (inu ? &mg.w_u[(row - NDX) * NU + col - NDX] : &mg.w_x[0]);
-            wv[tt * 4 + v] = *src;
-          }
+            for (int v = 0; v < 4; v++)
+            {
+              const int row = 16 * T3I[tt] + lr + 4 * v, col = 16 * T3J[tt] + lc;
+              const double dv = row < NDX ? md.wxd[row] : md.wud[row < NDX + NU ? row - NDX : 0];
+              wv[tt * 4 + v] = row == col ? dv : 0.0;
+            }
+        }
+        else
+        {
+#pragma unroll
+          for (int tt = 0; tt < 6; tt++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+            {
+              const int row = 16 * T3I[tt] + lr + 4 * v, col = 16 * T3J[tt] + lc;
+              const bool inx = row >= 6 && row < NDX && col >= 6 && col < NDX;
+              const bool inu = row >= NDX && row < NDX + NU && col >= NDX && col < NDX + NU;
+              const double * src = inx ? &mg.w_x[row * NDX + col] : (inu ? &mg.w_u[(row - NDX) * NU + col - NDX] : &mg.w_x[0]);
+              wv[tt * 4 + v] = *src;
+            }
+        }
 #pragma unroll
         for (int tt = 0; tt < 6; tt++)
 #pragma unroll
@@ -575,7 +601,10 @@ namespace smpc
           double rv[NR]; // batched: a rolled load -> store loop would pay the global latency NR times
 #pragma unroll
           for (int n = 0; n < NR; n++)
-            rv[n] = mg.w_u[lane + n * NT < NU * NU ? lane + n * NT : 0];
+          {
+            const int idx = lane + n * NT < NU * NU ? lane + n * NT : 0;
+            rv[n] = md.w_diag ? (idx / NU == idx % NU ? md.wud[idx / NU] : 0.0) : mg.w_u[idx];
+          }
 #pragma unroll
           for (int n = 0; n < NR; n++)
           {

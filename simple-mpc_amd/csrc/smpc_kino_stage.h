@@ -821,9 +821,14 @@ namespace smpc
       if (lane < NDX)
       {
         double s = 0.0;
-#pragma unroll 6
-        for (int j = 0; j < NDX; j++)
-          s += mg.w_xT[j * NDX + lane] * sc.rx[j];
+        if (md.w_diag)
+          s = md.wxd[lane] * sc.rx[lane];
+        else
+        {
+#pragma unroll
+          for (int j = 0; j < NDX; j++)
+            s += mg.w_xT[j * NDX + lane] * sc.rx[j];
+        }
         sc.Wrx[lane] = s;
       }
       if (lane >= 40 && lane < 46)
@@ -862,9 +867,14 @@ namespace smpc
       if (lane < NU)
       {
         double s = 0.0;
-#pragma unroll 6
-        for (int j = 0; j < NU; j++)
-          s += mg.w_uT[j * NU + lane] * sc.ru[j];
+        if (md.w_diag)
+          s = md.wud[lane] * sc.ru[lane];
+        else
+        {
+#pragma unroll
+          for (int j = 0; j < NU; j++)
+            s += mg.w_uT[j * NU + lane] * sc.ru[j];
+        }
         sc.Wru[lane] = s;
       }
       SMPC_LANES_END_WAVE

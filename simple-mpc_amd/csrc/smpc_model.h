@@ -71,6 +71,7 @@ namespace smpc
     double w_centder[36];
     double qmin[D::NA];
     double qmax[D::NA];
+    double wxd[D::NDX], wud[D::NU]; // diagonals of w_x, w_u (used when w_diag: both weight matrices are diagonal)
     // solver
     double mu;
     int parent[D::NJ];
@@ -81,7 +82,8 @@ namespace smpc
     int foot_joint[D::NF];
     int nlevels;
     int kinematics_limits;
-    int pad_[2 + (5 * D::NJ + D::NF) % 2]; // keeps sizeof a multiple of 8
+    int w_diag; // 1: w_x and w_u are diagonal (the usual case) -> no large-weight traffic in the kernels
+    int pad_[1 + (5 * D::NJ + D::NF) % 2]; // keeps sizeof a multiple of 8
   };
   template <class D>
   struct DevModel : DevModelSmall<D>

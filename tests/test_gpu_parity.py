@@ -62,6 +62,30 @@ def test_line_search_backtracking_matches(built):
     assert seen
 
 
+def test_dense_weight_matrices(built):
+    """General (non-diagonal) w_x / w_u: the kernels' dense-weight path."""
+    import oracle_lib as O
+
+    rb = O.Robot("go2_like")
+    s0 = O.go2_kino_settings(rb)
+    rng = np.random.default_rng(5)
+
+    def couple(w, eps):
+        w = np.array(w, float)
+        d = np.sqrt(np.abs(np.diag(w)))
+        m = rng.standard_normal(w.shape)
+        return w + eps * np.outer(d, d) * (m + m.T) / 2
+
+    over = dict(w_x=couple(s0["w_x"], 0.05), w_u=couple(s0["w_u"], 0.05))
+    om, gm, rb = S.make_pair(4, max_iters=2, settings_override=over)
+    X = S.random_states(rb, 4)
+    for _ in range(3):
+        om.iterate(X)
+        gm.iterate(X)
+        assert S.rel_err(om.xs, gm.xs) < TOL
+        X = om.xs[:, 1, :].copy()
+
+
 def test_stage_knots_match_oracle(built):
     om, gm, rb = S.make_pair(batch=2)
     om.keep_knots()

@@ -102,6 +102,30 @@ def test_joint_limit_rows_activate(lib):
     assert S.rel_err(om.vs, gm.vs) < 1e-4
 
 
+def test_dense_weight_matrices(lib):
+    """Non-diagonal (symmetric) w_x / w_u take the general weight path of the kernels (the settings of record are
+    diagonal and take the fast path)."""
+    rb = O.Robot("go2_like")
+    s0 = O.go2_kino_settings(rb)
+    rng = np.random.default_rng(5)
+
+    def couple(w, eps):
+        w = np.array(w, float)
+        d = np.sqrt(np.abs(np.diag(w)))
+        m = rng.standard_normal(w.shape)
+        return w + eps * np.outer(d, d) * (m + m.T) / 2
+
+    over = dict(w_x=couple(s0["w_x"], 0.05), w_u=couple(s0["w_u"], 0.05))
+    om, gm, rb = S.make_pair(2, max_iters=2, lib=lib, settings_override=over)
+    X = S.random_states(rb, 2)
+    for _ in range(3):
+        om.iterate(X)
+        gm.iterate(X)
+        assert S.rel_err(om.xs, gm.xs) < 1e-7
+        assert S.rel_err(om.K0, gm.K0) < 1e-6
+        X = om.xs[:, 1, :].copy()
+
+
 def test_line_search_backtracking_matches(lib):
     """Large perturbations make some instances reject alpha = 1: the speculative line search (alpha = 1 for all,
     then 2^-1..2^-9 only for the undecided ones) must pick the same step as sequential backtracking."""
