@@ -47,17 +47,18 @@ def rooflines(kt, B, H, ndx, nu, nc, nx):
             pmc = json.load(f).get("kernels", {})
     traffic = lambda k: (pmc.get(k, {}).get("hbm_bytes_per_launch_corrected"), os.path.basename(files[-1]) if pmc else None)
     if "deriv" in kt and kt["deriv"][1]:
-        # algorithmic bytes per (instance, stage): the LQ knot written (A B Q S R C q r f d lx lu lpd vpd = 6000
-        # doubles) + the iterate read (x, u, nu, lam, lam+, centres)
-        per_stage = 8 * (ndx * ndx * 2 + ndx * nu * 2 + nu * nu + nc * ndx + 4 * ndx + 2 * nu + 2 * nc
+        # algorithmic bytes per (instance, stage): the LQ knot written per iteration (Q S R C, the 12 state-dependent
+        # rows of [A|B] -- the integrator rows are constant and written once --, q r f d lx lu lpd vpd) + the iterate
+        # read (x, u, nu, lam, lam+, centres)
+        per_stage = 8 * (ndx * ndx + ndx * nu + nu * nu + nc * ndx + 12 * (ndx + nu) + 4 * ndx + 2 * nu + 2 * nc
                          + nx + nu + 2 * nc + 4 * ndx)
         avg = kt["deriv"][0] / kt["deriv"][1] * 1e-3
         ach = B * H * per_stage / avg / 1e9
         out["deriv"] = {"bound": "hbm", "kernel": "deriv_body (stage evaluation + derivatives + LQ knot)", "achieved": ach,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic("deriv_body")[0],
                         "traffic_source": traffic("deriv_body")[1], "algorithmic_bytes": B * H * per_stage, "avg_launch_ms": avg * 1e3,
-                        "note": "algorithmic bytes = B*H*%d per launch; the kernel is latency bound (one wave per (instance, stage), "
-                                "4 waves/CU by LDS), not bandwidth bound" % per_stage}
+                        "note": "algorithmic bytes = B*H*%d per launch; the kernel is FP64-VALU issue bound (one wave per (instance, stage) "
+                                "keeps its SIMD's issue slot busy; co-resident waves do not add throughput), not bandwidth bound" % per_stage}
     if "riccati" in kt and kt["riccati"][1]:
         avg = kt["riccati"][0] / kt["riccati"][1] * 1e-3
         ach = B * H * f_ric(ndx, nu, nc) / avg / 1e12

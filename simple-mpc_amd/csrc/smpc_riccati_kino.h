@@ -1,22 +1,21 @@
 // smpc_riccati_kino.h -- structure-exploiting proximal Riccati sweep for the kinodynamics stage
 // (HOT(4)/(5) of SolverProxDDP::run, reference src/mpc.cpp:212; LQ solver choice src/mpc.cpp:52).
 //
-// One 64-lane wavefront per instance, per-stage blocks in LDS (36 KB), no workgroup-wide barriers: phases are
+// One 64-lane wavefront per instance, 8 per CU (19.8 KB LDS, 256 registers), no workgroup-wide barriers: phases are
 // separated by wave-level ordering points only.  Same KKT system as riccati_body (smpc_solver_kernels.h), reorganised:
 //
 //   * semi-implicit Euler structure (reference src/kinodynamics.cpp:88): with the tangent split
 //     [qb(6) | qj | vb(6) | vj], only the 12 rows G = qb u vb of A and B are dense; rows qj are
 //     e_i + dt e_{v(i)} (A) / dt^2 e_a (B), rows vj are e_i / dt e_a.  Products with A, B cost 12/36 of dense.
-//   * only forward substitutions:  L L^T = I + mu P,  Y = L^-1 [P | p + P f],
-//         P~ = P - mu Y^T Y   (= (I + mu P)^-1 P),   p~ = (I - mu P~)(p + P f)
-//         L_R L_R^T = R^,  W = L_R^-1 [S^^T | r^],  P_t = Q^ - W^T W + C^T C / mu,  p_t = q^ - W^T w + C^T d / mu
-//     The feedback is kept in factored form (W, L_R^-1): du = -(L_R^-1)^T (W_x dx + w) in the forward sweep.
+//   * both eliminations are Schur complements of bordered symmetric matrices, computed by symmetric block sweeps on
+//     the FP64 matrix cores (wave_block_sweep):
+//         [ I + mu P     sqrt(mu) P   sqrt(mu) pt0 ]                       [ Q^ + C^T C/mu   S^   q^ + C^T d/mu ]
+//         [ sqrt(mu) P   P            pt0          ]  -> P~, p~   and      [ S^^T            R^   r^            ]  -> P_t, p_t, K, k
+//     (pt0 = p + P f; P~ = (I + mu P)^-1 P, p~ = (I - mu P~) pt0; K = -R^^-1 S^^T, k = -R^^-1 r^)
 //   * constraint rows: joint-box rows are unit selectors (diagonal contribution), contact rows are dense.
-//   * where the FLOPs go:  the four GEMM-shaped products (Y^T Y, P~[G,G] NAB, [A|B]^T P~ [A|B], W^T W + C^T C) run on
-//     the FP64 matrix cores (v_mfma_f64_16x16x4_f64; 16-padded upper tiles, operands read once from LDS, symmetric
-//     results kept in accumulator registers between phases); the two Cholesky factorisations and their forward
-//     substitutions run in registers with one matrix row / right-hand side per lane and v_readlane broadcasts
-//     (a broadcast LDS read costs a full LDS pass per value; see tools/micro/xlane_bench.hip).
+//   * the GEMM-shaped products (P~[G,G] NAB, [A|B]^T P~ [A|B], C^T C) run on the matrix cores as well; operands are
+//     read once from LDS, and blocks of <= 12 rows (TG, PEG) never leave the accumulator registers because the
+//     accumulator layout of v_mfma_f64_16x16x4_f64 is the operand layout of the next product.
 #pragma once
 #include "smpc_solver_kernels.h"
 
@@ -42,66 +41,6 @@ namespace smpc
     SMPC_HD static bool isQj(int i) { return i >= 6 && i < NV; }
     SMPC_HD static bool isVj(int i) { return i >= NV + 6; }
   };
-
-  // Cholesky + forward substitution by ONE wave, entirely in registers: lane i keeps row i of the matrix
-  // (N doubles); entries of other lanes' rows are fetched with v_readlane (SMPC_XLANE), so neither the
-  // factorisation nor the substitution touches LDS for L (a broadcast ds_read costs a full LDS pass and the
-  // waves of a CU share one LDS pipe).  On exit of the factor part lane i holds L[i][k] in row[k] (k < i) and
-  // 1 / L[i][i] in row[i].  Then, one right-hand side per lane c < ncols:  y = L^-1 b,  b = get(i, c),  put(i, c, y_i).
-  // getm(i, j): matrix entry (only j <= i is used).
-  template <int N, int NT, class GetM, class Get, class Put>
-  SMPC_DEV void wave_chol_solve(GetM getm, int ncols, Get get, Put put)
-  {
-    SMPC_PLA(double, row, NT, N);
-    SMPC_PL(double, lcur, NT);
-    SMPC_PL(double, rcur, NT);
-    SMPC_LANES(NT)
-    {
-#pragma unroll
-      for (int j = 0; j < N; j++)
-        SMPC_PLV(row)[j] = lane < N ? getm(lane, j) : 0.0;
-    }
-    SMPC_LANES_END_WAVE
-#pragma unroll
-    for (int k = 0; k < N; k++)
-    {
-      SMPC_LANES(NT)
-      {
-        const double d = SMPC_XLANE_A(row, k, k);
-        const double rs = SMPC_RSQRT(d);
-        SMPC_PLV(rcur) = rs;
-        SMPC_PLV(lcur) = SMPC_PLV(row)[k] * rs;
-      }
-      SMPC_LANES_END_WAVE
-      SMPC_LANES(NT)
-      {
-        const double l = SMPC_PLV(lcur);
-        SMPC_PLV(row)[k] = lane == k ? SMPC_PLV(rcur) : l;
-#pragma unroll
-        for (int j = k + 1; j < N; j++)
-          SMPC_PLV(row)[j] -= l * SMPC_XLANE(lcur, j);
-      }
-      SMPC_LANES_END_WAVE
-    }
-    SMPC_LANES(NT)
-    if (lane < ncols)
-    {
-      double b[N];
-#pragma unroll
-      for (int i = 0; i < N; i++)
-        b[i] = get(i, lane);
-#pragma unroll
-      for (int k = 0; k < N; k++)
-      {
-        const double xk = b[k] * SMPC_XLANE_A(row, k, k);
-        put(k, lane, xk);
-#pragma unroll
-        for (int i = k + 1; i < N; i++)
-          b[i] -= SMPC_XLANE_A(row, k, i) * xk;
-      }
-    }
-    SMPC_LANES_END_WAVE
-  }
 
   // index of the upper tile (I <= J) of an NTI x NTI tile grid, row-major over the upper triangle
   template <int NTI>
