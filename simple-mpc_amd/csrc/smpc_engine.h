@@ -135,6 +135,7 @@ namespace smpc
     // profiling
     bool profiling = false;
     static constexpr int LS_SLOTS = 256; // instance slots of the backtracking trial launch
+    bool speculative_ls = std::getenv("SMPC_NO_SPECULATIVE_LS") == nullptr; // tentative full steps (run_iterations)
     double kernel_ms[KID_N] = {0};
     long kernel_calls[KID_N] = {0};
     std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
@@ -246,6 +247,10 @@ namespace smpc
       buf.lams = dalloc(BR * D::NDX);
       buf.vs_e = dalloc(BR * D::NC);
       buf.lams_e = dalloc(BR * D::NDX);
+      buf.xs_b = dalloc(BR * D::NX);
+      buf.us_b = dalloc(BR * D::NU);
+      buf.vs_b = dalloc(BR * D::NC);
+      buf.lams_b = dalloc(BR * D::NDX);
       buf.dxs = dalloc((size_t)B * (H + 1) * D::NDX);
       buf.dus = dalloc(BH * D::NU);
       buf.dvs = dalloc(BH * D::NC);
@@ -292,7 +297,7 @@ namespace smpc
     }
     ~KinoEngine()
     {
-      for (double * p : {buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref, buf.ftraj, buf.lq,
+      for (double * p : {buf.xs_b, buf.us_b, buf.vs_b, buf.lams_b, buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref, buf.ftraj, buf.lq,
                          buf.gains, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, X_dev, stage_out})
         dev_free(p);
       dev_free(buf.ls_sel);
@@ -346,19 +351,28 @@ namespace smpc
       pending_events.clear();
     }
 
-    // one ProxDDP iteration for the instances covered by b (b.B may be < B for the cold solve)
-    void run_iteration(const Buffers<D> & b)
+    StageKernelArgs<D> stage_args(const Buffers<D> & b, int slots = 0) const
     {
       StageKernelArgs<D> sk;
       sk.b = b;
       sk.head = head;
       sk.j0 = 0;
       sk.nj = 0;
-      sk.slots = 0;
-      timed_launch<StageKernelArgs<D>, deriv_body<D>, 64>(KID_DERIV, b.B * (H + 1), sk);
+      sk.slots = slots;
+      return sk;
+    }
+    void launch_deriv(const Buffers<D> & b, int slots = 0)
+    {
+      // list-mode launches (backtracking path, normally empty) are booked under "select" so that the per-kernel
+      // averages of deriv / trial / apply stay those of full-batch launches
+      timed_launch<StageKernelArgs<D>, deriv_body<D>, 64>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots));
+    }
+    // backward + forward sweep: Newton step and merit directional derivative
+    void launch_sweeps(const Buffers<D> & b)
+    {
       if (structured_riccati)
       {
-        // kinodynamics-structured sweep, one wavefront per instance, factored feedback
+        // kinodynamics-structured sweep, one wavefront per instance
         timed_launch<SolverArgs<D>, riccati_kino_body<D>, 64, RICCATI_MINW>(KID_RICCATI, b.B, solver_args(b));
         timed_launch<SolverArgs<D>, forward_kino_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
       }
@@ -378,26 +392,84 @@ namespace smpc
         }
         timed_launch<SolverArgs<D>, forward_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
       }
-      // alpha = 1 for everybody; the backtracking candidates 2^-1 .. 2^-9 only for instances that rejected it
-      const int groups[2][2] = {{0, 1}, {1, D::LS_N - 1}};
-      for (auto & gq : groups)
-      {
-        sk.j0 = gq[0];
-        sk.nj = gq[1];
-        if (gq[0] == 0)
-        {
-          sk.slots = 0;
-          timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_TRIAL, b.B * (H + 1), sk);
-        }
-        else
-        {
-          sk.slots = b.B < LS_SLOTS ? b.B : LS_SLOTS;
-          timed_launch<SolverArgs<D>, compact_body<D>, 64>(KID_SELECT, 1, solver_args(b));
-          timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_TRIAL, sk.slots * (H + 1), sk);
-        }
-        timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, gq[0], gq[1]));
-      }
+    }
+    // backtracking candidates 2^-1 .. 2^-9 for the instances that are still undecided (compacted list)
+    int launch_backtracking(const Buffers<D> & b)
+    {
+      const int slots = b.B < LS_SLOTS ? b.B : LS_SLOTS;
+      StageKernelArgs<D> sk = stage_args(b, slots);
+      sk.j0 = 1;
+      sk.nj = D::LS_N - 1;
+      timed_launch<SolverArgs<D>, compact_body<D>, 64>(KID_SELECT, 1, solver_args(b));
+      return slots;
+    }
+    // line search with explicit trial evaluations: alpha = 1 for everybody, then the rest for the undecided
+    void launch_line_search(const Buffers<D> & b)
+    {
+      StageKernelArgs<D> sk = stage_args(b);
+      sk.j0 = 0;
+      sk.nj = 1;
+      timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_TRIAL, b.B * (H + 1), sk);
+      timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, 0, 1));
+      const int slots = launch_backtracking(b);
+      sk.slots = slots;
+      sk.j0 = 1;
+      sk.nj = D::LS_N - 1;
+      timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk);
+      timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, 1, D::LS_N - 1));
       timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B * (H + 1), solver_args(b));
+    }
+    // one ProxDDP iteration for the instances covered by b (b.B may be < B for the cold solve)
+    void run_iteration(const Buffers<D> & b)
+    {
+      launch_deriv(b);
+      launch_sweeps(b);
+      launch_line_search(b);
+    }
+    // k ProxDDP iterations of one control step.  Iterations before the last take the full step TENTATIVELY and run the
+    // next derivative pass at once: its merit IS the line-search value phi(1), so in the common case (Armijo accepts
+    // alpha = 1) no separate trial evaluation is launched, and the result is the sequential algorithm's.  Instances
+    // that reject alpha = 1 are restored, backtracked with explicit trial evaluations and re-derived (compacted list).
+    void run_iterations(const Buffers<D> & b, int k)
+    {
+      if (!speculative_ls || k <= 1)
+      {
+        for (int it = 0; it < k; it++)
+          run_iteration(b);
+        return;
+      }
+      const int nb = (b.B + 63) / 64;
+      launch_deriv(b);
+      timed_launch<SolverArgs<D>, merit0_body<D>, 64>(KID_SELECT, nb, solver_args(b));
+      for (int it = 0; it < k; it++)
+      {
+        launch_sweeps(b);
+        if (it == k - 1)
+        {
+          launch_line_search(b);
+          break;
+        }
+        SolverArgs<D> sa = solver_args(b);
+        sa.mode = 1;
+        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B * (H + 1), sa);
+        launch_deriv(b);
+        timed_launch<SolverArgs<D>, spec_select_body<D>, 64>(KID_SELECT, nb, solver_args(b));
+        // rejected instances (usually none: every launch below then exits at once)
+        const int slots = launch_backtracking(b);
+        sa = solver_args(b);
+        sa.slots = slots;
+        sa.mode = 2;
+        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_SELECT, slots * (H + 1), sa);
+        StageKernelArgs<D> sk = stage_args(b, slots);
+        sk.j0 = 1;
+        sk.nj = D::LS_N - 1;
+        timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk);
+        timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, nb, solver_args(b, 1, D::LS_N - 1));
+        sa.mode = 0;
+        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_SELECT, slots * (H + 1), sa);
+        launch_deriv(b, slots);
+        timed_launch<SolverArgs<D>, merit0_body<D>, 64>(KID_SELECT, nb, sa);
+      }
     }
     void copy_centres(const Buffers<D> & b)
     {
@@ -593,8 +665,7 @@ namespace smpc
       ra.reg_init = REG_INIT;
       timed_launch<RecedeArgs<D>, recede_body<D>, 64>(KID_RECEDE, B, ra);
       copy_centres(buf);
-      for (int it = 0; it < ms.max_iters; it++)
-        run_iteration(buf);
+      run_iterations(buf, ms.max_iters);
     }
     void iterate_host(const double * X)
     {

@@ -70,14 +70,29 @@ namespace smpc
   // deriv_body: grid = B * (H+1); block (inst, t); t == H is the terminal node.
   // =============================================================================================
   template <class D>
+  SMPC_DEV void deriv_one(const StageKernelArgs<D> & ka, int inst, int t);
+
+  // grid = B * (H+1) (slots == 0) or slots * (H+1) walking the compacted list of instances that rejected the
+  // tentative full step (slots > 0) -- one loop, one inlined copy of the stage body
+  template <class D>
   SMPC_DEV void deriv_body(const StageKernelArgs<D> & ka, int block)
+  {
+    const int H = ka.b.H;
+    const int slot = block / (H + 1), t = block % (H + 1);
+    const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : slot + 1;
+    const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
+    for (int m = slot; m < count; m += stride)
+      deriv_one<D>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t);
+  }
+
+  template <class D>
+  SMPC_DEV void deriv_one(const StageKernelArgs<D> & ka, int inst, int t)
   {
     typedef KinoScratch<D, true> KinoScratchT;
     constexpr int NT = 64;
     constexpr int NV = D::NV, NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF, NA = D::NA;
     const Buffers<D> & b = ka.b;
     const int H = b.H, R = b.R;
-    const int inst = block / (H + 1), t = block % (H + 1);
     const bool term = t == H;
     const DevModel<D> & mg = *b.model; // global: large weights only
     SMPC_LDS(KinoScratchT, scs, 1);
@@ -98,7 +113,7 @@ namespace smpc
     in.x_tgt = term ? mg.x_term : b.stages[t].x_tgt;
     in.foot_ref = term ? nullptr : b.foot_ref + ((size_t)inst * H + t) * NF * 3;
     long long tprev = SMPC_CLOCK();
-    in.prof = (b.dbg != nullptr && block == 17) ? b.dbg : nullptr; // optional phase timers: one mid-horizon block
+    in.prof = (b.dbg != nullptr && inst == 0 && t == 17 && ka.slots == 0) ? b.dbg : nullptr; // optional phase timers: one mid-horizon block
     in.tprev = &tprev;
 
     SMPC_LANES(NT)

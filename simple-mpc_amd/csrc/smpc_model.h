@@ -113,6 +113,7 @@ namespace smpc
     // ring state, [B][R][.]
     double *xs = nullptr, *us = nullptr, *vs = nullptr, *lams = nullptr; // lams[slot(t)] = lambda_{t+1}
     double *vs_e = nullptr, *lams_e = nullptr;                           // AL centres
+    double *xs_b = nullptr, *us_b = nullptr, *vs_b = nullptr, *lams_b = nullptr; // iterate before a tentative full step
     // steps, [B][H(+1)][.] (linear in t)
     double *dxs = nullptr, *dus = nullptr, *dvs = nullptr, *dlams = nullptr;
     // per-instance references, [B][H][NF*3]
@@ -147,6 +148,7 @@ namespace smpc
     SC_COST = 9,
     SC_COST_NEW = 10,
     SC_LS_INDEX = 11,
+    SC_PREG_OLD = 12, // regularisation before a tentative full step
     SC_N = 16
   };
 

@@ -20,6 +20,8 @@ namespace smpc
     int head;
     int j0, nj;
     double armijo_c1, reg_min, reg_max, reg_inc, reg_dec;
+    int mode = 0;  // apply_body: 0 accept alpha, 1 tentative full step (with backup), 2 restore the backup
+    int slots = 0; // > 0: the launch walks the compacted list of undecided instances, `slots` at a time
   };
 
   // out(i,j) = init(i,j) + sum_k X[k*ldx + i] * Y[k*ldy + j]  for an M x N output, register tiles TM x TN
@@ -568,36 +570,186 @@ namespace smpc
   // apply_body: grid = B * (H+1), 64 lanes: accept the step of size alpha for (inst, t)
   // =============================================================================================
   template <class D>
+  SMPC_DEV void apply_one(const SolverArgs<D> & ka, int inst, int t);
+
+  template <class D>
   SMPC_DEV void apply_body(const SolverArgs<D> & ka, int block)
+  {
+    const int H = ka.b.H;
+    const int slot = block / (H + 1), t = block % (H + 1);
+    // slots > 0: only the instances on the compacted list (they rejected the tentative full step)
+    const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : slot + 1;
+    const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
+    for (int m = slot; m < count; m += stride)
+      apply_one<D>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t);
+  }
+
+  // mode 0: x <- x (+) alpha dx, u, nu, lam += alpha d.  (alpha of the instance's accepted candidate)
+  // mode 1: tentative full step: the same with alpha = 1, the old values saved to the backup buffers, and the
+  //         regularisation moved as after a successful line search (reference ProxDDP: decrease on success)
+  // mode 2: restore the backup (the full step was rejected)
+  template <class D>
+  SMPC_DEV void apply_one(const SolverArgs<D> & ka, int inst, int t)
   {
     constexpr int NT = 64;
     constexpr int NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC;
     const Buffers<D> & b = ka.b;
     const int H = b.H, R = b.R;
-    const int inst = block / (H + 1), t = block % (H + 1);
-    const double alpha = b.scal[(size_t)inst * SC_N + SC_ALPHA];
     const int st = ring_slot(ka.head, t, R);
     const size_t ib = (size_t)inst * R;
+    if (ka.mode == 2)
+    {
+      SMPC_LANES(NT)
+      {
+        for (int i = lane; i < NX; i += NT)
+          b.xs[(ib + st) * NX + i] = b.xs_b[(ib + st) * NX + i];
+        if (t < H)
+        {
+          for (int i = lane; i < NU; i += NT)
+            b.us[(ib + st) * NU + i] = b.us_b[(ib + st) * NU + i];
+          for (int i = lane; i < NC; i += NT)
+            b.vs[(ib + st) * NC + i] = b.vs_b[(ib + st) * NC + i];
+          for (int i = lane; i < NDX; i += NT)
+            b.lams[(ib + st) * NDX + i] = b.lams_b[(ib + st) * NDX + i];
+        }
+      }
+      SMPC_LANES_END_WAVE
+      return;
+    }
+    const bool tent = ka.mode == 1;
+    const double alpha = tent ? 1.0 : b.scal[(size_t)inst * SC_N + SC_ALPHA];
     SMPC_LDS(double, xn, D::NX);
     SMPC_LANES(NT)
     lanes_integrate<D>(b.xs + (ib + st) * NX, b.dxs + ((size_t)inst * (H + 1) + t) * NDX, alpha, xn, lane, 0);
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
     {
       for (int i = lane; i < NX; i += NT)
+      {
+        if (tent)
+          b.xs_b[(ib + st) * NX + i] = b.xs[(ib + st) * NX + i];
         b.xs[(ib + st) * NX + i] = xn[i];
+      }
       if (t < H)
       {
         const size_t lt = (size_t)inst * H + t;
         for (int i = lane; i < NU; i += NT)
-          b.us[(ib + st) * NU + i] += alpha * b.dus[lt * NU + i];
+        {
+          const double v = b.us[(ib + st) * NU + i];
+          if (tent)
+            b.us_b[(ib + st) * NU + i] = v;
+          b.us[(ib + st) * NU + i] = v + alpha * b.dus[lt * NU + i];
+        }
         for (int i = lane; i < NC; i += NT)
-          b.vs[(ib + st) * NC + i] += alpha * b.dvs[lt * NC + i];
+        {
+          const double v = b.vs[(ib + st) * NC + i];
+          if (tent)
+            b.vs_b[(ib + st) * NC + i] = v;
+          b.vs[(ib + st) * NC + i] = v + alpha * b.dvs[lt * NC + i];
+        }
         for (int i = lane; i < NDX; i += NT)
-          b.lams[(ib + st) * NDX + i] += alpha * b.dlams[lt * NDX + i];
+        {
+          const double v = b.lams[(ib + st) * NDX + i];
+          if (tent)
+            b.lams_b[(ib + st) * NDX + i] = v;
+          b.lams[(ib + st) * NDX + i] = v + alpha * b.dlams[lt * NDX + i];
+        }
+      }
+      if (tent && t == 0 && lane == 0)
+      {
+        double * sc = b.scal + (size_t)inst * SC_N;
+        sc[SC_PREG_OLD] = sc[SC_PREG];
+        sc[SC_PREG] = fmax(sc[SC_PREG] * ka.reg_dec, ka.reg_min);
       }
     }
-    SMPC_LANES_END
+    SMPC_LANES_END_WAVE
+  }
+
+  // =============================================================================================
+  // merit0_body: grid = ceil(B / 64), lane = instance: merit, cost and infeasibilities of the current point from the
+  // per-stage partials of the derivative pass (fixed stage order).  slots > 0: the listed instances only.
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void merit0_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H;
+    SMPC_LANES(NT)
+    {
+      const int m = block * NT + lane;
+      const int count = ka.slots > 0 ? b.und_list[b.B] : b.B;
+      if (m < count)
+      {
+        const int inst = ka.slots > 0 ? b.und_list[m] : m;
+        double * sc = b.scal + (size_t)inst * SC_N;
+        double phi = 0.0, cost = 0.0, prim = 0.0, dual = 0.0;
+        for (int t = 0; t <= H; t++)
+        {
+          const double * p = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
+          phi += p[0];
+          cost += p[1];
+          prim = fmax(prim, p[2]);
+          dual = fmax(dual, p[3]);
+        }
+        sc[SC_PHI0] = phi;
+        sc[SC_COST] = cost;
+        sc[SC_PRIM] = prim;
+        sc[SC_DUAL] = dual;
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // =============================================================================================
+  // spec_select_body: grid = ceil(B / 64), lane = instance.  The derivative pass has just been run at the tentative
+  // point x (+) dx: its merit is the line-search value phi(alpha = 1).  Armijo accepted -> the step is final (and the
+  // knot of the next iteration is already there); rejected -> mark the instance undecided and put the old
+  // regularisation back (the backtracking path restores the iterate, tries alpha = 2^-1 .. and re-derives).
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void spec_select_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H;
+    SMPC_LANES(NT)
+    {
+      const int inst = block * NT + lane;
+      if (inst < b.B)
+      {
+        double * sc = b.scal + (size_t)inst * SC_N;
+        double phi = 0.0, cost = 0.0, prim = 0.0, dual = 0.0;
+        for (int t = 0; t <= H; t++)
+        {
+          const double * p = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
+          phi += p[0];
+          cost += p[1];
+          prim = fmax(prim, p[2]);
+          dual = fmax(dual, p[3]);
+        }
+        const bool ok = phi <= sc[SC_PHI0] + ka.armijo_c1 * sc[SC_DPHI0];
+        if (ok)
+        {
+          b.ls_sel[inst] = 0;
+          sc[SC_ALPHA] = 1.0;
+          sc[SC_PHI_NEW] = phi;
+          sc[SC_PRIM_NEW] = prim;
+          sc[SC_LS_INDEX] = 0.0;
+          sc[SC_LS_FAILED] = 0.0;
+          sc[SC_PHI0] = phi;
+          sc[SC_COST] = cost;
+          sc[SC_PRIM] = prim;
+          sc[SC_DUAL] = dual;
+        }
+        else
+        {
+          b.ls_sel[inst] = -1;
+          sc[SC_PREG] = sc[SC_PREG_OLD];
+        }
+      }
+    }
+    SMPC_LANES_END_WAVE
   }
 
   // =============================================================================================
