@@ -165,6 +165,36 @@ def test_dense_and_structured_riccati_agree(built):
     assert S.rel_err(outs[0]["K0"], outs[1]["K0"]) < 1e-6
 
 
+def test_speculative_line_search_is_the_sequential_algorithm(built):
+    """Tentative full step + next derivative pass as the alpha = 1 trial (run_iterations) against explicit trial
+    evaluations in every iteration (SMPC_NO_SPECULATIVE_LS): bit-identical iterates, on a scenario that rejects alpha = 1
+    in early and late iterations (restore / backtrack / re-derive path)."""
+    code = (
+        "import sys; sys.path.insert(0, %r); import numpy as np, mpc_setup as S\n"
+        "import oracle_lib as O\n"
+        "gm, rb, _, _ = S.make_product(6, max_iters=3, lib=S.emu_lib())\n"
+        "gm.generateCycleHorizon(O.trot_cycle()); gm.switchToWalk(np.array([0.2,0,0,0,0,0.]))\n"
+        "X = S.random_states(rb, 6, seed=3, scale=4.0)\n"
+        "al = []\n"
+        "for _ in range(3):\n"
+        "    gm.iterate(X); X = gm.xs[:,1,:].copy(); al.append(gm.info[:,2].copy())\n"
+        "np.savez(sys.argv[1], xs=gm.xs, us=gm.us, al=np.array(al))\n" % os.path.dirname(os.path.abspath(__file__))
+    )
+    outs = []
+    for mode in ("spec", "seq"):
+        path = "/tmp/smpc_emu_ls_%s.npz" % mode
+        env = dict(os.environ)
+        env.pop("SMPC_NO_SPECULATIVE_LS", None)
+        if mode == "seq":
+            env["SMPC_NO_SPECULATIVE_LS"] = "1"
+        subprocess.check_call([sys.executable, "-c", code, path], env=env)
+        outs.append(np.load(path))
+    assert (outs[0]["al"] < 1.0).any(), "scenario no longer exercises backtracking"
+    assert np.array_equal(outs[0]["al"], outs[1]["al"])
+    assert np.array_equal(outs[0]["xs"], outs[1]["xs"])
+    assert np.array_equal(outs[0]["us"], outs[1]["us"])
+
+
 def test_batch_instances_are_independent(lib):
     gm4, rb, _, _ = S.make_product(4, lib=lib)
     gm1, _, _, _ = S.make_product(1, lib=lib)
