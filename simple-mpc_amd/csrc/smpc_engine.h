@@ -365,7 +365,7 @@ namespace smpc
     {
       // list-mode launches (backtracking path, normally empty) are booked under "select" so that the per-kernel
       // averages of deriv / trial / apply stay those of full-batch launches
-      timed_launch<StageKernelArgs<D>, deriv_body<D>, 64>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots));
+      timed_launch<StageKernelArgs<D>, deriv_body<D>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots));
     }
     // backward + forward sweep: Newton step and merit directional derivative
     void launch_sweeps(const Buffers<D> & b)

@@ -41,9 +41,13 @@ namespace smpc
     double com[3];
     double Ag[6 * D::NV];
     double b0[6], hd[6], hg[6];
-    double gjA[36], gjB[36], Agbi[36];
+    double Agbi[36];
     double a[D::NV];
     double xnext[D::NX], e[D::NDX], xn1[D::NX];
+    // ping-pong buffers of the 6x6 Gauss-Jordan: they live in xnext | e, which are written only after Agbi is formed
+    SMPC_HD double * gjA_() { return xnext; }
+    SMPC_HD double * gjB_() { return xnext + 36; }
+    static_assert(D::NX + D::NDX >= 72, "Gauss-Jordan scratch inside xnext | e");
     double cval[D::NC];
     // residuals and weighted residuals
     double rx[D::NDX], Wrx[D::NDX], ru[D::NU], Wru[D::NU], Whg[6], Whd[6], rf[D::NF * 3], Wrf[D::NF * 3];
@@ -409,7 +413,7 @@ namespace smpc
         // dense 6x6 of the composite inertia Ic0 (about the world origin), for Gauss-Jordan
         const double m = I0.m;
         const V3 c = I0.mc;
-        double * A = sc.gjA;
+        double * A = sc.gjA_();
         for (int i = 0; i < 36; i++)
           A[i] = 0.0;
         A[0] = A[7] = A[14] = m;
@@ -439,8 +443,8 @@ namespace smpc
     // ---- in-place Gauss-Jordan inverse of the SPD 6x6 (36 lanes, ping-pong gjA <-> gjB) ----
     for (int pv = 0; pv < 6; pv++)
     {
-      const double * src = (pv & 1) ? sc.gjB : sc.gjA;
-      double * dst = (pv & 1) ? sc.gjA : sc.gjB;
+      const double * src = (pv & 1) ? sc.gjB_() : sc.gjA_();
+      double * dst = (pv & 1) ? sc.gjA_() : sc.gjB_();
       SMPC_LANES(NT)
       if (lane < 36)
       {
@@ -461,7 +465,7 @@ namespace smpc
     if (lane < 36)
     {
       const int r = lane / 6, c = lane % 6;
-      const double * Ii = sc.gjA;
+      const double * Ii = sc.gjA_();
       double val = Ii[r * 6 + c];
       if (c < 3)
       {
@@ -471,7 +475,7 @@ namespace smpc
         const V3 col = cross(cm, e);
         val += Ii[r * 6 + 3] * col.x + Ii[r * 6 + 4] * col.y + Ii[r * 6 + 5] * col.z;
       }
-      sc.gjB[lane] = val;
+      sc.gjB_()[lane] = val;
     if (in.prof) prof_tick(in.prof, 22, *in.tprev);
     }
     SMPC_LANES_END_WAVE
@@ -482,8 +486,8 @@ namespace smpc
       const int r = lane / 6, c = lane % 6;
       const M3 R = ldm3(&sc.oR[0]);
       const V3 p = ld3(&sc.op[0]);
-      const V3 ml = mk3(sc.gjB[0 * 6 + c], sc.gjB[1 * 6 + c], sc.gjB[2 * 6 + c]);
-      const V3 ma = mk3(sc.gjB[3 * 6 + c], sc.gjB[4 * 6 + c], sc.gjB[5 * 6 + c]);
+      const V3 ml = mk3(sc.gjB_()[0 * 6 + c], sc.gjB_()[1 * 6 + c], sc.gjB_()[2 * 6 + c]);
+      const V3 ma = mk3(sc.gjB_()[3 * 6 + c], sc.gjB_()[4 * 6 + c], sc.gjB_()[5 * 6 + c]);
       V3 out;
       if (r < 3)
         out = tmul(R, ml - cross(p, ma));
