@@ -112,6 +112,7 @@ namespace smpc
     in.u_ref = term ? nullptr : b.stages[t].u_ref;
     in.x_tgt = term ? mg.x_term : b.stages[t].x_tgt;
     in.foot_ref = term ? nullptr : b.foot_ref + ((size_t)inst * H + t) * NF * 3;
+    in.C_rows = term ? nullptr : b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE + D::O_C + (size_t)NA * NDX;
     long long tprev = SMPC_CLOCK();
     in.prof = (b.dbg != nullptr && inst == 0 && t == 17 && ka.slots == 0) ? b.dbg : nullptr; // optional phase timers: one mid-horizon block
     in.tprev = &tprev;
@@ -197,7 +198,7 @@ namespace smpc
         const double qn = g - sc.lam_prev[k];
         qN[k] = qn;
         dual = fabs(qn);
-        sc.lx[k] = dual;
+        sc.rx[k] = dual; // reuse as dual-infeasibility scratch
         for (int i = 0; i < NDX; i++)
         {
           double v;
@@ -222,7 +223,7 @@ namespace smpc
       {
         double dual = 0.0;
         for (int k = 0; k < NDX; k++)
-          dual = fmax(dual, sc.lx[k]);
+          dual = fmax(dual, sc.rx[k]);
         parts[0] = sc.red[0];
         parts[1] = sc.red[0];
         parts[2] = 0.0;
@@ -336,13 +337,13 @@ namespace smpc
         {
           if (k < NV)
           {
-            Dbot[m] = dt * sc.ab_dq[m * NV + k];
+            Dbot[m] = dt * sc.ab_dq()[m * NV + k];
             Dtop[m] = dt * Dbot[m];
           }
           else
           {
             const int kk = k - NV;
-            Dbot[m] = dt * sc.ab_dv[m * NV + kk];
+            Dbot[m] = dt * sc.ab_dv()[m * NV + kk];
             Dtop[m] = dt * Dbot[m] + (m == kk ? dt : 0.0);
           }
         }
@@ -417,15 +418,10 @@ namespace smpc
           for (int fa = 0; fa < NF * 3; fa++)
             g += sc.Jfoot[fa * NV + k] * sc.Wrf[fa];
         }
-        sc.lx[k] = g;
-        // C_x^T nu (full Jacobian)
-        double cn = 0.0;
+        // C_x^T nu: box rows are unit selectors, the contact rows were contracted with nu when their columns were formed
+        double cn = sc.cn[k];
         if (md.kinematics_limits && k >= 6 && k < NV)
           cn += sc.nu[k - 6];
-        for (int f = 0; f < NF; f++)
-          if ((in.mask >> f) & 1u)
-            for (int r = 0; r < 3; r++)
-              cn += (k < NV ? sc.dcq()[(f * 3 + r) * NV + k] : sc.dcv[(f * 3 + r) * NV + k - NV]) * sc.nu[NA + 3 * f + r];
         double q = g + acc + cn - sc.lam_prev[k];
         if (t == 0)
           q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
@@ -448,7 +444,6 @@ namespace smpc
             g += sc.Whd[j] + xc.x * sc.Whd[3] + xc.y * sc.Whd[4] + xc.z * sc.Whd[5];
           }
         }
-        sc.lu[k] = g;
         const double r = g + acc;
         lq[D::O_r + k] = r;
         lq[D::O_lu + k] = g;
@@ -633,19 +628,12 @@ namespace smpc
     }
     SMPC_LANES(NT)
     {
-      // C (active rows; coalesced row runs), d, vpd
-      for (int idx = lane; idx < NC * NDX; idx += NT)
+      // joint-box rows of C (unit selectors when active; the contact rows are written with the constraint Jacobian
+      // columns), d, vpd
+      for (int idx = lane; idx < NA * NDX; idx += NT)
       {
         const int i = idx / NDX, k = idx % NDX;
-        double v = 0.0;
-        if (sc.act[i])
-        {
-          if (i < NA)
-            v = (k == 6 + i) ? 1.0 : 0.0;
-          else
-            v = k < NV ? sc.dcq()[(i - NA) * NV + k] : sc.dcv[(i - NA) * NV + k - NV];
-        }
-        lq[D::O_C + idx] = v;
+        lq[D::O_C + idx] = (sc.act[i] && k == 6 + i) ? 1.0 : 0.0;
       }
       if (lane < NC)
       {

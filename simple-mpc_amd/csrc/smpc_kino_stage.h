@@ -43,7 +43,7 @@ namespace smpc
     double b0[6], hd[6], hg[6];
     double Agbi[36];
     double a[D::NV];
-    double xnext[D::NX], e[D::NDX], xn1[D::NX];
+    double xnext[D::NX], e[D::NDX];
     // ping-pong buffers of the 6x6 Gauss-Jordan: they live in xnext | e, which are written only after Agbi is formed
     SMPC_HD double * gjA_() { return xnext; }
     SMPC_HD double * gjB_() { return xnext + 36; }
@@ -58,32 +58,36 @@ namespace smpc
   template <class D>
   struct KinoScratchDerivPart
   {
-    double dh_dq[6 * D::NV], dhd_dq[6 * D::NV], dhd_dv[6 * D::NV];
-    double Jcom[3 * D::NV], Jfoot[D::NF * 3 * D::NV];
+    double dh_dq[6 * D::NV], dhd_dq[6 * D::NV], dhd_dv[6 * D::NV]; // dhd_*: overwritten in place by ab_dq / ab_dv
+    double Jfoot[D::NF * 3 * D::NV];
     double dtgt[3 * D::NV];
-    double ab_dq[6 * D::NV], ab_dv[6 * D::NV], ab_du[6 * D::NU];
+    double ab_du[6 * D::NU];
+    double cn[D::NDX]; // C_x^T nu of the contact rows (formed with the constraint Jacobian columns)
     double Je3[9], JeQ[9], Jq[36], Jl[36];
     double WJl[D::NDX * 6];           // w_x[:,0:6] * Jl
     double JtW[6 * D::NDX];           // Jl^T w_x[0:6,:]
     double JWJ[36];                   // Jl^T w_x[0:6,0:6] Jl
-    double dcv[D::NF * 3 * D::NV];
-    double lx[D::NDX], lu[D::NU];
   };
+  template <class D>
   struct KinoScratchNoDeriv
   {
+    double xn1[D::NX]; // trial point of the next state (line search only)
   };
   template <class D, bool DERIV>
-  struct KinoScratch : KinoScratchEval<D>, std::conditional<DERIV, KinoScratchDerivPart<D>, KinoScratchNoDeriv>::type
+  struct KinoScratch : KinoScratchEval<D>, std::conditional<DERIV, KinoScratchDerivPart<D>, KinoScratchNoDeriv<D>>::type
   {
     // tables living in tree block A (written by the table phase, after the last reader of the tree data)
     SMPC_HD double * WJc() { return this->oR; }       // [6][NDX]     w_cent * [dh_dq | Ag]
     SMPC_HD double * WD() { return this->oR + 216; }  // [6][NV]      w_centder[:,3:6] * dtgt
     SMPC_HD double * WJu() { return this->oR + 324; } // [6][3 NF]    w_centder * Ju (force columns)
     SMPC_HD double * WJf() { return this->oR + 396; } // [3 NF][NV]   w_frame * Jfoot
-    SMPC_HD double * dcq() { return this->op; }       // [3 NF][NV]   d(contact velocity)/dq, in tree block B
+    SMPC_HD double * aS() { return this->op; }             // [NV][6] temporaries of the net-force update, in tree block B
+    SMPC_HD double * IaS() { return this->op + 6 * D::NV; } // [NV][6]
+    SMPC_HD double * ab_dq() { return this->dhd_dq; }      // [6][NV] in place
+    SMPC_HD double * ab_dv() { return this->dhd_dv; }      // [6][NV] in place
     static_assert(6 * D::NDX == 216 && 6 * D::NV == 108 && 18 * D::NF == 72 && 396 + 3 * D::NF * D::NV <= D::NJ * 9 + D::NV * 6 + D::NJ * 40,
                   "table layout inside tree block A");
-    static_assert(3 * D::NF * D::NV <= D::NJ * 19, "dcq inside tree block B");
+    static_assert(12 * D::NV <= D::NJ * 19, "net-force temporaries inside tree block B");
   };
 
   // inputs describing one stage evaluation
@@ -95,6 +99,7 @@ namespace smpc
     const double * u_ref;    // NU (global)
     const double * x_tgt;    // NX (global)
     const double * foot_ref; // NF*3 (global)
+    double * C_rows = nullptr; // derivative pass: contact rows of the knot's C block (global, [3 NF][NDX])
     bool terminal;
     double * prof = nullptr; // optional phase timers (null = off)
     long long * tprev = nullptr;
@@ -228,6 +233,28 @@ namespace smpc
     //      the joint-local part before and the inertia / momentum / force part after run once for all joints ----
     const double * vq = &sc.x[NQ];
     SMPC_PLA(double, rl, NT, 9); // jpR * Rq of this lane's joint
+    // geometry / inertia constants of this lane's joint: global -> registers once (the loads fly during the sincos)
+    SMPC_PLA(double, jg, NT, 24); // jpR 0..8 | jpp 9..11 | mass 12 | com 13..15 | inertia 16..21
+    SMPC_LANES(NT)
+    {
+      const int j = lane < NJ ? lane : 0;
+#pragma unroll
+      for (int i = 0; i < 9; i++)
+        SMPC_PLV(jg)[i] = mg.jpR[j][i];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+      {
+        SMPC_PLV(jg)[9 + i] = mg.jpp[j][i];
+        SMPC_PLV(jg)[13 + i] = mg.com[j][i];
+      }
+      SMPC_PLV(jg)[12] = mg.mass[j];
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+        SMPC_PLV(jg)[16 + i] = mg.inertia[j][i];
+      SMPC_PLV(jg)[22] = 0.0;
+      SMPC_PLV(jg)[23] = 0.0;
+    }
+    SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
     if (lane < NJ)
     {
@@ -256,7 +283,7 @@ namespace smpc
         const double s = sin(ang), c = cos(ang);
         const int jt = md.jtype[j];
         const M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -s, 0, s, c} : (jt == 2 ? M3{c, 0, s, 0, 1, 0, -s, 0, c} : M3{c, -s, 0, s, c, 0, 0, 0, 1});
-        const M3 Rl = ldm3(md.jpR[j]) * Rq;
+        const M3 Rl = ldm3(&SMPC_PLV(jg)[0]) * Rq;
         stm3(SMPC_PLV(rl), Rl);
       }
     }
@@ -270,7 +297,7 @@ namespace smpc
         const int par = md.parent[j];
         const M3 Rp = ldm3(&sc.oR[par * 9]);
         const M3 R = Rp * ldm3(SMPC_PLV(rl));
-        const V3 p = ld3(&sc.op[par * 3]) + Rp * ld3(md.jpp[j]);
+        const V3 p = ld3(&sc.op[par * 3]) + Rp * ld3(&SMPC_PLV(jg)[9]);
         const int col = md.jtype[j] - 1;
         const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
         const SV sk = SV{cross(p, ax), ax};
@@ -292,9 +319,9 @@ namespace smpc
       const V3 p = ld3(&sc.op[j * 3]);
       const SV v = ldsv(&sc.vel[j * 6]), a = ldsv(&sc.acc[j * 6]);
       // world inertia about the origin
-      const double m = md.mass[j];
-      const V3 c = R * ld3(md.com[j]) + p;
-      const double * il = md.inertia[j];
+      const double m = SMPC_PLV(jg)[12];
+      const V3 c = R * ld3(&SMPC_PLV(jg)[13]) + p;
+      const double * il = &SMPC_PLV(jg)[16];
       const M3 Il = M3{il[0], il[1], il[3], il[1], il[2], il[4], il[3], il[4], il[5]};
       const M3 Iw = R * Il * transpose(R);
       const double cc = dot(c, c);
@@ -551,10 +578,9 @@ namespace smpc
     //      Fc_i(a)  = Fc_i(0) + sum_{k <= i} a_k Ic_i S_k + sum_{k strictly below i} a_k Ic_{j(k)} S_k ----
     //      With aS_k = a_k S_k and dacc_i = sum_{k <= i} aS_k the middle term is Ic_i dacc_i; the last one sums
     //      the per-dof vectors Ic_{j(k)} aS_k.  Both per-dof vectors are formed once (lane = dof), then lane = joint
-    //      only adds (the scratch of the constraint derivatives, written later, holds them meanwhile).
-    double * aS = sc.dcq();  // [NV][6]
-    double * IaS = sc.dcv; // [NV][6]
-    static_assert(NF * 3 >= 6, "temporary storage");
+    //      only adds.
+    double * aS = sc.aS();
+    double * IaS = sc.IaS();
     SMPC_LANES(NT)
     if (lane < NV)
     {
@@ -656,37 +682,49 @@ namespace smpc
       sc.dhd_dv[3 * NV + k] = dFva.x;
       sc.dhd_dv[4 * NV + k] = dFva.y;
       sc.dhd_dv[5 * NV + k] = dFva.z;
-      sc.Jcom[0 * NV + k] = jc.x;
-      sc.Jcom[1 * NV + k] = jc.y;
-      sc.Jcom[2 * NV + k] = jc.z;
-      // feet: linear Jacobian columns, local-velocity constraint derivative columns, d hdot_tgt / dq
+      // feet: linear Jacobian columns, d hdot_tgt / dq, and the local-velocity constraint Jacobian columns: these
+      // go straight into the contact rows of the knot's C block (zero rows for feet in the air) and into C_x^T nu
       V3 dt_ang = mk3(0, 0, 0);
+      double cnq = 0.0, cnv = 0.0;
       for (int f = 0; f < NF; f++)
       {
         const int lj = md.foot_joint[f];
         const bool anc = (md.anc[lj] >> i) & 1u;
+        const bool contact = (in.mask >> f) & 1u;
         const V3 pf = ld3(&sc.footp[f * 3]);
         V3 jf = mk3(0, 0, 0), cq = mk3(0, 0, 0), cv = mk3(0, 0, 0);
         if (anc)
         {
           jf = s.l + cross(s.a, pf);
-          const M3 Rl = ldm3(&sc.oR[lj * 9]);
-          cv = tmul(Rl, jf);
-          if (lam >= 0)
-            cq = tmul(Rl, d.l + cross(d.a, pf));
+          if (contact)
+          {
+            const M3 Rl = ldm3(&sc.oR[lj * 9]);
+            cv = tmul(Rl, jf);
+            if (lam >= 0)
+              cq = tmul(Rl, d.l + cross(d.a, pf));
+          }
         }
         sc.Jfoot[(f * 3 + 0) * NV + k] = jf.x;
         sc.Jfoot[(f * 3 + 1) * NV + k] = jf.y;
         sc.Jfoot[(f * 3 + 2) * NV + k] = jf.z;
-        sc.dcq()[(f * 3 + 0) * NV + k] = cq.x;
-        sc.dcq()[(f * 3 + 1) * NV + k] = cq.y;
-        sc.dcq()[(f * 3 + 2) * NV + k] = cq.z;
-        sc.dcv[(f * 3 + 0) * NV + k] = cv.x;
-        sc.dcv[(f * 3 + 1) * NV + k] = cv.y;
-        sc.dcv[(f * 3 + 2) * NV + k] = cv.z;
-        if ((in.mask >> f) & 1u)
+        if (in.C_rows != nullptr)
+        {
+          double * cr = in.C_rows + (size_t)(3 * f) * D::NDX;
+          cr[0 * D::NDX + k] = cq.x;
+          cr[1 * D::NDX + k] = cq.y;
+          cr[2 * D::NDX + k] = cq.z;
+          cr[0 * D::NDX + NV + k] = cv.x;
+          cr[1 * D::NDX + NV + k] = cv.y;
+          cr[2 * D::NDX + NV + k] = cv.z;
+        }
+        const double * nuf = &sc.nu[D::NA + 3 * f];
+        cnq += cq.x * nuf[0] + cq.y * nuf[1] + cq.z * nuf[2];
+        cnv += cv.x * nuf[0] + cv.y * nuf[1] + cv.z * nuf[2];
+        if (contact)
           dt_ang = dt_ang + cross(jf - jc, ld3(&sc.u[3 * f]));
       }
+      sc.cn[k] = cnq;
+      sc.cn[NV + k] = cnv;
       sc.dtgt[0 * NV + k] = dt_ang.x;
       sc.dtgt[1 * NV + k] = dt_ang.y;
       sc.dtgt[2 * NV + k] = dt_ang.z;
@@ -709,7 +747,7 @@ namespace smpc
 #pragma unroll
           for (int m = 0; m < 6; m++)
             rhs[m] = (m >= 3 ? sc.dtgt[(m - 3) * NV + c] : 0.0) - sc.dhd_dq[m * NV + c];
-          dst = &sc.ab_dq[c];
+          dst = &sc.ab_dq()[c];
           ld = NV;
         }
         else if (c < 2 * NV)
@@ -718,7 +756,7 @@ namespace smpc
 #pragma unroll
           for (int m = 0; m < 6; m++)
             rhs[m] = -sc.dhd_dv[m * NV + k];
-          dst = &sc.ab_dv[k];
+          dst = &sc.ab_dv()[k];
           ld = NV;
         }
         else

@@ -49,19 +49,13 @@ namespace smpc
   };
 
   // Model + settings, device resident (one copy per handle).
-  // Model constants.  The "small" part (tree tables, small weights, scalars: 3.6 KB) is copied into LDS by every
+  // Model constants.  The "small" part (tree tables, small weights, scalars: 1.9 KB) is copied into LDS by every
   // rigid-body kernel block at start, so that no phase of the tree algorithms waits on a global load; the large
   // weight matrices stay in global memory (L2-resident, read in the assembly phases only).
   template <class D>
   struct DevModelSmall
   {
-    double jpR[D::NJ][9];
-    double jpp[D::NJ][3];
-    double mass[D::NJ];
-    double com[D::NJ][3];
-    double inertia[D::NJ][6];
     double foot_p[D::NF][3];
-    double foot_ref_p[D::NF][3];
     double total_mass;
     // KinodynamicsSettings (include/simple-mpc/kinodynamics.hpp:24-51)
     double dt;
@@ -88,6 +82,13 @@ namespace smpc
   template <class D>
   struct DevModel : DevModelSmall<D>
   {
+    // per-joint geometry / inertia: each lane keeps its joint's 24 constants in registers (loaded once per block)
+    double jpR[D::NJ][9];
+    double jpp[D::NJ][3];
+    double mass[D::NJ];
+    double com[D::NJ][3];
+    double inertia[D::NJ][6];
+    double foot_ref_p[D::NF][3];
     double w_x[D::NDX * D::NDX];
     double w_u[D::NU * D::NU];
     double w_xT[D::NDX * D::NDX]; // transposes: lane = row matvecs read them with coalesced loads
