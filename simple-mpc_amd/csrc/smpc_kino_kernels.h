@@ -237,88 +237,6 @@ namespace smpc
     kino_multipliers<D, true>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
     if (in.prof) prof_tick(in.prof, 31, tprev);
 
-    // ---- small weighted-Jacobian tables ----
-    SMPC_LANES(NT)
-    {
-      const bool wdiag = md.w_diag != 0; // diagonal w_x, w_u: their entries come from the LDS model block
-      for (int idx = lane; idx < NDX * 6; idx += NT)
-      {
-        const int a = idx / 6, k = idx % 6;
-        double s = 0.0;
-        if (wdiag)
-          s = a < 6 ? md.wxd[a] * sc.Jl[a * 6 + k] : 0.0;
-        else
-          for (int bb = 0; bb < 6; bb++)
-            s += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + k];
-        sc.WJl[idx] = s;
-      }
-      for (int idx = lane; idx < 6 * NDX; idx += NT)
-      {
-        const int a = idx / NDX, k = idx % NDX;
-        double s = 0.0;
-        for (int bb = 0; bb < 6; bb++)
-          s += md.w_cent[a * 6 + bb] * (k < NV ? sc.dh_dq[bb * NV + k] : sc.Ag[bb * NV + k - NV]);
-        sc.WJc()[idx] = s;
-        // JtW[i][k] = sum_a Jl[a][i] w_x[a][k]  (rows of J_x^T w_x for the base block)
-        double t = 0.0;
-        if (wdiag)
-          t = k < 6 ? sc.Jl[k * 6 + a] * md.wxd[k] : 0.0;
-        else
-          for (int bb = 0; bb < 6; bb++)
-            t += sc.Jl[bb * 6 + a] * mg.w_x[bb * NDX + k];
-        sc.JtW[idx] = t;
-      }
-      for (int idx = lane; idx < 6 * NV; idx += NT)
-      {
-        const int a = idx / NV, k = idx % NV;
-        double s = 0.0;
-        for (int bb = 0; bb < 3; bb++)
-          s += md.w_centder[a * 6 + 3 + bb] * sc.dtgt[bb * NV + k];
-        sc.WD()[idx] = s;
-      }
-      for (int idx = lane; idx < 6 * 3 * NF; idx += NT)
-      {
-        const int a = idx / (3 * NF), k = idx % (3 * NF);
-        const int f = k / 3, j = k % 3;
-        double s = 0.0;
-        if ((in.mask >> f) & 1u)
-        {
-          const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
-          const V3 xc = cross(rr, mk3(j == 0, j == 1, j == 2)); // column j of [rr]x
-          s = md.w_centder[a * 6 + j] + md.w_centder[a * 6 + 3] * xc.x + md.w_centder[a * 6 + 4] * xc.y + md.w_centder[a * 6 + 5] * xc.z;
-        }
-        sc.WJu()[idx] = s;
-      }
-      for (int idx = lane; idx < NF * 3 * NV; idx += NT)
-      {
-        const int fa = idx / NV, k = idx % NV;
-        const int f = fa / 3, a = fa % 3;
-        double s = 0.0;
-        for (int bb = 0; bb < 3; bb++)
-          s += md.w_frame[a * 3 + bb] * sc.Jfoot[(f * 3 + bb) * NV + k];
-        sc.WJf()[idx] = s;
-      }
-      if (lane < 36)
-      {
-        // JWJ = Jl^T w_x[0:6,0:6] Jl (base block of the state Hessian)
-        const int i = lane / 6, j = lane % 6;
-        double s = 0.0;
-        for (int a = 0; a < 6; a++)
-        {
-          double t = 0.0;
-          if (wdiag)
-            t = md.wxd[a] * sc.Jl[a * 6 + j];
-          else
-            for (int bb = 0; bb < 6; bb++)
-              t += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + j];
-          s += sc.Jl[a * 6 + i] * t;
-        }
-        sc.JWJ[lane] = s;
-      }
-    }
-    SMPC_LANES_END_WAVE
-
-    if (in.prof) prof_tick(in.prof, 32, tprev);
     double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
     const double dt = md.dt;
     const double mu = md.mu;
@@ -349,7 +267,7 @@ namespace smpc
         }
         else
         {
-          Dbot[m] = dt * sc.ab_du[m * NU + k];
+          Dbot[m] = dt * sc.ab_du()[m * NU + k];
           Dtop[m] = dt * Dbot[m];
         }
       }
@@ -453,6 +371,89 @@ namespace smpc
     SMPC_LANES_END_WAVE
 
     if (in.prof) prof_tick(in.prof, 33, tprev);
+    // ---- small weighted-Jacobian tables (after the [A|B] assembly: the state-cost tables take over the block that held
+    //      d a_b / du) ----
+    SMPC_LANES(NT)
+    {
+      const bool wdiag = md.w_diag != 0; // diagonal w_x, w_u: their entries come from the LDS model block
+      for (int idx = lane; idx < NDX * 6; idx += NT)
+      {
+        const int a = idx / 6, k = idx % 6;
+        double s = 0.0;
+        if (wdiag)
+          s = a < 6 ? md.wxd[a] * sc.Jl[a * 6 + k] : 0.0;
+        else
+          for (int bb = 0; bb < 6; bb++)
+            s += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + k];
+        sc.WJl[idx] = s;
+      }
+      for (int idx = lane; idx < 6 * NDX; idx += NT)
+      {
+        const int a = idx / NDX, k = idx % NDX;
+        double s = 0.0;
+        for (int bb = 0; bb < 6; bb++)
+          s += md.w_cent[a * 6 + bb] * (k < NV ? sc.dh_dq[bb * NV + k] : sc.Ag[bb * NV + k - NV]);
+        sc.WJc()[idx] = s;
+        // JtW[i][k] = sum_a Jl[a][i] w_x[a][k]  (rows of J_x^T w_x for the base block)
+        double t = 0.0;
+        if (wdiag)
+          t = k < 6 ? sc.Jl[k * 6 + a] * md.wxd[k] : 0.0;
+        else
+          for (int bb = 0; bb < 6; bb++)
+            t += sc.Jl[bb * 6 + a] * mg.w_x[bb * NDX + k];
+        sc.JtW[idx] = t;
+      }
+      for (int idx = lane; idx < 6 * NV; idx += NT)
+      {
+        const int a = idx / NV, k = idx % NV;
+        double s = 0.0;
+        for (int bb = 0; bb < 3; bb++)
+          s += md.w_centder[a * 6 + 3 + bb] * sc.dtgt[bb * NV + k];
+        sc.WD()[idx] = s;
+      }
+      for (int idx = lane; idx < 6 * 3 * NF; idx += NT)
+      {
+        const int a = idx / (3 * NF), k = idx % (3 * NF);
+        const int f = k / 3, j = k % 3;
+        double s = 0.0;
+        if ((in.mask >> f) & 1u)
+        {
+          const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
+          const V3 xc = cross(rr, mk3(j == 0, j == 1, j == 2)); // column j of [rr]x
+          s = md.w_centder[a * 6 + j] + md.w_centder[a * 6 + 3] * xc.x + md.w_centder[a * 6 + 4] * xc.y + md.w_centder[a * 6 + 5] * xc.z;
+        }
+        sc.WJu()[idx] = s;
+      }
+      for (int idx = lane; idx < NF * 3 * NV; idx += NT)
+      {
+        const int fa = idx / NV, k = idx % NV;
+        const int f = fa / 3, a = fa % 3;
+        double s = 0.0;
+        for (int bb = 0; bb < 3; bb++)
+          s += md.w_frame[a * 3 + bb] * sc.Jfoot[(f * 3 + bb) * NV + k];
+        sc.WJf()[idx] = s;
+      }
+      if (lane < 36)
+      {
+        // JWJ = Jl^T w_x[0:6,0:6] Jl (base block of the state Hessian)
+        const int i = lane / 6, j = lane % 6;
+        double s = 0.0;
+        for (int a = 0; a < 6; a++)
+        {
+          double t = 0.0;
+          if (wdiag)
+            t = md.wxd[a] * sc.Jl[a * 6 + j];
+          else
+            for (int bb = 0; bb < 6; bb++)
+              t += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + j];
+          s += sc.Jl[a * 6 + i] * t;
+        }
+        sc.JWJ[lane] = s;
+      }
+    }
+    SMPC_LANES_END_WAVE
+
+    if (in.prof) prof_tick(in.prof, 32, tprev);
     // ---- Q, S, R on the matrix cores:  H = [Q S; S^T R] = H_0 + J^T (W J)  with the stacked Gauss-Newton Jacobian
     //        rows  0.. 5  centroidal momentum      J = [dh_dq | Ag | 0]                    W J = WJc
     //        rows  8..13  momentum derivative      J = [[0; dtgt] | 0 | Ju (contact) | 0]  W J = [WD | 0 | WJu | 0]

@@ -31,9 +31,8 @@ namespace smpc
     // reused -- in this order of time -- by the wave reductions of the cost / multiplier phases and by the
     // weighted-Jacobian tables of the assembly phases (accessors below)
     double oR[D::NJ * 9], S[D::NV * 6], vel[D::NJ * 6], acc[D::NJ * 6], Ic[D::NJ * 10], hc[D::NJ * 6], Fc[D::NJ * 6];
-    // tree block B (contiguous, 247 doubles): dead before the derivative columns; reused by the contact-constraint
-    // Jacobian dcq (and, before that, by a temporary of the net-force update)
-    double op[D::NJ * 3], I[D::NJ * 10], h[D::NJ * 6];
+    // placements and body inertias (needed until the velocity-product matrices are formed)
+    double op[D::NJ * 3], I[D::NJ * 10];
     SMPC_HD double * part() { return oR; }        // [64]
     SMPC_HD double * part2() { return oR + 64; }  // [64]
     SMPC_HD double * part8() { return oR + 128; } // [16]
@@ -53,7 +52,7 @@ namespace smpc
     double rx[D::NDX], Wrx[D::NDX], ru[D::NU], Wru[D::NU], Whg[6], Whd[6], rf[D::NF * 3], Wrf[D::NF * 3];
     double vplus[D::NC], lamp[D::NDX], lam_next[D::NDX], lam_prev[D::NDX], nu[D::NC];
     int act[D::NC];
-    double red[8];
+    double red[4];
   };
   template <class D>
   struct KinoScratchDerivPart
@@ -61,7 +60,6 @@ namespace smpc
     double dh_dq[6 * D::NV], dhd_dq[6 * D::NV], dhd_dv[6 * D::NV]; // dhd_*: overwritten in place by ab_dq / ab_dv
     double Jfoot[D::NF * 3 * D::NV];
     double dtgt[3 * D::NV];
-    double ab_du[6 * D::NU];
     double cn[D::NDX]; // C_x^T nu of the contact rows (formed with the constraint Jacobian columns)
     double Je3[9], JeQ[9], Jq[36], Jl[36];
     double WJl[D::NDX * 6];           // w_x[:,0:6] * Jl
@@ -81,13 +79,14 @@ namespace smpc
     SMPC_HD double * WD() { return this->oR + 216; }  // [6][NV]      w_centder[:,3:6] * dtgt
     SMPC_HD double * WJu() { return this->oR + 324; } // [6][3 NF]    w_centder * Ju (force columns)
     SMPC_HD double * WJf() { return this->oR + 396; } // [3 NF][NV]   w_frame * Jfoot
-    SMPC_HD double * aS() { return this->op; }             // [NV][6] temporaries of the net-force update, in tree block B
-    SMPC_HD double * IaS() { return this->op + 6 * D::NV; } // [NV][6]
+    SMPC_HD double * aS() { return this->dhd_dq; }  // [NV][6] temporaries of the net-force update: dhd_dq | dhd_dv are
+    SMPC_HD double * IaS() { return this->dhd_dv; } // [NV][6] written afterwards, by the derivative columns
+    SMPC_HD double * ab_du() { return this->WJl; }  // [6][NU] lives in the block of the state-cost tables, which are
+                                                     //         formed after the [A|B] assembly has consumed it
     SMPC_HD double * ab_dq() { return this->dhd_dq; }      // [6][NV] in place
     SMPC_HD double * ab_dv() { return this->dhd_dv; }      // [6][NV] in place
     static_assert(6 * D::NDX == 216 && 6 * D::NV == 108 && 18 * D::NF == 72 && 396 + 3 * D::NF * D::NV <= D::NJ * 9 + D::NV * 6 + D::NJ * 40,
                   "table layout inside tree block A");
-    static_assert(12 * D::NV <= D::NJ * 19, "net-force temporaries inside tree block B");
   };
 
   // inputs describing one stage evaluation
@@ -337,14 +336,13 @@ namespace smpc
       stsi(&sc.I[j * 10], I);
       stsi(&sc.Ic[j * 10], I);
       const SV h = I * v;
-      stsv(&sc.h[j * 6], h);
       stsv(&sc.hc[j * 6], h);
       stsv(&sc.Fc[j * 6], I * a + crf(v, h));
     }
     else if (lane >= 32 && lane < 32 + NF)
     {
       const int f = lane - 32, j = md.foot_joint[f];
-      st3(&sc.footp[f * 3], ldm3(&sc.oR[j * 9]) * ld3(md.foot_p[f]) + ld3(&sc.op[j * 3]));
+      st3(&sc.footp[f * 3], ldm3(&sc.oR[j * 9]) * ld3(mg.foot_p[f]) + ld3(&sc.op[j * 3]));
     }
     SMPC_LANES_END_WAVE
     if (in.prof) prof_tick(in.prof, 16, *in.tprev);
@@ -785,7 +783,7 @@ namespace smpc
             for (int m = 0; m < 6; m++)
               rhs[m] = -sc.Ag[m * NV + kk];
           }
-          dst = &sc.ab_du[k];
+          dst = &sc.ab_du()[k];
           ld = D::NU;
         }
 #pragma unroll

@@ -55,7 +55,6 @@ namespace smpc
   template <class D>
   struct DevModelSmall
   {
-    double foot_p[D::NF][3];
     double total_mass;
     // KinodynamicsSettings (include/simple-mpc/kinodynamics.hpp:24-51)
     double dt;
@@ -88,6 +87,7 @@ namespace smpc
     double mass[D::NJ];
     double com[D::NJ][3];
     double inertia[D::NJ][6];
+    double foot_p[D::NF][3];
     double foot_ref_p[D::NF][3];
     double w_x[D::NDX * D::NDX];
     double w_u[D::NU * D::NU];
