@@ -146,6 +146,22 @@ int smpc_set_profiling(smpc_handle * h, int enabled);
 int smpc_get_kernel_times(smpc_handle * h, double * ms, long * calls);
 int smpc_reset_kernel_times(smpc_handle * h);
 
+/* ---- interpolation between MPC knots (replaces the Interpolator class,
+ *      reference include/simple-mpc/interpolator.hpp, src/interpolator.cpp:5-78) ----
+ * smpc_interpolate: batched targets for the whole-body controller that follows the MPC, from the solution held by the
+ *   handle, as the reference examples compute them (examples/go2_kinodynamics.py:276-284):
+ *     x_out     [B][nx]    interpolateState over xs[0 .. knots-1] (configuration on the manifold, velocity linear)
+ *     acc_out   [B][nv]    interpolateLinear over getStateDerivative(t)[nv:] with the joint part replaced by
+ *                          us[t][3 nf:], t = 0, 1
+ *     force_out [B][3 nf]  interpolateLinear over us[t][: 3 nf], t = 0, 1
+ *   delay >= 0 (seconds after the last smpc_iterate); beyond the last interval the last knot is returned, like the
+ *   reference.  Any output pointer may be NULL.  Host buffers.
+ * smpc_interpolate_knots: the Interpolator methods on explicit host knot lists [n][dim]:
+ *     kind 0 interpolateState (dim = nq + nv), 1 interpolateConfiguration (dim = nq), 2 interpolateLinear (any dim).
+ *   Errors mirror the reference's assertions ("State is not of the right size"). */
+int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, double * acc_out, double * force_out);
+int smpc_interpolate_knots(int kind, double delay, double timestep, const double * knots, int n, int dim, double * out, int device_id);
+
 #ifdef __cplusplus
 }
 #endif

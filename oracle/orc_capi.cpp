@@ -413,6 +413,46 @@ extern "C"
   }
   // single ProxDDP iteration on explicit inputs, for stage-by-stage GPU parity:
   // returns the LQ knots of iteration 1 for instance b (packed like orc_riccati inputs)
+  // Interpolator (reference src/interpolator.cpp:5-78), floating-base robot with nq = nv + 1.
+  //   kind 0: interpolateState (knots of size nq + nv), 1: interpolateConfiguration (nq), 2: interpolateLinear (dim)
+  // step = (size_t)(delay / timestep); beyond the last interval -> last knot; else knot[step] towards knot[step+1]
+  // by progress = (delay - step * timestep) / timestep: the configuration on the manifold
+  // (integrate(q0, progress * difference(q0, q1)), what pinocchio::interpolate does), everything else linearly.
+  void orc_interpolate(int kind, int nv, double delay, double timestep, const double * knots, int n, int dim, double * out)
+  {
+    const size_t step = (size_t)(delay / timestep);
+    const double s = (delay - (double)step * timestep) / timestep;
+    if (step >= (size_t)n - 1)
+    {
+      for (int i = 0; i < dim; i++)
+        out[i] = knots[(size_t)(n - 1) * dim + i];
+      return;
+    }
+    const double * k0 = knots + step * dim;
+    const double * k1 = knots + (step + 1) * dim;
+    if (kind == 2)
+    {
+      for (int i = 0; i < dim; i++)
+        out[i] = k1[i] * s + k0[i] * (1.0 - s);
+      return;
+    }
+    const int nq = nv + 1;
+    std::vector<double> x0(nq + nv, 0.0), x1(nq + nv, 0.0), d(2 * nv), xo(nq + nv);
+    std::copy(k0, k0 + nq, x0.begin());
+    std::copy(k1, k1 + nq, x1.begin());
+    x_difference(nq, nv, x0.data(), x1.data(), d.data());
+    for (int i = 0; i < nv; i++)
+    {
+      d[i] *= s;
+      d[nv + i] = 0.0;
+    }
+    x_integrate(nq, nv, x0.data(), d.data(), xo.data());
+    for (int i = 0; i < nq; i++)
+      out[i] = xo[i];
+    if (kind == 0)
+      for (int i = 0; i < nv; i++)
+        out[nq + i] = k1[nq + i] * s + k0[nq + i] * (1.0 - s);
+  }
   int orc_num_threads()
   {
 #ifdef _OPENMP

@@ -295,4 +295,40 @@ extern "C"
       }
     });
   }
+  int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, double * acc_out, double * force_out)
+  {
+    if (!h)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { h->eng->interpolate(delay, knots, x_out, acc_out, force_out); });
+  }
+  int smpc_interpolate_knots(int kind, double delay, double timestep, const double * knots, int n, int dim, double * out, int device_id)
+  {
+    if (!knots || !out || n < 1 || dim < 1 || kind < 0 || kind > 2 || !(timestep > 0.0) || !(delay >= 0.0))
+      return fail(SMPC_ERR_INVALID, "invalid argument");
+    if (kind == 0 && dim != DimsGo2::NX)
+      return fail(SMPC_ERR_INVALID, "State is not of the right size");
+    if (kind == 1 && dim != DimsGo2::NQ)
+      return fail(SMPC_ERR_INVALID, "Configuration is not of the right size");
+    if (device_count() <= 0)
+      return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the interpolator has no CPU path");
+    return guarded([&] {
+      set_device(device_id);
+      stream_t st = stream_create();
+      double * dk = (double *)dev_alloc(((size_t)n * dim + dim) * sizeof(double));
+      h2d(dk, knots, (size_t)n * dim * sizeof(double), st);
+      InterpKnotsArgs<DimsGo2> ia;
+      ia.kind = kind;
+      ia.n = n;
+      ia.dim = dim;
+      ia.delay = delay;
+      ia.timestep = timestep;
+      ia.knots = dk;
+      ia.out = dk + (size_t)n * dim;
+      launch<InterpKnotsArgs<DimsGo2>, interp_knots_body<DimsGo2>, 64>(1, st, ia);
+      d2h(out, ia.out, (size_t)dim * sizeof(double), st);
+      stream_sync(st);
+      dev_free(dk);
+      stream_destroy(st);
+    });
+  }
 }

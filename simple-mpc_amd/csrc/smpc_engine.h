@@ -687,6 +687,34 @@ namespace smpc
       launch<GatherArgs<D>, gather_x_body<D>, 256>((int)(((size_t)B * D::NX + 255) / 256), stream, ga);
     }
 
+    // interpolated whole-body targets at `delay` after the last solve; host outputs, any may be null
+    void interpolate(double delay, int knots, double * x_out, double * acc_out, double * f_out)
+    {
+      if (knots < 2 || knots > H + 1)
+        throw std::runtime_error("interpolate: knots must be in [2, horizon + 1]");
+      if (!(delay >= 0.0))
+        throw std::runtime_error("interpolate: delay must be non-negative");
+      const size_t nx = (size_t)B * D::NX, na = (size_t)B * D::NV, nf = (size_t)B * 3 * D::NF;
+      double * st = staging((nx + na + nf) * sizeof(double));
+      InterpArgs<D> ia;
+      ia.b = buf;
+      ia.head = head;
+      ia.knots = knots;
+      ia.delay = delay;
+      ia.timestep = ms.timestep;
+      ia.x_out = x_out ? st : nullptr;
+      ia.acc_out = acc_out ? st + nx : nullptr;
+      ia.f_out = f_out ? st + nx + na : nullptr;
+      launch<InterpArgs<D>, interp_body<D>, 64>(B, stream, ia);
+      if (x_out)
+        d2h(x_out, st, nx * sizeof(double), stream);
+      if (acc_out)
+        d2h(acc_out, st + nx, na * sizeof(double), stream);
+      if (f_out)
+        d2h(f_out, st + nx + na, nf * sizeof(double), stream);
+      stream_sync(stream);
+    }
+
     double * staging(size_t bytes)
     {
       if (bytes > stage_out_bytes)

@@ -661,6 +661,132 @@ namespace smpc
   }
 
   // =============================================================================================
+  // interp_body: grid = B, 64 lanes.  Targets between MPC knots for the whole-body controller that follows the MPC
+  // (reference src/interpolator.cpp:5-78 used as in examples/go2_kinodynamics.py:276-284):
+  //   x    interpolateState over xs[0 .. knots-1]: q on the manifold (q0 (+) s (q1 (-) q0)), v linear
+  //   acc  interpolateLinear over [getStateDerivative(t)[nv:] with the joint part replaced by us[t][3 nf:]], t = 0, 1
+  //   f    interpolateLinear over us[t][: 3 nf], t = 0, 1
+  // =============================================================================================
+  template <class D>
+  struct InterpArgs
+  {
+    Buffers<D> b;
+    int head, knots;
+    double delay, timestep;
+    double *x_out, *acc_out, *f_out; // device, any may be null
+  };
+  template <class D>
+  SMPC_DEV void interp_body(const InterpArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NX = D::NX, NDX = D::NDX, NV = D::NV, NU = D::NU, NF = D::NF;
+    const Buffers<D> & b = ka.b;
+    const int inst = block, R = b.R;
+    const size_t step = (size_t)(ka.delay / ka.timestep);
+    const double s = (ka.delay - (double)step * ka.timestep) / ka.timestep;
+    SMPC_LDS(double, e, D::NDX);
+    if (ka.x_out != nullptr)
+    {
+      double * xo = ka.x_out + (size_t)inst * NX;
+      if (step >= (size_t)ka.knots - 1)
+      {
+        const double * xl = b.xs + ((size_t)inst * R + ring_slot(ka.head, ka.knots - 1, R)) * NX;
+        SMPC_LANES(NT)
+        if (lane < NX)
+          xo[lane] = xl[lane];
+        SMPC_LANES_END_WAVE
+      }
+      else
+      {
+        const double * x0 = b.xs + ((size_t)inst * R + ring_slot(ka.head, (int)step, R)) * NX;
+        const double * x1 = b.xs + ((size_t)inst * R + ring_slot(ka.head, (int)step + 1, R)) * NX;
+        SMPC_LANES(NT)
+        lanes_difference<D>(x0, x1, e, lane, 0);
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        lanes_integrate<D>(x0, e, s, xo, lane, 0);
+        SMPC_LANES_END_WAVE
+      }
+    }
+    static_assert(NDX <= NT && NU <= NT, "one entry per lane");
+    // two knots (t = 0, 1) for the accelerations and the forces
+    const bool last = step >= 1;
+    const double w1 = last ? 1.0 : s, w0 = last ? 0.0 : 1.0 - s;
+    const double * u0 = b.us + ((size_t)inst * R + ring_slot(ka.head, 0, R)) * NU;
+    const double * u1 = b.us + ((size_t)inst * R + ring_slot(ka.head, 1, R)) * NU;
+    SMPC_LANES(NT)
+    {
+      if (ka.acc_out != nullptr && lane < NV)
+      {
+        const double * xd = b.xdot01 + (size_t)inst * 4 * NV;
+        const double a0 = lane < 6 ? xd[NV + lane] : u0[3 * NF + lane - 6];
+        const double a1 = lane < 6 ? xd[2 * NV + NV + lane] : u1[3 * NF + lane - 6];
+        ka.acc_out[(size_t)inst * NV + lane] = a1 * w1 + a0 * w0;
+      }
+      if (ka.f_out != nullptr && lane < 3 * NF)
+        ka.f_out[(size_t)inst * 3 * NF + lane] = u1[lane] * w1 + u0[lane] * w0;
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // interpolation of explicit knot lists (the reference's Interpolator class on host data): one block
+  //   kind 0: state knots [n][NX], 1: configuration knots [n][NQ], 2: linear [n][dim]
+  template <class D>
+  struct InterpKnotsArgs
+  {
+    int kind, n, dim;
+    double delay, timestep;
+    const double * knots; // device
+    double * out;         // device
+  };
+  template <class D>
+  SMPC_DEV void interp_knots_body(const InterpKnotsArgs<D> & ka, int)
+  {
+    constexpr int NT = 64;
+    constexpr int NX = D::NX, NQ = D::NQ, NV = D::NV;
+    const size_t step = (size_t)(ka.delay / ka.timestep);
+    const double s = (ka.delay - (double)step * ka.timestep) / ka.timestep;
+    SMPC_LDS(double, buf, 3 * D::NX + D::NDX);
+    double *x0 = buf, *x1 = buf + NX, *xo = buf + 2 * NX, *e = buf + 3 * NX;
+    if (step >= (size_t)ka.n - 1)
+    {
+      SMPC_LANES(NT)
+      for (int i = lane; i < ka.dim; i += NT)
+        ka.out[i] = ka.knots[(size_t)(ka.n - 1) * ka.dim + i];
+      SMPC_LANES_END_WAVE
+      return;
+    }
+    const double * k0 = ka.knots + step * ka.dim;
+    const double * k1 = ka.knots + (step + 1) * ka.dim;
+    if (ka.kind == 2)
+    {
+      SMPC_LANES(NT)
+      for (int i = lane; i < ka.dim; i += NT)
+        ka.out[i] = k1[i] * s + k0[i] * (1.0 - s);
+      SMPC_LANES_END_WAVE
+      return;
+    }
+    SMPC_LANES(NT)
+    if (lane < NX)
+    {
+      x0[lane] = lane < ka.dim ? k0[lane] : 0.0;
+      x1[lane] = lane < ka.dim ? k1[lane] : 0.0;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    lanes_difference<D>(x0, x1, e, lane, 0);
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    lanes_integrate<D>(x0, e, s, xo, lane, 0);
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane < ka.dim)
+      ka.out[lane] = (lane < NQ) ? xo[lane] : k1[lane] * s + k0[lane] * (1.0 - s);
+    SMPC_LANES_END_WAVE
+    (void)NV;
+  }
+
+  // =============================================================================================
   // lq_init_body: grid = B * H, run once: the state-independent rows (qj, vj) of A and B of every knot
   // (semi-implicit Euler: q+ = q + dt (v + dt a), v+ = v + dt a, reference src/kinodynamics.cpp:88)
   // =============================================================================================

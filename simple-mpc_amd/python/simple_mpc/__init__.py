@@ -17,7 +17,7 @@ import numpy as np
 from . import _capi
 from ._capi import KinodynamicsSettingsC, MpcSettingsC, SmpcLib, default_lib
 
-__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "MPC", "BatchedMPC"]
+__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "MPC", "BatchedMPC", "Interpolator"]
 
 
 def load_robot(name, lib=None):
@@ -309,6 +309,17 @@ class BatchedMPC:
     def getReferencePoses(self):
         return self._get("smpc_get_reference_poses", (self.B, self.H, self.nf, 3))
 
+    def interpolate(self, delay, knots=2):
+        """Targets between MPC knots for the whole-body controller, batched on the device (reference
+        examples/go2_kinodynamics.py:276-284 with src/interpolator.cpp:5-78): returns (x[B, nx], acc[B, nv],
+        forces[B, nf, 3]) at `delay` seconds after the last iterate."""
+        x = np.zeros((self.B, self.nx))
+        a = np.zeros((self.B, self.nv))
+        f = np.zeros((self.B, self.nf * 3))
+        self._lib.check(self._lib.L.smpc_interpolate(
+            self._h, float(delay), int(knots), x.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p)))
+        return x, a, f.reshape(self.B, self.nf, 3)
+
     def _timing(self, which):
         names = self.ocp_handler.model_handler.getFeetFrameNames()
         out = {}
@@ -413,3 +424,34 @@ class MPC(BatchedMPC):
 
     def getStateDerivative(self, t):
         return super().getStateDerivative(t)[0]
+
+
+class Interpolator:
+    """reference include/simple-mpc/interpolator.hpp / bindings/expose-interpolate.cpp: same four methods, on lists of
+    numpy vectors.  The arithmetic runs in the HIP library (smpc_interpolate_knots); contacts are a table look-up."""
+
+    def __init__(self, model, lib=None, device_id=0):
+        self._lib = lib or default_lib()
+        self._dev = device_id
+        self.model = model
+
+    def _run(self, kind, delay, timestep, knots):
+        k = np.ascontiguousarray(np.array(knots, dtype=np.float64))
+        if k.ndim != 2:
+            raise RuntimeError("knots must be a list of equally sized vectors")
+        out = np.zeros(k.shape[1])
+        self._lib.check(self._lib.L.smpc_interpolate_knots(kind, float(delay), float(timestep), k, k.shape[0], k.shape[1], out, self._dev))
+        return out
+
+    def interpolateConfiguration(self, delay, timestep, qs):
+        return self._run(1, delay, timestep, qs)
+
+    def interpolateState(self, delay, timestep, xs):
+        return self._run(0, delay, timestep, xs)
+
+    def interpolateLinear(self, delay, timestep, vs):
+        return self._run(2, delay, timestep, vs)
+
+    def interpolateContacts(self, delay, timestep, cs):
+        step = int(delay / timestep)
+        return list(cs[min(max(step, 0), len(cs) - 1)])

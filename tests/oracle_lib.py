@@ -90,6 +90,7 @@ def lib():
     L.orc_mpc_cold_trace.argtypes = [vp, _dp]
     L.orc_mpc_timing.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
     L.orc_num_threads.restype = C.c_int
+    L.orc_interpolate.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int, _dp]
     _lib = L
     return L
 
@@ -350,3 +351,11 @@ class OracleMPC:
         out = np.zeros(64, np.int32)
         n = lib().orc_mpc_timing(self.h, foot, which, out, 64)
         return [int(v) for v in out[:n]]
+
+
+def interpolate(kind, nv, delay, timestep, knots):
+    """Oracle restatement of the reference Interpolator (src/interpolator.cpp:5-78): kind 0 state, 1 configuration, 2 linear."""
+    k = np.ascontiguousarray(np.array(knots, dtype=np.float64))
+    out = np.zeros(k.shape[1])
+    lib().orc_interpolate(kind, nv, float(delay), float(timestep), k, k.shape[0], k.shape[1], out)
+    return out
