@@ -162,6 +162,15 @@ int smpc_reset_kernel_times(smpc_handle * h);
 int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, double * acc_out, double * force_out);
 int smpc_interpolate_knots(int kind, double delay, double timestep, const double * knots, int n, int dim, double * out, int device_id);
 
+/* ---- friction compensation (replaces FrictionCompensation::computeFriction, reference
+ *      src/friction-compensation.cpp:22-37): torque[b][j] += viscous[j] * velocity[b][j] + dry[j] * sign(velocity[b][j])
+ *      for a batch of joint velocity / torque vectors of size nu (host buffers, torque in / out).  velocity_size /
+ *      torque_size are the per-instance vector lengths the caller holds: a mismatch with nu is the reference's
+ *      "Velocity has wrong size" / "Torque has wrong size" error. */
+int smpc_friction_compensation(
+  const double * dry, const double * viscous, int nu, const double * velocity, int velocity_size, double * torque, int torque_size,
+  int batch, int device_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -453,6 +453,16 @@ extern "C"
       for (int i = 0; i < nv; i++)
         out[nq + i] = k1[nq + i] * s + k0[nq + i] * (1.0 - s);
   }
+  // FrictionCompensation::computeFriction (reference src/friction-compensation.cpp:22-37)
+  void orc_friction(const double * dry, const double * viscous, int nu, const double * velocity, double * torque, int batch)
+  {
+    for (int b = 0; b < batch; b++)
+      for (int j = 0; j < nu; j++)
+      {
+        const double v = velocity[(size_t)b * nu + j];
+        torque[(size_t)b * nu + j] += viscous[j] * v + dry[j] * (double)((v > 0) - (v < 0));
+      }
+  }
   int orc_num_threads()
   {
 #ifdef _OPENMP

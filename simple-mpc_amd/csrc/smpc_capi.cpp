@@ -331,4 +331,39 @@ extern "C"
       stream_destroy(st);
     });
   }
+  int smpc_friction_compensation(
+    const double * dry, const double * viscous, int nu, const double * velocity, int velocity_size, double * torque, int torque_size,
+    int batch, int device_id)
+  {
+    if (!dry || !viscous || !velocity || !torque || nu < 1 || batch < 1)
+      return fail(SMPC_ERR_INVALID, "invalid argument");
+    if (velocity_size != nu)
+      return fail(SMPC_ERR_INVALID, "Velocity has wrong size");
+    if (torque_size != nu)
+      return fail(SMPC_ERR_INVALID, "Torque has wrong size");
+    if (device_count() <= 0)
+      return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the friction compensation has no CPU path");
+    return guarded([&] {
+      set_device(device_id);
+      stream_t st = stream_create();
+      const size_t total = (size_t)batch * nu;
+      double * d = (double *)dev_alloc((2 * (size_t)nu + 2 * total) * sizeof(double));
+      h2d(d, dry, (size_t)nu * sizeof(double), st);
+      h2d(d + nu, viscous, (size_t)nu * sizeof(double), st);
+      h2d(d + 2 * nu, velocity, total * sizeof(double), st);
+      h2d(d + 2 * nu + total, torque, total * sizeof(double), st);
+      FrictionArgs fa;
+      fa.dry = d;
+      fa.viscous = d + nu;
+      fa.velocity = d + 2 * nu;
+      fa.torque = d + 2 * nu + total;
+      fa.nu = nu;
+      fa.total = total;
+      launch<FrictionArgs, friction_body, 256>((int)((total + 255) / 256), st, fa);
+      d2h(torque, fa.torque, total * sizeof(double), st);
+      stream_sync(st);
+      dev_free(d);
+      stream_destroy(st);
+    });
+  }
 }

@@ -895,6 +895,31 @@ namespace smpc
     SMPC_LANES_END
   }
 
+  // torque += viscous * v + dry * sign(v), elementwise over [B][nu] (reference src/friction-compensation.cpp:22-37)
+  struct FrictionArgs
+  {
+    const double *dry, *viscous, *velocity; // [nu], [nu], [B][nu] (device)
+    double * torque;                        // [B][nu] in / out (device)
+    int nu;
+    size_t total; // B * nu
+  };
+  SMPC_DEV void friction_body(const FrictionArgs & ka, int block)
+  {
+    constexpr int NT = 256;
+    SMPC_LANES(NT)
+    {
+      const size_t i = (size_t)block * NT + lane;
+      if (i < ka.total)
+      {
+        const int j = (int)(i % (size_t)ka.nu);
+        const double v = ka.velocity[i];
+        const double sgn = (double)((v > 0.0) - (v < 0.0));
+        ka.torque[i] += ka.viscous[j] * v + ka.dry[j] * sgn;
+      }
+    }
+    SMPC_LANES_END
+  }
+
   // gather one horizon node t of every instance out of the ring into a dense [B][NX] device buffer
   template <class D>
   struct GatherArgs

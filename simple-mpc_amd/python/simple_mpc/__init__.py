@@ -17,7 +17,7 @@ import numpy as np
 from . import _capi
 from ._capi import KinodynamicsSettingsC, MpcSettingsC, SmpcLib, default_lib
 
-__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "MPC", "BatchedMPC", "Interpolator"]
+__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "MPC", "BatchedMPC", "Interpolator", "FrictionCompensation"]
 
 
 def load_robot(name, lib=None):
@@ -455,3 +455,27 @@ class Interpolator:
     def interpolateContacts(self, delay, timestep, cs):
         step = int(delay / timestep)
         return list(cs[min(max(step, 0), len(cs) - 1)])
+
+
+class FrictionCompensation:
+    """reference include/simple-mpc/friction-compensation.hpp: torque += viscuous * v + dry * sign(v).  The reference reads
+    the coefficients from the tail of `model.friction` / `model.damping`; here they are passed as arrays (there is no
+    pinocchio.Model).  `computeFriction` accepts one vector pair or a batch [B, nu]; the torque is updated in place."""
+
+    def __init__(self, dry_friction, viscuous_friction, lib=None, device_id=0):
+        self.dry_friction_ = np.ascontiguousarray(np.array(dry_friction, dtype=np.float64))
+        self.viscuous_friction_ = np.ascontiguousarray(np.array(viscuous_friction, dtype=np.float64))
+        if self.dry_friction_.shape != self.viscuous_friction_.shape or self.dry_friction_.ndim != 1:
+            raise RuntimeError("friction coefficient vectors must have the same size")
+        self.nu_ = int(self.dry_friction_.size)
+        self._lib = lib or default_lib()
+        self._dev = device_id
+
+    def computeFriction(self, velocity, torque):
+        v = np.ascontiguousarray(np.array(velocity, dtype=np.float64))
+        if not (isinstance(torque, np.ndarray) and torque.dtype == np.float64 and torque.flags["C_CONTIGUOUS"]):
+            raise RuntimeError("torque must be a C-contiguous float64 array (updated in place)")
+        batch = 1 if v.ndim == 1 else v.shape[0]
+        self._lib.check(self._lib.L.smpc_friction_compensation(
+            self.dry_friction_, self.viscuous_friction_, self.nu_, v, v.shape[-1], torque, torque.shape[-1], batch, self._dev))
+        return torque

@@ -90,6 +90,7 @@ def lib():
     L.orc_mpc_cold_trace.argtypes = [vp, _dp]
     L.orc_mpc_timing.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
     L.orc_num_threads.restype = C.c_int
+    L.orc_friction.argtypes = [_dp, _dp, C.c_int, _dp, _dp, C.c_int]
     L.orc_interpolate.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int, _dp]
     _lib = L
     return L
