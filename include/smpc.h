@@ -160,6 +160,12 @@ int smpc_reset_kernel_times(smpc_handle * h);
  *     kind 0 interpolateState (dim = nq + nv), 1 interpolateConfiguration (dim = nq), 2 interpolateLinear (any dim).
  *   Errors mirror the reference's assertions ("State is not of the right size"). */
 int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, double * acc_out, double * force_out);
+
+/* ---- state feedback front-end (replaces RobotDataHandler::updateInternalData(x, false) and
+ *      getCentroidalState, reference src/robot-handler.cpp:106-127,142-149) for a batch of measured multibody states
+ *      X [B][nx] (host): feet [B][nf][3] foot positions (world), com [B][3], hg [B][6] centroidal momentum
+ *      [linear; angular about the CoM], centroidal_state [B][9] = [com; h_lin; h_ang].  Any output may be NULL. */
+int smpc_update_internal_data(smpc_handle * h, const double * X, double * feet, double * com, double * hg, double * centroidal_state);
 int smpc_interpolate_knots(int kind, double delay, double timestep, const double * knots, int n, int dim, double * out, int device_id);
 
 /* ---- friction compensation (replaces FrictionCompensation::computeFriction, reference

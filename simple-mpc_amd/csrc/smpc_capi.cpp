@@ -295,6 +295,12 @@ extern "C"
       }
     });
   }
+  int smpc_update_internal_data(smpc_handle * h, const double * X, double * feet, double * com, double * hg, double * centroidal_state)
+  {
+    if (!h || !X)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { h->eng->update_internal_data(X, feet, com, hg, centroidal_state); });
+  }
   int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, double * acc_out, double * force_out)
   {
     if (!h)

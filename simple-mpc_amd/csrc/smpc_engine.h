@@ -687,6 +687,31 @@ namespace smpc
       launch<GatherArgs<D>, gather_x_body<D>, 256>((int)(((size_t)B * D::NX + 255) / 256), stream, ga);
     }
 
+    // state feedback front-end on measured states X [B][NX] (host): host outputs, any may be null
+    void update_internal_data(const double * X, double * feet, double * com, double * hg, double * cstate)
+    {
+      const size_t nf = (size_t)B * D::NF * 3, nc = (size_t)B * 3, nh = (size_t)B * 6, ns = (size_t)B * 9;
+      double * st = staging((nf + nc + nh + ns) * sizeof(double));
+      h2d(X_dev, X, (size_t)B * D::NX * sizeof(double), stream);
+      FrontendArgs<D> fa;
+      fa.b = buf;
+      fa.X = X_dev;
+      fa.feet = feet ? st : nullptr;
+      fa.com = com ? st + nf : nullptr;
+      fa.hg = hg ? st + nf + nc : nullptr;
+      fa.cstate = cstate ? st + nf + nc + nh : nullptr;
+      launch<FrontendArgs<D>, frontend_body<D>, 64>(B, stream, fa);
+      if (feet)
+        d2h(feet, st, nf * sizeof(double), stream);
+      if (com)
+        d2h(com, st + nf, nc * sizeof(double), stream);
+      if (hg)
+        d2h(hg, st + nf + nc, nh * sizeof(double), stream);
+      if (cstate)
+        d2h(cstate, st + nf + nc + nh, ns * sizeof(double), stream);
+      stream_sync(stream);
+    }
+
     // interpolated whole-body targets at `delay` after the last solve; host outputs, any may be null
     void interpolate(double delay, int knots, double * x_out, double * acc_out, double * f_out)
     {

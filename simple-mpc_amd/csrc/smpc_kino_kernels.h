@@ -661,6 +661,61 @@ namespace smpc
   }
 
   // =============================================================================================
+  // frontend_body: grid = B, 64 lanes.  State feedback front-end: what
+  // RobotDataHandler::updateInternalData(x, false) + getCentroidalState provide for a measured multibody state
+  // (reference src/robot-handler.cpp:106-149): foot positions, centre of mass, centroidal momentum, and the
+  // centroidal state [com; h_lin; h_ang].
+  // =============================================================================================
+  template <class D>
+  struct FrontendArgs
+  {
+    Buffers<D> b;
+    const double * X;                     // [B][NX] measured states (device)
+    double *feet, *com, *hg, *cstate;     // [B][NF*3], [B][3], [B][6], [B][9] (device), any may be null
+  };
+  template <class D>
+  SMPC_DEV void frontend_body(const FrontendArgs<D> & ka, int block)
+  {
+    typedef KinoScratch<D, false> KinoScratchT;
+    constexpr int NT = 64;
+    constexpr int NX = D::NX, NU = D::NU, NF = D::NF;
+    const Buffers<D> & b = ka.b;
+    const int inst = block;
+    const DevModel<D> & mg = *b.model;
+    SMPC_LDS(KinoScratchT, scs, 1);
+    KinoScratchT & sc = scs[0];
+    StageIn<D> in;
+    in.md = &mg;
+    in.terminal = true;
+    in.mask = 0u;
+    in.u_ref = nullptr;
+    in.x_tgt = mg.x_term;
+    in.foot_ref = nullptr;
+    SMPC_LANES(NT)
+    {
+      lanes_load_model<D, NT>(sc, &mg, lane);
+      if (lane < NX)
+        sc.x[lane] = ka.X[(size_t)inst * NX + lane];
+      if (lane < NU)
+        sc.u[lane] = 0.0;
+    }
+    SMPC_LANES_END_WAVE
+    kino_tree_phases<D, false, true>(sc, in);
+    SMPC_LANES(NT)
+    {
+      if (ka.feet != nullptr && lane < NF * 3)
+        ka.feet[(size_t)inst * NF * 3 + lane] = sc.footp[lane];
+      if (ka.com != nullptr && lane < 3)
+        ka.com[(size_t)inst * 3 + lane] = sc.com[lane];
+      if (ka.hg != nullptr && lane < 6)
+        ka.hg[(size_t)inst * 6 + lane] = sc.hg[lane];
+      if (ka.cstate != nullptr && lane < 9)
+        ka.cstate[(size_t)inst * 9 + lane] = lane < 3 ? sc.com[lane] : sc.hg[lane - 3];
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // =============================================================================================
   // interp_body: grid = B, 64 lanes.  Targets between MPC knots for the whole-body controller that follows the MPC
   // (reference src/interpolator.cpp:5-78 used as in examples/go2_kinodynamics.py:276-284):
   //   x    interpolateState over xs[0 .. knots-1]: q on the manifold (q0 (+) s (q1 (-) q0)), v linear

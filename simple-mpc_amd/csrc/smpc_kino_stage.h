@@ -217,7 +217,8 @@ namespace smpc
   // composite quantities, Ag, hg, b0, hd, Agbi, a, xnext.  If DERIV, also acc/Fc for the solved
   // acceleration and every derivative column.
   // ---------------------------------------------------------------------------------------------
-  template <class D, bool DERIV>
+  // KIN_ONLY: stop after the kinematics / centroidal quantities (state front-end: no controls needed)
+  template <class D, bool DERIV, bool KIN_ONLY = false>
   SMPC_DEV void kino_tree_phases(KinoScratch<D, DERIV> & sc, const StageIn<D> & in)
   {
     constexpr int NT = 64;
@@ -465,6 +466,8 @@ namespace smpc
     if (in.prof) prof_tick(in.prof, 20, *in.tprev);
     }
     SMPC_LANES_END_WAVE
+    if constexpr (KIN_ONLY)
+      return;
     // ---- in-place Gauss-Jordan inverse of the SPD 6x6 (36 lanes, ping-pong gjA <-> gjB) ----
     for (int pv = 0; pv < 6; pv++)
     {

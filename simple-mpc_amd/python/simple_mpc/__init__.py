@@ -309,6 +309,18 @@ class BatchedMPC:
     def getReferencePoses(self):
         return self._get("smpc_get_reference_poses", (self.B, self.H, self.nf, 3))
 
+    def updateInternalData(self, X):
+        """State feedback front-end, batched on the device (reference src/robot-handler.cpp:106-149): for measured
+        states X[B, nx] returns dict(feet[B, nf, 3], com[B, 3], hg[B, 6], centroidal_state[B, 9])."""
+        X = np.ascontiguousarray(np.array(X, dtype=np.float64))
+        if X.shape != (self.B, self.nx):
+            raise RuntimeError("X must have shape (batch, nx)")
+        feet, com = np.zeros((self.B, self.nf, 3)), np.zeros((self.B, 3))
+        hg, cs = np.zeros((self.B, 6)), np.zeros((self.B, 9))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._lib.check(self._lib.L.smpc_update_internal_data(self._h, X, p(feet), p(com), p(hg), p(cs)))
+        return dict(feet=feet, com=com, hg=hg, centroidal_state=cs)
+
     def interpolate(self, delay, knots=2):
         """Targets between MPC knots for the whole-body controller, batched on the device (reference
         examples/go2_kinodynamics.py:276-284 with src/interpolator.cpp:5-78): returns (x[B, nx], acc[B, nv],
