@@ -371,8 +371,8 @@ namespace smpc
     SMPC_LANES_END_WAVE
 
     if (in.prof) prof_tick(in.prof, 33, tprev);
-    // ---- small weighted-Jacobian tables (after the [A|B] assembly: the state-cost tables take over the block that held
-    //      d a_b / du) ----
+    // ---- state-cost tables (after the [A|B] assembly: they take over the block that held d a_b / du);
+    //      the weighted Gauss-Newton Jacobians are formed on the matrix cores below ----
     SMPC_LANES(NT)
     {
       const bool wdiag = md.w_diag != 0; // diagonal w_x, w_u: their entries come from the LDS model block
@@ -390,10 +390,6 @@ namespace smpc
       for (int idx = lane; idx < 6 * NDX; idx += NT)
       {
         const int a = idx / NDX, k = idx % NDX;
-        double s = 0.0;
-        for (int bb = 0; bb < 6; bb++)
-          s += md.w_cent[a * 6 + bb] * (k < NV ? sc.dh_dq[bb * NV + k] : sc.Ag[bb * NV + k - NV]);
-        sc.WJc()[idx] = s;
         // JtW[i][k] = sum_a Jl[a][i] w_x[a][k]  (rows of J_x^T w_x for the base block)
         double t = 0.0;
         if (wdiag)
@@ -402,36 +398,6 @@ namespace smpc
           for (int bb = 0; bb < 6; bb++)
             t += sc.Jl[bb * 6 + a] * mg.w_x[bb * NDX + k];
         sc.JtW[idx] = t;
-      }
-      for (int idx = lane; idx < 6 * NV; idx += NT)
-      {
-        const int a = idx / NV, k = idx % NV;
-        double s = 0.0;
-        for (int bb = 0; bb < 3; bb++)
-          s += md.w_centder[a * 6 + 3 + bb] * sc.dtgt[bb * NV + k];
-        sc.WD()[idx] = s;
-      }
-      for (int idx = lane; idx < 6 * 3 * NF; idx += NT)
-      {
-        const int a = idx / (3 * NF), k = idx % (3 * NF);
-        const int f = k / 3, j = k % 3;
-        double s = 0.0;
-        if ((in.mask >> f) & 1u)
-        {
-          const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
-          const V3 xc = cross(rr, mk3(j == 0, j == 1, j == 2)); // column j of [rr]x
-          s = md.w_centder[a * 6 + j] + md.w_centder[a * 6 + 3] * xc.x + md.w_centder[a * 6 + 4] * xc.y + md.w_centder[a * 6 + 5] * xc.z;
-        }
-        sc.WJu()[idx] = s;
-      }
-      for (int idx = lane; idx < NF * 3 * NV; idx += NT)
-      {
-        const int fa = idx / NV, k = idx % NV;
-        const int f = fa / 3, a = fa % 3;
-        double s = 0.0;
-        for (int bb = 0; bb < 3; bb++)
-          s += md.w_frame[a * 3 + bb] * sc.Jfoot[(f * 3 + bb) * NV + k];
-        sc.WJf()[idx] = s;
       }
       if (lane < 36)
       {
@@ -452,7 +418,6 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
-
     if (in.prof) prof_tick(in.prof, 32, tprev);
     // ---- Q, S, R on the matrix cores:  H = [Q S; S^T R] = H_0 + J^T (W J)  with the stacked Gauss-Newton Jacobian
     //        rows  0.. 5  centroidal momentum      J = [dh_dq | Ag | 0]                    W J = WJc
@@ -464,11 +429,18 @@ namespace smpc
     {
       constexpr int T3I[6] = {0, 0, 0, 1, 1, 2}, T3J[6] = {0, 1, 2, 1, 2, 2};
       SMPC_ACC(qacc, NT, 6);
+      SMPC_ACC(wjacc, NT, 6);
       SMPC_PLA(double, av, NT, 7 * 3);
       SMPC_PLA(double, bv, NT, 7 * 3);
+      SMPC_PLA(double, wop, NT, 7);
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int tt = 0; tt < 6; tt++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+            SMPC_ACCV(wjacc, tt, v) = 0.0;
         // H_0 in accumulator layout: the weight entries come from global memory -- all loads are issued first
         // (one per accumulator entry, address-selected), the table look-ups and selects follow
         double wv[24];
@@ -519,14 +491,13 @@ namespace smpc
           for (int I = 0; I < 3; I++)
           {
             const int col = 16 * I + lc;
-            double a = 0.0, bq = 0.0;
+            double a = 0.0;
             if (ks < 2)
             {
               const int r = 4 * ks + lr;
               if (r < 6 && col < NDX)
               {
                 a = col < NV ? sc.dh_dq[r * NV + col] : sc.Ag[r * NV + col - NV];
-                bq = sc.WJc()[r * NDX + col];
               }
             }
             else if (ks < 4)
@@ -537,7 +508,6 @@ namespace smpc
                 if (col < NV)
                 {
                   a = r >= 3 ? sc.dtgt[(r - 3) * NV + col] : 0.0;
-                  bq = sc.WD()[r * NV + col];
                 }
                 else if (col >= NDX && col < NDX + 3 * NF)
                 {
@@ -548,7 +518,6 @@ namespace smpc
                     const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
                     const V3 xc = cross(rr, mk3(j == 0, j == 1, j == 2));
                     a = r < 3 ? (r == j ? 1.0 : 0.0) : (r == 3 ? xc.x : (r == 4 ? xc.y : xc.z));
-                    bq = sc.WJu()[r * 3 * NF + k];
                   }
                 }
               }
@@ -559,12 +528,42 @@ namespace smpc
               if (col < NV)
               {
                 a = sc.Jfoot[r * NV + col];
-                bq = sc.WJf()[r * NV + col];
               }
             }
             SMPC_PLV(av)[ks * 3 + I] = a;
-            SMPC_PLV(bv)[ks * 3 + I] = bq;
           }
+        // block-diagonal weight W~ = diag(w_cent, 0, w_centder, 0, w_frame x NF) as the A operand of W~ J~:
+        // entry (16 R + lc, 4 ks + lr), tile row R = ks / 4
+#pragma unroll
+        for (int ks = 0; ks < 7; ks++)
+        {
+          const int r = 16 * (ks / 4) + lc, k = 4 * ks + lr;
+          double w = 0.0;
+          if (ks < 2)
+            w = (r < 6 && k < 6) ? md.w_cent[r * 6 + k] : 0.0;
+          else if (ks < 4)
+            w = (r >= 8 && r < 14 && k < 14) ? md.w_centder[(r - 8) * 6 + k - 8] : 0.0;
+          else
+            w = (r < 16 + 3 * NF && (r - 16) / 3 == (k - 16) / 3) ? md.w_frame[((r - 16) % 3) * 3 + (k - 16) % 3] : 0.0;
+          SMPC_PLV(wop)[ks] = w;
+        }
+      }
+      SMPC_LANES_END_WAVE
+      // W~ J~ (28 x 48) on the matrix cores; its accumulator layout (rows lr + 4 v of tile row R) is the B-operand
+      // layout of K-step 4 R + v of the next product, so the weighted Jacobian never leaves the registers
+#pragma unroll
+      for (int ks = 0; ks < 7; ks++)
+#pragma unroll
+        for (int J = 0; J < 3; J++)
+          if (ks < 4 || J < 2)
+            SMPC_MFMA(wjacc, (ks / 4) * 3 + J, wop, ks, av, ks * 3 + J);
+      SMPC_LANES(NT)
+      {
+#pragma unroll
+        for (int ks = 0; ks < 7; ks++)
+#pragma unroll
+          for (int J = 0; J < 3; J++)
+            SMPC_PLV(bv)[ks * 3 + J] = SMPC_ACCV(wjacc, (ks / 4) * 3 + J, ks % 4);
       }
       SMPC_LANES_END_WAVE
 #pragma unroll
