@@ -417,7 +417,7 @@ namespace smpc
       sk.nj = D::LS_N - 1;
       timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk);
       timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, 1, D::LS_N - 1));
-      timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B * (H + 1), solver_args(b));
+      timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B, solver_args(b));
     }
     // one ProxDDP iteration for the instances covered by b (b.B may be < B for the cold solve)
     void run_iteration(const Buffers<D> & b)
@@ -451,7 +451,7 @@ namespace smpc
         }
         SolverArgs<D> sa = solver_args(b);
         sa.mode = 1;
-        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B * (H + 1), sa);
+        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B, sa);
         launch_deriv(b);
         timed_launch<SolverArgs<D>, spec_select_body<D>, 64>(KID_SELECT, nb, solver_args(b));
         // rejected instances (usually none: every launch below then exits at once)
@@ -459,14 +459,14 @@ namespace smpc
         sa = solver_args(b);
         sa.slots = slots;
         sa.mode = 2;
-        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_SELECT, slots * (H + 1), sa);
+        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_SELECT, slots, sa);
         StageKernelArgs<D> sk = stage_args(b, slots);
         sk.j0 = 1;
         sk.nj = D::LS_N - 1;
         timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk);
         timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, nb, solver_args(b, 1, D::LS_N - 1));
         sa.mode = 0;
-        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_SELECT, slots * (H + 1), sa);
+        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_SELECT, slots, sa);
         launch_deriv(b, slots);
         timed_launch<SolverArgs<D>, merit0_body<D>, 64>(KID_SELECT, nb, sa);
       }

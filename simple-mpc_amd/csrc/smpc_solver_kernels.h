@@ -570,92 +570,138 @@ namespace smpc
   // apply_body: grid = B * (H+1), 64 lanes: accept the step of size alpha for (inst, t)
   // =============================================================================================
   template <class D>
-  SMPC_DEV void apply_one(const SolverArgs<D> & ka, int inst, int t);
+  SMPC_DEV void apply_inst(const SolverArgs<D> & ka, int inst);
 
+  // grid = B (slots == 0) or `slots` walking the compacted list of undecided instances (slots > 0); one wave per instance
   template <class D>
   SMPC_DEV void apply_body(const SolverArgs<D> & ka, int block)
   {
-    const int H = ka.b.H;
-    const int slot = block / (H + 1), t = block % (H + 1);
-    // slots > 0: only the instances on the compacted list (they rejected the tentative full step)
-    const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : slot + 1;
+    const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : block + 1;
     const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
-    for (int m = slot; m < count; m += stride)
-      apply_one<D>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t);
+    for (int m = block; m < count; m += stride)
+      apply_inst<D>(ka, ka.slots > 0 ? ka.b.und_list[m] : m);
   }
 
   // mode 0: x <- x (+) alpha dx, u, nu, lam += alpha d.  (alpha of the instance's accepted candidate)
   // mode 1: tentative full step: the same with alpha = 1, the old values saved to the backup buffers, and the
   //         regularisation moved as after a successful line search (reference ProxDDP: decrease on success)
   // mode 2: restore the backup (the full step was rejected)
+  // A SIMD pass costs the same for 1 or 64 lanes: the SE(3) parts of all H+1 nodes are integrated side by side
+  // (lane = node), everything else is a flat coalesced stream over the instance's ring.
   template <class D>
-  SMPC_DEV void apply_one(const SolverArgs<D> & ka, int inst, int t)
+  SMPC_DEV void apply_inst(const SolverArgs<D> & ka, int inst)
   {
     constexpr int NT = 64;
-    constexpr int NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC;
+    constexpr int NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NQ = D::NQ, NV = D::NV;
     const Buffers<D> & b = ka.b;
     const int H = b.H, R = b.R;
-    const int st = ring_slot(ka.head, t, R);
     const size_t ib = (size_t)inst * R;
-    if (ka.mode == 2)
+    const bool tent = ka.mode == 1, restore = ka.mode == 2;
+    const double alpha = tent ? 1.0 : b.scal[(size_t)inst * SC_N + SC_ALPHA];
+    // ---- states: base pose on the manifold (lane = node), joints / velocities linearly ----
+    for (int t0 = 0; t0 <= H; t0 += NT)
     {
       SMPC_LANES(NT)
       {
-        for (int i = lane; i < NX; i += NT)
-          b.xs[(ib + st) * NX + i] = b.xs_b[(ib + st) * NX + i];
-        if (t < H)
+        const int t = t0 + lane;
+        if (t <= H)
         {
-          for (int i = lane; i < NU; i += NT)
-            b.us[(ib + st) * NU + i] = b.us_b[(ib + st) * NU + i];
-          for (int i = lane; i < NC; i += NT)
-            b.vs[(ib + st) * NC + i] = b.vs_b[(ib + st) * NC + i];
-          for (int i = lane; i < NDX; i += NT)
-            b.lams[(ib + st) * NDX + i] = b.lams_b[(ib + st) * NDX + i];
+          const int st = ring_slot(ka.head, t, R);
+          double * x = b.xs + (ib + st) * NX;
+          double * xb = b.xs_b + (ib + st) * NX;
+          const double * dx = b.dxs + ((size_t)inst * (H + 1) + t) * NDX;
+          if (restore)
+          {
+            for (int i = 0; i < 7; i++)
+              x[i] = xb[i];
+          }
+          else
+          {
+            const V3 dv = alpha * ld3(dx), dw = alpha * ld3(dx + 3);
+            const Quat q0{x[3], x[4], x[5], x[6]};
+            const V3 p0 = ld3(x);
+            if (tent)
+            {
+              st3(xb, p0);
+              xb[3] = q0.x;
+              xb[4] = q0.y;
+              xb[5] = q0.z;
+              xb[6] = q0.w;
+            }
+            const SE3 E = exp6(dv, dw);
+            st3(x, p0 + quat_to_R(q0) * E.p);
+            Quat qn = quat_mul(q0, quat_exp(dw));
+            const double n = 1.0 / sqrt(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+            x[3] = qn.x * n;
+            x[4] = qn.y * n;
+            x[5] = qn.z * n;
+            x[6] = qn.w * n;
+          }
         }
       }
       SMPC_LANES_END_WAVE
-      return;
     }
-    const bool tent = ka.mode == 1;
-    const double alpha = tent ? 1.0 : b.scal[(size_t)inst * SC_N + SC_ALPHA];
-    SMPC_LDS(double, xn, D::NX);
-    SMPC_LANES(NT)
-    lanes_integrate<D>(b.xs + (ib + st) * NX, b.dxs + ((size_t)inst * (H + 1) + t) * NDX, alpha, xn, lane, 0);
-    SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
     {
-      for (int i = lane; i < NX; i += NT)
+      constexpr int NL = NX - 7; // linear entries of a state: joints (q[7:]) and velocities
+      for (int idx = lane; idx < (H + 1) * NL; idx += NT)
       {
-        if (tent)
-          b.xs_b[(ib + st) * NX + i] = b.xs[(ib + st) * NX + i];
-        b.xs[(ib + st) * NX + i] = xn[i];
-      }
-      if (t < H)
-      {
-        const size_t lt = (size_t)inst * H + t;
-        for (int i = lane; i < NU; i += NT)
+        const int t = idx / NL, k = idx % NL; // k-th linear entry: x[7 + k] <-> dx[6 + k]
+        const size_t o = (ib + ring_slot(ka.head, t, R)) * NX + 7 + k;
+        if (restore)
+          b.xs[o] = b.xs_b[o];
+        else
         {
-          const double v = b.us[(ib + st) * NU + i];
+          const double v = b.xs[o];
           if (tent)
-            b.us_b[(ib + st) * NU + i] = v;
-          b.us[(ib + st) * NU + i] = v + alpha * b.dus[lt * NU + i];
-        }
-        for (int i = lane; i < NC; i += NT)
-        {
-          const double v = b.vs[(ib + st) * NC + i];
-          if (tent)
-            b.vs_b[(ib + st) * NC + i] = v;
-          b.vs[(ib + st) * NC + i] = v + alpha * b.dvs[lt * NC + i];
-        }
-        for (int i = lane; i < NDX; i += NT)
-        {
-          const double v = b.lams[(ib + st) * NDX + i];
-          if (tent)
-            b.lams_b[(ib + st) * NDX + i] = v;
-          b.lams[(ib + st) * NDX + i] = v + alpha * b.dlams[lt * NDX + i];
+            b.xs_b[o] = v;
+          b.xs[o] = v + alpha * b.dxs[((size_t)inst * (H + 1) + t) * NDX + 6 + k];
         }
       }
-      if (tent && t == 0 && lane == 0)
+      // controls and multipliers: ring slot of node t, flat over (t, i)
+      for (int idx = lane; idx < H * NU; idx += NT)
+      {
+        const int t = idx / NU, i = idx % NU;
+        const size_t o = (ib + ring_slot(ka.head, t, R)) * NU + i;
+        if (restore)
+          b.us[o] = b.us_b[o];
+        else
+        {
+          const double v = b.us[o];
+          if (tent)
+            b.us_b[o] = v;
+          b.us[o] = v + alpha * b.dus[((size_t)inst * H + t) * NU + i];
+        }
+      }
+      for (int idx = lane; idx < H * NC; idx += NT)
+      {
+        const int t = idx / NC, i = idx % NC;
+        const size_t o = (ib + ring_slot(ka.head, t, R)) * NC + i;
+        if (restore)
+          b.vs[o] = b.vs_b[o];
+        else
+        {
+          const double v = b.vs[o];
+          if (tent)
+            b.vs_b[o] = v;
+          b.vs[o] = v + alpha * b.dvs[((size_t)inst * H + t) * NC + i];
+        }
+      }
+      for (int idx = lane; idx < H * NDX; idx += NT)
+      {
+        const int t = idx / NDX, i = idx % NDX;
+        const size_t o = (ib + ring_slot(ka.head, t, R)) * NDX + i;
+        if (restore)
+          b.lams[o] = b.lams_b[o];
+        else
+        {
+          const double v = b.lams[o];
+          if (tent)
+            b.lams_b[o] = v;
+          b.lams[o] = v + alpha * b.dlams[((size_t)inst * H + t) * NDX + i];
+        }
+      }
+      if (tent && lane == 0)
       {
         double * sc = b.scal + (size_t)inst * SC_N;
         sc[SC_PREG_OLD] = sc[SC_PREG];
@@ -663,6 +709,7 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
+    static_assert(NQ == NV + 1, "free-flyer state layout");
   }
 
   // =============================================================================================
