@@ -81,6 +81,18 @@ extern "C"
     for (int i = 0; i < 3; i++)
       ks.gravity[i] = ocp->gravity[i];
     ks.kinematics_limits = ocp->kinematics_limits;
+    for (int i = 0; i < nv - 6; i++)
+      if (!(ks.qmin[i] <= ks.qmax[i]))
+        return fail(SMPC_ERR_INVALID, "qmin must not exceed qmax (joint limits are indexed by actuated joint, 0 .. nv - 7)");
+    // the weights enter the Gauss-Newton Hessian as they are: they must be symmetric
+    for (int i = 0; i < ndx; i++)
+      for (int j = 0; j < i; j++)
+        if (std::fabs(ks.w_x[(size_t)i * ndx + j] - ks.w_x[(size_t)j * ndx + i]) > 1e-12 * (1.0 + std::fabs(ks.w_x[(size_t)i * ndx + j])))
+          return fail(SMPC_ERR_INVALID, "w_x must be symmetric");
+    for (int i = 0; i < nu; i++)
+      for (int j = 0; j < i; j++)
+        if (std::fabs(ks.w_u[(size_t)i * nu + j] - ks.w_u[(size_t)j * nu + i]) > 1e-12 * (1.0 + std::fabs(ks.w_u[(size_t)i * nu + j])))
+          return fail(SMPC_ERR_INVALID, "w_u must be symmetric");
     HostMpcSettings ms;
     ms.swing_apex = mpc->swing_apex;
     ms.support_force = mpc->support_force;

@@ -1,0 +1,130 @@
+// C++ host-side test of the drop-in boundary, written like the reference's own tests/mpc.cpp:95-190 (mpc_kinodynamics):
+// build the settings structs, construct the MPC through the header mirror include/simple-mpc/batched-mpc.hpp (which only
+// speaks the C ABI of include/smpc.h), generate the cycle horizon of the reference test, check the container sizes
+// (tests/mpc.cpp:43-44) and the foot-timing known answers (tests/mpc.cpp:78-81, :87-90), iterate, check the outputs.
+// Linked against libsmpc_hip.so on the GPU tier and against the sequential-lane test build on the CPU tier.
+#include "simple-mpc/batched-mpc.hpp"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(cond)                                                                                                    \
+  do                                                                                                                   \
+  {                                                                                                                    \
+    if (!(cond))                                                                                                       \
+    {                                                                                                                  \
+      std::fprintf(stderr, "CHECK failed at line %d: %s\n", __LINE__, #cond);                                          \
+      return 1;                                                                                                        \
+    }                                                                                                                  \
+  } while (0)
+
+using namespace simple_mpc;
+
+int main()
+{
+  const smpc_robot_model * robot = smpc_builtin_robot("go2_like");
+  CHECK(robot != nullptr);
+  const int nv = robot->nv, nq = robot->nq, nf = robot->nfeet;
+  CHECK(nv == 18 && nq == 19 && nf == 4);
+
+  // KinodynamicsSettings of the reference example (examples/go2_kinodynamics.py:42-85)
+  KinodynamicsSettings ks;
+  const int ndx = 2 * nv, nu = nv - 6 + 3 * nf;
+  const double wbp[6] = {0, 0, 100, 10, 10, 0};
+  ks.w_x.assign((size_t)ndx * ndx, 0.0);
+  for (int i = 0; i < 6; i++)
+    ks.w_x[(size_t)i * ndx + i] = wbp[i];
+  for (int i = 6; i < nv; i++)
+    ks.w_x[(size_t)i * ndx + i] = 1.0;
+  for (int i = 0; i < 6; i++)
+    ks.w_x[(size_t)(nv + i) * ndx + nv + i] = 10.0;
+  for (int i = 6; i < nv; i++)
+    ks.w_x[(size_t)(nv + i) * ndx + nv + i] = 0.1;
+  ks.w_u.assign((size_t)nu * nu, 0.0);
+  for (int i = 0; i < nu; i++)
+    ks.w_u[(size_t)i * nu + i] = i < 3 * nf ? 0.01 : 1e-5;
+  ks.w_frame = {2000, 0, 0, 0, 2000, 0, 0, 0, 2000};
+  const double wc[6] = {0, 0, 1, 0.1, 0.1, 10}, wcd[6] = {0, 0, 0, 0.1, 0.1, 0.1};
+  ks.w_cent.assign(36, 0.0);
+  ks.w_centder.assign(36, 0.0);
+  for (int i = 0; i < 6; i++)
+  {
+    ks.w_cent[i * 7] = wc[i];
+    ks.w_centder[i * 7] = wcd[i];
+  }
+  ks.qmin.assign(robot->q_lo, robot->q_lo + (nv - 6)); // joint limits, index = v index - 6
+  ks.qmax.assign(robot->q_hi, robot->q_hi + (nv - 6));
+  ks.kinematics_limits = true;
+  ks.force_size = 3;
+
+  MPCSettings ms; // reference tests/mpc.cpp:112-125
+  ms.max_iters = 1;
+  ms.support_force = robot->total_mass * 9.81;
+  ms.TOL = 1e-6;
+  ms.mu_init = 1e-8;
+  ms.num_threads = 8;
+  ms.swing_apex = 0.1;
+  ms.T_fly = 80;
+  ms.T_contact = 20;
+  ms.T = 100;
+  ms.timestep = 0.01;
+
+  BatchedMPC mpc(robot, ks, ms, /*batch=*/2);
+  CHECK(mpc.horizon() == 100 && mpc.nx() == nq + nv && mpc.nu() == nu);
+
+  // gait of the reference test (tests/mpc.cpp:130-165): feet 0 / 1 carry the left / right patterns, feet 2 / 3 mirror them
+  std::vector<std::map<std::string, bool>> contact_states;
+  auto push = [&](int n, bool left, bool right) {
+    for (int i = 0; i < n; i++)
+      contact_states.push_back({{robot->foot_name[0], left}, {robot->foot_name[1], right}, {robot->foot_name[2], left}, {robot->foot_name[3], right}});
+  };
+  push(10, true, true);
+  push(50, true, false);
+  push(10, true, true);
+  push(50, false, true);
+  mpc.generateCycleHorizon(contact_states);
+  CHECK(mpc.getFootTakeoffCycle(robot->foot_name[0])[0] == 170); // tests/mpc.cpp:78-81
+  CHECK(mpc.getFootTakeoffCycle(robot->foot_name[1])[0] == 110);
+  CHECK(mpc.getFootLandCycle(robot->foot_name[0])[0] == 219);
+  CHECK(mpc.getFootLandCycle(robot->foot_name[1])[0] == 160);
+
+  std::vector<double> X((size_t)2 * mpc.nx(), 0.0);
+  for (int b = 0; b < 2; b++)
+    for (int i = 0; i < nq; i++)
+      X[(size_t)b * mpc.nx() + i] = robot->q_ref[i];
+  mpc.iterate(X);
+  {
+    // standing at the reference posture, all feet in contact: the contact forces carry the weight
+    double fz = 0.0;
+    for (int f = 0; f < nf; f++)
+      fz += mpc.us_[3 * f + 2];
+    CHECK(std::fabs(fz - robot->total_mass * 9.81) < 0.10 * robot->total_mass * 9.81); // (H = 100 cold start stalls at 6 %)
+  }
+  for (int it = 1; it < 10; it++)
+    mpc.iterate(X);
+  CHECK((int)mpc.xs_.size() == 2 * (100 + 1) * mpc.nx()); // xs_.size() == T + 1 per instance (tests/mpc.cpp:43)
+  CHECK((int)mpc.us_.size() == 2 * 100 * mpc.nu());       // us_.size() == T     (tests/mpc.cpp:44)
+  CHECK(mpc.getFootTakeoffCycle(robot->foot_name[0])[0] == 160); // tests/mpc.cpp:87-90
+  CHECK(mpc.getFootTakeoffCycle(robot->foot_name[1])[0] == 100);
+  CHECK(mpc.getFootLandCycle(robot->foot_name[0])[0] == 209);
+  CHECK(mpc.getFootLandCycle(robot->foot_name[1])[0] == 150);
+  for (double v : mpc.xs_)
+    CHECK(std::isfinite(v));
+  // both instances got the same measured state: identical solutions
+  const size_t half = mpc.xs_.size() / 2;
+  for (size_t i = 0; i < half; i++)
+    CHECK(mpc.xs_[i] == mpc.xs_[half + i]);
+  // errors surface as std::runtime_error, as in the reference
+  bool threw = false;
+  try
+  {
+    mpc.iterate(std::vector<double>(3, 0.0));
+  }
+  catch (const std::runtime_error &)
+  {
+    threw = true;
+  }
+  CHECK(threw);
+  std::puts("host mirror KAT: OK");
+  return 0;
+}
