@@ -173,13 +173,15 @@ namespace smpc
   }
 
   // MINW = minimum waves per SIMD the register allocator must leave room for (caps VGPRs at 512 / MINW)
-  template <class Args, void (*Body)(const Args &, int), int NT, int MINW>
+  // TAG gives auxiliary launches (cold start on one instance, list-mode launches of the backtracking path) their own
+  // kernel symbol, so that a profiler's per-kernel average of the TAG = 0 symbol is the full-batch launch only
+  template <class Args, void (*Body)(const Args &, int), int NT, int MINW, int TAG>
   __global__ __launch_bounds__(NT, MINW) void kernel_entry(const Args a)
   {
     Body(a, (int)blockIdx.x);
   }
 
-  template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1>
+  template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1, int TAG = 0>
   inline void launch(int grid, stream_t s, const Args & a)
   {
     if (grid <= 0)
@@ -192,13 +194,13 @@ namespace smpc
       {
         once = true;
         int nb = 0;
-        SMPC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel_entry<Args, Body, NT, MINW>, NT, 0));
+        SMPC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel_entry<Args, Body, NT, MINW, TAG>, NT, 0));
         hipFuncAttributes fa;
-        SMPC_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel_entry<Args, Body, NT, MINW>)));
+        SMPC_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel_entry<Args, Body, NT, MINW, TAG>)));
         std::fprintf(stderr, "[smpc] %s: %d blocks/CU (NT %d, LDS %zu B, %d regs)\n", __PRETTY_FUNCTION__, nb, NT, (size_t)fa.sharedSizeBytes, fa.numRegs);
       }
     }
-    hipLaunchKernelGGL((kernel_entry<Args, Body, NT, MINW>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL((kernel_entry<Args, Body, NT, MINW, TAG>), dim3((unsigned)grid), dim3(NT), 0, s, a);
     SMPC_HIP(hipGetLastError());
   }
 } // namespace smpc

@@ -87,7 +87,7 @@ namespace smpc
   inline void event_record(event_t, stream_t) {}
   inline float event_elapsed_ms(event_t, event_t) { return 0.f; }
 
-  template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1>
+  template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1, int TAG = 0>
   inline void launch(int grid, stream_t, const Args & a)
   {
 #pragma omp parallel for schedule(dynamic)
