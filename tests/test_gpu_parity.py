@@ -86,6 +86,18 @@ def test_dense_weight_matrices(built):
         X = om.xs[:, 1, :].copy()
 
 
+@pytest.mark.parametrize("horizon", [3, 65])
+def test_unusual_horizons(built, horizon):
+    om, gm, rb = S.make_pair(5, max_iters=2, horizon=horizon)
+    X = S.random_states(rb, 5)
+    for _ in range(3):
+        om.iterate(X)
+        gm.iterate(X)
+        assert S.rel_err(om.xs, gm.xs) < TOL
+        assert np.array_equal(om.info[:, 2], gm.info[:, 2])
+        X = om.xs[:, 1, :].copy()
+
+
 def test_stage_knots_match_oracle(built):
     om, gm, rb = S.make_pair(batch=2)
     om.keep_knots()

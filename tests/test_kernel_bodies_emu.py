@@ -52,6 +52,19 @@ def test_closed_loop_parity(lib, iters):
         assert om.timing(f, 1) == gm.foot_land_times[S.FEET[f]]
 
 
+@pytest.mark.parametrize("horizon", [2, 7, 65])
+def test_unusual_horizons(lib, horizon):
+    """Shortest horizon, an odd one, and one with more than 64 nodes (lane = node in the apply kernel)."""
+    om, gm, rb = S.make_pair(2, max_iters=2, lib=lib, horizon=horizon)
+    X = S.random_states(rb, 2)
+    for _ in range(4):
+        om.iterate(X)
+        gm.iterate(X)
+        assert S.rel_err(om.xs, gm.xs) < 1e-7
+        assert np.array_equal(om.info[:, 2], gm.info[:, 2])
+        X = om.xs[:, 1, :].copy()
+
+
 def test_stage_knots_match_oracle(lib):
     om, gm, rb = S.make_pair(2, lib=lib)
     om.keep_knots()
