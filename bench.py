@@ -47,10 +47,13 @@ def rooflines(kt, B, H, ndx, nu, nc, nx):
             pmc = json.load(f).get("kernels", {})
     traffic = lambda k: (pmc.get(k, {}).get("hbm_bytes_per_launch_corrected"), os.path.basename(files[-1]) if pmc else None)
     if "deriv" in kt and kt["deriv"][1]:
-        # algorithmic bytes per (instance, stage): the LQ knot written per iteration (Q S R C, the 12 state-dependent
-        # rows of [A|B] -- the integrator rows are constant and written once --, q r f d lx lu lpd vpd) + the iterate
-        # read (x, u, nu, lam, lam+, centres)
-        per_stage = 8 * (ndx * ndx + ndx * nu + nu * nu + nc * ndx + 12 * (ndx + nu) + 4 * ndx + 2 * nu + 2 * nc
+        # algorithmic bytes per (instance, stage): the state-dependent part of the LQ knot, written per iteration --
+        # Q, the force columns of S, the force block of R + the regularised diagonal, the contact rows of C + the box
+        # selectors, the 12 dense rows of [A|B], q r f d lx lu lpd vpd (integrator rows, zero blocks and constant
+        # weight entries are written once at start-up) -- plus the iterate read (x, u, nu, lam, lam+, centres)
+        nfc = 12                 # 3 * nf force components (Go2: 4 point feet)
+        na = nu - nfc            # actuated joints = box rows
+        per_stage = 8 * (ndx * ndx + ndx * nfc + nfc * nfc + na + (nc - na) * ndx + na + 12 * (ndx + nu) + 4 * ndx + 2 * nu + 2 * nc
                          + nx + nu + 2 * nc + 4 * ndx)
         avg = kt["deriv"][0] / kt["deriv"][1] * 1e-3
         ach = B * H * per_stage / avg / 1e9

@@ -599,42 +599,21 @@ namespace smpc
                 lq[D::O_R + (row - NDX) * NU + col - NDX] = val;
             }
           }
-        // columns / rows of the joint accelerations (u indices >= 16 * 3 - NDX): no Jacobian entries
+        // columns / rows of the joint accelerations (u indices >= UC): no Jacobian entries.  Their S columns (zero)
+        // and the off-diagonal R entries (weights) are constant and written once by lq_init_body; only the diagonal
+        // carries the current primal regularisation
         constexpr int UC = 16 * 3 - NDX; // u columns covered by the tiles
-        for (int idx = lane; idx < NDX * (NU - UC); idx += NT)
-        {
-          const int i = idx / (NU - UC), j = UC + idx % (NU - UC);
-          lq[D::O_S + i * NU + j] = 0.0;
-        }
-        {
-          constexpr int NR = (NU * NU + NT - 1) / NT;
-          double rv[NR]; // batched: a rolled load -> store loop would pay the global latency NR times
-#pragma unroll
-          for (int n = 0; n < NR; n++)
-          {
-            const int idx = lane + n * NT < NU * NU ? lane + n * NT : 0;
-            rv[n] = md.w_diag ? (idx / NU == idx % NU ? md.wud[idx / NU] : 0.0) : mg.w_u[idx];
-          }
-#pragma unroll
-          for (int n = 0; n < NR; n++)
-          {
-            const int idx = lane + n * NT, i = idx / NU, j = idx % NU;
-            if (idx < NU * NU && (i >= UC || j >= UC))
-              lq[D::O_R + idx] = rv[n] + (i == j ? preg : 0.0);
-          }
-        }
+        if (lane >= UC && lane < NU)
+          lq[D::O_R + lane * NU + lane] = (md.w_diag ? md.wud[lane] : mg.w_u[lane * NU + lane]) + preg;
       }
       SMPC_LANES_END_WAVE
     }
     SMPC_LANES(NT)
     {
-      // joint-box rows of C (unit selectors when active; the contact rows are written with the constraint Jacobian
-      // columns), d, vpd
-      for (int idx = lane; idx < NA * NDX; idx += NT)
-      {
-        const int i = idx / NDX, k = idx % NDX;
-        lq[D::O_C + idx] = (sc.act[i] && k == 6 + i) ? 1.0 : 0.0;
-      }
+      // joint-box rows of C: unit selectors when active (the zeros of these rows are written once by lq_init_body, the
+      // contact rows with the constraint Jacobian columns), d, vpd
+      if (lane < NA)
+        lq[D::O_C + lane * NDX + 6 + lane] = sc.act[lane] ? 1.0 : 0.0;
       if (lane < NC)
       {
         lq[D::O_d + lane] = mu * (sc.vplus[lane] - sc.nu[lane]);
@@ -868,6 +847,25 @@ namespace smpc
           v = isA ? ((k == i) ? 1.0 : 0.0) : ((k == 3 * NF + i - NV - 6) ? dt : 0.0);
         lq[(isA ? D::O_A + i * NDX : D::O_B + i * NU) + k] = v;
       }
+    }
+    SMPC_LANES_END_WAVE
+    // blocks without Jacobian entries: S columns and off-diagonal R entries of the joint accelerations, the zeros of the
+    // joint-box rows of C
+    SMPC_LANES(NT)
+    {
+      constexpr int UC = 16 * 3 - NDX, NA = D::NA;
+      const DevModel<D> & mg = *ka.b.model;
+      for (int idx = lane; idx < NDX * NU; idx += NT)
+        if (idx % NU >= UC)
+          lq[D::O_S + idx] = 0.0;
+      for (int idx = lane; idx < NU * NU; idx += NT)
+      {
+        const int i = idx / NU, j = idx % NU;
+        if ((i >= UC || j >= UC) && i != j)
+          lq[D::O_R + idx] = mg.w_u[idx];
+      }
+      for (int idx = lane; idx < NA * NDX; idx += NT)
+        lq[D::O_C + idx] = 0.0;
     }
     SMPC_LANES_END_WAVE
   }
