@@ -48,12 +48,14 @@ def rooflines(kt, B, H, ndx, nu, nc, nx):
     traffic = lambda k: (pmc.get(k, {}).get("hbm_bytes_per_launch_corrected"), os.path.basename(files[-1]) if pmc else None)
     if "deriv" in kt and kt["deriv"][1]:
         # algorithmic bytes per (instance, stage): the state-dependent part of the LQ knot, written per iteration --
-        # Q, the force columns of S, the force block of R + the regularised diagonal, the contact rows of C + the box
+        # the upper tiles of Q, the force columns of S, the force block of R + the regularised diagonal, the contact rows of C + the box
         # selectors, the 12 dense rows of [A|B], q r f d lx lu lpd vpd (integrator rows, zero blocks and constant
         # weight entries are written once at start-up) -- plus the iterate read (x, u, nu, lam, lam+, centres)
         nfc = 12                 # 3 * nf force components (Go2: 4 point feet)
         na = nu - nfc            # actuated joints = box rows
-        per_stage = 8 * (ndx * ndx + ndx * nfc + nfc * nfc + na + (nc - na) * ndx + na + 12 * (ndx + nu) + 4 * ndx + 2 * nu + 2 * nc
+        tl = [min(16, ndx - 16 * i) for i in range((ndx + 15) // 16)]
+        q_upper = sum(tl[i] * tl[j] for i in range(len(tl)) for j in range(i, len(tl)))  # upper 16x16 tiles of Q (912 of 1296)
+        per_stage = 8 * (q_upper + ndx * nfc + nfc * nfc + na + (nc - na) * ndx + na + 12 * (ndx + nu) + 4 * ndx + 2 * nu + 2 * nc
                          + nx + nu + 2 * nc + 4 * ndx)
         avg = kt["deriv"][0] / kt["deriv"][1] * 1e-3
         ach = B * H * per_stage / avg / 1e9

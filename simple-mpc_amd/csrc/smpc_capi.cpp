@@ -254,6 +254,12 @@ extern "C"
       return fail(SMPC_ERR_INVALID, "Stage index exceeds stage vector size");
     return guarded([&] {
       h->eng->get_linear(h->eng->buf.lq + ((size_t)inst * h->eng->H + t) * DimsGo2::LQ_STRIDE, DimsGo2::LQ_STRIDE, out);
+      // the derivative pass writes the upper 16x16 tiles of Q only (its readers take the upper triangle): mirror here
+      constexpr int n = DimsGo2::NDX;
+      double * Q = out + DimsGo2::O_Q;
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+          Q[i * n + j] = Q[j * n + i];
     });
   }
   int smpc_debug_get_steps(smpc_handle * h, double * dxs, double * dus)

@@ -586,9 +586,7 @@ namespace smpc
             {
               if (row < NDX)
               {
-                lq[D::O_Q + row * NDX + col] = val;
-                if (T3I[tt] != T3J[tt])
-                  lq[D::O_Q + col * NDX + row] = val; // off-diagonal tiles: mirror
+                lq[D::O_Q + row * NDX + col] = val; // upper tiles only: every reader takes Q[min(i,j)][max(i,j)] there
               }
             }
             else if (col < NDX + 16 * 3 - NDX && col < NDX + NU)
