@@ -126,9 +126,21 @@ namespace smpc
       const double vl = b.lams[(ib + st) * NDX + (lane < NDX ? lane : 0)];
       const double vlp = b.lams[(ib + sprev) * NDX + (lane < NDX ? lane : 0)];
       const double vn = b.vs[(ib + st) * NC + (lane < NC ? lane : 0)];
+      const double vxt = in.x_tgt[lane < NX ? lane : 0];
+      const double vur = term ? 0.0 : in.u_ref[lane < NU ? lane : 0];
+      const double vfr = term ? 0.0 : in.foot_ref[lane < NF * 3 ? lane : 0];
+      const double vxn = xn_g[lane < NX ? lane : 0];
       lanes_load_model<D, NT>(sc, &mg, lane);
       if (lane < NX)
+      {
         sc.x[lane] = vx;
+        sc.in_x_tgt[lane] = vxt;
+        sc.in_xn[lane] = vxn;
+      }
+      if (lane < NU)
+        sc.in_u_ref[lane] = vur;
+      if (lane < NF * 3)
+        sc.in_foot_ref[lane] = vfr;
       if (lane < NU)
         sc.u[lane] = term ? 0.0 : vu;
       if (lane < NDX)
@@ -147,7 +159,7 @@ namespace smpc
     if (!term)
     {
       SMPC_LANES(NT)
-      lanes_difference<D>(xn_g, sc.xnext, sc.e, lane, 61);
+      lanes_difference<D>(sc.in_xn, sc.xnext, sc.e, lane, 61);
       SMPC_LANES_END_WAVE
     }
     if (in.prof) prof_tick(in.prof, 29, tprev);
@@ -925,23 +937,70 @@ namespace smpc
     const double * dx = b.dxs + ((size_t)inst * (H + 1) + t) * NDX;
     SMPC_LANES(NT)
     {
+      // all global loads of the block back to back (index clamped), then committed to LDS: raw x_t, x_{t+1} and their
+      // steps (the manifold update follows), u, lam, nu at the trial point, the stage inputs
+      static_assert(NX <= NT && NU <= NT && NDX <= NT && NC <= NT, "one element per lane");
+      const int sn = ring_slot(ka.head, term ? t : t + 1, R);
+      const size_t lt = (size_t)inst * H + (term ? 0 : t);
+      const double vx = b.xs[(ib + st) * NX + (lane < NX ? lane : 0)];
+      const double vxn = b.xs[(ib + sn) * NX + (lane < NX ? lane : 0)];
+      const double vdx = dx[lane < NDX ? lane : 0];
+      const double vdxn = dx[(term ? 0 : NDX) + (lane < NDX ? lane : 0)];
+      const double vu = b.us[(ib + st) * NU + (lane < NU ? lane : 0)], vdu = b.dus[lt * NU + (lane < NU ? lane : 0)];
+      const double vl = b.lams[(ib + st) * NDX + (lane < NDX ? lane : 0)], vdl = b.dlams[lt * NDX + (lane < NDX ? lane : 0)];
+      const double vn = b.vs[(ib + st) * NC + (lane < NC ? lane : 0)], vdn = b.dvs[lt * NC + (lane < NC ? lane : 0)];
+      const double vxt = in.x_tgt[lane < NX ? lane : 0];
+      const double vur = term ? 0.0 : in.u_ref[lane < NU ? lane : 0];
+      const double vfr = term ? 0.0 : in.foot_ref[lane < NF * 3 ? lane : 0];
       lanes_load_model<D, NT>(sc, &mg, lane);
-      lanes_integrate<D>(b.xs + (ib + st) * NX, dx, alpha, sc.x, lane, 0);
-      if (!term)
+      if (lane < NX)
       {
-        const int sn = ring_slot(ka.head, t + 1, R);
-        lanes_integrate<D>(b.xs + (ib + sn) * NX, dx + NDX, alpha, sc.xn1, lane, 1);
-        const size_t lt = (size_t)inst * H + t;
-        for (int i = lane; i < NU; i += NT)
-          sc.u[i] = b.us[(ib + st) * NU + i] + alpha * b.dus[lt * NU + i];
-        for (int i = lane; i < NDX; i += NT)
-          sc.lam_next[i] = b.lams[(ib + st) * NDX + i] + alpha * b.dlams[lt * NDX + i];
-        for (int i = lane; i < NC; i += NT)
-          sc.nu[i] = b.vs[(ib + st) * NC + i] + alpha * b.dvs[lt * NC + i];
+        sc.x[lane] = vx;
+        sc.xn1[lane] = vxn;
+        sc.in_x_tgt[lane] = vxt;
       }
-      else
-        for (int i = lane; i < NU; i += NT)
-          sc.u[i] = 0.0;
+      if (lane < NDX)
+      {
+        sc.e[lane] = vdx;   // (temporaries: e and rx are computed later)
+        sc.rx[lane] = vdxn;
+        sc.lam_next[lane] = term ? 0.0 : vl + alpha * vdl;
+      }
+      if (lane < NU)
+      {
+        sc.u[lane] = term ? 0.0 : vu + alpha * vdu;
+        sc.in_u_ref[lane] = vur;
+      }
+      if (lane < NC)
+        sc.nu[lane] = term ? 0.0 : vn + alpha * vdn;
+      if (lane < NF * 3)
+        sc.in_foot_ref[lane] = vfr;
+    }
+    SMPC_LANES_END_WAVE
+    // x_t (+) alpha dx_t and x_{t+1} (+) alpha dx_{t+1} in place: the two SE(3) updates run side by side on lanes 0 / 1
+    SMPC_LANES(NT)
+    {
+      if (lane < 2)
+      {
+        double * x = lane == 0 ? sc.x : sc.xn1;
+        const double * d = lane == 0 ? sc.e : sc.rx;
+        const V3 dv = alpha * ld3(d), dw = alpha * ld3(d + 3);
+        const Quat q0{x[3], x[4], x[5], x[6]};
+        const SE3 E = exp6(dv, dw);
+        st3(x, ld3(x) + quat_to_R(q0) * E.p);
+        Quat qn = quat_mul(q0, quat_exp(dw));
+        const double n = 1.0 / sqrt(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+        x[3] = qn.x * n;
+        x[4] = qn.y * n;
+        x[5] = qn.z * n;
+        x[6] = qn.w * n;
+      }
+      else if (lane >= 6 && lane < 2 * NV)
+      {
+        // linear entries: tangent index i <-> x[i + 1] (joints) or x[NQ + i - NV] (velocities)
+        const int i = lane, o = i < NV ? i + 1 : D::NQ + i - NV;
+        sc.x[o] += alpha * sc.e[i];
+        sc.xn1[o] += alpha * sc.rx[i];
+      }
     }
     SMPC_LANES_END_WAVE
 

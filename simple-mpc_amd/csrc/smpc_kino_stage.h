@@ -27,6 +27,8 @@ namespace smpc
   {
     DevModelSmall<D> ml; // model constants (copied from global memory once per block)
     double x[D::NX], u[D::NU];
+    // stage inputs fetched with the block's other global loads, so that no later phase waits on global memory
+    double in_x_tgt[D::NX], in_u_ref[D::NU], in_foot_ref[D::NF * 3], in_xn[D::NX]; // x target, u reference, foot refs, x_{t+1}
     // tree block A (contiguous, 667 doubles): dead once the derivative columns and the constraint values are formed;
     // reused -- in this order of time -- by the wave reductions of the cost / multiplier phases and by the
     // weighted-Jacobian tables of the assembly phases (accessors below)
@@ -95,9 +97,9 @@ namespace smpc
   {
     const DevModel<D> * md;
     unsigned mask;
-    const double * u_ref;    // NU (global)
-    const double * x_tgt;    // NX (global)
-    const double * foot_ref; // NF*3 (global)
+    const double * u_ref;    // NU (global)   -- these three are read once, by the caller's load phase, into the
+    const double * x_tgt;    // NX (global)      scratch copies in_u_ref / in_x_tgt / in_foot_ref that the stage
+    const double * foot_ref; // NF*3 (global)    functions use
     double * C_rows = nullptr; // derivative pass: contact rows of the knot's C block (global, [3 NF][NDX])
     bool terminal;
     double * prof = nullptr; // optional phase timers (null = off)
@@ -139,7 +141,7 @@ namespace smpc
     }
     else
     {
-      const double * xt = in.x_tgt;
+      const double * xt = sc.in_x_tgt; // (LDS copy made by the block's load phase)
       const SE3 Mt{quat_to_R(Quat{xt[3], xt[4], xt[5], xt[6]}), ld3(xt)};
       const SE3 M = se3_mul(se3_inv(Mt), SE3{ldm3(&sc.oR[0]), ld3(&sc.op[0])});
       w = log3(M.R);
@@ -830,15 +832,15 @@ namespace smpc
     (void)mg;
     SMPC_LANES(NT)
     {
-      kino_state_residual<D, DERIV>(sc, in.x_tgt, lane);
+      kino_state_residual<D, DERIV>(sc, sc.in_x_tgt, lane);
       if (!in.terminal)
       {
         if (lane >= 32 && lane < 32 + NU)
-          sc.ru[lane - 32] = sc.u[lane - 32] - in.u_ref[lane - 32];
+          sc.ru[lane - 32] = sc.u[lane - 32] - sc.in_u_ref[lane - 32];
         if (lane >= 20 && lane < 20 + NF * 3)
         {
           const int i = lane - 20;
-          sc.rf[i] = sc.footp[i] - in.foot_ref[i];
+          sc.rf[i] = sc.footp[i] - sc.in_foot_ref[i];
         }
         // constraint values
         if (lane < NA)
