@@ -177,6 +177,17 @@ int smpc_friction_compensation(
   const double * dry, const double * viscous, int nu, const double * velocity, int velocity_size, double * torque, int torque_size,
   int batch, int device_id);
 
+/* ---- centroidal model (replaces CentroidalFwdDynamics + IntegratorEuler as composed in
+ *      reference src/centroidal-dynamics.cpp:79-81; the centroidal state itself comes from smpc_update_internal_data) ----
+ * Batched forward step with derivatives, 3-D contact forces:
+ *     x = [c; h; L] (CoM, linear momentum, angular momentum about the CoM),  u = [f_1 .. f_nfeet]
+ *     xdot = [h / m ;  m g + sum_{contact} f_i ;  sum_{contact} (p_i - c) x f_i],   Xnext = x + timestep * xdot
+ *     A = d Xnext / dx  [B][9][9],   B = d Xnext / du  [B][9][3 nfeet]   (row-major; columns of feet in the air are zero)
+ * X [B][9], U [B][3 nfeet], contact [B][nfeet] (0 / 1), contact_pos [B][nfeet][3]; host buffers; A and B may be NULL. */
+int smpc_centroidal_dynamics(
+  double mass, const double * gravity, double timestep, int nfeet, const double * X, const double * U, const unsigned char * contact,
+  const double * contact_pos, int batch, double * Xnext, double * A, double * B, int device_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -463,6 +463,55 @@ extern "C"
         torque[(size_t)b * nu + j] += viscous[j] * v + dry[j] * (double)((v > 0) - (v < 0));
       }
   }
+  // CentroidalFwdDynamics + IntegratorEuler (reference src/centroidal-dynamics.cpp:79-81), 3-D forces:
+  //   x = [c; h; L],  xdot = [h / m ; m g + sum_contact f_i ; sum_contact (p_i - c) x f_i],  x+ = x + dt xdot
+  //   A = I + dt d(xdot)/dx,  B = dt d(xdot)/du   (row-major 9x9, 9x(3 nf); columns of feet in the air are zero)
+  void orc_centroidal_dynamics(
+    double mass, const double * gravity, double dt, int nf, const double * x, const double * u, const unsigned char * contact,
+    const double * pos, double * xnext, double * A, double * B)
+  {
+    const int nu = 3 * nf;
+    double xd[9];
+    for (int i = 0; i < 3; i++)
+    {
+      xd[i] = x[3 + i] / mass;
+      xd[3 + i] = mass * gravity[i];
+      xd[6 + i] = 0.0;
+    }
+    for (int i = 0; i < 81; i++)
+      A[i] = 0.0;
+    for (int i = 0; i < 9 * nu; i++)
+      B[i] = 0.0;
+    for (int i = 0; i < 9; i++)
+      A[i * 9 + i] = 1.0;
+    for (int i = 0; i < 3; i++)
+      A[i * 9 + 3 + i] = dt / mass;
+    for (int f = 0; f < nf; f++)
+    {
+      if (!contact[f])
+        continue;
+      const double * F = u + 3 * f;
+      const double r[3] = {pos[3 * f] - x[0], pos[3 * f + 1] - x[1], pos[3 * f + 2] - x[2]};
+      for (int i = 0; i < 3; i++)
+        xd[3 + i] += F[i];
+      xd[6] += r[1] * F[2] - r[2] * F[1];
+      xd[7] += r[2] * F[0] - r[0] * F[2];
+      xd[8] += r[0] * F[1] - r[1] * F[0];
+      // d(r x F)/dc = -d(r x F)/dr = [F]x ;  d(r x F)/dF = [r]x
+      const double Fx[9] = {0, -F[2], F[1], F[2], 0, -F[0], -F[1], F[0], 0};
+      const double rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+        {
+          A[(6 + i) * 9 + j] += dt * Fx[i * 3 + j];
+          B[(6 + i) * nu + 3 * f + j] = dt * rx[i * 3 + j];
+        }
+      for (int i = 0; i < 3; i++)
+        B[(3 + i) * nu + 3 * f + i] = dt;
+    }
+    for (int i = 0; i < 9; i++)
+      xnext[i] = x[i] + dt * xd[i];
+  }
   int orc_num_threads()
   {
 #ifdef _OPENMP

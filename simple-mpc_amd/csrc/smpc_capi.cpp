@@ -390,4 +390,49 @@ extern "C"
       stream_destroy(st);
     });
   }
+  int smpc_centroidal_dynamics(
+    double mass, const double * gravity, double timestep, int nfeet, const double * X, const double * U, const unsigned char * contact,
+    const double * contact_pos, int batch, double * Xnext, double * A, double * B, int device_id)
+  {
+    if (!gravity || !X || !U || !contact || !contact_pos || !Xnext || nfeet < 1 || batch < 1 || !(mass > 0.0) || !(timestep > 0.0))
+      return fail(SMPC_ERR_INVALID, "invalid argument");
+    if (device_count() <= 0)
+      return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the centroidal dynamics has no CPU path");
+    return guarded([&] {
+      set_device(device_id);
+      stream_t st = stream_create();
+      const size_t nu = 3 * (size_t)nfeet, nb = (size_t)batch;
+      const size_t n_in = nb * 9 + nb * nu + nb * nfeet * 3, n_out = nb * 9 + nb * 81 + nb * 9 * nu;
+      double * d = (double *)dev_alloc((n_in + n_out) * sizeof(double) + nb * nfeet);
+      double *dX = d, *dU = dX + nb * 9, *dP = dU + nb * nu, *dXn = dP + nb * nfeet * 3, *dA = dXn + nb * 9, *dB = dA + nb * 81;
+      unsigned char * dC = reinterpret_cast<unsigned char *>(dB + nb * 9 * nu);
+      h2d(dX, X, nb * 9 * sizeof(double), st);
+      h2d(dU, U, nb * nu * sizeof(double), st);
+      h2d(dP, contact_pos, nb * nfeet * 3 * sizeof(double), st);
+      h2d(dC, contact, nb * nfeet, st);
+      CentroidalArgs ca;
+      ca.mass = mass;
+      ca.dt = timestep;
+      for (int i = 0; i < 3; i++)
+        ca.g[i] = gravity[i];
+      ca.nf = nfeet;
+      ca.batch = batch;
+      ca.X = dX;
+      ca.U = dU;
+      ca.pos = dP;
+      ca.contact = dC;
+      ca.Xn = dXn;
+      ca.A = A ? dA : nullptr;
+      ca.Bm = B ? dB : nullptr;
+      launch<CentroidalArgs, centroidal_body, 64>((batch + 63) / 64, st, ca);
+      d2h(Xnext, dXn, nb * 9 * sizeof(double), st);
+      if (A)
+        d2h(A, dA, nb * 81 * sizeof(double), st);
+      if (B)
+        d2h(B, dB, nb * 9 * nu * sizeof(double), st);
+      stream_sync(st);
+      dev_free(d);
+      stream_destroy(st);
+    });
+  }
 }

@@ -942,6 +942,90 @@ namespace smpc
     SMPC_LANES_END
   }
 
+  // CentroidalFwdDynamics + IntegratorEuler with derivatives (reference src/centroidal-dynamics.cpp:79-81; SURVEY 8a row
+  // a6, App. B.1), batched: lane = instance (the model is 9-dimensional: one instance per lane is the wide mapping).
+  struct CentroidalArgs
+  {
+    double mass, dt, g[3];
+    int nf, batch;
+    const double *X, *U, *pos;       // [B][9], [B][3 nf], [B][nf][3] (device)
+    const unsigned char * contact;   // [B][nf] (device)
+    double *Xn, *A, *Bm;             // [B][9], [B][81], [B][9][3 nf] (device); A / Bm may be null
+  };
+  SMPC_DEV void centroidal_body(const CentroidalArgs & ka, int block)
+  {
+    constexpr int NT = 64;
+    SMPC_LANES(NT)
+    {
+      const int inst = block * NT + lane;
+      if (inst < ka.batch)
+      {
+        const int nf = ka.nf, nu = 3 * nf;
+        const double * x = ka.X + (size_t)inst * 9;
+        const double * u = ka.U + (size_t)inst * nu;
+        const double dt = ka.dt, im = 1.0 / ka.mass;
+        double hd[3] = {ka.mass * ka.g[0], ka.mass * ka.g[1], ka.mass * ka.g[2]}, Ld[3] = {0, 0, 0};
+        double * A = ka.A ? ka.A + (size_t)inst * 81 : nullptr;
+        double * Bm = ka.Bm ? ka.Bm + (size_t)inst * 9 * nu : nullptr;
+        if (A)
+        {
+          for (int i = 0; i < 81; i++)
+            A[i] = 0.0;
+          for (int i = 0; i < 9; i++)
+            A[i * 9 + i] = 1.0;
+          for (int i = 0; i < 3; i++)
+            A[i * 9 + 3 + i] = dt * im;
+        }
+        if (Bm)
+          for (int i = 0; i < 9 * nu; i++)
+            Bm[i] = 0.0;
+        for (int f = 0; f < nf; f++)
+        {
+          if (!ka.contact[(size_t)inst * nf + f])
+            continue;
+          const double * F = u + 3 * f;
+          const double * p = ka.pos + ((size_t)inst * nf + f) * 3;
+          const double r[3] = {p[0] - x[0], p[1] - x[1], p[2] - x[2]};
+          for (int i = 0; i < 3; i++)
+            hd[i] += F[i];
+          Ld[0] += r[1] * F[2] - r[2] * F[1];
+          Ld[1] += r[2] * F[0] - r[0] * F[2];
+          Ld[2] += r[0] * F[1] - r[1] * F[0];
+          if (A)
+          {
+            // d(r x F)/dc = [F]x
+            A[6 * 9 + 1] += -dt * F[2];
+            A[6 * 9 + 2] += dt * F[1];
+            A[7 * 9 + 0] += dt * F[2];
+            A[7 * 9 + 2] += -dt * F[0];
+            A[8 * 9 + 0] += -dt * F[1];
+            A[8 * 9 + 1] += dt * F[0];
+          }
+          if (Bm)
+          {
+            for (int i = 0; i < 3; i++)
+              Bm[(3 + i) * nu + 3 * f + i] = dt;
+            // d(r x F)/dF = [r]x
+            Bm[6 * nu + 3 * f + 1] = -dt * r[2];
+            Bm[6 * nu + 3 * f + 2] = dt * r[1];
+            Bm[7 * nu + 3 * f + 0] = dt * r[2];
+            Bm[7 * nu + 3 * f + 2] = -dt * r[0];
+            Bm[8 * nu + 3 * f + 0] = -dt * r[1];
+            Bm[8 * nu + 3 * f + 1] = dt * r[0];
+          }
+        }
+        double * xn = ka.Xn + (size_t)inst * 9;
+        for (int i = 0; i < 3; i++)
+        {
+          xn[i] = x[i] + dt * x[3 + i] * im;
+          xn[3 + i] = x[3 + i] + dt * hd[i];
+          xn[6 + i] = x[6 + i] + dt * Ld[i];
+        }
+      }
+    }
+    SMPC_LANES_END
+  }
+
   // torque += viscous * v + dry * sign(v), elementwise over [B][nu] (reference src/friction-compensation.cpp:22-37)
   struct FrictionArgs
   {

@@ -17,7 +17,7 @@ import numpy as np
 from . import _capi
 from ._capi import KinodynamicsSettingsC, MpcSettingsC, SmpcLib, default_lib
 
-__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "MPC", "BatchedMPC", "Interpolator", "FrictionCompensation"]
+__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "MPC", "BatchedMPC", "Interpolator", "FrictionCompensation", "centroidal_dynamics"]
 
 
 def load_robot(name, lib=None):
@@ -491,3 +491,21 @@ class FrictionCompensation:
         self._lib.check(self._lib.L.smpc_friction_compensation(
             self.dry_friction_, self.viscuous_friction_, self.nu_, v, v.shape[-1], torque, torque.shape[-1], batch, self._dev))
         return torque
+
+
+def centroidal_dynamics(mass, gravity, timestep, X, U, contact, contact_pos, lib=None, device_id=0):
+    """CentroidalFwdDynamics + IntegratorEuler with derivatives for a batch (reference src/centroidal-dynamics.cpp:79-81):
+    X[B, 9] = [com; linear momentum; angular momentum], U[B, 3 nf] contact forces, contact[B, nf] flags,
+    contact_pos[B, nf, 3] -> (Xnext[B, 9], A[B, 9, 9], B[B, 9, 3 nf])."""
+    lib = lib or default_lib()
+    X = np.ascontiguousarray(np.array(X, dtype=np.float64))
+    U = np.ascontiguousarray(np.array(U, dtype=np.float64))
+    cs = np.ascontiguousarray(np.array(contact, dtype=np.uint8))
+    pos = np.ascontiguousarray(np.array(contact_pos, dtype=np.float64))
+    Bn, nf = cs.shape
+    if X.shape != (Bn, 9) or U.shape != (Bn, 3 * nf) or pos.shape != (Bn, nf, 3):
+        raise RuntimeError("force size in settings does not match reference force size")
+    Xn, A, Bm = np.zeros((Bn, 9)), np.zeros((Bn, 9, 9)), np.zeros((Bn, 9, 3 * nf))
+    lib.check(lib.L.smpc_centroidal_dynamics(float(mass), np.ascontiguousarray(gravity, dtype=np.float64), float(timestep), nf,
+                                             X, U, cs, pos, Bn, Xn, A, Bm, device_id))
+    return Xn, A, Bm

@@ -90,6 +90,7 @@ def lib():
     L.orc_mpc_cold_trace.argtypes = [vp, _dp]
     L.orc_mpc_timing.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
     L.orc_num_threads.restype = C.c_int
+    L.orc_centroidal_dynamics.argtypes = [C.c_double, _dp, C.c_double, C.c_int, _dp, _dp, _bp, _dp, _dp, _dp, _dp]
     L.orc_friction.argtypes = [_dp, _dp, C.c_int, _dp, _dp, C.c_int]
     L.orc_interpolate.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int, _dp]
     _lib = L
@@ -360,3 +361,13 @@ def interpolate(kind, nv, delay, timestep, knots):
     out = np.zeros(k.shape[1])
     lib().orc_interpolate(kind, nv, float(delay), float(timestep), k, k.shape[0], k.shape[1], out)
     return out
+
+
+def centroidal_dynamics(mass, gravity, dt, x, u, contact, pos):
+    """Oracle: CentroidalFwdDynamics + IntegratorEuler for one instance -> (xnext[9], A[9,9], B[9,3nf])."""
+    nf = len(contact)
+    xn, A, B = np.zeros(9), np.zeros((9, 9)), np.zeros((9, 3 * nf))
+    lib().orc_centroidal_dynamics(float(mass), np.ascontiguousarray(gravity, float), float(dt), nf, np.ascontiguousarray(x, float),
+                                  np.ascontiguousarray(u, float), np.ascontiguousarray(contact, np.uint8),
+                                  np.ascontiguousarray(pos, float), xn, A, B)
+    return xn, A, B
