@@ -166,6 +166,10 @@ int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, d
  *      X [B][nx] (host): feet [B][nf][3] foot positions (world), com [B][3], hg [B][6] centroidal momentum
  *      [linear; angular about the CoM], centroidal_state [B][9] = [com; h_lin; h_ang].  Any output may be NULL. */
 int smpc_update_internal_data(smpc_handle * h, const double * X, double * feet, double * com, double * hg, double * centroidal_state);
+/* Riccati feedback application between MPC knots (reference examples/go2_fulldynamics.py:271-285):
+ *   u_out[b] = interpolateLinear(us)[b] - Ks[0][b] * difference(X_meas[b], interpolateState(xs)[b])
+ * X_meas [B][nx], u_out [B][nu] (host). */
+int smpc_riccati_feedback(smpc_handle * h, double delay, const double * X_meas, double * u_out);
 int smpc_interpolate_knots(int kind, double delay, double timestep, const double * knots, int n, int dim, double * out, int device_id);
 
 /* ---- friction compensation (replaces FrictionCompensation::computeFriction, reference

@@ -319,6 +319,12 @@ extern "C"
       return fail(SMPC_ERR_INVALID, "null argument");
     return guarded([&] { h->eng->update_internal_data(X, feet, com, hg, centroidal_state); });
   }
+  int smpc_riccati_feedback(smpc_handle * h, double delay, const double * X_meas, double * u_out)
+  {
+    if (!h || !X_meas || !u_out)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { h->eng->riccati_feedback(delay, X_meas, u_out); });
+  }
   int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, double * acc_out, double * force_out)
   {
     if (!h)

@@ -699,6 +699,45 @@ namespace smpc
       launch<GatherArgs<D>, gather_x_body<D>, 256>((int)(((size_t)B * D::NX + 255) / 256), stream, ga);
     }
 
+    // u = u_interp - K_0 (x_interp (-) x_meas) at `delay` after the last solve, for measured states X [B][NX] (host)
+    void riccati_feedback(double delay, const double * X, double * u_out)
+    {
+      if (!structured_riccati)
+        throw std::runtime_error("riccati_feedback needs the structured Riccati sweep (unset SMPC_RICCATI)");
+      if (!(delay >= 0.0))
+        throw std::runtime_error("riccati_feedback: delay must be non-negative");
+      const size_t nx = (size_t)B * D::NX, nu = (size_t)B * D::NU, nk = (size_t)B * D::NU * D::NDX;
+      double * st = staging((nx + 2 * nu + nk) * sizeof(double));
+      double *xi = st, *ui = st + nx, *uo = ui + nu, *k0 = uo + nu;
+      h2d(X_dev, X, nx * sizeof(double), stream);
+      InterpArgs<D> ia;
+      ia.b = buf;
+      ia.head = head;
+      ia.knots = 2;
+      ia.delay = delay;
+      ia.timestep = ms.timestep;
+      ia.x_out = xi;
+      ia.acc_out = nullptr;
+      ia.f_out = nullptr;
+      ia.u_out = ui;
+      launch<InterpArgs<D>, interp_body<D>, 64>(B, stream, ia);
+      GainOutArgs<D> ga;
+      ga.b = buf;
+      ga.nt = 1;
+      ga.out = k0;
+      launch<GainOutArgs<D>, gains_out_body<D>, 64>(B, stream, ga);
+      FeedbackArgs<D> fa;
+      fa.b = buf;
+      fa.X_meas = X_dev;
+      fa.x_interp = xi;
+      fa.u_interp = ui;
+      fa.K0 = k0;
+      fa.u_out = uo;
+      launch<FeedbackArgs<D>, feedback_body<D>, 64>(B, stream, fa);
+      d2h(u_out, uo, nu * sizeof(double), stream);
+      stream_sync(stream);
+    }
+
     // state feedback front-end on measured states X [B][NX] (host): host outputs, any may be null
     void update_internal_data(const double * X, double * feet, double * com, double * hg, double * cstate)
     {

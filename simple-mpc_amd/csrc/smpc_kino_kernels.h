@@ -717,6 +717,7 @@ namespace smpc
     int head, knots;
     double delay, timestep;
     double *x_out, *acc_out, *f_out; // device, any may be null
+    double * u_out = nullptr;        // [B][NU] interpolateLinear over us[0], us[1] (device, may be null)
   };
   template <class D>
   SMPC_DEV void interp_body(const InterpArgs<D> & ka, int block)
@@ -768,6 +769,40 @@ namespace smpc
       }
       if (ka.f_out != nullptr && lane < 3 * NF)
         ka.f_out[(size_t)inst * 3 * NF + lane] = u1[lane] * w1 + u0[lane] * w0;
+      if (ka.u_out != nullptr && lane < NU)
+        ka.u_out[(size_t)inst * NU + lane] = u1[lane] * w1 + u0[lane] * w0;
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // Riccati feedback application (reference examples/go2_fulldynamics.py:283-285):
+  //   u = u_interp - K_0 (x_interp (-) x_meas),   x_interp / u_interp from interp_body, K_0 the first-stage feedback gain
+  template <class D>
+  struct FeedbackArgs
+  {
+    Buffers<D> b;
+    const double *X_meas, *x_interp, *u_interp; // [B][NX], [B][NX], [B][NU] (device)
+    const double * K0;                          // [B][NU][NDX] (device)
+    double * u_out;                             // [B][NU] (device)
+  };
+  template <class D>
+  SMPC_DEV void feedback_body(const FeedbackArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NX = D::NX, NDX = D::NDX, NU = D::NU;
+    const int inst = block;
+    SMPC_LDS(double, e, D::NDX);
+    SMPC_LANES(NT)
+    lanes_difference<D>(ka.X_meas + (size_t)inst * NX, ka.x_interp + (size_t)inst * NX, e, lane, 0); // x_interp (-) x_meas
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane < NU)
+    {
+      const double * Kr = ka.K0 + ((size_t)inst * NU + lane) * NDX;
+      double acc = ka.u_interp[(size_t)inst * NU + lane];
+      for (int j = 0; j < NDX; j++)
+        acc -= Kr[j] * e[j];
+      ka.u_out[(size_t)inst * NU + lane] = acc;
     }
     SMPC_LANES_END_WAVE
   }

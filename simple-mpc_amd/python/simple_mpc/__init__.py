@@ -321,6 +321,16 @@ class BatchedMPC:
         self._lib.check(self._lib.L.smpc_update_internal_data(self._h, X, p(feet), p(com), p(hg), p(cs)))
         return dict(feet=feet, com=com, hg=hg, centroidal_state=cs)
 
+    def riccatiFeedback(self, delay, X_meas):
+        """u = interpolateLinear(us) - Ks[0] @ difference(x_meas, interpolateState(xs)) for every instance (reference
+        examples/go2_fulldynamics.py:271-285)."""
+        X = np.ascontiguousarray(np.array(X_meas, dtype=np.float64))
+        if X.shape != (self.B, self.nx):
+            raise RuntimeError("X_meas must have shape (batch, nx)")
+        u = np.zeros((self.B, self.nu))
+        self._lib.check(self._lib.L.smpc_riccati_feedback(self._h, float(delay), X, u))
+        return u
+
     def interpolate(self, delay, knots=2):
         """Targets between MPC knots for the whole-body controller, batched on the device (reference
         examples/go2_kinodynamics.py:276-284 with src/interpolator.cpp:5-78): returns (x[B, nx], acc[B, nv],

@@ -85,6 +85,17 @@ def _check_batched_targets(lib):
             assert np.abs(x[b] - O.interpolate(0, rb.nv, delay, DT, [xs[b, 0], xs[b, 1]])).max() < 1e-12
             assert np.abs(a[b] - O.interpolate(2, rb.nv, delay, DT, acc)).max() < 1e-12
             assert np.abs(f[b].ravel() - O.interpolate(2, rb.nv, delay, DT, [us[b, 0, :nf3], us[b, 1, :nf3]])).max() < 1e-12
+    # Riccati feedback between knots (reference examples/go2_fulldynamics.py:271-285)
+    Xm = xs[:, 0, :] + 0.0
+    Xm[:, 7:] += np.random.default_rng(3).normal(0, 1e-2, Xm[:, 7:].shape)
+    K0 = gm.K0
+    for delay in (0.0, 0.006):
+        ufb = gm.riccatiFeedback(delay, Xm)
+        for b in range(B):
+            xi = O.interpolate(0, rb.nv, delay, DT, [xs[b, 0], xs[b, 1]])
+            ui = O.interpolate(2, rb.nv, delay, DT, [us[b, 0], us[b, 1]])
+            ref = ui - K0[b] @ rb.difference(Xm[b], xi)
+            assert np.abs(ufb[b] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
     # more knots: anywhere along the horizon
     x, _, _ = gm.interpolate(0.237, knots=gm.H + 1)
     assert np.abs(x[1] - O.interpolate(0, rb.nv, 0.237, DT, list(xs[1]))).max() < 1e-12
