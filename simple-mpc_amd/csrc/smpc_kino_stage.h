@@ -436,74 +436,38 @@ namespace smpc
         st3(&sc.hd[0], fl);
         st3(&sc.hd[3], fa);
       }
-      else if (lane == 34)
-      {
-        // dense 6x6 of the composite inertia Ic0 (about the world origin), for Gauss-Jordan
-        const double m = I0.m;
-        const V3 c = I0.mc;
-        double * A = sc.gjA_();
-        for (int i = 0; i < 36; i++)
-          A[i] = 0.0;
-        A[0] = A[7] = A[14] = m;
-        // top-right = -[mc]x ; bottom-left = [mc]x
-        A[0 * 6 + 4] = c.z;
-        A[0 * 6 + 5] = -c.y;
-        A[1 * 6 + 3] = -c.z;
-        A[1 * 6 + 5] = c.x;
-        A[2 * 6 + 3] = c.y;
-        A[2 * 6 + 4] = -c.x;
-        A[3 * 6 + 1] = -c.z;
-        A[3 * 6 + 2] = c.y;
-        A[4 * 6 + 0] = c.z;
-        A[4 * 6 + 2] = -c.x;
-        A[5 * 6 + 0] = -c.y;
-        A[5 * 6 + 1] = c.x;
-        A[3 * 6 + 3] = I0.jxx;
-        A[3 * 6 + 4] = A[4 * 6 + 3] = I0.jxy;
-        A[3 * 6 + 5] = A[5 * 6 + 3] = I0.jxz;
-        A[4 * 6 + 4] = I0.jyy;
-        A[4 * 6 + 5] = A[5 * 6 + 4] = I0.jyz;
-        A[5 * 6 + 5] = I0.jzz;
-      }
     if (in.prof) prof_tick(in.prof, 20, *in.tprev);
     }
     SMPC_LANES_END_WAVE
     if constexpr (KIN_ONLY)
       return;
-    // ---- in-place Gauss-Jordan inverse of the SPD 6x6 (36 lanes, ping-pong gjA <-> gjB) ----
-    for (int pv = 0; pv < 6; pv++)
-    {
-      const double * src = (pv & 1) ? sc.gjB_() : sc.gjA_();
-      double * dst = (pv & 1) ? sc.gjA_() : sc.gjB_();
-      SMPC_LANES(NT)
-      if (lane < 36)
-      {
-        const int r = lane / 6, c = lane % 6;
-        const double piv = 1.0 / src[pv * 6 + pv];
-        double val;
-        if (r == pv)
-          val = (c == pv) ? piv : src[pv * 6 + c] * piv;
-        else
-          val = (c == pv) ? -src[r * 6 + pv] * piv : src[r * 6 + c] - src[r * 6 + pv] * src[pv * 6 + c] * piv;
-        dst[lane] = val;
-      }
-      SMPC_LANES_END_WAVE
-    }
-    if (in.prof) prof_tick(in.prof, 21, *in.tprev);
-    // after 6 steps the inverse sits in gjA.  M1 = Ic0^-1 * T(c)^-1  with T^-1 = [[I,0],[[c]x, I]]
+    // ---- M1 = Ic0^-1 T(c)^-1 in closed form.  It maps the centroidal momentum [m v_c; Jc w] to the base twist at the
+    //      world origin [v_c + c x w; w]:   M1 = [[I/m, [c]x Jc^-1], [0, Jc^-1]],  Jc = J_o - m (|c|^2 I - c c^T) the
+    //      composite rotational inertia about the CoM (3x3 SPD, inverted by its adjugate; every lane does it itself:
+    //      one phase instead of six Gauss-Jordan sweeps with an LDS round trip and a division each) ----
     SMPC_LANES(NT)
     if (lane < 36)
     {
       const int r = lane / 6, c = lane % 6;
-      const double * Ii = sc.gjA_();
-      double val = Ii[r * 6 + c];
+      const SI I0 = ldsi(&sc.Ic[0]);
+      const double im = 1.0 / I0.m;
+      const V3 cm = im * I0.mc;
+      const double cc = dot(cm, cm);
+      const double jxx = I0.jxx - I0.m * (cc - cm.x * cm.x), jyy = I0.jyy - I0.m * (cc - cm.y * cm.y), jzz = I0.jzz - I0.m * (cc - cm.z * cm.z);
+      const double jxy = I0.jxy + I0.m * cm.x * cm.y, jxz = I0.jxz + I0.m * cm.x * cm.z, jyz = I0.jyz + I0.m * cm.y * cm.z;
+      // adjugate of the symmetric 3x3
+      const double a00 = jyy * jzz - jyz * jyz, a01 = jxz * jyz - jxy * jzz, a02 = jxy * jyz - jxz * jyy;
+      const double a11 = jxx * jzz - jxz * jxz, a12 = jxy * jxz - jxx * jyz, a22 = jxx * jyy - jxy * jxy;
+      const double idet = 1.0 / (jxx * a00 + jxy * a01 + jxz * a02);
+      const M3 Ji = M3{a00 * idet, a01 * idet, a02 * idet, a01 * idet, a11 * idet, a12 * idet, a02 * idet, a12 * idet, a22 * idet};
+      double val;
       if (c < 3)
+        val = (r == c) ? im : 0.0;
+      else
       {
-        const V3 cm = ld3(sc.com);
-        // column c of [c]x : [c]x e_c = c x e_c
-        const V3 e = mk3(c == 0, c == 1, c == 2);
-        const V3 col = cross(cm, e);
-        val += Ii[r * 6 + 3] * col.x + Ii[r * 6 + 4] * col.y + Ii[r * 6 + 5] * col.z;
+        const V3 jc = c == 3 ? mk3(Ji.a00, Ji.a10, Ji.a20) : (c == 4 ? mk3(Ji.a01, Ji.a11, Ji.a21) : mk3(Ji.a02, Ji.a12, Ji.a22));
+        const V3 top = cross(cm, jc); // column c - 3 of [c]x Jc^-1
+        val = r == 0 ? top.x : (r == 1 ? top.y : (r == 2 ? top.z : (r == 3 ? jc.x : (r == 4 ? jc.y : jc.z))));
       }
       sc.gjB_()[lane] = val;
     if (in.prof) prof_tick(in.prof, 22, *in.tprev);
