@@ -134,7 +134,7 @@ namespace smpc
     std::vector<double> cold_trace; // [n][4] phi0, prim, dual, alpha
     // profiling
     bool profiling = false;
-    static constexpr int LS_SLOTS = 256; // instance slots of the backtracking trial launch
+    static constexpr int LS_SLOTS = 64; // instance slots of the list-mode (backtracking) launches: 64 x (H+1) blocks when the list is empty
     bool speculative_ls = std::getenv("SMPC_NO_SPECULATIVE_LS") == nullptr; // tentative full steps (run_iterations)
     bool aux_launches = false; // true during the cold start: every launch uses the auxiliary kernel symbols
     double kernel_ms[KID_N] = {0};
