@@ -60,17 +60,44 @@ namespace smpc
   // block holds the Schur complement T_jj' - T_jS T_SS^-1 T_Sj'.  ALL = false maintains only the tiles at or beyond
   // the current pivot's tile row (Schur complement of leading pivots: what a Cholesky-based elimination would give).
   // prow / urow: LDS, 4 x 16 NTI doubles each.  prof: optional phase timers (slots 36..39).
+  // scheduling class of tile (I, J) in panel p of a sweep: 0 = not maintained any more, 1 = must be updated before the
+  // next panel's pivot entries are gathered (or is rewritten by this panel's fix-up), 2 = can be updated later
+  template <int NTI, bool ALL, int PIV0, int NP>
+  SMPC_HD constexpr int sweep_tile_class(int p, int I, int J)
+  {
+    const int kb = PIV0 + 4 * p, Ip = kb / 16;
+    const bool last = p == NP - 1;
+    const int Ipn = last ? -1 : (kb + 4) / 16;
+    if (!ALL)
+    {
+      if (I < Ip)
+        return 0;
+      // a tile row made of pivots only is dead once its last panel has been swept
+      if (I == Ip && Ipn != Ip && PIV0 + 4 * NP >= 16 * (Ip + 1))
+        return 0;
+      return (last || I == Ipn) ? 1 : 2;
+    }
+    if (last)
+      return 1;
+    const bool fixup = (I == Ip) || (J == Ip);             // pivot rows / columns rewritten by (d)
+    const bool gather = (I == Ipn) || (J == Ipn && I < Ipn); // read by the next (a)
+    return (fixup || gather) ? 1 : 2;
+  }
+
   template <int NT, int NTI, bool ALL, int PIV0, int NP, class Acc>
   SMPC_DEV void wave_block_sweep(Acc & acc, double * prow, double * urow, double * prof, long long & tprev)
   {
     constexpr int LDW = 16 * NTI;
     static_assert(NT == 64 && PIV0 % 4 == 0 && PIV0 + 4 * NP <= LDW && LDW <= 2 * NT, "sweep geometry");
-    SMPC_PLA(double, aop, NT, NTI);
-    SMPC_PLA(double, bop, NT, NTI);
+    // operands of two consecutive panels: the rank-4 updates that the next panel does not depend on are issued
+    // between the next panel's gather / pivot-inverse phases, so the matrix pipe works while the VALU / LDS chain runs
+    SMPC_PLA(double, aop, NT, 2 * NTI);
+    SMPC_PLA(double, bop, NT, 2 * NTI);
 #pragma unroll
     for (int p = 0; p < NP; p++)
     {
       const int kb = PIV0 + 4 * p, Ip = kb / 16, c0 = kb % 16, vp = c0 / 4;
+      const int ob = (p & 1) * NTI, obp = ((p + 1) & 1) * NTI; // operand sets of this / the previous panel
       // (a) pivot entries -> prow[k][m]
       SMPC_LANES(NT)
       {
@@ -89,6 +116,21 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 36, tprev);
+      // deferred updates of the previous panel, first half
+      if (p > 0)
+      {
+        int cnt = 0;
+#pragma unroll
+        for (int I = 0; I < NTI; I++)
+#pragma unroll
+          for (int J = I; J < NTI; J++)
+            if (sweep_tile_class<NTI, ALL, PIV0, NP>(p - 1, I, J) == 2)
+            {
+              if ((cnt & 1) == 0)
+                SMPC_MFMA(acc, tix<NTI>(I, J), aop, obp + I, bop, obp + J);
+              cnt++;
+            }
+      }
       // (b) U_m = D^-1 P_m, lane = index m (every lane factors the 4x4 pivot block D = L diag(d) L^T itself)
       SMPC_LANES(NT)
       {
@@ -128,24 +170,39 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 37, tprev);
-      // (c) rank-4 update of every maintained tile
-      const int I0 = ALL ? 0 : Ip;
+      // deferred updates of the previous panel, second half
+      if (p > 0)
+      {
+        int cnt = 0;
+#pragma unroll
+        for (int I = 0; I < NTI; I++)
+#pragma unroll
+          for (int J = I; J < NTI; J++)
+            if (sweep_tile_class<NTI, ALL, PIV0, NP>(p - 1, I, J) == 2)
+            {
+              if ((cnt & 1) == 1)
+                SMPC_MFMA(acc, tix<NTI>(I, J), aop, obp + I, bop, obp + J);
+              cnt++;
+            }
+      }
+      // (c) operands of this panel's rank-4 updates ; the updates the next panel depends on
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-        for (int I = I0; I < NTI; I++)
+        for (int I = 0; I < NTI; I++)
         {
-          SMPC_PLV(aop)[I] = -urow[lr * LDW + 16 * I + lc];
-          SMPC_PLV(bop)[I] = prow[lr * LDW + 16 * I + lc];
+          SMPC_PLV(aop)[ob + I] = -urow[lr * LDW + 16 * I + lc];
+          SMPC_PLV(bop)[ob + I] = prow[lr * LDW + 16 * I + lc];
         }
       }
       SMPC_LANES_END_WAVE
 #pragma unroll
-      for (int I = I0; I < NTI; I++)
+      for (int I = 0; I < NTI; I++)
 #pragma unroll
         for (int J = I; J < NTI; J++)
-          SMPC_MFMA(acc, tix<NTI>(I, J), aop, I, bop, J);
+          if (sweep_tile_class<NTI, ALL, PIV0, NP>(p, I, J) == 1)
+            SMPC_MFMA(acc, tix<NTI>(I, J), aop, ob + I, bop, ob + J);
       prof_tick(prof, 38, tprev);
       // (d) pivot entries := U
       if (ALL)
@@ -170,6 +227,7 @@ namespace smpc
         prof_tick(prof, 39, tprev);
       }
     }
+    // (the last panel defers nothing)
   }
 
   template <class D>
