@@ -3,7 +3,7 @@
 // orc_capi.cpp: extern "C" surface of the CPU oracle, loaded with ctypes by tests/ and by
 // bench.py's cpu_baseline leg.  Nothing in simple-mpc_amd/ links or loads this library.
 #include "../include/smpc_robots_builtin.h"
-#include "orc_mpc.hpp"
+#include "orc_mpc_cent.hpp"
 #include <chrono>
 #include <cstring>
 #ifdef _OPENMP
@@ -33,6 +33,92 @@ namespace
     for (int f = 0; f < md.nf; f++)
       r.foot_ref[f] = v3(foot_ref[3 * f], foot_ref[3 * f + 1], foot_ref[3 * f + 2]);
     return r;
+  }
+  // orc_mpc_get / orc_cmpc_get. what: 0 xs [B][H+1][nx], 1 us [B][H][nu], 2 K0 [B][nu][ndx], 3 vs [B][H][nc], 4 lams [B][H+1][ndx],
+  //       5 foot refs [B][H][nf][3], 6 info [B][12], 7 xdot [B][H][2nv], 8 Ks [B][H][nu][ndx]
+  template <class MPC>
+  void mpc_get_impl(MPC * m, int what, double * out)
+  {
+    const auto & md = m->md;
+    const int H = m->H;
+    for (int b = 0; b < m->B; b++)
+    {
+      const SolverState & S = m->sol[b];
+      switch (what)
+      {
+      case 0:
+        for (int t = 0; t <= H; t++)
+          vec_to(S.xs[t], out + ((size_t)b * (H + 1) + t) * md.nx);
+        break;
+      case 1:
+        for (int t = 0; t < H; t++)
+          vec_to(S.us[t], out + ((size_t)b * H + t) * md.nu);
+        break;
+      case 2:
+        if (!S.Ks.empty())
+          mat_to(S.Ks[0], out + (size_t)b * md.nu * md.ndx);
+        break;
+      case 3:
+        for (int t = 0; t < H; t++)
+          vec_to(S.vs[t], out + ((size_t)b * H + t) * md.nc);
+        break;
+      case 4:
+        for (int t = 0; t <= H; t++)
+          vec_to(S.lams[t], out + ((size_t)b * (H + 1) + t) * md.ndx);
+        break;
+      case 5:
+        for (int t = 0; t < H; t++)
+          for (int f = 0; f < md.nf; f++)
+            for (int i = 0; i < 3; i++)
+              out[(((size_t)b * H + t) * md.nf + f) * 3 + i] = m->ocp[b].stages[t].foot_ref[f][i];
+        break;
+      case 6: {
+        const IterInfo & I = m->last_info[b];
+        double * o = out + (size_t)b * 12;
+        o[0] = I.phi0;
+        o[1] = I.dphi0;
+        o[2] = I.alpha;
+        o[3] = I.phi_new;
+        o[4] = I.prim_infeas;
+        o[5] = I.dual_infeas;
+        o[6] = I.ls_failed;
+        o[7] = S.preg;
+        o[8] = I.prim_new;
+        o[9] = I.cost;
+        o[10] = I.cost_new;
+        o[11] = I.ls_index;
+        break;
+      }
+      case 7:
+        for (int t = 0; t < H && t < (int)S.xdot.size(); t++)
+          vec_to(S.xdot[t], out + ((size_t)b * H + t) * 2 * md.nv);
+        break;
+      case 8:
+        for (int t = 0; t < H && t < (int)S.Ks.size(); t++)
+          mat_to(S.Ks[t], out + ((size_t)b * H + t) * md.nu * md.ndx);
+        break;
+      }
+    }
+  }
+  // LQ knot (b, t) of the last iteration, packed A,B,Q,S,R,C,q,r,f,d (row-major)
+  template <class MPC>
+  int mpc_get_knot_impl(MPC * m, int b, int t, double * out)
+  {
+    if (b < 0 || b >= m->B || t < 0 || t >= (int)m->last_knots[b].size())
+      return -1;
+    const Knot & k = m->last_knots[b][t];
+    double * o = out;
+    for (const Mat * M : {&k.A, &k.B, &k.Q, &k.S, &k.R, &k.C})
+    {
+      mat_to(*M, o);
+      o += M->a.size();
+    }
+    for (const Vec * v : {&k.q, &k.r, &k.f, &k.d})
+    {
+      vec_to(*v, o);
+      o += v->size();
+    }
+    return (int)(o - out);
   }
 } // namespace
 
@@ -303,98 +389,14 @@ extern "C"
     ((BatchMPC *)h)->iterate(X);
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
-  // what: 0 xs [B][H+1][nx], 1 us [B][H][nu], 2 K0 [B][nu][ndx], 3 vs [B][H][nc], 4 lams [B][H+1][ndx],
-  //       5 foot refs [B][H][nf][3], 6 info [B][12], 7 xdot [B][H][2nv], 8 Ks [B][H][nu][ndx]
-  void orc_mpc_get(void * h, int what, double * out)
-  {
-    BatchMPC * m = (BatchMPC *)h;
-    const KinoModel & md = m->md;
-    const int H = m->H;
-    for (int b = 0; b < m->B; b++)
-    {
-      const SolverState & S = m->sol[b];
-      switch (what)
-      {
-      case 0:
-        for (int t = 0; t <= H; t++)
-          vec_to(S.xs[t], out + ((size_t)b * (H + 1) + t) * md.nx);
-        break;
-      case 1:
-        for (int t = 0; t < H; t++)
-          vec_to(S.us[t], out + ((size_t)b * H + t) * md.nu);
-        break;
-      case 2:
-        if (!S.Ks.empty())
-          mat_to(S.Ks[0], out + (size_t)b * md.nu * md.ndx);
-        break;
-      case 3:
-        for (int t = 0; t < H; t++)
-          vec_to(S.vs[t], out + ((size_t)b * H + t) * md.nc);
-        break;
-      case 4:
-        for (int t = 0; t <= H; t++)
-          vec_to(S.lams[t], out + ((size_t)b * (H + 1) + t) * md.ndx);
-        break;
-      case 5:
-        for (int t = 0; t < H; t++)
-          for (int f = 0; f < md.nf; f++)
-            for (int i = 0; i < 3; i++)
-              out[(((size_t)b * H + t) * md.nf + f) * 3 + i] = m->ocp[b].stages[t].foot_ref[f][i];
-        break;
-      case 6: {
-        const IterInfo & I = m->last_info[b];
-        double * o = out + (size_t)b * 12;
-        o[0] = I.phi0;
-        o[1] = I.dphi0;
-        o[2] = I.alpha;
-        o[3] = I.phi_new;
-        o[4] = I.prim_infeas;
-        o[5] = I.dual_infeas;
-        o[6] = I.ls_failed;
-        o[7] = S.preg;
-        o[8] = I.prim_new;
-        o[9] = I.cost;
-        o[10] = I.cost_new;
-        o[11] = I.ls_index;
-        break;
-      }
-      case 7:
-        for (int t = 0; t < H && t < (int)S.xdot.size(); t++)
-          vec_to(S.xdot[t], out + ((size_t)b * H + t) * 2 * md.nv);
-        break;
-      case 8:
-        for (int t = 0; t < H && t < (int)S.Ks.size(); t++)
-          mat_to(S.Ks[t], out + ((size_t)b * H + t) * md.nu * md.ndx);
-        break;
-      }
-    }
-  }
+  void orc_mpc_get(void * h, int what, double * out) { mpc_get_impl((BatchMPC *)h, what, out); }
   void orc_mpc_keep_knots(void * h, int on)
   {
     BatchMPC * m = (BatchMPC *)h;
     m->keep_knots = on != 0;
     m->last_knots.assign(m->B, std::vector<Knot>());
   }
-  // LQ knot (b, t) of the last iteration, packed A,B,Q,S,R,C,q,r,f,d (row-major)
-  int orc_mpc_get_knot(void * h, int b, int t, double * out)
-  {
-    BatchMPC * m = (BatchMPC *)h;
-    if (b < 0 || b >= m->B || t < 0 || t >= (int)m->last_knots[b].size())
-      return -1;
-    const Knot & k = m->last_knots[b][t];
-    double * o = out;
-    for (const Mat * M : {&k.A, &k.B, &k.Q, &k.S, &k.R, &k.C})
-    {
-      mat_to(*M, o);
-      o += M->a.size();
-    }
-    for (const Vec * v : {&k.q, &k.r, &k.f, &k.d})
-    {
-      vec_to(*v, o);
-      o += v->size();
-    }
-    return (int)(o - out);
-  }
+  int orc_mpc_get_knot(void * h, int b, int t, double * out) { return mpc_get_knot_impl((BatchMPC *)h, b, t, out); }
   int orc_mpc_cold_iters(void * h) { return (int)((BatchMPC *)h)->cold_trace.size(); }
   void orc_mpc_cold_trace(void * h, double * out) // [n][4]: phi0, prim, dual, alpha
   {
@@ -511,6 +513,144 @@ extern "C"
     }
     for (int i = 0; i < 9; i++)
       xnext[i] = x[i] + dt * xd[i];
+  }
+
+  // ---- centroidal OCP + MPC (orc_cent.hpp, orc_mpc_cent.hpp) ----
+  void * orc_cent_create(
+    const smpc_robot_model * m, double dt, const double * w_u, const double * w_com, const double * w_linear_mom,
+    const double * w_angular_mom, const double * w_linear_acc, const double * w_angular_acc, const double * gravity, double mu)
+  {
+    CentSettings s;
+    const int nu = 3 * m->nfeet;
+    s.timestep = dt;
+    s.w_u = mat_from(w_u, nu, nu);
+    s.w_com = mat_from(w_com, 3, 3);
+    s.w_linear_mom = mat_from(w_linear_mom, 3, 3);
+    s.w_angular_mom = mat_from(w_angular_mom, 3, 3);
+    s.w_linear_acc = mat_from(w_linear_acc, 3, 3);
+    s.w_angular_acc = mat_from(w_angular_acc, 3, 3);
+    for (int i = 0; i < 3; i++)
+      s.gravity[i] = gravity[i];
+    s.mu = mu;
+    return new CentModel(m, s);
+  }
+  void orc_cent_destroy(void * h) { delete (CentModel *)h; }
+  static StageRef cent_ref(const CentModel & md, unsigned mask, const double * u_ref, const double * x_tgt, const double * pos)
+  {
+    StageRef r;
+    r.mask = mask;
+    r.u_ref.assign(u_ref, u_ref + md.nu);
+    r.x_tgt.assign(x_tgt, x_tgt + 9);
+    r.foot_ref.resize(md.nf);
+    for (int f = 0; f < md.nf; f++)
+      r.foot_ref[f] = v3(pos[3 * f], pos[3 * f + 1], pos[3 * f + 2]);
+    return r;
+  }
+  void orc_cent_eval(
+    void * h, unsigned mask, const double * u_ref, const double * x_tgt, const double * pos, const double * x, const double * u,
+    double * xnext, double * xdot, double * cost, double * c)
+  {
+    CentModel * md = (CentModel *)h;
+    Rigid scratch(md->M);
+    StageEval o;
+    md->eval(scratch, cent_ref(*md, mask, u_ref, x_tgt, pos), x, u, o);
+    vec_to(o.xnext, xnext);
+    vec_to(o.xdot, xdot);
+    *cost = o.cost;
+    vec_to(o.c, c);
+  }
+  void orc_cent_deriv(
+    void * h, unsigned mask, const double * u_ref, const double * x_tgt, const double * pos, const double * x, const double * u,
+    double * A, double * B, double * lx, double * lu, double * Lxx, double * Lxu, double * Luu, double * Cx, double * Cu)
+  {
+    CentModel * md = (CentModel *)h;
+    Rigid scratch(md->M);
+    StageDer o;
+    md->deriv(scratch, cent_ref(*md, mask, u_ref, x_tgt, pos), x, u, o);
+    mat_to(o.A, A);
+    mat_to(o.B, B);
+    vec_to(o.lx, lx);
+    vec_to(o.lu, lu);
+    mat_to(o.Lxx, Lxx);
+    mat_to(o.Lxu, Lxu);
+    mat_to(o.Luu, Luu);
+    mat_to(o.Cx, Cx);
+    mat_to(o.Cu, Cu);
+  }
+  void orc_cent_term(void * h, const double * x, double * cost, double * lx, double * Lxx)
+  {
+    CentModel * md = (CentModel *)h;
+    Rigid scratch(md->M);
+    Vec dummy, g;
+    Mat Hm;
+    *cost = md->term_eval(scratch, dummy, x);
+    md->term_deriv(scratch, dummy, x, g, Hm);
+    vec_to(g, lx);
+    mat_to(Hm, Lxx);
+  }
+  void * orc_cmpc_create(void * cent, const smpc_robot_model * robot, const orc_mpc_settings * s, int B, double gravity_arg)
+  {
+    CentModel * md = (CentModel *)cent;
+    MPCSettings ms;
+    ms.swing_apex = s->swing_apex;
+    ms.support_force = s->support_force;
+    ms.TOL = s->TOL;
+    ms.mu_init = s->mu_init;
+    ms.timestep = s->timestep;
+    ms.max_iters = s->max_iters;
+    ms.num_threads = s->num_threads;
+    ms.T_fly = s->T_fly;
+    ms.T_contact = s->T_contact;
+    ms.T = s->T;
+#ifdef _OPENMP
+    if (s->num_threads > 0)
+      omp_set_num_threads(s->num_threads);
+#endif
+    return new BatchMPCCent(robot, md->s, ms, s->T, B, gravity_arg);
+  }
+  void orc_cmpc_destroy(void * h) { delete (BatchMPCCent *)h; }
+  void orc_cmpc_generate_cycle(void * h, const unsigned char * cs, int n)
+  {
+    BatchMPCCent * m = (BatchMPCCent *)h;
+    std::vector<std::vector<char>> v(n, std::vector<char>(m->nf));
+    for (int i = 0; i < n; i++)
+      for (int f = 0; f < m->nf; f++)
+        v[i][f] = cs[i * m->nf + f];
+    m->generateCycleHorizon(v);
+  }
+  void orc_cmpc_switch_to_walk(void * h, const double * v6) { ((BatchMPCCent *)h)->switchToWalk(v6); }
+  void orc_cmpc_switch_to_stand(void * h) { ((BatchMPCCent *)h)->switchToStand(); }
+  void orc_cmpc_set_x_reference(void * h, const double * x9) { ((BatchMPCCent *)h)->x_reference.assign(x9, x9 + 9); }
+  double orc_cmpc_iterate(void * h, const double * X)
+  {
+    auto t0 = std::chrono::steady_clock::now();
+    ((BatchMPCCent *)h)->iterate(X);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  // same `what` codes as orc_mpc_get; 7 = xdot [B][H][18] (2 nv with nv = 9: only the first 9 entries are used)
+  void orc_cmpc_get(void * h, int what, double * out) { mpc_get_impl((BatchMPCCent *)h, what, out); }
+  void orc_cmpc_keep_knots(void * h, int on)
+  {
+    BatchMPCCent * m = (BatchMPCCent *)h;
+    m->keep_knots = on != 0;
+    m->last_knots.assign(m->B, std::vector<Knot>());
+  }
+  int orc_cmpc_get_knot(void * h, int b, int t, double * out) { return mpc_get_knot_impl((BatchMPCCent *)h, b, t, out); }
+  int orc_cmpc_cold_iters(void * h) { return (int)((BatchMPCCent *)h)->cold_trace.size(); }
+  void orc_cmpc_cold_trace(void * h, double * out)
+  {
+    BatchMPCCent * m = (BatchMPCCent *)h;
+    for (size_t i = 0; i < m->cold_trace.size(); i++)
+    {
+      out[4 * i] = m->cold_trace[i].phi0;
+      out[4 * i + 1] = m->cold_trace[i].prim_infeas;
+      out[4 * i + 2] = m->cold_trace[i].dual_infeas;
+      out[4 * i + 3] = m->cold_trace[i].alpha;
+    }
+  }
+  int orc_cmpc_timing(void * h, int foot, int which, int * out, int cap)
+  {
+    return orc_timer_get(&((BatchMPCCent *)h)->timer, foot, which, out, cap);
   }
   int orc_num_threads()
   {

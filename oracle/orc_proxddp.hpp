@@ -18,7 +18,7 @@
 //   5. proximal Riccati backward / forward  -> (dx, du, dnu, dlam)
 //   6. backtracking Armijo line search on phi over alpha in {1, 1/2, ..., 2^-(LS_N-1)}
 #pragma once
-#include "orc_kino.hpp"
+#include "orc_cent.hpp"
 
 namespace orc
 {
@@ -216,11 +216,13 @@ namespace orc
     int ls_index = 0, ls_failed = 0;
   };
 
-  struct ProxDDP
+  // Model: KinoModel (orc_kino.hpp) or CentModel (orc_cent.hpp)
+  template <class Model>
+  struct ProxDDPT
   {
-    const KinoModel & md;
+    const Model & md;
     double mu;
-    ProxDDP(const KinoModel & m, double mu_) : md(m), mu(mu_) {}
+    ProxDDPT(const Model & m, double mu_) : md(m), mu(mu_) {}
 
     struct Eval
     {
@@ -248,7 +250,7 @@ namespace orc
       {
         md.eval(R, ocp.stages[t], xs[t].data(), us[t].data(), E.ev[t]);
         cost += E.ev[t].cost;
-        x_difference(md.nq, md.nv, xs[t + 1].data(), E.ev[t].xnext.data(), E.e[t + 1].data());
+        md.difference(xs[t + 1].data(), E.ev[t].xnext.data(), E.e[t + 1].data());
         for (int i = 0; i < md.ndx; i++)
         {
           const double lp = lams_e[t + 1][i] + E.e[t + 1][i] / mu;
@@ -418,7 +420,7 @@ namespace orc
           for (auto & e : adx)
             e *= alpha;
           txs[t].assign(md.nx, 0.0);
-          x_integrate(md.nq, md.nv, S.xs[t].data(), adx.data(), txs[t].data());
+          md.integrate(S.xs[t].data(), adx.data(), txs[t].data());
           tl[t] = S.lams[t];
           axpy(tl[t], dlams[t], alpha);
         }
@@ -458,4 +460,5 @@ namespace orc
       return info;
     }
   };
+  typedef ProxDDPT<KinoModel> ProxDDP;
 } // namespace orc

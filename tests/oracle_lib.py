@@ -90,6 +90,29 @@ def lib():
     L.orc_mpc_cold_trace.argtypes = [vp, _dp]
     L.orc_mpc_timing.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
     L.orc_num_threads.restype = C.c_int
+    L.orc_cent_create.restype = vp
+    L.orc_cent_create.argtypes = [vp, C.c_double] + [_dp] * 7 + [C.c_double]
+    L.orc_cent_destroy.argtypes = [vp]
+    L.orc_cent_eval.argtypes = [vp, C.c_uint] + [_dp] * 9
+    L.orc_cent_deriv.argtypes = [vp, C.c_uint] + [_dp] * 14
+    L.orc_cent_term.argtypes = [vp, _dp, _dp, _dp, _dp]
+    L.orc_cmpc_create.restype = vp
+    L.orc_cmpc_create.argtypes = [vp, vp, C.POINTER(MpcSettingsC), C.c_int, C.c_double]
+    L.orc_cmpc_destroy.argtypes = [vp]
+    L.orc_cmpc_generate_cycle.argtypes = [vp, _bp, C.c_int]
+    L.orc_cmpc_switch_to_walk.argtypes = [vp, _dp]
+    L.orc_cmpc_switch_to_stand.argtypes = [vp]
+    L.orc_cmpc_set_x_reference.argtypes = [vp, _dp]
+    L.orc_cmpc_iterate.restype = C.c_double
+    L.orc_cmpc_iterate.argtypes = [vp, _dp]
+    L.orc_cmpc_get.argtypes = [vp, C.c_int, _dp]
+    L.orc_cmpc_cold_iters.argtypes = [vp]
+    L.orc_cmpc_cold_trace.argtypes = [vp, _dp]
+    L.orc_cmpc_timing.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
+    L.orc_cmpc_keep_knots.argtypes = [vp, C.c_int]
+    L.orc_cmpc_get_knot.argtypes = [vp, C.c_int, C.c_int, _dp]
+    L.orc_mpc_keep_knots.argtypes = [vp, C.c_int]
+    L.orc_mpc_get_knot.argtypes = [vp, C.c_int, C.c_int, _dp]
     L.orc_centroidal_dynamics.argtypes = [C.c_double, _dp, C.c_double, C.c_int, _dp, _dp, _bp, _dp, _dp, _dp, _dp]
     L.orc_friction.argtypes = [_dp, _dp, C.c_int, _dp, _dp, C.c_int]
     L.orc_interpolate.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int, _dp]
@@ -259,8 +282,17 @@ class Timer:
 class OracleMPC:
     """Batched restatement of simple_mpc.MPC (reference: include/simple-mpc/mpc.hpp:55-197)."""
 
+    _p = "orc_mpc_"
+
+    def _f(self, name):
+        return getattr(lib(), self._p + name)
+
+    def _create(self, s, B, gravity_arg):
+        return lib().orc_mpc_create(self.kino.h, C.byref(s), B, gravity_arg)
+
     def __init__(self, kino, mpc_settings, B, gravity_arg=-9.81):
         self.kino = kino
+        self.nx_in = kino.nx
         self.B = B
         self.H = mpc_settings["T"]
         s = MpcSettingsC(
@@ -268,26 +300,26 @@ class OracleMPC:
             mpc_settings["timestep"], mpc_settings["max_iters"], mpc_settings.get("num_threads", 0),
             mpc_settings["T_fly"], mpc_settings["T_contact"], mpc_settings["T"],
         )
-        self.h = lib().orc_mpc_create(kino.h, C.byref(s), B, gravity_arg)
+        self.h = self._create(s, B, gravity_arg)
 
     def generateCycleHorizon(self, cs):
         cs = np.ascontiguousarray(cs, np.uint8)
-        lib().orc_mpc_generate_cycle(self.h, cs, cs.shape[0])
+        self._f("generate_cycle")(self.h, cs, cs.shape[0])
 
     def switchToWalk(self, v6):
-        lib().orc_mpc_switch_to_walk(self.h, np.ascontiguousarray(v6, float))
+        self._f("switch_to_walk")(self.h, np.ascontiguousarray(v6, float))
 
     def switchToStand(self):
-        lib().orc_mpc_switch_to_stand(self.h)
+        self._f("switch_to_stand")(self.h)
 
     def iterate(self, X):
         X = np.ascontiguousarray(X, float)
-        assert X.shape == (self.B, self.kino.nx)
-        return lib().orc_mpc_iterate(self.h, X)
+        assert X.shape == (self.B, self.nx_in)
+        return self._f("iterate")(self.h, X)
 
     def _get(self, what, shape):
         out = np.zeros(shape)
-        lib().orc_mpc_get(self.h, what, out)
+        self._f("get")(self.h, what, out)
         return out
 
     @property
@@ -323,15 +355,13 @@ class OracleMPC:
         return self._get(7, (self.B, self.H, 2 * self.kino.nv))
 
     def keep_knots(self, on=True):
-        lib().orc_mpc_keep_knots.argtypes = [C.c_void_p, C.c_int]
-        lib().orc_mpc_keep_knots(self.h, int(on))
+        self._f("keep_knots")(self.h, int(on))
 
     def knot(self, b, t):
         k = self.kino
         ndx, nu, nc = k.ndx, k.nu, k.nc
-        lib().orc_mpc_get_knot.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
         out = np.zeros(2 * ndx * ndx + 2 * ndx * nu + nu * nu + nc * ndx + 2 * ndx + nu + nc)
-        n = lib().orc_mpc_get_knot(self.h, b, t, out)
+        n = self._f("get_knot")(self.h, b, t, out)
         assert n == out.size, n
         res, o = {}, 0
         for name, shape in (
@@ -344,15 +374,96 @@ class OracleMPC:
         return res
 
     def cold_trace(self):
-        n = lib().orc_mpc_cold_iters(self.h)
+        n = self._f("cold_iters")(self.h)
         out = np.zeros((n, 4))
-        lib().orc_mpc_cold_trace(self.h, out)
+        self._f("cold_trace")(self.h, out)
         return out
 
     def timing(self, foot, which):
         out = np.zeros(64, np.int32)
-        n = lib().orc_mpc_timing(self.h, foot, which, out, 64)
+        n = self._f("timing")(self.h, foot, which, out, 64)
         return [int(v) for v in out[:n]]
+
+
+
+def go2_centroidal_settings(robot):
+    """CentroidalSettings for the BASELINE "Go2 centroidal, H=50" configuration.  The reference ships no Go2 centroidal
+    script: the weights are those of its centroidal example (examples/talos_centroidal.py:50-76) with 3-D contact forces."""
+    nf = robot.nf
+    return dict(
+        timestep=0.01,
+        w_u=np.diag(np.ones(3 * nf) * 0.001),
+        w_com=np.zeros((3, 3)),
+        w_linear_mom=np.diag([0.01, 0.01, 100.0]),
+        w_angular_mom=np.diag([0.1, 0.1, 1000.0]),
+        w_linear_acc=0.01 * np.eye(3),
+        w_angular_acc=0.01 * np.eye(3),
+        gravity=np.array([0.0, 0.0, -9.81]),
+        mu=0.8,
+        Lfoot=0.01,
+        Wfoot=0.01,
+        force_size=3,
+    )
+
+
+class Cent:
+    """Oracle centroidal stage model (oracle/orc_cent.hpp)."""
+
+    def __init__(self, robot, s):
+        c = lambda a: np.ascontiguousarray(a, float)
+        self.robot, self.s = robot, s
+        self.h = lib().orc_cent_create(
+            robot.ptr, s["timestep"], c(s["w_u"]), c(s["w_com"]), c(s["w_linear_mom"]), c(s["w_angular_mom"]),
+            c(s["w_linear_acc"]), c(s["w_angular_acc"]), c(s["gravity"]), float(s["mu"]),
+        )
+        self.nf = robot.nf
+        self.nx = self.ndx = self.nv = 9
+        self.nu, self.nc = 3 * self.nf, 2 * self.nf
+
+    def eval(self, mask, u_ref, x_tgt, pos, x, u):
+        c = lambda a: np.ascontiguousarray(a, float)
+        xnext, xdot, cost, cc = np.zeros(9), np.zeros(9), np.zeros(1), np.zeros(self.nc)
+        lib().orc_cent_eval(self.h, mask, c(u_ref), c(x_tgt), c(pos), c(x), c(u), xnext, xdot, cost, cc)
+        return dict(xnext=xnext, xdot=xdot, cost=float(cost[0]), c=cc)
+
+    def deriv(self, mask, u_ref, x_tgt, pos, x, u):
+        c = lambda a: np.ascontiguousarray(a, float)
+        n, m, k = 9, self.nu, self.nc
+        o = dict(
+            A=np.zeros((n, n)), B=np.zeros((n, m)), lx=np.zeros(n), lu=np.zeros(m), Lxx=np.zeros((n, n)),
+            Lxu=np.zeros((n, m)), Luu=np.zeros((m, m)), Cx=np.zeros((k, n)), Cu=np.zeros((k, m)),
+        )
+        lib().orc_cent_deriv(
+            self.h, mask, c(u_ref), c(x_tgt), c(pos), c(x), c(u), o["A"], o["B"], o["lx"], o["lu"], o["Lxx"], o["Lxu"],
+            o["Luu"], o["Cx"], o["Cu"],
+        )
+        return o
+
+    def term(self, x):
+        cost, lx, Lxx = np.zeros(1), np.zeros(9), np.zeros((9, 9))
+        lib().orc_cent_term(self.h, np.ascontiguousarray(x, float), cost, lx, Lxx)
+        return float(cost[0]), lx, Lxx
+
+
+class OracleCentMPC(OracleMPC):
+    """simple_mpc.MPC over a CentroidalOCP, batched (oracle/orc_mpc_cent.hpp).  iterate() takes the measured MULTIBODY
+    states [B][nq + nv] like the reference; xs are centroidal states [B][H+1][9]."""
+
+    _p = "orc_cmpc_"
+
+    def _create(self, s, B, gravity_arg):
+        return lib().orc_cmpc_create(self.kino.h, self.kino.robot.ptr, C.byref(s), B, gravity_arg)
+
+    def __init__(self, cent, mpc_settings, B, gravity_arg=-9.81):
+        OracleMPC.__init__(self, cent, mpc_settings, B, gravity_arg)
+        self.nx_in = cent.robot.nq + cent.robot.nv
+
+    def set_x_reference(self, x9):
+        lib().orc_cmpc_set_x_reference(self.h, np.ascontiguousarray(x9, float))
+
+    @property
+    def xdot(self):
+        return self._get(7, (self.B, self.H, 18))[:, :, :9]
 
 
 def interpolate(kind, nv, delay, timestep, knots):
