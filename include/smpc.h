@@ -51,6 +51,24 @@ typedef struct smpc_kinodynamics_settings
   int land_cstr;
 } smpc_kinodynamics_settings;
 
+/* CentroidalSettings: reference include/simple-mpc/centroidal-dynamics.hpp:27-43 (same field names).
+ * w_u (nu x nu, nu = force_size * nfeet) dense row-major; the other weights are 3 x 3. */
+typedef struct smpc_centroidal_settings
+{
+  double timestep;
+  const double * w_u;
+  const double * w_com;
+  const double * w_linear_mom;
+  const double * w_angular_mom;
+  const double * w_linear_acc;
+  const double * w_angular_acc;
+  double gravity[3];
+  double mu;
+  double Lfoot;
+  double Wfoot;
+  int force_size;
+} smpc_centroidal_settings;
+
 /* MPCSettings: reference include/simple-mpc/mpc.hpp:29-49 (same field names). */
 typedef struct smpc_mpc_settings
 {
@@ -81,6 +99,18 @@ int smpc_device_count(void);
  * SURVEY App. C.8).  Performs the cold solve (<= 100 ProxDDP iterations). */
 int smpc_create(
   const smpc_robot_model * robot, const smpc_kinodynamics_settings * ocp, const smpc_mpc_settings * mpc, int batch,
+  double gravity_arg, int device_id, smpc_handle ** out);
+/* CentroidalOCP(settings, model) + createProblem(getCentroidalState(), T, force_size, gravity, false) + MPC(settings, ocp):
+ * reference src/centroidal-dynamics.cpp:27-37, src/ocp-handler.cpp:96-137, src/mpc.cpp:19-99 (SURVEY 8a rows a6, a8, a9;
+ * BASELINE config "Go2 centroidal (9-dim state), H = 50").  The handle is used through the same entry points as a
+ * kinodynamics handle: smpc_iterate still takes the measured MULTIBODY states [B][nq + nv] (the reference reduces them with
+ * getCentroidalState, src/mpc.cpp:200); the problem state is [com; h_lin; h_ang], so xs is [B][H+1][9], us [B][H][3 nfeet],
+ * K0 [B][3 nfeet][9], vs [B][H][2 nfeet] (friction-cone rows), smpc_get_state_derivative01 [B][2][9],
+ * smpc_get_reference_poses the contact positions [B][H][nfeet][3], smpc_set_x_reference takes 9 doubles.
+ * smpc_get_dims reports nq, nv of the robot and nx = ndx = 9.  Entry points that are specific to the kinodynamics
+ * problem (interpolate, riccati_feedback, debug_get_lq, get_x_device) fail with SMPC_ERR_INVALID on such a handle. */
+int smpc_create_centroidal(
+  const smpc_robot_model * robot, const smpc_centroidal_settings * ocp, const smpc_mpc_settings * mpc, int batch,
   double gravity_arg, int device_id, smpc_handle ** out);
 int smpc_destroy(smpc_handle * h);
 

@@ -2,7 +2,7 @@
 // gfx950 (kernels are instantiated here); there is no CPU implementation behind these symbols.
 #include "../../include/smpc.h"
 #include "../../include/smpc_robots_builtin.h"
-#include "smpc_engine.h"
+#include "smpc_cent_engine.h"
 #include <cstring>
 #include <memory>
 #include <string>
@@ -11,9 +11,13 @@ using namespace smpc;
 
 typedef Dims<13, 4> DimsGo2; // free-flyer + 12 revolute joints, 4 point feet
 
+typedef CentDims<4> CentGo2;
+typedef CentEngine<DimsGo2, CentGo2> CentEngineGo2;
+
 struct smpc_handle
 {
   std::unique_ptr<KinoEngine<DimsGo2>> eng;
+  std::unique_ptr<CentEngineGo2> cent; // centroidal handle (smpc_create_centroidal): eng is null
 };
 
 namespace
@@ -37,6 +41,22 @@ namespace
       return fail(SMPC_ERR_RUNTIME, e.what());
     }
   }
+  HostMpcSettings host_mpc(const smpc_mpc_settings * mpc)
+  {
+    HostMpcSettings ms;
+    ms.swing_apex = mpc->swing_apex;
+    ms.support_force = mpc->support_force;
+    ms.TOL = mpc->TOL;
+    ms.mu_init = mpc->mu_init;
+    ms.timestep = mpc->timestep;
+    ms.max_iters = mpc->max_iters;
+    ms.num_threads = mpc->num_threads;
+    ms.T_fly = mpc->T_fly;
+    ms.T_contact = mpc->T_contact;
+    ms.T = mpc->T;
+    return ms;
+  }
+  const char * KINO_ONLY = "this entry point needs a kinodynamics handle (smpc_create)";
 } // namespace
 
 extern "C"
@@ -110,6 +130,50 @@ extern "C"
       *out = h.release();
     });
   }
+  int smpc_create_centroidal(
+    const smpc_robot_model * robot, const smpc_centroidal_settings * ocp, const smpc_mpc_settings * mpc, int batch, double gravity_arg,
+    int device_id, smpc_handle ** out)
+  {
+    if (!robot || !ocp || !mpc || !out || !ocp->w_u || !ocp->w_com || !ocp->w_linear_mom || !ocp->w_angular_mom || !ocp->w_linear_acc
+        || !ocp->w_angular_acc)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (device_count() <= 0)
+      return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the MPC engine has no CPU path");
+    if (ocp->force_size != 3)
+      return fail(SMPC_ERR_INVALID, "force size in settings does not match reference force size (only 3-D point feet are built)");
+    if (robot->nfeet != CentGo2::NF || robot->njoints != DimsGo2::NJ)
+      return fail(SMPC_ERR_INVALID, "robot shape (njoints, nfeet) does not match this kernel instantiation");
+    if (mpc->T < 2)
+      return fail(SMPC_ERR_INVALID, "horizon must have at least 2 stages");
+    const int nu = 3 * robot->nfeet;
+    HostCentSettings cs;
+    cs.timestep = ocp->timestep;
+    cs.w_u.assign(ocp->w_u, ocp->w_u + (size_t)nu * nu);
+    cs.w_com.assign(ocp->w_com, ocp->w_com + 9);
+    cs.w_linear_mom.assign(ocp->w_linear_mom, ocp->w_linear_mom + 9);
+    cs.w_angular_mom.assign(ocp->w_angular_mom, ocp->w_angular_mom + 9);
+    cs.w_linear_acc.assign(ocp->w_linear_acc, ocp->w_linear_acc + 9);
+    cs.w_angular_acc.assign(ocp->w_angular_acc, ocp->w_angular_acc + 9);
+    for (int i = 0; i < 3; i++)
+      cs.gravity[i] = ocp->gravity[i];
+    cs.mu = ocp->mu;
+    auto sym = [](const std::vector<double> & w, int n) {
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+          if (std::fabs(w[(size_t)i * n + j] - w[(size_t)j * n + i]) > 1e-12 * (1.0 + std::fabs(w[(size_t)i * n + j])))
+            return false;
+      return true;
+    };
+    if (!sym(cs.w_u, nu) || !sym(cs.w_com, 3) || !sym(cs.w_linear_mom, 3) || !sym(cs.w_angular_mom, 3) || !sym(cs.w_linear_acc, 3)
+        || !sym(cs.w_angular_acc, 3))
+      return fail(SMPC_ERR_INVALID, "weight matrices must be symmetric");
+    const HostMpcSettings ms = host_mpc(mpc);
+    return guarded([&] {
+      std::unique_ptr<smpc_handle> h(new smpc_handle());
+      h->cent.reset(new CentEngineGo2(robot, cs, ms, batch, gravity_arg, device_id));
+      *out = h.release();
+    });
+  }
   int smpc_destroy(smpc_handle * h)
   {
     delete h;
@@ -119,6 +183,18 @@ extern "C"
   {
     if (!h || !d)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+    {
+      d[0] = DimsGo2::NQ;
+      d[1] = DimsGo2::NV;
+      d[2] = 9;
+      d[3] = 9;
+      d[4] = CentGo2::NU;
+      d[5] = CentGo2::NC;
+      d[6] = CentGo2::NF;
+      d[7] = h->cent->H;
+      return SMPC_OK;
+    }
     d[0] = DimsGo2::NQ;
     d[1] = DimsGo2::NV;
     d[2] = DimsGo2::NX;
@@ -133,68 +209,105 @@ extern "C"
   {
     if (!h || !cs)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return guarded([&] { h->cent->generate_cycle_horizon(cs, n); });
     return guarded([&] { h->eng->generate_cycle_horizon(cs, n); });
   }
   int smpc_switch_to_walk(smpc_handle * h, const double * v6)
   {
     if (!h || !v6)
       return fail(SMPC_ERR_INVALID, "null argument");
-    h->eng->switch_to_walk(v6);
+    if (h->cent)
+      h->cent->switch_to_walk(v6);
+    else
+      h->eng->switch_to_walk(v6);
     return SMPC_OK;
   }
   int smpc_switch_to_stand(smpc_handle * h)
   {
     if (!h)
       return fail(SMPC_ERR_INVALID, "null argument");
-    h->eng->switch_to_stand();
+    if (h->cent)
+      h->cent->switch_to_stand();
+    else
+      h->eng->switch_to_stand();
     return SMPC_OK;
   }
   int smpc_set_x_reference(smpc_handle * h, const double * x)
   {
     if (!h || !x)
       return fail(SMPC_ERR_INVALID, "null argument");
-    h->eng->x_reference.assign(x, x + DimsGo2::NX);
+    if (h->cent)
+      std::copy(x, x + 9, h->cent->x_reference);
+    else
+      h->eng->x_reference.assign(x, x + DimsGo2::NX);
     return SMPC_OK;
   }
   int smpc_iterate(smpc_handle * h, const double * X)
   {
     if (!h || !X)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return guarded([&] { h->cent->iterate_host(X); });
     return guarded([&] { h->eng->iterate_host(X); });
   }
   int smpc_iterate_device(smpc_handle * h, const double * Xd)
   {
     if (!h || !Xd)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return guarded([&] { h->cent->iterate_device(Xd); });
     return guarded([&] { h->eng->iterate_device(Xd); });
   }
   int smpc_wait(smpc_handle * h)
   {
     if (!h)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return guarded([&] { h->cent->sync(); });
     return guarded([&] { h->eng->sync(); });
   }
   int smpc_get_x_device(smpc_handle * h, int t, double * out_device)
   {
     if (!h || !out_device)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return fail(SMPC_ERR_INVALID, KINO_ONLY);
     return guarded([&] { h->eng->gather_x_device(t, out_device); });
   }
   int smpc_get_xs(smpc_handle * h, double * out)
   {
+    if (h->cent)
+      return guarded([&] { h->cent->get_ring(h->cent->buf.xs, 9, h->cent->H + 1, out); });
     return guarded([&] { h->eng->get_ring(h->eng->buf.xs, DimsGo2::NX, h->eng->H + 1, out); });
   }
   int smpc_get_us(smpc_handle * h, double * out)
   {
+    if (h->cent)
+      return guarded([&] { h->cent->get_ring(h->cent->buf.us, CentGo2::NU, h->cent->H, out); });
     return guarded([&] { h->eng->get_ring(h->eng->buf.us, DimsGo2::NU, h->eng->H, out); });
   }
   int smpc_get_vs(smpc_handle * h, double * out)
   {
+    if (h->cent)
+      return guarded([&] { h->cent->get_ring(h->cent->buf.vs, CentGo2::NC, h->cent->H, out); });
     return guarded([&] { h->eng->get_ring(h->eng->buf.vs, DimsGo2::NC, h->eng->H, out); });
   }
   int smpc_get_lams(smpc_handle * h, double * out)
   {
     // device arrays hold lambda_{t+1} at stage t; the API returns lams[0..H] with lams[0] = 0
+    if (h->cent)
+      return guarded([&] {
+        auto & e = *h->cent;
+        std::vector<double> tmp((size_t)e.B * e.H * 9);
+        e.get_ring(e.buf.lams, 9, e.H, tmp.data());
+        for (int b = 0; b < e.B; b++)
+        {
+          double * o = out + (size_t)b * (e.H + 1) * 9;
+          std::memset(o, 0, 9 * sizeof(double));
+          std::memcpy(o + 9, tmp.data() + (size_t)b * e.H * 9, (size_t)e.H * 9 * sizeof(double));
+        }
+      });
     return guarded([&] {
       auto & e = *h->eng;
       std::vector<double> tmp((size_t)e.B * e.H * DimsGo2::NDX);
@@ -209,47 +322,61 @@ extern "C"
   }
   int smpc_get_K0(smpc_handle * h, double * out)
   {
+    if (h->cent)
+      return guarded([&] { h->cent->get_K(out, false); });
     return guarded([&] { h->eng->get_K(out, false); });
   }
   int smpc_get_Ks(smpc_handle * h, double * out)
   {
+    if (h->cent)
+      return guarded([&] { h->cent->get_K(out, true); });
     return guarded([&] { h->eng->get_K(out, true); });
   }
   int smpc_get_state_derivative01(smpc_handle * h, double * out)
   {
+    if (h->cent)
+      return guarded([&] { h->cent->get_linear(h->cent->buf.xdot01, (size_t)h->cent->B * 18, out); });
     return guarded([&] { h->eng->get_linear(h->eng->buf.xdot01, (size_t)h->eng->B * 4 * DimsGo2::NV, out); });
   }
   int smpc_get_reference_poses(smpc_handle * h, double * out)
   {
+    if (h->cent)
+      return guarded([&] { h->cent->get_linear(h->cent->buf.foot, (size_t)h->cent->B * h->cent->H * CentGo2::NF * 3, out); });
     return guarded([&] { h->eng->get_linear(h->eng->buf.foot_ref, (size_t)h->eng->B * h->eng->H * DimsGo2::NF * 3, out); });
   }
   int smpc_get_foot_timing(smpc_handle * h, int foot, int which, int * out, int cap)
   {
-    if (!h || foot < 0 || foot >= DimsGo2::NF || h->eng->timer.nf == 0)
+    const GaitTimer * tm = !h ? nullptr : (h->cent ? &h->cent->timer : &h->eng->timer);
+    if (!tm || foot < 0 || foot >= DimsGo2::NF || tm->nf == 0)
     {
       fail(SMPC_ERR_INVALID, "invalid foot index or cycle horizon not generated");
       return SMPC_ERR_INVALID;
     }
-    const std::vector<int> & v = which ? h->eng->timer.land[foot] : h->eng->timer.takeoff[foot];
+    const std::vector<int> & v = which ? tm->land[foot] : tm->takeoff[foot];
     for (int i = 0; i < (int)v.size() && i < cap; i++)
       out[i] = v[i];
     return (int)v.size();
   }
   int smpc_get_info(smpc_handle * h, double * out)
   {
+    if (h->cent)
+      return guarded([&] { h->cent->get_linear(h->cent->buf.scal, (size_t)h->cent->B * SC_N, out); });
     return guarded([&] { h->eng->get_linear(h->eng->buf.scal, (size_t)h->eng->B * SC_N, out); });
   }
   int smpc_get_cold_trace(smpc_handle * h, double * out, int cap)
   {
-    const int n = h->eng->cold_iters;
+    const int n = h->cent ? h->cent->cold_iters : h->eng->cold_iters;
+    const std::vector<double> & tr = h->cent ? h->cent->cold_trace : h->eng->cold_trace;
     for (int i = 0; i < n && i < cap; i++)
       for (int k = 0; k < 4; k++)
-        out[i * 4 + k] = h->eng->cold_trace[(size_t)i * 4 + k];
+        out[i * 4 + k] = tr[(size_t)i * 4 + k];
     return n;
   }
   int smpc_lq_size(const smpc_handle *) { return DimsGo2::LQ_STRIDE; }
   int smpc_debug_get_lq(smpc_handle * h, int inst, int t, double * out)
   {
+    if (h && h->cent)
+      return fail(SMPC_ERR_INVALID, KINO_ONLY);
     if (!h || inst < 0 || inst >= h->eng->B || t < 0 || t >= h->eng->H)
       return fail(SMPC_ERR_INVALID, "Stage index exceeds stage vector size");
     return guarded([&] {
@@ -264,6 +391,12 @@ extern "C"
   }
   int smpc_debug_get_steps(smpc_handle * h, double * dxs, double * dus)
   {
+    if (h && h->cent)
+      return guarded([&] {
+        auto & e = *h->cent;
+        e.get_linear(e.buf.dxs, (size_t)e.B * (e.H + 1) * 9, dxs);
+        e.get_linear(e.buf.dus, (size_t)e.B * e.H * CentGo2::NU, dus);
+      });
     return guarded([&] {
       auto & e = *h->eng;
       e.get_linear(e.buf.dxs, (size_t)e.B * (e.H + 1) * DimsGo2::NDX, dxs);
@@ -272,6 +405,8 @@ extern "C"
   }
   int smpc_debug_get_terminal(smpc_handle * h, int inst, double * QN, double * qN)
   {
+    if (h && h->cent)
+      return fail(SMPC_ERR_INVALID, KINO_ONLY);
     if (!h || inst < 0 || inst >= h->eng->B)
       return fail(SMPC_ERR_INVALID, "instance index out of range");
     return guarded([&] {
@@ -282,17 +417,30 @@ extern "C"
   }
   int smpc_debug_get_phase_cycles(smpc_handle * h, double * out64)
   {
-    if (!h || !h->eng->buf.dbg)
+    if (!h || h->cent || !h->eng->buf.dbg)
       return fail(SMPC_ERR_INVALID, "phase timers are off (set SMPC_PHASE_PROFILE=1 before smpc_create)");
     return guarded([&] { h->eng->get_linear(h->eng->buf.dbg, 64, out64); });
   }
   int smpc_set_profiling(smpc_handle * h, int en)
   {
-    h->eng->profiling = en != 0;
+    if (h->cent)
+      h->cent->profiling = en != 0;
+    else
+      h->eng->profiling = en != 0;
     return SMPC_OK;
   }
   int smpc_get_kernel_times(smpc_handle * h, double * ms, long * calls)
   {
+    if (h->cent)
+      return guarded([&] {
+        // centroidal handle: slot 0 = front-end kernel, slot 1 = the fused control-step kernel
+        h->cent->collect_profile();
+        for (int i = 0; i < KID_N; i++)
+        {
+          ms[i] = i < CKID_N ? h->cent->kernel_ms[i] : 0.0;
+          calls[i] = i < CKID_N ? h->cent->kernel_calls[i] : 0;
+        }
+      });
     return guarded([&] {
       h->eng->collect_profile();
       for (int i = 0; i < KID_N; i++)
@@ -304,6 +452,15 @@ extern "C"
   }
   int smpc_reset_kernel_times(smpc_handle * h)
   {
+    if (h->cent)
+      return guarded([&] {
+        h->cent->collect_profile();
+        for (int i = 0; i < CKID_N; i++)
+        {
+          h->cent->kernel_ms[i] = 0;
+          h->cent->kernel_calls[i] = 0;
+        }
+      });
     return guarded([&] {
       h->eng->collect_profile();
       for (int i = 0; i < KID_N; i++)
@@ -317,18 +474,24 @@ extern "C"
   {
     if (!h || !X)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return fail(SMPC_ERR_INVALID, KINO_ONLY);
     return guarded([&] { h->eng->update_internal_data(X, feet, com, hg, centroidal_state); });
   }
   int smpc_riccati_feedback(smpc_handle * h, double delay, const double * X_meas, double * u_out)
   {
     if (!h || !X_meas || !u_out)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return fail(SMPC_ERR_INVALID, KINO_ONLY);
     return guarded([&] { h->eng->riccati_feedback(delay, X_meas, u_out); });
   }
   int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, double * acc_out, double * force_out)
   {
     if (!h)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return fail(SMPC_ERR_INVALID, KINO_ONLY);
     return guarded([&] { h->eng->interpolate(delay, knots, x_out, acc_out, force_out); });
   }
   int smpc_interpolate_knots(int kind, double delay, double timestep, const double * knots, int n, int dim, double * out, int device_id)

@@ -1,0 +1,415 @@
+// smpc_cent_engine.h -- host side of the batched centroidal MPC: the reference's MPC class (smpc_engine.h cites it line
+// by line) over a CentroidalOCP (reference src/centroidal-dynamics.cpp).  One control step = two launches:
+//   frontend_body   measured multibody states -> getCentroidalState + foot positions (src/mpc.cpp:192,200)
+//   cent_step_body  recede + references + k ProxDDP iterations, one wavefront per instance (smpc_cent_kernels.h)
+// What differs from the kinodynamics host logic (reference file:line in oracle/orc_mpc_cent.hpp's header): the problem
+// state is the centroidal state, foot references are contact positions, velocity references are momenta (m v),
+// x_reference_ starts at zero, the default problem has contact positions at the origin, no terminal constraint.
+#pragma once
+#include "smpc_cent_kernels.h"
+#include "smpc_engine.h"
+
+namespace smpc
+{
+  struct HostCentSettings // include/simple-mpc/centroidal-dynamics.hpp:27-43
+  {
+    double timestep;
+    std::vector<double> w_u, w_com, w_linear_mom, w_angular_mom, w_linear_acc, w_angular_acc;
+    double gravity[3];
+    double mu;
+  };
+
+  enum CentKernelId
+  {
+    CKID_FRONTEND = 0,
+    CKID_STEP,
+    CKID_N
+  };
+
+  // DK: Dims of the multibody robot (front-end FK), DC: CentDims
+  template <class DK, class DC>
+  class CentEngine
+  {
+  public:
+    CentBuffers<DC> buf;
+    Buffers<DK> fk; // only .model is used (front-end kernel)
+    int B, H, R, head = 0;
+    HostMpcSettings ms;
+    std::vector<CentStage<DC>> horizon, cycle;
+    CentStage<DC> standing;
+    GaitTimer timer;
+    bool walking = true;
+    double velocity_base[6] = {0, 0, 0, 0, 0, 0};
+    double x_reference[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double com_ref_member[3] = {0, 0, 0}; // CentroidalOCP::com_ref_ (last setPoseBase)
+    double mass;
+    std::vector<double> x_model_ref;
+    stream_t stream;
+    double *X_dev = nullptr, *cstate_dev = nullptr, *feet_dev = nullptr;
+    int cold_iters = 0;
+    std::vector<double> cold_trace;
+    bool profiling = false;
+    double kernel_ms[CKID_N] = {0};
+    long kernel_calls[CKID_N] = {0};
+    std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
+    static constexpr double ARMIJO_C1 = 1e-4, REG_INIT = 1e-9, REG_MIN = 1e-10, REG_MAX = 1e9, REG_INC = 10.0, REG_DEC = 1.0 / 3.0, STALL_REL = 1e-9;
+
+    CentEngine(const smpc_robot_model * rm, const HostCentSettings & cs, const HostMpcSettings & ms_, int batch, double gravity_arg, int device)
+    : ms(ms_)
+    {
+      if (batch <= 0)
+        throw std::runtime_error("batch must be positive");
+      if ((int)cs.w_u.size() != DC::NU * DC::NU || cs.w_com.size() != 9 || cs.w_linear_mom.size() != 9 || cs.w_angular_mom.size() != 9
+          || cs.w_linear_acc.size() != 9 || cs.w_angular_acc.size() != 9)
+        throw std::runtime_error("centroidal settings: weight sizes do not match the robot");
+      if (ms.T < 2)
+        throw std::runtime_error("horizon must have at least 2 stages");
+      set_device(device);
+      stream = stream_create();
+      B = batch;
+      H = ms.T;
+      R = H + 1;
+      mass = rm->total_mass;
+      // ---- models ----
+      std::vector<DevModel<DK>> hk(1);
+      std::memset(&hk[0], 0, sizeof(DevModel<DK>));
+      fill_tree_model<DK>(rm, hk[0]);
+      fk.model = (DevModel<DK> *)dev_alloc(sizeof(DevModel<DK>));
+      h2d(fk.model, hk.data(), sizeof(DevModel<DK>), stream);
+      std::vector<CentDevModel<DC>> hc(1);
+      CentDevModel<DC> & m = hc[0];
+      std::memset(&m, 0, sizeof(m));
+      m.mass = mass;
+      m.dt = cs.timestep;
+      m.mu = ms.mu_init;
+      m.mu_fric = cs.mu;
+      m.cone_eps = 1e-4; // src/centroidal-dynamics.cpp:96
+      for (int i = 0; i < 3; i++)
+        m.gravity[i] = cs.gravity[i];
+      std::copy(cs.w_com.begin(), cs.w_com.end(), m.w_com);
+      std::copy(cs.w_linear_mom.begin(), cs.w_linear_mom.end(), m.w_lm);
+      std::copy(cs.w_angular_mom.begin(), cs.w_angular_mom.end(), m.w_am);
+      std::copy(cs.w_linear_acc.begin(), cs.w_linear_acc.end(), m.w_la);
+      std::copy(cs.w_angular_acc.begin(), cs.w_angular_acc.end(), m.w_aa);
+      std::copy(cs.w_u.begin(), cs.w_u.end(), m.w_u);
+      for (int f = 0; f < DC::NF; f++)
+        for (int i = 0; i < 3; i++)
+          m.foot_ref_p[f][i] = rm->foot_ref_p[f][i];
+      // ---- buffers ----
+      buf.B = B;
+      buf.H = H;
+      buf.R = R;
+      auto dalloc = [&](size_t n) { return (double *)dev_alloc(n * sizeof(double)); };
+      const size_t BR = (size_t)B * R, BH = (size_t)B * H;
+      buf.xs = dalloc(BR * 9);
+      buf.us = dalloc(BR * DC::NU);
+      buf.vs = dalloc(BR * DC::NC);
+      buf.lams = dalloc(BR * 9);
+      buf.vs_e = dalloc(BR * DC::NC);
+      buf.lams_e = dalloc(BR * 9);
+      buf.dxs = dalloc((size_t)B * (H + 1) * 9);
+      buf.dus = dalloc(BH * DC::NU);
+      buf.dvs = dalloc(BH * DC::NC);
+      buf.dlams = dalloc(BH * 9);
+      buf.foot = dalloc(BH * DC::NF * 3);
+      buf.ftraj = dalloc((size_t)B * DC::NF * 6);
+      buf.gains = dalloc(BH * DC::G_STRIDE);
+      buf.scal = dalloc((size_t)B * SC_N);
+      buf.xdot01 = dalloc((size_t)B * 18);
+      buf.zeros = dalloc(64);
+      buf.stages = (CentStage<DC> *)dev_alloc((size_t)H * sizeof(CentStage<DC>));
+      buf.model = (CentDevModel<DC> *)dev_alloc(sizeof(CentDevModel<DC>));
+      X_dev = dalloc((size_t)B * DK::NX);
+      cstate_dev = dalloc((size_t)B * 9);
+      feet_dev = dalloc((size_t)B * DC::NF * 3);
+      h2d(buf.model, hc.data(), sizeof(CentDevModel<DC>), stream);
+      stream_sync(stream);
+      x_model_ref.assign(DK::NX, 0.0);
+      for (int i = 0; i < DK::NQ; i++)
+        x_model_ref[i] = rm->q_ref[i];
+
+      // ---- default problem (OCPHandler::createProblem, src/ocp-handler.cpp:96-137): all feet in contact, identity
+      //      contact poses, zero references ----
+      CentStage<DC> def;
+      std::memset(&def, 0, sizeof(def));
+      def.mask = (1u << DC::NF) - 1u;
+      for (int f = 0; f < DC::NF; f++)
+        def.u_ref[3 * f + 2] = -mass * gravity_arg / (double)DC::NF;
+      horizon.assign(H, def);
+      standing = def;
+      cold_solve(def);
+    }
+    ~CentEngine()
+    {
+      for (double * p : {buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot, buf.ftraj, buf.gains, buf.scal, buf.xdot01,
+                         buf.zeros, X_dev, cstate_dev, feet_dev, stage_out})
+        dev_free(p);
+      dev_free(buf.stages);
+      dev_free(buf.model);
+      dev_free(fk.model);
+      stream_destroy(stream);
+    }
+    CentEngine(const CentEngine &) = delete;
+    CentEngine & operator=(const CentEngine &) = delete;
+
+    template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1>
+    void timed_launch(int kid, int grid, const Args & a, bool aux = false)
+    {
+      event_t e0{}, e1{};
+      if (profiling)
+      {
+        e0 = event_create();
+        e1 = event_create();
+        event_record(e0, stream);
+      }
+      if (aux)
+        launch<Args, Body, NT, MINW, 1>(grid, stream, a);
+      else
+        launch<Args, Body, NT, MINW, 0>(grid, stream, a);
+      if (profiling)
+      {
+        event_record(e1, stream);
+        pending_events.push_back({kid, {e0, e1}});
+      }
+      kernel_calls[kid]++;
+    }
+    void collect_profile()
+    {
+      stream_sync(stream);
+      for (auto & pe : pending_events)
+      {
+        kernel_ms[pe.first] += event_elapsed_ms(pe.second.first, pe.second.second);
+        event_destroy(pe.second.first);
+        event_destroy(pe.second.second);
+      }
+      pending_events.clear();
+    }
+
+    void upload_stages()
+    {
+      h2d(buf.stages, horizon.data(), (size_t)H * sizeof(CentStage<DC>), stream);
+    }
+    void launch_frontend(const double * Xd, bool aux = false)
+    {
+      FrontendArgs<DK> fa;
+      fa.b = fk;
+      fa.X = Xd;
+      fa.feet = feet_dev;
+      fa.com = nullptr;
+      fa.hg = nullptr;
+      fa.cstate = cstate_dev;
+      timed_launch<FrontendArgs<DK>, frontend_body<DK>, 64>(CKID_FRONTEND, B, fa, aux);
+    }
+    CentStepArgs<DC> step_args(const double * Xd) const
+    {
+      CentStepArgs<DC> a;
+      a.b = buf;
+      a.head = head;
+      a.shift = 0;
+      a.set_centres = 0;
+      a.reset_preg = 0;
+      a.iters = 1;
+      a.X = Xd;
+      a.nx_mb = DK::NX;
+      a.cstate = cstate_dev;
+      a.feet = feet_dev;
+      for (int f = 0; f < DC::NF; f++)
+        a.land[f] = -1;
+      a.T_fly = ms.T_fly;
+      a.T_contact = ms.T_contact;
+      a.swing_apex = ms.swing_apex;
+      a.timestep = ms.timestep;
+      for (int i = 0; i < 6; i++)
+        a.vbase[i] = velocity_base[i];
+      a.armijo_c1 = ARMIJO_C1;
+      a.reg_init = REG_INIT;
+      a.reg_min = REG_MIN;
+      a.reg_max = REG_MAX;
+      a.reg_inc = REG_INC;
+      a.reg_dec = REG_DEC;
+      return a;
+    }
+
+    // MPC constructor (src/mpc.cpp:62-91): every instance starts from the solution of the default problem at the
+    // reference state.  All B wavefronts run the same cold solve (it is identical work, and cheaper than a broadcast).
+    void cold_solve(const CentStage<DC> & def)
+    {
+      std::vector<double> X((size_t)B * DK::NX);
+      for (int b = 0; b < B; b++)
+        std::copy(x_model_ref.begin(), x_model_ref.end(), X.begin() + (size_t)b * DK::NX);
+      h2d(X_dev, X.data(), X.size() * sizeof(double), stream);
+      launch_frontend(X_dev, true);
+      std::vector<double> cst((size_t)B * 9), feet((size_t)B * DC::NF * 3);
+      d2h(cst.data(), cstate_dev, cst.size() * sizeof(double), stream);
+      d2h(feet.data(), feet_dev, feet.size() * sizeof(double), stream);
+      stream_sync(stream);
+      std::vector<double> xs((size_t)B * R * 9), us((size_t)B * R * DC::NU), ft((size_t)B * DC::NF * 6);
+      for (int b = 0; b < B; b++)
+      {
+        for (int t = 0; t < R; t++)
+        {
+          std::copy(cst.begin() + (size_t)b * 9, cst.begin() + (size_t)(b + 1) * 9, xs.begin() + ((size_t)b * R + t) * 9);
+          std::copy(def.u_ref, def.u_ref + DC::NU, us.begin() + ((size_t)b * R + t) * DC::NU);
+        }
+        for (int f = 0; f < DC::NF; f++)
+          for (int i = 0; i < 3; i++)
+            ft[((size_t)b * DC::NF + f) * 6 + i] = ft[((size_t)b * DC::NF + f) * 6 + 3 + i] = feet[((size_t)b * DC::NF + f) * 3 + i];
+      }
+      h2d(buf.xs, xs.data(), xs.size() * sizeof(double), stream);
+      h2d(buf.us, us.data(), us.size() * sizeof(double), stream);
+      h2d(buf.ftraj, ft.data(), ft.size() * sizeof(double), stream);
+      upload_stages();
+      stream_sync(stream);
+      bool centres = true;
+      std::vector<double> sc(SC_N);
+      for (int it = 0; it < 100; it++)
+      {
+        CentStepArgs<DC> a = step_args(X_dev);
+        a.set_centres = centres ? 1 : 0;
+        a.reset_preg = it == 0 ? 1 : 0;
+        timed_launch<CentStepArgs<DC>, cent_step_body<DC>, 64, 2>(CKID_STEP, B, a, true);
+        d2h(sc.data(), buf.scal, SC_N * sizeof(double), stream);
+        stream_sync(stream);
+        cold_iters = it + 1;
+        cold_trace.insert(cold_trace.end(), {sc[SC_PHI0], sc[SC_PRIM], sc[SC_DUAL], sc[SC_ALPHA]});
+        centres = false;
+        if (std::fmax(sc[SC_PRIM], sc[SC_DUAL]) <= ms.TOL)
+          break;
+        if (std::fabs(sc[SC_DPHI0]) <= STALL_REL * std::fmax(1.0, std::fabs(sc[SC_PHI0])))
+          break;
+        if (sc[SC_DUAL] <= ms.TOL)
+          centres = true;
+      }
+      kernel_calls[CKID_FRONTEND] = kernel_calls[CKID_STEP] = 0;
+    }
+
+    void generate_cycle_horizon(const unsigned char * cs, int n)
+    {
+      if (n <= 0)
+        throw std::runtime_error("contact sequence must not be empty");
+      timer.generate(cs, n, DC::NF, H);
+      cycle.clear();
+      for (auto & st : timer.states)
+      {
+        int active = 0;
+        for (int f = 0; f < DC::NF; f++)
+          active += st[f] ? 1 : 0;
+        CentStage<DC> s;
+        std::memset(&s, 0, sizeof(s));
+        for (int f = 0; f < DC::NF; f++)
+          if (st[f])
+          {
+            s.mask |= 1u << f;
+            s.u_ref[3 * f + 2] = ms.support_force / (double)active;
+          }
+        for (int i = 0; i < 3; i++)
+          s.x_tgt[i] = com_ref_member[i];
+        cycle.push_back(s);
+      }
+    }
+    void switch_to_walk(const double * v6)
+    {
+      walking = true;
+      for (int i = 0; i < 6; i++)
+        velocity_base[i] = v6[i];
+    }
+    void switch_to_stand()
+    {
+      walking = false;
+      for (int i = 0; i < 6; i++)
+        velocity_base[i] = 0.0;
+    }
+
+    void iterate_device(const double * Xd)
+    {
+      if (cycle.empty())
+        throw std::runtime_error("generateCycleHorizon must be called before iterate");
+      int last_support = 0;
+      for (int f = 0; f < DC::NF; f++)
+        last_support += (horizon[H - 1].mask >> f) & 1u;
+      CentStage<DC> incoming;
+      if (walking || last_support < DC::NF)
+      {
+        incoming = cycle[0];
+        std::rotate(cycle.begin(), cycle.begin() + 1, cycle.end());
+        timer.recede_cycle();
+      }
+      else
+      {
+        incoming = standing;
+        timer.update_timing(true);
+      }
+      horizon.erase(horizon.begin());
+      horizon.push_back(incoming);
+      // setReferenceState(H-1, x_reference_) ; setVelocityBase(H-1, velocity_base_): momentum references are m v
+      for (int i = 0; i < 3; i++)
+      {
+        horizon[H - 1].x_tgt[i] = x_reference[i];
+        com_ref_member[i] = x_reference[i];
+        horizon[H - 1].x_tgt[3 + i] = mass * velocity_base[i];
+        horizon[H - 1].x_tgt[6 + i] = mass * velocity_base[3 + i];
+      }
+      upload_stages();
+      head = head + 1 == R ? 0 : head + 1;
+      launch_frontend(Xd);
+      CentStepArgs<DC> a = step_args(Xd);
+      a.shift = 1;
+      a.set_centres = 1;
+      a.reset_preg = 1;
+      a.iters = ms.max_iters;
+      for (int f = 0; f < DC::NF; f++)
+        a.land[f] = timer.land[f].empty() ? -1 : timer.land[f][0];
+      timed_launch<CentStepArgs<DC>, cent_step_body<DC>, 64, 2>(CKID_STEP, B, a);
+    }
+    void iterate_host(const double * X)
+    {
+      h2d(X_dev, X, (size_t)B * DK::NX * sizeof(double), stream);
+      iterate_device(X_dev);
+      stream_sync(stream);
+    }
+    void sync() { stream_sync(stream); }
+
+    double * stage_out = nullptr;
+    size_t stage_out_bytes = 0;
+    double * staging(size_t bytes)
+    {
+      if (bytes > stage_out_bytes)
+      {
+        stream_sync(stream);
+        dev_free(stage_out);
+        stage_out = (double *)dev_alloc(bytes);
+        stage_out_bytes = bytes;
+      }
+      return stage_out;
+    }
+    void get_ring(const double * src, int n, int count, double * out)
+    {
+      stream_sync(stream);
+      std::vector<double> tmp((size_t)B * R * n);
+      d2h(tmp.data(), src, tmp.size() * sizeof(double), stream);
+      stream_sync(stream);
+      for (int b = 0; b < B; b++)
+        for (int t = 0; t < count; t++)
+          std::memcpy(out + ((size_t)b * count + t) * n, tmp.data() + ((size_t)b * R + ring_slot(head, t, R)) * n, n * sizeof(double));
+    }
+    void get_linear(const double * src, size_t n, double * out)
+    {
+      stream_sync(stream);
+      d2h(out, src, n * sizeof(double), stream);
+      stream_sync(stream);
+    }
+    void get_K(double * out, bool all)
+    {
+      const int nt = all ? H : 1;
+      const size_t n = (size_t)B * nt * DC::NU * 9;
+      double * dev = staging(n * sizeof(double));
+      CentGainsOutArgs<DC> ga;
+      ga.b = buf;
+      ga.out = dev;
+      ga.all = all ? 1 : 0;
+      launch<CentGainsOutArgs<DC>, cent_gains_out_body<DC>, 64>(B * nt, stream, ga);
+      d2h(out, dev, n * sizeof(double), stream);
+      stream_sync(stream);
+    }
+  };
+} // namespace smpc

@@ -1,0 +1,1179 @@
+// smpc_cent_kernels.h -- the centroidal OCP (BASELINE config "Go2 centroidal (9-dim state), H = 50") as ONE fused
+// kernel per control step: one wavefront per MPC instance runs the whole of MPC::iterate's solver part
+// (reference src/mpc.cpp:189-218 over a CentroidalOCP, src/centroidal-dynamics.cpp:39-106, 306-316):
+//   recede (ring advance, warm-start shift, Raibert foothold + Bezier swing references -> contact positions)
+//   k ProxDDP iterations, each:
+//     backward  t = H-1 .. 0 : stage evaluation + derivatives + LQ knot, built in LDS from the iterate; proximal Riccati
+//                              step as two symmetric block sweeps on the FP64 matrix cores (wave_block_sweep):
+//                              [[I + mu P, sqrt(mu) P, sqrt(mu) pt0], [., P, pt0]]      -> P~, p~        (9 pivots)
+//                              [[R^, D^T, S^^T, r^], [D, -mu I, C, d], [., ., Q^, q^]]  -> K, k, Z, z, P_t, p_t
+//                              (the stage KKT matrix is quasi-definite: the friction-cone rows have D != 0, so the
+//                               multiplier block is pivoted explicitly instead of folding D^T D / mu into R^)
+//     forward   t = 0 .. H-1 : (dx, du, dnu, dlam) and the directional derivative of the merit
+//     line search            : lane = stage trial evaluations, Armijo backtracking (alpha = 1, 1/2, ..)
+//   The stage matrices are 9 x 9 / 9 x 12: nothing but the per-stage gains leaves the CU between the phases of an
+//   iteration (gains go through L2 to the forward pass).  Algorithm and constants: oracle/orc_proxddp.hpp restates
+//   them; SURVEY App. B.1, B.4, B.5.
+#pragma once
+#include "smpc_riccati_kino.h"
+#include "smpc_solver_kernels.h"
+
+namespace smpc
+{
+  template <int NF_>
+  struct CentDims
+  {
+    static constexpr int NF = NF_;
+    static constexpr int NX = 9, NDX = 9;
+    static constexpr int NU = 3 * NF_;
+    static constexpr int NC = 2 * NF_;            // rows 2f, 2f+1: friction-cone block of foot f
+    static constexpr int NUP = (NU + 3) / 4 * 4;  // pivot panels are 4 wide: pad rows are decoupled unit pivots
+    static constexpr int NCP = (NC + 3) / 4 * 4;
+    static constexpr int VO = NUP;                // sweep 2 index space: u | nu | x | vector column
+    static constexpr int XO = NUP + NCP;
+    static constexpr int ZC = XO + 9;
+    static constexpr int NP2 = (NUP + NCP) / 4;
+    static constexpr int X1 = 12, Z1 = 21;        // sweep 1 index space: 9 pivots (+3 pad) | x | vector column
+    static constexpr int LDM = 32;
+    static_assert(ZC < LDM, "the stage KKT matrix must fit two 16 x 16 tile rows");
+    // per (instance, stage) record written by the backward pass for the forward pass
+    static constexpr int G_K = 0;                 // [K | k]  NU x 10
+    static constexpr int G_Z = G_K + NU * 10;     // [Z | z]  NC x 10
+    static constexpr int G_Pt = G_Z + NC * 10;    // P~_{t+1} 9 x 9
+    static constexpr int G_pn = G_Pt + 81;        // p_{t+1}
+    static constexpr int G_fs = G_pn + 9;         // sum of the active forces (A = I + dt [[0, I/m, 0], [0], [[fs]x, 0, 0]])
+    static constexpr int G_r = G_fs + 3;          // act_f (p_f - c) per foot (B rows of the angular momentum)
+    static constexpr int G_act = G_r + 3 * NF;    // contact flags as 0 / 1
+    static constexpr int G_f = G_act + NF;        // mu (lam+ - lam)
+    static constexpr int G_gx = G_f + 9;          // lx + A^T (2 lam+ - lam)
+    static constexpr int G_gu = G_gx + 9;         // lu + B^T (2 lam+ - lam) + Cu^T vpd
+    static constexpr int G_lpd = G_gu + NU;       // 2 lam+ - lam
+    static constexpr int G_d = G_lpd + 9;         // mu (nu+ - nu)
+    static constexpr int G_N = G_d + NC;
+    static constexpr int G_REGS = (G_N + 63) / 64;
+    static constexpr int G_STRIDE = G_REGS * 64;
+    // stage inputs gathered one stage ahead by the backward pass
+    static constexpr int I_x = 0, I_xn = 9, I_l1 = 18, I_l1e = 27, I_l0 = 36, I_u = 45, I_v = I_u + NU, I_ve = I_v + NC;
+    static constexpr int I_p = I_ve + NC, I_ur = I_p + 3 * NF, I_xt = I_ur + NU, I_N = I_xt + 9;
+    static constexpr int I_REGS = (I_N + 63) / 64;
+    static constexpr int LS_N = 10;
+  };
+
+  template <class D>
+  struct CentDevModel
+  {
+    double mass, dt, mu, mu_fric, cone_eps, pad_;
+    double gravity[3];
+    double w_com[9], w_lm[9], w_am[9], w_la[9], w_aa[9];
+    double w_u[D::NU * D::NU];
+    double foot_ref_p[D::NF][3];
+  };
+  template <class D>
+  struct CentStage // shared by the batch (phase-aligned), one per horizon stage
+  {
+    unsigned mask, pad;
+    double u_ref[D::NU];
+    double x_tgt[9]; // [com_ref; h_ref; L_ref]
+  };
+  template <class D>
+  struct CentBuffers
+  {
+    int B = 0, H = 0, R = 0;
+    double *xs = nullptr, *us = nullptr, *vs = nullptr, *lams = nullptr; // rings [B][R][.]; lams[slot(t)] = lambda_{t+1}
+    double *vs_e = nullptr, *lams_e = nullptr;
+    double *dxs = nullptr, *dus = nullptr, *dvs = nullptr, *dlams = nullptr; // [B][H+1][9], [B][H][.] linear in t
+    double * foot = nullptr;   // [B][H][NF*3] contact positions (MPC::setReferencePose -> contact map)
+    double * ftraj = nullptr;  // [B][NF][6] swing start / end
+    double * gains = nullptr;  // [B][H][G_STRIDE]
+    double * scal = nullptr;   // [B][SC_N]
+    double * xdot01 = nullptr; // [B][2][9]
+    double * zeros = nullptr;  // [64] zeros (address target of masked-out prefetch slots)
+    CentStage<D> * stages = nullptr;
+    CentDevModel<D> * model = nullptr;
+  };
+  template <class D>
+  struct CentStepArgs
+  {
+    CentBuffers<D> b;
+    int head;
+    int shift;        // 1: control step (warm-start shift at the new head, references); 0: iterate in place (cold solve)
+    int set_centres;  // 1: AL centres := current multipliers
+    int reset_preg;   // 1: regularisation restarts (every solver run of the MPC)
+    int iters;
+    const double * X; // [B][nx_mb] measured multibody states (base pose for the Raibert heuristic)
+    int nx_mb;
+    const double * cstate; // [B][9]  getCentroidalState of the measured state (front-end kernel)
+    const double * feet;   // [B][NF*3] measured foot positions (front-end kernel)
+    int land[D::NF];
+    int T_fly, T_contact;
+    double swing_apex, timestep;
+    double vbase[6];
+    double armijo_c1, reg_init, reg_min, reg_max, reg_inc, reg_dec;
+  };
+
+  template <class D>
+  struct CentLds
+  {
+    static constexpr int NU = D::NU, NC = D::NC, NF = D::NF;
+    CentDevModel<D> md;
+    double in[D::I_REGS * 64];       // stage inputs (I_* offsets)
+    double P[81], p[9], Pt[81], pt[9], pt0[9];
+    double ABp[9 * D::LDM];          // [A B] in sweep-2 column order (B at 0, A at XO)
+    double M[D::LDM * D::LDM];       // bordered matrix of the current sweep (built here, swept in registers)
+    double prow[4 * D::LDM], urow[4 * D::LDM];
+    double fs[3], ts[3], rf[3 * NF], act[NF], Cu[NC * 3], cact[NC];
+    double f[9], dvec[NC], lpd[9], vpd[NC];
+    double ru[NU], rx[9], rla[3], N[NF * 9], G[9], wla[3], waa[3], wrx[9], wu[NU];
+    double lx[9], lu[NU], q[9], r[NU], gxp[9], gu[NU];
+    double rec[D::G_STRIDE];         // forward pass: record of the current stage
+    double dx[9], du[NU], dv[NC], y[9], w[9];
+    double red[64];
+    double sc[16];
+  };
+
+  SMPC_HD double skew_el(V3 v, int a, int b)
+  {
+    // [v]x (a, b)
+    if (a == b)
+      return 0.0;
+    const int k = 3 - a - b; // the remaining axis
+    const double c = k == 0 ? v.x : (k == 1 ? v.y : v.z);
+    const bool pos = (a == 0 && b == 2) || (a == 1 && b == 0) || (a == 2 && b == 1);
+    return pos ? c : -c;
+  }
+
+  // deterministic wave reduction of a per-lane value through LDS: red[lane] then lane 0 folds in lane order
+  template <bool MAX>
+  SMPC_DEV double fold64(const double * red)
+  {
+    double a = red[0];
+    for (int i = 1; i < 64; i++)
+      a = MAX ? fmax(a, red[i]) : a + red[i];
+    return a;
+  }
+
+  // Stage merit terms at a point (each lane evaluates one whole stage: used by the line search).
+  // Returns cost, penalty and primal infeasibility of stage t; xdot optionally.
+  template <class D>
+  SMPC_DEV void cent_stage_merit(
+    const CentDevModel<D> & md, unsigned mask, const double * x, const double * u, const double * xn, const double * v, const double * ve,
+    const double * l1, const double * l1e, const double * p, const double * uref, const double * xtgt, double & cost, double & pen,
+    double & prim, double * xdot)
+  {
+    constexpr int NF = D::NF, NU = D::NU;
+    const V3 c = ld3(x), h = ld3(x + 3), L = ld3(x + 6);
+    V3 fs = mk3(0, 0, 0), ts = mk3(0, 0, 0);
+    pen = 0.0;
+    prim = 0.0;
+    for (int f = 0; f < NF; f++)
+    {
+      const bool on = (mask >> f) & 1u;
+      const V3 F = ld3(u + 3 * f);
+      double vp0 = 0.0, vp1 = 0.0;
+      if (on)
+      {
+        fs = fs + F;
+        ts = ts + cross(ld3(p + 3 * f) - c, F);
+        const double c0 = -F.z + md.cone_eps, c1 = F.x * F.x + F.y * F.y - md.mu_fric * md.mu_fric * F.z * F.z;
+        const double z0 = c0 + md.mu * ve[2 * f], z1 = c1 + md.mu * ve[2 * f + 1];
+        vp0 = (z0 - fmin(z0, 0.0)) / md.mu;
+        vp1 = (z1 - fmin(z1, 0.0)) / md.mu;
+        prim = fmax(prim, fmax(fmax(c0, 0.0), fmax(c1, 0.0)));
+      }
+      const double d0 = vp0 - v[2 * f], d1 = vp1 - v[2 * f + 1];
+      pen += 0.5 * md.mu * (vp0 * vp0 + d0 * d0);
+      pen += 0.5 * md.mu * (vp1 * vp1 + d1 * d1);
+    }
+    const V3 g = ld3(md.gravity);
+    double xd[9];
+    xd[0] = h.x / md.mass;
+    xd[1] = h.y / md.mass;
+    xd[2] = h.z / md.mass;
+    xd[3] = md.mass * g.x + fs.x;
+    xd[4] = md.mass * g.y + fs.y;
+    xd[5] = md.mass * g.z + fs.z;
+    xd[6] = ts.x;
+    xd[7] = ts.y;
+    xd[8] = ts.z;
+    for (int i = 0; i < 9; i++)
+    {
+      const double e = x[i] + md.dt * xd[i] - xn[i];
+      const double lp = l1e[i] + e / md.mu, dl = lp - l1[i];
+      pen += 0.5 * md.mu * (lp * lp + dl * dl);
+      prim = fmax(prim, fabs(e));
+      if (xdot)
+        xdot[i] = xd[i];
+    }
+    auto quad3 = [](const double * W, V3 r) {
+      const V3 Wr = ldm3(W) * r;
+      return 0.5 * dot(r, Wr);
+    };
+    cost = quad3(md.w_com, c - ld3(xtgt));
+    double cu = 0.0;
+    for (int i = 0; i < NU; i++)
+    {
+      double wr = 0.0;
+      for (int j = 0; j < NU; j++)
+        wr += md.w_u[i * NU + j] * (u[j] - uref[j]);
+      cu += (u[i] - uref[i]) * wr;
+    }
+    cost += 0.5 * cu;
+    cost += quad3(md.w_lm, h - ld3(xtgt + 3));
+    cost += quad3(md.w_am, L - ld3(xtgt + 6));
+    cost += quad3(md.w_la, g + (1.0 / md.mass) * fs);
+    cost += quad3(md.w_aa, ts);
+  }
+
+  // address of stage-input slot s of stage t (backward-pass prefetch); masked-out slots read a zero
+  template <class D>
+  SMPC_DEV const double * cent_in_addr(const CentBuffers<D> & b, size_t inst, int head, int t, int s)
+  {
+    constexpr int NU = D::NU, NC = D::NC, NF = D::NF;
+    const int R = b.R, H = b.H;
+    const size_t ib = inst * R;
+    const int st = ring_slot(head, t, R), st1 = ring_slot(head, t + 1, R), stm = ring_slot(head, t > 0 ? t - 1 : 0, R);
+    const double * a = b.zeros;
+    if (s < D::I_xn)
+      a = b.xs + (ib + st) * 9 + s;
+    else if (s < D::I_l1)
+      a = b.xs + (ib + st1) * 9 + (s - D::I_xn);
+    else if (s < D::I_l1e)
+      a = b.lams + (ib + st) * 9 + (s - D::I_l1);
+    else if (s < D::I_l0)
+      a = b.lams_e + (ib + st) * 9 + (s - D::I_l1e);
+    else if (s < D::I_u)
+      a = t > 0 ? b.lams + (ib + stm) * 9 + (s - D::I_l0) : b.zeros;
+    else if (s < D::I_v)
+      a = b.us + (ib + st) * NU + (s - D::I_u);
+    else if (s < D::I_ve)
+      a = b.vs + (ib + st) * NC + (s - D::I_v);
+    else if (s < D::I_p)
+      a = b.vs_e + (ib + st) * NC + (s - D::I_ve);
+    else if (s < D::I_ur)
+      a = b.foot + (inst * H + t) * (3 * NF) + (s - D::I_p);
+    else if (s < D::I_xt)
+      a = b.stages[t].u_ref + (s - D::I_ur);
+    else if (s < D::I_N)
+      a = b.stages[t].x_tgt + (s - D::I_xt);
+    return a;
+  }
+
+  template <class D>
+  SMPC_DEV void cent_step_body(const CentStepArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NU = D::NU, NC = D::NC, NF = D::NF, LDM = D::LDM;
+    constexpr int NUP = D::NUP, VO = D::VO, XO = D::XO, ZC = D::ZC, X1 = D::X1, Z1 = D::Z1;
+    const CentBuffers<D> & b = ka.b;
+    const int H = b.H, R = b.R, head = ka.head;
+    const size_t inst = (size_t)block;
+    const size_t ib = inst * R;
+    SMPC_LDS(CentLds<D>, ldsv, 1);
+    CentLds<D> & s = ldsv[0];
+    long long tprev = 0;
+    double * gsc = b.scal + inst * SC_N;
+
+    // ---- model constants -> LDS ----
+    SMPC_LANES(NT)
+    {
+      constexpr int N = (int)(sizeof(CentDevModel<D>) / sizeof(double));
+      const double * src = reinterpret_cast<const double *>(b.model);
+      double * dst = reinterpret_cast<double *>(&s.md);
+      for (int i = lane; i < N; i += NT)
+        dst[i] = src[i];
+      if (lane < 16)
+        s.sc[lane] = lane == SC_PREG && !ka.reset_preg ? gsc[SC_PREG] : 0.0;
+    }
+    SMPC_LANES_END_WAVE
+    const CentDevModel<D> & md = s.md;
+    const double mu = md.mu, dt = md.dt, mass = md.mass;
+
+    // ---- recede: warm-start shift on the ring (src/mpc.cpp:201-207), references (src/mpc.cpp:278-309) ----
+    if (ka.shift)
+    {
+      const int s0 = ring_slot(head, 0, R), sHm1 = ring_slot(head, H - 1, R), sH = ring_slot(head, H, R), sHm2 = ring_slot(head, H - 2, R);
+      SMPC_LANES(NT)
+      {
+        if (lane < 9)
+        {
+          b.xs[(ib + s0) * 9 + lane] = ka.cstate[inst * 9 + lane];
+          b.xs[(ib + sH) * 9 + lane] = b.xs[(ib + sHm1) * 9 + lane];
+          b.lams[(ib + sHm1) * 9 + lane] = 0.0;
+        }
+        if (lane < NU)
+          b.us[(ib + sHm1) * NU + lane] = b.us[(ib + sHm2) * NU + lane];
+        if (lane < NC)
+          b.vs[(ib + sHm1) * NC + lane] = 0.0;
+        if (lane < NF)
+        {
+          const int f = lane;
+          const double * xm = ka.X + inst * ka.nx_mb;
+          const V3 pf = ld3(ka.feet + (inst * NF + f) * 3);
+          const V3 bp = ld3(xm);
+          const M3 Rb = quat_to_R(Quat{xm[3], xm[4], xm[5], xm[6]});
+          const V3 refp = Rb * ld3(md.foot_ref_p[f]) + bp;
+          const double tw0 = -(refp.y - bp.y), tw1 = refp.x - bp.x;
+          const double span = (double)(ka.T_fly + ka.T_contact) * ka.timestep;
+          const V3 next = mk3(refp.x + (ka.vbase[0] + ka.vbase[5] * tw0) * span, refp.y + (ka.vbase[1] + ka.vbase[5] * tw1) * span, pf.z);
+          double * ft = b.ftraj + (inst * NF + f) * 6;
+          if (!(ka.land[f] < ka.T_fly))
+          {
+            st3(ft, pf);
+            st3(ft + 3, next);
+          }
+          st3(&s.rec[f * 6], ld3(ft));
+          st3(&s.rec[f * 6 + 3], ld3(ft + 3));
+        }
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < H * NF; idx += NT)
+      {
+        const int k = idx / NF, f = idx % NF;
+        const int t = ka.land[f] - k;
+        const V3 p0 = ld3(&s.rec[f * 6]), p1 = ld3(&s.rec[f * 6 + 3]);
+        V3 p;
+        if (t < 0)
+          p = p1;
+        else if (t > ka.T_fly)
+          p = p0;
+        else
+          p = bezier8(p0, p1, ka.swing_apex, float(ka.T_fly - t) / float(ka.T_fly));
+        st3(b.foot + ((inst * H + k) * NF + f) * 3, p);
+      }
+      SMPC_LANES_END_WAVE
+    }
+    if (ka.set_centres)
+    {
+      SMPC_LANES(NT)
+      for (int t = lane; t < H; t += NT)
+      {
+        const size_t sl = ib + ring_slot(head, t, R);
+        for (int i = 0; i < NC; i++)
+          b.vs_e[sl * NC + i] = b.vs[sl * NC + i];
+        for (int i = 0; i < 9; i++)
+          b.lams_e[sl * 9 + i] = b.lams[sl * 9 + i];
+      }
+      SMPC_LANES_END_WAVE
+    }
+
+    SMPC_PL(double, acc_cost, NT);
+    SMPC_PL(double, acc_pen, NT);
+    SMPC_PL(double, acc_prim, NT);
+    SMPC_PL(double, acc_dual, NT);
+    SMPC_PL(double, acc_dphi, NT);
+    SMPC_PLA(double, pin, NT, D::I_REGS);
+    SMPC_PLA(double, prec, NT, D::G_REGS);
+    SMPC_ACC(macc, NT, 3);
+    SMPC_ACC(tacc, NT, 2);
+    SMPC_PLA(double, aop, NT, 6);
+    SMPC_PLA(double, pop, NT, 3);
+    SMPC_PLA(double, top, NT, 6);
+
+    for (int it = 0; it < ka.iters; it++)
+    {
+      const double preg = s.sc[SC_PREG] > 0.0 ? s.sc[SC_PREG] : ka.reg_init;
+      // =====================================================================================
+      // backward pass
+      // =====================================================================================
+      SMPC_LANES(NT)
+      {
+        SMPC_PLV(acc_cost) = 0.0;
+        SMPC_PLV(acc_pen) = 0.0;
+        SMPC_PLV(acc_prim) = 0.0;
+        SMPC_PLV(acc_dual) = 0.0;
+        // terminal node: P = Lxx_N + preg I, p = lx_N - lambda_H ; prefetch of stage H-1
+        const double * xH = b.xs + (ib + ring_slot(head, H, R)) * 9;
+        const double * lH = b.lams + (ib + ring_slot(head, H - 1, R)) * 9;
+#pragma unroll
+        for (int n = 0; n < D::I_REGS; n++)
+          SMPC_PLV(pin)[n] = *cent_in_addr<D>(b, inst, head, H - 1, lane + n * NT);
+        for (int idx = lane; idx < 81; idx += NT)
+        {
+          const int i = idx / 9, j = idx % 9;
+          double v = i == j ? preg : 0.0;
+          if (i >= 3 && i / 3 == j / 3)
+            v += (i < 6 ? md.w_lm : md.w_am)[(i % 3) * 3 + j % 3];
+          s.P[idx] = v;
+        }
+        if (lane < 9)
+        {
+          double g = 0.0;
+          if (lane >= 3)
+          {
+            const double * W = lane < 6 ? md.w_lm : md.w_am;
+            const int bo = lane < 6 ? 3 : 6;
+            for (int j = 0; j < 3; j++)
+              g += W[(lane - bo) * 3 + j] * xH[bo + j];
+          }
+          const double qn = g - lH[lane];
+          s.p[lane] = qn;
+          SMPC_PLV(acc_dual) = fabs(qn);
+        }
+        if (lane == 9)
+          SMPC_PLV(acc_cost) = 0.5 * dot(ld3(xH + 3), ldm3(md.w_lm) * ld3(xH + 3)) + 0.5 * dot(ld3(xH + 6), ldm3(md.w_am) * ld3(xH + 6));
+      }
+      SMPC_LANES_END_WAVE
+
+      for (int t = H - 1; t >= 0; t--)
+      {
+        const unsigned mask = b.stages[t].mask;
+        double * g = b.gains + (inst * H + t) * D::G_STRIDE;
+        // ---- stage inputs -> LDS ; prefetch of stage t-1 ----
+        SMPC_LANES(NT)
+        {
+#pragma unroll
+          for (int n = 0; n < D::I_REGS; n++)
+            s.in[lane + n * NT] = SMPC_PLV(pin)[n];
+          if (t > 0)
+          {
+#pragma unroll
+            for (int n = 0; n < D::I_REGS; n++)
+              SMPC_PLV(pin)[n] = *cent_in_addr<D>(b, inst, head, t - 1, lane + n * NT);
+          }
+          if (lane < 9)
+            g[D::G_pn + lane] = s.p[lane];
+        }
+        SMPC_LANES_END_WAVE
+        const double *x = s.in + D::I_x, *xn = s.in + D::I_xn, *l1 = s.in + D::I_l1, *l1e = s.in + D::I_l1e, *l0 = s.in + D::I_l0;
+        const double *u = s.in + D::I_u, *v = s.in + D::I_v, *ve = s.in + D::I_ve, *pp = s.in + D::I_p, *uref = s.in + D::I_ur, *xtgt = s.in + D::I_xt;
+        // ---- point quantities: forces, lever arms, defect, multiplier estimates ----
+        SMPC_LANES(NT)
+        {
+          const V3 c = ld3(x);
+          V3 fs = mk3(0, 0, 0), ts = mk3(0, 0, 0);
+#pragma unroll
+          for (int f = 0; f < NF; f++)
+            if ((mask >> f) & 1u)
+            {
+              const V3 F = ld3(u + 3 * f);
+              fs = fs + F;
+              ts = ts + cross(ld3(pp + 3 * f) - c, F);
+            }
+          if (lane < 9)
+          {
+            const V3 gv = ld3(md.gravity);
+            const int k = lane % 3;
+            const double hk = k == 0 ? x[3] : (k == 1 ? x[4] : x[5]);
+            const double fk = k == 0 ? fs.x : (k == 1 ? fs.y : fs.z);
+            const double tk = k == 0 ? ts.x : (k == 1 ? ts.y : ts.z);
+            const double gk = k == 0 ? gv.x : (k == 1 ? gv.y : gv.z);
+            const double xd = lane < 3 ? hk / mass : (lane < 6 ? mass * gk + fk : tk);
+            const double e = x[lane] + dt * xd - xn[lane];
+            const double lp = l1e[lane] + e / mu, dl = lp - l1[lane];
+            s.f[lane] = mu * dl;
+            s.lpd[lane] = 2.0 * lp - l1[lane];
+            SMPC_PLV(acc_pen) += 0.5 * mu * (lp * lp + dl * dl);
+            SMPC_PLV(acc_prim) = fmax(SMPC_PLV(acc_prim), fabs(e));
+            s.rx[lane] = x[lane] - xtgt[lane];
+            if (lane < 3)
+            {
+              s.fs[lane] = fk;
+              s.ts[lane] = tk;
+              s.rla[lane] = gk + fk / mass;
+            }
+          }
+          if (lane >= 16 && lane < 16 + NC)
+          {
+            const int row = lane - 16, f = row / 2;
+            const bool on = (mask >> f) & 1u;
+            const V3 F = ld3(u + 3 * f);
+            double vp = 0.0, act = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0;
+            if (on)
+            {
+              const bool cone = row & 1;
+              const double cv = cone ? F.x * F.x + F.y * F.y - md.mu_fric * md.mu_fric * F.z * F.z : -F.z + md.cone_eps;
+              const double z = cv + mu * ve[row];
+              const double proj = fmin(z, 0.0);
+              vp = (z - proj) / mu;
+              act = z != proj ? 1.0 : 0.0;
+              SMPC_PLV(acc_prim) = fmax(SMPC_PLV(acc_prim), fmax(cv, 0.0));
+              c0 = cone ? 2.0 * F.x : 0.0;
+              c1 = cone ? 2.0 * F.y : 0.0;
+              c2 = cone ? -2.0 * md.mu_fric * md.mu_fric * F.z : -1.0;
+            }
+            const double dv = vp - v[row];
+            s.dvec[row] = mu * dv;
+            s.vpd[row] = act != 0.0 ? 2.0 * vp - v[row] : 0.0;
+            s.cact[row] = act;
+            s.Cu[row * 3 + 0] = c0;
+            s.Cu[row * 3 + 1] = c1;
+            s.Cu[row * 3 + 2] = c2;
+            SMPC_PLV(acc_pen) += 0.5 * mu * (vp * vp + dv * dv);
+          }
+          if (lane >= 32 && lane < 32 + NU)
+            s.ru[lane - 32] = u[lane - 32] - uref[lane - 32];
+          if (lane >= 48 && lane < 48 + NF)
+          {
+            const int f = lane - 48;
+            const bool on = (mask >> f) & 1u;
+            const V3 r = ld3(pp + 3 * f) - c;
+            s.act[f] = on ? 1.0 : 0.0;
+            st3(&s.rf[3 * f], on ? r : mk3(0, 0, 0));
+          }
+        }
+        SMPC_LANES_END_WAVE
+        // ---- small products: N_f = W_aa [r_f]x, G = W_aa [fs]x, W r of every residual ----
+        SMPC_LANES(NT)
+        {
+          const V3 fsv = ld3(s.fs);
+          for (int item = lane; item < NF * 9 + 9 + 15 + NU; item += NT)
+          {
+            if (item < NF * 9)
+            {
+              const int f = item / 9, i = (item % 9) / 3, j = item % 3;
+              const V3 r = ld3(&s.rf[3 * f]);
+              s.N[item] = md.w_aa[i * 3 + 0] * skew_el(r, 0, j) + md.w_aa[i * 3 + 1] * skew_el(r, 1, j) + md.w_aa[i * 3 + 2] * skew_el(r, 2, j);
+            }
+            else if (item < NF * 9 + 9)
+            {
+              const int e = item - NF * 9, i = e / 3, j = e % 3;
+              s.G[e] = md.w_aa[i * 3 + 0] * skew_el(fsv, 0, j) + md.w_aa[i * 3 + 1] * skew_el(fsv, 1, j) + md.w_aa[i * 3 + 2] * skew_el(fsv, 2, j);
+            }
+            else if (item < NF * 9 + 9 + 15)
+            {
+              const int e = item - NF * 9 - 9; // 0..2 la, 3..5 aa, 6..14 x blocks
+              if (e < 3)
+                s.wla[e] = md.w_la[e * 3] * s.rla[0] + md.w_la[e * 3 + 1] * s.rla[1] + md.w_la[e * 3 + 2] * s.rla[2];
+              else if (e < 6)
+                s.waa[e - 3] = md.w_aa[(e - 3) * 3] * s.ts[0] + md.w_aa[(e - 3) * 3 + 1] * s.ts[1] + md.w_aa[(e - 3) * 3 + 2] * s.ts[2];
+              else
+              {
+                const int i = e - 6, bo = (i / 3) * 3, k = i % 3;
+                const double * W = i < 3 ? md.w_com : (i < 6 ? md.w_lm : md.w_am);
+                s.wrx[i] = W[k * 3] * s.rx[bo] + W[k * 3 + 1] * s.rx[bo + 1] + W[k * 3 + 2] * s.rx[bo + 2];
+              }
+            }
+            else
+            {
+              const int i = item - NF * 9 - 9 - 15;
+              double a = 0.0;
+              for (int j = 0; j < NU; j++)
+                a += md.w_u[i * NU + j] * s.ru[j];
+              s.wu[i] = a;
+            }
+          }
+          // [A B] in sweep-2 column order
+          for (int idx = lane; idx < 9 * LDM; idx += NT)
+          {
+            const int k = idx / LDM, j = idx % LDM;
+            double a = 0.0;
+            if (j < NU)
+            {
+              const int f = j / 3, jj = j % 3;
+              const V3 r = ld3(&s.rf[3 * f]); // zero for a foot in the air
+              if (k >= 3 && k < 6)
+                a = k - 3 == jj ? dt * s.act[f] : 0.0;
+              else if (k >= 6)
+                a = dt * skew_el(r, k - 6, jj);
+            }
+            else if (j >= XO && j < XO + 9)
+            {
+              const int i = j - XO;
+              a = k == i ? 1.0 : 0.0;
+              if (k < 3 && i == k + 3)
+                a += dt / mass;
+              if (k >= 6 && i < 3)
+                a += dt * skew_el(fsv, k - 6, i);
+            }
+            s.ABp[idx] = a;
+          }
+        }
+        SMPC_LANES_END_WAVE
+        // ---- cost gradient, cost ; pt0 = p + P f ----
+        SMPC_LANES(NT)
+        {
+          const V3 fsv = ld3(s.fs), waa = ld3(s.waa);
+          if (lane < 9)
+          {
+            double a = s.wrx[lane];
+            if (lane < 3)
+            {
+              const V3 w = cross(waa, fsv); // [fs]x^T w = w x fs
+              a += lane == 0 ? w.x : (lane == 1 ? w.y : w.z);
+            }
+            s.lx[lane] = a;
+            double pa = s.p[lane];
+            for (int j = 0; j < 9; j++)
+              pa += s.P[lane * 9 + j] * s.f[j];
+            s.pt0[lane] = pa;
+          }
+          if (lane >= 16 && lane < 16 + NU)
+          {
+            const int j = lane - 16, f = j / 3, k = j % 3;
+            const V3 w = cross(waa, ld3(&s.rf[3 * f])); // [r]x^T w (r = 0 for a foot in the air)
+            s.lu[j] = s.wu[j] + s.act[f] * s.wla[k] / mass + (k == 0 ? w.x : (k == 1 ? w.y : w.z));
+          }
+          if (lane == 40)
+          {
+            double cst = 0.0;
+            for (int i = 0; i < 9; i++)
+              cst += s.rx[i] * s.wrx[i];
+            for (int i = 0; i < NU; i++)
+              cst += s.ru[i] * s.wu[i];
+            for (int i = 0; i < 3; i++)
+              cst += s.rla[i] * s.wla[i] + s.ts[i] * s.waa[i];
+            SMPC_PLV(acc_cost) += 0.5 * cst;
+          }
+        }
+        SMPC_LANES_END_WAVE
+        // ---- knot vectors q, r and the merit-gradient pieces ; sweep-1 matrix ----
+        SMPC_LANES(NT)
+        {
+          if (lane < 9)
+          {
+            double a = 0.0, gx = 0.0;
+            for (int k = 0; k < 9; k++)
+            {
+              a += s.ABp[k * LDM + XO + lane] * l1[k];
+              gx += s.ABp[k * LDM + XO + lane] * s.lpd[k];
+            }
+            const double q = t > 0 ? s.lx[lane] + a - l0[lane] : 0.0; // x_0 is fixed (force_initial_condition)
+            s.q[lane] = q;
+            s.gxp[lane] = s.lx[lane] + gx;
+            SMPC_PLV(acc_dual) = fmax(SMPC_PLV(acc_dual), fabs(q));
+          }
+          if (lane >= 16 && lane < 16 + NU)
+          {
+            const int j = lane - 16, f = j / 3, k = j % 3;
+            double a = 0.0, gu = 0.0;
+            for (int kk = 0; kk < 9; kk++)
+            {
+              a += s.ABp[kk * LDM + j] * l1[kk];
+              gu += s.ABp[kk * LDM + j] * s.lpd[kk];
+            }
+            for (int rr = 0; rr < 2; rr++)
+            {
+              a += s.Cu[(2 * f + rr) * 3 + k] * v[2 * f + rr];
+              gu += s.Cu[(2 * f + rr) * 3 + k] * s.vpd[2 * f + rr];
+            }
+            const double r = s.lu[j] + a;
+            s.r[j] = r;
+            s.gu[j] = s.lu[j] + gu;
+            SMPC_PLV(acc_dual) = fmax(SMPC_PLV(acc_dual), fabs(r));
+          }
+          // M1 = [[I + mu P, sqrt(mu) P, sqrt(mu) pt0], [., P, pt0]] (pad pivots 9..11: unit diagonal)
+          const double smu = sqrt(mu);
+          for (int idx = lane; idx < LDM * LDM; idx += NT)
+          {
+            const int i = idx / LDM, j = idx % LDM;
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            double a = 0.0;
+            if (hi < 9)
+              a = mu * s.P[lo * 9 + hi] + (lo == hi ? 1.0 : 0.0);
+            else if (hi < X1)
+              a = lo == hi ? 1.0 : 0.0;
+            else if (hi < Z1)
+            {
+              if (lo < 9)
+                a = smu * s.P[lo * 9 + hi - X1];
+              else if (lo >= X1)
+                a = s.P[(lo - X1) * 9 + hi - X1];
+            }
+            else if (hi == Z1)
+            {
+              if (lo < 9)
+                a = smu * s.pt0[lo];
+              else if (lo >= X1 && lo < Z1)
+                a = s.pt0[lo - X1];
+            }
+            s.M[idx] = a;
+          }
+        }
+        SMPC_LANES_END_WAVE
+        // ---- sweep 1: P~, p~ ----
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int J = I; J < 2; J++)
+#pragma unroll
+              for (int vv = 0; vv < 4; vv++)
+                SMPC_ACCV(macc, tix<2>(I, J), vv) = s.M[(16 * I + lr + 4 * vv) * LDM + 16 * J + lc];
+        }
+        SMPC_LANES_END_WAVE
+        wave_block_sweep<NT, 2, false, 0, 3>(macc, s.prow, s.urow, nullptr, tprev);
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int J = I; J < 2; J++)
+#pragma unroll
+              for (int vv = 0; vv < 4; vv++)
+                s.M[(16 * I + lr + 4 * vv) * LDM + 16 * J + lc] = SMPC_ACCV(macc, tix<2>(I, J), vv);
+        }
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        {
+          for (int idx = lane; idx < 81; idx += NT)
+          {
+            const int i = idx / 9, j = idx % 9;
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const double a = s.M[(X1 + lo) * LDM + X1 + hi]; // upper triangle is authoritative
+            s.Pt[idx] = a;
+            g[D::G_Pt + idx] = a;
+          }
+          if (lane < 9)
+            s.pt[lane] = s.M[(X1 + lane) * LDM + Z1];
+        }
+        SMPC_LANES_END_WAVE
+        // ---- sweep-2 matrix: cost / constraint part ----
+        SMPC_LANES(NT)
+        {
+          const V3 fsv = ld3(s.fs);
+          for (int idx = lane; idx < LDM * LDM; idx += NT)
+          {
+            const int i = idx / LDM, j = idx % LDM;
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            double a = 0.0;
+            if (hi < NU)
+            { // R = Luu + preg I
+              const int fa = lo / 3, ia = lo % 3, fb = hi / 3, jb = hi % 3;
+              a = md.w_u[lo * NU + hi] + (lo == hi ? preg : 0.0) + s.act[fa] * s.act[fb] * md.w_la[ia * 3 + jb] / (mass * mass);
+              const V3 ra = ld3(&s.rf[3 * fa]);
+              for (int k = 0; k < 3; k++)
+                a += skew_el(ra, k, ia) * s.N[fb * 9 + k * 3 + jb];
+            }
+            else if (hi < NUP)
+              a = lo == hi ? 1.0 : 0.0;
+            else if (hi < VO + NC)
+            { // D^T (active rows) ; -mu I
+              const int row = hi - VO, f = row / 2;
+              if (lo < NU)
+                a = lo / 3 == f && s.cact[row] != 0.0 ? s.Cu[row * 3 + lo % 3] : 0.0;
+              else if (lo == hi)
+                a = -mu;
+            }
+            else if (hi < XO)
+              a = lo == hi ? 1.0 : 0.0;
+            else if (hi < ZC)
+            {
+              const int xi = hi - XO;
+              if (lo < NU)
+              { // S^T: Lxu(xi, lo), only the com rows
+                if (xi < 3)
+                {
+                  const int f = lo / 3, jb = lo % 3;
+                  for (int k = 0; k < 3; k++)
+                    a += skew_el(fsv, k, xi) * s.N[f * 9 + k * 3 + jb];
+                }
+              }
+              else if (lo >= XO)
+              { // Q = Lxx + preg I
+                const int xl = lo - XO;
+                if (xl / 3 == xi / 3)
+                {
+                  const double * W = xl < 3 ? md.w_com : (xl < 6 ? md.w_lm : md.w_am);
+                  a = W[(xl % 3) * 3 + xi % 3];
+                  if (xl < 3)
+                    for (int k = 0; k < 3; k++)
+                      a += skew_el(fsv, k, xl) * s.G[k * 3 + xi];
+                }
+                if (xl == xi)
+                  a += preg;
+              }
+            }
+            else if (hi == ZC)
+            {
+              if (lo < NU)
+                a = s.r[lo];
+              else if (lo >= VO && lo < VO + NC)
+                a = s.dvec[lo - VO];
+              else if (lo >= XO && lo < ZC)
+                a = s.q[lo - XO];
+            }
+            s.M[idx] = a;
+          }
+        }
+        SMPC_LANES_END_WAVE
+        // ---- M2 += [A B]^T P~ [A B] (and the vector column += [A B]^T p~) on the matrix cores ----
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int sk = 0; sk < 3; sk++)
+          {
+            const int k = 4 * sk + lr;
+            SMPC_PLV(pop)[sk] = lc < 9 && k < 9 ? s.Pt[lc * 9 + k] : 0.0;
+#pragma unroll
+            for (int I = 0; I < 2; I++)
+              SMPC_PLV(aop)[sk * 2 + I] = k < 9 ? s.ABp[k * LDM + 16 * I + lc] : 0.0;
+          }
+#pragma unroll
+          for (int J = 0; J < 2; J++)
+#pragma unroll
+            for (int vv = 0; vv < 4; vv++)
+              SMPC_ACCV(tacc, J, vv) = 0.0;
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int J = I; J < 2; J++)
+#pragma unroll
+              for (int vv = 0; vv < 4; vv++)
+                SMPC_ACCV(macc, tix<2>(I, J), vv) = s.M[(16 * I + lr + 4 * vv) * LDM + 16 * J + lc];
+        }
+        SMPC_LANES_END_WAVE
+#pragma unroll
+        for (int sk = 0; sk < 3; sk++)
+#pragma unroll
+          for (int J = 0; J < 2; J++)
+            SMPC_MFMA(tacc, J, pop, sk, aop, sk * 2 + J);
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int sk = 0; sk < 3; sk++)
+          {
+            SMPC_PLV(top)[sk * 2 + 0] = SMPC_ACCV(tacc, 0, sk);
+            // column ZC of the right factor is p~ (so that the vector column receives [A B]^T p~)
+            const int row = lr + 4 * sk;
+            SMPC_PLV(top)[sk * 2 + 1] = lc == ZC - 16 ? (row < 9 ? s.pt[row] : 0.0) : SMPC_ACCV(tacc, 1, sk);
+          }
+        }
+        SMPC_LANES_END_WAVE
+#pragma unroll
+        for (int sk = 0; sk < 3; sk++)
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int J = I; J < 2; J++)
+              SMPC_MFMA(macc, tix<2>(I, J), aop, sk * 2 + I, top, sk * 2 + J);
+        // ---- sweep 2: pivots = [u | nu] ----
+        wave_block_sweep<NT, 2, true, 0, D::NP2>(macc, s.prow, s.urow, nullptr, tprev);
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int J = I; J < 2; J++)
+#pragma unroll
+              for (int vv = 0; vv < 4; vv++)
+                s.M[(16 * I + lr + 4 * vv) * LDM + 16 * J + lc] = SMPC_ACCV(macc, tix<2>(I, J), vv);
+        }
+        SMPC_LANES_END_WAVE
+        // ---- gains, P_t, p_t, record for the forward pass ----
+        SMPC_LANES(NT)
+        {
+          for (int idx = lane; idx < NU * 10; idx += NT)
+            g[D::G_K + idx] = -s.M[(idx / 10) * LDM + XO + idx % 10];
+          for (int idx = lane; idx < NC * 10; idx += NT)
+            g[D::G_Z + idx] = -s.M[(VO + idx / 10) * LDM + XO + idx % 10];
+          for (int idx = lane; idx < 81; idx += NT)
+          {
+            const int i = idx / 9, j = idx % 9;
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            s.P[idx] = s.M[(XO + lo) * LDM + XO + hi];
+          }
+          if (lane < 9)
+          {
+            s.p[lane] = s.M[(XO + lane) * LDM + ZC];
+            g[D::G_f + lane] = s.f[lane];
+            g[D::G_gx + lane] = s.gxp[lane];
+            g[D::G_lpd + lane] = s.lpd[lane];
+          }
+          if (lane < 3)
+            g[D::G_fs + lane] = s.fs[lane];
+          if (lane < 3 * NF)
+            g[D::G_r + lane] = s.rf[lane];
+          if (lane < NF)
+            g[D::G_act + lane] = s.act[lane];
+          if (lane < NU)
+            g[D::G_gu + lane] = s.gu[lane];
+          if (lane < NC)
+            g[D::G_d + lane] = s.dvec[lane];
+        }
+        SMPC_LANES_END_WAVE
+      }
+
+      // =====================================================================================
+      // forward pass: dx_0 = 0
+      // =====================================================================================
+      SMPC_LANES(NT)
+      {
+        SMPC_PLV(acc_dphi) = 0.0;
+        const double * g0 = b.gains + (inst * H) * D::G_STRIDE;
+#pragma unroll
+        for (int n = 0; n < D::G_REGS; n++)
+          SMPC_PLV(prec)[n] = g0[lane + n * NT];
+        if (lane < 9)
+        {
+          s.dx[lane] = 0.0;
+          b.dxs[(inst * (H + 1)) * 9 + lane] = 0.0;
+        }
+      }
+      SMPC_LANES_END_WAVE
+      for (int t = 0; t < H; t++)
+      {
+        SMPC_LANES(NT)
+        {
+#pragma unroll
+          for (int n = 0; n < D::G_REGS; n++)
+            s.rec[lane + n * NT] = SMPC_PLV(prec)[n];
+          if (t + 1 < H)
+          {
+            const double * gn = b.gains + (inst * H + t + 1) * D::G_STRIDE;
+#pragma unroll
+            for (int n = 0; n < D::G_REGS; n++)
+              SMPC_PLV(prec)[n] = gn[lane + n * NT];
+          }
+        }
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        {
+          if (lane < NU)
+          {
+            const double * K = s.rec + D::G_K + lane * 10;
+            double a = K[9];
+            for (int j = 0; j < 9; j++)
+              a += K[j] * s.dx[j];
+            s.du[lane] = a;
+            b.dus[(inst * H + t) * NU + lane] = a;
+            SMPC_PLV(acc_dphi) += s.rec[D::G_gu + lane] * a;
+          }
+          if (lane >= 16 && lane < 16 + NC)
+          {
+            const int row = lane - 16;
+            const double * Z = s.rec + D::G_Z + row * 10;
+            double a = Z[9];
+            for (int j = 0; j < 9; j++)
+              a += Z[j] * s.dx[j];
+            b.dvs[(inst * H + t) * NC + row] = a;
+            SMPC_PLV(acc_dphi) -= s.rec[D::G_d + row] * a;
+          }
+          if (lane >= 32 && lane < 41)
+            SMPC_PLV(acc_dphi) += s.rec[D::G_gx + lane - 32] * s.dx[lane - 32];
+        }
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        if (lane < 9)
+        {
+          // y = A dx + B du + f - mu p_{t+1}
+          double a = s.dx[lane];
+          const int k = lane % 3;
+          if (lane < 3)
+            a += dt * s.dx[3 + lane] / mass;
+          else if (lane < 6)
+          {
+            double sf = 0.0;
+            for (int f = 0; f < NF; f++)
+              sf += s.rec[D::G_act + f] * s.du[3 * f + k];
+            a += dt * sf;
+          }
+          else
+          {
+            V3 tq = cross(ld3(s.rec + D::G_fs), ld3(s.dx)); // [fs]x dc
+            for (int f = 0; f < NF; f++)
+              tq = tq + cross(ld3(s.rec + D::G_r + 3 * f), ld3(&s.du[3 * f]));
+            a += dt * (k == 0 ? tq.x : (k == 1 ? tq.y : tq.z));
+          }
+          s.y[lane] = a + s.rec[D::G_f + lane] - mu * s.rec[D::G_pn + lane];
+        }
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        if (lane < 9)
+        {
+          double w = 0.0;
+          for (int j = 0; j < 9; j++)
+            w += s.rec[D::G_Pt + lane * 9 + j] * s.y[j];
+          const double dxn = s.y[lane] - mu * w;
+          const double dl = w + s.rec[D::G_pn + lane];
+          s.w[lane] = dxn;
+          b.dxs[(inst * (H + 1) + t + 1) * 9 + lane] = dxn;
+          b.dlams[(inst * H + t) * 9 + lane] = dl;
+          SMPC_PLV(acc_dphi) -= s.rec[D::G_lpd + lane] * dxn + s.rec[D::G_f + lane] * dl;
+        }
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        if (lane < 9)
+          s.dx[lane] = s.w[lane];
+        SMPC_LANES_END_WAVE
+      }
+      // terminal gradient lx_N . dx_H ; reductions
+      SMPC_LANES(NT)
+      {
+        if (lane >= 3 && lane < 9)
+        {
+          const double * xH = b.xs + (ib + ring_slot(head, H, R)) * 9;
+          const double * W = lane < 6 ? md.w_lm : md.w_am;
+          const int bo = lane < 6 ? 3 : 6;
+          double gN = 0.0;
+          for (int j = 0; j < 3; j++)
+            gN += W[(lane - bo) * 3 + j] * xH[bo + j];
+          SMPC_PLV(acc_dphi) += gN * s.dx[lane];
+        }
+      }
+      SMPC_LANES_END_WAVE
+      // five reductions through LDS (lane order: deterministic)
+      for (int which = 0; which < 5; which++)
+      {
+        SMPC_LANES(NT)
+        s.red[lane] = which == 0 ? SMPC_PLV(acc_cost) : (which == 1 ? SMPC_PLV(acc_pen) : (which == 2 ? SMPC_PLV(acc_prim) : (which == 3 ? SMPC_PLV(acc_dual) : SMPC_PLV(acc_dphi))));
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        if (lane == 0)
+        {
+          if (which == 0)
+            s.sc[SC_COST] = fold64<false>(s.red);
+          else if (which == 1)
+            s.sc[SC_PHI0] = s.sc[SC_COST] + fold64<false>(s.red);
+          else if (which == 2)
+            s.sc[SC_PRIM] = fold64<true>(s.red);
+          else if (which == 3)
+            s.sc[SC_DUAL] = fold64<true>(s.red);
+          else
+            s.sc[SC_DPHI0] = fold64<false>(s.red);
+        }
+        SMPC_LANES_END_WAVE
+      }
+
+      // =====================================================================================
+      // line search (lane = stage; lane / slot H carries the terminal cost)
+      // =====================================================================================
+      double alpha = 1.0;
+      int accepted = -1, jlast = 0;
+      for (int j = 0; j < D::LS_N; j++)
+      {
+        jlast = j;
+        SMPC_LANES(NT)
+        {
+          double cst = 0.0, pen = 0.0, prm = 0.0;
+          for (int t = lane; t <= H; t += NT)
+          {
+            double xt[9], xn[9];
+            const double * xg = b.xs + (ib + ring_slot(head, t, R)) * 9;
+            const double * dxg = b.dxs + (inst * (H + 1) + t) * 9;
+            for (int i = 0; i < 9; i++)
+              xt[i] = xg[i] + alpha * dxg[i];
+            if (t == H)
+            {
+              cst += 0.5 * dot(ld3(xt + 3), ldm3(md.w_lm) * ld3(xt + 3)) + 0.5 * dot(ld3(xt + 6), ldm3(md.w_am) * ld3(xt + 6));
+              continue;
+            }
+            const size_t sl = ib + ring_slot(head, t, R);
+            const double * xng = b.xs + (ib + ring_slot(head, t + 1, R)) * 9;
+            double ut[NU], vt[NC], lt[9];
+            for (int i = 0; i < 9; i++)
+            {
+              xn[i] = xng[i] + alpha * dxg[9 + i];
+              lt[i] = b.lams[sl * 9 + i] + alpha * b.dlams[(inst * H + t) * 9 + i];
+            }
+            for (int i = 0; i < NU; i++)
+              ut[i] = b.us[sl * NU + i] + alpha * b.dus[(inst * H + t) * NU + i];
+            for (int i = 0; i < NC; i++)
+              vt[i] = b.vs[sl * NC + i] + alpha * b.dvs[(inst * H + t) * NC + i];
+            double c1, p1, r1;
+            cent_stage_merit<D>(
+              md, b.stages[t].mask, xt, ut, xn, vt, b.vs_e + sl * NC, lt, b.lams_e + sl * 9, b.foot + (inst * H + t) * (3 * NF), b.stages[t].u_ref,
+              b.stages[t].x_tgt, c1, p1, r1, nullptr);
+            cst += c1;
+            pen += p1;
+            prm = fmax(prm, r1);
+          }
+          SMPC_PLV(acc_cost) = cst;
+          SMPC_PLV(acc_pen) = pen;
+          SMPC_PLV(acc_prim) = prm;
+        }
+        SMPC_LANES_END_WAVE
+        for (int which = 0; which < 3; which++)
+        {
+          SMPC_LANES(NT)
+          s.red[lane] = which == 0 ? SMPC_PLV(acc_cost) : (which == 1 ? SMPC_PLV(acc_pen) : SMPC_PLV(acc_prim));
+          SMPC_LANES_END_WAVE
+          SMPC_LANES(NT)
+          if (lane == 0)
+          {
+            if (which == 0)
+              s.sc[SC_COST_NEW] = fold64<false>(s.red);
+            else if (which == 1)
+              s.sc[SC_PHI_NEW] = s.sc[SC_COST_NEW] + fold64<false>(s.red);
+            else
+              s.sc[SC_PRIM_NEW] = fold64<true>(s.red);
+          }
+          SMPC_LANES_END_WAVE
+        }
+        if (s.sc[SC_PHI_NEW] <= s.sc[SC_PHI0] + ka.armijo_c1 * alpha * s.sc[SC_DPHI0])
+        {
+          accepted = j;
+          break;
+        }
+        if (j + 1 < D::LS_N)
+          alpha *= 0.5;
+      }
+      // ---- accept (the last candidate is taken when none passes, like the restated solver) ----
+      SMPC_LANES(NT)
+      {
+        for (int t = lane; t <= H; t += NT)
+        {
+          double * xg = b.xs + (ib + ring_slot(head, t, R)) * 9;
+          const double * dxg = b.dxs + (inst * (H + 1) + t) * 9;
+          for (int i = 0; i < 9; i++)
+            xg[i] += alpha * dxg[i];
+          if (t < H)
+          {
+            const size_t sl = ib + ring_slot(head, t, R);
+            for (int i = 0; i < NU; i++)
+              b.us[sl * NU + i] += alpha * b.dus[(inst * H + t) * NU + i];
+            for (int i = 0; i < NC; i++)
+              b.vs[sl * NC + i] += alpha * b.dvs[(inst * H + t) * NC + i];
+            for (int i = 0; i < 9; i++)
+              b.lams[sl * 9 + i] += alpha * b.dlams[(inst * H + t) * 9 + i];
+          }
+        }
+        if (lane == 0)
+        {
+          s.sc[SC_ALPHA] = alpha;
+          s.sc[SC_LS_FAILED] = accepted < 0 ? 1.0 : 0.0;
+          s.sc[SC_LS_INDEX] = (double)jlast;
+          s.sc[SC_PREG] = accepted < 0 ? fmin(preg * ka.reg_inc, ka.reg_max) : fmax(preg * ka.reg_dec, ka.reg_min);
+        }
+      }
+      SMPC_LANES_END_WAVE
+    }
+
+    // ---- outputs: solver scalars, xdot at t = 0, 1 of the accepted iterate (MPC::getStateDerivative) ----
+    SMPC_LANES(NT)
+    {
+      if (lane < 16)
+        gsc[lane] = s.sc[lane];
+      if (lane >= 32 && lane < 34 && ka.iters > 0)
+      {
+        const int t = lane - 32;
+        const size_t sl = ib + ring_slot(head, t, R);
+        double c1, p1, r1, xd[9];
+        cent_stage_merit<D>(
+          md, b.stages[t].mask, b.xs + sl * 9, b.us + sl * NU, b.xs + (ib + ring_slot(head, t + 1, R)) * 9, b.vs + sl * NC, b.vs_e + sl * NC, b.lams + sl * 9,
+          b.lams_e + sl * 9, b.foot + (inst * H + t) * (3 * NF), b.stages[t].u_ref, b.stages[t].x_tgt, c1, p1, r1, xd);
+        for (int i = 0; i < 9; i++)
+          b.xdot01[(inst * 2 + t) * 9 + i] = xd[i];
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // K_t of every stage -> dense [B][H][NU][9] (MPC::Ks_) or K_0 only
+  template <class D>
+  struct CentGainsOutArgs
+  {
+    CentBuffers<D> b;
+    double * out;
+    int all;
+  };
+  template <class D>
+  SMPC_DEV void cent_gains_out_body(const CentGainsOutArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64, NU = D::NU;
+    const int H = ka.b.H;
+    const int inst = ka.all ? block / H : block, t = ka.all ? block % H : 0;
+    const double * g = ka.b.gains + ((size_t)inst * H + t) * D::G_STRIDE + D::G_K;
+    double * o = ka.out + (size_t)block * NU * 9;
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NU * 9; idx += NT)
+      o[idx] = g[(idx / 9) * 10 + idx % 9];
+    SMPC_LANES_END_WAVE
+  }
+} // namespace smpc

@@ -109,6 +109,49 @@ namespace smpc
     KID_N
   };
 
+  // kinematic tree, inertias and feet of the robot table -> device model (shared by the kinodynamics engine and the
+  // front-end of the centroidal engine)
+  template <class D>
+  inline void fill_tree_model(const smpc_robot_model * rm, DevModel<D> & m)
+  {
+    if (rm->njoints != D::NJ || rm->nfeet != D::NF)
+      throw std::runtime_error("robot shape (njoints, nfeet) does not match this kernel instantiation");
+    int maxlev = 0;
+    for (int j = 0; j < D::NJ; j++)
+    {
+      m.parent[j] = rm->parent[j];
+      if (j > 0 && (rm->parent[j] < 0 || rm->parent[j] >= j))
+        throw std::runtime_error("robot joints must be topologically ordered");
+      m.jtype[j] = rm->jtype[j];
+      m.level[j] = j == 0 ? 0 : m.level[rm->parent[j]] + 1;
+      maxlev = std::max(maxlev, m.level[j]);
+      m.anc[j] = (j == 0 ? 0u : m.anc[rm->parent[j]]) | (1u << j);
+      if (j > 0)
+        m.children[rm->parent[j]] |= 1u << j;
+      for (int i = 0; i < 9; i++)
+        m.jpR[j][i] = rm->jp_R[j][i];
+      for (int i = 0; i < 3; i++)
+      {
+        m.jpp[j][i] = rm->jp_p[j][i];
+        m.com[j][i] = rm->com[j][i];
+      }
+      m.mass[j] = rm->mass[j];
+      for (int i = 0; i < 6; i++)
+        m.inertia[j][i] = rm->inertia[j][i];
+    }
+    m.nlevels = maxlev + 1;
+    for (int f = 0; f < D::NF; f++)
+    {
+      m.foot_joint[f] = rm->foot_joint[f];
+      for (int i = 0; i < 3; i++)
+      {
+        m.foot_p[f][i] = rm->foot_p[f][i];
+        m.foot_ref_p[f][i] = rm->foot_ref_p[f][i];
+      }
+    }
+    m.total_mass = rm->total_mass;
+  }
+
   template <class D>
   class KinoEngine
   {
@@ -163,40 +206,7 @@ namespace smpc
       std::vector<DevModel<D>> hm(1);
       DevModel<D> & m = hm[0];
       std::memset(&m, 0, sizeof(m));
-      int maxlev = 0;
-      for (int j = 0; j < D::NJ; j++)
-      {
-        m.parent[j] = rm->parent[j];
-        if (j > 0 && (rm->parent[j] < 0 || rm->parent[j] >= j))
-          throw std::runtime_error("robot joints must be topologically ordered");
-        m.jtype[j] = rm->jtype[j];
-        m.level[j] = j == 0 ? 0 : m.level[rm->parent[j]] + 1;
-        maxlev = std::max(maxlev, m.level[j]);
-        m.anc[j] = (j == 0 ? 0u : m.anc[rm->parent[j]]) | (1u << j);
-        if (j > 0)
-          m.children[rm->parent[j]] |= 1u << j;
-        for (int i = 0; i < 9; i++)
-          m.jpR[j][i] = rm->jp_R[j][i];
-        for (int i = 0; i < 3; i++)
-        {
-          m.jpp[j][i] = rm->jp_p[j][i];
-          m.com[j][i] = rm->com[j][i];
-        }
-        m.mass[j] = rm->mass[j];
-        for (int i = 0; i < 6; i++)
-          m.inertia[j][i] = rm->inertia[j][i];
-      }
-      m.nlevels = maxlev + 1;
-      for (int f = 0; f < D::NF; f++)
-      {
-        m.foot_joint[f] = rm->foot_joint[f];
-        for (int i = 0; i < 3; i++)
-        {
-          m.foot_p[f][i] = rm->foot_p[f][i];
-          m.foot_ref_p[f][i] = rm->foot_ref_p[f][i];
-        }
-      }
-      m.total_mass = rm->total_mass;
+      fill_tree_model<D>(rm, m);
       m.dt = ks.timestep;
       for (int i = 0; i < 3; i++)
         m.gravity[i] = ks.gravity[i];

@@ -15,9 +15,9 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import KinodynamicsSettingsC, MpcSettingsC, SmpcLib, default_lib
+from ._capi import CentroidalSettingsC, KinodynamicsSettingsC, MpcSettingsC, SmpcLib, default_lib
 
-__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "MPC", "BatchedMPC", "Interpolator", "FrictionCompensation", "centroidal_dynamics"]
+__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "CentroidalOCP", "MPC", "BatchedMPC", "Interpolator", "FrictionCompensation", "centroidal_dynamics"]
 
 
 def load_robot(name, lib=None):
@@ -144,23 +144,17 @@ class KinodynamicsOCP:
             raise RuntimeError("Create problem first!")
         return self._problem["horizon"]
 
+    def _default_x_reference(self):
+        return self.model_handler.getReferenceState()
 
-_MPC_KEYS = ["support_force", "TOL", "mu_init", "max_iters", "num_threads", "swing_apex", "T_fly", "T_contact", "timestep"]
+    def _xdot_size(self):
+        return 2 * self.model_handler.nv
 
+    def _kernel_names(self):
+        return ["recede", "deriv", "riccati", "forward", "trial", "select", "apply"]
 
-class BatchedMPC:
-    """B phase-aligned instances of the reference's MPC (include/simple-mpc/mpc.hpp:55-197) solved together."""
-
-    def __init__(self, settings, ocp, batch, device_id=0, lib=None):
-        for k in _MPC_KEYS:
-            if k not in settings:
-                raise KeyError(k)
-        if ocp._problem is None:
-            raise RuntimeError("Create problem first!")
-        self._lib = lib or default_lib()
-        L = self._lib.L
-        self.settings = dict(settings)
-        self.ocp_handler = ocp
+    def _create_handle(self, lib, ms, batch, device_id):
+        ocp = self
         s = ocp.settings
         c = lambda a: np.ascontiguousarray(np.asarray(a, float))
         self._keep = [c(s[k]) for k in ("w_x", "w_u", "w_frame", "w_cent", "w_centder", "qmin", "qmax")]
@@ -181,6 +175,100 @@ class BatchedMPC:
         ks.kinematics_limits = int(bool(s["kinematics_limits"]))
         ks.force_cone = int(bool(s["force_cone"]))
         ks.land_cstr = int(bool(s["land_cstr"]))
+        h = C.c_void_p()
+        lib.check(lib.L.smpc_create(mh._ptr, C.byref(ks), C.byref(ms), batch, ocp._problem["gravity"], device_id, C.byref(h)))
+        return h
+
+
+_CENT_KEYS = [
+    "timestep", "w_u", "w_com", "w_linear_mom", "w_angular_mom", "w_linear_acc", "w_angular_acc", "gravity", "mu", "Lfoot",
+    "Wfoot", "force_size",
+]
+
+
+class CentroidalOCP:
+    """reference: src/centroidal-dynamics.cpp:27-37 (ctor), bindings/expose-centroidal.cpp (dict keys =
+    CentroidalSettings fields, include/simple-mpc/centroidal-dynamics.hpp:27-43).  State [com; h_lin; h_ang], control = the
+    stacked 3-D contact forces."""
+
+    def __init__(self, settings, model_handler):
+        for k in _CENT_KEYS:
+            if k not in settings:
+                raise KeyError(k)
+        self.settings = dict(settings)
+        self.model_handler = model_handler
+        self._problem = None
+        self.nu = int(settings["force_size"]) * model_handler.getFeetNb()
+
+    def getSettings(self):
+        return dict(self.settings)
+
+    def getModelHandler(self):
+        return self.model_handler
+
+    def getNu(self):
+        return self.nu
+
+    def createProblem(self, x0, horizon, force_size, gravity, terminal_constraint=False):
+        """reference src/ocp-handler.cpp:96-137; the terminal constraint of this OCP is disabled upstream
+        (src/centroidal-dynamics.cpp:318-328), so the flag is accepted and has no effect, like there."""
+        if force_size != self.settings["force_size"]:
+            raise RuntimeError("force size in settings does not match reference force size")
+        self._problem = dict(x0=np.array(x0, float), horizon=int(horizon), gravity=float(gravity))
+
+    def getSize(self):
+        if self._problem is None:
+            raise RuntimeError("Create problem first!")
+        return self._problem["horizon"]
+
+    def _default_x_reference(self):
+        return np.zeros(9)  # getReferenceState(0) of the default problem (src/centroidal-dynamics.cpp:293-298, com_ref_ = 0)
+
+    def _xdot_size(self):
+        return 9
+
+    def _kernel_names(self):
+        return ["frontend", "step", "-", "-", "-", "-", "-"]
+
+    def _create_handle(self, lib, ms, batch, device_id):
+        s = self.settings
+        c = lambda a: np.ascontiguousarray(np.asarray(a, float))
+        names = ("w_u", "w_com", "w_linear_mom", "w_angular_mom", "w_linear_acc", "w_angular_acc")
+        self._keep = [c(s[k]) for k in names]
+        shapes = [(self.nu, self.nu)] + [(3, 3)] * 5
+        for a, sh, k in zip(self._keep, shapes, names):
+            if a.shape != sh:
+                raise RuntimeError("%s has shape %s, expected %s" % (k, a.shape, sh))
+        cs = CentroidalSettingsC()
+        cs.timestep = s["timestep"]
+        for name, arr in zip(names, self._keep):
+            setattr(cs, name, arr.ctypes.data)
+        for i in range(3):
+            cs.gravity[i] = float(s["gravity"][i])
+        cs.mu, cs.Lfoot, cs.Wfoot = s["mu"], s["Lfoot"], s["Wfoot"]
+        cs.force_size = int(s["force_size"])
+        h = C.c_void_p()
+        lib.check(lib.L.smpc_create_centroidal(
+            self.model_handler._ptr, C.byref(cs), C.byref(ms), batch, self._problem["gravity"], device_id, C.byref(h)))
+        return h
+
+
+_MPC_KEYS = ["support_force", "TOL", "mu_init", "max_iters", "num_threads", "swing_apex", "T_fly", "T_contact", "timestep"]
+
+
+class BatchedMPC:
+    """B phase-aligned instances of the reference's MPC (include/simple-mpc/mpc.hpp:55-197) solved together."""
+
+    def __init__(self, settings, ocp, batch, device_id=0, lib=None):
+        for k in _MPC_KEYS:
+            if k not in settings:
+                raise KeyError(k)
+        if ocp._problem is None:
+            raise RuntimeError("Create problem first!")
+        self._lib = lib or default_lib()
+        L = self._lib.L
+        self.settings = dict(settings)
+        self.ocp_handler = ocp
         ms = MpcSettingsC()
         ms.swing_apex = settings["swing_apex"]
         ms.support_force = settings["support_force"]
@@ -192,14 +280,14 @@ class BatchedMPC:
         ms.T_contact = int(settings["T_contact"])
         ms.T = int(ocp._problem["horizon"])
         ms.timestep = settings["timestep"]
-        h = C.c_void_p()
-        self._lib.check(L.smpc_create(mh._ptr, C.byref(ks), C.byref(ms), int(batch), ocp._problem["gravity"], int(device_id), C.byref(h)))
-        self._h = h
+        mh = ocp.model_handler
+        self._h = ocp._create_handle(self._lib, ms, int(batch), int(device_id))
         d = np.zeros(8, np.int32)
         L.smpc_get_dims(self._h, d)
         self.nq, self.nv, self.nx, self.ndx, self.nu, self.nc, self.nf, self.H = (int(v) for v in d)
         self.B = int(batch)
-        self._x_reference = mh.getReferenceState()
+        self.nx_in = self.nq + self.nv  # iterate takes measured multibody states (reference src/mpc.cpp:189-192)
+        self._x_reference = ocp._default_x_reference()
         self._velocity_base = np.zeros(6)
 
     def __del__(self):
@@ -254,7 +342,7 @@ class BatchedMPC:
 
     def iterate(self, X):
         X = np.ascontiguousarray(X, float)
-        if X.shape != (self.B, self.nx):
+        if X.shape != (self.B, self.nx_in):
             raise RuntimeError("X must have shape (batch, nq+nv)")
         self._lib.check(self._lib.L.smpc_iterate(self._h, X))
 
@@ -304,7 +392,7 @@ class BatchedMPC:
     def getStateDerivative(self, t):
         if t not in (0, 1):
             raise RuntimeError("state derivative is retained for t = 0, 1 only")
-        return self._get("smpc_get_state_derivative01", (self.B, 2, 2 * self.nv))[:, t, :]
+        return self._get("smpc_get_state_derivative01", (self.B, 2, self.ocp_handler._xdot_size()))[:, t, :]
 
     def getReferencePoses(self):
         return self._get("smpc_get_reference_poses", (self.B, self.H, self.nf, 3))
@@ -412,7 +500,7 @@ class BatchedMPC:
         ms = np.zeros(7)
         calls = np.zeros(7, np.int64)
         self._lib.check(self._lib.L.smpc_get_kernel_times(self._h, ms, calls))
-        names = ["recede", "deriv", "riccati", "forward", "trial", "select", "apply"]
+        names = self.ocp_handler._kernel_names()
         return {n: (float(m), int(c)) for n, m, c in zip(names, ms, calls)}
 
     def reset_kernel_times(self):

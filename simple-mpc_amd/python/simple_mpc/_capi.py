@@ -39,6 +39,23 @@ class KinodynamicsSettingsC(C.Structure):
     ]
 
 
+class CentroidalSettingsC(C.Structure):
+    _fields_ = [
+        ("timestep", C.c_double),
+        ("w_u", C.c_void_p),
+        ("w_com", C.c_void_p),
+        ("w_linear_mom", C.c_void_p),
+        ("w_angular_mom", C.c_void_p),
+        ("w_linear_acc", C.c_void_p),
+        ("w_angular_acc", C.c_void_p),
+        ("gravity", C.c_double * 3),
+        ("mu", C.c_double),
+        ("Lfoot", C.c_double),
+        ("Wfoot", C.c_double),
+        ("force_size", C.c_int),
+    ]
+
+
 class MpcSettingsC(C.Structure):
     _fields_ = [
         ("swing_apex", C.c_double),
@@ -86,7 +103,7 @@ class RobotModelC(C.Structure):
 
 # every symbol declared in include/smpc.h
 SYMBOLS = [
-    "smpc_builtin_robot", "smpc_last_error", "smpc_device_count", "smpc_create", "smpc_destroy", "smpc_get_dims",
+    "smpc_builtin_robot", "smpc_last_error", "smpc_device_count", "smpc_create", "smpc_create_centroidal", "smpc_destroy", "smpc_get_dims",
     "smpc_generate_cycle_horizon", "smpc_switch_to_walk", "smpc_switch_to_stand", "smpc_set_x_reference",
     "smpc_iterate", "smpc_iterate_device", "smpc_wait", "smpc_get_x_device", "smpc_get_xs", "smpc_get_us", "smpc_get_K0", "smpc_get_Ks",
     "smpc_get_vs", "smpc_get_lams", "smpc_get_state_derivative01", "smpc_get_reference_poses",
@@ -114,6 +131,10 @@ class SmpcLib:
         L.smpc_device_count.restype = C.c_int
         L.smpc_create.argtypes = [
             C.POINTER(RobotModelC), C.POINTER(KinodynamicsSettingsC), C.POINTER(MpcSettingsC), C.c_int, C.c_double,
+            C.c_int, C.POINTER(vp),
+        ]
+        L.smpc_create_centroidal.argtypes = [
+            C.POINTER(RobotModelC), C.POINTER(CentroidalSettingsC), C.POINTER(MpcSettingsC), C.c_int, C.c_double,
             C.c_int, C.POINTER(vp),
         ]
         L.smpc_destroy.argtypes = [vp]

@@ -86,3 +86,48 @@ def random_states(rb, batch, seed=20240529, scale=1.0):
 
 def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(a).max()))
+
+
+def make_cent_product(batch, max_iters=1, lib=None, horizon=50, settings_override=None, mpc_override=None, device_id=0):
+    """simple_mpc.BatchedMPC over a CentroidalOCP with the centroidal settings of record (oracle_lib.go2_centroidal_settings)."""
+    rb = O.Robot("go2_like")
+    s = O.go2_centroidal_settings(rb)
+    if settings_override:
+        s.update(settings_override)
+    ms = O.go2_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if mpc_override:
+        ms.update(mpc_override)
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+    for n in FEET:
+        mh.addPointFoot(n, "root_joint")
+    ocp = simple_mpc.CentroidalOCP(s, mh)
+    ocp.createProblem(np.zeros(9), horizon, 3, -9.81, False)
+    conf = {k: ms[k] for k in MPC_KEYS}
+    gm = simple_mpc.BatchedMPC(conf, ocp, batch, device_id=device_id, lib=lib)
+    return gm, rb, s, ms
+
+
+def make_cent_oracle(batch, max_iters=1, horizon=50, settings_override=None, mpc_override=None):
+    rb = O.Robot("go2_like")
+    s = O.go2_centroidal_settings(rb)
+    if settings_override:
+        s.update(settings_override)
+    ms = O.go2_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if mpc_override:
+        ms.update(mpc_override)
+    Cn = O.Cent(rb, s)
+    return O.OracleCentMPC(Cn, ms, batch), rb, Cn
+
+
+def make_cent_pair(batch, max_iters=1, lib=None, horizon=50, walk=(0.2, 0, 0, 0, 0, 0), **kw):
+    om, rb, _ = make_cent_oracle(batch, max_iters, horizon, **kw)
+    gm, _, _, _ = make_cent_product(batch, max_iters, lib, horizon, **kw)
+    cs = O.trot_cycle()
+    om.generateCycleHorizon(cs)
+    gm.generateCycleHorizon(cs)
+    v = np.array(walk, float)
+    om.switchToWalk(v)
+    gm.switchToWalk(v)
+    return om, gm, rb

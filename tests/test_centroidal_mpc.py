@@ -1,0 +1,185 @@
+"""Centroidal OCP + MPC (BASELINE config "Go2 centroidal (9-dim state), H = 50"): the fused
+HIP control-step kernel (simple-mpc_amd/csrc/smpc_cent_kernels.h) through the C ABI against the CPU oracle
+(oracle/orc_cent.hpp, orc_mpc_cent.hpp) on the same seeded inputs.
+
+CPU tier: the same kernel body compiled with the sequential-lane test backend (tests/emu); GPU tier (-m gpu): the
+shipped library on the device.  Tolerance (north_star): <= 1e-4 relative state-trajectory error; the emulation is held
+to 1e-9 (same arithmetic up to summation order)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mpc_setup as S
+import oracle_lib as O
+
+TOL = 1e-4
+HARD = dict(settings_override=dict(mu=0.1), walk=(0.8, 0.5, 0, 0, 0, 0.5))  # friction cones active, backtracking
+
+
+def _run_pair(om, gm, rb, B, steps, tol, scale=1.0, check_alpha=True):
+    X = S.random_states(rb, B, scale=scale)
+    worst = 0.0
+    for step in range(steps):
+        om.iterate(X)
+        gm.iterate(X)
+        e = S.rel_err(om.xs, gm.xs)
+        worst = max(worst, e)
+        assert e < tol, (step, e)
+        assert S.rel_err(om.us, gm.us) < 10 * tol
+        assert S.rel_err(om.lams, gm.lams) < 10 * tol
+        assert S.rel_err(om.vs, gm.vs) < 10 * tol
+        assert S.rel_err(om.K0, gm.K0) < 10 * tol
+        if check_alpha:
+            assert np.array_equal(om.info[:, 2], gm.info[:, 2]), "line-search step sizes differ"
+        assert S.rel_err(om.foot_refs, gm.getReferencePoses()) < 1e-12
+        xd = np.stack([gm.getStateDerivative(0), gm.getStateDerivative(1)], 1)
+        assert S.rel_err(om.xdot[:, :2], xd) < 10 * tol
+        # the measured state moves: base drifts forward, as a simulator would report
+        X = np.stack([rb.integrate(X[b], np.r_[np.zeros(18), 0.02, 0.01, np.zeros(16)]) for b in range(B)])
+    for f in range(4):
+        assert om.timing(f, 0) == gm.foot_takeoff_times[S.FEET[f]]
+        assert om.timing(f, 1) == gm.foot_land_times[S.FEET[f]]
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------ CPU tier
+@pytest.fixture(scope="module")
+def lib(built):
+    return S.emu_lib()
+
+
+def test_emu_cold_solve_matches_oracle(lib):
+    om, gm, rb = S.make_cent_pair(2, lib=lib)
+    assert len(om.cold_trace()) == len(gm.cold_trace())
+    assert S.rel_err(om.cold_trace(), gm.cold_trace()) < 1e-9
+    assert S.rel_err(om.xs, gm.xs) < 1e-9 and S.rel_err(om.us, gm.us) < 1e-9
+    assert np.array_equal(gm.xs[0], gm.xs[1])
+    assert (gm.nx, gm.ndx, gm.nu, gm.nc, gm.nf, gm.H) == (9, 9, 12, 8, 4, 50)
+    assert gm.xs.shape == (2, 51, 9) and gm.us.shape == (2, 50, 12) and gm.Ks.shape == (2, 50, 12, 9)
+
+
+@pytest.mark.parametrize("iters", [1, 3])
+def test_emu_closed_loop_parity(lib, iters):
+    om, gm, rb = S.make_cent_pair(3, iters, lib=lib)
+    _run_pair(om, gm, rb, 3, 5, 1e-9)
+
+
+def test_emu_active_friction_cones_and_backtracking(lib):
+    om, gm, rb = S.make_cent_pair(2, 2, lib=lib, **HARD)
+    _run_pair(om, gm, rb, 2, 4, 1e-9, scale=2.0)
+    assert (om.vs != 0).sum() > 10, "the scenario must activate cone rows"
+    assert (om.info[:, 2] < 1.0).any(), "the scenario must backtrack"
+
+
+@pytest.mark.parametrize("horizon", [2, 7, 65])
+def test_emu_unusual_horizons(lib, horizon):
+    om, gm, rb = S.make_cent_pair(2, 2, lib=lib, horizon=horizon)
+    _run_pair(om, gm, rb, 2, 3, 1e-9)
+
+
+def test_emu_dense_weights_and_com_reference(lib):
+    rng = np.random.default_rng(4)
+
+    def spd(n, s):
+        a = rng.normal(size=(n, n))
+        return s * (a @ a.T / n + np.eye(n))
+
+    ov = dict(w_u=spd(12, 1e-3), w_com=spd(3, 10.0), w_linear_mom=spd(3, 1.0), w_angular_mom=spd(3, 5.0), w_linear_acc=spd(3, 0.01),
+              w_angular_acc=spd(3, 0.01))
+    om, gm, rb = S.make_cent_pair(2, 2, lib=lib, settings_override=ov)
+    xr = np.r_[0.02, -0.01, 0.31, np.zeros(6)]
+    om.set_x_reference(xr)
+    gm.x_reference = xr
+    _run_pair(om, gm, rb, 2, 4, 1e-9)
+
+
+def test_emu_standing_and_lane_order(lib):
+    om, gm, rb = S.make_cent_pair(2, 1, lib=lib)
+    om.switchToStand()
+    gm.switchToStand()
+    _run_pair(om, gm, rb, 2, 3, 1e-9)
+    code = (
+        "import sys; sys.path.insert(0, %r); import numpy as np, mpc_setup as S\n"
+        "om, gm, rb = S.make_cent_pair(2, 2, lib=S.emu_lib(), settings_override=dict(mu=0.1), walk=(0.8, 0.5, 0, 0, 0, 0.5))\n"
+        "X = S.random_states(rb, 2, scale=2.0)\n"
+        "for _ in range(3): gm.iterate(X)\n"
+        "np.save(sys.argv[1], np.concatenate([gm.xs.ravel(), gm.us.ravel(), gm.vs.ravel()]))\n" % os.path.dirname(os.path.abspath(__file__))
+    )
+    outs = []
+    for rev in ("0", "1"):
+        path = "/tmp/smpc_cent_order_%s.npy" % rev
+        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, SMPC_EMU_REVERSE=rev))
+        outs.append(np.load(path))
+    assert np.array_equal(outs[0], outs[1]), "a missing phase barrier makes the result depend on the lane order"
+
+
+def test_centroidal_handle_surface(lib):
+    gm, rb, s, _ = S.make_cent_product(1, lib=lib)
+    import simple_mpc
+
+    with pytest.raises(KeyError):
+        simple_mpc.CentroidalOCP({k: v for k, v in s.items() if k != "w_com"}, gm.ocp_handler.model_handler)
+    bad = simple_mpc.CentroidalOCP(dict(s, w_u=np.eye(11)), gm.ocp_handler.model_handler)
+    bad.createProblem(np.zeros(9), 50, 3, -9.81)
+    with pytest.raises(RuntimeError):
+        simple_mpc.BatchedMPC(gm.settings, bad, 1, lib=lib)
+    with pytest.raises(RuntimeError, match="force size"):
+        gm.ocp_handler.createProblem(np.zeros(9), 50, 6, -9.81)
+    with pytest.raises(RuntimeError, match="generateCycleHorizon"):
+        gm.iterate(rb.x_ref[None, :])
+    with pytest.raises(RuntimeError, match="kinodynamics handle"):
+        gm.interpolate(0.001)
+    with pytest.raises(RuntimeError, match="shape"):
+        gm.iterate(np.zeros((1, 9)))
+    # reference tests/problem.cpp:236-247: sizes and weights echo
+    assert gm.ocp_handler.getSize() == 50 and gm.ocp_handler.getNu() == 12
+    assert np.array_equal(gm.ocp_handler.getSettings()["w_linear_mom"], s["w_linear_mom"])
+
+
+# ------------------------------------------------------------------------------------------------ GPU tier
+@pytest.mark.gpu
+def test_gpu_cold_solve_and_closed_loop(built):
+    om, gm, rb = S.make_cent_pair(8, 3)
+    assert S.rel_err(om.cold_trace(), gm.cold_trace()) < 1e-6
+    assert S.rel_err(om.xs, gm.xs) < TOL
+    w = _run_pair(om, gm, rb, 8, 10, TOL)
+    print("centroidal: worst relative xs error over the run: %.3e" % w)
+
+
+@pytest.mark.gpu
+def test_gpu_active_friction_cones(built):
+    om, gm, rb = S.make_cent_pair(4, 2, **HARD)
+    _run_pair(om, gm, rb, 4, 5, TOL, scale=2.0)
+    assert (gm.vs != 0).sum() > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("horizon", [3, 100])
+def test_gpu_unusual_horizons(built, horizon):
+    om, gm, rb = S.make_cent_pair(2, 2, horizon=horizon)
+    _run_pair(om, gm, rb, 2, 3, TOL)
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_properties(built):
+    """BASELINE size (B = 4096, H = 50, 3 iterations): replicated instances are bit-identical, the iterate is primal
+    feasible, the forces carry the weight, every step is a descent step."""
+    B = 4096
+    gm, rb, _, _ = S.make_cent_product(B, max_iters=3)
+    gm.generateCycleHorizon(O.trot_cycle())
+    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = np.tile(S.random_states(rb, 64), (B // 64, 1))
+    for _ in range(4):
+        gm.iterate(X)
+    xs, us, info = gm.xs, gm.us, gm.info
+    r = xs.reshape(B // 64, 64, *xs.shape[1:])
+    assert np.abs(r - r[0:1]).max() == 0.0, "replicated instances must be bit-identical"
+    assert np.all(np.isfinite(info)) and np.all(np.isfinite(us))
+    assert np.all(info[:, 8] < 1e-3), "primal infeasibility after the step"
+    assert np.all(info[:, 1] <= 0), "merit directional derivative must not be positive"
+    assert np.all(info[:, 3] <= info[:, 0] + 1e-9 * np.abs(info[:, 0])), "merit must not increase"
+    fz = us.reshape(B, 50, 4, 3)[:, :, :, 2].sum(2)
+    assert np.abs(fz / (rb.mass * 9.81) - 1.0).max() < 0.5

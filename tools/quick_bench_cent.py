@@ -1,0 +1,21 @@
+"""Quick timing of the centroidal control step on the GPU: python tools/quick_bench_cent.py [B] [iters] [steps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import mpc_setup as S, oracle_lib as O
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+gm, rb, _, _ = S.make_cent_product(B, max_iters=iters)
+gm.generateCycleHorizon(O.trot_cycle()); gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.]))
+X = S.random_states(rb, B)
+gm.iterate(X)
+gm.set_profiling(True); gm.reset_kernel_times()
+t0 = time.time()
+for _ in range(steps):
+    gm.iterate(X)
+dt = (time.time() - t0) / steps
+kt = gm.kernel_times()
+print('centroidal B=%d k=%d: %.2f ms/step  %.0f steps/s |' % (B, iters, dt * 1e3, B / dt), ' '.join('%s %.3f' % (k, v[0] / max(1, v[1])) for k, v in kt.items() if k != '-'),
+      '| finite', bool(np.isfinite(gm.info).all()), 'ls idx max', gm.info[:, 11].max())
