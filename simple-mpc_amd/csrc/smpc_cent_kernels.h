@@ -35,7 +35,7 @@ namespace smpc
     static constexpr int NP2 = (NUP + NCP) / 4;
     static constexpr int X1 = 12, Z1 = 21;        // sweep 1 index space: 9 pivots (+3 pad) | x | vector column
     static constexpr int LDM = 32;
-    static_assert(ZC < LDM, "the stage KKT matrix must fit two 16 x 16 tile rows");
+    static_assert(ZC < LDM && NU <= 16 && NC <= 16, "the stage KKT matrix must fit two 16 x 16 tile rows");
     // per (instance, stage) record written by the backward pass for the forward pass
     static constexpr int G_K = 0;                 // [K | k]  NU x 10
     static constexpr int G_Z = G_K + NU * 10;     // [Z | z]  NC x 10
@@ -165,6 +165,7 @@ namespace smpc
     V3 fs = mk3(0, 0, 0), ts = mk3(0, 0, 0);
     pen = 0.0;
     prim = 0.0;
+#pragma unroll
     for (int f = 0; f < NF; f++)
     {
       const bool on = (mask >> f) & 1u;
@@ -195,6 +196,7 @@ namespace smpc
     xd[6] = ts.x;
     xd[7] = ts.y;
     xd[8] = ts.z;
+#pragma unroll
     for (int i = 0; i < 9; i++)
     {
       const double e = x[i] + md.dt * xd[i] - xn[i];
@@ -209,13 +211,18 @@ namespace smpc
       return 0.5 * dot(r, Wr);
     };
     cost = quad3(md.w_com, c - ld3(xtgt));
-    double cu = 0.0;
+    double cu = 0.0, ru[NU];
+#pragma unroll
+    for (int i = 0; i < NU; i++)
+      ru[i] = u[i] - uref[i];
+#pragma unroll
     for (int i = 0; i < NU; i++)
     {
       double wr = 0.0;
+#pragma unroll
       for (int j = 0; j < NU; j++)
-        wr += md.w_u[i * NU + j] * (u[j] - uref[j]);
-      cu += (u[i] - uref[i]) * wr;
+        wr += md.w_u[i * NU + j] * ru[j];
+      cu += ru[i] * wr;
     }
     cost += 0.5 * cu;
     cost += quad3(md.w_lm, h - ld3(xtgt + 3));
@@ -502,7 +509,15 @@ namespace smpc
             SMPC_PLV(acc_pen) += 0.5 * mu * (vp * vp + dv * dv);
           }
           if (lane >= 32 && lane < 32 + NU)
-            s.ru[lane - 32] = u[lane - 32] - uref[lane - 32];
+          {
+            const int i = lane - 32;
+            s.ru[i] = u[i] - uref[i];
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NU; j++)
+              a += md.w_u[i * NU + j] * (u[j] - uref[j]);
+            s.wu[i] = a;
+          }
           if (lane >= 48 && lane < 48 + NF)
           {
             const int f = lane - 48;
@@ -513,70 +528,64 @@ namespace smpc
           }
         }
         SMPC_LANES_END_WAVE
-        // ---- small products: N_f = W_aa [r_f]x, G = W_aa [fs]x, W r of every residual ----
+        // ---- small products: N_f = W_aa [r_f]x, G = W_aa [fs]x, W r of every residual ; [A B] ----
+        static_assert(NF * 9 + 9 + 15 <= NT, "one small product per lane");
         SMPC_LANES(NT)
         {
           const V3 fsv = ld3(s.fs);
-          for (int item = lane; item < NF * 9 + 9 + 15 + NU; item += NT)
+          if (lane < NF * 9 + 9)
           {
-            if (item < NF * 9)
-            {
-              const int f = item / 9, i = (item % 9) / 3, j = item % 3;
-              const V3 r = ld3(&s.rf[3 * f]);
-              s.N[item] = md.w_aa[i * 3 + 0] * skew_el(r, 0, j) + md.w_aa[i * 3 + 1] * skew_el(r, 1, j) + md.w_aa[i * 3 + 2] * skew_el(r, 2, j);
-            }
-            else if (item < NF * 9 + 9)
-            {
-              const int e = item - NF * 9, i = e / 3, j = e % 3;
-              s.G[e] = md.w_aa[i * 3 + 0] * skew_el(fsv, 0, j) + md.w_aa[i * 3 + 1] * skew_el(fsv, 1, j) + md.w_aa[i * 3 + 2] * skew_el(fsv, 2, j);
-            }
-            else if (item < NF * 9 + 9 + 15)
-            {
-              const int e = item - NF * 9 - 9; // 0..2 la, 3..5 aa, 6..14 x blocks
-              if (e < 3)
-                s.wla[e] = md.w_la[e * 3] * s.rla[0] + md.w_la[e * 3 + 1] * s.rla[1] + md.w_la[e * 3 + 2] * s.rla[2];
-              else if (e < 6)
-                s.waa[e - 3] = md.w_aa[(e - 3) * 3] * s.ts[0] + md.w_aa[(e - 3) * 3 + 1] * s.ts[1] + md.w_aa[(e - 3) * 3 + 2] * s.ts[2];
-              else
-              {
-                const int i = e - 6, bo = (i / 3) * 3, k = i % 3;
-                const double * W = i < 3 ? md.w_com : (i < 6 ? md.w_lm : md.w_am);
-                s.wrx[i] = W[k * 3] * s.rx[bo] + W[k * 3 + 1] * s.rx[bo + 1] + W[k * 3 + 2] * s.rx[bo + 2];
-              }
-            }
+            // lanes 0 .. 9 NF - 1: N_f(i, j) ; next 9 lanes: G(i, j)
+            const bool isN = lane < NF * 9;
+            const int e = isN ? lane % 9 : lane - NF * 9, i = e / 3, j = e % 3;
+            const V3 r = isN ? ld3(&s.rf[3 * (lane / 9)]) : fsv;
+            const double a = md.w_aa[i * 3 + 0] * skew_el(r, 0, j) + md.w_aa[i * 3 + 1] * skew_el(r, 1, j) + md.w_aa[i * 3 + 2] * skew_el(r, 2, j);
+            if (isN)
+              s.N[lane] = a;
             else
-            {
-              const int i = item - NF * 9 - 9 - 15;
-              double a = 0.0;
-              for (int j = 0; j < NU; j++)
-                a += md.w_u[i * NU + j] * s.ru[j];
-              s.wu[i] = a;
-            }
+              s.G[e] = a;
           }
-          // [A B] in sweep-2 column order
-          for (int idx = lane; idx < 9 * LDM; idx += NT)
+          else if (lane < NF * 9 + 9 + 15)
           {
-            const int k = idx / LDM, j = idx % LDM;
-            double a = 0.0;
-            if (j < NU)
+            const int e = lane - NF * 9 - 9; // 0..2 la, 3..5 aa, 6..14 x blocks
+            const int k = e % 3;
+            const double * W = e < 3 ? md.w_la : (e < 6 ? md.w_aa : (e < 9 ? md.w_com : (e < 12 ? md.w_lm : md.w_am)));
+            const double * rv = e < 3 ? s.rla : (e < 6 ? s.ts : s.rx + (e - 6) / 3 * 3);
+            const double a = W[k * 3] * rv[0] + W[k * 3 + 1] * rv[1] + W[k * 3 + 2] * rv[2];
+            double * dst = e < 3 ? s.wla + e : (e < 6 ? s.waa + (e - 3) : s.wrx + (e - 6));
+            *dst = a;
+          }
+          // [A B] in sweep-2 column order: zero, then the structural non-zeros
+          for (int idx = lane; idx < 9 * LDM; idx += NT)
+            s.ABp[idx] = 0.0;
+        }
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        {
+          const V3 fsv = ld3(s.fs);
+          if (lane < NU)
+          { // B: rows 3..5 <- dt act I ; rows 6..8 <- dt [r_f]x (r_f = 0 for a foot in the air)
+            const int f = lane / 3, jj = lane % 3;
+            const V3 r = ld3(&s.rf[3 * f]);
+            s.ABp[(3 + jj) * LDM + lane] = dt * s.act[f];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+              if (k != jj)
+                s.ABp[(6 + k) * LDM + lane] = dt * skew_el(r, k, jj);
+          }
+          else if (lane >= 16 && lane < 25)
+          { // A = I + dt [[0, I/m, 0], [0, 0, 0], [[fs]x, 0, 0]], column i = lane - 16
+            const int i = lane - 16;
+            s.ABp[i * LDM + XO + i] = 1.0;
+            if (i >= 3 && i < 6)
+              s.ABp[(i - 3) * LDM + XO + i] = dt / mass;
+            if (i < 3)
             {
-              const int f = j / 3, jj = j % 3;
-              const V3 r = ld3(&s.rf[3 * f]); // zero for a foot in the air
-              if (k >= 3 && k < 6)
-                a = k - 3 == jj ? dt * s.act[f] : 0.0;
-              else if (k >= 6)
-                a = dt * skew_el(r, k - 6, jj);
+#pragma unroll
+              for (int k = 0; k < 3; k++)
+                if (k != i)
+                  s.ABp[(6 + k) * LDM + XO + i] = dt * skew_el(fsv, k, i);
             }
-            else if (j >= XO && j < XO + 9)
-            {
-              const int i = j - XO;
-              a = k == i ? 1.0 : 0.0;
-              if (k < 3 && i == k + 3)
-                a += dt / mass;
-              if (k >= 6 && i < 3)
-                a += dt * skew_el(fsv, k - 6, i);
-            }
-            s.ABp[idx] = a;
           }
         }
         SMPC_LANES_END_WAVE
@@ -623,6 +632,7 @@ namespace smpc
           if (lane < 9)
           {
             double a = 0.0, gx = 0.0;
+#pragma unroll
             for (int k = 0; k < 9; k++)
             {
               a += s.ABp[k * LDM + XO + lane] * l1[k];
@@ -637,6 +647,7 @@ namespace smpc
           {
             const int j = lane - 16, f = j / 3, k = j % 3;
             double a = 0.0, gu = 0.0;
+#pragma unroll
             for (int kk = 0; kk < 9; kk++)
             {
               a += s.ABp[kk * LDM + j] * l1[kk];
@@ -652,33 +663,33 @@ namespace smpc
             s.gu[j] = s.lu[j] + gu;
             SMPC_PLV(acc_dual) = fmax(SMPC_PLV(acc_dual), fabs(r));
           }
-          // M1 = [[I + mu P, sqrt(mu) P, sqrt(mu) pt0], [., P, pt0]] (pad pivots 9..11: unit diagonal)
-          const double smu = sqrt(mu);
           for (int idx = lane; idx < LDM * LDM; idx += NT)
+            s.M[idx] = 0.0;
+        }
+        SMPC_LANES_END_WAVE
+        // M1 = [[I + mu P, sqrt(mu) P, sqrt(mu) pt0], [., P, pt0]] (pad pivots 9..11: unit diagonal)
+        SMPC_LANES(NT)
+        {
+          const double smu = sqrt(mu);
+          for (int idx = lane; idx < 81; idx += NT)
           {
-            const int i = idx / LDM, j = idx % LDM;
-            const int lo = i < j ? i : j, hi = i < j ? j : i;
-            double a = 0.0;
-            if (hi < 9)
-              a = mu * s.P[lo * 9 + hi] + (lo == hi ? 1.0 : 0.0);
-            else if (hi < X1)
-              a = lo == hi ? 1.0 : 0.0;
-            else if (hi < Z1)
-            {
-              if (lo < 9)
-                a = smu * s.P[lo * 9 + hi - X1];
-              else if (lo >= X1)
-                a = s.P[(lo - X1) * 9 + hi - X1];
-            }
-            else if (hi == Z1)
-            {
-              if (lo < 9)
-                a = smu * s.pt0[lo];
-              else if (lo >= X1 && lo < Z1)
-                a = s.pt0[lo - X1];
-            }
-            s.M[idx] = a;
+            const int i = idx / 9, j = idx % 9;
+            const double pv = s.P[idx];
+            s.M[i * LDM + j] = mu * pv + (i == j ? 1.0 : 0.0);
+            s.M[i * LDM + X1 + j] = smu * pv;
+            s.M[(X1 + j) * LDM + i] = smu * pv;
+            s.M[(X1 + i) * LDM + X1 + j] = pv;
           }
+          if (lane < 9)
+          {
+            const double a = s.pt0[lane];
+            s.M[lane * LDM + Z1] = smu * a;
+            s.M[Z1 * LDM + lane] = smu * a;
+            s.M[(X1 + lane) * LDM + Z1] = a;
+            s.M[Z1 * LDM + X1 + lane] = a;
+          }
+          else if (lane < X1)
+            s.M[lane * LDM + lane] = 1.0;
         }
         SMPC_LANES_END_WAVE
         // ---- sweep 1: P~, p~ ----
@@ -721,72 +732,91 @@ namespace smpc
             s.pt[lane] = s.M[(X1 + lane) * LDM + Z1];
         }
         SMPC_LANES_END_WAVE
-        // ---- sweep-2 matrix: cost / constraint part ----
+        // ---- sweep-2 matrix: cost / constraint part (M was stored back by the sweep-1 epilogue: clear it first) ----
+        SMPC_LANES(NT)
+        for (int idx = lane; idx < LDM * LDM; idx += NT)
+          s.M[idx] = 0.0;
+        SMPC_LANES_END_WAVE
         SMPC_LANES(NT)
         {
           const V3 fsv = ld3(s.fs);
-          for (int idx = lane; idx < LDM * LDM; idx += NT)
+          // R = Luu + preg I
+          for (int idx = lane; idx < NU * NU; idx += NT)
           {
-            const int i = idx / LDM, j = idx % LDM;
-            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const int i = idx / NU, j = idx % NU;
+            const int fa = i / 3, ia = i % 3, fb = j / 3, jb = j % 3;
+            const V3 ra = ld3(&s.rf[3 * fa]);
+            double a = md.w_u[idx] + (i == j ? preg : 0.0) + s.act[fa] * s.act[fb] * md.w_la[ia * 3 + jb] / (mass * mass);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+              a += skew_el(ra, k, ia) * s.N[fb * 9 + k * 3 + jb];
+            s.M[i * LDM + j] = a;
+          }
+          // Q = Lxx + preg I (block diagonal)
+          for (int idx = lane; idx < 81; idx += NT)
+          {
+            const int xl = idx / 9, xi = idx % 9;
+            double a = xl == xi ? preg : 0.0;
+            if (xl / 3 == xi / 3)
+            {
+              const double * W = xl < 3 ? md.w_com : (xl < 6 ? md.w_lm : md.w_am);
+              a += W[(xl % 3) * 3 + xi % 3];
+              if (xl < 3)
+              {
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                  a += skew_el(fsv, k, xl) * s.G[k * 3 + xi];
+              }
+            }
+            s.M[(XO + xl) * LDM + XO + xi] = a;
+          }
+          // S^T: Lxu(xi, j), only the com rows
+          for (int idx = lane; idx < 3 * NU; idx += NT)
+          {
+            const int xi = idx / NU, j = idx % NU, f = j / 3, jb = j % 3;
             double a = 0.0;
-            if (hi < NU)
-            { // R = Luu + preg I
-              const int fa = lo / 3, ia = lo % 3, fb = hi / 3, jb = hi % 3;
-              a = md.w_u[lo * NU + hi] + (lo == hi ? preg : 0.0) + s.act[fa] * s.act[fb] * md.w_la[ia * 3 + jb] / (mass * mass);
-              const V3 ra = ld3(&s.rf[3 * fa]);
-              for (int k = 0; k < 3; k++)
-                a += skew_el(ra, k, ia) * s.N[fb * 9 + k * 3 + jb];
-            }
-            else if (hi < NUP)
-              a = lo == hi ? 1.0 : 0.0;
-            else if (hi < VO + NC)
-            { // D^T (active rows) ; -mu I
-              const int row = hi - VO, f = row / 2;
-              if (lo < NU)
-                a = lo / 3 == f && s.cact[row] != 0.0 ? s.Cu[row * 3 + lo % 3] : 0.0;
-              else if (lo == hi)
-                a = -mu;
-            }
-            else if (hi < XO)
-              a = lo == hi ? 1.0 : 0.0;
-            else if (hi < ZC)
-            {
-              const int xi = hi - XO;
-              if (lo < NU)
-              { // S^T: Lxu(xi, lo), only the com rows
-                if (xi < 3)
-                {
-                  const int f = lo / 3, jb = lo % 3;
-                  for (int k = 0; k < 3; k++)
-                    a += skew_el(fsv, k, xi) * s.N[f * 9 + k * 3 + jb];
-                }
-              }
-              else if (lo >= XO)
-              { // Q = Lxx + preg I
-                const int xl = lo - XO;
-                if (xl / 3 == xi / 3)
-                {
-                  const double * W = xl < 3 ? md.w_com : (xl < 6 ? md.w_lm : md.w_am);
-                  a = W[(xl % 3) * 3 + xi % 3];
-                  if (xl < 3)
-                    for (int k = 0; k < 3; k++)
-                      a += skew_el(fsv, k, xl) * s.G[k * 3 + xi];
-                }
-                if (xl == xi)
-                  a += preg;
-              }
-            }
-            else if (hi == ZC)
-            {
-              if (lo < NU)
-                a = s.r[lo];
-              else if (lo >= VO && lo < VO + NC)
-                a = s.dvec[lo - VO];
-              else if (lo >= XO && lo < ZC)
-                a = s.q[lo - XO];
-            }
-            s.M[idx] = a;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+              a += skew_el(fsv, k, xi) * s.N[f * 9 + k * 3 + jb];
+            s.M[j * LDM + XO + xi] = a;
+            s.M[(XO + xi) * LDM + j] = a;
+          }
+          // D^T (active rows), -mu I, unit pad pivots
+          if (lane < NC * 3)
+          {
+            const int row = lane / 3, k = lane % 3, f = row / 2;
+            const double a = s.cact[row] != 0.0 ? s.Cu[row * 3 + k] : 0.0;
+            s.M[(3 * f + k) * LDM + VO + row] = a;
+            s.M[(VO + row) * LDM + 3 * f + k] = a;
+          }
+          else if (lane < NC * 3 + NC)
+          {
+            const int row = lane - NC * 3;
+            s.M[(VO + row) * LDM + VO + row] = -mu;
+          }
+          else if (lane < NC * 3 + NC + (NUP - NU) + (D::NCP - NC))
+          {
+            const int e = lane - NC * 3 - NC;
+            const int i = e < NUP - NU ? NU + e : VO + NC + (e - (NUP - NU));
+            s.M[i * LDM + i] = 1.0;
+          }
+          // vector column
+          if (lane >= 32 && lane < 32 + NU)
+          {
+            s.M[(lane - 32) * LDM + ZC] = s.r[lane - 32];
+            s.M[ZC * LDM + lane - 32] = s.r[lane - 32];
+          }
+          else if (lane >= 32 + NU && lane < 32 + NU + NC)
+          {
+            const int row = lane - 32 - NU;
+            s.M[(VO + row) * LDM + ZC] = s.dvec[row];
+            s.M[ZC * LDM + VO + row] = s.dvec[row];
+          }
+          else if (lane >= 32 + NU + NC && lane < 32 + NU + NC + 9)
+          {
+            const int i = lane - 32 - NU - NC;
+            s.M[(XO + i) * LDM + ZC] = s.q[i];
+            s.M[ZC * LDM + XO + i] = s.q[i];
           }
         }
         SMPC_LANES_END_WAVE
