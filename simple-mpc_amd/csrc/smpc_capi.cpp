@@ -417,6 +417,8 @@ extern "C"
   }
   int smpc_debug_get_phase_cycles(smpc_handle * h, double * out64)
   {
+    if (h && h->cent && h->cent->buf.dbg)
+      return guarded([&] { h->cent->get_linear(h->cent->buf.dbg, 64, out64); });
     if (!h || h->cent || !h->eng->buf.dbg)
       return fail(SMPC_ERR_INVALID, "phase timers are off (set SMPC_PHASE_PROFILE=1 before smpc_create)");
     return guarded([&] { h->eng->get_linear(h->eng->buf.dbg, 64, out64); });

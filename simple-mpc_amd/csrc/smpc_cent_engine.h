@@ -117,6 +117,8 @@ namespace smpc
       buf.scal = dalloc((size_t)B * SC_N);
       buf.xdot01 = dalloc((size_t)B * 18);
       buf.zeros = dalloc(64);
+      if (std::getenv("SMPC_PHASE_PROFILE"))
+        buf.dbg = dalloc(64);
       buf.stages = (CentStage<DC> *)dev_alloc((size_t)H * sizeof(CentStage<DC>));
       buf.model = (CentDevModel<DC> *)dev_alloc(sizeof(CentDevModel<DC>));
       X_dev = dalloc((size_t)B * DK::NX);
@@ -142,7 +144,7 @@ namespace smpc
     ~CentEngine()
     {
       for (double * p : {buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot, buf.ftraj, buf.gains, buf.scal, buf.xdot01,
-                         buf.zeros, X_dev, cstate_dev, feet_dev, stage_out})
+                         buf.zeros, buf.dbg, X_dev, cstate_dev, feet_dev, stage_out})
         dev_free(p);
       dev_free(buf.stages);
       dev_free(buf.model);

@@ -18,6 +18,16 @@
 #include "smpc_riccati_kino.h"
 #include "smpc_solver_kernels.h"
 
+// fine-grained phase timers inside the stage loop (each tick is a global read-modify-write by block 0: they perturb
+// what they measure, so they are a build-time option; the coarse timers per pass are always available)
+#ifdef SMPC_CENT_FINE_PROF
+#define CENT_FINE_TICK(n) prof_tick(dbg, n, tprev)
+#define CENT_FINE_DBG dbg
+#else
+#define CENT_FINE_TICK(n)
+#define CENT_FINE_DBG nullptr
+#endif
+
 namespace smpc
 {
   template <int NF_>
@@ -35,7 +45,8 @@ namespace smpc
     static constexpr int NP2 = (NUP + NCP) / 4;
     static constexpr int X1 = 12, Z1 = 21;        // sweep 1 index space: 9 pivots (+3 pad) | x | vector column
     static constexpr int LDM = 32;
-    static_assert(ZC < LDM && NU <= 16 && NC <= 16, "the stage KKT matrix must fit two 16 x 16 tile rows");
+    static constexpr int R1 = Z1 + 1, R2 = XO + 10; // rows of the two bordered matrices that are ever non-zero
+    static_assert(ZC < LDM && NU <= 16 && NC <= 16 && 3 * NU <= 64, "the stage KKT matrix must fit two 16 x 16 tile rows");
     // per (instance, stage) record written by the backward pass for the forward pass
     static constexpr int G_K = 0;                 // [K | k]  NU x 10
     static constexpr int G_Z = G_K + NU * 10;     // [Z | z]  NC x 10
@@ -88,6 +99,7 @@ namespace smpc
     double * scal = nullptr;   // [B][SC_N]
     double * xdot01 = nullptr; // [B][2][9]
     double * zeros = nullptr;  // [64] zeros (address target of masked-out prefetch slots)
+    double * dbg = nullptr;    // [64] optional in-kernel phase timers (block 0 only; null = off)
     CentStage<D> * stages = nullptr;
     CentDevModel<D> * model = nullptr;
   };
@@ -119,7 +131,9 @@ namespace smpc
     double in[D::I_REGS * 64];       // stage inputs (I_* offsets)
     double P[81], p[9], Pt[81], pt[9], pt0[9];
     double ABp[9 * D::LDM];          // [A B] in sweep-2 column order (B at 0, A at XO)
-    double M[D::LDM * D::LDM];       // bordered matrix of the current sweep (built here, swept in registers)
+    // bordered matrices of the two sweeps (built here, swept in registers): zero-filled once, after that only the
+    // structural non-zeros are rewritten per stage (results leave the accumulators directly, never through these)
+    double M1[D::R1 * D::LDM], M2[D::R2 * D::LDM];
     double prow[4 * D::LDM], urow[4 * D::LDM];
     double fs[3], ts[3], rf[3 * NF], act[NF], Cu[NC * 3], cact[NC];
     double f[9], dvec[NC], lpd[9], vpd[NC];
@@ -152,36 +166,50 @@ namespace smpc
     return a;
   }
 
-  // Stage merit terms at a point (each lane evaluates one whole stage: used by the line search).
+  // Stage merit terms at the trial point  w + alpha dw  (each lane evaluates one whole stage: used by the line search;
+  // the point is formed entry by entry from the iterate and the step, so no per-lane copy of it is kept in registers).
   // Returns cost, penalty and primal infeasibility of stage t; xdot optionally.
   template <class D>
-  SMPC_DEV void cent_stage_merit(
-    const CentDevModel<D> & md, unsigned mask, const double * x, const double * u, const double * xn, const double * v, const double * ve,
-    const double * l1, const double * l1e, const double * p, const double * uref, const double * xtgt, double & cost, double & pen,
-    double & prim, double * xdot)
+  struct CentTrial
+  {
+    const double *x, *dx, *xn, *dxn, *u, *du, *v, *dv, *l1, *dl; // iterate and step (dxn = dx of stage t + 1)
+    const double *ve, *l1e, *p, *uref, *xtgt;
+    double alpha;
+    unsigned mask;
+  };
+  template <class D>
+  SMPC_DEV void cent_stage_merit(const CentDevModel<D> & md, const CentTrial<D> & q, double & cost, double & pen, double & prim, double * xdot, double * ru_lds)
   {
     constexpr int NF = D::NF, NU = D::NU;
-    const V3 c = ld3(x), h = ld3(x + 3), L = ld3(x + 6);
+    const double al = q.alpha;
+    auto X = [&](int i) { return q.x[i] + al * q.dx[i]; };
+    const V3 c = mk3(X(0), X(1), X(2)), h = mk3(X(3), X(4), X(5)), L = mk3(X(6), X(7), X(8));
     V3 fs = mk3(0, 0, 0), ts = mk3(0, 0, 0);
     pen = 0.0;
     prim = 0.0;
+    double cu = 0.0;
 #pragma unroll
     for (int f = 0; f < NF; f++)
     {
-      const bool on = (mask >> f) & 1u;
-      const V3 F = ld3(u + 3 * f);
+      const bool on = (q.mask >> f) & 1u;
+      const V3 F = mk3(q.u[3 * f] + al * q.du[3 * f], q.u[3 * f + 1] + al * q.du[3 * f + 1], q.u[3 * f + 2] + al * q.du[3 * f + 2]);
+      // control residual to a lane-private LDS strip: the NU x NU weight is applied by a rolled loop below (a fully
+      // unrolled form keeps all of W_u live and spills)
+      ru_lds[3 * f] = F.x - q.uref[3 * f];
+      ru_lds[3 * f + 1] = F.y - q.uref[3 * f + 1];
+      ru_lds[3 * f + 2] = F.z - q.uref[3 * f + 2];
       double vp0 = 0.0, vp1 = 0.0;
       if (on)
       {
         fs = fs + F;
-        ts = ts + cross(ld3(p + 3 * f) - c, F);
+        ts = ts + cross(ld3(q.p + 3 * f) - c, F);
         const double c0 = -F.z + md.cone_eps, c1 = F.x * F.x + F.y * F.y - md.mu_fric * md.mu_fric * F.z * F.z;
-        const double z0 = c0 + md.mu * ve[2 * f], z1 = c1 + md.mu * ve[2 * f + 1];
+        const double z0 = c0 + md.mu * q.ve[2 * f], z1 = c1 + md.mu * q.ve[2 * f + 1];
         vp0 = (z0 - fmin(z0, 0.0)) / md.mu;
         vp1 = (z1 - fmin(z1, 0.0)) / md.mu;
         prim = fmax(prim, fmax(fmax(c0, 0.0), fmax(c1, 0.0)));
       }
-      const double d0 = vp0 - v[2 * f], d1 = vp1 - v[2 * f + 1];
+      const double d0 = vp0 - (q.v[2 * f] + al * q.dv[2 * f]), d1 = vp1 - (q.v[2 * f + 1] + al * q.dv[2 * f + 1]);
       pen += 0.5 * md.mu * (vp0 * vp0 + d0 * d0);
       pen += 0.5 * md.mu * (vp1 * vp1 + d1 * d1);
     }
@@ -199,8 +227,8 @@ namespace smpc
 #pragma unroll
     for (int i = 0; i < 9; i++)
     {
-      const double e = x[i] + md.dt * xd[i] - xn[i];
-      const double lp = l1e[i] + e / md.mu, dl = lp - l1[i];
+      const double e = X(i) + md.dt * xd[i] - (q.xn[i] + al * q.dxn[i]);
+      const double lp = q.l1e[i] + e / md.mu, dl = lp - (q.l1[i] + al * q.dl[i]);
       pen += 0.5 * md.mu * (lp * lp + dl * dl);
       prim = fmax(prim, fabs(e));
       if (xdot)
@@ -210,23 +238,19 @@ namespace smpc
       const V3 Wr = ldm3(W) * r;
       return 0.5 * dot(r, Wr);
     };
-    cost = quad3(md.w_com, c - ld3(xtgt));
-    double cu = 0.0, ru[NU];
-#pragma unroll
-    for (int i = 0; i < NU; i++)
-      ru[i] = u[i] - uref[i];
-#pragma unroll
+    cost = quad3(md.w_com, c - ld3(q.xtgt));
+#pragma unroll 1
     for (int i = 0; i < NU; i++)
     {
       double wr = 0.0;
-#pragma unroll
+#pragma unroll 4
       for (int j = 0; j < NU; j++)
-        wr += md.w_u[i * NU + j] * ru[j];
-      cu += ru[i] * wr;
+        wr += md.w_u[i * NU + j] * ru_lds[j];
+      cu += ru_lds[i] * wr;
     }
     cost += 0.5 * cu;
-    cost += quad3(md.w_lm, h - ld3(xtgt + 3));
-    cost += quad3(md.w_am, L - ld3(xtgt + 6));
+    cost += quad3(md.w_lm, h - ld3(q.xtgt + 3));
+    cost += quad3(md.w_am, L - ld3(q.xtgt + 6));
     cost += quad3(md.w_la, g + (1.0 / md.mass) * fs);
     cost += quad3(md.w_aa, ts);
   }
@@ -277,7 +301,8 @@ namespace smpc
     const size_t ib = inst * R;
     SMPC_LDS(CentLds<D>, ldsv, 1);
     CentLds<D> & s = ldsv[0];
-    long long tprev = 0;
+    double * dbg = block == 0 ? b.dbg : nullptr;
+    long long tprev = SMPC_CLOCK();
     double * gsc = b.scal + inst * SC_N;
 
     // ---- model constants -> LDS ----
@@ -290,6 +315,19 @@ namespace smpc
         dst[i] = src[i];
       if (lane < 16)
         s.sc[lane] = lane == SC_PREG && !ka.reset_preg ? gsc[SC_PREG] : 0.0;
+      for (int i = lane; i < D::R1 * LDM; i += NT)
+        s.M1[i] = 0.0;
+      for (int i = lane; i < D::R2 * LDM; i += NT)
+        s.M2[i] = 0.0;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    {
+      // decoupled unit pivots of the pad rows (panels are 4 pivots wide)
+      if (lane >= 9 && lane < X1)
+        s.M1[lane * LDM + lane] = 1.0;
+      if ((lane >= NU && lane < NUP) || (lane >= VO + NC && lane < XO))
+        s.M2[lane * LDM + lane] = 1.0;
     }
     SMPC_LANES_END_WAVE
     const CentDevModel<D> & md = s.md;
@@ -442,6 +480,7 @@ namespace smpc
             g[D::G_pn + lane] = s.p[lane];
         }
         SMPC_LANES_END_WAVE
+        CENT_FINE_TICK(0);
         const double *x = s.in + D::I_x, *xn = s.in + D::I_xn, *l1 = s.in + D::I_l1, *l1e = s.in + D::I_l1e, *l0 = s.in + D::I_l0;
         const double *u = s.in + D::I_u, *v = s.in + D::I_v, *ve = s.in + D::I_ve, *pp = s.in + D::I_p, *uref = s.in + D::I_ur, *xtgt = s.in + D::I_xt;
         // ---- point quantities: forces, lever arms, defect, multiplier estimates ----
@@ -528,6 +567,7 @@ namespace smpc
           }
         }
         SMPC_LANES_END_WAVE
+        CENT_FINE_TICK(1);
         // ---- small products: N_f = W_aa [r_f]x, G = W_aa [fs]x, W r of every residual ; [A B] ----
         static_assert(NF * 9 + 9 + 15 <= NT, "one small product per lane");
         SMPC_LANES(NT)
@@ -589,6 +629,7 @@ namespace smpc
           }
         }
         SMPC_LANES_END_WAVE
+        CENT_FINE_TICK(2);
         // ---- cost gradient, cost ; pt0 = p + P f ----
         SMPC_LANES(NT)
         {
@@ -626,6 +667,7 @@ namespace smpc
           }
         }
         SMPC_LANES_END_WAVE
+        CENT_FINE_TICK(3);
         // ---- knot vectors q, r and the merit-gradient pieces ; sweep-1 matrix ----
         SMPC_LANES(NT)
         {
@@ -663,35 +705,38 @@ namespace smpc
             s.gu[j] = s.lu[j] + gu;
             SMPC_PLV(acc_dual) = fmax(SMPC_PLV(acc_dual), fabs(r));
           }
-          for (int idx = lane; idx < LDM * LDM; idx += NT)
-            s.M[idx] = 0.0;
         }
         SMPC_LANES_END_WAVE
+        CENT_FINE_TICK(4);
         // M1 = [[I + mu P, sqrt(mu) P, sqrt(mu) pt0], [., P, pt0]] (pad pivots 9..11: unit diagonal)
         SMPC_LANES(NT)
         {
           const double smu = sqrt(mu);
-          for (int idx = lane; idx < 81; idx += NT)
+#pragma unroll
+          for (int n = 0; n < 2; n++)
           {
-            const int i = idx / 9, j = idx % 9;
-            const double pv = s.P[idx];
-            s.M[i * LDM + j] = mu * pv + (i == j ? 1.0 : 0.0);
-            s.M[i * LDM + X1 + j] = smu * pv;
-            s.M[(X1 + j) * LDM + i] = smu * pv;
-            s.M[(X1 + i) * LDM + X1 + j] = pv;
+            const int idx = lane + n * NT;
+            if (idx < 81)
+            {
+              const int i = idx / 9, j = idx % 9;
+              const double pv = s.P[idx];
+              s.M1[i * LDM + j] = mu * pv + (i == j ? 1.0 : 0.0);
+              s.M1[i * LDM + X1 + j] = smu * pv;
+              s.M1[(X1 + j) * LDM + i] = smu * pv;
+              s.M1[(X1 + i) * LDM + X1 + j] = pv;
+            }
           }
           if (lane < 9)
           {
             const double a = s.pt0[lane];
-            s.M[lane * LDM + Z1] = smu * a;
-            s.M[Z1 * LDM + lane] = smu * a;
-            s.M[(X1 + lane) * LDM + Z1] = a;
-            s.M[Z1 * LDM + X1 + lane] = a;
+            s.M1[lane * LDM + Z1] = smu * a;
+            s.M1[Z1 * LDM + lane] = smu * a;
+            s.M1[(X1 + lane) * LDM + Z1] = a;
+            s.M1[Z1 * LDM + X1 + lane] = a;
           }
-          else if (lane < X1)
-            s.M[lane * LDM + lane] = 1.0;
         }
         SMPC_LANES_END_WAVE
+        CENT_FINE_TICK(5);
         // ---- sweep 1: P~, p~ ----
         SMPC_LANES(NT)
         {
@@ -702,10 +747,15 @@ namespace smpc
             for (int J = I; J < 2; J++)
 #pragma unroll
               for (int vv = 0; vv < 4; vv++)
-                SMPC_ACCV(macc, tix<2>(I, J), vv) = s.M[(16 * I + lr + 4 * vv) * LDM + 16 * J + lc];
+              {
+                const int r = 16 * I + lr + 4 * vv;
+                SMPC_ACCV(macc, tix<2>(I, J), vv) = r < D::R1 ? s.M1[r * LDM + 16 * J + lc] : 0.0;
+              }
         }
         SMPC_LANES_END_WAVE
-        wave_block_sweep<NT, 2, false, 0, 3>(macc, s.prow, s.urow, nullptr, tprev);
+        CENT_FINE_TICK(6);
+        wave_block_sweep<NT, 2, false, 0, 3>(macc, s.prow, s.urow, CENT_FINE_DBG, tprev);
+        // P~ (upper triangle of the Schur block is authoritative, mirrored) and p~ straight out of the accumulators
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
@@ -715,34 +765,33 @@ namespace smpc
             for (int J = I; J < 2; J++)
 #pragma unroll
               for (int vv = 0; vv < 4; vv++)
-                s.M[(16 * I + lr + 4 * vv) * LDM + 16 * J + lc] = SMPC_ACCV(macc, tix<2>(I, J), vv);
+              {
+                const int r = 16 * I + lr + 4 * vv - X1, c = 16 * J + lc - X1;
+                const double a = SMPC_ACCV(macc, tix<2>(I, J), vv);
+                if (r >= 0 && r < 9 && c >= r && c < 9)
+                {
+                  s.Pt[r * 9 + c] = a;
+                  s.Pt[c * 9 + r] = a;
+                  g[D::G_Pt + r * 9 + c] = a;
+                  g[D::G_Pt + c * 9 + r] = a;
+                }
+                if (r >= 0 && r < 9 && c == 9)
+                  s.pt[r] = a;
+              }
         }
         SMPC_LANES_END_WAVE
-        SMPC_LANES(NT)
-        {
-          for (int idx = lane; idx < 81; idx += NT)
-          {
-            const int i = idx / 9, j = idx % 9;
-            const int lo = i < j ? i : j, hi = i < j ? j : i;
-            const double a = s.M[(X1 + lo) * LDM + X1 + hi]; // upper triangle is authoritative
-            s.Pt[idx] = a;
-            g[D::G_Pt + idx] = a;
-          }
-          if (lane < 9)
-            s.pt[lane] = s.M[(X1 + lane) * LDM + Z1];
-        }
-        SMPC_LANES_END_WAVE
-        // ---- sweep-2 matrix: cost / constraint part (M was stored back by the sweep-1 epilogue: clear it first) ----
-        SMPC_LANES(NT)
-        for (int idx = lane; idx < LDM * LDM; idx += NT)
-          s.M[idx] = 0.0;
-        SMPC_LANES_END_WAVE
+        CENT_FINE_TICK(7);
+        // ---- sweep-2 matrix: cost / constraint part ----
         SMPC_LANES(NT)
         {
           const V3 fsv = ld3(s.fs);
           // R = Luu + preg I
-          for (int idx = lane; idx < NU * NU; idx += NT)
+#pragma unroll
+          for (int n = 0; n < (NU * NU + NT - 1) / NT; n++)
           {
+            const int idx = lane + n * NT;
+            if (idx >= NU * NU)
+              break;
             const int i = idx / NU, j = idx % NU;
             const int fa = i / 3, ia = i % 3, fb = j / 3, jb = j % 3;
             const V3 ra = ld3(&s.rf[3 * fa]);
@@ -750,11 +799,15 @@ namespace smpc
 #pragma unroll
             for (int k = 0; k < 3; k++)
               a += skew_el(ra, k, ia) * s.N[fb * 9 + k * 3 + jb];
-            s.M[i * LDM + j] = a;
+            s.M2[i * LDM + j] = a;
           }
           // Q = Lxx + preg I (block diagonal)
-          for (int idx = lane; idx < 81; idx += NT)
+#pragma unroll
+          for (int n = 0; n < 2; n++)
           {
+            const int idx = lane + n * NT;
+            if (idx >= 81)
+              break;
             const int xl = idx / 9, xi = idx % 9;
             double a = xl == xi ? preg : 0.0;
             if (xl / 3 == xi / 3)
@@ -768,58 +821,54 @@ namespace smpc
                   a += skew_el(fsv, k, xl) * s.G[k * 3 + xi];
               }
             }
-            s.M[(XO + xl) * LDM + XO + xi] = a;
+            s.M2[(XO + xl) * LDM + XO + xi] = a;
           }
           // S^T: Lxu(xi, j), only the com rows
-          for (int idx = lane; idx < 3 * NU; idx += NT)
+          if (lane < 3 * NU)
           {
+            const int idx = lane;
             const int xi = idx / NU, j = idx % NU, f = j / 3, jb = j % 3;
             double a = 0.0;
 #pragma unroll
             for (int k = 0; k < 3; k++)
               a += skew_el(fsv, k, xi) * s.N[f * 9 + k * 3 + jb];
-            s.M[j * LDM + XO + xi] = a;
-            s.M[(XO + xi) * LDM + j] = a;
+            s.M2[j * LDM + XO + xi] = a;
+            s.M2[(XO + xi) * LDM + j] = a;
           }
           // D^T (active rows), -mu I, unit pad pivots
           if (lane < NC * 3)
           {
             const int row = lane / 3, k = lane % 3, f = row / 2;
             const double a = s.cact[row] != 0.0 ? s.Cu[row * 3 + k] : 0.0;
-            s.M[(3 * f + k) * LDM + VO + row] = a;
-            s.M[(VO + row) * LDM + 3 * f + k] = a;
+            s.M2[(3 * f + k) * LDM + VO + row] = a;
+            s.M2[(VO + row) * LDM + 3 * f + k] = a;
           }
           else if (lane < NC * 3 + NC)
           {
             const int row = lane - NC * 3;
-            s.M[(VO + row) * LDM + VO + row] = -mu;
-          }
-          else if (lane < NC * 3 + NC + (NUP - NU) + (D::NCP - NC))
-          {
-            const int e = lane - NC * 3 - NC;
-            const int i = e < NUP - NU ? NU + e : VO + NC + (e - (NUP - NU));
-            s.M[i * LDM + i] = 1.0;
+            s.M2[(VO + row) * LDM + VO + row] = -mu;
           }
           // vector column
           if (lane >= 32 && lane < 32 + NU)
           {
-            s.M[(lane - 32) * LDM + ZC] = s.r[lane - 32];
-            s.M[ZC * LDM + lane - 32] = s.r[lane - 32];
+            s.M2[(lane - 32) * LDM + ZC] = s.r[lane - 32];
+            s.M2[ZC * LDM + lane - 32] = s.r[lane - 32];
           }
           else if (lane >= 32 + NU && lane < 32 + NU + NC)
           {
             const int row = lane - 32 - NU;
-            s.M[(VO + row) * LDM + ZC] = s.dvec[row];
-            s.M[ZC * LDM + VO + row] = s.dvec[row];
+            s.M2[(VO + row) * LDM + ZC] = s.dvec[row];
+            s.M2[ZC * LDM + VO + row] = s.dvec[row];
           }
           else if (lane >= 32 + NU + NC && lane < 32 + NU + NC + 9)
           {
             const int i = lane - 32 - NU - NC;
-            s.M[(XO + i) * LDM + ZC] = s.q[i];
-            s.M[ZC * LDM + XO + i] = s.q[i];
+            s.M2[(XO + i) * LDM + ZC] = s.q[i];
+            s.M2[ZC * LDM + XO + i] = s.q[i];
           }
         }
         SMPC_LANES_END_WAVE
+        CENT_FINE_TICK(8);
         // ---- M2 += [A B]^T P~ [A B] (and the vector column += [A B]^T p~) on the matrix cores ----
         SMPC_LANES(NT)
         {
@@ -844,7 +893,10 @@ namespace smpc
             for (int J = I; J < 2; J++)
 #pragma unroll
               for (int vv = 0; vv < 4; vv++)
-                SMPC_ACCV(macc, tix<2>(I, J), vv) = s.M[(16 * I + lr + 4 * vv) * LDM + 16 * J + lc];
+              {
+                const int r = 16 * I + lr + 4 * vv;
+                SMPC_ACCV(macc, tix<2>(I, J), vv) = r < D::R2 ? s.M2[r * LDM + 16 * J + lc] : 0.0;
+              }
         }
         SMPC_LANES_END_WAVE
 #pragma unroll
@@ -872,8 +924,10 @@ namespace smpc
 #pragma unroll
             for (int J = I; J < 2; J++)
               SMPC_MFMA(macc, tix<2>(I, J), aop, sk * 2 + I, top, sk * 2 + J);
+        CENT_FINE_TICK(9);
         // ---- sweep 2: pivots = [u | nu] ----
-        wave_block_sweep<NT, 2, true, 0, D::NP2>(macc, s.prow, s.urow, nullptr, tprev);
+        wave_block_sweep<NT, 2, true, 0, D::NP2>(macc, s.prow, s.urow, CENT_FINE_DBG, tprev);
+        // ---- gains, P_t, p_t straight out of the accumulators ; record for the forward pass ----
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
@@ -883,25 +937,30 @@ namespace smpc
             for (int J = I; J < 2; J++)
 #pragma unroll
               for (int vv = 0; vv < 4; vv++)
-                s.M[(16 * I + lr + 4 * vv) * LDM + 16 * J + lc] = SMPC_ACCV(macc, tix<2>(I, J), vv);
-        }
-        SMPC_LANES_END_WAVE
-        // ---- gains, P_t, p_t, record for the forward pass ----
-        SMPC_LANES(NT)
-        {
-          for (int idx = lane; idx < NU * 10; idx += NT)
-            g[D::G_K + idx] = -s.M[(idx / 10) * LDM + XO + idx % 10];
-          for (int idx = lane; idx < NC * 10; idx += NT)
-            g[D::G_Z + idx] = -s.M[(VO + idx / 10) * LDM + XO + idx % 10];
-          for (int idx = lane; idx < 81; idx += NT)
-          {
-            const int i = idx / 9, j = idx % 9;
-            const int lo = i < j ? i : j, hi = i < j ? j : i;
-            s.P[idx] = s.M[(XO + lo) * LDM + XO + hi];
-          }
+              {
+                const int r = 16 * I + lr + 4 * vv, c = 16 * J + lc - XO; // c: 0..8 state columns, 9 vector column
+                const double a = SMPC_ACCV(macc, tix<2>(I, J), vv);
+                if (c >= 0 && c < 10)
+                {
+                  if (r < NU)
+                    g[D::G_K + r * 10 + c] = -a;
+                  else if (r >= VO && r < VO + NC)
+                    g[D::G_Z + (r - VO) * 10 + c] = -a;
+                  else if (r >= XO && r < XO + 9)
+                  {
+                    const int i = r - XO;
+                    if (c == 9)
+                      s.p[i] = a;
+                    else if (c >= i)
+                    {
+                      s.P[i * 9 + c] = a;
+                      s.P[c * 9 + i] = a;
+                    }
+                  }
+                }
+              }
           if (lane < 9)
           {
-            s.p[lane] = s.M[(XO + lane) * LDM + ZC];
             g[D::G_f + lane] = s.f[lane];
             g[D::G_gx + lane] = s.gxp[lane];
             g[D::G_lpd + lane] = s.lpd[lane];
@@ -920,6 +979,7 @@ namespace smpc
         SMPC_LANES_END_WAVE
       }
 
+      prof_tick(dbg, 10, tprev);
       // =====================================================================================
       // forward pass: dx_0 = 0
       // =====================================================================================
@@ -1023,6 +1083,7 @@ namespace smpc
           s.dx[lane] = s.w[lane];
         SMPC_LANES_END_WAVE
       }
+      prof_tick(dbg, 11, tprev);
       // terminal gradient lx_N . dx_H ; reductions
       SMPC_LANES(NT)
       {
@@ -1061,6 +1122,7 @@ namespace smpc
         SMPC_LANES_END_WAVE
       }
 
+      prof_tick(dbg, 12, tprev);
       // =====================================================================================
       // line search (lane = stage; lane / slot H carries the terminal cost)
       // =====================================================================================
@@ -1074,32 +1136,36 @@ namespace smpc
           double cst = 0.0, pen = 0.0, prm = 0.0;
           for (int t = lane; t <= H; t += NT)
           {
-            double xt[9], xn[9];
             const double * xg = b.xs + (ib + ring_slot(head, t, R)) * 9;
             const double * dxg = b.dxs + (inst * (H + 1) + t) * 9;
-            for (int i = 0; i < 9; i++)
-              xt[i] = xg[i] + alpha * dxg[i];
             if (t == H)
             {
-              cst += 0.5 * dot(ld3(xt + 3), ldm3(md.w_lm) * ld3(xt + 3)) + 0.5 * dot(ld3(xt + 6), ldm3(md.w_am) * ld3(xt + 6));
+              const V3 hh = mk3(xg[3] + alpha * dxg[3], xg[4] + alpha * dxg[4], xg[5] + alpha * dxg[5]);
+              const V3 LL = mk3(xg[6] + alpha * dxg[6], xg[7] + alpha * dxg[7], xg[8] + alpha * dxg[8]);
+              cst += 0.5 * dot(hh, ldm3(md.w_lm) * hh) + 0.5 * dot(LL, ldm3(md.w_am) * LL);
               continue;
             }
             const size_t sl = ib + ring_slot(head, t, R);
-            const double * xng = b.xs + (ib + ring_slot(head, t + 1, R)) * 9;
-            double ut[NU], vt[NC], lt[9];
-            for (int i = 0; i < 9; i++)
-            {
-              xn[i] = xng[i] + alpha * dxg[9 + i];
-              lt[i] = b.lams[sl * 9 + i] + alpha * b.dlams[(inst * H + t) * 9 + i];
-            }
-            for (int i = 0; i < NU; i++)
-              ut[i] = b.us[sl * NU + i] + alpha * b.dus[(inst * H + t) * NU + i];
-            for (int i = 0; i < NC; i++)
-              vt[i] = b.vs[sl * NC + i] + alpha * b.dvs[(inst * H + t) * NC + i];
+            CentTrial<D> q;
+            q.x = xg;
+            q.dx = dxg;
+            q.xn = b.xs + (ib + ring_slot(head, t + 1, R)) * 9;
+            q.dxn = dxg + 9;
+            q.u = b.us + sl * NU;
+            q.du = b.dus + (inst * H + t) * NU;
+            q.v = b.vs + sl * NC;
+            q.dv = b.dvs + (inst * H + t) * NC;
+            q.l1 = b.lams + sl * 9;
+            q.dl = b.dlams + (inst * H + t) * 9;
+            q.ve = b.vs_e + sl * NC;
+            q.l1e = b.lams_e + sl * 9;
+            q.p = b.foot + (inst * H + t) * (3 * NF);
+            q.uref = b.stages[t].u_ref;
+            q.xtgt = b.stages[t].x_tgt;
+            q.alpha = alpha;
+            q.mask = b.stages[t].mask;
             double c1, p1, r1;
-            cent_stage_merit<D>(
-              md, b.stages[t].mask, xt, ut, xn, vt, b.vs_e + sl * NC, lt, b.lams_e + sl * 9, b.foot + (inst * H + t) * (3 * NF), b.stages[t].u_ref,
-              b.stages[t].x_tgt, c1, p1, r1, nullptr);
+            cent_stage_merit<D>(md, q, c1, p1, r1, nullptr, &s.M2[lane * NU]);
             cst += c1;
             pen += p1;
             prm = fmax(prm, r1);
@@ -1134,6 +1200,7 @@ namespace smpc
         if (j + 1 < D::LS_N)
           alpha *= 0.5;
       }
+      prof_tick(dbg, 13, tprev);
       // ---- accept (the last candidate is taken when none passes, like the restated solver) ----
       SMPC_LANES(NT)
       {
@@ -1163,8 +1230,22 @@ namespace smpc
         }
       }
       SMPC_LANES_END_WAVE
+      // the line search used the sweep-2 template as per-lane scratch: restore its zero pattern
+      SMPC_LANES(NT)
+      {
+#pragma unroll
+        for (int n = 0; n < (D::R2 * LDM + NT - 1) / NT; n++)
+          if (lane + n * NT < D::R2 * LDM)
+            s.M2[lane + n * NT] = 0.0;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      if ((lane >= NU && lane < NUP) || (lane >= VO + NC && lane < XO))
+        s.M2[lane * LDM + lane] = 1.0;
+      SMPC_LANES_END_WAVE
     }
 
+    prof_tick(dbg, 14, tprev);
     // ---- outputs: solver scalars, xdot at t = 0, 1 of the accepted iterate (MPC::getStateDerivative) ----
     SMPC_LANES(NT)
     {
@@ -1174,10 +1255,21 @@ namespace smpc
       {
         const int t = lane - 32;
         const size_t sl = ib + ring_slot(head, t, R);
+        CentTrial<D> q;
+        q.x = q.dx = b.xs + sl * 9;
+        q.xn = q.dxn = b.xs + (ib + ring_slot(head, t + 1, R)) * 9;
+        q.u = q.du = b.us + sl * NU;
+        q.v = q.dv = b.vs + sl * NC;
+        q.l1 = q.dl = b.lams + sl * 9;
+        q.ve = b.vs_e + sl * NC;
+        q.l1e = b.lams_e + sl * 9;
+        q.p = b.foot + (inst * H + t) * (3 * NF);
+        q.uref = b.stages[t].u_ref;
+        q.xtgt = b.stages[t].x_tgt;
+        q.alpha = 0.0; // the accepted iterate itself
+        q.mask = b.stages[t].mask;
         double c1, p1, r1, xd[9];
-        cent_stage_merit<D>(
-          md, b.stages[t].mask, b.xs + sl * 9, b.us + sl * NU, b.xs + (ib + ring_slot(head, t + 1, R)) * 9, b.vs + sl * NC, b.vs_e + sl * NC, b.lams + sl * 9,
-          b.lams_e + sl * 9, b.foot + (inst * H + t) * (3 * NF), b.stages[t].u_ref, b.stages[t].x_tgt, c1, p1, r1, xd);
+        cent_stage_merit<D>(md, q, c1, p1, r1, xd, &s.M2[lane * NU]);
         for (int i = 0; i < 9; i++)
           b.xdot01[(inst * 2 + t) * 9 + i] = xd[i];
       }

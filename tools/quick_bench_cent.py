@@ -19,3 +19,9 @@ dt = (time.time() - t0) / steps
 kt = gm.kernel_times()
 print('centroidal B=%d k=%d: %.2f ms/step  %.0f steps/s |' % (B, iters, dt * 1e3, B / dt), ' '.join('%s %.3f' % (k, v[0] / max(1, v[1])) for k, v in kt.items() if k != '-'),
       '| finite', bool(np.isfinite(gm.info).all()), 'ls idx max', gm.info[:, 11].max())
+if os.environ.get('SMPC_PHASE_PROFILE'):
+    out = np.zeros(64); gm._lib.check(gm._lib.L.smpc_debug_get_phase_cycles(gm._h, out))
+    names = ['inputs', 'point', 'small+AB', 'grad', 'knot+zero', 'M1', 'load', 'sweep1+ext', 'M2', 'mfma', 'sweep2+epi(bwd)', 'forward', 'reduce', 'linesearch', 'accept']
+    n = (steps + 1) * iters
+    print('cycles per iteration (block 0):', ' '.join('%s %.0f' % (nm, out[i] / n) for i, nm in enumerate(names)), '| total %.0f' % (out[:40].sum() / n))
+    print('  sweep parts per iteration: gather %.0f invert %.0f mfma %.0f fixup %.0f' % tuple(out[36:40] / n))
