@@ -46,6 +46,7 @@ namespace smpc
     static constexpr int X1 = 12, Z1 = 21;        // sweep 1 index space: 9 pivots (+3 pad) | x | vector column
     static constexpr int LDM = 32;
     static constexpr int R1 = Z1 + 1, R2 = XO + 10; // rows of the two bordered matrices that are ever non-zero
+    static constexpr int LD1 = 24;                  // row stride of the sweep-1 matrix (columns 0 .. Z1)
     static_assert(ZC < LDM && NU <= 16 && NC <= 16 && 3 * NU <= 64, "the stage KKT matrix must fit two 16 x 16 tile rows");
     // per (instance, stage) record written by the backward pass for the forward pass
     static constexpr int G_K = 0;                 // [K | k]  NU x 10
@@ -63,6 +64,7 @@ namespace smpc
     static constexpr int G_N = G_d + NC;
     static constexpr int G_REGS = (G_N + 63) / 64;
     static constexpr int G_STRIDE = G_REGS * 64;
+    static_assert(G_STRIDE <= R1 * LD1, "the forward-pass record is staged over the sweep-1 matrix");
     // stage inputs gathered one stage ahead by the backward pass
     static constexpr int I_x = 0, I_xn = 9, I_l1 = 18, I_l1e = 27, I_l0 = 36, I_u = 45, I_v = I_u + NU, I_ve = I_v + NC;
     static constexpr int I_p = I_ve + NC, I_ur = I_p + 3 * NF, I_xt = I_ur + NU, I_N = I_xt + 9;
@@ -133,15 +135,13 @@ namespace smpc
     double ABp[9 * D::LDM];          // [A B] in sweep-2 column order (B at 0, A at XO)
     // bordered matrices of the two sweeps (built here, swept in registers): zero-filled once, after that only the
     // structural non-zeros are rewritten per stage (results leave the accumulators directly, never through these)
-    double M1[D::R1 * D::LDM], M2[D::R2 * D::LDM];
+    double M1[D::R1 * D::LD1], M2[D::R2 * D::LDM];
     double prow[4 * D::LDM], urow[4 * D::LDM];
     double fs[3], ts[3], rf[3 * NF], act[NF], Cu[NC * 3], cact[NC];
     double f[9], dvec[NC], lpd[9], vpd[NC];
     double ru[NU], rx[9], rla[3], N[NF * 9], G[9], wla[3], waa[3], wrx[9], wu[NU];
     double lx[9], lu[NU], q[9], r[NU], gxp[9], gu[NU];
-    double rec[D::G_STRIDE];         // forward pass: record of the current stage
     double dx[9], du[NU], dv[NC], y[9], w[9];
-    double red[64];
     double sc[16];
   };
 
@@ -301,6 +301,8 @@ namespace smpc
     const size_t ib = inst * R;
     SMPC_LDS(CentLds<D>, ldsv, 1);
     CentLds<D> & s = ldsv[0];
+    double * const rec = s.M1;  // forward pass / recede scratch: record of the current stage (the backward pass is over)
+    double * const red = s.in;  // reductions happen between the passes
     double * dbg = block == 0 ? b.dbg : nullptr;
     long long tprev = SMPC_CLOCK();
     double * gsc = b.scal + inst * SC_N;
@@ -315,19 +317,6 @@ namespace smpc
         dst[i] = src[i];
       if (lane < 16)
         s.sc[lane] = lane == SC_PREG && !ka.reset_preg ? gsc[SC_PREG] : 0.0;
-      for (int i = lane; i < D::R1 * LDM; i += NT)
-        s.M1[i] = 0.0;
-      for (int i = lane; i < D::R2 * LDM; i += NT)
-        s.M2[i] = 0.0;
-    }
-    SMPC_LANES_END_WAVE
-    SMPC_LANES(NT)
-    {
-      // decoupled unit pivots of the pad rows (panels are 4 pivots wide)
-      if (lane >= 9 && lane < X1)
-        s.M1[lane * LDM + lane] = 1.0;
-      if ((lane >= NU && lane < NUP) || (lane >= VO + NC && lane < XO))
-        s.M2[lane * LDM + lane] = 1.0;
     }
     SMPC_LANES_END_WAVE
     const CentDevModel<D> & md = s.md;
@@ -366,8 +355,8 @@ namespace smpc
             st3(ft, pf);
             st3(ft + 3, next);
           }
-          st3(&s.rec[f * 6], ld3(ft));
-          st3(&s.rec[f * 6 + 3], ld3(ft + 3));
+          st3(&rec[f * 6], ld3(ft));
+          st3(&rec[f * 6 + 3], ld3(ft + 3));
         }
       }
       SMPC_LANES_END_WAVE
@@ -376,7 +365,7 @@ namespace smpc
       {
         const int k = idx / NF, f = idx % NF;
         const int t = ka.land[f] - k;
-        const V3 p0 = ld3(&s.rec[f * 6]), p1 = ld3(&s.rec[f * 6 + 3]);
+        const V3 p0 = ld3(&rec[f * 6]), p1 = ld3(&rec[f * 6 + 3]);
         V3 p;
         if (t < 0)
           p = p1;
@@ -418,6 +407,28 @@ namespace smpc
     for (int it = 0; it < ka.iters; it++)
     {
       const double preg = s.sc[SC_PREG] > 0.0 ? s.sc[SC_PREG] : ka.reg_init;
+      // sweep templates: zero pattern and the decoupled unit pivots of the pad rows (the forward pass and the line search
+      // of the previous iteration used these areas as scratch)
+      SMPC_LANES(NT)
+      {
+#pragma unroll
+        for (int n = 0; n < (D::R1 * D::LD1 + NT - 1) / NT; n++)
+          if (lane + n * NT < D::R1 * D::LD1)
+            s.M1[lane + n * NT] = 0.0;
+#pragma unroll
+        for (int n = 0; n < (D::R2 * LDM + NT - 1) / NT; n++)
+          if (lane + n * NT < D::R2 * LDM)
+            s.M2[lane + n * NT] = 0.0;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
+        if (lane >= 9 && lane < X1)
+          s.M1[lane * D::LD1 + lane] = 1.0;
+        if ((lane >= NU && lane < NUP) || (lane >= VO + NC && lane < XO))
+          s.M2[lane * LDM + lane] = 1.0;
+      }
+      SMPC_LANES_END_WAVE
       // =====================================================================================
       // backward pass
       // =====================================================================================
@@ -720,19 +731,19 @@ namespace smpc
             {
               const int i = idx / 9, j = idx % 9;
               const double pv = s.P[idx];
-              s.M1[i * LDM + j] = mu * pv + (i == j ? 1.0 : 0.0);
-              s.M1[i * LDM + X1 + j] = smu * pv;
-              s.M1[(X1 + j) * LDM + i] = smu * pv;
-              s.M1[(X1 + i) * LDM + X1 + j] = pv;
+              s.M1[i * D::LD1 + j] = mu * pv + (i == j ? 1.0 : 0.0);
+              s.M1[i * D::LD1 + X1 + j] = smu * pv;
+              s.M1[(X1 + j) * D::LD1 + i] = smu * pv;
+              s.M1[(X1 + i) * D::LD1 + X1 + j] = pv;
             }
           }
           if (lane < 9)
           {
             const double a = s.pt0[lane];
-            s.M1[lane * LDM + Z1] = smu * a;
-            s.M1[Z1 * LDM + lane] = smu * a;
-            s.M1[(X1 + lane) * LDM + Z1] = a;
-            s.M1[Z1 * LDM + X1 + lane] = a;
+            s.M1[lane * D::LD1 + Z1] = smu * a;
+            s.M1[Z1 * D::LD1 + lane] = smu * a;
+            s.M1[(X1 + lane) * D::LD1 + Z1] = a;
+            s.M1[Z1 * D::LD1 + X1 + lane] = a;
           }
         }
         SMPC_LANES_END_WAVE
@@ -749,7 +760,7 @@ namespace smpc
               for (int vv = 0; vv < 4; vv++)
               {
                 const int r = 16 * I + lr + 4 * vv;
-                SMPC_ACCV(macc, tix<2>(I, J), vv) = r < D::R1 ? s.M1[r * LDM + 16 * J + lc] : 0.0;
+                SMPC_ACCV(macc, tix<2>(I, J), vv) = r < D::R1 && 16 * J + lc < D::LD1 ? s.M1[r * D::LD1 + 16 * J + lc] : 0.0;
               }
         }
         SMPC_LANES_END_WAVE
@@ -926,7 +937,15 @@ namespace smpc
               SMPC_MFMA(macc, tix<2>(I, J), aop, sk * 2 + I, top, sk * 2 + J);
         CENT_FINE_TICK(9);
         // ---- sweep 2: pivots = [u | nu] ----
-        wave_block_sweep<NT, 2, true, 0, D::NP2>(macc, s.prow, s.urow, CENT_FINE_DBG, tprev);
+        // no active cone row: D = 0, the multiplier pivots -mu are decoupled (Z = 0, z = d / mu) and their panels are skipped
+        bool anyact = false;
+#pragma unroll
+        for (int row = 0; row < NC; row++)
+          anyact = anyact || s.cact[row] != 0.0;
+        if (anyact)
+          wave_block_sweep<NT, 2, true, 0, D::NP2>(macc, s.prow, s.urow, CENT_FINE_DBG, tprev);
+        else
+          wave_block_sweep<NT, 2, true, 0, NUP / 4>(macc, s.prow, s.urow, CENT_FINE_DBG, tprev);
         // ---- gains, P_t, p_t straight out of the accumulators ; record for the forward pass ----
         SMPC_LANES(NT)
         {
@@ -945,7 +964,7 @@ namespace smpc
                   if (r < NU)
                     g[D::G_K + r * 10 + c] = -a;
                   else if (r >= VO && r < VO + NC)
-                    g[D::G_Z + (r - VO) * 10 + c] = -a;
+                    g[D::G_Z + (r - VO) * 10 + c] = anyact ? -a : a / mu;
                   else if (r >= XO && r < XO + 9)
                   {
                     const int i = r - XO;
@@ -1003,7 +1022,7 @@ namespace smpc
         {
 #pragma unroll
           for (int n = 0; n < D::G_REGS; n++)
-            s.rec[lane + n * NT] = SMPC_PLV(prec)[n];
+            rec[lane + n * NT] = SMPC_PLV(prec)[n];
           if (t + 1 < H)
           {
             const double * gn = b.gains + (inst * H + t + 1) * D::G_STRIDE;
@@ -1017,26 +1036,26 @@ namespace smpc
         {
           if (lane < NU)
           {
-            const double * K = s.rec + D::G_K + lane * 10;
+            const double * K = rec + D::G_K + lane * 10;
             double a = K[9];
             for (int j = 0; j < 9; j++)
               a += K[j] * s.dx[j];
             s.du[lane] = a;
             b.dus[(inst * H + t) * NU + lane] = a;
-            SMPC_PLV(acc_dphi) += s.rec[D::G_gu + lane] * a;
+            SMPC_PLV(acc_dphi) += rec[D::G_gu + lane] * a;
           }
           if (lane >= 16 && lane < 16 + NC)
           {
             const int row = lane - 16;
-            const double * Z = s.rec + D::G_Z + row * 10;
+            const double * Z = rec + D::G_Z + row * 10;
             double a = Z[9];
             for (int j = 0; j < 9; j++)
               a += Z[j] * s.dx[j];
             b.dvs[(inst * H + t) * NC + row] = a;
-            SMPC_PLV(acc_dphi) -= s.rec[D::G_d + row] * a;
+            SMPC_PLV(acc_dphi) -= rec[D::G_d + row] * a;
           }
           if (lane >= 32 && lane < 41)
-            SMPC_PLV(acc_dphi) += s.rec[D::G_gx + lane - 32] * s.dx[lane - 32];
+            SMPC_PLV(acc_dphi) += rec[D::G_gx + lane - 32] * s.dx[lane - 32];
         }
         SMPC_LANES_END_WAVE
         SMPC_LANES(NT)
@@ -1051,17 +1070,17 @@ namespace smpc
           {
             double sf = 0.0;
             for (int f = 0; f < NF; f++)
-              sf += s.rec[D::G_act + f] * s.du[3 * f + k];
+              sf += rec[D::G_act + f] * s.du[3 * f + k];
             a += dt * sf;
           }
           else
           {
-            V3 tq = cross(ld3(s.rec + D::G_fs), ld3(s.dx)); // [fs]x dc
+            V3 tq = cross(ld3(rec + D::G_fs), ld3(s.dx)); // [fs]x dc
             for (int f = 0; f < NF; f++)
-              tq = tq + cross(ld3(s.rec + D::G_r + 3 * f), ld3(&s.du[3 * f]));
+              tq = tq + cross(ld3(rec + D::G_r + 3 * f), ld3(&s.du[3 * f]));
             a += dt * (k == 0 ? tq.x : (k == 1 ? tq.y : tq.z));
           }
-          s.y[lane] = a + s.rec[D::G_f + lane] - mu * s.rec[D::G_pn + lane];
+          s.y[lane] = a + rec[D::G_f + lane] - mu * rec[D::G_pn + lane];
         }
         SMPC_LANES_END_WAVE
         SMPC_LANES(NT)
@@ -1069,13 +1088,13 @@ namespace smpc
         {
           double w = 0.0;
           for (int j = 0; j < 9; j++)
-            w += s.rec[D::G_Pt + lane * 9 + j] * s.y[j];
+            w += rec[D::G_Pt + lane * 9 + j] * s.y[j];
           const double dxn = s.y[lane] - mu * w;
-          const double dl = w + s.rec[D::G_pn + lane];
+          const double dl = w + rec[D::G_pn + lane];
           s.w[lane] = dxn;
           b.dxs[(inst * (H + 1) + t + 1) * 9 + lane] = dxn;
           b.dlams[(inst * H + t) * 9 + lane] = dl;
-          SMPC_PLV(acc_dphi) -= s.rec[D::G_lpd + lane] * dxn + s.rec[D::G_f + lane] * dl;
+          SMPC_PLV(acc_dphi) -= rec[D::G_lpd + lane] * dxn + rec[D::G_f + lane] * dl;
         }
         SMPC_LANES_END_WAVE
         SMPC_LANES(NT)
@@ -1103,21 +1122,21 @@ namespace smpc
       for (int which = 0; which < 5; which++)
       {
         SMPC_LANES(NT)
-        s.red[lane] = which == 0 ? SMPC_PLV(acc_cost) : (which == 1 ? SMPC_PLV(acc_pen) : (which == 2 ? SMPC_PLV(acc_prim) : (which == 3 ? SMPC_PLV(acc_dual) : SMPC_PLV(acc_dphi))));
+        red[lane] = which == 0 ? SMPC_PLV(acc_cost) : (which == 1 ? SMPC_PLV(acc_pen) : (which == 2 ? SMPC_PLV(acc_prim) : (which == 3 ? SMPC_PLV(acc_dual) : SMPC_PLV(acc_dphi))));
         SMPC_LANES_END_WAVE
         SMPC_LANES(NT)
         if (lane == 0)
         {
           if (which == 0)
-            s.sc[SC_COST] = fold64<false>(s.red);
+            s.sc[SC_COST] = fold64<false>(red);
           else if (which == 1)
-            s.sc[SC_PHI0] = s.sc[SC_COST] + fold64<false>(s.red);
+            s.sc[SC_PHI0] = s.sc[SC_COST] + fold64<false>(red);
           else if (which == 2)
-            s.sc[SC_PRIM] = fold64<true>(s.red);
+            s.sc[SC_PRIM] = fold64<true>(red);
           else if (which == 3)
-            s.sc[SC_DUAL] = fold64<true>(s.red);
+            s.sc[SC_DUAL] = fold64<true>(red);
           else
-            s.sc[SC_DPHI0] = fold64<false>(s.red);
+            s.sc[SC_DPHI0] = fold64<false>(red);
         }
         SMPC_LANES_END_WAVE
       }
@@ -1178,17 +1197,17 @@ namespace smpc
         for (int which = 0; which < 3; which++)
         {
           SMPC_LANES(NT)
-          s.red[lane] = which == 0 ? SMPC_PLV(acc_cost) : (which == 1 ? SMPC_PLV(acc_pen) : SMPC_PLV(acc_prim));
+          red[lane] = which == 0 ? SMPC_PLV(acc_cost) : (which == 1 ? SMPC_PLV(acc_pen) : SMPC_PLV(acc_prim));
           SMPC_LANES_END_WAVE
           SMPC_LANES(NT)
           if (lane == 0)
           {
             if (which == 0)
-              s.sc[SC_COST_NEW] = fold64<false>(s.red);
+              s.sc[SC_COST_NEW] = fold64<false>(red);
             else if (which == 1)
-              s.sc[SC_PHI_NEW] = s.sc[SC_COST_NEW] + fold64<false>(s.red);
+              s.sc[SC_PHI_NEW] = s.sc[SC_COST_NEW] + fold64<false>(red);
             else
-              s.sc[SC_PRIM_NEW] = fold64<true>(s.red);
+              s.sc[SC_PRIM_NEW] = fold64<true>(red);
           }
           SMPC_LANES_END_WAVE
         }
@@ -1229,19 +1248,6 @@ namespace smpc
           s.sc[SC_PREG] = accepted < 0 ? fmin(preg * ka.reg_inc, ka.reg_max) : fmax(preg * ka.reg_dec, ka.reg_min);
         }
       }
-      SMPC_LANES_END_WAVE
-      // the line search used the sweep-2 template as per-lane scratch: restore its zero pattern
-      SMPC_LANES(NT)
-      {
-#pragma unroll
-        for (int n = 0; n < (D::R2 * LDM + NT - 1) / NT; n++)
-          if (lane + n * NT < D::R2 * LDM)
-            s.M2[lane + n * NT] = 0.0;
-      }
-      SMPC_LANES_END_WAVE
-      SMPC_LANES(NT)
-      if ((lane >= NU && lane < NUP) || (lane >= VO + NC && lane < XO))
-        s.M2[lane * LDM + lane] = 1.0;
       SMPC_LANES_END_WAVE
     }
 
