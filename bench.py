@@ -107,6 +107,74 @@ def cpu_baseline(iters, seconds_budget=20.0):
     }
 
 
+def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
+    """BASELINE config "Go2 centroidal (9-dim state), H=50, batch=4096": same step definition on the centroidal OCP
+    (one fused kernel per control step).  Measured states: x_ref (+) N(0, sigma^2), resident in HBM, re-drawn on the
+    device every step (the centroidal solution has no multibody state to feed back)."""
+    import numpy as np
+    import torch
+    import mpc_setup as S
+    import oracle_lib as O
+
+    gm, rb, _, _ = S.make_cent_product(batch, max_iters=iters, device_id=device_id)
+    gm.generateCycleHorizon(O.trot_cycle())
+    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    dev = torch.device("cuda", device_id)
+    X0 = torch.from_numpy(S.random_states(rb, batch)).to(dev)
+    X = X0.clone()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+
+    def step():
+        gm.iterate_device(X.data_ptr())
+        gm.wait()
+        X.copy_(X0)
+        X[:, :3].add_(torch.randn((batch, 3), generator=gen, device=dev, dtype=torch.float64) * 1e-3)
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    gm.set_profiling(True)
+    gm.reset_kernel_times()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = gm.kernel_times()
+    avg = kt["step"][0] / max(kt["step"][1], 1) * 1e-3
+    flops = batch * gm.H * iters * f_ric(9, gm.nu, gm.nc)
+    out = {
+        "metric": "MPC control-steps/sec at fixed ProxDDP iters, Go2 centroidal H=50",
+        "value": batch * steps / dt, "unit": "control-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": "f64",
+        "config": {"workload": "Go2 centroidal (go2_like table), H=%d, %d ProxDDP iters/step, batch=%d, trot 10/30/10/30, "
+                   "x_meas = x_ref (+) N(0, sigma^2)" % (gm.H, iters, batch), "finite": bool(np.all(np.isfinite(gm.info)))},
+        "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if k != "-"},
+        "roofline": {"bound": "mfma", "kernel": "cent_step_body (whole control step: recede + %d ProxDDP iterations)" % iters,
+                     "achieved": flops / avg / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / avg / 1e12 / FP64_PEAK_TFLOPS,
+                     "traffic": None, "avg_launch_ms": avg * 1e3,
+                     "note": "algorithmic FLOPs = B*H*k*F_ric(9,12,8) (SURVEY 8d); the 21 x 21 stage systems leave the matrix cores "
+                             "mostly idle: the kernel is bound by the instruction issue of its index / assembly code (DESIGN.md 3.6)"},
+    }
+    if with_cpu:
+        threads = O.lib().orc_num_threads()
+        Bc = max(threads * 4, 16)
+        om, rbc, _ = S.make_cent_oracle(Bc, max_iters=iters)
+        om.generateCycleHorizon(O.trot_cycle())
+        om.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+        Xc = S.random_states(rbc, Bc)
+        om.iterate(Xc)
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < 5.0 and n < 200:
+            om.iterate(Xc)
+            n += 1
+        out["cpu_baseline"] = {"value": Bc * n / (time.time() - t0), "unit": "control-steps/s", "cores": threads, "kind": "port",
+                               "sample": "CPU restatement (oracle/, not Aligator): %d instances x %d steps, k=%d" % (Bc, n, iters)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +184,9 @@ def main():
     ap.add_argument("--iters", type=int, default=3, help="ProxDDP iterations per control step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--workload", default="kinodynamics", choices=["kinodynamics", "centroidal"],
+                    help="kinodynamics = the headline metric (with the centroidal configuration measured briefly beside it at 1 GPU); "
+                    "centroidal = only the centroidal line")
     args = ap.parse_args()
 
     import numpy as np
@@ -143,6 +214,13 @@ def main():
     import oracle_lib as O
 
     B = args.batch
+    if args.workload == "centroidal":
+        if world > 1:
+            raise SystemExit("--workload centroidal is a single-GPU line")
+        line = centroidal_line(B, args.iters, args.steps, args.warmup, local_rank, not args.no_cpu_baseline)
+        line.update({"n_gpus": 1, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
+        print(json.dumps(line))
+        return
     gm, rb, _, _ = S.make_product(B, max_iters=args.iters, device_id=local_rank)
     gm.generateCycleHorizon(O.trot_cycle())
     gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
@@ -219,6 +297,10 @@ def main():
             out["roofline_other"] = {k: v for k, v in rl.items() if k != dom}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.iters)
+        if world == 1 and not args.no_profile:
+            # the other single-GPU BASELINE configuration, measured briefly beside the headline (not part of `value`)
+            del gm
+            out["other_workloads"] = {"centroidal": centroidal_line(B, args.iters, 10, 3, local_rank, not args.no_cpu_baseline)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

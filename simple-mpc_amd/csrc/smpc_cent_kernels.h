@@ -492,6 +492,7 @@ namespace smpc
         }
         SMPC_LANES_END_WAVE
         CENT_FINE_TICK(0);
+        CENT_FINE_TICK(15); // cost of a tick itself
         const double *x = s.in + D::I_x, *xn = s.in + D::I_xn, *l1 = s.in + D::I_l1, *l1e = s.in + D::I_l1e, *l0 = s.in + D::I_l0;
         const double *u = s.in + D::I_u, *v = s.in + D::I_v, *ve = s.in + D::I_ve, *pp = s.in + D::I_p, *uref = s.in + D::I_ur, *xtgt = s.in + D::I_xt;
         // ---- point quantities: forces, lever arms, defect, multiplier estimates ----

@@ -24,4 +24,5 @@ if os.environ.get('SMPC_PHASE_PROFILE'):
     names = ['inputs', 'point', 'small+AB', 'grad', 'knot+zero', 'M1', 'load', 'sweep1+ext', 'M2', 'mfma', 'sweep2+epi(bwd)', 'forward', 'reduce', 'linesearch', 'accept']
     n = (steps + 1) * iters
     print('cycles per iteration (block 0):', ' '.join('%s %.0f' % (nm, out[i] / n) for i, nm in enumerate(names)), '| total %.0f' % (out[:40].sum() / n))
+    print('  one tick costs %.0f cycles per stage-iteration' % (out[15] / n / 50))
     print('  sweep parts per iteration: gather %.0f invert %.0f mfma %.0f fixup %.0f' % tuple(out[36:40] / n))
