@@ -23,6 +23,16 @@ namespace simple_mpc
     bool kinematics_limits = true, force_cone = false, land_cstr = false;
   };
 
+  struct CentroidalSettings // reference include/simple-mpc/centroidal-dynamics.hpp:27-43
+  {
+    double timestep = 0.01;
+    std::vector<double> w_u;                                                         // nu x nu
+    std::vector<double> w_com, w_linear_mom, w_angular_mom, w_linear_acc, w_angular_acc; // 3 x 3
+    double gravity[3] = {0, 0, -9.81};
+    double mu = 0.8, Lfoot = 0.1, Wfoot = 0.075;
+    int force_size = 3;
+  };
+
   struct MPCSettings // reference include/simple-mpc/mpc.hpp:29-49
   {
     double swing_apex = 0.15;
@@ -76,27 +86,44 @@ namespace simple_mpc
       ks.kinematics_limits = ocp.kinematics_limits;
       ks.force_cone = ocp.force_cone;
       ks.land_cstr = ocp.land_cstr;
-      smpc_mpc_settings ms{};
-      ms.swing_apex = settings.swing_apex;
-      ms.support_force = settings.support_force;
-      ms.TOL = settings.TOL;
-      ms.mu_init = settings.mu_init;
-      ms.max_iters = (int)settings.max_iters;
-      ms.num_threads = (int)settings.num_threads;
-      ms.T_fly = settings.T_fly;
-      ms.T_contact = settings.T_contact;
-      ms.T = (int)settings.T;
-      ms.timestep = settings.timestep;
+      smpc_mpc_settings ms = c_settings(settings);
       check(smpc_create(robot, &ks, &ms, batch, gravity_arg, device_id, &h_));
-      check(smpc_get_dims(h_, dims_));
-      for (int f = 0; f < robot->nfeet; f++)
-        ee_names_.push_back(robot->foot_name[f]);
+      finish(robot);
+    }
+    // CentroidalOCP(settings, model) + createProblem(getCentroidalState(), T, force_size, gravity, false) + MPC(settings, ocp)
+    // (reference src/centroidal-dynamics.cpp:27-37; tests/mpc.cpp:172-258).  iterate() still takes the measured multibody
+    // states [B][nq + nv]; xs_ holds centroidal states [B][H+1][9].
+    BatchedMPC(const smpc_robot_model * robot, const CentroidalSettings & ocp, const MPCSettings & settings, int batch,
+               double gravity_arg = -9.81, int device_id = 0)
+    : batch_(batch), settings_(settings)
+    {
+      smpc_centroidal_settings cs{};
+      cs.timestep = ocp.timestep;
+      cs.w_u = ocp.w_u.data();
+      cs.w_com = ocp.w_com.data();
+      cs.w_linear_mom = ocp.w_linear_mom.data();
+      cs.w_angular_mom = ocp.w_angular_mom.data();
+      cs.w_linear_acc = ocp.w_linear_acc.data();
+      cs.w_angular_acc = ocp.w_angular_acc.data();
+      for (int i = 0; i < 3; i++)
+        cs.gravity[i] = ocp.gravity[i];
+      cs.mu = ocp.mu;
+      cs.Lfoot = ocp.Lfoot;
+      cs.Wfoot = ocp.Wfoot;
+      cs.force_size = ocp.force_size;
+      if ((int)ocp.w_u.size() != ocp.force_size * robot->nfeet * ocp.force_size * robot->nfeet || ocp.w_com.size() != 9 || ocp.w_linear_mom.size() != 9
+          || ocp.w_angular_mom.size() != 9 || ocp.w_linear_acc.size() != 9 || ocp.w_angular_acc.size() != 9)
+        throw std::runtime_error("centroidal settings: weight sizes do not match the robot");
+      smpc_mpc_settings ms = c_settings(settings);
+      check(smpc_create_centroidal(robot, &cs, &ms, batch, gravity_arg, device_id, &h_));
+      finish(robot);
     }
     ~BatchedMPC() { smpc_destroy(h_); }
     BatchedMPC(const BatchedMPC &) = delete;
     BatchedMPC & operator=(const BatchedMPC &) = delete;
 
-    int nx() const { return dims_[2]; }
+    int nx() const { return dims_[2]; }             // problem state (centroidal handle: 9)
+    int nx_in() const { return dims_[0] + dims_[1]; } // measured multibody state nq + nv
     int ndx() const { return dims_[3]; }
     int nu() const { return dims_[4]; }
     int horizon() const { return dims_[7]; }
@@ -113,7 +140,7 @@ namespace simple_mpc
     // reference src/mpc.cpp:189-218; X is [B][nx]
     void iterate(const std::vector<double> & X)
     {
-      if ((int)X.size() != batch_ * nx())
+      if ((int)X.size() != batch_ * nx_in())
         throw std::runtime_error("X must hold batch * (nq + nv) values");
       check(smpc_iterate(h_, X.data()));
       xs_.resize((size_t)batch_ * (horizon() + 1) * nx());
@@ -129,7 +156,42 @@ namespace simple_mpc
     std::vector<int> getFootLandCycle(const std::string & ee) { return timing(ee, 1); }
     smpc_handle * handle() { return h_; }
 
+    // reference src/mpc.cpp:346-352, t = 0 or 1: [B][dim] with dim = 2 nv (kinodynamics) or 9 (centroidal)
+    std::vector<double> getStateDerivative(int t)
+    {
+      if (t != 0 && t != 1)
+        throw std::runtime_error("state derivative is retained for t = 0, 1 only");
+      const int dim = nx() == 9 ? 9 : 2 * dims_[1];
+      std::vector<double> all((size_t)batch_ * 2 * dim), out((size_t)batch_ * dim);
+      check(smpc_get_state_derivative01(h_, all.data()));
+      for (int b = 0; b < batch_; b++)
+        for (int i = 0; i < dim; i++)
+          out[(size_t)b * dim + i] = all[((size_t)b * 2 + t) * dim + i];
+      return out;
+    }
+
   private:
+    static smpc_mpc_settings c_settings(const MPCSettings & settings)
+    {
+      smpc_mpc_settings ms{};
+      ms.swing_apex = settings.swing_apex;
+      ms.support_force = settings.support_force;
+      ms.TOL = settings.TOL;
+      ms.mu_init = settings.mu_init;
+      ms.max_iters = (int)settings.max_iters;
+      ms.num_threads = (int)settings.num_threads;
+      ms.T_fly = settings.T_fly;
+      ms.T_contact = settings.T_contact;
+      ms.T = (int)settings.T;
+      ms.timestep = settings.timestep;
+      return ms;
+    }
+    void finish(const smpc_robot_model * robot)
+    {
+      check(smpc_get_dims(h_, dims_));
+      for (int f = 0; f < robot->nfeet; f++)
+        ee_names_.push_back(robot->foot_name[f]);
+    }
     std::vector<int> timing(const std::string & ee, int which)
     {
       for (size_t f = 0; f < ee_names_.size(); f++)

@@ -2,9 +2,15 @@
 // by line) over a CentroidalOCP (reference src/centroidal-dynamics.cpp).  One control step = two launches:
 //   frontend_body   measured multibody states -> getCentroidalState + foot positions (src/mpc.cpp:192,200)
 //   cent_step_body  recede + references + k ProxDDP iterations, one wavefront per instance (smpc_cent_kernels.h)
-// What differs from the kinodynamics host logic (reference file:line in oracle/orc_mpc_cent.hpp's header): the problem
-// state is the centroidal state, foot references are contact positions, velocity references are momenta (m v),
-// x_reference_ starts at zero, the default problem has contact positions at the origin, no terminal constraint.
+// What differs from the kinodynamics host logic:
+//   - the problem state is RobotDataHandler::getCentroidalState() of the measured multibody state
+//     (src/mpc.cpp:200, src/centroidal-dynamics.cpp:261-264, src/robot-handler.cpp:142-149)
+//   - setReferencePose writes the contact POSITION of the stage's contact map (src/centroidal-dynamics.cpp:151-169)
+//   - setReferenceState = setPoseBase + setVelocityBase, and setVelocityBase stores momentum references m v
+//     (src/centroidal-dynamics.cpp:227-239, 286-291)
+//   - x_reference_ starts as getReferenceState(0) of the default problem = 0 (src/centroidal-dynamics.cpp:36)
+//   - the default problem has identity contact poses, i.e. contact positions at the origin (src/ocp-handler.cpp:117)
+//   - no terminal constraint (src/centroidal-dynamics.cpp:318-337)
 #pragma once
 #include "smpc_cent_kernels.h"
 #include "smpc_engine.h"

@@ -12,8 +12,8 @@
 //     forward   t = 0 .. H-1 : (dx, du, dnu, dlam) and the directional derivative of the merit
 //     line search            : lane = stage trial evaluations, Armijo backtracking (alpha = 1, 1/2, ..)
 //   The stage matrices are 9 x 9 / 9 x 12: nothing but the per-stage gains leaves the CU between the phases of an
-//   iteration (gains go through L2 to the forward pass).  Algorithm and constants: oracle/orc_proxddp.hpp restates
-//   them; SURVEY App. B.1, B.4, B.5.
+//   iteration (gains go through L2 to the forward pass).  Algorithm and constants: DESIGN.md 2
+//   ("solver constants"); SURVEY App. B.1, B.4, B.5.
 #pragma once
 #include "smpc_riccati_kino.h"
 #include "smpc_solver_kernels.h"

@@ -125,6 +125,51 @@ int main()
     threw = true;
   }
   CHECK(threw);
+  // ---- centroidal OCP, written like the reference's mpc_centroidal test (tests/mpc.cpp:172-258) ----
+  {
+    CentroidalSettings cs; // tests/test_utils.cpp:194-218 with 3-D forces
+    const int nuc = 3 * nf;
+    cs.w_u.assign((size_t)nuc * nuc, 0.0);
+    for (int i = 0; i < nuc; i++)
+      cs.w_u[(size_t)i * nuc + i] = 1.0;
+    cs.w_com.assign(9, 0.0);
+    cs.w_linear_mom = {0.01, 0, 0, 0, 0.01, 0, 0, 0, 100};
+    cs.w_angular_mom = {0.1, 0, 0, 0, 0.1, 0, 0, 0, 1000};
+    cs.w_linear_acc = {0.01, 0, 0, 0, 0.01, 0, 0, 0, 0.01};
+    cs.w_angular_acc = {0.01, 0, 0, 0, 0.01, 0, 0, 0, 0.01};
+    cs.force_size = 3;
+    BatchedMPC cmpc(robot, cs, ms, /*batch=*/2);
+    CHECK(cmpc.horizon() == 100 && cmpc.nx() == 9 && cmpc.nu() == nuc && cmpc.nx_in() == nq + nv);
+    cmpc.generateCycleHorizon(contact_states);
+    CHECK(cmpc.getFootTakeoffCycle(robot->foot_name[0])[0] == 170);
+    for (int it = 0; it < 10; it++)
+      cmpc.iterate(X); // the multibody state, as in the reference test (x_multibody)
+    CHECK((int)cmpc.xs_.size() == 2 * 101 * 9 && (int)cmpc.us_.size() == 2 * 100 * nuc);
+    CHECK(cmpc.getFootTakeoffCycle(robot->foot_name[0])[0] == 160);
+    const std::vector<double> xdot = cmpc.getStateDerivative(0); // tests/mpc.cpp:257
+    CHECK((int)xdot.size() == 2 * 9);
+    for (double v : cmpc.xs_)
+      CHECK(std::isfinite(v));
+    for (double v : xdot)
+      CHECK(std::isfinite(v));
+    // xdot = [h / m ; m g + sum f ; ...]: linear-momentum rate consistent with the first control
+    double fz = 0.0;
+    for (int f = 0; f < nf; f++)
+      fz += cmpc.us_[3 * f + 2];
+    CHECK(std::fabs(xdot[5] - (fz - robot->total_mass * 9.81)) < 1e-9 * (1.0 + std::fabs(fz)));
+    bool threw2 = false;
+    try
+    {
+      CentroidalSettings bad = cs;
+      bad.w_com.assign(4, 0.0);
+      BatchedMPC nope(robot, bad, ms, 1);
+    }
+    catch (const std::runtime_error &)
+    {
+      threw2 = true;
+    }
+    CHECK(threw2);
+  }
   std::puts("host mirror KAT: OK");
   return 0;
 }

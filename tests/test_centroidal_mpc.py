@@ -187,4 +187,5 @@ def test_gpu_full_size_properties(built):
     assert np.all(info[:, 1] <= 0), "merit directional derivative must not be positive"
     assert np.all(info[ok, 3] <= info[ok, 0] + 1e-9 * np.abs(info[ok, 0])), "merit must not increase on accepted steps"
     fz = us.reshape(B, 50, 4, 3)[:, :, :, 2].sum(2)
-    assert np.abs(fz / (rb.mass * 9.81) - 1.0).max() < 0.5
+    # the first stages absorb the random initial momentum; after that the forces carry the weight
+    assert np.abs(fz[:, 10:] / (rb.mass * 9.81) - 1.0).max() < 0.05
