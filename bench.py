@@ -145,6 +145,13 @@ def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     kt = gm.kernel_times()
     avg = kt["step"][0] / max(kt["step"][1], 1) * 1e-3
     flops = batch * gm.H * iters * f_ric(9, gm.nu, gm.nc)
+    import glob
+    traffic, src = None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))
+    if files and batch == 4096 and iters == 3:
+        with open(files[-1]) as f:
+            traffic = json.load(f).get("kernels", {}).get("cent_step_body", {}).get("hbm_bytes_per_launch_corrected")
+        src = os.path.basename(files[-1])
     out = {
         "metric": "MPC control-steps/sec at fixed ProxDDP iters, Go2 centroidal H=50",
         "value": batch * steps / dt, "unit": "control-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": "f64",
@@ -153,7 +160,7 @@ def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
         "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if k != "-"},
         "roofline": {"bound": "mfma", "kernel": "cent_step_body (whole control step: recede + %d ProxDDP iterations)" % iters,
                      "achieved": flops / avg / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / avg / 1e12 / FP64_PEAK_TFLOPS,
-                     "traffic": None, "avg_launch_ms": avg * 1e3,
+                     "traffic": traffic, "traffic_source": src, "avg_launch_ms": avg * 1e3,
                      "note": "algorithmic FLOPs = B*H*k*F_ric(9,12,8) (SURVEY 8d); the 21 x 21 stage systems leave the matrix cores "
                              "mostly idle: the kernel is bound by the instruction issue of its index / assembly code (DESIGN.md 3.6)"},
     }

@@ -5,7 +5,7 @@ import csv
 import json
 import sys
 
-KEYS = ("deriv_body", "riccati_kino_body", "trial_body", "forward_kino_body", "apply_body", "select_body", "recede_body", "compact_body")
+KEYS = ("deriv_body", "riccati_kino_body", "trial_body", "forward_kino_body", "apply_body", "select_body", "recede_body", "compact_body", "cent_step_body")
 res = collections.defaultdict(dict)
 for name, f in (("FETCH_SIZE", sys.argv[1]), ("WRITE_SIZE", sys.argv[2])):
     acc = collections.defaultdict(list)
