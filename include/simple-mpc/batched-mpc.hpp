@@ -152,6 +152,24 @@ namespace simple_mpc
     }
     void switchToWalk(const double * velocity_base6) { check(smpc_switch_to_walk(h_, velocity_base6)); }
     void switchToStand() { check(smpc_switch_to_stand(h_)); }
+    // one velocity command per instance, V: [B][6] (the reference's MPC::velocity_base_, one per robot of the batch)
+    void setVelocityBaseBatched(const std::vector<double> & V)
+    {
+      if ((int)V.size() != batch_ * 6)
+        throw std::runtime_error("velocity_base size should be batch * 6");
+      check(smpc_set_velocity_base_batched(h_, V.data()));
+    }
+    // checkpoint / resume of the whole batch
+    std::vector<unsigned char> saveState()
+    {
+      size_t n = 0, w = 0;
+      check(smpc_state_size(h_, &n));
+      std::vector<unsigned char> buf(n);
+      check(smpc_save_state(h_, buf.data(), n, &w));
+      buf.resize(w);
+      return buf;
+    }
+    void loadState(const std::vector<unsigned char> & buf) { check(smpc_load_state(h_, buf.data(), buf.size())); }
     std::vector<int> getFootTakeoffCycle(const std::string & ee) { return timing(ee, 0); }
     std::vector<int> getFootLandCycle(const std::string & ee) { return timing(ee, 1); }
     smpc_handle * handle() { return h_; }

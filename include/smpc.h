@@ -16,6 +16,7 @@
 #ifndef SMPC_H
 #define SMPC_H
 #include "smpc_robot.h"
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -122,6 +123,10 @@ int smpc_generate_cycle_horizon(smpc_handle * h, const uint8_t * contact_states,
 /* MPC::switchToWalk / switchToStand (reference src/mpc.cpp:382-392) */
 int smpc_switch_to_walk(smpc_handle * h, const double * velocity_base6);
 int smpc_switch_to_stand(smpc_handle * h);
+/* One velocity command per instance, V: [B][6] (MPC::velocity_base_ is a public member the callers of the reference assign
+ * directly, bindings/expose-mpc.cpp:86; a batch of robots is not steered by one joystick).  The walking / standing state is
+ * unchanged.  smpc_switch_to_walk / smpc_switch_to_stand broadcast one command to every instance. */
+int smpc_set_velocity_base_batched(smpc_handle * h, const double * V);
 /* MPC::x_reference_ (public member, reference include/simple-mpc/mpc.hpp:191) */
 int smpc_set_x_reference(smpc_handle * h, const double * x_ref);
 
@@ -131,6 +136,16 @@ int smpc_iterate(smpc_handle * h, const double * X);
 /* Same with X already resident in HBM; asynchronous on the handle's stream (pair with smpc_wait). */
 int smpc_iterate_device(smpc_handle * h, const double * X_device);
 int smpc_wait(smpc_handle * h);
+/* Checkpoint / resume (the reference has none; a batched simulator needs it to roll back or migrate a batch).
+ * The state is everything a later smpc_iterate depends on: iterate, multipliers, swing trajectories, references, velocity
+ * commands, gait bookkeeping -- not the feedback gains of the last solve (the next iterate recomputes them).
+ *   smpc_state_size   bytes needed for this handle (it grows with the gait cycle: call it after generateCycleHorizon)
+ *   smpc_save_state   writes at most `capacity` bytes to `buffer` (host), returns the number written through *written
+ *   smpc_load_state   restores; the buffer must come from a handle of the same kind, batch, horizon and robot
+ * After smpc_load_state the handle continues bit-identically to the handle the state was saved from. */
+int smpc_state_size(smpc_handle * h, size_t * bytes);
+int smpc_save_state(smpc_handle * h, void * buffer, size_t capacity, size_t * written);
+int smpc_load_state(smpc_handle * h, const void * buffer, size_t size);
 /* xs_[t] of every instance into a dense device buffer [B][nx]; asynchronous on the handle's stream.
  * Lets a closed loop keep the measured states resident in HBM (x_meas = xs[1] + noise). */
 int smpc_get_x_device(smpc_handle * h, int t, double * out_device);

@@ -378,6 +378,7 @@ extern "C"
   }
   void orc_mpc_switch_to_walk(void * h, const double * v6) { ((BatchMPC *)h)->switchToWalk(v6); }
   void orc_mpc_switch_to_stand(void * h) { ((BatchMPC *)h)->switchToStand(); }
+  void orc_mpc_set_velocity_batched(void * h, const double * V) { ((BatchMPC *)h)->setVelocityBaseBatched(V); }
   void orc_mpc_set_x_reference(void * h, const double * x)
   {
     BatchMPC * m = (BatchMPC *)h;
@@ -620,6 +621,7 @@ extern "C"
   }
   void orc_cmpc_switch_to_walk(void * h, const double * v6) { ((BatchMPCCent *)h)->switchToWalk(v6); }
   void orc_cmpc_switch_to_stand(void * h) { ((BatchMPCCent *)h)->switchToStand(); }
+  void orc_cmpc_set_velocity_batched(void * h, const double * V) { ((BatchMPCCent *)h)->setVelocityBaseBatched(V); }
   void orc_cmpc_set_x_reference(void * h, const double * x9) { ((BatchMPCCent *)h)->x_reference.assign(x9, x9 + 9); }
   double orc_cmpc_iterate(void * h, const double * X)
   {

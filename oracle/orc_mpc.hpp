@@ -13,6 +13,7 @@
 #pragma once
 #include "orc_proxddp.hpp"
 #include <algorithm>
+#include <array>
 
 namespace orc
 {
@@ -123,6 +124,10 @@ namespace orc
     int H, B, nf;
     bool walking = true;
     double velocity_base[6] = {0, 0, 0, 0, 0, 0};
+    // one velocity command per instance (the reference's MPC has one velocity_base_; a batch = B such objects) and the
+    // velocity part of the state_cost target each horizon stage received when it entered (setVelocityBase, src/mpc.cpp:312)
+    std::vector<std::array<double, 6>> vbase_inst;
+    std::vector<std::vector<std::array<double, 6>>> vref;
     Vec x_reference;  // MPC::x_reference_
     Vec x_model_ref;  // model reference state
     V3 com0;
@@ -195,8 +200,22 @@ namespace orc
         for (int f = 0; f < nf; f++)
           ftraj[b][f] = FootTraj{R.foot_p[f], R.foot_p[f]};
       last_info.resize(B);
+      vbase_inst.assign(B, std::array<double, 6>{{0, 0, 0, 0, 0, 0}});
+      vref.assign(B, std::vector<std::array<double, 6>>(H, std::array<double, 6>{{0, 0, 0, 0, 0, 0}}));
     }
     std::vector<IterInfo> cold_trace;
+    void set_velocity_all(const double * v6)
+    {
+      for (auto & v : vbase_inst)
+        for (int i = 0; i < 6; i++)
+          v[i] = v6[i];
+    }
+    void setVelocityBaseBatched(const double * V) // [B][6]
+    {
+      for (int b = 0; b < B; b++)
+        for (int i = 0; i < 6; i++)
+          vbase_inst[b][i] = V[(size_t)b * 6 + i];
+    }
 
     void generateCycleHorizon(const std::vector<std::vector<char>> & cs)
     {
@@ -231,12 +250,14 @@ namespace orc
       walking = true;
       for (int i = 0; i < 6; i++)
         velocity_base[i] = v6[i];
+      set_velocity_all(v6);
     }
     void switchToStand()
     {
       walking = false;
       for (int i = 0; i < 6; i++)
         velocity_base[i] = 0;
+      set_velocity_all(velocity_base);
     }
 
     // X: [B][nx] measured states
@@ -284,6 +305,12 @@ namespace orc
           o.stages[t].u_ref = horizon[t].u_ref;
           o.stages[t].x_tgt = horizon[t].x_tgt;
         }
+        const std::array<double, 6> & vb = vbase_inst[b];
+        vref[b].erase(vref[b].begin());
+        vref[b].push_back(vb);
+        for (int t = 0; t < H; t++)
+          for (int i = 0; i < 6; i++)
+            o.stages[t].x_tgt[md.nq + i] = vref[b][t][i];
         S.vs.erase(S.vs.begin());
         S.vs.push_back(Vec(md.nc, 0.0));
         S.lams.erase(S.lams.begin() + 1);
@@ -301,8 +328,8 @@ namespace orc
           double tw1 = refp[0] - base_p[0];
           V3 next;
           const double span = (double)(st.T_fly + st.T_contact) * st.timestep;
-          next[0] = refp[0] + (velocity_base[0] + velocity_base[5] * tw0) * span;
-          next[1] = refp[1] + (velocity_base[1] + velocity_base[5] * tw1) * span;
+          next[0] = refp[0] + (vb[0] + vb[5] * tw0) * span;
+          next[1] = refp[1] + (vb[1] + vb[5] * tw1) * span;
           next[2] = R.foot_p[f][2];
           FootTraj & ft = ftraj[b][f];
           if (update)

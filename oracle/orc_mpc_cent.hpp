@@ -24,6 +24,8 @@ namespace orc
     int H, B, nf, nx_mb;
     bool walking = true;
     double velocity_base[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<std::array<double, 6>> vbase_inst;          // one command per instance
+    std::vector<std::vector<std::array<double, 6>>> vref;   // momentum references [m v_lin; m v_ang] per horizon stage
     Vec x_reference; // MPC::x_reference_ (9)
     Vec x_model_ref; // multibody reference state
     V3 com0;
@@ -100,6 +102,20 @@ namespace orc
         for (int f = 0; f < nf; f++)
           ftraj[b][f] = FootTraj{R.foot_p[f], R.foot_p[f]};
       last_info.resize(B);
+      vbase_inst.assign(B, std::array<double, 6>{{0, 0, 0, 0, 0, 0}});
+      vref.assign(B, std::vector<std::array<double, 6>>(H, std::array<double, 6>{{0, 0, 0, 0, 0, 0}}));
+    }
+    void set_velocity_all(const double * v6)
+    {
+      for (auto & v : vbase_inst)
+        for (int i = 0; i < 6; i++)
+          v[i] = v6[i];
+    }
+    void setVelocityBaseBatched(const double * V)
+    {
+      for (int b = 0; b < B; b++)
+        for (int i = 0; i < 6; i++)
+          vbase_inst[b][i] = V[(size_t)b * 6 + i];
     }
 
     void generateCycleHorizon(const std::vector<std::vector<char>> & cs)
@@ -140,12 +156,14 @@ namespace orc
       walking = true;
       for (int i = 0; i < 6; i++)
         velocity_base[i] = v6[i];
+      set_velocity_all(v6);
     }
     void switchToStand()
     {
       walking = false;
       for (int i = 0; i < 6; i++)
         velocity_base[i] = 0;
+      set_velocity_all(velocity_base);
     }
 
     // X: [B][nq+nv] measured multibody states
@@ -196,6 +214,15 @@ namespace orc
           o.stages[t].u_ref = horizon[t].u_ref;
           o.stages[t].x_tgt = horizon[t].x_tgt;
         }
+        const std::array<double, 6> & vb = vbase_inst[b];
+        std::array<double, 6> mv;
+        for (int i = 0; i < 6; i++)
+          mv[i] = md.mass * vb[i];
+        vref[b].erase(vref[b].begin());
+        vref[b].push_back(mv);
+        for (int t = 0; t < H; t++)
+          for (int i = 0; i < 6; i++)
+            o.stages[t].x_tgt[3 + i] = vref[b][t][i];
         S.vs.erase(S.vs.begin());
         S.vs.push_back(Vec(md.nc, 0.0));
         S.lams.erase(S.lams.begin() + 1);
@@ -212,8 +239,8 @@ namespace orc
           double tw1 = refp[0] - base_p[0];
           V3 next;
           const double span = (double)(st.T_fly + st.T_contact) * st.timestep;
-          next[0] = refp[0] + (velocity_base[0] + velocity_base[5] * tw0) * span;
-          next[1] = refp[1] + (velocity_base[1] + velocity_base[5] * tw1) * span;
+          next[0] = refp[0] + (vb[0] + vb[5] * tw0) * span;
+          next[1] = refp[1] + (vb[1] + vb[5] * tw1) * span;
           next[2] = R.foot_p[f][2];
           FootTraj & ft = ftraj[b][f];
           if (update)

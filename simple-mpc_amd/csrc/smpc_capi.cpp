@@ -218,20 +218,24 @@ extern "C"
     if (!h || !v6)
       return fail(SMPC_ERR_INVALID, "null argument");
     if (h->cent)
-      h->cent->switch_to_walk(v6);
-    else
-      h->eng->switch_to_walk(v6);
-    return SMPC_OK;
+      return guarded([&] { h->cent->switch_to_walk(v6); });
+    return guarded([&] { h->eng->switch_to_walk(v6); });
   }
   int smpc_switch_to_stand(smpc_handle * h)
   {
     if (!h)
       return fail(SMPC_ERR_INVALID, "null argument");
     if (h->cent)
-      h->cent->switch_to_stand();
-    else
-      h->eng->switch_to_stand();
-    return SMPC_OK;
+      return guarded([&] { h->cent->switch_to_stand(); });
+    return guarded([&] { h->eng->switch_to_stand(); });
+  }
+  int smpc_set_velocity_base_batched(smpc_handle * h, const double * V)
+  {
+    if (!h || !V)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return guarded([&] { h->cent->set_velocity_base_batched(V); });
+    return guarded([&] { h->eng->set_velocity_base_batched(V); });
   }
   int smpc_set_x_reference(smpc_handle * h, const double * x)
   {
@@ -266,6 +270,38 @@ extern "C"
     if (h->cent)
       return guarded([&] { h->cent->sync(); });
     return guarded([&] { h->eng->sync(); });
+  }
+  static size_t state_pass(smpc_handle * h, StateIO::Mode mode, void * buf, size_t cap)
+  {
+    if (h->cent)
+    {
+      StateIO io(mode, buf, cap, h->cent->stream);
+      return h->cent->state_io(io);
+    }
+    StateIO io(mode, buf, cap, h->eng->stream);
+    return h->eng->state_io(io);
+  }
+  int smpc_state_size(smpc_handle * h, size_t * bytes)
+  {
+    if (!h || !bytes)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { *bytes = state_pass(h, StateIO::COUNT, nullptr, 0); });
+  }
+  int smpc_save_state(smpc_handle * h, void * buffer, size_t capacity, size_t * written)
+  {
+    if (!h || !buffer)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] {
+      const size_t n = state_pass(h, StateIO::SAVE, buffer, capacity);
+      if (written)
+        *written = n;
+    });
+  }
+  int smpc_load_state(smpc_handle * h, const void * buffer, size_t size)
+  {
+    if (!h || !buffer)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { state_pass(h, StateIO::LOAD, const_cast<void *>(buffer), size); });
   }
   int smpc_get_x_device(smpc_handle * h, int t, double * out_device)
   {

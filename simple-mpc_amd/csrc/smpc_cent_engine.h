@@ -119,6 +119,8 @@ namespace smpc
       buf.dlams = dalloc(BH * 9);
       buf.foot = dalloc(BH * DC::NF * 3);
       buf.ftraj = dalloc((size_t)B * DC::NF * 6);
+      buf.vbase = dalloc((size_t)B * 6);
+      buf.vref = dalloc(BR * 6);
       buf.gains = dalloc(BH * DC::G_STRIDE);
       buf.scal = dalloc((size_t)B * SC_N);
       buf.xdot01 = dalloc((size_t)B * 18);
@@ -149,7 +151,7 @@ namespace smpc
     }
     ~CentEngine()
     {
-      for (double * p : {buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot, buf.ftraj, buf.gains, buf.scal, buf.xdot01,
+      for (double * p : {buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot, buf.ftraj, buf.vbase, buf.vref, buf.gains, buf.scal, buf.xdot01,
                          buf.zeros, buf.dbg, X_dev, cstate_dev, feet_dev, stage_out})
         dev_free(p);
       dev_free(buf.stages);
@@ -227,8 +229,6 @@ namespace smpc
       a.T_contact = ms.T_contact;
       a.swing_apex = ms.swing_apex;
       a.timestep = ms.timestep;
-      for (int i = 0; i < 6; i++)
-        a.vbase[i] = velocity_base[i];
       a.armijo_c1 = ARMIJO_C1;
       a.reg_init = REG_INIT;
       a.reg_min = REG_MIN;
@@ -315,17 +315,34 @@ namespace smpc
         cycle.push_back(s);
       }
     }
+    void upload_velocity(const double * V, bool broadcast)
+    {
+      std::vector<double> h((size_t)B * 6);
+      for (int b = 0; b < B; b++)
+        for (int i = 0; i < 6; i++)
+          h[(size_t)b * 6 + i] = broadcast ? V[i] : V[(size_t)b * 6 + i];
+      h2d(buf.vbase, h.data(), h.size() * sizeof(double), stream);
+      stream_sync(stream);
+    }
     void switch_to_walk(const double * v6)
     {
       walking = true;
       for (int i = 0; i < 6; i++)
         velocity_base[i] = v6[i];
+      upload_velocity(v6, true);
     }
     void switch_to_stand()
     {
       walking = false;
       for (int i = 0; i < 6; i++)
         velocity_base[i] = 0.0;
+      upload_velocity(velocity_base, true);
+    }
+    void set_velocity_base_batched(const double * V)
+    {
+      for (int i = 0; i < 6; i++)
+        velocity_base[i] = V[i];
+      upload_velocity(V, false);
     }
 
     void iterate_device(const double * Xd)
@@ -368,6 +385,37 @@ namespace smpc
       for (int f = 0; f < DC::NF; f++)
         a.land[f] = timer.land[f].empty() ? -1 : timer.land[f][0];
       timed_launch<CentStepArgs<DC>, cent_step_body<DC>, 64, 2>(CKID_STEP, B, a);
+    }
+    size_t state_io(StateIO & io)
+    {
+      stream_sync(stream);
+      io.tag(0x534d504343454e54LL, "kind (centroidal)");
+      io.tag(B, "batch");
+      io.tag(H, "horizon");
+      io.tag(DC::NU, "nu");
+      io.pod(head);
+      io.pod(walking);
+      io.host(velocity_base, sizeof(velocity_base));
+      io.host(x_reference, sizeof(x_reference));
+      io.host(com_ref_member, sizeof(com_ref_member));
+      io.vec(horizon);
+      io.vec(cycle);
+      io.timer(timer);
+      const size_t BR = (size_t)B * R;
+      io.dev(buf.xs, BR * 9 * sizeof(double));
+      io.dev(buf.us, BR * DC::NU * sizeof(double));
+      io.dev(buf.vs, BR * DC::NC * sizeof(double));
+      io.dev(buf.lams, BR * 9 * sizeof(double));
+      io.dev(buf.ftraj, (size_t)B * DC::NF * 6 * sizeof(double));
+      io.dev(buf.foot, (size_t)B * H * DC::NF * 3 * sizeof(double));
+      io.dev(buf.vbase, (size_t)B * 6 * sizeof(double));
+      io.dev(buf.vref, BR * 6 * sizeof(double));
+      io.dev(buf.scal, (size_t)B * SC_N * sizeof(double));
+      io.dev(buf.xdot01, (size_t)B * 18 * sizeof(double));
+      if (io.mode == StateIO::LOAD)
+        upload_stages();
+      stream_sync(stream);
+      return io.pos;
     }
     void iterate_host(const double * X)
     {

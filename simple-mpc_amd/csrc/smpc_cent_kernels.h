@@ -97,6 +97,9 @@ namespace smpc
     double *dxs = nullptr, *dus = nullptr, *dvs = nullptr, *dlams = nullptr; // [B][H+1][9], [B][H][.] linear in t
     double * foot = nullptr;   // [B][H][NF*3] contact positions (MPC::setReferencePose -> contact map)
     double * ftraj = nullptr;  // [B][NF][6] swing start / end
+    // velocity command per instance [B][6] and the momentum references [m v_lin; m v_ang] of every stage in the horizon
+    // (ring [B][R][6]: what setVelocityBase wrote when the stage entered, src/mpc.cpp:312, src/centroidal-dynamics.cpp:227-239)
+    double *vbase = nullptr, *vref = nullptr;
     double * gains = nullptr;  // [B][H][G_STRIDE]
     double * scal = nullptr;   // [B][SC_N]
     double * xdot01 = nullptr; // [B][2][9]
@@ -121,7 +124,6 @@ namespace smpc
     int land[D::NF];
     int T_fly, T_contact;
     double swing_apex, timestep;
-    double vbase[6];
     double armijo_c1, reg_init, reg_min, reg_max, reg_inc, reg_dec;
   };
 
@@ -173,7 +175,7 @@ namespace smpc
   struct CentTrial
   {
     const double *x, *dx, *xn, *dxn, *u, *du, *v, *dv, *l1, *dl; // iterate and step (dxn = dx of stage t + 1)
-    const double *ve, *l1e, *p, *uref, *xtgt;
+    const double *ve, *l1e, *p, *uref, *xtgt, *href; // xtgt: CoM reference (shared), href: momentum references (per instance)
     double alpha;
     unsigned mask;
   };
@@ -249,8 +251,8 @@ namespace smpc
       cu += ru_lds[i] * wr;
     }
     cost += 0.5 * cu;
-    cost += quad3(md.w_lm, h - ld3(q.xtgt + 3));
-    cost += quad3(md.w_am, L - ld3(q.xtgt + 6));
+    cost += quad3(md.w_lm, h - ld3(q.href));
+    cost += quad3(md.w_am, L - ld3(q.href + 3));
     cost += quad3(md.w_la, g + (1.0 / md.mass) * fs);
     cost += quad3(md.w_aa, ts);
   }
@@ -284,8 +286,10 @@ namespace smpc
       a = b.foot + (inst * H + t) * (3 * NF) + (s - D::I_p);
     else if (s < D::I_xt)
       a = b.stages[t].u_ref + (s - D::I_ur);
-    else if (s < D::I_N)
+    else if (s < D::I_xt + 3)
       a = b.stages[t].x_tgt + (s - D::I_xt);
+    else if (s < D::I_N)
+      a = b.vref + (ib + st) * 6 + (s - D::I_xt - 3); // momentum references are per instance
     return a;
   }
 
@@ -338,6 +342,8 @@ namespace smpc
           b.us[(ib + sHm1) * NU + lane] = b.us[(ib + sHm2) * NU + lane];
         if (lane < NC)
           b.vs[(ib + sHm1) * NC + lane] = 0.0;
+        if (lane >= 32 && lane < 38)
+          b.vref[(ib + sHm1) * 6 + lane - 32] = md.mass * b.vbase[inst * 6 + lane - 32];
         if (lane < NF)
         {
           const int f = lane;
@@ -348,7 +354,8 @@ namespace smpc
           const V3 refp = Rb * ld3(md.foot_ref_p[f]) + bp;
           const double tw0 = -(refp.y - bp.y), tw1 = refp.x - bp.x;
           const double span = (double)(ka.T_fly + ka.T_contact) * ka.timestep;
-          const V3 next = mk3(refp.x + (ka.vbase[0] + ka.vbase[5] * tw0) * span, refp.y + (ka.vbase[1] + ka.vbase[5] * tw1) * span, pf.z);
+          const double * vb = b.vbase + inst * 6;
+          const V3 next = mk3(refp.x + (vb[0] + vb[5] * tw0) * span, refp.y + (vb[1] + vb[5] * tw1) * span, pf.z);
           double * ft = b.ftraj + (inst * NF + f) * 6;
           if (!(ka.land[f] < ka.T_fly))
           {
@@ -1182,6 +1189,7 @@ namespace smpc
             q.p = b.foot + (inst * H + t) * (3 * NF);
             q.uref = b.stages[t].u_ref;
             q.xtgt = b.stages[t].x_tgt;
+            q.href = b.vref + sl * 6;
             q.alpha = alpha;
             q.mask = b.stages[t].mask;
             double c1, p1, r1;
@@ -1273,6 +1281,7 @@ namespace smpc
         q.p = b.foot + (inst * H + t) * (3 * NF);
         q.uref = b.stages[t].u_ref;
         q.xtgt = b.stages[t].x_tgt;
+        q.href = b.vref + sl * 6;
         q.alpha = 0.0; // the accepted iterate itself
         q.mask = b.stages[t].mask;
         double c1, p1, r1, xd[9];

@@ -109,6 +109,93 @@ namespace smpc
     KID_N
   };
 
+  // checkpoint / resume of a handle (smpc_save_state / smpc_load_state): one pass over the state in a fixed order, in one
+  // of three modes (count the bytes, copy out, copy in)
+  struct StateIO
+  {
+    enum Mode
+    {
+      COUNT,
+      SAVE,
+      LOAD
+    } mode;
+    char * buf;
+    size_t cap, pos = 0;
+    stream_t st;
+    StateIO(Mode m, void * b, size_t c, stream_t s) : mode(m), buf((char *)b), cap(c), st(s) {}
+    void need(size_t n) const
+    {
+      if (mode != COUNT && pos + n > cap)
+        throw std::runtime_error(mode == SAVE ? "state buffer too small" : "state buffer truncated");
+    }
+    void host(void * p, size_t n)
+    {
+      need(n);
+      if (mode == SAVE)
+        std::memcpy(buf + pos, p, n);
+      else if (mode == LOAD)
+        std::memcpy(p, buf + pos, n);
+      pos += n;
+    }
+    void dev(void * p, size_t n)
+    {
+      need(n);
+      if (mode == SAVE)
+        d2h(buf + pos, p, n, st);
+      else if (mode == LOAD)
+        h2d(p, buf + pos, n, st);
+      pos += n;
+    }
+    template <class T>
+    void pod(T & v)
+    {
+      host(&v, sizeof(T));
+    }
+    // a value that must be the same in the handle and in the buffer (shape of the problem)
+    void tag(long long v, const char * what)
+    {
+      long long w = v;
+      pod(w);
+      if (mode == LOAD && w != v)
+        throw std::runtime_error(std::string("saved state does not match this handle: ") + what);
+    }
+    template <class T>
+    void vec(std::vector<T> & v)
+    {
+      unsigned long long n = v.size();
+      pod(n);
+      if (mode == LOAD)
+      {
+        if (n * sizeof(T) > cap)
+          throw std::runtime_error("state buffer corrupt");
+        v.resize((size_t)n);
+      }
+      if (n)
+        host(v.data(), (size_t)n * sizeof(T));
+    }
+    void timer(GaitTimer & t)
+    {
+      pod(t.H);
+      pod(t.nf);
+      unsigned long long ns = t.states.size();
+      pod(ns);
+      if (mode == LOAD)
+        t.states.assign((size_t)ns, std::vector<unsigned char>());
+      for (auto & s : t.states)
+        vec(s);
+      if (mode == LOAD)
+      {
+        t.takeoff.assign(t.nf, {});
+        t.land.assign(t.nf, {});
+      }
+      for (int f = 0; f < t.nf; f++)
+      {
+        vec(t.takeoff[f]);
+        vec(t.land[f]);
+      }
+    }
+  };
+
   // kinematic tree, inertias and feet of the robot table -> device model (shared by the kinodynamics engine and the
   // front-end of the centroidal engine)
   template <class D>
@@ -268,6 +355,8 @@ namespace smpc
       buf.dlams = dalloc(BH * D::NDX);
       buf.foot_ref = dalloc(BH * D::NF * 3);
       buf.ftraj = dalloc((size_t)B * D::NF * 6);
+      buf.vbase = dalloc((size_t)B * 6);
+      buf.vref = dalloc(BR * 6);
       buf.lq = dalloc(BH * D::LQ_STRIDE);
       buf.gains = dalloc(BH * (size_t)std::max((int)D::G_STRIDE, (int)GainsK<D>::STRIDE));
       buf.QN = dalloc((size_t)B * D::NDX * D::NDX);
@@ -308,7 +397,7 @@ namespace smpc
     }
     ~KinoEngine()
     {
-      for (double * p : {buf.xs_b, buf.us_b, buf.vs_b, buf.lams_b, buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref, buf.ftraj, buf.lq,
+      for (double * p : {buf.xs_b, buf.us_b, buf.vs_b, buf.lams_b, buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref, buf.ftraj, buf.vbase, buf.vref, buf.lq,
                          buf.gains, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, X_dev, stage_out})
         dev_free(p);
       dev_free(buf.ls_sel);
@@ -628,17 +717,36 @@ namespace smpc
         cycle.push_back(s);
       }
     }
+    // velocity commands live on the device, one per instance; the reference's single velocity_base_ is a broadcast
+    void upload_velocity(const double * V, bool broadcast)
+    {
+      std::vector<double> h((size_t)B * 6);
+      for (int b = 0; b < B; b++)
+        for (int i = 0; i < 6; i++)
+          h[(size_t)b * 6 + i] = broadcast ? V[i] : V[(size_t)b * 6 + i];
+      h2d(buf.vbase, h.data(), h.size() * sizeof(double), stream);
+      stream_sync(stream);
+    }
     void switch_to_walk(const double * v6)
     {
       walking = true;
       for (int i = 0; i < 6; i++)
         velocity_base[i] = v6[i];
+      upload_velocity(v6, true);
     }
     void switch_to_stand()
     {
       walking = false;
       for (int i = 0; i < 6; i++)
         velocity_base[i] = 0.0;
+      upload_velocity(velocity_base, true);
+    }
+    // one velocity command per instance, V: [B][6] (the walking state is unchanged, like assigning MPC::velocity_base_)
+    void set_velocity_base_batched(const double * V)
+    {
+      for (int i = 0; i < 6; i++)
+        velocity_base[i] = V[i];
+      upload_velocity(V, false);
     }
 
     // One control step for the whole batch; Xd: device pointer [B][NX]
@@ -681,13 +789,44 @@ namespace smpc
       ra.T_contact = ms.T_contact;
       ra.swing_apex = ms.swing_apex;
       ra.timestep = ms.timestep;
-      for (int i = 0; i < 6; i++)
-        ra.vbase[i] = velocity_base[i];
       ra.shift = 1;
       ra.reg_init = REG_INIT;
       timed_launch<RecedeArgs<D>, recede_body<D>, 64>(KID_RECEDE, B, ra);
       copy_centres(buf);
       run_iterations(buf, ms.max_iters);
+    }
+    // Everything a later iterate() depends on: iterate, multipliers, swing trajectories, references, velocity commands, gait
+    // bookkeeping.  Not included: the feedback gains and the LQ knots of the last solve (recomputed by the next iterate).
+    size_t state_io(StateIO & io)
+    {
+      stream_sync(stream);
+      io.tag(0x534d50434b494e4fLL, "kind (kinodynamics)");
+      io.tag(B, "batch");
+      io.tag(H, "horizon");
+      io.tag(D::NX, "nx");
+      io.tag(D::NU, "nu");
+      io.pod(head);
+      io.pod(walking);
+      io.host(velocity_base, sizeof(velocity_base));
+      io.vec(x_reference);
+      io.vec(horizon);
+      io.vec(cycle);
+      io.timer(timer);
+      const size_t BR = (size_t)B * R;
+      io.dev(buf.xs, BR * D::NX * sizeof(double));
+      io.dev(buf.us, BR * D::NU * sizeof(double));
+      io.dev(buf.vs, BR * D::NC * sizeof(double));
+      io.dev(buf.lams, BR * D::NDX * sizeof(double));
+      io.dev(buf.ftraj, (size_t)B * D::NF * 6 * sizeof(double));
+      io.dev(buf.foot_ref, (size_t)B * H * D::NF * 3 * sizeof(double));
+      io.dev(buf.vbase, (size_t)B * 6 * sizeof(double));
+      io.dev(buf.vref, BR * 6 * sizeof(double));
+      io.dev(buf.scal, (size_t)B * SC_N * sizeof(double));
+      io.dev(buf.xdot01, (size_t)B * 4 * D::NV * sizeof(double));
+      if (io.mode == StateIO::LOAD)
+        upload_stages();
+      stream_sync(stream);
+      return io.pos;
     }
     void iterate_host(const double * X)
     {

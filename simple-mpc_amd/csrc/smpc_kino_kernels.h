@@ -126,7 +126,8 @@ namespace smpc
       const double vl = b.lams[(ib + st) * NDX + (lane < NDX ? lane : 0)];
       const double vlp = b.lams[(ib + sprev) * NDX + (lane < NDX ? lane : 0)];
       const double vn = b.vs[(ib + st) * NC + (lane < NC ? lane : 0)];
-      const double vxt = in.x_tgt[lane < NX ? lane : 0];
+      // state_cost target: shared pose part, per-instance base-velocity part (address select, one load)
+      const double vxt = *((!term && lane >= D::NQ && lane < D::NQ + 6) ? b.vref + (ib + st) * 6 + (lane - D::NQ) : in.x_tgt + (lane < NX ? lane : 0));
       const double vur = term ? 0.0 : in.u_ref[lane < NU ? lane : 0];
       const double vfr = term ? 0.0 : in.foot_ref[lane < NF * 3 ? lane : 0];
       const double vxn = xn_g[lane < NX ? lane : 0];
@@ -984,7 +985,8 @@ namespace smpc
       const double vu = b.us[(ib + st) * NU + (lane < NU ? lane : 0)], vdu = b.dus[lt * NU + (lane < NU ? lane : 0)];
       const double vl = b.lams[(ib + st) * NDX + (lane < NDX ? lane : 0)], vdl = b.dlams[lt * NDX + (lane < NDX ? lane : 0)];
       const double vn = b.vs[(ib + st) * NC + (lane < NC ? lane : 0)], vdn = b.dvs[lt * NC + (lane < NC ? lane : 0)];
-      const double vxt = in.x_tgt[lane < NX ? lane : 0];
+      // state_cost target: shared pose part, per-instance base-velocity part (address select, one load)
+      const double vxt = *((!term && lane >= D::NQ && lane < D::NQ + 6) ? b.vref + (ib + st) * 6 + (lane - D::NQ) : in.x_tgt + (lane < NX ? lane : 0));
       const double vur = term ? 0.0 : in.u_ref[lane < NU ? lane : 0];
       const double vfr = term ? 0.0 : in.foot_ref[lane < NF * 3 ? lane : 0];
       lanes_load_model<D, NT>(sc, &mg, lane);

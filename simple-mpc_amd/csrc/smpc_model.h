@@ -120,6 +120,9 @@ namespace smpc
     // per-instance references, [B][H][NF*3]
     double * foot_ref = nullptr;
     double * ftraj = nullptr; // [B][NF][6] swing start / end
+    // velocity command per instance (MPC::velocity_base_, [B][6]) and the velocity part of the state_cost target of every
+    // stage in the horizon (ring [B][R][6]: what setVelocityBase wrote when the stage entered, src/mpc.cpp:312)
+    double *vbase = nullptr, *vref = nullptr;
     // LQ + gains
     double *lq = nullptr, *gains = nullptr;
     double *QN = nullptr, *qN = nullptr; // [B][NDX*NDX], [B][NDX]

@@ -811,7 +811,7 @@ namespace smpc
     int land[D::NF];    // first landing time per foot or -1 (src/mpc.cpp:283-285)
     int T_fly, T_contact;
     double swing_apex, timestep;
-    double vbase[6];
+    // (velocity commands are per instance: Buffers::vbase)
     int shift;          // 1: regular control step; 0: only (re)generate references
     double reg_init;
   };
@@ -863,6 +863,8 @@ namespace smpc
         b.us[(ib + sHm1) * NU + i] = b.us[(ib + sHm2) * NU + i];
       for (int i = lane; i < NC; i += NT)
         b.vs[(ib + sHm1) * NC + i] = 0.0;
+      if (lane < 6)
+        b.vref[(ib + sHm1) * 6 + lane] = b.vbase[(size_t)inst * 6 + lane]; // setVelocityBase(H-1, velocity_base_)
       for (int i = lane; i < NDX; i += NT)
         b.lams[(ib + sHm1) * NDX + i] = 0.0;
       if (lane == 0)
@@ -911,7 +913,8 @@ namespace smpc
       const V3 refp = ldm3(&oR[0]) * ld3(md.foot_ref_p[f]) + bp;
       const double tw0 = -(refp.y - bp.y), tw1 = refp.x - bp.x;
       const double span = (double)(ka.T_fly + ka.T_contact) * ka.timestep;
-      const V3 next = mk3(refp.x + (ka.vbase[0] + ka.vbase[5] * tw0) * span, refp.y + (ka.vbase[1] + ka.vbase[5] * tw1) * span, pf.z);
+      const double * vb = b.vbase + (size_t)inst * 6;
+      const V3 next = mk3(refp.x + (vb[0] + vb[5] * tw0) * span, refp.y + (vb[1] + vb[5] * tw1) * span, pf.z);
       double * ft = b.ftraj + ((size_t)inst * NF + f) * 6;
       const bool update = !(ka.land[f] < ka.T_fly);
       if (update)

@@ -328,6 +328,14 @@ class BatchedMPC:
         self._velocity_base = v.copy()
         self._lib.check(self._lib.L.smpc_switch_to_walk(self._h, v))
 
+    def setVelocityBaseBatched(self, V):
+        """One velocity command per instance, V[B, 6] (the reference has one `velocity_base` per MPC object)."""
+        V = np.ascontiguousarray(V, float)
+        if V.shape != (self.B, 6):
+            raise RuntimeError("velocity_base size should be (batch, 6)")
+        self._velocity_base = V.copy()
+        self._lib.check(self._lib.L.smpc_set_velocity_base_batched(self._h, V))
+
     @property
     def x_reference(self):
         return self._x_reference
@@ -355,6 +363,20 @@ class BatchedMPC:
     def get_x_device(self, t, device_ptr):
         """xs[t] of every instance into a device buffer [B][nx] (asynchronous on the engine's stream)."""
         self._lib.check(self._lib.L.smpc_get_x_device(self._h, int(t), C.c_void_p(int(device_ptr))))
+
+    def save_state(self):
+        """Checkpoint of the whole batch (bytes): everything a later iterate depends on."""
+        n = C.c_size_t()
+        self._lib.check(self._lib.L.smpc_state_size(self._h, C.byref(n)))
+        buf = np.zeros(n.value, np.uint8)
+        w = C.c_size_t()
+        self._lib.check(self._lib.L.smpc_save_state(self._h, buf.ctypes.data_as(C.c_void_p), n.value, C.byref(w)))
+        return buf[: w.value].tobytes()
+
+    def load_state(self, blob):
+        """Resume from save_state() of a handle of the same kind, batch, horizon and robot."""
+        buf = np.frombuffer(blob, np.uint8).copy()
+        self._lib.check(self._lib.L.smpc_load_state(self._h, buf.ctypes.data_as(C.c_void_p), buf.size))
 
     def _get(self, fn, shape):
         out = np.zeros(shape)

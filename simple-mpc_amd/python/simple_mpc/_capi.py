@@ -104,8 +104,8 @@ class RobotModelC(C.Structure):
 # every symbol declared in include/smpc.h
 SYMBOLS = [
     "smpc_builtin_robot", "smpc_last_error", "smpc_device_count", "smpc_create", "smpc_create_centroidal", "smpc_destroy", "smpc_get_dims",
-    "smpc_generate_cycle_horizon", "smpc_switch_to_walk", "smpc_switch_to_stand", "smpc_set_x_reference",
-    "smpc_iterate", "smpc_iterate_device", "smpc_wait", "smpc_get_x_device", "smpc_get_xs", "smpc_get_us", "smpc_get_K0", "smpc_get_Ks",
+    "smpc_generate_cycle_horizon", "smpc_switch_to_walk", "smpc_switch_to_stand", "smpc_set_velocity_base_batched", "smpc_set_x_reference",
+    "smpc_state_size", "smpc_save_state", "smpc_load_state", "smpc_iterate", "smpc_iterate_device", "smpc_wait", "smpc_get_x_device", "smpc_get_xs", "smpc_get_us", "smpc_get_K0", "smpc_get_Ks",
     "smpc_get_vs", "smpc_get_lams", "smpc_get_state_derivative01", "smpc_get_reference_poses",
     "smpc_get_foot_timing", "smpc_get_info", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
     "smpc_debug_get_steps", "smpc_debug_get_terminal", "smpc_debug_get_phase_cycles", "smpc_set_profiling", "smpc_get_kernel_times", "smpc_reset_kernel_times",
@@ -142,7 +142,11 @@ class SmpcLib:
         L.smpc_generate_cycle_horizon.argtypes = [vp, _bp, C.c_int]
         L.smpc_switch_to_walk.argtypes = [vp, _dp]
         L.smpc_switch_to_stand.argtypes = [vp]
+        L.smpc_set_velocity_base_batched.argtypes = [vp, _dp]
         L.smpc_set_x_reference.argtypes = [vp, _dp]
+        L.smpc_state_size.argtypes = [vp, C.POINTER(C.c_size_t)]
+        L.smpc_save_state.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.smpc_load_state.argtypes = [vp, vp, C.c_size_t]
         L.smpc_iterate.argtypes = [vp, _dp]
         L.smpc_iterate_device.argtypes = [vp, vp]
         L.smpc_wait.argtypes = [vp]

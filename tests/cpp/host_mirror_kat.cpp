@@ -125,6 +125,25 @@ int main()
     threw = true;
   }
   CHECK(threw);
+  {
+    // checkpoint / resume through the header mirror: the restored handle repeats the step bit for bit
+    const std::vector<unsigned char> ck = mpc.saveState();
+    mpc.iterate(X);
+    const std::vector<double> xs_a = mpc.xs_;
+    mpc.loadState(ck);
+    mpc.iterate(X);
+    CHECK(xs_a == mpc.xs_);
+    std::vector<double> V(12, 0.0);
+    V[0] = 0.3;
+    V[6 + 5] = 0.4;
+    mpc.setVelocityBaseBatched(V);
+    mpc.iterate(X);
+    bool differ = false;
+    const size_t hh = mpc.xs_.size() / 2;
+    for (size_t i = 0; i < hh; i++)
+      differ = differ || mpc.xs_[i] != mpc.xs_[hh + i];
+    CHECK(differ); // two commands, two plans
+  }
   // ---- centroidal OCP, written like the reference's mpc_centroidal test (tests/mpc.cpp:172-258) ----
   {
     CentroidalSettings cs; // tests/test_utils.cpp:194-218 with 3-D forces

@@ -82,6 +82,8 @@ def lib():
     L.orc_mpc_generate_cycle.argtypes = [vp, _bp, C.c_int]
     L.orc_mpc_switch_to_walk.argtypes = [vp, _dp]
     L.orc_mpc_switch_to_stand.argtypes = [vp]
+    L.orc_mpc_set_velocity_batched.argtypes = [vp, _dp]
+    L.orc_cmpc_set_velocity_batched.argtypes = [vp, _dp]
     L.orc_mpc_set_x_reference.argtypes = [vp, _dp]
     L.orc_mpc_iterate.restype = C.c_double
     L.orc_mpc_iterate.argtypes = [vp, _dp]
@@ -311,6 +313,11 @@ class OracleMPC:
 
     def switchToStand(self):
         self._f("switch_to_stand")(self.h)
+
+    def setVelocityBaseBatched(self, V):
+        V = np.ascontiguousarray(V, float)
+        assert V.shape == (self.B, 6)
+        self._f("set_velocity_batched")(self.h, V)
 
     def iterate(self, X):
         X = np.ascontiguousarray(X, float)

@@ -116,6 +116,35 @@ def test_emu_standing_and_lane_order(lib):
     assert np.array_equal(outs[0], outs[1]), "a missing phase barrier makes the result depend on the lane order"
 
 
+def _velocity_case(lib, tol):
+    B = 3
+    V = np.array([[0.3, 0, 0, 0, 0, 0], [0.0, 0.2, 0, 0, 0, 0.4], [-0.2, 0.1, 0, 0, 0, -0.3]])
+    om, gm, rb = S.make_cent_pair(B, 2, lib=lib)
+    om.setVelocityBaseBatched(V)
+    gm.setVelocityBaseBatched(V)
+    singles = []
+    for b in range(B):
+        g1, _, _, _ = S.make_cent_product(1, 2, lib=lib)
+        g1.generateCycleHorizon(O.trot_cycle())
+        g1.switchToWalk(V[b])
+        singles.append(g1)
+    X = S.random_states(rb, B)
+    for _ in range(4):
+        om.iterate(X)
+        gm.iterate(X)
+        for b in range(B):
+            singles[b].iterate(X[b : b + 1])
+        assert S.rel_err(om.xs, gm.xs) < tol and S.rel_err(om.us, gm.us) < 10 * tol
+        assert S.rel_err(om.foot_refs, gm.getReferencePoses()) < 1e-12
+    for b in range(B):
+        assert np.array_equal(singles[b].xs[0], gm.xs[b]), "instance %d must equal the one-instance MPC with its command" % b
+    assert np.abs(gm.xs[0] - gm.xs[1]).max() > 1e-4
+
+
+def test_emu_per_instance_velocity_commands(lib):
+    _velocity_case(lib, 1e-9)
+
+
 def test_centroidal_handle_surface(lib):
     gm, rb, s, _ = S.make_cent_product(1, lib=lib)
     import simple_mpc
@@ -147,6 +176,11 @@ def test_gpu_cold_solve_and_closed_loop(built):
     assert S.rel_err(om.xs, gm.xs) < TOL
     w = _run_pair(om, gm, rb, 8, 10, TOL)
     print("centroidal: worst relative xs error over the run: %.3e" % w)
+
+
+@pytest.mark.gpu
+def test_gpu_per_instance_velocity_commands(built):
+    _velocity_case(None, TOL)
 
 
 @pytest.mark.gpu

@@ -168,3 +168,20 @@ def test_long_closed_loop_walk_is_stable_and_deterministic(built):
     assert np.all(xs[:, 0, 0] > 0.0) and xs[:, 0, 0].mean() > 0.15, "the base should advance under the 0.2 m/s command"
     assert np.all(np.abs(xs[:, 0, 2] - rb.x_ref[2]) < 0.1), "the base height should stay near the reference posture"
     assert np.array_equal(xs, runs[1][0]) and np.array_equal(us, runs[1][1])
+
+
+def test_per_instance_velocity_commands(built):
+    B = 4
+    V = np.array([[0.3, 0, 0, 0, 0, 0], [0.0, 0.2, 0, 0, 0, 0.4], [-0.2, 0.1, 0, 0, 0, -0.3], [0, 0, 0, 0, 0, 0.0]])
+    om, gm, rb = S.make_pair(B, 3)
+    om.setVelocityBaseBatched(V)
+    gm.setVelocityBaseBatched(V)
+    X = S.random_states(rb, B)
+    for _ in range(6):
+        om.iterate(X)
+        gm.iterate(X)
+        assert S.rel_err(om.xs, gm.xs) < TOL and S.rel_err(om.us, gm.us) < 10 * TOL
+        assert S.rel_err(om.foot_refs, gm.getReferencePoses()) < 1e-12
+        X = om.xs[:, 1, :].copy()
+    refs = gm.getReferencePoses()
+    assert np.abs(refs[0] - refs[1]).max() > 1e-3

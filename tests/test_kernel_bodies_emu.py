@@ -256,3 +256,34 @@ def test_reference_gait_kat_through_the_c_abi(lib):
         gm.iterate(x[None, :])
     to, ld = gm.foot_takeoff_times, gm.foot_land_times
     assert (to["FL_foot"][0], to["FR_foot"][0], ld["FL_foot"][0], ld["FR_foot"][0]) == (160, 100, 209, 150)
+
+
+def test_per_instance_velocity_commands(lib):
+    """smpc_set_velocity_base_batched: every instance follows its own command (Raibert footholds and the velocity part of
+    the state targets) exactly as a one-instance MPC given that command would."""
+    B = 3
+    V = np.array([[0.3, 0, 0, 0, 0, 0], [0.0, 0.2, 0, 0, 0, 0.4], [-0.2, 0.1, 0, 0, 0, -0.3]])
+    om, gm, rb = S.make_pair(B, 2, lib=lib)
+    om.setVelocityBaseBatched(V)
+    gm.setVelocityBaseBatched(V)
+    X = S.random_states(rb, B)
+    singles = []
+    for b in range(B):
+        g1, _, _, _ = S.make_product(1, 2, lib=lib)
+        g1.generateCycleHorizon(O.trot_cycle())
+        g1.switchToWalk(V[b])
+        singles.append(g1)
+    for _ in range(4):
+        om.iterate(X)
+        gm.iterate(X)
+        for b in range(B):
+            singles[b].iterate(X[b : b + 1])
+        assert S.rel_err(om.xs, gm.xs) < 1e-8 and S.rel_err(om.us, gm.us) < 1e-7
+        assert S.rel_err(om.foot_refs, gm.getReferencePoses()) < 1e-12
+        X = om.xs[:, 1, :].copy()
+    for b in range(B):
+        assert np.array_equal(singles[b].xs[0], gm.xs[b]), "instance %d must equal the one-instance MPC with its command" % b
+    refs = gm.getReferencePoses()
+    assert np.abs(refs[0] - refs[1]).max() > 1e-3, "different commands must give different footholds"
+    with pytest.raises(RuntimeError):
+        gm.setVelocityBaseBatched(np.zeros((B, 5)))
