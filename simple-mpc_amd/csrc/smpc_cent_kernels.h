@@ -482,6 +482,70 @@ namespace smpc
       {
         const unsigned mask = b.stages[t].mask;
         double * g = b.gains + (inst * H + t) * D::G_STRIDE;
+        // ---- sweep 1 first: P~ = (I + mu P)^-1 P depends on P_{t+1} only, so it runs while the record stores of the previous
+        //      stage are still being acknowledged (the stage inputs are committed after it; gfx950 has one counter for loads
+        //      and stores).  M1 = [[I + mu P, sqrt(mu) P], [., P]] (pad pivots 9..11: unit diagonal); the vector part follows
+        //      from (I + mu P)^-1 = I - mu P~ once the defect is known:  p~ = pt0 - mu P~ pt0 ----
+        SMPC_LANES(NT)
+        {
+          const double smu = sqrt(mu);
+#pragma unroll
+          for (int n = 0; n < 2; n++)
+          {
+            const int idx = lane + n * NT;
+            if (idx < 81)
+            {
+              const int i = idx / 9, j = idx % 9;
+              const double pv = s.P[idx];
+              s.M1[i * D::LD1 + j] = mu * pv + (i == j ? 1.0 : 0.0);
+              s.M1[i * D::LD1 + X1 + j] = smu * pv;
+              s.M1[(X1 + j) * D::LD1 + i] = smu * pv;
+              s.M1[(X1 + i) * D::LD1 + X1 + j] = pv;
+            }
+          }
+        }
+        SMPC_LANES_END_WAVE
+        CENT_FINE_TICK(5);
+        // ---- sweep 1: P~, p~ ----
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int J = I; J < 2; J++)
+#pragma unroll
+              for (int vv = 0; vv < 4; vv++)
+              {
+                const int r = 16 * I + lr + 4 * vv;
+                SMPC_ACCV(macc, tix<2>(I, J), vv) = r < D::R1 && 16 * J + lc < D::LD1 ? s.M1[r * D::LD1 + 16 * J + lc] : 0.0;
+              }
+        }
+        SMPC_LANES_END_WAVE
+        CENT_FINE_TICK(6);
+        wave_block_sweep<NT, 2, false, 0, 3>(macc, s.prow, s.urow, CENT_FINE_DBG, tprev);
+        // P~ (upper triangle of the Schur block is authoritative, mirrored) straight out of the accumulators
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int I = 0; I < 2; I++)
+#pragma unroll
+            for (int J = I; J < 2; J++)
+#pragma unroll
+              for (int vv = 0; vv < 4; vv++)
+              {
+                const int r = 16 * I + lr + 4 * vv - X1, c = 16 * J + lc - X1;
+                const double a = SMPC_ACCV(macc, tix<2>(I, J), vv);
+                if (r >= 0 && r < 9 && c >= r && c < 9)
+                {
+                  s.Pt[r * 9 + c] = a;
+                  s.Pt[c * 9 + r] = a;
+                }
+              }
+        }
+        SMPC_LANES_END_WAVE
+        CENT_FINE_TICK(7);
         // ---- stage inputs -> LDS ; prefetch of stage t-1 ----
         SMPC_LANES(NT)
         {
@@ -699,6 +763,11 @@ namespace smpc
               a += s.ABp[k * LDM + XO + lane] * l1[k];
               gx += s.ABp[k * LDM + XO + lane] * s.lpd[k];
             }
+            double pa = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; k++)
+              pa += s.Pt[lane * 9 + k] * s.pt0[k];
+            s.pt[lane] = s.pt0[lane] - mu * pa; // p~ = (I - mu P~) pt0
             const double q = t > 0 ? s.lx[lane] + a - l0[lane] : 0.0; // x_0 is fixed (force_initial_condition)
             s.q[lane] = q;
             s.gxp[lane] = s.lx[lane] + gx;
@@ -727,79 +796,6 @@ namespace smpc
         }
         SMPC_LANES_END_WAVE
         CENT_FINE_TICK(4);
-        // M1 = [[I + mu P, sqrt(mu) P, sqrt(mu) pt0], [., P, pt0]] (pad pivots 9..11: unit diagonal)
-        SMPC_LANES(NT)
-        {
-          const double smu = sqrt(mu);
-#pragma unroll
-          for (int n = 0; n < 2; n++)
-          {
-            const int idx = lane + n * NT;
-            if (idx < 81)
-            {
-              const int i = idx / 9, j = idx % 9;
-              const double pv = s.P[idx];
-              s.M1[i * D::LD1 + j] = mu * pv + (i == j ? 1.0 : 0.0);
-              s.M1[i * D::LD1 + X1 + j] = smu * pv;
-              s.M1[(X1 + j) * D::LD1 + i] = smu * pv;
-              s.M1[(X1 + i) * D::LD1 + X1 + j] = pv;
-            }
-          }
-          if (lane < 9)
-          {
-            const double a = s.pt0[lane];
-            s.M1[lane * D::LD1 + Z1] = smu * a;
-            s.M1[Z1 * D::LD1 + lane] = smu * a;
-            s.M1[(X1 + lane) * D::LD1 + Z1] = a;
-            s.M1[Z1 * D::LD1 + X1 + lane] = a;
-          }
-        }
-        SMPC_LANES_END_WAVE
-        CENT_FINE_TICK(5);
-        // ---- sweep 1: P~, p~ ----
-        SMPC_LANES(NT)
-        {
-          const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-          for (int I = 0; I < 2; I++)
-#pragma unroll
-            for (int J = I; J < 2; J++)
-#pragma unroll
-              for (int vv = 0; vv < 4; vv++)
-              {
-                const int r = 16 * I + lr + 4 * vv;
-                SMPC_ACCV(macc, tix<2>(I, J), vv) = r < D::R1 && 16 * J + lc < D::LD1 ? s.M1[r * D::LD1 + 16 * J + lc] : 0.0;
-              }
-        }
-        SMPC_LANES_END_WAVE
-        CENT_FINE_TICK(6);
-        wave_block_sweep<NT, 2, false, 0, 3>(macc, s.prow, s.urow, CENT_FINE_DBG, tprev);
-        // P~ (upper triangle of the Schur block is authoritative, mirrored) and p~ straight out of the accumulators
-        SMPC_LANES(NT)
-        {
-          const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-          for (int I = 0; I < 2; I++)
-#pragma unroll
-            for (int J = I; J < 2; J++)
-#pragma unroll
-              for (int vv = 0; vv < 4; vv++)
-              {
-                const int r = 16 * I + lr + 4 * vv - X1, c = 16 * J + lc - X1;
-                const double a = SMPC_ACCV(macc, tix<2>(I, J), vv);
-                if (r >= 0 && r < 9 && c >= r && c < 9)
-                {
-                  s.Pt[r * 9 + c] = a;
-                  s.Pt[c * 9 + r] = a;
-                  g[D::G_Pt + r * 9 + c] = a;
-                  g[D::G_Pt + c * 9 + r] = a;
-                }
-                if (r >= 0 && r < 9 && c == 9)
-                  s.pt[r] = a;
-              }
-        }
-        SMPC_LANES_END_WAVE
-        CENT_FINE_TICK(7);
         // ---- sweep-2 matrix: cost / constraint part ----
         SMPC_LANES(NT)
         {
@@ -992,6 +988,10 @@ namespace smpc
             g[D::G_gx + lane] = s.gxp[lane];
             g[D::G_lpd + lane] = s.lpd[lane];
           }
+#pragma unroll
+          for (int n = 0; n < 2; n++)
+            if (lane + n * NT < 81)
+              g[D::G_Pt + lane + n * NT] = s.Pt[lane + n * NT];
           if (lane < 3)
             g[D::G_fs + lane] = s.fs[lane];
           if (lane < 3 * NF)
