@@ -180,6 +180,7 @@ namespace smpc
   {
     constexpr int NF = D::NF, NU = D::NU;
     const double al = q.alpha;
+    const double imu = 1.0 / md.mu, imass = 1.0 / md.mass;
     auto X = [&](int i) { return q.x[i] + al * q.dx[i]; };
     const V3 c = mk3(X(0), X(1), X(2)), h = mk3(X(3), X(4), X(5)), L = mk3(X(6), X(7), X(8));
     V3 fs = mk3(0, 0, 0), ts = mk3(0, 0, 0);
@@ -203,8 +204,8 @@ namespace smpc
         ts = ts + cross(ld3(q.p + 3 * f) - c, F);
         const double c0 = -F.z + md.cone_eps, c1 = F.x * F.x + F.y * F.y - md.mu_fric * md.mu_fric * F.z * F.z;
         const double z0 = c0 + md.mu * q.ve[2 * f], z1 = c1 + md.mu * q.ve[2 * f + 1];
-        vp0 = (z0 - fmin(z0, 0.0)) / md.mu;
-        vp1 = (z1 - fmin(z1, 0.0)) / md.mu;
+        vp0 = (z0 - fmin(z0, 0.0)) * imu;
+        vp1 = (z1 - fmin(z1, 0.0)) * imu;
         prim = fmax(prim, fmax(fmax(c0, 0.0), fmax(c1, 0.0)));
       }
       const double d0 = vp0 - (q.v[2 * f] + al * q.dv[2 * f]), d1 = vp1 - (q.v[2 * f + 1] + al * q.dv[2 * f + 1]);
@@ -213,9 +214,9 @@ namespace smpc
     }
     const V3 g = ld3(md.gravity);
     double xd[9];
-    xd[0] = h.x / md.mass;
-    xd[1] = h.y / md.mass;
-    xd[2] = h.z / md.mass;
+    xd[0] = h.x * imass;
+    xd[1] = h.y * imass;
+    xd[2] = h.z * imass;
     xd[3] = md.mass * g.x + fs.x;
     xd[4] = md.mass * g.y + fs.y;
     xd[5] = md.mass * g.z + fs.z;
@@ -226,7 +227,7 @@ namespace smpc
     for (int i = 0; i < 9; i++)
     {
       const double e = X(i) + md.dt * xd[i] - (q.xn[i] + al * q.dxn[i]);
-      const double lp = q.l1e[i] + e / md.mu, dl = lp - (q.l1[i] + al * q.dl[i]);
+      const double lp = q.l1e[i] + e * imu, dl = lp - (q.l1[i] + al * q.dl[i]);
       pen += 0.5 * md.mu * (lp * lp + dl * dl);
       prim = fmax(prim, fabs(e));
       if (xdot)
@@ -249,7 +250,7 @@ namespace smpc
     cost += 0.5 * cu;
     cost += quad3(md.w_lm, h - ld3(q.href));
     cost += quad3(md.w_am, L - ld3(q.href + 3));
-    cost += quad3(md.w_la, g + (1.0 / md.mass) * fs);
+    cost += quad3(md.w_la, g + imass * fs);
     cost += quad3(md.w_aa, ts);
   }
 
@@ -321,6 +322,7 @@ namespace smpc
     SMPC_LANES_END_WAVE
     const CentDevModel<D> & md = s.md;
     const double mu = md.mu, dt = md.dt, mass = md.mass;
+    const double imu = 1.0 / mu, imass = 1.0 / mass; // (the stage loop multiplies: an FP64 division is ~35 instructions)
 
     // ---- recede: warm-start shift on the ring (src/mpc.cpp:201-207), references (src/mpc.cpp:278-309) ----
     if (ka.shift)
@@ -583,9 +585,9 @@ namespace smpc
             const double fk = k == 0 ? fs.x : (k == 1 ? fs.y : fs.z);
             const double tk = k == 0 ? ts.x : (k == 1 ? ts.y : ts.z);
             const double gk = k == 0 ? gv.x : (k == 1 ? gv.y : gv.z);
-            const double xd = lane < 3 ? hk / mass : (lane < 6 ? mass * gk + fk : tk);
+            const double xd = lane < 3 ? hk * imass : (lane < 6 ? mass * gk + fk : tk);
             const double e = x[lane] + dt * xd - xn[lane];
-            const double lp = l1e[lane] + e / mu, dl = lp - l1[lane];
+            const double lp = l1e[lane] + e * imu, dl = lp - l1[lane];
             s.f[lane] = mu * dl;
             s.lpd[lane] = 2.0 * lp - l1[lane];
             SMPC_PLV(acc_pen) += 0.5 * mu * (lp * lp + dl * dl);
@@ -595,7 +597,7 @@ namespace smpc
             {
               s.fs[lane] = fk;
               s.ts[lane] = tk;
-              s.rla[lane] = gk + fk / mass;
+              s.rla[lane] = gk + fk * imass;
             }
           }
           if (lane >= 16 && lane < 16 + NC)
@@ -610,7 +612,7 @@ namespace smpc
               const double cv = cone ? F.x * F.x + F.y * F.y - md.mu_fric * md.mu_fric * F.z * F.z : -F.z + md.cone_eps;
               const double z = cv + mu * ve[row];
               const double proj = fmin(z, 0.0);
-              vp = (z - proj) / mu;
+              vp = (z - proj) * imu;
               act = z != proj ? 1.0 : 0.0;
               SMPC_PLV(acc_prim) = fmax(SMPC_PLV(acc_prim), fmax(cv, 0.0));
               c0 = cone ? 2.0 * F.x : 0.0;
@@ -697,7 +699,7 @@ namespace smpc
             const int i = lane - 16;
             s.ABp[i * LDM + XO + i] = 1.0;
             if (i >= 3 && i < 6)
-              s.ABp[(i - 3) * LDM + XO + i] = dt / mass;
+              s.ABp[(i - 3) * LDM + XO + i] = dt * imass;
             if (i < 3)
             {
 #pragma unroll
@@ -723,26 +725,21 @@ namespace smpc
             }
             s.lx[lane] = a;
             double pa = s.p[lane];
+#pragma unroll
             for (int j = 0; j < 9; j++)
               pa += s.P[lane * 9 + j] * s.f[j];
             s.pt0[lane] = pa;
+            // cost terms are accumulated where their factors are at hand (per-lane partial sums, folded once per iteration)
+            SMPC_PLV(acc_cost) += 0.5 * s.rx[lane] * s.wrx[lane];
+            if (lane < 3)
+              SMPC_PLV(acc_cost) += 0.5 * (s.rla[lane] * s.wla[lane] + s.ts[lane] * s.waa[lane]);
           }
           if (lane >= 16 && lane < 16 + NU)
           {
             const int j = lane - 16, f = j / 3, k = j % 3;
             const V3 w = cross(waa, ld3(&s.rf[3 * f])); // [r]x^T w (r = 0 for a foot in the air)
-            s.lu[j] = s.wu[j] + s.act[f] * s.wla[k] / mass + (k == 0 ? w.x : (k == 1 ? w.y : w.z));
-          }
-          if (lane == 40)
-          {
-            double cst = 0.0;
-            for (int i = 0; i < 9; i++)
-              cst += s.rx[i] * s.wrx[i];
-            for (int i = 0; i < NU; i++)
-              cst += s.ru[i] * s.wu[i];
-            for (int i = 0; i < 3; i++)
-              cst += s.rla[i] * s.wla[i] + s.ts[i] * s.waa[i];
-            SMPC_PLV(acc_cost) += 0.5 * cst;
+            s.lu[j] = s.wu[j] + s.act[f] * s.wla[k] * imass + (k == 0 ? w.x : (k == 1 ? w.y : w.z));
+            SMPC_PLV(acc_cost) += 0.5 * s.ru[j] * s.wu[j];
           }
         }
         SMPC_LANES_END_WAVE
@@ -806,7 +803,7 @@ namespace smpc
             const int i = idx / NU, j = idx % NU;
             const int fa = i / 3, ia = i % 3, fb = j / 3, jb = j % 3;
             const V3 ra = ld3(&s.rf[3 * fa]);
-            double a = md.w_u[idx] + (i == j ? preg : 0.0) + s.act[fa] * s.act[fb] * md.w_la[ia * 3 + jb] / (mass * mass);
+            double a = md.w_u[idx] + (i == j ? preg : 0.0) + s.act[fa] * s.act[fb] * md.w_la[ia * 3 + jb] * (imass * imass);
 #pragma unroll
             for (int k = 0; k < 3; k++)
               a += skew_el(ra, k, ia) * s.N[fb * 9 + k * 3 + jb];
@@ -964,7 +961,7 @@ namespace smpc
                   if (r < NU)
                     g[D::G_K + r * 10 + c] = -a;
                   else if (r >= VO && r < VO + NC)
-                    g[D::G_Z + (r - VO) * 10 + c] = anyact ? -a : a / mu;
+                    g[D::G_Z + (r - VO) * 10 + c] = anyact ? -a : a * imu;
                   else if (r >= XO && r < XO + 9)
                   {
                     const int i = r - XO;
@@ -1069,7 +1066,7 @@ namespace smpc
           double a = s.dx[lane];
           const int k = lane % 3;
           if (lane < 3)
-            a += dt * s.dx[3 + lane] / mass;
+            a += dt * s.dx[3 + lane] * imass;
           else if (lane < 6)
           {
             double sf = 0.0;
