@@ -159,6 +159,34 @@ namespace simple_mpc
         throw std::runtime_error("velocity_base size should be batch * 6");
       check(smpc_set_velocity_base_batched(h_, V.data()));
     }
+    // OCPHandler per-stage setters / getters (reference include/simple-mpc/ocp-handler.hpp:66-127), broadcast over the batch
+    void setReferenceControl(std::size_t t, const std::vector<double> & u_ref) { check(smpc_set_stage_reference(h_, (int)t, 0, u_ref.data(), (int)u_ref.size())); }
+    std::vector<double> getReferenceControl(std::size_t t)
+    {
+      std::vector<double> u(nu());
+      check(smpc_get_stage_reference(h_, (int)t, 0, u.data(), nu()));
+      return u;
+    }
+    void setReferenceState(std::size_t t, const std::vector<double> & x_ref) { check(smpc_set_stage_reference(h_, (int)t, 1, x_ref.data(), (int)x_ref.size())); }
+    std::vector<double> getReferenceState(std::size_t t)
+    {
+      std::vector<double> x(nx());
+      check(smpc_get_stage_reference(h_, (int)t, 1, x.data(), nx()));
+      return x;
+    }
+    void setReferencePose(std::size_t t, const std::string & ee_name, const double * translation3) { check(smpc_set_reference_pose(h_, (int)t, foot(ee_name), translation3)); }
+    std::vector<double> getReferencePose(std::size_t t, const std::string & ee_name)
+    {
+      std::vector<double> p(3);
+      check(smpc_get_reference_pose(h_, (int)t, foot(ee_name), 0, p.data()));
+      return p;
+    }
+    std::vector<bool> getContactState(std::size_t t)
+    {
+      std::vector<uint8_t> c(ee_names_.size());
+      check(smpc_get_contact_state(h_, (int)t, c.data()));
+      return std::vector<bool>(c.begin(), c.end());
+    }
     // checkpoint / resume of the whole batch
     std::vector<unsigned char> saveState()
     {
@@ -209,6 +237,13 @@ namespace simple_mpc
       check(smpc_get_dims(h_, dims_));
       for (int f = 0; f < robot->nfeet; f++)
         ee_names_.push_back(robot->foot_name[f]);
+    }
+    int foot(const std::string & ee) const
+    {
+      for (size_t f = 0; f < ee_names_.size(); f++)
+        if (ee_names_[f] == ee)
+          return (int)f;
+      throw std::runtime_error("unknown end effector " + ee);
     }
     std::vector<int> timing(const std::string & ee, int which)
     {

@@ -127,6 +127,22 @@ int smpc_switch_to_stand(smpc_handle * h);
  * directly, bindings/expose-mpc.cpp:86; a batch of robots is not steered by one joystick).  The walking / standing state is
  * unchanged.  smpc_switch_to_walk / smpc_switch_to_stand broadcast one command to every instance. */
 int smpc_set_velocity_base_batched(smpc_handle * h, const double * V);
+/* Per-stage references of the horizon -- the OCPHandler setters / getters (reference include/simple-mpc/ocp-handler.hpp:
+ * 66-127; src/kinodynamics.cpp:154-306, src/centroidal-dynamics.cpp:120-304, src/ocp-handler.cpp:58-81), broadcast over the
+ * batch; t >= horizon is the reference's "Stage index exceeds stage vector size" error.
+ *   what = 0: control target (setReferenceControl; setReferenceForce(s) are segments of it), n = nu
+ *   what = 1: reference state as setReferenceState / getReferenceState define it, n = nx (kinodynamics: the state_cost
+ *             target; centroidal: [com_ref; v_lin; v_ang], stored as momenta m v like the reference does)
+ * setPoseBase / setVelocityBase are read-modify-write of what = 1, as in the reference.  Getters return instance 0.
+ * Like in the reference, the next smpc_iterate overwrites the foot references of every stage and the state target of the
+ * last stage (MPC::updateStepTrackerReferences, src/mpc.cpp:278-313). */
+int smpc_set_stage_reference(smpc_handle * h, int t, int what, const double * v, int n);
+int smpc_get_stage_reference(smpc_handle * h, int t, int what, double * v, int n);
+/* setReferencePose / getReferencePose (translation; src/kinodynamics.cpp:154-169, src/centroidal-dynamics.cpp:151-188) */
+int smpc_set_reference_pose(smpc_handle * h, int t, int foot, const double * p3);
+int smpc_get_reference_pose(smpc_handle * h, int t, int foot, int instance, double * p3);
+/* getContactState(t): contact flag per foot (src/kinodynamics.cpp:343-349); getContactSupport = their sum */
+int smpc_get_contact_state(smpc_handle * h, int t, uint8_t * out_nfeet);
 /* MPC::x_reference_ (public member, reference include/simple-mpc/mpc.hpp:191) */
 int smpc_set_x_reference(smpc_handle * h, const double * x_ref);
 

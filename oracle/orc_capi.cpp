@@ -379,6 +379,37 @@ extern "C"
   void orc_mpc_switch_to_walk(void * h, const double * v6) { ((BatchMPC *)h)->switchToWalk(v6); }
   void orc_mpc_switch_to_stand(void * h) { ((BatchMPC *)h)->switchToStand(); }
   void orc_mpc_set_velocity_batched(void * h, const double * V) { ((BatchMPC *)h)->setVelocityBaseBatched(V); }
+  // OCPHandler per-stage setters on the shared horizon (what: 0 control target, 1 state target; broadcast over the batch)
+  void orc_mpc_set_stage_reference(void * h, int t, int what, const double * v)
+  {
+    BatchMPC * m = (BatchMPC *)h;
+    if (what == 0)
+      m->horizon[t].u_ref.assign(v, v + m->md.nu);
+    else
+    {
+      m->horizon[t].x_tgt.assign(v, v + m->md.nx);
+      for (int b = 0; b < m->B; b++)
+        for (int i = 0; i < 6; i++)
+          m->vref[b][t][i] = v[m->md.nq + i];
+    }
+  }
+  void orc_cmpc_set_stage_reference(void * h, int t, int what, const double * v)
+  {
+    BatchMPCCent * m = (BatchMPCCent *)h;
+    if (what == 0)
+      m->horizon[t].u_ref.assign(v, v + m->md.nu);
+    else
+    {
+      for (int i = 0; i < 3; i++)
+      {
+        m->horizon[t].x_tgt[i] = v[i];
+        m->com_ref_member[i] = v[i];
+      }
+      for (int b = 0; b < m->B; b++)
+        for (int i = 0; i < 6; i++)
+          m->vref[b][t][i] = m->md.mass * v[3 + i];
+    }
+  }
   void orc_mpc_set_x_reference(void * h, const double * x)
   {
     BatchMPC * m = (BatchMPC *)h;

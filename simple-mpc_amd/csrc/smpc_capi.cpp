@@ -237,6 +237,48 @@ extern "C"
       return guarded([&] { h->cent->set_velocity_base_batched(V); });
     return guarded([&] { h->eng->set_velocity_base_batched(V); });
   }
+  int smpc_set_stage_reference(smpc_handle * h, int t, int what, const double * v, int n)
+  {
+    if (!h || !v)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return guarded([&] { h->cent->set_stage_reference(t, what, v, n); });
+    return guarded([&] { h->eng->set_stage_reference(t, what, v, n); });
+  }
+  int smpc_get_stage_reference(smpc_handle * h, int t, int what, double * v, int n)
+  {
+    if (!h || !v)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return guarded([&] { h->cent->get_stage_reference(t, what, v, n); });
+    return guarded([&] { h->eng->get_stage_reference(t, what, v, n); });
+  }
+  int smpc_set_reference_pose(smpc_handle * h, int t, int foot, const double * p3)
+  {
+    if (!h || !p3)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return guarded([&] { h->cent->set_reference_pose(t, foot, p3); });
+    return guarded([&] { h->eng->set_reference_pose(t, foot, p3); });
+  }
+  int smpc_get_reference_pose(smpc_handle * h, int t, int foot, int instance, double * p3)
+  {
+    if (!h || !p3)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->cent)
+      return guarded([&] { h->cent->get_reference_pose(t, foot, instance, p3); });
+    return guarded([&] { h->eng->get_reference_pose(t, foot, instance, p3); });
+  }
+  int smpc_get_contact_state(smpc_handle * h, int t, uint8_t * out)
+  {
+    if (!h || !out)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] {
+      const unsigned m = h->cent ? h->cent->contact_mask(t) : h->eng->contact_mask(t);
+      for (int f = 0; f < DimsGo2::NF; f++)
+        out[f] = (m >> f) & 1u;
+    });
+  }
   int smpc_set_x_reference(smpc_handle * h, const double * x)
   {
     if (!h || !x)

@@ -386,6 +386,90 @@ namespace smpc
         a.land[f] = timer.land[f].empty() ? -1 : timer.land[f][0];
       timed_launch<CentStepArgs<DC>, cent_step_body<DC>, 64, 2>(CKID_STEP, B, a);
     }
+    // ---- per-stage references (OCPHandler setters / getters of the centroidal OCP, reference src/centroidal-dynamics.cpp:
+    //      120-304), broadcast over the batch ----
+    void check_stage(int t) const
+    {
+      if (t < 0 || t >= H)
+        throw std::runtime_error("Stage index exceeds stage vector size");
+    }
+    void fill_strided(double * base, size_t stride, int count, const double * v, int n)
+    {
+      FillStridedArgs fa;
+      fa.base = base;
+      fa.stride = stride;
+      fa.count = count;
+      fa.n = n;
+      for (int i = 0; i < n; i++)
+        fa.v[i] = v[i];
+      launch<FillStridedArgs, fill_strided_body, 64>((count + 63) / 64, stream, fa);
+      stream_sync(stream);
+    }
+    // what: 0 = control target (nu); 1 = reference state as get / setReferenceState define it: [com_ref; v_lin; v_ang]
+    // (setReferenceState = setPoseBase + setVelocityBase, which stores the momenta m v; getReferenceState divides by m)
+    void set_stage_reference(int t, int what, const double * v, int n)
+    {
+      check_stage(t);
+      if (what == 0)
+      {
+        if (n != DC::NU)
+          throw std::runtime_error("u_ref not of the right size");
+        std::copy(v, v + n, horizon[t].u_ref);
+      }
+      else if (what == 1)
+      {
+        if (n != 9)
+          throw std::runtime_error("x_ref not of the right size");
+        double mv[6];
+        for (int i = 0; i < 3; i++)
+        {
+          horizon[t].x_tgt[i] = v[i];
+          com_ref_member[i] = v[i]; // setPoseBase updates CentroidalOCP::com_ref_
+        }
+        for (int i = 0; i < 6; i++)
+          horizon[t].x_tgt[3 + i] = mv[i] = mass * v[3 + i];
+        fill_strided(buf.vref + (size_t)ring_slot(head, t, R) * 6, (size_t)R * 6, B, mv, 6);
+      }
+      else
+        throw std::runtime_error("unknown stage reference");
+    }
+    void get_stage_reference(int t, int what, double * v, int n)
+    {
+      check_stage(t);
+      if (what == 0 && n == DC::NU)
+        std::copy(horizon[t].u_ref, horizon[t].u_ref + n, v);
+      else if (what == 1 && n == 9)
+      {
+        double mv[6];
+        get_linear(buf.vref + (size_t)ring_slot(head, t, R) * 6, 6, mv); // instance 0
+        for (int i = 0; i < 3; i++)
+          v[i] = horizon[t].x_tgt[i];
+        for (int i = 0; i < 6; i++)
+          v[3 + i] = mv[i] / mass;
+      }
+      else
+        throw std::runtime_error("unknown stage reference or wrong size");
+    }
+    void set_reference_pose(int t, int foot, const double * p3)
+    {
+      check_stage(t);
+      if (foot < 0 || foot >= DC::NF)
+        throw std::runtime_error("unknown end effector");
+      fill_strided(buf.foot + ((size_t)t * DC::NF + foot) * 3, (size_t)H * DC::NF * 3, B, p3, 3);
+    }
+    void get_reference_pose(int t, int foot, int inst, double * p3)
+    {
+      check_stage(t);
+      if (foot < 0 || foot >= DC::NF || inst < 0 || inst >= B)
+        throw std::runtime_error("unknown end effector or instance");
+      get_linear(buf.foot + (((size_t)inst * H + t) * DC::NF + foot) * 3, 3, p3);
+    }
+    unsigned contact_mask(int t) const
+    {
+      check_stage(t);
+      return horizon[t].mask;
+    }
+
     size_t state_io(StateIO & io)
     {
       stream_sync(stream);

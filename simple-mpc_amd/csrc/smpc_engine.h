@@ -795,6 +795,79 @@ namespace smpc
       copy_centres(buf);
       run_iterations(buf, ms.max_iters);
     }
+    // ---- per-stage references of the horizon: the OCPHandler setters / getters (reference src/kinodynamics.cpp:154-306,
+    //      src/ocp-handler.cpp:58-81), broadcast over the batch.  The next iterate() overwrites the foot references of
+    //      every stage and the state target of stage H-1, exactly like MPC::updateStepTrackerReferences does. ----
+    void check_stage(int t) const
+    {
+      if (t < 0 || t >= H)
+        throw std::runtime_error("Stage index exceeds stage vector size");
+    }
+    void fill_strided(double * base, size_t stride, int count, const double * v, int n)
+    {
+      FillStridedArgs fa;
+      fa.base = base;
+      fa.stride = stride;
+      fa.count = count;
+      fa.n = n;
+      for (int i = 0; i < n; i++)
+        fa.v[i] = v[i];
+      launch<FillStridedArgs, fill_strided_body, 64>((count + 63) / 64, stream, fa);
+      stream_sync(stream);
+    }
+    // what: 0 = control target (nu), 1 = state target (nx)
+    void set_stage_reference(int t, int what, const double * v, int n)
+    {
+      check_stage(t);
+      if (what == 0)
+      {
+        if (n != D::NU)
+          throw std::runtime_error("u_ref not of the right size");
+        std::copy(v, v + n, horizon[t].u_ref);
+      }
+      else if (what == 1)
+      {
+        if (n != D::NX)
+          throw std::runtime_error("x_ref not of the right size");
+        std::copy(v, v + n, horizon[t].x_tgt);
+        fill_strided(buf.vref + (size_t)ring_slot(head, t, R) * 6, (size_t)R * 6, B, v + D::NQ, 6); // velocity part is per instance
+      }
+      else
+        throw std::runtime_error("unknown stage reference");
+    }
+    void get_stage_reference(int t, int what, double * v, int n)
+    {
+      check_stage(t);
+      if (what == 0 && n == D::NU)
+        std::copy(horizon[t].u_ref, horizon[t].u_ref + n, v);
+      else if (what == 1 && n == D::NX)
+      {
+        std::copy(horizon[t].x_tgt, horizon[t].x_tgt + n, v);
+        get_linear(buf.vref + (size_t)ring_slot(head, t, R) * 6, 6, v + D::NQ); // instance 0
+      }
+      else
+        throw std::runtime_error("unknown stage reference or wrong size");
+    }
+    void set_reference_pose(int t, int foot, const double * p3)
+    {
+      check_stage(t);
+      if (foot < 0 || foot >= D::NF)
+        throw std::runtime_error("unknown end effector");
+      fill_strided(buf.foot_ref + ((size_t)t * D::NF + foot) * 3, (size_t)H * D::NF * 3, B, p3, 3);
+    }
+    void get_reference_pose(int t, int foot, int inst, double * p3)
+    {
+      check_stage(t);
+      if (foot < 0 || foot >= D::NF || inst < 0 || inst >= B)
+        throw std::runtime_error("unknown end effector or instance");
+      get_linear(buf.foot_ref + (((size_t)inst * H + t) * D::NF + foot) * 3, 3, p3);
+    }
+    unsigned contact_mask(int t) const
+    {
+      check_stage(t);
+      return horizon[t].mask;
+    }
+
     // Everything a later iterate() depends on: iterate, multipliers, swing trajectories, references, velocity commands, gait
     // bookkeeping.  Not included: the feedback gains and the LQ knots of the last solve (recomputed by the next iterate).
     size_t state_io(StateIO & io)

@@ -945,6 +945,27 @@ namespace smpc
     SMPC_LANES_END
   }
 
+  // the same n <= 8 values into a strided array of `count` records (per-stage reference setters, broadcast over the batch)
+  struct FillStridedArgs
+  {
+    double * base;
+    size_t stride;
+    int count, n;
+    double v[8];
+  };
+  SMPC_DEV void fill_strided_body(const FillStridedArgs & ka, int block)
+  {
+    constexpr int NT = 64;
+    SMPC_LANES(NT)
+    {
+      const int r = block * NT + lane;
+      if (r < ka.count)
+        for (int i = 0; i < ka.n; i++)
+          ka.base[(size_t)r * ka.stride + i] = ka.v[i];
+    }
+    SMPC_LANES_END_WAVE
+  }
+
   // CentroidalFwdDynamics + IntegratorEuler with derivatives (reference src/centroidal-dynamics.cpp:79-81; SURVEY 8a row
   // a6, App. B.1), batched: lane = instance (the model is 9-dimensional: one instance per lane is the wide mapping).
   struct CentroidalArgs

@@ -103,13 +103,115 @@ class RobotDataHandler:
         self.model_handler = model_handler
 
 
+
+
+class _StageReferences:
+    """Per-stage setters / getters of OCPHandler (reference include/simple-mpc/ocp-handler.hpp:66-127), broadcast over the
+    batch.  The batched problem lives in the MPC handle: they work once BatchedMPC / MPC has been constructed on this OCP.
+    Poses are translations (3-vectors; an object with a `.translation` attribute is accepted); getters return instance 0."""
+
+    _mpc = None
+
+    def _handle(self):
+        if self._problem is None:
+            raise RuntimeError("Create problem first!")
+        if self._mpc is None:
+            raise RuntimeError("the batched problem lives in the MPC handle: construct BatchedMPC(settings, ocp, batch) first")
+        return self._mpc
+
+    def _foot(self, ee_name):
+        names = self.model_handler.getFeetFrameNames()
+        if ee_name not in names:
+            raise RuntimeError("unknown end effector %r" % ee_name)
+        return names.index(ee_name)
+
+    def _set(self, t, what, v):
+        m = self._handle()
+        v = np.ascontiguousarray(v, float)
+        m._lib.check(m._lib.L.smpc_set_stage_reference(m._h, int(t), what, v, v.size))
+
+    def _get(self, t, what, n):
+        m = self._handle()
+        out = np.zeros(n)
+        m._lib.check(m._lib.L.smpc_get_stage_reference(m._h, int(t), what, out, n))
+        return out
+
+    # control target and its force segments (reference src/ocp-handler.cpp:58-70, src/kinodynamics.cpp:229-265)
+    def setReferenceControl(self, t, u_ref):
+        u = np.ascontiguousarray(u_ref, float)
+        if u.shape != (self.nu,):
+            raise RuntimeError("u_ref not of the right size")
+        self._set(t, 0, u)
+
+    def getReferenceControl(self, t):
+        return self._get(t, 0, self.nu)
+
+    def _control_from_forces(self, force_refs):
+        fs = int(self.settings["force_size"])
+        for i, name in enumerate(self.model_handler.getFeetFrameNames()):
+            f = np.asarray(force_refs[name], float)
+            if f.size != fs:
+                raise RuntimeError("force size in settings does not match reference force size")
+            self._control_ref[i * fs : (i + 1) * fs] = f
+
+    def setReferenceForces(self, t, force_refs):
+        self._control_from_forces(force_refs)
+        self.setReferenceControl(t, self._control_ref)
+
+    def setReferenceForce(self, t, ee_name, force_ref):
+        # like the reference, the other segments come from the handler's control_ref_ member, not from stage t
+        fs, i = int(self.settings["force_size"]), self._foot(ee_name)
+        self._control_ref[i * fs : (i + 1) * fs] = np.asarray(force_ref, float)
+        self.setReferenceControl(t, self._control_ref)
+
+    def getReferenceForce(self, t, ee_name):
+        fs, i = int(self.settings["force_size"]), self._foot(ee_name)
+        return self.getReferenceControl(t)[i * fs : (i + 1) * fs]
+
+    # foot references (reference src/kinodynamics.cpp:154-228, src/centroidal-dynamics.cpp:120-188)
+    def setReferencePose(self, t, ee_name, pose_ref):
+        m = self._handle()
+        p = np.ascontiguousarray(getattr(pose_ref, "translation", pose_ref), float).reshape(3)
+        m._lib.check(m._lib.L.smpc_set_reference_pose(m._h, int(t), self._foot(ee_name), p))
+
+    def setReferencePoses(self, t, pose_refs):
+        if len(pose_refs) != self.model_handler.getFeetNb():
+            raise RuntimeError("pose_refs size does not match number of end effectors")
+        for name in self.model_handler.getFeetFrameNames():
+            self.setReferencePose(t, name, pose_refs[name])
+
+    def getReferencePose(self, t, ee_name):
+        m = self._handle()
+        p = np.zeros(3)
+        m._lib.check(m._lib.L.smpc_get_reference_pose(m._h, int(t), self._foot(ee_name), 0, p))
+        return p
+
+    # state target and its segments
+    def setReferenceState(self, t, x_ref):
+        x = np.ascontiguousarray(x_ref, float)
+        if x.shape != (self._nx_ref,):
+            raise RuntimeError("x_ref not of the right size")
+        self._set(t, 1, x)
+
+    def getReferenceState(self, t):
+        return self._get(t, 1, self._nx_ref)
+
+    def getContactState(self, t):
+        m = self._handle()
+        out = np.zeros(self.model_handler.getFeetNb(), np.uint8)
+        m._lib.check(m._lib.L.smpc_get_contact_state(m._h, int(t), out))
+        return [bool(v) for v in out]
+
+    def getContactSupport(self, t):
+        return int(sum(self.getContactState(t)))
+
 _KINO_KEYS = [
     "timestep", "w_x", "w_u", "w_frame", "w_cent", "w_centder", "qmin", "qmax", "gravity", "mu", "Lfoot", "Wfoot",
     "force_size", "kinematics_limits", "force_cone", "land_cstr",
 ]
 
 
-class KinodynamicsOCP:
+class KinodynamicsOCP(_StageReferences):
     """reference: src/kinodynamics.cpp:29-38 (ctor), bindings/expose-kinodynamics.cpp:9-34 (dict keys)."""
 
     def __init__(self, settings, model_handler):
@@ -146,6 +248,36 @@ class KinodynamicsOCP:
 
     def _default_x_reference(self):
         return self.model_handler.getReferenceState()
+
+    @property
+    def _nx_ref(self):
+        return self.model_handler.nq + self.model_handler.nv
+
+    def getCostNumber(self):
+        return 4 + self.model_handler.getFeetNb()  # state, control, centroidal, centroidal derivative, one pose cost per foot
+
+    # reference src/kinodynamics.cpp:267-306
+    def setVelocityBase(self, t, velocity_base):
+        v = np.asarray(velocity_base, float)
+        if v.size != 6:
+            raise RuntimeError("velocity_base size should be 6")
+        x = self.getReferenceState(t)
+        x[self.model_handler.nq : self.model_handler.nq + 6] = v
+        self.setReferenceState(t, x)
+
+    def getVelocityBase(self, t):
+        return self.getReferenceState(t)[self.model_handler.nq : self.model_handler.nq + 6]
+
+    def setPoseBase(self, t, pose_base):
+        p = np.asarray(pose_base, float)
+        if p.size != 7:
+            raise RuntimeError("pose_base size should be 7")
+        x = self.getReferenceState(t)
+        x[:7] = p
+        self.setReferenceState(t, x)
+
+    def getPoseBase(self, t):
+        return self.getReferenceState(t)[:7]
 
     def _xdot_size(self):
         return 2 * self.model_handler.nv
@@ -186,7 +318,7 @@ _CENT_KEYS = [
 ]
 
 
-class CentroidalOCP:
+class CentroidalOCP(_StageReferences):
     """reference: src/centroidal-dynamics.cpp:27-37 (ctor), bindings/expose-centroidal.cpp (dict keys =
     CentroidalSettings fields, include/simple-mpc/centroidal-dynamics.hpp:27-43).  State [com; h_lin; h_ang], control = the
     stacked 3-D contact forces."""
@@ -220,6 +352,34 @@ class CentroidalOCP:
         if self._problem is None:
             raise RuntimeError("Create problem first!")
         return self._problem["horizon"]
+
+    _nx_ref = 9
+
+    def getCostNumber(self):
+        return 6  # com, control, linear / angular momentum, linear / angular acceleration (tests/problem.cpp:232)
+
+    # reference src/centroidal-dynamics.cpp:212-257: velocities are stored as momenta m v, the CoM reference is 3-D
+    def setVelocityBase(self, t, velocity_base):
+        v = np.asarray(velocity_base, float)
+        if v.size != 6:
+            raise RuntimeError("velocity_base not of the right size")
+        x = self.getReferenceState(t)
+        x[3:] = v
+        self.setReferenceState(t, x)
+
+    def getVelocityBase(self, t):
+        return self.getReferenceState(t)[3:]
+
+    def setPoseBase(self, t, pose_base):
+        p = np.asarray(pose_base, float)
+        if p.size != 3:
+            raise RuntimeError("pose_base not of the right size")
+        x = self.getReferenceState(t)
+        x[:3] = p
+        self.setReferenceState(t, x)
+
+    def getPoseBase(self, t):
+        return self.getReferenceState(t)[:3]
 
     def _default_x_reference(self):
         return np.zeros(9)  # getReferenceState(0) of the default problem (src/centroidal-dynamics.cpp:293-298, com_ref_ = 0)
@@ -286,6 +446,11 @@ class BatchedMPC:
         L.smpc_get_dims(self._h, d)
         self.nq, self.nv, self.nx, self.ndx, self.nu, self.nc, self.nf, self.H = (int(v) for v in d)
         self.B = int(batch)
+        ocp._mpc = self
+        # OCPHandler::control_ref_ as the constructors leave it (createProblem's default forces, src/ocp-handler.cpp:107-109)
+        fs = int(ocp.settings["force_size"])
+        ocp._control_ref = np.zeros(ocp.nu)
+        ocp._control_ref[2 : fs * mh.getFeetNb() : fs] = -mh.getMass() * ocp._problem["gravity"] / mh.getFeetNb()
         self.nx_in = self.nq + self.nv  # iterate takes measured multibody states (reference src/mpc.cpp:189-192)
         self._x_reference = ocp._default_x_reference()
         self._velocity_base = np.zeros(6)
@@ -305,6 +470,20 @@ class BatchedMPC:
         else:
             cs = np.ascontiguousarray(contact_states, np.uint8)
         self._lib.check(self._lib.L.smpc_generate_cycle_horizon(self._h, cs, cs.shape[0]))
+        # control_ref_ ends as the force distribution of the last cycle stage created (src/mpc.cpp:144-163)
+        ocp, last = self.ocp_handler, cs[-1]
+        fs = int(ocp.settings["force_size"])
+        ocp._control_ref[:] = 0.0
+        for f in range(len(last)):
+            if last[f]:
+                ocp._control_ref[f * fs + 2] = self.settings["support_force"] / max(1, int(last.sum()))
+
+    # MPC::setReferencePose / getReferencePose (reference src/mpc.cpp:326-339)
+    def setReferencePose(self, t, ee_name, pose_ref):
+        self.ocp_handler.setReferencePose(t, ee_name, pose_ref)
+
+    def getReferencePose(self, t, ee_name):
+        return self.ocp_handler.getReferencePose(t, ee_name)
 
     def switchToWalk(self, velocity_base):
         v = np.ascontiguousarray(velocity_base, float)

@@ -133,6 +133,25 @@ int main()
     mpc.loadState(ck);
     mpc.iterate(X);
     CHECK(xs_a == mpc.xs_);
+    // setter / getter round trips of tests/problem.cpp:157-195 through the mirror
+    const double pl[3] = {1, 0, 2};
+    mpc.setReferencePose(4, robot->foot_name[0], pl);
+    CHECK(mpc.getReferencePose(4, robot->foot_name[0])[2] == 2.0);
+    std::vector<double> ur = mpc.getReferenceControl(3);
+    ur[1] = 1.0;
+    mpc.setReferenceControl(3, ur);
+    CHECK(mpc.getReferenceControl(3)[1] == 1.0);
+    CHECK(mpc.getContactState(2).size() == 4 && mpc.getContactState(2)[0]);
+    bool threw3 = false;
+    try
+    {
+      mpc.getReferenceState(100);
+    }
+    catch (const std::runtime_error &)
+    {
+      threw3 = true;
+    }
+    CHECK(threw3);
     std::vector<double> V(12, 0.0);
     V[0] = 0.3;
     V[6 + 5] = 0.4;

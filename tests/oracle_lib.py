@@ -83,6 +83,8 @@ def lib():
     L.orc_mpc_switch_to_walk.argtypes = [vp, _dp]
     L.orc_mpc_switch_to_stand.argtypes = [vp]
     L.orc_mpc_set_velocity_batched.argtypes = [vp, _dp]
+    L.orc_mpc_set_stage_reference.argtypes = [vp, C.c_int, C.c_int, _dp]
+    L.orc_cmpc_set_stage_reference.argtypes = [vp, C.c_int, C.c_int, _dp]
     L.orc_cmpc_set_velocity_batched.argtypes = [vp, _dp]
     L.orc_mpc_set_x_reference.argtypes = [vp, _dp]
     L.orc_mpc_iterate.restype = C.c_double
@@ -313,6 +315,10 @@ class OracleMPC:
 
     def switchToStand(self):
         self._f("switch_to_stand")(self.h)
+
+    def set_stage_reference(self, t, what, v):
+        """OCPHandler setReferenceControl (what = 0) / setReferenceState (what = 1) on stage t, all instances."""
+        self._f("set_stage_reference")(self.h, int(t), int(what), np.ascontiguousarray(v, float))
 
     def setVelocityBaseBatched(self, V):
         V = np.ascontiguousarray(V, float)
