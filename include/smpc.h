@@ -109,7 +109,7 @@ int smpc_create(
  * K0 [B][3 nfeet][9], vs [B][H][2 nfeet] (friction-cone rows), smpc_get_state_derivative01 [B][2][9],
  * smpc_get_reference_poses the contact positions [B][H][nfeet][3], smpc_set_x_reference takes 9 doubles.
  * smpc_get_dims reports nq, nv of the robot and nx = ndx = 9.  Entry points that are specific to the kinodynamics
- * problem (interpolate, riccati_feedback, debug_get_lq, get_x_device) fail with SMPC_ERR_INVALID on such a handle. */
+ * problem (debug_get_lq, debug_get_terminal, get_x_device) fail with SMPC_ERR_INVALID on such a handle. */
 int smpc_create_centroidal(
   const smpc_robot_model * robot, const smpc_centroidal_settings * ocp, const smpc_mpc_settings * mpc, int batch,
   double gravity_arg, int device_id, smpc_handle ** out);
@@ -217,6 +217,8 @@ int smpc_reset_kernel_times(smpc_handle * h);
  *     force_out [B][3 nf]  interpolateLinear over us[t][: 3 nf], t = 0, 1
  *   delay >= 0 (seconds after the last smpc_iterate); beyond the last interval the last knot is returned, like the
  *   reference.  Any output pointer may be NULL.  Host buffers.
+ *   Centroidal handle (examples/talos_centroidal.py: interpolateLinear over states, state derivatives and forces):
+ *     x_out [B][9], acc_out [B][9] = interpolated getStateDerivative, force_out [B][3 nf].
  * smpc_interpolate_knots: the Interpolator methods on explicit host knot lists [n][dim]:
  *     kind 0 interpolateState (dim = nq + nv), 1 interpolateConfiguration (dim = nq), 2 interpolateLinear (any dim).
  *   Errors mirror the reference's assertions ("State is not of the right size"). */
@@ -229,7 +231,8 @@ int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, d
 int smpc_update_internal_data(smpc_handle * h, const double * X, double * feet, double * com, double * hg, double * centroidal_state);
 /* Riccati feedback application between MPC knots (reference examples/go2_fulldynamics.py:271-285):
  *   u_out[b] = interpolateLinear(us)[b] - Ks[0][b] * difference(X_meas[b], interpolateState(xs)[b])
- * X_meas [B][nx], u_out [B][nu] (host). */
+ * X_meas [B][nx], u_out [B][nu] (host).  Centroidal handle: X_meas are still the measured multibody states [B][nq + nv];
+ * the feedback acts on their centroidal state, u_out[b] = f(d) - K0 (x(d) - getCentroidalState(X_meas[b])). */
 int smpc_riccati_feedback(smpc_handle * h, double delay, const double * X_meas, double * u_out);
 int smpc_interpolate_knots(int kind, double delay, double timestep, const double * knots, int n, int dim, double * out, int device_id);
 

@@ -555,7 +555,7 @@ extern "C"
     if (!h || !X)
       return fail(SMPC_ERR_INVALID, "null argument");
     if (h->cent)
-      return fail(SMPC_ERR_INVALID, KINO_ONLY);
+      return guarded([&] { h->cent->update_internal_data(X, feet, com, hg, centroidal_state); });
     return guarded([&] { h->eng->update_internal_data(X, feet, com, hg, centroidal_state); });
   }
   int smpc_riccati_feedback(smpc_handle * h, double delay, const double * X_meas, double * u_out)
@@ -563,15 +563,15 @@ extern "C"
     if (!h || !X_meas || !u_out)
       return fail(SMPC_ERR_INVALID, "null argument");
     if (h->cent)
-      return fail(SMPC_ERR_INVALID, KINO_ONLY);
+      return guarded([&] { h->cent->interpolate(delay, 2, X_meas, nullptr, nullptr, nullptr, u_out); });
     return guarded([&] { h->eng->riccati_feedback(delay, X_meas, u_out); });
   }
   int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, double * acc_out, double * force_out)
   {
     if (!h)
       return fail(SMPC_ERR_INVALID, "null argument");
-    if (h->cent)
-      return fail(SMPC_ERR_INVALID, KINO_ONLY);
+    if (h->cent) // centroidal handle: x_out [B][9], acc_out = state derivative [B][9], force_out [B][3 nfeet]
+      return guarded([&] { h->cent->interpolate(delay, knots, nullptr, x_out, acc_out, force_out, nullptr); });
     return guarded([&] { h->eng->interpolate(delay, knots, x_out, acc_out, force_out); });
   }
   int smpc_interpolate_knots(int kind, double delay, double timestep, const double * knots, int n, int dim, double * out, int device_id)

@@ -470,6 +470,68 @@ namespace smpc
       return horizon[t].mask;
     }
 
+    // state feedback front-end on measured states X [B][nq + nv] (host): host outputs, any may be null
+    void update_internal_data(const double * X, double * feet, double * com, double * hg, double * cstate)
+    {
+      const size_t nf = (size_t)B * DC::NF * 3, nc = (size_t)B * 3, nh = (size_t)B * 6, ns = (size_t)B * 9;
+      double * st = staging((nf + nc + nh + ns) * sizeof(double));
+      h2d(X_dev, X, (size_t)B * DK::NX * sizeof(double), stream);
+      FrontendArgs<DK> fa;
+      fa.b = fk;
+      fa.X = X_dev;
+      fa.feet = st;
+      fa.com = st + nf;
+      fa.hg = st + nf + nc;
+      fa.cstate = st + nf + nc + nh;
+      launch<FrontendArgs<DK>, frontend_body<DK>, 64, 1, 1>(B, stream, fa);
+      if (feet)
+        d2h(feet, st, nf * sizeof(double), stream);
+      if (com)
+        d2h(com, st + nf, nc * sizeof(double), stream);
+      if (hg)
+        d2h(hg, st + nf + nc, nh * sizeof(double), stream);
+      if (cstate)
+        d2h(cstate, st + nf + nc + nh, ns * sizeof(double), stream);
+      stream_sync(stream);
+    }
+    // interpolated targets at `delay` after the last solve (host outputs, any may be null): x [B][9], xdot [B][9],
+    // forces [B][NU]; with X_meas (measured multibody states [B][nq + nv]) also the Riccati feedback u [B][NU]
+    void interpolate(double delay, int knots, const double * X_meas, double * x_out, double * xdot_out, double * f_out, double * u_out)
+    {
+      if (knots < 2 || knots > H + 1)
+        throw std::runtime_error("interpolate: knots must be in [2, horizon + 1]");
+      if (!(delay >= 0.0))
+        throw std::runtime_error("interpolate: delay must be non-negative");
+      const size_t n9 = (size_t)B * 9, nu = (size_t)B * DC::NU;
+      double * st = staging((2 * n9 + 2 * nu) * sizeof(double));
+      if (X_meas)
+      {
+        h2d(X_dev, X_meas, (size_t)B * DK::NX * sizeof(double), stream);
+        launch_frontend(X_dev, true);
+      }
+      CentInterpArgs<DC> ia;
+      ia.b = buf;
+      ia.head = head;
+      ia.knots = knots;
+      ia.delay = delay;
+      ia.timestep = ms.timestep;
+      ia.x_meas = X_meas ? cstate_dev : nullptr;
+      ia.x_out = st;
+      ia.xdot_out = st + n9;
+      ia.f_out = st + 2 * n9;
+      ia.u_out = X_meas ? st + 2 * n9 + nu : nullptr;
+      launch<CentInterpArgs<DC>, cent_interp_body<DC>, 64>(B, stream, ia);
+      if (x_out)
+        d2h(x_out, st, n9 * sizeof(double), stream);
+      if (xdot_out)
+        d2h(xdot_out, st + n9, n9 * sizeof(double), stream);
+      if (f_out)
+        d2h(f_out, st + 2 * n9, nu * sizeof(double), stream);
+      if (u_out && X_meas)
+        d2h(u_out, st + 2 * n9 + nu, nu * sizeof(double), stream);
+      stream_sync(stream);
+    }
+
     size_t state_io(StateIO & io)
     {
       stream_sync(stream);

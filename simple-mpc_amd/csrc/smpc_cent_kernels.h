@@ -1286,6 +1286,69 @@ namespace smpc
     SMPC_LANES_END_WAVE
   }
 
+  // Targets between MPC knots (reference src/interpolator.cpp:44-78 as used in examples/talos_centroidal.py: interpolateLinear
+  // over the centroidal states, their derivatives and the contact forces) and the Riccati feedback on the centroidal state:
+  //   x(d) = interpolateLinear(xs[0 .. knots-1]),  xdot(d) = interpolateLinear(getStateDerivative(0), (1)),
+  //   f(d) = interpolateLinear(us[0], us[1]),      u = f(d) - K_0 (x(d) - x_meas)        (the state space is a vector space)
+  template <class D>
+  struct CentInterpArgs
+  {
+    CentBuffers<D> b;
+    int head, knots;
+    double delay, timestep;
+    const double * x_meas;                // [B][9] centroidal state of the measured multibody state, or null
+    double *x_out, *xdot_out, *f_out;     // [B][9], [B][9], [B][NU] (device), any may be null
+    double * u_out;                       // [B][NU] Riccati feedback (needs x_meas), may be null
+  };
+  template <class D>
+  SMPC_DEV void cent_interp_body(const CentInterpArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64, NU = D::NU;
+    const CentBuffers<D> & b = ka.b;
+    const size_t inst = (size_t)block;
+    const int R = b.R, H = b.H;
+    const size_t step = (size_t)(ka.delay / ka.timestep);
+    const double sx = (ka.delay - (double)step * ka.timestep) / ka.timestep;
+    const bool lastx = step >= (size_t)ka.knots - 1; // beyond the last interval: the last knot (reference :50-53)
+    const bool last2 = step >= 1;                    // two knots for xdot and the forces
+    SMPC_LDS(double, e, 9);
+    SMPC_LANES(NT)
+    {
+      if (lane < 9)
+      {
+        const int t0 = lastx ? ka.knots - 1 : (int)step, t1 = lastx ? ka.knots - 1 : (int)step + 1;
+        const double x0 = b.xs[(inst * R + ring_slot(ka.head, t0, R)) * 9 + lane], x1 = b.xs[(inst * R + ring_slot(ka.head, t1, R)) * 9 + lane];
+        const double xi = lastx ? x0 : x1 * sx + x0 * (1.0 - sx);
+        if (ka.x_out)
+          ka.x_out[inst * 9 + lane] = xi;
+        if (ka.xdot_out)
+        {
+          const double d0 = b.xdot01[(inst * 2) * 9 + lane], d1 = b.xdot01[(inst * 2 + 1) * 9 + lane];
+          ka.xdot_out[inst * 9 + lane] = last2 ? d1 : d1 * sx + d0 * (1.0 - sx);
+        }
+        e[lane] = ka.x_meas ? xi - ka.x_meas[inst * 9 + lane] : 0.0;
+      }
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane < NU)
+    {
+      const double u0 = b.us[(inst * R + ring_slot(ka.head, 0, R)) * NU + lane], u1 = b.us[(inst * R + ring_slot(ka.head, 1, R)) * NU + lane];
+      const double ui = last2 ? u1 : u1 * sx + u0 * (1.0 - sx);
+      if (ka.f_out)
+        ka.f_out[inst * NU + lane] = ui;
+      if (ka.u_out)
+      {
+        const double * K = b.gains + (inst * H) * D::G_STRIDE + D::G_K + lane * 10;
+        double a = ui;
+        for (int j = 0; j < 9; j++)
+          a -= K[j] * e[j];
+        ka.u_out[inst * NU + lane] = a;
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
   // K_t of every stage -> dense [B][H][NU][9] (MPC::Ks_) or K_0 only
   template <class D>
   struct CentGainsOutArgs

@@ -602,8 +602,8 @@ class BatchedMPC:
         """State feedback front-end, batched on the device (reference src/robot-handler.cpp:106-149): for measured
         states X[B, nx] returns dict(feet[B, nf, 3], com[B, 3], hg[B, 6], centroidal_state[B, 9])."""
         X = np.ascontiguousarray(np.array(X, dtype=np.float64))
-        if X.shape != (self.B, self.nx):
-            raise RuntimeError("X must have shape (batch, nx)")
+        if X.shape != (self.B, self.nx_in):
+            raise RuntimeError("X must have shape (batch, nq + nv)")
         feet, com = np.zeros((self.B, self.nf, 3)), np.zeros((self.B, 3))
         hg, cs = np.zeros((self.B, 6)), np.zeros((self.B, 9))
         p = lambda a: a.ctypes.data_as(C.c_void_p)
@@ -614,8 +614,8 @@ class BatchedMPC:
         """u = interpolateLinear(us) - Ks[0] @ difference(x_meas, interpolateState(xs)) for every instance (reference
         examples/go2_fulldynamics.py:271-285)."""
         X = np.ascontiguousarray(np.array(X_meas, dtype=np.float64))
-        if X.shape != (self.B, self.nx):
-            raise RuntimeError("X_meas must have shape (batch, nx)")
+        if X.shape != (self.B, self.nx_in):
+            raise RuntimeError("X_meas must have shape (batch, nq + nv)")
         u = np.zeros((self.B, self.nu))
         self._lib.check(self._lib.L.smpc_riccati_feedback(self._h, float(delay), X, u))
         return u
@@ -625,7 +625,7 @@ class BatchedMPC:
         examples/go2_kinodynamics.py:276-284 with src/interpolator.cpp:5-78): returns (x[B, nx], acc[B, nv],
         forces[B, nf, 3]) at `delay` seconds after the last iterate."""
         x = np.zeros((self.B, self.nx))
-        a = np.zeros((self.B, self.nv))
+        a = np.zeros((self.B, self.nv if self.nx != 9 else 9))  # centroidal handle: the interpolated state derivative
         f = np.zeros((self.B, self.nf * 3))
         self._lib.check(self._lib.L.smpc_interpolate(
             self._h, float(delay), int(knots), x.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p)))

@@ -145,6 +145,40 @@ def test_emu_per_instance_velocity_commands(lib):
     _velocity_case(lib, 1e-9)
 
 
+def _interp_case(lib, tol):
+    """Targets between knots and the Riccati feedback on the centroidal state (examples/talos_centroidal.py pattern) against
+    numpy on the oracle's solution: interpolateLinear semantics of src/interpolator.cpp:44-78."""
+    B = 3
+    om, gm, rb = S.make_cent_pair(B, 2, lib=lib)
+    X = S.random_states(rb, B)
+    for _ in range(2):
+        om.iterate(X)
+        gm.iterate(X)
+    xs, us, xd, K0 = om.xs, om.us, om.xdot, om.K0
+    dt = 0.01
+    for delay in (0.0, 0.0037, 0.01, 0.0123, 0.5):
+        step = int(delay / dt)
+        s_ = (delay - step * dt) / dt
+        x, a, f = gm.interpolate(delay, knots=3)
+        xe = xs[:, 2] if step >= 2 else xs[:, step + 1] * s_ + xs[:, step] * (1 - s_)
+        ae = xd[:, 1] if step >= 1 else xd[:, 1] * s_ + xd[:, 0] * (1 - s_)
+        fe = us[:, 1] if step >= 1 else us[:, 1] * s_ + us[:, 0] * (1 - s_)
+        assert S.rel_err(xe, x) < tol and S.rel_err(ae, a) < 10 * tol and S.rel_err(fe, f.reshape(B, 12)) < 10 * tol
+    Xm = S.random_states(rb, B, seed=5, scale=0.3)
+    cst = np.stack([np.r_[rb.centroidal(x)["com"], rb.centroidal(x)["hg"]] for x in Xm])
+    u = gm.riccatiFeedback(0.004, Xm)
+    xi = xs[:, 1] * 0.4 + xs[:, 0] * 0.6
+    ui = us[:, 1] * 0.4 + us[:, 0] * 0.6
+    ue = ui - np.einsum("bij,bj->bi", K0, xi - cst)
+    assert S.rel_err(ue, u) < 100 * tol
+    with pytest.raises(RuntimeError, match="knots"):
+        gm.interpolate(0.0, knots=1)
+
+
+def test_emu_interpolation_and_riccati_feedback(lib):
+    _interp_case(lib, 1e-10)
+
+
 def test_centroidal_handle_surface(lib):
     gm, rb, s, _ = S.make_cent_product(1, lib=lib)
     import simple_mpc
@@ -160,7 +194,9 @@ def test_centroidal_handle_surface(lib):
     with pytest.raises(RuntimeError, match="generateCycleHorizon"):
         gm.iterate(rb.x_ref[None, :])
     with pytest.raises(RuntimeError, match="kinodynamics handle"):
-        gm.interpolate(0.001)
+        gm.debug_lq(0, 0)
+    fe = gm.updateInternalData(rb.x_ref[None, :])  # the front-end of the handle (getCentroidalState of the measured state)
+    assert np.allclose(fe["centroidal_state"][0, :3], rb.centroidal(rb.x_ref)["com"], atol=1e-12) and np.allclose(fe["hg"], 0)
     with pytest.raises(RuntimeError, match="shape"):
         gm.iterate(np.zeros((1, 9)))
     # reference tests/problem.cpp:236-247: sizes and weights echo
@@ -181,6 +217,11 @@ def test_gpu_cold_solve_and_closed_loop(built):
 @pytest.mark.gpu
 def test_gpu_per_instance_velocity_commands(built):
     _velocity_case(None, TOL)
+
+
+@pytest.mark.gpu
+def test_gpu_interpolation_and_riccati_feedback(built):
+    _interp_case(None, 1e-8)
 
 
 @pytest.mark.gpu
