@@ -33,8 +33,6 @@ namespace smpc
     // reused -- in this order of time -- by the wave reductions of the cost / multiplier phases and by the
     // weighted-Jacobian tables of the assembly phases (accessors below)
     double oR[D::NJ * 9], S[D::NV * 6], vel[D::NJ * 6], acc[D::NJ * 6], Ic[D::NJ * 10], hc[D::NJ * 6], Fc[D::NJ * 6];
-    // placements and body inertias (needed until the velocity-product matrices are formed)
-    double op[D::NJ * 3], I[D::NJ * 10];
     SMPC_HD double * part() { return oR; }        // [64]
     SMPC_HD double * part2() { return oR + 64; }  // [64]
     SMPC_HD double * part8() { return oR + 128; } // [16]
@@ -59,6 +57,7 @@ namespace smpc
   template <class D>
   struct KinoScratchDerivPart
   {
+    static_assert(3 * D::NV >= D::NJ * 3 && D::NF * 3 * D::NV >= D::NJ * 10, "op_() / I_() overlays");
     double dh_dq[6 * D::NV], dhd_dq[6 * D::NV], dhd_dv[6 * D::NV]; // dhd_*: overwritten in place by ab_dq / ab_dv
     double Jfoot[D::NF * 3 * D::NV];
     double dtgt[3 * D::NV];
@@ -72,10 +71,27 @@ namespace smpc
   struct KinoScratchNoDeriv
   {
     double xn1[D::NX]; // trial point of the next state (line search only)
+    double op[D::NJ * 3], I[D::NJ * 10]; // joint positions, body inertias (the derivative kernel overlays them, see op_() / I_())
   };
   template <class D, bool DERIV>
   struct KinoScratch : KinoScratchEval<D>, std::conditional<DERIV, KinoScratchDerivPart<D>, KinoScratchNoDeriv<D>>::type
   {
+    // joint positions (read until the base integration) and world-frame body inertias (read until the velocity-product
+    // matrices are formed): in the derivative kernel they live in dtgt / Jfoot, which the derivative columns write later
+    SMPC_HD double * op_()
+    {
+      if constexpr (DERIV)
+        return this->dtgt;
+      else
+        return this->op;
+    }
+    SMPC_HD double * I_()
+    {
+      if constexpr (DERIV)
+        return this->Jfoot;
+      else
+        return this->I;
+    }
     // tables living in tree block A (written by the table phase, after the last reader of the tree data)
     SMPC_HD double * WJc() { return this->oR; }       // [6][NDX]     w_cent * [dh_dq | Ag]
     SMPC_HD double * WD() { return this->oR + 216; }  // [6][NV]      w_centder[:,3:6] * dtgt
@@ -143,7 +159,7 @@ namespace smpc
     {
       const double * xt = sc.in_x_tgt; // (LDS copy made by the block's load phase)
       const SE3 Mt{quat_to_R(Quat{xt[3], xt[4], xt[5], xt[6]}), ld3(xt)};
-      const SE3 M = se3_mul(se3_inv(Mt), SE3{ldm3(&sc.oR[0]), ld3(&sc.op[0])});
+      const SE3 M = se3_mul(se3_inv(Mt), SE3{ldm3(&sc.oR[0]), ld3(&sc.op_()[0])});
       w = log3(M.R);
       vec = M.p;
     }
@@ -165,7 +181,7 @@ namespace smpc
     if (ex)
     {
       const M3 R0 = ldm3(&sc.oR[0]);
-      st3(&sc.xnext[0], ld3(&sc.op[0]) + R0 * out);
+      st3(&sc.xnext[0], ld3(&sc.op_()[0]) + R0 * out);
       const double qs = 0.5 * kf.sinch;
       Quat qn = quat_mul(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]}, Quat{qs * w.x, qs * w.y, qs * w.z, kf.ch});
       const double n = 1.0 / sqrt(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
@@ -275,7 +291,7 @@ namespace smpc
           v = v + vq[k] * sk;
         }
         stm3(&sc.oR[0], R);
-        st3(&sc.op[0], p);
+        st3(&sc.op_()[0], p);
         stsv(&sc.vel[0], v);
         stsv(&sc.acc[0], sv0());
       }
@@ -299,14 +315,14 @@ namespace smpc
         const int par = md.parent[j];
         const M3 Rp = ldm3(&sc.oR[par * 9]);
         const M3 R = Rp * ldm3(SMPC_PLV(rl));
-        const V3 p = ld3(&sc.op[par * 3]) + Rp * ld3(&SMPC_PLV(jg)[9]);
+        const V3 p = ld3(&sc.op_()[par * 3]) + Rp * ld3(&SMPC_PLV(jg)[9]);
         const int col = md.jtype[j] - 1;
         const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
         const SV sk = SV{cross(p, ax), ax};
         const SV vp = ldsv(&sc.vel[par * 6]);
         const double qd = vq[j + 5];
         stm3(&sc.oR[j * 9], R);
-        st3(&sc.op[j * 3], p);
+        st3(&sc.op_()[j * 3], p);
         stsv(&sc.S[(j + 5) * 6], sk);
         stsv(&sc.vel[j * 6], vp + qd * sk);
         stsv(&sc.acc[j * 6], ldsv(&sc.acc[par * 6]) + qd * crm(vp, sk));
@@ -318,7 +334,7 @@ namespace smpc
     {
       const int j = lane;
       const M3 R = ldm3(&sc.oR[j * 9]);
-      const V3 p = ld3(&sc.op[j * 3]);
+      const V3 p = ld3(&sc.op_()[j * 3]);
       const SV v = ldsv(&sc.vel[j * 6]), a = ldsv(&sc.acc[j * 6]);
       // world inertia about the origin
       const double m = SMPC_PLV(jg)[12];
@@ -336,7 +352,7 @@ namespace smpc
       I.jyy = Iw.a11 + m * (cc - c.y * c.y);
       I.jyz = Iw.a12 - m * c.y * c.z;
       I.jzz = Iw.a22 + m * (cc - c.z * c.z);
-      stsi(&sc.I[j * 10], I);
+      stsi(&sc.I_()[j * 10], I);
       stsi(&sc.Ic[j * 10], I);
       const SV h = I * v;
       stsv(&sc.hc[j * 6], h);
@@ -345,7 +361,7 @@ namespace smpc
     else if (lane >= 32 && lane < 32 + NF)
     {
       const int f = lane - 32, j = md.foot_joint[f];
-      st3(&sc.footp[f * 3], ldm3(&sc.oR[j * 9]) * ld3(mg.foot_p[f]) + ld3(&sc.op[j * 3]));
+      st3(&sc.footp[f * 3], ldm3(&sc.oR[j * 9]) * ld3(mg.foot_p[f]) + ld3(&sc.op_()[j * 3]));
     }
     SMPC_LANES_END_WAVE
     if (in.prof) prof_tick(in.prof, 16, *in.tprev);
@@ -363,7 +379,7 @@ namespace smpc
       for (int idx = lane; idx < NJ * 6; idx += NT)
       {
         const int l = idx / 6, m = idx % 6;
-        const SI Il = ldsi(&sc.I[l * 10]);
+        const SI Il = ldsi(&sc.I_()[l * 10]);
         const SV vl = ldsv(&sc.vel[l * 6]);
         const V3 e = mk3(m % 3 == 0, m % 3 == 1, m % 3 == 2), z = mk3(0, 0, 0);
         const SV y = m < 3 ? SV{e, z} : SV{z, e};
@@ -479,7 +495,7 @@ namespace smpc
     {
       const int r = lane / 6, c = lane % 6;
       const M3 R = ldm3(&sc.oR[0]);
-      const V3 p = ld3(&sc.op[0]);
+      const V3 p = ld3(&sc.op_()[0]);
       const V3 ml = mk3(sc.gjB_()[0 * 6 + c], sc.gjB_()[1 * 6 + c], sc.gjB_()[2 * 6 + c]);
       const V3 ma = mk3(sc.gjB_()[3 * 6 + c], sc.gjB_()[4 * 6 + c], sc.gjB_()[5 * 6 + c]);
       V3 out;
