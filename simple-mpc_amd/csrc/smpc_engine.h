@@ -284,6 +284,13 @@ namespace smpc
       if ((int)ks.w_x.size() != D::NDX * D::NDX || (int)ks.w_u.size() != D::NU * D::NU || (int)ks.w_frame.size() != 9 || (int)ks.w_cent.size() != 36
           || (int)ks.w_centder.size() != 36 || (int)ks.qmin.size() != D::NA || (int)ks.qmax.size() != D::NA)
         throw std::runtime_error("kinodynamics settings: weight / limit sizes do not match the robot");
+      {
+        // LDS layout the rigid-body kernel relies on: the velocity-product matrices run across the end of the evaluation part
+        // into the start of the derivative part (KinoScratch: late block | WJl | JWJ)
+        static KinoScratch<D, true> probe;
+        if ((const char *)probe.WJl - (const char *)probe.cval != (std::ptrdiff_t)(KinoScratchEval<D>::LATE_DOUBLES * sizeof(double)))
+          throw std::runtime_error("internal: KinoScratch layout is not contiguous across its two parts");
+      }
       set_device(device);
       stream = stream_create();
       B = batch;

@@ -117,6 +117,10 @@ namespace smpc
     in.prof = (b.dbg != nullptr && inst == 0 && t == 17 && ka.slots == 0) ? b.dbg : nullptr; // optional phase timers: one mid-horizon block
     in.tprev = &tprev;
 
+    // block inputs that are consumed once, by the lane that loaded them, stay in registers: lambda_t (q of the knot) and
+    // x_{t+1} (committed to LDS only for the defect phase, into the then idle late block)
+    SMPC_PL(double, lam_prev_r, NT);
+    SMPC_PL(double, xn_r, NT);
     SMPC_LANES(NT)
     {
       // all global loads of the block are issued back to back (index clamped, one wait), then committed to LDS
@@ -136,8 +140,9 @@ namespace smpc
       {
         sc.x[lane] = vx;
         sc.in_x_tgt[lane] = vxt;
-        sc.in_xn[lane] = vxn;
       }
+      SMPC_PLV(xn_r) = vxn;
+      SMPC_PLV(lam_prev_r) = (lane < NDX && t > 0) ? vlp : 0.0;
       if (lane < NU)
         sc.in_u_ref[lane] = vur;
       if (lane < NF * 3)
@@ -147,7 +152,6 @@ namespace smpc
       if (lane < NDX)
       {
         sc.lam_next[lane] = term ? 0.0 : vl;
-        sc.lam_prev[lane] = t > 0 ? vlp : 0.0;
       }
       if (lane < NC)
         sc.nu[lane] = term ? 0.0 : vn;
@@ -159,8 +163,13 @@ namespace smpc
 
     if (!term)
     {
+      static_assert(KinoScratchEval<D>::LATE_DOUBLES >= NX, "x_{t+1} is staged at the start of the late block");
       SMPC_LANES(NT)
-      lanes_difference<D>(sc.in_xn, sc.xnext, sc.e, lane, 61);
+      if (lane < NX)
+        sc.cval[lane] = SMPC_PLV(xn_r); // (cval | Wrx ...: idle until the cost phase)
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      lanes_difference<D>(sc.cval, sc.xnext, sc.e, lane, 61);
       SMPC_LANES_END_WAVE
     }
     if (in.prof) prof_tick(in.prof, 29, tprev);
@@ -208,7 +217,7 @@ namespace smpc
           g = sc.Wrx[k];
         for (int a = 0; a < 6; a++)
           g += (k < NV ? sc.dh_dq[a * NV + k] : sc.Ag[a * NV + k - NV]) * sc.Whg[a];
-        const double qn = g - sc.lam_prev[k];
+        const double qn = g - SMPC_PLV(lam_prev_r);
         qN[k] = qn;
         dual = fabs(qn);
         sc.rx[k] = dual; // reuse as dual-infeasibility scratch
@@ -353,7 +362,7 @@ namespace smpc
         double cn = sc.cn[k];
         if (md.kinematics_limits && k >= 6 && k < NV)
           cn += sc.nu[k - 6];
-        double q = g + acc + cn - sc.lam_prev[k];
+        double q = g + acc + cn - SMPC_PLV(lam_prev_r);
         if (t == 0)
           q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
         lq[D::O_q + k] = q;
@@ -399,18 +408,6 @@ namespace smpc
           for (int bb = 0; bb < 6; bb++)
             s += mg.w_x[a * NDX + bb] * sc.Jl[bb * 6 + k];
         sc.WJl[idx] = s;
-      }
-      for (int idx = lane; idx < 6 * NDX; idx += NT)
-      {
-        const int a = idx / NDX, k = idx % NDX;
-        // JtW[i][k] = sum_a Jl[a][i] w_x[a][k]  (rows of J_x^T w_x for the base block)
-        double t = 0.0;
-        if (wdiag)
-          t = k < 6 ? sc.Jl[k * 6 + a] * md.wxd[k] : 0.0;
-        else
-          for (int bb = 0; bb < 6; bb++)
-            t += sc.Jl[bb * 6 + a] * mg.w_x[bb * NDX + k];
-        sc.JtW[idx] = t;
       }
       if (lane < 36)
       {
@@ -494,7 +491,7 @@ namespace smpc
             const bool inu = row >= NDX && row < NDX + NU && col >= NDX && col < NDX + NU;
             double val = (inx || inu) ? wv[tt * 4 + v] : 0.0;
             if (row < NDX && col < NDX && (row < 6 || col < 6))
-              val = row < 6 ? (col < 6 ? sc.JWJ[row * 6 + col] : sc.JtW[row * NDX + col]) : sc.WJl[row * 6 + col];
+              val = row < 6 ? (col < 6 ? sc.JWJ[row * 6 + col] : sc.WJl[col * 6 + row]) : sc.WJl[row * 6 + col];
             SMPC_ACCV(qacc, tt, v) = val + ((row == col && row < NDX + NU) ? preg : 0.0);
           }
         // operands
@@ -557,7 +554,7 @@ namespace smpc
           else if (ks < 4)
             w = (r >= 8 && r < 14 && k < 14) ? md.w_centder[(r - 8) * 6 + k - 8] : 0.0;
           else
-            w = (r < 16 + 3 * NF && (r - 16) / 3 == (k - 16) / 3) ? md.w_frame[((r - 16) % 3) * 3 + (k - 16) % 3] : 0.0;
+            w = (r < 16 + 3 * NF && (r - 16) / 3 == (k - 16) / 3) ? mg.w_frame[((r - 16) % 3) * 3 + (k - 16) % 3] : 0.0;
           SMPC_PLV(wop)[ks] = w;
         }
       }

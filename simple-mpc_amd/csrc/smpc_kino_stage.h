@@ -28,7 +28,7 @@ namespace smpc
     DevModelSmall<D> ml; // model constants (copied from global memory once per block)
     double x[D::NX], u[D::NU];
     // stage inputs fetched with the block's other global loads, so that no later phase waits on global memory
-    double in_x_tgt[D::NX], in_u_ref[D::NU], in_foot_ref[D::NF * 3], in_xn[D::NX]; // x target, u reference, foot refs, x_{t+1}
+    double in_x_tgt[D::NX], in_u_ref[D::NU], in_foot_ref[D::NF * 3]; // x target, u reference, foot refs
     // tree block A (contiguous, 667 doubles): dead once the derivative columns and the constraint values are formed;
     // reused -- in this order of time -- by the wave reductions of the cost / multiplier phases and by the
     // weighted-Jacobian tables of the assembly phases (accessors below)
@@ -47,25 +47,30 @@ namespace smpc
     SMPC_HD double * gjA_() { return xnext; }
     SMPC_HD double * gjB_() { return xnext + 36; }
     static_assert(D::NX + D::NDX >= 72, "Gauss-Jordan scratch inside xnext | e");
-    double cval[D::NC];
-    // residuals and weighted residuals
-    double rx[D::NDX], Wrx[D::NDX], ru[D::NU], Wru[D::NU], Whg[6], Whd[6], rf[D::NF * 3], Wrf[D::NF * 3];
-    double vplus[D::NC], lamp[D::NDX], lam_next[D::NDX], lam_prev[D::NDX], nu[D::NC];
-    int act[D::NC];
     double red[4];
+    double rx[D::NDX];                                          // state residual (its base block comes out of the SE(3) pair, early)
+    double lam_next[D::NDX], nu[D::NC];                         // multipliers (block inputs)
+    // ---- "late block": written only after the derivative columns are formed (constraint values, residuals, weighted
+    //      residuals, multiplier estimates).  Until then the derivative kernel keeps the first 216 doubles of the per-body
+    //      velocity-product matrices here (they continue into WJl | JWJ of the derivative part, which follows directly) ----
+    double cval[D::NC];
+    double Wrx[D::NDX], ru[D::NU], Wru[D::NU], Whg[6], Whd[6], rf[D::NF * 3], Wrf[D::NF * 3];
+    double vplus[D::NC], lamp[D::NDX];
+    int act[D::NC];
+    static constexpr int LATE_DOUBLES = 2 * D::NC + 2 * D::NDX + 2 * D::NU + 12 + 6 * D::NF + D::NC / 2;
   };
   template <class D>
   struct KinoScratchDerivPart
   {
     static_assert(3 * D::NV >= D::NJ * 3 && D::NF * 3 * D::NV >= D::NJ * 10, "op_() / I_() overlays");
+    // state-cost tables of the base block, first members: they continue the late block of the evaluation part
+    double WJl[D::NDX * 6];           // w_x[:,0:6] * Jl ;  (Jl^T w_x[0:6,:])(i, k) = WJl[k][i] since w_x is symmetric
+    double JWJ[36];                   // Jl^T w_x[0:6,0:6] Jl
     double dh_dq[6 * D::NV], dhd_dq[6 * D::NV], dhd_dv[6 * D::NV]; // dhd_*: overwritten in place by ab_dq / ab_dv
     double Jfoot[D::NF * 3 * D::NV];
     double dtgt[3 * D::NV];
     double cn[D::NDX]; // C_x^T nu of the contact rows (formed with the constraint Jacobian columns)
     double Je3[9], JeQ[9], Jq[36], Jl[36];
-    double WJl[D::NDX * 6];           // w_x[:,0:6] * Jl
-    double JtW[6 * D::NDX];           // Jl^T w_x[0:6,:]
-    double JWJ[36];                   // Jl^T w_x[0:6,0:6] Jl
   };
   template <class D>
   struct KinoScratchNoDeriv
@@ -371,10 +376,14 @@ namespace smpc
     double * Bm = nullptr;
     if constexpr (DERIV)
     {
-      static_assert(D::NDX * 6 + 6 * D::NDX + 36 >= NJ * 36, "B matrices overlay WJl | JtW | JWJ");
-      static_assert(offsetof(KinoScratchDerivPart<D>, JWJ) - offsetof(KinoScratchDerivPart<D>, WJl) == D::NDX * 12 * sizeof(double),
-                    "table block must be contiguous");
-      Bm = sc.WJl;
+      // [late block | WJl | JWJ] is one contiguous run: the evaluation part ends with the late block, the derivative part
+      // starts with WJl
+      typedef KinoScratchEval<D> EV;
+      static_assert(EV::LATE_DOUBLES + D::NDX * 6 + 36 >= NJ * 36, "B matrices overlay late block | WJl | JWJ");
+      static_assert(offsetof(EV, cval) + EV::LATE_DOUBLES * sizeof(double) == sizeof(EV) && D::NC % 2 == 0, "late block must end the evaluation part");
+      static_assert(offsetof(KinoScratchDerivPart<D>, WJl) == 0 && offsetof(KinoScratchDerivPart<D>, JWJ) == D::NDX * 6 * sizeof(double),
+                    "tables must start the derivative part");
+      Bm = sc.cval;
       SMPC_LANES(NT)
       for (int idx = lane; idx < NJ * 6; idx += NT)
       {
@@ -880,7 +889,7 @@ namespace smpc
           const int i = lane - 52, f = i / 3, r = i % 3;
           double s = 0.0;
           for (int j = 0; j < 3; j++)
-            s += md.w_frame[r * 3 + j] * sc.rf[f * 3 + j];
+            s += in.md->w_frame[r * 3 + j] * sc.rf[f * 3 + j];
           sc.Wrf[i] = s;
         }
       }

@@ -59,7 +59,6 @@ namespace smpc
     // KinodynamicsSettings (include/simple-mpc/kinodynamics.hpp:24-51)
     double dt;
     double gravity[3];
-    double w_frame[9];
     double w_cent[36];
     double w_centder[36];
     double qmin[D::NA];
@@ -89,6 +88,7 @@ namespace smpc
     double inertia[D::NJ][6];
     double foot_p[D::NF][3];
     double foot_ref_p[D::NF][3];
+    double w_frame[9]; // (read from global memory by the two phases that use it: 72 B of LDS decide the 8th resident wave)
     double w_x[D::NDX * D::NDX];
     double w_u[D::NU * D::NU];
     double w_xT[D::NDX * D::NDX]; // transposes: lane = row matvecs read them with coalesced loads
