@@ -287,3 +287,24 @@ def test_per_instance_velocity_commands(lib):
     assert np.abs(refs[0] - refs[1]).max() > 1e-3, "different commands must give different footholds"
     with pytest.raises(RuntimeError):
         gm.setVelocityBaseBatched(np.zeros((B, 5)))
+
+
+def test_without_kinematics_limits_and_other_settings(lib):
+    """The settings of the reference's own CPU benchmark (benchmark/go2.cpp:60-101: no joint box, zero centroidal weight,
+    lighter frame weight, T_contact = 5, apex 0.2) on the kinodynamics OCP."""
+    ov = dict(kinematics_limits=False, w_cent=np.zeros((6, 6)), w_frame=np.eye(3) * 1000.0)
+    mo = dict(T_contact=5, swing_apex=0.2)
+    om, rb, _ = S.make_oracle(2, 2, settings_override=ov, mpc_override=mo)
+    gm, _, _, _ = S.make_product(2, 2, lib=lib, settings_override=ov, mpc_override=mo)
+    cs = O.trot_cycle(T_ds=5, T_ss=30)
+    for m in (om, gm):
+        m.generateCycleHorizon(cs)
+        m.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = S.random_states(rb, 2)
+    for _ in range(5):
+        om.iterate(X)
+        gm.iterate(X)
+        assert S.rel_err(om.xs, gm.xs) < 1e-8 and S.rel_err(om.us, gm.us) < 1e-6
+        assert np.array_equal(om.info[:, 2], gm.info[:, 2])
+        X = om.xs[:, 1, :].copy()
+    assert np.abs(gm.vs[:, :, :12]).max() == 0.0, "no joint-box multipliers without kinematics_limits"
