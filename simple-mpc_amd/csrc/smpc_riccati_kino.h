@@ -27,9 +27,10 @@ namespace smpc
   {
     static constexpr int NDX = D::NDX, NU = D::NU;
     static constexpr int G_W = 0;                     // [K | k] = -R^^-1 [S^^T | r^]   NU x (NDX+1)
-    static constexpr int G_Pt = G_W + NU * (NDX + 1); // P~ NDX x NDX
-    static constexpr int G_pn = G_Pt + NDX * NDX;     // p_{t+1}
+    static constexpr int G_Pt = G_W + NU * (NDX + 1);       // P~, upper triangle packed row by row (the forward sweep is
+    static constexpr int G_pn = G_Pt + NDX * (NDX + 1) / 2; //     HBM bound: half of P~ is 18 % of what it reads); p_{t+1}
     static constexpr int STRIDE = ((G_pn + NDX + 7) / 8) * 8;
+    SMPC_HD static constexpr int pt_off(int i, int j) { return G_Pt + i * NDX - i * (i - 1) / 2 + (j - i); } // i <= j
   };
 
   template <class D>
@@ -423,7 +424,11 @@ namespace smpc
       SMPC_LANES(NT)
       {
         for (int idx = lane; idx < NDX * NDX; idx += NT)
-          g[GK::G_Pt + idx] = s.P[idx];
+        {
+          const int i = idx / NDX, j = idx % NDX;
+          if (j >= i)
+            g[GK::pt_off(i, j)] = s.P[idx];
+        }
 #pragma unroll
         for (int n = 0; n < NAB_PL; n++)
         {
@@ -805,7 +810,6 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     const double * W = s.st + GK::G_W;
-    const double * Pt = s.st + GK::G_Pt;
     const double * pn = s.st + GK::G_pn;
     const double * vf = s.st + FL::O_V;
     const double *vd = vf + NDX, *vlx = vd + NC, *vlu = vlx + NDX, *vlpd = vlu + NU, *vvpd = vlpd + NDX;
@@ -882,14 +886,17 @@ namespace smpc
         s.y[lane] = acc + vf[lane] - mu * pn[lane];
       }
       SMPC_LANES_END_WAVE
-      // ---- w = P~ y (P~ symmetric: column reads are conflict-free) ; dx+ = y - mu w ; dlam+ = w + p_{t+1} ----
+      // ---- w = P~ y (P~ symmetric, upper triangle packed) ; dx+ = y - mu w ; dlam+ = w + p_{t+1} ----
       SMPC_LANES(NT)
       if (lane < NDX)
       {
         double w = 0.0;
 #pragma unroll 4
         for (int j = 0; j < NDX; j++)
-          w += Pt[j * NDX + lane] * s.y[j];
+        {
+          const int lo = j < lane ? j : lane, hi = j < lane ? lane : j;
+          w += s.st[GK::pt_off(lo, hi)] * s.y[j];
+        }
         const double dxn = s.y[lane] - mu * w;
         const double dl = w + pn[lane];
         b.dxs[((size_t)inst * (H + 1) + t + 1) * NDX + lane] = dxn;
