@@ -10,7 +10,7 @@
 //   MPC::switchToWalk/Stand    src/mpc.cpp:382-392
 #pragma once
 #ifndef SMPC_TRIAL_MINW
-#define SMPC_TRIAL_MINW 2
+#define SMPC_TRIAL_MINW 3
 #endif
 #include "smpc_riccati_kino.h"
 #include "smpc_solver_kernels.h"

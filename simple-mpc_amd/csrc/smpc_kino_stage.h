@@ -76,7 +76,8 @@ namespace smpc
   struct KinoScratchNoDeriv
   {
     double xn1[D::NX]; // trial point of the next state (line search only)
-    double op[D::NJ * 3], I[D::NJ * 10]; // joint positions, body inertias (the derivative kernel overlays them, see op_() / I_())
+    double op[D::NJ * 3]; // joint positions (the derivative kernel overlays them, see op_(); the world-frame body inertias are
+                          // only read by the derivative kernel)
   };
   template <class D, bool DERIV>
   struct KinoScratch : KinoScratchEval<D>, std::conditional<DERIV, KinoScratchDerivPart<D>, KinoScratchNoDeriv<D>>::type
@@ -92,10 +93,8 @@ namespace smpc
     }
     SMPC_HD double * I_()
     {
-      if constexpr (DERIV)
-        return this->Jfoot;
-      else
-        return this->I;
+      static_assert(DERIV, "body inertias are kept by the derivative kernel only");
+      return this->Jfoot;
     }
     // tables living in tree block A (written by the table phase, after the last reader of the tree data)
     SMPC_HD double * WJc() { return this->oR; }       // [6][NDX]     w_cent * [dh_dq | Ag]
@@ -357,7 +356,8 @@ namespace smpc
       I.jyy = Iw.a11 + m * (cc - c.y * c.y);
       I.jyz = Iw.a12 - m * c.y * c.z;
       I.jzz = Iw.a22 + m * (cc - c.z * c.z);
-      stsi(&sc.I_()[j * 10], I);
+      if constexpr (DERIV)
+        stsi(&sc.I_()[j * 10], I);
       stsi(&sc.Ic[j * 10], I);
       const SV h = I * v;
       stsv(&sc.hc[j * 6], h);
