@@ -42,7 +42,7 @@ namespace smpc
     static constexpr int X1 = 12, Z1 = 21;        // sweep 1 index space: 9 pivots (+3 pad) | x | vector column
     static constexpr int LDM = 32;
     static constexpr int R1 = Z1 + 1, R2 = XO + 10; // rows of the two bordered matrices that are ever non-zero
-    static constexpr int LD1 = 24;                  // row stride of the sweep-1 matrix (columns 0 .. Z1)
+    static constexpr int LD1 = Z1 + 1;              // row stride of the sweep-1 matrix (columns 0 .. Z1)
     static_assert(ZC < LDM && NU <= 16 && NC <= 16 && 3 * NU <= 64, "the stage KKT matrix must fit two 16 x 16 tile rows");
     // per (instance, stage) record written by the backward pass for the forward pass
     static constexpr int G_K = 0;                 // [K | k]  NU x 10
@@ -128,18 +128,17 @@ namespace smpc
   {
     static constexpr int NU = D::NU, NC = D::NC, NF = D::NF;
     CentDevModel<D> md;
-    double in[D::I_REGS * 64];       // stage inputs (I_* offsets)
+    double in[D::I_N > 64 ? D::I_N : 64]; // stage inputs (I_* offsets); also the 64-entry reduction buffer between the passes
     double P[81], p[9], Pt[81], pt[9], pt0[9];
     double ABp[9 * D::LDM];          // [A B] in sweep-2 column order (B at 0, A at XO)
     // bordered matrices of the two sweeps (built here, swept in registers): zero-filled once, after that only the
     // structural non-zeros are rewritten per stage (results leave the accumulators directly, never through these)
     double M1[D::R1 * D::LD1], M2[D::R2 * D::LDM];
-    double prow[4 * D::LDM], urow[4 * D::LDM];
     double fs[3], ts[3], rf[3 * NF], act[NF], Cu[NC * 3], cact[NC];
     double f[9], dvec[NC], lpd[9], vpd[NC];
     double ru[NU], rx[9], rla[3], N[NF * 9], G[9], wla[3], waa[3], wrx[9], wu[NU];
     double lx[9], lu[NU], q[9], r[NU], gxp[9], gu[NU];
-    double dx[9], du[NU], dv[NC], y[9], w[9];
+    double dx[9], du[NU], y[9], w[9];
     double sc[16];
   };
 
@@ -304,6 +303,11 @@ namespace smpc
     CentLds<D> & s = ldsv[0];
     double * const rec = s.M1;  // forward pass / recede scratch: record of the current stage (the backward pass is over)
     double * const red = s.in;  // reductions happen between the passes
+    // pivot rows / U rows of the block sweeps live in the [A B] area: sweep 1 runs before [A B] of the stage is built,
+    // sweep 2 after its last reader (the operand loads of the products)
+    static_assert(9 * LDM >= 8 * LDM, "sweep scratch inside ABp");
+    double * const prow = s.ABp;
+    double * const urow = s.ABp + 4 * LDM;
     double * dbg = block == 0 ? b.dbg : nullptr;
     long long tprev = SMPC_CLOCK();
     double * gsc = b.scal + inst * SC_N;
@@ -521,7 +525,7 @@ namespace smpc
         }
         SMPC_LANES_END_WAVE
         CENT_FINE_TICK(6);
-        wave_block_sweep<NT, 2, false, 0, 3>(macc, s.prow, s.urow, CENT_FINE_DBG, tprev);
+        wave_block_sweep<NT, 2, false, 0, 3>(macc, prow, urow, CENT_FINE_DBG, tprev);
         // P~ (upper triangle of the Schur block is authoritative, mirrored) straight out of the accumulators
         SMPC_LANES(NT)
         {
@@ -549,7 +553,8 @@ namespace smpc
         {
 #pragma unroll
           for (int n = 0; n < D::I_REGS; n++)
-            s.in[lane + n * NT] = SMPC_PLV(pin)[n];
+            if (lane + n * NT < D::I_N)
+              s.in[lane + n * NT] = SMPC_PLV(pin)[n];
           if (t > 0)
           {
 #pragma unroll
@@ -940,9 +945,9 @@ namespace smpc
         for (int row = 0; row < NC; row++)
           anyact = anyact || s.cact[row] != 0.0;
         if (anyact)
-          wave_block_sweep<NT, 2, true, 0, D::NP2>(macc, s.prow, s.urow, CENT_FINE_DBG, tprev);
+          wave_block_sweep<NT, 2, true, 0, D::NP2>(macc, prow, urow, CENT_FINE_DBG, tprev);
         else
-          wave_block_sweep<NT, 2, true, 0, NUP / 4>(macc, s.prow, s.urow, CENT_FINE_DBG, tprev);
+          wave_block_sweep<NT, 2, true, 0, NUP / 4>(macc, prow, urow, CENT_FINE_DBG, tprev);
         // ---- gains, P_t, p_t straight out of the accumulators ; record for the forward pass ----
         SMPC_LANES(NT)
         {
