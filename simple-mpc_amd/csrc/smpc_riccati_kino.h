@@ -719,26 +719,37 @@ namespace smpc
   struct ForwardKinoLds
   {
     static constexpr int NDX = D::NDX, NU = D::NU, NG = 12;
-    static constexpr int N_G = GainsK<D>::G_pn + NDX;                        // [K | k] | P~ | p+
+    typedef GainsK<D> GK;
+    static constexpr int N_W = NU * (NDX + 1), N_P = NDX * (NDX + 1) / 2;    // [K | k] ; packed P~
     static constexpr int N_A = 6 * NDX, N_B = 6 * NU, N_C = NG * NDX;        // row groups qb / vb of A, B; contact rows of C
     static constexpr int N_V = D::O_vpd + D::NC - D::O_f;                    // f d lx lu lpd vpd
-    static constexpr int O_A0 = N_G, O_A1 = O_A0 + N_A, O_B0 = O_A1 + N_A, O_B1 = O_B0 + N_B, O_Cc = O_B1 + N_B,
-                         O_V = O_Cc + N_C, O_box = O_V + N_V, N_STAGE = O_box + D::NA;
+    // flat staging index of a stage.  Early part (committed to LDS at the stage boundary):
+    //   0 [K | k] | 1 p+ | 2,3 A rows qb, vb | 4,5 B rows qb, vb | 6 contact rows of C | 7 vectors | 8 box diag
+    // late part: 9 packed P~, committed over [K | k] once du is formed (P~ is read last) | 10 pad
+    static constexpr int O_pn = N_W, O_A0 = O_pn + NDX, O_A1 = O_A0 + N_A, O_B0 = O_A1 + N_A, O_B1 = O_B0 + N_B, O_Cc = O_B1 + N_B,
+                         O_V = O_Cc + N_C, O_box = O_V + N_V, O_late = O_box + D::NA, N_STAGE = O_late + N_P;
+    static_assert(N_P <= N_W, "P~ is staged over [K | k]");
     static constexpr int PER_LANE = (N_STAGE + 63) / 64;
-    // staging chunks: 0 gains | 1,2 A rows qb, vb | 3,4 B rows qb, vb | 5 contact rows of C | 6 vectors | 7 box diag | 8 pad
+    static constexpr int PER_EARLY = (O_late + 63) / 64;   // registers holding early entries (the last one may straddle)
+    static constexpr int FULL_EARLY = O_late / 64;         // registers holding early entries only
     SMPC_HD static constexpr int start(int c)
     {
-      return c == 0 ? 0 : c == 1 ? O_A0 : c == 2 ? O_A1 : c == 3 ? O_B0 : c == 4 ? O_B1 : c == 5 ? O_Cc : c == 6 ? O_V : c == 7 ? O_box : N_STAGE;
+      return c == 0 ? 0 : c == 1 ? O_pn : c == 2 ? O_A0 : c == 3 ? O_A1 : c == 4 ? O_B0 : c == 5 ? O_B1 : c == 6 ? O_Cc : c == 7 ? O_V : c == 8 ? O_box
+                                                                                                                                   : c == 9 ? O_late : N_STAGE;
     }
     SMPC_HD static constexpr int chunk(int idx)
     {
-      return idx < O_A0 ? 0 : idx < O_A1 ? 1 : idx < O_B0 ? 2 : idx < O_B1 ? 3 : idx < O_Cc ? 4 : idx < O_V ? 5 : idx < O_box ? 6 : idx < N_STAGE ? 7 : 8;
+      return idx < O_pn ? 0 : idx < O_A0 ? 1 : idx < O_A1 ? 2 : idx < O_B0 ? 3 : idx < O_B1 ? 4 : idx < O_Cc ? 5 : idx < O_V ? 6 : idx < O_box ? 7 : idx < O_late ? 8
+                                                                                                                                    : idx < N_STAGE ? 9 : 10;
     }
-    SMPC_HD static constexpr int src(int c) // offset of the chunk's source in the LQ block (chunks 1..6)
+    SMPC_HD static constexpr bool from_gains(int c) { return c == 0 || c == 1 || c == 9; }
+    // offset of the chunk's source: in the gains block (chunks 0, 1, 9) or in the LQ block (chunks 2 .. 7)
+    SMPC_HD static constexpr int src(int c)
     {
-      return c == 1 ? D::O_A : c == 2 ? D::O_A + D::NV * NDX : c == 3 ? D::O_B : c == 4 ? D::O_B + D::NV * NU : c == 5 ? D::O_C + D::NA * NDX : D::O_f;
+      return c == 0 ? GK::G_W : c == 1 ? GK::G_pn : c == 9 ? GK::G_Pt : c == 2 ? D::O_A : c == 3 ? D::O_A + D::NV * NDX : c == 4 ? D::O_B
+             : c == 5 ? D::O_B + D::NV * NU : c == 6 ? D::O_C + D::NA * NDX : D::O_f;
     }
-    double st[PER_LANE * 64];
+    double st[PER_EARLY * 64];
     double dx[NDX], du[NU], y[NDX], part[64], lpd_prev[NDX];
   };
 
@@ -750,7 +761,6 @@ namespace smpc
     typedef GainsK<D> GK;
     typedef KinoIdx<D> IX;
     typedef ForwardKinoLds<D> FL;
-    static_assert(GK::G_W == 0 && GK::G_pn + NDX == FL::N_G, "gains chunk must be contiguous");
     static_assert(D::O_d == D::O_f + NDX && D::O_lx == D::O_d + NC && D::O_lu == D::O_lx + NDX && D::O_lpd == D::O_lu + NU &&
                     D::O_vpd == D::O_lpd + NDX,
                   "vector chunk must be contiguous");
@@ -765,21 +775,23 @@ namespace smpc
     // fetch stage t into the per-lane registers (flat staging index -> source chunk).  Chunk boundaries are
     // compile-time: for most n all 64 lanes fall into one chunk (plain base + lane address); the few straddling
     // ones use an integer select chain -- no divergent branches.
-    auto fetch = [&](int lane, double * r, int t) {
+    auto fetch = [&](int lane, double * r, int t, int n0, int n1) {
       const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
       const double * g = b.gains + ((size_t)inst * H + t) * GK::STRIDE;
 #pragma unroll
       for (int n = 0; n < PER; n++)
       {
+        if (n < n0 || n >= n1)
+          continue;
         const int lo = n * NT, hi = n * NT + NT - 1;
         if (FL::chunk(lo) == FL::chunk(hi))
         {
           const int c = FL::chunk(lo);
-          if (c == 0)
-            r[n] = g[lo + lane];
-          else if (c < 7)
+          if (FL::from_gains(c))
+            r[n] = g[FL::src(c) + lo - FL::start(c) + lane];
+          else if (c < 8)
             r[n] = lq[FL::src(c) + lo - FL::start(c) + lane];
-          else if (c == 7)
+          else if (c == 8)
             r[n] = lq[D::O_C + (lo + lane - FL::O_box) * (NDX + 1) + 6];
           else
             r[n] = 0.0;
@@ -787,13 +799,20 @@ namespace smpc
         else
         {
           const int idx = lo + lane;
-          int off = 0; // offset into lq
+          int off = 0;       // offset into lq or into the gains block
+          bool ing = false;
 #pragma unroll
-          for (int c = 1; c < 7; c++)
-            off = (idx >= FL::start(c) && idx < FL::start(c + 1)) ? FL::src(c) + idx - FL::start(c) : off;
-          off = (idx >= FL::O_box && idx < FL::N_STAGE) ? D::O_C + (idx - FL::O_box) * (NDX + 1) + 6 : off;
-          const double * src = idx < FL::N_G ? g + idx : lq + off; // address select, ONE load, no wait on its value
-          r[n] = *src;                                             // (pad entries load lq[0]; never read back)
+          for (int c = 0; c < 10; c++)
+          {
+            const bool in = idx >= FL::start(c) && idx < FL::start(c + 1);
+            if (c == 8)
+              off = in ? D::O_C + (idx - FL::O_box) * (NDX + 1) + 6 : off;
+            else
+              off = in ? FL::src(c) + idx - FL::start(c) : off;
+            ing = (in && FL::from_gains(c)) ? true : ing;
+          }
+          const double * src = ing ? g + off : lq + off; // address select, ONE load, no wait on its value
+          r[n] = *src;                                   // (pad entries load lq[0]; never read back)
         }
       }
     };
@@ -806,11 +825,11 @@ namespace smpc
         b.dxs[((size_t)inst * (H + 1)) * NDX + lane] = 0.0;
       }
       s.part[lane] = 0.0;
-      fetch(lane, SMPC_PLV(pf), 0);
+      fetch(lane, SMPC_PLV(pf), 0, 0, PER);
     }
     SMPC_LANES_END_WAVE
-    const double * W = s.st + GK::G_W;
-    const double * pn = s.st + GK::G_pn;
+    const double * W = s.st;              // [K | k] until du is formed, then the packed P~
+    const double * pn = s.st + FL::O_pn;
     const double * vf = s.st + FL::O_V;
     const double *vd = vf + NDX, *vlx = vd + NC, *vlu = vlx + NDX, *vlpd = vlu + NU, *vvpd = vlpd + NDX;
     const double * boxact = s.st + FL::O_box;
@@ -821,10 +840,11 @@ namespace smpc
       SMPC_LANES(NT)
       {
 #pragma unroll
-        for (int n = 0; n < PER; n++)
-          s.st[lane + n * NT] = SMPC_PLV(pf)[n];
+        for (int n = 0; n < FL::PER_EARLY; n++)
+          if (lane + n * NT < FL::O_late)
+            s.st[lane + n * NT] = SMPC_PLV(pf)[n];
         if (t + 1 < H)
-          fetch(lane, SMPC_PLV(pf), t + 1);
+          fetch(lane, SMPC_PLV(pf), t + 1, 0, FL::FULL_EARLY);
       }
       SMPC_LANES_END_WAVE
       // ---- du = K dx + k ; dnu = (C dx + d)/mu ----
@@ -862,6 +882,18 @@ namespace smpc
       SMPC_LANES_END_WAVE
       // ---- y = A dx + B du + f - mu p_{t+1}  (dense rows G; unit rows by structure) ----
       SMPC_LANES(NT)
+      {
+        // [K | k] is dead: the packed P~ takes its place ; the registers that held it start fetching stage t+1
+#pragma unroll
+        for (int n = FL::FULL_EARLY; n < PER; n++)
+        {
+          const int idx = lane + n * NT;
+          if (idx >= FL::O_late && idx < FL::N_STAGE)
+            s.st[idx - FL::O_late] = SMPC_PLV(pf)[n];
+        }
+        if (t + 1 < H)
+          fetch(lane, SMPC_PLV(pf), t + 1, FL::FULL_EARLY, PER);
+      }
       if (lane < NDX)
       {
         const int i = lane;
@@ -895,7 +927,7 @@ namespace smpc
         for (int j = 0; j < NDX; j++)
         {
           const int lo = j < lane ? j : lane, hi = j < lane ? lane : j;
-          w += s.st[GK::pt_off(lo, hi)] * s.y[j];
+          w += s.st[GK::pt_off(lo, hi) - GK::G_Pt] * s.y[j];
         }
         const double dxn = s.y[lane] - mu * w;
         const double dl = w + pn[lane];
