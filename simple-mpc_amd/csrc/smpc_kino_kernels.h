@@ -119,7 +119,6 @@ namespace smpc
 
     // block inputs that are consumed once, by the lane that loaded them, stay in registers: lambda_t (q of the knot) and
     // x_{t+1} (committed to LDS only for the defect phase, into the then idle late block)
-    SMPC_PL(double, lam_prev_r, NT);
     SMPC_PL(double, xn_r, NT);
     SMPC_LANES(NT)
     {
@@ -128,7 +127,6 @@ namespace smpc
       const double vx = xg[lane < NX ? lane : 0];
       const double vu = b.us[(ib + st) * NU + (lane < NU ? lane : 0)];
       const double vl = b.lams[(ib + st) * NDX + (lane < NDX ? lane : 0)];
-      const double vlp = b.lams[(ib + sprev) * NDX + (lane < NDX ? lane : 0)];
       const double vn = b.vs[(ib + st) * NC + (lane < NC ? lane : 0)];
       // state_cost target: shared pose part, per-instance base-velocity part (address select, one load)
       const double vxt = *((!term && lane >= D::NQ && lane < D::NQ + 6) ? b.vref + (ib + st) * 6 + (lane - D::NQ) : in.x_tgt + (lane < NX ? lane : 0));
@@ -142,7 +140,6 @@ namespace smpc
         sc.in_x_tgt[lane] = vxt;
       }
       SMPC_PLV(xn_r) = vxn;
-      SMPC_PLV(lam_prev_r) = (lane < NDX && t > 0) ? vlp : 0.0;
       if (lane < NU)
         sc.in_u_ref[lane] = vur;
       if (lane < NF * 3)
@@ -217,7 +214,7 @@ namespace smpc
           g = sc.Wrx[k];
         for (int a = 0; a < 6; a++)
           g += (k < NV ? sc.dh_dq[a * NV + k] : sc.Ag[a * NV + k - NV]) * sc.Whg[a];
-        const double qn = g - SMPC_PLV(lam_prev_r);
+        const double qn = g - b.lams[(ib + sprev) * NDX + k];
         qN[k] = qn;
         dual = fabs(qn);
         sc.rx[k] = dual; // reuse as dual-infeasibility scratch
@@ -269,6 +266,7 @@ namespace smpc
     {
       const bool isA = lane < NDX;
       const int k = isA ? lane : lane - NDX;
+      const double lam_prev_v = b.lams[(ib + sprev) * NDX + (isA ? k : 0)]; // lambda_t (used at the end of the phase)
       // top block source column: Dtop[m] (m<6) = d(dx_q)[m]/d(col)
       double Dtop[6], Dbot[6];
       for (int m = 0; m < 6; m++)
@@ -362,7 +360,7 @@ namespace smpc
         double cn = sc.cn[k];
         if (md.kinematics_limits && k >= 6 && k < NV)
           cn += sc.nu[k - 6];
-        double q = g + acc + cn - SMPC_PLV(lam_prev_r);
+        double q = g + acc + cn - (t > 0 ? lam_prev_v : 0.0);
         if (t == 0)
           q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
         lq[D::O_q + k] = q;
