@@ -162,7 +162,7 @@ def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
                      "achieved": flops / avg / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / avg / 1e12 / FP64_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_source": src, "avg_launch_ms": avg * 1e3,
                      "note": "algorithmic FLOPs = B*H*k*F_ric(9,12,8) (SURVEY 8d); the 21 x 21 stage systems leave the matrix cores "
-                             "mostly idle: the kernel is bound by the instruction issue of its index / assembly code (DESIGN.md 3.6)"},
+                             "mostly idle: the kernel is bound by the instruction issue of its index / assembly code (DESIGN.md 3.4)"},
     }
     if with_cpu:
         threads = O.lib().orc_num_threads()
