@@ -21,7 +21,8 @@
 namespace smpc
 {
   // LDS scratch of one (instance, stage) wavefront.  The evaluation-only part (trial points of the line
-  // search) is 13.6 KB; the derivative part adds 21 KB and is only instantiated by the derivative kernel.
+  // search) is 13.3 KB; the derivative part adds 7 KB (arrays with disjoint lifetimes share storage, see the overlays
+  // below) and is only instantiated by the derivative kernel: 20.4 KB = 8 resident waves per CU.
   template <class D>
   struct KinoScratchEval
   {
