@@ -40,6 +40,7 @@ namespace smpc
     CentBuffers<DC> buf;
     Buffers<DK> fk; // only .model is used (front-end kernel)
     int B, H, R, head = 0;
+    int device_id = 0; // every entry point makes this the current device first
     HostMpcSettings ms;
     std::vector<CentStage<DC>> horizon, cycle;
     CentStage<DC> standing;
@@ -70,6 +71,7 @@ namespace smpc
         throw std::runtime_error("centroidal settings: weight sizes do not match the robot");
       if (ms.T < 2)
         throw std::runtime_error("horizon must have at least 2 stages");
+      device_id = device;
       set_device(device);
       stream = stream_create();
       B = batch;
@@ -165,6 +167,7 @@ namespace smpc
     template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1>
     void timed_launch(int kid, int grid, const Args & a, bool aux = false)
     {
+      set_device(device_id);
       event_t e0{}, e1{};
       if (profiling)
       {
@@ -317,6 +320,7 @@ namespace smpc
     }
     void upload_velocity(const double * V, bool broadcast)
     {
+      set_device(device_id);
       std::vector<double> h((size_t)B * 6);
       for (int b = 0; b < B; b++)
         for (int i = 0; i < 6; i++)
@@ -395,6 +399,7 @@ namespace smpc
     }
     void fill_strided(double * base, size_t stride, int count, const double * v, int n)
     {
+      set_device(device_id);
       FillStridedArgs fa;
       fa.base = base;
       fa.stride = stride;
@@ -534,6 +539,7 @@ namespace smpc
 
     size_t state_io(StateIO & io)
     {
+      set_device(device_id);
       stream_sync(stream);
       io.tag(0x534d504343454e54LL, "kind (centroidal)");
       io.tag(B, "batch");
@@ -565,16 +571,22 @@ namespace smpc
     }
     void iterate_host(const double * X)
     {
+      set_device(device_id);
       h2d(X_dev, X, (size_t)B * DK::NX * sizeof(double), stream);
       iterate_device(X_dev);
       stream_sync(stream);
     }
-    void sync() { stream_sync(stream); }
+    void sync()
+    {
+      set_device(device_id);
+      stream_sync(stream);
+    }
 
     double * stage_out = nullptr;
     size_t stage_out_bytes = 0;
     double * staging(size_t bytes)
     {
+      set_device(device_id);
       if (bytes > stage_out_bytes)
       {
         stream_sync(stream);
@@ -586,6 +598,7 @@ namespace smpc
     }
     void get_ring(const double * src, int n, int count, double * out)
     {
+      set_device(device_id);
       stream_sync(stream);
       std::vector<double> tmp((size_t)B * R * n);
       d2h(tmp.data(), src, tmp.size() * sizeof(double), stream);
@@ -596,6 +609,7 @@ namespace smpc
     }
     void get_linear(const double * src, size_t n, double * out)
     {
+      set_device(device_id);
       stream_sync(stream);
       d2h(out, src, n * sizeof(double), stream);
       stream_sync(stream);

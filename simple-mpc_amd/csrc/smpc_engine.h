@@ -246,6 +246,7 @@ namespace smpc
     typedef Dims<D::NJ, D::NF> DD;
     Buffers<D> buf;
     int B, H, R, head = 0;
+    int device_id = 0; // every entry point makes this the current device first: a process may hold handles on several GPUs
     HostMpcSettings ms;
     std::vector<StageShared<D>> horizon, cycle;
     StageShared<D> standing;
@@ -291,6 +292,7 @@ namespace smpc
         if ((const char *)probe.WJl - (const char *)probe.cval != (std::ptrdiff_t)(KinoScratchEval<D>::LATE_DOUBLES * sizeof(double)))
           throw std::runtime_error("internal: KinoScratch layout is not contiguous across its two parts");
       }
+      device_id = device;
       set_device(device);
       stream = stream_create();
       B = batch;
@@ -436,6 +438,7 @@ namespace smpc
     template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1>
     void timed_launch(int kid, int grid, const Args & a, bool aux = false)
     {
+      set_device(device_id);
       aux = aux || aux_launches;
       event_t e0{}, e1{};
       if (profiling)
@@ -727,6 +730,7 @@ namespace smpc
     // velocity commands live on the device, one per instance; the reference's single velocity_base_ is a broadcast
     void upload_velocity(const double * V, bool broadcast)
     {
+      set_device(device_id);
       std::vector<double> h((size_t)B * 6);
       for (int b = 0; b < B; b++)
         for (int i = 0; i < 6; i++)
@@ -812,6 +816,7 @@ namespace smpc
     }
     void fill_strided(double * base, size_t stride, int count, const double * v, int n)
     {
+      set_device(device_id);
       FillStridedArgs fa;
       fa.base = base;
       fa.stride = stride;
@@ -879,6 +884,7 @@ namespace smpc
     // bookkeeping.  Not included: the feedback gains and the LQ knots of the last solve (recomputed by the next iterate).
     size_t state_io(StateIO & io)
     {
+      set_device(device_id);
       stream_sync(stream);
       io.tag(0x534d50434b494e4fLL, "kind (kinodynamics)");
       io.tag(B, "batch");
@@ -910,11 +916,16 @@ namespace smpc
     }
     void iterate_host(const double * X)
     {
+      set_device(device_id);
       h2d(X_dev, X, (size_t)B * D::NX * sizeof(double), stream);
       iterate_device(X_dev);
       stream_sync(stream);
     }
-    void sync() { stream_sync(stream); }
+    void sync()
+    {
+      set_device(device_id);
+      stream_sync(stream);
+    }
     // xs[t] of every instance -> dense device buffer [B][NX], asynchronous on the engine's stream
     void gather_x_device(int t, double * out_dev)
     {
@@ -1022,6 +1033,7 @@ namespace smpc
 
     double * staging(size_t bytes)
     {
+      set_device(device_id);
       if (bytes > stage_out_bytes)
       {
         dev_free(stage_out);
@@ -1033,6 +1045,7 @@ namespace smpc
     // ring array [B][R][n] -> host linear [B][count][n] for t = 0..count-1
     void get_ring(const double * src, int n, int count, double * out)
     {
+      set_device(device_id);
       stream_sync(stream);
       std::vector<double> tmp((size_t)B * R * n);
       d2h(tmp.data(), src, tmp.size() * sizeof(double), stream);
@@ -1043,6 +1056,7 @@ namespace smpc
     }
     void get_linear(const double * src, size_t n, double * out)
     {
+      set_device(device_id);
       stream_sync(stream);
       d2h(out, src, n * sizeof(double), stream);
       stream_sync(stream);
