@@ -132,7 +132,8 @@ namespace smpc
       const double vxt = *((!term && lane >= D::NQ && lane < D::NQ + 6) ? b.vref + (ib + st) * 6 + (lane - D::NQ) : in.x_tgt + (lane < NX ? lane : 0));
       const double vur = term ? 0.0 : in.u_ref[lane < NU ? lane : 0];
       const double vfr = term ? 0.0 : in.foot_ref[lane < NF * 3 ? lane : 0];
-      const double vxn = xn_g[lane < NX ? lane : 0];
+      static_assert(NX + 9 <= NT && D::NV >= 9, "w_frame rides in the spare lanes of the x_{t+1} register");
+      const double vxn = *(lane < NX ? xn_g + lane : mg.w_frame + (lane < NX + 9 ? lane - NX : 0));
       lanes_load_model<D, NT>(sc, &mg, lane);
       if (lane < NX)
       {
@@ -162,8 +163,12 @@ namespace smpc
     {
       static_assert(KinoScratchEval<D>::LATE_DOUBLES >= NX, "x_{t+1} is staged at the start of the late block");
       SMPC_LANES(NT)
-      if (lane < NX)
-        sc.cval[lane] = SMPC_PLV(xn_r); // (cval | Wrx ...: idle until the cost phase)
+      {
+        if (lane < NX)
+          sc.cval[lane] = SMPC_PLV(xn_r); // (cval | Wrx ...: idle until the cost phase)
+        else if (lane < NX + 9)
+          sc.wframe_()[lane - NX] = SMPC_PLV(xn_r); // w_frame into the (now dead) acceleration vector
+      }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
       lanes_difference<D>(sc.cval, sc.xnext, sc.e, lane, 61);
@@ -552,7 +557,7 @@ namespace smpc
           else if (ks < 4)
             w = (r >= 8 && r < 14 && k < 14) ? md.w_centder[(r - 8) * 6 + k - 8] : 0.0;
           else
-            w = (r < 16 + 3 * NF && (r - 16) / 3 == (k - 16) / 3) ? mg.w_frame[((r - 16) % 3) * 3 + (k - 16) % 3] : 0.0;
+            w = (r < 16 + 3 * NF && (r - 16) / 3 == (k - 16) / 3) ? sc.wframe_()[((r - 16) % 3) * 3 + (k - 16) % 3] : 0.0;
           SMPC_PLV(wop)[ks] = w;
         }
       }
@@ -984,6 +989,7 @@ namespace smpc
       const double vxt = *((!term && lane >= D::NQ && lane < D::NQ + 6) ? b.vref + (ib + st) * 6 + (lane - D::NQ) : in.x_tgt + (lane < NX ? lane : 0));
       const double vur = term ? 0.0 : in.u_ref[lane < NU ? lane : 0];
       const double vfr = term ? 0.0 : in.foot_ref[lane < NF * 3 ? lane : 0];
+      const double vwf = mg.w_frame[lane < 9 ? lane : 0];
       lanes_load_model<D, NT>(sc, &mg, lane);
       if (lane < NX)
       {
@@ -1006,6 +1012,8 @@ namespace smpc
         sc.nu[lane] = term ? 0.0 : vn + alpha * vdn;
       if (lane < NF * 3)
         sc.in_foot_ref[lane] = vfr;
+      if (lane < 9)
+        sc.wframe_()[lane] = vwf;
     }
     SMPC_LANES_END_WAVE
     // x_t (+) alpha dx_t and x_{t+1} (+) alpha dx_{t+1} in place: the two SE(3) updates run side by side on lanes 0 / 1

@@ -77,6 +77,7 @@ namespace smpc
   struct KinoScratchNoDeriv
   {
     double xn1[D::NX]; // trial point of the next state (line search only)
+    double wfr[9];        // w_frame (the derivative kernel keeps it in the dead acceleration vector, see wframe_())
     double op[D::NJ * 3]; // joint positions (the derivative kernel overlays them, see op_(); the world-frame body inertias are
                           // only read by the derivative kernel)
   };
@@ -91,6 +92,16 @@ namespace smpc
         return this->dtgt;
       else
         return this->op;
+    }
+    // foot-position weight (3 x 3): 72 B of LDS decide the derivative kernel's 8th resident wave, so there it is parked in
+    // the joint-acceleration vector `a` once the net-force update has consumed it (the block's load phase fetches it
+    // into spare lanes of the x_{t+1} register)
+    SMPC_HD double * wframe_()
+    {
+      if constexpr (DERIV)
+        return this->a;
+      else
+        return this->wfr;
     }
     SMPC_HD double * I_()
     {
@@ -890,7 +901,7 @@ namespace smpc
           const int i = lane - 52, f = i / 3, r = i % 3;
           double s = 0.0;
           for (int j = 0; j < 3; j++)
-            s += in.md->w_frame[r * 3 + j] * sc.rf[f * 3 + j];
+            s += sc.wframe_()[r * 3 + j] * sc.rf[f * 3 + j];
           sc.Wrf[i] = s;
         }
       }

@@ -423,12 +423,13 @@ namespace smpc
       // stream P~ out ; load the dense rows of [A|B]
       SMPC_LANES(NT)
       {
-        for (int idx = lane; idx < NDX * NDX; idx += NT)
-        {
-          const int i = idx / NDX, j = idx % NDX;
-          if (j >= i)
-            g[GK::pt_off(i, j)] = s.P[idx];
-        }
+        // packed upper triangle, row by row: lane = column (no index arithmetic in the stage loop; each row is one
+        // contiguous run of the gains block)
+        static_assert(NDX <= NT, "one column per lane");
+#pragma unroll
+        for (int i = 0; i < NDX; i++)
+          if (lane >= i && lane < NDX)
+            g[GK::pt_off(i, i) + lane - i] = s.P[i * NDX + lane];
 #pragma unroll
         for (int n = 0; n < NAB_PL; n++)
         {
