@@ -314,7 +314,8 @@ namespace smpc
       else
       {
         const double ang = sc.x[6 + j];
-        const double s = sin(ang), c = cos(ang);
+        double s, c;
+        sincos(ang, &s, &c); // one argument reduction for both
         const int jt = md.jtype[j];
         const M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -s, 0, s, c} : (jt == 2 ? M3{c, 0, s, 0, 1, 0, -s, 0, c} : M3{c, -s, 0, s, c, 0, 0, 0, 1});
         const M3 Rl = ldm3(&SMPC_PLV(jg)[0]) * Rq;
