@@ -214,7 +214,9 @@ def main():
     import __graft_entry__ as g
 
     if rank == 0:
+        # rank 0 (re)builds what is stale, the others wait: no concurrent compiler / make runs on the shared tree
         g.build_hip()
+        g.build_oracle()
     if dist is not None:
         dist.barrier()
     import mpc_setup as S
