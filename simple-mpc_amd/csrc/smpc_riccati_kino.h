@@ -426,10 +426,22 @@ namespace smpc
         // packed upper triangle, row by row: lane = column (no index arithmetic in the stage loop; each row is one
         // contiguous run of the gains block)
         static_assert(NDX <= NT, "one column per lane");
+        // (LDS reads of a chunk of rows first, unconditionally, then the masked stores: a read-wait-store chain per row
+        //  would expose the LDS latency 36 times)
+        static_assert(NDX % 9 == 0, "row chunks of 9");
+        const int pcol = lane < NDX ? lane : 0;
 #pragma unroll
-        for (int i = 0; i < NDX; i++)
-          if (lane >= i && lane < NDX)
-            g[GK::pt_off(i, i) + lane - i] = s.P[i * NDX + lane];
+        for (int c = 0; c < NDX / 9; c++)
+        {
+          double pv[9];
+#pragma unroll
+          for (int r = 0; r < 9; r++)
+            pv[r] = s.P[(9 * c + r) * NDX + pcol];
+#pragma unroll
+          for (int r = 0; r < 9; r++)
+            if (lane >= 9 * c + r && lane < NDX)
+              g[GK::pt_off(9 * c + r, 9 * c + r) + lane - (9 * c + r)] = pv[r];
+        }
 #pragma unroll
         for (int n = 0; n < NAB_PL; n++)
         {
