@@ -715,8 +715,18 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
-      for (int idx = lane; idx < NU * (NDX + 1); idx += NT)
-        g[GK::G_W + idx] = Wm[idx];
+      {
+        // [K | k] out: all LDS reads first, then the stores (a read-wait-store chain per row of 64 exposes the LDS latency 14 times)
+        constexpr int NW = (NU * (NDX + 1) + NT - 1) / NT;
+        double wv[NW];
+#pragma unroll
+        for (int n = 0; n < NW; n++)
+          wv[n] = Wm[lane + n * NT < NU * (NDX + 1) ? lane + n * NT : 0];
+#pragma unroll
+        for (int n = 0; n < NW; n++)
+          if (lane + n * NT < NU * (NDX + 1))
+            g[GK::G_W + lane + n * NT] = wv[n];
+      }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 13, tprev);
     }
