@@ -59,6 +59,9 @@
 #define SMPC_ACCV(name, t, v) name[t][v]
 #define SMPC_MFMA(acc, t, av, ia, bv, ib) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ia], bv[ib], acc[t], 0, 0, 0)
 #define SMPC_CLOCK() ((long long)__builtin_readcyclecounter())
+// an int the compiler cannot see through: loads addressed with it stay after this point (the optimiser otherwise
+// hoists loads of read-only buffers across whole phases and then spills what it loaded)
+#define SMPC_PIN(x) ::smpc::pin_int(x)
 // 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps (full FP64 accuracy, no division)
 #define SMPC_RSQRT(x) ::smpc::rsqrt_nr(x)
 // 1/x: hardware estimate (v_rcp_f64) + two Newton steps (a full IEEE division is ~3x the dependent latency)
@@ -66,6 +69,11 @@
 
 namespace smpc
 {
+  __device__ __forceinline__ int pin_int(int x)
+  {
+    asm volatile("" : "+v"(x));
+    return x;
+  }
   typedef double d4 __attribute__((ext_vector_type(4)));
   __device__ __forceinline__ double readlane_f64(double v, int src)
   {

@@ -295,8 +295,9 @@ namespace smpc
       SMPC_ACC(hacc, NT, 10); // H^ = [Q S; S^T R] + [A|B]^T P~ [A|B], upper tiles; swept in place
       constexpr int NAB_PL = (NG * NXU + NT - 1) / NT, CC_PL = (NG * NDX + NT - 1) / NT;
       SMPC_PLA(double, nab_pf, NT, NAB_PL);
-      SMPC_PLA(double, cc_pf, NT, CC_PL);
-      SMPC_PLA(double, vec_pf, NT, 4);
+      SMPC_PL(double, vq_pf, NT);                   // q / r of the stage (one double per lane)
+      SMPC_PL(double, touch_c, NT);
+      SMPC_PL(double, touch_b, NT);
       // ---- (1) f ; save p_{t+1} ; pt0 = p + P f ----
       SMPC_LANES(NT)
       if (lane < NDX)
@@ -317,8 +318,9 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 1, tprev);
-      // ---- (2b) register prefetch of the dense rows of [A|B], the contact rows of C and the stage vectors;
-      //           the latency overlaps with the P~ product ----
+      // ---- (2b) register prefetch of the dense rows of [A|B]: the latency overlaps with the P~ sweep.  (The contact rows
+      //           of C and the stage vectors are fetched after the sweep, once the [A|B] registers are free again: held
+      //           across the sweep's 15 accumulator tiles they were spilled right after the load, i.e. waited for) ----
       SMPC_LANES(NT)
       {
 #pragma unroll
@@ -329,18 +331,6 @@ namespace smpc
           // (address selects, one load each: a select on a loaded VALUE would make the wave wait for it here)
           SMPC_PLV(nab_pf)[n] = lq[j < NDX ? D::O_A + IX::G(gi) * NDX + j : D::O_B + IX::G(gi) * NU + j - NDX];
         }
-#pragma unroll
-        for (int n = 0; n < CC_PL; n++)
-        {
-          const int idx = lane + n * NT;
-          const int r = idx < NG * NDX ? idx / NDX : 0;
-          SMPC_PLV(cc_pf)[n] = lq[D::O_C + (NA + r) * NDX + idx % NDX];
-        }
-        // (values of out-of-range lanes are never used: clamp the index instead of masking the value)
-        SMPC_PLV(vec_pf)[0] = lq[lane < NDX ? D::O_q + lane : (lane < NXU ? D::O_r + lane - NDX : D::O_q)];
-        SMPC_PLV(vec_pf)[1] = lq[D::O_d + NA + (lane < NG ? lane : 0)];
-        SMPC_PLV(vec_pf)[2] = lq[D::O_C + (lane < NA ? lane * NDX + 6 + lane : 0)]; // 1 if the box row is active
-        SMPC_PLV(vec_pf)[3] = lq[D::O_d + (lane < NA ? lane : 0)];
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 2, tprev);
@@ -449,6 +439,14 @@ namespace smpc
           if (idx < NG * NXU)
             NAB[idx] = SMPC_PLV(nab_pf)[n];
         }
+        // The contact rows of C, d and the box selectors are consumed after the products.  Eleven prefetch registers per lane
+        // do not survive the products' accumulator tiles (the compiler spilled them right after the load, i.e. waited for
+        // every one of them), so the lines are only TOUCHED here -- one load per 64-byte line, two registers -- which
+        // brings them into L2; the real loads in (5) then return in one L2 round trip.
+        static_assert(NG * NDX <= 54 * 8 && NA + NG <= 24 && NA <= NT, "line touches: 54 lines of C, 3 of d, one per box row");
+        SMPC_PLV(touch_c) = lq[lane < 54 ? D::O_C + NA * NDX + lane * 8 : D::O_d + (lane < 57 ? (lane - 54) * 8 : 0)];
+        SMPC_PLV(touch_b) = lq[D::O_C + (lane < NA ? lane * NDX + 6 + lane : 0)];
+        SMPC_PLV(vq_pf) = lq[lane < NDX ? D::O_q + lane : (lane < NXU ? D::O_r + lane - NDX : D::O_q)];
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 5, tprev);
@@ -557,7 +555,7 @@ namespace smpc
           if (lane < NXU)
           {
             const int j = lane;
-            double acc = SMPC_PLV(vec_pf)[0];
+            double acc = SMPC_PLV(vq_pf);
             if (j < NDX)
             {
               if (IX::isQj(j))
@@ -594,20 +592,37 @@ namespace smpc
       //          [q^ + C^T d / mu ; r^] goes into column NXU of the H^ grid ----
       SMPC_LANES(NT)
       {
+        // (all loads first -- index clamped, values of out-of-range lanes unused --, then the LDS commits)
+        double ccv[CC_PL];
+        const int pl = SMPC_PIN(lane); // (keeps these loads here: hoisted above the products they are spilled)
+        static_assert(NT * CC_PL >= NG * NDX && NT * (CC_PL - 1) < NG * NDX, "the contact rows of C: CC_PL per lane");
+#pragma unroll
+        for (int n = 0; n < CC_PL; n++)
+        {
+          // the contact rows are one contiguous run of C
+          const int idx = pl + n * NT;
+          ccv[n] = lq[D::O_C + NA * NDX + (idx < NG * NDX ? idx : 0)];
+        }
+        const double vdc = lq[D::O_d + NA + (pl < NG ? pl : 0)];
+        const double vba = lq[D::O_C + (pl < NA ? pl * NDX + 6 + pl : 0)]; // 1 if the box row is active
+        const double vbd = lq[D::O_d + (pl < NA ? pl : 0)];
 #pragma unroll
         for (int n = 0; n < CC_PL; n++)
         {
           const int idx = lane + n * NT;
           if (idx < NG * NDX)
-            Cc[idx] = SMPC_PLV(cc_pf)[n];
+            Cc[idx] = ccv[n];
         }
         if (lane < NG)
-          s.dc[lane] = SMPC_PLV(vec_pf)[1];
+          s.dc[lane] = vdc;
         if (lane < NA)
         {
-          s.boxact[lane] = SMPC_PLV(vec_pf)[2];
-          s.boxd[lane] = SMPC_PLV(vec_pf)[3];
+          s.boxact[lane] = vba;
+          s.boxd[lane] = vbd;
         }
+        // the line touches end here (their values are irrelevant: the branch is never taken)
+        if (SMPC_PLV(touch_c) + SMPC_PLV(touch_b) == 1.2345678912345e300)
+          s.dc[0] = 0.0;
       }
       SMPC_LANES_END_WAVE
       {
