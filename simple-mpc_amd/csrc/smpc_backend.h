@@ -62,6 +62,9 @@
 // an int the compiler cannot see through: loads addressed with it stay after this point (the optimiser otherwise
 // hoists loads of read-only buffers across whole phases and then spills what it loaded)
 #define SMPC_PIN(x) ::smpc::pin_int(x)
+// fire-and-forget touch of one cache line per lane: a 4-byte load that lands in an LDS sink nobody reads -- no destination
+// register, hence nothing to wait for and nothing to spill; the line is in L2 when the real load comes
+#define SMPC_TOUCH(gptr, lds_sink) ::smpc::touch_line((gptr), (lds_sink))
 // 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps (full FP64 accuracy, no division)
 #define SMPC_RSQRT(x) ::smpc::rsqrt_nr(x)
 // 1/x: hardware estimate (v_rcp_f64) + two Newton steps (a full IEEE division is ~3x the dependent latency)
@@ -73,6 +76,12 @@ namespace smpc
   {
     asm volatile("" : "+v"(x));
     return x;
+  }
+  __device__ __forceinline__ void touch_line(const void * gptr, void * lds_sink)
+  {
+    // LDS destination of lane l: M0 + 4 l (the sink is 256 bytes)
+    const unsigned lds_off = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds_sink;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(gptr), "s"(lds_off) : "memory", "m0");
   }
   typedef double d4 __attribute__((ext_vector_type(4)));
   __device__ __forceinline__ double readlane_f64(double v, int src)

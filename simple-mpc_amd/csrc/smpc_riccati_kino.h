@@ -245,6 +245,7 @@ namespace smpc
     double scr[SCR];
     double p[NDX], pt0[NDX], pt[NDX], qh[NDX], rh[NU], f[NDX];
     double dc[NG], boxd[D::NA], boxact[D::NA];
+    float sink[64]; // destination of the line touches (never read)
   };
 
   // =============================================================================================
@@ -296,8 +297,6 @@ namespace smpc
       constexpr int NAB_PL = (NG * NXU + NT - 1) / NT, CC_PL = (NG * NDX + NT - 1) / NT;
       SMPC_PLA(double, nab_pf, NT, NAB_PL);
       SMPC_PL(double, vq_pf, NT);                   // q / r of the stage (one double per lane)
-      SMPC_PL(double, touch_c, NT);
-      SMPC_PL(double, touch_b, NT);
       // ---- (1) f ; save p_{t+1} ; pt0 = p + P f ----
       SMPC_LANES(NT)
       if (lane < NDX)
@@ -441,11 +440,11 @@ namespace smpc
         }
         // The contact rows of C, d and the box selectors are consumed after the products.  Eleven prefetch registers per lane
         // do not survive the products' accumulator tiles (the compiler spilled them right after the load, i.e. waited for
-        // every one of them), so the lines are only TOUCHED here -- one load per 64-byte line, two registers -- which
-        // brings them into L2; the real loads in (5) then return in one L2 round trip.
+        // every one of them), so the lines are only TOUCHED here -- one 4-byte load per 64-byte line into an LDS sink, no
+        // register and no wait -- which brings them into L2; the real loads in (5) then return in one L2 round trip.
         static_assert(NG * NDX <= 54 * 8 && NA + NG <= 24 && NA <= NT, "line touches: 54 lines of C, 3 of d, one per box row");
-        SMPC_PLV(touch_c) = lq[lane < 54 ? D::O_C + NA * NDX + lane * 8 : D::O_d + (lane < 57 ? (lane - 54) * 8 : 0)];
-        SMPC_PLV(touch_b) = lq[D::O_C + (lane < NA ? lane * NDX + 6 + lane : 0)];
+        SMPC_TOUCH(lq + (lane < 54 ? D::O_C + NA * NDX + lane * 8 : D::O_d + (lane < 57 ? (lane - 54) * 8 : 0)), s.sink);
+        SMPC_TOUCH(lq + D::O_C + (lane < NA ? lane * NDX + 6 + lane : 0), s.sink);
         SMPC_PLV(vq_pf) = lq[lane < NDX ? D::O_q + lane : (lane < NXU ? D::O_r + lane - NDX : D::O_q)];
       }
       SMPC_LANES_END_WAVE
@@ -620,9 +619,7 @@ namespace smpc
           s.boxact[lane] = vba;
           s.boxd[lane] = vbd;
         }
-        // the line touches end here (their values are irrelevant: the branch is never taken)
-        if (SMPC_PLV(touch_c) + SMPC_PLV(touch_b) == 1.2345678912345e300)
-          s.dc[0] = 0.0;
+
       }
       SMPC_LANES_END_WAVE
       {
