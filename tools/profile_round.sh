@@ -1,0 +1,38 @@
+#!/bin/bash
+# Everything profiles/<tag>_* is made from, in one call on the GPU box:
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r01o'
+# Writes gpurun_out/<tag>_{bench,bench_centroidal}.json, <tag>_kernel_stats.csv, <tag>_pmc_hbm_traffic.json, <tag>_pmc_sq.json;
+# copy them into profiles/ afterwards.  The PMC passes are separate rocprofv3 runs with --kernel-trace only (no other trace
+# domain), FETCH_SIZE and WRITE_SIZE in passes of their own (MI355X_MICROARCH.md, HBM section).
+set -u
+TAG=${1:-rXX}
+cd "$(dirname "$0")/.."
+ROOT=$PWD # (the program is named by an absolute path: rocprofv3 runs from /tmp)
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT/prof_$TAG"
+export TMPDIR=/tmp
+BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+
+python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err" || echo "bench failed"
+tail -1 "$OUT/${TAG}_bench.json" | cut -c1-300
+python3 bench.py --workload centroidal > "$OUT/${TAG}_bench_centroidal.json" 2>> "$OUT/${TAG}_bench.err" || echo "centroidal bench failed"
+
+run_prof() { # name, rocprofv3 options...
+  local name=$1
+  shift
+  (cd /tmp && rocprofv3 "$@" --output-format csv -d "$OUT/prof_$TAG/$name" -o "$name" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/prof_$TAG/$name.log" 2>&1) || echo "$name failed"
+}
+run_prof stats --kernel-trace --stats
+run_prof fetch --kernel-trace --pmc FETCH_SIZE
+run_prof write --kernel-trace --pmc WRITE_SIZE
+run_prof sq1 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_WAIT_ANY SQ_WAIT_INST_ANY
+run_prof sq2 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64
+run_prof sq3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU_TRANS_F64
+
+f() { find "$OUT/prof_$TAG/$1" -name "*$2" | head -1; }
+cp "$(f stats kernel_stats.csv)" "$OUT/${TAG}_kernel_stats.csv" || echo "no kernel stats"
+python3 tools/pmc_summary.py "$(f fetch counter_collection.csv)" "$(f write counter_collection.csv)" "$OUT/${TAG}_pmc_hbm_traffic.json"
+python3 tools/pmc_sq_summary.py "$OUT/${TAG}_pmc_sq.json" "$(f sq1 counter_collection.csv)" "$(f sq2 counter_collection.csv)" "$(f sq3 counter_collection.csv)"
+head -6 "$OUT/${TAG}_kernel_stats.csv" | cut -c1-60,150-260
+# keep the merge-back small
+find "$OUT/prof_$TAG" -name "*.csv" -size +8M -delete
