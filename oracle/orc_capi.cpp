@@ -4,6 +4,7 @@
 // bench.py's cpu_baseline leg.  Nothing in simple-mpc_amd/ links or loads this library.
 #include "../include/smpc_robots_builtin.h"
 #include "orc_mpc_cent.hpp"
+#include "orc_full.hpp"
 #include <chrono>
 #include <cstring>
 #ifdef _OPENMP
@@ -270,6 +271,30 @@ extern "C"
     for (int f = 0; f < m->nfeet; f++)
       for (int i = 0; i < 3; i++)
         feet[3 * f + i] = R.foot_p[f][i];
+  }
+
+  // ---- constrained forward dynamics of the full-dynamics model (orc_full.hpp) ----
+  // x = [q; v], tau (nv - 6), contact mask, Kp / Kd (3) -> a (nv), lam (3 per foot in contact, contact frame),
+  // M (nv x nv), nle (nv), J (3 nc x nv), gamma (3 nc), tau_rnea (nv) = RNEA(q, v, a);  returns the proximal iteration count
+  int orc_full_forward_dynamics(
+    const smpc_robot_model * m, const double * x, const double * tau, unsigned mask, const double * Kp, const double * Kd,
+    double * a, double * lam, double * Mq, double * nle, double * J, double * gamma, double * tau_rnea)
+  {
+    ConstraintDynamics cd(m);
+    for (int i = 0; i < 3; i++)
+    {
+      cd.Kp[i] = Kp[i];
+      cd.Kd[i] = Kd[i];
+    }
+    cd.compute(x, x + m->nq, tau, mask);
+    vec_to(cd.a, a);
+    vec_to(cd.lam, lam);
+    mat_to(cd.Mq, Mq);
+    vec_to(cd.nle, nle);
+    mat_to(cd.Jc, J);
+    vec_to(cd.gamma, gamma);
+    vec_to(cd.rnea(x + m->nq, cd.a.data()), tau_rnea);
+    return cd.prox_iters;
   }
 
   // ---- proximal Riccati on packed knots (row-major, stage-major) ----

@@ -69,6 +69,8 @@ def lib():
     L.orc_kino_deriv.argtypes = [vp, C.c_uint] + [_dp] * 14
     L.orc_kino_term.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
     L.orc_centroidal.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_full_forward_dynamics.argtypes = [vp, _dp, _dp, C.c_uint, _dp, _dp] + [_dp] * 7
+    L.orc_full_forward_dynamics.restype = C.c_int
     L.orc_riccati.argtypes = [C.c_int] * 4 + [C.c_double] + [_dp] * 18
     L.orc_timer_create.restype = vp
     L.orc_timer_create.argtypes = [_bp, C.c_int, C.c_int, C.c_int]
@@ -156,6 +158,16 @@ class Robot:
         hg, Ag, dAgv, com, feet = np.zeros(6), np.zeros((6, self.nv)), np.zeros(6), np.zeros(3), np.zeros((self.nf, 3))
         lib().orc_centroidal(self.ptr, np.ascontiguousarray(x, float), hg, Ag, dAgv, com, feet)
         return dict(hg=hg, Ag=Ag, dAgv=dAgv, com=com, feet=feet)
+
+    def full_forward_dynamics(self, x, tau, mask, Kp=(0, 0, 0), Kd=(0, 0, 0)):
+        """Constrained forward dynamics of the full-dynamics model (oracle/orc_full.hpp)."""
+        nv, nc = self.nv, 3 * bin(int(mask)).count("1")
+        a, lam, M, nle = np.zeros(nv), np.zeros(max(nc, 1)), np.zeros((nv, nv)), np.zeros(nv)
+        J, gamma, tau_rnea = np.zeros((max(nc, 1), nv)), np.zeros(max(nc, 1)), np.zeros(nv)
+        it = lib().orc_full_forward_dynamics(self.ptr, np.ascontiguousarray(x, float), np.ascontiguousarray(tau, float), int(mask),
+                                             np.ascontiguousarray(Kp, float), np.ascontiguousarray(Kd, float), a, lam, M, nle,
+                                             J, gamma, tau_rnea)
+        return dict(a=a, lam=lam[:nc], M=M, nle=nle, J=J[:nc], gamma=gamma[:nc], tau_rnea=tau_rnea, prox_iters=it)
 
 
 def go2_kino_settings(robot):

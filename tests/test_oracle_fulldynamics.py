@@ -1,0 +1,133 @@
+"""Oracle self-validation (CPU) of the first full-dynamics block (oracle/orc_full.hpp): the constrained
+forward dynamics -- CRBA, RNEA, 3-D LOCAL point contacts with Baumgarte corrector, proximal iteration -- against physics
+identities that go through independently validated code (the centroidal quantities of test_oracle_model.py)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+G = np.array([0.0, 0.0, -9.81])
+
+
+@pytest.fixture(scope="module")
+def rb():
+    return O.Robot("go2_like")
+
+
+def _randx(rb, rng, scale=1.0):
+    dx = np.concatenate([rng.normal(size=3) * 0.05, rng.normal(size=3) * 0.3, rng.normal(size=12) * 0.3,
+                         rng.normal(size=6) * 0.5, rng.normal(size=12) * 1.0]) * scale
+    return rb.integrate(rb.x_ref, dx)
+
+
+def _quat_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _base_wrench_to_centroidal(rb, x, w6):
+    """generalized force on the free-flyer dofs (LOCAL base frame) -> wrench about the CoM in world axes"""
+    R, p = _quat_R(x[3:7]), x[:3]
+    com = rb.centroidal(x)["com"]
+    f = R @ w6[:3]
+    return np.concatenate([f, R @ w6[3:] - np.cross(com - p, f)])
+
+
+def test_joint_space_inertia_matches_the_centroidal_momentum(rb):
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        x = _randx(rb, rng)
+        r = rb.full_forward_dynamics(x, np.zeros(rb.nv - 6), 0)
+        M, v = r["M"], x[rb.nq:]
+        assert np.abs(M - M.T).max() == 0.0
+        assert np.linalg.eigvalsh(M).min() > 1e-4
+        # rows of the free-flyer = total momentum in the base frame
+        hg = rb.centroidal(x)["hg"]
+        assert np.abs(_base_wrench_to_centroidal(rb, x, (M @ v)[:6]) - hg).max() < 1e-11
+
+
+def test_free_fall_momentum_rate_is_gravity(rb):
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        x = _randx(rb, rng)
+        tau = rng.normal(size=rb.nv - 6) * 5
+        r = rb.full_forward_dynamics(x, tau, 0)
+        c = rb.centroidal(x)
+        hdot = c["Ag"] @ r["a"] + c["dAgv"]
+        assert np.abs(hdot - np.concatenate([rb.mass * G, np.zeros(3)])).max() < 1e-9
+        assert r["prox_iters"] == 0 and r["lam"].size == 0
+
+
+@pytest.mark.parametrize("mask", [0b1111, 0b0110, 0b1001, 0b0001])
+def test_contact_constraint_and_momentum_balance(rb, mask):
+    rng = np.random.default_rng(2 + mask)
+    for _ in range(4):
+        x = _randx(rb, rng, 0.5)
+        tau = rng.normal(size=rb.nv - 6) * 5
+        r = rb.full_forward_dynamics(x, tau, mask)
+        nc = 3 * bin(mask).count("1")
+        assert r["J"].shape == (nc, rb.nv) and np.linalg.matrix_rank(r["J"]) == nc
+        # the contact points do not accelerate (Kp = Kd = 0): the proximal iteration removes the mu-relaxation
+        assert np.abs(r["J"] @ r["a"] + r["gamma"]).max() < 1e-7
+        assert 1 <= r["prox_iters"] <= 10
+        # Newton-Euler on the whole robot: gravity + contact forces
+        c = rb.centroidal(x)
+        hdot = c["Ag"] @ r["a"] + c["dAgv"]
+        ext = _base_wrench_to_centroidal(rb, x, (r["J"].T @ r["lam"])[:6])
+        assert np.abs(hdot - np.concatenate([rb.mass * G, np.zeros(3)]) - ext).max() < 1e-8
+        # inverse dynamics of the result returns the applied generalized forces
+        applied = np.concatenate([np.zeros(6), tau]) + r["J"].T @ r["lam"]
+        assert np.abs(r["tau_rnea"] - applied).max() < 1e-8
+        assert np.abs(r["M"] @ r["a"] + r["nle"] - applied).max() < 1e-8
+
+
+def test_baumgarte_velocity_term(rb):
+    rng = np.random.default_rng(7)
+    x = _randx(rb, rng, 0.5)
+    tau = rng.normal(size=rb.nv - 6)
+    r0 = rb.full_forward_dynamics(x, tau, 0b1111)
+    Kd = np.array([100.0, 50.0, 20.0])
+    r1 = rb.full_forward_dynamics(x, tau, 0b1111, Kd=Kd)
+    vc = (r0["J"] @ x[rb.nq:]).reshape(4, 3)  # foot velocities in their contact frames
+    assert np.abs((r1["gamma"] - r0["gamma"]).reshape(4, 3) - Kd * vc).max() < 1e-11
+    assert np.abs(r1["J"] @ r1["a"] + r1["gamma"]).max() < 1e-7
+    # position term: pulls the foot to the origin of the universe frame (the reference's joint2 placement)
+    r2 = rb.full_forward_dynamics(x, tau, 0b0001, Kp=[0, 0, 50.0])
+    r3 = rb.full_forward_dynamics(x, tau, 0b0001)
+    d = r2["gamma"] - r3["gamma"]
+    assert abs(d[0]) < 1e-12 and abs(d[1]) < 1e-12 and abs(d[2]) > 1e-3
+
+
+def test_gravity_term_is_the_gradient_of_the_potential(rb):
+    rng = np.random.default_rng(3)
+    x = _randx(rb, rng)
+    x[rb.nq:] = 0.0
+    nle = rb.full_forward_dynamics(x, np.zeros(rb.nv - 6), 0)["nle"]
+    h = 1e-6
+    for k in range(rb.nv):
+        d = np.zeros(2 * rb.nv)
+        d[k] = h
+        pe = [-rb.mass * G @ rb.centroidal(rb.integrate(x, s * d))["com"] for s in (1, -1)]
+        assert abs((pe[0] - pe[1]) / (2 * h) - nle[k]) < 1e-6
+
+
+def test_power_balance_along_the_free_motion(rb):
+    """d/dt (kinetic + potential energy) = joint torque power: pins the Coriolis part of nle (joint rows included)"""
+    rng = np.random.default_rng(4)
+    nv = rb.nv
+
+    def energy(x):
+        r = rb.full_forward_dynamics(x, np.zeros(nv - 6), 0)
+        v = x[rb.nq:]
+        return 0.5 * v @ r["M"] @ v - rb.mass * G @ rb.centroidal(x)["com"]
+
+    for _ in range(3):
+        x = _randx(rb, rng)
+        tau = rng.normal(size=nv - 6) * 3
+        a = rb.full_forward_dynamics(x, tau, 0)["a"]
+        v = x[rb.nq:]
+        h = 1e-4
+        e = [energy(rb.integrate(x, np.concatenate([s * h * v, s * h * a]))) for s in (1, -1)]
+        assert abs((e[0] - e[1]) / (2 * h) - tau @ v[6:]) < 1e-5 * max(1.0, abs(tau @ v[6:]))
