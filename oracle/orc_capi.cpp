@@ -296,6 +296,45 @@ extern "C"
     vec_to(cd.rnea(x + m->nq, cd.a.data()), tau_rnea);
     return cd.prox_iters;
   }
+  // same inputs + proximal accuracy / iteration cap (<= 0: the reference's settings) -> a, lam and their derivatives wrt
+  // the tangent of q, v and tau (row-major; lam rows = 3 per foot in contact), and the RNEA partials at the solution
+  int orc_full_dynamics_derivatives(
+    const smpc_robot_model * m, const double * x, const double * tau, unsigned mask, const double * Kp, const double * Kd,
+    double prox_accuracy, int prox_max_iter, double * a, double * lam, double * da_dq, double * da_dv, double * da_dtau,
+    double * dlam_dq, double * dlam_dv, double * dlam_dtau, double * dtau_dq, double * dtau_dv)
+  {
+    ConstraintDynamics cd(m);
+    for (int i = 0; i < 3; i++)
+    {
+      cd.Kp[i] = Kp[i];
+      cd.Kd[i] = Kd[i];
+    }
+    if (prox_accuracy > 0)
+      cd.prox_accuracy = prox_accuracy;
+    if (prox_max_iter > 0)
+      cd.prox_max_iter = prox_max_iter;
+    cd.compute(x, x + m->nq, tau, mask);
+    cd.derivatives(x + m->nq);
+    vec_to(cd.a, a);
+    vec_to(cd.lam, lam);
+    mat_to(cd.da_dq, da_dq);
+    mat_to(cd.da_dv, da_dv);
+    mat_to(cd.da_dtau, da_dtau);
+    mat_to(cd.dlam_dq, dlam_dq);
+    mat_to(cd.dlam_dv, dlam_dv);
+    mat_to(cd.dlam_dtau, dlam_dtau);
+    mat_to(cd.dtau_dq, dtau_dq);
+    mat_to(cd.dtau_dv, dtau_dv);
+    return cd.prox_iters;
+  }
+  // RNEA(q, v, a) with the gravity field (for the finite-difference checks of the partials)
+  void orc_full_rnea(const smpc_robot_model * m, const double * x, const double * a, double * tau)
+  {
+    ConstraintDynamics cd(m);
+    cd.R.fk(x);
+    cd.R.velocities(x + m->nq);
+    vec_to(cd.rnea(x + m->nq, a), tau);
+  }
 
   // ---- proximal Riccati on packed knots (row-major, stage-major) ----
   void orc_riccati(

@@ -20,7 +20,13 @@
 //   J   : LOCAL linear Jacobian of the foot point;  drift : its classical acceleration at zero joint accelerations
 // The anchor of the corrector is the ORIGIN of the universe frame (joint2 = 0, placement identity), as the reference
 // builds it: with Kp = diag(0, 0, kz) it pulls the foot height to z = 0 (examples/talos_fulldynamics.py:86).
-// Derivatives (d a / d(q, v, tau), d lam / d(q, v, tau)) and the OCP on top are the next block.
+// derivatives() restates pinocchio::computeConstraintDynamicsDerivatives: implicit differentiation of
+//     r1 = RNEA(q, v, a) - S tau - J^T lam = 0,      r2 = (contact acceleration)(q, v, a) + Kd v_c - Kp p_err = 0
+// at the solution, with the partial derivatives of RNEA and of the contact-frame acceleration written in the world-frame
+// formulation of orc_rigid.hpp (d_k = v_lam x S_k, A_k = (a_lam - g) x S_k + v_lam x d_k):
+//     d tau_m / d q_k = S_m . (Ic_s A_k + Bc_s d_k)  [+ S_m . (S_k x* Fc_i) if joint(m) is a strict ancestor of joint(k)]
+//     d tau_m / d v_k = S_m . (Bc_s S_k + Ic_s (v_i x S_k + d_k))        s = the lower of joint(m), joint(k) (same branch)
+// The OCP on top (costs, constraints, integrator) is the next block.
 #pragma once
 #include "orc_rigid.hpp"
 
@@ -43,6 +49,10 @@ namespace orc
     Vec a, lam;          // nv ; 3 n_c (force ON the robot at the foot, contact frame)
     int prox_iters = 0;
     std::vector<int> feet; // feet in contact, in order
+    Mat Lm, MJ, Gc;      // Cholesky factor of M ; M^-1 J^T ; Cholesky factor of the damped Delassus matrix
+    // derivatives() results
+    Mat da_dq, da_dv, da_dtau, dlam_dq, dlam_dv, dlam_dtau;
+    Mat dtau_dq, dtau_dv; // partial derivatives of RNEA(q, v, a) at the solution
 
     explicit ConstraintDynamics(const smpc_robot_model * m) : M(m), R(m), nv(m->nv), nu(m->nv - 6) {}
 
@@ -120,6 +130,7 @@ namespace orc
       // M = L L^T ;  Minv_b = M^-1 (S tau - nle) ;  MJ = M^-1 J^T
       Mat L = Mq;
       cholesky(L);
+      Lm = L;
       Vec b(nv);
       for (int k = 0; k < nv; k++)
         b[k] = (k >= 6 ? tau[k - 6] : 0.0) - nle[k];
@@ -138,6 +149,8 @@ namespace orc
         for (int c = 0; c < nc; c++)
           G(c, c) += prox_mu;
         cholesky(G);
+        Gc = G;
+        this->MJ = MJ;
         const Vec JMb = mul(Jc, Mb);
         for (int it = 0; it < prox_max_iter; it++)
         {
@@ -160,6 +173,134 @@ namespace orc
       }
       else
         a = Mb;
+    }
+
+    bool anc_or_eq(int ja, int jb) const // joint ja is jb or one of its ancestors
+    {
+      for (int j = jb; j >= 0; j = M->parent[j])
+        if (j == ja)
+          return true;
+      return false;
+    }
+    static SV mat_sv(const Mat & B, const SV & x) { return vec_sv(mul(B, sv_vec(x))); }
+
+    // needs compute(); v = the same velocity
+    void derivatives(const double * v)
+    {
+      const int nc = 3 * (int)feet.size();
+      const SV g{v3(gravity[0], gravity[1], gravity[2]), v3(0, 0, 0)};
+      // body accelerations / forces at the solution, gravity included in the composite forces
+      R.forces(v, a.data());
+      R.compute_Bc();
+      std::vector<SV> Fg(R.nj);
+      for (int j = 0; j < R.nj; j++)
+        Fg[j] = R.F[j] - R.I[j] * g;
+      for (int j = R.nj - 1; j > 0; j--)
+        Fg[M->parent[j]] = Fg[M->parent[j]] + Fg[j];
+      std::vector<SV> dk(nv), Ak(nv);
+      for (int k = 0; k < nv; k++)
+      {
+        const int lam_ = M->parent[R.dof2j[k]];
+        dk[k] = lam_ >= 0 ? crm(R.vel[lam_], R.S[k]) : sv_zero();
+        Ak[k] = (lam_ >= 0 ? crm(R.acc[lam_] - g, R.S[k]) + crm(R.vel[lam_], dk[k]) : crm(sv_zero() - g, R.S[k]));
+      }
+      dtau_dq = Mat(nv, nv);
+      dtau_dv = Mat(nv, nv);
+      for (int m = 0; m < nv; m++)
+        for (int k = 0; k < nv; k++)
+        {
+          const int jm = R.dof2j[m], i = R.dof2j[k];
+          int s;
+          bool below = false; // joint(k) strictly below joint(m)
+          if (anc_or_eq(i, jm))
+            s = jm;
+          else if (anc_or_eq(jm, i))
+          {
+            s = i;
+            below = true;
+          }
+          else
+            continue;
+          SV Xq = R.Ic[s] * Ak[k] + mat_sv(R.Bc[s], dk[k]);
+          if (below)
+            Xq = Xq + crf(R.S[k], Fg[i]);
+          const SV Xv = mat_sv(R.Bc[s], R.S[k]) + R.Ic[s] * (crm(R.vel[i], R.S[k]) + dk[k]);
+          dtau_dq(m, k) = sv_dot(R.S[m], Xq);
+          dtau_dv(m, k) = sv_dot(R.S[m], Xv);
+        }
+      // residual partials
+      Mat r1q = dtau_dq, r1v = dtau_dv, r2q(nc, nv), r2v(nc, nv);
+      for (size_t c = 0; c < feet.size(); c++)
+      {
+        const int f = feet[c], l = M->foot_joint[f];
+        const M3 Rf = foot_R(f), Rt = tr(Rf);
+        const V3 p = R.foot_p[f];
+        const V3 lc = v3(lam[3 * c], lam[3 * c + 1], lam[3 * c + 2]);
+        const V3 fw = Rf * lc;
+        const SV W{fw, cross(p, fw)}; // the contact force as a spatial force at the world origin
+        const V3 w = R.vel[l].a;
+        const V3 vp = R.vel[l].l + cross(w, p);
+        for (int k = 0; k < nv; k++)
+        {
+          const int i = R.dof2j[k];
+          if (!anc_or_eq(i, l))
+            continue;
+          // - d(J^T lam)/dq_k: the force moves with the foot; only dofs above joint(k) see a change
+          for (int m = 0; m < nv; m++)
+          {
+            const int jm = R.dof2j[m];
+            if (jm != i && anc_or_eq(jm, i))
+              r1q(m, k) -= sv_dot(R.S[m], crf(R.S[k], W));
+          }
+          // contact acceleration (classical, contact frame): rigid parts of the variation cancel in the local frame
+          const SV & d = dk[k];
+          const int lam_ = M->parent[i];
+          // non-rigid part of the variation of the body acceleration: A_k + d_k x v_l (kinematic: no gravity here)
+          const SV A = lam_ >= 0 ? crm(R.acc[lam_], R.S[k]) + crm(R.vel[lam_], d) + crm(d, R.vel[l]) : sv_zero();
+          const V3 aq = A.l + cross(A.a, p) + cross(d.a, vp) + cross(w, d.l + cross(d.a, p));
+          const SV Av = d + crm(R.S[k], R.vel[l] - R.vel[i]);
+          const V3 av = Av.l + cross(Av.a, p) + cross(R.S[k].a, vp) + cross(w, R.S[k].l + cross(R.S[k].a, p));
+          const V3 vq = d.l + cross(d.a, p);                      // d(point velocity)/dq_k, non-rigid part
+          const V3 vv = R.S[k].l + cross(R.S[k].a, p);            // d(point velocity)/dv_k
+          const V3 cq = Rt * aq, cv = Rt * av, eq = Rt * vq, ev = Rt * vv, pq = (-1.0) * (Rt * R.S[k].l);
+          for (int r = 0; r < 3; r++)
+          {
+            r2q(3 * (int)c + r, k) = cq[r] + Kd[r] * eq[r] - Kp[r] * pq[r];
+            r2v(3 * (int)c + r, k) = cv[r] + Kd[r] * ev[r];
+          }
+        }
+      }
+      // [M -J^T; J mu] [da; dlam] = -[r1; r2]   (the damped factorisation of the forward solve, as the reference's backend)
+      auto solve = [&](const Mat & r1, const Mat & r2, Mat & da, Mat & dl) {
+        const int n = r1.c;
+        Mat Mr = r1; // M^-1 r1
+        chol_solve_inplace(Lm, Mr);
+        da = Mat(nv, n);
+        dl = Mat(nc > 0 ? nc : 0, n);
+        if (nc > 0)
+        {
+          Mat rhs = mul(Jc, Mr);
+          for (int c = 0; c < nc; c++)
+            for (int j = 0; j < n; j++)
+              rhs(c, j) -= r2(c, j);
+          chol_solve_inplace(Gc, rhs);
+          dl = rhs;
+        }
+        for (int k = 0; k < nv; k++)
+          for (int j = 0; j < n; j++)
+          {
+            double acc_ = -Mr(k, j);
+            for (int c = 0; c < nc; c++)
+              acc_ += MJ(k, c) * dl(c, j);
+            da(k, j) = acc_;
+          }
+      };
+      solve(r1q, r2q, da_dq, dlam_dq);
+      solve(r1v, r2v, da_dv, dlam_dv);
+      Mat r1t(nv, nu), r2t(nc, nu);
+      for (int j = 0; j < nu; j++)
+        r1t(6 + j, j) = -1.0;
+      solve(r1t, r2t, da_dtau, dlam_dtau);
     }
   };
 } // namespace orc

@@ -71,6 +71,9 @@ def lib():
     L.orc_centroidal.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_full_forward_dynamics.argtypes = [vp, _dp, _dp, C.c_uint, _dp, _dp] + [_dp] * 7
     L.orc_full_forward_dynamics.restype = C.c_int
+    L.orc_full_dynamics_derivatives.argtypes = [vp, _dp, _dp, C.c_uint, _dp, _dp, C.c_double, C.c_int] + [_dp] * 10
+    L.orc_full_dynamics_derivatives.restype = C.c_int
+    L.orc_full_rnea.argtypes = [vp, _dp, _dp, _dp]
     L.orc_riccati.argtypes = [C.c_int] * 4 + [C.c_double] + [_dp] * 18
     L.orc_timer_create.restype = vp
     L.orc_timer_create.argtypes = [_bp, C.c_int, C.c_int, C.c_int]
@@ -168,6 +171,25 @@ class Robot:
                                              np.ascontiguousarray(Kp, float), np.ascontiguousarray(Kd, float), a, lam, M, nle,
                                              J, gamma, tau_rnea)
         return dict(a=a, lam=lam[:nc], M=M, nle=nle, J=J[:nc], gamma=gamma[:nc], tau_rnea=tau_rnea, prox_iters=it)
+
+    def full_dynamics_derivatives(self, x, tau, mask, Kp=(0, 0, 0), Kd=(0, 0, 0), prox_accuracy=0.0, prox_max_iter=0):
+        nv, nu, nc = self.nv, self.nv - 6, 3 * bin(int(mask)).count("1")
+        n1 = max(nc, 1)
+        o = dict(a=np.zeros(nv), lam=np.zeros(n1), da_dq=np.zeros((nv, nv)), da_dv=np.zeros((nv, nv)), da_dtau=np.zeros((nv, nu)),
+                 dlam_dq=np.zeros((n1, nv)), dlam_dv=np.zeros((n1, nv)), dlam_dtau=np.zeros((n1, nu)),
+                 dtau_dq=np.zeros((nv, nv)), dtau_dv=np.zeros((nv, nv)))
+        it = lib().orc_full_dynamics_derivatives(self.ptr, np.ascontiguousarray(x, float), np.ascontiguousarray(tau, float), int(mask),
+                                                 np.ascontiguousarray(Kp, float), np.ascontiguousarray(Kd, float),
+                                                 float(prox_accuracy), int(prox_max_iter), *o.values())
+        for k in ("lam", "dlam_dq", "dlam_dv", "dlam_dtau"):
+            o[k] = o[k][:nc]
+        o["prox_iters"] = it
+        return o
+
+    def full_rnea(self, x, a):
+        tau = np.zeros(self.nv)
+        lib().orc_full_rnea(self.ptr, np.ascontiguousarray(x, float), np.ascontiguousarray(a, float), tau)
+        return tau
 
 
 def go2_kino_settings(robot):

@@ -131,3 +131,58 @@ def test_power_balance_along_the_free_motion(rb):
         h = 1e-4
         e = [energy(rb.integrate(x, np.concatenate([s * h * v, s * h * a]))) for s in (1, -1)]
         assert abs((e[0] - e[1]) / (2 * h) - tau @ v[6:]) < 1e-5 * max(1.0, abs(tau @ v[6:]))
+
+
+def _fd(fun, rb, x, h=1e-6):
+    """central differences along the tangent of the phase space: columns [q tangent (nv) | v (nv)]"""
+    cols = []
+    for k in range(2 * rb.nv):
+        d = np.zeros(2 * rb.nv)
+        d[k] = h
+        cols.append((fun(rb.integrate(x, d)) - fun(rb.integrate(x, -d))) / (2 * h))
+    return np.array(cols).T
+
+
+@pytest.mark.parametrize("mask", [0b1111, 0b0110, 0])
+def test_rnea_partials_against_finite_differences(rb, mask):
+    rng = np.random.default_rng(11 + mask)
+    x = _randx(rb, rng, 0.7)
+    tau = rng.normal(size=rb.nv - 6) * 4
+    r = rb.full_dynamics_derivatives(x, tau, mask)
+    num = _fd(lambda xx: rb.full_rnea(xx, r["a"]), rb, x)
+    scale = max(1.0, np.abs(num).max())
+    assert np.abs(r["dtau_dq"] - num[:, :rb.nv]).max() < 2e-7 * scale
+    assert np.abs(r["dtau_dv"] - num[:, rb.nv:]).max() < 2e-7 * scale
+
+
+@pytest.mark.parametrize("mask,Kp,Kd", [(0b1111, (0, 0, 0), (0, 0, 0)), (0b1001, (0, 0, 0), (0, 0, 0)),
+                                        (0b0110, (0, 0, 50.0), (100.0, 100.0, 100.0)), (0, (0, 0, 0), (0, 0, 0))])
+def test_constraint_dynamics_derivatives_against_finite_differences(rb, mask, Kp, Kd):
+    rng = np.random.default_rng(23 + mask)
+    x = _randx(rb, rng, 0.5)
+    tau = rng.normal(size=rb.nv - 6) * 4
+    kw = dict(Kp=Kp, Kd=Kd, prox_accuracy=1e-14, prox_max_iter=60)
+    r = rb.full_dynamics_derivatives(x, tau, mask, **kw)
+    nv, nc = rb.nv, 3 * bin(mask).count("1")
+
+    def sol(xx, tt=tau):
+        o = rb.full_dynamics_derivatives(xx, tt, mask, **kw)
+        return np.concatenate([o["a"], o["lam"]])
+
+    num = _fd(sol, rb, x)
+    sa, sl = max(1.0, np.abs(num[:nv]).max()), max(1.0, np.abs(num[nv:]).max() if nc else 1.0)
+    assert np.abs(r["da_dq"] - num[:nv, :nv]).max() < 1e-6 * sa
+    assert np.abs(r["da_dv"] - num[:nv, nv:]).max() < 1e-6 * sa
+    if nc:
+        assert np.abs(r["dlam_dq"] - num[nv:, :nv]).max() < 1e-6 * sl
+        assert np.abs(r["dlam_dv"] - num[nv:, nv:]).max() < 1e-6 * sl
+    h = 1e-5
+    cols = []
+    for j in range(nv - 6):
+        d = np.zeros(nv - 6)
+        d[j] = h
+        cols.append((sol(x, tau + d) - sol(x, tau - d)) / (2 * h))
+    numt = np.array(cols).T
+    assert np.abs(r["da_dtau"] - numt[:nv]).max() < 1e-7 * max(1.0, np.abs(numt).max())
+    if nc:
+        assert np.abs(r["dlam_dtau"] - numt[nv:]).max() < 1e-7 * max(1.0, np.abs(numt).max())
