@@ -4,7 +4,7 @@
 // bench.py's cpu_baseline leg.  Nothing in simple-mpc_amd/ links or loads this library.
 #include "../include/smpc_robots_builtin.h"
 #include "orc_mpc_cent.hpp"
-#include "orc_full.hpp"
+#include "orc_fulldyn.hpp"
 #include <chrono>
 #include <cstring>
 #ifdef _OPENMP
@@ -326,6 +326,140 @@ extern "C"
     mat_to(cd.dtau_dq, dtau_dq);
     mat_to(cd.dtau_dv, dtau_dv);
     return cd.prox_iters;
+  }
+  // ---- full-dynamics stage model (orc_fulldyn.hpp) ----
+  void * orc_full_create(
+    const smpc_robot_model * m, double dt, const double * w_x, const double * w_u, const double * w_cent, const double * w_forces,
+    const double * w_frame, const double * gravity, const double * Kp, const double * Kd, const double * umin,
+    const double * umax, const double * qmin, const double * qmax, int torque_limits, int kinematics_limits)
+  {
+    FullSettings s;
+    const int ndx = 2 * m->nv, nu = m->nv - 6;
+    s.timestep = dt;
+    s.w_x = mat_from(w_x, ndx, ndx);
+    s.w_u = mat_from(w_u, nu, nu);
+    s.w_cent = mat_from(w_cent, 6, 6);
+    s.w_forces = mat_from(w_forces, 3, 3);
+    s.w_frame = mat_from(w_frame, 3, 3);
+    for (int i = 0; i < 3; i++)
+    {
+      s.gravity[i] = gravity[i];
+      s.Kp[i] = Kp[i];
+      s.Kd[i] = Kd[i];
+    }
+    s.umin.assign(umin, umin + nu);
+    s.umax.assign(umax, umax + nu);
+    s.qmin.assign(qmin, qmin + nu);
+    s.qmax.assign(qmax, qmax + nu);
+    s.torque_limits = torque_limits != 0;
+    s.kinematics_limits = kinematics_limits != 0;
+    return new FullModel(m, s);
+  }
+  void orc_full_destroy(void * h) { delete (FullModel *)h; }
+  void orc_full_dims(void * h, int * out) // nx ndx nu nc nf
+  {
+    FullModel * md = (FullModel *)h;
+    out[0] = md->nx;
+    out[1] = md->ndx;
+    out[2] = md->nu;
+    out[3] = md->nc;
+    out[4] = md->nf;
+  }
+  static StageRef full_ref(const FullModel & md, unsigned mask, const double * u_ref, const double * x_tgt, const double * foot_ref)
+  {
+    StageRef r;
+    r.mask = mask;
+    r.u_ref.assign(u_ref, u_ref + md.nu + 3 * md.nf); // [control reference ; force reference per foot]
+    r.x_tgt.assign(x_tgt, x_tgt + md.nx);
+    r.foot_ref.resize(md.nf);
+    for (int f = 0; f < md.nf; f++)
+      r.foot_ref[f] = v3(foot_ref[3 * f], foot_ref[3 * f + 1], foot_ref[3 * f + 2]);
+    return r;
+  }
+  void orc_full_eval(
+    void * h, unsigned mask, const double * u_ref, const double * x_tgt, const double * foot_ref, const double * x,
+    const double * u, double * xnext, double * xdot, double * cost, double * c)
+  {
+    FullModel * md = (FullModel *)h;
+    Rigid R(md->M);
+    StageEval o;
+    md->eval(R, full_ref(*md, mask, u_ref, x_tgt, foot_ref), x, u, o);
+    vec_to(o.xnext, xnext);
+    vec_to(o.xdot, xdot);
+    *cost = o.cost;
+    vec_to(o.c, c);
+  }
+  void orc_full_deriv(
+    void * h, unsigned mask, const double * u_ref, const double * x_tgt, const double * foot_ref, const double * x,
+    const double * u, double * A, double * B, double * lx, double * lu, double * Lxx, double * Lxu, double * Luu,
+    double * Cx, double * Cu)
+  {
+    FullModel * md = (FullModel *)h;
+    Rigid R(md->M);
+    StageDer o;
+    md->deriv(R, full_ref(*md, mask, u_ref, x_tgt, foot_ref), x, u, o);
+    mat_to(o.A, A);
+    mat_to(o.B, B);
+    vec_to(o.lx, lx);
+    vec_to(o.lu, lu);
+    mat_to(o.Lxx, Lxx);
+    mat_to(o.Lxu, Lxu);
+    mat_to(o.Luu, Luu);
+    mat_to(o.Cx, Cx);
+    mat_to(o.Cu, Cu);
+  }
+  // ProxDDP on an H-stage problem with the same references at every stage (masks per stage), from the constant guess
+  // (x0, u0): up to max_iter iterations with the stopping rules of the cold solve (orc_mpc.hpp).  trace: [iter][6] =
+  // prim_infeas, dual_infeas, cost, phi0, alpha, ls_failed.  Returns the iteration count.
+  int orc_full_solve(
+    void * h, int H, const unsigned * masks, const double * u_ref, const double * x_tgt, const double * foot_ref,
+    const double * x0, const double * u0, int max_iter, double tol, double mu, double * trace, double * xs, double * us)
+  {
+    FullModel * md = (FullModel *)h;
+    Rigid R(md->M);
+    OcpInstance o;
+    for (int t = 0; t < H; t++)
+      o.stages.push_back(full_ref(*md, masks[t], u_ref, x_tgt, foot_ref));
+    o.x_tgt_term.assign(x_tgt, x_tgt + md->nx);
+    SolverState S;
+    S.xs.assign(H + 1, Vec(x0, x0 + md->nx));
+    S.us.assign(H, Vec(u0, u0 + md->nu));
+    S.vs.assign(H, Vec(md->nc, 0.0));
+    S.lams.assign(H + 1, Vec(md->ndx, 0.0));
+    ProxDDPT<FullModel> solver(*md, mu);
+    std::vector<Vec> vs_e = S.vs, lams_e = S.lams;
+    int it = 0;
+    for (; it < max_iter; it++)
+    {
+      const IterInfo info = solver.iterate(R, o, S, vs_e, lams_e);
+      double * tr = trace + 6 * it;
+      tr[0] = info.prim_infeas;
+      tr[1] = info.dual_infeas;
+      tr[2] = info.cost;
+      tr[3] = info.phi0;
+      tr[4] = info.alpha;
+      tr[5] = info.ls_failed;
+      if (std::fmax(info.prim_infeas, info.dual_infeas) <= tol)
+      {
+        it++;
+        break;
+      }
+      if (std::fabs(info.dphi0) <= SolverConsts::STALL_REL * std::fmax(1.0, std::fabs(info.phi0)))
+      {
+        it++;
+        break;
+      }
+      if (info.dual_infeas <= tol)
+      {
+        vs_e = S.vs;
+        lams_e = S.lams;
+      }
+    }
+    for (int t = 0; t <= H; t++)
+      std::memcpy(xs + (size_t)t * md->nx, S.xs[t].data(), sizeof(double) * md->nx);
+    for (int t = 0; t < H; t++)
+      std::memcpy(us + (size_t)t * md->nu, S.us[t].data(), sizeof(double) * md->nu);
+    return it;
   }
   // RNEA(q, v, a) with the gravity field (for the finite-difference checks of the partials)
   void orc_full_rnea(const smpc_robot_model * m, const double * x, const double * a, double * tau)

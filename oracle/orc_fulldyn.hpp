@@ -1,0 +1,295 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_linalg.hpp header).  PARITY UNPINNED.
+//
+// orc_fulldyn.hpp: the stage model of the full-dynamics OCP, restating what
+// FullDynamicsOCP::createStage composes from Aligator pieces [REF src/fulldynamics.cpp:78-214] for 3-D feet
+// (force_size 3, the Go2 configuration of examples/go2_fulldynamics.py and benchmark/go2.cpp):
+//   state  x = (q, v) on SE3 x R^(nq-7) x R^nv, control u = joint torques (nu = nv - 6) [REF src/ocp-handler.cpp:15-18]
+//   dynamics   MultibodyConstraintFwdDynamics(actuation [0; I], contacts of the stage) + IntegratorSemiImplEuler
+//              [REF src/fulldynamics.cpp:139-140]  -> orc_full.hpp
+//   costs      state_cost (x (-) x_ref, w_x), control_cost (u - 0, w_u), centroidal_cost (hg(q, v), w_cent),
+//              <foot>_pose_cost (FrameTranslationResidual, w_frame) for EVERY foot, <foot>_force_cost
+//              (ContactForceResidual: contact force of the constrained dynamics - reference, w_forces) for the feet in
+//              contact [REF src/fulldynamics.cpp:88-137]
+//   constraints  torque box  umin <= u <= umax  (ControlErrorResidual, rows 0 .. nu-1) if torque_limits;
+//              joint box  qmin <= (x (-) neutral)[6 .. nv) <= qmax  (rows nu .. nu+nv-7) if kinematics_limits
+//              [REF src/fulldynamics.cpp:144-162]
+//   terminal   state_cost + 10 x centroidal_cost [REF src/fulldynamics.cpp:418-430]
+// force_cone / land_cstr rows [REF :164-211] and 6-D feet are not restated yet.
+// StageRef::u_ref carries [control reference (nu) ; force reference per foot (3 nf)] for this model.
+#pragma once
+#include "orc_full.hpp"
+#include "orc_kino.hpp"
+
+namespace orc
+{
+  struct FullSettings // mirrors FullDynamicsSettings (include/simple-mpc/fulldynamics.hpp:28-65)
+  {
+    double timestep = 0.01;
+    Mat w_x, w_u, w_cent, w_forces, w_frame;
+    double gravity[3] = {0, 0, -9.81};
+    double mu = 0.8;
+    bool torque_limits = true, kinematics_limits = true;
+    Vec umin, umax, qmin, qmax;
+    double Kp[3] = {0, 0, 0}, Kd[3] = {0, 0, 0};
+  };
+
+  struct FullModel
+  {
+    const smpc_robot_model * M;
+    FullSettings s;
+    int nq, nv, nx, ndx, nu, nf, nc;
+
+    FullModel(const smpc_robot_model * m, const FullSettings & st) : M(m), s(st)
+    {
+      nq = m->nq;
+      nv = m->nv;
+      nx = nq + nv;
+      ndx = 2 * nv;
+      nu = nv - 6;
+      nf = m->nfeet;
+      nc = nu + (nv - 6);
+    }
+    int row_kind(const StageRef &, int row) const
+    {
+      if (row < nu)
+        return s.torque_limits ? ROW_BOX : ROW_ABSENT;
+      return s.kinematics_limits ? ROW_BOX : ROW_ABSENT;
+    }
+    double row_lo_v(int row) const { return row < nu ? s.umin[row] : s.qmin[row - nu]; }
+    double row_hi_v(int row) const { return row < nu ? s.umax[row] : s.qmax[row - nu]; }
+    void integrate(const double * x, const double * dx, double * out) const { x_integrate(nq, nv, x, dx, out); }
+    void difference(const double * x0, const double * x1, double * out) const { x_difference(nq, nv, x0, x1, out); }
+
+    ConstraintDynamics dynamics() const
+    {
+      ConstraintDynamics cd(M);
+      for (int i = 0; i < 3; i++)
+      {
+        cd.gravity[i] = s.gravity[i];
+        cd.Kp[i] = s.Kp[i];
+        cd.Kd[i] = s.Kd[i];
+      }
+      return cd;
+    }
+    static double quad(const Mat & W, const Vec & r) { return 0.5 * dot(r, mul(W, r)); }
+
+    void eval(Rigid & R, const StageRef & r, const double * x, const double * u, StageEval & o) const
+    {
+      const double dt = s.timestep;
+      ConstraintDynamics cd = dynamics();
+      cd.compute(x, x + nq, u, r.mask);
+      o.xdot.assign(2 * nv, 0.0);
+      Vec dx(ndx);
+      for (int i = 0; i < nv; i++)
+      {
+        o.xdot[i] = x[nq + i];
+        o.xdot[nv + i] = cd.a[i];
+        dx[nv + i] = dt * cd.a[i];
+        dx[i] = dt * (x[nq + i] + dx[nv + i]);
+      }
+      o.xnext.assign(nx, 0.0);
+      x_integrate(nq, nv, x, dx.data(), o.xnext.data());
+      double cost = 0;
+      Vec rx(ndx);
+      x_difference(nq, nv, r.x_tgt.data(), x, rx.data());
+      cost += quad(s.w_x, rx);
+      Vec ru(nu);
+      for (int i = 0; i < nu; i++)
+        ru[i] = u[i] - r.u_ref[i];
+      cost += quad(s.w_u, ru);
+      cost += quad(s.w_cent, sv_vec(cd.R.hg()));
+      for (int f = 0; f < nf; f++)
+      {
+        const V3 e = cd.R.foot_p[f] - r.foot_ref[f];
+        cost += quad(s.w_frame, Vec{e[0], e[1], e[2]});
+      }
+      for (size_t c = 0; c < cd.feet.size(); c++)
+      {
+        const int f = cd.feet[c];
+        Vec e(3);
+        for (int i = 0; i < 3; i++)
+          e[i] = cd.lam[3 * c + i] - r.u_ref[nu + 3 * f + i];
+        cost += quad(s.w_forces, e);
+      }
+      o.cost = cost;
+      o.c.assign(nc, 0.0);
+      if (s.torque_limits)
+        for (int i = 0; i < nu; i++)
+          o.c[i] = u[i];
+      if (s.kinematics_limits)
+        for (int i = 0; i < nv - 6; i++)
+          o.c[nu + i] = x[7 + i];
+      R = cd.R;
+    }
+
+    void deriv(Rigid & R, const StageRef & r, const double * x, const double * u, StageDer & o) const
+    {
+      const double dt = s.timestep;
+      ConstraintDynamics cd = dynamics();
+      cd.compute(x, x + nq, u, r.mask);
+      cd.derivatives(x + nq);
+      const Vec & a = cd.a;
+      // d(dx)/dx and d(dx)/du, dx = [dt (v + dt a); dt a]  (semi-implicit Euler, as orc_kino.hpp)
+      Mat Dx(ndx, ndx), Du(ndx, nu);
+      for (int i = 0; i < nv; i++)
+      {
+        for (int k = 0; k < nv; k++)
+        {
+          Dx(nv + i, k) = dt * cd.da_dq(i, k);
+          Dx(nv + i, nv + k) = dt * cd.da_dv(i, k);
+          Dx(i, k) = dt * dt * cd.da_dq(i, k);
+          Dx(i, nv + k) = dt * dt * cd.da_dv(i, k);
+        }
+        Dx(i, nv + i) += dt;
+        for (int k = 0; k < nu; k++)
+        {
+          Du(nv + i, k) = dt * cd.da_dtau(i, k);
+          Du(i, k) = dt * dt * cd.da_dtau(i, k);
+        }
+      }
+      double nu6[6];
+      for (int i = 0; i < 6; i++)
+        nu6[i] = dt * (x[nq + i] + dt * a[i]);
+      const Mat Je = Jexp6(nu6);
+      const Mat Jq = action_matrix(inv(exp6(nu6)));
+      o.A.resize(ndx, ndx);
+      o.B.resize(ndx, nu);
+      for (int i = 0; i < ndx; i++)
+      {
+        for (int k = 0; k < ndx; k++)
+        {
+          double sacc = 0;
+          if (i < 6)
+            for (int m = 0; m < 6; m++)
+              sacc += Je(i, m) * Dx(m, k);
+          else
+            sacc = Dx(i, k);
+          o.A(i, k) = sacc;
+        }
+        for (int k = 0; k < nu; k++)
+        {
+          double sacc = 0;
+          if (i < 6)
+            for (int m = 0; m < 6; m++)
+              sacc += Je(i, m) * Du(m, k);
+          else
+            sacc = Du(i, k);
+          o.B(i, k) = sacc;
+        }
+      }
+      for (int i = 0; i < 6; i++)
+        for (int k = 0; k < 6; k++)
+          o.A(i, k) += Jq(i, k);
+      for (int i = 6; i < ndx; i++)
+        o.A(i, i) += 1.0;
+
+      o.lx.assign(ndx, 0.0);
+      o.lu.assign(nu, 0.0);
+      o.Lxx.resize(ndx, ndx);
+      o.Lxu.resize(ndx, nu);
+      o.Luu.resize(nu, nu);
+      auto add_cost = [&](const Mat & W, const Vec & res, const Mat & Jx, const Mat * Ju) {
+        const Vec Wr = mul(W, res);
+        axpy(o.lx, mulT(Jx, Wr));
+        const Mat WJx = mul(W, Jx);
+        add_inplace(o.Lxx, mulTN(Jx, WJx));
+        if (Ju)
+        {
+          axpy(o.lu, mulT(*Ju, Wr));
+          const Mat WJu = mul(W, *Ju);
+          add_inplace(o.Lxu, mulTN(Jx, WJu));
+          add_inplace(o.Luu, mulTN(*Ju, WJu));
+        }
+      };
+      { // state cost
+        Vec rx(ndx);
+        x_difference(nq, nv, r.x_tgt.data(), x, rx.data());
+        SE3 Mt{quat_to_R(r.x_tgt.data() + 3), v3(r.x_tgt[0], r.x_tgt[1], r.x_tgt[2])};
+        SE3 Mx{quat_to_R(x + 3), v3(x[0], x[1], x[2])};
+        const Mat Jl = Jlog6(inv(Mt) * Mx);
+        Mat Jx = Mat::identity(ndx);
+        for (int i = 0; i < 6; i++)
+          for (int k = 0; k < 6; k++)
+            Jx(i, k) = Jl(i, k);
+        add_cost(s.w_x, rx, Jx, nullptr);
+      }
+      { // control cost
+        Vec ru(nu);
+        for (int i = 0; i < nu; i++)
+          ru[i] = u[i] - r.u_ref[i];
+        axpy(o.lu, mul(s.w_u, ru));
+        add_inplace(o.Luu, s.w_u);
+      }
+      { // centroidal momentum cost (cd.derivatives left forces(v, a) and Bc in cd.R)
+        Mat dh_dq, d1, d2;
+        cd.R.centroidal_derivatives(dh_dq, d1, d2);
+        const Mat Ag = cd.R.Ag();
+        Mat Jx(6, ndx);
+        for (int i = 0; i < 6; i++)
+          for (int k = 0; k < nv; k++)
+          {
+            Jx(i, k) = dh_dq(i, k);
+            Jx(i, nv + k) = Ag(i, k);
+          }
+        add_cost(s.w_cent, sv_vec(cd.R.hg()), Jx, nullptr);
+      }
+      for (int f = 0; f < nf; f++)
+      { // foot translation cost
+        Mat Jx(3, ndx);
+        for (int k = 0; k < nv; k++)
+        {
+          const V3 c = cd.R.Jfoot_col(f, k);
+          for (int i = 0; i < 3; i++)
+            Jx(i, k) = c[i];
+        }
+        const V3 e = cd.R.foot_p[f] - r.foot_ref[f];
+        add_cost(s.w_frame, Vec{e[0], e[1], e[2]}, Jx, nullptr);
+      }
+      for (size_t c = 0; c < cd.feet.size(); c++)
+      { // contact force cost
+        const int f = cd.feet[c];
+        Vec e(3);
+        Mat Jx(3, ndx), Ju(3, nu);
+        for (int i = 0; i < 3; i++)
+        {
+          e[i] = cd.lam[3 * c + i] - r.u_ref[nu + 3 * f + i];
+          for (int k = 0; k < nv; k++)
+          {
+            Jx(i, k) = cd.dlam_dq(3 * (int)c + i, k);
+            Jx(i, nv + k) = cd.dlam_dv(3 * (int)c + i, k);
+          }
+          for (int k = 0; k < nu; k++)
+            Ju(i, k) = cd.dlam_dtau(3 * (int)c + i, k);
+        }
+        add_cost(s.w_forces, e, Jx, &Ju);
+      }
+      o.Cx.resize(nc, ndx);
+      o.Cu.resize(nc, nu);
+      if (s.torque_limits)
+        for (int i = 0; i < nu; i++)
+          o.Cu(i, i) = 1.0;
+      if (s.kinematics_limits)
+        for (int i = 0; i < nv - 6; i++)
+          o.Cx(nu + i, 6 + i) = 1.0;
+      R = cd.R;
+    }
+
+    // terminal cost = the kinodynamics one (state + 10 x centroidal): delegate to the restatement in orc_kino.hpp
+    KinoModel terminal_model() const
+    {
+      KinoSettings ks;
+      ks.timestep = s.timestep;
+      ks.w_x = s.w_x;
+      ks.w_cent = s.w_cent;
+      ks.w_u = Mat(1, 1);
+      ks.w_frame = s.w_frame;
+      ks.w_centder = s.w_cent;
+      return KinoModel(M, ks);
+    }
+    double term_eval(Rigid & R, const Vec & x_tgt, const double * x) const { return terminal_model().term_eval(R, x_tgt, x); }
+    void term_deriv(Rigid & R, const Vec & x_tgt, const double * x, Vec & lx, Mat & Lxx) const
+    {
+      terminal_model().term_deriv(R, x_tgt, x, lx, Lxx);
+    }
+  };
+} // namespace orc

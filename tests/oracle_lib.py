@@ -74,6 +74,14 @@ def lib():
     L.orc_full_dynamics_derivatives.argtypes = [vp, _dp, _dp, C.c_uint, _dp, _dp, C.c_double, C.c_int] + [_dp] * 10
     L.orc_full_dynamics_derivatives.restype = C.c_int
     L.orc_full_rnea.argtypes = [vp, _dp, _dp, _dp]
+    L.orc_full_create.argtypes = [vp, C.c_double] + [_dp] * 12 + [C.c_int, C.c_int]
+    L.orc_full_create.restype = vp
+    L.orc_full_destroy.argtypes = [vp]
+    L.orc_full_dims.argtypes = [vp, _ip]
+    L.orc_full_eval.argtypes = [vp, C.c_uint, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_full_deriv.argtypes = [vp, C.c_uint] + [_dp] * 14
+    L.orc_full_solve.argtypes = [vp, C.c_int, C.POINTER(C.c_uint), _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]
+    L.orc_full_solve.restype = C.c_int
     L.orc_riccati.argtypes = [C.c_int] * 4 + [C.c_double] + [_dp] * 18
     L.orc_timer_create.restype = vp
     L.orc_timer_create.argtypes = [_bp, C.c_int, C.c_int, C.c_int]
@@ -287,6 +295,56 @@ class Kino:
         cost, lx, Lxx = np.zeros(1), np.zeros(self.ndx), np.zeros((self.ndx, self.ndx))
         lib().orc_kino_term(self.h, c(x_tgt), c(x), cost, lx, Lxx)
         return float(cost[0]), lx, Lxx
+
+
+def go2_full_settings(robot):
+    """FullDynamicsSettings of record: reference examples/go2_fulldynamics.py:42-77 (3-D feet).  The robot table holds no
+    effort limits: Go2's actuator limits (hip / thigh 23.7 N m, calf 45.43 N m) are used."""
+    nv = robot.nv
+    w_x = np.diag(np.array([0] * 6 + [1, 1, 1] * 4 + [10] * 6 + [0.1, 0.1, 0.1] * 4, float))
+    eff = np.array([23.7, 23.7, 45.43] * 4)
+    return dict(timestep=0.01, w_x=w_x, w_u=np.eye(nv - 6) * 1e-4, w_cent=np.diag([0.04, 0.04, 0, 0, 0, 0.0]),
+                w_forces=np.eye(3) * 1e-4, w_frame=np.eye(3) * 1000.0, gravity=np.array([0, 0, -9.81]),
+                Kp_correction=np.zeros(3), Kd_correction=np.zeros(3), umin=-eff, umax=eff, qmin=robot.q_lo.copy(),
+                qmax=robot.q_hi.copy(), torque_limits=True, kinematics_limits=True)
+
+
+class Full:
+    """Stage model of the full-dynamics OCP (oracle/orc_fulldyn.hpp); u_ref = [control reference ; force reference per foot]."""
+
+    def __init__(self, robot, s):
+        L = lib()
+        self.robot, self.s = robot, s
+        c = lambda a: np.ascontiguousarray(a, float)
+        self.h = L.orc_full_create(robot.ptr, s["timestep"], c(s["w_x"]), c(s["w_u"]), c(s["w_cent"]), c(s["w_forces"]),
+                                   c(s["w_frame"]), c(s["gravity"]), c(s["Kp_correction"]), c(s["Kd_correction"]), c(s["umin"]),
+                                   c(s["umax"]), c(s["qmin"]), c(s["qmax"]), int(s["torque_limits"]), int(s["kinematics_limits"]))
+        d = np.zeros(5, np.int32)
+        L.orc_full_dims(self.h, d)
+        self.nx, self.ndx, self.nu, self.nc, self.nf = (int(v) for v in d)
+        self.nv = robot.nv
+
+    def eval(self, mask, u_ref, x_tgt, foot_ref, x, u):
+        c = lambda a: np.ascontiguousarray(a, float)
+        xnext, xdot, cost, cc = np.zeros(self.nx), np.zeros(2 * self.nv), np.zeros(1), np.zeros(self.nc)
+        lib().orc_full_eval(self.h, mask, c(u_ref), c(x_tgt), c(foot_ref), c(x), c(u), xnext, xdot, cost, cc)
+        return dict(xnext=xnext, xdot=xdot, cost=float(cost[0]), c=cc)
+
+    def deriv(self, mask, u_ref, x_tgt, foot_ref, x, u):
+        c = lambda a: np.ascontiguousarray(a, float)
+        n, m, k = self.ndx, self.nu, self.nc
+        o = dict(A=np.zeros((n, n)), B=np.zeros((n, m)), lx=np.zeros(n), lu=np.zeros(m), Lxx=np.zeros((n, n)),
+                 Lxu=np.zeros((n, m)), Luu=np.zeros((m, m)), Cx=np.zeros((k, n)), Cu=np.zeros((k, m)))
+        lib().orc_full_deriv(self.h, mask, c(u_ref), c(x_tgt), c(foot_ref), c(x), c(u), *o.values())
+        return o
+
+    def solve(self, masks, u_ref, x_tgt, foot_ref, x0, u0, max_iter=50, tol=1e-4, mu=1e-8):
+        c = lambda a: np.ascontiguousarray(a, float)
+        H = len(masks)
+        mk = (C.c_uint * H)(*[int(m) for m in masks])
+        trace, xs, us = np.zeros((max_iter, 6)), np.zeros((H + 1, self.nx)), np.zeros((H, self.nu))
+        it = lib().orc_full_solve(self.h, H, mk, c(u_ref), c(x_tgt), c(foot_ref), c(x0), c(u0), max_iter, tol, mu, trace, xs, us)
+        return dict(iters=it, trace=trace[:it], xs=xs, us=us)
 
 
 def riccati(Q, S, R, q, r, A, B, f, Cm, D, d, QN, qN, mu):

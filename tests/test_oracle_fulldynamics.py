@@ -186,3 +186,83 @@ def test_constraint_dynamics_derivatives_against_finite_differences(rb, mask, Kp
     assert np.abs(r["da_dtau"] - numt[:nv]).max() < 1e-7 * max(1.0, np.abs(numt).max())
     if nc:
         assert np.abs(r["dlam_dtau"] - numt[nv:]).max() < 1e-7 * max(1.0, np.abs(numt).max())
+
+
+# ---- the stage model of the full-dynamics OCP (oracle/orc_fulldyn.hpp) ----
+@pytest.fixture(scope="module")
+def full(rb):
+    return O.Full(rb, O.go2_full_settings(rb))
+
+
+def _refs(rb, full, rng=None):
+    fref = np.tile([0.0, 0.0, rb.mass * 9.81 / 4], 4)
+    u_ref = np.concatenate([np.zeros(full.nu), fref])
+    feet = rb.centroidal(rb.x_ref)["feet"].copy()
+    if rng is not None:
+        feet = feet + rng.normal(size=feet.shape) * 0.02
+    return u_ref, rb.x_ref.copy(), feet
+
+
+def test_stage_structure_matches_the_reference_counts(rb, full):
+    # tests/problem.cpp:48-49: the full-dynamics stage has 3 constraint blocks with torque + kinematics limits on (the third,
+    # the friction cone, is off in the Go2 example): here rows = torque box (12) + joint box (12); u = 12 joint torques
+    assert (full.nx, full.ndx, full.nu, full.nc) == (37, 36, 12, 24)
+
+
+@pytest.mark.parametrize("mask", [0b1111, 0b0110, 0b1001])
+def test_stage_derivatives_against_finite_differences(rb, full, mask):
+    rng = np.random.default_rng(31 + mask)
+    x = _randx(rb, rng, 0.4)
+    u = rng.normal(size=full.nu) * 3
+    u_ref, x_tgt, feet = _refs(rb, full, rng)
+    d = full.deriv(mask, u_ref, x_tgt, feet, x, u)
+    e0 = full.eval(mask, u_ref, x_tgt, feet, x, u)
+    h = 1e-6
+    A, B = np.zeros((36, 36)), np.zeros((36, 12))
+    lx, lu = np.zeros(36), np.zeros(12)
+    Cx, Cu = np.zeros((24, 36)), np.zeros((24, 12))
+    for k in range(36):
+        dd = np.zeros(36)
+        dd[k] = h
+        ep, em = (full.eval(mask, u_ref, x_tgt, feet, rb.integrate(x, s * dd), u) for s in (1, -1))
+        A[:, k] = (rb.difference(e0["xnext"], ep["xnext"]) - rb.difference(e0["xnext"], em["xnext"])) / (2 * h)
+        lx[k] = (ep["cost"] - em["cost"]) / (2 * h)
+        Cx[:, k] = (ep["c"] - em["c"]) / (2 * h)
+    for k in range(12):
+        dd = np.zeros(12)
+        dd[k] = h
+        ep, em = (full.eval(mask, u_ref, x_tgt, feet, x, u + s * dd) for s in (1, -1))
+        B[:, k] = (rb.difference(e0["xnext"], ep["xnext"]) - rb.difference(e0["xnext"], em["xnext"])) / (2 * h)
+        lu[k] = (ep["cost"] - em["cost"]) / (2 * h)
+        Cu[:, k] = (ep["c"] - em["c"]) / (2 * h)
+    assert np.abs(d["A"] - A).max() < 2e-6 * max(1.0, np.abs(A).max())
+    assert np.abs(d["B"] - B).max() < 2e-6 * max(1.0, np.abs(B).max())
+    assert np.abs(d["lx"] - lx).max() < 2e-6 * max(1.0, np.abs(lx).max())
+    assert np.abs(d["lu"] - lu).max() < 2e-6 * max(1.0, np.abs(lu).max())
+    assert np.abs(d["Cx"] - Cx).max() < 1e-8 and np.abs(d["Cu"] - Cu).max() < 1e-8
+    # Gauss-Newton Hessian: symmetric positive semi-definite
+    Hm = np.block([[d["Lxx"], d["Lxu"]], [d["Lxu"].T, d["Luu"]]])
+    assert np.abs(Hm - Hm.T).max() < 1e-9 * np.abs(Hm).max() and np.linalg.eigvalsh(Hm).min() > -1e-9 * np.abs(Hm).max()
+
+
+def test_proxddp_converges_on_the_standing_problem(rb, full):
+    """ProxDDP (orc_proxddp.hpp, templated on the stage model) on 20 standing stages from zero torques: converges to the
+    static solution -- joint torques that hold the robot, contact forces m g / 4 per foot within the box limits"""
+    u_ref, x_tgt, feet = _refs(rb, full)
+    H = 20
+    r = full.solve([0b1111] * H, u_ref, x_tgt, feet, rb.x_ref, np.zeros(full.nu), max_iter=60, tol=1e-4)
+    tr = r["trace"]
+    assert r["iters"] < 60 and max(tr[-1, 0], tr[-1, 1]) <= 1e-4, tr[:, :2]
+    assert np.all(np.isfinite(r["xs"])) and np.all(np.isfinite(r["us"]))
+    # the robot stays where it is (base position is not weighted in the example: the legs settle by a few mrad)
+    D = np.array([rb.difference(rb.x_ref, x) for x in r["xs"]])
+    assert np.abs(D[:, :rb.nv]).max() < 1e-2 and np.abs(D[:, rb.nv:]).max() < 0.3
+    assert r["iters"] <= 10 and np.all(tr[:, 5] == 0)  # no failed line search
+    eff = full.s["umax"]
+    assert np.all(np.abs(r["us"]) <= eff + 1e-6)
+    # the contact forces carry the weight: the momentum rate of the whole robot is small against m g
+    xm, um = r["xs"][H // 2], r["us"][H // 2]
+    f = rb.full_forward_dynamics(xm, um, 0b1111)
+    c = rb.centroidal(xm)
+    assert np.abs(c["Ag"] @ f["a"] + c["dAgv"]).max() < 0.05 * rb.mass * 9.81
+    assert np.linalg.norm(f["lam"].reshape(4, 3), axis=1).min() > 0.15 * rb.mass * 9.81
