@@ -12,6 +12,7 @@
 #endif
 
 using namespace orc;
+typedef BatchMPCT<FullModel, FullSettings> BatchMPCFull;
 
 namespace
 {
@@ -642,6 +643,77 @@ extern "C"
   int orc_mpc_timing(void * h, int foot, int which, int * out, int cap)
   {
     return orc_timer_get(&((BatchMPC *)h)->timer, foot, which, out, cap);
+  }
+
+  // ---- the same host state machine on the full-dynamics stage model (orc_fulldyn.hpp) ----
+  void * orc_fmpc_create(void * full, const orc_mpc_settings * s, int B, double gravity_arg)
+  {
+    FullModel * md = (FullModel *)full;
+    MPCSettings ms;
+    ms.swing_apex = s->swing_apex;
+    ms.support_force = s->support_force;
+    ms.TOL = s->TOL;
+    ms.mu_init = s->mu_init;
+    ms.timestep = s->timestep;
+    ms.max_iters = s->max_iters;
+    ms.num_threads = s->num_threads;
+    ms.T_fly = s->T_fly;
+    ms.T_contact = s->T_contact;
+    ms.T = s->T;
+#ifdef _OPENMP
+    if (s->num_threads > 0)
+      omp_set_num_threads(s->num_threads);
+#endif
+    return new BatchMPCFull(md->M, md->s, ms, s->T, B, gravity_arg);
+  }
+  void orc_fmpc_destroy(void * h) { delete (BatchMPCFull *)h; }
+  void orc_fmpc_generate_cycle(void * h, const unsigned char * cs, int n)
+  {
+    BatchMPCFull * m = (BatchMPCFull *)h;
+    std::vector<std::vector<char>> v(n, std::vector<char>(m->nf));
+    for (int i = 0; i < n; i++)
+      for (int f = 0; f < m->nf; f++)
+        v[i][f] = cs[i * m->nf + f];
+    m->generateCycleHorizon(v);
+  }
+  void orc_fmpc_switch_to_walk(void * h, const double * v6) { ((BatchMPCFull *)h)->switchToWalk(v6); }
+  void orc_fmpc_switch_to_stand(void * h) { ((BatchMPCFull *)h)->switchToStand(); }
+  void orc_fmpc_set_velocity_batched(void * h, const double * V) { ((BatchMPCFull *)h)->setVelocityBaseBatched(V); }
+  // OCPHandler per-stage setters on the shared horizon (what: 0 control target, 1 state target; broadcast over the batch)
+  void orc_fmpc_set_x_reference(void * h, const double * x)
+  {
+    BatchMPCFull * m = (BatchMPCFull *)h;
+    m->x_reference.assign(x, x + m->md.nx);
+  }
+  double orc_fmpc_iterate(void * h, const double * X)
+  {
+    auto t0 = std::chrono::steady_clock::now();
+    ((BatchMPCFull *)h)->iterate(X);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  void orc_fmpc_get(void * h, int what, double * out) { mpc_get_impl((BatchMPCFull *)h, what, out); }
+  void orc_fmpc_keep_knots(void * h, int on)
+  {
+    BatchMPCFull * m = (BatchMPCFull *)h;
+    m->keep_knots = on != 0;
+    m->last_knots.assign(m->B, std::vector<Knot>());
+  }
+  int orc_fmpc_get_knot(void * h, int b, int t, double * out) { return mpc_get_knot_impl((BatchMPCFull *)h, b, t, out); }
+  int orc_fmpc_cold_iters(void * h) { return (int)((BatchMPCFull *)h)->cold_trace.size(); }
+  void orc_fmpc_cold_trace(void * h, double * out) // [n][4]: phi0, prim, dual, alpha
+  {
+    BatchMPCFull * m = (BatchMPCFull *)h;
+    for (size_t i = 0; i < m->cold_trace.size(); i++)
+    {
+      out[4 * i] = m->cold_trace[i].phi0;
+      out[4 * i + 1] = m->cold_trace[i].prim_infeas;
+      out[4 * i + 2] = m->cold_trace[i].dual_infeas;
+      out[4 * i + 3] = m->cold_trace[i].alpha;
+    }
+  }
+  int orc_fmpc_timing(void * h, int foot, int which, int * out, int cap)
+  {
+    return orc_timer_get(&((BatchMPCFull *)h)->timer, foot, which, out, cap);
   }
   // single ProxDDP iteration on explicit inputs, for stage-by-stage GPU parity:
   // returns the LQ knots of iteration 1 for instance b (packed like orc_riccati inputs)

@@ -59,6 +59,8 @@ namespace orc
     double row_hi_v(int row) const { return row < nu ? s.umax[row] : s.qmax[row - nu]; }
     void integrate(const double * x, const double * dx, double * out) const { x_integrate(nq, nv, x, dx, out); }
     void difference(const double * x0, const double * x1, double * out) const { x_difference(nq, nv, x0, x1, out); }
+    int force_ref_index(int f) const { return nu + 3 * f; }
+    int n_uref() const { return nu + 3 * nf; }
 
     ConstraintDynamics dynamics() const
     {

@@ -82,6 +82,9 @@ namespace orc
     double row_hi_v(int row) const { return row < nv - 6 ? s.qmax[row] : 0.0; }
     void integrate(const double * x, const double * dx, double * out) const { x_integrate(nq, nv, x, dx, out); }
     void difference(const double * x0, const double * x1, double * out) const { x_difference(nq, nv, x0, x1, out); }
+    // where a stage's reference vector keeps the force reference of foot f (here: the control reference itself)
+    int force_ref_index(int f) const { return 3 * f; }
+    int n_uref() const { return nu; }
 
     // ---- continuous dynamics  xdot = (v, a) ----
     // hdot target from contact forces: [m g + sum f ; sum (p_f - c) x f]

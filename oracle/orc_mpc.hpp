@@ -116,10 +116,13 @@ namespace orc
     V3 initial, final_;
   };
 
-  struct BatchMPC
+  // Model = KinoModel (orc_kino.hpp) or FullModel (orc_fulldyn.hpp): the host state machine is the same; the models say where a
+  // stage keeps its force references (Model::force_ref_index) and how long its reference vector is (Model::n_uref)
+  template <class Model, class ModelSettings>
+  struct BatchMPCT
   {
     const smpc_robot_model * M;
-    KinoModel md;
+    Model md;
     MPCSettings st;
     int H, B, nf;
     bool walking = true;
@@ -143,7 +146,7 @@ namespace orc
     bool keep_knots = false;
     std::vector<std::vector<Knot>> last_knots; // [b][t], filled when keep_knots (tests only)
 
-    BatchMPC(const smpc_robot_model * m, const KinoSettings & ks, const MPCSettings & ms, int H_, int B_, double gravity_arg)
+    BatchMPCT(const smpc_robot_model * m, const ModelSettings & ks, const MPCSettings & ms, int H_, int B_, double gravity_arg)
     : M(m), md(m, ks), st(ms), H(H_), B(B_)
     {
       nf = m->nfeet;
@@ -157,9 +160,9 @@ namespace orc
       // default problem (OCPHandler::createProblem): all contacts, identity contact poses
       StageRef def;
       def.mask = (1u << nf) - 1u;
-      def.u_ref.assign(md.nu, 0.0);
+      def.u_ref.assign(md.n_uref(), 0.0);
       for (int f = 0; f < nf; f++)
-        def.u_ref[3 * f + 2] = -m->total_mass * gravity_arg / (double)nf;
+        def.u_ref[md.force_ref_index(f) + 2] = -m->total_mass * gravity_arg / (double)nf;
       def.x_tgt = x_model_ref;
       def.foot_ref.assign(nf, v3(0, 0, 0));
       horizon.assign(H, def);
@@ -172,10 +175,10 @@ namespace orc
       o.x_tgt_term = x_model_ref;
       SolverState s0;
       s0.xs.assign(H + 1, x_model_ref);
-      s0.us.assign(H, def.u_ref);
+      s0.us.assign(H, Vec(def.u_ref.begin(), def.u_ref.begin() + md.nu)); // getReferenceControl(0) (src/mpc.cpp:75)
       s0.vs.assign(H, Vec(md.nc, 0.0));
       s0.lams.assign(H + 1, Vec(md.ndx, 0.0));
-      ProxDDP solver(md, st.mu_init);
+      ProxDDPT<Model> solver(md, st.mu_init);
       std::vector<Vec> vs_e = s0.vs, lams_e = s0.lams;
       for (int it = 0; it < 100; it++)
       {
@@ -230,12 +233,12 @@ namespace orc
           active += state[f] ? 1 : 0;
         StageRef sr;
         sr.mask = 0;
-        sr.u_ref.assign(md.nu, 0.0);
+        sr.u_ref.assign(md.n_uref(), 0.0);
         for (int f = 0; f < nf; f++)
           if (state[f])
           {
             sr.mask |= 1u << f;
-            sr.u_ref[3 * f + 2] = st.support_force / (double)active;
+            sr.u_ref[md.force_ref_index(f) + 2] = st.support_force / (double)active;
           }
         sr.x_tgt = x_model_ref;
         sr.foot_ref.resize(nf);
@@ -287,7 +290,7 @@ namespace orc
       for (int i = 0; i < 6; i++)
         horizon[H - 1].x_tgt[md.nq + i] = velocity_base[i];
 
-      ProxDDP solver(md, st.mu_init);
+      ProxDDPT<Model> solver(md, st.mu_init);
 #pragma omp parallel for schedule(dynamic)
       for (int b = 0; b < B; b++)
       {
@@ -364,4 +367,5 @@ namespace orc
       }
     }
   };
+  typedef BatchMPCT<KinoModel, KinoSettings> BatchMPC;
 } // namespace orc

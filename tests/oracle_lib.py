@@ -106,6 +106,22 @@ def lib():
     L.orc_mpc_cold_iters.argtypes = [vp]
     L.orc_mpc_cold_trace.argtypes = [vp, _dp]
     L.orc_mpc_timing.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
+    L.orc_fmpc_create.restype = vp
+    L.orc_fmpc_create.argtypes = [vp, C.POINTER(MpcSettingsC), C.c_int, C.c_double]
+    L.orc_fmpc_destroy.argtypes = [vp]
+    L.orc_fmpc_generate_cycle.argtypes = [vp, _bp, C.c_int]
+    L.orc_fmpc_switch_to_walk.argtypes = [vp, _dp]
+    L.orc_fmpc_switch_to_stand.argtypes = [vp]
+    L.orc_fmpc_set_velocity_batched.argtypes = [vp, _dp]
+    L.orc_fmpc_set_x_reference.argtypes = [vp, _dp]
+    L.orc_fmpc_iterate.restype = C.c_double
+    L.orc_fmpc_iterate.argtypes = [vp, _dp]
+    L.orc_fmpc_get.argtypes = [vp, C.c_int, _dp]
+    L.orc_fmpc_cold_iters.argtypes = [vp]
+    L.orc_fmpc_cold_trace.argtypes = [vp, _dp]
+    L.orc_fmpc_timing.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
+    L.orc_fmpc_keep_knots.argtypes = [vp, C.c_int]
+    L.orc_fmpc_get_knot.argtypes = [vp, C.c_int, C.c_int, _dp]
     L.orc_num_threads.restype = C.c_int
     L.orc_cent_create.restype = vp
     L.orc_cent_create.argtypes = [vp, C.c_double] + [_dp] * 7 + [C.c_double]
@@ -569,6 +585,16 @@ class OracleCentMPC(OracleMPC):
     @property
     def xdot(self):
         return self._get(7, (self.B, self.H, 18))[:, :, :9]
+
+
+class OracleFullMPC(OracleMPC):
+    """simple_mpc.MPC over a FullDynamicsOCP (3-D feet), batched: the host state machine of orc_mpc.hpp on the stage model of
+    oracle/orc_fulldyn.hpp.  us are joint torques [B][H][nv - 6]."""
+
+    _p = "orc_fmpc_"
+
+    def _create(self, s, B, gravity_arg):
+        return lib().orc_fmpc_create(self.kino.h, C.byref(s), B, gravity_arg)
 
 
 def interpolate(kind, nv, delay, timestep, knots):

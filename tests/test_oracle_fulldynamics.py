@@ -266,3 +266,32 @@ def test_proxddp_converges_on_the_standing_problem(rb, full):
     c = rb.centroidal(xm)
     assert np.abs(c["Ag"] @ f["a"] + c["dAgv"]).max() < 0.05 * rb.mass * 9.81
     assert np.linalg.norm(f["lam"].reshape(4, 3), axis=1).min() > 0.15 * rb.mass * 9.81
+
+
+def test_full_dynamics_mpc_closed_loop(rb, full):
+    """The reference's MPC state machine (orc_mpc.hpp, templated on the stage model) over the full-dynamics OCP: cold solve,
+    trot cycle, closed loop on its own prediction -- finite, feasible, the gait advances, torques inside their box."""
+    ms = O.go2_mpc_settings(rb, max_iters=2)
+    ms["T"] = 30
+    B = 2
+    mpc = O.OracleFullMPC(full, ms, B)
+    tr = mpc.cold_trace()
+    # (the default problem has identity contact poses -- src/ocp-handler.cpp:117 --, i.e. a large constant pose cost: the
+    #  cold solve ends on the merit-resolution rule of DESIGN.md 4, as the kinodynamics one does)
+    assert len(tr) < 100 and tr[-1][1] < 1e-3 and tr[-1][2] < 1e-2, tr[-3:]
+    mpc.generateCycleHorizon(O.trot_cycle())
+    mpc.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = np.tile(rb.x_ref, (B, 1))
+    rng = np.random.default_rng(5)
+    X[1] = rb.integrate(rb.x_ref, np.concatenate([rng.normal(size=18) * 0.01, rng.normal(size=18) * 0.05]))
+    for step in range(45):
+        mpc.iterate(X)
+        xs, us = mpc.xs, mpc.us
+        assert np.all(np.isfinite(xs)) and np.all(np.isfinite(us))
+        X = xs[:, 1].copy()
+    info = mpc.info
+    assert np.all(info[:, 4] < 1e-2), info[:, :6]          # primal infeasibility of the last iteration
+    assert np.all(np.abs(us) <= full.s["umax"] + 1e-3)
+    # the swing phase has started (feet leave the ground in the predicted horizon) and the base moves forward
+    assert xs[0, -1, 0] > xs[0, 0, 0] + 0.01
+    assert np.abs(X[:, 2] - rb.x_ref[2]).max() < 0.05
