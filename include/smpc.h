@@ -224,6 +224,20 @@ int smpc_reset_kernel_times(smpc_handle * h);
  *   Errors mirror the reference's assertions ("State is not of the right size"). */
 int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, double * acc_out, double * force_out);
 
+/* ---- full-dynamics model, first block: constrained forward dynamics of n states -- replaces
+ *      pinocchio::constraintDynamics as called by Aligator's MultibodyConstraintFwdDynamics for the contacts
+ *      FullDynamicsOCP builds (reference src/fulldynamics.cpp:39,50-75,139): CONTACT_3D, LOCAL frame, Baumgarte corrector
+ *      Kp / Kd [3] (NULL = 0), actuation [0; I].  X [n][nq + nv], tau [n][nv - 6], contact_mask [n] (bit f = foot f in
+ *      contact), all host.  Outputs (host): a_out [n][nv]; lambda_out [n][3 nfeet] contact forces ON the robot in the contact
+ *      frames, the feet in contact first (in foot order), remaining entries 0; iters_out [n] proximal iterations (may be
+ *      NULL); kernel_ms: wall time of the launch (may be NULL).  prox_accuracy / prox_mu / prox_max_iter <= 0 select the
+ *      reference's ProximalSettings(1e-9, 1e-10, 10).  n need not be the handle's batch size; the handle supplies the
+ *      robot table and gravity (kinodynamics handles only). */
+int smpc_full_forward_dynamics(
+  smpc_handle * h, int n, const double * X, const double * tau, const unsigned * contact_mask, const double * Kp,
+  const double * Kd, double prox_accuracy, double prox_mu, int prox_max_iter, double * a_out, double * lambda_out,
+  int * iters_out, double * kernel_ms);
+
 /* ---- state feedback front-end (replaces RobotDataHandler::updateInternalData(x, false) and
  *      getCentroidalState, reference src/robot-handler.cpp:106-127,142-149) for a batch of measured multibody states
  *      X [B][nx] (host): feet [B][nf][3] foot positions (world), com [B][3], hg [B][6] centroidal momentum

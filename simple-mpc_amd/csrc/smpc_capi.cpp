@@ -558,6 +558,20 @@ extern "C"
       return guarded([&] { h->cent->update_internal_data(X, feet, com, hg, centroidal_state); });
     return guarded([&] { h->eng->update_internal_data(X, feet, com, hg, centroidal_state); });
   }
+  int smpc_full_forward_dynamics(
+    smpc_handle * h, int n, const double * X, const double * tau, const unsigned * contact_mask, const double * Kp,
+    const double * Kd, double prox_accuracy, double prox_mu, int prox_max_iter, double * a_out, double * lambda_out,
+    int * iters_out, double * kernel_ms)
+  {
+    if (!h || !X || !tau || !contact_mask || !a_out || !lambda_out)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (!h->eng)
+      return fail(SMPC_ERR_INVALID, "smpc_full_forward_dynamics needs a kinodynamics handle (it carries the multibody model)");
+    return guarded([&] {
+      h->eng->full_forward_dynamics(n, X, tau, contact_mask, Kp, Kd, prox_accuracy, prox_mu, prox_max_iter, a_out, lambda_out,
+                                    iters_out, kernel_ms);
+    });
+  }
   int smpc_riccati_feedback(smpc_handle * h, double delay, const double * X_meas, double * u_out)
   {
     if (!h || !X_meas || !u_out)

@@ -14,7 +14,9 @@
 #endif
 #include "smpc_riccati_kino.h"
 #include "smpc_solver_kernels.h"
+#include "smpc_full_kernels.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -1000,6 +1002,50 @@ namespace smpc
         d2h(hg, st + nf + nc, nh * sizeof(double), stream);
       if (cstate)
         d2h(cstate, st + nf + nc + nh, ns * sizeof(double), stream);
+      stream_sync(stream);
+    }
+
+    // constrained forward dynamics of the full-dynamics model for n states (host buffers; iters / kernel_ms may be null)
+    void full_forward_dynamics(
+      int n, const double * X, const double * tau, const unsigned * mask, const double * Kp, const double * Kd,
+      double prox_accuracy, double prox_mu, int prox_max_iter, double * a, double * lam, int * iters, double * kernel_ms)
+    {
+      if (n < 1)
+        throw std::runtime_error("full_forward_dynamics: n must be positive");
+      constexpr int NV = D::NV, NX = D::NX, NCM = 3 * D::NF;
+      // staging layout (doubles): X | tau | a | lam | mask (unsigned) | iters (int)
+      const size_t oX = 0, oT = oX + (size_t)n * NX, oA = oT + (size_t)n * (NV - 6), oL = oA + (size_t)n * NV,
+                   oM = oL + (size_t)n * NCM, oI = oM + ((size_t)n + 1) / 2, total = oI + ((size_t)n + 1) / 2;
+      double * st = staging(total * sizeof(double));
+      h2d(st + oX, X, (size_t)n * NX * sizeof(double), stream);
+      h2d(st + oT, tau, (size_t)n * (NV - 6) * sizeof(double), stream);
+      h2d(st + oM, mask, (size_t)n * sizeof(unsigned), stream);
+      FullFdArgs<D> fa;
+      fa.b = buf;
+      fa.X = st + oX;
+      fa.tau = st + oT;
+      fa.mask = reinterpret_cast<const unsigned *>(st + oM);
+      for (int i = 0; i < 3; i++)
+      {
+        fa.Kp[i] = Kp ? Kp[i] : 0.0;
+        fa.Kd[i] = Kd ? Kd[i] : 0.0;
+      }
+      fa.prox_accuracy = prox_accuracy > 0 ? prox_accuracy : 1e-9; // ProximalSettings(1e-9, 1e-10, 10), src/fulldynamics.cpp:39
+      fa.prox_mu = prox_mu > 0 ? prox_mu : 1e-10;
+      fa.prox_max_iter = prox_max_iter > 0 ? prox_max_iter : 10;
+      fa.a_out = st + oA;
+      fa.lam_out = st + oL;
+      fa.iters_out = reinterpret_cast<int *>(st + oI);
+      stream_sync(stream);
+      const auto t0 = std::chrono::steady_clock::now();
+      launch<FullFdArgs<D>, full_fd_body<D>, 64>(n, stream, fa);
+      stream_sync(stream);
+      if (kernel_ms)
+        *kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      d2h(a, st + oA, (size_t)n * NV * sizeof(double), stream);
+      d2h(lam, st + oL, (size_t)n * NCM * sizeof(double), stream);
+      if (iters)
+        d2h(iters, st + oI, (size_t)n * sizeof(int), stream);
       stream_sync(stream);
     }
 

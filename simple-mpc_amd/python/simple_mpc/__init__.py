@@ -610,6 +610,26 @@ class BatchedMPC:
         self._lib.check(self._lib.L.smpc_update_internal_data(self._h, X, p(feet), p(com), p(hg), p(cs)))
         return dict(feet=feet, com=com, hg=hg, centroidal_state=cs)
 
+    def constraintDynamics(self, X, tau, contact_mask, Kp=None, Kd=None, prox_accuracy=0.0, prox_mu=0.0, prox_max_iter=0):
+        """Constrained forward dynamics of the full-dynamics model, batched on the device (what the reference's
+        FullDynamicsOCP gets from MultibodyConstraintFwdDynamics, src/fulldynamics.cpp:39,50-75,139): for states X[n, nx], joint
+        torques tau[n, nv - 6] and contact masks [n] returns dict(a[n, nv], lam[n, 3 nf] (contact frames, feet in contact
+        first), iters[n], kernel_ms).  Kinodynamics handles only."""
+        X = np.ascontiguousarray(np.array(X, dtype=np.float64))
+        tau = np.ascontiguousarray(np.array(tau, dtype=np.float64))
+        mk = np.ascontiguousarray(np.array(contact_mask, dtype=np.uint32))
+        n = X.shape[0]
+        if X.ndim != 2 or X.shape[1] != self.nx_in or tau.shape != (n, self.nv - 6) or mk.shape != (n,):
+            raise RuntimeError("X [n, nq + nv], tau [n, nv - 6], contact_mask [n] expected")
+        a, lam, it, ms = np.zeros((n, self.nv)), np.zeros((n, 3 * self.nf)), np.zeros(n, np.int32), np.zeros(1)
+        p = lambda v: v.ctypes.data_as(C.c_void_p)
+        kp = None if Kp is None else np.ascontiguousarray(np.array(Kp, dtype=np.float64))
+        kd = None if Kd is None else np.ascontiguousarray(np.array(Kd, dtype=np.float64))
+        self._lib.check(self._lib.L.smpc_full_forward_dynamics(
+            self._h, n, X, tau, p(mk), None if kp is None else p(kp), None if kd is None else p(kd), float(prox_accuracy),
+            float(prox_mu), int(prox_max_iter), a, lam, p(it), p(ms)))
+        return dict(a=a, lam=lam, iters=it, kernel_ms=float(ms[0]))
+
     def riccatiFeedback(self, delay, X_meas):
         """u = interpolateLinear(us) - Ks[0] @ difference(x_meas, interpolateState(xs)) for every instance (reference
         examples/go2_fulldynamics.py:271-285)."""

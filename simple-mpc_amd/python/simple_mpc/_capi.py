@@ -110,7 +110,7 @@ SYMBOLS = [
     "smpc_get_vs", "smpc_get_lams", "smpc_get_state_derivative01", "smpc_get_reference_poses",
     "smpc_get_foot_timing", "smpc_get_info", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
     "smpc_debug_get_steps", "smpc_debug_get_terminal", "smpc_debug_get_phase_cycles", "smpc_set_profiling", "smpc_get_kernel_times", "smpc_reset_kernel_times",
-    "smpc_interpolate", "smpc_interpolate_knots", "smpc_friction_compensation", "smpc_update_internal_data", "smpc_centroidal_dynamics", "smpc_riccati_feedback",
+    "smpc_interpolate", "smpc_interpolate_knots", "smpc_friction_compensation", "smpc_update_internal_data", "smpc_full_forward_dynamics", "smpc_centroidal_dynamics", "smpc_riccati_feedback",
 ]
 
 
@@ -174,6 +174,7 @@ class SmpcLib:
         L.smpc_centroidal_dynamics.argtypes = [C.c_double, _dp, C.c_double, C.c_int, _dp, _dp, _bp, _dp, C.c_int, _dp, _dp, _dp, C.c_int]
         L.smpc_riccati_feedback.argtypes = [vp, C.c_double, _dp, _dp]
         L.smpc_update_internal_data.argtypes = [vp, _dp, vp, vp, vp, vp]
+        L.smpc_full_forward_dynamics.argtypes = [vp, C.c_int, _dp, _dp, vp, vp, vp, C.c_double, C.c_double, C.c_int, _dp, _dp, vp, vp]
         L.smpc_interpolate_knots.argtypes = [C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int, _dp, C.c_int]
 
     def check(self, code):
