@@ -53,50 +53,78 @@ namespace smpc
   }
   SMPC_HD double sv_dot(const SV & m, const SV & f) { return dot(m.l, f.l) + dot(m.a, f.a); }
 
-  // in-place Cholesky of the leading n x n block of A (row stride ld), lower factor; lane = row
-  template <int NT>
-  SMPC_DEV void wave_cholesky(double * A, int n, int ld, double * tmp)
+  // in-place Cholesky of the N x N matrix A (row-major, stride N), lower factor; lane = row.  The lane keeps its row in
+  // registers; the finished entries of row j are broadcast reads from LDS (all loads of a column step are independent)
+  template <int NT, int N>
+  SMPC_DEV void wave_cholesky(double * A, double * tmp)
   {
-    for (int j = 0; j < n; j++)
+    SMPC_PLA(double, row, NT, N);
+    SMPC_LANES(NT)
+    {
+      const int r = lane < N ? lane : 0;
+#pragma unroll
+      for (int k = 0; k < N; k++)
+        SMPC_PLV(row)[k] = A[r * N + k];
+    }
+    SMPC_LANES_END_WAVE
+#pragma unroll
+    for (int j = 0; j < N; j++)
     {
       SMPC_LANES(NT)
-      if (lane >= j && lane < n)
       {
-        double s = A[lane * ld + j];
+        double s = SMPC_PLV(row)[j];
+#pragma unroll
         for (int k = 0; k < j; k++)
-          s -= A[lane * ld + k] * A[j * ld + k];
-        tmp[lane] = s;
+          s -= SMPC_PLV(row)[k] * A[j * N + k];
+        if (lane >= j && lane < N)
+          tmp[lane] = s;
       }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
-      if (lane >= j && lane < n)
       {
         const double d = sqrt(tmp[j]);
-        A[lane * ld + j] = lane == j ? d : tmp[lane] / d;
+        const double v = lane == j ? d : tmp[lane < N ? lane : 0] / d;
+        SMPC_PLV(row)[j] = v;
+        if (lane >= j && lane < N)
+          A[lane * N + j] = v;
       }
       SMPC_LANES_END_WAVE
     }
   }
-  // columns of X (n x nrhs, row stride ldx) <- (L L^T)^-1 X ; lane = column
-  template <int NT>
-  SMPC_DEV void wave_chol_solve(const double * L, int n, int ld, double * X, int nrhs, int ldx)
+  // columns of X (N x nrhs, row stride ldx) <- (L L^T)^-1 X ; lane = column, held in registers
+  template <int NT, int N>
+  SMPC_DEV void wave_chol_solve(const double * L, double * X, int nrhs, int ldx)
   {
     SMPC_LANES(NT)
-    if (lane < nrhs)
     {
-      for (int i = 0; i < n; i++)
+      const int c = lane < nrhs ? lane : 0;
+      double y[N];
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        y[i] = X[i * ldx + c];
+#pragma unroll
+      for (int i = 0; i < N; i++)
       {
-        double s = X[i * ldx + lane];
+        double s = y[i];
+#pragma unroll
         for (int k = 0; k < i; k++)
-          s -= L[i * ld + k] * X[k * ldx + lane];
-        X[i * ldx + lane] = s / L[i * ld + i];
+          s -= L[i * N + k] * y[k];
+        y[i] = s / L[i * N + i];
       }
-      for (int i = n - 1; i >= 0; i--)
+#pragma unroll
+      for (int i = N - 1; i >= 0; i--)
       {
-        double s = X[i * ldx + lane];
-        for (int k = i + 1; k < n; k++)
-          s -= L[k * ld + i] * X[k * ldx + lane];
-        X[i * ldx + lane] = s / L[i * ld + i];
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++)
+          s -= L[k * N + i] * y[k];
+        y[i] = s / L[i * N + i];
+      }
+      if (lane < nrhs)
+      {
+#pragma unroll
+        for (int i = 0; i < N; i++)
+          X[i * ldx + lane] = y[i];
       }
     }
     SMPC_LANES_END_WAVE
@@ -211,7 +239,7 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     // ---- M = L L^T ; W = M^-1 [S tau - nle | J^T] ----
-    wave_cholesky<NT>(s.M, NV, NV, s.tmp);
+    wave_cholesky<NT, NV>(s.M, s.tmp);
     SMPC_LANES(NT)
     for (int idx = lane; idx < NV * NCM; idx += NT)
     {
@@ -219,7 +247,7 @@ namespace smpc
       s.W[k * NR + 1 + c] = s.J[c * NV + k];
     }
     SMPC_LANES_END_WAVE
-    wave_chol_solve<NT>(s.M, NV, NV, s.W, NR, NR);
+    wave_chol_solve<NT, NV>(s.M, s.W, NR, NR);
     // ---- damped Delassus matrix (unit diagonal on the rows of absent contacts), its inverse, J M^-1 b ----
     const int nc = 3 * __builtin_popcount(mask);
     SMPC_LANES(NT)
@@ -244,8 +272,8 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
-    wave_cholesky<NT>(s.G, NCM, NCM, s.tmp);
-    wave_chol_solve<NT>(s.G, NCM, NCM, s.Gi, NCM, NCM);
+    wave_cholesky<NT, NCM>(s.G, s.tmp);
+    wave_chol_solve<NT, NCM>(s.G, s.Gi, NCM, NCM);
     // ---- proximal iteration:  lam <- G^-1 (mu lam - gamma - J M^-1 b)  until |d lam|_inf <= accuracy ----
     int iters = 0;
     if (nc > 0)
