@@ -107,6 +107,22 @@ def cpu_baseline(iters, seconds_budget=20.0):
     }
 
 
+def constraint_dynamics_line(gm, rb, batch, horizon):
+    """First device block of the full-dynamics model (BASELINE config 4 is not on the device yet): the constrained forward
+    dynamics kernel on batch x horizon states, all feet in contact -- one launch, timed around the launch itself."""
+    import numpy as np
+    import mpc_setup as S
+
+    n = batch * horizon
+    X = np.tile(S.random_states(rb, 512, seed=3), ((n + 511) // 512, 1))[:n]
+    tau, mask = np.zeros((n, rb.nv - 6)), np.full(n, (1 << rb.nf) - 1, np.uint32)
+    ms = [gm.constraintDynamics(X, tau, mask)["kernel_ms"] for _ in range(3)]
+    return {"metric": "constrained forward dynamics (full-dynamics model), states/sec", "value": n / (min(ms) * 1e-3), "unit": "states/s",
+            "kernel_ms": min(ms), "states": n, "dtype": "f64",
+            "note": "smpc_full_forward_dynamics: forward dynamics only; derivatives / stage / solver of the full-dynamics OCP "
+                    "are not on the device yet (DESIGN.md 0, 3.8)"}
+
+
 def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     """BASELINE config "Go2 centroidal (9-dim state), H=50, batch=4096": same step definition on the centroidal OCP
     (one fused kernel per control step).  Measured states: x_ref (+) N(0, sigma^2), resident in HBM, re-drawn on the
@@ -308,8 +324,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.iters)
         if world == 1 and not args.no_profile:
             # the other single-GPU BASELINE configuration, measured briefly beside the headline (not part of `value`)
+            fd = constraint_dynamics_line(gm, rb, B, gm.H)
             del gm
-            out["other_workloads"] = {"centroidal": centroidal_line(B, args.iters, 10, 3, local_rank, not args.no_cpu_baseline)}
+            out["other_workloads"] = {"centroidal": centroidal_line(B, args.iters, 10, 3, local_rank, not args.no_cpu_baseline),
+                                      "fulldynamics_forward_dynamics": fd}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
