@@ -41,6 +41,7 @@ namespace smpc
     double Gi[NCM * NCM];   // its inverse
     double gam[NCM], JMb[NCM], lam[NCM], rhs[NCM], dl[NCM];
     double tmp[NV];
+    unsigned anc[D::NJ]; // bit a of anc[j]: joint a is j or one of its ancestors
   };
 
   template <class D>
@@ -177,7 +178,16 @@ namespace smpc
       const double nle = sv_dot(Sl, Fg);
       s.W[l * NR] = (l >= 6 ? ka.tau[(size_t)inst * (NV - 6) + l - 6] : 0.0) - nle;
     }
+    else if (lane >= 32 && lane < 32 + D::NJ)
+    {
+      // ancestor sets, once: the entry loops below test a bit instead of walking the tree
+      unsigned bits = 0u;
+      for (int j = lane - 32; j >= 0; j = md.parent[j])
+        bits |= 1u << j;
+      s.anc[lane - 32] = bits;
+    }
     SMPC_LANES_END_WAVE
+    static_assert(D::NJ <= 32, "ancestor bit sets");
     // ---- joint-space inertia ----
     SMPC_LANES(NT)
     for (int idx = lane; idx < NV * NV; idx += NT)
@@ -185,9 +195,9 @@ namespace smpc
       const int k = idx / NV, l = idx % NV;
       const int jk = k < 6 ? 0 : k - 5, jl = l < 6 ? 0 : l - 5;
       double v = 0.0;
-      if (full_anc_or_eq<D>(md, jk, jl))
+      if ((s.anc[jl] >> jk) & 1u)
         v = sv_dot(ldsv(&sc.S[k * 6]), ldsv(&s.FS[l * 6]));
-      else if (full_anc_or_eq<D>(md, jl, jk))
+      else if ((s.anc[jk] >> jl) & 1u)
         v = sv_dot(ldsv(&sc.S[l * 6]), ldsv(&s.FS[k * 6]));
       s.M[idx] = v;
     }
@@ -209,7 +219,7 @@ namespace smpc
     {
       const int f = idx / NV, k = idx % NV;
       const int jf = md.foot_joint[f], jk = k < 6 ? 0 : k - 5;
-      if (((mask >> f) & 1u) && full_anc_or_eq<D>(md, jk, jf))
+      if (((mask >> f) & 1u) && ((s.anc[jf] >> jk) & 1u))
       {
         const int c = __builtin_popcount(mask & ((1u << f) - 1u));
         const M3 Rt = transpose(ldm3(&sc.oR[jf * 9])); // foot frame rotation = joint rotation
