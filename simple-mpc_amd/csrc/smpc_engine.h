@@ -1038,7 +1038,7 @@ namespace smpc
       fa.iters_out = reinterpret_cast<int *>(st + oI);
       stream_sync(stream);
       const auto t0 = std::chrono::steady_clock::now();
-      launch<FullFdArgs<D>, full_fd_body<D>, 64>(n, stream, fa);
+      launch<FullFdArgs<D>, full_fd_body<D>, 64, 2>(n, stream, fa); // 256 registers: 8 waves per CU with the 20.2 KB of LDS
       stream_sync(stream);
       if (kernel_ms)
         *kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -33,12 +33,16 @@ namespace smpc
   struct FullFdLds
   {
     static constexpr int NV = D::NV, NCM = 3 * D::NF, NR = NCM + 1;
-    double M[NV * NV];      // joint-space inertia -> its Cholesky factor (lower)
-    double FS[NV * 6];      // Ic_j S_l
+    // two blocks reused along the kernel (8 resident waves per CU need <= 20 KB with the evaluation scratch):
+    //   M : joint-space inertia -> its Cholesky factor -> (dead after the W solve) the damped Delassus matrix / its factor
+    //   J : Ic_j S_l (dead once M is formed) -> contact Jacobian (dead once G and J M^-1 b are formed) -> inverse of G
+    double M[NV * NV];
     double J[NCM * NV];     // contact Jacobian, rows of absent contacts zero
     double W[NV * NR];      // [M^-1 (S tau - nle) | M^-1 J^T], row-major [NV][NR]
-    double G[NCM * NCM];    // damped Delassus matrix -> its Cholesky factor
-    double Gi[NCM * NCM];   // its inverse
+    SMPC_HD double * FS_() { return J; } // [NV * 6]
+    SMPC_HD double * G_() { return M; }  // [NCM * NCM]
+    SMPC_HD double * Gi_() { return J; } // [NCM * NCM]
+    static_assert(NV * 6 <= NCM * NV && NCM * NCM <= NCM * NV && NCM * NCM <= NV * NV, "overlays");
     double gam[NCM], JMb[NCM], lam[NCM], rhs[NCM], dl[NCM];
     double tmp[NV];
     unsigned anc[D::NJ]; // bit a of anc[j]: joint a is j or one of its ancestors
@@ -172,7 +176,7 @@ namespace smpc
       const int l = lane, j = l < 6 ? 0 : l - 5;
       const SI Ic = ldsi(&sc.Ic[j * 10]);
       const SV Sl = ldsv(&sc.S[l * 6]);
-      stsv(&s.FS[l * 6], Ic * Sl);
+      stsv(&s.FS_()[l * 6], Ic * Sl);
       const SV g{ld3(md.gravity), mk3(0, 0, 0)};
       const SV Fg = ldsv(&sc.Fc[j * 6]) - Ic * g; // uniform field: every body accelerates with -g relative to free fall
       const double nle = sv_dot(Sl, Fg);
@@ -196,9 +200,9 @@ namespace smpc
       const int jk = k < 6 ? 0 : k - 5, jl = l < 6 ? 0 : l - 5;
       double v = 0.0;
       if ((s.anc[jl] >> jk) & 1u)
-        v = sv_dot(ldsv(&sc.S[k * 6]), ldsv(&s.FS[l * 6]));
+        v = sv_dot(ldsv(&sc.S[k * 6]), ldsv(&s.FS_()[l * 6]));
       else if ((s.anc[jk] >> jl) & 1u)
-        v = sv_dot(ldsv(&sc.S[l * 6]), ldsv(&s.FS[k * 6]));
+        v = sv_dot(ldsv(&sc.S[l * 6]), ldsv(&s.FS_()[k * 6]));
       s.M[idx] = v;
     }
     SMPC_LANES_END_WAVE
@@ -270,8 +274,7 @@ namespace smpc
           acc += s.J[c * NV + k] * s.W[k * NR + 1 + d];
         if (c == d)
           acc += c < nc ? ka.prox_mu : 1.0;
-        s.G[idx] = acc;
-        s.Gi[idx] = c == d ? 1.0 : 0.0;
+        s.G_()[idx] = acc;
       }
       if (lane < NCM)
       {
@@ -282,8 +285,13 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
-    wave_cholesky<NT, NCM>(s.G, s.tmp);
-    wave_chol_solve<NT, NCM>(s.G, s.Gi, NCM, NCM);
+    // (the Jacobian is dead now: its block takes the inverse)
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NCM * NCM; idx += NT)
+      s.Gi_()[idx] = idx / NCM == idx % NCM ? 1.0 : 0.0;
+    SMPC_LANES_END_WAVE
+    wave_cholesky<NT, NCM>(s.G_(), s.tmp);
+    wave_chol_solve<NT, NCM>(s.G_(), s.Gi_(), NCM, NCM);
     // ---- proximal iteration:  lam <- G^-1 (mu lam - gamma - J M^-1 b)  until |d lam|_inf <= accuracy ----
     int iters = 0;
     if (nc > 0)
@@ -298,7 +306,7 @@ namespace smpc
         {
           double acc = 0.0;
           for (int d = 0; d < NCM; d++)
-            acc += s.Gi[lane * NCM + d] * s.rhs[d];
+            acc += s.Gi_()[lane * NCM + d] * s.rhs[d];
           s.dl[lane] = fabs(acc - s.lam[lane]);
           s.lam[lane] = acc;
         }
