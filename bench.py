@@ -7,20 +7,29 @@ are resident in HBM when the timed region starts: the closed loop feeds back xs[
 generated on the device.  Multi-GPU: one process per GPU, batch sharded by instance, no
 collective on the solve path (weak scaling).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 4096] [--iters 3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch-per-gpu B] [--iters 3]
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU; it starts N fresh ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`), waits and relays rank 0's JSON line.  Under a launcher
+(WORLD_SIZE set) it is one rank.  `--dry-run` exercises the same launch / shard / barrier / reduce path on CPU (gloo, the
+test-only emulation build of the kernel bodies, a tiny batch): launch-path test infrastructure, never a measurement.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "simple-mpc_amd", "python"))
+# (tests/ holds the oracle binding: it goes on the path only inside the cpu_baseline legs)
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix dense peak (public spec; SURVEY 8d)
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
 
 
 def f_ric(ndx, nu, nc):
@@ -29,57 +38,94 @@ def f_ric(ndx, nu, nc):
             + 2 * ndx**2 * (nu + nc) + 2 * ndx * (nu + nc))
 
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
+def flop_counts():
+    """Algorithmic FLOPs of the stage evaluation / derivative passes, counted by instrumentation in the oracle
+    (tools/count_flops.py -> profiles/flop_counts.json).  {} if the file is absent."""
+    p = os.path.join(ROOT, "profiles", "flop_counts.json")
+    if not os.path.exists(p):
+        return {}
+    with open(p) as f:
+        return json.load(f)
 
 
-def rooflines(kt, B, H, ndx, nu, nc, nx):
-    """Roofline entries of the two kernels that carry the step: average launch duration from the
-    HIP events the engine records on ITS stream around every launch inside the timed region."""
-    out = {}
-    # HBM traffic per launch: PMC counters cannot be collected from inside this process; the figure comes from the
-    # committed rocprofv3 --pmc summary of this same command (profiles/, newest round), collected and corrected as
-    # MI355X_MICROARCH.md prescribes.  None if no summary is present.
-    import glob
-    pmc = {}
+def pmc_traffic(kernel, want):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary of this command (PMC counters cannot
+    be collected from inside this process); None unless the summary was taken on the configuration `want` describes."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))
-    if files and B == 4096:
-        with open(files[-1]) as f:
-            pmc = json.load(f).get("kernels", {})
-    traffic = lambda k: (pmc.get(k, {}).get("hbm_bytes_per_launch_corrected"), os.path.basename(files[-1]) if pmc else None)
-    if "deriv" in kt and kt["deriv"][1]:
-        # algorithmic bytes per (instance, stage): the state-dependent part of the LQ knot, written per iteration --
-        # the upper tiles of Q, the force columns of S, the force block of R + the regularised diagonal, the contact rows of C + the box
-        # selectors, the 12 dense rows of [A|B], q r f d lx lu lpd vpd (integrator rows, zero blocks and constant
-        # weight entries are written once at start-up) -- plus the iterate read (x, u, nu, lam, lam+, centres)
-        nfc = 12                 # 3 * nf force components (Go2: 4 point feet)
-        na = nu - nfc            # actuated joints = box rows
-        tl = [min(16, ndx - 16 * i) for i in range((ndx + 15) // 16)]
-        q_upper = sum(tl[i] * tl[j] for i in range(len(tl)) for j in range(i, len(tl)))  # upper 16x16 tiles of Q (912 of 1296)
-        per_stage = 8 * (q_upper + ndx * nfc + nfc * nfc + na + (nc - na) * ndx + na + 12 * (ndx + nu) + 4 * ndx + 2 * nu + 2 * nc
-                         + nx + nu + 2 * nc + 4 * ndx)
-        avg = kt["deriv"][0] / kt["deriv"][1] * 1e-3
-        ach = B * H * per_stage / avg / 1e9
-        out["deriv"] = {"bound": "hbm", "kernel": "deriv_body (stage evaluation + derivatives + LQ knot)", "achieved": ach,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic("deriv_body")[0],
-                        "traffic_source": traffic("deriv_body")[1], "algorithmic_bytes": B * H * per_stage, "avg_launch_ms": avg * 1e3,
-                        "note": "algorithmic bytes = B*H*%d per launch; the kernel is FP64-VALU issue bound (one wave per (instance, stage) "
-                                "keeps its SIMD's issue slot busy; co-resident waves do not add throughput), not bandwidth bound" % per_stage}
-    if "riccati" in kt and kt["riccati"][1]:
-        avg = kt["riccati"][0] / kt["riccati"][1] * 1e-3
-        ach = B * H * f_ric(ndx, nu, nc) / avg / 1e12
-        out["riccati"] = {"bound": "mfma", "kernel": "riccati_kino_body (proximal Riccati backward sweep)", "achieved": ach,
-                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic("riccati_kino_body")[0],
-                          "traffic_source": traffic("riccati_kino_body")[1], "avg_launch_ms": avg * 1e3,
-                          "note": "FP64 dense peak (vector = matrix on MI355X); algorithmic FLOPs = B*H*F_ric(36,24,24) of the "
-                                  "unstructured recursion (SURVEY 8d) per launch"}
+    if not files or not want:
+        return None, None
+    with open(files[-1]) as f:
+        k = json.load(f).get("kernels", {})
+    return k.get(kernel, {}).get("hbm_bytes_per_launch_corrected"), os.path.basename(files[-1])
+
+
+def both_bounds(flops, bytes_, avg_s, primary):
+    """Roofline entry with BOTH fractions: `achieved/peak/unit/frac` are those of the primary bound."""
+    fp = None if flops is None else {"achieved": flops / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_PEAK_TFLOPS,
+                                     "algorithmic_flops": flops}
+    hb = None if bytes_ is None else {"achieved": bytes_ / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_ / avg_s / 1e9 / HBM_PEAK_GBS,
+                                      "algorithmic_bytes": bytes_}
+    pr = fp if (primary == "mfma" and fp is not None) else hb
+    out = {"bound": "mfma" if pr is fp else "hbm", "achieved": pr["achieved"], "peak": pr["peak"], "unit": pr["unit"], "frac": pr["frac"],
+           "avg_launch_ms": avg_s * 1e3, "fp64": fp, "hbm": hb}
     return out
 
 
-def cpu_baseline(iters, seconds_budget=20.0):
-    """Oracle (CPU restatement, not Aligator) on the host cores, bounded sample of the same workload."""
-    import numpy as np
+def rooflines(kt, B, H, ndx, nu, nc, nx, at_record_size):
+    """Roofline entries of the kernels that carry the kinodynamics step: average launch duration from the HIP
+    events the engine records on ITS stream around every launch inside the timed region."""
+    out = {}
+    fc = flop_counts().get("kinodynamics", {})
+    nfc = 12                 # 3 * nf force components (Go2: 4 point feet)
+    na = nu - nfc            # actuated joints = box rows
+    tl = [min(16, ndx - 16 * i) for i in range((ndx + 15) // 16)]
+    q_upper = sum(tl[i] * tl[j] for i in range(len(tl)) for j in range(i, len(tl)))  # upper 16x16 tiles of Q (912 of 1296)
+    # state-dependent part of the knot written per iteration (DESIGN.md 2) + the iterate read
+    knot_w = 8 * (q_upper + ndx * nfc + nfc * nfc + na + (nc - na) * ndx + na + 12 * (ndx + nu) + 4 * ndx + 2 * nu + 2 * nc)
+    iter_r = 8 * (nx + nu + 2 * nc + 4 * ndx)
+    if "deriv" in kt and kt["deriv"][1]:
+        avg = kt["deriv"][0] / kt["deriv"][1] * 1e-3
+        fl = fc.get("deriv_flops_per_stage")
+        e = both_bounds(None if fl is None else B * H * fl, B * H * (knot_w + iter_r), avg, "mfma")
+        tr, src = pmc_traffic("deriv_body", at_record_size)
+        e.update({"kernel": "deriv_body (stage evaluation + derivatives + LQ knot)", "traffic": tr, "traffic_source": src,
+                  "note": "FP64 bound: algorithmic FLOPs of one stage evaluation + derivative + Gauss-Newton assembly counted by "
+                          "instrumentation in the oracle (profiles/flop_counts.json) x B*H; HBM side: B*H*%d bytes per launch" % (knot_w + iter_r)})
+        out["deriv"] = e
+    if "riccati" in kt and kt["riccati"][1]:
+        avg = kt["riccati"][0] / kt["riccati"][1] * 1e-3
+        # bytes: the knot read (full A B Q S R C + vectors as the structured sweep reads them) + gains written
+        gains_w = 8 * (nu * (ndx + 1) + ndx * (ndx + 1) // 2 + ndx)
+        e = both_bounds(B * H * f_ric(ndx, nu, nc), B * H * (knot_w + gains_w), avg, "mfma")
+        tr, src = pmc_traffic("riccati_kino_body", at_record_size)
+        e.update({"kernel": "riccati_kino_body (proximal Riccati backward sweep)", "traffic": tr, "traffic_source": src,
+                  "note": "FP64 dense peak (vector = matrix on MI355X); algorithmic FLOPs = B*H*F_ric(36,24,24) of the "
+                          "unstructured recursion (SURVEY 8d) per launch"})
+        out["riccati"] = e
+    if "forward" in kt and kt["forward"][1]:
+        avg = kt["forward"][0] / kt["forward"][1] * 1e-3
+        rd = 8 * (nu * (ndx + 1) + ndx * (ndx + 1) // 2 + ndx + 12 * (ndx + nu) + (nc - na) * ndx + 6 * ndx + 2 * nu + 2 * nc)
+        wr = 8 * (2 * ndx + nu + nc)
+        fl = 2 * (nu * ndx + nc * ndx + 12 * (ndx + nu) + ndx * ndx)
+        e = both_bounds(B * H * fl, B * H * (rd + wr), avg, "hbm")
+        tr, src = pmc_traffic("forward_kino_body", at_record_size)
+        e.update({"kernel": "forward_kino_body (gains -> Newton step)", "traffic": tr, "traffic_source": src})
+        out["forward"] = e
+    return out
+
+
+def _oracle_imports():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import mpc_setup as S
     import oracle_lib as O
+    return S, O
+
+
+def cpu_baseline(iters, seconds_budget=20.0):
+    """Oracle (CPU restatement, not Aligator) on the host cores, bounded sample of the same workload; plus the single-thread
+    latency of one control step at B = 1."""
+    import numpy as np
+    S, O = _oracle_imports()
 
     threads = O.lib().orc_num_threads()
     B = max(threads * 2, 8)
@@ -98,29 +144,66 @@ def cpu_baseline(iters, seconds_budget=20.0):
         if time.time() - t0 > seconds_budget or n >= 50:
             break
     dt = time.time() - t0
+    # B = 1: one instance = one OpenMP work item = one thread
+    o1, rb1, _ = S.make_oracle(1, max_iters=iters)
+    o1.generateCycleHorizon(O.trot_cycle())
+    o1.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X1 = S.random_states(rb1, 1)
+    o1.iterate(X1)
+    lat = []
+    for _ in range(5):
+        X1 = o1.xs[:, 1, :].copy()
+        t1 = time.time()
+        o1.iterate(X1)
+        lat.append(time.time() - t1)
     return {
         "value": B * n / dt,
         "unit": "control-steps/s",
         "cores": threads,
         "kind": "port",
-        "sample": "CPU restatement (oracle/, not Aligator): %d instances x %d steps, k=%d, OpenMP over instances" % (B, n, iters),
+        "b1_latency_ms": 1e3 * min(lat),
+        "sample": "CPU restatement (oracle/, not Aligator): %d instances x %d steps, k=%d, OpenMP over instances; b1_latency_ms = one "
+                  "control step of one instance on one thread (best of 5)" % (B, n, iters),
     }
 
 
-def constraint_dynamics_line(gm, rb, batch, horizon):
-    """First device block of the full-dynamics model (BASELINE config 4 is not on the device yet): the constrained forward
-    dynamics kernel on batch x horizon states, all feet in contact -- one launch, timed around the launch itself."""
+def make_mpc(kind, batch, iters, device_id, lib=None, horizon=50):
+    """BatchedMPC on the settings of record (simple_mpc.presets): kind in kinodynamics / centroidal / fulldynamics."""
     import numpy as np
-    import mpc_setup as S
+    import simple_mpc
+    from simple_mpc import presets as P
+
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+    for n in P.GO2_FEET:
+        mh.addPointFoot(n, "root_joint")
+    if kind == "kinodynamics":
+        ocp = simple_mpc.KinodynamicsOCP(P.go2_kino_settings(mh), mh)
+        ocp.createProblem(mh.getReferenceState(), horizon, 3, -9.81, False)
+    elif kind == "centroidal":
+        ocp = simple_mpc.CentroidalOCP(P.go2_centroidal_settings(mh), mh)
+        ocp.createProblem(np.zeros(9), horizon, 3, -9.81, False)
+    else:
+        ocp = simple_mpc.FullDynamicsOCP(P.go2_full_settings(mh), mh)
+        ocp.createProblem(mh.getReferenceState(), horizon, 3, -9.81, False)
+    ms = P.go2_mpc_settings(mh, max_iters=iters)
+    gm = simple_mpc.BatchedMPC({k: ms[k] for k in P.MPC_KEYS}, ocp, batch, device_id=device_id, lib=lib)
+    gm.generateCycleHorizon(P.trot_cycle())
+    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    return gm, mh
+
+
+def constraint_dynamics_line(gm, mh, batch, horizon):
+    """Constrained forward dynamics kernel of the full-dynamics model alone, on batch x horizon states, all feet in contact --
+    one launch, timed around the launch itself."""
+    import numpy as np
+    from simple_mpc import presets as P
 
     n = batch * horizon
-    X = np.tile(S.random_states(rb, 512, seed=3), ((n + 511) // 512, 1))[:n]
-    tau, mask = np.zeros((n, rb.nv - 6)), np.full(n, (1 << rb.nf) - 1, np.uint32)
+    X = np.tile(P.random_states(mh, 512, seed=3), ((n + 511) // 512, 1))[:n]
+    tau, mask = np.zeros((n, mh.nv - 6)), np.full(n, (1 << mh.getFeetNb()) - 1, np.uint32)
     ms = [gm.constraintDynamics(X, tau, mask)["kernel_ms"] for _ in range(3)]
     return {"metric": "constrained forward dynamics (full-dynamics model), states/sec", "value": n / (min(ms) * 1e-3), "unit": "states/s",
-            "kernel_ms": min(ms), "states": n, "dtype": "f64",
-            "note": "smpc_full_forward_dynamics: forward dynamics only; derivatives / stage / solver of the full-dynamics OCP "
-                    "are not on the device yet (DESIGN.md 0, 3.8)"}
+            "kernel_ms": min(ms), "states": n, "dtype": "f64", "note": "smpc_full_forward_dynamics: the forward dynamics kernel alone"}
 
 
 def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
@@ -129,14 +212,11 @@ def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     device every step (the centroidal solution has no multibody state to feed back)."""
     import numpy as np
     import torch
-    import mpc_setup as S
-    import oracle_lib as O
+    from simple_mpc import presets as P
 
-    gm, rb, _, _ = S.make_cent_product(batch, max_iters=iters, device_id=device_id)
-    gm.generateCycleHorizon(O.trot_cycle())
-    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    gm, mh = make_mpc("centroidal", batch, iters, device_id)
     dev = torch.device("cuda", device_id)
-    X0 = torch.from_numpy(S.random_states(rb, batch)).to(dev)
+    X0 = torch.from_numpy(P.random_states(mh, batch)).to(dev)
     X = X0.clone()
     gen = torch.Generator(device=dev)
     gen.manual_seed(7)
@@ -161,26 +241,21 @@ def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     kt = gm.kernel_times()
     avg = kt["step"][0] / max(kt["step"][1], 1) * 1e-3
     flops = batch * gm.H * iters * f_ric(9, gm.nu, gm.nc)
-    import glob
-    traffic, src = None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))
-    if files and batch == 4096 and iters == 3:
-        with open(files[-1]) as f:
-            traffic = json.load(f).get("kernels", {}).get("cent_step_body", {}).get("hbm_bytes_per_launch_corrected")
-        src = os.path.basename(files[-1])
+    io_bytes = batch * 8 * (2 * (gm.H + 1) * 9 + 2 * gm.H * gm.nu + gm.nu * 9 + (gm.H + 1) * 9 + gm.H * gm.nc)  # compulsory I/O per step
+    rl = both_bounds(flops, io_bytes, avg, "hbm")
+    tr, src = pmc_traffic("cent_step_body", batch == 4096 and iters == 3)
+    rl.update({"kernel": "cent_step_body (whole control step: recede + %d ProxDDP iterations)" % iters, "traffic": tr, "traffic_source": src,
+               "note": "HBM side: compulsory I/O of a control step (SURVEY 8d, 24.7 KB per instance); FP64 side: B*H*k*F_ric(9,12,8)"})
     out = {
         "metric": "MPC control-steps/sec at fixed ProxDDP iters, Go2 centroidal H=50",
         "value": batch * steps / dt, "unit": "control-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": "f64",
         "config": {"workload": "Go2 centroidal (go2_like table), H=%d, %d ProxDDP iters/step, batch=%d, trot 10/30/10/30, "
                    "x_meas = x_ref (+) N(0, sigma^2)" % (gm.H, iters, batch), "finite": bool(np.all(np.isfinite(gm.info)))},
         "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if k != "-"},
-        "roofline": {"bound": "mfma", "kernel": "cent_step_body (whole control step: recede + %d ProxDDP iterations)" % iters,
-                     "achieved": flops / avg / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / avg / 1e12 / FP64_PEAK_TFLOPS,
-                     "traffic": traffic, "traffic_source": src, "avg_launch_ms": avg * 1e3,
-                     "note": "algorithmic FLOPs = B*H*k*F_ric(9,12,8) (SURVEY 8d); the 21 x 21 stage systems leave the matrix cores "
-                             "mostly idle: the kernel is bound by the instruction issue of its index / assembly code (DESIGN.md 3.4)"},
+        "roofline": rl,
     }
     if with_cpu:
+        S, O = _oracle_imports()
         threads = O.lib().orc_num_threads()
         Bc = max(threads * 4, 16)
         om, rbc, _ = S.make_cent_oracle(Bc, max_iters=iters)
@@ -198,19 +273,119 @@ def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     return out
 
 
+def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True):
+    """Go2 full-dynamics OCP (reference examples/go2_fulldynamics.py; the Go2 case of BASELINE's full-dynamics configuration):
+    same step definition and closed loop as the headline, joint torques as controls, dense A / B."""
+    import numpy as np
+    import torch
+    from simple_mpc import presets as P
+
+    gm, mh = make_mpc("fulldynamics", batch, iters, device_id)
+    dev = torch.device("cuda", device_id)
+    X = torch.from_numpy(P.random_states(mh, batch)).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+
+    def step():
+        gm.iterate_device(X.data_ptr())
+        gm.get_x_device(1, X.data_ptr())
+        gm.wait()
+        X.add_(torch.randn(X.shape, generator=gen, device=dev, dtype=torch.float64) * 1e-3)
+        q = X[:, 3:7]
+        q.div_(q.norm(dim=1, keepdim=True))
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    gm.set_profiling(True)
+    gm.reset_kernel_times()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = gm.kernel_times()
+    H, ndx, nu, nc = gm.H, gm.ndx, gm.nu, gm.nc
+    out = {
+        "metric": "MPC control-steps/sec at fixed ProxDDP iters, Go2 fulldynamics H=50",
+        "value": batch * steps / dt, "unit": "control-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": "f64",
+        "config": {"workload": "Go2 full dynamics (go2_like table, 3-D contacts), H=%d, %d ProxDDP iters/step, batch=%d, trot 10/30/10/30, "
+                   "closed loop x_meas = xs[1] + N(0,1e-3^2)" % (H, iters, batch), "finite": bool(np.all(np.isfinite(gm.info)))},
+        "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if k != "-"},
+    }
+    if kt.get("riccati", (0, 0))[1]:
+        avg = kt["riccati"][0] / kt["riccati"][1] * 1e-3
+        lq_bytes = 8 * (2 * ndx * ndx + 2 * ndx * nu + nu * nu + 2 * ndx + nu + 2 * nc)  # dense knot read (box rows are selectors)
+        rl = both_bounds(batch * H * f_ric(ndx, nu, nc), batch * H * lq_bytes, avg, "mfma")
+        rl.update({"kernel": "riccati_dense_body (proximal Riccati backward sweep, dense A / B)",
+                   "note": "algorithmic FLOPs = B*H*F_ric(%d,%d,%d) per launch (SURVEY 8d)" % (ndx, nu, nc), "traffic": None})
+        out["roofline"] = rl
+    if with_cpu:
+        S, O = _oracle_imports()
+        threads = O.lib().orc_num_threads()
+        Bc = max(threads, 8)
+        om, rbc = S.make_full_oracle(Bc, max_iters=iters)
+        Xc = S.random_states(rbc, Bc)
+        om.iterate(Xc)
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < 10.0 and n < 50:
+            om.iterate(Xc)
+            Xc = om.xs[:, 1, :].copy()
+            n += 1
+        out["cpu_baseline"] = {"value": Bc * n / (time.time() - t0), "unit": "control-steps/s", "cores": threads, "kind": "port",
+                               "sample": "CPU restatement (oracle/, not Aligator): %d instances x %d steps, k=%d" % (Bc, n, iters)}
+    return out
+
+
+def launch_ranks(args, argv):
+    """Parent of a multi-GPU run: starts N ranks with torch.distributed.run as a CHILD process (this process has not touched a
+    GPU and never re-execs), relays rank 0's JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry_run:
+        env.setdefault("OMP_NUM_THREADS", "2")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0 or line is None:
+        raise SystemExit("bench.py: the %d-rank run failed (exit code %d)" % (args.gpus, p.returncode))
+    out = json.loads(line)
+    assert out["n_gpus"] == args.gpus, (out["n_gpus"], args.gpus)
+    print(line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch-per-gpu", "--batch", dest="batch", type=int, default=None,
+                    help="instances per GPU (default 4096; 8192 at 8 GPUs = BASELINE's 65536-instance configuration)")
     ap.add_argument("--iters", type=int, default=3, help="ProxDDP iterations per control step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--workload", default="kinodynamics", choices=["kinodynamics", "centroidal"],
-                    help="kinodynamics = the headline metric (with the centroidal configuration measured briefly beside it at 1 GPU); "
-                    "centroidal = only the centroidal line")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch path (gloo + emulated kernel bodies): not a measurement")
+    ap.add_argument("--workload", default="kinodynamics", choices=["kinodynamics", "centroidal", "fulldynamics"],
+                    help="kinodynamics = the headline metric (with the other single-GPU configurations measured briefly beside it at 1 GPU)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 2 if args.dry_run else (8192 if args.gpus >= 8 else 4096)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])
+        return
 
     import numpy as np
     import torch
@@ -218,74 +393,98 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the MPC engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    dry = args.dry_run
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the MPC engine has no CPU path")
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as g
 
     if rank == 0:
         # rank 0 (re)builds what is stale, the others wait: no concurrent compiler / make runs on the shared tree
-        g.build_hip()
-        g.build_oracle()
+        if dry:
+            g.build_emu()
+        else:
+            g.build_hip()
+            g.build_oracle()
     if dist is not None:
         dist.barrier()
-    import mpc_setup as S
-    import oracle_lib as O
+    from simple_mpc import presets as P
 
     B = args.batch
-    if args.workload == "centroidal":
-        if world > 1:
-            raise SystemExit("--workload centroidal is a single-GPU line")
-        line = centroidal_line(B, args.iters, args.steps, args.warmup, local_rank, not args.no_cpu_baseline)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    if args.workload != "kinodynamics":
+        if world > 1 or dry:
+            raise SystemExit("--workload %s is a single-GPU line" % args.workload)
+        fn = centroidal_line if args.workload == "centroidal" else fulldynamics_line
+        line = fn(B, args.iters, args.steps, args.warmup, local_rank, not args.no_cpu_baseline)
         line.update({"n_gpus": 1, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
         print(json.dumps(line))
         return
-    gm, rb, _, _ = S.make_product(B, max_iters=args.iters, device_id=local_rank)
-    gm.generateCycleHorizon(O.trot_cycle())
-    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    lib = None
+    if dry:
+        from simple_mpc._capi import SmpcLib
 
-    dev = torch.device("cuda", local_rank)
-    X0 = S.random_states(rb, B, seed=20240529 + rank)
-    X = torch.from_numpy(X0).to(dev)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(20240529 + rank)
+        lib = SmpcLib(g.EMU_LIB)
+    gm, mh = make_mpc("kinodynamics", B, args.iters, local_rank, lib)
 
-    def step():
-        gm.iterate_device(X.data_ptr())
-        gm.get_x_device(1, X.data_ptr())  # x_meas <- xs[1] (same stream, ordered after the solve)
-        gm.wait()
-        noise = torch.randn(X.shape, generator=gen, device=dev, dtype=torch.float64) * 1e-3
-        X.add_(noise)
-        q = X[:, 3:7]
-        q.div_(q.norm(dim=1, keepdim=True))
-        torch.cuda.synchronize()
+    X0 = P.random_states(mh, B, seed=20240529 + rank)  # contiguous block of the global batch: rank r owns instances [r B, (r+1) B)
+    if dry:
+        rng = np.random.default_rng(20240529 + rank)
+        Xh = X0.copy()
+
+        def step():
+            gm.iterate(Xh)
+            Xh[:] = gm.xs[:, 1, :] + rng.normal(0.0, 1e-3, Xh.shape)
+            Xh[:, 3:7] /= np.linalg.norm(Xh[:, 3:7], axis=1, keepdims=True)
+    else:
+        dev = torch.device("cuda", local_rank)
+        X = torch.from_numpy(X0).to(dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(20240529 + rank)
+
+        def step():
+            gm.iterate_device(X.data_ptr())
+            gm.get_x_device(1, X.data_ptr())  # x_meas <- xs[1] (same stream, ordered after the solve)
+            gm.wait()
+            noise = torch.randn(X.shape, generator=gen, device=dev, dtype=torch.float64) * 1e-3
+            X.add_(noise)
+            q = X[:, 3:7]
+            q.div_(q.norm(dim=1, keepdim=True))
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    if not args.no_profile:
+    profile = not args.no_profile and not dry
+    if profile:
         gm.set_profiling(True)
         gm.reset_kernel_times()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kt = gm.kernel_times() if not args.no_profile else {}
+    kt = gm.kernel_times() if profile else {}
     info = gm.info
     ok = bool(np.all(np.isfinite(info)))
 
@@ -308,26 +507,38 @@ def main():
             "config": {
                 "workload": "Go2 kinodynamics (go2_like table), H=%d, %d ProxDDP iters/step, batch=%d per GPU, trot 10/30/10/30, "
                 "closed loop x_meas = xs[1] + N(0,1e-3^2)" % (H, args.iters, B),
+                "batch_per_gpu": B,
                 "global_batch": world * B,
                 "parallelism": "instance-sharded x%d, no collective on the solve path" % world,
                 "finite": ok,
             },
         }
+        if dry:
+            out["data"] = "synthetic (DRY RUN on CPU: emulated kernel bodies + gloo, launch-path rehearsal, not a measurement)"
         if kt:
             out["kernel_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}
             out["kernel_share"] = {k: round(v[0] / max(1e-9, sum(x[0] for x in kt.values())), 3) for k, v in kt.items()}
-            rl = rooflines(kt, B, H, ndx, nu, nc, gm.nx)
+            rl = rooflines(kt, B, H, ndx, nu, nc, gm.nx, B == 4096 and args.iters == 3)
             dom = max(rl, key=lambda k: kt[k][0])  # dominant kernel = largest share of the timed region
             out["roofline"] = rl[dom]
             out["roofline_other"] = {k: v for k, v in rl.items() if k != dom}
-        if world == 1 and not args.no_cpu_baseline:
+            # whole step against both bounds: Riccati + derivative FLOPs of k iterations / compulsory I/O of a control step
+            fc = flop_counts().get("kinodynamics", {})
+            step_fl = args.iters * H * (f_ric(ndx, nu, nc) + fc.get("deriv_flops_per_stage", 0.0))
+            step_io = 8 * (2 * (H + 1) * gm.nx + 2 * H * nu + nu * ndx + (H + 1) * ndx + H * nc)
+            out["step_roofline"] = both_bounds(B * step_fl, B * step_io, dt / args.steps, "mfma")
+        if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(args.iters)
-        if world == 1 and not args.no_profile:
-            # the other single-GPU BASELINE configuration, measured briefly beside the headline (not part of `value`)
-            fd = constraint_dynamics_line(gm, rb, B, gm.H)
+        if world == 1 and profile:
+            # the other single-GPU BASELINE configurations, measured briefly beside the headline (not part of `value`)
+            other = {"fulldynamics_forward_dynamics": constraint_dynamics_line(gm, mh, B, gm.H)}
             del gm
-            out["other_workloads"] = {"centroidal": centroidal_line(B, args.iters, 10, 3, local_rank, not args.no_cpu_baseline),
-                                      "fulldynamics_forward_dynamics": fd}
+            other["centroidal"] = centroidal_line(B, args.iters, 10, 3, local_rank, not args.no_cpu_baseline)
+            try:
+                other["fulldynamics"] = fulldynamics_line(min(B, 4096), args.iters, 10, 3, local_rank, not args.no_cpu_baseline)
+            except Exception as e:  # reported, never hidden: the headline line stands on its own
+                other["fulldynamics"] = {"error": repr(e)}
+            out["other_workloads"] = other
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -42,6 +42,7 @@ def _check(gm, cold, k):
     assert S.rel_err(G["loop%d_cold_xs" % k], cold) < TOL
     assert S.rel_err(G["loop%d_xs" % k], gm.xs) < TOL
     assert S.rel_err(G["loop%d_us" % k], gm.us) < 10 * TOL
+    assert S.rel_err(G["loop%d_K0" % k], gm.K0) < TOL  # Ks_[0] is an output of MPC::iterate (reference src/mpc.cpp:216)
     assert np.array_equal(G["loop%d_alpha" % k], gm.info[:, 2])
 
 

@@ -29,11 +29,14 @@ def test_cold_solve_matches_oracle(built):
 
 @pytest.mark.parametrize("iters", [1, 3])
 def test_closed_loop_parity(built, iters):
-    B = 16
+    """48 control steps: the window covers the first swing phase entering the horizon, a take-off (step 10), the swing
+    and the touch-down of FL / RR (step 40) of the trot cycle (reference src/mpc.cpp:220-254)."""
+    B = 8
     om, gm, rb = S.make_pair(batch=B, max_iters=iters)
     X = S.random_states(rb, B)
-    worst = 0.0
-    for step in range(12):
+    worst = worst_k = 0.0
+    masks = set()
+    for step in range(48):
         om.iterate(X)
         gm.iterate(X)
         worst = max(worst, S.rel_err(om.xs, gm.xs))
@@ -41,11 +44,19 @@ def test_closed_loop_parity(built, iters):
         assert S.rel_err(om.us, gm.us) < TOL * 10
         assert np.array_equal(om.info[:, 2], gm.info[:, 2]), "line-search step sizes differ"
         assert S.rel_err(om.foot_refs, gm.getReferencePoses()) < 1e-12
+        # the first-stage feedback gain Ks_[0] (an output of MPC::iterate, reference src/mpc.cpp:216)
+        ek = S.rel_err(om.K0, gm.K0)
+        worst_k = max(worst_k, ek)
+        assert ek < TOL, (step, ek)
+        masks.add(tuple(gm.ocp_handler.getContactState(0)))
         X = om.xs[:, 1, :].copy()
+    assert len(masks) >= 2, "the window must contain a contact switch at stage 0"
+    Ks = gm.Ks
+    assert S.rel_err(om.K0, Ks[:, 0]) < TOL and np.all(np.isfinite(Ks))
     for f in range(4):
         assert om.timing(f, 0) == gm.foot_takeoff_times[S.FEET[f]]
         assert om.timing(f, 1) == gm.foot_land_times[S.FEET[f]]
-    print("worst relative xs error over the run: %.3e" % worst)
+    print("worst relative error over the run: xs %.3e, K0 %.3e" % (worst, worst_k))
 
 
 def test_line_search_backtracking_matches(built):
@@ -128,8 +139,18 @@ def test_full_size_properties(built):
         gm.iterate(X)
         xs = gm.xs
         X = xs[:, 1, :].copy()
+    us, K0 = gm.us, gm.K0
     xs = xs.reshape(B // 64, 64, *xs.shape[1:])
     assert np.abs(xs - xs[0:1]).max() == 0.0, "replicated instances must be bit-identical"
+    # the 64 distinct instances against the oracle (same three control steps)
+    om, _, _ = S.make_oracle(64, max_iters=3)
+    om.generateCycleHorizon(O.trot_cycle())
+    om.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    Xo = S.random_states(rb, 64)
+    for _ in range(3):
+        om.iterate(Xo)
+        Xo = om.xs[:, 1, :].copy()
+    assert S.rel_err(om.xs, xs[0]) < TOL and S.rel_err(om.us, us[:64]) < 10 * TOL and S.rel_err(om.K0, K0[:64]) < TOL
     info = gm.info
     assert np.all(np.isfinite(info))
     assert np.all(info[:, 8] < 1e-2), "primal infeasibility after the step"
@@ -185,3 +206,29 @@ def test_per_instance_velocity_commands(built):
         X = om.xs[:, 1, :].copy()
     refs = gm.getReferencePoses()
     assert np.abs(refs[0] - refs[1]).max() > 1e-3
+
+
+def test_per_gpu_size_of_the_sharded_configuration(built):
+    """B = 8192 on one GPU = the per-GPU share of BASELINE's 65536-instance, 8-GPU configuration: 32 distinct states against the
+    oracle, replicas bit-identical."""
+    import oracle_lib as O
+
+    B, nd = 8192, 32
+    gm, rb, _, _ = S.make_product(B, max_iters=3)
+    gm.generateCycleHorizon(O.trot_cycle())
+    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    om, _, _ = S.make_oracle(nd, max_iters=3)
+    om.generateCycleHorizon(O.trot_cycle())
+    om.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    Xo = S.random_states(rb, nd, seed=11)
+    X = np.tile(Xo, (B // nd, 1))
+    for _ in range(2):
+        gm.iterate(X)
+        om.iterate(Xo)
+        xs = gm.xs
+        X = xs[:, 1, :].copy()
+        Xo = om.xs[:, 1, :].copy()
+    xs = xs.reshape(B // nd, nd, *xs.shape[1:])
+    assert np.abs(xs - xs[0:1]).max() == 0.0
+    assert S.rel_err(om.xs, xs[0]) < TOL
+    assert np.all(np.isfinite(gm.info))
