@@ -70,6 +70,34 @@ typedef struct smpc_centroidal_settings
   int force_size;
 } smpc_centroidal_settings;
 
+/* FullDynamicsSettings: reference include/simple-mpc/fulldynamics.hpp:28-65 (same field names).
+ * w_x (ndx x ndx), w_u (nu x nu, nu = nv - 6), w_cent (6 x 6), w_forces, w_frame (force_size x force_size), dense row-major;
+ * umin / umax (nu), qmin / qmax (nv - 6), Kp_correction / Kd_correction (force_size). */
+typedef struct smpc_fulldynamics_settings
+{
+  double timestep;
+  const double * w_x;
+  const double * w_u;
+  const double * w_cent;
+  const double * w_forces;
+  const double * w_frame;
+  const double * umin;
+  const double * umax;
+  const double * qmin;
+  const double * qmax;
+  const double * Kp_correction;
+  const double * Kd_correction;
+  double gravity[3];
+  double mu;
+  double Lfoot;
+  double Wfoot;
+  int force_size;
+  int torque_limits;
+  int kinematics_limits;
+  int force_cone;
+  int land_cstr;
+} smpc_fulldynamics_settings;
+
 /* MPCSettings: reference include/simple-mpc/mpc.hpp:29-49 (same field names). */
 typedef struct smpc_mpc_settings
 {
@@ -113,6 +141,18 @@ int smpc_create(
 int smpc_create_centroidal(
   const smpc_robot_model * robot, const smpc_centroidal_settings * ocp, const smpc_mpc_settings * mpc, int batch,
   double gravity_arg, int device_id, smpc_handle ** out);
+/* FullDynamicsOCP(settings, model) + createProblem(x_ref, T, force_size, gravity, false) + MPC(settings, ocp):
+ * reference src/fulldynamics.cpp:30-76 (contact models, ProximalSettings(1e-9, 1e-10, 10)), :78-214 (createStage),
+ * :418-455 (terminal cost), src/mpc.cpp:19-99 (BASELINE's full-dynamics configuration).  State (q, v),
+ * control = the nv - 6 joint torques; nc = nu (torque box) + nv - 6 (joint box) [+ cone rows of 6-D feet].  Used through the
+ * same entry points as a kinodynamics handle; smpc_set_stage_reference takes what = 2 for the contact-force references
+ * (setReferenceForces, src/fulldynamics.cpp:258-300) and smpc_get_contact_forces reads MPC::getContactForces. */
+int smpc_create_fulldynamics(
+  const smpc_robot_model * robot, const smpc_fulldynamics_settings * ocp, const smpc_mpc_settings * mpc, int batch,
+  double gravity_arg, int device_id, smpc_handle ** out);
+/* MPC::getContactForces(t) for every stage (reference src/mpc.cpp:354-380): contact forces of the constrained dynamics at the
+ * solution, out [B][H][nfeet][force_size], zero for feet that are not in contact at that stage.  Full-dynamics handles only. */
+int smpc_get_contact_forces(smpc_handle * h, double * out);
 int smpc_destroy(smpc_handle * h);
 
 /* dims[0..7] = nq, nv, nx, ndx, nu, nc, nfeet, H */

@@ -3,6 +3,7 @@
 #include "../../include/smpc.h"
 #include "../../include/smpc_robots_builtin.h"
 #include "smpc_cent_engine.h"
+#include "smpc_full_engine.h"
 #include <cstring>
 #include <memory>
 #include <string>
@@ -13,11 +14,13 @@ typedef Dims<13, 4> DimsGo2; // free-flyer + 12 revolute joints, 4 point feet
 
 typedef CentDims<4> CentGo2;
 typedef CentEngine<DimsGo2, CentGo2> CentEngineGo2;
+typedef FullDims<13, 4, 3> FullGo2; // full dynamics: 12 joint torques, 3-D contacts
 
 struct smpc_handle
 {
   std::unique_ptr<KinoEngine<DimsGo2>> eng;
   std::unique_ptr<CentEngineGo2> cent; // centroidal handle (smpc_create_centroidal): eng is null
+  std::unique_ptr<FullEngineBase> full; // full-dynamics handle (smpc_create_fulldynamics): eng and cent are null
 };
 
 namespace
@@ -174,6 +177,73 @@ extern "C"
       *out = h.release();
     });
   }
+  int smpc_create_fulldynamics(
+    const smpc_robot_model * robot, const smpc_fulldynamics_settings * ocp, const smpc_mpc_settings * mpc, int batch, double gravity_arg,
+    int device_id, smpc_handle ** out)
+  {
+    if (!robot || !ocp || !mpc || !out || !ocp->w_x || !ocp->w_u || !ocp->w_cent || !ocp->w_forces || !ocp->w_frame || !ocp->umin || !ocp->umax
+        || !ocp->qmin || !ocp->qmax || !ocp->Kp_correction || !ocp->Kd_correction)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (device_count() <= 0)
+      return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the MPC engine has no CPU path");
+    if (ocp->force_size != 3 && ocp->force_size != 6)
+      return fail(SMPC_ERR_INVALID, "force size in settings does not match reference force size");
+    if (mpc->T < 2)
+      return fail(SMPC_ERR_INVALID, "horizon must have at least 2 stages");
+    const int nv = robot->nv, ndx = 2 * nv, nu = nv - 6, fs = ocp->force_size;
+    HostFullSettings s;
+    s.timestep = ocp->timestep;
+    s.w_x.assign(ocp->w_x, ocp->w_x + (size_t)ndx * ndx);
+    s.w_u.assign(ocp->w_u, ocp->w_u + (size_t)nu * nu);
+    s.w_cent.assign(ocp->w_cent, ocp->w_cent + 36);
+    s.w_forces.assign(ocp->w_forces, ocp->w_forces + fs * fs);
+    s.w_frame.assign(ocp->w_frame, ocp->w_frame + fs * fs);
+    s.umin.assign(ocp->umin, ocp->umin + nu);
+    s.umax.assign(ocp->umax, ocp->umax + nu);
+    s.qmin.assign(ocp->qmin, ocp->qmin + nu);
+    s.qmax.assign(ocp->qmax, ocp->qmax + nu);
+    s.Kp.assign(ocp->Kp_correction, ocp->Kp_correction + fs);
+    s.Kd.assign(ocp->Kd_correction, ocp->Kd_correction + fs);
+    for (int i = 0; i < 3; i++)
+      s.gravity[i] = ocp->gravity[i];
+    s.mu = ocp->mu;
+    s.Lfoot = ocp->Lfoot;
+    s.Wfoot = ocp->Wfoot;
+    s.force_size = fs;
+    s.torque_limits = ocp->torque_limits;
+    s.kinematics_limits = ocp->kinematics_limits;
+    s.force_cone = ocp->force_cone;
+    s.land_cstr = ocp->land_cstr;
+    for (int i = 0; i < nu; i++)
+      if (!(s.qmin[i] <= s.qmax[i]) || !(s.umin[i] <= s.umax[i]))
+        return fail(SMPC_ERR_INVALID, "lower limits must not exceed upper limits (indexed by actuated joint, 0 .. nv - 7)");
+    auto sym = [](const std::vector<double> & w, int n) {
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+          if (std::fabs(w[(size_t)i * n + j] - w[(size_t)j * n + i]) > 1e-12 * (1.0 + std::fabs(w[(size_t)i * n + j])))
+            return false;
+      return true;
+    };
+    if (!sym(s.w_x, ndx) || !sym(s.w_u, nu) || !sym(s.w_cent, 6) || !sym(s.w_forces, fs) || !sym(s.w_frame, fs))
+      return fail(SMPC_ERR_INVALID, "weight matrices must be symmetric");
+    const HostMpcSettings ms = host_mpc(mpc);
+    return guarded([&] {
+      std::unique_ptr<smpc_handle> h(new smpc_handle());
+      if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS)
+        h->full.reset(new FullEngine<FullGo2>(robot, s, ms, batch, gravity_arg, device_id));
+      else
+        throw std::runtime_error("robot shape (njoints, nfeet, force_size) does not match a built kernel instantiation");
+      *out = h.release();
+    });
+  }
+  int smpc_get_contact_forces(smpc_handle * h, double * out)
+  {
+    if (!h || !out)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (!h->full)
+      return fail(SMPC_ERR_INVALID, "smpc_get_contact_forces needs a full-dynamics handle (the other problems carry the forces in us)");
+    return guarded([&] { h->full->get(9, out); });
+  }
   int smpc_destroy(smpc_handle * h)
   {
     delete h;
@@ -183,6 +253,12 @@ extern "C"
   {
     if (!h || !d)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+    {
+      for (int i = 0; i < 8; i++)
+        d[i] = h->full->dims[i];
+      return SMPC_OK;
+    }
     if (h->cent)
     {
       d[0] = DimsGo2::NQ;
@@ -209,6 +285,8 @@ extern "C"
   {
     if (!h || !cs)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->generate_cycle_horizon(cs, n); });
     if (h->cent)
       return guarded([&] { h->cent->generate_cycle_horizon(cs, n); });
     return guarded([&] { h->eng->generate_cycle_horizon(cs, n); });
@@ -217,6 +295,8 @@ extern "C"
   {
     if (!h || !v6)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->switch_to_walk(v6); });
     if (h->cent)
       return guarded([&] { h->cent->switch_to_walk(v6); });
     return guarded([&] { h->eng->switch_to_walk(v6); });
@@ -225,6 +305,8 @@ extern "C"
   {
     if (!h)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->switch_to_stand(); });
     if (h->cent)
       return guarded([&] { h->cent->switch_to_stand(); });
     return guarded([&] { h->eng->switch_to_stand(); });
@@ -233,6 +315,8 @@ extern "C"
   {
     if (!h || !V)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->set_velocity_base_batched(V); });
     if (h->cent)
       return guarded([&] { h->cent->set_velocity_base_batched(V); });
     return guarded([&] { h->eng->set_velocity_base_batched(V); });
@@ -241,6 +325,8 @@ extern "C"
   {
     if (!h || !v)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->set_stage_reference(t, what, v, n); });
     if (h->cent)
       return guarded([&] { h->cent->set_stage_reference(t, what, v, n); });
     return guarded([&] { h->eng->set_stage_reference(t, what, v, n); });
@@ -249,6 +335,8 @@ extern "C"
   {
     if (!h || !v)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->get_stage_reference(t, what, v, n); });
     if (h->cent)
       return guarded([&] { h->cent->get_stage_reference(t, what, v, n); });
     return guarded([&] { h->eng->get_stage_reference(t, what, v, n); });
@@ -257,6 +345,8 @@ extern "C"
   {
     if (!h || !p3)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->set_reference_pose(t, foot, p3); });
     if (h->cent)
       return guarded([&] { h->cent->set_reference_pose(t, foot, p3); });
     return guarded([&] { h->eng->set_reference_pose(t, foot, p3); });
@@ -265,6 +355,8 @@ extern "C"
   {
     if (!h || !p3)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->get_reference_pose(t, foot, instance, p3); });
     if (h->cent)
       return guarded([&] { h->cent->get_reference_pose(t, foot, instance, p3); });
     return guarded([&] { h->eng->get_reference_pose(t, foot, instance, p3); });
@@ -274,8 +366,9 @@ extern "C"
     if (!h || !out)
       return fail(SMPC_ERR_INVALID, "null argument");
     return guarded([&] {
-      const unsigned m = h->cent ? h->cent->contact_mask(t) : h->eng->contact_mask(t);
-      for (int f = 0; f < DimsGo2::NF; f++)
+      const unsigned m = h->full ? h->full->contact_mask(t) : (h->cent ? h->cent->contact_mask(t) : h->eng->contact_mask(t));
+      const int nf = h->full ? h->full->dims[6] : DimsGo2::NF;
+      for (int f = 0; f < nf; f++)
         out[f] = (m >> f) & 1u;
     });
   }
@@ -283,7 +376,9 @@ extern "C"
   {
     if (!h || !x)
       return fail(SMPC_ERR_INVALID, "null argument");
-    if (h->cent)
+    if (h->full)
+      h->full->x_reference.assign(x, x + h->full->dims[2]);
+    else if (h->cent)
       std::copy(x, x + 9, h->cent->x_reference);
     else
       h->eng->x_reference.assign(x, x + DimsGo2::NX);
@@ -293,6 +388,8 @@ extern "C"
   {
     if (!h || !X)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->iterate_host(X); });
     if (h->cent)
       return guarded([&] { h->cent->iterate_host(X); });
     return guarded([&] { h->eng->iterate_host(X); });
@@ -301,6 +398,8 @@ extern "C"
   {
     if (!h || !Xd)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->iterate_device(Xd); });
     if (h->cent)
       return guarded([&] { h->cent->iterate_device(Xd); });
     return guarded([&] { h->eng->iterate_device(Xd); });
@@ -309,12 +408,19 @@ extern "C"
   {
     if (!h)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->sync(); });
     if (h->cent)
       return guarded([&] { h->cent->sync(); });
     return guarded([&] { h->eng->sync(); });
   }
   static size_t state_pass(smpc_handle * h, StateIO::Mode mode, void * buf, size_t cap)
   {
+    if (h->full)
+    {
+      StateIO io(mode, buf, cap, h->full->stream);
+      return h->full->state_io(io);
+    }
     if (h->cent)
     {
       StateIO io(mode, buf, cap, h->cent->stream);
@@ -349,30 +455,40 @@ extern "C"
   {
     if (!h || !out_device)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->gather_x_device(t, out_device); });
     if (h->cent)
       return fail(SMPC_ERR_INVALID, KINO_ONLY);
     return guarded([&] { h->eng->gather_x_device(t, out_device); });
   }
   int smpc_get_xs(smpc_handle * h, double * out)
   {
+    if (h->full)
+      return guarded([&] { h->full->get(0, out); });
     if (h->cent)
       return guarded([&] { h->cent->get_ring(h->cent->buf.xs, 9, h->cent->H + 1, out); });
     return guarded([&] { h->eng->get_ring(h->eng->buf.xs, DimsGo2::NX, h->eng->H + 1, out); });
   }
   int smpc_get_us(smpc_handle * h, double * out)
   {
+    if (h->full)
+      return guarded([&] { h->full->get(1, out); });
     if (h->cent)
       return guarded([&] { h->cent->get_ring(h->cent->buf.us, CentGo2::NU, h->cent->H, out); });
     return guarded([&] { h->eng->get_ring(h->eng->buf.us, DimsGo2::NU, h->eng->H, out); });
   }
   int smpc_get_vs(smpc_handle * h, double * out)
   {
+    if (h->full)
+      return guarded([&] { h->full->get(4, out); });
     if (h->cent)
       return guarded([&] { h->cent->get_ring(h->cent->buf.vs, CentGo2::NC, h->cent->H, out); });
     return guarded([&] { h->eng->get_ring(h->eng->buf.vs, DimsGo2::NC, h->eng->H, out); });
   }
   int smpc_get_lams(smpc_handle * h, double * out)
   {
+    if (h->full)
+      return guarded([&] { h->full->get(5, out); });
     // device arrays hold lambda_{t+1} at stage t; the API returns lams[0..H] with lams[0] = 0
     if (h->cent)
       return guarded([&] {
@@ -400,32 +516,40 @@ extern "C"
   }
   int smpc_get_K0(smpc_handle * h, double * out)
   {
+    if (h->full)
+      return guarded([&] { h->full->get(2, out); });
     if (h->cent)
       return guarded([&] { h->cent->get_K(out, false); });
     return guarded([&] { h->eng->get_K(out, false); });
   }
   int smpc_get_Ks(smpc_handle * h, double * out)
   {
+    if (h->full)
+      return guarded([&] { h->full->get(3, out); });
     if (h->cent)
       return guarded([&] { h->cent->get_K(out, true); });
     return guarded([&] { h->eng->get_K(out, true); });
   }
   int smpc_get_state_derivative01(smpc_handle * h, double * out)
   {
+    if (h->full)
+      return guarded([&] { h->full->get(6, out); });
     if (h->cent)
       return guarded([&] { h->cent->get_linear(h->cent->buf.xdot01, (size_t)h->cent->B * 18, out); });
     return guarded([&] { h->eng->get_linear(h->eng->buf.xdot01, (size_t)h->eng->B * 4 * DimsGo2::NV, out); });
   }
   int smpc_get_reference_poses(smpc_handle * h, double * out)
   {
+    if (h->full)
+      return guarded([&] { h->full->get(7, out); });
     if (h->cent)
       return guarded([&] { h->cent->get_linear(h->cent->buf.foot, (size_t)h->cent->B * h->cent->H * CentGo2::NF * 3, out); });
     return guarded([&] { h->eng->get_linear(h->eng->buf.foot_ref, (size_t)h->eng->B * h->eng->H * DimsGo2::NF * 3, out); });
   }
   int smpc_get_foot_timing(smpc_handle * h, int foot, int which, int * out, int cap)
   {
-    const GaitTimer * tm = !h ? nullptr : (h->cent ? &h->cent->timer : &h->eng->timer);
-    if (!tm || foot < 0 || foot >= DimsGo2::NF || tm->nf == 0)
+    const GaitTimer * tm = !h ? nullptr : (h->full ? &h->full->timer : (h->cent ? &h->cent->timer : &h->eng->timer));
+    if (!tm || foot < 0 || foot >= tm->nf || tm->nf == 0)
     {
       fail(SMPC_ERR_INVALID, "invalid foot index or cycle horizon not generated");
       return SMPC_ERR_INVALID;
@@ -437,22 +561,26 @@ extern "C"
   }
   int smpc_get_info(smpc_handle * h, double * out)
   {
+    if (h->full)
+      return guarded([&] { h->full->get(8, out); });
     if (h->cent)
       return guarded([&] { h->cent->get_linear(h->cent->buf.scal, (size_t)h->cent->B * SC_N, out); });
     return guarded([&] { h->eng->get_linear(h->eng->buf.scal, (size_t)h->eng->B * SC_N, out); });
   }
   int smpc_get_cold_trace(smpc_handle * h, double * out, int cap)
   {
-    const int n = h->cent ? h->cent->cold_iters : h->eng->cold_iters;
-    const std::vector<double> & tr = h->cent ? h->cent->cold_trace : h->eng->cold_trace;
+    const int n = h->full ? h->full->cold_iters : (h->cent ? h->cent->cold_iters : h->eng->cold_iters);
+    const std::vector<double> & tr = h->full ? h->full->cold_trace : (h->cent ? h->cent->cold_trace : h->eng->cold_trace);
     for (int i = 0; i < n && i < cap; i++)
       for (int k = 0; k < 4; k++)
         out[i * 4 + k] = tr[(size_t)i * 4 + k];
     return n;
   }
-  int smpc_lq_size(const smpc_handle *) { return DimsGo2::LQ_STRIDE; }
+  int smpc_lq_size(const smpc_handle * h) { return (h && h->full) ? h->full->lq_size() : DimsGo2::LQ_STRIDE; }
   int smpc_debug_get_lq(smpc_handle * h, int inst, int t, double * out)
   {
+    if (h && h->full)
+      return guarded([&] { h->full->debug_lq(inst, t, out); });
     if (h && h->cent)
       return fail(SMPC_ERR_INVALID, KINO_ONLY);
     if (!h || inst < 0 || inst >= h->eng->B || t < 0 || t >= h->eng->H)
@@ -469,6 +597,8 @@ extern "C"
   }
   int smpc_debug_get_steps(smpc_handle * h, double * dxs, double * dus)
   {
+    if (h && h->full)
+      return guarded([&] { h->full->debug_steps(dxs, dus); });
     if (h && h->cent)
       return guarded([&] {
         auto & e = *h->cent;
@@ -483,6 +613,8 @@ extern "C"
   }
   int smpc_debug_get_terminal(smpc_handle * h, int inst, double * QN, double * qN)
   {
+    if (h && h->full)
+      return guarded([&] { h->full->debug_terminal(inst, QN, qN); });
     if (h && h->cent)
       return fail(SMPC_ERR_INVALID, KINO_ONLY);
     if (!h || inst < 0 || inst >= h->eng->B)
@@ -495,6 +627,8 @@ extern "C"
   }
   int smpc_debug_get_phase_cycles(smpc_handle * h, double * out64)
   {
+    if (h && h->full)
+      return fail(SMPC_ERR_INVALID, "phase timers are not built for full-dynamics handles");
     if (h && h->cent && h->cent->buf.dbg)
       return guarded([&] { h->cent->get_linear(h->cent->buf.dbg, 64, out64); });
     if (!h || h->cent || !h->eng->buf.dbg)
@@ -503,7 +637,9 @@ extern "C"
   }
   int smpc_set_profiling(smpc_handle * h, int en)
   {
-    if (h->cent)
+    if (h->full)
+      h->full->profiling = en != 0;
+    else if (h->cent)
       h->cent->profiling = en != 0;
     else
       h->eng->profiling = en != 0;
@@ -511,6 +647,15 @@ extern "C"
   }
   int smpc_get_kernel_times(smpc_handle * h, double * ms, long * calls)
   {
+    if (h->full)
+      return guarded([&] {
+        h->full->collect_profile();
+        for (int i = 0; i < KID_N; i++)
+        {
+          ms[i] = h->full->kernel_ms[i];
+          calls[i] = h->full->kernel_calls[i];
+        }
+      });
     if (h->cent)
       return guarded([&] {
         // centroidal handle: slot 0 = front-end kernel, slot 1 = the fused control-step kernel
@@ -532,6 +677,15 @@ extern "C"
   }
   int smpc_reset_kernel_times(smpc_handle * h)
   {
+    if (h->full)
+      return guarded([&] {
+        h->full->collect_profile();
+        for (int i = 0; i < KID_N; i++)
+        {
+          h->full->kernel_ms[i] = 0;
+          h->full->kernel_calls[i] = 0;
+        }
+      });
     if (h->cent)
       return guarded([&] {
         h->cent->collect_profile();
@@ -554,6 +708,8 @@ extern "C"
   {
     if (!h || !X)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return fail(SMPC_ERR_INVALID, "smpc_update_internal_data: use a kinodynamics or centroidal handle of the same robot");
     if (h->cent)
       return guarded([&] { h->cent->update_internal_data(X, feet, com, hg, centroidal_state); });
     return guarded([&] { h->eng->update_internal_data(X, feet, com, hg, centroidal_state); });
@@ -576,6 +732,8 @@ extern "C"
   {
     if (!h || !X_meas || !u_out)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return fail(SMPC_ERR_INVALID, "smpc_riccati_feedback is not built for full-dynamics handles yet");
     if (h->cent)
       return guarded([&] { h->cent->interpolate(delay, 2, X_meas, nullptr, nullptr, nullptr, u_out); });
     return guarded([&] { h->eng->riccati_feedback(delay, X_meas, u_out); });
@@ -584,6 +742,8 @@ extern "C"
   {
     if (!h)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return fail(SMPC_ERR_INVALID, "smpc_interpolate is not built for full-dynamics handles yet");
     if (h->cent) // centroidal handle: x_out [B][9], acc_out = state derivative [B][9], force_out [B][3 nfeet]
       return guarded([&] { h->cent->interpolate(delay, knots, nullptr, x_out, acc_out, force_out, nullptr); });
     return guarded([&] { h->eng->interpolate(delay, knots, x_out, acc_out, force_out); });

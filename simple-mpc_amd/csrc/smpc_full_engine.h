@@ -1,0 +1,796 @@
+// smpc_full_engine.h -- host side of the batched FULL-DYNAMICS MPC engine (reference FullDynamicsOCP under the MPC class:
+// src/fulldynamics.cpp:30-455, src/mpc.cpp:19-392).  Same state machine, ring discipline and launch sequence as KinoEngine
+// (smpc_engine.h); the stage kernels are fdyn_deriv_body / fdyn_trial_body (smpc_full_stage.h), the sweeps are dense
+// (riccati_dense_body on the matrix cores, or the VALU cross-check riccati_full_body with SMPC_RICCATI=valu).
+#pragma once
+#include "smpc_engine.h"
+#include "smpc_full_solver.h"
+#include "smpc_full_stage.h"
+
+namespace smpc
+{
+  struct HostFullSettings // FullDynamicsSettings, include/simple-mpc/fulldynamics.hpp:28-65
+  {
+    double timestep;
+    std::vector<double> w_x, w_u, w_cent, w_forces, w_frame, umin, umax, qmin, qmax, Kp, Kd;
+    double gravity[3];
+    double mu, Lfoot, Wfoot;
+    int force_size, torque_limits, kinematics_limits, force_cone, land_cstr;
+  };
+
+  // what the C ABI needs from a full-dynamics engine of any robot shape
+  struct FullEngineBase
+  {
+    int B = 0, H = 0, R = 0, head = 0;
+    int dims[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // nq nv nx ndx nu nc nf H
+    int force_size = 3;
+    GaitTimer timer;
+    stream_t stream;
+    bool profiling = false;
+    double kernel_ms[KID_N] = {0};
+    long kernel_calls[KID_N] = {0};
+    int cold_iters = 0;
+    std::vector<double> cold_trace;
+    std::vector<double> x_reference;
+    virtual ~FullEngineBase() {}
+    virtual void generate_cycle_horizon(const unsigned char * cs, int n) = 0;
+    virtual void switch_to_walk(const double * v6) = 0;
+    virtual void switch_to_stand() = 0;
+    virtual void set_velocity_base_batched(const double * V) = 0;
+    virtual void iterate_host(const double * X) = 0;
+    virtual void iterate_device(const double * Xd) = 0;
+    virtual void sync() = 0;
+    virtual void gather_x_device(int t, double * out_dev) = 0;
+    virtual void get(int what, double * out) = 0; // 0 xs 1 us 2 K0 3 Ks 4 vs 5 lams 6 xdot01 7 foot refs 8 info 9 contact forces
+    virtual void set_stage_reference(int t, int what, const double * v, int n) = 0;
+    virtual void get_stage_reference(int t, int what, double * v, int n) = 0;
+    virtual void set_reference_pose(int t, int foot, const double * p3) = 0;
+    virtual void get_reference_pose(int t, int foot, int inst, double * p3) = 0;
+    virtual unsigned contact_mask(int t) const = 0;
+    virtual size_t state_io(StateIO & io) = 0;
+    virtual void collect_profile() = 0;
+    virtual int lq_size() const = 0;
+    virtual void debug_lq(int inst, int t, double * out) = 0;
+    virtual void debug_steps(double * dxs, double * dus) = 0;
+    virtual void debug_terminal(int inst, double * QN, double * qN) = 0;
+  };
+
+  template <class D>
+  class FullEngine : public FullEngineBase
+  {
+  public:
+    Buffers<D> buf;
+    int device_id = 0;
+    HostMpcSettings ms;
+    std::vector<StageShared<D>> horizon, cycle;
+    StageShared<D> standing;
+    bool walking = true;
+    double velocity_base[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<double> x_model_ref;
+    double * X_dev = nullptr;
+    double * stage_out = nullptr;
+    size_t stage_out_bytes = 0;
+    bool valu_riccati = std::getenv("SMPC_RICCATI") && std::string(std::getenv("SMPC_RICCATI")) == "valu";
+    bool speculative_ls = std::getenv("SMPC_NO_SPECULATIVE_LS") == nullptr;
+    bool aux_launches = false;
+    std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
+    static constexpr int LS_SLOTS = 64;
+    static constexpr double ARMIJO_C1 = 1e-4, REG_INIT = 1e-9, REG_MIN = 1e-10, REG_MAX = 1e9, REG_INC = 10.0, REG_DEC = 1.0 / 3.0, STALL_REL = 1e-9;
+    double ref_foot_pos[D::NF][3];
+
+    FullEngine(const smpc_robot_model * rm, const HostFullSettings & fs, const HostMpcSettings & ms_, int batch, double gravity_arg, int device)
+    : ms(ms_)
+    {
+      if (rm->njoints != D::NJ || rm->nfeet != D::NF)
+        throw std::runtime_error("robot shape (njoints, nfeet) does not match this kernel instantiation");
+      if (fs.force_size != D::FS)
+        throw std::runtime_error("force size in settings does not match reference force size");
+      if (batch <= 0)
+        throw std::runtime_error("batch must be positive");
+      if ((int)fs.Kp.size() != D::FS)
+        throw std::runtime_error("Force must be of same size as Kp correction"); // src/fulldynamics.cpp:41-44
+      if ((int)fs.Kd.size() != D::FS)
+        throw std::runtime_error("Force must be of same size as Kd correction"); // src/fulldynamics.cpp:45-48
+      if ((int)fs.w_x.size() != D::NDX * D::NDX || (int)fs.w_u.size() != D::NU * D::NU || (int)fs.w_cent.size() != 36
+          || (int)fs.w_forces.size() != D::FS * D::FS || (int)fs.w_frame.size() != D::FS * D::FS || (int)fs.umin.size() != D::NU
+          || (int)fs.umax.size() != D::NU || (int)fs.qmin.size() != D::NA || (int)fs.qmax.size() != D::NA)
+        throw std::runtime_error("full-dynamics settings: weight / limit sizes do not match the robot");
+      if (fs.land_cstr || (fs.force_cone && D::FS == 3))
+        throw std::runtime_error("land_cstr / friction-cone rows of 3-D feet are not built yet");
+      device_id = device;
+      set_device(device);
+      stream = stream_create();
+      B = batch;
+      H = ms.T;
+      R = H + 1;
+      force_size = D::FS;
+      const int dd[8] = {D::NQ, D::NV, D::NX, D::NDX, D::NU, D::NC, D::NF, H};
+      std::copy(dd, dd + 8, dims);
+      // ---- model table ----
+      std::vector<DevModel<D>> hm(1);
+      DevModel<D> & m = hm[0];
+      std::memset(&m, 0, sizeof(m));
+      fill_tree_model<D>(rm, m);
+      m.dt = fs.timestep;
+      for (int i = 0; i < 3; i++)
+        m.gravity[i] = fs.gravity[i];
+      std::copy(fs.w_x.begin(), fs.w_x.end(), m.w_x);
+      std::copy(fs.w_u.begin(), fs.w_u.end(), m.w_u);
+      m.w_diag = 1;
+      for (int i = 0; i < D::NDX; i++)
+        for (int j = 0; j < D::NDX; j++)
+          if (i != j && m.w_x[i * D::NDX + j] != 0.0)
+            m.w_diag = 0;
+      for (int i = 0; i < D::NU; i++)
+        for (int j = 0; j < D::NU; j++)
+          if (i != j && m.w_u[i * D::NU + j] != 0.0)
+            m.w_diag = 0;
+      if (std::getenv("SMPC_FORCE_DENSE_WEIGHTS"))
+        m.w_diag = 0;
+      for (int i = 0; i < D::NDX; i++)
+        m.wxd[i] = m.w_x[i * D::NDX + i];
+      for (int i = 0; i < D::NU; i++)
+        m.wud[i] = m.w_u[i * D::NU + i];
+      std::copy(fs.w_cent.begin(), fs.w_cent.end(), m.w_cent);
+      std::copy(fs.w_forces.begin(), fs.w_forces.end(), m.w_forces);
+      std::copy(fs.w_frame.begin(), fs.w_frame.end(), m.w_frame);
+      std::copy(fs.Kp.begin(), fs.Kp.end(), m.Kp);
+      std::copy(fs.Kd.begin(), fs.Kd.end(), m.Kd);
+      std::copy(fs.umin.begin(), fs.umin.end(), m.umin);
+      std::copy(fs.umax.begin(), fs.umax.end(), m.umax);
+      std::copy(fs.qmin.begin(), fs.qmin.end(), m.qmin);
+      std::copy(fs.qmax.begin(), fs.qmax.end(), m.qmax);
+      m.fric_mu = fs.mu;
+      m.Lfoot = fs.Lfoot;
+      m.Wfoot = fs.Wfoot;
+      m.prox_accuracy = 1e-9; // ProximalSettings(1e-9, 1e-10, 10), src/fulldynamics.cpp:39
+      m.prox_mu = 1e-10;
+      m.prox_max_iter = 10;
+      m.torque_limits = fs.torque_limits;
+      m.kinematics_limits = fs.kinematics_limits;
+      m.force_cone = fs.force_cone;
+      m.mu = ms.mu_init;
+      x_model_ref.assign(D::NX, 0.0);
+      for (int i = 0; i < D::NQ; i++)
+        x_model_ref[i] = rm->q_ref[i];
+      x_reference = x_model_ref;
+      for (int i = 0; i < D::NX; i++)
+        m.x_term[i] = x_model_ref[i];
+      // ---- buffers ----
+      buf.B = B;
+      buf.H = H;
+      buf.R = R;
+      auto dalloc = [&](size_t n) { return (double *)dev_alloc(n * sizeof(double)); };
+      const size_t BR = (size_t)B * R, BH = (size_t)B * H;
+      buf.xs = dalloc(BR * D::NX);
+      buf.us = dalloc(BR * D::NU);
+      buf.vs = dalloc(BR * D::NC);
+      buf.lams = dalloc(BR * D::NDX);
+      buf.vs_e = dalloc(BR * D::NC);
+      buf.lams_e = dalloc(BR * D::NDX);
+      buf.xs_b = dalloc(BR * D::NX);
+      buf.us_b = dalloc(BR * D::NU);
+      buf.vs_b = dalloc(BR * D::NC);
+      buf.lams_b = dalloc(BR * D::NDX);
+      buf.dxs = dalloc((size_t)B * (H + 1) * D::NDX);
+      buf.dus = dalloc(BH * D::NU);
+      buf.dvs = dalloc(BH * D::NC);
+      buf.dlams = dalloc(BH * D::NDX);
+      buf.foot_ref = dalloc(BH * D::NF * 3);
+      buf.ftraj = dalloc((size_t)B * D::NF * 6);
+      buf.vbase = dalloc((size_t)B * 6);
+      buf.vref = dalloc(BR * 6);
+      buf.lq = dalloc(BH * D::LQ_STRIDE);
+      buf.gains = dalloc(BH * (size_t)D::G_STRIDE);
+      buf.QN = dalloc((size_t)B * D::NDX * D::NDX);
+      buf.qN = dalloc((size_t)B * D::NDX);
+      buf.parts0 = dalloc((size_t)B * (H + 1) * 4);
+      buf.partsT = dalloc((size_t)B * D::LS_N * (H + 1) * 2);
+      buf.scal = dalloc((size_t)B * SC_N);
+      buf.xdotT = dalloc((size_t)B * D::LS_N * 4 * D::NV);
+      buf.xdot01 = dalloc((size_t)B * 4 * D::NV);
+      buf.nforce = D::NCM;
+      buf.forcesT = dalloc(BH * D::LS_N * D::NCM);
+      buf.forces = dalloc(BH * D::NCM);
+      buf.ls_sel = (int *)dev_alloc((size_t)B * sizeof(int));
+      buf.und_list = (int *)dev_alloc((size_t)(B + 1) * sizeof(int));
+      buf.stages = (StageShared<D> *)dev_alloc((size_t)H * sizeof(StageShared<D>));
+      buf.model = (DevModel<D> *)dev_alloc(sizeof(DevModel<D>));
+      X_dev = dalloc((size_t)B * D::NX);
+      h2d(buf.model, hm.data(), sizeof(DevModel<D>), stream);
+      stream_sync(stream);
+      // ---- default problem (OCPHandler::createProblem, src/ocp-handler.cpp:96-137) ----
+      StageShared<D> def;
+      std::memset(&def, 0, sizeof(def));
+      def.mask = (1u << D::NF) - 1u;
+      for (int f = 0; f < D::NF; f++)
+        def.f_ref[D::FS * f + 2] = -rm->total_mass * gravity_arg / (double)D::NF;
+      for (int i = 0; i < D::NX; i++)
+        def.x_tgt[i] = x_model_ref[i];
+      horizon.assign(H, def);
+      standing = def;
+      cold_solve(def, m);
+    }
+    ~FullEngine()
+    {
+      for (double * p : {buf.xs_b, buf.us_b, buf.vs_b, buf.lams_b, buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref,
+                         buf.ftraj, buf.vbase, buf.vref, buf.lq, buf.gains, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, buf.forces,
+                         buf.forcesT, X_dev, stage_out})
+        dev_free(p);
+      dev_free(buf.ls_sel);
+      dev_free(buf.und_list);
+      dev_free(buf.stages);
+      dev_free(buf.model);
+      stream_destroy(stream);
+    }
+    FullEngine(const FullEngine &) = delete;
+    FullEngine & operator=(const FullEngine &) = delete;
+
+    SolverArgs<D> solver_args(const Buffers<D> & b, int j0 = 0, int nj = 0) const
+    {
+      SolverArgs<D> a;
+      a.b = b;
+      a.head = head;
+      a.j0 = j0;
+      a.nj = nj;
+      a.armijo_c1 = ARMIJO_C1;
+      a.reg_min = REG_MIN;
+      a.reg_max = REG_MAX;
+      a.reg_inc = REG_INC;
+      a.reg_dec = REG_DEC;
+      return a;
+    }
+    template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1>
+    void timed_launch(int kid, int grid, const Args & a, bool aux = false)
+    {
+      set_device(device_id);
+      aux = aux || aux_launches;
+      event_t e0{}, e1{};
+      if (profiling)
+      {
+        e0 = event_create();
+        e1 = event_create();
+        event_record(e0, stream);
+      }
+      if (aux)
+        launch<Args, Body, NT, MINW, 1>(grid, stream, a);
+      else
+        launch<Args, Body, NT, MINW, 0>(grid, stream, a);
+      if (profiling)
+      {
+        event_record(e1, stream);
+        pending_events.push_back({kid, {e0, e1}});
+      }
+      kernel_calls[kid]++;
+    }
+    void collect_profile() override
+    {
+      stream_sync(stream);
+      for (auto & pe : pending_events)
+      {
+        kernel_ms[pe.first] += event_elapsed_ms(pe.second.first, pe.second.second);
+        event_destroy(pe.second.first);
+        event_destroy(pe.second.second);
+      }
+      pending_events.clear();
+    }
+    StageKernelArgs<D> stage_args(const Buffers<D> & b, int slots = 0) const
+    {
+      StageKernelArgs<D> sk;
+      sk.b = b;
+      sk.head = head;
+      sk.j0 = 0;
+      sk.nj = 0;
+      sk.slots = slots;
+      return sk;
+    }
+    void launch_deriv(const Buffers<D> & b, int slots = 0)
+    {
+      timed_launch<StageKernelArgs<D>, fdyn_deriv_body<D>, 64>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
+    }
+    void launch_sweeps(const Buffers<D> & b)
+    {
+      timed_launch<SolverArgs<D>, riccati_full_body<D, 256>, 256>(KID_RICCATI, b.B, solver_args(b));
+      timed_launch<SolverArgs<D>, forward_full_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
+    }
+    int launch_backtracking(const Buffers<D> & b)
+    {
+      const int slots = b.B < LS_SLOTS ? b.B : LS_SLOTS;
+      timed_launch<SolverArgs<D>, compact_body<D>, 64>(KID_SELECT, 1, solver_args(b));
+      return slots;
+    }
+    void launch_line_search(const Buffers<D> & b)
+    {
+      StageKernelArgs<D> sk = stage_args(b);
+      sk.j0 = 0;
+      sk.nj = 1;
+      timed_launch<StageKernelArgs<D>, fdyn_trial_body<D>, 64>(KID_TRIAL, b.B * (H + 1), sk);
+      timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, 0, 1));
+      const int slots = launch_backtracking(b);
+      sk.slots = slots;
+      sk.j0 = 1;
+      sk.nj = D::LS_N - 1;
+      timed_launch<StageKernelArgs<D>, fdyn_trial_body<D>, 64>(KID_SELECT, slots * (H + 1), sk, true);
+      timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, 1, D::LS_N - 1));
+      timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B, solver_args(b));
+    }
+    void run_iteration(const Buffers<D> & b)
+    {
+      launch_deriv(b);
+      launch_sweeps(b);
+      launch_line_search(b);
+    }
+    // k ProxDDP iterations of one control step; tentative full steps as in KinoEngine::run_iterations
+    void run_iterations(const Buffers<D> & b, int k)
+    {
+      if (!speculative_ls || k <= 1)
+      {
+        for (int it = 0; it < k; it++)
+          run_iteration(b);
+        return;
+      }
+      const int nb = (b.B + 63) / 64;
+      launch_deriv(b);
+      timed_launch<SolverArgs<D>, merit0_body<D>, 64>(KID_SELECT, nb, solver_args(b));
+      for (int it = 0; it < k; it++)
+      {
+        launch_sweeps(b);
+        if (it == k - 1)
+        {
+          launch_line_search(b);
+          break;
+        }
+        SolverArgs<D> sa = solver_args(b);
+        sa.mode = 1;
+        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B, sa);
+        launch_deriv(b);
+        timed_launch<SolverArgs<D>, spec_select_body<D>, 64>(KID_SELECT, nb, solver_args(b));
+        const int slots = launch_backtracking(b);
+        sa = solver_args(b);
+        sa.slots = slots;
+        sa.mode = 2;
+        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_SELECT, slots, sa, true);
+        StageKernelArgs<D> sk = stage_args(b, slots);
+        sk.j0 = 1;
+        sk.nj = D::LS_N - 1;
+        timed_launch<StageKernelArgs<D>, fdyn_trial_body<D>, 64>(KID_SELECT, slots * (H + 1), sk, true);
+        timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, nb, solver_args(b, 1, D::LS_N - 1));
+        sa.mode = 0;
+        timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_SELECT, slots, sa, true);
+        launch_deriv(b, slots);
+        timed_launch<SolverArgs<D>, merit0_body<D>, 64>(KID_SELECT, nb, sa);
+      }
+    }
+    void copy_centres(const Buffers<D> & b)
+    {
+      d2d(b.vs_e, b.vs, (size_t)b.B * R * D::NC * sizeof(double), stream);
+      d2d(b.lams_e, b.lams, (size_t)b.B * R * D::NDX * sizeof(double), stream);
+    }
+    void upload_stages() { h2d(buf.stages, horizon.data(), (size_t)H * sizeof(StageShared<D>), stream); }
+
+    // reference: src/mpc.cpp:72-91.  All instances share x0 = reference state: solve instance 0, broadcast.
+    void cold_solve(const StageShared<D> & def, const DevModel<D> & m)
+    {
+      std::vector<double> xs0((size_t)R * D::NX), us0((size_t)R * D::NU, 0.0);
+      for (int t = 0; t < R; t++)
+        std::copy(x_model_ref.begin(), x_model_ref.end(), xs0.begin() + (size_t)t * D::NX);
+      for (int t = 0; t < R; t++)
+        std::copy(def.u_ref, def.u_ref + D::NU, us0.begin() + (size_t)t * D::NU); // getReferenceControl(0) (src/mpc.cpp:75)
+      head = 0;
+      h2d(buf.xs, xs0.data(), xs0.size() * sizeof(double), stream);
+      h2d(buf.us, us0.data(), us0.size() * sizeof(double), stream);
+      std::vector<double> sc0(SC_N, 0.0);
+      sc0[SC_PREG] = REG_INIT;
+      h2d(buf.scal, sc0.data(), SC_N * sizeof(double), stream);
+      upload_stages();
+      dev_zero(buf.foot_ref, (size_t)H * D::NF * 3 * sizeof(double), stream); // identity contact poses (src/ocp-handler.cpp:116)
+      Buffers<D> b1 = buf;
+      b1.B = 1;
+      aux_launches = true;
+      copy_centres(b1);
+      std::vector<double> sc(SC_N);
+      cold_trace.clear();
+      const int cold_max = std::getenv("SMPC_COLD_MAX_ITERS") ? std::atoi(std::getenv("SMPC_COLD_MAX_ITERS")) : 100; // (diagnostics)
+      for (int it = 0; it < cold_max; it++)
+      {
+        run_iteration(b1);
+        d2h(sc.data(), buf.scal, SC_N * sizeof(double), stream);
+        stream_sync(stream);
+        cold_iters = it + 1;
+        cold_trace.insert(cold_trace.end(), {sc[SC_PHI0], sc[SC_PRIM], sc[SC_DUAL], sc[SC_ALPHA]});
+        if (std::fmax(sc[SC_PRIM], sc[SC_DUAL]) <= ms.TOL)
+          break;
+        if (std::fabs(sc[SC_DPHI0]) <= STALL_REL * std::fmax(1.0, std::fabs(sc[SC_PHI0])))
+          break;
+        if (sc[SC_DUAL] <= ms.TOL)
+          copy_centres(b1);
+      }
+      aux_launches = false;
+      auto bc = [&](double * p, size_t per) {
+        for (size_t done = 1; done < (size_t)B;)
+        {
+          const size_t n = std::min(done, (size_t)B - done);
+          d2d(p + done * per, p, n * per * sizeof(double), stream);
+          done += n;
+        }
+      };
+      bc(buf.xs, (size_t)R * D::NX);
+      bc(buf.us, (size_t)R * D::NU);
+      bc(buf.vs, (size_t)R * D::NC);
+      bc(buf.lams, (size_t)R * D::NDX);
+      bc(buf.scal, SC_N);
+      bc(buf.forces, (size_t)H * D::NCM);
+      // swing start / end = foot positions at the reference state (FootTrajectory ctor, src/foot-trajectory.cpp:20-39)
+      std::vector<double> ft((size_t)D::NF * 6);
+      host_foot_positions(m, x_model_ref.data(), ft.data());
+      h2d(buf.ftraj, ft.data(), ft.size() * sizeof(double), stream);
+      stream_sync(stream);
+      bc(buf.ftraj, (size_t)D::NF * 6);
+      stream_sync(stream);
+      for (int f = 0; f < D::NF; f++)
+        for (int i = 0; i < 3; i++)
+          ref_foot_pos[f][i] = ft[f * 6 + i];
+    }
+    static void host_foot_positions(const DevModel<D> & m, const double * x, double * out)
+    {
+      M3 Rj[D::NJ];
+      V3 pj[D::NJ];
+      for (int j = 0; j < D::NJ; j++)
+      {
+        if (j == 0)
+        {
+          Rj[0] = quat_to_R(Quat{x[3], x[4], x[5], x[6]});
+          pj[0] = ld3(x);
+        }
+        else
+        {
+          const double ang = x[6 + j], s = std::sin(ang), c = std::cos(ang);
+          const int jt = m.jtype[j];
+          M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -s, 0, s, c} : (jt == 2 ? M3{c, 0, s, 0, 1, 0, -s, 0, c} : M3{c, -s, 0, s, c, 0, 0, 0, 1});
+          Rj[j] = Rj[m.parent[j]] * (ldm3(m.jpR[j]) * Rq);
+          pj[j] = pj[m.parent[j]] + Rj[m.parent[j]] * ld3(m.jpp[j]);
+        }
+      }
+      for (int f = 0; f < D::NF; f++)
+      {
+        const V3 p = Rj[m.foot_joint[f]] * ld3(m.foot_p[f]) + pj[m.foot_joint[f]];
+        st3(out + f * 6, p);
+        st3(out + f * 6 + 3, p);
+      }
+    }
+
+    void generate_cycle_horizon(const unsigned char * cs, int n) override
+    {
+      if (n <= 0)
+        throw std::runtime_error("contact sequence must not be empty");
+      timer.generate(cs, n, D::NF, H);
+      cycle.clear();
+      for (auto & st : timer.states)
+      {
+        int active = 0;
+        for (int f = 0; f < D::NF; f++)
+          active += st[f] ? 1 : 0;
+        StageShared<D> s;
+        std::memset(&s, 0, sizeof(s));
+        for (int f = 0; f < D::NF; f++)
+          if (st[f])
+          {
+            s.mask |= 1u << f;
+            s.f_ref[D::FS * f + 2] = ms.support_force / (double)active; // src/mpc.cpp:149-167
+          }
+        for (int i = 0; i < D::NX; i++)
+          s.x_tgt[i] = x_model_ref[i];
+        cycle.push_back(s);
+      }
+    }
+    void upload_velocity(const double * V, bool broadcast)
+    {
+      set_device(device_id);
+      std::vector<double> hh((size_t)B * 6);
+      for (int b = 0; b < B; b++)
+        for (int i = 0; i < 6; i++)
+          hh[(size_t)b * 6 + i] = broadcast ? V[i] : V[(size_t)b * 6 + i];
+      h2d(buf.vbase, hh.data(), hh.size() * sizeof(double), stream);
+      stream_sync(stream);
+    }
+    void switch_to_walk(const double * v6) override
+    {
+      walking = true;
+      for (int i = 0; i < 6; i++)
+        velocity_base[i] = v6[i];
+      upload_velocity(v6, true);
+    }
+    void switch_to_stand() override
+    {
+      walking = false;
+      for (int i = 0; i < 6; i++)
+        velocity_base[i] = 0.0;
+      upload_velocity(velocity_base, true);
+    }
+    void set_velocity_base_batched(const double * V) override
+    {
+      for (int i = 0; i < 6; i++)
+        velocity_base[i] = V[i];
+      upload_velocity(V, false);
+    }
+
+    void iterate_device(const double * Xd) override
+    {
+      if (cycle.empty())
+        throw std::runtime_error("generateCycleHorizon must be called before iterate");
+      int last_support = 0;
+      for (int f = 0; f < D::NF; f++)
+        last_support += (horizon[H - 1].mask >> f) & 1u;
+      StageShared<D> incoming;
+      if (walking || last_support < D::NF)
+      {
+        incoming = cycle[0];
+        std::rotate(cycle.begin(), cycle.begin() + 1, cycle.end());
+        timer.recede_cycle();
+      }
+      else
+      {
+        incoming = standing;
+        timer.update_timing(true);
+      }
+      horizon.erase(horizon.begin());
+      horizon.push_back(incoming);
+      for (int i = 0; i < D::NX; i++)
+        horizon[H - 1].x_tgt[i] = x_reference[i];
+      for (int i = 0; i < 6; i++)
+        horizon[H - 1].x_tgt[D::NQ + i] = velocity_base[i];
+      upload_stages();
+      head = head + 1 == R ? 0 : head + 1;
+      RecedeArgs<D> ra;
+      ra.b = buf;
+      ra.head = head;
+      ra.X = Xd;
+      for (int f = 0; f < D::NF; f++)
+        ra.land[f] = timer.land[f].empty() ? -1 : timer.land[f][0];
+      ra.T_fly = ms.T_fly;
+      ra.T_contact = ms.T_contact;
+      ra.swing_apex = ms.swing_apex;
+      ra.timestep = ms.timestep;
+      ra.shift = 1;
+      ra.reg_init = REG_INIT;
+      timed_launch<RecedeArgs<D>, recede_body<D>, 64>(KID_RECEDE, B, ra);
+      copy_centres(buf);
+      run_iterations(buf, ms.max_iters);
+    }
+    void iterate_host(const double * X) override
+    {
+      set_device(device_id);
+      h2d(X_dev, X, (size_t)B * D::NX * sizeof(double), stream);
+      iterate_device(X_dev);
+      stream_sync(stream);
+    }
+    void sync() override
+    {
+      set_device(device_id);
+      stream_sync(stream);
+    }
+    void gather_x_device(int t, double * out_dev) override
+    {
+      if (t < 0 || t > H)
+        throw std::runtime_error("Stage index exceeds stage vector size");
+      GatherArgs<D> ga;
+      ga.b = buf;
+      ga.head = head;
+      ga.t = t;
+      ga.out = out_dev;
+      launch<GatherArgs<D>, gather_x_body<D>, 256>((int)(((size_t)B * D::NX + 255) / 256), stream, ga);
+    }
+    void check_stage(int t) const
+    {
+      if (t < 0 || t >= H)
+        throw std::runtime_error("Stage index exceeds stage vector size");
+    }
+    void fill_strided(double * base, size_t stride, int count, const double * v, int n)
+    {
+      set_device(device_id);
+      FillStridedArgs fa;
+      fa.base = base;
+      fa.stride = stride;
+      fa.count = count;
+      fa.n = n;
+      for (int i = 0; i < n; i++)
+        fa.v[i] = v[i];
+      launch<FillStridedArgs, fill_strided_body, 64>((count + 63) / 64, stream, fa);
+      stream_sync(stream);
+    }
+    // what: 0 = control target (nu), 1 = state target (nx), 2 = contact-force references (force_size * nfeet)
+    void set_stage_reference(int t, int what, const double * v, int n) override
+    {
+      check_stage(t);
+      if (what == 0)
+      {
+        if (n != D::NU)
+          throw std::runtime_error("u_ref not of the right size");
+        std::copy(v, v + n, horizon[t].u_ref);
+      }
+      else if (what == 1)
+      {
+        if (n != D::NX)
+          throw std::runtime_error("x_ref not of the right size");
+        std::copy(v, v + n, horizon[t].x_tgt);
+        fill_strided(buf.vref + (size_t)ring_slot(head, t, R) * 6, (size_t)R * 6, B, v + D::NQ, 6);
+      }
+      else if (what == 2)
+      {
+        if (n != D::NCM)
+          throw std::runtime_error("Reference forces do not have the right dimension");
+        std::copy(v, v + n, horizon[t].f_ref);
+      }
+      else
+        throw std::runtime_error("unknown stage reference");
+    }
+    void get_stage_reference(int t, int what, double * v, int n) override
+    {
+      check_stage(t);
+      if (what == 0 && n == D::NU)
+        std::copy(horizon[t].u_ref, horizon[t].u_ref + n, v);
+      else if (what == 1 && n == D::NX)
+      {
+        std::copy(horizon[t].x_tgt, horizon[t].x_tgt + n, v);
+        get_linear(buf.vref + (size_t)ring_slot(head, t, R) * 6, 6, v + D::NQ);
+      }
+      else if (what == 2 && n == D::NCM)
+        std::copy(horizon[t].f_ref, horizon[t].f_ref + n, v);
+      else
+        throw std::runtime_error("unknown stage reference or wrong size");
+    }
+    void set_reference_pose(int t, int foot, const double * p3) override
+    {
+      check_stage(t);
+      if (foot < 0 || foot >= D::NF)
+        throw std::runtime_error("unknown end effector");
+      fill_strided(buf.foot_ref + ((size_t)t * D::NF + foot) * 3, (size_t)H * D::NF * 3, B, p3, 3);
+    }
+    void get_reference_pose(int t, int foot, int inst, double * p3) override
+    {
+      check_stage(t);
+      if (foot < 0 || foot >= D::NF || inst < 0 || inst >= B)
+        throw std::runtime_error("unknown end effector or instance");
+      get_linear(buf.foot_ref + (((size_t)inst * H + t) * D::NF + foot) * 3, 3, p3);
+    }
+    unsigned contact_mask(int t) const override
+    {
+      check_stage(t);
+      return horizon[t].mask;
+    }
+    size_t state_io(StateIO & io) override
+    {
+      set_device(device_id);
+      stream_sync(stream);
+      io.tag(0x534d504346554c4cLL, "kind (full dynamics)");
+      io.tag(B, "batch");
+      io.tag(H, "horizon");
+      io.tag(D::NX, "nx");
+      io.tag(D::NU, "nu");
+      io.pod(head);
+      io.pod(walking);
+      io.host(velocity_base, sizeof(velocity_base));
+      io.vec(x_reference);
+      io.vec(horizon);
+      io.vec(cycle);
+      io.timer(timer);
+      const size_t BR = (size_t)B * R;
+      io.dev(buf.xs, BR * D::NX * sizeof(double));
+      io.dev(buf.us, BR * D::NU * sizeof(double));
+      io.dev(buf.vs, BR * D::NC * sizeof(double));
+      io.dev(buf.lams, BR * D::NDX * sizeof(double));
+      io.dev(buf.ftraj, (size_t)B * D::NF * 6 * sizeof(double));
+      io.dev(buf.foot_ref, (size_t)B * H * D::NF * 3 * sizeof(double));
+      io.dev(buf.vbase, (size_t)B * 6 * sizeof(double));
+      io.dev(buf.vref, BR * 6 * sizeof(double));
+      io.dev(buf.scal, (size_t)B * SC_N * sizeof(double));
+      io.dev(buf.xdot01, (size_t)B * 4 * D::NV * sizeof(double));
+      io.dev(buf.forces, (size_t)B * H * D::NCM * sizeof(double));
+      if (io.mode == StateIO::LOAD)
+        upload_stages();
+      stream_sync(stream);
+      return io.pos;
+    }
+    double * staging(size_t bytes)
+    {
+      set_device(device_id);
+      if (bytes > stage_out_bytes)
+      {
+        dev_free(stage_out);
+        stage_out = (double *)dev_alloc(bytes);
+        stage_out_bytes = bytes;
+      }
+      return stage_out;
+    }
+    void get_ring(const double * src, int n, int count, double * out)
+    {
+      set_device(device_id);
+      stream_sync(stream);
+      std::vector<double> tmp((size_t)B * R * n);
+      d2h(tmp.data(), src, tmp.size() * sizeof(double), stream);
+      stream_sync(stream);
+      for (int b = 0; b < B; b++)
+        for (int t = 0; t < count; t++)
+          std::memcpy(out + ((size_t)b * count + t) * n, tmp.data() + ((size_t)b * R + ring_slot(head, t, R)) * n, n * sizeof(double));
+    }
+    void get_linear(const double * src, size_t n, double * out)
+    {
+      set_device(device_id);
+      stream_sync(stream);
+      d2h(out, src, n * sizeof(double), stream);
+      stream_sync(stream);
+    }
+    void get_K(double * out, bool all)
+    {
+      stream_sync(stream);
+      const int nt = all ? H : 1;
+      std::vector<double> g((size_t)D::G_STRIDE);
+      for (int b = 0; b < B; b++)
+        for (int t = 0; t < nt; t++)
+        {
+          d2h(g.data(), buf.gains + ((size_t)b * H + t) * D::G_STRIDE + D::G_K, (size_t)D::NU * (D::NDX + 1) * sizeof(double), stream);
+          stream_sync(stream);
+          for (int i = 0; i < D::NU; i++)
+            std::memcpy(out + (((size_t)b * nt + t) * D::NU + i) * D::NDX, g.data() + (size_t)i * (D::NDX + 1), D::NDX * sizeof(double));
+        }
+    }
+    void get(int what, double * out) override
+    {
+      switch (what)
+      {
+      case 0:
+        return get_ring(buf.xs, D::NX, H + 1, out);
+      case 1:
+        return get_ring(buf.us, D::NU, H, out);
+      case 2:
+        return get_K(out, false);
+      case 3:
+        return get_K(out, true);
+      case 4:
+        return get_ring(buf.vs, D::NC, H, out);
+      case 5:
+      {
+        // device arrays hold lambda_{t+1} at stage t; the API returns lams[0..H] with lams[0] = 0
+        std::vector<double> tmp((size_t)B * H * D::NDX);
+        get_ring(buf.lams, D::NDX, H, tmp.data());
+        for (int b = 0; b < B; b++)
+        {
+          double * o = out + (size_t)b * (H + 1) * D::NDX;
+          std::memset(o, 0, D::NDX * sizeof(double));
+          std::memcpy(o + D::NDX, tmp.data() + (size_t)b * H * D::NDX, (size_t)H * D::NDX * sizeof(double));
+        }
+        return;
+      }
+      case 6:
+        return get_linear(buf.xdot01, (size_t)B * 4 * D::NV, out);
+      case 7:
+        return get_linear(buf.foot_ref, (size_t)B * H * D::NF * 3, out);
+      case 8:
+        return get_linear(buf.scal, (size_t)B * SC_N, out);
+      case 9:
+        return get_linear(buf.forces, (size_t)B * H * D::NCM, out);
+      default:
+        throw std::runtime_error("unknown output");
+      }
+    }
+    int lq_size() const override { return D::LQ_STRIDE; }
+    void debug_lq(int inst, int t, double * out) override
+    {
+      if (inst < 0 || inst >= B || t < 0 || t >= H)
+        throw std::runtime_error("Stage index exceeds stage vector size");
+      get_linear(buf.lq + ((size_t)inst * H + t) * D::LQ_STRIDE, D::LQ_STRIDE, out);
+    }
+    void debug_steps(double * dxs, double * dus) override
+    {
+      get_linear(buf.dxs, (size_t)B * (H + 1) * D::NDX, dxs);
+      get_linear(buf.dus, (size_t)B * H * D::NU, dus);
+    }
+    void debug_terminal(int inst, double * QN, double * qN) override
+    {
+      if (inst < 0 || inst >= B)
+        throw std::runtime_error("instance index out of range");
+      get_linear(buf.QN + (size_t)inst * D::NDX * D::NDX, D::NDX * D::NDX, QN);
+      get_linear(buf.qN + (size_t)inst * D::NDX, D::NDX, qN);
+    }
+  };
+} // namespace smpc

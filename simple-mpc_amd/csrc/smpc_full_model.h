@@ -1,0 +1,113 @@
+// smpc_full_model.h -- compile-time dimensions, device model table and LQ knot layout of the FULL-DYNAMICS OCP
+// (reference FullDynamicsOCP: src/fulldynamics.cpp:30-214, settings include/simple-mpc/fulldynamics.hpp:28-65).
+//
+//   state   x = (q, v)                 control  u = joint torques (nu = nv - 6, actuation [0; I], src/fulldynamics.cpp:35-37)
+//   dynamics  MultibodyConstraintFwdDynamics (one rigid contact per foot in contact) + IntegratorSemiImplEuler
+//   constraint rows per stage (NC):  [ torque box (nu) | joint box (nv - 6) | cone rows on the contact forces (NCONE) ]
+//     - the two box blocks are unit selectors on u / x: they enter the stage KKT as diagonal terms and are never stored
+//       as matrices
+//     - the cone rows (6-D feet with force_cone: 17 rows per foot, src/fulldynamics.cpp:163-173) are dense in x and u
+//       (through the contact-force derivatives): blocks Cd (NCONE x NDX) and Dd (NCONE x NU) of the knot
+// FS = force size: 3 (point feet, CONTACT_3D LOCAL) or 6 (quad feet, CONTACT_6D LOCAL_WORLD_ALIGNED), src/fulldynamics.cpp:56-75.
+//
+// The model-independent kernels of smpc_solver_kernels.h (line search bookkeeping, apply, recede, gather) are instantiated
+// on FullDims unchanged: DevModel / StageShared are specialised here with the member names those kernels use.
+#pragma once
+#include "smpc_model.h"
+
+namespace smpc
+{
+  template <int NJ_, int NF_, int FS_>
+  struct FullDims
+  {
+    static constexpr int NJ = NJ_;     // joints incl. free-flyer
+    static constexpr int NF = NF_;     // feet
+    static constexpr int FS = FS_;     // contact force size
+    static constexpr int NV = NJ_ + 5;
+    static constexpr int NQ = NJ_ + 6;
+    static constexpr int NX = NQ + NV;
+    static constexpr int NDX = 2 * NV;
+    static constexpr int NA = NV - 6;
+    static constexpr int NU = NA;
+    static constexpr int NCM = FS_ * NF_;                     // contact rows when every foot is in contact
+    static constexpr int NCONE1 = FS_ == 6 ? 17 : 0;          // cone rows per foot (wrench cone, 6-D feet)
+    static constexpr int NCONE = NCONE1 * NF_;
+    static constexpr int NC = NU + NA + NCONE;
+    static constexpr int NXU = NDX + NU;
+    // LQ knot block (doubles), one per (instance, stage)
+    static constexpr int O_A = 0;
+    static constexpr int O_B = O_A + NDX * NDX;
+    static constexpr int O_Q = O_B + NDX * NU;
+    static constexpr int O_S = O_Q + NDX * NDX;
+    static constexpr int O_R = O_S + NDX * NU;
+    static constexpr int O_C = O_R + NU * NU;       // Cd: dense cone rows, NCONE x NDX (active rows, else zero)
+    static constexpr int O_D = O_C + NCONE * NDX;   // Dd: NCONE x NU
+    static constexpr int O_q = O_D + NCONE * NU;
+    static constexpr int O_r = O_q + NDX;
+    static constexpr int O_f = O_r + NU;
+    static constexpr int O_d = O_f + NDX;           // mu (nu+ - nu), all NC rows
+    static constexpr int O_lx = O_d + NC;
+    static constexpr int O_lu = O_lx + NDX;
+    static constexpr int O_lpd = O_lu + NU;
+    static constexpr int O_vpd = O_lpd + NDX;       // active ? 2 nu+ - nu : 0, all NC rows
+    static constexpr int O_act = O_vpd + NC;        // 1.0 / 0.0 activity of the NU + NA box rows
+    static constexpr int LQ_STRIDE = ((O_act + NU + NA + 7) / 8) * 8;
+    // gains block per (instance, stage)
+    static constexpr int G_K = 0;                          // [K k]  NU x (NDX+1)
+    static constexpr int G_Z = G_K + NU * (NDX + 1);       // [Z z]  NCONE x (NDX+1)  (multiplier feedback of the dense rows)
+    static constexpr int G_Pt = G_Z + NCONE * (NDX + 1);   // P~ (NDX x NDX)
+    static constexpr int G_pn = G_Pt + NDX * NDX;          // p_{t+1}
+    static constexpr int G_STRIDE = ((G_pn + NDX + 7) / 8) * 8;
+    static constexpr int LS_N = 10;
+    static_assert(NJ_ <= 32, "ancestor bit sets");
+  };
+
+  // the part of the device model every phase reads: copied into LDS once per block
+  template <class D>
+  struct FullHead
+  {
+    double total_mass, dt, gravity[3], mu; // mu: ProxDDP penalty (mu_init)
+    // FullDynamicsSettings (include/simple-mpc/fulldynamics.hpp:28-65)
+    double w_cent[36], w_forces[D::FS * D::FS], w_frame[D::FS * D::FS];
+    double Kp[D::FS], Kd[D::FS];
+    double umin[D::NU], umax[D::NU], qmin[D::NA], qmax[D::NA];
+    double fric_mu, Lfoot, Wfoot;
+    double prox_accuracy, prox_mu; // ProximalSettings(1e-9, 1e-10, 10), src/fulldynamics.cpp:39
+    int prox_max_iter, torque_limits, kinematics_limits, force_cone, w_diag, nlevels;
+    int parent[D::NJ], jtype[D::NJ], level[D::NJ];
+    unsigned anc[D::NJ], children[D::NJ]; // bit a of anc[j]: joint a is j or one of its ancestors
+    int foot_joint[D::NF];
+    int pad_[2 + (6 + 5 * D::NJ + D::NF) % 2];
+    double wxd[D::NDX], wud[D::NU]; // diagonals of w_x, w_u
+  };
+  template <class D>
+  struct FullDevModel : FullHead<D>
+  {
+    double jpR[D::NJ][9];
+    double jpp[D::NJ][3];
+    double mass[D::NJ];
+    double com[D::NJ][3];
+    double inertia[D::NJ][6];
+    double foot_p[D::NF][3];
+    double foot_ref_p[D::NF][3];
+    double w_x[D::NDX * D::NDX];
+    double w_u[D::NU * D::NU];
+    double x_term[D::NX];
+  };
+  template <int NJ_, int NF_, int FS_>
+  struct DevModel<FullDims<NJ_, NF_, FS_>> : FullDevModel<FullDims<NJ_, NF_, FS_>>
+  {
+  };
+
+  // stage descriptor shared by the phase-aligned batch
+  template <int NJ_, int NF_, int FS_>
+  struct StageShared<FullDims<NJ_, NF_, FS_>>
+  {
+    typedef FullDims<NJ_, NF_, FS_> D;
+    unsigned mask;
+    unsigned pad;
+    double u_ref[D::NU];   // control reference (zero in the reference's stages, src/fulldynamics.cpp:89)
+    double f_ref[D::NCM];  // contact-force reference per foot (src/fulldynamics.cpp:122-137)
+    double x_tgt[D::NX];
+  };
+} // namespace smpc

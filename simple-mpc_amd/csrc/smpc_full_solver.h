@@ -1,0 +1,292 @@
+// smpc_full_solver.h -- proximal Riccati backward / forward sweeps for stages with DENSE A, B (full-dynamics OCP): the same
+// recursion as riccati_body / forward_body (smpc_solver_kernels.h; reference gar::ProximalRiccatiSolver, src/mpc.cpp:52;
+// SURVEY App. B.5), with the constraint rows of the full-dynamics stage:
+//   torque box rows  (unit selectors on u):  R^_ii += act_i / mu,  r^_i += act_i d_i / mu,   dnu_i = (act_i du_i + d_i) / mu
+//   joint box rows   (unit selectors on x):  P_t(6+i, 6+i) += act_i / mu,  p_t(6+i) += act_i d_i / mu,  dnu = (act dx_{6+i} + d) / mu
+// (eliminating a multiplier row whose Jacobian is a unit selector adds a diagonal term: no loss of accuracy, unlike the dense
+// cone rows of the centroidal kernel).  This file holds the model-independent VALU version (cross-check, any size); the
+// matrix-core version is riccati_dense_body in smpc_riccati_dense.h.
+#pragma once
+#include "smpc_full_model.h"
+#include "smpc_solver_kernels.h"
+
+namespace smpc
+{
+  template <class D>
+  struct RiccatiFullLds
+  {
+    static constexpr int NDX = D::NDX, NU = D::NU, NC = D::NC, NXU = D::NDX + D::NU;
+    double P[NDX * NDX];
+    double MT[NDX * NXU];
+    double AB[NDX * NXU];
+    double QS[NDX * NXU];
+    double Rh[NU * NU];
+    double p[NDX], pt[NDX], qh[NDX], rh[NU], f[NDX], d[NC], act[D::NU + D::NA], col[NDX], wr[NU], kk[NU];
+  };
+
+  template <class D, int NT>
+  SMPC_DEV void riccati_full_body(const SolverArgs<D> & ka, int block)
+  {
+    static_assert(NT >= 64, "needs one lane per right-hand side column");
+    constexpr int NDX = D::NDX, NU = D::NU, NC = D::NC, NXU = NDX + NU, NA = D::NA;
+    constexpr int TL = (NDX % 3 == 0 && NXU % 3 == 0 && NU % 3 == 0) ? 3 : 2;
+    static_assert(NDX % TL == 0 && NXU % TL == 0 && NU % TL == 0, "register tiles must divide the dimensions");
+    static_assert(NDX + 1 <= NT, "one lane per right-hand side column");
+    static_assert(D::NCONE == 0, "dense cone rows are handled by the matrix-core sweep only");
+    const Buffers<D> & b = ka.b;
+    const int H = b.H;
+    const int inst = block;
+    const double mu = b.model->mu, imu = 1.0 / mu;
+    SMPC_LDS(RiccatiFullLds<D>, lds, 1);
+    RiccatiFullLds<D> & s = lds[0];
+    SMPC_LANES(NT)
+    {
+      for (int i = lane; i < NDX * NDX; i += NT)
+        s.P[i] = b.QN[(size_t)inst * NDX * NDX + i];
+      for (int i = lane; i < NDX; i += NT)
+        s.p[i] = b.qN[(size_t)inst * NDX + i];
+    }
+    SMPC_LANES_END
+    for (int t = H - 1; t >= 0; t--)
+    {
+      const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
+      double * g = b.gains + ((size_t)inst * H + t) * D::G_STRIDE;
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NDX * NDX; idx += NT)
+        {
+          const int i = idx / NDX, j = idx % NDX;
+          s.AB[i * NXU + j] = lq[D::O_A + idx];
+          s.MT[i * NDX + j] = mu * s.P[idx] + (i == j ? 1.0 : 0.0);
+        }
+        for (int idx = lane; idx < NDX * NU; idx += NT)
+        {
+          const int i = idx / NU, j = idx % NU;
+          s.AB[i * NXU + NDX + j] = lq[D::O_B + idx];
+        }
+        for (int i = lane; i < NDX; i += NT)
+        {
+          s.f[i] = lq[D::O_f + i];
+          g[D::G_pn + i] = s.p[i];
+        }
+        for (int i = lane; i < NC; i += NT)
+          s.d[i] = lq[D::O_d + i];
+        for (int i = lane; i < NU + NA; i += NT)
+          s.act[i] = lq[D::O_act + i];
+      }
+      SMPC_LANES_END
+      SMPC_LANES(NT)
+      if (lane < NDX)
+      {
+        double acc = s.p[lane];
+        for (int j = 0; j < NDX; j++)
+          acc += s.P[lane * NDX + j] * s.f[j];
+        s.pt[lane] = acc;
+      }
+      SMPC_LANES_END
+      wg_cholesky<NDX, NT>(s.MT, NDX, s.col);
+      SMPC_LANES(NT)
+      lane_chol_solve<NDX, NT>(
+        s.MT, NDX, NDX + 1, lane, [&](int i, int c) { return c < NDX ? s.P[i * NDX + c] : s.pt[i]; }, [&](int, int, double) {},
+        [&](int i, int c, double v) {
+          if (c < NDX)
+            s.P[i * NDX + c] = v;
+          else
+            s.pt[i] = v;
+        });
+      SMPC_LANES_END
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < NDX * NDX; idx += NT)
+      {
+        const int i = idx / NDX, j = idx % NDX;
+        if (j < i)
+        {
+          const double v = 0.5 * (s.P[i * NDX + j] + s.P[j * NDX + i]);
+          s.P[i * NDX + j] = v;
+          s.P[j * NDX + i] = v;
+        }
+      }
+      SMPC_LANES_END
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NDX * NDX; idx += NT)
+          g[D::G_Pt + idx] = s.P[idx];
+        mm_tn<NDX, NXU, NDX, TL, TL, NT>(
+          s.P, NDX, s.AB, NXU, lane, [](int, int) { return 0.0; }, [&](int i, int j, double v) { s.MT[i * NXU + j] = v; });
+      }
+      SMPC_LANES_END
+      SMPC_LANES(NT)
+      {
+        mm_tn<NDX, NXU, NDX, TL, TL, NT>(
+          s.AB, NXU, s.MT, NXU, lane, [&](int i, int j) { return j < NDX ? lq[D::O_Q + i * NDX + j] : lq[D::O_S + i * NU + j - NDX]; },
+          [&](int i, int j, double v) { s.QS[i * NXU + j] = v; });
+        mm_tn<NU, NU, NDX, TL, TL, NT>(
+          s.AB + NDX, NXU, s.MT + NDX, NXU, lane,
+          [&](int i, int j) { return lq[D::O_R + i * NU + j] + (i == j ? imu * s.act[i] : 0.0); }, // torque box rows
+          [&](int i, int j, double v) { s.Rh[i * NU + j] = v; });
+        for (int c = lane; c < NXU; c += NT)
+        {
+          double acc = c < NDX ? lq[D::O_q + c] : lq[D::O_r + c - NDX] + imu * s.act[c - NDX] * s.d[c - NDX];
+          for (int k = 0; k < NDX; k++)
+            acc += s.AB[k * NXU + c] * s.pt[k];
+          if (c < NDX)
+            s.qh[c] = acc;
+          else
+            s.rh[c - NDX] = acc;
+        }
+      }
+      SMPC_LANES_END
+      wg_cholesky<NU, NT>(s.Rh, NU, s.col);
+      SMPC_LANES(NT)
+      lane_chol_solve<NU, NT>(
+        s.Rh, NU, NDX + 1, lane, [&](int i, int c) { return c < NDX ? s.QS[c * NXU + NDX + i] : s.rh[i]; },
+        [&](int i, int c, double v) { s.MT[i * (NDX + 1) + c] = v; },
+        [&](int i, int c, double v) { g[D::G_K + i * (NDX + 1) + c] = -v; });
+      SMPC_LANES_END
+      // P_t = Q^ - W^T W + box ;  p_t = q^ - W^T w_r + box
+      SMPC_LANES(NT)
+      {
+        mm_tn<NDX, NDX, NU, TL, TL, NT>(
+          s.MT, NDX + 1, s.MT, NDX + 1, lane, [](int, int) { return 0.0; },
+          [&](int i, int j, double v) {
+            const bool bx = i == j && i >= 6 && i < 6 + NA;
+            s.P[i * NDX + j] = s.QS[i * NXU + j] - v + (bx ? imu * s.act[NU + i - 6] : 0.0);
+          });
+        if (lane >= NT - 64 && lane < NT - 64 + NDX)
+        {
+          const int i = lane - (NT - 64);
+          double acc = s.qh[i];
+          for (int m = 0; m < NU; m++)
+            acc -= s.MT[m * (NDX + 1) + i] * s.MT[m * (NDX + 1) + NDX];
+          if (i >= 6 && i < 6 + NA)
+            acc += imu * s.act[NU + i - 6] * s.d[NU + i - 6];
+          s.p[i] = acc;
+        }
+      }
+      SMPC_LANES_END
+      static_assert(NDX <= 64, "one lane per row in the p_t phase");
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < NDX * NDX; idx += NT)
+      {
+        const int i = idx / NDX, j = idx % NDX;
+        if (j < i)
+        {
+          const double v = 0.5 * (s.P[i * NDX + j] + s.P[j * NDX + i]);
+          s.P[i * NDX + j] = v;
+          s.P[j * NDX + i] = v;
+        }
+      }
+      SMPC_LANES_END
+    }
+  }
+
+  // forward sweep + merit directional derivative, one wavefront per instance (dense A, B, P~ from the gains block)
+  template <class D>
+  SMPC_DEV void forward_full_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NDX = D::NDX, NU = D::NU, NC = D::NC, NA = D::NA;
+    static_assert(D::NCONE == 0, "dense cone rows: Z feedback of the matrix-core sweep");
+    const Buffers<D> & b = ka.b;
+    const int H = b.H, R = b.R;
+    const int inst = block;
+    const double mu = b.model->mu;
+    SMPC_LDS(double, dx, D::NDX);
+    SMPC_LDS(double, du, D::NU);
+    SMPC_LDS(double, y, D::NDX);
+    SMPC_LDS(double, part, 64);
+    SMPC_LDS(double, lpd_prev, D::NDX);
+    SMPC_LANES(NT)
+    {
+      for (int i = lane; i < NDX; i += NT)
+      {
+        dx[i] = 0.0;
+        lpd_prev[i] = 0.0;
+        b.dxs[((size_t)inst * (H + 1)) * NDX + i] = 0.0;
+      }
+      part[lane] = 0.0;
+    }
+    SMPC_LANES_END_WAVE
+    for (int t = 0; t < H; t++)
+    {
+      const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
+      const double * g = b.gains + ((size_t)inst * H + t) * D::G_STRIDE;
+      const size_t lt = (size_t)inst * H + t;
+      // du = k + K dx
+      SMPC_LANES(NT)
+      for (int i = lane; i < NU; i += NT)
+      {
+        const double * Kr = g + D::G_K + i * (NDX + 1);
+        double acc = Kr[NDX];
+        for (int j = 0; j < NDX; j++)
+          acc += Kr[j] * dx[j];
+        du[i] = acc;
+        b.dus[lt * NU + i] = acc;
+        part[lane] += lq[D::O_lu + i] * acc;
+      }
+      SMPC_LANES_END_WAVE
+      // dnu of the box rows ; y = A dx + B du + f - mu p_{t+1}
+      SMPC_LANES(NT)
+      {
+        for (int r = lane; r < NU + NA; r += NT)
+        {
+          const double d = lq[D::O_d + r], act = lq[D::O_act + r];
+          const double lin = r < NU ? du[r] : dx[6 + r - NU];
+          const double dnu = (act * lin + d) / mu;
+          b.dvs[lt * NC + r] = dnu;
+          part[lane] += lq[D::O_vpd + r] * (mu * dnu - d) - d * dnu;
+        }
+        for (int i = lane; i < NDX; i += NT)
+        {
+          const double * Ar = lq + D::O_A + i * NDX;
+          const double * Br = lq + D::O_B + i * NU;
+          double acc = 0.0;
+          for (int j = 0; j < NDX; j++)
+            acc += Ar[j] * dx[j];
+          for (int j = 0; j < NU; j++)
+            acc += Br[j] * du[j];
+          const double fi = lq[D::O_f + i], pn = g[D::G_pn + i];
+          part[lane] += (lq[D::O_lx + i] - lpd_prev[i]) * dx[i] + lq[D::O_lpd + i] * acc;
+          y[i] = acc + fi - mu * pn;
+        }
+      }
+      SMPC_LANES_END_WAVE
+      // w = P~ y ; dx+ = y - mu w ; dlam+ = w + p_{t+1}
+      SMPC_LANES(NT)
+      for (int i = lane; i < NDX; i += NT)
+      {
+        const double * Pr = g + D::G_Pt + i * NDX;
+        double w = 0.0;
+        for (int j = 0; j < NDX; j++)
+          w += Pr[j] * y[j];
+        const double dxn = y[i] - mu * w;
+        const double dl = w + g[D::G_pn + i];
+        b.dxs[((size_t)inst * (H + 1) + t + 1) * NDX + i] = dxn;
+        b.dlams[lt * NDX + i] = dl;
+        part[lane] -= lq[D::O_f + i] * dl;
+        lpd_prev[i] = lq[D::O_lpd + i];
+        dx[i] = dxn; // (only y is read in this phase)
+      }
+      SMPC_LANES_END_WAVE
+    }
+    SMPC_LANES(NT)
+    for (int i = lane; i < NDX; i += NT)
+    {
+      const int sl = ring_slot(ka.head, H - 1, R);
+      const double lamH = b.lams[((size_t)inst * R + sl) * NDX + i];
+      const double lxN = b.qN[(size_t)inst * NDX + i] + lamH;
+      part[lane] += (lxN - lpd_prev[i]) * dx[i];
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      double sacc = 0.0;
+      for (int i = 0; i < 64; i++)
+        sacc += part[i];
+      b.scal[(size_t)inst * SC_N + SC_DPHI0] = sacc;
+      b.ls_sel[inst] = -1;
+    }
+    SMPC_LANES_END_WAVE
+  }
+} // namespace smpc

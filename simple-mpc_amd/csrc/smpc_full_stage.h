@@ -1,0 +1,1507 @@
+// smpc_full_stage.h -- the per-(instance, stage) body of the FULL-DYNAMICS OCP: one 64-lane wavefront evaluates the
+// stage the reference builds in FullDynamicsOCP::createStage (src/fulldynamics.cpp:78-214):
+//   HOT(1) evaluate    constrained forward dynamics (MultibodyConstraintFwdDynamics, contacts of src/fulldynamics.cpp:50-75,
+//                      ProximalSettings(1e-9, 1e-10, 10) :39) + IntegratorSemiImplEuler (:139-140), the cost stack (:88-137:
+//                      state, control, centroidal momentum, foot pose per foot, contact force per foot in contact), the
+//                      torque / joint boxes (:144-162)
+//   HOT(2) derivatives d a / d(q, v, tau), d lambda / d(q, v, tau) by implicit differentiation of the contact KKT system
+//                      (what pinocchio::computeConstraintDynamicsDerivatives provides), A, B, Gauss-Newton Hessians
+//   HOT(3) LQ assembly knot (A, B, Q, S, R, q, r, f, d, ...) straight to HBM
+// World-frame spatial formulation (the one of smpc_kino_stage.h, DESIGN.md "Rigid-body derivatives"):
+//   d_k = v_lam x S_k,  A_k = (a_lam - g) x S_k + v_lam x d_k
+//   d tau_m / d q_k = S_m . (Ic_s A_k + Bc_s d_k) [+ S_m . (S_k x* (Fc_i - contact wrenches below i)) if joint(m) is a strict
+//                     ancestor of joint(k) = i],   s = the lower of joint(m), joint(k) (same branch)
+//   d tau_m / d v_k = S_m . (Bc_s S_k + Ic_s (v_i x S_k + d_k))
+// Generic in the robot shape (FullDims<NJ, NF, FS>): every lane map is a strided loop, nothing assumes NV <= 20.
+#pragma once
+#include "smpc_full_model.h"
+#include "smpc_kino_kernels.h" // lanes_integrate / lanes_difference, StageKernelArgs
+#include <cstddef>
+
+namespace smpc
+{
+  SMPC_HD int jof(int k) { return k < 6 ? 0 : k - 5; } // joint of dof k
+
+  template <class D, bool DERIV>
+  struct FullScratch
+  {
+    static constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX, NX = D::NX, NC = D::NC;
+    static constexpr int NR = NCM + 1;           // columns of W = [M^-1 b | M^-1 J^T]
+    static constexpr int NCOL = 2 * NV + NU;     // derivative columns (q | v | tau)
+    static constexpr int NGN = 6 + 3 * NF + NCM; // rows of the stacked Gauss-Newton Jacobian: momentum | foot positions | forces
+    FullHead<D> h;
+    // block inputs
+    double x[NX], u[NU], xn1[NX], x_tgt[NX], u_ref[NU], f_ref[NCM], foot_ref[NF * 3];
+    double lam_next[NDX], nu[NC];
+    // kinematics
+    double oR[NJ * 9], op[NJ * 3], S[NV * 6], vel[NJ * 6], acc[NJ * 6], I[NJ * 10], Ic[NJ * 10], hc[NJ * 6], Fc[NJ * 6];
+    double footp[NF * 3], com[3], hg[6];
+    // constrained dynamics
+    double M[NV * NV];    // joint-space inertia -> its Cholesky factor
+    double J[NCM * NV];   // contact Jacobian (rows of absent contacts zero)
+    double W[NV * NR];    // [M^-1 (S tau - nle) | M^-1 J^T]
+    double G[NCM * NCM];  // damped Delassus matrix -> its factor
+    double Gi[NCM * NCM]; // its inverse
+    double IcS[NV * 6];
+    double gam[NCM], JMb[NCM], lam[NCM], rhs[NCM], dl[NCM], tmp[64];
+    double a[NV];
+    double xnext[NX], e[NDX];
+    // costs / constraints / multipliers
+    double rx[NDX], Wrx[NDX], ru[NU], Wru[NU], Whg[6], rf[NF * 3], Wrf[NF * 3], rl[NCM], Wrl[NCM];
+    double cval[NC], vplus[NC], lamp[NDX];
+    int act[NC + NC % 2];
+    double part[64], part2[64], part8[16], red[4];
+    int iters_[2];
+  };
+  template <class D>
+  struct FullScratchDeriv
+  {
+    static constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX;
+    static constexpr int NCOL = 2 * NV + NU, NGN = 6 + 3 * NF + NCM;
+    double Bc[NJ * 36], dk[NV * 6], Ak[NV * 6], Fgc[NJ * 6], Wc[NF * 6];
+    double R1[NV * NCOL];       // [r1q | r1v | r1t] -> M^-1 R1 -> [da_dq | da_dv | da_dtau]
+    double JT[NGN * NCOL];      // stacked Gauss-Newton Jacobian; rows 0..NCM-1: [r2q | r2v | 0] -> [dlam_dq | dlam_dv | dlam_dtau]
+    double WJ[NGN * NCOL];      // block-diagonal weight times JT
+    double Ag[6 * NV], dh_dq[6 * NV], Jfoot[NF * 3 * NV];
+    double Je3[9], JeQ[9], Jq[36], Jl[36], WJl[NDX * 6], JWJ[36];
+    double gx[NDX], gu[NU]; // cost gradients
+    double dual[128];
+  };
+
+  // copy the head of the device model into LDS (all loads in flight before the first store)
+  template <class D, int NT>
+  SMPC_DEV void full_load_head(FullHead<D> & dst, const DevModel<D> * gm, int lane)
+  {
+    constexpr int N = (int)(sizeof(FullHead<D>) / sizeof(double)), PER = (N + NT - 1) / NT;
+    static_assert(sizeof(FullHead<D>) % sizeof(double) == 0, "LDS copy is done in doubles");
+    const double * src = reinterpret_cast<const double *>(static_cast<const FullHead<D> *>(gm));
+    double * d = reinterpret_cast<double *>(&dst);
+    double r[PER];
+#pragma unroll
+    for (int n = 0; n < PER; n++)
+      r[n] = src[lane + n * NT < N ? lane + n * NT : 0];
+#pragma unroll
+    for (int n = 0; n < PER; n++)
+      if (lane + n * NT < N)
+        d[lane + n * NT] = r[n];
+  }
+
+  SMPC_HD double sv_dot6(const SV & m, const SV & f) { return dot(m.l, f.l) + dot(m.a, f.a); }
+
+  // in-place lower Cholesky of the N x N matrix A (row-major), lane = row held in registers, finished rows broadcast from LDS
+  template <int NT, int N>
+  SMPC_DEV void fwave_cholesky(double * A, double * tmp)
+  {
+    static_assert(N <= NT, "one row per lane");
+    SMPC_PLA(double, row, NT, N);
+    SMPC_LANES(NT)
+    {
+      const int r = lane < N ? lane : 0;
+#pragma unroll
+      for (int k = 0; k < N; k++)
+        SMPC_PLV(row)[k] = A[r * N + k];
+    }
+    SMPC_LANES_END_WAVE
+#pragma unroll
+    for (int j = 0; j < N; j++)
+    {
+      SMPC_LANES(NT)
+      {
+        double s = SMPC_PLV(row)[j];
+#pragma unroll
+        for (int k = 0; k < j; k++)
+          s -= SMPC_PLV(row)[k] * A[j * N + k];
+        if (lane >= j && lane < N)
+          tmp[lane] = s;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
+        const double d = sqrt(tmp[j]);
+        const double v = lane == j ? d : tmp[lane < N ? lane : 0] / d;
+        SMPC_PLV(row)[j] = v;
+        if (lane >= j && lane < N)
+          A[lane * N + j] = v;
+      }
+      SMPC_LANES_END_WAVE
+    }
+  }
+  // columns c0 .. c0 + NT - 1 (< ncols) of X (N rows, row stride ldx) <- (L L^T)^-1 X ; lane = column, held in registers
+  template <int NT, int N>
+  SMPC_DEV void fwave_chol_solve(const double * L, double * X, int ncols, int ldx)
+  {
+    for (int c0 = 0; c0 < ncols; c0 += NT)
+    {
+      SMPC_LANES(NT)
+      {
+        const int c = c0 + lane < ncols ? c0 + lane : c0;
+        double y[N];
+#pragma unroll
+        for (int i = 0; i < N; i++)
+          y[i] = X[i * ldx + c];
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+          double s = y[i];
+#pragma unroll
+          for (int k = 0; k < i; k++)
+            s -= L[i * N + k] * y[k];
+          y[i] = s / L[i * N + i];
+        }
+#pragma unroll
+        for (int i = N - 1; i >= 0; i--)
+        {
+          double s = y[i];
+#pragma unroll
+          for (int k = i + 1; k < N; k++)
+            s -= L[k * N + i] * y[k];
+          y[i] = s / L[i * N + i];
+        }
+        if (c0 + lane < ncols)
+        {
+#pragma unroll
+          for (int i = 0; i < N; i++)
+            X[i * ldx + c] = y[i];
+        }
+      }
+      SMPC_LANES_END_WAVE
+    }
+  }
+
+  // -------------------------------------------------------------------------------------------------------------
+  // Kinematics, composites, joint-space inertia, contact rows, factorisations, proximal iteration, accelerations.
+  // dyn = false: kinematics / momentum only (terminal node).
+  // -------------------------------------------------------------------------------------------------------------
+  template <class D, bool DERIV, class SC, class SD>
+  SMPC_DEV void full_dynamics_phases(SC & sc, SD * sd, const DevModel<D> & mg, unsigned mask, bool dyn)
+  {
+    constexpr int NT = 64;
+    constexpr int NJ = D::NJ, NV = D::NV, NQ = D::NQ, NF = D::NF, NCM = D::NCM, NR = SC::NR, FS = D::FS;
+    static_assert(NJ <= NT && NV <= NT && NR <= NT, "one joint / dof / right-hand side per lane");
+    static_assert(FS == 3, "6-D contacts: LOCAL_WORLD_ALIGNED rows are added with the Talos table");
+    const FullHead<D> & h = sc.h;
+    const int nlev = h.nlevels;
+    const double * vq = &sc.x[NQ];
+    SMPC_PLA(double, rl, NT, 9);
+    // ---- joint-local transforms (all joints at once) ----
+    SMPC_LANES(NT)
+    if (lane < NJ)
+    {
+      const int j = lane;
+      if (j == 0)
+      {
+        const M3 R = quat_to_R(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]});
+        const V3 p = ld3(sc.x);
+        SV v = sv0();
+        for (int k = 0; k < 6; k++)
+        {
+          const int col = k % 3;
+          const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
+          const SV sk = k < 3 ? SV{ax, mk3(0, 0, 0)} : SV{cross(p, ax), ax};
+          stsv(&sc.S[k * 6], sk);
+          v = v + vq[k] * sk;
+        }
+        stm3(&sc.oR[0], R);
+        st3(&sc.op[0], p);
+        stsv(&sc.vel[0], v);
+        stsv(&sc.acc[0], sv0());
+      }
+      else
+      {
+        double s, c;
+        sincos(sc.x[6 + j], &s, &c);
+        const int jt = h.jtype[j];
+        const M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -s, 0, s, c} : (jt == 2 ? M3{c, 0, s, 0, 1, 0, -s, 0, c} : M3{c, -s, 0, s, c, 0, 0, 0, 1});
+        stm3(SMPC_PLV(rl), ldm3(mg.jpR[j]) * Rq);
+      }
+    }
+    SMPC_LANES_END_WAVE
+    // ---- root -> leaf: placement, motion column, velocity, bias acceleration ----
+    for (int lvl = 1; lvl < nlev; lvl++)
+    {
+      SMPC_LANES(NT)
+      if (lane > 0 && lane < NJ && h.level[lane] == lvl)
+      {
+        const int j = lane, par = h.parent[j];
+        const M3 Rp = ldm3(&sc.oR[par * 9]);
+        const M3 R = Rp * ldm3(SMPC_PLV(rl));
+        const V3 p = ld3(&sc.op[par * 3]) + Rp * ld3(mg.jpp[j]);
+        const int col = h.jtype[j] - 1;
+        const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
+        const SV sk = SV{cross(p, ax), ax};
+        const SV vp = ldsv(&sc.vel[par * 6]);
+        const double qd = vq[j + 5];
+        stm3(&sc.oR[j * 9], R);
+        st3(&sc.op[j * 3], p);
+        stsv(&sc.S[(j + 5) * 6], sk);
+        stsv(&sc.vel[j * 6], vp + qd * sk);
+        stsv(&sc.acc[j * 6], ldsv(&sc.acc[par * 6]) + qd * crm(vp, sk));
+      }
+      SMPC_LANES_END_WAVE
+    }
+    // ---- world inertias, momenta, bias forces (all joints at once); foot positions ----
+    SMPC_LANES(NT)
+    if (lane < NJ)
+    {
+      const int j = lane;
+      const M3 R = ldm3(&sc.oR[j * 9]);
+      const V3 p = ld3(&sc.op[j * 3]);
+      const SV v = ldsv(&sc.vel[j * 6]), a = ldsv(&sc.acc[j * 6]);
+      const double m = mg.mass[j];
+      const V3 c = R * ld3(mg.com[j]) + p;
+      const double * il = mg.inertia[j];
+      const M3 Il = M3{il[0], il[1], il[3], il[1], il[2], il[4], il[3], il[4], il[5]};
+      const M3 Iw = R * Il * transpose(R);
+      const double cc = dot(c, c);
+      SI I;
+      I.m = m;
+      I.mc = m * c;
+      I.jxx = Iw.a00 + m * (cc - c.x * c.x);
+      I.jxy = Iw.a01 - m * c.x * c.y;
+      I.jxz = Iw.a02 - m * c.x * c.z;
+      I.jyy = Iw.a11 + m * (cc - c.y * c.y);
+      I.jyz = Iw.a12 - m * c.y * c.z;
+      I.jzz = Iw.a22 + m * (cc - c.z * c.z);
+      stsi(&sc.I[j * 10], I);
+      stsi(&sc.Ic[j * 10], I);
+      const SV hh = I * v;
+      stsv(&sc.hc[j * 6], hh);
+      stsv(&sc.Fc[j * 6], I * a + crf(v, hh));
+    }
+    else if (lane >= 32 && lane < 32 + NF)
+    {
+      const int f = lane - 32, j = h.foot_joint[f];
+      st3(&sc.footp[f * 3], ldm3(&sc.oR[j * 9]) * ld3(mg.foot_p[f]) + ld3(&sc.op[j * 3]));
+    }
+    SMPC_LANES_END_WAVE
+    static_assert(NF <= 32 && NJ <= 32, "lane map of the inertia / foot phase");
+    if constexpr (DERIV)
+    {
+      // per-body velocity-product matrices  B_l y = v_l x* (I_l y) - I_l (v_l x y)  (lane = (body, column))
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < NJ * 6; idx += NT)
+      {
+        const int l = idx / 6, m = idx % 6;
+        const SI Il = ldsi(&sc.I[l * 10]);
+        const SV vl = ldsv(&sc.vel[l * 6]);
+        const V3 e = mk3(m % 3 == 0, m % 3 == 1, m % 3 == 2), z = mk3(0, 0, 0);
+        const SV y = m < 3 ? SV{e, z} : SV{z, e};
+        const SV col = crf(vl, Il * y) - Il * crm(vl, y);
+        double * dst = &sd->Bc[l * 36 + m];
+        dst[0] = col.l.x;
+        dst[6] = col.l.y;
+        dst[12] = col.l.z;
+        dst[18] = col.a.x;
+        dst[24] = col.a.y;
+        dst[30] = col.a.z;
+      }
+      SMPC_LANES_END_WAVE
+    }
+    // ---- composites, leaf -> root: lane = one scalar of (Ic | hc | Fc | Bc) ----
+    SMPC_LANES(NT)
+    if (lane < 22 + (DERIV ? 36 : 0))
+    {
+      double * base = lane < 10 ? sc.Ic : (lane < 16 ? sc.hc : (lane < 22 ? sc.Fc : (DERIV ? sd->Bc : sc.Fc)));
+      const int stride = lane < 10 ? 10 : (lane < 22 ? 6 : 36);
+      const int e = lane < 10 ? lane : (lane < 16 ? lane - 10 : (lane < 22 ? lane - 16 : lane - 22));
+      for (int j = NJ - 1; j >= 1; j--)
+      {
+        const int par = h.parent[j];
+        base[par * stride + e] += base[j * stride + e];
+      }
+    }
+    SMPC_LANES_END_WAVE
+    // ---- CoM, centroidal momentum; centroidal map columns (derivative pass) ----
+    SMPC_LANES(NT)
+    {
+      const SI I0 = ldsi(&sc.Ic[0]);
+      const V3 com = (1.0 / I0.m) * I0.mc;
+      if (lane == 32)
+      {
+        st3(sc.com, com);
+        const SV h0 = ldsv(&sc.hc[0]);
+        st3(&sc.hg[0], h0.l);
+        st3(&sc.hg[3], h0.a - cross(com, h0.l));
+      }
+      if constexpr (DERIV)
+      {
+        if (lane < NV)
+        {
+          const int k = lane, j = jof(k);
+          const SV c = ldsi(&sc.Ic[j * 10]) * ldsv(&sc.S[k * 6]);
+          const V3 ang = c.a - cross(com, c.l);
+          sd->Ag[0 * NV + k] = c.l.x;
+          sd->Ag[1 * NV + k] = c.l.y;
+          sd->Ag[2 * NV + k] = c.l.z;
+          sd->Ag[3 * NV + k] = ang.x;
+          sd->Ag[4 * NV + k] = ang.y;
+          sd->Ag[5 * NV + k] = ang.z;
+        }
+      }
+    }
+    SMPC_LANES_END_WAVE
+    if (!dyn)
+      return;
+    // ---- Ic_j S_l ; bias forces ; right-hand side S tau - nle ----
+    SMPC_LANES(NT)
+    if (lane < NV)
+    {
+      const int l = lane, j = jof(l);
+      const SI Ic = ldsi(&sc.Ic[j * 10]);
+      const SV Sl = ldsv(&sc.S[l * 6]);
+      stsv(&sc.IcS[l * 6], Ic * Sl);
+      const SV g{ld3(h.gravity), mk3(0, 0, 0)};
+      const SV Fg = ldsv(&sc.Fc[j * 6]) - Ic * g; // uniform field: every body accelerates with -g relative to free fall
+      sc.W[l * NR] = (l >= 6 ? sc.u[l - 6] : 0.0) - sv_dot6(Sl, Fg);
+    }
+    SMPC_LANES_END_WAVE
+    // ---- joint-space inertia M_kl = S_k . (Ic_j S_l) on the branch ; contact rows zeroed ----
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < NV * NV; idx += NT)
+      {
+        const int k = idx / NV, l = idx % NV;
+        const int jk = jof(k), jl = jof(l);
+        double v = 0.0;
+        if ((h.anc[jl] >> jk) & 1u)
+          v = sv_dot6(ldsv(&sc.S[k * 6]), ldsv(&sc.IcS[l * 6]));
+        else if ((h.anc[jk] >> jl) & 1u)
+          v = sv_dot6(ldsv(&sc.S[l * 6]), ldsv(&sc.IcS[k * 6]));
+        sc.M[idx] = v;
+      }
+      for (int idx = lane; idx < NCM * NV; idx += NT)
+        sc.J[idx] = 0.0;
+      if (lane < NCM)
+      {
+        sc.gam[lane] = 0.0;
+        sc.lam[lane] = 0.0;
+      }
+    }
+    SMPC_LANES_END_WAVE
+    // ---- contact rows (feet in contact first, in order): LOCAL linear Jacobian of the foot point, drift + corrector ----
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < NF * NV; idx += NT)
+      {
+        const int f = idx / NV, k = idx % NV;
+        const int jf = h.foot_joint[f], jk = jof(k);
+        if (((mask >> f) & 1u) && ((h.anc[jf] >> jk) & 1u))
+        {
+          const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+          const M3 Rf = ldm3(&sc.oR[jf * 9]); // foot frame rotation = joint rotation
+          const SV Sk = ldsv(&sc.S[k * 6]);
+          const V3 col = tmul(Rf, Sk.l + cross(Sk.a, ld3(&sc.footp[f * 3])));
+          sc.J[(3 * c + 0) * NV + k] = col.x;
+          sc.J[(3 * c + 1) * NV + k] = col.y;
+          sc.J[(3 * c + 2) * NV + k] = col.z;
+        }
+      }
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane < NF && ((mask >> lane) & 1u))
+    {
+      const int f = lane, jf = h.foot_joint[f];
+      const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+      const M3 Rf = ldm3(&sc.oR[jf * 9]);
+      const V3 p = ld3(&sc.footp[f * 3]);
+      const SV v = ldsv(&sc.vel[jf * 6]), ab = ldsv(&sc.acc[jf * 6]);
+      const V3 vp = v.l + cross(v.a, p);
+      const V3 ap = ab.l + cross(ab.a, p) + cross(v.a, vp); // classical acceleration of the point at zero joint accelerations
+      const V3 drift = tmul(Rf, ap), verr = tmul(Rf, vp), perr = tmul(Rf, (-1.0) * p);
+      sc.gam[3 * c + 0] = drift.x + h.Kd[0] * verr.x - h.Kp[0] * perr.x;
+      sc.gam[3 * c + 1] = drift.y + h.Kd[1] * verr.y - h.Kp[1] * perr.y;
+      sc.gam[3 * c + 2] = drift.z + h.Kd[2] * verr.z - h.Kp[2] * perr.z;
+    }
+    SMPC_LANES_END_WAVE
+    // ---- M = L L^T ; W = M^-1 [S tau - nle | J^T] ----
+    fwave_cholesky<NT, NV>(sc.M, sc.tmp);
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NV * NCM; idx += NT)
+    {
+      const int k = idx / NCM, c = idx % NCM;
+      sc.W[k * NR + 1 + c] = sc.J[c * NV + k];
+    }
+    SMPC_LANES_END_WAVE
+    fwave_chol_solve<NT, NV>(sc.M, sc.W, NR, NR);
+    // ---- damped Delassus matrix (unit diagonal on the rows of absent contacts), its inverse, J M^-1 b ----
+    const int nc = FS * __builtin_popcount(mask & ((1u << NF) - 1u));
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < NCM * NCM; idx += NT)
+      {
+        const int c = idx / NCM, d = idx % NCM;
+        double acc = 0.0;
+        for (int k = 0; k < NV; k++)
+          acc += sc.J[c * NV + k] * sc.W[k * NR + 1 + d];
+        if (c == d)
+          acc += c < nc ? h.prox_mu : 1.0;
+        sc.G[idx] = acc;
+        sc.Gi[idx] = c == d ? 1.0 : 0.0;
+      }
+      if (lane < NCM)
+      {
+        double acc = 0.0;
+        for (int k = 0; k < NV; k++)
+          acc += sc.J[lane * NV + k] * sc.W[k * NR];
+        sc.JMb[lane] = acc;
+      }
+    }
+    SMPC_LANES_END_WAVE
+    fwave_cholesky<NT, NCM>(sc.G, sc.tmp);
+    fwave_chol_solve<NT, NCM>(sc.G, sc.Gi, NCM, NCM);
+    // ---- proximal iteration:  lam <- G^-1 (mu lam - gamma - J M^-1 b)  until |d lam|_inf <= accuracy ----
+    int iters = 0;
+    if (nc > 0)
+      for (int it = 0; it < h.prox_max_iter; it++)
+      {
+        SMPC_LANES(NT)
+        if (lane < NCM)
+          sc.rhs[lane] = lane < nc ? h.prox_mu * sc.lam[lane] - sc.gam[lane] - sc.JMb[lane] : 0.0;
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        if (lane < NCM)
+        {
+          double acc = 0.0;
+          for (int d = 0; d < NCM; d++)
+            acc += sc.Gi[lane * NCM + d] * sc.rhs[d];
+          sc.dl[lane] = fabs(acc - sc.lam[lane]);
+          sc.lam[lane] = acc;
+        }
+        SMPC_LANES_END_WAVE
+        iters = it + 1;
+        double diff = 0.0; // wave-uniform: every lane reads the same values
+        for (int c = 0; c < NCM; c++)
+          diff = fmax(diff, sc.dl[c]);
+        if (diff <= h.prox_accuracy)
+          break;
+      }
+    // ---- a = M^-1 (S tau - nle) + M^-1 J^T lam ----
+    SMPC_LANES(NT)
+    {
+      if (lane < NV)
+      {
+        double acc = sc.W[lane * NR];
+        for (int c = 0; c < NCM; c++)
+          acc += sc.W[lane * NR + 1 + c] * sc.lam[c];
+        sc.a[lane] = acc;
+      }
+      if (lane == 0)
+        sc.iters_[0] = iters;
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // SE(3) work of a stage on two lanes: lane 0 integrates the base (x+ and, with derivatives, Jexp6(nu) and the action matrix
+  // of exp6(nu)^-1), lane 1 forms the base block of the state residual log6(M_tgt^-1 M) (and Jlog6).  One instruction stream.
+  template <class D, bool DERIV, class SC, class SD>
+  SMPC_DEV void full_se3_pair(SC & sc, SD * sd, double dt, bool zero_acc, int lane)
+  {
+    constexpr int NQ = D::NQ;
+    const double * vq = &sc.x[NQ];
+    const bool ex = lane == 0;
+    V3 vec, w;
+    if (ex)
+    {
+      const double a0 = zero_acc ? 0.0 : sc.a[0], a1 = zero_acc ? 0.0 : sc.a[1], a2 = zero_acc ? 0.0 : sc.a[2];
+      const double a3 = zero_acc ? 0.0 : sc.a[3], a4 = zero_acc ? 0.0 : sc.a[4], a5 = zero_acc ? 0.0 : sc.a[5];
+      vec = mk3(dt * (vq[0] + dt * a0), dt * (vq[1] + dt * a1), dt * (vq[2] + dt * a2));
+      w = mk3(dt * (vq[3] + dt * a3), dt * (vq[4] + dt * a4), dt * (vq[5] + dt * a5));
+    }
+    else
+    {
+      const double * xt = sc.x_tgt;
+      const SE3 Mt{quat_to_R(Quat{xt[3], xt[4], xt[5], xt[6]}), ld3(xt)};
+      const SE3 M = se3_mul(se3_inv(Mt), SE3{ldm3(&sc.oR[0]), ld3(&sc.op[0])});
+      w = log3(M.R);
+      vec = M.p;
+    }
+    const double t = sqrt(dot(w, w));
+    const M3 W = skew(w);
+    const M3 W2 = W * W;
+    const SE3Coef kf = se3_coef(t);
+    const double cB = kf.B, cC = kf.C, cD = kf.D;
+    const double c1 = ex ? cB : -0.5, c2 = ex ? cC : cD;
+    const V3 out = vec + c1 * (W * vec) + c2 * (W2 * vec);
+    const V3 v = ex ? vec : out;
+    M3 J = m3_id(), Q = m3_id();
+    if constexpr (DERIV)
+    {
+      Q = se3_Q(-1.0 * v, -1.0 * w, kf);
+      J = m3_id() + (ex ? -cB : 0.5) * W + c2 * W2; // Jexp3(w) | Jlog3(w)
+    }
+    if (ex)
+    {
+      const M3 R0 = ldm3(&sc.oR[0]);
+      st3(&sc.xnext[0], ld3(&sc.op[0]) + R0 * out);
+      const double qs = 0.5 * kf.sinch;
+      Quat qn = quat_mul(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]}, Quat{qs * w.x, qs * w.y, qs * w.z, kf.ch});
+      const double n = 1.0 / sqrt(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+      sc.xnext[3] = qn.x * n;
+      sc.xnext[4] = qn.y * n;
+      sc.xnext[5] = qn.z * n;
+      sc.xnext[6] = qn.w * n;
+      if constexpr (DERIV)
+      {
+        stm3(sd->Je3, J);
+        stm3(sd->JeQ, Q);
+        const M3 Rt = transpose(m3_id() + kf.sinc * W + cB * W2);
+        const M3 X = (-1.0) * (Rt * skew(out));
+        const double rt[9] = {Rt.a00, Rt.a01, Rt.a02, Rt.a10, Rt.a11, Rt.a12, Rt.a20, Rt.a21, Rt.a22};
+        const double xx[9] = {X.a00, X.a01, X.a02, X.a10, X.a11, X.a12, X.a20, X.a21, X.a22};
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++)
+          {
+            sd->Jq[i * 6 + j] = rt[i * 3 + j];
+            sd->Jq[(i + 3) * 6 + j + 3] = rt[i * 3 + j];
+            sd->Jq[i * 6 + j + 3] = xx[i * 3 + j];
+            sd->Jq[(i + 3) * 6 + j] = 0.0;
+          }
+      }
+    }
+    else
+    {
+      st3(&sc.rx[0], out);
+      st3(&sc.rx[3], w);
+      if constexpr (DERIV)
+      {
+        const M3 X = (-1.0) * (J * Q * J);
+        const double ji[9] = {J.a00, J.a01, J.a02, J.a10, J.a11, J.a12, J.a20, J.a21, J.a22};
+        const double xx[9] = {X.a00, X.a01, X.a02, X.a10, X.a11, X.a12, X.a20, X.a21, X.a22};
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++)
+          {
+            sd->Jl[i * 6 + j] = ji[i * 3 + j];
+            sd->Jl[(i + 3) * 6 + j + 3] = ji[i * 3 + j];
+            sd->Jl[i * 6 + j + 3] = xx[i * 3 + j];
+            sd->Jl[(i + 3) * 6 + j] = 0.0;
+          }
+      }
+    }
+  }
+
+  // x+ (semi-implicit Euler), defect, residuals, weighted residuals, cost, constraint values, AL multipliers, merit pieces.
+  // Results: sc.red[0] cost, sc.red[1] penalty part of the merit, sc.red[2] primal infeasibility.
+  template <class D, bool DERIV, class SC, class SD>
+  SMPC_DEV void full_eval_tail(SC & sc, SD * sd, const DevModel<D> & mg, unsigned mask, bool term, const double * lam_e, const double * nu_e)
+  {
+    constexpr int NT = 64;
+    constexpr int NV = D::NV, NQ = D::NQ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX, NC = D::NC, NA = D::NA, FS = D::FS, NX = D::NX;
+    const FullHead<D> & h = sc.h;
+    const double dt = h.dt, mu = h.mu;
+    const double * vq = &sc.x[NQ];
+    // ---- x+ = x (+) [dt (v + dt a); dt a] ; base block of the state residual ----
+    SMPC_LANES(NT)
+    {
+      if (lane < 2)
+        full_se3_pair<D, DERIV>(sc, sd, dt, term, lane);
+      for (int i = 6 + lane; i < NV; i += NT)
+        sc.xnext[i + 1] = sc.x[i + 1] + dt * (vq[i] + dt * (term ? 0.0 : sc.a[i]));
+      for (int i = lane; i < NV; i += NT)
+        sc.xnext[NQ + i] = vq[i] + dt * (term ? 0.0 : sc.a[i]);
+    }
+    SMPC_LANES_END_WAVE
+    if (!term)
+    {
+      SMPC_LANES(NT)
+      lanes_difference<D>(sc.xn1, sc.xnext, sc.e, lane, 61);
+      SMPC_LANES_END_WAVE
+    }
+    // ---- residuals and constraint values ----
+    SMPC_LANES(NT)
+    {
+      for (int i = 6 + lane; i < NV; i += NT)
+        sc.rx[i] = sc.x[i + 1] - sc.x_tgt[i + 1];
+      for (int i = lane; i < NV; i += NT)
+        sc.rx[NV + i] = sc.x[NQ + i] - sc.x_tgt[NQ + i];
+      if (!term)
+      {
+        for (int i = lane; i < NU; i += NT)
+        {
+          sc.ru[i] = sc.u[i] - sc.u_ref[i];
+          sc.cval[i] = h.torque_limits ? sc.u[i] : 0.0;
+        }
+        for (int i = lane; i < NA; i += NT)
+          sc.cval[NU + i] = h.kinematics_limits ? sc.x[7 + i] : 0.0;
+        for (int i = lane; i < NF * 3; i += NT)
+          sc.rf[i] = sc.footp[i] - sc.foot_ref[i];
+        // contact-force residual of the feet in contact (compact row c of foot f)
+        for (int i = lane; i < NCM; i += NT)
+        {
+          int f = -1, cnt = 0;
+          for (int ff = 0; ff < NF; ff++)
+            if ((mask >> ff) & 1u)
+            {
+              if (cnt == i / FS)
+                f = ff;
+              cnt++;
+            }
+          sc.rl[i] = f >= 0 ? sc.lam[i] - sc.f_ref[f * FS + i % FS] : 0.0;
+        }
+      }
+    }
+    SMPC_LANES_END_WAVE
+    // ---- weighted residuals ----
+    SMPC_LANES(NT)
+    {
+      for (int i = lane; i < NDX; i += NT)
+      {
+        double s = 0.0;
+        if (h.w_diag)
+          s = h.wxd[i] * sc.rx[i];
+        else
+          for (int j = 0; j < NDX; j++)
+            s += mg.w_x[i * NDX + j] * sc.rx[j];
+        sc.Wrx[i] = s;
+      }
+      if (lane >= 40 && lane < 46)
+      {
+        const int i = lane - 40;
+        double s = 0.0;
+        const double sc10 = term ? 10.0 : 1.0; // terminal: 10 * w_cent (src/fulldynamics.cpp:427)
+        for (int j = 0; j < 6; j++)
+          s += sc10 * h.w_cent[i * 6 + j] * sc.hg[j];
+        sc.Whg[i] = s;
+      }
+      if (!term)
+      {
+        for (int i = lane; i < NU; i += NT)
+        {
+          double s = 0.0;
+          if (h.w_diag)
+            s = h.wud[i] * sc.ru[i];
+          else
+            for (int j = 0; j < NU; j++)
+              s += mg.w_u[i * NU + j] * sc.ru[j];
+          sc.Wru[i] = s;
+        }
+        for (int i = lane; i < NF * 3; i += NT)
+        {
+          const int f = i / 3, r = i % 3;
+          double s = 0.0;
+          for (int j = 0; j < 3; j++)
+            s += h.w_frame[r * FS + j] * sc.rf[f * 3 + j];
+          sc.Wrf[i] = s;
+        }
+        for (int i = lane; i < NCM; i += NT)
+        {
+          const int c = i / FS, r = i % FS;
+          double s = 0.0;
+          for (int j = 0; j < FS; j++)
+            s += h.w_forces[r * FS + j] * sc.rl[c * FS + j];
+          sc.Wrl[i] = s;
+        }
+      }
+    }
+    SMPC_LANES_END_WAVE
+    // ---- cost: lane-strided partial sums, fixed-order reduction ----
+    SMPC_LANES(NT)
+    {
+      double c = 0.0;
+      for (int i = lane; i < NDX; i += NT)
+        c += sc.rx[i] * sc.Wrx[i];
+      if (lane < 6)
+        c += sc.hg[lane] * sc.Whg[lane];
+      if (!term)
+      {
+        for (int i = lane; i < NU; i += NT)
+          c += sc.ru[i] * sc.Wru[i];
+        for (int i = lane; i < NF * 3; i += NT)
+          c += sc.rf[i] * sc.Wrf[i];
+        for (int i = lane; i < NCM; i += NT)
+          c += sc.rl[i] * sc.Wrl[i];
+      }
+      sc.part[lane] = c;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane < 8)
+    {
+      double c = 0.0;
+      for (int i = 0; i < 8; i++)
+        c += sc.part[lane * 8 + i];
+      sc.part8[lane] = c;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      double c = 0.0;
+      for (int i = 0; i < 8; i++)
+        c += sc.part8[i];
+      sc.red[0] = 0.5 * c;
+    }
+    SMPC_LANES_END_WAVE
+    if (term)
+      return;
+    // ---- AL multipliers (SolverProxDDP computeMultipliers), merit penalty, primal infeasibility ----
+    SMPC_LANES(NT)
+    {
+      double pen = 0.0, prim = 0.0;
+      for (int i = lane; i < NDX; i += NT)
+      {
+        const double lp = lam_e[i] + sc.e[i] / mu;
+        sc.lamp[i] = lp;
+        const double dl = lp - sc.lam_next[i];
+        pen += 0.5 * mu * (lp * lp + dl * dl);
+        prim = fmax(prim, fabs(sc.e[i]));
+      }
+      for (int i = lane; i < NC; i += NT)
+      {
+        // rows: torque box | joint box | cone rows (none for 3-D feet)
+        const bool present = i < NU ? h.torque_limits != 0 : (i < NU + NA ? h.kinematics_limits != 0 : false);
+        double vp = 0.0;
+        int act = 0;
+        if (present)
+        {
+          const double lo = i < NU ? h.umin[i] : h.qmin[i - NU], hi = i < NU ? h.umax[i] : h.qmax[i - NU];
+          const double z = sc.cval[i] + mu * nu_e[i];
+          const double proj = fmin(fmax(z, lo), hi);
+          vp = (z - proj) / mu;
+          act = z != proj;
+          prim = fmax(prim, fmax(fmax(sc.cval[i] - hi, lo - sc.cval[i]), 0.0));
+        }
+        sc.vplus[i] = vp;
+        sc.act[i] = act;
+        const double dv = vp - sc.nu[i];
+        pen += 0.5 * mu * (vp * vp + dv * dv);
+      }
+      sc.part[lane] = pen;
+      sc.part2[lane] = prim;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane < 8)
+    {
+      double pen = 0.0, prim = 0.0;
+      for (int i = 0; i < 8; i++)
+      {
+        pen += sc.part[lane * 8 + i];
+        prim = fmax(prim, sc.part2[lane * 8 + i]);
+      }
+      sc.part8[lane] = pen;
+      sc.part8[8 + lane] = prim;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      double pen = 0.0, prim = 0.0;
+      for (int i = 0; i < 8; i++)
+      {
+        pen += sc.part8[i];
+        prim = fmax(prim, sc.part8[8 + i]);
+      }
+      sc.red[1] = pen;
+      sc.red[2] = prim;
+    }
+    SMPC_LANES_END_WAVE
+    (void)NX;
+  }
+} // namespace smpc
+
+namespace smpc
+{
+  // -------------------------------------------------------------------------------------------------------------
+  // Derivative phases.  In: everything full_dynamics_phases / full_eval_tail left in the scratch.  Out (sd):
+  //   R1 = [da_dq | da_dv | da_dtau] (NV x NCOL),  JT rows: [dlam_* (NCM) ; centroidal momentum (6) ; foot positions (3 NF)],
+  //   WJ = block-diagonal weight x JT,  Je3 / JeQ / Jq / Jl from the SE(3) pair.
+  // -------------------------------------------------------------------------------------------------------------
+  template <class D, class SC, class SD>
+  SMPC_DEV void full_deriv_phases(SC & sc, SD & sd, const DevModel<D> & mg, unsigned mask, bool term)
+  {
+    constexpr int NT = 64;
+    constexpr int NJ = D::NJ, NV = D::NV, NF = D::NF, NCM = D::NCM, NU = D::NU, NR = SC::NR, NCOL = SC::NCOL, FS = D::FS, NGN = SC::NGN;
+    const FullHead<D> & h = sc.h;
+    (void)mg;
+    const SV g6{ld3(h.gravity), mk3(0, 0, 0)};
+    if (!term)
+    {
+      // ---- body accelerations at the solved a ; body forces with the gravity field ; contact wrenches at the world origin ----
+      SMPC_LANES(NT)
+      if (lane < NJ)
+      {
+        const int i = lane;
+        const unsigned anci = h.anc[i];
+        SV dacc = sv0();
+        for (int k = 0; k < NV; k++)
+          if ((anci >> jof(k)) & 1u)
+            dacc = dacc + sc.a[k] * ldsv(&sc.S[k * 6]);
+        const SV acc = ldsv(&sc.acc[i * 6]) + dacc;
+        stsv(&sc.acc[i * 6], acc);
+        const SI I = ldsi(&sc.I[i * 10]);
+        const SV v = ldsv(&sc.vel[i * 6]);
+        stsv(&sc.Fc[i * 6], I * (acc - g6) + crf(v, I * v));
+      }
+      else if (lane >= 32 && lane < 32 + NF)
+      {
+        const int f = lane - 32;
+        SV W = sv0();
+        if ((mask >> f) & 1u)
+        {
+          const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+          const V3 fw = ldm3(&sc.oR[h.foot_joint[f] * 9]) * ld3(&sc.lam[3 * c]);
+          W = SV{fw, cross(ld3(&sc.footp[f * 3]), fw)};
+        }
+        stsv(&sd.Wc[f * 6], W);
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      if (lane < 6)
+        for (int j = NJ - 1; j >= 1; j--)
+          sc.Fc[h.parent[j] * 6 + lane] += sc.Fc[j * 6 + lane];
+      SMPC_LANES_END_WAVE
+      // composite force below joint i minus the contact wrenches applied below it
+      SMPC_LANES(NT)
+      if (lane < NJ)
+      {
+        const int i = lane;
+        SV F = ldsv(&sc.Fc[i * 6]);
+        for (int f = 0; f < NF; f++)
+          if ((h.anc[h.foot_joint[f]] >> i) & 1u)
+            F = F - ldsv(&sd.Wc[f * 6]);
+        stsv(&sd.Fgc[i * 6], F);
+      }
+      SMPC_LANES_END_WAVE
+    }
+    // ---- per dof: d_k, A_k ; centroidal-momentum and foot-position Jacobian columns (rows NCM .. of JT) ----
+    SMPC_LANES(NT)
+    if (lane < NV)
+    {
+      const int k = lane, i = jof(k), lam = h.parent[i];
+      const SV s = ldsv(&sc.S[k * 6]);
+      SV d = sv0(), A = crm(sv0() - g6, s);
+      if (lam >= 0)
+      {
+        const SV vl = ldsv(&sc.vel[lam * 6]);
+        d = crm(vl, s);
+        A = crm(ldsv(&sc.acc[lam * 6]) - g6, s) + crm(vl, d);
+      }
+      stsv(&sd.dk[k * 6], d);
+      stsv(&sd.Ak[k * 6], A);
+      const SI Ici = ldsi(&sc.Ic[i * 10]);
+      const SV hci = ldsv(&sc.hc[i * 6]);
+      const SV dh = crf(s, hci) + Ici * d;
+      const V3 com = ld3(sc.com);
+      const V3 jc = (1.0 / h.total_mass) * (Ici * s).l;
+      const SV h0 = ldsv(&sc.hc[0]);
+      const V3 dha = dh.a - cross(com, dh.l) - cross(jc, h0.l);
+      double * jc6 = &sd.JT[NCM * NCOL];
+      jc6[0 * NCOL + k] = dh.l.x;
+      jc6[1 * NCOL + k] = dh.l.y;
+      jc6[2 * NCOL + k] = dh.l.z;
+      jc6[3 * NCOL + k] = dha.x;
+      jc6[4 * NCOL + k] = dha.y;
+      jc6[5 * NCOL + k] = dha.z;
+      for (int r = 0; r < 6; r++)
+      {
+        jc6[r * NCOL + NV + k] = sd.Ag[r * NV + k];
+        if (k < NU)
+          jc6[r * NCOL + 2 * NV + k] = 0.0;
+      }
+      double * jf = &sd.JT[(NCM + 6) * NCOL];
+      for (int f = 0; f < NF; f++)
+      {
+        V3 c = mk3(0, 0, 0);
+        if ((h.anc[h.foot_joint[f]] >> i) & 1u)
+          c = s.l + cross(s.a, ld3(&sc.footp[f * 3]));
+        jf[(3 * f + 0) * NCOL + k] = c.x;
+        jf[(3 * f + 1) * NCOL + k] = c.y;
+        jf[(3 * f + 2) * NCOL + k] = c.z;
+        for (int r = 0; r < 3; r++)
+        {
+          jf[(3 * f + r) * NCOL + NV + k] = 0.0;
+          if (k < NU)
+            jf[(3 * f + r) * NCOL + 2 * NV + k] = 0.0;
+        }
+      }
+    }
+    SMPC_LANES_END_WAVE
+    static_assert(NU <= NV, "tau columns are zeroed by the dof lanes");
+    if (term)
+      return;
+    // ---- partial derivatives of RNEA(q, v, a) - J^T lam at the solution: R1 = [r1q | r1v | -S] ----
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < NV * NV; idx += NT)
+      {
+        const int m = idx / NV, k = idx % NV;
+        const int jm = jof(m), i = jof(k);
+        double vq = 0.0, vv = 0.0;
+        int s = -1;
+        bool below = false; // joint(k) strictly below joint(m)
+        if ((h.anc[jm] >> i) & 1u)
+          s = jm;
+        else if ((h.anc[i] >> jm) & 1u)
+        {
+          s = i;
+          below = true;
+        }
+        if (s >= 0)
+        {
+          const SV Sk = ldsv(&sc.S[k * 6]), Sm = ldsv(&sc.S[m * 6]);
+          const SV d = ldsv(&sd.dk[k * 6]), A = ldsv(&sd.Ak[k * 6]);
+          const SI Ics = ldsi(&sc.Ic[s * 10]);
+          const double * Bc = &sd.Bc[s * 36];
+          const double dv[6] = {d.l.x, d.l.y, d.l.z, d.a.x, d.a.y, d.a.z};
+          const double sv[6] = {Sk.l.x, Sk.l.y, Sk.l.z, Sk.a.x, Sk.a.y, Sk.a.z};
+          double o1[6], o2[6];
+          for (int r = 0; r < 6; r++)
+          {
+            double a1 = 0.0, a2 = 0.0;
+            for (int c = 0; c < 6; c++)
+            {
+              a1 += Bc[r * 6 + c] * dv[c];
+              a2 += Bc[r * 6 + c] * sv[c];
+            }
+            o1[r] = a1;
+            o2[r] = a2;
+          }
+          // Bc holds v x* I - I v x only; the (. x* h) part of the composite velocity-product matrix is added here
+          const SV hcs = ldsv(&sc.hc[s * 6]);
+          SV Xq = Ics * A + SV{mk3(o1[0], o1[1], o1[2]), mk3(o1[3], o1[4], o1[5])} + crf(d, hcs);
+          if (below)
+            Xq = Xq + crf(Sk, ldsv(&sd.Fgc[i * 6]));
+          const SV Xv = SV{mk3(o2[0], o2[1], o2[2]), mk3(o2[3], o2[4], o2[5])} + crf(Sk, hcs) + Ics * (crm(ldsv(&sc.vel[i * 6]), Sk) + d);
+          vq = sv_dot6(Sm, Xq);
+          vv = sv_dot6(Sm, Xv);
+        }
+        sd.R1[m * NCOL + k] = vq;
+        sd.R1[m * NCOL + NV + k] = vv;
+      }
+      for (int idx = lane; idx < NV * NU; idx += NT)
+      {
+        const int m = idx / NU, j = idx % NU;
+        sd.R1[m * NCOL + 2 * NV + j] = m == 6 + j ? -1.0 : 0.0;
+      }
+      for (int idx = lane; idx < NCM * NCOL; idx += NT)
+        sd.JT[idx] = 0.0;
+    }
+    SMPC_LANES_END_WAVE
+    // ---- partial derivatives of the contact acceleration residual (classical acceleration, contact frame, corrector) ----
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NF * NV; idx += NT)
+    {
+      const int f = idx / NV, k = idx % NV;
+      const int l = h.foot_joint[f], i = jof(k);
+      if (((mask >> f) & 1u) && ((h.anc[l] >> i) & 1u))
+      {
+        const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+        const M3 Rf = ldm3(&sc.oR[l * 9]);
+        const V3 p = ld3(&sc.footp[f * 3]);
+        const SV vl = ldsv(&sc.vel[l * 6]);
+        const V3 w = vl.a, vp = vl.l + cross(w, p);
+        const SV Sk = ldsv(&sc.S[k * 6]), d = ldsv(&sd.dk[k * 6]);
+        const int lam = h.parent[i];
+        // non-rigid part of the variation of the body acceleration (kinematic: no gravity here)
+        SV A = sv0();
+        if (lam >= 0)
+          A = crm(ldsv(&sc.acc[lam * 6]), Sk) + crm(ldsv(&sc.vel[lam * 6]), d) + crm(d, vl);
+        const V3 aq = A.l + cross(A.a, p) + cross(d.a, vp) + cross(w, d.l + cross(d.a, p));
+        const SV Av = d + crm(Sk, vl - ldsv(&sc.vel[i * 6]));
+        const V3 av = Av.l + cross(Av.a, p) + cross(Sk.a, vp) + cross(w, Sk.l + cross(Sk.a, p));
+        const V3 vq = d.l + cross(d.a, p), vv = Sk.l + cross(Sk.a, p);
+        const V3 cq = tmul(Rf, aq), cv = tmul(Rf, av), eq = tmul(Rf, vq), ev = tmul(Rf, vv), pq = (-1.0) * tmul(Rf, Sk.l);
+        double * r2 = &sd.JT[(3 * c) * NCOL];
+        r2[0 * NCOL + k] = cq.x + h.Kd[0] * eq.x - h.Kp[0] * pq.x;
+        r2[1 * NCOL + k] = cq.y + h.Kd[1] * eq.y - h.Kp[1] * pq.y;
+        r2[2 * NCOL + k] = cq.z + h.Kd[2] * eq.z - h.Kp[2] * pq.z;
+        r2[0 * NCOL + NV + k] = cv.x + h.Kd[0] * ev.x;
+        r2[1 * NCOL + NV + k] = cv.y + h.Kd[1] * ev.y;
+        r2[2 * NCOL + NV + k] = cv.z + h.Kd[2] * ev.z;
+      }
+    }
+    SMPC_LANES_END_WAVE
+    static_assert(FS == 3, "contact-acceleration partials of the 6-D LOCAL_WORLD_ALIGNED contact come with the Talos table");
+    // ---- [M -J^T; J mu] [da; dlam] = -[r1; r2]:  Mr = M^-1 R1 ; rhs = J Mr - r2 ; dlam = G^-1 rhs ; da = -Mr + M^-1 J^T dlam ----
+    fwave_chol_solve<NT, NV>(sc.M, sd.R1, NCOL, NCOL);
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NCM * NCOL; idx += NT)
+    {
+      const int c = idx / NCOL, j = idx % NCOL;
+      double acc = -sd.JT[idx];
+      for (int k = 0; k < NV; k++)
+        acc += sc.J[c * NV + k] * sd.R1[k * NCOL + j];
+      sd.JT[idx] = acc;
+    }
+    SMPC_LANES_END_WAVE
+    for (int c0 = 0; c0 < NCOL; c0 += NT)
+    {
+      SMPC_LANES(NT)
+      {
+        const int j = c0 + lane < NCOL ? c0 + lane : c0;
+        double r[NCM], o[NCM];
+#pragma unroll
+        for (int c = 0; c < NCM; c++)
+          r[c] = sd.JT[c * NCOL + j];
+#pragma unroll
+        for (int c = 0; c < NCM; c++)
+        {
+          double acc = 0.0;
+#pragma unroll
+          for (int d = 0; d < NCM; d++)
+            acc += sc.Gi[c * NCM + d] * r[d];
+          o[c] = acc;
+        }
+        if (c0 + lane < NCOL)
+        {
+#pragma unroll
+          for (int c = 0; c < NCM; c++)
+            sd.JT[c * NCOL + j] = o[c];
+        }
+      }
+      SMPC_LANES_END_WAVE
+    }
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NV * NCOL; idx += NT)
+    {
+      const int k = idx / NCOL, j = idx % NCOL;
+      double acc = -sd.R1[idx];
+      for (int c = 0; c < NCM; c++)
+        acc += sc.W[k * NR + 1 + c] * sd.JT[c * NCOL + j];
+      sd.R1[idx] = acc;
+    }
+    SMPC_LANES_END_WAVE
+    (void)NGN;
+  }
+
+  // weighted Gauss-Newton Jacobian WJ = blockdiag(w_forces per contact, w_cent (x10 at the terminal node), w_frame per foot) * JT
+  // and the stacked weighted residual (sd.dual[0 .. NGN) used as scratch)
+  template <class D, class SC, class SD>
+  SMPC_DEV void full_weighted_jacobian(SC & sc, SD & sd, bool term)
+  {
+    constexpr int NT = 64;
+    constexpr int NF = D::NF, NCM = D::NCM, NCOL = SC::NCOL, FS = D::FS, NGN = SC::NGN;
+    const FullHead<D> & h = sc.h;
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NGN * NCOL; idx += NT)
+    {
+      const int r = idx / NCOL, j = idx % NCOL;
+      double acc = 0.0;
+      if (r < NCM)
+      {
+        if (!term)
+        {
+          const int c = r / FS, rr = r % FS;
+          for (int b = 0; b < FS; b++)
+            acc += h.w_forces[rr * FS + b] * sd.JT[(c * FS + b) * NCOL + j];
+        }
+      }
+      else if (r < NCM + 6)
+      {
+        const double sc10 = term ? 10.0 : 1.0;
+        for (int b = 0; b < 6; b++)
+          acc += sc10 * h.w_cent[(r - NCM) * 6 + b] * sd.JT[(NCM + b) * NCOL + j];
+      }
+      else if (!term)
+      {
+        const int f = (r - NCM - 6) / 3, rr = (r - NCM - 6) % 3;
+        for (int b = 0; b < 3; b++)
+          acc += h.w_frame[rr * FS + b] * sd.JT[(NCM + 6 + 3 * f + b) * NCOL + j];
+      }
+      sd.WJ[idx] = acc;
+    }
+    SMPC_LANES_END_WAVE
+    (void)NF;
+  }
+
+  // entry (i, j) of the state-cost Hessian Jx^T w_x Jx, Jx = blockdiag(Jlog6, I)
+  template <class D, class SC, class SD>
+  SMPC_DEV double full_state_hessian(const SC & sc, const SD & sd, const DevModel<D> & mg, int i, int j)
+  {
+    constexpr int NDX = D::NDX;
+    const FullHead<D> & h = sc.h;
+    if (i >= 6 && j >= 6)
+      return h.w_diag ? (i == j ? h.wxd[i] : 0.0) : mg.w_x[i * NDX + j];
+    if (i < 6 && j < 6)
+      return sd.JWJ[i * 6 + j];
+    return i < 6 ? sd.WJl[j * 6 + i] : sd.WJl[i * 6 + j];
+  }
+
+  // tables of the state cost: WJl = w_x[:, 0:6] Jl (NDX x 6), JWJ = Jl^T w_x[0:6, 0:6] Jl
+  template <class D, class SC, class SD>
+  SMPC_DEV void full_state_tables(SC & sc, SD & sd, const DevModel<D> & mg)
+  {
+    constexpr int NT = 64;
+    constexpr int NDX = D::NDX;
+    const FullHead<D> & h = sc.h;
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NDX * 6; idx += NT)
+    {
+      const int a = idx / 6, k = idx % 6;
+      double s = 0.0;
+      if (h.w_diag)
+        s = a < 6 ? h.wxd[a] * sd.Jl[a * 6 + k] : 0.0;
+      else
+        for (int b = 0; b < 6; b++)
+          s += mg.w_x[a * NDX + b] * sd.Jl[b * 6 + k];
+      sd.WJl[idx] = s;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane < 36)
+    {
+      const int i = lane / 6, j = lane % 6;
+      double s = 0.0;
+      for (int a = 0; a < 6; a++)
+        s += sd.Jl[a * 6 + i] * sd.WJl[a * 6 + j];
+      sd.JWJ[lane] = s;
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // =============================================================================================
+  // fdyn_deriv_body: grid = B * (H+1) (or slots * (H+1) walking the list of undecided instances); block (inst, t);
+  // t == H is the terminal node (state cost + 10 x centroidal cost, src/fulldynamics.cpp:418-430).
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void fdyn_deriv_one(const StageKernelArgs<D> & ka, int inst, int t)
+  {
+    typedef FullScratch<D, true> SC;
+    typedef FullScratchDeriv<D> SD;
+    constexpr int NT = 64;
+    constexpr int NV = D::NV, NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF, NA = D::NA, NCM = D::NCM, NCOL = SC::NCOL, NGN = SC::NGN,
+                  NXU = D::NXU, NQ = D::NQ;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H, R = b.R;
+    const bool term = t == H;
+    const DevModel<D> & mg = *b.model;
+    SMPC_LDS(SC, scs, 1);
+    SMPC_LDS(SD, sds, 1);
+    SC & sc = scs[0];
+    SD & sd = sds[0];
+    const FullHead<D> & h = sc.h;
+    const int st = ring_slot(ka.head, t, R);
+    const size_t ib = (size_t)inst * R;
+    const int sprev = ring_slot(ka.head, t > 0 ? t - 1 : 0, R);
+    const int snext = ring_slot(ka.head, term ? t : t + 1, R);
+    const double preg = b.scal[(size_t)inst * SC_N + SC_PREG];
+    const unsigned mask = term ? 0u : (b.stages[t].mask & ((1u << NF) - 1u));
+    // ---- block inputs ----
+    SMPC_LANES(NT)
+    {
+      full_load_head<D, NT>(sc.h, &mg, lane);
+      for (int i = lane; i < NX; i += NT)
+      {
+        sc.x[i] = b.xs[(ib + st) * NX + i];
+        sc.xn1[i] = b.xs[(ib + snext) * NX + i];
+        // state_cost target: shared pose part, per-instance base-velocity part
+        sc.x_tgt[i] = term ? mg.x_term[i] : ((i >= NQ && i < NQ + 6) ? b.vref[(ib + st) * 6 + (i - NQ)] : b.stages[t].x_tgt[i]);
+      }
+      for (int i = lane; i < NU; i += NT)
+      {
+        sc.u[i] = term ? 0.0 : b.us[(ib + st) * NU + i];
+        sc.u_ref[i] = term ? 0.0 : b.stages[t].u_ref[i];
+      }
+      for (int i = lane; i < NCM; i += NT)
+        sc.f_ref[i] = term ? 0.0 : b.stages[t].f_ref[i];
+      for (int i = lane; i < NF * 3; i += NT)
+        sc.foot_ref[i] = term ? 0.0 : b.foot_ref[((size_t)inst * H + t) * NF * 3 + i];
+      for (int i = lane; i < NDX; i += NT)
+        sc.lam_next[i] = term ? 0.0 : b.lams[(ib + st) * NDX + i];
+      for (int i = lane; i < NC; i += NT)
+        sc.nu[i] = term ? 0.0 : b.vs[(ib + st) * NC + i];
+    }
+    SMPC_LANES_END_WAVE
+    full_dynamics_phases<D, true>(sc, &sd, mg, mask, !term);
+    full_eval_tail<D, true>(sc, &sd, mg, mask, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+    full_deriv_phases<D>(sc, sd, mg, mask, term);
+    full_weighted_jacobian<D>(sc, sd, term);
+    full_state_tables<D>(sc, sd, mg);
+    double * parts = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
+    // stacked weighted residual [Wrl | Whg | Wrf] for the gradients
+    SMPC_LANES(NT)
+    for (int r = lane; r < NGN; r += NT)
+      sd.dual[r] = r < NCM ? (term ? 0.0 : sc.Wrl[r]) : (r < NCM + 6 ? sc.Whg[r - NCM] : (term ? 0.0 : sc.Wrf[r - NCM - 6]));
+    SMPC_LANES_END_WAVE
+    // ---- cost gradients ----
+    SMPC_LANES(NT)
+    for (int k = lane; k < NXU; k += NT)
+    {
+      double g = 0.0;
+      if (k < NDX)
+      {
+        if (k < 6)
+          for (int a = 0; a < 6; a++)
+            g += sd.Jl[a * 6 + k] * sc.Wrx[a];
+        else
+          g = sc.Wrx[k];
+      }
+      else if (!term)
+        g = sc.Wru[k - NDX];
+      // (terminal node: only the momentum rows exist)
+      for (int r = term ? NCM : 0; r < (term ? NCM + 6 : NGN); r++)
+        g += sd.JT[r * NCOL + k] * sd.dual[r];
+      if (k < NDX)
+        sd.gx[k] = g;
+      else
+        sd.gu[k - NDX] = g;
+    }
+    SMPC_LANES_END_WAVE
+    if (term)
+    {
+      // ---- terminal node: Q_N = Lxx + preg I, q_N = lx - lambda_H ----
+      double * QN = b.QN + (size_t)inst * NDX * NDX;
+      double * qN = b.qN + (size_t)inst * NDX;
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NDX * NDX; idx += NT)
+        {
+          const int i = idx / NDX, j = idx % NDX;
+          double v = full_state_hessian<D>(sc, sd, mg, i, j);
+          for (int r = NCM; r < NCM + 6; r++)
+            v += sd.JT[r * NCOL + i] * sd.WJ[r * NCOL + j];
+          if (i == j)
+            v += preg;
+          QN[idx] = v;
+        }
+        double dual = 0.0;
+        for (int k = lane; k < NDX; k += NT)
+        {
+          const double qn = sd.gx[k] - b.lams[(ib + sprev) * NDX + k];
+          qN[k] = qn;
+          dual = fmax(dual, fabs(qn));
+        }
+        sc.part[lane] = dual;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      if (lane == 0)
+      {
+        double dual = 0.0;
+        for (int k = 0; k < NT; k++)
+          dual = fmax(dual, sc.part[k]);
+        parts[0] = sc.red[0];
+        parts[1] = sc.red[0];
+        parts[2] = 0.0;
+        parts[3] = dual;
+      }
+      SMPC_LANES_END_WAVE
+      return;
+    }
+    double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
+    const double dt = h.dt, mu = h.mu;
+    // ---- [A | B] (lane = column), Lagrangian gradients q, r ----
+    SMPC_LANES(NT)
+    {
+      double dual = 0.0;
+      for (int col = lane; col < NXU; col += NT)
+      {
+        const bool isA = col < NDX;
+        const int k = isA ? col : col - NDX;
+        const int cc = isA ? k : 2 * NV + k; // column of [da_dq | da_dv | da_dtau]
+        double * dst = lq + (isA ? D::O_A : D::O_B);
+        const int ld = isA ? NDX : NU;
+        double acc = 0.0; // (A^T lam_next)[k] or (B^T lam_next)[k], rows in order
+        double Dtop[6];
+        for (int m = 0; m < 6; m++)
+          Dtop[m] = dt * dt * sd.R1[m * NCOL + cc] + ((isA && k == NV + m) ? dt : 0.0);
+        for (int i = 0; i < 6; i++)
+        {
+          double v;
+          if (i < 3)
+            v = sd.Je3[i * 3 + 0] * Dtop[0] + sd.Je3[i * 3 + 1] * Dtop[1] + sd.Je3[i * 3 + 2] * Dtop[2] + sd.JeQ[i * 3 + 0] * Dtop[3]
+                + sd.JeQ[i * 3 + 1] * Dtop[4] + sd.JeQ[i * 3 + 2] * Dtop[5];
+          else
+            v = sd.Je3[(i - 3) * 3 + 0] * Dtop[3] + sd.Je3[(i - 3) * 3 + 1] * Dtop[4] + sd.Je3[(i - 3) * 3 + 2] * Dtop[5];
+          if (isA && k < 6)
+            v += sd.Jq[i * 6 + k];
+          dst[i * ld + k] = v;
+          acc += v * sc.lam_next[i];
+        }
+        for (int i = 6; i < NV; i++)
+        {
+          const double v = dt * dt * sd.R1[i * NCOL + cc] + ((isA && k == NV + i) ? dt : 0.0) + ((isA && k == i) ? 1.0 : 0.0);
+          dst[i * ld + k] = v;
+          acc += v * sc.lam_next[i];
+        }
+        for (int i = 0; i < NV; i++)
+        {
+          const double v = dt * sd.R1[i * NCOL + cc] + ((isA && k == NV + i) ? 1.0 : 0.0);
+          dst[(NV + i) * ld + k] = v;
+          acc += v * sc.lam_next[NV + i];
+        }
+        if (isA)
+        {
+          // C_x^T nu: the joint-box rows are unit selectors (unmasked Jacobian)
+          double cn = 0.0;
+          if (h.kinematics_limits && k >= 6 && k < NV)
+            cn = sc.nu[NU + k - 6];
+          double q = sd.gx[k] + acc + cn - (t > 0 ? b.lams[(ib + sprev) * NDX + k] : 0.0);
+          if (t == 0)
+            q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
+          lq[D::O_q + k] = q;
+          lq[D::O_lx + k] = sd.gx[k];
+          lq[D::O_f + k] = mu * (sc.lamp[k] - sc.lam_next[k]);
+          lq[D::O_lpd + k] = 2.0 * sc.lamp[k] - sc.lam_next[k];
+          dual = fmax(dual, fabs(q));
+        }
+        else
+        {
+          const double cn = h.torque_limits ? sc.nu[k] : 0.0;
+          const double r = sd.gu[k] + acc + cn;
+          lq[D::O_r + k] = r;
+          lq[D::O_lu + k] = sd.gu[k];
+          dual = fmax(dual, fabs(r));
+        }
+      }
+      sc.part[lane] = dual;
+    }
+    SMPC_LANES_END_WAVE
+    // ---- [Q S; S^T R] = H_0 + JT^T WJ + preg I ----
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < NDX * NXU; idx += NT)
+      {
+        const int i = idx / NXU, j = idx % NXU;
+        double v = j < NDX ? full_state_hessian<D>(sc, sd, mg, i, j) : 0.0;
+        for (int r = 0; r < NGN; r++)
+          v += sd.JT[r * NCOL + i] * sd.WJ[r * NCOL + j];
+        if (i == j)
+          v += preg;
+        if (j < NDX)
+          lq[D::O_Q + i * NDX + j] = v;
+        else
+          lq[D::O_S + i * NU + j - NDX] = v;
+      }
+      for (int idx = lane; idx < NU * NU; idx += NT)
+      {
+        const int i = idx / NU, j = idx % NU;
+        double v = h.w_diag ? (i == j ? h.wud[i] : 0.0) : mg.w_u[idx];
+        for (int r = 0; r < NCM; r++)
+          v += sd.JT[r * NCOL + NDX + i] * sd.WJ[r * NCOL + NDX + j];
+        if (i == j)
+          v += preg;
+        lq[D::O_R + idx] = v;
+      }
+      for (int i = lane; i < NC; i += NT)
+      {
+        lq[D::O_d + i] = mu * (sc.vplus[i] - sc.nu[i]);
+        lq[D::O_vpd + i] = sc.act[i] ? 2.0 * sc.vplus[i] - sc.nu[i] : 0.0;
+        if (i < NU + NA)
+          lq[D::O_act + i] = sc.act[i] ? 1.0 : 0.0;
+      }
+    }
+    SMPC_LANES_END_WAVE
+    static_assert(D::NCONE == 0, "dense cone rows (Cd, Dd) come with the 6-D feet");
+    SMPC_LANES(NT)
+    {
+      if (lane == 0)
+      {
+        double dual = 0.0;
+        for (int k = 0; k < NT; k++)
+          dual = fmax(dual, sc.part[k]);
+        parts[0] = sc.red[0] + sc.red[1];
+        parts[1] = sc.red[0];
+        parts[2] = sc.red[2];
+        parts[3] = dual;
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  template <class D>
+  SMPC_DEV void fdyn_deriv_body(const StageKernelArgs<D> & ka, int block)
+  {
+    const int H = ka.b.H;
+    const int slot = block / (H + 1), t = block % (H + 1);
+    const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : slot + 1;
+    const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
+    for (int m = slot; m < count; m += stride)
+      fdyn_deriv_one<D>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t);
+  }
+
+  // =============================================================================================
+  // fdyn_trial_body: one line-search candidate (LINEAR rollout point, reference src/mpc.cpp:44): re-evaluation, AL
+  // multipliers, merit partials.  Same launch geometry as trial_body (smpc_kino_kernels.h).
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void fdyn_trial_one(const StageKernelArgs<D> & ka, int inst, int t, int j)
+  {
+    typedef FullScratch<D, false> SC;
+    constexpr int NT = 64;
+    constexpr int NV = D::NV, NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF, NCM = D::NCM, NQ = D::NQ;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H, R = b.R;
+    const bool term = t == H;
+    const DevModel<D> & mg = *b.model;
+    SMPC_LDS(SC, scs, 1);
+    SC & sc = scs[0];
+    const int st = ring_slot(ka.head, t, R), sn = ring_slot(ka.head, term ? t : t + 1, R);
+    const size_t ib = (size_t)inst * R;
+    double alpha = 1.0;
+    for (int i = 0; i < j; i++)
+      alpha *= 0.5;
+    const unsigned mask = term ? 0u : (b.stages[t].mask & ((1u << NF) - 1u));
+    const double * dx = b.dxs + ((size_t)inst * (H + 1) + t) * NDX;
+    const size_t lt = (size_t)inst * H + (term ? 0 : t);
+    SMPC_LANES(NT)
+    {
+      full_load_head<D, NT>(sc.h, &mg, lane);
+      for (int i = lane; i < NX; i += NT)
+        sc.x_tgt[i] = term ? mg.x_term[i] : ((i >= NQ && i < NQ + 6) ? b.vref[(ib + st) * 6 + (i - NQ)] : b.stages[t].x_tgt[i]);
+      for (int i = lane; i < NU; i += NT)
+      {
+        sc.u[i] = term ? 0.0 : b.us[(ib + st) * NU + i] + alpha * b.dus[lt * NU + i];
+        sc.u_ref[i] = term ? 0.0 : b.stages[t].u_ref[i];
+      }
+      for (int i = lane; i < NCM; i += NT)
+        sc.f_ref[i] = term ? 0.0 : b.stages[t].f_ref[i];
+      for (int i = lane; i < NF * 3; i += NT)
+        sc.foot_ref[i] = term ? 0.0 : b.foot_ref[((size_t)inst * H + t) * NF * 3 + i];
+      for (int i = lane; i < NDX; i += NT)
+        sc.lam_next[i] = term ? 0.0 : b.lams[(ib + st) * NDX + i] + alpha * b.dlams[lt * NDX + i];
+      for (int i = lane; i < NC; i += NT)
+        sc.nu[i] = term ? 0.0 : b.vs[(ib + st) * NC + i] + alpha * b.dvs[lt * NC + i];
+      // trial points x_t (+) alpha dx_t and x_{t+1} (+) alpha dx_{t+1}
+      lanes_integrate<D>(b.xs + (ib + st) * NX, dx, alpha, sc.x, lane, 0);
+      lanes_integrate<D>(b.xs + (ib + sn) * NX, dx + (term ? 0 : NDX), alpha, sc.xn1, lane, 1);
+    }
+    SMPC_LANES_END_WAVE
+    full_dynamics_phases<D, false>(sc, (FullScratchDeriv<D> *)nullptr, mg, mask, !term);
+    full_eval_tail<D, false>(sc, (FullScratchDeriv<D> *)nullptr, mg, mask, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+    double * parts = b.partsT + (((size_t)inst * D::LS_N + j) * (H + 1) + t) * 2;
+    SMPC_LANES(NT)
+    {
+      if (lane == 0)
+      {
+        parts[0] = term ? sc.red[0] : sc.red[0] + sc.red[1];
+        parts[1] = term ? 0.0 : sc.red[2];
+      }
+      if (!term && t < 2)
+        for (int i = lane; i < NV; i += NT)
+        {
+          double * xd = b.xdotT + (((size_t)inst * D::LS_N + j) * 2 + t) * 2 * NV;
+          xd[i] = sc.x[NQ + i];
+          xd[NV + i] = sc.a[i];
+        }
+      // contact forces at the trial point: the accepted candidate's are the stage's forces (MPC::getContactForces)
+      if (!term && b.forcesT != nullptr)
+        for (int i = lane; i < NCM; i += NT)
+        {
+          const int f = i / D::FS;
+          const bool on = (mask >> f) & 1u;
+          const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+          b.forcesT[(((size_t)inst * D::LS_N + j) * H + t) * NCM + i] = on ? sc.lam[c * D::FS + i % D::FS] : 0.0;
+        }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  template <class D>
+  SMPC_DEV void fdyn_trial_body(const StageKernelArgs<D> & ka, int block)
+  {
+    const int H = ka.b.H;
+    const int slot = block / (H + 1), t = block % (H + 1);
+    const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : slot + 1;
+    const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
+    for (int m = slot; m < count; m += stride)
+    {
+      const int inst = ka.slots > 0 ? ka.b.und_list[m] : m;
+      if (ka.slots == 0 && ka.b.ls_sel[inst] >= 0)
+        break;
+      for (int jj = 0; jj < ka.nj; jj++)
+        fdyn_trial_one<D>(ka, inst, t, ka.j0 + jj);
+    }
+  }
+} // namespace smpc

@@ -132,6 +132,10 @@ namespace smpc
     double * scal = nullptr;     // [B][16] per-instance scalars, see SC_*
     double * xdotT = nullptr;    // [B][LS_N][2][2NV] trial xdot for t = 0,1
     double * xdot01 = nullptr;   // [B][2][2NV]
+    // full-dynamics handles: contact forces of every stage (MPC::getContactForces, reference src/mpc.cpp:354-380) at the trial
+    // points [B][LS_N][H][FS NF] and at the accepted point [B][H][FS NF]; null on the other handles
+    double *forcesT = nullptr, *forces = nullptr;
+    int nforce = 0; // FS * NF
     int * ls_sel = nullptr;      // [B] selected candidate, -1 = undecided
     int * und_list = nullptr;    // [B + 1] compacted indices of the undecided instances; und_list[B] = their count
     double * dbg = nullptr;      // [64] optional in-kernel phase timers (null = off)

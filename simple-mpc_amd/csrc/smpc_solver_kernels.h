@@ -516,6 +516,9 @@ namespace smpc
             sc[SC_PREG] = sc[SC_LS_FAILED] != 0.0 ? fmin(preg * ka.reg_inc, ka.reg_max) : fmax(preg * ka.reg_dec, ka.reg_min);
             for (int i = 0; i < 4 * D::NV; i++)
               b.xdot01[(size_t)inst * 4 * D::NV + i] = b.xdotT[((size_t)inst * D::LS_N + sel) * 4 * D::NV + i];
+            if (b.forcesT != nullptr)
+              for (int i = 0; i < H * b.nforce; i++)
+                b.forces[(size_t)inst * H * b.nforce + i] = b.forcesT[((size_t)inst * D::LS_N + sel) * H * b.nforce + i];
           }
         }
       }

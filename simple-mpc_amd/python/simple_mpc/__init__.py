@@ -15,9 +15,9 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import CentroidalSettingsC, KinodynamicsSettingsC, MpcSettingsC, SmpcLib, default_lib
+from ._capi import CentroidalSettingsC, FullDynamicsSettingsC, KinodynamicsSettingsC, MpcSettingsC, SmpcLib, default_lib
 
-__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "CentroidalOCP", "MPC", "BatchedMPC", "Interpolator", "FrictionCompensation", "centroidal_dynamics"]
+__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "CentroidalOCP", "FullDynamicsOCP", "MPC", "BatchedMPC", "Interpolator", "FrictionCompensation", "centroidal_dynamics"]
 
 
 def load_robot(name, lib=None):
@@ -413,6 +413,99 @@ class CentroidalOCP(_StageReferences):
         return h
 
 
+_FULL_KEYS = [
+    "timestep", "w_x", "w_u", "w_cent", "gravity", "force_size", "w_forces", "w_frame", "umin", "umax", "qmin", "qmax",
+    "Kp_correction", "Kd_correction", "mu", "Lfoot", "Wfoot", "torque_limits", "kinematics_limits", "force_cone", "land_cstr",
+]
+
+
+class FullDynamicsOCP(KinodynamicsOCP):
+    """reference: src/fulldynamics.cpp:30-76 (ctor), bindings/expose-fulldynamics.cpp:12-42 (dict keys = FullDynamicsSettings
+    fields, include/simple-mpc/fulldynamics.hpp:28-65).  State (q, v), control = the nv - 6 joint torques; the contact forces
+    are outputs of the constrained dynamics (MPC.getContactForces), their references live beside the control reference."""
+
+    def __init__(self, settings, model_handler):
+        for k in _FULL_KEYS:
+            if k not in settings:
+                raise KeyError(k)
+        self.settings = dict(settings)
+        self.model_handler = model_handler
+        self._problem = None
+        self.nu = model_handler.nv - 6
+        fs = int(settings["force_size"])
+        if np.asarray(settings["Kp_correction"]).size != fs:
+            raise RuntimeError("Force must be of same size as Kp correction")  # src/fulldynamics.cpp:41-44
+        if np.asarray(settings["Kd_correction"]).size != fs:
+            raise RuntimeError("Force must be of same size as Kd correction")
+
+    def createProblem(self, x0, horizon, force_size, gravity, terminal_constraint=False):
+        if force_size != self.settings["force_size"]:
+            raise RuntimeError("force size in settings does not match reference force size")
+        if terminal_constraint:
+            raise RuntimeError("terminal (DCM) constraint is not built yet")
+        self._problem = dict(x0=np.array(x0, float), horizon=int(horizon), gravity=float(gravity))
+
+    def getCostNumber(self):
+        # state, control, centroidal + one pose cost per foot + one force cost per foot in contact (tests/problem.cpp:48)
+        return 3 + 2 * self.model_handler.getFeetNb()
+
+    # force references: their own vector beside the control reference (src/fulldynamics.cpp:258-334)
+    def _force_refs(self, t):
+        n = int(self.settings["force_size"]) * self.model_handler.getFeetNb()
+        return self._get(t, 2, n)
+
+    def setReferenceForces(self, t, force_refs):
+        fs = int(self.settings["force_size"])
+        names = self.model_handler.getFeetFrameNames()
+        if len(force_refs) != len(names):
+            raise RuntimeError("force_refs size does not match number of end effectors")
+        v = self._force_refs(t)
+        for i, name in enumerate(names):
+            f = np.asarray(force_refs[name], float)
+            if f.size != fs:
+                raise RuntimeError("Reference forces do not have the right dimension")
+            v[i * fs : (i + 1) * fs] = f
+        self._set(t, 2, v)
+
+    def setReferenceForce(self, t, ee_name, force_ref):
+        fs, i = int(self.settings["force_size"]), self._foot(ee_name)
+        f = np.asarray(force_ref, float)
+        if f.size != fs:
+            raise RuntimeError("Reference forces do not have the right dimension")
+        v = self._force_refs(t)
+        v[i * fs : (i + 1) * fs] = f
+        self._set(t, 2, v)
+
+    def getReferenceForce(self, t, ee_name):
+        fs, i = int(self.settings["force_size"]), self._foot(ee_name)
+        return self._force_refs(t)[i * fs : (i + 1) * fs]
+
+    def _create_handle(self, lib, ms, batch, device_id):
+        s = self.settings
+        c = lambda a: np.ascontiguousarray(np.asarray(a, float))
+        mh = self.model_handler
+        ndx, nu, fs = 2 * mh.nv, self.nu, int(s["force_size"])
+        names = ("w_x", "w_u", "w_cent", "w_forces", "w_frame", "umin", "umax", "qmin", "qmax", "Kp_correction", "Kd_correction")
+        shapes = [(ndx, ndx), (nu, nu), (6, 6), (fs, fs), (fs, fs), (nu,), (nu,), (nu,), (nu,), (fs,), (fs,)]
+        self._keep = [c(s[k]) for k in names]
+        for a, sh, k in zip(self._keep, shapes, names):
+            if a.shape != sh:
+                raise RuntimeError("%s has shape %s, expected %s" % (k, a.shape, sh))
+        fsx = FullDynamicsSettingsC()
+        fsx.timestep = s["timestep"]
+        for name, arr in zip(names, self._keep):
+            setattr(fsx, name, arr.ctypes.data)
+        for i in range(3):
+            fsx.gravity[i] = float(s["gravity"][i])
+        fsx.mu, fsx.Lfoot, fsx.Wfoot = s["mu"], s["Lfoot"], s["Wfoot"]
+        fsx.force_size = fs
+        for k in ("torque_limits", "kinematics_limits", "force_cone", "land_cstr"):
+            setattr(fsx, k, int(bool(s[k])))
+        h = C.c_void_p()
+        lib.check(lib.L.smpc_create_fulldynamics(mh._ptr, C.byref(fsx), C.byref(ms), batch, self._problem["gravity"], device_id, C.byref(h)))
+        return h
+
+
 _MPC_KEYS = ["support_force", "TOL", "mu_init", "max_iters", "num_threads", "swing_apex", "T_fly", "T_contact", "timestep"]
 
 
@@ -450,7 +543,8 @@ class BatchedMPC:
         # OCPHandler::control_ref_ as the constructors leave it (createProblem's default forces, src/ocp-handler.cpp:107-109)
         fs = int(ocp.settings["force_size"])
         ocp._control_ref = np.zeros(ocp.nu)
-        ocp._control_ref[2 : fs * mh.getFeetNb() : fs] = -mh.getMass() * ocp._problem["gravity"] / mh.getFeetNb()
+        if not isinstance(ocp, FullDynamicsOCP):
+            ocp._control_ref[2 : fs * mh.getFeetNb() : fs] = -mh.getMass() * ocp._problem["gravity"] / mh.getFeetNb()
         self.nx_in = self.nq + self.nv  # iterate takes measured multibody states (reference src/mpc.cpp:189-192)
         self._x_reference = ocp._default_x_reference()
         self._velocity_base = np.zeros(6)
@@ -474,9 +568,10 @@ class BatchedMPC:
         ocp, last = self.ocp_handler, cs[-1]
         fs = int(ocp.settings["force_size"])
         ocp._control_ref[:] = 0.0
-        for f in range(len(last)):
-            if last[f]:
-                ocp._control_ref[f * fs + 2] = self.settings["support_force"] / max(1, int(last.sum()))
+        if not isinstance(ocp, FullDynamicsOCP):
+            for f in range(len(last)):
+                if last[f]:
+                    ocp._control_ref[f * fs + 2] = self.settings["support_force"] / max(1, int(last.sum()))
 
     # MPC::setReferencePose / getReferencePose (reference src/mpc.cpp:326-339)
     def setReferencePose(self, t, ee_name, pose_ref):
@@ -598,6 +693,13 @@ class BatchedMPC:
     def getReferencePoses(self):
         return self._get("smpc_get_reference_poses", (self.B, self.H, self.nf, 3))
 
+    def getContactForces(self, t=None):
+        """MPC::getContactForces (reference src/mpc.cpp:354-380): contact forces of the constrained dynamics at the solution,
+        [B, nf, force_size] for stage t or [B, H, nf, force_size] for every stage.  Full-dynamics problems only."""
+        fs = int(self.ocp_handler.settings["force_size"])
+        f = self._get("smpc_get_contact_forces", (self.B, self.H, self.nf, fs))
+        return f if t is None else f[:, t]
+
     def updateInternalData(self, X):
         """State feedback front-end, batched on the device (reference src/robot-handler.cpp:106-149): for measured
         states X[B, nx] returns dict(feet[B, nf, 3], com[B, 3], hg[B, 6], centroidal_state[B, 9])."""
@@ -693,11 +795,22 @@ class BatchedMPC:
         ndx, nu, nc = self.ndx, self.nu, self.nc
         o = 0
         res = {}
-        for name, shape in (
+        layout = (
             ("A", (ndx, ndx)), ("B", (ndx, nu)), ("Q", (ndx, ndx)), ("S", (ndx, nu)), ("R", (nu, nu)), ("C", (nc, ndx)),
             ("q", (ndx,)), ("r", (nu,)), ("f", (ndx,)), ("d", (nc,)), ("lx", (ndx,)), ("lu", (nu,)), ("lpd", (ndx,)),
             ("vpd", (nc,)),
-        ):
+        )
+        if isinstance(self.ocp_handler, FullDynamicsOCP):
+            # full-dynamics knot (smpc_full_model.h): the box rows are unit selectors kept as activity flags; Cd / Dd hold the
+            # dense cone rows of 6-D feet only
+            nbox = 2 * nu
+            ncone = nc - nbox
+            layout = (
+                ("A", (ndx, ndx)), ("B", (ndx, nu)), ("Q", (ndx, ndx)), ("S", (ndx, nu)), ("R", (nu, nu)), ("Cd", (ncone, ndx)),
+                ("Dd", (ncone, nu)), ("q", (ndx,)), ("r", (nu,)), ("f", (ndx,)), ("d", (nc,)), ("lx", (ndx,)), ("lu", (nu,)),
+                ("lpd", (ndx,)), ("vpd", (nc,)), ("act", (nbox,)),
+            )
+        for name, shape in layout:
             sz = int(np.prod(shape))
             res[name] = out[o : o + sz].reshape(shape).copy()
             o += sz

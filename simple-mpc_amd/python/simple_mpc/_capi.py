@@ -56,6 +56,32 @@ class CentroidalSettingsC(C.Structure):
     ]
 
 
+class FullDynamicsSettingsC(C.Structure):
+    _fields_ = [
+        ("timestep", C.c_double),
+        ("w_x", C.c_void_p),
+        ("w_u", C.c_void_p),
+        ("w_cent", C.c_void_p),
+        ("w_forces", C.c_void_p),
+        ("w_frame", C.c_void_p),
+        ("umin", C.c_void_p),
+        ("umax", C.c_void_p),
+        ("qmin", C.c_void_p),
+        ("qmax", C.c_void_p),
+        ("Kp_correction", C.c_void_p),
+        ("Kd_correction", C.c_void_p),
+        ("gravity", C.c_double * 3),
+        ("mu", C.c_double),
+        ("Lfoot", C.c_double),
+        ("Wfoot", C.c_double),
+        ("force_size", C.c_int),
+        ("torque_limits", C.c_int),
+        ("kinematics_limits", C.c_int),
+        ("force_cone", C.c_int),
+        ("land_cstr", C.c_int),
+    ]
+
+
 class MpcSettingsC(C.Structure):
     _fields_ = [
         ("swing_apex", C.c_double),
@@ -103,7 +129,7 @@ class RobotModelC(C.Structure):
 
 # every symbol declared in include/smpc.h
 SYMBOLS = [
-    "smpc_builtin_robot", "smpc_last_error", "smpc_device_count", "smpc_create", "smpc_create_centroidal", "smpc_destroy", "smpc_get_dims",
+    "smpc_builtin_robot", "smpc_last_error", "smpc_device_count", "smpc_create", "smpc_create_centroidal", "smpc_create_fulldynamics", "smpc_get_contact_forces", "smpc_destroy", "smpc_get_dims",
     "smpc_generate_cycle_horizon", "smpc_switch_to_walk", "smpc_switch_to_stand", "smpc_set_velocity_base_batched", "smpc_set_stage_reference", "smpc_get_stage_reference", "smpc_set_reference_pose",
     "smpc_get_reference_pose", "smpc_get_contact_state", "smpc_set_x_reference",
     "smpc_state_size", "smpc_save_state", "smpc_load_state", "smpc_iterate", "smpc_iterate_device", "smpc_wait", "smpc_get_x_device", "smpc_get_xs", "smpc_get_us", "smpc_get_K0", "smpc_get_Ks",
@@ -138,6 +164,11 @@ class SmpcLib:
             C.POINTER(RobotModelC), C.POINTER(CentroidalSettingsC), C.POINTER(MpcSettingsC), C.c_int, C.c_double,
             C.c_int, C.POINTER(vp),
         ]
+        L.smpc_create_fulldynamics.argtypes = [
+            C.POINTER(RobotModelC), C.POINTER(FullDynamicsSettingsC), C.POINTER(MpcSettingsC), C.c_int, C.c_double,
+            C.c_int, C.POINTER(vp),
+        ]
+        L.smpc_get_contact_forces.argtypes = [vp, _dp]
         L.smpc_destroy.argtypes = [vp]
         L.smpc_get_dims.argtypes = [vp, _ip]
         L.smpc_generate_cycle_horizon.argtypes = [vp, _bp, C.c_int]

@@ -131,3 +131,49 @@ def make_cent_pair(batch, max_iters=1, lib=None, horizon=50, walk=(0.2, 0, 0, 0,
     om.switchToWalk(v)
     gm.switchToWalk(v)
     return om, gm, rb
+
+
+def make_full_product(batch, max_iters=1, lib=None, horizon=50, settings_override=None, mpc_override=None, device_id=0):
+    """simple_mpc.BatchedMPC over a FullDynamicsOCP with the Go2 settings of record (oracle_lib.go2_full_settings)."""
+    rb = O.Robot("go2_like")
+    s = O.go2_full_settings(rb)
+    s.update(dict(force_size=3, mu=0.8, Lfoot=0.01, Wfoot=0.01, force_cone=False, land_cstr=False))
+    if settings_override:
+        s.update(settings_override)
+    ms = O.go2_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if mpc_override:
+        ms.update(mpc_override)
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+    for n in FEET:
+        mh.addPointFoot(n, "root_joint")
+    ocp = simple_mpc.FullDynamicsOCP(s, mh)
+    ocp.createProblem(mh.getReferenceState(), horizon, 3, -9.81, False)
+    conf = {k: ms[k] for k in MPC_KEYS}
+    gm = simple_mpc.BatchedMPC(conf, ocp, batch, device_id=device_id, lib=lib)
+    return gm, rb, s, ms
+
+
+def make_full_oracle(batch, max_iters=1, horizon=50, settings_override=None, mpc_override=None, walk=(0.2, 0, 0, 0, 0, 0)):
+    rb = O.Robot("go2_like")
+    s = O.go2_full_settings(rb)
+    if settings_override:
+        s.update(settings_override)
+    ms = O.go2_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if mpc_override:
+        ms.update(mpc_override)
+    F = O.Full(rb, s)
+    om = O.OracleFullMPC(F, ms, batch)
+    if walk is not None:
+        om.generateCycleHorizon(O.trot_cycle())
+        om.switchToWalk(np.array(walk, float))
+    return om, rb
+
+
+def make_full_pair(batch, max_iters=1, lib=None, horizon=50, walk=(0.2, 0, 0, 0, 0, 0), **kw):
+    om, rb = make_full_oracle(batch, max_iters, horizon, walk=walk, **kw)
+    gm, _, _, _ = make_full_product(batch, max_iters, lib, horizon, **kw)
+    gm.generateCycleHorizon(O.trot_cycle())
+    gm.switchToWalk(np.array(walk, float))
+    return om, gm, rb
