@@ -5,6 +5,7 @@
 #pragma once
 #include "smpc_engine.h"
 #include "smpc_full_solver.h"
+#include "smpc_riccati_dense.h"
 #include "smpc_full_stage.h"
 
 namespace smpc
@@ -290,7 +291,10 @@ namespace smpc
     }
     void launch_sweeps(const Buffers<D> & b)
     {
-      timed_launch<SolverArgs<D>, riccati_full_body<D, 256>, 256>(KID_RICCATI, b.B, solver_args(b));
+      if (valu_riccati)
+        timed_launch<SolverArgs<D>, riccati_full_body<D, 256>, 256>(KID_RICCATI, b.B, solver_args(b)); // cross-check
+      else
+        timed_launch<SolverArgs<D>, riccati_dense_body<D>, 64, 2>(KID_RICCATI, b.B, solver_args(b));
       timed_launch<SolverArgs<D>, forward_full_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
     }
     int launch_backtracking(const Buffers<D> & b)

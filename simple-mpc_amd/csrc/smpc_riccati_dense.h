@@ -1,0 +1,350 @@
+// smpc_riccati_dense.h -- proximal Riccati backward sweep for stages with DENSE A, B on the FP64 matrix cores
+// (v_mfma_f64_16x16x4_f64), one 64-lane wavefront per instance: the full-dynamics OCP (HOT(4) of SolverProxDDP::run, reference
+// src/mpc.cpp:212; LQ solver choice src/mpc.cpp:52).
+//
+// Same KKT system and the same two symmetric block sweeps as riccati_kino_body (smpc_riccati_kino.h), without the semi-implicit
+// row structure (A and B of the constrained dynamics are dense):
+//   (2)  P~, p~ = Schur complement of  [[I + mu P, sqrt(mu) P, sqrt(mu) pt0], [., P, pt0]]        (NDX pivots, NT1 x NT1 tiles)
+//   (4)  T  = P~ [A | B]            -- accumulator tiles; the accumulator layout of T IS the B-operand layout of the next product
+//        H^ = [Q S; S^T R] + [A | B]^T T,  vector column [q; r] + [A | B]^T p~ (p~ rides as one more column of T)
+//   (5)  box rows (unit selectors): diagonal terms act / mu on R^ (torque box) and Q^ (joint box), act d / mu on the vector column
+//   (6)  sweep of the control pivots of [[Q^, S^, q^], [S^^T, R^, r^]] in place  ->  P_t, p_t, -K, -k
+// Generic in (NDX, NU): tile grids are computed from the dimensions; control pivots are padded to a multiple of 4 with unit rows.
+#pragma once
+#include "smpc_full_model.h"
+#include "smpc_riccati_kino.h"
+
+namespace smpc
+{
+  template <class D>
+  struct RiccatiDenseGeom
+  {
+    static constexpr int NDX = D::NDX, NU = D::NU, NXU = NDX + NU;
+    static constexpr int NUP = ((NU + 3) / 4) * 4;     // control pivots padded to whole panels
+    static constexpr int NXUP = NDX + NUP;
+    static constexpr int NT1 = (2 * NDX + 1 + 15) / 16; // tile grid of the first sweep
+    static constexpr int NTX = (NDX + 15) / 16;         // tile rows of P~ / T
+    static constexpr int NTJ = (NXUP + 15) / 16;        // tile columns holding [A | B]
+    static constexpr int VC = NXUP;                     // vector column of the second grid
+    static constexpr int NT2 = (NXUP + 1 + 15) / 16;    // tile grid of the second sweep
+    static constexpr int NTM = NT1 > NT2 ? NT1 : NT2;
+    static_assert(NDX % 4 == 0, "pivot panels and K steps of 4");
+    static_assert(NT1 <= 8 && NT2 <= 8, "sweep geometry: at most 128 columns");
+  };
+
+  template <class D>
+  struct RiccatiDenseLds
+  {
+    typedef RiccatiDenseGeom<D> GM;
+    static constexpr int NDX = D::NDX, NU = D::NU;
+    static constexpr int SWP = 4 * 16 * GM::NTM;
+    static constexpr int N_AB = NDX * GM::NXUP, N_W = NU * (NDX + 1);
+    static constexpr int N_SCR = (2 * SWP > N_W ? 2 * SWP : N_W);
+    double P[NDX * NDX];      // P_{t+1} -> P~ -> P_t
+    double AB[N_AB];          // [A | B | 0] row-major, row stride NXUP
+    double scr[N_SCR];        // sweep operands (2 x 4 x 16 NT) ; staging of [K | k]
+    double p[NDX], pt0[NDX], pt[NDX], f[NDX];
+    double boxa[D::NU + D::NA], boxd[D::NU + D::NA];
+  };
+
+  template <class D>
+  SMPC_DEV void riccati_dense_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    typedef RiccatiDenseGeom<D> GM;
+    typedef RiccatiDenseLds<D> LDS;
+    constexpr int NDX = D::NDX, NU = D::NU, NA = D::NA, NXU = GM::NXU, NXUP = GM::NXUP, NT1 = GM::NT1, NTX = GM::NTX, NTJ = GM::NTJ, NT2 = GM::NT2,
+                  VC = GM::VC, NUP = GM::NUP;
+    static_assert(D::NCONE == 0, "dense cone rows: explicit multiplier pivots (next)");
+    const Buffers<D> & b = ka.b;
+    const int H = b.H;
+    const int inst = block;
+    const double mu = b.model->mu, imu = 1.0 / mu, smu = sqrt(mu);
+    SMPC_LDS(LDS, lds, 1);
+    LDS & s = lds[0];
+    double * sw = s.scr;
+    double * Wm = s.scr;
+    SMPC_LANES(NT)
+    {
+      for (int i = lane; i < NDX * NDX; i += NT)
+        s.P[i] = b.QN[(size_t)inst * NDX * NDX + i];
+      for (int i = lane; i < NDX; i += NT)
+        s.p[i] = b.qN[(size_t)inst * NDX + i];
+    }
+    SMPC_LANES_END_WAVE
+    double * prof = nullptr;
+    long long tprev = 0;
+    for (int t = H - 1; t >= 0; t--)
+    {
+      const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
+      double * g = b.gains + ((size_t)inst * H + t) * D::G_STRIDE;
+      // ---- (1) f ; box rows ; save p_{t+1} ; pt0 = p + P f ----
+      SMPC_LANES(NT)
+      {
+        for (int i = lane; i < NDX; i += NT)
+        {
+          s.f[i] = lq[D::O_f + i];
+          g[D::G_pn + i] = s.p[i];
+        }
+        for (int i = lane; i < NU + NA; i += NT)
+        {
+          s.boxa[i] = lq[D::O_act + i];
+          s.boxd[i] = lq[D::O_d + i];
+        }
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      for (int i = lane; i < NDX; i += NT)
+      {
+        double acc = s.p[i];
+#pragma unroll 4
+        for (int j = 0; j < NDX; j++)
+          acc += s.P[i * NDX + j] * s.f[j];
+        s.pt0[i] = acc;
+      }
+      SMPC_LANES_END_WAVE
+      // ---- (2) P~ and p~: Schur complement of the bordered matrix (pivots: the first NDX rows) ----
+      {
+        SMPC_ACC(t1, NT, NT1 * (NT1 + 1) / 2);
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int I = 0; I < NT1; I++)
+#pragma unroll
+            for (int J = I; J < NT1; J++)
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+              {
+                const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+                const int r = row < col ? row : col, c = row < col ? col : row;
+                const int ri = r < NDX ? r : r - NDX, ci = c < NDX ? c : c - NDX;
+                const bool isv = c == 2 * NDX && r < 2 * NDX, ism = c < 2 * NDX;
+                const double pv = s.P[(ism ? ri * NDX + ci : 0)];
+                const double tv = s.pt0[isv ? ri : 0];
+                double val = ism ? pv : (isv ? tv : 0.0);
+                const double scale = c < NDX ? mu : ((r < NDX && (ism || isv)) ? smu : 1.0);
+                val = val * scale + ((c < NDX && r == c) ? 1.0 : 0.0);
+                SMPC_ACCV(t1, tix<NT1>(I, J), v) = val;
+              }
+        }
+        SMPC_LANES_END_WAVE
+        wave_block_sweep<NT, NT1, false, 0, NDX / 4>(t1, sw, sw + LDS::SWP, prof, tprev);
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int I = NDX / 16; I < NT1; I++) // tile rows that reach into the Schur block (rows NDX .. 2 NDX)
+#pragma unroll
+            for (int J = I; J < NT1; J++)
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+              {
+                const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+                const double val = SMPC_ACCV(t1, tix<NT1>(I, J), v);
+                if (row >= NDX && row < 2 * NDX && col >= row)
+                {
+                  if (col < 2 * NDX)
+                  {
+                    s.P[(row - NDX) * NDX + col - NDX] = val;
+                    s.P[(col - NDX) * NDX + row - NDX] = val;
+                  }
+                  else if (col == 2 * NDX)
+                    s.pt[row - NDX] = val;
+                }
+              }
+        }
+        SMPC_LANES_END_WAVE
+      }
+      // ---- (3) [A | B] into LDS ; P~ out (forward sweep) ; prefetch of [Q S q; S^T R r] in accumulator layout ----
+      SMPC_ACC(hacc, NT, NT2 * (NT2 + 1) / 2);
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int I = 0; I < NT2; I++)
+#pragma unroll
+          for (int J = I; J < NT2; J++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+            {
+              const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+              // upper storage: row <= col inside a diagonal tile is not guaranteed: take (min, max)
+              const int r0 = row < col ? row : col, c0 = row < col ? col : row;
+              int off = D::O_Q; // entries outside the problem load Q[0][0] and are overwritten below
+              if (c0 < NDX)
+                off = D::O_Q + r0 * NDX + c0;
+              else if (c0 < NXU)
+                off = r0 < NDX ? D::O_S + r0 * NU + c0 - NDX : D::O_R + (r0 - NDX) * NU + c0 - NDX;
+              else if (c0 == VC && r0 < NXU)
+                off = r0 < NDX ? D::O_q + r0 : D::O_r + r0 - NDX;
+              SMPC_ACCV(hacc, tix<NT2>(I, J), v) = lq[off];
+            }
+        for (int idx = lane; idx < NDX * NXUP; idx += NT)
+        {
+          const int i = idx / NXUP, j = idx % NXUP;
+          const double v = lq[j < NDX ? D::O_A + i * NDX + j : D::O_B + i * NU + (j < NXU ? j - NDX : 0)];
+          s.AB[idx] = j < NXU ? v : 0.0;
+        }
+        for (int idx = lane; idx < NDX * NDX; idx += NT)
+          g[D::G_Pt + idx] = s.P[idx];
+      }
+      SMPC_LANES_END_WAVE
+      // ---- (4) T = P~ [A | B] with p~ as column VC ; H^ += [A | B]^T T ----
+      {
+        SMPC_ACC(tacc, NT, NTX * NT2);
+        SMPC_PLA(double, pav, NT, NTX);
+        SMPC_PLA(double, abv, NT, NTJ);
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int I = 0; I < NTX; I++)
+#pragma unroll
+            for (int J = 0; J < NT2; J++)
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+              {
+                const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+                const double pv = s.pt[row < NDX ? row : 0];
+                SMPC_ACCV(tacc, I * NT2 + J, v) = (col == VC && row < NDX) ? pv : 0.0;
+              }
+        }
+        SMPC_LANES_END_WAVE
+        for (int ks = 0; ks < NDX / 4; ks++)
+        {
+          SMPC_LANES(NT)
+          {
+            const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+            for (int I = 0; I < NTX; I++)
+            {
+              // A operand: P~[16 I + lc][4 ks + lr] (symmetric: read along the row of 4 ks + lr)
+              const int r = 16 * I + lc;
+              const double pv = s.P[(4 * ks + lr) * NDX + (r < NDX ? r : 0)];
+              SMPC_PLV(pav)[I] = r < NDX ? pv : 0.0;
+            }
+#pragma unroll
+            for (int J = 0; J < NTJ; J++)
+            {
+              const int c = 16 * J + lc;
+              const double av = s.AB[(4 * ks + lr) * NXUP + (c < NXUP ? c : 0)];
+              SMPC_PLV(abv)[J] = c < NXUP ? av : 0.0;
+            }
+          }
+          SMPC_LANES_END_WAVE
+#pragma unroll
+          for (int I = 0; I < NTX; I++)
+#pragma unroll
+            for (int J = 0; J < NTJ; J++)
+              SMPC_MFMA(tacc, I * NT2 + J, pav, I, abv, J);
+        }
+        // H^(I, J) += sum_ks ABop(ks, I)^T T(ks, J): the B operand of K-step ks = 4 Ix + v is accumulator entry v of T's tile (Ix, J)
+        SMPC_PLA(double, tbv, NT, NT2);
+#pragma unroll
+        for (int Ix = 0; Ix < NTX; Ix++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            if (16 * Ix + 4 * v >= NDX)
+              continue;
+            SMPC_LANES(NT)
+            {
+              const int lr = lane >> 4, lc = lane & 15;
+              const int ks = 4 * Ix + v;
+#pragma unroll
+              for (int J = 0; J < NTJ; J++)
+              {
+                const int c = 16 * J + lc;
+                const double av = s.AB[(4 * ks + lr) * NXUP + (c < NXUP ? c : 0)];
+                SMPC_PLV(abv)[J] = c < NXUP ? av : 0.0;
+              }
+#pragma unroll
+              for (int J = 0; J < NT2; J++)
+                SMPC_PLV(tbv)[J] = SMPC_ACCV(tacc, Ix * NT2 + J, v);
+            }
+            SMPC_LANES_END_WAVE
+#pragma unroll
+            for (int I = 0; I < NTJ; I++)
+#pragma unroll
+              for (int J = I; J < NT2; J++)
+                SMPC_MFMA(hacc, tix<NT2>(I, J), abv, I, tbv, J);
+          }
+      }
+      // ---- (5) box rows ; padding pivots ; entries outside the problem ----
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int I = 0; I < NT2; I++)
+#pragma unroll
+          for (int J = I; J < NT2; J++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+            {
+              const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+              const int r0 = row < col ? row : col, c0 = row < col ? col : row;
+              double val = SMPC_ACCV(hacc, tix<NT2>(I, J), v);
+              // box index of a (state / control) index: joint box on x[6 .. 6 + NA), torque box on u
+              const int bi = (r0 >= 6 && r0 < 6 + NA) ? NU + r0 - 6 : ((r0 >= NDX && r0 < NXU) ? r0 - NDX : -1);
+              const double ba = s.boxa[bi >= 0 ? bi : 0], bd = s.boxd[bi >= 0 ? bi : 0];
+              if (bi >= 0 && c0 == r0)
+                val += imu * ba;
+              if (bi >= 0 && c0 == VC)
+                val += imu * ba * bd;
+              if (r0 >= NXU || (c0 >= NXU && c0 != VC) || c0 > VC)
+                val = (r0 == c0 && r0 < NXUP) ? 1.0 : 0.0; // unit padding pivots, zero elsewhere
+              SMPC_ACCV(hacc, tix<NT2>(I, J), v) = val;
+            }
+      }
+      SMPC_LANES_END_WAVE
+      // ---- (6) sweep the control pivots in place:  x-x block -> P_t,  x-vector -> p_t,  (x, u) entries -> -K,  (u, vector) -> -k ----
+      wave_block_sweep<NT, NT2, true, NDX, NUP / 4>(hacc, sw, sw + LDS::SWP, prof, tprev);
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int I = 0; I < NT2; I++)
+#pragma unroll
+          for (int J = I; J < NT2; J++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+            {
+              const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+              const double val = SMPC_ACCV(hacc, tix<NT2>(I, J), v);
+              if (row < NDX)
+              {
+                if (col < NDX)
+                {
+                  if (row <= col)
+                  {
+                    s.P[row * NDX + col] = val;
+                    s.P[col * NDX + row] = val;
+                  }
+                }
+                else if (col < NXU)
+                  Wm[(col - NDX) * (NDX + 1) + row] = -val; // K
+                else if (col == VC)
+                  s.p[row] = val; // p_t
+              }
+              else if (row < NXU && col == VC)
+                Wm[(row - NDX) * (NDX + 1) + NDX] = -val; // k
+            }
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
+        constexpr int NW = (NU * (NDX + 1) + NT - 1) / NT;
+        double wv[NW];
+#pragma unroll
+        for (int n = 0; n < NW; n++)
+          wv[n] = Wm[lane + n * NT < NU * (NDX + 1) ? lane + n * NT : 0];
+#pragma unroll
+        for (int n = 0; n < NW; n++)
+          if (lane + n * NT < NU * (NDX + 1))
+            g[D::G_K + lane + n * NT] = wv[n];
+      }
+      SMPC_LANES_END_WAVE
+    }
+  }
+} // namespace smpc
