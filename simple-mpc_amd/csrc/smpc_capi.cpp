@@ -628,7 +628,10 @@ extern "C"
   int smpc_debug_get_phase_cycles(smpc_handle * h, double * out64)
   {
     if (h && h->full)
-      return fail(SMPC_ERR_INVALID, "phase timers are not built for full-dynamics handles");
+      return guarded([&] {
+        if (!h->full->phase_cycles(out64))
+          throw std::runtime_error("phase timers are off (set SMPC_PHASE_PROFILE=1 before smpc_create_fulldynamics)");
+      });
     if (h && h->cent && h->cent->buf.dbg)
       return guarded([&] { h->cent->get_linear(h->cent->buf.dbg, 64, out64); });
     if (!h || h->cent || !h->eng->buf.dbg)

@@ -54,6 +54,7 @@ namespace smpc
     virtual void debug_lq(int inst, int t, double * out) = 0;
     virtual void debug_steps(double * dxs, double * dus) = 0;
     virtual void debug_terminal(int inst, double * QN, double * qN) = 0;
+    virtual bool phase_cycles(double * out64) = 0;
   };
 
   template <class D>
@@ -198,6 +199,8 @@ namespace smpc
       buf.stages = (StageShared<D> *)dev_alloc((size_t)H * sizeof(StageShared<D>));
       buf.model = (DevModel<D> *)dev_alloc(sizeof(DevModel<D>));
       X_dev = dalloc((size_t)B * D::NX);
+      if (std::getenv("SMPC_PHASE_PROFILE"))
+        buf.dbg = dalloc(64);
       h2d(buf.model, hm.data(), sizeof(DevModel<D>), stream);
       stream_sync(stream);
       // ---- default problem (OCPHandler::createProblem, src/ocp-handler.cpp:96-137) ----
@@ -777,12 +780,26 @@ namespace smpc
         throw std::runtime_error("unknown output");
       }
     }
+    bool phase_cycles(double * out64) override
+    {
+      if (!buf.dbg)
+        return false;
+      get_linear(buf.dbg, 64, out64);
+      return true;
+    }
     int lq_size() const override { return D::LQ_STRIDE; }
     void debug_lq(int inst, int t, double * out) override
     {
       if (inst < 0 || inst >= B || t < 0 || t >= H)
         throw std::runtime_error("Stage index exceeds stage vector size");
       get_linear(buf.lq + ((size_t)inst * H + t) * D::LQ_STRIDE, D::LQ_STRIDE, out);
+      // the derivative pass writes the upper 16 x 16 tiles of Q and R only (readers take the upper triangle): mirror here
+      for (int i = 0; i < D::NDX; i++)
+        for (int j = 0; j < i; j++)
+          out[D::O_Q + i * D::NDX + j] = out[D::O_Q + j * D::NDX + i];
+      for (int i = 0; i < D::NU; i++)
+        for (int j = 0; j < i; j++)
+          out[D::O_R + i * D::NU + j] = out[D::O_R + j * D::NU + i];
     }
     void debug_steps(double * dxs, double * dus) override
     {

@@ -118,11 +118,11 @@ namespace smpc
       SMPC_LANES(NT)
       {
         mm_tn<NDX, NXU, NDX, TL, TL, NT>(
-          s.AB, NXU, s.MT, NXU, lane, [&](int i, int j) { return j < NDX ? lq[D::O_Q + i * NDX + j] : lq[D::O_S + i * NU + j - NDX]; },
+          s.AB, NXU, s.MT, NXU, lane, [&](int i, int j) { return j < NDX ? lq[D::O_Q + (i < j ? i : j) * NDX + (i < j ? j : i)] : lq[D::O_S + i * NU + j - NDX]; }, // upper triangle is authoritative
           [&](int i, int j, double v) { s.QS[i * NXU + j] = v; });
         mm_tn<NU, NU, NDX, TL, TL, NT>(
           s.AB + NDX, NXU, s.MT + NDX, NXU, lane,
-          [&](int i, int j) { return lq[D::O_R + i * NU + j] + (i == j ? imu * s.act[i] : 0.0); }, // torque box rows
+          [&](int i, int j) { return lq[D::O_R + (i < j ? i : j) * NU + (i < j ? j : i)] + (i == j ? imu * s.act[i] : 0.0); }, // torque box rows
           [&](int i, int j, double v) { s.Rh[i * NU + j] = v; });
         for (int c = lane; c < NXU; c += NT)
         {

@@ -22,6 +22,18 @@ namespace smpc
 {
   SMPC_HD int jof(int k) { return k < 6 ? 0 : k - 5; } // joint of dof k
 
+  // optional in-kernel phase timers (SMPC_PHASE_PROFILE=1): cycles since the previous tick accumulate into prof[slot]
+  struct FullProf
+  {
+    double * prof = nullptr;
+    long long tprev = 0;
+  };
+  SMPC_DEV void ftick(FullProf & fp, int slot)
+  {
+    if (fp.prof)
+      prof_tick(fp.prof, slot, fp.tprev);
+  }
+
   template <class D, bool DERIV>
   struct FullScratch
   {
@@ -61,8 +73,7 @@ namespace smpc
     double Bc[NJ * 36], dk[NV * 6], Ak[NV * 6], Fgc[NJ * 6], Wc[NF * 6];
     double R1[NV * NCOL];       // [r1q | r1v | r1t] -> M^-1 R1 -> [da_dq | da_dv | da_dtau]
     double JT[NGN * NCOL];      // stacked Gauss-Newton Jacobian; rows 0..NCM-1: [r2q | r2v | 0] -> [dlam_dq | dlam_dv | dlam_dtau]
-    double WJ[NGN * NCOL];      // block-diagonal weight times JT
-    double Ag[6 * NV], dh_dq[6 * NV], Jfoot[NF * 3 * NV];
+    double Ag[6 * NV];
     double Je3[9], JeQ[9], Jq[36], Jl[36], WJl[NDX * 6], JWJ[36];
     double gx[NDX], gu[NU]; // cost gradients
     double dual[128];
@@ -173,7 +184,7 @@ namespace smpc
   // dyn = false: kinematics / momentum only (terminal node).
   // -------------------------------------------------------------------------------------------------------------
   template <class D, bool DERIV, class SC, class SD>
-  SMPC_DEV void full_dynamics_phases(SC & sc, SD * sd, const DevModel<D> & mg, unsigned mask, bool dyn)
+  SMPC_DEV void full_dynamics_phases(SC & sc, SD * sd, const DevModel<D> & mg, unsigned mask, bool dyn, FullProf & fp)
   {
     constexpr int NT = 64;
     constexpr int NJ = D::NJ, NV = D::NV, NQ = D::NQ, NF = D::NF, NCM = D::NCM, NR = SC::NR, FS = D::FS;
@@ -275,6 +286,7 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     static_assert(NF <= 32 && NJ <= 32, "lane map of the inertia / foot phase");
+    ftick(fp, 1);
     if constexpr (DERIV)
     {
       // per-body velocity-product matrices  B_l y = v_l x* (I_l y) - I_l (v_l x y)  (lane = (body, column))
@@ -340,6 +352,7 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
+    ftick(fp, 2);
     if (!dyn)
       return;
     // ---- Ic_j S_l ; bias forces ; right-hand side S tau - nle ----
@@ -414,6 +427,7 @@ namespace smpc
       sc.gam[3 * c + 2] = drift.z + h.Kd[2] * verr.z - h.Kp[2] * perr.z;
     }
     SMPC_LANES_END_WAVE
+    ftick(fp, 3);
     // ---- M = L L^T ; W = M^-1 [S tau - nle | J^T] ----
     fwave_cholesky<NT, NV>(sc.M, sc.tmp);
     SMPC_LANES(NT)
@@ -424,6 +438,7 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     fwave_chol_solve<NT, NV>(sc.M, sc.W, NR, NR);
+    ftick(fp, 4);
     // ---- damped Delassus matrix (unit diagonal on the rows of absent contacts), its inverse, J M^-1 b ----
     const int nc = FS * __builtin_popcount(mask & ((1u << NF) - 1u));
     SMPC_LANES(NT)
@@ -450,6 +465,7 @@ namespace smpc
     SMPC_LANES_END_WAVE
     fwave_cholesky<NT, NCM>(sc.G, sc.tmp);
     fwave_chol_solve<NT, NCM>(sc.G, sc.Gi, NCM, NCM);
+    ftick(fp, 5);
     // ---- proximal iteration:  lam <- G^-1 (mu lam - gamma - J M^-1 b)  until |d lam|_inf <= accuracy ----
     int iters = 0;
     if (nc > 0)
@@ -490,6 +506,7 @@ namespace smpc
         sc.iters_[0] = iters;
     }
     SMPC_LANES_END_WAVE
+    ftick(fp, 6);
   }
 
   // SE(3) work of a stage on two lanes: lane 0 integrates the base (x+ and, with derivatives, Jexp6(nu) and the action matrix
@@ -808,7 +825,7 @@ namespace smpc
   //   WJ = block-diagonal weight x JT,  Je3 / JeQ / Jq / Jl from the SE(3) pair.
   // -------------------------------------------------------------------------------------------------------------
   template <class D, class SC, class SD>
-  SMPC_DEV void full_deriv_phases(SC & sc, SD & sd, const DevModel<D> & mg, unsigned mask, bool term)
+  SMPC_DEV void full_deriv_phases(SC & sc, SD & sd, const DevModel<D> & mg, unsigned mask, bool term, FullProf & fp)
   {
     constexpr int NT = 64;
     constexpr int NJ = D::NJ, NV = D::NV, NF = D::NF, NCM = D::NCM, NU = D::NU, NR = SC::NR, NCOL = SC::NCOL, FS = D::FS, NGN = SC::NGN;
@@ -864,6 +881,7 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
     }
+    ftick(fp, 8);
     // ---- per dof: d_k, A_k ; centroidal-momentum and foot-position Jacobian columns (rows NCM .. of JT) ----
     SMPC_LANES(NT)
     if (lane < NV)
@@ -918,6 +936,7 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     static_assert(NU <= NV, "tau columns are zeroed by the dof lanes");
+    ftick(fp, 9);
     if (term)
       return;
     // ---- partial derivatives of RNEA(q, v, a) - J^T lam at the solution: R1 = [r1q | r1v | -S] ----
@@ -978,6 +997,7 @@ namespace smpc
         sd.JT[idx] = 0.0;
     }
     SMPC_LANES_END_WAVE
+    ftick(fp, 10);
     // ---- partial derivatives of the contact acceleration residual (classical acceleration, contact frame, corrector) ----
     SMPC_LANES(NT)
     for (int idx = lane; idx < NF * NV; idx += NT)
@@ -1013,6 +1033,7 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     static_assert(FS == 3, "contact-acceleration partials of the 6-D LOCAL_WORLD_ALIGNED contact come with the Talos table");
+    ftick(fp, 11);
     // ---- [M -J^T; J mu] [da; dlam] = -[r1; r2]:  Mr = M^-1 R1 ; rhs = J Mr - r2 ; dlam = G^-1 rhs ; da = -Mr + M^-1 J^T dlam ----
     fwave_chol_solve<NT, NV>(sc.M, sd.R1, NCOL, NCOL);
     SMPC_LANES(NT)
@@ -1062,47 +1083,24 @@ namespace smpc
       sd.R1[idx] = acc;
     }
     SMPC_LANES_END_WAVE
+    ftick(fp, 12);
     (void)NGN;
   }
 
-  // weighted Gauss-Newton Jacobian WJ = blockdiag(w_forces per contact, w_cent (x10 at the terminal node), w_frame per foot) * JT
-  // and the stacked weighted residual (sd.dual[0 .. NGN) used as scratch)
-  template <class D, class SC, class SD>
-  SMPC_DEV void full_weighted_jacobian(SC & sc, SD & sd, bool term)
+  // entry (r, k) of the block-diagonal Gauss-Newton weight W~ = blockdiag(w_forces per contact, w_cent (x 10 at the terminal
+  // node), w_frame per foot) over the rows of JT
+  template <class D, class SC>
+  SMPC_DEV double full_wtilde(const FullHead<D> & h, int r, int k, bool term)
   {
-    constexpr int NT = 64;
-    constexpr int NF = D::NF, NCM = D::NCM, NCOL = SC::NCOL, FS = D::FS, NGN = SC::NGN;
-    const FullHead<D> & h = sc.h;
-    SMPC_LANES(NT)
-    for (int idx = lane; idx < NGN * NCOL; idx += NT)
-    {
-      const int r = idx / NCOL, j = idx % NCOL;
-      double acc = 0.0;
-      if (r < NCM)
-      {
-        if (!term)
-        {
-          const int c = r / FS, rr = r % FS;
-          for (int b = 0; b < FS; b++)
-            acc += h.w_forces[rr * FS + b] * sd.JT[(c * FS + b) * NCOL + j];
-        }
-      }
-      else if (r < NCM + 6)
-      {
-        const double sc10 = term ? 10.0 : 1.0;
-        for (int b = 0; b < 6; b++)
-          acc += sc10 * h.w_cent[(r - NCM) * 6 + b] * sd.JT[(NCM + b) * NCOL + j];
-      }
-      else if (!term)
-      {
-        const int f = (r - NCM - 6) / 3, rr = (r - NCM - 6) % 3;
-        for (int b = 0; b < 3; b++)
-          acc += h.w_frame[rr * FS + b] * sd.JT[(NCM + 6 + 3 * f + b) * NCOL + j];
-      }
-      sd.WJ[idx] = acc;
-    }
-    SMPC_LANES_END_WAVE
-    (void)NF;
+    constexpr int NCM = D::NCM, FS = D::FS, NGN = SC::NGN;
+    if (r >= NGN || k >= NGN)
+      return 0.0;
+    if (r < NCM)
+      return (term || k >= NCM || r / FS != k / FS) ? 0.0 : h.w_forces[(r % FS) * FS + k % FS];
+    if (r < NCM + 6)
+      return (k < NCM || k >= NCM + 6) ? 0.0 : (term ? 10.0 : 1.0) * h.w_cent[(r - NCM) * 6 + k - NCM];
+    const int a = r - NCM - 6, bb = k - NCM - 6;
+    return (term || bb < 0 || a / 3 != bb / 3) ? 0.0 : h.w_frame[(a % 3) * FS + bb % 3];
   }
 
   // entry (i, j) of the state-cost Hessian Jx^T w_x Jx, Jx = blockdiag(Jlog6, I)
@@ -1146,6 +1144,138 @@ namespace smpc
       for (int a = 0; a < 6; a++)
         s += sd.Jl[a * 6 + i] * sd.WJl[a * 6 + j];
       sd.JWJ[lane] = s;
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // Gauss-Newton Hessian  [Q S; S^T R] = H_0 + JT^T (W~ JT) + preg I  on the FP64 matrix cores:  W~ JT in accumulator tiles
+  // (tile row R of the NGN rows, tile column J of the NXU columns); the accumulator layout (rows lr + 4 v of tile row R) is the
+  // B-operand layout of K-step 4 R + v of the second product, so the weighted Jacobian never leaves the registers.  Upper 16 x 16
+  // tiles of the (x, u) grid are written: Q (upper tiles; mirrored when `mirror`), S, R (readers take (min, max) indices).
+  template <class D, class SC, class SD>
+  SMPC_DEV void full_hessian_mfma(SC & sc, SD & sd, const DevModel<D> & mg, bool term, double preg, double * Qd, double * Sd, double * Rd, bool mirror)
+  {
+    constexpr int NT = 64;
+    constexpr int NDX = D::NDX, NU = D::NU, NXU = D::NXU, NCOL = SC::NCOL, NGN = SC::NGN;
+    constexpr int NTC = (NXU + 15) / 16, NTR = (NGN + 15) / 16, KS = (NGN + 3) / 4;
+    static_assert(NCOL == NXU, "the derivative columns (q, v, tau) are the (x, u) columns");
+    const FullHead<D> & h = sc.h;
+    SMPC_ACC(wj, NT, NTR * NTC);
+    SMPC_ACC(qa, NT, NTC * (NTC + 1) / 2);
+    SMPC_PLA(double, jtv, NT, NTC);
+    SMPC_PLA(double, wop, NT, NTR);
+    SMPC_LANES(NT)
+    {
+      const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+      for (int tt = 0; tt < NTR * NTC; tt++)
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+          SMPC_ACCV(wj, tt, v) = 0.0;
+      // H_0: state-cost block (with the Jlog6 base block), control weight, primal regularisation
+#pragma unroll
+      for (int I = 0; I < NTC; I++)
+#pragma unroll
+        for (int J = I; J < NTC; J++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+            double val = 0.0;
+            if (row < NDX && col < NDX)
+              val = full_state_hessian<D>(sc, sd, mg, row, col);
+            else if (!term && row >= NDX && row < NXU && col >= NDX && col < NXU)
+              val = h.w_diag ? (row == col ? h.wud[row - NDX] : 0.0) : mg.w_u[(row - NDX) * NU + col - NDX];
+            if (row == col && row < (term ? NDX : NXU))
+              val += preg;
+            SMPC_ACCV(qa, tix<NTC>(I, J), v) = val;
+          }
+    }
+    SMPC_LANES_END_WAVE
+    for (int ks = 0; ks < KS; ks++)
+    {
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+        const int r = 4 * ks + lr;
+#pragma unroll
+        for (int J = 0; J < NTC; J++)
+        {
+          const int c = 16 * J + lc;
+          const bool ok = r < NGN && c < NCOL && (!term || (r >= D::NCM && r < D::NCM + 6)); // terminal node: momentum rows only
+          const double v = sd.JT[(ok ? r : D::NCM) * NCOL + (c < NCOL ? c : 0)];
+          SMPC_PLV(jtv)[J] = ok ? v : 0.0;
+        }
+#pragma unroll
+        for (int R = 0; R < NTR; R++)
+          SMPC_PLV(wop)[R] = full_wtilde<D, SC>(h, 16 * R + lc, r, term);
+      }
+      SMPC_LANES_END_WAVE
+#pragma unroll
+      for (int R = 0; R < NTR; R++)
+#pragma unroll
+        for (int J = 0; J < NTC; J++)
+          SMPC_MFMA(wj, R * NTC + J, wop, R, jtv, J);
+    }
+    SMPC_PLA(double, bv, NT, NTC);
+#pragma unroll
+    for (int R = 0; R < NTR; R++)
+#pragma unroll
+      for (int v = 0; v < 4; v++)
+      {
+        if (16 * R + 4 * v >= NGN)
+          continue;
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+          const int r = 4 * (4 * R + v) + lr;
+#pragma unroll
+          for (int J = 0; J < NTC; J++)
+          {
+            const int c = 16 * J + lc;
+            const bool ok = r < NGN && c < NCOL && (!term || (r >= D::NCM && r < D::NCM + 6));
+            const double x = sd.JT[(ok ? r : D::NCM) * NCOL + (c < NCOL ? c : 0)];
+            SMPC_PLV(jtv)[J] = ok ? x : 0.0;
+            SMPC_PLV(bv)[J] = SMPC_ACCV(wj, R * NTC + J, v);
+          }
+        }
+        SMPC_LANES_END_WAVE
+#pragma unroll
+        for (int I = 0; I < NTC; I++)
+#pragma unroll
+          for (int J = I; J < NTC; J++)
+            SMPC_MFMA(qa, tix<NTC>(I, J), jtv, I, bv, J);
+      }
+    SMPC_LANES(NT)
+    {
+      const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+      for (int I = 0; I < NTC; I++)
+#pragma unroll
+        for (int J = I; J < NTC; J++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+            const double val = SMPC_ACCV(qa, tix<NTC>(I, J), v);
+            // (diagonal tiles hold both triangles: only the upper one is written, so that no two lanes target one address)
+            if (col < NDX)
+            {
+              if (row <= col)
+              {
+                Qd[row * NDX + col] = val;
+                if (mirror && row < col)
+                  Qd[col * NDX + row] = val;
+              }
+            }
+            else if (col < NXU && Sd != nullptr)
+            {
+              if (row < NDX)
+                Sd[row * NU + col - NDX] = val;
+              else if (row <= col)
+                Rd[(row - NDX) * NU + col - NDX] = val;
+            }
+          }
     }
     SMPC_LANES_END_WAVE
   }
@@ -1203,10 +1333,15 @@ namespace smpc
         sc.nu[i] = term ? 0.0 : b.vs[(ib + st) * NC + i];
     }
     SMPC_LANES_END_WAVE
-    full_dynamics_phases<D, true>(sc, &sd, mg, mask, !term);
+    FullProf fp;
+    fp.prof = (b.dbg != nullptr && inst == 0 && t == 17 && ka.slots == 0) ? b.dbg : nullptr; // one mid-horizon block
+    fp.tprev = SMPC_CLOCK();
+    ftick(fp, 0);
+    full_dynamics_phases<D, true>(sc, &sd, mg, mask, !term, fp);
     full_eval_tail<D, true>(sc, &sd, mg, mask, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
-    full_deriv_phases<D>(sc, sd, mg, mask, term);
-    full_weighted_jacobian<D>(sc, sd, term);
+    ftick(fp, 7);
+    full_deriv_phases<D>(sc, sd, mg, mask, term, fp);
+    ftick(fp, 13);
     full_state_tables<D>(sc, sd, mg);
     double * parts = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
     // stacked weighted residual [Wrl | Whg | Wrf] for the gradients
@@ -1243,18 +1378,9 @@ namespace smpc
       // ---- terminal node: Q_N = Lxx + preg I, q_N = lx - lambda_H ----
       double * QN = b.QN + (size_t)inst * NDX * NDX;
       double * qN = b.qN + (size_t)inst * NDX;
+      full_hessian_mfma<D>(sc, sd, mg, true, preg, QN, (double *)nullptr, (double *)nullptr, true);
       SMPC_LANES(NT)
       {
-        for (int idx = lane; idx < NDX * NDX; idx += NT)
-        {
-          const int i = idx / NDX, j = idx % NDX;
-          double v = full_state_hessian<D>(sc, sd, mg, i, j);
-          for (int r = NCM; r < NCM + 6; r++)
-            v += sd.JT[r * NCOL + i] * sd.WJ[r * NCOL + j];
-          if (i == j)
-            v += preg;
-          QN[idx] = v;
-        }
         double dual = 0.0;
         for (int k = lane; k < NDX; k += NT)
         {
@@ -1281,6 +1407,7 @@ namespace smpc
     }
     double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
     const double dt = h.dt, mu = h.mu;
+    ftick(fp, 14);
     // ---- [A | B] (lane = column), Lagrangian gradients q, r ----
     SMPC_LANES(NT)
     {
@@ -1348,32 +1475,11 @@ namespace smpc
       sc.part[lane] = dual;
     }
     SMPC_LANES_END_WAVE
-    // ---- [Q S; S^T R] = H_0 + JT^T WJ + preg I ----
+    ftick(fp, 15);
+    // ---- [Q S; S^T R] = H_0 + JT^T (W~ JT) + preg I on the matrix cores ----
+    full_hessian_mfma<D>(sc, sd, mg, false, preg, lq + D::O_Q, lq + D::O_S, lq + D::O_R, false);
     SMPC_LANES(NT)
     {
-      for (int idx = lane; idx < NDX * NXU; idx += NT)
-      {
-        const int i = idx / NXU, j = idx % NXU;
-        double v = j < NDX ? full_state_hessian<D>(sc, sd, mg, i, j) : 0.0;
-        for (int r = 0; r < NGN; r++)
-          v += sd.JT[r * NCOL + i] * sd.WJ[r * NCOL + j];
-        if (i == j)
-          v += preg;
-        if (j < NDX)
-          lq[D::O_Q + i * NDX + j] = v;
-        else
-          lq[D::O_S + i * NU + j - NDX] = v;
-      }
-      for (int idx = lane; idx < NU * NU; idx += NT)
-      {
-        const int i = idx / NU, j = idx % NU;
-        double v = h.w_diag ? (i == j ? h.wud[i] : 0.0) : mg.w_u[idx];
-        for (int r = 0; r < NCM; r++)
-          v += sd.JT[r * NCOL + NDX + i] * sd.WJ[r * NCOL + NDX + j];
-        if (i == j)
-          v += preg;
-        lq[D::O_R + idx] = v;
-      }
       for (int i = lane; i < NC; i += NT)
       {
         lq[D::O_d + i] = mu * (sc.vplus[i] - sc.nu[i]);
@@ -1383,6 +1489,7 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
+    ftick(fp, 16);
     static_assert(D::NCONE == 0, "dense cone rows (Cd, Dd) come with the 6-D feet");
     SMPC_LANES(NT)
     {
@@ -1458,7 +1565,8 @@ namespace smpc
       lanes_integrate<D>(b.xs + (ib + sn) * NX, dx + (term ? 0 : NDX), alpha, sc.xn1, lane, 1);
     }
     SMPC_LANES_END_WAVE
-    full_dynamics_phases<D, false>(sc, (FullScratchDeriv<D> *)nullptr, mg, mask, !term);
+    FullProf fp;
+    full_dynamics_phases<D, false>(sc, (FullScratchDeriv<D> *)nullptr, mg, mask, !term, fp);
     full_eval_tail<D, false>(sc, (FullScratchDeriv<D> *)nullptr, mg, mask, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
     double * parts = b.partsT + (((size_t)inst * D::LS_N + j) * (H + 1) + t) * 2;
     SMPC_LANES(NT)
