@@ -132,6 +132,8 @@ extern "C"
       return &SMPC_ROBOT_GO2_LIKE;
     if (!std::strcmp(name, "biped_like"))
       return &SMPC_ROBOT_BIPED_LIKE;
+    if (!std::strcmp(name, "talos_like"))
+      return &SMPC_ROBOT_TALOS_LIKE;
     return nullptr;
   }
   int orc_robot_dims(const smpc_robot_model * m, int * out) // nq nv nfeet njoints
@@ -278,11 +280,12 @@ extern "C"
   // x = [q; v], tau (nv - 6), contact mask, Kp / Kd (3) -> a (nv), lam (3 per foot in contact, contact frame),
   // M (nv x nv), nle (nv), J (3 nc x nv), gamma (3 nc), tau_rnea (nv) = RNEA(q, v, a);  returns the proximal iteration count
   int orc_full_forward_dynamics(
-    const smpc_robot_model * m, const double * x, const double * tau, unsigned mask, const double * Kp, const double * Kd,
+    const smpc_robot_model * m, const double * x, const double * tau, unsigned mask, int fs, const double * Kp, const double * Kd,
     double * a, double * lam, double * Mq, double * nle, double * J, double * gamma, double * tau_rnea)
   {
     ConstraintDynamics cd(m);
-    for (int i = 0; i < 3; i++)
+    cd.fs = fs;
+    for (int i = 0; i < fs; i++)
     {
       cd.Kp[i] = Kp[i];
       cd.Kd[i] = Kd[i];
@@ -300,12 +303,13 @@ extern "C"
   // same inputs + proximal accuracy / iteration cap (<= 0: the reference's settings) -> a, lam and their derivatives wrt
   // the tangent of q, v and tau (row-major; lam rows = 3 per foot in contact), and the RNEA partials at the solution
   int orc_full_dynamics_derivatives(
-    const smpc_robot_model * m, const double * x, const double * tau, unsigned mask, const double * Kp, const double * Kd,
+    const smpc_robot_model * m, const double * x, const double * tau, unsigned mask, int fs, const double * Kp, const double * Kd,
     double prox_accuracy, int prox_max_iter, double * a, double * lam, double * da_dq, double * da_dv, double * da_dtau,
     double * dlam_dq, double * dlam_dv, double * dlam_dtau, double * dtau_dq, double * dtau_dv)
   {
     ConstraintDynamics cd(m);
-    for (int i = 0; i < 3; i++)
+    cd.fs = fs;
+    for (int i = 0; i < fs; i++)
     {
       cd.Kp[i] = Kp[i];
       cd.Kd[i] = Kd[i];
@@ -332,19 +336,26 @@ extern "C"
   void * orc_full_create(
     const smpc_robot_model * m, double dt, const double * w_x, const double * w_u, const double * w_cent, const double * w_forces,
     const double * w_frame, const double * gravity, const double * Kp, const double * Kd, const double * umin,
-    const double * umax, const double * qmin, const double * qmax, int torque_limits, int kinematics_limits)
+    const double * umax, const double * qmin, const double * qmax, int torque_limits, int kinematics_limits, int force_size,
+    int force_cone, double mu, double Lfoot, double Wfoot)
   {
     FullSettings s;
-    const int ndx = 2 * m->nv, nu = m->nv - 6;
+    const int ndx = 2 * m->nv, nu = m->nv - 6, fs = force_size;
     s.timestep = dt;
+    s.force_size = fs;
+    s.force_cone = force_cone != 0;
+    s.mu = mu;
+    s.Lfoot = Lfoot;
+    s.Wfoot = Wfoot;
     s.w_x = mat_from(w_x, ndx, ndx);
     s.w_u = mat_from(w_u, nu, nu);
     s.w_cent = mat_from(w_cent, 6, 6);
-    s.w_forces = mat_from(w_forces, 3, 3);
-    s.w_frame = mat_from(w_frame, 3, 3);
+    s.w_forces = mat_from(w_forces, fs, fs);
+    s.w_frame = mat_from(w_frame, fs, fs);
     for (int i = 0; i < 3; i++)
-    {
       s.gravity[i] = gravity[i];
+    for (int i = 0; i < fs; i++)
+    {
       s.Kp[i] = Kp[i];
       s.Kd[i] = Kd[i];
     }
@@ -370,7 +381,7 @@ extern "C"
   {
     StageRef r;
     r.mask = mask;
-    r.u_ref.assign(u_ref, u_ref + md.nu + 3 * md.nf); // [control reference ; force reference per foot]
+    r.u_ref.assign(u_ref, u_ref + md.n_uref()); // [control reference ; force reference per foot]
     r.x_tgt.assign(x_tgt, x_tgt + md.nx);
     r.foot_ref.resize(md.nf);
     for (int f = 0; f < md.nf; f++)

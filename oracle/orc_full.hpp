@@ -26,7 +26,14 @@
 // formulation of orc_rigid.hpp (d_k = v_lam x S_k, A_k = (a_lam - g) x S_k + v_lam x d_k):
 //     d tau_m / d q_k = S_m . (Ic_s A_k + Bc_s d_k)  [+ S_m . (S_k x* Fc_i) if joint(m) is a strict ancestor of joint(k)]
 //     d tau_m / d v_k = S_m . (Bc_s S_k + Ic_s (v_i x S_k + d_k))        s = the lower of joint(m), joint(k) (same branch)
-// The OCP on top (costs, constraints, integrator) is the next block.
+// 6-D feet (fs = 6): RigidConstraintModel(CONTACT_6D, LOCAL_WORLD_ALIGNED) [REF src/fulldynamics.cpp:56-65]: the contact frame has
+// its origin at the foot frame and the axes of the world; rows = [linear ; angular]:
+//   J_k   = [S_k.l + S_k.a x p ; S_k.a],   drift = [classical acceleration of the point ; angular acceleration] at zero joint
+//   accelerations,  corrector  Kd o [v_p ; w]  +  Kp o [p ; log3(R)]   (anchor = universe frame, identity placement),
+//   lam   = the wrench [f ; tau] ON the robot at the foot point, world axes.
+// The world-aligned components of a body-fixed vector u turn with the body when q_k moves: d u / d q_k = (co-moving part, the
+// LOCAL formulas) + S_k.a x u; a world-aligned force does not turn, only its point of application moves (dp = J_k lin).
+// The OCP on top (costs, constraints, integrator): orc_fulldyn.hpp.
 #pragma once
 #include "orc_rigid.hpp"
 
@@ -42,11 +49,12 @@ namespace orc
     double prox_accuracy = 1e-9, prox_mu = 1e-10;
     int prox_max_iter = 10;
     double gravity[3] = {0, 0, -9.81};
-    double Kp[3] = {0, 0, 0}, Kd[3] = {0, 0, 0};
+    int fs = 3;          // contact size: 3 (CONTACT_3D, LOCAL) or 6 (CONTACT_6D, LOCAL_WORLD_ALIGNED)
+    double Kp[6] = {0, 0, 0, 0, 0, 0}, Kd[6] = {0, 0, 0, 0, 0, 0};
     // results of the last call
-    Mat Mq, Jc;          // nv x nv ; 3 n_c x nv
-    Vec nle, gamma;      // nv ; 3 n_c
-    Vec a, lam;          // nv ; 3 n_c (force ON the robot at the foot, contact frame)
+    Mat Mq, Jc;          // nv x nv ; fs n_c x nv
+    Vec nle, gamma;      // nv ; fs n_c
+    Vec a, lam;          // nv ; fs n_c (force ON the robot at the foot, contact frame)
     int prox_iters = 0;
     std::vector<int> feet; // feet in contact, in order
     Mat Lm, MJ, Gc;      // Cholesky factor of M ; M^-1 J^T ; Cholesky factor of the damped Delassus matrix
@@ -105,10 +113,34 @@ namespace orc
       for (int f = 0; f < M->nfeet; f++)
         if ((mask >> f) & 1u)
           feet.push_back(f);
-      const int nc = 3 * (int)feet.size();
+      const int nc = fs * (int)feet.size();
       Jc = Mat(nc, nv);
       gamma.assign(nc, 0.0);
-      for (size_t c = 0; c < feet.size(); c++)
+      for (size_t c = 0; c < feet.size() && fs == 6; c++)
+      {
+        const int f = feet[c], j = M->foot_joint[f];
+        for (int k = 0; k < nv; k++)
+          if (R.is_ancestor_dof(k, j))
+          {
+            const V3 col = R.Jfoot_col(f, k);
+            for (int i = 0; i < 3; i++)
+            {
+              Jc(6 * (int)c + i, k) = col[i];
+              Jc(6 * (int)c + 3 + i, k) = R.S[k].a[i];
+            }
+          }
+        const V3 p = R.foot_p[f];
+        const V3 w = R.vel[j].a;
+        const V3 vp = R.vel[j].l + cross(w, p);
+        const V3 ap = R.acc[j].l + cross(R.acc[j].a, p) + cross(w, vp);
+        const V3 rot = log3(foot_R(f));
+        for (int i = 0; i < 3; i++)
+        {
+          gamma[6 * c + i] = ap[i] + Kd[i] * vp[i] + Kp[i] * p[i];
+          gamma[6 * c + 3 + i] = R.acc[j].a[i] + Kd[3 + i] * w[i] + Kp[3 + i] * rot[i];
+        }
+      }
+      for (size_t c = 0; c < feet.size() && fs == 3; c++)
       {
         const int f = feet[c], j = M->foot_joint[f];
         const M3 Rt = tr(foot_R(f));
@@ -187,7 +219,7 @@ namespace orc
     // needs compute(); v = the same velocity
     void derivatives(const double * v)
     {
-      const int nc = 3 * (int)feet.size();
+      const int nc = fs * (int)feet.size();
       const SV g{v3(gravity[0], gravity[1], gravity[2]), v3(0, 0, 0)};
       // body accelerations / forces at the solution, gravity included in the composite forces
       R.forces(v, a.data());
@@ -230,7 +262,59 @@ namespace orc
         }
       // residual partials
       Mat r1q = dtau_dq, r1v = dtau_dv, r2q(nc, nv), r2v(nc, nv);
-      for (size_t c = 0; c < feet.size(); c++)
+      for (size_t c = 0; c < feet.size() && fs == 6; c++)
+      {
+        const int f = feet[c], l = M->foot_joint[f];
+        const V3 p = R.foot_p[f];
+        const V3 fl = v3(lam[6 * c], lam[6 * c + 1], lam[6 * c + 2]), ft = v3(lam[6 * c + 3], lam[6 * c + 4], lam[6 * c + 5]);
+        const SV W{fl, cross(p, fl) + ft}; // the contact wrench as a spatial force at the world origin
+        const V3 w = R.vel[l].a;
+        const V3 vp = R.vel[l].l + cross(w, p);
+        const V3 ap = R.acc[l].l + cross(R.acc[l].a, p) + cross(w, vp); // at the solution
+        const V3 al = R.acc[l].a;
+        const V3 rotv = log3(foot_R(f));
+        // d log3(R) for a rotation increment expressed in the world frame: inverse left Jacobian = Jlog3(-phi)
+        const M3 Jl = Jlog3((-1.0) * rotv);
+        for (int k = 0; k < nv; k++)
+        {
+          const int i = R.dof2j[k];
+          if (!anc_or_eq(i, l))
+            continue;
+          const V3 vv = R.S[k].l + cross(R.S[k].a, p); // d(point position)/dq_k = d(point velocity)/dv_k
+          // - d(J^T lam)/dq_k: the wrench keeps its world axes, its point of application moves; the columns S_m below joint(k)
+          // (and the other base columns, for a base dof) move with S_k
+          const SV U{v3(0, 0, 0), cross(vv, fl)};
+          for (int m = 0; m < nv; m++)
+          {
+            const int jm = R.dof2j[m];
+            if (!anc_or_eq(jm, l))
+              continue;
+            double t = sv_dot(R.S[m], U);
+            const bool moves = (jm != i && anc_or_eq(i, jm)) || (jm == 0 && i == 0);
+            if (moves)
+              t -= sv_dot(R.S[m], crf(R.S[k], W));
+            r1q(m, k) -= t;
+          }
+          const SV & d = dk[k];
+          const int lam_ = M->parent[i];
+          const SV A = lam_ >= 0 ? crm(R.acc[lam_], R.S[k]) + crm(R.vel[lam_], d) + crm(d, R.vel[l]) : sv_zero();
+          const V3 aq = A.l + cross(A.a, p) + cross(d.a, vp) + cross(w, d.l + cross(d.a, p));
+          const SV Av = d + crm(R.S[k], R.vel[l] - R.vel[i]);
+          const V3 av = Av.l + cross(Av.a, p) + cross(R.S[k].a, vp) + cross(w, vv);
+          const V3 vq = d.l + cross(d.a, p);
+          const V3 sa = R.S[k].a;
+          const V3 lq = aq + cross(sa, ap), lvq = vq + cross(sa, vp);
+          const V3 aqq = A.a + cross(sa, al), wq = d.a + cross(sa, w), rq = Jl * sa;
+          for (int r = 0; r < 3; r++)
+          {
+            r2q(6 * (int)c + r, k) = lq[r] + Kd[r] * lvq[r] + Kp[r] * vv[r];
+            r2q(6 * (int)c + 3 + r, k) = aqq[r] + Kd[3 + r] * wq[r] + Kp[3 + r] * rq[r];
+            r2v(6 * (int)c + r, k) = av[r] + Kd[r] * vv[r];
+            r2v(6 * (int)c + 3 + r, k) = Av.a[r] + Kd[3 + r] * sa[r];
+          }
+        }
+      }
+      for (size_t c = 0; c < feet.size() && fs == 3; c++)
       {
         const int f = feet[c], l = M->foot_joint[f];
         const M3 Rf = foot_R(f), Rt = tr(Rf);

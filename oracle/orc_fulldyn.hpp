@@ -14,8 +14,13 @@
 //              joint box  qmin <= (x (-) neutral)[6 .. nv) <= qmax  (rows nu .. nu+nv-7) if kinematics_limits
 //              [REF src/fulldynamics.cpp:144-162]
 //   terminal   state_cost + 10 x centroidal_cost [REF src/fulldynamics.cpp:418-430]
-// force_cone / land_cstr rows [REF :164-211] and 6-D feet are not restated yet.
-// StageRef::u_ref carries [control reference (nu) ; force reference per foot (3 nf)] for this model.
+// 6-D feet (force_size 6, the Talos configuration of examples/talos_fulldynamics.py): <foot>_pose_cost is a FramePlacementResidual
+//   log6(M_ref^-1 oMf) with the LOCAL frame Jacobian [REF src/fulldynamics.cpp:103-109], the force cost is on the 6-D contact
+//   wrench, and with force_cone every foot in contact adds MultibodyWrenchConeResidual rows in the negative orthant
+//   [REF src/fulldynamics.cpp:163-173]: 17 linear rows A_cone lam (unilaterality, friction pyramid, centre of pressure inside
+//   the sole, yaw torque bounds; [UPSTREAM-RECALL] Aligator's wrench-cone matrix after Caron et al. 2015), rows after the boxes.
+// land_cstr rows [REF :175-209] and the friction cone of 3-D feet [REF :185-190] are not restated.
+// StageRef::u_ref carries [control reference (nu) ; force reference per foot (force_size nf)] for this model.
 #pragma once
 #include "orc_full.hpp"
 #include "orc_kino.hpp"
@@ -27,17 +32,36 @@ namespace orc
     double timestep = 0.01;
     Mat w_x, w_u, w_cent, w_forces, w_frame;
     double gravity[3] = {0, 0, -9.81};
-    double mu = 0.8;
-    bool torque_limits = true, kinematics_limits = true;
+    double mu = 0.8, Lfoot = 0.1, Wfoot = 0.075;
+    int force_size = 3;
+    bool torque_limits = true, kinematics_limits = true, force_cone = false;
     Vec umin, umax, qmin, qmax;
-    double Kp[3] = {0, 0, 0}, Kd[3] = {0, 0, 0};
+    double Kp[6] = {0, 0, 0, 0, 0, 0}, Kd[6] = {0, 0, 0, 0, 0, 0};
   };
+
+  // wrench cone of a rectangular sole (half length L, half width W, friction mu) on the contact wrench [f ; tau]: A lam <= 0
+  inline Mat wrench_cone_matrix(double mu, double L, double W)
+  {
+    const double m = mu * (L + W);
+    const double rows[17][6] = {
+      {0, 0, -1, 0, 0, 0},
+      {-1, 0, -mu, 0, 0, 0}, {1, 0, -mu, 0, 0, 0}, {0, -1, -mu, 0, 0, 0}, {0, 1, -mu, 0, 0, 0},
+      {0, 0, -W, -1, 0, 0}, {0, 0, -W, 1, 0, 0}, {0, 0, -L, 0, -1, 0}, {0, 0, -L, 0, 1, 0},
+      {W, L, -m, -mu, -mu, -1}, {W, -L, -m, -mu, mu, -1}, {-W, L, -m, mu, -mu, -1}, {-W, -L, -m, mu, mu, -1},
+      {W, L, -m, mu, mu, 1}, {W, -L, -m, mu, -mu, 1}, {-W, L, -m, -mu, mu, 1}, {-W, -L, -m, -mu, -mu, 1}};
+    Mat A(17, 6);
+    for (int i = 0; i < 17; i++)
+      for (int j = 0; j < 6; j++)
+        A(i, j) = rows[i][j];
+    return A;
+  }
 
   struct FullModel
   {
     const smpc_robot_model * M;
     FullSettings s;
-    int nq, nv, nx, ndx, nu, nf, nc;
+    int nq, nv, nx, ndx, nu, nf, nc, fs, ncone1;
+    Mat Acone;
 
     FullModel(const smpc_robot_model * m, const FullSettings & st) : M(m), s(st)
     {
@@ -47,31 +71,52 @@ namespace orc
       ndx = 2 * nv;
       nu = nv - 6;
       nf = m->nfeet;
-      nc = nu + (nv - 6);
+      fs = st.force_size;
+      ncone1 = (fs == 6 && st.force_cone) ? 17 : 0;
+      nc = nu + (nv - 6) + ncone1 * nf;
+      Acone = wrench_cone_matrix(st.mu, st.Lfoot, st.Wfoot);
     }
-    int row_kind(const StageRef &, int row) const
+    int row_kind(const StageRef & r, int row) const
     {
       if (row < nu)
         return s.torque_limits ? ROW_BOX : ROW_ABSENT;
-      return s.kinematics_limits ? ROW_BOX : ROW_ABSENT;
+      if (row < 2 * nu)
+        return s.kinematics_limits ? ROW_BOX : ROW_ABSENT;
+      return ((r.mask >> ((row - 2 * nu) / 17)) & 1u) ? ROW_NEG : ROW_ABSENT; // wrench cone of a foot in contact
     }
     double row_lo_v(int row) const { return row < nu ? s.umin[row] : s.qmin[row - nu]; }
     double row_hi_v(int row) const { return row < nu ? s.umax[row] : s.qmax[row - nu]; }
     void integrate(const double * x, const double * dx, double * out) const { x_integrate(nq, nv, x, dx, out); }
     void difference(const double * x0, const double * x1, double * out) const { x_difference(nq, nv, x0, x1, out); }
-    int force_ref_index(int f) const { return nu + 3 * f; }
-    int n_uref() const { return nu + 3 * nf; }
+    int force_ref_index(int f) const { return nu + fs * f; }
+    int n_uref() const { return nu + fs * nf; }
 
     ConstraintDynamics dynamics() const
     {
       ConstraintDynamics cd(M);
+      cd.fs = fs;
       for (int i = 0; i < 3; i++)
-      {
         cd.gravity[i] = s.gravity[i];
+      for (int i = 0; i < fs; i++)
+      {
         cd.Kp[i] = s.Kp[i];
         cd.Kd[i] = s.Kd[i];
       }
       return cd;
+    }
+    // <foot>_pose_cost residual: translation error (3-D feet) or log6(M_ref^-1 oMf), M_ref = (identity rotation, reference
+    // translation) as MPC::updateStepTrackerReferences sets it [REF src/mpc.cpp:304-308]
+    Vec pose_residual(const ConstraintDynamics & cd, const StageRef & r, int f) const
+    {
+      if (fs == 3)
+      {
+        const V3 e = cd.R.foot_p[f] - r.foot_ref[f];
+        return Vec{e[0], e[1], e[2]};
+      }
+      const SE3 Mref{m3_id(), r.foot_ref[f]}, Mf{cd.foot_R(f), cd.R.foot_p[f]};
+      Vec e(6);
+      log6(inv(Mref) * Mf, e.data());
+      return e;
     }
     static double quad(const Mat & W, const Vec & r) { return 0.5 * dot(r, mul(W, r)); }
 
@@ -101,20 +146,28 @@ namespace orc
       cost += quad(s.w_u, ru);
       cost += quad(s.w_cent, sv_vec(cd.R.hg()));
       for (int f = 0; f < nf; f++)
-      {
-        const V3 e = cd.R.foot_p[f] - r.foot_ref[f];
-        cost += quad(s.w_frame, Vec{e[0], e[1], e[2]});
-      }
+        cost += quad(s.w_frame, pose_residual(cd, r, f));
       for (size_t c = 0; c < cd.feet.size(); c++)
       {
         const int f = cd.feet[c];
-        Vec e(3);
-        for (int i = 0; i < 3; i++)
-          e[i] = cd.lam[3 * c + i] - r.u_ref[nu + 3 * f + i];
+        Vec e(fs);
+        for (int i = 0; i < fs; i++)
+          e[i] = cd.lam[fs * c + i] - r.u_ref[nu + fs * f + i];
         cost += quad(s.w_forces, e);
       }
       o.cost = cost;
       o.c.assign(nc, 0.0);
+      for (size_t c = 0; c < cd.feet.size() && ncone1 > 0; c++)
+      {
+        const int f = cd.feet[c];
+        for (int i = 0; i < 17; i++)
+        {
+          double acc = 0;
+          for (int j = 0; j < 6; j++)
+            acc += Acone(i, j) * cd.lam[6 * c + j];
+          o.c[2 * nu + 17 * f + i] = acc;
+        }
+      }
       if (s.torque_limits)
         for (int i = 0; i < nu; i++)
           o.c[i] = u[i];
@@ -236,37 +289,82 @@ namespace orc
         add_cost(s.w_cent, sv_vec(cd.R.hg()), Jx, nullptr);
       }
       for (int f = 0; f < nf; f++)
-      { // foot translation cost
-        Mat Jx(3, ndx);
-        for (int k = 0; k < nv; k++)
+      { // foot pose cost
+        Mat Jx(fs, ndx);
+        if (fs == 3)
         {
-          const V3 c = cd.R.Jfoot_col(f, k);
-          for (int i = 0; i < 3; i++)
-            Jx(i, k) = c[i];
+          for (int k = 0; k < nv; k++)
+          {
+            const V3 c = cd.R.Jfoot_col(f, k);
+            for (int i = 0; i < 3; i++)
+              Jx(i, k) = c[i];
+          }
         }
-        const V3 e = cd.R.foot_p[f] - r.foot_ref[f];
-        add_cost(s.w_frame, Vec{e[0], e[1], e[2]}, Jx, nullptr);
+        else
+        {
+          // FramePlacementResidual: Jlog6(M_ref^-1 oMf) * (LOCAL 6-D frame Jacobian)
+          const SE3 Mref{m3_id(), r.foot_ref[f]}, Mf{cd.foot_R(f), cd.R.foot_p[f]};
+          const Mat Jl = Jlog6(inv(Mref) * Mf);
+          const M3 Rt = tr(Mf.R);
+          Mat Jloc(6, nv);
+          for (int k = 0; k < nv; k++)
+            if (cd.R.is_ancestor_dof(k, M->foot_joint[f]))
+            {
+              const V3 lin = Rt * cd.R.Jfoot_col(f, k), ang = Rt * cd.R.S[k].a;
+              for (int i = 0; i < 3; i++)
+              {
+                Jloc(i, k) = lin[i];
+                Jloc(3 + i, k) = ang[i];
+              }
+            }
+          const Mat Jq = mul(Jl, Jloc);
+          for (int i = 0; i < 6; i++)
+            for (int k = 0; k < nv; k++)
+              Jx(i, k) = Jq(i, k);
+        }
+        add_cost(s.w_frame, pose_residual(cd, r, f), Jx, nullptr);
       }
       for (size_t c = 0; c < cd.feet.size(); c++)
       { // contact force cost
         const int f = cd.feet[c];
-        Vec e(3);
-        Mat Jx(3, ndx), Ju(3, nu);
-        for (int i = 0; i < 3; i++)
+        Vec e(fs);
+        Mat Jx(fs, ndx), Ju(fs, nu);
+        for (int i = 0; i < fs; i++)
         {
-          e[i] = cd.lam[3 * c + i] - r.u_ref[nu + 3 * f + i];
+          e[i] = cd.lam[fs * c + i] - r.u_ref[nu + fs * f + i];
           for (int k = 0; k < nv; k++)
           {
-            Jx(i, k) = cd.dlam_dq(3 * (int)c + i, k);
-            Jx(i, nv + k) = cd.dlam_dv(3 * (int)c + i, k);
+            Jx(i, k) = cd.dlam_dq(fs * (int)c + i, k);
+            Jx(i, nv + k) = cd.dlam_dv(fs * (int)c + i, k);
           }
           for (int k = 0; k < nu; k++)
-            Ju(i, k) = cd.dlam_dtau(3 * (int)c + i, k);
+            Ju(i, k) = cd.dlam_dtau(fs * (int)c + i, k);
         }
         add_cost(s.w_forces, e, Jx, &Ju);
       }
       o.Cx.resize(nc, ndx);
       o.Cu.resize(nc, nu);
+      for (size_t c = 0; c < cd.feet.size() && ncone1 > 0; c++)
+      { // wrench cone rows: A_cone * d lam / d(x, u)
+        const int f = cd.feet[c];
+        for (int i = 0; i < 17; i++)
+        {
+          const int row = 2 * nu + 17 * f + i;
+          for (int j = 0; j < 6; j++)
+          {
+            const double aij = Acone(i, j);
+            if (aij == 0.0)
+              continue;
+            for (int k = 0; k < nv; k++)
+            {
+              o.Cx(row, k) += aij * cd.dlam_dq(6 * (int)c + j, k);
+              o.Cx(row, nv + k) += aij * cd.dlam_dv(6 * (int)c + j, k);
+            }
+            for (int k = 0; k < nu; k++)
+              o.Cu(row, k) += aij * cd.dlam_dtau(6 * (int)c + j, k);
+          }
+        }
+      }
       if (s.torque_limits)
         for (int i = 0; i < nu; i++)
           o.Cu(i, i) = 1.0;

@@ -72,6 +72,8 @@ extern "C"
       return &SMPC_ROBOT_GO2_LIKE;
     if (!std::strcmp(name, "biped_like"))
       return &SMPC_ROBOT_BIPED_LIKE;
+    if (!std::strcmp(name, "talos_like"))
+      return &SMPC_ROBOT_TALOS_LIKE;
     return nullptr;
   }
   const char * smpc_last_error(void) { return g_err.c_str(); }

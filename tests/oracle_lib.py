@@ -69,12 +69,12 @@ def lib():
     L.orc_kino_deriv.argtypes = [vp, C.c_uint] + [_dp] * 14
     L.orc_kino_term.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
     L.orc_centroidal.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
-    L.orc_full_forward_dynamics.argtypes = [vp, _dp, _dp, C.c_uint, _dp, _dp] + [_dp] * 7
+    L.orc_full_forward_dynamics.argtypes = [vp, _dp, _dp, C.c_uint, C.c_int, _dp, _dp] + [_dp] * 7
     L.orc_full_forward_dynamics.restype = C.c_int
-    L.orc_full_dynamics_derivatives.argtypes = [vp, _dp, _dp, C.c_uint, _dp, _dp, C.c_double, C.c_int] + [_dp] * 10
+    L.orc_full_dynamics_derivatives.argtypes = [vp, _dp, _dp, C.c_uint, C.c_int, _dp, _dp, C.c_double, C.c_int] + [_dp] * 10
     L.orc_full_dynamics_derivatives.restype = C.c_int
     L.orc_full_rnea.argtypes = [vp, _dp, _dp, _dp]
-    L.orc_full_create.argtypes = [vp, C.c_double] + [_dp] * 12 + [C.c_int, C.c_int]
+    L.orc_full_create.argtypes = [vp, C.c_double] + [_dp] * 12 + [C.c_int] * 4 + [C.c_double] * 3
     L.orc_full_create.restype = vp
     L.orc_full_destroy.argtypes = [vp]
     L.orc_full_dims.argtypes = [vp, _ip]
@@ -186,23 +186,28 @@ class Robot:
         lib().orc_centroidal(self.ptr, np.ascontiguousarray(x, float), hg, Ag, dAgv, com, feet)
         return dict(hg=hg, Ag=Ag, dAgv=dAgv, com=com, feet=feet)
 
-    def full_forward_dynamics(self, x, tau, mask, Kp=(0, 0, 0), Kd=(0, 0, 0)):
-        """Constrained forward dynamics of the full-dynamics model (oracle/orc_full.hpp)."""
-        nv, nc = self.nv, 3 * bin(int(mask)).count("1")
+    def full_forward_dynamics(self, x, tau, mask, Kp=None, Kd=None, fs=3):
+        """Constrained forward dynamics of the full-dynamics model (oracle/orc_full.hpp); fs = contact size (3: LOCAL point
+        contacts, 6: LOCAL_WORLD_ALIGNED 6-D contacts)."""
+        Kp = np.zeros(fs) if Kp is None else Kp
+        Kd = np.zeros(fs) if Kd is None else Kd
+        nv, nc = self.nv, fs * bin(int(mask)).count("1")
         a, lam, M, nle = np.zeros(nv), np.zeros(max(nc, 1)), np.zeros((nv, nv)), np.zeros(nv)
         J, gamma, tau_rnea = np.zeros((max(nc, 1), nv)), np.zeros(max(nc, 1)), np.zeros(nv)
-        it = lib().orc_full_forward_dynamics(self.ptr, np.ascontiguousarray(x, float), np.ascontiguousarray(tau, float), int(mask),
+        it = lib().orc_full_forward_dynamics(self.ptr, np.ascontiguousarray(x, float), np.ascontiguousarray(tau, float), int(mask), int(fs),
                                              np.ascontiguousarray(Kp, float), np.ascontiguousarray(Kd, float), a, lam, M, nle,
                                              J, gamma, tau_rnea)
         return dict(a=a, lam=lam[:nc], M=M, nle=nle, J=J[:nc], gamma=gamma[:nc], tau_rnea=tau_rnea, prox_iters=it)
 
-    def full_dynamics_derivatives(self, x, tau, mask, Kp=(0, 0, 0), Kd=(0, 0, 0), prox_accuracy=0.0, prox_max_iter=0):
-        nv, nu, nc = self.nv, self.nv - 6, 3 * bin(int(mask)).count("1")
+    def full_dynamics_derivatives(self, x, tau, mask, Kp=None, Kd=None, prox_accuracy=0.0, prox_max_iter=0, fs=3):
+        Kp = np.zeros(fs) if Kp is None else Kp
+        Kd = np.zeros(fs) if Kd is None else Kd
+        nv, nu, nc = self.nv, self.nv - 6, fs * bin(int(mask)).count("1")
         n1 = max(nc, 1)
         o = dict(a=np.zeros(nv), lam=np.zeros(n1), da_dq=np.zeros((nv, nv)), da_dv=np.zeros((nv, nv)), da_dtau=np.zeros((nv, nu)),
                  dlam_dq=np.zeros((n1, nv)), dlam_dv=np.zeros((n1, nv)), dlam_dtau=np.zeros((n1, nu)),
                  dtau_dq=np.zeros((nv, nv)), dtau_dv=np.zeros((nv, nv)))
-        it = lib().orc_full_dynamics_derivatives(self.ptr, np.ascontiguousarray(x, float), np.ascontiguousarray(tau, float), int(mask),
+        it = lib().orc_full_dynamics_derivatives(self.ptr, np.ascontiguousarray(x, float), np.ascontiguousarray(tau, float), int(mask), int(fs),
                                                  np.ascontiguousarray(Kp, float), np.ascontiguousarray(Kd, float),
                                                  float(prox_accuracy), int(prox_max_iter), *o.values())
         for k in ("lam", "dlam_dq", "dlam_dv", "dlam_dtau"):
@@ -334,7 +339,9 @@ class Full:
         c = lambda a: np.ascontiguousarray(a, float)
         self.h = L.orc_full_create(robot.ptr, s["timestep"], c(s["w_x"]), c(s["w_u"]), c(s["w_cent"]), c(s["w_forces"]),
                                    c(s["w_frame"]), c(s["gravity"]), c(s["Kp_correction"]), c(s["Kd_correction"]), c(s["umin"]),
-                                   c(s["umax"]), c(s["qmin"]), c(s["qmax"]), int(s["torque_limits"]), int(s["kinematics_limits"]))
+                                   c(s["umax"]), c(s["qmin"]), c(s["qmax"]), int(s["torque_limits"]), int(s["kinematics_limits"]),
+                                   int(s.get("force_size", 3)), int(s.get("force_cone", False)), float(s.get("mu", 0.8)),
+                                   float(s.get("Lfoot", 0.1)), float(s.get("Wfoot", 0.075)))
         d = np.zeros(5, np.int32)
         L.orc_full_dims(self.h, d)
         self.nx, self.ndx, self.nu, self.nc, self.nf = (int(v) for v in d)
@@ -361,6 +368,31 @@ class Full:
         trace, xs, us = np.zeros((max_iter, 6)), np.zeros((H + 1, self.nx)), np.zeros((H, self.nu))
         it = lib().orc_full_solve(self.h, H, mk, c(u_ref), c(x_tgt), c(foot_ref), c(x0), c(u0), max_iter, tol, mu, trace, xs, us)
         return dict(iters=it, trace=trace[:it], xs=xs, us=us)
+
+
+def talos_full_settings(robot):
+    """FullDynamicsSettings of the Talos example: reference examples/talos_fulldynamics.py:47-115 (6-D feet, wrench cones).  The
+    robot table holds no effort limits: Talos-like actuator limits are used (legs 100/160/160/300/160/100, torso 200, arms
+    44/44/22/22 N m)."""
+    w_x = np.diag(np.array([0, 0, 0, 10, 10, 10] + [0.1] * 6 * 2 + [1, 100] + [1, 1, 10, 10] * 2 + [10] * 6 + [1] * 6 * 2 + [1, 100]
+                           + [10] * 4 * 2, float))
+    eff = np.array([100, 160, 160, 300, 160, 100] * 2 + [200, 200] + [44, 44, 22, 22] * 2, float)
+    nu = robot.nv - 6
+    return dict(timestep=0.01, w_x=w_x, w_u=np.eye(nu) * 1e-4, w_cent=np.diag([0.1, 0.1, 10, 0.1, 0.1, 10.0]), w_forces=np.eye(6) * 1e-3,
+                w_frame=np.eye(6) * 2000.0, gravity=np.array([0, 0, -9.81]), force_size=6, Kp_correction=np.array([0, 0, 50, 0, 0, 0.0]),
+                Kd_correction=np.ones(6) * 100.0, umin=-eff, umax=eff, qmin=robot.q_lo.copy(), qmax=robot.q_hi.copy(), mu=0.8, Lfoot=0.1,
+                Wfoot=0.075, torque_limits=True, kinematics_limits=True, force_cone=True, land_cstr=False)
+
+
+def talos_mpc_settings(robot, max_iters=1, num_threads=0):
+    """MPC settings of the Talos example: reference examples/talos_fulldynamics.py:101-113 (T = 100, T_fly 80, T_contact 20)."""
+    return dict(support_force=robot.mass * 9.81, TOL=1e-4, mu_init=1e-8, max_iters=max_iters, num_threads=num_threads, swing_apex=0.15,
+                T_fly=80, T_contact=20, timestep=0.01, T=100)
+
+
+def walk_cycle(T_ds=20, T_ss=80):
+    """Biped contact cycle of reference examples/talos_fulldynamics.py:117-136, order left, right."""
+    return np.array([[1, 1]] * T_ds + [[1, 0]] * T_ss + [[1, 1]] * T_ds + [[0, 1]] * T_ss, np.uint8)
 
 
 def riccati(Q, S, R, q, r, A, B, f, Cm, D, d, QN, qN, mu):

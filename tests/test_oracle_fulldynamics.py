@@ -295,3 +295,133 @@ def test_full_dynamics_mpc_closed_loop(rb, full):
     # the swing phase has started (feet leave the ground in the predicted horizon) and the base moves forward
     assert xs[0, -1, 0] > xs[0, 0, 0] + 0.01
     assert np.abs(X[:, 2] - rb.x_ref[2]).max() < 0.05
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Talos-class robot: 6-D feet, LOCAL_WORLD_ALIGNED contacts, wrench cones (reference src/fulldynamics.cpp:56-65, 103-109,
+# 163-173; settings examples/talos_fulldynamics.py:47-115; robot tests/test_utils.cpp:26-62: nq 29 / nv 28)
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tb():
+    return O.Robot("talos_like")
+
+
+@pytest.fixture(scope="module")
+def tfull(tb):
+    return O.Full(tb, O.talos_full_settings(tb))
+
+
+def _trand(tb, rng, scale=1.0):
+    sg = np.concatenate([np.ones(3) * 0.02, np.ones(3) * 0.05, np.ones(tb.nv - 6) * 0.1, np.ones(3) * 0.1, np.ones(3) * 0.2, np.ones(tb.nv - 6) * 0.5])
+    return tb.integrate(tb.x_ref, rng.normal(size=tb.ndx) * sg * scale)
+
+
+def test_talos_table_has_the_reduced_model_dimensions(tb):
+    assert (tb.nq, tb.nv, tb.nf) == (29, 28, 2)  # tests/test_utils.cpp:26-62 (22 actuated joints), benchmark/talos.cpp:95-107
+    feet = tb.centroidal(tb.x_ref)["feet"]
+    assert np.abs(feet[:, 2]).max() < 1e-12 and abs(feet[0, 1] + feet[1, 1]) < 1e-12  # soles on the ground, symmetric
+
+
+@pytest.mark.parametrize("mask", [0b11, 0b01, 0b10])
+def test_6d_contact_dynamics_and_derivatives(tb, mask):
+    rng = np.random.default_rng(100 + mask)
+    Kp, Kd = np.array([0, 0, 50, 0, 0, 7.0]), np.array([100, 100, 100, 100, 90, 80.0])
+    x, tau = _trand(tb, rng), rng.normal(size=tb.nv - 6) * 20
+    r = tb.full_forward_dynamics(x, tau, mask, Kp, Kd, fs=6)
+    nc = 6 * bin(mask).count("1")
+    assert r["lam"].shape == (nc,)
+    assert np.abs(r["J"] @ r["a"] + r["gamma"]).max() < 1e-9               # contact acceleration = corrector
+    lhs = r["M"] @ r["a"] + r["nle"]
+    rhs = np.concatenate([np.zeros(6), tau]) + r["J"].T @ r["lam"]
+    assert np.abs(lhs - rhs).max() < 1e-9 * max(1.0, np.abs(rhs).max())     # equations of motion
+    assert np.abs(r["tau_rnea"] - rhs).max() < 1e-8 * max(1.0, np.abs(rhs).max())
+    d = tb.full_dynamics_derivatives(x, tau, mask, Kp, Kd, prox_accuracy=1e-14, prox_max_iter=50, fs=6)
+    h = 1e-6
+
+    def sol(xx, tt):
+        rr = tb.full_dynamics_derivatives(xx, tt, mask, Kp, Kd, 1e-14, 50, fs=6)
+        return np.concatenate([rr["a"], rr["lam"]])
+
+    for name, n, off in (("q", tb.nv, 0), ("v", tb.nv, tb.nv)):
+        F = np.zeros((tb.nv + nc, n))
+        for k in range(n):
+            dd = np.zeros(tb.ndx)
+            dd[off + k] = h
+            F[:, k] = (sol(tb.integrate(x, dd), tau) - sol(tb.integrate(x, -dd), tau)) / (2 * h)
+        An = np.vstack([d["da_d" + name], d["dlam_d" + name]])
+        assert np.abs(An - F).max() < 1e-6 * max(1.0, np.abs(F).max()), name
+    F = np.zeros((tb.nv + nc, tb.nv - 6))
+    for k in range(tb.nv - 6):
+        dd = np.zeros(tb.nv - 6)
+        dd[k] = h
+        F[:, k] = (sol(x, tau + dd) - sol(x, tau - dd)) / (2 * h)
+    assert np.abs(np.vstack([d["da_dtau"], d["dlam_dtau"]]) - F).max() < 1e-6 * max(1.0, np.abs(F).max())
+
+
+def test_talos_stage_structure_matches_the_reference_counts(tb, tfull):
+    # tests/problem.cpp:14-49: Talos stage, left foot in contact, force_cone on, land_cstr off: 6 cost components, 3 constraint
+    # blocks = torque box (22) + joint box (22) + the wrench cone of the foot in contact (17)
+    assert (tfull.nx, tfull.ndx, tfull.nu, tfull.nc) == (57, 56, 22, 22 + 22 + 2 * 17)
+    fref = np.concatenate([[0, 0, 800.0, 0, 0, 0], np.zeros(6)])
+    u_ref = np.concatenate([np.zeros(22), fref])
+    feet = tb.centroidal(tb.x_ref)["feet"]
+    e = tfull.eval(0b01, u_ref, tb.x_ref, feet, tb.x_ref, np.zeros(22))
+    c = e["c"]
+    assert np.all(c[44 + 17 :] == 0.0) and np.abs(c[44 : 44 + 17]).max() > 0  # only the left foot's cone block is present
+
+
+@pytest.mark.parametrize("mask", [0b11, 0b01])
+def test_talos_stage_derivatives_against_finite_differences(tb, tfull, mask):
+    rng = np.random.default_rng(200 + mask)
+    full, rb = tfull, tb
+    x = _trand(tb, rng, 0.4)
+    u = rng.normal(size=full.nu) * 10
+    fref = np.tile([0.0, 0.0, rb.mass * 9.81 / 2, 0, 0, 0], 2)
+    u_ref = np.concatenate([np.zeros(full.nu), fref])
+    feet = rb.centroidal(rb.x_ref)["feet"] + rng.normal(size=(2, 3)) * 0.02
+    d = full.deriv(mask, u_ref, rb.x_ref, feet, x, u)
+    e0 = full.eval(mask, u_ref, rb.x_ref, feet, x, u)
+    h = 1e-6
+    n, m, k_ = full.ndx, full.nu, full.nc
+    A, B, lx, lu, Cx, Cu = np.zeros((n, n)), np.zeros((n, m)), np.zeros(n), np.zeros(m), np.zeros((k_, n)), np.zeros((k_, m))
+    for k in range(n):
+        dd = np.zeros(n)
+        dd[k] = h
+        ep, em = (full.eval(mask, u_ref, rb.x_ref, feet, rb.integrate(x, s * dd), u) for s in (1, -1))
+        A[:, k] = (rb.difference(e0["xnext"], ep["xnext"]) - rb.difference(e0["xnext"], em["xnext"])) / (2 * h)
+        lx[k] = (ep["cost"] - em["cost"]) / (2 * h)
+        Cx[:, k] = (ep["c"] - em["c"]) / (2 * h)
+    for k in range(m):
+        dd = np.zeros(m)
+        dd[k] = h
+        ep, em = (full.eval(mask, u_ref, rb.x_ref, feet, x, u + s * dd) for s in (1, -1))
+        B[:, k] = (rb.difference(e0["xnext"], ep["xnext"]) - rb.difference(e0["xnext"], em["xnext"])) / (2 * h)
+        lu[k] = (ep["cost"] - em["cost"]) / (2 * h)
+        Cu[:, k] = (ep["c"] - em["c"]) / (2 * h)
+    for nm, an, nu_ in (("A", d["A"], A), ("B", d["B"], B), ("lx", d["lx"], lx), ("lu", d["lu"], lu), ("Cx", d["Cx"], Cx), ("Cu", d["Cu"], Cu)):
+        assert np.abs(an - nu_).max() < 5e-6 * max(1.0, np.abs(nu_).max()), (nm, np.abs(an - nu_).max(), np.abs(nu_).max())
+    Hm = np.block([[d["Lxx"], d["Lxu"]], [d["Lxu"].T, d["Luu"]]])
+    assert np.abs(Hm - Hm.T).max() < 1e-9 * np.abs(Hm).max() and np.linalg.eigvalsh(Hm).min() > -1e-9 * np.abs(Hm).max()
+
+
+def test_talos_mpc_closed_loop(tb, tfull):
+    """MPC state machine over the Talos full-dynamics OCP (H = 30 here): cold solve, walking cycle, closed loop on its own
+    prediction: finite, feasible, torques inside their box, cone rows respected within the penalty accuracy."""
+    ms = O.talos_mpc_settings(tb, max_iters=2)
+    ms["T"] = 30
+    ms["T_fly"], ms["T_contact"] = 20, 5
+    mpc = O.OracleFullMPC(tfull, ms, 2)
+    tr = mpc.cold_trace()
+    assert len(tr) < 100 and np.all(np.isfinite(tr))
+    mpc.generateCycleHorizon(O.walk_cycle(5, 20))
+    mpc.switchToWalk(np.array([0.1, 0, 0, 0, 0, 0.0]))
+    X = np.tile(tb.x_ref, (2, 1))
+    rng = np.random.default_rng(5)
+    X[1] = _trand(tb, rng, 0.1)
+    for step in range(20):
+        mpc.iterate(X)
+        xs, us = mpc.xs, mpc.us
+        assert np.all(np.isfinite(xs)) and np.all(np.isfinite(us))
+        X = xs[:, 1].copy()
+    assert np.all(np.abs(us) <= tfull.s["umax"] + 1e-2)
+    assert np.abs(X[:, 2] - tb.x_ref[2]).max() < 0.08

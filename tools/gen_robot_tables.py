@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate include/smpc_robots_builtin.h: the built-in robot tables ("go2_like", "biped_like").
+"""Generate include/smpc_robots_builtin.h: the built-in robot tables ("go2_like", "biped_like", "talos_like").
 
 The reference loads Go2/Talos URDFs from example-robot-data (reference:
 examples/go2_kinodynamics.py:17-27, tests/test_utils.cpp:14-97), which is not available here
@@ -144,6 +144,40 @@ def biped_like():
     return r
 
 
+def talos_like():
+    """Talos-like reduced humanoid: free-flyer + 2 x 6 leg joints + 2 torso joints + 2 x 4 arm joints (nq 29, nv 28), two 6-D
+    feet -- the joint list the reference keeps when it builds its reduced Talos (tests/test_utils.cpp:26-62, examples/utils.py:
+    14-25): legs 1-6, torso 1-2, arms 1-4, everything else locked at half_sitting and merged into the parent body.  Link
+    parameters are Talos-like values entered by hand (the URDF is not available here); total mass about 91 kg."""
+    r = Robot("talos_like")
+    b = lambda m, c, d: (m, c, inertia_mat(d[0], 0, 0, d[1], 0, d[2]))
+    r.add_joint(-1, 0, [0, 0, 0], (15.0, [-0.05, 0.0, -0.02], inertia_mat(0.2, 0.0, 0.01, 0.1, 0.0, 0.2)))
+    for nm, sy in (("left", 1), ("right", -1)):
+        j1 = r.add_joint(0, 3, [-0.02, 0.085 * sy, -0.27], b(1.9, [0.02, 0.0, 0.03], (0.004, 0.006, 0.004)), -0.35, 1.57)
+        j2 = r.add_joint(j1, 1, [0, 0, 0], b(2.0, [-0.01, 0.0, 0.0], (0.004, 0.004, 0.003)), -0.52, 0.52)
+        j3 = r.add_joint(j2, 2, [0, 0, 0], b(6.2, [0.0, 0.02 * sy, -0.15], (0.12, 0.11, 0.02)), -2.1, 0.7)
+        j4 = r.add_joint(j3, 2, [0, 0, -0.38], b(3.8, [0.01, 0.0, -0.14], (0.06, 0.06, 0.008)), 0.0, 2.62)
+        j5 = r.add_joint(j4, 2, [0, 0, -0.325], b(1.3, [-0.01, 0.0, 0.01], (0.003, 0.004, 0.003)), -1.27, 0.68)
+        j6 = r.add_joint(j5, 1, [0, 0, 0], b(1.6, [-0.0, 0.0, -0.08], (0.004, 0.008, 0.009)), -0.52, 0.52)
+        r.feet.append((nm + "_sole_link", j6, [0.0, 0.0, -0.107]))
+    t1 = r.add_joint(0, 3, [0.0, 0.0, 0.0722], b(3.0, [0.0, 0.0, 0.05], (0.008, 0.008, 0.006)), -1.26, 1.26)
+    # torso_2 carries the chest, the head and nothing else (the arms hang below it)
+    t2 = r.add_joint(t1, 2, [0.0, 0.0, 0.0], (18.0, [-0.04, 0.0, 0.2], inertia_mat(0.45, 0.0, 0.02, 0.35, 0.0, 0.25)), -0.23, 0.73)
+    for nm, sy in (("left", 1), ("right", -1)):
+        a1 = r.add_joint(t2, 3, [0.0, 0.1575 * sy, 0.232], b(2.7, [-0.01, 0.04 * sy, -0.02], (0.012, 0.004, 0.011)), -1.57 if sy > 0 else -0.79, 0.79 if sy > 0 else 1.57)
+        a2 = r.add_joint(a1, 1, [0.00493, 0.1365 * sy, 0.04673], b(2.4, [0.02, 0.0, -0.03], (0.004, 0.006, 0.004)), 0.0 if sy > 0 else -2.87, 2.87 if sy > 0 else 0.0)
+        a3 = r.add_joint(a2, 3, [0.0, 0.0, 0.0], b(2.2, [0.0, 0.0, -0.12], (0.02, 0.02, 0.003)), -2.43, 2.43)
+        # arm_4 carries the forearm, the wrist and the hand (locked joints merged)
+        a4 = r.add_joint(a3, 2, [0.02, 0.0, -0.273], b(3.5, [0.0, 0.0, -0.15], (0.04, 0.04, 0.004)), -2.23, 0.0)
+    leg = [0.0, 0.0, -0.4, 0.8, -0.4, 0.0]
+    arm_l, arm_r = [0.25, 0.17, 0.0, -0.5], [-0.25, -0.17, 0.0, -0.5]
+    r.q_ref = [0, 0, 1.0, 0, 0, 0, 1] + leg + leg + [0.0, 0.006] + arm_l + arm_r  # "half_sitting"
+    R, p = r.fk(r.q_ref)
+    zf = (p[r.feet[0][1]] + R[r.feet[0][1]] @ np.asarray(r.feet[0][2]))[2]
+    r.q_ref[2] -= zf
+    return r
+
+
 def fmt(v):
     return ", ".join(repr(float(x)) for x in np.asarray(v, float).ravel())
 
@@ -193,6 +227,8 @@ def main():
     out.append(emit(go2_like(), "SMPC_ROBOT_GO2_LIKE"))
     out.append("")
     out.append(emit(biped_like(), "SMPC_ROBOT_BIPED_LIKE"))
+    out.append("")
+    out.append(emit(talos_like(), "SMPC_ROBOT_TALOS_LIKE"))
     out.append("")
     out.append("#endif")
     with open(OUT, "w") as f:
