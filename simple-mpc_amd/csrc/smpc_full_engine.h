@@ -294,10 +294,16 @@ namespace smpc
     }
     void launch_sweeps(const Buffers<D> & b)
     {
-      if (valu_riccati)
-        timed_launch<SolverArgs<D>, riccati_full_body<D, 256>, 256>(KID_RICCATI, b.B, solver_args(b)); // cross-check
-      else
-        timed_launch<SolverArgs<D>, riccati_dense_body<D>, 64, 2>(KID_RICCATI, b.B, solver_args(b));
+      if constexpr (D::NCONE == 0)
+      {
+        if (valu_riccati)
+        {
+          timed_launch<SolverArgs<D>, riccati_full_body<D, 256>, 256>(KID_RICCATI, b.B, solver_args(b)); // cross-check (box rows only)
+          timed_launch<SolverArgs<D>, forward_full_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
+          return;
+        }
+      }
+      timed_launch<SolverArgs<D>, riccati_dense_body<D>, 64, (RiccatiDenseGeom<D>::NT2 > 6 ? 1 : 2)>(KID_RICCATI, b.B, solver_args(b));
       timed_launch<SolverArgs<D>, forward_full_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
     }
     int launch_backtracking(const Buffers<D> & b)

@@ -29,6 +29,7 @@ namespace smpc
     static constexpr int NDX = 2 * NV;
     static constexpr int NA = NV - 6;
     static constexpr int NU = NA;
+    static constexpr int PF = FS_;                            // size of a foot-pose residual: translation (3) or log6 placement (6)
     static constexpr int NCM = FS_ * NF_;                     // contact rows when every foot is in contact
     static constexpr int NCONE1 = FS_ == 6 ? 17 : 0;          // cone rows per foot (wrench cone, 6-D feet)
     static constexpr int NCONE = NCONE1 * NF_;

@@ -186,7 +186,6 @@ namespace smpc
   {
     constexpr int NT = 64;
     constexpr int NDX = D::NDX, NU = D::NU, NC = D::NC, NA = D::NA;
-    static_assert(D::NCONE == 0, "dense cone rows: Z feedback of the matrix-core sweep");
     const Buffers<D> & b = ka.b;
     const int H = b.H, R = b.R;
     const int inst = block;
@@ -233,6 +232,17 @@ namespace smpc
           const double d = lq[D::O_d + r], act = lq[D::O_act + r];
           const double lin = r < NU ? du[r] : dx[6 + r - NU];
           const double dnu = (act * lin + d) / mu;
+          b.dvs[lt * NC + r] = dnu;
+          part[lane] += lq[D::O_vpd + r] * (mu * dnu - d) - d * dnu;
+        }
+        // dense rows (wrench cones): dnu = Z dx + z from the explicitly pivoted multipliers
+        for (int r = NU + NA + lane; r < NC; r += NT)
+        {
+          const double * Zr = g + D::G_Z + (r - NU - NA) * (NDX + 1);
+          double dnu = Zr[NDX];
+          for (int j = 0; j < NDX; j++)
+            dnu += Zr[j] * dx[j];
+          const double d = lq[D::O_d + r];
           b.dvs[lt * NC + r] = dnu;
           part[lane] += lq[D::O_vpd + r] * (mu * dnu - d) - d * dnu;
         }

@@ -40,7 +40,7 @@ namespace smpc
     static constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX, NX = D::NX, NC = D::NC;
     static constexpr int NR = NCM + 1;           // columns of W = [M^-1 b | M^-1 J^T]
     static constexpr int NCOL = 2 * NV + NU;     // derivative columns (q | v | tau)
-    static constexpr int NGN = 6 + 3 * NF + NCM; // rows of the stacked Gauss-Newton Jacobian: momentum | foot positions | forces
+    static constexpr int NGN = 6 + D::PF * NF + NCM; // rows of the stacked Gauss-Newton Jacobian: forces | momentum | foot poses
     FullHead<D> h;
     // block inputs
     double x[NX], u[NU], xn1[NX], x_tgt[NX], u_ref[NU], f_ref[NCM], foot_ref[NF * 3];
@@ -59,7 +59,8 @@ namespace smpc
     double a[NV];
     double xnext[NX], e[NDX];
     // costs / constraints / multipliers
-    double rx[NDX], Wrx[NDX], ru[NU], Wru[NU], Whg[6], rf[NF * 3], Wrf[NF * 3], rl[NCM], Wrl[NCM];
+    double rx[NDX], Wrx[NDX], ru[NU], Wru[NU], Whg[6], rf[NF * D::PF], Wrf[NF * D::PF], rl[NCM], Wrl[NCM];
+    double rotl[NF * 3]; // log3 of the foot rotations (6-D contacts: angular part of the corrector)
     double cval[NC], vplus[NC], lamp[NDX];
     int act[NC + NC % 2];
     double part[64], part2[64], part8[16], red[4];
@@ -69,13 +70,15 @@ namespace smpc
   struct FullScratchDeriv
   {
     static constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX;
-    static constexpr int NCOL = 2 * NV + NU, NGN = 6 + 3 * NF + NCM;
+    static constexpr int NCOL = 2 * NV + NU, NGN = 6 + D::PF * NF + NCM;
     double Bc[NJ * 36], dk[NV * 6], Ak[NV * 6], Fgc[NJ * 6], Wc[NF * 6];
     double R1[NV * NCOL];       // [r1q | r1v | r1t] -> M^-1 R1 -> [da_dq | da_dv | da_dtau]
     double JT[NGN * NCOL];      // stacked Gauss-Newton Jacobian; rows 0..NCM-1: [r2q | r2v | 0] -> [dlam_dq | dlam_dv | dlam_dtau]
     double Ag[6 * NV];
     double Je3[9], JeQ[9], Jq[36], Jl[36], WJl[NDX * 6], JWJ[36];
     double gx[NDX], gu[NU]; // cost gradients
+    double Jlf[NF * 36];    // Jlog6 of the foot-placement residuals (6-D feet)
+    double yc[NCM + 1], cq[NDX + NU]; // cone rows: A_cone^T nu per contact, and its image (C_x^T nu ; C_u^T nu)
     double dual[128];
   };
 
@@ -189,7 +192,6 @@ namespace smpc
     constexpr int NT = 64;
     constexpr int NJ = D::NJ, NV = D::NV, NQ = D::NQ, NF = D::NF, NCM = D::NCM, NR = SC::NR, FS = D::FS;
     static_assert(NJ <= NT && NV <= NT && NR <= NT, "one joint / dof / right-hand side per lane");
-    static_assert(FS == 3, "6-D contacts: LOCAL_WORLD_ALIGNED rows are added with the Talos table");
     const FullHead<D> & h = sc.h;
     const int nlev = h.nlevels;
     const double * vq = &sc.x[NQ];
@@ -391,7 +393,54 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
-    // ---- contact rows (feet in contact first, in order): LOCAL linear Jacobian of the foot point, drift + corrector ----
+    // ---- contact rows (feet in contact first, in order) ----
+    if constexpr (FS == 6)
+    {
+      // CONTACT_6D, LOCAL_WORLD_ALIGNED (src/fulldynamics.cpp:56-65): rows [linear ; angular] in world axes at the foot point
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NF * NV; idx += NT)
+        {
+          const int f = idx / NV, k = idx % NV;
+          const int jf = h.foot_joint[f], jk = jof(k);
+          if (((mask >> f) & 1u) && ((h.anc[jf] >> jk) & 1u))
+          {
+            const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+            const SV Sk = ldsv(&sc.S[k * 6]);
+            const V3 col = Sk.l + cross(Sk.a, ld3(&sc.footp[f * 3]));
+            sc.J[(6 * c + 0) * NV + k] = col.x;
+            sc.J[(6 * c + 1) * NV + k] = col.y;
+            sc.J[(6 * c + 2) * NV + k] = col.z;
+            sc.J[(6 * c + 3) * NV + k] = Sk.a.x;
+            sc.J[(6 * c + 4) * NV + k] = Sk.a.y;
+            sc.J[(6 * c + 5) * NV + k] = Sk.a.z;
+          }
+        }
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      if (lane < NF && ((mask >> lane) & 1u))
+      {
+        const int f = lane, jf = h.foot_joint[f];
+        const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+        const V3 p = ld3(&sc.footp[f * 3]);
+        const SV v = ldsv(&sc.vel[jf * 6]), ab = ldsv(&sc.acc[jf * 6]);
+        const V3 vp = v.l + cross(v.a, p);
+        const V3 ap = ab.l + cross(ab.a, p) + cross(v.a, vp);
+        const V3 rot = log3(ldm3(&sc.oR[jf * 9]));
+        st3(&sc.rotl[f * 3], rot);
+        sc.gam[6 * c + 0] = ap.x + h.Kd[0] * vp.x + h.Kp[0] * p.x;
+        sc.gam[6 * c + 1] = ap.y + h.Kd[1] * vp.y + h.Kp[1] * p.y;
+        sc.gam[6 * c + 2] = ap.z + h.Kd[2] * vp.z + h.Kp[2] * p.z;
+        sc.gam[6 * c + 3] = ab.a.x + h.Kd[3] * v.a.x + h.Kp[3] * rot.x;
+        sc.gam[6 * c + 4] = ab.a.y + h.Kd[4] * v.a.y + h.Kp[4] * rot.y;
+        sc.gam[6 * c + 5] = ab.a.z + h.Kd[5] * v.a.z + h.Kp[5] * rot.z;
+      }
+      SMPC_LANES_END_WAVE
+    }
+    else
+    {
+    // CONTACT_3D, LOCAL (src/fulldynamics.cpp:66-74): LOCAL linear Jacobian of the foot point, drift + corrector
     SMPC_LANES(NT)
     {
       for (int idx = lane; idx < NF * NV; idx += NT)
@@ -427,6 +476,7 @@ namespace smpc
       sc.gam[3 * c + 2] = drift.z + h.Kd[2] * verr.z - h.Kp[2] * perr.z;
     }
     SMPC_LANES_END_WAVE
+    }
     ftick(fp, 3);
     // ---- M = L L^T ; W = M^-1 [S tau - nle | J^T] ----
     fwave_cholesky<NT, NV>(sc.M, sc.tmp);
@@ -507,6 +557,45 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     ftick(fp, 6);
+  }
+
+  // entry (i, j) of the 17 x 6 wrench-cone matrix of a rectangular sole (half length L, half width W, friction mu) acting on the
+  // contact wrench [f ; tau]:  A lam <= 0  (MultibodyWrenchConeResidual, reference src/fulldynamics.cpp:167-172; rows: unilateral
+  // force, friction pyramid (4), centre of pressure inside the sole (4), yaw-torque bounds (8))
+  SMPC_HD double wrench_cone_entry(int i, int j, double mu, double L, double W)
+  {
+    if (i == 0)
+      return j == 2 ? -1.0 : 0.0;
+    if (i < 5)
+    {
+      const int a = (i - 1) / 2;                 // 0: x, 1: y
+      const double sgn = ((i - 1) % 2) ? 1.0 : -1.0;
+      return j == a ? sgn : (j == 2 ? -mu : 0.0);
+    }
+    if (i < 9)
+    {
+      const int a = (i - 5) / 2;                 // 0: tau_x with W, 1: tau_y with L
+      const double sgn = ((i - 5) % 2) ? 1.0 : -1.0;
+      return j == 3 + a ? sgn : (j == 2 ? (a == 0 ? -W : -L) : 0.0);
+    }
+    const int q = i - 9, hi = q / 4, r = q % 4; // r: signs of (W, L) = (+,+) (+,-) (-,+) (-,-)
+    const double sw = (r < 2) ? 1.0 : -1.0, sl = (r % 2 == 0) ? 1.0 : -1.0;
+    const double st = hi ? 1.0 : -1.0;           // sign of the tau_z entry; the tau_x / tau_y entries are st * mu * (sw, sl)
+    switch (j)
+    {
+    case 0:
+      return sw * W;
+    case 1:
+      return sl * L;
+    case 2:
+      return -mu * (L + W);
+    case 3:
+      return st * sw * mu;
+    case 4:
+      return st * sl * mu;
+    default:
+      return st;
+    }
   }
 
   // SE(3) work of a stage on two lanes: lane 0 integrates the base (x+ and, with derivatives, Jexp6(nu) and the action matrix
@@ -640,8 +729,53 @@ namespace smpc
         }
         for (int i = lane; i < NA; i += NT)
           sc.cval[NU + i] = h.kinematics_limits ? sc.x[7 + i] : 0.0;
-        for (int i = lane; i < NF * 3; i += NT)
-          sc.rf[i] = sc.footp[i] - sc.foot_ref[i];
+        if constexpr (FS == 3)
+        {
+          for (int i = lane; i < NF * 3; i += NT)
+            sc.rf[i] = sc.footp[i] - sc.foot_ref[i];
+        }
+        else
+        {
+          // FramePlacementResidual: log6(M_ref^-1 oMf), M_ref = (identity rotation, reference translation) (src/mpc.cpp:304-308)
+          if (lane >= 48 && lane < 48 + NF)
+          {
+            const int f = lane - 48;
+            const SE3 M{ldm3(&sc.oR[h.foot_joint[f] * 9]), ld3(&sc.footp[f * 3]) - ld3(&sc.foot_ref[f * 3])};
+            V3 v, w;
+            log6(M, v, w);
+            st3(&sc.rf[6 * f], v);
+            st3(&sc.rf[6 * f + 3], w);
+            if constexpr (DERIV)
+            {
+              M3 Ji, X;
+              Jlog6(v, w, Ji, X);
+              const double ji[9] = {Ji.a00, Ji.a01, Ji.a02, Ji.a10, Ji.a11, Ji.a12, Ji.a20, Ji.a21, Ji.a22};
+              const double xx[9] = {X.a00, X.a01, X.a02, X.a10, X.a11, X.a12, X.a20, X.a21, X.a22};
+              double * Jl = &sd->Jlf[f * 36];
+              for (int a = 0; a < 3; a++)
+                for (int bb = 0; bb < 3; bb++)
+                {
+                  Jl[a * 6 + bb] = ji[a * 3 + bb];
+                  Jl[(a + 3) * 6 + bb + 3] = ji[a * 3 + bb];
+                  Jl[a * 6 + bb + 3] = xx[a * 3 + bb];
+                  Jl[(a + 3) * 6 + bb] = 0.0;
+                }
+            }
+          }
+        }
+        // wrench-cone rows of the feet in contact: A_cone lam
+        for (int i = lane; i < D::NCONE; i += NT)
+        {
+          const int f = i / D::NCONE1, r = i % D::NCONE1;
+          double acc = 0.0;
+          if (h.force_cone && ((mask >> f) & 1u))
+          {
+            const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+            for (int j = 0; j < 6; j++)
+              acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * sc.lam[c * FS + j];
+          }
+          sc.cval[NU + NA + i] = acc;
+        }
         // contact-force residual of the feet in contact (compact row c of foot f)
         for (int i = lane; i < NCM; i += NT)
         {
@@ -692,12 +826,12 @@ namespace smpc
               s += mg.w_u[i * NU + j] * sc.ru[j];
           sc.Wru[i] = s;
         }
-        for (int i = lane; i < NF * 3; i += NT)
+        for (int i = lane; i < NF * D::PF; i += NT)
         {
-          const int f = i / 3, r = i % 3;
+          const int f = i / D::PF, r = i % D::PF;
           double s = 0.0;
-          for (int j = 0; j < 3; j++)
-            s += h.w_frame[r * FS + j] * sc.rf[f * 3 + j];
+          for (int j = 0; j < D::PF; j++)
+            s += h.w_frame[r * FS + j] * sc.rf[f * D::PF + j];
           sc.Wrf[i] = s;
         }
         for (int i = lane; i < NCM; i += NT)
@@ -723,7 +857,7 @@ namespace smpc
       {
         for (int i = lane; i < NU; i += NT)
           c += sc.ru[i] * sc.Wru[i];
-        for (int i = lane; i < NF * 3; i += NT)
+        for (int i = lane; i < NF * D::PF; i += NT)
           c += sc.rf[i] * sc.Wrf[i];
         for (int i = lane; i < NCM; i += NT)
           c += sc.rl[i] * sc.Wrl[i];
@@ -765,18 +899,19 @@ namespace smpc
       }
       for (int i = lane; i < NC; i += NT)
       {
-        // rows: torque box | joint box | cone rows (none for 3-D feet)
-        const bool present = i < NU ? h.torque_limits != 0 : (i < NU + NA ? h.kinematics_limits != 0 : false);
+        // rows: torque box | joint box | wrench-cone rows of the feet in contact (negative orthant)
+        const bool box = i < NU + NA;
+        const bool present = i < NU ? h.torque_limits != 0 : (box ? h.kinematics_limits != 0 : (h.force_cone != 0 && ((mask >> ((i - NU - NA) / (D::NCONE1 > 0 ? D::NCONE1 : 1))) & 1u)));
         double vp = 0.0;
         int act = 0;
         if (present)
         {
-          const double lo = i < NU ? h.umin[i] : h.qmin[i - NU], hi = i < NU ? h.umax[i] : h.qmax[i - NU];
+          const double lo = i < NU ? h.umin[i] : (box ? h.qmin[i - NU] : -1e300), hi = i < NU ? h.umax[i] : (box ? h.qmax[i - NU] : 0.0);
           const double z = sc.cval[i] + mu * nu_e[i];
-          const double proj = fmin(fmax(z, lo), hi);
+          const double proj = box ? fmin(fmax(z, lo), hi) : fmin(z, 0.0);
           vp = (z - proj) / mu;
           act = z != proj;
-          prim = fmax(prim, fmax(fmax(sc.cval[i] - hi, lo - sc.cval[i]), 0.0));
+          prim = fmax(prim, box ? fmax(fmax(sc.cval[i] - hi, lo - sc.cval[i]), 0.0) : fmax(sc.cval[i], 0.0));
         }
         sc.vplus[i] = vp;
         sc.act[i] = act;
@@ -857,8 +992,16 @@ namespace smpc
         if ((mask >> f) & 1u)
         {
           const int c = __builtin_popcount(mask & ((1u << f) - 1u));
-          const V3 fw = ldm3(&sc.oR[h.foot_joint[f] * 9]) * ld3(&sc.lam[3 * c]);
-          W = SV{fw, cross(ld3(&sc.footp[f * 3]), fw)};
+          if constexpr (FS == 3)
+          {
+            const V3 fw = ldm3(&sc.oR[h.foot_joint[f] * 9]) * ld3(&sc.lam[3 * c]); // LOCAL contact force in world axes
+            W = SV{fw, cross(ld3(&sc.footp[f * 3]), fw)};
+          }
+          else
+          {
+            const V3 fl = ld3(&sc.lam[6 * c]);                                       // world-aligned wrench at the foot point
+            W = SV{fl, cross(ld3(&sc.footp[f * 3]), fl) + ld3(&sc.lam[6 * c + 3])};
+          }
         }
         stsv(&sd.Wc[f * 6], W);
       }
@@ -874,9 +1017,10 @@ namespace smpc
       {
         const int i = lane;
         SV F = ldsv(&sc.Fc[i * 6]);
-        for (int f = 0; f < NF; f++)
-          if ((h.anc[h.foot_joint[f]] >> i) & 1u)
-            F = F - ldsv(&sd.Wc[f * 6]);
+        if constexpr (FS == 3) // a LOCAL contact force turns with the foot: it joins the composite force below joint i
+          for (int f = 0; f < NF; f++)
+            if ((h.anc[h.foot_joint[f]] >> i) & 1u)
+              F = F - ldsv(&sd.Wc[f * 6]);
         stsv(&sd.Fgc[i * 6], F);
       }
       SMPC_LANES_END_WAVE
@@ -918,19 +1062,41 @@ namespace smpc
           jc6[r * NCOL + 2 * NV + k] = 0.0;
       }
       double * jf = &sd.JT[(NCM + 6) * NCOL];
+      constexpr int PF = D::PF;
       for (int f = 0; f < NF; f++)
       {
+        const bool on = (h.anc[h.foot_joint[f]] >> i) & 1u;
         V3 c = mk3(0, 0, 0);
-        if ((h.anc[h.foot_joint[f]] >> i) & 1u)
+        if (on)
           c = s.l + cross(s.a, ld3(&sc.footp[f * 3]));
-        jf[(3 * f + 0) * NCOL + k] = c.x;
-        jf[(3 * f + 1) * NCOL + k] = c.y;
-        jf[(3 * f + 2) * NCOL + k] = c.z;
-        for (int r = 0; r < 3; r++)
+        if constexpr (FS == 3)
         {
-          jf[(3 * f + r) * NCOL + NV + k] = 0.0;
+          jf[(3 * f + 0) * NCOL + k] = c.x;
+          jf[(3 * f + 1) * NCOL + k] = c.y;
+          jf[(3 * f + 2) * NCOL + k] = c.z;
+        }
+        else
+        {
+          // FramePlacementResidual: Jlog6(M_ref^-1 oMf) * (LOCAL 6-D frame Jacobian column)
+          double col[6] = {0, 0, 0, 0, 0, 0};
+          if (on && !term)
+          {
+            const M3 Rf = ldm3(&sc.oR[h.foot_joint[f] * 9]);
+            const V3 lin = tmul(Rf, c), ang = tmul(Rf, s.a);
+            const double lv[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z};
+            const double * Jl = &sd.Jlf[f * 36];
+            for (int r = 0; r < 6; r++)
+              for (int m = 0; m < 6; m++)
+                col[r] += Jl[r * 6 + m] * lv[m];
+          }
+          for (int r = 0; r < 6; r++)
+            jf[(6 * f + r) * NCOL + k] = col[r];
+        }
+        for (int r = 0; r < PF; r++)
+        {
+          jf[(PF * f + r) * NCOL + NV + k] = 0.0;
           if (k < NU)
-            jf[(3 * f + r) * NCOL + 2 * NV + k] = 0.0;
+            jf[(PF * f + r) * NCOL + 2 * NV + k] = 0.0;
         }
       }
     }
@@ -985,6 +1151,25 @@ namespace smpc
           vq = sv_dot6(Sm, Xq);
           vv = sv_dot6(Sm, Xv);
         }
+        if constexpr (FS == 6)
+        {
+          // - d(J^T lam)/dq_k of world-aligned wrenches: the wrench keeps its axes, its point of application moves; the columns S_m
+          // below joint(k) (and the other base columns, for a base dof) move with S_k
+          for (int f = 0; f < NF; f++)
+          {
+            const int l = h.foot_joint[f];
+            if (!((mask >> f) & 1u) || !((h.anc[l] >> jm) & 1u) || !((h.anc[l] >> i) & 1u))
+              continue;
+            const SV Sk = ldsv(&sc.S[k * 6]), Sm = ldsv(&sc.S[m * 6]);
+            const SV W = ldsv(&sd.Wc[f * 6]);
+            const V3 pv = Sk.l + cross(Sk.a, ld3(&sc.footp[f * 3]));
+            double tq = dot(Sm.a, cross(pv, W.l));
+            const bool moves = (jm != i && ((h.anc[jm] >> i) & 1u)) || (jm == 0 && i == 0);
+            if (moves)
+              tq -= sv_dot6(Sm, crf(Sk, W));
+            vq -= tq;
+          }
+        }
         sd.R1[m * NCOL + k] = vq;
         sd.R1[m * NCOL + NV + k] = vv;
       }
@@ -999,6 +1184,52 @@ namespace smpc
     SMPC_LANES_END_WAVE
     ftick(fp, 10);
     // ---- partial derivatives of the contact acceleration residual (classical acceleration, contact frame, corrector) ----
+    if constexpr (FS == 6)
+    {
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < NF * NV; idx += NT)
+      {
+        const int f = idx / NV, k = idx % NV;
+        const int l = h.foot_joint[f], i = jof(k);
+        if (((mask >> f) & 1u) && ((h.anc[l] >> i) & 1u))
+        {
+          const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+          const V3 p = ld3(&sc.footp[f * 3]);
+          const SV vl = ldsv(&sc.vel[l * 6]), al = ldsv(&sc.acc[l * 6]); // (acc: at the solution)
+          const V3 w = vl.a, vp = vl.l + cross(w, p);
+          const V3 ap = al.l + cross(al.a, p) + cross(w, vp);
+          const SV Sk = ldsv(&sc.S[k * 6]), d = ldsv(&sd.dk[k * 6]);
+          const int lam = h.parent[i];
+          SV A = sv0();
+          if (lam >= 0)
+            A = crm(ldsv(&sc.acc[lam * 6]), Sk) + crm(ldsv(&sc.vel[lam * 6]), d) + crm(d, vl);
+          const V3 pv = Sk.l + cross(Sk.a, p); // d(point position)/dq_k = d(point velocity)/dv_k
+          const V3 aq = A.l + cross(A.a, p) + cross(d.a, vp) + cross(w, d.l + cross(d.a, p));
+          const SV Av = d + crm(Sk, vl - ldsv(&sc.vel[i * 6]));
+          const V3 av = Av.l + cross(Av.a, p) + cross(Sk.a, vp) + cross(w, pv);
+          const V3 vq = d.l + cross(d.a, p);
+          // world-aligned components of body-fixed vectors turn with the body: + S_k.a x u
+          const V3 lq = aq + cross(Sk.a, ap), lvq = vq + cross(Sk.a, vp);
+          const V3 aqq = A.a + cross(Sk.a, al.a), wq = d.a + cross(Sk.a, w);
+          // d log3(R) for a rotation increment expressed in the world frame: inverse left Jacobian = Jlog3(-phi)
+          const V3 rq = Jlog3((-1.0) * ld3(&sc.rotl[f * 3])) * Sk.a;
+          double * r2 = &sd.JT[(6 * c) * NCOL];
+          const double lqv[3] = {lq.x, lq.y, lq.z}, lvqv[3] = {lvq.x, lvq.y, lvq.z}, pvv[3] = {pv.x, pv.y, pv.z};
+          const double aqv[3] = {aqq.x, aqq.y, aqq.z}, wqv[3] = {wq.x, wq.y, wq.z}, rqv[3] = {rq.x, rq.y, rq.z};
+          const double avv[3] = {av.x, av.y, av.z}, ava[3] = {Av.a.x, Av.a.y, Av.a.z}, sav[3] = {Sk.a.x, Sk.a.y, Sk.a.z};
+          for (int r = 0; r < 3; r++)
+          {
+            r2[r * NCOL + k] = lqv[r] + h.Kd[r] * lvqv[r] + h.Kp[r] * pvv[r];
+            r2[(3 + r) * NCOL + k] = aqv[r] + h.Kd[3 + r] * wqv[r] + h.Kp[3 + r] * rqv[r];
+            r2[r * NCOL + NV + k] = avv[r] + h.Kd[r] * pvv[r];
+            r2[(3 + r) * NCOL + NV + k] = ava[r] + h.Kd[3 + r] * sav[r];
+          }
+        }
+      }
+      SMPC_LANES_END_WAVE
+    }
+    else
+    {
     SMPC_LANES(NT)
     for (int idx = lane; idx < NF * NV; idx += NT)
     {
@@ -1032,7 +1263,7 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
-    static_assert(FS == 3, "contact-acceleration partials of the 6-D LOCAL_WORLD_ALIGNED contact come with the Talos table");
+    }
     ftick(fp, 11);
     // ---- [M -J^T; J mu] [da; dlam] = -[r1; r2]:  Mr = M^-1 R1 ; rhs = J Mr - r2 ; dlam = G^-1 rhs ; da = -Mr + M^-1 J^T dlam ----
     fwave_chol_solve<NT, NV>(sc.M, sd.R1, NCOL, NCOL);
@@ -1099,8 +1330,9 @@ namespace smpc
       return (term || k >= NCM || r / FS != k / FS) ? 0.0 : h.w_forces[(r % FS) * FS + k % FS];
     if (r < NCM + 6)
       return (k < NCM || k >= NCM + 6) ? 0.0 : (term ? 10.0 : 1.0) * h.w_cent[(r - NCM) * 6 + k - NCM];
+    constexpr int PF = D::PF;
     const int a = r - NCM - 6, bb = k - NCM - 6;
-    return (term || bb < 0 || a / 3 != bb / 3) ? 0.0 : h.w_frame[(a % 3) * FS + bb % 3];
+    return (term || bb < 0 || a / PF != bb / PF) ? 0.0 : h.w_frame[(a % PF) * FS + bb % PF];
   }
 
   // entry (i, j) of the state-cost Hessian Jx^T w_x Jx, Jx = blockdiag(Jlog6, I)
@@ -1346,8 +1578,34 @@ namespace smpc
     double * parts = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
     // stacked weighted residual [Wrl | Whg | Wrf] for the gradients
     SMPC_LANES(NT)
-    for (int r = lane; r < NGN; r += NT)
-      sd.dual[r] = r < NCM ? (term ? 0.0 : sc.Wrl[r]) : (r < NCM + 6 ? sc.Whg[r - NCM] : (term ? 0.0 : sc.Wrf[r - NCM - 6]));
+    {
+      for (int r = lane; r < NGN; r += NT)
+        sd.dual[r] = r < NCM ? (term ? 0.0 : sc.Wrl[r]) : (r < NCM + 6 ? sc.Whg[r - NCM] : (term ? 0.0 : sc.Wrf[r - NCM - 6]));
+      // wrench-cone rows: A_cone^T nu per contact (the multipliers of the unmasked rows enter the Lagrangian gradient)
+      for (int r = lane; r < NCM; r += NT)
+      {
+        double acc = 0.0;
+        if constexpr (D::NCONE > 0)
+        {
+          if (!term && h.force_cone)
+          {
+            const int c = r / D::FS, j = r % D::FS;
+            int f = -1, cnt = 0;
+            for (int ff = 0; ff < NF; ff++)
+              if ((mask >> ff) & 1u)
+              {
+                if (cnt == c)
+                  f = ff;
+                cnt++;
+              }
+            if (f >= 0)
+              for (int i = 0; i < D::NCONE1; i++)
+                acc += wrench_cone_entry(i, j, h.fric_mu, h.Lfoot, h.Wfoot) * sc.nu[NU + NA + D::NCONE1 * f + i];
+          }
+        }
+        sd.yc[r] = acc;
+      }
+    }
     SMPC_LANES_END_WAVE
     // ---- cost gradients ----
     SMPC_LANES(NT)
@@ -1371,6 +1629,12 @@ namespace smpc
         sd.gx[k] = g;
       else
         sd.gu[k - NDX] = g;
+      double cqv = 0.0;
+      if constexpr (D::NCONE > 0)
+        if (!term)
+          for (int r = 0; r < NCM; r++)
+            cqv += sd.JT[r * NCOL + k] * sd.yc[r];
+      sd.cq[k] = cqv;
     }
     SMPC_LANES_END_WAVE
     if (term)
@@ -1454,7 +1718,7 @@ namespace smpc
           double cn = 0.0;
           if (h.kinematics_limits && k >= 6 && k < NV)
             cn = sc.nu[NU + k - 6];
-          double q = sd.gx[k] + acc + cn - (t > 0 ? b.lams[(ib + sprev) * NDX + k] : 0.0);
+          double q = sd.gx[k] + acc + cn + sd.cq[k] - (t > 0 ? b.lams[(ib + sprev) * NDX + k] : 0.0);
           if (t == 0)
             q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
           lq[D::O_q + k] = q;
@@ -1466,7 +1730,7 @@ namespace smpc
         else
         {
           const double cn = h.torque_limits ? sc.nu[k] : 0.0;
-          const double r = sd.gu[k] + acc + cn;
+          const double r = sd.gu[k] + acc + cn + sd.cq[NDX + k];
           lq[D::O_r + k] = r;
           lq[D::O_lu + k] = sd.gu[k];
           dual = fmax(dual, fabs(r));
@@ -1490,7 +1754,28 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     ftick(fp, 16);
-    static_assert(D::NCONE == 0, "dense cone rows (Cd, Dd) come with the 6-D feet");
+    if constexpr (D::NCONE > 0)
+    {
+      // dense cone rows of the knot: A_cone d lam / d(x, u) for the active rows, zero otherwise
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < D::NCONE * NXU; idx += NT)
+      {
+        const int i = idx / NXU, k = idx % NXU;
+        const int f = i / D::NCONE1, r = i % D::NCONE1;
+        double acc = 0.0;
+        if (sc.act[NU + NA + i])
+        {
+          const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+          for (int j = 0; j < 6; j++)
+            acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * sd.JT[(6 * c + j) * NCOL + k];
+        }
+        if (k < NDX)
+          lq[D::O_C + i * NDX + k] = acc;
+        else
+          lq[D::O_D + i * NU + k - NDX] = acc;
+      }
+      SMPC_LANES_END_WAVE
+    }
     SMPC_LANES(NT)
     {
       if (lane == 0)

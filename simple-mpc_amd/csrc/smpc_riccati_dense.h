@@ -9,7 +9,12 @@
 //        H^ = [Q S; S^T R] + [A | B]^T T,  vector column [q; r] + [A | B]^T p~ (p~ rides as one more column of T)
 //   (5)  box rows (unit selectors): diagonal terms act / mu on R^ (torque box) and Q^ (joint box), act d / mu on the vector column
 //   (6)  sweep of the control pivots of [[Q^, S^, q^], [S^^T, R^, r^]] in place  ->  P_t, p_t, -K, -k
-// Generic in (NDX, NU): tile grids are computed from the dimensions; control pivots are padded to a multiple of 4 with unit rows.
+// Dense constraint rows (the wrench-cone rows of 6-D feet: C and D both dense through the contact-force derivatives) are NOT
+// folded into R^ (D^T D / mu would swamp the weakly determined directions, as in the centroidal kernel): their multipliers are
+// pivoted explicitly after the controls,
+//        [[Q^, S^, C^T, q^], [., R^, D^T, r^], [., ., -mu I, d]]   pivots [u | nu]  ->  P_t, p_t, -K, -k, -Z, -z
+// (the stage KKT matrix is quasi-definite: LDL^T without pivoting is stable, 4 x 4 pivot blocks are definite of either sign).
+// Generic in (NDX, NU, NCONE): tile grids are computed from the dimensions; pivots are padded to whole panels with unit rows.
 #pragma once
 #include "smpc_full_model.h"
 #include "smpc_riccati_kino.h"
@@ -22,11 +27,16 @@ namespace smpc
     static constexpr int NDX = D::NDX, NU = D::NU, NXU = NDX + NU;
     static constexpr int NUP = ((NU + 3) / 4) * 4;     // control pivots padded to whole panels
     static constexpr int NXUP = NDX + NUP;
+    static constexpr int NCD = D::NCONE;               // dense constraint rows (multipliers pivoted explicitly)
+    static constexpr int NCP = ((NCD + 3) / 4) * 4;
+    static constexpr int NXC = NXUP + NCP;              // [x | u | nu]
     static constexpr int NT1 = (2 * NDX + 1 + 15) / 16; // tile grid of the first sweep
     static constexpr int NTX = (NDX + 15) / 16;         // tile rows of P~ / T
     static constexpr int NTJ = (NXUP + 15) / 16;        // tile columns holding [A | B]
-    static constexpr int VC = NXUP;                     // vector column of the second grid
-    static constexpr int NT2 = (NXUP + 1 + 15) / 16;    // tile grid of the second sweep
+    static constexpr int VC = NXC;                      // vector column of the second grid
+    static constexpr int NT2 = (NXC + 1 + 15) / 16;     // tile grid of the second sweep
+    static constexpr int VT = VC / 16;                  // tile column of the vector column
+    static_assert(VT >= NTJ, "the vector column lives in a tile column of its own (or of the multipliers)");
     static constexpr int NTM = NT1 > NT2 ? NT1 : NT2;
     static_assert(NDX % 4 == 0, "pivot panels and K steps of 4");
     static_assert(NT1 <= 8 && NT2 <= 8, "sweep geometry: at most 128 columns");
@@ -38,13 +48,13 @@ namespace smpc
     typedef RiccatiDenseGeom<D> GM;
     static constexpr int NDX = D::NDX, NU = D::NU;
     static constexpr int SWP = 4 * 16 * GM::NTM;
-    static constexpr int N_AB = NDX * GM::NXUP, N_W = NU * (NDX + 1);
+    static constexpr int N_AB = NDX * GM::NXUP, N_W = (NU > GM::NCD ? NU : GM::NCD) * (NDX + 1);
     static constexpr int N_SCR = (2 * SWP > N_W ? 2 * SWP : N_W);
     double P[NDX * NDX];      // P_{t+1} -> P~ -> P_t
     double AB[N_AB];          // [A | B | 0] row-major, row stride NXUP
     double scr[N_SCR];        // sweep operands (2 x 4 x 16 NT) ; staging of [K | k]
     double p[NDX], pt0[NDX], pt[NDX], f[NDX];
-    double boxa[D::NU + D::NA], boxd[D::NU + D::NA];
+    double boxa[D::NU + D::NA], boxd[D::NU + D::NA + GM::NCD]; // activity of the box rows ; d = mu (nu+ - nu) of all rows
   };
 
   template <class D>
@@ -54,8 +64,7 @@ namespace smpc
     typedef RiccatiDenseGeom<D> GM;
     typedef RiccatiDenseLds<D> LDS;
     constexpr int NDX = D::NDX, NU = D::NU, NA = D::NA, NXU = GM::NXU, NXUP = GM::NXUP, NT1 = GM::NT1, NTX = GM::NTX, NTJ = GM::NTJ, NT2 = GM::NT2,
-                  VC = GM::VC, NUP = GM::NUP;
-    static_assert(D::NCONE == 0, "dense cone rows: explicit multiplier pivots (next)");
+                  VC = GM::VC, NUP = GM::NUP, NCD = GM::NCD, NCP = GM::NCP, NXC = GM::NXC, VT = GM::VT;
     const Buffers<D> & b = ka.b;
     const int H = b.H;
     const int inst = block;
@@ -87,10 +96,9 @@ namespace smpc
           g[D::G_pn + i] = s.p[i];
         }
         for (int i = lane; i < NU + NA; i += NT)
-        {
           s.boxa[i] = lq[D::O_act + i];
+        for (int i = lane; i < NU + NA + NCD; i += NT)
           s.boxd[i] = lq[D::O_d + i];
-        }
       }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
@@ -176,6 +184,8 @@ namespace smpc
                 off = D::O_Q + r0 * NDX + c0;
               else if (c0 < NXU)
                 off = r0 < NDX ? D::O_S + r0 * NU + c0 - NDX : D::O_R + (r0 - NDX) * NU + c0 - NDX;
+              else if (c0 >= NXUP && c0 < NXUP + NCD && r0 < NXU) // dense constraint rows: (x, nu_i) = C_i, (u, nu_i) = D_i
+                off = r0 < NDX ? D::O_C + (c0 - NXUP) * NDX + r0 : D::O_D + (c0 - NXUP) * NU + r0 - NDX;
               else if (c0 == VC && r0 < NXU)
                 off = r0 < NDX ? D::O_q + r0 : D::O_r + r0 - NDX;
               SMPC_ACCV(hacc, tix<NT2>(I, J), v) = lq[off];
@@ -192,7 +202,8 @@ namespace smpc
       SMPC_LANES_END_WAVE
       // ---- (4) T = P~ [A | B] with p~ as column VC ; H^ += [A | B]^T T ----
       {
-        SMPC_ACC(tacc, NT, NTX * NT2);
+        constexpr int NTT = NTJ + 1; // tile columns of T: [A | B] columns + the tile of the vector column
+        SMPC_ACC(tacc, NT, NTX * NTT);
         SMPC_PLA(double, pav, NT, NTX);
         SMPC_PLA(double, abv, NT, NTJ);
         SMPC_LANES(NT)
@@ -201,13 +212,13 @@ namespace smpc
 #pragma unroll
           for (int I = 0; I < NTX; I++)
 #pragma unroll
-            for (int J = 0; J < NT2; J++)
+            for (int J = 0; J < NTT; J++)
 #pragma unroll
               for (int v = 0; v < 4; v++)
               {
-                const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+                const int row = 16 * I + lr + 4 * v, col = 16 * (J < NTJ ? J : VT) + lc;
                 const double pv = s.pt[row < NDX ? row : 0];
-                SMPC_ACCV(tacc, I * NT2 + J, v) = (col == VC && row < NDX) ? pv : 0.0;
+                SMPC_ACCV(tacc, I * NTT + J, v) = (col == VC && row < NDX) ? pv : 0.0;
               }
         }
         SMPC_LANES_END_WAVE
@@ -237,10 +248,10 @@ namespace smpc
           for (int I = 0; I < NTX; I++)
 #pragma unroll
             for (int J = 0; J < NTJ; J++)
-              SMPC_MFMA(tacc, I * NT2 + J, pav, I, abv, J);
+              SMPC_MFMA(tacc, I * NTT + J, pav, I, abv, J);
         }
         // H^(I, J) += sum_ks ABop(ks, I)^T T(ks, J): the B operand of K-step ks = 4 Ix + v is accumulator entry v of T's tile (Ix, J)
-        SMPC_PLA(double, tbv, NT, NT2);
+        SMPC_PLA(double, tbv, NT, NTT);
 #pragma unroll
         for (int Ix = 0; Ix < NTX; Ix++)
 #pragma unroll
@@ -260,15 +271,16 @@ namespace smpc
                 SMPC_PLV(abv)[J] = c < NXUP ? av : 0.0;
               }
 #pragma unroll
-              for (int J = 0; J < NT2; J++)
-                SMPC_PLV(tbv)[J] = SMPC_ACCV(tacc, Ix * NT2 + J, v);
+              for (int J = 0; J < NTT; J++)
+                SMPC_PLV(tbv)[J] = SMPC_ACCV(tacc, Ix * NTT + J, v);
             }
             SMPC_LANES_END_WAVE
 #pragma unroll
             for (int I = 0; I < NTJ; I++)
 #pragma unroll
               for (int J = I; J < NT2; J++)
-                SMPC_MFMA(hacc, tix<NT2>(I, J), abv, I, tbv, J);
+                if (J < NTJ || J == VT) // (T is zero in the multiplier columns)
+                  SMPC_MFMA(hacc, tix<NT2>(I, J), abv, I, tbv, J < NTJ ? J : NTJ);
           }
       }
       // ---- (5) box rows ; padding pivots ; entries outside the problem ----
@@ -292,14 +304,20 @@ namespace smpc
                 val += imu * ba;
               if (bi >= 0 && c0 == VC)
                 val += imu * ba * bd;
-              if (r0 >= NXU || (c0 >= NXU && c0 != VC) || c0 > VC)
-                val = (r0 == c0 && r0 < NXUP) ? 1.0 : 0.0; // unit padding pivots, zero elsewhere
+              const bool rx = r0 < NXU, rn = r0 >= NXUP && r0 < NXUP + NCD; // problem rows: (x, u) ; explicit multipliers
+              const bool cx = c0 < NXU, cn = c0 >= NXUP && c0 < NXUP + NCD;
+              if (rn && c0 == r0)
+                val = -mu;                                   // multiplier block -mu I
+              else if (rn && c0 == VC)
+                val = s.boxd[NU + NA + (r0 - NXUP)];          // d of the dense rows
+              else if (!((rx && (cx || cn || c0 == VC))))
+                val = (r0 == c0 && r0 < NXC) ? 1.0 : 0.0;     // unit padding pivots, zero elsewhere
               SMPC_ACCV(hacc, tix<NT2>(I, J), v) = val;
             }
       }
       SMPC_LANES_END_WAVE
       // ---- (6) sweep the control pivots in place:  x-x block -> P_t,  x-vector -> p_t,  (x, u) entries -> -K,  (u, vector) -> -k ----
-      wave_block_sweep<NT, NT2, true, NDX, NUP / 4>(hacc, sw, sw + LDS::SWP, prof, tprev);
+      wave_block_sweep<NT, NT2, true, NDX, (NUP + NCP) / 4>(hacc, sw, sw + LDS::SWP, prof, tprev);
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
@@ -345,6 +363,33 @@ namespace smpc
             g[D::G_K + lane + n * NT] = wv[n];
       }
       SMPC_LANES_END_WAVE
+      if constexpr (NCD > 0)
+      {
+        // multiplier feedback of the dense rows: [Z | z] = -(stored entries pairing (x | vector) with the nu pivots)
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int I = 0; I < NT2; I++)
+#pragma unroll
+            for (int J = I; J < NT2; J++)
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+              {
+                const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+                const double val = SMPC_ACCV(hacc, tix<NT2>(I, J), v);
+                if (row < NDX && col >= NXUP && col < NXUP + NCD)
+                  Wm[(col - NXUP) * (NDX + 1) + row] = -val;
+                else if (row >= NXUP && row < NXUP + NCD && col == VC)
+                  Wm[(row - NXUP) * (NDX + 1) + NDX] = -val;
+              }
+        }
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        for (int idx = lane; idx < NCD * (NDX + 1); idx += NT)
+          g[D::G_Z + idx] = Wm[idx];
+        SMPC_LANES_END_WAVE
+      }
     }
   }
 } // namespace smpc

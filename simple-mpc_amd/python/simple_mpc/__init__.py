@@ -54,7 +54,18 @@ class RobotModelHandler:
         return f
 
     def addQuadFoot(self, foot_name, reference_parent_frame_name, contact_points):
-        raise RuntimeError("6-D (quad) feet are not built yet")
+        """6-D foot (reference src/robot-handler.cpp:62-79).  The four sole corners only matter to the whole-body ID controllers;
+        the MPC problems use the sole half-sizes of their settings (Lfoot, Wfoot)."""
+        f = self._table_foot(foot_name)
+        if f != len(self._feet):
+            raise RuntimeError("feet must be added in the order of the robot table")
+        q = np.asarray(contact_points, float)
+        if q.shape != (4, 3):
+            raise RuntimeError("contact_points must be a 4 x 3 matrix")
+        self._feet.append(foot_name)
+        self._quads = getattr(self, "_quads", {})
+        self._quads[foot_name] = q
+        return f
 
     def getFeetNb(self):
         return len(self._feet)

@@ -67,6 +67,31 @@ def go2_full_mpc_settings(model_handler, max_iters=1, num_threads=0):
     return go2_mpc_settings(model_handler, max_iters, num_threads)
 
 
+TALOS_EFFORT = np.array([100, 160, 160, 300, 160, 100] * 2 + [200, 200] + [44, 44, 22, 22] * 2, float)
+
+
+def talos_full_settings(model_handler):
+    """FullDynamicsSettings of the Talos example: reference examples/talos_fulldynamics.py:47-115 (6-D feet, wrench cones).  The
+    robot table holds no effort limits: Talos-like actuator limits are used (TALOS_EFFORT)."""
+    w_x = np.diag(np.array([0, 0, 0, 10, 10, 10] + [0.1] * 6 * 2 + [1, 100] + [1, 1, 10, 10] * 2 + [10] * 6 + [1] * 6 * 2 + [1, 100]
+                           + [10] * 4 * 2, float))
+    nu = model_handler.nv - 6
+    return dict(timestep=0.01, w_x=w_x, w_u=np.eye(nu) * 1e-4, w_cent=np.diag([0.1, 0.1, 10, 0.1, 0.1, 10.0]), w_forces=np.eye(6) * 1e-3,
+                w_frame=np.eye(6) * 2000.0, gravity=np.array([0, 0, -9.81]), force_size=6, Kp_correction=np.array([0, 0, 50, 0, 0, 0.0]),
+                Kd_correction=np.ones(6) * 100.0, umin=-TALOS_EFFORT, umax=TALOS_EFFORT.copy(), qmin=model_handler.lowerPositionLimit[7:].copy(),
+                qmax=model_handler.upperPositionLimit[7:].copy(), mu=0.8, Lfoot=0.1, Wfoot=0.075, torque_limits=True, kinematics_limits=True,
+                force_cone=True, land_cstr=False)
+
+
+def talos_mpc_settings(model_handler, max_iters=1, num_threads=0):
+    """MPC settings of the Talos example: reference examples/talos_fulldynamics.py:101-113 (T = 100, T_fly 80, T_contact 20)."""
+    return dict(support_force=model_handler.getMass() * 9.81, TOL=1e-4, mu_init=1e-8, max_iters=max_iters, num_threads=num_threads,
+                swing_apex=0.15, T_fly=80, T_contact=20, timestep=0.01)
+
+
+TALOS_QUAD = np.array([[0.1, 0.075, 0], [-0.1, 0.075, 0], [-0.1, -0.075, 0], [0.1, -0.075, 0]])  # examples/talos_fulldynamics.py:22-33
+
+
 def trot_cycle(T_ds=10, T_ss=30):
     """Contact cycle of reference examples/go2_kinodynamics.py:111-139, foot order FL FR RL RR."""
     quad, lift_fl, lift_fr = [1, 1, 1, 1], [0, 1, 1, 0], [1, 0, 0, 1]

@@ -177,3 +177,51 @@ def make_full_pair(batch, max_iters=1, lib=None, horizon=50, walk=(0.2, 0, 0, 0,
     gm.generateCycleHorizon(O.trot_cycle())
     gm.switchToWalk(np.array(walk, float))
     return om, gm, rb
+
+
+TALOS_FEET = ["left_sole_link", "right_sole_link"]
+TALOS_QUAD = np.array([[0.1, 0.075, 0], [-0.1, 0.075, 0], [-0.1, -0.075, 0], [0.1, -0.075, 0]])
+
+
+def make_talos_product(batch, max_iters=1, lib=None, horizon=100, settings_override=None, mpc_override=None, device_id=0):
+    """simple_mpc.BatchedMPC over the Talos full-dynamics OCP (6-D feet, wrench cones; oracle_lib.talos_full_settings)."""
+    rb = O.Robot("talos_like")
+    s = O.talos_full_settings(rb)
+    if settings_override:
+        s.update(settings_override)
+    ms = O.talos_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if mpc_override:
+        ms.update(mpc_override)
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("talos_like", lib), "standing", "root_joint")
+    for n in TALOS_FEET:
+        mh.addQuadFoot(n, "root_joint", TALOS_QUAD)
+    ocp = simple_mpc.FullDynamicsOCP(s, mh)
+    ocp.createProblem(mh.getReferenceState(), horizon, 6, -9.81, False)
+    conf = {k: ms[k] for k in MPC_KEYS}
+    gm = simple_mpc.BatchedMPC(conf, ocp, batch, device_id=device_id, lib=lib)
+    return gm, rb, s, ms
+
+
+def make_talos_pair(batch, max_iters=1, lib=None, horizon=100, walk=(0.1, 0, 0, 0, 0, 0), cycle=None, **kw):
+    rb = O.Robot("talos_like")
+    s = O.talos_full_settings(rb)
+    if kw.get("settings_override"):
+        s.update(kw["settings_override"])
+    ms = O.talos_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if kw.get("mpc_override"):
+        ms.update(kw["mpc_override"])
+    om = O.OracleFullMPC(O.Full(rb, s), ms, batch)
+    gm, _, _, _ = make_talos_product(batch, max_iters, lib, horizon, **kw)
+    cs = O.walk_cycle() if cycle is None else cycle
+    for m in (om, gm):
+        m.generateCycleHorizon(cs)
+        m.switchToWalk(np.array(walk, float))
+    return om, gm, rb
+
+
+def talos_random_states(rb, batch, seed=20240529, scale=1.0):
+    rng = np.random.default_rng(seed)
+    sg = np.concatenate([np.ones(3) * 0.02, np.ones(3) * 0.05, np.ones(rb.nv - 6) * 0.1, np.ones(3) * 0.1, np.ones(3) * 0.2, np.ones(rb.nv - 6) * 0.5])
+    return np.stack([rb.integrate(rb.x_ref, rng.normal(size=rb.ndx) * sg * scale) for _ in range(batch)])
