@@ -168,11 +168,22 @@ def cpu_baseline(iters, seconds_budget=20.0):
 
 
 def make_mpc(kind, batch, iters, device_id, lib=None, horizon=50):
-    """BatchedMPC on the settings of record (simple_mpc.presets): kind in kinodynamics / centroidal / fulldynamics."""
+    """BatchedMPC on the settings of record (simple_mpc.presets): kind in kinodynamics / centroidal / fulldynamics / talos."""
     import numpy as np
     import simple_mpc
     from simple_mpc import presets as P
 
+    if kind == "talos":
+        mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("talos_like", lib), "half_sitting", "root_joint")
+        for n in P.TALOS_FEET:
+            mh.addQuadFoot(n, "root_joint", P.TALOS_QUAD)
+        ocp = simple_mpc.FullDynamicsOCP(P.talos_full_settings(mh), mh)
+        ocp.createProblem(mh.getReferenceState(), horizon, 6, -9.81, False)
+        ms = P.talos_mpc_settings(mh, max_iters=iters)
+        gm = simple_mpc.BatchedMPC({k: ms[k] for k in P.MPC_KEYS}, ocp, batch, device_id=device_id, lib=lib)
+        gm.generateCycleHorizon(P.walk_cycle())
+        gm.switchToWalk(np.array([0.1, 0, 0, 0, 0, 0.0]))
+        return gm, mh
     mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
     for n in P.GO2_FEET:
         mh.addPointFoot(n, "root_joint")
@@ -273,16 +284,18 @@ def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     return out
 
 
-def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True):
-    """Go2 full-dynamics OCP (reference examples/go2_fulldynamics.py; the Go2 case of BASELINE's full-dynamics configuration):
-    same step definition and closed loop as the headline, joint torques as controls, dense A / B."""
+def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True, robot="go2"):
+    """Full-dynamics OCP: robot = "go2" (reference examples/go2_fulldynamics.py, 3-D contacts, H = 50) or "talos" (BASELINE
+    configs[3]: examples/talos_fulldynamics.py, 6-D contacts + wrench cones, H = 100).  Same step definition and closed loop as
+    the headline, joint torques as controls, dense A / B."""
     import numpy as np
     import torch
     from simple_mpc import presets as P
 
-    gm, mh = make_mpc("fulldynamics", batch, iters, device_id)
+    talos = robot == "talos"
+    gm, mh = make_mpc("talos" if talos else "fulldynamics", batch, iters, device_id, horizon=100 if talos else 50)
     dev = torch.device("cuda", device_id)
-    X = torch.from_numpy(P.random_states(mh, batch)).to(dev)
+    X = torch.from_numpy(P.random_states(mh, batch, scale=0.7 if talos else 1.0)).to(dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(11)
 
@@ -307,16 +320,20 @@ def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     dt = time.perf_counter() - t0
     kt = gm.kernel_times()
     H, ndx, nu, nc = gm.H, gm.ndx, gm.nu, gm.nc
+    name = "Talos" if talos else "Go2"
     out = {
-        "metric": "MPC control-steps/sec at fixed ProxDDP iters, Go2 fulldynamics H=50",
+        "metric": "MPC control-steps/sec at fixed ProxDDP iters, %s fulldynamics H=%d" % (name, H),
         "value": batch * steps / dt, "unit": "control-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": "f64",
-        "config": {"workload": "Go2 full dynamics (go2_like table, 3-D contacts), H=%d, %d ProxDDP iters/step, batch=%d, trot 10/30/10/30, "
-                   "closed loop x_meas = xs[1] + N(0,1e-3^2)" % (H, iters, batch), "finite": bool(np.all(np.isfinite(gm.info)))},
+        "config": {"workload": ("Talos full dynamics (talos_like table, nq 29 / nv 28, two 6-D feet, wrench cones), H=%d, %d ProxDDP iters/step, "
+                                "batch=%d, walk 20/80/20/80, closed loop x_meas = xs[1] + N(0,1e-3^2)" if talos else
+                                "Go2 full dynamics (go2_like table, 3-D contacts), H=%d, %d ProxDDP iters/step, batch=%d, trot 10/30/10/30, "
+                                "closed loop x_meas = xs[1] + N(0,1e-3^2)") % (H, iters, batch), "finite": bool(np.all(np.isfinite(gm.info)))},
         "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if k != "-"},
     }
     if kt.get("riccati", (0, 0))[1]:
         avg = kt["riccati"][0] / kt["riccati"][1] * 1e-3
-        lq_bytes = 8 * (2 * ndx * ndx + 2 * ndx * nu + nu * nu + 2 * ndx + nu + 2 * nc)  # dense knot read (box rows are selectors)
+        ncd = nc - 2 * nu  # dense (wrench-cone) rows
+        lq_bytes = 8 * (2 * ndx * ndx + 2 * ndx * nu + nu * nu + ncd * (ndx + nu) + 2 * ndx + nu + 2 * nc)  # dense knot read (box rows are selectors)
         rl = both_bounds(batch * H * f_ric(ndx, nu, nc), batch * H * lq_bytes, avg, "mfma")
         rl.update({"kernel": "riccati_dense_body (proximal Riccati backward sweep, dense A / B)",
                    "note": "algorithmic FLOPs = B*H*F_ric(%d,%d,%d) per launch (SURVEY 8d)" % (ndx, nu, nc), "traffic": None})
@@ -325,8 +342,17 @@ def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True):
         S, O = _oracle_imports()
         threads = O.lib().orc_num_threads()
         Bc = max(threads, 8)
-        om, rbc = S.make_full_oracle(Bc, max_iters=iters)
-        Xc = S.random_states(rbc, Bc)
+        if talos:
+            om, _, rbc = None, None, None
+            rbc = O.Robot("talos_like")
+            ms = O.talos_mpc_settings(rbc, max_iters=iters)
+            om = O.OracleFullMPC(O.Full(rbc, O.talos_full_settings(rbc)), ms, Bc)
+            om.generateCycleHorizon(O.walk_cycle())
+            om.switchToWalk(np.array([0.1, 0, 0, 0, 0, 0.0]))
+            Xc = S.talos_random_states(rbc, Bc, scale=0.7)
+        else:
+            om, rbc = S.make_full_oracle(Bc, max_iters=iters)
+            Xc = S.random_states(rbc, Bc)
         om.iterate(Xc)
         t0 = time.time()
         n = 0
@@ -377,11 +403,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch path (gloo + emulated kernel bodies): not a measurement")
-    ap.add_argument("--workload", default="kinodynamics", choices=["kinodynamics", "centroidal", "fulldynamics"],
+    ap.add_argument("--workload", default="kinodynamics", choices=["kinodynamics", "centroidal", "fulldynamics", "talos"],
                     help="kinodynamics = the headline metric (with the other single-GPU configurations measured briefly beside it at 1 GPU)")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 2 if args.dry_run else (8192 if args.gpus >= 8 else 4096)
+        args.batch = 2 if args.dry_run else (1024 if args.workload == "talos" else (8192 if args.gpus >= 8 else 4096))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args, sys.argv[1:])
@@ -427,8 +453,11 @@ def main():
     if args.workload != "kinodynamics":
         if world > 1 or dry:
             raise SystemExit("--workload %s is a single-GPU line" % args.workload)
-        fn = centroidal_line if args.workload == "centroidal" else fulldynamics_line
-        line = fn(B, args.iters, args.steps, args.warmup, local_rank, not args.no_cpu_baseline)
+        if args.workload == "centroidal":
+            line = centroidal_line(B, args.iters, args.steps, args.warmup, local_rank, not args.no_cpu_baseline)
+        else:
+            line = fulldynamics_line(B, args.iters, args.steps, args.warmup, local_rank, not args.no_cpu_baseline,
+                                     robot="talos" if args.workload == "talos" else "go2")
         line.update({"n_gpus": 1, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
         print(json.dumps(line))
         return
@@ -534,10 +563,8 @@ def main():
             other = {"fulldynamics_forward_dynamics": constraint_dynamics_line(gm, mh, B, gm.H)}
             del gm
             other["centroidal"] = centroidal_line(B, args.iters, 10, 3, local_rank, not args.no_cpu_baseline)
-            try:
-                other["fulldynamics"] = fulldynamics_line(min(B, 4096), args.iters, 10, 3, local_rank, not args.no_cpu_baseline)
-            except Exception as e:  # reported, never hidden: the headline line stands on its own
-                other["fulldynamics"] = {"error": repr(e)}
+            other["fulldynamics_go2"] = fulldynamics_line(min(B, 4096), args.iters, 10, 3, local_rank, not args.no_cpu_baseline)
+            other["fulldynamics_talos"] = fulldynamics_line(1024, args.iters, 5, 2, local_rank, not args.no_cpu_baseline, robot="talos")
             out["other_workloads"] = other
         print(json.dumps(out))
     if dist is not None:

@@ -35,7 +35,7 @@ class RobotModelHandler:
     def __init__(self, model, reference_configuration_name="standing", base_frame_name="root_joint"):
         self._ptr = model
         self._m = model.contents
-        if reference_configuration_name != "standing":
+        if reference_configuration_name not in ("standing", "half_sitting", "straight_standing"):  # the table holds one reference posture
             raise RuntimeError("unknown reference configuration %r" % reference_configuration_name)
         self._base = base_frame_name
         self._feet = []

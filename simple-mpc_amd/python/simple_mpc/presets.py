@@ -141,7 +141,7 @@ def integrate(x, dx, nq):
     return out
 
 
-def random_states(model_handler, batch, seed=20240529, scale=1.0):
+def random_states(model_handler, batch, seed=20240529, scale=1.0):  # scale: 1 for Go2; 0.7 keeps a biped near its balanced posture
     """Synthetic initial states of SURVEY 8(d): x_ref (+) N(0, diag(sigma^2)), numpy default_rng(seed)."""
     rng = np.random.default_rng(seed)
     x_ref = model_handler.getReferenceState()
