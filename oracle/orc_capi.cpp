@@ -966,6 +966,21 @@ extern "C"
   {
     return orc_timer_get(&((BatchMPCCent *)h)->timer, foot, which, out, cap);
   }
+  // FLOP instrumentation (only in the -DORC_COUNT_FLOPS build made by tools/count_flops.py; -1 otherwise)
+  void orc_flops_reset()
+  {
+#ifdef ORC_COUNT_FLOPS
+    flop_counter = 0.0;
+#endif
+  }
+  double orc_flops_get()
+  {
+#ifdef ORC_COUNT_FLOPS
+    return flop_counter;
+#else
+    return -1.0;
+#endif
+  }
   int orc_num_threads()
   {
 #ifdef _OPENMP

@@ -12,6 +12,18 @@
 #include <cstring>
 #include <vector>
 
+// FLOP instrumentation ("derivative FLOPs counted by instrumentation in the oracle"): compiled in only with
+// -DORC_COUNT_FLOPS (tools/count_flops.py builds that variant as oracle/_flops/liborc_flops.so); an FMA counts 2.
+#ifdef ORC_COUNT_FLOPS
+namespace orc
+{
+  inline thread_local double flop_counter = 0.0;
+}
+#define ORC_FLOP(n) (::orc::flop_counter += (double)(n))
+#else
+#define ORC_FLOP(n) ((void)0)
+#endif
+
 namespace orc
 {
   typedef std::vector<double> Vec;
@@ -60,6 +72,7 @@ namespace orc
         const double aik = A(i, k);
         if (aik == 0.0)
           continue;
+        ORC_FLOP(2 * B.c);
         for (int j = 0; j < B.c; j++)
           C(i, j) += aik * B(k, j);
       }
@@ -76,6 +89,7 @@ namespace orc
         const double aki = A(k, i);
         if (aki == 0.0)
           continue;
+        ORC_FLOP(2 * B.c);
         for (int j = 0; j < B.c; j++)
           C(i, j) += aki * B(k, j);
       }
@@ -84,6 +98,7 @@ namespace orc
   inline Vec mul(const Mat & A, const Vec & x)
   {
     assert(A.c == (int)x.size());
+    ORC_FLOP(2 * A.r * A.c);
     Vec y(A.r, 0.0);
     for (int i = 0; i < A.r; i++)
     {
@@ -97,6 +112,7 @@ namespace orc
   inline Vec mulT(const Mat & A, const Vec & x)
   {
     assert(A.r == (int)x.size());
+    ORC_FLOP(2 * A.r * A.c);
     Vec y(A.c, 0.0);
     for (int i = 0; i < A.r; i++)
       for (int j = 0; j < A.c; j++)
@@ -106,18 +122,21 @@ namespace orc
   inline void add_inplace(Mat & A, const Mat & B, double s = 1.0)
   {
     assert(A.r == B.r && A.c == B.c);
+    ORC_FLOP(2 * A.a.size());
     for (size_t i = 0; i < A.a.size(); i++)
       A.a[i] += s * B.a[i];
   }
   inline void axpy(Vec & y, const Vec & x, double s = 1.0)
   {
     assert(x.size() == y.size());
+    ORC_FLOP(2 * y.size());
     for (size_t i = 0; i < y.size(); i++)
       y[i] += s * x[i];
   }
   inline double dot(const Vec & a, const Vec & b)
   {
     assert(a.size() == b.size());
+    ORC_FLOP(2 * a.size());
     double s = 0;
     for (size_t i = 0; i < a.size(); i++)
       s += a[i] * b[i];
@@ -136,6 +155,7 @@ namespace orc
   inline bool cholesky(Mat & A)
   {
     const int n = A.r;
+    ORC_FLOP((double)n * n * n / 3.0);
     for (int j = 0; j < n; j++)
     {
       double d = A(j, j);
@@ -159,6 +179,7 @@ namespace orc
   inline void solve_L(const Mat & L, double * b, int stride = 1)
   {
     const int n = L.r;
+    ORC_FLOP(n * n);
     for (int i = 0; i < n; i++)
     {
       double s = b[i * stride];
@@ -171,6 +192,7 @@ namespace orc
   inline void solve_LT(const Mat & L, double * b, int stride = 1)
   {
     const int n = L.r;
+    ORC_FLOP(n * n);
     for (int i = n - 1; i >= 0; i--)
     {
       double s = b[i * stride];
@@ -198,6 +220,7 @@ namespace orc
   inline Mat inverse(const Mat & A)
   {
     const int n = A.r;
+    ORC_FLOP(2.0 * n * n * n);
     Mat M = A, I = Mat::identity(n);
     for (int col = 0; col < n; col++)
     {

@@ -17,14 +17,15 @@ namespace orc
     double operator[](int i) const { return x[i]; }
   };
   inline V3 v3(double a, double b, double c) { return V3{{a, b, c}}; }
-  inline V3 operator+(const V3 & a, const V3 & b) { return v3(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
-  inline V3 operator-(const V3 & a, const V3 & b) { return v3(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
-  inline V3 operator*(double s, const V3 & a) { return v3(s * a[0], s * a[1], s * a[2]); }
+  inline V3 operator+(const V3 & a, const V3 & b) { ORC_FLOP(3); return v3(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
+  inline V3 operator-(const V3 & a, const V3 & b) { ORC_FLOP(3); return v3(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+  inline V3 operator*(double s, const V3 & a) { ORC_FLOP(3); return v3(s * a[0], s * a[1], s * a[2]); }
   inline V3 cross(const V3 & a, const V3 & b)
   {
+    ORC_FLOP(9);
     return v3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
   }
-  inline double dot(const V3 & a, const V3 & b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+  inline double dot(const V3 & a, const V3 & b) { ORC_FLOP(5); return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
   struct M3
   {
@@ -47,6 +48,7 @@ namespace orc
   }
   inline M3 operator*(const M3 & a, const M3 & b)
   {
+    ORC_FLOP(45);
     M3 r = m3_zero();
     for (int i = 0; i < 3; i++)
       for (int j = 0; j < 3; j++)
@@ -56,6 +58,7 @@ namespace orc
   }
   inline M3 operator+(const M3 & a, const M3 & b)
   {
+    ORC_FLOP(9);
     M3 r;
     for (int i = 0; i < 9; i++)
       r.m[i] = a.m[i] + b.m[i];
@@ -63,6 +66,7 @@ namespace orc
   }
   inline M3 operator*(double s, const M3 & a)
   {
+    ORC_FLOP(9);
     M3 r;
     for (int i = 0; i < 9; i++)
       r.m[i] = s * a.m[i];
@@ -70,6 +74,7 @@ namespace orc
   }
   inline V3 operator*(const M3 & a, const V3 & v)
   {
+    ORC_FLOP(15);
     return v3(
       a(0, 0) * v[0] + a(0, 1) * v[1] + a(0, 2) * v[2], a(1, 0) * v[0] + a(1, 1) * v[1] + a(1, 2) * v[2],
       a(2, 0) * v[0] + a(2, 1) * v[1] + a(2, 2) * v[2]);
