@@ -15,7 +15,7 @@
 // Generic in the robot shape (FullDims<NJ, NF, FS>): every lane map is a strided loop, nothing assumes NV <= 20.
 #pragma once
 #include "smpc_full_model.h"
-#include "smpc_kino_kernels.h" // lanes_integrate / lanes_difference, StageKernelArgs
+#include "smpc_riccati_kino.h" // wave_block_sweep, tix; lanes_integrate / lanes_difference, StageKernelArgs
 #include <cstddef>
 
 namespace smpc
@@ -49,13 +49,16 @@ namespace smpc
     double oR[NJ * 9], op[NJ * 3], S[NV * 6], vel[NJ * 6], acc[NJ * 6], I[NJ * 10], Ic[NJ * 10], hc[NJ * 6], Fc[NJ * 6];
     double footp[NF * 3], com[3], hg[6];
     // constrained dynamics
-    double M[NV * NV];    // joint-space inertia -> its Cholesky factor
+    double M[NV * NV];    // joint-space inertia -> its inverse
     double J[NCM * NV];   // contact Jacobian (rows of absent contacts zero)
     double W[NV * NR];    // [M^-1 (S tau - nle) | M^-1 J^T]
-    double G[NCM * NCM];  // damped Delassus matrix -> its factor
+    double G[NCM * NCM];  // damped Delassus matrix
     double Gi[NCM * NCM]; // its inverse
     double IcS[NV * 6];
-    double gam[NCM], JMb[NCM], lam[NCM], rhs[NCM], dl[NCM], tmp[64];
+    double gam[NCM], JMb[NCM], lam[NCM], rhs[NCM], dl[NCM];
+    static constexpr int NVP = ((NV + 3) / 4) * 4, NCP = ((NCM + 3) / 4) * 4;
+    static constexpr int NTM = (2 * NVP + 15) / 16, NTG = (2 * NCP + 15) / 16; // tile grids of the two bordered inverses
+    double swp[2 * 4 * 16 * (NTM > NTG ? NTM : NTG)];                           // sweep operands
     double a[NV];
     double xnext[NX], e[NDX];
     // costs / constraints / multipliers
@@ -180,6 +183,127 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
     }
+  }
+
+  // C (M x N) = sum_k a(i, k) b(k, j) on the FP64 matrix cores, one wave; a / b read their operand entries (LDS), store(i, j, v)
+  // receives every entry once after the last K-step (so C may overwrite an operand).  K-steps of 4, 16 x 16 tiles.
+  template <int M, int N, int K, class FA, class FB, class FS_>
+  SMPC_DEV void fwave_gemm(FA a, FB b, FS_ store)
+  {
+    constexpr int NT = 64, TI = (M + 15) / 16, TJ = (N + 15) / 16, KS = (K + 3) / 4;
+    SMPC_ACC(acc, NT, TI * TJ);
+    SMPC_PLA(double, av, NT, TI);
+    SMPC_PLA(double, bv, NT, TJ);
+    SMPC_LANES(NT)
+    {
+#pragma unroll
+      for (int t = 0; t < TI * TJ; t++)
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+          SMPC_ACCV(acc, t, v) = 0.0;
+    }
+    SMPC_LANES_END_WAVE
+    for (int ks = 0; ks < KS; ks++)
+    {
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+        const int k = 4 * ks + lr;
+#pragma unroll
+        for (int I = 0; I < TI; I++)
+        {
+          const int i = 16 * I + lc;
+          const bool ok = i < M && k < K;
+          const double x = a(ok ? i : 0, ok ? k : 0);
+          SMPC_PLV(av)[I] = ok ? x : 0.0;
+        }
+#pragma unroll
+        for (int J = 0; J < TJ; J++)
+        {
+          const int j = 16 * J + lc;
+          const bool ok = j < N && k < K;
+          const double x = b(ok ? k : 0, ok ? j : 0);
+          SMPC_PLV(bv)[J] = ok ? x : 0.0;
+        }
+      }
+      SMPC_LANES_END_WAVE
+#pragma unroll
+      for (int I = 0; I < TI; I++)
+#pragma unroll
+        for (int J = 0; J < TJ; J++)
+          SMPC_MFMA(acc, I * TJ + J, av, I, bv, J);
+    }
+    SMPC_LANES(NT)
+    {
+      const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+      for (int I = 0; I < TI; I++)
+#pragma unroll
+        for (int J = 0; J < TJ; J++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            const int i = 16 * I + lr + 4 * v, j = 16 * J + lc;
+            if (i < M && j < N)
+              store(i, j, SMPC_ACCV(acc, I * TJ + J, v));
+          }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // A (N x N, row-major, SPD) <- A^-1 in place: Schur complement of the bordered matrix [[A, I], [I, 0]] = -A^-1, by the symmetric
+  // block sweep of the Riccati kernels (wave_block_sweep, 4 x 4 pivot blocks, rank-4 updates on the matrix cores)
+  template <int N>
+  SMPC_DEV void fwave_spd_inverse(double * A, double * swp)
+  {
+    constexpr int NT = 64, NP4 = ((N + 3) / 4) * 4, NTI = (2 * NP4 + 15) / 16, LDW = 16 * NTI;
+    SMPC_ACC(t, NT, NTI * (NTI + 1) / 2);
+    SMPC_LANES(NT)
+    {
+      const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+      for (int I = 0; I < NTI; I++)
+#pragma unroll
+        for (int J = I; J < NTI; J++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+            const int r = row < col ? row : col, c = row < col ? col : row;
+            double val = 0.0;
+            if (c < N)
+              val = A[r * N + c];
+            else if (c < NP4)
+              val = r == c ? 1.0 : 0.0;       // padding pivots
+            else if (c < 2 * NP4 && r < NP4)
+              val = (c - NP4 == r) ? 1.0 : 0.0; // identity border
+            SMPC_ACCV(t, tix<NTI>(I, J), v) = val;
+          }
+    }
+    SMPC_LANES_END_WAVE
+    double * prof = nullptr;
+    long long tprev = 0;
+    wave_block_sweep<NT, NTI, false, 0, NP4 / 4>(t, swp, swp + 4 * LDW, prof, tprev);
+    SMPC_LANES(NT)
+    {
+      const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+      for (int I = NP4 / 16; I < NTI; I++)
+#pragma unroll
+        for (int J = I; J < NTI; J++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            const int row = 16 * I + lr + 4 * v - NP4, col = 16 * J + lc - NP4;
+            if (row >= 0 && row < N && col >= row && col < N)
+            {
+              const double val = -SMPC_ACCV(t, tix<NTI>(I, J), v);
+              A[row * N + col] = val;
+              A[col * N + row] = val;
+            }
+          }
+    }
+    SMPC_LANES_END_WAVE
   }
 
   // -------------------------------------------------------------------------------------------------------------
@@ -478,43 +602,31 @@ namespace smpc
     SMPC_LANES_END_WAVE
     }
     ftick(fp, 3);
-    // ---- M = L L^T ; W = M^-1 [S tau - nle | J^T] ----
-    fwave_cholesky<NT, NV>(sc.M, sc.tmp);
-    SMPC_LANES(NT)
-    for (int idx = lane; idx < NV * NCM; idx += NT)
-    {
-      const int k = idx / NCM, c = idx % NCM;
-      sc.W[k * NR + 1 + c] = sc.J[c * NV + k];
-    }
-    SMPC_LANES_END_WAVE
-    fwave_chol_solve<NT, NV>(sc.M, sc.W, NR, NR);
+    // ---- M <- M^-1 (bordered symmetric sweep) ; W = M^-1 [S tau - nle | J^T] on the matrix cores ----
+    fwave_spd_inverse<NV>(sc.M, sc.swp);
+    fwave_gemm<NV, NR, NV>(
+      [&](int i, int k) { return sc.M[k * NV + i]; },                                     // symmetric: read along the row of k
+      [&](int k, int j) { return j == 0 ? sc.W[k * NR] : sc.J[(j - 1) * NV + k]; },       // [b | J^T]
+      [&](int i, int j, double v) { sc.W[i * NR + j] = v; });
     ftick(fp, 4);
     // ---- damped Delassus matrix (unit diagonal on the rows of absent contacts), its inverse, J M^-1 b ----
     const int nc = FS * __builtin_popcount(mask & ((1u << NF) - 1u));
-    SMPC_LANES(NT)
     {
-      for (int idx = lane; idx < NCM * NCM; idx += NT)
-      {
-        const int c = idx / NCM, d = idx % NCM;
-        double acc = 0.0;
-        for (int k = 0; k < NV; k++)
-          acc += sc.J[c * NV + k] * sc.W[k * NR + 1 + d];
-        if (c == d)
-          acc += c < nc ? h.prox_mu : 1.0;
-        sc.G[idx] = acc;
-        sc.Gi[idx] = c == d ? 1.0 : 0.0;
-      }
-      if (lane < NCM)
-      {
-        double acc = 0.0;
-        for (int k = 0; k < NV; k++)
-          acc += sc.J[lane * NV + k] * sc.W[k * NR];
-        sc.JMb[lane] = acc;
-      }
+      const double pmu = h.prox_mu;
+      fwave_gemm<NCM, NR, NV>(
+        [&](int i, int k) { return sc.J[i * NV + k]; }, [&](int k, int j) { return sc.W[k * NR + j]; },
+        [&](int i, int j, double v) {
+          if (j == 0)
+            sc.JMb[i] = v;
+          else
+          {
+            const double g = v + (i == j - 1 ? (i < nc ? pmu : 1.0) : 0.0);
+            sc.G[i * NCM + j - 1] = g;
+            sc.Gi[i * NCM + j - 1] = g;
+          }
+        });
     }
-    SMPC_LANES_END_WAVE
-    fwave_cholesky<NT, NCM>(sc.G, sc.tmp);
-    fwave_chol_solve<NT, NCM>(sc.G, sc.Gi, NCM, NCM);
+    fwave_spd_inverse<NCM>(sc.Gi, sc.swp);
     ftick(fp, 5);
     // ---- proximal iteration:  lam <- G^-1 (mu lam - gamma - J M^-1 b)  until |d lam|_inf <= accuracy ----
     int iters = 0;
@@ -1266,54 +1378,22 @@ namespace smpc
     }
     ftick(fp, 11);
     // ---- [M -J^T; J mu] [da; dlam] = -[r1; r2]:  Mr = M^-1 R1 ; rhs = J Mr - r2 ; dlam = G^-1 rhs ; da = -Mr + M^-1 J^T dlam ----
-    fwave_chol_solve<NT, NV>(sc.M, sd.R1, NCOL, NCOL);
-    SMPC_LANES(NT)
-    for (int idx = lane; idx < NCM * NCOL; idx += NT)
-    {
-      const int c = idx / NCOL, j = idx % NCOL;
-      double acc = -sd.JT[idx];
-      for (int k = 0; k < NV; k++)
-        acc += sc.J[c * NV + k] * sd.R1[k * NCOL + j];
-      sd.JT[idx] = acc;
-    }
-    SMPC_LANES_END_WAVE
-    for (int c0 = 0; c0 < NCOL; c0 += NT)
-    {
-      SMPC_LANES(NT)
-      {
-        const int j = c0 + lane < NCOL ? c0 + lane : c0;
-        double r[NCM], o[NCM];
-#pragma unroll
-        for (int c = 0; c < NCM; c++)
-          r[c] = sd.JT[c * NCOL + j];
-#pragma unroll
-        for (int c = 0; c < NCM; c++)
-        {
-          double acc = 0.0;
-#pragma unroll
-          for (int d = 0; d < NCM; d++)
-            acc += sc.Gi[c * NCM + d] * r[d];
-          o[c] = acc;
-        }
-        if (c0 + lane < NCOL)
-        {
-#pragma unroll
-          for (int c = 0; c < NCM; c++)
-            sd.JT[c * NCOL + j] = o[c];
-        }
-      }
-      SMPC_LANES_END_WAVE
-    }
-    SMPC_LANES(NT)
-    for (int idx = lane; idx < NV * NCOL; idx += NT)
-    {
-      const int k = idx / NCOL, j = idx % NCOL;
-      double acc = -sd.R1[idx];
-      for (int c = 0; c < NCM; c++)
-        acc += sc.W[k * NR + 1 + c] * sd.JT[c * NCOL + j];
-      sd.R1[idx] = acc;
-    }
-    SMPC_LANES_END_WAVE
+    // Mr = M^-1 R1 (in place)
+    fwave_gemm<NV, NCOL, NV>(
+      [&](int i, int k) { return sc.M[k * NV + i]; }, [&](int k, int j) { return sd.R1[k * NCOL + j]; },
+      [&](int i, int j, double v) { sd.R1[i * NCOL + j] = v; });
+    // rhs = J Mr - r2 (in place on the force rows of JT)
+    fwave_gemm<NCM, NCOL, NV>(
+      [&](int i, int k) { return sc.J[i * NV + k]; }, [&](int k, int j) { return sd.R1[k * NCOL + j]; },
+      [&](int i, int j, double v) { sd.JT[i * NCOL + j] = v - sd.JT[i * NCOL + j]; });
+    // dlam = G^-1 rhs (in place)
+    fwave_gemm<NCM, NCOL, NCM>(
+      [&](int i, int k) { return sc.Gi[k * NCM + i]; }, [&](int k, int j) { return sd.JT[k * NCOL + j]; },
+      [&](int i, int j, double v) { sd.JT[i * NCOL + j] = v; });
+    // da = -Mr + M^-1 J^T dlam (in place on R1)
+    fwave_gemm<NV, NCOL, NCM>(
+      [&](int i, int k) { return sc.W[i * NR + 1 + k]; }, [&](int k, int j) { return sd.JT[k * NCOL + j]; },
+      [&](int i, int j, double v) { sd.R1[i * NCOL + j] = v - sd.R1[i * NCOL + j]; });
     ftick(fp, 12);
     (void)NGN;
   }

@@ -225,3 +225,18 @@ def talos_random_states(rb, batch, seed=20240529, scale=1.0):
     rng = np.random.default_rng(seed)
     sg = np.concatenate([np.ones(3) * 0.02, np.ones(3) * 0.05, np.ones(rb.nv - 6) * 0.1, np.ones(3) * 0.1, np.ones(3) * 0.2, np.ones(rb.nv - 6) * 0.5])
     return np.stack([rb.integrate(rb.x_ref, rng.normal(size=rb.ndx) * sg * scale) for _ in range(batch)])
+
+
+def alphas_agree(om, gm, rtol=1e-8):
+    """Line-search decisions of oracle and product: identical, except where the Armijo test itself is decided by rounding -- then
+    the side that accepted the larger step must have done so with a slack below rtol * |phi0| (info: phi0, dphi0, alpha, phi_new)."""
+    io, ig = om.info, gm.info
+    for b in range(io.shape[0]):
+        ao, ag = io[b, 2], ig[b, 2]
+        if ao == ag:
+            continue
+        big = io[b] if ao > ag else ig[b]
+        slack = big[0] + 1e-4 * big[2] * big[1] - big[3]
+        if not (0.0 <= slack <= rtol * max(1.0, abs(big[0]))):
+            return False
+    return True

@@ -30,7 +30,7 @@ def _closed_loop(lib, iters, steps, B=3, horizon=50, check_knots=False, **kw):
         assert e < TOL, (step, e)
         assert S.rel_err(om.us, gm.us) < 10 * TOL, (step, S.rel_err(om.us, gm.us))
         assert S.rel_err(om.K0, gm.K0) < TOL, (step, S.rel_err(om.K0, gm.K0))
-        assert np.array_equal(om.info[:, 2], gm.info[:, 2]), "line-search step sizes differ"
+        assert S.alphas_agree(om, gm), ("line-search step sizes differ", om.info[:, :4], gm.info[:, :4])
         assert S.rel_err(om.foot_refs, gm.getReferencePoses()) < 1e-12
         X = om.xs[:, 1, :].copy()
     return om, gm, rb, worst

@@ -25,7 +25,7 @@ def _loop(om, gm, rb, steps, scale=0.7, B=2, expect_cones=False):
         worst = max(worst, e)
         assert e < TOL, (step, e)
         assert S.rel_err(om.us, gm.us) < 10 * TOL and S.rel_err(om.K0, gm.K0) < TOL
-        assert np.array_equal(om.info[:, 2], gm.info[:, 2]), "line-search step sizes differ"
+        assert S.alphas_agree(om, gm), ("line-search step sizes differ", om.info[:, :4], gm.info[:, :4])
         assert S.rel_err(om.foot_refs, gm.getReferencePoses()) < 1e-12
         nb = 2 * gm.nu
         assert S.rel_err(om.vs, gm.vs) < 1e-3  # multipliers = residual / mu: rounding of the residual times 1e8
