@@ -77,6 +77,7 @@ namespace smpc
     bool aux_launches = false;
     std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
     static constexpr int LS_SLOTS = 64;
+    static constexpr int TRIAL_MINW = D::NV <= 20 ? 2 : 1; // waves per SIMD the evaluation kernel's register budget is capped for
     static constexpr double ARMIJO_C1 = 1e-4, REG_INIT = 1e-9, REG_MIN = 1e-10, REG_MAX = 1e9, REG_INC = 10.0, REG_DEC = 1.0 / 3.0, STALL_REL = 1e-9;
     double ref_foot_pos[D::NF][3];
 
@@ -317,13 +318,13 @@ namespace smpc
       StageKernelArgs<D> sk = stage_args(b);
       sk.j0 = 0;
       sk.nj = 1;
-      timed_launch<StageKernelArgs<D>, fdyn_trial_body<D>, 64>(KID_TRIAL, b.B * (H + 1), sk);
+      timed_launch<StageKernelArgs<D>, fdyn_trial_body<D>, 64, TRIAL_MINW>(KID_TRIAL, b.B * (H + 1), sk);
       timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, 0, 1));
       const int slots = launch_backtracking(b);
       sk.slots = slots;
       sk.j0 = 1;
       sk.nj = D::LS_N - 1;
-      timed_launch<StageKernelArgs<D>, fdyn_trial_body<D>, 64>(KID_SELECT, slots * (H + 1), sk, true);
+      timed_launch<StageKernelArgs<D>, fdyn_trial_body<D>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
       timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, 1, D::LS_N - 1));
       timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B, solver_args(b));
     }
@@ -366,7 +367,7 @@ namespace smpc
         StageKernelArgs<D> sk = stage_args(b, slots);
         sk.j0 = 1;
         sk.nj = D::LS_N - 1;
-        timed_launch<StageKernelArgs<D>, fdyn_trial_body<D>, 64>(KID_SELECT, slots * (H + 1), sk, true);
+        timed_launch<StageKernelArgs<D>, fdyn_trial_body<D>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
         timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, nb, solver_args(b, 1, D::LS_N - 1));
         sa.mode = 0;
         timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_SELECT, slots, sa, true);

@@ -49,40 +49,55 @@ namespace smpc
     double oR[NJ * 9], op[NJ * 3], S[NV * 6], vel[NJ * 6], acc[NJ * 6], I[NJ * 10], Ic[NJ * 10], hc[NJ * 6], Fc[NJ * 6];
     double footp[NF * 3], com[3], hg[6];
     // constrained dynamics
+    // (one contiguous block: dead after the derivative solves, it then takes the momentum / foot-pose rows of the stacked
+    //  Gauss-Newton Jacobian, see jt2_())
     double M[NV * NV];    // joint-space inertia -> its inverse
     double J[NCM * NV];   // contact Jacobian (rows of absent contacts zero)
     double W[NV * NR];    // [M^-1 (S tau - nle) | M^-1 J^T]
-    double G[NCM * NCM];  // damped Delassus matrix
-    double Gi[NCM * NCM]; // its inverse
+    double Gi[NCM * NCM]; // damped Delassus matrix -> its inverse
     double IcS[NV * 6];
+    static constexpr int DYN_DOUBLES = NV * NV + NCM * NV + NV * NR + NCM * NCM + NV * 6;
+    static_assert(DYN_DOUBLES >= (NGN - NCM) * NCOL, "the momentum / pose rows of the Gauss-Newton Jacobian fit the dead dynamics block");
+    SMPC_HD double * jt2_() { return M; } // rows NCM .. NGN-1 of the stacked Jacobian, [NGN - NCM][NCOL]
     double gam[NCM], JMb[NCM], lam[NCM], rhs[NCM], dl[NCM];
+    double rotl[NF * 3]; // log3 of the foot rotations (6-D contacts: angular part of the corrector)
     static constexpr int NVP = ((NV + 3) / 4) * 4, NCP = ((NCM + 3) / 4) * 4;
     static constexpr int NTM = (2 * NVP + 15) / 16, NTG = (2 * NCP + 15) / 16; // tile grids of the two bordered inverses
-    double swp[2 * 4 * 16 * (NTM > NTG ? NTM : NTG)];                           // sweep operands
+    static constexpr int SWP_DOUBLES = 2 * 4 * 16 * (NTM > NTG ? NTM : NTG);     // sweep operands
     double a[NV];
+    // ---- "late block": written only after the dynamics phases (integration, residuals, multipliers, reductions); until then its
+    //      head serves as the operand scratch of the two bordered inverses, see swp_() ----
     double xnext[NX], e[NDX];
     // costs / constraints / multipliers
     double rx[NDX], Wrx[NDX], ru[NU], Wru[NU], Whg[6], rf[NF * D::PF], Wrf[NF * D::PF], rl[NCM], Wrl[NCM];
-    double rotl[NF * 3]; // log3 of the foot rotations (6-D contacts: angular part of the corrector)
     double cval[NC], vplus[NC], lamp[NDX];
     int act[NC + NC % 2];
     double part[64], part2[64], part8[16], red[4];
     int iters_[2];
+    SMPC_HD double * swp_() { return xnext; } // (size checked where the inverses are called)
   };
   template <class D>
   struct FullScratchDeriv
   {
     static constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX;
     static constexpr int NCOL = 2 * NV + NU, NGN = 6 + D::PF * NF + NCM;
-    double Bc[NJ * 36], dk[NV * 6], Ak[NV * 6], Fgc[NJ * 6], Wc[NF * 6];
+    double Bc[NJ * 36], dk[NV * 6], Ak[NV * 6], Wc[NF * 6];
     double R1[NV * NCOL];       // [r1q | r1v | r1t] -> M^-1 R1 -> [da_dq | da_dv | da_dtau]
-    double JT[NGN * NCOL];      // stacked Gauss-Newton Jacobian; rows 0..NCM-1: [r2q | r2v | 0] -> [dlam_dq | dlam_dv | dlam_dtau]
-    double Ag[6 * NV];
-    double Je3[9], JeQ[9], Jq[36], Jl[36], WJl[NDX * 6], JWJ[36];
-    double gx[NDX], gu[NU]; // cost gradients
-    double Jlf[NF * 36];    // Jlog6 of the foot-placement residuals (6-D feet)
-    double yc[NCM + 1], cq[NDX + NU]; // cone rows: A_cone^T nu per contact, and its image (C_x^T nu ; C_u^T nu)
-    double dual[128];
+    double JT[NCM * NCOL];      // force rows of the stacked Gauss-Newton Jacobian: [r2q | r2v | 0] -> [dlam_dq | dlam_dv | dlam_dtau]
+                                // (the momentum / foot-pose rows live in the dead dynamics block of the evaluation scratch)
+    double Je3[9], JeQ[9], Jq[36], Jl[36];
+    double Jlf[D::FS == 6 ? NF * 36 : 2]; // Jlog6 of the foot-placement residuals (6-D feet)
+    // tables of the assembly phases: they live in the composite velocity-product matrices, dead once R1 is formed
+    //   WJl (NDX x 6), JWJ (36): state-cost tables ; gx, gu: cost gradients ; cq: (C_x^T nu ; C_u^T nu) of the cone rows ;
+    //   yc: A_cone^T nu per contact ; dual: stacked weighted residual
+    SMPC_HD double * WJl_() const { return const_cast<double *>(Bc); }
+    SMPC_HD double * JWJ_() const { return WJl_() + NDX * 6; }
+    SMPC_HD double * gx_() const { return JWJ_() + 36; }
+    SMPC_HD double * gu_() const { return gx_() + NDX; }
+    SMPC_HD double * cq_() const { return gu_() + NU; }
+    SMPC_HD double * yc_() const { return cq_() + NDX + NU; }
+    SMPC_HD double * dual_() const { return yc_() + NCM + 1; }
+    static_assert(NDX * 6 + 36 + NDX + NU + NDX + NU + NCM + 1 + NGN <= NJ * 36, "assembly tables fit the dead Bc block");
   };
 
   // copy the head of the device model into LDS (all loads in flight before the first store)
@@ -461,21 +476,6 @@ namespace smpc
         st3(&sc.hg[0], h0.l);
         st3(&sc.hg[3], h0.a - cross(com, h0.l));
       }
-      if constexpr (DERIV)
-      {
-        if (lane < NV)
-        {
-          const int k = lane, j = jof(k);
-          const SV c = ldsi(&sc.Ic[j * 10]) * ldsv(&sc.S[k * 6]);
-          const V3 ang = c.a - cross(com, c.l);
-          sd->Ag[0 * NV + k] = c.l.x;
-          sd->Ag[1 * NV + k] = c.l.y;
-          sd->Ag[2 * NV + k] = c.l.z;
-          sd->Ag[3 * NV + k] = ang.x;
-          sd->Ag[4 * NV + k] = ang.y;
-          sd->Ag[5 * NV + k] = ang.z;
-        }
-      }
     }
     SMPC_LANES_END_WAVE
     ftick(fp, 2);
@@ -603,7 +603,8 @@ namespace smpc
     }
     ftick(fp, 3);
     // ---- M <- M^-1 (bordered symmetric sweep) ; W = M^-1 [S tau - nle | J^T] on the matrix cores ----
-    fwave_spd_inverse<NV>(sc.M, sc.swp);
+    static_assert(sizeof(SC) - offsetof(SC, xnext) >= SC::SWP_DOUBLES * sizeof(double), "the sweep scratch fits the late block");
+    fwave_spd_inverse<NV>(sc.M, sc.swp_());
     fwave_gemm<NV, NR, NV>(
       [&](int i, int k) { return sc.M[k * NV + i]; },                                     // symmetric: read along the row of k
       [&](int k, int j) { return j == 0 ? sc.W[k * NR] : sc.J[(j - 1) * NV + k]; },       // [b | J^T]
@@ -620,13 +621,11 @@ namespace smpc
             sc.JMb[i] = v;
           else
           {
-            const double g = v + (i == j - 1 ? (i < nc ? pmu : 1.0) : 0.0);
-            sc.G[i * NCM + j - 1] = g;
-            sc.Gi[i * NCM + j - 1] = g;
+            sc.Gi[i * NCM + j - 1] = v + (i == j - 1 ? (i < nc ? pmu : 1.0) : 0.0);
           }
         });
     }
-    fwave_spd_inverse<NCM>(sc.Gi, sc.swp);
+    fwave_spd_inverse<NCM>(sc.Gi, sc.swp_());
     ftick(fp, 5);
     // ---- proximal iteration:  lam <- G^-1 (mu lam - gamma - J M^-1 b)  until |d lam|_inf <= accuracy ----
     int iters = 0;
@@ -801,7 +800,7 @@ namespace smpc
   // x+ (semi-implicit Euler), defect, residuals, weighted residuals, cost, constraint values, AL multipliers, merit pieces.
   // Results: sc.red[0] cost, sc.red[1] penalty part of the merit, sc.red[2] primal infeasibility.
   template <class D, bool DERIV, class SC, class SD>
-  SMPC_DEV void full_eval_tail(SC & sc, SD * sd, const DevModel<D> & mg, unsigned mask, bool term, const double * lam_e, const double * nu_e)
+  SMPC_DEV void full_eval_tail(SC & sc, SD * sd, const DevModel<D> & mg, unsigned mask, bool term, const double * lam_e, const double * nu_e, FullProf * fpp = nullptr)
   {
     constexpr int NT = 64;
     constexpr int NV = D::NV, NQ = D::NQ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX, NC = D::NC, NA = D::NA, FS = D::FS, NX = D::NX;
@@ -819,11 +818,13 @@ namespace smpc
         sc.xnext[NQ + i] = vq[i] + dt * (term ? 0.0 : sc.a[i]);
     }
     SMPC_LANES_END_WAVE
+    if (fpp) ftick(*fpp, 20);
     if (!term)
     {
       SMPC_LANES(NT)
       lanes_difference<D>(sc.xn1, sc.xnext, sc.e, lane, 61);
       SMPC_LANES_END_WAVE
+    if (fpp) ftick(*fpp, 21);
     }
     // ---- residuals and constraint values ----
     SMPC_LANES(NT)
@@ -904,6 +905,7 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
+    if (fpp) ftick(*fpp, 22);
     // ---- weighted residuals ----
     SMPC_LANES(NT)
     {
@@ -957,6 +959,7 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
+    if (fpp) ftick(*fpp, 23);
     // ---- cost: lane-strided partial sums, fixed-order reduction ----
     SMPC_LANES(NT)
     {
@@ -995,6 +998,7 @@ namespace smpc
       sc.red[0] = 0.5 * c;
     }
     SMPC_LANES_END_WAVE
+    if (fpp) ftick(*fpp, 24);
     if (term)
       return;
     // ---- AL multipliers (SolverProxDDP computeMultipliers), merit penalty, primal infeasibility ----
@@ -1066,6 +1070,88 @@ namespace smpc
 
 namespace smpc
 {
+  // Momentum and foot-pose rows of the stacked Gauss-Newton Jacobian (rows NCM .. NGN-1): written into the dynamics block of the
+  // evaluation scratch (M | J | W | Gi | IcS), which is dead once the derivative solves are done (terminal node: never used).
+  template <class D, class SC, class SD>
+  SMPC_DEV void full_gn_rows(SC & sc, SD & sd, bool term)
+  {
+    constexpr int NT = 64;
+    constexpr int NV = D::NV, NF = D::NF, NU = D::NU, NCOL = SC::NCOL, FS = D::FS;
+    const FullHead<D> & h = sc.h;
+    SMPC_LANES(NT)
+    if (lane < NV)
+    {
+      const int k = lane, i = jof(k);
+      const SV s = ldsv(&sc.S[k * 6]);
+      const SV d = ldsv(&sd.dk[k * 6]);
+      const SI Ici = ldsi(&sc.Ic[i * 10]);
+      const SV hci = ldsv(&sc.hc[i * 6]);
+      const SV dh = crf(s, hci) + Ici * d;
+      const V3 com = ld3(sc.com);
+      const V3 jc = (1.0 / h.total_mass) * (Ici * s).l;
+      const SV h0 = ldsv(&sc.hc[0]);
+      const V3 dha = dh.a - cross(com, dh.l) - cross(jc, h0.l);
+      double * jc6 = sc.jt2_();
+      jc6[0 * NCOL + k] = dh.l.x;
+      jc6[1 * NCOL + k] = dh.l.y;
+      jc6[2 * NCOL + k] = dh.l.z;
+      jc6[3 * NCOL + k] = dha.x;
+      jc6[4 * NCOL + k] = dha.y;
+      jc6[5 * NCOL + k] = dha.z;
+      {
+        // centroidal map column: (Ic_i S_k) translated to the CoM
+        const SV c = Ici * s;
+        const V3 ang = c.a - cross(com, c.l);
+        const double agc[6] = {c.l.x, c.l.y, c.l.z, ang.x, ang.y, ang.z};
+        for (int r = 0; r < 6; r++)
+        {
+          jc6[r * NCOL + NV + k] = agc[r];
+          if (k < NU)
+            jc6[r * NCOL + 2 * NV + k] = 0.0;
+        }
+      }
+      double * jf = sc.jt2_() + 6 * NCOL;
+      constexpr int PF = D::PF;
+      for (int f = 0; f < NF; f++)
+      {
+        const bool on = (h.anc[h.foot_joint[f]] >> i) & 1u;
+        V3 c = mk3(0, 0, 0);
+        if (on)
+          c = s.l + cross(s.a, ld3(&sc.footp[f * 3]));
+        if constexpr (FS == 3)
+        {
+          jf[(3 * f + 0) * NCOL + k] = c.x;
+          jf[(3 * f + 1) * NCOL + k] = c.y;
+          jf[(3 * f + 2) * NCOL + k] = c.z;
+        }
+        else
+        {
+          // FramePlacementResidual: Jlog6(M_ref^-1 oMf) * (LOCAL 6-D frame Jacobian column)
+          double col[6] = {0, 0, 0, 0, 0, 0};
+          if (on && !term)
+          {
+            const M3 Rf = ldm3(&sc.oR[h.foot_joint[f] * 9]);
+            const V3 lin = tmul(Rf, c), ang = tmul(Rf, s.a);
+            const double lv[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z};
+            const double * Jl = &sd.Jlf[f * 36];
+            for (int r = 0; r < 6; r++)
+              for (int m = 0; m < 6; m++)
+                col[r] += Jl[r * 6 + m] * lv[m];
+          }
+          for (int r = 0; r < 6; r++)
+            jf[(6 * f + r) * NCOL + k] = col[r];
+        }
+        for (int r = 0; r < PF; r++)
+        {
+          jf[(PF * f + r) * NCOL + NV + k] = 0.0;
+          if (k < NU)
+            jf[(PF * f + r) * NCOL + 2 * NV + k] = 0.0;
+        }
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
   // -------------------------------------------------------------------------------------------------------------
   // Derivative phases.  In: everything full_dynamics_phases / full_eval_tail left in the scratch.  Out (sd):
   //   R1 = [da_dq | da_dv | da_dtau] (NV x NCOL),  JT rows: [dlam_* (NCM) ; centroidal momentum (6) ; foot positions (3 NF)],
@@ -1133,12 +1219,12 @@ namespace smpc
           for (int f = 0; f < NF; f++)
             if ((h.anc[h.foot_joint[f]] >> i) & 1u)
               F = F - ldsv(&sd.Wc[f * 6]);
-        stsv(&sd.Fgc[i * 6], F);
+        stsv(&sc.I[i * 6], F); // (the body inertias are dead: their block takes the composite forces)
       }
       SMPC_LANES_END_WAVE
     }
     ftick(fp, 8);
-    // ---- per dof: d_k, A_k ; centroidal-momentum and foot-position Jacobian columns (rows NCM .. of JT) ----
+    // ---- per dof: d_k, A_k ; ----
     SMPC_LANES(NT)
     if (lane < NV)
     {
@@ -1153,70 +1239,15 @@ namespace smpc
       }
       stsv(&sd.dk[k * 6], d);
       stsv(&sd.Ak[k * 6], A);
-      const SI Ici = ldsi(&sc.Ic[i * 10]);
-      const SV hci = ldsv(&sc.hc[i * 6]);
-      const SV dh = crf(s, hci) + Ici * d;
-      const V3 com = ld3(sc.com);
-      const V3 jc = (1.0 / h.total_mass) * (Ici * s).l;
-      const SV h0 = ldsv(&sc.hc[0]);
-      const V3 dha = dh.a - cross(com, dh.l) - cross(jc, h0.l);
-      double * jc6 = &sd.JT[NCM * NCOL];
-      jc6[0 * NCOL + k] = dh.l.x;
-      jc6[1 * NCOL + k] = dh.l.y;
-      jc6[2 * NCOL + k] = dh.l.z;
-      jc6[3 * NCOL + k] = dha.x;
-      jc6[4 * NCOL + k] = dha.y;
-      jc6[5 * NCOL + k] = dha.z;
-      for (int r = 0; r < 6; r++)
-      {
-        jc6[r * NCOL + NV + k] = sd.Ag[r * NV + k];
-        if (k < NU)
-          jc6[r * NCOL + 2 * NV + k] = 0.0;
-      }
-      double * jf = &sd.JT[(NCM + 6) * NCOL];
-      constexpr int PF = D::PF;
-      for (int f = 0; f < NF; f++)
-      {
-        const bool on = (h.anc[h.foot_joint[f]] >> i) & 1u;
-        V3 c = mk3(0, 0, 0);
-        if (on)
-          c = s.l + cross(s.a, ld3(&sc.footp[f * 3]));
-        if constexpr (FS == 3)
-        {
-          jf[(3 * f + 0) * NCOL + k] = c.x;
-          jf[(3 * f + 1) * NCOL + k] = c.y;
-          jf[(3 * f + 2) * NCOL + k] = c.z;
-        }
-        else
-        {
-          // FramePlacementResidual: Jlog6(M_ref^-1 oMf) * (LOCAL 6-D frame Jacobian column)
-          double col[6] = {0, 0, 0, 0, 0, 0};
-          if (on && !term)
-          {
-            const M3 Rf = ldm3(&sc.oR[h.foot_joint[f] * 9]);
-            const V3 lin = tmul(Rf, c), ang = tmul(Rf, s.a);
-            const double lv[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z};
-            const double * Jl = &sd.Jlf[f * 36];
-            for (int r = 0; r < 6; r++)
-              for (int m = 0; m < 6; m++)
-                col[r] += Jl[r * 6 + m] * lv[m];
-          }
-          for (int r = 0; r < 6; r++)
-            jf[(6 * f + r) * NCOL + k] = col[r];
-        }
-        for (int r = 0; r < PF; r++)
-        {
-          jf[(PF * f + r) * NCOL + NV + k] = 0.0;
-          if (k < NU)
-            jf[(PF * f + r) * NCOL + 2 * NV + k] = 0.0;
-        }
-      }
     }
     SMPC_LANES_END_WAVE
     static_assert(NU <= NV, "tau columns are zeroed by the dof lanes");
     ftick(fp, 9);
     if (term)
+    {
+      full_gn_rows<D>(sc, sd, true);
       return;
+    }
     // ---- partial derivatives of RNEA(q, v, a) - J^T lam at the solution: R1 = [r1q | r1v | -S] ----
     SMPC_LANES(NT)
     {
@@ -1258,7 +1289,7 @@ namespace smpc
           const SV hcs = ldsv(&sc.hc[s * 6]);
           SV Xq = Ics * A + SV{mk3(o1[0], o1[1], o1[2]), mk3(o1[3], o1[4], o1[5])} + crf(d, hcs);
           if (below)
-            Xq = Xq + crf(Sk, ldsv(&sd.Fgc[i * 6]));
+            Xq = Xq + crf(Sk, ldsv(&sc.I[i * 6]));
           const SV Xv = SV{mk3(o2[0], o2[1], o2[2]), mk3(o2[3], o2[4], o2[5])} + crf(Sk, hcs) + Ics * (crm(ldsv(&sc.vel[i * 6]), Sk) + d);
           vq = sv_dot6(Sm, Xq);
           vv = sv_dot6(Sm, Xv);
@@ -1394,6 +1425,7 @@ namespace smpc
     fwave_gemm<NV, NCOL, NCM>(
       [&](int i, int k) { return sc.W[i * NR + 1 + k]; }, [&](int k, int j) { return sd.JT[k * NCOL + j]; },
       [&](int i, int j, double v) { sd.R1[i * NCOL + j] = v - sd.R1[i * NCOL + j]; });
+    full_gn_rows<D>(sc, sd, false);
     ftick(fp, 12);
     (void)NGN;
   }
@@ -1424,8 +1456,8 @@ namespace smpc
     if (i >= 6 && j >= 6)
       return h.w_diag ? (i == j ? h.wxd[i] : 0.0) : mg.w_x[i * NDX + j];
     if (i < 6 && j < 6)
-      return sd.JWJ[i * 6 + j];
-    return i < 6 ? sd.WJl[j * 6 + i] : sd.WJl[i * 6 + j];
+      return sd.JWJ_()[i * 6 + j];
+    return i < 6 ? sd.WJl_()[j * 6 + i] : sd.WJl_()[i * 6 + j];
   }
 
   // tables of the state cost: WJl = w_x[:, 0:6] Jl (NDX x 6), JWJ = Jl^T w_x[0:6, 0:6] Jl
@@ -1445,7 +1477,7 @@ namespace smpc
       else
         for (int b = 0; b < 6; b++)
           s += mg.w_x[a * NDX + b] * sd.Jl[b * 6 + k];
-      sd.WJl[idx] = s;
+      sd.WJl_()[idx] = s;
     }
     SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
@@ -1454,8 +1486,8 @@ namespace smpc
       const int i = lane / 6, j = lane % 6;
       double s = 0.0;
       for (int a = 0; a < 6; a++)
-        s += sd.Jl[a * 6 + i] * sd.WJl[a * 6 + j];
-      sd.JWJ[lane] = s;
+        s += sd.Jl[a * 6 + i] * sd.WJl_()[a * 6 + j];
+      sd.JWJ_()[lane] = s;
     }
     SMPC_LANES_END_WAVE
   }
@@ -1515,7 +1547,8 @@ namespace smpc
         {
           const int c = 16 * J + lc;
           const bool ok = r < NGN && c < NCOL && (!term || (r >= D::NCM && r < D::NCM + 6)); // terminal node: momentum rows only
-          const double v = sd.JT[(ok ? r : D::NCM) * NCOL + (c < NCOL ? c : 0)];
+          const double * row = (ok && r < D::NCM) ? &sd.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL;
+          const double v = row[c < NCOL ? c : 0];
           SMPC_PLV(jtv)[J] = ok ? v : 0.0;
         }
 #pragma unroll
@@ -1546,7 +1579,8 @@ namespace smpc
           {
             const int c = 16 * J + lc;
             const bool ok = r < NGN && c < NCOL && (!term || (r >= D::NCM && r < D::NCM + 6));
-            const double x = sd.JT[(ok ? r : D::NCM) * NCOL + (c < NCOL ? c : 0)];
+            const double * row = (ok && r < D::NCM) ? &sd.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL;
+            const double x = row[c < NCOL ? c : 0];
             SMPC_PLV(jtv)[J] = ok ? x : 0.0;
             SMPC_PLV(bv)[J] = SMPC_ACCV(wj, R * NTC + J, v);
           }
@@ -1650,7 +1684,7 @@ namespace smpc
     fp.tprev = SMPC_CLOCK();
     ftick(fp, 0);
     full_dynamics_phases<D, true>(sc, &sd, mg, mask, !term, fp);
-    full_eval_tail<D, true>(sc, &sd, mg, mask, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+    full_eval_tail<D, true>(sc, &sd, mg, mask, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC, &fp);
     ftick(fp, 7);
     full_deriv_phases<D>(sc, sd, mg, mask, term, fp);
     ftick(fp, 13);
@@ -1660,7 +1694,7 @@ namespace smpc
     SMPC_LANES(NT)
     {
       for (int r = lane; r < NGN; r += NT)
-        sd.dual[r] = r < NCM ? (term ? 0.0 : sc.Wrl[r]) : (r < NCM + 6 ? sc.Whg[r - NCM] : (term ? 0.0 : sc.Wrf[r - NCM - 6]));
+        sd.dual_()[r] = r < NCM ? (term ? 0.0 : sc.Wrl[r]) : (r < NCM + 6 ? sc.Whg[r - NCM] : (term ? 0.0 : sc.Wrf[r - NCM - 6]));
       // wrench-cone rows: A_cone^T nu per contact (the multipliers of the unmasked rows enter the Lagrangian gradient)
       for (int r = lane; r < NCM; r += NT)
       {
@@ -1683,7 +1717,7 @@ namespace smpc
                 acc += wrench_cone_entry(i, j, h.fric_mu, h.Lfoot, h.Wfoot) * sc.nu[NU + NA + D::NCONE1 * f + i];
           }
         }
-        sd.yc[r] = acc;
+        sd.yc_()[r] = acc;
       }
     }
     SMPC_LANES_END_WAVE
@@ -1704,17 +1738,17 @@ namespace smpc
         g = sc.Wru[k - NDX];
       // (terminal node: only the momentum rows exist)
       for (int r = term ? NCM : 0; r < (term ? NCM + 6 : NGN); r++)
-        g += sd.JT[r * NCOL + k] * sd.dual[r];
+        g += (r < NCM ? sd.JT[r * NCOL + k] : sc.jt2_()[(r - NCM) * NCOL + k]) * sd.dual_()[r];
       if (k < NDX)
-        sd.gx[k] = g;
+        sd.gx_()[k] = g;
       else
-        sd.gu[k - NDX] = g;
+        sd.gu_()[k - NDX] = g;
       double cqv = 0.0;
       if constexpr (D::NCONE > 0)
         if (!term)
           for (int r = 0; r < NCM; r++)
-            cqv += sd.JT[r * NCOL + k] * sd.yc[r];
-      sd.cq[k] = cqv;
+            cqv += sd.JT[r * NCOL + k] * sd.yc_()[r];
+      sd.cq_()[k] = cqv;
     }
     SMPC_LANES_END_WAVE
     if (term)
@@ -1728,7 +1762,7 @@ namespace smpc
         double dual = 0.0;
         for (int k = lane; k < NDX; k += NT)
         {
-          const double qn = sd.gx[k] - b.lams[(ib + sprev) * NDX + k];
+          const double qn = sd.gx_()[k] - b.lams[(ib + sprev) * NDX + k];
           qN[k] = qn;
           dual = fmax(dual, fabs(qn));
         }
@@ -1798,11 +1832,11 @@ namespace smpc
           double cn = 0.0;
           if (h.kinematics_limits && k >= 6 && k < NV)
             cn = sc.nu[NU + k - 6];
-          double q = sd.gx[k] + acc + cn + sd.cq[k] - (t > 0 ? b.lams[(ib + sprev) * NDX + k] : 0.0);
+          double q = sd.gx_()[k] + acc + cn + sd.cq_()[k] - (t > 0 ? b.lams[(ib + sprev) * NDX + k] : 0.0);
           if (t == 0)
             q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
           lq[D::O_q + k] = q;
-          lq[D::O_lx + k] = sd.gx[k];
+          lq[D::O_lx + k] = sd.gx_()[k];
           lq[D::O_f + k] = mu * (sc.lamp[k] - sc.lam_next[k]);
           lq[D::O_lpd + k] = 2.0 * sc.lamp[k] - sc.lam_next[k];
           dual = fmax(dual, fabs(q));
@@ -1810,9 +1844,9 @@ namespace smpc
         else
         {
           const double cn = h.torque_limits ? sc.nu[k] : 0.0;
-          const double r = sd.gu[k] + acc + cn + sd.cq[NDX + k];
+          const double r = sd.gu_()[k] + acc + cn + sd.cq_()[NDX + k];
           lq[D::O_r + k] = r;
-          lq[D::O_lu + k] = sd.gu[k];
+          lq[D::O_lu + k] = sd.gu_()[k];
           dual = fmax(dual, fabs(r));
         }
       }

@@ -23,4 +23,5 @@ if os.environ.get('SMPC_PHASE_PROFILE'):
     out = np.zeros(64); gm._lib.check(gm._lib.L.smpc_debug_get_phase_cycles(gm._h, out))
     names = ['load','kin','composite','M/J','cholM/W','G/Gi','prox/a','eval-tail','forces','dk/Ak/Jc','R1','R2','solves','WJ','tables/grad','AB','QSR']
     nd = (steps+1)*iters
+    print('eval-tail parts:', ' '.join('%s %.0f' % (nm, out[20+i]/nd) for i,nm in enumerate(['se3','defect','resid','weighted','cost'])))
     print('deriv phase cycles (inst 0, stage 17):', ' '.join('%s %.0f' % (nm, out[i]/nd) for i,nm in enumerate(names)), '| total %.0f' % (out[:17].sum()/nd))
