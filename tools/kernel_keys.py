@@ -1,0 +1,28 @@
+"""Kernel classification shared by the rocprofv3 summaries: the full-batch launch of each hot kernel of each workload."""
+# key -> (substring of the kernel symbol, robot tag, minimal grid size (blocks * 64 lanes) of a full-batch launch)
+KEYS = {
+    "deriv_body": ("10deriv_body", "DimsILi13ELi4EEE", 4096 * 51 * 64),
+    "riccati_kino_body": ("riccati_kino_body", "", 4096 * 64),
+    "forward_kino_body": ("forward_kino_body", "", 4096 * 64),
+    "trial_body": ("10trial_body", "", 4096 * 51 * 64),
+    "apply_body": ("apply_body", "DimsILi13ELi4EEE", 4096 * 64),
+    "cent_step_body": ("cent_step_body", "", 4096 * 64),
+    "fdyn_deriv_body_go2": ("fdyn_deriv_body", "FullDimsILi13E", 4096 * 51 * 64),
+    "fdyn_trial_body_go2": ("fdyn_trial_body", "FullDimsILi13E", 4096 * 51 * 64),
+    "riccati_dense_body_go2": ("riccati_dense_body", "FullDimsILi13E", 4096 * 64),
+    "forward_full_body_go2": ("forward_full_body", "FullDimsILi13E", 4096 * 64),
+    "fdyn_deriv_body_talos": ("fdyn_deriv_body", "FullDimsILi23E", 1024 * 101 * 64),
+    "fdyn_trial_body_talos": ("fdyn_trial_body", "FullDimsILi23E", 1024 * 101 * 64),
+    "riccati_dense_body_talos": ("riccati_dense_body", "FullDimsILi23E", 1024 * 64),
+    "forward_full_body_talos": ("forward_full_body", "FullDimsILi23E", 1024 * 64),
+}
+
+
+def kernel_key(name, grid_size):
+    """Key of a full-batch main-symbol launch (TAG = 0), or None."""
+    if "ELi0EEE" not in name:
+        return None
+    for key, (sub, tag, grid) in KEYS.items():
+        if sub in name and tag in name and int(grid_size) >= grid:
+            return key
+    return None

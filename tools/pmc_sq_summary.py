@@ -3,15 +3,18 @@ python tools/pmc_sq_summary.py out.json pass1_counter_collection.csv [pass2_coun
 import collections
 import csv
 import json
+import os
 import sys
 
-KEYS = ("deriv_body", "riccati_kino_body", "trial_body", "forward_kino_body", "cent_step_body")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_keys import KEYS, kernel_key
+
 res = {k: collections.defaultdict(list) for k in KEYS}
 for f in sys.argv[2:]:
     for r in csv.DictReader(open(f)):
-        for key in KEYS:
-            if key in r["Kernel_Name"] and int(r["Grid_Size"]) >= 4096 * 64 and "ELi0EEE" in r["Kernel_Name"]:
-                res[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        key = kernel_key(r["Kernel_Name"], r["Grid_Size"])
+        if key:
+            res[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, d in res.items():
     if not d:

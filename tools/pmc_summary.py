@@ -3,17 +3,19 @@ summary bench.py reads: python tools/pmc_summary.py <fetch_counter_collection.cs
 import collections
 import csv
 import json
+import os
 import sys
 
-KEYS = ("deriv_body", "riccati_kino_body", "trial_body", "forward_kino_body", "apply_body", "select_body", "recede_body", "compact_body", "cent_step_body")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_keys import kernel_key
 res = collections.defaultdict(dict)
 for name, f in (("FETCH_SIZE", sys.argv[1]), ("WRITE_SIZE", sys.argv[2])):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name:
-            for key in KEYS:
-                if key in r["Kernel_Name"] and int(r["Grid_Size"]) >= 4096 * 64:
-                    acc[key].append(float(r["Counter_Value"]))
+            key = kernel_key(r["Kernel_Name"], r["Grid_Size"])
+            if key:
+                acc[key].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         res[k][name + "_KiB_avg_full_batch_launch"] = sum(v) / len(v)
         res[k][name + "_launches"] = len(v)
@@ -23,9 +25,9 @@ for k in res:
     res[k]["hbm_bytes_per_launch_corrected"] = (2 * f + w) * 1024
 json.dump({
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
-              "--no-cpu-baseline; launches with the full batch (B=4096) only",
+              "--no-cpu-baseline; full-batch launches only (B = 4096; Talos B = 1024, H = 100), see tools/kernel_keys.py",
     "correction": "FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section: gfx950 reports half the bytes of wide coalesced reads); "
                   "WRITE_SIZE as reported (matches the algorithmic knot write of deriv_body to 1%)",
     "kernels": res}, open(sys.argv[3], "w"), indent=1)
-for k in ("deriv_body", "riccati_kino_body", "forward_kino_body"):
+for k in res:
     print(k, "%.2f GB/launch" % (res[k]["hbm_bytes_per_launch_corrected"] / 1e9))
