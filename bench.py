@@ -127,7 +127,7 @@ def cpu_baseline(iters, seconds_budget=20.0):
     import numpy as np
     S, O = _oracle_imports()
 
-    threads = O.lib().orc_num_threads()
+    threads = O.use_effective_cpus()  # hardware threads capped by the cgroup CPU quota
     B = max(threads * 2, 8)
     om, rb, _ = S.make_oracle(B, max_iters=iters)
     om.generateCycleHorizon(O.trot_cycle())
@@ -160,6 +160,7 @@ def cpu_baseline(iters, seconds_budget=20.0):
         "value": B * n / dt,
         "unit": "control-steps/s",
         "cores": threads,
+        "host_hw_threads": os.cpu_count(),
         "kind": "port",
         "b1_latency_ms": 1e3 * min(lat),
         "sample": "CPU restatement (oracle/, not Aligator): %d instances x %d steps, k=%d, OpenMP over instances; b1_latency_ms = one "
@@ -267,7 +268,7 @@ def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     }
     if with_cpu:
         S, O = _oracle_imports()
-        threads = O.lib().orc_num_threads()
+        threads = O.use_effective_cpus()  # hardware threads capped by the cgroup CPU quota
         Bc = max(threads * 4, 16)
         om, rbc, _ = S.make_cent_oracle(Bc, max_iters=iters)
         om.generateCycleHorizon(O.trot_cycle())
@@ -340,7 +341,7 @@ def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True, rob
         out["roofline"] = rl
     if with_cpu:
         S, O = _oracle_imports()
-        threads = O.lib().orc_num_threads()
+        threads = O.use_effective_cpus()  # hardware threads capped by the cgroup CPU quota
         Bc = max(threads, 8)
         if talos:
             om, _, rbc = None, None, None

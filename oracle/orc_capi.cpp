@@ -981,6 +981,12 @@ extern "C"
     return -1.0;
 #endif
   }
+  // number of OpenMP threads of the batched loops (the host may be under a CPU quota smaller than its hardware thread count)
+  void orc_set_num_threads(int n)
+  {
+    if (n > 0)
+      omp_set_num_threads(n);
+  }
   int orc_num_threads()
   {
 #ifdef _OPENMP

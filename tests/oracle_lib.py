@@ -123,6 +123,7 @@ def lib():
     L.orc_fmpc_keep_knots.argtypes = [vp, C.c_int]
     L.orc_fmpc_get_knot.argtypes = [vp, C.c_int, C.c_int, _dp]
     L.orc_num_threads.restype = C.c_int
+    L.orc_set_num_threads.argtypes = [C.c_int]
     L.orc_cent_create.restype = vp
     L.orc_cent_create.argtypes = [vp, C.c_double] + [_dp] * 7 + [C.c_double]
     L.orc_cent_destroy.argtypes = [vp]
@@ -151,6 +152,33 @@ def lib():
     L.orc_interpolate.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int, _dp]
     _lib = L
     return L
+
+
+def effective_cpus():
+    """CPUs this process may really use: hardware threads capped by the cgroup CPU quota (a container with a 16-CPU quota on a
+    256-thread host is throttled, not sped up, by 128 OpenMP threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(p))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p = int(f.read()), int(g.read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def use_effective_cpus():
+    """Size the oracle's OpenMP team to the CPUs the process may use; returns the thread count."""
+    n = effective_cpus()
+    lib().orc_set_num_threads(n)
+    return n
 
 
 class Robot:
