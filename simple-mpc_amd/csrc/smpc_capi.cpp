@@ -741,7 +741,7 @@ extern "C"
     if (!h || !X_meas || !u_out)
       return fail(SMPC_ERR_INVALID, "null argument");
     if (h->full)
-      return fail(SMPC_ERR_INVALID, "smpc_riccati_feedback is not built for full-dynamics handles yet");
+      return guarded([&] { h->full->riccati_feedback(delay, X_meas, u_out); });
     if (h->cent)
       return guarded([&] { h->cent->interpolate(delay, 2, X_meas, nullptr, nullptr, nullptr, u_out); });
     return guarded([&] { h->eng->riccati_feedback(delay, X_meas, u_out); });
@@ -750,8 +750,8 @@ extern "C"
   {
     if (!h)
       return fail(SMPC_ERR_INVALID, "null argument");
-    if (h->full)
-      return fail(SMPC_ERR_INVALID, "smpc_interpolate is not built for full-dynamics handles yet");
+    if (h->full) // full-dynamics handle: force_out [B][nfeet][force_size] = interpolated MPC::getContactForces
+      return guarded([&] { h->full->interpolate(delay, knots, x_out, acc_out, force_out); });
     if (h->cent) // centroidal handle: x_out [B][9], acc_out = state derivative [B][9], force_out [B][3 nfeet]
       return guarded([&] { h->cent->interpolate(delay, knots, nullptr, x_out, acc_out, force_out, nullptr); });
     return guarded([&] { h->eng->interpolate(delay, knots, x_out, acc_out, force_out); });

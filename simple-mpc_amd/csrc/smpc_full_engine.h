@@ -55,6 +55,8 @@ namespace smpc
     virtual void debug_steps(double * dxs, double * dus) = 0;
     virtual void debug_terminal(int inst, double * QN, double * qN) = 0;
     virtual bool phase_cycles(double * out64) = 0;
+    virtual void interpolate(double delay, int knots, double * x_out, double * acc_out, double * f_out) = 0;
+    virtual void riccati_feedback(double delay, const double * X, double * u_out) = 0;
   };
 
   template <class D>
@@ -738,15 +740,15 @@ namespace smpc
     {
       stream_sync(stream);
       const int nt = all ? H : 1;
-      std::vector<double> g((size_t)D::G_STRIDE);
-      for (int b = 0; b < B; b++)
-        for (int t = 0; t < nt; t++)
-        {
-          d2h(g.data(), buf.gains + ((size_t)b * H + t) * D::G_STRIDE + D::G_K, (size_t)D::NU * (D::NDX + 1) * sizeof(double), stream);
-          stream_sync(stream);
-          for (int i = 0; i < D::NU; i++)
-            std::memcpy(out + (((size_t)b * nt + t) * D::NU + i) * D::NDX, g.data() + (size_t)i * (D::NDX + 1), D::NDX * sizeof(double));
-        }
+      const size_t n = (size_t)B * nt * D::NU * D::NDX;
+      double * dev = staging(n * sizeof(double));
+      FullGainOutArgs<D> ga;
+      ga.b = buf;
+      ga.nt = nt;
+      ga.out = dev;
+      launch<FullGainOutArgs<D>, full_gains_out_body<D>, 64>(B * nt, stream, ga);
+      d2h(out, dev, n * sizeof(double), stream);
+      stream_sync(stream);
     }
     void get(int what, double * out) override
     {
@@ -786,6 +788,70 @@ namespace smpc
       default:
         throw std::runtime_error("unknown output");
       }
+    }
+    // interpolated whole-body targets at `delay` after the last solve; host outputs, any may be null
+    void interpolate(double delay, int knots, double * x_out, double * acc_out, double * f_out) override
+    {
+      if (knots < 2 || knots > H + 1)
+        throw std::runtime_error("interpolate: knots must be in [2, horizon + 1]");
+      if (!(delay >= 0.0))
+        throw std::runtime_error("interpolate: delay must be non-negative");
+      const size_t nx = (size_t)B * D::NX, na = (size_t)B * D::NV, nf = (size_t)B * D::NCM;
+      double * st = staging((nx + na + nf) * sizeof(double));
+      FullInterpArgs<D> ia;
+      ia.b = buf;
+      ia.head = head;
+      ia.knots = knots;
+      ia.delay = delay;
+      ia.timestep = ms.timestep;
+      ia.x_out = x_out ? st : nullptr;
+      ia.acc_out = acc_out ? st + nx : nullptr;
+      ia.f_out = f_out ? st + nx + na : nullptr;
+      ia.u_out = nullptr;
+      launch<FullInterpArgs<D>, full_interp_body<D>, 64>(B, stream, ia);
+      if (x_out)
+        d2h(x_out, st, nx * sizeof(double), stream);
+      if (acc_out)
+        d2h(acc_out, st + nx, na * sizeof(double), stream);
+      if (f_out)
+        d2h(f_out, st + nx + na, nf * sizeof(double), stream);
+      stream_sync(stream);
+    }
+    // u = u_interp - K_0 (x_interp (-) x_meas) at `delay` after the last solve (reference examples/go2_fulldynamics.py:271-285)
+    void riccati_feedback(double delay, const double * X, double * u_out) override
+    {
+      if (!(delay >= 0.0))
+        throw std::runtime_error("riccati_feedback: delay must be non-negative");
+      const size_t nx = (size_t)B * D::NX, nu = (size_t)B * D::NU, nk = (size_t)B * D::NU * D::NDX;
+      double * st = staging((nx + 2 * nu + nk) * sizeof(double));
+      double *xi = st, *ui = st + nx, *uo = ui + nu, *k0 = uo + nu;
+      h2d(X_dev, X, nx * sizeof(double), stream);
+      FullInterpArgs<D> ia;
+      ia.b = buf;
+      ia.head = head;
+      ia.knots = 2;
+      ia.delay = delay;
+      ia.timestep = ms.timestep;
+      ia.x_out = xi;
+      ia.acc_out = nullptr;
+      ia.f_out = nullptr;
+      ia.u_out = ui;
+      launch<FullInterpArgs<D>, full_interp_body<D>, 64>(B, stream, ia);
+      FullGainOutArgs<D> ga;
+      ga.b = buf;
+      ga.nt = 1;
+      ga.out = k0;
+      launch<FullGainOutArgs<D>, full_gains_out_body<D>, 64>(B, stream, ga);
+      FeedbackArgs<D> fa;
+      fa.b = buf;
+      fa.X_meas = X_dev;
+      fa.x_interp = xi;
+      fa.u_interp = ui;
+      fa.K0 = k0;
+      fa.u_out = uo;
+      launch<FeedbackArgs<D>, feedback_body<D>, 64>(B, stream, fa);
+      d2h(u_out, uo, nu * sizeof(double), stream);
+      stream_sync(stream);
     }
     bool phase_cycles(double * out64) override
     {

@@ -299,4 +299,91 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
   }
+  // K_t of stages 0 .. nt-1 out of the gains block: [B][nt][NU][NDX] dense (grid = B * nt)
+  template <class D>
+  struct FullGainOutArgs
+  {
+    Buffers<D> b;
+    int nt;
+    double * out;
+  };
+  template <class D>
+  SMPC_DEV void full_gains_out_body(const FullGainOutArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NDX = D::NDX, NU = D::NU;
+    const Buffers<D> & b = ka.b;
+    const int inst = block / ka.nt, t = block % ka.nt;
+    const double * g = b.gains + ((size_t)inst * b.H + t) * D::G_STRIDE + D::G_K;
+    double * out = ka.out + ((size_t)inst * ka.nt + t) * NU * NDX;
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NU * NDX; idx += NT)
+      out[idx] = g[(idx / NDX) * (NDX + 1) + idx % NDX];
+    SMPC_LANES_END_WAVE
+  }
+
+  // Targets between MPC knots for the whole-body loop of the full-dynamics examples (reference examples/go2_fulldynamics.py:
+  // 268-292 with src/interpolator.cpp:5-78): x = interpolateState(xs[0 .. knots-1]), acc = interpolateLinear of the state
+  // derivatives' acceleration part at t = 0, 1, forces = interpolateLinear of MPC::getContactForces(0 / 1), u = interpolateLinear
+  // of us[0], us[1].  grid = B.
+  template <class D>
+  struct FullInterpArgs
+  {
+    Buffers<D> b;
+    int head, knots;
+    double delay, timestep;
+    double *x_out, *acc_out, *f_out, *u_out; // device, any may be null
+  };
+  template <class D>
+  SMPC_DEV void full_interp_body(const FullInterpArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64;
+    constexpr int NX = D::NX, NDX = D::NDX, NV = D::NV, NU = D::NU, NCM = D::NCM;
+    const Buffers<D> & b = ka.b;
+    const int inst = block, R = b.R;
+    const size_t step = (size_t)(ka.delay / ka.timestep);
+    const double s = (ka.delay - (double)step * ka.timestep) / ka.timestep;
+    SMPC_LDS(double, e, D::NDX);
+    SMPC_LDS(double, xo, D::NX);
+    if (ka.x_out != nullptr)
+    {
+      const bool last = step >= (size_t)ka.knots - 1;
+      const double * x0 = b.xs + ((size_t)inst * R + ring_slot(ka.head, last ? ka.knots - 1 : (int)step, R)) * NX;
+      const double * x1 = b.xs + ((size_t)inst * R + ring_slot(ka.head, last ? ka.knots - 1 : (int)step + 1, R)) * NX;
+      SMPC_LANES(NT)
+      lanes_difference<D>(x0, x1, e, lane, 0);
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      lanes_integrate<D>(x0, e, last ? 0.0 : s, xo, lane, 0);
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      for (int i = lane; i < NX; i += NT)
+        ka.x_out[(size_t)inst * NX + i] = last ? x0[i] : xo[i];
+      SMPC_LANES_END_WAVE
+    }
+    const bool last1 = step >= 1;
+    const double w1 = last1 ? 1.0 : s, w0 = last1 ? 0.0 : 1.0 - s;
+    const double * u0 = b.us + ((size_t)inst * R + ring_slot(ka.head, 0, R)) * NU;
+    const double * u1 = b.us + ((size_t)inst * R + ring_slot(ka.head, 1, R)) * NU;
+    SMPC_LANES(NT)
+    {
+      if (ka.acc_out != nullptr)
+        for (int i = lane; i < NV; i += NT)
+        {
+          const double * xd = b.xdot01 + (size_t)inst * 4 * NV;
+          ka.acc_out[(size_t)inst * NV + i] = xd[2 * NV + NV + i] * w1 + xd[NV + i] * w0;
+        }
+      if (ka.f_out != nullptr)
+        for (int i = lane; i < NCM; i += NT)
+        {
+          const double * f = b.forces + (size_t)inst * b.H * NCM;
+          ka.f_out[(size_t)inst * NCM + i] = f[NCM + i] * w1 + f[i] * w0;
+        }
+      if (ka.u_out != nullptr)
+        for (int i = lane; i < NU; i += NT)
+          ka.u_out[(size_t)inst * NU + i] = u1[i] * w1 + u0[i] * w0;
+    }
+    SMPC_LANES_END_WAVE
+    (void)NDX;
+  }
 } // namespace smpc

@@ -757,12 +757,13 @@ class BatchedMPC:
         """Targets between MPC knots for the whole-body controller, batched on the device (reference
         examples/go2_kinodynamics.py:276-284 with src/interpolator.cpp:5-78): returns (x[B, nx], acc[B, nv],
         forces[B, nf, 3]) at `delay` seconds after the last iterate."""
+        fs = int(self.ocp_handler.settings["force_size"])
         x = np.zeros((self.B, self.nx))
         a = np.zeros((self.B, self.nv if self.nx != 9 else 9))  # centroidal handle: the interpolated state derivative
-        f = np.zeros((self.B, self.nf * 3))
+        f = np.zeros((self.B, self.nf * fs))
         self._lib.check(self._lib.L.smpc_interpolate(
             self._h, float(delay), int(knots), x.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p)))
-        return x, a, f.reshape(self.B, self.nf, 3)
+        return x, a, f.reshape(self.B, self.nf, fs)
 
     def _timing(self, which):
         names = self.ocp_handler.model_handler.getFeetFrameNames()

@@ -204,3 +204,46 @@ def test_hip_full_size_properties(built):
     info = gm.info
     assert np.all(np.isfinite(info)) and np.all(info[:, 1] < 0) and np.all(info[:, 3] <= info[:, 0])
     assert np.all(np.isfinite(gm.getContactForces()))
+
+
+def _interp_checks(lib):
+    """interpolate / riccatiFeedback on a full-dynamics handle against the oracle interpolator and the outputs of the solve
+    (reference examples/go2_fulldynamics.py:268-292)."""
+    B = 3
+    gm, rb, _, _ = S.make_full_product(B, max_iters=2, lib=lib)
+    gm.generateCycleHorizon(O.trot_cycle())
+    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = S.random_states(rb, B)
+    for _ in range(3):
+        gm.iterate(X)
+        X = gm.xs[:, 1, :].copy()
+    xs, us, K0, f = gm.xs, gm.us, gm.K0, gm.getContactForces()
+    xd = np.stack([gm.getStateDerivative(0), gm.getStateDerivative(1)], axis=1)
+    dt = gm.settings["timestep"]
+    for delay in (0.0, 0.004, 0.0099, 0.013):
+        x, a, fo = gm.interpolate(delay, knots=2)
+        step, s = int(delay / dt), (delay - int(delay / dt) * dt) / dt
+        for b in range(B):
+            xe = O.interpolate(0, rb.nv, delay, dt, [xs[b, 0], xs[b, 1]])
+            assert np.abs(x[b] - xe).max() < 1e-12
+            w1 = 1.0 if step >= 1 else s
+            assert np.abs(a[b] - (xd[b, 1, rb.nv:] * w1 + xd[b, 0, rb.nv:] * (1 - w1))).max() < 1e-12
+            assert np.abs(fo[b] - (f[b, 1] * w1 + f[b, 0] * (1 - w1))).max() < 1e-12
+        Xm = np.stack([rb.integrate(xs[b, 0], np.full(rb.ndx, 0.01 * (b + 1))) for b in range(B)])
+        u = gm.riccatiFeedback(delay, Xm)
+        for b in range(B):
+            w1 = 1.0 if step >= 1 else s
+            ui = us[b, 1] * w1 + us[b, 0] * (1 - w1)
+            ue = ui - K0[b] @ rb.difference(Xm[b], x[b])
+            assert np.abs(u[b] - ue).max() < 1e-9 * max(1.0, np.abs(ue).max())
+    Ks = gm.Ks
+    assert Ks.shape == (B, gm.H, gm.nu, gm.ndx) and np.array_equal(Ks[:, 0], K0)
+
+
+def test_emulated_kernels_interpolation_and_feedback(built):
+    _interp_checks(S.emu_lib())
+
+
+@pytest.mark.gpu
+def test_hip_interpolation_and_feedback(built):
+    _interp_checks(None)
