@@ -48,11 +48,11 @@ namespace smpc
     typedef RiccatiDenseGeom<D> GM;
     static constexpr int NDX = D::NDX, NU = D::NU;
     static constexpr int SWP = 4 * 16 * GM::NTM;
-    static constexpr int N_AB = NDX * GM::NXUP, N_W = (NU > GM::NCD ? NU : GM::NCD) * (NDX + 1);
-    static constexpr int N_SCR = (2 * SWP > N_W ? 2 * SWP : N_W);
+    static constexpr int N_SCR = 2 * SWP;
     double P[NDX * NDX];      // P_{t+1} -> P~ -> P_t
-    double AB[N_AB];          // [A | B | 0] row-major, row stride NXUP
-    double scr[N_SCR];        // sweep operands (2 x 4 x 16 NT) ; staging of [K | k]
+    double scr[N_SCR];        // sweep operands (2 x 4 x 16 NT)
+    // ([A | B] is not staged: its 16 x 4 operand slices are read from the knot twice, coalesced along the rows, one K-step ahead
+    //  of the products that consume them -- 36 KB of LDS per wave are worth more as resident waves)
     double p[NDX], pt0[NDX], pt[NDX], f[NDX];
     double boxa[D::NU + D::NA], boxd[D::NU + D::NA + GM::NCD]; // activity of the box rows ; d = mu (nu+ - nu) of all rows
   };
@@ -72,7 +72,6 @@ namespace smpc
     SMPC_LDS(LDS, lds, 1);
     LDS & s = lds[0];
     double * sw = s.scr;
-    double * Wm = s.scr;
     SMPC_LANES(NT)
     {
       for (int i = lane; i < NDX * NDX; i += NT)
@@ -190,12 +189,6 @@ namespace smpc
                 off = r0 < NDX ? D::O_q + r0 : D::O_r + r0 - NDX;
               SMPC_ACCV(hacc, tix<NT2>(I, J), v) = lq[off];
             }
-        for (int idx = lane; idx < NDX * NXUP; idx += NT)
-        {
-          const int i = idx / NXUP, j = idx % NXUP;
-          const double v = lq[j < NDX ? D::O_A + i * NDX + j : D::O_B + i * NU + (j < NXU ? j - NDX : 0)];
-          s.AB[idx] = j < NXU ? v : 0.0;
-        }
         for (int idx = lane; idx < NDX * NDX; idx += NT)
           g[D::G_Pt + idx] = s.P[idx];
       }
@@ -206,9 +199,19 @@ namespace smpc
         SMPC_ACC(tacc, NT, NTX * NTT);
         SMPC_PLA(double, pav, NT, NTX);
         SMPC_PLA(double, abv, NT, NTJ);
+        SMPC_PLA(double, abn, NT, NTJ); // operand slice of the next K-step (in flight while the current products run)
+        // slice ks of [A | B | 0]: entry (4 ks + lr, 16 J + lc), address selected, loaded once, masked at the use
+        auto ab_fetch = [&](int ks, int J, int lr, int lc) {
+          const int r = 4 * ks + lr, c = 16 * J + lc;
+          const double * src = c < NDX ? lq + D::O_A + r * NDX + c : lq + D::O_B + r * NU + (c < NXU ? c - NDX : 0);
+          return *src;
+        };
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+          for (int J = 0; J < NTJ; J++)
+            SMPC_PLV(abn)[J] = ab_fetch(0, J, lr, lc);
 #pragma unroll
           for (int I = 0; I < NTX; I++)
 #pragma unroll
@@ -238,9 +241,9 @@ namespace smpc
 #pragma unroll
             for (int J = 0; J < NTJ; J++)
             {
-              const int c = 16 * J + lc;
-              const double av = s.AB[(4 * ks + lr) * NXUP + (c < NXUP ? c : 0)];
-              SMPC_PLV(abv)[J] = c < NXUP ? av : 0.0;
+              SMPC_PLV(abv)[J] = 16 * J + lc < NXU ? SMPC_PLV(abn)[J] : 0.0;
+              // next slice (the second product starts again at slice 0)
+              SMPC_PLV(abn)[J] = ab_fetch(ks + 1 < NDX / 4 ? ks + 1 : 0, J, lr, lc);
             }
           }
           SMPC_LANES_END_WAVE
@@ -266,9 +269,9 @@ namespace smpc
 #pragma unroll
               for (int J = 0; J < NTJ; J++)
               {
-                const int c = 16 * J + lc;
-                const double av = s.AB[(4 * ks + lr) * NXUP + (c < NXUP ? c : 0)];
-                SMPC_PLV(abv)[J] = c < NXUP ? av : 0.0;
+                SMPC_PLV(abv)[J] = 16 * J + lc < NXU ? SMPC_PLV(abn)[J] : 0.0;
+                if (ks + 1 < NDX / 4)
+                  SMPC_PLV(abn)[J] = ab_fetch(ks + 1, J, lr, lc);
               }
 #pragma unroll
               for (int J = 0; J < NTT; J++)
@@ -341,55 +344,19 @@ namespace smpc
                   }
                 }
                 else if (col < NXU)
-                  Wm[(col - NDX) * (NDX + 1) + row] = -val; // K
+                  g[D::G_K + (col - NDX) * (NDX + 1) + row] = -val; // K
+                else if (col >= NXUP && col < NXUP + NCD)
+                  g[D::G_Z + (col - NXUP) * (NDX + 1) + row] = -val; // Z: multiplier feedback of the dense rows
                 else if (col == VC)
                   s.p[row] = val; // p_t
               }
               else if (row < NXU && col == VC)
-                Wm[(row - NDX) * (NDX + 1) + NDX] = -val; // k
+                g[D::G_K + (row - NDX) * (NDX + 1) + NDX] = -val; // k
+              else if (row >= NXUP && row < NXUP + NCD && col == VC)
+                g[D::G_Z + (row - NXUP) * (NDX + 1) + NDX] = -val; // z
             }
       }
       SMPC_LANES_END_WAVE
-      SMPC_LANES(NT)
-      {
-        constexpr int NW = (NU * (NDX + 1) + NT - 1) / NT;
-        double wv[NW];
-#pragma unroll
-        for (int n = 0; n < NW; n++)
-          wv[n] = Wm[lane + n * NT < NU * (NDX + 1) ? lane + n * NT : 0];
-#pragma unroll
-        for (int n = 0; n < NW; n++)
-          if (lane + n * NT < NU * (NDX + 1))
-            g[D::G_K + lane + n * NT] = wv[n];
-      }
-      SMPC_LANES_END_WAVE
-      if constexpr (NCD > 0)
-      {
-        // multiplier feedback of the dense rows: [Z | z] = -(stored entries pairing (x | vector) with the nu pivots)
-        SMPC_LANES(NT)
-        {
-          const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-          for (int I = 0; I < NT2; I++)
-#pragma unroll
-            for (int J = I; J < NT2; J++)
-#pragma unroll
-              for (int v = 0; v < 4; v++)
-              {
-                const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
-                const double val = SMPC_ACCV(hacc, tix<NT2>(I, J), v);
-                if (row < NDX && col >= NXUP && col < NXUP + NCD)
-                  Wm[(col - NXUP) * (NDX + 1) + row] = -val;
-                else if (row >= NXUP && row < NXUP + NCD && col == VC)
-                  Wm[(row - NXUP) * (NDX + 1) + NDX] = -val;
-              }
-        }
-        SMPC_LANES_END_WAVE
-        SMPC_LANES(NT)
-        for (int idx = lane; idx < NCD * (NDX + 1); idx += NT)
-          g[D::G_Z + idx] = Wm[idx];
-        SMPC_LANES_END_WAVE
-      }
     }
   }
 } // namespace smpc
