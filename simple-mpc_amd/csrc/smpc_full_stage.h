@@ -1248,83 +1248,117 @@ namespace smpc
       full_gn_rows<D>(sc, sd, true);
       return;
     }
-    // ---- partial derivatives of RNEA(q, v, a) - J^T lam at the solution: R1 = [r1q | r1v | -S] ----
-    SMPC_LANES(NT)
+    // ---- partial derivatives of RNEA(q, v, a) - J^T lam at the solution: R1 = [r1q | r1v | -S], as masked small GEMMs ----
+    //   joint(k) at or above joint(m) (s = joint(m)):  r1q(m,k) = (Ic_s S_m) . A_k + D_m . d_k ,  r1v(m,k) = (Ic_s S_m) . E_k + D_m . S_k
+    //       D_m = Bc_s^T S_m - S_m x* hc_s ,  E_k = v_i x S_k + d_k          (S_m . (d x* h) = -d . (S_m x* h))
+    //   joint(k) strictly below joint(m) (s = i = joint(k)):  r1q(m,k) = S_m . Yq_k ,  r1v(m,k) = S_m . Yv_k
+    //       Yq_k = Ic_i A_k + Bc_i d_k + d_k x* hc_i + S_k x* Fgc_i ,  Yv_k = Bc_i S_k + S_k x* hc_i + Ic_i E_k
+    // The per-dof vectors live in the force rows of JT (written only afterwards, by the contact partials).
     {
-      for (int idx = lane; idx < NV * NV; idx += NT)
+      double * E_ = sd.JT, * Dm_ = E_ + NV * 6, * Yq_ = Dm_ + NV * 6, * Yv_ = Yq_ + NV * 6;
+      static_assert(4 * NV * 6 <= NCM * NCOL && (FS != 6 || 12 * NF * NV <= NCM * NCOL), "per-dof vectors fit the force rows of JT");
+      SMPC_LANES(NT)
       {
-        const int m = idx / NV, k = idx % NV;
-        const int jm = jof(m), i = jof(k);
-        double vq = 0.0, vv = 0.0;
-        int s = -1;
-        bool below = false; // joint(k) strictly below joint(m)
-        if ((h.anc[jm] >> i) & 1u)
-          s = jm;
-        else if ((h.anc[i] >> jm) & 1u)
+        if (lane < NV)
         {
-          s = i;
-          below = true;
-        }
-        if (s >= 0)
-        {
-          const SV Sk = ldsv(&sc.S[k * 6]), Sm = ldsv(&sc.S[m * 6]);
-          const SV d = ldsv(&sd.dk[k * 6]), A = ldsv(&sd.Ak[k * 6]);
-          const SI Ics = ldsi(&sc.Ic[s * 10]);
-          const double * Bc = &sd.Bc[s * 36];
+          const int k = lane, i = jof(k);
+          const SV Sk = ldsv(&sc.S[k * 6]), d = ldsv(&sd.dk[k * 6]), A = ldsv(&sd.Ak[k * 6]);
+          const SI Ici = ldsi(&sc.Ic[i * 10]);
+          const SV hci = ldsv(&sc.hc[i * 6]);
+          const double * Bc = &sd.Bc[i * 36];
           const double dv[6] = {d.l.x, d.l.y, d.l.z, d.a.x, d.a.y, d.a.z};
           const double sv[6] = {Sk.l.x, Sk.l.y, Sk.l.z, Sk.a.x, Sk.a.y, Sk.a.z};
-          double o1[6], o2[6];
+          double o1[6], o2[6], o3[6] = {0, 0, 0, 0, 0, 0};
           for (int r = 0; r < 6; r++)
           {
             double a1 = 0.0, a2 = 0.0;
             for (int c = 0; c < 6; c++)
             {
-              a1 += Bc[r * 6 + c] * dv[c];
-              a2 += Bc[r * 6 + c] * sv[c];
+              const double bv = Bc[r * 6 + c];
+              a1 += bv * dv[c];
+              a2 += bv * sv[c];
+              o3[c] += bv * sv[r]; // Bc^T S_k
             }
             o1[r] = a1;
             o2[r] = a2;
           }
-          // Bc holds v x* I - I v x only; the (. x* h) part of the composite velocity-product matrix is added here
-          const SV hcs = ldsv(&sc.hc[s * 6]);
-          SV Xq = Ics * A + SV{mk3(o1[0], o1[1], o1[2]), mk3(o1[3], o1[4], o1[5])} + crf(d, hcs);
-          if (below)
-            Xq = Xq + crf(Sk, ldsv(&sc.I[i * 6]));
-          const SV Xv = SV{mk3(o2[0], o2[1], o2[2]), mk3(o2[3], o2[4], o2[5])} + crf(Sk, hcs) + Ics * (crm(ldsv(&sc.vel[i * 6]), Sk) + d);
-          vq = sv_dot6(Sm, Xq);
-          vv = sv_dot6(Sm, Xv);
+          const SV E = crm(ldsv(&sc.vel[i * 6]), Sk) + d;
+          const SV Cm = crf(Sk, hci);
+          const SV Dm = SV{mk3(o3[0], o3[1], o3[2]), mk3(o3[3], o3[4], o3[5])} - Cm;
+          const SV Yq = Ici * A + SV{mk3(o1[0], o1[1], o1[2]), mk3(o1[3], o1[4], o1[5])} + crf(d, hci) + crf(Sk, ldsv(&sc.I[i * 6]));
+          const SV Yv = SV{mk3(o2[0], o2[1], o2[2]), mk3(o2[3], o2[4], o2[5])} + Cm + Ici * E;
+          stsv(&E_[k * 6], E);
+          stsv(&Dm_[k * 6], Dm);
+          stsv(&Yq_[k * 6], Yq);
+          stsv(&Yv_[k * 6], Yv);
         }
-        if constexpr (FS == 6)
+        for (int idx = lane; idx < NV * NU; idx += NT)
         {
-          // - d(J^T lam)/dq_k of world-aligned wrenches: the wrench keeps its axes, its point of application moves; the columns S_m
-          // below joint(k) (and the other base columns, for a base dof) move with S_k
-          for (int f = 0; f < NF; f++)
-          {
-            const int l = h.foot_joint[f];
-            if (!((mask >> f) & 1u) || !((h.anc[l] >> jm) & 1u) || !((h.anc[l] >> i) & 1u))
-              continue;
-            const SV Sk = ldsv(&sc.S[k * 6]), Sm = ldsv(&sc.S[m * 6]);
-            const SV W = ldsv(&sd.Wc[f * 6]);
-            const V3 pv = Sk.l + cross(Sk.a, ld3(&sc.footp[f * 3]));
-            double tq = dot(Sm.a, cross(pv, W.l));
+          const int m = idx / NU, j = idx % NU;
+          sd.R1[m * NCOL + 2 * NV + j] = m == 6 + j ? -1.0 : 0.0;
+        }
+      }
+      SMPC_LANES_END_WAVE
+      fwave_gemm<NV, 2 * NV, 12>(
+        [&](int m, int kk) { return kk < 6 ? sc.IcS[m * 6 + kk] : Dm_[m * 6 + kk - 6]; },
+        [&](int kk, int j) {
+          const int jj = j < NV ? j : j - NV;
+          const double * src = j < NV ? (kk < 6 ? &sd.Ak[jj * 6 + kk] : &sd.dk[jj * 6 + kk - 6]) : (kk < 6 ? &E_[jj * 6 + kk] : &sc.S[jj * 6 + kk - 6]);
+          return *src;
+        },
+        [&](int m, int j, double v) {
+          const int jm = jof(m), i = jof(j < NV ? j : j - NV);
+          sd.R1[m * NCOL + j] = ((h.anc[jm] >> i) & 1u) ? v : 0.0;
+        });
+      fwave_gemm<NV, 2 * NV, 6>(
+        [&](int m, int kk) { return sc.S[m * 6 + kk]; },
+        [&](int kk, int j) { return j < NV ? Yq_[j * 6 + kk] : Yv_[(j - NV) * 6 + kk]; },
+        [&](int m, int j, double v) {
+          const int jm = jof(m), i = jof(j < NV ? j : j - NV);
+          if (!((h.anc[jm] >> i) & 1u) && ((h.anc[i] >> jm) & 1u))
+            sd.R1[m * NCOL + j] = v;
+        });
+      if constexpr (FS == 6)
+      {
+        // - d(J^T lam)/dq_k of world-aligned wrenches: the wrench keeps its axes, its point of application moves (first product);
+        // the columns S_m below joint(k) -- and the other base columns, for a base dof -- move with S_k (second product):
+        //   r1q(m,k) -= sum_f [m, k above foot f] ( (f_f x S_m.ang) . dp_kf + [S_m moves with S_k] (S_m x* W_f) . S_k )
+        double * Gm_ = sd.JT, * Hm_ = Gm_ + NV * 3 * NF, * Pv_ = Hm_ + NV * 6 * NF;
+        SMPC_LANES(NT)
+        for (int idx = lane; idx < NV * NF; idx += NT)
+        {
+          const int m = idx / NF, f = idx % NF;
+          const int l = h.foot_joint[f];
+          const bool on = ((mask >> f) & 1u) && ((h.anc[l] >> jof(m)) & 1u);
+          const SV Sm = ldsv(&sc.S[m * 6]), W = ldsv(&sd.Wc[f * 6]);
+          const V3 z = mk3(0, 0, 0);
+          st3(&Gm_[m * 3 * NF + 3 * f], on ? cross(W.l, Sm.a) : z);
+          stsv(&Hm_[m * 6 * NF + 6 * f], on ? crf(Sm, W) : SV{z, z});
+          st3(&Pv_[m * 3 * NF + 3 * f], on ? Sm.l + cross(Sm.a, ld3(&sc.footp[f * 3])) : z);
+        }
+        SMPC_LANES_END_WAVE
+        fwave_gemm<NV, NV, 3 * NF>(
+          [&](int m, int kk) { return Gm_[m * 3 * NF + kk]; }, [&](int kk, int j) { return Pv_[j * 3 * NF + kk]; },
+          [&](int m, int j, double v) { sd.R1[m * NCOL + j] -= v; });
+        fwave_gemm<NV, NV, 6 * NF>(
+          [&](int m, int kk) { return Hm_[m * 6 * NF + kk]; },
+          [&](int kk, int j) {
+            const int f = kk / 6;
+            const double x = sc.S[j * 6 + kk % 6];
+            return (((mask >> f) & 1u) && ((h.anc[h.foot_joint[f]] >> jof(j)) & 1u)) ? x : 0.0;
+          },
+          [&](int m, int j, double v) {
+            const int jm = jof(m), i = jof(j);
             const bool moves = (jm != i && ((h.anc[jm] >> i) & 1u)) || (jm == 0 && i == 0);
             if (moves)
-              tq -= sv_dot6(Sm, crf(Sk, W));
-            vq -= tq;
-          }
-        }
-        sd.R1[m * NCOL + k] = vq;
-        sd.R1[m * NCOL + NV + k] = vv;
+              sd.R1[m * NCOL + j] -= v;
+          });
       }
-      for (int idx = lane; idx < NV * NU; idx += NT)
-      {
-        const int m = idx / NU, j = idx % NU;
-        sd.R1[m * NCOL + 2 * NV + j] = m == 6 + j ? -1.0 : 0.0;
-      }
+      SMPC_LANES(NT)
       for (int idx = lane; idx < NCM * NCOL; idx += NT)
         sd.JT[idx] = 0.0;
+      SMPC_LANES_END_WAVE
     }
-    SMPC_LANES_END_WAVE
     ftick(fp, 10);
     // ---- partial derivatives of the contact acceleration residual (classical acceleration, contact frame, corrector) ----
     if constexpr (FS == 6)

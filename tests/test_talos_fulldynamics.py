@@ -56,17 +56,25 @@ def test_emulated_kernels_talos_stage_knots(built):
     om, gm, rb = S.make_talos_pair(1, max_iters=1, lib=S.emu_lib(), walk=(0.2, 0.1, 0, 0, 0, 0.2), settings_override=TIGHT, **SHORT)
     om.keep_knots()
     X = S.talos_random_states(rb, 1, scale=0.7)
-    for _ in range(6):
+    nb = 2 * gm.nu
+    # the first iterates agree to rounding; later ones only as far as the closed loop (active-set changes, Armijo decisions) carries
+    # the rounding of the earlier ones, so the comparison is tight early and loose once wrench-cone rows are active
+    for it in range(6):
         om.iterate(X)
         gm.iterate(X)
         X = om.xs[:, 1, :].copy()
-    nb = 2 * gm.nu
-    for t in (0, 3, 12, 19):
-        ko, kg = om.knot(0, t), gm.debug_lq(0, t)
-        for k in ("A", "B", "Q", "S", "R", "f"):
-            assert S.rel_err(ko[k], kg[k]) < 1e-8, (t, k, S.rel_err(ko[k], kg[k]))
-        assert S.rel_err(ko["C"][nb:], kg["Cd"]) < 1e-8, t  # active wrench-cone rows A_cone d lam / dx (zero when inactive)
-        assert np.abs(ko["d"] - kg["d"]).max() < 1e-6 * max(1.0, np.abs(ko["d"]).max())
+        if it not in (1, 5):
+            continue
+        tol = 1e-11 if it == 1 else 1e-6
+        active = 0
+        for t in (0, 3, 12, 19):
+            ko, kg = om.knot(0, t), gm.debug_lq(0, t)
+            for k in ("A", "B", "Q", "S", "R", "f"):
+                assert S.rel_err(ko[k], kg[k]) < tol, (it, t, k, S.rel_err(ko[k], kg[k]))
+            assert S.rel_err(ko["C"][nb:], kg["Cd"]) < tol, (it, t)  # active wrench-cone rows A_cone d lam / dx (zero when inactive)
+            assert np.abs(ko["d"] - kg["d"]).max() < 1e3 * tol * max(1.0, np.abs(ko["d"]).max())
+            active += int(np.abs(kg["Cd"]).max() > 0)
+    assert active > 0, "the last iterate must hold active wrench-cone rows"
 
 
 @pytest.mark.gpu
