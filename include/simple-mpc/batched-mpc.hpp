@@ -33,6 +33,18 @@ namespace simple_mpc
     int force_size = 3;
   };
 
+  struct FullDynamicsSettings // reference include/simple-mpc/fulldynamics.hpp:28-65
+  {
+    double timestep = 0.01;
+    std::vector<double> w_x, w_u, w_cent, w_forces, w_frame; // dense row-major: ndx^2, nu^2 (nu = nv - 6), 36, force_size^2 twice
+    std::vector<double> umin, umax, qmin, qmax;               // nu each
+    std::vector<double> Kp_correction, Kd_correction;         // force_size each
+    double gravity[3] = {0, 0, -9.81};
+    double mu = 0.8, Lfoot = 0.1, Wfoot = 0.075;
+    int force_size = 6;
+    bool torque_limits = true, kinematics_limits = true, force_cone = true, land_cstr = false;
+  };
+
   struct MPCSettings // reference include/simple-mpc/mpc.hpp:29-49
   {
     double swing_apex = 0.15;
@@ -52,6 +64,7 @@ namespace simple_mpc
     smpc_handle * h_ = nullptr;
     int dims_[8] = {0};
     int batch_ = 0;
+    int force_size_ = 3;
     std::vector<std::string> ee_names_;
     static void check(int code)
     {
@@ -118,6 +131,45 @@ namespace simple_mpc
       check(smpc_create_centroidal(robot, &cs, &ms, batch, gravity_arg, device_id, &h_));
       finish(robot);
     }
+    // FullDynamicsOCP(settings, model) + createProblem(x_ref, T, force_size, gravity, false) + MPC(settings, ocp)
+    // (reference src/fulldynamics.cpp:30-76; benchmark/talos.cpp).  us_ holds the nv - 6 joint torques.
+    BatchedMPC(const smpc_robot_model * robot, const FullDynamicsSettings & ocp, const MPCSettings & settings, int batch,
+               double gravity_arg = -9.81, int device_id = 0)
+    : batch_(batch), settings_(settings)
+    {
+      const size_t nu = (size_t)robot->nv - 6, ndx = 2 * (size_t)robot->nv, fs = (size_t)ocp.force_size;
+      if (ocp.w_x.size() != ndx * ndx || ocp.w_u.size() != nu * nu || ocp.w_cent.size() != 36 || ocp.w_forces.size() != fs * fs
+          || ocp.w_frame.size() != fs * fs || ocp.umin.size() != nu || ocp.umax.size() != nu || ocp.qmin.size() != nu
+          || ocp.qmax.size() != nu || ocp.Kp_correction.size() != fs || ocp.Kd_correction.size() != fs)
+        throw std::runtime_error("full-dynamics settings: sizes do not match the robot");
+      smpc_fulldynamics_settings fsn{};
+      fsn.timestep = ocp.timestep;
+      fsn.w_x = ocp.w_x.data();
+      fsn.w_u = ocp.w_u.data();
+      fsn.w_cent = ocp.w_cent.data();
+      fsn.w_forces = ocp.w_forces.data();
+      fsn.w_frame = ocp.w_frame.data();
+      fsn.umin = ocp.umin.data();
+      fsn.umax = ocp.umax.data();
+      fsn.qmin = ocp.qmin.data();
+      fsn.qmax = ocp.qmax.data();
+      fsn.Kp_correction = ocp.Kp_correction.data();
+      fsn.Kd_correction = ocp.Kd_correction.data();
+      for (int i = 0; i < 3; i++)
+        fsn.gravity[i] = ocp.gravity[i];
+      fsn.mu = ocp.mu;
+      fsn.Lfoot = ocp.Lfoot;
+      fsn.Wfoot = ocp.Wfoot;
+      fsn.force_size = ocp.force_size;
+      fsn.torque_limits = ocp.torque_limits;
+      fsn.kinematics_limits = ocp.kinematics_limits;
+      fsn.force_cone = ocp.force_cone;
+      fsn.land_cstr = ocp.land_cstr;
+      force_size_ = ocp.force_size;
+      smpc_mpc_settings ms = c_settings(settings);
+      check(smpc_create_fulldynamics(robot, &fsn, &ms, batch, gravity_arg, device_id, &h_));
+      finish(robot);
+    }
     ~BatchedMPC() { smpc_destroy(h_); }
     BatchedMPC(const BatchedMPC &) = delete;
     BatchedMPC & operator=(const BatchedMPC &) = delete;
@@ -149,6 +201,13 @@ namespace simple_mpc
       check(smpc_get_xs(h_, xs_.data()));
       check(smpc_get_us(h_, us_.data()));
       check(smpc_get_K0(h_, K0_.data()));
+    }
+    // MPC::getContactForces for every stage (reference src/mpc.cpp:354-380): [B][H][nfeet][force_size]; full-dynamics handles only
+    std::vector<double> getContactForces()
+    {
+      std::vector<double> f((size_t)batch_ * horizon() * ee_names_.size() * force_size_);
+      check(smpc_get_contact_forces(h_, f.data()));
+      return f;
     }
     void switchToWalk(const double * velocity_base6) { check(smpc_switch_to_walk(h_, velocity_base6)); }
     void switchToStand() { check(smpc_switch_to_stand(h_)); }

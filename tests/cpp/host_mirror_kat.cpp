@@ -208,6 +208,74 @@ int main()
     }
     CHECK(threw2);
   }
+  // ---- full-dynamics OCP, written like the reference's mpc_fulldynamics test (tests/mpc.cpp:20-91) with the Go2 settings of
+  // examples/go2_fulldynamics.py:42-77; a short horizon keeps the CPU build of the kernels quick ----
+  {
+    FullDynamicsSettings fs;
+    const int nuf = nv - 6;
+    fs.w_x.assign((size_t)ndx * ndx, 0.0);
+    for (int i = 6; i < nv; i++)
+      fs.w_x[(size_t)i * ndx + i] = 1.0;
+    for (int i = nv; i < nv + 6; i++)
+      fs.w_x[(size_t)i * ndx + i] = 10.0;
+    for (int i = nv + 6; i < ndx; i++)
+      fs.w_x[(size_t)i * ndx + i] = 0.1;
+    fs.w_u.assign((size_t)nuf * nuf, 0.0);
+    for (int i = 0; i < nuf; i++)
+      fs.w_u[(size_t)i * nuf + i] = 1e-4;
+    fs.w_cent.assign(36, 0.0);
+    fs.w_cent[0] = fs.w_cent[7] = 0.04;
+    fs.w_forces = {1e-4, 0, 0, 0, 1e-4, 0, 0, 0, 1e-4};
+    fs.w_frame = {1000, 0, 0, 0, 1000, 0, 0, 0, 1000};
+    fs.umin.assign(nuf, -40.0);
+    fs.umax.assign(nuf, 40.0);
+    fs.qmin.assign(robot->q_lo, robot->q_lo + nuf);
+    fs.qmax.assign(robot->q_hi, robot->q_hi + nuf);
+    fs.Kp_correction.assign(3, 0.0);
+    fs.Kd_correction.assign(3, 0.0);
+    fs.force_size = 3;
+    fs.mu = 0.8;
+    fs.Lfoot = fs.Wfoot = 0.01;
+    fs.force_cone = false;
+    MPCSettings fms = ms;
+    fms.T = 12;
+    fms.T_fly = 6;
+    fms.T_contact = 2;
+    BatchedMPC fmpc(robot, fs, fms, /*batch=*/2);
+    CHECK(fmpc.horizon() == 12 && fmpc.nx() == nq + nv && fmpc.nu() == nuf);
+    std::vector<std::map<std::string, bool>> cyc;
+    for (int i = 0; i < 16; i++)
+    {
+      std::map<std::string, bool> st;
+      for (int f = 0; f < nf; f++)
+        st[robot->foot_name[f]] = (i < 2 || (i >= 8 && i < 10)) ? true : ((i < 8) == (f == 0 || f == 3));
+      cyc.push_back(st);
+    }
+    fmpc.generateCycleHorizon(cyc);
+    for (int it = 0; it < 4; it++)
+      fmpc.iterate(X);
+    CHECK((int)fmpc.xs_.size() == 2 * 13 * (nq + nv) && (int)fmpc.us_.size() == 2 * 12 * nuf);
+    for (double v : fmpc.xs_)
+      CHECK(std::isfinite(v));
+    const std::vector<double> lam = fmpc.getContactForces(); // [B][H][nfeet][3]
+    CHECK((int)lam.size() == 2 * 12 * nf * 3);
+    double fz0 = 0.0;
+    for (int f = 0; f < nf; f++)
+      fz0 += lam[3 * f + 2];
+    CHECK(fz0 > 0.5 * robot->total_mass * 9.81 && fz0 < 1.5 * robot->total_mass * 9.81); // the stance feet carry the robot
+    bool threw4 = false;
+    try
+    {
+      FullDynamicsSettings bad = fs;
+      bad.land_cstr = true; // not built: rejected, not approximated
+      BatchedMPC nope(robot, bad, fms, 1);
+    }
+    catch (const std::runtime_error &)
+    {
+      threw4 = true;
+    }
+    CHECK(threw4);
+  }
   std::puts("host mirror KAT: OK");
   return 0;
 }
