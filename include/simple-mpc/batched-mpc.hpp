@@ -21,6 +21,7 @@ namespace simple_mpc
     double mu = 0.8, Lfoot = 0.01, Wfoot = 0.01;
     int force_size = 3;
     bool kinematics_limits = true, force_cone = false, land_cstr = false;
+    bool terminal_constraint = false; // createProblem's last argument (reference src/ocp-handler.cpp:96-137)
   };
 
   struct CentroidalSettings // reference include/simple-mpc/centroidal-dynamics.hpp:27-43
@@ -43,6 +44,7 @@ namespace simple_mpc
     double mu = 0.8, Lfoot = 0.1, Wfoot = 0.075;
     int force_size = 6;
     bool torque_limits = true, kinematics_limits = true, force_cone = true, land_cstr = false;
+    bool terminal_constraint = false; // createProblem's last argument
   };
 
   struct MPCSettings // reference include/simple-mpc/mpc.hpp:29-49
@@ -99,6 +101,7 @@ namespace simple_mpc
       ks.kinematics_limits = ocp.kinematics_limits;
       ks.force_cone = ocp.force_cone;
       ks.land_cstr = ocp.land_cstr;
+      ks.terminal_constraint = ocp.terminal_constraint;
       smpc_mpc_settings ms = c_settings(settings);
       check(smpc_create(robot, &ks, &ms, batch, gravity_arg, device_id, &h_));
       finish(robot);
@@ -165,6 +168,7 @@ namespace simple_mpc
       fsn.kinematics_limits = ocp.kinematics_limits;
       fsn.force_cone = ocp.force_cone;
       fsn.land_cstr = ocp.land_cstr;
+      fsn.terminal_constraint = ocp.terminal_constraint;
       force_size_ = ocp.force_size;
       smpc_mpc_settings ms = c_settings(settings);
       check(smpc_create_fulldynamics(robot, &fsn, &ms, batch, gravity_arg, device_id, &h_));

@@ -50,6 +50,9 @@ typedef struct smpc_kinodynamics_settings
   int kinematics_limits;
   int force_cone;
   int land_cstr;
+  /* createProblem(x0, T, force_size, gravity, terminal_constraint): the last argument (reference src/ocp-handler.cpp:96-137).
+   * Non-zero adds the DCM equality com + tau vcom = com_ref at the terminal node (src/kinodynamics.cpp:366-388). */
+  int terminal_constraint;
 } smpc_kinodynamics_settings;
 
 /* CentroidalSettings: reference include/simple-mpc/centroidal-dynamics.hpp:27-43 (same field names).
@@ -96,6 +99,7 @@ typedef struct smpc_fulldynamics_settings
   int kinematics_limits;
   int force_cone;
   int land_cstr;
+  int terminal_constraint; /* createProblem's last argument: DCM terminal equality (reference src/fulldynamics.cpp:433-455) */
 } smpc_fulldynamics_settings;
 
 /* MPCSettings: reference include/simple-mpc/mpc.hpp:29-49 (same field names). */

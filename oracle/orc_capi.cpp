@@ -13,6 +13,8 @@
 
 using namespace orc;
 typedef BatchMPCT<FullModel, FullSettings> BatchMPCFull;
+// createProblem(x0, T, force_size, gravity, terminal_constraint): the last argument, for the next orc_mpc_create / orc_fmpc_create
+static bool g_terminal_constraint = false;
 
 namespace
 {
@@ -98,6 +100,14 @@ namespace
       case 8:
         for (int t = 0; t < H && t < (int)S.Ks.size(); t++)
           mat_to(S.Ks[t], out + ((size_t)b * H + t) * md.nu * md.ndx);
+        break;
+      case 9: // terminal constraint: multipliers (3) | reference (3) | tau
+        for (int i = 0; i < 3; i++)
+        {
+          out[(size_t)b * 7 + i] = i < (int)S.vN.size() ? S.vN[i] : 0.0;
+          out[(size_t)b * 7 + 3 + i] = m->ocp[b].dcm_ref[i];
+        }
+        out[(size_t)b * 7 + 6] = m->ocp[b].dcm_tau;
         break;
       }
     }
@@ -245,6 +255,15 @@ extern "C"
     mat_to(o.Luu, Luu);
     mat_to(o.Cx, Cx);
     mat_to(o.Cu, Cu);
+  }
+  // DCM terminal constraint value c (3) and Jacobian C (3 x ndx)
+  void orc_kino_term_cstr(void * h, const double * x, const double * ref, double tau, double * c, double * C)
+  {
+    KinoModel * md = (KinoModel *)h;
+    Rigid R(md->M);
+    Mat Cm;
+    md->term_cstr(R, x, ref, tau, c, &Cm);
+    mat_to(Cm, C);
   }
   void orc_kino_term(void * h, const double * x_tgt, const double * x, double * cost, double * lx, double * Lxx)
   {
@@ -574,8 +593,9 @@ extern "C"
     if (s->num_threads > 0)
       omp_set_num_threads(s->num_threads);
 #endif
-    return new BatchMPC(md->M, md->s, ms, s->T, B, gravity_arg);
+    return new BatchMPC(md->M, md->s, ms, s->T, B, gravity_arg, g_terminal_constraint);
   }
+  void orc_set_terminal_constraint(int on) { g_terminal_constraint = on != 0; }
   void orc_mpc_destroy(void * h) { delete (BatchMPC *)h; }
   void orc_mpc_generate_cycle(void * h, const unsigned char * cs, int n)
   {
@@ -675,7 +695,7 @@ extern "C"
     if (s->num_threads > 0)
       omp_set_num_threads(s->num_threads);
 #endif
-    return new BatchMPCFull(md->M, md->s, ms, s->T, B, gravity_arg);
+    return new BatchMPCFull(md->M, md->s, ms, s->T, B, gravity_arg, g_terminal_constraint);
   }
   void orc_fmpc_destroy(void * h) { delete (BatchMPCFull *)h; }
   void orc_fmpc_generate_cycle(void * h, const unsigned char * cs, int n)

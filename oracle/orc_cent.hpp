@@ -223,6 +223,8 @@ namespace orc
     {
       return quad3(s.w_linear_mom, v3(x[3], x[4], x[5])) + quad3(s.w_angular_mom, v3(x[6], x[7], x[8]));
     }
+    // CentroidalOCP::createTerminalConstraint leaves the constraint out (reference src/centroidal-dynamics.cpp:318-328)
+    void term_cstr(Rigid &, const double *, const double *, double, double *, Mat *) const {}
     void term_deriv(Rigid &, const Vec &, const double * x, Vec & lx, Mat & Lxx) const
     {
       lx.assign(9, 0.0);

@@ -391,5 +391,10 @@ namespace orc
     {
       terminal_model().term_deriv(R, x_tgt, x, lx, Lxx);
     }
+    // DCM terminal constraint of src/fulldynamics.cpp:433-446: the same residual as the kinodynamics one
+    void term_cstr(Rigid & R, const double * x, const double ref[3], double tau, double * c, Mat * C) const
+    {
+      terminal_model().term_cstr(R, x, ref, tau, c, C);
+    }
   };
 } // namespace orc

@@ -448,6 +448,33 @@ namespace orc
         e *= 10.0;
       return quad(s.w_x, rx) + quad(W10, sv_vec(R.hg()));
     }
+    // terminal constraint DCMPositionResidual: c = com(q) + tau vcom(q, v) - ref, C = [Jcom + tau dvcom/dq | tau Jcom]
+    // (reference src/kinodynamics.cpp:366-377; [UPSTREAM-RECALL] aligator DCMPositionResidualTpl: centerOfMass + alpha vcom - dcm_ref,
+    // Jacobian from jacobianCenterOfMass and getCenterOfMassVelocityDerivatives)
+    void term_cstr(Rigid & R, const double * x, const double ref[3], double tau, double * c, Mat * C) const
+    {
+      R.fk(x);
+      R.velocities(x + nq);
+      const SV h = R.hg();
+      const double m = M->total_mass;
+      for (int i = 0; i < 3; i++)
+        c[i] = R.com[i] + tau * h.l[i] / m - ref[i];
+      if (!C)
+        return;
+      Vec zero(nv, 0.0);
+      R.forces(x + nq, zero.data());
+      R.compute_Bc();
+      Mat dh_dq, d1, d2;
+      R.centroidal_derivatives(dh_dq, d1, d2);
+      const Mat Ag = R.Ag();
+      C->resize(3, ndx);
+      for (int i = 0; i < 3; i++)
+        for (int k = 0; k < nv; k++)
+        {
+          (*C)(i, k) = (Ag(i, k) + tau * dh_dq(i, k)) / m;
+          (*C)(i, nv + k) = tau * Ag(i, k) / m;
+        }
+    }
     void term_deriv(Rigid & R, const Vec & x_tgt, const double * x, Vec & lx, Mat & Lxx) const
     {
       R.fk(x);

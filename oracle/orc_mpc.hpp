@@ -146,8 +146,10 @@ namespace orc
     bool keep_knots = false;
     std::vector<std::vector<Knot>> last_knots; // [b][t], filled when keep_knots (tests only)
 
-    BatchMPCT(const smpc_robot_model * m, const ModelSettings & ks, const MPCSettings & ms, int H_, int B_, double gravity_arg)
-    : M(m), md(m, ks), st(ms), H(H_), B(B_)
+    bool terminal_constraint = false;
+    BatchMPCT(const smpc_robot_model * m, const ModelSettings & ks, const MPCSettings & ms, int H_, int B_, double gravity_arg,
+              bool terminal_constraint_ = false)
+    : M(m), md(m, ks), st(ms), H(H_), B(B_), terminal_constraint(terminal_constraint_)
     {
       nf = m->nfeet;
       x_model_ref.assign(md.nx, 0.0);
@@ -173,16 +175,25 @@ namespace orc
       OcpInstance o;
       o.stages = horizon;
       o.x_tgt_term = x_model_ref;
+      if (terminal_constraint)
+      { // createTerminalConstraint(x0.head<3>()): the reference is the base position until the first iterate (src/ocp-handler.cpp:133-136)
+        o.term_cstr = true;
+        for (int i = 0; i < 3; i++)
+          o.dcm_ref[i] = x_model_ref[i];
+        o.dcm_tau = std::sqrt(x_model_ref[2] / 9.81);
+      }
       SolverState s0;
+      s0.vN.assign(3, 0.0);
       s0.xs.assign(H + 1, x_model_ref);
       s0.us.assign(H, Vec(def.u_ref.begin(), def.u_ref.begin() + md.nu)); // getReferenceControl(0) (src/mpc.cpp:75)
       s0.vs.assign(H, Vec(md.nc, 0.0));
       s0.lams.assign(H + 1, Vec(md.ndx, 0.0));
       ProxDDPT<Model> solver(md, st.mu_init);
       std::vector<Vec> vs_e = s0.vs, lams_e = s0.lams;
+      Vec vN_e = s0.vN;
       for (int it = 0; it < 100; it++)
       {
-        IterInfo info = solver.iterate(R, o, s0, vs_e, lams_e);
+        IterInfo info = solver.iterate(R, o, s0, vs_e, lams_e, nullptr, &vN_e);
         cold_trace.push_back(info);
         if (std::fmax(info.prim_infeas, info.dual_infeas) <= st.TOL)
           break;
@@ -194,6 +205,7 @@ namespace orc
         {
           vs_e = s0.vs;
           lams_e = s0.lams;
+          vN_e = s0.vN;
         }
       }
       ocp.assign(B, o);
@@ -353,6 +365,15 @@ namespace orc
             o.stages[k].foot_ref[f] = p;
           }
         }
+        if (o.term_cstr)
+        { // updateTerminalConstraint: mean of the last foot references, at the CoM height of the reference state (src/mpc.cpp:313-323)
+          V3 cr = v3(0, 0, 0);
+          for (int f = 0; f < nf; f++)
+            cr = cr + o.stages[H - 1].foot_ref[f];
+          for (int i = 0; i < 3; i++)
+            o.dcm_ref[i] = cr[i] / (double)nf;
+          o.dcm_ref[2] += com0[2];
+        }
         // ---- warm start shift (src/mpc.cpp:201-207) ----
         S.xs.erase(S.xs.begin());
         S.xs[0].assign(x, x + md.nx);
@@ -361,9 +382,10 @@ namespace orc
         S.us.push_back(S.us.back());
         // ---- solver run: max_iters iterations, centres = incoming multipliers ----
         std::vector<Vec> vs_e = S.vs, lams_e = S.lams;
+        const Vec vN_e = S.vN;
         S.preg = SolverConsts::REG_INIT; // regularisation restarts with every solver run
         for (int it = 0; it < st.max_iters; it++)
-          last_info[b] = solver.iterate(R, o, S, vs_e, lams_e, keep_knots ? &last_knots[b] : nullptr);
+          last_info[b] = solver.iterate(R, o, S, vs_e, lams_e, keep_knots ? &last_knots[b] : nullptr, &vN_e);
       }
     }
   };

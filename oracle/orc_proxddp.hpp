@@ -202,10 +202,16 @@ namespace orc
   {
     std::vector<StageRef> stages; // H
     Vec x_tgt_term;               // terminal state_cost target
+    // terminal equality constraint DCMPositionResidual(com_ref, tau): com + tau vcom = dcm_ref (createProblem(..., terminal_constraint = true):
+    // reference src/ocp-handler.cpp:133-136, src/kinodynamics.cpp:366-377)
+    bool term_cstr = false;
+    double dcm_ref[3] = {0, 0, 0};
+    double dcm_tau = 0;
   };
   struct SolverState
   {
     std::vector<Vec> xs, us, vs, lams; // lams[0] unused (initial condition is forced)
+    Vec vN;                            // multipliers of the terminal constraint (3 when the problem has one)
     double preg = SolverConsts::REG_INIT;
     std::vector<Mat> Ks;               // feedback gains of the last iteration
     std::vector<Vec> xdot;             // continuous xdot per stage at the accepted point
@@ -230,6 +236,7 @@ namespace orc
       std::vector<Vec> e;      // defects, index t+1
       std::vector<Vec> lam_plus, v_plus;
       std::vector<std::vector<char>> active;
+      Vec vN_plus, cN;
       double cost = 0, phi = 0, prim = 0;
     };
 
@@ -237,7 +244,7 @@ namespace orc
     void evaluate(
       Rigid & R, const OcpInstance & ocp, const std::vector<Vec> & xs, const std::vector<Vec> & us,
       const std::vector<Vec> & vs, const std::vector<Vec> & lams, const std::vector<Vec> & vs_e,
-      const std::vector<Vec> & lams_e, Eval & E) const
+      const std::vector<Vec> & lams_e, Eval & E, const Vec * vN = nullptr, const Vec * vN_e = nullptr) const
     {
       const int H = (int)ocp.stages.size();
       E.ev.resize(H);
@@ -293,6 +300,20 @@ namespace orc
         }
       }
       cost += md.term_eval(R, ocp.x_tgt_term, xs[H].data());
+      if (ocp.term_cstr)
+      {
+        E.cN.assign(3, 0.0);
+        E.vN_plus.assign(3, 0.0);
+        md.term_cstr(R, xs[H].data(), ocp.dcm_ref, ocp.dcm_tau, E.cN.data(), nullptr);
+        for (int i = 0; i < 3; i++)
+        {
+          const double vp = (*vN_e)[i] + E.cN[i] / mu; // equality row: always active
+          E.vN_plus[i] = vp;
+          const double dv = vp - (*vN)[i];
+          pen += 0.5 * mu * (vp * vp + dv * dv);
+          prim = std::fmax(prim, std::fabs(E.cN[i]));
+        }
+      }
       E.cost = cost;
       E.phi = cost + pen;
       E.prim = prim;
@@ -301,13 +322,13 @@ namespace orc
     // One full iteration; vs_e / lams_e are the AL centres.
     IterInfo iterate(
       Rigid & R, const OcpInstance & ocp, SolverState & S, const std::vector<Vec> & vs_e,
-      const std::vector<Vec> & lams_e, std::vector<Knot> * knots_out = nullptr) const
+      const std::vector<Vec> & lams_e, std::vector<Knot> * knots_out = nullptr, const Vec * vN_e = nullptr) const
     {
       const int H = (int)ocp.stages.size();
       const int ndx = md.ndx, nu = md.nu, nc = md.nc;
       IterInfo info;
       Eval E0;
-      evaluate(R, ocp, S.xs, S.us, S.vs, S.lams, vs_e, lams_e, E0);
+      evaluate(R, ocp, S.xs, S.us, S.vs, S.lams, vs_e, lams_e, E0, &S.vN, vN_e);
       info.phi0 = E0.phi;
       info.cost = E0.cost;
       info.prim_infeas = E0.prim;
@@ -365,13 +386,43 @@ namespace orc
       Mat QN = LxxN;
       for (int i = 0; i < ndx; i++)
         QN(i, i) += S.preg;
+      // terminal constraint rows C dx - mu dv + mu (v+ - v) = 0, eliminated: QN += C^T C / mu, qN + C^T v += C^T (v+ - v)
+      Mat CN;
+      Vec dN(3, 0.0);
+      if (ocp.term_cstr)
+      {
+        Vec c3(3);
+        md.term_cstr(R, S.xs[H].data(), ocp.dcm_ref, ocp.dcm_tau, c3.data(), &CN);
+        axpy(qN, mulT(CN, S.vN));
+        for (int i = 0; i < 3; i++)
+          dN[i] = mu * (E0.vN_plus[i] - S.vN[i]);
+      }
       dual = std::fmax(dual, norm_inf(qN));
       info.dual_infeas = dual;
+      if (ocp.term_cstr)
+      {
+        for (int r = 0; r < 3; r++)
+          for (int i = 0; i < ndx; i++)
+          {
+            qN[i] += CN(r, i) * dN[r] / mu;
+            for (int j = 0; j < ndx; j++)
+              QN(i, j) += CN(r, i) * CN(r, j) / mu;
+          }
+      }
       if (knots_out)
         *knots_out = kn;
 
       std::vector<Vec> dxs, dus, dvs, dlams;
       prox_riccati(kn, QN, qN, mu, dxs, dus, dvs, dlams, &S.Ks);
+      Vec dvN(3, 0.0);
+      if (ocp.term_cstr)
+        for (int r = 0; r < 3; r++)
+        {
+          double acc = dN[r];
+          for (int i = 0; i < ndx; i++)
+            acc += CN(r, i) * dxs[H][i];
+          dvN[r] = acc / mu;
+        }
 
       // directional derivative of the merit
       double dphi = 0;
@@ -403,12 +454,21 @@ namespace orc
         Vec gx = lxN;
         for (int i = 0; i < ndx; i++)
           gx[i] -= 2.0 * E0.lam_plus[H][i] - S.lams[H][i];
+        if (ocp.term_cstr)
+          for (int r = 0; r < 3; r++)
+          {
+            const double vpd = 2.0 * E0.vN_plus[r] - S.vN[r];
+            for (int i = 0; i < ndx; i++)
+              gx[i] += CN(r, i) * vpd;
+            dphi -= mu * (E0.vN_plus[r] - S.vN[r]) * dvN[r];
+          }
         dphi += dot(gx, dxs[H]);
       }
       info.dphi0 = dphi;
 
       // line search
       std::vector<Vec> txs(H + 1), tus(H), tvs(H), tl(H + 1);
+      Vec tvN = S.vN;
       Eval Et;
       double alpha = 1.0;
       int accepted = -1;
@@ -431,7 +491,10 @@ namespace orc
           tvs[t] = S.vs[t];
           axpy(tvs[t], dvs[t], alpha);
         }
-        evaluate(R, ocp, txs, tus, tvs, tl, vs_e, lams_e, Et);
+        if (ocp.term_cstr)
+          for (int r = 0; r < 3; r++)
+            tvN[r] = S.vN[r] + alpha * dvN[r];
+        evaluate(R, ocp, txs, tus, tvs, tl, vs_e, lams_e, Et, &tvN, vN_e);
         info.ls_index = j;
         if (Et.phi <= info.phi0 + SolverConsts::ARMIJO_C1 * alpha * dphi)
         {
@@ -450,6 +513,7 @@ namespace orc
       S.us = tus;
       S.vs = tvs;
       S.lams = tl;
+      S.vN = tvN;
       S.xdot.resize(H);
       for (int t = 0; t < H; t++)
         S.xdot[t] = Et.ev[t].xdot;

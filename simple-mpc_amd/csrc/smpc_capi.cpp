@@ -107,6 +107,7 @@ extern "C"
     for (int i = 0; i < 3; i++)
       ks.gravity[i] = ocp->gravity[i];
     ks.kinematics_limits = ocp->kinematics_limits;
+    ks.terminal_constraint = ocp->terminal_constraint;
     for (int i = 0; i < nv - 6; i++)
       if (!(ks.qmin[i] <= ks.qmax[i]))
         return fail(SMPC_ERR_INVALID, "qmin must not exceed qmax (joint limits are indexed by actuated joint, 0 .. nv - 7)");
@@ -217,6 +218,7 @@ extern "C"
     s.kinematics_limits = ocp->kinematics_limits;
     s.force_cone = ocp->force_cone;
     s.land_cstr = ocp->land_cstr;
+    s.terminal_constraint = ocp->terminal_constraint;
     for (int i = 0; i < nu; i++)
       if (!(s.qmin[i] <= s.qmax[i]) || !(s.umin[i] <= s.umax[i]))
         return fail(SMPC_ERR_INVALID, "lower limits must not exceed upper limits (indexed by actuated joint, 0 .. nv - 7)");

@@ -29,12 +29,64 @@ namespace smpc
     std::vector<double> w_x, w_u, w_frame, w_cent, w_centder, qmin, qmax;
     double gravity[3];
     int kinematics_limits;
+    int terminal_constraint = 0; // createProblem(..., terminal_constraint)
   };
   struct HostMpcSettings
   {
     double swing_apex, support_force, TOL, mu_init, timestep;
     int max_iters, num_threads, T_fly, T_contact, T;
   };
+
+  // CoM height at state x from the host copy of a device model (MPC::com0_ at the reference state, reference src/mpc.cpp:93)
+  template <class M>
+  double host_com_height(const M & m, const double * x)
+  {
+    constexpr int NJ = sizeof(m.mass) / sizeof(double);
+    M3 Rj[NJ];
+    V3 pj[NJ];
+    double mt = 0.0, mz = 0.0;
+    for (int j = 0; j < NJ; j++)
+    {
+      if (j == 0)
+      {
+        Rj[0] = quat_to_R(Quat{x[3], x[4], x[5], x[6]});
+        pj[0] = ld3(x);
+      }
+      else
+      {
+        const double ang = x[6 + j], s = std::sin(ang), c = std::cos(ang);
+        const int jt = m.jtype[j];
+        M3 Rq = jt == 1 ? M3{1, 0, 0, 0, c, -s, 0, s, c} : (jt == 2 ? M3{c, 0, s, 0, 1, 0, -s, 0, c} : M3{c, -s, 0, s, c, 0, 0, 0, 1});
+        Rj[j] = Rj[m.parent[j]] * (ldm3(m.jpR[j]) * Rq);
+        pj[j] = pj[m.parent[j]] + Rj[m.parent[j]] * ld3(m.jpp[j]);
+      }
+      const V3 cw = pj[j] + Rj[j] * ld3(m.com[j]);
+      mt += m.mass[j];
+      mz += m.mass[j] * cw.z;
+    }
+    return mz / mt;
+  }
+
+  // createTerminalConstraint(x0.head<3>()): tau = sqrt(x0_z / 9.81), reference = the base position until the first control step
+  // (reference src/ocp-handler.cpp:133-136, src/kinodynamics.cpp:366-377); multipliers start at zero
+  template <class D>
+  void alloc_terminal_constraint(Buffers<D> & bf, const double * x0, double com_height, stream_t stream)
+  {
+    auto dalloc = [&](size_t n) {
+      double * p = (double *)dev_alloc(n * sizeof(double));
+      dev_zero(p, n * sizeof(double), stream);
+      return p;
+    };
+    bf.CN = dalloc((size_t)bf.B * (3 * D::NDX + 3));
+    bf.vN = dalloc((size_t)bf.B * 3);
+    bf.vN_e = dalloc((size_t)bf.B * 3);
+    bf.vN_b = dalloc((size_t)bf.B * 3);
+    bf.dvN = dalloc((size_t)bf.B * 3);
+    bf.dcm_ref = dalloc((size_t)bf.B * 3);
+    bf.dcm_tau = std::sqrt(x0[2] / 9.81);
+    bf.com0z = com_height;
+    h2d(bf.dcm_ref, x0, 3 * sizeof(double), stream);
+  }
 
   // integer gait bookkeeping (reference src/mpc.cpp:101-132, 220-276)
   struct GaitTimer
@@ -382,6 +434,8 @@ namespace smpc
       buf.stages = (StageShared<D> *)dev_alloc((size_t)H * sizeof(StageShared<D>));
       buf.model = (DevModel<D> *)dev_alloc(sizeof(DevModel<D>));
       X_dev = dalloc((size_t)B * D::NX);
+      if (ks.terminal_constraint)
+        alloc_terminal_constraint<D>(buf, x_model_ref.data(), host_com_height(m, x_model_ref.data()), stream);
       if (std::getenv("SMPC_PHASE_PROFILE"))
         buf.dbg = dalloc(64);
       h2d(buf.model, hm.data(), sizeof(DevModel<D>), stream);
@@ -408,6 +462,8 @@ namespace smpc
     }
     ~KinoEngine()
     {
+      for (double * p : {buf.CN, buf.vN, buf.vN_e, buf.vN_b, buf.dvN, buf.dcm_ref})
+        dev_free(p);
       for (double * p : {buf.xs_b, buf.us_b, buf.vs_b, buf.lams_b, buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref, buf.ftraj, buf.vbase, buf.vref, buf.lq,
                          buf.gains, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, X_dev, stage_out})
         dev_free(p);
@@ -513,6 +569,8 @@ namespace smpc
         }
         timed_launch<SolverArgs<D>, forward_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
       }
+      if (b.CN != nullptr)
+        timed_launch<SolverArgs<D>, term_step_body<D>, 64>(KID_FORWARD, (b.B + 63) / 64, solver_args(b));
     }
     // backtracking candidates 2^-1 .. 2^-9 for the instances that are still undecided (compacted list)
     int launch_backtracking(const Buffers<D> & b)
@@ -596,6 +654,8 @@ namespace smpc
     {
       d2d(b.vs_e, b.vs, (size_t)b.B * R * D::NC * sizeof(double), stream);
       d2d(b.lams_e, b.lams, (size_t)b.B * R * D::NDX * sizeof(double), stream);
+      if (b.CN != nullptr)
+        d2d(b.vN_e, b.vN, (size_t)b.B * 3 * sizeof(double), stream);
     }
 
     void upload_stages()
@@ -657,6 +717,11 @@ namespace smpc
       bc(buf.vs, (size_t)R * D::NC);
       bc(buf.lams, (size_t)R * D::NDX);
       bc(buf.scal, SC_N);
+      if (buf.CN != nullptr)
+      {
+        bc(buf.vN, 3);
+        bc(buf.dcm_ref, 3);
+      }
       // swing start/end = reference foot positions (FootTrajectory ctor, src/foot-trajectory.cpp:20-39):
       // a reference-only recede call with land = -1 < T_fly keeps them, so initialise them here on the host
       std::vector<double> ft((size_t)D::NF * 6);
@@ -893,6 +958,7 @@ namespace smpc
       io.tag(H, "horizon");
       io.tag(D::NX, "nx");
       io.tag(D::NU, "nu");
+      io.tag(buf.CN != nullptr ? 1 : 0, "terminal constraint");
       io.pod(head);
       io.pod(walking);
       io.host(velocity_base, sizeof(velocity_base));
@@ -911,6 +977,8 @@ namespace smpc
       io.dev(buf.vref, BR * 6 * sizeof(double));
       io.dev(buf.scal, (size_t)B * SC_N * sizeof(double));
       io.dev(buf.xdot01, (size_t)B * 4 * D::NV * sizeof(double));
+      if (buf.CN != nullptr)
+        io.dev(buf.vN, (size_t)B * 3 * sizeof(double));
       if (io.mode == StateIO::LOAD)
         upload_stages();
       stream_sync(stream);

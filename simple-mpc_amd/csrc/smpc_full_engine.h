@@ -17,6 +17,7 @@ namespace smpc
     double gravity[3];
     double mu, Lfoot, Wfoot;
     int force_size, torque_limits, kinematics_limits, force_cone, land_cstr;
+    int terminal_constraint = 0; // createProblem(..., terminal_constraint)
   };
 
   // what the C ABI needs from a full-dynamics engine of any robot shape
@@ -202,6 +203,8 @@ namespace smpc
       buf.stages = (StageShared<D> *)dev_alloc((size_t)H * sizeof(StageShared<D>));
       buf.model = (DevModel<D> *)dev_alloc(sizeof(DevModel<D>));
       X_dev = dalloc((size_t)B * D::NX);
+      if (fs.terminal_constraint)
+        alloc_terminal_constraint<D>(buf, x_model_ref.data(), host_com_height(m, x_model_ref.data()), stream);
       if (std::getenv("SMPC_PHASE_PROFILE"))
         buf.dbg = dalloc(64);
       h2d(buf.model, hm.data(), sizeof(DevModel<D>), stream);
@@ -220,6 +223,8 @@ namespace smpc
     }
     ~FullEngine()
     {
+      for (double * p : {buf.CN, buf.vN, buf.vN_e, buf.vN_b, buf.dvN, buf.dcm_ref})
+        dev_free(p);
       for (double * p : {buf.xs_b, buf.us_b, buf.vs_b, buf.lams_b, buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref,
                          buf.ftraj, buf.vbase, buf.vref, buf.lq, buf.gains, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, buf.forces,
                          buf.forcesT, X_dev, stage_out})
@@ -303,11 +308,18 @@ namespace smpc
         {
           timed_launch<SolverArgs<D>, riccati_full_body<D, 256>, 256>(KID_RICCATI, b.B, solver_args(b)); // cross-check (box rows only)
           timed_launch<SolverArgs<D>, forward_full_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
+          launch_term_step(b);
           return;
         }
       }
       timed_launch<SolverArgs<D>, riccati_dense_body<D>, 64, (RiccatiDenseGeom<D>::NT2 > 6 ? 1 : 2)>(KID_RICCATI, b.B, solver_args(b));
       timed_launch<SolverArgs<D>, forward_full_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
+      launch_term_step(b);
+    }
+    void launch_term_step(const Buffers<D> & b)
+    {
+      if (b.CN != nullptr)
+        timed_launch<SolverArgs<D>, term_step_body<D>, 64>(KID_FORWARD, (b.B + 63) / 64, solver_args(b));
     }
     int launch_backtracking(const Buffers<D> & b)
     {
@@ -381,6 +393,8 @@ namespace smpc
     {
       d2d(b.vs_e, b.vs, (size_t)b.B * R * D::NC * sizeof(double), stream);
       d2d(b.lams_e, b.lams, (size_t)b.B * R * D::NDX * sizeof(double), stream);
+      if (b.CN != nullptr)
+        d2d(b.vN_e, b.vN, (size_t)b.B * 3 * sizeof(double), stream);
     }
     void upload_stages() { h2d(buf.stages, horizon.data(), (size_t)H * sizeof(StageShared<D>), stream); }
 
@@ -436,6 +450,11 @@ namespace smpc
       bc(buf.lams, (size_t)R * D::NDX);
       bc(buf.scal, SC_N);
       bc(buf.forces, (size_t)H * D::NCM);
+      if (buf.CN != nullptr)
+      {
+        bc(buf.vN, 3);
+        bc(buf.dcm_ref, 3);
+      }
       // swing start / end = foot positions at the reference state (FootTrajectory ctor, src/foot-trajectory.cpp:20-39)
       std::vector<double> ft((size_t)D::NF * 6);
       host_foot_positions(m, x_model_ref.data(), ft.data());
@@ -683,6 +702,7 @@ namespace smpc
       io.tag(H, "horizon");
       io.tag(D::NX, "nx");
       io.tag(D::NU, "nu");
+      io.tag(buf.CN != nullptr ? 1 : 0, "terminal constraint");
       io.pod(head);
       io.pod(walking);
       io.host(velocity_base, sizeof(velocity_base));
@@ -702,6 +722,8 @@ namespace smpc
       io.dev(buf.scal, (size_t)B * SC_N * sizeof(double));
       io.dev(buf.xdot01, (size_t)B * 4 * D::NV * sizeof(double));
       io.dev(buf.forces, (size_t)B * H * D::NCM * sizeof(double));
+      if (buf.CN != nullptr)
+        io.dev(buf.vN, (size_t)B * 3 * sizeof(double));
       if (io.mode == StateIO::LOAD)
         upload_stages();
       stream_sync(stream);

@@ -1467,11 +1467,13 @@ namespace smpc
   // entry (r, k) of the block-diagonal Gauss-Newton weight W~ = blockdiag(w_forces per contact, w_cent (x 10 at the terminal
   // node), w_frame per foot) over the rows of JT
   template <class D, class SC>
-  SMPC_DEV double full_wtilde(const FullHead<D> & h, int r, int k, bool term)
+  SMPC_DEV double full_wtilde(const FullHead<D> & h, int r, int k, bool term, bool tcs = false)
   {
     constexpr int NCM = D::NCM, FS = D::FS, NGN = SC::NGN;
     if (r >= NGN || k >= NGN)
       return 0.0;
+    if (r < NCM && term) // terminal node: the first three rows hold the terminal constraint's Jacobian, weight 1 / mu (C^T C / mu)
+      return (tcs && r < 3 && r == k) ? 1.0 / h.mu : 0.0;
     if (r < NCM)
       return (term || k >= NCM || r / FS != k / FS) ? 0.0 : h.w_forces[(r % FS) * FS + k % FS];
     if (r < NCM + 6)
@@ -1531,7 +1533,7 @@ namespace smpc
   // B-operand layout of K-step 4 R + v of the second product, so the weighted Jacobian never leaves the registers.  Upper 16 x 16
   // tiles of the (x, u) grid are written: Q (upper tiles; mirrored when `mirror`), S, R (readers take (min, max) indices).
   template <class D, class SC, class SD>
-  SMPC_DEV void full_hessian_mfma(SC & sc, SD & sd, const DevModel<D> & mg, bool term, double preg, double * Qd, double * Sd, double * Rd, bool mirror)
+  SMPC_DEV void full_hessian_mfma(SC & sc, SD & sd, const DevModel<D> & mg, bool term, double preg, double * Qd, double * Sd, double * Rd, bool mirror, bool tcs = false)
   {
     constexpr int NT = 64;
     constexpr int NDX = D::NDX, NU = D::NU, NXU = D::NXU, NCOL = SC::NCOL, NGN = SC::NGN;
@@ -1580,14 +1582,14 @@ namespace smpc
         for (int J = 0; J < NTC; J++)
         {
           const int c = 16 * J + lc;
-          const bool ok = r < NGN && c < NCOL && (!term || (r >= D::NCM && r < D::NCM + 6)); // terminal node: momentum rows only
+          const bool ok = r < NGN && c < NCOL && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3)); // terminal node: momentum (+ constraint) rows only
           const double * row = (ok && r < D::NCM) ? &sd.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL;
           const double v = row[c < NCOL ? c : 0];
           SMPC_PLV(jtv)[J] = ok ? v : 0.0;
         }
 #pragma unroll
         for (int R = 0; R < NTR; R++)
-          SMPC_PLV(wop)[R] = full_wtilde<D, SC>(h, 16 * R + lc, r, term);
+          SMPC_PLV(wop)[R] = full_wtilde<D, SC>(h, 16 * R + lc, r, term, tcs);
       }
       SMPC_LANES_END_WAVE
 #pragma unroll
@@ -1612,7 +1614,7 @@ namespace smpc
           for (int J = 0; J < NTC; J++)
           {
             const int c = 16 * J + lc;
-            const bool ok = r < NGN && c < NCOL && (!term || (r >= D::NCM && r < D::NCM + 6));
+            const bool ok = r < NGN && c < NCOL && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3));
             const double * row = (ok && r < D::NCM) ? &sd.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL;
             const double x = row[c < NCOL ? c : 0];
             SMPC_PLV(jtv)[J] = ok ? x : 0.0;
@@ -1790,15 +1792,61 @@ namespace smpc
       // ---- terminal node: Q_N = Lxx + preg I, q_N = lx - lambda_H ----
       double * QN = b.QN + (size_t)inst * NDX * NDX;
       double * qN = b.qN + (size_t)inst * NDX;
-      full_hessian_mfma<D>(sc, sd, mg, true, preg, QN, (double *)nullptr, (double *)nullptr, true);
+      // terminal constraint c = com + tau vcom - ref (DCMPositionResidual, reference src/fulldynamics.cpp:433-455): the rows
+      // C = [Jcom + tau dvcom/dq | tau Jcom] go where the (absent) force rows of JT would be, v | v+ | c behind them; the product
+      // below then carries C^T C / mu, and q_N gets C^T v+
+      const bool tcs = b.CN != nullptr;
+      double * tv = &sd.JT[3 * NCOL];
+      static_assert(NCM >= 4 && NCOL >= 9, "terminal constraint scratch inside the force rows");
+      if (tcs)
+      {
+        SMPC_LANES(NT)
+        {
+          const double im = 1.0 / h.total_mass, tau = b.dcm_tau;
+          const double * hrow = sc.jt2_(); // momentum rows [dh/dq | Ag | 0]
+          for (int idx = lane; idx < 3 * NCOL; idx += NT)
+          {
+            const int r = idx / NCOL, k = idx % NCOL;
+            double v = 0.0;
+            if (k < NV)
+              v = (hrow[r * NCOL + NV + k] + tau * hrow[r * NCOL + k]) * im;
+            else if (k < NDX)
+              v = tau * hrow[r * NCOL + k] * im;
+            sd.JT[idx] = v;
+            if (k < NDX)
+              b.CN[(size_t)inst * (3 * NDX + 3) + r * NDX + k] = v;
+          }
+          if (lane < 3)
+          {
+            const double c = sc.com[lane] + tau * sc.hg[lane] * im - b.dcm_ref[(size_t)inst * 3 + lane];
+            const double v = b.vN[(size_t)inst * 3 + lane];
+            const double vp = b.vN_e[(size_t)inst * 3 + lane] + c / h.mu;
+            tv[lane] = v;
+            tv[3 + lane] = vp;
+            tv[6 + lane] = c;
+            b.CN[(size_t)inst * (3 * NDX + 3) + 3 * NDX + lane] = h.mu * (vp - v);
+          }
+        }
+        SMPC_LANES_END_WAVE
+      }
+      full_hessian_mfma<D>(sc, sd, mg, true, preg, QN, (double *)nullptr, (double *)nullptr, true, tcs);
       SMPC_LANES(NT)
       {
         double dual = 0.0;
         for (int k = lane; k < NDX; k += NT)
         {
-          const double qn = sd.gx_()[k] - b.lams[(ib + sprev) * NDX + k];
+          double qn = sd.gx_()[k] - b.lams[(ib + sprev) * NDX + k];
+          if (tcs)
+          {
+            for (int r = 0; r < 3; r++)
+              qn += sd.JT[r * NCOL + k] * tv[r];
+            dual = fmax(dual, fabs(qn)); // dual residual with the current multipliers; the Newton right-hand side uses v+
+            for (int r = 0; r < 3; r++)
+              qn += sd.JT[r * NCOL + k] * (h.mu * (tv[3 + r] - tv[r])) / h.mu;
+          }
+          else
+            dual = fmax(dual, fabs(qn));
           qN[k] = qn;
-          dual = fmax(dual, fabs(qn));
         }
         sc.part[lane] = dual;
       }
@@ -1809,9 +1857,17 @@ namespace smpc
         double dual = 0.0;
         for (int k = 0; k < NT; k++)
           dual = fmax(dual, sc.part[k]);
-        parts[0] = sc.red[0];
+        double pen = 0.0, prim = 0.0;
+        if (tcs)
+          for (int r = 0; r < 3; r++)
+          {
+            const double vp = tv[3 + r], dv = vp - tv[r];
+            pen += 0.5 * h.mu * (vp * vp + dv * dv);
+            prim = fmax(prim, fabs(tv[6 + r]));
+          }
+        parts[0] = sc.red[0] + pen;
         parts[1] = sc.red[0];
-        parts[2] = 0.0;
+        parts[2] = prim;
         parts[3] = dual;
       }
       SMPC_LANES_END_WAVE
@@ -2006,8 +2062,18 @@ namespace smpc
     {
       if (lane == 0)
       {
-        parts[0] = term ? sc.red[0] : sc.red[0] + sc.red[1];
-        parts[1] = term ? 0.0 : sc.red[2];
+        double pen = 0.0, prim = 0.0;
+        if (term && b.CN != nullptr)
+          for (int r = 0; r < 3; r++)
+          { // terminal constraint at the trial point, multipliers v + alpha dv
+            const double c = sc.com[r] + b.dcm_tau * sc.hg[r] / sc.h.total_mass - b.dcm_ref[(size_t)inst * 3 + r];
+            const double vp = b.vN_e[(size_t)inst * 3 + r] + c / sc.h.mu;
+            const double dv = vp - (b.vN[(size_t)inst * 3 + r] + alpha * b.dvN[(size_t)inst * 3 + r]);
+            pen += 0.5 * sc.h.mu * (vp * vp + dv * dv);
+            prim = fmax(prim, fabs(c));
+          }
+        parts[0] = term ? sc.red[0] + pen : sc.red[0] + sc.red[1];
+        parts[1] = term ? prim : sc.red[2];
       }
       if (!term && t < 2)
         for (int i = lane; i < NV; i += NT)

@@ -205,6 +205,43 @@ namespace smpc
       SMPC_LANES_END_WAVE
       double * QN = b.QN + (size_t)inst * NDX * NDX;
       double * qN = b.qN + (size_t)inst * NDX;
+      // terminal constraint c = com + tau vcom - ref (DCMPositionResidual): rows C = [Jcom + tau dvcom/dq | tau Jcom] into the (dead)
+      // weighted-Jacobian block, v+ = v_e + c / mu; folded below: Q_N += C^T C / mu, q_N += C^T v+
+      const bool tcs = b.CN != nullptr;
+      double * tC = sc.Jfoot; // 3 x NDX, then v | v+ | c  (the terminal node has no foot rows)
+      static_assert(NF * 3 * NV >= 3 * NDX + 9, "terminal constraint rows fit the foot Jacobian block");
+      if (tcs)
+      {
+        SMPC_LANES(NT)
+        {
+          const double im = 1.0 / md.total_mass, tau = b.dcm_tau;
+          double cr[3];
+          if (lane < NDX)
+            for (int r = 0; r < 3; r++)
+              cr[r] = lane < NV ? (sc.Ag[r * NV + lane] + tau * sc.dh_dq[r * NV + lane]) * im : tau * sc.Ag[r * NV + lane - NV] * im;
+          double v = 0.0, vp = 0.0, c = 0.0;
+          if (lane < 3)
+          {
+            c = sc.com[lane] + tau * sc.hg[lane] * im - b.dcm_ref[(size_t)inst * 3 + lane];
+            v = b.vN[(size_t)inst * 3 + lane];
+            vp = b.vN_e[(size_t)inst * 3 + lane] + c / md.mu;
+          }
+          if (lane < NDX)
+            for (int r = 0; r < 3; r++)
+            {
+              tC[r * NDX + lane] = cr[r];
+              b.CN[(size_t)inst * (3 * NDX + 3) + r * NDX + lane] = cr[r];
+            }
+          if (lane < 3)
+          {
+            tC[3 * NDX + lane] = v;
+            tC[3 * NDX + 3 + lane] = vp;
+            tC[3 * NDX + 6 + lane] = c;
+            b.CN[(size_t)inst * (3 * NDX + 3) + 3 * NDX + lane] = md.mu * (vp - v);
+          }
+        }
+        SMPC_LANES_END_WAVE
+      }
       SMPC_LANES(NT)
       if (lane < NDX)
       {
@@ -219,9 +256,18 @@ namespace smpc
           g = sc.Wrx[k];
         for (int a = 0; a < 6; a++)
           g += (k < NV ? sc.dh_dq[a * NV + k] : sc.Ag[a * NV + k - NV]) * sc.Whg[a];
-        const double qn = g - b.lams[(ib + sprev) * NDX + k];
+        double qn = g - b.lams[(ib + sprev) * NDX + k];
+        if (tcs)
+        {
+          for (int r = 0; r < 3; r++)
+            qn += tC[r * NDX + k] * tC[3 * NDX + r];
+          dual = fabs(qn); // dual residual with the current multipliers; the Newton right-hand side uses v+
+          for (int r = 0; r < 3; r++)
+            qn += tC[r * NDX + k] * (md.mu * (tC[3 * NDX + 3 + r] - tC[3 * NDX + r])) / md.mu;
+        }
+        else
+          dual = fabs(qn);
         qN[k] = qn;
-        dual = fabs(qn);
         sc.rx[k] = dual; // reuse as dual-infeasibility scratch
         for (int i = 0; i < NDX; i++)
         {
@@ -238,6 +284,9 @@ namespace smpc
             v += (i < NV ? sc.dh_dq[a * NV + i] : sc.Ag[a * NV + i - NV]) * sc.WJc()[a * NDX + k];
           if (i == k)
             v += preg;
+          if (tcs)
+            for (int r = 0; r < 3; r++)
+              v += tC[r * NDX + i] * tC[r * NDX + k] / md.mu;
           QN[i * NDX + k] = v;
         }
       }
@@ -248,9 +297,17 @@ namespace smpc
         double dual = 0.0;
         for (int k = 0; k < NDX; k++)
           dual = fmax(dual, sc.rx[k]);
-        parts[0] = sc.red[0];
+        double pen = 0.0, prim = 0.0;
+        if (tcs)
+          for (int r = 0; r < 3; r++)
+          {
+            const double vp = tC[3 * NDX + 3 + r], dv = vp - tC[3 * NDX + r];
+            pen += 0.5 * md.mu * (vp * vp + dv * dv);
+            prim = fmax(prim, fabs(tC[3 * NDX + 6 + r]));
+          }
+        parts[0] = sc.red[0] + pen;
         parts[1] = sc.red[0];
-        parts[2] = 0.0;
+        parts[2] = prim;
         parts[3] = dual;
       }
       SMPC_LANES_END_WAVE
@@ -1058,8 +1115,18 @@ namespace smpc
       SMPC_LANES(NT)
       if (lane == 0)
       {
-        parts[0] = sc.red[0];
-        parts[1] = 0.0;
+        double pen = 0.0, prim = 0.0;
+        if (b.CN != nullptr)
+          for (int r = 0; r < 3; r++)
+          { // terminal constraint at the trial point, multipliers v + alpha dv
+            const double c = sc.com[r] + b.dcm_tau * sc.hg[r] / md.total_mass - b.dcm_ref[(size_t)inst * 3 + r];
+            const double vp = b.vN_e[(size_t)inst * 3 + r] + c / md.mu;
+            const double dv = vp - (b.vN[(size_t)inst * 3 + r] + alpha * b.dvN[(size_t)inst * 3 + r]);
+            pen += 0.5 * md.mu * (vp * vp + dv * dv);
+            prim = fmax(prim, fabs(c));
+          }
+        parts[0] = sc.red[0] + pen;
+        parts[1] = prim;
       }
       SMPC_LANES_END_WAVE
       return;

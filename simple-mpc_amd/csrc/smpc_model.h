@@ -126,6 +126,12 @@ namespace smpc
     // LQ + gains
     double *lq = nullptr, *gains = nullptr;
     double *QN = nullptr, *qN = nullptr; // [B][NDX*NDX], [B][NDX]
+    // terminal equality constraint com + tau vcom = dcm_ref (DCMPositionResidual; createProblem(..., terminal_constraint = true),
+    // reference src/ocp-handler.cpp:133-136, src/kinodynamics.cpp:366-388).  CN == nullptr: the problem has none.
+    double * CN = nullptr;      // [B][3 NDX + 3]: Jacobian rows | mu (v+ - v) of the current point
+    double *vN = nullptr, *vN_e = nullptr, *vN_b = nullptr, *dvN = nullptr; // [B][3] multipliers, AL centres, backup, step
+    double * dcm_ref = nullptr; // [B][3]
+    double dcm_tau = 0.0, com0z = 0.0;
     // merit bookkeeping
     double * parts0 = nullptr;   // [B][H+1][4] phi, cost, prim, dual at the current point
     double * partsT = nullptr;   // [B][LS_N][H+1][2] phi, prim at trial points

@@ -704,6 +704,19 @@ namespace smpc
           b.lams[o] = v + alpha * b.dlams[((size_t)inst * H + t) * NDX + i];
         }
       }
+      if (b.CN != nullptr && lane < 3)
+      { // multipliers of the terminal constraint
+        const size_t o = (size_t)inst * 3 + lane;
+        if (restore)
+          b.vN[o] = b.vN_b[o];
+        else
+        {
+          const double v = b.vN[o];
+          if (tent)
+            b.vN_b[o] = v;
+          b.vN[o] = v + alpha * b.dvN[o];
+        }
+      }
       if (tent && lane == 0)
       {
         double * sc = b.scal + (size_t)inst * SC_N;
@@ -713,6 +726,40 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     static_assert(NQ == NV + 1, "free-flyer state layout");
+  }
+
+  // =============================================================================================
+  // term_step_body: grid = ceil(B / 64), lane = instance; after the forward sweep of a problem with a terminal constraint.
+  // The derivative pass folded the rows into the terminal node (Q_N += C^T C / mu, q_N += C^T v+), so the sweeps are unchanged;
+  // here dv_N = (C dx_H + d) / mu, and the directional derivative of the merit gets what the fold leaves out:
+  // C^T (v+ - v) . dx_H - d . dv_N = -|d|^2 / mu   (d = mu (v+ - v)).
+  // =============================================================================================
+  template <class D>
+  SMPC_DEV void term_step_body(const SolverArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64, NDX = D::NDX;
+    const Buffers<D> & b = ka.b;
+    SMPC_LANES(NT)
+    {
+      const int inst = block * NT + lane;
+      if (inst < b.B && b.CN != nullptr)
+      {
+        const double * cn = b.CN + (size_t)inst * (3 * NDX + 3);
+        const double * dx = b.dxs + ((size_t)inst * (b.H + 1) + b.H) * NDX;
+        const double mu = b.model->mu;
+        double corr = 0.0;
+        for (int r = 0; r < 3; r++)
+        {
+          double acc = cn[3 * NDX + r];
+          for (int i = 0; i < NDX; i++)
+            acc += cn[r * NDX + i] * dx[i];
+          b.dvN[(size_t)inst * 3 + r] = acc / mu;
+          corr += cn[3 * NDX + r] * cn[3 * NDX + r];
+        }
+        b.scal[(size_t)inst * SC_N + SC_DPHI0] -= corr / mu;
+      }
+    }
+    SMPC_LANES_END_WAVE
   }
 
   // =============================================================================================
@@ -946,6 +993,27 @@ namespace smpc
       st3(b.foot_ref + (((size_t)inst * H + k) * NF + f) * 3, p);
     }
     SMPC_LANES_END
+    // ---- updateTerminalConstraint: mean of the last foot references, at the CoM height of the reference state (src/mpc.cpp:313-323) ----
+    if (b.CN != nullptr)
+    {
+      SMPC_LANES(NT)
+      if (lane < NF)
+      {
+        const int f = lane, t = ka.land[f] - (H - 1);
+        const V3 p0 = ld3(&fse[f * 6]), p1 = ld3(&fse[f * 6 + 3]);
+        st3(&fp[f * 3], t < 0 ? p1 : (t > ka.T_fly ? p0 : bezier8(p0, p1, ka.swing_apex, float(ka.T_fly - t) / float(ka.T_fly))));
+      }
+      SMPC_LANES_END
+      SMPC_LANES(NT)
+      if (lane < 3)
+      {
+        double acc = 0.0;
+        for (int f = 0; f < NF; f++)
+          acc += fp[f * 3 + lane];
+        b.dcm_ref[(size_t)inst * 3 + lane] = acc / (double)NF + (lane == 2 ? b.com0z : 0.0);
+      }
+      SMPC_LANES_END
+    }
   }
 
   // the same n <= 8 values into a strided array of `count` records (per-stage reference setters, broadcast over the batch)

@@ -248,9 +248,8 @@ class KinodynamicsOCP(_StageReferences):
         """reference src/ocp-handler.cpp:96-137"""
         if force_size != self.settings["force_size"]:
             raise RuntimeError("force size in settings does not match reference force size")
-        if terminal_constraint:
-            raise RuntimeError("terminal (DCM) constraint is not built yet")
-        self._problem = dict(x0=np.array(x0, float), horizon=int(horizon), gravity=float(gravity))
+        self._problem = dict(x0=np.array(x0, float), horizon=int(horizon), gravity=float(gravity),
+                             terminal_constraint=bool(terminal_constraint))
 
     def getSize(self):
         if self._problem is None:
@@ -318,6 +317,7 @@ class KinodynamicsOCP(_StageReferences):
         ks.kinematics_limits = int(bool(s["kinematics_limits"]))
         ks.force_cone = int(bool(s["force_cone"]))
         ks.land_cstr = int(bool(s["land_cstr"]))
+        ks.terminal_constraint = int(ocp._problem.get("terminal_constraint", False))
         h = C.c_void_p()
         lib.check(lib.L.smpc_create(mh._ptr, C.byref(ks), C.byref(ms), batch, ocp._problem["gravity"], device_id, C.byref(h)))
         return h
@@ -452,9 +452,8 @@ class FullDynamicsOCP(KinodynamicsOCP):
     def createProblem(self, x0, horizon, force_size, gravity, terminal_constraint=False):
         if force_size != self.settings["force_size"]:
             raise RuntimeError("force size in settings does not match reference force size")
-        if terminal_constraint:
-            raise RuntimeError("terminal (DCM) constraint is not built yet")
-        self._problem = dict(x0=np.array(x0, float), horizon=int(horizon), gravity=float(gravity))
+        self._problem = dict(x0=np.array(x0, float), horizon=int(horizon), gravity=float(gravity),
+                             terminal_constraint=bool(terminal_constraint))
 
     def getCostNumber(self):
         # state, control, centroidal + one pose cost per foot + one force cost per foot in contact (tests/problem.cpp:48)
@@ -512,6 +511,7 @@ class FullDynamicsOCP(KinodynamicsOCP):
         fsx.force_size = fs
         for k in ("torque_limits", "kinematics_limits", "force_cone", "land_cstr"):
             setattr(fsx, k, int(bool(s[k])))
+        fsx.terminal_constraint = int(self._problem.get("terminal_constraint", False))
         h = C.c_void_p()
         lib.check(lib.L.smpc_create_fulldynamics(mh._ptr, C.byref(fsx), C.byref(ms), batch, self._problem["gravity"], device_id, C.byref(h)))
         return h

@@ -36,6 +36,7 @@ class KinodynamicsSettingsC(C.Structure):
         ("kinematics_limits", C.c_int),
         ("force_cone", C.c_int),
         ("land_cstr", C.c_int),
+        ("terminal_constraint", C.c_int),
     ]
 
 
@@ -79,6 +80,7 @@ class FullDynamicsSettingsC(C.Structure):
         ("kinematics_limits", C.c_int),
         ("force_cone", C.c_int),
         ("land_cstr", C.c_int),
+        ("terminal_constraint", C.c_int),
     ]
 
 

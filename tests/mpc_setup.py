@@ -46,7 +46,7 @@ def make_product(batch, max_iters=1, lib=None, horizon=50, settings_override=Non
     for n in FEET:
         mh.addPointFoot(n, "root_joint")
     ocp = simple_mpc.KinodynamicsOCP(s, mh)
-    ocp.createProblem(mh.getReferenceState(), horizon, 3, -9.81, False)
+    ocp.createProblem(mh.getReferenceState(), horizon, 3, -9.81, bool(ms.get("terminal_constraint", False)))
     conf = {k: ms[k] for k in MPC_KEYS}
     gm = simple_mpc.BatchedMPC(conf, ocp, batch, device_id=device_id, lib=lib)
     return gm, rb, s, ms
@@ -148,7 +148,7 @@ def make_full_product(batch, max_iters=1, lib=None, horizon=50, settings_overrid
     for n in FEET:
         mh.addPointFoot(n, "root_joint")
     ocp = simple_mpc.FullDynamicsOCP(s, mh)
-    ocp.createProblem(mh.getReferenceState(), horizon, 3, -9.81, False)
+    ocp.createProblem(mh.getReferenceState(), horizon, 3, -9.81, bool(ms.get("terminal_constraint", False)))
     conf = {k: ms[k] for k in MPC_KEYS}
     gm = simple_mpc.BatchedMPC(conf, ocp, batch, device_id=device_id, lib=lib)
     return gm, rb, s, ms
@@ -197,7 +197,7 @@ def make_talos_product(batch, max_iters=1, lib=None, horizon=100, settings_overr
     for n in TALOS_FEET:
         mh.addQuadFoot(n, "root_joint", TALOS_QUAD)
     ocp = simple_mpc.FullDynamicsOCP(s, mh)
-    ocp.createProblem(mh.getReferenceState(), horizon, 6, -9.81, False)
+    ocp.createProblem(mh.getReferenceState(), horizon, 6, -9.81, bool(ms.get("terminal_constraint", False)))
     conf = {k: ms[k] for k in MPC_KEYS}
     gm = simple_mpc.BatchedMPC(conf, ocp, batch, device_id=device_id, lib=lib)
     return gm, rb, s, ms

@@ -68,6 +68,7 @@ def lib():
     L.orc_kino_eval.argtypes = [vp, C.c_uint, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_kino_deriv.argtypes = [vp, C.c_uint] + [_dp] * 14
     L.orc_kino_term.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_kino_term_cstr.argtypes = [vp, _dp, _dp, C.c_double, _dp, _dp]
     L.orc_centroidal.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_full_forward_dynamics.argtypes = [vp, _dp, _dp, C.c_uint, C.c_int, _dp, _dp] + [_dp] * 7
     L.orc_full_forward_dynamics.restype = C.c_int
@@ -106,6 +107,7 @@ def lib():
     L.orc_mpc_cold_iters.argtypes = [vp]
     L.orc_mpc_cold_trace.argtypes = [vp, _dp]
     L.orc_mpc_timing.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
+    L.orc_set_terminal_constraint.argtypes = [C.c_int]
     L.orc_fmpc_create.restype = vp
     L.orc_fmpc_create.argtypes = [vp, C.POINTER(MpcSettingsC), C.c_int, C.c_double]
     L.orc_fmpc_destroy.argtypes = [vp]
@@ -339,6 +341,12 @@ class Kino:
         )
         return o
 
+    def term_cstr(self, x, ref, tau):
+        """DCMPositionResidual at the terminal node: value (3) and Jacobian (3 x ndx)."""
+        c, Cm = np.zeros(3), np.zeros((3, self.ndx))
+        lib().orc_kino_term_cstr(self.h, np.ascontiguousarray(x, float), np.ascontiguousarray(ref, float), float(tau), c, Cm)
+        return c, Cm
+
     def term(self, x_tgt, x):
         c = lambda a: np.ascontiguousarray(a, float)
         cost, lx, Lxx = np.zeros(1), np.zeros(self.ndx), np.zeros((self.ndx, self.ndx))
@@ -472,7 +480,11 @@ class OracleMPC:
             mpc_settings["timestep"], mpc_settings["max_iters"], mpc_settings.get("num_threads", 0),
             mpc_settings["T_fly"], mpc_settings["T_contact"], mpc_settings["T"],
         )
-        self.h = self._create(s, B, gravity_arg)
+        lib().orc_set_terminal_constraint(int(bool(mpc_settings.get("terminal_constraint", False))))  # createProblem's last argument
+        try:
+            self.h = self._create(s, B, gravity_arg)
+        finally:
+            lib().orc_set_terminal_constraint(0)
 
     def generateCycleHorizon(self, cs):
         cs = np.ascontiguousarray(cs, np.uint8)
@@ -534,6 +546,12 @@ class OracleMPC:
     @property
     def xdot(self):
         return self._get(7, (self.B, self.H, 2 * self.kino.nv))
+
+    @property
+    def terminal(self):
+        """Terminal constraint state: multipliers [B][3], DCM reference [B][3], tau [B]."""
+        o = self._get(9, (self.B, 7))
+        return o[:, :3], o[:, 3:6], o[:, 6]
 
     def keep_knots(self, on=True):
         self._f("keep_knots")(self.h, int(on))
