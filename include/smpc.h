@@ -187,6 +187,10 @@ int smpc_set_reference_pose(smpc_handle * h, int t, int foot, const double * p3)
 int smpc_get_reference_pose(smpc_handle * h, int t, int foot, int instance, double * p3);
 /* getContactState(t): contact flag per foot (src/kinodynamics.cpp:343-349); getContactSupport = their sum */
 int smpc_get_contact_state(smpc_handle * h, int t, uint8_t * out_nfeet);
+/* MPC::getCyclingContactState(t, ee_name) for every foot: entry t of the (rotating) contact sequence the cycle horizon was generated
+ * from (reference include/simple-mpc/mpc.hpp:144-147, src/mpc.cpp:103-110,230); returns the sequence length, or the length alone
+ * when out is NULL.  Error before generateCycleHorizon or for t outside the sequence. */
+int smpc_get_cycling_contact_state(smpc_handle * h, int t, uint8_t * out_nfeet);
 /* MPC::x_reference_ (public member, reference include/simple-mpc/mpc.hpp:191) */
 int smpc_set_x_reference(smpc_handle * h, const double * x_ref);
 

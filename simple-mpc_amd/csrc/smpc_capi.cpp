@@ -379,6 +379,22 @@ extern "C"
         out[f] = (m >> f) & 1u;
     });
   }
+  int smpc_get_cycling_contact_state(smpc_handle * h, int t, uint8_t * out)
+  {
+    if (!h)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    const GaitTimer & tm = h->full ? h->full->timer : (h->cent ? h->cent->timer : h->eng->timer);
+    const int n = (int)tm.states.size();
+    if (!out)
+      return n;
+    if (n == 0)
+      return fail(SMPC_ERR_INVALID, "generateCycleHorizon has not been called");
+    if (t < 0 || t >= n)
+      return fail(SMPC_ERR_INVALID, "Stage index exceeds the cycle length");
+    for (int f = 0; f < tm.nf; f++)
+      out[f] = tm.states[t][f];
+    return n;
+  }
   int smpc_set_x_reference(smpc_handle * h, const double * x)
   {
     if (!h || !x)

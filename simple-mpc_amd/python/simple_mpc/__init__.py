@@ -782,6 +782,31 @@ class BatchedMPC:
     def foot_land_times(self):
         return self._timing(1)
 
+    # MPC::getCyclingContactState (reference include/simple-mpc/mpc.hpp:144-147): the contact sequence of generateCycleHorizon,
+    # repeated to cover the horizon and rotated with every walking control step (src/mpc.cpp:103-110,230)
+    def getCyclingContactState(self, t, ee_name):
+        names = self.ocp_handler.model_handler.getFeetFrameNames()
+        out = np.zeros(len(names), np.uint8)
+        self._lib.check(self._lib.L.smpc_get_cycling_contact_state(self._h, int(t), out.ctypes.data))
+        return bool(out[names.index(ee_name)])
+
+    def getCycleHorizon(self):
+        """The cycle horizon as contact states per stage ({foot: bool}); the reference returns its StageModel objects
+        (include/simple-mpc/mpc.hpp:139-142), which exist only as device data here."""
+        names = self.ocp_handler.model_handler.getFeetFrameNames()
+        n = self._lib.L.smpc_get_cycling_contact_state(self._h, 0, None)
+        out = np.zeros(len(names), np.uint8)
+        res = []
+        for t in range(n):
+            self._lib.check(self._lib.L.smpc_get_cycling_contact_state(self._h, t, out.ctypes.data))
+            res.append({nm: bool(out[i]) for i, nm in enumerate(names)})
+        return res
+
+    # MPC::setTerminalReferencePose (reference src/mpc.cpp:331-334) asks the terminal cost stack for "<foot>_pose_cost"; neither
+    # OCP puts one there (src/kinodynamics.cpp:350-363, src/fulldynamics.cpp:418-431), so upstream the call fails in the lookup
+    def setTerminalReferencePose(self, ee_name, pose_ref):
+        raise RuntimeError("the terminal cost has no %s_pose_cost component" % ee_name)
+
     def getFootTakeoffCycle(self, name):
         return self._timing(0)[name]
 

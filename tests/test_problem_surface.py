@@ -121,3 +121,29 @@ def test_stage_references_steer_the_solve_centroidal(lib):
 def test_stage_references_on_the_gpu(built):
     _steer(S.make_pair, None, True)
     _steer(S.make_cent_pair, None, False)
+
+
+def test_cycling_contact_state_follows_the_gait(lib):
+    """MPC::getCyclingContactState / getCycleHorizon (reference include/simple-mpc/mpc.hpp:139-147): the sequence given to
+    generateCycleHorizon, repeated 1 + H / n times (src/mpc.cpp:103-110) and rotated left by every walking control step (:230)."""
+    gm, rb, _, _ = S.make_product(1, lib=lib)
+    with pytest.raises(RuntimeError, match="generateCycleHorizon"):
+        gm.getCyclingContactState(0, "FL_foot")
+    cs = O.trot_cycle()  # 80 stages; H = 50 -> one copy, 80 entries
+    gm.generateCycleHorizon(cs)
+    cyc = gm.getCycleHorizon()
+    assert len(cyc) == 80 * (1 + 50 // 80)
+    for t in (0, 9, 10, 39, 40, 50, 79):
+        for f, n in enumerate(S.FEET):
+            assert gm.getCyclingContactState(t, n) == bool(cs[t][f]) == cyc[t][n]
+    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = S.random_states(rb, 1)
+    for k in range(1, 4):
+        gm.iterate(X)
+        for t in (0, 9, 38, 79):
+            for f, n in enumerate(S.FEET):
+                assert gm.getCyclingContactState(t, n) == bool(cs[(t + k) % 80][f])
+    with pytest.raises(RuntimeError, match="Stage index"):
+        gm.getCyclingContactState(80, "FL_foot")
+    with pytest.raises(RuntimeError, match="pose_cost"):
+        gm.setTerminalReferencePose("FL_foot", [0, 0, 0])  # the terminal cost stack has no pose cost, upstream as here
