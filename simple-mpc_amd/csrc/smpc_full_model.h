@@ -51,8 +51,8 @@ namespace smpc
     static constexpr int O_lu = O_lx + NDX;
     static constexpr int O_lpd = O_lu + NU;
     static constexpr int O_vpd = O_lpd + NDX;       // active ? 2 nu+ - nu : 0, all NC rows
-    static constexpr int O_act = O_vpd + NC;        // 1.0 / 0.0 activity of the NU + NA box rows
-    static constexpr int LQ_STRIDE = ((O_act + NU + NA + 7) / 8) * 8;
+    static constexpr int O_act = O_vpd + NC;        // 1.0 / 0.0 activity of all NC rows (box rows, then the dense cone rows)
+    static constexpr int LQ_STRIDE = ((O_act + NC + 7) / 8) * 8;
     // gains block per (instance, stage)
     static constexpr int G_K = 0;                          // [K k]  NU x (NDX+1)
     static constexpr int G_Z = G_K + NU * (NDX + 1);       // [Z z]  NCONE x (NDX+1)  (multiplier feedback of the dense rows)

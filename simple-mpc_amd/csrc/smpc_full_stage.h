@@ -207,19 +207,12 @@ namespace smpc
   {
     constexpr int NT = 64, TI = (M + 15) / 16, TJ = (N + 15) / 16, KS = (K + 3) / 4;
     SMPC_ACC(acc, NT, TI * TJ);
-    SMPC_PLA(double, av, NT, TI);
-    SMPC_PLA(double, bv, NT, TJ);
-    SMPC_LANES(NT)
-    {
-#pragma unroll
-      for (int t = 0; t < TI * TJ; t++)
-#pragma unroll
-        for (int v = 0; v < 4; v++)
-          SMPC_ACCV(acc, t, v) = 0.0;
-    }
-    SMPC_LANES_END_WAVE
-    for (int ks = 0; ks < KS; ks++)
-    {
+    // two operand sets: the LDS reads of K-step k + 1 are issued before the matrix instructions of step k, so that with one
+    // resident wave per SIMD the matrix pipe does not idle through every LDS round trip
+    SMPC_PLA(double, av, NT, 2 * TI);
+    SMPC_PLA(double, bv, NT, 2 * TJ);
+    auto fetch = [&](int ks) {
+      const int ob = ks & 1;
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
@@ -230,7 +223,7 @@ namespace smpc
           const int i = 16 * I + lc;
           const bool ok = i < M && k < K;
           const double x = a(ok ? i : 0, ok ? k : 0);
-          SMPC_PLV(av)[I] = ok ? x : 0.0;
+          SMPC_PLV(av)[ob * TI + I] = ok ? x : 0.0;
         }
 #pragma unroll
         for (int J = 0; J < TJ; J++)
@@ -238,15 +231,32 @@ namespace smpc
           const int j = 16 * J + lc;
           const bool ok = j < N && k < K;
           const double x = b(ok ? k : 0, ok ? j : 0);
-          SMPC_PLV(bv)[J] = ok ? x : 0.0;
+          SMPC_PLV(bv)[ob * TJ + J] = ok ? x : 0.0;
         }
       }
       SMPC_LANES_END_WAVE
+    };
+    SMPC_LANES(NT)
+    {
+#pragma unroll
+      for (int t = 0; t < TI * TJ; t++)
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+          SMPC_ACCV(acc, t, v) = 0.0;
+    }
+    SMPC_LANES_END_WAVE
+    fetch(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+    {
+      if (ks + 1 < KS)
+        fetch(ks + 1);
+      const int ob = ks & 1;
 #pragma unroll
       for (int I = 0; I < TI; I++)
 #pragma unroll
         for (int J = 0; J < TJ; J++)
-          SMPC_MFMA(acc, I * TJ + J, av, I, bv, J);
+          SMPC_MFMA(acc, I * TJ + J, av, ob * TI + I, bv, ob * TJ + J);
     }
     SMPC_LANES(NT)
     {
@@ -1680,6 +1690,11 @@ namespace smpc
     const DevModel<D> & mg = *b.model;
     SMPC_LDS(SC, scs, 1);
     SMPC_LDS(SD, sds, 1);
+#ifdef SMPC_FDYN_PAD
+    SMPC_LDS(double, padlds, SMPC_FDYN_PAD); // (occupancy experiment)
+    if (ka.b.B < 0)
+      padlds[ka.b.H] = 1.0;
+#endif
     SC & sc = scs[0];
     SD & sd = sds[0];
     const FullHead<D> & h = sc.h;
@@ -1952,8 +1967,7 @@ namespace smpc
       {
         lq[D::O_d + i] = mu * (sc.vplus[i] - sc.nu[i]);
         lq[D::O_vpd + i] = sc.act[i] ? 2.0 * sc.vplus[i] - sc.nu[i] : 0.0;
-        if (i < NU + NA)
-          lq[D::O_act + i] = sc.act[i] ? 1.0 : 0.0;
+        lq[D::O_act + i] = sc.act[i] ? 1.0 : 0.0;
       }
     }
     SMPC_LANES_END_WAVE

@@ -86,6 +86,20 @@ namespace smpc
     {
       const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
       double * g = b.gains + ((size_t)inst * H + t) * D::G_STRIDE;
+      // pivot panels of the second sweep that hold inactive dense rows only: such a row is [0 ... -mu ... d] and couples to
+      // nothing, so its panel is left out of the sweep and z = d / mu is written directly (the loads are wave-uniform)
+      unsigned skip = 0u;
+      if constexpr (NCD > 0)
+      {
+        for (int q = 0; q < GM::NCP / 4; q++)
+        {
+          double any = 0.0;
+          for (int r = 4 * q; r < 4 * q + 4 && r < NCD; r++)
+            any += lq[D::O_act + NU + NA + r];
+          if (any == 0.0)
+            skip |= 1u << (GM::NUP / 4 + q);
+        }
+      }
       // ---- (1) f ; box rows ; save p_{t+1} ; pt0 = p + P f ----
       SMPC_LANES(NT)
       {
@@ -320,7 +334,7 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       // ---- (6) sweep the control pivots in place:  x-x block -> P_t,  x-vector -> p_t,  (x, u) entries -> -K,  (u, vector) -> -k ----
-      wave_block_sweep<NT, NT2, true, NDX, (NUP + NCP) / 4>(hacc, sw, sw + LDS::SWP, prof, tprev);
+      wave_block_sweep<NT, NT2, true, NDX, (NUP + NCP) / 4, (NCD > 0)>(hacc, sw, sw + LDS::SWP, prof, tprev, skip);
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
@@ -353,7 +367,7 @@ namespace smpc
               else if (row < NXU && col == VC)
                 g[D::G_K + (row - NDX) * (NDX + 1) + NDX] = -val; // k
               else if (row >= NXUP && row < NXUP + NCD && col == VC)
-                g[D::G_Z + (row - NXUP) * (NDX + 1) + NDX] = -val; // z
+                g[D::G_Z + (row - NXUP) * (NDX + 1) + NDX] = ((skip >> ((row - NDX) / 4)) & 1u) ? val / mu : -val; // z
             }
       }
       SMPC_LANES_END_WAVE

@@ -85,8 +85,9 @@ namespace smpc
     return (fixup || gather) ? 1 : 2;
   }
 
-  template <int NT, int NTI, bool ALL, int PIV0, int NP, class Acc>
-  SMPC_DEV void wave_block_sweep(Acc & acc, double * prow, double * urow, double * prof, long long & tprev)
+  // SKIPPABLE: bit p of `skip` set = panel p is left out (its 4 pivots couple to nothing: the caller deals with their rows).
+  template <int NT, int NTI, bool ALL, int PIV0, int NP, bool SKIPPABLE = false, class Acc>
+  SMPC_DEV void wave_block_sweep(Acc & acc, double * prow, double * urow, double * prof, long long & tprev, unsigned skip = 0u)
   {
     constexpr int LDW = 16 * NTI;
     static_assert(NT == 64 && PIV0 % 4 == 0 && PIV0 + 4 * NP <= LDW && LDW <= 2 * NT, "sweep geometry");
@@ -99,7 +100,11 @@ namespace smpc
     {
       const int kb = PIV0 + 4 * p, Ip = kb / 16, c0 = kb % 16, vp = c0 / 4;
       const int ob = (p & 1) * NTI, obp = ((p + 1) & 1) * NTI; // operand sets of this / the previous panel
+      const bool skp = SKIPPABLE && ((skip >> p) & 1u);                     // (wave-uniform)
+      const bool prev = p > 0 && !(SKIPPABLE && ((skip >> (p > 0 ? p - 1 : 0)) & 1u)); // the previous panel ran: it deferred updates
       // (a) pivot entries -> prow[k][m]
+      if (!skp)
+      {
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
@@ -116,9 +121,10 @@ namespace smpc
         }
       }
       SMPC_LANES_END_WAVE
+      }
       prof_tick(prof, 36, tprev);
       // deferred updates of the previous panel, first half
-      if (p > 0)
+      if (prev)
       {
         int cnt = 0;
 #pragma unroll
@@ -133,6 +139,8 @@ namespace smpc
             }
       }
       // (b) U_m = D^-1 P_m, lane = index m (every lane factors the 4x4 pivot block D = L diag(d) L^T itself)
+      if (!skp)
+      {
       SMPC_LANES(NT)
       {
         const double * d = prow + kb;
@@ -170,9 +178,10 @@ namespace smpc
         }
       }
       SMPC_LANES_END_WAVE
+      }
       prof_tick(prof, 37, tprev);
       // deferred updates of the previous panel, second half
-      if (p > 0)
+      if (prev)
       {
         int cnt = 0;
 #pragma unroll
@@ -187,6 +196,8 @@ namespace smpc
             }
       }
       // (c) operands of this panel's rank-4 updates ; the updates the next panel depends on
+      if (skp)
+        continue;
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;

@@ -845,7 +845,7 @@ class BatchedMPC:
             layout = (
                 ("A", (ndx, ndx)), ("B", (ndx, nu)), ("Q", (ndx, ndx)), ("S", (ndx, nu)), ("R", (nu, nu)), ("Cd", (ncone, ndx)),
                 ("Dd", (ncone, nu)), ("q", (ndx,)), ("r", (nu,)), ("f", (ndx,)), ("d", (nc,)), ("lx", (ndx,)), ("lu", (nu,)),
-                ("lpd", (ndx,)), ("vpd", (nc,)), ("act", (nbox,)),
+                ("lpd", (ndx,)), ("vpd", (nc,)), ("act", (nc,)),
             )
         for name, shape in layout:
             sz = int(np.prod(shape))
