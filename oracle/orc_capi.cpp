@@ -212,6 +212,15 @@ extern "C"
     s.kinematics_limits = kinematics_limits != 0;
     return new KinoModel(m, s);
   }
+  // force_cone rows of the kinodynamics stage (CentroidalFrictionConeResidual per foot in contact) and the friction coefficient
+  void orc_kino_set_force_cone(void * h, int on, double mu)
+  {
+    KinoModel * md = (KinoModel *)h;
+    md->s.force_cone = on != 0;
+    md->s.mu = mu;
+    md->configure();
+  }
+  void orc_set_fold_u_rows(int on) { fold_u_rows() = on != 0; }
   void orc_kino_destroy(void * h) { delete (KinoModel *)h; }
   void orc_kino_dims(void * h, int * out) // nx ndx nu nc nf
   {

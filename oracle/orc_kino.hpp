@@ -8,7 +8,7 @@
 //                  (src/kinodynamics.cpp:60-83)
 //   constraints  : joint box (src/kinodynamics.cpp:91-101), LOCAL frame velocity = 0 per contact
 //                  foot (src/kinodynamics.cpp:110-133)
-// force_size == 3 (point feet) only; force_cone / land_cstr rows are not restated yet.
+// force_size == 3 (point feet) only; force_cone rows: CentroidalFrictionConeResidual per foot in contact; land_cstr is not restated.
 #pragma once
 #include "orc_rigid.hpp"
 
@@ -68,13 +68,20 @@ namespace orc
       ndx = 2 * nv;
       nf = m->nfeet;
       nu = nv - 6 + 3 * nf;
-      nc = (nv - 6) + 3 * nf;
+      configure();
     }
-    // fixed row layout: rows [0, nv-6) joint box, rows nv-6+3f.. frame velocity of foot f
+    void configure() { nc = (nv - 6) + 3 * nf + (s.force_cone ? 2 * nf : 0); }
+    int cone_base() const { return (nv - 6) + 3 * nf; }
+    // fixed row layout: rows [0, nv-6) joint box, rows nv-6+3f.. frame velocity of foot f, then (force_cone) two friction-cone rows
+    // per foot: CentroidalFrictionConeResidual(ndx, nu, f, mu, 1e-4) in NegativeOrthant (reference src/kinodynamics.cpp:124-129):
+    //   [ -f_z + epsilon ; f_x^2 + f_y^2 - mu^2 f_z^2 ] <= 0   ([UPSTREAM-RECALL] aligator centroidal-friction-cone.hxx; the same
+    //   residual as the centroidal OCP's, orc_cent.hpp)
     int row_kind(const StageRef & r, int row) const
     {
       if (row < nv - 6)
         return s.kinematics_limits ? ROW_BOX : ROW_ABSENT;
+      if (row >= cone_base())
+        return ((r.mask >> ((row - cone_base()) / 2)) & 1u) ? ROW_NEG : ROW_ABSENT;
       int f = (row - (nv - 6)) / 3;
       return ((r.mask >> f) & 1u) ? ROW_EQ : ROW_ABSENT;
     }
@@ -259,6 +266,12 @@ namespace orc
           V3 c = tr(R.oMi[l].R) * vw;
           for (int i = 0; i < 3; i++)
             o.c[nv - 6 + 3 * f + i] = c[i];
+          if (s.force_cone)
+          {
+            const double fx = u[3 * f], fy = u[3 * f + 1], fz = u[3 * f + 2];
+            o.c[cone_base() + 2 * f] = -fz + 1e-4;
+            o.c[cone_base() + 2 * f + 1] = fx * fx + fy * fy - s.mu * s.mu * fz * fz;
+          }
         }
     }
 
@@ -433,6 +446,14 @@ namespace orc
               o.Cx(nv - 6 + 3 * f + i, k) = dq(i, k);
               o.Cx(nv - 6 + 3 * f + i, nv + k) = dv(i, k);
             }
+          if (s.force_cone)
+          {
+            const int cb = cone_base() + 2 * f;
+            o.Cu(cb, 3 * f + 2) = -1.0;
+            o.Cu(cb + 1, 3 * f) = 2.0 * u[3 * f];
+            o.Cu(cb + 1, 3 * f + 1) = 2.0 * u[3 * f + 1];
+            o.Cu(cb + 1, 3 * f + 2) = -2.0 * s.mu * s.mu * u[3 * f + 2];
+          }
         }
     }
 

@@ -47,6 +47,12 @@ namespace orc
   //   Q dx + S du + A^T dl+ + C^T dnu - dl + q = 0 ;  S^T dx + R du + B^T dl+ + D^T dnu + r = 0
   //   A dx + B du - dx+ + f - mu dl+ = 0 ;             C dx + D du + d - mu dnu = 0
   //   Q_N dx_N - dl_N + q_N = 0
+  inline bool & fold_u_rows()
+  {
+    static bool on = false;
+    return on;
+  }
+
   inline void prox_riccati(
     const std::vector<Knot> & kn, const Mat & QN, const Vec & qN, double mu, std::vector<Vec> & dxs,
     std::vector<Vec> & dus, std::vector<Vec> & dvs, std::vector<Vec> & dlams, std::vector<Mat> * K_out = nullptr)
@@ -89,6 +95,29 @@ namespace orc
       Vec qh = k.q, rh = k.r;
       axpy(qh, mulT(k.A, pt));
       axpy(rh, mulT(k.B, pt));
+      // (numerical experiment, off by default: eliminate the rows that act on u only -- R^ += D^T D / mu, r^ += D^T d / mu -- the
+      //  way a kernel that folds them would; fold_u_rows() is set by the test that measures what the fold costs in accuracy)
+      Mat Dk = k.D;
+      std::vector<char> folded(nc, 0);
+      if (fold_u_rows())
+        for (int i = 0; i < nc; i++)
+        {
+          bool hasD = false, hasC = false;
+          for (int j = 0; j < nu; j++)
+            hasD = hasD || k.D(i, j) != 0.0;
+          for (int j = 0; j < ndx; j++)
+            hasC = hasC || k.C(i, j) != 0.0;
+          if (!hasD || hasC)
+            continue;
+          folded[i] = 1;
+          for (int a = 0; a < nu; a++)
+          {
+            rh[a] += k.D(i, a) * k.d[i] / mu;
+            for (int bb = 0; bb < nu; bb++)
+              Rh(a, bb) += k.D(i, a) * k.D(i, bb) / mu;
+            Dk(i, a) = 0.0;
+          }
+        }
       // stage KKT: [Rh D^T; D -mu I] [K k; Z z] = -[Sh^T rh; C d]
       Mat LR = Rh;
       ok = cholesky(LR);
@@ -105,7 +134,7 @@ namespace orc
       Mat Y(nu, nc); // L^-1 D^T
       for (int i = 0; i < nu; i++)
         for (int j = 0; j < nc; j++)
-          Y(i, j) = k.D(j, i);
+          Y(i, j) = Dk(j, i);
       for (int j = 0; j < nc; j++)
         solve_L(LR, &Y.a[j], nc);
       Mat Sc = mulTN(Y, Y);
@@ -144,6 +173,20 @@ namespace orc
         for (int j = 0; j < ndx; j++)
           g.Z(i, j) = Zz(i, j);
         g.z[i] = Zz(i, ndx);
+        if (folded[i])
+        { // dv = (D du + d) / mu
+          for (int j = 0; j < ndx; j++)
+          {
+            double acc = 0.0;
+            for (int a = 0; a < nu; a++)
+              acc += k.D(i, a) * g.K(a, j);
+            g.Z(i, j) = acc / mu;
+          }
+          double acc = k.d[i];
+          for (int a = 0; a < nu; a++)
+            acc += k.D(i, a) * g.k[a];
+          g.z[i] = acc / mu;
+        }
       }
       g.Pt = Pt;
       g.pnext = p;

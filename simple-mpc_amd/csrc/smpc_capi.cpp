@@ -90,8 +90,8 @@ extern "C"
       return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the MPC engine has no CPU path");
     if (ocp->force_size != 3)
       return fail(SMPC_ERR_INVALID, "force size in settings does not match reference force size (only 3-D point feet are built)");
-    if (ocp->force_cone || ocp->land_cstr)
-      return fail(SMPC_ERR_INVALID, "force_cone / land_cstr constraint rows are not built yet");
+    if (ocp->land_cstr)
+      return fail(SMPC_ERR_INVALID, "land_cstr constraint rows are not built yet");
     if (mpc->T < 2)
       return fail(SMPC_ERR_INVALID, "horizon must have at least 2 stages");
     const int nv = robot->nv, ndx = 2 * nv, nu = nv - 6 + 3 * robot->nfeet;
@@ -108,6 +108,8 @@ extern "C"
       ks.gravity[i] = ocp->gravity[i];
     ks.kinematics_limits = ocp->kinematics_limits;
     ks.terminal_constraint = ocp->terminal_constraint;
+    ks.force_cone = ocp->force_cone;
+    ks.mu = ocp->mu;
     for (int i = 0; i < nv - 6; i++)
       if (!(ks.qmin[i] <= ks.qmax[i]))
         return fail(SMPC_ERR_INVALID, "qmin must not exceed qmax (joint limits are indexed by actuated joint, 0 .. nv - 7)");

@@ -30,6 +30,8 @@ namespace smpc
     double gravity[3];
     int kinematics_limits;
     int terminal_constraint = 0; // createProblem(..., terminal_constraint)
+    int force_cone = 0;          // friction-cone rows per foot in contact (3-D feet)
+    double mu = 0.8;             // friction coefficient
   };
   struct HostMpcSettings
   {
@@ -436,6 +438,22 @@ namespace smpc
       X_dev = dalloc((size_t)B * D::NX);
       if (ks.terminal_constraint)
         alloc_terminal_constraint<D>(buf, x_model_ref.data(), host_com_height(m, x_model_ref.data()), stream);
+      if (ks.force_cone)
+      {
+        if (!structured_riccati)
+          throw std::runtime_error("force_cone needs the structured Riccati sweep (unset SMPC_RICCATI)");
+        auto zalloc = [&](size_t n) {
+          double * p = dalloc(n);
+          dev_zero(p, n * sizeof(double), stream);
+          return p;
+        };
+        buf.es = zalloc(BR * 2 * D::NF);
+        buf.es_e = zalloc(BR * 2 * D::NF);
+        buf.es_b = zalloc(BR * 2 * D::NF);
+        buf.des = zalloc(BH * 2 * D::NF);
+        buf.ek = zalloc(BH * 12 * D::NF);
+        buf.cone_mu2 = ks.mu * ks.mu;
+      }
       if (std::getenv("SMPC_PHASE_PROFILE"))
         buf.dbg = dalloc(64);
       h2d(buf.model, hm.data(), sizeof(DevModel<D>), stream);
@@ -462,7 +480,7 @@ namespace smpc
     }
     ~KinoEngine()
     {
-      for (double * p : {buf.CN, buf.vN, buf.vN_e, buf.vN_b, buf.dvN, buf.dcm_ref})
+      for (double * p : {buf.CN, buf.vN, buf.vN_e, buf.vN_b, buf.dvN, buf.dcm_ref, buf.es, buf.es_e, buf.es_b, buf.des, buf.ek})
         dev_free(p);
       for (double * p : {buf.xs_b, buf.us_b, buf.vs_b, buf.lams_b, buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref, buf.ftraj, buf.vbase, buf.vref, buf.lq,
                          buf.gains, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, X_dev, stage_out})
@@ -656,6 +674,8 @@ namespace smpc
       d2d(b.lams_e, b.lams, (size_t)b.B * R * D::NDX * sizeof(double), stream);
       if (b.CN != nullptr)
         d2d(b.vN_e, b.vN, (size_t)b.B * 3 * sizeof(double), stream);
+      if (b.es != nullptr)
+        d2d(b.es_e, b.es, (size_t)b.B * R * 2 * D::NF * sizeof(double), stream);
     }
 
     void upload_stages()
@@ -722,6 +742,8 @@ namespace smpc
         bc(buf.vN, 3);
         bc(buf.dcm_ref, 3);
       }
+      if (buf.es != nullptr)
+        bc(buf.es, (size_t)R * 2 * D::NF);
       // swing start/end = reference foot positions (FootTrajectory ctor, src/foot-trajectory.cpp:20-39):
       // a reference-only recede call with land = -1 < T_fly keeps them, so initialise them here on the host
       std::vector<double> ft((size_t)D::NF * 6);
@@ -959,6 +981,7 @@ namespace smpc
       io.tag(D::NX, "nx");
       io.tag(D::NU, "nu");
       io.tag(buf.CN != nullptr ? 1 : 0, "terminal constraint");
+      io.tag(buf.es != nullptr ? 1 : 0, "friction-cone rows");
       io.pod(head);
       io.pod(walking);
       io.host(velocity_base, sizeof(velocity_base));
@@ -979,6 +1002,8 @@ namespace smpc
       io.dev(buf.xdot01, (size_t)B * 4 * D::NV * sizeof(double));
       if (buf.CN != nullptr)
         io.dev(buf.vN, (size_t)B * 3 * sizeof(double));
+      if (buf.es != nullptr)
+        io.dev(buf.es, BR * 2 * D::NF * sizeof(double));
       if (io.mode == StateIO::LOAD)
         upload_stages();
       stream_sync(stream);

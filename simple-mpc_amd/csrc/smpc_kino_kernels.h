@@ -316,6 +316,10 @@ namespace smpc
 
     // ---- multipliers, active set ----
     kino_multipliers<D, true>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+    const bool cones = b.es != nullptr;
+    if (cones)
+      kino_cone_rows<D, true>(sc, in, b.cone_mu2, b.es + (ib + st) * 2 * NF, (const double *)nullptr, 0.0, b.es_e + (ib + st) * 2 * NF,
+                              b.ek + ((size_t)inst * H + t) * 12 * NF);
     if (in.prof) prof_tick(in.prof, 31, tprev);
 
     double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
@@ -444,7 +448,17 @@ namespace smpc
             g += sc.Whd[j] + xc.x * sc.Whd[3] + xc.y * sc.Whd[4] + xc.z * sc.Whd[5];
           }
         }
-        const double r = g + acc;
+        double r = g + acc;
+        if (cones && k < 3 * NF)
+        { // C_u^T nu of the friction-cone rows (unmasked Jacobian, current multipliers)
+          const int f = k / 3;
+          const double * cs = kino_cone_scratch<D, true>(sc);
+          double j0[3], j1[3];
+          kino_cone_jac(0, sc.u[3 * f], sc.u[3 * f + 1], sc.u[3 * f + 2], b.cone_mu2, j0);
+          kino_cone_jac(1, sc.u[3 * f], sc.u[3 * f + 1], sc.u[3 * f + 2], b.cone_mu2, j1);
+          if ((in.mask >> f) & 1u)
+            r += j0[k % 3] * cs[6 * NF + 2 * f] + j1[k % 3] * cs[6 * NF + 2 * f + 1];
+        }
         lq[D::O_r + k] = r;
         lq[D::O_lu + k] = g;
         sc.ru[k] = fabs(r);
@@ -1132,6 +1146,9 @@ namespace smpc
       return;
     }
     kino_multipliers<D, false>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+    if (b.es != nullptr)
+      kino_cone_rows<D, false>(sc, in, b.cone_mu2, b.es + (ib + st) * 2 * NF, b.des + ((size_t)inst * H + t) * 2 * NF, alpha,
+                               b.es_e + (ib + st) * 2 * NF, (double *)nullptr);
     SMPC_LANES(NT)
     {
       if (lane == 0)

@@ -1063,4 +1063,79 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
   }
+
+  // Friction-cone rows of the stage (force_cone): per foot in contact  [ -f_z + 1e-4 ; f_x^2 + f_y^2 - mu^2 f_z^2 ] <= 0 on the
+  // force part of u (CentroidalFrictionConeResidual in NegativeOrthant, reference src/kinodynamics.cpp:124-129).  After
+  // kino_multipliers: projects, adds the penalty / infeasibility to red[1] / red[2], leaves  value | nu+ | active | nu  in the
+  // tail of tree block A (dead since the derivative columns), and -- derivative pass -- writes the rows' block of the knot (ek).
+  //   nu: multipliers of the rows at the evaluation point, nu_e: AL centres (both 2 NF, global).
+  template <class D, bool DERIV>
+  SMPC_HD double * kino_cone_scratch(KinoScratch<D, DERIV> & sc)
+  {
+    static_assert(D::NJ * 9 + D::NV * 6 + D::NJ * 40 >= 612 + 8 * D::NF, "cone scratch behind the assembly tables of tree block A");
+    return sc.oR + 612;
+  }
+  // Jacobian row w (0 / 1) of a foot's cone block w.r.t. its force, at force (fx, fy, fz)
+  SMPC_HD void kino_cone_jac(int w, double fx, double fy, double fz, double mu2, double * out3)
+  {
+    out3[0] = w == 0 ? 0.0 : 2.0 * fx;
+    out3[1] = w == 0 ? 0.0 : 2.0 * fy;
+    out3[2] = w == 0 ? -1.0 : -2.0 * mu2 * fz;
+  }
+  template <class D, bool DERIV>
+  SMPC_DEV void kino_cone_rows(KinoScratch<D, DERIV> & sc, const StageIn<D> & in, double mu2, const double * nu, const double * dnu,
+                               double alpha, const double * nu_e, double * ek)
+  {
+    constexpr int NT = 64, NF = D::NF, NE = 2 * NF;
+    const double mu = sc.ml.mu;
+    double * cs = kino_cone_scratch<D, DERIV>(sc);
+    SMPC_LANES(NT)
+    if (lane < NE)
+    {
+      const int f = lane / 2, w = lane % 2;
+      const bool on = (in.mask >> f) & 1u;
+      const double fx = sc.u[3 * f], fy = sc.u[3 * f + 1], fz = sc.u[3 * f + 2];
+      const double c = w == 0 ? -fz + 1e-4 : fx * fx + fy * fy - mu2 * fz * fz;
+      const double v = nu[lane] + (dnu ? alpha * dnu[lane] : 0.0);
+      double vp = 0.0;
+      int act = 0;
+      if (on)
+      {
+        const double z = c + mu * nu_e[lane];
+        const double proj = fmin(z, 0.0);
+        vp = (z - proj) / mu;
+        act = z != proj;
+      }
+      cs[lane] = on ? c : 0.0;
+      cs[NE + lane] = vp;
+      cs[2 * NE + lane] = act ? 1.0 : 0.0;
+      cs[3 * NE + lane] = v;
+      if (ek != nullptr)
+      {
+        double jr[3];
+        kino_cone_jac(w, fx, fy, fz, mu2, jr);
+        for (int a = 0; a < 3; a++)
+          ek[lane * 3 + a] = act ? jr[a] : 0.0;
+        ek[3 * NE + lane] = mu * (vp - v);
+        ek[4 * NE + lane] = act ? 2.0 * vp - v : 0.0;
+        ek[5 * NE + lane] = act ? 1.0 : 0.0;
+      }
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      double pen = 0.0, prim = sc.red[2];
+      for (int i = 0; i < NE; i++)
+      {
+        const double vp = cs[NE + i], dv = vp - cs[3 * NE + i];
+        pen += 0.5 * mu * (vp * vp + dv * dv);
+        if ((in.mask >> (i / 2)) & 1u)
+          prim = fmax(prim, fmax(cs[i], 0.0));
+      }
+      sc.red[1] += pen;
+      sc.red[2] = prim;
+    }
+    SMPC_LANES_END_WAVE
+  }
 } // namespace smpc

@@ -132,6 +132,12 @@ namespace smpc
     double *vN = nullptr, *vN_e = nullptr, *vN_b = nullptr, *dvN = nullptr; // [B][3] multipliers, AL centres, backup, step
     double * dcm_ref = nullptr; // [B][3]
     double dcm_tau = 0.0, com0z = 0.0;
+    // friction-cone rows of the kinodynamics stage (force_cone; CentroidalFrictionConeResidual per foot in contact, reference
+    // src/kinodynamics.cpp:124-129): two rows per foot on the force part of u.  es == nullptr: the problem has none.
+    //   es / es_e / es_b [B][R][2 NF] multipliers, centres, backup ; des [B][H][2 NF] step ;
+    //   ek [B][H][12 NF]: Jacobian rows of the active rows (2 NF x 3) | d = mu (nu+ - nu) | active ? 2 nu+ - nu : 0 | activity
+    double *es = nullptr, *es_e = nullptr, *es_b = nullptr, *des = nullptr, *ek = nullptr;
+    double cone_mu2 = 0.0; // friction coefficient squared
     // merit bookkeeping
     double * parts0 = nullptr;   // [B][H+1][4] phi, cost, prim, dual at the current point
     double * partsT = nullptr;   // [B][LS_N][H+1][2] phi, prim at trial points

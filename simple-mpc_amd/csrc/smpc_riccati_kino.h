@@ -256,6 +256,7 @@ namespace smpc
     double scr[SCR];
     double p[NDX], pt0[NDX], pt[NDX], qh[NDX], rh[NU], f[NDX];
     double dc[NG], boxd[D::NA], boxact[D::NA];
+    double cone[8 * D::NF]; // friction-cone rows of the stage (force_cone): active Jacobian rows (2 NF x 3) | d (2 NF)
     float sink[64]; // destination of the line touches (never read)
   };
 
@@ -616,6 +617,8 @@ namespace smpc
         const double vdc = lq[D::O_d + NA + (pl < NG ? pl : 0)];
         const double vba = lq[D::O_C + (pl < NA ? pl * NDX + 6 + pl : 0)]; // 1 if the box row is active
         const double vbd = lq[D::O_d + (pl < NA ? pl : 0)];
+        const double * ekp = b.es != nullptr ? b.ek + ((size_t)inst * H + t) * 12 * NF : lq; // (cone rows: [D | d] are contiguous)
+        const double vce = ekp[pl < 8 * NF ? pl : 0];
 #pragma unroll
         for (int n = 0; n < CC_PL; n++)
         {
@@ -630,7 +633,8 @@ namespace smpc
           s.boxact[lane] = vba;
           s.boxd[lane] = vbd;
         }
-
+        if (lane < 8 * NF)
+          s.cone[lane] = b.es != nullptr ? vce : 0.0;
       }
       SMPC_LANES_END_WAVE
       {
@@ -662,6 +666,11 @@ namespace smpc
               cd += s.boxact[i - 6] * s.boxd[i - 6];
             s.qh[i] += imu * cd;
           }
+          else if (b.es != nullptr && lane < NDX + 3 * NF)
+          { // r^ += D^T d / mu of the friction-cone rows
+            const int k = lane - NDX, f = k / 3;
+            s.rh[k] += imu * (s.cone[(2 * f) * 3 + k % 3] * s.cone[6 * NF + 2 * f] + s.cone[(2 * f + 1) * 3 + k % 3] * s.cone[6 * NF + 2 * f + 1]);
+          }
         }
         SMPC_LANES_END_WAVE
 #pragma unroll
@@ -682,6 +691,22 @@ namespace smpc
               if (lc == lr + 4 * v && IX::isQj(row))
                 SMPC_ACCV(hacc, tix<4>(I, I), v) += imu * s.boxact[row - 6];
             }
+          // friction-cone rows act on the force part of u only: R^ += D^T D / mu (3 x 3 block per foot), r^ += D^T d / mu
+          if (b.es != nullptr)
+          {
+            static_assert(NDX / 16 == 2 && NDX + 3 * NF <= 48, "the force block of R^ lives in tile (2, 2)");
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+            {
+              const int row = 32 + lr + 4 * v - NDX, col = 32 + lc - NDX; // force indices
+              if (row >= 0 && row < 3 * NF && col >= 0 && col < 3 * NF && row / 3 == col / 3)
+              {
+                const int f = row / 3;
+                const double * d0 = &s.cone[(2 * f) * 3], * d1 = d0 + 3;
+                SMPC_ACCV(hacc, tix<4>(2, 2), v) += imu * (d0[row % 3] * d0[col % 3] + d1[row % 3] * d1[col % 3]);
+              }
+            }
+          }
           // vector column NXU (lanes with lc == NXU % 16 of the last tile column)
           if (lc == NXU % 16)
           {
@@ -894,8 +919,19 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       // ---- du = K dx + k ; dnu = (C dx + d)/mu ----
+      SMPC_PLA(double, ce, NT, 5); // friction-cone row of lanes NDX .. NDX + 2 NF: Jacobian row (3) | d | vpd, in flight until phase 3
       SMPC_LANES(NT)
       {
+        if (b.es != nullptr && lane >= NDX && lane < NDX + 2 * NF)
+        {
+          const double * ekp = b.ek + lt * 12 * NF;
+          const int i = lane - NDX;
+          SMPC_PLV(ce)[0] = ekp[i * 3];
+          SMPC_PLV(ce)[1] = ekp[i * 3 + 1];
+          SMPC_PLV(ce)[2] = ekp[i * 3 + 2];
+          SMPC_PLV(ce)[3] = ekp[6 * NF + i];
+          SMPC_PLV(ce)[4] = ekp[8 * NF + i];
+        }
         if (lane < NU)
         {
           const double * Wr = &W[lane * (NDX + 1)];
@@ -962,6 +998,15 @@ namespace smpc
           acc = s.dx[i] + dt * s.du[3 * NF + i - NV - 6];
         s.part[lane] += (vlx[lane] - s.lpd_prev[lane]) * s.dx[lane] + vlpd[lane] * acc;
         s.y[lane] = acc + vf[lane] - mu * pn[lane];
+      }
+      else if (b.es != nullptr && lane < NDX + 2 * NF)
+      { // friction-cone rows: dnu = (D du + d) / mu
+        const int i = lane - NDX, f = i / 2;
+        const double dd = SMPC_PLV(ce)[3];
+        const double acc = dd + SMPC_PLV(ce)[0] * s.du[3 * f] + SMPC_PLV(ce)[1] * s.du[3 * f + 1] + SMPC_PLV(ce)[2] * s.du[3 * f + 2];
+        const double dnu = acc / mu;
+        b.des[lt * 2 * NF + i] = dnu;
+        s.part[lane] += SMPC_PLV(ce)[4] * (mu * dnu - dd) - dd * dnu;
       }
       SMPC_LANES_END_WAVE
       // ---- w = P~ y (P~ symmetric, upper triangle packed) ; dx+ = y - mu w ; dlam+ = w + p_{t+1} ----

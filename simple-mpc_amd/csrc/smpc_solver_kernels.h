@@ -704,6 +704,24 @@ namespace smpc
           b.lams[o] = v + alpha * b.dlams[((size_t)inst * H + t) * NDX + i];
         }
       }
+      if (b.es != nullptr)
+      { // multipliers of the friction-cone rows
+        constexpr int NE = 2 * D::NF;
+        for (int idx = lane; idx < H * NE; idx += NT)
+        {
+          const int t = idx / NE, i = idx % NE;
+          const size_t o = (ib + ring_slot(ka.head, t, R)) * NE + i;
+          if (restore)
+            b.es[o] = b.es_b[o];
+          else
+          {
+            const double v = b.es[o];
+            if (tent)
+              b.es_b[o] = v;
+            b.es[o] = v + alpha * b.des[((size_t)inst * H + t) * NE + i];
+          }
+        }
+      }
       if (b.CN != nullptr && lane < 3)
       { // multipliers of the terminal constraint
         const size_t o = (size_t)inst * 3 + lane;
@@ -913,6 +931,8 @@ namespace smpc
         b.us[(ib + sHm1) * NU + i] = b.us[(ib + sHm2) * NU + i];
       for (int i = lane; i < NC; i += NT)
         b.vs[(ib + sHm1) * NC + i] = 0.0;
+      if (b.es != nullptr && lane < 2 * NF)
+        b.es[(ib + sHm1) * 2 * NF + lane] = 0.0;
       if (lane < 6)
         b.vref[(ib + sHm1) * 6 + lane] = b.vbase[(size_t)inst * 6 + lane]; // setVelocityBase(H-1, velocity_base_)
       for (int i = lane; i < NDX; i += NT)

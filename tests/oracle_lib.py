@@ -67,6 +67,8 @@ def lib():
     L.orc_kino_dims.argtypes = [vp, _ip]
     L.orc_kino_eval.argtypes = [vp, C.c_uint, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_kino_deriv.argtypes = [vp, C.c_uint] + [_dp] * 14
+    L.orc_kino_set_force_cone.argtypes = [vp, C.c_int, C.c_double]
+    L.orc_set_fold_u_rows.argtypes = [C.c_int]
     L.orc_kino_term.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
     L.orc_kino_term_cstr.argtypes = [vp, _dp, _dp, C.c_double, _dp, _dp]
     L.orc_centroidal.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
@@ -317,6 +319,8 @@ class Kino:
             robot.ptr, s["timestep"], c(s["w_x"]), c(s["w_u"]), c(s["w_frame"]), c(s["w_cent"]), c(s["w_centder"]),
             c(s["qmin"]), c(s["qmax"]), c(s["gravity"]), int(s["kinematics_limits"]),
         )
+        if s.get("force_cone", False):
+            L.orc_kino_set_force_cone(self.h, 1, float(s.get("mu", 0.8)))
         d = np.zeros(5, np.int32)
         L.orc_kino_dims(self.h, d)
         self.nx, self.ndx, self.nu, self.nc, self.nf = (int(v) for v in d)

@@ -97,11 +97,11 @@ def test_settings_dict_keys_and_errors(built):
     ocp_bad.createProblem(rb.x_ref, 50, 3, -9.81, False)
     with pytest.raises(RuntimeError, match="w_x"):
         simple_mpc.BatchedMPC(conf, ocp_bad, 1, lib=lib)
-    s_cone = dict(s, force_cone=True)
-    ocp_cone = simple_mpc.KinodynamicsOCP(s_cone, mh)
-    ocp_cone.createProblem(rb.x_ref, 50, 3, -9.81, False)
+    s_land = dict(s, land_cstr=True)  # (force_cone is built: tests/test_kino_force_cone.py)
+    ocp_land = simple_mpc.KinodynamicsOCP(s_land, mh)
+    ocp_land.createProblem(rb.x_ref, 50, 3, -9.81, False)
     with pytest.raises(RuntimeError, match="not built"):
-        simple_mpc.BatchedMPC(conf, ocp_cone, 1, lib=lib)
+        simple_mpc.BatchedMPC(conf, ocp_land, 1, lib=lib)
 
 
 def test_mpc_single_instance_surface(built):
