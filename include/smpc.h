@@ -222,6 +222,9 @@ int smpc_get_K0(smpc_handle * h, double * out);
 int smpc_get_Ks(smpc_handle * h, double * out);
 /* solver multipliers (results_.vs / results_.lams): vs [B][H][nc], lams [B][H+1][ndx] (lams[0] = 0) */
 int smpc_get_vs(smpc_handle * h, double * out);
+/* (tests) multipliers of the optional rows of a kinodynamics handle: which = 0 friction-cone rows [B][H][2 nfeet],
+ * 1 land rows [B][H][nfeet] */
+int smpc_debug_get_extra_multipliers(smpc_handle * h, int which, double * out);
 int smpc_get_lams(smpc_handle * h, double * out);
 /* MPC::getStateDerivative(t) for t = 0,1 (reference src/mpc.cpp:346-352). out: [B][2][2 nv] */
 int smpc_get_state_derivative01(smpc_handle * h, double * out);

@@ -30,7 +30,8 @@ namespace
   StageRef make_ref(const KinoModel & md, unsigned mask, const double * u_ref, const double * x_tgt, const double * foot_ref)
   {
     StageRef r;
-    r.mask = mask;
+    r.mask = mask & 0xFFu;        // bits 0-7: feet in contact
+    r.land = (mask >> 8) & 0xFFu; // bits 8-15: feet that land at this stage (land_cstr rows)
     r.u_ref.assign(u_ref, u_ref + md.nu);
     r.x_tgt.assign(x_tgt, x_tgt + md.nx);
     r.foot_ref.resize(md.nf);
@@ -218,6 +219,12 @@ extern "C"
     KinoModel * md = (KinoModel *)h;
     md->s.force_cone = on != 0;
     md->s.mu = mu;
+    md->configure();
+  }
+  void orc_kino_set_land_cstr(void * h, int on)
+  {
+    KinoModel * md = (KinoModel *)h;
+    md->s.land_cstr = on != 0;
     md->configure();
   }
   void orc_set_fold_u_rows(int on) { fold_u_rows() = on != 0; }

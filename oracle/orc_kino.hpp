@@ -8,7 +8,8 @@
 //                  (src/kinodynamics.cpp:60-83)
 //   constraints  : joint box (src/kinodynamics.cpp:91-101), LOCAL frame velocity = 0 per contact
 //                  foot (src/kinodynamics.cpp:110-133)
-// force_size == 3 (point feet) only; force_cone rows: CentroidalFrictionConeResidual per foot in contact; land_cstr is not restated.
+// force_size == 3 (point feet) only; force_cone rows: CentroidalFrictionConeResidual per foot in contact; land_cstr: the height
+// of a landing foot pinned to its contact pose (FrameTranslationResidual, z slice).
 #pragma once
 #include "orc_rigid.hpp"
 
@@ -36,6 +37,7 @@ namespace orc
   struct StageRef
   {
     unsigned mask = 0xF;      // contact bit per foot
+    unsigned land = 0;        // bit per foot: the foot lands at this stage (in contact here, not in the stage before of the cycle)
     Vec u_ref;                // nu   (control_cost target, src/kinodynamics.cpp:61,229-240)
     Vec x_tgt;                // nx   (state_cost target)
     std::vector<V3> foot_ref; // nf   (<foot>_pose_cost references)
@@ -70,8 +72,19 @@ namespace orc
       nu = nv - 6 + 3 * nf;
       configure();
     }
-    void configure() { nc = (nv - 6) + 3 * nf + (s.force_cone ? 2 * nf : 0); }
+    std::vector<double> land_z; // height of the contact poses the cycle stages are created with: feet at the reference state
+    void configure()
+    {
+      nc = (nv - 6) + 3 * nf + (s.force_cone ? 2 * nf : 0) + (s.land_cstr ? nf : 0);
+      Rigid R(M);
+      Vec q(M->q_ref, M->q_ref + nq);
+      R.fk(q.data());
+      land_z.resize(nf);
+      for (int f = 0; f < nf; f++)
+        land_z[f] = R.foot_p[f][2];
+    }
     int cone_base() const { return (nv - 6) + 3 * nf; }
+    int land_base() const { return cone_base() + (s.force_cone ? 2 * nf : 0); }
     // fixed row layout: rows [0, nv-6) joint box, rows nv-6+3f.. frame velocity of foot f, then (force_cone) two friction-cone rows
     // per foot: CentroidalFrictionConeResidual(ndx, nu, f, mu, 1e-4) in NegativeOrthant (reference src/kinodynamics.cpp:124-129):
     //   [ -f_z + epsilon ; f_x^2 + f_y^2 - mu^2 f_z^2 ] <= 0   ([UPSTREAM-RECALL] aligator centroidal-friction-cone.hxx; the same
@@ -80,6 +93,10 @@ namespace orc
     {
       if (row < nv - 6)
         return s.kinematics_limits ? ROW_BOX : ROW_ABSENT;
+      // land_cstr: one equality row per foot that lands at this stage, FrameTranslationResidual(contact pose) sliced to z
+      // (reference src/kinodynamics.cpp:134-146; land flags of the cycle stages: src/mpc.cpp:167-178)
+      if (s.land_cstr && row >= land_base())
+        return (((r.land & r.mask) >> (row - land_base())) & 1u) ? ROW_EQ : ROW_ABSENT;
       if (row >= cone_base())
         return ((r.mask >> ((row - cone_base()) / 2)) & 1u) ? ROW_NEG : ROW_ABSENT;
       int f = (row - (nv - 6)) / 3;
@@ -272,6 +289,8 @@ namespace orc
             o.c[cone_base() + 2 * f] = -fz + 1e-4;
             o.c[cone_base() + 2 * f + 1] = fx * fx + fy * fy - s.mu * s.mu * fz * fz;
           }
+          if (s.land_cstr && ((r.land >> f) & 1u))
+            o.c[land_base() + f] = R.foot_p[f][2] - land_z[f];
         }
     }
 
@@ -453,6 +472,12 @@ namespace orc
             o.Cu(cb + 1, 3 * f) = 2.0 * u[3 * f];
             o.Cu(cb + 1, 3 * f + 1) = 2.0 * u[3 * f + 1];
             o.Cu(cb + 1, 3 * f + 2) = -2.0 * s.mu * s.mu * u[3 * f + 2];
+          }
+          if (s.land_cstr && ((r.land >> f) & 1u))
+          { // d p_z / dq = (R_l J_local)_z: the local velocity Jacobian turned into the world frame
+            const M3 & Rl = R.oMi[M->foot_joint[f]].R;
+            for (int k = 0; k < nv; k++)
+              o.Cx(land_base() + f, k) = Rl(2, 0) * dv(0, k) + Rl(2, 1) * dv(1, k) + Rl(2, 2) * dv(2, k);
           }
         }
     }

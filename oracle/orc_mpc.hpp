@@ -238,6 +238,7 @@ namespace orc
       Rigid R(M);
       R.fk(x_model_ref.data()); // data handler still holds the reference state (src/mpc.cpp:26,162)
       cycle_horizon.clear();
+      std::vector<char> previous(nf, 1); // land flags: in contact here, not in the stage before (src/mpc.cpp:133-137,167-185)
       for (auto & state : timer.contact_states)
       {
         int active = 0;
@@ -256,6 +257,13 @@ namespace orc
         sr.foot_ref.resize(nf);
         for (int f = 0; f < nf; f++)
           sr.foot_ref[f] = R.foot_p[f];
+        sr.land = 0;
+        for (int f = 0; f < nf; f++)
+        {
+          if (state[f] && !previous[f])
+            sr.land |= 1u << f;
+          previous[f] = state[f] ? 1 : 0;
+        }
         cycle_horizon.push_back(sr);
       }
     }
@@ -317,6 +325,7 @@ namespace orc
         for (int t = 0; t < H; t++)
         {
           o.stages[t].mask = horizon[t].mask;
+          o.stages[t].land = horizon[t].land;
           o.stages[t].u_ref = horizon[t].u_ref;
           o.stages[t].x_tgt = horizon[t].x_tgt;
         }

@@ -90,8 +90,6 @@ extern "C"
       return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the MPC engine has no CPU path");
     if (ocp->force_size != 3)
       return fail(SMPC_ERR_INVALID, "force size in settings does not match reference force size (only 3-D point feet are built)");
-    if (ocp->land_cstr)
-      return fail(SMPC_ERR_INVALID, "land_cstr constraint rows are not built yet");
     if (mpc->T < 2)
       return fail(SMPC_ERR_INVALID, "horizon must have at least 2 stages");
     const int nv = robot->nv, ndx = 2 * nv, nu = nv - 6 + 3 * robot->nfeet;
@@ -110,6 +108,7 @@ extern "C"
     ks.terminal_constraint = ocp->terminal_constraint;
     ks.force_cone = ocp->force_cone;
     ks.mu = ocp->mu;
+    ks.land_cstr = ocp->land_cstr;
     for (int i = 0; i < nv - 6; i++)
       if (!(ks.qmin[i] <= ks.qmax[i]))
         return fail(SMPC_ERR_INVALID, "qmin must not exceed qmax (joint limits are indexed by actuated joint, 0 .. nv - 7)");
@@ -509,6 +508,15 @@ extern "C"
     if (h->cent)
       return guarded([&] { h->cent->get_ring(h->cent->buf.vs, CentGo2::NC, h->cent->H, out); });
     return guarded([&] { h->eng->get_ring(h->eng->buf.vs, DimsGo2::NC, h->eng->H, out); });
+  }
+  int smpc_debug_get_extra_multipliers(smpc_handle * h, int which, double * out)
+  {
+    if (!h || !out || h->full || h->cent)
+      return fail(SMPC_ERR_INVALID, "kinodynamics handles only");
+    double * src = which == 0 ? h->eng->buf.es : h->eng->buf.ls;
+    if (!src)
+      return fail(SMPC_ERR_INVALID, "the problem has no such rows");
+    return guarded([&] { h->eng->get_ring(src, which == 0 ? 2 * DimsGo2::NF : DimsGo2::NF, h->eng->H, out); });
   }
   int smpc_get_lams(smpc_handle * h, double * out)
   {

@@ -31,6 +31,7 @@ namespace smpc
     int kinematics_limits;
     int terminal_constraint = 0; // createProblem(..., terminal_constraint)
     int force_cone = 0;          // friction-cone rows per foot in contact (3-D feet)
+    int land_cstr = 0;           // height of a landing foot pinned to its contact pose
     double mu = 0.8;             // friction coefficient
   };
   struct HostMpcSettings
@@ -454,6 +455,22 @@ namespace smpc
         buf.ek = zalloc(BH * 12 * D::NF);
         buf.cone_mu2 = ks.mu * ks.mu;
       }
+      land_cstr = ks.land_cstr != 0;
+      if (land_cstr)
+      {
+        if (!structured_riccati)
+          throw std::runtime_error("land_cstr needs the structured Riccati sweep (unset SMPC_RICCATI)");
+        auto zalloc = [&](size_t n) {
+          double * p = dalloc(n);
+          dev_zero(p, n * sizeof(double), stream);
+          return p;
+        };
+        buf.ls = zalloc(BR * D::NF);
+        buf.ls_e = zalloc(BR * D::NF);
+        buf.ls_b = zalloc(BR * D::NF);
+        buf.dls = zalloc(BH * D::NF);
+        buf.lk = zalloc(BH * D::NF * (D::NV + 2));
+      }
       if (std::getenv("SMPC_PHASE_PROFILE"))
         buf.dbg = dalloc(64);
       h2d(buf.model, hm.data(), sizeof(DevModel<D>), stream);
@@ -477,10 +494,13 @@ namespace smpc
         launch<StageKernelArgs<D>, lq_init_body<D>, 64>(B * H, stream, sk);
       }
       cold_solve(def);
+      for (int f = 0; f < D::NF; f++)
+        buf.land_z[f] = ref_foot_pos[f][2]; // contact poses of the cycle stages: the feet at the reference state (src/mpc.cpp:162)
     }
+    bool land_cstr = false;
     ~KinoEngine()
     {
-      for (double * p : {buf.CN, buf.vN, buf.vN_e, buf.vN_b, buf.dvN, buf.dcm_ref, buf.es, buf.es_e, buf.es_b, buf.des, buf.ek})
+      for (double * p : {buf.CN, buf.vN, buf.vN_e, buf.vN_b, buf.dvN, buf.dcm_ref, buf.es, buf.es_e, buf.es_b, buf.des, buf.ek, buf.ls, buf.ls_e, buf.ls_b, buf.dls, buf.lk})
         dev_free(p);
       for (double * p : {buf.xs_b, buf.us_b, buf.vs_b, buf.lams_b, buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref, buf.ftraj, buf.vbase, buf.vref, buf.lq,
                          buf.gains, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, X_dev, stage_out})
@@ -676,6 +696,8 @@ namespace smpc
         d2d(b.vN_e, b.vN, (size_t)b.B * 3 * sizeof(double), stream);
       if (b.es != nullptr)
         d2d(b.es_e, b.es, (size_t)b.B * R * 2 * D::NF * sizeof(double), stream);
+      if (b.ls != nullptr)
+        d2d(b.ls_e, b.ls, (size_t)b.B * R * D::NF * sizeof(double), stream);
     }
 
     void upload_stages()
@@ -744,6 +766,8 @@ namespace smpc
       }
       if (buf.es != nullptr)
         bc(buf.es, (size_t)R * 2 * D::NF);
+      if (buf.ls != nullptr)
+        bc(buf.ls, (size_t)R * D::NF);
       // swing start/end = reference foot positions (FootTrajectory ctor, src/foot-trajectory.cpp:20-39):
       // a reference-only recede call with land = -1 < T_fly keeps them, so initialise them here on the host
       std::vector<double> ft((size_t)D::NF * 6);
@@ -798,6 +822,7 @@ namespace smpc
         throw std::runtime_error("contact sequence must not be empty");
       timer.generate(cs, n, D::NF, H);
       cycle.clear();
+      unsigned previous = (1u << D::NF) - 1u; // land flags: in contact here, not in the stage before (src/mpc.cpp:133-137,167-185)
       for (auto & st : timer.states)
       {
         int active = 0;
@@ -811,6 +836,8 @@ namespace smpc
             s.mask |= 1u << f;
             s.u_ref[3 * f + 2] = ms.support_force / (double)active;
           }
+        s.land = s.mask & ~previous;
+        previous = s.mask;
         for (int i = 0; i < D::NX; i++)
           s.x_tgt[i] = x_model_ref[i];
         cycle.push_back(s);
@@ -982,6 +1009,7 @@ namespace smpc
       io.tag(D::NU, "nu");
       io.tag(buf.CN != nullptr ? 1 : 0, "terminal constraint");
       io.tag(buf.es != nullptr ? 1 : 0, "friction-cone rows");
+      io.tag(buf.ls != nullptr ? 1 : 0, "land rows");
       io.pod(head);
       io.pod(walking);
       io.host(velocity_base, sizeof(velocity_base));
@@ -1004,6 +1032,8 @@ namespace smpc
         io.dev(buf.vN, (size_t)B * 3 * sizeof(double));
       if (buf.es != nullptr)
         io.dev(buf.es, BR * 2 * D::NF * sizeof(double));
+      if (buf.ls != nullptr)
+        io.dev(buf.ls, BR * D::NF * sizeof(double));
       if (io.mode == StateIO::LOAD)
         upload_stages();
       stream_sync(stream);

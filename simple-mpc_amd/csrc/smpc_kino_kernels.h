@@ -320,6 +320,10 @@ namespace smpc
     if (cones)
       kino_cone_rows<D, true>(sc, in, b.cone_mu2, b.es + (ib + st) * 2 * NF, (const double *)nullptr, 0.0, b.es_e + (ib + st) * 2 * NF,
                               b.ek + ((size_t)inst * H + t) * 12 * NF);
+    const unsigned land = b.ls != nullptr ? (b.stages[t].land & in.mask) : 0u;
+    if (b.ls != nullptr)
+      kino_land_rows<D, true>(sc, in, land, b.land_z, b.ls + (ib + st) * NF, (const double *)nullptr, 0.0, b.ls_e + (ib + st) * NF,
+                              b.lk + ((size_t)inst * H + t) * NF * (NV + 2));
     if (in.prof) prof_tick(in.prof, 31, tprev);
 
     double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
@@ -426,6 +430,13 @@ namespace smpc
         double cn = sc.cn[k];
         if (md.kinematics_limits && k >= 6 && k < NV)
           cn += sc.nu[k - 6];
+        if (land != 0u && k < NV)
+        { // C_x^T nu of the land rows (current multipliers)
+          const double * lsc = kino_land_scratch<D, true>(sc);
+          for (int f = 0; f < NF; f++)
+            if ((land >> f) & 1u)
+              cn += sc.Jfoot[(3 * f + 2) * NV + k] * lsc[2 * NF + f];
+        }
         double q = g + acc + cn - (t > 0 ? lam_prev_v : 0.0);
         if (t == 0)
           q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
@@ -1149,6 +1160,9 @@ namespace smpc
     if (b.es != nullptr)
       kino_cone_rows<D, false>(sc, in, b.cone_mu2, b.es + (ib + st) * 2 * NF, b.des + ((size_t)inst * H + t) * 2 * NF, alpha,
                                b.es_e + (ib + st) * 2 * NF, (double *)nullptr);
+    if (b.ls != nullptr)
+      kino_land_rows<D, false>(sc, in, b.stages[t].land, b.land_z, b.ls + (ib + st) * NF, b.dls + ((size_t)inst * H + t) * NF, alpha,
+                               b.ls_e + (ib + st) * NF, (double *)nullptr);
     SMPC_LANES(NT)
     {
       if (lane == 0)

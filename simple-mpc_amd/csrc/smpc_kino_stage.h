@@ -1138,4 +1138,67 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
   }
+
+  // land_cstr rows of the stage: for every foot that lands here (in contact now, not in the previous stage of the cycle) the
+  // equality p_z(foot) = z of its contact pose (reference src/kinodynamics.cpp:134-146).  After kino_multipliers / kino_cone_rows:
+  // value | nu+ | nu  go behind the cone scratch; the penalty / infeasibility are added to red[1] / red[2]; the derivative pass
+  // writes the rows (d p_z / dq: z row of the foot's world-frame point Jacobian), d and 2 nu+ - nu into the knot block lk.
+  template <class D, bool DERIV>
+  SMPC_HD double * kino_land_scratch(KinoScratch<D, DERIV> & sc)
+  {
+    static_assert(D::NJ * 9 + D::NV * 6 + D::NJ * 40 >= 612 + 8 * D::NF + 3 * D::NF, "land scratch behind the cone scratch");
+    return sc.oR + 612 + 8 * D::NF;
+  }
+  template <class D, bool DERIV>
+  SMPC_DEV void kino_land_rows(KinoScratch<D, DERIV> & sc, const StageIn<D> & in, unsigned land, const double * land_z, const double * nu,
+                               const double * dnu, double alpha, const double * nu_e, double * lk)
+  {
+    constexpr int NT = 64, NF = D::NF, NV = D::NV;
+    const double mu = sc.ml.mu;
+    double * ls = kino_land_scratch<D, DERIV>(sc);
+    const unsigned rows = land & in.mask;
+    SMPC_LANES(NT)
+    {
+      if (lane < NF)
+      {
+        const int f = lane;
+        const bool on = (rows >> f) & 1u;
+        const double c = on ? sc.footp[3 * f + 2] - land_z[f] : 0.0;
+        const double v = nu[f] + (dnu ? alpha * dnu[f] : 0.0);
+        const double vp = on ? nu_e[f] + c / mu : 0.0; // equality row: always active
+        ls[f] = c;
+        ls[NF + f] = vp;
+        ls[2 * NF + f] = v;
+        if (lk != nullptr)
+        {
+          lk[NF * NV + f] = mu * (vp - v);
+          lk[NF * NV + NF + f] = on ? 2.0 * vp - v : 0.0;
+        }
+      }
+      if constexpr (DERIV)
+      {
+        if (lk != nullptr)
+          for (int idx = lane; idx < NF * NV; idx += NT)
+          {
+            const int f = idx / NV, k = idx % NV;
+            lk[idx] = ((rows >> f) & 1u) ? sc.Jfoot[(3 * f + 2) * NV + k] : 0.0; // (world-frame point Jacobian, z row)
+          }
+      }
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      double pen = 0.0, prim = sc.red[2];
+      for (int f = 0; f < NF; f++)
+      {
+        const double vp = ls[NF + f], dv = vp - ls[2 * NF + f];
+        pen += 0.5 * mu * (vp * vp + dv * dv);
+        prim = fmax(prim, fabs(ls[f]));
+      }
+      sc.red[1] += pen;
+      sc.red[2] = prim;
+    }
+    SMPC_LANES_END_WAVE
+  }
 } // namespace smpc

@@ -102,7 +102,7 @@ namespace smpc
   struct StageShared
   {
     unsigned mask;
-    unsigned pad;
+    unsigned land; // bit per foot: the foot lands at this stage of the cycle (land_cstr rows; reference src/mpc.cpp:167-178)
     double u_ref[D::NU];
     double x_tgt[D::NX];
   };
@@ -138,6 +138,11 @@ namespace smpc
     //   ek [B][H][12 NF]: Jacobian rows of the active rows (2 NF x 3) | d = mu (nu+ - nu) | active ? 2 nu+ - nu : 0 | activity
     double *es = nullptr, *es_e = nullptr, *es_b = nullptr, *des = nullptr, *ek = nullptr;
     double cone_mu2 = 0.0; // friction coefficient squared
+    // land_cstr rows of the kinodynamics stage: the height of a foot that lands at the stage is pinned to its contact pose
+    // (FrameTranslationResidual sliced to z, EqualityConstraint; reference src/kinodynamics.cpp:134-146).  ls == nullptr: none.
+    //   ls / ls_e / ls_b [B][R][NF], dls [B][H][NF], lk [B][H][NF (NV + 2)]: rows d p_z / dq (NF x NV) | d | 2 nu+ - nu
+    double *ls = nullptr, *ls_e = nullptr, *ls_b = nullptr, *dls = nullptr, *lk = nullptr;
+    double land_z[D::NF] = {0}; // contact-pose heights: the feet at the reference state (src/mpc.cpp:162)
     // merit bookkeeping
     double * parts0 = nullptr;   // [B][H+1][4] phi, cost, prim, dual at the current point
     double * partsT = nullptr;   // [B][LS_N][H+1][2] phi, prim at trial points

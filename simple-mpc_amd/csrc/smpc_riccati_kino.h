@@ -599,6 +599,8 @@ namespace smpc
           }
       }
       prof_tick(prof, 8, tprev);
+      // land_cstr rows present at this stage (wave-uniform: the stage descriptors are shared by the batch)
+      const unsigned landrows = b.ls != nullptr ? (b.stages[t].land & b.stages[t].mask) : 0u;
       // ---- (5) contact rows of C into LDS ; then  Q^ += C^T C / mu + box  (matrix cores, K = NG), the vector column
       //          [q^ + C^T d / mu ; r^] goes into column NXU of the H^ grid ----
       SMPC_LANES(NT)
@@ -666,7 +668,16 @@ namespace smpc
               cd += s.boxact[i - 6] * s.boxd[i - 6];
             s.qh[i] += imu * cd;
           }
-          else if (b.es != nullptr && lane < NDX + 3 * NF)
+          if (landrows != 0u && lane < NV)
+          { // q^ += c^T d / mu of the land rows (rows on q only)
+            const double * lkp = b.lk + ((size_t)inst * H + t) * NF * (NV + 2);
+            double acc = 0.0;
+            for (int f = 0; f < NF; f++)
+              if ((landrows >> f) & 1u)
+                acc += lkp[f * NV + lane] * lkp[NF * NV + f];
+            s.qh[lane] += imu * acc;
+          }
+          else if (b.es != nullptr && lane >= NDX && lane < NDX + 3 * NF)
           { // r^ += D^T d / mu of the friction-cone rows
             const int k = lane - NDX, f = k / 3;
             s.rh[k] += imu * (s.cone[(2 * f) * 3 + k % 3] * s.cone[6 * NF + 2 * f] + s.cone[(2 * f + 1) * 3 + k % 3] * s.cone[6 * NF + 2 * f + 1]);
@@ -691,6 +702,33 @@ namespace smpc
               if (lc == lr + 4 * v && IX::isQj(row))
                 SMPC_ACCV(hacc, tix<4>(I, I), v) += imu * s.boxact[row - 6];
             }
+          // land rows: Q^[q, q] += c^T c / mu (rank one per landing foot; at most a few stages of a horizon have any)
+          if (landrows != 0u)
+          {
+            static_assert(NV <= 32, "the q-q block lives in tiles (0,0), (0,1), (1,1)");
+            const double * lkp = b.lk + ((size_t)inst * H + t) * NF * (NV + 2);
+            for (int f = 0; f < NF; f++)
+              if ((landrows >> f) & 1u)
+              {
+                const double * cf = lkp + f * NV;
+#pragma unroll
+                for (int I = 0; I < 2; I++)
+#pragma unroll
+                  for (int J = I; J < 2; J++)
+                  {
+                    const int col = 16 * J + lc;
+                    const double cc = cf[col < NV ? col : 0];
+#pragma unroll
+                    for (int v = 0; v < 4; v++)
+                    {
+                      const int row = 16 * I + lr + 4 * v;
+                      const double cr = cf[row < NV ? row : 0];
+                      if (row < NV && col < NV)
+                        SMPC_ACCV(hacc, tix<4>(I, J), v) += imu * cr * cc;
+                    }
+                  }
+              }
+          }
           // friction-cone rows act on the force part of u only: R^ += D^T D / mu (3 x 3 block per foot), r^ += D^T d / mu
           if (b.es != nullptr)
           {
@@ -959,6 +997,19 @@ namespace smpc
           const double dnu = acc / mu;
           b.dvs[lt * NC + r] = dnu;
           s.part[lane] += vvpd[r] * (mu * dnu - vd[r]) - vd[r] * dnu;
+        }
+        else if (b.ls != nullptr && lane < NU + NC + NF)
+        { // land rows: dnu = (c dx_q + d) / mu  (absent rows: c = 0)
+          const int f = lane - NU - NC;
+          const double * lkp = b.lk + lt * NF * (NV + 2);
+          const double dd = lkp[NF * NV + f], vpd = lkp[NF * NV + NF + f];
+          double acc = dd;
+          if (((b.stages[t].land & b.stages[t].mask) >> f) & 1u)
+            for (int j = 0; j < NV; j++)
+              acc += lkp[f * NV + j] * s.dx[j];
+          const double dnu = acc / mu;
+          b.dls[lt * NF + f] = dnu;
+          s.part[lane] += vpd * (mu * dnu - dd) - dd * dnu;
         }
       }
       SMPC_LANES_END_WAVE

@@ -722,6 +722,24 @@ namespace smpc
           }
         }
       }
+      if (b.ls != nullptr)
+      { // multipliers of the land_cstr rows
+        constexpr int NL = D::NF;
+        for (int idx = lane; idx < H * NL; idx += NT)
+        {
+          const int t = idx / NL, i = idx % NL;
+          const size_t o = (ib + ring_slot(ka.head, t, R)) * NL + i;
+          if (restore)
+            b.ls[o] = b.ls_b[o];
+          else
+          {
+            const double v = b.ls[o];
+            if (tent)
+              b.ls_b[o] = v;
+            b.ls[o] = v + alpha * b.dls[((size_t)inst * H + t) * NL + i];
+          }
+        }
+      }
       if (b.CN != nullptr && lane < 3)
       { // multipliers of the terminal constraint
         const size_t o = (size_t)inst * 3 + lane;
@@ -933,6 +951,8 @@ namespace smpc
         b.vs[(ib + sHm1) * NC + i] = 0.0;
       if (b.es != nullptr && lane < 2 * NF)
         b.es[(ib + sHm1) * 2 * NF + lane] = 0.0;
+      if (b.ls != nullptr && lane < NF)
+        b.ls[(ib + sHm1) * NF + lane] = 0.0;
       if (lane < 6)
         b.vref[(ib + sHm1) * 6 + lane] = b.vbase[(size_t)inst * 6 + lane]; // setVelocityBase(H-1, velocity_base_)
       for (int i = lane; i < NDX; i += NT)

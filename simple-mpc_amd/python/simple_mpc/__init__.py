@@ -686,7 +686,16 @@ class BatchedMPC:
 
     @property
     def vs(self):
-        return self._get("smpc_get_vs", (self.B, self.H, self.nc))
+        v = self._get("smpc_get_vs", (self.B, self.H, self.nc))
+        st = getattr(self.ocp_handler, "settings", {})
+        if isinstance(self.ocp_handler, KinodynamicsOCP) and not isinstance(self.ocp_handler, FullDynamicsOCP):
+            nf = self.ocp_handler.model_handler.getFeetNb()
+            for which, key, n in ((0, "force_cone", 2 * nf), (1, "land_cstr", nf)):  # optional rows, in the oracle's order
+                if st.get(key, False):
+                    e = np.zeros((self.B, self.H, n))
+                    self._lib.check(self._lib.L.smpc_debug_get_extra_multipliers(self._h, which, e))
+                    v = np.concatenate([v, e], axis=2)
+        return v
 
     @property
     def lams(self):

@@ -69,6 +69,7 @@ def lib():
     L.orc_kino_deriv.argtypes = [vp, C.c_uint] + [_dp] * 14
     L.orc_kino_set_force_cone.argtypes = [vp, C.c_int, C.c_double]
     L.orc_set_fold_u_rows.argtypes = [C.c_int]
+    L.orc_kino_set_land_cstr.argtypes = [vp, C.c_int]
     L.orc_kino_term.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
     L.orc_kino_term_cstr.argtypes = [vp, _dp, _dp, C.c_double, _dp, _dp]
     L.orc_centroidal.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
@@ -321,6 +322,8 @@ class Kino:
         )
         if s.get("force_cone", False):
             L.orc_kino_set_force_cone(self.h, 1, float(s.get("mu", 0.8)))
+        if s.get("land_cstr", False):
+            L.orc_kino_set_land_cstr(self.h, 1)
         d = np.zeros(5, np.int32)
         L.orc_kino_dims(self.h, d)
         self.nx, self.ndx, self.nu, self.nc, self.nf = (int(v) for v in d)
