@@ -576,11 +576,16 @@ namespace smpc
       sk.slots = slots;
       return sk;
     }
+    // optional constraint blocks present: the kernels' EXT instantiations (the default ones carry none of that code)
+    static bool has_ext(const Buffers<D> & b) { return b.es != nullptr || b.ls != nullptr || b.CN != nullptr; }
     void launch_deriv(const Buffers<D> & b, int slots = 0)
     {
       // list-mode launches (backtracking path, normally empty) are booked under "select" so that the per-kernel
       // averages of deriv / trial / apply stay those of full-batch launches
-      timed_launch<StageKernelArgs<D>, deriv_body<D>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
+      if (has_ext(b))
+        timed_launch<StageKernelArgs<D>, deriv_body<D, true>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
+      else
+        timed_launch<StageKernelArgs<D>, deriv_body<D, false>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
     }
     // backward + forward sweep: Newton step and merit directional derivative
     void launch_sweeps(const Buffers<D> & b)
@@ -588,8 +593,16 @@ namespace smpc
       if (structured_riccati)
       {
         // kinodynamics-structured sweep, one wavefront per instance
-        timed_launch<SolverArgs<D>, riccati_kino_body<D>, 64, RICCATI_MINW>(KID_RICCATI, b.B, solver_args(b));
-        timed_launch<SolverArgs<D>, forward_kino_body<D>, 64>(KID_FORWARD, b.B, solver_args(b));
+        if (has_ext(b))
+        {
+          timed_launch<SolverArgs<D>, riccati_kino_body<D, true>, 64, RICCATI_MINW>(KID_RICCATI, b.B, solver_args(b));
+          timed_launch<SolverArgs<D>, forward_kino_body<D, true>, 64>(KID_FORWARD, b.B, solver_args(b));
+        }
+        else
+        {
+          timed_launch<SolverArgs<D>, riccati_kino_body<D, false>, 64, RICCATI_MINW>(KID_RICCATI, b.B, solver_args(b));
+          timed_launch<SolverArgs<D>, forward_kino_body<D, false>, 64>(KID_FORWARD, b.B, solver_args(b));
+        }
       }
       else
       {
@@ -626,13 +639,21 @@ namespace smpc
       StageKernelArgs<D> sk = stage_args(b);
       sk.j0 = 0;
       sk.nj = 1;
-      timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_TRIAL, b.B * (H + 1), sk);
+      if (has_ext(b))
+        timed_launch<StageKernelArgs<D>, trial_body<D, true>, 64, TRIAL_MINW>(KID_TRIAL, b.B * (H + 1), sk);
+      else
+        timed_launch<StageKernelArgs<D>, trial_body<D, false>, 64, TRIAL_MINW>(KID_TRIAL, b.B * (H + 1), sk);
       timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, 0, 1));
       const int slots = launch_backtracking(b);
       sk.slots = slots;
       sk.j0 = 1;
       sk.nj = D::LS_N - 1;
-      timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
+      {
+        if (has_ext(b))
+          timed_launch<StageKernelArgs<D>, trial_body<D, true>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
+        else
+          timed_launch<StageKernelArgs<D>, trial_body<D, false>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
+      }
       timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, 1, D::LS_N - 1));
       timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B, solver_args(b));
     }
@@ -680,7 +701,12 @@ namespace smpc
         StageKernelArgs<D> sk = stage_args(b, slots);
         sk.j0 = 1;
         sk.nj = D::LS_N - 1;
-        timed_launch<StageKernelArgs<D>, trial_body<D>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
+        {
+        if (has_ext(b))
+          timed_launch<StageKernelArgs<D>, trial_body<D, true>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
+        else
+          timed_launch<StageKernelArgs<D>, trial_body<D, false>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
+      }
         timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, nb, solver_args(b, 1, D::LS_N - 1));
         sa.mode = 0;
         timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_SELECT, slots, sa, true);

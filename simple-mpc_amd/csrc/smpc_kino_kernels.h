@@ -69,12 +69,14 @@ namespace smpc
   // =============================================================================================
   // deriv_body: grid = B * (H+1); block (inst, t); t == H is the terminal node.
   // =============================================================================================
-  template <class D>
+  template <class D, bool EXT = false>
   SMPC_DEV void deriv_one(const StageKernelArgs<D> & ka, int inst, int t);
 
   // grid = B * (H+1) (slots == 0) or slots * (H+1) walking the compacted list of instances that rejected the
   // tentative full step (slots > 0) -- one loop, one inlined copy of the stage body
-  template <class D>
+  // EXT: the problem has optional constraint blocks (friction cones, land rows, terminal constraint); the default instantiation
+  // carries none of their code
+  template <class D, bool EXT = false>
   SMPC_DEV void deriv_body(const StageKernelArgs<D> & ka, int block)
   {
     const int H = ka.b.H;
@@ -82,10 +84,10 @@ namespace smpc
     const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : slot + 1;
     const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
     for (int m = slot; m < count; m += stride)
-      deriv_one<D>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t);
+      deriv_one<D, EXT>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t);
   }
 
-  template <class D>
+  template <class D, bool EXT>
   SMPC_DEV void deriv_one(const StageKernelArgs<D> & ka, int inst, int t)
   {
     typedef KinoScratch<D, true> KinoScratchT;
@@ -207,7 +209,7 @@ namespace smpc
       double * qN = b.qN + (size_t)inst * NDX;
       // terminal constraint c = com + tau vcom - ref (DCMPositionResidual): rows C = [Jcom + tau dvcom/dq | tau Jcom] into the (dead)
       // weighted-Jacobian block, v+ = v_e + c / mu; folded below: Q_N += C^T C / mu, q_N += C^T v+
-      const bool tcs = b.CN != nullptr;
+      const bool tcs = EXT && b.CN != nullptr;
       double * tC = sc.Jfoot; // 3 x NDX, then v | v+ | c  (the terminal node has no foot rows)
       static_assert(NF * 3 * NV >= 3 * NDX + 9, "terminal constraint rows fit the foot Jacobian block");
       if (tcs)
@@ -316,12 +318,12 @@ namespace smpc
 
     // ---- multipliers, active set ----
     kino_multipliers<D, true>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
-    const bool cones = b.es != nullptr;
+    const bool cones = EXT && b.es != nullptr;
     if (cones)
       kino_cone_rows<D, true>(sc, in, b.cone_mu2, b.es + (ib + st) * 2 * NF, (const double *)nullptr, 0.0, b.es_e + (ib + st) * 2 * NF,
                               b.ek + ((size_t)inst * H + t) * 12 * NF);
-    const unsigned land = b.ls != nullptr ? (b.stages[t].land & in.mask) : 0u;
-    if (b.ls != nullptr)
+    const unsigned land = (EXT && b.ls != nullptr) ? (b.stages[t].land & in.mask) : 0u;
+    if (EXT && b.ls != nullptr)
       kino_land_rows<D, true>(sc, in, land, b.land_z, b.ls + (ib + st) * NF, (const double *)nullptr, 0.0, b.ls_e + (ib + st) * NF,
                               b.lk + ((size_t)inst * H + t) * NF * (NV + 2));
     if (in.prof) prof_tick(in.prof, 31, tprev);
@@ -1003,10 +1005,12 @@ namespace smpc
   // The backtracking launch (slots > 0) has grid = slots * (H+1) and walks the compacted list of instances that
   // rejected alpha = 1: the common case (everybody accepted) costs a few thousand empty blocks, not B * (H+1).
   // =============================================================================================
-  template <class D>
+  template <class D, bool EXT = false>
   SMPC_DEV void trial_one(const StageKernelArgs<D> & ka, int inst, int t, int j);
 
-  template <class D>
+  // EXT: the problem has optional constraint blocks (friction cones, land rows, terminal constraint); the default instantiation
+  // carries none of their code
+  template <class D, bool EXT = false>
   SMPC_DEV void trial_body(const StageKernelArgs<D> & ka, int block)
   {
     const int H = ka.b.H;
@@ -1021,11 +1025,11 @@ namespace smpc
       if (ka.slots == 0 && ka.b.ls_sel[inst] >= 0)
         break; // already accepted an earlier candidate (uniform across the workgroup)
       for (int jj = 0; jj < ka.nj; jj++)
-        trial_one<D>(ka, inst, t, ka.j0 + jj);
+        trial_one<D, EXT>(ka, inst, t, ka.j0 + jj);
     }
   }
 
-  template <class D>
+  template <class D, bool EXT>
   SMPC_DEV void trial_one(const StageKernelArgs<D> & ka, int inst, int t, int j)
   {
     typedef KinoScratch<D, false> KinoScratchT;
@@ -1141,7 +1145,7 @@ namespace smpc
       if (lane == 0)
       {
         double pen = 0.0, prim = 0.0;
-        if (b.CN != nullptr)
+        if (EXT && b.CN != nullptr)
           for (int r = 0; r < 3; r++)
           { // terminal constraint at the trial point, multipliers v + alpha dv
             const double c = sc.com[r] + b.dcm_tau * sc.hg[r] / md.total_mass - b.dcm_ref[(size_t)inst * 3 + r];
@@ -1157,10 +1161,10 @@ namespace smpc
       return;
     }
     kino_multipliers<D, false>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
-    if (b.es != nullptr)
+    if (EXT && b.es != nullptr)
       kino_cone_rows<D, false>(sc, in, b.cone_mu2, b.es + (ib + st) * 2 * NF, b.des + ((size_t)inst * H + t) * 2 * NF, alpha,
                                b.es_e + (ib + st) * 2 * NF, (double *)nullptr);
-    if (b.ls != nullptr)
+    if (EXT && b.ls != nullptr)
       kino_land_rows<D, false>(sc, in, b.stages[t].land, b.land_z, b.ls + (ib + st) * NF, b.dls + ((size_t)inst * H + t) * NF, alpha,
                                b.ls_e + (ib + st) * NF, (double *)nullptr);
     SMPC_LANES(NT)

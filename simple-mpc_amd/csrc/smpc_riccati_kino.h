@@ -263,7 +263,7 @@ namespace smpc
   // =============================================================================================
   // riccati_kino_body: grid = B, NT = 64 lanes (one wavefront per instance)
   // =============================================================================================
-  template <class D>
+  template <class D, bool EXT = false> // EXT: optional constraint blocks present (see deriv_body)
   SMPC_DEV void riccati_kino_body(const SolverArgs<D> & ka, int block)
   {
     constexpr int NT = 64; // exactly one wavefront per workgroup: phases end with SMPC_LANES_END_WAVE
@@ -600,7 +600,7 @@ namespace smpc
       }
       prof_tick(prof, 8, tprev);
       // land_cstr rows present at this stage (wave-uniform: the stage descriptors are shared by the batch)
-      const unsigned landrows = b.ls != nullptr ? (b.stages[t].land & b.stages[t].mask) : 0u;
+      const unsigned landrows = (EXT && b.ls != nullptr) ? (b.stages[t].land & b.stages[t].mask) : 0u;
       // ---- (5) contact rows of C into LDS ; then  Q^ += C^T C / mu + box  (matrix cores, K = NG), the vector column
       //          [q^ + C^T d / mu ; r^] goes into column NXU of the H^ grid ----
       SMPC_LANES(NT)
@@ -619,7 +619,7 @@ namespace smpc
         const double vdc = lq[D::O_d + NA + (pl < NG ? pl : 0)];
         const double vba = lq[D::O_C + (pl < NA ? pl * NDX + 6 + pl : 0)]; // 1 if the box row is active
         const double vbd = lq[D::O_d + (pl < NA ? pl : 0)];
-        const double * ekp = b.es != nullptr ? b.ek + ((size_t)inst * H + t) * 12 * NF : lq; // (cone rows: [D | d] are contiguous)
+        const double * ekp = (EXT && b.es != nullptr) ? b.ek + ((size_t)inst * H + t) * 12 * NF : lq; // (cone rows: [D | d] are contiguous)
         const double vce = ekp[pl < 8 * NF ? pl : 0];
 #pragma unroll
         for (int n = 0; n < CC_PL; n++)
@@ -635,8 +635,9 @@ namespace smpc
           s.boxact[lane] = vba;
           s.boxd[lane] = vbd;
         }
-        if (lane < 8 * NF)
-          s.cone[lane] = b.es != nullptr ? vce : 0.0;
+        if constexpr (EXT)
+          if (lane < 8 * NF)
+            s.cone[lane] = b.es != nullptr ? vce : 0.0;
       }
       SMPC_LANES_END_WAVE
       {
@@ -677,7 +678,7 @@ namespace smpc
                 acc += lkp[f * NV + lane] * lkp[NF * NV + f];
             s.qh[lane] += imu * acc;
           }
-          else if (b.es != nullptr && lane >= NDX && lane < NDX + 3 * NF)
+          else if ((EXT && b.es != nullptr) && lane >= NDX && lane < NDX + 3 * NF)
           { // r^ += D^T d / mu of the friction-cone rows
             const int k = lane - NDX, f = k / 3;
             s.rh[k] += imu * (s.cone[(2 * f) * 3 + k % 3] * s.cone[6 * NF + 2 * f] + s.cone[(2 * f + 1) * 3 + k % 3] * s.cone[6 * NF + 2 * f + 1]);
@@ -730,7 +731,7 @@ namespace smpc
               }
           }
           // friction-cone rows act on the force part of u only: R^ += D^T D / mu (3 x 3 block per foot), r^ += D^T d / mu
-          if (b.es != nullptr)
+          if ((EXT && b.es != nullptr))
           {
             static_assert(NDX / 16 == 2 && NDX + 3 * NF <= 48, "the force block of R^ lives in tile (2, 2)");
 #pragma unroll
@@ -862,7 +863,7 @@ namespace smpc
     double dx[NDX], du[NU], y[NDX], part[64], lpd_prev[NDX];
   };
 
-  template <class D>
+  template <class D, bool EXT = false> // EXT: optional constraint blocks present (see deriv_body)
   SMPC_DEV void forward_kino_body(const SolverArgs<D> & ka, int block)
   {
     constexpr int NT = 64;
@@ -960,7 +961,7 @@ namespace smpc
       SMPC_PLA(double, ce, NT, 5); // friction-cone row of lanes NDX .. NDX + 2 NF: Jacobian row (3) | d | vpd, in flight until phase 3
       SMPC_LANES(NT)
       {
-        if (b.es != nullptr && lane >= NDX && lane < NDX + 2 * NF)
+        if ((EXT && b.es != nullptr) && lane >= NDX && lane < NDX + 2 * NF)
         {
           const double * ekp = b.ek + lt * 12 * NF;
           const int i = lane - NDX;
@@ -998,7 +999,7 @@ namespace smpc
           b.dvs[lt * NC + r] = dnu;
           s.part[lane] += vvpd[r] * (mu * dnu - vd[r]) - vd[r] * dnu;
         }
-        else if (b.ls != nullptr && lane < NU + NC + NF)
+        else if ((EXT && b.ls != nullptr) && lane < NU + NC + NF)
         { // land rows: dnu = (c dx_q + d) / mu  (absent rows: c = 0)
           const int f = lane - NU - NC;
           const double * lkp = b.lk + lt * NF * (NV + 2);
@@ -1050,7 +1051,7 @@ namespace smpc
         s.part[lane] += (vlx[lane] - s.lpd_prev[lane]) * s.dx[lane] + vlpd[lane] * acc;
         s.y[lane] = acc + vf[lane] - mu * pn[lane];
       }
-      else if (b.es != nullptr && lane < NDX + 2 * NF)
+      else if ((EXT && b.es != nullptr) && lane < NDX + 2 * NF)
       { // friction-cone rows: dnu = (D du + d) / mu
         const int i = lane - NDX, f = i / 2;
         const double dd = SMPC_PLV(ce)[3];
