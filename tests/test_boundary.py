@@ -97,11 +97,14 @@ def test_settings_dict_keys_and_errors(built):
     ocp_bad.createProblem(rb.x_ref, 50, 3, -9.81, False)
     with pytest.raises(RuntimeError, match="w_x"):
         simple_mpc.BatchedMPC(conf, ocp_bad, 1, lib=lib)
-    s_land = dict(s, land_cstr=True)  # (force_cone is built: tests/test_kino_force_cone.py)
-    ocp_land = simple_mpc.KinodynamicsOCP(s_land, mh)
-    ocp_land.createProblem(rb.x_ref, 50, 3, -9.81, False)
-    with pytest.raises(RuntimeError, match="not built"):
-        simple_mpc.BatchedMPC(conf, ocp_land, 1, lib=lib)
+    # every option of the kinodynamics OCP with 3-D feet is built (tests/test_kino_force_cone.py, test_kino_land_cstr.py,
+    # test_terminal_constraint.py); 6-D feet are not: the reference's own size check fires first, as there
+    s_all = dict(s, land_cstr=True, force_cone=True)
+    ocp_all = simple_mpc.KinodynamicsOCP(s_all, mh)
+    ocp_all.createProblem(rb.x_ref, 50, 3, -9.81, True)
+    assert simple_mpc.BatchedMPC(conf, ocp_all, 1, lib=lib).nc == 24
+    with pytest.raises(RuntimeError, match="force size"):
+        ocp_all.createProblem(rb.x_ref, 50, 6, -9.81, False)
 
 
 def test_mpc_single_instance_surface(built):
