@@ -401,12 +401,17 @@ def main():
     ap.add_argument("--batch-per-gpu", "--batch", dest="batch", type=int, default=None,
                     help="instances per GPU (default 4096; 8192 at 8 GPUs = BASELINE's 65536-instance configuration)")
     ap.add_argument("--iters", type=int, default=3, help="ProxDDP iterations per control step")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="kinodynamics: run the iterations of N parts of the batch on N HIP streams (SMPC_STREAMS; tails of one part's "
+                    "launches are filled by the next part's). Per-kernel rooflines then refer to launches of batch/N instances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch path (gloo + emulated kernel bodies): not a measurement")
     ap.add_argument("--workload", default="kinodynamics", choices=["kinodynamics", "centroidal", "fulldynamics", "talos"],
                     help="kinodynamics = the headline metric (with the other single-GPU configurations measured briefly beside it at 1 GPU)")
     args = ap.parse_args()
+    if args.streams > 1:
+        os.environ["SMPC_STREAMS"] = str(args.streams)  # read by the engine when the handle is created
     if args.batch is None:
         args.batch = 2 if args.dry_run else (1024 if args.workload == "talos" else (8192 if args.gpus >= 8 else 4096))
 
@@ -540,6 +545,7 @@ def main():
                 "batch_per_gpu": B,
                 "global_batch": world * B,
                 "parallelism": "instance-sharded x%d, no collective on the solve path" % world,
+                "streams": args.streams,
                 "finite": ok,
             },
         }
@@ -550,13 +556,19 @@ def main():
             out["kernel_share"] = {k: round(v[0] / max(1e-9, sum(x[0] for x in kt.values())), 3) for k, v in kt.items()}
             rl = rooflines(kt, B, H, ndx, nu, nc, gm.nx, B == 4096 and args.iters == 3)
             dom = max(rl, key=lambda k: kt[k][0])  # dominant kernel = largest share of the timed region
-            out["roofline"] = rl[dom]
-            out["roofline_other"] = {k: v for k, v in rl.items() if k != dom}
+            if args.streams == 1:
+                out["roofline"] = rl[dom]
+                out["roofline_other"] = {k: v for k, v in rl.items() if k != dom}
             # whole step against both bounds: Riccati + derivative FLOPs of k iterations / compulsory I/O of a control step
             fc = flop_counts().get("kinodynamics", {})
             step_fl = args.iters * H * (f_ric(ndx, nu, nc) + fc.get("deriv_flops_per_stage", 0.0))
             step_io = 8 * (2 * (H + 1) * gm.nx + 2 * H * nu + nu * ndx + (H + 1) * ndx + H * nc)
             out["step_roofline"] = both_bounds(B * step_fl, B * step_io, dt / args.steps, "mfma")
+            if args.streams > 1:
+                # launches of different streams overlap: event-to-event durations of single launches include the time they share the
+                # GPU with other launches, so only the whole-step figure is meaningful in this mode
+                out["roofline"] = dict(out["step_roofline"], kernel="whole control step (--streams %d: per-kernel durations overlap)" % args.streams, traffic=None)
+                del out["kernel_share"]
         if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(args.iters)
         if world == 1 and profile:

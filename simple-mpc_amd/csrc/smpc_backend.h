@@ -181,6 +181,7 @@ namespace smpc
   }
   inline void event_destroy(event_t ev) { (void)hipEventDestroy(ev.e); }
   inline void event_record(event_t ev, stream_t s) { SMPC_HIP(hipEventRecord(ev.e, s)); }
+  inline void stream_wait_event(stream_t s, event_t ev) { SMPC_HIP(hipStreamWaitEvent(s, ev.e, 0)); }
   inline float event_elapsed_ms(event_t a, event_t b)
   {
     float ms = 0;

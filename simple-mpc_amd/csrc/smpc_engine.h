@@ -312,6 +312,14 @@ namespace smpc
     double velocity_base[6] = {0, 0, 0, 0, 0, 0};
     std::vector<double> x_reference, x_model_ref;
     stream_t stream;
+    // SMPC_STREAMS=2: the iterations of the two halves of the batch run on two streams, so that workgroups of the matrix-core bound
+    // Riccati sweep of one half share the CUs with the VALU bound stage kernels of the other
+    static constexpr int MAX_STREAMS = 4;
+    stream_t streams[MAX_STREAMS] = {};  // streams[0] == stream
+    stream_t cur{};      // stream of the launches being issued
+    int n_streams = 1;
+    int * und_lists[MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr}; // und_lists[0] == buf.und_list
+    event_t ev_fork{}, ev_join[MAX_STREAMS] = {};
     double * X_dev = nullptr;
     double * stage_out = nullptr; // staging for linearised outputs
     size_t stage_out_bytes = 0;
@@ -352,6 +360,19 @@ namespace smpc
       device_id = device;
       set_device(device);
       stream = stream_create();
+      cur = stream;
+      streams[0] = stream;
+      if (std::getenv("SMPC_STREAMS"))
+        n_streams = std::min(std::max(std::atoi(std::getenv("SMPC_STREAMS")), 1), (int)MAX_STREAMS);
+      if (n_streams > 1)
+      {
+        ev_fork = event_create();
+        for (int i = 1; i < n_streams; i++)
+        {
+          streams[i] = stream_create();
+          ev_join[i] = event_create();
+        }
+      }
       B = batch;
       H = ms.T;
       R = H + 1;
@@ -434,6 +455,9 @@ namespace smpc
       buf.xdot01 = dalloc((size_t)B * 4 * D::NV);
       buf.ls_sel = (int *)dev_alloc((size_t)B * sizeof(int));
       buf.und_list = (int *)dev_alloc((size_t)(B + 1) * sizeof(int));
+      und_lists[0] = buf.und_list;
+      for (int i = 1; i < n_streams; i++)
+        und_lists[i] = (int *)dev_alloc((size_t)(B + 1) * sizeof(int));
       buf.stages = (StageShared<D> *)dev_alloc((size_t)H * sizeof(StageShared<D>));
       buf.model = (DevModel<D> *)dev_alloc(sizeof(DevModel<D>));
       X_dev = dalloc((size_t)B * D::NX);
@@ -507,6 +531,14 @@ namespace smpc
         dev_free(p);
       dev_free(buf.ls_sel);
       dev_free(buf.und_list);
+      for (int i = 1; i < n_streams; i++)
+      {
+        dev_free(und_lists[i]);
+        stream_destroy(streams[i]);
+        event_destroy(ev_join[i]);
+      }
+      if (n_streams > 1)
+        event_destroy(ev_fork);
       dev_free(buf.stages);
       dev_free(buf.model);
       stream_destroy(stream);
@@ -541,15 +573,15 @@ namespace smpc
       {
         e0 = event_create();
         e1 = event_create();
-        event_record(e0, stream);
+        event_record(e0, cur);
       }
       if (aux)
-        launch<Args, Body, NT, MINW, 1>(grid, stream, a);
+        launch<Args, Body, NT, MINW, 1>(grid, cur, a);
       else
-        launch<Args, Body, NT, MINW, 0>(grid, stream, a);
+        launch<Args, Body, NT, MINW, 0>(grid, cur, a);
       if (profiling)
       {
-        event_record(e1, stream);
+        event_record(e1, cur);
         pending_events.push_back({kid, {e0, e1}});
       }
       kernel_calls[kid]++;
@@ -680,12 +712,19 @@ namespace smpc
       launch_deriv(b);
       timed_launch<SolverArgs<D>, merit0_body<D>, 64>(KID_SELECT, nb, solver_args(b));
       for (int it = 0; it < k; it++)
+        speculative_step(b, it == k - 1);
+    }
+    // one iteration of the speculative scheme: sweeps, then either the explicit line search (last iteration) or the tentative
+    // full step + next derivative pass + repair of the instances that rejected it
+    void speculative_step(const Buffers<D> & b, bool last)
+    {
+      const int nb = (b.B + 63) / 64;
       {
         launch_sweeps(b);
-        if (it == k - 1)
+        if (last)
         {
           launch_line_search(b);
-          break;
+          return;
         }
         SolverArgs<D> sa = solver_args(b);
         sa.mode = 1;
@@ -716,14 +755,14 @@ namespace smpc
     }
     void copy_centres(const Buffers<D> & b)
     {
-      d2d(b.vs_e, b.vs, (size_t)b.B * R * D::NC * sizeof(double), stream);
-      d2d(b.lams_e, b.lams, (size_t)b.B * R * D::NDX * sizeof(double), stream);
+      d2d(b.vs_e, b.vs, (size_t)b.B * R * D::NC * sizeof(double), cur);
+      d2d(b.lams_e, b.lams, (size_t)b.B * R * D::NDX * sizeof(double), cur);
       if (b.CN != nullptr)
-        d2d(b.vN_e, b.vN, (size_t)b.B * 3 * sizeof(double), stream);
+        d2d(b.vN_e, b.vN, (size_t)b.B * 3 * sizeof(double), cur);
       if (b.es != nullptr)
-        d2d(b.es_e, b.es, (size_t)b.B * R * 2 * D::NF * sizeof(double), stream);
+        d2d(b.es_e, b.es, (size_t)b.B * R * 2 * D::NF * sizeof(double), cur);
       if (b.ls != nullptr)
-        d2d(b.ls_e, b.ls, (size_t)b.B * R * D::NF * sizeof(double), stream);
+        d2d(b.ls_e, b.ls, (size_t)b.B * R * D::NF * sizeof(double), cur);
     }
 
     void upload_stages()
@@ -945,8 +984,76 @@ namespace smpc
       ra.shift = 1;
       ra.reg_init = REG_INIT;
       timed_launch<RecedeArgs<D>, recede_body<D>, 64>(KID_RECEDE, B, ra);
+      if (n_streams > 1 && B >= 64 * n_streams && !has_ext(buf))
+      {
+        // the parts of the batch run their iterations on separate streams: the tail of one part's launch is filled by the next
+        // launch of another part (every launch alone is a whole number of rounds of resident waves plus a partial one)
+        Buffers<D> part[MAX_STREAMS];
+        event_record(ev_fork, stream);
+        for (int i = 0; i < n_streams; i++)
+        {
+          const int i0 = (int)((long long)B * i / n_streams), i1 = (int)((long long)B * (i + 1) / n_streams);
+          part[i] = slice(buf, i0, i1 - i0, und_lists[i]);
+          cur = streams[i];
+          if (i > 0)
+            stream_wait_event(streams[i], ev_fork);
+          copy_centres(part[i]);
+        }
+        run_iterations_parts(part, ms.max_iters);
+        for (int i = 1; i < n_streams; i++)
+        {
+          event_record(ev_join[i], streams[i]);
+          stream_wait_event(stream, ev_join[i]);
+        }
+        cur = stream;
+        return;
+      }
       copy_centres(buf);
       run_iterations(buf, ms.max_iters);
+    }
+    // instances i0 .. i0 + n of every per-instance array
+    Buffers<D> slice(const Buffers<D> & b, int i0, int n, int * und) const
+    {
+      Buffers<D> s = b;
+      s.B = n;
+      const size_t o = (size_t)i0, BRs = (size_t)R, Hs = (size_t)H;
+      auto adv = [&](double *& p, size_t per) {
+        if (p)
+          p += o * per;
+      };
+      adv(s.xs, BRs * D::NX); adv(s.us, BRs * D::NU); adv(s.vs, BRs * D::NC); adv(s.lams, BRs * D::NDX);
+      adv(s.vs_e, BRs * D::NC); adv(s.lams_e, BRs * D::NDX);
+      adv(s.xs_b, BRs * D::NX); adv(s.us_b, BRs * D::NU); adv(s.vs_b, BRs * D::NC); adv(s.lams_b, BRs * D::NDX);
+      adv(s.dxs, (Hs + 1) * D::NDX); adv(s.dus, Hs * D::NU); adv(s.dvs, Hs * D::NC); adv(s.dlams, Hs * D::NDX);
+      adv(s.foot_ref, Hs * D::NF * 3); adv(s.ftraj, (size_t)D::NF * 6); adv(s.vbase, 6); adv(s.vref, BRs * 6);
+      adv(s.lq, Hs * D::LQ_STRIDE); adv(s.gains, Hs * (size_t)std::max((int)D::G_STRIDE, (int)GainsK<D>::STRIDE));
+      adv(s.QN, (size_t)D::NDX * D::NDX); adv(s.qN, D::NDX);
+      adv(s.parts0, (Hs + 1) * 4); adv(s.partsT, (size_t)D::LS_N * (Hs + 1) * 2); adv(s.scal, SC_N);
+      adv(s.xdotT, (size_t)D::LS_N * 4 * D::NV); adv(s.xdot01, (size_t)4 * D::NV);
+      s.ls_sel = b.ls_sel + i0;
+      s.und_list = und;
+      return s;
+    }
+    // run_iterations of the parts of the batch, their launches issued alternately so that every queue stays filled
+    void run_iterations_parts(const Buffers<D> * part, int k)
+    {
+      auto on = [&](int i) -> const Buffers<D> & { cur = streams[i]; return part[i]; };
+      if (!speculative_ls || k <= 1)
+      {
+        for (int it = 0; it < k; it++)
+          for (int i = 0; i < n_streams; i++)
+            run_iteration(on(i));
+        return;
+      }
+      for (int i = 0; i < n_streams; i++)
+      {
+        const Buffers<D> & b = on(i);
+        launch_deriv(b);
+        timed_launch<SolverArgs<D>, merit0_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b));
+      }
+      for (int it = 0; it < k; it++)
+        for (int i = 0; i < n_streams; i++)
+          speculative_step(on(i), it == k - 1);
     }
     // ---- per-stage references of the horizon: the OCPHandler setters / getters (reference src/kinodynamics.cpp:154-306,
     //      src/ocp-handler.cpp:58-81), broadcast over the batch.  The next iterate() overwrites the foot references of

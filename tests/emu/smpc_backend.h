@@ -87,6 +87,7 @@ namespace smpc
   inline event_t event_create() { return event_t{0}; }
   inline void event_destroy(event_t) {}
   inline void event_record(event_t, stream_t) {}
+  inline void stream_wait_event(stream_t, event_t) {}
   inline float event_elapsed_ms(event_t, event_t) { return 0.f; }
 
   template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1, int TAG = 0>

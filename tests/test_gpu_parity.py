@@ -233,3 +233,30 @@ def test_per_gpu_size_of_the_sharded_configuration(built):
     assert np.abs(xs - xs[0:1]).max() == 0.0
     assert S.rel_err(om.xs, xs[0]) < TOL
     assert np.all(np.isfinite(gm.info))
+
+
+def test_multi_stream_iterations_are_bit_identical(built, tmp_path):
+    """SMPC_STREAMS=n runs the iterations of n parts of the batch on n streams: every instance's arithmetic is unchanged, so
+    the trajectories must be those of the single-stream run, bit for bit -- including an instance that backtracks."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, mpc_setup as S, oracle_lib as O\n"
+        "gm, rb, _, _ = S.make_product(300, max_iters=3)\n"
+        "gm.generateCycleHorizon(O.trot_cycle()); gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.1]))\n"
+        "X = S.random_states(rb, 300, scale=2.0)\n"
+        "for _ in range(4):\n"
+        "    gm.iterate(X); X = gm.xs[:, 1, :].copy()\n"
+        "np.savez(sys.argv[1], xs=gm.xs, us=gm.us, info=gm.info)\n" % (root, os.path.join(root, "tests"))
+    )
+    outs = []
+    for n in ("1", "3"):
+        out = str(tmp_path / ("s%s.npz" % n))
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, SMPC_STREAMS=n), timeout=900)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]["xs"], outs[1]["xs"]) and np.array_equal(outs[0]["us"], outs[1]["us"])
+    assert np.array_equal(outs[0]["info"][:, 2], outs[1]["info"][:, 2]) and outs[0]["info"][:, 2].min() < 1.0
