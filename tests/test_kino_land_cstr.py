@@ -154,3 +154,28 @@ def test_hip_all_optional_constraints_together(built):
     om, gm, rb = S.make_pair(2, max_iters=1, settings_override=ALL, mpc_override={"terminal_constraint": True}, walk=WALK)
     cone, land = _loop_all(om, gm, S.random_states(rb, 2), 44, 1e-4)
     assert cone >= 10 and land >= 4
+
+
+@pytest.mark.gpu
+def test_hip_full_size_with_all_optional_constraints(built):
+    """B = 4096 (BASELINE's batch) with cones + land rows + terminal constraint: 16 distinct states replicated 256 times must give
+    bit-identical replicas (the EXT instantiations at full occupancy), follow the oracle on the distinct ones, and stay finite."""
+    B, nd = 4096, 16
+    so, mo = ALL, {"terminal_constraint": True}
+    gm, rb, _, _ = S.make_product(B, 1, None, 50, settings_override=so, mpc_override=mo)
+    om, _, _ = S.make_oracle(nd, 1, 50, settings_override=so, mpc_override=mo)
+    for m in (gm, om):
+        m.generateCycleHorizon(O.trot_cycle())
+        m.switchToWalk(np.array(WALK, float))
+    Xo = S.random_states(rb, nd, seed=5)
+    X = np.tile(Xo, (B // nd, 1))
+    for _ in range(3):
+        gm.iterate(X)
+        om.iterate(Xo)
+        xs = gm.xs
+        X = xs[:, 1, :].copy()
+        Xo = om.xs[:, 1, :].copy()
+    xs = xs.reshape(B // nd, nd, *xs.shape[1:])
+    assert np.abs(xs - xs[0:1]).max() == 0.0
+    assert S.rel_err(om.xs, xs[0]) < 1e-6
+    assert np.all(np.isfinite(gm.info))
