@@ -958,18 +958,26 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       // ---- du = K dx + k ; dnu = (C dx + d)/mu ----
-      SMPC_PLA(double, ce, NT, 5); // friction-cone row of lanes NDX .. NDX + 2 NF: Jacobian row (3) | d | vpd, in flight until phase 3
+      // friction-cone row of lanes NDX .. NDX + 2 NF: Jacobian row (3) | d | vpd | the foot's other row (3) | activity of both rows
+      SMPC_PLA(double, ce, NT, 10);
+      SMPC_PL(double, gpart, NT); // lanes 48 .. 48 + 3 NF: stationarity residual of force component k without the B^T dlam term
+      SMPC_PL(double, dlr, NT);   // lanes < NDX: dlam of this stage
       SMPC_LANES(NT)
       {
         if ((EXT && b.es != nullptr) && lane >= NDX && lane < NDX + 2 * NF)
         {
           const double * ekp = b.ek + lt * 12 * NF;
-          const int i = lane - NDX;
+          const int i = lane - NDX, ip = i ^ 1;
           SMPC_PLV(ce)[0] = ekp[i * 3];
           SMPC_PLV(ce)[1] = ekp[i * 3 + 1];
           SMPC_PLV(ce)[2] = ekp[i * 3 + 2];
           SMPC_PLV(ce)[3] = ekp[6 * NF + i];
           SMPC_PLV(ce)[4] = ekp[8 * NF + i];
+          SMPC_PLV(ce)[5] = ekp[ip * 3];
+          SMPC_PLV(ce)[6] = ekp[ip * 3 + 1];
+          SMPC_PLV(ce)[7] = ekp[ip * 3 + 2];
+          SMPC_PLV(ce)[8] = ekp[10 * NF + i];
+          SMPC_PLV(ce)[9] = ekp[10 * NF + ip];
         }
         if (lane < NU)
         {
@@ -1051,14 +1059,23 @@ namespace smpc
         s.part[lane] += (vlx[lane] - s.lpd_prev[lane]) * s.dx[lane] + vlpd[lane] * acc;
         s.y[lane] = acc + vf[lane] - mu * pn[lane];
       }
-      else if ((EXT && b.es != nullptr) && lane < NDX + 2 * NF)
-      { // friction-cone rows: dnu = (D du + d) / mu
-        const int i = lane - NDX, f = i / 2;
-        const double dd = SMPC_PLV(ce)[3];
-        const double acc = dd + SMPC_PLV(ce)[0] * s.du[3 * f] + SMPC_PLV(ce)[1] * s.du[3 * f + 1] + SMPC_PLV(ce)[2] * s.du[3 * f + 2];
-        const double dnu = acc / mu;
-        b.des[lt * 2 * NF + i] = dnu;
-        s.part[lane] += SMPC_PLV(ce)[4] * (mu * dnu - dd) - dd * dnu;
+      else if ((EXT && b.es != nullptr) && lane >= 48 && lane < 48 + 3 * NF)
+      {
+        // Multiplier steps of the (eliminated) friction-cone rows.  dnu = (D du + d) / mu would divide the difference of two O(1)
+        // numbers by mu: every digit du lost to the 1 / mu entries of R^ costs |delta du| / mu in dnu.  The stationarity row of the
+        // foot's force components holds the same dnu among O(1) terms:  D^T dnu = -(R du + S^T dx + r + B^T dlam)  (knot R, S, r:
+        // unfolded).  Here: everything but B^T dlam for force component k.
+        const int k = lane - 48;
+        const double * lq = b.lq + lt * D::LQ_STRIDE;
+        double acc = lq[D::O_r + k];
+        const double * Rk = lq + D::O_R + k * NU;
+#pragma unroll 4
+        for (int j = 0; j < NU; j++)
+          acc += Rk[j] * s.du[j];
+#pragma unroll 4
+        for (int i = 0; i < NDX; i++)
+          acc += lq[D::O_S + i * NU + k] * s.dx[i];
+        SMPC_PLV(gpart) = acc;
       }
       SMPC_LANES_END_WAVE
       // ---- w = P~ y (P~ symmetric, upper triangle packed) ; dx+ = y - mu w ; dlam+ = w + p_{t+1} ----
@@ -1079,8 +1096,52 @@ namespace smpc
         s.part[lane] -= vf[lane] * dl;
         s.lpd_prev[lane] = vlpd[lane];
         s.dx[lane] = dxn;
+        SMPC_PLV(dlr) = dl;
       }
       SMPC_LANES_END_WAVE
+      if (EXT && b.es != nullptr)
+      {
+        SMPC_LANES(NT)
+        if (lane < NDX)
+          s.y[lane] = SMPC_PLV(dlr); // (y is dead: it becomes dlam)
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        if (lane >= 48 && lane < 48 + 3 * NF)
+        {
+          const int k = lane - 48;
+          double acc = SMPC_PLV(gpart);
+#pragma unroll
+          for (int m = 0; m < 12; m++)
+            acc += s.st[(m < 6 ? FL::O_B0 + m * NU : FL::O_B1 + (m - 6) * NU) + k] * s.y[IX::G(m)];
+          s.du[k] = -acc; // (du is dead until the next stage: it takes D^T dnu of the force components)
+        }
+        SMPC_LANES_END_WAVE
+        SMPC_LANES(NT)
+        if (lane >= NDX && lane < NDX + 2 * NF)
+        {
+          const int i = lane - NDX, f = i / 2;
+          const double dd = SMPC_PLV(ce)[3];
+          const double g0 = s.du[3 * f], g1 = s.du[3 * f + 1], g2 = s.du[3 * f + 2];
+          const double a0 = SMPC_PLV(ce)[0], a1 = SMPC_PLV(ce)[1], a2 = SMPC_PLV(ce)[2];
+          const double p0 = SMPC_PLV(ce)[5], p1 = SMPC_PLV(ce)[6], p2 = SMPC_PLV(ce)[7];
+          double dnu = dd / mu; // inactive row: D = 0
+          if (SMPC_PLV(ce)[8] != 0.0)
+          {
+            const double aa = a0 * a0 + a1 * a1 + a2 * a2, ag = a0 * g0 + a1 * g1 + a2 * g2;
+            dnu = ag / aa;
+            if (SMPC_PLV(ce)[9] != 0.0)
+            { // both rows of the foot active: 2 x 2 normal equations (parallel rows: the single-row value stands)
+              const double pp = p0 * p0 + p1 * p1 + p2 * p2, ap = a0 * p0 + a1 * p1 + a2 * p2, pg = p0 * g0 + p1 * g1 + p2 * g2;
+              const double det = aa * pp - ap * ap;
+              if (det > 1e-12 * aa * pp)
+                dnu = (pp * ag - ap * pg) / det;
+            }
+          }
+          b.des[lt * 2 * NF + i] = dnu;
+          s.part[lane] += SMPC_PLV(ce)[4] * (mu * dnu - dd) - dd * dnu;
+        }
+        SMPC_LANES_END_WAVE
+      }
     }
     SMPC_LANES(NT)
     if (lane < NDX)
