@@ -59,6 +59,8 @@
 #define SMPC_ACCV(name, t, v) name[t][v]
 #define SMPC_MFMA(acc, t, av, ia, bv, ib) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ia], bv[ib], acc[t], 0, 0, 0)
 #define SMPC_CLOCK() ((long long)__builtin_readcyclecounter())
+// a value that is the same in every lane, moved to a scalar register (branches on it are scalar branches)
+#define SMPC_UNIFORM_U32(x) ((unsigned)__builtin_amdgcn_readfirstlane((int)(x)))
 // an int the compiler cannot see through: loads addressed with it stay after this point (the optimiser otherwise
 // hoists loads of read-only buffers across whole phases and then spills what it loaded)
 #define SMPC_PIN(x) ::smpc::pin_int(x)

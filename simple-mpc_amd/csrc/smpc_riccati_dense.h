@@ -55,6 +55,7 @@ namespace smpc
     //  of the products that consume them -- 36 KB of LDS per wave are worth more as resident waves)
     double p[NDX], pt0[NDX], pt[NDX], f[NDX];
     double boxa[D::NU + D::NA], boxd[D::NU + D::NA + GM::NCD]; // activity of the box rows ; d = mu (nu+ - nu) of all rows
+    double cact[GM::NCP > 0 ? GM::NCP : 1];                    // activity of the dense rows (padded to whole panels)
   };
 
   template <class D>
@@ -80,26 +81,16 @@ namespace smpc
         s.p[i] = b.qN[(size_t)inst * NDX + i];
     }
     SMPC_LANES_END_WAVE
-    double * prof = nullptr;
-    long long tprev = 0;
+    double * prof = (b.dbg != nullptr && block == 0) ? b.dbg : nullptr; // optional phase timers (block 0 only): slots 40 .. 46
+    long long tprev = prof ? SMPC_CLOCK() : 0;
     for (int t = H - 1; t >= 0; t--)
     {
       const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
       double * g = b.gains + ((size_t)inst * H + t) * D::G_STRIDE;
       // pivot panels of the second sweep that hold inactive dense rows only: such a row is [0 ... -mu ... d] and couples to
-      // nothing, so its panel is left out of the sweep and z = d / mu is written directly (the loads are wave-uniform)
+      // nothing, so its panel is left out of the sweep and z = d / mu is written directly.  (The flags are fetched by the lanes of
+      // phase (1) with their other loads; the mask is formed from LDS afterwards.)
       unsigned skip = 0u;
-      if constexpr (NCD > 0)
-      {
-        for (int q = 0; q < GM::NCP / 4; q++)
-        {
-          double any = 0.0;
-          for (int r = 4 * q; r < 4 * q + 4 && r < NCD; r++)
-            any += lq[D::O_act + NU + NA + r];
-          if (any == 0.0)
-            skip |= 1u << (GM::NUP / 4 + q);
-        }
-      }
       // ---- (1) f ; box rows ; save p_{t+1} ; pt0 = p + P f ----
       SMPC_LANES(NT)
       {
@@ -112,18 +103,36 @@ namespace smpc
           s.boxa[i] = lq[D::O_act + i];
         for (int i = lane; i < NU + NA + NCD; i += NT)
           s.boxd[i] = lq[D::O_d + i];
+        if constexpr (NCD > 0)
+          for (int i = lane; i < GM::NCP; i += NT)
+            s.cact[i] = i < NCD ? lq[D::O_act + NU + NA + i] : 0.0;
       }
       SMPC_LANES_END_WAVE
+      if constexpr (NCD > 0)
+      {
+        unsigned m = 0u;
+        SMPC_LANES(NT)
+        {
+          unsigned mm = 0u;
+          for (int q = 0; q < GM::NCP / 4; q++)
+            if (s.cact[4 * q] + s.cact[4 * q + 1] + s.cact[4 * q + 2] + s.cact[4 * q + 3] == 0.0)
+              mm |= 1u << (GM::NUP / 4 + q);
+          m = SMPC_UNIFORM_U32(mm); // (every lane computes the same value)
+        }
+        SMPC_LANES_END_WAVE
+        skip = m;
+      }
       SMPC_LANES(NT)
       for (int i = lane; i < NDX; i += NT)
       {
         double acc = s.p[i];
 #pragma unroll 4
         for (int j = 0; j < NDX; j++)
-          acc += s.P[i * NDX + j] * s.f[j];
+          acc += s.P[j * NDX + i] * s.f[j];
         s.pt0[i] = acc;
       }
       SMPC_LANES_END_WAVE
+      prof_tick(prof, 40, tprev);
       // ---- (2) P~ and p~: Schur complement of the bordered matrix (pivots: the first NDX rows) ----
       {
         SMPC_ACC(t1, NT, NT1 * (NT1 + 1) / 2);
@@ -177,6 +186,7 @@ namespace smpc
         }
         SMPC_LANES_END_WAVE
       }
+      prof_tick(prof, 41, tprev);
       // ---- (3) [A | B] into LDS ; P~ out (forward sweep) ; prefetch of [Q S q; S^T R r] in accumulator layout ----
       SMPC_ACC(hacc, NT, NT2 * (NT2 + 1) / 2);
       SMPC_LANES(NT)
@@ -207,6 +217,7 @@ namespace smpc
           g[D::G_Pt + idx] = s.P[idx];
       }
       SMPC_LANES_END_WAVE
+      prof_tick(prof, 42, tprev);
       // ---- (4) T = P~ [A | B] with p~ as column VC ; H^ += [A | B]^T T ----
       {
         constexpr int NTT = NTJ + 1; // tile columns of T: [A | B] columns + the tile of the vector column
@@ -300,6 +311,7 @@ namespace smpc
                   SMPC_MFMA(hacc, tix<NT2>(I, J), abv, I, tbv, J < NTJ ? J : NTJ);
           }
       }
+      prof_tick(prof, 43, tprev);
       // ---- (5) box rows ; padding pivots ; entries outside the problem ----
       SMPC_LANES(NT)
       {
@@ -333,8 +345,10 @@ namespace smpc
             }
       }
       SMPC_LANES_END_WAVE
+      prof_tick(prof, 44, tprev);
       // ---- (6) sweep the control pivots in place:  x-x block -> P_t,  x-vector -> p_t,  (x, u) entries -> -K,  (u, vector) -> -k ----
       wave_block_sweep<NT, NT2, true, NDX, (NUP + NCP) / 4, (NCD > 0)>(hacc, sw, sw + LDS::SWP, prof, tprev, skip);
+      prof_tick(prof, 45, tprev);
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
@@ -371,6 +385,7 @@ namespace smpc
             }
       }
       SMPC_LANES_END_WAVE
+      prof_tick(prof, 46, tprev);
     }
   }
 } // namespace smpc

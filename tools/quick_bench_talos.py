@@ -24,3 +24,7 @@ if os.environ.get('SMPC_PHASE_PROFILE'):
     names = ['load','kin','composite','M/J','cholM/W','G/Gi','prox/a','eval-tail','forces','dk/Ak/Jc','R1','R2','solves','WJ','tables/grad','AB','QSR']
     nd = (steps+1)*iters
     print('deriv phase cycles (inst 0, stage 17):', ' '.join('%s %.0f' % (nm, out[i]/nd) for i,nm in enumerate(names)), '| total %.0f' % (out[:17].sum()/nd))
+    rn = ['pt0', 'sweep1', 'Pt-out/prefetch', 'products', 'box/pad', 'sweep2', 'readout']
+    nr = (steps + 1) * iters * gm.H
+    print('riccati phase cycles per stage (inst 0):', ' '.join('%s %.0f' % (nm, out[40 + i] / nr) for i, nm in enumerate(rn)), '| total %.0f' % (out[40:47].sum() / nr),
+          '| sweep parts: gather %.0f invert+U %.0f operands+mfma %.0f fixup %.0f' % tuple(out[36:40] / nr))
