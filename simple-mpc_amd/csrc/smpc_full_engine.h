@@ -80,6 +80,10 @@ namespace smpc
     bool aux_launches = false;
     std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
     static constexpr int LS_SLOTS = 64;
+#ifndef SMPC_FDYN_DERIV_MINW
+#define SMPC_FDYN_DERIV_MINW 1
+#endif
+    static constexpr int DERIV_MINW = D::NV <= 20 ? SMPC_FDYN_DERIV_MINW : 1; // (register-cap experiment: -DSMPC_FDYN_DERIV_MINW=2)
     static constexpr int TRIAL_MINW = D::NV <= 20 ? 2 : 1; // waves per SIMD the evaluation kernel's register budget is capped for
     static constexpr double ARMIJO_C1 = 1e-4, REG_INIT = 1e-9, REG_MIN = 1e-10, REG_MAX = 1e9, REG_INC = 10.0, REG_DEC = 1.0 / 3.0, STALL_REL = 1e-9;
     double ref_foot_pos[D::NF][3];
@@ -298,7 +302,7 @@ namespace smpc
     }
     void launch_deriv(const Buffers<D> & b, int slots = 0)
     {
-      timed_launch<StageKernelArgs<D>, fdyn_deriv_body<D>, 64>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
+      timed_launch<StageKernelArgs<D>, fdyn_deriv_body<D>, 64, DERIV_MINW>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
     }
     void launch_sweeps(const Buffers<D> & b)
     {
