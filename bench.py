@@ -331,14 +331,28 @@ def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True, rob
                                 "closed loop x_meas = xs[1] + N(0,1e-3^2)") % (H, iters, batch), "finite": bool(np.all(np.isfinite(gm.info)))},
         "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if k != "-"},
     }
-    if kt.get("riccati", (0, 0))[1]:
-        avg = kt["riccati"][0] / kt["riccati"][1] * 1e-3
+    if kt.get("riccati", (0, 0))[1] and kt.get("deriv", (0, 0))[1]:
+        tag = "talos" if talos else "go2"
+        at_record = batch == (1024 if talos else 4096) and iters == 3  # the configuration the committed PMC summary was taken on
         ncd = nc - 2 * nu  # dense (wrench-cone) rows
-        lq_bytes = 8 * (2 * ndx * ndx + 2 * ndx * nu + nu * nu + ncd * (ndx + nu) + 2 * ndx + nu + 2 * nc)  # dense knot read (box rows are selectors)
-        rl = both_bounds(batch * H * f_ric(ndx, nu, nc), batch * H * lq_bytes, avg, "mfma")
-        rl.update({"kernel": "riccati_dense_body (proximal Riccati backward sweep, dense A / B)",
-                   "note": "algorithmic FLOPs = B*H*F_ric(%d,%d,%d) per launch (SURVEY 8d)" % (ndx, nu, nc), "traffic": None})
-        out["roofline"] = rl
+        lq_bytes = 8 * (2 * ndx * ndx + 2 * ndx * nu + nu * nu + ncd * (ndx + nu) + 2 * ndx + nu + 2 * nc)  # dense knot (box rows are selectors)
+        avg = kt["riccati"][0] / kt["riccati"][1] * 1e-3
+        ric = both_bounds(batch * H * f_ric(ndx, nu, nc), batch * H * lq_bytes, avg, "mfma")
+        tr, src = pmc_traffic("riccati_dense_body_" + tag, at_record)
+        ric.update({"kernel": "riccati_dense_body (proximal Riccati backward sweep, dense A / B)",
+                    "note": "algorithmic FLOPs = B*H*F_ric(%d,%d,%d) per launch (SURVEY 8d)" % (ndx, nu, nc), "traffic": tr, "traffic_source": src})
+        # the stage kernel (evaluation + derivatives of the constrained dynamics + Gauss-Newton assembly): FP64 side = the FLOPs the
+        # instrumented oracle counts per stage (profiles/flop_counts.json), HBM side = the knot it writes
+        fl = flop_counts().get("fulldynamics_" + tag, {}).get("deriv_flops_per_stage")
+        avgd = kt["deriv"][0] / kt["deriv"][1] * 1e-3
+        der = both_bounds(None if fl is None else batch * (H + 1) * fl, batch * H * lq_bytes, avgd, "mfma" if fl is not None else "hbm")
+        tr, src = pmc_traffic("fdyn_deriv_body_" + tag, at_record)
+        der.update({"kernel": "fdyn_deriv_body (constrained dynamics, derivatives, Gauss-Newton knot)",
+                    "note": "FP64 bound: algorithmic FLOPs per stage counted by instrumentation in the oracle (profiles/flop_counts.json)",
+                    "traffic": tr, "traffic_source": src})
+        dom_deriv = kt["deriv"][0] >= kt["riccati"][0]  # the dominant kernel carries the line's roofline
+        out["roofline"] = der if dom_deriv else ric
+        out["roofline_other"] = {"riccati": ric} if dom_deriv else {"deriv": der}
     if with_cpu:
         S, O = _oracle_imports()
         threads = O.use_effective_cpus()  # hardware threads capped by the cgroup CPU quota
