@@ -82,6 +82,41 @@ class RobotModelHandler:
     def getMass(self):
         return float(self._m.total_mass)
 
+    # reference src/robot-handler.cpp:81-95
+    def difference(self, x1, x2):
+        from . import _hostmath as hm
+
+        return hm.difference(self.nq, self.nv, x1, x2)
+
+    def getBaseFrameName(self):
+        return self._base
+
+    # frame ids: the table has no frame list; the ids are stable integers with the meaning the reference gives them (0 = base frame,
+    # 1 + 2 i / 2 + 2 i = foot i / its reference frame), good for comparisons and dictionary keys
+    def getBaseFrameId(self):
+        return 0
+
+    def getFootFrameId(self, i):
+        return 1 + 2 * int(i)
+
+    def getFootRefFrameId(self, i):
+        return 2 + 2 * int(i)
+
+    def getFeetFrameIds(self):
+        return [self.getFootFrameId(i) for i in range(len(self._feet))]
+
+    def setFootReferencePlacement(self, foot_nb, parentframeMfootref):
+        """reference src/robot-handler.cpp:76-79: the placement of the foot's reference frame in the base frame (the Raibert heuristic of
+        MPC::updateStepTrackerReferences starts from it).  Takes an SE3-like object (.translation) or 3 numbers; the handler then owns a
+        private copy of the robot table."""
+        if not getattr(self, "_owned", None):
+            self._owned = _capi.RobotModelC.from_buffer_copy(self._m)
+            self._m = self._owned
+            self._ptr = C.pointer(self._owned)
+        t = np.asarray(getattr(parentframeMfootref, "translation", parentframeMfootref), float).reshape(3)
+        for k in range(3):
+            self._m.foot_ref_p[int(foot_nb)][k] = float(t[k])
+
     def getReferenceState(self):
         return np.concatenate([np.array(self._m.q_ref[: self._m.nq]), np.zeros(self._m.nv)])
 
@@ -107,11 +142,55 @@ class RobotModelHandler:
 
 
 class RobotDataHandler:
-    """Placeholder with the reference's name; the batched FK runs on the device inside iterate
-    (reference src/robot-handler.cpp:106-149)."""
+    """Host-side data of ONE state (reference include/simple-mpc/robot-handler.hpp:152-225, src/robot-handler.cpp:97-149): frame
+    placements, centre of mass, centroidal momentum, computed with NumPy from the robot table.  The batch's counterpart runs on the device
+    (BatchedMPC.updateInternalData / inside iterate); this class serves the scripts written for the reference, which read foot poses and
+    the centroidal state of the measured state between control steps."""
 
     def __init__(self, model_handler):
         self.model_handler = model_handler
+        self.updateInternalData(model_handler.getReferenceState(), True)
+
+    def updateInternalData(self, x, updateJacobians=False):
+        from . import _hostmath as hm
+
+        self._x = np.array(x, float).copy()
+        self._k = hm.kinematics(self.model_handler._m, self._x)
+
+    def updateJacobiansMassMatrix(self, x):
+        raise RuntimeError("joint Jacobians / mass matrix are not kept on the host; the kernels form them per stage on the device")
+
+    def getData(self):
+        raise RuntimeError("there is no pinocchio.Data behind this handler; use getFootPose / getBaseFramePose / getCentroidalState")
+
+    def getModelHandler(self):
+        return self.model_handler
+
+    def getState(self):
+        return self._x.copy()
+
+    def getBaseFramePose(self):
+        from . import _hostmath as hm
+
+        return hm.SE3(self._k["R"][0], self._k["p"][0])
+
+    def getFootPose(self, i):
+        from . import _hostmath as hm
+
+        m = self.model_handler._m
+        f = self.model_handler._table_foot(self.model_handler.getFootFrameName(i))
+        j = m.foot_joint[f]
+        return hm.SE3(self._k["R"][j], self._k["p"][j] + self._k["R"][j] @ np.array(m.foot_p[f]))
+
+    def getFootRefPose(self, i):
+        from . import _hostmath as hm
+
+        m = self.model_handler._m
+        f = self.model_handler._table_foot(self.model_handler.getFootFrameName(i))
+        return hm.SE3(self._k["R"][0], self._k["p"][0] + self._k["R"][0] @ np.array(m.foot_ref_p[f]))
+
+    def getCentroidalState(self):
+        return np.concatenate([self._k["com"], self._k["hg"]])
 
 
 
@@ -638,6 +717,7 @@ class BatchedMPC:
         if X.shape != (self.B, self.nx_in):
             raise RuntimeError("X must have shape (batch, nq+nv)")
         self._lib.check(self._lib.L.smpc_iterate(self._h, X))
+        self._last_X = X  # (getDataHandler)
 
     def iterate_device(self, device_ptr):
         self._lib.check(self._lib.L.smpc_iterate_device(self._h, C.c_void_p(int(device_ptr))))
@@ -833,6 +913,15 @@ class BatchedMPC:
     def getModelHandler(self):
         return self.ocp_handler.model_handler
 
+    def getDataHandler(self, instance=0):
+        """MPC::getDataHandler (reference include/simple-mpc/mpc.hpp:131-134): host-side data of the measured state the last iterate(X)
+        received for `instance` (the reference state before the first control step)."""
+        dh = RobotDataHandler(self.ocp_handler.model_handler)
+        X = getattr(self, "_last_X", None)
+        if X is not None:
+            dh.updateInternalData(X[instance], False)
+        return dh
+
     # ---- debug / profiling ----
     def debug_lq(self, inst, t):
         n = self._lib.L.smpc_lq_size(self._h)
@@ -960,6 +1049,15 @@ class FrictionCompensation:
         self.nu_ = int(self.dry_friction_.size)
         self._lib = lib or default_lib()
         self._dev = device_id
+
+    # the reference's read-only properties (bindings/expose-friction-compensation.cpp:33-34)
+    @property
+    def dry_friction(self):
+        return self.dry_friction_.copy()
+
+    @property
+    def viscuous_friction(self):
+        return self.viscuous_friction_.copy()
 
     def computeFriction(self, velocity, torque):
         v = np.ascontiguousarray(np.array(velocity, dtype=np.float64))
