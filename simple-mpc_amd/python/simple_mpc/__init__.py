@@ -335,6 +335,25 @@ class KinodynamicsOCP(_StageReferences):
             raise RuntimeError("Create problem first!")
         return self._problem["horizon"]
 
+    # reference src/kinodynamics.cpp:308-311, src/fulldynamics.cpp:365-368
+    def getProblemState(self, data_handler):
+        return data_handler.getState()
+
+    # reference src/kinodynamics.cpp:366-388: createProblem(..., terminal_constraint = True) calls createTerminalConstraint(x0.head<3>());
+    # called by hand it adds the same DCM constraint.  Its reference is the base position of x0 until the first control step, after which
+    # MPC::updateStepTrackerReferences overwrites it every step (src/mpc.cpp:313-323) -- which is also all updateTerminalConstraint does.
+    def createTerminalConstraint(self, com_ref):
+        if self._problem is None:
+            raise RuntimeError("Create problem first!")
+        if not np.allclose(np.asarray(com_ref, float).reshape(3), self._problem["x0"][:3]):
+            raise RuntimeError("the terminal constraint is created with the base position of x0 as its reference (createProblem's choice)")
+        self._problem["terminal_constraint"] = True
+
+    def updateTerminalConstraint(self, com_ref):
+        if self._problem is None:
+            raise RuntimeError("Create problem first!")
+        self._problem["terminal_com_ref"] = np.asarray(com_ref, float).reshape(3).copy()  # (every iterate() recomputes it on the device)
+
     def _default_x_reference(self):
         return self.model_handler.getReferenceState()
 
@@ -444,6 +463,18 @@ class CentroidalOCP(_StageReferences):
         return self._problem["horizon"]
 
     _nx_ref = 9
+
+    # reference src/centroidal-dynamics.cpp:259-262
+    def getProblemState(self, data_handler):
+        return data_handler.getCentroidalState()
+
+    # reference src/centroidal-dynamics.cpp:318-335: the constraint is left out upstream; both calls succeed and change nothing
+    def createTerminalConstraint(self, com_ref):
+        if self._problem is None:
+            raise RuntimeError("Create problem first!")
+
+    def updateTerminalConstraint(self, com_ref):
+        pass
 
     def getCostNumber(self):
         return 6  # com, control, linear / angular momentum, linear / angular acceleration (tests/problem.cpp:232)

@@ -147,3 +147,33 @@ def test_cycling_contact_state_follows_the_gait(lib):
         gm.getCyclingContactState(80, "FL_foot")
     with pytest.raises(RuntimeError, match="pose_cost"):
         gm.setTerminalReferencePose("FL_foot", [0, 0, 0])  # the terminal cost stack has no pose cost, upstream as here
+
+
+def test_problem_state_and_terminal_constraint_calls(lib):
+    """getProblemState (src/kinodynamics.cpp:308-311, src/centroidal-dynamics.cpp:259-262) and the by-hand terminal-constraint calls
+    (src/kinodynamics.cpp:366-388; left out upstream for the centroidal OCP, src/centroidal-dynamics.cpp:318-335)."""
+    import simple_mpc
+
+    rb = O.Robot("go2_like")
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+    for n in S.FEET:
+        mh.addPointFoot(n, "root_joint")
+    dh = simple_mpc.RobotDataHandler(mh)
+    x = S.random_states(rb, 1)[0]
+    dh.updateInternalData(x, False)
+    kin = simple_mpc.KinodynamicsOCP(O.go2_kino_settings(rb), mh)
+    with pytest.raises(RuntimeError, match="Create problem first"):
+        kin.createTerminalConstraint(x[:3])
+    kin.createProblem(mh.getReferenceState(), 20, 3, -9.81, False)
+    assert np.array_equal(kin.getProblemState(dh), x)
+    kin.createTerminalConstraint(mh.getReferenceState()[:3])  # what createProblem(..., True) does
+    kin.updateTerminalConstraint([0.1, 0.0, 0.3])
+    ms = {k: v for k, v in O.go2_mpc_settings(rb, max_iters=1).items() if k in S.MPC_KEYS}
+    gm = simple_mpc.BatchedMPC(ms, kin, 1, lib=lib)
+    ref, _, _ = S.make_product(1, lib=lib, horizon=20, mpc_override={"terminal_constraint": True})[0], None, None
+    assert np.array_equal(gm.xs, ref.xs)  # the same problem as createProblem(..., terminal_constraint = True)
+    cen = simple_mpc.CentroidalOCP(O.go2_centroidal_settings(rb), mh)
+    cen.createProblem(np.zeros(9), 20, 3, -9.81, False)
+    assert np.allclose(cen.getProblemState(dh), dh.getCentroidalState())
+    cen.createTerminalConstraint([0, 0, 0.3])
+    cen.updateTerminalConstraint([0, 0, 0.3])
