@@ -213,6 +213,14 @@ namespace simple_mpc
       check(smpc_get_contact_forces(h_, f.data()));
       return f;
     }
+    // per-instance status words of the last control step (smpc_get_status: SMPC_STATUS_* bits, 0 = healthy); returns how many are not
+    int status(std::vector<int> & words)
+    {
+      words.assign((size_t)batch_, 0);
+      const int rc = smpc_get_status(h_, words.data());
+      check(rc);
+      return rc;
+    }
     void switchToWalk(const double * velocity_base6) { check(smpc_switch_to_walk(h_, velocity_base6)); }
     void switchToStand() { check(smpc_switch_to_stand(h_)); }
     // one velocity command per instance, V: [B][6] (the reference's MPC::velocity_base_, one per robot of the batch)

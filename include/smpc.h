@@ -236,6 +236,14 @@ int smpc_get_foot_timing(smpc_handle * h, int foot, int which, int * out, int ca
 /* per-instance solver scalars of the last iteration, [B][16]:
  * phi0, dphi0, alpha, phi_new, prim_infeas, dual_infeas, ls_failed, preg, prim_new, cost, cost_new, ls_index */
 int smpc_get_info(smpc_handle * h, double * out);
+/* Per-instance status word of the last control step (the reference ignores the solver's return value, src/mpc.cpp:212; a batch needs to
+ * know which of its members went wrong), out [B]: bit 0 = a non-finite number among the solver scalars (the instance's trajectory
+ * must not be used), bit 1 = the last line search failed (the smallest step was taken), bit 2 = the primal regularisation has reached
+ * its upper limit.  Returns the number of instances with a non-zero word, or a negative error code. */
+#define SMPC_STATUS_NONFINITE 1
+#define SMPC_STATUS_LS_FAILED 2
+#define SMPC_STATUS_REG_SATURATED 4
+int smpc_get_status(smpc_handle * h, int * out);
 /* cold-solve trace of the constructor: returns n iterations; out [n][4] = phi0, prim, dual, alpha (cap rows) */
 int smpc_get_cold_trace(smpc_handle * h, double * out, int cap);
 

@@ -600,6 +600,32 @@ extern "C"
       return guarded([&] { h->cent->get_linear(h->cent->buf.scal, (size_t)h->cent->B * SC_N, out); });
     return guarded([&] { h->eng->get_linear(h->eng->buf.scal, (size_t)h->eng->B * SC_N, out); });
   }
+  int smpc_get_status(smpc_handle * h, int * out)
+  {
+    if (!h || !out)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    const int B = h->full ? h->full->B : (h->cent ? h->cent->B : h->eng->B);
+    std::vector<double> info((size_t)B * SC_N);
+    const int rc = smpc_get_info(h, info.data());
+    if (rc < 0)
+      return rc;
+    int bad = 0;
+    for (int b = 0; b < B; b++)
+    {
+      const double * s = &info[(size_t)b * SC_N];
+      int w = 0;
+      for (int i = 0; i < 12; i++)
+        if (!std::isfinite(s[i]))
+          w |= SMPC_STATUS_NONFINITE;
+      if (s[SC_LS_FAILED] != 0.0)
+        w |= SMPC_STATUS_LS_FAILED;
+      if (s[SC_PREG] >= 1e9)
+        w |= SMPC_STATUS_REG_SATURATED;
+      out[b] = w;
+      bad += w != 0;
+    }
+    return bad;
+  }
   int smpc_get_cold_trace(smpc_handle * h, double * out, int cap)
   {
     const int n = h->full ? h->full->cold_iters : (h->cent ? h->cent->cold_iters : h->eng->cold_iters);

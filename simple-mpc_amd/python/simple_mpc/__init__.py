@@ -816,6 +816,16 @@ class BatchedMPC:
     def info(self):
         return self._get("smpc_get_info", (self.B, 16))
 
+    @property
+    def status(self):
+        """Per-instance status word of the last control step (smpc_get_status): bit 0 non-finite scalars, bit 1 the last line search
+        failed, bit 2 primal regularisation at its upper limit.  0 = healthy."""
+        out = np.zeros(self.B, np.int32)
+        rc = self._lib.L.smpc_get_status(self._h, out)
+        if rc < 0:
+            self._lib.check(rc)
+        return out
+
     def getStateDerivative(self, t):
         if t not in (0, 1):
             raise RuntimeError("state derivative is retained for t = 0, 1 only")

@@ -136,7 +136,7 @@ SYMBOLS = [
     "smpc_get_reference_pose", "smpc_get_contact_state", "smpc_get_cycling_contact_state", "smpc_debug_get_extra_multipliers", "smpc_set_x_reference",
     "smpc_state_size", "smpc_save_state", "smpc_load_state", "smpc_iterate", "smpc_iterate_device", "smpc_wait", "smpc_get_x_device", "smpc_get_xs", "smpc_get_us", "smpc_get_K0", "smpc_get_Ks",
     "smpc_get_vs", "smpc_get_lams", "smpc_get_state_derivative01", "smpc_get_reference_poses",
-    "smpc_get_foot_timing", "smpc_get_info", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
+    "smpc_get_foot_timing", "smpc_get_info", "smpc_get_status", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
     "smpc_debug_get_steps", "smpc_debug_get_terminal", "smpc_debug_get_phase_cycles", "smpc_set_profiling", "smpc_get_kernel_times", "smpc_reset_kernel_times",
     "smpc_interpolate", "smpc_interpolate_knots", "smpc_friction_compensation", "smpc_update_internal_data", "smpc_full_forward_dynamics", "smpc_centroidal_dynamics", "smpc_riccati_feedback",
 ]
@@ -183,6 +183,7 @@ class SmpcLib:
         L.smpc_get_reference_pose.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp]
         L.smpc_get_contact_state.argtypes = [vp, C.c_int, _bp]
         L.smpc_get_cycling_contact_state.argtypes = [vp, C.c_int, C.c_void_p]
+        L.smpc_get_status.argtypes = [vp, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]
         L.smpc_debug_get_extra_multipliers.argtypes = [vp, C.c_int, _dp]
         L.smpc_set_x_reference.argtypes = [vp, _dp]
         L.smpc_state_size.argtypes = [vp, C.POINTER(C.c_size_t)]

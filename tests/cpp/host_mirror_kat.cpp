@@ -110,6 +110,10 @@ int main()
   CHECK(mpc.getFootLandCycle(robot->foot_name[1])[0] == 150);
   for (double v : mpc.xs_)
     CHECK(std::isfinite(v));
+  {
+    std::vector<int> words;
+    CHECK(mpc.status(words) == 0 && words.size() == 2 && words[0] == 0 && words[1] == 0);
+  }
   // both instances got the same measured state: identical solutions
   const size_t half = mpc.xs_.size() / 2;
   for (size_t i = 0; i < half; i++)

@@ -149,3 +149,19 @@ def test_c_abi_argument_validation(built):
     assert b"Stage index" in L.smpc_last_error()
     buf = np.zeros(8, np.int32)
     assert L.smpc_get_foot_timing(gm._h, 0, 0, buf, 8) < 0  # cycle horizon not generated yet
+
+
+def test_status_word_flags_failed_instances(built):
+    """smpc_get_status: healthy instances report 0; an instance fed a non-finite measured state is flagged (and only that one)."""
+    lib = S.emu_lib()
+    gm, rb, _, _ = S.make_product(3, max_iters=1, lib=lib, horizon=20)
+    gm.generateCycleHorizon(O.trot_cycle())
+    gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = S.random_states(rb, 3)
+    gm.iterate(X)
+    assert np.array_equal(gm.status, [0, 0, 0])
+    X[1, 9] = np.nan
+    gm.iterate(X)
+    st = gm.status
+    assert st[1] & 1 and st[0] == 0 and st[2] == 0
+    assert np.all(np.isfinite(gm.xs[0])) and np.all(np.isfinite(gm.xs[2]))  # the others are untouched
