@@ -5,6 +5,7 @@
 #include "../include/smpc_robots_builtin.h"
 #include "orc_mpc_cent.hpp"
 #include "orc_fulldyn.hpp"
+#include "orc_id.hpp"
 #include <chrono>
 #include <cstring>
 #ifdef _OPENMP
@@ -1030,5 +1031,93 @@ extern "C"
 #else
     return 1;
 #endif
+  }
+
+  // ---- whole-body inverse-dynamics QP (orc_id.hpp): KinodynamicsID for a batch ----
+  struct orc_id_settings
+  {
+    double friction_coefficient, contact_weight_ratio_max, contact_weight_ratio_min;
+    double kp_base, kp_posture, kp_contact;
+    double w_base, w_posture, w_contact_motion, w_contact_force;
+    int contact_motion_equality;
+    double control_dt;
+    const double *tau_max, *v_max, *q_min, *q_max;
+    int admm_iters;
+    double rho, sigma, alpha;
+  };
+  static IDSettings id_settings_from(const smpc_robot_model * m, const orc_id_settings * c)
+  {
+    IDSettings s;
+    s.friction_coefficient = c->friction_coefficient;
+    s.contact_weight_ratio_max = c->contact_weight_ratio_max;
+    s.contact_weight_ratio_min = c->contact_weight_ratio_min;
+    s.kp_base = c->kp_base;
+    s.kp_posture = c->kp_posture;
+    s.kp_contact = c->kp_contact;
+    s.w_base = c->w_base;
+    s.w_posture = c->w_posture;
+    s.w_contact_motion = c->w_contact_motion;
+    s.w_contact_force = c->w_contact_force;
+    s.contact_motion_equality = c->contact_motion_equality != 0;
+    s.control_dt = c->control_dt;
+    const int na = m->nv - 6;
+    s.tau_max.assign(c->tau_max, c->tau_max + na);
+    s.v_max.assign(c->v_max, c->v_max + na);
+    s.q_min.assign(c->q_min, c->q_min + na);
+    s.q_max.assign(c->q_max, c->q_max + na);
+    s.admm_iters = c->admm_iters;
+    s.rho = c->rho;
+    s.sigma = c->sigma;
+    s.alpha = c->alpha;
+    return s;
+  }
+  void * orc_id_create(const smpc_robot_model * m, const orc_id_settings * c, int B) { return new BatchKinoID(m, id_settings_from(m, c), B); }
+  void orc_id_destroy(void * h) { delete (BatchKinoID *)h; }
+  // target of instance b (b < 0: every instance): q (nq), v (nv), a (nv), contact mask, f (3 nf)
+  void orc_id_set_target(void * h, int b, const double * q, const double * v, const double * a, unsigned mask, const double * f)
+  {
+    BatchKinoID * k = (BatchKinoID *)h;
+    IDTarget t;
+    t.q.assign(q, q + k->M->nq);
+    t.v.assign(v, v + k->M->nv);
+    t.a.assign(a, a + k->M->nv);
+    t.mask = mask;
+    t.f.assign(f, f + 3 * k->M->nfeet);
+    for (int i = 0; i < k->B; i++)
+      if (b < 0 || b == i)
+        k->tgt[i] = t;
+  }
+  void orc_id_solve(void * h, const double * X, double * tau, double * a, double * f, double * resid)
+  {
+    BatchKinoID * k = (BatchKinoID *)h;
+    k->solve(X, tau, a, f);
+    for (int b = 0; b < k->B; b++)
+      resid[b] = k->resid[b];
+  }
+  // pieces, for the tests of the kernels: M (nv x nv), nle (nv), J (3 nf x nv), Jdv (3 nf), vfoot (3 nf)
+  void orc_id_quantities(const smpc_robot_model * m, const double * x, double * Mq, double * nle, double * J, double * Jdv, double * vfoot)
+  {
+    IDQuantities Q;
+    id_quantities(m, x, Q);
+    mat_to(Q.M, Mq);
+    vec_to(Q.nle, nle);
+    mat_to(Q.J, J);
+    vec_to(Q.Jdv, Jdv);
+    vec_to(Q.vfoot, vfoot);
+  }
+  // QP of instance b at state x: H (n x n), g (n), C (m x n), l, u (m); returns m
+  int orc_id_qp(void * h, int b, const double * x, double * H, double * g, double * C, double * l, double * u)
+  {
+    BatchKinoID * k = (BatchKinoID *)h;
+    IDQuantities Q;
+    id_quantities(k->M, x, Q);
+    QP qp;
+    id_assemble(k->M, k->s, k->tgt[b], x, Q, qp);
+    mat_to(qp.H, H);
+    vec_to(qp.g, g);
+    mat_to(qp.C, C);
+    vec_to(qp.l, l);
+    vec_to(qp.u, u);
+    return qp.m;
   }
 }

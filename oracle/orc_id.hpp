@@ -1,0 +1,347 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_linalg.hpp header).  PARITY UNPINNED.
+//
+// orc_id.hpp: CPU restatement of the whole-body inverse-dynamics QP of KinodynamicsID (reference
+// src/inverse-dynamics/kinodynamics-id.cpp:7-237, include/simple-mpc/inverse-dynamics/kinodynamics-id.hpp:24-50), for robots with
+// 3-D point feet.  The reference delegates the formulation to TSID 1.9 (InverseDynamicsFormulationAccForce, TaskJointPosture,
+// TaskSE3Equality, ContactPoint, TaskJointPosVelAccBounds, TaskActuationBounds) and the solve to proxsuite's ProxQP, neither of which is
+// in the image; what follows restates their published formulation ([UPSTREAM-RECALL] where the library's source would decide):
+//
+//   variables        y = [a (nv) ; f (3 per foot, world frame)]                    (inactive feet keep their variables, pinned to 0)
+//   equality         M_b a + h_b = J_b^T f                                         (the six unactuated rows of the dynamics)
+//   posture task     w_posture |a_j - (a_t + Kp (q_t - q) + Kd (v_t - v))|^2      (Kd = 2 sqrt(Kp) everywhere, as the reference sets it)
+//   base task        w_base |a_b + drift - (Kp log6(M_b^-1 M_t) + Kd (v_ref - v_b))|^2, local frame, drift = [w x v ; 0]
+//                    (v_ref: the reference hands its base ACCELERATION target to TSID as the velocity reference -- setDerivative is called
+//                     twice, kinodynamics-id.cpp:222-223 -- and no acceleration reference; restated as coded)
+//   contact motion   J_f a + dJ_f v = -Kd v_f  (the contact reference is reset to the measured foot pose at every solve, :196-213:
+//                    no position error) -- a cost with w_contact_motion, or an equality with contact_motion_equality
+//   contact force    w_contact_force |f_f - f_t|^2 ; friction pyramid |f_x|, |f_y| <= mu f_z ; f_min <= f_z <= f_max
+//   joint bounds     position / velocity limits as acceleration bounds over one control period (TaskJointPosVelAccBounds with the
+//                    acceleration bound off; its viability refinement is not restated):  a in [max((-vmax - v)/dt, 2 (qmin - q - v dt)/dt^2),
+//                    min((vmax - v)/dt, 2 (qmax - q - v dt)/dt^2)]
+//   actuation        |M_a a + h_a - J_a^T f| <= tau_max  ;  output tau = M_a a + h_a - J_a^T f
+//
+// Solver: ADMM on  min 1/2 y^T H y + g^T y  s.t.  l <= C y <= u  (the operator splitting of OSQP: one factorisation of
+// H + sigma I + C^T diag(rho) C per solve, then matrix-vector iterations; equality rows carry 1e3 rho, free rows 1e-6 rho), a fixed number
+// of iterations, warm-started from the previous control tick.  ProxQP is a proximal augmented-Lagrangian method; both converge to the
+// same (unique, H + constraints) solution, which the tests check through KKT residuals.
+#pragma once
+#include "orc_full.hpp"
+
+namespace orc
+{
+  struct IDSettings
+  {
+    double friction_coefficient = 0.6, contact_weight_ratio_max = 10.0, contact_weight_ratio_min = 0.01;
+    double kp_base = 0, kp_posture = 0, kp_contact = 0;
+    double w_base = -1, w_posture = -1, w_contact_motion = -1, w_contact_force = -1;
+    bool contact_motion_equality = false;
+    double control_dt = 1e-3;
+    Vec tau_max, v_max, q_min, q_max; // nv - 6 each (the robot table holds position limits only)
+    int admm_iters = 100;
+    double rho = 0.1, sigma = 1e-6, alpha = 1.6;
+  };
+  struct IDTarget
+  {
+    Vec q, v, a; // nq, nv, nv
+    unsigned mask = 0;
+    Vec f;       // 3 nf
+  };
+  struct IDQuantities
+  {
+    Mat M;          // nv x nv
+    Vec nle;        // nv
+    Mat J;          // 3 nf x nv: world-frame linear Jacobians of the foot points
+    Vec Jdv, vfoot; // 3 nf: classical acceleration of the points at zero joint accelerations ; their velocity
+  };
+  struct QP
+  {
+    int n = 0, m = 0;
+    Mat H, C;
+    Vec g, l, u;
+  };
+  constexpr double ID_INF = 1e20;
+
+  inline void id_quantities(const smpc_robot_model * m, const double * x, IDQuantities & o)
+  {
+    ConstraintDynamics cd(m);
+    cd.fs = 6; // LOCAL_WORLD_ALIGNED rows: the first three of each foot are the world-frame point Jacobian and its drift
+    Vec tau(m->nv - 6, 0.0);
+    cd.compute(x, x + m->nq, tau.data(), (1u << m->nfeet) - 1u);
+    const int nv = m->nv, nf = m->nfeet;
+    o.M = cd.Mq;
+    o.nle = cd.nle;
+    o.J = Mat(3 * nf, nv);
+    o.Jdv.assign(3 * nf, 0.0);
+    o.vfoot.assign(3 * nf, 0.0);
+    for (int f = 0; f < nf; f++)
+      for (int i = 0; i < 3; i++)
+      {
+        for (int k = 0; k < nv; k++)
+        {
+          o.J(3 * f + i, k) = cd.Jc(6 * f + i, k);
+          o.vfoot[3 * f + i] += cd.Jc(6 * f + i, k) * x[m->nq + k];
+        }
+        o.Jdv[3 * f + i] = cd.gamma[6 * f + i];
+      }
+  }
+
+  // row layout of C: [0, n) box on y ; 6 dynamics rows ; 3 nf contact-motion rows ; 4 nf friction rows ; nv - 6 actuation rows
+  inline void id_assemble(const smpc_robot_model * m, const IDSettings & s, const IDTarget & t, const double * x, const IDQuantities & Q, QP & qp)
+  {
+    const int nq = m->nq, nv = m->nv, nf = m->nfeet, na = nv - 6, n = nv + 3 * nf;
+    const int mrows = n + 6 + 3 * nf + 4 * nf + na;
+    qp.n = n;
+    qp.m = mrows;
+    qp.H = Mat(n, n);
+    qp.g.assign(n, 0.0);
+    qp.C = Mat(mrows, n);
+    qp.l.assign(mrows, -ID_INF);
+    qp.u.assign(mrows, ID_INF);
+    const double * q = x;
+    const double * v = x + nq;
+    auto kd = [](double kp) { return 2.0 * std::sqrt(kp); };
+    // ---- costs ----
+    if (s.w_posture > 0)
+      for (int j = 0; j < na; j++)
+      {
+        const double b = t.a[6 + j] + s.kp_posture * (t.q[7 + j] - q[7 + j]) + kd(s.kp_posture) * (t.v[6 + j] - v[6 + j]);
+        qp.H(6 + j, 6 + j) += s.w_posture;
+        qp.g[6 + j] -= s.w_posture * b;
+      }
+    if (s.w_base > 0)
+    {
+      const SE3 Mb{quat_to_R(q + 3), v3(q[0], q[1], q[2])}, Mt{quat_to_R(t.q.data() + 3), v3(t.q[0], t.q[1], t.q[2])};
+      double e[6];
+      log6(inv(Mb) * Mt, e);
+      const V3 wl = v3(v[3], v[4], v[5]), vl = v3(v[0], v[1], v[2]);
+      const V3 dr = cross(wl, vl);
+      for (int i = 0; i < 6; i++)
+      {
+        const double ades = s.kp_base * e[i] + kd(s.kp_base) * (t.a[i] - v[i]); // (velocity reference = acceleration target: as coded upstream)
+        const double b = ades - (i < 3 ? dr[i] : 0.0);
+        qp.H(i, i) += s.w_base;
+        qp.g[i] -= s.w_base * b;
+      }
+    }
+    const double kdc = kd(s.kp_contact);
+    for (int f = 0; f < nf; f++)
+    {
+      if (!((t.mask >> f) & 1u))
+        continue;
+      if (!s.contact_motion_equality && s.w_contact_motion > 0)
+        for (int i = 0; i < 3; i++)
+        {
+          const int r = 3 * f + i;
+          const double b = -Q.Jdv[r] - kdc * Q.vfoot[r];
+          for (int a = 0; a < nv; a++)
+          {
+            qp.g[a] -= s.w_contact_motion * Q.J(r, a) * b;
+            for (int c = 0; c < nv; c++)
+              qp.H(a, c) += s.w_contact_motion * Q.J(r, a) * Q.J(r, c);
+          }
+        }
+      if (s.w_contact_force > 0)
+        for (int i = 0; i < 3; i++)
+        {
+          qp.H(nv + 3 * f + i, nv + 3 * f + i) += s.w_contact_force;
+          qp.g[nv + 3 * f + i] -= s.w_contact_force * t.f[3 * f + i];
+        }
+    }
+    // ---- constraints ----
+    const double W = m->total_mass * 9.81, fmax = s.contact_weight_ratio_max * W, fmin = s.contact_weight_ratio_min * W, dt = s.control_dt;
+    for (int i = 0; i < n; i++)
+      qp.C(i, i) = 1.0;
+    for (int j = 0; j < na; j++)
+    {
+      const double qa = q[7 + j], va = v[6 + j];
+      double lb = std::fmax((-s.v_max[j] - va) / dt, 2.0 * (s.q_min[j] - qa - va * dt) / (dt * dt));
+      double ub = std::fmin((s.v_max[j] - va) / dt, 2.0 * (s.q_max[j] - qa - va * dt) / (dt * dt));
+      if (lb > ub) // (a joint beyond both: the tighter one wins)
+        lb = ub = std::fmin(lb, ub);
+      qp.l[6 + j] = lb;
+      qp.u[6 + j] = ub;
+    }
+    for (int f = 0; f < nf; f++)
+    {
+      const bool on = (t.mask >> f) & 1u;
+      for (int i = 0; i < 3; i++)
+        if (!on)
+          qp.l[nv + 3 * f + i] = qp.u[nv + 3 * f + i] = 0.0;
+      if (on)
+      {
+        qp.l[nv + 3 * f + 2] = fmin;
+        qp.u[nv + 3 * f + 2] = fmax;
+      }
+    }
+    int r0 = n;
+    for (int i = 0; i < 6; i++)
+    {
+      for (int k = 0; k < nv; k++)
+        qp.C(r0 + i, k) = Q.M(i, k);
+      for (int r = 0; r < 3 * nf; r++)
+        qp.C(r0 + i, nv + r) = -Q.J(r, i);
+      qp.l[r0 + i] = qp.u[r0 + i] = -Q.nle[i];
+    }
+    r0 += 6;
+    for (int f = 0; f < nf; f++)
+      if (((t.mask >> f) & 1u) && s.contact_motion_equality)
+        for (int i = 0; i < 3; i++)
+        {
+          const int r = 3 * f + i;
+          for (int k = 0; k < nv; k++)
+            qp.C(r0 + r, k) = Q.J(r, k);
+          qp.l[r0 + r] = qp.u[r0 + r] = -Q.Jdv[r] - kdc * Q.vfoot[r];
+        }
+    r0 += 3 * nf;
+    for (int f = 0; f < nf; f++)
+      if ((t.mask >> f) & 1u)
+        for (int k = 0; k < 4; k++)
+        {
+          qp.C(r0 + 4 * f + k, nv + 3 * f + k / 2) = (k % 2 == 0) ? 1.0 : -1.0;
+          qp.C(r0 + 4 * f + k, nv + 3 * f + 2) = -s.friction_coefficient;
+          qp.u[r0 + 4 * f + k] = 0.0;
+        }
+    r0 += 4 * nf;
+    for (int j = 0; j < na; j++)
+    {
+      for (int k = 0; k < nv; k++)
+        qp.C(r0 + j, k) = Q.M(6 + j, k);
+      for (int r = 0; r < 3 * nf; r++)
+        qp.C(r0 + j, nv + r) = -Q.J(r, 6 + j);
+      qp.l[r0 + j] = -s.tau_max[j] - Q.nle[6 + j];
+      qp.u[r0 + j] = s.tau_max[j] - Q.nle[6 + j];
+    }
+  }
+
+  // ADMM (x = y of the QP); x, z, lam are the warm start on entry and the iterate on exit.  Returns max(primal, dual) residual.
+  inline double qp_admm(const QP & qp, double rho, double sigma, double alpha, int iters, Vec & x, Vec & z, Vec & lam)
+  {
+    const int n = qp.n, m = qp.m;
+    Vec r(m);
+    for (int i = 0; i < m; i++)
+      r[i] = (qp.u[i] - qp.l[i] < 1e-12) ? 1e3 * rho : ((qp.l[i] <= -ID_INF && qp.u[i] >= ID_INF) ? 1e-6 * rho : rho);
+    Mat K = qp.H;
+    for (int i = 0; i < n; i++)
+      K(i, i) += sigma;
+    for (int k = 0; k < m; k++)
+      for (int i = 0; i < n; i++)
+      {
+        const double ci = qp.C(k, i);
+        if (ci == 0.0)
+          continue;
+        for (int j = 0; j < n; j++)
+          K(i, j) += r[k] * ci * qp.C(k, j);
+      }
+    bool ok = cholesky(K);
+    assert(ok);
+    (void)ok;
+    if ((int)x.size() != n)
+    {
+      x.assign(n, 0.0);
+      z.assign(m, 0.0);
+      lam.assign(m, 0.0);
+      for (int k = 0; k < m; k++)
+        z[k] = std::fmin(std::fmax(0.0, qp.l[k]), qp.u[k]);
+    }
+    Vec rhs(n), zt(m);
+    for (int it = 0; it < iters; it++)
+    {
+      for (int i = 0; i < n; i++)
+        rhs[i] = sigma * x[i] - qp.g[i];
+      for (int k = 0; k < m; k++)
+      {
+        const double w = r[k] * z[k] - lam[k];
+        for (int i = 0; i < n; i++)
+          rhs[i] += qp.C(k, i) * w;
+      }
+      chol_solve_inplace(K, rhs);
+      for (int k = 0; k < m; k++)
+      {
+        double acc = 0.0;
+        for (int i = 0; i < n; i++)
+          acc += qp.C(k, i) * rhs[i];
+        zt[k] = acc;
+      }
+      for (int i = 0; i < n; i++)
+        x[i] = alpha * rhs[i] + (1.0 - alpha) * x[i];
+      for (int k = 0; k < m; k++)
+      {
+        const double zh = alpha * zt[k] + (1.0 - alpha) * z[k];
+        const double zn = std::fmin(std::fmax(zh + lam[k] / r[k], qp.l[k]), qp.u[k]);
+        lam[k] += r[k] * (zh - zn);
+        z[k] = zn;
+      }
+    }
+    double pr = 0.0, du = 0.0;
+    for (int k = 0; k < m; k++)
+    {
+      double acc = 0.0;
+      for (int i = 0; i < n; i++)
+        acc += qp.C(k, i) * x[i];
+      pr = std::fmax(pr, std::fabs(acc - z[k]));
+    }
+    for (int i = 0; i < n; i++)
+    {
+      double acc = qp.g[i];
+      for (int j = 0; j < n; j++)
+        acc += qp.H(i, j) * x[j];
+      for (int k = 0; k < m; k++)
+        acc += qp.C(k, i) * lam[k];
+      du = std::fmax(du, std::fabs(acc));
+    }
+    return std::fmax(pr, du);
+  }
+
+  // KinodynamicsID for a batch of robots: setTarget (shared or per instance) + solve
+  struct BatchKinoID
+  {
+    const smpc_robot_model * M;
+    IDSettings s;
+    int B;
+    std::vector<IDTarget> tgt;
+    std::vector<Vec> x, z, lam; // ADMM state per instance (warm start)
+    std::vector<double> resid;
+    BatchKinoID(const smpc_robot_model * m, const IDSettings & st, int B_) : M(m), s(st), B(B_), tgt(B_), x(B_), z(B_), lam(B_), resid(B_, 0.0)
+    {
+      // default target: the reference state, every foot in contact with an equal share of the weight (kinodynamics-id.cpp:96-112)
+      IDTarget t;
+      t.q.assign(m->q_ref, m->q_ref + m->nq);
+      t.v.assign(m->nv, 0.0);
+      t.a.assign(m->nv, 0.0);
+      t.mask = (1u << m->nfeet) - 1u;
+      t.f.assign(3 * m->nfeet, 0.0);
+      for (int f = 0; f < m->nfeet; f++)
+        t.f[3 * f + 2] = m->total_mass * 9.81 / m->nfeet;
+      for (auto & e : tgt)
+        e = t;
+    }
+    // X [B][nq + nv] -> tau [B][nv - 6], a [B][nv], f [B][3 nf]
+    void solve(const double * X, double * tau, double * a, double * f)
+    {
+      const int nq = M->nq, nv = M->nv, nf = M->nfeet, na = nv - 6;
+#pragma omp parallel for schedule(dynamic)
+      for (int b = 0; b < B; b++)
+      {
+        const double * xb = X + (size_t)b * (nq + nv);
+        IDQuantities Q;
+        id_quantities(M, xb, Q);
+        QP qp;
+        id_assemble(M, s, tgt[b], xb, Q, qp);
+        resid[b] = qp_admm(qp, s.rho, s.sigma, s.alpha, s.admm_iters, x[b], z[b], lam[b]);
+        for (int k = 0; k < nv; k++)
+          a[(size_t)b * nv + k] = x[b][k];
+        for (int k = 0; k < 3 * nf; k++)
+          f[(size_t)b * 3 * nf + k] = x[b][nv + k];
+        for (int j = 0; j < na; j++)
+        {
+          double acc = Q.nle[6 + j];
+          for (int k = 0; k < nv; k++)
+            acc += Q.M(6 + j, k) * x[b][k];
+          for (int r = 0; r < 3 * nf; r++)
+            acc -= Q.J(r, 6 + j) * x[b][nv + r];
+          tau[(size_t)b * na + j] = acc;
+        }
+      }
+    }
+  };
+} // namespace orc

@@ -26,6 +26,17 @@ def build(force=False):
     return LIB_PATH
 
 
+class IdSettingsC(C.Structure):
+    _fields_ = [
+        ("friction_coefficient", C.c_double), ("contact_weight_ratio_max", C.c_double), ("contact_weight_ratio_min", C.c_double),
+        ("kp_base", C.c_double), ("kp_posture", C.c_double), ("kp_contact", C.c_double),
+        ("w_base", C.c_double), ("w_posture", C.c_double), ("w_contact_motion", C.c_double), ("w_contact_force", C.c_double),
+        ("contact_motion_equality", C.c_int), ("control_dt", C.c_double),
+        ("tau_max", C.c_void_p), ("v_max", C.c_void_p), ("q_min", C.c_void_p), ("q_max", C.c_void_p),
+        ("admm_iters", C.c_int), ("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
+    ]
+
+
 class MpcSettingsC(C.Structure):
     _fields_ = [
         ("swing_apex", C.c_double),
@@ -111,6 +122,14 @@ def lib():
     L.orc_mpc_cold_trace.argtypes = [vp, _dp]
     L.orc_mpc_timing.argtypes = [vp, C.c_int, C.c_int, _ip, C.c_int]
     L.orc_set_terminal_constraint.argtypes = [C.c_int]
+    L.orc_id_create.restype = vp
+    L.orc_id_create.argtypes = [vp, C.POINTER(IdSettingsC), C.c_int]
+    L.orc_id_destroy.argtypes = [vp]
+    L.orc_id_set_target.argtypes = [vp, C.c_int, _dp, _dp, _dp, C.c_uint, _dp]
+    L.orc_id_solve.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_id_quantities.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_id_qp.restype = C.c_int
+    L.orc_id_qp.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_fmpc_create.restype = vp
     L.orc_fmpc_create.argtypes = [vp, C.POINTER(MpcSettingsC), C.c_int, C.c_double]
     L.orc_fmpc_destroy.argtypes = [vp]
@@ -698,3 +717,65 @@ def centroidal_dynamics(mass, gravity, dt, x, u, contact, pos):
                                   np.ascontiguousarray(u, float), np.ascontiguousarray(contact, np.uint8),
                                   np.ascontiguousarray(pos, float), xn, A, B)
     return xn, A, B
+
+
+ID_DEFAULTS = dict(friction_coefficient=0.6, contact_weight_ratio_max=10.0, contact_weight_ratio_min=0.01, kp_base=0.0, kp_posture=0.0,
+                   kp_contact=0.0, w_base=-1.0, w_posture=-1.0, w_contact_motion=-1.0, w_contact_force=-1.0, contact_motion_equality=False,
+                   admm_iters=100, rho=0.1, sigma=1e-6, alpha=1.6)  # reference include/simple-mpc/inverse-dynamics/kinodynamics-id.hpp:24-50
+GO2_EFFORT = np.array([23.7, 23.7, 45.43] * 4)
+GO2_VMAX = np.array([30.1, 30.1, 15.7] * 4)
+
+
+def id_settings(robot, control_dt=1e-3, tau_max=None, v_max=None, **kw):
+    """KinodynamicsID::Settings + what the reference reads from the pinocchio model (effort / velocity / position limits)."""
+    s = dict(ID_DEFAULTS, control_dt=control_dt, tau_max=GO2_EFFORT if tau_max is None else tau_max, v_max=GO2_VMAX if v_max is None else v_max,
+             q_min=robot.q_lo.copy(), q_max=robot.q_hi.copy())
+    s.update(kw)
+    return s
+
+
+class OracleKinoID:
+    """Batched restatement of simple_mpc.KinodynamicsID (oracle/orc_id.hpp)."""
+
+    def __init__(self, robot, s, B):
+        self.robot, self.B = robot, B
+        self._keep = [np.ascontiguousarray(s[k], float) for k in ("tau_max", "v_max", "q_min", "q_max")]
+        c = IdSettingsC(s["friction_coefficient"], s["contact_weight_ratio_max"], s["contact_weight_ratio_min"], s["kp_base"], s["kp_posture"],
+                        s["kp_contact"], s["w_base"], s["w_posture"], s["w_contact_motion"], s["w_contact_force"],
+                        int(s["contact_motion_equality"]), s["control_dt"], *[a.ctypes.data for a in self._keep], int(s["admm_iters"]),
+                        s["rho"], s["sigma"], s["alpha"])
+        self.h = lib().orc_id_create(robot.ptr, C.byref(c), B)
+        self.n = robot.nv + 3 * robot.nf
+        self.m = self.n + 6 + 3 * robot.nf + 4 * robot.nf + robot.nv - 6
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_id_destroy(self.h)
+            self.h = None
+
+    def setTarget(self, q, v, a, contact_state, f, instance=-1):
+        mask = sum(1 << i for i, on in enumerate(contact_state) if on)
+        c = lambda x: np.ascontiguousarray(x, float)
+        lib().orc_id_set_target(self.h, instance, c(q), c(v), c(a), mask, c(np.asarray(f, float).reshape(-1)))
+
+    def solve(self, X):
+        rb = self.robot
+        X = np.ascontiguousarray(X, float)
+        tau, a, f, res = np.zeros((self.B, rb.nv - 6)), np.zeros((self.B, rb.nv)), np.zeros((self.B, 3 * rb.nf)), np.zeros(self.B)
+        lib().orc_id_solve(self.h, X, tau, a, f, res)
+        self.resid = res
+        return tau, a, f
+
+    def qp(self, b, x):
+        H, g = np.zeros((self.n, self.n)), np.zeros(self.n)
+        Cm, l, u = np.zeros((self.m, self.n)), np.zeros(self.m), np.zeros(self.m)
+        m = lib().orc_id_qp(self.h, b, np.ascontiguousarray(x, float), H, g, Cm, l, u)
+        assert m == self.m
+        return H, g, Cm, l, u
+
+
+def id_quantities(robot, x):
+    nv, nf = robot.nv, robot.nf
+    M, nle, J, Jdv, vf = np.zeros((nv, nv)), np.zeros(nv), np.zeros((3 * nf, nv)), np.zeros(3 * nf), np.zeros(3 * nf)
+    lib().orc_id_quantities(robot.ptr, np.ascontiguousarray(x, float), M, nle, J, Jdv, vf)
+    return dict(M=M, nle=nle, J=J, Jdv=Jdv, vfoot=vf)

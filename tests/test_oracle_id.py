@@ -1,0 +1,144 @@
+"""Oracle of the whole-body inverse-dynamics QP (oracle/orc_id.hpp): the acceptance properties of the reference's own
+tests (tests/inverse-dynamics/kinodynamics-id.cpp:46-91 joint / torque limits at every step, :110-143 posture error decreasing, :145-175
+contact velocity below 1e-2, :231-266 base error decreasing then below 2e-2, :268-300 whole-state error decreasing) on the go2_like robot,
+integrated the way that test integrates (:53-60), plus the KKT conditions of the QP the ADMM iterations return."""
+import numpy as np
+import pytest
+
+import mpc_setup as S
+import oracle_lib as O
+
+DT = 1e-3
+
+
+@pytest.fixture(scope="module")
+def rb():
+    return O.Robot("go2_like")
+
+
+def crouch(rb):
+    """The reference test's start (solo_q_start, :14-27) for this robot: legs folded, base lowered so that the feet stay where they are."""
+    x = rb.x_ref.copy()
+    for leg in range(4):
+        x[7 + 3 * leg + 1] += 0.25
+        x[7 + 3 * leg + 2] -= 0.5
+    x[2] += (rb.centroidal(rb.x_ref)["feet"][:, 2] - rb.centroidal(x)["feet"][:, 2]).mean()
+    return x
+
+
+def step(rb, x, a):
+    """q <- integrate(q, (v + a dt / 2) dt) ; v <- v + a dt (reference test :53-60)."""
+    nq, nv = rb.nq, rb.nv
+    q = rb.integrate(np.r_[x[:nq], np.zeros(nv)], np.r_[(x[nq:] + 0.5 * a * DT) * DT, np.zeros(nv)])[:nq]
+    return np.r_[q, x[nq:] + a * DT]
+
+
+def qerr(rb, x, sl):
+    d = rb.difference(np.r_[x[: rb.nq], np.zeros(rb.nv)], np.r_[rb.x_ref[: rb.nq], np.zeros(rb.nv)]) if hasattr(rb, "difference") else None
+    return np.linalg.norm(d[sl])
+
+
+class Sim:
+    def __init__(self, rb, **kw):
+        self.rb = rb
+        self.s = O.id_settings(rb, DT, **kw)
+        self.id = O.OracleKinoID(rb, self.s, 1)
+        self.x = rb.x_ref.copy()
+        self.tau = np.zeros(rb.nv - 6)
+
+    def step(self):
+        tau, a, f = self.id.solve(self.x[None, :])
+        self.tau, self.a, self.f = tau[0], a[0], f[0]
+        self.x = step(self.rb, self.x, self.a)
+        q, v = self.x[7 : self.rb.nq], self.x[self.rb.nq + 6 :]
+        assert np.all(q <= self.s["q_max"] + 1e-9) and np.all(q >= self.s["q_min"] - 1e-9)  # check_joint_limits, :74-88
+        assert np.all(np.abs(v) <= self.s["v_max"] + 1e-6)
+        assert np.all(np.abs(self.tau) <= self.s["tau_max"] + 1e-6)
+
+
+def static_forces(rb):
+    """Vertical force distribution that holds the reference posture still (the reference's default target shares the weight equally,
+    which is static for its symmetric test robot; this robot's centre of mass sits ahead of the feet's centroid)."""
+    sim = Sim(rb, kp_base=1.0, w_base=1.0, kp_contact=10.0, w_contact_motion=10.0, w_contact_force=1e-6)
+    for _ in range(3):
+        sim.id.solve(rb.x_ref[None, :])
+    return sim.id.solve(rb.x_ref[None, :])[2][0]
+
+
+def test_qp_solution_satisfies_kkt(rb):
+    s = O.id_settings(rb, DT, kp_base=10.0, kp_posture=1.0, kp_contact=10.0, w_base=10.0, w_posture=0.1, w_contact_force=1.0, w_contact_motion=1.0,
+                      admm_iters=400)
+    kid = O.OracleKinoID(rb, s, 1)
+    x = S.random_states(rb, 1)[0]
+    tau, a, f = kid.solve(x[None, :])
+    assert kid.resid[0] < 1e-8
+    H, g, Cm, l, u = kid.qp(0, x)
+    y = np.r_[a[0], f[0]]
+    z = Cm @ y
+    assert np.all(z >= l - 1e-7 * (1 + np.abs(l) * (l > -1e19))) and np.all(z <= u + 1e-7 * (1 + np.abs(u) * (u < 1e19)))
+    # stationarity with multipliers of the right sign: solve the equality-constrained QP on the active set and compare
+    act = (np.abs(z - l) < 1e-6) | (np.abs(z - u) < 1e-6)
+    A = Cm[act]
+    KKT = np.block([[H + 1e-12 * np.eye(len(y)), A.T], [A, np.zeros((A.shape[0], A.shape[0]))]])
+    sol = np.linalg.lstsq(KKT, np.r_[-g, z[act]], rcond=None)[0]
+    assert np.abs(sol[: len(y)] - y).max() < 1e-5 * (1 + np.abs(y).max())
+    # the dynamics hold: M a + h = S^T tau + J^T f
+    Q = O.id_quantities(rb, x)
+    res = Q["M"] @ a[0] + Q["nle"] - Q["J"].T @ f[0] - np.r_[np.zeros(6), tau[0]]
+    assert np.abs(res).max() < 1e-6 * (1 + np.abs(Q["nle"]).max())
+
+
+def test_posture_task(rb):
+    sim = Sim(rb, kp_posture=20.0, w_posture=1.0)
+    sim.id.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [False] * 4, np.zeros(12))
+    sim.x = crouch(rb)
+    prev = None
+    for _ in range(400):
+        sim.step()
+        sim.x[:7] = rb.x_ref[:7]  # compensate the free fall: only the posture matters (:131-133)
+        sim.x[rb.nq : rb.nq + 6] = 0.0
+        e = np.linalg.norm(sim.x[7 : rb.nq] - rb.x_ref[7 : rb.nq])
+        assert prev is None or e <= prev
+        prev = e
+    assert prev < 1.0
+
+
+@pytest.mark.parametrize("equality", [False, True])
+def test_contacts_hold(rb, equality):
+    sim = Sim(rb, kp_base=1.0, kp_contact=10.0, w_base=1.0, w_contact_motion=10.0, w_contact_force=1.0, contact_motion_equality=equality)
+    sim.id.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True] * 4, static_forces(rb))
+    sim.x = crouch(rb)
+    for _ in range(300):
+        sim.step()
+        vf = O.id_quantities(rb, sim.x)["vfoot"].reshape(4, 3)
+        assert np.linalg.norm(vf, axis=1).max() <= 1e-2  # :158-160
+    assert np.all(sim.f[2::3] > 0.0)
+
+
+def test_base_task(rb):
+    # (force weight: the reference uses 1.0 with a robot whose static forces ARE its default force target; here the crouched posture
+    #  shifts the static distribution, and a strong pull towards the standing one tilts the base before it rises)
+    sim = Sim(rb, kp_base=7.0, kp_contact=0.1, w_base=100.0, w_contact_force=1e-3, w_contact_motion=1.0)
+    sim.id.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True] * 4, static_forces(rb))
+    sim.x = crouch(rb)
+    prev, n = None, 2500
+    for i in range(n):
+        sim.step()
+        e = np.linalg.norm(rb.difference(sim.x, rb.x_ref)[:6])
+        if e > 2e-2:
+            assert prev is None or e <= prev  # strictly decreasing until converged (:253-260)
+        if i > 9 * n // 10:
+            assert e < 2e-2
+        prev = e
+
+
+def test_all_tasks(rb):
+    sim = Sim(rb, kp_base=10.0, kp_posture=1.0, kp_contact=10.0, w_base=10.0, w_posture=0.1, w_contact_force=1e-3, w_contact_motion=1.0)
+    sim.id.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True] * 4, static_forces(rb))
+    sim.x = crouch(rb)
+    prev = None
+    for _ in range(600):
+        sim.step()
+        e = np.linalg.norm(rb.difference(sim.x, rb.x_ref)[: rb.nv])
+        assert prev is None or e <= prev  # :293-297
+        prev = e
