@@ -329,6 +329,42 @@ int smpc_centroidal_dynamics(
   double mass, const double * gravity, double timestep, int nfeet, const double * X, const double * U, const unsigned char * contact,
   const double * contact_pos, int batch, double * Xnext, double * A, double * B, int device_id);
 
+/* ---- whole-body inverse-dynamics QP: KinodynamicsID (reference include/simple-mpc/inverse-dynamics/kinodynamics-id.hpp:17-92,
+ *      src/inverse-dynamics/kinodynamics-id.cpp:7-237), batched: one QP per robot and control tick, 3-D point feet.
+ *      Field names of KinodynamicsID::Settings; the limits the reference reads from the pinocchio model (effortLimit, velocityLimit,
+ *      lower / upperPositionLimit of the actuated joints) are passed explicitly; admm_* are the solver's own (0 = defaults). ---- */
+typedef struct smpc_id_settings
+{
+  double friction_coefficient;
+  double contact_weight_ratio_max;
+  double contact_weight_ratio_min;
+  double kp_base, kp_posture, kp_contact;
+  double w_base, w_posture, w_contact_motion, w_contact_force; /* <= 0: task disabled, as in the reference */
+  int contact_motion_equality;
+  double control_dt;
+  const double * effort_limit;   /* nv - 6 */
+  const double * velocity_limit; /* nv - 6 */
+  const double * q_min;          /* nv - 6 */
+  const double * q_max;          /* nv - 6 */
+  int admm_iters;                /* iterations per solve (default 100; warm-started from the previous tick) */
+  double admm_rho, admm_sigma, admm_alpha; /* defaults 0.1, 1e-6, 1.6 */
+} smpc_id_settings;
+typedef struct smpc_id_handle smpc_id_handle;
+/* KinodynamicsID(model_handler, control_dt, settings): the default target is the reference state, every foot in contact with an equal
+ * share of the weight (kinodynamics-id.cpp:96-112). */
+int smpc_id_create(const smpc_robot_model * robot, const smpc_id_settings * settings, int batch, int device_id, smpc_id_handle ** out);
+void smpc_id_destroy(smpc_id_handle * h);
+/* setTarget(q, v, a, contact_state, f) (kinodynamics-id.cpp:120-183) of one instance, or of every instance (instance < 0):
+ * q (nq), v (nv), a (nv), contact flag per foot, f (3 per foot, world frame) */
+int smpc_id_set_target(smpc_id_handle * h, int instance, const double * q, const double * v, const double * a, const uint8_t * contact, const double * f);
+/* solve(t, q_meas, v_meas, tau) + getAccelerations for the batch (kinodynamics-id.cpp:185-237): X [B][nq + nv] (host) ->
+ * tau [B][nv - 6], a [B][nv] (may be NULL), f [B][3 nfeet] contact forces of the solution (may be NULL), resid [B] the larger of the
+ * QP's primal / dual residuals (may be NULL) */
+int smpc_id_solve(smpc_id_handle * h, const double * X, double * tau, double * a, double * f, double * resid);
+/* (tests) intermediate results of the last solve, padded layouts of simple-mpc_amd/csrc/smpc_id.h: what = 0 M, 1 nle, 2 J, 3 dJ v, 4 foot
+ * velocities, 5 H [32][32], 6 g [32], 7 C [80][32], 8 l [80], 9 u [80]; every one [B][...] */
+int smpc_id_debug_get(smpc_id_handle * h, int what, double * out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@
 #include "../../include/smpc_robots_builtin.h"
 #include "smpc_cent_engine.h"
 #include "smpc_full_engine.h"
+#include "smpc_id.h"
 #include <cstring>
 #include <memory>
 #include <string>
@@ -919,5 +920,77 @@ extern "C"
       dev_free(d);
       stream_destroy(st);
     });
+  }
+
+  // ---- whole-body inverse-dynamics QP (smpc_id.h) ----
+  int smpc_id_create(const smpc_robot_model * robot, const smpc_id_settings * c, int batch, int device_id, smpc_id_handle ** out)
+  {
+    if (!robot || !c || !out)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (device_count() <= 0)
+      return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the inverse-dynamics engine has no CPU path");
+    if (!c->effort_limit || !c->velocity_limit || !c->q_min || !c->q_max)
+      return fail(SMPC_ERR_INVALID, "effort, velocity and position limits of the actuated joints are required");
+    HostIdSettings hs;
+    hs.dev.friction_coefficient = c->friction_coefficient;
+    hs.dev.ratio_max = c->contact_weight_ratio_max;
+    hs.dev.ratio_min = c->contact_weight_ratio_min;
+    hs.dev.kp_base = c->kp_base;
+    hs.dev.kp_posture = c->kp_posture;
+    hs.dev.kp_contact = c->kp_contact;
+    hs.dev.w_base = c->w_base;
+    hs.dev.w_posture = c->w_posture;
+    hs.dev.w_contact_motion = c->w_contact_motion;
+    hs.dev.w_contact_force = c->w_contact_force;
+    hs.dev.contact_motion_equality = c->contact_motion_equality;
+    hs.dev.control_dt = c->control_dt;
+    hs.dev.admm_iters = c->admm_iters > 0 ? c->admm_iters : 100;
+    hs.dev.rho = c->admm_rho > 0 ? c->admm_rho : 0.1;
+    hs.dev.sigma = c->admm_sigma > 0 ? c->admm_sigma : 1e-6;
+    hs.dev.alpha = c->admm_alpha > 0 ? c->admm_alpha : 1.6;
+    if (!(c->kp_base >= 0.0 && c->kp_posture >= 0.0 && c->kp_contact >= 0.0))
+      return fail(SMPC_ERR_INVALID, "task gains must not be negative");
+    const int na = robot->nv - 6;
+    hs.tau_max.assign(c->effort_limit, c->effort_limit + na);
+    hs.v_max.assign(c->velocity_limit, c->velocity_limit + na);
+    hs.q_min.assign(c->q_min, c->q_min + na);
+    hs.q_max.assign(c->q_max, c->q_max + na);
+    return guarded([&] {
+      if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF)
+        *out = reinterpret_cast<smpc_id_handle *>(static_cast<IdEngineBase *>(new IdEngine<FullGo2>(robot, hs, batch, device_id)));
+      else
+        throw std::runtime_error("the inverse-dynamics engine is instantiated for 13 joints / 4 point feet");
+    });
+  }
+  void smpc_id_destroy(smpc_id_handle * h) { delete reinterpret_cast<IdEngineBase *>(h); }
+  int smpc_id_set_target(smpc_id_handle * h, int instance, const double * q, const double * v, const double * a, const uint8_t * contact, const double * f)
+  {
+    if (!h || !q || !v || !a || !contact || !f)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    IdEngineBase * e = reinterpret_cast<IdEngineBase *>(h);
+    unsigned mask = 0;
+    for (int k = 0; k < e->nf; k++)
+      mask |= contact[k] ? (1u << k) : 0u;
+    return guarded([&] { e->set_target(instance, q, v, a, mask, f); });
+  }
+  int smpc_id_solve(smpc_id_handle * h, const double * X, double * tau, double * a, double * f, double * resid)
+  {
+    if (!h || !X || !tau)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    IdEngineBase * e = reinterpret_cast<IdEngineBase *>(h);
+    return guarded([&] {
+      std::vector<double> ta, tf;
+      if (!a)
+        ta.resize((size_t)e->B * e->nv);
+      if (!f)
+        tf.resize((size_t)e->B * 3 * e->nf);
+      e->solve(X, tau, a ? a : ta.data(), f ? f : tf.data(), resid);
+    });
+  }
+  int smpc_id_debug_get(smpc_id_handle * h, int what, double * out)
+  {
+    if (!h || !out)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { reinterpret_cast<IdEngineBase *>(h)->debug_get(what, out); });
   }
 }

@@ -336,7 +336,7 @@ namespace smpc
   // dyn = false: kinematics / momentum only (terminal node).
   // -------------------------------------------------------------------------------------------------------------
   template <class D, bool DERIV, class SC, class SD>
-  SMPC_DEV void full_dynamics_phases(SC & sc, SD * sd, const DevModel<D> & mg, unsigned mask, bool dyn, FullProf & fp)
+  SMPC_DEV void full_dynamics_phases(SC & sc, SD * sd, const DevModel<D> & mg, unsigned mask, bool dyn, FullProf & fp, bool rows_only = false)
   {
     constexpr int NT = 64;
     constexpr int NJ = D::NJ, NV = D::NV, NQ = D::NQ, NF = D::NF, NCM = D::NCM, NR = SC::NR, FS = D::FS;
@@ -612,6 +612,8 @@ namespace smpc
     SMPC_LANES_END_WAVE
     }
     ftick(fp, 3);
+    if (rows_only) // (inverse-dynamics front end, smpc_id.h: M, S tau - nle, the contact rows and their drift are what it needs)
+      return;
     // ---- M <- M^-1 (bordered symmetric sweep) ; W = M^-1 [S tau - nle | J^T] on the matrix cores ----
     static_assert(sizeof(SC) - offsetof(SC, xnext) >= SC::SWP_DOUBLES * sizeof(double), "the sweep scratch fits the late block");
     fwave_spd_inverse<NV>(sc.M, sc.swp_());

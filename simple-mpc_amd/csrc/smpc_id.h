@@ -1,0 +1,608 @@
+// smpc_id.h -- batched whole-body inverse-dynamics QP: the KinodynamicsID controller of the reference
+// (src/inverse-dynamics/kinodynamics-id.cpp:7-237; SURVEY 8f row f3, the "proxsuite contact-force QP" downstream of MPC::iterate)
+// for robots with 3-D point feet, one wavefront per robot.
+//
+// The reference builds the problem with TSID 1.9 (InverseDynamicsFormulationAccForce + tasks) and solves it with proxsuite's ProxQP;
+// neither library is available, so the formulation is restated (oracle/orc_id.hpp holds the same statement, term by term, with the
+// places where upstream source would decide marked [UPSTREAM-RECALL]):
+//     y = [a ; f],   M_b a + h_b = J_b^T f,   posture / base / contact-motion / contact-force least-squares tasks,
+//     friction pyramids, force bounds, joint position / velocity limits as acceleration bounds, |tau| <= tau_max,   tau = M_a a + h_a - J_a^T f
+// Three kernels, each with its own parity test against the oracle:
+//   id_quant_body     joint-space inertia, bias forces, world-frame foot Jacobians, their drift and the foot velocities: the phases of the
+//                     full-dynamics stage kernel (smpc_full_stage.h) up to the contact rows
+//   id_assemble_body  H, g, C, l, u of the QP (n = nv + 3 nf = 30 variables, m = 76 rows for a quadruped), padded to 32 x 80
+//   qp_admm_body      min 1/2 y^T H y + g^T y, l <= C y <= u by ADMM (the operator splitting of OSQP: K = H + sigma I + C^T diag(rho) C is
+//                     inverted once per solve by the bordered block sweep on the matrix cores, the iterations are matrix-vector
+//                     products out of LDS), warm-started from the previous control tick; then tau
+#pragma once
+#include "smpc_full_stage.h"
+
+namespace smpc
+{
+  struct IdSettingsDev
+  {
+    double friction_coefficient, ratio_max, ratio_min;
+    double kp_base, kp_posture, kp_contact;
+    double w_base, w_posture, w_contact_motion, w_contact_force;
+    int contact_motion_equality, admm_iters;
+    double control_dt, rho, sigma, alpha;
+  };
+  template <class D>
+  struct IdDims
+  {
+    static constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NA = D::NV - 6;
+    static constexpr int N = NV + 3 * NF;                       // variables [a ; f]
+    static constexpr int M = N + 6 + 3 * NF + 4 * NF + NA;      // rows: box | dynamics | contact motion | friction | actuation
+    static constexpr int NP = ((N + 15) / 16) * 16, MP = ((M + 15) / 16) * 16, LDC = NP + 1; // padded sizes ; row stride of C in LDS
+    static constexpr int R_DYN = N, R_MOT = N + 6, R_FRI = R_MOT + 3 * NF, R_ACT = R_FRI + 4 * NF;
+    static_assert(NP == 32, "the K inverse is instantiated for 32 x 32");
+  };
+  constexpr double ID_INF = 1e20;
+
+  template <class D>
+  struct IdBuffers
+  {
+    int B = 0;
+    DevModel<D> * model = nullptr;
+    const double * X = nullptr;                                   // [B][NX] measured states
+    double *Mq = nullptr, *nle = nullptr, *J = nullptr, *Jdv = nullptr, *vfoot = nullptr; // [B][NV NV], [NV], [3 NF][NV], [3 NF], [3 NF]
+    double *H = nullptr, *g = nullptr, *C = nullptr, *l = nullptr, *u = nullptr;           // [B][NP NP], [NP], [MP][NP], [MP], [MP]
+    double *x = nullptr, *z = nullptr, *lam = nullptr;                                     // ADMM iterate [B][NP], [MP], [MP]
+    int * warm = nullptr;                                                                   // [B] 0 = start from scratch
+    double *tq = nullptr, *tv = nullptr, *ta = nullptr, *tf = nullptr;                     // targets [B][NQ], [NV], [NV], [3 NF]
+    unsigned * tmask = nullptr;                                                             // [B]
+    double *tau = nullptr, *a = nullptr, *f = nullptr, *resid = nullptr;                   // [B][NA], [NV], [3 NF], [B]
+    double *tau_max = nullptr, *v_max = nullptr, *q_min = nullptr, *q_max = nullptr;       // [NA] each
+    IdSettingsDev s;
+  };
+
+  // ---- kernel 1: rigid-body quantities ----
+  template <class D>
+  SMPC_DEV void id_quant_body(const IdBuffers<D> & b, int block)
+  {
+    typedef FullScratch<D, false> SC;
+    constexpr int NT = 64, NV = D::NV, NX = D::NX, NF = D::NF, NQ = D::NQ, NR = SC::NR;
+    static_assert(D::FS == 3, "point feet");
+    const int inst = block;
+    const DevModel<D> & mg = *b.model;
+    SMPC_LDS(SC, scs, 1);
+    SC & sc = scs[0];
+    SMPC_LANES(NT)
+    {
+      full_load_head<D, NT>(sc.h, &mg, lane);
+      for (int i = lane; i < NX; i += NT)
+        sc.x[i] = b.X[(size_t)inst * NX + i];
+      for (int i = lane; i < D::NU; i += NT)
+        sc.u[i] = 0.0;
+    }
+    SMPC_LANES_END_WAVE
+    FullProf fp;
+    fp.prof = nullptr;
+    fp.tprev = 0;
+    const unsigned mask = (1u << NF) - 1u; // every foot's rows (the QP decides which are contacts)
+    full_dynamics_phases<D, false>(sc, (FullScratchDeriv<D> *)nullptr, mg, mask, true, fp, true);
+    // M, nle = -(S tau - nle) at tau = 0 ; LOCAL rows -> world frame: J_w = R_f J_loc, drift likewise (Kp = Kd = 0 in this model)
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < NV * NV; idx += NT)
+        b.Mq[(size_t)inst * NV * NV + idx] = sc.M[idx];
+      for (int i = lane; i < NV; i += NT)
+        b.nle[(size_t)inst * NV + i] = -sc.W[i * NR];
+      for (int idx = lane; idx < 3 * NF * NV; idx += NT)
+      {
+        const int r = idx / NV, k = idx % NV, f = r / 3, i = r % 3;
+        const double * Rf = &sc.oR[sc.h.foot_joint[f] * 9];
+        b.J[(size_t)inst * 3 * NF * NV + idx] =
+          Rf[i * 3] * sc.J[(3 * f) * NV + k] + Rf[i * 3 + 1] * sc.J[(3 * f + 1) * NV + k] + Rf[i * 3 + 2] * sc.J[(3 * f + 2) * NV + k];
+      }
+      if (lane < 3 * NF)
+      {
+        const int f = lane / 3, i = lane % 3;
+        const double * Rf = &sc.oR[sc.h.foot_joint[f] * 9];
+        b.Jdv[(size_t)inst * 3 * NF + lane] = Rf[i * 3] * sc.gam[3 * f] + Rf[i * 3 + 1] * sc.gam[3 * f + 1] + Rf[i * 3 + 2] * sc.gam[3 * f + 2];
+        // velocity of the foot point: v_joint.lin + w x p (world frame)
+        const int jf = sc.h.foot_joint[f];
+        const SV v = ldsv(&sc.vel[jf * 6]);
+        const V3 vp = v.l + cross(v.a, ld3(&sc.footp[f * 3]));
+        b.vfoot[(size_t)inst * 3 * NF + lane] = i == 0 ? vp.x : (i == 1 ? vp.y : vp.z);
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // ---- kernel 2: QP data ----
+  template <class D>
+  SMPC_DEV void id_assemble_body(const IdBuffers<D> & b, int block)
+  {
+    typedef IdDims<D> G;
+    constexpr int NT = 64, NV = G::NV, NQ = G::NQ, NF = G::NF, NA = G::NA, N = G::N, NP = G::NP, MP = G::MP;
+    const int inst = block;
+    const IdSettingsDev & s = b.s;
+    const double * x = b.X + (size_t)inst * G::NX;
+    const double * q = x;
+    const double * v = x + NQ;
+    const double * Mq = b.Mq + (size_t)inst * NV * NV;
+    const double * nle = b.nle + (size_t)inst * NV;
+    const double * J = b.J + (size_t)inst * 3 * NF * NV;
+    const double * Jdv = b.Jdv + (size_t)inst * 3 * NF;
+    const double * vf = b.vfoot + (size_t)inst * 3 * NF;
+    const double *tq = b.tq + (size_t)inst * NQ, *tv = b.tv + (size_t)inst * NV, *ta = b.ta + (size_t)inst * NV, *tf = b.tf + (size_t)inst * 3 * NF;
+    const unsigned mask = b.tmask[inst];
+    double * H = b.H + (size_t)inst * NP * NP;
+    double * g = b.g + (size_t)inst * NP;
+    double * C = b.C + (size_t)inst * MP * NP;
+    double * l = b.l + (size_t)inst * MP;
+    double * u = b.u + (size_t)inst * MP;
+    const double kdp = 2.0 * sqrt(s.kp_posture), kdb = 2.0 * sqrt(s.kp_base), kdc = 2.0 * sqrt(s.kp_contact);
+    SMPC_LDS(double, e6, 6);
+    SMPC_LANES(NT)
+    if (lane == 0)
+    { // base error log6(M_b^-1 M_t), local frame
+      const SE3 Mb{quat_to_R(Quat{q[3], q[4], q[5], q[6]}), mk3(q[0], q[1], q[2])};
+      const SE3 Mt{quat_to_R(Quat{tq[3], tq[4], tq[5], tq[6]}), mk3(tq[0], tq[1], tq[2])};
+      V3 ev, ew;
+      log6(se3_mul(se3_inv(Mb), Mt), ev, ew);
+      st3(e6, ev);
+      st3(e6 + 3, ew);
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    {
+      // ---- H (N x N, padded with unit diagonal) and g ----
+      for (int idx = lane; idx < NP * NP; idx += NT)
+      {
+        const int i = idx / NP, j = idx % NP;
+        double h = 0.0;
+        if (i >= N || j >= N)
+          h = (i == j) ? 1.0 : 0.0; // padding variables: pinned by their own unit curvature and zero gradient
+        else
+        {
+          if (i == j && i >= 6 && i < NV && s.w_posture > 0)
+            h += s.w_posture;
+          if (i == j && i < 6 && s.w_base > 0)
+            h += s.w_base;
+          if (i < NV && j < NV && !s.contact_motion_equality && s.w_contact_motion > 0)
+            for (int r = 0; r < 3 * NF; r++)
+              if ((mask >> (r / 3)) & 1u)
+                h += s.w_contact_motion * J[r * NV + i] * J[r * NV + j];
+          if (i == j && i >= NV && s.w_contact_force > 0 && ((mask >> ((i - NV) / 3)) & 1u))
+            h += s.w_contact_force;
+        }
+        H[idx] = h;
+      }
+      for (int i = lane; i < NP; i += NT)
+      {
+        double gi = 0.0;
+        if (i < N)
+        {
+          if (i >= 6 && i < NV && s.w_posture > 0)
+            gi -= s.w_posture * (ta[i] + s.kp_posture * (tq[i + 1] - q[i + 1]) + kdp * (tv[i] - v[i]));
+          if (i < 6 && s.w_base > 0)
+          {
+            const V3 dr = cross(mk3(v[3], v[4], v[5]), mk3(v[0], v[1], v[2]));
+            const double ades = s.kp_base * e6[i] + kdb * (ta[i] - v[i]); // (velocity reference = acceleration target: as coded upstream)
+            gi -= s.w_base * (ades - (i == 0 ? dr.x : (i == 1 ? dr.y : (i == 2 ? dr.z : 0.0))));
+          }
+          if (i < NV && !s.contact_motion_equality && s.w_contact_motion > 0)
+            for (int r = 0; r < 3 * NF; r++)
+              if ((mask >> (r / 3)) & 1u)
+                gi -= s.w_contact_motion * J[r * NV + i] * (-Jdv[r] - kdc * vf[r]);
+          if (i >= NV && s.w_contact_force > 0 && ((mask >> ((i - NV) / 3)) & 1u))
+            gi -= s.w_contact_force * tf[i - NV];
+        }
+        g[i] = gi;
+      }
+      // ---- C, l, u ----
+      for (int idx = lane; idx < MP * NP; idx += NT)
+      {
+        const int r = idx / NP, c = idx % NP;
+        double val = 0.0;
+        if (r < N)
+          val = (r == c) ? 1.0 : 0.0;
+        else if (c < N && r < G::R_MOT)
+        { // dynamics rows: [M_b | -J_b^T]
+          const int i = r - G::R_DYN;
+          val = c < NV ? Mq[i * NV + c] : -J[(c - NV) * NV + i];
+        }
+        else if (c < N && r < G::R_FRI)
+        { // contact motion rows (equality variant, feet in contact)
+          const int rr = r - G::R_MOT;
+          if (s.contact_motion_equality && ((mask >> (rr / 3)) & 1u) && c < NV)
+            val = J[rr * NV + c];
+        }
+        else if (c < N && r < G::R_ACT)
+        { // friction pyramid: +-f_x - mu f_z, +-f_y - mu f_z
+          const int rr = r - G::R_FRI, f = rr / 4, k = rr % 4;
+          if ((mask >> f) & 1u)
+          {
+            if (c == NV + 3 * f + k / 2)
+              val = (k % 2 == 0) ? 1.0 : -1.0;
+            else if (c == NV + 3 * f + 2)
+              val = -s.friction_coefficient;
+          }
+        }
+        else if (c < N && r < G::M)
+        { // actuation rows: [M_a | -J_a^T]
+          const int j = r - G::R_ACT;
+          val = c < NV ? Mq[(6 + j) * NV + c] : -J[(c - NV) * NV + 6 + j];
+        }
+        C[idx] = val;
+      }
+      for (int r = lane; r < MP; r += NT)
+      {
+        double lo = -ID_INF, hi = ID_INF;
+        const double W = b.model->total_mass * 9.81, dt = s.control_dt;
+        if (r >= 6 && r < NV)
+        { // joint limits as acceleration bounds over one control period
+          const int j = r - 6;
+          const double qa = q[7 + j], va = v[6 + j];
+          lo = fmax((-b.v_max[j] - va) / dt, 2.0 * (b.q_min[j] - qa - va * dt) / (dt * dt));
+          hi = fmin((b.v_max[j] - va) / dt, 2.0 * (b.q_max[j] - qa - va * dt) / (dt * dt));
+          if (lo > hi)
+            lo = hi = fmin(lo, hi);
+        }
+        else if (r >= NV && r < N)
+        {
+          const int f = (r - NV) / 3, i = (r - NV) % 3;
+          if (!((mask >> f) & 1u))
+            lo = hi = 0.0;
+          else if (i == 2)
+          {
+            lo = s.ratio_min * W;
+            hi = s.ratio_max * W;
+          }
+        }
+        else if (r >= N && r < G::R_MOT)
+          lo = hi = -nle[r - G::R_DYN];
+        else if (r >= G::R_MOT && r < G::R_FRI)
+        {
+          const int rr = r - G::R_MOT;
+          if (s.contact_motion_equality && ((mask >> (rr / 3)) & 1u))
+            lo = hi = -Jdv[rr] - kdc * vf[rr];
+        }
+        else if (r >= G::R_FRI && r < G::R_ACT)
+        {
+          if ((mask >> ((r - G::R_FRI) / 4)) & 1u)
+            hi = 0.0;
+        }
+        else if (r >= G::R_ACT && r < G::M)
+        {
+          const int j = r - G::R_ACT;
+          lo = -b.tau_max[j] - nle[6 + j];
+          hi = b.tau_max[j] - nle[6 + j];
+        }
+        l[r] = lo;
+        u[r] = hi;
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // ---- kernel 3: ADMM ----
+  template <class D>
+  struct QpLds
+  {
+    typedef IdDims<D> G;
+    double K[G::NP * G::NP];   // H + sigma I + C^T diag(rho) C -> its inverse
+    double C[G::MP * G::LDC];  // row stride NP + 1: columns (lane = variable) and rows (lane = constraint) both read without conflicts
+    double swp[2 * 4 * 16 * ((2 * G::NP + 15) / 16)];
+    double g[G::NP], x[G::NP], rhs[G::NP], xt[G::NP];
+    double l[G::MP], u[G::MP], r[G::MP], z[G::MP], lam[G::MP], w[G::MP], zt[G::MP];
+    double red[64];
+  };
+  template <class D>
+  SMPC_DEV void qp_admm_body(const IdBuffers<D> & b, int block)
+  {
+    typedef IdDims<D> G;
+    constexpr int NT = 64, NV = G::NV, NF = G::NF, NA = G::NA, N = G::N, NP = G::NP, MP = G::MP, M = G::M, LDC = G::LDC;
+    const int inst = block;
+    const IdSettingsDev & st = b.s;
+    const double rho = st.rho, sigma = st.sigma, alpha = st.alpha;
+    SMPC_LDS(QpLds<D>, ls, 1);
+    QpLds<D> & s = ls[0];
+    const double * Hg = b.H + (size_t)inst * NP * NP;
+    const double * Cg = b.C + (size_t)inst * MP * NP;
+    const bool warm = b.warm[inst] != 0;
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < MP * NP; idx += NT)
+        s.C[(idx / NP) * LDC + idx % NP] = Cg[idx];
+      for (int i = lane; i < NP; i += NT)
+      {
+        s.g[i] = b.g[(size_t)inst * NP + i];
+        s.x[i] = warm ? b.x[(size_t)inst * NP + i] : 0.0;
+      }
+      for (int k = lane; k < MP; k += NT)
+      {
+        const double lo = b.l[(size_t)inst * MP + k], hi = b.u[(size_t)inst * MP + k];
+        s.l[k] = lo;
+        s.u[k] = hi;
+        // padding rows (k >= M) are free rows of zeros
+        s.r[k] = (hi - lo < 1e-12) ? 1e3 * rho : ((lo <= -ID_INF && hi >= ID_INF) ? 1e-6 * rho : rho);
+        s.z[k] = warm ? b.z[(size_t)inst * MP + k] : fmin(fmax(0.0, lo), hi);
+        s.lam[k] = warm ? b.lam[(size_t)inst * MP + k] : 0.0;
+      }
+    }
+    SMPC_LANES_END_WAVE
+    // K = H + sigma I + C^T diag(r) C
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NP * NP; idx += NT)
+    {
+      const int i = idx / NP, j = idx % NP;
+      double acc = Hg[idx] + (i == j ? sigma : 0.0);
+      for (int k = 0; k < M; k++)
+        acc += s.r[k] * s.C[k * LDC + i] * s.C[k * LDC + j];
+      s.K[idx] = acc;
+    }
+    SMPC_LANES_END_WAVE
+    fwave_spd_inverse<NP>(s.K, s.swp);
+    for (int it = 0; it < st.admm_iters; it++)
+    {
+      SMPC_LANES(NT)
+      for (int k = lane; k < MP; k += NT)
+        s.w[k] = s.r[k] * s.z[k] - s.lam[k];
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      if (lane < NP)
+      {
+        double acc = sigma * s.x[lane] - s.g[lane];
+        for (int k = 0; k < M; k++)
+          acc += s.C[k * LDC + lane] * s.w[k];
+        s.rhs[lane] = acc;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      if (lane < NP)
+      {
+        double acc = 0.0;
+        for (int j = 0; j < NP; j++)
+          acc += s.K[j * NP + lane] * s.rhs[j]; // (K^-1 is symmetric: read along the row of j)
+        s.xt[lane] = acc;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
+        for (int k = lane; k < MP; k += NT)
+        {
+          double acc = 0.0;
+          for (int i = 0; i < NP; i++)
+            acc += s.C[k * LDC + i] * s.xt[i];
+          s.zt[k] = acc;
+        }
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
+        if (lane < NP)
+          s.x[lane] = alpha * s.xt[lane] + (1.0 - alpha) * s.x[lane];
+        for (int k = lane; k < MP; k += NT)
+        {
+          const double zh = alpha * s.zt[k] + (1.0 - alpha) * s.z[k];
+          const double zn = fmin(fmax(zh + s.lam[k] / s.r[k], s.l[k]), s.u[k]);
+          s.lam[k] += s.r[k] * (zh - zn);
+          s.z[k] = zn;
+        }
+      }
+      SMPC_LANES_END_WAVE
+    }
+    // residuals of the returned iterate: |C x - z|_inf, |H x + g + C^T lam|_inf
+    SMPC_LANES(NT)
+    {
+      double pr = 0.0;
+      for (int k = lane; k < M; k += NT)
+      {
+        double acc = 0.0;
+        for (int i = 0; i < N; i++)
+          acc += s.C[k * LDC + i] * s.x[i];
+        pr = fmax(pr, fabs(acc - s.z[k]));
+      }
+      double du = 0.0;
+      if (lane < N)
+      {
+        double acc = s.g[lane];
+        for (int j = 0; j < N; j++)
+          acc += Hg[lane * NP + j] * s.x[j];
+        for (int k = 0; k < M; k++)
+          acc += s.C[k * LDC + lane] * s.lam[k];
+        du = fabs(acc);
+      }
+      s.red[lane] = fmax(pr, du);
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    {
+      for (int i = lane; i < NP; i += NT)
+        b.x[(size_t)inst * NP + i] = s.x[i];
+      for (int k = lane; k < MP; k += NT)
+      {
+        b.z[(size_t)inst * MP + k] = s.z[k];
+        b.lam[(size_t)inst * MP + k] = s.lam[k];
+      }
+      for (int i = lane; i < NV; i += NT)
+        b.a[(size_t)inst * NV + i] = s.x[i];
+      for (int i = lane; i < 3 * NF; i += NT)
+        b.f[(size_t)inst * 3 * NF + i] = s.x[NV + i];
+      if (lane < NA)
+      { // tau = M_a a + h_a - J_a^T f
+        const double * Mq = b.Mq + (size_t)inst * NV * NV;
+        const double * J = b.J + (size_t)inst * 3 * NF * NV;
+        double acc = b.nle[(size_t)inst * NV + 6 + lane];
+        for (int k = 0; k < NV; k++)
+          acc += Mq[(6 + lane) * NV + k] * s.x[k];
+        for (int r = 0; r < 3 * NF; r++)
+          acc -= J[r * NV + 6 + lane] * s.x[NV + r];
+        b.tau[(size_t)inst * NA + lane] = acc;
+      }
+      if (lane == 0)
+      {
+        double m = 0.0;
+        for (int i = 0; i < 64; i++)
+          m = fmax(m, s.red[i]);
+        b.resid[inst] = m;
+        b.warm[inst] = 1;
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // ---- host engine ----
+  struct HostIdSettings
+  {
+    IdSettingsDev dev;
+    std::vector<double> tau_max, v_max, q_min, q_max;
+  };
+  struct IdEngineBase
+  {
+    int B = 0, nq = 0, nv = 0, nf = 0, n = 0, m = 0, np = 0, mp = 0;
+    virtual ~IdEngineBase() {}
+    virtual void set_target(int inst, const double * q, const double * v, const double * a, unsigned mask, const double * f) = 0;
+    virtual void solve(const double * X, double * tau, double * a, double * f, double * resid) = 0;
+    virtual void debug_get(int what, double * out) = 0; // 0 M, 1 nle, 2 J, 3 Jdv, 4 vfoot, 5 H, 6 g, 7 C, 8 l, 9 u (padded layouts)
+  };
+  template <class D>
+  struct IdEngine : IdEngineBase
+  {
+    typedef IdDims<D> G;
+    IdBuffers<D> buf;
+    stream_t stream;
+    int device_id = 0;
+    double * Xd = nullptr;
+    std::vector<void *> allocs;
+    IdEngine(const smpc_robot_model * rm, const HostIdSettings & hs, int batch, int device)
+    {
+      if (rm->njoints != D::NJ || rm->nfeet != D::NF)
+        throw std::runtime_error("robot shape (njoints, nfeet) does not match this kernel instantiation");
+      if (batch <= 0)
+        throw std::runtime_error("batch must be positive");
+      if ((int)hs.tau_max.size() != G::NA || (int)hs.v_max.size() != G::NA || (int)hs.q_min.size() != G::NA || (int)hs.q_max.size() != G::NA)
+        throw std::runtime_error("inverse-dynamics settings: limit vectors must have nv - 6 entries");
+      if (!(hs.dev.control_dt > 0.0) || hs.dev.admm_iters <= 0)
+        throw std::runtime_error("inverse-dynamics settings: control_dt and the iteration count must be positive");
+      device_id = device;
+      set_device(device);
+      stream = stream_create();
+      B = batch;
+      nq = D::NQ;
+      nv = D::NV;
+      nf = D::NF;
+      n = G::N;
+      m = G::M;
+      np = G::NP;
+      mp = G::MP;
+      std::vector<DevModel<D>> hm(1);
+      std::memset(&hm[0], 0, sizeof(DevModel<D>));
+      fill_tree_model<D>(rm, hm[0]);
+      hm[0].gravity[2] = -9.81; // (Kp = Kd = 0: plain contact rows)
+      auto dalloc = [&](size_t cnt) {
+        void * p = dev_alloc(cnt * sizeof(double));
+        dev_zero(p, cnt * sizeof(double), stream);
+        allocs.push_back(p);
+        return (double *)p;
+      };
+      buf.B = B;
+      buf.model = (DevModel<D> *)dev_alloc(sizeof(DevModel<D>));
+      allocs.push_back(buf.model);
+      h2d(buf.model, hm.data(), sizeof(DevModel<D>), stream);
+      const size_t Bs = (size_t)B;
+      Xd = dalloc(Bs * D::NX);
+      buf.X = Xd;
+      buf.Mq = dalloc(Bs * nv * nv);
+      buf.nle = dalloc(Bs * nv);
+      buf.J = dalloc(Bs * 3 * nf * nv);
+      buf.Jdv = dalloc(Bs * 3 * nf);
+      buf.vfoot = dalloc(Bs * 3 * nf);
+      buf.H = dalloc(Bs * np * np);
+      buf.g = dalloc(Bs * np);
+      buf.C = dalloc(Bs * mp * np);
+      buf.l = dalloc(Bs * mp);
+      buf.u = dalloc(Bs * mp);
+      buf.x = dalloc(Bs * np);
+      buf.z = dalloc(Bs * mp);
+      buf.lam = dalloc(Bs * mp);
+      buf.warm = (int *)dev_alloc(Bs * sizeof(int));
+      allocs.push_back(buf.warm);
+      dev_zero(buf.warm, Bs * sizeof(int), stream);
+      buf.tq = dalloc(Bs * nq);
+      buf.tv = dalloc(Bs * nv);
+      buf.ta = dalloc(Bs * nv);
+      buf.tf = dalloc(Bs * 3 * nf);
+      buf.tmask = (unsigned *)dev_alloc(Bs * sizeof(unsigned));
+      allocs.push_back(buf.tmask);
+      buf.tau = dalloc(Bs * G::NA);
+      buf.a = dalloc(Bs * nv);
+      buf.f = dalloc(Bs * 3 * nf);
+      buf.resid = dalloc(Bs);
+      buf.tau_max = dalloc(G::NA);
+      buf.v_max = dalloc(G::NA);
+      buf.q_min = dalloc(G::NA);
+      buf.q_max = dalloc(G::NA);
+      h2d(buf.tau_max, hs.tau_max.data(), G::NA * sizeof(double), stream);
+      h2d(buf.v_max, hs.v_max.data(), G::NA * sizeof(double), stream);
+      h2d(buf.q_min, hs.q_min.data(), G::NA * sizeof(double), stream);
+      h2d(buf.q_max, hs.q_max.data(), G::NA * sizeof(double), stream);
+      buf.s = hs.dev;
+      stream_sync(stream);
+      // default target: the reference state, every foot in contact with an equal share of the weight (kinodynamics-id.cpp:96-112)
+      std::vector<double> q(rm->q_ref, rm->q_ref + nq), z(nv, 0.0), f(3 * nf, 0.0);
+      for (int k = 0; k < nf; k++)
+        f[3 * k + 2] = rm->total_mass * 9.81 / nf;
+      set_target(-1, q.data(), z.data(), z.data(), (1u << nf) - 1u, f.data());
+    }
+    ~IdEngine()
+    {
+      for (void * p : allocs)
+        dev_free(p);
+      stream_destroy(stream);
+    }
+    void set_target(int inst, const double * q, const double * v, const double * a, unsigned mask, const double * f) override
+    {
+      set_device(device_id);
+      if (inst >= B)
+        throw std::runtime_error("instance index exceeds the batch");
+      const int i0 = inst < 0 ? 0 : inst, i1 = inst < 0 ? B : inst + 1;
+      std::vector<double> tq((size_t)(i1 - i0) * nq), tv((size_t)(i1 - i0) * nv), ta((size_t)(i1 - i0) * nv), tf((size_t)(i1 - i0) * 3 * nf);
+      std::vector<unsigned> tm(i1 - i0, mask);
+      for (int i = 0; i < i1 - i0; i++)
+      {
+        std::copy(q, q + nq, tq.begin() + (size_t)i * nq);
+        std::copy(v, v + nv, tv.begin() + (size_t)i * nv);
+        std::copy(a, a + nv, ta.begin() + (size_t)i * nv);
+        std::copy(f, f + 3 * nf, tf.begin() + (size_t)i * 3 * nf);
+      }
+      h2d(buf.tq + (size_t)i0 * nq, tq.data(), tq.size() * sizeof(double), stream);
+      h2d(buf.tv + (size_t)i0 * nv, tv.data(), tv.size() * sizeof(double), stream);
+      h2d(buf.ta + (size_t)i0 * nv, ta.data(), ta.size() * sizeof(double), stream);
+      h2d(buf.tf + (size_t)i0 * 3 * nf, tf.data(), tf.size() * sizeof(double), stream);
+      h2d(buf.tmask + i0, tm.data(), tm.size() * sizeof(unsigned), stream);
+      stream_sync(stream);
+    }
+    void launch_all()
+    {
+      launch<IdBuffers<D>, id_quant_body<D>, 64, 1, 0>(B, stream, buf);
+      launch<IdBuffers<D>, id_assemble_body<D>, 64, 1, 0>(B, stream, buf);
+      launch<IdBuffers<D>, qp_admm_body<D>, 64, 1, 0>(B, stream, buf);
+    }
+    void solve(const double * X, double * tau, double * a, double * f, double * resid) override
+    {
+      set_device(device_id);
+      h2d(Xd, X, (size_t)B * D::NX * sizeof(double), stream);
+      launch_all();
+      d2h(tau, buf.tau, (size_t)B * G::NA * sizeof(double), stream);
+      d2h(a, buf.a, (size_t)B * nv * sizeof(double), stream);
+      d2h(f, buf.f, (size_t)B * 3 * nf * sizeof(double), stream);
+      if (resid)
+        d2h(resid, buf.resid, (size_t)B * sizeof(double), stream);
+      stream_sync(stream);
+    }
+    void debug_get(int what, double * out) override
+    {
+      set_device(device_id);
+      const double * src[10] = {buf.Mq, buf.nle, buf.J, buf.Jdv, buf.vfoot, buf.H, buf.g, buf.C, buf.l, buf.u};
+      const size_t per[10] = {(size_t)nv * nv, (size_t)nv, (size_t)3 * nf * nv, (size_t)3 * nf, (size_t)3 * nf, (size_t)np * np, (size_t)np, (size_t)mp * np, (size_t)mp, (size_t)mp};
+      if (what < 0 || what > 9)
+        throw std::runtime_error("unknown quantity");
+      d2h(out, src[what], (size_t)B * per[what] * sizeof(double), stream);
+      stream_sync(stream);
+    }
+  };
+} // namespace smpc

@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import CentroidalSettingsC, FullDynamicsSettingsC, KinodynamicsSettingsC, MpcSettingsC, SmpcLib, default_lib
+from ._capi import IdSettingsC, CentroidalSettingsC, FullDynamicsSettingsC, KinodynamicsSettingsC, MpcSettingsC, SmpcLib, default_lib
 
 __all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "CentroidalOCP", "FullDynamicsOCP", "MPC", "BatchedMPC", "Interpolator", "FrictionCompensation", "centroidal_dynamics"]
 
@@ -1075,6 +1075,89 @@ class Interpolator:
     def interpolateContacts(self, delay, timestep, cs):
         step = int(delay / timestep)
         return list(cs[min(max(step, 0), len(cs) - 1)])
+
+
+class KinodynamicsID:
+    """Whole-body inverse-dynamics controller of the reference (include/simple-mpc/inverse-dynamics/kinodynamics-id.hpp:17-92,
+    src/inverse-dynamics/kinodynamics-id.cpp:7-237; bindings/expose-kinodynamics-id.cpp), batched: `batch` robots, one QP each per
+    control tick, solved on the device (simple-mpc_amd/csrc/smpc_id.h).  `settings`: the reference's KinodynamicsIDSettings keys
+    (friction_coefficient, contact_weight_ratio_max / min, kp_base, kp_posture, kp_contact, w_base, w_posture, w_contact_motion,
+    w_contact_force, contact_motion_equality).  The reference reads effort and velocity limits from its pinocchio model; the robot table
+    holds position limits only, so `effort_limit` and `velocity_limit` (nv - 6 each) are arguments.  3-D point feet."""
+
+    _KEYS = ["friction_coefficient", "contact_weight_ratio_max", "contact_weight_ratio_min", "kp_base", "kp_posture", "kp_contact", "w_base",
+             "w_posture", "w_contact_motion", "w_contact_force", "contact_motion_equality"]
+    _DEFAULTS = dict(friction_coefficient=0.6, contact_weight_ratio_max=10.0, contact_weight_ratio_min=0.01, kp_base=0.0, kp_posture=0.0,
+                     kp_contact=0.0, w_base=-1.0, w_posture=-1.0, w_contact_motion=-1.0, w_contact_force=-1.0, contact_motion_equality=False)
+
+    def __init__(self, model_handler, control_dt, settings, effort_limit, velocity_limit, batch=1, device_id=0, lib=None, admm_iters=0):
+        unknown = [k for k in settings if k not in self._KEYS]
+        if unknown:
+            raise KeyError("unknown KinodynamicsID settings: %s" % unknown)
+        self.settings = dict(self._DEFAULTS, **settings)
+        self.model_handler = model_handler
+        self._lib = lib or default_lib()
+        self.B = int(batch)
+        na = model_handler.nv - 6
+        self._keep = [np.ascontiguousarray(np.array(a, dtype=np.float64)) for a in
+                      (effort_limit, velocity_limit, model_handler.lowerPositionLimit[7:], model_handler.upperPositionLimit[7:])]
+        if any(a.shape != (na,) for a in self._keep):
+            raise RuntimeError("effort_limit and velocity_limit must have nv - 6 entries")
+        s = self.settings
+        c = IdSettingsC(s["friction_coefficient"], s["contact_weight_ratio_max"], s["contact_weight_ratio_min"], s["kp_base"], s["kp_posture"],
+                        s["kp_contact"], s["w_base"], s["w_posture"], s["w_contact_motion"], s["w_contact_force"],
+                        int(bool(s["contact_motion_equality"])), float(control_dt), *[a.ctypes.data for a in self._keep], int(admm_iters), 0.0, 0.0, 0.0)
+        h = C.c_void_p()
+        self._lib.check(self._lib.L.smpc_id_create(model_handler._ptr, C.byref(c), self.B, device_id, C.byref(h)))
+        self._h = h
+        self._nq, self._nv, self._nf = model_handler.nq, model_handler.nv, model_handler.getFeetNb()
+        self._a = np.zeros((self.B, self._nv))
+        self._f = np.zeros((self.B, 3 * self._nf))
+        self.resid = np.zeros(self.B)
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.L.smpc_id_destroy(self._h)
+            self._h = None
+
+    def setTarget(self, q_target, v_target, a_target, contact_state_target, f_target, instance=-1):
+        """reference kinodynamics-id.cpp:120-183.  f_target: one 3-vector per foot (a list, or an array [nf][3]); instance = -1: every robot."""
+        c = lambda x, n: np.ascontiguousarray(np.array(x, dtype=np.float64).reshape(n))
+        contact = np.ascontiguousarray(np.array([1 if b else 0 for b in contact_state_target], dtype=np.uint8))
+        if contact.size != self._nf:
+            raise RuntimeError("contact_state_target must have one entry per foot")
+        f = np.zeros(3 * self._nf) if len(f_target) == 0 else c(f_target, 3 * self._nf)  # (the reference's tests pass {} with no contact)
+        self._lib.check(self._lib.L.smpc_id_set_target(self._h, int(instance), c(q_target, self._nq), c(v_target, self._nv), c(a_target, self._nv), contact, f))
+
+    def solve(self, t, q_meas, v_meas, tau_res=None):
+        """reference kinodynamics-id.cpp:185-237: one robot (vectors) or the batch (q_meas [B][nq], v_meas [B][nv]); returns tau (and fills
+        tau_res when given, as the reference does)."""
+        q, v = np.array(q_meas, dtype=np.float64), np.array(v_meas, dtype=np.float64)
+        single = q.ndim == 1
+        X = np.ascontiguousarray(np.concatenate([q.reshape(self.B, self._nq), v.reshape(self.B, self._nv)], axis=1))
+        tau = np.zeros((self.B, self._nv - 6))
+        self._lib.check(self._lib.L.smpc_id_solve(self._h, X, tau, self._a.ctypes.data, self._f.ctypes.data, self.resid.ctypes.data))
+        out = tau[0] if single else tau
+        if tau_res is not None:
+            tau_res[...] = out
+        return out
+
+    def getAccelerations(self, ddq=None):
+        out = self._a[0] if self.B == 1 else self._a
+        if ddq is not None:
+            ddq[...] = out
+        return out.copy()
+
+    def getContactForces(self):
+        """Contact forces of the last solution, [B][nf][3] (world frame)."""
+        return self._f.reshape(self.B, self._nf, 3).copy()
+
+    def debug(self, what):
+        per = {0: (self._nv, self._nv), 1: (self._nv,), 2: (3 * self._nf, self._nv), 3: (3 * self._nf,), 4: (3 * self._nf,), 5: (32, 32), 6: (32,),
+               7: (80, 32), 8: (80,), 9: (80,)}[what]
+        out = np.zeros((self.B,) + per)
+        self._lib.check(self._lib.L.smpc_id_debug_get(self._h, what, out))
+        return out
 
 
 class FrictionCompensation:

@@ -102,6 +102,19 @@ class MpcSettingsC(C.Structure):
 MAXJ, MAXF, NAME = 32, 4, 32
 
 
+class IdSettingsC(C.Structure):
+    """Mirror of smpc_id_settings (include/smpc.h)."""
+
+    _fields_ = [
+        ("friction_coefficient", C.c_double), ("contact_weight_ratio_max", C.c_double), ("contact_weight_ratio_min", C.c_double),
+        ("kp_base", C.c_double), ("kp_posture", C.c_double), ("kp_contact", C.c_double),
+        ("w_base", C.c_double), ("w_posture", C.c_double), ("w_contact_motion", C.c_double), ("w_contact_force", C.c_double),
+        ("contact_motion_equality", C.c_int), ("control_dt", C.c_double),
+        ("effort_limit", C.c_void_p), ("velocity_limit", C.c_void_p), ("q_min", C.c_void_p), ("q_max", C.c_void_p),
+        ("admm_iters", C.c_int), ("admm_rho", C.c_double), ("admm_sigma", C.c_double), ("admm_alpha", C.c_double),
+    ]
+
+
 class RobotModelC(C.Structure):
     """Mirror of smpc_robot_model (include/smpc_robot.h)."""
 
@@ -139,6 +152,7 @@ SYMBOLS = [
     "smpc_get_foot_timing", "smpc_get_info", "smpc_get_status", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
     "smpc_debug_get_steps", "smpc_debug_get_terminal", "smpc_debug_get_phase_cycles", "smpc_set_profiling", "smpc_get_kernel_times", "smpc_reset_kernel_times",
     "smpc_interpolate", "smpc_interpolate_knots", "smpc_friction_compensation", "smpc_update_internal_data", "smpc_full_forward_dynamics", "smpc_centroidal_dynamics", "smpc_riccati_feedback",
+    "smpc_id_create", "smpc_id_destroy", "smpc_id_set_target", "smpc_id_solve", "smpc_id_debug_get",
 ]
 
 
@@ -183,6 +197,12 @@ class SmpcLib:
         L.smpc_get_reference_pose.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp]
         L.smpc_get_contact_state.argtypes = [vp, C.c_int, _bp]
         L.smpc_get_cycling_contact_state.argtypes = [vp, C.c_int, C.c_void_p]
+        L.smpc_id_create.argtypes = [vp, C.POINTER(IdSettingsC), C.c_int, C.c_int, C.POINTER(vp)]
+        L.smpc_id_destroy.argtypes = [vp]
+        L.smpc_id_destroy.restype = None
+        L.smpc_id_set_target.argtypes = [vp, C.c_int, _dp, _dp, _dp, _bp, _dp]
+        L.smpc_id_solve.argtypes = [vp, _dp, _dp, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.smpc_id_debug_get.argtypes = [vp, C.c_int, _dp]
         L.smpc_get_status.argtypes = [vp, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]
         L.smpc_debug_get_extra_multipliers.argtypes = [vp, C.c_int, _dp]
         L.smpc_set_x_reference.argtypes = [vp, _dp]

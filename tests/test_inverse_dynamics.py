@@ -1,0 +1,125 @@
+"""Batched whole-body inverse-dynamics QP on the device (simple-mpc_amd/csrc/smpc_id.h) against the oracle
+(oracle/orc_id.hpp): the three kernels one by one -- rigid-body quantities, QP data, ADMM iterate -- and closed loops integrated like the
+reference's tests (tests/inverse-dynamics/kinodynamics-id.cpp:53-60).  CPU tier: the kernel bodies compiled for the CPU; GPU tier: HIP."""
+import numpy as np
+import pytest
+
+import mpc_setup as S
+import oracle_lib as O
+import simple_mpc
+from test_oracle_id import DT, crouch, static_forces, step
+
+KEYS = simple_mpc.KinodynamicsID._KEYS
+ALL = dict(kp_base=10.0, kp_posture=1.0, kp_contact=10.0, w_base=10.0, w_posture=0.1, w_contact_force=1e-3, w_contact_motion=1.0)
+
+
+def make(lib, B, admm_iters=100, **kw):
+    rb = O.Robot("go2_like")
+    s = O.id_settings(rb, DT, admm_iters=admm_iters, **kw)
+    ok = O.OracleKinoID(rb, s, B)
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+    for n in S.FEET:
+        mh.addPointFoot(n, "root_joint")
+    gk = simple_mpc.KinodynamicsID(mh, DT, {k: s[k] for k in KEYS}, s["tau_max"], s["v_max"], batch=B, lib=lib, admm_iters=admm_iters)
+    return rb, ok, gk
+
+
+def _pieces(lib):
+    rb, ok, gk = make(lib, 3, **ALL)
+    X = S.random_states(rb, 3)
+    fs = static_forces(rb)
+    for k in (ok, gk):
+        k.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True, True, False, True], fs, instance=1)  # one robot with a foot in the air
+    to, ao, fo = ok.solve(X)
+    tg = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
+    n, m = ok.n, ok.m
+    for b in range(3):
+        Q = O.id_quantities(rb, X[b])
+        for what, key in ((0, "M"), (1, "nle"), (2, "J"), (3, "Jdv"), (4, "vfoot")):
+            assert S.rel_err(Q[key], gk.debug(what)[b]) < 1e-11, key
+        H, g, Cm, l, u = ok.qp(b, X[b])
+        assert S.rel_err(H, gk.debug(5)[b][:n, :n]) < 1e-11 and S.rel_err(g, gk.debug(6)[b][:n]) < 1e-11
+        assert S.rel_err(Cm, gk.debug(7)[b][:m, :n]) < 1e-11
+        lg, ug = gk.debug(8)[b][:m], gk.debug(9)[b][:m]
+        assert np.array_equal(np.abs(l) > 1e19, np.abs(lg) > 1e19) and np.array_equal(np.abs(u) > 1e19, np.abs(ug) > 1e19)
+        fin = np.abs(l) < 1e19
+        assert np.allclose(l[fin], lg[fin], rtol=1e-11, atol=1e-9) and np.allclose(u[np.abs(u) < 1e19], ug[np.abs(u) < 1e19], rtol=1e-11, atol=1e-9)
+    assert S.rel_err(to, tg) < 1e-8 and S.rel_err(ao, gk.getAccelerations()) < 1e-8 and S.rel_err(fo, gk.getContactForces().reshape(3, -1)) < 1e-8
+    assert np.allclose(gk.getContactForces()[1, 2], 0.0, atol=1e-6)  # the foot in the air carries nothing (to the ADMM residual)
+    assert gk.resid.max() < 1e-3 and np.allclose(gk.resid, ok.resid, rtol=1e-3, atol=1e-9)
+
+
+def _closed_loop(lib, n_steps, tol):
+    rb, ok, gk = make(lib, 2, **ALL)
+    fs = static_forces(rb)
+    for k in (ok, gk):
+        k.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True] * 4, fs)
+    X = np.stack([crouch(rb), S.random_states(rb, 1, scale=0.3)[0]])
+    prev = None
+    for _ in range(n_steps):
+        to, ao, fo = ok.solve(X)
+        tg = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
+        assert S.rel_err(to, tg) < tol and S.rel_err(ao, gk.getAccelerations()) < tol
+        assert np.all(np.abs(tg) <= O.GO2_EFFORT + 1e-6)
+        X = np.stack([step(rb, X[b], ao[b]) for b in range(2)])
+        e = np.linalg.norm(rb.difference(X[0], rb.x_ref)[: rb.nv])
+        assert prev is None or e <= prev  # the whole-state error of the crouched robot decreases (reference test :293-297)
+        prev = e
+
+
+def test_emulated_kernels_pieces(built):
+    _pieces(S.emu_lib())
+
+
+def test_emulated_kernels_closed_loop(built):
+    _closed_loop(S.emu_lib(), 60, 1e-7)
+
+
+def test_settings_and_errors(built):
+    lib = S.emu_lib()
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+    for n in S.FEET:
+        mh.addPointFoot(n, "root_joint")
+    with pytest.raises(KeyError):
+        simple_mpc.KinodynamicsID(mh, DT, {"kp_bas": 1.0}, O.GO2_EFFORT, O.GO2_VMAX, lib=lib)
+    with pytest.raises(RuntimeError, match="nv - 6"):
+        simple_mpc.KinodynamicsID(mh, DT, {}, O.GO2_EFFORT[:5], O.GO2_VMAX, lib=lib)
+    with pytest.raises(RuntimeError, match="control_dt"):
+        simple_mpc.KinodynamicsID(mh, 0.0, {}, O.GO2_EFFORT, O.GO2_VMAX, lib=lib)
+    k = simple_mpc.KinodynamicsID(mh, DT, {"kp_posture": 20.0, "w_posture": 1.0}, O.GO2_EFFORT, O.GO2_VMAX, lib=lib)
+    x = mh.getReferenceState()
+    k.setTarget(x[: mh.nq], np.zeros(mh.nv), np.zeros(mh.nv), [False] * 4, [])  # no contact, no forces: the reference's posture test
+    tau = np.zeros(mh.nv - 6)
+    assert k.solve(0.0, x[: mh.nq], x[mh.nq :], tau) is not None and np.all(np.isfinite(tau))
+    ddq = np.zeros(mh.nv)
+    k.getAccelerations(ddq)
+    assert abs(ddq[2] + 9.81) < 1e-6  # free fall of the base, posture held
+
+
+@pytest.mark.gpu
+def test_hip_pieces(built):
+    _pieces(None)
+
+
+@pytest.mark.gpu
+def test_hip_closed_loop(built):
+    _closed_loop(None, 200, 1e-7)
+
+
+@pytest.mark.gpu
+def test_hip_batch_of_4096_robots(built):
+    """4096 robots, 16 distinct states replicated: replicas bit-identical, the distinct ones follow the oracle, limits respected."""
+    B, nd = 4096, 16
+    rb, ok, gk = make(None, B, **ALL)
+    ok = O.OracleKinoID(rb, O.id_settings(rb, DT, **ALL), nd)
+    fs = static_forces(rb)
+    for k in (ok, gk):
+        k.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True] * 4, fs)
+    Xo = S.random_states(rb, nd, seed=3, scale=0.5)
+    for _ in range(3):
+        X = np.tile(Xo, (B // nd, 1))
+        tg = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :]).reshape(B // nd, nd, -1)
+        to, ao, fo = ok.solve(Xo)
+        assert np.abs(tg - tg[0:1]).max() == 0.0 and S.rel_err(to, tg[0]) < 1e-7
+        assert np.all(np.abs(tg) <= O.GO2_EFFORT + 1e-6)
+        Xo = np.stack([step(rb, Xo[b], ao[b]) for b in range(nd)])
