@@ -218,6 +218,47 @@ def constraint_dynamics_line(gm, mh, batch, horizon):
             "kernel_ms": min(ms), "states": n, "dtype": "f64", "note": "smpc_full_forward_dynamics: the forward dynamics kernel alone"}
 
 
+def inverse_dynamics_line(batch, device_id, with_cpu=True):
+    """Whole-body inverse-dynamics QP (KinodynamicsID, SURVEY 8f row f3): one QP per robot and control tick, `batch` robots per call;
+    all tasks on, the 1 kHz settings of the reference's tests.  Timed around solve() -- host copies of the states and torques included."""
+    import numpy as np
+    import simple_mpc
+    from simple_mpc import presets as P
+
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like"), "standing", "root_joint")
+    for n in P.GO2_FEET:
+        mh.addPointFoot(n, "root_joint")
+    eff, vmax = np.array([23.7, 23.7, 45.43] * 4), np.array([30.1, 30.1, 15.7] * 4)
+    st = dict(kp_base=10.0, kp_posture=1.0, kp_contact=10.0, w_base=10.0, w_posture=0.1, w_contact_force=1e-3, w_contact_motion=1.0)
+    kid = simple_mpc.KinodynamicsID(mh, 1e-3, st, eff, vmax, batch=batch, device_id=device_id)
+    X = P.random_states(mh, batch, scale=0.3)
+    q, v = X[:, : mh.nq], X[:, mh.nq :]
+    for _ in range(3):
+        kid.solve(0.0, q, v)
+    t0, n = time.perf_counter(), 20
+    for _ in range(n):
+        kid.solve(0.0, q, v)
+    dt = (time.perf_counter() - t0) / n
+    out = {"metric": "whole-body inverse-dynamics QPs/sec (KinodynamicsID: 30 variables, 76 rows, 100 ADMM iterations)", "value": batch / dt,
+           "unit": "QPs/s", "ms_per_call": dt * 1e3, "batch": batch, "dtype": "f64", "max_residual": float(kid.resid.max()),
+           "note": "smpc_id_solve: rigid-body quantities + QP assembly + ADMM, three kernels; host copies included"}
+    if with_cpu:
+        S, O = _oracle_imports()
+        threads = O.use_effective_cpus()
+        rbc = O.Robot("go2_like")
+        Bc = 8 * threads
+        ok = O.OracleKinoID(rbc, O.id_settings(rbc, 1e-3, **st), Bc)
+        Xc = S.random_states(rbc, Bc, scale=0.3)
+        ok.solve(Xc)
+        t0, n = time.time(), 0
+        while time.time() - t0 < 3.0:
+            ok.solve(Xc)
+            n += 1
+        out["cpu_baseline"] = {"value": Bc * n / (time.time() - t0), "unit": "QPs/s", "cores": threads, "kind": "port",
+                               "sample": "CPU restatement (oracle/, not TSID / ProxQP): %d robots x %d ticks, same ADMM" % (Bc, n)}
+    return out
+
+
 def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     """BASELINE config "Go2 centroidal (9-dim state), H=50, batch=4096": same step definition on the centroidal OCP
     (one fused kernel per control step).  Measured states: x_ref (+) N(0, sigma^2), resident in HBM, re-drawn on the
@@ -592,6 +633,7 @@ def main():
             other["centroidal"] = centroidal_line(B, args.iters, 10, 3, local_rank, not args.no_cpu_baseline)
             other["fulldynamics_go2"] = fulldynamics_line(min(B, 4096), args.iters, 10, 3, local_rank, not args.no_cpu_baseline)
             other["fulldynamics_talos"] = fulldynamics_line(1024, args.iters, 5, 2, local_rank, not args.no_cpu_baseline, robot="talos")
+            other["inverse_dynamics_qp"] = inverse_dynamics_line(B, local_rank, not args.no_cpu_baseline)
             out["other_workloads"] = other
         print(json.dumps(out))
     if dist is not None:
