@@ -357,6 +357,8 @@ void smpc_id_destroy(smpc_id_handle * h);
 /* setTarget(q, v, a, contact_state, f) (kinodynamics-id.cpp:120-183) of one instance, or of every instance (instance < 0):
  * q (nq), v (nv), a (nv), contact flag per foot, f (3 per foot, world frame) */
 int smpc_id_set_target(smpc_id_handle * h, int instance, const double * q, const double * v, const double * a, const uint8_t * contact, const double * f);
+/* one target per robot of the batch: Q [B][nq], V [B][nv], A [B][nv], contact [B][nfeet], F [B][3 nfeet] */
+int smpc_id_set_targets(smpc_id_handle * h, const double * Q, const double * V, const double * A, const uint8_t * contact, const double * F);
 /* solve(t, q_meas, v_meas, tau) + getAccelerations for the batch (kinodynamics-id.cpp:185-237): X [B][nq + nv] (host) ->
  * tau [B][nv - 6], a [B][nv] (may be NULL), f [B][3 nfeet] contact forces of the solution (may be NULL), resid [B] the larger of the
  * QP's primal / dual residuals (may be NULL) */

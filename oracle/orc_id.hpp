@@ -9,9 +9,12 @@
 //   variables        y = [a (nv) ; f (3 per foot, world frame)]                    (inactive feet keep their variables, pinned to 0)
 //   equality         M_b a + h_b = J_b^T f                                         (the six unactuated rows of the dynamics)
 //   posture task     w_posture |a_j - (a_t + Kp (q_t - q) + Kd (v_t - v))|^2      (Kd = 2 sqrt(Kp) everywhere, as the reference sets it)
-//   base task        w_base |a_b + drift - (Kp log6(M_b^-1 M_t) + Kd (v_ref - v_b))|^2, local frame, drift = [w x v ; 0]
-//                    (v_ref: the reference hands its base ACCELERATION target to TSID as the velocity reference -- setDerivative is called
-//                     twice, kinodynamics-id.cpp:222-223 -- and no acceleration reference; restated as coded)
+//   base task        w_base |a_b + drift - (Kp log6(M_b^-1 M_t) + Kd (v_t - v_b) + a_t)|^2, local frame, drift = [w x v ; 0]
+//                    (as coded, kinodynamics-id.cpp:222-223 calls setDerivative twice: the base ACCELERATION target becomes TSID's velocity
+//                     reference and no acceleration reference is set.  Restated literally, that closes a positive feedback from the MPC's
+//                     planned base acceleration into the commanded base velocity: the MPC + ID loop of examples/go2_mpc_id_batched.py blows up
+//                     within 20 control steps (factor 2.4 per step).  The evident intent -- velocity and acceleration references from the
+//                     velocity and acceleration targets -- is what is built; with zero targets, as in the reference's tests, both coincide)
 //   contact motion   J_f a + dJ_f v = -Kd v_f  (the contact reference is reset to the measured foot pose at every solve, :196-213:
 //                    no position error) -- a cost with w_contact_motion, or an equality with contact_motion_equality
 //   contact force    w_contact_force |f_f - f_t|^2 ; friction pyramid |f_x|, |f_y| <= mu f_z ; f_min <= f_z <= f_max
@@ -117,7 +120,7 @@ namespace orc
       const V3 dr = cross(wl, vl);
       for (int i = 0; i < 6; i++)
       {
-        const double ades = s.kp_base * e[i] + kd(s.kp_base) * (t.a[i] - v[i]); // (velocity reference = acceleration target: as coded upstream)
+        const double ades = s.kp_base * e[i] + kd(s.kp_base) * (t.v[i] - v[i]) + t.a[i]; // (the evident intent: see the header)
         const double b = ades - (i < 3 ? dr[i] : 0.0);
         qp.H(i, i) += s.w_base;
         qp.g[i] -= s.w_base * b;

@@ -973,6 +973,12 @@ extern "C"
       mask |= contact[k] ? (1u << k) : 0u;
     return guarded([&] { e->set_target(instance, q, v, a, mask, f); });
   }
+  int smpc_id_set_targets(smpc_id_handle * h, const double * Q, const double * V, const double * A, const uint8_t * contact, const double * F)
+  {
+    if (!h || !Q || !V || !A || !contact || !F)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { reinterpret_cast<IdEngineBase *>(h)->set_targets(Q, V, A, contact, F); });
+  }
   int smpc_id_solve(smpc_id_handle * h, const double * X, double * tau, double * a, double * f, double * resid)
   {
     if (!h || !X || !tau)

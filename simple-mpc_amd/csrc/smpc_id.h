@@ -180,7 +180,7 @@ namespace smpc
           if (i < 6 && s.w_base > 0)
           {
             const V3 dr = cross(mk3(v[3], v[4], v[5]), mk3(v[0], v[1], v[2]));
-            const double ades = s.kp_base * e6[i] + kdb * (ta[i] - v[i]); // (velocity reference = acceleration target: as coded upstream)
+            const double ades = s.kp_base * e6[i] + kdb * (tv[i] - v[i]) + ta[i]; // (velocity / acceleration references: oracle/orc_id.hpp header)
             gi -= s.w_base * (ades - (i == 0 ? dr.x : (i == 1 ? dr.y : (i == 2 ? dr.z : 0.0))));
           }
           if (i < NV && !s.contact_motion_equality && s.w_contact_motion > 0)
@@ -456,6 +456,7 @@ namespace smpc
     int B = 0, nq = 0, nv = 0, nf = 0, n = 0, m = 0, np = 0, mp = 0;
     virtual ~IdEngineBase() {}
     virtual void set_target(int inst, const double * q, const double * v, const double * a, unsigned mask, const double * f) = 0;
+    virtual void set_targets(const double * Q, const double * V, const double * A, const unsigned char * contact, const double * F) = 0;
     virtual void solve(const double * X, double * tau, double * a, double * f, double * resid) = 0;
     virtual void debug_get(int what, double * out) = 0; // 0 M, 1 nle, 2 J, 3 Jdv, 4 vfoot, 5 H, 6 g, 7 C, 8 l, 9 u (padded layouts)
   };
@@ -574,6 +575,21 @@ namespace smpc
       h2d(buf.ta + (size_t)i0 * nv, ta.data(), ta.size() * sizeof(double), stream);
       h2d(buf.tf + (size_t)i0 * 3 * nf, tf.data(), tf.size() * sizeof(double), stream);
       h2d(buf.tmask + i0, tm.data(), tm.size() * sizeof(unsigned), stream);
+      stream_sync(stream);
+    }
+    // one target per robot: Q [B][nq], V [B][nv], A [B][nv], contact [B][nf], F [B][3 nf]
+    void set_targets(const double * Q, const double * V, const double * A, const unsigned char * contact, const double * F) override
+    {
+      set_device(device_id);
+      std::vector<unsigned> tm(B, 0u);
+      for (int b = 0; b < B; b++)
+        for (int k = 0; k < nf; k++)
+          tm[b] |= contact[(size_t)b * nf + k] ? (1u << k) : 0u;
+      h2d(buf.tq, Q, (size_t)B * nq * sizeof(double), stream);
+      h2d(buf.tv, V, (size_t)B * nv * sizeof(double), stream);
+      h2d(buf.ta, A, (size_t)B * nv * sizeof(double), stream);
+      h2d(buf.tf, F, (size_t)B * 3 * nf * sizeof(double), stream);
+      h2d(buf.tmask, tm.data(), (size_t)B * sizeof(unsigned), stream);
       stream_sync(stream);
     }
     void launch_all()

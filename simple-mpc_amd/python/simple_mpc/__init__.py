@@ -1129,6 +1129,13 @@ class KinodynamicsID:
         f = np.zeros(3 * self._nf) if len(f_target) == 0 else c(f_target, 3 * self._nf)  # (the reference's tests pass {} with no contact)
         self._lib.check(self._lib.L.smpc_id_set_target(self._h, int(instance), c(q_target, self._nq), c(v_target, self._nv), c(a_target, self._nv), contact, f))
 
+    def setTargets(self, Q, V, A, contact_states, F):
+        """One target per robot: Q [B][nq], V [B][nv], A [B][nv], contact_states [B][nf] (or one list for all), F [B][nf][3]."""
+        c = lambda x, n: np.ascontiguousarray(np.array(x, dtype=np.float64).reshape(self.B, n))
+        cs = np.array(contact_states)
+        cs = np.ascontiguousarray(np.broadcast_to(cs.reshape(-1, self._nf), (self.B, self._nf)).astype(np.uint8))
+        self._lib.check(self._lib.L.smpc_id_set_targets(self._h, c(Q, self._nq), c(V, self._nv), c(A, self._nv), cs, c(F, 3 * self._nf)))
+
     def solve(self, t, q_meas, v_meas, tau_res=None):
         """reference kinodynamics-id.cpp:185-237: one robot (vectors) or the batch (q_meas [B][nq], v_meas [B][nv]); returns tau (and fills
         tau_res when given, as the reference does)."""

@@ -123,3 +123,51 @@ def test_hip_batch_of_4096_robots(built):
         assert np.abs(tg - tg[0:1]).max() == 0.0 and S.rel_err(to, tg[0]) < 1e-7
         assert np.all(np.abs(tg) <= O.GO2_EFFORT + 1e-6)
         Xo = np.stack([step(rb, Xo[b], ao[b]) for b in range(nd)])
+
+
+def _full_stack(lib, B, mpc_steps):
+    """MPC at 100 Hz -> interpolated targets -> KinodynamicsID at 1 kHz -> constrained forward dynamics as the simulator: the loop of the
+    reference's examples/go2_kinodynamics.py:216-300 (examples/go2_mpc_id_batched.py is the same for a larger batch)."""
+    from simple_mpc import presets as P
+
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+    for n in P.GO2_FEET:
+        mh.addPointFoot(n, "root_joint")
+    nq, nv = mh.nq, mh.nv
+    ocp = simple_mpc.KinodynamicsOCP(P.go2_kino_settings(mh), mh)
+    ocp.createProblem(mh.getReferenceState(), 50, 3, -9.81, False)
+    mpc = simple_mpc.BatchedMPC({k: v for k, v in P.go2_mpc_settings(mh, max_iters=1).items() if k in P.MPC_KEYS}, ocp, B, lib=lib)
+    mpc.generateCycleHorizon(P.trot_cycle())
+    V = np.zeros((B, 6))
+    V[:, 0] = np.linspace(0.0, 0.3, B)
+    mpc.switchToWalk(V[0])
+    mpc.setVelocityBaseBatched(V)
+    ids = dict(kp_base=7.0, kp_posture=10.0, kp_contact=10.0, w_base=100.0, w_posture=1.0, w_contact_force=1.0, w_contact_motion=1.0)
+    kid = simple_mpc.KinodynamicsID(mh, 1e-3, ids, O.GO2_EFFORT, O.GO2_VMAX, batch=B, lib=lib)
+    X = np.tile(mh.getReferenceState(), (B, 1))
+    swing = False
+    for step_i in range(mpc_steps):
+        mpc.iterate(X)
+        contact = mpc.ocp_handler.getContactState(0)
+        swing = swing or not all(contact)
+        mask = np.full(B, sum(1 << i for i, c in enumerate(contact) if c), np.uint32)
+        for sub in range(10):
+            x_i, a_i, f_i = mpc.interpolate(sub / 10.0 * 0.01)
+            kid.setTargets(x_i[:, :nq], x_i[:, nq:], a_i, contact, f_i)
+            tau = kid.solve(0.0, X[:, :nq], X[:, nq:])
+            assert np.all(np.abs(tau) <= O.GO2_EFFORT + 1e-6) and kid.resid.max() < 1e-3
+            a = mpc.constraintDynamics(X, tau, mask, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])["a"]
+            vn = X[:, nq:] + a * 1e-3
+            X = np.stack([P.integrate(np.r_[X[b, :nq], vn[b]], np.r_[vn[b] * 1e-3, np.zeros(nv)], nq) for b in range(B)])
+        assert np.all(np.isfinite(X)) and np.all(np.abs(X[:, 2] - mh.getReferenceState()[2]) < 0.05) and np.abs(X[:, nq:]).max() < 5.0
+    return X, swing
+
+
+def test_emulated_kernels_full_stack(built):
+    _full_stack(S.emu_lib(), 2, 5)
+
+
+@pytest.mark.gpu
+def test_hip_full_stack_through_a_swing_phase(built):
+    X, swing = _full_stack(None, 4, 75)  # the first take-off reaches stage 0 at control step 60
+    assert swing and X[-1, 0] > X[0, 0]  # the robot commanded forwards is ahead of the one commanded to stay
