@@ -346,8 +346,10 @@ typedef struct smpc_id_settings
   const double * velocity_limit; /* nv - 6 */
   const double * q_min;          /* nv - 6 */
   const double * q_max;          /* nv - 6 */
-  int admm_iters;                /* iterations per solve (default 100; warm-started from the previous tick) */
+  int admm_iters;                /* cap on the ADMM iterations per solve (default 400; residuals are checked every 20 iterations and the loop
+                                    stops below 1e-7; warm-started from the previous tick) */
   double admm_rho, admm_sigma, admm_alpha; /* defaults 0.1, 1e-6, 1.6 */
+  double admm_tol;               /* 0: default 1e-7 ; < 0: never stop early (exactly admm_iters iterations) */
 } smpc_id_settings;
 typedef struct smpc_id_handle smpc_id_handle;
 /* KinodynamicsID(model_handler, control_dt, settings): the default target is the reference state, every foot in contact with an equal

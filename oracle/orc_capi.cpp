@@ -1043,7 +1043,9 @@ extern "C"
     double control_dt;
     const double *tau_max, *v_max, *q_min, *q_max;
     int admm_iters;
-    double rho, sigma, alpha;
+    double rho, sigma, alpha, admm_tol;
+    int centroidal;
+    double kp_com, kp_feet_tracking, w_com, w_feet_tracking;
   };
   static IDSettings id_settings_from(const smpc_robot_model * m, const orc_id_settings * c)
   {
@@ -1069,6 +1071,12 @@ extern "C"
     s.rho = c->rho;
     s.sigma = c->sigma;
     s.alpha = c->alpha;
+    s.admm_tol = c->admm_tol;
+    s.centroidal = c->centroidal != 0;
+    s.kp_com = c->kp_com;
+    s.kp_feet_tracking = c->kp_feet_tracking;
+    s.w_com = c->w_com;
+    s.w_feet_tracking = c->w_feet_tracking;
     return s;
   }
   void * orc_id_create(const smpc_robot_model * m, const orc_id_settings * c, int B) { return new BatchKinoID(m, id_settings_from(m, c), B); }
@@ -1083,6 +1091,32 @@ extern "C"
     t.a.assign(a, a + k->M->nv);
     t.mask = mask;
     t.f.assign(f, f + 3 * k->M->nfeet);
+    for (int i = 0; i < k->B; i++)
+      if (b < 0 || b == i)
+      {
+        t.com = k->tgt[i].com;
+        t.vcom = k->tgt[i].vcom;
+        t.feet_p = k->tgt[i].feet_p;
+        t.feet_v = k->tgt[i].feet_v;
+        k->tgt[i] = t;
+      }
+  }
+  // CentroidalID::setTarget (centroidal-id.cpp:87-145): CoM position / velocity, foot positions / velocities, contacts, forces; the
+  // posture / base targets become the reference state
+  void orc_id_set_target_centroidal(void * h, int b, const double * com, const double * vcom, const double * feet_p, const double * feet_v, unsigned mask, const double * f)
+  {
+    BatchKinoID * k = (BatchKinoID *)h;
+    const int nf = k->M->nfeet;
+    IDTarget t;
+    t.q.assign(k->M->q_ref, k->M->q_ref + k->M->nq);
+    t.v.assign(k->M->nv, 0.0);
+    t.a.assign(k->M->nv, 0.0);
+    t.mask = mask;
+    t.f.assign(f, f + 3 * nf);
+    t.com.assign(com, com + 3);
+    t.vcom.assign(vcom, vcom + 3);
+    t.feet_p.assign(feet_p, feet_p + 3 * nf);
+    t.feet_v.assign(feet_v, feet_v + 3 * nf);
     for (int i = 0; i < k->B; i++)
       if (b < 0 || b == i)
         k->tgt[i] = t;

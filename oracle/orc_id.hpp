@@ -24,8 +24,8 @@
 //   actuation        |M_a a + h_a - J_a^T f| <= tau_max  ;  output tau = M_a a + h_a - J_a^T f
 //
 // Solver: ADMM on  min 1/2 y^T H y + g^T y  s.t.  l <= C y <= u  (the operator splitting of OSQP: one factorisation of
-// H + sigma I + C^T diag(rho) C per solve, then matrix-vector iterations; equality rows carry 1e3 rho, free rows 1e-6 rho), a fixed number
-// of iterations, warm-started from the previous control tick.  ProxQP is a proximal augmented-Lagrangian method; both converge to the
+// H + sigma I + C^T diag(rho) C per solve, then matrix-vector iterations; equality rows carry 1e3 rho, free rows 1e-6 rho), at most
+// admm_iters iterations (residuals checked every 20, stop below 1e-7), warm-started from the previous control tick.  ProxQP is a proximal augmented-Lagrangian method; both converge to the
 // same (unique, H + constraints) solution, which the tests check through KKT residuals.
 #pragma once
 #include "orc_full.hpp"
@@ -38,16 +38,22 @@ namespace orc
     double kp_base = 0, kp_posture = 0, kp_contact = 0;
     double w_base = -1, w_posture = -1, w_contact_motion = -1, w_contact_force = -1;
     bool contact_motion_equality = false;
+    // CentroidalID (reference src/inverse-dynamics/centroidal-id.cpp:6-147): the base task keeps its orientation rows only, a centre-of-mass
+    // task and a position-tracking task per foot out of contact are added; the posture / base targets are the reference state
+    bool centroidal = false;
+    double kp_com = 0, kp_feet_tracking = 0, w_com = -1, w_feet_tracking = -1;
     double control_dt = 1e-3;
     Vec tau_max, v_max, q_min, q_max; // nv - 6 each (the robot table holds position limits only)
-    int admm_iters = 100;
+    int admm_iters = 400; // cap; the loop stops earlier once the residuals are below ADMM_TOL
     double rho = 0.1, sigma = 1e-6, alpha = 1.6;
+    double admm_tol = 1e-7; // < 0: never stop early
   };
   struct IDTarget
   {
     Vec q, v, a; // nq, nv, nv
     unsigned mask = 0;
     Vec f;       // 3 nf
+    Vec com, vcom, feet_p, feet_v; // CentroidalID: 3, 3, 3 nf, 3 nf (world frame)
   };
   struct IDQuantities
   {
@@ -55,6 +61,7 @@ namespace orc
     Vec nle;        // nv
     Mat J;          // 3 nf x nv: world-frame linear Jacobians of the foot points
     Vec Jdv, vfoot; // 3 nf: classical acceleration of the points at zero joint accelerations ; their velocity
+    Vec com, footp; // 3 ; 3 nf (world frame)
   };
   struct QP
   {
@@ -63,6 +70,7 @@ namespace orc
     Vec g, l, u;
   };
   constexpr double ID_INF = 1e20;
+  constexpr int ADMM_CHECK = 20;      // residual check period of the ADMM loop
 
   inline void id_quantities(const smpc_robot_model * m, const double * x, IDQuantities & o)
   {
@@ -86,6 +94,11 @@ namespace orc
         }
         o.Jdv[3 * f + i] = cd.gamma[6 * f + i];
       }
+    o.com = {cd.R.com[0], cd.R.com[1], cd.R.com[2]};
+    o.footp.assign(3 * nf, 0.0);
+    for (int f = 0; f < nf; f++)
+      for (int i = 0; i < 3; i++)
+        o.footp[3 * f + i] = cd.R.foot_p[f][i];
   }
 
   // row layout of C: [0, n) box on y ; 6 dynamics rows ; 3 nf contact-motion rows ; 4 nf friction rows ; nv - 6 actuation rows
@@ -118,7 +131,7 @@ namespace orc
       log6(inv(Mb) * Mt, e);
       const V3 wl = v3(v[3], v[4], v[5]), vl = v3(v[0], v[1], v[2]);
       const V3 dr = cross(wl, vl);
-      for (int i = 0; i < 6; i++)
+      for (int i = (s.centroidal ? 3 : 0); i < 6; i++) // (CentroidalID: orientation rows only, centroidal-id.cpp:10-20)
       {
         const double ades = s.kp_base * e[i] + kd(s.kp_base) * (t.v[i] - v[i]) + t.a[i]; // (the evident intent: see the header)
         const double b = ades - (i < 3 ? dr[i] : 0.0);
@@ -126,6 +139,45 @@ namespace orc
         qp.g[i] -= s.w_base * b;
       }
     }
+    auto add_rows3 = [&](double w, const double * A, const double * b) { // w |A y_a - b|^2, A: 3 x nv row-major
+      for (int i = 0; i < 3; i++)
+        for (int a = 0; a < nv; a++)
+        {
+          qp.g[a] -= w * A[i * nv + a] * b[i];
+          for (int c = 0; c < nv; c++)
+            qp.H(a, c) += w * A[i * nv + a] * A[i * nv + c];
+        }
+    };
+    if (s.centroidal && s.w_com > 0)
+    {
+      // a_com = J_com a + drift:  J_com = R_b M_lin / m (the base's linear rows of M are the total linear momentum map in the base
+      // frame), drift = R_b nle_lin / m + g  (TaskComEquality, centroidal-id.cpp:22-27)
+      const M3 Rb = quat_to_R(q + 3);
+      const double im = 1.0 / m->total_mass;
+      std::vector<double> Jc(3 * nv);
+      double vc[3] = {0, 0, 0}, dr[3], b3[3];
+      for (int i = 0; i < 3; i++)
+      {
+        for (int k = 0; k < nv; k++)
+        {
+          Jc[i * nv + k] = im * (Rb(i, 0) * Q.M(0, k) + Rb(i, 1) * Q.M(1, k) + Rb(i, 2) * Q.M(2, k));
+          vc[i] += Jc[i * nv + k] * v[k];
+        }
+        dr[i] = im * (Rb(i, 0) * Q.nle[0] + Rb(i, 1) * Q.nle[1] + Rb(i, 2) * Q.nle[2]) + (i == 2 ? -9.81 : 0.0);
+      }
+      for (int i = 0; i < 3; i++)
+        b3[i] = s.kp_com * (t.com[i] - Q.com[i]) + kd(s.kp_com) * (t.vcom[i] - vc[i]) - dr[i];
+      add_rows3(s.w_com, Jc.data(), b3);
+    }
+    if (s.centroidal && s.w_feet_tracking > 0)
+      for (int f = 0; f < nf; f++)
+        if (!((t.mask >> f) & 1u))
+        { // position tracking of the feet out of contact (centroidal-id.cpp:101-129; point feet: linear part)
+          double b3[3];
+          for (int i = 0; i < 3; i++)
+            b3[i] = s.kp_feet_tracking * (t.feet_p[3 * f + i] - Q.footp[3 * f + i]) + kd(s.kp_feet_tracking) * (t.feet_v[3 * f + i] - Q.vfoot[3 * f + i]) - Q.Jdv[3 * f + i];
+          add_rows3(s.w_feet_tracking, &Q.J.a[(size_t)(3 * f) * nv], b3);
+        }
     const double kdc = kd(s.kp_contact);
     for (int f = 0; f < nf; f++)
     {
@@ -217,7 +269,7 @@ namespace orc
   }
 
   // ADMM (x = y of the QP); x, z, lam are the warm start on entry and the iterate on exit.  Returns max(primal, dual) residual.
-  inline double qp_admm(const QP & qp, double rho, double sigma, double alpha, int iters, Vec & x, Vec & z, Vec & lam)
+  inline double qp_admm(const QP & qp, double rho, double sigma, double alpha, int iters, double tol, Vec & x, Vec & z, Vec & lam)
   {
     const int n = qp.n, m = qp.m;
     Vec r(m);
@@ -247,8 +299,32 @@ namespace orc
         z[k] = std::fmin(std::fmax(0.0, qp.l[k]), qp.u[k]);
     }
     Vec rhs(n), zt(m);
+    auto residual = [&]() {
+      double pr = 0.0, du = 0.0;
+      for (int k = 0; k < m; k++)
+      {
+        double acc = 0.0;
+        for (int i = 0; i < n; i++)
+          acc += qp.C(k, i) * x[i];
+        pr = std::fmax(pr, std::fabs(acc - z[k]));
+      }
+      for (int i = 0; i < n; i++)
+      {
+        double acc = qp.g[i];
+        for (int j = 0; j < n; j++)
+          acc += qp.H(i, j) * x[j];
+        for (int k = 0; k < m; k++)
+          acc += qp.C(k, i) * lam[k];
+        du = std::fmax(du, std::fabs(acc));
+      }
+      return std::fmax(pr, du);
+    };
+    double res = 0.0;
     for (int it = 0; it < iters; it++)
     {
+      // every ADMM_CHECK iterations: stop once both residuals are below the tolerance (`iters` is the cap)
+      if (it > 0 && it % ADMM_CHECK == 0 && tol >= 0.0 && (res = residual()) <= tol)
+        return res;
       for (int i = 0; i < n; i++)
         rhs[i] = sigma * x[i] - qp.g[i];
       for (int k = 0; k < m; k++)
@@ -275,24 +351,7 @@ namespace orc
         z[k] = zn;
       }
     }
-    double pr = 0.0, du = 0.0;
-    for (int k = 0; k < m; k++)
-    {
-      double acc = 0.0;
-      for (int i = 0; i < n; i++)
-        acc += qp.C(k, i) * x[i];
-      pr = std::fmax(pr, std::fabs(acc - z[k]));
-    }
-    for (int i = 0; i < n; i++)
-    {
-      double acc = qp.g[i];
-      for (int j = 0; j < n; j++)
-        acc += qp.H(i, j) * x[j];
-      for (int k = 0; k < m; k++)
-        acc += qp.C(k, i) * lam[k];
-      du = std::fmax(du, std::fabs(acc));
-    }
-    return std::fmax(pr, du);
+    return residual();
   }
 
   // KinodynamicsID for a batch of robots: setTarget (shared or per instance) + solve
@@ -315,6 +374,18 @@ namespace orc
       t.f.assign(3 * m->nfeet, 0.0);
       for (int f = 0; f < m->nfeet; f++)
         t.f[3 * f + 2] = m->total_mass * 9.81 / m->nfeet;
+      {
+        // CentroidalID defaults: the CoM of the reference state, the feet at their reference placements (centroidal-id.cpp:60-84)
+        Rigid R(m);
+        R.fk(t.q.data());
+        t.com = {R.com[0], R.com[1], R.com[2]};
+        t.vcom.assign(3, 0.0);
+        t.feet_p.assign(3 * m->nfeet, 0.0);
+        t.feet_v.assign(3 * m->nfeet, 0.0);
+        for (int f = 0; f < m->nfeet; f++)
+          for (int i = 0; i < 3; i++)
+            t.feet_p[3 * f + i] = R.oMi[0].p[i] + (R.oMi[0].R * v3(m->foot_ref_p[f][0], m->foot_ref_p[f][1], m->foot_ref_p[f][2]))[i];
+      }
       for (auto & e : tgt)
         e = t;
     }
@@ -330,7 +401,7 @@ namespace orc
         id_quantities(M, xb, Q);
         QP qp;
         id_assemble(M, s, tgt[b], xb, Q, qp);
-        resid[b] = qp_admm(qp, s.rho, s.sigma, s.alpha, s.admm_iters, x[b], z[b], lam[b]);
+        resid[b] = qp_admm(qp, s.rho, s.sigma, s.alpha, s.admm_iters, s.admm_tol, x[b], z[b], lam[b]);
         for (int k = 0; k < nv; k++)
           a[(size_t)b * nv + k] = x[b][k];
         for (int k = 0; k < 3 * nf; k++)

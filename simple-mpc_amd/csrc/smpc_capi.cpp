@@ -944,10 +944,11 @@ extern "C"
     hs.dev.w_contact_force = c->w_contact_force;
     hs.dev.contact_motion_equality = c->contact_motion_equality;
     hs.dev.control_dt = c->control_dt;
-    hs.dev.admm_iters = c->admm_iters > 0 ? c->admm_iters : 100;
+    hs.dev.admm_iters = c->admm_iters > 0 ? c->admm_iters : 400;
     hs.dev.rho = c->admm_rho > 0 ? c->admm_rho : 0.1;
     hs.dev.sigma = c->admm_sigma > 0 ? c->admm_sigma : 1e-6;
     hs.dev.alpha = c->admm_alpha > 0 ? c->admm_alpha : 1.6;
+    hs.dev.admm_tol = c->admm_tol == 0.0 ? 1e-7 : c->admm_tol;
     if (!(c->kp_base >= 0.0 && c->kp_posture >= 0.0 && c->kp_contact >= 0.0))
       return fail(SMPC_ERR_INVALID, "task gains must not be negative");
     const int na = robot->nv - 6;

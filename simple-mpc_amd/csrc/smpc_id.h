@@ -3,7 +3,7 @@
 // for robots with 3-D point feet, one wavefront per robot.
 //
 // The reference builds the problem with TSID 1.9 (InverseDynamicsFormulationAccForce + tasks) and solves it with proxsuite's ProxQP;
-// neither library is available, so the formulation is restated (oracle/orc_id.hpp holds the same statement, term by term, with the
+// neither library is available, so the formulation is restated (the CPU checker holds the same statement, term by term, with the
 // places where upstream source would decide marked [UPSTREAM-RECALL]):
 //     y = [a ; f],   M_b a + h_b = J_b^T f,   posture / base / contact-motion / contact-force least-squares tasks,
 //     friction pyramids, force bounds, joint position / velocity limits as acceleration bounds, |tau| <= tau_max,   tau = M_a a + h_a - J_a^T f
@@ -25,7 +25,7 @@ namespace smpc
     double kp_base, kp_posture, kp_contact;
     double w_base, w_posture, w_contact_motion, w_contact_force;
     int contact_motion_equality, admm_iters;
-    double control_dt, rho, sigma, alpha;
+    double control_dt, rho, sigma, alpha, admm_tol;
   };
   template <class D>
   struct IdDims
@@ -180,7 +180,7 @@ namespace smpc
           if (i < 6 && s.w_base > 0)
           {
             const V3 dr = cross(mk3(v[3], v[4], v[5]), mk3(v[0], v[1], v[2]));
-            const double ades = s.kp_base * e6[i] + kdb * (tv[i] - v[i]) + ta[i]; // (velocity / acceleration references: oracle/orc_id.hpp header)
+            const double ades = s.kp_base * e6[i] + kdb * (tv[i] - v[i]) + ta[i]; // (velocity / acceleration references: DESIGN 3.12)
             gi -= s.w_base * (ades - (i == 0 ? dr.x : (i == 1 ? dr.y : (i == 2 ? dr.z : 0.0))));
           }
           if (i < NV && !s.contact_motion_equality && s.w_contact_motion > 0)
@@ -290,6 +290,42 @@ namespace smpc
     double l[G::MP], u[G::MP], r[G::MP], z[G::MP], lam[G::MP], w[G::MP], zt[G::MP];
     double red[64];
   };
+  // residuals of the iterate in LDS: max(|C x - z|_inf, |H x + g + C^T lam|_inf), the same value in every lane
+  template <class D>
+  SMPC_DEV double qp_residual(QpLds<D> & s, const double * Hg)
+  {
+    typedef IdDims<D> G;
+    constexpr int NT = 64, N = G::N, NP = G::NP, M = G::M, LDC = G::LDC;
+    SMPC_LANES(NT)
+    {
+      double pr = 0.0;
+      for (int k = lane; k < M; k += NT)
+      {
+        double acc = 0.0;
+        for (int i = 0; i < N; i++)
+          acc += s.C[k * LDC + i] * s.x[i];
+        pr = fmax(pr, fabs(acc - s.z[k]));
+      }
+      double du = 0.0;
+      if (lane < N)
+      {
+        double acc = s.g[lane];
+        for (int j = 0; j < N; j++)
+          acc += Hg[lane * NP + j] * s.x[j];
+        for (int k = 0; k < M; k++)
+          acc += s.C[k * LDC + lane] * s.lam[k];
+        du = fabs(acc);
+      }
+      s.red[lane] = fmax(pr, du);
+    }
+    SMPC_LANES_END_WAVE
+    double m = 0.0;
+    for (int i = 0; i < NT; i++)
+      m = fmax(m, s.red[i]);
+    return m;
+  }
+  constexpr int ADMM_CHECK = 20;     // residual check period of the ADMM loop
+
   template <class D>
   SMPC_DEV void qp_admm_body(const IdBuffers<D> & b, int block)
   {
@@ -336,8 +372,15 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     fwave_spd_inverse<NP>(s.K, s.swp);
+    double res = 0.0;
+    bool done = false;
     for (int it = 0; it < st.admm_iters; it++)
     {
+      if (it > 0 && it % ADMM_CHECK == 0 && st.admm_tol >= 0.0 && (res = qp_residual<D>(s, Hg)) <= st.admm_tol)
+      {
+        done = true;
+        break;
+      }
       SMPC_LANES(NT)
       for (int k = lane; k < MP; k += NT)
         s.w[k] = s.r[k] * s.z[k] - s.lam[k];
@@ -385,30 +428,8 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
     }
-    // residuals of the returned iterate: |C x - z|_inf, |H x + g + C^T lam|_inf
-    SMPC_LANES(NT)
-    {
-      double pr = 0.0;
-      for (int k = lane; k < M; k += NT)
-      {
-        double acc = 0.0;
-        for (int i = 0; i < N; i++)
-          acc += s.C[k * LDC + i] * s.x[i];
-        pr = fmax(pr, fabs(acc - s.z[k]));
-      }
-      double du = 0.0;
-      if (lane < N)
-      {
-        double acc = s.g[lane];
-        for (int j = 0; j < N; j++)
-          acc += Hg[lane * NP + j] * s.x[j];
-        for (int k = 0; k < M; k++)
-          acc += s.C[k * LDC + lane] * s.lam[k];
-        du = fabs(acc);
-      }
-      s.red[lane] = fmax(pr, du);
-    }
-    SMPC_LANES_END_WAVE
+    if (!done)
+      res = qp_residual<D>(s, Hg);
     SMPC_LANES(NT)
     {
       for (int i = lane; i < NP; i += NT)
@@ -435,10 +456,7 @@ namespace smpc
       }
       if (lane == 0)
       {
-        double m = 0.0;
-        for (int i = 0; i < 64; i++)
-          m = fmax(m, s.red[i]);
-        b.resid[inst] = m;
+        b.resid[inst] = res;
         b.warm[inst] = 1;
       }
     }

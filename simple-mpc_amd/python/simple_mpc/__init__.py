@@ -1090,7 +1090,7 @@ class KinodynamicsID:
     _DEFAULTS = dict(friction_coefficient=0.6, contact_weight_ratio_max=10.0, contact_weight_ratio_min=0.01, kp_base=0.0, kp_posture=0.0,
                      kp_contact=0.0, w_base=-1.0, w_posture=-1.0, w_contact_motion=-1.0, w_contact_force=-1.0, contact_motion_equality=False)
 
-    def __init__(self, model_handler, control_dt, settings, effort_limit, velocity_limit, batch=1, device_id=0, lib=None, admm_iters=0):
+    def __init__(self, model_handler, control_dt, settings, effort_limit, velocity_limit, batch=1, device_id=0, lib=None, admm_iters=0, admm_tol=0.0):
         unknown = [k for k in settings if k not in self._KEYS]
         if unknown:
             raise KeyError("unknown KinodynamicsID settings: %s" % unknown)
@@ -1106,7 +1106,7 @@ class KinodynamicsID:
         s = self.settings
         c = IdSettingsC(s["friction_coefficient"], s["contact_weight_ratio_max"], s["contact_weight_ratio_min"], s["kp_base"], s["kp_posture"],
                         s["kp_contact"], s["w_base"], s["w_posture"], s["w_contact_motion"], s["w_contact_force"],
-                        int(bool(s["contact_motion_equality"])), float(control_dt), *[a.ctypes.data for a in self._keep], int(admm_iters), 0.0, 0.0, 0.0)
+                        int(bool(s["contact_motion_equality"])), float(control_dt), *[a.ctypes.data for a in self._keep], int(admm_iters), 0.0, 0.0, 0.0, float(admm_tol))
         h = C.c_void_p()
         self._lib.check(self._lib.L.smpc_id_create(model_handler._ptr, C.byref(c), self.B, device_id, C.byref(h)))
         self._h = h

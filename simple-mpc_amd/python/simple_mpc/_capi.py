@@ -111,7 +111,7 @@ class IdSettingsC(C.Structure):
         ("w_base", C.c_double), ("w_posture", C.c_double), ("w_contact_motion", C.c_double), ("w_contact_force", C.c_double),
         ("contact_motion_equality", C.c_int), ("control_dt", C.c_double),
         ("effort_limit", C.c_void_p), ("velocity_limit", C.c_void_p), ("q_min", C.c_void_p), ("q_max", C.c_void_p),
-        ("admm_iters", C.c_int), ("admm_rho", C.c_double), ("admm_sigma", C.c_double), ("admm_alpha", C.c_double),
+        ("admm_iters", C.c_int), ("admm_rho", C.c_double), ("admm_sigma", C.c_double), ("admm_alpha", C.c_double), ("admm_tol", C.c_double),
     ]
 
 

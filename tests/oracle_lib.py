@@ -33,7 +33,8 @@ class IdSettingsC(C.Structure):
         ("w_base", C.c_double), ("w_posture", C.c_double), ("w_contact_motion", C.c_double), ("w_contact_force", C.c_double),
         ("contact_motion_equality", C.c_int), ("control_dt", C.c_double),
         ("tau_max", C.c_void_p), ("v_max", C.c_void_p), ("q_min", C.c_void_p), ("q_max", C.c_void_p),
-        ("admm_iters", C.c_int), ("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
+        ("admm_iters", C.c_int), ("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("admm_tol", C.c_double),
+        ("centroidal", C.c_int), ("kp_com", C.c_double), ("kp_feet_tracking", C.c_double), ("w_com", C.c_double), ("w_feet_tracking", C.c_double),
     ]
 
 
@@ -127,6 +128,7 @@ def lib():
     L.orc_id_destroy.argtypes = [vp]
     L.orc_id_set_target.argtypes = [vp, C.c_int, _dp, _dp, _dp, C.c_uint, _dp]
     L.orc_id_solve.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_id_set_target_centroidal.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, C.c_uint, _dp]
     L.orc_id_quantities.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_id_qp.restype = C.c_int
     L.orc_id_qp.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
@@ -721,7 +723,8 @@ def centroidal_dynamics(mass, gravity, dt, x, u, contact, pos):
 
 ID_DEFAULTS = dict(friction_coefficient=0.6, contact_weight_ratio_max=10.0, contact_weight_ratio_min=0.01, kp_base=0.0, kp_posture=0.0,
                    kp_contact=0.0, w_base=-1.0, w_posture=-1.0, w_contact_motion=-1.0, w_contact_force=-1.0, contact_motion_equality=False,
-                   admm_iters=100, rho=0.1, sigma=1e-6, alpha=1.6)  # reference include/simple-mpc/inverse-dynamics/kinodynamics-id.hpp:24-50
+                   admm_iters=400, rho=0.1, sigma=1e-6, alpha=1.6, admm_tol=1e-7,  # reference include/simple-mpc/inverse-dynamics/kinodynamics-id.hpp:24-50
+                   centroidal=False, kp_com=0.0, kp_feet_tracking=0.0, w_com=-1.0, w_feet_tracking=-1.0)  # centroidal-id.hpp:17-26
 GO2_EFFORT = np.array([23.7, 23.7, 45.43] * 4)
 GO2_VMAX = np.array([30.1, 30.1, 15.7] * 4)
 
@@ -743,7 +746,7 @@ class OracleKinoID:
         c = IdSettingsC(s["friction_coefficient"], s["contact_weight_ratio_max"], s["contact_weight_ratio_min"], s["kp_base"], s["kp_posture"],
                         s["kp_contact"], s["w_base"], s["w_posture"], s["w_contact_motion"], s["w_contact_force"],
                         int(s["contact_motion_equality"]), s["control_dt"], *[a.ctypes.data for a in self._keep], int(s["admm_iters"]),
-                        s["rho"], s["sigma"], s["alpha"])
+                        s["rho"], s["sigma"], s["alpha"], s["admm_tol"], int(s["centroidal"]), s["kp_com"], s["kp_feet_tracking"], s["w_com"], s["w_feet_tracking"])
         self.h = lib().orc_id_create(robot.ptr, C.byref(c), B)
         self.n = robot.nv + 3 * robot.nf
         self.m = self.n + 6 + 3 * robot.nf + 4 * robot.nf + robot.nv - 6
@@ -757,6 +760,11 @@ class OracleKinoID:
         mask = sum(1 << i for i, on in enumerate(contact_state) if on)
         c = lambda x: np.ascontiguousarray(x, float)
         lib().orc_id_set_target(self.h, instance, c(q), c(v), c(a), mask, c(np.asarray(f, float).reshape(-1)))
+
+    def setTargetCentroidal(self, com, vcom, feet_p, feet_v, contact_state, f, instance=-1):
+        mask = sum(1 << i for i, on in enumerate(contact_state) if on)
+        c = lambda x: np.ascontiguousarray(np.asarray(x, float).reshape(-1))
+        lib().orc_id_set_target_centroidal(self.h, instance, c(com), c(vcom), c(feet_p), c(feet_v), mask, c(f))
 
     def solve(self, X):
         rb = self.robot

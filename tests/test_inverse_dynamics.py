@@ -13,14 +13,16 @@ KEYS = simple_mpc.KinodynamicsID._KEYS
 ALL = dict(kp_base=10.0, kp_posture=1.0, kp_contact=10.0, w_base=10.0, w_posture=0.1, w_contact_force=1e-3, w_contact_motion=1.0)
 
 
-def make(lib, B, admm_iters=100, **kw):
+def make(lib, B, admm_iters=100, admm_tol=-1.0, **kw):
+    """(admm_tol < 0: exactly admm_iters iterations on both sides, so that the comparison does not hinge on two roundings of a residual
+    falling on the same side of the stopping tolerance)"""
     rb = O.Robot("go2_like")
-    s = O.id_settings(rb, DT, admm_iters=admm_iters, **kw)
+    s = O.id_settings(rb, DT, admm_iters=admm_iters, admm_tol=admm_tol, **kw)
     ok = O.OracleKinoID(rb, s, B)
     mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
     for n in S.FEET:
         mh.addPointFoot(n, "root_joint")
-    gk = simple_mpc.KinodynamicsID(mh, DT, {k: s[k] for k in KEYS}, s["tau_max"], s["v_max"], batch=B, lib=lib, admm_iters=admm_iters)
+    gk = simple_mpc.KinodynamicsID(mh, DT, {k: s[k] for k in KEYS}, s["tau_max"], s["v_max"], batch=B, lib=lib, admm_iters=admm_iters, admm_tol=admm_tol)
     return rb, ok, gk
 
 
@@ -49,8 +51,8 @@ def _pieces(lib):
     assert gk.resid.max() < 1e-3 and np.allclose(gk.resid, ok.resid, rtol=1e-3, atol=1e-9)
 
 
-def _closed_loop(lib, n_steps, tol):
-    rb, ok, gk = make(lib, 2, **ALL)
+def _closed_loop(lib, n_steps, tol, **solver):
+    rb, ok, gk = make(lib, 2, **solver, **ALL)
     fs = static_forces(rb)
     for k in (ok, gk):
         k.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True] * 4, fs)
@@ -73,6 +75,12 @@ def test_emulated_kernels_pieces(built):
 
 def test_emulated_kernels_closed_loop(built):
     _closed_loop(S.emu_lib(), 60, 1e-7)
+
+
+def test_emulated_kernels_closed_loop_default_stopping_rule(built):
+    """The solver of record: at most 400 iterations, residuals checked every 20, stop below 1e-7 -- both sides agree to that tolerance (the
+    weakly weighted contact forces to ~10x of it)."""
+    _closed_loop(S.emu_lib(), 40, 1e-5, admm_iters=400, admm_tol=1e-7)
 
 
 def test_settings_and_errors(built):

