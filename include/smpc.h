@@ -350,6 +350,12 @@ typedef struct smpc_id_settings
                                     stops below 1e-7; warm-started from the previous tick) */
   double admm_rho, admm_sigma, admm_alpha; /* defaults 0.1, 1e-6, 1.6 */
   double admm_tol;               /* 0: default 1e-7 ; < 0: never stop early (exactly admm_iters iterations) */
+  /* CentroidalID::Settings (include/simple-mpc/inverse-dynamics/centroidal-id.hpp): centroidal != 0 selects that controller -- the base
+   * task keeps its orientation rows, a centre-of-mass task and a position-tracking task per foot out of contact are added; the posture
+   * and base targets stay at the reference state (centroidal-id.cpp:60-84) */
+  int centroidal;
+  double kp_com, kp_feet_tracking;
+  double w_com, w_feet_tracking; /* <= 0: task disabled */
 } smpc_id_settings;
 typedef struct smpc_id_handle smpc_id_handle;
 /* KinodynamicsID(model_handler, control_dt, settings): the default target is the reference state, every foot in contact with an equal
@@ -361,12 +367,21 @@ void smpc_id_destroy(smpc_id_handle * h);
 int smpc_id_set_target(smpc_id_handle * h, int instance, const double * q, const double * v, const double * a, const uint8_t * contact, const double * f);
 /* one target per robot of the batch: Q [B][nq], V [B][nv], A [B][nv], contact [B][nfeet], F [B][3 nfeet] */
 int smpc_id_set_targets(smpc_id_handle * h, const double * Q, const double * V, const double * A, const uint8_t * contact, const double * F);
+/* CentroidalID::setTarget(com_position, com_velocity, feet_pose_vec, feet_velocity_vec, contact_state_target, f_target)
+ * (centroidal-id.cpp:86-147) of one instance or of every instance (instance < 0): com, vcom (3), feet_p, feet_v (3 per foot, world
+ * frame: the translations / linear velocities of the reference's SE3 / Motion arguments), contact flag per foot, f (3 per foot).
+ * SMPC_ERR_INVALID on a KinodynamicsID handle. */
+int smpc_id_set_target_centroidal(smpc_id_handle * h, int instance, const double * com, const double * vcom, const double * feet_p,
+                                  const double * feet_v, const uint8_t * contact, const double * f);
+/* one target per robot: COM, VCOM [B][3], FEET_P, FEET_V [B][3 nfeet], contact [B][nfeet], F [B][3 nfeet] */
+int smpc_id_set_targets_centroidal(smpc_id_handle * h, const double * COM, const double * VCOM, const double * FEET_P, const double * FEET_V,
+                                   const uint8_t * contact, const double * F);
 /* solve(t, q_meas, v_meas, tau) + getAccelerations for the batch (kinodynamics-id.cpp:185-237): X [B][nq + nv] (host) ->
  * tau [B][nv - 6], a [B][nv] (may be NULL), f [B][3 nfeet] contact forces of the solution (may be NULL), resid [B] the larger of the
  * QP's primal / dual residuals (may be NULL) */
 int smpc_id_solve(smpc_id_handle * h, const double * X, double * tau, double * a, double * f, double * resid);
 /* (tests) intermediate results of the last solve, padded layouts of simple-mpc_amd/csrc/smpc_id.h: what = 0 M, 1 nle, 2 J, 3 dJ v, 4 foot
- * velocities, 5 H [32][32], 6 g [32], 7 C [80][32], 8 l [80], 9 u [80]; every one [B][...] */
+ * velocities, 5 H [32][32], 6 g [32], 7 C [80][32], 8 l [80], 9 u [80], 10 centre of mass [3], 11 foot positions [3 nfeet]; every one [B][...] */
 int smpc_id_debug_get(smpc_id_handle * h, int what, double * out);
 
 #ifdef __cplusplus

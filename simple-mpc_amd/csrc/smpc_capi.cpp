@@ -949,6 +949,14 @@ extern "C"
     hs.dev.sigma = c->admm_sigma > 0 ? c->admm_sigma : 1e-6;
     hs.dev.alpha = c->admm_alpha > 0 ? c->admm_alpha : 1.6;
     hs.dev.admm_tol = c->admm_tol == 0.0 ? 1e-7 : c->admm_tol;
+    hs.dev.centroidal = c->centroidal != 0;
+    hs.dev.pad_ = 0;
+    hs.dev.kp_com = c->kp_com;
+    hs.dev.kp_feet_tracking = c->kp_feet_tracking;
+    hs.dev.w_com = c->w_com;
+    hs.dev.w_feet_tracking = c->w_feet_tracking;
+    if (c->centroidal && !(c->kp_com >= 0.0 && c->kp_feet_tracking >= 0.0))
+      return fail(SMPC_ERR_INVALID, "task gains must not be negative");
     if (!(c->kp_base >= 0.0 && c->kp_posture >= 0.0 && c->kp_contact >= 0.0))
       return fail(SMPC_ERR_INVALID, "task gains must not be negative");
     const int na = robot->nv - 6;
@@ -979,6 +987,24 @@ extern "C"
     if (!h || !Q || !V || !A || !contact || !F)
       return fail(SMPC_ERR_INVALID, "null argument");
     return guarded([&] { reinterpret_cast<IdEngineBase *>(h)->set_targets(Q, V, A, contact, F); });
+  }
+  int smpc_id_set_target_centroidal(smpc_id_handle * h, int instance, const double * com, const double * vcom, const double * feet_p,
+                                    const double * feet_v, const uint8_t * contact, const double * f)
+  {
+    if (!h || !com || !vcom || !feet_p || !feet_v || !contact || !f)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    IdEngineBase * e = reinterpret_cast<IdEngineBase *>(h);
+    unsigned mask = 0;
+    for (int k = 0; k < e->nf; k++)
+      mask |= contact[k] ? (1u << k) : 0u;
+    return guarded([&] { e->set_target_centroidal(instance, com, vcom, feet_p, feet_v, mask, f); });
+  }
+  int smpc_id_set_targets_centroidal(smpc_id_handle * h, const double * COM, const double * VCOM, const double * FEET_P, const double * FEET_V,
+                                     const uint8_t * contact, const double * F)
+  {
+    if (!h || !COM || !VCOM || !FEET_P || !FEET_V || !contact || !F)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { reinterpret_cast<IdEngineBase *>(h)->set_targets_centroidal(COM, VCOM, FEET_P, FEET_V, contact, F); });
   }
   int smpc_id_solve(smpc_id_handle * h, const double * X, double * tau, double * a, double * f, double * resid)
   {

@@ -26,6 +26,9 @@ namespace smpc
     double w_base, w_posture, w_contact_motion, w_contact_force;
     int contact_motion_equality, admm_iters;
     double control_dt, rho, sigma, alpha, admm_tol;
+    // CentroidalID (reference src/inverse-dynamics/centroidal-id.cpp:6-147): orientation-only base task, CoM task, tracking of the feet in the air
+    int centroidal, pad_;
+    double kp_com, kp_feet_tracking, w_com, w_feet_tracking;
   };
   template <class D>
   struct IdDims
@@ -46,11 +49,13 @@ namespace smpc
     DevModel<D> * model = nullptr;
     const double * X = nullptr;                                   // [B][NX] measured states
     double *Mq = nullptr, *nle = nullptr, *J = nullptr, *Jdv = nullptr, *vfoot = nullptr; // [B][NV NV], [NV], [3 NF][NV], [3 NF], [3 NF]
+    double *com = nullptr, *footp = nullptr;                                               // [B][3], [3 NF] world frame
     double *H = nullptr, *g = nullptr, *C = nullptr, *l = nullptr, *u = nullptr;           // [B][NP NP], [NP], [MP][NP], [MP], [MP]
     double *x = nullptr, *z = nullptr, *lam = nullptr;                                     // ADMM iterate [B][NP], [MP], [MP]
     int * warm = nullptr;                                                                   // [B] 0 = start from scratch
     double *tq = nullptr, *tv = nullptr, *ta = nullptr, *tf = nullptr;                     // targets [B][NQ], [NV], [NV], [3 NF]
     unsigned * tmask = nullptr;                                                             // [B]
+    double *tcom = nullptr, *tvcom = nullptr, *tfp = nullptr, *tfv = nullptr;              // CentroidalID targets [B][3], [3], [3 NF], [3 NF]
     double *tau = nullptr, *a = nullptr, *f = nullptr, *resid = nullptr;                   // [B][NA], [NV], [3 NF], [B]
     double *tau_max = nullptr, *v_max = nullptr, *q_min = nullptr, *q_max = nullptr;       // [NA] each
     IdSettingsDev s;
@@ -105,7 +110,10 @@ namespace smpc
         const SV v = ldsv(&sc.vel[jf * 6]);
         const V3 vp = v.l + cross(v.a, ld3(&sc.footp[f * 3]));
         b.vfoot[(size_t)inst * 3 * NF + lane] = i == 0 ? vp.x : (i == 1 ? vp.y : vp.z);
+        b.footp[(size_t)inst * 3 * NF + lane] = sc.footp[lane];
       }
+      if (lane < 3)
+        b.com[(size_t)inst * 3 + lane] = sc.com[lane];
     }
     SMPC_LANES_END_WAVE
   }
@@ -134,7 +142,49 @@ namespace smpc
     double * l = b.l + (size_t)inst * MP;
     double * u = b.u + (size_t)inst * MP;
     const double kdp = 2.0 * sqrt(s.kp_posture), kdb = 2.0 * sqrt(s.kp_base), kdc = 2.0 * sqrt(s.kp_contact);
+    const double kdm = 2.0 * sqrt(s.kp_com), kdt = 2.0 * sqrt(s.kp_feet_tracking);
+    const bool com_task = s.centroidal && s.w_com > 0, track_task = s.centroidal && s.w_feet_tracking > 0;
+    const int base0 = s.centroidal ? 3 : 0; // (CentroidalID: orientation rows only, centroidal-id.cpp:10-20)
     SMPC_LDS(double, e6, 6);
+    SMPC_LDS(double, Jc, 3 * NV); // CoM Jacobian R_b M_lin / m
+    SMPC_LDS(double, bc, 3);      // right-hand side of the CoM task
+    SMPC_LDS(double, bt, 3 * NF); // right-hand sides of the foot-tracking tasks
+    SMPC_LANES(NT)
+    if (com_task)
+      for (int idx = lane; idx < 3 * NV; idx += NT)
+      {
+        const int i = idx / NV, k = idx % NV;
+        const M3 Rb = quat_to_R(Quat{q[3], q[4], q[5], q[6]});
+        const double im = 1.0 / b.model->total_mass;
+        const double r0 = i == 0 ? Rb.a00 : (i == 1 ? Rb.a10 : Rb.a20), r1 = i == 0 ? Rb.a01 : (i == 1 ? Rb.a11 : Rb.a21),
+                     r2 = i == 0 ? Rb.a02 : (i == 1 ? Rb.a12 : Rb.a22);
+        Jc[idx] = im * (r0 * Mq[k] + r1 * Mq[NV + k] + r2 * Mq[2 * NV + k]);
+      }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    {
+      if (com_task && lane < 3)
+      { // a_com = J_com a + drift, drift = R_b nle_lin / m + g (TaskComEquality, centroidal-id.cpp:22-27)
+        const int i = lane;
+        const M3 Rb = quat_to_R(Quat{q[3], q[4], q[5], q[6]});
+        const double im = 1.0 / b.model->total_mass;
+        const double r0 = i == 0 ? Rb.a00 : (i == 1 ? Rb.a10 : Rb.a20), r1 = i == 0 ? Rb.a01 : (i == 1 ? Rb.a11 : Rb.a21),
+                     r2 = i == 0 ? Rb.a02 : (i == 1 ? Rb.a12 : Rb.a22);
+        double vc = 0.0;
+        for (int k = 0; k < NV; k++)
+          vc += Jc[i * NV + k] * v[k];
+        const double dr = im * (r0 * nle[0] + r1 * nle[1] + r2 * nle[2]) + (i == 2 ? -9.81 : 0.0);
+        bc[i] = s.kp_com * (b.tcom[(size_t)inst * 3 + i] - b.com[(size_t)inst * 3 + i]) + kdm * (b.tvcom[(size_t)inst * 3 + i] - vc) - dr;
+      }
+      if (track_task && lane >= 32 && lane < 32 + 3 * NF)
+      { // position tracking of the feet out of contact (centroidal-id.cpp:101-129; point feet: linear part)
+        const int r = lane - 32;
+        const size_t o = (size_t)inst * 3 * NF + r;
+        bt[r] = s.kp_feet_tracking * (b.tfp[o] - b.footp[o]) + kdt * (b.tfv[o] - vf[r]) - Jdv[r];
+      }
+    }
+    SMPC_LANES_END_WAVE
+    static_assert(3 * NF <= 32, "lane map of the task right-hand sides");
     SMPC_LANES(NT)
     if (lane == 0)
     { // base error log6(M_b^-1 M_t), local frame
@@ -159,8 +209,15 @@ namespace smpc
         {
           if (i == j && i >= 6 && i < NV && s.w_posture > 0)
             h += s.w_posture;
-          if (i == j && i < 6 && s.w_base > 0)
+          if (i == j && i >= base0 && i < 6 && s.w_base > 0)
             h += s.w_base;
+          if (i < NV && j < NV && com_task)
+            for (int r = 0; r < 3; r++)
+              h += s.w_com * Jc[r * NV + i] * Jc[r * NV + j];
+          if (i < NV && j < NV && track_task)
+            for (int r = 0; r < 3 * NF; r++)
+              if (!((mask >> (r / 3)) & 1u))
+                h += s.w_feet_tracking * J[r * NV + i] * J[r * NV + j];
           if (i < NV && j < NV && !s.contact_motion_equality && s.w_contact_motion > 0)
             for (int r = 0; r < 3 * NF; r++)
               if ((mask >> (r / 3)) & 1u)
@@ -177,12 +234,19 @@ namespace smpc
         {
           if (i >= 6 && i < NV && s.w_posture > 0)
             gi -= s.w_posture * (ta[i] + s.kp_posture * (tq[i + 1] - q[i + 1]) + kdp * (tv[i] - v[i]));
-          if (i < 6 && s.w_base > 0)
+          if (i >= base0 && i < 6 && s.w_base > 0)
           {
             const V3 dr = cross(mk3(v[3], v[4], v[5]), mk3(v[0], v[1], v[2]));
             const double ades = s.kp_base * e6[i] + kdb * (tv[i] - v[i]) + ta[i]; // (velocity / acceleration references: DESIGN 3.12)
             gi -= s.w_base * (ades - (i == 0 ? dr.x : (i == 1 ? dr.y : (i == 2 ? dr.z : 0.0))));
           }
+          if (i < NV && com_task)
+            for (int r = 0; r < 3; r++)
+              gi -= s.w_com * Jc[r * NV + i] * bc[r];
+          if (i < NV && track_task)
+            for (int r = 0; r < 3 * NF; r++)
+              if (!((mask >> (r / 3)) & 1u))
+                gi -= s.w_feet_tracking * J[r * NV + i] * bt[r];
           if (i < NV && !s.contact_motion_equality && s.w_contact_motion > 0)
             for (int r = 0; r < 3 * NF; r++)
               if ((mask >> (r / 3)) & 1u)
@@ -475,8 +539,11 @@ namespace smpc
     virtual ~IdEngineBase() {}
     virtual void set_target(int inst, const double * q, const double * v, const double * a, unsigned mask, const double * f) = 0;
     virtual void set_targets(const double * Q, const double * V, const double * A, const unsigned char * contact, const double * F) = 0;
+    // CentroidalID::setTarget (centroidal-id.cpp:86-147): com, vcom (3), feet positions / velocities (3 nf, world frame), contacts, forces
+    virtual void set_target_centroidal(int inst, const double * com, const double * vcom, const double * fp, const double * fv, unsigned mask, const double * f) = 0;
+    virtual void set_targets_centroidal(const double * COM, const double * VCOM, const double * FP, const double * FV, const unsigned char * contact, const double * F) = 0;
     virtual void solve(const double * X, double * tau, double * a, double * f, double * resid) = 0;
-    virtual void debug_get(int what, double * out) = 0; // 0 M, 1 nle, 2 J, 3 Jdv, 4 vfoot, 5 H, 6 g, 7 C, 8 l, 9 u (padded layouts)
+    virtual void debug_get(int what, double * out) = 0; // 0 M, 1 nle, 2 J, 3 Jdv, 4 vfoot, 5 H, 6 g, 7 C, 8 l, 9 u (padded layouts), 10 com, 11 footp
   };
   template <class D>
   struct IdEngine : IdEngineBase
@@ -530,6 +597,12 @@ namespace smpc
       buf.J = dalloc(Bs * 3 * nf * nv);
       buf.Jdv = dalloc(Bs * 3 * nf);
       buf.vfoot = dalloc(Bs * 3 * nf);
+      buf.com = dalloc(Bs * 3);
+      buf.footp = dalloc(Bs * 3 * nf);
+      buf.tcom = dalloc(Bs * 3);
+      buf.tvcom = dalloc(Bs * 3);
+      buf.tfp = dalloc(Bs * 3 * nf);
+      buf.tfv = dalloc(Bs * 3 * nf);
       buf.H = dalloc(Bs * np * np);
       buf.g = dalloc(Bs * np);
       buf.C = dalloc(Bs * mp * np);
@@ -566,6 +639,22 @@ namespace smpc
       for (int k = 0; k < nf; k++)
         f[3 * k + 2] = rm->total_mass * 9.81 / nf;
       set_target(-1, q.data(), z.data(), z.data(), (1u << nf) - 1u, f.data());
+      if (buf.s.centroidal)
+      { // CoM of the reference state (one pass of the first kernel), feet at their reference placements (centroidal-id.cpp:60-84)
+        std::vector<double> X((size_t)B * D::NX, 0.0);
+        for (int b = 0; b < B; b++)
+          std::copy(q.begin(), q.end(), X.begin() + (size_t)b * D::NX);
+        h2d(Xd, X.data(), X.size() * sizeof(double), stream);
+        launch<IdBuffers<D>, id_quant_body<D>, 64, 1, 0>(B, stream, buf);
+        double com[3];
+        d2h(com, buf.com, sizeof(com), stream);
+        stream_sync(stream);
+        const M3 R0 = quat_to_R(Quat{q[3], q[4], q[5], q[6]});
+        std::vector<double> fp(3 * nf), zf(3 * nf, 0.0);
+        for (int k = 0; k < nf; k++)
+          st3(&fp[3 * k], ld3(q.data()) + R0 * ld3(rm->foot_ref_p[k]));
+        set_target_centroidal(-1, com, z.data(), fp.data(), zf.data(), (1u << nf) - 1u, f.data());
+      }
     }
     ~IdEngine()
     {
@@ -610,6 +699,49 @@ namespace smpc
       h2d(buf.tmask, tm.data(), (size_t)B * sizeof(unsigned), stream);
       stream_sync(stream);
     }
+    void set_target_centroidal(int inst, const double * com, const double * vcom, const double * fp, const double * fv, unsigned mask, const double * f) override
+    {
+      set_device(device_id);
+      if (!buf.s.centroidal)
+        throw std::runtime_error("this inverse-dynamics engine was created as KinodynamicsID");
+      if (inst >= B)
+        throw std::runtime_error("instance index exceeds the batch");
+      const int i0 = inst < 0 ? 0 : inst, i1 = inst < 0 ? B : inst + 1, cnt = i1 - i0;
+      std::vector<double> c3((size_t)cnt * 3), v3((size_t)cnt * 3), tp((size_t)cnt * 3 * nf), tv((size_t)cnt * 3 * nf), tf((size_t)cnt * 3 * nf);
+      std::vector<unsigned> tm(cnt, mask);
+      for (int i = 0; i < cnt; i++)
+      {
+        std::copy(com, com + 3, c3.begin() + (size_t)i * 3);
+        std::copy(vcom, vcom + 3, v3.begin() + (size_t)i * 3);
+        std::copy(fp, fp + 3 * nf, tp.begin() + (size_t)i * 3 * nf);
+        std::copy(fv, fv + 3 * nf, tv.begin() + (size_t)i * 3 * nf);
+        std::copy(f, f + 3 * nf, tf.begin() + (size_t)i * 3 * nf);
+      }
+      h2d(buf.tcom + (size_t)i0 * 3, c3.data(), c3.size() * sizeof(double), stream);
+      h2d(buf.tvcom + (size_t)i0 * 3, v3.data(), v3.size() * sizeof(double), stream);
+      h2d(buf.tfp + (size_t)i0 * 3 * nf, tp.data(), tp.size() * sizeof(double), stream);
+      h2d(buf.tfv + (size_t)i0 * 3 * nf, tv.data(), tv.size() * sizeof(double), stream);
+      h2d(buf.tf + (size_t)i0 * 3 * nf, tf.data(), tf.size() * sizeof(double), stream);
+      h2d(buf.tmask + i0, tm.data(), tm.size() * sizeof(unsigned), stream);
+      stream_sync(stream);
+    }
+    void set_targets_centroidal(const double * COM, const double * VCOM, const double * FP, const double * FV, const unsigned char * contact, const double * F) override
+    {
+      set_device(device_id);
+      if (!buf.s.centroidal)
+        throw std::runtime_error("this inverse-dynamics engine was created as KinodynamicsID");
+      std::vector<unsigned> tm(B, 0u);
+      for (int b = 0; b < B; b++)
+        for (int k = 0; k < nf; k++)
+          tm[b] |= contact[(size_t)b * nf + k] ? (1u << k) : 0u;
+      h2d(buf.tcom, COM, (size_t)B * 3 * sizeof(double), stream);
+      h2d(buf.tvcom, VCOM, (size_t)B * 3 * sizeof(double), stream);
+      h2d(buf.tfp, FP, (size_t)B * 3 * nf * sizeof(double), stream);
+      h2d(buf.tfv, FV, (size_t)B * 3 * nf * sizeof(double), stream);
+      h2d(buf.tf, F, (size_t)B * 3 * nf * sizeof(double), stream);
+      h2d(buf.tmask, tm.data(), (size_t)B * sizeof(unsigned), stream);
+      stream_sync(stream);
+    }
     void launch_all()
     {
       launch<IdBuffers<D>, id_quant_body<D>, 64, 1, 0>(B, stream, buf);
@@ -631,9 +763,9 @@ namespace smpc
     void debug_get(int what, double * out) override
     {
       set_device(device_id);
-      const double * src[10] = {buf.Mq, buf.nle, buf.J, buf.Jdv, buf.vfoot, buf.H, buf.g, buf.C, buf.l, buf.u};
-      const size_t per[10] = {(size_t)nv * nv, (size_t)nv, (size_t)3 * nf * nv, (size_t)3 * nf, (size_t)3 * nf, (size_t)np * np, (size_t)np, (size_t)mp * np, (size_t)mp, (size_t)mp};
-      if (what < 0 || what > 9)
+      const double * src[12] = {buf.Mq, buf.nle, buf.J, buf.Jdv, buf.vfoot, buf.H, buf.g, buf.C, buf.l, buf.u, buf.com, buf.footp};
+      const size_t per[12] = {(size_t)nv * nv, (size_t)nv, (size_t)3 * nf * nv, (size_t)3 * nf, (size_t)3 * nf, (size_t)np * np, (size_t)np, (size_t)mp * np, (size_t)mp, (size_t)mp, 3, (size_t)3 * nf};
+      if (what < 0 || what > 11)
         throw std::runtime_error("unknown quantity");
       d2h(out, src[what], (size_t)B * per[what] * sizeof(double), stream);
       stream_sync(stream);

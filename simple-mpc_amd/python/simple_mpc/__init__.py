@@ -17,7 +17,7 @@ import numpy as np
 from . import _capi
 from ._capi import IdSettingsC, CentroidalSettingsC, FullDynamicsSettingsC, KinodynamicsSettingsC, MpcSettingsC, SmpcLib, default_lib
 
-__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "CentroidalOCP", "FullDynamicsOCP", "MPC", "BatchedMPC", "Interpolator", "FrictionCompensation", "centroidal_dynamics"]
+__all__ = ["load_robot", "RobotModelHandler", "RobotDataHandler", "KinodynamicsOCP", "CentroidalOCP", "FullDynamicsOCP", "MPC", "BatchedMPC", "Interpolator", "FrictionCompensation", "KinodynamicsID", "CentroidalID", "centroidal_dynamics"]
 
 
 def load_robot(name, lib=None):
@@ -1089,11 +1089,12 @@ class KinodynamicsID:
              "w_posture", "w_contact_motion", "w_contact_force", "contact_motion_equality"]
     _DEFAULTS = dict(friction_coefficient=0.6, contact_weight_ratio_max=10.0, contact_weight_ratio_min=0.01, kp_base=0.0, kp_posture=0.0,
                      kp_contact=0.0, w_base=-1.0, w_posture=-1.0, w_contact_motion=-1.0, w_contact_force=-1.0, contact_motion_equality=False)
+    _CENTROIDAL = False
 
     def __init__(self, model_handler, control_dt, settings, effort_limit, velocity_limit, batch=1, device_id=0, lib=None, admm_iters=0, admm_tol=0.0):
         unknown = [k for k in settings if k not in self._KEYS]
         if unknown:
-            raise KeyError("unknown KinodynamicsID settings: %s" % unknown)
+            raise KeyError("unknown %s settings: %s" % (type(self).__name__, unknown))
         self.settings = dict(self._DEFAULTS, **settings)
         self.model_handler = model_handler
         self._lib = lib or default_lib()
@@ -1106,7 +1107,9 @@ class KinodynamicsID:
         s = self.settings
         c = IdSettingsC(s["friction_coefficient"], s["contact_weight_ratio_max"], s["contact_weight_ratio_min"], s["kp_base"], s["kp_posture"],
                         s["kp_contact"], s["w_base"], s["w_posture"], s["w_contact_motion"], s["w_contact_force"],
-                        int(bool(s["contact_motion_equality"])), float(control_dt), *[a.ctypes.data for a in self._keep], int(admm_iters), 0.0, 0.0, 0.0, float(admm_tol))
+                        int(bool(s["contact_motion_equality"])), float(control_dt), *[a.ctypes.data for a in self._keep], int(admm_iters), 0.0, 0.0, 0.0, float(admm_tol),
+                        int(self._CENTROIDAL), float(s.get("kp_com", 0.0)), float(s.get("kp_feet_tracking", 0.0)), float(s.get("w_com", -1.0)),
+                        float(s.get("w_feet_tracking", -1.0)))
         h = C.c_void_p()
         self._lib.check(self._lib.L.smpc_id_create(model_handler._ptr, C.byref(c), self.B, device_id, C.byref(h)))
         self._h = h
@@ -1161,10 +1164,52 @@ class KinodynamicsID:
 
     def debug(self, what):
         per = {0: (self._nv, self._nv), 1: (self._nv,), 2: (3 * self._nf, self._nv), 3: (3 * self._nf,), 4: (3 * self._nf,), 5: (32, 32), 6: (32,),
-               7: (80, 32), 8: (80,), 9: (80,)}[what]
+               7: (80, 32), 8: (80,), 9: (80,), 10: (3,), 11: (3 * self._nf,)}[what]
         out = np.zeros((self.B,) + per)
         self._lib.check(self._lib.L.smpc_id_debug_get(self._h, what, out))
         return out
+
+
+def _positions(poses, nf):
+    """[nf][3] from an array of positions or a list of placements (objects with `.translation`)."""
+    return np.array([np.asarray(p.translation if hasattr(p, "translation") else p, dtype=np.float64).reshape(-1)[:3] for p in poses]).reshape(nf, 3)
+
+
+def _linear_velocities(vels, nf):
+    """[nf][3] from an array [nf][3], spatial velocities [nf][6] (linear part first) or objects with `.linear`."""
+    return np.array([np.asarray(m.linear if hasattr(m, "linear") else m, dtype=np.float64).reshape(-1)[:3] for m in vels]).reshape(nf, 3)
+
+
+class CentroidalID(KinodynamicsID):
+    """reference include/simple-mpc/inverse-dynamics/centroidal-id.hpp, src/inverse-dynamics/centroidal-id.cpp:6-147 (CentroidalIDSettings
+    = the KinodynamicsID keys + kp_com, kp_feet_tracking, w_com, w_feet_tracking): the base task keeps the orientation rows, a
+    centre-of-mass task and a position-tracking task for every foot out of contact are added; the posture and base-orientation targets are
+    the reference state.  Same device kernels as KinodynamicsID, same batch semantics."""
+
+    _KEYS = KinodynamicsID._KEYS + ["kp_com", "kp_feet_tracking", "w_com", "w_feet_tracking"]
+    _DEFAULTS = dict(KinodynamicsID._DEFAULTS, kp_com=0.0, kp_feet_tracking=0.0, w_com=-1.0, w_feet_tracking=-1.0)
+    _CENTROIDAL = True
+
+    def setTarget(self, com_position, com_velocity, feet_pose, feet_velocity, contact_state_target, f_target, instance=-1):
+        """reference centroidal-id.cpp:86-147.  feet_pose: one placement per foot (objects with `.translation`, or positions [nf][3]);
+        feet_velocity: one spatial velocity per foot (objects with `.linear`, [nf][6] linear part first, or [nf][3]); instance = -1: every
+        robot."""
+        c = lambda x, n: np.ascontiguousarray(np.array(x, dtype=np.float64).reshape(n))
+        contact = np.ascontiguousarray(np.array([1 if b else 0 for b in contact_state_target], dtype=np.uint8))
+        if contact.size != self._nf:
+            raise RuntimeError("contact_state_target must have one entry per foot")
+        f = np.zeros(3 * self._nf) if len(f_target) == 0 else c(f_target, 3 * self._nf)
+        self._lib.check(self._lib.L.smpc_id_set_target_centroidal(
+            self._h, int(instance), c(com_position, 3), c(com_velocity, 3), c(_positions(feet_pose, self._nf), 3 * self._nf),
+            c(_linear_velocities(feet_velocity, self._nf), 3 * self._nf), contact, f))
+
+    def setTargets(self, COM, VCOM, FEET_P, FEET_V, contact_states, F):
+        """One target per robot: COM, VCOM [B][3], FEET_P, FEET_V [B][nf][3], contact_states [B][nf] (or one list for all), F [B][nf][3]."""
+        c = lambda x, n: np.ascontiguousarray(np.array(x, dtype=np.float64).reshape(self.B, n))
+        cs = np.array(contact_states)
+        cs = np.ascontiguousarray(np.broadcast_to(cs.reshape(-1, self._nf), (self.B, self._nf)).astype(np.uint8))
+        self._lib.check(self._lib.L.smpc_id_set_targets_centroidal(self._h, c(COM, 3), c(VCOM, 3), c(FEET_P, 3 * self._nf), c(FEET_V, 3 * self._nf), cs,
+                                                                   c(F, 3 * self._nf)))
 
 
 class FrictionCompensation:

@@ -112,6 +112,7 @@ class IdSettingsC(C.Structure):
         ("contact_motion_equality", C.c_int), ("control_dt", C.c_double),
         ("effort_limit", C.c_void_p), ("velocity_limit", C.c_void_p), ("q_min", C.c_void_p), ("q_max", C.c_void_p),
         ("admm_iters", C.c_int), ("admm_rho", C.c_double), ("admm_sigma", C.c_double), ("admm_alpha", C.c_double), ("admm_tol", C.c_double),
+        ("centroidal", C.c_int), ("kp_com", C.c_double), ("kp_feet_tracking", C.c_double), ("w_com", C.c_double), ("w_feet_tracking", C.c_double),
     ]
 
 
@@ -152,7 +153,7 @@ SYMBOLS = [
     "smpc_get_foot_timing", "smpc_get_info", "smpc_get_status", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
     "smpc_debug_get_steps", "smpc_debug_get_terminal", "smpc_debug_get_phase_cycles", "smpc_set_profiling", "smpc_get_kernel_times", "smpc_reset_kernel_times",
     "smpc_interpolate", "smpc_interpolate_knots", "smpc_friction_compensation", "smpc_update_internal_data", "smpc_full_forward_dynamics", "smpc_centroidal_dynamics", "smpc_riccati_feedback",
-    "smpc_id_create", "smpc_id_destroy", "smpc_id_set_target", "smpc_id_set_targets", "smpc_id_solve", "smpc_id_debug_get",
+    "smpc_id_create", "smpc_id_destroy", "smpc_id_set_target", "smpc_id_set_targets", "smpc_id_set_target_centroidal", "smpc_id_set_targets_centroidal", "smpc_id_solve", "smpc_id_debug_get",
 ]
 
 
@@ -202,6 +203,8 @@ class SmpcLib:
         L.smpc_id_destroy.restype = None
         L.smpc_id_set_target.argtypes = [vp, C.c_int, _dp, _dp, _dp, _bp, _dp]
         L.smpc_id_set_targets.argtypes = [vp, _dp, _dp, _dp, _bp, _dp]
+        L.smpc_id_set_target_centroidal.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, _bp, _dp]
+        L.smpc_id_set_targets_centroidal.argtypes = [vp, _dp, _dp, _dp, _dp, _bp, _dp]
         L.smpc_id_solve.argtypes = [vp, _dp, _dp, C.c_void_p, C.c_void_p, C.c_void_p]
         L.smpc_id_debug_get.argtypes = [vp, C.c_int, _dp]
         L.smpc_get_status.argtypes = [vp, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]

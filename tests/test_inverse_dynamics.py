@@ -13,6 +13,10 @@ KEYS = simple_mpc.KinodynamicsID._KEYS
 ALL = dict(kp_base=10.0, kp_posture=1.0, kp_contact=10.0, w_base=10.0, w_posture=0.1, w_contact_force=1e-3, w_contact_motion=1.0)
 
 
+CKEYS = simple_mpc.CentroidalID._KEYS
+CALL = dict(ALL, kp_com=7.0, kp_feet_tracking=5.0, w_com=10.0, w_feet_tracking=100.0)  # every task of CentroidalID on
+
+
 def make(lib, B, admm_iters=100, admm_tol=-1.0, **kw):
     """(admm_tol < 0: exactly admm_iters iterations on both sides, so that the comparison does not hinge on two roundings of a residual
     falling on the same side of the stopping tolerance)"""
@@ -22,7 +26,10 @@ def make(lib, B, admm_iters=100, admm_tol=-1.0, **kw):
     mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
     for n in S.FEET:
         mh.addPointFoot(n, "root_joint")
-    gk = simple_mpc.KinodynamicsID(mh, DT, {k: s[k] for k in KEYS}, s["tau_max"], s["v_max"], batch=B, lib=lib, admm_iters=admm_iters, admm_tol=admm_tol)
+    if s["centroidal"]:
+        gk = simple_mpc.CentroidalID(mh, DT, {k: s[k] for k in CKEYS}, s["tau_max"], s["v_max"], batch=B, lib=lib, admm_iters=admm_iters, admm_tol=admm_tol)
+    else:
+        gk = simple_mpc.KinodynamicsID(mh, DT, {k: s[k] for k in KEYS}, s["tau_max"], s["v_max"], batch=B, lib=lib, admm_iters=admm_iters, admm_tol=admm_tol)
     return rb, ok, gk
 
 
@@ -34,21 +41,84 @@ def _pieces(lib):
         k.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True, True, False, True], fs, instance=1)  # one robot with a foot in the air
     to, ao, fo = ok.solve(X)
     tg = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
+    _compare_qp(rb, ok, gk, X)
+    assert S.rel_err(to, tg) < 1e-8 and S.rel_err(ao, gk.getAccelerations()) < 1e-8 and S.rel_err(fo, gk.getContactForces().reshape(3, -1)) < 1e-8
+    assert np.allclose(gk.getContactForces()[1, 2], 0.0, atol=1e-6)  # the foot in the air carries nothing (to the ADMM residual)
+    assert gk.resid.max() < 1e-3 and np.allclose(gk.resid, ok.resid, rtol=1e-3, atol=1e-9)
+
+
+def _compare_qp(rb, ok, gk, X):
     n, m = ok.n, ok.m
-    for b in range(3):
+    for b in range(X.shape[0]):
         Q = O.id_quantities(rb, X[b])
         for what, key in ((0, "M"), (1, "nle"), (2, "J"), (3, "Jdv"), (4, "vfoot")):
             assert S.rel_err(Q[key], gk.debug(what)[b]) < 1e-11, key
         H, g, Cm, l, u = ok.qp(b, X[b])
-        assert S.rel_err(H, gk.debug(5)[b][:n, :n]) < 1e-11 and S.rel_err(g, gk.debug(6)[b][:n]) < 1e-11
+        assert S.rel_err(H, gk.debug(5)[b][:n, :n]) < 1e-11 and S.rel_err(g, gk.debug(6)[b][:n]) < 1e-11, (b, S.rel_err(H, gk.debug(5)[b][:n, :n]))
         assert S.rel_err(Cm, gk.debug(7)[b][:m, :n]) < 1e-11
         lg, ug = gk.debug(8)[b][:m], gk.debug(9)[b][:m]
         assert np.array_equal(np.abs(l) > 1e19, np.abs(lg) > 1e19) and np.array_equal(np.abs(u) > 1e19, np.abs(ug) > 1e19)
         fin = np.abs(l) < 1e19
         assert np.allclose(l[fin], lg[fin], rtol=1e-11, atol=1e-9) and np.allclose(u[np.abs(u) < 1e19], ug[np.abs(u) < 1e19], rtol=1e-11, atol=1e-9)
+
+
+def _centroidal_pieces(lib):
+    """CentroidalID: default targets, a per-robot target with a foot in the air (tracking rows), the QP data and its solution."""
+    rb, ok, gk = make(lib, 3, centroidal=True, **CALL)
+    X = S.random_states(rb, 3)
+    # (defaults: CoM of the reference state, feet at their reference placements -- solved once before any setTarget)
+    to, ao, fo = ok.solve(X)
+    tg = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
+    _compare_qp(rb, ok, gk, X)
+    for b in range(3):
+        c = rb.centroidal(X[b])
+        assert S.rel_err(c["com"], gk.debug(10)[b]) < 1e-12 and S.rel_err(c["feet"].reshape(-1), gk.debug(11)[b]) < 1e-12
+    assert S.rel_err(to, tg) < 1e-8 and S.rel_err(ao, gk.getAccelerations()) < 1e-8
+    c = rb.centroidal(rb.x_ref)
+    feet = c["feet"].copy()
+    feet[2] += [0.05, -0.05, 0.05]
+    contact = [True, True, False, True]
+    fs = static_forces(rb, contact=contact)
+    vcom, fv = np.array([0.1, 0.0, -0.05]), np.zeros((4, 3))
+    fv[2] = [0.2, 0.0, 0.1]
+    ok.setTargetCentroidal(c["com"] + [0.01, 0.0, 0.02], vcom, feet, fv, contact, fs, instance=1)
+    gk.setTarget(c["com"] + [0.01, 0.0, 0.02], vcom, feet, np.c_[fv, np.zeros((4, 3))], contact, fs.reshape(4, 3), instance=1)  # (spatial velocities)
+    to, ao, fo = ok.solve(X)
+    tg = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
+    _compare_qp(rb, ok, gk, X)
     assert S.rel_err(to, tg) < 1e-8 and S.rel_err(ao, gk.getAccelerations()) < 1e-8 and S.rel_err(fo, gk.getContactForces().reshape(3, -1)) < 1e-8
-    assert np.allclose(gk.getContactForces()[1, 2], 0.0, atol=1e-6)  # the foot in the air carries nothing (to the ADMM residual)
-    assert gk.resid.max() < 1e-3 and np.allclose(gk.resid, ok.resid, rtol=1e-3, atol=1e-9)
+    assert np.allclose(gk.getContactForces()[1, 2], 0.0, atol=1e-6)
+    with pytest.raises(RuntimeError, match="KinodynamicsID"):
+        kk = make(lib, 1, **ALL)[2]
+        kk._lib.check(kk._lib.L.smpc_id_set_target_centroidal(kk._h, -1, np.zeros(3), np.zeros(3), np.zeros(12), np.zeros(12), np.ones(4, np.uint8), np.zeros(12)))
+
+
+def _centroidal_closed_loop(lib, n_steps, tol):
+    """The foot-tracking scenario of tests/test_oracle_id.py (reference tests/inverse-dynamics/centroidal-id.cpp:345-405) for two robots, one
+    target each through the batched setTargets."""
+    kw = dict(kp_feet_tracking=5.0, kp_posture=0.1, kp_contact=1.0, w_feet_tracking=1e3, w_posture=1.0, w_contact_force=1e-3, contact_motion_equality=True,
+              kp_com=7.0, w_com=10.0, kp_base=7.0, w_base=10.0)
+    rb, ok, gk = make(lib, 2, centroidal=True, **kw)
+    c = rb.centroidal(rb.x_ref)
+    contact = [True, True, False, True]
+    fs = static_forces(rb, contact=contact)
+    FP = np.stack([c["feet"], c["feet"]])
+    FP[0, 2] += [0.05, -0.05, 0.05]
+    FP[1, 2] += [-0.03, 0.0, 0.08]
+    COM = np.stack([c["com"], c["com"] + [0.0, 0.01, 0.0]])
+    for b in range(2):
+        ok.setTargetCentroidal(COM[b], np.zeros(3), FP[b], np.zeros((4, 3)), contact, fs, instance=b)
+    gk.setTargets(COM, np.zeros((2, 3)), FP, np.zeros((2, 4, 3)), contact, np.tile(fs, (2, 1)))
+    X = np.stack([rb.x_ref.copy(), rb.x_ref.copy()])
+    e0 = None
+    for _ in range(n_steps):
+        to, ao, fo = ok.solve(X)
+        tg = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
+        assert S.rel_err(to, tg) < tol and S.rel_err(ao, gk.getAccelerations()) < tol
+        X = np.stack([step(rb, X[b], ao[b]) for b in range(2)])
+        e = [np.linalg.norm(rb.centroidal(X[b])["feet"][2] - FP[b, 2]) for b in range(2)]
+        e0 = e0 or e
+    assert e[0] < e0[0] and e[1] < e0[1]  # the feet in the air move towards their targets
 
 
 def _closed_loop(lib, n_steps, tol, **solver):
@@ -83,6 +153,14 @@ def test_emulated_kernels_closed_loop_default_stopping_rule(built):
     _closed_loop(S.emu_lib(), 40, 1e-5, admm_iters=400, admm_tol=1e-7)
 
 
+def test_emulated_kernels_centroidal_id_pieces(built):
+    _centroidal_pieces(S.emu_lib())
+
+
+def test_emulated_kernels_centroidal_id_closed_loop(built):
+    _centroidal_closed_loop(S.emu_lib(), 60, 1e-7)
+
+
 def test_settings_and_errors(built):
     lib = S.emu_lib()
     mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
@@ -115,11 +193,26 @@ def test_hip_closed_loop(built):
 
 
 @pytest.mark.gpu
+def test_hip_closed_loop_default_stopping_rule(built):
+    _closed_loop(None, 200, 1e-5, admm_iters=400, admm_tol=1e-7)
+
+
+@pytest.mark.gpu
+def test_hip_centroidal_id_pieces(built):
+    _centroidal_pieces(None)
+
+
+@pytest.mark.gpu
+def test_hip_centroidal_id_closed_loop(built):
+    _centroidal_closed_loop(None, 400, 1e-7)
+
+
+@pytest.mark.gpu
 def test_hip_batch_of_4096_robots(built):
     """4096 robots, 16 distinct states replicated: replicas bit-identical, the distinct ones follow the oracle, limits respected."""
     B, nd = 4096, 16
     rb, ok, gk = make(None, B, **ALL)
-    ok = O.OracleKinoID(rb, O.id_settings(rb, DT, **ALL), nd)
+    ok = O.OracleKinoID(rb, O.id_settings(rb, DT, admm_iters=100, admm_tol=-1.0, **ALL), nd)
     fs = static_forces(rb)
     for k in (ok, gk):
         k.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True] * 4, fs)
