@@ -269,27 +269,34 @@ namespace orc
   }
 
   // ADMM (x = y of the QP); x, z, lam are the warm start on entry and the iterate on exit.  Returns max(primal, dual) residual.
-  inline double qp_admm(const QP & qp, double rho, double sigma, double alpha, int iters, double tol, Vec & x, Vec & z, Vec & lam)
+  // `rho` is the step-size parameter of this instance: kept across solves (warm start) and adapted as OSQP does (Stellato et al. 2020,
+  // section 5.2): at a residual check, rho <- rho sqrt((r_prim / max(|Cx|, |z|)) / (r_dual / max(|Hx|, |C^T lam|, |g|))), applied -- with a
+  // new factorisation of K -- when it moves by more than a factor 5.
+  inline double qp_admm(const QP & qp, double & rho, double sigma, double alpha, int iters, double tol, Vec & x, Vec & z, Vec & lam)
   {
     const int n = qp.n, m = qp.m;
     Vec r(m);
-    for (int i = 0; i < m; i++)
-      r[i] = (qp.u[i] - qp.l[i] < 1e-12) ? 1e3 * rho : ((qp.l[i] <= -ID_INF && qp.u[i] >= ID_INF) ? 1e-6 * rho : rho);
-    Mat K = qp.H;
-    for (int i = 0; i < n; i++)
-      K(i, i) += sigma;
-    for (int k = 0; k < m; k++)
+    Mat K;
+    auto factor = [&]() {
+      for (int i = 0; i < m; i++)
+        r[i] = (qp.u[i] - qp.l[i] < 1e-12) ? 1e3 * rho : ((qp.l[i] <= -ID_INF && qp.u[i] >= ID_INF) ? 1e-6 * rho : rho);
+      K = qp.H;
       for (int i = 0; i < n; i++)
-      {
-        const double ci = qp.C(k, i);
-        if (ci == 0.0)
-          continue;
-        for (int j = 0; j < n; j++)
-          K(i, j) += r[k] * ci * qp.C(k, j);
-      }
-    bool ok = cholesky(K);
-    assert(ok);
-    (void)ok;
+        K(i, i) += sigma;
+      for (int k = 0; k < m; k++)
+        for (int i = 0; i < n; i++)
+        {
+          const double ci = qp.C(k, i);
+          if (ci == 0.0)
+            continue;
+          for (int j = 0; j < n; j++)
+            K(i, j) += r[k] * ci * qp.C(k, j);
+        }
+      bool ok = cholesky(K);
+      assert(ok);
+      (void)ok;
+    };
+    factor();
     if ((int)x.size() != n)
     {
       x.assign(n, 0.0);
@@ -299,32 +306,45 @@ namespace orc
         z[k] = std::fmin(std::fmax(0.0, qp.l[k]), qp.u[k]);
     }
     Vec rhs(n), zt(m);
+    double pr, du, np_, nd_; // residuals and the norms they are measured against
     auto residual = [&]() {
-      double pr = 0.0, du = 0.0;
+      pr = du = np_ = nd_ = 0.0;
       for (int k = 0; k < m; k++)
       {
         double acc = 0.0;
         for (int i = 0; i < n; i++)
           acc += qp.C(k, i) * x[i];
         pr = std::fmax(pr, std::fabs(acc - z[k]));
+        np_ = std::fmax(np_, std::fmax(std::fabs(acc), std::fabs(z[k])));
       }
       for (int i = 0; i < n; i++)
       {
-        double acc = qp.g[i];
+        double hx = 0.0, cl = 0.0;
         for (int j = 0; j < n; j++)
-          acc += qp.H(i, j) * x[j];
+          hx += qp.H(i, j) * x[j];
         for (int k = 0; k < m; k++)
-          acc += qp.C(k, i) * lam[k];
-        du = std::fmax(du, std::fabs(acc));
+          cl += qp.C(k, i) * lam[k];
+        du = std::fmax(du, std::fabs((qp.g[i] + hx) + cl));
+        nd_ = std::fmax(nd_, std::fmax(std::fabs(hx), std::fmax(std::fabs(cl), std::fabs(qp.g[i]))));
       }
       return std::fmax(pr, du);
     };
     double res = 0.0;
     for (int it = 0; it < iters; it++)
     {
-      // every ADMM_CHECK iterations: stop once both residuals are below the tolerance (`iters` is the cap)
-      if (it > 0 && it % ADMM_CHECK == 0 && tol >= 0.0 && (res = residual()) <= tol)
-        return res;
+      // every ADMM_CHECK iterations: stop once both residuals are below the tolerance (`iters` is the cap) ; adapt rho
+      if (it > 0 && it % ADMM_CHECK == 0)
+      {
+        res = residual();
+        if (tol >= 0.0 && res <= tol)
+          return res;
+        const double est = std::fmin(std::fmax(rho * std::sqrt((pr / (np_ + 1e-10)) / (du / (nd_ + 1e-10) + 1e-10)), 1e-6), 1e6);
+        if (est > 5.0 * rho || est < 0.2 * rho)
+        {
+          rho = est;
+          factor();
+        }
+      }
       for (int i = 0; i < n; i++)
         rhs[i] = sigma * x[i] - qp.g[i];
       for (int k = 0; k < m; k++)
@@ -362,8 +382,8 @@ namespace orc
     int B;
     std::vector<IDTarget> tgt;
     std::vector<Vec> x, z, lam; // ADMM state per instance (warm start)
-    std::vector<double> resid;
-    BatchKinoID(const smpc_robot_model * m, const IDSettings & st, int B_) : M(m), s(st), B(B_), tgt(B_), x(B_), z(B_), lam(B_), resid(B_, 0.0)
+    std::vector<double> resid, rho; // rho: the ADMM step-size parameter each instance has adapted to
+    BatchKinoID(const smpc_robot_model * m, const IDSettings & st, int B_) : M(m), s(st), B(B_), tgt(B_), x(B_), z(B_), lam(B_), resid(B_, 0.0), rho(B_, st.rho)
     {
       // default target: the reference state, every foot in contact with an equal share of the weight (kinodynamics-id.cpp:96-112)
       IDTarget t;
@@ -401,7 +421,7 @@ namespace orc
         id_quantities(M, xb, Q);
         QP qp;
         id_assemble(M, s, tgt[b], xb, Q, qp);
-        resid[b] = qp_admm(qp, s.rho, s.sigma, s.alpha, s.admm_iters, s.admm_tol, x[b], z[b], lam[b]);
+        resid[b] = qp_admm(qp, rho[b], s.sigma, s.alpha, s.admm_iters, s.admm_tol, x[b], z[b], lam[b]);
         for (int k = 0; k < nv; k++)
           a[(size_t)b * nv + k] = x[b][k];
         for (int k = 0; k < 3 * nf; k++)

@@ -51,7 +51,7 @@ namespace smpc
     double *Mq = nullptr, *nle = nullptr, *J = nullptr, *Jdv = nullptr, *vfoot = nullptr; // [B][NV NV], [NV], [3 NF][NV], [3 NF], [3 NF]
     double *com = nullptr, *footp = nullptr;                                               // [B][3], [3 NF] world frame
     double *H = nullptr, *g = nullptr, *C = nullptr, *l = nullptr, *u = nullptr;           // [B][NP NP], [NP], [MP][NP], [MP], [MP]
-    double *x = nullptr, *z = nullptr, *lam = nullptr;                                     // ADMM iterate [B][NP], [MP], [MP]
+    double *x = nullptr, *z = nullptr, *lam = nullptr, *rho = nullptr;                     // ADMM iterate [B][NP], [MP], [MP] and step-size parameter [B]
     int * warm = nullptr;                                                                   // [B] 0 = start from scratch
     double *tq = nullptr, *tv = nullptr, *ta = nullptr, *tf = nullptr;                     // targets [B][NQ], [NV], [NV], [3 NF]
     unsigned * tmask = nullptr;                                                             // [B]
@@ -352,57 +352,99 @@ namespace smpc
     double swp[2 * 4 * 16 * ((2 * G::NP + 15) / 16)];
     double g[G::NP], x[G::NP], rhs[G::NP], xt[G::NP];
     double l[G::MP], u[G::MP], r[G::MP], z[G::MP], lam[G::MP], w[G::MP], zt[G::MP];
-    double red[64];
+    double red[256], red4[4];
   };
-  // residuals of the iterate in LDS: max(|C x - z|_inf, |H x + g + C^T lam|_inf), the same value in every lane
+  // residuals of the iterate in LDS and the norms they are measured against (the same values in every lane):
+  //   out[0] = |C x - z|_inf, out[1] = |H x + g + C^T lam|_inf, out[2] = max(|C x|, |z|)_inf, out[3] = max(|H x|, |C^T lam|, |g|)_inf
   template <class D>
-  SMPC_DEV double qp_residual(QpLds<D> & s, const double * Hg)
+  SMPC_DEV void qp_residual(QpLds<D> & s, const double * Hg, double out[4])
   {
     typedef IdDims<D> G;
     constexpr int NT = 64, N = G::N, NP = G::NP, M = G::M, LDC = G::LDC;
     SMPC_LANES(NT)
     {
-      double pr = 0.0;
+      double pr = 0.0, np = 0.0;
       for (int k = lane; k < M; k += NT)
       {
         double acc = 0.0;
         for (int i = 0; i < N; i++)
           acc += s.C[k * LDC + i] * s.x[i];
         pr = fmax(pr, fabs(acc - s.z[k]));
+        np = fmax(np, fmax(fabs(acc), fabs(s.z[k])));
       }
-      double du = 0.0;
+      double du = 0.0, nd = 0.0;
       if (lane < N)
       {
-        double acc = s.g[lane];
+        double hx = 0.0, cl = 0.0;
         for (int j = 0; j < N; j++)
-          acc += Hg[lane * NP + j] * s.x[j];
+          hx += Hg[lane * NP + j] * s.x[j];
         for (int k = 0; k < M; k++)
-          acc += s.C[k * LDC + lane] * s.lam[k];
-        du = fabs(acc);
+          cl += s.C[k * LDC + lane] * s.lam[k];
+        du = fabs((s.g[lane] + hx) + cl);
+        nd = fmax(fabs(hx), fmax(fabs(cl), fabs(s.g[lane])));
       }
-      s.red[lane] = fmax(pr, du);
+      s.red[lane] = pr;
+      s.red[64 + lane] = du;
+      s.red[128 + lane] = np;
+      s.red[192 + lane] = nd;
     }
     SMPC_LANES_END_WAVE
-    double m = 0.0;
-    for (int i = 0; i < NT; i++)
-      m = fmax(m, s.red[i]);
-    return m;
+    SMPC_LANES(NT)
+    if (lane < 4)
+    {
+      double m = 0.0;
+      for (int i = 0; i < NT; i++)
+        m = fmax(m, s.red[64 * lane + i]);
+      s.red4[lane] = m;
+    }
+    SMPC_LANES_END_WAVE
+    for (int i = 0; i < 4; i++)
+      out[i] = s.red4[i];
   }
-  constexpr int ADMM_CHECK = 20;     // residual check period of the ADMM loop
+  // row weights r = rho (1e3 rho on equality rows, 1e-6 rho on free rows) ; K = H + sigma I + C^T diag(r) C -> its inverse
+  template <class D>
+  SMPC_DEV void qp_factor(QpLds<D> & s, const double * Hg, double sigma, double rho)
+  {
+    typedef IdDims<D> G;
+    constexpr int NT = 64, NP = G::NP, MP = G::MP, M = G::M, LDC = G::LDC;
+    SMPC_LANES(NT)
+    for (int k = lane; k < MP; k += NT)
+    { // padding rows (k >= M) are free rows of zeros
+      const double lo = s.l[k], hi = s.u[k];
+      s.r[k] = (hi - lo < 1e-12) ? 1e3 * rho : ((lo <= -ID_INF && hi >= ID_INF) ? 1e-6 * rho : rho);
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NP * NP; idx += NT)
+    {
+      const int i = idx / NP, j = idx % NP;
+      double acc = Hg[idx] + (i == j ? sigma : 0.0);
+      for (int k = 0; k < M; k++)
+        acc += s.r[k] * s.C[k * LDC + i] * s.C[k * LDC + j];
+      s.K[idx] = acc;
+    }
+    SMPC_LANES_END_WAVE
+    fwave_spd_inverse<NP>(s.K, s.swp);
+  }
+  constexpr int ADMM_CHECK = 20; // residual check period of the ADMM loop
 
+  // The step-size parameter rho of a robot is kept across solves with the iterate and adapted as OSQP does (Stellato et al. 2020, section
+  // 5.2): at a residual check, rho <- rho sqrt((r_prim / max(|Cx|, |z|)) / (r_dual / max(|Hx|, |C^T lam|, |g|))), applied -- with a new
+  // inverse of K -- when it moves by more than a factor 5.
   template <class D>
   SMPC_DEV void qp_admm_body(const IdBuffers<D> & b, int block)
   {
     typedef IdDims<D> G;
-    constexpr int NT = 64, NV = G::NV, NF = G::NF, NA = G::NA, N = G::N, NP = G::NP, MP = G::MP, M = G::M, LDC = G::LDC;
+    constexpr int NT = 64, NV = G::NV, NF = G::NF, NA = G::NA, NP = G::NP, MP = G::MP, M = G::M, LDC = G::LDC;
     const int inst = block;
     const IdSettingsDev & st = b.s;
-    const double rho = st.rho, sigma = st.sigma, alpha = st.alpha;
+    const double sigma = st.sigma, alpha = st.alpha;
     SMPC_LDS(QpLds<D>, ls, 1);
     QpLds<D> & s = ls[0];
     const double * Hg = b.H + (size_t)inst * NP * NP;
     const double * Cg = b.C + (size_t)inst * MP * NP;
     const bool warm = b.warm[inst] != 0;
+    double rho = warm ? b.rho[inst] : st.rho;
     SMPC_LANES(NT)
     {
       for (int idx = lane; idx < MP * NP; idx += NT)
@@ -417,33 +459,30 @@ namespace smpc
         const double lo = b.l[(size_t)inst * MP + k], hi = b.u[(size_t)inst * MP + k];
         s.l[k] = lo;
         s.u[k] = hi;
-        // padding rows (k >= M) are free rows of zeros
-        s.r[k] = (hi - lo < 1e-12) ? 1e3 * rho : ((lo <= -ID_INF && hi >= ID_INF) ? 1e-6 * rho : rho);
         s.z[k] = warm ? b.z[(size_t)inst * MP + k] : fmin(fmax(0.0, lo), hi);
         s.lam[k] = warm ? b.lam[(size_t)inst * MP + k] : 0.0;
       }
     }
     SMPC_LANES_END_WAVE
-    // K = H + sigma I + C^T diag(r) C
-    SMPC_LANES(NT)
-    for (int idx = lane; idx < NP * NP; idx += NT)
-    {
-      const int i = idx / NP, j = idx % NP;
-      double acc = Hg[idx] + (i == j ? sigma : 0.0);
-      for (int k = 0; k < M; k++)
-        acc += s.r[k] * s.C[k * LDC + i] * s.C[k * LDC + j];
-      s.K[idx] = acc;
-    }
-    SMPC_LANES_END_WAVE
-    fwave_spd_inverse<NP>(s.K, s.swp);
-    double res = 0.0;
+    qp_factor<D>(s, Hg, sigma, rho);
+    double rs[4] = {0.0, 0.0, 0.0, 0.0};
     bool done = false;
     for (int it = 0; it < st.admm_iters; it++)
     {
-      if (it > 0 && it % ADMM_CHECK == 0 && st.admm_tol >= 0.0 && (res = qp_residual<D>(s, Hg)) <= st.admm_tol)
+      if (it > 0 && it % ADMM_CHECK == 0)
       {
-        done = true;
-        break;
+        qp_residual<D>(s, Hg, rs);
+        if (st.admm_tol >= 0.0 && fmax(rs[0], rs[1]) <= st.admm_tol)
+        {
+          done = true;
+          break;
+        }
+        const double est = fmin(fmax(rho * sqrt((rs[0] / (rs[2] + 1e-10)) / (rs[1] / (rs[3] + 1e-10) + 1e-10)), 1e-6), 1e6);
+        if (est > 5.0 * rho || est < 0.2 * rho)
+        {
+          rho = est;
+          qp_factor<D>(s, Hg, sigma, rho);
+        }
       }
       SMPC_LANES(NT)
       for (int k = lane; k < MP; k += NT)
@@ -493,7 +532,8 @@ namespace smpc
       SMPC_LANES_END_WAVE
     }
     if (!done)
-      res = qp_residual<D>(s, Hg);
+      qp_residual<D>(s, Hg, rs);
+    const double res = fmax(rs[0], rs[1]);
     SMPC_LANES(NT)
     {
       for (int i = lane; i < NP; i += NT)
@@ -521,6 +561,7 @@ namespace smpc
       if (lane == 0)
       {
         b.resid[inst] = res;
+        b.rho[inst] = rho;
         b.warm[inst] = 1;
       }
     }
@@ -611,6 +652,7 @@ namespace smpc
       buf.x = dalloc(Bs * np);
       buf.z = dalloc(Bs * mp);
       buf.lam = dalloc(Bs * mp);
+      buf.rho = dalloc(Bs);
       buf.warm = (int *)dev_alloc(Bs * sizeof(int));
       allocs.push_back(buf.warm);
       dev_zero(buf.warm, Bs * sizeof(int), stream);
