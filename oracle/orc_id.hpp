@@ -71,6 +71,7 @@ namespace orc
   };
   constexpr double ID_INF = 1e20;
   constexpr int ADMM_CHECK = 20;      // residual check period of the ADMM loop
+  constexpr double ADMM_ADAPT_FLOOR = 1e-7; // rho is adapted only while the residuals are above
 
   inline void id_quantities(const smpc_robot_model * m, const double * x, IDQuantities & o)
   {
@@ -339,7 +340,7 @@ namespace orc
         if (tol >= 0.0 && res <= tol)
           return res;
         const double est = std::fmin(std::fmax(rho * std::sqrt((pr / (np_ + 1e-10)) / (du / (nd_ + 1e-10) + 1e-10)), 1e-6), 1e6);
-        if (est > 5.0 * rho || est < 0.2 * rho)
+        if (res > ADMM_ADAPT_FLOOR && (est > 5.0 * rho || est < 0.2 * rho)) // (below the floor the ratio of the residuals is rounding noise)
         {
           rho = est;
           factor();

@@ -427,6 +427,7 @@ namespace smpc
     fwave_spd_inverse<NP>(s.K, s.swp);
   }
   constexpr int ADMM_CHECK = 20; // residual check period of the ADMM loop
+  constexpr double ADMM_ADAPT_FLOOR = 1e-7; // rho is adapted only while the residuals are above
 
   // The step-size parameter rho of a robot is kept across solves with the iterate and adapted as OSQP does (Stellato et al. 2020, section
   // 5.2): at a residual check, rho <- rho sqrt((r_prim / max(|Cx|, |z|)) / (r_dual / max(|Hx|, |C^T lam|, |g|))), applied -- with a new
@@ -478,7 +479,7 @@ namespace smpc
           break;
         }
         const double est = fmin(fmax(rho * sqrt((rs[0] / (rs[2] + 1e-10)) / (rs[1] / (rs[3] + 1e-10) + 1e-10)), 1e-6), 1e6);
-        if (est > 5.0 * rho || est < 0.2 * rho)
+        if (fmax(rs[0], rs[1]) > ADMM_ADAPT_FLOOR && (est > 5.0 * rho || est < 0.2 * rho)) // (below the floor the ratio is rounding noise)
         {
           rho = est;
           qp_factor<D>(s, Hg, sigma, rho);
