@@ -29,6 +29,7 @@
 // same (unique, H + constraints) solution, which the tests check through KKT residuals.
 #pragma once
 #include "orc_full.hpp"
+#include <stdexcept>
 
 namespace orc
 {
@@ -276,6 +277,10 @@ namespace orc
   inline double qp_admm(const QP & qp, double & rho, double sigma, double alpha, int iters, double tol, Vec & x, Vec & z, Vec & lam)
   {
     const int n = qp.n, m = qp.m;
+    for (int i = 0; i < n; i++) // the first n rows are the box on y (id_assemble): the iteration below uses it
+      for (int j = 0; j < n; j++)
+        if (qp.C(i, j) != (i == j ? 1.0 : 0.0))
+          throw std::runtime_error("qp_admm: the first n rows of C must be the identity");
     Vec r(m);
     Mat K;
     auto factor = [&]() {
@@ -347,12 +352,12 @@ namespace orc
         }
       }
       for (int i = 0; i < n; i++)
-        rhs[i] = sigma * x[i] - qp.g[i];
-      for (int k = 0; k < m; k++)
       {
-        const double w = r[k] * z[k] - lam[k];
-        for (int i = 0; i < n; i++)
-          rhs[i] += qp.C(k, i) * w;
+        double acc = sigma * x[i] - qp.g[i];
+        acc += r[i] * z[i] - lam[i]; // box row i: C(i, i) = 1
+        for (int k = n; k < m; k++)
+          acc += qp.C(k, i) * (r[k] * z[k] - lam[k]);
+        rhs[i] = acc;
       }
       chol_solve_inplace(K, rhs);
       for (int k = 0; k < m; k++)
@@ -360,7 +365,7 @@ namespace orc
         double acc = 0.0;
         for (int i = 0; i < n; i++)
           acc += qp.C(k, i) * rhs[i];
-        zt[k] = acc;
+        zt[k] = k < n ? rhs[k] : acc;
       }
       for (int i = 0; i < n; i++)
         x[i] = alpha * rhs[i] + (1.0 - alpha) * x[i];

@@ -51,6 +51,9 @@
 // result lives in SGPRs and feeds VALU FMAs directly -- no LDS round trip, no barrier
 #define SMPC_XLANE(name, src) ::smpc::readlane_f64(name, src)
 #define SMPC_XLANE_A(name, idx, src) ::smpc::readlane_f64(name[idx], src)
+// no instruction is scheduled across this point (keeps the machine scheduler from hoisting a whole unrolled loop's cross-lane reads
+// to its top, where they overflow the scalar registers and are parked in vector lanes)
+#define SMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // FP64 matrix cores (v_mfma_f64_16x16x4_f64), one wave:  D(16x16) += A(16x4) B(4x16).
 //   operands, one double per lane:   A[i][k] in lane i + 16 k ,  B[k][j] in lane j + 16 k
 //   accumulator tile t, 4 doubles per lane:   D[(lane >> 4) + 4 v][lane & 15]  in  SMPC_ACCV(acc, t, v)

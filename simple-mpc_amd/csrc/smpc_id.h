@@ -343,89 +343,21 @@ namespace smpc
   }
 
   // ---- kernel 3: ADMM ----
+  // One wavefront per robot; the iteration runs out of registers.  The first N rows of C are the identity (box on y), so only the
+  // GR = M - N general rows are stored: lane k < GR holds row k (NP doubles), lane i < NP holds column i (GR doubles) and row i of
+  // K^-1 (NP doubles); the vectors live one element per lane and are broadcast with v_readlane (SMPC_XLANE): no LDS traffic in the
+  // loop, so the four SIMDs of a CU iterate independently instead of queueing on the CU's one LDS pipe.
   template <class D>
   struct QpLds
   {
     typedef IdDims<D> G;
-    double K[G::NP * G::NP];   // H + sigma I + C^T diag(rho) C -> its inverse
-    double C[G::MP * G::LDC];  // row stride NP + 1: columns (lane = variable) and rows (lane = constraint) both read without conflicts
+    static constexpr int GR = G::M - G::N;
+    double K[G::NP * G::NP];   // H + sigma I + C^T diag(r) C -> its inverse
+    double C[GR * G::LDC];     // general rows, row stride NP + 1
+    double rg[GR];
     double swp[2 * 4 * 16 * ((2 * G::NP + 15) / 16)];
-    double g[G::NP], x[G::NP], rhs[G::NP], xt[G::NP];
-    double l[G::MP], u[G::MP], r[G::MP], z[G::MP], lam[G::MP], w[G::MP], zt[G::MP];
     double red[256], red4[4];
   };
-  // residuals of the iterate in LDS and the norms they are measured against (the same values in every lane):
-  //   out[0] = |C x - z|_inf, out[1] = |H x + g + C^T lam|_inf, out[2] = max(|C x|, |z|)_inf, out[3] = max(|H x|, |C^T lam|, |g|)_inf
-  template <class D>
-  SMPC_DEV void qp_residual(QpLds<D> & s, const double * Hg, double out[4])
-  {
-    typedef IdDims<D> G;
-    constexpr int NT = 64, N = G::N, NP = G::NP, M = G::M, LDC = G::LDC;
-    SMPC_LANES(NT)
-    {
-      double pr = 0.0, np = 0.0;
-      for (int k = lane; k < M; k += NT)
-      {
-        double acc = 0.0;
-        for (int i = 0; i < N; i++)
-          acc += s.C[k * LDC + i] * s.x[i];
-        pr = fmax(pr, fabs(acc - s.z[k]));
-        np = fmax(np, fmax(fabs(acc), fabs(s.z[k])));
-      }
-      double du = 0.0, nd = 0.0;
-      if (lane < N)
-      {
-        double hx = 0.0, cl = 0.0;
-        for (int j = 0; j < N; j++)
-          hx += Hg[lane * NP + j] * s.x[j];
-        for (int k = 0; k < M; k++)
-          cl += s.C[k * LDC + lane] * s.lam[k];
-        du = fabs((s.g[lane] + hx) + cl);
-        nd = fmax(fabs(hx), fmax(fabs(cl), fabs(s.g[lane])));
-      }
-      s.red[lane] = pr;
-      s.red[64 + lane] = du;
-      s.red[128 + lane] = np;
-      s.red[192 + lane] = nd;
-    }
-    SMPC_LANES_END_WAVE
-    SMPC_LANES(NT)
-    if (lane < 4)
-    {
-      double m = 0.0;
-      for (int i = 0; i < NT; i++)
-        m = fmax(m, s.red[64 * lane + i]);
-      s.red4[lane] = m;
-    }
-    SMPC_LANES_END_WAVE
-    for (int i = 0; i < 4; i++)
-      out[i] = s.red4[i];
-  }
-  // row weights r = rho (1e3 rho on equality rows, 1e-6 rho on free rows) ; K = H + sigma I + C^T diag(r) C -> its inverse
-  template <class D>
-  SMPC_DEV void qp_factor(QpLds<D> & s, const double * Hg, double sigma, double rho)
-  {
-    typedef IdDims<D> G;
-    constexpr int NT = 64, NP = G::NP, MP = G::MP, M = G::M, LDC = G::LDC;
-    SMPC_LANES(NT)
-    for (int k = lane; k < MP; k += NT)
-    { // padding rows (k >= M) are free rows of zeros
-      const double lo = s.l[k], hi = s.u[k];
-      s.r[k] = (hi - lo < 1e-12) ? 1e3 * rho : ((lo <= -ID_INF && hi >= ID_INF) ? 1e-6 * rho : rho);
-    }
-    SMPC_LANES_END_WAVE
-    SMPC_LANES(NT)
-    for (int idx = lane; idx < NP * NP; idx += NT)
-    {
-      const int i = idx / NP, j = idx % NP;
-      double acc = Hg[idx] + (i == j ? sigma : 0.0);
-      for (int k = 0; k < M; k++)
-        acc += s.r[k] * s.C[k * LDC + i] * s.C[k * LDC + j];
-      s.K[idx] = acc;
-    }
-    SMPC_LANES_END_WAVE
-    fwave_spd_inverse<NP>(s.K, s.swp);
-  }
   constexpr int ADMM_CHECK = 20; // residual check period of the ADMM loop
   constexpr double ADMM_ADAPT_FLOOR = 1e-7; // rho is adapted only while the residuals are above
 
@@ -436,43 +368,160 @@ namespace smpc
   SMPC_DEV void qp_admm_body(const IdBuffers<D> & b, int block)
   {
     typedef IdDims<D> G;
-    constexpr int NT = 64, NV = G::NV, NF = G::NF, NA = G::NA, NP = G::NP, MP = G::MP, M = G::M, LDC = G::LDC;
+    constexpr int NT = 64, NV = G::NV, NF = G::NF, NA = G::NA, N = G::N, NP = G::NP, MP = G::MP, LDC = G::LDC, GR = QpLds<D>::GR;
+    static_assert(GR <= NT && NP <= NT && N <= NP, "one general row / one variable per lane");
     const int inst = block;
     const IdSettingsDev & st = b.s;
     const double sigma = st.sigma, alpha = st.alpha;
     SMPC_LDS(QpLds<D>, ls, 1);
     QpLds<D> & s = ls[0];
     const double * Hg = b.H + (size_t)inst * NP * NP;
-    const double * Cg = b.C + (size_t)inst * MP * NP;
+    const double * Cg = b.C + (size_t)inst * MP * NP + (size_t)N * NP; // general rows
     const bool warm = b.warm[inst] != 0;
     double rho = warm ? b.rho[inst] : st.rho;
+    // per-lane state: variable `lane` (< NP), box row `lane` (< N), general row `lane` (< GR)
+    SMPC_PL(double, x, NT);
+    SMPC_PL(double, g, NT);
+    SMPC_PL(double, rhs, NT);
+    SMPC_PL(double, xt, NT);
+    SMPC_PL(double, zb, NT);
+    SMPC_PL(double, lamb, NT);
+    SMPC_PL(double, lb, NT);
+    SMPC_PL(double, ub, NT);
+    SMPC_PL(double, rb, NT);
+    SMPC_PL(double, zg, NT);
+    SMPC_PL(double, lamg, NT);
+    SMPC_PL(double, lg, NT);
+    SMPC_PL(double, ug, NT);
+    SMPC_PL(double, rg, NT);
+    SMPC_PL(double, wg, NT);
+    SMPC_PL(double, ztg, NT);
+    SMPC_PLA(double, Ccol, NT, GR);
+    SMPC_PLA(double, Crow, NT, NP);
+    SMPC_PLA(double, Krow, NT, NP);
     SMPC_LANES(NT)
     {
-      for (int idx = lane; idx < MP * NP; idx += NT)
+      for (int idx = lane; idx < GR * NP; idx += NT)
         s.C[(idx / NP) * LDC + idx % NP] = Cg[idx];
-      for (int i = lane; i < NP; i += NT)
+      const int i = lane < NP ? lane : 0, kb = lane < N ? lane : 0, kg = N + (lane < GR ? lane : 0);
+      SMPC_PLV(g) = b.g[(size_t)inst * NP + i];
+      SMPC_PLV(x) = warm ? b.x[(size_t)inst * NP + i] : 0.0;
+      SMPC_PLV(rhs) = SMPC_PLV(xt) = 0.0;
       {
-        s.g[i] = b.g[(size_t)inst * NP + i];
-        s.x[i] = warm ? b.x[(size_t)inst * NP + i] : 0.0;
+        const double lo = b.l[(size_t)inst * MP + kb], hi = b.u[(size_t)inst * MP + kb];
+        SMPC_PLV(lb) = lo;
+        SMPC_PLV(ub) = hi;
+        SMPC_PLV(zb) = warm ? b.z[(size_t)inst * MP + kb] : fmin(fmax(0.0, lo), hi);
+        SMPC_PLV(lamb) = warm ? b.lam[(size_t)inst * MP + kb] : 0.0;
       }
-      for (int k = lane; k < MP; k += NT)
       {
-        const double lo = b.l[(size_t)inst * MP + k], hi = b.u[(size_t)inst * MP + k];
-        s.l[k] = lo;
-        s.u[k] = hi;
-        s.z[k] = warm ? b.z[(size_t)inst * MP + k] : fmin(fmax(0.0, lo), hi);
-        s.lam[k] = warm ? b.lam[(size_t)inst * MP + k] : 0.0;
+        const double lo = b.l[(size_t)inst * MP + kg], hi = b.u[(size_t)inst * MP + kg];
+        SMPC_PLV(lg) = lo;
+        SMPC_PLV(ug) = hi;
+        SMPC_PLV(zg) = warm ? b.z[(size_t)inst * MP + kg] : fmin(fmax(0.0, lo), hi);
+        SMPC_PLV(lamg) = warm ? b.lam[(size_t)inst * MP + kg] : 0.0;
       }
+      SMPC_PLV(wg) = SMPC_PLV(ztg) = 0.0;
     }
     SMPC_LANES_END_WAVE
-    qp_factor<D>(s, Hg, sigma, rho);
+    SMPC_LANES(NT)
+    {
+      const int i = lane < NP ? lane : 0, k = lane < GR ? lane : 0;
+#pragma unroll
+      for (int kk = 0; kk < GR; kk++)
+        SMPC_PLV(Ccol)[kk] = s.C[kk * LDC + i];
+#pragma unroll
+      for (int ii = 0; ii < NP; ii++)
+        SMPC_PLV(Crow)[ii] = s.C[k * LDC + ii];
+    }
+    SMPC_LANES_END_WAVE
+    // row weights r = rho (1e3 rho on equality rows, 1e-6 rho on free rows) ; K = H + sigma I + C^T diag(r) C -> its inverse -> rows in registers
+    auto factor = [&]() {
+      SMPC_LANES(NT)
+      {
+        auto weight = [&](double lo, double hi) { return (hi - lo < 1e-12) ? 1e3 * rho : ((lo <= -ID_INF && hi >= ID_INF) ? 1e-6 * rho : rho); };
+        SMPC_PLV(rb) = weight(SMPC_PLV(lb), SMPC_PLV(ub));
+        SMPC_PLV(rg) = weight(SMPC_PLV(lg), SMPC_PLV(ug));
+        if (lane < GR)
+          s.rg[lane] = SMPC_PLV(rg);
+        if (lane < N)
+          s.red[lane] = SMPC_PLV(rb);
+      }
+      SMPC_LANES_END_WAVE
+      fwave_gemm<NP, NP, GR>(
+        [&](int i, int k) { return s.rg[k] * s.C[k * LDC + i]; }, [&](int k, int j) { return s.C[k * LDC + j]; },
+        [&](int i, int j, double v) { s.K[i * NP + j] = (Hg[i * NP + j] + (i == j ? sigma + (i < N ? s.red[i] : 0.0) : 0.0)) + v; });
+      fwave_spd_inverse<NP>(s.K, s.swp);
+      SMPC_LANES(NT)
+      {
+        const int i = lane < NP ? lane : 0;
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+          SMPC_PLV(Krow)[j] = s.K[j * NP + i]; // (K^-1 is symmetric: read along the row of j, conflict-free)
+      }
+      SMPC_LANES_END_WAVE
+    };
+    // residuals of the iterate and the norms they are measured against (the same values in every lane):
+    //   rs[0] = |C x - z|_inf, rs[1] = |H x + g + C^T lam|_inf, rs[2] = max(|C x|, |z|)_inf, rs[3] = max(|H x|, |C^T lam|, |g|)_inf
     double rs[4] = {0.0, 0.0, 0.0, 0.0};
+    auto residual = [&]() {
+      SMPC_LANES(NT)
+      {
+        double pr = 0.0, np = 0.0, du = 0.0, nd = 0.0;
+        double cx = 0.0, hx = 0.0, cl = SMPC_PLV(lamb);
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+          cx += SMPC_PLV(Crow)[i] * SMPC_XLANE(x, i);
+          if (i % 8 == 7)
+            SMPC_SCHED_FENCE();
+        }
+        for (int j = 0; j < N; j++)
+          hx += Hg[j * NP + (lane < NP ? lane : 0)] * SMPC_XLANE(x, j); // (H is symmetric: coalesced along the row of j)
+#pragma unroll
+        for (int k = 0; k < GR; k++)
+        {
+          cl += SMPC_PLV(Ccol)[k] * SMPC_XLANE(lamg, k);
+          if (k % 8 == 7)
+            SMPC_SCHED_FENCE();
+        }
+        if (lane < GR)
+        {
+          pr = fabs(cx - SMPC_PLV(zg));
+          np = fmax(fabs(cx), fabs(SMPC_PLV(zg)));
+        }
+        if (lane < N)
+        { // box rows: C x = x
+          pr = fmax(pr, fabs(SMPC_PLV(x) - SMPC_PLV(zb)));
+          np = fmax(np, fmax(fabs(SMPC_PLV(x)), fabs(SMPC_PLV(zb))));
+          du = fabs((SMPC_PLV(g) + hx) + cl);
+          nd = fmax(fabs(hx), fmax(fabs(cl), fabs(SMPC_PLV(g))));
+        }
+        s.red[lane] = pr;
+        s.red[64 + lane] = du;
+        s.red[128 + lane] = np;
+        s.red[192 + lane] = nd;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      if (lane < 4)
+      {
+        double m = 0.0;
+        for (int i = 0; i < NT; i++)
+          m = fmax(m, s.red[64 * lane + i]);
+        s.red4[lane] = m;
+      }
+      SMPC_LANES_END_WAVE
+      for (int i = 0; i < 4; i++)
+        rs[i] = s.red4[i];
+    };
+    factor();
     bool done = false;
     for (int it = 0; it < st.admm_iters; it++)
     {
       if (it > 0 && it % ADMM_CHECK == 0)
       {
-        qp_residual<D>(s, Hg, rs);
+        residual();
         if (st.admm_tol >= 0.0 && fmax(rs[0], rs[1]) <= st.admm_tol)
         {
           done = true;
@@ -482,81 +531,105 @@ namespace smpc
         if (fmax(rs[0], rs[1]) > ADMM_ADAPT_FLOOR && (est > 5.0 * rho || est < 0.2 * rho)) // (below the floor the ratio is rounding noise)
         {
           rho = est;
-          qp_factor<D>(s, Hg, sigma, rho);
+          factor();
         }
       }
       SMPC_LANES(NT)
-      for (int k = lane; k < MP; k += NT)
-        s.w[k] = s.r[k] * s.z[k] - s.lam[k];
+      SMPC_PLV(wg) = SMPC_PLV(rg) * SMPC_PLV(zg) - SMPC_PLV(lamg);
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
-      if (lane < NP)
-      {
-        double acc = sigma * s.x[lane] - s.g[lane];
-        for (int k = 0; k < M; k++)
-          acc += s.C[k * LDC + lane] * s.w[k];
-        s.rhs[lane] = acc;
+      { // rhs = sigma x - g + C^T (r z - lam): the box rows contribute their own entry
+        double acc = sigma * SMPC_PLV(x) - SMPC_PLV(g);
+        acc += lane < N ? SMPC_PLV(rb) * SMPC_PLV(zb) - SMPC_PLV(lamb) : 0.0; // (a select, not a branch: the cross-lane reads below stay in this block)
+#pragma unroll
+        for (int k = 0; k < GR; k++)
+        {
+          acc += SMPC_PLV(Ccol)[k] * SMPC_XLANE(wg, k);
+          if (k % 8 == 7)
+            SMPC_SCHED_FENCE();
+        }
+        SMPC_PLV(rhs) = acc;
       }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
-      if (lane < NP)
       {
         double acc = 0.0;
-        for (int j = 0; j < NP; j++)
-          acc += s.K[j * NP + lane] * s.rhs[j]; // (K^-1 is symmetric: read along the row of j)
-        s.xt[lane] = acc;
+#pragma unroll
+        for (int j = 0; j < N; j++) // (the padding variables are decoupled: their rows and columns of K^-1 are the identity's, their rhs is 0)
+        {
+          acc += SMPC_PLV(Krow)[j] * SMPC_XLANE(rhs, j);
+          if (j % 8 == 7)
+            SMPC_SCHED_FENCE();
+        }
+        SMPC_PLV(xt) = acc;
       }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
       {
-        for (int k = lane; k < MP; k += NT)
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; i++) // (columns N .. NP - 1 of C are zero)
         {
-          double acc = 0.0;
-          for (int i = 0; i < NP; i++)
-            acc += s.C[k * LDC + i] * s.xt[i];
-          s.zt[k] = acc;
+          acc += SMPC_PLV(Crow)[i] * SMPC_XLANE(xt, i);
+          if (i % 8 == 7)
+            SMPC_SCHED_FENCE();
         }
+        SMPC_PLV(ztg) = acc;
       }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
       {
-        if (lane < NP)
-          s.x[lane] = alpha * s.xt[lane] + (1.0 - alpha) * s.x[lane];
-        for (int k = lane; k < MP; k += NT)
-        {
-          const double zh = alpha * s.zt[k] + (1.0 - alpha) * s.z[k];
-          const double zn = fmin(fmax(zh + s.lam[k] / s.r[k], s.l[k]), s.u[k]);
-          s.lam[k] += s.r[k] * (zh - zn);
-          s.z[k] = zn;
+        { // box rows: z~ = x~
+          const double zh = alpha * SMPC_PLV(xt) + (1.0 - alpha) * SMPC_PLV(zb);
+          const double zn = fmin(fmax(zh + SMPC_PLV(lamb) / SMPC_PLV(rb), SMPC_PLV(lb)), SMPC_PLV(ub));
+          SMPC_PLV(lamb) += SMPC_PLV(rb) * (zh - zn);
+          SMPC_PLV(zb) = zn;
         }
+        {
+          const double zh = alpha * SMPC_PLV(ztg) + (1.0 - alpha) * SMPC_PLV(zg);
+          const double zn = fmin(fmax(zh + SMPC_PLV(lamg) / SMPC_PLV(rg), SMPC_PLV(lg)), SMPC_PLV(ug));
+          SMPC_PLV(lamg) += SMPC_PLV(rg) * (zh - zn);
+          SMPC_PLV(zg) = zn;
+        }
+        SMPC_PLV(x) = alpha * SMPC_PLV(xt) + (1.0 - alpha) * SMPC_PLV(x);
       }
       SMPC_LANES_END_WAVE
     }
     if (!done)
-      qp_residual<D>(s, Hg, rs);
+      residual();
     const double res = fmax(rs[0], rs[1]);
+    // the solution through LDS for the torque rows (red is free now)
+    SMPC_LANES(NT)
+    if (lane < NP)
+      s.red[lane] = SMPC_PLV(x);
+    SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
     {
-      for (int i = lane; i < NP; i += NT)
-        b.x[(size_t)inst * NP + i] = s.x[i];
-      for (int k = lane; k < MP; k += NT)
+      if (lane < NP)
+        b.x[(size_t)inst * NP + lane] = SMPC_PLV(x);
+      if (lane < N)
       {
-        b.z[(size_t)inst * MP + k] = s.z[k];
-        b.lam[(size_t)inst * MP + k] = s.lam[k];
+        b.z[(size_t)inst * MP + lane] = SMPC_PLV(zb);
+        b.lam[(size_t)inst * MP + lane] = SMPC_PLV(lamb);
+      }
+      if (lane < GR)
+      {
+        b.z[(size_t)inst * MP + N + lane] = SMPC_PLV(zg);
+        b.lam[(size_t)inst * MP + N + lane] = SMPC_PLV(lamg);
       }
       for (int i = lane; i < NV; i += NT)
-        b.a[(size_t)inst * NV + i] = s.x[i];
+        b.a[(size_t)inst * NV + i] = s.red[i];
       for (int i = lane; i < 3 * NF; i += NT)
-        b.f[(size_t)inst * 3 * NF + i] = s.x[NV + i];
+        b.f[(size_t)inst * 3 * NF + i] = s.red[NV + i];
       if (lane < NA)
       { // tau = M_a a + h_a - J_a^T f
         const double * Mq = b.Mq + (size_t)inst * NV * NV;
         const double * J = b.J + (size_t)inst * 3 * NF * NV;
         double acc = b.nle[(size_t)inst * NV + 6 + lane];
         for (int k = 0; k < NV; k++)
-          acc += Mq[(6 + lane) * NV + k] * s.x[k];
+          acc += Mq[(6 + lane) * NV + k] * s.red[k];
         for (int r = 0; r < 3 * NF; r++)
-          acc -= J[r * NV + 6 + lane] * s.x[NV + r];
+          acc -= J[r * NV + 6 + lane] * s.red[NV + r];
         b.tau[(size_t)inst * NA + lane] = acc;
       }
       if (lane == 0)

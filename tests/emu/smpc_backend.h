@@ -35,6 +35,7 @@
 #define SMPC_PLV(name) name[lane]
 #define SMPC_XLANE(name, src) name[src]
 #define SMPC_XLANE_A(name, idx, src) name[src][idx]
+#define SMPC_SCHED_FENCE() ((void)0)
 // wave-collective matrix-core step (see the HIP backend for the lane maps); called between lane phases
 #define SMPC_ACC(name, NT, n) double name[NT][n][4]
 #define SMPC_ACCV(name, t, v) name[lane][t][v]
