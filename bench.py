@@ -222,6 +222,7 @@ def inverse_dynamics_line(batch, device_id, with_cpu=True):
     """Whole-body inverse-dynamics QP (KinodynamicsID, SURVEY 8f row f3): one QP per robot and control tick, `batch` robots per call;
     all tasks on, the 1 kHz settings of the reference's tests.  Timed around solve() -- host copies of the states and torques included."""
     import numpy as np
+    import torch  # (before the HIP library initialises the runtime: torch's own copy of it then finds the devices)
     import simple_mpc
     from simple_mpc import presets as P
 
@@ -238,20 +239,33 @@ def inverse_dynamics_line(batch, device_id, with_cpu=True):
     t0, n = time.perf_counter(), 20
     for _ in range(n):
         kid.solve(0.0, q, v)
+    dt_host = (time.perf_counter() - t0) / n
+    Xd = torch.from_numpy(np.ascontiguousarray(X)).to(torch.device("cuda", device_id))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        kid.solve_device(Xd.data_ptr())
+    kid.wait()
     dt = (time.perf_counter() - t0) / n
     out = {"metric": "whole-body inverse-dynamics QPs/sec (KinodynamicsID: 30 variables, 76 rows, 100 ADMM iterations)", "value": batch / dt,
            "unit": "QPs/s", "ms_per_call": dt * 1e3, "batch": batch, "dtype": "f64", "max_residual": float(kid.resid.max()),
-           "note": "smpc_id_solve: rigid-body quantities + QP assembly + ADMM, three kernels; host copies included"}
+           "host_buffers": {"value": batch / dt_host, "unit": "QPs/s", "ms_per_call": dt_host * 1e3},
+           "note": "smpc_id_solve_device: rigid-body quantities + QP assembly + ADMM, three kernels, states and torques resident in HBM; "
+                   "host_buffers = smpc_id_solve with the copies of states, torques, accelerations and forces"}
     # the solver of record (stop on residuals <= 1e-7, checked every 20 iterations, cap 400) on states that move between ticks
     kid2 = simple_mpc.KinodynamicsID(mh, 1e-3, st, eff, vmax, batch=batch, device_id=device_id)
     rng = np.random.default_rng(5)
     Xs = [X + np.concatenate([np.zeros((batch, 7)), rng.normal(0.0, 2e-3, (batch, X.shape[1] - 7))], axis=1) for _ in range(8)]
     for k in range(3):
         kid2.solve(0.0, Xs[k][:, : mh.nq], Xs[k][:, mh.nq :])
+    Xds = [torch.from_numpy(np.ascontiguousarray(x)).to(torch.device("cuda", device_id)) for x in Xs]
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(n):
-        kid2.solve(0.0, Xs[k % 8][:, : mh.nq], Xs[k % 8][:, mh.nq :])
+        kid2.solve_device(Xds[k % 8].data_ptr())
+    kid2.wait()
     dt2 = (time.perf_counter() - t0) / n
+    kid2.solve(0.0, Xs[0][:, : mh.nq], Xs[0][:, mh.nq :])  # (the residuals come back with the host-buffer call)
     out["default_stopping_rule"] = {"value": batch / dt2, "unit": "QPs/s", "ms_per_call": dt2 * 1e3, "max_residual": float(kid2.resid.max()),
                                     "note": "residuals <= 1e-7 checked every 20 iterations (cap 400), warm start, joint states perturbed by N(0, 2e-3) per tick"}
     if with_cpu:

@@ -380,6 +380,11 @@ int smpc_id_set_targets_centroidal(smpc_id_handle * h, const double * COM, const
  * tau [B][nv - 6], a [B][nv] (may be NULL), f [B][3 nfeet] contact forces of the solution (may be NULL), resid [B] the larger of the
  * QP's primal / dual residuals (may be NULL) */
 int smpc_id_solve(smpc_id_handle * h, const double * X, double * tau, double * a, double * f, double * resid);
+/* Same with the states resident in HBM: X_device [B][nq + nv]; asynchronous on the handle's stream (pair with smpc_id_wait).  tau_device
+ * [B][nv - 6] may be NULL: the torques then stay in the handle's own buffer, smpc_id_get_tau_device. */
+int smpc_id_solve_device(smpc_id_handle * h, const double * X_device, double * tau_device);
+int smpc_id_wait(smpc_id_handle * h);
+const double * smpc_id_get_tau_device(smpc_id_handle * h);
 /* (tests) intermediate results of the last solve, padded layouts of simple-mpc_amd/csrc/smpc_id.h: what = 0 M, 1 nle, 2 J, 3 dJ v, 4 foot
  * velocities, 5 H [32][32], 6 g [32], 7 C [80][32], 8 l [80], 9 u [80], 10 centre of mass [3], 11 foot positions [3 nfeet]; every one [B][...] */
 int smpc_id_debug_get(smpc_id_handle * h, int what, double * out);

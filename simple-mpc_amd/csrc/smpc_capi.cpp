@@ -1020,6 +1020,19 @@ extern "C"
       e->solve(X, tau, a ? a : ta.data(), f ? f : tf.data(), resid);
     });
   }
+  int smpc_id_solve_device(smpc_id_handle * h, const double * X_device, double * tau_device)
+  {
+    if (!h || !X_device)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { reinterpret_cast<IdEngineBase *>(h)->solve_device(X_device, tau_device); });
+  }
+  int smpc_id_wait(smpc_id_handle * h)
+  {
+    if (!h)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { reinterpret_cast<IdEngineBase *>(h)->wait(); });
+  }
+  const double * smpc_id_get_tau_device(smpc_id_handle * h) { return h ? reinterpret_cast<IdEngineBase *>(h)->tau_device() : nullptr; }
   int smpc_id_debug_get(smpc_id_handle * h, int what, double * out)
   {
     if (!h || !out)

@@ -658,6 +658,11 @@ namespace smpc
     virtual void set_target_centroidal(int inst, const double * com, const double * vcom, const double * fp, const double * fv, unsigned mask, const double * f) = 0;
     virtual void set_targets_centroidal(const double * COM, const double * VCOM, const double * FP, const double * FV, const unsigned char * contact, const double * F) = 0;
     virtual void solve(const double * X, double * tau, double * a, double * f, double * resid) = 0;
+    // states and results resident in HBM; asynchronous on the engine's stream (wait() joins).  tau_dev may be null: results stay in
+    // the engine's own buffers (tau_device() ...)
+    virtual void solve_device(const double * X_dev, double * tau_dev) = 0;
+    virtual void wait() = 0;
+    virtual const double * tau_device() const = 0;
     virtual void debug_get(int what, double * out) = 0; // 0 M, 1 nle, 2 J, 3 Jdv, 4 vfoot, 5 H, 6 g, 7 C, 8 l, 9 u (padded layouts), 10 com, 11 footp
   };
   template <class D>
@@ -864,6 +869,21 @@ namespace smpc
       launch<IdBuffers<D>, id_assemble_body<D>, 64, 1, 0>(B, stream, buf);
       launch<IdBuffers<D>, qp_admm_body<D>, 64, 1, 0>(B, stream, buf);
     }
+    void solve_device(const double * X_dev, double * tau_dev) override
+    {
+      set_device(device_id);
+      buf.X = X_dev;
+      launch_all();
+      buf.X = Xd;
+      if (tau_dev)
+        d2d(tau_dev, buf.tau, (size_t)B * G::NA * sizeof(double), stream);
+    }
+    void wait() override
+    {
+      set_device(device_id);
+      stream_sync(stream);
+    }
+    const double * tau_device() const override { return buf.tau; }
     void solve(const double * X, double * tau, double * a, double * f, double * resid) override
     {
       set_device(device_id);

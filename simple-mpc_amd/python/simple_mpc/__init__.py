@@ -1152,6 +1152,17 @@ class KinodynamicsID:
             tau_res[...] = out
         return out
 
+    def solve_device(self, x_device_ptr, tau_device_ptr=None):
+        """The batch with states (and torques) resident in HBM: x [B][nq + nv], tau [B][nv - 6] device pointers; asynchronous, pair with wait().
+        Without tau_device_ptr the torques stay in the handle's buffer (tau_device_ptr())."""
+        self._lib.check(self._lib.L.smpc_id_solve_device(self._h, C.c_void_p(int(x_device_ptr)), C.c_void_p(int(tau_device_ptr)) if tau_device_ptr else None))
+
+    def wait(self):
+        self._lib.check(self._lib.L.smpc_id_wait(self._h))
+
+    def tau_device_ptr(self):
+        return int(self._lib.L.smpc_id_get_tau_device(self._h))
+
     def getAccelerations(self, ddq=None):
         out = self._a[0] if self.B == 1 else self._a
         if ddq is not None:

@@ -161,6 +161,35 @@ def test_emulated_kernels_centroidal_id_closed_loop(built):
     _centroidal_closed_loop(S.emu_lib(), 60, 1e-7)
 
 
+def test_emulated_kernels_resident_solve(built):
+    """smpc_id_solve_device: states and torques stay where the kernels read / write them (the emulated library's "device" memory is the
+    host's); same result as the host-buffer call."""
+    rb, ok, gk = make(S.emu_lib(), 3, **ALL)
+    X = np.ascontiguousarray(S.random_states(rb, 3))
+    tau = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :]).copy()
+    rb2, _, g2 = make(S.emu_lib(), 3, **ALL)
+    out = np.zeros((3, rb.nv - 6))
+    g2.solve_device(X.ctypes.data, out.ctypes.data)
+    g2.wait()
+    assert np.array_equal(out, tau) and g2.tau_device_ptr() != 0
+
+
+@pytest.mark.gpu
+def test_hip_resident_solve(built):
+    import torch
+
+    rb, ok, gk = make(None, 64, **ALL)
+    X = np.ascontiguousarray(S.random_states(rb, 64))
+    tau = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :]).copy()
+    rb2, _, g2 = make(None, 64, **ALL)
+    Xd = torch.from_numpy(X).cuda()
+    out = torch.zeros((64, rb.nv - 6), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    g2.solve_device(Xd.data_ptr(), out.data_ptr())
+    g2.wait()
+    assert np.array_equal(out.cpu().numpy(), tau)
+
+
 def test_settings_and_errors(built):
     lib = S.emu_lib()
     mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
