@@ -15,6 +15,9 @@ KEYS = {
     "fdyn_trial_body_talos": ("fdyn_trial_body", "FullDimsILi23E", 1024 * 101 * 64),
     "riccati_dense_body_talos": ("riccati_dense_body", "FullDimsILi23E", 1024 * 64),
     "forward_full_body_talos": ("forward_full_body", "FullDimsILi23E", 1024 * 64),
+    "id_quant_body": ("id_quant_body", "", 4096 * 64),
+    "id_assemble_body": ("id_assemble_body", "", 4096 * 64),
+    "qp_admm_body": ("qp_admm_body", "", 4096 * 64),
 }
 
 
