@@ -385,8 +385,21 @@ int smpc_id_solve(smpc_id_handle * h, const double * X, double * tau, double * a
 int smpc_id_solve_device(smpc_id_handle * h, const double * X_device, double * tau_device);
 int smpc_id_wait(smpc_id_handle * h);
 const double * smpc_id_get_tau_device(smpc_id_handle * h);
+/* the handle's own state buffer [B][nq + nv] in HBM (smpc_id_solve copies the host states there; a simulator may keep its states in it) */
+double * smpc_id_get_x_device(smpc_id_handle * h);
+/* The 1 kHz loop of the reference's examples (examples/go2_kinodynamics.py:264-300) without host round trips, for a kinodynamics MPC handle
+ * and a KinodynamicsID handle of the same batch on the same device:
+ *   smpc_id_set_targets_from_mpc  interpolateState / interpolateLinear of the MPC's solution at `delay` seconds after its last iterate
+ *                                 (as smpc_interpolate, `knots` as there) written straight into the controller's target buffers; the
+ *                                 contact flags are those of the MPC's stage 0.  Ordered after the MPC's work, before the next solve.
+ *   smpc_sim_step_device          one step of a simulated batch: constrained forward dynamics of the feet in contact (flags per foot;
+ *                                 Baumgarte gains Kp, Kd [3], NULL = 0; ProximalSettings of record) under torques tau_device, then
+ *                                 semi-implicit Euler over dt; X_device [B][nq + nv] is updated in place.  Asynchronous on the MPC
+ *                                 handle's stream (smpc_wait joins); kinodynamics handles only (they carry the multibody model). */
+int smpc_id_set_targets_from_mpc(smpc_id_handle * id, smpc_handle * mpc, double delay, int knots);
+int smpc_sim_step_device(smpc_handle * h, double * X_device, const double * tau_device, const uint8_t * contact, const double * Kp, const double * Kd, double dt);
 /* (tests) intermediate results of the last solve, padded layouts of simple-mpc_amd/csrc/smpc_id.h: what = 0 M, 1 nle, 2 J, 3 dJ v, 4 foot
- * velocities, 5 H [32][32], 6 g [32], 7 C [80][32], 8 l [80], 9 u [80], 10 centre of mass [3], 11 foot positions [3 nfeet]; every one [B][...] */
+ * velocities, 5 H [32][32], 6 g [32], 7 C [80][32], 8 l [80], 9 u [80], 10 centre of mass [3], 11 foot positions [3 nfeet], 12 torques [nv - 6]; every one [B][...] */
 int smpc_id_debug_get(smpc_id_handle * h, int what, double * out);
 
 #ifdef __cplusplus

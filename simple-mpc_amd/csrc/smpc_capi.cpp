@@ -1033,6 +1033,38 @@ extern "C"
     return guarded([&] { reinterpret_cast<IdEngineBase *>(h)->wait(); });
   }
   const double * smpc_id_get_tau_device(smpc_id_handle * h) { return h ? reinterpret_cast<IdEngineBase *>(h)->tau_device() : nullptr; }
+  int smpc_id_set_targets_from_mpc(smpc_id_handle * id, smpc_handle * mpc, double delay, int knots)
+  {
+    if (!id || !mpc)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (!mpc->eng)
+      return fail(SMPC_ERR_INVALID, "smpc_id_set_targets_from_mpc needs a kinodynamics MPC handle");
+    IdEngineBase * e = reinterpret_cast<IdEngineBase *>(id);
+    if (e->B != mpc->eng->B || e->nq != DimsGo2::NQ || e->nv != DimsGo2::NV)
+      return fail(SMPC_ERR_INVALID, "the controller and the MPC must hold the same batch of the same robot");
+    return guarded([&] {
+      double *x, *a, *f;
+      e->target_buffers(&x, &a, &f);
+      e->set_mask_all(mpc->eng->contact_mask(0));
+      e->wait(); // (the previous solve has read its targets)
+      mpc->eng->interpolate_device(delay, knots, x, a, f);
+      mpc->eng->wait_stream(e->solve_stream()); // the next solve starts after the targets are written
+    });
+  }
+  int smpc_sim_step_device(smpc_handle * h, double * X_device, const double * tau_device, const uint8_t * contact, const double * Kp, const double * Kd, double dt)
+  {
+    if (!h || !X_device || !tau_device || !contact)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (!h->eng)
+      return fail(SMPC_ERR_INVALID, "smpc_sim_step_device needs a kinodynamics handle (it carries the multibody model)");
+    if (!(dt > 0.0))
+      return fail(SMPC_ERR_INVALID, "dt must be positive");
+    unsigned mask = 0;
+    for (int k = 0; k < DimsGo2::NF; k++)
+      mask |= contact[k] ? (1u << k) : 0u;
+    return guarded([&] { h->eng->sim_step_device(X_device, tau_device, mask, Kp, Kd, dt); });
+  }
+  double * smpc_id_get_x_device(smpc_id_handle * h) { return h ? reinterpret_cast<IdEngineBase *>(h)->x_device() : nullptr; }
   int smpc_id_debug_get(smpc_id_handle * h, int what, double * out)
   {
     if (!h || !out)

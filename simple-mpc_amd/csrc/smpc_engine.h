@@ -531,6 +531,11 @@ namespace smpc
         dev_free(p);
       dev_free(buf.ls_sel);
       dev_free(buf.und_list);
+      if (ev_handoff_valid)
+        event_destroy(ev_handoff);
+      dev_free(sim_a);
+      dev_free(sim_lam);
+      dev_free(sim_mask);
       for (int i = 1; i < n_streams; i++)
       {
         dev_free(und_lists[i]);
@@ -1305,6 +1310,86 @@ namespace smpc
       stream_sync(stream);
     }
 
+    // One step of a simulated batch with states and torques resident in HBM (what the reference's examples do with a physics engine
+    // between two controller ticks): constrained forward dynamics of the feet in `mask` (Baumgarte gains Kp, Kd; proximal settings of
+    // record), then semi-implicit Euler over dt, X updated in place.  Asynchronous on this engine's stream.
+    void sim_step_device(double * X_dev, const double * tau_dev, unsigned mask, const double * Kp, const double * Kd, double dt)
+    {
+      set_device(device_id);
+      constexpr int NV = D::NV, NCM = 3 * D::NF;
+      if (!sim_a)
+      {
+        sim_a = (double *)dev_alloc((size_t)B * NV * sizeof(double));
+        sim_lam = (double *)dev_alloc((size_t)B * NCM * sizeof(double));
+        sim_mask = (unsigned *)dev_alloc((size_t)B * sizeof(unsigned));
+        sim_mask_value = ~0u;
+      }
+      if (mask != sim_mask_value)
+      {
+        std::vector<unsigned> m(B, mask);
+        h2d(sim_mask, m.data(), m.size() * sizeof(unsigned), stream);
+        stream_sync(stream); // (m goes out of scope)
+        sim_mask_value = mask;
+      }
+      FullFdArgs<D> fa;
+      fa.b = buf;
+      fa.X = X_dev;
+      fa.tau = tau_dev;
+      fa.mask = sim_mask;
+      for (int i = 0; i < 3; i++)
+      {
+        fa.Kp[i] = Kp ? Kp[i] : 0.0;
+        fa.Kd[i] = Kd ? Kd[i] : 0.0;
+      }
+      fa.prox_accuracy = 1e-9; // ProximalSettings(1e-9, 1e-10, 10), src/fulldynamics.cpp:39
+      fa.prox_mu = 1e-10;
+      fa.prox_max_iter = 10;
+      fa.a_out = sim_a;
+      fa.lam_out = sim_lam;
+      fa.iters_out = nullptr;
+      launch<FullFdArgs<D>, full_fd_body<D>, 64, 2>(B, stream, fa);
+      SimStepArgs<D> sa;
+      sa.X = X_dev;
+      sa.a = sim_a;
+      sa.dt = dt;
+      launch<SimStepArgs<D>, sim_integrate_body<D>, 64>(B, stream, sa);
+    }
+    // work issued on `other` from now on starts after what this engine's stream holds now
+    void wait_stream(stream_t other)
+    {
+      set_device(device_id);
+      if (!ev_handoff_valid)
+      {
+        ev_handoff = event_create();
+        ev_handoff_valid = true;
+      }
+      event_record(ev_handoff, stream);
+      stream_wait_event(other, ev_handoff);
+    }
+    event_t ev_handoff{};
+    bool ev_handoff_valid = false;
+    double *sim_a = nullptr, *sim_lam = nullptr;
+    unsigned * sim_mask = nullptr;
+    unsigned sim_mask_value = ~0u;
+    // the same into device buffers (the inverse-dynamics engine's target buffers), asynchronous on this engine's stream
+    void interpolate_device(double delay, int knots, double * x_dev, double * acc_dev, double * f_dev)
+    {
+      if (knots < 2 || knots > H + 1)
+        throw std::runtime_error("interpolate: knots must be in [2, horizon + 1]");
+      if (!(delay >= 0.0))
+        throw std::runtime_error("interpolate: delay must be non-negative");
+      set_device(device_id);
+      InterpArgs<D> ia;
+      ia.b = buf;
+      ia.head = head;
+      ia.knots = knots;
+      ia.delay = delay;
+      ia.timestep = ms.timestep;
+      ia.x_out = x_dev;
+      ia.acc_out = acc_dev;
+      ia.f_out = f_dev;
+      launch<InterpArgs<D>, interp_body<D>, 64>(B, stream, ia);
+    }
     // interpolated whole-body targets at `delay` after the last solve; host outputs, any may be null
     void interpolate(double delay, int knots, double * x_out, double * acc_out, double * f_out)
     {

@@ -53,7 +53,7 @@ namespace smpc
     double *H = nullptr, *g = nullptr, *C = nullptr, *l = nullptr, *u = nullptr;           // [B][NP NP], [NP], [MP][NP], [MP], [MP]
     double *x = nullptr, *z = nullptr, *lam = nullptr, *rho = nullptr;                     // ADMM iterate [B][NP], [MP], [MP] and step-size parameter [B]
     int * warm = nullptr;                                                                   // [B] 0 = start from scratch
-    double *tq = nullptr, *tv = nullptr, *ta = nullptr, *tf = nullptr;                     // targets [B][NQ], [NV], [NV], [3 NF]
+    double *tx = nullptr, *ta = nullptr, *tf = nullptr;                                    // targets [B][NQ + NV] (q | v, the layout of an MPC state), [NV], [3 NF]
     unsigned * tmask = nullptr;                                                             // [B]
     double *tcom = nullptr, *tvcom = nullptr, *tfp = nullptr, *tfv = nullptr;              // CentroidalID targets [B][3], [3], [3 NF], [3 NF]
     double *tau = nullptr, *a = nullptr, *f = nullptr, *resid = nullptr;                   // [B][NA], [NV], [3 NF], [B]
@@ -134,7 +134,7 @@ namespace smpc
     const double * J = b.J + (size_t)inst * 3 * NF * NV;
     const double * Jdv = b.Jdv + (size_t)inst * 3 * NF;
     const double * vf = b.vfoot + (size_t)inst * 3 * NF;
-    const double *tq = b.tq + (size_t)inst * NQ, *tv = b.tv + (size_t)inst * NV, *ta = b.ta + (size_t)inst * NV, *tf = b.tf + (size_t)inst * 3 * NF;
+    const double *tq = b.tx + (size_t)inst * G::NX, *tv = tq + NQ, *ta = b.ta + (size_t)inst * NV, *tf = b.tf + (size_t)inst * 3 * NF;
     const unsigned mask = b.tmask[inst];
     double * H = b.H + (size_t)inst * NP * NP;
     double * g = b.g + (size_t)inst * NP;
@@ -661,9 +661,15 @@ namespace smpc
     // states and results resident in HBM; asynchronous on the engine's stream (wait() joins).  tau_dev may be null: results stay in
     // the engine's own buffers (tau_device() ...)
     virtual void solve_device(const double * X_dev, double * tau_dev) = 0;
+    // device buffers the targets live in (an MPC engine's interpolation kernel writes them in place): states [B][nq + nv], accelerations
+    // [B][nv], forces [B][3 nf]; set_mask_all: the contact flags of every robot; stream(): where the solve is issued
+    virtual void target_buffers(double ** x, double ** a, double ** f) = 0;
+    virtual void set_mask_all(unsigned mask) = 0;
+    virtual stream_t solve_stream() = 0;
     virtual void wait() = 0;
     virtual const double * tau_device() const = 0;
-    virtual void debug_get(int what, double * out) = 0; // 0 M, 1 nle, 2 J, 3 Jdv, 4 vfoot, 5 H, 6 g, 7 C, 8 l, 9 u (padded layouts), 10 com, 11 footp
+    virtual double * x_device() = 0; // the engine's own state buffer [B][nq + nv] (what solve() copies the host states into)
+    virtual void debug_get(int what, double * out) = 0; // 0 M, 1 nle, 2 J, 3 Jdv, 4 vfoot, 5 H, 6 g, 7 C, 8 l, 9 u (padded layouts), 10 com, 11 footp, 12 tau
   };
   template <class D>
   struct IdEngine : IdEngineBase
@@ -674,6 +680,8 @@ namespace smpc
     int device_id = 0;
     double * Xd = nullptr;
     std::vector<void *> allocs;
+    unsigned mask_all = 0;
+    bool mask_all_valid = false; // (the per-robot setters invalidate it)
     IdEngine(const smpc_robot_model * rm, const HostIdSettings & hs, int batch, int device)
     {
       if (rm->njoints != D::NJ || rm->nfeet != D::NF)
@@ -735,8 +743,7 @@ namespace smpc
       buf.warm = (int *)dev_alloc(Bs * sizeof(int));
       allocs.push_back(buf.warm);
       dev_zero(buf.warm, Bs * sizeof(int), stream);
-      buf.tq = dalloc(Bs * nq);
-      buf.tv = dalloc(Bs * nv);
+      buf.tx = dalloc(Bs * (nq + nv));
       buf.ta = dalloc(Bs * nv);
       buf.tf = dalloc(Bs * 3 * nf);
       buf.tmask = (unsigned *)dev_alloc(Bs * sizeof(unsigned));
@@ -789,20 +796,21 @@ namespace smpc
       if (inst >= B)
         throw std::runtime_error("instance index exceeds the batch");
       const int i0 = inst < 0 ? 0 : inst, i1 = inst < 0 ? B : inst + 1;
-      std::vector<double> tq((size_t)(i1 - i0) * nq), tv((size_t)(i1 - i0) * nv), ta((size_t)(i1 - i0) * nv), tf((size_t)(i1 - i0) * 3 * nf);
+      const int nx = nq + nv;
+      std::vector<double> tx((size_t)(i1 - i0) * nx), ta((size_t)(i1 - i0) * nv), tf((size_t)(i1 - i0) * 3 * nf);
       std::vector<unsigned> tm(i1 - i0, mask);
       for (int i = 0; i < i1 - i0; i++)
       {
-        std::copy(q, q + nq, tq.begin() + (size_t)i * nq);
-        std::copy(v, v + nv, tv.begin() + (size_t)i * nv);
+        std::copy(q, q + nq, tx.begin() + (size_t)i * nx);
+        std::copy(v, v + nv, tx.begin() + (size_t)i * nx + nq);
         std::copy(a, a + nv, ta.begin() + (size_t)i * nv);
         std::copy(f, f + 3 * nf, tf.begin() + (size_t)i * 3 * nf);
       }
-      h2d(buf.tq + (size_t)i0 * nq, tq.data(), tq.size() * sizeof(double), stream);
-      h2d(buf.tv + (size_t)i0 * nv, tv.data(), tv.size() * sizeof(double), stream);
+      h2d(buf.tx + (size_t)i0 * nx, tx.data(), tx.size() * sizeof(double), stream);
       h2d(buf.ta + (size_t)i0 * nv, ta.data(), ta.size() * sizeof(double), stream);
       h2d(buf.tf + (size_t)i0 * 3 * nf, tf.data(), tf.size() * sizeof(double), stream);
       h2d(buf.tmask + i0, tm.data(), tm.size() * sizeof(unsigned), stream);
+      mask_all_valid = false;
       stream_sync(stream);
     }
     // one target per robot: Q [B][nq], V [B][nv], A [B][nv], contact [B][nf], F [B][3 nf]
@@ -813,11 +821,18 @@ namespace smpc
       for (int b = 0; b < B; b++)
         for (int k = 0; k < nf; k++)
           tm[b] |= contact[(size_t)b * nf + k] ? (1u << k) : 0u;
-      h2d(buf.tq, Q, (size_t)B * nq * sizeof(double), stream);
-      h2d(buf.tv, V, (size_t)B * nv * sizeof(double), stream);
+      const int nx = nq + nv;
+      std::vector<double> tx((size_t)B * nx);
+      for (int b = 0; b < B; b++)
+      {
+        std::copy(Q + (size_t)b * nq, Q + (size_t)(b + 1) * nq, tx.begin() + (size_t)b * nx);
+        std::copy(V + (size_t)b * nv, V + (size_t)(b + 1) * nv, tx.begin() + (size_t)b * nx + nq);
+      }
+      h2d(buf.tx, tx.data(), tx.size() * sizeof(double), stream);
       h2d(buf.ta, A, (size_t)B * nv * sizeof(double), stream);
       h2d(buf.tf, F, (size_t)B * 3 * nf * sizeof(double), stream);
       h2d(buf.tmask, tm.data(), (size_t)B * sizeof(unsigned), stream);
+      mask_all_valid = false;
       stream_sync(stream);
     }
     void set_target_centroidal(int inst, const double * com, const double * vcom, const double * fp, const double * fv, unsigned mask, const double * f) override
@@ -844,6 +859,7 @@ namespace smpc
       h2d(buf.tfv + (size_t)i0 * 3 * nf, tv.data(), tv.size() * sizeof(double), stream);
       h2d(buf.tf + (size_t)i0 * 3 * nf, tf.data(), tf.size() * sizeof(double), stream);
       h2d(buf.tmask + i0, tm.data(), tm.size() * sizeof(unsigned), stream);
+      mask_all_valid = false;
       stream_sync(stream);
     }
     void set_targets_centroidal(const double * COM, const double * VCOM, const double * FP, const double * FV, const unsigned char * contact, const double * F) override
@@ -861,6 +877,7 @@ namespace smpc
       h2d(buf.tfv, FV, (size_t)B * 3 * nf * sizeof(double), stream);
       h2d(buf.tf, F, (size_t)B * 3 * nf * sizeof(double), stream);
       h2d(buf.tmask, tm.data(), (size_t)B * sizeof(unsigned), stream);
+      mask_all_valid = false;
       stream_sync(stream);
     }
     void launch_all()
@@ -884,6 +901,26 @@ namespace smpc
       stream_sync(stream);
     }
     const double * tau_device() const override { return buf.tau; }
+    double * x_device() override { return Xd; }
+    void target_buffers(double ** x, double ** a, double ** f) override
+    {
+      *x = buf.tx;
+      *a = buf.ta;
+      *f = buf.tf;
+    }
+    void set_mask_all(unsigned mask) override
+    {
+      set_device(device_id);
+      if (mask != mask_all || !mask_all_valid)
+      {
+        std::vector<unsigned> tm(B, mask);
+        h2d(buf.tmask, tm.data(), tm.size() * sizeof(unsigned), stream);
+        stream_sync(stream);
+        mask_all = mask;
+        mask_all_valid = true;
+      }
+    }
+    stream_t solve_stream() override { return stream; }
     void solve(const double * X, double * tau, double * a, double * f, double * resid) override
     {
       set_device(device_id);
@@ -899,9 +936,9 @@ namespace smpc
     void debug_get(int what, double * out) override
     {
       set_device(device_id);
-      const double * src[12] = {buf.Mq, buf.nle, buf.J, buf.Jdv, buf.vfoot, buf.H, buf.g, buf.C, buf.l, buf.u, buf.com, buf.footp};
-      const size_t per[12] = {(size_t)nv * nv, (size_t)nv, (size_t)3 * nf * nv, (size_t)3 * nf, (size_t)3 * nf, (size_t)np * np, (size_t)np, (size_t)mp * np, (size_t)mp, (size_t)mp, 3, (size_t)3 * nf};
-      if (what < 0 || what > 11)
+      const double * src[13] = {buf.Mq, buf.nle, buf.J, buf.Jdv, buf.vfoot, buf.H, buf.g, buf.C, buf.l, buf.u, buf.com, buf.footp, buf.tau};
+      const size_t per[13] = {(size_t)nv * nv, (size_t)nv, (size_t)3 * nf * nv, (size_t)3 * nf, (size_t)3 * nf, (size_t)np * np, (size_t)np, (size_t)mp * np, (size_t)mp, (size_t)mp, 3, (size_t)3 * nf, (size_t)G::NA};
+      if (what < 0 || what > 12)
         throw std::runtime_error("unknown quantity");
       d2h(out, src[what], (size_t)B * per[what] * sizeof(double), stream);
       stream_sync(stream);

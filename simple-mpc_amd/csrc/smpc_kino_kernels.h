@@ -43,6 +43,33 @@ namespace smpc
         dst[NQ + i - NV] = x[NQ + i - NV] + alpha * dx[i];
     }
   }
+  // semi-implicit Euler step of a simulated robot, in place: v <- v + a dt ; q <- q (+) v dt   (one wavefront per robot)
+  template <class D>
+  struct SimStepArgs
+  {
+    double * X;       // [n][NX] states, updated in place
+    const double * a; // [n][NV] accelerations
+    double dt;
+  };
+  template <class D>
+  SMPC_DEV void sim_integrate_body(const SimStepArgs<D> & ka, int block)
+  {
+    constexpr int NT = 64, NV = D::NV, NQ = D::NQ, NX = D::NX;
+    SMPC_LDS(double, dx, 2 * NV);
+    double * x = ka.X + (size_t)block * NX;
+    const double * a = ka.a + (size_t)block * NV;
+    SMPC_LANES(NT)
+    for (int i = lane; i < NV; i += NT)
+    {
+      const double dv = a[i] * ka.dt;
+      dx[NV + i] = dv;
+      dx[i] = (x[NQ + i] + dv) * ka.dt;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    lanes_integrate<D>(x, dx, 1.0, x, lane, 0);
+    SMPC_LANES_END_WAVE
+  }
   // e = xa (-) xb  (tangent at xb): SE3 part by se3lane, rest by lanes
   template <class D>
   SMPC_DEV void lanes_difference(const double * xb, const double * xa, double * e, int lane, int se3lane)

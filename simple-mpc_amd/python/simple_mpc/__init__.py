@@ -883,6 +883,16 @@ class BatchedMPC:
         self._lib.check(self._lib.L.smpc_riccati_feedback(self._h, float(delay), X, u))
         return u
 
+    def simStepDevice(self, x_device_ptr, tau_device_ptr, contact_state, dt, Kp=None, Kd=None):
+        """One step of a simulated batch with states [B][nq + nv] and torques [B][nv - 6] resident in HBM: constrained forward dynamics of
+        the feet in contact (Baumgarte gains Kp, Kd), then semi-implicit Euler over dt; the states are updated in place.  Asynchronous on
+        this handle's stream (wait() joins); the torques must be complete (KinodynamicsID.wait()).  Kinodynamics handles only."""
+        c = np.ascontiguousarray(np.array([1 if b else 0 for b in contact_state], dtype=np.uint8))
+        kp = np.ascontiguousarray(np.array(Kp, dtype=np.float64)) if Kp is not None else None
+        kd = np.ascontiguousarray(np.array(Kd, dtype=np.float64)) if Kd is not None else None
+        self._lib.check(self._lib.L.smpc_sim_step_device(self._h, C.c_void_p(int(x_device_ptr)), C.c_void_p(int(tau_device_ptr)), c,
+                                                         kp.ctypes.data if kp is not None else None, kd.ctypes.data if kd is not None else None, float(dt)))
+
     def interpolate(self, delay, knots=2):
         """Targets between MPC knots for the whole-body controller, batched on the device (reference
         examples/go2_kinodynamics.py:276-284 with src/interpolator.cpp:5-78): returns (x[B, nx], acc[B, nv],
@@ -1163,6 +1173,16 @@ class KinodynamicsID:
     def tau_device_ptr(self):
         return int(self._lib.L.smpc_id_get_tau_device(self._h))
 
+    def setTargetsFromMPC(self, mpc, delay, knots=2):
+        """Targets of every robot from the solution a kinodynamics BatchedMPC holds, interpolated on the device at `delay` seconds after its
+        last iterate and written straight into this controller's target buffers (the contact flags are those of the MPC's stage 0): the
+        device-resident form of `setTargets(*mpc.interpolate(delay), ...)`."""
+        self._lib.check(self._lib.L.smpc_id_set_targets_from_mpc(self._h, mpc._h, float(delay), int(knots)))
+
+    def x_device_ptr(self):
+        """The handle's own state buffer [B][nq + nv] in HBM (solve() copies the host states there)."""
+        return int(self._lib.L.smpc_id_get_x_device(self._h))
+
     def getAccelerations(self, ddq=None):
         out = self._a[0] if self.B == 1 else self._a
         if ddq is not None:
@@ -1175,7 +1195,7 @@ class KinodynamicsID:
 
     def debug(self, what):
         per = {0: (self._nv, self._nv), 1: (self._nv,), 2: (3 * self._nf, self._nv), 3: (3 * self._nf,), 4: (3 * self._nf,), 5: (32, 32), 6: (32,),
-               7: (80, 32), 8: (80,), 9: (80,), 10: (3,), 11: (3 * self._nf,)}[what]
+               7: (80, 32), 8: (80,), 9: (80,), 10: (3,), 11: (3 * self._nf,), 12: (self._nv - 6,)}[what]
         out = np.zeros((self.B,) + per)
         self._lib.check(self._lib.L.smpc_id_debug_get(self._h, what, out))
         return out

@@ -6,6 +6,7 @@ entry point fails if no HIP device is visible.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -153,7 +154,7 @@ SYMBOLS = [
     "smpc_get_foot_timing", "smpc_get_info", "smpc_get_status", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
     "smpc_debug_get_steps", "smpc_debug_get_terminal", "smpc_debug_get_phase_cycles", "smpc_set_profiling", "smpc_get_kernel_times", "smpc_reset_kernel_times",
     "smpc_interpolate", "smpc_interpolate_knots", "smpc_friction_compensation", "smpc_update_internal_data", "smpc_full_forward_dynamics", "smpc_centroidal_dynamics", "smpc_riccati_feedback",
-    "smpc_id_create", "smpc_id_destroy", "smpc_id_set_target", "smpc_id_set_targets", "smpc_id_set_target_centroidal", "smpc_id_set_targets_centroidal", "smpc_id_solve", "smpc_id_solve_device", "smpc_id_wait", "smpc_id_get_tau_device", "smpc_id_debug_get",
+    "smpc_id_create", "smpc_id_destroy", "smpc_id_set_target", "smpc_id_set_targets", "smpc_id_set_target_centroidal", "smpc_id_set_targets_centroidal", "smpc_id_solve", "smpc_id_solve_device", "smpc_id_wait", "smpc_id_get_tau_device", "smpc_id_get_x_device", "smpc_id_set_targets_from_mpc", "smpc_sim_step_device", "smpc_id_debug_get",
 ]
 
 
@@ -166,6 +167,13 @@ class SmpcLib:
                 "(hipcc, gfx950).  There is no CPU fallback." % path
             )
         self.path = path
+        # PyTorch-ROCm wheels carry their own copy of the HIP runtime; if this library initialises the system runtime first, torch's copy
+        # then reports "No HIP GPUs are available".  Loading torch first (when it is installed) makes either import order work.
+        if os.path.basename(path).startswith("libsmpc_hip") and "torch" not in sys.modules and not os.environ.get("SMPC_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(path)
         self.L = L
         vp = C.c_void_p
@@ -211,6 +219,10 @@ class SmpcLib:
         L.smpc_id_wait.argtypes = [vp]
         L.smpc_id_get_tau_device.argtypes = [vp]
         L.smpc_id_get_tau_device.restype = C.c_void_p
+        L.smpc_id_get_x_device.argtypes = [vp]
+        L.smpc_id_set_targets_from_mpc.argtypes = [vp, vp, C.c_double, C.c_int]
+        L.smpc_sim_step_device.argtypes = [vp, vp, vp, _bp, C.c_void_p, C.c_void_p, C.c_double]
+        L.smpc_id_get_x_device.restype = C.c_void_p
         L.smpc_get_status.argtypes = [vp, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]
         L.smpc_debug_get_extra_multipliers.argtypes = [vp, C.c_int, _dp]
         L.smpc_set_x_reference.argtypes = [vp, _dp]

@@ -176,18 +176,17 @@ def test_emulated_kernels_resident_solve(built):
 
 @pytest.mark.gpu
 def test_hip_resident_solve(built):
-    import torch
-
+    """Second tick from the states already in HBM (the handle's own buffer) = second tick through host buffers."""
     rb, ok, gk = make(None, 64, **ALL)
     X = np.ascontiguousarray(S.random_states(rb, 64))
+    gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
     tau = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :]).copy()
     rb2, _, g2 = make(None, 64, **ALL)
-    Xd = torch.from_numpy(X).cuda()
-    out = torch.zeros((64, rb.nv - 6), dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-    g2.solve_device(Xd.data_ptr(), out.data_ptr())
+    g2.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
+    g2.solve_device(g2.x_device_ptr())
     g2.wait()
-    assert np.array_equal(out.cpu().numpy(), tau)
+    g2._lib.check(g2._lib.L.smpc_id_debug_get(g2._h, 12, out := np.zeros((64, rb.nv - 6))))
+    assert np.array_equal(out, tau)
 
 
 def test_settings_and_errors(built):
@@ -291,6 +290,91 @@ def _full_stack(lib, B, mpc_steps):
             X = np.stack([P.integrate(np.r_[X[b, :nq], vn[b]], np.r_[vn[b] * 1e-3, np.zeros(nv)], nq) for b in range(B)])
         assert np.all(np.isfinite(X)) and np.all(np.abs(X[:, 2] - mh.getReferenceState()[2]) < 0.05) and np.abs(X[:, nq:]).max() < 5.0
     return X, swing
+
+
+def _resident_stack(lib, B, mpc_steps, alloc):
+    """The loop of _full_stack with nothing crossing the host between the MPC steps: targets written by the MPC's interpolation kernel
+    (setTargetsFromMPC), states and torques resident (solve_device, simStepDevice) -- against the same loop through host buffers."""
+    from simple_mpc import presets as P
+
+    def setup():
+        mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+        for n in P.GO2_FEET:
+            mh.addPointFoot(n, "root_joint")
+        ocp = simple_mpc.KinodynamicsOCP(P.go2_kino_settings(mh), mh)
+        ocp.createProblem(mh.getReferenceState(), 10, 3, -9.81, False)  # (a short horizon and cycle: swing phases reach stage 0 within the test)
+        conf = dict({k: v for k, v in P.go2_mpc_settings(mh, max_iters=1).items() if k in P.MPC_KEYS}, T_fly=6, T_contact=2)
+        mpc = simple_mpc.BatchedMPC(conf, ocp, B, lib=lib)
+        mpc.generateCycleHorizon(P.trot_cycle(2, 6))
+        V = np.zeros((B, 6))
+        V[:, 0] = np.linspace(0.0, 0.3, B)
+        mpc.switchToWalk(V[0])
+        mpc.setVelocityBaseBatched(V)
+        ids = dict(kp_base=7.0, kp_posture=10.0, kp_contact=10.0, w_base=100.0, w_posture=1.0, w_contact_force=1.0, w_contact_motion=1.0)
+        kid = simple_mpc.KinodynamicsID(mh, 1e-3, ids, O.GO2_EFFORT, O.GO2_VMAX, batch=B, lib=lib, admm_iters=100, admm_tol=-1.0)
+        return mh, mpc, kid
+
+    mh, mpc, kid = setup()
+    nq, nv = mh.nq, mh.nv
+    X = np.tile(mh.getReferenceState(), (B, 1))
+    swing = False
+    for _ in range(mpc_steps):  # host buffers
+        mpc.iterate(X)
+        contact = mpc.ocp_handler.getContactState(0)
+        swing = swing or not all(contact)
+        mask = np.full(B, sum(1 << i for i, c in enumerate(contact) if c), np.uint32)
+        for sub in range(10):
+            x_i, a_i, f_i = mpc.interpolate(sub / 10.0 * 0.01)
+            kid.setTargets(x_i[:, :nq], x_i[:, nq:], a_i, contact, f_i)
+            tau = kid.solve(0.0, X[:, :nq], X[:, nq:])
+            a = mpc.constraintDynamics(X, tau, mask, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])["a"]
+            vn = X[:, nq:] + a * 1e-3
+            X = np.stack([P.integrate(np.r_[X[b, :nq], vn[b]], np.r_[vn[b] * 1e-3, np.zeros(nv)], nq) for b in range(B)])
+    mh, mpc, kid = setup()
+    Xd = alloc(np.tile(mh.getReferenceState(), (B, 1)))  # resident
+    for _ in range(mpc_steps):
+        mpc.iterate_device(Xd.ptr)
+        mpc.wait()
+        contact = mpc.ocp_handler.getContactState(0)
+        for sub in range(10):
+            kid.setTargetsFromMPC(mpc, sub / 10.0 * 0.01)
+            kid.solve_device(Xd.ptr)
+            kid.wait()
+            mpc.simStepDevice(Xd.ptr, kid.tau_device_ptr(), contact, 1e-3, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])
+        mpc.wait()
+    assert swing
+    assert S.rel_err(X, Xd.get()) < 1e-8, S.rel_err(X, Xd.get())
+
+
+class _HostArray:
+    """(the emulated library's "device" memory is the host's)"""
+
+    def __init__(self, a):
+        self.a = np.ascontiguousarray(a)
+        self.ptr = self.a.ctypes.data
+
+    def get(self):
+        return self.a
+
+
+def test_emulated_kernels_resident_stack(built):
+    _resident_stack(S.emu_lib(), 2, 16, _HostArray)
+
+
+@pytest.mark.gpu
+def test_hip_resident_stack(built):
+    import torch
+
+    class Dev:
+        def __init__(self, a):
+            self.t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            torch.cuda.synchronize()
+            self.ptr = self.t.data_ptr()
+
+        def get(self):
+            return self.t.cpu().numpy()
+
+    _resident_stack(None, 16, 16, Dev)
 
 
 def _centroidal_stack(lib, B, mpc_steps):
