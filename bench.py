@@ -285,6 +285,47 @@ def inverse_dynamics_line(batch, device_id, with_cpu=True):
     return out
 
 
+def control_stack_line(batch, device_id, mpc_steps=30):
+    """The control stack of the reference's examples/go2_kinodynamics.py for `batch` simulated robots, nothing crossing the host inside
+    the loop: MPC (1 ProxDDP iteration, as the example runs it) at 100 Hz, interpolated targets + KinodynamicsID at 1 kHz, constrained
+    forward dynamics + semi-implicit Euler as the simulator (examples/go2_stack_resident.py)."""
+    import numpy as np
+    import torch
+    import simple_mpc
+    from simple_mpc import presets as P
+
+    gm, mh = make_mpc("kinodynamics", batch, 1, device_id)
+    eff, vmax = np.array([23.7, 23.7, 45.43] * 4), np.array([30.1, 30.1, 15.7] * 4)
+    ids = dict(kp_base=7.0, kp_posture=10.0, kp_contact=10.0, w_base=100.0, w_posture=1.0, w_contact_force=1.0, w_contact_motion=1.0)
+    kid = simple_mpc.KinodynamicsID(mh, 1e-3, ids, eff, vmax, batch=batch, device_id=device_id)
+    X = torch.from_numpy(np.tile(mh.getReferenceState(), (batch, 1))).to(torch.device("cuda", device_id))
+    torch.cuda.synchronize()
+
+    def period():
+        gm.iterate_device(X.data_ptr())
+        gm.wait()
+        contact = gm.ocp_handler.getContactState(0)
+        for sub in range(10):
+            kid.setTargetsFromMPC(gm, sub * 1e-3)
+            kid.solve_device(X.data_ptr())
+            kid.wait()
+            gm.simStepDevice(X.data_ptr(), kid.tau_device_ptr(), contact, 1e-3, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])
+
+    for _ in range(3):
+        period()
+    gm.wait()
+    t0 = time.perf_counter()
+    for _ in range(mpc_steps):
+        period()
+    gm.wait()
+    dt = (time.perf_counter() - t0) / mpc_steps
+    Xh = X.cpu().numpy()
+    ok = bool(np.all(np.isfinite(Xh)) and np.all(np.abs(Xh[:, 2] - mh.getReferenceState()[2]) < 0.05))
+    return {"metric": "simulated robot-seconds per second, MPC (100 Hz, 1 iteration) + KinodynamicsID (1 kHz) + forward-dynamics simulator",
+            "value": batch * 0.01 / dt, "unit": "robot-seconds/s", "ms_per_mpc_period": dt * 1e3, "batch": batch, "robots_upright": ok,
+            "note": "states, targets and torques resident in HBM; one MPC period = 1 iterate + 10 x (targets from the MPC, ID QP, simulator step)"}
+
+
 def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     """BASELINE config "Go2 centroidal (9-dim state), H=50, batch=4096": same step definition on the centroidal OCP
     (one fused kernel per control step).  Measured states: x_ref (+) N(0, sigma^2), resident in HBM, re-drawn on the
@@ -660,6 +701,7 @@ def main():
             other["fulldynamics_go2"] = fulldynamics_line(min(B, 4096), args.iters, 10, 3, local_rank, not args.no_cpu_baseline)
             other["fulldynamics_talos"] = fulldynamics_line(1024, args.iters, 5, 2, local_rank, not args.no_cpu_baseline, robot="talos")
             other["inverse_dynamics_qp"] = inverse_dynamics_line(B, local_rank, not args.no_cpu_baseline)
+            other["control_stack"] = control_stack_line(B, local_rank)
             out["other_workloads"] = other
         print(json.dumps(out))
     if dist is not None:
