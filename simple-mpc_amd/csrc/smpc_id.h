@@ -129,9 +129,20 @@ namespace smpc
     const double * x = b.X + (size_t)inst * G::NX;
     const double * q = x;
     const double * v = x + NQ;
-    const double * Mq = b.Mq + (size_t)inst * NV * NV;
+    // (the inertia matrix and the foot Jacobians are read tens of times per entry of H: staged in LDS)
+    SMPC_LDS(double, sM, NV * NV);
+    SMPC_LDS(double, sJ, 3 * NF * NV);
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < NV * NV; idx += NT)
+        sM[idx] = b.Mq[(size_t)inst * NV * NV + idx];
+      for (int idx = lane; idx < 3 * NF * NV; idx += NT)
+        sJ[idx] = b.J[(size_t)inst * 3 * NF * NV + idx];
+    }
+    SMPC_LANES_END_WAVE
+    const double * Mq = sM;
     const double * nle = b.nle + (size_t)inst * NV;
-    const double * J = b.J + (size_t)inst * 3 * NF * NV;
+    const double * J = sJ;
     const double * Jdv = b.Jdv + (size_t)inst * 3 * NF;
     const double * vf = b.vfoot + (size_t)inst * 3 * NF;
     const double *tq = b.tx + (size_t)inst * G::NX, *tv = tq + NQ, *ta = b.ta + (size_t)inst * NV, *tf = b.tf + (size_t)inst * 3 * NF;
