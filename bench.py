@@ -285,6 +285,31 @@ def inverse_dynamics_line(batch, device_id, with_cpu=True):
     return out
 
 
+def single_robot_latency(iters, device_id, steps=50):
+    """One robot (B = 1): wall time of MPC::iterate through host buffers, the reference's own use case (its control loop calls iterate once
+    per 10 ms period).  The stage kernels have 51 wavefronts of work and the Riccati sweeps one: this is a latency, not a throughput."""
+    import numpy as np
+    from simple_mpc import presets as P
+
+    out = {}
+    for kind in ("kinodynamics", "centroidal", "fulldynamics"):
+        gm, mh = make_mpc(kind, 1, iters, device_id)
+        X = np.tile(mh.getReferenceState(), (1, 1))
+        for _ in range(5):
+            gm.iterate(X)
+            X = gm.xs[:, 1, :].copy() if kind != "centroidal" else X
+        lat = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            gm.iterate(X)
+            lat.append(time.perf_counter() - t0)
+            X = gm.xs[:, 1, :].copy() if kind != "centroidal" else X
+        out[kind] = {"median_ms": 1e3 * float(np.median(lat)), "p99_ms": 1e3 * float(np.quantile(lat, 0.99))}
+        del gm
+    out["note"] = "B = 1, %d ProxDDP iterations per step, host buffers in and out, Go2, H = 50" % iters
+    return out
+
+
 def control_stack_line(batch, device_id, mpc_steps=30):
     """The control stack of the reference's examples/go2_kinodynamics.py for `batch` simulated robots, nothing crossing the host inside
     the loop: MPC (1 ProxDDP iteration, as the example runs it) at 100 Hz, interpolated targets + KinodynamicsID at 1 kHz, constrained
@@ -702,6 +727,7 @@ def main():
             other["fulldynamics_talos"] = fulldynamics_line(1024, args.iters, 5, 2, local_rank, not args.no_cpu_baseline, robot="talos")
             other["inverse_dynamics_qp"] = inverse_dynamics_line(B, local_rank, not args.no_cpu_baseline)
             other["control_stack"] = control_stack_line(B, local_rank)
+            other["single_robot_latency"] = single_robot_latency(args.iters, local_rank)
             out["other_workloads"] = other
         print(json.dumps(out))
     if dist is not None:
