@@ -3,6 +3,7 @@
 // speaks the C ABI of include/smpc.h), generate the cycle horizon of the reference test, check the container sizes
 // (tests/mpc.cpp:43-44) and the foot-timing known answers (tests/mpc.cpp:78-81, :87-90), iterate, check the outputs.
 // Linked against libsmpc_hip.so on the GPU tier and against the sequential-lane test build on the CPU tier.
+#include "simple-mpc/batched-id.hpp"
 #include "simple-mpc/batched-mpc.hpp"
 #include <cmath>
 #include <cstdio>
@@ -279,6 +280,82 @@ int main()
       threw4 = true;
     }
     CHECK(threw4);
+  }
+  {
+    // ---- the inverse-dynamics controllers, as the reference's tests/inverse-dynamics/kinodynamics-id.cpp:100-143 uses them:
+    //      posture task only, no contact -> the joints hold still, the base falls freely ; then all tasks, feet on the ground ----
+    const std::vector<double> effort = {23.7, 23.7, 45.43, 23.7, 23.7, 45.43, 23.7, 23.7, 45.43, 23.7, 23.7, 45.43};
+    const std::vector<double> vmax = {30.1, 30.1, 15.7, 30.1, 30.1, 15.7, 30.1, 30.1, 15.7, 30.1, 30.1, 15.7};
+    KinodynamicsIDSettings s;
+    s.kp_posture = 20.0;
+    s.w_posture = 1.0;
+    BatchedKinodynamicsID kid(robot, 1e-3, s, effort, vmax, /*batch=*/2);
+    std::vector<double> q(robot->q_ref, robot->q_ref + nq), z(nv, 0.0), f0(3 * nf, 0.0);
+    kid.setTarget(q, z, z, std::vector<bool>(nf, false), f0);
+    std::vector<double> Q(2 * nq), V(2 * nv, 0.0), tau, acc;
+    for (int b = 0; b < 2; b++)
+      std::copy(q.begin(), q.end(), Q.begin() + b * nq);
+    kid.solve(0.0, Q, V, tau);
+    kid.getAccelerations(acc);
+    CHECK((int)tau.size() == 2 * (nv - 6) && (int)acc.size() == 2 * nv);
+    CHECK(std::fabs(acc[2] + 9.81) < 1e-6 && std::fabs(acc[nv + 2] + 9.81) < 1e-6); // free fall of both bases
+    for (int j = 6; j < nv; j++)
+      CHECK(std::fabs(acc[j]) < 1e-5); // posture held
+    KinodynamicsIDSettings s2;
+    s2.kp_base = 10.0;
+    s2.kp_posture = 1.0;
+    s2.kp_contact = 10.0;
+    s2.w_base = 10.0;
+    s2.w_posture = 0.1;
+    s2.w_contact_force = 1e-3;
+    s2.w_contact_motion = 1.0;
+    BatchedKinodynamicsID kid2(robot, 1e-3, s2, effort, vmax, 2);
+    kid2.solve(0.0, Q, V, tau); // default target: the reference state, every foot in contact, equal shares of the weight
+    double fz = 0.0;
+    for (int k = 0; k < nf; k++)
+      fz += kid2.getContactForces()[3 * k + 2];
+    CHECK(std::fabs(fz - robot->total_mass * 9.81) < 0.05 * robot->total_mass * 9.81); // the feet carry the robot standing still
+    for (size_t i = 0; i < tau.size(); i++)
+      CHECK(std::fabs(tau[i]) <= effort[i % (nv - 6)] + 1e-6);
+    CHECK(kid2.residuals()[0] < 1e-4);
+    // CentroidalID: default targets (CoM and feet of the reference state), then a foot in the air with a target 5 cm up
+    CentroidalIDSettings cs;
+    static_cast<KinodynamicsIDSettings &>(cs) = s2;
+    cs.kp_com = 7.0;
+    cs.w_com = 10.0;
+    cs.kp_feet_tracking = 5.0;
+    cs.w_feet_tracking = 100.0;
+    BatchedCentroidalID cid(robot, 1e-3, cs, effort, vmax, 2);
+    cid.solve(0.0, Q, V, tau);
+    CHECK(cid.residuals()[0] < 1e-4);
+    std::vector<double> com(3), fp(3 * nf);
+    {
+      std::vector<double> dbg(2 * 3), dfp(2 * 3 * nf);
+      CHECK(smpc_id_debug_get(cid.handle(), 10, dbg.data()) == 0 && smpc_id_debug_get(cid.handle(), 11, dfp.data()) == 0);
+      std::copy(dbg.begin(), dbg.begin() + 3, com.begin());
+      std::copy(dfp.begin(), dfp.begin() + 3 * nf, fp.begin());
+    }
+    fp[3 * 2 + 2] += 0.05;
+    std::vector<bool> contact(nf, true);
+    contact[2] = false;
+    std::vector<double> ft(3 * nf, 0.0);
+    for (int k = 0; k < nf; k++)
+      ft[3 * k + 2] = k == 2 ? 0.0 : robot->total_mass * 9.81 / 3.0;
+    cid.setTarget(com, std::vector<double>(3, 0.0), fp, std::vector<double>(3 * nf, 0.0), contact, ft, /*instance=*/1);
+    cid.solve(0.0, Q, V, tau);
+    cid.getAccelerations(acc);
+    CHECK(std::fabs(cid.getContactForces()[3 * nf + 3 * 2 + 2]) < 1e-6); // robot 1: the foot in the air carries nothing
+    CHECK(std::fabs(cid.getContactForces()[3 * 2 + 2]) > 1.0);          // robot 0 still stands on it
+    bool threw5 = false;
+    try
+    {
+      kid2.setTarget(q, z, z, std::vector<bool>(nf - 1, true), f0);
+    }
+    catch (const std::runtime_error &)
+    {
+      threw5 = true;
+    }
+    CHECK(threw5);
   }
   std::puts("host mirror KAT: OK");
   return 0;
