@@ -208,6 +208,24 @@ def test_settings_and_errors(built):
     ddq = np.zeros(mh.nv)
     k.getAccelerations(ddq)
     assert abs(ddq[2] + 9.81) < 1e-6  # free fall of the base, posture held
+    # the device-resident legs refuse what they cannot serve
+    from simple_mpc import presets as P
+
+    cocp = simple_mpc.CentroidalOCP(P.go2_centroidal_settings(mh), mh)
+    cocp.createProblem(np.zeros(9), 10, 3, -9.81, False)
+    conf = dict({kk: v for kk, v in P.go2_mpc_settings(mh, max_iters=1).items() if kk in P.MPC_KEYS}, T_fly=6, T_contact=2)
+    cmpc = simple_mpc.BatchedMPC(conf, cocp, 1, lib=lib)
+    with pytest.raises(RuntimeError, match="kinodynamics MPC handle"):
+        k.setTargetsFromMPC(cmpc, 0.0)
+    with pytest.raises(RuntimeError, match="kinodynamics handle"):
+        cmpc.simStepDevice(x.ctypes.data, tau.ctypes.data, [True] * 4, 1e-3)
+    kocp = simple_mpc.KinodynamicsOCP(P.go2_kino_settings(mh), mh)
+    kocp.createProblem(mh.getReferenceState(), 10, 3, -9.81, False)
+    kmpc = simple_mpc.BatchedMPC(conf, kocp, 2, lib=lib)
+    with pytest.raises(RuntimeError, match="same batch"):
+        k.setTargetsFromMPC(kmpc, 0.0)
+    with pytest.raises(RuntimeError, match="dt must be positive"):
+        kmpc.simStepDevice(x.ctypes.data, tau.ctypes.data, [True] * 4, 0.0)
 
 
 @pytest.mark.gpu
