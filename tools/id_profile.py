@@ -18,7 +18,7 @@ for n in P.GO2_FEET:
     mh.addPointFoot(n, "root_joint")
 eff, vmax = np.array([23.7, 23.7, 45.43] * 4), np.array([30.1, 30.1, 15.7] * 4)
 st = dict(kp_base=10.0, kp_posture=1.0, kp_contact=10.0, w_base=10.0, w_posture=0.1, w_contact_force=1e-3, w_contact_motion=1.0)
-kw = dict(admm_iters=100, admm_tol=-1.0) if fixed else {}
+kw = dict(admm_iters=int(os.environ.get("ADMM_ITERS", "100")), admm_tol=-1.0) if fixed else {}
 kid = simple_mpc.KinodynamicsID(mh, 1e-3, st, eff, vmax, batch=B, lib=lib, **kw)
 X = P.random_states(mh, B, scale=0.3)
 rng = np.random.default_rng(5)
