@@ -254,14 +254,21 @@ def test_hip_centroidal_id_closed_loop(built):
 
 
 @pytest.mark.gpu
-def test_hip_batch_of_4096_robots(built):
+@pytest.mark.parametrize("centroidal", [False, True])
+def test_hip_batch_of_4096_robots(built, centroidal):
     """4096 robots, 16 distinct states replicated: replicas bit-identical, the distinct ones follow the oracle, limits respected."""
     B, nd = 4096, 16
-    rb, ok, gk = make(None, B, **ALL)
-    ok = O.OracleKinoID(rb, O.id_settings(rb, DT, admm_iters=100, admm_tol=-1.0, **ALL), nd)
+    kw = dict(CALL, centroidal=True) if centroidal else ALL
+    rb, ok, gk = make(None, B, **kw)
+    ok = O.OracleKinoID(rb, O.id_settings(rb, DT, admm_iters=100, admm_tol=-1.0, **kw), nd)
     fs = static_forces(rb)
-    for k in (ok, gk):
-        k.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True] * 4, fs)
+    if centroidal:
+        c = rb.centroidal(rb.x_ref)
+        ok.setTargetCentroidal(c["com"], np.zeros(3), c["feet"], np.zeros((4, 3)), [True] * 4, fs)
+        gk.setTarget(c["com"], np.zeros(3), c["feet"], np.zeros((4, 3)), [True] * 4, fs.reshape(4, 3))
+    else:
+        for k in (ok, gk):
+            k.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True] * 4, fs)
     Xo = S.random_states(rb, nd, seed=3, scale=0.5)
     for _ in range(3):
         X = np.tile(Xo, (B // nd, 1))
