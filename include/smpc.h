@@ -392,6 +392,9 @@ double * smpc_id_get_x_device(smpc_id_handle * h);
  *   smpc_id_set_targets_from_mpc  interpolateState / interpolateLinear of the MPC's solution at `delay` seconds after its last iterate
  *                                 (as smpc_interpolate, `knots` as there) written straight into the controller's target buffers; the
  *                                 contact flags are those of the MPC's stage 0.  Ordered after the MPC's work, before the next solve.
+ *                                 A centroidal MPC handle feeds a CentroidalID handle the same way (examples/talos_centroidal.py:218-243):
+ *                                 centre of mass, its velocity (momentum / mass), the foot references between stages 0 and 1 and
+ *                                 their velocities, the interpolated forces.
  *   smpc_sim_step_device          one step of a simulated batch: constrained forward dynamics of the feet in contact (flags per foot;
  *                                 Baumgarte gains Kp, Kd [3], NULL = 0; ProximalSettings of record) under torques tau_device, then
  *                                 semi-implicit Euler over dt; X_device [B][nq + nv] is updated in place.  Asynchronous on the MPC

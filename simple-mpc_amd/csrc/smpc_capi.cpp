@@ -1037,9 +1037,31 @@ extern "C"
   {
     if (!id || !mpc)
       return fail(SMPC_ERR_INVALID, "null argument");
-    if (!mpc->eng)
-      return fail(SMPC_ERR_INVALID, "smpc_id_set_targets_from_mpc needs a kinodynamics MPC handle");
     IdEngineBase * e = reinterpret_cast<IdEngineBase *>(id);
+    if (mpc->cent)
+    { // centroidal MPC -> CentroidalID (examples/talos_centroidal.py:218-243)
+      double *com, *vcom, *fp, *fv, *x, *a, *f;
+      e->centroidal_target_buffers(&com, &vcom, &fp, &fv);
+      if (!com)
+        return fail(SMPC_ERR_INVALID, "a centroidal MPC handle feeds a CentroidalID controller");
+      if (e->B != mpc->cent->B || e->nf != DimsGo2::NF)
+        return fail(SMPC_ERR_INVALID, "the controller and the MPC must hold the same batch of the same robot");
+      return guarded([&] {
+        e->target_buffers(&x, &a, &f);
+        e->set_mask_all(mpc->cent->contact_mask(0));
+        e->wait();
+        mpc->cent->interpolate_device_id(delay, knots, com, vcom, fp, fv, f);
+        mpc->cent->wait_stream(e->solve_stream());
+      });
+    }
+    if (!mpc->eng)
+      return fail(SMPC_ERR_INVALID, "smpc_id_set_targets_from_mpc needs a kinodynamics or a centroidal MPC handle");
+    {
+      double *com, *vcom, *fp, *fv;
+      e->centroidal_target_buffers(&com, &vcom, &fp, &fv);
+      if (com)
+        return fail(SMPC_ERR_INVALID, "a kinodynamics MPC handle feeds a KinodynamicsID controller");
+    }
     if (e->B != mpc->eng->B || e->nq != DimsGo2::NQ || e->nv != DimsGo2::NV)
       return fail(SMPC_ERR_INVALID, "the controller and the MPC must hold the same batch of the same robot");
     return guarded([&] {

@@ -156,6 +156,8 @@ namespace smpc
       for (double * p : {buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot, buf.ftraj, buf.vbase, buf.vref, buf.gains, buf.scal, buf.xdot01,
                          buf.zeros, buf.dbg, X_dev, cstate_dev, feet_dev, stage_out})
         dev_free(p);
+      if (ev_handoff_valid)
+        event_destroy(ev_handoff);
       dev_free(buf.stages);
       dev_free(buf.model);
       dev_free(fk.model);
@@ -501,6 +503,45 @@ namespace smpc
     }
     // interpolated targets at `delay` after the last solve (host outputs, any may be null): x [B][9], xdot [B][9],
     // forces [B][NU]; with X_meas (measured multibody states [B][nq + nv]) also the Riccati feedback u [B][NU]
+    // targets of a CentroidalID controller written into its device buffers; asynchronous on this engine's stream
+    void interpolate_device_id(double delay, int knots, double * com, double * vcom, double * fp, double * fv, double * f)
+    {
+      if (knots < 2 || knots > H + 1)
+        throw std::runtime_error("interpolate: knots must be in [2, horizon + 1]");
+      if (!(delay >= 0.0))
+        throw std::runtime_error("interpolate: delay must be non-negative");
+      set_device(device_id);
+      CentInterpArgs<DC> ia;
+      ia.b = buf;
+      ia.head = head;
+      ia.knots = knots;
+      ia.delay = delay;
+      ia.timestep = ms.timestep;
+      ia.x_meas = nullptr;
+      ia.x_out = nullptr;
+      ia.xdot_out = nullptr;
+      ia.f_out = f;
+      ia.u_out = nullptr;
+      ia.com_out = com;
+      ia.vcom_out = vcom;
+      ia.fp_out = fp;
+      ia.fv_out = fv;
+      ia.mass = mass;
+      launch<CentInterpArgs<DC>, cent_interp_body<DC>, 64>(B, stream, ia);
+    }
+    void wait_stream(stream_t other)
+    {
+      set_device(device_id);
+      if (!ev_handoff_valid)
+      {
+        ev_handoff = event_create();
+        ev_handoff_valid = true;
+      }
+      event_record(ev_handoff, stream);
+      stream_wait_event(other, ev_handoff);
+    }
+    event_t ev_handoff{};
+    bool ev_handoff_valid = false;
     void interpolate(double delay, int knots, const double * X_meas, double * x_out, double * xdot_out, double * f_out, double * u_out)
     {
       if (knots < 2 || knots > H + 1)

@@ -1304,6 +1304,10 @@ namespace smpc
     const double * x_meas;                // [B][9] centroidal state of the measured multibody state, or null
     double *x_out, *xdot_out, *f_out;     // [B][9], [B][9], [B][NU] (device), any may be null
     double * u_out;                       // [B][NU] Riccati feedback (needs x_meas), may be null
+    // targets of the CentroidalID controller (examples/talos_centroidal.py:218-243), any may be null: centre of mass and its velocity
+    // (linear momentum / mass) [B][3], foot references between stages 0 and 1 and their velocities [B][3 NF]
+    double *com_out = nullptr, *vcom_out = nullptr, *fp_out = nullptr, *fv_out = nullptr;
+    double mass = 1.0;
   };
   template <class D>
   SMPC_DEV void cent_interp_body(const CentInterpArgs<D> & ka, int block)
@@ -1332,9 +1336,21 @@ namespace smpc
           ka.xdot_out[inst * 9 + lane] = last2 ? d1 : d1 * sx + d0 * (1.0 - sx);
         }
         e[lane] = ka.x_meas ? xi - ka.x_meas[inst * 9 + lane] : 0.0;
+        if (ka.com_out && lane < 3)
+          ka.com_out[inst * 3 + lane] = xi;
+        if (ka.vcom_out && lane >= 3 && lane < 6)
+          ka.vcom_out[inst * 3 + lane - 3] = xi / ka.mass;
+      }
+      if (ka.fp_out && lane >= 16 && lane < 16 + 3 * D::NF)
+      {
+        const int i = lane - 16;
+        const double p0 = b.foot[(inst * H) * (3 * D::NF) + i], p1 = b.foot[(inst * H + 1) * (3 * D::NF) + i];
+        ka.fp_out[inst * 3 * D::NF + i] = last2 ? p1 : (1.0 - sx) * p0 + sx * p1;
+        ka.fv_out[inst * 3 * D::NF + i] = (p1 - p0) / ka.timestep;
       }
     }
     SMPC_LANES_END_WAVE
+    static_assert(16 + 3 * D::NF <= 64, "lane map of the foot targets");
     SMPC_LANES(NT)
     if (lane < NU)
     {

@@ -675,6 +675,7 @@ namespace smpc
     // device buffers the targets live in (an MPC engine's interpolation kernel writes them in place): states [B][nq + nv], accelerations
     // [B][nv], forces [B][3 nf]; set_mask_all: the contact flags of every robot; stream(): where the solve is issued
     virtual void target_buffers(double ** x, double ** a, double ** f) = 0;
+    virtual void centroidal_target_buffers(double ** com, double ** vcom, double ** fp, double ** fv) = 0; // CentroidalID; null otherwise
     virtual void set_mask_all(unsigned mask) = 0;
     virtual stream_t solve_stream() = 0;
     virtual void wait() = 0;
@@ -918,6 +919,14 @@ namespace smpc
       *x = buf.tx;
       *a = buf.ta;
       *f = buf.tf;
+    }
+    void centroidal_target_buffers(double ** com, double ** vcom, double ** fp, double ** fv) override
+    {
+      const bool c = buf.s.centroidal != 0;
+      *com = c ? buf.tcom : nullptr;
+      *vcom = c ? buf.tvcom : nullptr;
+      *fp = c ? buf.tfp : nullptr;
+      *fv = c ? buf.tfv : nullptr;
     }
     void set_mask_all(unsigned mask) override
     {

@@ -215,7 +215,7 @@ def test_settings_and_errors(built):
     cocp.createProblem(np.zeros(9), 10, 3, -9.81, False)
     conf = dict({kk: v for kk, v in P.go2_mpc_settings(mh, max_iters=1).items() if kk in P.MPC_KEYS}, T_fly=6, T_contact=2)
     cmpc = simple_mpc.BatchedMPC(conf, cocp, 1, lib=lib)
-    with pytest.raises(RuntimeError, match="kinodynamics MPC handle"):
+    with pytest.raises(RuntimeError, match="CentroidalID"):
         k.setTargetsFromMPC(cmpc, 0.0)
     with pytest.raises(RuntimeError, match="kinodynamics handle"):
         cmpc.simStepDevice(x.ctypes.data, tau.ctypes.data, [True] * 4, 1e-3)
@@ -400,6 +400,52 @@ def test_hip_resident_stack(built):
             return self.t.cpu().numpy()
 
     _resident_stack(None, 16, 16, Dev)
+
+
+def _centroidal_resident_targets(lib, B):
+    """setTargetsFromMPC of a centroidal MPC = setTargets of its interpolated solution, foot references and contact flags."""
+    from simple_mpc import presets as P
+
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+    for n in P.GO2_FEET:
+        mh.addPointFoot(n, "root_joint")
+    conf = dict({k: v for k, v in P.go2_mpc_settings(mh, max_iters=1).items() if k in P.MPC_KEYS}, T_fly=6, T_contact=2)
+    ocp = simple_mpc.CentroidalOCP(P.go2_centroidal_settings(mh), mh)
+    ocp.createProblem(np.zeros(9), 10, 3, -9.81, False)
+    mpc = simple_mpc.BatchedMPC(conf, ocp, B, lib=lib)
+    mpc.generateCycleHorizon(P.trot_cycle(2, 6))
+    V = np.zeros((B, 6))
+    V[:, 0] = np.linspace(0.1, 0.3, B)
+    mpc.switchToWalk(V[0])
+    mpc.setVelocityBaseBatched(V)
+    X = P.random_states(mh, B, scale=0.3)
+    for _ in range(14):  # (swing phase at stage 0)
+        mpc.iterate(X)
+    contact = mpc.ocp_handler.getContactState(0)
+    assert not all(contact)
+    ids = dict(kp_base=7.0, kp_com=7.0, kp_posture=10.0, kp_contact=10.0, kp_feet_tracking=100.0, w_base=50.0, w_com=100.0, w_posture=1.0,
+               w_contact_force=1e-3, w_contact_motion=1.0, w_feet_tracking=10.0)
+    mk = lambda: simple_mpc.CentroidalID(mh, 1e-3, ids, O.GO2_EFFORT, O.GO2_VMAX, batch=B, lib=lib, admm_iters=100, admm_tol=-1.0)
+    ka, kb = mk(), mk()
+    d = 0.4
+    x_i, _, f_i = mpc.interpolate(d * 0.01)
+    refs = mpc.getReferencePoses()
+    ka.setTargets(x_i[:, :3], x_i[:, 3:6] / mh.getMass(), (1 - d) * refs[:, 0] + d * refs[:, 1], (refs[:, 1] - refs[:, 0]) / 0.01, contact, f_i)
+    kb.setTargetsFromMPC(mpc, d * 0.01)
+    ta = ka.solve(0.0, X[:, : mh.nq], X[:, mh.nq :])
+    tb = kb.solve(0.0, X[:, : mh.nq], X[:, mh.nq :])
+    assert S.rel_err(ta, tb) < 1e-12 and S.rel_err(ka.debug(6), kb.debug(6)) < 1e-12
+    with pytest.raises(RuntimeError, match="CentroidalID"):
+        simple_mpc.KinodynamicsID(mh, 1e-3, {}, O.GO2_EFFORT, O.GO2_VMAX, batch=B, lib=lib).setTargetsFromMPC(mpc, 0.0)
+
+
+def test_emulated_kernels_centroidal_resident_targets(built):
+    _centroidal_resident_targets(S.emu_lib(), 3)
+
+
+@pytest.mark.gpu
+def test_hip_centroidal_resident_targets(built):
+    _centroidal_resident_targets(None, 8)
 
 
 def _centroidal_stack(lib, B, mpc_steps):
