@@ -1174,7 +1174,7 @@ class KinodynamicsID:
         return int(self._lib.L.smpc_id_get_tau_device(self._h))
 
     def setTargetsFromMPC(self, mpc, delay, knots=2):
-"""Targets of every robot from the solution a BatchedMPC holds (kinodynamics MPC -> KinodynamicsID, centroidal MPC -> CentroidalID),
+        """Targets of every robot from the solution a BatchedMPC holds (kinodynamics MPC -> KinodynamicsID, centroidal MPC -> CentroidalID),
         interpolated on the device at `delay` seconds after its last iterate and written straight into this controller's target buffers
         (the contact flags are those of the MPC's stage 0): the device-resident form of `setTargets(*mpc.interpolate(delay), ...)`."""
         self._lib.check(self._lib.L.smpc_id_set_targets_from_mpc(self._h, mpc._h, float(delay), int(knots)))
