@@ -402,6 +402,55 @@ def test_hip_resident_stack(built):
     _resident_stack(None, 16, 16, Dev)
 
 
+@pytest.mark.gpu
+def test_hip_resident_stack_three_gait_cycles(built):
+    """256 robots, 2.5 s of simulated time (250 MPC steps = three trot cycles, 2500 controller ticks and simulator steps per robot) with the
+    whole stack resident: every robot stays up, follows its velocity command, the torques respect the limits, and a second run from the
+    same state reproduces the first bit for bit."""
+    import torch
+    from simple_mpc import presets as P
+
+    B, steps = 256, 250
+    runs = []
+    for _ in range(2):
+        mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like"), "standing", "root_joint")
+        for n in P.GO2_FEET:
+            mh.addPointFoot(n, "root_joint")
+        ocp = simple_mpc.KinodynamicsOCP(P.go2_kino_settings(mh), mh)
+        ocp.createProblem(mh.getReferenceState(), 50, 3, -9.81, False)
+        mpc = simple_mpc.BatchedMPC({k: v for k, v in P.go2_mpc_settings(mh, max_iters=1).items() if k in P.MPC_KEYS}, ocp, B)
+        mpc.generateCycleHorizon(P.trot_cycle())
+        V = np.zeros((B, 6))
+        V[:, 0] = np.linspace(0.0, 0.3, B)
+        mpc.switchToWalk(V[0])
+        mpc.setVelocityBaseBatched(V)
+        ids = dict(kp_base=7.0, kp_posture=10.0, kp_contact=10.0, w_base=100.0, w_posture=1.0, w_contact_force=1.0, w_contact_motion=1.0)
+        kid = simple_mpc.KinodynamicsID(mh, 1e-3, ids, O.GO2_EFFORT, O.GO2_VMAX, batch=B)
+        X = torch.from_numpy(np.tile(mh.getReferenceState(), (B, 1))).cuda()
+        torch.cuda.synchronize()
+        tmax = 0.0
+        for step_i in range(steps):
+            mpc.iterate_device(X.data_ptr())
+            mpc.wait()
+            contact = mpc.ocp_handler.getContactState(0)
+            for sub in range(10):
+                kid.setTargetsFromMPC(mpc, sub * 1e-3)
+                kid.solve_device(X.data_ptr())
+                kid.wait()
+                mpc.simStepDevice(X.data_ptr(), kid.tau_device_ptr(), contact, 1e-3, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])
+            if step_i % 10 == 0:
+                tmax = max(tmax, np.abs(kid.debug(12)).max())
+        mpc.wait()
+        runs.append((X.cpu().numpy(), tmax))
+    Xh, tmax = runs[0]
+    z0 = mh.getReferenceState()[2]
+    print("base x %.3f .. %.3f m after 2.5 s, height %.3f .. %.3f (reference %.3f), max |tau| %.1f" % (Xh[0, 0], Xh[-1, 0], Xh[:, 2].min(), Xh[:, 2].max(), z0, tmax))
+    assert np.all(np.isfinite(Xh)) and np.all(np.abs(Xh[:, 2] - z0) < 0.05)
+    assert Xh[-1, 0] > 0.4 and abs(Xh[0, 0]) < 0.1 and np.all(np.diff(Xh[:, 0]) > -0.02)  # 0.3 m/s for 2.5 s; the commands order the robots
+    assert tmax <= O.GO2_EFFORT.max() + 1e-6
+    assert np.array_equal(Xh, runs[1][0])
+
+
 def _centroidal_resident_targets(lib, B):
     """setTargetsFromMPC of a centroidal MPC = setTargets of its interpolated solution, foot references and contact flags."""
     from simple_mpc import presets as P
