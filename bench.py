@@ -323,6 +323,7 @@ def control_stack_line(batch, device_id, mpc_steps=30):
     eff, vmax = np.array([23.7, 23.7, 45.43] * 4), np.array([30.1, 30.1, 15.7] * 4)
     ids = dict(kp_base=7.0, kp_posture=10.0, kp_contact=10.0, w_base=100.0, w_posture=1.0, w_contact_force=1.0, w_contact_motion=1.0)
     kid = simple_mpc.KinodynamicsID(mh, 1e-3, ids, eff, vmax, batch=batch, device_id=device_id)
+    kid.shareStream(gm)  # one in-order queue for the MPC step, the targets, the QP solves and the simulator steps
     X = torch.from_numpy(np.tile(mh.getReferenceState(), (batch, 1))).to(torch.device("cuda", device_id))
     torch.cuda.synchronize()
 
@@ -333,7 +334,6 @@ def control_stack_line(batch, device_id, mpc_steps=30):
         for sub in range(10):
             kid.setTargetsFromMPC(gm, sub * 1e-3)
             kid.solve_device(X.data_ptr())
-            kid.wait()
             gm.simStepDevice(X.data_ptr(), kid.tau_device_ptr(), contact, 1e-3, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])
 
     for _ in range(3):
@@ -345,6 +345,7 @@ def control_stack_line(batch, device_id, mpc_steps=30):
     gm.wait()
     dt = (time.perf_counter() - t0) / mpc_steps
     Xh = X.cpu().numpy()
+    kid.shareStream(None)
     ok = bool(np.all(np.isfinite(Xh)) and np.all(np.abs(Xh[:, 2] - mh.getReferenceState()[2]) < 0.05))
     return {"metric": "simulated robot-seconds per second, MPC (100 Hz, 1 iteration) + KinodynamicsID (1 kHz) + forward-dynamics simulator",
             "value": batch * 0.01 / dt, "unit": "robot-seconds/s", "ms_per_mpc_period": dt * 1e3, "batch": batch, "robots_upright": ok,

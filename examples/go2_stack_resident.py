@@ -36,6 +36,7 @@ dt_simu = dt_mpc / N_simu
 id_settings = dict(kp_base=7.0, kp_posture=10.0, kp_contact=10.0, w_base=100.0, w_posture=1.0, w_contact_force=1.0, w_contact_motion=1.0)  # :147-154
 effort, vmax = np.array([23.7, 23.7, 45.43] * 4), np.array([30.1, 30.1, 15.7] * 4)
 kino_ID = KinodynamicsID(mh, dt_simu, id_settings, effort, vmax, batch=B)
+kino_ID.shareStream(mpc)  # MPC step, targets, QP solves and simulator steps in one in-order queue
 
 X = torch.from_numpy(np.tile(mh.getReferenceState(), (B, 1))).cuda()
 torch.cuda.synchronize()
@@ -47,10 +48,10 @@ for step in range(steps):
     for sub in range(N_simu):
         kino_ID.setTargetsFromMPC(mpc, sub / float(N_simu) * dt_mpc)
         kino_ID.solve_device(X.data_ptr())
-        kino_ID.wait()
         mpc.simStepDevice(X.data_ptr(), kino_ID.tau_device_ptr(), contact, dt_simu, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])
 mpc.wait()
 wall = time.time() - t0
+kino_ID.shareStream(None)
 Xh = X.cpu().numpy()
 sim_time = steps * dt_mpc
 print("%d robots, %.2f s of simulated time (%d MPC steps x %d controller ticks) in %.2f s: %.1f ms per MPC period, %.2fx real time for the batch, "

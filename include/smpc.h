@@ -400,6 +400,10 @@ double * smpc_id_get_x_device(smpc_id_handle * h);
  *                                 semi-implicit Euler over dt; X_device [B][nq + nv] is updated in place.  Asynchronous on the MPC
  *                                 handle's stream (smpc_wait joins); kinodynamics handles only (they carry the multibody model). */
 int smpc_id_set_targets_from_mpc(smpc_id_handle * id, smpc_handle * mpc, double delay, int knots);
+/* From now on the controller issues its work on the MPC handle's stream (kinodynamics or centroidal handle; NULL: back to its own):
+ * MPC step, targets, QP solves and simulator steps then form one in-order queue -- smpc_id_wait / smpc_wait are needed only before the
+ * host reads a result, not between the legs of a tick. */
+int smpc_id_share_stream(smpc_id_handle * id, smpc_handle * mpc);
 int smpc_sim_step_device(smpc_handle * h, double * X_device, const double * tau_device, const uint8_t * contact, const double * Kp, const double * Kd, double dt);
 /* (tests) intermediate results of the last solve, padded layouts of simple-mpc_amd/csrc/smpc_id.h: what = 0 M, 1 nle, 2 J, 3 dJ v, 4 foot
  * velocities, 5 H [32][32], 6 g [32], 7 C [80][32], 8 l [80], 9 u [80], 10 centre of mass [3], 11 foot positions [3 nfeet], 12 torques [nv - 6]; every one [B][...] */

@@ -1049,9 +1049,12 @@ extern "C"
       return guarded([&] {
         e->target_buffers(&x, &a, &f);
         e->set_mask_all(mpc->cent->contact_mask(0));
-        e->wait();
+        const bool shared = e->solve_stream() == mpc->cent->stream; // (one in-order queue: nothing to order)
+        if (!shared)
+          e->wait();
         mpc->cent->interpolate_device_id(delay, knots, com, vcom, fp, fv, f);
-        mpc->cent->wait_stream(e->solve_stream());
+        if (!shared)
+          mpc->cent->wait_stream(e->solve_stream());
       });
     }
     if (!mpc->eng)
@@ -1068,10 +1071,24 @@ extern "C"
       double *x, *a, *f;
       e->target_buffers(&x, &a, &f);
       e->set_mask_all(mpc->eng->contact_mask(0));
-      e->wait(); // (the previous solve has read its targets)
+      const bool shared = e->solve_stream() == mpc->eng->stream; // (one in-order queue: nothing to order)
+      if (!shared)
+        e->wait(); // (the previous solve has read its targets)
       mpc->eng->interpolate_device(delay, knots, x, a, f);
-      mpc->eng->wait_stream(e->solve_stream()); // the next solve starts after the targets are written
+      if (!shared)
+        mpc->eng->wait_stream(e->solve_stream()); // the next solve starts after the targets are written
     });
+  }
+  int smpc_id_share_stream(smpc_id_handle * id, smpc_handle * mpc)
+  {
+    if (!id)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    IdEngineBase * e = reinterpret_cast<IdEngineBase *>(id);
+    if (!mpc)
+      return guarded([&] { e->adopt_stream(e->solve_stream(), true); });
+    if (mpc->full)
+      return fail(SMPC_ERR_INVALID, "smpc_id_share_stream needs a kinodynamics or a centroidal MPC handle");
+    return guarded([&] { e->adopt_stream(mpc->cent ? mpc->cent->stream : mpc->eng->stream, false); });
   }
   int smpc_sim_step_device(smpc_handle * h, double * X_device, const double * tau_device, const uint8_t * contact, const double * Kp, const double * Kd, double dt)
   {

@@ -678,6 +678,9 @@ namespace smpc
     virtual void centroidal_target_buffers(double ** com, double ** vcom, double ** fp, double ** fv) = 0; // CentroidalID; null otherwise
     virtual void set_mask_all(unsigned mask) = 0;
     virtual stream_t solve_stream() = 0;
+    // issue this controller's work on another engine's stream from now on (one in-order queue for MPC, controller and simulator: no
+    // events, no host-side waits between them); back_to_own: the controller's own stream again
+    virtual void adopt_stream(stream_t s, bool back_to_own) = 0;
     virtual void wait() = 0;
     virtual const double * tau_device() const = 0;
     virtual double * x_device() = 0; // the engine's own state buffer [B][nq + nv] (what solve() copies the host states into)
@@ -688,7 +691,7 @@ namespace smpc
   {
     typedef IdDims<D> G;
     IdBuffers<D> buf;
-    stream_t stream;
+    stream_t stream, own_stream;
     int device_id = 0;
     double * Xd = nullptr;
     std::vector<void *> allocs;
@@ -706,7 +709,7 @@ namespace smpc
         throw std::runtime_error("inverse-dynamics settings: control_dt and the iteration count must be positive");
       device_id = device;
       set_device(device);
-      stream = stream_create();
+      stream = own_stream = stream_create();
       B = batch;
       nq = D::NQ;
       nv = D::NV;
@@ -800,7 +803,7 @@ namespace smpc
     {
       for (void * p : allocs)
         dev_free(p);
-      stream_destroy(stream);
+      stream_destroy(own_stream);
     }
     void set_target(int inst, const double * q, const double * v, const double * a, unsigned mask, const double * f) override
     {
@@ -941,6 +944,12 @@ namespace smpc
       }
     }
     stream_t solve_stream() override { return stream; }
+    void adopt_stream(stream_t s, bool back_to_own) override
+    {
+      set_device(device_id);
+      stream_sync(stream);
+      stream = back_to_own ? own_stream : s;
+    }
     void solve(const double * X, double * tau, double * a, double * f, double * resid) override
     {
       set_device(device_id);

@@ -1179,6 +1179,11 @@ class KinodynamicsID:
         (the contact flags are those of the MPC's stage 0): the device-resident form of `setTargets(*mpc.interpolate(delay), ...)`."""
         self._lib.check(self._lib.L.smpc_id_set_targets_from_mpc(self._h, mpc._h, float(delay), int(knots)))
 
+    def shareStream(self, mpc):
+        """Issue this controller's work on the BatchedMPC's stream from now on (None: back to its own): MPC step, targets, QP solves and
+        simulator steps form one in-order queue, and wait() is needed only before the host reads a result."""
+        self._lib.check(self._lib.L.smpc_id_share_stream(self._h, mpc._h if mpc is not None else None))
+
     def x_device_ptr(self):
         """The handle's own state buffer [B][nq + nv] in HBM (solve() copies the host states there)."""
         return int(self._lib.L.smpc_id_get_x_device(self._h))

@@ -154,7 +154,7 @@ SYMBOLS = [
     "smpc_get_foot_timing", "smpc_get_info", "smpc_get_status", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
     "smpc_debug_get_steps", "smpc_debug_get_terminal", "smpc_debug_get_phase_cycles", "smpc_set_profiling", "smpc_get_kernel_times", "smpc_reset_kernel_times",
     "smpc_interpolate", "smpc_interpolate_knots", "smpc_friction_compensation", "smpc_update_internal_data", "smpc_full_forward_dynamics", "smpc_centroidal_dynamics", "smpc_riccati_feedback",
-    "smpc_id_create", "smpc_id_destroy", "smpc_id_set_target", "smpc_id_set_targets", "smpc_id_set_target_centroidal", "smpc_id_set_targets_centroidal", "smpc_id_solve", "smpc_id_solve_device", "smpc_id_wait", "smpc_id_get_tau_device", "smpc_id_get_x_device", "smpc_id_set_targets_from_mpc", "smpc_sim_step_device", "smpc_id_debug_get",
+    "smpc_id_create", "smpc_id_destroy", "smpc_id_set_target", "smpc_id_set_targets", "smpc_id_set_target_centroidal", "smpc_id_set_targets_centroidal", "smpc_id_solve", "smpc_id_solve_device", "smpc_id_wait", "smpc_id_get_tau_device", "smpc_id_get_x_device", "smpc_id_set_targets_from_mpc", "smpc_id_share_stream", "smpc_sim_step_device", "smpc_id_debug_get",
 ]
 
 
@@ -221,6 +221,7 @@ class SmpcLib:
         L.smpc_id_get_tau_device.restype = C.c_void_p
         L.smpc_id_get_x_device.argtypes = [vp]
         L.smpc_id_set_targets_from_mpc.argtypes = [vp, vp, C.c_double, C.c_int]
+        L.smpc_id_share_stream.argtypes = [vp, vp]
         L.smpc_sim_step_device.argtypes = [vp, vp, vp, _bp, C.c_void_p, C.c_void_p, C.c_double]
         L.smpc_id_get_x_device.restype = C.c_void_p
         L.smpc_get_status.argtypes = [vp, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]

@@ -355,20 +355,26 @@ def _resident_stack(lib, B, mpc_steps, alloc):
             a = mpc.constraintDynamics(X, tau, mask, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])["a"]
             vn = X[:, nq:] + a * 1e-3
             X = np.stack([P.integrate(np.r_[X[b, :nq], vn[b]], np.r_[vn[b] * 1e-3, np.zeros(nv)], nq) for b in range(B)])
-    mh, mpc, kid = setup()
-    Xd = alloc(np.tile(mh.getReferenceState(), (B, 1)))  # resident
-    for _ in range(mpc_steps):
-        mpc.iterate_device(Xd.ptr)
-        mpc.wait()
-        contact = mpc.ocp_handler.getContactState(0)
-        for sub in range(10):
-            kid.setTargetsFromMPC(mpc, sub / 10.0 * 0.01)
-            kid.solve_device(Xd.ptr)
-            kid.wait()
-            mpc.simStepDevice(Xd.ptr, kid.tau_device_ptr(), contact, 1e-3, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])
-        mpc.wait()
     assert swing
-    assert S.rel_err(X, Xd.get()) < 1e-8, S.rel_err(X, Xd.get())
+    for shared in (False, True):  # the controller on its own stream (events + waits between the legs), then on the MPC's stream (one queue)
+        mh, mpc, kid = setup()
+        if shared:
+            kid.shareStream(mpc)
+        Xd = alloc(np.tile(mh.getReferenceState(), (B, 1)))  # resident
+        for _ in range(mpc_steps):
+            mpc.iterate_device(Xd.ptr)
+            mpc.wait()
+            contact = mpc.ocp_handler.getContactState(0)
+            for sub in range(10):
+                kid.setTargetsFromMPC(mpc, sub / 10.0 * 0.01)
+                kid.solve_device(Xd.ptr)
+                if not shared:
+                    kid.wait()
+                mpc.simStepDevice(Xd.ptr, kid.tau_device_ptr(), contact, 1e-3, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])
+            mpc.wait()
+        assert S.rel_err(X, Xd.get()) < 1e-8, (shared, S.rel_err(X, Xd.get()))
+        if shared:
+            kid.shareStream(None)
 
 
 class _HostArray:
@@ -426,6 +432,7 @@ def test_hip_resident_stack_three_gait_cycles(built):
         mpc.setVelocityBaseBatched(V)
         ids = dict(kp_base=7.0, kp_posture=10.0, kp_contact=10.0, w_base=100.0, w_posture=1.0, w_contact_force=1.0, w_contact_motion=1.0)
         kid = simple_mpc.KinodynamicsID(mh, 1e-3, ids, O.GO2_EFFORT, O.GO2_VMAX, batch=B)
+        kid.shareStream(mpc)
         X = torch.from_numpy(np.tile(mh.getReferenceState(), (B, 1))).cuda()
         torch.cuda.synchronize()
         tmax = 0.0
@@ -436,12 +443,12 @@ def test_hip_resident_stack_three_gait_cycles(built):
             for sub in range(10):
                 kid.setTargetsFromMPC(mpc, sub * 1e-3)
                 kid.solve_device(X.data_ptr())
-                kid.wait()
                 mpc.simStepDevice(X.data_ptr(), kid.tau_device_ptr(), contact, 1e-3, Kp=[0.0, 0.0, 0.0], Kd=[50.0, 50.0, 50.0])
             if step_i % 10 == 0:
                 tmax = max(tmax, np.abs(kid.debug(12)).max())
         mpc.wait()
         runs.append((X.cpu().numpy(), tmax))
+        kid.shareStream(None)  # (the MPC handle may go first)
     Xh, tmax = runs[0]
     z0 = mh.getReferenceState()[2]
     print("base x %.3f .. %.3f m after 2.5 s, height %.3f .. %.3f (reference %.3f), max |tau| %.1f" % (Xh[0, 0], Xh[-1, 0], Xh[:, 2].min(), Xh[:, 2].max(), z0, tmax))
