@@ -412,9 +412,21 @@ namespace smpc
     SMPC_PLA(double, Krow, NT, NP);
     SMPC_LANES(NT)
     {
-      for (int idx = lane; idx < GR * NP; idx += NT)
-        s.C[(idx / NP) * LDC + idx % NP] = Cg[idx];
+      // rows and columns of C straight from HBM into the registers they stay in (all loads independent: in flight together); the
+      // LDS copy the matrix cores read K's operands from is written from the column registers
       const int i = lane < NP ? lane : 0, kb = lane < N ? lane : 0, kg = N + (lane < GR ? lane : 0);
+#pragma unroll
+      for (int kk = 0; kk < GR; kk++)
+        SMPC_PLV(Ccol)[kk] = Cg[kk * NP + i];
+#pragma unroll
+      for (int ii = 0; ii < NP; ii++)
+        SMPC_PLV(Crow)[ii] = Cg[(kg - N) * NP + ii];
+      if (lane < NP)
+      {
+#pragma unroll
+        for (int kk = 0; kk < GR; kk++)
+          s.C[kk * LDC + lane] = SMPC_PLV(Ccol)[kk];
+      }
       SMPC_PLV(g) = b.g[(size_t)inst * NP + i];
       SMPC_PLV(x) = warm ? b.x[(size_t)inst * NP + i] : 0.0;
       SMPC_PLV(rhs) = SMPC_PLV(xt) = 0.0;
@@ -433,17 +445,6 @@ namespace smpc
         SMPC_PLV(lamg) = warm ? b.lam[(size_t)inst * MP + kg] : 0.0;
       }
       SMPC_PLV(wg) = SMPC_PLV(ztg) = 0.0;
-    }
-    SMPC_LANES_END_WAVE
-    SMPC_LANES(NT)
-    {
-      const int i = lane < NP ? lane : 0, k = lane < GR ? lane : 0;
-#pragma unroll
-      for (int kk = 0; kk < GR; kk++)
-        SMPC_PLV(Ccol)[kk] = s.C[kk * LDC + i];
-#pragma unroll
-      for (int ii = 0; ii < NP; ii++)
-        SMPC_PLV(Crow)[ii] = s.C[k * LDC + ii];
     }
     SMPC_LANES_END_WAVE
     // row weights r = rho (1e3 rho on equality rows, 1e-6 rho on free rows) ; K = H + sigma I + C^T diag(r) C -> its inverse -> rows in registers
