@@ -267,8 +267,9 @@ namespace smpc
         }
         g[i] = gi;
       }
-      // ---- C, l, u ----
-      for (int idx = lane; idx < MP * NP; idx += NT)
+      // ---- C, l, u ----  (rows 0 .. N-1, the box on y, are the identity and the padding rows are zero: written once when the engine
+      //                     is created; only the general rows change with the state)
+      for (int idx = N * NP + lane; idx < G::M * NP; idx += NT)
       {
         const int r = idx / NP, c = idx % NP;
         double val = 0.0;
@@ -750,6 +751,14 @@ namespace smpc
       buf.H = dalloc(Bs * np * np);
       buf.g = dalloc(Bs * np);
       buf.C = dalloc(Bs * mp * np);
+      {
+        std::vector<double> c0(Bs * mp * np, 0.0); // constant rows of C: the identity of the box on y
+        for (size_t b = 0; b < Bs; b++)
+          for (int i = 0; i < n; i++)
+            c0[(b * mp + i) * np + i] = 1.0;
+        h2d(buf.C, c0.data(), c0.size() * sizeof(double), stream);
+        stream_sync(stream);
+      }
       buf.l = dalloc(Bs * mp);
       buf.u = dalloc(Bs * mp);
       buf.x = dalloc(Bs * np);
