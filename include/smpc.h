@@ -402,7 +402,8 @@ double * smpc_id_get_x_device(smpc_id_handle * h);
 int smpc_id_set_targets_from_mpc(smpc_id_handle * id, smpc_handle * mpc, double delay, int knots);
 /* From now on the controller issues its work on the MPC handle's stream (kinodynamics or centroidal handle; NULL: back to its own):
  * MPC step, targets, QP solves and simulator steps then form one in-order queue -- smpc_id_wait / smpc_wait are needed only before the
- * host reads a result, not between the legs of a tick. */
+ * host reads a result, not between the legs of a tick.  The stream belongs to the MPC handle: go back (NULL) before that handle is
+ * destroyed. */
 int smpc_id_share_stream(smpc_id_handle * id, smpc_handle * mpc);
 int smpc_sim_step_device(smpc_handle * h, double * X_device, const double * tau_device, const uint8_t * contact, const double * Kp, const double * Kd, double dt);
 /* (tests) intermediate results of the last solve, padded layouts of simple-mpc_amd/csrc/smpc_id.h: what = 0 M, 1 nle, 2 J, 3 dJ v, 4 foot
