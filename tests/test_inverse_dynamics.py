@@ -161,6 +161,57 @@ def test_emulated_kernels_centroidal_id_closed_loop(built):
     _centroidal_closed_loop(S.emu_lib(), 60, 1e-7)
 
 
+def _random_cases(lib, n_cases, seed):
+    """Random settings (gains, weights, task switches, contact-motion variant), random contact patterns (from no foot to all four) and
+    random targets, per robot: QP data and solution against the oracle."""
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        cent = bool(rng.integers(2))
+        kw = dict(kp_base=rng.uniform(1, 20), kp_posture=rng.uniform(0.1, 20), kp_contact=rng.uniform(0.1, 20),
+                  w_base=rng.choice([-1.0, 1.0, 50.0]), w_posture=rng.choice([0.01, 1.0]), w_contact_force=rng.choice([-1.0, 1e-3, 1.0]),
+                  w_contact_motion=rng.choice([0.1, 10.0]), contact_motion_equality=bool(rng.integers(2)),
+                  friction_coefficient=rng.uniform(0.3, 1.0))
+        if cent:
+            kw.update(centroidal=True, kp_com=rng.uniform(1, 10), kp_feet_tracking=rng.uniform(1, 100), w_com=rng.choice([-1.0, 10.0]),
+                      w_feet_tracking=rng.choice([-1.0, 100.0]))
+        B = 3
+        rb, ok, gk = make(lib, B, **kw)
+        X = S.random_states(rb, B, seed=100 + case, scale=rng.uniform(0.1, 0.6))
+        for b in range(B):
+            contact = [bool(c) for c in rng.integers(2, size=4)]
+            f = np.zeros((4, 3))
+            if any(contact):
+                f[contact, 2] = rb.mass * 9.81 / sum(contact)
+                f[contact, :2] = rng.normal(0, 2.0, (sum(contact), 2))
+            if cent:
+                c = rb.centroidal(X[b])
+                com, vcom = c["com"] + rng.normal(0, 0.02, 3), rng.normal(0, 0.1, 3)
+                fp, fv = c["feet"] + rng.normal(0, 0.03, (4, 3)), rng.normal(0, 0.2, (4, 3))
+                ok.setTargetCentroidal(com, vcom, fp, fv, contact, f.reshape(-1), instance=b)
+                gk.setTarget(com, vcom, fp, fv, contact, f, instance=b)
+            else:
+                xt = S.random_states(rb, 1, seed=500 + 7 * case + b, scale=0.2)[0]
+                at = rng.normal(0, 1.0, rb.nv)
+                ok.setTarget(xt[: rb.nq], xt[rb.nq :], at, contact, f.reshape(-1), instance=b)
+                gk.setTarget(xt[: rb.nq], xt[rb.nq :], at, contact, f, instance=b)
+        to, ao, fo = ok.solve(X)
+        tg = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
+        _compare_qp(rb, ok, gk, X)
+        # (fixed 100 iterations from a cold start: not every random QP has converged, the two sides iterate identically all the same)
+        assert S.rel_err(to, tg) < 1e-7 and S.rel_err(ao, gk.getAccelerations()) < 1e-7, (case, kw)
+        # (residuals: equal where they are large; below 1e-5 they are the rounding of sums of multipliers of size 1e3 .. 1e4)
+        assert np.all((np.abs(gk.resid - ok.resid) <= 1e-2 * ok.resid) | ((gk.resid < 1e-5) & (ok.resid < 1e-5))), (case, gk.resid, ok.resid)
+
+
+def test_emulated_kernels_random_settings_contacts_targets(built):
+    _random_cases(S.emu_lib(), 24, seed=7)
+
+
+@pytest.mark.gpu
+def test_hip_random_settings_contacts_targets(built):
+    _random_cases(None, 40, seed=8)
+
+
 def test_emulated_kernels_resident_solve(built):
     """smpc_id_solve_device: states and torques stay where the kernels read / write them (the emulated library's "device" memory is the
     host's); same result as the host-buffer call."""
