@@ -1,6 +1,6 @@
-// smpc_id.h -- batched whole-body inverse-dynamics QP: the KinodynamicsID controller of the reference
-// (src/inverse-dynamics/kinodynamics-id.cpp:7-237; SURVEY 8f row f3, the "proxsuite contact-force QP" downstream of MPC::iterate)
-// for robots with 3-D point feet, one wavefront per robot.
+// smpc_id.h -- batched whole-body inverse-dynamics QP: the KinodynamicsID and CentroidalID controllers of the reference
+// (src/inverse-dynamics/kinodynamics-id.cpp:7-237, centroidal-id.cpp:6-147; SURVEY 8f row f3, the "proxsuite contact-force QP"
+// downstream of MPC::iterate) for robots with 3-D point feet, one wavefront per robot.
 //
 // The reference builds the problem with TSID 1.9 (InverseDynamicsFormulationAccForce + tasks) and solves it with proxsuite's ProxQP;
 // neither library is available, so the formulation is restated (the CPU checker holds the same statement, term by term, with the
@@ -12,8 +12,9 @@
 //                     full-dynamics stage kernel (smpc_full_stage.h) up to the contact rows
 //   id_assemble_body  H, g, C, l, u of the QP (n = nv + 3 nf = 30 variables, m = 76 rows for a quadruped), padded to 32 x 80
 //   qp_admm_body      min 1/2 y^T H y + g^T y, l <= C y <= u by ADMM (the operator splitting of OSQP: K = H + sigma I + C^T diag(rho) C is
-//                     inverted once per solve by the bordered block sweep on the matrix cores, the iterations are matrix-vector
-//                     products out of LDS), warm-started from the previous control tick; then tau
+//                     assembled and inverted once per solve on the matrix cores, the iterations are matrix-vector products out of
+//                     registers with v_readlane broadcasts; residual-based stop, OSQP's rho adaptation), warm-started from the previous
+//                     control tick; then tau
 #pragma once
 #include "smpc_full_stage.h"
 
