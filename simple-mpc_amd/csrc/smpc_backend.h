@@ -47,6 +47,8 @@
 #define SMPC_PL(type, name, NT) type name
 #define SMPC_PLA(type, name, NT, n) type name[n]
 #define SMPC_PLV(name) name
+// a per-lane persistent variable as a function parameter
+#define SMPC_PL_REF(type, name, NT) type & name
 // value of a per-lane persistent variable / array element in lane `src` (wave-uniform src): v_readlane pairs, the
 // result lives in SGPRs and feeds VALU FMAs directly -- no LDS round trip, no barrier
 #define SMPC_XLANE(name, src) ::smpc::readlane_f64(name, src)

@@ -12,7 +12,11 @@
 #ifndef SMPC_TRIAL_MINW
 #define SMPC_TRIAL_MINW 3
 #endif
+#ifndef SMPC_LANE_MINW
+#define SMPC_LANE_MINW 1
+#endif
 #include "smpc_riccati_kino.h"
+#include "smpc_kino_lane.h"
 #include "smpc_solver_kernels.h"
 #include "smpc_full_kernels.h"
 #include <algorithm>
@@ -296,6 +300,32 @@ namespace smpc
     m.total_mass = rm->total_mass;
   }
 
+  // branch joints of the lane-per-problem evaluation (smpc_kino_lane.h): parents that are not the joint right before their child
+  template <class D>
+  inline void fill_lane_slots(const smpc_robot_model * rm, DevModel<D> & m)
+  {
+    int nslots = 0;
+    bool ok = true;
+    for (int j = 0; j < D::NJ; j++)
+      m.par_slot[j] = m.save_slot[j] = -1;
+    for (int j = 1; j < D::NJ; j++)
+      if (rm->parent[j] != j - 1)
+      {
+        const int par = rm->parent[j];
+        if (m.save_slot[par] < 0)
+        {
+          if (nslots == LANE_SLOTS)
+          {
+            ok = false;
+            break;
+          }
+          m.save_slot[par] = nslots++;
+        }
+        m.par_slot[j] = m.save_slot[par];
+      }
+    m.lane_slots = ok ? std::max(nslots, 1) : 0;
+  }
+
   template <class D>
   class KinoEngine
   {
@@ -333,6 +363,10 @@ namespace smpc
     static constexpr int LS_SLOTS = 64; // instance slots of the list-mode (backtracking) launches: 64 x (H+1) blocks when the list is empty
     bool speculative_ls = std::getenv("SMPC_NO_SPECULATIVE_LS") == nullptr; // tentative full steps (run_iterations)
     bool aux_launches = false; // true during the cold start: every launch uses the auxiliary kernel symbols
+    // lane-per-problem stage evaluation (smpc_kino_lane.h) for problems without optional constraint blocks; SMPC_LANE_EVAL=0: the
+    // wavefront-per-problem kernels throughout (A/B comparison)
+    int lane_slots = 1;
+    bool lane_eval = !(std::getenv("SMPC_LANE_EVAL") && std::atoi(std::getenv("SMPC_LANE_EVAL")) == 0);
     double kernel_ms[KID_N] = {0};
     long kernel_calls[KID_N] = {0};
     std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
@@ -381,6 +415,8 @@ namespace smpc
       DevModel<D> & m = hm[0];
       std::memset(&m, 0, sizeof(m));
       fill_tree_model<D>(rm, m);
+      fill_lane_slots<D>(rm, m);
+      lane_slots = m.lane_slots;
       m.dt = ks.timestep;
       for (int i = 0; i < 3; i++)
         m.gravity[i] = ks.gravity[i];
@@ -446,6 +482,8 @@ namespace smpc
       buf.vref = dalloc(BR * 6);
       buf.lq = dalloc(BH * D::LQ_STRIDE);
       buf.gains = dalloc(BH * (size_t)std::max((int)D::G_STRIDE, (int)GainsK<D>::STRIDE));
+      if (lane_eval && m.lane_slots > 0 && !ks.terminal_constraint && !ks.force_cone && !ks.land_cstr)
+        buf.ev = dalloc((((size_t)B * (H + 1) + EV_LS - 1) / EV_LS) * EV_LS * EvLayout<D>::STRIDE);
       buf.QN = dalloc((size_t)B * D::NDX * D::NDX);
       buf.qN = dalloc((size_t)B * D::NDX);
       buf.parts0 = dalloc((size_t)B * (H + 1) * 4);
@@ -527,7 +565,7 @@ namespace smpc
       for (double * p : {buf.CN, buf.vN, buf.vN_e, buf.vN_b, buf.dvN, buf.dcm_ref, buf.es, buf.es_e, buf.es_b, buf.des, buf.ek, buf.ls, buf.ls_e, buf.ls_b, buf.dls, buf.lk})
         dev_free(p);
       for (double * p : {buf.xs_b, buf.us_b, buf.vs_b, buf.lams_b, buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref, buf.ftraj, buf.vbase, buf.vref, buf.lq,
-                         buf.gains, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, X_dev, stage_out})
+                         buf.gains, buf.ev, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, X_dev, stage_out})
         dev_free(p);
       dev_free(buf.ls_sel);
       dev_free(buf.und_list);
@@ -624,6 +662,30 @@ namespace smpc
       else
         timed_launch<StageKernelArgs<D>, deriv_body<D, false>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
     }
+    // line-search evaluation of the candidates sk.j0 .. sk.j0 + sk.nj - 1 (sk.slots > 0: for the compacted list of undecided instances)
+    void launch_trial(const Buffers<D> & b, const StageKernelArgs<D> & sk, int kid, bool aux)
+    {
+      if (b.ev != nullptr)
+      {
+        LaneKernelArgs<D> la;
+        la.b = b;
+        la.head = sk.head;
+        la.j0 = sk.j0;
+        la.nj = sk.nj;
+        la.slots = sk.slots;
+        la.deriv = 0;
+        const int n = sk.slots > 0 ? sk.slots : b.B;
+        if (lane_slots == 1)
+          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, aux);
+        else
+          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, aux);
+        timed_launch<StageKernelArgs<D>, trial_rows_body<D>, 64>(kid, n * (H + 1), sk, aux);
+      }
+      else if (has_ext(b))
+        timed_launch<StageKernelArgs<D>, trial_body<D, true>, 64, TRIAL_MINW>(kid, (sk.slots > 0 ? sk.slots : b.B) * (H + 1), sk, aux);
+      else
+        timed_launch<StageKernelArgs<D>, trial_body<D, false>, 64, TRIAL_MINW>(kid, (sk.slots > 0 ? sk.slots : b.B) * (H + 1), sk, aux);
+    }
     // backward + forward sweep: Newton step and merit directional derivative
     void launch_sweeps(const Buffers<D> & b)
     {
@@ -676,21 +738,13 @@ namespace smpc
       StageKernelArgs<D> sk = stage_args(b);
       sk.j0 = 0;
       sk.nj = 1;
-      if (has_ext(b))
-        timed_launch<StageKernelArgs<D>, trial_body<D, true>, 64, TRIAL_MINW>(KID_TRIAL, b.B * (H + 1), sk);
-      else
-        timed_launch<StageKernelArgs<D>, trial_body<D, false>, 64, TRIAL_MINW>(KID_TRIAL, b.B * (H + 1), sk);
+      launch_trial(b, sk, KID_TRIAL, false);
       timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, 0, 1));
       const int slots = launch_backtracking(b);
       sk.slots = slots;
       sk.j0 = 1;
       sk.nj = D::LS_N - 1;
-      {
-        if (has_ext(b))
-          timed_launch<StageKernelArgs<D>, trial_body<D, true>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
-        else
-          timed_launch<StageKernelArgs<D>, trial_body<D, false>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
-      }
+      launch_trial(b, sk, KID_SELECT, true);
       timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, (b.B + 63) / 64, solver_args(b, 1, D::LS_N - 1));
       timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_APPLY, b.B, solver_args(b));
     }
@@ -745,12 +799,7 @@ namespace smpc
         StageKernelArgs<D> sk = stage_args(b, slots);
         sk.j0 = 1;
         sk.nj = D::LS_N - 1;
-        {
-        if (has_ext(b))
-          timed_launch<StageKernelArgs<D>, trial_body<D, true>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
-        else
-          timed_launch<StageKernelArgs<D>, trial_body<D, false>, 64, TRIAL_MINW>(KID_SELECT, slots * (H + 1), sk, true);
-      }
+        launch_trial(b, sk, KID_SELECT, true);
         timed_launch<SolverArgs<D>, select_body<D>, 64>(KID_SELECT, nb, solver_args(b, 1, D::LS_N - 1));
         sa.mode = 0;
         timed_launch<SolverArgs<D>, apply_body<D>, 64>(KID_SELECT, slots, sa, true);
@@ -1031,6 +1080,7 @@ namespace smpc
       adv(s.xs_b, BRs * D::NX); adv(s.us_b, BRs * D::NU); adv(s.vs_b, BRs * D::NC); adv(s.lams_b, BRs * D::NDX);
       adv(s.dxs, (Hs + 1) * D::NDX); adv(s.dus, Hs * D::NU); adv(s.dvs, Hs * D::NC); adv(s.dlams, Hs * D::NDX);
       adv(s.foot_ref, Hs * D::NF * 3); adv(s.ftraj, (size_t)D::NF * 6); adv(s.vbase, 6); adv(s.vref, BRs * 6);
+      s.ev_inst0 = b.ev_inst0 + i0;
       adv(s.lq, Hs * D::LQ_STRIDE); adv(s.gains, Hs * (size_t)std::max((int)D::G_STRIDE, (int)GainsK<D>::STRIDE));
       adv(s.QN, (size_t)D::NDX * D::NDX); adv(s.qN, D::NDX);
       adv(s.parts0, (Hs + 1) * 4); adv(s.partsT, (size_t)D::LS_N * (Hs + 1) * 2); adv(s.scal, SC_N);

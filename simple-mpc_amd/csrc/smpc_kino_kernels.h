@@ -114,103 +114,19 @@ namespace smpc
       deriv_one<D, EXT>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t);
   }
 
+  // ---- terminal node of the derivative pass: Q_N, q_N (+ the folded terminal constraint).  The scratch holds the derivative columns,
+  //      Jl, Wrx, Whg, red[0] of the terminal evaluation ----
   template <class D, bool EXT>
-  SMPC_DEV void deriv_one(const StageKernelArgs<D> & ka, int inst, int t)
+  SMPC_DEV void deriv_terminal_node(const StageKernelArgs<D> & ka, KinoScratch<D, true> & sc, int inst, int t, double preg, double * parts)
   {
-    typedef KinoScratch<D, true> KinoScratchT;
     constexpr int NT = 64;
-    constexpr int NV = D::NV, NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF, NA = D::NA;
+    constexpr int NV = D::NV, NDX = D::NDX, NF = D::NF;
     const Buffers<D> & b = ka.b;
-    const int H = b.H, R = b.R;
-    const bool term = t == H;
-    const DevModel<D> & mg = *b.model; // global: large weights only
-    SMPC_LDS(KinoScratchT, scs, 1);
-    KinoScratchT & sc = scs[0];
-    const DevModelSmall<D> & md = sc.ml; // LDS copy (filled in the load phase)
-    const int st = ring_slot(ka.head, t, R);
+    const int R = b.R;
+    const DevModel<D> & mg = *b.model;
+    const DevModelSmall<D> & md = sc.ml;
     const size_t ib = (size_t)inst * R;
-    const double * xg = b.xs + (ib + st) * NX;
-    const double * xn_g = b.xs + (ib + ring_slot(ka.head, term ? t : t + 1, R)) * NX;
     const int sprev = ring_slot(ka.head, t > 0 ? t - 1 : 0, R);
-    const double preg = b.scal[(size_t)inst * SC_N + SC_PREG];
-
-    StageIn<D> in;
-    in.md = &mg;
-    in.terminal = term;
-    in.mask = term ? 0u : b.stages[t].mask;
-    in.u_ref = term ? nullptr : b.stages[t].u_ref;
-    in.x_tgt = term ? mg.x_term : b.stages[t].x_tgt;
-    in.foot_ref = term ? nullptr : b.foot_ref + ((size_t)inst * H + t) * NF * 3;
-    in.C_rows = term ? nullptr : b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE + D::O_C + (size_t)NA * NDX;
-    long long tprev = SMPC_CLOCK();
-    in.prof = (b.dbg != nullptr && inst == 0 && t == 17 && ka.slots == 0) ? b.dbg : nullptr; // optional phase timers: one mid-horizon block
-    in.tprev = &tprev;
-
-    // block inputs that are consumed once, by the lane that loaded them, stay in registers: lambda_t (q of the knot) and
-    // x_{t+1} (committed to LDS only for the defect phase, into the then idle late block)
-    SMPC_PL(double, xn_r, NT);
-    SMPC_LANES(NT)
-    {
-      // all global loads of the block are issued back to back (index clamped, one wait), then committed to LDS
-      static_assert(NX <= NT && NU <= NT && NDX <= NT && NC <= NT, "one element per lane");
-      const double vx = xg[lane < NX ? lane : 0];
-      const double vu = b.us[(ib + st) * NU + (lane < NU ? lane : 0)];
-      const double vl = b.lams[(ib + st) * NDX + (lane < NDX ? lane : 0)];
-      const double vn = b.vs[(ib + st) * NC + (lane < NC ? lane : 0)];
-      // state_cost target: shared pose part, per-instance base-velocity part (address select, one load)
-      const double vxt = *((!term && lane >= D::NQ && lane < D::NQ + 6) ? b.vref + (ib + st) * 6 + (lane - D::NQ) : in.x_tgt + (lane < NX ? lane : 0));
-      const double vur = term ? 0.0 : in.u_ref[lane < NU ? lane : 0];
-      const double vfr = term ? 0.0 : in.foot_ref[lane < NF * 3 ? lane : 0];
-      static_assert(NX + 9 <= NT && D::NV >= 9, "w_frame rides in the spare lanes of the x_{t+1} register");
-      const double vxn = *(lane < NX ? xn_g + lane : mg.w_frame + (lane < NX + 9 ? lane - NX : 0));
-      lanes_load_model<D, NT>(sc, &mg, lane);
-      if (lane < NX)
-      {
-        sc.x[lane] = vx;
-        sc.in_x_tgt[lane] = vxt;
-      }
-      SMPC_PLV(xn_r) = vxn;
-      if (lane < NU)
-        sc.in_u_ref[lane] = vur;
-      if (lane < NF * 3)
-        sc.in_foot_ref[lane] = vfr;
-      if (lane < NU)
-        sc.u[lane] = term ? 0.0 : vu;
-      if (lane < NDX)
-      {
-        sc.lam_next[lane] = term ? 0.0 : vl;
-      }
-      if (lane < NC)
-        sc.nu[lane] = term ? 0.0 : vn;
-    }
-    SMPC_LANES_END_WAVE
-
-    if (in.prof) prof_tick(in.prof, 15, tprev);
-    kino_tree_phases<D, true>(sc, in);
-
-    if (!term)
-    {
-      static_assert(KinoScratchEval<D>::LATE_DOUBLES >= NX, "x_{t+1} is staged at the start of the late block");
-      SMPC_LANES(NT)
-      {
-        if (lane < NX)
-          sc.cval[lane] = SMPC_PLV(xn_r); // (cval | Wrx ...: idle until the cost phase)
-        else if (lane < NX + 9)
-          sc.wframe_()[lane - NX] = SMPC_PLV(xn_r); // w_frame into the (now dead) acceleration vector
-      }
-      SMPC_LANES_END_WAVE
-      SMPC_LANES(NT)
-      lanes_difference<D>(sc.cval, sc.xnext, sc.e, lane, 61);
-      SMPC_LANES_END_WAVE
-    }
-    if (in.prof) prof_tick(in.prof, 29, tprev);
-    kino_cost_constraints<D, true>(sc, in);
-    if (in.prof) prof_tick(in.prof, 30, tprev);
-
-    double * parts = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
-
-    if (term)
-    {
       // ---- terminal node: Q_N = Lxx + preg I, q_N = lx - lambda_H ----
       SMPC_LANES(NT)
       {
@@ -340,21 +256,22 @@ namespace smpc
         parts[3] = dual;
       }
       SMPC_LANES_END_WAVE
-      return;
-    }
+  }
 
-    // ---- multipliers, active set ----
-    kino_multipliers<D, true>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
-    const bool cones = EXT && b.es != nullptr;
-    if (cones)
-      kino_cone_rows<D, true>(sc, in, b.cone_mu2, b.es + (ib + st) * 2 * NF, (const double *)nullptr, 0.0, b.es_e + (ib + st) * 2 * NF,
-                              b.ek + ((size_t)inst * H + t) * 12 * NF);
-    const unsigned land = (EXT && b.ls != nullptr) ? (b.stages[t].land & in.mask) : 0u;
-    if (EXT && b.ls != nullptr)
-      kino_land_rows<D, true>(sc, in, land, b.land_z, b.ls + (ib + st) * NF, (const double *)nullptr, 0.0, b.ls_e + (ib + st) * NF,
-                              b.lk + ((size_t)inst * H + t) * NF * (NV + 2));
-    if (in.prof) prof_tick(in.prof, 31, tprev);
-
+  // ---- LQ knot of a running stage from the scratch of the derivative pass: [A | B], gradients, Q, S, R on the matrix cores, C, d.
+  //      The scratch holds the derivative columns, ab_d*, the SE(3) Jacobians, weighted residuals, multiplier estimates, red[0..2] ----
+  template <class D, bool EXT>
+  SMPC_DEV void deriv_stage_knot(const StageKernelArgs<D> & ka, KinoScratch<D, true> & sc, const StageIn<D> & in, int inst, int t, double preg,
+                                 double * parts, bool cones, unsigned land, long long & tprev)
+  {
+    constexpr int NT = 64;
+    constexpr int NV = D::NV, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF, NA = D::NA;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H, R = b.R;
+    const DevModel<D> & mg = *b.model;
+    const DevModelSmall<D> & md = sc.ml;
+    const size_t ib = (size_t)inst * R;
+    const int sprev = ring_slot(ka.head, t > 0 ? t - 1 : 0, R);
     double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
     const double dt = md.dt;
     const double mu = md.mu;
@@ -758,6 +675,122 @@ namespace smpc
       parts[3] = dual;
     }
     SMPC_LANES_END_WAVE
+  }
+
+  template <class D, bool EXT>
+  SMPC_DEV void deriv_one(const StageKernelArgs<D> & ka, int inst, int t)
+  {
+    typedef KinoScratch<D, true> KinoScratchT;
+    constexpr int NT = 64;
+    constexpr int NV = D::NV, NX = D::NX, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF, NA = D::NA;
+    const Buffers<D> & b = ka.b;
+    const int H = b.H, R = b.R;
+    const bool term = t == H;
+    const DevModel<D> & mg = *b.model; // global: large weights only
+    SMPC_LDS(KinoScratchT, scs, 1);
+    KinoScratchT & sc = scs[0];
+    const DevModelSmall<D> & md = sc.ml; // LDS copy (filled in the load phase)
+    const int st = ring_slot(ka.head, t, R);
+    const size_t ib = (size_t)inst * R;
+    const double * xg = b.xs + (ib + st) * NX;
+    const double * xn_g = b.xs + (ib + ring_slot(ka.head, term ? t : t + 1, R)) * NX;
+    const int sprev = ring_slot(ka.head, t > 0 ? t - 1 : 0, R);
+    const double preg = b.scal[(size_t)inst * SC_N + SC_PREG];
+
+    StageIn<D> in;
+    in.md = &mg;
+    in.terminal = term;
+    in.mask = term ? 0u : b.stages[t].mask;
+    in.u_ref = term ? nullptr : b.stages[t].u_ref;
+    in.x_tgt = term ? mg.x_term : b.stages[t].x_tgt;
+    in.foot_ref = term ? nullptr : b.foot_ref + ((size_t)inst * H + t) * NF * 3;
+    in.C_rows = term ? nullptr : b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE + D::O_C + (size_t)NA * NDX;
+    long long tprev = SMPC_CLOCK();
+    in.prof = (b.dbg != nullptr && inst == 0 && t == 17 && ka.slots == 0) ? b.dbg : nullptr; // optional phase timers: one mid-horizon block
+    in.tprev = &tprev;
+
+    // block inputs that are consumed once, by the lane that loaded them, stay in registers: lambda_t (q of the knot) and
+    // x_{t+1} (committed to LDS only for the defect phase, into the then idle late block)
+    SMPC_PL(double, xn_r, NT);
+    SMPC_LANES(NT)
+    {
+      // all global loads of the block are issued back to back (index clamped, one wait), then committed to LDS
+      static_assert(NX <= NT && NU <= NT && NDX <= NT && NC <= NT, "one element per lane");
+      const double vx = xg[lane < NX ? lane : 0];
+      const double vu = b.us[(ib + st) * NU + (lane < NU ? lane : 0)];
+      const double vl = b.lams[(ib + st) * NDX + (lane < NDX ? lane : 0)];
+      const double vn = b.vs[(ib + st) * NC + (lane < NC ? lane : 0)];
+      // state_cost target: shared pose part, per-instance base-velocity part (address select, one load)
+      const double vxt = *((!term && lane >= D::NQ && lane < D::NQ + 6) ? b.vref + (ib + st) * 6 + (lane - D::NQ) : in.x_tgt + (lane < NX ? lane : 0));
+      const double vur = term ? 0.0 : in.u_ref[lane < NU ? lane : 0];
+      const double vfr = term ? 0.0 : in.foot_ref[lane < NF * 3 ? lane : 0];
+      static_assert(NX + 9 <= NT && D::NV >= 9, "w_frame rides in the spare lanes of the x_{t+1} register");
+      const double vxn = *(lane < NX ? xn_g + lane : mg.w_frame + (lane < NX + 9 ? lane - NX : 0));
+      lanes_load_model<D, NT>(sc, &mg, lane);
+      if (lane < NX)
+      {
+        sc.x[lane] = vx;
+        sc.in_x_tgt[lane] = vxt;
+      }
+      SMPC_PLV(xn_r) = vxn;
+      if (lane < NU)
+        sc.in_u_ref[lane] = vur;
+      if (lane < NF * 3)
+        sc.in_foot_ref[lane] = vfr;
+      if (lane < NU)
+        sc.u[lane] = term ? 0.0 : vu;
+      if (lane < NDX)
+      {
+        sc.lam_next[lane] = term ? 0.0 : vl;
+      }
+      if (lane < NC)
+        sc.nu[lane] = term ? 0.0 : vn;
+    }
+    SMPC_LANES_END_WAVE
+
+    if (in.prof) prof_tick(in.prof, 15, tprev);
+    kino_tree_phases<D, true>(sc, in);
+
+    if (!term)
+    {
+      static_assert(KinoScratchEval<D>::LATE_DOUBLES >= NX, "x_{t+1} is staged at the start of the late block");
+      SMPC_LANES(NT)
+      {
+        if (lane < NX)
+          sc.cval[lane] = SMPC_PLV(xn_r); // (cval | Wrx ...: idle until the cost phase)
+        else if (lane < NX + 9)
+          sc.wframe_()[lane - NX] = SMPC_PLV(xn_r); // w_frame into the (now dead) acceleration vector
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      lanes_difference<D>(sc.cval, sc.xnext, sc.e, lane, 61);
+      SMPC_LANES_END_WAVE
+    }
+    if (in.prof) prof_tick(in.prof, 29, tprev);
+    kino_cost_constraints<D, true>(sc, in);
+    if (in.prof) prof_tick(in.prof, 30, tprev);
+
+    double * parts = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
+
+    if (term)
+    {
+      deriv_terminal_node<D, EXT>(ka, sc, inst, t, preg, parts);
+      return;
+    }
+
+    // ---- multipliers, active set ----
+    kino_multipliers<D, true>(sc, in, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+    const bool cones = EXT && b.es != nullptr;
+    if (cones)
+      kino_cone_rows<D, true>(sc, in, b.cone_mu2, b.es + (ib + st) * 2 * NF, (const double *)nullptr, 0.0, b.es_e + (ib + st) * 2 * NF,
+                              b.ek + ((size_t)inst * H + t) * 12 * NF);
+    const unsigned land = (EXT && b.ls != nullptr) ? (b.stages[t].land & in.mask) : 0u;
+    if (EXT && b.ls != nullptr)
+      kino_land_rows<D, true>(sc, in, land, b.land_z, b.ls + (ib + st) * NF, (const double *)nullptr, 0.0, b.ls_e + (ib + st) * NF,
+                              b.lk + ((size_t)inst * H + t) * NF * (NV + 2));
+    if (in.prof) prof_tick(in.prof, 31, tprev);
+
+    deriv_stage_knot<D, EXT>(ka, sc, in, inst, t, preg, parts, cones, land, tprev);
   }
 
   // =============================================================================================

@@ -246,6 +246,209 @@ namespace smpc
     }
   }
 
+  // Derivative columns of the momentum, its rate and the foot points (lane = dof), then the base-acceleration derivatives
+  // Agbi * [dtgt - dhd_dq | -dhd_dv | G_f | -Ag_j] (lane = column).  Inputs in the scratch: S, vel, acc and Fc for the solved
+  // accelerations, Ic, hc, the composite velocity-product matrices Bm, com, footp, oR of the foot joints, Ag, Agbi, u, nu.
+  template <class D>
+  SMPC_DEV void kino_deriv_columns(KinoScratch<D, true> & sc, const StageIn<D> & in, double * Bm)
+  {
+    constexpr int NT = 64;
+    constexpr int NV = D::NV, NF = D::NF;
+    const DevModelSmall<D> & md = sc.ml;
+    // ---- derivative columns: lane k < NV ----
+    SMPC_LANES(NT)
+    if (lane < NV)
+    {
+      const int k = lane;
+      const int i = k < 6 ? 0 : k - 5;
+      const int lam = md.parent[i];
+      const SV s = ldsv(&sc.S[k * 6]);
+      const SI Ici = ldsi(&sc.Ic[i * 10]);
+      const SV vi = ldsv(&sc.vel[i * 6]);
+      SV d = sv0(), Ak = sv0();
+      if (lam >= 0)
+      {
+        const SV vl = ldsv(&sc.vel[lam * 6]);
+        d = crm(vl, s);
+        Ak = crm(ldsv(&sc.acc[lam * 6]), s) + crm(vl, d);
+      }
+      // sum over subtree bodies of  v_l x* (I_l y) - I_l (v_l x y)  for y = S_k and y = d_k: composite B_i y
+      SV BS, Bd;
+      {
+        const double * Bc = &Bm[i * 36];
+        const double sv[6] = {s.l.x, s.l.y, s.l.z, s.a.x, s.a.y, s.a.z};
+        const double dv[6] = {d.l.x, d.l.y, d.l.z, d.a.x, d.a.y, d.a.z};
+        double o1[6], o2[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+        {
+          double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+          for (int m = 0; m < 6; m++)
+          {
+            const double bv = Bc[r * 6 + m];
+            a1 += bv * sv[m];
+            a2 += bv * dv[m];
+          }
+          o1[r] = a1;
+          o2[r] = a2;
+        }
+        BS = SV{mk3(o1[0], o1[1], o1[2]), mk3(o1[3], o1[4], o1[5])};
+        Bd = SV{mk3(o2[0], o2[1], o2[2]), mk3(o2[3], o2[4], o2[5])};
+      }
+      const SV hci = ldsv(&sc.hc[i * 6]);
+      BS = BS + crf(s, hci);
+      Bd = Bd + crf(d, hci);
+      const SV dh = crf(s, hci) + Ici * d;
+      const SV dF = crf(s, ldsv(&sc.Fc[i * 6])) + Ici * Ak + Bd;
+      const SV dFv = BS + Ici * (crm(vi, s) + d);
+      const V3 com = ld3(sc.com);
+      const double im = 1.0 / md.total_mass;
+      const V3 jc = im * (Ici * s).l;
+      const SV h0 = ldsv(&sc.hc[0]);
+      const SV F0 = ldsv(&sc.Fc[0]);
+      const V3 dha = dh.a - cross(com, dh.l) - cross(jc, h0.l);
+      const V3 dFa = dF.a - cross(com, dF.l) - cross(jc, F0.l);
+      const V3 dFva = dFv.a - cross(com, dFv.l);
+      sc.dh_dq[0 * NV + k] = dh.l.x;
+      sc.dh_dq[1 * NV + k] = dh.l.y;
+      sc.dh_dq[2 * NV + k] = dh.l.z;
+      sc.dh_dq[3 * NV + k] = dha.x;
+      sc.dh_dq[4 * NV + k] = dha.y;
+      sc.dh_dq[5 * NV + k] = dha.z;
+      sc.dhd_dq[0 * NV + k] = dF.l.x;
+      sc.dhd_dq[1 * NV + k] = dF.l.y;
+      sc.dhd_dq[2 * NV + k] = dF.l.z;
+      sc.dhd_dq[3 * NV + k] = dFa.x;
+      sc.dhd_dq[4 * NV + k] = dFa.y;
+      sc.dhd_dq[5 * NV + k] = dFa.z;
+      sc.dhd_dv[0 * NV + k] = dFv.l.x;
+      sc.dhd_dv[1 * NV + k] = dFv.l.y;
+      sc.dhd_dv[2 * NV + k] = dFv.l.z;
+      sc.dhd_dv[3 * NV + k] = dFva.x;
+      sc.dhd_dv[4 * NV + k] = dFva.y;
+      sc.dhd_dv[5 * NV + k] = dFva.z;
+      // feet: linear Jacobian columns, d hdot_tgt / dq, and the local-velocity constraint Jacobian columns: these
+      // go straight into the contact rows of the knot's C block (zero rows for feet in the air) and into C_x^T nu
+      V3 dt_ang = mk3(0, 0, 0);
+      double cnq = 0.0, cnv = 0.0;
+      for (int f = 0; f < NF; f++)
+      {
+        const int lj = md.foot_joint[f];
+        const bool anc = (md.anc[lj] >> i) & 1u;
+        const bool contact = (in.mask >> f) & 1u;
+        const V3 pf = ld3(&sc.footp[f * 3]);
+        V3 jf = mk3(0, 0, 0), cq = mk3(0, 0, 0), cv = mk3(0, 0, 0);
+        if (anc)
+        {
+          jf = s.l + cross(s.a, pf);
+          if (contact)
+          {
+            const M3 Rl = ldm3(&sc.oR[lj * 9]);
+            cv = tmul(Rl, jf);
+            if (lam >= 0)
+              cq = tmul(Rl, d.l + cross(d.a, pf));
+          }
+        }
+        sc.Jfoot[(f * 3 + 0) * NV + k] = jf.x;
+        sc.Jfoot[(f * 3 + 1) * NV + k] = jf.y;
+        sc.Jfoot[(f * 3 + 2) * NV + k] = jf.z;
+        if (in.C_rows != nullptr)
+        {
+          double * cr = in.C_rows + (size_t)(3 * f) * D::NDX;
+          cr[0 * D::NDX + k] = cq.x;
+          cr[1 * D::NDX + k] = cq.y;
+          cr[2 * D::NDX + k] = cq.z;
+          cr[0 * D::NDX + NV + k] = cv.x;
+          cr[1 * D::NDX + NV + k] = cv.y;
+          cr[2 * D::NDX + NV + k] = cv.z;
+        }
+        const double * nuf = &sc.nu[D::NA + 3 * f];
+        cnq += cq.x * nuf[0] + cq.y * nuf[1] + cq.z * nuf[2];
+        cnv += cv.x * nuf[0] + cv.y * nuf[1] + cv.z * nuf[2];
+        if (contact)
+          dt_ang = dt_ang + cross(jf - jc, ld3(&sc.u[3 * f]));
+      }
+      sc.cn[k] = cnq;
+      sc.cn[NV + k] = cnv;
+      sc.dtgt[0 * NV + k] = dt_ang.x;
+      sc.dtgt[1 * NV + k] = dt_ang.y;
+      sc.dtgt[2 * NV + k] = dt_ang.z;
+    if (in.prof) prof_tick(in.prof, 27, *in.tprev);
+    }
+    SMPC_LANES_END_WAVE
+    // ---- base-acceleration derivatives: Agbi * [dtgt - dhd_dq | -dhd_dv | G_f | -Ag_j]; lane = column ----
+    SMPC_LANES(NT)
+    {
+      constexpr int NCOL = 2 * NV + D::NU;
+      static_assert(NCOL <= NT - 2, "one lane per column, two spare lanes");
+      if (lane < NCOL)
+      {
+        const int c = lane;
+        double rhs[6] = {0, 0, 0, 0, 0, 0};
+        double * dst;
+        int ld;
+        if (c < NV)
+        {
+#pragma unroll
+          for (int m = 0; m < 6; m++)
+            rhs[m] = (m >= 3 ? sc.dtgt[(m - 3) * NV + c] : 0.0) - sc.dhd_dq[m * NV + c];
+          dst = &sc.ab_dq()[c];
+          ld = NV;
+        }
+        else if (c < 2 * NV)
+        {
+          const int k = c - NV;
+#pragma unroll
+          for (int m = 0; m < 6; m++)
+            rhs[m] = -sc.dhd_dv[m * NV + k];
+          dst = &sc.ab_dv()[k];
+          ld = NV;
+        }
+        else
+        {
+          const int k = c - 2 * NV;
+          if (k < 3 * NF)
+          {
+            const int f = k / 3, jj = k % 3;
+            if ((in.mask >> f) & 1u)
+            {
+              const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
+              const V3 e = mk3(jj == 0, jj == 1, jj == 2);
+              const V3 xc = cross(rr, e); // column jj of [rr]x
+              rhs[0] = e.x;
+              rhs[1] = e.y;
+              rhs[2] = e.z;
+              rhs[3] = xc.x;
+              rhs[4] = xc.y;
+              rhs[5] = xc.z;
+            }
+          }
+          else
+          {
+            const int kk = k - 3 * NF + 6;
+#pragma unroll
+            for (int m = 0; m < 6; m++)
+              rhs[m] = -sc.Ag[m * NV + kk];
+          }
+          dst = &sc.ab_du()[k];
+          ld = D::NU;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+        {
+          double acc = 0.0;
+#pragma unroll
+          for (int m = 0; m < 6; m++)
+            acc += sc.Agbi[r * 6 + m] * rhs[m];
+          dst[r * ld] = acc;
+        }
+      }
+    }
+    SMPC_LANES_END_WAVE
+    if (in.prof) prof_tick(in.prof, 28, *in.tprev);
+  }
+
   // ---------------------------------------------------------------------------------------------
   // Tree + dynamics phases.  On return (all lanes synchronised) the scratch holds: kinematics,
   // composite quantities, Ag, hg, b0, hd, Agbi, a, xnext.  If DERIV, also acc/Fc for the solved
@@ -614,198 +817,7 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     if (in.prof) prof_tick(in.prof, 26, *in.tprev);
-    // ---- derivative columns: lane k < NV ----
-    SMPC_LANES(NT)
-    if (lane < NV)
-    {
-      const int k = lane;
-      const int i = k < 6 ? 0 : k - 5;
-      const int lam = md.parent[i];
-      const SV s = ldsv(&sc.S[k * 6]);
-      const SI Ici = ldsi(&sc.Ic[i * 10]);
-      const SV vi = ldsv(&sc.vel[i * 6]);
-      SV d = sv0(), Ak = sv0();
-      if (lam >= 0)
-      {
-        const SV vl = ldsv(&sc.vel[lam * 6]);
-        d = crm(vl, s);
-        Ak = crm(ldsv(&sc.acc[lam * 6]), s) + crm(vl, d);
-      }
-      // sum over subtree bodies of  v_l x* (I_l y) - I_l (v_l x y)  for y = S_k and y = d_k: composite B_i y
-      SV BS, Bd;
-      {
-        const double * Bc = &Bm[i * 36];
-        const double sv[6] = {s.l.x, s.l.y, s.l.z, s.a.x, s.a.y, s.a.z};
-        const double dv[6] = {d.l.x, d.l.y, d.l.z, d.a.x, d.a.y, d.a.z};
-        double o1[6], o2[6];
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-        {
-          double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-          for (int m = 0; m < 6; m++)
-          {
-            const double bv = Bc[r * 6 + m];
-            a1 += bv * sv[m];
-            a2 += bv * dv[m];
-          }
-          o1[r] = a1;
-          o2[r] = a2;
-        }
-        BS = SV{mk3(o1[0], o1[1], o1[2]), mk3(o1[3], o1[4], o1[5])};
-        Bd = SV{mk3(o2[0], o2[1], o2[2]), mk3(o2[3], o2[4], o2[5])};
-      }
-      const SV hci = ldsv(&sc.hc[i * 6]);
-      BS = BS + crf(s, hci);
-      Bd = Bd + crf(d, hci);
-      const SV dh = crf(s, hci) + Ici * d;
-      const SV dF = crf(s, ldsv(&sc.Fc[i * 6])) + Ici * Ak + Bd;
-      const SV dFv = BS + Ici * (crm(vi, s) + d);
-      const V3 com = ld3(sc.com);
-      const double im = 1.0 / md.total_mass;
-      const V3 jc = im * (Ici * s).l;
-      const SV h0 = ldsv(&sc.hc[0]);
-      const SV F0 = ldsv(&sc.Fc[0]);
-      const V3 dha = dh.a - cross(com, dh.l) - cross(jc, h0.l);
-      const V3 dFa = dF.a - cross(com, dF.l) - cross(jc, F0.l);
-      const V3 dFva = dFv.a - cross(com, dFv.l);
-      sc.dh_dq[0 * NV + k] = dh.l.x;
-      sc.dh_dq[1 * NV + k] = dh.l.y;
-      sc.dh_dq[2 * NV + k] = dh.l.z;
-      sc.dh_dq[3 * NV + k] = dha.x;
-      sc.dh_dq[4 * NV + k] = dha.y;
-      sc.dh_dq[5 * NV + k] = dha.z;
-      sc.dhd_dq[0 * NV + k] = dF.l.x;
-      sc.dhd_dq[1 * NV + k] = dF.l.y;
-      sc.dhd_dq[2 * NV + k] = dF.l.z;
-      sc.dhd_dq[3 * NV + k] = dFa.x;
-      sc.dhd_dq[4 * NV + k] = dFa.y;
-      sc.dhd_dq[5 * NV + k] = dFa.z;
-      sc.dhd_dv[0 * NV + k] = dFv.l.x;
-      sc.dhd_dv[1 * NV + k] = dFv.l.y;
-      sc.dhd_dv[2 * NV + k] = dFv.l.z;
-      sc.dhd_dv[3 * NV + k] = dFva.x;
-      sc.dhd_dv[4 * NV + k] = dFva.y;
-      sc.dhd_dv[5 * NV + k] = dFva.z;
-      // feet: linear Jacobian columns, d hdot_tgt / dq, and the local-velocity constraint Jacobian columns: these
-      // go straight into the contact rows of the knot's C block (zero rows for feet in the air) and into C_x^T nu
-      V3 dt_ang = mk3(0, 0, 0);
-      double cnq = 0.0, cnv = 0.0;
-      for (int f = 0; f < NF; f++)
-      {
-        const int lj = md.foot_joint[f];
-        const bool anc = (md.anc[lj] >> i) & 1u;
-        const bool contact = (in.mask >> f) & 1u;
-        const V3 pf = ld3(&sc.footp[f * 3]);
-        V3 jf = mk3(0, 0, 0), cq = mk3(0, 0, 0), cv = mk3(0, 0, 0);
-        if (anc)
-        {
-          jf = s.l + cross(s.a, pf);
-          if (contact)
-          {
-            const M3 Rl = ldm3(&sc.oR[lj * 9]);
-            cv = tmul(Rl, jf);
-            if (lam >= 0)
-              cq = tmul(Rl, d.l + cross(d.a, pf));
-          }
-        }
-        sc.Jfoot[(f * 3 + 0) * NV + k] = jf.x;
-        sc.Jfoot[(f * 3 + 1) * NV + k] = jf.y;
-        sc.Jfoot[(f * 3 + 2) * NV + k] = jf.z;
-        if (in.C_rows != nullptr)
-        {
-          double * cr = in.C_rows + (size_t)(3 * f) * D::NDX;
-          cr[0 * D::NDX + k] = cq.x;
-          cr[1 * D::NDX + k] = cq.y;
-          cr[2 * D::NDX + k] = cq.z;
-          cr[0 * D::NDX + NV + k] = cv.x;
-          cr[1 * D::NDX + NV + k] = cv.y;
-          cr[2 * D::NDX + NV + k] = cv.z;
-        }
-        const double * nuf = &sc.nu[D::NA + 3 * f];
-        cnq += cq.x * nuf[0] + cq.y * nuf[1] + cq.z * nuf[2];
-        cnv += cv.x * nuf[0] + cv.y * nuf[1] + cv.z * nuf[2];
-        if (contact)
-          dt_ang = dt_ang + cross(jf - jc, ld3(&sc.u[3 * f]));
-      }
-      sc.cn[k] = cnq;
-      sc.cn[NV + k] = cnv;
-      sc.dtgt[0 * NV + k] = dt_ang.x;
-      sc.dtgt[1 * NV + k] = dt_ang.y;
-      sc.dtgt[2 * NV + k] = dt_ang.z;
-    if (in.prof) prof_tick(in.prof, 27, *in.tprev);
-    }
-    SMPC_LANES_END_WAVE
-    // ---- base-acceleration derivatives: Agbi * [dtgt - dhd_dq | -dhd_dv | G_f | -Ag_j]; lane = column ----
-    SMPC_LANES(NT)
-    {
-      constexpr int NCOL = 2 * NV + D::NU;
-      static_assert(NCOL <= NT - 2, "one lane per column, two spare lanes");
-      if (lane < NCOL)
-      {
-        const int c = lane;
-        double rhs[6] = {0, 0, 0, 0, 0, 0};
-        double * dst;
-        int ld;
-        if (c < NV)
-        {
-#pragma unroll
-          for (int m = 0; m < 6; m++)
-            rhs[m] = (m >= 3 ? sc.dtgt[(m - 3) * NV + c] : 0.0) - sc.dhd_dq[m * NV + c];
-          dst = &sc.ab_dq()[c];
-          ld = NV;
-        }
-        else if (c < 2 * NV)
-        {
-          const int k = c - NV;
-#pragma unroll
-          for (int m = 0; m < 6; m++)
-            rhs[m] = -sc.dhd_dv[m * NV + k];
-          dst = &sc.ab_dv()[k];
-          ld = NV;
-        }
-        else
-        {
-          const int k = c - 2 * NV;
-          if (k < 3 * NF)
-          {
-            const int f = k / 3, jj = k % 3;
-            if ((in.mask >> f) & 1u)
-            {
-              const V3 rr = ld3(&sc.footp[f * 3]) - ld3(sc.com);
-              const V3 e = mk3(jj == 0, jj == 1, jj == 2);
-              const V3 xc = cross(rr, e); // column jj of [rr]x
-              rhs[0] = e.x;
-              rhs[1] = e.y;
-              rhs[2] = e.z;
-              rhs[3] = xc.x;
-              rhs[4] = xc.y;
-              rhs[5] = xc.z;
-            }
-          }
-          else
-          {
-            const int kk = k - 3 * NF + 6;
-#pragma unroll
-            for (int m = 0; m < 6; m++)
-              rhs[m] = -sc.Ag[m * NV + kk];
-          }
-          dst = &sc.ab_du()[k];
-          ld = D::NU;
-        }
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-        {
-          double acc = 0.0;
-#pragma unroll
-          for (int m = 0; m < 6; m++)
-            acc += sc.Agbi[r * 6 + m] * rhs[m];
-          dst[r * ld] = acc;
-        }
-      }
-    }
-    SMPC_LANES_END_WAVE
-    if (in.prof) prof_tick(in.prof, 28, *in.tprev);
+    kino_deriv_columns<D>(sc, in, Bm);
     } // if constexpr (DERIV)
   }
 

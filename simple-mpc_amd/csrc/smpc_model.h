@@ -95,7 +95,13 @@ namespace smpc
     double w_uT[D::NU * D::NU];
     // terminal state_cost target (model reference state)
     double x_term[D::NX];
+    // lane-per-problem evaluation (smpc_kino_lane.h): the kinematic state of a joint's parent is either that of the joint before it
+    // (par_slot < 0) or one of LANE_SLOTS saved branch joints (par_slot = slot the parent was saved into: save_slot of that joint)
+    int par_slot[D::NJ];
+    int save_slot[D::NJ];
+    int lane_slots; // saved branch joints the tree needs (the lane kernel is instantiated for 1 and 2; more: 0 = not available)
   };
+  constexpr int LANE_SLOTS = 2;
 
   // stage descriptors shared by all instances (phase-aligned batch), uploaded per control step
   template <class D>
@@ -125,6 +131,10 @@ namespace smpc
     double *vbase = nullptr, *vref = nullptr;
     // LQ + gains
     double *lq = nullptr, *gains = nullptr;
+    // lane-per-problem stage evaluation (smpc_kino_lane.h): one block per (instance, stage), [B][H+1][EvLayout::STRIDE]; the
+    // working set of the evaluating lane and the hand-over to the derivative kernel.  nullptr: the handle does not use it.
+    double * ev = nullptr;
+    int ev_inst0 = 0; // first instance of this view of the batch (the blocks are tiled over the whole batch)
     double *QN = nullptr, *qN = nullptr; // [B][NDX*NDX], [B][NDX]
     // terminal equality constraint com + tau vcom = dcm_ref (DCMPositionResidual; createProblem(..., terminal_constraint = true),
     // reference src/ocp-handler.cpp:133-136, src/kinodynamics.cpp:366-388).  CN == nullptr: the problem has none.

@@ -33,6 +33,7 @@
 #define SMPC_PL(type, name, NT) type name[NT]
 #define SMPC_PLA(type, name, NT, n) type name[NT][n]
 #define SMPC_PLV(name) name[lane]
+#define SMPC_PL_REF(type, name, NT) type(&name)[NT]
 #define SMPC_XLANE(name, src) name[src]
 #define SMPC_XLANE_A(name, idx, src) name[src][idx]
 #define SMPC_SCHED_FENCE() ((void)0)
