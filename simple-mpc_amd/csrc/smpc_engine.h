@@ -16,7 +16,7 @@
 #define SMPC_LANE_MINW 1
 #endif
 #include "smpc_riccati_kino.h"
-#include "smpc_kino_lane.h"
+#include "smpc_kino_deriv2.h"
 #include "smpc_solver_kernels.h"
 #include "smpc_full_kernels.h"
 #include <algorithm>
@@ -366,6 +366,10 @@ namespace smpc
     // lane-per-problem stage evaluation (smpc_kino_lane.h) for problems without optional constraint blocks; SMPC_LANE_EVAL=0: the
     // wavefront-per-problem kernels throughout (A/B comparison)
     int lane_slots = 1;
+    // SMPC_LANE_DERIV=1: the derivative pass too starts from the lane-per-problem evaluation (lane_tree_body + deriv2_body).  Measured
+    // on MI355X: the kernels themselves are faster (0.25 + 3.1 ms against 4.34 ms per launch), but the per-joint hand-over
+    // (5 KB per problem, 1 GB per launch, written as 512-byte rows scattered over 580 MB) costs 1.8 ms of HBM time -- off by default
+    bool lane_deriv = std::getenv("SMPC_LANE_DERIV") && std::atoi(std::getenv("SMPC_LANE_DERIV")) != 0;
     bool lane_eval = !(std::getenv("SMPC_LANE_EVAL") && std::atoi(std::getenv("SMPC_LANE_EVAL")) == 0);
     double kernel_ms[KID_N] = {0};
     long kernel_calls[KID_N] = {0};
@@ -483,7 +487,7 @@ namespace smpc
       buf.lq = dalloc(BH * D::LQ_STRIDE);
       buf.gains = dalloc(BH * (size_t)std::max((int)D::G_STRIDE, (int)GainsK<D>::STRIDE));
       if (lane_eval && m.lane_slots > 0 && !ks.terminal_constraint && !ks.force_cone && !ks.land_cstr)
-        buf.ev = dalloc((((size_t)B * (H + 1) + EV_LS - 1) / EV_LS) * EV_LS * EvLayout<D>::STRIDE);
+        buf.ev = dalloc((((size_t)B * (H + 1) + EV_LS - 1) / EV_LS) * ev_tile_doubles<D>());
       buf.QN = dalloc((size_t)B * D::NDX * D::NDX);
       buf.qN = dalloc((size_t)B * D::NDX);
       buf.parts0 = dalloc((size_t)B * (H + 1) * 4);
@@ -657,7 +661,23 @@ namespace smpc
     {
       // list-mode launches (backtracking path, normally empty) are booked under "select" so that the per-kernel
       // averages of deriv / trial / apply stay those of full-batch launches
-      if (has_ext(b))
+      if (b.ev != nullptr && lane_deriv)
+      {
+        // lane-per-problem evaluation, then the wavefront-per-problem derivative kernel that starts from it
+        LaneKernelArgs<D> la;
+        la.b = b;
+        la.head = head;
+        la.j0 = la.nj = 0;
+        la.slots = slots;
+        la.deriv = 1;
+        const int n = slots > 0 ? slots : b.B, kid = slots > 0 ? KID_SELECT : KID_DERIV;
+        if (lane_slots == 1)
+          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, slots > 0);
+        else
+          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, slots > 0);
+        timed_launch<StageKernelArgs<D>, deriv2_body<D>, 64, 2>(kid, xcd_grid(n * (H + 1)), stage_args(b, slots), slots > 0);
+      }
+      else if (has_ext(b))
         timed_launch<StageKernelArgs<D>, deriv_body<D, true>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
       else
         timed_launch<StageKernelArgs<D>, deriv_body<D, false>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
@@ -679,7 +699,7 @@ namespace smpc
           timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, aux);
         else
           timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, aux);
-        timed_launch<StageKernelArgs<D>, trial_rows_body<D>, 64>(kid, n * (H + 1), sk, aux);
+        timed_launch<StageKernelArgs<D>, trial_rows_body<D>, 64>(kid, xcd_grid(n * (H + 1)), sk, aux);
       }
       else if (has_ext(b))
         timed_launch<StageKernelArgs<D>, trial_body<D, true>, 64, TRIAL_MINW>(kid, (sk.slots > 0 ? sk.slots : b.B) * (H + 1), sk, aux);
@@ -848,7 +868,8 @@ namespace smpc
       copy_centres(b1);
       std::vector<double> sc(SC_N);
       cold_trace.clear();
-      for (int it = 0; it < 100; it++)
+      const int cold_max = std::getenv("SMPC_COLD_MAX_ITERS") ? std::atoi(std::getenv("SMPC_COLD_MAX_ITERS")) : 100; // (diagnostics)
+      for (int it = 0; it < cold_max; it++)
       {
         run_iteration(b1);
         d2h(sc.data(), buf.scal, SC_N * sizeof(double), stream);

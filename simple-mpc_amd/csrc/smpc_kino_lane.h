@@ -74,12 +74,31 @@ namespace smpc
     double * p;
     SMPC_HD double & operator[](int i) const { return p[(size_t)i * EV_LS]; }
   };
+  // doubles from one tile to the next: the rows of a tile plus an odd number of 128-byte lines, so that the same field of different
+  // tiles (what the wavefronts of a launch write at about the same time) does not map to the same memory channels
+  template <class D>
+  SMPC_HD constexpr size_t ev_tile_doubles()
+  {
+    return (size_t)EvLayout<D>::STRIDE * EV_LS + 9 * 16;
+  }
   template <class D>
   SMPC_HD LaneBlk lane_block(const Buffers<D> & b, int inst, int t)
   {
     const size_t prob = (size_t)(b.ev_inst0 + inst) * (b.H + 1) + t;
-    return LaneBlk{b.ev + (prob / EV_LS) * EvLayout<D>::STRIDE * EV_LS + prob % EV_LS};
+    return LaneBlk{b.ev + (prob / EV_LS) * ev_tile_doubles<D>() + prob % EV_LS};
   }
+  // Block index -> problem index of the wavefront-per-problem kernels that READ the tiles (one field per lane, 512 bytes apart: a
+  // 64-byte sector holds the same field of 8 neighbouring problems).  The hardware deals consecutive workgroups round-robin to the 8
+  // XCDs, each with its own L2: with the identity map the 8 readers of a sector sit on 8 different L2s and every sector crosses the
+  // fabric 8 times.  Here XCD x takes tiles x, x + 8, ... and walks the 64 problems of a tile with consecutive workgroups, so a sector
+  // is fetched once and its other 7 readers hit in L2.  (n is rounded up to whole groups of 8 tiles by the launch; p >= n: idle block)
+  constexpr int EV_XCDS = 8;
+  SMPC_HD int xcd_problem(int block)
+  {
+    const int q = block / EV_XCDS, x = block % EV_XCDS;
+    return ((q / EV_LS) * EV_XCDS + x) * EV_LS + q % EV_LS;
+  }
+  SMPC_HD int xcd_grid(int n) { return ((n + EV_XCDS * EV_LS - 1) / (EV_XCDS * EV_LS)) * (EV_XCDS * EV_LS); }
   SMPC_HD void st3(LaneBlk b, int o, V3 v)
   {
     b[o] = v.x;
@@ -169,6 +188,16 @@ namespace smpc
     static constexpr int N = F_u + D::NU;
   };
 
+  // Model constants the tree pass reads joint by joint, copied into LDS once per block: the hand-over stores of joint j - 1 and the
+  // (scalar) loads of joint j's constants would otherwise be ordered through memory -- the compiler cannot know that the model table
+  // and the hand-over blocks never alias and waits for every outstanding store before each of those loads
+  template <class D>
+  struct LaneModel
+  {
+    double jpR[D::NJ][9], jpp[D::NJ][3], mass[D::NJ], com[D::NJ][3], inertia[D::NJ][6], foot_p[D::NF][3];
+    int jtype[D::NJ], par_slot[D::NJ], save_slot[D::NJ], foot_joint[D::NF];
+  };
+
   // =============================================================================================
   // lane_tree_body: lanes of a block share the stage t; lane <-> instance (full-batch launch) or entry of the compacted list of
   // undecided instances (slots > 0).  grid = (H + 1) * ceil(n / 64), n = B or slots.
@@ -193,6 +222,34 @@ namespace smpc
     const int stride = ka.slots > 0 ? ka.slots : b.B; // entries per sweep of the grid
     const double dt = mg.dt;
     SMPC_LDS(double, stg, ST::N * LANE_PAD);
+    SMPC_LDS(LaneModel<D>, lms, 1);
+    LaneModel<D> & lm = lms[0];
+    SMPC_LANES(NT)
+    {
+      for (int i = lane; i < NJ * 9; i += NT)
+        lm.jpR[i / 9][i % 9] = mg.jpR[i / 9][i % 9];
+      for (int i = lane; i < NJ * 6; i += NT)
+        lm.inertia[i / 6][i % 6] = mg.inertia[i / 6][i % 6];
+      for (int i = lane; i < NJ * 3; i += NT)
+      {
+        lm.jpp[i / 3][i % 3] = mg.jpp[i / 3][i % 3];
+        lm.com[i / 3][i % 3] = mg.com[i / 3][i % 3];
+      }
+      if (lane < NJ)
+      {
+        lm.mass[lane] = mg.mass[lane];
+        lm.jtype[lane] = mg.jtype[lane];
+        lm.par_slot[lane] = mg.par_slot[lane];
+        lm.save_slot[lane] = mg.save_slot[lane];
+      }
+      if (lane < NF * 3)
+        lm.foot_p[lane / 3][lane % 3] = mg.foot_p[lane / 3][lane % 3];
+      if (lane < NF)
+        lm.foot_joint[lane] = mg.foot_joint[lane];
+    }
+    SMPC_LANES_END_WAVE
+    const double total_mass = mg.total_mass;
+    const V3 gravity = ld3(mg.gravity);
     for (int base = g * NT; base < count; base += stride)
     {
       const int np = count - base < NT ? count - base : NT; // problems of this sweep
@@ -298,18 +355,18 @@ namespace smpc
               }
               else
               {
-                const int ps = mg.par_slot[j]; // (uniform: scalar branches)
+                const int ps = lm.par_slot[j]; // (uniform: scalar branches)
 #pragma unroll
                 for (int s = 0; s < NSLOT; s++)
                   if (ps == s)
                     cur = slot[s];
                 double sn_, cs_;
                 sincos(SG(ST::F_q + j - 1), &sn_, &cs_);
-                const int jt = mg.jtype[j];
+                const int jt = lm.jtype[j];
                 const M3 Rq = jt == 1 ? M3{1, 0, 0, 0, cs_, -sn_, 0, sn_, cs_}
                                       : (jt == 2 ? M3{cs_, 0, sn_, 0, 1, 0, -sn_, 0, cs_} : M3{cs_, -sn_, 0, sn_, cs_, 0, 0, 0, 1});
-                const M3 Rj = cur.R * (ldm3(mg.jpR[j]) * Rq);
-                const V3 pj = cur.p + cur.R * ld3(mg.jpp[j]);
+                const M3 Rj = cur.R * (ldm3(lm.jpR[j]) * Rq);
+                const V3 pj = cur.p + cur.R * ld3(lm.jpp[j]);
                 const V3 ax = m3_col(Rj, jt - 1);
                 const SV sk = SV{cross(pj, ax), ax};
                 const double qd = SG(ST::F_v + j + 5), aj = SG(ST::F_u + 3 * NF + j - 1);
@@ -322,7 +379,7 @@ namespace smpc
                   stsv(blk, L::O_S + (j + 5) * 6, sk);
               }
               {
-                const int ss = mg.save_slot[j];
+                const int ss = lm.save_slot[j];
 #pragma unroll
                 for (int s = 0; s < NSLOT; s++)
                   if (ss == s)
@@ -330,9 +387,9 @@ namespace smpc
               }
               // world inertia about the origin, momentum, net force
               {
-                const double m = mg.mass[j];
-                const V3 c = cur.R * ld3(mg.com[j]) + cur.p;
-                const double * il = mg.inertia[j];
+                const double m = lm.mass[j];
+                const V3 c = cur.R * ld3(lm.com[j]) + cur.p;
+                const double * il = lm.inertia[j];
                 const M3 Il = M3{il[0], il[1], il[3], il[1], il[2], il[4], il[3], il[4], il[5]};
                 const M3 Iw = cur.R * Il * transpose(cur.R);
                 const double cc = dot(c, c);
@@ -368,9 +425,9 @@ namespace smpc
               }
 #pragma unroll 1
               for (int f = 0; f < NF; f++)
-                if (j == mg.foot_joint[f])
+                if (j == lm.foot_joint[f])
                 {
-                  const V3 fp = cur.R * ld3(mg.foot_p[f]) + cur.p;
+                  const V3 fp = cur.R * ld3(lm.foot_p[f]) + cur.p;
                   st3(blk, hd0 + L::H_footp + f * 3, fp);
                   // LOCAL-frame velocity of the foot point (the contact rows)
                   st3(blk, hd0 + L::H_fv + f * 3, tmul(cur.R, cur.v.l + cross(cur.v.a, fp)));
@@ -392,7 +449,7 @@ namespace smpc
               const V3 hga = htot.a - cross(com, htot.l);
               st3(blk, hd0 + L::H_hg, htot.l);
               st3(blk, hd0 + L::H_hg + 3, hga);
-              const V3 fl = mg.total_mass * ld3(mg.gravity) + fsum;
+              const V3 fl = total_mass * gravity + fsum;
               const V3 fa = msum - cross(com, fsum); // sum (p_f - c) x F_f
               st3(blk, hd0 + L::H_hd, fl);
               st3(blk, hd0 + L::H_hd + 3, fa);
@@ -570,14 +627,27 @@ namespace smpc
   // (HOT(6); reference RolloutType::LINEAR, src/mpc.cpp:44): defect, residuals, costs, constraint rows, AL multipliers -> merit
   // partials partsT, xdotT.  The serial part of the evaluation comes from lane_tree_body's HEAD of the candidate.
   // =============================================================================================
+  // LDS scratch of the row phases: plain double pointers into a block of RowsScratch<D>::N doubles (the derivative kernel places it
+  // inside arrays of its own scratch that are idle at that time: no second struct type may name that memory)
   template <class D>
   struct RowsScratch
   {
-    double px[D::NX], pxn[D::NX], pu[D::NU];
-    double head[64];
-    double rx[D::NDX]; // (general weight matrices: the residual for the row products)
-    double ru[D::NU];
-    double red[3 * 64], red8[3 * 8];
+    double *px, *pxn, *pu; // NX, NX, NU: the evaluation point, x_{t+1}, controls
+    double * head;         // 64
+    double *rx, *ru;       // NDX, NU (general weight matrices: the residuals for the row products)
+    double *red, *red8;    // 3 * 64, 3 * 8
+    static constexpr int N = 2 * D::NX + D::NU + 64 + D::NDX + D::NU + 3 * 64 + 3 * 8;
+    SMPC_HD explicit RowsScratch(double * base)
+    {
+      px = base;
+      pxn = px + D::NX;
+      pu = pxn + D::NX;
+      head = pu + D::NU;
+      rx = head + 64;
+      ru = rx + D::NDX;
+      red = ru + D::NU;
+      red8 = red + 3 * 64;
+    }
   };
   template <class D>
   SMPC_DEV void trial_rows_one(const StageKernelArgs<D> & ka, int inst, int t, int j);
@@ -586,8 +656,9 @@ namespace smpc
   SMPC_DEV void trial_rows_body(const StageKernelArgs<D> & ka, int block)
   {
     const int H = ka.b.H;
-    const int slot = block / (H + 1), t = block % (H + 1);
-    const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : slot + 1;
+    const int prob = xcd_problem(block); // (XCD-aware: see xcd_problem)
+    const int slot = prob / (H + 1), t = prob % (H + 1);
+    const int count = ka.slots > 0 ? (slot < ka.slots ? ka.b.und_list[ka.b.B] : 0) : (slot < ka.b.B ? slot + 1 : 0); // (padding blocks: idle)
     const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
     for (int m = slot; m < count; m += stride)
     {
@@ -606,7 +677,7 @@ namespace smpc
   //   lane map of the weighted residuals wres:  0 .. NDX-1 state (W r)_i | NDX .. NDX+5 W hg | NDX+6 .. NDX+11 W hd | NDX+12 .. +3NF W rf
   //   wru (lane < NU): (W_u r_u)_i
   template <class D, bool OUT, class Sc>
-  SMPC_DEV void kino_rows(Sc & sc, const DevModel<D> & mg, unsigned mask, bool term, const double * x_tgt, const double * vref, const double * u_ref,
+  SMPC_DEV void kino_rows(const Sc & sc, const DevModelSmall<D> & md, const DevModel<D> & mg, const double * wframe, unsigned mask, bool term, const double * x_tgt, const double * vref, const double * u_ref,
                           const double * foot_ref, SMPC_PL_REF(double, plam_, 64), SMPC_PL_REF(double, lam_e_, 64), SMPC_PL_REF(double, pnu_, 64),
                           SMPC_PL_REF(double, nu_e_, 64), SMPC_PL_REF(double, lamp_, 64), SMPC_PL_REF(double, vplus_, 64), SMPC_PL_REF(int, act_, 64),
                           SMPC_PL_REF(double, wres_, 64), SMPC_PL_REF(double, wru_, 64), double * red);
@@ -621,8 +692,8 @@ namespace smpc
     const int H = b.H, R = b.R;
     const bool term = t == H;
     const DevModel<D> & mg = *b.model;
-    SMPC_LDS(RowsScratch<D>, scs, 1);
-    RowsScratch<D> & sc = scs[0];
+    SMPC_LDS(double, rows_lds, RowsScratch<D>::N);
+    RowsScratch<D> sc(rows_lds);
     const int st = ring_slot(ka.head, t, R), sn = ring_slot(ka.head, term ? t : t + 1, R);
     const size_t ib = (size_t)inst * R;
     double alpha = 1.0;
@@ -671,7 +742,7 @@ namespace smpc
     double red[3];
     SMPC_PL(double, dmy, NT);
     SMPC_PL(int, dmyi, NT);
-    kino_rows<D, false>(sc, mg, mask, term, x_tgt, vref, u_ref, foot_ref, plam, lame, pnu, nue, dmy, dmy, dmyi, dmy, dmy, red);
+    kino_rows<D, false>(sc, mg, mg, mg.w_frame, mask, term, x_tgt, vref, u_ref, foot_ref, plam, lame, pnu, nue, dmy, dmy, dmyi, dmy, dmy, red);
     double * parts = b.partsT + (((size_t)inst * D::LS_N + j) * (H + 1) + t) * 2;
     SMPC_LANES(NT)
     {
@@ -691,7 +762,7 @@ namespace smpc
   }
 
   template <class D, bool OUT, class Sc>
-  SMPC_DEV void kino_rows(Sc & sc, const DevModel<D> & mg, unsigned mask, bool term, const double * x_tgt, const double * vref, const double * u_ref,
+  SMPC_DEV void kino_rows(const Sc & sc, const DevModelSmall<D> & md, const DevModel<D> & mg, const double * wframe, unsigned mask, bool term, const double * x_tgt, const double * vref, const double * u_ref,
                           const double * foot_ref, SMPC_PL_REF(double, plam_, 64), SMPC_PL_REF(double, lam_e_, 64), SMPC_PL_REF(double, pnu_, 64),
                           SMPC_PL_REF(double, nu_e_, 64), SMPC_PL_REF(double, lamp_, 64), SMPC_PL_REF(double, vplus_, 64), SMPC_PL_REF(int, act_, 64),
                           SMPC_PL_REF(double, wres_, 64), SMPC_PL_REF(double, wru_, 64), double * red)
@@ -700,8 +771,8 @@ namespace smpc
     constexpr int NT = 64;
     constexpr int NV = D::NV, NQ = D::NQ, NDX = D::NDX, NU = D::NU, NC = D::NC, NF = D::NF, NA = D::NA;
     static_assert(NDX + 12 + 3 * NF <= NT && NDX + NC <= NT + NC, "one residual term per lane");
-    const double dt = mg.dt, mu = mg.mu;
-    const bool wdiag = mg.w_diag != 0;
+    const double dt = md.dt, mu = md.mu;
+    const bool wdiag = md.w_diag != 0;
     if (!wdiag)
     {
       // general weight matrices: residuals through LDS for the row products
@@ -747,7 +818,7 @@ namespace smpc
         const double r = i < 6 ? sc.head[L::H_rb + i]
                                : sc.px[i + 1] - ((vref != nullptr && i >= NV && i < NV + 6) ? vref[i - NV] : x_tgt[i + 1]);
         if (wdiag)
-          wres = mg.wxd[i] * r;
+          wres = md.wxd[i] * r;
         else
         {
           double s = 0.0;
@@ -764,7 +835,7 @@ namespace smpc
         const double sc10 = term ? 10.0 : 1.0; // terminal: 10 * w_cent (src/kinodynamics.cpp:361)
         double s = 0.0;
         for (int k = 0; k < 6; k++)
-          s += sc10 * mg.w_cent[i * 6 + k] * sc.head[L::H_hg + k];
+          s += sc10 * md.w_cent[i * 6 + k] * sc.head[L::H_hg + k];
         wres = s;
         cost = sc.head[L::H_hg + i] * s;
       }
@@ -773,7 +844,7 @@ namespace smpc
         const int i = lane - NDX - 6;
         double s = 0.0;
         for (int k = 0; k < 6; k++)
-          s += mg.w_centder[i * 6 + k] * sc.head[L::H_hd + k];
+          s += md.w_centder[i * 6 + k] * sc.head[L::H_hd + k];
         wres = s;
         cost = sc.head[L::H_hd + i] * s;
       }
@@ -782,7 +853,7 @@ namespace smpc
         const int i = lane - NDX - 12, f = i / 3, r = i % 3;
         double s = 0.0;
         for (int k = 0; k < 3; k++)
-          s += mg.w_frame[r * 3 + k] * (sc.head[L::H_footp + f * 3 + k] - foot_ref[f * 3 + k]);
+          s += wframe[r * 3 + k] * (sc.head[L::H_footp + f * 3 + k] - foot_ref[f * 3 + k]);
         wres = s;
         cost = (sc.head[L::H_footp + i] - foot_ref[i]) * s;
       }
@@ -794,7 +865,7 @@ namespace smpc
         const double r = sc.pu[lane] - u_ref[lane];
         double wr;
         if (wdiag)
-          wr = mg.wud[lane] * r;
+          wr = md.wud[lane] * r;
         else
         {
           double s = 0.0;
@@ -815,8 +886,8 @@ namespace smpc
         double c = 0.0;
         if (i < NA)
         {
-          kind = mg.kinematics_limits ? 2 : 0;
-          c = mg.kinematics_limits ? sc.px[7 + i] : 0.0;
+          kind = md.kinematics_limits ? 2 : 0;
+          c = md.kinematics_limits ? sc.px[7 + i] : 0.0;
         }
         else
         {
@@ -830,14 +901,14 @@ namespace smpc
           const double z = c + mu * SMPC_PLV(nu_e_);
           double proj = 0.0;
           if (kind == 2)
-            proj = fmin(fmax(z, mg.qmin[i < NA ? i : 0]), mg.qmax[i < NA ? i : 0]);
+            proj = fmin(fmax(z, md.qmin[i < NA ? i : 0]), md.qmax[i < NA ? i : 0]);
           vp = (z - proj) / mu;
           act = (z != proj) || kind == 1;
         }
         const double dv = vp - SMPC_PLV(pnu_);
         pen += 0.5 * mu * (vp * vp + dv * dv);
         if (kind == 2)
-          prim = fmax(prim, fmax(fmax(c - mg.qmax[i < NA ? i : 0], mg.qmin[i < NA ? i : 0] - c), 0.0));
+          prim = fmax(prim, fmax(fmax(c - md.qmax[i < NA ? i : 0], md.qmin[i < NA ? i : 0] - c), 0.0));
         else if (kind == 1)
           prim = fmax(prim, fabs(c));
         if constexpr (OUT)
