@@ -20,6 +20,10 @@ namespace simple_mpc
     double kp_base = 0., kp_posture = 0., kp_contact = 0.;
     double w_base = -1., w_posture = -1., w_contact_motion = -1., w_contact_force = -1.; // <= 0: task disabled
     bool contact_motion_equality = false;
+    // extensions (see include/smpc.h): the base task literally as the reference codes it (kinodynamics-id.cpp:222-223); TSID's
+    // TaskJointPosVelAccBounds in full
+    bool base_reference_as_coded = false;
+    bool tsid_joint_bounds = false;
   };
   struct CentroidalIDSettings : KinodynamicsIDSettings // reference centroidal-id.hpp
   {
@@ -93,6 +97,8 @@ namespace simple_mpc
       c.kp_feet_tracking = s.kp_feet_tracking;
       c.w_com = s.w_com;
       c.w_feet_tracking = s.w_feet_tracking;
+      c.base_reference_as_coded = s.base_reference_as_coded ? 1 : 0;
+      c.tsid_joint_bounds = s.tsid_joint_bounds ? 1 : 0;
       check(smpc_id_create(robot, &c, batch, device_id, &h_));
     }
     static void check(int rc)

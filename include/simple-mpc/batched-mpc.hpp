@@ -59,6 +59,9 @@ namespace simple_mpc
     int T_contact = 20;
     std::size_t T = 100;
     double timestep = 0.01;
+    // extension: SolverProxDDP's convergence test inside iterate (the reference passes TOL to its solver, src/mpc.cpp:43,212); off: exactly
+    // max_iters iterations per control step (the metric of record)
+    bool early_exit_on_tol = false;
   };
 
   class BatchedMPC
@@ -104,6 +107,8 @@ namespace simple_mpc
       ks.terminal_constraint = ocp.terminal_constraint;
       smpc_mpc_settings ms = c_settings(settings);
       check(smpc_create(robot, &ks, &ms, batch, gravity_arg, device_id, &h_));
+      if (settings.early_exit_on_tol)
+        check(smpc_set_early_exit_on_tol(h_, 1));
       finish(robot);
     }
     // CentroidalOCP(settings, model) + createProblem(getCentroidalState(), T, force_size, gravity, false) + MPC(settings, ocp)
@@ -172,6 +177,8 @@ namespace simple_mpc
       force_size_ = ocp.force_size;
       smpc_mpc_settings ms = c_settings(settings);
       check(smpc_create_fulldynamics(robot, &fsn, &ms, batch, gravity_arg, device_id, &h_));
+      if (settings.early_exit_on_tol)
+        check(smpc_set_early_exit_on_tol(h_, 1));
       finish(robot);
     }
     ~BatchedMPC() { smpc_destroy(h_); }

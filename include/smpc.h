@@ -123,6 +123,11 @@ typedef struct smpc_mpc_settings
 const smpc_robot_model * smpc_builtin_robot(const char * name);
 
 const char * smpc_last_error(void);
+/* SolverProxDDP's convergence test inside iterate (reference src/mpc.cpp:43 hands TOL to the solver, :212 runs it: `run` returns as soon
+ * as the primal and dual infeasibilities are below TOL).  Off by default -- the metric of record is "at fixed ProxDDP iterations"; on: an
+ * instance that is converged at the start of an iteration takes no further step in this control step (its iterate, multipliers and
+ * regularisation stay; the feedback gains are those of the sweep at the converged point).  Kinodynamics and full-dynamics handles. */
+int smpc_set_early_exit_on_tol(smpc_handle * h, int on);
 /* number of HIP devices visible (0 => every compute entry point fails loudly) */
 int smpc_device_count(void);
 
@@ -356,6 +361,14 @@ typedef struct smpc_id_settings
   int centroidal;
   double kp_com, kp_feet_tracking;
   double w_com, w_feet_tracking; /* <= 0: task disabled */
+  /* The reference AS CODED (src/inverse-dynamics/kinodynamics-id.cpp:222-223: setDerivative is called twice, so the base acceleration
+   * target becomes the velocity reference of the base task and its acceleration reference stays zero).  0 (default): velocity and
+   * acceleration references from the respective targets -- with zero base targets, as in the reference's tests, both coincide. */
+  int base_reference_as_coded;
+  /* TSID's TaskJointPosVelAccBounds in full (time step 2 control_dt, braking-distance position bounds, viability bounds with the default
+   * acceleration limit; setImposeBounds(true, true, true, false) of kinodynamics-id.cpp:80-88).  0 (default): position / velocity limits
+   * as acceleration bounds over one control period. */
+  int tsid_joint_bounds;
 } smpc_id_settings;
 typedef struct smpc_id_handle smpc_id_handle;
 /* KinodynamicsID(model_handler, control_dt, settings): the default target is the reference state, every foot in contact with an equal
@@ -384,6 +397,11 @@ int smpc_id_solve(smpc_id_handle * h, const double * X, double * tau, double * a
  * [B][nv - 6] may be NULL: the torques then stay in the handle's own buffer, smpc_id_get_tau_device. */
 int smpc_id_solve_device(smpc_id_handle * h, const double * X_device, double * tau_device);
 int smpc_id_wait(smpc_id_handle * h);
+/* residuals of the last solve, resid [B] (the larger of the QP's primal / dual residuals; not finite: the solve of that robot failed,
+ * its warm start was dropped and its next solve starts from scratch); joins the handle's stream */
+int smpc_id_get_resid(smpc_id_handle * h, double * resid);
+/* forget the warm start (ADMM iterate, step-size parameter) of one robot, or of every robot (instance < 0) */
+int smpc_id_reset(smpc_id_handle * h, int instance);
 const double * smpc_id_get_tau_device(smpc_id_handle * h);
 /* the handle's own state buffer [B][nq + nv] in HBM (smpc_id_solve copies the host states there; a simulator may keep its states in it) */
 double * smpc_id_get_x_device(smpc_id_handle * h);

@@ -662,6 +662,7 @@ extern "C"
     BatchMPC * m = (BatchMPC *)h;
     m->x_reference.assign(x, x + m->md.nx);
   }
+  void orc_mpc_set_early_exit(void * h, int on) { ((BatchMPC *)h)->early_exit_on_tol = on != 0; }
   double orc_mpc_iterate(void * h, const double * X)
   {
     auto t0 = std::chrono::steady_clock::now();
@@ -1046,6 +1047,7 @@ extern "C"
     double rho, sigma, alpha, admm_tol;
     int centroidal;
     double kp_com, kp_feet_tracking, w_com, w_feet_tracking;
+    int base_reference_as_coded, tsid_joint_bounds;
   };
   static IDSettings id_settings_from(const smpc_robot_model * m, const orc_id_settings * c)
   {
@@ -1077,6 +1079,8 @@ extern "C"
     s.kp_feet_tracking = c->kp_feet_tracking;
     s.w_com = c->w_com;
     s.w_feet_tracking = c->w_feet_tracking;
+    s.base_reference_as_coded = c->base_reference_as_coded != 0;
+    s.tsid_joint_bounds = c->tsid_joint_bounds != 0;
     return s;
   }
   void * orc_id_create(const smpc_robot_model * m, const orc_id_settings * c, int B) { return new BatchKinoID(m, id_settings_from(m, c), B); }

@@ -48,7 +48,70 @@ namespace orc
     int admm_iters = 400; // cap; the loop stops earlier once the residuals are below ADMM_TOL
     double rho = 0.1, sigma = 1e-6, alpha = 1.6;
     double admm_tol = 1e-7; // < 0: never stop early
+    // the reference AS CODED: kinodynamics-id.cpp:222-223 calls sampleBase_.setDerivative twice, so the base ACCELERATION target is TSID's
+    // velocity reference and the acceleration reference stays zero (TaskSE3Equality turns the world-aligned reference back into the
+    // local frame with the measured rotation, i.e. the local target itself); off: the evident intent (see the header)
+    bool base_reference_as_coded = false;
+    // TSID's TaskJointPosVelAccBounds restated in full ([UPSTREAM-RECALL] tsid 1.9 src/tasks/task-joint-posVelAcc-bounds.cpp): its time
+    // step is TWICE the control period, the position bounds switch to the braking-distance form when the joint moves towards a
+    // limit it cannot reach within a step, and the viability bounds (setImposeBounds(true, true, true, false)) are evaluated with the
+    // default acceleration limit 1e10; off: position / velocity limits over one control period
+    bool tsid_joint_bounds = false;
   };
+  // acceleration bounds [lb, ub] of one joint as TaskJointPosVelAccBounds::computeAccLimits forms them ([UPSTREAM-RECALL])
+  inline void tsid_acc_limits(double q, double dq, double qmin, double qmax, double dqmax, double control_dt, double & lb, double & ub)
+  {
+    const double dt = 2.0 * control_dt, ddqmax = 1e10, big = 1e10;
+    // position
+    const double two_dt_sq = 2.0 / (dt * dt);
+    const double max_q3 = two_dt_sq * (qmax - q - dt * dq), min_q3 = two_dt_sq * (qmin - q - dt * dq), mdq = -dq / dt;
+    double lbp = -big, ubp = big;
+    if (dq <= 0.0)
+    {
+      ubp = max_q3;
+      if (min_q3 < mdq)
+        lbp = min_q3;
+      else if (q != qmin)
+        lbp = std::fmax(dq * dq / (2.0 * (q - qmin)), mdq);
+      else
+        lbp = 1e6;
+    }
+    else
+    {
+      lbp = min_q3;
+      if (max_q3 > mdq)
+        ubp = max_q3;
+      else if (q != qmax)
+        ubp = std::fmin(-dq * dq / (2.0 * (qmax - q)), mdq);
+      else
+        ubp = -1e6;
+    }
+    // velocity
+    const double lbv = (-dqmax - dq) / dt, ubv = (dqmax - dq) / dt;
+    // viability
+    const double dt_sq = dt * dt, dt_dq = dt * dq, two_a = 2.0 * dt_sq, q_plus = q + dt_dq;
+    const double b1 = 2.0 * dt_dq + ddqmax * dt_sq, b2 = 2.0 * dt_dq - ddqmax * dt_sq;
+    const double c1 = dq * dq - 2.0 * ddqmax * (qmax - q_plus), c2 = dq * dq - 2.0 * ddqmax * (q_plus - qmin);
+    double ddq1 = mdq, ddq2 = mdq;
+    const double d1 = b1 * b1 - 2.0 * two_a * c1, d2 = b2 * b2 - 2.0 * two_a * c2;
+    if (d1 >= 0.0)
+      ddq1 = (-b1 + std::sqrt(d1)) / two_a;
+    if (d2 >= 0.0)
+      ddq2 = (-b2 - std::sqrt(d2)) / two_a;
+    const double ubvia = std::fmax(ddq1, mdq), lbvia = std::fmin(ddq2, mdq);
+    // the most conservative of position / viability / velocity (the acceleration bound itself is not imposed)
+    ub = std::fmin(ubp, std::fmin(ubvia, ubv));
+    lb = std::fmax(lbp, std::fmax(lbvia, lbv));
+    if (ub < lb)
+    { // conflict: priority to the position bounds
+      if (ub == ubp)
+        lb = lbp;
+      else
+        ub = ubp;
+      if (ub < lb) // (still inverted: a joint outside its range) the tighter one wins, as in the plain variant
+        lb = ub = std::fmin(lb, ub);
+    }
+  }
   struct IDTarget
   {
     Vec q, v, a; // nq, nv, nv
@@ -135,7 +198,8 @@ namespace orc
       const V3 dr = cross(wl, vl);
       for (int i = (s.centroidal ? 3 : 0); i < 6; i++) // (CentroidalID: orientation rows only, centroidal-id.cpp:10-20)
       {
-        const double ades = s.kp_base * e[i] + kd(s.kp_base) * (t.v[i] - v[i]) + t.a[i]; // (the evident intent: see the header)
+        const double ades = s.base_reference_as_coded ? s.kp_base * e[i] + kd(s.kp_base) * (t.a[i] - v[i])
+                                                      : s.kp_base * e[i] + kd(s.kp_base) * (t.v[i] - v[i]) + t.a[i]; // (the evident intent: see the header)
         const double b = ades - (i < 3 ? dr[i] : 0.0);
         qp.H(i, i) += s.w_base;
         qp.g[i] -= s.w_base * b;
@@ -215,6 +279,8 @@ namespace orc
       double ub = std::fmin((s.v_max[j] - va) / dt, 2.0 * (s.q_max[j] - qa - va * dt) / (dt * dt));
       if (lb > ub) // (a joint beyond both: the tighter one wins)
         lb = ub = std::fmin(lb, ub);
+      if (s.tsid_joint_bounds)
+        tsid_acc_limits(qa, va, s.q_min[j], s.q_max[j], s.v_max[j], dt, lb, ub);
       qp.l[6 + j] = lb;
       qp.u[6 + j] = ub;
     }

@@ -219,6 +219,7 @@ namespace orc
       vref.assign(B, std::vector<std::array<double, 6>>(H, std::array<double, 6>{{0, 0, 0, 0, 0, 0}}));
     }
     std::vector<IterInfo> cold_trace;
+    bool early_exit_on_tol = false; // SolverProxDDP::run's convergence test inside iterate (reference src/mpc.cpp:43,212)
     void set_velocity_all(const double * v6)
     {
       for (auto & v : vbase_inst)
@@ -394,7 +395,11 @@ namespace orc
         const Vec vN_e = S.vN;
         S.preg = SolverConsts::REG_INIT; // regularisation restarts with every solver run
         for (int it = 0; it < st.max_iters; it++)
-          last_info[b] = solver.iterate(R, o, S, vs_e, lams_e, keep_knots ? &last_knots[b] : nullptr, &vN_e);
+        {
+          last_info[b] = solver.iterate(R, o, S, vs_e, lams_e, keep_knots ? &last_knots[b] : nullptr, &vN_e, early_exit_on_tol ? st.TOL : -1.0);
+          if (early_exit_on_tol && std::fmax(last_info[b].prim_infeas, last_info[b].dual_infeas) <= st.TOL)
+            break;
+        }
       }
     }
   };

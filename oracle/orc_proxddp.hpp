@@ -365,7 +365,7 @@ namespace orc
     // One full iteration; vs_e / lams_e are the AL centres.
     IterInfo iterate(
       Rigid & R, const OcpInstance & ocp, SolverState & S, const std::vector<Vec> & vs_e,
-      const std::vector<Vec> & lams_e, std::vector<Knot> * knots_out = nullptr, const Vec * vN_e = nullptr) const
+      const std::vector<Vec> & lams_e, std::vector<Knot> * knots_out = nullptr, const Vec * vN_e = nullptr, double stop_tol = -1.0) const
     {
       const int H = (int)ocp.stages.size();
       const int ndx = md.ndx, nu = md.nu, nc = md.nc;
@@ -442,6 +442,14 @@ namespace orc
       }
       dual = std::fmax(dual, norm_inf(qN));
       info.dual_infeas = dual;
+      if (stop_tol >= 0.0 && std::fmax(info.prim_infeas, dual) <= stop_tol)
+      { // SolverProxDDP::run's convergence test (reference src/mpc.cpp:43,212): converged, no step
+        if (knots_out)
+          *knots_out = kn;
+        info.phi_new = info.phi0;
+        info.prim_new = info.prim_infeas;
+        return info;
+      }
       if (ocp.term_cstr)
       {
         for (int r = 0; r < 3; r++)

@@ -637,6 +637,17 @@ extern "C"
     return n;
   }
   int smpc_lq_size(const smpc_handle * h) { return (h && h->full) ? h->full->lq_size() : DimsGo2::LQ_STRIDE; }
+  int smpc_set_early_exit_on_tol(smpc_handle * h, int on)
+  {
+    if (!h)
+      return fail(SMPC_ERR_INVALID, "null handle");
+    if (h->cent)
+      return fail(SMPC_ERR_INVALID, "smpc_set_early_exit_on_tol: kinodynamics and full-dynamics handles (the centroidal step is one fused kernel)");
+    if (h->full)
+      return guarded([&] { h->full->set_early_exit(on != 0); });
+    h->eng->early_exit_on_tol = on != 0;
+    return SMPC_OK;
+  }
   int smpc_debug_get_lq(smpc_handle * h, int inst, int t, double * out)
   {
     if (h && h->full)
@@ -951,6 +962,8 @@ extern "C"
     hs.dev.admm_tol = c->admm_tol == 0.0 ? 1e-7 : c->admm_tol;
     hs.dev.centroidal = c->centroidal != 0;
     hs.dev.pad_ = 0;
+    hs.dev.base_as_coded = c->base_reference_as_coded != 0;
+    hs.dev.tsid_bounds = c->tsid_joint_bounds != 0;
     hs.dev.kp_com = c->kp_com;
     hs.dev.kp_feet_tracking = c->kp_feet_tracking;
     hs.dev.w_com = c->w_com;
@@ -1032,6 +1045,18 @@ extern "C"
       return fail(SMPC_ERR_INVALID, "null argument");
     return guarded([&] { reinterpret_cast<IdEngineBase *>(h)->wait(); });
   }
+  int smpc_id_get_resid(smpc_id_handle * h, double * resid)
+  {
+    if (!h || !resid)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { reinterpret_cast<IdEngineBase *>(h)->get_resid(resid); });
+  }
+  int smpc_id_reset(smpc_id_handle * h, int instance)
+  {
+    if (!h)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    return guarded([&] { reinterpret_cast<IdEngineBase *>(h)->reset(instance); });
+  }
   const double * smpc_id_get_tau_device(smpc_id_handle * h) { return h ? reinterpret_cast<IdEngineBase *>(h)->tau_device() : nullptr; }
   int smpc_id_set_targets_from_mpc(smpc_id_handle * id, smpc_handle * mpc, double delay, int knots)
   {
@@ -1088,6 +1113,8 @@ extern "C"
       return guarded([&] { e->adopt_stream(e->solve_stream(), true); });
     if (mpc->full)
       return fail(SMPC_ERR_INVALID, "smpc_id_share_stream needs a kinodynamics or a centroidal MPC handle");
+    if ((mpc->cent ? mpc->cent->device_id : mpc->eng->device_id) != e->device())
+      return fail(SMPC_ERR_INVALID, "smpc_id_share_stream: the controller and the MPC handle live on different devices");
     return guarded([&] { e->adopt_stream(mpc->cent ? mpc->cent->stream : mpc->eng->stream, false); });
   }
   int smpc_sim_step_device(smpc_handle * h, double * X_device, const double * tau_device, const uint8_t * contact, const double * Kp, const double * Kd, double dt)

@@ -362,6 +362,7 @@ namespace smpc
     bool profiling = false;
     static constexpr int LS_SLOTS = 64; // instance slots of the list-mode (backtracking) launches: 64 x (H+1) blocks when the list is empty
     bool speculative_ls = std::getenv("SMPC_NO_SPECULATIVE_LS") == nullptr; // tentative full steps (run_iterations)
+    bool early_exit_on_tol = false; // smpc_set_early_exit_on_tol: iterate() stops an instance's iterations once it is converged to TOL
     bool aux_launches = false; // true during the cold start: every launch uses the auxiliary kernel symbols
     // lane-per-problem stage evaluation (smpc_kino_lane.h) for problems without optional constraint blocks; SMPC_LANE_EVAL=0: the
     // wavefront-per-problem kernels throughout (A/B comparison)
@@ -605,6 +606,7 @@ namespace smpc
       a.reg_max = REG_MAX;
       a.reg_inc = REG_INC;
       a.reg_dec = REG_DEC;
+      a.stop_tol = early_exit_on_tol ? ms.TOL : -1.0;
       return a;
     }
 
@@ -781,7 +783,7 @@ namespace smpc
     // that reject alpha = 1 are restored, backtracked with explicit trial evaluations and re-derived (compacted list).
     void run_iterations(const Buffers<D> & b, int k)
     {
-      if (!speculative_ls || k <= 1)
+      if (!speculative_ls || k <= 1 || early_exit_on_tol) // (the convergence test belongs to the sequential scheme)
       {
         for (int it = 0; it < k; it++)
           run_iteration(b);
@@ -1114,7 +1116,7 @@ namespace smpc
     void run_iterations_parts(const Buffers<D> * part, int k)
     {
       auto on = [&](int i) -> const Buffers<D> & { cur = streams[i]; return part[i]; };
-      if (!speculative_ls || k <= 1)
+      if (!speculative_ls || k <= 1 || early_exit_on_tol) // (the convergence test belongs to the sequential scheme)
       {
         for (int it = 0; it < k; it++)
           for (int i = 0; i < n_streams; i++)

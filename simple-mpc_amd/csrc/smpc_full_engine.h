@@ -34,6 +34,7 @@ namespace smpc
     int cold_iters = 0;
     std::vector<double> cold_trace;
     std::vector<double> x_reference;
+    virtual void set_early_exit(bool on) = 0;
     virtual ~FullEngineBase() {}
     virtual void generate_cycle_horizon(const unsigned char * cs, int n) = 0;
     virtual void switch_to_walk(const double * v6) = 0;
@@ -77,6 +78,8 @@ namespace smpc
     size_t stage_out_bytes = 0;
     bool valu_riccati = std::getenv("SMPC_RICCATI") && std::string(std::getenv("SMPC_RICCATI")) == "valu";
     bool speculative_ls = std::getenv("SMPC_NO_SPECULATIVE_LS") == nullptr;
+    bool early_exit_on_tol = false; // smpc_set_early_exit_on_tol
+    void set_early_exit(bool on) override { early_exit_on_tol = on; }
     bool aux_launches = false;
     std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
     static constexpr int LS_SLOTS = 64;
@@ -254,6 +257,7 @@ namespace smpc
       a.reg_max = REG_MAX;
       a.reg_inc = REG_INC;
       a.reg_dec = REG_DEC;
+      a.stop_tol = early_exit_on_tol ? ms.TOL : -1.0;
       return a;
     }
     template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1>
@@ -355,7 +359,7 @@ namespace smpc
     // k ProxDDP iterations of one control step; tentative full steps as in KinoEngine::run_iterations
     void run_iterations(const Buffers<D> & b, int k)
     {
-      if (!speculative_ls || k <= 1)
+      if (!speculative_ls || k <= 1 || early_exit_on_tol) // (the convergence test belongs to the sequential scheme)
       {
         for (int it = 0; it < k; it++)
           run_iteration(b);

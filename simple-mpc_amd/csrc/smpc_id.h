@@ -28,8 +28,9 @@ namespace smpc
     int contact_motion_equality, admm_iters;
     double control_dt, rho, sigma, alpha, admm_tol;
     // CentroidalID (reference src/inverse-dynamics/centroidal-id.cpp:6-147): orientation-only base task, CoM task, tracking of the feet in the air
-    int centroidal, pad_;
+    int centroidal, base_as_coded;
     double kp_com, kp_feet_tracking, w_com, w_feet_tracking;
+    int tsid_bounds, pad_;
   };
   template <class D>
   struct IdDims
@@ -117,6 +118,58 @@ namespace smpc
         b.com[(size_t)inst * 3 + lane] = sc.com[lane];
     }
     SMPC_LANES_END_WAVE
+  }
+
+  // acceleration bounds of one joint as TSID's TaskJointPosVelAccBounds::computeAccLimits forms them with position, velocity and
+  // viability bounds imposed and the default acceleration limit ([UPSTREAM-RECALL] tsid 1.9; the CPU checker holds the same statement)
+  SMPC_HD void id_tsid_acc_limits(double q, double dq, double qmin, double qmax, double dqmax, double control_dt, double & lb, double & ub)
+  {
+    const double dt = 2.0 * control_dt, ddqmax = 1e10, big = 1e10;
+    const double two_dt_sq = 2.0 / (dt * dt);
+    const double max_q3 = two_dt_sq * (qmax - q - dt * dq), min_q3 = two_dt_sq * (qmin - q - dt * dq), mdq = -dq / dt;
+    double lbp = -big, ubp = big;
+    if (dq <= 0.0)
+    {
+      ubp = max_q3;
+      if (min_q3 < mdq)
+        lbp = min_q3;
+      else if (q != qmin)
+        lbp = fmax(dq * dq / (2.0 * (q - qmin)), mdq);
+      else
+        lbp = 1e6;
+    }
+    else
+    {
+      lbp = min_q3;
+      if (max_q3 > mdq)
+        ubp = max_q3;
+      else if (q != qmax)
+        ubp = fmin(-dq * dq / (2.0 * (qmax - q)), mdq);
+      else
+        ubp = -1e6;
+    }
+    const double lbv = (-dqmax - dq) / dt, ubv = (dqmax - dq) / dt;
+    const double dt_sq = dt * dt, dt_dq = dt * dq, two_a = 2.0 * dt_sq, q_plus = q + dt_dq;
+    const double b1 = 2.0 * dt_dq + ddqmax * dt_sq, b2 = 2.0 * dt_dq - ddqmax * dt_sq;
+    const double c1 = dq * dq - 2.0 * ddqmax * (qmax - q_plus), c2 = dq * dq - 2.0 * ddqmax * (q_plus - qmin);
+    double ddq1 = mdq, ddq2 = mdq;
+    const double d1 = b1 * b1 - 2.0 * two_a * c1, d2 = b2 * b2 - 2.0 * two_a * c2;
+    if (d1 >= 0.0)
+      ddq1 = (-b1 + sqrt(d1)) / two_a;
+    if (d2 >= 0.0)
+      ddq2 = (-b2 - sqrt(d2)) / two_a;
+    const double ubvia = fmax(ddq1, mdq), lbvia = fmin(ddq2, mdq);
+    ub = fmin(ubp, fmin(ubvia, ubv));
+    lb = fmax(lbp, fmax(lbvia, lbv));
+    if (ub < lb)
+    {
+      if (ub == ubp)
+        lb = lbp;
+      else
+        ub = ubp;
+      if (ub < lb)
+        lb = ub = fmin(lb, ub);
+    }
   }
 
   // ---- kernel 2: QP data ----
@@ -249,7 +302,8 @@ namespace smpc
           if (i >= base0 && i < 6 && s.w_base > 0)
           {
             const V3 dr = cross(mk3(v[3], v[4], v[5]), mk3(v[0], v[1], v[2]));
-            const double ades = s.kp_base * e6[i] + kdb * (tv[i] - v[i]) + ta[i]; // (velocity / acceleration references: DESIGN 3.12)
+            // (velocity / acceleration references: DESIGN 3.12; base_as_coded: the reference literally, kinodynamics-id.cpp:222-223)
+            const double ades = s.base_as_coded ? s.kp_base * e6[i] + kdb * (ta[i] - v[i]) : s.kp_base * e6[i] + kdb * (tv[i] - v[i]) + ta[i];
             gi -= s.w_base * (ades - (i == 0 ? dr.x : (i == 1 ? dr.y : (i == 2 ? dr.z : 0.0))));
           }
           if (i < NV && com_task)
@@ -317,6 +371,8 @@ namespace smpc
           hi = fmin((b.v_max[j] - va) / dt, 2.0 * (b.q_max[j] - qa - va * dt) / (dt * dt));
           if (lo > hi)
             lo = hi = fmin(lo, hi);
+          if (s.tsid_bounds)
+            id_tsid_acc_limits(qa, va, b.q_min[j], b.q_max[j], b.v_max[j], dt, lo, hi);
         }
         else if (r >= NV && r < N)
         {
@@ -520,9 +576,12 @@ namespace smpc
       SMPC_LANES(NT)
       if (lane < 4)
       {
-        double m = 0.0;
+        double m = 0.0; // (a NaN entry must survive the reduction: fmax would drop it and a failed solve would look converged)
         for (int i = 0; i < NT; i++)
-          m = fmax(m, s.red[64 * lane + i]);
+        {
+          const double v = s.red[64 * lane + i];
+          m = (v != v) ? v : ((m != m) ? m : fmax(m, v));
+        }
         s.red4[lane] = m;
       }
       SMPC_LANES_END_WAVE
@@ -611,7 +670,7 @@ namespace smpc
     }
     if (!done)
       residual();
-    const double res = fmax(rs[0], rs[1]);
+    const double res = (rs[0] != rs[0] || rs[1] != rs[1]) ? rs[0] + rs[1] : fmax(rs[0], rs[1]);
     // the solution through LDS for the torque rows (red is free now)
     SMPC_LANES(NT)
     if (lane < NP)
@@ -619,14 +678,17 @@ namespace smpc
     SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
     {
-      if (lane < NP)
+      // the iterate is kept as the next tick's warm start only when the solve ended finite: a NaN state or target (a diverged simulator,
+      // an MPC instance with a non-zero status) must not disable this robot's controller for good
+      const bool ok = res == res && res < 1e300;
+      if (ok && lane < NP)
         b.x[(size_t)inst * NP + lane] = SMPC_PLV(x);
-      if (lane < N)
+      if (ok && lane < N)
       {
         b.z[(size_t)inst * MP + lane] = SMPC_PLV(zb);
         b.lam[(size_t)inst * MP + lane] = SMPC_PLV(lamb);
       }
-      if (lane < GR)
+      if (ok && lane < GR)
       {
         b.z[(size_t)inst * MP + N + lane] = SMPC_PLV(zg);
         b.lam[(size_t)inst * MP + N + lane] = SMPC_PLV(lamg);
@@ -649,8 +711,8 @@ namespace smpc
       if (lane == 0)
       {
         b.resid[inst] = res;
-        b.rho[inst] = rho;
-        b.warm[inst] = 1;
+        b.rho[inst] = ok ? rho : st.rho;
+        b.warm[inst] = ok ? 1 : 0;
       }
     }
     SMPC_LANES_END_WAVE
@@ -685,8 +747,11 @@ namespace smpc
     // events, no host-side waits between them); back_to_own: the controller's own stream again
     virtual void adopt_stream(stream_t s, bool back_to_own) = 0;
     virtual void wait() = 0;
+    virtual int device() const = 0;
     virtual const double * tau_device() const = 0;
     virtual double * x_device() = 0; // the engine's own state buffer [B][nq + nv] (what solve() copies the host states into)
+    virtual void reset(int inst) = 0;          // forget the warm start of one robot (inst < 0: all)
+    virtual void get_resid(double * out) = 0;  // residuals of the last solve [B] (joins the stream)
     virtual void debug_get(int what, double * out) = 0; // 0 M, 1 nle, 2 J, 3 Jdv, 4 vfoot, 5 H, 6 g, 7 C, 8 l, 9 u (padded layouts), 10 com, 11 footp, 12 tau
   };
   template <class D>
@@ -713,6 +778,20 @@ namespace smpc
       device_id = device;
       set_device(device);
       stream = own_stream = stream_create();
+      try
+      {
+        construct(rm, hs, batch);
+      }
+      catch (...)
+      { // (the destructor does not run for a partially constructed engine)
+        for (void * p : allocs)
+          dev_free(p);
+        stream_destroy(own_stream);
+        throw;
+      }
+    }
+    void construct(const smpc_robot_model * rm, const HostIdSettings & hs, int batch)
+    {
       B = batch;
       nq = D::NQ;
       nv = D::NV;
@@ -926,6 +1005,7 @@ namespace smpc
       set_device(device_id);
       stream_sync(stream);
     }
+    int device() const override { return device_id; }
     const double * tau_device() const override { return buf.tau; }
     double * x_device() override { return Xd; }
     void target_buffers(double ** x, double ** a, double ** f) override
@@ -971,6 +1051,21 @@ namespace smpc
       d2h(f, buf.f, (size_t)B * 3 * nf * sizeof(double), stream);
       if (resid)
         d2h(resid, buf.resid, (size_t)B * sizeof(double), stream);
+      stream_sync(stream);
+    }
+    void reset(int inst) override
+    {
+      set_device(device_id);
+      if (inst >= B)
+        throw std::runtime_error("instance index exceeds the batch");
+      const int i0 = inst < 0 ? 0 : inst, cnt = inst < 0 ? B : 1;
+      dev_zero(buf.warm + i0, (size_t)cnt * sizeof(int), stream);
+      stream_sync(stream);
+    }
+    void get_resid(double * out) override
+    {
+      set_device(device_id);
+      d2h(out, buf.resid, (size_t)B * sizeof(double), stream);
       stream_sync(stream);
     }
     void debug_get(int what, double * out) override

@@ -22,6 +22,9 @@ namespace smpc
     double armijo_c1, reg_min, reg_max, reg_inc, reg_dec;
     int mode = 0;  // apply_body: 0 accept alpha, 1 tentative full step (with backup), 2 restore the backup
     int slots = 0; // > 0: the launch walks the compacted list of undecided instances, `slots` at a time
+    // >= 0: SolverProxDDP::run's convergence test (reference src/mpc.cpp:43,212: TOL is the solver's tolerance): an instance whose
+    // primal and dual infeasibilities are below it at the start of an iteration takes no step in that and the following iterations
+    double stop_tol = -1.0;
   };
 
   // out(i,j) = init(i,j) + sum_k X[k*ldx + i] * Y[k*ldy + j]  for an M x N output, register tiles TM x TN
@@ -474,6 +477,15 @@ namespace smpc
           sc[SC_COST] = cost;
           sc[SC_PRIM] = prim;
           sc[SC_DUAL] = dual;
+          if (ka.stop_tol >= 0.0 && fmax(prim, dual) <= ka.stop_tol)
+          { // converged: alpha = 0, the iterate stays (no candidate is looked at, the regularisation is left alone)
+            b.ls_sel[inst] = 0;
+            sc[SC_ALPHA] = 0.0;
+            sc[SC_PHI_NEW] = phi;
+            sc[SC_PRIM_NEW] = prim;
+            sc[SC_LS_INDEX] = 0.0;
+            sc[SC_LS_FAILED] = 0.0;
+          }
         }
         if (b.ls_sel[inst] < 0)
         {

@@ -756,6 +756,11 @@ class BatchedMPC:
     def wait(self):
         self._lib.check(self._lib.L.smpc_wait(self._h))
 
+    def setEarlyExitOnTol(self, on=True):
+        """SolverProxDDP's convergence test inside iterate (reference src/mpc.cpp:43,212): an instance converged to settings TOL at the
+        start of an iteration takes no further step in that control step.  Off by default (the metric is at fixed iterations)."""
+        self._lib.check(self._lib.L.smpc_set_early_exit_on_tol(self._h, int(bool(on))))
+
     def get_x_device(self, t, device_ptr):
         """xs[t] of every instance into a device buffer [B][nx] (asynchronous on the engine's stream)."""
         self._lib.check(self._lib.L.smpc_get_x_device(self._h, int(t), C.c_void_p(int(device_ptr))))
@@ -890,6 +895,8 @@ class BatchedMPC:
         c = np.ascontiguousarray(np.array([1 if b else 0 for b in contact_state], dtype=np.uint8))
         kp = np.ascontiguousarray(np.array(Kp, dtype=np.float64)) if Kp is not None else None
         kd = np.ascontiguousarray(np.array(Kd, dtype=np.float64)) if Kd is not None else None
+        if c.shape != (self.nf,) or any(g is not None and g.shape != (3,) for g in (kp, kd)):
+            raise RuntimeError("simStepDevice: one contact flag per foot, three Baumgarte gains each for Kp and Kd")
         self._lib.check(self._lib.L.smpc_sim_step_device(self._h, C.c_void_p(int(x_device_ptr)), C.c_void_p(int(tau_device_ptr)), c,
                                                          kp.ctypes.data if kp is not None else None, kd.ctypes.data if kd is not None else None, float(dt)))
 
@@ -1101,7 +1108,10 @@ class KinodynamicsID:
                      kp_contact=0.0, w_base=-1.0, w_posture=-1.0, w_contact_motion=-1.0, w_contact_force=-1.0, contact_motion_equality=False)
     _CENTROIDAL = False
 
-    def __init__(self, model_handler, control_dt, settings, effort_limit, velocity_limit, batch=1, device_id=0, lib=None, admm_iters=0, admm_tol=0.0):
+    def __init__(self, model_handler, control_dt, settings, effort_limit, velocity_limit, batch=1, device_id=0, lib=None, admm_iters=0, admm_tol=0.0,
+                 base_reference_as_coded=False, tsid_joint_bounds=False):
+        """base_reference_as_coded: the base task exactly as the reference codes it (kinodynamics-id.cpp:222-223, the acceleration target
+        as velocity reference); tsid_joint_bounds: TSID's TaskJointPosVelAccBounds in full -- see include/smpc.h."""
         unknown = [k for k in settings if k not in self._KEYS]
         if unknown:
             raise KeyError("unknown %s settings: %s" % (type(self).__name__, unknown))
@@ -1119,7 +1129,7 @@ class KinodynamicsID:
                         s["kp_contact"], s["w_base"], s["w_posture"], s["w_contact_motion"], s["w_contact_force"],
                         int(bool(s["contact_motion_equality"])), float(control_dt), *[a.ctypes.data for a in self._keep], int(admm_iters), 0.0, 0.0, 0.0, float(admm_tol),
                         int(self._CENTROIDAL), float(s.get("kp_com", 0.0)), float(s.get("kp_feet_tracking", 0.0)), float(s.get("w_com", -1.0)),
-                        float(s.get("w_feet_tracking", -1.0)))
+                        float(s.get("w_feet_tracking", -1.0)), int(bool(base_reference_as_coded)), int(bool(tsid_joint_bounds)))
         h = C.c_void_p()
         self._lib.check(self._lib.L.smpc_id_create(model_handler._ptr, C.byref(c), self.B, device_id, C.byref(h)))
         self._h = h
@@ -1132,6 +1142,15 @@ class KinodynamicsID:
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.L.smpc_id_destroy(self._h)
             self._h = None
+
+    def reset(self, instance=-1):
+        """Forget the warm start (ADMM iterate, step-size parameter) of one robot, or of every robot."""
+        self._lib.check(self._lib.L.smpc_id_reset(self._h, int(instance)))
+
+    def getResiduals(self):
+        """Residuals [B] of the last solve (also after solveDevice); not finite: that robot's solve failed and its warm start was dropped."""
+        self._lib.check(self._lib.L.smpc_id_get_resid(self._h, self.resid))
+        return self.resid.copy()
 
     def setTarget(self, q_target, v_target, a_target, contact_state_target, f_target, instance=-1):
         """reference kinodynamics-id.cpp:120-183.  f_target: one 3-vector per foot (a list, or an array [nf][3]); instance = -1: every robot."""
@@ -1183,6 +1202,7 @@ class KinodynamicsID:
         """Issue this controller's work on the BatchedMPC's stream from now on (None: back to its own): MPC step, targets, QP solves and
         simulator steps form one in-order queue, and wait() is needed only before the host reads a result."""
         self._lib.check(self._lib.L.smpc_id_share_stream(self._h, mpc._h if mpc is not None else None))
+        self._shared_mpc = mpc  # (keeps the owner of the stream alive for as long as this controller issues work on it)
 
     def x_device_ptr(self):
         """The handle's own state buffer [B][nq + nv] in HBM (solve() copies the host states there)."""

@@ -35,6 +35,7 @@ class IdSettingsC(C.Structure):
         ("tau_max", C.c_void_p), ("v_max", C.c_void_p), ("q_min", C.c_void_p), ("q_max", C.c_void_p),
         ("admm_iters", C.c_int), ("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("admm_tol", C.c_double),
         ("centroidal", C.c_int), ("kp_com", C.c_double), ("kp_feet_tracking", C.c_double), ("w_com", C.c_double), ("w_feet_tracking", C.c_double),
+        ("base_reference_as_coded", C.c_int), ("tsid_joint_bounds", C.c_int),
     ]
 
 
@@ -538,6 +539,11 @@ class OracleMPC:
         assert X.shape == (self.B, self.nx_in)
         return self._f("iterate")(self.h, X)
 
+    def setEarlyExitOnTol(self, on=True):
+        lib().orc_mpc_set_early_exit.argtypes = [C.c_void_p, C.c_int]
+        lib().orc_mpc_set_early_exit.restype = None
+        lib().orc_mpc_set_early_exit(self.h, int(on))
+
     def _get(self, what, shape):
         out = np.zeros(shape)
         self._f("get")(self.h, what, out)
@@ -724,7 +730,8 @@ def centroidal_dynamics(mass, gravity, dt, x, u, contact, pos):
 ID_DEFAULTS = dict(friction_coefficient=0.6, contact_weight_ratio_max=10.0, contact_weight_ratio_min=0.01, kp_base=0.0, kp_posture=0.0,
                    kp_contact=0.0, w_base=-1.0, w_posture=-1.0, w_contact_motion=-1.0, w_contact_force=-1.0, contact_motion_equality=False,
                    admm_iters=400, rho=0.1, sigma=1e-6, alpha=1.6, admm_tol=1e-7,  # reference include/simple-mpc/inverse-dynamics/kinodynamics-id.hpp:24-50
-                   centroidal=False, kp_com=0.0, kp_feet_tracking=0.0, w_com=-1.0, w_feet_tracking=-1.0)  # centroidal-id.hpp:17-26
+                   centroidal=False, kp_com=0.0, kp_feet_tracking=0.0, w_com=-1.0, w_feet_tracking=-1.0,  # centroidal-id.hpp:17-26
+                   base_reference_as_coded=False, tsid_joint_bounds=False)
 GO2_EFFORT = np.array([23.7, 23.7, 45.43] * 4)
 GO2_VMAX = np.array([30.1, 30.1, 15.7] * 4)
 
@@ -746,7 +753,8 @@ class OracleKinoID:
         c = IdSettingsC(s["friction_coefficient"], s["contact_weight_ratio_max"], s["contact_weight_ratio_min"], s["kp_base"], s["kp_posture"],
                         s["kp_contact"], s["w_base"], s["w_posture"], s["w_contact_motion"], s["w_contact_force"],
                         int(s["contact_motion_equality"]), s["control_dt"], *[a.ctypes.data for a in self._keep], int(s["admm_iters"]),
-                        s["rho"], s["sigma"], s["alpha"], s["admm_tol"], int(s["centroidal"]), s["kp_com"], s["kp_feet_tracking"], s["w_com"], s["w_feet_tracking"])
+                        s["rho"], s["sigma"], s["alpha"], s["admm_tol"], int(s["centroidal"]), s["kp_com"], s["kp_feet_tracking"], s["w_com"], s["w_feet_tracking"],
+                        int(s["base_reference_as_coded"]), int(s["tsid_joint_bounds"]))
         self.h = lib().orc_id_create(robot.ptr, C.byref(c), B)
         self.n = robot.nv + 3 * robot.nf
         self.m = self.n + 6 + 3 * robot.nf + 4 * robot.nf + robot.nv - 6

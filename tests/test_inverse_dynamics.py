@@ -618,3 +618,65 @@ def test_emulated_kernels_full_stack(built):
 def test_hip_full_stack_through_a_swing_phase(built):
     X, swing = _full_stack(None, 4, 75)  # the first take-off reaches stage 0 at control step 60
     assert swing and X[-1, 0] > X[0, 0]  # the robot commanded forwards is ahead of the one commanded to stay
+
+
+# ---- reference-fidelity switches, failed solves (round 3) ----
+def _switches(lib, tol):
+    rng = np.random.default_rng(8)
+    for flags in (dict(base_reference_as_coded=True), dict(tsid_joint_bounds=True), dict(base_reference_as_coded=True, tsid_joint_bounds=True)):
+        rb = O.Robot("go2_like")
+        s = O.id_settings(rb, DT, admm_iters=100, admm_tol=-1.0, **ALL, **flags)
+        ok = O.OracleKinoID(rb, s, 3)
+        mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("go2_like", lib), "standing", "root_joint")
+        for n in S.FEET:
+            mh.addPointFoot(n, "root_joint")
+        gk = simple_mpc.KinodynamicsID(mh, DT, {k: s[k] for k in KEYS}, s["tau_max"], s["v_max"], batch=3, lib=lib, admm_iters=100, admm_tol=-1.0, **flags)
+        X = S.random_states(rb, 3, seed=21)
+        X[1, 7 + 2] = s["q_max"][2] - 1e-3  # a joint about to hit its limit
+        X[1, rb.nq + 6 + 2] = 2.0
+        fs = static_forces(rb)
+        vt, at = rng.normal(size=rb.nv) * 0.2, rng.normal(size=rb.nv)
+        for k in (ok, gk):
+            k.setTarget(rb.x_ref[: rb.nq], vt, at, [True] * 4, fs)
+        to, ao, fo = ok.solve(X)
+        tg = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
+        _compare_qp(rb, ok, gk, X)
+        assert S.rel_err(to, tg) < tol and S.rel_err(ao, gk.getAccelerations()) < tol, flags
+
+
+def _failed_solve_recovers(lib):
+    """a NaN state for one tick must not disable that robot's controller: the warm start of a failed solve is dropped"""
+    rb, ok, gk = make(lib, 3, admm_iters=60, **ALL)
+    fs = static_forces(rb)
+    gk.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [True] * 4, fs)
+    X = S.random_states(rb, 3, scale=0.3)
+    t0 = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :]).copy()
+    Xbad = X.copy()
+    Xbad[1, 8] = np.nan
+    tb = gk.solve(0.0, Xbad[:, : rb.nq], Xbad[:, rb.nq :])
+    assert not np.isfinite(tb[1]).all() and np.isfinite(tb[0]).all() and np.isfinite(tb[2]).all()
+    assert not np.isfinite(gk.getResiduals()[1])
+    t1 = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
+    assert np.isfinite(t1).all()
+    assert S.rel_err(t0[1], t1[1]) < 1e-6  # (robot 1 restarted from scratch, exactly like its first solve)
+    gk.reset()  # and the explicit reset: every robot from scratch again
+    t2 = gk.solve(0.0, X[:, : rb.nq], X[:, rb.nq :])
+    assert S.rel_err(t0, t2) < 1e-12
+
+
+def test_emulated_kernels_reference_switches(built):
+    _switches(S.emu_lib(), 1e-8)
+
+
+def test_emulated_kernels_failed_solve_recovers(built):
+    _failed_solve_recovers(S.emu_lib())
+
+
+@pytest.mark.gpu
+def test_hip_reference_switches(built):
+    _switches(None, 1e-8)
+
+
+@pytest.mark.gpu
+def test_hip_failed_solve_recovers(built):
+    _failed_solve_recovers(None)

@@ -220,3 +220,81 @@ def test_centroidal_id_foot_tracking_task(rb):
             assert e < 1e-3
         prev = e
     assert abs(sim.x[2] - rb.x_ref[2]) < 2e-2
+
+
+# ---- the two reference-fidelity switches (include/smpc.h: base_reference_as_coded, tsid_joint_bounds) ----
+def test_base_reference_as_coded_is_the_reference_literally(rb):
+    """kinodynamics-id.cpp:222-223 sets the base ACCELERATION target as the velocity reference and no acceleration reference: the QP of the
+    as-coded variant with targets (v, a) is the QP of the default variant with targets (a, 0); with zero base targets -- the reference's
+    own tests -- the two variants coincide."""
+    kw = dict(kp_base=10.0, kp_posture=1.0, kp_contact=10.0, w_base=10.0, w_posture=0.1, w_contact_force=1e-3, w_contact_motion=1.0)
+    coded = O.OracleKinoID(rb, O.id_settings(rb, DT, base_reference_as_coded=True, **kw), 1)
+    plain = O.OracleKinoID(rb, O.id_settings(rb, DT, **kw), 1)
+    rng = np.random.default_rng(3)
+    x = S.random_states(rb, 1, seed=4)[0]
+    fs = static_forces(rb)
+    vt, at = rng.normal(size=rb.nv) * 0.3, rng.normal(size=rb.nv)
+    # as coded with (v, a)  ==  default with base velocity target a[:6] and base acceleration target 0 (joint parts untouched)
+    vt2, at2 = vt.copy(), at.copy()
+    vt2[:6], at2[:6] = at[:6], 0.0
+    coded.setTarget(rb.x_ref[: rb.nq], vt, at, [True] * 4, fs)
+    plain.setTarget(rb.x_ref[: rb.nq], vt2, at2, [True] * 4, fs)
+    Hc, gc, Cc, lc, uc = coded.qp(0, x)
+    Hp, gp, Cp, lp, up = plain.qp(0, x)
+    assert np.array_equal(Hc, Hp) and np.allclose(gc, gp, rtol=0, atol=1e-12) and np.array_equal(Cc, Cp)
+    # the variants differ for non-zero base targets ...
+    plain.setTarget(rb.x_ref[: rb.nq], vt, at, [True] * 4, fs)
+    assert np.abs(plain.qp(0, x)[1] - gc).max() > 1e-2
+    # ... and coincide for zero ones
+    z = np.zeros(rb.nv)
+    coded.setTarget(rb.x_ref[: rb.nq], z, z, [True] * 4, fs)
+    plain.setTarget(rb.x_ref[: rb.nq], z, z, [True] * 4, fs)
+    assert np.array_equal(coded.qp(0, x)[1], plain.qp(0, x)[1])
+
+
+def _acc_rows(rb, x, **kw):
+    k = O.OracleKinoID(rb, O.id_settings(rb, DT, kp_posture=1.0, w_posture=1.0, **kw), 1)
+    _, _, _, l, u = k.qp(0, x)
+    return l[6 : rb.nv], u[6 : rb.nv]
+
+
+def test_tsid_joint_bounds_properties(rb):
+    """TaskJointPosVelAccBounds restated ([UPSTREAM-RECALL], oracle/orc_id.hpp tsid_acc_limits): time step 2 dt; away from the limits the
+    velocity bound binds; the viability bound evaluated with TSID's default acceleration limit 1e10 equals the position bound to rounding
+    (i.e. it is inactive on any trajectory, which is what the default variant assumes); close to a limit and moving towards it the
+    braking-distance form takes over; a lower bound never exceeds the upper one."""
+    s = O.id_settings(rb, DT)
+    x = rb.x_ref.copy()
+    x[rb.nq + 6 :] = 0.5
+    l, u = _acc_rows(rb, x, tsid_joint_bounds=True)
+    dt2 = 2 * DT
+    q, v = x[7 : rb.nq], x[rb.nq + 6 :]
+    assert np.all(l <= u)
+    pos_u = 2.0 * (s["q_max"] - q - dt2 * v) / dt2**2
+    vel_u = (s["v_max"] - v) / dt2
+    assert np.allclose(u, np.minimum(pos_u, vel_u), rtol=1e-5)  # (the viability bound coincides with pos_u to ~1e-6: 4e4 against O(1) in fp64)
+    # moving towards the upper limit from 1 mm below it, faster than one step can stop: the braking form
+    j = 2
+    x2 = rb.x_ref.copy()
+    x2[7 + j] = s["q_max"][j] - 1e-3
+    x2[rb.nq + 6 + j] = 2.0
+    l2, u2 = _acc_rows(rb, x2, tsid_joint_bounds=True)
+    assert np.isclose(u2[j], min(-(2.0**2) / (2 * 1e-3), -2.0 / dt2), rtol=1e-9) and l2[j] <= u2[j]
+    # the default variant on the same state (one control period, plain position / velocity bounds)
+    l0, u0 = _acc_rows(rb, x)
+    assert np.allclose(u0, np.minimum(2.0 * (s["q_max"] - q - DT * v) / DT**2, (s["v_max"] - v) / DT), rtol=1e-12)
+
+
+def test_posture_task_with_tsid_joint_bounds(rb):
+    """the reference's posture test (tests/inverse-dynamics/kinodynamics-id.cpp:110-143) with the full TSID bounds: limits kept, error down"""
+    sim = Sim(rb, kp_posture=20.0, w_posture=1.0, tsid_joint_bounds=True)
+    sim.id.setTarget(rb.x_ref[: rb.nq], np.zeros(rb.nv), np.zeros(rb.nv), [False] * 4, np.zeros(12))
+    sim.x = crouch(rb)
+    prev = None
+    for _ in range(300):
+        sim.step()
+        sim.x[:7] = rb.x_ref[:7]
+        sim.x[rb.nq : rb.nq + 6] = 0.0
+        e = np.linalg.norm(sim.x[7 : rb.nq] - rb.x_ref[7 : rb.nq])
+        assert prev is None or e <= prev
+        prev = e
