@@ -30,6 +30,22 @@ sys.path.insert(0, os.path.join(ROOT, "simple-mpc_amd", "python"))
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix dense peak (public spec)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
+MEASURED_PEAK = None     # {"fma_tflops", "mfma_tflops", ...} of THIS device, from tools/micro/fp64_peak.bin ("quote the measured peak")
+
+
+def measure_fp64_peak(seconds=0.5):
+    """Dependency-free v_fma_f64 / v_mfma_f64_16x16x4 loops on all CUs (tools/micro/fp64_peak.hip, built by __graft_entry__.build):
+    the peak this device actually reaches, carried beside the spec value in every FP64 roofline entry."""
+    global MEASURED_PEAK
+    exe = os.path.join(ROOT, "tools", "micro", "fp64_peak.bin")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, str(seconds)], stdout=subprocess.PIPE, text=True, timeout=60).stdout.strip().splitlines()[-1]
+        MEASURED_PEAK = json.loads(out)
+    except Exception:  # (a diagnostic: the bench line stands without it)
+        MEASURED_PEAK = None
+    return MEASURED_PEAK
 
 
 def f_ric(ndx, nu, nc):
@@ -55,19 +71,25 @@ def pmc_traffic(kernel, want):
     if not files or not want:
         return None, None
     with open(files[-1]) as f:
-        k = json.load(f).get("kernels", {})
-    return k.get(kernel, {}).get("hbm_bytes_per_launch_corrected"), os.path.basename(files[-1])
+        doc = json.load(f)
+    src = os.path.basename(files[-1]) + ("@" + doc["git_commit"] if doc.get("git_commit") else "")  # (the tree the profile was taken on)
+    return doc.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch_corrected"), src
 
 
 def both_bounds(flops, bytes_, avg_s, primary):
     """Roofline entry with BOTH fractions: `achieved/peak/unit/frac` are those of the primary bound."""
     fp = None if flops is None else {"achieved": flops / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_PEAK_TFLOPS,
                                      "algorithmic_flops": flops}
+    if fp is not None and MEASURED_PEAK:
+        pm = max(MEASURED_PEAK.get("fma_tflops", 0.0), MEASURED_PEAK.get("mfma_tflops", 0.0))
+        fp.update({"peak_measured": pm, "frac_of_measured": fp["achieved"] / pm, "peak_measured_detail": MEASURED_PEAK})
     hb = None if bytes_ is None else {"achieved": bytes_ / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_ / avg_s / 1e9 / HBM_PEAK_GBS,
                                       "algorithmic_bytes": bytes_}
     pr = fp if (primary == "mfma" and fp is not None) else hb
     out = {"bound": "mfma" if pr is fp else "hbm", "achieved": pr["achieved"], "peak": pr["peak"], "unit": pr["unit"], "frac": pr["frac"],
            "avg_launch_ms": avg_s * 1e3, "fp64": fp, "hbm": hb}
+    if pr is fp and "peak_measured" in fp:
+        out["peak_measured"] = fp["peak_measured"]
     return out
 
 
@@ -121,14 +143,14 @@ def _oracle_imports():
     return S, O
 
 
-def cpu_baseline(iters, seconds_budget=20.0):
+def cpu_baseline(iters, seconds_budget=14.0):
     """Oracle (CPU restatement, not Aligator) on the host cores, bounded sample of the same workload; plus the single-thread
     latency of one control step at B = 1."""
     import numpy as np
     S, O = _oracle_imports()
 
     threads = O.use_effective_cpus()  # hardware threads capped by the cgroup CPU quota
-    B = max(threads * 2, 8)
+    B = max(threads * 4, 16)
     om, rb, _ = S.make_oracle(B, max_iters=iters)
     om.generateCycleHorizon(O.trot_cycle())
     om.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
@@ -141,7 +163,7 @@ def cpu_baseline(iters, seconds_budget=20.0):
         om.iterate(X)
         X = om.xs[:, 1, :].copy()
         n += 1
-        if time.time() - t0 > seconds_budget or n >= 50:
+        if time.time() - t0 > seconds_budget or (n >= 400 and time.time() - t0 > 12.0):
             break
     dt = time.time() - t0
     # B = 1: one instance = one OpenMP work item = one thread
@@ -156,10 +178,26 @@ def cpu_baseline(iters, seconds_budget=20.0):
         t1 = time.time()
         o1.iterate(X1)
         lat.append(time.time() - t1)
+    # BASELINE configs[0] ("Go2 kinodynamics, H=50, 1 ProxDDP iter, batch=1 -- CPU reference, plumbing"): the reference's own operating
+    # point, one robot, one iteration per control step, one core
+    c1, rbc1, _ = S.make_oracle(1, max_iters=1)
+    c1.generateCycleHorizon(O.trot_cycle())
+    c1.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    Xc1 = S.random_states(rbc1, 1)
+    c1.iterate(Xc1)
+    lat1 = []
+    for _ in range(20):
+        Xc1 = c1.xs[:, 1, :].copy()
+        t1 = time.time()
+        c1.iterate(Xc1)
+        lat1.append(time.time() - t1)
     return {
         "value": B * n / dt,
         "unit": "control-steps/s",
         "cores": threads,
+        "cfg1_k1_b1": {"ms_per_step": 1e3 * float(np.median(lat1)), "control_steps_per_s": 1.0 / float(np.median(lat1)),
+                       "note": "BASELINE configs[0]: Go2 kinodynamics, H=50, 1 ProxDDP iteration, batch 1, one CPU thread (median of 20 steps)"},
+        "seconds": dt,
         "host_hw_threads": os.cpu_count(),
         "kind": "port",
         "b1_latency_ms": 1e3 * min(lat),
@@ -618,6 +656,7 @@ def main():
     if args.workload != "kinodynamics":
         if world > 1 or dry:
             raise SystemExit("--workload %s is a single-GPU line" % args.workload)
+        measure_fp64_peak()
         if args.workload == "centroidal":
             line = centroidal_line(B, args.iters, args.steps, args.warmup, local_rank, not args.no_cpu_baseline)
         else:
@@ -631,6 +670,8 @@ def main():
         from simple_mpc._capi import SmpcLib
 
         lib = SmpcLib(g.EMU_LIB)
+    if rank == 0 and not dry:
+        measure_fp64_peak()
     gm, mh = make_mpc("kinodynamics", B, args.iters, local_rank, lib)
 
     X0 = P.random_states(mh, B, seed=20240529 + rank)  # contiguous block of the global batch: rank r owns instances [r B, (r+1) B)

@@ -8,6 +8,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <vector>
 
 namespace simple_mpc
@@ -213,6 +214,12 @@ namespace simple_mpc
       check(smpc_get_us(h_, us_.data()));
       check(smpc_get_K0(h_, K0_.data()));
     }
+    // the pieces of iterate() for callers that drive several handles (BatchedMPCGroup): launch without waiting, the small return set
+    // [x1 | u0 | K0] of every instance as rows of a caller-owned (pinned) buffer, wait
+    void iterateAsync(const double * X) { check(smpc_iterate_async(h_, X)); }
+    void gatherOutputs(double * out, std::size_t row_doubles) { check(smpc_gather_outputs(h_, out, row_doubles)); }
+    void wait() { check(smpc_wait(h_)); }
+    int gatherRow() const { return nx() + nu() + nu() * ndx(); }
     // MPC::getContactForces for every stage (reference src/mpc.cpp:354-380): [B][H][nfeet][force_size]; full-dynamics handles only
     std::vector<double> getContactForces()
     {
@@ -335,6 +342,66 @@ namespace simple_mpc
           return v;
         }
       throw std::runtime_error("unknown end effector " + ee);
+    }
+  };
+
+  // The batch sharded over the GPUs of one node: one BatchedMPC per device, contiguous blocks of instances, no collective on
+  // the solve path; one control step = every device launched back to back from this thread, then one pass collecting what the
+  // controllers consume -- xs[1], us[0], K_0 -- into ONE host buffer (rows [x1 | u0 | K0]; pass pinned memory for full PCIe rate).
+  // Kinodynamics OCP.  Every handle runs the same gait, commands and settings.
+  class BatchedMPCGroup
+  {
+    std::vector<std::unique_ptr<BatchedMPC>> parts_;
+    std::vector<int> first_; // first instance of every part
+    int batch_ = 0;
+
+  public:
+    BatchedMPCGroup(const smpc_robot_model * robot, const KinodynamicsSettings & ocp, const MPCSettings & settings, int batch,
+                    const std::vector<int> & device_ids, double gravity_arg = -9.81)
+    : batch_(batch)
+    {
+      const int n = (int)device_ids.size();
+      if (n <= 0 || batch < n)
+        throw std::runtime_error("BatchedMPCGroup: at least one device and one instance per device");
+      for (int i = 0; i < n; i++)
+      {
+        const int i0 = (int)((long long)batch * i / n), i1 = (int)((long long)batch * (i + 1) / n);
+        first_.push_back(i0);
+        parts_.emplace_back(new BatchedMPC(robot, ocp, settings, i1 - i0, gravity_arg, device_ids[i]));
+      }
+      first_.push_back(batch);
+    }
+    int parts() const { return (int)parts_.size(); }
+    int batch() const { return batch_; }
+    BatchedMPC & part(int i) { return *parts_[i]; }
+    int firstInstance(int i) const { return first_[i]; }
+    int gatherRow() const { return parts_[0]->gatherRow(); }
+    void generateCycleHorizon(const std::vector<std::map<std::string, bool>> & contact_states)
+    {
+      for (auto & p : parts_)
+        p->generateCycleHorizon(contact_states);
+    }
+    void switchToWalk(const double * v6)
+    {
+      for (auto & p : parts_)
+        p->switchToWalk(v6);
+    }
+    void switchToStand()
+    {
+      for (auto & p : parts_)
+        p->switchToStand();
+    }
+    // X: [batch][nx] measured states; out: [batch][gatherRow()] rows [x1 | u0 | K0] (both caller-owned; they must stay valid until this
+    // returns).  All devices work concurrently; returns when every part is complete.
+    void iterate(const double * X, double * out)
+    {
+      const int nxin = parts_[0]->nx_in(), row = gatherRow();
+      for (int i = 0; i < parts(); i++)
+        parts_[i]->iterateAsync(X + (std::size_t)first_[i] * nxin);
+      for (int i = 0; i < parts(); i++)
+        parts_[i]->gatherOutputs(out + (std::size_t)first_[i] * row, (std::size_t)row);
+      for (auto & p : parts_)
+        p->wait();
     }
   };
 } // namespace simple_mpc

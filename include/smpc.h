@@ -205,6 +205,15 @@ int smpc_iterate(smpc_handle * h, const double * X);
 /* Same with X already resident in HBM; asynchronous on the handle's stream (pair with smpc_wait). */
 int smpc_iterate_device(smpc_handle * h, const double * X_device);
 int smpc_wait(smpc_handle * h);
+/* smpc_iterate without the final synchronisation (X must stay valid until smpc_wait): one host thread keeps several handles -- one per
+ * device, each with its share of the batch -- busy at once (include/simple-mpc/batched-mpc.hpp BatchedMPCGroup). */
+int smpc_iterate_async(smpc_handle * h, const double * X);
+/* The small return set of a control step -- xs[1], us[0], K_0 (what MPC::iterate's caller consumes: reference examples/go2_kinodynamics.py
+ * :254-292) -- of every instance of this handle as rows [x1 (nx) | u0 (nu) | K0 (nu x ndx, row-major)] of `out`, `row_doubles` (>= nx + nu
+ * + nu ndx) doubles apart.  `out` is typically one slice of a single pinned host buffer that the handles of all devices fill side by
+ * side ("async D2H into one pinned host buffer").  Asynchronous on the handle's stream: smpc_wait completes it.
+ * Kinodynamics handles. */
+int smpc_gather_outputs(smpc_handle * h, double * out, size_t row_doubles);
 /* Checkpoint / resume (the reference has none; a batched simulator needs it to roll back or migrate a batch).
  * The state is everything a later smpc_iterate depends on: iterate, multipliers, swing trajectories, references, velocity
  * commands, gait bookkeeping -- not the feedback gains of the last solve (the next iterate recomputes them).

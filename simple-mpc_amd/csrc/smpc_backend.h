@@ -154,6 +154,11 @@ namespace smpc
   {
     SMPC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
   }
+  // `height` rows of `width` bytes, source rows `spitch` bytes apart on the device, destination rows `dpitch` bytes apart on the host
+  inline void d2h_2d(void * dst, size_t dpitch, const void * src, size_t spitch, size_t width, size_t height, stream_t s)
+  {
+    SMPC_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, s));
+  }
   inline void d2d(void * dst, const void * src, size_t bytes, stream_t s)
   {
     SMPC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));

@@ -419,6 +419,24 @@ extern "C"
       return guarded([&] { h->cent->iterate_host(X); });
     return guarded([&] { h->eng->iterate_host(X); });
   }
+  int smpc_iterate_async(smpc_handle * h, const double * X)
+  {
+    if (!h || !X)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full)
+      return guarded([&] { h->full->iterate_host(X); }); // (synchronous on these handles)
+    if (h->cent)
+      return guarded([&] { h->cent->iterate_host(X); });
+    return guarded([&] { h->eng->iterate_host_async(X); });
+  }
+  int smpc_gather_outputs(smpc_handle * h, double * out, size_t row_doubles)
+  {
+    if (!h || !out)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (!h->eng)
+      return fail(SMPC_ERR_INVALID, KINO_ONLY);
+    return guarded([&] { h->eng->gather_outputs_async(out, row_doubles); });
+  }
   int smpc_iterate_device(smpc_handle * h, const double * Xd)
   {
     if (!h || !Xd)

@@ -1257,10 +1257,46 @@ namespace smpc
       iterate_device(X_dev);
       stream_sync(stream);
     }
+    // the same without the final synchronisation: X must stay valid until sync() (one host thread can then keep several devices busy)
+    void iterate_host_async(const double * X)
+    {
+      set_device(device_id);
+      h2d(X_dev, X, (size_t)B * D::NX * sizeof(double), stream);
+      iterate_device(X_dev);
+    }
     void sync()
     {
       set_device(device_id);
       stream_sync(stream);
+    }
+    // What a controller consumes of a control step -- xs[1], us[0], K_0 -- of every instance as rows [x1 (NX) | u0 (NU) | K0 (NU x NDX)] of
+    // `out`, `row_doubles` apart (the small return set of the sharded batch, gathered into ONE host buffer -- pinned by the
+    // caller for full PCIe rate -- that several handles, one per device, fill side by side).  Asynchronous: sync() completes it.
+    static constexpr int GATHER_ROW = D::NX + D::NU + D::NU * D::NDX;
+    void gather_outputs_async(double * out, size_t row_doubles)
+    {
+      set_device(device_id);
+      if (row_doubles < (size_t)GATHER_ROW)
+        throw std::runtime_error("smpc_gather_outputs: the row stride is smaller than nx + nu + nu * ndx");
+      const size_t dp = row_doubles * sizeof(double);
+      const int s1 = ring_slot(head, 1, R), s0 = ring_slot(head, 0, R);
+      d2h_2d(out, dp, buf.xs + (size_t)s1 * D::NX, (size_t)R * D::NX * sizeof(double), D::NX * sizeof(double), B, stream);
+      d2h_2d(out + D::NX, dp, buf.us + (size_t)s0 * D::NU, (size_t)R * D::NU * sizeof(double), D::NU * sizeof(double), B, stream);
+      const size_t n = (size_t)B * D::NU * D::NDX;
+      double * dev = staging(n * sizeof(double));
+      if (structured_riccati)
+      {
+        GainOutArgs<D> ga;
+        ga.b = buf;
+        ga.nt = 1;
+        ga.out = dev;
+        launch<GainOutArgs<D>, gains_out_body<D>, 64>(B, stream, ga);
+        d2h_2d(out + D::NX + D::NU, dp, dev, (size_t)D::NU * D::NDX * sizeof(double), (size_t)D::NU * D::NDX * sizeof(double), B, stream);
+      }
+      else
+        for (int i = 0; i < D::NU; i++) // dense sweep: rows of [K k] are NDX + 1 apart
+          d2h_2d(out + D::NX + D::NU + (size_t)i * D::NDX, dp, buf.gains + D::G_K + (size_t)i * (D::NDX + 1), (size_t)H * D::G_STRIDE * sizeof(double),
+                 D::NDX * sizeof(double), B, stream);
     }
     // xs[t] of every instance -> dense device buffer [B][NX], asynchronous on the engine's stream
     void gather_x_device(int t, double * out_dev)

@@ -756,6 +756,22 @@ class BatchedMPC:
     def wait(self):
         self._lib.check(self._lib.L.smpc_wait(self._h))
 
+    def iterateAsync(self, X):
+        """iterate() without the final synchronisation and without fetching the solution: X (kept alive until wait()) -> launches only.
+        With gatherOutputs / wait, one host thread drives several handles, one per device."""
+        self._x_async = np.ascontiguousarray(X, dtype=np.float64)
+        if self._x_async.shape != (self.B, self.nx_in):
+            raise RuntimeError("X must be [batch, nq + nv]")
+        self._lib.check(self._lib.L.smpc_iterate_async(self._h, self._x_async))
+
+    def gatherOutputs(self, out, first_row=0):
+        """Rows [x1 | u0 | K0] of this handle's instances into rows first_row .. first_row + batch of `out` (a C-contiguous float64 array
+        [n, nx + nu + nu ndx] -- one buffer for the handles of all devices; pinned memory for full PCIe rate).  Asynchronous: wait()."""
+        row = self.nx + self.nu + self.nu * self.ndx
+        if out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"] or out.ndim != 2 or out.shape[1] < row or out.shape[0] < first_row + self.B:
+            raise RuntimeError("out must be a C-contiguous float64 array [>= first_row + batch, >= nx + nu + nu * ndx]")
+        self._lib.check(self._lib.L.smpc_gather_outputs(self._h, C.c_void_p(out.ctypes.data + first_row * out.shape[1] * 8), out.shape[1]))
+
     def setEarlyExitOnTol(self, on=True):
         """SolverProxDDP's convergence test inside iterate (reference src/mpc.cpp:43,212): an instance converged to settings TOL at the
         start of an iteration takes no further step in that control step.  Off by default (the metric is at fixed iterations)."""

@@ -119,6 +119,40 @@ int main()
   const size_t half = mpc.xs_.size() / 2;
   for (size_t i = 0; i < half; i++)
     CHECK(mpc.xs_[i] == mpc.xs_[half + i]);
+  {
+    // the batch sharded over two handles ("devices": both may be device 0) + the gathered return set [x1 | u0 | K0] in ONE host buffer:
+    // the same rows as a single handle's outputs, instance by instance (no collective on the solve path)
+    MPCSettings gs = ms;
+    gs.T = 12;
+    BatchedMPCGroup grp(robot, ks, gs, /*batch=*/3, std::vector<int>{0, 0});
+    BatchedMPC one(robot, ks, gs, 3);
+    grp.generateCycleHorizon(contact_states);
+    one.generateCycleHorizon(contact_states);
+    CHECK(grp.parts() == 2 && grp.firstInstance(1) == 1 && grp.gatherRow() == one.nx() + one.nu() + one.nu() * one.ndx());
+    std::vector<double> X3((size_t)3 * one.nx(), 0.0);
+    for (int b = 0; b < 3; b++)
+    {
+      for (int i = 0; i < nq; i++)
+        X3[(size_t)b * one.nx() + i] = robot->q_ref[i];
+      X3[(size_t)b * one.nx() + 2] += 0.004 * b; // three different measured heights
+    }
+    std::vector<double> rows((size_t)3 * grp.gatherRow(), -1.0);
+    for (int it = 0; it < 3; it++)
+    {
+      grp.iterate(X3.data(), rows.data());
+      one.iterate(X3);
+    }
+    const int row = grp.gatherRow(), nx1 = one.nx(), nu1 = one.nu(), H1 = one.horizon();
+    for (int b = 0; b < 3; b++)
+    {
+      for (int i = 0; i < nx1; i++)
+        CHECK(rows[(size_t)b * row + i] == one.xs_[((size_t)b * (H1 + 1) + 1) * nx1 + i]);
+      for (int i = 0; i < nu1; i++)
+        CHECK(rows[(size_t)b * row + nx1 + i] == one.us_[(size_t)b * H1 * nu1 + i]);
+      for (int i = 0; i < nu1 * one.ndx(); i++)
+        CHECK(rows[(size_t)b * row + nx1 + nu1 + i] == one.K0_[(size_t)b * nu1 * one.ndx() + i]);
+    }
+  }
   // errors surface as std::runtime_error, as in the reference
   bool threw = false;
   try

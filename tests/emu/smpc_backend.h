@@ -76,6 +76,11 @@ namespace smpc
   inline void dev_free(void * p) { std::free(p); }
   inline void h2d(void * dst, const void * src, size_t bytes, stream_t) { std::memcpy(dst, src, bytes); }
   inline void d2h(void * dst, const void * src, size_t bytes, stream_t) { std::memcpy(dst, src, bytes); }
+  inline void d2h_2d(void * dst, size_t dpitch, const void * src, size_t spitch, size_t width, size_t height, stream_t)
+  {
+    for (size_t r = 0; r < height; r++)
+      std::memcpy((char *)dst + r * dpitch, (const char *)src + r * spitch, width);
+  }
   inline void d2d(void * dst, const void * src, size_t bytes, stream_t) { std::memmove(dst, src, bytes); }
   inline void dev_zero(void * dst, size_t bytes, stream_t) { std::memset(dst, 0, bytes); }
   inline void stream_sync(stream_t) {}

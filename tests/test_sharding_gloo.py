@@ -62,3 +62,32 @@ def test_two_rank_sharding_matches_single_process(built, tmp_path):
         gm.iterate(X)
         X = gm.xs[:, 1, :].copy()
     assert np.array_equal(gathered, gm.xs)
+
+
+def test_two_handles_gather_into_one_buffer():
+    """The in-process form of the sharded batch: two handles ("devices"), each with its block of instances, launched without
+    waiting, their return sets [x1 | u0 | K0] gathered into ONE host buffer -- identical to a single handle over the whole batch."""
+    import mpc_setup as S
+    import oracle_lib as O
+
+    lib = S.emu_lib()
+    parts = [S.make_product(n, max_iters=2, lib=lib, horizon=10)[0] for n in (2, 3)]
+    whole, rb, _, _ = S.make_product(5, max_iters=2, lib=lib, horizon=10)
+    for m in parts + [whole]:
+        m.generateCycleHorizon(O.trot_cycle())
+        m.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = S.random_states(rb, 5, seed=9)
+    row = whole.nx + whole.nu + whole.nu * whole.ndx
+    out = np.full((5, row), np.nan)
+    for _ in range(3):
+        parts[0].iterateAsync(X[:2])
+        parts[1].iterateAsync(X[2:])
+        parts[0].gatherOutputs(out, 0)
+        parts[1].gatherOutputs(out, 2)
+        for p in parts:
+            p.wait()
+        whole.iterate(X)
+        assert np.array_equal(out[:, : whole.nx], whole.xs[:, 1, :])
+        assert np.array_equal(out[:, whole.nx : whole.nx + whole.nu], whole.us[:, 0, :])
+        assert np.array_equal(out[:, whole.nx + whole.nu :].reshape(5, whole.nu, whole.ndx), whole.K0.reshape(5, whole.nu, whole.ndx))
+        X = whole.xs[:, 1, :].copy()

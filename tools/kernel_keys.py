@@ -5,6 +5,9 @@ KEYS = {
     "riccati_kino_body": ("riccati_kino_body", "", 4096 * 64),
     "forward_kino_body": ("forward_kino_body", "", 4096 * 64),
     "trial_body": ("10trial_body", "", 4096 * 51 * 64),
+    "lane_tree_body": ("lane_tree_body", "", 51 * 64 * 64),        # line search: lane-per-problem tree pass (64 problems per block)
+    "trial_rows_body": ("trial_rows_body", "", 4096 * 51 * 64),    # line search: rows of the candidate (block per problem)
+    "deriv2_body": ("deriv2_body", "", 4096 * 51 * 64),            # SMPC_LANE_DERIV=1 only
     "apply_body": ("apply_body", "DimsILi13ELi4EEE", 4096 * 64),
     "cent_step_body": ("cent_step_body", "", 4096 * 64),
     "fdyn_deriv_body_go2": ("fdyn_deriv_body", "FullDimsILi13E", 4096 * 51 * 64),

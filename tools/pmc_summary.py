@@ -24,6 +24,7 @@ for k in res:
     w = res[k].get("WRITE_SIZE_KiB_avg_full_batch_launch", 0)
     res[k]["hbm_bytes_per_launch_corrected"] = (2 * f + w) * 1024
 json.dump({
+    "git_commit": os.environ.get("SMPC_PROFILE_COMMIT", ""),
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
               "--no-cpu-baseline; full-batch launches only (B = 4096; Talos B = 1024, H = 100), see tools/kernel_keys.py",
     "correction": "FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section: gfx950 reports half the bytes of wide coalesced reads); "

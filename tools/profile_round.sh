@@ -1,11 +1,13 @@
 #!/bin/bash
 # Everything profiles/<tag>_* is made from, in one call on the GPU box:
-#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r01o'
-# Writes gpurun_out/<tag>_{bench,bench_centroidal}.json, <tag>_kernel_stats.csv, <tag>_pmc_hbm_traffic.json, <tag>_pmc_sq.json;
+#   gpurun --timeout 2400 -- "bash tools/profile_round.sh r03a $(git rev-parse --short HEAD)"
+# Writes gpurun_out/<tag>_{bench,bench_centroidal}.json, <tag>_kernel_stats.csv, <tag>_kernel_durations.json (full-batch launches only,
+# checked against the bench line's avg_launch_ms), <tag>_pmc_hbm_traffic.json, <tag>_pmc_sq.json, <tag>_fp64_peak.json;
 # copy them into profiles/ afterwards.  The PMC passes are separate rocprofv3 runs with --kernel-trace only (no other trace
 # domain), FETCH_SIZE and WRITE_SIZE in passes of their own (MI355X_MICROARCH.md, HBM section).
 set -u
 TAG=${1:-rXX}
+export SMPC_PROFILE_COMMIT=${2:-} # (the GPU box has no .git: pass `git rev-parse --short HEAD` of the tree that was sent)
 cd "$(dirname "$0")/.."
 ROOT=$PWD # (the program is named by an absolute path: rocprofv3 runs from /tmp)
 OUT=$ROOT/gpurun_out
@@ -13,6 +15,7 @@ mkdir -p "$OUT/prof_$TAG"
 export TMPDIR=/tmp
 BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 
+[ -x tools/micro/fp64_peak.bin ] && ./tools/micro/fp64_peak.bin 1.0 > "$OUT/${TAG}_fp64_peak.json"
 python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err" || echo "bench failed"
 tail -1 "$OUT/${TAG}_bench.json" | cut -c1-300
 python3 bench.py --workload centroidal > "$OUT/${TAG}_bench_centroidal.json" 2>> "$OUT/${TAG}_bench.err" || echo "centroidal bench failed"
@@ -31,6 +34,9 @@ run_prof sq3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU_TRANS_F64
 
 f() { find "$OUT/prof_$TAG/$1" -name "*$2" | head -1; }
 cp "$(f stats kernel_stats.csv)" "$OUT/${TAG}_kernel_stats.csv" || echo "no kernel stats"
+# durations of the full-batch launches only, from the per-dispatch trace of the same profiled command; must agree with the HIP-event
+# averages of the profiled bench line itself (the headline run above is a different process: its averages are printed beside for the eye)
+python3 tools/kernel_durations.py "$(f stats kernel_trace.csv)" "$OUT/${TAG}_kernel_durations.json" "$OUT/prof_$TAG/stats.log" || echo "DURATION CHECK FAILED"
 python3 tools/pmc_summary.py "$(f fetch counter_collection.csv)" "$(f write counter_collection.csv)" "$OUT/${TAG}_pmc_hbm_traffic.json"
 python3 tools/pmc_sq_summary.py "$OUT/${TAG}_pmc_sq.json" "$(f sq1 counter_collection.csv)" "$(f sq2 counter_collection.csv)" "$(f sq3 counter_collection.csv)"
 head -6 "$OUT/${TAG}_kernel_stats.csv" | cut -c1-60,150-260
