@@ -79,6 +79,8 @@
 
 namespace smpc
 {
+  // a double that may alias any other type: the model blocks (doubles and ints) are copied into LDS eight bytes at a time
+  typedef double __attribute__((may_alias)) alias_double;
   __device__ __forceinline__ int pin_int(int x)
   {
     asm volatile("" : "+v"(x));

@@ -316,8 +316,8 @@ namespace smpc
     SMPC_LANES(NT)
     {
       constexpr int N = (int)(sizeof(CentDevModel<D>) / sizeof(double));
-      const double * src = reinterpret_cast<const double *>(b.model);
-      double * dst = reinterpret_cast<double *>(&s.md);
+      const alias_double * src = reinterpret_cast<const alias_double *>(b.model);
+      alias_double * dst = reinterpret_cast<alias_double *>(&s.md);
       for (int i = lane; i < N; i += NT)
         dst[i] = src[i];
       if (lane < 16)

@@ -367,10 +367,9 @@ namespace smpc
     // lane-per-problem stage evaluation (smpc_kino_lane.h) for problems without optional constraint blocks; SMPC_LANE_EVAL=0: the
     // wavefront-per-problem kernels throughout (A/B comparison)
     int lane_slots = 1;
-    // SMPC_LANE_DERIV=1: the derivative pass too starts from the lane-per-problem evaluation (lane_tree_body + deriv2_body).  Measured
-    // on MI355X: the kernels themselves are faster (0.25 + 3.1 ms against 4.34 ms per launch), but the per-joint hand-over
-    // (5 KB per problem, 1 GB per launch, written as 512-byte rows scattered over 580 MB) costs 1.8 ms of HBM time -- off by default
-    bool lane_deriv = std::getenv("SMPC_LANE_DERIV") && std::atoi(std::getenv("SMPC_LANE_DERIV")) != 0;
+    // The derivative pass starts from the lane-per-problem evaluation too (lane_tree_body + deriv2_body: 0.27 + 3.1 ms per launch at
+    // B = 4096 against 4.3 - 4.7 ms for the one-kernel path); SMPC_LANE_DERIV=0: the one-kernel path (A/B comparison)
+    bool lane_deriv = !(std::getenv("SMPC_LANE_DERIV") && std::atoi(std::getenv("SMPC_LANE_DERIV")) == 0);
     bool lane_eval = !(std::getenv("SMPC_LANE_EVAL") && std::atoi(std::getenv("SMPC_LANE_EVAL")) == 0);
     double kernel_ms[KID_N] = {0};
     long kernel_calls[KID_N] = {0};
@@ -488,7 +487,7 @@ namespace smpc
       buf.lq = dalloc(BH * D::LQ_STRIDE);
       buf.gains = dalloc(BH * (size_t)std::max((int)D::G_STRIDE, (int)GainsK<D>::STRIDE));
       if (lane_eval && m.lane_slots > 0 && !ks.terminal_constraint && !ks.force_cone && !ks.land_cstr)
-        buf.ev = dalloc((((size_t)B * (H + 1) + EV_LS - 1) / EV_LS) * ev_tile_doubles<D>());
+        buf.ev = dalloc((((size_t)B + EV_LS - 1) / EV_LS) * (H + 1) * ev_tile_doubles<D>());
       buf.QN = dalloc((size_t)B * D::NDX * D::NDX);
       buf.qN = dalloc((size_t)B * D::NDX);
       buf.parts0 = dalloc((size_t)B * (H + 1) * 4);
@@ -677,7 +676,7 @@ namespace smpc
           timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, slots > 0);
         else
           timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, slots > 0);
-        timed_launch<StageKernelArgs<D>, deriv2_body<D>, 64, 2>(kid, xcd_grid(n * (H + 1)), stage_args(b, slots), slots > 0);
+        timed_launch<StageKernelArgs<D>, deriv2_body<D>, 64, 2>(kid, xcd_grid(n, H), stage_args(b, slots), slots > 0);
       }
       else if (has_ext(b))
         timed_launch<StageKernelArgs<D>, deriv_body<D, true>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
@@ -701,7 +700,7 @@ namespace smpc
           timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, aux);
         else
           timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, aux);
-        timed_launch<StageKernelArgs<D>, trial_rows_body<D>, 64>(kid, xcd_grid(n * (H + 1)), sk, aux);
+        timed_launch<StageKernelArgs<D>, trial_rows_body<D>, 64>(kid, xcd_grid(n, H), sk, aux);
       }
       else if (has_ext(b))
         timed_launch<StageKernelArgs<D>, trial_body<D, true>, 64, TRIAL_MINW>(kid, (sk.slots > 0 ? sk.slots : b.B) * (H + 1), sk, aux);

@@ -106,8 +106,8 @@ namespace smpc
   {
     constexpr int N = (int)(sizeof(FullHead<D>) / sizeof(double)), PER = (N + NT - 1) / NT;
     static_assert(sizeof(FullHead<D>) % sizeof(double) == 0, "LDS copy is done in doubles");
-    const double * src = reinterpret_cast<const double *>(static_cast<const FullHead<D> *>(gm));
-    double * d = reinterpret_cast<double *>(&dst);
+    const alias_double * src = reinterpret_cast<const alias_double *>(static_cast<const FullHead<D> *>(gm));
+    alias_double * d = reinterpret_cast<alias_double *>(&dst);
     double r[PER];
 #pragma unroll
     for (int n = 0; n < PER; n++)

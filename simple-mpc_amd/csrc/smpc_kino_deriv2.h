@@ -22,8 +22,10 @@ namespace smpc
   SMPC_DEV void deriv2_body(const StageKernelArgs<D> & ka, int block)
   {
     const int H = ka.b.H;
-    const int prob = xcd_problem(block); // (XCD-aware: see xcd_problem)
-    const int slot = prob / (H + 1), t = prob % (H + 1);
+    int slot, t;
+    xcd_problem(block, H, slot, t); // (XCD-aware: see xcd_problem)
+    if (slot >= (ka.slots > 0 ? ka.slots : ka.b.B))
+      return;
     const int count = ka.slots > 0 ? (slot < ka.slots ? ka.b.und_list[ka.b.B] : 0) : (slot < ka.b.B ? slot + 1 : 0); // (padding blocks: idle)
     const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
     for (int m = slot; m < count; m += stride)
@@ -85,6 +87,7 @@ namespace smpc
     SMPC_PL(double, lame, NT);
     SMPC_PL(double, pnu, NT);
     SMPC_PL(double, nue, NT);
+    SMPC_PLA(double, vb, NT, NLOAD);
     SMPC_LANES(NT)
     {
       // every global load of the block back to back (index clamped, one wait), then committed to LDS
@@ -97,17 +100,26 @@ namespace smpc
       const double vle = b.lams_e[(ib + st) * NDX + (lane < NDX ? lane : 0)];
       const double vne = b.vs_e[(ib + st) * NC + (lane < NC ? lane : 0)];
       const double vh = blk[L::O_head + (lane < L::HEAD ? lane : 0)];
-      double vb[NLOAD];
+      const double vxt = *((vref != nullptr && lane >= D::NQ && lane < D::NQ + 6) ? vref + (lane - D::NQ) : in.x_tgt + (lane < NX ? lane : 0));
+      const double vur = term ? 0.0 : in.u_ref[lane < NU ? lane : 0];
+      const double vfr = term ? 0.0 : in.foot_ref[lane < NF * 3 ? lane : 0];
+      // (the per-joint part of the block is issued last and committed after the row phase, which does not need it: its latency hides
+      //  behind that phase)
 #pragma unroll
       for (int n = 0; n < NLOAD; n++)
-        vb[n] = blk[L::O_S + (lane + n * NT < L::N_DERIV ? lane + n * NT : 0)];
+        SMPC_PLV(vb)[n] = blk[L::O_S + (lane + n * NT < L::N_DERIV ? lane + n * NT : 0)];
       lanes_load_model<D, NT>(sc, &mg, lane);
       if (lane < NX)
       {
         sc.x[lane] = vx;
         rs.px[lane] = vx;
         rs.pxn[lane] = vxn;
+        rs.xt[lane] = vxt;
       }
+      if (lane < NU)
+        rs.uref[lane] = vur;
+      if (lane < NF * 3)
+        rs.fref[lane] = vfr;
       else if (lane < NX + 9)
         sc.wframe_()[lane - NX] = vxn;
       if (lane < NU)
@@ -130,27 +142,6 @@ namespace smpc
       SMPC_PLV(lame) = vle;
       SMPC_PLV(pnu) = term ? 0.0 : vn;
       SMPC_PLV(nue) = vne;
-#pragma unroll
-      for (int n = 0; n < NLOAD; n++)
-      {
-        const int i = lane + n * NT;
-        if (i < N_TREE)
-          run_tree[i] = vb[n]; // S | vel | acc | Ic (= the bodies' own inertias until the composite phase)
-        else if (i < L::N_DERIV)
-        {
-          const int r = i - O_REST;
-          if (r < 9 * NF)
-            sc.oR[mg.foot_joint[r / 9] * 9 + r % 9] = vb[n];
-          else if (r < 9 * NF + 3)
-            sc.com[r - 9 * NF] = vb[n];
-          else if (r < 9 * NF + 9)
-            sc.b0[r - 9 * NF - 3] = vb[n]; // (b0 carries the base's spatial acceleration here)
-          else if (r < 9 * NF + 45)
-            sc.Agbi[r - 9 * NF - 9] = vb[n];
-          else
-            run_se3[r - 9 * NF - 45] = vb[n]; // Je3 | JeQ | Jq | Jl
-        }
-      }
     }
     SMPC_LANES_END_WAVE
     static_assert(offsetof(KinoScratchDerivPart<D>, JeQ) == offsetof(KinoScratchDerivPart<D>, Je3) + 9 * sizeof(double)
@@ -166,8 +157,33 @@ namespace smpc
     SMPC_PL(double, wres_r, NT);
     SMPC_PL(double, wru_r, NT);
     double red[3];
-    kino_rows<D, true>(rs, md, mg, sc.wframe_(), in.mask, term, in.x_tgt, vref, in.u_ref, in.foot_ref, plam, lame, pnu, nue, lamp_r, vplus_r, act_r, wres_r, wru_r, red);
+    kino_rows<D, true>(rs, md, mg, sc.wframe_(), in.mask, term, plam, lame, pnu, nue, lamp_r, vplus_r, act_r, wres_r, wru_r, red);
     if (in.prof) prof_tick(in.prof, 30, tprev);
+    SMPC_LANES(NT)
+    {
+#pragma unroll
+      for (int n = 0; n < NLOAD; n++)
+      {
+        const int i = lane + n * NT;
+        if (i < N_TREE)
+          run_tree[i] = SMPC_PLV(vb)[n]; // S | vel | acc | Ic (= the bodies' own inertias until the composite phase)
+        else if (i < L::N_DERIV)
+        {
+          const int r = i - O_REST;
+          if (r < 9 * NF)
+            sc.oR[mg.foot_joint[r / 9] * 9 + r % 9] = SMPC_PLV(vb)[n];
+          else if (r < 9 * NF + 3)
+            sc.com[r - 9 * NF] = SMPC_PLV(vb)[n];
+          else if (r < 9 * NF + 9)
+            sc.b0[r - 9 * NF - 3] = SMPC_PLV(vb)[n]; // (b0 carries the base's spatial acceleration here)
+          else if (r < 9 * NF + 45)
+            sc.Agbi[r - 9 * NF - 9] = SMPC_PLV(vb)[n];
+          else
+            run_se3[r - 9 * NF - 45] = SMPC_PLV(vb)[n]; // Je3 | JeQ | Jq | Jl
+        }
+      }
+    }
+    SMPC_LANES_END_WAVE
 
     // ---- bodies: inertia copy, accelerations for the solved base acceleration, momenta, net forces (lane = joint) ----
     SMPC_LANES(NT)

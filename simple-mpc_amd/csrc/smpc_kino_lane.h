@@ -84,8 +84,9 @@ namespace smpc
   template <class D>
   SMPC_HD LaneBlk lane_block(const Buffers<D> & b, int inst, int t)
   {
-    const size_t prob = (size_t)(b.ev_inst0 + inst) * (b.H + 1) + t;
-    return LaneBlk{b.ev + (prob / EV_LS) * ev_tile_doubles<D>() + prob % EV_LS};
+    // tile = (group of 64 consecutive instances, stage): exactly the 64 problems one wavefront of lane_tree_body evaluates
+    const size_t gi = (size_t)(b.ev_inst0 + inst);
+    return LaneBlk{b.ev + ((gi / EV_LS) * (b.H + 1) + t) * ev_tile_doubles<D>() + gi % EV_LS};
   }
   // Block index -> problem index of the wavefront-per-problem kernels that READ the tiles (one field per lane, 512 bytes apart: a
   // 64-byte sector holds the same field of 8 neighbouring problems).  The hardware deals consecutive workgroups round-robin to the 8
@@ -93,12 +94,21 @@ namespace smpc
   // fabric 8 times.  Here XCD x takes tiles x, x + 8, ... and walks the 64 problems of a tile with consecutive workgroups, so a sector
   // is fetched once and its other 7 readers hit in L2.  (n is rounded up to whole groups of 8 tiles by the launch; p >= n: idle block)
   constexpr int EV_XCDS = 8;
-  SMPC_HD int xcd_problem(int block)
+  // block -> (instance slot, stage) for a launch over n instance slots and H + 1 stages: tile = block's (q / 64) * 8 + XCD, the tile's
+  // (instance group, stage) = (tile / (H + 1), tile % (H + 1)), slot = group * 64 + q % 64
+  SMPC_HD void xcd_problem(int block, int H, int & slot, int & t)
   {
     const int q = block / EV_XCDS, x = block % EV_XCDS;
-    return ((q / EV_LS) * EV_XCDS + x) * EV_LS + q % EV_LS;
+    const int tile = (q / EV_LS) * EV_XCDS + x;
+    slot = (tile / (H + 1)) * EV_LS + q % EV_LS;
+    t = tile % (H + 1);
   }
-  SMPC_HD int xcd_grid(int n) { return ((n + EV_XCDS * EV_LS - 1) / (EV_XCDS * EV_LS)) * (EV_XCDS * EV_LS); }
+  // blocks of such a launch: whole groups of 8 tiles covering ceil(n / 64) * (H + 1) tiles (slots >= n: idle blocks)
+  SMPC_HD int xcd_grid(int n, int H)
+  {
+    const int tiles = ((n + EV_LS - 1) / EV_LS) * (H + 1);
+    return ((tiles + EV_XCDS - 1) / EV_XCDS) * EV_XCDS * EV_LS;
+  }
   SMPC_HD void st3(LaneBlk b, int o, V3 v)
   {
     b[o] = v.x;
@@ -636,7 +646,8 @@ namespace smpc
     double * head;         // 64
     double *rx, *ru;       // NDX, NU (general weight matrices: the residuals for the row products)
     double *red, *red8;    // 3 * 64, 3 * 8
-    static constexpr int N = 2 * D::NX + D::NU + 64 + D::NDX + D::NU + 3 * 64 + 3 * 8;
+    double *xt, *uref, *fref; // NX, NU, 3 NF: state target (its base-velocity part per instance), control reference, foot references
+    static constexpr int N = 2 * D::NX + D::NU + 64 + D::NDX + D::NU + 3 * 64 + 3 * 8 + D::NX + D::NU + 3 * D::NF;
     SMPC_HD explicit RowsScratch(double * base)
     {
       px = base;
@@ -647,6 +658,9 @@ namespace smpc
       ru = rx + D::NDX;
       red = ru + D::NU;
       red8 = red + 3 * 64;
+      xt = red8 + 3 * 8;
+      uref = xt + D::NX;
+      fref = uref + D::NU;
     }
   };
   template <class D>
@@ -656,8 +670,10 @@ namespace smpc
   SMPC_DEV void trial_rows_body(const StageKernelArgs<D> & ka, int block)
   {
     const int H = ka.b.H;
-    const int prob = xcd_problem(block); // (XCD-aware: see xcd_problem)
-    const int slot = prob / (H + 1), t = prob % (H + 1);
+    int slot, t;
+    xcd_problem(block, H, slot, t); // (XCD-aware: see xcd_problem)
+    if (t > H || slot >= (ka.slots > 0 ? ka.slots : ka.b.B))
+      return;
     const int count = ka.slots > 0 ? (slot < ka.slots ? ka.b.und_list[ka.b.B] : 0) : (slot < ka.b.B ? slot + 1 : 0); // (padding blocks: idle)
     const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
     for (int m = slot; m < count; m += stride)
@@ -677,8 +693,7 @@ namespace smpc
   //   lane map of the weighted residuals wres:  0 .. NDX-1 state (W r)_i | NDX .. NDX+5 W hg | NDX+6 .. NDX+11 W hd | NDX+12 .. +3NF W rf
   //   wru (lane < NU): (W_u r_u)_i
   template <class D, bool OUT, class Sc>
-  SMPC_DEV void kino_rows(const Sc & sc, const DevModelSmall<D> & md, const DevModel<D> & mg, const double * wframe, unsigned mask, bool term, const double * x_tgt, const double * vref, const double * u_ref,
-                          const double * foot_ref, SMPC_PL_REF(double, plam_, 64), SMPC_PL_REF(double, lam_e_, 64), SMPC_PL_REF(double, pnu_, 64),
+  SMPC_DEV void kino_rows(const Sc & sc, const DevModelSmall<D> & md, const DevModel<D> & mg, const double * wframe, unsigned mask, bool term, SMPC_PL_REF(double, plam_, 64), SMPC_PL_REF(double, lam_e_, 64), SMPC_PL_REF(double, pnu_, 64),
                           SMPC_PL_REF(double, nu_e_, 64), SMPC_PL_REF(double, lamp_, 64), SMPC_PL_REF(double, vplus_, 64), SMPC_PL_REF(int, act_, 64),
                           SMPC_PL_REF(double, wres_, 64), SMPC_PL_REF(double, wru_, 64), double * red);
 
@@ -725,11 +740,20 @@ namespace smpc
       const double vle = b.lams_e[(ib + st) * NDX + (lane < NDX ? lane : 0)];
       const double vne = b.vs_e[(ib + st) * NC + (lane < NC ? lane : 0)];
       const double vh = blk[L::O_head + j * L::HEAD + (lane < L::HEAD ? lane : 0)];
+      // state target: shared pose part, per-instance base-velocity part (address select, one load); control and foot references
+      const double vxt = *((vref != nullptr && lane >= D::NQ && lane < D::NQ + 6) ? vref + (lane - D::NQ) : x_tgt + (lane < NX ? lane : 0));
+      const double vur = term ? 0.0 : u_ref[lane < NU ? lane : 0];
+      const double vfr = term ? 0.0 : foot_ref[lane < NF * 3 ? lane : 0];
       if (lane < NX)
       {
         sc.px[lane] = vx + alpha * vdx;
         sc.pxn[lane] = vxn + alpha * vdxn;
+        sc.xt[lane] = vxt;
       }
+      if (lane < NU)
+        sc.uref[lane] = vur;
+      if (lane < NF * 3)
+        sc.fref[lane] = vfr;
       if (lane < NU)
         sc.pu[lane] = term ? 0.0 : vu + alpha * vdu;
       sc.head[lane] = vh;
@@ -742,7 +766,7 @@ namespace smpc
     double red[3];
     SMPC_PL(double, dmy, NT);
     SMPC_PL(int, dmyi, NT);
-    kino_rows<D, false>(sc, mg, mg, mg.w_frame, mask, term, x_tgt, vref, u_ref, foot_ref, plam, lame, pnu, nue, dmy, dmy, dmyi, dmy, dmy, red);
+    kino_rows<D, false>(sc, mg, mg, mg.w_frame, mask, term, plam, lame, pnu, nue, dmy, dmy, dmyi, dmy, dmy, red);
     double * parts = b.partsT + (((size_t)inst * D::LS_N + j) * (H + 1) + t) * 2;
     SMPC_LANES(NT)
     {
@@ -762,8 +786,7 @@ namespace smpc
   }
 
   template <class D, bool OUT, class Sc>
-  SMPC_DEV void kino_rows(const Sc & sc, const DevModelSmall<D> & md, const DevModel<D> & mg, const double * wframe, unsigned mask, bool term, const double * x_tgt, const double * vref, const double * u_ref,
-                          const double * foot_ref, SMPC_PL_REF(double, plam_, 64), SMPC_PL_REF(double, lam_e_, 64), SMPC_PL_REF(double, pnu_, 64),
+  SMPC_DEV void kino_rows(const Sc & sc, const DevModelSmall<D> & md, const DevModel<D> & mg, const double * wframe, unsigned mask, bool term, SMPC_PL_REF(double, plam_, 64), SMPC_PL_REF(double, lam_e_, 64), SMPC_PL_REF(double, pnu_, 64),
                           SMPC_PL_REF(double, nu_e_, 64), SMPC_PL_REF(double, lamp_, 64), SMPC_PL_REF(double, vplus_, 64), SMPC_PL_REF(int, act_, 64),
                           SMPC_PL_REF(double, wres_, 64), SMPC_PL_REF(double, wru_, 64), double * red)
   {
@@ -780,9 +803,9 @@ namespace smpc
       {
         if (lane < NDX)
           sc.rx[lane] = lane < 6 ? sc.head[L::H_rb + lane]
-                                 : sc.px[lane + 1] - ((vref != nullptr && lane >= NV && lane < NV + 6) ? vref[lane - NV] : x_tgt[lane + 1]);
+                                 : sc.px[lane + 1] - sc.xt[lane + 1];
         if (!term && lane < NU)
-          sc.ru[lane] = sc.pu[lane] - u_ref[lane];
+          sc.ru[lane] = sc.pu[lane] - sc.uref[lane];
       }
       SMPC_LANES_END_WAVE
     }
@@ -816,7 +839,7 @@ namespace smpc
       {
         const int i = lane;
         const double r = i < 6 ? sc.head[L::H_rb + i]
-                               : sc.px[i + 1] - ((vref != nullptr && i >= NV && i < NV + 6) ? vref[i - NV] : x_tgt[i + 1]);
+                               : sc.px[i + 1] - sc.xt[i + 1];
         if (wdiag)
           wres = md.wxd[i] * r;
         else
@@ -853,16 +876,16 @@ namespace smpc
         const int i = lane - NDX - 12, f = i / 3, r = i % 3;
         double s = 0.0;
         for (int k = 0; k < 3; k++)
-          s += wframe[r * 3 + k] * (sc.head[L::H_footp + f * 3 + k] - foot_ref[f * 3 + k]);
+          s += wframe[r * 3 + k] * (sc.head[L::H_footp + f * 3 + k] - sc.fref[f * 3 + k]);
         wres = s;
-        cost = (sc.head[L::H_footp + i] - foot_ref[i]) * s;
+        cost = (sc.head[L::H_footp + i] - sc.fref[i]) * s;
       }
       if constexpr (OUT)
         SMPC_PLV(wres_) = wres;
       // ---- control residual (lane < NU) ----
       if (!term && lane < NU)
       {
-        const double r = sc.pu[lane] - u_ref[lane];
+        const double r = sc.pu[lane] - sc.uref[lane];
         double wr;
         if (wdiag)
           wr = md.wud[lane] * r;

@@ -144,8 +144,8 @@ namespace smpc
   {
     constexpr int N = (int)(sizeof(DevModelSmall<D>) / sizeof(double)), PER = (N + NT - 1) / NT;
     static_assert(sizeof(DevModelSmall<D>) % sizeof(double) == 0, "LDS copy is done in doubles");
-    const double * src = reinterpret_cast<const double *>(static_cast<const DevModelSmall<D> *>(gm));
-    double * dst = reinterpret_cast<double *>(&sc.ml);
+    const alias_double * src = reinterpret_cast<const alias_double *>(static_cast<const DevModelSmall<D> *>(gm));
+    alias_double * dst = reinterpret_cast<alias_double *>(&sc.ml);
     double r[PER]; // all loads in flight before the first store (a rolled loop would serialise the latencies)
 #pragma unroll
     for (int n = 0; n < PER; n++)

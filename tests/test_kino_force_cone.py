@@ -79,9 +79,12 @@ def test_emulated_kernels_with_active_cones(built):
     assert _loop(om, gm, S.random_states(rb, 2), 8, 1e-5) >= 10  # (instance 1 backtracks to alpha = 1 / 128 on the way)
 
 
-def test_emulated_kernels_inactive_cones_change_nothing(built):
-    # a gentle forward trot never reaches a cone of mu = 0.8: the result is the cone-free one, bit for bit
+def test_emulated_kernels_inactive_cones_change_nothing(built, monkeypatch):
+    # a gentle forward trot never reaches a cone of mu = 0.8: the result is the cone-free one, bit for bit -- of the same kernels (problems
+    # with optional constraint blocks run on the one-kernel stage path, SMPC_LANE_EVAL=0 puts the cone-free problem there too)
+    monkeypatch.setenv("SMPC_LANE_EVAL", "0")
     g0, rb, _, _ = S.make_product(1, 2, lib=S.emu_lib(), horizon=20)
+    monkeypatch.delenv("SMPC_LANE_EVAL")
     g1, _, _, _ = S.make_product(1, 2, lib=S.emu_lib(), horizon=20, settings_override={"force_cone": True, "mu": 0.8})
     X = S.random_states(rb, 1)
     for g in (g0, g1):

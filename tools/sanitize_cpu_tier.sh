@@ -4,7 +4,7 @@
 # GPU sanitizers are not available on the pool: the same bodies compiled for gfx950 share every index expression with this build.
 set -u
 cd "$(dirname "$0")/.."
-g++ -O1 -g -fno-strict-aliasing -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -fPIC -fopenmp -shared -Itests/emu -Isimple-mpc_amd/csrc -Iinclude \
+g++ -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -fPIC -fopenmp -shared -Itests/emu -Isimple-mpc_amd/csrc -Iinclude \
   -Wno-unknown-pragmas simple-mpc_amd/csrc/smpc_capi.cpp -o tests/emu/libsmpc_emu.so || exit 1
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 \
   UBSAN_OPTIONS=print_stacktrace=1 OMP_NUM_THREADS=4 python -m pytest tests -q -m "not gpu" > /tmp/smpc_sanitize.log 2>&1
