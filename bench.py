@@ -106,13 +106,23 @@ def rooflines(kt, B, H, ndx, nu, nc, nx, at_record_size):
     knot_w = 8 * (q_upper + ndx * nfc + nfc * nfc + na + (nc - na) * ndx + na + 12 * (ndx + nu) + 4 * ndx + 2 * nu + 2 * nc)
     iter_r = 8 * (nx + nu + 2 * nc + 4 * ndx)
     if "deriv" in kt and kt["deriv"][1]:
-        avg = kt["deriv"][0] / kt["deriv"][1] * 1e-3
+        # the derivative pass of a launch = lane_tree_body (lane-per-problem evaluation, hand-over) + deriv2_body (wavefront per problem);
+        # SMPC_LANE_DERIV=0: deriv_body alone ("tree" then only counts the line-search launches)
+        two = kt.get("tree", (0.0, 0))[1] > kt.get("trial", (0.0, 0))[1]
+        avg2 = kt["deriv"][0] / kt["deriv"][1] * 1e-3
+        avgt = kt["tree"][0] / kt["tree"][1] * 1e-3 if two else 0.0
+        avg = avg2 + avgt
         fl = fc.get("deriv_flops_per_stage")
-        e = both_bounds(None if fl is None else B * H * fl, B * H * (knot_w + iter_r), avg, "mfma")
-        tr, src = pmc_traffic("deriv_body", at_record_size)
-        e.update({"kernel": "deriv_body (stage evaluation + derivatives + LQ knot)", "traffic": tr, "traffic_source": src,
+        ho = 8 * 619 if two else 0  # hand-over block written by the tree pass and read by the derivative kernel (EvLayout)
+        e = both_bounds(None if fl is None else B * H * fl, B * H * (knot_w + iter_r + 2 * ho), avg, "mfma")
+        kname = "deriv2_body" if two else "deriv_body"
+        tr, src = pmc_traffic(kname, at_record_size)
+        tr2, _ = pmc_traffic("lane_tree_body", at_record_size) if two else (0.0, None)
+        e.update({"kernel": ("derivative pass = lane_tree_body + deriv2_body" if two else "deriv_body") + " (stage evaluation + derivatives + LQ knot)",
+                  "avg_launch_ms_parts": {"lane_tree_body": avgt * 1e3, kname: avg2 * 1e3},
+                  "traffic": None if tr is None else tr + (tr2 or 0.0), "traffic_source": src,
                   "note": "FP64 bound: algorithmic FLOPs of one stage evaluation + derivative + Gauss-Newton assembly counted by "
-                          "instrumentation in the oracle (profiles/flop_counts.json) x B*H; HBM side: B*H*%d bytes per launch" % (knot_w + iter_r)})
+                          "instrumentation in the oracle (profiles/flop_counts.json) x B*H; HBM side: B*H*%d bytes per launch" % (knot_w + iter_r + 2 * ho)})
         out["deriv"] = e
     if "riccati" in kt and kt["riccati"][1]:
         avg = kt["riccati"][0] / kt["riccati"][1] * 1e-3
@@ -755,7 +765,8 @@ def main():
             out["kernel_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}
             out["kernel_share"] = {k: round(v[0] / max(1e-9, sum(x[0] for x in kt.values())), 3) for k, v in kt.items()}
             rl = rooflines(kt, B, H, ndx, nu, nc, gm.nx, B == 4096 and args.iters == 3)
-            dom = max(rl, key=lambda k: kt[k][0])  # dominant kernel = largest share of the timed region
+            share = {k: kt[k][0] + (kt.get("tree", (0.0, 0))[0] if k == "deriv" else 0.0) for k in rl}
+            dom = max(rl, key=lambda k: share[k])  # dominant kernel (pass) = largest share of the timed region
             if args.streams == 1:
                 out["roofline"] = rl[dom]
                 out["roofline_other"] = {k: v for k, v in rl.items() if k != dom}

@@ -167,6 +167,7 @@ namespace smpc
     KID_TRIAL,
     KID_SELECT,
     KID_APPLY,
+    KID_TREE, // lane-per-problem tree pass (smpc_kino_lane.h) of the full-batch derivative / line-search launches
     KID_N
   };
 
@@ -671,11 +672,11 @@ namespace smpc
         la.j0 = la.nj = 0;
         la.slots = slots;
         la.deriv = 1;
-        const int n = slots > 0 ? slots : b.B, kid = slots > 0 ? KID_SELECT : KID_DERIV;
+        const int n = slots > 0 ? slots : b.B, kid = slots > 0 ? KID_SELECT : KID_DERIV, kid_tree = slots > 0 ? KID_SELECT : KID_TREE;
         if (lane_slots == 1)
-          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, slots > 0);
+          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid_tree, (H + 1) * ((n + 63) / 64), la, slots > 0);
         else
-          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, slots > 0);
+          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid_tree, (H + 1) * ((n + 63) / 64), la, slots > 0);
         timed_launch<StageKernelArgs<D>, deriv2_body<D>, 64, 2>(kid, xcd_grid(n, H), stage_args(b, slots), slots > 0);
       }
       else if (has_ext(b))
@@ -695,11 +696,11 @@ namespace smpc
         la.nj = sk.nj;
         la.slots = sk.slots;
         la.deriv = 0;
-        const int n = sk.slots > 0 ? sk.slots : b.B;
+        const int n = sk.slots > 0 ? sk.slots : b.B, kid_tree = kid == KID_TRIAL ? KID_TREE : kid;
         if (lane_slots == 1)
-          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, aux);
+          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid_tree, (H + 1) * ((n + 63) / 64), la, aux);
         else
-          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid, (H + 1) * ((n + 63) / 64), la, aux);
+          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid_tree, (H + 1) * ((n + 63) / 64), la, aux);
         timed_launch<StageKernelArgs<D>, trial_rows_body<D>, 64>(kid, xcd_grid(n, H), sk, aux);
       }
       else if (has_ext(b))
