@@ -19,7 +19,7 @@
 //   wrench, and with force_cone every foot in contact adds MultibodyWrenchConeResidual rows in the negative orthant
 //   [REF src/fulldynamics.cpp:163-173]: 17 linear rows A_cone lam (unilaterality, friction pyramid, centre of pressure inside
 //   the sole, yaw torque bounds; [UPSTREAM-RECALL] Aligator's wrench-cone matrix after Caron et al. 2015), rows after the boxes.
-// land_cstr rows [REF :175-209] and the friction cone of 3-D feet [REF :185-190] are not restated.
+// land_cstr rows [REF :175-209] are not restated.
 // StageRef::u_ref carries [control reference (nu) ; force reference per foot (force_size nf)] for this model.
 #pragma once
 #include "orc_full.hpp"
@@ -72,7 +72,10 @@ namespace orc
       nu = nv - 6;
       nf = m->nfeet;
       fs = st.force_size;
-      ncone1 = (fs == 6 && st.force_cone) ? 17 : 0;
+      // force_cone: 17 wrench-cone rows per 6-D foot [REF src/fulldynamics.cpp:163-173]; 5 friction-pyramid rows per 3-D foot (MultibodyFrictionConeResidual
+      // [REF :185-190]; [UPSTREAM-RECALL] its 5 x 3 matrix: unilaterality and +-f_x, +-f_y <= mu f_z on the contact force in the contact's frame =
+      // rows 0 .. 4 / columns 0 .. 2 of the wrench-cone matrix)
+      ncone1 = st.force_cone ? (fs == 6 ? 17 : 5) : 0;
       nc = nu + (nv - 6) + ncone1 * nf;
       Acone = wrench_cone_matrix(st.mu, st.Lfoot, st.Wfoot);
     }
@@ -82,7 +85,7 @@ namespace orc
         return s.torque_limits ? ROW_BOX : ROW_ABSENT;
       if (row < 2 * nu)
         return s.kinematics_limits ? ROW_BOX : ROW_ABSENT;
-      return ((r.mask >> ((row - 2 * nu) / 17)) & 1u) ? ROW_NEG : ROW_ABSENT; // wrench cone of a foot in contact
+      return ((r.mask >> ((row - 2 * nu) / ncone1)) & 1u) ? ROW_NEG : ROW_ABSENT; // cone rows of a foot in contact
     }
     double row_lo_v(int row) const { return row < nu ? s.umin[row] : s.qmin[row - nu]; }
     double row_hi_v(int row) const { return row < nu ? s.umax[row] : s.qmax[row - nu]; }
@@ -160,12 +163,12 @@ namespace orc
       for (size_t c = 0; c < cd.feet.size() && ncone1 > 0; c++)
       {
         const int f = cd.feet[c];
-        for (int i = 0; i < 17; i++)
+        for (int i = 0; i < ncone1; i++)
         {
           double acc = 0;
-          for (int j = 0; j < 6; j++)
-            acc += Acone(i, j) * cd.lam[6 * c + j];
-          o.c[2 * nu + 17 * f + i] = acc;
+          for (int j = 0; j < fs; j++)
+            acc += Acone(i, j) * cd.lam[fs * c + j];
+          o.c[2 * nu + ncone1 * f + i] = acc;
         }
       }
       if (s.torque_limits)
@@ -347,21 +350,21 @@ namespace orc
       for (size_t c = 0; c < cd.feet.size() && ncone1 > 0; c++)
       { // wrench cone rows: A_cone * d lam / d(x, u)
         const int f = cd.feet[c];
-        for (int i = 0; i < 17; i++)
+        for (int i = 0; i < ncone1; i++)
         {
-          const int row = 2 * nu + 17 * f + i;
-          for (int j = 0; j < 6; j++)
+          const int row = 2 * nu + ncone1 * f + i;
+          for (int j = 0; j < fs; j++)
           {
             const double aij = Acone(i, j);
             if (aij == 0.0)
               continue;
             for (int k = 0; k < nv; k++)
             {
-              o.Cx(row, k) += aij * cd.dlam_dq(6 * (int)c + j, k);
-              o.Cx(row, nv + k) += aij * cd.dlam_dv(6 * (int)c + j, k);
+              o.Cx(row, k) += aij * cd.dlam_dq(fs * (int)c + j, k);
+              o.Cx(row, nv + k) += aij * cd.dlam_dv(fs * (int)c + j, k);
             }
             for (int k = 0; k < nu; k++)
-              o.Cu(row, k) += aij * cd.dlam_dtau(6 * (int)c + j, k);
+              o.Cu(row, k) += aij * cd.dlam_dtau(fs * (int)c + j, k);
           }
         }
       }

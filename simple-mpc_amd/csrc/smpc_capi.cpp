@@ -16,6 +16,7 @@ typedef Dims<13, 4> DimsGo2; // free-flyer + 12 revolute joints, 4 point feet
 typedef CentDims<4> CentGo2;
 typedef CentEngine<DimsGo2, CentGo2> CentEngineGo2;
 typedef FullDims<13, 4, 3> FullGo2;   // full dynamics: 12 joint torques, 3-D contacts
+typedef FullDims<13, 4, 3, 5> FullGo2Cone; // the same with force_cone: 5 friction-pyramid rows per foot in contact
 typedef FullDims<23, 2, 6> FullTalos; // Talos-class humanoid: 22 joint torques, two 6-D feet with wrench cones
 
 struct smpc_handle
@@ -236,7 +237,9 @@ extern "C"
     const HostMpcSettings ms = host_mpc(mpc);
     return guarded([&] {
       std::unique_ptr<smpc_handle> h(new smpc_handle());
-      if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS)
+      if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS && s.force_cone)
+        h->full.reset(new FullEngine<FullGo2Cone>(robot, s, ms, batch, gravity_arg, device_id));
+      else if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS)
         h->full.reset(new FullEngine<FullGo2>(robot, s, ms, batch, gravity_arg, device_id));
       else if (robot->njoints == FullTalos::NJ && robot->nfeet == FullTalos::NF && fs == FullTalos::FS)
         h->full.reset(new FullEngine<FullTalos>(robot, s, ms, batch, gravity_arg, device_id));

@@ -108,8 +108,10 @@ namespace smpc
           || (int)fs.w_forces.size() != D::FS * D::FS || (int)fs.w_frame.size() != D::FS * D::FS || (int)fs.umin.size() != D::NU
           || (int)fs.umax.size() != D::NU || (int)fs.qmin.size() != D::NA || (int)fs.qmax.size() != D::NA)
         throw std::runtime_error("full-dynamics settings: weight / limit sizes do not match the robot");
-      if (fs.land_cstr || (fs.force_cone && D::FS == 3))
-        throw std::runtime_error("land_cstr / friction-cone rows of 3-D feet are not built yet");
+      if (fs.land_cstr)
+        throw std::runtime_error("land_cstr rows of the full-dynamics OCP are not built yet");
+      if (fs.force_cone && D::NCONE1 == 0)
+        throw std::runtime_error("internal: force_cone needs the instantiation with cone rows");
       device_id = device;
       set_device(device);
       stream = stream_create();

@@ -6,7 +6,8 @@
 //   constraint rows per stage (NC):  [ torque box (nu) | joint box (nv - 6) | cone rows on the contact forces (NCONE) ]
 //     - the two box blocks are unit selectors on u / x: they enter the stage KKT as diagonal terms and are never stored
 //       as matrices
-//     - the cone rows (6-D feet with force_cone: 17 rows per foot, src/fulldynamics.cpp:163-173) are dense in x and u
+//     - the cone rows (force_cone: 17 wrench-cone rows per 6-D foot, src/fulldynamics.cpp:163-173; 5 friction-pyramid rows per 3-D
+//       foot, :185-190) are dense in x and u
 //       (through the contact-force derivatives): blocks Cd (NCONE x NDX) and Dd (NCONE x NU) of the knot
 // FS = force size: 3 (point feet, CONTACT_3D LOCAL) or 6 (quad feet, CONTACT_6D LOCAL_WORLD_ALIGNED), src/fulldynamics.cpp:56-75.
 //
@@ -17,7 +18,9 @@
 
 namespace smpc
 {
-  template <int NJ_, int NF_, int FS_>
+  // CN_: cone rows per 3-D foot (0: none -- the instantiation of the Go2 example of record, force_cone = false; 5: the friction
+  // pyramid of MultibodyFrictionConeResidual, src/fulldynamics.cpp:185-190); 6-D feet always carry their 17 wrench-cone rows
+  template <int NJ_, int NF_, int FS_, int CN_ = 0>
   struct FullDims
   {
     static constexpr int NJ = NJ_;     // joints incl. free-flyer
@@ -31,7 +34,7 @@ namespace smpc
     static constexpr int NU = NA;
     static constexpr int PF = FS_;                            // size of a foot-pose residual: translation (3) or log6 placement (6)
     static constexpr int NCM = FS_ * NF_;                     // contact rows when every foot is in contact
-    static constexpr int NCONE1 = FS_ == 6 ? 17 : 0;          // cone rows per foot (wrench cone, 6-D feet)
+    static constexpr int NCONE1 = FS_ == 6 ? 17 : CN_;        // cone rows per foot (wrench cone of 6-D feet / friction pyramid of 3-D feet)
     static constexpr int NCONE = NCONE1 * NF_;
     static constexpr int NC = NU + NA + NCONE;
     static constexpr int NXU = NDX + NU;
@@ -95,16 +98,16 @@ namespace smpc
     double w_u[D::NU * D::NU];
     double x_term[D::NX];
   };
-  template <int NJ_, int NF_, int FS_>
-  struct DevModel<FullDims<NJ_, NF_, FS_>> : FullDevModel<FullDims<NJ_, NF_, FS_>>
+  template <int NJ_, int NF_, int FS_, int CN_>
+  struct DevModel<FullDims<NJ_, NF_, FS_, CN_>> : FullDevModel<FullDims<NJ_, NF_, FS_, CN_>>
   {
   };
 
   // stage descriptor shared by the phase-aligned batch
-  template <int NJ_, int NF_, int FS_>
-  struct StageShared<FullDims<NJ_, NF_, FS_>>
+  template <int NJ_, int NF_, int FS_, int CN_>
+  struct StageShared<FullDims<NJ_, NF_, FS_, CN_>>
   {
-    typedef FullDims<NJ_, NF_, FS_> D;
+    typedef FullDims<NJ_, NF_, FS_, CN_> D;
     unsigned mask;
     unsigned pad;
     double u_ref[D::NU];   // control reference (zero in the reference's stages, src/fulldynamics.cpp:89)

@@ -896,7 +896,7 @@ namespace smpc
           if (h.force_cone && ((mask >> f) & 1u))
           {
             const int c = __builtin_popcount(mask & ((1u << f) - 1u));
-            for (int j = 0; j < 6; j++)
+            for (int j = 0; j < FS; j++) // (3-D feet: rows 0 .. 4 and columns 0 .. 2 of the wrench cone = the friction pyramid on the force)
               acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * sc.lam[c * FS + j];
           }
           sc.cval[NU + NA + i] = acc;
@@ -1986,8 +1986,8 @@ namespace smpc
         if (sc.act[NU + NA + i])
         {
           const int c = __builtin_popcount(mask & ((1u << f) - 1u));
-          for (int j = 0; j < 6; j++)
-            acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * sd.JT[(6 * c + j) * NCOL + k];
+          for (int j = 0; j < D::FS; j++)
+            acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * sd.JT[(D::FS * c + j) * NCOL + k];
         }
         if (k < NDX)
           lq[D::O_C + i * NDX + k] = acc;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Golden vectors of the full-dynamics path (tests/golden/go2_full_golden.npz, talos_full_golden.npz), produced by the CPU
+"""Golden vectors of the full-dynamics path (tests/golden/go2_full_golden.npz, talos_full_golden.npz, go2_full_cone_golden.npz), produced by the CPU
 oracle in the build container (the reference cannot be built or imported here):
 
     python tests/golden/make_golden_fulldyn.py
@@ -82,5 +82,20 @@ def main():
     print("talos: wrote", len(out), "arrays")
 
 
+def cone():
+    """Go2 with force_cone (five friction-pyramid rows per foot in contact, round 3): H = 20, k = 2, 6 control steps, mu = 0.6"""
+    out = {}
+    rb = O.Robot("go2_like")
+    om, _ = S.make_full_oracle(2, max_iters=2, horizon=20, walk=(0.3, 0.1, 0, 0, 0, 0.2), settings_override={"force_cone": True, "mu": 0.6})
+    loop(out, "cone", om, rb, S.random_states(rb, 2), 6)
+    out["cone_vs"] = om.vs
+    np.savez_compressed(os.path.join(HERE, "go2_full_cone_golden.npz"), **out)
+    print("go2 cone: wrote", len(out), "arrays; active cone rows", int((om.vs[:, :, 24:] != 0).sum()))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "cone":
+        cone()
+    else:
+        main()
+        cone()

@@ -12,6 +12,7 @@ import oracle_lib as O
 HERE = os.path.dirname(os.path.abspath(__file__))
 G2 = np.load(os.path.join(HERE, "golden", "go2_full_golden.npz"))
 GT = np.load(os.path.join(HERE, "golden", "talos_full_golden.npz"))
+GC = np.load(os.path.join(HERE, "golden", "go2_full_cone_golden.npz"))
 TOL = 1e-4
 TALOS_SHORT = dict(horizon=20, cycle=O.walk_cycle(5, 20), mpc_override=dict(T_fly=20, T_contact=5))
 TIGHT = dict(mu=0.3, Lfoot=0.05, Wfoot=0.04)
@@ -86,3 +87,26 @@ def test_hip_reproduces_go2_closed_loop(built, k):
 @pytest.mark.parametrize("tag", ["loop", "cone"])
 def test_hip_reproduces_talos_closed_loop(built, tag):
     _talos(tag, None)
+
+
+def _go2_cone(lib):
+    """Go2 with friction-pyramid rows (force_cone, 3-D feet): replay of the committed closed loop"""
+    gm, rb, _, _ = S.make_full_product(2, 2, lib, 20, settings_override={"force_cone": True, "mu": 0.6})
+    gm.generateCycleHorizon(O.trot_cycle())
+    gm.switchToWalk(np.array([0.3, 0.1, 0, 0, 0, 0.2]))
+    assert S.rel_err(GC["cone_cold_xs"], gm.xs[0]) < TOL
+    X = GC["cone_X0"]
+    for _ in range(6):
+        gm.iterate(X)
+        X = gm.xs[:, 1, :].copy()
+    assert S.rel_err(GC["cone_xs"], gm.xs) < TOL and S.rel_err(GC["cone_us"], gm.us) < 10 * TOL
+    assert np.array_equal(GC["cone_vs"][:, :, 24:] != 0, gm.vs[:, :, 24:] != 0)  # the same rows are active
+
+
+def test_emulated_kernels_reproduce_go2_cone_closed_loop(built):
+    _go2_cone(S.emu_lib())
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_go2_cone_closed_loop(built):
+    _go2_cone(None)
