@@ -404,6 +404,14 @@ extern "C"
     return new FullModel(m, s);
   }
   void orc_full_destroy(void * h) { delete (FullModel *)h; }
+  // land_cstr rows of the full-dynamics stage (frame velocity / height of a landing foot): rebuilds the model with the switch
+  void orc_full_set_land_cstr(void * h, int on)
+  {
+    FullModel * md = (FullModel *)h;
+    FullSettings s = md->s;
+    s.land_cstr = on != 0;
+    *md = FullModel(md->M, s);
+  }
   void orc_full_dims(void * h, int * out) // nx ndx nu nc nf
   {
     FullModel * md = (FullModel *)h;
@@ -416,7 +424,8 @@ extern "C"
   static StageRef full_ref(const FullModel & md, unsigned mask, const double * u_ref, const double * x_tgt, const double * foot_ref)
   {
     StageRef r;
-    r.mask = mask;
+    r.mask = mask & 0xFFu;        // bits 0-7: feet in contact ; bits 8-15: feet that land at this stage (as make_ref)
+    r.land = (mask >> 8) & 0xFFu;
     r.u_ref.assign(u_ref, u_ref + md.n_uref()); // [control reference ; force reference per foot]
     r.x_tgt.assign(x_tgt, x_tgt + md.nx);
     r.foot_ref.resize(md.nf);

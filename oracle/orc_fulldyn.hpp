@@ -34,7 +34,7 @@ namespace orc
     double gravity[3] = {0, 0, -9.81};
     double mu = 0.8, Lfoot = 0.1, Wfoot = 0.075;
     int force_size = 3;
-    bool torque_limits = true, kinematics_limits = true, force_cone = false;
+    bool torque_limits = true, kinematics_limits = true, force_cone = false, land_cstr = false;
     Vec umin, umax, qmin, qmax;
     double Kp[6] = {0, 0, 0, 0, 0, 0}, Kd[6] = {0, 0, 0, 0, 0, 0};
   };
@@ -60,8 +60,9 @@ namespace orc
   {
     const smpc_robot_model * M;
     FullSettings s;
-    int nq, nv, nx, ndx, nu, nf, nc, fs, ncone1;
+    int nq, nv, nx, ndx, nu, nf, nc, fs, ncone1, nland1;
     Mat Acone;
+    std::vector<double> land_z; // height of the contact poses the cycle stages are created with: feet at the reference state
 
     FullModel(const smpc_robot_model * m, const FullSettings & st) : M(m), s(st)
     {
@@ -76,16 +77,31 @@ namespace orc
       // [REF :185-190]; [UPSTREAM-RECALL] its 5 x 3 matrix: unilaterality and +-f_x, +-f_y <= mu f_z on the contact force in the contact's frame =
       // rows 0 .. 4 / columns 0 .. 2 of the wrench-cone matrix)
       ncone1 = st.force_cone ? (fs == 6 ? 17 : 5) : 0;
-      nc = nu + (nv - 6) + ncone1 * nf;
+      // land_cstr: a foot that lands at this stage keeps a zero LOCAL_WORLD_ALIGNED frame velocity (6 rows of a 6-D foot [REF :175-181]; the 3
+      // linear rows of a 3-D foot and the height of the contact pose, FrameTranslationResidual sliced to z [REF :191-210]); equality rows
+      nland1 = st.land_cstr ? (fs == 6 ? 6 : 4) : 0;
+      nc = nu + (nv - 6) + ncone1 * nf + nland1 * nf;
       Acone = wrench_cone_matrix(st.mu, st.Lfoot, st.Wfoot);
+      if (st.land_cstr)
+      {
+        Rigid R(m);
+        Vec q(m->q_ref, m->q_ref + nq);
+        R.fk(q.data());
+        land_z.resize(nf);
+        for (int f = 0; f < nf; f++)
+          land_z[f] = R.foot_p[f][2];
+      }
     }
+    int land_base() const { return 2 * nu + ncone1 * nf; }
     int row_kind(const StageRef & r, int row) const
     {
       if (row < nu)
         return s.torque_limits ? ROW_BOX : ROW_ABSENT;
       if (row < 2 * nu)
         return s.kinematics_limits ? ROW_BOX : ROW_ABSENT;
-      return ((r.mask >> ((row - 2 * nu) / ncone1)) & 1u) ? ROW_NEG : ROW_ABSENT; // cone rows of a foot in contact
+      if (row < land_base())
+        return ((r.mask >> ((row - 2 * nu) / ncone1)) & 1u) ? ROW_NEG : ROW_ABSENT; // cone rows of a foot in contact
+      return (((r.land & r.mask) >> ((row - land_base()) / nland1)) & 1u) ? ROW_EQ : ROW_ABSENT; // rows of a landing foot
     }
     double row_lo_v(int row) const { return row < nu ? s.umin[row] : s.qmin[row - nu]; }
     double row_hi_v(int row) const { return row < nu ? s.umax[row] : s.qmax[row - nu]; }
@@ -171,6 +187,21 @@ namespace orc
           o.c[2 * nu + ncone1 * f + i] = acc;
         }
       }
+      for (int f = 0; f < nf && nland1 > 0; f++)
+        if (((r.land & r.mask) >> f) & 1u)
+        {
+          const int j = M->foot_joint[f], row = land_base() + nland1 * f;
+          const V3 p = cd.R.foot_p[f], w = cd.R.vel[j].a;
+          const V3 vp = cd.R.vel[j].l + cross(w, p);
+          for (int i = 0; i < 3; i++)
+          {
+            o.c[row + i] = vp[i];
+            if (fs == 6)
+              o.c[row + 3 + i] = w[i];
+          }
+          if (fs == 3)
+            o.c[row + 3] = p[2] - land_z[f];
+        }
       if (s.torque_limits)
         for (int i = 0; i < nu; i++)
           o.c[i] = u[i];
@@ -368,6 +399,34 @@ namespace orc
           }
         }
       }
+      for (int f = 0; f < nf && nland1 > 0; f++)
+        if (((r.land & r.mask) >> f) & 1u)
+        { // frame velocity (LOCAL_WORLD_ALIGNED) and height of a landing foot: functions of the state only
+          const int l = M->foot_joint[f], row = land_base() + nland1 * f;
+          const V3 p = cd.R.foot_p[f], w = cd.R.vel[l].a;
+          const V3 vp = cd.R.vel[l].l + cross(w, p);
+          for (int k = 0; k < nv; k++)
+          {
+            if (!cd.R.is_ancestor_dof(k, l))
+              continue;
+            const int lam_ = M->parent[cd.R.dof2j[k]];
+            const SV d = lam_ >= 0 ? crm(cd.R.vel[lam_], cd.R.S[k]) : sv_zero(); // non-rigid part of d(v_l)/dq_k (orc_full.hpp)
+            const V3 sa = cd.R.S[k].a, vv = cd.R.S[k].l + cross(sa, p); // d(point position)/dq_k = d(point velocity)/dv_k
+            const V3 vq = d.l + cross(d.a, p) + cross(sa, vp), wq = d.a + cross(sa, w);
+            for (int i = 0; i < 3; i++)
+            {
+              o.Cx(row + i, k) = vq[i];
+              o.Cx(row + i, nv + k) = vv[i];
+              if (fs == 6)
+              {
+                o.Cx(row + 3 + i, k) = wq[i];
+                o.Cx(row + 3 + i, nv + k) = sa[i];
+              }
+            }
+            if (fs == 3)
+              o.Cx(row + 3, k) = vv[2];
+          }
+        }
       if (s.torque_limits)
         for (int i = 0; i < nu; i++)
           o.Cu(i, i) = 1.0;

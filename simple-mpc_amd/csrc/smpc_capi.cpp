@@ -17,7 +17,10 @@ typedef CentDims<4> CentGo2;
 typedef CentEngine<DimsGo2, CentGo2> CentEngineGo2;
 typedef FullDims<13, 4, 3> FullGo2;   // full dynamics: 12 joint torques, 3-D contacts
 typedef FullDims<13, 4, 3, 5> FullGo2Cone; // the same with force_cone: 5 friction-pyramid rows per foot in contact
+typedef FullDims<13, 4, 3, 0, 4> FullGo2Land; // land_cstr: 4 rows per landing foot
+typedef FullDims<13, 4, 3, 5, 4> FullGo2ConeLand; // force_cone and land_cstr: the land rows behind the pyramid rows
 typedef FullDims<23, 2, 6> FullTalos; // Talos-class humanoid: 22 joint torques, two 6-D feet with wrench cones
+typedef FullDims<23, 2, 6, 0, 6> FullTalosLand; // land_cstr: 6 frame-velocity rows per landing foot
 
 struct smpc_handle
 {
@@ -237,7 +240,13 @@ extern "C"
     const HostMpcSettings ms = host_mpc(mpc);
     return guarded([&] {
       std::unique_ptr<smpc_handle> h(new smpc_handle());
-      if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS && s.force_cone)
+      if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS && s.land_cstr && s.force_cone)
+        h->full.reset(new FullEngine<FullGo2ConeLand>(robot, s, ms, batch, gravity_arg, device_id));
+      else if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS && s.land_cstr)
+        h->full.reset(new FullEngine<FullGo2Land>(robot, s, ms, batch, gravity_arg, device_id));
+      else if (robot->njoints == FullTalos::NJ && robot->nfeet == FullTalos::NF && fs == FullTalos::FS && s.land_cstr)
+        h->full.reset(new FullEngine<FullTalosLand>(robot, s, ms, batch, gravity_arg, device_id));
+      else if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS && s.force_cone)
         h->full.reset(new FullEngine<FullGo2Cone>(robot, s, ms, batch, gravity_arg, device_id));
       else if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS)
         h->full.reset(new FullEngine<FullGo2>(robot, s, ms, batch, gravity_arg, device_id));

@@ -108,8 +108,8 @@ namespace smpc
           || (int)fs.w_forces.size() != D::FS * D::FS || (int)fs.w_frame.size() != D::FS * D::FS || (int)fs.umin.size() != D::NU
           || (int)fs.umax.size() != D::NU || (int)fs.qmin.size() != D::NA || (int)fs.qmax.size() != D::NA)
         throw std::runtime_error("full-dynamics settings: weight / limit sizes do not match the robot");
-      if (fs.land_cstr)
-        throw std::runtime_error("land_cstr rows of the full-dynamics OCP are not built yet");
+      if (fs.land_cstr && D::NLAND1 == 0)
+        throw std::runtime_error("internal: land_cstr needs the instantiation with land rows");
       if (fs.force_cone && D::NCONE1 == 0)
         throw std::runtime_error("internal: force_cone needs the instantiation with cone rows");
       device_id = device;
@@ -171,6 +171,14 @@ namespace smpc
       x_reference = x_model_ref;
       for (int i = 0; i < D::NX; i++)
         m.x_term[i] = x_model_ref[i];
+      m.land_cstr = fs.land_cstr;
+      {
+        // contact poses of the cycle stages: the feet at the reference state (src/mpc.cpp:162); land_cstr pins the height of a landing 3-D foot to them
+        std::vector<double> ft((size_t)D::NF * 6);
+        host_foot_positions(m, x_model_ref.data(), ft.data());
+        for (int f = 0; f < D::NF; f++)
+          m.land_z[f] = ft[f * 6 + 2];
+      }
       // ---- buffers ----
       buf.B = B;
       buf.H = H;
@@ -312,7 +320,7 @@ namespace smpc
     }
     void launch_sweeps(const Buffers<D> & b)
     {
-      if constexpr (D::NCONE == 0)
+      if constexpr (D::NCD == 0)
       {
         if (valu_riccati)
         {
@@ -510,6 +518,7 @@ namespace smpc
         throw std::runtime_error("contact sequence must not be empty");
       timer.generate(cs, n, D::NF, H);
       cycle.clear();
+      unsigned previous = (1u << D::NF) - 1u; // land flags: in contact here, not in the stage before (src/mpc.cpp:133-137,167-185)
       for (auto & st : timer.states)
       {
         int active = 0;
@@ -523,6 +532,8 @@ namespace smpc
             s.mask |= 1u << f;
             s.f_ref[D::FS * f + 2] = ms.support_force / (double)active; // src/mpc.cpp:149-167
           }
+        s.land = s.mask & ~previous;
+        previous = s.mask;
         for (int i = 0; i < D::NX; i++)
           s.x_tgt[i] = x_model_ref[i];
         cycle.push_back(s);

@@ -20,9 +20,12 @@ namespace smpc
 {
   // CN_: cone rows per 3-D foot (0: none -- the instantiation of the Go2 example of record, force_cone = false; 5: the friction
   // pyramid of MultibodyFrictionConeResidual, src/fulldynamics.cpp:185-190); 6-D feet always carry their 17 wrench-cone rows
-  template <int NJ_, int NF_, int FS_, int CN_ = 0>
+  // LN_: land_cstr rows per foot (0: none; 6: the LOCAL_WORLD_ALIGNED frame velocity of a landing 6-D foot, src/fulldynamics.cpp:175-181; 4: its 3
+  // linear rows and the height of the contact pose for a 3-D foot, src/fulldynamics.cpp:191-210)
+  template <int NJ_, int NF_, int FS_, int CN_ = 0, int LN_ = 0>
   struct FullDims
   {
+    static_assert(LN_ == 0 || LN_ == (FS_ == 6 ? 6 : 4), "land_cstr rows per foot");
     static constexpr int NJ = NJ_;     // joints incl. free-flyer
     static constexpr int NF = NF_;     // feet
     static constexpr int FS = FS_;     // contact force size
@@ -36,7 +39,10 @@ namespace smpc
     static constexpr int NCM = FS_ * NF_;                     // contact rows when every foot is in contact
     static constexpr int NCONE1 = FS_ == 6 ? 17 : CN_;        // cone rows per foot (wrench cone of 6-D feet / friction pyramid of 3-D feet)
     static constexpr int NCONE = NCONE1 * NF_;
-    static constexpr int NC = NU + NA + NCONE;
+    static constexpr int NLAND1 = LN_;                        // land_cstr rows per foot (equality rows on the state)
+    static constexpr int NLAND = NLAND1 * NF_;
+    static constexpr int NCD = NCONE + NLAND;                 // dense rows of the knot: cone rows, then land rows
+    static constexpr int NC = NU + NA + NCD;
     static constexpr int NXU = NDX + NU;
     // LQ knot block (doubles), one per (instance, stage)
     static constexpr int O_A = 0;
@@ -44,9 +50,9 @@ namespace smpc
     static constexpr int O_Q = O_B + NDX * NU;
     static constexpr int O_S = O_Q + NDX * NDX;
     static constexpr int O_R = O_S + NDX * NU;
-    static constexpr int O_C = O_R + NU * NU;       // Cd: dense cone rows, NCONE x NDX (active rows, else zero)
-    static constexpr int O_D = O_C + NCONE * NDX;   // Dd: NCONE x NU
-    static constexpr int O_q = O_D + NCONE * NU;
+    static constexpr int O_C = O_R + NU * NU;       // Cd: dense rows (cone | land), NCD x NDX (active rows, else zero)
+    static constexpr int O_D = O_C + NCD * NDX;     // Dd: NCD x NU
+    static constexpr int O_q = O_D + NCD * NU;
     static constexpr int O_r = O_q + NDX;
     static constexpr int O_f = O_r + NU;
     static constexpr int O_d = O_f + NDX;           // mu (nu+ - nu), all NC rows
@@ -58,8 +64,8 @@ namespace smpc
     static constexpr int LQ_STRIDE = ((O_act + NC + 7) / 8) * 8;
     // gains block per (instance, stage)
     static constexpr int G_K = 0;                          // [K k]  NU x (NDX+1)
-    static constexpr int G_Z = G_K + NU * (NDX + 1);       // [Z z]  NCONE x (NDX+1)  (multiplier feedback of the dense rows)
-    static constexpr int G_Pt = G_Z + NCONE * (NDX + 1);   // P~ (NDX x NDX)
+    static constexpr int G_Z = G_K + NU * (NDX + 1);       // [Z z]  NCD x (NDX+1)  (multiplier feedback of the dense rows)
+    static constexpr int G_Pt = G_Z + NCD * (NDX + 1);     // P~ (NDX x NDX)
     static constexpr int G_pn = G_Pt + NDX * NDX;          // p_{t+1}
     static constexpr int G_STRIDE = ((G_pn + NDX + 7) / 8) * 8;
     static constexpr int LS_N = 10;
@@ -76,8 +82,9 @@ namespace smpc
     double Kp[D::FS], Kd[D::FS];
     double umin[D::NU], umax[D::NU], qmin[D::NA], qmax[D::NA];
     double fric_mu, Lfoot, Wfoot;
+    double land_z[D::NF]; // land_cstr: heights of the contact poses the cycle stages are created with (the feet at the reference state, src/mpc.cpp:162)
     double prox_accuracy, prox_mu; // ProximalSettings(1e-9, 1e-10, 10), src/fulldynamics.cpp:39
-    int prox_max_iter, torque_limits, kinematics_limits, force_cone, w_diag, nlevels;
+    int prox_max_iter, torque_limits, kinematics_limits, force_cone, w_diag, nlevels, land_cstr, pad0_;
     int parent[D::NJ], jtype[D::NJ], level[D::NJ];
     unsigned anc[D::NJ], children[D::NJ]; // bit a of anc[j]: joint a is j or one of its ancestors
     int foot_joint[D::NF];
@@ -98,18 +105,18 @@ namespace smpc
     double w_u[D::NU * D::NU];
     double x_term[D::NX];
   };
-  template <int NJ_, int NF_, int FS_, int CN_>
-  struct DevModel<FullDims<NJ_, NF_, FS_, CN_>> : FullDevModel<FullDims<NJ_, NF_, FS_, CN_>>
+  template <int NJ_, int NF_, int FS_, int CN_, int LN_>
+  struct DevModel<FullDims<NJ_, NF_, FS_, CN_, LN_>> : FullDevModel<FullDims<NJ_, NF_, FS_, CN_, LN_>>
   {
   };
 
   // stage descriptor shared by the phase-aligned batch
-  template <int NJ_, int NF_, int FS_, int CN_>
-  struct StageShared<FullDims<NJ_, NF_, FS_, CN_>>
+  template <int NJ_, int NF_, int FS_, int CN_, int LN_>
+  struct StageShared<FullDims<NJ_, NF_, FS_, CN_, LN_>>
   {
-    typedef FullDims<NJ_, NF_, FS_, CN_> D;
+    typedef FullDims<NJ_, NF_, FS_, CN_, LN_> D;
     unsigned mask;
-    unsigned pad;
+    unsigned land; // bit per foot: the foot lands at this stage of the cycle (land_cstr rows; reference src/mpc.cpp:167-178)
     double u_ref[D::NU];   // control reference (zero in the reference's stages, src/fulldynamics.cpp:89)
     double f_ref[D::NCM];  // contact-force reference per foot (src/fulldynamics.cpp:122-137)
     double x_tgt[D::NX];

@@ -32,7 +32,7 @@ namespace smpc
     constexpr int TL = (NDX % 3 == 0 && NXU % 3 == 0 && NU % 3 == 0) ? 3 : 2;
     static_assert(NDX % TL == 0 && NXU % TL == 0 && NU % TL == 0, "register tiles must divide the dimensions");
     static_assert(NDX + 1 <= NT, "one lane per right-hand side column");
-    static_assert(D::NCONE == 0, "dense cone rows are handled by the matrix-core sweep only");
+    static_assert(D::NCD == 0, "dense rows (cones, landing feet) are handled by the matrix-core sweep only");
     const Buffers<D> & b = ka.b;
     const int H = b.H;
     const int inst = block;

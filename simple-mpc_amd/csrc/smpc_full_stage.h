@@ -809,10 +809,56 @@ namespace smpc
     }
   }
 
+  // land_cstr rows of a landing foot f (reference src/fulldynamics.cpp:175-181, 191-210): its LOCAL_WORLD_ALIGNED frame velocity (the point
+  // velocity in world axes, rows 0 .. 2; 6-D feet: the angular velocity of the body, rows 3 .. 5), 3-D feet: row 3 = height above the contact pose
+  template <class D, class SC>
+  SMPC_DEV double full_land_value(const SC & sc, int f, int r)
+  {
+    const int jf = sc.h.foot_joint[f];
+    const V3 p = ld3(&sc.footp[f * 3]);
+    const SV v = ldsv(&sc.vel[jf * 6]);
+    if (r < 3)
+    {
+      const V3 vp = v.l + cross(v.a, p);
+      return r == 0 ? vp.x : (r == 1 ? vp.y : vp.z);
+    }
+    if (D::FS == 6)
+      return r == 3 ? v.a.x : (r == 4 ? v.a.y : v.a.z);
+    return p.z - sc.h.land_z[f];
+  }
+  // entry (r, k) of their Jacobian, k a tangent index of the state (q | v): with d_k = v_parent(k) x S_k (the part of d v_l / d q_k that is
+  // not the rigid motion of the subtree by S_k) d(point velocity)/dq_k = d_k.l + d_k.a x p + S_k.a x v_p, d(omega)/dq_k = d_k.a + S_k.a x omega,
+  // d(.)/dv_k = the point / angular Jacobian column, which is d(position)/dq_k too
+  template <class D, class SC, class SD>
+  SMPC_DEV double full_land_entry(const SC & sc, const SD & sd, int f, int r, int k)
+  {
+    constexpr int NV = D::NV;
+    const int jf = sc.h.foot_joint[f], kk = k < NV ? k : k - NV;
+    if (!((sc.h.anc[jf] >> jof(kk)) & 1u))
+      return 0.0;
+    const V3 p = ld3(&sc.footp[f * 3]);
+    const SV Sk = ldsv(&sc.S[kk * 6]);
+    V3 o;
+    if (k >= NV) // velocity columns
+      o = r < 3 ? Sk.l + cross(Sk.a, p) : (D::FS == 6 ? Sk.a : V3{0.0, 0.0, 0.0});
+    else
+    {
+      const SV v = ldsv(&sc.vel[jf * 6]), d = ldsv(&sd.dk[kk * 6]);
+      if (r < 3)
+        o = d.l + cross(d.a, p) + cross(Sk.a, v.l + cross(v.a, p));
+      else if (D::FS == 6)
+        o = d.a + cross(Sk.a, v.a);
+      else
+        return (Sk.l + cross(Sk.a, p)).z;
+    }
+    const int c = r % 3;
+    return c == 0 ? o.x : (c == 1 ? o.y : o.z);
+  }
+
   // x+ (semi-implicit Euler), defect, residuals, weighted residuals, cost, constraint values, AL multipliers, merit pieces.
   // Results: sc.red[0] cost, sc.red[1] penalty part of the merit, sc.red[2] primal infeasibility.
   template <class D, bool DERIV, class SC, class SD>
-  SMPC_DEV void full_eval_tail(SC & sc, SD * sd, const DevModel<D> & mg, unsigned mask, bool term, const double * lam_e, const double * nu_e, FullProf * fpp = nullptr)
+  SMPC_DEV void full_eval_tail(SC & sc, SD * sd, const DevModel<D> & mg, unsigned mask, unsigned land, bool term, const double * lam_e, const double * nu_e, FullProf * fpp = nullptr)
   {
     constexpr int NT = 64;
     constexpr int NV = D::NV, NQ = D::NQ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX, NC = D::NC, NA = D::NA, FS = D::FS, NX = D::NX;
@@ -891,7 +937,7 @@ namespace smpc
         // wrench-cone rows of the feet in contact: A_cone lam
         for (int i = lane; i < D::NCONE; i += NT)
         {
-          const int f = i / D::NCONE1, r = i % D::NCONE1;
+          const int f = i / (D::NCONE1 > 0 ? D::NCONE1 : 1), r = i % (D::NCONE1 > 0 ? D::NCONE1 : 1);
           double acc = 0.0;
           if (h.force_cone && ((mask >> f) & 1u))
           {
@@ -900,6 +946,12 @@ namespace smpc
               acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * sc.lam[c * FS + j];
           }
           sc.cval[NU + NA + i] = acc;
+        }
+        // land_cstr rows of the feet that land at this stage (`land`: already masked by the contacts and the switch)
+        for (int i = lane; i < D::NLAND; i += NT)
+        {
+          const int f = i / (D::NLAND1 > 0 ? D::NLAND1 : 1), r = i % (D::NLAND1 > 0 ? D::NLAND1 : 1);
+          sc.cval[NU + NA + D::NCONE + i] = ((land >> f) & 1u) ? full_land_value<D>(sc, f, r) : 0.0;
         }
         // contact-force residual of the feet in contact (compact row c of foot f)
         for (int i = lane; i < NCM; i += NT)
@@ -1027,19 +1079,22 @@ namespace smpc
       }
       for (int i = lane; i < NC; i += NT)
       {
-        // rows: torque box | joint box | wrench-cone rows of the feet in contact (negative orthant)
-        const bool box = i < NU + NA;
-        const bool present = i < NU ? h.torque_limits != 0 : (box ? h.kinematics_limits != 0 : (h.force_cone != 0 && ((mask >> ((i - NU - NA) / (D::NCONE1 > 0 ? D::NCONE1 : 1))) & 1u)));
+        // rows: torque box | joint box | wrench-cone rows of the feet in contact (negative orthant) | rows of the landing feet (equality)
+        const bool box = i < NU + NA, eq = i >= NU + NA + D::NCONE;
+        const bool present = i < NU ? h.torque_limits != 0
+                                    : (box ? h.kinematics_limits != 0
+                                           : (eq ? ((land >> ((i - NU - NA - D::NCONE) / (D::NLAND1 > 0 ? D::NLAND1 : 1))) & 1u) != 0u
+                                                 : (h.force_cone != 0 && ((mask >> ((i - NU - NA) / (D::NCONE1 > 0 ? D::NCONE1 : 1))) & 1u))));
         double vp = 0.0;
         int act = 0;
         if (present)
         {
           const double lo = i < NU ? h.umin[i] : (box ? h.qmin[i - NU] : -1e300), hi = i < NU ? h.umax[i] : (box ? h.qmax[i - NU] : 0.0);
           const double z = sc.cval[i] + mu * nu_e[i];
-          const double proj = box ? fmin(fmax(z, lo), hi) : fmin(z, 0.0);
+          const double proj = box ? fmin(fmax(z, lo), hi) : (eq ? 0.0 : fmin(z, 0.0));
           vp = (z - proj) / mu;
-          act = z != proj;
-          prim = fmax(prim, box ? fmax(fmax(sc.cval[i] - hi, lo - sc.cval[i]), 0.0) : fmax(sc.cval[i], 0.0));
+          act = eq || z != proj;
+          prim = fmax(prim, box ? fmax(fmax(sc.cval[i] - hi, lo - sc.cval[i]), 0.0) : (eq ? fabs(sc.cval[i]) : fmax(sc.cval[i], 0.0)));
         }
         sc.vplus[i] = vp;
         sc.act[i] = act;
@@ -1706,6 +1761,7 @@ namespace smpc
     const int snext = ring_slot(ka.head, term ? t : t + 1, R);
     const double preg = b.scal[(size_t)inst * SC_N + SC_PREG];
     const unsigned mask = term ? 0u : (b.stages[t].mask & ((1u << NF) - 1u));
+    const unsigned land = (D::NLAND > 0 && !term && mg.land_cstr) ? (b.stages[t].land & mask) : 0u; // feet with land_cstr rows at this stage
     // ---- block inputs ----
     SMPC_LANES(NT)
     {
@@ -1737,7 +1793,7 @@ namespace smpc
     fp.tprev = SMPC_CLOCK();
     ftick(fp, 0);
     full_dynamics_phases<D, true>(sc, &sd, mg, mask, !term, fp);
-    full_eval_tail<D, true>(sc, &sd, mg, mask, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC, &fp);
+    full_eval_tail<D, true>(sc, &sd, mg, mask, land, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC, &fp);
     ftick(fp, 7);
     full_deriv_phases<D>(sc, sd, mg, mask, term, fp);
     ftick(fp, 13);
@@ -1801,6 +1857,12 @@ namespace smpc
         if (!term)
           for (int r = 0; r < NCM; r++)
             cqv += sd.JT[r * NCOL + k] * sd.yc_()[r];
+      if constexpr (D::NLAND > 0)
+        if (land != 0u && k < NDX) // land rows: C_x^T nu (rows of the state only)
+          for (int f = 0; f < NF; f++)
+            if ((land >> f) & 1u)
+              for (int r = 0; r < D::NLAND1; r++)
+                cqv += full_land_entry<D>(sc, sd, f, r, k) * sc.nu[NU + NA + D::NCONE + D::NLAND1 * f + r];
       sd.cq_()[k] = cqv;
     }
     SMPC_LANES_END_WAVE
@@ -1996,6 +2058,22 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
     }
+    if constexpr (D::NLAND > 0)
+    {
+      // land rows of the knot (equality rows: always active where present), behind the cone rows; no control columns
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < D::NLAND * NXU; idx += NT)
+      {
+        const int i = idx / NXU, k = idx % NXU;
+        const int f = i / D::NLAND1, r = i % D::NLAND1;
+        const double v = (k < NDX && ((land >> f) & 1u)) ? full_land_entry<D>(sc, sd, f, r, k) : 0.0;
+        if (k < NDX)
+          lq[D::O_C + (D::NCONE + i) * NDX + k] = v;
+        else
+          lq[D::O_D + (D::NCONE + i) * NU + k - NDX] = v;
+      }
+      SMPC_LANES_END_WAVE
+    }
     SMPC_LANES(NT)
     {
       if (lane == 0)
@@ -2045,6 +2123,7 @@ namespace smpc
     for (int i = 0; i < j; i++)
       alpha *= 0.5;
     const unsigned mask = term ? 0u : (b.stages[t].mask & ((1u << NF) - 1u));
+    const unsigned land = (D::NLAND > 0 && !term && mg.land_cstr) ? (b.stages[t].land & mask) : 0u; // feet with land_cstr rows at this stage
     const double * dx = b.dxs + ((size_t)inst * (H + 1) + t) * NDX;
     const size_t lt = (size_t)inst * H + (term ? 0 : t);
     SMPC_LANES(NT)
@@ -2072,7 +2151,7 @@ namespace smpc
     SMPC_LANES_END_WAVE
     FullProf fp;
     full_dynamics_phases<D, false>(sc, (FullScratchDeriv<D> *)nullptr, mg, mask, !term, fp);
-    full_eval_tail<D, false>(sc, (FullScratchDeriv<D> *)nullptr, mg, mask, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
+    full_eval_tail<D, false>(sc, (FullScratchDeriv<D> *)nullptr, mg, mask, land, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC);
     double * parts = b.partsT + (((size_t)inst * D::LS_N + j) * (H + 1) + t) * 2;
     SMPC_LANES(NT)
     {

@@ -14,7 +14,9 @@
 // pivoted explicitly after the controls,
 //        [[Q^, S^, C^T, q^], [., R^, D^T, r^], [., ., -mu I, d]]   pivots [u | nu]  ->  P_t, p_t, -K, -k, -Z, -z
 // (the stage KKT matrix is quasi-definite: LDL^T without pivoting is stable, 4 x 4 pivot blocks are definite of either sign).
-// Generic in (NDX, NU, NCONE): tile grids are computed from the dimensions; pivots are padded to whole panels with unit rows.
+// Generic in (NDX, NU, NCD): tile grids are computed from the dimensions; pivots are padded to whole panels with unit rows.  When the grid
+// would exceed 128 columns (Talos with wrench cones and land rows: 56 + 24 + 48 + 1), the first dense rows take the padding pivots of the
+// last control panel (a mixed panel: the 4 x 4 pivot block is factored L diag(d) L^T in pivot order, signs of d free).
 #pragma once
 #include "smpc_full_model.h"
 #include "smpc_riccati_kino.h"
@@ -27,9 +29,14 @@ namespace smpc
     static constexpr int NDX = D::NDX, NU = D::NU, NXU = NDX + NU;
     static constexpr int NUP = ((NU + 3) / 4) * 4;     // control pivots padded to whole panels
     static constexpr int NXUP = NDX + NUP;
-    static constexpr int NCD = D::NCONE;               // dense constraint rows (multipliers pivoted explicitly)
-    static constexpr int NCP = ((NCD + 3) / 4) * 4;
-    static constexpr int NXC = NXUP + NCP;              // [x | u | nu]
+    static constexpr int NCD = D::NCD;                 // dense constraint rows (multipliers pivoted explicitly)
+    static constexpr int FILL0 = (NUP - NU) < NCD ? (NUP - NU) : NCD;
+    static constexpr int FILL = (NXUP + ((NCD + 3) / 4) * 4 + 1 > 128) ? FILL0 : 0; // dense rows in the padding pivots of the control panels
+    static constexpr int NCP = ((NCD - FILL + 3) / 4) * 4;
+    static constexpr int NXC = NXUP + NCP;              // [x | u (+ FILL dense rows) | nu]
+    // column of dense row i / dense row of column c (-1: none)
+    SMPC_HD static constexpr int dcol(int i) { return i < FILL ? NXU + i : NXUP + i - FILL; }
+    SMPC_HD static constexpr int drow(int c) { return (c >= NXU && c < NXU + FILL) ? c - NXU : ((c >= NXUP && c < NXUP + NCD - FILL) ? c - NXUP + FILL : -1); }
     static constexpr int NT1 = (2 * NDX + 1 + 15) / 16; // tile grid of the first sweep
     static constexpr int NTX = (NDX + 15) / 16;         // tile rows of P~ / T
     static constexpr int NTJ = (NXUP + 15) / 16;        // tile columns holding [A | B]
@@ -104,8 +111,8 @@ namespace smpc
         for (int i = lane; i < NU + NA + NCD; i += NT)
           s.boxd[i] = lq[D::O_d + i];
         if constexpr (NCD > 0)
-          for (int i = lane; i < GM::NCP; i += NT)
-            s.cact[i] = i < NCD ? lq[D::O_act + NU + NA + i] : 0.0;
+          for (int i = lane; i < GM::NCP; i += NT) // (rows behind the control panels; the FILL rows in a control panel are never skipped)
+            s.cact[i] = i + GM::FILL < NCD ? lq[D::O_act + NU + NA + GM::FILL + i] : 0.0;
       }
       SMPC_LANES_END_WAVE
       if constexpr (NCD > 0)
@@ -207,8 +214,8 @@ namespace smpc
                 off = D::O_Q + r0 * NDX + c0;
               else if (c0 < NXU)
                 off = r0 < NDX ? D::O_S + r0 * NU + c0 - NDX : D::O_R + (r0 - NDX) * NU + c0 - NDX;
-              else if (c0 >= NXUP && c0 < NXUP + NCD && r0 < NXU) // dense constraint rows: (x, nu_i) = C_i, (u, nu_i) = D_i
-                off = r0 < NDX ? D::O_C + (c0 - NXUP) * NDX + r0 : D::O_D + (c0 - NXUP) * NU + r0 - NDX;
+              else if (GM::drow(c0) >= 0 && r0 < NXU) // dense constraint rows: (x, nu_i) = C_i, (u, nu_i) = D_i
+                off = r0 < NDX ? D::O_C + GM::drow(c0) * NDX + r0 : D::O_D + GM::drow(c0) * NU + r0 - NDX;
               else if (c0 == VC && r0 < NXU)
                 off = r0 < NDX ? D::O_q + r0 : D::O_r + r0 - NDX;
               SMPC_ACCV(hacc, tix<NT2>(I, J), v) = lq[off];
@@ -333,12 +340,12 @@ namespace smpc
                 val += imu * ba;
               if (bi >= 0 && c0 == VC)
                 val += imu * ba * bd;
-              const bool rx = r0 < NXU, rn = r0 >= NXUP && r0 < NXUP + NCD; // problem rows: (x, u) ; explicit multipliers
-              const bool cx = c0 < NXU, cn = c0 >= NXUP && c0 < NXUP + NCD;
+              const bool rx = r0 < NXU, rn = GM::drow(r0) >= 0; // problem rows: (x, u) ; explicit multipliers
+              const bool cx = c0 < NXU, cn = GM::drow(c0) >= 0;
               if (rn && c0 == r0)
                 val = -mu;                                   // multiplier block -mu I
               else if (rn && c0 == VC)
-                val = s.boxd[NU + NA + (r0 - NXUP)];          // d of the dense rows
+                val = s.boxd[NU + NA + GM::drow(r0)];         // d of the dense rows
               else if (!((rx && (cx || cn || c0 == VC))))
                 val = (r0 == c0 && r0 < NXC) ? 1.0 : 0.0;     // unit padding pivots, zero elsewhere
               SMPC_ACCV(hacc, tix<NT2>(I, J), v) = val;
@@ -373,15 +380,15 @@ namespace smpc
                 }
                 else if (col < NXU)
                   g[D::G_K + (col - NDX) * (NDX + 1) + row] = -val; // K
-                else if (col >= NXUP && col < NXUP + NCD)
-                  g[D::G_Z + (col - NXUP) * (NDX + 1) + row] = -val; // Z: multiplier feedback of the dense rows
+                else if (GM::drow(col) >= 0)
+                  g[D::G_Z + GM::drow(col) * (NDX + 1) + row] = -val; // Z: multiplier feedback of the dense rows
                 else if (col == VC)
                   s.p[row] = val; // p_t
               }
               else if (row < NXU && col == VC)
                 g[D::G_K + (row - NDX) * (NDX + 1) + NDX] = -val; // k
-              else if (row >= NXUP && row < NXUP + NCD && col == VC)
-                g[D::G_Z + (row - NXUP) * (NDX + 1) + NDX] = ((skip >> ((row - NDX) / 4)) & 1u) ? val / mu : -val; // z
+              else if (GM::drow(row) >= 0 && col == VC)
+                g[D::G_Z + GM::drow(row) * (NDX + 1) + NDX] = ((skip >> ((row - NDX) / 4)) & 1u) ? val / mu : -val; // z
             }
       }
       SMPC_LANES_END_WAVE

@@ -83,6 +83,7 @@ def lib():
     L.orc_kino_set_force_cone.argtypes = [vp, C.c_int, C.c_double]
     L.orc_set_fold_u_rows.argtypes = [C.c_int]
     L.orc_kino_set_land_cstr.argtypes = [vp, C.c_int]
+    L.orc_full_set_land_cstr.argtypes = [vp, C.c_int]
     L.orc_kino_term.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
     L.orc_kino_term_cstr.argtypes = [vp, _dp, _dp, C.c_double, _dp, _dp]
     L.orc_centroidal.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
@@ -407,6 +408,8 @@ class Full:
                                    c(s["umax"]), c(s["qmin"]), c(s["qmax"]), int(s["torque_limits"]), int(s["kinematics_limits"]),
                                    int(s.get("force_size", 3)), int(s.get("force_cone", False)), float(s.get("mu", 0.8)),
                                    float(s.get("Lfoot", 0.1)), float(s.get("Wfoot", 0.075)))
+        if s.get("land_cstr", False):
+            L.orc_full_set_land_cstr(self.h, 1)
         d = np.zeros(5, np.int32)
         L.orc_full_dims(self.h, d)
         self.nx, self.ndx, self.nu, self.nc, self.nf = (int(v) for v in d)
