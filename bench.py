@@ -33,6 +33,31 @@ HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6300 GB/s ac
 MEASURED_PEAK = None     # {"fma_tflops", "mfma_tflops", ...} of THIS device, from tools/micro/fp64_peak.bin ("quote the measured peak")
 
 
+def loop_stream(gm, dev):
+    """torch work of a closed loop on the handle's own stream (smpc_get_stream): one in-order queue, no host-side wait between control steps.
+    --sync-steps (SYNC_STEPS) restores a host synchronisation after every step."""
+    import contextlib
+
+    import torch
+
+    ptr = 0 if SYNC_STEPS else gm.stream()
+    if not ptr:
+        return contextlib.nullcontext
+    ext = torch.cuda.ExternalStream(ptr, device=dev)
+    return lambda: torch.cuda.stream(ext)
+
+
+def step_sync(gm):
+    if SYNC_STEPS:
+        import torch
+
+        gm.wait()
+        torch.cuda.synchronize()
+
+
+SYNC_STEPS = False
+
+
 def measure_fp64_peak(seconds=0.5):
     """Dependency-free v_fma_f64 / v_mfma_f64_16x16x4 loops on all CUs (tools/micro/fp64_peak.hip, built by __graft_entry__.build):
     the peak this device actually reaches, carried beside the spec value in every FP64 roofline entry."""
@@ -426,12 +451,16 @@ def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     gen = torch.Generator(device=dev)
     gen.manual_seed(7)
 
+    on_stream = loop_stream(gm, dev)
+
     def step():
         gm.iterate_device(X.data_ptr())
-        gm.wait()
-        X.copy_(X0)
-        X[:, :3].add_(torch.randn((batch, 3), generator=gen, device=dev, dtype=torch.float64) * 1e-3)
-        torch.cuda.synchronize()
+        if SYNC_STEPS:
+            gm.wait()
+        with on_stream():
+            X.copy_(X0)
+            X[:, :3].add_(torch.randn((batch, 3), generator=gen, device=dev, dtype=torch.float64) * 1e-3)
+        step_sync(gm)
 
     for _ in range(warmup):
         step()
@@ -493,14 +522,18 @@ def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True, rob
     gen = torch.Generator(device=dev)
     gen.manual_seed(11)
 
+    on_stream = loop_stream(gm, dev)
+
     def step():
         gm.iterate_device(X.data_ptr())
         gm.get_x_device(1, X.data_ptr())
-        gm.wait()
-        X.add_(torch.randn(X.shape, generator=gen, device=dev, dtype=torch.float64) * 1e-3)
-        q = X[:, 3:7]
-        q.div_(q.norm(dim=1, keepdim=True))
-        torch.cuda.synchronize()
+        if SYNC_STEPS:
+            gm.wait()
+        with on_stream():
+            X.add_(torch.randn(X.shape, generator=gen, device=dev, dtype=torch.float64) * 1e-3)
+            q = X[:, 3:7]
+            q.div_(q.norm(dim=1, keepdim=True))
+        step_sync(gm)
 
     for _ in range(warmup):
         step()
@@ -613,10 +646,14 @@ def main():
                     "launches are filled by the next part's). Per-kernel rooflines then refer to launches of batch/N instances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true", help="host synchronisation after every control step (default: the closed loop is one in-order queue "
+                    "on the handle's stream, synchronised only at the ends of the timed region)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch path (gloo + emulated kernel bodies): not a measurement")
     ap.add_argument("--workload", default="kinodynamics", choices=["kinodynamics", "centroidal", "fulldynamics", "talos"],
                     help="kinodynamics = the headline metric (with the other single-GPU configurations measured briefly beside it at 1 GPU)")
     args = ap.parse_args()
+    global SYNC_STEPS
+    SYNC_STEPS = bool(args.sync_steps)
     if args.streams > 1:
         os.environ["SMPC_STREAMS"] = str(args.streams)  # read by the engine when the handle is created
     if args.batch is None:
@@ -699,15 +736,19 @@ def main():
         gen = torch.Generator(device=dev)
         gen.manual_seed(20240529 + rank)
 
+        on_stream = loop_stream(gm, dev)
+
         def step():
             gm.iterate_device(X.data_ptr())
             gm.get_x_device(1, X.data_ptr())  # x_meas <- xs[1] (same stream, ordered after the solve)
-            gm.wait()
-            noise = torch.randn(X.shape, generator=gen, device=dev, dtype=torch.float64) * 1e-3
-            X.add_(noise)
-            q = X[:, 3:7]
-            q.div_(q.norm(dim=1, keepdim=True))
-            torch.cuda.synchronize()
+            if SYNC_STEPS:
+                gm.wait()
+            with on_stream():  # the noise kernels queue behind the solve on the handle's stream: no host-side wait inside the timed region
+                noise = torch.randn(X.shape, generator=gen, device=dev, dtype=torch.float64) * 1e-3
+                X.add_(noise)
+                q = X[:, 3:7]
+                q.div_(q.norm(dim=1, keepdim=True))
+            step_sync(gm)
 
     for _ in range(args.warmup):
         step()

@@ -205,6 +205,11 @@ int smpc_iterate(smpc_handle * h, const double * X);
 /* Same with X already resident in HBM; asynchronous on the handle's stream (pair with smpc_wait). */
 int smpc_iterate_device(smpc_handle * h, const double * X_device);
 int smpc_wait(smpc_handle * h);
+/* The hipStream_t (as void *) every launch of this handle is issued on.  A caller that produces the measured states on the device -- a
+ * batched simulator, torch through torch.cuda.ExternalStream -- enqueues its own kernels there: the closed loop
+ * iterate_device -> get_x_device -> (caller's kernels) -> iterate_device is then one in-order queue with no host-side wait between control
+ * steps.  The stream belongs to the handle.  NULL in the CPU test build. */
+void * smpc_get_stream(smpc_handle * h);
 /* smpc_iterate without the final synchronisation (X must stay valid until smpc_wait): one host thread keeps several handles -- one per
  * device, each with its share of the batch -- busy at once (include/simple-mpc/batched-mpc.hpp BatchedMPCGroup). */
 int smpc_iterate_async(smpc_handle * h, const double * X);

@@ -13,6 +13,7 @@
 // backend the shipped library is built with; it has no CPU path.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -132,6 +133,7 @@ namespace smpc
 #define SMPC_HIP(x) ::smpc::hip_check((x), #x, __FILE__, __LINE__)
 
   typedef hipStream_t stream_t;
+  inline void * stream_native(stream_t s) { return (void *)s; } // the hipStream_t itself, for callers that enqueue their own work on it
 
   inline void * dev_alloc(size_t bytes)
   {
@@ -196,6 +198,57 @@ namespace smpc
   inline void event_destroy(event_t ev) { (void)hipEventDestroy(ev.e); }
   inline void event_record(event_t ev, stream_t s) { SMPC_HIP(hipEventRecord(ev.e, s)); }
   inline void stream_wait_event(stream_t s, event_t ev) { SMPC_HIP(hipStreamWaitEvent(s, ev.e, 0)); }
+  // Per-step uploads of small host tables (the shared stage descriptors): a ring of pinned staging buffers, each guarded by an event, so that
+  // the host may run several control steps ahead of the device (no host-side wait inside a closed loop that lives on the handle's stream)
+  // without a later step's table overwriting one a queued copy has not read yet.
+  struct UploadRing
+  {
+    static constexpr int N = 4;
+    void * host[N] = {};
+    event_t ev[N] = {};
+    bool used[N] = {};
+    size_t cap = 0;
+    int next = 0;
+    void upload(void * dst, const void * src, size_t bytes, stream_t s)
+    {
+      if (bytes > cap)
+      {
+        release();
+        for (int i = 0; i < N; i++)
+        {
+          SMPC_HIP(hipHostMalloc(&host[i], bytes, hipHostMallocDefault));
+          ev[i] = event_create();
+        }
+        cap = bytes;
+      }
+      const int i = next;
+      next = (next + 1) % N;
+      if (used[i])
+        SMPC_HIP(hipEventSynchronize(ev[i].e)); // the copy that read this slot N uploads ago has completed
+      std::memcpy(host[i], src, bytes);
+      SMPC_HIP(hipMemcpyAsync(dst, host[i], bytes, hipMemcpyHostToDevice, s));
+      event_record(ev[i], s);
+      used[i] = true;
+    }
+    void release()
+    {
+      for (int i = 0; i < N; i++)
+        if (host[i])
+        {
+          if (used[i])
+            (void)hipEventSynchronize(ev[i].e);
+          (void)hipHostFree(host[i]);
+          event_destroy(ev[i]);
+          host[i] = nullptr;
+          used[i] = false;
+        }
+      cap = 0;
+    }
+    ~UploadRing() { release(); }
+    UploadRing() = default;
+    UploadRing(const UploadRing &) = delete;
+    UploadRing & operator=(const UploadRing &) = delete;
+  };
   inline float event_elapsed_ms(event_t a, event_t b)
   {
     float ms = 0;

@@ -469,6 +469,12 @@ extern "C"
       return guarded([&] { h->cent->sync(); });
     return guarded([&] { h->eng->sync(); });
   }
+  void * smpc_get_stream(smpc_handle * h)
+  {
+    if (!h)
+      return nullptr;
+    return stream_native(h->full ? h->full->stream : (h->cent ? h->cent->stream : h->eng->stream));
+  }
   static size_t state_pass(smpc_handle * h, StateIO::Mode mode, void * buf, size_t cap)
   {
     if (h->full)

@@ -52,6 +52,7 @@ namespace smpc
     double mass;
     std::vector<double> x_model_ref;
     stream_t stream;
+    UploadRing stage_ring; // pinned staging of the per-step stage table
     double *X_dev = nullptr, *cstate_dev = nullptr, *feet_dev = nullptr;
     int cold_iters = 0;
     std::vector<double> cold_trace;
@@ -202,7 +203,7 @@ namespace smpc
 
     void upload_stages()
     {
-      h2d(buf.stages, horizon.data(), (size_t)H * sizeof(CentStage<DC>), stream);
+      stage_ring.upload(buf.stages, horizon.data(), (size_t)H * sizeof(CentStage<DC>), stream);
     }
     void launch_frontend(const double * Xd, bool aux = false)
     {

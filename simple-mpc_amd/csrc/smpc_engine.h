@@ -843,8 +843,9 @@ namespace smpc
 
     void upload_stages()
     {
-      h2d(buf.stages, horizon.data(), (size_t)H * sizeof(StageShared<D>), stream);
+      stage_ring.upload(buf.stages, horizon.data(), (size_t)H * sizeof(StageShared<D>), stream);
     }
+    UploadRing stage_ring;
 
     // reference: src/mpc.cpp:72-91.  All instances share x0 = reference state: solve instance 0, broadcast.
     void cold_solve(const StageShared<D> & def)

@@ -414,7 +414,8 @@ namespace smpc
       if (b.CN != nullptr)
         d2d(b.vN_e, b.vN, (size_t)b.B * 3 * sizeof(double), stream);
     }
-    void upload_stages() { h2d(buf.stages, horizon.data(), (size_t)H * sizeof(StageShared<D>), stream); }
+    void upload_stages() { stage_ring.upload(buf.stages, horizon.data(), (size_t)H * sizeof(StageShared<D>), stream); }
+    UploadRing stage_ring;
 
     // reference: src/mpc.cpp:72-91.  All instances share x0 = reference state: solve instance 0, broadcast.
     void cold_solve(const StageShared<D> & def, const DevModel<D> & m)

@@ -756,6 +756,11 @@ class BatchedMPC:
     def wait(self):
         self._lib.check(self._lib.L.smpc_wait(self._h))
 
+    def stream(self):
+        """The handle's hipStream_t as an integer (0 in the CPU test build): torch.cuda.ExternalStream(mpc.stream()) puts a caller's device work
+        in the same in-order queue as the control steps."""
+        return int(self._lib.L.smpc_get_stream(self._h) or 0)
+
     def iterateAsync(self, X):
         """iterate() without the final synchronisation and without fetching the solution: X (kept alive until wait()) -> launches only.
         With gatherOutputs / wait, one host thread drives several handles, one per device."""

@@ -302,11 +302,26 @@ int main()
     for (int f = 0; f < nf; f++)
       fz0 += lam[3 * f + 2];
     CHECK(fz0 > 0.5 * robot->total_mass * 9.81 && fz0 < 1.5 * robot->total_mass * 9.81); // the stance feet carry the robot
+    {
+      // every option of FullDynamicsSettings is built: land_cstr and force_cone together, across the first touch-down of the cycle
+      FullDynamicsSettings all = fs;
+      all.land_cstr = true;
+      all.force_cone = true;
+      BatchedMPC lmpc(robot, all, fms, 1);
+      lmpc.generateCycleHorizon(cyc);
+      const std::vector<double> X1(X.begin(), X.begin() + nq + nv);
+      for (int it = 0; it < 10; it++)
+        lmpc.iterate(X1);
+      for (double v : lmpc.xs_)
+        CHECK(std::isfinite(v));
+    }
     bool threw4 = false;
     try
     {
       FullDynamicsSettings bad = fs;
-      bad.land_cstr = true; // not built: rejected, not approximated
+      bad.force_size = 6; // point feet carry 3-D forces: rejected, not approximated
+      bad.Kp_correction.assign(6, 0.0);
+      bad.Kd_correction.assign(6, 0.0);
       BatchedMPC nope(robot, bad, fms, 1);
     }
     catch (const std::runtime_error &)

@@ -68,6 +68,7 @@ namespace smpc
   }
   inline bool emu_reverse = std::getenv("SMPC_EMU_REVERSE") != nullptr && std::getenv("SMPC_EMU_REVERSE")[0] == '1';
   typedef int stream_t;
+  inline void * stream_native(stream_t) { return nullptr; } // (no streams in the sequential build)
   inline void * dev_alloc(size_t bytes)
   {
     void * p = std::calloc(bytes ? bytes : 8, 1);
@@ -99,6 +100,10 @@ namespace smpc
   inline void event_record(event_t, stream_t) {}
   inline void stream_wait_event(stream_t, event_t) {}
   inline float event_elapsed_ms(event_t, event_t) { return 0.f; }
+  struct UploadRing // (sequential build: a copy)
+  {
+    void upload(void * dst, const void * src, size_t bytes, stream_t) { std::memcpy(dst, src, bytes); }
+  };
 
   template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1, int TAG = 0>
   inline void launch(int grid, stream_t, const Args & a)
