@@ -103,12 +103,16 @@ namespace smpc
       const double vxt = *((vref != nullptr && lane >= D::NQ && lane < D::NQ + 6) ? vref + (lane - D::NQ) : in.x_tgt + (lane < NX ? lane : 0));
       const double vur = term ? 0.0 : in.u_ref[lane < NU ? lane : 0];
       const double vfr = term ? 0.0 : in.foot_ref[lane < NF * 3 ? lane : 0];
-      // (the per-joint part of the block is issued last and committed after the row phase, which does not need it: its latency hides
-      //  behind that phase)
+      ModelLoad<D, NT> ml;
+      ml.issue(&mg, lane);
+      SMPC_SCHED_FENCE(); // (the scheduler otherwise sinks one of the model's loads below the strided ones, and its commit then waits for all)
+      // (the per-joint part of the block is issued last and committed after the row phase, which does not need it: the commits below wait
+      //  for the loads above only -- the counter is in order --, and the latency of these strided loads hides behind the row phase)
 #pragma unroll
       for (int n = 0; n < NLOAD; n++)
         SMPC_PLV(vb)[n] = blk[L::O_S + (lane + n * NT < L::N_DERIV ? lane + n * NT : 0)];
-      lanes_load_model<D, NT>(sc, &mg, lane);
+      SMPC_SCHED_FENCE();
+      ml.commit(sc, lane);
       if (lane < NX)
       {
         sc.x[lane] = vx;
@@ -171,7 +175,7 @@ namespace smpc
         {
           const int r = i - O_REST;
           if (r < 9 * NF)
-            sc.oR[mg.foot_joint[r / 9] * 9 + r % 9] = SMPC_PLV(vb)[n];
+            sc.oR[md.foot_joint[r / 9] * 9 + r % 9] = SMPC_PLV(vb)[n]; // (md: the LDS copy of the small model block -- a global read here would wait for every load in flight)
           else if (r < 9 * NF + 3)
             sc.com[r - 9 * NF] = SMPC_PLV(vb)[n];
           else if (r < 9 * NF + 9)

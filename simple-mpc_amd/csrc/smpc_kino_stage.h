@@ -156,6 +156,30 @@ namespace smpc
         dst[lane + n * NT] = r[n];
   }
 
+  // the same in two halves, for load phases that issue further (slower) loads between them: the commit then waits for the model's loads only
+  template <class D, int NT>
+  struct ModelLoad
+  {
+    static constexpr int N = (int)(sizeof(DevModelSmall<D>) / sizeof(double)), PER = (N + NT - 1) / NT;
+    double r[PER];
+    SMPC_DEV void issue(const DevModel<D> * gm, int lane)
+    {
+      const alias_double * src = reinterpret_cast<const alias_double *>(static_cast<const DevModelSmall<D> *>(gm));
+#pragma unroll
+      for (int n = 0; n < PER; n++)
+        r[n] = src[lane + n * NT < N ? lane + n * NT : 0];
+    }
+    template <class Scratch>
+    SMPC_DEV void commit(Scratch & sc, int lane) const
+    {
+      alias_double * dst = reinterpret_cast<alias_double *>(&sc.ml);
+#pragma unroll
+      for (int n = 0; n < PER; n++)
+        if (lane + n * NT < N)
+          dst[lane + n * NT] = r[n];
+    }
+  };
+
   // SE(3) work of a stage on two lanes in lockstep.  Lane 0 integrates the base (exp side, nu = dt (v + dt a)): x+ and,
   // with derivatives, Jexp6(nu) and the action matrix of exp6(nu)^-1.  Lane 1 forms the base block of the state
   // residual (log side, nu = log6(M_tgt^-1 M)) and, with derivatives, Jlog6(nu).  Both need W = [w]x, W^2, the same
