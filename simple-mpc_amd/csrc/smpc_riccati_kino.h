@@ -138,7 +138,9 @@ namespace smpc
               cnt++;
             }
       }
-      // (b) U_m = D^-1 P_m, lane = index m (every lane factors the 4x4 pivot block D = L diag(d) L^T itself)
+      // (b) U_m = D^-1 P_m, lane = index m (every lane factors the 4x4 pivot block D = L diag(d) L^T itself; the substitution is a
+      //     backward-stable solve -- two 2x2 block pivots with closed-form inverses save a fifth of this phase's instructions and were
+      //     measured, but cost the ill-conditioned stage KKT blocks of the constrained problems half a digit: 1e-5 -> 4e-5 in a closed loop)
       if (!skp)
       {
       SMPC_LANES(NT)
@@ -156,10 +158,12 @@ namespace smpc
         const double t32 = D23 - l30 * D02 - l31 * t21;
         const double l32 = t32 * i2;
         const double i3 = SMPC_RCP(D33 - l30 * D03 - l31 * t31 - l32 * t32);
+        // columns at or beyond the pivot's tile row only when the tiles before it are not maintained (ALL = false)
+        const int M0 = ALL ? 0 : 16 * Ip; // (a constant once the panel loop is unrolled)
 #pragma unroll
-        for (int rr = 0; rr < (LDW + NT - 1) / NT; rr++)
+        for (int rr = 0; rr < (LDW - M0 + NT - 1) / NT; rr++)
         {
-          const int m = lane + rr * NT;
+          const int m = M0 + lane + rr * NT;
           if (m < LDW)
           {
             const double a0 = prow[m], a1 = prow[LDW + m], a2 = prow[2 * LDW + m], a3 = prow[3 * LDW + m];
