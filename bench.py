@@ -646,6 +646,8 @@ def main():
                     "launches are filled by the next part's). Per-kernel rooflines then refer to launches of batch/N instances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the other single-GPU workloads measured beside the headline (profiling passes "
+                    "whose per-kernel means must be those of the headline launches)")
     ap.add_argument("--sync-steps", action="store_true", help="host synchronisation after every control step (default: the closed loop is one in-order queue "
                     "on the handle's stream, synchronised only at the ends of the timed region)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch path (gloo + emulated kernel bodies): not a measurement")
@@ -823,7 +825,7 @@ def main():
                 del out["kernel_share"]
         if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(args.iters)
-        if world == 1 and profile:
+        if world == 1 and profile and not args.headline_only:
             # the other single-GPU BASELINE configurations, measured briefly beside the headline (not part of `value`)
             other = {"fulldynamics_forward_dynamics": constraint_dynamics_line(gm, mh, B, gm.H)}
             del gm
