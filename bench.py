@@ -818,6 +818,15 @@ def main():
             step_fl = args.iters * H * (f_ric(ndx, nu, nc) + fc.get("deriv_flops_per_stage", 0.0))
             step_io = 8 * (2 * (H + 1) * gm.nx + 2 * H * nu + nu * ndx + (H + 1) * ndx + H * nc)
             out["step_roofline"] = both_bounds(B * step_fl, B * step_io, dt / args.steps, "mfma")
+            # HBM bytes of a whole control step by the PMC counters: per-launch bytes of the newest committed summary x launches per step
+            # (the materialised LQ problem: knots and gains go through HBM between the kernels of an iteration)
+            per = {k: pmc_traffic(k, B == 4096 and args.iters == 3) for k in ("lane_tree_body", "deriv2_body", "riccati_kino_body", "forward_kino_body", "apply_body", "trial_rows_body")}
+            if all(v[0] is not None for v in per.values()):
+                it = args.iters
+                tot = it * (per["lane_tree_body"][0] + per["deriv2_body"][0] + per["riccati_kino_body"][0] + per["forward_kino_body"][0] + per["apply_body"][0]) \
+                    + per["lane_tree_body"][0] + per["trial_rows_body"][0]
+                out["step_roofline"].update({"traffic": tot, "traffic_source": per["deriv2_body"][1], "traffic_over_compulsory": tot / (B * step_io),
+                                             "traffic_GBps": tot / (dt / args.steps) / 1e9})
             if args.streams > 1:
                 # launches of different streams overlap: event-to-event durations of single launches include the time they share the
                 # GPU with other launches, so only the whole-step figure is meaningful in this mode
@@ -829,9 +838,9 @@ def main():
             # the other single-GPU BASELINE configurations, measured briefly beside the headline (not part of `value`)
             other = {"fulldynamics_forward_dynamics": constraint_dynamics_line(gm, mh, B, gm.H)}
             del gm
-            other["centroidal"] = centroidal_line(B, args.iters, 10, 3, local_rank, not args.no_cpu_baseline)
-            other["fulldynamics_go2"] = fulldynamics_line(min(B, 4096), args.iters, 10, 3, local_rank, not args.no_cpu_baseline)
-            other["fulldynamics_talos"] = fulldynamics_line(1024, args.iters, 5, 2, local_rank, not args.no_cpu_baseline, robot="talos")
+            other["centroidal"] = centroidal_line(B, args.iters, 40, 5, local_rank, not args.no_cpu_baseline)
+            other["fulldynamics_go2"] = fulldynamics_line(min(B, 4096), args.iters, 20, 3, local_rank, not args.no_cpu_baseline)
+            other["fulldynamics_talos"] = fulldynamics_line(1024, args.iters, 10, 2, local_rank, not args.no_cpu_baseline, robot="talos")
             other["inverse_dynamics_qp"] = inverse_dynamics_line(B, local_rank, not args.no_cpu_baseline)
             other["control_stack"] = control_stack_line(B, local_rank)
             other["single_robot_latency"] = single_robot_latency(args.iters, local_rank)
