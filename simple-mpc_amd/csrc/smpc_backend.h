@@ -57,6 +57,9 @@
 // no instruction is scheduled across this point (keeps the machine scheduler from hoisting a whole unrolled loop's cross-lane reads
 // to its top, where they overflow the scalar registers and are parked in vector lanes)
 #define SMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// 1: the lanes of a wavefront run a lane phase in lockstep -- an exchange through LDS between the lanes is legal INSIDE a phase as long as the
+// control flow around it is uniform (the sequential-lane test backend says 0 and takes the per-lane form of such code)
+#define SMPC_LOCKSTEP 1
 // FP64 matrix cores (v_mfma_f64_16x16x4_f64), one wave:  D(16x16) += A(16x4) B(4x16).
 //   operands, one double per lane:   A[i][k] in lane i + 16 k ,  B[k][j] in lane j + 16 k
 //   accumulator tile t, 4 doubles per lane:   D[(lane >> 4) + 4 v][lane & 15]  in  SMPC_ACCV(acc, t, v)
@@ -80,6 +83,14 @@
 
 namespace smpc
 {
+  // 16-byte store the compiler does not track: a known store makes a non-inlined function wait for the write to complete before it returns
+  // (1 .. 2 us); for data nothing in the kernel reads back.  dst: 16-byte aligned.
+  __device__ __forceinline__ void store2_nowait(double * dst, double v0, double v1)
+  {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t vv = {v0, v1};
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(vv) : "memory");
+  }
   // a double that may alias any other type: the model blocks (doubles and ints) are copied into LDS eight bytes at a time
   typedef double __attribute__((may_alias)) alias_double;
   __device__ __forceinline__ int pin_int(int x)

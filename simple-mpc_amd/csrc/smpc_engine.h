@@ -372,6 +372,8 @@ namespace smpc
     // B = 4096 against 4.3 - 4.7 ms for the one-kernel path); SMPC_LANE_DERIV=0: the one-kernel path (A/B comparison)
     bool lane_deriv = !(std::getenv("SMPC_LANE_DERIV") && std::atoi(std::getenv("SMPC_LANE_DERIV")) == 0);
     bool lane_eval = !(std::getenv("SMPC_LANE_EVAL") && std::atoi(std::getenv("SMPC_LANE_EVAL")) == 0);
+    bool lane_stream = !(std::getenv("SMPC_LANE_STREAM") && std::atoi(std::getenv("SMPC_LANE_STREAM")) == 0);
+    bool stream_order_recorded = false;
     double kernel_ms[KID_N] = {0};
     long kernel_calls[KID_N] = {0};
     std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
@@ -488,7 +490,14 @@ namespace smpc
       buf.lq = dalloc(BH * D::LQ_STRIDE);
       buf.gains = dalloc(BH * (size_t)std::max((int)D::G_STRIDE, (int)GainsK<D>::STRIDE));
       if (lane_eval && m.lane_slots > 0 && !ks.terminal_constraint && !ks.force_cone && !ks.land_cstr)
+      {
         buf.ev = dalloc((((size_t)B + EV_LS - 1) / EV_LS) * (H + 1) * ev_tile_doubles<D>());
+        if (lane_deriv && lane_stream)
+        { // derivative pass: per-problem contiguous hand-over (SMPC_LANE_STREAM=0: the strided tile)
+          buf.evd = dalloc((size_t)B * (H + 1) * EvStream<D>::STRIDE);
+          buf.ev_order = (int *)dev_alloc((size_t)EvStream<D>::STRIDE * sizeof(int));
+        }
+      }
       buf.QN = dalloc((size_t)B * D::NDX * D::NDX);
       buf.qN = dalloc((size_t)B * D::NDX);
       buf.parts0 = dalloc((size_t)B * (H + 1) * 4);
@@ -574,6 +583,8 @@ namespace smpc
         dev_free(p);
       dev_free(buf.ls_sel);
       dev_free(buf.und_list);
+      dev_free(buf.evd);
+      dev_free(buf.ev_order);
       if (ev_handoff_valid)
         event_destroy(ev_handoff);
       dev_free(sim_a);
@@ -672,12 +683,41 @@ namespace smpc
         la.j0 = la.nj = 0;
         la.slots = slots;
         la.deriv = 1;
+        la.order = nullptr;
         const int n = slots > 0 ? slots : b.B, kid = slots > 0 ? KID_SELECT : KID_DERIV, kid_tree = slots > 0 ? KID_SELECT : KID_TREE;
-        if (lane_slots == 1)
-          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid_tree, (H + 1) * ((n + 63) / 64), la, slots > 0);
+        if (b.evd != nullptr && !stream_order_recorded)
+        {
+          // once per handle: the tree kernel itself records the order in which it produces a problem's fields (one wavefront: the order
+          // does not depend on the problem); the derivative kernel reads the fields back by that table
+          LaneKernelArgs<D> lo = la;
+          lo.b.B = b.B < 64 ? b.B : 64;
+          lo.slots = 0;
+          lo.order = b.ev_order;
+          const bool prof = profiling;
+          profiling = false;
+          if (lane_slots == 1)
+            timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1, true, true>, 64, SMPC_LANE_MINW>(KID_SELECT, 1, lo, true);
+          else
+            timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2, true, true>, 64, SMPC_LANE_MINW>(KID_SELECT, 1, lo, true);
+          profiling = prof;
+          stream_order_recorded = true;
+        }
+        const int gtree = (H + 1) * ((n + 63) / 64);
+        if (b.evd != nullptr)
+        {
+          if (lane_slots == 1)
+            timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1, true>, 64, SMPC_LANE_MINW>(kid_tree, gtree, la, slots > 0);
+          else
+            timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2, true>, 64, SMPC_LANE_MINW>(kid_tree, gtree, la, slots > 0);
+        }
+        else if (lane_slots == 1)
+          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid_tree, gtree, la, slots > 0);
         else
-          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid_tree, (H + 1) * ((n + 63) / 64), la, slots > 0);
-        timed_launch<StageKernelArgs<D>, deriv2_body<D>, 64, 2>(kid, xcd_grid(n, H), stage_args(b, slots), slots > 0);
+          timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid_tree, gtree, la, slots > 0);
+        if (b.evd != nullptr)
+          timed_launch<StageKernelArgs<D>, deriv2_body<D, true>, 64, 2>(kid, xcd_grid(n, H), stage_args(b, slots), slots > 0);
+        else
+          timed_launch<StageKernelArgs<D>, deriv2_body<D, false>, 64, 2>(kid, xcd_grid(n, H), stage_args(b, slots), slots > 0);
       }
       else if (has_ext(b))
         timed_launch<StageKernelArgs<D>, deriv_body<D, true>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
@@ -696,6 +736,7 @@ namespace smpc
         la.nj = sk.nj;
         la.slots = sk.slots;
         la.deriv = 0;
+        la.order = nullptr;
         const int n = sk.slots > 0 ? sk.slots : b.B, kid_tree = kid == KID_TRIAL ? KID_TREE : kid;
         if (lane_slots == 1)
           timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid_tree, (H + 1) * ((n + 63) / 64), la, aux);

@@ -14,11 +14,12 @@
 
 namespace smpc
 {
-  template <class D>
+  template <class D, bool STREAM>
   SMPC_DEV void deriv2_one(const StageKernelArgs<D> & ka, int inst, int t);
 
   // grid = B * (H+1) (slots == 0) or slots * (H+1) walking the compacted list of instances that rejected the tentative full step
-  template <class D>
+  // STREAM: the problem's fields arrive as one contiguous run in production order (Buffers::evd, ev_order) instead of the strided tile
+  template <class D, bool STREAM = false>
   SMPC_DEV void deriv2_body(const StageKernelArgs<D> & ka, int block)
   {
     const int H = ka.b.H;
@@ -29,10 +30,10 @@ namespace smpc
     const int count = ka.slots > 0 ? (slot < ka.slots ? ka.b.und_list[ka.b.B] : 0) : (slot < ka.b.B ? slot + 1 : 0); // (padding blocks: idle)
     const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
     for (int m = slot; m < count; m += stride)
-      deriv2_one<D>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t);
+      deriv2_one<D, STREAM>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t);
   }
 
-  template <class D>
+  template <class D, bool STREAM>
   SMPC_DEV void deriv2_one(const StageKernelArgs<D> & ka, int inst, int t)
   {
     typedef KinoScratch<D, true> KinoScratchT;
@@ -77,7 +78,8 @@ namespace smpc
                   "scratch layout: S | vel | acc | Ic contiguous");
     static_assert(L::O_JeQ == L::O_Je3 + 9 && L::O_Jq == L::O_JeQ + 9 && L::O_Jl == L::O_Jq + 36, "block layout: SE(3) Jacobians contiguous");
     constexpr int O_REST = L::O_oRf - L::O_S; // fields after the tree run: oRf 9 NF | com 3 | dab 6 | Agbi 36 | Je3 .. Jl 90
-    constexpr int NLOAD = (L::N_DERIV + NT - 1) / NT;
+    constexpr int NLOAD = STREAM ? EvStream<D>::NLOAD : (L::N_DERIV + NT - 1) / NT;
+    const double * const pblk = STREAM ? b.evd + ((size_t)(b.ev_inst0 + inst) * (H + 1) + t) * EvStream<D>::STRIDE : nullptr;
     // the two runs as plain double pointers into the scratch (an index past the end of the first member array of a run must not be
     // visible to the optimiser as an out-of-bounds subscript)
     double * const run_tree = reinterpret_cast<double *>(&sc) + offsetof(KinoScratchT, S) / sizeof(double);
@@ -88,6 +90,7 @@ namespace smpc
     SMPC_PL(double, pnu, NT);
     SMPC_PL(double, nue, NT);
     SMPC_PLA(double, vb, NT, NLOAD);
+    SMPC_PLA(int, oi, NT, NLOAD); // STREAM: field id of each loaded element (EvLayout offsets; < HEAD: head of candidate 0)
     SMPC_LANES(NT)
     {
       // every global load of the block back to back (index clamped, one wait), then committed to LDS
@@ -99,7 +102,7 @@ namespace smpc
       const double vn = b.vs[(ib + st) * NC + (lane < NC ? lane : 0)];
       const double vle = b.lams_e[(ib + st) * NDX + (lane < NDX ? lane : 0)];
       const double vne = b.vs_e[(ib + st) * NC + (lane < NC ? lane : 0)];
-      const double vh = blk[L::O_head + (lane < L::HEAD ? lane : 0)];
+      const double vh = STREAM ? 0.0 : blk[L::O_head + (lane < L::HEAD ? lane : 0)];
       const double vxt = *((vref != nullptr && lane >= D::NQ && lane < D::NQ + 6) ? vref + (lane - D::NQ) : in.x_tgt + (lane < NX ? lane : 0));
       const double vur = term ? 0.0 : in.u_ref[lane < NU ? lane : 0];
       const double vfr = term ? 0.0 : in.foot_ref[lane < NF * 3 ? lane : 0];
@@ -110,7 +113,16 @@ namespace smpc
       //  for the loads above only -- the counter is in order --, and the latency of these strided loads hides behind the row phase)
 #pragma unroll
       for (int n = 0; n < NLOAD; n++)
-        SMPC_PLV(vb)[n] = blk[L::O_S + (lane + n * NT < L::N_DERIV ? lane + n * NT : 0)];
+      {
+        if constexpr (STREAM)
+        {
+          const int idx = lane + n * NT < EvStream<D>::STRIDE ? lane + n * NT : EvStream<D>::STRIDE - 1; // (the last position is padding)
+          SMPC_PLV(vb)[n] = pblk[idx];
+          SMPC_PLV(oi)[n] = b.ev_order[idx];
+        }
+        else
+          SMPC_PLV(vb)[n] = blk[L::O_S + (lane + n * NT < L::N_DERIV ? lane + n * NT : 0)];
+      }
       SMPC_SCHED_FENCE();
       ml.commit(sc, lane);
       if (lane < NX)
@@ -135,13 +147,36 @@ namespace smpc
         sc.lam_next[lane] = term ? 0.0 : vl;
       if (lane < NC)
         sc.nu[lane] = term ? 0.0 : vn;
-      rs.head[lane] = vh;
-      if (lane >= L::H_footp && lane < L::H_footp + 3 * NF)
-        sc.footp[lane - L::H_footp] = vh;
-      if (lane >= L::H_hg && lane < L::H_hg + 6)
-        sc.hg[lane - L::H_hg] = vh;
-      if (lane >= L::H_hd && lane < L::H_hd + 6)
-        sc.hd[lane - L::H_hd] = vh;
+      if constexpr (STREAM)
+      {
+        // the head's 54 fields sit among the others (production order): the rows need them now, the rest is committed after the rows
+#pragma unroll
+        for (int n = 0; n < NLOAD; n++)
+        {
+          const int h = SMPC_PLV(oi)[n];
+          const double v = SMPC_PLV(vb)[n];
+          if (h >= 0 && h < L::HEAD)
+          {
+            rs.head[h] = v;
+            if (h >= L::H_footp && h < L::H_footp + 3 * NF)
+              sc.footp[h - L::H_footp] = v;
+            if (h >= L::H_hg && h < L::H_hg + 6)
+              sc.hg[h - L::H_hg] = v;
+            if (h >= L::H_hd && h < L::H_hd + 6)
+              sc.hd[h - L::H_hd] = v;
+          }
+        }
+      }
+      else
+      {
+        rs.head[lane] = vh;
+        if (lane >= L::H_footp && lane < L::H_footp + 3 * NF)
+          sc.footp[lane - L::H_footp] = vh;
+        if (lane >= L::H_hg && lane < L::H_hg + 6)
+          sc.hg[lane - L::H_hg] = vh;
+        if (lane >= L::H_hd && lane < L::H_hd + 6)
+          sc.hd[lane - L::H_hd] = vh;
+      }
       SMPC_PLV(plam) = term ? 0.0 : vl;
       SMPC_PLV(lame) = vle;
       SMPC_PLV(pnu) = term ? 0.0 : vn;
@@ -168,7 +203,7 @@ namespace smpc
 #pragma unroll
       for (int n = 0; n < NLOAD; n++)
       {
-        const int i = lane + n * NT;
+        const int i = STREAM ? (SMPC_PLV(oi)[n] >= L::O_S ? SMPC_PLV(oi)[n] - L::O_S : L::N_DERIV) : lane + n * NT; // (STREAM: head / padding -> no-op)
         if (i < N_TREE)
           run_tree[i] = SMPC_PLV(vb)[n]; // S | vel | acc | Ic (= the bodies' own inertias until the composite phase)
         else if (i < L::N_DERIV)

@@ -65,8 +65,22 @@ namespace smpc
     int j0, nj; // TRIAL: candidate range
     int slots;  // 0: lane per (instance, stage) of the batch; > 0: walk the compacted list of undecided instances
     int deriv;  // 1: DERIV mode
+    int * order; // DERIV mode, set-up launch only: record the field id of every position of the problem's stream (Buffers::ev_order)
   };
 
+  // Derivative pass: the tree kernel's fields of a problem (head of candidate 0 + the derivative part) as ONE contiguous run, in production
+  // order -- the wavefront that reads a problem then takes it with ten fully coalesced loads instead of 619 doubles at a stride of 512
+  // bytes (16 x the L2 -> L1 line traffic: 0.28 ms of the derivative kernel's 3.1).  The tree kernel parks EV_CH fields per lane in LDS
+  // rows it no longer needs (the base part of its staged inputs) and flushes them transposed: every store instruction writes four
+  // problems' 128-byte runs.
+  constexpr int EV_CH = 16;
+  template <class D>
+  struct EvStream
+  {
+    static constexpr int N = EvLayout<D>::HEAD + EvLayout<D>::N_DERIV;
+    static constexpr int STRIDE = ((N + EV_CH - 1) / EV_CH) * EV_CH;
+    static constexpr int NLOAD = (STRIDE + 63) / 64;
+  };
   // Field i of lane l of tile w lives at ev[(w * STRIDE + i) * 64 + l].
   constexpr int EV_LS = 64;
   struct LaneBlk
@@ -192,10 +206,14 @@ namespace smpc
   {
     static constexpr int F_xb = 0;            // 7  base of x (raw)
     static constexpr int F_dxb = F_xb + 7;    // 6  base of dx (raw)
-    static constexpr int F_q = F_dxb + 6;     // NJ - 1 joint angles of the evaluation point
-    static constexpr int F_v = F_q + D::NJ - 1; // NV velocities of the evaluation point
-    static constexpr int F_u = F_v + D::NV;   // NU controls of the evaluation point
+    static constexpr int F_vb = F_dxb + 6;    // 6  base velocities of the evaluation point
+    static constexpr int F_q = F_vb + 6;      // NJ - 1 joint angles of the evaluation point
+    static constexpr int F_vj = F_q + D::NJ - 1; // NV - 6 joint velocities
+    static constexpr int F_u = F_vj + D::NV - 6; // NU controls of the evaluation point
     static constexpr int N = F_u + D::NU;
+    // rows F_xb .. F_vb + 5 are read into registers before a lane produces its first output: in DERIV mode with the stream hand-over that
+    // memory (FREE rows of LANE_PAD doubles) becomes the lanes' field-parking area
+    static constexpr int FREE = F_q;
   };
 
   // Model constants the tree pass reads joint by joint, copied into LDS once per block: the hand-over stores of joint j - 1 and the
@@ -208,11 +226,34 @@ namespace smpc
     int jtype[D::NJ], par_slot[D::NJ], save_slot[D::NJ], foot_joint[D::NF];
   };
 
+  // Stream hand-over, device side.  Every lane parks the fields it produces in its own EV_CH (+1 pad) doubles of the parking area
+  // (lane-major: park[lane * EV_PP + k]); when EV_CH are there the wavefront flushes them transposed: lane -> (problem q * 8 + lane / 8,
+  // fields 2 (lane % 8), + 1), i.e. eight problems' 128-byte runs per store instruction.  Not inlined: reached from every store site.
+  constexpr int EV_PP = EV_CH + 1;
+  template <class D>
+  SMPC_DEV_NOINLINE void ev_stream_flush(const double * park, const unsigned * poff, double * evd, int np, int c0, int lane)
+  {
+    constexpr int NT = 64, PB = NT / (EV_CH / 2); // problems per store instruction
+#pragma unroll
+    for (int q = 0; q < NT / PB; q++)
+    {
+      const int p = q * PB + lane / (EV_CH / 2), f = 2 * (lane % (EV_CH / 2));
+      const double v0 = park[p * EV_PP + f], v1 = park[p * EV_PP + f + 1];
+      double * dst = evd + (size_t)poff[p] + c0 + f;
+      if (p < np)
+      {
+        store2_nowait(dst, v0, v1);
+      }
+    }
+  }
+
   // =============================================================================================
   // lane_tree_body: lanes of a block share the stage t; lane <-> instance (full-batch launch) or entry of the compacted list of
   // undecided instances (slots > 0).  grid = (H + 1) * ceil(n / 64), n = B or slots.
   // =============================================================================================
-  template <class D, int NSLOT>
+  // STREAM (DERIV mode only): the derivative pass's hand-over as a per-problem contiguous stream (EvStream) instead of the tile
+  // RECORD: the set-up launch that writes the order of the stream's fields (LaneKernelArgs::order)
+  template <class D, int NSLOT, bool STREAM = false, bool RECORD = false>
   SMPC_DEV void lane_tree_body(const LaneKernelArgs<D> & ka, int block)
   {
     typedef EvLayout<D> L;
@@ -231,8 +272,12 @@ namespace smpc
     const int count = ka.slots > 0 ? b.und_list[b.B] : b.B;
     const int stride = ka.slots > 0 ? ka.slots : b.B; // entries per sweep of the grid
     const double dt = mg.dt;
+    typedef EvStream<D> ES;
     SMPC_LDS(double, stg, ST::N * LANE_PAD);
+    SMPC_LDS(unsigned, poff, NT); // offset of every lane's problem in the stream buffer, in doubles (the flush addresses other lanes' blocks)
     SMPC_LDS(LaneModel<D>, lms, 1);
+    constexpr bool stream = STREAM; // (DERIV mode with Buffers::evd)
+    static_assert(NT * EV_PP <= ST::FREE * LANE_PAD, "the parking area fits the staged rows that are read before the first field is produced");
     LaneModel<D> & lm = lms[0];
     SMPC_LANES(NT)
     {
@@ -260,6 +305,7 @@ namespace smpc
     SMPC_LANES_END_WAVE
     const double total_mass = mg.total_mass;
     const V3 gravity = ld3(mg.gravity);
+    int spos = 0; // position in a problem's stream: the same in every lane (declared here, in uniform control flow, so that it lives in a scalar register)
     for (int base = g * NT; base < count; base += stride)
     {
       const int np = count - base < NT ? count - base : NT; // problems of this sweep
@@ -298,7 +344,8 @@ namespace smpc
               {
                 if (lane < NX)
                 {
-                  const int f = lane < 7 ? ST::F_xb + lane : ST::F_q + lane - 7; // (F_q .. F_v + NV - 1 is one run: x[7 ..])
+                  // x = [base 7 | joint angles NJ-1 | base velocities 6 | joint velocities]
+                  const int f = lane < 7 ? ST::F_xb + lane : (lane < 7 + NJ - 1 ? ST::F_q + lane - 7 : (lane < 7 + NJ - 1 + 6 ? ST::F_vb + lane - (7 + NJ - 1) : ST::F_vj + lane - (7 + NJ - 1 + 6)));
                   stg[f * LANE_PAD + p] = (!deriv && lane >= 7) ? vx[q] + alpha * vdx[q] : vx[q];
                 }
                 if (!deriv && lane < 6)
@@ -310,17 +357,75 @@ namespace smpc
           }
         }
         SMPC_LANES_END_WAVE
-        static_assert(ST::F_v == ST::F_q + NJ - 1 && ST::F_u == ST::F_v + NV, "x[7 ..] is staged as one run");
         // ---- lane = problem ----
         SMPC_LANES(NT)
-        if (lane < np)
+        if (lane < np || (stream && SMPC_LOCKSTEP)) // (stream: the flush is a wave-wide transposition -- idle lanes run along on a neighbour's instance and store nothing)
         {
-          const int inst = ka.slots > 0 ? b.und_list[base + lane] : base + lane;
+          const int pl = lane < np ? lane : np - 1;
+          const int inst = ka.slots > 0 ? b.und_list[base + pl] : base + pl;
           if (deriv || ka.slots > 0 || b.ls_sel[inst] < 0) // (full-batch trial launch: skip the instances that already accepted a candidate)
           {
             const LaneBlk blk = lane_block<D>(b, inst, t);
             const int hd0 = L::O_head + cand * L::HEAD;
             auto SG = [&](int f) { return stg[f * LANE_PAD + lane]; };
+            // ---- outputs: tile (field-major, EVAL mode) or stream (DERIV mode: EV_CH fields parked in this lane's column of the
+            //      rows that staged the base inputs, then flushed transposed; `spos` is the same in every lane) ----
+            spos = 0;
+            const size_t pbase = ((size_t)(b.ev_inst0 + inst) * (H + 1) + t) * ES::STRIDE; // (< 2^32 doubles: 34 GB of stream)
+            double * wp = stg + lane * EV_PP; // this lane's parking slot of the next field
+            if (stream)
+              poff[lane] = (unsigned)pbase;
+            auto put = [&](int id, double v) {
+              if constexpr (SMPC_LOCKSTEP)
+                *wp++ = v;
+              else
+                b.evd[pbase + spos] = v; // (lanes one after the other: straight into the lane's own block)
+              if constexpr (RECORD)
+                ka.order[spos] = id;
+              spos++;
+              if constexpr (SMPC_LOCKSTEP)
+                if (spos % EV_CH == 0)
+                {
+                  ev_stream_flush<D>(stg, poff, b.evd, np, spos - EV_CH, lane);
+                  wp -= EV_CH;
+                }
+            };
+            auto O1 = [&](int off, double v) {
+              if (stream)
+                put(off, v);
+              else
+                blk[off] = v;
+            };
+            auto O3 = [&](int off, V3 v) {
+              O1(off, v.x);
+              O1(off + 1, v.y);
+              O1(off + 2, v.z);
+            };
+            auto OSV = [&](int off, const SV & sv_) {
+              O3(off, sv_.l);
+              O3(off + 3, sv_.a);
+            };
+            auto OM3 = [&](int off, const M3 & m) {
+              O1(off, m.a00);
+              O1(off + 1, m.a01);
+              O1(off + 2, m.a02);
+              O1(off + 3, m.a10);
+              O1(off + 4, m.a11);
+              O1(off + 5, m.a12);
+              O1(off + 6, m.a20);
+              O1(off + 7, m.a21);
+              O1(off + 8, m.a22);
+            };
+            auto OSI = [&](int off, const SI & I_) {
+              O1(off, I_.m);
+              O3(off + 1, I_.mc);
+              O1(off + 4, I_.jxx);
+              O1(off + 5, I_.jxy);
+              O1(off + 6, I_.jxz);
+              O1(off + 7, I_.jyy);
+              O1(off + 8, I_.jyz);
+              O1(off + 9, I_.jzz);
+            };
             double xb[7];
             {
               double xr[7], dxr[6];
@@ -335,7 +440,7 @@ namespace smpc
             double vb[6];
 #pragma unroll
             for (int k = 0; k < 6; k++)
-              vb[k] = SG(ST::F_v + k);
+              vb[k] = SG(ST::F_vb + k);
             // ---- root -> leaf, one pass: placements, motion columns, velocities, accelerations, body inertias; totals at the
             //      root.  The loop stays rolled: j is uniform, the model constants of a joint are scalar loads of that iteration ----
             LaneJoint cur, slot[NSLOT];
@@ -359,7 +464,7 @@ namespace smpc
                   const SV sk = k < 3 ? SV{ax, mk3(0, 0, 0)} : SV{cross(p0, ax), ax};
                   cur.v = cur.v + vb[k] * sk;
                   if (deriv)
-                    stsv(blk, L::O_S + k * 6, sk);
+                    OSV(L::O_S + k * 6, sk);
                 }
                 cur.a = sv0();
               }
@@ -379,14 +484,14 @@ namespace smpc
                 const V3 pj = cur.p + cur.R * ld3(lm.jpp[j]);
                 const V3 ax = m3_col(Rj, jt - 1);
                 const SV sk = SV{cross(pj, ax), ax};
-                const double qd = SG(ST::F_v + j + 5), aj = SG(ST::F_u + 3 * NF + j - 1);
+                const double qd = SG(ST::F_vj + j - 1), aj = SG(ST::F_u + 3 * NF + j - 1);
                 const SV vp = cur.v;
                 cur.R = Rj;
                 cur.p = pj;
                 cur.v = vp + qd * sk;
                 cur.a = cur.a + qd * crm(vp, sk) + aj * sk;
                 if (deriv)
-                  stsv(blk, L::O_S + (j + 5) * 6, sk);
+                  OSV(L::O_S + (j + 5) * 6, sk);
               }
               {
                 const int ss = lm.save_slot[j];
@@ -428,9 +533,9 @@ namespace smpc
                 }
                 if (deriv)
                 {
-                  stsv(blk, L::O_vel + j * 6, cur.v);
-                  stsv(blk, L::O_acc + j * 6, cur.a);
-                  stsi(blk, L::O_I + j * 10, I);
+                  OSV(L::O_vel + j * 6, cur.v);
+                  OSV(L::O_acc + j * 6, cur.a);
+                  OSI(L::O_I + j * 10, I);
                 }
               }
 #pragma unroll 1
@@ -438,9 +543,9 @@ namespace smpc
                 if (j == lm.foot_joint[f])
                 {
                   const V3 fp = cur.R * ld3(lm.foot_p[f]) + cur.p;
-                  st3(blk, hd0 + L::H_footp + f * 3, fp);
+                  O3(hd0 + L::H_footp + f * 3, fp);
                   // LOCAL-frame velocity of the foot point (the contact rows)
-                  st3(blk, hd0 + L::H_fv + f * 3, tmul(cur.R, cur.v.l + cross(cur.v.a, fp)));
+                  O3(hd0 + L::H_fv + f * 3, tmul(cur.R, cur.v.l + cross(cur.v.a, fp)));
                   if ((mask >> f) & 1u)
                   {
                     const V3 Ff = mk3(SG(ST::F_u + 3 * f), SG(ST::F_u + 3 * f + 1), SG(ST::F_u + 3 * f + 2));
@@ -448,7 +553,7 @@ namespace smpc
                     msum = msum + cross(fp, Ff);
                   }
                   if (deriv)
-                    stm3(blk, L::O_oRf + f * 9, cur.R);
+                    OM3(L::O_oRf + f * 9, cur.R);
                 }
             }
             // ---- centre of mass, centroidal momentum, its rate without the base acceleration, the target rate ----
@@ -457,12 +562,12 @@ namespace smpc
             double rhs[6];
             {
               const V3 hga = htot.a - cross(com, htot.l);
-              st3(blk, hd0 + L::H_hg, htot.l);
-              st3(blk, hd0 + L::H_hg + 3, hga);
+              O3(hd0 + L::H_hg, htot.l);
+              O3(hd0 + L::H_hg + 3, hga);
               const V3 fl = total_mass * gravity + fsum;
               const V3 fa = msum - cross(com, fsum); // sum (p_f - c) x F_f
-              st3(blk, hd0 + L::H_hd, fl);
-              st3(blk, hd0 + L::H_hd + 3, fa);
+              O3(hd0 + L::H_hd, fl);
+              O3(hd0 + L::H_hd + 3, fa);
               const V3 ba = Ftot.a - cross(com, Ftot.l);
               rhs[0] = fl.x - Ftot.l.x;
               rhs[1] = fl.y - Ftot.l.y;
@@ -514,14 +619,14 @@ namespace smpc
                 for (int m = 0; m < 6; m++)
                   s += Agbi[r * 6 + m] * rhs[m];
                 ab[r] = term ? 0.0 : s;
-                blk[hd0 + L::H_ab + r] = ab[r];
+                O1(hd0 + L::H_ab + r, ab[r]);
               }
               if (deriv)
               {
 #pragma unroll
                 for (int i = 0; i < 36; i++)
-                  blk[L::O_Agbi + i] = Agbi[i];
-                st3(blk, L::O_com, com);
+                  O1(L::O_Agbi + i, Agbi[i]);
+                O3(L::O_com, com);
                 SV dab = sv0();
 #pragma unroll
                 for (int k = 0; k < 6; k++)
@@ -529,7 +634,7 @@ namespace smpc
                   const V3 ax = m3_col(R0, k % 3);
                   dab = dab + ab[k] * (k < 3 ? SV{ax, mk3(0, 0, 0)} : SV{cross(p0, ax), ax});
                 }
-                stsv(blk, L::O_dab, dab);
+                OSV(L::O_dab, dab);
               }
             }
             // ---- x+ = x (+) [dt (v + dt a); dt a]: base on SE(3); base rows of the defect e = x+ (-) x_{t+1} ----
@@ -550,8 +655,8 @@ namespace smpc
               {
                 const M3 Q = se3_Q(-1.0 * vec, -1.0 * w, kf);
                 const M3 J = m3_id() + (-kf.B) * W + kf.C * W2; // Jexp3(w)
-                stm3(blk, L::O_Je3, J);
-                stm3(blk, L::O_JeQ, Q);
+                OM3(L::O_Je3, J);
+                OM3(L::O_JeQ, Q);
                 // action matrix of exp6(nu)^-1 = [[R^T, -R^T [p]x],[0, R^T]]
                 const M3 Rt = transpose(m3_id() + kf.sinc * W + kf.B * W2);
                 const M3 Xm = (-1.0) * (Rt * skew(out));
@@ -562,10 +667,10 @@ namespace smpc
 #pragma unroll
                   for (int jx = 0; jx < 3; jx++)
                   {
-                    blk[L::O_Jq + i * 6 + jx] = rt[i * 3 + jx];
-                    blk[L::O_Jq + (i + 3) * 6 + jx + 3] = rt[i * 3 + jx];
-                    blk[L::O_Jq + i * 6 + jx + 3] = xx[i * 3 + jx];
-                    blk[L::O_Jq + (i + 3) * 6 + jx] = 0.0;
+                    O1(L::O_Jq + i * 6 + jx, rt[i * 3 + jx]);
+                    O1(L::O_Jq + (i + 3) * 6 + jx + 3, rt[i * 3 + jx]);
+                    O1(L::O_Jq + i * 6 + jx + 3, xx[i * 3 + jx]);
+                    O1(L::O_Jq + (i + 3) * 6 + jx, 0.0);
                   }
               }
               if (!term)
@@ -585,8 +690,13 @@ namespace smpc
                 const SE3 Ma{quat_to_R(qn), pn};
                 V3 ev, ew;
                 log6(se3_mul(se3_inv(Mb), Ma), ev, ew);
-                st3(blk, hd0 + L::H_eb, ev);
-                st3(blk, hd0 + L::H_eb + 3, ew);
+                O3(hd0 + L::H_eb, ev);
+                O3(hd0 + L::H_eb + 3, ew);
+              }
+              else if (stream)
+              { // (the stream has the same fields at every node: the terminal node has no defect)
+                O3(hd0 + L::H_eb, mk3(0, 0, 0));
+                O3(hd0 + L::H_eb + 3, mk3(0, 0, 0));
               }
             }
             // ---- base rows of the state residual rx = x (-) x_tgt (SE(3) log), Jlog6 for the derivative pass ----
@@ -603,8 +713,8 @@ namespace smpc
               const M3 W2 = W * W;
               const SE3Coef kf = se3_coef(tw);
               const V3 out = M.p + (-0.5) * (W * M.p) + kf.D * (W2 * M.p);
-              st3(blk, hd0 + L::H_rb, out);
-              st3(blk, hd0 + L::H_rb + 3, w);
+              O3(hd0 + L::H_rb, out);
+              O3(hd0 + L::H_rb + 3, w);
               if (deriv)
               {
                 const M3 Q = se3_Q(-1.0 * out, -1.0 * w, kf);
@@ -617,13 +727,16 @@ namespace smpc
 #pragma unroll
                   for (int jx = 0; jx < 3; jx++)
                   {
-                    blk[L::O_Jl + i * 6 + jx] = ji[i * 3 + jx];
-                    blk[L::O_Jl + (i + 3) * 6 + jx + 3] = ji[i * 3 + jx];
-                    blk[L::O_Jl + i * 6 + jx + 3] = xx[i * 3 + jx];
-                    blk[L::O_Jl + (i + 3) * 6 + jx] = 0.0;
+                    O1(L::O_Jl + i * 6 + jx, ji[i * 3 + jx]);
+                    O1(L::O_Jl + (i + 3) * 6 + jx + 3, ji[i * 3 + jx]);
+                    O1(L::O_Jl + i * 6 + jx + 3, xx[i * 3 + jx]);
+                    O1(L::O_Jl + (i + 3) * 6 + jx, 0.0);
                   }
               }
             }
+            if (stream)
+              while (spos % EV_CH != 0)
+                put(-1, 0.0); // (padding up to the last flush)
           }
         }
         SMPC_LANES_END_WAVE

@@ -135,6 +135,10 @@ namespace smpc
     // working set of the evaluating lane and the hand-over to the derivative kernel.  nullptr: the handle does not use it.
     double * ev = nullptr;
     int ev_inst0 = 0; // first instance of this view of the batch (the blocks are tiled over the whole batch)
+    // derivative pass: the hand-over of a problem as one contiguous run [B][H+1][EvStream::STRIDE] in the order the tree kernel produces its
+    // fields, and that order (ev_order[position] = field id of EvLayout, -1: padding; recorded once by the kernel itself).  nullptr: tiles.
+    double * evd = nullptr;
+    int * ev_order = nullptr;
     double *QN = nullptr, *qN = nullptr; // [B][NDX*NDX], [B][NDX]
     // terminal equality constraint com + tau vcom = dcm_ref (DCMPositionResidual; createProblem(..., terminal_constraint = true),
     // reference src/ocp-handler.cpp:133-136, src/kinodynamics.cpp:366-388).  CN == nullptr: the problem has none.

@@ -37,6 +37,7 @@
 #define SMPC_XLANE(name, src) name[src]
 #define SMPC_XLANE_A(name, idx, src) name[src][idx]
 #define SMPC_SCHED_FENCE() ((void)0)
+#define SMPC_LOCKSTEP 0 // (lanes run one after the other)
 // wave-collective matrix-core step (see the HIP backend for the lane maps); called between lane phases
 #define SMPC_ACC(name, NT, n) double name[NT][n][4]
 #define SMPC_ACCV(name, t, v) name[lane][t][v]
@@ -68,6 +69,11 @@ namespace smpc
   }
   inline bool emu_reverse = std::getenv("SMPC_EMU_REVERSE") != nullptr && std::getenv("SMPC_EMU_REVERSE")[0] == '1';
   typedef int stream_t;
+  inline void store2_nowait(double * dst, double v0, double v1)
+  {
+    dst[0] = v0;
+    dst[1] = v1;
+  }
   inline void * stream_native(stream_t) { return nullptr; } // (no streams in the sequential build)
   inline void * dev_alloc(size_t bytes)
   {

@@ -9,7 +9,7 @@ import oracle_lib as O
 
 
 def _loop(env, monkeypatch, lib, steps=4, batch=3, max_iters=2, horizon=12):
-    for k in ("SMPC_LANE_EVAL", "SMPC_LANE_DERIV"):
+    for k in ("SMPC_LANE_EVAL", "SMPC_LANE_DERIV", "SMPC_LANE_STREAM"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -53,3 +53,30 @@ def test_lane_derivative_path_matches_oracle_emulated(monkeypatch):
 @pytest.mark.gpu
 def test_lane_paths_match_the_one_kernel_path_gpu(monkeypatch):
     _check(None, monkeypatch, 1e-8)
+
+
+def _stream_pair(monkeypatch, lib, bitwise, **kw):
+    a = _loop({"SMPC_LANE_STREAM": "0"}, monkeypatch, lib, **kw)
+    b = _loop({}, monkeypatch, lib, **kw)
+    for (xa, ua), (xb, ub) in zip(a, b):
+        assert np.all(np.isfinite(xb))
+        if bitwise:
+            assert np.array_equal(xa, xb) and np.array_equal(ua, ub)
+        else:
+            assert S.rel_err(xa, xb) < 1e-12 and S.rel_err(ua, ub) < 1e-11
+
+
+def test_stream_handover_is_the_tile_handover_emulated(monkeypatch):
+    """The derivative pass takes the tree kernel's fields as one contiguous run per problem, in production order, through the order table the
+    kernel records itself (Buffers::evd / ev_order; SMPC_LANE_STREAM=0: the strided tile): the same numbers by another route."""
+    _stream_pair(monkeypatch, S.emu_lib(), True, steps=4, batch=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [3, 70, 200])
+def test_stream_handover_is_the_tile_handover_gpu(monkeypatch, batch):
+    # (on the GPU the stream is flushed by a wave-wide transposition through LDS: partial wavefronts -- 3, 70 = 64 + 6 -- have idle lanes
+    #  running along; the random states make some instances backtrack: list-mode launches with a few entries.  The two forms of the tree
+    #  kernel are separate template instantiations: the compiler contracts a few multiply-adds differently in them, so single instances
+    #  differ in the last bit after some steps -- 1e-16 .. 4e-14 observed, tools/stream_cmp.py; the CPU build of the kernels is bit-identical)
+    _stream_pair(monkeypatch, None, False, steps=6, batch=batch, max_iters=3, horizon=20)

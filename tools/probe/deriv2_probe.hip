@@ -3,4 +3,4 @@
 #include "smpc_engine.h"
 using namespace smpc;
 typedef Dims<13, 4> D;
-template __global__ void smpc::kernel_entry<StageKernelArgs<D>, deriv2_body<D>, 64, 2, 0>(StageKernelArgs<D>);
+template __global__ void smpc::kernel_entry<StageKernelArgs<D>, deriv2_body<D, false>, 64, 2, 0>(StageKernelArgs<D>);
