@@ -89,7 +89,9 @@ namespace smpc
   {
     typedef double d2_t __attribute__((ext_vector_type(2)));
     const d2_t vv = {v0, v1};
-    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(vv) : "memory");
+    // (s_nop: a store of more than 64 bits needs a wait state before a VALU write of its data registers -- the hazard recogniser does not
+    //  look into inline assembly)
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(vv) : "memory");
   }
   // a double that may alias any other type: the model blocks (doubles and ints) are copied into LDS eight bytes at a time
   typedef double __attribute__((may_alias)) alias_double;

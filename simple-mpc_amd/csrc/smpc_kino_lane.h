@@ -234,17 +234,22 @@ namespace smpc
   SMPC_DEV_NOINLINE void ev_stream_flush(const double * park, const unsigned * poff, double * evd, int np, int c0, int lane)
   {
     constexpr int NT = 64, PB = NT / (EV_CH / 2); // problems per store instruction
+    // (straight-line: all LDS reads, one wait, all stores.  A lane whose problem does not exist -- partial wavefront -- repeats the last
+    //  problem's store: the same bytes to the same address)
+    const int f = 2 * (lane % (EV_CH / 2));
+    double v0[NT / PB], v1[NT / PB];
+    unsigned po[NT / PB];
 #pragma unroll
     for (int q = 0; q < NT / PB; q++)
     {
-      const int p = q * PB + lane / (EV_CH / 2), f = 2 * (lane % (EV_CH / 2));
-      const double v0 = park[p * EV_PP + f], v1 = park[p * EV_PP + f + 1];
-      double * dst = evd + (size_t)poff[p] + c0 + f;
-      if (p < np)
-      {
-        store2_nowait(dst, v0, v1);
-      }
+      const int p0 = q * PB + lane / (EV_CH / 2), p = p0 < np ? p0 : np - 1;
+      v0[q] = park[p * EV_PP + f];
+      v1[q] = park[p * EV_PP + f + 1];
+      po[q] = poff[p];
     }
+#pragma unroll
+    for (int q = 0; q < NT / PB; q++)
+      store2_nowait(evd + (size_t)po[q] + c0 + f, v0[q], v1[q]);
   }
 
   // =============================================================================================
