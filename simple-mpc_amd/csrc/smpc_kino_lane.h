@@ -19,7 +19,10 @@
 // table says which: DevModel::par_slot / save_slot).  The evaluation needs no composite quantity per joint -- only the totals at
 // the root (momentum, its rate including the joint accelerations) -- so there is no leaf -> root pass.
 // Lanes of a wavefront share the stage index t (hence the contact mask: branches on it are scalar), consecutive lanes are
-// consecutive instances.  The blocks of the 64 problems of a wavefront are interleaved (field-major tile).
+// consecutive instances.  Outputs: line-search evaluations go to field-major tiles of the wavefront's 64 problems (EvLayout: coalesced
+// stores, one strided load per reader); the derivative pass goes to a per-problem contiguous stream in production order (EvStream,
+// ev_stream_flush: parked per lane in LDS, flushed by a wave-wide transposition; the reader takes it with coalesced loads and commits it
+// by the order table the kernel records itself).
 #pragma once
 #include "smpc_kino_kernels.h"
 
