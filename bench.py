@@ -823,8 +823,9 @@ def main():
             per = {k: pmc_traffic(k, B == 4096 and args.iters == 3) for k in ("lane_tree_body", "deriv2_body", "riccati_kino_body", "forward_kino_body", "apply_body", "trial_rows_body")}
             if all(v[0] is not None for v in per.values()):
                 it = args.iters
+                tls = pmc_traffic("lane_tree_ls_body", True)[0]  # (line-search launch of the tree kernel; older summaries: one key for both modes)
                 tot = it * (per["lane_tree_body"][0] + per["deriv2_body"][0] + per["riccati_kino_body"][0] + per["forward_kino_body"][0] + per["apply_body"][0]) \
-                    + per["lane_tree_body"][0] + per["trial_rows_body"][0]
+                    + (tls if tls is not None else per["lane_tree_body"][0]) + per["trial_rows_body"][0]
                 out["step_roofline"].update({"traffic": tot, "traffic_source": per["deriv2_body"][1], "traffic_over_compulsory": tot / (B * step_io),
                                              "traffic_GBps": tot / (dt / args.steps) / 1e9})
             if args.streams > 1:

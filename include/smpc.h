@@ -280,8 +280,8 @@ int smpc_debug_get_terminal(smpc_handle * h, int inst, double * QN, double * qN)
 int smpc_debug_get_phase_cycles(smpc_handle * h, double * out64);
 
 /* profiling: when enabled every kernel launch is bracketed by HIP events on the handle's stream.
- * smpc_get_kernel_times: ms[8], calls[8] for recede, deriv, riccati, forward, trial, select, apply, tree (the lane-per-problem tree pass
- * that precedes the derivative and line-search kernels of a kinodynamics handle). */
+ * smpc_get_kernel_times: ms[9], calls[9] for recede, deriv, riccati, forward, trial, select, apply, tree, tree_ls (the lane-per-problem tree
+ * pass that precedes the derivative resp. the line-search kernel of a kinodynamics handle). */
 int smpc_set_profiling(smpc_handle * h, int enabled);
 int smpc_get_kernel_times(smpc_handle * h, double * ms, long * calls);
 int smpc_reset_kernel_times(smpc_handle * h);

@@ -167,7 +167,8 @@ namespace smpc
     KID_TRIAL,
     KID_SELECT,
     KID_APPLY,
-    KID_TREE, // lane-per-problem tree pass (smpc_kino_lane.h) of the full-batch derivative / line-search launches
+    KID_TREE,    // lane-per-problem tree pass (smpc_kino_lane.h) of the full-batch derivative launches
+    KID_TREE_LS, // ... of the full-batch line-search launches (evaluation mode: heads only)
     KID_N
   };
 
@@ -737,7 +738,7 @@ namespace smpc
         la.slots = sk.slots;
         la.deriv = 0;
         la.order = nullptr;
-        const int n = sk.slots > 0 ? sk.slots : b.B, kid_tree = kid == KID_TRIAL ? KID_TREE : kid;
+        const int n = sk.slots > 0 ? sk.slots : b.B, kid_tree = kid == KID_TRIAL ? KID_TREE_LS : kid;
         if (lane_slots == 1)
           timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 1>, 64, SMPC_LANE_MINW>(kid_tree, (H + 1) * ((n + 63) / 64), la, aux);
         else

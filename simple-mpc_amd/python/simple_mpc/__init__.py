@@ -391,7 +391,7 @@ class KinodynamicsOCP(_StageReferences):
         return 2 * self.model_handler.nv
 
     def _kernel_names(self):
-        return ["recede", "deriv", "riccati", "forward", "trial", "select", "apply", "tree"]
+        return ["recede", "deriv", "riccati", "forward", "trial", "select", "apply", "tree", "tree_ls"]
 
     def _create_handle(self, lib, ms, batch, device_id):
         ocp = self
@@ -1045,8 +1045,8 @@ class BatchedMPC:
         self._lib.L.smpc_set_profiling(self._h, int(on))
 
     def kernel_times(self):
-        ms = np.zeros(8)
-        calls = np.zeros(8, np.int64)
+        ms = np.zeros(9)
+        calls = np.zeros(9, np.int64)
         self._lib.check(self._lib.L.smpc_get_kernel_times(self._h, ms, calls))
         names = self.ocp_handler._kernel_names()
         return {n: (float(m), int(c)) for n, m, c in zip(names, ms, calls)}

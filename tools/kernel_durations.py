@@ -41,8 +41,7 @@ def main():
                 for kern, a in e["avg_launch_ms_parts"].items():
                     if kern in res and a > 0:
                         b = res[kern]["mean_ms"]
-                        # (lane_tree_body serves derivative and line-search launches, 0.27 / 0.20 ms: its mean depends on their mix)
-                        ok = abs(a - b) <= (0.15 if kern == "lane_tree_body" else (0.03 if b >= 0.5 else 0.08)) * b
+                        ok = abs(a - b) <= (0.03 if b >= 0.5 else 0.08) * b
                         checks[kern] = {"bench_avg_launch_ms": a, "profiler_mean_ms": b, "agree": ok}
                         status = status if ok else 1
                 continue

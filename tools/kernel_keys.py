@@ -5,7 +5,8 @@ KEYS = {
     "riccati_kino_body": ("riccati_kino_body", "", 4096 * 64),
     "forward_kino_body": ("forward_kino_body", "", 4096 * 64),
     "trial_body": ("10trial_body", "", 4096 * 51 * 64),
-    "lane_tree_body": ("lane_tree_body", "", 51 * 64 * 64),        # line search: lane-per-problem tree pass (64 problems per block)
+    "lane_tree_body": ("lane_tree_body", "ELb1ELb0E", 51 * 64 * 64),     # derivative pass: lane-per-problem tree pass, stream hand-over (64 problems per block)
+    "lane_tree_ls_body": ("lane_tree_body", "ELb0ELb0E", 51 * 64 * 64),  # line search: the same kernel in evaluation mode (heads into tiles)
     "trial_rows_body": ("trial_rows_body", "", 4096 * 51 * 64),    # line search: rows of the candidate (block per problem)
     "deriv2_body": ("deriv2_body", "", 4096 * 51 * 64),            # SMPC_LANE_DERIV=1 only
     "apply_body": ("apply_body", "DimsILi13ELi4EEE", 4096 * 64),
