@@ -493,7 +493,8 @@ namespace smpc
       if (lane_eval && m.lane_slots > 0 && !ks.terminal_constraint && !ks.force_cone && !ks.land_cstr)
       {
         buf.ev = dalloc((((size_t)B + EV_LS - 1) / EV_LS) * (H + 1) * ev_tile_doubles<D>());
-        if (lane_deriv && lane_stream)
+        // (the flush addresses a problem's block by a 32-bit offset in doubles: 34 GB of stream -- B = 134 000 at H = 50)
+        if (lane_deriv && lane_stream && (size_t)B * (H + 1) * EvStream<D>::STRIDE < ((size_t)1 << 32))
         { // derivative pass: per-problem contiguous hand-over (SMPC_LANE_STREAM=0: the strided tile)
           buf.evd = dalloc((size_t)B * (H + 1) * EvStream<D>::STRIDE);
           buf.ev_order = (int *)dev_alloc((size_t)EvStream<D>::STRIDE * sizeof(int));
