@@ -240,19 +240,24 @@ namespace smpc
     // (straight-line: all LDS reads, one wait, all stores.  A lane whose problem does not exist -- partial wavefront -- repeats the last
     //  problem's store: the same bytes to the same address)
     const int f = 2 * (lane % (EV_CH / 2));
-    double v0[NT / PB], v1[NT / PB];
-    unsigned po[NT / PB];
+    constexpr int NB = 4; // problems-per-lane of one batch (two batches: the function's register footprint is the caller's to keep free)
 #pragma unroll
-    for (int q = 0; q < NT / PB; q++)
+    for (int q0 = 0; q0 < NT / PB; q0 += NB)
     {
-      const int p0 = q * PB + lane / (EV_CH / 2), p = p0 < np ? p0 : np - 1;
-      v0[q] = park[p * EV_PP + f];
-      v1[q] = park[p * EV_PP + f + 1];
-      po[q] = poff[p];
-    }
+      double v0[NB], v1[NB];
+      unsigned po[NB];
 #pragma unroll
-    for (int q = 0; q < NT / PB; q++)
-      store2_nowait(evd + (size_t)po[q] + c0 + f, v0[q], v1[q]);
+      for (int q = 0; q < NB; q++)
+      {
+        const int p0 = (q0 + q) * PB + lane / (EV_CH / 2), p = p0 < np ? p0 : np - 1;
+        v0[q] = park[p * EV_PP + f];
+        v1[q] = park[p * EV_PP + f + 1];
+        po[q] = poff[p];
+      }
+#pragma unroll
+      for (int q = 0; q < NB; q++)
+        store2_nowait(evd + (size_t)po[q] + c0 + f, v0[q], v1[q]);
+    }
   }
 
   // =============================================================================================
