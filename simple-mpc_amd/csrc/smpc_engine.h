@@ -375,6 +375,7 @@ namespace smpc
     bool lane_eval = !(std::getenv("SMPC_LANE_EVAL") && std::atoi(std::getenv("SMPC_LANE_EVAL")) == 0);
     bool lane_stream = !(std::getenv("SMPC_LANE_STREAM") && std::atoi(std::getenv("SMPC_LANE_STREAM")) == 0);
     bool stream_order_recorded = false;
+    int foot_joint_h[D::NF] = {0}; // (host copy for deriv2_commit_code)
     double kernel_ms[KID_N] = {0};
     long kernel_calls[KID_N] = {0};
     std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
@@ -425,6 +426,8 @@ namespace smpc
       fill_tree_model<D>(rm, m);
       fill_lane_slots<D>(rm, m);
       lane_slots = m.lane_slots;
+      for (int f = 0; f < D::NF; f++)
+        foot_joint_h[f] = m.foot_joint[f];
       m.dt = ks.timestep;
       for (int i = 0; i < 3; i++)
         m.gravity[i] = ks.gravity[i];
@@ -702,6 +705,14 @@ namespace smpc
           else
             timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2, true, true>, 64, SMPC_LANE_MINW>(KID_SELECT, 1, lo, true);
           profiling = prof;
+          // field ids -> commit codes of the derivative kernel (where each element of the stream goes in its scratch)
+          std::vector<int> ord(EvStream<D>::STRIDE);
+          d2h(ord.data(), b.ev_order, ord.size() * sizeof(int), cur);
+          stream_sync(cur);
+          for (int & v : ord)
+            v = deriv2_commit_code<D>(foot_joint_h, v);
+          h2d(b.ev_order, ord.data(), ord.size() * sizeof(int), cur);
+          stream_sync(cur); // (ord is a local)
           stream_order_recorded = true;
         }
         const int gtree = (H + 1) * ((n + 63) / 64);

@@ -17,6 +17,45 @@ namespace smpc
   template <class D, bool STREAM>
   SMPC_DEV void deriv2_one(const StageKernelArgs<D> & ka, int inst, int t);
 
+  // Commit code of a field of the stream (host side, once per handle: the engine turns the field ids the tree kernel recorded into these):
+  // (head index + 1) << 16 | (offset in doubles from the start of the derivative kernel's LDS scratch + 1); 0 parts: not a head field /
+  // nothing to commit after the rows.  The same mapping as the tile form's commit phase below.
+  template <class D>
+  inline int deriv2_commit_code(const int * foot_joint, int id)
+  {
+    typedef KinoScratch<D, true> KS;
+    typedef EvLayout<D> L;
+    constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF;
+    constexpr int N_TREE = NV * 6 + NJ * 6 + NJ * 6 + NJ * 10;
+    alignas(16) static char probe[sizeof(KS)]; // (addresses only: no object is created or read)
+    KS * sc = reinterpret_cast<KS *>(probe);
+    auto off = [&](const void * p) { return (int)((reinterpret_cast<const char *>(p) - probe) / (std::ptrdiff_t)sizeof(double)); };
+    int h = -1, d = -1;
+    if (id >= 0 && id < L::HEAD)
+      h = id;
+    else if (id >= L::O_S && id < L::O_S + L::N_DERIV)
+    {
+      const int i = id - L::O_S;
+      if (i < N_TREE)
+        d = off(sc->S) + i; // S | vel | acc | Ic contiguous
+      else
+      {
+        const int r = i - N_TREE;
+        if (r < 9 * NF)
+          d = off(sc->oR) + foot_joint[r / 9] * 9 + r % 9;
+        else if (r < 9 * NF + 3)
+          d = off(sc->com) + r - 9 * NF;
+        else if (r < 9 * NF + 9)
+          d = off(sc->b0) + r - 9 * NF - 3;
+        else if (r < 9 * NF + 45)
+          d = off(sc->Agbi) + r - 9 * NF - 9;
+        else
+          d = off(static_cast<KinoScratchDerivPart<D> *>(sc)->Je3) + r - 9 * NF - 45; // Je3 | JeQ | Jq | Jl contiguous
+      }
+    }
+    return ((h + 1) << 16) | (d + 1);
+  }
+
   // grid = B * (H+1) (slots == 0) or slots * (H+1) walking the compacted list of instances that rejected the tentative full step
   // STREAM: the problem's fields arrive as one contiguous run in production order (Buffers::evd, ev_order) instead of the strided tile
   template <class D, bool STREAM = false>
@@ -153,9 +192,9 @@ namespace smpc
 #pragma unroll
         for (int n = 0; n < NLOAD; n++)
         {
-          const int h = SMPC_PLV(oi)[n];
+          const int h = (SMPC_PLV(oi)[n] >> 16) - 1; // (commit code: deriv2_commit_code)
           const double v = SMPC_PLV(vb)[n];
-          if (h >= 0 && h < L::HEAD)
+          if (h >= 0)
           {
             rs.head[h] = v;
             if (h >= L::H_footp && h < L::H_footp + 3 * NF)
@@ -198,12 +237,29 @@ namespace smpc
     double red[3];
     kino_rows<D, true>(rs, md, mg, sc.wframe_(), in.mask, term, plam, lame, pnu, nue, lamp_r, vplus_r, act_r, wres_r, wru_r, red);
     if (in.prof) prof_tick(in.prof, 30, tprev);
+    if constexpr (STREAM)
+    {
+      double * const scb = reinterpret_cast<double *>(&sc);
+      SMPC_LANES(NT)
+      {
+#pragma unroll
+        for (int n = 0; n < NLOAD; n++)
+        {
+          const int d = (SMPC_PLV(oi)[n] & 0xFFFF) - 1; // destination in the scratch, from the commit code of the element
+          if (d >= 0)
+            scb[d] = SMPC_PLV(vb)[n];
+        }
+      }
+      SMPC_LANES_END_WAVE
+    }
+    else
+    {
     SMPC_LANES(NT)
     {
 #pragma unroll
       for (int n = 0; n < NLOAD; n++)
       {
-        const int i = STREAM ? (SMPC_PLV(oi)[n] >= L::O_S ? SMPC_PLV(oi)[n] - L::O_S : L::N_DERIV) : lane + n * NT; // (STREAM: head / padding -> no-op)
+        const int i = lane + n * NT;
         if (i < N_TREE)
           run_tree[i] = SMPC_PLV(vb)[n]; // S | vel | acc | Ic (= the bodies' own inertias until the composite phase)
         else if (i < L::N_DERIV)
@@ -223,6 +279,7 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
+    }
 
     // ---- bodies: inertia copy, accelerations for the solved base acceleration, momenta, net forces (lane = joint) ----
     SMPC_LANES(NT)
