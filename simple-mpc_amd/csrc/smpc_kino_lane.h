@@ -333,7 +333,7 @@ namespace smpc
         //      once per problem ----
         SMPC_LANES(NT)
         {
-          constexpr int SB = 8;
+          constexpr int SB = STREAM ? 32 : 16; // problems per batch of loads (DERIV mode fetches no steps: twice the batch in the same registers)
           const int lx = lane < NX ? lane : 0, ldx = (lane >= 7 && lane < NX) ? lane - 1 : (lane < 6 ? lane : 0), lu = lane < NU ? lane : 0;
           for (int p0 = 0; p0 < np; p0 += SB)
           {
@@ -346,8 +346,8 @@ namespace smpc
               const size_t ib = (size_t)inst * R;
               vx[q] = b.xs[(ib + st) * NX + lx];
               vu[q] = b.us[(ib + st) * NU + lu];
-              vdx[q] = deriv ? 0.0 : b.dxs[((size_t)inst * (H + 1) + t) * NDX + ldx];
-              vdu[q] = deriv ? 0.0 : b.dus[((size_t)inst * H + (term ? 0 : t)) * NU + lu];
+              vdx[q] = (STREAM || deriv) ? 0.0 : b.dxs[((size_t)inst * (H + 1) + t) * NDX + ldx];
+              vdu[q] = (STREAM || deriv) ? 0.0 : b.dus[((size_t)inst * H + (term ? 0 : t)) * NU + lu];
             }
 #pragma unroll
             for (int q = 0; q < SB; q++)
