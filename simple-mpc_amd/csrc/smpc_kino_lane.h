@@ -25,6 +25,7 @@
 // by the order table the kernel records itself).
 #pragma once
 #include "smpc_kino_kernels.h"
+#include <type_traits>
 
 namespace smpc
 {
@@ -81,7 +82,12 @@ namespace smpc
   struct EvStream
   {
     static constexpr int N = EvLayout<D>::HEAD + EvLayout<D>::N_DERIV;
-    static constexpr int STRIDE = ((N + EV_CH - 1) / EV_CH) * EV_CH;
+    // the kernel pads its groups of fields to whole flushes, so that every store site knows its place in the parking slot at compile time
+    // (one LDS store with an immediate offset; the flush calls sit at fixed places): base joint 58 -> 64, every other joint 28 -> 32, a
+    // foot's 15 -> 16, the tail (totals, base acceleration, SE(3) Jacobians: 165) -> 176
+    static constexpr int G_BASE = 64, G_JOINT = 32, G_FOOT = 16, G_TAIL = 176;
+    static constexpr int STRIDE = G_BASE + (D::NJ - 1) * G_JOINT + D::NF * G_FOOT + G_TAIL;
+    static_assert(STRIDE >= N && STRIDE % EV_CH == 0, "padded stream");
     static constexpr int NLOAD = (STRIDE + 63) / 64;
   };
   // Field i of lane l of tile w lives at ev[(w * STRIDE + i) * 64 + l].
@@ -277,7 +283,7 @@ namespace smpc
     const int H = b.H, R = b.R;
     const int t = block % (H + 1), g = block / (H + 1);
     const bool term = t == H;
-    const bool deriv = ka.deriv != 0;
+    const bool deriv = STREAM || ka.deriv != 0; // (STREAM: the derivative-mode instantiation -- a constant there)
     const DevModel<D> & mg = *b.model;
     const unsigned mask = term ? 0u : b.stages[t].mask;
     const double * x_tgt = term ? mg.x_term : b.stages[t].x_tgt;
@@ -383,25 +389,35 @@ namespace smpc
             auto SG = [&](int f) { return stg[f * LANE_PAD + lane]; };
             // ---- outputs: tile (field-major, EVAL mode) or stream (DERIV mode: EV_CH fields parked in this lane's column of the
             //      rows that staged the base inputs, then flushed transposed; `spos` is the same in every lane) ----
-            spos = 0;
+            spos = 0; // (position of the current flush group in the problem's stream)
+            int kpos = 0; // place of the next field in this lane's parking slot: a compile-time constant at every store site (padded groups)
             const size_t pbase = ((size_t)(b.ev_inst0 + inst) * (H + 1) + t) * ES::STRIDE; // (< 2^32 doubles: 34 GB of stream)
-            double * wp = stg + lane * EV_PP; // this lane's parking slot of the next field
+            double * const park = stg + lane * EV_PP;
             if (stream)
               poff[lane] = (unsigned)pbase;
             auto put = [&](int id, double v) {
               if constexpr (SMPC_LOCKSTEP)
-                *wp++ = v;
+                park[kpos] = v;
               else
-                b.evd[pbase + spos] = v; // (lanes one after the other: straight into the lane's own block)
+                b.evd[pbase + spos + kpos] = v; // (lanes one after the other: straight into the lane's own block)
               if constexpr (RECORD)
-                ka.order[spos] = id;
-              spos++;
-              if constexpr (SMPC_LOCKSTEP)
-                if (spos % EV_CH == 0)
-                {
-                  ev_stream_flush<D>(stg, poff, b.evd, np, spos - EV_CH, lane);
-                  wp -= EV_CH;
-                }
+                ka.order[spos + kpos] = id;
+              kpos++;
+              if (kpos == EV_CH)
+              {
+                if constexpr (SMPC_LOCKSTEP)
+                  ev_stream_flush<D>(stg, poff, b.evd, np, spos, lane);
+                spos += EV_CH;
+                kpos = 0;
+              }
+            };
+            auto pad = [&](auto n_) { // n_: std::integral_constant -- n fields of padding
+              if (stream)
+              {
+#pragma unroll
+                for (int i = 0; i < decltype(n_)::value; i++)
+                  put(-1, 0.0);
+              }
             };
             auto O1 = [&](int off, double v) {
               if (stream)
@@ -479,6 +495,7 @@ namespace smpc
                   if (deriv)
                     OSV(L::O_S + k * 6, sk);
                 }
+                pad(std::integral_constant<int, 2>()); // (36 + 2: the same place in the slot as after a joint's one column)
                 cur.a = sv0();
               }
               else
@@ -550,6 +567,7 @@ namespace smpc
                   OSV(L::O_acc + j * 6, cur.a);
                   OSI(L::O_I + j * 10, I);
                 }
+                pad(std::integral_constant<int, 4>()); // (6 + 22 + 4 = 32, base 38 + 22 + 4 = 64)
               }
 #pragma unroll 1
               for (int f = 0; f < NF; f++)
@@ -567,6 +585,7 @@ namespace smpc
                   }
                   if (deriv)
                     OM3(L::O_oRf + f * 9, cur.R);
+                  pad(std::integral_constant<int, 1>()); // (15 + 1)
                 }
             }
             // ---- centre of mass, centroidal momentum, its rate without the base acceleration, the target rate ----
@@ -747,9 +766,7 @@ namespace smpc
                   }
               }
             }
-            if (stream)
-              while (spos % EV_CH != 0)
-                put(-1, 0.0); // (padding up to the last flush)
+            pad(std::integral_constant<int, ES::G_TAIL - 165>()); // (the tail's 165 fields)
           }
         }
         SMPC_LANES_END_WAVE
