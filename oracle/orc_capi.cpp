@@ -228,6 +228,22 @@ extern "C"
     md->s.land_cstr = on != 0;
     md->configure();
   }
+  // 6-D feet (force_size 6): control = [(f, tau) per foot ; joint accelerations], 6 x 6 foot-pose weight, sole half-length / half-width of
+  // the wrench cone (reference KinodynamicsSettings force_size / Lfoot / Wfoot, include/simple-mpc/kinodynamics.hpp:24-51)
+  void orc_kino_set_force_size(void * h, int fs, const double * w_u, const double * w_frame, double mu, double Lfoot, double Wfoot)
+  {
+    KinoModel * md = (KinoModel *)h;
+    md->fs = fs;
+    md->s.force_size = fs;
+    md->nu = md->nv - 6 + fs * md->nf;
+    md->s.w_u = mat_from(w_u, md->nu, md->nu);
+    md->s.w_frame = mat_from(w_frame, fs, fs);
+    md->s.mu = mu;
+    md->s.Lfoot = Lfoot;
+    md->s.Wfoot = Wfoot;
+    md->Acone = wrench_cone_matrix(mu, Lfoot, Wfoot);
+    md->configure();
+  }
   void orc_set_fold_u_rows(int on) { fold_u_rows() = on != 0; }
   void orc_kino_destroy(void * h) { delete (KinoModel *)h; }
   void orc_kino_dims(void * h, int * out) // nx ndx nu nc nf
@@ -892,6 +908,30 @@ extern "C"
     for (int i = 0; i < 3; i++)
       s.gravity[i] = gravity[i];
     s.mu = mu;
+    return new CentModel(m, s);
+  }
+  // 6-D feet: u = [(f, tau) per foot], wrench cones of a 2 Lfoot x 2 Wfoot sole (reference CentroidalSettings force_size / Lfoot / Wfoot,
+  // include/simple-mpc/centroidal-dynamics.hpp:27-43).  Returns a new model; the old one stays valid.
+  void * orc_cent_create6(
+    const smpc_robot_model * m, double dt, const double * w_u, const double * w_com, const double * w_linear_mom,
+    const double * w_angular_mom, const double * w_linear_acc, const double * w_angular_acc, const double * gravity, double mu, double Lfoot,
+    double Wfoot)
+  {
+    CentSettings s;
+    const int nu = 6 * m->nfeet;
+    s.timestep = dt;
+    s.force_size = 6;
+    s.w_u = mat_from(w_u, nu, nu);
+    s.w_com = mat_from(w_com, 3, 3);
+    s.w_linear_mom = mat_from(w_linear_mom, 3, 3);
+    s.w_angular_mom = mat_from(w_angular_mom, 3, 3);
+    s.w_linear_acc = mat_from(w_linear_acc, 3, 3);
+    s.w_angular_acc = mat_from(w_angular_acc, 3, 3);
+    for (int i = 0; i < 3; i++)
+      s.gravity[i] = gravity[i];
+    s.mu = mu;
+    s.Lfoot = Lfoot;
+    s.Wfoot = Wfoot;
     return new CentModel(m, s);
   }
   void orc_cent_destroy(void * h) { delete (CentModel *)h; }

@@ -14,6 +14,10 @@
 //              linear_acc g + sum f_i / m | angular_acc sum (p_i - c) x f_i        (Gauss-Newton Hessians)
 //   constraint per foot in contact (CentroidalFrictionConeResidual, set = NegativeOrthant), epsilon = 1e-4:
 //              [ -f_z + epsilon ;  f_x^2 + f_y^2 - mu^2 f_z^2 ] <= 0
+// 6-D feet (force_size 6; the Talos configuration of examples/talos_centroidal.py, tests/test_utils.cpp:199-218): u = [(f_i, tau_i) per
+//   foot]; the contact torques add to the angular momentum rate and to the angular_acc residual ([UPSTREAM-RECALL] aligator
+//   centroidal-fwd.hxx / angular-acceleration.hxx: xdot.tail<3>() += u.segment(i * 6 + 3, 3)); constraint per foot in contact:
+//   CentroidalWrenchConeResidual (src/centroidal-dynamics.cpp:86-91), 17 constant linear rows A_cone(mu, L, W) u_i <= 0.
 // Choice where the upstream scaling could not be checked: linear_acc is the CoM acceleration
 // g + sum f / m (not the force balance m g + sum f).
 #pragma once
@@ -36,15 +40,20 @@ namespace orc
     const smpc_robot_model * M;
     double mass;
     CentSettings s;
-    int nq = 9, nv = 9, nx = 9, ndx = 9, nu, nf, nc;
+    int nq = 9, nv = 9, nx = 9, ndx = 9, nu, nf, nc, fs = 3, nc1 = 2;
+    Mat Acone;
 
     CentModel(const smpc_robot_model * m, const CentSettings & st) : M(m), mass(m->total_mass), s(st)
     {
       nf = m->nfeet;
-      nu = 3 * nf;
-      nc = 2 * nf; // rows 2f, 2f+1: friction cone block of foot f (present while the foot is in contact)
+      fs = st.force_size;
+      nc1 = fs == 6 ? 17 : 2;
+      nu = fs * nf;
+      nc = nc1 * nf; // rows nc1 f ..: cone block of foot f (present while the foot is in contact): friction cone (2) / wrench cone (17)
+      Acone = wrench_cone_matrix(st.mu, st.Lfoot, st.Wfoot);
     }
-    int row_kind(const StageRef & r, int row) const { return ((r.mask >> (row / 2)) & 1u) ? ROW_NEG : ROW_ABSENT; }
+    int row_kind(const StageRef & r, int row) const { return ((r.mask >> (row / nc1)) & 1u) ? ROW_NEG : ROW_ABSENT; }
+    int force_ref_index(int f) const { return fs * f; }
     double row_lo_v(int) const { return 0.0; }
     double row_hi_v(int) const { return 0.0; }
     void integrate(const double * x, const double * dx, double * out) const
@@ -86,9 +95,11 @@ namespace orc
       for (int f = 0; f < nf; f++)
         if ((r.mask >> f) & 1u)
         {
-          const V3 F = v3(u[3 * f], u[3 * f + 1], u[3 * f + 2]);
+          const V3 F = v3(u[fs * f], u[fs * f + 1], u[fs * f + 2]);
           fsum = fsum + F;
           tsum = tsum + cross(r.foot_ref[f] - c, F);
+          if (fs == 6)
+            tsum = tsum + v3(u[6 * f + 3], u[6 * f + 4], u[6 * f + 5]);
         }
       o.xdot.assign(9, 0.0);
       for (int i = 0; i < 3; i++)
@@ -115,6 +126,17 @@ namespace orc
       for (int f = 0; f < nf; f++)
         if ((r.mask >> f) & 1u)
         {
+          if (fs == 6)
+          {
+            for (int i = 0; i < 17; i++)
+            {
+              double acc = 0.0;
+              for (int j = 0; j < 6; j++)
+                acc += Acone(i, j) * u[6 * f + j];
+              o.c[17 * f + i] = acc;
+            }
+            continue;
+          }
           const double fx = u[3 * f], fy = u[3 * f + 1], fz = u[3 * f + 2];
           o.c[2 * f] = -fz + CONE_EPS;
           o.c[2 * f + 1] = fx * fx + fy * fy - s.mu * s.mu * fz * fz;
@@ -137,21 +159,28 @@ namespace orc
       for (int f = 0; f < nf; f++)
         if ((r.mask >> f) & 1u)
         {
-          const V3 F = v3(u[3 * f], u[3 * f + 1], u[3 * f + 2]);
+          const V3 F = v3(u[fs * f], u[fs * f + 1], u[fs * f + 2]);
           const V3 rr = r.foot_ref[f] - c;
           fsum = fsum + F;
           tsum = tsum + cross(rr, F);
+          if (fs == 6)
+            tsum = tsum + v3(u[6 * f + 3], u[6 * f + 4], u[6 * f + 5]);
           const Mat Fx = skew(F), Rx = skew(rr);
           for (int i = 0; i < 3; i++)
           {
             for (int j = 0; j < 3; j++)
             {
               Jaa_c(i, j) += Fx(i, j);
-              Jaa_u(i, 3 * f + j) = Rx(i, j);
-              o.B(6 + i, 3 * f + j) = dt * Rx(i, j);
+              Jaa_u(i, fs * f + j) = Rx(i, j);
+              o.B(6 + i, fs * f + j) = dt * Rx(i, j);
             }
-            Jla_u(i, 3 * f + i) = 1.0 / mass;
-            o.B(3 + i, 3 * f + i) = dt;
+            Jla_u(i, fs * f + i) = 1.0 / mass;
+            o.B(3 + i, fs * f + i) = dt;
+            if (fs == 6)
+            { // contact torque
+              Jaa_u(i, 6 * f + 3 + i) = 1.0;
+              o.B(6 + i, 6 * f + 3 + i) = dt;
+            }
           }
         }
       for (int i = 0; i < 3; i++)
@@ -210,6 +239,13 @@ namespace orc
       for (int f = 0; f < nf; f++)
         if ((r.mask >> f) & 1u)
         {
+          if (fs == 6)
+          {
+            for (int i = 0; i < 17; i++)
+              for (int j = 0; j < 6; j++)
+                o.Cu(17 * f + i, 6 * f + j) = Acone(i, j);
+            continue;
+          }
           const double fx = u[3 * f], fy = u[3 * f + 1], fz = u[3 * f + 2];
           o.Cu(2 * f, 3 * f + 2) = -1.0;
           o.Cu(2 * f + 1, 3 * f) = 2.0 * fx;

@@ -19,7 +19,7 @@
 //   wrench, and with force_cone every foot in contact adds MultibodyWrenchConeResidual rows in the negative orthant
 //   [REF src/fulldynamics.cpp:163-173]: 17 linear rows A_cone lam (unilaterality, friction pyramid, centre of pressure inside
 //   the sole, yaw torque bounds; [UPSTREAM-RECALL] Aligator's wrench-cone matrix after Caron et al. 2015), rows after the boxes.
-// land_cstr rows [REF :175-209] are not restated.
+// land_cstr rows [REF :175-209]: 6 LOCAL_WORLD_ALIGNED frame-velocity rows of a landing 6-D foot, 3 + the height of the contact pose for a 3-D foot.
 // StageRef::u_ref carries [control reference (nu) ; force reference per foot (force_size nf)] for this model.
 #pragma once
 #include "orc_full.hpp"
@@ -39,23 +39,7 @@ namespace orc
     double Kp[6] = {0, 0, 0, 0, 0, 0}, Kd[6] = {0, 0, 0, 0, 0, 0};
   };
 
-  // wrench cone of a rectangular sole (half length L, half width W, friction mu) on the contact wrench [f ; tau]: A lam <= 0
-  inline Mat wrench_cone_matrix(double mu, double L, double W)
-  {
-    const double m = mu * (L + W);
-    const double rows[17][6] = {
-      {0, 0, -1, 0, 0, 0},
-      {-1, 0, -mu, 0, 0, 0}, {1, 0, -mu, 0, 0, 0}, {0, -1, -mu, 0, 0, 0}, {0, 1, -mu, 0, 0, 0},
-      {0, 0, -W, -1, 0, 0}, {0, 0, -W, 1, 0, 0}, {0, 0, -L, 0, -1, 0}, {0, 0, -L, 0, 1, 0},
-      {W, L, -m, -mu, -mu, -1}, {W, -L, -m, -mu, mu, -1}, {-W, L, -m, mu, -mu, -1}, {-W, -L, -m, mu, mu, -1},
-      {W, L, -m, mu, mu, 1}, {W, -L, -m, mu, -mu, 1}, {-W, L, -m, -mu, mu, 1}, {-W, -L, -m, -mu, -mu, 1}};
-    Mat A(17, 6);
-    for (int i = 0; i < 17; i++)
-      for (int j = 0; j < 6; j++)
-        A(i, j) = rows[i][j];
-    return A;
-  }
-
+  // (wrench_cone_matrix: orc_kino.hpp -- the kinodynamics and centroidal OCPs of 6-D feet use the same 17 x 6 matrix on u)
   struct FullModel
   {
     const smpc_robot_model * M;

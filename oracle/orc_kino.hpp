@@ -8,8 +8,14 @@
 //                  (src/kinodynamics.cpp:60-83)
 //   constraints  : joint box (src/kinodynamics.cpp:91-101), LOCAL frame velocity = 0 per contact
 //                  foot (src/kinodynamics.cpp:110-133)
-// force_size == 3 (point feet) only; force_cone rows: CentroidalFrictionConeResidual per foot in contact; land_cstr: the height
-// of a landing foot pinned to its contact pose (FrameTranslationResidual, z slice).
+// force_size 3 (point feet): force_cone rows = CentroidalFrictionConeResidual per foot in contact; land_cstr: the height of a landing
+// foot pinned to its contact pose (FrameTranslationResidual, z slice).
+// force_size 6 (flat feet, the Talos configuration of examples/talos_kinodynamics.py and tests/test_utils.cpp:147-197): u = [(f_i, tau_i) per
+// foot ; joint accelerations]; the contact torques enter the angular momentum rate [UPSTREAM-RECALL aligator kinodynamics-fwd.hxx /
+// centroidal-momentum-derivative.hxx: hdot.angular += u.segment(i * 6 + 3, 3)]; <foot>_pose_cost is FramePlacementResidual
+// log6(M_ref^-1 oMf) (src/kinodynamics.cpp:66-72); the contact constraint is the whole 6-row LOCAL FrameVelocityResidual (:105-123);
+// force_cone adds CentroidalWrenchConeResidual per foot in contact: 17 constant linear rows A_cone u_i <= 0 (:114-119); land_cstr has no
+// rows for 6-D feet (the branch at :134-146 is the 3-D one).
 #pragma once
 #include "orc_rigid.hpp"
 
@@ -54,11 +60,29 @@ namespace orc
     Vec lx, lu;
   };
 
+  // wrench cone of a rectangular sole (half length L, half width W, friction mu) on the contact wrench [f ; tau]: A lam <= 0
+  inline Mat wrench_cone_matrix(double mu, double L, double W)
+  {
+    const double m = mu * (L + W);
+    const double rows[17][6] = {
+      {0, 0, -1, 0, 0, 0},
+      {-1, 0, -mu, 0, 0, 0}, {1, 0, -mu, 0, 0, 0}, {0, -1, -mu, 0, 0, 0}, {0, 1, -mu, 0, 0, 0},
+      {0, 0, -W, -1, 0, 0}, {0, 0, -W, 1, 0, 0}, {0, 0, -L, 0, -1, 0}, {0, 0, -L, 0, 1, 0},
+      {W, L, -m, -mu, -mu, -1}, {W, -L, -m, -mu, mu, -1}, {-W, L, -m, mu, -mu, -1}, {-W, -L, -m, mu, mu, -1},
+      {W, L, -m, mu, mu, 1}, {W, -L, -m, mu, -mu, 1}, {-W, L, -m, -mu, mu, 1}, {-W, -L, -m, -mu, -mu, 1}};
+    Mat A(17, 6);
+    for (int i = 0; i < 17; i++)
+      for (int j = 0; j < 6; j++)
+        A(i, j) = rows[i][j];
+    return A;
+  }
+
   struct KinoModel
   {
     const smpc_robot_model * M;
     KinoSettings s;
-    int nq, nv, nx, ndx, nu, nf, nc;
+    int nq, nv, nx, ndx, nu, nf, nc, fs = 3;
+    Mat Acone; // 17 x 6 (6-D feet)
     std::vector<int> row_kind_base; // per-row kind when present
     Vec row_lo, row_hi;
 
@@ -69,13 +93,15 @@ namespace orc
       nx = nq + nv;
       ndx = 2 * nv;
       nf = m->nfeet;
-      nu = nv - 6 + 3 * nf;
+      fs = st.force_size;
+      nu = nv - 6 + fs * nf;
+      Acone = wrench_cone_matrix(st.mu, st.Lfoot, st.Wfoot);
       configure();
     }
     std::vector<double> land_z; // height of the contact poses the cycle stages are created with: feet at the reference state
     void configure()
     {
-      nc = (nv - 6) + 3 * nf + (s.force_cone ? 2 * nf : 0) + (s.land_cstr ? nf : 0);
+      nc = (nv - 6) + fs * nf + (s.force_cone ? ncone1() * nf : 0) + (has_land() ? nf : 0);
       Rigid R(M);
       Vec q(M->q_ref, M->q_ref + nq);
       R.fk(q.data());
@@ -83,8 +109,10 @@ namespace orc
       for (int f = 0; f < nf; f++)
         land_z[f] = R.foot_p[f][2];
     }
-    int cone_base() const { return (nv - 6) + 3 * nf; }
-    int land_base() const { return cone_base() + (s.force_cone ? 2 * nf : 0); }
+    int ncone1() const { return fs == 6 ? 17 : 2; }                  // cone rows per foot: wrench cone / friction cone
+    bool has_land() const { return s.land_cstr && fs == 3; }         // (no land rows for 6-D feet, src/kinodynamics.cpp:134)
+    int cone_base() const { return (nv - 6) + fs * nf; }
+    int land_base() const { return cone_base() + (s.force_cone ? ncone1() * nf : 0); }
     // fixed row layout: rows [0, nv-6) joint box, rows nv-6+3f.. frame velocity of foot f, then (force_cone) two friction-cone rows
     // per foot: CentroidalFrictionConeResidual(ndx, nu, f, mu, 1e-4) in NegativeOrthant (reference src/kinodynamics.cpp:124-129):
     //   [ -f_z + epsilon ; f_x^2 + f_y^2 - mu^2 f_z^2 ] <= 0   ([UPSTREAM-RECALL] aligator centroidal-friction-cone.hxx; the same
@@ -95,11 +123,11 @@ namespace orc
         return s.kinematics_limits ? ROW_BOX : ROW_ABSENT;
       // land_cstr: one equality row per foot that lands at this stage, FrameTranslationResidual(contact pose) sliced to z
       // (reference src/kinodynamics.cpp:134-146; land flags of the cycle stages: src/mpc.cpp:167-178)
-      if (s.land_cstr && row >= land_base())
+      if (has_land() && row >= land_base())
         return (((r.land & r.mask) >> (row - land_base())) & 1u) ? ROW_EQ : ROW_ABSENT;
       if (row >= cone_base())
-        return ((r.mask >> ((row - cone_base()) / 2)) & 1u) ? ROW_NEG : ROW_ABSENT;
-      int f = (row - (nv - 6)) / 3;
+        return ((r.mask >> ((row - cone_base()) / ncone1())) & 1u) ? ROW_NEG : ROW_ABSENT;
+      int f = (row - (nv - 6)) / fs;
       return ((r.mask >> f) & 1u) ? ROW_EQ : ROW_ABSENT;
     }
     double row_lo_v(int row) const { return row < nv - 6 ? s.qmin[row] : 0.0; }
@@ -107,7 +135,7 @@ namespace orc
     void integrate(const double * x, const double * dx, double * out) const { x_integrate(nq, nv, x, dx, out); }
     void difference(const double * x0, const double * x1, double * out) const { x_difference(nq, nv, x0, x1, out); }
     // where a stage's reference vector keeps the force reference of foot f (here: the control reference itself)
-    int force_ref_index(int f) const { return 3 * f; }
+    int force_ref_index(int f) const { return fs * f; }
     int n_uref() const { return nu; }
 
     // ---- continuous dynamics  xdot = (v, a) ----
@@ -118,9 +146,11 @@ namespace orc
       for (int f = 0; f < nf; f++)
         if ((r.mask >> f) & 1u)
         {
-          V3 F = v3(u[3 * f], u[3 * f + 1], u[3 * f + 2]);
+          V3 F = v3(u[fs * f], u[fs * f + 1], u[fs * f + 2]);
           hd.l = hd.l + F;
           hd.a = hd.a + cross(R.foot_p[f] - R.com, F);
+          if (fs == 6)
+            hd.a = hd.a + v3(u[6 * f + 3], u[6 * f + 4], u[6 * f + 5]);
         }
       return hd;
     }
@@ -137,7 +167,7 @@ namespace orc
       Mat Ag = R.Ag();
       SV hd = hdot_target(R, r, u);
       Vec rhs = sv_vec(hd - b);
-      const double * aj = u + 3 * nf;
+      const double * aj = u + fs * nf;
       for (int i = 0; i < 6; i++)
         for (int k = 6; k < nv; k++)
           rhs[i] -= Ag(i, k) * aj[k - 6];
@@ -174,7 +204,7 @@ namespace orc
       for (int f = 0; f < nf; f++)
         if ((r.mask >> f) & 1u)
         {
-          V3 F = v3(u[3 * f], u[3 * f + 1], u[3 * f + 2]);
+          V3 F = v3(u[fs * f], u[fs * f + 1], u[fs * f + 2]);
           for (int k = 0; k < nv; k++)
           {
             V3 dp = R.Jfoot_col(f, k) - R.Jcom_col(k);
@@ -201,17 +231,19 @@ namespace orc
         if ((r.mask >> f) & 1u)
         {
           M3 X = skew(R.foot_p[f] - R.com);
-          Mat G(6, 3);
+          Mat G(6, fs);
           for (int i = 0; i < 3; i++)
           {
             G(i, i) = 1.0;
             for (int j = 0; j < 3; j++)
               G(3 + i, j) = X(i, j);
+            if (fs == 6)
+              G(3 + i, 3 + i) = 1.0; // contact torque
           }
           Mat AG = mul(Agb_inv, G);
           for (int i = 0; i < 6; i++)
-            for (int j = 0; j < 3; j++)
-              da_du(i, 3 * f + j) = AG(i, j);
+            for (int j = 0; j < fs; j++)
+              da_du(i, fs * f + j) = AG(i, j);
         }
       // joint accelerations
       Mat Agj(6, nv - 6);
@@ -221,9 +253,53 @@ namespace orc
       Mat AA = mul(Agb_inv, Agj);
       for (int i = 0; i < 6; i++)
         for (int k = 0; k < nv - 6; k++)
-          da_du(i, 3 * nf + k) = -AA(i, k);
+          da_du(i, fs * nf + k) = -AA(i, k);
       for (int k = 0; k < nv - 6; k++)
-        da_du(6 + k, 3 * nf + k) = 1.0;
+        da_du(6 + k, fs * nf + k) = 1.0;
+    }
+
+    // <foot>_pose_cost residual and its Jacobian w.r.t. q: translation error (3-D feet) or log6(M_ref^-1 oMf) with the LOCAL 6-D frame
+    // Jacobian (FramePlacementResidual; M_ref = (identity rotation, reference translation), as MPC::updateStepTrackerReferences sets
+    // it, src/mpc.cpp:304-308)
+    Vec pose_residual(const Rigid & R, const StageRef & r, int f, Mat * Jq = nullptr) const
+    {
+      const int l = M->foot_joint[f];
+      if (fs == 3)
+      {
+        V3 e = R.foot_p[f] - r.foot_ref[f];
+        if (Jq)
+        {
+          Jq->resize(3, nv);
+          for (int k = 0; k < nv; k++)
+          {
+            V3 c = R.Jfoot_col(f, k);
+            for (int i = 0; i < 3; i++)
+              (*Jq)(i, k) = c[i];
+          }
+        }
+        return Vec{e[0], e[1], e[2]};
+      }
+      const SE3 Mref{m3_id(), r.foot_ref[f]}, Mf{R.oMi[l].R, R.foot_p[f]};
+      Vec e(6);
+      log6(inv(Mref) * Mf, e.data());
+      if (Jq)
+      {
+        const Mat Jl = Jlog6(inv(Mref) * Mf);
+        const M3 Rt = tr(Mf.R);
+        Mat Jloc(6, nv);
+        for (int k = 0; k < nv; k++)
+          if (R.is_ancestor_dof(k, l))
+          {
+            const V3 lin = Rt * R.Jfoot_col(f, k), ang = Rt * R.S[k].a;
+            for (int i = 0; i < 3; i++)
+            {
+              Jloc(i, k) = lin[i];
+              Jloc(3 + i, k) = ang[i];
+            }
+          }
+        *Jq = mul(Jl, Jloc);
+      }
+      return e;
     }
 
     // ---- cost pieces ----
@@ -265,10 +341,7 @@ namespace orc
       cost += quad(s.w_cent, sv_vec(R.hg()));
       cost += quad(s.w_centder, sv_vec(hdot_target(R, r, u)));
       for (int f = 0; f < nf; f++)
-      {
-        V3 e = R.foot_p[f] - r.foot_ref[f];
-        cost += quad(s.w_frame, Vec{e[0], e[1], e[2]});
-      }
+        cost += quad(s.w_frame, pose_residual(R, r, f));
       o.cost = cost;
       // constraints
       o.c.assign(nc, 0.0);
@@ -282,7 +355,22 @@ namespace orc
           V3 vw = R.vel[l].l + cross(R.vel[l].a, R.foot_p[f]);
           V3 c = tr(R.oMi[l].R) * vw;
           for (int i = 0; i < 3; i++)
-            o.c[nv - 6 + 3 * f + i] = c[i];
+            o.c[nv - 6 + fs * f + i] = c[i];
+          if (fs == 6)
+          {
+            V3 w = tr(R.oMi[l].R) * R.vel[l].a;
+            for (int i = 0; i < 3; i++)
+              o.c[nv - 6 + 6 * f + 3 + i] = w[i];
+            if (s.force_cone)
+              for (int i = 0; i < 17; i++)
+              {
+                double acc = 0.0;
+                for (int j = 0; j < 6; j++)
+                  acc += Acone(i, j) * u[6 * f + j];
+                o.c[cone_base() + 17 * f + i] = acc;
+              }
+            continue;
+          }
           if (s.force_cone)
           {
             const double fx = u[3 * f], fy = u[3 * f + 1], fz = u[3 * f + 2];
@@ -418,7 +506,7 @@ namespace orc
         for (int f = 0; f < nf; f++)
           if ((r.mask >> f) & 1u)
           {
-            V3 F = v3(u[3 * f], u[3 * f + 1], u[3 * f + 2]);
+            V3 F = v3(u[fs * f], u[fs * f + 1], u[fs * f + 2]);
             for (int k = 0; k < nv; k++)
             {
               V3 t = cross(R.Jfoot_col(f, k) - R.Jcom_col(k), F);
@@ -428,24 +516,24 @@ namespace orc
             M3 X = skew(R.foot_p[f] - R.com);
             for (int i = 0; i < 3; i++)
             {
-              Ju(i, 3 * f + i) = 1.0;
+              Ju(i, fs * f + i) = 1.0;
               for (int j = 0; j < 3; j++)
-                Ju(3 + i, 3 * f + j) = X(i, j);
+                Ju(3 + i, fs * f + j) = X(i, j);
+              if (fs == 6)
+                Ju(3 + i, 6 * f + 3 + i) = 1.0;
             }
           }
         add_cost(s.w_centder, sv_vec(hdot_target(R, r, u)), Jx, &Ju);
       }
       for (int f = 0; f < nf; f++)
-      { // foot translation cost
-        Mat Jx(3, ndx);
-        for (int k = 0; k < nv; k++)
-        {
-          V3 c = R.Jfoot_col(f, k);
-          for (int i = 0; i < 3; i++)
-            Jx(i, k) = c[i];
-        }
-        V3 e = R.foot_p[f] - r.foot_ref[f];
-        add_cost(s.w_frame, Vec{e[0], e[1], e[2]}, Jx, nullptr);
+      { // foot pose cost (translation / placement)
+        Mat Jq;
+        const Vec e = pose_residual(R, r, f, &Jq);
+        Mat Jx(fs, ndx);
+        for (int i = 0; i < fs; i++)
+          for (int k = 0; k < nv; k++)
+            Jx(i, k) = Jq(i, k);
+        add_cost(s.w_frame, e, Jx, nullptr);
       }
       // ---- constraints ----
       o.Cx.resize(nc, ndx);
@@ -456,6 +544,23 @@ namespace orc
       for (int f = 0; f < nf; f++)
         if ((r.mask >> f) & 1u)
         {
+          if (fs == 6)
+          {
+            Vec c6;
+            Mat dq, dv;
+            R.foot_local_velocity6(f, c6, dq, dv);
+            for (int i = 0; i < 6; i++)
+              for (int k = 0; k < nv; k++)
+              {
+                o.Cx(nv - 6 + 6 * f + i, k) = dq(i, k);
+                o.Cx(nv - 6 + 6 * f + i, nv + k) = dv(i, k);
+              }
+            if (s.force_cone)
+              for (int i = 0; i < 17; i++)
+                for (int j = 0; j < 6; j++)
+                  o.Cu(cone_base() + 17 * f + i, 6 * f + j) = Acone(i, j);
+            continue;
+          }
           V3 c;
           Mat dq, dv;
           R.foot_local_velocity(f, c, dq, dv);

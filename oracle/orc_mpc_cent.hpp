@@ -64,7 +64,7 @@ namespace orc
       def.mask = (1u << nf) - 1u;
       def.u_ref.assign(md.nu, 0.0);
       for (int f = 0; f < nf; f++)
-        def.u_ref[3 * f + 2] = -m->total_mass * gravity_arg / (double)nf;
+        def.u_ref[md.fs * f + 2] = -m->total_mass * gravity_arg / (double)nf;
       def.x_tgt.assign(9, 0.0);
       def.foot_ref.assign(nf, v3(0, 0, 0));
       horizon.assign(H, def);
@@ -136,7 +136,7 @@ namespace orc
           if (state[f])
           {
             sr.mask |= 1u << f;
-            sr.u_ref[3 * f + 2] = st.support_force / (double)active;
+            sr.u_ref[md.fs * f + 2] = st.support_force / (double)active;
           }
         // com_ref_ of the OCP at creation time: the last setPoseBase call, i.e. x_reference_[0:3] once a control step
         // has run (src/centroidal-dynamics.cpp:249-257); momentum references start at zero

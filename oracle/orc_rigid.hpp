@@ -385,6 +385,39 @@ namespace orc
         }
       }
     }
+    // the same for a 6-D foot: the whole LOCAL frame velocity [R^T v_point ; R^T omega] (FrameVelocityResidual(..., LOCAL) unsliced,
+    // reference src/kinodynamics.cpp:110-123) and its derivatives (Pinocchio getFrameVelocityDerivatives, LOCAL):
+    //   d(R^T u)/dq_k = R^T (du/dq_k - S_k.a x u)  -- the rigid turn of the subtree by S_k cancels, what is left is d_k = v_parent x S_k
+    void foot_local_velocity6(int f, Vec & c, Mat & dc_dq, Mat & dc_dv) const
+    {
+      const int l = M->foot_joint[f];
+      const M3 Rt = tr(oMi[l].R);
+      const V3 vl = Rt * (vel[l].l + cross(vel[l].a, foot_p[f])), va = Rt * vel[l].a;
+      c = Vec{vl[0], vl[1], vl[2], va[0], va[1], va[2]};
+      dc_dq.resize(6, nv);
+      dc_dv.resize(6, nv);
+      for (int k = 0; k < nv; k++)
+      {
+        if (!is_ancestor_dof(k, l))
+          continue;
+        const int lam = M->parent[dof2j[k]];
+        const V3 cvl = Rt * (S[k].l + cross(S[k].a, foot_p[f])), cva = Rt * S[k].a;
+        V3 cql = v3(0, 0, 0), cqa = v3(0, 0, 0);
+        if (lam >= 0)
+        {
+          const SV d = crm(vel[lam], S[k]);
+          cql = Rt * (d.l + cross(d.a, foot_p[f]));
+          cqa = Rt * d.a;
+        }
+        for (int r = 0; r < 3; r++)
+        {
+          dc_dv(r, k) = cvl[r];
+          dc_dv(3 + r, k) = cva[r];
+          dc_dq(r, k) = cql[r];
+          dc_dq(3 + r, k) = cqa[r];
+        }
+      }
+    }
   };
 
   // ---- configuration-space (manifold) operations: SE3 x R^(nq-7) for q, vector space for v ----

@@ -83,6 +83,7 @@ def lib():
     L.orc_kino_set_force_cone.argtypes = [vp, C.c_int, C.c_double]
     L.orc_set_fold_u_rows.argtypes = [C.c_int]
     L.orc_kino_set_land_cstr.argtypes = [vp, C.c_int]
+    L.orc_kino_set_force_size.argtypes = [vp, C.c_int, _dp, _dp, C.c_double, C.c_double, C.c_double]
     L.orc_full_set_land_cstr.argtypes = [vp, C.c_int]
     L.orc_kino_term.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
     L.orc_kino_term_cstr.argtypes = [vp, _dp, _dp, C.c_double, _dp, _dp]
@@ -154,6 +155,8 @@ def lib():
     L.orc_set_num_threads.argtypes = [C.c_int]
     L.orc_cent_create.restype = vp
     L.orc_cent_create.argtypes = [vp, C.c_double] + [_dp] * 7 + [C.c_double]
+    L.orc_cent_create6.restype = vp
+    L.orc_cent_create6.argtypes = [vp, C.c_double] + [_dp] * 7 + [C.c_double] * 3
     L.orc_cent_destroy.argtypes = [vp]
     L.orc_cent_eval.argtypes = [vp, C.c_uint] + [_dp] * 9
     L.orc_cent_deriv.argtypes = [vp, C.c_uint] + [_dp] * 14
@@ -343,6 +346,9 @@ class Kino:
             robot.ptr, s["timestep"], c(s["w_x"]), c(s["w_u"]), c(s["w_frame"]), c(s["w_cent"]), c(s["w_centder"]),
             c(s["qmin"]), c(s["qmax"]), c(s["gravity"]), int(s["kinematics_limits"]),
         )
+        if int(s.get("force_size", 3)) == 6:  # (orc_kino_create read the 3-D prefixes of w_u / w_frame; this call takes the whole matrices)
+            L.orc_kino_set_force_size(self.h, 6, c(s["w_u"]), c(s["w_frame"]), float(s.get("mu", 0.8)), float(s.get("Lfoot", 0.1)),
+                                      float(s.get("Wfoot", 0.075)))
         if s.get("force_cone", False):
             L.orc_kino_set_force_cone(self.h, 1, float(s.get("mu", 0.8)))
         if s.get("land_cstr", False):
@@ -450,6 +456,27 @@ def talos_full_settings(robot):
                 w_frame=np.eye(6) * 2000.0, gravity=np.array([0, 0, -9.81]), force_size=6, Kp_correction=np.array([0, 0, 50, 0, 0, 0.0]),
                 Kd_correction=np.ones(6) * 100.0, umin=-eff, umax=eff, qmin=robot.q_lo.copy(), qmax=robot.q_hi.copy(), mu=0.8, Lfoot=0.1,
                 Wfoot=0.075, torque_limits=True, kinematics_limits=True, force_cone=True, land_cstr=False)
+
+
+def talos_kino_settings(robot, force_cone=True):
+    """KinodynamicsSettings of the reference's Talos configuration with 6-D feet: weights of examples/talos_kinodynamics.py:50-106
+    (force_cone as in tests/test_utils.cpp:147-197, which the reference's own problem / MPC tests use)."""
+    nv = robot.nv
+    w_x = 10.0 * np.diag(np.array([0, 0, 1000, 1000, 1000, 1000] + [0.1] * 6 * 2 + [1, 1000] + [1, 1, 10, 10] * 2 + [10] * 6 + [1] * 6 * 2
+                                  + [0.1, 100] + [10] * 4 * 2, float))
+    w_u = np.diag(np.concatenate([[0.001, 0.001, 0.01], np.ones(3) * 0.1] * 2 + [np.ones(nv - 6) * 1e-4]))
+    return dict(timestep=0.01, w_x=w_x, w_u=w_u, w_cent=np.diag([0.0, 0.0, 1.0, 0.1, 0.1, 10.0]), w_centder=np.diag([0.0, 0.0, 0.0, 0.1, 0.1, 0.1]),
+                gravity=np.array([0.0, 0.0, -9.81]), force_size=6, w_frame=np.eye(6) * 100000.0, qmin=robot.q_lo.copy(), qmax=robot.q_hi.copy(),
+                mu=0.8, Lfoot=0.1, Wfoot=0.075, kinematics_limits=True, force_cone=bool(force_cone), land_cstr=False)
+
+
+def talos_centroidal_settings(robot):
+    """CentroidalSettings of the reference's Talos configuration with 6-D feet: examples/talos_centroidal.py:50-76 =
+    tests/test_utils.cpp:199-218 but for w_u (identity there; the example's force / torque weights are used)."""
+    nf = robot.nf
+    return dict(timestep=0.01, w_u=np.diag([0.001] * 3 + [0.1] * 3) if nf == 1 else np.diag(([0.001] * 3 + [0.1] * 3) * nf), w_com=np.zeros((3, 3)), w_linear_mom=np.diag([0.01, 0.01, 100.0]),
+                w_angular_mom=np.diag([0.1, 0.1, 1000.0]), w_linear_acc=0.01 * np.eye(3), w_angular_acc=0.01 * np.eye(3),
+                gravity=np.array([0.0, 0.0, -9.81]), mu=0.8, Lfoot=0.1, Wfoot=0.075, force_size=6)
 
 
 def talos_mpc_settings(robot, max_iters=1, num_threads=0):
@@ -648,13 +675,20 @@ class Cent:
     def __init__(self, robot, s):
         c = lambda a: np.ascontiguousarray(a, float)
         self.robot, self.s = robot, s
-        self.h = lib().orc_cent_create(
-            robot.ptr, s["timestep"], c(s["w_u"]), c(s["w_com"]), c(s["w_linear_mom"]), c(s["w_angular_mom"]),
-            c(s["w_linear_acc"]), c(s["w_angular_acc"]), c(s["gravity"]), float(s["mu"]),
-        )
+        self.fs = int(s.get("force_size", 3))
+        if self.fs == 6:
+            self.h = lib().orc_cent_create6(
+                robot.ptr, s["timestep"], c(s["w_u"]), c(s["w_com"]), c(s["w_linear_mom"]), c(s["w_angular_mom"]),
+                c(s["w_linear_acc"]), c(s["w_angular_acc"]), c(s["gravity"]), float(s["mu"]), float(s["Lfoot"]), float(s["Wfoot"]),
+            )
+        else:
+            self.h = lib().orc_cent_create(
+                robot.ptr, s["timestep"], c(s["w_u"]), c(s["w_com"]), c(s["w_linear_mom"]), c(s["w_angular_mom"]),
+                c(s["w_linear_acc"]), c(s["w_angular_acc"]), c(s["gravity"]), float(s["mu"]),
+            )
         self.nf = robot.nf
         self.nx = self.ndx = self.nv = 9
-        self.nu, self.nc = 3 * self.nf, 2 * self.nf
+        self.nu, self.nc = self.fs * self.nf, (17 if self.fs == 6 else 2) * self.nf
 
     def eval(self, mask, u_ref, x_tgt, pos, x, u):
         c = lambda a: np.ascontiguousarray(a, float)
