@@ -159,6 +159,7 @@ namespace orc
       Rigid R(m);
       R.fk(x_model_ref.data());
       com0 = R.com;
+      const std::vector<V3> ref_feet(R.foot_p.begin(), R.foot_p.begin() + nf); // FootTrajectory starting poses: the feet at the reference state (src/mpc.cpp:26-36)
       // default problem (OCPHandler::createProblem): all contacts, identity contact poses
       StageRef def;
       def.mask = (1u << nf) - 1u;
@@ -213,7 +214,7 @@ namespace orc
       ftraj.assign(B, std::vector<FootTraj>(nf));
       for (int b = 0; b < B; b++)
         for (int f = 0; f < nf; f++)
-          ftraj[b][f] = FootTraj{R.foot_p[f], R.foot_p[f]};
+          ftraj[b][f] = FootTraj{ref_feet[f], ref_feet[f]}; // (not R.foot_p: the cold solve above has moved R to its last trial point)
       last_info.resize(B);
       vbase_inst.assign(B, std::array<double, 6>{{0, 0, 0, 0, 0, 0}});
       vref.assign(B, std::vector<std::array<double, 6>>(H, std::array<double, 6>{{0, 0, 0, 0, 0, 0}}));

@@ -21,6 +21,7 @@ typedef FullDims<13, 4, 3, 0, 4> FullGo2Land; // land_cstr: 4 rows per landing f
 typedef FullDims<13, 4, 3, 5, 4> FullGo2ConeLand; // force_cone and land_cstr: the land rows behind the pyramid rows
 typedef FullDims<23, 2, 6> FullTalos; // Talos-class humanoid: 22 joint torques, two 6-D feet with wrench cones
 typedef FullDims<23, 2, 6, 0, 6> FullTalosLand; // land_cstr: 6 frame-velocity rows per landing foot
+typedef FullDims<23, 2, 6, 0, 0, 1> KinoTalos;  // KINODYNAMICS OCP of the Talos-class biped: 6-D feet, wrench cones (KinodynamicsOCP with force_size 6)
 
 struct smpc_handle
 {
@@ -93,10 +94,60 @@ extern "C"
       return fail(SMPC_ERR_INVALID, "null argument");
     if (device_count() <= 0)
       return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the MPC engine has no CPU path");
-    if (ocp->force_size != 3)
-      return fail(SMPC_ERR_INVALID, "force size in settings does not match reference force size (only 3-D point feet are built)");
+    if (ocp->force_size != 3 && ocp->force_size != 6)
+      return fail(SMPC_ERR_INVALID, "force size in settings does not match reference force size");
     if (mpc->T < 2)
       return fail(SMPC_ERR_INVALID, "horizon must have at least 2 stages");
+    if (ocp->force_size == 6)
+    {
+      // 6-D (flat) feet: the kinodynamics variant of the dense stage / solver kernels (FullDims<..., KIN = 1>, smpc_full_model.h)
+      if (robot->njoints != KinoTalos::NJ || robot->nfeet != KinoTalos::NF)
+        return fail(SMPC_ERR_INVALID, "robot shape (njoints, nfeet, force_size) does not match a built kernel instantiation");
+      const int nv = robot->nv, ndx = 2 * nv, na = nv - 6, nu = na + 6 * robot->nfeet;
+      HostFullSettings s;
+      s.timestep = ocp->timestep;
+      s.w_x.assign(ocp->w_x, ocp->w_x + (size_t)ndx * ndx);
+      s.w_u.assign(ocp->w_u, ocp->w_u + (size_t)nu * nu);
+      s.w_cent.assign(ocp->w_cent, ocp->w_cent + 36);
+      s.w_centder.assign(ocp->w_centder, ocp->w_centder + 36);
+      s.w_forces.assign(36, 0.0);
+      s.w_frame.assign(ocp->w_frame, ocp->w_frame + 36);
+      s.umin.assign(nu, 0.0); // (no torque box in this OCP)
+      s.umax.assign(nu, 0.0);
+      s.qmin.assign(ocp->qmin, ocp->qmin + na);
+      s.qmax.assign(ocp->qmax, ocp->qmax + na);
+      s.Kp.assign(6, 0.0);
+      s.Kd.assign(6, 0.0);
+      for (int i = 0; i < 3; i++)
+        s.gravity[i] = ocp->gravity[i];
+      s.mu = ocp->mu;
+      s.Lfoot = ocp->Lfoot;
+      s.Wfoot = ocp->Wfoot;
+      s.force_size = 6;
+      s.torque_limits = 0;
+      s.kinematics_limits = ocp->kinematics_limits;
+      s.force_cone = ocp->force_cone;
+      s.land_cstr = 0; // (src/kinodynamics.cpp:134-146: land rows exist for 3-D feet only)
+      s.terminal_constraint = ocp->terminal_constraint;
+      for (int i = 0; i < na; i++)
+        if (!(s.qmin[i] <= s.qmax[i]))
+          return fail(SMPC_ERR_INVALID, "qmin must not exceed qmax (joint limits are indexed by actuated joint, 0 .. nv - 7)");
+      auto sym = [](const std::vector<double> & w, int n) {
+        for (int i = 0; i < n; i++)
+          for (int j = 0; j < i; j++)
+            if (std::fabs(w[(size_t)i * n + j] - w[(size_t)j * n + i]) > 1e-12 * (1.0 + std::fabs(w[(size_t)i * n + j])))
+              return false;
+        return true;
+      };
+      if (!sym(s.w_x, ndx) || !sym(s.w_u, nu) || !sym(s.w_cent, 6) || !sym(s.w_centder, 6) || !sym(s.w_frame, 6))
+        return fail(SMPC_ERR_INVALID, "weight matrices must be symmetric");
+      const HostMpcSettings ms6 = host_mpc(mpc);
+      return guarded([&] {
+        std::unique_ptr<smpc_handle> h(new smpc_handle());
+        h->full.reset(new FullEngine<KinoTalos>(robot, s, ms6, batch, gravity_arg, device_id));
+        *out = h.release();
+      });
+    }
     const int nv = robot->nv, ndx = 2 * nv, nu = nv - 6 + 3 * robot->nfeet;
     HostKinoSettings ks;
     ks.timestep = ocp->timestep;

@@ -14,6 +14,7 @@ namespace smpc
   {
     double timestep;
     std::vector<double> w_x, w_u, w_cent, w_forces, w_frame, umin, umax, qmin, qmax, Kp, Kd;
+    std::vector<double> w_centder; // kinodynamics variant (FullDims<..., KIN = 1>): KinodynamicsSettings::w_centder
     double gravity[3];
     double mu, Lfoot, Wfoot;
     int force_size, torque_limits, kinematics_limits, force_cone, land_cstr;
@@ -149,6 +150,12 @@ namespace smpc
       std::copy(fs.w_cent.begin(), fs.w_cent.end(), m.w_cent);
       std::copy(fs.w_forces.begin(), fs.w_forces.end(), m.w_forces);
       std::copy(fs.w_frame.begin(), fs.w_frame.end(), m.w_frame);
+      if constexpr (D::KINO)
+      {
+        if ((int)fs.w_centder.size() != 36)
+          throw std::runtime_error("kinodynamics settings: w_centder must be 6 x 6");
+        std::copy(fs.w_centder.begin(), fs.w_centder.end(), m.w_centder);
+      }
       std::copy(fs.Kp.begin(), fs.Kp.end(), m.Kp);
       std::copy(fs.Kd.begin(), fs.Kd.end(), m.Kd);
       std::copy(fs.umin.begin(), fs.umin.end(), m.umin);
@@ -231,7 +238,11 @@ namespace smpc
       std::memset(&def, 0, sizeof(def));
       def.mask = (1u << D::NF) - 1u;
       for (int f = 0; f < D::NF; f++)
+      {
         def.f_ref[D::FS * f + 2] = -rm->total_mass * gravity_arg / (double)D::NF;
+        if constexpr (D::KINO) // the force references are the head of the control reference (computeControlFromForces, src/kinodynamics.cpp:229-240)
+          def.u_ref[D::FS * f + 2] = def.f_ref[D::FS * f + 2];
+      }
       for (int i = 0; i < D::NX; i++)
         def.x_tgt[i] = x_model_ref[i];
       horizon.assign(H, def);
@@ -532,6 +543,8 @@ namespace smpc
           {
             s.mask |= 1u << f;
             s.f_ref[D::FS * f + 2] = ms.support_force / (double)active; // src/mpc.cpp:149-167
+            if constexpr (D::KINO)
+              s.u_ref[D::FS * f + 2] = s.f_ref[D::FS * f + 2];
           }
         s.land = s.mask & ~previous;
         previous = s.mask;
@@ -677,6 +690,8 @@ namespace smpc
         if (n != D::NCM)
           throw std::runtime_error("Reference forces do not have the right dimension");
         std::copy(v, v + n, horizon[t].f_ref);
+        if constexpr (D::KINO)
+          std::copy(v, v + n, horizon[t].u_ref);
       }
       else
         throw std::runtime_error("unknown stage reference");

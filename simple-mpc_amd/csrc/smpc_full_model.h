@@ -22,10 +22,21 @@ namespace smpc
   // pyramid of MultibodyFrictionConeResidual, src/fulldynamics.cpp:185-190); 6-D feet always carry their 17 wrench-cone rows
   // LN_: land_cstr rows per foot (0: none; 6: the LOCAL_WORLD_ALIGNED frame velocity of a landing 6-D foot, src/fulldynamics.cpp:175-181; 4: its 3
   // linear rows and the height of the contact pose for a 3-D foot, src/fulldynamics.cpp:191-210)
-  template <int NJ_, int NF_, int FS_, int CN_ = 0, int LN_ = 0>
+  // KIN_: 0 = full dynamics (above); 1 = the KINODYNAMICS OCP of a robot with 6-D feet on the same stage / solver kernels (reference
+  // KinodynamicsOCP with force_size == 6, src/kinodynamics.cpp:40-152: examples/talos_kinodynamics.py, tests/test_utils.cpp:147-197):
+  //   control u = [contact wrench (f, tau) per foot (NCM) ; joint accelerations (NA)], the base acceleration follows from the six unactuated
+  //   rows of the equations of motion (= Aligator's KinodynamicsFwdDynamics in another frame: Ag a + dAg v = hdot(u, q));
+  //   costs: state, control, centroidal momentum, its derivative hdot(u, q) (w_centder), foot placement;
+  //   constraint rows: [ (no torque box) | joint box (NA) | CentroidalWrenchConeResidual: 17 constant rows on u per foot in contact (NCONE,
+  //   dense block Dd, pivoted explicitly) | 6-row LOCAL frame velocity of every foot in contact (NVEL: equality rows on the state only --
+  //   they are FOLDED by the stage kernel, Q += Cv^T Cv / mu, q += Cv^T d / mu, as the structured kinodynamics sweep does; the rows are kept
+  //   in the knot for the multiplier step of the forward sweep) ]
+  template <int NJ_, int NF_, int FS_, int CN_ = 0, int LN_ = 0, int KIN_ = 0>
   struct FullDims
   {
     static_assert(LN_ == 0 || LN_ == (FS_ == 6 ? 6 : 4), "land_cstr rows per foot");
+    static_assert(KIN_ == 0 || (FS_ == 6 && LN_ == 0), "kinodynamics variant: 6-D feet (point feet run on KinoEngine), no land rows (src/kinodynamics.cpp:134)");
+    static constexpr bool KINO = KIN_ != 0;
     static constexpr int NJ = NJ_;     // joints incl. free-flyer
     static constexpr int NF = NF_;     // feet
     static constexpr int FS = FS_;     // contact force size
@@ -34,7 +45,7 @@ namespace smpc
     static constexpr int NX = NQ + NV;
     static constexpr int NDX = 2 * NV;
     static constexpr int NA = NV - 6;
-    static constexpr int NU = NA;
+    static constexpr int NU = KINO ? NA + FS_ * NF_ : NA;
     static constexpr int PF = FS_;                            // size of a foot-pose residual: translation (3) or log6 placement (6)
     static constexpr int NCM = FS_ * NF_;                     // contact rows when every foot is in contact
     static constexpr int NCONE1 = FS_ == 6 ? 17 : CN_;        // cone rows per foot (wrench cone of 6-D feet / friction pyramid of 3-D feet)
@@ -42,7 +53,8 @@ namespace smpc
     static constexpr int NLAND1 = LN_;                        // land_cstr rows per foot (equality rows on the state)
     static constexpr int NLAND = NLAND1 * NF_;
     static constexpr int NCD = NCONE + NLAND;                 // dense rows of the knot: cone rows, then land rows
-    static constexpr int NC = NU + NA + NCD;
+    static constexpr int NVEL = KINO ? FS_ * NF_ : 0;         // kinodynamics: frame-velocity rows (state only, folded), behind the dense rows
+    static constexpr int NC = NU + NA + NCD + NVEL;
     static constexpr int NXU = NDX + NU;
     // LQ knot block (doubles), one per (instance, stage)
     static constexpr int O_A = 0;
@@ -52,7 +64,8 @@ namespace smpc
     static constexpr int O_R = O_S + NDX * NU;
     static constexpr int O_C = O_R + NU * NU;       // Cd: dense rows (cone | land), NCD x NDX (active rows, else zero)
     static constexpr int O_D = O_C + NCD * NDX;     // Dd: NCD x NU
-    static constexpr int O_q = O_D + NCD * NU;
+    static constexpr int O_V = O_D + NCD * NU;      // Cv: NVEL x NDX (kinodynamics: frame-velocity rows of the feet in contact, else zero)
+    static constexpr int O_q = O_V + NVEL * NDX;
     static constexpr int O_r = O_q + NDX;
     static constexpr int O_f = O_r + NU;
     static constexpr int O_d = O_f + NDX;           // mu (nu+ - nu), all NC rows
@@ -79,6 +92,7 @@ namespace smpc
     double total_mass, dt, gravity[3], mu; // mu: ProxDDP penalty (mu_init)
     // FullDynamicsSettings (include/simple-mpc/fulldynamics.hpp:28-65)
     double w_cent[36], w_forces[D::FS * D::FS], w_frame[D::FS * D::FS];
+    double w_centder[36]; // kinodynamics variant: weight of the centroidal_derivative_cost (src/kinodynamics.cpp:63-64)
     double Kp[D::FS], Kd[D::FS];
     double umin[D::NU], umax[D::NU], qmin[D::NA], qmax[D::NA];
     double fric_mu, Lfoot, Wfoot;
@@ -105,16 +119,16 @@ namespace smpc
     double w_u[D::NU * D::NU];
     double x_term[D::NX];
   };
-  template <int NJ_, int NF_, int FS_, int CN_, int LN_>
-  struct DevModel<FullDims<NJ_, NF_, FS_, CN_, LN_>> : FullDevModel<FullDims<NJ_, NF_, FS_, CN_, LN_>>
+  template <int NJ_, int NF_, int FS_, int CN_, int LN_, int KIN_>
+  struct DevModel<FullDims<NJ_, NF_, FS_, CN_, LN_, KIN_>> : FullDevModel<FullDims<NJ_, NF_, FS_, CN_, LN_, KIN_>>
   {
   };
 
   // stage descriptor shared by the phase-aligned batch
-  template <int NJ_, int NF_, int FS_, int CN_, int LN_>
-  struct StageShared<FullDims<NJ_, NF_, FS_, CN_, LN_>>
+  template <int NJ_, int NF_, int FS_, int CN_, int LN_, int KIN_>
+  struct StageShared<FullDims<NJ_, NF_, FS_, CN_, LN_, KIN_>>
   {
-    typedef FullDims<NJ_, NF_, FS_, CN_, LN_> D;
+    typedef FullDims<NJ_, NF_, FS_, CN_, LN_, KIN_> D;
     unsigned mask;
     unsigned land; // bit per foot: the foot lands at this stage of the cycle (land_cstr rows; reference src/mpc.cpp:167-178)
     double u_ref[D::NU];   // control reference (zero in the reference's stages, src/fulldynamics.cpp:89)

@@ -236,7 +236,7 @@ namespace smpc
           part[lane] += lq[D::O_vpd + r] * (mu * dnu - d) - d * dnu;
         }
         // dense rows (wrench cones): dnu = Z dx + z from the explicitly pivoted multipliers
-        for (int r = NU + NA + lane; r < NC; r += NT)
+        for (int r = NU + NA + lane; r < NU + NA + D::NCD; r += NT)
         {
           const double * Zr = g + D::G_Z + (r - NU - NA) * (NDX + 1);
           double dnu = Zr[NDX];
@@ -246,6 +246,20 @@ namespace smpc
           b.dvs[lt * NC + r] = dnu;
           part[lane] += lq[D::O_vpd + r] * (mu * dnu - d) - d * dnu;
         }
+        // kinodynamics variant: the folded frame-velocity rows (state only): dnu = (Cv dx + d) / mu
+        if constexpr (D::NVEL > 0)
+          for (int r = lane; r < D::NVEL; r += NT)
+          {
+            const double * Cr = lq + D::O_V + r * NDX;
+            const int row = NU + NA + D::NCD + r;
+            const double d = lq[D::O_d + row];
+            double acc = d;
+            for (int j = 0; j < NDX; j++)
+              acc += Cr[j] * dx[j];
+            const double dnu = acc / mu;
+            b.dvs[lt * NC + row] = dnu;
+            part[lane] += lq[D::O_vpd + row] * (mu * dnu - d) - d * dnu;
+          }
         for (int i = lane; i < NDX; i += NT)
         {
           const double * Ar = lq + D::O_A + i * NDX;

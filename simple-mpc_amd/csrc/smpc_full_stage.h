@@ -82,9 +82,21 @@ namespace smpc
     static constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX;
     static constexpr int NCOL = 2 * NV + NU, NGN = 6 + D::PF * NF + NCM;
     double Bc[NJ * 36], dk[NV * 6], Ak[NV * 6], Wc[NF * 6];
-    double R1[NV * NCOL];       // [r1q | r1v | r1t] -> M^-1 R1 -> [da_dq | da_dv | da_dtau]
+    // kinodynamics variant: only the six base rows are solved for (rows 6 .. of [da_dq | da_dv | da_du] are the unit block of the joint
+    // accelerations in u: r1()); the space takes the frame-velocity rows Cv (NVEL x NDX) of the feet in contact instead
+    static constexpr int R1ROWS = D::KINO ? 6 : NV;
+    double R1[R1ROWS * NCOL];   // [r1q | r1v | r1t] -> M^-1 R1 -> [da_dq | da_dv | da_dtau]
+    double Cv[D::KINO ? D::NVEL * NDX : 1];
+    SMPC_HD double r1(int i, int cc) const
+    {
+      if constexpr (D::KINO)
+        return i < 6 ? R1[i * NCOL + cc] : (cc == 2 * NV + NCM + i - 6 ? 1.0 : 0.0);
+      else
+        return R1[i * NCOL + cc];
+    }
     double JT[NCM * NCOL];      // force rows of the stacked Gauss-Newton Jacobian: [r2q | r2v | 0] -> [dlam_dq | dlam_dv | dlam_dtau]
                                 // (the momentum / foot-pose rows live in the dead dynamics block of the evaluation scratch)
+                                // kinodynamics variant: rows 0 .. 5 = Jacobian of the centroidal_derivative residual hdot(u, q), the rest zero
     double Je3[9], JeQ[9], Jq[36], Jl[36];
     double Jlf[D::FS == 6 ? NF * 36 : 2]; // Jlog6 of the foot-placement residuals (6-D feet)
     // tables of the assembly phases: they live in the composite velocity-product matrices, dead once R1 is formed
@@ -501,13 +513,13 @@ namespace smpc
       stsv(&sc.IcS[l * 6], Ic * Sl);
       const SV g{ld3(h.gravity), mk3(0, 0, 0)};
       const SV Fg = ldsv(&sc.Fc[j * 6]) - Ic * g; // uniform field: every body accelerates with -g relative to free fall
-      sc.W[l * NR] = (l >= 6 ? sc.u[l - 6] : 0.0) - sv_dot6(Sl, Fg);
+      sc.W[l * NR] = ((l >= 6 && !D::KINO) ? sc.u[l - 6] : 0.0) - sv_dot6(Sl, Fg); // (kinodynamics variant: no joint torques)
     }
     SMPC_LANES_END_WAVE
     // ---- joint-space inertia M_kl = S_k . (Ic_j S_l) on the branch ; contact rows zeroed ----
     SMPC_LANES(NT)
     {
-      for (int idx = lane; idx < NV * NV; idx += NT)
+      for (int idx = lane; idx < (D::KINO ? 6 : NV) * NV; idx += NT) // (kinodynamics variant: the six base rows are all it needs)
       {
         const int k = idx / NV, l = idx % NV;
         const int jk = jof(k), jl = jof(l);
@@ -614,6 +626,62 @@ namespace smpc
     ftick(fp, 3);
     if (rows_only) // (inverse-dynamics front end, smpc_id.h: M, S tau - nle, the contact rows and their drift are what it needs)
       return;
+    if constexpr (D::KINO)
+    {
+      // ---- kinodynamics variant (KinodynamicsFwdDynamics, constructed at reference src/kinodynamics.cpp:85-87): the contact wrenches and the
+      //      joint accelerations are controls; the base acceleration solves the six unactuated rows of the equations of motion,
+      //      M_bb a_b = -nle_b + (J^T lam)_b - M_bj a_j  (J: the world-aligned 6-D rows at the foot points = the wrench [f ; (p - 0) x f + tau]
+      //      at the world origin; the same balance as Ag a + dAg v = [m g + sum f ; sum (p - c) x f + tau] taken at the CoM) ----
+      SMPC_LANES(NT)
+      {
+        if (lane < NCM)
+        {
+          const int c = lane / FS;
+          int f = -1, cnt = 0;
+          for (int ff = 0; ff < NF; ff++)
+            if ((mask >> ff) & 1u)
+            {
+              if (cnt == c)
+                f = ff;
+              cnt++;
+            }
+          sc.lam[lane] = f >= 0 ? sc.u[FS * f + lane % FS] : 0.0; // compact: wrenches of the feet in contact, in order
+        }
+        for (int idx = lane; idx < 36; idx += NT)
+          sc.Gi[idx] = sc.M[(idx / 6) * NV + idx % 6];
+      }
+      SMPC_LANES_END_WAVE
+      static_assert(sizeof(SC) - offsetof(SC, xnext) >= 2 * 4 * 16 * sizeof(double), "the sweep scratch fits the late block");
+      fwave_spd_inverse<6>(sc.Gi, sc.swp_());
+      SMPC_LANES(NT)
+      if (lane < 6)
+      {
+        double r = sc.W[lane * NR];
+        for (int i = 0; i < NCM; i++)
+          r += sc.J[i * NV + lane] * sc.lam[i];
+        for (int l = 6; l < NV; l++)
+          r -= sc.M[lane * NV + l] * sc.u[NCM + l - 6];
+        sc.rhs[lane] = r;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
+        if (lane < 6)
+        {
+          double acc = 0.0;
+          for (int d = 0; d < 6; d++)
+            acc += sc.Gi[lane * 6 + d] * sc.rhs[d];
+          sc.a[lane] = acc;
+        }
+        else if (lane < NV)
+          sc.a[lane] = sc.u[NCM + lane - 6];
+        if (lane == 0)
+          sc.iters_[0] = 0;
+      }
+      SMPC_LANES_END_WAVE
+      ftick(fp, 6);
+      return;
+    }
     // ---- M <- M^-1 (bordered symmetric sweep) ; W = M^-1 [S tau - nle | J^T] on the matrix cores ----
     static_assert(sizeof(SC) - offsetof(SC, xnext) >= SC::SWP_DOUBLES * sizeof(double), "the sweep scratch fits the late block");
     fwave_spd_inverse<NV>(sc.M, sc.swp_());
@@ -855,6 +923,23 @@ namespace smpc
     return c == 0 ? o.x : (c == 1 ? o.y : o.z);
   }
 
+  // kinodynamics variant: entry (r, k) of the Jacobian of the LOCAL 6-D frame velocity of foot f (rows: R^T v_point, R^T omega), k a tangent
+  // index of the state (q | v).  The rigid turn of the subtree by S_k cancels in the LOCAL frame: what is left of d/dq_k is d_k = v_parent x S_k;
+  // d/dv_k is the LOCAL frame Jacobian column (Pinocchio getFrameVelocityDerivatives, LOCAL)
+  template <class D, class SC, class SD>
+  SMPC_DEV double kino_vel_entry(const SC & sc, const SD & sd, int f, int r, int k)
+  {
+    constexpr int NV = D::NV;
+    const int jf = sc.h.foot_joint[f], kk = k < NV ? k : k - NV;
+    if (!((sc.h.anc[jf] >> jof(kk)) & 1u))
+      return 0.0;
+    const V3 p = ld3(&sc.footp[f * 3]);
+    const SV m = k >= NV ? ldsv(&sc.S[kk * 6]) : ldsv(&sd.dk[kk * 6]);
+    const V3 o = tmul(ldm3(&sc.oR[jf * 9]), r < 3 ? m.l + cross(m.a, p) : m.a);
+    const int c = r % 3;
+    return c == 0 ? o.x : (c == 1 ? o.y : o.z);
+  }
+
   // x+ (semi-implicit Euler), defect, residuals, weighted residuals, cost, constraint values, AL multipliers, merit pieces.
   // Results: sc.red[0] cost, sc.red[1] penalty part of the merit, sc.red[2] primal infeasibility.
   template <class D, bool DERIV, class SC, class SD>
@@ -953,8 +1038,45 @@ namespace smpc
           const int f = i / (D::NLAND1 > 0 ? D::NLAND1 : 1), r = i % (D::NLAND1 > 0 ? D::NLAND1 : 1);
           sc.cval[NU + NA + D::NCONE + i] = ((land >> f) & 1u) ? full_land_value<D>(sc, f, r) : 0.0;
         }
+        if constexpr (D::KINO)
+        {
+          // frame-velocity rows of the feet in contact: the LOCAL 6-D frame velocity [R^T v_point ; R^T omega] (FrameVelocityResidual(..., LOCAL),
+          // reference src/kinodynamics.cpp:110-123)
+          for (int i = lane; i < D::NVEL; i += NT)
+          {
+            const int f = i / FS, r = i % FS;
+            double v = 0.0;
+            if ((mask >> f) & 1u)
+            {
+              const int jf = h.foot_joint[f];
+              const SV vl = ldsv(&sc.vel[jf * 6]);
+              const V3 w = r < 3 ? vl.l + cross(vl.a, ld3(&sc.footp[f * 3])) : vl.a;
+              const V3 o = tmul(ldm3(&sc.oR[jf * 9]), w);
+              v = r % 3 == 0 ? o.x : (r % 3 == 1 ? o.y : o.z);
+            }
+            sc.cval[NU + NA + D::NCD + i] = v;
+          }
+          // centroidal_derivative residual hdot(u, q) = [m g + sum f ; sum (p - c) x f + tau] over the feet in contact (rows 0 .. 5 of the
+          // "force" block of the stacked residual; src/kinodynamics.cpp:57-59, 63-64)
+          if (lane >= 56 && lane < 62)
+          {
+            const int r = lane - 56;
+            V3 lin = h.total_mass * ld3(h.gravity), ang = mk3(0, 0, 0);
+            const V3 com = ld3(sc.com);
+            for (int f = 0; f < NF; f++)
+              if ((mask >> f) & 1u)
+              {
+                const V3 F = ld3(&sc.u[FS * f]);
+                lin = lin + F;
+                ang = ang + cross(ld3(&sc.footp[f * 3]) - com, F) + ld3(&sc.u[FS * f + 3]);
+              }
+            sc.rl[r] = r < 3 ? (r == 0 ? lin.x : (r == 1 ? lin.y : lin.z)) : (r == 3 ? ang.x : (r == 4 ? ang.y : ang.z));
+          }
+          for (int i = 6 + lane; i < NCM; i += NT)
+            sc.rl[i] = 0.0;
+        }
         // contact-force residual of the feet in contact (compact row c of foot f)
-        for (int i = lane; i < NCM; i += NT)
+        for (int i = lane; i < (D::KINO ? 0 : NCM); i += NT)
         {
           int f = -1, cnt = 0;
           for (int ff = 0; ff < NF; ff++)
@@ -1016,8 +1138,15 @@ namespace smpc
         {
           const int c = i / FS, r = i % FS;
           double s = 0.0;
-          for (int j = 0; j < FS; j++)
-            s += h.w_forces[r * FS + j] * sc.rl[c * FS + j];
+          if constexpr (D::KINO)
+          {
+            if (i < 6)
+              for (int j = 0; j < 6; j++)
+                s += h.w_centder[i * 6 + j] * sc.rl[j];
+          }
+          else
+            for (int j = 0; j < FS; j++)
+              s += h.w_forces[r * FS + j] * sc.rl[c * FS + j];
           sc.Wrl[i] = s;
         }
       }
@@ -1080,11 +1209,13 @@ namespace smpc
       for (int i = lane; i < NC; i += NT)
       {
         // rows: torque box | joint box | wrench-cone rows of the feet in contact (negative orthant) | rows of the landing feet (equality)
-        const bool box = i < NU + NA, eq = i >= NU + NA + D::NCONE;
+        // (kinodynamics variant: | frame-velocity rows of the feet in contact (equality), behind the dense rows)
+        const bool box = i < NU + NA, eq = i >= NU + NA + D::NCONE, vel = i >= NU + NA + D::NCD;
         const bool present = i < NU ? h.torque_limits != 0
                                     : (box ? h.kinematics_limits != 0
-                                           : (eq ? ((land >> ((i - NU - NA - D::NCONE) / (D::NLAND1 > 0 ? D::NLAND1 : 1))) & 1u) != 0u
-                                                 : (h.force_cone != 0 && ((mask >> ((i - NU - NA) / (D::NCONE1 > 0 ? D::NCONE1 : 1))) & 1u))));
+                                           : (vel ? ((mask >> ((i - NU - NA - D::NCD) / FS)) & 1u) != 0u
+                                            : (eq ? ((land >> ((i - NU - NA - D::NCONE) / (D::NLAND1 > 0 ? D::NLAND1 : 1))) & 1u) != 0u
+                                                 : (h.force_cone != 0 && ((mask >> ((i - NU - NA) / (D::NCONE1 > 0 ? D::NCONE1 : 1))) & 1u)))));
         double vp = 0.0;
         int act = 0;
         if (present)
@@ -1173,8 +1304,8 @@ namespace smpc
         for (int r = 0; r < 6; r++)
         {
           jc6[r * NCOL + NV + k] = agc[r];
-          if (k < NU)
-            jc6[r * NCOL + 2 * NV + k] = 0.0;
+          for (int c = k; c < NU; c += NV)
+            jc6[r * NCOL + 2 * NV + c] = 0.0;
         }
       }
       double * jf = sc.jt2_() + 6 * NCOL;
@@ -1211,8 +1342,8 @@ namespace smpc
         for (int r = 0; r < PF; r++)
         {
           jf[(PF * f + r) * NCOL + NV + k] = 0.0;
-          if (k < NU)
-            jf[(PF * f + r) * NCOL + 2 * NV + k] = 0.0;
+          for (int c = k; c < NU; c += NV)
+            jf[(PF * f + r) * NCOL + 2 * NV + c] = 0.0;
         }
       }
     }
@@ -1308,7 +1439,6 @@ namespace smpc
       stsv(&sd.Ak[k * 6], A);
     }
     SMPC_LANES_END_WAVE
-    static_assert(NU <= NV, "tau columns are zeroed by the dof lanes");
     ftick(fp, 9);
     if (term)
     {
@@ -1359,14 +1489,16 @@ namespace smpc
           stsv(&Yq_[k * 6], Yq);
           stsv(&Yv_[k * 6], Yv);
         }
-        for (int idx = lane; idx < NV * NU; idx += NT)
-        {
-          const int m = idx / NU, j = idx % NU;
-          sd.R1[m * NCOL + 2 * NV + j] = m == 6 + j ? -1.0 : 0.0;
-        }
+        if constexpr (!D::KINO)
+          for (int idx = lane; idx < NV * NU; idx += NT)
+          {
+            const int m = idx / NU, j = idx % NU;
+            sd.R1[m * NCOL + 2 * NV + j] = m == 6 + j ? -1.0 : 0.0;
+          }
       }
       SMPC_LANES_END_WAVE
-      fwave_gemm<NV, 2 * NV, 12>(
+      constexpr int MR = SD::R1ROWS; // (kinodynamics variant: the six base rows)
+      fwave_gemm<MR, 2 * NV, 12>(
         [&](int m, int kk) { return kk < 6 ? sc.IcS[m * 6 + kk] : Dm_[m * 6 + kk - 6]; },
         [&](int kk, int j) {
           const int jj = j < NV ? j : j - NV;
@@ -1377,7 +1509,7 @@ namespace smpc
           const int jm = jof(m), i = jof(j < NV ? j : j - NV);
           sd.R1[m * NCOL + j] = ((h.anc[jm] >> i) & 1u) ? v : 0.0;
         });
-      fwave_gemm<NV, 2 * NV, 6>(
+      fwave_gemm<MR, 2 * NV, 6>(
         [&](int m, int kk) { return sc.S[m * 6 + kk]; },
         [&](int kk, int j) { return j < NV ? Yq_[j * 6 + kk] : Yv_[(j - NV) * 6 + kk]; },
         [&](int m, int j, double v) {
@@ -1404,10 +1536,10 @@ namespace smpc
           st3(&Pv_[m * 3 * NF + 3 * f], on ? Sm.l + cross(Sm.a, ld3(&sc.footp[f * 3])) : z);
         }
         SMPC_LANES_END_WAVE
-        fwave_gemm<NV, NV, 3 * NF>(
+        fwave_gemm<MR, NV, 3 * NF>(
           [&](int m, int kk) { return Gm_[m * 3 * NF + kk]; }, [&](int kk, int j) { return Pv_[j * 3 * NF + kk]; },
           [&](int m, int j, double v) { sd.R1[m * NCOL + j] -= v; });
-        fwave_gemm<NV, NV, 6 * NF>(
+        fwave_gemm<MR, NV, 6 * NF>(
           [&](int m, int kk) { return Hm_[m * 6 * NF + kk]; },
           [&](int kk, int j) {
             const int f = kk / 6;
@@ -1427,6 +1559,96 @@ namespace smpc
       SMPC_LANES_END_WAVE
     }
     ftick(fp, 10);
+    if constexpr (D::KINO)
+    {
+      // ---- kinodynamics variant: the base rows  M_bb da_b = -(r1q | r1v) dq,dv + (J^T)_b d lam - M_bj d a_j ; the joint accelerations are
+      //      controls (r1()).  Right-hand sides in place on the six rows of R1, then R1 <- M_bb^-1 R1 (lane = column) ----
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < 6 * NCOL; idx += NT)
+      {
+        const int b = idx / NCOL, c = idx % NCOL;
+        double v;
+        if (c < 2 * NV)
+          v = -sd.R1[idx];
+        else if (c < 2 * NV + NCM)
+        {
+          const int f = (c - 2 * NV) / FS, j = (c - 2 * NV) % FS;
+          const int cc = __builtin_popcount(mask & ((1u << f) - 1u));
+          const double jv = sc.J[(FS * (((mask >> f) & 1u) ? cc : 0) + j) * NV + b];
+          v = ((mask >> f) & 1u) ? jv : 0.0;
+        }
+        else
+          v = -sc.M[b * NV + 6 + (c - 2 * NV - NCM)];
+        sd.R1[idx] = v;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      for (int c = lane; c < NCOL; c += NT)
+      {
+        double t[6], o[6];
+        for (int b = 0; b < 6; b++)
+          t[b] = sd.R1[b * NCOL + c];
+        for (int b = 0; b < 6; b++)
+        {
+          double acc = 0.0;
+          for (int d = 0; d < 6; d++)
+            acc += sc.Gi[b * 6 + d] * t[d];
+          o[b] = acc;
+        }
+        for (int b = 0; b < 6; b++)
+          sd.R1[b * NCOL + c] = o[b];
+      }
+      SMPC_LANES_END_WAVE
+      // ---- Jacobian of the centroidal_derivative residual hdot(u, q) (rows 0 .. 5 of JT):  d/dq_k = sum_f (dp_f/dq_k - dc/dq_k) x f_f on the
+      //      angular rows;  d/du_f = [I 0 ; [p_f - c]x I] for a foot in contact ; frame-velocity rows Cv of the feet in contact ----
+      SMPC_LANES(NT)
+      {
+        const V3 com = ld3(sc.com);
+        if (lane < NV)
+        {
+          const int k = lane, i = jof(k);
+          const SV sk = ldsv(&sc.S[k * 6]);
+          const V3 jc = (1.0 / h.total_mass) * (ldsi(&sc.Ic[i * 10]) * sk).l;
+          V3 acc = mk3(0, 0, 0);
+          for (int f = 0; f < NF; f++)
+            if ((mask >> f) & 1u)
+            {
+              const bool on = (h.anc[h.foot_joint[f]] >> i) & 1u;
+              const V3 pf = on ? sk.l + cross(sk.a, ld3(&sc.footp[f * 3])) : mk3(0, 0, 0);
+              acc = acc + cross(pf - jc, ld3(&sc.u[FS * f]));
+            }
+          sd.JT[3 * NCOL + k] = acc.x;
+          sd.JT[4 * NCOL + k] = acc.y;
+          sd.JT[5 * NCOL + k] = acc.z;
+        }
+        for (int idx = lane; idx < 6 * NCM; idx += NT)
+        {
+          const int r = idx / NCM, c = idx % NCM, f = c / FS, j = c % FS;
+          double v = 0.0;
+          if ((mask >> f) & 1u)
+          {
+            if (j < 3)
+            {
+              const V3 e = mk3(j == 0, j == 1, j == 2);
+              const V3 x = cross(ld3(&sc.footp[f * 3]) - com, e);
+              v = r < 3 ? (r == j ? 1.0 : 0.0) : (r == 3 ? x.x : (r == 4 ? x.y : x.z));
+            }
+            else
+              v = r == j ? 1.0 : 0.0;
+          }
+          sd.JT[r * NCOL + 2 * NV + c] = v;
+        }
+        for (int idx = lane; idx < D::NVEL * D::NDX; idx += NT)
+        {
+          const int row = idx / D::NDX, k = idx % D::NDX, f = row / FS, r = row % FS;
+          sd.Cv[idx] = ((mask >> f) & 1u) ? kino_vel_entry<D>(sc, sd, f, r, k) : 0.0;
+        }
+      }
+      SMPC_LANES_END_WAVE
+      full_gn_rows<D>(sc, sd, false);
+      ftick(fp, 12);
+      return;
+    }
     // ---- partial derivatives of the contact acceleration residual (classical acceleration, contact frame, corrector) ----
     if constexpr (FS == 6)
     {
@@ -1537,10 +1759,16 @@ namespace smpc
   SMPC_DEV double full_wtilde(const FullHead<D> & h, int r, int k, bool term, bool tcs = false)
   {
     constexpr int NCM = D::NCM, FS = D::FS, NGN = SC::NGN;
+    if constexpr (D::KINO) // frame-velocity rows behind the cost rows: folded equality rows, weight 1 / mu (Cv^T Cv / mu)
+      if (r >= NGN && r < NGN + D::NVEL)
+        return (!term && r == k) ? 1.0 / h.mu : 0.0;
     if (r >= NGN || k >= NGN)
       return 0.0;
     if (r < NCM && term) // terminal node: the first three rows hold the terminal constraint's Jacobian, weight 1 / mu (C^T C / mu)
       return (tcs && r < 3 && r == k) ? 1.0 / h.mu : 0.0;
+    if constexpr (D::KINO) // rows 0 .. 5: centroidal_derivative residual, weight w_centder
+      if (r < NCM)
+        return (r < 6 && k < 6) ? h.w_centder[r * 6 + k] : 0.0;
     if (r < NCM)
       return (term || k >= NCM || r / FS != k / FS) ? 0.0 : h.w_forces[(r % FS) * FS + k % FS];
     if (r < NCM + 6)
@@ -1603,7 +1831,8 @@ namespace smpc
   SMPC_DEV void full_hessian_mfma(SC & sc, SD & sd, const DevModel<D> & mg, bool term, double preg, double * Qd, double * Sd, double * Rd, bool mirror, bool tcs = false)
   {
     constexpr int NT = 64;
-    constexpr int NDX = D::NDX, NU = D::NU, NXU = D::NXU, NCOL = SC::NCOL, NGN = SC::NGN;
+    constexpr int NDX = D::NDX, NU = D::NU, NXU = D::NXU, NCOL = SC::NCOL, NGN0 = SC::NGN;
+    constexpr int NGN = NGN0 + D::NVEL; // (kinodynamics variant: the folded frame-velocity rows ride behind the cost rows, from sd.Cv)
     constexpr int NTC = (NXU + 15) / 16, NTR = (NGN + 15) / 16, KS = (NGN + 3) / 4;
     static_assert(NCOL == NXU, "the derivative columns (q, v, tau) are the (x, u) columns");
     const FullHead<D> & h = sc.h;
@@ -1649,9 +1878,11 @@ namespace smpc
         for (int J = 0; J < NTC; J++)
         {
           const int c = 16 * J + lc;
-          const bool ok = r < NGN && c < NCOL && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3)); // terminal node: momentum (+ constraint) rows only
-          const double * row = (ok && r < D::NCM) ? &sd.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL;
-          const double v = row[c < NCOL ? c : 0];
+          const bool velr = D::KINO && r >= NGN0;
+          const bool ok = r < NGN && (velr ? (c < NDX && !term) : c < NCOL) && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3)); // terminal node: momentum (+ constraint) rows only
+          const double * row = (ok && velr) ? &sd.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
+                                            : ((ok && r < D::NCM) ? &sd.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL);
+          const double v = row[(c < NCOL && ok) ? c : 0];
           SMPC_PLV(jtv)[J] = ok ? v : 0.0;
         }
 #pragma unroll
@@ -1681,9 +1912,11 @@ namespace smpc
           for (int J = 0; J < NTC; J++)
           {
             const int c = 16 * J + lc;
-            const bool ok = r < NGN && c < NCOL && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3));
-            const double * row = (ok && r < D::NCM) ? &sd.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL;
-            const double x = row[c < NCOL ? c : 0];
+            const bool velr = D::KINO && r >= NGN0;
+            const bool ok = r < NGN && (velr ? (c < NDX && !term) : c < NCOL) && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3));
+            const double * row = (ok && velr) ? &sd.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
+                                              : ((ok && r < D::NCM) ? &sd.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL);
+            const double x = row[(c < NCOL && ok) ? c : 0];
             SMPC_PLV(jtv)[J] = ok ? x : 0.0;
             SMPC_PLV(bv)[J] = SMPC_ACCV(wj, R * NTC + J, v);
           }
@@ -1853,7 +2086,20 @@ namespace smpc
       else
         sd.gu_()[k - NDX] = g;
       double cqv = 0.0;
-      if constexpr (D::NCONE > 0)
+      if constexpr (D::KINO)
+      {
+        if (!term)
+        {
+          // wrench-cone rows act on the control itself: D^T nu = A_cone^T nu on the wrench columns of the feet in contact
+          if (k >= NDX && k < NDX + NCM && ((mask >> ((k - NDX) / D::FS)) & 1u))
+            cqv = sd.yc_()[D::FS * __builtin_popcount(mask & ((1u << ((k - NDX) / D::FS)) - 1u)) + (k - NDX) % D::FS];
+          // frame-velocity rows: Cv^T nu
+          if (k < NDX)
+            for (int r = 0; r < D::NVEL; r++)
+              cqv += sd.Cv[r * NDX + k] * sc.nu[NU + NA + D::NCD + r];
+        }
+      }
+      else if constexpr (D::NCONE > 0)
         if (!term)
           for (int r = 0; r < NCM; r++)
             cqv += sd.JT[r * NCOL + k] * sd.yc_()[r];
@@ -1969,7 +2215,7 @@ namespace smpc
         double acc = 0.0; // (A^T lam_next)[k] or (B^T lam_next)[k], rows in order
         double Dtop[6];
         for (int m = 0; m < 6; m++)
-          Dtop[m] = dt * dt * sd.R1[m * NCOL + cc] + ((isA && k == NV + m) ? dt : 0.0);
+          Dtop[m] = dt * dt * sd.r1(m, cc) + ((isA && k == NV + m) ? dt : 0.0);
         for (int i = 0; i < 6; i++)
         {
           double v;
@@ -1985,13 +2231,13 @@ namespace smpc
         }
         for (int i = 6; i < NV; i++)
         {
-          const double v = dt * dt * sd.R1[i * NCOL + cc] + ((isA && k == NV + i) ? dt : 0.0) + ((isA && k == i) ? 1.0 : 0.0);
+          const double v = dt * dt * sd.r1(i, cc) + ((isA && k == NV + i) ? dt : 0.0) + ((isA && k == i) ? 1.0 : 0.0);
           dst[i * ld + k] = v;
           acc += v * sc.lam_next[i];
         }
         for (int i = 0; i < NV; i++)
         {
-          const double v = dt * sd.R1[i * NCOL + cc] + ((isA && k == NV + i) ? 1.0 : 0.0);
+          const double v = dt * sd.r1(i, cc) + ((isA && k == NV + i) ? 1.0 : 0.0);
           dst[(NV + i) * ld + k] = v;
           acc += v * sc.lam_next[NV + i];
         }
@@ -2004,7 +2250,11 @@ namespace smpc
           double q = sd.gx_()[k] + acc + cn + sd.cq_()[k] - (t > 0 ? b.lams[(ib + sprev) * NDX + k] : 0.0);
           if (t == 0)
             q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
-          lq[D::O_q + k] = q;
+          double qf = q;
+          if constexpr (D::KINO) // folded frame-velocity rows: the Newton right-hand side gets Cv^T d / mu = Cv^T (nu+ - nu)
+            for (int r = 0; r < (t == 0 ? 0 : D::NVEL); r++)
+              qf += sd.Cv[r * NDX + k] * (sc.vplus[NU + NA + D::NCD + r] - sc.nu[NU + NA + D::NCD + r]);
+          lq[D::O_q + k] = qf;
           lq[D::O_lx + k] = sd.gx_()[k];
           lq[D::O_f + k] = mu * (sc.lamp[k] - sc.lam_next[k]);
           lq[D::O_lpd + k] = 2.0 * sc.lamp[k] - sc.lam_next[k];
@@ -2047,15 +2297,31 @@ namespace smpc
         double acc = 0.0;
         if (sc.act[NU + NA + i])
         {
-          const int c = __builtin_popcount(mask & ((1u << f) - 1u));
-          for (int j = 0; j < D::FS; j++)
-            acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * sd.JT[(D::FS * c + j) * NCOL + k];
+          if constexpr (D::KINO)
+          { // CentroidalWrenchConeResidual: constant rows on the wrench of foot f
+            if (k >= NDX + D::FS * f && k < NDX + D::FS * (f + 1))
+              acc = wrench_cone_entry(r, k - NDX - D::FS * f, h.fric_mu, h.Lfoot, h.Wfoot);
+          }
+          else
+          {
+            const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+            for (int j = 0; j < D::FS; j++)
+              acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * sd.JT[(D::FS * c + j) * NCOL + k];
+          }
         }
         if (k < NDX)
           lq[D::O_C + i * NDX + k] = acc;
         else
           lq[D::O_D + i * NU + k - NDX] = acc;
       }
+      SMPC_LANES_END_WAVE
+    }
+    if constexpr (D::KINO)
+    {
+      // frame-velocity rows (folded into Q, q above): kept for the multiplier step of the forward sweep, dnu = (Cv dx + d) / mu
+      SMPC_LANES(NT)
+      for (int idx = lane; idx < D::NVEL * NDX; idx += NT)
+        lq[D::O_V + idx] = sd.Cv[idx];
       SMPC_LANES_END_WAVE
     }
     if constexpr (D::NLAND > 0)

@@ -400,7 +400,8 @@ class KinodynamicsOCP(_StageReferences):
         self._keep = [c(s[k]) for k in ("w_x", "w_u", "w_frame", "w_cent", "w_centder", "qmin", "qmax")]
         mh = ocp.model_handler
         ndx, nu = 2 * mh.nv, ocp.nu
-        shapes = [(ndx, ndx), (nu, nu), (3, 3), (6, 6), (6, 6), (mh.nv - 6,), (mh.nv - 6,)]
+        fs = int(s["force_size"])  # w_frame: 3 x 3 on the translation of a point foot, 6 x 6 on the placement of a flat foot
+        shapes = [(ndx, ndx), (nu, nu), (fs, fs), (6, 6), (6, 6), (mh.nv - 6,), (mh.nv - 6,)]
         for a, sh, k in zip(self._keep, shapes, ("w_x", "w_u", "w_frame", "w_cent", "w_centder", "qmin", "qmax")):
             if a.shape != sh:
                 raise RuntimeError("%s has shape %s, expected %s" % (k, a.shape, sh))
@@ -825,6 +826,15 @@ class BatchedMPC:
     def vs(self):
         v = self._get("smpc_get_vs", (self.B, self.H, self.nc))
         st = getattr(self.ocp_handler, "settings", {})
+        if isinstance(self.ocp_handler, KinodynamicsOCP) and not isinstance(self.ocp_handler, FullDynamicsOCP) and int(st.get("force_size", 3)) == 6:
+            # 6-D feet: the device keeps [control box (absent) | joint box | wrench-cone rows | frame-velocity rows] (smpc_full_model.h); returned in
+            # the order the stage adds them (src/kinodynamics.cpp:91-133): joint box | 6 velocity rows per foot | (force_cone) 17 cone rows per foot
+            nf = self.ocp_handler.model_handler.getFeetNb()
+            na = self.nu - 6 * nf
+            parts = [v[:, :, self.nu : self.nu + na], v[:, :, self.nu + na + 17 * nf :]]
+            if st.get("force_cone", False):
+                parts.append(v[:, :, self.nu + na : self.nu + na + 17 * nf])
+            return np.concatenate(parts, axis=2)
         if isinstance(self.ocp_handler, KinodynamicsOCP) and not isinstance(self.ocp_handler, FullDynamicsOCP):
             nf = self.ocp_handler.model_handler.getFeetNb()
             for which, key, n in ((0, "force_cone", 2 * nf), (1, "land_cstr", nf)):  # optional rows, in the oracle's order
@@ -1023,6 +1033,16 @@ class BatchedMPC:
                 ("A", (ndx, ndx)), ("B", (ndx, nu)), ("Q", (ndx, ndx)), ("S", (ndx, nu)), ("R", (nu, nu)), ("Cd", (ncone, ndx)),
                 ("Dd", (ncone, nu)), ("q", (ndx,)), ("r", (nu,)), ("f", (ndx,)), ("d", (nc,)), ("lx", (ndx,)), ("lu", (nu,)),
                 ("lpd", (ndx,)), ("vpd", (nc,)), ("act", (nc,)),
+            )
+        elif int(self.ocp_handler.settings.get("force_size", 3)) == 6 and isinstance(self.ocp_handler, KinodynamicsOCP):
+            # kinodynamics OCP with 6-D feet on the dense stage kernels (FullDims<..., KIN = 1>): rows [u box (absent) | joint box | 17 wrench-cone
+            # rows per foot (Cd = 0, Dd constant) | 6 frame-velocity rows per foot (Cv: folded into Q / q, kept for the multiplier step)]
+            nf = self.ocp_handler.model_handler.getFeetNb()
+            ncone, nvel = 17 * nf, 6 * nf
+            layout = (
+                ("A", (ndx, ndx)), ("B", (ndx, nu)), ("Q", (ndx, ndx)), ("S", (ndx, nu)), ("R", (nu, nu)), ("Cd", (ncone, ndx)),
+                ("Dd", (ncone, nu)), ("Cv", (nvel, ndx)), ("q", (ndx,)), ("r", (nu,)), ("f", (ndx,)), ("d", (nc,)), ("lx", (ndx,)),
+                ("lu", (nu,)), ("lpd", (ndx,)), ("vpd", (nc,)), ("act", (nc,)),
             )
         for name, shape in layout:
             sz = int(np.prod(shape))

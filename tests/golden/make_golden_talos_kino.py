@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Golden vectors of the kinodynamics OCP with 6-D feet (tests/golden/talos_kino_golden.npz), produced by the CPU oracle in the build
+container (the reference cannot be built or imported here):
+
+    python tests/golden/make_golden_talos_kino.py
+
+(1) the stage model at seeded points (dynamics, costs, 6-row frame velocity, wrench-cone rows, all derivatives), (2) closed loops of the
+batched MPC on the Talos-class robot: H = 20 with the short walking cycle so that the CPU tier can replay it, k = 2, 6 control steps; the
+soles of record and small slippery soles that activate the wrench-cone rows.  Inputs and expected outputs only, no code."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import mpc_setup as S  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+SHORT = dict(horizon=20, cycle=O.walk_cycle(5, 20), mpc_override=dict(T_fly=20, T_contact=5))
+TIGHT = dict(mu=0.1, Lfoot=0.01, Wfoot=0.01)
+
+
+def main():
+    rng = np.random.default_rng(2025)
+    out = {}
+    rb = O.Robot("talos_like")
+    kino = O.Kino(rb, O.talos_kino_settings(rb))
+    masks = [3, 1, 2]
+    xs = S.talos_random_states(rb, len(masks), seed=11, scale=0.5)
+    us = np.stack([np.concatenate([rng.normal(size=3) * 30 + [0, 0, 400], rng.normal(size=3) * 5, rng.normal(size=3) * 30 + [0, 0, 400],
+                                   rng.normal(size=3) * 5, rng.normal(size=rb.nv - 6) * 2]) for _ in masks])
+    u_ref = np.concatenate([[0, 0, rb.mass * 9.81 / 2, 0, 0, 0] * 2, np.zeros(rb.nv - 6)])
+    feet = rb.centroidal(rb.x_ref)["feet"] + rng.normal(size=(2, 3)) * 0.02
+    out.update(stage_x=xs, stage_u=us, stage_mask=np.array(masks), stage_u_ref=u_ref, stage_foot_ref=feet)
+    for i, m in enumerate(masks):
+        e = kino.eval(m, u_ref, rb.x_ref, feet, xs[i], us[i])
+        d = kino.deriv(m, u_ref, rb.x_ref, feet, xs[i], us[i])
+        out["stage%d_xnext" % i], out["stage%d_cost" % i], out["stage%d_c" % i], out["stage%d_xdot" % i] = e["xnext"], e["cost"], e["c"], e["xdot"]
+        for k in ("A", "B", "lx", "lu", "Lxx", "Lxu", "Luu", "Cx", "Cu"):
+            out["stage%d_%s" % (i, k)] = d[k]
+    for tag, over, walk in (("loop", None, (0.1, 0, 0, 0, 0, 0)), ("cone", TIGHT, (0.3, 0.2, 0, 0, 0, 0.3))):
+        s = O.talos_kino_settings(rb)
+        if over:
+            s.update(over)
+        ms = O.talos_mpc_settings(rb, max_iters=2)
+        ms["T"] = SHORT["horizon"]
+        ms.update(SHORT["mpc_override"])
+        om = O.OracleMPC(O.Kino(rb, s), ms, 2)
+        om.generateCycleHorizon(SHORT["cycle"])
+        om.switchToWalk(np.array(walk, float))
+        X = S.talos_random_states(rb, 2, scale=0.7)
+        out[tag + "_X0"] = X
+        out[tag + "_cold_xs"] = om.xs[0]
+        for _ in range(6):
+            om.iterate(X)
+            X = om.xs[:, 1, :].copy()
+        out[tag + "_xs"], out[tag + "_us"], out[tag + "_K0"], out[tag + "_alpha"], out[tag + "_vs"] = om.xs, om.us, om.K0, om.info[:, 2], om.vs
+    np.savez_compressed(os.path.join(HERE, "talos_kino_golden.npz"), **out)
+    print("talos kinodynamics: wrote", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

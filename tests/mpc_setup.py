@@ -240,3 +240,45 @@ def alphas_agree(om, gm, rtol=1e-8):
         if not (0.0 <= slack <= rtol * max(1.0, abs(big[0]))):
             return False
     return True
+
+
+def make_talos_kino_product(batch, max_iters=1, lib=None, horizon=100, settings_override=None, mpc_override=None, device_id=0):
+    """simple_mpc.BatchedMPC over the Talos KINODYNAMICS OCP with 6-D feet (oracle_lib.talos_kino_settings: the weights of the reference's
+    examples/talos_kinodynamics.py, force_cone as in its tests/test_utils.cpp)."""
+    rb = O.Robot("talos_like")
+    s = O.talos_kino_settings(rb)
+    if settings_override:
+        s.update(settings_override)
+    ms = O.talos_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if mpc_override:
+        ms.update(mpc_override)
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("talos_like", lib), "standing", "root_joint")
+    for n in TALOS_FEET:
+        mh.addQuadFoot(n, "root_joint", TALOS_QUAD)
+    ocp = simple_mpc.KinodynamicsOCP(s, mh)
+    ocp.createProblem(mh.getReferenceState(), horizon, 6, -9.81, bool(ms.get("terminal_constraint", False)))
+    conf = {k: ms[k] for k in MPC_KEYS}
+    gm = simple_mpc.BatchedMPC(conf, ocp, batch, device_id=device_id, lib=lib)
+    return gm, rb, s, ms
+
+
+def make_talos_kino_pair(batch, max_iters=1, lib=None, horizon=100, walk=(0.1, 0, 0, 0, 0, 0), cycle=None, **kw):
+    rb = O.Robot("talos_like")
+    s = O.talos_kino_settings(rb)
+    if kw.get("settings_override"):
+        s.update(kw["settings_override"])
+    ms = O.talos_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if kw.get("mpc_override"):
+        ms.update(kw["mpc_override"])
+    if ms.get("terminal_constraint", False):
+        O.lib().orc_set_terminal_constraint(1)
+    om = O.OracleMPC(O.Kino(rb, s), ms, batch)
+    O.lib().orc_set_terminal_constraint(0)
+    gm, _, _, _ = make_talos_kino_product(batch, max_iters, lib, horizon, **kw)
+    cs = O.walk_cycle() if cycle is None else cycle
+    for m in (om, gm):
+        m.generateCycleHorizon(cs)
+        m.switchToWalk(np.array(walk, float))
+    return om, gm, rb
