@@ -283,6 +283,12 @@ int smpc_debug_get_phase_cycles(smpc_handle * h, double * out64);
  * smpc_get_kernel_times: ms[9], calls[9] for recede, deriv, riccati, forward, trial, select, apply, tree, tree_ls (the lane-per-problem tree
  * pass that precedes the derivative resp. the line-search kernel of a kinodynamics handle). */
 int smpc_set_profiling(smpc_handle * h, int enabled);
+/* number of kernel slots this library reports (9 today; grows when kernels are added) */
+int smpc_kernel_time_slots(void);
+/* the first min(n, smpc_kernel_time_slots()) slots into ms[n], calls[n].  Centroidal handles: frontend, step (6-D feet: recede), deriv, riccati,
+ * forward, line search. */
+int smpc_get_kernel_times_n(smpc_handle * h, double * ms, long * calls, int n);
+/* the same without a capacity: writes smpc_kernel_time_slots() entries -- size the arrays with that call, or use the _n form */
 int smpc_get_kernel_times(smpc_handle * h, double * ms, long * calls);
 int smpc_reset_kernel_times(smpc_handle * h);
 

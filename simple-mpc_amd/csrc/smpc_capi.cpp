@@ -15,6 +15,7 @@ typedef Dims<13, 4> DimsGo2; // free-flyer + 12 revolute joints, 4 point feet
 
 typedef CentDims<4> CentGo2;
 typedef CentEngine<DimsGo2, CentGo2> CentEngineGo2;
+typedef CentDims<2, 6> CentTalos; // centroidal OCP of the Talos-class biped: 6-D feet, wrench cones (CentroidalOCP with force_size 6)
 typedef FullDims<13, 4, 3> FullGo2;   // full dynamics: 12 joint torques, 3-D contacts
 typedef FullDims<13, 4, 3, 5> FullGo2Cone; // the same with force_cone: 5 friction-pyramid rows per foot in contact
 typedef FullDims<13, 4, 3, 0, 4> FullGo2Land; // land_cstr: 4 rows per landing foot
@@ -26,7 +27,7 @@ typedef FullDims<23, 2, 6, 0, 0, 1> KinoTalos;  // KINODYNAMICS OCP of the Talos
 struct smpc_handle
 {
   std::unique_ptr<KinoEngine<DimsGo2>> eng;
-  std::unique_ptr<CentEngineGo2> cent; // centroidal handle (smpc_create_centroidal): eng is null
+  std::unique_ptr<CentEngineBase> cent; // centroidal handle (smpc_create_centroidal): eng is null
   std::unique_ptr<FullEngineBase> full; // full-dynamics handle (smpc_create_fulldynamics): eng and cent are null
 };
 
@@ -203,13 +204,14 @@ extern "C"
       return fail(SMPC_ERR_INVALID, "null argument");
     if (device_count() <= 0)
       return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the MPC engine has no CPU path");
-    if (ocp->force_size != 3)
-      return fail(SMPC_ERR_INVALID, "force size in settings does not match reference force size (only 3-D point feet are built)");
-    if (robot->nfeet != CentGo2::NF || robot->njoints != DimsGo2::NJ)
-      return fail(SMPC_ERR_INVALID, "robot shape (njoints, nfeet) does not match this kernel instantiation");
+    if (ocp->force_size != 3 && ocp->force_size != 6)
+      return fail(SMPC_ERR_INVALID, "force size in settings does not match reference force size");
+    const bool quad = ocp->force_size == 6;
+    if (quad ? (robot->nfeet != CentTalos::NF || robot->njoints != FullTalos::NJ) : (robot->nfeet != CentGo2::NF || robot->njoints != DimsGo2::NJ))
+      return fail(SMPC_ERR_INVALID, "robot shape (njoints, nfeet, force_size) does not match a built kernel instantiation");
     if (mpc->T < 2)
       return fail(SMPC_ERR_INVALID, "horizon must have at least 2 stages");
-    const int nu = 3 * robot->nfeet;
+    const int nu = ocp->force_size * robot->nfeet;
     HostCentSettings cs;
     cs.timestep = ocp->timestep;
     cs.w_u.assign(ocp->w_u, ocp->w_u + (size_t)nu * nu);
@@ -221,6 +223,9 @@ extern "C"
     for (int i = 0; i < 3; i++)
       cs.gravity[i] = ocp->gravity[i];
     cs.mu = ocp->mu;
+    cs.Lfoot = ocp->Lfoot;
+    cs.Wfoot = ocp->Wfoot;
+    cs.force_size = ocp->force_size;
     auto sym = [](const std::vector<double> & w, int n) {
       for (int i = 0; i < n; i++)
         for (int j = 0; j < i; j++)
@@ -234,7 +239,10 @@ extern "C"
     const HostMpcSettings ms = host_mpc(mpc);
     return guarded([&] {
       std::unique_ptr<smpc_handle> h(new smpc_handle());
-      h->cent.reset(new CentEngineGo2(robot, cs, ms, batch, gravity_arg, device_id));
+      if (quad)
+        h->cent.reset(new CentEngine<FullTalos, CentTalos>(robot, cs, ms, batch, gravity_arg, device_id));
+      else
+        h->cent.reset(new CentEngineGo2(robot, cs, ms, batch, gravity_arg, device_id));
       *out = h.release();
     });
   }
@@ -333,13 +341,13 @@ extern "C"
     }
     if (h->cent)
     {
-      d[0] = DimsGo2::NQ;
-      d[1] = DimsGo2::NV;
+      d[0] = h->cent->nq_mb;
+      d[1] = h->cent->nv_mb;
       d[2] = 9;
       d[3] = 9;
-      d[4] = CentGo2::NU;
-      d[5] = CentGo2::NC;
-      d[6] = CentGo2::NF;
+      d[4] = h->cent->nu;
+      d[5] = h->cent->nc;
+      d[6] = h->cent->nf;
       d[7] = h->cent->H;
       return SMPC_OK;
     }
@@ -578,7 +586,7 @@ extern "C"
     if (h->full)
       return guarded([&] { h->full->get(0, out); });
     if (h->cent)
-      return guarded([&] { h->cent->get_ring(h->cent->buf.xs, 9, h->cent->H + 1, out); });
+      return guarded([&] { h->cent->get_ring(h->cent->bufs().xs, 9, h->cent->H + 1, out); });
     return guarded([&] { h->eng->get_ring(h->eng->buf.xs, DimsGo2::NX, h->eng->H + 1, out); });
   }
   int smpc_get_us(smpc_handle * h, double * out)
@@ -586,7 +594,7 @@ extern "C"
     if (h->full)
       return guarded([&] { h->full->get(1, out); });
     if (h->cent)
-      return guarded([&] { h->cent->get_ring(h->cent->buf.us, CentGo2::NU, h->cent->H, out); });
+      return guarded([&] { h->cent->get_ring(h->cent->bufs().us, h->cent->nu, h->cent->H, out); });
     return guarded([&] { h->eng->get_ring(h->eng->buf.us, DimsGo2::NU, h->eng->H, out); });
   }
   int smpc_get_vs(smpc_handle * h, double * out)
@@ -594,7 +602,7 @@ extern "C"
     if (h->full)
       return guarded([&] { h->full->get(4, out); });
     if (h->cent)
-      return guarded([&] { h->cent->get_ring(h->cent->buf.vs, CentGo2::NC, h->cent->H, out); });
+      return guarded([&] { h->cent->get_ring(h->cent->bufs().vs, h->cent->nc, h->cent->H, out); });
     return guarded([&] { h->eng->get_ring(h->eng->buf.vs, DimsGo2::NC, h->eng->H, out); });
   }
   int smpc_debug_get_extra_multipliers(smpc_handle * h, int which, double * out)
@@ -615,7 +623,7 @@ extern "C"
       return guarded([&] {
         auto & e = *h->cent;
         std::vector<double> tmp((size_t)e.B * e.H * 9);
-        e.get_ring(e.buf.lams, 9, e.H, tmp.data());
+        e.get_ring(e.bufs().lams, 9, e.H, tmp.data());
         for (int b = 0; b < e.B; b++)
         {
           double * o = out + (size_t)b * (e.H + 1) * 9;
@@ -656,7 +664,7 @@ extern "C"
     if (h->full)
       return guarded([&] { h->full->get(6, out); });
     if (h->cent)
-      return guarded([&] { h->cent->get_linear(h->cent->buf.xdot01, (size_t)h->cent->B * 18, out); });
+      return guarded([&] { h->cent->get_linear(h->cent->bufs().xdot01, (size_t)h->cent->B * 18, out); });
     return guarded([&] { h->eng->get_linear(h->eng->buf.xdot01, (size_t)h->eng->B * 4 * DimsGo2::NV, out); });
   }
   int smpc_get_reference_poses(smpc_handle * h, double * out)
@@ -664,7 +672,7 @@ extern "C"
     if (h->full)
       return guarded([&] { h->full->get(7, out); });
     if (h->cent)
-      return guarded([&] { h->cent->get_linear(h->cent->buf.foot, (size_t)h->cent->B * h->cent->H * CentGo2::NF * 3, out); });
+      return guarded([&] { h->cent->get_linear(h->cent->bufs().foot, (size_t)h->cent->B * h->cent->H * h->cent->nf * 3, out); });
     return guarded([&] { h->eng->get_linear(h->eng->buf.foot_ref, (size_t)h->eng->B * h->eng->H * DimsGo2::NF * 3, out); });
   }
   int smpc_get_foot_timing(smpc_handle * h, int foot, int which, int * out, int cap)
@@ -685,7 +693,7 @@ extern "C"
     if (h->full)
       return guarded([&] { h->full->get(8, out); });
     if (h->cent)
-      return guarded([&] { h->cent->get_linear(h->cent->buf.scal, (size_t)h->cent->B * SC_N, out); });
+      return guarded([&] { h->cent->get_linear(h->cent->bufs().scal, (size_t)h->cent->B * SC_N, out); });
     return guarded([&] { h->eng->get_linear(h->eng->buf.scal, (size_t)h->eng->B * SC_N, out); });
   }
   int smpc_get_status(smpc_handle * h, int * out)
@@ -760,8 +768,8 @@ extern "C"
     if (h && h->cent)
       return guarded([&] {
         auto & e = *h->cent;
-        e.get_linear(e.buf.dxs, (size_t)e.B * (e.H + 1) * 9, dxs);
-        e.get_linear(e.buf.dus, (size_t)e.B * e.H * CentGo2::NU, dus);
+        e.get_linear(e.bufs().dxs, (size_t)e.B * (e.H + 1) * 9, dxs);
+        e.get_linear(e.bufs().dus, (size_t)e.B * e.H * e.nu, dus);
       });
     return guarded([&] {
       auto & e = *h->eng;
@@ -790,8 +798,8 @@ extern "C"
         if (!h->full->phase_cycles(out64))
           throw std::runtime_error("phase timers are off (set SMPC_PHASE_PROFILE=1 before smpc_create_fulldynamics)");
       });
-    if (h && h->cent && h->cent->buf.dbg)
-      return guarded([&] { h->cent->get_linear(h->cent->buf.dbg, 64, out64); });
+    if (h && h->cent && h->cent->bufs().dbg)
+      return guarded([&] { h->cent->get_linear(h->cent->bufs().dbg, 64, out64); });
     if (!h || h->cent || !h->eng->buf.dbg)
       return fail(SMPC_ERR_INVALID, "phase timers are off (set SMPC_PHASE_PROFILE=1 before smpc_create)");
     return guarded([&] { h->eng->get_linear(h->eng->buf.dbg, 64, out64); });
@@ -806,12 +814,16 @@ extern "C"
       h->eng->profiling = en != 0;
     return SMPC_OK;
   }
-  int smpc_get_kernel_times(smpc_handle * h, double * ms, long * calls)
+  int smpc_kernel_time_slots(void) { return KID_N; }
+  int smpc_get_kernel_times_n(smpc_handle * h, double * ms, long * calls, int n)
   {
+    if (!h || !ms || !calls || n < 0)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    const int m = n < KID_N ? n : (int)KID_N;
     if (h->full)
       return guarded([&] {
         h->full->collect_profile();
-        for (int i = 0; i < KID_N; i++)
+        for (int i = 0; i < m; i++)
         {
           ms[i] = h->full->kernel_ms[i];
           calls[i] = h->full->kernel_calls[i];
@@ -819,9 +831,10 @@ extern "C"
       });
     if (h->cent)
       return guarded([&] {
-        // centroidal handle: slot 0 = front-end kernel, slot 1 = the fused control-step kernel
+        // centroidal handle: slot 0 = front-end kernel, slot 1 = the fused control-step kernel (6-D feet: recede, then deriv / riccati / forward /
+        // line search in slots 2 .. 5)
         h->cent->collect_profile();
-        for (int i = 0; i < KID_N; i++)
+        for (int i = 0; i < m; i++)
         {
           ms[i] = i < CKID_N ? h->cent->kernel_ms[i] : 0.0;
           calls[i] = i < CKID_N ? h->cent->kernel_calls[i] : 0;
@@ -829,13 +842,15 @@ extern "C"
       });
     return guarded([&] {
       h->eng->collect_profile();
-      for (int i = 0; i < KID_N; i++)
+      for (int i = 0; i < m; i++)
       {
         ms[i] = h->eng->kernel_ms[i];
         calls[i] = h->eng->kernel_calls[i];
       }
     });
   }
+  // (kept for callers of the first form: it writes smpc_kernel_time_slots() entries -- use smpc_get_kernel_times_n with the capacity of your arrays)
+  int smpc_get_kernel_times(smpc_handle * h, double * ms, long * calls) { return smpc_get_kernel_times_n(h, ms, calls, KID_N); }
   int smpc_reset_kernel_times(smpc_handle * h)
   {
     if (h->full)

@@ -12,7 +12,7 @@
 //   - the default problem has identity contact poses, i.e. contact positions at the origin (src/ocp-handler.cpp:117)
 //   - no terminal constraint (src/centroidal-dynamics.cpp:318-337)
 #pragma once
-#include "smpc_cent_kernels.h"
+#include "smpc_cent6_kernels.h"
 #include "smpc_engine.h"
 
 namespace smpc
@@ -23,42 +23,117 @@ namespace smpc
     std::vector<double> w_u, w_com, w_linear_mom, w_angular_mom, w_linear_acc, w_angular_acc;
     double gravity[3];
     double mu;
+    double Lfoot = 0.1, Wfoot = 0.075; // sole half-length / half-width (wrench cones of 6-D feet)
+    int force_size = 3;
   };
 
   enum CentKernelId
   {
     CKID_FRONTEND = 0,
-    CKID_STEP,
+    CKID_STEP,    // point feet: the fused control-step kernel ; 6-D feet: recede
+    CKID_DERIV,   // 6-D feet (smpc_cent6_kernels.h): stage evaluation + derivatives + knot
+    CKID_RICCATI, //   dense backward sweep
+    CKID_FORWARD, //   forward sweep
+    CKID_LS,      //   line search + step
     CKID_N
   };
 
-  // DK: Dims of the multibody robot (front-end FK), DC: CentDims
-  template <class DK, class DC>
-  class CentEngine
+  template <class DK>
+  struct cent_is_full_dims
   {
-  public:
-    CentBuffers<DC> buf;
-    Buffers<DK> fk; // only .model is used (front-end kernel)
-    int B, H, R, head = 0;
+    static constexpr bool value = false;
+  };
+  template <int NJ_, int NF_, int FS_, int CN_, int LN_, int KIN_>
+  struct cent_is_full_dims<FullDims<NJ_, NF_, FS_, CN_, LN_, KIN_>>
+  {
+    static constexpr bool value = true;
+  };
+  // buffers of the dense path (6-D feet); empty for point feet
+  template <class DC, int FS>
+  struct Cent6Extra
+  {
+  };
+  template <class DC>
+  struct Cent6Extra<DC, 6>
+  {
+    Buffers<typename DC::DD> sb;
+    double * parts0 = nullptr;
+  };
+
+  // what the C ABI needs from a centroidal engine of any robot shape / foot type
+  struct CentEngineBase
+  {
+    int B = 0, H = 0, R = 0, head = 0;
+    int nu = 0, nc = 0, nf = 0, nq_mb = 0, nv_mb = 0;
     int device_id = 0; // every entry point makes this the current device first
-    HostMpcSettings ms;
-    std::vector<CentStage<DC>> horizon, cycle;
-    CentStage<DC> standing;
     GaitTimer timer;
-    bool walking = true;
-    double velocity_base[6] = {0, 0, 0, 0, 0, 0};
-    double x_reference[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double com_ref_member[3] = {0, 0, 0}; // CentroidalOCP::com_ref_ (last setPoseBase)
-    double mass;
-    std::vector<double> x_model_ref;
     stream_t stream;
-    UploadRing stage_ring; // pinned staging of the per-step stage table
-    double *X_dev = nullptr, *cstate_dev = nullptr, *feet_dev = nullptr;
+    double x_reference[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int cold_iters = 0;
     std::vector<double> cold_trace;
     bool profiling = false;
     double kernel_ms[CKID_N] = {0};
     long kernel_calls[CKID_N] = {0};
+    virtual ~CentEngineBase() {}
+    virtual const CentBuffersBase & bufs() const = 0;
+    virtual void collect_profile() = 0;
+    virtual void generate_cycle_horizon(const unsigned char * cs, int n) = 0;
+    virtual void switch_to_walk(const double * v6) = 0;
+    virtual void switch_to_stand() = 0;
+    virtual void set_velocity_base_batched(const double * V) = 0;
+    virtual void iterate_device(const double * Xd) = 0;
+    virtual void iterate_host(const double * X) = 0;
+    virtual void sync() = 0;
+    virtual void set_stage_reference(int t, int what, const double * v, int n) = 0;
+    virtual void get_stage_reference(int t, int what, double * v, int n) = 0;
+    virtual void set_reference_pose(int t, int foot, const double * p3) = 0;
+    virtual void get_reference_pose(int t, int foot, int inst, double * p3) = 0;
+    virtual unsigned contact_mask(int t) const = 0;
+    virtual void update_internal_data(const double * X, double * feet, double * com, double * hg, double * cstate) = 0;
+    virtual void interpolate_device_id(double delay, int knots, double * com, double * vcom, double * fp, double * fv, double * f) = 0;
+    virtual void wait_stream(stream_t other) = 0;
+    virtual void interpolate(double delay, int knots, const double * X_meas, double * x_out, double * xdot_out, double * f_out, double * u_out) = 0;
+    virtual size_t state_io(StateIO & io) = 0;
+    virtual void get_K(double * out, bool all) = 0;
+    void get_ring(const double * src, int n, int count, double * out)
+    {
+      set_device(device_id);
+      stream_sync(stream);
+      std::vector<double> tmp((size_t)B * R * n);
+      d2h(tmp.data(), src, tmp.size() * sizeof(double), stream);
+      stream_sync(stream);
+      for (int b = 0; b < B; b++)
+        for (int t = 0; t < count; t++)
+          std::memcpy(out + ((size_t)b * count + t) * n, tmp.data() + ((size_t)b * R + ring_slot(head, t, R)) * n, n * sizeof(double));
+    }
+    void get_linear(const double * src, size_t n, double * out)
+    {
+      set_device(device_id);
+      stream_sync(stream);
+      d2h(out, src, n * sizeof(double), stream);
+      stream_sync(stream);
+    }
+  };
+
+  // DK: Dims of the multibody robot (front-end FK; a FullDims selects the front end of the dense stage kernels), DC: CentDims
+  template <class DK, class DC>
+  class CentEngine : public CentEngineBase
+  {
+  public:
+    CentBuffers<DC> buf;
+    const CentBuffersBase & bufs() const override { return buf; }
+    Cent6Extra<DC, DC::FS> x6; // 6-D feet: knots, dense gains, terminal node, merit partials
+    Buffers<DK> fk; // only .model is used (front-end kernel)
+    HostMpcSettings ms;
+    std::vector<CentStage<DC>> horizon, cycle;
+    CentStage<DC> standing;
+    bool walking = true;
+    double velocity_base[6] = {0, 0, 0, 0, 0, 0};
+    double com_ref_member[3] = {0, 0, 0}; // CentroidalOCP::com_ref_ (last setPoseBase)
+    double mass;
+    std::vector<double> x_model_ref;
+    UploadRing stage_ring; // pinned staging of the per-step stage table
+    double *X_dev = nullptr, *cstate_dev = nullptr, *feet_dev = nullptr;
     std::vector<std::pair<int, std::pair<event_t, event_t>>> pending_events;
     static constexpr double ARMIJO_C1 = 1e-4, REG_INIT = 1e-9, REG_MIN = 1e-10, REG_MAX = 1e9, REG_INC = 10.0, REG_DEC = 1.0 / 3.0, STALL_REL = 1e-9;
 
@@ -67,6 +142,10 @@ namespace smpc
     {
       if (batch <= 0)
         throw std::runtime_error("batch must be positive");
+      if (cs.force_size != DC::FS)
+        throw std::runtime_error("force size in settings does not match reference force size");
+      if (rm->nfeet != DC::NF || rm->njoints != DK::NJ)
+        throw std::runtime_error("robot shape (njoints, nfeet) does not match this kernel instantiation");
       if ((int)cs.w_u.size() != DC::NU * DC::NU || cs.w_com.size() != 9 || cs.w_linear_mom.size() != 9 || cs.w_angular_mom.size() != 9
           || cs.w_linear_acc.size() != 9 || cs.w_angular_acc.size() != 9)
         throw std::runtime_error("centroidal settings: weight sizes do not match the robot");
@@ -78,6 +157,11 @@ namespace smpc
       B = batch;
       H = ms.T;
       R = H + 1;
+      nu = DC::NU;
+      nc = DC::NC;
+      nf = DC::NF;
+      nq_mb = DK::NQ;
+      nv_mb = DK::NV;
       mass = rm->total_mass;
       // ---- models ----
       std::vector<DevModel<DK>> hk(1);
@@ -93,6 +177,8 @@ namespace smpc
       m.mu = ms.mu_init;
       m.mu_fric = cs.mu;
       m.cone_eps = 1e-4; // src/centroidal-dynamics.cpp:96
+      m.Lfoot = cs.Lfoot;
+      m.Wfoot = cs.Wfoot;
       for (int i = 0; i < 3; i++)
         m.gravity[i] = cs.gravity[i];
       std::copy(cs.w_com.begin(), cs.w_com.end(), m.w_com);
@@ -125,6 +211,25 @@ namespace smpc
       buf.vbase = dalloc((size_t)B * 6);
       buf.vref = dalloc(BR * 6);
       buf.gains = dalloc(BH * DC::G_STRIDE);
+      if constexpr (DC::FS == 6)
+      {
+        typedef typename DC::DD DD;
+        x6.sb.B = B;
+        x6.sb.H = H;
+        x6.sb.R = R;
+        x6.sb.lq = dalloc(BH * DD::LQ_STRIDE);
+        x6.sb.gains = buf.gains; // (the dense gains block: [K | k] rows at G_K with stride GKS, read by the interpolation / gain read-out kernels)
+        x6.sb.QN = dalloc((size_t)B * DD::NDX * DD::NDX);
+        x6.sb.qN = dalloc((size_t)B * DD::NDX);
+        x6.sb.model = (DevModel<DD> *)dev_alloc(sizeof(DevModel<DD>));
+        DevModel<DD> hm;
+        hm.mu = ms.mu_init;
+        h2d(x6.sb.model, &hm, sizeof(hm), stream);
+        stream_sync(stream);
+        x6.parts0 = dalloc((size_t)B * (H + 1) * 4);
+        if (H + 1 > 256)
+          throw std::runtime_error("centroidal OCP with 6-D feet: at most 255 stages");
+      }
       buf.scal = dalloc((size_t)B * SC_N);
       buf.xdot01 = dalloc((size_t)B * 18);
       buf.zeros = dalloc(64);
@@ -147,7 +252,7 @@ namespace smpc
       std::memset(&def, 0, sizeof(def));
       def.mask = (1u << DC::NF) - 1u;
       for (int f = 0; f < DC::NF; f++)
-        def.u_ref[3 * f + 2] = -mass * gravity_arg / (double)DC::NF;
+        def.u_ref[DC::FS * f + 2] = -mass * gravity_arg / (double)DC::NF;
       horizon.assign(H, def);
       standing = def;
       cold_solve(def);
@@ -159,6 +264,12 @@ namespace smpc
         dev_free(p);
       if (ev_handoff_valid)
         event_destroy(ev_handoff);
+      if constexpr (DC::FS == 6)
+      {
+        for (double * p : {x6.sb.lq, x6.sb.QN, x6.sb.qN, x6.parts0})
+          dev_free(p);
+        dev_free(x6.sb.model);
+      }
       dev_free(buf.stages);
       dev_free(buf.model);
       dev_free(fk.model);
@@ -189,7 +300,7 @@ namespace smpc
       }
       kernel_calls[kid]++;
     }
-    void collect_profile()
+    void collect_profile() override
     {
       stream_sync(stream);
       for (auto & pe : pending_events)
@@ -214,7 +325,62 @@ namespace smpc
       fa.com = nullptr;
       fa.hg = nullptr;
       fa.cstate = cstate_dev;
-      timed_launch<FrontendArgs<DK>, frontend_body<DK>, 64>(CKID_FRONTEND, B, fa, aux);
+      if constexpr (cent_is_full_dims<DK>::value)
+        timed_launch<FrontendArgs<DK>, frontend_full_body<DK>, 64>(CKID_FRONTEND, B, fa, aux);
+      else
+        timed_launch<FrontendArgs<DK>, frontend_body<DK>, 64>(CKID_FRONTEND, B, fa, aux);
+    }
+    // one solver run of `a.iters` iterations (with the recede / centre bookkeeping the flags of `a` ask for)
+    void launch_step(const CentStepArgs<DC> & a, bool aux = false)
+    {
+      if constexpr (DC::FS == 6)
+      {
+        Cent6Args<DC> c;
+        c.b = buf;
+        c.sb = x6.sb;
+        c.parts0 = x6.parts0;
+        c.head = a.head;
+        c.shift = a.shift;
+        c.set_centres = a.set_centres;
+        c.reset_preg = a.reset_preg;
+        c.X = a.X;
+        c.nx_mb = a.nx_mb;
+        c.cstate = a.cstate;
+        c.feet = a.feet;
+        for (int f = 0; f < DC::NF; f++)
+          c.land[f] = a.land[f];
+        c.T_fly = a.T_fly;
+        c.T_contact = a.T_contact;
+        c.swing_apex = a.swing_apex;
+        c.timestep = a.timestep;
+        c.armijo_c1 = a.armijo_c1;
+        c.reg_init = a.reg_init;
+        c.reg_min = a.reg_min;
+        c.reg_max = a.reg_max;
+        c.reg_inc = a.reg_inc;
+        c.reg_dec = a.reg_dec;
+        typedef typename DC::DD DD;
+        SolverArgs<DD> sa;
+        sa.b = x6.sb;
+        sa.head = a.head;
+        sa.j0 = 0;
+        sa.nj = 0;
+        sa.armijo_c1 = a.armijo_c1;
+        sa.reg_min = a.reg_min;
+        sa.reg_max = a.reg_max;
+        sa.reg_inc = a.reg_inc;
+        sa.reg_dec = a.reg_dec;
+        timed_launch<Cent6Args<DC>, cent6_recede_body<DC>, 64>(CKID_STEP, B, c, aux);
+        for (int it = 0; it < a.iters; it++)
+        {
+          timed_launch<Cent6Args<DC>, cent6_deriv_body<DC>, 64>(CKID_DERIV, B * (H + 1), c, aux);
+          timed_launch<SolverArgs<DD>, riccati_dense_body<DD>, 64, 2>(CKID_RICCATI, B, sa, aux);
+          timed_launch<Cent6Args<DC>, cent6_forward_body<DC>, 64>(CKID_FORWARD, B, c, aux);
+          timed_launch<Cent6Args<DC>, cent6_ls_body<DC>, 64>(CKID_LS, B, c, aux);
+        }
+      }
+      else
+        timed_launch<CentStepArgs<DC>, cent_step_body<DC>, 64, 2>(CKID_STEP, B, a, aux);
     }
     CentStepArgs<DC> step_args(const double * Xd) const
     {
@@ -281,7 +447,7 @@ namespace smpc
         CentStepArgs<DC> a = step_args(X_dev);
         a.set_centres = centres ? 1 : 0;
         a.reset_preg = it == 0 ? 1 : 0;
-        timed_launch<CentStepArgs<DC>, cent_step_body<DC>, 64, 2>(CKID_STEP, B, a, true);
+        launch_step(a, true);
         d2h(sc.data(), buf.scal, SC_N * sizeof(double), stream);
         stream_sync(stream);
         cold_iters = it + 1;
@@ -294,10 +460,11 @@ namespace smpc
         if (sc[SC_DUAL] <= ms.TOL)
           centres = true;
       }
-      kernel_calls[CKID_FRONTEND] = kernel_calls[CKID_STEP] = 0;
+      for (int i = 0; i < CKID_N; i++)
+        kernel_calls[i] = 0;
     }
 
-    void generate_cycle_horizon(const unsigned char * cs, int n)
+    void generate_cycle_horizon(const unsigned char * cs, int n) override
     {
       if (n <= 0)
         throw std::runtime_error("contact sequence must not be empty");
@@ -314,7 +481,7 @@ namespace smpc
           if (st[f])
           {
             s.mask |= 1u << f;
-            s.u_ref[3 * f + 2] = ms.support_force / (double)active;
+            s.u_ref[DC::FS * f + 2] = ms.support_force / (double)active;
           }
         for (int i = 0; i < 3; i++)
           s.x_tgt[i] = com_ref_member[i];
@@ -331,28 +498,28 @@ namespace smpc
       h2d(buf.vbase, h.data(), h.size() * sizeof(double), stream);
       stream_sync(stream);
     }
-    void switch_to_walk(const double * v6)
+    void switch_to_walk(const double * v6) override
     {
       walking = true;
       for (int i = 0; i < 6; i++)
         velocity_base[i] = v6[i];
       upload_velocity(v6, true);
     }
-    void switch_to_stand()
+    void switch_to_stand() override
     {
       walking = false;
       for (int i = 0; i < 6; i++)
         velocity_base[i] = 0.0;
       upload_velocity(velocity_base, true);
     }
-    void set_velocity_base_batched(const double * V)
+    void set_velocity_base_batched(const double * V) override
     {
       for (int i = 0; i < 6; i++)
         velocity_base[i] = V[i];
       upload_velocity(V, false);
     }
 
-    void iterate_device(const double * Xd)
+    void iterate_device(const double * Xd) override
     {
       if (cycle.empty())
         throw std::runtime_error("generateCycleHorizon must be called before iterate");
@@ -391,7 +558,7 @@ namespace smpc
       a.iters = ms.max_iters;
       for (int f = 0; f < DC::NF; f++)
         a.land[f] = timer.land[f].empty() ? -1 : timer.land[f][0];
-      timed_launch<CentStepArgs<DC>, cent_step_body<DC>, 64, 2>(CKID_STEP, B, a);
+      launch_step(a);
     }
     // ---- per-stage references (OCPHandler setters / getters of the centroidal OCP, reference src/centroidal-dynamics.cpp:
     //      120-304), broadcast over the batch ----
@@ -415,7 +582,7 @@ namespace smpc
     }
     // what: 0 = control target (nu); 1 = reference state as get / setReferenceState define it: [com_ref; v_lin; v_ang]
     // (setReferenceState = setPoseBase + setVelocityBase, which stores the momenta m v; getReferenceState divides by m)
-    void set_stage_reference(int t, int what, const double * v, int n)
+    void set_stage_reference(int t, int what, const double * v, int n) override
     {
       check_stage(t);
       if (what == 0)
@@ -441,7 +608,7 @@ namespace smpc
       else
         throw std::runtime_error("unknown stage reference");
     }
-    void get_stage_reference(int t, int what, double * v, int n)
+    void get_stage_reference(int t, int what, double * v, int n) override
     {
       check_stage(t);
       if (what == 0 && n == DC::NU)
@@ -458,28 +625,28 @@ namespace smpc
       else
         throw std::runtime_error("unknown stage reference or wrong size");
     }
-    void set_reference_pose(int t, int foot, const double * p3)
+    void set_reference_pose(int t, int foot, const double * p3) override
     {
       check_stage(t);
       if (foot < 0 || foot >= DC::NF)
         throw std::runtime_error("unknown end effector");
       fill_strided(buf.foot + ((size_t)t * DC::NF + foot) * 3, (size_t)H * DC::NF * 3, B, p3, 3);
     }
-    void get_reference_pose(int t, int foot, int inst, double * p3)
+    void get_reference_pose(int t, int foot, int inst, double * p3) override
     {
       check_stage(t);
       if (foot < 0 || foot >= DC::NF || inst < 0 || inst >= B)
         throw std::runtime_error("unknown end effector or instance");
       get_linear(buf.foot + (((size_t)inst * H + t) * DC::NF + foot) * 3, 3, p3);
     }
-    unsigned contact_mask(int t) const
+    unsigned contact_mask(int t) const override
     {
       check_stage(t);
       return horizon[t].mask;
     }
 
     // state feedback front-end on measured states X [B][nq + nv] (host): host outputs, any may be null
-    void update_internal_data(const double * X, double * feet, double * com, double * hg, double * cstate)
+    void update_internal_data(const double * X, double * feet, double * com, double * hg, double * cstate) override
     {
       const size_t nf = (size_t)B * DC::NF * 3, nc = (size_t)B * 3, nh = (size_t)B * 6, ns = (size_t)B * 9;
       double * st = staging((nf + nc + nh + ns) * sizeof(double));
@@ -491,7 +658,10 @@ namespace smpc
       fa.com = st + nf;
       fa.hg = st + nf + nc;
       fa.cstate = st + nf + nc + nh;
-      launch<FrontendArgs<DK>, frontend_body<DK>, 64, 1, 1>(B, stream, fa);
+      if constexpr (cent_is_full_dims<DK>::value)
+        launch<FrontendArgs<DK>, frontend_full_body<DK>, 64, 1, 1>(B, stream, fa);
+      else
+        launch<FrontendArgs<DK>, frontend_body<DK>, 64, 1, 1>(B, stream, fa);
       if (feet)
         d2h(feet, st, nf * sizeof(double), stream);
       if (com)
@@ -505,7 +675,7 @@ namespace smpc
     // interpolated targets at `delay` after the last solve (host outputs, any may be null): x [B][9], xdot [B][9],
     // forces [B][NU]; with X_meas (measured multibody states [B][nq + nv]) also the Riccati feedback u [B][NU]
     // targets of a CentroidalID controller written into its device buffers; asynchronous on this engine's stream
-    void interpolate_device_id(double delay, int knots, double * com, double * vcom, double * fp, double * fv, double * f)
+    void interpolate_device_id(double delay, int knots, double * com, double * vcom, double * fp, double * fv, double * f) override
     {
       if (knots < 2 || knots > H + 1)
         throw std::runtime_error("interpolate: knots must be in [2, horizon + 1]");
@@ -530,7 +700,7 @@ namespace smpc
       ia.mass = mass;
       launch<CentInterpArgs<DC>, cent_interp_body<DC>, 64>(B, stream, ia);
     }
-    void wait_stream(stream_t other)
+    void wait_stream(stream_t other) override
     {
       set_device(device_id);
       if (!ev_handoff_valid)
@@ -543,7 +713,7 @@ namespace smpc
     }
     event_t ev_handoff{};
     bool ev_handoff_valid = false;
-    void interpolate(double delay, int knots, const double * X_meas, double * x_out, double * xdot_out, double * f_out, double * u_out)
+    void interpolate(double delay, int knots, const double * X_meas, double * x_out, double * xdot_out, double * f_out, double * u_out) override
     {
       if (knots < 2 || knots > H + 1)
         throw std::runtime_error("interpolate: knots must be in [2, horizon + 1]");
@@ -579,7 +749,7 @@ namespace smpc
       stream_sync(stream);
     }
 
-    size_t state_io(StateIO & io)
+    size_t state_io(StateIO & io) override
     {
       set_device(device_id);
       stream_sync(stream);
@@ -611,14 +781,14 @@ namespace smpc
       stream_sync(stream);
       return io.pos;
     }
-    void iterate_host(const double * X)
+    void iterate_host(const double * X) override
     {
       set_device(device_id);
       h2d(X_dev, X, (size_t)B * DK::NX * sizeof(double), stream);
       iterate_device(X_dev);
       stream_sync(stream);
     }
-    void sync()
+    void sync() override
     {
       set_device(device_id);
       stream_sync(stream);
@@ -638,25 +808,7 @@ namespace smpc
       }
       return stage_out;
     }
-    void get_ring(const double * src, int n, int count, double * out)
-    {
-      set_device(device_id);
-      stream_sync(stream);
-      std::vector<double> tmp((size_t)B * R * n);
-      d2h(tmp.data(), src, tmp.size() * sizeof(double), stream);
-      stream_sync(stream);
-      for (int b = 0; b < B; b++)
-        for (int t = 0; t < count; t++)
-          std::memcpy(out + ((size_t)b * count + t) * n, tmp.data() + ((size_t)b * R + ring_slot(head, t, R)) * n, n * sizeof(double));
-    }
-    void get_linear(const double * src, size_t n, double * out)
-    {
-      set_device(device_id);
-      stream_sync(stream);
-      d2h(out, src, n * sizeof(double), stream);
-      stream_sync(stream);
-    }
-    void get_K(double * out, bool all)
+    void get_K(double * out, bool all) override
     {
       const int nt = all ? H : 1;
       const size_t n = (size_t)B * nt * DC::NU * 9;

@@ -26,10 +26,12 @@
 
 namespace smpc
 {
-  template <int NF_>
+  // FS_: contact force size.  3 (point feet): this file; 6 (flat feet, wrench cones): the specialisation in smpc_cent6_kernels.h
+  template <int NF_, int FS_ = 3>
   struct CentDims
   {
-    static constexpr int NF = NF_;
+    static_assert(FS_ == 3, "6-D feet: CentDims<NF, 6> of smpc_cent6_kernels.h");
+    static constexpr int NF = NF_, FS = 3;
     static constexpr int NX = 9, NDX = 9;
     static constexpr int NU = 3 * NF_;
     static constexpr int NC = 2 * NF_;            // rows 2f, 2f+1: friction-cone block of foot f
@@ -46,6 +48,7 @@ namespace smpc
     static_assert(ZC < LDM && NU <= 16 && NC <= 16 && 3 * NU <= 64, "the stage KKT matrix must fit two 16 x 16 tile rows");
     // per (instance, stage) record written by the backward pass for the forward pass
     static constexpr int G_K = 0;                 // [K | k]  NU x 10
+    static constexpr int GKS = 10;                // row stride of [K | k]
     static constexpr int G_Z = G_K + NU * 10;     // [Z | z]  NC x 10
     static constexpr int G_Pt = G_Z + NC * 10;    // P~_{t+1} 9 x 9
     static constexpr int G_pn = G_Pt + 81;        // p_{t+1}
@@ -72,6 +75,7 @@ namespace smpc
   struct CentDevModel
   {
     double mass, dt, mu, mu_fric, cone_eps, pad_;
+    double Lfoot, Wfoot; // half length / half width of the sole (wrench cones of 6-D feet)
     double gravity[3];
     double w_com[9], w_lm[9], w_am[9], w_la[9], w_aa[9];
     double w_u[D::NU * D::NU];
@@ -84,8 +88,8 @@ namespace smpc
     double u_ref[D::NU];
     double x_tgt[9]; // [com_ref; h_ref; L_ref]
   };
-  template <class D>
-  struct CentBuffers
+  // (the pointers are the same for every foot type: CentBuffersBase is what the C ABI reads through CentEngineBase)
+  struct CentBuffersBase
   {
     int B = 0, H = 0, R = 0;
     double *xs = nullptr, *us = nullptr, *vs = nullptr, *lams = nullptr; // rings [B][R][.]; lams[slot(t)] = lambda_{t+1}
@@ -101,6 +105,10 @@ namespace smpc
     double * xdot01 = nullptr; // [B][2][9]
     double * zeros = nullptr;  // [64] zeros (address target of masked-out prefetch slots)
     double * dbg = nullptr;    // [64] optional in-kernel phase timers (block 0 only; null = off)
+  };
+  template <class D>
+  struct CentBuffers : CentBuffersBase
+  {
     CentStage<D> * stages = nullptr;
     CentDevModel<D> * model = nullptr;
   };
@@ -1360,7 +1368,7 @@ namespace smpc
         ka.f_out[inst * NU + lane] = ui;
       if (ka.u_out)
       {
-        const double * K = b.gains + (inst * H) * D::G_STRIDE + D::G_K + lane * 10;
+        const double * K = b.gains + (inst * H) * D::G_STRIDE + D::G_K + lane * D::GKS;
         double a = ui;
         for (int j = 0; j < 9; j++)
           a -= K[j] * e[j];
@@ -1388,7 +1396,7 @@ namespace smpc
     double * o = ka.out + (size_t)block * NU * 9;
     SMPC_LANES(NT)
     for (int idx = lane; idx < NU * 9; idx += NT)
-      o[idx] = g[(idx / 9) * 10 + idx % 9];
+      o[idx] = g[(idx / 9) * D::GKS + idx % 9];
     SMPC_LANES_END_WAVE
   }
 } // namespace smpc

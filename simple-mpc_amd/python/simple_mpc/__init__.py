@@ -510,7 +510,9 @@ class CentroidalOCP(_StageReferences):
         return 9
 
     def _kernel_names(self):
-        return ["frontend", "step", "-", "-", "-", "-", "-", "-"]
+        if int(self.settings.get("force_size", 3)) == 6:  # (6-D feet: smpc_cent6_kernels.h)
+            return ["frontend", "recede", "deriv", "riccati", "forward", "line_search", "-6", "-7", "-8"]
+        return ["frontend", "step", "-2", "-3", "-4", "-5", "-6", "-7", "-8"]
 
     def _create_handle(self, lib, ms, batch, device_id):
         s = self.settings
@@ -1065,11 +1067,13 @@ class BatchedMPC:
         self._lib.L.smpc_set_profiling(self._h, int(on))
 
     def kernel_times(self):
-        ms = np.zeros(9)
-        calls = np.zeros(9, np.int64)
-        self._lib.check(self._lib.L.smpc_get_kernel_times(self._h, ms, calls))
-        names = self.ocp_handler._kernel_names()
-        return {n: (float(m), int(c)) for n, m, c in zip(names, ms, calls)}
+        n = int(self._lib.L.smpc_kernel_time_slots())  # (the library says how many slots it reports; the call carries the capacity)
+        ms = np.zeros(n)
+        calls = np.zeros(n, np.int64)
+        self._lib.check(self._lib.L.smpc_get_kernel_times_n(self._h, ms, calls, n))
+        names = list(self.ocp_handler._kernel_names())
+        names += ["slot%d" % i for i in range(len(names), n)]
+        return {nm: (float(m), int(c)) for nm, m, c in zip(names, ms, calls) if not nm.startswith("-")}
 
     def reset_kernel_times(self):
         self._lib.check(self._lib.L.smpc_reset_kernel_times(self._h))

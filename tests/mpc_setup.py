@@ -282,3 +282,41 @@ def make_talos_kino_pair(batch, max_iters=1, lib=None, horizon=100, walk=(0.1, 0
         m.generateCycleHorizon(cs)
         m.switchToWalk(np.array(walk, float))
     return om, gm, rb
+
+
+def make_talos_cent_product(batch, max_iters=1, lib=None, horizon=100, settings_override=None, mpc_override=None, device_id=0):
+    """simple_mpc.BatchedMPC over the Talos CENTROIDAL OCP with 6-D feet (oracle_lib.talos_centroidal_settings: examples/talos_centroidal.py)."""
+    rb = O.Robot("talos_like")
+    s = O.talos_centroidal_settings(rb)
+    if settings_override:
+        s.update(settings_override)
+    ms = O.talos_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if mpc_override:
+        ms.update(mpc_override)
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("talos_like", lib), "standing", "root_joint")
+    for n in TALOS_FEET:
+        mh.addQuadFoot(n, "root_joint", TALOS_QUAD)
+    ocp = simple_mpc.CentroidalOCP(s, mh)
+    ocp.createProblem(np.zeros(9), horizon, 6, -9.81, False)
+    conf = {k: ms[k] for k in MPC_KEYS}
+    gm = simple_mpc.BatchedMPC(conf, ocp, batch, device_id=device_id, lib=lib)
+    return gm, rb, s, ms
+
+
+def make_talos_cent_pair(batch, max_iters=1, lib=None, horizon=100, walk=(0.1, 0, 0, 0, 0, 0), cycle=None, **kw):
+    rb = O.Robot("talos_like")
+    s = O.talos_centroidal_settings(rb)
+    if kw.get("settings_override"):
+        s.update(kw["settings_override"])
+    ms = O.talos_mpc_settings(rb, max_iters=max_iters)
+    ms["T"] = horizon
+    if kw.get("mpc_override"):
+        ms.update(kw["mpc_override"])
+    om = O.OracleCentMPC(O.Cent(rb, s), ms, batch)
+    gm, _, _, _ = make_talos_cent_product(batch, max_iters, lib, horizon, **kw)
+    cs = O.walk_cycle() if cycle is None else cycle
+    for m in (om, gm):
+        m.generateCycleHorizon(cs)
+        m.switchToWalk(np.array(walk, float))
+    return om, gm, rb
