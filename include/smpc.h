@@ -390,6 +390,12 @@ typedef struct smpc_id_settings
    * acceleration limit; setImposeBounds(true, true, true, false) of kinodynamics-id.cpp:80-88).  0 (default): position / velocity limits
    * as acceleration bounds over one control period. */
   int tsid_joint_bounds;
+  /* Robots with flat (QUAD) feet -- RobotModelHandler::addQuadFoot, tsid::contacts::Contact6d (kinodynamics-id.cpp:41-49, 163-167, 204-208):
+   * force_size 6 and the four corners of every sole in its foot frame, quad_contact_points [nfeet][4][3] (getQuadFootContactPoints).  The QP then
+   * holds the forces at the corners (12 per foot, foot frame), the 6-D LOCAL contact motion, a friction pyramid per corner and the bound on the
+   * total normal force; force targets and reported contact forces are 6-D wrenches per foot (foot frame).  0 or 3: point feet. */
+  int force_size;
+  const double * quad_contact_points;
 } smpc_id_settings;
 typedef struct smpc_id_handle smpc_id_handle;
 /* KinodynamicsID(model_handler, control_dt, settings): the default target is the reference state, every foot in contact with an equal
@@ -397,7 +403,8 @@ typedef struct smpc_id_handle smpc_id_handle;
 int smpc_id_create(const smpc_robot_model * robot, const smpc_id_settings * settings, int batch, int device_id, smpc_id_handle ** out);
 void smpc_id_destroy(smpc_id_handle * h);
 /* setTarget(q, v, a, contact_state, f) (kinodynamics-id.cpp:120-183) of one instance, or of every instance (instance < 0):
- * q (nq), v (nv), a (nv), contact flag per foot, f (3 per foot, world frame) */
+ * q (nq), v (nv), a (nv), contact flag per foot, f (3 per foot, world frame; flat feet: the 6-D wrench per foot, foot frame -- wherever
+ * this section says "3 per foot" / "3 nfeet" for a force, a flat-foot handle takes 6) */
 int smpc_id_set_target(smpc_id_handle * h, int instance, const double * q, const double * v, const double * a, const uint8_t * contact, const double * f);
 /* one target per robot of the batch: Q [B][nq], V [B][nv], A [B][nv], contact [B][nfeet], F [B][3 nfeet] */
 int smpc_id_set_targets(smpc_id_handle * h, const double * Q, const double * V, const double * A, const uint8_t * contact, const double * F);

@@ -1097,6 +1097,8 @@ extern "C"
     int centroidal;
     double kp_com, kp_feet_tracking, w_com, w_feet_tracking;
     int base_reference_as_coded, tsid_joint_bounds;
+    int force_size;              // 3: point feet ; 6: flat feet (tsid Contact6d)
+    const double * quad_points;  // force_size 6: [nf][4][3] corners of the soles in their foot frames
   };
   static IDSettings id_settings_from(const smpc_robot_model * m, const orc_id_settings * c)
   {
@@ -1130,6 +1132,9 @@ extern "C"
     s.w_feet_tracking = c->w_feet_tracking;
     s.base_reference_as_coded = c->base_reference_as_coded != 0;
     s.tsid_joint_bounds = c->tsid_joint_bounds != 0;
+    s.force_size = c->force_size == 6 ? 6 : 3;
+    if (s.force_size == 6)
+      s.quad_points.assign(c->quad_points, c->quad_points + (size_t)m->nfeet * 12);
     return s;
   }
   void * orc_id_create(const smpc_robot_model * m, const orc_id_settings * c, int B) { return new BatchKinoID(m, id_settings_from(m, c), B); }
@@ -1143,7 +1148,7 @@ extern "C"
     t.v.assign(v, v + k->M->nv);
     t.a.assign(a, a + k->M->nv);
     t.mask = mask;
-    t.f.assign(f, f + 3 * k->M->nfeet);
+    t.f.assign(f, f + k->s.nfw() * k->M->nfeet);
     for (int i = 0; i < k->B; i++)
       if (b < 0 || b == i)
       {
@@ -1165,7 +1170,7 @@ extern "C"
     t.v.assign(k->M->nv, 0.0);
     t.a.assign(k->M->nv, 0.0);
     t.mask = mask;
-    t.f.assign(f, f + 3 * nf);
+    t.f.assign(f, f + k->s.nfw() * nf);
     t.com.assign(com, com + 3);
     t.vcom.assign(vcom, vcom + 3);
     t.feet_p.assign(feet_p, feet_p + 3 * nf);
@@ -1182,6 +1187,17 @@ extern "C"
       resid[b] = k->resid[b];
   }
   // pieces, for the tests of the kernels: M (nv x nv), nle (nv), J (3 nf x nv), Jdv (3 nf), vfoot (3 nf)
+  // (orc_id_quantities6: the LOCAL 6-D rows of flat feet, J (6 nf x nv), Jdv, vfoot (6 nf))
+  void orc_id_quantities6(const smpc_robot_model * m, const double * x, double * Mq, double * nle, double * J, double * Jdv, double * vfoot)
+  {
+    IDQuantities Q;
+    id_quantities(m, x, Q, 6);
+    mat_to(Q.M, Mq);
+    vec_to(Q.nle, nle);
+    mat_to(Q.J, J);
+    vec_to(Q.Jdv, Jdv);
+    vec_to(Q.vfoot, vfoot);
+  }
   void orc_id_quantities(const smpc_robot_model * m, const double * x, double * Mq, double * nle, double * J, double * Jdv, double * vfoot)
   {
     IDQuantities Q;
@@ -1197,7 +1213,7 @@ extern "C"
   {
     BatchKinoID * k = (BatchKinoID *)h;
     IDQuantities Q;
-    id_quantities(k->M, x, Q);
+    id_quantities(k->M, x, Q, k->s.force_size);
     QP qp;
     id_assemble(k->M, k->s, k->tgt[b], x, Q, qp);
     mat_to(qp.H, H);

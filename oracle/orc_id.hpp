@@ -23,6 +23,18 @@
 //                    min((vmax - v)/dt, 2 (qmax - q - v dt)/dt^2)]
 //   actuation        |M_a a + h_a - J_a^T f| <= tau_max  ;  output tau = M_a a + h_a - J_a^T f
 //
+// Robots with 6-D (flat) feet -- tsid::contacts::Contact6d, kinodynamics-id.cpp:41-49, 163-167, 204-208 (IDSettings::force_size == 6)
+// [UPSTREAM-RECALL tsid 1.9 src/contacts/contact-6d.cpp]:
+//   variables        12 per foot: the forces at the four corners of the sole (getQuadFootContactPoints), in the foot's LOCAL frame; the contact
+//                    wrench is T f, T = [I I I I ; [p_1]x .. [p_4]x] (force generator matrix, 6 x 12); dynamics M a + h = S^T tau + J^T T f with the
+//                    LOCAL 6-D frame Jacobian J
+//   contact motion   the whole 6-D LOCAL frame acceleration: J a + dJ v = -Kd v_frame (reference pose = measured pose at every solve)
+//   contact force    w_contact_force |diag(1, 1, 1e-3, 2, 2, 2) (T f - wrench_target)|^2  (Contact6d's force regularisation task weights)
+//   friction         per corner the pyramid |f_x|, |f_y| <= mu f_z (16 rows) + f_min <= sum of the normal forces <= f_max (1 row): 17 rows per foot
+//   foot tracking    (CentroidalID, feet in the air; position_mask all ones for QUAD feet, centroidal-id.cpp:38-41) the 6-D LOCAL task
+//                    J a + dJ v = Kp log6(M_foot^-1 M_ref) + Kd (v_ref - v_frame), M_ref = (identity rotation, target position) -- the pose
+//                    MPC::getReferencePose hands over (src/mpc.cpp:304-308), angular velocity target zero
+//
 // Solver: ADMM on  min 1/2 y^T H y + g^T y  s.t.  l <= C y <= u  (the operator splitting of OSQP: one factorisation of
 // H + sigma I + C^T diag(rho) C per solve, then matrix-vector iterations; equality rows carry 1e3 rho, free rows 1e-6 rho), at most
 // admm_iters iterations (residuals checked every 20, stop below 1e-7), warm-started from the previous control tick.  ProxQP is a proximal augmented-Lagrangian method; both converge to the
@@ -57,7 +69,32 @@ namespace orc
     // limit it cannot reach within a step, and the viability bounds (setImposeBounds(true, true, true, false)) are evaluated with the
     // default acceleration limit 1e10; off: position / velocity limits over one control period
     bool tsid_joint_bounds = false;
+    // 6-D feet: force_size 6 and the four corners of every sole in its foot frame, [nf][4][3] (RobotModelHandler::addQuadFoot)
+    int force_size = 3;
+    Vec quad_points;
+    int nmot() const { return force_size == 6 ? 6 : 3; }   // contact-motion rows per foot
+    int nfv() const { return force_size == 6 ? 12 : 3; }   // force variables per foot
+    int nfric() const { return force_size == 6 ? 17 : 4; } // friction / force-bound rows per foot
+    int nfw() const { return force_size == 6 ? 6 : 3; }    // size of a force target / of the reported contact force (wrench)
   };
+  // force generator matrix of foot f: wrench (local frame, at the frame origin) = T [f_1; f_2; f_3; f_4]
+  inline Mat id_force_generator(const IDSettings & s, int f)
+  {
+    Mat T(6, 12);
+    for (int c = 0; c < 4; c++)
+    {
+      const V3 p = v3(s.quad_points[(f * 4 + c) * 3], s.quad_points[(f * 4 + c) * 3 + 1], s.quad_points[(f * 4 + c) * 3 + 2]);
+      const M3 X = skew(p);
+      for (int i = 0; i < 3; i++)
+      {
+        T(i, 3 * c + i) = 1.0;
+        for (int j = 0; j < 3; j++)
+          T(3 + i, 3 * c + j) = X(i, j);
+      }
+    }
+    return T;
+  }
+  constexpr double ID_WRENCH_W[6] = {1.0, 1.0, 1e-3, 2.0, 2.0, 2.0}; // Contact6d::m_weightForceRegTask [UPSTREAM-RECALL]
   // acceleration bounds [lb, ub] of one joint as TaskJointPosVelAccBounds::computeAccLimits forms them ([UPSTREAM-RECALL])
   inline void tsid_acc_limits(double q, double dq, double qmin, double qmax, double dqmax, double control_dt, double & lb, double & ub)
   {
@@ -116,16 +153,17 @@ namespace orc
   {
     Vec q, v, a; // nq, nv, nv
     unsigned mask = 0;
-    Vec f;       // 3 nf
+    Vec f;       // 3 nf (6 nf for 6-D feet: wrench targets in the foot frames)
     Vec com, vcom, feet_p, feet_v; // CentroidalID: 3, 3, 3 nf, 3 nf (world frame)
   };
   struct IDQuantities
   {
     Mat M;          // nv x nv
     Vec nle;        // nv
-    Mat J;          // 3 nf x nv: world-frame linear Jacobians of the foot points
-    Vec Jdv, vfoot; // 3 nf: classical acceleration of the points at zero joint accelerations ; their velocity
+    Mat J;          // 3 nf x nv: world-frame linear Jacobians of the foot points (6-D feet: 6 nf x nv, LOCAL 6-D frame Jacobians)
+    Vec Jdv, vfoot; // 3 nf: classical acceleration of the points at zero joint accelerations ; their velocity (6-D feet: 6 nf, LOCAL frame)
     Vec com, footp; // 3 ; 3 nf (world frame)
+    std::vector<M3> footR; // foot rotations (6-D feet)
   };
   struct QP
   {
@@ -137,7 +175,7 @@ namespace orc
   constexpr int ADMM_CHECK = 20;      // residual check period of the ADMM loop
   constexpr double ADMM_ADAPT_FLOOR = 1e-7; // rho is adapted only while the residuals are above
 
-  inline void id_quantities(const smpc_robot_model * m, const double * x, IDQuantities & o)
+  inline void id_quantities(const smpc_robot_model * m, const double * x, IDQuantities & o, int force_size = 3)
   {
     ConstraintDynamics cd(m);
     cd.fs = 6; // LOCAL_WORLD_ALIGNED rows: the first three of each foot are the world-frame point Jacobian and its drift
@@ -159,6 +197,33 @@ namespace orc
         }
         o.Jdv[3 * f + i] = cd.gamma[6 * f + i];
       }
+    if (force_size == 6)
+    { // LOCAL 6-D rows: the world-aligned rows at the frame origin turned into the foot frame, [R^T lin ; R^T ang]
+      o.J = Mat(6 * nf, nv);
+      o.Jdv.assign(6 * nf, 0.0);
+      o.vfoot.assign(6 * nf, 0.0);
+      o.footR.resize(nf);
+      for (int f = 0; f < nf; f++)
+      {
+        const M3 R = cd.R.oMi[m->foot_joint[f]].R;
+        o.footR[f] = R;
+        for (int blk = 0; blk < 2; blk++)
+          for (int i = 0; i < 3; i++)
+          {
+            const int r = 6 * f + 3 * blk + i;
+            for (int k = 0; k < nv; k++)
+            {
+              double acc = 0.0;
+              for (int j = 0; j < 3; j++)
+                acc += R(j, i) * cd.Jc(6 * f + 3 * blk + j, k);
+              o.J(r, k) = acc;
+              o.vfoot[r] += acc * x[m->nq + k];
+            }
+            for (int j = 0; j < 3; j++)
+              o.Jdv[r] += R(j, i) * cd.gamma[6 * f + 3 * blk + j];
+          }
+      }
+    }
     o.com = {cd.R.com[0], cd.R.com[1], cd.R.com[2]};
     o.footp.assign(3 * nf, 0.0);
     for (int f = 0; f < nf; f++)
@@ -169,8 +234,31 @@ namespace orc
   // row layout of C: [0, n) box on y ; 6 dynamics rows ; 3 nf contact-motion rows ; 4 nf friction rows ; nv - 6 actuation rows
   inline void id_assemble(const smpc_robot_model * m, const IDSettings & s, const IDTarget & t, const double * x, const IDQuantities & Q, QP & qp)
   {
-    const int nq = m->nq, nv = m->nv, nf = m->nfeet, na = nv - 6, n = nv + 3 * nf;
-    const int mrows = n + 6 + 3 * nf + 4 * nf + na;
+    const int nq = m->nq, nv = m->nv, nf = m->nfeet, na = nv - 6;
+    const int NM = s.nmot(), NFV = s.nfv(), NFR = s.nfric();
+    const bool quad = s.force_size == 6;
+    const int n = nv + NFV * nf;
+    const int mrows = n + 6 + NM * nf + NFR * nf + na;
+    // J^T G of foot f as an (nv x NFV) block: the generalised force of its force variables (G = I for a point foot, T for a flat one)
+    std::vector<Mat> JG(nf);
+    std::vector<Mat> Tg(nf);
+    for (int f = 0; f < nf; f++)
+    {
+      JG[f] = Mat(nv, NFV);
+      if (quad)
+        Tg[f] = id_force_generator(s, f);
+      for (int k = 0; k < nv; k++)
+        for (int c = 0; c < NFV; c++)
+        {
+          double acc = 0.0;
+          if (quad)
+            for (int r = 0; r < 6; r++)
+              acc += Q.J(6 * f + r, k) * Tg[f](r, c);
+          else
+            acc = Q.J(3 * f + c, k);
+          JG[f](k, c) = acc;
+        }
+    }
     qp.n = n;
     qp.m = mrows;
     qp.H = Mat(n, n);
@@ -205,8 +293,8 @@ namespace orc
         qp.g[i] -= s.w_base * b;
       }
     }
-    auto add_rows3 = [&](double w, const double * A, const double * b) { // w |A y_a - b|^2, A: 3 x nv row-major
-      for (int i = 0; i < 3; i++)
+    auto add_rows3 = [&](double w, const double * A, const double * b, int rows = 3) { // w |A y_a - b|^2, A: rows x nv row-major
+      for (int i = 0; i < rows; i++)
         for (int a = 0; a < nv; a++)
         {
           qp.g[a] -= w * A[i * nv + a] * b[i];
@@ -239,6 +327,18 @@ namespace orc
       for (int f = 0; f < nf; f++)
         if (!((t.mask >> f) & 1u))
         { // position tracking of the feet out of contact (centroidal-id.cpp:101-129; point feet: linear part)
+          if (quad)
+          { // flat feet: the 6-D LOCAL task towards (identity rotation, target position), zero angular velocity target
+            const SE3 Mf{Q.footR[f], v3(Q.footp[3 * f], Q.footp[3 * f + 1], Q.footp[3 * f + 2])};
+            const SE3 Mr{m3_id(), v3(t.feet_p[3 * f], t.feet_p[3 * f + 1], t.feet_p[3 * f + 2])};
+            double e[6], b6[6];
+            log6(inv(Mf) * Mr, e);
+            const V3 vr = tr(Q.footR[f]) * v3(t.feet_v[3 * f], t.feet_v[3 * f + 1], t.feet_v[3 * f + 2]);
+            for (int i = 0; i < 6; i++)
+              b6[i] = s.kp_feet_tracking * e[i] + kd(s.kp_feet_tracking) * ((i < 3 ? vr[i] : 0.0) - Q.vfoot[6 * f + i]) - Q.Jdv[6 * f + i];
+            add_rows3(s.w_feet_tracking, &Q.J.a[(size_t)(6 * f) * nv], b6, 6);
+            continue;
+          }
           double b3[3];
           for (int i = 0; i < 3; i++)
             b3[i] = s.kp_feet_tracking * (t.feet_p[3 * f + i] - Q.footp[3 * f + i]) + kd(s.kp_feet_tracking) * (t.feet_v[3 * f + i] - Q.vfoot[3 * f + i]) - Q.Jdv[3 * f + i];
@@ -250,9 +350,9 @@ namespace orc
       if (!((t.mask >> f) & 1u))
         continue;
       if (!s.contact_motion_equality && s.w_contact_motion > 0)
-        for (int i = 0; i < 3; i++)
+        for (int i = 0; i < NM; i++)
         {
-          const int r = 3 * f + i;
+          const int r = NM * f + i;
           const double b = -Q.Jdv[r] - kdc * Q.vfoot[r];
           for (int a = 0; a < nv; a++)
           {
@@ -261,7 +361,24 @@ namespace orc
               qp.H(a, c) += s.w_contact_motion * Q.J(r, a) * Q.J(r, c);
           }
         }
-      if (s.w_contact_force > 0)
+      if (s.w_contact_force > 0 && quad)
+      { // |diag(w6) (T f - wrench_target)|^2
+        for (int a = 0; a < 12; a++)
+        {
+          for (int c = 0; c < 12; c++)
+          {
+            double acc = 0.0;
+            for (int r = 0; r < 6; r++)
+              acc += Tg[f](r, a) * ID_WRENCH_W[r] * ID_WRENCH_W[r] * Tg[f](r, c);
+            qp.H(nv + 12 * f + a, nv + 12 * f + c) += s.w_contact_force * acc;
+          }
+          double gb = 0.0;
+          for (int r = 0; r < 6; r++)
+            gb += Tg[f](r, a) * ID_WRENCH_W[r] * ID_WRENCH_W[r] * t.f[6 * f + r];
+          qp.g[nv + 12 * f + a] -= s.w_contact_force * gb;
+        }
+      }
+      else if (s.w_contact_force > 0)
         for (int i = 0; i < 3; i++)
         {
           qp.H(nv + 3 * f + i, nv + 3 * f + i) += s.w_contact_force;
@@ -287,10 +404,10 @@ namespace orc
     for (int f = 0; f < nf; f++)
     {
       const bool on = (t.mask >> f) & 1u;
-      for (int i = 0; i < 3; i++)
+      for (int i = 0; i < NFV; i++)
         if (!on)
-          qp.l[nv + 3 * f + i] = qp.u[nv + 3 * f + i] = 0.0;
-      if (on)
+          qp.l[nv + NFV * f + i] = qp.u[nv + NFV * f + i] = 0.0;
+      if (on && !quad)
       {
         qp.l[nv + 3 * f + 2] = fmin;
         qp.u[nv + 3 * f + 2] = fmax;
@@ -301,36 +418,55 @@ namespace orc
     {
       for (int k = 0; k < nv; k++)
         qp.C(r0 + i, k) = Q.M(i, k);
-      for (int r = 0; r < 3 * nf; r++)
-        qp.C(r0 + i, nv + r) = -Q.J(r, i);
+      for (int f = 0; f < nf; f++)
+        for (int c = 0; c < NFV; c++)
+          qp.C(r0 + i, nv + NFV * f + c) = -JG[f](i, c);
       qp.l[r0 + i] = qp.u[r0 + i] = -Q.nle[i];
     }
     r0 += 6;
     for (int f = 0; f < nf; f++)
       if (((t.mask >> f) & 1u) && s.contact_motion_equality)
-        for (int i = 0; i < 3; i++)
+        for (int i = 0; i < NM; i++)
         {
-          const int r = 3 * f + i;
+          const int r = NM * f + i;
           for (int k = 0; k < nv; k++)
             qp.C(r0 + r, k) = Q.J(r, k);
           qp.l[r0 + r] = qp.u[r0 + r] = -Q.Jdv[r] - kdc * Q.vfoot[r];
         }
-    r0 += 3 * nf;
+    r0 += NM * nf;
     for (int f = 0; f < nf; f++)
       if ((t.mask >> f) & 1u)
+      {
+        if (quad)
+        { // per corner c: rows 4 c + k: +-f_x - mu f_z, +-f_y - mu f_z <= 0 ; row 16: f_min <= sum of the normal forces <= f_max
+          for (int c = 0; c < 4; c++)
+            for (int k = 0; k < 4; k++)
+            {
+              qp.C(r0 + 17 * f + 4 * c + k, nv + 12 * f + 3 * c + k / 2) = (k % 2 == 0) ? 1.0 : -1.0;
+              qp.C(r0 + 17 * f + 4 * c + k, nv + 12 * f + 3 * c + 2) = -s.friction_coefficient;
+              qp.u[r0 + 17 * f + 4 * c + k] = 0.0;
+            }
+          for (int c = 0; c < 4; c++)
+            qp.C(r0 + 17 * f + 16, nv + 12 * f + 3 * c + 2) = 1.0;
+          qp.l[r0 + 17 * f + 16] = fmin;
+          qp.u[r0 + 17 * f + 16] = fmax;
+          continue;
+        }
         for (int k = 0; k < 4; k++)
         {
           qp.C(r0 + 4 * f + k, nv + 3 * f + k / 2) = (k % 2 == 0) ? 1.0 : -1.0;
           qp.C(r0 + 4 * f + k, nv + 3 * f + 2) = -s.friction_coefficient;
           qp.u[r0 + 4 * f + k] = 0.0;
         }
-    r0 += 4 * nf;
+      }
+    r0 += NFR * nf;
     for (int j = 0; j < na; j++)
     {
       for (int k = 0; k < nv; k++)
         qp.C(r0 + j, k) = Q.M(6 + j, k);
-      for (int r = 0; r < 3 * nf; r++)
-        qp.C(r0 + j, nv + r) = -Q.J(r, 6 + j);
+      for (int f = 0; f < nf; f++)
+        for (int c = 0; c < NFV; c++)
+          qp.C(r0 + j, nv + NFV * f + c) = -JG[f](6 + j, c);
       qp.l[r0 + j] = -s.tau_max[j] - Q.nle[6 + j];
       qp.u[r0 + j] = s.tau_max[j] - Q.nle[6 + j];
     }
@@ -463,9 +599,9 @@ namespace orc
       t.v.assign(m->nv, 0.0);
       t.a.assign(m->nv, 0.0);
       t.mask = (1u << m->nfeet) - 1u;
-      t.f.assign(3 * m->nfeet, 0.0);
+      t.f.assign(s.nfw() * m->nfeet, 0.0);
       for (int f = 0; f < m->nfeet; f++)
-        t.f[3 * f + 2] = m->total_mass * 9.81 / m->nfeet;
+        t.f[s.nfw() * f + 2] = m->total_mass * 9.81 / m->nfeet;
       {
         // CentroidalID defaults: the CoM of the reference state, the feet at their reference placements (centroidal-id.cpp:60-84)
         Rigid R(m);
@@ -481,32 +617,49 @@ namespace orc
       for (auto & e : tgt)
         e = t;
     }
-    // X [B][nq + nv] -> tau [B][nv - 6], a [B][nv], f [B][3 nf]
+    // X [B][nq + nv] -> tau [B][nv - 6], a [B][nv], f [B][3 nf] (6-D feet: the contact wrenches T f, [B][6 nf], foot frames)
     void solve(const double * X, double * tau, double * a, double * f)
     {
       const int nq = M->nq, nv = M->nv, nf = M->nfeet, na = nv - 6;
+      const int NFW = s.nfw();
 #pragma omp parallel for schedule(dynamic)
       for (int b = 0; b < B; b++)
       {
         const double * xb = X + (size_t)b * (nq + nv);
         IDQuantities Q;
-        id_quantities(M, xb, Q);
+        id_quantities(M, xb, Q, s.force_size);
         QP qp;
         id_assemble(M, s, tgt[b], xb, Q, qp);
         resid[b] = qp_admm(qp, rho[b], s.sigma, s.alpha, s.admm_iters, s.admm_tol, x[b], z[b], lam[b]);
         for (int k = 0; k < nv; k++)
           a[(size_t)b * nv + k] = x[b][k];
-        for (int k = 0; k < 3 * nf; k++)
-          f[(size_t)b * 3 * nf + k] = x[b][nv + k];
+        // contact forces: the force variables of a point foot, the wrench T f of a flat one
+        Vec w(NFW * nf, 0.0);
+        for (int ff = 0; ff < nf; ff++)
+        {
+          if (s.force_size == 6)
+          {
+            const Mat T = id_force_generator(s, ff);
+            for (int r = 0; r < 6; r++)
+              for (int c = 0; c < 12; c++)
+                w[6 * ff + r] += T(r, c) * x[b][nv + 12 * ff + c];
+          }
+          else
+            for (int i = 0; i < 3; i++)
+              w[3 * ff + i] = x[b][nv + 3 * ff + i];
+        }
+        for (int k = 0; k < NFW * nf; k++)
+          f[(size_t)b * NFW * nf + k] = w[k];
         for (int j = 0; j < na; j++)
         {
           double acc = Q.nle[6 + j];
           for (int k = 0; k < nv; k++)
             acc += Q.M(6 + j, k) * x[b][k];
-          for (int r = 0; r < 3 * nf; r++)
-            acc -= Q.J(r, 6 + j) * x[b][nv + r];
+          for (int r = 0; r < NFW * nf; r++) // tau = M_a a + h_a - J_a^T (contact force / wrench)
+            acc -= Q.J(r, 6 + j) * w[r];
           tau[(size_t)b * na + j] = acc;
         }
+
       }
     }
   };

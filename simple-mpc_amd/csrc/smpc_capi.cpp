@@ -1079,11 +1079,22 @@ extern "C"
     hs.v_max.assign(c->velocity_limit, c->velocity_limit + na);
     hs.q_min.assign(c->q_min, c->q_min + na);
     hs.q_max.assign(c->q_max, c->q_max + na);
+    const bool quad = c->force_size == 6;
+    if (c->force_size != 0 && c->force_size != 3 && c->force_size != 6)
+      return fail(SMPC_ERR_INVALID, "force size must be 3 (point feet) or 6 (flat feet)");
+    if (quad)
+    {
+      if (!c->quad_contact_points)
+        return fail(SMPC_ERR_INVALID, "flat feet need the four corners of every sole (quad_contact_points, [nfeet][4][3])");
+      hs.quad_points.assign(c->quad_contact_points, c->quad_contact_points + (size_t)robot->nfeet * 12);
+    }
     return guarded([&] {
-      if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF)
+      if (!quad && robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF)
         *out = reinterpret_cast<smpc_id_handle *>(static_cast<IdEngineBase *>(new IdEngine<FullGo2>(robot, hs, batch, device_id)));
+      else if (quad && robot->njoints == FullTalos::NJ && robot->nfeet == FullTalos::NF)
+        *out = reinterpret_cast<smpc_id_handle *>(static_cast<IdEngineBase *>(new IdEngine<FullTalos>(robot, hs, batch, device_id)));
       else
-        throw std::runtime_error("the inverse-dynamics engine is instantiated for 13 joints / 4 point feet");
+        throw std::runtime_error("the inverse-dynamics engine is instantiated for 13 joints / 4 point feet and for 23 joints / 2 flat feet");
     });
   }
   void smpc_id_destroy(smpc_id_handle * h) { delete reinterpret_cast<IdEngineBase *>(h); }
@@ -1171,7 +1182,7 @@ extern "C"
       e->centroidal_target_buffers(&com, &vcom, &fp, &fv);
       if (!com)
         return fail(SMPC_ERR_INVALID, "a centroidal MPC handle feeds a CentroidalID controller");
-      if (e->B != mpc->cent->B || e->nf != DimsGo2::NF)
+      if (e->B != mpc->cent->B || e->nf != mpc->cent->nf || e->nv != mpc->cent->nv_mb || e->nfw * e->nf != mpc->cent->nu)
         return fail(SMPC_ERR_INVALID, "the controller and the MPC must hold the same batch of the same robot");
       return guarded([&] {
         e->target_buffers(&x, &a, &f);

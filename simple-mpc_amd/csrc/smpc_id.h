@@ -35,12 +35,17 @@ namespace smpc
   template <class D>
   struct IdDims
   {
-    static constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NA = D::NV - 6;
-    static constexpr int N = NV + 3 * NF;                       // variables [a ; f]
-    static constexpr int M = N + 6 + 3 * NF + 4 * NF + NA;      // rows: box | dynamics | contact motion | friction | actuation
+    static constexpr int NV = D::NV, NQ = D::NQ, NX = D::NX, NF = D::NF, NA = D::NV - 6, FS = D::FS;
+    // point feet (tsid ContactPoint): 3 force variables, 3 motion rows, 4 friction rows per foot; flat feet (tsid Contact6d, FS == 6): the forces at
+    // the four corners of the sole (12 variables, foot frame), the 6-D LOCAL frame motion (6 rows), 16 pyramid rows + the bound on the total
+    // normal force (17 rows); NFW: size of a force target / of the reported contact force (the wrench T f of a flat foot)
+    static constexpr int NFV = FS == 6 ? 12 : 3, NM = FS == 6 ? 6 : 3, NFR = FS == 6 ? 17 : 4, NFW = FS == 6 ? 6 : 3;
+    static constexpr int N = NV + NFV * NF;                     // variables [a ; f]
+    static constexpr int M = N + 6 + NM * NF + NFR * NF + NA;   // rows: box | dynamics | contact motion | friction | actuation
     static constexpr int NP = ((N + 15) / 16) * 16, MP = ((M + 15) / 16) * 16, LDC = NP + 1; // padded sizes ; row stride of C in LDS
-    static constexpr int R_DYN = N, R_MOT = N + 6, R_FRI = R_MOT + 3 * NF, R_ACT = R_FRI + 4 * NF;
-    static_assert(NP == 32, "the K inverse is instantiated for 32 x 32");
+    static constexpr int R_DYN = N, R_MOT = N + 6, R_FRI = R_MOT + NM * NF, R_ACT = R_FRI + NFR * NF;
+    static constexpr int GR = M - N;                            // general rows (the first N rows of C are the identity: the box on y)
+    static_assert(FS == 6 || NP == 32, "point feet: the K inverse is instantiated for 32 x 32");
   };
   constexpr double ID_INF = 1e20;
 
@@ -52,6 +57,9 @@ namespace smpc
     const double * X = nullptr;                                   // [B][NX] measured states
     double *Mq = nullptr, *nle = nullptr, *J = nullptr, *Jdv = nullptr, *vfoot = nullptr; // [B][NV NV], [NV], [3 NF][NV], [3 NF], [3 NF]
     double *com = nullptr, *footp = nullptr;                                               // [B][3], [3 NF] world frame
+    // flat feet (FS == 6): J / Jdv / vfoot hold the LOCAL 6-D rows (6 NF); footR [B][NF][9] foot rotations; quad [NF][4][3] corners of the soles;
+    // tf / f are wrenches (6 NF)
+    double *footR = nullptr, *quad = nullptr;
     double *H = nullptr, *g = nullptr, *C = nullptr, *l = nullptr, *u = nullptr;           // [B][NP NP], [NP], [MP][NP], [MP], [MP]
     double *x = nullptr, *z = nullptr, *lam = nullptr, *rho = nullptr;                     // ADMM iterate [B][NP], [MP], [MP] and step-size parameter [B]
     int * warm = nullptr;                                                                   // [B] 0 = start from scratch
@@ -69,7 +77,6 @@ namespace smpc
   {
     typedef FullScratch<D, false> SC;
     constexpr int NT = 64, NV = D::NV, NX = D::NX, NF = D::NF, NQ = D::NQ, NR = SC::NR;
-    static_assert(D::FS == 3, "point feet");
     const int inst = block;
     const DevModel<D> & mg = *b.model;
     SMPC_LDS(SC, scs, 1);
@@ -88,6 +95,44 @@ namespace smpc
     fp.tprev = 0;
     const unsigned mask = (1u << NF) - 1u; // every foot's rows (the QP decides which are contacts)
     full_dynamics_phases<D, false>(sc, (FullScratchDeriv<D> *)nullptr, mg, mask, true, fp, true);
+    if constexpr (D::FS == 6)
+    {
+      // flat feet: the stage kernel's rows are LOCAL_WORLD_ALIGNED at the frame origin; tsid's Contact6d works in the foot's LOCAL frame:
+      // [R^T lin ; R^T ang] of the Jacobian, of the drift (classical acceleration at zero joint accelerations) and of the frame velocity
+      SMPC_LANES(NT)
+      {
+        for (int idx = lane; idx < NV * NV; idx += NT)
+          b.Mq[(size_t)inst * NV * NV + idx] = sc.M[idx];
+        for (int i = lane; i < NV; i += NT)
+          b.nle[(size_t)inst * NV + i] = -sc.W[i * NR];
+        for (int idx = lane; idx < 6 * NF * NV; idx += NT)
+        {
+          const int r = idx / NV, k = idx % NV, f = r / 6, blk = (r % 6) / 3, i = r % 3;
+          const double * Rf = &sc.oR[sc.h.foot_joint[f] * 9];
+          const int r0 = 6 * f + 3 * blk;
+          b.J[(size_t)inst * 6 * NF * NV + idx] = Rf[i] * sc.J[r0 * NV + k] + Rf[3 + i] * sc.J[(r0 + 1) * NV + k] + Rf[6 + i] * sc.J[(r0 + 2) * NV + k];
+        }
+        if (lane < 6 * NF)
+        {
+          const int f = lane / 6, blk = (lane % 6) / 3, i = lane % 3;
+          const int jf = sc.h.foot_joint[f];
+          const double * Rf = &sc.oR[jf * 9];
+          const int r0 = 6 * f + 3 * blk;
+          b.Jdv[(size_t)inst * 6 * NF + lane] = Rf[i] * sc.gam[r0] + Rf[3 + i] * sc.gam[r0 + 1] + Rf[6 + i] * sc.gam[r0 + 2];
+          const SV v = ldsv(&sc.vel[jf * 6]);
+          const V3 w = blk == 0 ? v.l + cross(v.a, ld3(&sc.footp[f * 3])) : v.a;
+          b.vfoot[(size_t)inst * 6 * NF + lane] = Rf[i] * w.x + Rf[3 + i] * w.y + Rf[6 + i] * w.z;
+        }
+        if (lane >= 32 && lane < 32 + 3 * NF)
+          b.footp[(size_t)inst * 3 * NF + lane - 32] = sc.footp[lane - 32];
+        for (int i = lane; i < 9 * NF; i += NT)
+          b.footR[(size_t)inst * 9 * NF + i] = sc.oR[sc.h.foot_joint[i / 9] * 9 + i % 9];
+        if (lane < 3)
+          b.com[(size_t)inst * 3 + lane] = sc.com[lane];
+      }
+      SMPC_LANES_END_WAVE
+      return;
+    }
     // M, nle = -(S tau - nle) at tau = 0 ; LOCAL rows -> world frame: J_w = R_f J_loc, drift likewise (Kp = Kd = 0 in this model)
     SMPC_LANES(NT)
     {
@@ -718,15 +763,543 @@ namespace smpc
     SMPC_LANES_END_WAVE
   }
 
+  // =====================================================================================================================
+  // Flat feet (tsid::contacts::Contact6d; reference kinodynamics-id.cpp:41-49, 163-167, 204-208; centroidal-id.cpp:38-41): QP data and ADMM of the
+  // 52-variable / 74-general-row problem of a Talos-class biped.  Same formulation as the CPU checker (oracle/orc_id.hpp, "Robots with 6-D feet").
+  // =====================================================================================================================
+  SMPC_HD double id6_tgen(const double * quad, int f, int r, int c)
+  { // force generator matrix T (6 x 12) of foot f: [I I I I ; [p_1]x .. [p_4]x]
+    const int k = c / 3, j = c % 3;
+    if (r < 3)
+      return r == j ? 1.0 : 0.0;
+    const double * p = quad + (f * 4 + k) * 3;
+    const int i = r - 3;
+    if (i == j)
+      return 0.0;
+    const int o = 3 - i - j; // the remaining axis: [p]x (i, j) = +-p_o
+    const bool pos = (i == 0 && j == 2) || (i == 1 && j == 0) || (i == 2 && j == 1);
+    return pos ? p[o] : -p[o];
+  }
+  SMPC_HD double id6_wrench_w(int r) { return r < 2 ? 1.0 : (r == 2 ? 1e-3 : 2.0); } // Contact6d::m_weightForceRegTask [UPSTREAM-RECALL]
+
+  template <class D>
+  SMPC_DEV void id6_assemble_body(const IdBuffers<D> & b, int block)
+  {
+    typedef IdDims<D> G;
+    constexpr int NT = 64, NV = G::NV, NQ = G::NQ, NF = G::NF, NA = G::NA, N = G::N, NP = G::NP, MP = G::MP, NFV = G::NFV;
+    static_assert(G::FS == 6, "flat feet");
+    const int inst = block;
+    const IdSettingsDev & s = b.s;
+    const double * x = b.X + (size_t)inst * G::NX;
+    const double * q = x;
+    const double * v = x + NQ;
+    SMPC_LDS(double, sM, NV * NV);
+    SMPC_LDS(double, sJ, 6 * NF * NV);
+    SMPC_LDS(double, JG, NV * NFV * NF); // J^T T per foot: generalised force of the corner forces
+    SMPC_LDS(double, Jc, 3 * NV);
+    SMPC_LDS(double, bc, 3);
+    SMPC_LDS(double, bt, 6 * NF);
+    SMPC_LDS(double, e6, 6);
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < NV * NV; idx += NT)
+        sM[idx] = b.Mq[(size_t)inst * NV * NV + idx];
+      for (int idx = lane; idx < 6 * NF * NV; idx += NT)
+        sJ[idx] = b.J[(size_t)inst * 6 * NF * NV + idx];
+    }
+    SMPC_LANES_END_WAVE
+    const double * Mq = sM;
+    const double * nle = b.nle + (size_t)inst * NV;
+    const double * J = sJ;
+    const double * Jdv = b.Jdv + (size_t)inst * 6 * NF;
+    const double * vf = b.vfoot + (size_t)inst * 6 * NF;
+    const double *tq = b.tx + (size_t)inst * G::NX, *tv = tq + NQ, *ta = b.ta + (size_t)inst * NV, *tf = b.tf + (size_t)inst * 6 * NF;
+    const unsigned mask = b.tmask[inst];
+    double * H = b.H + (size_t)inst * NP * NP;
+    double * g = b.g + (size_t)inst * NP;
+    double * C = b.C + (size_t)inst * MP * NP;
+    double * l = b.l + (size_t)inst * MP;
+    double * u = b.u + (size_t)inst * MP;
+    const double kdp = 2.0 * sqrt(s.kp_posture), kdb = 2.0 * sqrt(s.kp_base), kdc = 2.0 * sqrt(s.kp_contact);
+    const double kdm = 2.0 * sqrt(s.kp_com), kdt = 2.0 * sqrt(s.kp_feet_tracking);
+    const bool com_task = s.centroidal && s.w_com > 0, track_task = s.centroidal && s.w_feet_tracking > 0;
+    const bool mot_cost = !s.contact_motion_equality && s.w_contact_motion > 0;
+    const int base0 = s.centroidal ? 3 : 0;
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < NV * NFV * NF; idx += NT)
+      {
+        const int k = idx / (NFV * NF), c = idx % (NFV * NF), f = c / NFV, cc = c % NFV;
+        double acc = 0.0;
+        for (int r = 0; r < 6; r++)
+          acc += J[(6 * f + r) * NV + k] * id6_tgen(b.quad, f, r, cc);
+        JG[idx] = acc;
+      }
+      if (com_task)
+        for (int idx = lane; idx < 3 * NV; idx += NT)
+        {
+          const int i = idx / NV, k = idx % NV;
+          const M3 Rb = quat_to_R(Quat{q[3], q[4], q[5], q[6]});
+          const double im = 1.0 / b.model->total_mass;
+          const double r0 = i == 0 ? Rb.a00 : (i == 1 ? Rb.a10 : Rb.a20), r1 = i == 0 ? Rb.a01 : (i == 1 ? Rb.a11 : Rb.a21),
+                       r2 = i == 0 ? Rb.a02 : (i == 1 ? Rb.a12 : Rb.a22);
+          Jc[idx] = im * (r0 * Mq[k] + r1 * Mq[NV + k] + r2 * Mq[2 * NV + k]);
+        }
+      if (lane == 63)
+      { // base error log6(M_b^-1 M_t), local frame
+        const SE3 Mb{quat_to_R(Quat{q[3], q[4], q[5], q[6]}), mk3(q[0], q[1], q[2])};
+        const SE3 Mt{quat_to_R(Quat{tq[3], tq[4], tq[5], tq[6]}), mk3(tq[0], tq[1], tq[2])};
+        V3 ev, ew;
+        log6(se3_mul(se3_inv(Mb), Mt), ev, ew);
+        st3(e6, ev);
+        st3(e6 + 3, ew);
+      }
+      if (track_task && lane >= 32 && lane < 32 + NF)
+      { // feet in the air: 6-D LOCAL task towards (identity rotation, target position), zero angular velocity target
+        const int f = lane - 32;
+        const size_t o = (size_t)inst * 3 * NF + 3 * f;
+        const M3 Rf = ldm3(b.footR + ((size_t)inst * NF + f) * 9);
+        const SE3 Mf{Rf, ld3(b.footp + o)}, Mr{m3_id(), ld3(b.tfp + o)};
+        V3 ev, ew;
+        log6(se3_mul(se3_inv(Mf), Mr), ev, ew);
+        const V3 vr = tmul(Rf, ld3(b.tfv + o));
+        const double e[6] = {ev.x, ev.y, ev.z, ew.x, ew.y, ew.z}, vrr[6] = {vr.x, vr.y, vr.z, 0.0, 0.0, 0.0};
+        for (int i = 0; i < 6; i++)
+          bt[6 * f + i] = s.kp_feet_tracking * e[i] + kdt * (vrr[i] - vf[6 * f + i]) - Jdv[6 * f + i];
+      }
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (com_task && lane < 3)
+    {
+      const int i = lane;
+      const M3 Rb = quat_to_R(Quat{q[3], q[4], q[5], q[6]});
+      const double im = 1.0 / b.model->total_mass;
+      const double r0 = i == 0 ? Rb.a00 : (i == 1 ? Rb.a10 : Rb.a20), r1 = i == 0 ? Rb.a01 : (i == 1 ? Rb.a11 : Rb.a21),
+                   r2 = i == 0 ? Rb.a02 : (i == 1 ? Rb.a12 : Rb.a22);
+      double vc = 0.0;
+      for (int k = 0; k < NV; k++)
+        vc += Jc[i * NV + k] * v[k];
+      const double dr = im * (r0 * nle[0] + r1 * nle[1] + r2 * nle[2]) + (i == 2 ? -9.81 : 0.0);
+      bc[i] = s.kp_com * (b.tcom[(size_t)inst * 3 + i] - b.com[(size_t)inst * 3 + i]) + kdm * (b.tvcom[(size_t)inst * 3 + i] - vc) - dr;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    {
+      // ---- H and g ----
+      for (int idx = lane; idx < NP * NP; idx += NT)
+      {
+        const int i = idx / NP, j = idx % NP;
+        double h = 0.0;
+        if (i >= N || j >= N)
+          h = (i == j) ? 1.0 : 0.0;
+        else
+        {
+          if (i == j && i >= 6 && i < NV && s.w_posture > 0)
+            h += s.w_posture;
+          if (i == j && i >= base0 && i < 6 && s.w_base > 0)
+            h += s.w_base;
+          if (i < NV && j < NV)
+          {
+            if (com_task)
+              for (int r = 0; r < 3; r++)
+                h += s.w_com * Jc[r * NV + i] * Jc[r * NV + j];
+            for (int f = 0; f < NF; f++)
+            {
+              const bool on = (mask >> f) & 1u;
+              const double w = on ? (mot_cost ? s.w_contact_motion : 0.0) : (track_task ? s.w_feet_tracking : 0.0);
+              if (w != 0.0)
+                for (int r = 6 * f; r < 6 * f + 6; r++)
+                  h += w * J[r * NV + i] * J[r * NV + j];
+            }
+          }
+          if (i >= NV && j >= NV && (i - NV) / NFV == (j - NV) / NFV && s.w_contact_force > 0 && ((mask >> ((i - NV) / NFV)) & 1u))
+          { // force regularisation: T^T diag(w^2) T of the foot
+            const int f = (i - NV) / NFV, a = (i - NV) % NFV, c = (j - NV) % NFV;
+            double acc = 0.0;
+            for (int r = 0; r < 6; r++)
+              acc += id6_tgen(b.quad, f, r, a) * id6_wrench_w(r) * id6_wrench_w(r) * id6_tgen(b.quad, f, r, c);
+            h += s.w_contact_force * acc;
+          }
+        }
+        H[idx] = h;
+      }
+      for (int i = lane; i < NP; i += NT)
+      {
+        double gi = 0.0;
+        if (i < N)
+        {
+          if (i >= 6 && i < NV && s.w_posture > 0)
+            gi -= s.w_posture * (ta[i] + s.kp_posture * (tq[i + 1] - q[i + 1]) + kdp * (tv[i] - v[i]));
+          if (i >= base0 && i < 6 && s.w_base > 0)
+          {
+            const V3 dr = cross(mk3(v[3], v[4], v[5]), mk3(v[0], v[1], v[2]));
+            const double ades = s.base_as_coded ? s.kp_base * e6[i] + kdb * (ta[i] - v[i]) : s.kp_base * e6[i] + kdb * (tv[i] - v[i]) + ta[i];
+            gi -= s.w_base * (ades - (i == 0 ? dr.x : (i == 1 ? dr.y : (i == 2 ? dr.z : 0.0))));
+          }
+          if (i < NV)
+          {
+            if (com_task)
+              for (int r = 0; r < 3; r++)
+                gi -= s.w_com * Jc[r * NV + i] * bc[r];
+            for (int f = 0; f < NF; f++)
+            {
+              const bool on = (mask >> f) & 1u;
+              if (on && mot_cost)
+                for (int r = 6 * f; r < 6 * f + 6; r++)
+                  gi -= s.w_contact_motion * J[r * NV + i] * (-Jdv[r] - kdc * vf[r]);
+              if (!on && track_task)
+                for (int r = 6 * f; r < 6 * f + 6; r++)
+                  gi -= s.w_feet_tracking * J[r * NV + i] * bt[r];
+            }
+          }
+          if (i >= NV && s.w_contact_force > 0 && ((mask >> ((i - NV) / NFV)) & 1u))
+          {
+            const int f = (i - NV) / NFV, a = (i - NV) % NFV;
+            double acc = 0.0;
+            for (int r = 0; r < 6; r++)
+              acc += id6_tgen(b.quad, f, r, a) * id6_wrench_w(r) * id6_wrench_w(r) * tf[6 * f + r];
+            gi -= s.w_contact_force * acc;
+          }
+        }
+        g[i] = gi;
+      }
+      // ---- general rows of C, l, u ----
+      for (int idx = N * NP + lane; idx < G::M * NP; idx += NT)
+      {
+        const int r = idx / NP, c = idx % NP;
+        double val = 0.0;
+        if (c < N && r < G::R_MOT)
+        { // dynamics rows: [M_b | -(J^T T)_b]
+          const int i = r - G::R_DYN;
+          val = c < NV ? Mq[i * NV + c] : -JG[i * (NFV * NF) + c - NV];
+        }
+        else if (c < N && r < G::R_FRI)
+        { // contact motion rows (equality variant, feet in contact)
+          const int rr = r - G::R_MOT;
+          if (s.contact_motion_equality && ((mask >> (rr / 6)) & 1u) && c < NV)
+            val = J[rr * NV + c];
+        }
+        else if (c < N && r < G::R_ACT)
+        { // per corner k of foot f: rows 4 k + m: +-f_x - mu f_z, +-f_y - mu f_z ; row 16: sum of the normal forces
+          const int rr = r - G::R_FRI, f = rr / 17, m = rr % 17;
+          if (((mask >> f) & 1u) && c >= NV + NFV * f && c < NV + NFV * (f + 1))
+          {
+            const int cc = c - NV - NFV * f, k = cc / 3, j = cc % 3;
+            if (m == 16)
+              val = j == 2 ? 1.0 : 0.0;
+            else if (m / 4 == k)
+              val = j == 2 ? -s.friction_coefficient : (j == (m % 4) / 2 ? ((m % 2 == 0) ? 1.0 : -1.0) : 0.0);
+          }
+        }
+        else if (c < N && r < G::M)
+        { // actuation rows: [M_a | -(J^T T)_a]
+          const int j = r - G::R_ACT;
+          val = c < NV ? Mq[(6 + j) * NV + c] : -JG[(6 + j) * (NFV * NF) + c - NV];
+        }
+        C[idx] = val;
+      }
+      for (int r = lane; r < MP; r += NT)
+      {
+        double lo = -ID_INF, hi = ID_INF;
+        const double W = b.model->total_mass * 9.81, dt = s.control_dt;
+        if (r >= 6 && r < NV)
+        {
+          const int j = r - 6;
+          const double qa = q[7 + j], va = v[6 + j];
+          lo = fmax((-b.v_max[j] - va) / dt, 2.0 * (b.q_min[j] - qa - va * dt) / (dt * dt));
+          hi = fmin((b.v_max[j] - va) / dt, 2.0 * (b.q_max[j] - qa - va * dt) / (dt * dt));
+          if (lo > hi)
+            lo = hi = fmin(lo, hi);
+          if (s.tsid_bounds)
+            id_tsid_acc_limits(qa, va, b.q_min[j], b.q_max[j], b.v_max[j], dt, lo, hi);
+        }
+        else if (r >= NV && r < N)
+        {
+          if (!((mask >> ((r - NV) / NFV)) & 1u))
+            lo = hi = 0.0;
+        }
+        else if (r >= N && r < G::R_MOT)
+          lo = hi = -nle[r - G::R_DYN];
+        else if (r >= G::R_MOT && r < G::R_FRI)
+        {
+          const int rr = r - G::R_MOT;
+          if (s.contact_motion_equality && ((mask >> (rr / 6)) & 1u))
+            lo = hi = -Jdv[rr] - kdc * vf[rr];
+        }
+        else if (r >= G::R_FRI && r < G::R_ACT)
+        {
+          const int rr = r - G::R_FRI;
+          if ((mask >> (rr / 17)) & 1u)
+          {
+            if (rr % 17 == 16)
+            {
+              lo = s.ratio_min * W;
+              hi = s.ratio_max * W;
+            }
+            else
+              hi = 0.0;
+          }
+        }
+        else if (r >= G::R_ACT && r < G::M)
+        {
+          const int j = r - G::R_ACT;
+          lo = -b.tau_max[j] - nle[6 + j];
+          hi = b.tau_max[j] - nle[6 + j];
+        }
+        l[r] = lo;
+        u[r] = hi;
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
+  // ADMM of the flat-foot QP: the algorithm of qp_admm_body (and of the CPU checker's qp_admm) for any size -- the general rows of C and K^-1 stay
+  // in LDS (74 rows x 52 columns do not fit the one-row-per-lane register layout of the point-foot kernel), the vectors are exchanged through LDS;
+  // K = H + sigma I + C^T diag(r) C is assembled and inverted on the matrix cores.
+  template <class D>
+  struct Qp6Lds
+  {
+    typedef IdDims<D> G;
+    double K[G::NP * G::NP];
+    double C[G::GR * G::LDC];
+    double swp[2 * 4 * 16 * ((2 * G::NP + 15) / 16)];
+    double x[G::NP], g[G::NP], rhs[G::NP], xt[G::NP];
+    double z[G::MP], lam[G::MP], lo[G::MP], hi[G::MP], r[G::MP], w[G::MP], zt[G::MP];
+    double red[256], red4[4];
+  };
+  template <class D>
+  SMPC_DEV void qp6_admm_body(const IdBuffers<D> & b, int block)
+  {
+    typedef IdDims<D> G;
+    constexpr int NT = 64, NV = G::NV, NF = G::NF, NA = G::NA, N = G::N, NP = G::NP, MP = G::MP, M = G::M, LDC = G::LDC, GR = G::GR, NFV = G::NFV;
+    static_assert(NP == NT, "one variable per lane");
+    const int inst = block;
+    const IdSettingsDev & st = b.s;
+    const double sigma = st.sigma, alpha = st.alpha;
+    SMPC_LDS(Qp6Lds<D>, ls, 1);
+    Qp6Lds<D> & s = ls[0];
+    const double * Hg = b.H + (size_t)inst * NP * NP;
+    const double * Cg = b.C + (size_t)inst * MP * NP + (size_t)N * NP;
+    const bool warm = b.warm[inst] != 0;
+    double rho = warm ? b.rho[inst] : st.rho;
+    SMPC_PLA(double, Krow, NT, NP);
+    SMPC_LANES(NT)
+    {
+      for (int idx = lane; idx < GR * NP; idx += NT)
+        s.C[(idx / NP) * LDC + idx % NP] = Cg[idx];
+      s.g[lane] = b.g[(size_t)inst * NP + lane];
+      s.x[lane] = warm ? b.x[(size_t)inst * NP + lane] : 0.0;
+      for (int k = lane; k < MP; k += NT)
+      {
+        const double lo = k < M ? b.l[(size_t)inst * MP + k] : -ID_INF, hi = k < M ? b.u[(size_t)inst * MP + k] : ID_INF;
+        s.lo[k] = lo;
+        s.hi[k] = hi;
+        s.z[k] = warm ? b.z[(size_t)inst * MP + k] : fmin(fmax(0.0, lo), hi);
+        s.lam[k] = warm ? b.lam[(size_t)inst * MP + k] : 0.0;
+      }
+    }
+    SMPC_LANES_END_WAVE
+    auto factor = [&]() {
+      SMPC_LANES(NT)
+      for (int k = lane; k < MP; k += NT)
+      {
+        const double lo = s.lo[k], hi = s.hi[k];
+        s.r[k] = (hi - lo < 1e-12) ? 1e3 * rho : ((lo <= -ID_INF && hi >= ID_INF) ? 1e-6 * rho : rho);
+      }
+      SMPC_LANES_END_WAVE
+      fwave_gemm<NP, NP, GR>(
+        [&](int i, int k) { return s.r[N + k] * s.C[k * LDC + i]; }, [&](int k, int j) { return s.C[k * LDC + j]; },
+        [&](int i, int j, double v) { s.K[i * NP + j] = (Hg[i * NP + j] + (i == j ? sigma + (i < N ? s.r[i] : 0.0) : 0.0)) + v; });
+      fwave_spd_inverse<NP>(s.K, s.swp);
+      SMPC_LANES(NT)
+      {
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+          SMPC_PLV(Krow)[j] = s.K[j * NP + lane]; // (K^-1 is symmetric: read along the row of j, conflict-free)
+      }
+      SMPC_LANES_END_WAVE
+    };
+    double rs[4] = {0.0, 0.0, 0.0, 0.0};
+    auto residual = [&]() {
+      SMPC_LANES(NT)
+      {
+        double pr = 0.0, np = 0.0, du = 0.0, nd = 0.0;
+        for (int k = lane; k < GR; k += NT)
+        {
+          double cx = 0.0;
+          for (int i = 0; i < N; i++)
+            cx += s.C[k * LDC + i] * s.x[i];
+          pr = fmax(pr, fabs(cx - s.z[N + k]));
+          np = fmax(np, fmax(fabs(cx), fabs(s.z[N + k])));
+        }
+        if (lane < N)
+        {
+          double hx = 0.0, cl = s.lam[lane];
+          for (int j = 0; j < N; j++)
+            hx += Hg[j * NP + lane] * s.x[j];
+          for (int k = 0; k < GR; k++)
+            cl += s.C[k * LDC + lane] * s.lam[N + k];
+          pr = fmax(pr, fabs(s.x[lane] - s.z[lane]));
+          np = fmax(np, fmax(fabs(s.x[lane]), fabs(s.z[lane])));
+          du = fabs((s.g[lane] + hx) + cl);
+          nd = fmax(fabs(hx), fmax(fabs(cl), fabs(s.g[lane])));
+        }
+        s.red[lane] = pr;
+        s.red[64 + lane] = du;
+        s.red[128 + lane] = np;
+        s.red[192 + lane] = nd;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      if (lane < 4)
+      {
+        double m = 0.0;
+        for (int i = 0; i < NT; i++)
+        {
+          const double v = s.red[64 * lane + i];
+          m = (v != v) ? v : ((m != m) ? m : fmax(m, v));
+        }
+        s.red4[lane] = m;
+      }
+      SMPC_LANES_END_WAVE
+      for (int i = 0; i < 4; i++)
+        rs[i] = s.red4[i];
+    };
+    factor();
+    bool done = false;
+    for (int it = 0; it < st.admm_iters; it++)
+    {
+      if (it > 0 && it % ADMM_CHECK == 0)
+      {
+        residual();
+        if (st.admm_tol >= 0.0 && fmax(rs[0], rs[1]) <= st.admm_tol)
+        {
+          done = true;
+          break;
+        }
+        const double est = fmin(fmax(rho * sqrt((rs[0] / (rs[2] + 1e-10)) / (rs[1] / (rs[3] + 1e-10) + 1e-10)), 1e-6), 1e6);
+        if (fmax(rs[0], rs[1]) > ADMM_ADAPT_FLOOR && (est > 5.0 * rho || est < 0.2 * rho))
+        {
+          rho = est;
+          factor();
+        }
+      }
+      SMPC_LANES(NT)
+      for (int k = lane; k < M; k += NT)
+        s.w[k] = s.r[k] * s.z[k] - s.lam[k];
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      { // rhs = sigma x - g + C^T (r z - lam): the box rows contribute their own entry
+        double acc = sigma * s.x[lane] - s.g[lane];
+        if (lane < N)
+        {
+          acc += s.w[lane];
+          for (int k = 0; k < GR; k++)
+            acc += s.C[k * LDC + lane] * s.w[N + k];
+        }
+        s.rhs[lane] = acc;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; j++)
+          acc += SMPC_PLV(Krow)[j] * s.rhs[j];
+        s.xt[lane] = lane < N ? acc : 0.0;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
+        for (int k = lane; k < GR; k += NT)
+        {
+          double acc = 0.0;
+          for (int i = 0; i < N; i++)
+            acc += s.C[k * LDC + i] * s.xt[i];
+          s.zt[N + k] = acc;
+        }
+        if (lane < N)
+          s.zt[lane] = s.xt[lane];
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
+        for (int k = lane; k < M; k += NT)
+        {
+          const double zh = alpha * s.zt[k] + (1.0 - alpha) * s.z[k];
+          const double zn = fmin(fmax(zh + s.lam[k] / s.r[k], s.lo[k]), s.hi[k]);
+          s.lam[k] += s.r[k] * (zh - zn);
+          s.z[k] = zn;
+        }
+        s.x[lane] = alpha * s.xt[lane] + (1.0 - alpha) * s.x[lane];
+      }
+      SMPC_LANES_END_WAVE
+    }
+    if (!done)
+      residual();
+    const double res = (rs[0] != rs[0] || rs[1] != rs[1]) ? rs[0] + rs[1] : fmax(rs[0], rs[1]);
+    SMPC_LANES(NT)
+    {
+      const bool ok = res == res && res < 1e300;
+      if (ok)
+      {
+        b.x[(size_t)inst * NP + lane] = s.x[lane];
+        for (int k = lane; k < M; k += NT)
+        {
+          b.z[(size_t)inst * MP + k] = s.z[k];
+          b.lam[(size_t)inst * MP + k] = s.lam[k];
+        }
+      }
+      for (int i = lane; i < NV; i += NT)
+        b.a[(size_t)inst * NV + i] = s.x[i];
+      // contact wrenches T f (foot frames) -> red[0 .. 6 NF)
+      if (lane < 6 * NF)
+      {
+        const int f = lane / 6, r = lane % 6;
+        double acc = 0.0;
+        for (int c = 0; c < NFV; c++)
+          acc += id6_tgen(b.quad, f, r, c) * s.x[NV + NFV * f + c];
+        s.red[lane] = acc;
+        b.f[(size_t)inst * 6 * NF + lane] = acc;
+      }
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    {
+      if (lane < NA)
+      { // tau = M_a a + h_a - J_a^T (T f)
+        const double * Mq = b.Mq + (size_t)inst * NV * NV;
+        const double * J = b.J + (size_t)inst * 6 * NF * NV;
+        double acc = b.nle[(size_t)inst * NV + 6 + lane];
+        for (int k = 0; k < NV; k++)
+          acc += Mq[(6 + lane) * NV + k] * s.x[k];
+        for (int r = 0; r < 6 * NF; r++)
+          acc -= J[r * NV + 6 + lane] * s.red[r];
+        b.tau[(size_t)inst * NA + lane] = acc;
+      }
+      if (lane == 0)
+      {
+        const bool ok = res == res && res < 1e300;
+        b.resid[inst] = res;
+        b.rho[inst] = ok ? rho : st.rho;
+        b.warm[inst] = ok ? 1 : 0;
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
   // ---- host engine ----
   struct HostIdSettings
   {
     IdSettingsDev dev;
     std::vector<double> tau_max, v_max, q_min, q_max;
+    std::vector<double> quad_points; // flat feet: [nf][4][3] corners of the soles in their foot frames
   };
   struct IdEngineBase
   {
     int B = 0, nq = 0, nv = 0, nf = 0, n = 0, m = 0, np = 0, mp = 0;
+    int nfw = 3, nmot = 3; // size of a force target / reported contact force per foot (3, or the 6-D wrench of a flat foot) ; contact-motion rows per foot
     virtual ~IdEngineBase() {}
     virtual void set_target(int inst, const double * q, const double * v, const double * a, unsigned mask, const double * f) = 0;
     virtual void set_targets(const double * Q, const double * V, const double * A, const unsigned char * contact, const double * F) = 0;
@@ -796,6 +1369,8 @@ namespace smpc
       nq = D::NQ;
       nv = D::NV;
       nf = D::NF;
+      nfw = G::NFW;
+      nmot = G::NM;
       n = G::N;
       m = G::M;
       np = G::NP;
@@ -819,9 +1394,9 @@ namespace smpc
       buf.X = Xd;
       buf.Mq = dalloc(Bs * nv * nv);
       buf.nle = dalloc(Bs * nv);
-      buf.J = dalloc(Bs * 3 * nf * nv);
-      buf.Jdv = dalloc(Bs * 3 * nf);
-      buf.vfoot = dalloc(Bs * 3 * nf);
+      buf.J = dalloc(Bs * nmot * nf * nv);
+      buf.Jdv = dalloc(Bs * nmot * nf);
+      buf.vfoot = dalloc(Bs * nmot * nf);
       buf.com = dalloc(Bs * 3);
       buf.footp = dalloc(Bs * 3 * nf);
       buf.tcom = dalloc(Bs * 3);
@@ -850,12 +1425,20 @@ namespace smpc
       dev_zero(buf.warm, Bs * sizeof(int), stream);
       buf.tx = dalloc(Bs * (nq + nv));
       buf.ta = dalloc(Bs * nv);
-      buf.tf = dalloc(Bs * 3 * nf);
+      buf.tf = dalloc(Bs * nfw * nf);
       buf.tmask = (unsigned *)dev_alloc(Bs * sizeof(unsigned));
       allocs.push_back(buf.tmask);
       buf.tau = dalloc(Bs * G::NA);
       buf.a = dalloc(Bs * nv);
-      buf.f = dalloc(Bs * 3 * nf);
+      buf.f = dalloc(Bs * nfw * nf);
+      if constexpr (D::FS == 6)
+      {
+        if ((int)hs.quad_points.size() != nf * 12)
+          throw std::runtime_error("inverse-dynamics settings: flat feet need the four corners of every sole (quad_points, [nfeet][4][3])");
+        buf.footR = dalloc(Bs * 9 * nf);
+        buf.quad = dalloc((size_t)nf * 12);
+        h2d(buf.quad, hs.quad_points.data(), (size_t)nf * 12 * sizeof(double), stream);
+      }
       buf.resid = dalloc(Bs);
       buf.tau_max = dalloc(G::NA);
       buf.v_max = dalloc(G::NA);
@@ -868,9 +1451,9 @@ namespace smpc
       buf.s = hs.dev;
       stream_sync(stream);
       // default target: the reference state, every foot in contact with an equal share of the weight (kinodynamics-id.cpp:96-112)
-      std::vector<double> q(rm->q_ref, rm->q_ref + nq), z(nv, 0.0), f(3 * nf, 0.0);
+      std::vector<double> q(rm->q_ref, rm->q_ref + nq), z(nv, 0.0), f((size_t)nfw * nf, 0.0);
       for (int k = 0; k < nf; k++)
-        f[3 * k + 2] = rm->total_mass * 9.81 / nf;
+        f[nfw * k + 2] = rm->total_mass * 9.81 / nf;
       set_target(-1, q.data(), z.data(), z.data(), (1u << nf) - 1u, f.data());
       if (buf.s.centroidal)
       { // CoM of the reference state (one pass of the first kernel), feet at their reference placements (centroidal-id.cpp:60-84)
@@ -902,18 +1485,18 @@ namespace smpc
         throw std::runtime_error("instance index exceeds the batch");
       const int i0 = inst < 0 ? 0 : inst, i1 = inst < 0 ? B : inst + 1;
       const int nx = nq + nv;
-      std::vector<double> tx((size_t)(i1 - i0) * nx), ta((size_t)(i1 - i0) * nv), tf((size_t)(i1 - i0) * 3 * nf);
+      std::vector<double> tx((size_t)(i1 - i0) * nx), ta((size_t)(i1 - i0) * nv), tf((size_t)(i1 - i0) * nfw * nf);
       std::vector<unsigned> tm(i1 - i0, mask);
       for (int i = 0; i < i1 - i0; i++)
       {
         std::copy(q, q + nq, tx.begin() + (size_t)i * nx);
         std::copy(v, v + nv, tx.begin() + (size_t)i * nx + nq);
         std::copy(a, a + nv, ta.begin() + (size_t)i * nv);
-        std::copy(f, f + 3 * nf, tf.begin() + (size_t)i * 3 * nf);
+        std::copy(f, f + nfw * nf, tf.begin() + (size_t)i * nfw * nf);
       }
       h2d(buf.tx + (size_t)i0 * nx, tx.data(), tx.size() * sizeof(double), stream);
       h2d(buf.ta + (size_t)i0 * nv, ta.data(), ta.size() * sizeof(double), stream);
-      h2d(buf.tf + (size_t)i0 * 3 * nf, tf.data(), tf.size() * sizeof(double), stream);
+      h2d(buf.tf + (size_t)i0 * nfw * nf, tf.data(), tf.size() * sizeof(double), stream);
       h2d(buf.tmask + i0, tm.data(), tm.size() * sizeof(unsigned), stream);
       mask_all_valid = false;
       stream_sync(stream);
@@ -935,7 +1518,7 @@ namespace smpc
       }
       h2d(buf.tx, tx.data(), tx.size() * sizeof(double), stream);
       h2d(buf.ta, A, (size_t)B * nv * sizeof(double), stream);
-      h2d(buf.tf, F, (size_t)B * 3 * nf * sizeof(double), stream);
+      h2d(buf.tf, F, (size_t)B * nfw * nf * sizeof(double), stream);
       h2d(buf.tmask, tm.data(), (size_t)B * sizeof(unsigned), stream);
       mask_all_valid = false;
       stream_sync(stream);
@@ -948,7 +1531,7 @@ namespace smpc
       if (inst >= B)
         throw std::runtime_error("instance index exceeds the batch");
       const int i0 = inst < 0 ? 0 : inst, i1 = inst < 0 ? B : inst + 1, cnt = i1 - i0;
-      std::vector<double> c3((size_t)cnt * 3), v3((size_t)cnt * 3), tp((size_t)cnt * 3 * nf), tv((size_t)cnt * 3 * nf), tf((size_t)cnt * 3 * nf);
+      std::vector<double> c3((size_t)cnt * 3), v3((size_t)cnt * 3), tp((size_t)cnt * 3 * nf), tv((size_t)cnt * 3 * nf), tf((size_t)cnt * nfw * nf);
       std::vector<unsigned> tm(cnt, mask);
       for (int i = 0; i < cnt; i++)
       {
@@ -956,13 +1539,13 @@ namespace smpc
         std::copy(vcom, vcom + 3, v3.begin() + (size_t)i * 3);
         std::copy(fp, fp + 3 * nf, tp.begin() + (size_t)i * 3 * nf);
         std::copy(fv, fv + 3 * nf, tv.begin() + (size_t)i * 3 * nf);
-        std::copy(f, f + 3 * nf, tf.begin() + (size_t)i * 3 * nf);
+        std::copy(f, f + nfw * nf, tf.begin() + (size_t)i * nfw * nf);
       }
       h2d(buf.tcom + (size_t)i0 * 3, c3.data(), c3.size() * sizeof(double), stream);
       h2d(buf.tvcom + (size_t)i0 * 3, v3.data(), v3.size() * sizeof(double), stream);
       h2d(buf.tfp + (size_t)i0 * 3 * nf, tp.data(), tp.size() * sizeof(double), stream);
       h2d(buf.tfv + (size_t)i0 * 3 * nf, tv.data(), tv.size() * sizeof(double), stream);
-      h2d(buf.tf + (size_t)i0 * 3 * nf, tf.data(), tf.size() * sizeof(double), stream);
+      h2d(buf.tf + (size_t)i0 * nfw * nf, tf.data(), tf.size() * sizeof(double), stream);
       h2d(buf.tmask + i0, tm.data(), tm.size() * sizeof(unsigned), stream);
       mask_all_valid = false;
       stream_sync(stream);
@@ -980,7 +1563,7 @@ namespace smpc
       h2d(buf.tvcom, VCOM, (size_t)B * 3 * sizeof(double), stream);
       h2d(buf.tfp, FP, (size_t)B * 3 * nf * sizeof(double), stream);
       h2d(buf.tfv, FV, (size_t)B * 3 * nf * sizeof(double), stream);
-      h2d(buf.tf, F, (size_t)B * 3 * nf * sizeof(double), stream);
+      h2d(buf.tf, F, (size_t)B * nfw * nf * sizeof(double), stream);
       h2d(buf.tmask, tm.data(), (size_t)B * sizeof(unsigned), stream);
       mask_all_valid = false;
       stream_sync(stream);
@@ -988,8 +1571,16 @@ namespace smpc
     void launch_all()
     {
       launch<IdBuffers<D>, id_quant_body<D>, 64, 1, 0>(B, stream, buf);
-      launch<IdBuffers<D>, id_assemble_body<D>, 64, 1, 0>(B, stream, buf);
-      launch<IdBuffers<D>, qp_admm_body<D>, 64, 1, 0>(B, stream, buf);
+      if constexpr (D::FS == 6)
+      { // flat feet (tsid Contact6d): 52 variables / 74 general rows
+        launch<IdBuffers<D>, id6_assemble_body<D>, 64, 1, 0>(B, stream, buf);
+        launch<IdBuffers<D>, qp6_admm_body<D>, 64, 1, 0>(B, stream, buf);
+      }
+      else
+      {
+        launch<IdBuffers<D>, id_assemble_body<D>, 64, 1, 0>(B, stream, buf);
+        launch<IdBuffers<D>, qp_admm_body<D>, 64, 1, 0>(B, stream, buf);
+      }
     }
     void solve_device(const double * X_dev, double * tau_dev) override
     {
@@ -1048,7 +1639,7 @@ namespace smpc
       launch_all();
       d2h(tau, buf.tau, (size_t)B * G::NA * sizeof(double), stream);
       d2h(a, buf.a, (size_t)B * nv * sizeof(double), stream);
-      d2h(f, buf.f, (size_t)B * 3 * nf * sizeof(double), stream);
+      d2h(f, buf.f, (size_t)B * nfw * nf * sizeof(double), stream);
       if (resid)
         d2h(resid, buf.resid, (size_t)B * sizeof(double), stream);
       stream_sync(stream);
@@ -1072,7 +1663,7 @@ namespace smpc
     {
       set_device(device_id);
       const double * src[13] = {buf.Mq, buf.nle, buf.J, buf.Jdv, buf.vfoot, buf.H, buf.g, buf.C, buf.l, buf.u, buf.com, buf.footp, buf.tau};
-      const size_t per[13] = {(size_t)nv * nv, (size_t)nv, (size_t)3 * nf * nv, (size_t)3 * nf, (size_t)3 * nf, (size_t)np * np, (size_t)np, (size_t)mp * np, (size_t)mp, (size_t)mp, 3, (size_t)3 * nf, (size_t)G::NA};
+      const size_t per[13] = {(size_t)nv * nv, (size_t)nv, (size_t)nmot * nf * nv, (size_t)nmot * nf, (size_t)nmot * nf, (size_t)np * np, (size_t)np, (size_t)mp * np, (size_t)mp, (size_t)mp, 3, (size_t)3 * nf, (size_t)G::NA};
       if (what < 0 || what > 12)
         throw std::runtime_error("unknown quantity");
       d2h(out, src[what], (size_t)B * per[what] * sizeof(double), stream);

@@ -1145,7 +1145,8 @@ class KinodynamicsID:
     control tick, solved on the device (simple-mpc_amd/csrc/smpc_id.h).  `settings`: the reference's KinodynamicsIDSettings keys
     (friction_coefficient, contact_weight_ratio_max / min, kp_base, kp_posture, kp_contact, w_base, w_posture, w_contact_motion,
     w_contact_force, contact_motion_equality).  The reference reads effort and velocity limits from its pinocchio model; the robot table
-    holds position limits only, so `effort_limit` and `velocity_limit` (nv - 6 each) are arguments.  3-D point feet."""
+    holds position limits only, so `effort_limit` and `velocity_limit` (nv - 6 each) are arguments.  Point feet (addPointFoot: tsid ContactPoint)
+    or flat feet (addQuadFoot: tsid Contact6d -- force targets and contact forces are then 6-D wrenches per foot, in the foot frames)."""
 
     _KEYS = ["friction_coefficient", "contact_weight_ratio_max", "contact_weight_ratio_min", "kp_base", "kp_posture", "kp_contact", "w_base",
              "w_posture", "w_contact_motion", "w_contact_force", "contact_motion_equality"]
@@ -1174,13 +1175,21 @@ class KinodynamicsID:
                         s["kp_contact"], s["w_base"], s["w_posture"], s["w_contact_motion"], s["w_contact_force"],
                         int(bool(s["contact_motion_equality"])), float(control_dt), *[a.ctypes.data for a in self._keep], int(admm_iters), 0.0, 0.0, 0.0, float(admm_tol),
                         int(self._CENTROIDAL), float(s.get("kp_com", 0.0)), float(s.get("kp_feet_tracking", 0.0)), float(s.get("w_com", -1.0)),
-                        float(s.get("w_feet_tracking", -1.0)), int(bool(base_reference_as_coded)), int(bool(tsid_joint_bounds)))
+                        float(s.get("w_feet_tracking", -1.0)), int(bool(base_reference_as_coded)), int(bool(tsid_joint_bounds)), 3, None)
+        quads = getattr(model_handler, "_quads", {})
+        self._fs = 3
+        if quads:  # flat feet (RobotModelHandler.addQuadFoot): every foot must be one
+            names = model_handler.getFeetFrameNames()
+            if any(n not in quads for n in names):
+                raise RuntimeError("point and flat feet cannot be mixed")
+            self._quad = np.ascontiguousarray(np.stack([quads[n] for n in names]), float)
+            c.force_size, c.quad_contact_points, self._fs = 6, self._quad.ctypes.data, 6
         h = C.c_void_p()
         self._lib.check(self._lib.L.smpc_id_create(model_handler._ptr, C.byref(c), self.B, device_id, C.byref(h)))
         self._h = h
         self._nq, self._nv, self._nf = model_handler.nq, model_handler.nv, model_handler.getFeetNb()
         self._a = np.zeros((self.B, self._nv))
-        self._f = np.zeros((self.B, 3 * self._nf))
+        self._f = np.zeros((self.B, self._fs * self._nf))
         self.resid = np.zeros(self.B)
 
     def __del__(self):
@@ -1203,7 +1212,7 @@ class KinodynamicsID:
         contact = np.ascontiguousarray(np.array([1 if b else 0 for b in contact_state_target], dtype=np.uint8))
         if contact.size != self._nf:
             raise RuntimeError("contact_state_target must have one entry per foot")
-        f = np.zeros(3 * self._nf) if len(f_target) == 0 else c(f_target, 3 * self._nf)  # (the reference's tests pass {} with no contact)
+        f = np.zeros(self._fs * self._nf) if len(f_target) == 0 else c(f_target, self._fs * self._nf)  # (the reference's tests pass {} with no contact)
         self._lib.check(self._lib.L.smpc_id_set_target(self._h, int(instance), c(q_target, self._nq), c(v_target, self._nv), c(a_target, self._nv), contact, f))
 
     def setTargets(self, Q, V, A, contact_states, F):
@@ -1211,7 +1220,7 @@ class KinodynamicsID:
         c = lambda x, n: np.ascontiguousarray(np.array(x, dtype=np.float64).reshape(self.B, n))
         cs = np.array(contact_states)
         cs = np.ascontiguousarray(np.broadcast_to(cs.reshape(-1, self._nf), (self.B, self._nf)).astype(np.uint8))
-        self._lib.check(self._lib.L.smpc_id_set_targets(self._h, c(Q, self._nq), c(V, self._nv), c(A, self._nv), cs, c(F, 3 * self._nf)))
+        self._lib.check(self._lib.L.smpc_id_set_targets(self._h, c(Q, self._nq), c(V, self._nv), c(A, self._nv), cs, c(F, self._fs * self._nf)))
 
     def solve(self, t, q_meas, v_meas, tau_res=None):
         """reference kinodynamics-id.cpp:185-237: one robot (vectors) or the batch (q_meas [B][nq], v_meas [B][nv]); returns tau (and fills
@@ -1264,8 +1273,12 @@ class KinodynamicsID:
         return self._f.reshape(self.B, self._nf, 3).copy()
 
     def debug(self, what):
-        per = {0: (self._nv, self._nv), 1: (self._nv,), 2: (3 * self._nf, self._nv), 3: (3 * self._nf,), 4: (3 * self._nf,), 5: (32, 32), 6: (32,),
-               7: (80, 32), 8: (80,), 9: (80,), 10: (3,), 11: (3 * self._nf,), 12: (self._nv - 6,)}[what]
+        nm = self._fs * self._nf  # contact-motion rows: 3 per point foot, 6 per flat foot
+        n = self._nv + (12 if self._fs == 6 else 3) * self._nf
+        m = n + 6 + nm + (17 if self._fs == 6 else 4) * self._nf + self._nv - 6
+        npad, mpad = (n + 15) // 16 * 16, (m + 15) // 16 * 16
+        per = {0: (self._nv, self._nv), 1: (self._nv,), 2: (nm, self._nv), 3: (nm,), 4: (nm,), 5: (npad, npad), 6: (npad,),
+               7: (mpad, npad), 8: (mpad,), 9: (mpad,), 10: (3,), 11: (3 * self._nf,), 12: (self._nv - 6,)}[what]
         out = np.zeros((self.B,) + per)
         self._lib.check(self._lib.L.smpc_id_debug_get(self._h, what, out))
         return out
@@ -1299,7 +1312,7 @@ class CentroidalID(KinodynamicsID):
         contact = np.ascontiguousarray(np.array([1 if b else 0 for b in contact_state_target], dtype=np.uint8))
         if contact.size != self._nf:
             raise RuntimeError("contact_state_target must have one entry per foot")
-        f = np.zeros(3 * self._nf) if len(f_target) == 0 else c(f_target, 3 * self._nf)
+        f = np.zeros(self._fs * self._nf) if len(f_target) == 0 else c(f_target, self._fs * self._nf)
         self._lib.check(self._lib.L.smpc_id_set_target_centroidal(
             self._h, int(instance), c(com_position, 3), c(com_velocity, 3), c(_positions(feet_pose, self._nf), 3 * self._nf),
             c(_linear_velocities(feet_velocity, self._nf), 3 * self._nf), contact, f))
@@ -1310,7 +1323,7 @@ class CentroidalID(KinodynamicsID):
         cs = np.array(contact_states)
         cs = np.ascontiguousarray(np.broadcast_to(cs.reshape(-1, self._nf), (self.B, self._nf)).astype(np.uint8))
         self._lib.check(self._lib.L.smpc_id_set_targets_centroidal(self._h, c(COM, 3), c(VCOM, 3), c(FEET_P, 3 * self._nf), c(FEET_V, 3 * self._nf), cs,
-                                                                   c(F, 3 * self._nf)))
+                                                                   c(F, self._fs * self._nf)))
 
 
 class FrictionCompensation:

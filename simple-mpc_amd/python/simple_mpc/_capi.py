@@ -115,6 +115,7 @@ class IdSettingsC(C.Structure):
         ("admm_iters", C.c_int), ("admm_rho", C.c_double), ("admm_sigma", C.c_double), ("admm_alpha", C.c_double), ("admm_tol", C.c_double),
         ("centroidal", C.c_int), ("kp_com", C.c_double), ("kp_feet_tracking", C.c_double), ("w_com", C.c_double), ("w_feet_tracking", C.c_double),
         ("base_reference_as_coded", C.c_int), ("tsid_joint_bounds", C.c_int),
+        ("force_size", C.c_int), ("quad_contact_points", C.c_void_p),
     ]
 
 

@@ -36,6 +36,7 @@ class IdSettingsC(C.Structure):
         ("admm_iters", C.c_int), ("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("admm_tol", C.c_double),
         ("centroidal", C.c_int), ("kp_com", C.c_double), ("kp_feet_tracking", C.c_double), ("w_com", C.c_double), ("w_feet_tracking", C.c_double),
         ("base_reference_as_coded", C.c_int), ("tsid_joint_bounds", C.c_int),
+        ("force_size", C.c_int), ("quad_points", C.c_void_p),
     ]
 
 
@@ -133,6 +134,7 @@ def lib():
     L.orc_id_solve.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
     L.orc_id_set_target_centroidal.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, C.c_uint, _dp]
     L.orc_id_quantities.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_id_quantities6.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_id_qp.restype = C.c_int
     L.orc_id_qp.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_fmpc_create.restype = vp
@@ -768,7 +770,17 @@ ID_DEFAULTS = dict(friction_coefficient=0.6, contact_weight_ratio_max=10.0, cont
                    kp_contact=0.0, w_base=-1.0, w_posture=-1.0, w_contact_motion=-1.0, w_contact_force=-1.0, contact_motion_equality=False,
                    admm_iters=400, rho=0.1, sigma=1e-6, alpha=1.6, admm_tol=1e-7,  # reference include/simple-mpc/inverse-dynamics/kinodynamics-id.hpp:24-50
                    centroidal=False, kp_com=0.0, kp_feet_tracking=0.0, w_com=-1.0, w_feet_tracking=-1.0,  # centroidal-id.hpp:17-26
-                   base_reference_as_coded=False, tsid_joint_bounds=False)
+                   base_reference_as_coded=False, tsid_joint_bounds=False,
+                   force_size=3, quad_points=None)  # 6-D feet (tsid Contact6d): force_size 6 and the corners of the soles [nf][4][3]
+TALOS_EFFORT = np.array([100, 160, 160, 300, 160, 100] * 2 + [200, 200] + [44, 44, 22, 22] * 2, float)
+TALOS_VMAX = np.array([3.87, 5.86, 5.86, 7.0, 5.86, 4.8] * 2 + [5.4, 5.4] + [2.7, 3.66, 4.58, 4.58] * 2, float)
+TALOS_QUAD = np.array([[0.1, 0.075, 0], [-0.1, 0.075, 0], [-0.1, -0.075, 0], [0.1, -0.075, 0]])
+
+
+def talos_id_settings(robot, control_dt=1e-3, **kw):
+    """KinodynamicsID::Settings for the Talos-class robot with flat feet (reference tests/inverse-dynamics/kinodynamics-id.cpp:192-236 use
+    getTalosModelHandler(): soles of 0.2 x 0.15 m; the robot table holds no effort / velocity limits: Talos-like values)."""
+    return id_settings(robot, control_dt, tau_max=TALOS_EFFORT, v_max=TALOS_VMAX, force_size=6, quad_points=np.tile(TALOS_QUAD, (robot.nf, 1, 1)), **kw)
 GO2_EFFORT = np.array([23.7, 23.7, 45.43] * 4)
 GO2_VMAX = np.array([30.1, 30.1, 15.7] * 4)
 
@@ -791,10 +803,16 @@ class OracleKinoID:
                         s["kp_contact"], s["w_base"], s["w_posture"], s["w_contact_motion"], s["w_contact_force"],
                         int(s["contact_motion_equality"]), s["control_dt"], *[a.ctypes.data for a in self._keep], int(s["admm_iters"]),
                         s["rho"], s["sigma"], s["alpha"], s["admm_tol"], int(s["centroidal"]), s["kp_com"], s["kp_feet_tracking"], s["w_com"], s["w_feet_tracking"],
-                        int(s["base_reference_as_coded"]), int(s["tsid_joint_bounds"]))
+                        int(s["base_reference_as_coded"]), int(s["tsid_joint_bounds"]), int(s.get("force_size", 3)), None)
+        self.fs = int(s.get("force_size", 3))
+        if self.fs == 6:
+            self._quad = np.ascontiguousarray(s["quad_points"], float).reshape(robot.nf, 4, 3)
+            c.quad_points = self._quad.ctypes.data
         self.h = lib().orc_id_create(robot.ptr, C.byref(c), B)
-        self.n = robot.nv + 3 * robot.nf
-        self.m = self.n + 6 + 3 * robot.nf + 4 * robot.nf + robot.nv - 6
+        nfv, nmot, nfr = (12, 6, 17) if self.fs == 6 else (3, 3, 4)
+        self.nfw = 6 if self.fs == 6 else 3
+        self.n = robot.nv + nfv * robot.nf
+        self.m = self.n + 6 + nmot * robot.nf + nfr * robot.nf + robot.nv - 6
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -814,7 +832,7 @@ class OracleKinoID:
     def solve(self, X):
         rb = self.robot
         X = np.ascontiguousarray(X, float)
-        tau, a, f, res = np.zeros((self.B, rb.nv - 6)), np.zeros((self.B, rb.nv)), np.zeros((self.B, 3 * rb.nf)), np.zeros(self.B)
+        tau, a, f, res = np.zeros((self.B, rb.nv - 6)), np.zeros((self.B, rb.nv)), np.zeros((self.B, self.nfw * rb.nf)), np.zeros(self.B)
         lib().orc_id_solve(self.h, X, tau, a, f, res)
         self.resid = res
         return tau, a, f
@@ -825,6 +843,14 @@ class OracleKinoID:
         m = lib().orc_id_qp(self.h, b, np.ascontiguousarray(x, float), H, g, Cm, l, u)
         assert m == self.m
         return H, g, Cm, l, u
+
+
+def id_quantities6(robot, x):
+    """LOCAL 6-D rows of flat feet: J (6 nf x nv), their drift and the frame velocities (6 nf)."""
+    nv, nf = robot.nv, robot.nf
+    M, nle, J, Jdv, vf = np.zeros((nv, nv)), np.zeros(nv), np.zeros((6 * nf, nv)), np.zeros(6 * nf), np.zeros(6 * nf)
+    lib().orc_id_quantities6(robot.ptr, np.ascontiguousarray(x, float), M, nle, J, Jdv, vf)
+    return dict(M=M, nle=nle, J=J, Jdv=Jdv, vfoot=vf)
 
 
 def id_quantities(robot, x):

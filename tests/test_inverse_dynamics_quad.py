@@ -1,0 +1,188 @@
+"""Whole-body inverse-dynamics controllers for robots with flat (QUAD) feet: tsid::contacts::Contact6d in KinodynamicsID / CentroidalID
+(reference src/inverse-dynamics/kinodynamics-id.cpp:41-49, 155-168, 199-209; centroidal-id.cpp:38-41).  (1) the oracle passes the acceptance
+properties of the reference's own tests (tests/inverse-dynamics/kinodynamics-id.cpp:150-236: contactQuad_cost / contactQuad_equality -- feet at
+rest, joint / velocity / torque limits; centroidal-id.cpp:202-247) on the talos_like robot; (2) the kernels (CPU build of the bodies, HIP library
+on the GPU) agree with the oracle on the QP data and on the solutions; (3) golden replay (tests/golden/talos_id_golden.npz)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import mpc_setup as S
+import oracle_lib as O
+import simple_mpc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden_id_quad as M  # noqa: E402  (settings, targets and integration step of the fixture)
+
+G = np.load(os.path.join(HERE, "golden", "talos_id_golden.npz"))
+NV, NF = 28, 2
+
+
+def _handler(lib):
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("talos_like", lib), "standing", "root_joint")
+    for n in S.TALOS_FEET:
+        mh.addQuadFoot(n, "root_joint", S.TALOS_QUAD)
+    return mh
+
+
+@pytest.mark.parametrize("equality", [False, True])
+def test_oracle_contact_quad_acceptance(equality):
+    """KinodynamicsID_contactQuad_cost / _equality of the reference: from the reference configuration the feet stay at rest (linear velocity
+    <= 1e-2, angular <= 1e-1), joints, joint velocities and torques stay inside their limits, over 500 ticks of 1 ms.  One adaptation, the one
+    the point-foot tests of this repository make too (tests/test_oracle_id.py): the force weight is 1e-3 instead of 1 -- a simulation without
+    ground is an inverted pendulum, and with the wrench regularisation at weight 1 (vertical forces, no sole torques) the 0.05 mm offset of
+    this synthetic robot's centre of mass grows: in the cost variant the feet creep at 1.0e-2 m/s after 0.41 s (7.5e-3 at 0.3 s), in the
+    equality variant a joint bound meets the contact equalities after 0.49 s."""
+    rb = O.Robot("talos_like")
+    kw = dict(M.KINO, w_contact_force=1e-3)
+    k = O.OracleKinoID(rb, O.talos_id_settings(rb, M.DT, contact_motion_equality=equality, **kw), 1)
+    assert (k.n, k.m) == (NV + 12 * NF, NV + 12 * NF + 6 + 6 * NF + 17 * NF + NV - 6)  # 52 variables, 126 rows (74 general)
+    x = rb.x_ref.copy()
+    for i in range(500):
+        tau, a, f = k.solve(x[None])
+        assert k.resid[0] < 1e-5, (i, k.resid)
+        x = M.step(rb, x, a[0])
+        vf = O.id_quantities6(rb, x)["vfoot"].reshape(NF, 6)
+        assert np.linalg.norm(vf[:, :3], axis=1).max() <= 1e-2 and np.linalg.norm(vf[:, 3:], axis=1).max() <= 1e-1, i
+        assert np.all(np.abs(tau[0]) <= O.TALOS_EFFORT + 1e-6) and np.all(np.abs(x[rb.nq + 6:]) <= O.TALOS_VMAX + 1e-9)
+        assert np.all(x[7: rb.nq] <= rb.q_hi + 1e-9) and np.all(x[7: rb.nq] >= rb.q_lo - 1e-9)
+    w = f[0].reshape(NF, 6)
+    assert abs(w[:, 2].sum() - rb.mass * 9.81) < 0.05 * rb.mass * 9.81, "the feet carry the robot"
+
+
+def test_oracle_qp_structure():
+    """Contact6d: the friction rows are pyramids on the four corner forces plus the bound on the total normal force; a foot in the air has its
+    twelve variables pinned and no rows."""
+    rb = O.Robot("talos_like")
+    k = O.OracleKinoID(rb, O.talos_id_settings(rb, M.DT, contact_motion_equality=True, **M.KINO), 1)
+    w = np.zeros((2, 6))
+    w[0, 2] = rb.mass * 9.81
+    k.setTarget(rb.x_ref[: rb.nq], np.zeros(NV), np.zeros(NV), [True, False], w)
+    H, g, C, l, u = k.qp(0, rb.x_ref)
+    n, r_mot, r_fri = k.n, k.n + 6, k.n + 6 + 12
+    assert np.all(l[NV + 12: NV + 24] == 0) and np.all(u[NV + 12: NV + 24] == 0)          # right foot: variables pinned
+    assert np.all(C[r_mot + 6: r_mot + 12] == 0) and np.all(C[r_fri + 17: r_fri + 34] == 0)  # ... and no motion / friction rows
+    fr = C[r_fri: r_fri + 17, NV: NV + 12]
+    assert np.all((fr[:16] != 0).sum(1) == 2) and np.allclose(fr[16], [0, 0, 1] * 4)
+    assert l[r_fri + 16] == pytest.approx(0.01 * rb.mass * 9.81) and u[r_fri + 16] == pytest.approx(10 * rb.mass * 9.81)
+    # the dynamics rows balance the wrench of the corner forces: a uniform vertical force at the corners = a pure vertical force at the frame
+    y = np.zeros(n)
+    y[NV + 2: NV + 12: 3] = 1.0
+    Q = O.id_quantities6(rb, rb.x_ref)
+    assert np.allclose(-C[n: n + 6] @ y, 4.0 * Q["J"][2, :6], atol=1e-12)
+
+
+@pytest.mark.parametrize("equality", [False, True])
+def test_oracle_centroidal_contact_quad_acceptance(equality):
+    """CentroidalID_contactQuad_cost / _equality of the reference (tests/inverse-dynamics/centroidal-id.cpp:202-247): both flat feet stay at rest
+    over 500 ticks (the force weight adapted as above)."""
+    rb = O.Robot("talos_like")
+    kw = dict(M.KINO, w_contact_force=1e-3, contact_motion_equality=equality)
+    k = O.OracleKinoID(rb, O.talos_id_settings(rb, M.DT, centroidal=True, **kw), 1)
+    x = rb.x_ref.copy()
+    for i in range(500):
+        tau, a, f = k.solve(x[None])
+        x = M.step(rb, x, a[0])
+        vf = O.id_quantities6(rb, x)["vfoot"].reshape(NF, 6)
+        assert np.linalg.norm(vf[:, :3], axis=1).max() <= 1e-2 and np.linalg.norm(vf[:, 3:], axis=1).max() <= 1e-1, i
+        assert np.all(np.abs(tau[0]) <= O.TALOS_EFFORT + 1e-6)
+
+
+def test_oracle_centroidal_id_tracks_a_flat_foot():
+    """CentroidalID with a flat foot in the air (centroidal-id.cpp:38-41: the tracking task of a QUAD foot is 6-D): the foot converges to its
+    target position 5.8 cm away and stays flat while the stance foot -- held by the contact equalities -- stays at rest.  (The reference has no
+    test of this task for flat feet; a biped on one foot in a simulation without ground falls over eventually: 300 ticks with a stiff tracking
+    gain, so that the swing is over before that.)"""
+    rb = O.Robot("talos_like")
+    contact, w, com, feet = M.cent_targets(rb)
+    kw = dict(M.CENT, kp_feet_tracking=400.0, w_contact_force=1e-3, contact_motion_equality=True, w_contact_motion=10.0, kp_com=0.0, w_com=-1.0)
+    k = O.OracleKinoID(rb, O.talos_id_settings(rb, M.DT, centroidal=True, **kw), 1)
+    k.setTargetCentroidal(com, np.zeros(3), feet, np.zeros((2, 3)), contact, w)
+    x = rb.x_ref.copy()
+    errs = []
+    for i in range(300):
+        tau, a, f = k.solve(x[None])
+        x = M.step(rb, x, a[0])
+        errs.append(np.linalg.norm(rb.centroidal(x)["feet"][1] - feet[1]))
+        vf = O.id_quantities6(rb, x)["vfoot"].reshape(NF, 6)
+        assert np.linalg.norm(vf[0, :3]) <= 1e-2, "the stance foot stays at rest"
+        assert np.linalg.norm(vf[1, 3:]) <= 1e-1, "the swing foot stays flat"
+    assert errs[-1] < 0.05 * errs[0] and np.all(np.diff(errs[20:]) < 1e-6), (errs[0], errs[-1])
+    assert np.all(np.abs(tau[0]) <= O.TALOS_EFFORT + 1e-6)
+
+
+def test_oracle_reproduces_the_golden_vectors(built):
+    rb = O.Robot("talos_like")
+    for kind, eq in (("cost", False), ("equality", True)):
+        ok = O.OracleKinoID(rb, O.talos_id_settings(rb, M.DT, admm_iters=100, admm_tol=-1.0, contact_motion_equality=eq, **M.KINO), M.B)
+        for t in range(M.TICKS):
+            tau, a, f = ok.solve(G[kind + "_X"][t])
+            assert S.rel_err(G[kind + "_tau"][t], tau) < 1e-9 and S.rel_err(G[kind + "_a"][t], a) < 1e-9 and S.rel_err(G[kind + "_f"][t], f) < 1e-9, (kind, t)
+
+
+def _device(lib, tol):
+    rb = O.Robot("talos_like")
+    mh = _handler(lib)
+    # QP data of the first tick against the oracle's
+    ko = O.OracleKinoID(rb, O.talos_id_settings(rb, M.DT, admm_iters=100, admm_tol=-1.0, contact_motion_equality=True, **M.KINO), M.B)
+    kg = simple_mpc.KinodynamicsID(mh, M.DT, dict(M.KINO, contact_motion_equality=True), O.TALOS_EFFORT, O.TALOS_VMAX, batch=M.B, lib=lib, admm_iters=100,
+                                   admm_tol=-1.0)
+    X = G["equality_X"][0]
+    kg.solve(0.0, X[:, : rb.nq], X[:, rb.nq:])
+    n, m = ko.n, ko.m
+    for b in range(M.B):
+        H, g, C, l, u = ko.qp(b, X[b])
+        assert S.rel_err(H, kg.debug(5)[b][:n, :n]) < 1e-12 and S.rel_err(g, kg.debug(6)[b][:n]) < 1e-12
+        assert np.abs(C[n:] - kg.debug(7)[b][n:m, :n]).max() < 1e-11 * max(1.0, np.abs(C).max())
+        assert np.abs(np.clip(l, -1e9, 1e9) - np.clip(kg.debug(8)[b][:m], -1e9, 1e9)).max() < 1e-9 * max(1.0, np.abs(np.clip(l, -1e9, 1e9)).max())
+        assert np.abs(np.clip(u, -1e9, 1e9) - np.clip(kg.debug(9)[b][:m], -1e9, 1e9)).max() < 1e-9 * max(1.0, np.abs(np.clip(u, -1e9, 1e9)).max())
+    # golden replay, tick by tick from the recorded states
+    for kind, eq in (("cost", False), ("equality", True)):
+        k = simple_mpc.KinodynamicsID(mh, M.DT, dict(M.KINO, contact_motion_equality=eq), O.TALOS_EFFORT, O.TALOS_VMAX, batch=M.B, lib=lib, admm_iters=100,
+                                      admm_tol=-1.0)
+        for t in range(M.TICKS):
+            X = G[kind + "_X"][t]
+            tau = k.solve(0.0, X[:, : rb.nq], X[:, rb.nq:])
+            e = max(S.rel_err(G[kind + "_tau"][t], tau), S.rel_err(G[kind + "_a"][t], k.getAccelerations()), S.rel_err(G[kind + "_f"][t], k._f))
+            assert e < tol, (kind, t, e)
+    contact, w, com, feet = M.cent_targets(rb)
+    kc = simple_mpc.CentroidalID(mh, M.DT, M.CENT, O.TALOS_EFFORT, O.TALOS_VMAX, batch=M.B, lib=lib, admm_iters=100, admm_tol=-1.0)
+    kc.setTarget(com, np.zeros(3), feet, np.zeros((2, 3)), contact, w)
+    for t in range(M.TICKS):
+        X = G["cent_X"][t]
+        tau = kc.solve(0.0, X[:, : rb.nq], X[:, rb.nq:])
+        e = max(S.rel_err(G["cent_tau"][t], tau), S.rel_err(G["cent_a"][t], kc.getAccelerations()), S.rel_err(G["cent_f"][t], kc._f))
+        assert e < tol, ("cent", t, e)
+
+
+def test_emulated_kernels_follow_the_oracle_and_the_golden_vectors(built):
+    _device(S.emu_lib(), 1e-6)  # (100 fixed iterations from random states: the equality rows carry 1e3 rho, their rounding shows at 2e-7)
+
+
+@pytest.mark.gpu
+def test_hip_follows_the_oracle_and_the_golden_vectors(built):
+    _device(None, 1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_closed_loop_and_batch(built):
+    """300 ticks of the contactQuad_equality loop on the HIP library with the default stopping rule against the oracle; 256 robots give
+    bit-identical replicas."""
+    rb = O.Robot("talos_like")
+    mh = _handler(None)
+    B = 256
+    kw = dict(M.KINO, contact_motion_equality=True)
+    ko = O.OracleKinoID(rb, O.talos_id_settings(rb, M.DT, **kw), 1)
+    kg = simple_mpc.KinodynamicsID(mh, M.DT, kw, O.TALOS_EFFORT, O.TALOS_VMAX, batch=B)
+    x = rb.x_ref.copy()
+    for i in range(300):
+        to, ao, fo = ko.solve(x[None])
+        X = np.tile(x, (B, 1))
+        tg = kg.solve(0.0, X[:, : rb.nq], X[:, rb.nq:])
+        assert np.abs(tg - tg[0:1]).max() == 0.0
+        assert S.rel_err(to, tg[:1]) < 1e-4 and S.rel_err(ao, kg.getAccelerations()[:1]) < 1e-4, i
+        assert kg.getResiduals().max() < 1e-5
+        x = M.step(rb, x, ao[0])
