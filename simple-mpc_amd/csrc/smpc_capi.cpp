@@ -145,7 +145,11 @@ extern "C"
       const HostMpcSettings ms6 = host_mpc(mpc);
       return guarded([&] {
         std::unique_ptr<smpc_handle> h(new smpc_handle());
+#ifndef SMPC_KINO_ONLY
         h->full.reset(new FullEngine<KinoTalos>(robot, s, ms6, batch, gravity_arg, device_id));
+#else
+        throw std::runtime_error("SMPC_KINO_ONLY experiment build");
+#endif
         *out = h.release();
       });
     }
@@ -239,10 +243,15 @@ extern "C"
     const HostMpcSettings ms = host_mpc(mpc);
     return guarded([&] {
       std::unique_ptr<smpc_handle> h(new smpc_handle());
+#ifndef SMPC_KINO_ONLY
       if (quad)
         h->cent.reset(new CentEngine<FullTalos, CentTalos>(robot, cs, ms, batch, gravity_arg, device_id));
       else
         h->cent.reset(new CentEngineGo2(robot, cs, ms, batch, gravity_arg, device_id));
+#else
+      (void)quad;
+      throw std::runtime_error("SMPC_KINO_ONLY experiment build");
+#endif
       *out = h.release();
     });
   }
@@ -299,6 +308,9 @@ extern "C"
     const HostMpcSettings ms = host_mpc(mpc);
     return guarded([&] {
       std::unique_ptr<smpc_handle> h(new smpc_handle());
+#ifdef SMPC_KINO_ONLY
+      throw std::runtime_error("SMPC_KINO_ONLY experiment build");
+#else
       if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS && s.land_cstr && s.force_cone)
         h->full.reset(new FullEngine<FullGo2ConeLand>(robot, s, ms, batch, gravity_arg, device_id));
       else if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS && s.land_cstr)
@@ -313,6 +325,7 @@ extern "C"
         h->full.reset(new FullEngine<FullTalos>(robot, s, ms, batch, gravity_arg, device_id));
       else
         throw std::runtime_error("robot shape (njoints, nfeet, force_size) does not match a built kernel instantiation");
+#endif
       *out = h.release();
     });
   }
@@ -731,7 +744,12 @@ extern "C"
         out[i * 4 + k] = tr[(size_t)i * 4 + k];
     return n;
   }
-  int smpc_lq_size(const smpc_handle * h) { return (h && h->full) ? h->full->lq_size() : DimsGo2::LQ_STRIDE; }
+  // (size of what smpc_debug_get_lq returns: the row-major form of a kinodynamics knot)
+  int smpc_lq_size(const smpc_handle * h)
+  {
+    typedef DimsGo2 D;
+    return (h && h->full) ? h->full->lq_size() : (D::O_T - D::O_A) + D::NDX * D::NDX + D::NDX * D::NU + D::NU * D::NU + (D::O_vpd + D::NC - D::O_C);
+  }
   int smpc_set_early_exit_on_tol(smpc_handle * h, int on)
   {
     if (!h)
@@ -752,13 +770,25 @@ extern "C"
     if (!h || inst < 0 || inst >= h->eng->B || t < 0 || t >= h->eng->H)
       return fail(SMPC_ERR_INVALID, "Stage index exceeds stage vector size");
     return guarded([&] {
-      h->eng->get_linear(h->eng->buf.lq + ((size_t)inst * h->eng->H + t) * DimsGo2::LQ_STRIDE, DimsGo2::LQ_STRIDE, out);
-      // the derivative pass writes the upper 16x16 tiles of Q only (its readers take the upper triangle): mirror here
-      constexpr int n = DimsGo2::NDX;
-      double * Q = out + DimsGo2::O_Q;
+      // the device keeps [Q S; S^T R] as accumulator-layout tiles (Dims::O_T); returned in the documented row-major order
+      // A | B | Q | S | R | C | q | r | f | d | lx | lu | lpd | vpd
+      typedef DimsGo2 D;
+      std::vector<double> raw(D::LQ_STRIDE);
+      h->eng->get_linear(h->eng->buf.lq + ((size_t)inst * h->eng->H + t) * D::LQ_STRIDE, D::LQ_STRIDE, raw.data());
+      constexpr int n = D::NDX, m = D::NU;
+      double * o = out;
+      std::copy(raw.begin() + D::O_A, raw.begin() + D::O_T, o); // A | B
+      o += D::O_T - D::O_A;
       for (int i = 0; i < n; i++)
-        for (int j = 0; j < i; j++)
-          Q[i * n + j] = Q[j * n + i];
+        for (int j = 0; j < n; j++)
+          *o++ = raw[D::q_off(i, j)];
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < m; j++)
+          *o++ = raw[D::s_off(i, j)];
+      for (int i = 0; i < m; i++)
+        for (int j = 0; j < m; j++)
+          *o++ = raw[D::r_off(i, j)];
+      std::copy(raw.begin() + D::O_C, raw.begin() + D::O_vpd + D::NC, o);
     });
   }
   int smpc_debug_get_steps(smpc_handle * h, double * dxs, double * dus)
@@ -1089,6 +1119,9 @@ extern "C"
       hs.quad_points.assign(c->quad_contact_points, c->quad_contact_points + (size_t)robot->nfeet * 12);
     }
     return guarded([&] {
+#ifdef SMPC_KINO_ONLY
+      throw std::runtime_error("SMPC_KINO_ONLY experiment build");
+#endif
       if (!quad && robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF)
         *out = reinterpret_cast<smpc_id_handle *>(static_cast<IdEngineBase *>(new IdEngine<FullGo2>(robot, hs, batch, device_id)));
       else if (quad && robot->njoints == FullTalos::NJ && robot->nfeet == FullTalos::NF)

@@ -11,7 +11,7 @@
 //   riccati_dense_body  B blocks          backward sweep, wrench-cone multipliers pivoted explicitly
 //   cent6_forward_body  B blocks          (dx, du, dnu, dlam) and the directional derivative of the merit
 //   cent6_ls_body       B blocks          Armijo backtracking (lane = stage trial evaluations), step, regularisation update
-// Algorithm and constants: those of cent_step_body / the oracle (oracle/orc_proxddp.hpp, oracle/orc_cent.hpp).
+// Algorithm and constants: those of cent_step_body (smpc_cent_kernels.h), i.e. of the solver stack in DESIGN.md section 2.
 #pragma once
 #include "smpc_cent_kernels.h"
 #include "smpc_full_stage.h" // wrench_cone_entry, full_dynamics_phases (front end of a robot with any tree)

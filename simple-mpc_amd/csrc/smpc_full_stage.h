@@ -288,60 +288,7 @@ namespace smpc
     SMPC_LANES_END_WAVE
   }
 
-  // A (N x N, row-major, SPD) <- A^-1 in place: Schur complement of the bordered matrix [[A, I], [I, 0]] = -A^-1, by the symmetric
-  // block sweep of the Riccati kernels (wave_block_sweep, 4 x 4 pivot blocks, rank-4 updates on the matrix cores)
-  template <int N>
-  SMPC_DEV void fwave_spd_inverse(double * A, double * swp)
-  {
-    constexpr int NT = 64, NP4 = ((N + 3) / 4) * 4, NTI = (2 * NP4 + 15) / 16, LDW = 16 * NTI;
-    SMPC_ACC(t, NT, NTI * (NTI + 1) / 2);
-    SMPC_LANES(NT)
-    {
-      const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-      for (int I = 0; I < NTI; I++)
-#pragma unroll
-        for (int J = I; J < NTI; J++)
-#pragma unroll
-          for (int v = 0; v < 4; v++)
-          {
-            const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
-            const int r = row < col ? row : col, c = row < col ? col : row;
-            double val = 0.0;
-            if (c < N)
-              val = A[r * N + c];
-            else if (c < NP4)
-              val = r == c ? 1.0 : 0.0;       // padding pivots
-            else if (c < 2 * NP4 && r < NP4)
-              val = (c - NP4 == r) ? 1.0 : 0.0; // identity border
-            SMPC_ACCV(t, tix<NTI>(I, J), v) = val;
-          }
-    }
-    SMPC_LANES_END_WAVE
-    double * prof = nullptr;
-    long long tprev = 0;
-    wave_block_sweep<NT, NTI, false, 0, NP4 / 4>(t, swp, swp + 4 * LDW, prof, tprev);
-    SMPC_LANES(NT)
-    {
-      const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-      for (int I = NP4 / 16; I < NTI; I++)
-#pragma unroll
-        for (int J = I; J < NTI; J++)
-#pragma unroll
-          for (int v = 0; v < 4; v++)
-          {
-            const int row = 16 * I + lr + 4 * v - NP4, col = 16 * J + lc - NP4;
-            if (row >= 0 && row < N && col >= row && col < N)
-            {
-              const double val = -SMPC_ACCV(t, tix<NTI>(I, J), v);
-              A[row * N + col] = val;
-              A[col * N + row] = val;
-            }
-          }
-    }
-    SMPC_LANES_END_WAVE
-  }
+  // (fwave_spd_inverse: smpc_riccati_kino.h, beside the block sweep it is made of)
 
   // -------------------------------------------------------------------------------------------------------------
   // Kinematics, composites, joint-space inertia, contact rows, factorisations, proximal iteration, accelerations.

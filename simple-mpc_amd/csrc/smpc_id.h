@@ -765,7 +765,7 @@ namespace smpc
 
   // =====================================================================================================================
   // Flat feet (tsid::contacts::Contact6d; reference kinodynamics-id.cpp:41-49, 163-167, 204-208; centroidal-id.cpp:38-41): QP data and ADMM of the
-  // 52-variable / 74-general-row problem of a Talos-class biped.  Same formulation as the CPU checker (oracle/orc_id.hpp, "Robots with 6-D feet").
+  // 52-variable / 74-general-row problem of a Talos-class biped.  Formulation: DESIGN.md, "Robots with 6-D feet".
   // =====================================================================================================================
   SMPC_HD double id6_tgen(const double * quad, int f, int r, int c)
   { // force generator matrix T (6 x 12) of foot f: [I I I I ; [p_1]x .. [p_4]x]

@@ -621,21 +621,17 @@ namespace smpc
 #pragma unroll
           for (int v = 0; v < 4; v++)
           {
-            const int row = 16 * T3I[tt] + lr + 4 * v, col = 16 * T3J[tt] + lc;
+            // the knot keeps [Q S; S^T R] as tiles in this very layout (Dims::O_T): off-diagonal tiles are stored as they are, of a diagonal
+            // tile the upper triangle goes to its own place and to its mirror image (so that the tile is exactly symmetric for the sweep)
+            const int I = T3I[tt], J = T3J[tt];
             const double val = SMPC_ACCV(qacc, tt, v);
-            if (col < NDX)
+            double * tile = lq + D::O_T + (I * D::NTT - I * (I - 1) / 2 + (J - I)) * 256;
+            if (I != J)
+              tile[v * 64 + lane] = val;
+            else if (lr + 4 * v <= lc)
             {
-              if (row < NDX)
-              {
-                lq[D::O_Q + row * NDX + col] = val; // upper tiles only: every reader takes Q[min(i,j)][max(i,j)] there
-              }
-            }
-            else if (col < NDX + 16 * 3 - NDX && col < NDX + NU)
-            {
-              if (row < NDX)
-                lq[D::O_S + row * NU + col - NDX] = val;
-              else
-                lq[D::O_R + (row - NDX) * NU + col - NDX] = val;
+              tile[v * 64 + lane] = val;
+              tile[(lc >> 2) * 64 + (lc & 3) * 16 + lr + 4 * v] = val; // entry (lc, lr + 4 v) of the tile
             }
           }
         // columns / rows of the joint accelerations (u indices >= UC): no Jacobian entries.  Their S columns (zero)
@@ -643,7 +639,7 @@ namespace smpc
         // carries the current primal regularisation
         constexpr int UC = 16 * 3 - NDX; // u columns covered by the tiles
         if (lane >= UC && lane < NU)
-          lq[D::O_R + lane * NU + lane] = (md.w_diag ? md.wud[lane] : mg.w_u[lane * NU + lane]) + preg;
+          lq[D::r_off(lane, lane)] = (md.w_diag ? md.wud[lane] : mg.w_u[lane * NU + lane]) + preg;
       }
       SMPC_LANES_END_WAVE
     }
@@ -1043,16 +1039,25 @@ namespace smpc
     // joint-box rows of C
     SMPC_LANES(NT)
     {
+      // (first the whole tile block: the padding entries beyond the problem are loaded by the sweep and must be finite)
+      for (int idx = lane; idx < D::N_T; idx += NT)
+        lq[D::O_T + idx] = 0.0;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    {
       constexpr int UC = 16 * 3 - NDX, NA = D::NA;
       const DevModel<D> & mg = *ka.b.model;
-      for (int idx = lane; idx < NDX * NU; idx += NT)
-        if (idx % NU >= UC)
-          lq[D::O_S + idx] = 0.0;
       for (int idx = lane; idx < NU * NU; idx += NT)
       {
         const int i = idx / NU, j = idx % NU;
         if ((i >= UC || j >= UC) && i != j)
-          lq[D::O_R + idx] = mg.w_u[idx];
+        { // off-diagonal weights of the joint accelerations; inside a diagonal tile both triangles are kept
+          if (i < j)
+            lq[D::r_off(i, j)] = mg.w_u[idx];
+          else if ((NDX + i) / 16 == (NDX + j) / 16)
+            lq[D::O_T + ((((NDX + j) / 16) * D::NTT - ((NDX + j) / 16) * ((NDX + j) / 16 - 1) / 2) * 4 + ((NDX + i) % 16) / 4) * 64 + (((NDX + i) % 16) % 4) * 16 + (NDX + j) % 16] = mg.w_u[idx];
+        }
       }
       for (int idx = lane; idx < NA * NDX; idx += NT)
         lq[D::O_C + idx] = 0.0;

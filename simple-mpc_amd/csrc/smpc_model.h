@@ -27,10 +27,22 @@ namespace smpc
     // LQ knot block (doubles), one per (instance, stage)
     static constexpr int O_A = 0;
     static constexpr int O_B = O_A + NDX * NDX;
-    static constexpr int O_Q = O_B + NDX * NU;
-    static constexpr int O_S = O_Q + NDX * NDX;
-    static constexpr int O_R = O_S + NDX * NU;
-    static constexpr int O_C = O_R + NU * NU;
+    // [Q S; S^T R] as the UPPER 16 x 16 TILES of the (x | u) grid in the accumulator layout of v_mfma_f64_16x16x4 -- tile (I, J), I <= J, element v
+    // of lane l holds entry (16 I + (l >> 4) + 4 v, 16 J + (l & 15)), at O_T + ((tile * 4 + v) * 64 + l): the derivative pass stores its accumulator
+    // registers as they are (512-byte runs) and the Riccati sweep loads its own (no per-element address arithmetic on either side).  Diagonal tiles
+    // hold both triangles (the writer mirrors the upper one).  Readers that want single entries: q_off / s_off / r_off.
+    static constexpr int NXU = NDX + NU;
+    static constexpr int NTT = (NXU + 15) / 16;                       // tile rows / columns of the grid
+    static constexpr int O_T = O_B + NDX * NU;
+    static constexpr int N_T = NTT * (NTT + 1) / 2 * 256;
+    SMPC_HD static constexpr int t_off(int r, int c)                  // entry (r, c) of the grid, r / 16 <= c / 16
+    {
+      return O_T + (((r / 16) * NTT - (r / 16) * (r / 16 - 1) / 2 + (c / 16 - r / 16)) * 4 + (r % 16) / 4) * 64 + ((r % 16) % 4) * 16 + c % 16;
+    }
+    SMPC_HD static constexpr int q_off(int i, int j) { return i <= j ? t_off(i, j) : t_off(j, i); }      // Q(i, j)
+    SMPC_HD static constexpr int s_off(int i, int j) { return t_off(i, NDX + j); }                        // S(i, j)
+    SMPC_HD static constexpr int r_off(int i, int j) { return i <= j ? t_off(NDX + i, NDX + j) : t_off(NDX + j, NDX + i); } // R(i, j)
+    static constexpr int O_C = O_T + N_T;
     static constexpr int O_q = O_C + NC * NDX;
     static constexpr int O_r = O_q + NDX;
     static constexpr int O_f = O_r + NU;

@@ -246,6 +246,61 @@ namespace smpc
     // (the last panel defers nothing)
   }
 
+  // A (N x N, row-major, SPD) <- A^-1 in place: Schur complement of the bordered matrix [[A, I], [I, 0]] = -A^-1, by the symmetric
+  // block sweep of the Riccati kernels (wave_block_sweep, 4 x 4 pivot blocks, rank-4 updates on the matrix cores)
+  template <int N>
+  SMPC_DEV void fwave_spd_inverse(double * A, double * swp)
+  {
+    constexpr int NT = 64, NP4 = ((N + 3) / 4) * 4, NTI = (2 * NP4 + 15) / 16, LDW = 16 * NTI;
+    SMPC_ACC(t, NT, NTI * (NTI + 1) / 2);
+    SMPC_LANES(NT)
+    {
+      const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+      for (int I = 0; I < NTI; I++)
+#pragma unroll
+        for (int J = I; J < NTI; J++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+            const int r = row < col ? row : col, c = row < col ? col : row;
+            double val = 0.0;
+            if (c < N)
+              val = A[r * N + c];
+            else if (c < NP4)
+              val = r == c ? 1.0 : 0.0;       // padding pivots
+            else if (c < 2 * NP4 && r < NP4)
+              val = (c - NP4 == r) ? 1.0 : 0.0; // identity border
+            SMPC_ACCV(t, tix<NTI>(I, J), v) = val;
+          }
+    }
+    SMPC_LANES_END_WAVE
+    double * prof = nullptr;
+    long long tprev = 0;
+    wave_block_sweep<NT, NTI, false, 0, NP4 / 4>(t, swp, swp + 4 * LDW, prof, tprev);
+    SMPC_LANES(NT)
+    {
+      const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+      for (int I = NP4 / 16; I < NTI; I++)
+#pragma unroll
+        for (int J = I; J < NTI; J++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            const int row = 16 * I + lr + 4 * v - NP4, col = 16 * J + lc - NP4;
+            if (row >= 0 && row < N && col >= row && col < N)
+            {
+              const double val = -SMPC_ACCV(t, tix<NTI>(I, J), v);
+              A[row * N + col] = val;
+              A[col * N + row] = val;
+            }
+          }
+    }
+    SMPC_LANES_END_WAVE
+  }
+
   template <class D>
   struct RiccatiKinoLds
   {
@@ -328,7 +383,7 @@ namespace smpc
         double acc = s.p[lane];
 #pragma unroll 4
         for (int j = 0; j < NDX; j++)
-          acc += s.P[lane * NDX + j] * s.f[j];
+          acc += s.P[j * NDX + lane] * s.f[j]; // (P is symmetric: along the row of j the lanes read consecutive addresses -- conflict-free)
         s.pt0[lane] = acc;
       }
       SMPC_LANES_END_WAVE
@@ -377,7 +432,7 @@ namespace smpc
         }
         SMPC_LANES_END_WAVE
         prof_tick(prof, 3, tprev);
-        wave_block_sweep<NT, 5, false, 0, NDX / 4>(t1, sw1, sw1 + RiccatiKinoLds<D>::SWP, prof, tprev);
+wave_block_sweep<NT, 5, false, 0, NDX / 4>(t1, sw1, sw1 + RiccatiKinoLds<D>::SWP, prof, tprev);
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
@@ -414,14 +469,9 @@ namespace smpc
 #pragma unroll
           for (int v = 0; v < 4; v++)
           {
-            const int row = 16 * T4I[tt] + lr + 4 * v, col = 16 * T4J[tt] + lc;
-            const int r0 = row < col ? row : col, c0 = row < col ? col : row;
-            const bool valid = c0 < NXU;
-            const int r = valid ? r0 : 0, c = valid ? c0 : 0;
-            const int off = c < NDX ? D::O_Q + r * NDX + c : (r < NDX ? D::O_S + r * NU + c - NDX : D::O_R + (r - NDX) * NU + c - NDX);
-            // padding rows / cols (>= NXU) load Q[0][0]: an accumulator entry only ever feeds itself and those are never
-            // read back, so they need no masking (a select on the loaded value would stall the prefetch here)
-            SMPC_ACCV(hacc, tt, v) = lq[off];
+            // the knot keeps the tiles in this layout (Dims::O_T): one 512-byte run per accumulator register, no address arithmetic
+            // (padding entries beyond the problem are zeros written once by lq_init_body; they only ever feed themselves)
+            SMPC_ACCV(hacc, tt, v) = lq[D::O_T + (tt * 4 + v) * 64 + lane];
           }
       }
       SMPC_LANES_END_WAVE
@@ -1072,13 +1122,12 @@ namespace smpc
         const int k = lane - 48;
         const double * lq = b.lq + lt * D::LQ_STRIDE;
         double acc = lq[D::O_r + k];
-        const double * Rk = lq + D::O_R + k * NU;
 #pragma unroll 4
         for (int j = 0; j < NU; j++)
-          acc += Rk[j] * s.du[j];
+          acc += lq[D::r_off(k, j)] * s.du[j];
 #pragma unroll 4
         for (int i = 0; i < NDX; i++)
-          acc += lq[D::O_S + i * NU + k] * s.dx[i];
+          acc += lq[D::s_off(i, k)] * s.dx[i];
         SMPC_PLV(gpart) = acc;
       }
       SMPC_LANES_END_WAVE

@@ -244,10 +244,10 @@ namespace smpc
       SMPC_LANES(NT)
       {
         mm_tn<NDX, NXU, NDX, 3, 3, NT>(
-          s.AB, NXU, s.MT, NXU, lane, [&](int i, int j) { return j < NDX ? lq[D::O_Q + (i < j ? i : j) * NDX + (i < j ? j : i)] : lq[D::O_S + i * NU + j - NDX]; }, // Q: upper triangle is authoritative
+          s.AB, NXU, s.MT, NXU, lane, [&](int i, int j) { return j < NDX ? lq[D::q_off(i, j)] : lq[D::s_off(i, j - NDX)]; }, // (tile layout of the knot, Dims::O_T)
           [&](int i, int j, double v) { s.QS[i * NXU + j] = v; });
         mm_tn<NU, NU, NDX, 3, 3, NT>(
-          s.AB + NDX, NXU, s.MT + NDX, NXU, lane, [&](int i, int j) { return lq[D::O_R + i * NU + j]; },
+          s.AB + NDX, NXU, s.MT + NDX, NXU, lane, [&](int i, int j) { return lq[D::r_off(i, j)]; },
           [&](int i, int j, double v) { s.Rh[i * NU + j] = v; });
         if (lane < NXU)
         {

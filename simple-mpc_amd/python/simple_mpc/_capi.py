@@ -162,7 +162,7 @@ SYMBOLS = [
 
 class SmpcLib:
     def __init__(self, path=None):
-        path = path or DEFAULT_LIB
+        path = path or os.environ.get("SMPC_LIB_PATH") or DEFAULT_LIB  # (SMPC_LIB_PATH: experiment builds, tools/variant_build.sh)
         if not os.path.exists(path):
             raise RuntimeError(
                 "simple_mpc: native library %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
