@@ -138,7 +138,7 @@ def rooflines(kt, B, H, ndx, nu, nc, nx, at_record_size):
         avgt = kt["tree"][0] / kt["tree"][1] * 1e-3 if two else 0.0
         avg = avg2 + avgt
         fl = fc.get("deriv_flops_per_stage")
-        ho = 8 * 619 if two else 0  # hand-over block written by the tree pass and read by the derivative kernel (EvLayout)
+        ho = 8 * 688 if two else 0  # hand-over stream written by the tree pass and read by the derivative kernel (EvStream::STRIDE on Go2: 64 + 12 * 32 + 4 * 16 + 176)
         e = both_bounds(None if fl is None else B * H * fl, B * H * (knot_w + iter_r + 2 * ho), avg, "mfma")
         kname = "deriv2_body" if two else "deriv_body"
         tr, src = pmc_traffic(kname, at_record_size)
@@ -650,6 +650,8 @@ def main():
                     "whose per-kernel means must be those of the headline launches)")
     ap.add_argument("--sync-steps", action="store_true", help="host synchronisation after every control step (default: the closed loop is one in-order queue "
                     "on the handle's stream, synchronised only at the ends of the timed region)")
+    ap.add_argument("--no-gather", action="store_true", help="leave the return set [x1 | u0 | K0] of every control step on the devices (default: every step "
+                    "packs it on the device and moves it, overlapped with the next step, into ONE pinned host buffer on rank 0)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch path (gloo + emulated kernel bodies): not a measurement")
     ap.add_argument("--workload", default="kinodynamics", choices=["kinodynamics", "centroidal", "fulldynamics", "talos"],
                     help="kinodynamics = the headline metric (with the other single-GPU configurations measured briefly beside it at 1 GPU)")
@@ -752,8 +754,59 @@ def main():
                 q.div_(q.norm(dim=1, keepdim=True))
             step_sync(gm)
 
+    # ---- return set of every control step -> one pinned host buffer on rank 0, inside the timed region ----
+    # What leaves the devices per step is what the controllers consume: rows [x1 | u0 | K0] (nx + nu + nu ndx doubles per instance).  Each rank
+    # packs its rows on the device (one kernel on the solve stream), then a SIDE stream moves them while the next control step runs: ranks > 0
+    # send theirs to rank 0 (torch.distributed gather = RCCL send / recv over xGMI -- the one exchange this path has, off the solve path), rank
+    # 0 copies the whole [N B][row] block into pinned memory.  Two slots: the solve stream waits for the move of step k - 2 before it repacks.
+    row = gm.nx + gm.nu + gm.nu * gm.ndx
+    gather_on = not args.no_gather and args.streams == 1
+    g_events = []
+    if gather_on and not dry:
+        main_s = torch.cuda.ExternalStream(gm.stream(), device=dev)
+        side_s = torch.cuda.Stream(device=dev)
+        pack = [torch.empty((B, row), dtype=torch.float64, device=dev) for _ in range(2)]
+        ev_packed = [torch.cuda.Event() for _ in range(2)]
+        ev_moved = [torch.cuda.Event() for _ in range(2)]
+        if rank == 0:
+            recv = [torch.empty((world, B, row), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+            pinned = torch.empty((2, world * B, row), dtype=torch.float64).pin_memory()
+    elif gather_on:
+        pack_h = np.zeros((B, row))
+        gathered_h = [torch.zeros((B, row), dtype=torch.float64) for _ in range(world)] if rank == 0 else None
+    step_no = [0]
+
+    def emit(timed):
+        if not gather_on:
+            return
+        if dry:  # rehearsal of the same exchange on CPU tensors (gloo), no streams
+            gm.gather_outputs_device(pack_h.ctypes.data)
+            gm.wait()
+            if dist is not None:
+                dist.gather(torch.from_numpy(pack_h), gather_list=gathered_h, dst=0)
+            return
+        slot = step_no[0] & 1
+        step_no[0] += 1
+        main_s.wait_event(ev_moved[slot])
+        gm.gather_outputs_device(pack[slot].data_ptr())
+        ev_packed[slot].record(main_s)
+        side_s.wait_event(ev_packed[slot])
+        with torch.cuda.stream(side_s):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side_s)
+            if world > 1:
+                dist.gather(pack[slot], gather_list=[recv[slot][r] for r in range(world)] if rank == 0 else None, dst=0)
+            if rank == 0:
+                pinned[slot].copy_(recv[slot].view(world * B, row) if world > 1 else pack[slot], non_blocking=True)
+            if timed:
+                e1.record(side_s)
+                g_events.append((e0, e1))
+            ev_moved[slot].record(side_s)
+
     for _ in range(args.warmup):
         step()
+        emit(False)
     profile = not args.no_profile and not dry
     if profile:
         gm.set_profiling(True)
@@ -764,10 +817,16 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        emit(True)
     if dist is not None:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    gather_ms = sum(a.elapsed_time(b) for a, b in g_events) / max(1, len(g_events)) if g_events else None
+    if gather_on and not dry and rank == 0:
+        # the last step's rows are in the pinned buffer, every rank's block in place
+        last = pinned[(step_no[0] - 1) & 1]
+        gather_ok = bool(torch.isfinite(last).all()) and bool((last.view(world, B, row)[:, :, 3:7].norm(dim=2) - 1).abs().max() < 1e-9)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -802,6 +861,12 @@ def main():
                 "finite": ok,
             },
         }
+        if gather_on:
+            out["gather"] = {"what": "rows [x1 | u0 | K0] of every instance, every control step, into one pinned host buffer on rank 0 (inside the timed region, "
+                             "on a side stream: overlaps the next step)", "row_doubles": row, "bytes_per_step": world * B * row * 8,
+                             "mode": "rehearsal (gloo, host tensors)" if dry else ("device pack + RCCL gather to rank 0 + D2H" if world > 1 else "device pack + D2H")}
+            if gather_ms is not None:
+                out["gather"].update({"side_stream_ms_per_step": gather_ms, "share_of_step": gather_ms / (1e3 * dt / args.steps), "rows_ok": gather_ok})
         if dry:
             out["data"] = "synthetic (DRY RUN on CPU: emulated kernel bodies + gloo, launch-path rehearsal, not a measurement)"
         if kt:
@@ -846,6 +911,11 @@ def main():
             other["control_stack"] = control_stack_line(B, local_rank)
             other["single_robot_latency"] = single_robot_latency(args.iters, local_rank)
             out["other_workloads"] = other
+            # the other BASELINE configurations as flat keys (configs[1], configs[3]; configs[0] = cpu_baseline.cfg1_k1_b1; configs[4] = --gpus 8)
+            out["cfg2_centroidal_steps_per_s"] = other["centroidal"]["value"]
+            out["cfg4_talos_fulldynamics_steps_per_s"] = other["fulldynamics_talos"]["value"]
+            out["go2_fulldynamics_steps_per_s"] = other["fulldynamics_go2"]["value"]
+            out["inverse_dynamics_qps_per_s"] = other["inverse_dynamics_qp"]["value"]
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

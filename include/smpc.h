@@ -219,6 +219,10 @@ int smpc_iterate_async(smpc_handle * h, const double * X);
  * side ("async D2H into one pinned host buffer").  Asynchronous on the handle's stream: smpc_wait completes it.
  * Kinodynamics handles. */
 int smpc_gather_outputs(smpc_handle * h, double * out, size_t row_doubles);
+/* The same rows packed into a DEVICE buffer [batch][row_doubles] by one kernel on the handle's stream, for a caller that moves them itself:
+ * a collective towards the process that owns the controllers (one process per device: torch.distributed gather over RCCL), a peer copy, or
+ * one copy into pinned memory from a side stream so that the transfer overlaps the next control step.  Kinodynamics handles. */
+int smpc_gather_outputs_device(smpc_handle * h, double * out_device, size_t row_doubles);
 /* Checkpoint / resume (the reference has none; a batched simulator needs it to roll back or migrate a batch).
  * The state is everything a later smpc_iterate depends on: iterate, multipliers, swing trajectories, references, velocity
  * commands, gait bookkeeping -- not the feedback gains of the last solve (the next iterate recomputes them).

@@ -85,6 +85,13 @@ namespace smpc
 {
   // 16-byte store the compiler does not track: a known store makes a non-inlined function wait for the write to complete before it returns
   // (1 .. 2 us); for data nothing in the kernel reads back.  dst: 16-byte aligned.
+  // Valid under three conditions, all of them true here and none of them visible to the compiler: (1) memory operations retire through
+  // ONE in-order counter (vmcnt of the gfx9 family: the s_endpgm drain covers this store), (2) NO instruction of the same kernel reads
+  // the stored bytes back (the compiler would not wait for the store), (3) `s_nop 1` covers the wait state a > 64-bit store needs before
+  // its data registers are overwritten.  A target with split load / store counters must not compile this.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "store2_nowait: inline global_store_dwordx4 relies on the gfx950 (gfx9 family) single in-order vmcnt"
+#endif
   __device__ __forceinline__ void store2_nowait(double * dst, double v0, double v1)
   {
     typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -158,6 +165,7 @@ namespace smpc
     SMPC_HIP(hipDeviceSynchronize());
     return p;
   }
+  inline void dev_clear_error() { (void)hipGetLastError(); } // after a failed allocation that the caller handles
   inline void dev_free(void * p)
   {
     if (p)

@@ -521,6 +521,14 @@ extern "C"
       return fail(SMPC_ERR_INVALID, KINO_ONLY);
     return guarded([&] { h->eng->gather_outputs_async(out, row_doubles); });
   }
+  int smpc_gather_outputs_device(smpc_handle * h, double * out_device, size_t row_doubles)
+  {
+    if (!h || !out_device)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (!h->eng)
+      return fail(SMPC_ERR_INVALID, KINO_ONLY);
+    return guarded([&] { h->eng->gather_outputs_device(out_device, row_doubles); });
+  }
   int smpc_iterate_device(smpc_handle * h, const double * Xd)
   {
     if (!h || !Xd)

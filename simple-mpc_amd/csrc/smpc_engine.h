@@ -372,6 +372,7 @@ namespace smpc
     // The derivative pass starts from the lane-per-problem evaluation too (lane_tree_body + deriv2_body: 0.27 + 3.1 ms per launch at
     // B = 4096 against 4.3 - 4.7 ms for the one-kernel path); SMPC_LANE_DERIV=0: the one-kernel path (A/B comparison)
     bool lane_deriv = !(std::getenv("SMPC_LANE_DERIV") && std::atoi(std::getenv("SMPC_LANE_DERIV")) == 0);
+    size_t handover_bytes = 0; // device memory of the lane hand-over (tiles + stream)
     bool lane_eval = !(std::getenv("SMPC_LANE_EVAL") && std::atoi(std::getenv("SMPC_LANE_EVAL")) == 0);
     bool lane_stream = !(std::getenv("SMPC_LANE_STREAM") && std::atoi(std::getenv("SMPC_LANE_STREAM")) == 0);
     bool stream_order_recorded = false;
@@ -495,13 +496,34 @@ namespace smpc
       buf.gains = dalloc(BH * (size_t)std::max((int)D::G_STRIDE, (int)GainsK<D>::STRIDE));
       if (lane_eval && m.lane_slots > 0 && !ks.terminal_constraint && !ks.force_cone && !ks.land_cstr)
       {
-        buf.ev = dalloc((((size_t)B + EV_LS - 1) / EV_LS) * (H + 1) * ev_tile_doubles<D>());
+        // hand-over of the lane-per-problem evaluation.  With the stream (derivative pass: per-problem contiguous run, 688 doubles per
+        // problem on Go2) the tiles hold the line-search heads only; without it (SMPC_LANE_STREAM=0, or no memory for it) every field.
+        // A failed allocation falls back one level -- stream -> tiles -> the one-kernel evaluation -- instead of failing the handle.
         // (the flush addresses a problem's block by a 32-bit offset in doubles: 34 GB of stream -- B = 134 000 at H = 50)
+        const size_t tiles = (((size_t)B + EV_LS - 1) / EV_LS) * (H + 1);
+        auto try_alloc = [&](size_t doubles) -> double * {
+          try
+          {
+            return dalloc(doubles);
+          }
+          catch (const std::exception &)
+          {
+            dev_clear_error();
+            return nullptr;
+          }
+        };
         if (lane_deriv && lane_stream && (size_t)B * (H + 1) * EvStream<D>::STRIDE < ((size_t)1 << 32))
-        { // derivative pass: per-problem contiguous hand-over (SMPC_LANE_STREAM=0: the strided tile)
-          buf.evd = dalloc((size_t)B * (H + 1) * EvStream<D>::STRIDE);
-          buf.ev_order = (int *)dev_alloc((size_t)EvStream<D>::STRIDE * sizeof(int));
+          buf.evd = try_alloc((size_t)B * (H + 1) * EvStream<D>::STRIDE);
+        buf.ev_tile = ev_tile_doubles<D>(buf.evd != nullptr);
+        buf.ev = try_alloc(tiles * buf.ev_tile);
+        if (buf.ev == nullptr && buf.evd != nullptr)
+        {
+          dev_free(buf.evd);
+          buf.evd = nullptr;
         }
+        if (buf.evd != nullptr)
+          buf.ev_order = (int *)dev_alloc((size_t)EvStream<D>::STRIDE * sizeof(int));
+        handover_bytes = (buf.ev ? tiles * buf.ev_tile : 0) * sizeof(double) + (buf.evd ? (size_t)B * (H + 1) * EvStream<D>::STRIDE * sizeof(double) : 0);
       }
       buf.QN = dalloc((size_t)B * D::NDX * D::NDX);
       buf.qN = dalloc((size_t)B * D::NDX);
@@ -1352,6 +1374,24 @@ namespace smpc
         for (int i = 0; i < D::NU; i++) // dense sweep: rows of [K k] are NDX + 1 apart
           d2h_2d(out + D::NX + D::NU + (size_t)i * D::NDX, dp, buf.gains + D::G_K + (size_t)i * (D::NDX + 1), (size_t)H * D::G_STRIDE * sizeof(double),
                  D::NDX * sizeof(double), B, stream);
+    }
+    // the same rows packed into a DEVICE buffer (one kernel), for a caller that moves them itself: a collective towards the rank that
+    // owns the controllers, or one copy into pinned memory from a side stream.  Asynchronous on the engine's stream.
+    void gather_outputs_device(double * out_dev, size_t row_doubles)
+    {
+      set_device(device_id);
+      if (row_doubles < (size_t)GATHER_ROW)
+        throw std::runtime_error("smpc_gather_outputs_device: the row stride is smaller than nx + nu + nu * ndx");
+      PackOutArgs<D> pa;
+      pa.b = buf;
+      pa.s1 = ring_slot(head, 1, R);
+      pa.s0 = ring_slot(head, 0, R);
+      pa.R = R;
+      pa.g_off = structured_riccati ? GainsK<D>::G_W : D::G_K;
+      pa.g_str = structured_riccati ? GainsK<D>::STRIDE : D::G_STRIDE;
+      pa.row = row_doubles;
+      pa.out = out_dev;
+      launch<PackOutArgs<D>, pack_outputs_body<D>, 64>(B, stream, pa);
     }
     // xs[t] of every instance -> dense device buffer [B][NX], asynchronous on the engine's stream
     void gather_x_device(int t, double * out_dev)

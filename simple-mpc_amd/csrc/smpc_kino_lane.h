@@ -99,17 +99,18 @@ namespace smpc
   };
   // doubles from one tile to the next: the rows of a tile plus an odd number of 128-byte lines, so that the same field of different
   // tiles (what the wavefronts of a launch write at about the same time) does not map to the same memory channels
+  // (heads_only: the tile of a handle whose derivative fields travel in the stream -- the [LS_N][HEAD] heads, which come first, are all it holds)
   template <class D>
-  SMPC_HD constexpr size_t ev_tile_doubles()
+  SMPC_HD constexpr size_t ev_tile_doubles(bool heads_only = false)
   {
-    return (size_t)EvLayout<D>::STRIDE * EV_LS + 9 * 16;
+    return (size_t)(heads_only ? ((EvLayout<D>::O_S + 7) / 8) * 8 : EvLayout<D>::STRIDE) * EV_LS + 9 * 16;
   }
   template <class D>
   SMPC_HD LaneBlk lane_block(const Buffers<D> & b, int inst, int t)
   {
     // tile = (group of 64 consecutive instances, stage): exactly the 64 problems one wavefront of lane_tree_body evaluates
     const size_t gi = (size_t)(b.ev_inst0 + inst);
-    return LaneBlk{b.ev + ((gi / EV_LS) * (b.H + 1) + t) * ev_tile_doubles<D>() + gi % EV_LS};
+    return LaneBlk{b.ev + ((gi / EV_LS) * (b.H + 1) + t) * b.ev_tile + gi % EV_LS};
   }
   // Block index -> problem index of the wavefront-per-problem kernels that READ the tiles (one field per lane, 512 bytes apart: a
   // 64-byte sector holds the same field of 8 neighbouring problems).  The hardware deals consecutive workgroups round-robin to the 8
@@ -238,6 +239,7 @@ namespace smpc
   // Stream hand-over, device side.  Every lane parks the fields it produces in its own EV_CH (+1 pad) doubles of the parking area
   // (lane-major: park[lane * EV_PP + k]); when EV_CH are there the wavefront flushes them transposed: lane -> (problem q * 8 + lane / 8,
   // fields 2 (lane % 8), + 1), i.e. eight problems' 128-byte runs per store instruction.  Not inlined: reached from every store site.
+  // INVARIANT: nothing in lane_tree_body reads `evd` back -- the stores are untracked (store2_nowait); the reader is the next kernel.
   constexpr int EV_PP = EV_CH + 1;
   template <class D>
   SMPC_DEV_NOINLINE void ev_stream_flush(const double * park, const unsigned * poff, double * evd, int np, int c0, int lane)

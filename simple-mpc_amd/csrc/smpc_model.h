@@ -147,6 +147,7 @@ namespace smpc
     // working set of the evaluating lane and the hand-over to the derivative kernel.  nullptr: the handle does not use it.
     double * ev = nullptr;
     int ev_inst0 = 0; // first instance of this view of the batch (the blocks are tiled over the whole batch)
+    size_t ev_tile = 0; // doubles from one tile of `ev` to the next (ev_tile_doubles: all fields, or the heads only when the stream carries the rest)
     // derivative pass: the hand-over of a problem as one contiguous run [B][H+1][EvStream::STRIDE] in the order the tree kernel produces its
     // fields, and that order (ev_order[position] = field id of EvLayout, -1: padding; recorded once by the kernel itself).  nullptr: tiles.
     double * evd = nullptr;

@@ -1244,4 +1244,38 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4>(t1, sw1, sw1 + RiccatiKinoLds<D>::SWP
     }
     SMPC_LANES_END_WAVE
   }
+
+  // Return set of a control step, packed on the device: row [x1 (NX) | u0 (NU) | K0 (NU x NDX)] per instance, `row` doubles apart (what a
+  // controller consumes).  One block of 64 lanes per instance.
+  template <class D>
+  struct PackOutArgs
+  {
+    Buffers<D> b;
+    int s1, s0;        // ring slots of xs[1], us[0]
+    int R;             // ring length
+    int g_off, g_str;  // [K k] rows (NDX + 1 apart) of stage 0 inside an instance's gains; doubles per (instance, stage)
+    size_t row;
+    double * out;
+  };
+  template <class D>
+  SMPC_DEV void pack_outputs_body(const PackOutArgs<D> & pa, int inst)
+  {
+    constexpr int NT = 64;
+    constexpr int NDX = D::NDX, NU = D::NU, NX = D::NX;
+    const Buffers<D> & b = pa.b;
+    const double * g = b.gains + (size_t)inst * b.H * pa.g_str + pa.g_off;
+    const double * x = b.xs + ((size_t)inst * pa.R + pa.s1) * NX;
+    const double * u = b.us + ((size_t)inst * pa.R + pa.s0) * NU;
+    double * out = pa.out + (size_t)inst * pa.row;
+    SMPC_LANES(NT)
+    {
+      for (int i = lane; i < NX; i += NT)
+        out[i] = x[i];
+      for (int i = lane; i < NU; i += NT)
+        out[NX + i] = u[i];
+      for (int i = lane; i < NU * NDX; i += NT)
+        out[NX + NU + i] = g[(i / NDX) * (NDX + 1) + i % NDX];
+    }
+    SMPC_LANES_END_WAVE
+  }
 } // namespace smpc

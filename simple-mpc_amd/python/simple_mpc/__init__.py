@@ -758,6 +758,7 @@ class BatchedMPC:
 
     def wait(self):
         self._lib.check(self._lib.L.smpc_wait(self._h))
+        self._out_async = None
 
     def stream(self):
         """The handle's hipStream_t as an integer (0 in the CPU test build): torch.cuda.ExternalStream(mpc.stream()) puts a caller's device work
@@ -778,7 +779,14 @@ class BatchedMPC:
         row = self.nx + self.nu + self.nu * self.ndx
         if out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"] or out.ndim != 2 or out.shape[1] < row or out.shape[0] < first_row + self.B:
             raise RuntimeError("out must be a C-contiguous float64 array [>= first_row + batch, >= nx + nu + nu * ndx]")
+        assert out.strides == (out.shape[1] * 8, 8)
+        self._out_async = out  # the copies land after this call returns: the buffer lives until the next gather / wait()
         self._lib.check(self._lib.L.smpc_gather_outputs(self._h, C.c_void_p(out.ctypes.data + first_row * out.shape[1] * 8), out.shape[1]))
+
+    def gather_outputs_device(self, device_ptr, row_doubles=None):
+        """The same rows packed into a device buffer [batch][row_doubles] (one kernel on the handle's stream)."""
+        row = self.nx + self.nu + self.nu * self.ndx
+        self._lib.check(self._lib.L.smpc_gather_outputs_device(self._h, C.c_void_p(int(device_ptr)), int(row_doubles or row)))
 
     def setEarlyExitOnTol(self, on=True):
         """SolverProxDDP's convergence test inside iterate (reference src/mpc.cpp:43,212): an instance converged to settings TOL at the

@@ -82,6 +82,7 @@ namespace smpc
       throw std::runtime_error("emu: out of memory");
     return p;
   }
+  inline void dev_clear_error() {}
   inline void dev_free(void * p) { std::free(p); }
   inline void h2d(void * dst, const void * src, size_t bytes, stream_t) { std::memcpy(dst, src, bytes); }
   inline void d2h(void * dst, const void * src, size_t bytes, stream_t) { std::memcpy(dst, src, bytes); }

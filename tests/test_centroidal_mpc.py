@@ -246,9 +246,27 @@ def test_gpu_full_size_properties(built):
     gm, rb, _, _ = S.make_cent_product(B, max_iters=3)
     gm.generateCycleHorizon(O.trot_cycle())
     gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
-    X = np.tile(S.random_states(rb, 64), (B // 64, 1))
+    # the 64 distinct instances of the batch, solved by the oracle beside the full-size launch (same cold solve, same measured states)
+    om, _, _ = S.make_cent_oracle(64, max_iters=3)
+    om.generateCycleHorizon(O.trot_cycle())
+    om.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X64 = S.random_states(rb, 64)
+    X = np.tile(X64, (B // 64, 1))
+    worst = 0.0
     for _ in range(4):
         gm.iterate(X)
+        om.iterate(X64)
+        e = S.rel_err(om.xs, gm.xs[:64])
+        worst = max(worst, e)
+        assert e < TOL and S.rel_err(om.us, gm.us[:64]) < 10 * TOL and S.rel_err(om.K0, gm.K0[:64]) < 10 * TOL
+        # random measured states make most of these instances backtrack; where the Armijo test is decided by the last bits either
+        # neighbour is accepted (S.alphas_agree), everywhere else the decisions are identical
+        class _First64:
+            info = gm.info[:64]
+
+        assert S.alphas_agree(om, _First64), "line-search step sizes differ"
+        assert (om.info[:, 2] == _First64.info[:, 2]).mean() > 0.9
+    print("centroidal, B = 4096: worst relative xs error of the 64 distinct instances vs the oracle: %.3e" % worst)
     xs, us, info = gm.xs, gm.us, gm.info
     r = xs.reshape(B // 64, 64, *xs.shape[1:])
     assert np.abs(r - r[0:1]).max() == 0.0, "replicated instances must be bit-identical"

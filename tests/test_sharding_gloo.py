@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -90,4 +91,62 @@ def test_two_handles_gather_into_one_buffer():
         assert np.array_equal(out[:, : whole.nx], whole.xs[:, 1, :])
         assert np.array_equal(out[:, whole.nx : whole.nx + whole.nu], whole.us[:, 0, :])
         assert np.array_equal(out[:, whole.nx + whole.nu :].reshape(5, whole.nu, whole.ndx), whole.K0.reshape(5, whole.nu, whole.ndx))
+        # the packed form ("device" memory is host memory in the CPU test build), with a row stride wider than the row
+        packed = np.full((5, row + 3), np.nan)
+        whole.gather_outputs_device(packed.ctypes.data, row + 3)
+        whole.wait()
+        assert np.array_equal(packed[:, :row], out) and np.isnan(packed[:, row:]).all()
         X = whole.xs[:, 1, :].copy()
+
+
+@pytest.mark.gpu
+def test_gpu_two_handles_gather_into_one_pinned_buffer():
+    """The same on the HIP library: two handles (two streams; two devices when the box has them, else both on device 0), launched
+    back to back from one host thread without waiting, return sets gathered into ONE pinned host buffer; bit-identical to one handle over
+    the whole batch (instances are independent: the split cannot change a result), and the launches of the two handles overlap in time."""
+    import time
+
+    import torch
+
+    import mpc_setup as S
+    import oracle_lib as O
+
+    ndev = torch.cuda.device_count()
+    sizes = (96, 160)
+    parts = [S.make_product(n, max_iters=2, device_id=(i % ndev))[0] for i, n in enumerate(sizes)]
+    whole, rb, _, _ = S.make_product(sum(sizes), max_iters=2)
+    for m in parts + [whole]:
+        m.generateCycleHorizon(O.trot_cycle())
+        m.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+    X = S.random_states(rb, sum(sizes), seed=9)
+    row = whole.nx + whole.nu + whole.nu * whole.ndx
+    pinned = torch.full((sum(sizes), row), float("nan"), dtype=torch.float64).pin_memory()
+    out = pinned.numpy()
+    assert parts[0].stream() != parts[1].stream() and parts[0].stream() != 0
+    for it in range(4):
+        t0 = time.perf_counter()
+        parts[0].iterateAsync(X[: sizes[0]])
+        parts[1].iterateAsync(X[sizes[0] :])
+        parts[0].gatherOutputs(out, 0)
+        parts[1].gatherOutputs(out, sizes[0])
+        t_launch = time.perf_counter() - t0
+        for p in parts:
+            p.wait()
+        t_all = time.perf_counter() - t0
+        whole.iterate(X)
+        assert np.array_equal(out[:, : whole.nx], whole.xs[:, 1, :])
+        assert np.array_equal(out[:, whole.nx : whole.nx + whole.nu], whole.us[:, 0, :])
+        assert np.array_equal(out[:, whole.nx + whole.nu :].reshape(-1, whole.nu, whole.ndx), whole.K0.reshape(-1, whole.nu, whole.ndx))
+        packed = torch.full((sum(sizes), row + 3), float("nan"), dtype=torch.float64, device="cuda:0")
+        whole.gather_outputs_device(packed.data_ptr(), row + 3)
+        whole.wait()
+        ph = packed.cpu().numpy()
+        assert np.array_equal(ph[:, :row], out) and np.isnan(ph[:, row:]).all()
+        # the host thread came back from the launches before the device work was done (nothing in iterateAsync / gatherOutputs waits)
+        if it > 0:
+            assert t_launch < 0.5 * t_all, (t_launch, t_all)
+        X = whole.xs[:, 1, :] + 1e-3 * np.random.default_rng(it).standard_normal(whole.xs[:, 1, :].shape)
+        X[:, 3:7] /= np.linalg.norm(X[:, 3:7], axis=1, keepdims=True)
+    # the accessors of a part agree with the gathered rows (same ring slots)
+    for p, r0 in zip(parts, (0, sizes[0])):
+        assert np.array_equal(p.xs[:, 1, :], out[r0 : r0 + p.B, : whole.nx])
