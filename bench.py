@@ -247,12 +247,19 @@ def make_mpc(kind, batch, iters, device_id, lib=None, horizon=50):
     import simple_mpc
     from simple_mpc import presets as P
 
-    if kind == "talos":
+    if kind.startswith("talos"):
         mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("talos_like", lib), "half_sitting", "root_joint")
         for n in P.TALOS_FEET:
             mh.addQuadFoot(n, "root_joint", P.TALOS_QUAD)
-        ocp = simple_mpc.FullDynamicsOCP(P.talos_full_settings(mh), mh)
-        ocp.createProblem(mh.getReferenceState(), horizon, 6, -9.81, False)
+        if kind == "talos_kinodynamics":  # (6-D feet in the kinodynamics / centroidal OCPs: round 4)
+            ocp = simple_mpc.KinodynamicsOCP(P.talos_kino_settings(mh), mh)
+            ocp.createProblem(mh.getReferenceState(), horizon, 6, -9.81, False)
+        elif kind == "talos_centroidal":
+            ocp = simple_mpc.CentroidalOCP(P.talos_centroidal_settings(mh), mh)
+            ocp.createProblem(np.zeros(9), horizon, 6, -9.81, False)
+        else:
+            ocp = simple_mpc.FullDynamicsOCP(P.talos_full_settings(mh), mh)
+            ocp.createProblem(mh.getReferenceState(), horizon, 6, -9.81, False)
         ms = P.talos_mpc_settings(mh, max_iters=iters)
         gm = simple_mpc.BatchedMPC({k: ms[k] for k in P.MPC_KEYS}, ocp, batch, device_id=device_id, lib=lib)
         gm.generateCycleHorizon(P.walk_cycle())
@@ -367,6 +374,34 @@ def inverse_dynamics_line(batch, device_id, with_cpu=True):
         out["cpu_baseline"] = {"value": Bc * n / (time.time() - t0), "unit": "QPs/s", "cores": threads, "kind": "port",
                                "sample": "CPU restatement (oracle/, not TSID / ProxQP): %d robots x %d ticks, same ADMM" % (Bc, n)}
     return out
+
+
+def inverse_dynamics_quad_line(batch, device_id):
+    """KinodynamicsID of a biped with flat feet (tsid Contact6d: 12 corner forces per foot, 52 variables / 126 rows): the gains of the
+    reference's contactQuad test, 100 ADMM iterations of fixed work per QP, states resident in HBM."""
+    import numpy as np
+    import torch
+    import simple_mpc
+    from simple_mpc import presets as P
+
+    mh = simple_mpc.RobotModelHandler(simple_mpc.load_robot("talos_like"), "half_sitting", "root_joint")
+    for n in P.TALOS_FEET:
+        mh.addQuadFoot(n, "root_joint", P.TALOS_QUAD)
+    st = dict(kp_base=1.0, kp_posture=1.0, kp_contact=10.0, w_base=1.0, w_posture=0.05, w_contact_motion=10.0, w_contact_force=1.0)
+    kid = simple_mpc.KinodynamicsID(mh, 1e-3, st, P.TALOS_EFFORT, P.TALOS_VMAX, batch=batch, device_id=device_id, admm_iters=100, admm_tol=-1.0)
+    X = P.random_states(mh, batch, scale=0.2)
+    for _ in range(3):
+        kid.solve(0.0, X[:, : mh.nq], X[:, mh.nq :])
+    Xd = torch.from_numpy(np.ascontiguousarray(X)).to(torch.device("cuda", device_id))
+    torch.cuda.synchronize()
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        kid.solve_device(Xd.data_ptr())
+    kid.wait()
+    dt = (time.perf_counter() - t0) / n
+    return {"metric": "whole-body inverse-dynamics QPs/sec, flat feet (KinodynamicsID with Contact6d: 52 variables, 126 rows, 100 ADMM iterations)",
+            "value": batch / dt, "unit": "QPs/s", "ms_per_call": dt * 1e3, "batch": batch, "dtype": "f64", "max_residual": float(kid.resid.max())}
 
 
 def single_robot_latency(iters, device_id, steps=50):
@@ -604,6 +639,59 @@ def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True, rob
         out["cpu_baseline"] = {"value": Bc * n / (time.time() - t0), "unit": "control-steps/s", "cores": threads, "kind": "port",
                                "sample": "CPU restatement (oracle/, not Aligator): %d instances x %d steps, k=%d" % (Bc, n, iters)}
     return out
+
+
+def talos_flat_feet_line(kind, batch, iters, steps, warmup, device_id):
+    """The kinodynamics / centroidal OCPs of a Talos-class biped with 6-D feet (reference examples/talos_kinodynamics.py,
+    talos_centroidal.py; H = 100, walk 20/80/20/80): the same control step as the other lines, brief."""
+    import numpy as np
+    import torch
+    from simple_mpc import presets as P
+
+    gm, mh = make_mpc(kind, batch, iters, device_id, horizon=100)
+    dev = torch.device("cuda", device_id)
+    X0 = torch.from_numpy(P.random_states(mh, batch, scale=0.7)).to(dev)
+    X = X0.clone()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(13)
+    on_stream = loop_stream(gm, dev)
+    cent = kind == "talos_centroidal"
+
+    def step():
+        gm.iterate_device(X.data_ptr())
+        if not cent:
+            gm.get_x_device(1, X.data_ptr())
+        if SYNC_STEPS:
+            gm.wait()
+        with on_stream():
+            if cent:  # (no multibody state to feed back: x_ref (+) noise on the base position, as the Go2 centroidal line)
+                X.copy_(X0)
+                X[:, :3].add_(torch.randn((batch, 3), generator=gen, device=dev, dtype=torch.float64) * 1e-3)
+            else:
+                X.add_(torch.randn(X.shape, generator=gen, device=dev, dtype=torch.float64) * 1e-3)
+                q = X[:, 3:7]
+                q.div_(q.norm(dim=1, keepdim=True))
+        step_sync(gm)
+
+    for _ in range(warmup):
+        step()
+    gm.set_profiling(True)
+    gm.reset_kernel_times()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = gm.kernel_times()
+    return {
+        "metric": "MPC control-steps/sec at fixed ProxDDP iters, Talos %s (6-D feet) H=%d" % (kind.split("_")[1], gm.H),
+        "value": batch * steps / dt, "unit": "control-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": "f64",
+        "config": {"workload": "Talos %s OCP (talos_like table, two 6-D feet, wrench cones), H=%d, %d ProxDDP iters/step, batch=%d, walk 20/80/20/80"
+                   % (kind.split("_")[1], gm.H, iters, batch), "sizes": {"ndx": gm.ndx, "nu": gm.nu, "nc": gm.nc},
+                   "finite": bool(np.all(np.isfinite(gm.info)))},
+        "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if k != "-" and v[1]},
+    }
 
 
 def launch_ranks(args, argv):
@@ -907,7 +995,10 @@ def main():
             other["centroidal"] = centroidal_line(B, args.iters, 40, 5, local_rank, not args.no_cpu_baseline)
             other["fulldynamics_go2"] = fulldynamics_line(min(B, 4096), args.iters, 20, 3, local_rank, not args.no_cpu_baseline)
             other["fulldynamics_talos"] = fulldynamics_line(1024, args.iters, 10, 2, local_rank, not args.no_cpu_baseline, robot="talos")
+            other["talos_kinodynamics_6d"] = talos_flat_feet_line("talos_kinodynamics", 1024, args.iters, 8, 2, local_rank)
+            other["talos_centroidal_6d"] = talos_flat_feet_line("talos_centroidal", 1024, args.iters, 20, 3, local_rank)
             other["inverse_dynamics_qp"] = inverse_dynamics_line(B, local_rank, not args.no_cpu_baseline)
+            other["inverse_dynamics_qp_flat_feet"] = inverse_dynamics_quad_line(B, local_rank)
             other["control_stack"] = control_stack_line(B, local_rank)
             other["single_robot_latency"] = single_robot_latency(args.iters, local_rank)
             out["other_workloads"] = other

@@ -83,12 +83,34 @@ def talos_full_settings(model_handler):
                 force_cone=True, land_cstr=False)
 
 
+def talos_kino_settings(model_handler, force_cone=True):
+    """KinodynamicsSettings of the reference's Talos configuration with 6-D feet: weights of examples/talos_kinodynamics.py:50-106
+    (force_cone as in tests/test_utils.cpp:147-197, which the reference's own problem / MPC tests use)."""
+    nv = model_handler.nv
+    w_x = 10.0 * np.diag(np.array([0, 0, 1000, 1000, 1000, 1000] + [0.1] * 6 * 2 + [1, 1000] + [1, 1, 10, 10] * 2 + [10] * 6 + [1] * 6 * 2
+                                  + [0.1, 100] + [10] * 4 * 2, float))
+    w_u = np.diag(np.concatenate([[0.001, 0.001, 0.01], np.ones(3) * 0.1] * 2 + [np.ones(nv - 6) * 1e-4]))
+    return dict(timestep=0.01, w_x=w_x, w_u=w_u, w_cent=np.diag([0.0, 0.0, 1.0, 0.1, 0.1, 10.0]), w_centder=np.diag([0.0, 0.0, 0.0, 0.1, 0.1, 0.1]),
+                gravity=np.array([0.0, 0.0, -9.81]), force_size=6, w_frame=np.eye(6) * 100000.0, qmin=model_handler.lowerPositionLimit[7:].copy(),
+                qmax=model_handler.upperPositionLimit[7:].copy(), mu=0.8, Lfoot=0.1, Wfoot=0.075, kinematics_limits=True,
+                force_cone=bool(force_cone), land_cstr=False)
+
+
+def talos_centroidal_settings(model_handler):
+    """CentroidalSettings of the reference's Talos configuration with 6-D feet: examples/talos_centroidal.py:50-76."""
+    nf = model_handler.getFeetNb()
+    return dict(timestep=0.01, w_u=np.diag(([0.001] * 3 + [0.1] * 3) * nf), w_com=np.zeros((3, 3)), w_linear_mom=np.diag([0.01, 0.01, 100.0]),
+                w_angular_mom=np.diag([0.1, 0.1, 1000.0]), w_linear_acc=0.01 * np.eye(3), w_angular_acc=0.01 * np.eye(3),
+                gravity=np.array([0.0, 0.0, -9.81]), mu=0.8, Lfoot=0.1, Wfoot=0.075, force_size=6)
+
+
 def talos_mpc_settings(model_handler, max_iters=1, num_threads=0):
     """MPC settings of the Talos example: reference examples/talos_fulldynamics.py:101-113 (T = 100, T_fly 80, T_contact 20)."""
     return dict(support_force=model_handler.getMass() * 9.81, TOL=1e-4, mu_init=1e-8, max_iters=max_iters, num_threads=num_threads,
                 swing_apex=0.15, T_fly=80, T_contact=20, timestep=0.01)
 
 
+TALOS_VMAX = np.array([3.87, 5.86, 5.86, 7.0, 5.86, 4.8] * 2 + [5.4, 5.4] + [2.7, 3.66, 4.58, 4.58] * 2, float)  # Talos-like joint velocity limits
 TALOS_QUAD = np.array([[0.1, 0.075, 0], [-0.1, 0.075, 0], [-0.1, -0.075, 0], [0.1, -0.075, 0]])  # examples/talos_fulldynamics.py:22-33
 
 
