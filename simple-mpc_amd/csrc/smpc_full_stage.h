@@ -60,7 +60,7 @@ namespace smpc
     static_assert(DYN_DOUBLES >= (NGN - NCM) * NCOL, "the momentum / pose rows of the Gauss-Newton Jacobian fit the dead dynamics block");
     SMPC_HD double * jt2_() { return M; } // rows NCM .. NGN-1 of the stacked Jacobian, [NGN - NCM][NCOL]
     double gam[NCM], JMb[NCM], lam[NCM], rhs[NCM], dl[NCM];
-    double rotl[NF * 3]; // log3 of the foot rotations (6-D contacts: angular part of the corrector)
+    double rotl[D::FS == 6 ? NF * 3 : 1]; // log3 of the foot rotations (6-D contacts: angular part of the corrector)
     static constexpr int NVP = ((NV + 3) / 4) * 4, NCP = ((NCM + 3) / 4) * 4;
     static constexpr int NTM = (2 * NVP + 15) / 16, NTG = (2 * NCP + 15) / 16; // tile grids of the two bordered inverses
     static constexpr int SWP_DOUBLES = 2 * 4 * 16 * (NTM > NTG ? NTM : NTG);     // sweep operands
@@ -72,7 +72,7 @@ namespace smpc
     double rx[NDX], Wrx[NDX], ru[NU], Wru[NU], Whg[6], rf[NF * D::PF], Wrf[NF * D::PF], rl[NCM], Wrl[NCM];
     double cval[NC], vplus[NC], lamp[NDX];
     int act[NC + NC % 2];
-    double part[64], part2[64], part8[16], red[4];
+    double part[64], part8[16], red[4];
     int iters_[2];
     SMPC_HD double * swp_() { return xnext; } // (size checked where the inverses are called)
   };
@@ -1142,6 +1142,8 @@ namespace smpc
     if (term)
       return;
     // ---- AL multipliers (SolverProxDDP computeMultipliers), merit penalty, primal infeasibility ----
+    SMPC_PL(double, prim_l, NT); // (the two reductions share `part`, one after the other: 512 B of LDS decide between 3 and 4 resident blocks)
+    SMPC_PL(double, pen8_l, NT);
     SMPC_LANES(NT)
     {
       double pen = 0.0, prim = 0.0;
@@ -1180,19 +1182,30 @@ namespace smpc
         pen += 0.5 * mu * (vp * vp + dv * dv);
       }
       sc.part[lane] = pen;
-      sc.part2[lane] = prim;
+      SMPC_PLV(prim_l) = prim;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    {
+      double pen = 0.0;
+      if (lane < 8)
+        for (int i = 0; i < 8; i++)
+          pen += sc.part[lane * 8 + i];
+      SMPC_PLV(pen8_l) = pen;
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    {
+      sc.part[lane] = SMPC_PLV(prim_l);
     }
     SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
     if (lane < 8)
     {
-      double pen = 0.0, prim = 0.0;
+      double prim = 0.0;
       for (int i = 0; i < 8; i++)
-      {
-        pen += sc.part[lane * 8 + i];
-        prim = fmax(prim, sc.part2[lane * 8 + i]);
-      }
-      sc.part8[lane] = pen;
+        prim = fmax(prim, sc.part[lane * 8 + i]);
+      sc.part8[lane] = SMPC_PLV(pen8_l);
       sc.part8[8 + lane] = prim;
     }
     SMPC_LANES_END_WAVE

@@ -1061,9 +1061,9 @@ namespace smpc
   struct Qp6Lds
   {
     typedef IdDims<D> G;
-    double K[G::NP * G::NP];
+    double K[G::N * G::N]; // (N x N, not the padded NP x NP: with it 80 KB instead of 91 -- two resident waves per CU instead of one)
     double C[G::GR * G::LDC];
-    double swp[2 * 4 * 16 * ((2 * G::NP + 15) / 16)];
+    double swp[2 * 4 * 16 * ((2 * G::N + 15) / 16)];
     double x[G::NP], g[G::NP], rhs[G::NP], xt[G::NP];
     double z[G::MP], lam[G::MP], lo[G::MP], hi[G::MP], r[G::MP], w[G::MP], zt[G::MP];
     double red[256], red4[4];
@@ -1083,7 +1083,7 @@ namespace smpc
     const double * Cg = b.C + (size_t)inst * MP * NP + (size_t)N * NP;
     const bool warm = b.warm[inst] != 0;
     double rho = warm ? b.rho[inst] : st.rho;
-    SMPC_PLA(double, Krow, NT, NP);
+    SMPC_PLA(double, Krow, NT, N);
     SMPC_LANES(NT)
     {
       for (int idx = lane; idx < GR * NP; idx += NT)
@@ -1108,15 +1108,16 @@ namespace smpc
         s.r[k] = (hi - lo < 1e-12) ? 1e3 * rho : ((lo <= -ID_INF && hi >= ID_INF) ? 1e-6 * rho : rho);
       }
       SMPC_LANES_END_WAVE
-      fwave_gemm<NP, NP, GR>(
+      fwave_gemm<N, N, GR>(
         [&](int i, int k) { return s.r[N + k] * s.C[k * LDC + i]; }, [&](int k, int j) { return s.C[k * LDC + j]; },
-        [&](int i, int j, double v) { s.K[i * NP + j] = (Hg[i * NP + j] + (i == j ? sigma + (i < N ? s.r[i] : 0.0) : 0.0)) + v; });
-      fwave_spd_inverse<NP>(s.K, s.swp);
+        [&](int i, int j, double v) { s.K[i * N + j] = (Hg[i * NP + j] + (i == j ? sigma + s.r[i] : 0.0)) + v; });
+      fwave_spd_inverse<N>(s.K, s.swp);
       SMPC_LANES(NT)
       {
+        const int ln = lane < N ? lane : 0; // (lanes N .. 63 carry no variable: their x~ is zero)
 #pragma unroll
-        for (int j = 0; j < NP; j++)
-          SMPC_PLV(Krow)[j] = s.K[j * NP + lane]; // (K^-1 is symmetric: read along the row of j, conflict-free)
+        for (int j = 0; j < N; j++)
+          SMPC_PLV(Krow)[j] = s.K[j * N + ln]; // (K^-1 is symmetric: read along the row of j, conflict-free)
       }
       SMPC_LANES_END_WAVE
     };
