@@ -1,0 +1,62 @@
+"""Batched counterpart of the reference's examples/talos_kinodynamics.py (settings :50-106, MPC :108-150, inverse dynamics :160-169, loop
+:214-270) without the simulator: B bipeds (the built-in talos_like table: Talos' joint tree, two flat feet) run the KINODYNAMICS MPC with 6-D
+feet -- contact wrenches and joint accelerations as controls, 6-D foot placement costs, wrench cones -- at 100 Hz (H = 100), and between
+two MPC steps the whole-body inverse-dynamics QP with flat-foot contacts (tsid Contact6d: 12 corner forces per foot) turns the interpolated
+MPC targets into joint torques at 1 kHz.  The measured state of every robot is the MPC's own prediction (x_meas = interpolated xs).
+
+    python examples/talos_kinodynamics_id_batched.py [batch] [mpc_steps]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "simple-mpc_amd", "python"))
+from simple_mpc import BatchedMPC, KinodynamicsID, KinodynamicsOCP, RobotModelHandler, load_robot, presets  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+LIB = None  # (tests pass the CPU test build here)
+
+mh = RobotModelHandler(load_robot("talos_like", LIB), "half_sitting", "root_joint")
+for n in presets.TALOS_FEET:
+    mh.addQuadFoot(n, "root_joint", presets.TALOS_QUAD)
+nq, nv = mh.nq, mh.nv
+
+T = int(os.environ.get("SMPC_EXAMPLE_HORIZON", "100"))
+ocp = KinodynamicsOCP(presets.talos_kino_settings(mh), mh)  # the dict of the reference script: force_size 6, w_frame 6 x 6, wrench cones
+ocp.createProblem(mh.getReferenceState(), T, 6, -9.81, False)
+mpc = BatchedMPC({k: v for k, v in presets.talos_mpc_settings(mh, max_iters=1).items() if k in presets.MPC_KEYS}, ocp, B, lib=LIB)
+mpc.generateCycleHorizon(presets.walk_cycle())  # 20 / 80 / 20 / 80: double support, left swing, double support, right swing
+V = np.zeros((B, 6))
+V[:, 0] = np.linspace(0.05, 0.15, B)  # the reference walks at 0.1 m/s
+mpc.switchToWalk(V[0])
+mpc.setVelocityBaseBatched(V)
+
+dt_mpc, N_simu = 0.01, 10
+dt_simu = dt_mpc / N_simu
+id_settings = dict(kp_base=7.0, kp_posture=10.0, kp_contact=10.0, w_base=100.0, w_posture=1.0, w_contact_force=0.001, w_contact_motion=1.0)  # :160-167
+kino_ID = KinodynamicsID(mh, dt_simu, id_settings, presets.TALOS_EFFORT, presets.TALOS_VMAX, batch=B, lib=LIB)
+
+X = np.tile(mh.getReferenceState(), (B, 1))
+t_mpc = t_id = 0.0
+for step in range(steps):
+    t0 = time.time()
+    mpc.iterate(X)
+    t_mpc += time.time() - t0
+    contact = mpc.ocp_handler.getContactState(0)
+    for sub in range(N_simu):
+        x_i, a_i, f_i = mpc.interpolate(sub / float(N_simu) * dt_mpc)  # states, accelerations, contact wrenches [B][2][6]
+        t0 = time.time()
+        kino_ID.setTargets(x_i[:, :nq], x_i[:, nq:], a_i, contact, f_i)
+        tau = kino_ID.solve(step * dt_mpc + sub * dt_simu, x_i[:, :nq], x_i[:, nq:])
+        t_id += time.time() - t0
+    X = mpc.xs[:, 1, :]
+wrench = kino_ID.getContactForces()  # [B][2][6]: the wrenches T f of the corner forces, foot frames
+print("%d bipeds, %d MPC steps x %d controller ticks: MPC %.2f ms / step, flat-foot inverse dynamics %.2f ms / tick (host copies included)" % (
+    B, steps, N_simu, 1e3 * t_mpc / steps, 1e3 * t_id / (steps * N_simu)))
+print("base x after %.2f s: %.3f m (0.05 m/s command) ... %.3f m (0.15 m/s command); max |tau| / limit %.2f; vertical contact force %.0f N of %.0f N weight" % (
+    steps * dt_mpc, X[0, 0], X[-1, 0], np.abs(tau / presets.TALOS_EFFORT).max(), wrench[0, :, 2].sum(), mh.getMass() * 9.81))
+assert np.all(np.isfinite(X)) and np.all(np.isfinite(tau)) and np.all(np.abs(tau) <= presets.TALOS_EFFORT + 1e-6)

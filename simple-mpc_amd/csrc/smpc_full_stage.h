@@ -1940,6 +1940,10 @@ namespace smpc
     const DevModel<D> & mg = *b.model;
     SMPC_LDS(SC, scs, 1);
     SMPC_LDS(SD, sds, 1);
+    // LDS decides the resident blocks per CU here (160 KB / block size, one wave per SIMD at most): the quadruped with neither cone nor
+    // land rows must stay under 40 KB -- four blocks; at 41.2 KB it ran three and the launch took 15.2 ms instead of 11.9
+    static_assert(!(D::NJ == 13 && D::FS == 3 && D::NCONE == 0 && D::NLAND == 0 && !D::KINO) || sizeof(SC) + sizeof(SD) <= 40960,
+                  "fdyn_deriv_body of the point-foot quadruped: 4 resident blocks per CU");
 #ifdef SMPC_FDYN_PAD
     SMPC_LDS(double, padlds, SMPC_FDYN_PAD); // (occupancy experiment)
     if (ka.b.B < 0)

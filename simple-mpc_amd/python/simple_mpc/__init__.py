@@ -1277,8 +1277,8 @@ class KinodynamicsID:
         return out.copy()
 
     def getContactForces(self):
-        """Contact forces of the last solution, [B][nf][3] (world frame)."""
-        return self._f.reshape(self.B, self._nf, 3).copy()
+        """Contact forces of the last solution: [B][nf][3] (point feet, world frame) or the wrenches T f [B][nf][6] of flat feet (foot frames)."""
+        return self._f.reshape(self.B, self._nf, self._fs).copy()
 
     def debug(self, what):
         nm = self._fs * self._nf  # contact-motion rows: 3 per point foot, 6 per flat foot
