@@ -1,8 +1,10 @@
 // simple-mpc/batched-id.hpp -- header-only C++ host mirror of the reference's whole-body inverse-dynamics controllers over the C ABI of
 // smpc.h: KinodynamicsID (include/simple-mpc/inverse-dynamics/kinodynamics-id.hpp:17-92) and CentroidalID
 // (include/simple-mpc/inverse-dynamics/centroidal-id.hpp), one controller per robot of a batch.  Same verbs and settings-field names as
-// the reference; Eigen types replaced by std::vector<double>, pinocchio::SE3 / Motion arguments by translations / linear velocities (3-D
-// point feet).  The reference reads effort / velocity limits from its pinocchio model: here they are constructor arguments, the position
+// the reference; Eigen types replaced by std::vector<double>, pinocchio::SE3 / Motion arguments by translations / linear velocities.
+// Point feet (tsid ContactPoint, 3 force components per foot) by default; a robot with flat feet (tsid Contact6d: addQuadFoot in the
+// reference, kinodynamics-id.cpp:41-49) passes force_size = 6 and the corners of its soles -- forces are then wrenches, 6 per foot.
+// The reference reads effort / velocity limits from its pinocchio model: here they are constructor arguments, the position
 // limits come from the robot table.  Errors are rethrown as std::runtime_error.
 #pragma once
 #include "../smpc.h"
@@ -24,6 +26,10 @@ namespace simple_mpc
     // TaskJointPosVelAccBounds in full
     bool base_reference_as_coded = false;
     bool tsid_joint_bounds = false;
+    // contact model: 3 = point feet; 6 = flat feet with quad_contact_points [nfeet][4][3], the corners of every sole in its foot frame
+    // (RobotModelHandler::getQuadFootContactPoints of the reference)
+    int force_size = 3;
+    std::vector<double> quad_contact_points;
   };
   struct CentroidalIDSettings : KinodynamicsIDSettings // reference centroidal-id.hpp
   {
@@ -55,12 +61,12 @@ namespace simple_mpc
       }
       tau_res.resize((size_t)batch_ * (nv_ - 6));
       a_.resize((size_t)batch_ * nv_);
-      f_.resize((size_t)batch_ * 3 * nf_);
+      f_.resize((size_t)batch_ * fs_ * nf_);
       resid_.resize(batch_);
       check(smpc_id_solve(h_, X.data(), tau_res.data(), a_.data(), f_.data(), resid_.data()));
     }
     void getAccelerations(std::vector<double> & a) const { a = a_; }          // [B][nv] of the last solve
-    const std::vector<double> & getContactForces() const { return f_; }       // [B][3 nfeet], world frame
+    const std::vector<double> & getContactForces() const { return f_; }       // [B][nfeet][3] world frame (point feet) / [B][nfeet][6] wrenches in the foot frames (flat feet)
     const std::vector<double> & residuals() const { return resid_; }          // [B] the larger of the QP's primal / dual residuals
     smpc_id_handle * handle() { return h_; }
 
@@ -99,6 +105,13 @@ namespace simple_mpc
       c.w_feet_tracking = s.w_feet_tracking;
       c.base_reference_as_coded = s.base_reference_as_coded ? 1 : 0;
       c.tsid_joint_bounds = s.tsid_joint_bounds ? 1 : 0;
+      fs_ = s.force_size;
+      if (fs_ != 3 && fs_ != 6)
+        throw std::runtime_error("force_size must be 3 (point feet) or 6 (flat feet)");
+      if (fs_ == 6 && (int)s.quad_contact_points.size() != nf_ * 12)
+        throw std::runtime_error("flat feet: quad_contact_points must hold the four corners of every sole ([nfeet][4][3])");
+      c.force_size = fs_;
+      c.quad_contact_points = fs_ == 6 ? s.quad_contact_points.data() : nullptr;
       check(smpc_id_create(robot, &c, batch, device_id, &h_));
     }
     static void check(int rc)
@@ -113,7 +126,7 @@ namespace simple_mpc
       return std::vector<uint8_t>(contact_state_target.begin(), contact_state_target.end());
     }
     smpc_id_handle * h_ = nullptr;
-    int batch_ = 0, nq_ = 0, nv_ = 0, nf_ = 0;
+    int batch_ = 0, nq_ = 0, nv_ = 0, nf_ = 0, fs_ = 3;
     std::vector<double> a_, f_, resid_;
   };
 
@@ -129,12 +142,12 @@ namespace simple_mpc
       create(robot, control_dt, s, false, effort_limit, velocity_limit, batch, device_id);
     }
     // setTarget(q_target, v_target, a_target, contact_state_target, f_target) (kinodynamics-id.cpp:120-183): one robot, or every robot
-    // (instance < 0); f_target 3 per foot, world frame
+    // (instance < 0); f_target 3 per foot, world frame (point feet) / the contact wrench, 6 per foot (flat feet)
     void setTarget(const std::vector<double> & q_target, const std::vector<double> & v_target, const std::vector<double> & a_target,
                    const std::vector<bool> & contact_state_target, const std::vector<double> & f_target, int instance = -1)
     {
-      if ((int)q_target.size() != nq_ || (int)v_target.size() != nv_ || (int)a_target.size() != nv_ || (int)f_target.size() != 3 * nf_)
-        throw std::runtime_error("setTarget: q (nq), v (nv), a (nv), f (3 per foot)");
+      if ((int)q_target.size() != nq_ || (int)v_target.size() != nv_ || (int)a_target.size() != nv_ || (int)f_target.size() != fs_ * nf_)
+        throw std::runtime_error("setTarget: q (nq), v (nv), a (nv), f (force_size per foot)");
       const std::vector<uint8_t> c = flags(contact_state_target);
       check(smpc_id_set_target(h_, instance, q_target.data(), v_target.data(), a_target.data(), c.data(), f_target.data()));
     }
@@ -156,8 +169,8 @@ namespace simple_mpc
                    int instance = -1)
     {
       if (com_position.size() != 3 || com_velocity.size() != 3 || (int)feet_position.size() != 3 * nf_ || (int)feet_velocity.size() != 3 * nf_ ||
-          (int)f_target.size() != 3 * nf_)
-        throw std::runtime_error("setTarget: com (3), com velocity (3), feet positions / velocities / forces (3 per foot)");
+          (int)f_target.size() != fs_ * nf_)
+        throw std::runtime_error("setTarget: com (3), com velocity (3), feet positions / velocities (3 per foot), forces (force_size per foot)");
       const std::vector<uint8_t> c = flags(contact_state_target);
       check(smpc_id_set_target_centroidal(h_, instance, com_position.data(), com_velocity.data(), feet_position.data(), feet_velocity.data(), c.data(),
                                           f_target.data()));

@@ -406,6 +406,120 @@ int main()
     }
     CHECK(threw5);
   }
+  {
+    // ---- a biped with flat feet (the Talos configuration of the reference's own MPC tests, tests/mpc.cpp:97-170 / test_utils.cpp:147-197):
+    //      kinodynamics OCP with 6-D feet behind the same BatchedMPC, then the flat-foot inverse dynamics (tsid Contact6d) ----
+    const smpc_robot_model * talos = smpc_builtin_robot("talos_like");
+    CHECK(talos != nullptr);
+    const int tnv = talos->nv, tnq = talos->nq, tnf = talos->nfeet;
+    CHECK(tnv == 28 && tnq == 29 && tnf == 2);
+    KinodynamicsSettings tk;
+    const int tndx = 2 * tnv, tnu = tnv - 6 + 6 * tnf;
+    const double wq[28] = {0, 0, 1000, 1000, 1000, 1000, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 1, 1000, 1, 1, 10, 10, 1, 1, 10, 10};
+    const double wv[28] = {10, 10, 10, 10, 10, 10, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.1, 100, 10, 10, 10, 10, 10, 10, 10, 10};
+    tk.w_x.assign((size_t)tndx * tndx, 0.0);
+    for (int i = 0; i < tnv; i++)
+    {
+      tk.w_x[(size_t)i * tndx + i] = 10.0 * wq[i];
+      tk.w_x[(size_t)(tnv + i) * tndx + tnv + i] = 10.0 * wv[i];
+    }
+    tk.w_u.assign((size_t)tnu * tnu, 0.0);
+    const double wf[6] = {0.001, 0.001, 0.01, 0.1, 0.1, 0.1};
+    for (int i = 0; i < tnu; i++)
+      tk.w_u[(size_t)i * tnu + i] = i < 6 * tnf ? wf[i % 6] : 1e-4;
+    tk.w_frame.assign(36, 0.0);
+    for (int i = 0; i < 6; i++)
+      tk.w_frame[i * 7] = 100000.0;
+    const double twc[6] = {0, 0, 1, 0.1, 0.1, 10}, twcd[6] = {0, 0, 0, 0.1, 0.1, 0.1};
+    tk.w_cent.assign(36, 0.0);
+    tk.w_centder.assign(36, 0.0);
+    for (int i = 0; i < 6; i++)
+    {
+      tk.w_cent[i * 7] = twc[i];
+      tk.w_centder[i * 7] = twcd[i];
+    }
+    tk.qmin.assign(talos->q_lo, talos->q_lo + (tnv - 6));
+    tk.qmax.assign(talos->q_hi, talos->q_hi + (tnv - 6));
+    tk.kinematics_limits = true;
+    tk.force_cone = true;
+    tk.force_size = 6;
+    tk.mu = 0.8;
+    tk.Lfoot = 0.1;
+    tk.Wfoot = 0.075;
+    MPCSettings tm;
+    tm.max_iters = 1;
+    tm.support_force = talos->total_mass * 9.81;
+    tm.TOL = 1e-4;
+    tm.mu_init = 1e-8;
+    tm.swing_apex = 0.15;
+    tm.T_fly = 80;
+    tm.T_contact = 20;
+    tm.T = 30;
+    tm.timestep = 0.01;
+    BatchedMPC tmpc(talos, tk, tm, /*batch=*/2);
+    CHECK(tmpc.horizon() == 30 && tmpc.nx() == tnq + tnv && tmpc.nu() == tnu);
+    std::vector<std::map<std::string, bool>> walk;
+    auto tpush = [&](int n, bool left, bool right) {
+      for (int i = 0; i < n; i++)
+        walk.push_back({{talos->foot_name[0], left}, {talos->foot_name[1], right}});
+    };
+    tpush(20, true, true);
+    tpush(80, true, false);
+    tpush(20, true, true);
+    tpush(80, false, true);
+    tmpc.generateCycleHorizon(walk);
+    std::vector<double> TX((size_t)2 * tmpc.nx(), 0.0);
+    for (int b = 0; b < 2; b++)
+      for (int i = 0; i < tnq; i++)
+        TX[(size_t)b * tmpc.nx() + i] = talos->q_ref[i];
+    for (int it = 0; it < 3; it++)
+      tmpc.iterate(TX);
+    double tfz = 0.0; // controls = [wrench of the left foot (6) | wrench of the right foot (6) | joint accelerations]
+    for (int f = 0; f < tnf; f++)
+      tfz += tmpc.us_[6 * f + 2];
+    CHECK(std::fabs(tfz - talos->total_mass * 9.81) < 0.10 * talos->total_mass * 9.81);
+    for (size_t i = 0; i < tmpc.xs_.size(); i++)
+      CHECK(std::isfinite(tmpc.xs_[i]));
+
+    const double eff[22] = {100, 160, 160, 300, 160, 100, 100, 160, 160, 300, 160, 100, 200, 200, 44, 44, 22, 22, 44, 44, 22, 22};
+    const double vm[22] = {3.87, 5.86, 5.86, 7.0, 5.86, 4.8, 3.87, 5.86, 5.86, 7.0, 5.86, 4.8, 5.4, 5.4, 2.7, 3.66, 4.58, 4.58, 2.7, 3.66, 4.58, 4.58};
+    KinodynamicsIDSettings ts; // gains of the reference's contactQuad tests (tests/inverse-dynamics/kinodynamics-id.cpp:192-204)
+    ts.kp_base = 1.0;
+    ts.kp_posture = 1.0;
+    ts.kp_contact = 10.0;
+    ts.w_base = 1.0;
+    ts.w_posture = 0.05;
+    ts.w_contact_motion = 10.0;
+    ts.w_contact_force = 1.0;
+    ts.force_size = 6;
+    const double quad[12] = {0.1, 0.075, 0, -0.1, 0.075, 0, -0.1, -0.075, 0, 0.1, -0.075, 0};
+    for (int f = 0; f < tnf; f++)
+      ts.quad_contact_points.insert(ts.quad_contact_points.end(), quad, quad + 12);
+    BatchedKinodynamicsID tid(talos, 1e-3, ts, std::vector<double>(eff, eff + 22), std::vector<double>(vm, vm + 22), 2);
+    std::vector<double> TQ(2 * tnq), TV(2 * tnv, 0.0), ttau;
+    for (int b = 0; b < 2; b++)
+      std::copy(talos->q_ref, talos->q_ref + tnq, TQ.begin() + b * tnq);
+    tid.solve(0.0, TQ, TV, ttau); // default target: the reference state, both feet in contact
+    CHECK((int)ttau.size() == 2 * (tnv - 6) && (int)tid.getContactForces().size() == 2 * 6 * tnf);
+    double wz = 0.0; // the wrenches T f of the corner forces, foot frames (soles flat on the ground: z = vertical)
+    for (int f = 0; f < tnf; f++)
+      wz += tid.getContactForces()[6 * f + 2];
+    CHECK(std::fabs(wz - talos->total_mass * 9.81) < 0.05 * talos->total_mass * 9.81);
+    for (size_t i = 0; i < ttau.size(); i++)
+      CHECK(std::fabs(ttau[i]) <= eff[i % 22] + 1e-6);
+    bool threw6 = false;
+    try
+    {
+      KinodynamicsIDSettings bad = ts;
+      bad.quad_contact_points.clear();
+      BatchedKinodynamicsID nope(talos, 1e-3, bad, std::vector<double>(eff, eff + 22), std::vector<double>(vm, vm + 22), 1);
+    }
+    catch (const std::runtime_error &)
+    {
+      threw6 = true;
+    }
+    CHECK(threw6);
+  }
   std::puts("host mirror KAT: OK");
   return 0;
 }
