@@ -460,7 +460,7 @@ extern "C"
       return fail(SMPC_ERR_INVALID, "null argument");
     return guarded([&] {
       const unsigned m = h->full ? h->full->contact_mask(t) : (h->cent ? h->cent->contact_mask(t) : h->eng->contact_mask(t));
-      const int nf = h->full ? h->full->dims[6] : DimsGo2::NF;
+      const int nf = h->full ? h->full->dims[6] : (h->cent ? h->cent->nf : DimsGo2::NF);
       for (int f = 0; f < nf; f++)
         out[f] = (m >> f) & 1u;
     });
