@@ -231,7 +231,13 @@ namespace smpc
         SMPC_ACC(tacc, NT, NTX * NTT);
         SMPC_PLA(double, pav, NT, NTX);
         SMPC_PLA(double, abv, NT, NTJ);
-        SMPC_PLA(double, abn, NT, NTJ); // operand slice of the next K-step (in flight while the current products run)
+        // operand slices of the next TWO K-steps, in flight while the current products run: a K-step of MFMAs (1.0 - 1.5 k cycles) is shorter
+        // than a round trip to L2 / HBM (2 - 5 k), so with one slice ahead every K-step waited for its operands
+        // (measured per instantiation: Go2 full dynamics 3.95 -> 3.82 ms, Talos kinodynamics 14.2 -> 12.3 ms per launch; the Talos full-dynamics
+        //  sweep -- 56 states, 22 controls, up to 78 rows -- is at its register limit, the second slice is spilled there and costs 6 %: one ahead)
+        constexpr bool TWO_AHEAD = !(NDX == 56 && NU == 22);
+        SMPC_PLA(double, abn, NT, NTJ);
+        SMPC_PLA(double, abn2, NT, (TWO_AHEAD ? NTJ : 1));
         // slice ks of [A | B | 0]: entry (4 ks + lr, 16 J + lc), address selected, loaded once, masked at the use
         auto ab_fetch = [&](int ks, int J, int lr, int lc) {
           const int r = 4 * ks + lr, c = 16 * J + lc;
@@ -243,7 +249,11 @@ namespace smpc
           const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
           for (int J = 0; J < NTJ; J++)
+          {
             SMPC_PLV(abn)[J] = ab_fetch(0, J, lr, lc);
+            if constexpr (TWO_AHEAD)
+              SMPC_PLV(abn2)[J] = ab_fetch(1, J, lr, lc);
+          }
 #pragma unroll
           for (int I = 0; I < NTX; I++)
 #pragma unroll
@@ -274,8 +284,14 @@ namespace smpc
             for (int J = 0; J < NTJ; J++)
             {
               SMPC_PLV(abv)[J] = 16 * J + lc < NXU ? SMPC_PLV(abn)[J] : 0.0;
-              // next slice (the second product starts again at slice 0)
-              SMPC_PLV(abn)[J] = ab_fetch(ks + 1 < NDX / 4 ? ks + 1 : 0, J, lr, lc);
+              // slice after next (the second product starts again at slice 0)
+              if constexpr (TWO_AHEAD)
+              {
+                SMPC_PLV(abn)[J] = SMPC_PLV(abn2)[J];
+                SMPC_PLV(abn2)[J] = ab_fetch((ks + 2) % (NDX / 4), J, lr, lc);
+              }
+              else
+                SMPC_PLV(abn)[J] = ab_fetch(ks + 1 < NDX / 4 ? ks + 1 : 0, J, lr, lc);
             }
           }
           SMPC_LANES_END_WAVE
@@ -302,7 +318,13 @@ namespace smpc
               for (int J = 0; J < NTJ; J++)
               {
                 SMPC_PLV(abv)[J] = 16 * J + lc < NXU ? SMPC_PLV(abn)[J] : 0.0;
-                if (ks + 1 < NDX / 4)
+                if constexpr (TWO_AHEAD)
+                {
+                  SMPC_PLV(abn)[J] = SMPC_PLV(abn2)[J];
+                  if (ks + 2 < NDX / 4)
+                    SMPC_PLV(abn2)[J] = ab_fetch(ks + 2, J, lr, lc);
+                }
+                else if (ks + 1 < NDX / 4)
                   SMPC_PLV(abn)[J] = ab_fetch(ks + 1, J, lr, lc);
               }
 #pragma unroll
