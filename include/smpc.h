@@ -223,6 +223,10 @@ int smpc_gather_outputs(smpc_handle * h, double * out, size_t row_doubles);
  * a collective towards the process that owns the controllers (one process per device: torch.distributed gather over RCCL), a peer copy, or
  * one copy into pinned memory from a side stream so that the transfer overlaps the next control step.  Kinodynamics handles. */
 int smpc_gather_outputs_device(smpc_handle * h, double * out_device, size_t row_doubles);
+/* ... and into a buffer on ANOTHER device of the node (hipMemcpyPeerAsync over xGMI on the handle's stream, after the pack kernel): one
+ * process, one handle per device, every device's rows gathered on the device that runs the controllers.  `out_peer` points to
+ * [batch][nx + nu + nu ndx] doubles on device `dst_device`, rows contiguous.  Kinodynamics handles. */
+int smpc_gather_outputs_peer(smpc_handle * h, double * out_peer, int dst_device);
 /* Checkpoint / resume (the reference has none; a batched simulator needs it to roll back or migrate a batch).
  * The state is everything a later smpc_iterate depends on: iterate, multipliers, swing trajectories, references, velocity
  * commands, gait bookkeeping -- not the feedback gains of the last solve (the next iterate recomputes them).

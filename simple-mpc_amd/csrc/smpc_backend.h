@@ -188,6 +188,11 @@ namespace smpc
   {
     SMPC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
   }
+  // device -> another device of the node (xGMI; the runtime stages through host memory when peer access is not available)
+  inline void d2peer(void * dst, int dst_device, const void * src, int src_device, size_t bytes, stream_t s)
+  {
+    SMPC_HIP(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, s));
+  }
   inline void dev_zero(void * dst, size_t bytes, stream_t s) { SMPC_HIP(hipMemsetAsync(dst, 0, bytes, s)); }
   inline void stream_sync(stream_t s) { SMPC_HIP(hipStreamSynchronize(s)); }
   inline stream_t stream_create()

@@ -529,6 +529,16 @@ extern "C"
       return fail(SMPC_ERR_INVALID, KINO_ONLY);
     return guarded([&] { h->eng->gather_outputs_device(out_device, row_doubles); });
   }
+  int smpc_gather_outputs_peer(smpc_handle * h, double * out_peer, int dst_device)
+  {
+    if (!h || !out_peer)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    if (!h->eng)
+      return fail(SMPC_ERR_INVALID, KINO_ONLY);
+    if (dst_device < 0 || dst_device >= device_count())
+      return fail(SMPC_ERR_INVALID, "destination device out of range");
+    return guarded([&] { h->eng->gather_outputs_peer(out_peer, dst_device); });
+  }
   int smpc_iterate_device(smpc_handle * h, const double * Xd)
   {
     if (!h || !Xd)

@@ -1393,6 +1393,16 @@ namespace smpc
       pa.out = out_dev;
       launch<PackOutArgs<D>, pack_outputs_body<D>, 64>(B, stream, pa);
     }
+    // ... and into a buffer of ANOTHER device of the node: packed here, then one peer copy over xGMI on this engine's stream (the form
+    // SURVEY 8e lists for a single process that drives all devices: every device's rows land in one buffer on the device -- or next to the
+    // host thread -- that runs the controllers).  dst: [batch][GATHER_ROW] doubles, contiguous.
+    void gather_outputs_peer(double * dst, int dst_device)
+    {
+      const size_t bytes = (size_t)B * GATHER_ROW * sizeof(double);
+      double * dev = staging(bytes);
+      gather_outputs_device(dev, GATHER_ROW);
+      d2peer(dst, dst_device, dev, device_id, bytes, stream);
+    }
     // xs[t] of every instance -> dense device buffer [B][NX], asynchronous on the engine's stream
     void gather_x_device(int t, double * out_dev)
     {

@@ -788,6 +788,10 @@ class BatchedMPC:
         row = self.nx + self.nu + self.nu * self.ndx
         self._lib.check(self._lib.L.smpc_gather_outputs_device(self._h, C.c_void_p(int(device_ptr)), int(row_doubles or row)))
 
+    def gather_outputs_peer(self, device_ptr, dst_device):
+        """The packed rows [batch][nx + nu + nu ndx] into a buffer on another device of the node (peer copy on the handle's stream)."""
+        self._lib.check(self._lib.L.smpc_gather_outputs_peer(self._h, C.c_void_p(int(device_ptr)), int(dst_device)))
+
     def setEarlyExitOnTol(self, on=True):
         """SolverProxDDP's convergence test inside iterate (reference src/mpc.cpp:43,212): an instance converged to settings TOL at the
         start of an iteration takes no further step in that control step.  Off by default (the metric is at fixed iterations)."""

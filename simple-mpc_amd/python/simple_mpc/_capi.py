@@ -153,7 +153,7 @@ SYMBOLS = [
     "smpc_get_reference_pose", "smpc_get_contact_state", "smpc_get_cycling_contact_state", "smpc_debug_get_extra_multipliers", "smpc_set_x_reference",
     "smpc_state_size", "smpc_save_state", "smpc_load_state", "smpc_iterate", "smpc_iterate_device", "smpc_wait", "smpc_get_stream", "smpc_get_x_device", "smpc_get_xs", "smpc_get_us", "smpc_get_K0", "smpc_get_Ks",
     "smpc_get_vs", "smpc_get_lams", "smpc_get_state_derivative01", "smpc_get_reference_poses",
-    "smpc_set_early_exit_on_tol", "smpc_iterate_async", "smpc_gather_outputs", "smpc_gather_outputs_device", "smpc_get_foot_timing", "smpc_get_info", "smpc_get_status", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
+    "smpc_set_early_exit_on_tol", "smpc_iterate_async", "smpc_gather_outputs", "smpc_gather_outputs_device", "smpc_gather_outputs_peer", "smpc_get_foot_timing", "smpc_get_info", "smpc_get_status", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
     "smpc_debug_get_steps", "smpc_debug_get_terminal", "smpc_debug_get_phase_cycles", "smpc_set_profiling", "smpc_get_kernel_times", "smpc_get_kernel_times_n", "smpc_kernel_time_slots", "smpc_reset_kernel_times",
     "smpc_interpolate", "smpc_interpolate_knots", "smpc_friction_compensation", "smpc_update_internal_data", "smpc_full_forward_dynamics", "smpc_centroidal_dynamics", "smpc_riccati_feedback",
     "smpc_id_create", "smpc_id_destroy", "smpc_id_set_target", "smpc_id_set_targets", "smpc_id_set_target_centroidal", "smpc_id_set_targets_centroidal", "smpc_id_solve", "smpc_id_solve_device", "smpc_id_wait", "smpc_id_get_resid", "smpc_id_reset", "smpc_id_get_tau_device", "smpc_id_get_x_device", "smpc_id_set_targets_from_mpc", "smpc_id_share_stream", "smpc_sim_step_device", "smpc_id_debug_get",
@@ -200,6 +200,7 @@ class SmpcLib:
         L.smpc_iterate_async.argtypes = [vp, _dp]
         L.smpc_gather_outputs.argtypes = [vp, C.c_void_p, C.c_size_t]
         L.smpc_gather_outputs_device.argtypes = [vp, C.c_void_p, C.c_size_t]
+        L.smpc_gather_outputs_peer.argtypes = [vp, C.c_void_p, C.c_int]
         L.smpc_destroy.argtypes = [vp]
         L.smpc_get_dims.argtypes = [vp, _ip]
         L.smpc_generate_cycle_horizon.argtypes = [vp, _bp, C.c_int]

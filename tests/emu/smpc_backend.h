@@ -92,6 +92,7 @@ namespace smpc
       std::memcpy((char *)dst + r * dpitch, (const char *)src + r * spitch, width);
   }
   inline void d2d(void * dst, const void * src, size_t bytes, stream_t) { std::memmove(dst, src, bytes); }
+  inline void d2peer(void * dst, int, const void * src, int, size_t bytes, stream_t) { std::memmove(dst, src, bytes); }
   inline void dev_zero(void * dst, size_t bytes, stream_t) { std::memset(dst, 0, bytes); }
   inline void stream_sync(stream_t) {}
   inline stream_t stream_create() { return 0; }

@@ -96,6 +96,13 @@ def test_two_handles_gather_into_one_buffer():
         whole.gather_outputs_device(packed.ctypes.data, row + 3)
         whole.wait()
         assert np.array_equal(packed[:, :row], out) and np.isnan(packed[:, row:]).all()
+        # the peer-copy form: every handle's rows into one buffer "on device 0"
+        peer = np.full((5, row), np.nan)
+        parts[0].gather_outputs_peer(peer.ctypes.data, 0)
+        parts[1].gather_outputs_peer(peer.ctypes.data + 2 * row * 8, 0)
+        for p in parts:
+            p.wait()
+        assert np.array_equal(peer, out)
         X = whole.xs[:, 1, :].copy()
 
 
@@ -142,6 +149,13 @@ def test_gpu_two_handles_gather_into_one_pinned_buffer():
         whole.wait()
         ph = packed.cpu().numpy()
         assert np.array_equal(ph[:, :row], out) and np.isnan(ph[:, row:]).all()
+        # peer-copy form (hipMemcpyPeerAsync on each handle's stream): all rows into one buffer on device 0
+        peer = torch.full((sum(sizes), row), float("nan"), dtype=torch.float64, device="cuda:0")
+        parts[0].gather_outputs_peer(peer.data_ptr(), 0)
+        parts[1].gather_outputs_peer(peer.data_ptr() + sizes[0] * row * 8, 0)
+        for p in parts:
+            p.wait()
+        assert np.array_equal(peer.cpu().numpy(), out)
         # the host thread came back from the launches before the device work was done (nothing in iterateAsync / gatherOutputs waits)
         if it > 0:
             assert t_launch < 0.5 * t_all, (t_launch, t_all)
