@@ -334,7 +334,8 @@ int smpc_full_forward_dynamics(
 /* ---- state feedback front-end (replaces RobotDataHandler::updateInternalData(x, false) and
  *      getCentroidalState, reference src/robot-handler.cpp:106-127,142-149) for a batch of measured multibody states
  *      X [B][nx] (host): feet [B][nf][3] foot positions (world), com [B][3], hg [B][6] centroidal momentum
- *      [linear; angular about the CoM], centroidal_state [B][9] = [com; h_lin; h_ang].  Any output may be NULL. */
+ *      [linear; angular about the CoM], centroidal_state [B][9] = [com; h_lin; h_ang].  Any output may be NULL.
+ *      Every kind of handle: the kinodynamics, centroidal and full-dynamics OCPs of the quadruped and of the biped. */
 int smpc_update_internal_data(smpc_handle * h, const double * X, double * feet, double * com, double * hg, double * centroidal_state);
 /* Riccati feedback application between MPC knots (reference examples/go2_fulldynamics.py:271-285):
  *   u_out[b] = interpolateLinear(us)[b] - Ks[0][b] * difference(X_meas[b], interpolateState(xs)[b])

@@ -933,7 +933,7 @@ extern "C"
     if (!h || !X)
       return fail(SMPC_ERR_INVALID, "null argument");
     if (h->full)
-      return fail(SMPC_ERR_INVALID, "smpc_update_internal_data: use a kinodynamics or centroidal handle of the same robot");
+      return guarded([&] { h->full->update_internal_data(X, feet, com, hg, centroidal_state); });
     if (h->cent)
       return guarded([&] { h->cent->update_internal_data(X, feet, com, hg, centroidal_state); });
     return guarded([&] { h->eng->update_internal_data(X, feet, com, hg, centroidal_state); });

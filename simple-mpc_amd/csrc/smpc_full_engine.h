@@ -51,6 +51,7 @@ namespace smpc
     virtual void set_reference_pose(int t, int foot, const double * p3) = 0;
     virtual void get_reference_pose(int t, int foot, int inst, double * p3) = 0;
     virtual unsigned contact_mask(int t) const = 0;
+    virtual void update_internal_data(const double * X, double * feet, double * com, double * hg, double * cstate) = 0;
     virtual size_t state_io(StateIO & io) = 0;
     virtual void collect_profile() = 0;
     virtual int lq_size() const = 0;
@@ -765,6 +766,32 @@ namespace smpc
         upload_stages();
       stream_sync(stream);
       return io.pos;
+    }
+    // state feedback front-end on measured states X [B][nq + nv] (host): feet [B][NF][3], com [B][3], hg [B][6], centroidal state [B][9]
+    // (host outputs, any may be null) -- RobotDataHandler::updateInternalData + getCentroidalState on the stage kernel's kinematics
+    void update_internal_data(const double * X, double * feet, double * com, double * hg, double * cstate) override
+    {
+      set_device(device_id);
+      const size_t nf = (size_t)B * D::NF * 3, nc = (size_t)B * 3, nh = (size_t)B * 6, ns = (size_t)B * 9;
+      double * st = staging((nf + nc + nh + ns) * sizeof(double));
+      h2d(X_dev, X, (size_t)B * D::NX * sizeof(double), stream);
+      FrontendArgs<D> fa;
+      fa.b = buf;
+      fa.X = X_dev;
+      fa.feet = st;
+      fa.com = st + nf;
+      fa.hg = st + nf + nc;
+      fa.cstate = st + nf + nc + nh;
+      launch<FrontendArgs<D>, frontend_full_body<D>, 64, 1, 1>(B, stream, fa);
+      if (feet)
+        d2h(feet, st, nf * sizeof(double), stream);
+      if (com)
+        d2h(com, st + nf, nc * sizeof(double), stream);
+      if (hg)
+        d2h(hg, st + nf + nc, nh * sizeof(double), stream);
+      if (cstate)
+        d2h(cstate, st + nf + nc + nh, ns * sizeof(double), stream);
+      stream_sync(stream);
     }
     double * staging(size_t bytes)
     {

@@ -2436,4 +2436,40 @@ namespace smpc
         fdyn_trial_one<D>(ka, inst, t, ka.j0 + jj);
     }
   }
+
+  // ---------------------------------------------------------------------------------------------------------------
+  // state front end of a robot with any tree (RobotDataHandler::updateInternalData + getCentroidalState, reference
+  // src/robot-handler.cpp:106-149) on the kinematics phases of the dense stage kernel; DF = a FullDims of the robot
+  // ---------------------------------------------------------------------------------------------------------------
+  template <class DF>
+  SMPC_DEV void frontend_full_body(const FrontendArgs<DF> & ka, int block)
+  {
+    typedef FullScratch<DF, false> SC;
+    constexpr int NT = 64, NX = DF::NX, NF = DF::NF;
+    const int inst = block;
+    const DevModel<DF> & mg = *ka.b.model;
+    SMPC_LDS(SC, scs, 1);
+    SC & sc = scs[0];
+    SMPC_LANES(NT)
+    {
+      full_load_head<DF, NT>(sc.h, &mg, lane);
+      for (int i = lane; i < NX; i += NT)
+        sc.x[i] = ka.X[(size_t)inst * NX + i];
+    }
+    SMPC_LANES_END_WAVE
+    FullProf fp;
+    full_dynamics_phases<DF, false>(sc, (FullScratchDeriv<DF> *)nullptr, mg, 0u, false, fp);
+    SMPC_LANES(NT)
+    {
+      if (ka.feet != nullptr && lane < NF * 3)
+        ka.feet[(size_t)inst * NF * 3 + lane] = sc.footp[lane];
+      if (ka.com != nullptr && lane < 3)
+        ka.com[(size_t)inst * 3 + lane] = sc.com[lane];
+      if (ka.hg != nullptr && lane < 6)
+        ka.hg[(size_t)inst * 6 + lane] = sc.hg[lane];
+      if (ka.cstate != nullptr && lane < 9)
+        ka.cstate[(size_t)inst * 9 + lane] = lane < 3 ? sc.com[lane] : sc.hg[lane - 3];
+    }
+    SMPC_LANES_END_WAVE
+  }
 } // namespace smpc
