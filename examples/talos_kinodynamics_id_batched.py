@@ -1,10 +1,12 @@
 """Batched counterpart of the reference's examples/talos_kinodynamics.py (settings :50-106, MPC :108-150, inverse dynamics :160-169, loop
-:214-270) without the simulator: B bipeds (the built-in talos_like table: Talos' joint tree, two flat feet) run the KINODYNAMICS MPC with 6-D
+:214-270): B bipeds (the built-in talos_like table: Talos' joint tree, two flat feet) run the KINODYNAMICS MPC with 6-D
 feet -- contact wrenches and joint accelerations as controls, 6-D foot placement costs, wrench cones -- at 100 Hz (H = 100), and between
 two MPC steps the whole-body inverse-dynamics QP with flat-foot contacts (tsid Contact6d: 12 corner forces per foot) turns the interpolated
-MPC targets into joint torques at 1 kHz.  The measured state of every robot is the MPC's own prediction (x_meas = interpolated xs).
+MPC targets into joint torques at 1 kHz.  The simulator of the reference is replaced by the constrained forward dynamics kernel with 6-D
+contacts (a full-dynamics handle of the same robot): every robot is integrated under the torques of its own QP.  With a third argument
+"open" the measured state is the MPC's own prediction instead (no simulated robot).
 
-    python examples/talos_kinodynamics_id_batched.py [batch] [mpc_steps]
+    python examples/talos_kinodynamics_id_batched.py [batch] [mpc_steps] [open]
 """
 import os
 import sys
@@ -14,10 +16,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "simple-mpc_amd", "python"))
-from simple_mpc import BatchedMPC, KinodynamicsID, KinodynamicsOCP, RobotModelHandler, load_robot, presets  # noqa: E402
+from simple_mpc import BatchedMPC, FullDynamicsOCP, KinodynamicsID, KinodynamicsOCP, RobotModelHandler, load_robot, presets  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+SIMULATE = not (len(sys.argv) > 3 and sys.argv[3] == "open")
 LIB = None  # (tests pass the CPU test build here)
 
 mh = RobotModelHandler(load_robot("talos_like", LIB), "half_sitting", "root_joint")
@@ -40,6 +43,12 @@ dt_simu = dt_mpc / N_simu
 id_settings = dict(kp_base=7.0, kp_posture=10.0, kp_contact=10.0, w_base=100.0, w_posture=1.0, w_contact_force=0.001, w_contact_motion=1.0)  # :160-167
 kino_ID = KinodynamicsID(mh, dt_simu, id_settings, presets.TALOS_EFFORT, presets.TALOS_VMAX, batch=B, lib=LIB)
 
+sim = None
+if SIMULATE:  # the "robot": constrained forward dynamics with 6-D contacts, from a (short-horizon) full-dynamics handle of the same model
+    focp = FullDynamicsOCP(presets.talos_full_settings(mh), mh)
+    focp.createProblem(mh.getReferenceState(), 2, 6, -9.81, False)
+    sim = BatchedMPC({k: v for k, v in presets.talos_mpc_settings(mh, max_iters=1).items() if k in presets.MPC_KEYS}, focp, 1, lib=LIB)
+
 X = np.tile(mh.getReferenceState(), (B, 1))
 t_mpc = t_id = 0.0
 for step in range(steps):
@@ -51,12 +60,23 @@ for step in range(steps):
         x_i, a_i, f_i = mpc.interpolate(sub / float(N_simu) * dt_mpc)  # states, accelerations, contact wrenches [B][2][6]
         t0 = time.time()
         kino_ID.setTargets(x_i[:, :nq], x_i[:, nq:], a_i, contact, f_i)
-        tau = kino_ID.solve(step * dt_mpc + sub * dt_simu, x_i[:, :nq], x_i[:, nq:])
+        xm = X if SIMULATE else x_i
+        tau = kino_ID.solve(step * dt_mpc + sub * dt_simu, xm[:, :nq], xm[:, nq:])
         t_id += time.time() - t0
-    X = mpc.xs[:, 1, :]
+        if SIMULATE:
+            # "device.execute(tau)": constrained forward dynamics of the feet in contact (Baumgarte-stabilised), semi-implicit Euler
+            mask = np.full(B, sum(1 << i for i, c in enumerate(contact) if c), np.uint32)
+            a = sim.constraintDynamics(X, tau, mask, Kp=[0.0] * 6, Kd=[50.0] * 6)["a"]
+            vn = X[:, nq:] + a * dt_simu
+            X = np.stack([presets.integrate(np.r_[X[b, :nq], vn[b]], np.r_[vn[b] * dt_simu, np.zeros(nv)], nq) for b in range(B)])
+    if not SIMULATE:
+        X = mpc.xs[:, 1, :]
 wrench = kino_ID.getContactForces()  # [B][2][6]: the wrenches T f of the corner forces, foot frames
 print("%d bipeds, %d MPC steps x %d controller ticks: MPC %.2f ms / step, flat-foot inverse dynamics %.2f ms / tick (host copies included)" % (
     B, steps, N_simu, 1e3 * t_mpc / steps, 1e3 * t_id / (steps * N_simu)))
 print("base x after %.2f s: %.3f m (0.05 m/s command) ... %.3f m (0.15 m/s command); max |tau| / limit %.2f; vertical contact force %.0f N of %.0f N weight" % (
     steps * dt_mpc, X[0, 0], X[-1, 0], np.abs(tau / presets.TALOS_EFFORT).max(), wrench[0, :, 2].sum(), mh.getMass() * 9.81))
 assert np.all(np.isfinite(X)) and np.all(np.isfinite(tau)) and np.all(np.abs(tau) <= presets.TALOS_EFFORT + 1e-6)
+if SIMULATE:
+    print("simulated robots: base height %.3f .. %.3f m (reference %.3f)" % (X[:, 2].min(), X[:, 2].max(), mh.getReferenceState()[2]))
+    assert X[:, 2].min() > 0.8 * mh.getReferenceState()[2], "a simulated robot fell"

@@ -325,7 +325,9 @@ int smpc_interpolate(smpc_handle * h, double delay, int knots, double * x_out, d
  *      frames, the feet in contact first (in foot order), remaining entries 0; iters_out [n] proximal iterations (may be
  *      NULL); kernel_ms: wall time of the launch (may be NULL).  prox_accuracy / prox_mu / prox_max_iter <= 0 select the
  *      reference's ProximalSettings(1e-9, 1e-10, 10).  n need not be the handle's batch size; the handle supplies the
- *      robot table and gravity (kinodynamics handles only). */
+ *      robot table and gravity.  Kinodynamics handles (the quadruped, CONTACT_3D) and -- round 4 -- full-dynamics handles of either
+ *      robot: the contact model is the handle's (3-D LOCAL point feet, or 6-D LOCAL_WORLD_ALIGNED flat feet with Kp / Kd [6] and
+ *      lambda_out [n][6 nfeet] contact wrenches). */
 int smpc_full_forward_dynamics(
   smpc_handle * h, int n, const double * X, const double * tau, const unsigned * contact_mask, const double * Kp,
   const double * Kd, double prox_accuracy, double prox_mu, int prox_max_iter, double * a_out, double * lambda_out,

@@ -945,8 +945,12 @@ extern "C"
   {
     if (!h || !X || !tau || !contact_mask || !a_out || !lambda_out)
       return fail(SMPC_ERR_INVALID, "null argument");
+    if (h->full) // full-dynamics handle: its own robot, 3-D or 6-D contacts (Kp / Kd: force_size entries)
+      return guarded([&] {
+        h->full->full_forward_dynamics(n, X, tau, contact_mask, Kp, Kd, prox_accuracy, prox_mu, prox_max_iter, a_out, lambda_out, iters_out, kernel_ms);
+      });
     if (!h->eng)
-      return fail(SMPC_ERR_INVALID, "smpc_full_forward_dynamics needs a kinodynamics handle (it carries the multibody model)");
+      return fail(SMPC_ERR_INVALID, "smpc_full_forward_dynamics needs a kinodynamics or a full-dynamics handle (they carry the multibody model)");
     return guarded([&] {
       h->eng->full_forward_dynamics(n, X, tau, contact_mask, Kp, Kd, prox_accuracy, prox_mu, prox_max_iter, a_out, lambda_out,
                                     iters_out, kernel_ms);

@@ -3,6 +3,7 @@
 // (smpc_engine.h); the stage kernels are fdyn_deriv_body / fdyn_trial_body (smpc_full_stage.h), the sweeps are dense
 // (riccati_dense_body on the matrix cores, or the VALU cross-check riccati_full_body with SMPC_RICCATI=valu).
 #pragma once
+#include <chrono>
 #include "smpc_engine.h"
 #include "smpc_full_solver.h"
 #include "smpc_riccati_dense.h"
@@ -52,6 +53,8 @@ namespace smpc
     virtual void get_reference_pose(int t, int foot, int inst, double * p3) = 0;
     virtual unsigned contact_mask(int t) const = 0;
     virtual void update_internal_data(const double * X, double * feet, double * com, double * hg, double * cstate) = 0;
+    virtual void full_forward_dynamics(int n, const double * X, const double * tau, const unsigned * mask, const double * Kp, const double * Kd,
+                                       double prox_accuracy, double prox_mu, int prox_max_iter, double * a, double * lam, int * iters, double * kernel_ms) = 0;
     virtual size_t state_io(StateIO & io) = 0;
     virtual void collect_profile() = 0;
     virtual int lq_size() const = 0;
@@ -792,6 +795,54 @@ namespace smpc
       if (cstate)
         d2h(cstate, st + nf + nc + nh, ns * sizeof(double), stream);
       stream_sync(stream);
+    }
+    // constrained forward dynamics of n states (host buffers): a [n][NV], lam [n][FS NF] (feet in contact first), iters [n] (may be null)
+    void full_forward_dynamics(int n, const double * X, const double * tau, const unsigned * mask, const double * Kp, const double * Kd,
+                               double prox_accuracy, double prox_mu, int prox_max_iter, double * a, double * lam, int * iters, double * kernel_ms) override
+    {
+      if constexpr (D::KINO)
+        throw std::runtime_error("full_forward_dynamics: the kinodynamics variant has no constrained forward dynamics (use a full-dynamics handle)");
+      else
+      {
+        if (n < 1)
+          throw std::runtime_error("full_forward_dynamics: n must be positive");
+        set_device(device_id);
+        constexpr int NV = D::NV, NX = D::NX, NCM = D::NCM, NU = D::NU;
+        // staging layout (doubles): X | tau | a | lam | mask (unsigned) | iters (int)
+        const size_t oX = 0, oT = oX + (size_t)n * NX, oA = oT + (size_t)n * NU, oL = oA + (size_t)n * NV, oM = oL + (size_t)n * NCM,
+                     oI = oM + ((size_t)n + 1) / 2, total = oI + ((size_t)n + 1) / 2;
+        double * st = staging(total * sizeof(double));
+        h2d(st + oX, X, (size_t)n * NX * sizeof(double), stream);
+        h2d(st + oT, tau, (size_t)n * NU * sizeof(double), stream);
+        h2d(st + oM, mask, (size_t)n * sizeof(unsigned), stream);
+        FdynFdArgs<D> fa;
+        fa.b = buf;
+        fa.X = st + oX;
+        fa.tau = st + oT;
+        fa.mask = reinterpret_cast<const unsigned *>(st + oM);
+        for (int i = 0; i < 6; i++)
+        {
+          fa.Kp[i] = (Kp && i < D::FS) ? Kp[i] : 0.0;
+          fa.Kd[i] = (Kd && i < D::FS) ? Kd[i] : 0.0;
+        }
+        fa.prox_accuracy = prox_accuracy > 0 ? prox_accuracy : 1e-9; // ProximalSettings(1e-9, 1e-10, 10), src/fulldynamics.cpp:39
+        fa.prox_mu = prox_mu > 0 ? prox_mu : 1e-10;
+        fa.prox_max_iter = prox_max_iter > 0 ? prox_max_iter : 10;
+        fa.a_out = st + oA;
+        fa.lam_out = st + oL;
+        fa.iters_out = reinterpret_cast<int *>(st + oI);
+        stream_sync(stream);
+        const auto t0 = std::chrono::steady_clock::now();
+        launch<FdynFdArgs<D>, fdyn_fd_body<D>, 64, 1, 1>(n, stream, fa);
+        stream_sync(stream);
+        if (kernel_ms)
+          *kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        d2h(a, st + oA, (size_t)n * NV * sizeof(double), stream);
+        d2h(lam, st + oL, (size_t)n * NCM * sizeof(double), stream);
+        if (iters)
+          d2h(iters, st + oI, (size_t)n * sizeof(int), stream);
+        stream_sync(stream);
+      }
     }
     double * staging(size_t bytes)
     {

@@ -2472,4 +2472,73 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
   }
+
+  // ---------------------------------------------------------------------------------------------------------------
+  // The constrained forward dynamics alone, for any robot of the full-dynamics engine (MultibodyConstraintFwdDynamics::forward ->
+  // pinocchio::constraintDynamics with the contacts of FullDynamicsOCP, reference src/fulldynamics.cpp:39,50-75,139): point feet (3-D
+  // LOCAL) and flat feet (6-D LOCAL_WORLD_ALIGNED).  One wavefront per state; the phases are those of the stage kernel.
+  // ---------------------------------------------------------------------------------------------------------------
+  template <class D>
+  struct FdynFdArgs
+  {
+    Buffers<D> b;          // only b.model is read
+    const double * X;      // [n][NX] states (device)
+    const double * tau;    // [n][NV - 6] joint torques (device)
+    const unsigned * mask; // [n] contact bit per foot (device)
+    double Kp[6], Kd[6];   // Baumgarte corrector (the first FS entries)
+    double prox_accuracy, prox_mu;
+    int prox_max_iter;
+    double * a_out;   // [n][NV]
+    double * lam_out; // [n][FS NF]: contact forces / wrenches ON the robot, feet in contact first (in order), rest 0
+    int * iters_out;  // [n] proximal iterations taken (may be null)
+  };
+  template <class D>
+  SMPC_DEV void fdyn_fd_body(const FdynFdArgs<D> & ka, int block)
+  {
+    typedef FullScratch<D, false> SC;
+    constexpr int NT = 64, NX = D::NX, NV = D::NV, NU = D::NU, NCM = D::NCM, FS = D::FS;
+    static_assert(!D::KINO, "the forward dynamics of the full model");
+    const int inst = block;
+    const DevModel<D> & mg = *ka.b.model;
+    const unsigned mask = ka.mask[inst];
+    SMPC_LDS(SC, scs, 1);
+    SC & sc = scs[0];
+    SMPC_LANES(NT)
+    {
+      full_load_head<D, NT>(sc.h, &mg, lane);
+      for (int i = lane; i < NX; i += NT)
+        sc.x[i] = ka.X[(size_t)inst * NX + i];
+      for (int i = lane; i < NU; i += NT)
+        sc.u[i] = ka.tau[(size_t)inst * NU + i];
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    {
+      if (lane < FS)
+      {
+        sc.h.Kp[lane] = ka.Kp[lane];
+        sc.h.Kd[lane] = ka.Kd[lane];
+      }
+      if (lane == 0)
+      {
+        sc.h.prox_accuracy = ka.prox_accuracy;
+        sc.h.prox_mu = ka.prox_mu;
+        sc.h.prox_max_iter = ka.prox_max_iter;
+      }
+    }
+    SMPC_LANES_END_WAVE
+    FullProf fp;
+    full_dynamics_phases<D, false>(sc, (FullScratchDeriv<D> *)nullptr, mg, mask, true, fp);
+    SMPC_LANES(NT)
+    {
+      const int nact = FS * __builtin_popcount(mask);
+      for (int i = lane; i < NV; i += NT)
+        ka.a_out[(size_t)inst * NV + i] = sc.a[i];
+      for (int i = lane; i < NCM; i += NT)
+        ka.lam_out[(size_t)inst * NCM + i] = i < nact ? sc.lam[i] : 0.0;
+      if (ka.iters_out != nullptr && lane == 0)
+        ka.iters_out[inst] = sc.iters_[0];
+    }
+    SMPC_LANES_END_WAVE
+  }
 } // namespace smpc

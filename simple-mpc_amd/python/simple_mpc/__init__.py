@@ -906,15 +906,17 @@ class BatchedMPC:
     def constraintDynamics(self, X, tau, contact_mask, Kp=None, Kd=None, prox_accuracy=0.0, prox_mu=0.0, prox_max_iter=0):
         """Constrained forward dynamics of the full-dynamics model, batched on the device (what the reference's
         FullDynamicsOCP gets from MultibodyConstraintFwdDynamics, src/fulldynamics.cpp:39,50-75,139): for states X[n, nx], joint
-        torques tau[n, nv - 6] and contact masks [n] returns dict(a[n, nv], lam[n, 3 nf] (contact frames, feet in contact
-        first), iters[n], kernel_ms).  Kinodynamics handles only."""
+        torques tau[n, nv - 6] and contact masks [n] returns dict(a[n, nv], lam[n, fs nf] (contact frames, feet in contact
+        first; fs = 3 for point feet, 6 = wrenches of flat feet), iters[n], kernel_ms).  Kinodynamics handles of the quadruped and
+        full-dynamics handles of either robot (Kp / Kd: fs entries)."""
         X = np.ascontiguousarray(np.array(X, dtype=np.float64))
         tau = np.ascontiguousarray(np.array(tau, dtype=np.float64))
         mk = np.ascontiguousarray(np.array(contact_mask, dtype=np.uint32))
         n = X.shape[0]
         if X.ndim != 2 or X.shape[1] != self.nx_in or tau.shape != (n, self.nv - 6) or mk.shape != (n,):
             raise RuntimeError("X [n, nq + nv], tau [n, nv - 6], contact_mask [n] expected")
-        a, lam, it, ms = np.zeros((n, self.nv)), np.zeros((n, 3 * self.nf)), np.zeros(n, np.int32), np.zeros(1)
+        fs = int(self.ocp_handler.settings.get("force_size", 3)) if isinstance(self.ocp_handler, FullDynamicsOCP) else 3
+        a, lam, it, ms = np.zeros((n, self.nv)), np.zeros((n, fs * self.nf)), np.zeros(n, np.int32), np.zeros(1)
         p = lambda v: v.ctypes.data_as(C.c_void_p)
         kp = None if Kp is None else np.ascontiguousarray(np.array(Kp, dtype=np.float64))
         kd = None if Kd is None else np.ascontiguousarray(np.array(Kd, dtype=np.float64))

@@ -47,9 +47,37 @@ def _properties(gm, rb, X, tau, masks, out):
             assert np.abs(c["Ag"] @ out["a"][i] + c["dAgv"] - np.concatenate([rb.mass * G, np.zeros(3)])).max() < 1e-8
 
 
+def _check_full_handles(lib):
+    """The same entry point on full-dynamics handles (fdyn_fd_body: the stage kernel's own dynamics phases): the quadruped with 3-D LOCAL
+    contacts and the biped with 6-D LOCAL_WORLD_ALIGNED contacts, with the Baumgarte gains of the reference's Talos example."""
+    for talos in (False, True):
+        gm, rb, _, _ = (S.make_talos_product if talos else S.make_full_product)(2, lib=lib, horizon=10)
+        fs, masks_all = (6, [0b11, 0b01, 0b10, 0b00]) if talos else (3, MASKS)
+        n = 10
+        rng = np.random.default_rng(3)
+        X = (S.talos_random_states(rb, n, seed=3, scale=0.7) if talos else S.random_states(rb, n, seed=3, scale=2.0))
+        tau = rng.normal(size=(n, rb.nv - 6)) * 5
+        masks = np.array([masks_all[i % len(masks_all)] for i in range(n)], np.uint32)
+        Kp, Kd = ((0, 0, 50.0, 0, 0, 0), (100.0,) * 6) if talos else ((0, 0, 50.0), (100.0,) * 3)
+        out = gm.constraintDynamics(X, tau, masks, Kp=Kp, Kd=Kd)
+        assert out["lam"].shape == (n, fs * rb.nf)
+        for i in range(n):
+            r = rb.full_forward_dynamics(X[i], tau[i], int(masks[i]), Kp, Kd, fs=fs)
+            nc = r["lam"].size
+            sa, sl = max(1.0, np.abs(r["a"]).max()), max(1.0, np.abs(r["lam"]).max() if nc else 1.0)
+            assert np.abs(out["a"][i] - r["a"]).max() < 1e-9 * sa, (talos, i, masks[i])
+            if nc:
+                assert np.abs(out["lam"][i, :nc] - r["lam"]).max() < 1e-9 * sl, (talos, i, masks[i])
+            assert np.all(out["lam"][i, nc:] == 0.0) and out["iters"][i] == r["prox_iters"]
+            # Newton-Euler on the whole robot with the returned accelerations and forces
+            res = r["M"] @ out["a"][i] + r["nle"] - np.concatenate([np.zeros(6), tau[i]]) - r["J"].T @ out["lam"][i, :nc]
+            assert np.abs(res).max() < 1e-6 * max(1.0, np.abs(r["nle"]).max())
+
+
 def test_kernel_body_on_cpu(built):
     _properties(*_check(S.emu_lib()))
     _check(S.emu_lib(), n=6, seed=9, Kp=(0, 0, 50.0), Kd=(100.0, 100.0, 100.0))
+    _check_full_handles(S.emu_lib())
 
 
 def test_argument_checks(built):
@@ -65,6 +93,7 @@ def test_argument_checks(built):
 def test_hip_library(built):
     _properties(*_check(None))
     _check(None, n=6, seed=9, Kp=(0, 0, 50.0), Kd=(100.0, 100.0, 100.0))
+    _check_full_handles(None)
 
 
 @pytest.mark.gpu

@@ -28,5 +28,5 @@ def test_talos_kinodynamics_id_stack_on_the_cpu_build(built):
 
 @pytest.mark.gpu
 def test_talos_kinodynamics_id_stack(built):
-    out = _run("talos_kinodynamics_id_batched.py", [64, 25], False)
-    assert "64 bipeds" in out
+    out = _run("talos_kinodynamics_id_batched.py", [16, 120], False)  # 1.2 s: double support, then the whole first swing of the left foot
+    assert "16 bipeds" in out and "simulated robots: base height" in out
