@@ -30,3 +30,14 @@ def test_talos_kinodynamics_id_stack_on_the_cpu_build(built):
 def test_talos_kinodynamics_id_stack(built):
     out = _run("talos_kinodynamics_id_batched.py", [16, 120], False)  # 1.2 s: double support, then the whole first swing of the left foot
     assert "16 bipeds" in out and "simulated robots: base height" in out
+
+
+def test_talos_centroidal_id_stack_on_the_cpu_build(built):
+    out = _run("talos_centroidal_id_batched.py", [2, 2], True, {"SMPC_EXAMPLE_HORIZON": "12"})
+    assert "flat-foot inverse dynamics" in out and "base height 1.026 .. 1.026" in out
+
+
+@pytest.mark.gpu
+def test_talos_centroidal_id_stack(built):
+    out = _run("talos_centroidal_id_batched.py", [16, 120], False)
+    assert "16 bipeds" in out
