@@ -980,9 +980,11 @@ extern "C"
   {
     if (!knots || !out || n < 1 || dim < 1 || kind < 0 || kind > 2 || !(timestep > 0.0) || !(delay >= 0.0))
       return fail(SMPC_ERR_INVALID, "invalid argument");
-    if (kind == 0 && dim != DimsGo2::NX)
+    // the robot is told by the size of the knots: the two topologies the engines are instantiated for (free-flyer + nv - 6 joints)
+    const bool biped = (kind == 0 && dim == FullTalos::NX) || (kind == 1 && dim == FullTalos::NQ);
+    if (kind == 0 && dim != DimsGo2::NX && !biped)
       return fail(SMPC_ERR_INVALID, "State is not of the right size");
-    if (kind == 1 && dim != DimsGo2::NQ)
+    if (kind == 1 && dim != DimsGo2::NQ && !biped)
       return fail(SMPC_ERR_INVALID, "Configuration is not of the right size");
     if (device_count() <= 0)
       return fail(SMPC_ERR_NO_DEVICE, "no HIP device visible: the interpolator has no CPU path");
@@ -991,16 +993,25 @@ extern "C"
       stream_t st = stream_create();
       double * dk = (double *)dev_alloc(((size_t)n * dim + dim) * sizeof(double));
       h2d(dk, knots, (size_t)n * dim * sizeof(double), st);
-      InterpKnotsArgs<DimsGo2> ia;
-      ia.kind = kind;
-      ia.n = n;
-      ia.dim = dim;
-      ia.delay = delay;
-      ia.timestep = timestep;
-      ia.knots = dk;
-      ia.out = dk + (size_t)n * dim;
-      launch<InterpKnotsArgs<DimsGo2>, interp_knots_body<DimsGo2>, 64>(1, st, ia);
-      d2h(out, ia.out, (size_t)dim * sizeof(double), st);
+      auto run = [&](auto dims) {
+        typedef decltype(dims) DD;
+        InterpKnotsArgs<DD> ia;
+        ia.kind = kind;
+        ia.n = n;
+        ia.dim = dim;
+        ia.delay = delay;
+        ia.timestep = timestep;
+        ia.knots = dk;
+        ia.out = dk + (size_t)n * dim;
+        launch<InterpKnotsArgs<DD>, interp_knots_body<DD>, 64>(1, st, ia);
+      };
+#ifndef SMPC_KINO_ONLY
+      if (biped)
+        run(FullTalos());
+      else
+#endif
+        run(DimsGo2());
+      d2h(out, dk + (size_t)n * dim, (size_t)dim * sizeof(double), st);
       stream_sync(st);
       dev_free(dk);
       stream_destroy(st);

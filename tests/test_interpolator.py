@@ -67,6 +67,16 @@ def _check_knot_lists(lib):
     assert ip.interpolateContacts(1.0, DT, cs) == cs[2]  # reference tests/interpolator.cpp:153-182
     with pytest.raises(RuntimeError, match="State is not of the right size"):
         ip.interpolateState(0.0, DT, qs)
+    # the biped (nq 29 / nv 28: the robot the reference's own interpolator test runs on, tests/interpolator.cpp:13-35)
+    rt = O.Robot("talos_like")
+    it = simple_mpc.Interpolator(simple_mpc.load_robot("talos_like", lib), lib=lib)
+    X = S.talos_random_states(rt, 4, seed=2, scale=0.8)
+    for delay in (0.0, 0.0031, 0.0199, 0.0273, 0.5):
+        step = min(int(delay / DT), 3)
+        sfrac = (delay - step * DT) / DT
+        e = X[3] if step >= 3 else rt.integrate(X[step], sfrac * rt.difference(X[step], X[step + 1]))
+        assert np.abs(it.interpolateState(delay, DT, list(X)) - e).max() < 1e-13
+        assert np.abs(it.interpolateConfiguration(delay, DT, [x[: rt.nq] for x in X]) - e[: rt.nq]).max() < 1e-13
 
 
 def _check_batched_targets(lib):
