@@ -455,7 +455,11 @@ double * smpc_id_get_x_device(smpc_id_handle * h);
  *   smpc_sim_step_device          one step of a simulated batch: constrained forward dynamics of the feet in contact (flags per foot;
  *                                 Baumgarte gains Kp, Kd [3], NULL = 0; ProximalSettings of record) under torques tau_device, then
  *                                 semi-implicit Euler over dt; X_device [B][nq + nv] is updated in place.  Asynchronous on the MPC
- *                                 handle's stream (smpc_wait joins); kinodynamics handles only (they carry the multibody model). */
+ *                                 handle's stream (smpc_wait joins).  Kinodynamics handles of the quadruped, and full-dynamics handles of
+ *                                 either robot (their own contact model: Kp, Kd of force_size entries).
+ * Round 4: the MPC handle of smpc_id_set_targets_from_mpc / smpc_id_share_stream may be of any kind -- the kinodynamics OCP of the biped
+ * with flat feet and the full-dynamics OCPs feed a KinodynamicsID controller of the same robot (states, accelerations, contact forces /
+ * wrenches of stage 0 .. 1 interpolated on the device). */
 int smpc_id_set_targets_from_mpc(smpc_id_handle * id, smpc_handle * mpc, double delay, int knots);
 /* From now on the controller issues its work on the MPC handle's stream (kinodynamics or centroidal handle; NULL: back to its own):
  * MPC step, targets, QP solves and simulator steps then form one in-order queue -- smpc_id_wait / smpc_wait are needed only before the

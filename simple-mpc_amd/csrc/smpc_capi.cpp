@@ -1261,14 +1261,31 @@ extern "C"
           mpc->cent->wait_stream(e->solve_stream());
       });
     }
-    if (!mpc->eng)
-      return fail(SMPC_ERR_INVALID, "smpc_id_set_targets_from_mpc needs a kinodynamics or a centroidal MPC handle");
     {
       double *com, *vcom, *fp, *fv;
       e->centroidal_target_buffers(&com, &vcom, &fp, &fv);
       if (com)
         return fail(SMPC_ERR_INVALID, "a kinodynamics MPC handle feeds a KinodynamicsID controller");
     }
+    if (mpc->full)
+    { // kinodynamics OCP of a robot with flat feet (dense engine) or a full-dynamics OCP -> KinodynamicsID: states, accelerations, contact forces
+      FullEngineBase & fe = *mpc->full;
+      if (e->B != fe.B || e->nq != fe.dims[0] || e->nv != fe.dims[1] || e->nf != fe.dims[6] || e->nfw != fe.force_size)
+        return fail(SMPC_ERR_INVALID, "the controller and the MPC must hold the same batch of the same robot");
+      return guarded([&] {
+        double *x, *a, *f;
+        e->target_buffers(&x, &a, &f);
+        e->set_mask_all(fe.contact_mask(0));
+        const bool shared = e->solve_stream() == fe.stream;
+        if (!shared)
+          e->wait();
+        fe.interpolate_device(delay, knots, x, a, f);
+        if (!shared)
+          fe.wait_stream(e->solve_stream());
+      });
+    }
+    if (!mpc->eng)
+      return fail(SMPC_ERR_INVALID, "smpc_id_set_targets_from_mpc needs an MPC handle");
     if (e->B != mpc->eng->B || e->nq != DimsGo2::NQ || e->nv != DimsGo2::NV)
       return fail(SMPC_ERR_INVALID, "the controller and the MPC must hold the same batch of the same robot");
     return guarded([&] {
@@ -1290,20 +1307,25 @@ extern "C"
     IdEngineBase * e = reinterpret_cast<IdEngineBase *>(id);
     if (!mpc)
       return guarded([&] { e->adopt_stream(e->solve_stream(), true); });
-    if (mpc->full)
-      return fail(SMPC_ERR_INVALID, "smpc_id_share_stream needs a kinodynamics or a centroidal MPC handle");
-    if ((mpc->cent ? mpc->cent->device_id : mpc->eng->device_id) != e->device())
+    if ((mpc->full ? mpc->full->device_id : (mpc->cent ? mpc->cent->device_id : mpc->eng->device_id)) != e->device())
       return fail(SMPC_ERR_INVALID, "smpc_id_share_stream: the controller and the MPC handle live on different devices");
-    return guarded([&] { e->adopt_stream(mpc->cent ? mpc->cent->stream : mpc->eng->stream, false); });
+    return guarded([&] { e->adopt_stream(mpc->full ? mpc->full->stream : (mpc->cent ? mpc->cent->stream : mpc->eng->stream), false); });
   }
   int smpc_sim_step_device(smpc_handle * h, double * X_device, const double * tau_device, const uint8_t * contact, const double * Kp, const double * Kd, double dt)
   {
     if (!h || !X_device || !tau_device || !contact)
       return fail(SMPC_ERR_INVALID, "null argument");
-    if (!h->eng)
-      return fail(SMPC_ERR_INVALID, "smpc_sim_step_device needs a kinodynamics handle (it carries the multibody model)");
     if (!(dt > 0.0))
       return fail(SMPC_ERR_INVALID, "dt must be positive");
+    if (h->full)
+    { // full-dynamics handle: its own robot and contact model (Kp / Kd: force_size entries)
+      unsigned mask = 0;
+      for (int k = 0; k < h->full->dims[6]; k++)
+        mask |= contact[k] ? (1u << k) : 0u;
+      return guarded([&] { h->full->sim_step_device(X_device, tau_device, mask, Kp, Kd, dt); });
+    }
+    if (!h->eng)
+      return fail(SMPC_ERR_INVALID, "smpc_sim_step_device needs a kinodynamics or a full-dynamics handle (they carry the multibody model)");
     unsigned mask = 0;
     for (int k = 0; k < DimsGo2::NF; k++)
       mask |= contact[k] ? (1u << k) : 0u;

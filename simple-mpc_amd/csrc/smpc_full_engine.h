@@ -26,6 +26,7 @@ namespace smpc
   struct FullEngineBase
   {
     int B = 0, H = 0, R = 0, head = 0;
+    int device_id = 0;
     int dims[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // nq nv nx ndx nu nc nf H
     int force_size = 3;
     GaitTimer timer;
@@ -63,6 +64,11 @@ namespace smpc
     virtual void debug_terminal(int inst, double * QN, double * qN) = 0;
     virtual bool phase_cycles(double * out64) = 0;
     virtual void interpolate(double delay, int knots, double * x_out, double * acc_out, double * f_out) = 0;
+    // device-resident forms (nothing crosses the host between two MPC steps): the interpolated targets written into the
+    // inverse-dynamics engine's device buffers, the simulated robot stepped in place, ordering with another stream
+    virtual void interpolate_device(double delay, int knots, double * x_dev, double * acc_dev, double * f_dev) = 0;
+    virtual void sim_step_device(double * X_dev, const double * tau_dev, unsigned mask, const double * Kp, const double * Kd, double dt) = 0;
+    virtual void wait_stream(stream_t other) = 0;
     virtual void riccati_feedback(double delay, const double * X, double * u_out) = 0;
   };
 
@@ -71,7 +77,6 @@ namespace smpc
   {
   public:
     Buffers<D> buf;
-    int device_id = 0;
     HostMpcSettings ms;
     std::vector<StageShared<D>> horizon, cycle;
     StageShared<D> standing;
@@ -265,6 +270,11 @@ namespace smpc
       dev_free(buf.und_list);
       dev_free(buf.stages);
       dev_free(buf.model);
+      dev_free(sim_a);
+      dev_free(sim_lam);
+      dev_free(sim_mask);
+      if (ev_handoff_valid)
+        event_destroy(ev_handoff);
       stream_destroy(stream);
     }
     FullEngine(const FullEngine &) = delete;
@@ -953,6 +963,87 @@ namespace smpc
       if (f_out)
         d2h(f_out, st + nx + na, nf * sizeof(double), stream);
       stream_sync(stream);
+    }
+    void interpolate_device(double delay, int knots, double * x_dev, double * acc_dev, double * f_dev) override
+    {
+      if (knots < 2 || knots > H + 1)
+        throw std::runtime_error("interpolate: knots must be in [2, horizon + 1]");
+      if (!(delay >= 0.0))
+        throw std::runtime_error("interpolate: delay must be non-negative");
+      set_device(device_id);
+      FullInterpArgs<D> ia;
+      ia.b = buf;
+      ia.head = head;
+      ia.knots = knots;
+      ia.delay = delay;
+      ia.timestep = ms.timestep;
+      ia.x_out = x_dev;
+      ia.acc_out = acc_dev;
+      ia.f_out = f_dev;
+      ia.u_out = nullptr;
+      launch<FullInterpArgs<D>, full_interp_body<D>, 64>(B, stream, ia);
+    }
+    // One step of a simulated batch resident in HBM: constrained forward dynamics of the feet in `mask` (Baumgarte gains Kp, Kd [FS];
+    // proximal settings of record), then semi-implicit Euler over dt, X updated in place.  Asynchronous on this engine's stream.
+    double *sim_a = nullptr, *sim_lam = nullptr;
+    unsigned * sim_mask = nullptr;
+    unsigned sim_mask_value = ~0u;
+    void sim_step_device(double * X_dev_, const double * tau_dev, unsigned mask, const double * Kp, const double * Kd, double dt) override
+    {
+      if constexpr (D::KINO)
+        throw std::runtime_error("sim_step_device: the kinodynamics variant has no constrained forward dynamics (use a full-dynamics handle)");
+      else
+      {
+        set_device(device_id);
+        if (!sim_a)
+        {
+          sim_a = (double *)dev_alloc((size_t)B * D::NV * sizeof(double));
+          sim_lam = (double *)dev_alloc((size_t)B * D::NCM * sizeof(double));
+          sim_mask = (unsigned *)dev_alloc((size_t)B * sizeof(unsigned));
+        }
+        if (mask != sim_mask_value)
+        {
+          std::vector<unsigned> m(B, mask);
+          h2d(sim_mask, m.data(), m.size() * sizeof(unsigned), stream);
+          stream_sync(stream); // (m goes out of scope)
+          sim_mask_value = mask;
+        }
+        FdynFdArgs<D> fa;
+        fa.b = buf;
+        fa.X = X_dev_;
+        fa.tau = tau_dev;
+        fa.mask = sim_mask;
+        for (int i = 0; i < 6; i++)
+        {
+          fa.Kp[i] = (Kp && i < D::FS) ? Kp[i] : 0.0;
+          fa.Kd[i] = (Kd && i < D::FS) ? Kd[i] : 0.0;
+        }
+        fa.prox_accuracy = 1e-9; // ProximalSettings(1e-9, 1e-10, 10), src/fulldynamics.cpp:39
+        fa.prox_mu = 1e-10;
+        fa.prox_max_iter = 10;
+        fa.a_out = sim_a;
+        fa.lam_out = sim_lam;
+        fa.iters_out = nullptr;
+        launch<FdynFdArgs<D>, fdyn_fd_body<D>, 64, 1, 1>(B, stream, fa);
+        SimStepArgs<D> sa;
+        sa.X = X_dev_;
+        sa.a = sim_a;
+        sa.dt = dt;
+        launch<SimStepArgs<D>, sim_integrate_body<D>, 64, 1, 1>(B, stream, sa);
+      }
+    }
+    event_t ev_handoff{};
+    bool ev_handoff_valid = false;
+    void wait_stream(stream_t other) override
+    {
+      set_device(device_id);
+      if (!ev_handoff_valid)
+      {
+        ev_handoff = event_create();
+        ev_handoff_valid = true;
+      }
+      event_record(ev_handoff, stream);
+      stream_wait_event(other, ev_handoff);
     }
     // u = u_interp - K_0 (x_interp (-) x_meas) at `delay` after the last solve (reference examples/go2_fulldynamics.py:271-285)
     void riccati_feedback(double delay, const double * X, double * u_out) override

@@ -938,12 +938,14 @@ class BatchedMPC:
     def simStepDevice(self, x_device_ptr, tau_device_ptr, contact_state, dt, Kp=None, Kd=None):
         """One step of a simulated batch with states [B][nq + nv] and torques [B][nv - 6] resident in HBM: constrained forward dynamics of
         the feet in contact (Baumgarte gains Kp, Kd), then semi-implicit Euler over dt; the states are updated in place.  Asynchronous on
-        this handle's stream (wait() joins); the torques must be complete (KinodynamicsID.wait()).  Kinodynamics handles only."""
+        this handle's stream (wait() joins); the torques must be complete (KinodynamicsID.wait()).  Kinodynamics handles of the quadruped
+        and full-dynamics handles of either robot (Kp / Kd: force_size entries)."""
         c = np.ascontiguousarray(np.array([1 if b else 0 for b in contact_state], dtype=np.uint8))
         kp = np.ascontiguousarray(np.array(Kp, dtype=np.float64)) if Kp is not None else None
         kd = np.ascontiguousarray(np.array(Kd, dtype=np.float64)) if Kd is not None else None
-        if c.shape != (self.nf,) or any(g is not None and g.shape != (3,) for g in (kp, kd)):
-            raise RuntimeError("simStepDevice: one contact flag per foot, three Baumgarte gains each for Kp and Kd")
+        fs = int(self.ocp_handler.settings.get("force_size", 3)) if isinstance(self.ocp_handler, FullDynamicsOCP) else 3
+        if c.shape != (self.nf,) or any(g is not None and g.shape != (fs,) for g in (kp, kd)):
+            raise RuntimeError("simStepDevice: one contact flag per foot, force_size Baumgarte gains each for Kp and Kd")
         self._lib.check(self._lib.L.smpc_sim_step_device(self._h, C.c_void_p(int(x_device_ptr)), C.c_void_p(int(tau_device_ptr)), c,
                                                          kp.ctypes.data if kp is not None else None, kd.ctypes.data if kd is not None else None, float(dt)))
 

@@ -186,3 +186,91 @@ def test_hip_closed_loop_and_batch(built):
         assert S.rel_err(to, tg[:1]) < 1e-4 and S.rel_err(ao, kg.getAccelerations()[:1]) < 1e-4, i
         assert kg.getResiduals().max() < 1e-5
         x = M.step(rb, x, ao[0])
+
+
+def _talos_resident_stack(lib, B, mpc_steps, alloc):
+    """The biped's control stack with nothing crossing the host between two MPC steps -- kinodynamics MPC with 6-D feet (targets written by its
+    interpolation kernel: setTargetsFromMPC), KinodynamicsID with flat feet (solve_device), simulated robot (simStepDevice of a full-dynamics
+    handle: constrained forward dynamics with 6-D contacts) -- against the same loop through host buffers."""
+    from simple_mpc import presets as P
+
+    def setup():
+        mh = _handler(lib)
+        ocp = simple_mpc.KinodynamicsOCP(P.talos_kino_settings(mh), mh)
+        ocp.createProblem(mh.getReferenceState(), 10, 6, -9.81, False)
+        conf = dict({k: v for k, v in P.talos_mpc_settings(mh, max_iters=1).items() if k in P.MPC_KEYS}, T_fly=6, T_contact=2)
+        mpc = simple_mpc.BatchedMPC(conf, ocp, B, lib=lib)
+        mpc.generateCycleHorizon(P.walk_cycle(2, 6))
+        mpc.switchToWalk(np.array([0.1, 0, 0, 0, 0, 0.0]))
+        focp = simple_mpc.FullDynamicsOCP(P.talos_full_settings(mh), mh)
+        focp.createProblem(mh.getReferenceState(), 2, 6, -9.81, False)
+        sim = simple_mpc.BatchedMPC(conf, focp, B, lib=lib)
+        ids = dict(kp_base=7.0, kp_posture=10.0, kp_contact=10.0, w_base=100.0, w_posture=1.0, w_contact_force=0.001, w_contact_motion=1.0)
+        kid = simple_mpc.KinodynamicsID(mh, 1e-3, ids, O.TALOS_EFFORT, O.TALOS_VMAX, batch=B, lib=lib, admm_iters=100, admm_tol=-1.0)
+        return mh, mpc, sim, kid
+
+    mh, mpc, sim, kid = setup()
+    nq, nv = mh.nq, mh.nv
+    X = np.tile(mh.getReferenceState(), (B, 1))
+    swing = False
+    for _ in range(mpc_steps):  # host buffers
+        mpc.iterate(X)
+        contact = mpc.ocp_handler.getContactState(0)
+        swing = swing or not all(contact)
+        mask = np.full(B, sum(1 << i for i, c in enumerate(contact) if c), np.uint32)
+        for sub in range(10):
+            x_i, a_i, f_i = mpc.interpolate(sub / 10.0 * 0.01)
+            kid.setTargets(x_i[:, :nq], x_i[:, nq:], a_i, contact, f_i)
+            tau = kid.solve(0.0, X[:, :nq], X[:, nq:])
+            a = sim.constraintDynamics(X, tau, mask, Kp=[0.0] * 6, Kd=[50.0] * 6)["a"]
+            vn = X[:, nq:] + a * 1e-3
+            X = np.stack([P.integrate(np.r_[X[b, :nq], vn[b]], np.r_[vn[b] * 1e-3, np.zeros(nv)], nq) for b in range(B)])
+    assert swing
+    for shared in (False, True):
+        mh, mpc, sim, kid = setup()
+        if shared:
+            kid.shareStream(mpc)
+        Xd = alloc(np.tile(mh.getReferenceState(), (B, 1)))
+        for _ in range(mpc_steps):
+            mpc.iterate_device(Xd.ptr)
+            mpc.wait()
+            contact = mpc.ocp_handler.getContactState(0)
+            for sub in range(10):
+                kid.setTargetsFromMPC(mpc, sub / 10.0 * 0.01)
+                kid.solve_device(Xd.ptr)
+                kid.wait()  # (the simulator runs on the stream of ITS handle: the torques must be complete)
+                sim.simStepDevice(Xd.ptr, kid.tau_device_ptr(), contact, 1e-3, Kp=[0.0] * 6, Kd=[50.0] * 6)
+                sim.wait()
+            mpc.wait()
+        assert S.rel_err(X, Xd.get()) < 1e-8, (shared, S.rel_err(X, Xd.get()))
+        if shared:
+            kid.shareStream(None)
+
+
+class _HostArray:
+    def __init__(self, a):
+        self.a = np.ascontiguousarray(a)
+        self.ptr = self.a.ctypes.data
+
+    def get(self):
+        return self.a
+
+
+def test_emulated_kernels_talos_resident_stack(built):
+    _talos_resident_stack(S.emu_lib(), 2, 14, _HostArray)
+
+
+@pytest.mark.gpu
+def test_hip_talos_resident_stack(built):
+    import torch
+
+    class Dev:
+        def __init__(self, a):
+            self.t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            torch.cuda.synchronize()
+            self.ptr = self.t.data_ptr()
+
+        def get(self):
+            return self.t.cpu().numpy()
+
+    _talos_resident_stack(None, 8, 16, Dev)
