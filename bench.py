@@ -471,6 +471,54 @@ def control_stack_line(batch, device_id, mpc_steps=30):
             "note": "states, targets and torques resident in HBM; one MPC period = 1 iterate + 10 x (targets from the MPC, ID QP, simulator step)"}
 
 
+def control_stack_talos_line(batch, device_id, mpc_steps=20):
+    """The control stack of the reference's examples/talos_kinodynamics.py for `batch` simulated bipeds, nothing crossing the host inside
+    the loop: kinodynamics MPC with 6-D feet (1 ProxDDP iteration) at 100 Hz, interpolated targets + KinodynamicsID with flat feet at 1 kHz,
+    constrained forward dynamics with 6-D contacts + semi-implicit Euler as the simulator (a full-dynamics handle of the same robot)."""
+    import numpy as np
+    import torch
+    import simple_mpc
+    from simple_mpc import presets as P
+
+    gm, mh = make_mpc("talos_kinodynamics", batch, 1, device_id, horizon=100)
+    focp = simple_mpc.FullDynamicsOCP(P.talos_full_settings(mh), mh)
+    focp.createProblem(mh.getReferenceState(), 2, 6, -9.81, False)
+    ms = P.talos_mpc_settings(mh, max_iters=1)
+    sim = simple_mpc.BatchedMPC({k: ms[k] for k in P.MPC_KEYS}, focp, batch, device_id=device_id)
+    ids = dict(kp_base=7.0, kp_posture=10.0, kp_contact=10.0, w_base=100.0, w_posture=1.0, w_contact_force=0.001, w_contact_motion=1.0)
+    kid = simple_mpc.KinodynamicsID(mh, 1e-3, ids, P.TALOS_EFFORT, P.TALOS_VMAX, batch=batch, device_id=device_id)
+    kid.shareStream(gm)
+    X = torch.from_numpy(np.tile(mh.getReferenceState(), (batch, 1))).to(torch.device("cuda", device_id))
+    torch.cuda.synchronize()
+
+    def period():
+        gm.iterate_device(X.data_ptr())
+        gm.wait()
+        contact = gm.ocp_handler.getContactState(0)
+        for sub in range(10):
+            kid.setTargetsFromMPC(gm, sub * 1e-3)
+            kid.solve_device(X.data_ptr())
+            kid.wait()  # (the simulator runs on its own handle's stream: the torques must be complete)
+            sim.simStepDevice(X.data_ptr(), kid.tau_device_ptr(), contact, 1e-3, Kp=[0.0] * 6, Kd=[50.0] * 6)
+            sim.wait()
+
+    for _ in range(3):
+        period()
+    gm.wait()
+    t0 = time.perf_counter()
+    for _ in range(mpc_steps):
+        period()
+    gm.wait()
+    dt = (time.perf_counter() - t0) / mpc_steps
+    Xh = X.cpu().numpy()
+    kid.shareStream(None)
+    ok = bool(np.all(np.isfinite(Xh)) and np.all(np.abs(Xh[:, 2] - mh.getReferenceState()[2]) < 0.05))
+    return {"metric": "simulated robot-seconds per second, biped: kinodynamics MPC with 6-D feet (100 Hz, 1 iteration) + KinodynamicsID with flat feet "
+                      "(1 kHz) + forward-dynamics simulator with 6-D contacts",
+            "value": batch * 0.01 / dt, "unit": "robot-seconds/s", "ms_per_mpc_period": dt * 1e3, "batch": batch, "robots_upright": ok,
+            "note": "states, targets and torques resident in HBM; the simulator is a second handle (host-side waits between its stream and the controller's)"}
+
+
 def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     """BASELINE config "Go2 centroidal (9-dim state), H=50, batch=4096": same step definition on the centroidal OCP
     (one fused kernel per control step).  Measured states: x_ref (+) N(0, sigma^2), resident in HBM, re-drawn on the
@@ -1027,6 +1075,7 @@ def main():
             other["inverse_dynamics_qp"] = inverse_dynamics_line(B, local_rank, not args.no_cpu_baseline)
             other["inverse_dynamics_qp_flat_feet"] = inverse_dynamics_quad_line(B, local_rank)
             other["control_stack"] = control_stack_line(B, local_rank)
+            other["control_stack_talos"] = control_stack_talos_line(1024, local_rank)
             other["single_robot_latency"] = single_robot_latency(args.iters, local_rank)
             out["other_workloads"] = other
             # the other BASELINE configurations as flat keys (configs[1], configs[3]; configs[0] = cpu_baseline.cfg1_k1_b1; configs[4] = --gpus 8)
