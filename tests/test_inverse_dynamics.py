@@ -268,7 +268,7 @@ def test_settings_and_errors(built):
     cmpc = simple_mpc.BatchedMPC(conf, cocp, 1, lib=lib)
     with pytest.raises(RuntimeError, match="CentroidalID"):
         k.setTargetsFromMPC(cmpc, 0.0)
-    with pytest.raises(RuntimeError, match="kinodynamics handle"):
+    with pytest.raises(RuntimeError, match="kinodynamics or a full-dynamics handle"):
         cmpc.simStepDevice(x.ctypes.data, tau.ctypes.data, [True] * 4, 1e-3)
     kocp = simple_mpc.KinodynamicsOCP(P.go2_kino_settings(mh), mh)
     kocp.createProblem(mh.getReferenceState(), 10, 3, -9.81, False)
