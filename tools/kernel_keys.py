@@ -15,13 +15,25 @@ KEYS = {
     "fdyn_trial_body_go2": ("fdyn_trial_body", "FullDimsILi13E", 4096 * 51 * 64),
     "riccati_dense_body_go2": ("riccati_dense_body", "FullDimsILi13E", 4096 * 64),
     "forward_full_body_go2": ("forward_full_body", "FullDimsILi13E", 4096 * 64),
-    "fdyn_deriv_body_talos": ("fdyn_deriv_body", "FullDimsILi23E", 1024 * 101 * 64),
-    "fdyn_trial_body_talos": ("fdyn_trial_body", "FullDimsILi23E", 1024 * 101 * 64),
-    "riccati_dense_body_talos": ("riccati_dense_body", "FullDimsILi23E", 1024 * 64),
-    "forward_full_body_talos": ("forward_full_body", "FullDimsILi23E", 1024 * 64),
+    # Talos full dynamics = FullDims<23,2,6,0,0,0>; the kinodynamics OCP with 6-D feet runs the same kernels as FullDims<23,2,6,0,0,1>
+    "fdyn_deriv_body_talos": ("fdyn_deriv_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi0E", 1024 * 101 * 64),
+    "fdyn_trial_body_talos": ("fdyn_trial_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi0E", 1024 * 101 * 64),
+    "riccati_dense_body_talos": ("riccati_dense_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi0E", 1024 * 64),
+    "forward_full_body_talos": ("forward_full_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi0E", 1024 * 64),
+    "fdyn_deriv_body_taloskino": ("fdyn_deriv_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi1E", 1024 * 101 * 64),
+    "fdyn_trial_body_taloskino": ("fdyn_trial_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi1E", 1024 * 101 * 64),
+    "riccati_dense_body_taloskino": ("riccati_dense_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi1E", 1024 * 64),
+    "forward_full_body_taloskino": ("forward_full_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi1E", 1024 * 64),
+    # centroidal OCP with 6-D feet: (instance x stage) kernels around the dense sweep
+    "cent6_deriv_body": ("cent6_deriv_body", "", 1024 * 101 * 64),
+    "riccati_dense_body_cent6": ("riccati_dense_body", "Cent6DimsILi2E", 1024 * 64),
+    "cent6_forward_body": ("cent6_forward_body", "", 1024 * 64),
+    "cent6_ls_body": ("cent6_ls_body", "", 1024 * 64),
     "id_quant_body": ("id_quant_body", "", 4096 * 64),
     "id_assemble_body": ("id_assemble_body", "", 4096 * 64),
     "qp_admm_body": ("qp_admm_body", "", 4096 * 64),
+    "id6_assemble_body": ("id6_assemble_body", "", 4096 * 64),
+    "qp6_admm_body": ("qp6_admm_body", "", 4096 * 64),
 }
 
 
