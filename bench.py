@@ -944,10 +944,15 @@ def main():
                 g_events.append((e0, e1))
             ev_moved[slot].record(side_s)
 
+    gather_error = None
     for _ in range(args.warmup):
         step()
         if gather_timed:
-            emit(False)
+            try:
+                emit(False)
+            except Exception as exc:  # (a collective this build / node cannot run fails on every rank alike, at the first warm-up step)
+                gather_error = repr(exc)
+                gather_on = gather_timed = False
     profile = not args.no_profile and not dry
     if profile:
         gm.set_profiling(True)
@@ -1019,6 +1024,8 @@ def main():
                 "finite": ok,
             },
         }
+        if gather_error is not None:
+            out["gather"] = {"in_timed_region": False, "error": gather_error}
         if gather_on:
             out["gather"] = {"what": "rows [x1 | u0 | K0] of every instance, every control step, into one pinned host buffer on rank 0 (on a side stream: "
                              "overlaps the next step)", "in_timed_region": bool(gather_timed), "row_doubles": row, "bytes_per_step": world * B * row * 8,
