@@ -218,6 +218,10 @@ namespace simple_mpc
     // [x1 | u0 | K0] of every instance as rows of a caller-owned (pinned) buffer, wait
     void iterateAsync(const double * X) { check(smpc_iterate_async(h_, X)); }
     void gatherOutputs(double * out, std::size_t row_doubles) { check(smpc_gather_outputs(h_, out, row_doubles)); }
+    // ... packed into a device buffer of this handle's device ([batch][row_doubles]), or into a buffer on another device of the node (peer
+    // copy over xGMI; rows contiguous: [batch][gatherRow()]) -- both asynchronous on the handle's stream
+    void gatherOutputsDevice(double * out_device, std::size_t row_doubles) { check(smpc_gather_outputs_device(h_, out_device, row_doubles)); }
+    void gatherOutputsPeer(double * out_peer, int dst_device) { check(smpc_gather_outputs_peer(h_, out_peer, dst_device)); }
     void wait() { check(smpc_wait(h_)); }
     int gatherRow() const { return nx() + nu() + nu() * ndx(); }
     // MPC::getContactForces for every stage (reference src/mpc.cpp:354-380): [B][H][nfeet][force_size]; full-dynamics handles only
