@@ -274,3 +274,46 @@ def test_hip_talos_resident_stack(built):
             return self.t.cpu().numpy()
 
     _talos_resident_stack(None, 8, 16, Dev)
+
+
+def _talos_centroidal_resident_targets(lib, B):
+    """setTargetsFromMPC of the biped's centroidal MPC (6-D feet) into CentroidalID with flat feet = setTargets of its interpolated solution
+    (CoM, momentum / mass, foot references, contact wrenches) and contact flags -- the device-resident form of the loop of the reference's
+    examples/talos_centroidal.py:218-243."""
+    from simple_mpc import presets as P
+
+    mh = _handler(lib)
+    conf = dict({k: v for k, v in P.talos_mpc_settings(mh, max_iters=1).items() if k in P.MPC_KEYS}, T_fly=6, T_contact=2)
+    ocp = simple_mpc.CentroidalOCP(P.talos_centroidal_settings(mh), mh)
+    ocp.createProblem(np.zeros(9), 10, 6, -9.81, False)
+    mpc = simple_mpc.BatchedMPC(conf, ocp, B, lib=lib)
+    mpc.generateCycleHorizon(P.walk_cycle(2, 6))
+    mpc.switchToWalk(np.array([0.1, 0, 0, 0, 0, 0.0]))
+    rb = O.Robot("talos_like")
+    X = S.talos_random_states(rb, B, seed=2, scale=0.2)
+    for _ in range(14):  # (single support at stage 0)
+        mpc.iterate(X)
+    contact = mpc.ocp_handler.getContactState(0)
+    assert not all(contact)
+    ids = dict(kp_base=7.0, kp_com=7.0, kp_posture=10.0, kp_contact=10.0, kp_feet_tracking=100.0, w_base=50.0, w_com=100.0, w_posture=1.0,
+               w_contact_force=1e-3, w_contact_motion=1.0, w_feet_tracking=10.0)
+    mk = lambda: simple_mpc.CentroidalID(mh, 1e-3, ids, O.TALOS_EFFORT, O.TALOS_VMAX, batch=B, lib=lib, admm_iters=100, admm_tol=-1.0)
+    ka, kb = mk(), mk()
+    d = 0.4
+    x_i, _, f_i = mpc.interpolate(d * 0.01)
+    assert f_i.shape == (B, 2, 6)
+    refs = mpc.getReferencePoses()
+    ka.setTargets(x_i[:, :3], x_i[:, 3:6] / mh.getMass(), (1 - d) * refs[:, 0] + d * refs[:, 1], (refs[:, 1] - refs[:, 0]) / 0.01, contact, f_i)
+    kb.setTargetsFromMPC(mpc, d * 0.01)
+    ta = ka.solve(0.0, X[:, : mh.nq], X[:, mh.nq :])
+    tb = kb.solve(0.0, X[:, : mh.nq], X[:, mh.nq :])
+    assert np.all(np.isfinite(ta)) and S.rel_err(ta, tb) < 1e-12 and S.rel_err(ka.debug(6), kb.debug(6)) < 1e-12
+
+
+def test_emulated_kernels_talos_centroidal_resident_targets(built):
+    _talos_centroidal_resident_targets(S.emu_lib(), 2)
+
+
+@pytest.mark.gpu
+def test_hip_talos_centroidal_resident_targets(built):
+    _talos_centroidal_resident_targets(None, 8)
