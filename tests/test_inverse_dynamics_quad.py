@@ -307,7 +307,10 @@ def _talos_centroidal_resident_targets(lib, B):
     kb.setTargetsFromMPC(mpc, d * 0.01)
     ta = ka.solve(0.0, X[:, : mh.nq], X[:, mh.nq :])
     tb = kb.solve(0.0, X[:, : mh.nq], X[:, mh.nq :])
-    assert np.all(np.isfinite(ta)) and S.rel_err(ta, tb) < 1e-12 and S.rel_err(ka.debug(6), kb.debug(6)) < 1e-12
+    # the QP data agree to rounding; the torques after 100 ADMM iterations to 1e-7 -- on the GPU the interpolation kernel contracts
+    # multiply-adds that numpy does not, and the explicit K^-1 of the 52-variable QP (condition ~1e9) amplifies that last bit
+    assert S.rel_err(ka.debug(6), kb.debug(6)) < 1e-12
+    assert np.all(np.isfinite(ta)) and S.rel_err(ta, tb) < 1e-7
 
 
 def test_emulated_kernels_talos_centroidal_resident_targets(built):
