@@ -11,6 +11,8 @@ gm.set_profiling(True); gm.reset_kernel_times()
 for _ in range(3): gm.iterate(X)
 kt = gm.kernel_times()
 print(' '.join('%s %.2f' % (k, v[0]/max(1,v[1])) for k,v in kt.items()))
+if not os.environ.get('SMPC_PHASE_PROFILE'):
+    sys.exit(0)
 out = np.zeros(64); gm._lib.check(gm._lib.L.smpc_debug_get_phase_cycles(gm._h, out))
 names = ['load','kin','composite','M/J','cholM/W','G/Gi','prox/a','eval-tail','forces','dk/Ak/Jc','R1','R2','solves','WJ','tables/grad','AB','QSR']
 nd = 4*3
