@@ -17,7 +17,7 @@
 // 6-D feet (force_size 6; the Talos configuration of examples/talos_centroidal.py, tests/test_utils.cpp:199-218): u = [(f_i, tau_i) per
 //   foot]; the contact torques add to the angular momentum rate and to the angular_acc residual ([UPSTREAM-RECALL] aligator
 //   centroidal-fwd.hxx / angular-acceleration.hxx: xdot.tail<3>() += u.segment(i * 6 + 3, 3)); constraint per foot in contact:
-//   CentroidalWrenchConeResidual (src/centroidal-dynamics.cpp:86-91), 17 constant linear rows A_cone(mu, L, W) u_i <= 0.
+//   CentroidalWrenchConeResidual (src/centroidal-dynamics.cpp:90-95), 17 constant linear rows A_cone(mu, L, W) u_i <= 0.
 // Choice where the upstream scaling could not be checked: linear_acc is the CoM acceleration
 // g + sum f / m (not the force balance m g + sum f).
 #pragma once

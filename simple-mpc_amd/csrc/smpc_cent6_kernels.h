@@ -1,7 +1,7 @@
 // smpc_cent6_kernels.h -- the centroidal OCP of a robot with 6-D (flat) feet (reference CentroidalOCP with force_size == 6:
 // src/centroidal-dynamics.cpp:39-106 -- the Talos configuration of examples/talos_centroidal.py:39-96 and tests/test_utils.cpp:199-218):
 //   control u = [(f_i, tau_i) per foot]; the contact torques add to the angular-momentum rate and to the angular_acc residual;
-//   constraint per foot in contact: CentroidalWrenchConeResidual, 17 constant linear rows A_cone(mu, L, W) u_i <= 0 (:86-91).
+//   constraint per foot in contact: CentroidalWrenchConeResidual, 17 constant linear rows A_cone(mu, L, W) u_i <= 0 (:90-95).
 // Unlike the point-foot problem (cent_step_body: the whole control step fused in one wavefront, smpc_cent_kernels.h) a stage of this one
 // carries up to 34 explicit multiplier pivots; it runs as (instance x stage) kernels around the dense proximal Riccati sweep on the FP64
 // matrix cores (riccati_dense_body, smpc_riccati_dense.h) -- the sweep the full-dynamics and the 6-D kinodynamics OCPs use:

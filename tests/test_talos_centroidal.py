@@ -1,6 +1,6 @@
 """Centroidal OCP of a robot with 6-D (flat) feet on the device: the Talos configuration of the reference (CentroidalOCP with force_size = 6:
 src/centroidal-dynamics.cpp:39-106 -- contact torques in the angular-momentum rate and the angular_acc residual, CentroidalWrenchConeResidual per
-foot in contact :86-91; settings examples/talos_centroidal.py:39-96, tests/test_utils.cpp:199-218; what tests/problem.cpp:196-286 and the
+foot in contact :90-95; settings examples/talos_centroidal.py:39-96, tests/test_utils.cpp:199-218; what tests/problem.cpp:196-286 and the
 `mpc_centroidal` test exercise).  (instance x stage) kernels around the dense Riccati sweep (smpc_cent6_kernels.h).  HIP path / emulated kernel
 bodies against the oracle, <= 1e-4 relative; golden replay (tests/golden/talos_cent_golden.npz, make_golden_talos_cent.py)."""
 import os
