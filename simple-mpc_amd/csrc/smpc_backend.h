@@ -44,6 +44,15 @@
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                               \
   __builtin_amdgcn_wave_barrier();                                                                                     \
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// the same ordering point INSIDE a lane phase (one-wavefront workgroups, uniform control flow): LDS written by the lanes before it is visible to
+// every lane after it.  Only for code that is written for lockstep lanes (SMPC_LOCKSTEP); the sequential test backend has the per-lane form.
+#define SMPC_WAVE_SYNC()                                                                                               \
+  do                                                                                                                   \
+  {                                                                                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                             \
+    __builtin_amdgcn_wave_barrier();                                                                                   \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                             \
+  } while (0)
 // per-lane value that must survive a phase boundary (register on the GPU)
 #define SMPC_PL(type, name, NT) type name
 #define SMPC_PLA(type, name, NT, n) type name[n]

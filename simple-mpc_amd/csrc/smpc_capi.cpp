@@ -195,7 +195,11 @@ extern "C"
     ms.T = mpc->T;
     return guarded([&] {
       std::unique_ptr<smpc_handle> h(new smpc_handle());
+#ifdef SMPC_CENT_ONLY
+      throw std::runtime_error("SMPC_CENT_ONLY experiment build");
+#else
       h->eng.reset(new KinoEngine<DimsGo2>(robot, ks, ms, batch, gravity_arg, device_id));
+#endif
       *out = h.release();
     });
   }
@@ -243,11 +247,15 @@ extern "C"
     const HostMpcSettings ms = host_mpc(mpc);
     return guarded([&] {
       std::unique_ptr<smpc_handle> h(new smpc_handle());
-#ifndef SMPC_KINO_ONLY
+#if !defined(SMPC_KINO_ONLY)
       if (quad)
         h->cent.reset(new CentEngine<FullTalos, CentTalos>(robot, cs, ms, batch, gravity_arg, device_id));
       else
         h->cent.reset(new CentEngineGo2(robot, cs, ms, batch, gravity_arg, device_id));
+#elif defined(SMPC_CENT_ONLY)
+      if (quad)
+        throw std::runtime_error("SMPC_CENT_ONLY experiment build");
+      h->cent.reset(new CentEngineGo2(robot, cs, ms, batch, gravity_arg, device_id));
 #else
       (void)quad;
       throw std::runtime_error("SMPC_KINO_ONLY experiment build");

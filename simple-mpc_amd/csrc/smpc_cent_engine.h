@@ -13,6 +13,7 @@
 //   - no terminal constraint (src/centroidal-dynamics.cpp:318-337)
 #pragma once
 #include "smpc_cent6_kernels.h"
+#include "smpc_cent_split.h"
 #include "smpc_engine.h"
 
 namespace smpc
@@ -30,9 +31,9 @@ namespace smpc
   enum CentKernelId
   {
     CKID_FRONTEND = 0,
-    CKID_STEP,    // point feet: the fused control-step kernel ; 6-D feet: recede
-    CKID_DERIV,   // 6-D feet (smpc_cent6_kernels.h): stage evaluation + derivatives + knot
-    CKID_RICCATI, //   dense backward sweep
+    CKID_STEP,    // recede (point feet with SMPC_CENT_FUSED=1: the one-kernel control step)
+    CKID_DERIV,   // point feet (smpc_cent_split.h): lane-per-stage pre-pass ; 6-D feet (smpc_cent6_kernels.h): stage evaluation + derivatives + knot
+    CKID_RICCATI, //   backward sweep
     CKID_FORWARD, //   forward sweep
     CKID_LS,      //   line search + step
     CKID_N
@@ -123,6 +124,8 @@ namespace smpc
     CentBuffers<DC> buf;
     const CentBuffersBase & bufs() const override { return buf; }
     Cent6Extra<DC, DC::FS> x6; // 6-D feet: knots, dense gains, terminal node, merit partials
+    CentSplitBuffers sbuf;     // point feet: hand-over records of the kernel pipeline (smpc_cent_split.h)
+    bool fused = false;        // point feet: SMPC_CENT_FUSED=1 runs the one-kernel control step (cross-check)
     Buffers<DK> fk; // only .model is used (front-end kernel)
     HostMpcSettings ms;
     std::vector<CentStage<DC>> horizon, cycle;
@@ -203,9 +206,10 @@ namespace smpc
       buf.vs_e = dalloc(BR * DC::NC);
       buf.lams_e = dalloc(BR * 9);
       buf.dxs = dalloc((size_t)B * (H + 1) * 9);
-      buf.dus = dalloc(BH * DC::NU);
-      buf.dvs = dalloc(BH * DC::NC);
-      buf.dlams = dalloc(BH * 9);
+      // (steps: [B][H][.] linear in t for the one-kernel / 6-D paths; the kernel pipeline of point feet keeps them on the iterate's ring slots, [B][R][.])
+      buf.dus = dalloc(BR * DC::NU);
+      buf.dvs = dalloc(BR * DC::NC);
+      buf.dlams = dalloc(BR * 9);
       buf.foot = dalloc(BH * DC::NF * 3);
       buf.ftraj = dalloc((size_t)B * DC::NF * 6);
       buf.vbase = dalloc((size_t)B * 6);
@@ -229,6 +233,17 @@ namespace smpc
         x6.parts0 = dalloc((size_t)B * (H + 1) * 4);
         if (H + 1 > 256)
           throw std::runtime_error("centroidal OCP with 6-D feet: at most 255 stages");
+      }
+      if constexpr (DC::FS == 3)
+      {
+        fused = std::getenv("SMPC_CENT_FUSED") != nullptr && std::getenv("SMPC_CENT_FUSED")[0] == '1';
+        if (!fused)
+        {
+          if (BH * CentRec<DC>::STRIDE >= ((size_t)1 << 32))
+            throw std::runtime_error("centroidal OCP: batch x horizon too large for the 32-bit record offsets");
+          sbuf.rec = dalloc(BH * CentRec<DC>::STRIDE);
+          sbuf.term = dalloc((size_t)B * CentRec<DC>::T_STRIDE);
+        }
       }
       buf.scal = dalloc((size_t)B * SC_N);
       buf.xdot01 = dalloc((size_t)B * 18);
@@ -260,7 +275,7 @@ namespace smpc
     ~CentEngine()
     {
       for (double * p : {buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot, buf.ftraj, buf.vbase, buf.vref, buf.gains, buf.scal, buf.xdot01,
-                         buf.zeros, buf.dbg, X_dev, cstate_dev, feet_dev, stage_out})
+                         buf.zeros, buf.dbg, X_dev, cstate_dev, feet_dev, stage_out, sbuf.rec, sbuf.term})
         dev_free(p);
       if (ev_handoff_valid)
         event_destroy(ev_handoff);
@@ -379,8 +394,24 @@ namespace smpc
           timed_launch<Cent6Args<DC>, cent6_ls_body<DC>, 64>(CKID_LS, B, c, aux);
         }
       }
-      else
+      else if (fused)
         timed_launch<CentStepArgs<DC>, cent_step_body<DC>, 64, 2>(CKID_STEP, B, a, aux);
+      else
+      {
+        CentSplitArgs<DC> c;
+        c.a = a;
+        c.sb = sbuf;
+        c.last = 0;
+        timed_launch<CentSplitArgs<DC>, cent_recede_body<DC>, 64>(CKID_STEP, B, c, aux);
+        for (int it = 0; it < a.iters; it++)
+        {
+          c.last = it + 1 == a.iters ? 1 : 0;
+          timed_launch<CentSplitArgs<DC>, cent_pre_body<DC>, 64, 2>(CKID_DERIV, B, c, aux);
+          timed_launch<CentSplitArgs<DC>, cent_bwd_body<DC>, 64, 2>(CKID_RICCATI, B, c, aux);
+          timed_launch<CentSplitArgs<DC>, cent_fwd_body<DC>, 64, 4>(CKID_FORWARD, B, c, aux);
+          timed_launch<CentSplitArgs<DC>, cent_ls_body<DC>, 64, 1>(CKID_LS, B, c, aux);
+        }
+      }
     }
     CentStepArgs<DC> step_args(const double * Xd) const
     {

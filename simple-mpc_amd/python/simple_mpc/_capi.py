@@ -162,7 +162,10 @@ SYMBOLS = [
 
 class SmpcLib:
     def __init__(self, path=None):
-        path = path or os.environ.get("SMPC_LIB_PATH") or DEFAULT_LIB  # (SMPC_LIB_PATH: experiment builds, tools/variant_build.sh)
+        if path is None and os.environ.get("SMPC_LIB_PATH"):
+            path = os.environ["SMPC_LIB_PATH"]  # experiment builds (tools/variant_build.sh): say so, a stale variant must not pass for the product
+            print("simple_mpc: SMPC_LIB_PATH overrides the shipped library: %s" % path, file=sys.stderr)
+        path = path or DEFAULT_LIB
         if not os.path.exists(path):
             raise RuntimeError(
                 "simple_mpc: native library %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "

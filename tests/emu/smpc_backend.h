@@ -30,6 +30,7 @@
     (void)lane;
 #define SMPC_LANES_END }
 #define SMPC_LANES_END_WAVE }
+#define SMPC_WAVE_SYNC() ((void)0) // (lockstep-only code has a per-lane form here)
 #define SMPC_PL(type, name, NT) type name[NT]
 #define SMPC_PLA(type, name, NT, n) type name[NT][n]
 #define SMPC_PLV(name) name[lane]
