@@ -521,7 +521,7 @@ def control_stack_talos_line(batch, device_id, mpc_steps=20):
 
 def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
     """BASELINE config "Go2 centroidal (9-dim state), H=50, batch=4096": same step definition on the centroidal OCP
-    (one fused kernel per control step).  Measured states: x_ref (+) N(0, sigma^2), resident in HBM, re-drawn on the
+    (round 5: a pipeline of kernels per ProxDDP iteration, smpc_cent_split.h).  Measured states: x_ref (+) N(0, sigma^2), resident in HBM, re-drawn on the
     device every step (the centroidal solution has no multibody state to feed back)."""
     import numpy as np
     import torch
@@ -547,28 +547,60 @@ def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
 
     for _ in range(warmup):
         step()
-    gm.set_profiling(True)
-    gm.reset_kernel_times()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # per-kernel durations: a short profiled loop of the same closed loop AFTER the timed one (HIP events around every launch; the engine
+    # runs the batch as ONE part while profiling -- the timed loop above overlaps the launches of two parts on two streams)
+    gm.set_profiling(True)
+    gm.reset_kernel_times()
+    for _ in range(min(steps, 10)):
+        step()
+    torch.cuda.synchronize()
     kt = gm.kernel_times()
-    avg = kt["step"][0] / max(kt["step"][1], 1) * 1e-3
-    flops = batch * gm.H * iters * f_ric(9, gm.nu, gm.nc)
+    gm.set_profiling(False)
+    ms = {k: v[0] / max(v[1], 1) for k, v in kt.items() if k != "-"}
+    per_step = {k: v[0] / min(steps, 10) for k, v in kt.items() if k != "-"}  # ms of a control step spent in each kernel
+    fused = ms.get("backward", 0.0) == 0.0  # (SMPC_CENT_FUSED=1: the one-kernel control step)
+    BH = batch * gm.H
+    fr = f_ric(9, gm.nu, gm.nc)
     io_bytes = batch * 8 * (2 * (gm.H + 1) * 9 + 2 * gm.H * gm.nu + gm.nu * 9 + (gm.H + 1) * 9 + gm.H * gm.nc)  # compulsory I/O per step
-    rl = both_bounds(flops, io_bytes, avg, "hbm")
-    tr, src = pmc_traffic("cent_step_body", batch == 4096 and iters == 3)
-    rl.update({"kernel": "cent_step_body (whole control step: recede + %d ProxDDP iterations)" % iters, "traffic": tr, "traffic_source": src,
-               "note": "HBM side: compulsory I/O of a control step (SURVEY 8d, 24.7 KB per instance); FP64 side: B*H*k*F_ric(9,12,8)"})
+    if fused:
+        avg = ms["step"] * 1e-3
+        rl = both_bounds(batch * gm.H * iters * fr, io_bytes, avg, "hbm")
+        tr, src = pmc_traffic("cent_step_body", batch == 4096 and iters == 3)
+        rl.update({"kernel": "cent_step_body (whole control step: recede + %d ProxDDP iterations)" % iters, "traffic": tr, "traffic_source": src})
+    else:
+        # dominant kernel of the pipeline: the backward sweep (FP64: B*H*F_ric(9,12,8) per launch; bytes: the stage record read + gains written)
+        REC, GAIN = 247 * 8, 290 * 8  # CentRec::N doubles read, [K k | Z z | P~ | p+] doubles written per stage (smpc_cent_split.h)
+        rl = both_bounds(BH * fr, BH * (REC + GAIN), ms["backward"] * 1e-3, "mfma")
+        tr, src = pmc_traffic("cent_bwd_body", batch == 4096 and iters == 3)
+        rl.update({"kernel": "cent_bwd_body (proximal Riccati recursion of one ProxDDP iteration; %.0f %% of the step's kernel time)"
+                   % (100.0 * per_step["backward"] / max(sum(per_step.values()), 1e-12)), "traffic": tr, "traffic_source": src})
+        # the memory-bound kernels of the pipeline: algorithmic bytes per launch
+        ITER = 8 * (9 * 2 + gm.nu + gm.nc * 2 + 9 * 3 + 3 * 4 + 6 + gm.nu + 3)  # iterate + references a stage evaluation reads
+        STEPB = 8 * (9 + gm.nu + gm.nc + 9)                                      # dx, du, dnu, dlam of a stage
+        other = {
+            "pre": both_bounds(None, BH * (ITER + 256 * 8), ms["pre"] * 1e-3, "hbm"),
+            "forward": both_bounds(None, BH * (GAIN + 192 * 8 + STEPB), ms["forward"] * 1e-3, "hbm"),
+            "line_search": both_bounds(None, BH * (ITER + 3 * STEPB + STEPB), ms["line_search"] * 1e-3, "hbm"),
+        }
+        for k in other:
+            t2, _ = pmc_traffic("cent_%s_body" % {"pre": "pre", "forward": "fwd", "line_search": "ls"}[k], batch == 4096 and iters == 3)
+            other[k]["traffic"] = t2
+        rl["pipeline"] = other
+        rl["step"] = both_bounds(batch * gm.H * iters * fr, io_bytes, dt / steps, "hbm")
+        rl["step"]["note"] = "whole control step: B*H*k*F_ric(9,12,8) and the compulsory I/O of a step (SURVEY 8d, 24.7 KB per instance) over the measured step time"
+    rl["note"] = "FP64 side: F_ric(9,12,8) of SURVEY 8d per (instance, stage); HBM side: algorithmic bytes of the launch"
     out = {
         "metric": "MPC control-steps/sec at fixed ProxDDP iters, Go2 centroidal H=50",
         "value": batch * steps / dt, "unit": "control-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": "f64",
         "config": {"workload": "Go2 centroidal (go2_like table), H=%d, %d ProxDDP iters/step, batch=%d, trot 10/30/10/30, "
                    "x_meas = x_ref (+) N(0, sigma^2)" % (gm.H, iters, batch), "finite": bool(np.all(np.isfinite(gm.info)))},
-        "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if k != "-"},
+        "kernel_ms": {k: round(v, 4) for k, v in ms.items()},
         "roofline": rl,
     }
     if with_cpu:
@@ -951,6 +983,17 @@ def main():
             try:
                 emit(False)
             except Exception as exc:  # (a collective this build / node cannot run fails on every rank alike, at the first warm-up step)
+                if world > 1:
+                    # N > 1: the return-set exchange is part of the measured step ("xGMI used only to gather outputs").  A run that
+                    # cannot execute it must not report a throughput without it: fail, loudly, on every rank.
+                    sys.stderr.write("bench.py: rank %d: the return-set exchange failed at the first warm-up step: %r\n" % (rank, exc))
+                    sys.stderr.flush()
+                    if dist is not None:
+                        try:
+                            dist.destroy_process_group()
+                        except Exception:
+                            pass
+                    sys.exit(3)
                 gather_error = repr(exc)
                 gather_on = gather_timed = False
     profile = not args.no_profile and not dry
@@ -1037,6 +1080,10 @@ def main():
                     out["gather"].update({"ms_per_step_with_gather": step_ms, "value_with_gather": B / dt_with_gather,
                                           "note": "N = 1: no exchange between devices; the device-to-host copy is PCIe traffic and stays outside `value` -- the same "
                                                   "loop with the copy every step, measured right after the timed region (--gather puts it inside)"})
+        if dry and gather_on and dist is not None and gathered_h is not None:
+            # the rehearsal checks the same thing the device path does: every rank's block arrived (finite rows, unit quaternions of x1)
+            gl = torch.stack(gathered_h)
+            out["gather"]["rows_ok"] = bool(torch.isfinite(gl).all()) and bool((gl[:, :, 3:7].norm(dim=2) - 1).abs().max() < 1e-9)
         if dry:
             out["data"] = "synthetic (DRY RUN on CPU: emulated kernel bodies + gloo, launch-path rehearsal, not a measurement)"
         if kt:

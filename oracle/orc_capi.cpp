@@ -134,6 +134,85 @@ namespace
     }
     return (int)(o - out);
   }
+  // ProxDDP on an H-stage problem with per-stage references, run to convergence with the stopping rules of the cold solve (orc_mpc.hpp) --
+  // for the checks of the converged answer against an independent NLP solver (tests/test_oracle_vs_scipy.py).
+  // trace: [iter][6] = prim_infeas, dual_infeas, cost, phi0, alpha, ls_failed.  Returns the iteration count.
+  template <class Model, class MakeRef>
+  int generic_solve(
+    const Model & md, const smpc_robot_model * rm, int H, MakeRef make, const double * x_tgt_term, const double * x0, const double * u0, int max_iter,
+    double tol, double mu, double * trace, double * xs, double * us, double * vs, double * lams)
+  {
+    Rigid R(rm);
+    OcpInstance o;
+    for (int t = 0; t < H; t++)
+      o.stages.push_back(make(t));
+    o.x_tgt_term.assign(x_tgt_term, x_tgt_term + md.nx);
+    SolverState S;
+    S.xs.assign(H + 1, Vec(x0, x0 + md.nx));
+    S.us.assign(H, Vec(u0, u0 + md.nu));
+    S.vs.assign(H, Vec(md.nc, 0.0));
+    S.lams.assign(H + 1, Vec(md.ndx, 0.0));
+    ProxDDPT<Model> solver(md, mu);
+    std::vector<Vec> vs_e = S.vs, lams_e = S.lams;
+    // outer loop of the augmented Lagrangian: whenever the inner problem (fixed multiplier centres) has converged -- dual residual below the
+    // inner tolerance, or the merit stalls at FP64 resolution -- the centres move to the current multipliers; the run ends when primal AND dual
+    // residuals are below `tol`, or when two refreshes in a row bring nothing
+    const double inner_tol = std::fmax(tol, 1e-7);
+    int it = 0, idle_refresh = 0;
+    for (; it < max_iter; it++)
+    {
+      const IterInfo info = solver.iterate(R, o, S, vs_e, lams_e);
+      double * tr = trace + 6 * it;
+      tr[0] = info.prim_infeas;
+      tr[1] = info.dual_infeas;
+      tr[2] = info.cost;
+      tr[3] = info.phi0;
+      tr[4] = info.alpha;
+      tr[5] = info.ls_failed;
+      if (std::fmax(info.prim_infeas, info.dual_infeas) <= tol)
+      {
+        it++;
+        break;
+      }
+      const bool stall = std::fabs(info.dphi0) <= SolverConsts::STALL_REL * std::fmax(1.0, std::fabs(info.phi0));
+      if (info.dual_infeas <= inner_tol || stall)
+      {
+        vs_e = S.vs;
+        lams_e = S.lams;
+        idle_refresh = stall ? idle_refresh + 1 : 0;
+        if (idle_refresh >= 3)
+        {
+          it++;
+          break;
+        }
+      }
+      else
+        idle_refresh = 0;
+    }
+    for (int t = 0; t <= H; t++)
+      std::memcpy(xs + (size_t)t * md.nx, S.xs[t].data(), sizeof(double) * md.nx);
+    for (int t = 0; t < H; t++)
+    {
+      std::memcpy(us + (size_t)t * md.nu, S.us[t].data(), sizeof(double) * md.nu);
+      if (vs)
+        std::memcpy(vs + (size_t)t * md.nc, S.vs[t].data(), sizeof(double) * md.nc);
+    }
+    if (lams)
+      for (int t = 0; t <= H; t++)
+        std::memcpy(lams + (size_t)t * md.ndx, S.lams[t].data(), sizeof(double) * md.ndx);
+    return it;
+  }
+  // kind of every constraint row of a stage (0 absent, 1 equality, 2 box [lo, hi], 3 <= 0) and its bounds
+  template <class Model>
+  void generic_row_kinds(const Model & md, const StageRef & r, int * kind, double * lo, double * hi)
+  {
+    for (int i = 0; i < md.nc; i++)
+    {
+      kind[i] = md.row_kind(r, i);
+      lo[i] = md.row_lo_v(i);
+      hi[i] = md.row_hi_v(i);
+    }
+  }
 } // namespace
 
 extern "C"
@@ -1222,5 +1301,43 @@ extern "C"
     vec_to(qp.l, l);
     vec_to(qp.u, u);
     return qp.m;
+  }
+
+  // ---- converged solves and constraint typing of the three stage models (tests/test_oracle_vs_scipy.py) ----
+  // masks [H]; u_ref [H][nu], x_tgt [H][nx], foot_ref [H][nf*3] per stage; x_tgt_term [nx]
+  int orc_kino_solve(
+    void * h, int H, const unsigned * masks, const double * u_ref, const double * x_tgt, const double * foot_ref, const double * x_tgt_term,
+    const double * x0, const double * u0, int max_iter, double tol, double mu, double * trace, double * xs, double * us, double * vs, double * lams)
+  {
+    KinoModel * md = (KinoModel *)h;
+    return generic_solve(*md, md->M, H, [&](int t) { return make_ref(*md, masks[t], u_ref + (size_t)t * md->nu, x_tgt + (size_t)t * md->nx, foot_ref + (size_t)t * md->nf * 3); },
+                         x_tgt_term, x0, u0, max_iter, tol, mu, trace, xs, us, vs, lams);
+  }
+  void orc_kino_row_kinds(void * h, unsigned mask, int * kind, double * lo, double * hi)
+  {
+    KinoModel * md = (KinoModel *)h;
+    std::vector<double> z(md->nx + md->nu + md->nf * 3, 0.0);
+    generic_row_kinds(*md, make_ref(*md, mask, z.data(), z.data(), z.data()), kind, lo, hi);
+  }
+  int orc_cent_solve(
+    void * h, int H, const unsigned * masks, const double * u_ref, const double * x_tgt, const double * pos, const double * x0, const double * u0,
+    int max_iter, double tol, double mu, double * trace, double * xs, double * us, double * vs, double * lams)
+  {
+    CentModel * md = (CentModel *)h;
+    std::vector<double> zt(9, 0.0);
+    return generic_solve(*md, md->M, H, [&](int t) { return cent_ref(*md, masks[t], u_ref + (size_t)t * md->nu, x_tgt + (size_t)t * 9, pos + (size_t)t * md->nf * 3); },
+                         zt.data(), x0, u0, max_iter, tol, mu, trace, xs, us, vs, lams);
+  }
+  void orc_cent_row_kinds(void * h, unsigned mask, int * kind, double * lo, double * hi)
+  {
+    CentModel * md = (CentModel *)h;
+    std::vector<double> z(64, 0.0);
+    generic_row_kinds(*md, cent_ref(*md, mask, z.data(), z.data(), z.data()), kind, lo, hi);
+  }
+  void orc_full_row_kinds(void * h, unsigned mask, int * kind, double * lo, double * hi)
+  {
+    FullModel * md = (FullModel *)h;
+    std::vector<double> z(md->nx + md->nu + md->nf * 3 + 64, 0.0);
+    generic_row_kinds(*md, full_ref(*md, mask, z.data(), z.data(), z.data()), kind, lo, hi);
   }
 }

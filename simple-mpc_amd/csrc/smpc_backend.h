@@ -53,6 +53,8 @@
     __builtin_amdgcn_wave_barrier();                                                                                   \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                             \
   } while (0)
+// a consistency check of the kernel SOURCE that only the sequential test build evaluates (there it throws); nothing on the device
+#define SMPC_TEST_CHECK(cond, msg) ((void)0)
 // per-lane value that must survive a phase boundary (register on the GPU)
 #define SMPC_PL(type, name, NT) type name
 #define SMPC_PLA(type, name, NT, n) type name[n]

@@ -126,6 +126,14 @@ namespace smpc
     Cent6Extra<DC, DC::FS> x6; // 6-D feet: knots, dense gains, terminal node, merit partials
     CentSplitBuffers sbuf;     // point feet: hand-over records of the kernel pipeline (smpc_cent_split.h)
     bool fused = false;        // point feet: SMPC_CENT_FUSED=1 runs the one-kernel control step (cross-check)
+    // point feet: the batch runs as `nparts` contiguous parts, each on its own stream (SMPC_CENT_PARTS; instances are independent): the
+    // backward sweep is bound by VALU / matrix-core issue, the pre-pass, forward sweep and line search by memory -- launches of different
+    // parts fill each other's idle units.  Part p > 0 starts one kernel late (it waits for part p - 1's first pre-pass), so that the parts do
+    // not march in step.
+    int nparts = 1;
+    std::vector<stream_t> part_stream; // [nparts - 1] (part 0 runs on `stream`)
+    std::vector<event_t> part_event;   // [nparts - 1] completion of a part, [nparts] stagger events
+    event_t ev_fork{};
     Buffers<DK> fk; // only .model is used (front-end kernel)
     HostMpcSettings ms;
     std::vector<CentStage<DC>> horizon, cycle;
@@ -243,6 +251,15 @@ namespace smpc
             throw std::runtime_error("centroidal OCP: batch x horizon too large for the 32-bit record offsets");
           sbuf.rec = dalloc(BH * CentRec<DC>::STRIDE);
           sbuf.term = dalloc((size_t)B * CentRec<DC>::T_STRIDE);
+          const char * pe = std::getenv("SMPC_CENT_PARTS");
+          nparts = pe ? std::atoi(pe) : (B >= 1024 ? 2 : 1);
+          if (nparts < 1 || nparts > 8 || B < 64 * nparts)
+            nparts = 1;
+          ev_fork = event_create();
+          for (int p = 1; p < nparts; p++)
+            part_stream.push_back(stream_create());
+          for (int p = 0; p < 2 * nparts; p++)
+            part_event.push_back(event_create());
         }
       }
       buf.scal = dalloc((size_t)B * SC_N);
@@ -279,6 +296,14 @@ namespace smpc
         dev_free(p);
       if (ev_handoff_valid)
         event_destroy(ev_handoff);
+      if (!part_event.empty())
+      {
+        event_destroy(ev_fork);
+        for (auto & e : part_event)
+          event_destroy(e);
+        for (auto & st : part_stream)
+          stream_destroy(st);
+      }
       if constexpr (DC::FS == 6)
       {
         for (double * p : {x6.sb.lq, x6.sb.QN, x6.sb.qN, x6.parts0})
@@ -294,23 +319,24 @@ namespace smpc
     CentEngine & operator=(const CentEngine &) = delete;
 
     template <class Args, void (*Body)(const Args &, int), int NT, int MINW = 1>
-    void timed_launch(int kid, int grid, const Args & a, bool aux = false)
+    void timed_launch(int kid, int grid, const Args & a, bool aux = false, const stream_t * on = nullptr)
     {
       set_device(device_id);
+      const stream_t st = on ? *on : stream;
       event_t e0{}, e1{};
       if (profiling)
       {
         e0 = event_create();
         e1 = event_create();
-        event_record(e0, stream);
+        event_record(e0, st);
       }
       if (aux)
-        launch<Args, Body, NT, MINW, 1>(grid, stream, a);
+        launch<Args, Body, NT, MINW, 1>(grid, st, a);
       else
-        launch<Args, Body, NT, MINW, 0>(grid, stream, a);
+        launch<Args, Body, NT, MINW, 0>(grid, st, a);
       if (profiling)
       {
-        event_record(e1, stream);
+        event_record(e1, st);
         pending_events.push_back({kid, {e0, e1}});
       }
       kernel_calls[kid]++;
@@ -331,19 +357,54 @@ namespace smpc
     {
       stage_ring.upload(buf.stages, horizon.data(), (size_t)H * sizeof(CentStage<DC>), stream);
     }
-    void launch_frontend(const double * Xd, bool aux = false)
+    void launch_frontend(const double * Xd, bool aux = false, int inst0 = 0, int count = -1, const stream_t * on = nullptr)
     {
+      if (count < 0)
+        count = B;
       FrontendArgs<DK> fa;
       fa.b = fk;
-      fa.X = Xd;
-      fa.feet = feet_dev;
+      fa.X = Xd + (size_t)inst0 * DK::NX;
+      fa.feet = feet_dev + (size_t)inst0 * DC::NF * 3;
       fa.com = nullptr;
       fa.hg = nullptr;
-      fa.cstate = cstate_dev;
+      fa.cstate = cstate_dev + (size_t)inst0 * 9;
       if constexpr (cent_is_full_dims<DK>::value)
-        timed_launch<FrontendArgs<DK>, frontend_full_body<DK>, 64>(CKID_FRONTEND, B, fa, aux);
+        timed_launch<FrontendArgs<DK>, frontend_full_body<DK>, 64>(CKID_FRONTEND, count, fa, aux, on);
       else
-        timed_launch<FrontendArgs<DK>, frontend_body<DK>, 64>(CKID_FRONTEND, B, fa, aux);
+        timed_launch<FrontendArgs<DK>, frontend_body<DK>, 64>(CKID_FRONTEND, count, fa, aux, on);
+    }
+    // first instance / instance count of part p (whole wavefront groups of 64)
+    void part_range(int p, int np, int & i0, int & n) const
+    {
+      const int per = ((B + np - 1) / np + 63) / 64 * 64;
+      i0 = p * per < B ? p * per : B;
+      n = i0 + per <= B ? per : B - i0;
+    }
+    // the kernel pipeline of one part of the batch, on stream `on` (null: the engine's stream); with_frontend: the state front end of the part first
+    void launch_split_part(const CentStepArgs<DC> & a, bool aux, int inst0, int count, const stream_t * on, const double * Xfront, event_t * after_first_pre, const event_t * wait_before_pre)
+    {
+      if (count <= 0)
+        return;
+      if (Xfront)
+        launch_frontend(Xfront, aux, inst0, count, on);
+      CentSplitArgs<DC> c;
+      c.a = a;
+      c.sb = sbuf;
+      c.last = 0;
+      c.inst0 = inst0;
+      timed_launch<CentSplitArgs<DC>, cent_recede_body<DC>, 64>(CKID_STEP, count, c, aux, on);
+      if (wait_before_pre)
+        stream_wait_event(on ? *on : stream, *wait_before_pre);
+      for (int it = 0; it < a.iters; it++)
+      {
+        c.last = it + 1 == a.iters ? 1 : 0;
+        timed_launch<CentSplitArgs<DC>, cent_pre_body<DC>, 64, 2>(CKID_DERIV, count, c, aux, on);
+        if (it == 0 && after_first_pre)
+          event_record(*after_first_pre, on ? *on : stream);
+        timed_launch<CentSplitArgs<DC>, cent_bwd_body<DC>, 64, 2>(CKID_RICCATI, count, c, aux, on);
+        timed_launch<CentSplitArgs<DC>, cent_fwd_body<DC>, 64, 4>(CKID_FORWARD, count, c, aux, on);
+        timed_launch<CentSplitArgs<DC>, cent_ls_body<DC>, 64, 1>(CKID_LS, count, c, aux, on);
+      }
     }
     // one solver run of `a.iters` iterations (with the recede / centre bookkeeping the flags of `a` ask for)
     void launch_step(const CentStepArgs<DC> & a, bool aux = false)
@@ -397,21 +458,7 @@ namespace smpc
       else if (fused)
         timed_launch<CentStepArgs<DC>, cent_step_body<DC>, 64, 2>(CKID_STEP, B, a, aux);
       else
-      {
-        CentSplitArgs<DC> c;
-        c.a = a;
-        c.sb = sbuf;
-        c.last = 0;
-        timed_launch<CentSplitArgs<DC>, cent_recede_body<DC>, 64>(CKID_STEP, B, c, aux);
-        for (int it = 0; it < a.iters; it++)
-        {
-          c.last = it + 1 == a.iters ? 1 : 0;
-          timed_launch<CentSplitArgs<DC>, cent_pre_body<DC>, 64, 2>(CKID_DERIV, B, c, aux);
-          timed_launch<CentSplitArgs<DC>, cent_bwd_body<DC>, 64, 2>(CKID_RICCATI, B, c, aux);
-          timed_launch<CentSplitArgs<DC>, cent_fwd_body<DC>, 64, 4>(CKID_FORWARD, B, c, aux);
-          timed_launch<CentSplitArgs<DC>, cent_ls_body<DC>, 64, 1>(CKID_LS, B, c, aux);
-        }
-      }
+        launch_split_part(a, aux, 0, B, nullptr, nullptr, nullptr, nullptr);
     }
     CentStepArgs<DC> step_args(const double * Xd) const
     {
@@ -581,7 +628,6 @@ namespace smpc
       }
       upload_stages();
       head = head + 1 == R ? 0 : head + 1;
-      launch_frontend(Xd);
       CentStepArgs<DC> a = step_args(Xd);
       a.shift = 1;
       a.set_centres = 1;
@@ -589,6 +635,31 @@ namespace smpc
       a.iters = ms.max_iters;
       for (int f = 0; f < DC::NF; f++)
         a.land[f] = timer.land[f].empty() ? -1 : timer.land[f][0];
+      if constexpr (DC::FS == 3)
+      {
+        if (!fused && nparts > 1 && !profiling) // (per-kernel event times mean something only when launches do not overlap: one part while profiling)
+        {
+          // fork: every part's stream sees what the engine's stream has done so far (the stage table upload, the caller's writes of Xd)
+          event_record(ev_fork, stream);
+          for (int p = 0; p < nparts; p++)
+          {
+            int i0, n;
+            part_range(p, nparts, i0, n);
+            const stream_t * on = p == 0 ? nullptr : &part_stream[p - 1];
+            if (p > 0)
+              stream_wait_event(*on, ev_fork);
+            launch_split_part(a, false, i0, n, on, Xd, &part_event[nparts + p], p > 0 ? &part_event[nparts + p - 1] : nullptr);
+          }
+          // join
+          for (int p = 1; p < nparts; p++)
+          {
+            event_record(part_event[p - 1], part_stream[p - 1]);
+            stream_wait_event(stream, part_event[p - 1]);
+          }
+          return;
+        }
+      }
+      launch_frontend(Xd);
       launch_step(a);
     }
     // ---- per-stage references (OCPHandler setters / getters of the centroidal OCP, reference src/centroidal-dynamics.cpp:

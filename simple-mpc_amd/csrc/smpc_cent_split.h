@@ -172,7 +172,8 @@ namespace smpc
   {
     CentStepArgs<D> a;
     CentSplitBuffers sb;
-    int last; // cent_ls_body: last iteration of the solver run (state derivatives of the accepted iterate)
+    int last;  // cent_ls_body: last iteration of the solver run (state derivatives of the accepted iterate)
+    int inst0; // first instance of this launch (the batch runs as several parts on several streams: block b = instance inst0 + b)
   };
 
   // ============================================================================================================
@@ -185,7 +186,7 @@ namespace smpc
     const CentStepArgs<D> & ka = sa.a;
     const CentBuffers<D> & b = ka.b;
     const int H = b.H, R = b.R, head = ka.head;
-    const size_t inst = (size_t)block, ib = inst * R;
+    const size_t inst = (size_t)(sa.inst0 + block), ib = inst * R;
     const CentDevModel<D> & md = *b.model;
     SMPC_LDS(double, rec, NF * 6);
     double * gsc = b.scal + inst * SC_N;
@@ -311,7 +312,7 @@ namespace smpc
     const CentStepArgs<D> & ka = sa.a;
     const CentBuffers<D> & b = ka.b;
     const int H = b.H, R = b.R, head = ka.head;
-    const size_t inst = (size_t)block, ib = inst * R;
+    const size_t inst = (size_t)(sa.inst0 + block), ib = inst * R;
     SMPC_LDS(CentPreLds<D>, ldsv, 1);
     CentPreLds<D> & s = ldsv[0];
     double * gsc = b.scal + inst * SC_N;
@@ -413,13 +414,8 @@ namespace smpc
           put(v.y);
           put(v.z);
         };
-#if defined(SMPC_CPU_EMU_BUILD)
-#define CENT_REC_AT(off)                                                                                                                  \
-  if (spos + kpos != (off))                                                                                                               \
-  throw std::runtime_error("cent_pre_body: the record is produced in a different order than CentRec lays it out")
-#else
-#define CENT_REC_AT(off) ((void)0)
-#endif
+        // (the sequential test build checks that the record is produced in the order CentRec lays it out; nothing on the device)
+#define CENT_REC_AT(off) SMPC_TEST_CHECK(spos + kpos == (off), "cent_pre_body: the record is produced in a different order than CentRec lays it out")
         // (the order of the sections is the order of the record: the Hessian blocks need the lever arms and W_aa [r_f]x of all feet at once and
         //  come first; everything after them re-reads its inputs -- the loads hit in L1 / L2 and the registers are free in between)
         const double * const xg = b.xs + sl * 9;
@@ -885,12 +881,12 @@ namespace smpc
     const CentStepArgs<D> & ka = sa.a;
     const CentBuffers<D> & b = ka.b;
     const int H = b.H;
-    const size_t inst = (size_t)block;
+    const size_t inst = (size_t)(sa.inst0 + block);
     SMPC_LDS(double, stg, RC::STAGE_N);
     SMPC_LDS(double, swp, 8 * 32);
     double * const prow = swp;
     double * const urow = swp + 4 * 32;
-    double * dbg = block == 0 ? b.dbg : nullptr;
+    double * dbg = inst == 0 ? b.dbg : nullptr;
     long long tprev = SMPC_CLOCK();
     const CentDevModel<D> & mg = *b.model;
     const double mu = mg.mu, smu = sqrt(mg.mu);
@@ -1106,7 +1102,7 @@ namespace smpc
     const CentStepArgs<D> & ka = sa.a;
     const CentBuffers<D> & b = ka.b;
     const int H = b.H, R = b.R, head = ka.head;
-    const size_t inst = (size_t)block, ib = inst * R;
+    const size_t inst = (size_t)(sa.inst0 + block), ib = inst * R;
     const CentDevModel<D> & mg = *b.model;
     const double mu = mg.mu, imu = 1.0 / mg.mu, dtm = mg.dt / mg.mass;
     SMPC_LDS(double, gb, NG * NT);
@@ -1264,7 +1260,7 @@ namespace smpc
     const CentStepArgs<D> & ka = sa.a;
     const CentBuffers<D> & b = ka.b;
     const int H = b.H, R = b.R, head = ka.head;
-    const size_t inst = (size_t)block, ib = inst * R;
+    const size_t inst = (size_t)(sa.inst0 + block), ib = inst * R;
     SMPC_LDS(CentLsLds<D>, ldsv, 1);
     CentLsLds<D> & s = ldsv[0];
     double * const red = s.red;

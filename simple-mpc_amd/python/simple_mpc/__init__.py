@@ -261,6 +261,7 @@ class _StageReferences:
     # foot references (reference src/kinodynamics.cpp:154-228, src/centroidal-dynamics.cpp:120-188)
     def setReferencePose(self, t, ee_name, pose_ref):
         m = self._handle()
+        _require_identity_rotation(pose_ref, self)
         p = np.ascontiguousarray(getattr(pose_ref, "translation", pose_ref), float).reshape(3)
         m._lib.check(m._lib.L.smpc_set_reference_pose(m._h, int(t), self._foot(ee_name), p))
 
@@ -1302,13 +1303,37 @@ class KinodynamicsID:
         return out
 
 
-def _positions(poses, nf):
+def _require_identity_rotation(pose_ref, ocp=None):
+    """The foot references of this build carry a translation only: the 6-D placement residual of flat feet (reference
+    src/kinodynamics.cpp:66-72,154-170, FramePlacementResidual with a full SE3 reference; CentroidalID's TaskSE3Equality, src/inverse-dynamics/
+    centroidal-id.cpp:109-113) is evaluated against (identity rotation, p) -- level soles.  A reference with another rotation must not be
+    replaced by the identity silently: it is refused.  (Point feet and the centroidal OCP use the translation only, as the reference does.)"""
+    rot = getattr(pose_ref, "rotation", None)
+    if rot is None:
+        return
+    if ocp is not None and not (int(ocp.settings.get("force_size", 3)) == 6 and isinstance(ocp, KinodynamicsOCP)):
+        return
+    if not np.allclose(np.asarray(rot, float).reshape(3, 3), np.eye(3), atol=1e-12):
+        raise RuntimeError("foot reference with a non-identity rotation: this build tracks level soles only (translation of the reference placement); "
+                           "rotated foot references are not implemented")
+
+
+def _positions(poses, nf, flat_feet=False):
     """[nf][3] from an array of positions or a list of placements (objects with `.translation`)."""
+    if flat_feet:
+        for p in poses:
+            _require_identity_rotation(p)
     return np.array([np.asarray(p.translation if hasattr(p, "translation") else p, dtype=np.float64).reshape(-1)[:3] for p in poses]).reshape(nf, 3)
 
 
-def _linear_velocities(vels, nf):
-    """[nf][3] from an array [nf][3], spatial velocities [nf][6] (linear part first) or objects with `.linear`."""
+def _linear_velocities(vels, nf, flat_feet=False):
+    """[nf][3] from an array [nf][3], spatial velocities [nf][6] (linear part first) or objects with `.linear`.  flat_feet: the angular part of
+    a 6-D target (TaskSE3Equality of flat feet) is not tracked by this build -- a non-zero one is refused instead of dropped."""
+    if flat_feet:
+        for m in vels:
+            w = np.asarray(m.angular, float) if hasattr(m, "angular") else np.asarray(m, float).reshape(-1)[3:6]
+            if w.size and np.abs(w).max() > 1e-12:
+                raise RuntimeError("foot velocity target with a non-zero angular part: this build tracks the linear velocity of level soles only")
     return np.array([np.asarray(m.linear if hasattr(m, "linear") else m, dtype=np.float64).reshape(-1)[:3] for m in vels]).reshape(nf, 3)
 
 
@@ -1332,8 +1357,8 @@ class CentroidalID(KinodynamicsID):
             raise RuntimeError("contact_state_target must have one entry per foot")
         f = np.zeros(self._fs * self._nf) if len(f_target) == 0 else c(f_target, self._fs * self._nf)
         self._lib.check(self._lib.L.smpc_id_set_target_centroidal(
-            self._h, int(instance), c(com_position, 3), c(com_velocity, 3), c(_positions(feet_pose, self._nf), 3 * self._nf),
-            c(_linear_velocities(feet_velocity, self._nf), 3 * self._nf), contact, f))
+            self._h, int(instance), c(com_position, 3), c(com_velocity, 3), c(_positions(feet_pose, self._nf, self._fs == 6), 3 * self._nf),
+            c(_linear_velocities(feet_velocity, self._nf, self._fs == 6), 3 * self._nf), contact, f))
 
     def setTargets(self, COM, VCOM, FEET_P, FEET_V, contact_states, F):
         """One target per robot: COM, VCOM [B][3], FEET_P, FEET_V [B][nf][3], contact_states [B][nf] (or one list for all), F [B][nf][3]."""

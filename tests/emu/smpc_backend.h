@@ -31,6 +31,12 @@
 #define SMPC_LANES_END }
 #define SMPC_LANES_END_WAVE }
 #define SMPC_WAVE_SYNC() ((void)0) // (lockstep-only code has a per-lane form here)
+#define SMPC_TEST_CHECK(cond, msg)                                                                                     \
+  do                                                                                                                   \
+  {                                                                                                                    \
+    if (!(cond))                                                                                                       \
+      throw std::runtime_error(msg);                                                                                   \
+  } while (0)
 #define SMPC_PL(type, name, NT) type name[NT]
 #define SMPC_PLA(type, name, NT, n) type name[NT][n]
 #define SMPC_PLV(name) name[lane]

@@ -102,6 +102,12 @@ def lib():
     L.orc_full_deriv.argtypes = [vp, C.c_uint] + [_dp] * 14
     L.orc_full_solve.argtypes = [vp, C.c_int, C.POINTER(C.c_uint), _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]
     L.orc_full_solve.restype = C.c_int
+    L.orc_kino_solve.argtypes = [vp, C.c_int, C.POINTER(C.c_uint)] + [_dp] * 6 + [C.c_int, C.c_double, C.c_double] + [_dp] * 5
+    L.orc_kino_solve.restype = C.c_int
+    L.orc_cent_solve.argtypes = [vp, C.c_int, C.POINTER(C.c_uint)] + [_dp] * 5 + [C.c_int, C.c_double, C.c_double] + [_dp] * 5
+    L.orc_cent_solve.restype = C.c_int
+    for _f in (L.orc_kino_row_kinds, L.orc_cent_row_kinds, L.orc_full_row_kinds):
+        _f.argtypes = [vp, C.c_uint, _ip, _dp, _dp]
     L.orc_riccati.argtypes = [C.c_int] * 4 + [C.c_double] + [_dp] * 18
     L.orc_timer_create.restype = vp
     L.orc_timer_create.argtypes = [_bp, C.c_int, C.c_int, C.c_int]
@@ -391,6 +397,23 @@ class Kino:
         lib().orc_kino_term(self.h, c(x_tgt), c(x), cost, lx, Lxx)
         return float(cost[0]), lx, Lxx
 
+    def row_kinds(self, mask):
+        """Per constraint row of a stage with this contact mask: kind (0 absent, 1 equality, 2 box [lo, hi], 3 <= 0), lo, hi."""
+        k, lo, hi = np.zeros(self.nc, np.int32), np.zeros(self.nc), np.zeros(self.nc)
+        lib().orc_kino_row_kinds(self.h, int(mask), k, lo, hi)
+        return k, lo, hi
+
+    def solve(self, masks, u_ref, x_tgt, foot_ref, x_tgt_term, x0, u0, max_iter=200, tol=1e-9, mu=1e-8):
+        """The oracle's ProxDDP run to convergence on an H-stage problem with per-stage references (u_ref [H][nu], x_tgt [H][nx],
+        foot_ref [H][nf*3]) from the constant guess (x0, u0)."""
+        c = lambda a: np.ascontiguousarray(a, float)
+        H = len(masks)
+        mk = (C.c_uint * H)(*[int(m) for m in masks])
+        trace, xs, us = np.zeros((max_iter, 6)), np.zeros((H + 1, self.nx)), np.zeros((H, self.nu))
+        vs, lams = np.zeros((H, self.nc)), np.zeros((H + 1, self.ndx))
+        it = lib().orc_kino_solve(self.h, H, mk, c(u_ref), c(x_tgt), c(foot_ref), c(x_tgt_term), c(x0), c(u0), max_iter, tol, mu, trace, xs, us, vs, lams)
+        return dict(iters=it, trace=trace[:it], xs=xs, us=us, vs=vs, lams=lams)
+
 
 def go2_full_settings(robot):
     """FullDynamicsSettings of record: reference examples/go2_fulldynamics.py:42-77 (3-D feet).  The robot table holds no
@@ -436,6 +459,11 @@ class Full:
                  Lxu=np.zeros((n, m)), Luu=np.zeros((m, m)), Cx=np.zeros((k, n)), Cu=np.zeros((k, m)))
         lib().orc_full_deriv(self.h, mask, c(u_ref), c(x_tgt), c(foot_ref), c(x), c(u), *o.values())
         return o
+
+    def row_kinds(self, mask):
+        k, lo, hi = np.zeros(self.nc, np.int32), np.zeros(self.nc), np.zeros(self.nc)
+        lib().orc_full_row_kinds(self.h, int(mask), k, lo, hi)
+        return k, lo, hi
 
     def solve(self, masks, u_ref, x_tgt, foot_ref, x0, u0, max_iter=50, tol=1e-4, mu=1e-8):
         c = lambda a: np.ascontiguousarray(a, float)
@@ -715,6 +743,22 @@ class Cent:
         cost, lx, Lxx = np.zeros(1), np.zeros(9), np.zeros((9, 9))
         lib().orc_cent_term(self.h, np.ascontiguousarray(x, float), cost, lx, Lxx)
         return float(cost[0]), lx, Lxx
+
+    def row_kinds(self, mask):
+        k, lo, hi = np.zeros(self.nc, np.int32), np.zeros(self.nc), np.zeros(self.nc)
+        lib().orc_cent_row_kinds(self.h, int(mask), k, lo, hi)
+        return k, lo, hi
+
+    def solve(self, masks, u_ref, x_tgt, pos, x0, u0, max_iter=200, tol=1e-9, mu=1e-8):
+        """The oracle's ProxDDP run to convergence on an H-stage centroidal problem with per-stage references (u_ref [H][nu], x_tgt [H][9],
+        contact positions pos [H][nf*3]) from the constant guess (x0, u0)."""
+        c = lambda a: np.ascontiguousarray(a, float)
+        H = len(masks)
+        mk = (C.c_uint * H)(*[int(m) for m in masks])
+        trace, xs, us = np.zeros((max_iter, 6)), np.zeros((H + 1, 9)), np.zeros((H, self.nu))
+        vs, lams = np.zeros((H, self.nc)), np.zeros((H + 1, 9))
+        it = lib().orc_cent_solve(self.h, H, mk, c(u_ref), c(x_tgt), c(pos), c(x0), c(u0), max_iter, tol, mu, trace, xs, us, vs, lams)
+        return dict(iters=it, trace=trace[:it], xs=xs, us=us, vs=vs, lams=lams)
 
 
 class OracleCentMPC(OracleMPC):

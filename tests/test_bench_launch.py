@@ -27,6 +27,10 @@ def test_gpus_flag_starts_that_many_ranks(built):
     for o in (one, two):
         assert o["scaling"] == "weak" and o["steps"] == 2 and o["warmup"] == 1 and o["config"]["finite"]
         assert "DRY RUN" in o["data"]
+    # N > 1: the return set is exchanged inside the timed region (rank 0 holds every rank's rows), and a run that could not do it does not
+    # report a value at all (bench.py exits non-zero at the first warm-up step)
+    g = two["gather"]
+    assert g["in_timed_region"] is True and "error" not in g and g["rows_ok"] is True
 
 
 def test_default_batch_is_the_baseline_configuration():
