@@ -131,6 +131,7 @@ namespace smpc
     // parts fill each other's idle units.  Part p > 0 starts one kernel late (it waits for part p - 1's first pre-pass), so that the parts do
     // not march in step.
     int nparts = 1;
+    bool ls_direct = false; // SMPC_CENT_LS=direct: the per-candidate re-evaluation (cent_ls_body) also for horizons the polynomial form covers
     std::vector<stream_t> part_stream; // [nparts - 1] (part 0 runs on `stream`)
     std::vector<event_t> part_event;   // [nparts - 1] completion of a part, [nparts] stagger events
     event_t ev_fork{};
@@ -251,6 +252,8 @@ namespace smpc
             throw std::runtime_error("centroidal OCP: batch x horizon too large for the 32-bit record offsets");
           sbuf.rec = dalloc(BH * CentRec<DC>::STRIDE);
           sbuf.term = dalloc((size_t)B * CentRec<DC>::T_STRIDE);
+          const char * le = std::getenv("SMPC_CENT_LS");
+          ls_direct = le != nullptr && le[0] == 'd';
           const char * pe = std::getenv("SMPC_CENT_PARTS");
           nparts = pe ? std::atoi(pe) : (B >= 1024 ? 2 : 1);
           if (nparts < 1 || nparts > 8 || B < 64 * nparts)
@@ -403,7 +406,11 @@ namespace smpc
           event_record(*after_first_pre, on ? *on : stream);
         timed_launch<CentSplitArgs<DC>, cent_bwd_body<DC>, 64, 2>(CKID_RICCATI, count, c, aux, on);
         timed_launch<CentSplitArgs<DC>, cent_fwd_body<DC>, 64, 4>(CKID_FORWARD, count, c, aux, on);
-        timed_launch<CentSplitArgs<DC>, cent_ls_body<DC>, 64, 1>(CKID_LS, count, c, aux, on);
+        // (line search: the polynomial form needs one lane per stage and the terminal node; longer horizons re-evaluate per candidate)
+        if (H + 1 <= 64 && !ls_direct)
+          timed_launch<CentSplitArgs<DC>, cent_ls_poly_body<DC>, 64, 2>(CKID_LS, count, c, aux, on);
+        else
+          timed_launch<CentSplitArgs<DC>, cent_ls_body<DC>, 64, 1>(CKID_LS, count, c, aux, on);
       }
     }
     // one solver run of `a.iters` iterations (with the recede / centre bookkeeping the flags of `a` ask for)

@@ -1416,4 +1416,329 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
   }
+
+  // ============================================================================================================
+  // line search, polynomial form (horizons of at most 63 stages: one lane per stage and one for the terminal node)
+  // ============================================================================================================
+  // Along the search direction every residual of the centroidal stage is a polynomial in the step size: states, forces and multipliers move
+  // linearly, the torque sum (p_f - c) x f_f is bilinear, the friction cone quadratic.  So the merit of stage t at w + alpha dw is
+  //     Q_t(alpha)  (one quartic: all costs, the dynamics penalty, the penalty of the rows of feet in the air)
+  //   + the cone rows of the feet in contact (a quadratic z(alpha) each, with the projection max(z, 0) applied per candidate).
+  // cent_ls_body re-reads iterate and step -- some 150 doubles a lane, 64 cache lines per load instruction -- for EVERY candidate; here they
+  // are read once, the quartic stays in 10 registers, the cone rows in LDS, and a candidate costs ~100 instructions and one reduction.
+  template <class D>
+  struct CentLsPolyLds
+  {
+    static constexpr int NCK = 9; // per foot in contact: z0 = a + b alpha ; z1 = q0 + q1 alpha + q2 alpha^2 ; v0, dv0, v1, dv1
+    CentDevModel<D> md;
+    double red[64];
+    double cone[D::NF * NCK][64];
+    double sc[16];
+  };
+  template <class D>
+  SMPC_DEV void cent_ls_poly_body(const CentSplitArgs<D> & sa, int block)
+  {
+    typedef CentLsPolyLds<D> LD;
+    constexpr int NT = 64, NU = D::NU, NC = D::NC, NF = D::NF, NCK = LD::NCK;
+    const CentStepArgs<D> & ka = sa.a;
+    const CentBuffers<D> & b = ka.b;
+    const int H = b.H, R = b.R, head = ka.head;
+    const size_t inst = (size_t)(sa.inst0 + block), ib = inst * R;
+    SMPC_LDS(LD, ldsv, 1);
+    LD & s = ldsv[0];
+    double * const red = s.red;
+    double * gsc = b.scal + inst * SC_N;
+    SMPC_LANES(NT)
+    {
+      constexpr int N = (int)(sizeof(CentDevModel<D>) / sizeof(double));
+      const alias_double * src = reinterpret_cast<const alias_double *>(b.model);
+      alias_double * dst = reinterpret_cast<alias_double *>(&s.md);
+      for (int i = lane; i < N; i += NT)
+        dst[i] = src[i];
+      if (lane < 16)
+        s.sc[lane] = gsc[lane];
+    }
+    SMPC_LANES_END_WAVE
+    const CentDevModel<D> & md = s.md;
+    const double mu = md.mu, imu = 1.0 / md.mu, imass = 1.0 / md.mass, dt = md.dt;
+    const double preg = s.sc[SC_PREG] > 0.0 ? s.sc[SC_PREG] : ka.reg_init;
+    // per-lane polynomial state
+    SMPC_PLA(double, qc, NT, 5); // cost part of the quartic
+    SMPC_PLA(double, qp, NT, 5); // penalty part
+    SMPC_PLA(double, e0, NT, 9);
+    SMPC_PLA(double, e1, NT, 9);
+    SMPC_PLA(double, e2, NT, 3);
+    SMPC_PL(unsigned, lmask, NT);
+    SMPC_LANES(NT)
+    {
+      const int t = lane;
+      double * QC = SMPC_PLV(qc), *QP = SMPC_PLV(qp);
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+        QC[i] = QP[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; i++)
+        SMPC_PLV(e0)[i] = SMPC_PLV(e1)[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+        SMPC_PLV(e2)[i] = 0.0;
+      SMPC_PLV(lmask) = 0u;
+      // 1/2 (r0 + alpha r1)^T W (r0 + alpha r1) into a quadratic
+      auto quad = [&](const double * W, V3 r0, V3 r1, double * Q) {
+        const M3 Wm = ldm3(W);
+        const V3 w0 = Wm * r0, w1 = Wm * r1;
+        Q[0] += 0.5 * dot(r0, w0);
+        Q[1] += dot(r1, w0);
+        Q[2] += 0.5 * dot(r1, w1);
+      };
+      if (t <= H)
+      {
+        const size_t sl = ib + ring_slot(head, t, R);
+        const double * xg = b.xs + sl * 9;
+        const double * dxg = b.dxs + sl * 9;
+        const V3 c0 = ld3(xg), dc = ld3(dxg), h0 = ld3(xg + 3), dh = ld3(dxg + 3), L0 = ld3(xg + 6), dL = ld3(dxg + 6);
+        if (t == H)
+        {
+          quad(md.w_lm, h0, dh, QC);
+          quad(md.w_am, L0, dL, QC);
+        }
+        else
+        {
+          const unsigned mask = b.stages[t].mask;
+          SMPC_PLV(lmask) = mask;
+          const size_t lt = inst * H + t;
+          // ---- forces: sums, torque sums, cone rows, control cost ----
+          V3 fs0 = mk3(0, 0, 0), fs1 = mk3(0, 0, 0), ts0 = mk3(0, 0, 0), ts1 = mk3(0, 0, 0);
+          double ru[NU], du[NU];
+#pragma unroll
+          for (int f = 0; f < NF; f++)
+          {
+            const bool on = (mask >> f) & 1u;
+            const V3 F0 = ld3(b.us + sl * NU + 3 * f), dF = ld3(b.dus + sl * NU + 3 * f), ur = ld3(b.stages[t].u_ref + 3 * f);
+            ru[3 * f] = F0.x - ur.x;
+            ru[3 * f + 1] = F0.y - ur.y;
+            ru[3 * f + 2] = F0.z - ur.z;
+            du[3 * f] = dF.x;
+            du[3 * f + 1] = dF.y;
+            du[3 * f + 2] = dF.z;
+            const double v0 = b.vs[sl * NC + 2 * f], dv0 = b.dvs[sl * NC + 2 * f], v1 = b.vs[sl * NC + 2 * f + 1], dv1 = b.dvs[sl * NC + 2 * f + 1];
+            // (vp - v(alpha))^2 + vp^2 = 2 vp^2 - 2 vp v(alpha) + v(alpha)^2: the last term is a polynomial whether the foot is in contact or not
+            QP[0] += 0.5 * mu * (v0 * v0 + v1 * v1);
+            QP[1] += mu * (v0 * dv0 + v1 * dv1);
+            QP[2] += 0.5 * mu * (dv0 * dv0 + dv1 * dv1);
+            double ck[NCK] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (on)
+            {
+              const V3 r0 = ld3(b.foot + lt * (3 * NF) + 3 * f) - c0;
+              fs0 = fs0 + F0;
+              fs1 = fs1 + dF;
+              ts0 = ts0 + cross(r0, F0);
+              ts1 = ts1 + cross(r0, dF);
+              const double mf2 = md.mu_fric * md.mu_fric;
+              ck[0] = -F0.z + md.cone_eps + mu * b.vs_e[sl * NC + 2 * f];
+              ck[1] = -dF.z;
+              ck[2] = F0.x * F0.x + F0.y * F0.y - mf2 * F0.z * F0.z + mu * b.vs_e[sl * NC + 2 * f + 1];
+              ck[3] = 2.0 * (F0.x * dF.x + F0.y * dF.y - mf2 * F0.z * dF.z);
+              ck[4] = dF.x * dF.x + dF.y * dF.y - mf2 * dF.z * dF.z;
+              ck[5] = v0;
+              ck[6] = dv0;
+              ck[7] = v1;
+              ck[8] = dv1;
+            }
+#pragma unroll
+            for (int k = 0; k < NCK; k++)
+              s.cone[f * NCK + k][lane] = ck[k];
+          }
+          {
+            double c00 = 0.0, c01 = 0.0, c11 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NU; i++)
+            {
+              double wr = 0.0, wd = 0.0;
+#pragma unroll
+              for (int jj = 0; jj < NU; jj++)
+              {
+                wr += md.w_u[i * NU + jj] * ru[jj];
+                wd += md.w_u[i * NU + jj] * du[jj];
+              }
+              c00 += ru[i] * wr;
+              c01 += du[i] * wr;
+              c11 += du[i] * wd;
+            }
+            QC[0] += 0.5 * c00;
+            QC[1] += c01;
+            QC[2] += 0.5 * c11;
+          }
+          ts1 = ts1 - cross(dc, fs0);
+          const V3 ts2 = mk3(0, 0, 0) - cross(dc, fs1);
+          // ---- costs ----
+          const V3 g = ld3(md.gravity);
+          quad(md.w_com, c0 - ld3(b.stages[t].x_tgt), dc, QC);
+          quad(md.w_lm, h0 - ld3(b.vref + sl * 6), dh, QC);
+          quad(md.w_am, L0 - ld3(b.vref + sl * 6 + 3), dL, QC);
+          quad(md.w_la, g + imass * fs0, imass * fs1, QC);
+          {
+            const M3 Wm = ldm3(md.w_aa);
+            const V3 w0 = Wm * ts0, w1 = Wm * ts1, w2 = Wm * ts2;
+            QC[0] += 0.5 * dot(ts0, w0);
+            QC[1] += dot(ts1, w0);
+            QC[2] += 0.5 * dot(ts1, w1) + dot(ts2, w0);
+            QC[3] += dot(ts2, w1);
+            QC[4] += 0.5 * dot(ts2, w2);
+          }
+          // ---- dynamics defect e(alpha) = e0 + alpha e1 + alpha^2 e2 and its penalty 1/2 mu (lp^2 + (lp - lam(alpha))^2), lp = lam_e + e / mu ----
+          const size_t sl1 = ib + ring_slot(head, t + 1, R);
+          const double xd0[9] = {h0.x * imass, h0.y * imass, h0.z * imass, md.mass * g.x + fs0.x, md.mass * g.y + fs0.y, md.mass * g.z + fs0.z, ts0.x, ts0.y, ts0.z};
+          const double xd1[9] = {dh.x * imass, dh.y * imass, dh.z * imass, fs1.x, fs1.y, fs1.z, ts1.x, ts1.y, ts1.z};
+          const double xd2[3] = {ts2.x, ts2.y, ts2.z};
+#pragma unroll
+          for (int i = 0; i < 9; i++)
+          {
+            const double a0 = xg[i] + dt * xd0[i] - b.xs[sl1 * 9 + i];
+            const double a1 = dxg[i] + dt * xd1[i] - b.dxs[sl1 * 9 + i];
+            const double a2 = i >= 6 ? dt * xd2[i - 6] : 0.0;
+            SMPC_PLV(e0)[i] = a0;
+            SMPC_PLV(e1)[i] = a1;
+            if (i >= 6)
+              SMPC_PLV(e2)[i - 6] = a2;
+            const double p0 = b.lams_e[sl * 9 + i] + a0 * imu, p1 = a1 * imu, p2 = a2 * imu;
+            const double d0 = p0 - b.lams[sl * 9 + i], d1 = p1 - b.dlams[sl * 9 + i];
+            QP[0] += 0.5 * mu * (p0 * p0 + d0 * d0);
+            QP[1] += mu * (p0 * p1 + d0 * d1);
+            QP[2] += 0.5 * mu * (p1 * p1 + d1 * d1 + 2.0 * p2 * (p0 + d0));
+            QP[3] += mu * p2 * (p1 + d1);
+            QP[4] += mu * p2 * p2;
+          }
+        }
+      }
+    }
+    SMPC_LANES_END_WAVE
+    // ---- candidates alpha = 1, 1/2, ... : merit from the stored polynomials ----
+    double alpha = 1.0;
+    int accepted = -1, jlast = 0;
+    for (int j = 0; j < D::LS_N; j++)
+    {
+      jlast = j;
+      SMPC_LANES(NT)
+      {
+        const double * QC = SMPC_PLV(qc), *QP = SMPC_PLV(qp);
+        double phi = ((((QC[4] + QP[4]) * alpha + (QC[3] + QP[3])) * alpha + (QC[2] + QP[2])) * alpha + (QC[1] + QP[1])) * alpha + (QC[0] + QP[0]);
+        const unsigned mask = SMPC_PLV(lmask);
+#pragma unroll
+        for (int f = 0; f < NF; f++)
+          if ((mask >> f) & 1u)
+          {
+            const double z0 = s.cone[f * NCK + 0][lane] + alpha * s.cone[f * NCK + 1][lane];
+            const double z1 = s.cone[f * NCK + 2][lane] + alpha * (s.cone[f * NCK + 3][lane] + alpha * s.cone[f * NCK + 4][lane]);
+            const double vp0 = fmax(z0, 0.0) * imu, vp1 = fmax(z1, 0.0) * imu;
+            const double va0 = s.cone[f * NCK + 5][lane] + alpha * s.cone[f * NCK + 6][lane], va1 = s.cone[f * NCK + 7][lane] + alpha * s.cone[f * NCK + 8][lane];
+            phi += mu * (vp0 * (vp0 - va0) + vp1 * (vp1 - va1));
+          }
+        red[lane] = phi;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      if (lane == 0)
+        s.sc[SC_PHI_NEW] = fold64<false>(red);
+      SMPC_LANES_END_WAVE
+      if (s.sc[SC_PHI_NEW] <= s.sc[SC_PHI0] + ka.armijo_c1 * alpha * s.sc[SC_DPHI0])
+      {
+        accepted = j;
+        break;
+      }
+      if (j + 1 < D::LS_N)
+        alpha *= 0.5;
+    }
+    // ---- cost and primal infeasibility at the accepted candidate (reported, not part of the test) ----
+    SMPC_LANES(NT)
+    {
+      const double * QC = SMPC_PLV(qc);
+      red[lane] = (((QC[4] * alpha + QC[3]) * alpha + QC[2]) * alpha + QC[1]) * alpha + QC[0];
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane == 0)
+      s.sc[SC_COST_NEW] = fold64<false>(red);
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    {
+      double prm = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; i++)
+        prm = fmax(prm, fabs(SMPC_PLV(e0)[i] + alpha * (SMPC_PLV(e1)[i] + (i >= 6 ? alpha * SMPC_PLV(e2)[i - 6] : 0.0))));
+      const unsigned mask = SMPC_PLV(lmask);
+      if (mask != 0u)
+      {
+        const size_t sl = ib + ring_slot(head, lane, R);
+#pragma unroll
+        for (int f = 0; f < NF; f++)
+          if ((mask >> f) & 1u)
+          {
+            const double c0 = s.cone[f * NCK + 0][lane] + alpha * s.cone[f * NCK + 1][lane] - mu * b.vs_e[sl * NC + 2 * f];
+            const double c1 = s.cone[f * NCK + 2][lane] + alpha * (s.cone[f * NCK + 3][lane] + alpha * s.cone[f * NCK + 4][lane]) - mu * b.vs_e[sl * NC + 2 * f + 1];
+            prm = fmax(prm, fmax(fmax(c0, 0.0), fmax(c1, 0.0)));
+          }
+      }
+      red[lane] = prm;
+    }
+    SMPC_LANES_END_WAVE
+    // ---- accept (the last candidate is taken when none passes, like the restated solver): flat axpy; the slot of stage H carries no
+    //      control / multiplier ----
+    SMPC_LANES(NT)
+    {
+      if (lane == 0)
+        s.sc[SC_PRIM_NEW] = fold64<true>(red);
+      const int sH = ring_slot(head, H, R);
+      for (int e = lane; e < R * 9; e += NT)
+      {
+        b.xs[ib * 9 + e] += alpha * b.dxs[ib * 9 + e];
+        if (e / 9 != sH)
+          b.lams[ib * 9 + e] += alpha * b.dlams[ib * 9 + e];
+      }
+      for (int e = lane; e < R * NU; e += NT)
+        if (e / NU != sH)
+          b.us[ib * NU + e] += alpha * b.dus[ib * NU + e];
+      for (int e = lane; e < R * NC; e += NT)
+        if (e / NC != sH)
+          b.vs[ib * NC + e] += alpha * b.dvs[ib * NC + e];
+      if (lane == 0)
+      {
+        s.sc[SC_ALPHA] = alpha;
+        s.sc[SC_LS_FAILED] = accepted < 0 ? 1.0 : 0.0;
+        s.sc[SC_LS_INDEX] = (double)jlast;
+        s.sc[SC_PREG] = accepted < 0 ? fmin(preg * ka.reg_inc, ka.reg_max) : fmax(preg * ka.reg_dec, ka.reg_min);
+      }
+    }
+    SMPC_LANES_END_WAVE
+    // ---- outputs: solver scalars ; xdot at t = 0, 1 of the accepted iterate (MPC::getStateDerivative) after the last iteration ----
+    SMPC_LANES(NT)
+    {
+      if (lane < 16)
+        gsc[lane] = s.sc[lane];
+      if (lane >= 32 && lane < 34 && sa.last)
+      {
+        const int t = lane - 32;
+        const size_t sl = ib + ring_slot(head, t, R);
+        const double * xg = b.xs + sl * 9;
+        const unsigned mask = b.stages[t].mask;
+        const V3 c = ld3(xg);
+        V3 fs = mk3(0, 0, 0), ts = mk3(0, 0, 0);
+        for (int f = 0; f < NF; f++)
+          if ((mask >> f) & 1u)
+          {
+            const V3 F = ld3(b.us + sl * NU + 3 * f);
+            fs = fs + F;
+            ts = ts + cross(ld3(b.foot + (inst * H + t) * (3 * NF) + 3 * f) - c, F);
+          }
+        double * xo = b.xdot01 + (inst * 2 + t) * 9;
+        for (int i = 0; i < 3; i++)
+        {
+          xo[i] = xg[3 + i] * imass;
+          xo[3 + i] = md.mass * md.gravity[i] + (i == 0 ? fs.x : (i == 1 ? fs.y : fs.z));
+          xo[6 + i] = i == 0 ? ts.x : (i == 1 ? ts.y : ts.z);
+        }
+      }
+    }
+    SMPC_LANES_END_WAVE
+  }
 } // namespace smpc
