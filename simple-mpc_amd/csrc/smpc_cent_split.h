@@ -32,16 +32,19 @@ namespace smpc
   {
     static constexpr int NF = D::NF, NU = D::NU, NC = D::NC;
     static_assert(NC <= 8 && NU <= 12, "cone rows live in the 4 + 4 spare slots of the two tile rows");
-    static constexpr int O_DTACT = 0;               // NF     dt act_f                      ([A B], forward sweep)
+    // quarters 0, 1 (only the backward sweep reads them): the Hessian blocks
+    static constexpr int O_RR = 0;                  // R = Luu + preg I as 3 x 3 foot blocks (fa <= fb; diagonal blocks: upper triangle)
+    static constexpr int N_RR = 6 * NF + 9 * (NF * (NF - 1) / 2);
+    static constexpr int O_QC = O_RR + N_RR;        // 6      CoM block of Q = Lxx + preg I, upper triangle
+    static constexpr int O_S = O_QC + 6;            // 9 NF   Lxu of the CoM rows: [f][xi][jb]
+    static constexpr int N_HESS = O_S + 9 * NF;
+    // quarters 2, 3 (forward sweep AND backward sweep): [A B] entries, vectors, cone rows
+    static constexpr int O_DTACT = ((N_HESS + 63) / 64) * 64; // NF dt act_f
     static constexpr int O_DTRP = O_DTACT + NF;     // 3 NF   +dt r_f   (r_f = 0 for a foot in the air)
     static constexpr int O_DTRN = O_DTRP + 3 * NF;  // 3 NF   -dt r_f
     static constexpr int O_DTFP = O_DTRN + 3 * NF;  // 3      +dt sum of the active forces
     static constexpr int O_DTFN = O_DTFP + 3;       // 3      -dt ...
-    static constexpr int O_RR = O_DTFN + 3;         // R = Luu + preg I as 3 x 3 foot blocks (fa <= fb; diagonal blocks: upper triangle)
-    static constexpr int N_RR = 6 * NF + 9 * (NF * (NF - 1) / 2);
-    static constexpr int O_QC = O_RR + N_RR;        // 6      CoM block of Q = Lxx + preg I, upper triangle
-    static constexpr int O_S = O_QC + 6;            // 9 NF   Lxu of the CoM rows: [f][xi][jb]
-    static constexpr int O_F = O_S + 9 * NF;        // 9      mu (lam+ - lam)
+    static constexpr int O_F = O_DTFN + 3;          // 9      mu (lam+ - lam)
     static constexpr int O_LPD = O_F + 9;           // 9      2 lam+ - lam
     static constexpr int O_Q = O_LPD + 9;           // 9      q
     static constexpr int O_GX = O_Q + 9;            // 9      lx + A^T (2 lam+ - lam)
@@ -50,6 +53,7 @@ namespace smpc
     static constexpr int O_FT = O_GX + 9, FT_N = 14;
     static constexpr int O_ANY = O_FT + FT_N * NF;  // 1      any cone row active
     static constexpr int N = O_ANY + 1;
+    static constexpr int Q_FWD = O_DTACT / 64;      // first quarter the forward sweep reads
     SMPC_HD static constexpr int d_off(int row, int k) { return O_FT + (row / 2) * FT_N + (row % 2) * 3 + k; }
     SMPC_HD static constexpr int dv_off(int row) { return O_FT + (row / 2) * FT_N + 6 + row % 2; }
     SMPC_HD static constexpr int r_off(int j) { return O_FT + (j / 3) * FT_N + 8 + j % 3; }
@@ -57,6 +61,11 @@ namespace smpc
     static constexpr int STRIDE = ((N + 63) / 64) * 64;
     static constexpr int NLOAD = STRIDE / 64;
     static_assert(STRIDE % EV_CH == 0, "whole flushes");
+    // gains of a stage, backward -> forward sweep: [K k] NU x 10 (rows of stride D::GKS: the read-out kernels of the handle use the same place),
+    // P~ as packed upper triangle, p+, and -- read only when a cone row of the stage is active -- [Z z] NC x 10
+    static constexpr int G_K = 0, G_Pt = NU * 10, G_pn = G_Pt + 45, G_Z = ((G_pn + 9 + 63) / 64) * 64, G_N = G_Z + NC * 10;
+    static_assert(G_N <= D::G_STRIDE && G_K == D::G_K && D::GKS == 10, "gains block of the handle");
+    SMPC_HD static constexpr int pt_off(int i, int j) { return i <= j ? G_Pt + i * 9 - i * (i - 1) / 2 + (j - i) : G_Pt + j * 9 - j * (j - 1) / 2 + (i - j); }
     // constants the gather of cent_bwd_body addresses behind the record in LDS
     static constexpr int C_ZERO = STRIDE, C_ONE = STRIDE + 1, C_DTM = STRIDE + 2, C_NMU = STRIDE + 3, C_QLM = STRIDE + 4, C_QAM = STRIDE + 10;
     static constexpr int STAGE_N = STRIDE + 16;
@@ -441,19 +450,6 @@ namespace smpc
             ts = ts + cross(rf[f], F);
           }
         }
-        // ---- [A B] entries ----
-        CENT_REC_AT(RC::O_DTACT);
-#pragma unroll
-        for (int f = 0; f < NF; f++)
-          put(dt * act[f]);
-#pragma unroll
-        for (int f = 0; f < NF; f++)
-          put3(dt * rf[f]);
-#pragma unroll
-        for (int f = 0; f < NF; f++)
-          put3((-dt) * rf[f]);
-        put3(dt * fs);
-        put3((-dt) * fs);
         // ---- Hessian blocks (Gauss-Newton) ----
         {
           M3 Nf[NF];
@@ -505,6 +501,23 @@ namespace smpc
             put(Y.a22);
           }
         }
+        // (pad to the quarter boundary: what follows is what the forward sweep reads too)
+#pragma unroll
+        for (int i = RC::N_HESS; i < RC::O_DTACT; i++)
+          put(0.0);
+        // ---- [A B] entries ----
+        CENT_REC_AT(RC::O_DTACT);
+#pragma unroll
+        for (int f = 0; f < NF; f++)
+          put(dt * act[f]);
+#pragma unroll
+        for (int f = 0; f < NF; f++)
+          put3(dt * rf[f]);
+#pragma unroll
+        for (int f = 0; f < NF; f++)
+          put3((-dt) * rf[f]);
+        put3(dt * fs);
+        put3((-dt) * fs);
         // ---- defect, multiplier estimates ----
         const V3 gv = ld3(md.gravity);
         double l1[9], lpd[9];
@@ -987,7 +1000,7 @@ namespace smpc
           SMPC_ACCV(m1, tix<2>(0, 1), v) = smu * pv;
           SMPC_ACCV(m1, tix<2>(0, 0), v) = mu * pv + (r == lc ? 1.0 : 0.0);
           if (lc == 9 && r < 9)
-            g[D::G_pn + r] = SMPC_ACCV(Pa, 0, v);
+            g[RC::G_pn + r] = SMPC_ACCV(Pa, 0, v);
         }
       }
       SMPC_LANES_END_WAVE
@@ -1001,8 +1014,8 @@ namespace smpc
         for (int v = 0; v < 4; v++)
         {
           const int r = lr + 4 * v;
-          if (r < 9 && lc < 9)
-            g[D::G_Pt + r * 9 + lc] = SMPC_ACCV(m1, tix<2>(1, 1), v);
+          if (lc < 9 && r <= lc)
+            g[RC::pt_off(r, lc)] = SMPC_ACCV(m1, tix<2>(1, 1), v);
           SMPC_ACCV(pc, 0, v) = (lc == 9 && r < 9) ? SMPC_ACCV(Pa, 0, v) : 0.0;
         }
 #pragma unroll
@@ -1072,9 +1085,9 @@ namespace smpc
           if (anyact)
           {
             if (lr < NC)
-              g[D::G_Z + lr * 10 + lc] = -SMPC_ACCV(m2, tix<2>(0, 1), 3);
+              g[RC::G_Z + lr * 10 + lc] = -SMPC_ACCV(m2, tix<2>(0, 1), 3);
             if (4 + lr < NC)
-              g[D::G_Z + (4 + lr) * 10 + lc] = -SMPC_ACCV(m2, tix<2>(1, 1), 3);
+              g[RC::G_Z + (4 + lr) * 10 + lc] = -SMPC_ACCV(m2, tix<2>(1, 1), 3);
           }
         }
 #pragma unroll
@@ -1097,8 +1110,9 @@ namespace smpc
     constexpr int NT = 64, NU = D::NU, NC = D::NC, NF = D::NF;
     // what the sweep reads of a stage: gains [K k | Z z | P~ | p+] (one contiguous run) and three of the four 64-double quarters of the
     // pre-pass record ([A B] entries in the first, vectors in the last two) -- coalesced loads one stage ahead, handed to the lanes through LDS
-    constexpr int NG = (D::G_pn + 9 + NT - 1) / NT;
-    static_assert(RC::NLOAD == 4 && RC::O_DTFP + 3 <= 64 && RC::O_F >= 128, "quarters of the record the forward sweep skips / needs");
+    constexpr int NG = RC::G_Z / NT; // [K k | P~ | p+]; [Z z] comes straight from memory in the stages that have an active cone row
+    constexpr int QF = RC::Q_FWD, NR = RC::NLOAD - QF;
+    static_assert(NR == 2 && RC::G_Z % NT == 0, "quarters of the record the forward sweep needs");
     const CentStepArgs<D> & ka = sa.a;
     const CentBuffers<D> & b = ka.b;
     const int H = b.H, R = b.R, head = ka.head;
@@ -1113,7 +1127,8 @@ namespace smpc
     SMPC_PL(double, yr, NT);
     SMPC_PL(double, acc_dphi, NT);
     SMPC_PLA(double, gpre, NT, NG);
-    SMPC_PLA(double, rpre, NT, 3);
+    SMPC_PLA(double, rpre, NT, NR);
+    SMPC_PLA(int, po, NT, 9); // lane i < 9: places of row i of the packed P~
     SMPC_LANES(NT)
     {
       SMPC_PLV(acc_dphi) = 0.0;
@@ -1127,9 +1142,12 @@ namespace smpc
 #pragma unroll
       for (int n = 0; n < NG; n++)
         SMPC_PLV(gpre)[n] = g[lane + n * NT];
-      SMPC_PLV(rpre)[0] = rc[lane];
-      SMPC_PLV(rpre)[1] = rc[lane + 2 * NT];
-      SMPC_PLV(rpre)[2] = rc[lane + 3 * NT];
+#pragma unroll
+      for (int n = 0; n < NR; n++)
+        SMPC_PLV(rpre)[n] = rc[lane + (QF + n) * NT];
+#pragma unroll
+      for (int j = 0; j < 9; j++)
+        SMPC_PLV(po)[j] = RC::pt_off(lane < 9 ? lane : 0, j);
     }
     SMPC_LANES_END_WAVE
     for (int t = 0; t < H; t++)
@@ -1140,9 +1158,9 @@ namespace smpc
 #pragma unroll
         for (int n = 0; n < NG; n++)
           gb[lane + n * NT] = SMPC_PLV(gpre)[n];
-        rb[lane] = SMPC_PLV(rpre)[0];
-        rb[lane + 2 * NT] = SMPC_PLV(rpre)[1];
-        rb[lane + 3 * NT] = SMPC_PLV(rpre)[2];
+#pragma unroll
+        for (int n = 0; n < NR; n++)
+          rb[lane + (QF + n) * NT] = SMPC_PLV(rpre)[n];
         if (t + 1 < H)
         {
           const double * g = b.gains + (inst * H + t + 1) * D::G_STRIDE;
@@ -1150,9 +1168,9 @@ namespace smpc
 #pragma unroll
           for (int n = 0; n < NG; n++)
             SMPC_PLV(gpre)[n] = g[lane + n * NT];
-          SMPC_PLV(rpre)[0] = rc[lane];
-          SMPC_PLV(rpre)[1] = rc[lane + 2 * NT];
-          SMPC_PLV(rpre)[2] = rc[lane + 3 * NT];
+#pragma unroll
+          for (int n = 0; n < NR; n++)
+            SMPC_PLV(rpre)[n] = rc[lane + (QF + n) * NT];
         }
       }
       SMPC_LANES_END_WAVE
@@ -1161,10 +1179,18 @@ namespace smpc
       SMPC_LANES(NT)
       {
         const bool urow = lane < NU, vrow = lane >= 16 && lane < 16 + NC;
-        const double * row = urow ? gb + D::G_K + lane * D::GKS : gb + D::G_Z + (vrow ? lane - 16 : 0) * 10;
         double a = 0.0;
-        if (urow || (vrow && any))
+        if (urow)
         {
+          const double * row = gb + RC::G_K + lane * D::GKS;
+          a = row[9];
+#pragma unroll
+          for (int j = 0; j < 9; j++)
+            a += row[j] * SMPC_XLANE(dxr, j);
+        }
+        else if (vrow && any) // (rare: the [Z z] row of this stage straight from memory)
+        {
+          const double * row = b.gains + (inst * H + t) * D::G_STRIDE + RC::G_Z + (lane - 16) * 10;
           a = row[9];
 #pragma unroll
           for (int j = 0; j < 9; j++)
@@ -1205,21 +1231,20 @@ namespace smpc
         const int k = lane % 3;
         const double add = lane < 3 ? (k == 0 ? lin.x : (k == 1 ? lin.y : lin.z)) : (lane < 6 ? (k == 0 ? sf.x : (k == 1 ? sf.y : sf.z)) : (k == 0 ? tq.x : (k == 1 ? tq.y : tq.z)));
         if (lane < 9)
-          SMPC_PLV(yr) = SMPC_PLV(dxr) + add + rb[RC::O_F + lane] - mu * gb[D::G_pn + lane];
+          SMPC_PLV(yr) = SMPC_PLV(dxr) + add + rb[RC::O_F + lane] - mu * gb[RC::G_pn + lane];
       }
       SMPC_LANES_END_WAVE
       // w = P~ y ; dx+ = y - mu w ; dlam+ = w + p+
       SMPC_LANES(NT)
       {
-        const int i = lane < 9 ? lane : 0;
         double w = 0.0;
 #pragma unroll
         for (int j = 0; j < 9; j++)
-          w += gb[D::G_Pt + i * 9 + j] * SMPC_XLANE(yr, j);
+          w += gb[SMPC_PLV(po)[j]] * SMPC_XLANE(yr, j);
         if (lane < 9)
         {
           const double dxn = SMPC_PLV(yr) - mu * w;
-          const double dl = w + gb[D::G_pn + lane];
+          const double dl = w + gb[RC::G_pn + lane];
           b.dxs[sl1 * 9 + lane] = dxn;
           b.dlams[sl * 9 + lane] = dl;
           SMPC_PLV(acc_dphi) -= rb[RC::O_LPD + lane] * dxn + rb[RC::O_F + lane] * dl;

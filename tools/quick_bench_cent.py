@@ -11,7 +11,8 @@ gm, rb, _, _ = S.make_cent_product(B, max_iters=iters)
 gm.generateCycleHorizon(O.trot_cycle()); gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.]))
 X = S.random_states(rb, B)
 gm.iterate(X)
-gm.set_profiling(True); gm.reset_kernel_times()
+prof = not os.environ.get('NOPROF')
+gm.set_profiling(prof); gm.reset_kernel_times()
 t0 = time.time()
 for _ in range(steps):
     gm.iterate(X)
