@@ -91,6 +91,8 @@
 #define SMPC_RSQRT(x) ::smpc::rsqrt_nr(x)
 // 1/x: hardware estimate (v_rcp_f64) + two Newton steps (a full IEEE division is ~3x the dependent latency)
 #define SMPC_RCP(x) ::smpc::rcp_nr(x)
+// 1/x with ONE Newton step: 2e-15 relative error (tools/micro/rcp_accuracy.hip), two dependent FMAs less per pivot
+#define SMPC_RCP1(x) ::smpc::rcp_nr1(x)
 
 namespace smpc
 {
@@ -141,6 +143,12 @@ namespace smpc
   {
     double r = __builtin_amdgcn_rcp(x);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+  }
+  __device__ __forceinline__ double rcp_nr1(double x)
+  {
+    double r = __builtin_amdgcn_rcp(x);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     return r;
   }

@@ -767,15 +767,15 @@ namespace smpc
         const double D00 = d[0], D01 = d[1], D02 = d[2], D03 = d[3];
         const double D11 = d[LDW + 1], D12 = d[LDW + 2], D13 = d[LDW + 3];
         const double D22 = d[2 * LDW + 2], D23 = d[2 * LDW + 3], D33 = d[3 * LDW + 3];
-        const double i0 = SMPC_RCP(D00);
+        const double i0 = SMPC_RCP1(D00);
         const double l10 = D01 * i0, l20 = D02 * i0, l30 = D03 * i0;
-        const double i1 = SMPC_RCP(D11 - l10 * D01);
+        const double i1 = SMPC_RCP1(D11 - l10 * D01);
         const double t21 = D12 - l20 * D01, t31 = D13 - l30 * D01;
         const double l21 = t21 * i1, l31 = t31 * i1;
-        const double i2 = SMPC_RCP(D22 - l20 * D02 - l21 * t21);
+        const double i2 = SMPC_RCP1(D22 - l20 * D02 - l21 * t21);
         const double t32 = D23 - l30 * D02 - l31 * t21;
         const double l32 = t32 * i2;
-        const double i3 = SMPC_RCP(D33 - l30 * D03 - l31 * t31 - l32 * t32);
+        const double i3 = SMPC_RCP1(D33 - l30 * D03 - l31 * t31 - l32 * t32);
         const int M0 = ALL ? 0 : 16 * Ip;
         const int m = M0 + lane;
         if (m < LDW)
@@ -912,11 +912,9 @@ namespace smpc
     SMPC_ACC(m1, NT, 3);
     SMPC_ACC(m2, NT, 3);
     SMPC_ACC(tacc, NT, 2);
-    SMPC_ACC(pc, NT, 1);
     SMPC_PLA(double, pin, NT, RC::NLOAD);
     SMPC_PLA(double, aop, NT, 6);
     SMPC_PLA(double, ptl, NT, 3);
-    SMPC_PLA(double, fop, NT, 3);
     SMPC_PLA(double, top, NT, 6);
 
     SMPC_LANES(NT)
@@ -1016,17 +1014,17 @@ namespace smpc
           const int r = lr + 4 * v;
           if (lc < 9 && r <= lc)
             g[RC::pt_off(r, lc)] = SMPC_ACCV(m1, tix<2>(1, 1), v);
-          SMPC_ACCV(pc, 0, v) = (lc == 9 && r < 9) ? SMPC_ACCV(Pa, 0, v) : 0.0;
         }
 #pragma unroll
         for (int sk = 0; sk < 3; sk++)
         {
           const int k = 4 * sk + lr;
           SMPC_PLV(ptl)[sk] = SMPC_ACCV(m1, tix<2>(1, 1), sk);
-          SMPC_PLV(fop)[sk] = (lc == 9 && k < 9) ? stg[RC::O_F + (k < 9 ? k : 0)] - mu * SMPC_ACCV(Pa, 0, sk) : 0.0;
-#pragma unroll
-          for (int I = 0; I < 2; I++)
-            SMPC_PLV(aop)[sk * 2 + I] = stg[SMPC_PLV(offab)[sk * 2 + I]];
+          SMPC_PLV(aop)[sk * 2 + 0] = stg[SMPC_PLV(offab)[sk * 2 + 0]];
+          // the vector column (ZC) of [A B] is structurally zero: it carries f - mu p, so that column ZC of P~ [A B] is P~ (f - mu p) for free.
+          // (As A operand of the second product the same entries land in ROW ZC of the stage matrix -- a row no sweep ever reads.)
+          const double ab1 = stg[SMPC_PLV(offab)[sk * 2 + 1]];
+          SMPC_PLV(aop)[sk * 2 + 1] = (lc == RC::ZC - 16 && k < 9) ? stg[RC::O_F + (k < 9 ? k : 0)] - mu * SMPC_ACCV(Pa, 0, sk) : ab1;
         }
 #pragma unroll
         for (int J = 0; J < 2; J++)
@@ -1041,21 +1039,18 @@ namespace smpc
       CENT_FINE_TICK(7);
 #pragma unroll
       for (int sk = 0; sk < 3; sk++)
-      {
-        SMPC_MFMA(pc, 0, ptl, sk, fop, sk);
 #pragma unroll
         for (int J = 0; J < 2; J++)
           SMPC_MFMA(tacc, J, ptl, sk, aop, sk * 2 + J);
-      }
       SMPC_LANES(NT)
       {
-        const int lc = lane & 15;
+        const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
         for (int sk = 0; sk < 3; sk++)
         {
           SMPC_PLV(top)[sk * 2 + 0] = SMPC_ACCV(tacc, 0, sk);
           // column ZC of the right factor is p~ (so that the vector column receives [A B]^T p~)
-          SMPC_PLV(top)[sk * 2 + 1] = lc == RC::ZC - 16 ? SMPC_ACCV(pc, 0, sk) : SMPC_ACCV(tacc, 1, sk);
+          SMPC_PLV(top)[sk * 2 + 1] = SMPC_ACCV(tacc, 1, sk) + ((lc == RC::ZC - 16 && 4 * sk + lr < 9) ? SMPC_ACCV(Pa, 0, sk) : 0.0);
         }
       }
       SMPC_LANES_END_WAVE

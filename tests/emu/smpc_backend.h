@@ -55,6 +55,7 @@
 #define SMPC_TOUCH(gptr, lds_sink) ((void)(gptr), (void)(lds_sink))
 #define SMPC_RSQRT(x) (1.0 / std::sqrt(x))
 #define SMPC_RCP(x) (1.0 / (x))
+#define SMPC_RCP1(x) (1.0 / (x))
 
 namespace smpc
 {
