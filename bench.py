@@ -575,18 +575,18 @@ def centroidal_line(batch, iters, steps, warmup, device_id, with_cpu=True):
         rl.update({"kernel": "cent_step_body (whole control step: recede + %d ProxDDP iterations)" % iters, "traffic": tr, "traffic_source": src})
     else:
         # dominant kernel of the pipeline: the backward sweep (FP64: B*H*F_ric(9,12,8) per launch; bytes: the stage record read + gains written)
-        REC, GAIN = 247 * 8, 290 * 8  # CentRec::N doubles read, [K k | Z z | P~ | p+] doubles written per stage (smpc_cent_split.h)
+        REC, GAIN = 256 * 8, 174 * 8  # CentRec::STRIDE doubles read; [K k | P~ packed | p+] doubles written per stage ([Z z] only with active cone rows)
         rl = both_bounds(BH * fr, BH * (REC + GAIN), ms["backward"] * 1e-3, "mfma")
         tr, src = pmc_traffic("cent_bwd_body", batch == 4096 and iters == 3)
         rl.update({"kernel": "cent_bwd_body (proximal Riccati recursion of one ProxDDP iteration; %.0f %% of the step's kernel time)"
                    % (100.0 * per_step["backward"] / max(sum(per_step.values()), 1e-12)), "traffic": tr, "traffic_source": src})
-        # the memory-bound kernels of the pipeline: algorithmic bytes per launch (DESIGN 3.4b)
+        # the memory-bound kernels of the pipeline: algorithmic bytes per launch (DESIGN 3.4)
         ITER = 8 * (9 * 2 + gm.nu + gm.nc * 2 + 9 * 3 + 3 * 4 + 6 + gm.nu + 3)  # iterate + references a stage evaluation reads
         STEPB = 8 * (9 + gm.nu + gm.nc + 9)                                      # dx, du, dnu, dlam of a stage
         other = {
             "pre": both_bounds(None, BH * (ITER + 256 * 8), ms["pre"] * 1e-3, "hbm"),
-            "forward": both_bounds(None, BH * (GAIN + 192 * 8 + STEPB), ms["forward"] * 1e-3, "hbm"),
-            "line_search": both_bounds(None, BH * (ITER + 3 * STEPB + STEPB), ms["line_search"] * 1e-3, "hbm"),
+            "forward": both_bounds(None, BH * (192 * 8 + 128 * 8 + STEPB), ms["forward"] * 1e-3, "hbm"),  # gains quarters 0-2, record quarters 2-3, steps out
+            "line_search": both_bounds(None, BH * (ITER + STEPB + 3 * STEPB), ms["line_search"] * 1e-3, "hbm"),  # evaluation inputs once + the accept axpy
         }
         for k in other:
             t2, _ = pmc_traffic("cent_%s_body" % {"pre": "pre", "forward": "fwd", "line_search": "ls"}[k], batch == 4096 and iters == 3)

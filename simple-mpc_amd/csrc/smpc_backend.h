@@ -53,6 +53,8 @@
     __builtin_amdgcn_wave_barrier();                                                                                   \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                             \
   } while (0)
+// a lambda that must be inlined into the kernel body (device code: a called function would save / restore the caller's registers)
+#define SMPC_LAMBDA_INLINE __attribute__((always_inline))
 // a consistency check of the kernel SOURCE that only the sequential test build evaluates (there it throws); nothing on the device
 #define SMPC_TEST_CHECK(cond, msg) ((void)0)
 // per-lane value that must survive a phase boundary (register on the GPU)

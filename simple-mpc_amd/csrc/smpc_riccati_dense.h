@@ -20,6 +20,7 @@
 #pragma once
 #include "smpc_full_model.h"
 #include "smpc_riccati_kino.h"
+#include <type_traits>
 
 namespace smpc
 {
@@ -194,226 +195,256 @@ namespace smpc
         SMPC_LANES_END_WAVE
       }
       prof_tick(prof, 41, tprev);
-      // ---- (3) [A | B] into LDS ; P~ out (forward sweep) ; prefetch of [Q S q; S^T R r] in accumulator layout ----
-      SMPC_ACC(hacc, NT, NT2 * (NT2 + 1) / 2);
-      SMPC_LANES(NT)
-      {
-        const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-        for (int I = 0; I < NT2; I++)
-#pragma unroll
-          for (int J = I; J < NT2; J++)
-#pragma unroll
-            for (int v = 0; v < 4; v++)
-            {
-              const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
-              // upper storage: row <= col inside a diagonal tile is not guaranteed: take (min, max)
-              const int r0 = row < col ? row : col, c0 = row < col ? col : row;
-              int off = D::O_Q; // entries outside the problem load Q[0][0] and are overwritten below
-              if (c0 < NDX)
-                off = D::O_Q + r0 * NDX + c0;
-              else if (c0 < NXU)
-                off = r0 < NDX ? D::O_S + r0 * NU + c0 - NDX : D::O_R + (r0 - NDX) * NU + c0 - NDX;
-              else if (GM::drow(c0) >= 0 && r0 < NXU) // dense constraint rows: (x, nu_i) = C_i, (u, nu_i) = D_i
-                off = r0 < NDX ? D::O_C + GM::drow(c0) * NDX + r0 : D::O_D + GM::drow(c0) * NU + r0 - NDX;
-              else if (c0 == VC && r0 < NXU)
-                off = r0 < NDX ? D::O_q + r0 : D::O_r + r0 - NDX;
-              SMPC_ACCV(hacc, tix<NT2>(I, J), v) = lq[off];
-            }
-        for (int idx = lane; idx < NDX * NDX; idx += NT)
-          g[D::G_Pt + idx] = s.P[idx];
-      }
-      SMPC_LANES_END_WAVE
-      prof_tick(prof, 42, tprev);
-      // ---- (4) T = P~ [A | B] with p~ as column VC ; H^ += [A | B]^T T ----
-      {
-        constexpr int NTT = NTJ + 1; // tile columns of T: [A | B] columns + the tile of the vector column
-        SMPC_ACC(tacc, NT, NTX * NTT);
-        SMPC_PLA(double, pav, NT, NTX);
-        SMPC_PLA(double, abv, NT, NTJ);
-        // operand slices of the next TWO K-steps, in flight while the current products run: a K-step of MFMAs (1.0 - 1.5 k cycles) is shorter
-        // than a round trip to L2 / HBM (2 - 5 k), so with one slice ahead every K-step waited for its operands
-        // (measured per instantiation: Go2 full dynamics 3.95 -> 3.82 ms, Talos kinodynamics 14.2 -> 12.3 ms per launch; the Talos full-dynamics
-        //  sweep -- 56 states, 22 controls, up to 78 rows -- is at its register limit, the second slice is spilled there and costs 6 %: one ahead)
-        constexpr bool TWO_AHEAD = !(NDX == 56 && NU == 22);
-        SMPC_PLA(double, abn, NT, NTJ);
-        SMPC_PLA(double, abn2, NT, (TWO_AHEAD ? NTJ : 1));
-        // slice ks of [A | B | 0]: entry (4 ks + lr, 16 J + lc), address selected, loaded once, masked at the use
-        auto ab_fetch = [&](int ks, int J, int lr, int lc) {
-          const int r = 4 * ks + lr, c = 16 * J + lc;
-          const double * src = c < NDX ? lq + D::O_A + r * NDX + c : lq + D::O_B + r * NU + (c < NXU ? c - NDX : 0);
-          return *src;
-        };
+      // Stages without an active dense row (the common case: wrench cones of feet that stand flat) run the LIGHT form of what follows: the
+      // multiplier columns are left out of the second grid altogether (NCPX = 0: 6 instead of 8 tile columns for the Talos-class problems,
+      // 21 instead of 36 accumulator tiles -- no spilled accumulators, 40 % fewer rank-4 updates in the control sweep); Z = 0, z = d / mu.
+      auto tail = [&](auto ncpx_) SMPC_LAMBDA_INLINE {
+        constexpr int NCPX = decltype(ncpx_)::value;                 // padded dense rows behind the control panels kept in the grid
+        constexpr int NXCX = NCPX == 0 ? 16 * NTJ : NXUP + NCPX, VCX = NXCX, NT2X = (NXCX + 1 + 15) / 16, VTX = VCX / 16; // (light: the vector column opens a tile column of its own)
+        static_assert(VTX >= NTJ, "the vector column lives in a tile column of its own (or of the multipliers)");
+        auto drowx = [](int c) -> int { return (NCPX == 0 && c >= GM::NXUP) ? -1 : GM::drow(c); };
+        // ---- (3) [A | B] into LDS ; P~ out (forward sweep) ; prefetch of [Q S q; S^T R r] in accumulator layout ----
+        SMPC_ACC(hacc, NT, NT2X * (NT2X + 1) / 2);
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-          for (int J = 0; J < NTJ; J++)
-          {
-            SMPC_PLV(abn)[J] = ab_fetch(0, J, lr, lc);
-            if constexpr (TWO_AHEAD)
-              SMPC_PLV(abn2)[J] = ab_fetch(1, J, lr, lc);
-          }
-#pragma unroll
-          for (int I = 0; I < NTX; I++)
-#pragma unroll
-            for (int J = 0; J < NTT; J++)
-#pragma unroll
+  #pragma unroll
+          for (int I = 0; I < NT2X; I++)
+  #pragma unroll
+            for (int J = I; J < NT2X; J++)
+  #pragma unroll
               for (int v = 0; v < 4; v++)
               {
-                const int row = 16 * I + lr + 4 * v, col = 16 * (J < NTJ ? J : VT) + lc;
-                const double pv = s.pt[row < NDX ? row : 0];
-                SMPC_ACCV(tacc, I * NTT + J, v) = (col == VC && row < NDX) ? pv : 0.0;
+                const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+                // upper storage: row <= col inside a diagonal tile is not guaranteed: take (min, max)
+                const int r0 = row < col ? row : col, c0 = row < col ? col : row;
+                int off = D::O_Q; // entries outside the problem load Q[0][0] and are overwritten below
+                if (c0 < NDX)
+                  off = D::O_Q + r0 * NDX + c0;
+                else if (c0 < NXU)
+                  off = r0 < NDX ? D::O_S + r0 * NU + c0 - NDX : D::O_R + (r0 - NDX) * NU + c0 - NDX;
+                else if (drowx(c0) >= 0 && r0 < NXU) // dense constraint rows: (x, nu_i) = C_i, (u, nu_i) = D_i
+                  off = r0 < NDX ? D::O_C + drowx(c0) * NDX + r0 : D::O_D + drowx(c0) * NU + r0 - NDX;
+                else if (c0 == VCX && r0 < NXU)
+                  off = r0 < NDX ? D::O_q + r0 : D::O_r + r0 - NDX;
+                SMPC_ACCV(hacc, tix<NT2X>(I, J), v) = lq[off];
               }
+          for (int idx = lane; idx < NDX * NDX; idx += NT)
+            g[D::G_Pt + idx] = s.P[idx];
         }
         SMPC_LANES_END_WAVE
-        for (int ks = 0; ks < NDX / 4; ks++)
+        prof_tick(prof, 42, tprev);
+        // ---- (4) T = P~ [A | B] with p~ as column VCX ; H^ += [A | B]^T T ----
         {
+          constexpr int NTT = NTJ + 1; // tile columns of T: [A | B] columns + the tile of the vector column
+          SMPC_ACC(tacc, NT, NTX * NTT);
+          SMPC_PLA(double, pav, NT, NTX);
+          SMPC_PLA(double, abv, NT, NTJ);
+          // operand slices of the next TWO K-steps, in flight while the current products run: a K-step of MFMAs (1.0 - 1.5 k cycles) is shorter
+          // than a round trip to L2 / HBM (2 - 5 k), so with one slice ahead every K-step waited for its operands
+          // (measured per instantiation: Go2 full dynamics 3.95 -> 3.82 ms, Talos kinodynamics 14.2 -> 12.3 ms per launch; the Talos full-dynamics
+          //  sweep -- 56 states, 22 controls, up to 78 rows -- is at its register limit, the second slice is spilled there and costs 6 %: one ahead)
+          constexpr bool TWO_AHEAD = !(NDX == 56 && NU == 22);
+          SMPC_PLA(double, abn, NT, NTJ);
+          SMPC_PLA(double, abn2, NT, (TWO_AHEAD ? NTJ : 1));
+          // slice ks of [A | B | 0]: entry (4 ks + lr, 16 J + lc), address selected, loaded once, masked at the use
+          auto ab_fetch = [&](int ks, int J, int lr, int lc) {
+            const int r = 4 * ks + lr, c = 16 * J + lc;
+            const double * src = c < NDX ? lq + D::O_A + r * NDX + c : lq + D::O_B + r * NU + (c < NXU ? c - NDX : 0);
+            return *src;
+          };
           SMPC_LANES(NT)
           {
             const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-            for (int I = 0; I < NTX; I++)
-            {
-              // A operand: P~[16 I + lc][4 ks + lr] (symmetric: read along the row of 4 ks + lr)
-              const int r = 16 * I + lc;
-              const double pv = s.P[(4 * ks + lr) * NDX + (r < NDX ? r : 0)];
-              SMPC_PLV(pav)[I] = r < NDX ? pv : 0.0;
-            }
-#pragma unroll
+  #pragma unroll
             for (int J = 0; J < NTJ; J++)
             {
-              SMPC_PLV(abv)[J] = 16 * J + lc < NXU ? SMPC_PLV(abn)[J] : 0.0;
-              // slice after next (the second product starts again at slice 0)
+              SMPC_PLV(abn)[J] = ab_fetch(0, J, lr, lc);
               if constexpr (TWO_AHEAD)
-              {
-                SMPC_PLV(abn)[J] = SMPC_PLV(abn2)[J];
-                SMPC_PLV(abn2)[J] = ab_fetch((ks + 2) % (NDX / 4), J, lr, lc);
-              }
-              else
-                SMPC_PLV(abn)[J] = ab_fetch(ks + 1 < NDX / 4 ? ks + 1 : 0, J, lr, lc);
+                SMPC_PLV(abn2)[J] = ab_fetch(1, J, lr, lc);
             }
+  #pragma unroll
+            for (int I = 0; I < NTX; I++)
+  #pragma unroll
+              for (int J = 0; J < NTT; J++)
+  #pragma unroll
+                for (int v = 0; v < 4; v++)
+                {
+                  const int row = 16 * I + lr + 4 * v, col = 16 * (J < NTJ ? J : VTX) + lc;
+                  const double pv = s.pt[row < NDX ? row : 0];
+                  SMPC_ACCV(tacc, I * NTT + J, v) = (col == VCX && row < NDX) ? pv : 0.0;
+                }
           }
           SMPC_LANES_END_WAVE
-#pragma unroll
-          for (int I = 0; I < NTX; I++)
-#pragma unroll
-            for (int J = 0; J < NTJ; J++)
-              SMPC_MFMA(tacc, I * NTT + J, pav, I, abv, J);
-        }
-        // H^(I, J) += sum_ks ABop(ks, I)^T T(ks, J): the B operand of K-step ks = 4 Ix + v is accumulator entry v of T's tile (Ix, J)
-        SMPC_PLA(double, tbv, NT, NTT);
-#pragma unroll
-        for (int Ix = 0; Ix < NTX; Ix++)
-#pragma unroll
-          for (int v = 0; v < 4; v++)
+          for (int ks = 0; ks < NDX / 4; ks++)
           {
-            if (16 * Ix + 4 * v >= NDX)
-              continue;
             SMPC_LANES(NT)
             {
               const int lr = lane >> 4, lc = lane & 15;
-              const int ks = 4 * Ix + v;
-#pragma unroll
+  #pragma unroll
+              for (int I = 0; I < NTX; I++)
+              {
+                // A operand: P~[16 I + lc][4 ks + lr] (symmetric: read along the row of 4 ks + lr)
+                const int r = 16 * I + lc;
+                const double pv = s.P[(4 * ks + lr) * NDX + (r < NDX ? r : 0)];
+                SMPC_PLV(pav)[I] = r < NDX ? pv : 0.0;
+              }
+  #pragma unroll
               for (int J = 0; J < NTJ; J++)
               {
                 SMPC_PLV(abv)[J] = 16 * J + lc < NXU ? SMPC_PLV(abn)[J] : 0.0;
+                // slice after next (the second product starts again at slice 0)
                 if constexpr (TWO_AHEAD)
                 {
                   SMPC_PLV(abn)[J] = SMPC_PLV(abn2)[J];
-                  if (ks + 2 < NDX / 4)
-                    SMPC_PLV(abn2)[J] = ab_fetch(ks + 2, J, lr, lc);
+                  SMPC_PLV(abn2)[J] = ab_fetch((ks + 2) % (NDX / 4), J, lr, lc);
                 }
-                else if (ks + 1 < NDX / 4)
-                  SMPC_PLV(abn)[J] = ab_fetch(ks + 1, J, lr, lc);
+                else
+                  SMPC_PLV(abn)[J] = ab_fetch(ks + 1 < NDX / 4 ? ks + 1 : 0, J, lr, lc);
               }
-#pragma unroll
-              for (int J = 0; J < NTT; J++)
-                SMPC_PLV(tbv)[J] = SMPC_ACCV(tacc, Ix * NTT + J, v);
             }
             SMPC_LANES_END_WAVE
-#pragma unroll
-            for (int I = 0; I < NTJ; I++)
-#pragma unroll
-              for (int J = I; J < NT2; J++)
-                if (J < NTJ || J == VT) // (T is zero in the multiplier columns)
-                  SMPC_MFMA(hacc, tix<NT2>(I, J), abv, I, tbv, J < NTJ ? J : NTJ);
+  #pragma unroll
+            for (int I = 0; I < NTX; I++)
+  #pragma unroll
+              for (int J = 0; J < NTJ; J++)
+                SMPC_MFMA(tacc, I * NTT + J, pav, I, abv, J);
           }
-      }
-      prof_tick(prof, 43, tprev);
-      // ---- (5) box rows ; padding pivots ; entries outside the problem ----
-      SMPC_LANES(NT)
-      {
-        const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-        for (int I = 0; I < NT2; I++)
-#pragma unroll
-          for (int J = I; J < NT2; J++)
-#pragma unroll
+          // H^(I, J) += sum_ks ABop(ks, I)^T T(ks, J): the B operand of K-step ks = 4 Ix + v is accumulator entry v of T's tile (Ix, J)
+          SMPC_PLA(double, tbv, NT, NTT);
+  #pragma unroll
+          for (int Ix = 0; Ix < NTX; Ix++)
+  #pragma unroll
             for (int v = 0; v < 4; v++)
             {
-              const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
-              const int r0 = row < col ? row : col, c0 = row < col ? col : row;
-              double val = SMPC_ACCV(hacc, tix<NT2>(I, J), v);
-              // box index of a (state / control) index: joint box on x[6 .. 6 + NA), torque box on u
-              const int bi = (r0 >= 6 && r0 < 6 + NA) ? NU + r0 - 6 : ((r0 >= NDX && r0 < NXU) ? r0 - NDX : -1);
-              const double ba = s.boxa[bi >= 0 ? bi : 0], bd = s.boxd[bi >= 0 ? bi : 0];
-              if (bi >= 0 && c0 == r0)
-                val += imu * ba;
-              if (bi >= 0 && c0 == VC)
-                val += imu * ba * bd;
-              const bool rx = r0 < NXU, rn = GM::drow(r0) >= 0; // problem rows: (x, u) ; explicit multipliers
-              const bool cx = c0 < NXU, cn = GM::drow(c0) >= 0;
-              if (rn && c0 == r0)
-                val = -mu;                                   // multiplier block -mu I
-              else if (rn && c0 == VC)
-                val = s.boxd[NU + NA + GM::drow(r0)];         // d of the dense rows
-              else if (!((rx && (cx || cn || c0 == VC))))
-                val = (r0 == c0 && r0 < NXC) ? 1.0 : 0.0;     // unit padding pivots, zero elsewhere
-              SMPC_ACCV(hacc, tix<NT2>(I, J), v) = val;
-            }
-      }
-      SMPC_LANES_END_WAVE
-      prof_tick(prof, 44, tprev);
-      // ---- (6) sweep the control pivots in place:  x-x block -> P_t,  x-vector -> p_t,  (x, u) entries -> -K,  (u, vector) -> -k ----
-      wave_block_sweep<NT, NT2, true, NDX, (NUP + NCP) / 4, (NCD > 0)>(hacc, sw, sw + LDS::SWP, prof, tprev, skip);
-      prof_tick(prof, 45, tprev);
-      SMPC_LANES(NT)
-      {
-        const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-        for (int I = 0; I < NT2; I++)
-#pragma unroll
-          for (int J = I; J < NT2; J++)
-#pragma unroll
-            for (int v = 0; v < 4; v++)
-            {
-              const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
-              const double val = SMPC_ACCV(hacc, tix<NT2>(I, J), v);
-              if (row < NDX)
+              if (16 * Ix + 4 * v >= NDX)
+                continue;
+              SMPC_LANES(NT)
               {
-                if (col < NDX)
+                const int lr = lane >> 4, lc = lane & 15;
+                const int ks = 4 * Ix + v;
+  #pragma unroll
+                for (int J = 0; J < NTJ; J++)
                 {
-                  if (row <= col)
+                  SMPC_PLV(abv)[J] = 16 * J + lc < NXU ? SMPC_PLV(abn)[J] : 0.0;
+                  if constexpr (TWO_AHEAD)
                   {
-                    s.P[row * NDX + col] = val;
-                    s.P[col * NDX + row] = val;
+                    SMPC_PLV(abn)[J] = SMPC_PLV(abn2)[J];
+                    if (ks + 2 < NDX / 4)
+                      SMPC_PLV(abn2)[J] = ab_fetch(ks + 2, J, lr, lc);
                   }
+                  else if (ks + 1 < NDX / 4)
+                    SMPC_PLV(abn)[J] = ab_fetch(ks + 1, J, lr, lc);
                 }
-                else if (col < NXU)
-                  g[D::G_K + (col - NDX) * (NDX + 1) + row] = -val; // K
-                else if (GM::drow(col) >= 0)
-                  g[D::G_Z + GM::drow(col) * (NDX + 1) + row] = -val; // Z: multiplier feedback of the dense rows
-                else if (col == VC)
-                  s.p[row] = val; // p_t
+  #pragma unroll
+                for (int J = 0; J < NTT; J++)
+                  SMPC_PLV(tbv)[J] = SMPC_ACCV(tacc, Ix * NTT + J, v);
               }
-              else if (row < NXU && col == VC)
-                g[D::G_K + (row - NDX) * (NDX + 1) + NDX] = -val; // k
-              else if (GM::drow(row) >= 0 && col == VC)
-                g[D::G_Z + GM::drow(row) * (NDX + 1) + NDX] = ((skip >> ((row - NDX) / 4)) & 1u) ? val / mu : -val; // z
+              SMPC_LANES_END_WAVE
+  #pragma unroll
+              for (int I = 0; I < NTJ; I++)
+  #pragma unroll
+                for (int J = I; J < NT2X; J++)
+                  if (J < NTJ || J == VTX) // (T is zero in the multiplier columns)
+                    SMPC_MFMA(hacc, tix<NT2X>(I, J), abv, I, tbv, J < NTJ ? J : NTJ);
             }
+        }
+        prof_tick(prof, 43, tprev);
+        // ---- (5) box rows ; padding pivots ; entries outside the problem ----
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+  #pragma unroll
+          for (int I = 0; I < NT2X; I++)
+  #pragma unroll
+            for (int J = I; J < NT2X; J++)
+  #pragma unroll
+              for (int v = 0; v < 4; v++)
+              {
+                const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+                const int r0 = row < col ? row : col, c0 = row < col ? col : row;
+                double val = SMPC_ACCV(hacc, tix<NT2X>(I, J), v);
+                // box index of a (state / control) index: joint box on x[6 .. 6 + NA), torque box on u
+                const int bi = (r0 >= 6 && r0 < 6 + NA) ? NU + r0 - 6 : ((r0 >= NDX && r0 < NXU) ? r0 - NDX : -1);
+                const double ba = s.boxa[bi >= 0 ? bi : 0], bd = s.boxd[bi >= 0 ? bi : 0];
+                if (bi >= 0 && c0 == r0)
+                  val += imu * ba;
+                if (bi >= 0 && c0 == VCX)
+                  val += imu * ba * bd;
+                const bool rx = r0 < NXU, rn = drowx(r0) >= 0; // problem rows: (x, u) ; explicit multipliers
+                const bool cx = c0 < NXU, cn = drowx(c0) >= 0;
+                if (rn && c0 == r0)
+                  val = -mu;                                   // multiplier block -mu I
+                else if (rn && c0 == VCX)
+                  val = s.boxd[NU + NA + drowx(r0)];         // d of the dense rows
+                else if (!((rx && (cx || cn || c0 == VCX))))
+                  val = (r0 == c0 && r0 < NXCX) ? 1.0 : 0.0;     // unit padding pivots, zero elsewhere
+                SMPC_ACCV(hacc, tix<NT2X>(I, J), v) = val;
+              }
+        }
+        SMPC_LANES_END_WAVE
+        prof_tick(prof, 44, tprev);
+        // ---- (6) sweep the control pivots in place:  x-x block -> P_t,  x-vector -> p_t,  (x, u) entries -> -K,  (u, vector) -> -k ----
+        wave_block_sweep<NT, NT2X, true, NDX, (NUP + NCPX) / 4, (NCPX > 0)>(hacc, sw, sw + LDS::SWP, prof, tprev, skip);
+        prof_tick(prof, 45, tprev);
+        SMPC_LANES(NT)
+        {
+          const int lr = lane >> 4, lc = lane & 15;
+  #pragma unroll
+          for (int I = 0; I < NT2X; I++)
+  #pragma unroll
+            for (int J = I; J < NT2X; J++)
+  #pragma unroll
+              for (int v = 0; v < 4; v++)
+              {
+                const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
+                const double val = SMPC_ACCV(hacc, tix<NT2X>(I, J), v);
+                if (row < NDX)
+                {
+                  if (col < NDX)
+                  {
+                    if (row <= col)
+                    {
+                      s.P[row * NDX + col] = val;
+                      s.P[col * NDX + row] = val;
+                    }
+                  }
+                  else if (col < NXU)
+                    g[D::G_K + (col - NDX) * (NDX + 1) + row] = -val; // K
+                  else if (drowx(col) >= 0)
+                    g[D::G_Z + drowx(col) * (NDX + 1) + row] = -val; // Z: multiplier feedback of the dense rows
+                  else if (col == VCX)
+                    s.p[row] = val; // p_t
+                }
+                else if (row < NXU && col == VCX)
+                  g[D::G_K + (row - NDX) * (NDX + 1) + NDX] = -val; // k
+                else if (drowx(row) >= 0 && col == VCX)
+                  g[D::G_Z + drowx(row) * (NDX + 1) + NDX] = ((skip >> ((row - NDX) / 4)) & 1u) ? val / mu : -val; // z
+              }
+        }
+        SMPC_LANES_END_WAVE
+
+        if constexpr (NCPX == 0 && NCP > 0)
+        {
+          // the dense rows that are not in the grid: all inactive -- Z = 0, z = d / mu
+          SMPC_LANES(NT)
+          for (int idx = lane; idx < (NCD - GM::FILL) * (NDX + 1); idx += NT)
+          {
+            const int i = GM::FILL + idx / (NDX + 1), c = idx % (NDX + 1);
+            g[D::G_Z + i * (NDX + 1) + c] = c < NDX ? 0.0 : s.boxd[NU + NA + i] / mu;
+          }
+          SMPC_LANES_END_WAVE
+        }
+      };
+      if constexpr (NCP > 0)
+      {
+        if (skip == (((1u << (NCP / 4)) - 1u) << (NUP / 4)))
+          tail(std::integral_constant<int, 0>());
+        else
+          tail(std::integral_constant<int, NCP>());
       }
-      SMPC_LANES_END_WAVE
+      else
+        tail(std::integral_constant<int, 0>());
       prof_tick(prof, 46, tprev);
     }
   }

@@ -30,6 +30,7 @@
     (void)lane;
 #define SMPC_LANES_END }
 #define SMPC_LANES_END_WAVE }
+#define SMPC_LAMBDA_INLINE
 #define SMPC_WAVE_SYNC() ((void)0) // (lockstep-only code has a per-lane form here)
 #define SMPC_TEST_CHECK(cond, msg)                                                                                     \
   do                                                                                                                   \
