@@ -376,7 +376,7 @@ def inverse_dynamics_line(batch, device_id, with_cpu=True):
     return out
 
 
-def inverse_dynamics_quad_line(batch, device_id):
+def inverse_dynamics_quad_line(batch, device_id, with_cpu=True):
     """KinodynamicsID of a biped with flat feet (tsid Contact6d: 12 corner forces per foot, 52 variables / 126 rows): the gains of the
     reference's contactQuad test, 100 ADMM iterations of fixed work per QP, states resident in HBM."""
     import numpy as np
@@ -400,8 +400,32 @@ def inverse_dynamics_quad_line(batch, device_id):
         kid.solve_device(Xd.data_ptr())
     kid.wait()
     dt = (time.perf_counter() - t0) / n
-    return {"metric": "whole-body inverse-dynamics QPs/sec, flat feet (KinodynamicsID with Contact6d: 52 variables, 126 rows, 100 ADMM iterations)",
-            "value": batch / dt, "unit": "QPs/s", "ms_per_call": dt * 1e3, "batch": batch, "dtype": "f64", "max_residual": float(kid.resid.max())}
+    out = {"metric": "whole-body inverse-dynamics QPs/sec, flat feet (KinodynamicsID with Contact6d: 52 variables, 126 rows, 100 ADMM iterations)",
+           "value": batch / dt, "unit": "QPs/s", "ms_per_call": dt * 1e3, "batch": batch, "dtype": "f64", "max_residual": float(kid.resid.max())}
+    # roofline of the dominant kernel (qp6_admm_body: per ADMM iteration one product with K^-1 (n x n) and two with the constraint matrix
+    # (m x n), n = 52 variables, m = 126 rows -> 2 (n^2 + 2 m n) FLOPs; x 100 iterations) over the whole call (three kernels; the ADMM kernel is
+    # > 90 % of it): FP64 side; HBM side = the assembled QP it reads once (K^-1 as built, C, bounds) + the solution
+    n_, m_, it_ = 52, 126, 100
+    fl = batch * it_ * 2.0 * (n_ * n_ + 2 * m_ * n_)
+    by = batch * 8.0 * (n_ * n_ + m_ * n_ + 3 * m_ + 2 * n_)
+    out["roofline"] = both_bounds(fl, by, dt, "mfma")
+    out["roofline"].update({"kernel": "id6_assemble_body + qp6_admm_body (whole solve_device call)",
+                            "note": "algorithmic FLOPs = B x 100 x 2 (n^2 + 2 m n), n = 52, m = 126 (matrix-vector products of an ADMM iteration)", "traffic": None})
+    if with_cpu:
+        S, O = _oracle_imports()
+        threads = O.use_effective_cpus()
+        rbc = O.Robot("talos_like")
+        Bc = 4 * threads
+        ok = O.OracleKinoID(rbc, O.talos_id_settings(rbc, 1e-3, admm_iters=100, admm_tol=-1.0, **st), Bc)
+        Xc = S.talos_random_states(rbc, Bc, scale=0.2)
+        ok.solve(Xc)
+        t0, nn = time.time(), 0
+        while time.time() - t0 < 3.0:
+            ok.solve(Xc)
+            nn += 1
+        out["cpu_baseline"] = {"value": Bc * nn / (time.time() - t0), "unit": "QPs/s", "cores": threads, "kind": "port",
+                               "sample": "CPU restatement (oracle/, not TSID / ProxQP): %d robots x %d ticks, same ADMM" % (Bc, nn)}
+    return out
 
 
 def single_robot_latency(iters, device_id, steps=50):
@@ -721,7 +745,7 @@ def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True, rob
     return out
 
 
-def talos_flat_feet_line(kind, batch, iters, steps, warmup, device_id):
+def talos_flat_feet_line(kind, batch, iters, steps, warmup, device_id, with_cpu=True):
     """The kinodynamics / centroidal OCPs of a Talos-class biped with 6-D feet (reference examples/talos_kinodynamics.py,
     talos_centroidal.py; H = 100, walk 20/80/20/80): the same control step as the other lines, brief."""
     import numpy as np
@@ -764,7 +788,7 @@ def talos_flat_feet_line(kind, batch, iters, steps, warmup, device_id):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kt = gm.kernel_times()
-    return {
+    out = {
         "metric": "MPC control-steps/sec at fixed ProxDDP iters, Talos %s (6-D feet) H=%d" % (kind.split("_")[1], gm.H),
         "value": batch * steps / dt, "unit": "control-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": "f64",
         "config": {"workload": "Talos %s OCP (talos_like table, two 6-D feet, wrench cones), H=%d, %d ProxDDP iters/step, batch=%d, walk 20/80/20/80"
@@ -772,6 +796,48 @@ def talos_flat_feet_line(kind, batch, iters, steps, warmup, device_id):
                    "finite": bool(np.all(np.isfinite(gm.info)))},
         "kernel_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if k != "-" and v[1]},
     }
+    # rooflines: the dense Riccati sweep on the FP64 side (F_ric of SURVEY 8d with the rows the sweep pivots explicitly: the 2 x 17 wrench-cone
+    # rows), the stage kernel on the HBM side (the knot it writes); the dominant one carries the line's `roofline`
+    H, ndx, nu, nc = gm.H, gm.ndx, gm.nu, gm.nc
+    ncd = 34
+    if kt.get("riccati", (0, 0))[1] and kt.get("deriv", (0, 0))[1]:
+        lq_bytes = 8 * (2 * ndx * ndx + 2 * ndx * nu + nu * nu + ncd * (ndx + nu) + 2 * ndx + nu + 2 * nc)
+        tag = "cent6" if cent else "taloskino"
+        at_record = batch == 1024 and iters == 3
+        ric = both_bounds(batch * H * f_ric(ndx, nu, ncd), batch * H * lq_bytes, kt["riccati"][0] / kt["riccati"][1] * 1e-3, "mfma")
+        tr, src = pmc_traffic("riccati_dense_body_" + tag, at_record)
+        ric.update({"kernel": "riccati_dense_body (dense proximal Riccati sweep, %d states / %d controls / %d explicit multiplier rows)" % (ndx, nu, ncd),
+                    "note": "algorithmic FLOPs = B*H*F_ric(%d,%d,%d) per launch (SURVEY 8d); stages without an active cone row run the light grid" % (ndx, nu, ncd),
+                    "traffic": tr, "traffic_source": src})
+        der = both_bounds(None, batch * H * lq_bytes, kt["deriv"][0] / kt["deriv"][1] * 1e-3, "hbm")
+        tr, src = pmc_traffic(("cent6_deriv_body" if cent else "fdyn_deriv_body_taloskino"), at_record)
+        der.update({"kernel": ("cent6_deriv_body" if cent else "fdyn_deriv_body<kinodynamics variant>") + " (stage evaluation, derivatives, Gauss-Newton knot)",
+                    "note": "HBM side: the dense knot the stage kernel writes (the oracle's FLOP count exists for the full-dynamics stage only)",
+                    "traffic": tr, "traffic_source": src})
+        dom_deriv = kt["deriv"][0] >= kt["riccati"][0]
+        out["roofline"] = der if dom_deriv else ric
+        out["roofline_other"] = {"riccati": ric} if dom_deriv else {"deriv": der}
+    if with_cpu:
+        S, O = _oracle_imports()
+        threads = O.use_effective_cpus()
+        Bc = max(threads, 8)
+        rbc = O.Robot("talos_like")
+        ms = O.talos_mpc_settings(rbc, max_iters=iters)
+        om = O.OracleCentMPC(O.Cent(rbc, O.talos_centroidal_settings(rbc)), ms, Bc) if cent else O.OracleMPC(O.Kino(rbc, O.talos_kino_settings(rbc)), ms, Bc)
+        om.generateCycleHorizon(O.walk_cycle())
+        om.switchToWalk(np.array([0.1, 0, 0, 0, 0, 0.0]))
+        Xc = S.talos_random_states(rbc, Bc, scale=0.7)
+        om.iterate(Xc)
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < 8.0 and n < 50:
+            om.iterate(Xc)
+            if not cent:
+                Xc = om.xs[:, 1, :].copy()
+            n += 1
+        out["cpu_baseline"] = {"value": Bc * n / (time.time() - t0), "unit": "control-steps/s", "cores": threads, "kind": "port",
+                               "sample": "CPU restatement (oracle/, not Aligator): %d instances x %d steps, k=%d" % (Bc, n, iters)}
+    return out
 
 
 def launch_ranks(args, argv):
@@ -1124,10 +1190,10 @@ def main():
             other["centroidal"] = centroidal_line(B, args.iters, 40, 5, local_rank, not args.no_cpu_baseline)
             other["fulldynamics_go2"] = fulldynamics_line(min(B, 4096), args.iters, 20, 3, local_rank, not args.no_cpu_baseline)
             other["fulldynamics_talos"] = fulldynamics_line(1024, args.iters, 10, 2, local_rank, not args.no_cpu_baseline, robot="talos")
-            other["talos_kinodynamics_6d"] = talos_flat_feet_line("talos_kinodynamics", 1024, args.iters, 8, 2, local_rank)
-            other["talos_centroidal_6d"] = talos_flat_feet_line("talos_centroidal", 1024, args.iters, 20, 3, local_rank)
+            other["talos_kinodynamics_6d"] = talos_flat_feet_line("talos_kinodynamics", 1024, args.iters, 8, 2, local_rank, not args.no_cpu_baseline)
+            other["talos_centroidal_6d"] = talos_flat_feet_line("talos_centroidal", 1024, args.iters, 20, 3, local_rank, not args.no_cpu_baseline)
             other["inverse_dynamics_qp"] = inverse_dynamics_line(B, local_rank, not args.no_cpu_baseline)
-            other["inverse_dynamics_qp_flat_feet"] = inverse_dynamics_quad_line(B, local_rank)
+            other["inverse_dynamics_qp_flat_feet"] = inverse_dynamics_quad_line(B, local_rank, not args.no_cpu_baseline)
             other["control_stack"] = control_stack_line(B, local_rank)
             other["control_stack_talos"] = control_stack_talos_line(1024, local_rank)
             other["single_robot_latency"] = single_robot_latency(args.iters, local_rank)

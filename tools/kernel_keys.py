@@ -10,7 +10,11 @@ KEYS = {
     "trial_rows_body": ("trial_rows_body", "", 4096 * 51 * 64),    # line search: rows of the candidate (block per problem)
     "deriv2_body": ("deriv2_body", "", 4096 * 51 * 64),            # SMPC_LANE_DERIV=1 only
     "apply_body": ("apply_body", "DimsILi13ELi4EEE", 4096 * 64),
-    "cent_step_body": ("cent_step_body", "", 4096 * 64),
+    "cent_step_body": ("cent_step_body", "", 4096 * 64),           # SMPC_CENT_FUSED=1 only (round 5: the pipeline below)
+    "cent_pre_body": ("cent_pre_body", "", 4096 * 64),
+    "cent_bwd_body": ("cent_bwd_body", "", 4096 * 64),
+    "cent_fwd_body": ("cent_fwd_body", "", 4096 * 64),
+    "cent_ls_body": ("cent_ls_", "", 4096 * 64),                   # cent_ls_poly_body (horizons <= 63) / cent_ls_body
     "fdyn_deriv_body_go2": ("fdyn_deriv_body", "FullDimsILi13E", 4096 * 51 * 64),
     "fdyn_trial_body_go2": ("fdyn_trial_body", "FullDimsILi13E", 4096 * 51 * 64),
     "riccati_dense_body_go2": ("riccati_dense_body", "FullDimsILi13E", 4096 * 64),
