@@ -180,10 +180,16 @@ namespace smpc
   {
     void * p = nullptr;
     SMPC_HIP(hipMalloc(&p, bytes ? bytes : 8));
-    SMPC_HIP(hipMemset(p, 0, bytes ? bytes : 8));
     // the engine's streams are non-blocking (no implicit ordering with the null stream the memset
     // runs on): make the zero-fill complete before any kernel can touch the buffer
-    SMPC_HIP(hipDeviceSynchronize());
+    hipError_t e = hipMemset(p, 0, bytes ? bytes : 8);
+    if (e == hipSuccess)
+      e = hipDeviceSynchronize();
+    if (e != hipSuccess)
+    {
+      (void)hipFree(p); // (a caller that handles the failure -- the hand-over fall-backs -- must not leak the block)
+      hip_check(e, "zero-fill of a fresh allocation", __FILE__, __LINE__);
+    }
     return p;
   }
   inline void dev_clear_error() { (void)hipGetLastError(); } // after a failed allocation that the caller handles

@@ -163,6 +163,8 @@ namespace smpc
         throw std::runtime_error("centroidal settings: weight sizes do not match the robot");
       if (ms.T < 2)
         throw std::runtime_error("horizon must have at least 2 stages");
+      if (DC::FS == 6 && ms.T + 1 > 256) // (before anything is allocated: a constructor that throws runs no destructor)
+        throw std::runtime_error("centroidal OCP with 6-D feet: at most 255 stages");
       device_id = device;
       set_device(device);
       stream = stream_create();
@@ -240,8 +242,6 @@ namespace smpc
         h2d(x6.sb.model, &hm, sizeof(hm), stream);
         stream_sync(stream);
         x6.parts0 = dalloc((size_t)B * (H + 1) * 4);
-        if (H + 1 > 256)
-          throw std::runtime_error("centroidal OCP with 6-D feet: at most 255 stages");
       }
       if constexpr (DC::FS == 3)
       {
@@ -404,7 +404,10 @@ namespace smpc
         timed_launch<CentSplitArgs<DC>, cent_pre_body<DC>, 64, 2>(CKID_DERIV, count, c, aux, on);
         if (it == 0 && after_first_pre)
           event_record(*after_first_pre, on ? *on : stream);
-        timed_launch<CentSplitArgs<DC>, cent_bwd_body<DC>, 64, 2>(CKID_RICCATI, count, c, aux, on);
+        if (buf.dbg != nullptr)
+          timed_launch<CentSplitArgs<DC>, cent_bwd_body<DC, true>, 64, 2>(CKID_RICCATI, count, c, aux, on);
+        else
+          timed_launch<CentSplitArgs<DC>, cent_bwd_body<DC, false>, 64, 2>(CKID_RICCATI, count, c, aux, on);
         timed_launch<CentSplitArgs<DC>, cent_fwd_body<DC>, 64, 4>(CKID_FORWARD, count, c, aux, on);
         // (line search: the polynomial form needs one lane per stage and the terminal node; longer horizons re-evaluate per candidate)
         if (H + 1 <= 64 && !ls_direct)

@@ -716,7 +716,7 @@ namespace smpc
   // Symmetric block sweep of smpc_riccati_kino.h (wave_block_sweep) with the pivot panels and the scheduling classes of the tiles given by
   // a plan: Plan::NP panels of 4 pivots starting at Plan::kb(p); Plan::cls(p, I, J) = 0 tile not maintained any more, 1 update before the
   // next panel's gather, 2 update deferred into the next panel's gather / inverse phases.
-  template <int NT, int NTI, bool ALL, class Plan, class Acc>
+  template <int NT, int NTI, bool ALL, class Plan, bool PROF = true, class Acc>
   SMPC_DEV void wave_block_sweep_plan(Acc & acc, double * prow, double * urow, double * prof, long long & tprev)
   {
     constexpr int LDW = 16 * NTI, NP = Plan::NP;
@@ -745,7 +745,8 @@ namespace smpc
         }
       }
       SMPC_LANES_END_WAVE
-      prof_tick(prof, 36, tprev);
+      if constexpr (PROF)
+        prof_tick(prof, 36, tprev);
       if (p > 0)
       {
         int cnt = 0;
@@ -795,7 +796,8 @@ namespace smpc
         }
       }
       SMPC_LANES_END_WAVE
-      prof_tick(prof, 37, tprev);
+      if constexpr (PROF)
+        prof_tick(prof, 37, tprev);
       if (p > 0)
       {
         int cnt = 0;
@@ -828,7 +830,8 @@ namespace smpc
         for (int J = I; J < NTI; J++)
           if (Plan::cls(p, I, J) == 1)
             SMPC_MFMA(acc, tix<NTI>(I, J), aop, ob + I, bop, ob + J);
-      prof_tick(prof, 38, tprev);
+      if constexpr (PROF)
+        prof_tick(prof, 38, tprev);
       // (d) pivot entries := U
       if (ALL)
       {
@@ -849,6 +852,7 @@ namespace smpc
           }
         }
         SMPC_LANES_END_WAVE
+        if constexpr (PROF)
         prof_tick(prof, 39, tprev);
       }
     }
@@ -886,7 +890,9 @@ namespace smpc
     }
   };
 
-  template <class D>
+  // PROF: in-kernel phase timers (SMPC_PHASE_PROFILE=1 handles launch this instantiation).  Without it the stage loop carries no timer branch:
+  // the sweep is bound by instruction issue, and the 25 scalar branches per stage the (disabled) timers cost are 2 % of it
+  template <class D, bool PROF = false>
   SMPC_DEV void cent_bwd_body(const CentSplitArgs<D> & sa, int block)
   {
     typedef CentRec<D> RC;
@@ -1002,8 +1008,9 @@ namespace smpc
         }
       }
       SMPC_LANES_END_WAVE
-      CENT_FINE_TICK(5);
-      wave_block_sweep_plan<NT, 2, false, CentPlan1>(m1, prow, urow, CENT_FINE_DBG, tprev);
+      if constexpr (PROF)
+        CENT_FINE_TICK(5);
+      wave_block_sweep_plan<NT, 2, false, CentPlan1, PROF>(m1, prow, urow, CENT_FINE_DBG, tprev);
       // ---- P~ (tile (1, 1)): out for the forward sweep; operand of the products.  p~ = p + P~ (f - mu p) ----
       SMPC_LANES(NT)
       {
@@ -1036,7 +1043,8 @@ namespace smpc
           SMPC_ACCV(m2, n / 4, n % 4) = stg[SMPC_PLV(off2)[n]];
       }
       SMPC_LANES_END_WAVE
-      CENT_FINE_TICK(7);
+      if constexpr (PROF)
+        CENT_FINE_TICK(7);
 #pragma unroll
       for (int sk = 0; sk < 3; sk++)
 #pragma unroll
@@ -1061,13 +1069,14 @@ namespace smpc
 #pragma unroll
           for (int J = I; J < 2; J++)
             SMPC_MFMA(m2, tix<2>(I, J), aop, sk * 2 + I, top, sk * 2 + J);
-      CENT_FINE_TICK(9);
+      if constexpr (PROF)
+        CENT_FINE_TICK(9);
       // ---- sweep 2: pivots u, then the multipliers of the active cone rows (quasi-definite KKT matrix: explicit pivots) ----
       const bool anyact = SMPC_UNIFORM_U32(stg[RC::O_ANY] != 0.0 ? 1u : 0u) != 0u;
       if (anyact)
-        wave_block_sweep_plan<NT, 2, true, CentPlan2<true>>(m2, prow, urow, CENT_FINE_DBG, tprev);
+        wave_block_sweep_plan<NT, 2, true, CentPlan2<true>, PROF>(m2, prow, urow, CENT_FINE_DBG, tprev);
       else
-        wave_block_sweep_plan<NT, 2, true, CentPlan2<false>>(m2, prow, urow, CENT_FINE_DBG, tprev);
+        wave_block_sweep_plan<NT, 2, true, CentPlan2<false>, PROF>(m2, prow, urow, CENT_FINE_DBG, tprev);
       // ---- gains out ; P_t, p_t stay in the accumulators ----
       SMPC_LANES(NT)
       {
@@ -1090,7 +1099,8 @@ namespace smpc
           SMPC_ACCV(Pa, 0, v) = SMPC_ACCV(m2, tix<2>(1, 1), v);
       }
       SMPC_LANES_END_WAVE
-      CENT_FINE_TICK(8);
+      if constexpr (PROF)
+        CENT_FINE_TICK(8);
     }
   }
 

@@ -518,8 +518,12 @@ namespace smpc
         buf.ev = try_alloc(tiles * buf.ev_tile);
         if (buf.ev == nullptr && buf.evd != nullptr)
         {
+          // stream allocated, heads-only tiles not: give the stream back and try the full-field tiles (the second level of the fall-back:
+          // stream -> tiles -> one-kernel stage evaluation)
           dev_free(buf.evd);
           buf.evd = nullptr;
+          buf.ev_tile = ev_tile_doubles<D>(false);
+          buf.ev = try_alloc(tiles * buf.ev_tile);
         }
         if (buf.evd != nullptr)
           buf.ev_order = (int *)dev_alloc((size_t)EvStream<D>::STRIDE * sizeof(int));

@@ -691,6 +691,8 @@ namespace smpc
         if (n != D::NU)
           throw std::runtime_error("u_ref not of the right size");
         std::copy(v, v + n, horizon[t].u_ref);
+        if constexpr (D::KINO) // getReferenceForce is a segment of the reference control (src/kinodynamics.cpp:258-265): keep the mirror in step
+          std::copy(v, v + D::NCM, horizon[t].f_ref);
       }
       else if (what == 1)
       {

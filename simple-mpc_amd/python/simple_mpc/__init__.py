@@ -844,8 +844,10 @@ class BatchedMPC:
         v = self._get("smpc_get_vs", (self.B, self.H, self.nc))
         st = getattr(self.ocp_handler, "settings", {})
         if isinstance(self.ocp_handler, KinodynamicsOCP) and not isinstance(self.ocp_handler, FullDynamicsOCP) and int(st.get("force_size", 3)) == 6:
-            # 6-D feet: the device keeps [control box (absent) | joint box | wrench-cone rows | frame-velocity rows] (smpc_full_model.h); returned in
-            # the order the stage adds them (src/kinodynamics.cpp:91-133): joint box | 6 velocity rows per foot | (force_cone) 17 cone rows per foot
+            # 6-D feet: the device keeps [control box (absent) | joint box | wrench-cone rows | frame-velocity rows] (smpc_full_model.h); returned as
+            # joint box | 6 velocity rows per foot (all feet) | (force_cone) 17 cone rows per foot (all feet) -- the order of THIS repository's
+            # oracle.  NOT the reference's constraint stack: src/kinodynamics.cpp:105-123 adds, foot by foot, the wrench cone and then the frame
+            # velocity (interleaved); a consumer comparing with Aligator's stack has to permute the per-foot blocks.
             nf = self.ocp_handler.model_handler.getFeetNb()
             na = self.nu - 6 * nf
             parts = [v[:, :, self.nu : self.nu + na], v[:, :, self.nu + na + 17 * nf :]]
