@@ -18,6 +18,9 @@
 //     accumulator layout of v_mfma_f64_16x16x4_f64 is the operand layout of the next product.
 #pragma once
 #include "smpc_solver_kernels.h"
+#ifndef SMPC_KINO_RCP1
+#define SMPC_KINO_RCP1 false // (experiment switch: one Newton step on the pivot reciprocals of the kinodynamics sweep)
+#endif
 
 namespace smpc
 {
@@ -86,7 +89,9 @@ namespace smpc
   }
 
   // SKIPPABLE: bit p of `skip` set = panel p is left out (its 4 pivots couple to nothing: the caller deals with their rows).
-  template <int NT, int NTI, bool ALL, int PIV0, int NP, bool SKIPPABLE = false, class Acc>
+  // RCP1: one Newton step on the pivot reciprocals instead of two (2e-15 instead of 1e-16 relative, tools/micro/rcp_accuracy.hip): two dependent
+  // FMAs less per pivot, 8 per panel
+  template <int NT, int NTI, bool ALL, int PIV0, int NP, bool SKIPPABLE = false, bool RCP1 = false, class Acc>
   SMPC_DEV void wave_block_sweep(Acc & acc, double * prow, double * urow, double * prof, long long & tprev, unsigned skip = 0u)
   {
     constexpr int LDW = 16 * NTI;
@@ -149,15 +154,16 @@ namespace smpc
         const double D00 = d[0], D01 = d[1], D02 = d[2], D03 = d[3];
         const double D11 = d[LDW + 1], D12 = d[LDW + 2], D13 = d[LDW + 3];
         const double D22 = d[2 * LDW + 2], D23 = d[2 * LDW + 3], D33 = d[3 * LDW + 3];
-        const double i0 = SMPC_RCP(D00);
+        auto rcp = [](double x) { return RCP1 ? SMPC_RCP1(x) : SMPC_RCP(x); };
+        const double i0 = rcp(D00);
         const double l10 = D01 * i0, l20 = D02 * i0, l30 = D03 * i0;
-        const double i1 = SMPC_RCP(D11 - l10 * D01);
+        const double i1 = rcp(D11 - l10 * D01);
         const double t21 = D12 - l20 * D01, t31 = D13 - l30 * D01;
         const double l21 = t21 * i1, l31 = t31 * i1;
-        const double i2 = SMPC_RCP(D22 - l20 * D02 - l21 * t21);
+        const double i2 = rcp(D22 - l20 * D02 - l21 * t21);
         const double t32 = D23 - l30 * D02 - l31 * t21;
         const double l32 = t32 * i2;
-        const double i3 = SMPC_RCP(D33 - l30 * D03 - l31 * t31 - l32 * t32);
+        const double i3 = rcp(D33 - l30 * D03 - l31 * t31 - l32 * t32);
         // columns at or beyond the pivot's tile row only when the tiles before it are not maintained (ALL = false)
         const int M0 = ALL ? 0 : 16 * Ip; // (a constant once the panel loop is unrolled)
 #pragma unroll
@@ -432,7 +438,7 @@ namespace smpc
         }
         SMPC_LANES_END_WAVE
         prof_tick(prof, 3, tprev);
-wave_block_sweep<NT, 5, false, 0, NDX / 4>(t1, sw1, sw1 + RiccatiKinoLds<D>::SWP, prof, tprev);
+wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 + RiccatiKinoLds<D>::SWP, prof, tprev);
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
@@ -823,7 +829,7 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4>(t1, sw1, sw1 + RiccatiKinoLds<D>::SWP
       //              [ S^^T            R^    r^            ]
       //          in place:  x-x block -> P_t,  x-vector -> p_t,  stored (x, u) entries -> R^^-1 S^^T = -K,
       //          (u, vector) entries -> R^^-1 r^ = -k ----
-      wave_block_sweep<NT, 4, true, NDX, NU / 4>(hacc, sw2, sw2 + 4 * 64, prof, tprev);
+      wave_block_sweep<NT, 4, true, NDX, NU / 4, false, SMPC_KINO_RCP1>(hacc, sw2, sw2 + 4 * 64, prof, tprev);
       prof_tick(prof, 10, tprev);
       SMPC_LANES(NT)
       {

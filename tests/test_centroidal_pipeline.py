@@ -1,0 +1,98 @@
+"""The kernel pipeline of the centroidal OCP (round 5, simple-mpc_amd/csrc/smpc_cent_split.h; reference path: MPC::iterate over a CentroidalOCP,
+src/mpc.cpp:189-218, src/centroidal-dynamics.cpp:39-106) against its own alternatives -- the forms the engine can be switched to:
+
+  SMPC_CENT_FUSED=1      the one-kernel control step of rounds 1 - 4 (cent_step_body) on the same buffers
+  SMPC_CENT_LS=direct    the line search that re-evaluates the stage merit per candidate instead of the polynomial form
+  SMPC_CENT_PARTS=n      the batch as n parts on n streams
+
+All of them must give the same trajectories (parity with the oracle is tests/test_centroidal_mpc.py).  CPU tier: the kernel bodies compiled with
+the sequential-lane test backend; the GPU tier repeats the comparisons on the device."""
+import os
+
+import numpy as np
+import pytest
+
+import mpc_setup as S
+import oracle_lib as O
+
+HARD = dict(settings_override=dict(mu=0.1))  # friction cones active, line searches backtrack
+
+
+def _run(lib, env, B, iters, steps, scale=1.0, walk=(0.2, 0, 0, 0, 0, 0), **kw):
+    old = {k: os.environ.get(k) for k in ("SMPC_CENT_FUSED", "SMPC_CENT_LS", "SMPC_CENT_PARTS")}
+    try:
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        gm, rb, _, _ = S.make_cent_product(B, iters, lib=lib, **kw)  # (the engine reads the switches when the handle is created)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    gm.generateCycleHorizon(O.trot_cycle())
+    gm.switchToWalk(np.array(walk, float))
+    X = S.random_states(rb, B, scale=scale)
+    out = []
+    for _ in range(steps):
+        gm.iterate(X)
+        out.append((gm.xs.copy(), gm.us.copy(), gm.vs.copy(), gm.lams.copy(), gm.K0.copy(), gm.info[:, 2].copy()))
+        X = np.stack([rb.integrate(X[b], np.r_[np.zeros(18), 0.02, 0.01, np.zeros(16)]) for b in range(B)])
+    return out
+
+
+def _agree(a, b, tol, alphas=True):
+    for (xa, ua, va, la, ka, aa), (xb, ub, vb, lb, kb, ab) in zip(a, b):
+        assert S.rel_err(xa, xb) < tol and S.rel_err(ua, ub) < 10 * tol and S.rel_err(la, lb) < 10 * tol and S.rel_err(va, vb) < 10 * tol
+        assert S.rel_err(ka, kb) < 10 * tol
+        if alphas:
+            assert np.array_equal(aa, ab), "line-search step sizes differ"
+
+
+@pytest.fixture(scope="module")
+def lib(built):
+    return S.emu_lib()
+
+
+def _cases(lib, tol):
+    # pipeline against the one-kernel form: plain closed loop, and the scenario with active cone rows and failing line searches
+    _agree(_run(lib, {}, 3, 3, 4), _run(lib, {"SMPC_CENT_FUSED": "1"}, 3, 3, 4), tol)
+    a = _run(lib, {}, 2, 2, 4, scale=2.0, walk=(0.8, 0.5, 0, 0, 0, 0.5), **HARD)
+    _agree(a, _run(lib, {"SMPC_CENT_FUSED": "1"}, 2, 2, 4, scale=2.0, walk=(0.8, 0.5, 0, 0, 0, 0.5), **HARD), tol)
+    assert any((s[5] < 1.0).any() for s in a) and any((s[2] != 0).any() for s in a), "the scenario must backtrack and activate cone rows"
+    # polynomial line search against the re-evaluating one (the same candidates must be accepted)
+    _agree(a, _run(lib, {"SMPC_CENT_LS": "direct"}, 2, 2, 4, scale=2.0, walk=(0.8, 0.5, 0, 0, 0, 0.5), **HARD), tol)
+
+
+def test_emu_pipeline_equals_its_alternatives(lib):
+    _cases(lib, 1e-9)
+
+
+def test_emu_parts_are_bit_identical(lib):
+    """Instances are independent: splitting the batch into parts changes nothing, bit for bit (130 instances: parts of 128 + 2)."""
+    a = _run(lib, {"SMPC_CENT_PARTS": "1"}, 130, 2, 2)
+    b = _run(lib, {"SMPC_CENT_PARTS": "2"}, 130, 2, 2)
+    for sa, sb in zip(a, b):
+        for u, v in zip(sa, sb):
+            assert np.array_equal(u, v)
+
+
+def test_emu_long_horizon_uses_the_reevaluating_line_search(lib):
+    """Horizons beyond 63 stages do not fit one lane per stage: the engine falls back to cent_ls_body; same answer as the one-kernel form."""
+    _agree(_run(lib, {}, 2, 2, 3, horizon=70), _run(lib, {"SMPC_CENT_FUSED": "1"}, 2, 2, 3, horizon=70), 1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ GPU tier
+@pytest.mark.gpu
+def test_hip_pipeline_equals_its_alternatives():
+    _cases(None, 1e-9)
+
+
+@pytest.mark.gpu
+def test_hip_parts_are_bit_identical():
+    a = _run(None, {"SMPC_CENT_PARTS": "1"}, 4096, 3, 2)
+    for n in ("2", "3"):
+        b = _run(None, {"SMPC_CENT_PARTS": n}, 4096, 3, 2)
+        for sa, sb in zip(a, b):
+            for u, v in zip(sa, sb):
+                assert np.array_equal(u, v)
