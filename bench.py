@@ -402,15 +402,18 @@ def inverse_dynamics_quad_line(batch, device_id, with_cpu=True):
     dt = (time.perf_counter() - t0) / n
     out = {"metric": "whole-body inverse-dynamics QPs/sec, flat feet (KinodynamicsID with Contact6d: 52 variables, 126 rows, 100 ADMM iterations)",
            "value": batch / dt, "unit": "QPs/s", "ms_per_call": dt * 1e3, "batch": batch, "dtype": "f64", "max_residual": float(kid.resid.max())}
-    # roofline of the dominant kernel (qp6_admm_body: per ADMM iteration one product with K^-1 (n x n) and two with the constraint matrix
-    # (m x n), n = 52 variables, m = 126 rows -> 2 (n^2 + 2 m n) FLOPs; x 100 iterations) over the whole call (three kernels; the ADMM kernel is
-    # > 90 % of it): FP64 side; HBM side = the assembled QP it reads once (K^-1 as built, C, bounds) + the solution
+    # roofline of the dominant kernel (qp6_admm_body) over the whole call (three kernels; the ADMM kernel is > 80 % of it).  FP64 side, counted on
+    # the STRUCTURE the kernel uses (round 5): per ADMM iteration one product with K^-1 (n x n, n = 52) and two with the constraint matrix, whose
+    # non-zeros are the 40 dense rows (dynamics 6, contact motion 12, actuation 22) x n, the 34 friction rows of Contact6d (32 pyramid rows of 2
+    # entries, 2 normal-force rows of 4) and the n box rows -> 2 (n^2 + 2 (40 n + 72 + n)) FLOPs; x 100 iterations.  (Counted dense over all 126
+    # rows, as rounds 3 - 4 did, the same work would read 2.2 x higher.)  HBM side = the assembled QP it reads once (H, C, bounds) + the solution
     n_, m_, it_ = 52, 126, 100
-    fl = batch * it_ * 2.0 * (n_ * n_ + 2 * m_ * n_)
+    fl = batch * it_ * 2.0 * (n_ * n_ + 2 * (40 * n_ + 72 + n_))
     by = batch * 8.0 * (n_ * n_ + m_ * n_ + 3 * m_ + 2 * n_)
     out["roofline"] = both_bounds(fl, by, dt, "mfma")
     out["roofline"].update({"kernel": "id6_assemble_body + qp6_admm_body (whole solve_device call)",
-                            "note": "algorithmic FLOPs = B x 100 x 2 (n^2 + 2 m n), n = 52, m = 126 (matrix-vector products of an ADMM iteration)", "traffic": None})
+                            "note": "algorithmic FLOPs = B x 100 x 2 (n^2 + 2 (40 n + 72 + n)), n = 52: K^-1 and the non-zeros of C (40 dense rows, "
+                                    "34 friction rows with 72 entries, n box rows) per ADMM iteration", "traffic": None})
     if with_cpu:
         S, O = _oracle_imports()
         threads = O.use_effective_cpus()

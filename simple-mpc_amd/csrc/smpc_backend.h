@@ -83,6 +83,8 @@
 #define SMPC_CLOCK() ((long long)__builtin_readcyclecounter())
 // a value that is the same in every lane, moved to a scalar register (branches on it are scalar branches)
 #define SMPC_UNIFORM_U32(x) ((unsigned)__builtin_amdgcn_readfirstlane((int)(x)))
+// the same for a double (two scalar registers): constants of a kernel that the compiler would otherwise keep -- and spill -- in vector registers
+#define SMPC_UNIFORM_F64(x) ::smpc::readlane_first_f64(x)
 // an int the compiler cannot see through: loads addressed with it stay after this point (the optimiser otherwise
 // hoists loads of read-only buffers across whole phases and then spills what it loaded)
 #define SMPC_PIN(x) ::smpc::pin_int(x)
@@ -139,6 +141,18 @@ namespace smpc
     u.d = v;
     u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
     u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+    return u.d;
+  }
+  __device__ __forceinline__ double readlane_first_f64(double v)
+  {
+    union
+    {
+      double d;
+      int i[2];
+    } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+    u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
     return u.d;
   }
   __device__ __forceinline__ double rcp_nr(double x)

@@ -1160,7 +1160,7 @@ extern "C"
       hs.quad_points.assign(c->quad_contact_points, c->quad_contact_points + (size_t)robot->nfeet * 12);
     }
     return guarded([&] {
-#ifdef SMPC_KINO_ONLY
+#if defined(SMPC_KINO_ONLY) && !defined(SMPC_WITH_ID) // (tools/variant_build.sh <name> -DSMPC_WITH_ID: the ID engines too)
       throw std::runtime_error("SMPC_KINO_ONLY experiment build");
 #endif
       if (!quad && robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF)

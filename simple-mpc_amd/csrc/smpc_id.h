@@ -1054,63 +1054,153 @@ namespace smpc
     SMPC_LANES_END_WAVE
   }
 
-  // ADMM of the flat-foot QP: the algorithm of qp_admm_body (and of the CPU checker's qp_admm) for any size -- the general rows of C and K^-1 stay
-  // in LDS (74 rows x 52 columns do not fit the one-row-per-lane register layout of the point-foot kernel), the vectors are exchanged through LDS;
-  // K = H + sigma I + C^T diag(r) C is assembled and inverted on the matrix cores.
+  // ADMM of the flat-foot QP (round 5): the algorithm of qp_admm_body (and of the CPU checker's qp_admm) in the same register layout -- one
+  // variable, one box row, one DENSE general row and one FRICTION row per lane, the matrix-vector products fed by v_readlane -- made to fit by
+  // what the rows are: of the 74 general rows only the 6 dynamics, 12 contact-motion and 22 actuation rows are dense (40 <= 64 lanes, 52
+  // entries each); the 34 friction rows of tsid::Contact6d are pyramids on single corner forces (+-f_t - mu f_n: two non-zeros) and the bound
+  // on a sole's total normal force (four non-zeros).  Their products, and their 12 x 12 blocks of C^T diag(r) C, are written out in closed form.
+  // LDS holds K (for the inverse on the matrix cores), the sweep operands and three small vectors: 31 KB instead of 79 KB -- five resident
+  // wavefronts per CU instead of two, and no LDS round trip inside a product (the first form kept C and K^-1 in LDS: 1.09 M QPs/s).
+  // The operands of C^T diag(r) C are read from the assembled QP in HBM / L2 (once per factorisation).
   template <class D>
   struct Qp6Lds
   {
     typedef IdDims<D> G;
-    double K[G::N * G::N]; // (N x N, not the padded NP x NP: with it 80 KB instead of 91 -- two resident waves per CU instead of one)
-    double C[G::GR * G::LDC];
+    double K[G::N * G::N];
     double swp[2 * 4 * 16 * ((2 * G::N + 15) / 16)];
-    double x[G::NP], g[G::NP], rhs[G::NP], xt[G::NP];
-    double z[G::MP], lam[G::MP], lo[G::MP], hi[G::MP], r[G::MP], w[G::MP], zt[G::MP];
+    double rd[64], wfl[64], xl[64]; // weights of the dense rows (operands of the gemm) ; friction-row vector / variable vector handed across lanes
     double red[256], red4[4];
   };
   template <class D>
   SMPC_DEV void qp6_admm_body(const IdBuffers<D> & b, int block)
   {
     typedef IdDims<D> G;
-    constexpr int NT = 64, NV = G::NV, NF = G::NF, NA = G::NA, N = G::N, NP = G::NP, MP = G::MP, M = G::M, LDC = G::LDC, GR = G::GR, NFV = G::NFV;
-    static_assert(NP == NT, "one variable per lane");
+    constexpr int NT = 64, NV = G::NV, NF = G::NF, NA = G::NA, N = G::N, NP = G::NP, MP = G::MP, M = G::M, NFV = G::NFV;
+    constexpr int DR = 6 + G::NM * NF + NA; // dense general rows: dynamics | contact motion | actuation
+    constexpr int FR = G::NFR * NF;        // friction rows
+    static_assert(NP == NT && DR <= NT && FR <= NT && G::NFR == 17 && NFV == 12, "one variable / dense row / friction row per lane; Contact6d rows");
     const int inst = block;
     const IdSettingsDev & st = b.s;
-    const double sigma = st.sigma, alpha = st.alpha;
+    const double sigma = st.sigma, alpha = st.alpha, fmu = st.friction_coefficient;
     SMPC_LDS(Qp6Lds<D>, ls, 1);
     Qp6Lds<D> & s = ls[0];
     const double * Hg = b.H + (size_t)inst * NP * NP;
-    const double * Cg = b.C + (size_t)inst * MP * NP + (size_t)N * NP;
+    const double * Cg = b.C + (size_t)inst * MP * NP + (size_t)N * NP; // general rows
+    const unsigned mask = b.tmask[inst];
     const bool warm = b.warm[inst] != 0;
     double rho = warm ? b.rho[inst] : st.rho;
+    // general row of dense row d / of friction row rr
+    auto drow = [](int d) { return d < 6 + G::NM * NF ? d : d + FR; };
+    SMPC_PL(double, x, NT);
+    SMPC_PL(double, g, NT);
+    SMPC_PL(double, rhs, NT);
+    SMPC_PL(double, xt, NT);
+    SMPC_PL(double, zb, NT);
+    SMPC_PL(double, lamb, NT);
+    SMPC_PL(double, lb, NT);
+    SMPC_PL(double, ub, NT);
+    SMPC_PL(double, rb, NT);
+    SMPC_PL(double, zd, NT);
+    SMPC_PL(double, lamd, NT);
+    SMPC_PL(double, ld, NT);
+    SMPC_PL(double, ud, NT);
+    SMPC_PL(double, rdv, NT);
+    SMPC_PL(double, wd, NT);
+    SMPC_PL(double, zf, NT);
+    SMPC_PL(double, lamf, NT);
+    SMPC_PL(double, lf, NT);
+    SMPC_PL(double, uf, NT);
+    SMPC_PL(double, rf, NT);
+    SMPC_PLA(double, Ccol, NT, DR);
+    SMPC_PLA(double, Crow, NT, N);
     SMPC_PLA(double, Krow, NT, N);
+    // ---- lane roles of the friction structure ----
+    //   variable lane i = NV + 12 f + 3 k + j (corner k, component j): its friction rows are 17 f + 4 k + {2 j, 2 j + 1} (j < 2) or
+    //   17 f + 4 k + {0..3} and 17 f + 16 (j == 2);  friction lane rr = 17 f + m: variables NV + 12 f + 3 (m / 4) + {(m % 4) / 2, 2} (m < 16)
+    // C^T w of the friction rows for variable lane `lane` (0 for the accelerations), w read from s.wfl
+    auto fric_t = [&](int lane) {
+      const int c = lane - NV;
+      if (c < 0 || c >= NFV * NF)
+        return 0.0;
+      const int f = c / NFV, k = (c % NFV) / 3, j = c % 3;
+      if (!((mask >> f) & 1u))
+        return 0.0;
+      const double * w = s.wfl + 17 * f;
+      if (j < 2)
+        return w[4 * k + 2 * j] - w[4 * k + 2 * j + 1];
+      return w[16] - fmu * (w[4 * k] + w[4 * k + 1] + w[4 * k + 2] + w[4 * k + 3]);
+    };
+    // C y of friction row `lane` (y read from s.xl)
+    auto fric_r = [&](int lane) {
+      if (lane >= FR)
+        return 0.0;
+      const int f = lane / 17, m = lane % 17;
+      if (!((mask >> f) & 1u))
+        return 0.0;
+      const double * y = s.xl + NV + NFV * f;
+      if (m == 16)
+        return y[2] + y[5] + y[8] + y[11];
+      const int k = m / 4, j = (m % 4) / 2;
+      return ((m % 2 == 0) ? y[3 * k + j] : -y[3 * k + j]) - fmu * y[3 * k + 2];
+    };
     SMPC_LANES(NT)
     {
-      for (int idx = lane; idx < GR * NP; idx += NT)
-        s.C[(idx / NP) * LDC + idx % NP] = Cg[idx];
-      s.g[lane] = b.g[(size_t)inst * NP + lane];
-      s.x[lane] = warm ? b.x[(size_t)inst * NP + lane] : 0.0;
-      for (int k = lane; k < MP; k += NT)
-      {
+      const int kb = lane < N ? lane : 0;
+      const int kd = N + drow(lane < DR ? lane : 0), kf = N + 6 + G::NM * NF + (lane < FR ? lane : 0);
+      SMPC_PLV(g) = b.g[(size_t)inst * NP + lane];
+      SMPC_PLV(x) = warm ? b.x[(size_t)inst * NP + lane] : 0.0;
+      SMPC_PLV(rhs) = SMPC_PLV(xt) = SMPC_PLV(wd) = 0.0;
+      auto row = [&](int k, double & lo_, double & hi_, double & z_, double & lam_) {
         const double lo = k < M ? b.l[(size_t)inst * MP + k] : -ID_INF, hi = k < M ? b.u[(size_t)inst * MP + k] : ID_INF;
-        s.lo[k] = lo;
-        s.hi[k] = hi;
-        s.z[k] = warm ? b.z[(size_t)inst * MP + k] : fmin(fmax(0.0, lo), hi);
-        s.lam[k] = warm ? b.lam[(size_t)inst * MP + k] : 0.0;
-      }
+        lo_ = lo;
+        hi_ = hi;
+        z_ = warm ? b.z[(size_t)inst * MP + k] : fmin(fmax(0.0, lo), hi);
+        lam_ = warm ? b.lam[(size_t)inst * MP + k] : 0.0;
+      };
+      row(kb, SMPC_PLV(lb), SMPC_PLV(ub), SMPC_PLV(zb), SMPC_PLV(lamb));
+      row(kd, SMPC_PLV(ld), SMPC_PLV(ud), SMPC_PLV(zd), SMPC_PLV(lamd));
+      row(kf, SMPC_PLV(lf), SMPC_PLV(uf), SMPC_PLV(zf), SMPC_PLV(lamf));
     }
     SMPC_LANES_END_WAVE
+    // row weights r = rho (1e3 rho on equality rows, 1e-6 rho on free rows) ; K = H + sigma I + C^T diag(r) C -> its inverse -> rows in registers
     auto factor = [&]() {
       SMPC_LANES(NT)
-      for (int k = lane; k < MP; k += NT)
       {
-        const double lo = s.lo[k], hi = s.hi[k];
-        s.r[k] = (hi - lo < 1e-12) ? 1e3 * rho : ((lo <= -ID_INF && hi >= ID_INF) ? 1e-6 * rho : rho);
+        auto weight = [&](double lo, double hi) { return (hi - lo < 1e-12) ? 1e3 * rho : ((lo <= -ID_INF && hi >= ID_INF) ? 1e-6 * rho : rho); };
+        SMPC_PLV(rb) = weight(SMPC_PLV(lb), SMPC_PLV(ub));
+        SMPC_PLV(rdv) = weight(SMPC_PLV(ld), SMPC_PLV(ud));
+        SMPC_PLV(rf) = weight(SMPC_PLV(lf), SMPC_PLV(uf));
+        s.rd[lane] = lane < DR ? SMPC_PLV(rdv) : 0.0;
+        s.wfl[lane] = lane < FR ? SMPC_PLV(rf) : 0.0;
+        s.xl[lane] = lane < N ? SMPC_PLV(rb) : 0.0;
       }
       SMPC_LANES_END_WAVE
-      fwave_gemm<N, N, GR>(
-        [&](int i, int k) { return s.r[N + k] * s.C[k * LDC + i]; }, [&](int k, int j) { return s.C[k * LDC + j]; },
-        [&](int i, int j, double v) { s.K[i * N + j] = (Hg[i * NP + j] + (i == j ? sigma + s.r[i] : 0.0)) + v; });
+      fwave_gemm<N, N, DR>(
+        [&](int i, int k) { return s.rd[k] * Cg[drow(k) * NP + i]; }, [&](int k, int j) { return Cg[drow(k) * NP + j]; },
+        [&](int i, int j, double v) {
+          double kk = Hg[i * NP + j] + (i == j ? sigma + s.xl[i] : 0.0);
+          // friction rows: 12 x 12 block per foot in contact
+          const int ci = i - NV, cj = j - NV;
+          if (ci >= 0 && cj >= 0 && ci / NFV == cj / NFV && ((mask >> (ci / NFV)) & 1u))
+          {
+            const int f = ci / NFV, ki = (ci % NFV) / 3, ji = ci % 3, kj = (cj % NFV) / 3, jj = cj % 3;
+            const double * r = s.wfl + 17 * f;
+            if (ki == kj)
+            {
+              const double * q = r + 4 * ki;
+              if (ji == jj)
+                kk += ji == 0 ? q[0] + q[1] : (ji == 1 ? q[2] + q[3] : fmu * fmu * (q[0] + q[1] + q[2] + q[3]) + r[16]);
+              else if (ji == 2 || jj == 2)
+              {
+                const int t = ji == 2 ? jj : ji; // the tangential component of the pair
+                kk -= fmu * (q[2 * t] - q[2 * t + 1]);
+              }
+            }
+            else if (ji == 2 && jj == 2)
+              kk += r[16];
+          }
+          s.K[i * N + j] = kk + v;
+        });
       fwave_spd_inverse<N>(s.K, s.swp);
       SMPC_LANES(NT)
       {
@@ -1118,6 +1208,15 @@ namespace smpc
 #pragma unroll
         for (int j = 0; j < N; j++)
           SMPC_PLV(Krow)[j] = s.K[j * N + ln]; // (K^-1 is symmetric: read along the row of j, conflict-free)
+        // rows and columns of the dense part of C straight from HBM / L2 into the registers they stay in -- (re)loaded AFTER the inverse, so that
+        // they are not live across it (the accumulators of the product and of the sweeps need the registers)
+        const int kd = drow(lane < DR ? lane : 0);
+#pragma unroll
+        for (int d = 0; d < DR; d++)
+          SMPC_PLV(Ccol)[d] = Cg[drow(d) * NP + ln];
+#pragma unroll
+        for (int ii = 0; ii < N; ii++)
+          SMPC_PLV(Crow)[ii] = Cg[kd * NP + ii];
       }
       SMPC_LANES_END_WAVE
     };
@@ -1125,26 +1224,48 @@ namespace smpc
     auto residual = [&]() {
       SMPC_LANES(NT)
       {
+        s.xl[lane] = lane < N ? SMPC_PLV(x) : 0.0;
+        s.wfl[lane] = lane < FR ? SMPC_PLV(lamf) : 0.0;
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      {
         double pr = 0.0, np = 0.0, du = 0.0, nd = 0.0;
-        for (int k = lane; k < GR; k += NT)
+        double cx = 0.0, hx = 0.0, cl = SMPC_PLV(lamb);
+#pragma unroll
+        for (int i = 0; i < N; i++)
         {
-          double cx = 0.0;
-          for (int i = 0; i < N; i++)
-            cx += s.C[k * LDC + i] * s.x[i];
-          pr = fmax(pr, fabs(cx - s.z[N + k]));
-          np = fmax(np, fmax(fabs(cx), fabs(s.z[N + k])));
+          cx += SMPC_PLV(Crow)[i] * SMPC_XLANE(x, i);
+          if (i % 8 == 7)
+            SMPC_SCHED_FENCE();
+        }
+        for (int j = 0; j < N; j++)
+          hx += Hg[j * NP + lane] * SMPC_XLANE(x, j); // (H is symmetric: coalesced along the row of j)
+#pragma unroll
+        for (int k = 0; k < DR; k++)
+        {
+          cl += SMPC_PLV(Ccol)[k] * SMPC_XLANE(lamd, k);
+          if (k % 8 == 7)
+            SMPC_SCHED_FENCE();
+        }
+        cl += fric_t(lane);
+        const double cf = fric_r(lane);
+        if (lane < DR)
+        {
+          pr = fabs(cx - SMPC_PLV(zd));
+          np = fmax(fabs(cx), fabs(SMPC_PLV(zd)));
+        }
+        if (lane < FR)
+        {
+          pr = fmax(pr, fabs(cf - SMPC_PLV(zf)));
+          np = fmax(np, fmax(fabs(cf), fabs(SMPC_PLV(zf))));
         }
         if (lane < N)
-        {
-          double hx = 0.0, cl = s.lam[lane];
-          for (int j = 0; j < N; j++)
-            hx += Hg[j * NP + lane] * s.x[j];
-          for (int k = 0; k < GR; k++)
-            cl += s.C[k * LDC + lane] * s.lam[N + k];
-          pr = fmax(pr, fabs(s.x[lane] - s.z[lane]));
-          np = fmax(np, fmax(fabs(s.x[lane]), fabs(s.z[lane])));
-          du = fabs((s.g[lane] + hx) + cl);
-          nd = fmax(fabs(hx), fmax(fabs(cl), fabs(s.g[lane])));
+        { // box rows: C x = x
+          pr = fmax(pr, fabs(SMPC_PLV(x) - SMPC_PLV(zb)));
+          np = fmax(np, fmax(fabs(SMPC_PLV(x)), fabs(SMPC_PLV(zb))));
+          du = fabs((SMPC_PLV(g) + hx) + cl);
+          nd = fmax(fabs(hx), fmax(fabs(cl), fabs(SMPC_PLV(g))));
         }
         s.red[lane] = pr;
         s.red[64 + lane] = du;
@@ -1155,7 +1276,7 @@ namespace smpc
       SMPC_LANES(NT)
       if (lane < 4)
       {
-        double m = 0.0;
+        double m = 0.0; // (a NaN entry must survive the reduction)
         for (int i = 0; i < NT; i++)
         {
           const double v = s.red[64 * lane + i];
@@ -1187,19 +1308,24 @@ namespace smpc
         }
       }
       SMPC_LANES(NT)
-      for (int k = lane; k < M; k += NT)
-        s.w[k] = s.r[k] * s.z[k] - s.lam[k];
+      {
+        SMPC_PLV(wd) = SMPC_PLV(rdv) * SMPC_PLV(zd) - SMPC_PLV(lamd);
+        s.wfl[lane] = lane < FR ? SMPC_PLV(rf) * SMPC_PLV(zf) - SMPC_PLV(lamf) : 0.0;
+      }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
-      { // rhs = sigma x - g + C^T (r z - lam): the box rows contribute their own entry
-        double acc = sigma * s.x[lane] - s.g[lane];
-        if (lane < N)
+      { // rhs = sigma x - g + C^T (r z - lam): the box rows contribute their own entry, the friction rows their closed form
+        double acc = sigma * SMPC_PLV(x) - SMPC_PLV(g);
+        acc += lane < N ? SMPC_PLV(rb) * SMPC_PLV(zb) - SMPC_PLV(lamb) : 0.0;
+#pragma unroll
+        for (int k = 0; k < DR; k++)
         {
-          acc += s.w[lane];
-          for (int k = 0; k < GR; k++)
-            acc += s.C[k * LDC + lane] * s.w[N + k];
+          acc += SMPC_PLV(Ccol)[k] * SMPC_XLANE(wd, k);
+          if (k % 8 == 7)
+            SMPC_SCHED_FENCE();
         }
-        s.rhs[lane] = acc;
+        acc += fric_t(lane);
+        SMPC_PLV(rhs) = lane < N ? acc : 0.0;
       }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
@@ -1207,33 +1333,36 @@ namespace smpc
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < N; j++)
-          acc += SMPC_PLV(Krow)[j] * s.rhs[j];
-        s.xt[lane] = lane < N ? acc : 0.0;
+        {
+          acc += SMPC_PLV(Krow)[j] * SMPC_XLANE(rhs, j);
+          if (j % 8 == 7)
+            SMPC_SCHED_FENCE();
+        }
+        SMPC_PLV(xt) = lane < N ? acc : 0.0;
+        s.xl[lane] = SMPC_PLV(xt);
       }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
       {
-        for (int k = lane; k < GR; k += NT)
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; i++)
         {
-          double acc = 0.0;
-          for (int i = 0; i < N; i++)
-            acc += s.C[k * LDC + i] * s.xt[i];
-          s.zt[N + k] = acc;
+          acc += SMPC_PLV(Crow)[i] * SMPC_XLANE(xt, i);
+          if (i % 8 == 7)
+            SMPC_SCHED_FENCE();
         }
-        if (lane < N)
-          s.zt[lane] = s.xt[lane];
-      }
-      SMPC_LANES_END_WAVE
-      SMPC_LANES(NT)
-      {
-        for (int k = lane; k < M; k += NT)
-        {
-          const double zh = alpha * s.zt[k] + (1.0 - alpha) * s.z[k];
-          const double zn = fmin(fmax(zh + s.lam[k] / s.r[k], s.lo[k]), s.hi[k]);
-          s.lam[k] += s.r[k] * (zh - zn);
-          s.z[k] = zn;
-        }
-        s.x[lane] = alpha * s.xt[lane] + (1.0 - alpha) * s.x[lane];
+        const double ztd = acc, ztf = fric_r(lane);
+        auto upd = [&](double zt, double & z, double & lam, double r, double lo, double hi) {
+          const double zh = alpha * zt + (1.0 - alpha) * z;
+          const double zn = fmin(fmax(zh + lam / r, lo), hi);
+          lam += r * (zh - zn);
+          z = zn;
+        };
+        upd(SMPC_PLV(xt), SMPC_PLV(zb), SMPC_PLV(lamb), SMPC_PLV(rb), SMPC_PLV(lb), SMPC_PLV(ub)); // box rows: z~ = x~
+        upd(ztd, SMPC_PLV(zd), SMPC_PLV(lamd), SMPC_PLV(rdv), SMPC_PLV(ld), SMPC_PLV(ud));
+        upd(ztf, SMPC_PLV(zf), SMPC_PLV(lamf), SMPC_PLV(rf), SMPC_PLV(lf), SMPC_PLV(uf));
+        SMPC_PLV(x) = alpha * SMPC_PLV(xt) + (1.0 - alpha) * SMPC_PLV(x);
       }
       SMPC_LANES_END_WAVE
     }
@@ -1241,26 +1370,39 @@ namespace smpc
       residual();
     const double res = (rs[0] != rs[0] || rs[1] != rs[1]) ? rs[0] + rs[1] : fmax(rs[0], rs[1]);
     SMPC_LANES(NT)
+    s.xl[lane] = SMPC_PLV(x);
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
     {
       const bool ok = res == res && res < 1e300;
       if (ok)
       {
-        b.x[(size_t)inst * NP + lane] = s.x[lane];
-        for (int k = lane; k < M; k += NT)
+        b.x[(size_t)inst * NP + lane] = SMPC_PLV(x);
+        if (lane < N)
         {
-          b.z[(size_t)inst * MP + k] = s.z[k];
-          b.lam[(size_t)inst * MP + k] = s.lam[k];
+          b.z[(size_t)inst * MP + lane] = SMPC_PLV(zb);
+          b.lam[(size_t)inst * MP + lane] = SMPC_PLV(lamb);
+        }
+        if (lane < DR)
+        {
+          b.z[(size_t)inst * MP + N + drow(lane)] = SMPC_PLV(zd);
+          b.lam[(size_t)inst * MP + N + drow(lane)] = SMPC_PLV(lamd);
+        }
+        if (lane < FR)
+        {
+          b.z[(size_t)inst * MP + N + 6 + G::NM * NF + lane] = SMPC_PLV(zf);
+          b.lam[(size_t)inst * MP + N + 6 + G::NM * NF + lane] = SMPC_PLV(lamf);
         }
       }
       for (int i = lane; i < NV; i += NT)
-        b.a[(size_t)inst * NV + i] = s.x[i];
+        b.a[(size_t)inst * NV + i] = s.xl[i];
       // contact wrenches T f (foot frames) -> red[0 .. 6 NF)
       if (lane < 6 * NF)
       {
         const int f = lane / 6, r = lane % 6;
         double acc = 0.0;
         for (int c = 0; c < NFV; c++)
-          acc += id6_tgen(b.quad, f, r, c) * s.x[NV + NFV * f + c];
+          acc += id6_tgen(b.quad, f, r, c) * s.xl[NV + NFV * f + c];
         s.red[lane] = acc;
         b.f[(size_t)inst * 6 * NF + lane] = acc;
       }
@@ -1274,7 +1416,7 @@ namespace smpc
         const double * J = b.J + (size_t)inst * 6 * NF * NV;
         double acc = b.nle[(size_t)inst * NV + 6 + lane];
         for (int k = 0; k < NV; k++)
-          acc += Mq[(6 + lane) * NV + k] * s.x[k];
+          acc += Mq[(6 + lane) * NV + k] * s.xl[k];
         for (int r = 0; r < 6 * NF; r++)
           acc -= J[r * NV + 6 + lane] * s.red[r];
         b.tau[(size_t)inst * NA + lane] = acc;

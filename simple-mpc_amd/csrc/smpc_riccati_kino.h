@@ -340,7 +340,8 @@ namespace smpc
     const Buffers<D> & b = ka.b;
     const int H = b.H;
     const int inst = block;
-    const double mu = b.model->mu, imu = 1.0 / mu, dt = b.model->dt, smu = sqrt(mu);
+    // (kernel constants in scalar registers: as vector registers three of them were spilled in the prologue and reloaded in every stage)
+    const double mu = SMPC_UNIFORM_F64(b.model->mu), imu = SMPC_UNIFORM_F64(1.0 / mu), dt = SMPC_UNIFORM_F64(b.model->dt), smu = SMPC_UNIFORM_F64(sqrt(mu));
     SMPC_LDS(RiccatiKinoLds<D>, lds, 1);
     RiccatiKinoLds<D> & s = lds[0];
     double * NAB = s.scr;                      // [NG][NXU]  dense rows of [A | B]           phase 4

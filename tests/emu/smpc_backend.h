@@ -52,6 +52,7 @@
 #define SMPC_MFMA(acc, t, av, ia, bv, ib) ::smpc::emu_mfma_f64_16x16x4(acc, t, av, ia, bv, ib)
 #define SMPC_CLOCK() (0LL)
 #define SMPC_UNIFORM_U32(x) ((unsigned)(x))
+#define SMPC_UNIFORM_F64(x) (x)
 #define SMPC_PIN(x) (x)
 #define SMPC_TOUCH(gptr, lds_sink) ((void)(gptr), (void)(lds_sink))
 #define SMPC_RSQRT(x) (1.0 / std::sqrt(x))
