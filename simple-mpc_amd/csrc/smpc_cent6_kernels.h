@@ -10,7 +10,8 @@
 //                                         pivot panels are 4 wide; the pad rows are zero and decoupled)
 //   riccati_dense_body  B blocks          backward sweep, wrench-cone multipliers pivoted explicitly
 //   cent6_forward_body  B blocks          (dx, du, dnu, dlam) and the directional derivative of the merit
-//   cent6_ls_body       B blocks          Armijo backtracking (lane = stage trial evaluations), step, regularisation update
+//   cent6_trial_body    B (H + 1) blocks  stage merit at line-search candidates (the full step; then alpha = 1/2, 1/4, .. where it failed)
+//   cent6_ls_body       B blocks          Armijo test over the candidates' merits, step, regularisation update
 // Algorithm and constants: those of cent_step_body (smpc_cent_kernels.h), i.e. of the solver stack in DESIGN.md section 2.
 #pragma once
 #include "smpc_cent_kernels.h"
@@ -85,7 +86,10 @@ namespace smpc
     CentBuffers<D> b;
     Buffers<typename D::DD> sb; // what the dense sweep reads: lq, gains, QN, qN, model (mu), dbg
     double *parts0 = nullptr;   // [B][H+1][4] phi, cost, prim, dual at the current point
+    double *partsT = nullptr;   // [B][LS_N][H+1][2] phi, prim of every line-search candidate (cent6_trial_body)
+    double *xdotT = nullptr;    // [B][LS_N][2][9] state derivative of stages 0, 1 at every candidate
     int head;
+    int j0 = 0, nj = 0;         // line search: candidate range of the launch
     int shift, set_centres, reset_preg;
     const double * X;
     int nx_mb;
@@ -719,208 +723,384 @@ namespace smpc
     SMPC_LANES_END_WAVE
   }
 
-  // merit terms of stage t at the trial point w + alpha dw (cost, penalty, primal infeasibility; xdot optionally)
+  // ---------------------------------------------------------------------------------------------------------------
+  // line search (round 5), in two kinds of launches around the host-free decision:
+  //   cent6_trial_body (grid B (H + 1))  candidates j0 .. j0 + nj - 1 of one stage per wavefront: the stage inputs are read once (coalesced, into
+  //                                      LDS); lane = one term of the stage merit (a wrench-cone row, a dynamics row, a row of the control cost,
+  //                                      one of the five 3 x 3 quadratic costs); lane j then adds the terms of candidate j in a fixed order.
+  //                                      Writes partsT[inst][j][t] = (phi, prim) and, for stages 0 and 1, the state derivative at the candidate.
+  //   cent6_ls_body (grid B)             adds the stage terms of its candidates in a fixed order, Armijo test, step, regularisation update.
+  // The engine launches trial(0, 1), ls(0, 1), trial(1, LS_N - 1), ls(1, LS_N - 1): an instance whose full step passes the Armijo test is
+  // finished by the first pair (its blocks of the second pair exit at once); the backtracking candidates alpha = 1/2, 1/4, .. are evaluated for
+  // the others only, all at once.  SC_LS_INDEX < 0 marks an instance as undecided between the pairs.
+  // (The first form -- lane = stage, one candidate after the other inside cent6_ls_body -- ran 101 stage evaluations of per-lane strided loads on
+  // one wavefront per instance: 0.72 ms of the 2.8 ms iteration at B = 1024.)
+  // ---------------------------------------------------------------------------------------------------------------
   template <class D>
-  SMPC_DEV void cent6_stage_merit(const CentDevModel<D> & md, const CentBuffers<D> & b, size_t inst, int head, int t, double al, double & cost, double & pen,
-                                  double & prim, double * xdot)
+  struct Cent6TrialLds
   {
-    constexpr int NU = D::NU, NC = D::NC, NF = D::NF;
-    const int H = b.H, R = b.R;
+    static constexpr int NU = D::NU, NC = D::NC, NF = D::NF, LS_N = D::LS_N;
+    static constexpr int NTERM = NC + 9 + NU + 5; // lanes with a term
+    double x[9], dx[9], xn[9], dxn[9], l1[9], dl[9], l1e[9], xt[9];
+    double u[NU], du[NU], uref[NU], v[NC], dv[NC], ve[NC], pp[3 * NF];
+    double val[LS_N][NTERM], prm[LS_N][NC + 9];
+  };
+  template <class D>
+  SMPC_DEV void cent6_trial_body(const Cent6Args<D> & ka, int block)
+  {
+    constexpr int NT = 64, NU = D::NU, NC = D::NC, NF = D::NF, LS_N = D::LS_N;
+    constexpr int L_DYN = NC, L_CU = NC + 9, L_Q = NC + 9 + NU, L_END = L_Q + 5;
+    static_assert(L_END <= NT && LS_N <= NT, "one term of the stage merit per lane");
+    const CentBuffers<D> & b = ka.b;
+    const int H = b.H, R = b.R, head = ka.head, j0 = ka.j0, j1 = ka.j0 + ka.nj;
+    const size_t inst = (size_t)(block / (H + 1));
+    const int t = block % (H + 1);
+    if (j0 > 0 && b.scal[inst * SC_N + SC_LS_INDEX] >= 0.0)
+      return; // decided by an earlier candidate
+    const bool term = t == H;
     const size_t ib = inst * R;
-    const int st = ring_slot(head, t, R), st1 = ring_slot(head, t + 1, R);
-    const double * x = b.xs + (ib + st) * 9, *xn = b.xs + (ib + st1) * 9, *dx = b.dxs + (inst * (H + 1) + t) * 9, *dxn = dx + 9;
-    const double * u = b.us + (ib + st) * NU, *du = b.dus + (inst * H + t) * NU;
-    const double * v = b.vs + (ib + st) * NC, *dv = b.dvs + (inst * H + t) * NC, *ve = b.vs_e + (ib + st) * NC;
-    const double * l1 = b.lams + (ib + st) * 9, *dl = b.dlams + (inst * H + t) * 9, *l1e = b.lams_e + (ib + st) * 9;
-    const double * pp = b.foot + (inst * H + t) * (3 * NF);
-    const double * uref = b.stages[t].u_ref;
-    const unsigned mask = b.stages[t].mask;
-    const double mu = md.mu, imu = 1.0 / mu, imass = 1.0 / md.mass;
-    auto X = [&](int i) { return x[i] + al * dx[i]; };
-    auto U = [&](int i) { return u[i] + al * du[i]; };
-    const Cent6Point<D> q = cent6_point<D>(mask, pp, X, U);
-    const V3 g = ld3(md.gravity);
-    pen = 0.0;
-    prim = 0.0;
-    for (int row = 0; row < NC; row++)
+    SMPC_LDS(Cent6TrialLds<D>, ldsv, 1);
+    Cent6TrialLds<D> & s = ldsv[0];
+    const int st = ring_slot(head, t, R), st1 = ring_slot(head, term ? t : t + 1, R);
+    const unsigned mask = term ? 0u : b.stages[t].mask;
+    SMPC_LANES(NT)
     {
-      const int f = row / 17, r = row % 17;
-      double vp = 0.0;
-      if ((mask >> f) & 1u)
+      if (lane < 9)
       {
-        double cv = 0.0;
-        for (int j = 0; j < 6; j++)
-          cv += wrench_cone_entry(r, j, md.mu_fric, md.Lfoot, md.Wfoot) * U(6 * f + j);
-        const double z = cv + mu * ve[row];
-        vp = (z - fmin(z, 0.0)) * imu;
-        prim = fmax(prim, fmax(cv, 0.0));
+        s.x[lane] = b.xs[(ib + st) * 9 + lane];
+        s.dx[lane] = b.dxs[(inst * (H + 1) + t) * 9 + lane];
+        s.xn[lane] = b.xs[(ib + st1) * 9 + lane];
+        s.dxn[lane] = term ? 0.0 : b.dxs[(inst * (H + 1) + t + 1) * 9 + lane];
+        s.l1[lane] = term ? 0.0 : b.lams[(ib + st) * 9 + lane];
+        s.dl[lane] = term ? 0.0 : b.dlams[(inst * H + t) * 9 + lane];
+        s.l1e[lane] = term ? 0.0 : b.lams_e[(ib + st) * 9 + lane];
+        s.xt[lane] = term ? 0.0 : (lane < 3 ? b.stages[t].x_tgt[lane] : b.vref[(ib + st) * 6 + lane - 3]);
       }
-      const double d = vp - (v[row] + al * dv[row]);
-      pen += 0.5 * mu * (vp * vp + d * d);
+      if (!term)
+      {
+        for (int i = lane; i < NU; i += NT)
+        {
+          s.u[i] = b.us[(ib + st) * NU + i];
+          s.du[i] = b.dus[(inst * H + t) * NU + i];
+          s.uref[i] = b.stages[t].u_ref[i];
+        }
+        for (int i = lane; i < NC; i += NT)
+        {
+          s.v[i] = b.vs[(ib + st) * NC + i];
+          s.dv[i] = b.dvs[(inst * H + t) * NC + i];
+          s.ve[i] = b.vs_e[(ib + st) * NC + i];
+        }
+        for (int i = lane; i < 3 * NF; i += NT)
+          s.pp[i] = b.foot[(inst * H + t) * (3 * NF) + i];
+      }
     }
-    double xd[9];
-    for (int k = 0; k < 3; k++)
+    SMPC_LANES_END_WAVE
+    const CentDevModel<D> & md = *b.model; // (the same 1.6 KB for every block: read where it lies, through the scalar / L1 caches)
+    double * out = ka.partsT + (inst * LS_N * (H + 1) + t) * 2; // candidate j: + j (H + 1) 2
+    auto alpha_of = [](int j) {
+      double al = 1.0;
+      for (int k = 0; k < j; k++)
+        al *= 0.5;
+      return al;
+    };
+    if (term)
+    { // terminal node: momentum cost at x_H + alpha dx_H
+      SMPC_LANES(NT)
+      if (lane >= j0 && lane < j1)
+      {
+        const double al = alpha_of(lane);
+        const V3 h = mk3(s.x[3] + al * s.dx[3], s.x[4] + al * s.dx[4], s.x[5] + al * s.dx[5]);
+        const V3 L = mk3(s.x[6] + al * s.dx[6], s.x[7] + al * s.dx[7], s.x[8] + al * s.dx[8]);
+        out[(size_t)lane * (H + 1) * 2] = 0.5 * dot(h, ldm3(md.w_lm) * h) + 0.5 * dot(L, ldm3(md.w_am) * L);
+        out[(size_t)lane * (H + 1) * 2 + 1] = 0.0;
+      }
+      SMPC_LANES_END_WAVE
+      return;
+    }
+    const double mu = md.mu, imu = 1.0 / mu, imass = 1.0 / md.mass;
+    SMPC_LANES(NT)
     {
-      xd[k] = X(3 + k) * imass;
-      xd[3 + k] = md.mass * v3c(g, k) + v3c(q.fs, k);
-      xd[6 + k] = v3c(q.ts, k);
+      const V3 g = ld3(md.gravity);
+      // Every term is a function of alpha through a few polynomials (the point moves along a line; the only product of two moving quantities
+      // is (p - c) x f in the angular-momentum rate): their coefficients once, Horner per candidate.
+      //   cone row:      A_cone (u + alpha du) = c0 + alpha c1 ; multiplier v + alpha dv = e0 + alpha e1
+      //   control cost:  row i of W (u + alpha du - u_ref) = c0 + alpha c1 ; (u + alpha du - u_ref)_i = e0 + alpha e1
+      //   dynamics row:  defect e = c0 + alpha c1 + alpha^2 c2 ; multiplier l1 + alpha dl = e0 + alpha e1 ; xdot = r0.x + alpha r1.x + alpha^2 r2.x
+      //   3 x 3 costs:   residual r0 + alpha r1 + alpha^2 r2
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0, e0 = 0.0, e1 = 0.0;
+      V3 r0 = mk3(0, 0, 0), r1 = r0, r2 = r0;
+      bool on = false;
+      // sums over the feet in contact: force fs0 + alpha fs1, torque about the CoM ts0 + alpha ts1 + alpha^2 ts2
+      auto contact_sums = [&](V3 & fs0, V3 & fs1, V3 & ts0, V3 & ts1, V3 & ts2) {
+        fs0 = fs1 = ts0 = ts1 = ts2 = mk3(0, 0, 0);
+        const V3 cc0 = ld3(s.x), cc1 = ld3(s.dx);
+#pragma unroll
+        for (int f = 0; f < NF; f++)
+          if ((mask >> f) & 1u)
+          {
+            const V3 F0 = ld3(s.u + 6 * f), F1 = ld3(s.du + 6 * f), p = ld3(s.pp + 3 * f) - cc0;
+            fs0 = fs0 + F0;
+            fs1 = fs1 + F1;
+            ts0 = ts0 + cross(p, F0) + ld3(s.u + 6 * f + 3);
+            ts1 = ts1 + cross(p, F1) - cross(cc1, F0) + ld3(s.du + 6 * f + 3);
+            ts2 = ts2 - cross(cc1, F1);
+          }
+      };
+      if (lane < L_DYN)
+      {
+        const int row = lane, f = row / 17, r = row % 17;
+        on = (mask >> f) & 1u;
+        if (on)
+          for (int k = 0; k < 6; k++)
+          {
+            const double a = wrench_cone_entry(r, k, md.mu_fric, md.Lfoot, md.Wfoot);
+            c0 += a * s.u[6 * f + k];
+            c1 += a * s.du[6 * f + k];
+          }
+        e0 = s.v[row];
+        e1 = s.dv[row];
+      }
+      else if (lane < L_CU)
+      {
+        const int i = lane - L_DYN;
+        V3 fs0, fs1, ts0, ts1, ts2;
+        contact_sums(fs0, fs1, ts0, ts1, ts2);
+        // xdot_i = r0.x + alpha r1.x + alpha^2 r2.x
+        if (i < 3)
+          r0 = mk3(s.x[3 + i] * imass, 0, 0), r1 = mk3(s.dx[3 + i] * imass, 0, 0);
+        else if (i < 6)
+          r0 = mk3(md.mass * v3c(g, i - 3) + v3c(fs0, i - 3), 0, 0), r1 = mk3(v3c(fs1, i - 3), 0, 0);
+        else
+          r0 = mk3(v3c(ts0, i - 6), 0, 0), r1 = mk3(v3c(ts1, i - 6), 0, 0), r2 = mk3(v3c(ts2, i - 6), 0, 0);
+        c0 = s.x[i] + md.dt * r0.x - s.xn[i];
+        c1 = s.dx[i] + md.dt * r1.x - s.dxn[i];
+        c2 = md.dt * r2.x;
+        e0 = s.l1[i];
+        e1 = s.dl[i];
+      }
+      else if (lane < L_Q)
+      {
+        const int i = lane - L_CU;
+        for (int k = 0; k < NU; k++)
+        {
+          c0 += md.w_u[i * NU + k] * (s.u[k] - s.uref[k]);
+          c1 += md.w_u[i * NU + k] * s.du[k];
+        }
+        e0 = s.u[i] - s.uref[i];
+        e1 = s.du[i];
+      }
+      else if (lane < L_END)
+      {
+        const int k = lane - L_Q;
+        if (k < 3)
+          r0 = ld3(s.x + 3 * k) - ld3(s.xt + 3 * k), r1 = ld3(s.dx + 3 * k);
+        else
+        {
+          V3 fs0, fs1, ts0, ts1, ts2;
+          contact_sums(fs0, fs1, ts0, ts1, ts2);
+          if (k == 3)
+            r0 = g + imass * fs0, r1 = imass * fs1;
+          else
+            r0 = ts0, r1 = ts1, r2 = ts2;
+        }
+      }
+      const double * Wq = lane == L_Q ? md.w_com : (lane == L_Q + 1 ? md.w_lm : (lane == L_Q + 2 ? md.w_am : (lane == L_Q + 3 ? md.w_la : md.w_aa)));
+      const M3 Wm = (lane >= L_Q && lane < L_END) ? ldm3(Wq) : M3{};
+      const double vel = lane < L_DYN ? s.ve[lane] : 0.0, l1e = (lane >= L_DYN && lane < L_CU) ? s.l1e[lane - L_DYN] : 0.0;
+      for (int j = j0; j < j1; j++)
+      {
+        const double al = alpha_of(j);
+        double val = 0.0, prm = 0.0;
+        if (lane < L_DYN)
+        { // penalty of the multiplier estimate of a cone row
+          double vp = 0.0;
+          if (on)
+          {
+            const double cv = c0 + al * c1;
+            const double z = cv + mu * vel;
+            vp = (z - fmin(z, 0.0)) * imu;
+            prm = fmax(cv, 0.0);
+          }
+          const double d = vp - (e0 + al * e1);
+          val = 0.5 * mu * (vp * vp + d * d);
+        }
+        else if (lane < L_CU)
+        { // dynamics row: defect e_i and its multiplier estimate
+          const double e = c0 + al * (c1 + al * c2);
+          const double lp = l1e + e * imu, dd = lp - (e0 + al * e1);
+          val = 0.5 * mu * (lp * lp + dd * dd);
+          prm = fabs(e);
+          if (t < 2)
+            ka.xdotT[((inst * LS_N + j) * 2 + t) * 9 + lane - L_DYN] = r0.x + al * (r1.x + al * r2.x);
+        }
+        else if (lane < L_Q)
+          val = (e0 + al * e1) * (c0 + al * c1);
+        else if (lane < L_END)
+        {
+          const V3 r = r0 + al * (r1 + al * r2);
+          val = 0.5 * dot(r, Wm * r);
+        }
+        if (lane < L_END)
+          s.val[j][lane] = val;
+        if (lane < L_CU)
+          s.prm[j][lane] = prm;
+      }
     }
-    for (int i = 0; i < 9; i++)
-    {
-      const double e = X(i) + md.dt * xd[i] - (xn[i] + al * dxn[i]);
-      const double lp = l1e[i] + e * imu, dd = lp - (l1[i] + al * dl[i]);
-      pen += 0.5 * mu * (lp * lp + dd * dd);
-      prim = fmax(prim, fabs(e));
-      if (xdot)
-        xdot[i] = xd[i];
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane >= j0 && lane < j1)
+    { // candidate `lane`: penalty terms row by row, then the costs
+      const double * vj = s.val[lane], *pj = s.prm[lane];
+      double pen = 0.0, prim = 0.0, cu = 0.0;
+      for (int i = 0; i < L_CU; i++)
+      {
+        pen += vj[i];
+        prim = fmax(prim, pj[i]);
+      }
+      for (int i = L_CU; i < L_Q; i++)
+        cu += vj[i];
+      double cost = vj[L_Q];
+      cost += 0.5 * cu;
+      cost += vj[L_Q + 1];
+      cost += vj[L_Q + 2];
+      cost += vj[L_Q + 3];
+      cost += vj[L_Q + 4];
+      out[(size_t)lane * (H + 1) * 2] = cost + pen;
+      out[(size_t)lane * (H + 1) * 2 + 1] = prim;
     }
-    auto quad3 = [](const double * W, V3 r) { return 0.5 * dot(r, ldm3(W) * r); };
-    const V3 c = mk3(X(0), X(1), X(2)), h = mk3(X(3), X(4), X(5)), L = mk3(X(6), X(7), X(8));
-    const double * href = b.vref + (ib + st) * 6;
-    cost = quad3(md.w_com, c - ld3(b.stages[t].x_tgt));
-    double cu = 0.0;
-    for (int i = 0; i < NU; i++)
-    {
-      double wr = 0.0;
-      for (int j = 0; j < NU; j++)
-        wr += md.w_u[i * NU + j] * (U(j) - uref[j]);
-      cu += (U(i) - uref[i]) * wr;
-    }
-    cost += 0.5 * cu;
-    cost += quad3(md.w_lm, h - ld3(href));
-    cost += quad3(md.w_am, L - ld3(href + 3));
-    cost += quad3(md.w_la, g + imass * q.fs);
-    cost += quad3(md.w_aa, q.ts);
+    SMPC_LANES_END_WAVE
   }
 
-  // ---------------------------------------------------------------------------------------------------------------
-  // line search + step: one wavefront per instance; lane = stage trial evaluations, fixed-order reductions; Armijo backtracking
-  // alpha = 1, 1/2, .. (the last candidate is taken on failure), regularisation update, x <- x + alpha dx, ...
-  // ---------------------------------------------------------------------------------------------------------------
   template <class D>
   SMPC_DEV void cent6_ls_body(const Cent6Args<D> & ka, int block)
   {
-    constexpr int NT = 64, NU = D::NU, NC = D::NC;
+    constexpr int NT = 64, NU = D::NU, NC = D::NC, LS_N = D::LS_N;
     const CentBuffers<D> & b = ka.b;
-    const int H = b.H, R = b.R, head = ka.head;
+    const int H = b.H, R = b.R, head = ka.head, j0 = ka.j0, j1 = ka.j0 + ka.nj;
     const size_t inst = (size_t)block, ib = inst * R;
-    constexpr int MAXS = 256;
-    SMPC_LDS(double, sphi, MAXS);
-    SMPC_LDS(double, sprim, MAXS);
+    SMPC_LDS(double, sp, LS_N * NT * 2); // per candidate: (phi, prim) summed over the stages lane, lane + 64, ..
+    SMPC_LDS(double, sp0, NT * 4);       // phi, cost, prim, dual at the current point, the same partial sums
+    SMPC_LDS(double, cand, 2 * LS_N);
     SMPC_LDS(double, res, 8);
-    SMPC_LDS(CentDevModel<D>, mds, 1);
     double * sc = b.scal + inst * SC_N;
+    if (j0 > 0 && sc[SC_LS_INDEX] >= 0.0)
+      return; // decided by an earlier candidate
+    // merits: stage terms added in a fixed order -- lane L adds its stages L, L + 64, .., then one lane per candidate adds the 64 partial sums
     SMPC_LANES(NT)
     {
-      constexpr int N = (int)(sizeof(CentDevModel<D>) / sizeof(double));
-      const alias_double * src = reinterpret_cast<const alias_double *>(b.model);
-      alias_double * dst = reinterpret_cast<alias_double *>(&mds[0]);
-      for (int i = lane; i < N; i += NT)
-        dst[i] = src[i];
-      if (lane == 0)
+      for (int j = j0; j < j1; j++)
       {
-        double phi = 0.0, cost = 0.0, prim = 0.0, dual = 0.0;
-        for (int t = 0; t <= H; t++)
+        const double * src = ka.partsT + (inst * LS_N + j) * (H + 1) * 2;
+        double phi = 0.0, prim = 0.0;
+        for (int t = lane; t <= H; t += NT)
         {
-          const double * p = ka.parts0 + (inst * (H + 1) + t) * 4;
-          phi += p[0];
-          cost += p[1];
-          prim = fmax(prim, p[2]);
-          dual = fmax(dual, p[3]);
+          phi += src[2 * t];
+          prim = fmax(prim, src[2 * t + 1]);
         }
-        sc[SC_PHI0] = phi;
-        sc[SC_COST] = cost;
-        sc[SC_PRIM] = prim;
-        sc[SC_DUAL] = dual;
-        res[0] = phi;
+        sp[(j * NT + lane) * 2] = phi;
+        sp[(j * NT + lane) * 2 + 1] = prim;
+      }
+      if (j0 == 0)
+      {
+        const double * src0 = ka.parts0 + inst * (H + 1) * 4;
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        for (int t = lane; t <= H; t += NT)
+        {
+          p0 += src0[4 * t];
+          p1 += src0[4 * t + 1];
+          p2 = fmax(p2, src0[4 * t + 2]);
+          p3 = fmax(p3, src0[4 * t + 3]);
+        }
+        sp0[lane * 4] = p0;
+        sp0[lane * 4 + 1] = p1;
+        sp0[lane * 4 + 2] = p2;
+        sp0[lane * 4 + 3] = p3;
       }
     }
     SMPC_LANES_END_WAVE
-    const CentDevModel<D> & md = mds[0];
-    const double phi0 = res[0], dphi0 = sc[SC_DPHI0];
-    double alpha = 1.0;
-    int sel = -1;
-    for (int j = 0; j < D::LS_N; j++)
+    SMPC_LANES(NT)
     {
-      SMPC_LANES(NT)
-      for (int t = lane; t <= H; t += NT)
-      {
-        double cost, pen = 0.0, prim = 0.0;
-        if (t < H)
-          cent6_stage_merit<D>(md, b, inst, head, t, alpha, cost, pen, prim, (double *)nullptr);
-        else
-        { // terminal node: momentum cost at x_H + alpha dx_H
-          const double * xH = b.xs + (ib + ring_slot(head, H, R)) * 9, *dxH = b.dxs + (inst * (H + 1) + H) * 9;
-          const V3 h = mk3(xH[3] + alpha * dxH[3], xH[4] + alpha * dxH[4], xH[5] + alpha * dxH[5]);
-          const V3 L = mk3(xH[6] + alpha * dxH[6], xH[7] + alpha * dxH[7], xH[8] + alpha * dxH[8]);
-          cost = 0.5 * dot(h, ldm3(md.w_lm) * h) + 0.5 * dot(L, ldm3(md.w_am) * L);
-        }
-        sphi[t] = cost + pen;
-        sprim[t] = prim;
-      }
-      SMPC_LANES_END_WAVE
-      SMPC_LANES(NT)
-      if (lane == 0)
+      if (lane >= j0 && lane < j1)
       {
         double phi = 0.0, prim = 0.0;
-        for (int t = 0; t <= H; t++)
+        for (int l = 0; l < NT; l++)
         {
-          phi += sphi[t];
-          prim = fmax(prim, sprim[t]);
+          phi += sp[(lane * NT + l) * 2];
+          prim = fmax(prim, sp[(lane * NT + l) * 2 + 1]);
         }
-        res[1] = phi;
-        res[2] = prim;
+        cand[2 * lane] = phi;
+        cand[2 * lane + 1] = prim;
       }
-      SMPC_LANES_END_WAVE
-      const bool ok = res[1] <= phi0 + ka.armijo_c1 * alpha * dphi0;
-      if (ok || j == D::LS_N - 1)
+      if (lane == 32)
       {
-        sel = j;
-        SMPC_LANES(NT)
-        if (lane == 0)
+        if (j0 == 0)
+        {
+          double phi = 0.0, cost = 0.0, prim = 0.0, dual = 0.0;
+          for (int l = 0; l < NT; l++)
+          {
+            const double * p = sp0 + l * 4;
+            phi += p[0];
+            cost += p[1];
+            prim = fmax(prim, p[2]);
+            dual = fmax(dual, p[3]);
+          }
+          sc[SC_PHI0] = phi;
+          sc[SC_COST] = cost;
+          sc[SC_PRIM] = prim;
+          sc[SC_DUAL] = dual;
+          res[0] = phi;
+        }
+        else
+          res[0] = sc[SC_PHI0];
+      }
+    }
+    SMPC_LANES_END_WAVE
+    SMPC_LANES(NT)
+    if (lane == 0)
+    {
+      const double phi0 = res[0], dphi0 = sc[SC_DPHI0];
+      res[2] = -1.0;
+      for (int j = j0; j < j1; j++)
+      {
+        double alpha = 1.0;
+        for (int k = 0; k < j; k++)
+          alpha *= 0.5;
+        const bool ok = cand[2 * j] <= phi0 + ka.armijo_c1 * alpha * dphi0;
+        if (ok || j == LS_N - 1)
         {
           sc[SC_LS_FAILED] = ok ? 0.0 : 1.0;
           sc[SC_ALPHA] = alpha;
-          sc[SC_PHI_NEW] = res[1];
-          sc[SC_PRIM_NEW] = res[2];
-          sc[SC_LS_INDEX] = (double)j;
+          sc[SC_PHI_NEW] = cand[2 * j];
+          sc[SC_PRIM_NEW] = cand[2 * j + 1];
           const double preg = sc[SC_PREG];
           sc[SC_PREG] = ok ? fmax(preg * ka.reg_dec, ka.reg_min) : fmin(preg * ka.reg_inc, ka.reg_max);
+          res[1] = alpha;
+          res[2] = (double)j;
+          break;
         }
-        SMPC_LANES_END_WAVE
-        break;
       }
-      alpha *= 0.5;
-    }
-    (void)sel;
-    // ---- state derivative of stages 0, 1 at the accepted point (MPC::getStateDerivative), then the step ----
-    SMPC_LANES(NT)
-    if (lane < 2)
-    {
-      double cost, pen, prim, xd[9];
-      cent6_stage_merit<D>(md, b, inst, head, lane, alpha, cost, pen, prim, xd);
-      for (int i = 0; i < 9; i++)
-        b.xdot01[(inst * 2 + lane) * 9 + i] = xd[i];
+      sc[SC_LS_INDEX] = res[2]; // (-1: undecided, the launch of the next candidates takes over)
     }
     SMPC_LANES_END_WAVE
+    if (res[2] < 0.0)
+      return;
+    const double alpha = res[1];
+    const int sel = (int)res[2];
+    // ---- state derivative of stages 0, 1 at the accepted point (MPC::getStateDerivative), then the step (coalesced over the horizon) ----
     SMPC_LANES(NT)
-    for (int t = lane; t <= H; t += NT)
     {
-      const size_t sl = ib + ring_slot(head, t, R);
-      for (int i = 0; i < 9; i++)
-        b.xs[sl * 9 + i] += alpha * b.dxs[(inst * (H + 1) + t) * 9 + i];
-      if (t < H)
-      {
-        for (int i = 0; i < NU; i++)
-          b.us[sl * NU + i] += alpha * b.dus[(inst * H + t) * NU + i];
-        for (int i = 0; i < NC; i++)
-          b.vs[sl * NC + i] += alpha * b.dvs[(inst * H + t) * NC + i];
-        for (int i = 0; i < 9; i++)
-          b.lams[sl * 9 + i] += alpha * b.dlams[(inst * H + t) * 9 + i];
-      }
+      if (lane < 18)
+        b.xdot01[inst * 18 + lane] = ka.xdotT[(inst * LS_N + sel) * 18 + lane];
+      for (int idx = lane; idx < (H + 1) * 9; idx += NT)
+        b.xs[(ib + ring_slot(head, idx / 9, R)) * 9 + idx % 9] += alpha * b.dxs[inst * (H + 1) * 9 + idx];
+      for (int idx = lane; idx < H * NU; idx += NT)
+        b.us[(ib + ring_slot(head, idx / NU, R)) * NU + idx % NU] += alpha * b.dus[inst * H * NU + idx];
+      for (int idx = lane; idx < H * NC; idx += NT)
+        b.vs[(ib + ring_slot(head, idx / NC, R)) * NC + idx % NC] += alpha * b.dvs[inst * H * NC + idx];
+      for (int idx = lane; idx < H * 9; idx += NT)
+        b.lams[(ib + ring_slot(head, idx / 9, R)) * 9 + idx % 9] += alpha * b.dlams[inst * H * 9 + idx];
     }
     SMPC_LANES_END_WAVE
-    static_assert(MAXS >= 201, "stages per instance");
   }
 
   // (frontend_full_body: smpc_full_stage.h)

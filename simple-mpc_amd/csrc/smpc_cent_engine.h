@@ -36,6 +36,7 @@ namespace smpc
     CKID_RICCATI, //   backward sweep
     CKID_FORWARD, //   forward sweep
     CKID_LS,      //   line search + step
+    CKID_TRIAL,   //   6-D feet: stage merits of the line-search candidates (cent6_trial_body)
     CKID_N
   };
 
@@ -58,7 +59,7 @@ namespace smpc
   struct Cent6Extra<DC, 6>
   {
     Buffers<typename DC::DD> sb;
-    double * parts0 = nullptr;
+    double *parts0 = nullptr, *partsT = nullptr, *xdotT = nullptr; // (Cent6Args, smpc_cent6_kernels.h)
   };
 
   // what the C ABI needs from a centroidal engine of any robot shape / foot type
@@ -131,6 +132,7 @@ namespace smpc
     // parts fill each other's idle units.  Part p > 0 starts one kernel late (it waits for part p - 1's first pre-pass), so that the parts do
     // not march in step.
     int nparts = 1;
+    int ls_passes = 1;      // 6-D feet: SMPC_CENT6_LS_PASSES=2 evaluates the full step first, the backtracking candidates where it failed
     bool ls_direct = false; // SMPC_CENT_LS=direct: the per-candidate re-evaluation (cent_ls_body) also for horizons the polynomial form covers
     std::vector<stream_t> part_stream; // [nparts - 1] (part 0 runs on `stream`)
     std::vector<event_t> part_event;   // [nparts - 1] completion of a part, [nparts] stagger events
@@ -242,6 +244,9 @@ namespace smpc
         h2d(x6.sb.model, &hm, sizeof(hm), stream);
         stream_sync(stream);
         x6.parts0 = dalloc((size_t)B * (H + 1) * 4);
+        x6.partsT = dalloc((size_t)B * DC::LS_N * (H + 1) * 2);
+        x6.xdotT = dalloc((size_t)B * DC::LS_N * 18);
+        ls_passes = (std::getenv("SMPC_CENT6_LS_PASSES") && std::getenv("SMPC_CENT6_LS_PASSES")[0] == '2' && DC::LS_N > 1) ? 2 : 1;
       }
       if constexpr (DC::FS == 3)
       {
@@ -309,7 +314,7 @@ namespace smpc
       }
       if constexpr (DC::FS == 6)
       {
-        for (double * p : {x6.sb.lq, x6.sb.QN, x6.sb.qN, x6.parts0})
+        for (double * p : {x6.sb.lq, x6.sb.QN, x6.sb.qN, x6.parts0, x6.partsT, x6.xdotT})
           dev_free(p);
         dev_free(x6.sb.model);
       }
@@ -425,6 +430,8 @@ namespace smpc
         c.b = buf;
         c.sb = x6.sb;
         c.parts0 = x6.parts0;
+        c.partsT = x6.partsT;
+        c.xdotT = x6.xdotT;
         c.head = a.head;
         c.shift = a.shift;
         c.set_centres = a.set_centres;
@@ -462,7 +469,16 @@ namespace smpc
           timed_launch<Cent6Args<DC>, cent6_deriv_body<DC>, 64>(CKID_DERIV, B * (H + 1), c, aux);
           timed_launch<SolverArgs<DD>, riccati_dense_body<DD>, 64, 2>(CKID_RICCATI, B, sa, aux);
           timed_launch<Cent6Args<DC>, cent6_forward_body<DC>, 64>(CKID_FORWARD, B, c, aux);
-          timed_launch<Cent6Args<DC>, cent6_ls_body<DC>, 64>(CKID_LS, B, c, aux);
+          // line search: every candidate in one pair of launches -- a launch of B (H + 1) one-wave blocks costs 0.3 ms whatever it evaluates (measured:
+          // the full step alone 0.30 ms, the nine backtracking candidates 0.32 ms), so the split `full step first, the rest where it failed'
+          // (SMPC_CENT6_LS_PASSES=2; the kernels take any candidate range) only pays when no instance backtracks
+          for (int pass = 0; pass < ls_passes; pass++)
+          {
+            c.j0 = pass;
+            c.nj = ls_passes == 1 ? DC::LS_N : (pass == 0 ? 1 : DC::LS_N - 1);
+            timed_launch<Cent6Args<DC>, cent6_trial_body<DC>, 64>(CKID_TRIAL, B * (H + 1), c, aux);
+            timed_launch<Cent6Args<DC>, cent6_ls_body<DC>, 64>(CKID_LS, B, c, aux);
+          }
         }
       }
       else if (fused)

@@ -15,6 +15,9 @@
 #ifndef SMPC_LANE_MINW
 #define SMPC_LANE_MINW 1
 #endif
+#ifndef SMPC_DERIV2_MINW
+#define SMPC_DERIV2_MINW 2 // waves per SIMD the register allocation of deriv2_body is capped for (3: measured refusal)
+#endif
 #include "smpc_riccati_kino.h"
 #include "smpc_kino_deriv2.h"
 #include "smpc_solver_kernels.h"
@@ -754,9 +757,9 @@ namespace smpc
         else
           timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid_tree, gtree, la, slots > 0);
         if (b.evd != nullptr)
-          timed_launch<StageKernelArgs<D>, deriv2_body<D, true>, 64, 2>(kid, xcd_grid(n, H), stage_args(b, slots), slots > 0);
+          timed_launch<StageKernelArgs<D>, deriv2_body<D, true>, 64, SMPC_DERIV2_MINW>(kid, xcd_grid(n, H), stage_args(b, slots), slots > 0);
         else
-          timed_launch<StageKernelArgs<D>, deriv2_body<D, false>, 64, 2>(kid, xcd_grid(n, H), stage_args(b, slots), slots > 0);
+          timed_launch<StageKernelArgs<D>, deriv2_body<D, false>, 64, SMPC_DERIV2_MINW>(kid, xcd_grid(n, H), stage_args(b, slots), slots > 0);
       }
       else if (has_ext(b))
         timed_launch<StageKernelArgs<D>, deriv_body<D, true>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);

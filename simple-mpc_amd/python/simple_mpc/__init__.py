@@ -512,7 +512,7 @@ class CentroidalOCP(_StageReferences):
 
     def _kernel_names(self):
         if int(self.settings.get("force_size", 3)) == 6:  # (6-D feet: smpc_cent6_kernels.h)
-            return ["frontend", "recede", "deriv", "riccati", "forward", "line_search", "-6", "-7", "-8"]
+            return ["frontend", "recede", "deriv", "riccati", "forward", "line_search", "trial", "-7", "-8"]
         # point feet (smpc_cent_split.h): recede | pre-pass | backward | forward | line search; with SMPC_CENT_FUSED=1 "step" is the one-kernel
         # control step and the others are never launched
         return ["frontend", "step", "pre", "backward", "forward", "line_search", "-6", "-7", "-8"]

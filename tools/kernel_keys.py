@@ -32,6 +32,7 @@ KEYS = {
     "cent6_deriv_body": ("cent6_deriv_body", "", 1024 * 101 * 64),
     "riccati_dense_body_cent6": ("riccati_dense_body", "Cent6DimsILi2E", 1024 * 64),
     "cent6_forward_body": ("cent6_forward_body", "", 1024 * 64),
+    "cent6_trial_body": ("cent6_trial_body", "", 1024 * 101 * 64),  # round 5: stage merits of all line-search candidates
     "cent6_ls_body": ("cent6_ls_body", "", 1024 * 64),
     "id_quant_body": ("id_quant_body", "", 4096 * 64),
     "id_assemble_body": ("id_assemble_body", "", 4096 * 64),
