@@ -220,7 +220,6 @@ namespace smpc
       }
     return q;
   }
-  SMPC_HD double v3c(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 
   // ---------------------------------------------------------------------------------------------------------------
   // derivative pass: one wavefront per (instance, stage); t == H is the terminal node (linear + angular momentum cost,

@@ -77,6 +77,7 @@ namespace smpc
   {
   public:
     Buffers<D> buf;
+    double * deriv_wide = nullptr; // D::WIDE_DEV: R1 / JT slices of the derivative kernel's blocks (FullDerivWide, smpc_full_stage.h)
     HostMpcSettings ms;
     std::vector<StageShared<D>> horizon, cycle;
     StageShared<D> standing;
@@ -236,6 +237,8 @@ namespace smpc
       buf.stages = (StageShared<D> *)dev_alloc((size_t)H * sizeof(StageShared<D>));
       buf.model = (DevModel<D> *)dev_alloc(sizeof(DevModel<D>));
       X_dev = dalloc((size_t)B * D::NX);
+      if constexpr (D::WIDE_DEV)
+        deriv_wide = (double *)dev_alloc((size_t)B * (H + 1) * sizeof(FullDerivWide<D>)); // (largest grid of fdyn_deriv_body)
       if (fs.terminal_constraint)
         alloc_terminal_constraint<D>(buf, x_model_ref.data(), host_com_height(m, x_model_ref.data()), stream);
       if (std::getenv("SMPC_PHASE_PROFILE"))
@@ -264,7 +267,7 @@ namespace smpc
         dev_free(p);
       for (double * p : {buf.xs_b, buf.us_b, buf.vs_b, buf.lams_b, buf.xs, buf.us, buf.vs, buf.lams, buf.vs_e, buf.lams_e, buf.dxs, buf.dus, buf.dvs, buf.dlams, buf.foot_ref,
                          buf.ftraj, buf.vbase, buf.vref, buf.lq, buf.gains, buf.QN, buf.qN, buf.parts0, buf.partsT, buf.scal, buf.xdotT, buf.xdot01, buf.forces,
-                         buf.forcesT, X_dev, stage_out})
+                         buf.forcesT, X_dev, stage_out, deriv_wide})
         dev_free(p);
       dev_free(buf.ls_sel);
       dev_free(buf.und_list);
@@ -337,6 +340,7 @@ namespace smpc
       sk.j0 = 0;
       sk.nj = 0;
       sk.slots = slots;
+      sk.wide = deriv_wide;
       return sk;
     }
     void launch_deriv(const Buffers<D> & b, int slots = 0)

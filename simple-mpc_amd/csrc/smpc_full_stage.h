@@ -76,17 +76,21 @@ namespace smpc
     int iters_[2];
     SMPC_HD double * swp_() { return xnext; } // (size checked where the inverses are called)
   };
+  // The two widest derivative blocks of a stage -- R1 (NV x NCOL) and the force rows JT (NCM x NCOL) of the Gauss-Newton Jacobian.  They are
+  // operands / results of the column-wise solve chain.  Where D::WIDE_DEV says so they live in a per-block slice of DEVICE MEMORY instead of LDS
+  // (round 5): LDS, not registers, decides the occupancy of this kernel (one wavefront per block), and for the biped these 24.4 KB are the
+  // difference between two and three resident blocks per CU.  A block writes and re-reads its slice within its lifetime (L2 of its XCD); the
+  // accesses are kept latency-tolerant: operand fetches of the matrix-core products run one K-step ahead, read-modify-write passes are
+  // products that START from the old value (fwave_gemm's `init`), columns are read into registers before anything is stored.
   template <class D>
-  struct FullScratchDeriv
+  struct FullDerivWide
   {
-    static constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX;
-    static constexpr int NCOL = 2 * NV + NU, NGN = 6 + D::PF * NF + NCM;
-    double Bc[NJ * 36], dk[NV * 6], Ak[NV * 6], Wc[NF * 6];
+    static constexpr int NV = D::NV, NCM = D::NCM, NU = D::NU;
+    static constexpr int NCOL = 2 * NV + NU;
     // kinodynamics variant: only the six base rows are solved for (rows 6 .. of [da_dq | da_dv | da_du] are the unit block of the joint
-    // accelerations in u: r1()); the space takes the frame-velocity rows Cv (NVEL x NDX) of the feet in contact instead
+    // accelerations in u: r1())
     static constexpr int R1ROWS = D::KINO ? 6 : NV;
     double R1[R1ROWS * NCOL];   // [r1q | r1v | r1t] -> M^-1 R1 -> [da_dq | da_dv | da_dtau]
-    double Cv[D::KINO ? D::NVEL * NDX : 1];
     SMPC_HD double r1(int i, int cc) const
     {
       if constexpr (D::KINO)
@@ -97,6 +101,30 @@ namespace smpc
     double JT[NCM * NCOL];      // force rows of the stacked Gauss-Newton Jacobian: [r2q | r2v | 0] -> [dlam_dq | dlam_dv | dlam_dtau]
                                 // (the momentum / foot-pose rows live in the dead dynamics block of the evaluation scratch)
                                 // kinodynamics variant: rows 0 .. 5 = Jacobian of the centroidal_derivative residual hdot(u, q), the rest zero
+  };
+  // LDS part of the wide blocks: the blocks themselves (WIDE_DEV = false), or the per-dof vectors of the R1 fill, which otherwise borrow the
+  // force rows of JT (strided per-lane accesses: not for device memory)
+  template <class D, bool DEV = D::WIDE_DEV>
+  struct FullDerivWideLds
+  {
+    FullDerivWide<D> w;
+    SMPC_HD double * tmp_(FullDerivWide<D> & sw) { return sw.JT; }
+  };
+  template <class D>
+  struct FullDerivWideLds<D, true>
+  {
+    static constexpr int NV = D::NV, NF = D::NF, FS = D::FS;
+    double tmp[(3 * NV * 6 > (FS == 6 ? 9 * NF * NV : 0)) ? 3 * NV * 6 : 9 * NF * NV];
+    SMPC_HD double * tmp_(FullDerivWide<D> &) { return tmp; }
+  };
+  template <class D>
+  struct FullScratchDeriv
+  {
+    static constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX;
+    static constexpr int NCOL = 2 * NV + NU, NGN = 6 + D::PF * NF + NCM;
+    double Bc[NJ * 36], dk[NV * 6], Ak[NV * 6], Wc[NF * 6];
+    // kinodynamics variant: the frame-velocity rows Cv (NVEL x NDX) of the feet in contact
+    double Cv[D::KINO ? D::NVEL * NDX : 1];
     double Je3[9], JeQ[9], Jq[36], Jl[36];
     double Jlf[D::FS == 6 ? NF * 36 : 2]; // Jlog6 of the foot-placement residuals (6-D feet)
     // tables of the assembly phases: they live in the composite velocity-product matrices, dead once R1 is formed
@@ -212,10 +240,18 @@ namespace smpc
     }
   }
 
-  // C (M x N) = sum_k a(i, k) b(k, j) on the FP64 matrix cores, one wave; a / b read their operand entries (LDS), store(i, j, v)
-  // receives every entry once after the last K-step (so C may overwrite an operand).  K-steps of 4, 16 x 16 tiles.
+  // C (M x N) = init(i, j) + sum_k a(i, k) b(k, j) on the FP64 matrix cores, one wave; a / b read their operand entries (LDS, or device memory: the
+  // fetch of K-step k + 1 is in flight during step k), store(i, j, v) receives every entry once after the last K-step (so C may overwrite an
+  // operand).  K-steps of 4, 16 x 16 tiles.  `init` makes a read-modify-write pass one product: all its reads are issued before the first K-step.
+  template <int M, int N, int K, class FA, class FB, class FI, class FS_>
+  SMPC_DEV void fwave_gemm(FA a, FB b, FI init, FS_ store);
   template <int M, int N, int K, class FA, class FB, class FS_>
   SMPC_DEV void fwave_gemm(FA a, FB b, FS_ store)
+  {
+    fwave_gemm<M, N, K>(a, b, [](int, int) { return 0.0; }, store);
+  }
+  template <int M, int N, int K, class FA, class FB, class FI, class FS_>
+  SMPC_DEV void fwave_gemm(FA a, FB b, FI init, FS_ store)
   {
     constexpr int NT = 64, TI = (M + 15) / 16, TJ = (N + 15) / 16, KS = (K + 3) / 4;
     SMPC_ACC(acc, NT, TI * TJ);
@@ -250,11 +286,19 @@ namespace smpc
     };
     SMPC_LANES(NT)
     {
+      const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-      for (int t = 0; t < TI * TJ; t++)
+      for (int I = 0; I < TI; I++)
 #pragma unroll
-        for (int v = 0; v < 4; v++)
-          SMPC_ACCV(acc, t, v) = 0.0;
+        for (int J = 0; J < TJ; J++)
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            const int i = 16 * I + lr + 4 * v, j = 16 * J + lc;
+            const bool ok = i < M && j < N;
+            const double x = init(ok ? i : 0, ok ? j : 0);
+            SMPC_ACCV(acc, I * TJ + J, v) = ok ? x : 0.0;
+          }
     }
     SMPC_LANES_END_WAVE
     fetch(0);
@@ -1316,7 +1360,7 @@ namespace smpc
   //   WJ = block-diagonal weight x JT,  Je3 / JeQ / Jq / Jl from the SE(3) pair.
   // -------------------------------------------------------------------------------------------------------------
   template <class D, class SC, class SD>
-  SMPC_DEV void full_deriv_phases(SC & sc, SD & sd, const DevModel<D> & mg, unsigned mask, bool term, FullProf & fp)
+  SMPC_DEV void full_deriv_phases(SC & sc, SD & sd, FullDerivWide<D> & sw, double * wtmp, const DevModel<D> & mg, unsigned mask, bool term, FullProf & fp)
   {
     constexpr int NT = 64;
     constexpr int NJ = D::NJ, NV = D::NV, NF = D::NF, NCM = D::NCM, NU = D::NU, NR = SC::NR, NCOL = SC::NCOL, FS = D::FS, NGN = SC::NGN;
@@ -1412,8 +1456,9 @@ namespace smpc
     //       Yq_k = Ic_i A_k + Bc_i d_k + d_k x* hc_i + S_k x* Fgc_i ,  Yv_k = Bc_i S_k + S_k x* hc_i + Ic_i E_k
     // The per-dof vectors live in the force rows of JT (written only afterwards, by the contact partials).
     {
-      double * E_ = sd.JT, * Dm_ = E_ + NV * 6, * Yq_ = Dm_ + NV * 6, * Yv_ = Yq_ + NV * 6;
-      static_assert(4 * NV * 6 <= NCM * NCOL && (FS != 6 || 12 * NF * NV <= NCM * NCOL), "per-dof vectors fit the force rows of JT");
+      // (E_k is not stored: the product that needs it forms its entries from vel, S and d_k as it fetches them)
+      double * Dm_ = wtmp, * Yq_ = Dm_ + NV * 6, * Yv_ = Yq_ + NV * 6;
+      static_assert(3 * NV * 6 <= NCM * NCOL && (FS != 6 || 9 * NF * NV <= NCM * NCOL), "per-dof vectors fit the force rows of JT");
       SMPC_LANES(NT)
       {
         if (lane < NV)
@@ -1444,7 +1489,6 @@ namespace smpc
           const SV Dm = SV{mk3(o3[0], o3[1], o3[2]), mk3(o3[3], o3[4], o3[5])} - Cm;
           const SV Yq = Ici * A + SV{mk3(o1[0], o1[1], o1[2]), mk3(o1[3], o1[4], o1[5])} + crf(d, hci) + crf(Sk, ldsv(&sc.I[i * 6]));
           const SV Yv = SV{mk3(o2[0], o2[1], o2[2]), mk3(o2[3], o2[4], o2[5])} + Cm + Ici * E;
-          stsv(&E_[k * 6], E);
           stsv(&Dm_[k * 6], Dm);
           stsv(&Yq_[k * 6], Yq);
           stsv(&Yv_[k * 6], Yv);
@@ -1453,21 +1497,26 @@ namespace smpc
           for (int idx = lane; idx < NV * NU; idx += NT)
           {
             const int m = idx / NU, j = idx % NU;
-            sd.R1[m * NCOL + 2 * NV + j] = m == 6 + j ? -1.0 : 0.0;
+            sw.R1[m * NCOL + 2 * NV + j] = m == 6 + j ? -1.0 : 0.0;
           }
       }
       SMPC_LANES_END_WAVE
-      constexpr int MR = SD::R1ROWS; // (kinodynamics variant: the six base rows)
+      constexpr int MR = FullDerivWide<D>::R1ROWS; // (kinodynamics variant: the six base rows)
       fwave_gemm<MR, 2 * NV, 12>(
         [&](int m, int kk) { return kk < 6 ? sc.IcS[m * 6 + kk] : Dm_[m * 6 + kk - 6]; },
         [&](int kk, int j) {
           const int jj = j < NV ? j : j - NV;
-          const double * src = j < NV ? (kk < 6 ? &sd.Ak[jj * 6 + kk] : &sd.dk[jj * 6 + kk - 6]) : (kk < 6 ? &E_[jj * 6 + kk] : &sc.S[jj * 6 + kk - 6]);
+          if (j >= NV && kk < 6)
+          { // E_k = v_i x S_k + d_k
+            const SV E = crm(ldsv(&sc.vel[jof(jj) * 6]), ldsv(&sc.S[jj * 6])) + ldsv(&sd.dk[jj * 6]);
+            return kk < 3 ? v3c(E.l, kk) : v3c(E.a, kk - 3);
+          }
+          const double * src = j < NV ? (kk < 6 ? &sd.Ak[jj * 6 + kk] : &sd.dk[jj * 6 + kk - 6]) : &sc.S[jj * 6 + kk - 6];
           return *src;
         },
         [&](int m, int j, double v) {
           const int jm = jof(m), i = jof(j < NV ? j : j - NV);
-          sd.R1[m * NCOL + j] = ((h.anc[jm] >> i) & 1u) ? v : 0.0;
+          sw.R1[m * NCOL + j] = ((h.anc[jm] >> i) & 1u) ? v : 0.0;
         });
       fwave_gemm<MR, 2 * NV, 6>(
         [&](int m, int kk) { return sc.S[m * 6 + kk]; },
@@ -1475,14 +1524,14 @@ namespace smpc
         [&](int m, int j, double v) {
           const int jm = jof(m), i = jof(j < NV ? j : j - NV);
           if (!((h.anc[jm] >> i) & 1u) && ((h.anc[i] >> jm) & 1u))
-            sd.R1[m * NCOL + j] = v;
+            sw.R1[m * NCOL + j] = v;
         });
       if constexpr (FS == 6)
       {
         // - d(J^T lam)/dq_k of world-aligned wrenches: the wrench keeps its axes, its point of application moves (first product);
         // the columns S_m below joint(k) -- and the other base columns, for a base dof -- move with S_k (second product):
         //   r1q(m,k) -= sum_f [m, k above foot f] ( (f_f x S_m.ang) . dp_kf + [S_m moves with S_k] (S_m x* W_f) . S_k )
-        double * Gm_ = sd.JT, * Hm_ = Gm_ + NV * 3 * NF, * Pv_ = Hm_ + NV * 6 * NF;
+        double * Hm_ = wtmp, * Pv_ = Hm_ + NV * 6 * NF; // (G_m = f_f x S_m.ang is formed by the product that needs it)
         SMPC_LANES(NT)
         for (int idx = lane; idx < NV * NF; idx += NT)
         {
@@ -1491,31 +1540,36 @@ namespace smpc
           const bool on = ((mask >> f) & 1u) && ((h.anc[l] >> jof(m)) & 1u);
           const SV Sm = ldsv(&sc.S[m * 6]), W = ldsv(&sd.Wc[f * 6]);
           const V3 z = mk3(0, 0, 0);
-          st3(&Gm_[m * 3 * NF + 3 * f], on ? cross(W.l, Sm.a) : z);
           stsv(&Hm_[m * 6 * NF + 6 * f], on ? crf(Sm, W) : SV{z, z});
           st3(&Pv_[m * 3 * NF + 3 * f], on ? Sm.l + cross(Sm.a, ld3(&sc.footp[f * 3])) : z);
         }
         SMPC_LANES_END_WAVE
         fwave_gemm<MR, NV, 3 * NF>(
-          [&](int m, int kk) { return Gm_[m * 3 * NF + kk]; }, [&](int kk, int j) { return Pv_[j * 3 * NF + kk]; },
-          [&](int m, int j, double v) { sd.R1[m * NCOL + j] -= v; });
+          [&](int m, int kk) {
+            const int f = kk / 3;
+            const bool on = ((mask >> f) & 1u) && ((h.anc[h.foot_joint[f]] >> jof(m)) & 1u);
+            return on ? -v3c(cross(ld3(&sd.Wc[f * 6]), ld3(&sc.S[m * 6 + 3])), kk % 3) : 0.0;
+          },
+          [&](int kk, int j) { return Pv_[j * 3 * NF + kk]; },
+          [&](int m, int j) { return sw.R1[m * NCOL + j]; }, [&](int m, int j, double v) { sw.R1[m * NCOL + j] = v; });
         fwave_gemm<MR, NV, 6 * NF>(
-          [&](int m, int kk) { return Hm_[m * 6 * NF + kk]; },
+          [&](int m, int kk) { return -Hm_[m * 6 * NF + kk]; },
           [&](int kk, int j) {
             const int f = kk / 6;
             const double x = sc.S[j * 6 + kk % 6];
             return (((mask >> f) & 1u) && ((h.anc[h.foot_joint[f]] >> jof(j)) & 1u)) ? x : 0.0;
           },
+          [&](int m, int j) { return sw.R1[m * NCOL + j]; },
           [&](int m, int j, double v) {
             const int jm = jof(m), i = jof(j);
             const bool moves = (jm != i && ((h.anc[jm] >> i) & 1u)) || (jm == 0 && i == 0);
             if (moves)
-              sd.R1[m * NCOL + j] -= v;
+              sw.R1[m * NCOL + j] = v;
           });
       }
       SMPC_LANES(NT)
       for (int idx = lane; idx < NCM * NCOL; idx += NT)
-        sd.JT[idx] = 0.0;
+        sw.JT[idx] = 0.0;
       SMPC_LANES_END_WAVE
     }
     ftick(fp, 10);
@@ -1529,7 +1583,7 @@ namespace smpc
         const int b = idx / NCOL, c = idx % NCOL;
         double v;
         if (c < 2 * NV)
-          v = -sd.R1[idx];
+          v = -sw.R1[idx];
         else if (c < 2 * NV + NCM)
         {
           const int f = (c - 2 * NV) / FS, j = (c - 2 * NV) % FS;
@@ -1539,7 +1593,7 @@ namespace smpc
         }
         else
           v = -sc.M[b * NV + 6 + (c - 2 * NV - NCM)];
-        sd.R1[idx] = v;
+        sw.R1[idx] = v;
       }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
@@ -1547,7 +1601,7 @@ namespace smpc
       {
         double t[6], o[6];
         for (int b = 0; b < 6; b++)
-          t[b] = sd.R1[b * NCOL + c];
+          t[b] = sw.R1[b * NCOL + c];
         for (int b = 0; b < 6; b++)
         {
           double acc = 0.0;
@@ -1556,7 +1610,7 @@ namespace smpc
           o[b] = acc;
         }
         for (int b = 0; b < 6; b++)
-          sd.R1[b * NCOL + c] = o[b];
+          sw.R1[b * NCOL + c] = o[b];
       }
       SMPC_LANES_END_WAVE
       // ---- Jacobian of the centroidal_derivative residual hdot(u, q) (rows 0 .. 5 of JT):  d/dq_k = sum_f (dp_f/dq_k - dc/dq_k) x f_f on the
@@ -1577,9 +1631,9 @@ namespace smpc
               const V3 pf = on ? sk.l + cross(sk.a, ld3(&sc.footp[f * 3])) : mk3(0, 0, 0);
               acc = acc + cross(pf - jc, ld3(&sc.u[FS * f]));
             }
-          sd.JT[3 * NCOL + k] = acc.x;
-          sd.JT[4 * NCOL + k] = acc.y;
-          sd.JT[5 * NCOL + k] = acc.z;
+          sw.JT[3 * NCOL + k] = acc.x;
+          sw.JT[4 * NCOL + k] = acc.y;
+          sw.JT[5 * NCOL + k] = acc.z;
         }
         for (int idx = lane; idx < 6 * NCM; idx += NT)
         {
@@ -1596,7 +1650,7 @@ namespace smpc
             else
               v = r == j ? 1.0 : 0.0;
           }
-          sd.JT[r * NCOL + 2 * NV + c] = v;
+          sw.JT[r * NCOL + 2 * NV + c] = v;
         }
         for (int idx = lane; idx < D::NVEL * D::NDX; idx += NT)
         {
@@ -1639,7 +1693,7 @@ namespace smpc
           const V3 aqq = A.a + cross(Sk.a, al.a), wq = d.a + cross(Sk.a, w);
           // d log3(R) for a rotation increment expressed in the world frame: inverse left Jacobian = Jlog3(-phi)
           const V3 rq = Jlog3((-1.0) * ld3(&sc.rotl[f * 3])) * Sk.a;
-          double * r2 = &sd.JT[(6 * c) * NCOL];
+          double * r2 = &sw.JT[(6 * c) * NCOL];
           const double lqv[3] = {lq.x, lq.y, lq.z}, lvqv[3] = {lvq.x, lvq.y, lvq.z}, pvv[3] = {pv.x, pv.y, pv.z};
           const double aqv[3] = {aqq.x, aqq.y, aqq.z}, wqv[3] = {wq.x, wq.y, wq.z}, rqv[3] = {rq.x, rq.y, rq.z};
           const double avv[3] = {av.x, av.y, av.z}, ava[3] = {Av.a.x, Av.a.y, Av.a.z}, sav[3] = {Sk.a.x, Sk.a.y, Sk.a.z};
@@ -1679,7 +1733,7 @@ namespace smpc
         const V3 av = Av.l + cross(Av.a, p) + cross(Sk.a, vp) + cross(w, Sk.l + cross(Sk.a, p));
         const V3 vq = d.l + cross(d.a, p), vv = Sk.l + cross(Sk.a, p);
         const V3 cq = tmul(Rf, aq), cv = tmul(Rf, av), eq = tmul(Rf, vq), ev = tmul(Rf, vv), pq = (-1.0) * tmul(Rf, Sk.l);
-        double * r2 = &sd.JT[(3 * c) * NCOL];
+        double * r2 = &sw.JT[(3 * c) * NCOL];
         r2[0 * NCOL + k] = cq.x + h.Kd[0] * eq.x - h.Kp[0] * pq.x;
         r2[1 * NCOL + k] = cq.y + h.Kd[1] * eq.y - h.Kp[1] * pq.y;
         r2[2 * NCOL + k] = cq.z + h.Kd[2] * eq.z - h.Kp[2] * pq.z;
@@ -1694,20 +1748,20 @@ namespace smpc
     // ---- [M -J^T; J mu] [da; dlam] = -[r1; r2]:  Mr = M^-1 R1 ; rhs = J Mr - r2 ; dlam = G^-1 rhs ; da = -Mr + M^-1 J^T dlam ----
     // Mr = M^-1 R1 (in place)
     fwave_gemm<NV, NCOL, NV>(
-      [&](int i, int k) { return sc.M[k * NV + i]; }, [&](int k, int j) { return sd.R1[k * NCOL + j]; },
-      [&](int i, int j, double v) { sd.R1[i * NCOL + j] = v; });
+      [&](int i, int k) { return sc.M[k * NV + i]; }, [&](int k, int j) { return sw.R1[k * NCOL + j]; },
+      [&](int i, int j, double v) { sw.R1[i * NCOL + j] = v; });
     // rhs = J Mr - r2 (in place on the force rows of JT)
     fwave_gemm<NCM, NCOL, NV>(
-      [&](int i, int k) { return sc.J[i * NV + k]; }, [&](int k, int j) { return sd.R1[k * NCOL + j]; },
-      [&](int i, int j, double v) { sd.JT[i * NCOL + j] = v - sd.JT[i * NCOL + j]; });
+      [&](int i, int k) { return sc.J[i * NV + k]; }, [&](int k, int j) { return sw.R1[k * NCOL + j]; },
+      [&](int i, int j) { return -sw.JT[i * NCOL + j]; }, [&](int i, int j, double v) { sw.JT[i * NCOL + j] = v; });
     // dlam = G^-1 rhs (in place)
     fwave_gemm<NCM, NCOL, NCM>(
-      [&](int i, int k) { return sc.Gi[k * NCM + i]; }, [&](int k, int j) { return sd.JT[k * NCOL + j]; },
-      [&](int i, int j, double v) { sd.JT[i * NCOL + j] = v; });
+      [&](int i, int k) { return sc.Gi[k * NCM + i]; }, [&](int k, int j) { return sw.JT[k * NCOL + j]; },
+      [&](int i, int j, double v) { sw.JT[i * NCOL + j] = v; });
     // da = -Mr + M^-1 J^T dlam (in place on R1)
     fwave_gemm<NV, NCOL, NCM>(
-      [&](int i, int k) { return sc.W[i * NR + 1 + k]; }, [&](int k, int j) { return sd.JT[k * NCOL + j]; },
-      [&](int i, int j, double v) { sd.R1[i * NCOL + j] = v - sd.R1[i * NCOL + j]; });
+      [&](int i, int k) { return sc.W[i * NR + 1 + k]; }, [&](int k, int j) { return sw.JT[k * NCOL + j]; },
+      [&](int i, int j) { return -sw.R1[i * NCOL + j]; }, [&](int i, int j, double v) { sw.R1[i * NCOL + j] = v; });
     full_gn_rows<D>(sc, sd, false);
     ftick(fp, 12);
     (void)NGN;
@@ -1788,7 +1842,7 @@ namespace smpc
   // B-operand layout of K-step 4 R + v of the second product, so the weighted Jacobian never leaves the registers.  Upper 16 x 16
   // tiles of the (x, u) grid are written: Q (upper tiles; mirrored when `mirror`), S, R (readers take (min, max) indices).
   template <class D, class SC, class SD>
-  SMPC_DEV void full_hessian_mfma(SC & sc, SD & sd, const DevModel<D> & mg, bool term, double preg, double * Qd, double * Sd, double * Rd, bool mirror, bool tcs = false)
+  SMPC_DEV void full_hessian_mfma(SC & sc, SD & sd, FullDerivWide<D> & sw, const DevModel<D> & mg, bool term, double preg, double * Qd, double * Sd, double * Rd, bool mirror, bool tcs = false)
   {
     constexpr int NT = 64;
     constexpr int NDX = D::NDX, NU = D::NU, NXU = D::NXU, NCOL = SC::NCOL, NGN0 = SC::NGN;
@@ -1841,7 +1895,7 @@ namespace smpc
           const bool velr = D::KINO && r >= NGN0;
           const bool ok = r < NGN && (velr ? (c < NDX && !term) : c < NCOL) && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3)); // terminal node: momentum (+ constraint) rows only
           const double * row = (ok && velr) ? &sd.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
-                                            : ((ok && r < D::NCM) ? &sd.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL);
+                                            : ((ok && r < D::NCM) ? &sw.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL);
           const double v = row[(c < NCOL && ok) ? c : 0];
           SMPC_PLV(jtv)[J] = ok ? v : 0.0;
         }
@@ -1875,7 +1929,7 @@ namespace smpc
             const bool velr = D::KINO && r >= NGN0;
             const bool ok = r < NGN && (velr ? (c < NDX && !term) : c < NCOL) && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3));
             const double * row = (ok && velr) ? &sd.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
-                                              : ((ok && r < D::NCM) ? &sd.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL);
+                                              : ((ok && r < D::NCM) ? &sw.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL);
             const double x = row[(c < NCOL && ok) ? c : 0];
             SMPC_PLV(jtv)[J] = ok ? x : 0.0;
             SMPC_PLV(bv)[J] = SMPC_ACCV(wj, R * NTC + J, v);
@@ -1927,7 +1981,7 @@ namespace smpc
   // t == H is the terminal node (state cost + 10 x centroidal cost, src/fulldynamics.cpp:418-430).
   // =============================================================================================
   template <class D>
-  SMPC_DEV void fdyn_deriv_one(const StageKernelArgs<D> & ka, int inst, int t)
+  SMPC_DEV void fdyn_deriv_one(const StageKernelArgs<D> & ka, int inst, int t, int block)
   {
     typedef FullScratch<D, true> SC;
     typedef FullScratchDeriv<D> SD;
@@ -1942,7 +1996,7 @@ namespace smpc
     SMPC_LDS(SD, sds, 1);
     // LDS decides the resident blocks per CU here (160 KB / block size, one wave per SIMD at most): the quadruped with neither cone nor
     // land rows must stay under 40 KB -- four blocks; at 41.2 KB it ran three and the launch took 15.2 ms instead of 11.9
-    static_assert(!(D::NJ == 13 && D::FS == 3 && D::NCONE == 0 && D::NLAND == 0 && !D::KINO) || sizeof(SC) + sizeof(SD) <= 40960,
+    static_assert(!(D::NJ == 13 && D::FS == 3 && D::NCONE == 0 && D::NLAND == 0 && !D::KINO) || sizeof(SC) + sizeof(SD) + sizeof(FullDerivWideLds<D>) <= 40960,
                   "fdyn_deriv_body of the point-foot quadruped: 4 resident blocks per CU");
 #ifdef SMPC_FDYN_PAD
     SMPC_LDS(double, padlds, SMPC_FDYN_PAD); // (occupancy experiment)
@@ -1951,6 +2005,14 @@ namespace smpc
 #endif
     SC & sc = scs[0];
     SD & sd = sds[0];
+    SMPC_LDS(FullDerivWideLds<D>, swls, 1);
+    FullDerivWideLds<D> & swl = swls[0];
+    FullDerivWide<D> * swp;
+    if constexpr (D::WIDE_DEV)
+      swp = reinterpret_cast<FullDerivWide<D> *>(ka.wide) + block; // (one slice per BLOCK of the launch: smpc_full_engine.h)
+    else
+      swp = &swl.w;
+    FullDerivWide<D> & sw = *swp;
     const FullHead<D> & h = sc.h;
     const int st = ring_slot(ka.head, t, R);
     const size_t ib = (size_t)inst * R;
@@ -1992,7 +2054,7 @@ namespace smpc
     full_dynamics_phases<D, true>(sc, &sd, mg, mask, !term, fp);
     full_eval_tail<D, true>(sc, &sd, mg, mask, land, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC, &fp);
     ftick(fp, 7);
-    full_deriv_phases<D>(sc, sd, mg, mask, term, fp);
+    full_deriv_phases<D>(sc, sd, sw, swl.tmp_(sw), mg, mask, term, fp);
     ftick(fp, 13);
     full_state_tables<D>(sc, sd, mg);
     double * parts = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
@@ -2044,7 +2106,7 @@ namespace smpc
         g = sc.Wru[k - NDX];
       // (terminal node: only the momentum rows exist)
       for (int r = term ? NCM : 0; r < (term ? NCM + 6 : NGN); r++)
-        g += (r < NCM ? sd.JT[r * NCOL + k] : sc.jt2_()[(r - NCM) * NCOL + k]) * sd.dual_()[r];
+        g += (r < NCM ? sw.JT[r * NCOL + k] : sc.jt2_()[(r - NCM) * NCOL + k]) * sd.dual_()[r];
       if (k < NDX)
         sd.gx_()[k] = g;
       else
@@ -2066,7 +2128,7 @@ namespace smpc
       else if constexpr (D::NCONE > 0)
         if (!term)
           for (int r = 0; r < NCM; r++)
-            cqv += sd.JT[r * NCOL + k] * sd.yc_()[r];
+            cqv += sw.JT[r * NCOL + k] * sd.yc_()[r];
       if constexpr (D::NLAND > 0)
         if (land != 0u && k < NDX) // land rows: C_x^T nu (rows of the state only)
           for (int f = 0; f < NF; f++)
@@ -2085,7 +2147,7 @@ namespace smpc
       // C = [Jcom + tau dvcom/dq | tau Jcom] go where the (absent) force rows of JT would be, v | v+ | c behind them; the product
       // below then carries C^T C / mu, and q_N gets C^T v+
       const bool tcs = b.CN != nullptr;
-      double * tv = &sd.JT[3 * NCOL];
+      double * tv = &sw.JT[3 * NCOL];
       static_assert(NCM >= 4 && NCOL >= 9, "terminal constraint scratch inside the force rows");
       if (tcs)
       {
@@ -2101,7 +2163,7 @@ namespace smpc
               v = (hrow[r * NCOL + NV + k] + tau * hrow[r * NCOL + k]) * im;
             else if (k < NDX)
               v = tau * hrow[r * NCOL + k] * im;
-            sd.JT[idx] = v;
+            sw.JT[idx] = v;
             if (k < NDX)
               b.CN[(size_t)inst * (3 * NDX + 3) + r * NDX + k] = v;
           }
@@ -2118,7 +2180,7 @@ namespace smpc
         }
         SMPC_LANES_END_WAVE
       }
-      full_hessian_mfma<D>(sc, sd, mg, true, preg, QN, (double *)nullptr, (double *)nullptr, true, tcs);
+      full_hessian_mfma<D>(sc, sd, sw, mg, true, preg, QN, (double *)nullptr, (double *)nullptr, true, tcs);
       SMPC_LANES(NT)
       {
         double dual = 0.0;
@@ -2128,10 +2190,10 @@ namespace smpc
           if (tcs)
           {
             for (int r = 0; r < 3; r++)
-              qn += sd.JT[r * NCOL + k] * tv[r];
+              qn += sw.JT[r * NCOL + k] * tv[r];
             dual = fmax(dual, fabs(qn)); // dual residual with the current multipliers; the Newton right-hand side uses v+
             for (int r = 0; r < 3; r++)
-              qn += sd.JT[r * NCOL + k] * (h.mu * (tv[3 + r] - tv[r])) / h.mu;
+              qn += sw.JT[r * NCOL + k] * (h.mu * (tv[3 + r] - tv[r])) / h.mu;
           }
           else
             dual = fmax(dual, fabs(qn));
@@ -2177,9 +2239,13 @@ namespace smpc
         double * dst = lq + (isA ? D::O_A : D::O_B);
         const int ld = isA ? NDX : NU;
         double acc = 0.0; // (A^T lam_next)[k] or (B^T lam_next)[k], rows in order
+        double r1c[NV]; // column cc of [da_dq | da_dv | da_dtau], read before anything of this column is stored
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+          r1c[i] = sw.r1(i, cc);
         double Dtop[6];
         for (int m = 0; m < 6; m++)
-          Dtop[m] = dt * dt * sd.r1(m, cc) + ((isA && k == NV + m) ? dt : 0.0);
+          Dtop[m] = dt * dt * r1c[m] + ((isA && k == NV + m) ? dt : 0.0);
         for (int i = 0; i < 6; i++)
         {
           double v;
@@ -2195,13 +2261,13 @@ namespace smpc
         }
         for (int i = 6; i < NV; i++)
         {
-          const double v = dt * dt * sd.r1(i, cc) + ((isA && k == NV + i) ? dt : 0.0) + ((isA && k == i) ? 1.0 : 0.0);
+          const double v = dt * dt * r1c[i] + ((isA && k == NV + i) ? dt : 0.0) + ((isA && k == i) ? 1.0 : 0.0);
           dst[i * ld + k] = v;
           acc += v * sc.lam_next[i];
         }
         for (int i = 0; i < NV; i++)
         {
-          const double v = dt * sd.r1(i, cc) + ((isA && k == NV + i) ? 1.0 : 0.0);
+          const double v = dt * r1c[i] + ((isA && k == NV + i) ? 1.0 : 0.0);
           dst[(NV + i) * ld + k] = v;
           acc += v * sc.lam_next[NV + i];
         }
@@ -2238,7 +2304,7 @@ namespace smpc
     SMPC_LANES_END_WAVE
     ftick(fp, 15);
     // ---- [Q S; S^T R] = H_0 + JT^T (W~ JT) + preg I on the matrix cores ----
-    full_hessian_mfma<D>(sc, sd, mg, false, preg, lq + D::O_Q, lq + D::O_S, lq + D::O_R, false);
+    full_hessian_mfma<D>(sc, sd, sw, mg, false, preg, lq + D::O_Q, lq + D::O_S, lq + D::O_R, false);
     SMPC_LANES(NT)
     {
       for (int i = lane; i < NC; i += NT)
@@ -2270,7 +2336,7 @@ namespace smpc
           {
             const int c = __builtin_popcount(mask & ((1u << f) - 1u));
             for (int j = 0; j < D::FS; j++)
-              acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * sd.JT[(D::FS * c + j) * NCOL + k];
+              acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * sw.JT[(D::FS * c + j) * NCOL + k];
           }
         }
         if (k < NDX)
@@ -2328,7 +2394,7 @@ namespace smpc
     const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : slot + 1;
     const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
     for (int m = slot; m < count; m += stride)
-      fdyn_deriv_one<D>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t);
+      fdyn_deriv_one<D>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t, block);
   }
 
   // =============================================================================================

@@ -264,6 +264,7 @@ namespace smpc
   {
     V3 l, a;
   };
+  SMPC_HD double v3c(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
   SMPC_HD SV sv0() { return SV{mk3(0, 0, 0), mk3(0, 0, 0)}; }
   SMPC_HD SV operator+(const SV & x, const SV & y) { return SV{x.l + y.l, x.a + y.a}; }
   SMPC_HD SV operator-(const SV & x, const SV & y) { return SV{x.l - y.l, x.a - y.a}; }
