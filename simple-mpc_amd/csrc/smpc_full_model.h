@@ -38,8 +38,9 @@ namespace smpc
     static_assert(KIN_ == 0 || (FS_ == 6 && LN_ == 0), "kinodynamics variant: 6-D feet (point feet run on KinoEngine), no land rows (src/kinodynamics.cpp:134)");
     static constexpr bool KINO = KIN_ != 0;
     // The two widest derivative blocks of a stage (R1, JT: FullDerivWide, smpc_full_stage.h) in a per-block slice of device memory instead of
-    // LDS: where that buys a third resident block per CU (the biped's full dynamics: 73.9 KB -> 54.4 KB; the quadruped already runs four)
-    static constexpr bool WIDE_DEV = NJ_ > 16 && KIN_ == 0;
+    // LDS: where that buys a third resident block per CU (the biped: full dynamics 73.9 KB -> 53.0 KB, kinodynamics variant 68.7 KB -> 53.3 KB;
+    // the quadruped already runs four)
+    static constexpr bool WIDE_DEV = NJ_ > 16;
     static constexpr int NJ = NJ_;     // joints incl. free-flyer
     static constexpr int NF = NF_;     // feet
     static constexpr int FS = FS_;     // contact force size

@@ -101,6 +101,7 @@ namespace smpc
     double JT[NCM * NCOL];      // force rows of the stacked Gauss-Newton Jacobian: [r2q | r2v | 0] -> [dlam_dq | dlam_dv | dlam_dtau]
                                 // (the momentum / foot-pose rows live in the dead dynamics block of the evaluation scratch)
                                 // kinodynamics variant: rows 0 .. 5 = Jacobian of the centroidal_derivative residual hdot(u, q), the rest zero
+    double Cv[D::KINO ? D::NVEL * D::NDX : 1]; // kinodynamics variant: the frame-velocity rows (NVEL x NDX) of the feet in contact
   };
   // LDS part of the wide blocks: the blocks themselves (WIDE_DEV = false), or the per-dof vectors of the R1 fill, which otherwise borrow the
   // force rows of JT (strided per-lane accesses: not for device memory)
@@ -114,7 +115,8 @@ namespace smpc
   struct FullDerivWideLds<D, true>
   {
     static constexpr int NV = D::NV, NF = D::NF, FS = D::FS;
-    double tmp[(3 * NV * 6 > (FS == 6 ? 9 * NF * NV : 0)) ? 3 * NV * 6 : 9 * NF * NV];
+    static constexpr int MR = FullDerivWide<D>::R1ROWS, N1 = (MR + 2 * NV) * 6, N2 = FS == 6 ? (6 * MR + 3 * NV) * NF : 0;
+    double tmp[N1 > N2 ? N1 : N2];
     SMPC_HD double * tmp_(FullDerivWide<D> &) { return tmp; }
   };
   template <class D>
@@ -123,8 +125,6 @@ namespace smpc
     static constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX;
     static constexpr int NCOL = 2 * NV + NU, NGN = 6 + D::PF * NF + NCM;
     double Bc[NJ * 36], dk[NV * 6], Ak[NV * 6], Wc[NF * 6];
-    // kinodynamics variant: the frame-velocity rows Cv (NVEL x NDX) of the feet in contact
-    double Cv[D::KINO ? D::NVEL * NDX : 1];
     double Je3[9], JeQ[9], Jq[36], Jl[36];
     double Jlf[D::FS == 6 ? NF * 36 : 2]; // Jlog6 of the foot-placement residuals (6-D feet)
     // tables of the assembly phases: they live in the composite velocity-product matrices, dead once R1 is formed
@@ -1457,8 +1457,9 @@ namespace smpc
     // The per-dof vectors live in the force rows of JT (written only afterwards, by the contact partials).
     {
       // (E_k is not stored: the product that needs it forms its entries from vel, S and d_k as it fetches them)
-      double * Dm_ = wtmp, * Yq_ = Dm_ + NV * 6, * Yv_ = Yq_ + NV * 6;
-      static_assert(3 * NV * 6 <= NCM * NCOL && (FS != 6 || 9 * NF * NV <= NCM * NCOL), "per-dof vectors fit the force rows of JT");
+      constexpr int MR = FullDerivWide<D>::R1ROWS; // (kinodynamics variant: the six base rows)
+      double * Dm_ = wtmp, * Yq_ = Dm_ + MR * 6, * Yv_ = Yq_ + NV * 6; // (D_m: one per ROW of R1)
+      static_assert((MR + 2 * NV) * 6 <= NCM * NCOL && (FS != 6 || (6 * MR + 3 * NV) * NF <= NCM * NCOL), "per-dof vectors fit the force rows of JT");
       SMPC_LANES(NT)
       {
         if (lane < NV)
@@ -1489,7 +1490,8 @@ namespace smpc
           const SV Dm = SV{mk3(o3[0], o3[1], o3[2]), mk3(o3[3], o3[4], o3[5])} - Cm;
           const SV Yq = Ici * A + SV{mk3(o1[0], o1[1], o1[2]), mk3(o1[3], o1[4], o1[5])} + crf(d, hci) + crf(Sk, ldsv(&sc.I[i * 6]));
           const SV Yv = SV{mk3(o2[0], o2[1], o2[2]), mk3(o2[3], o2[4], o2[5])} + Cm + Ici * E;
-          stsv(&Dm_[k * 6], Dm);
+          if (k < MR)
+            stsv(&Dm_[k * 6], Dm);
           stsv(&Yq_[k * 6], Yq);
           stsv(&Yv_[k * 6], Yv);
         }
@@ -1501,7 +1503,6 @@ namespace smpc
           }
       }
       SMPC_LANES_END_WAVE
-      constexpr int MR = FullDerivWide<D>::R1ROWS; // (kinodynamics variant: the six base rows)
       fwave_gemm<MR, 2 * NV, 12>(
         [&](int m, int kk) { return kk < 6 ? sc.IcS[m * 6 + kk] : Dm_[m * 6 + kk - 6]; },
         [&](int kk, int j) {
@@ -1531,7 +1532,7 @@ namespace smpc
         // - d(J^T lam)/dq_k of world-aligned wrenches: the wrench keeps its axes, its point of application moves (first product);
         // the columns S_m below joint(k) -- and the other base columns, for a base dof -- move with S_k (second product):
         //   r1q(m,k) -= sum_f [m, k above foot f] ( (f_f x S_m.ang) . dp_kf + [S_m moves with S_k] (S_m x* W_f) . S_k )
-        double * Hm_ = wtmp, * Pv_ = Hm_ + NV * 6 * NF; // (G_m = f_f x S_m.ang is formed by the product that needs it)
+        double * Hm_ = wtmp, * Pv_ = Hm_ + MR * 6 * NF; // (G_m = f_f x S_m.ang is formed by the product that needs it ; H_m: one per ROW of R1)
         SMPC_LANES(NT)
         for (int idx = lane; idx < NV * NF; idx += NT)
         {
@@ -1540,7 +1541,8 @@ namespace smpc
           const bool on = ((mask >> f) & 1u) && ((h.anc[l] >> jof(m)) & 1u);
           const SV Sm = ldsv(&sc.S[m * 6]), W = ldsv(&sd.Wc[f * 6]);
           const V3 z = mk3(0, 0, 0);
-          stsv(&Hm_[m * 6 * NF + 6 * f], on ? crf(Sm, W) : SV{z, z});
+          if (m < MR)
+            stsv(&Hm_[m * 6 * NF + 6 * f], on ? crf(Sm, W) : SV{z, z});
           st3(&Pv_[m * 3 * NF + 3 * f], on ? Sm.l + cross(Sm.a, ld3(&sc.footp[f * 3])) : z);
         }
         SMPC_LANES_END_WAVE
@@ -1655,7 +1657,7 @@ namespace smpc
         for (int idx = lane; idx < D::NVEL * D::NDX; idx += NT)
         {
           const int row = idx / D::NDX, k = idx % D::NDX, f = row / FS, r = row % FS;
-          sd.Cv[idx] = ((mask >> f) & 1u) ? kino_vel_entry<D>(sc, sd, f, r, k) : 0.0;
+          sw.Cv[idx] = ((mask >> f) & 1u) ? kino_vel_entry<D>(sc, sd, f, r, k) : 0.0;
         }
       }
       SMPC_LANES_END_WAVE
@@ -1846,7 +1848,7 @@ namespace smpc
   {
     constexpr int NT = 64;
     constexpr int NDX = D::NDX, NU = D::NU, NXU = D::NXU, NCOL = SC::NCOL, NGN0 = SC::NGN;
-    constexpr int NGN = NGN0 + D::NVEL; // (kinodynamics variant: the folded frame-velocity rows ride behind the cost rows, from sd.Cv)
+    constexpr int NGN = NGN0 + D::NVEL; // (kinodynamics variant: the folded frame-velocity rows ride behind the cost rows, from sw.Cv)
     constexpr int NTC = (NXU + 15) / 16, NTR = (NGN + 15) / 16, KS = (NGN + 3) / 4;
     static_assert(NCOL == NXU, "the derivative columns (q, v, tau) are the (x, u) columns");
     const FullHead<D> & h = sc.h;
@@ -1894,7 +1896,7 @@ namespace smpc
           const int c = 16 * J + lc;
           const bool velr = D::KINO && r >= NGN0;
           const bool ok = r < NGN && (velr ? (c < NDX && !term) : c < NCOL) && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3)); // terminal node: momentum (+ constraint) rows only
-          const double * row = (ok && velr) ? &sd.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
+          const double * row = (ok && velr) ? &sw.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
                                             : ((ok && r < D::NCM) ? &sw.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL);
           const double v = row[(c < NCOL && ok) ? c : 0];
           SMPC_PLV(jtv)[J] = ok ? v : 0.0;
@@ -1928,7 +1930,7 @@ namespace smpc
             const int c = 16 * J + lc;
             const bool velr = D::KINO && r >= NGN0;
             const bool ok = r < NGN && (velr ? (c < NDX && !term) : c < NCOL) && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3));
-            const double * row = (ok && velr) ? &sd.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
+            const double * row = (ok && velr) ? &sw.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
                                               : ((ok && r < D::NCM) ? &sw.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL);
             const double x = row[(c < NCOL && ok) ? c : 0];
             SMPC_PLV(jtv)[J] = ok ? x : 0.0;
@@ -2122,7 +2124,7 @@ namespace smpc
           // frame-velocity rows: Cv^T nu
           if (k < NDX)
             for (int r = 0; r < D::NVEL; r++)
-              cqv += sd.Cv[r * NDX + k] * sc.nu[NU + NA + D::NCD + r];
+              cqv += sw.Cv[r * NDX + k] * sc.nu[NU + NA + D::NCD + r];
         }
       }
       else if constexpr (D::NCONE > 0)
@@ -2283,7 +2285,7 @@ namespace smpc
           double qf = q;
           if constexpr (D::KINO) // folded frame-velocity rows: the Newton right-hand side gets Cv^T d / mu = Cv^T (nu+ - nu)
             for (int r = 0; r < (t == 0 ? 0 : D::NVEL); r++)
-              qf += sd.Cv[r * NDX + k] * (sc.vplus[NU + NA + D::NCD + r] - sc.nu[NU + NA + D::NCD + r]);
+              qf += sw.Cv[r * NDX + k] * (sc.vplus[NU + NA + D::NCD + r] - sc.nu[NU + NA + D::NCD + r]);
           lq[D::O_q + k] = qf;
           lq[D::O_lx + k] = sd.gx_()[k];
           lq[D::O_f + k] = mu * (sc.lamp[k] - sc.lam_next[k]);
@@ -2351,7 +2353,7 @@ namespace smpc
       // frame-velocity rows (folded into Q, q above): kept for the multiplier step of the forward sweep, dnu = (Cv dx + d) / mu
       SMPC_LANES(NT)
       for (int idx = lane; idx < D::NVEL * NDX; idx += NT)
-        lq[D::O_V + idx] = sd.Cv[idx];
+        lq[D::O_V + idx] = sw.Cv[idx];
       SMPC_LANES_END_WAVE
     }
     if constexpr (D::NLAND > 0)
