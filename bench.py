@@ -679,15 +679,21 @@ def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True, rob
 
     for _ in range(warmup):
         step()
-    gm.set_profiling(True)
-    gm.reset_kernel_times()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # per-kernel durations: a short profiled loop of the same closed loop AFTER the timed one (HIP events around every launch; the engine runs
+    # the batch as ONE part while profiling, whatever SMPC_FULL_PARTS says)
+    gm.set_profiling(True)
+    gm.reset_kernel_times()
+    for _ in range(min(steps, 5)):
+        step()
+    torch.cuda.synchronize()
     kt = gm.kernel_times()
+    gm.set_profiling(False)
     H, ndx, nu, nc = gm.H, gm.ndx, gm.nu, gm.nc
     name = "Talos" if talos else "Go2"
     out = {
@@ -782,15 +788,20 @@ def talos_flat_feet_line(kind, batch, iters, steps, warmup, device_id, with_cpu=
 
     for _ in range(warmup):
         step()
-    gm.set_profiling(True)
-    gm.reset_kernel_times()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # (per-kernel durations from a short profiled loop after the timed one: the kinodynamics engine runs the batch as one part while profiling)
+    gm.set_profiling(True)
+    gm.reset_kernel_times()
+    for _ in range(min(steps, 5)):
+        step()
+    torch.cuda.synchronize()
     kt = gm.kernel_times()
+    gm.set_profiling(False)
     out = {
         "metric": "MPC control-steps/sec at fixed ProxDDP iters, Talos %s (6-D feet) H=%d" % (kind.split("_")[1], gm.H),
         "value": batch * steps / dt, "unit": "control-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": "f64",

@@ -78,6 +78,17 @@ namespace smpc
   public:
     Buffers<D> buf;
     double * deriv_wide = nullptr; // D::WIDE_DEV: R1 / JT slices of the derivative kernel's blocks (FullDerivWide, smpc_full_stage.h)
+    // The batch as parts on streams of their own (round 5; SMPC_FULL_PARTS=n, default 1): one wavefront per instance is all the sweeps have, so
+    // at B = 1024 riccati_dense_body runs one wave per SIMD for its whole duration; with two parts the sweep of one could run beside the stage
+    // kernel of the other.  Measured on the biped (B = 1024, H = 100): 10.77 k control-steps/s with 1 part, 10.29 k with 2, 10.43 k with 3 --
+    // three derivative blocks fill a CU's LDS (3 x 53 KB), a sweep block (36 KB) finds no room beside them and the two kernels take turns as
+    // before; the quadruped (B = 4096): 70.5 k -> 71.3 k.  Kept off.  Instances are independent: bit-identical results (tests).
+    static constexpr int MAX_PARTS = 4;
+    int n_parts = 1;
+    stream_t cur{};                      // the stream the launches of the moment go to
+    stream_t part_stream[MAX_PARTS] = {}; // [0] = stream
+    event_t ev_fork{}, ev_join[MAX_PARTS] = {};
+    int * und_part[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     HostMpcSettings ms;
     std::vector<StageShared<D>> horizon, cycle;
     StageShared<D> standing;
@@ -126,6 +137,8 @@ namespace smpc
       device_id = device;
       set_device(device);
       stream = stream_create();
+      cur = stream;
+      part_stream[0] = stream;
       B = batch;
       H = ms.T;
       R = H + 1;
@@ -239,6 +252,23 @@ namespace smpc
       X_dev = dalloc((size_t)B * D::NX);
       if constexpr (D::WIDE_DEV)
         deriv_wide = (double *)dev_alloc((size_t)B * (H + 1) * sizeof(FullDerivWide<D>)); // (largest grid of fdyn_deriv_body)
+      {
+        const char * pe = std::getenv("SMPC_FULL_PARTS");
+        n_parts = pe ? std::atoi(pe) : 1;
+        if (n_parts < 1 || n_parts > MAX_PARTS || B < 64 * n_parts)
+          n_parts = 1;
+        if (n_parts > 1)
+        {
+          ev_fork = event_create();
+          for (int i = 1; i < n_parts; i++)
+          {
+            part_stream[i] = stream_create();
+            ev_join[i] = event_create();
+          }
+          for (int i = 0; i < n_parts; i++)
+            und_part[i] = (int *)dev_alloc((size_t)(B + 1) * sizeof(int));
+        }
+      }
       if (fs.terminal_constraint)
         alloc_terminal_constraint<D>(buf, x_model_ref.data(), host_com_height(m, x_model_ref.data()), stream);
       if (std::getenv("SMPC_PHASE_PROFILE"))
@@ -271,6 +301,17 @@ namespace smpc
         dev_free(p);
       dev_free(buf.ls_sel);
       dev_free(buf.und_list);
+      for (int i = 0; i < MAX_PARTS; i++)
+        dev_free(und_part[i]);
+      if (n_parts > 1)
+      {
+        event_destroy(ev_fork);
+        for (int i = 1; i < n_parts; i++)
+        {
+          event_destroy(ev_join[i]);
+          stream_destroy(part_stream[i]);
+        }
+      }
       dev_free(buf.stages);
       dev_free(buf.model);
       dev_free(sim_a);
@@ -308,15 +349,15 @@ namespace smpc
       {
         e0 = event_create();
         e1 = event_create();
-        event_record(e0, stream);
+        event_record(e0, cur);
       }
       if (aux)
-        launch<Args, Body, NT, MINW, 1>(grid, stream, a);
+        launch<Args, Body, NT, MINW, 1>(grid, cur, a);
       else
-        launch<Args, Body, NT, MINW, 0>(grid, stream, a);
+        launch<Args, Body, NT, MINW, 0>(grid, cur, a);
       if (profiling)
       {
-        event_record(e1, stream);
+        event_record(e1, cur);
         pending_events.push_back({kid, {e0, e1}});
       }
       kernel_calls[kid]++;
@@ -340,7 +381,8 @@ namespace smpc
       sk.j0 = 0;
       sk.nj = 0;
       sk.slots = slots;
-      sk.wide = deriv_wide;
+      // (a view of a part of the batch: its blocks index the slices behind those of the instances before it)
+      sk.wide = deriv_wide ? deriv_wide + (size_t)(b.xs - buf.xs) / ((size_t)R * D::NX) * (H + 1) * (sizeof(FullDerivWide<D>) / sizeof(double)) : nullptr;
       return sk;
     }
     void launch_deriv(const Buffers<D> & b, int slots = 0)
@@ -438,10 +480,10 @@ namespace smpc
     }
     void copy_centres(const Buffers<D> & b)
     {
-      d2d(b.vs_e, b.vs, (size_t)b.B * R * D::NC * sizeof(double), stream);
-      d2d(b.lams_e, b.lams, (size_t)b.B * R * D::NDX * sizeof(double), stream);
+      d2d(b.vs_e, b.vs, (size_t)b.B * R * D::NC * sizeof(double), cur);
+      d2d(b.lams_e, b.lams, (size_t)b.B * R * D::NDX * sizeof(double), cur);
       if (b.CN != nullptr)
-        d2d(b.vN_e, b.vN, (size_t)b.B * 3 * sizeof(double), stream);
+        d2d(b.vN_e, b.vN, (size_t)b.B * 3 * sizeof(double), cur);
     }
     void upload_stages() { stage_ring.upload(buf.stages, horizon.data(), (size_t)H * sizeof(StageShared<D>), stream); }
     UploadRing stage_ring;
@@ -642,8 +684,53 @@ namespace smpc
       ra.shift = 1;
       ra.reg_init = REG_INIT;
       timed_launch<RecedeArgs<D>, recede_body<D>, 64>(KID_RECEDE, B, ra);
+      if (n_parts > 1 && buf.CN == nullptr && !profiling) // (per-launch event timings mean nothing once launches overlap: one part while profiling)
+      {
+        event_record(ev_fork, stream);
+        for (int i = 0; i < n_parts; i++)
+        {
+          const int i0 = (int)((long long)B * i / n_parts), i1 = (int)((long long)B * (i + 1) / n_parts);
+          const Buffers<D> part = slice(buf, i0, i1 - i0, und_part[i]);
+          cur = part_stream[i];
+          if (i > 0)
+            stream_wait_event(cur, ev_fork);
+          copy_centres(part);
+          run_iterations(part, ms.max_iters);
+        }
+        for (int i = 1; i < n_parts; i++)
+        {
+          event_record(ev_join[i], part_stream[i]);
+          stream_wait_event(stream, ev_join[i]);
+        }
+        cur = stream;
+        return;
+      }
       copy_centres(buf);
       run_iterations(buf, ms.max_iters);
+    }
+    // instances i0 .. i0 + n of every per-instance array (problems without a terminal constraint)
+    Buffers<D> slice(const Buffers<D> & b, int i0, int n, int * und) const
+    {
+      Buffers<D> s = b;
+      s.B = n;
+      const size_t o = (size_t)i0, Rs = (size_t)R, Hs = (size_t)H;
+      auto adv = [&](double *& p, size_t per) {
+        if (p)
+          p += o * per;
+      };
+      adv(s.xs, Rs * D::NX); adv(s.us, Rs * D::NU); adv(s.vs, Rs * D::NC); adv(s.lams, Rs * D::NDX);
+      adv(s.vs_e, Rs * D::NC); adv(s.lams_e, Rs * D::NDX);
+      adv(s.xs_b, Rs * D::NX); adv(s.us_b, Rs * D::NU); adv(s.vs_b, Rs * D::NC); adv(s.lams_b, Rs * D::NDX);
+      adv(s.dxs, (Hs + 1) * D::NDX); adv(s.dus, Hs * D::NU); adv(s.dvs, Hs * D::NC); adv(s.dlams, Hs * D::NDX);
+      adv(s.foot_ref, Hs * D::NF * 3); adv(s.ftraj, (size_t)D::NF * 6); adv(s.vbase, 6); adv(s.vref, Rs * 6);
+      adv(s.lq, Hs * D::LQ_STRIDE); adv(s.gains, Hs * (size_t)D::G_STRIDE);
+      adv(s.QN, (size_t)D::NDX * D::NDX); adv(s.qN, D::NDX);
+      adv(s.parts0, (Hs + 1) * 4); adv(s.partsT, (size_t)D::LS_N * (Hs + 1) * 2); adv(s.scal, SC_N);
+      adv(s.xdotT, (size_t)D::LS_N * 4 * D::NV); adv(s.xdot01, (size_t)4 * D::NV);
+      adv(s.forcesT, Hs * D::LS_N * D::NCM); adv(s.forces, Hs * D::NCM);
+      s.ls_sel = b.ls_sel + i0;
+      s.und_list = und;
+      return s;
     }
     void iterate_host(const double * X) override
     {

@@ -181,6 +181,54 @@ def test_hip_unusual_horizon_and_backtracking(built):
         X = om.xs[:, 1, :].copy()
 
 
+def _parts_run(lib, parts, B, iters, steps, horizon, scale=1.0, talos=False):
+    """Closed loop with the batch as `parts` parts on streams of their own (SMPC_FULL_PARTS, read when the handle is created)."""
+    old = os.environ.get("SMPC_FULL_PARTS")
+    os.environ["SMPC_FULL_PARTS"] = str(parts)
+    try:
+        gm, rb, _, _ = (S.make_talos_product if talos else S.make_full_product)(B, max_iters=iters, lib=lib, horizon=horizon)
+    finally:
+        os.environ.pop("SMPC_FULL_PARTS", None)
+        if old is not None:
+            os.environ["SMPC_FULL_PARTS"] = old
+    if talos:
+        gm.generateCycleHorizon(O.walk_cycle())
+        gm.switchToWalk(np.array([0.1, 0, 0, 0, 0, 0.0]))
+        X = np.tile(S.talos_random_states(rb, 64, scale=scale), ((B + 63) // 64, 1))[:B]
+    else:
+        gm.generateCycleHorizon(O.trot_cycle())
+        gm.switchToWalk(np.array([0.2, 0, 0, 0, 0, 0.0]))
+        X = S.random_states(rb, B, scale=scale)
+    out = []
+    for _ in range(steps):
+        gm.iterate(X)
+        out.append((gm.xs.copy(), gm.us.copy(), gm.K0.copy(), gm.info.copy()))
+        X = gm.xs[:, 1, :].copy()
+    return out
+
+
+def test_emulated_kernels_parts_are_bit_identical(built):
+    """Instances are independent: the batch as parts on separate streams (per-part views of every buffer, per-part backtracking lists,
+    per-part slices of the derivative kernel's device scratch) changes nothing, bit for bit.  130 instances: parts of 65."""
+    a = _parts_run(S.emu_lib(), 1, 130, 2, 2, 6, scale=2.0)
+    b = _parts_run(S.emu_lib(), 2, 130, 2, 2, 6, scale=2.0)
+    for sa, sb in zip(a, b):
+        for u, v in zip(sa, sb):
+            assert np.array_equal(u, v)
+    assert any((s[3][:, 2] < 1.0).any() for s in a), "the scenario must backtrack (per-part backtracking lists)"
+
+
+@pytest.mark.gpu
+def test_hip_parts_are_bit_identical(built):
+    """The same on the device, biped (derivative blocks in device memory), B = 512."""
+    a = _parts_run(None, 1, 512, 3, 2, 100, scale=0.7, talos=True)
+    for n in (2, 3):
+        b = _parts_run(None, n, 512, 3, 2, 100, scale=0.7, talos=True)
+        for sa, sb in zip(a, b):
+            for u, v in zip(sa, sb):
+                assert np.array_equal(u, v)
+
+
 @pytest.mark.gpu
 def test_hip_full_size_properties(built):
     """B = 1024, H = 100 (the batch and horizon of BASELINE's full-dynamics configuration, on the Go2 table): 16 distinct states
