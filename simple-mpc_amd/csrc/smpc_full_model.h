@@ -39,7 +39,8 @@ namespace smpc
     static constexpr bool KINO = KIN_ != 0;
     // The two widest derivative blocks of a stage (R1, JT: FullDerivWide, smpc_full_stage.h) in a per-block slice of device memory instead of
     // LDS: where that buys a third resident block per CU (the biped: full dynamics 73.9 KB -> 53.0 KB, kinodynamics variant 68.7 KB -> 53.3 KB;
-    // the quadruped already runs four)
+    // the quadruped already runs four -- with its blocks in device memory five fit (31.6 KB), two of them share a SIMD and the launch goes
+    // 11.9 -> 13.0 ms: measured, not taken)
     static constexpr bool WIDE_DEV = NJ_ > 16;
     static constexpr int NJ = NJ_;     // joints incl. free-flyer
     static constexpr int NF = NF_;     // feet
