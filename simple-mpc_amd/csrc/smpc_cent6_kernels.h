@@ -641,46 +641,109 @@ namespace smpc
       part[lane] = 0.0;
     }
     SMPC_LANES_END_WAVE
-    for (int t = 0; t < H; t++)
-    {
+    // What a lane needs of a stage -- its rows of [K k], [Z z], [A | B], P~ and the vector entries beside them -- is read one stage AHEAD into
+    // registers (none of it depends on the sweep's state): the loads of stage t + 1 fly while stage t computes.  (First form: every phase
+    // waited for its own loads, 3 x 100 exposed round trips to device memory per launch: 0.39 ms.)
+    static_assert(NU <= NT && NC <= NT, "one row of K / Z per lane");
+    SMPC_PLA(double, kr, NT, 10);  // lane < NU: K row (9) | k
+    SMPC_PLA(double, zr, NT, 10);  // lane < NC: Z row (9) | z
+    SMPC_PLA(double, ab, NT, 9 + D::NU); // lane < 9: A row | B row
+    SMPC_PLA(double, pr, NT, 9);   // lane < 9: P~ row
+    SMPC_PLA(double, sv, NT, 8);   // lu_i | d_r, vpd_r | f_i, pn_i, lx_i, lpd_i
+    auto fetch = [&](int t) {
       const double * lq = ka.sb.lq + (inst * H + t) * DD::LQ_STRIDE;
       const double * g = ka.sb.gains + (inst * H + t) * DD::G_STRIDE;
+      SMPC_LANES(NT)
+      {
+        const int i = lane < NU ? lane : 0, r = lane < NC ? lane : 0, x = lane < 9 ? lane : 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+        {
+          SMPC_PLV(kr)[j] = g[DD::G_K + i * (NP + 1) + j];
+          SMPC_PLV(zr)[j] = g[DD::G_Z + r * (NP + 1) + j];
+          SMPC_PLV(ab)[j] = lq[DD::O_A + x * NP + j];
+          SMPC_PLV(pr)[j] = g[DD::G_Pt + x * NP + j];
+        }
+        SMPC_PLV(kr)[9] = g[DD::G_K + i * (NP + 1) + NP];
+        SMPC_PLV(zr)[9] = g[DD::G_Z + r * (NP + 1) + NP];
+#pragma unroll
+        for (int j = 0; j < NU; j++)
+          SMPC_PLV(ab)[9 + j] = lq[DD::O_B + x * NU + j];
+        SMPC_PLV(sv)[0] = lq[DD::O_lu + i];
+        SMPC_PLV(sv)[1] = lq[DD::O_d + NU + r];
+        SMPC_PLV(sv)[2] = lq[DD::O_vpd + NU + r];
+        SMPC_PLV(sv)[3] = lq[DD::O_f + x];
+        SMPC_PLV(sv)[4] = g[DD::G_pn + x];
+        SMPC_PLV(sv)[5] = lq[DD::O_lx + x];
+        SMPC_PLV(sv)[6] = lq[DD::O_lpd + x];
+      }
+      SMPC_LANES_END_WAVE
+    };
+    SMPC_PLA(double, ck, NT, 10);
+    SMPC_PLA(double, cz, NT, 10);
+    SMPC_PLA(double, cab, NT, 9 + D::NU);
+    SMPC_PLA(double, cp, NT, 9);
+    SMPC_PLA(double, cs, NT, 8);
+    fetch(0);
+    for (int t = 0; t < H; t++)
+    {
       const size_t lt = inst * H + t;
       SMPC_LANES(NT)
-      for (int i = lane; i < NU; i += NT)
-      {
-        const double * Kr = g + DD::G_K + i * (NP + 1);
-        double acc = Kr[NP];
+      { // this stage's operands out of the prefetch registers
+#pragma unroll
+        for (int j = 0; j < 10; j++)
+        {
+          SMPC_PLV(ck)[j] = SMPC_PLV(kr)[j];
+          SMPC_PLV(cz)[j] = SMPC_PLV(zr)[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 9 + NU; j++)
+          SMPC_PLV(cab)[j] = SMPC_PLV(ab)[j];
+#pragma unroll
         for (int j = 0; j < 9; j++)
-          acc += Kr[j] * dx[j];
-        du[i] = acc;
-        b.dus[lt * NU + i] = acc;
-        part[lane] += lq[DD::O_lu + i] * acc;
+          SMPC_PLV(cp)[j] = SMPC_PLV(pr)[j];
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+          SMPC_PLV(cs)[j] = SMPC_PLV(sv)[j];
+      }
+      SMPC_LANES_END_WAVE
+      if (t + 1 < H)
+        fetch(t + 1);
+      SMPC_LANES(NT)
+      if (lane < NU)
+      {
+        double acc = SMPC_PLV(ck)[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+          acc += SMPC_PLV(ck)[j] * dx[j];
+        du[lane] = acc;
+        b.dus[lt * NU + lane] = acc;
+        part[lane] += SMPC_PLV(cs)[0] * acc;
       }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
       {
-        for (int r = lane; r < NC; r += NT)
+        if (lane < NC)
         {
-          const double * Zr = g + DD::G_Z + r * (NP + 1);
-          double dnu = Zr[NP];
+          double dnu = SMPC_PLV(cz)[9];
+#pragma unroll
           for (int j = 0; j < 9; j++)
-            dnu += Zr[j] * dx[j];
-          const double d = lq[DD::O_d + NU + r];
-          b.dvs[lt * NC + r] = dnu;
-          part[lane] += lq[DD::O_vpd + NU + r] * (mu * dnu - d) - d * dnu;
+            dnu += SMPC_PLV(cz)[j] * dx[j];
+          const double d = SMPC_PLV(cs)[1];
+          b.dvs[lt * NC + lane] = dnu;
+          part[lane] += SMPC_PLV(cs)[2] * (mu * dnu - d) - d * dnu;
         }
         if (lane < 9)
         {
-          const double * Ar = lq + DD::O_A + lane * NP;
-          const double * Br = lq + DD::O_B + lane * NU;
           double acc = 0.0;
+#pragma unroll
           for (int j = 0; j < 9; j++)
-            acc += Ar[j] * dx[j];
+            acc += SMPC_PLV(cab)[j] * dx[j];
+#pragma unroll
           for (int j = 0; j < NU; j++)
-            acc += Br[j] * du[j];
-          const double fi = lq[DD::O_f + lane], pn = g[DD::G_pn + lane];
-          part[lane] += (lq[DD::O_lx + lane] - lpd_prev[lane]) * dx[lane] + lq[DD::O_lpd + lane] * acc;
+            acc += SMPC_PLV(cab)[9 + j] * du[j];
+          const double fi = SMPC_PLV(cs)[3], pn = SMPC_PLV(cs)[4];
+          part[lane] += (SMPC_PLV(cs)[5] - lpd_prev[lane]) * dx[lane] + SMPC_PLV(cs)[6] * acc;
           y[lane] = acc + fi - mu * pn;
         }
       }
@@ -688,16 +751,16 @@ namespace smpc
       SMPC_LANES(NT)
       if (lane < 9)
       {
-        const double * Pr = g + DD::G_Pt + lane * NP;
         double w = 0.0;
+#pragma unroll
         for (int j = 0; j < 9; j++)
-          w += Pr[j] * y[j];
+          w += SMPC_PLV(cp)[j] * y[j];
         const double dxn = y[lane] - mu * w;
-        const double dl = w + g[DD::G_pn + lane];
+        const double dl = w + SMPC_PLV(cs)[4];
         b.dxs[(inst * (H + 1) + t + 1) * 9 + lane] = dxn;
         b.dlams[lt * 9 + lane] = dl;
-        part[lane] -= lq[DD::O_f + lane] * dl;
-        lpd_prev[lane] = lq[DD::O_lpd + lane];
+        part[lane] -= SMPC_PLV(cs)[3] * dl;
+        lpd_prev[lane] = SMPC_PLV(cs)[6];
         dx[lane] = dxn;
       }
       SMPC_LANES_END_WAVE
