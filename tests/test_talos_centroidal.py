@@ -132,6 +132,44 @@ def test_emulated_kernels_reproduce_golden_closed_loop(built, tag):
     _golden(tag, S.emu_lib())
 
 
+def _two_pass_line_search(lib, steps):
+    """SMPC_CENT6_LS_PASSES=2 (the full step first, the backtracking candidates where it failed: smpc_cent6_kernels.h) against the default (every
+    candidate in one launch): the same kernels over other candidate ranges -- bit-identical trajectories, in a scenario that backtracks."""
+    import os
+
+    def run(passes):
+        old = os.environ.get("SMPC_CENT6_LS_PASSES")
+        os.environ["SMPC_CENT6_LS_PASSES"] = str(passes)
+        try:
+            gm, rb, _, _ = S.make_talos_cent_product(3, max_iters=2, lib=lib, horizon=20, settings_override=TIGHT, mpc_override=SHORT["mpc_override"])
+        finally:
+            os.environ.pop("SMPC_CENT6_LS_PASSES", None)
+            if old is not None:
+                os.environ["SMPC_CENT6_LS_PASSES"] = old
+        gm.generateCycleHorizon(SHORT["cycle"])
+        gm.switchToWalk(np.array([0.1, 0, 0, 0, 0, 0.0]))
+        out = []
+        for step in range(steps):
+            gm.iterate(S.talos_random_states(rb, 3, seed=step, scale=0.5))
+            out.append((gm.xs.copy(), gm.us.copy(), gm.vs.copy(), gm.info.copy(), gm.getStateDerivative(0).copy(), gm.getStateDerivative(1).copy()))
+        return out
+
+    a, b = run(1), run(2)
+    for sa, sb in zip(a, b):
+        for u, v in zip(sa, sb):
+            assert np.array_equal(u, v)
+    assert any((s[3][:, 2] < 1.0).any() for s in a), "the scenario must backtrack"
+
+
+def test_emulated_kernels_two_pass_line_search(built):
+    _two_pass_line_search(S.emu_lib(), 8)
+
+
+@pytest.mark.gpu
+def test_hip_two_pass_line_search(built):
+    _two_pass_line_search(None, 8)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["loop", "cone"])
 def test_hip_reproduces_golden_closed_loop(built, tag):
