@@ -195,7 +195,10 @@ def _device(lib, tol):
 
 
 def test_emulated_kernels_follow_the_oracle_and_the_golden_vectors(built):
-    _device(S.emu_lib(), 1e-6)  # (100 fixed iterations from random states: the equality rows carry 1e3 rho, their rounding shows at 2e-7)
+    # 100 fixed iterations per tick, warm-started: the cold ticks agree to 1e-10, the warm ones to 1e-7 .. 1e-6 -- the rho adaptation takes its
+    # estimate rho sqrt(r_prim / r_dual) from a dual residual that is rounding noise by then (1e-9 .. 1e-10), so the two sides run slightly
+    # different rho from the second tick on (the converged-answer tests below are not affected)
+    _device(S.emu_lib(), 1e-6)
 
 
 @pytest.mark.gpu
