@@ -722,7 +722,10 @@ def fulldynamics_line(batch, iters, steps, warmup, device_id, with_cpu=True, rob
         der = both_bounds(None if fl is None else batch * (H + 1) * fl, batch * H * lq_bytes, avgd, "mfma" if fl is not None else "hbm")
         tr, src = pmc_traffic("fdyn_deriv_body_" + tag, at_record)
         der.update({"kernel": "fdyn_deriv_body (constrained dynamics, derivatives, Gauss-Newton knot)",
-                    "note": "FP64 bound: algorithmic FLOPs per stage counted by instrumentation in the oracle (profiles/flop_counts.json)",
+                    "note": "FP64 bound: algorithmic FLOPs per stage counted by instrumentation in the oracle (profiles/flop_counts.json)"
+                            + ("; `traffic` above the algorithmic bytes (the knot) is the per-block device slice of the derivative blocks R1 / JT "
+                               "(24.4 KB per block, written and re-read three times by the solve chain: DESIGN 3.9a) -- scratch that buys the third "
+                               "resident block per CU, not re-reads of the inputs" if talos else ""),
                     "traffic": tr, "traffic_source": src})
         dom_deriv = kt["deriv"][0] >= kt["riccati"][0]  # the dominant kernel carries the line's roofline
         out["roofline"] = der if dom_deriv else ric
@@ -826,7 +829,8 @@ def talos_flat_feet_line(kind, batch, iters, steps, warmup, device_id, with_cpu=
         der = both_bounds(None, batch * H * lq_bytes, kt["deriv"][0] / kt["deriv"][1] * 1e-3, "hbm")
         tr, src = pmc_traffic(("cent6_deriv_body" if cent else "fdyn_deriv_body_taloskino"), at_record)
         der.update({"kernel": ("cent6_deriv_body" if cent else "fdyn_deriv_body<kinodynamics variant>") + " (stage evaluation, derivatives, Gauss-Newton knot)",
-                    "note": "HBM side: the dense knot the stage kernel writes (the oracle's FLOP count exists for the full-dynamics stage only)",
+                    "note": "HBM side: the dense knot the stage kernel writes (the oracle's FLOP count exists for the full-dynamics stage only)"
+                            + ("" if cent else "; `traffic` above it is the per-block device slice of the derivative blocks R1 / JT / Cv (DESIGN 3.9a)"),
                     "traffic": tr, "traffic_source": src})
         dom_deriv = kt["deriv"][0] >= kt["riccati"][0]
         out["roofline"] = der if dom_deriv else ric

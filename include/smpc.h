@@ -294,7 +294,7 @@ int smpc_set_profiling(smpc_handle * h, int enabled);
 /* number of kernel slots this library reports (9 today; grows when kernels are added) */
 int smpc_kernel_time_slots(void);
 /* the first min(n, smpc_kernel_time_slots()) slots into ms[n], calls[n].  Centroidal handles: frontend, step (6-D feet: recede), deriv, riccati,
- * forward, line search. */
+ * forward, line search, and for 6-D feet the candidate kernel of the line search in the slot behind them. */
 int smpc_get_kernel_times_n(smpc_handle * h, double * ms, long * calls, int n);
 /* the same without a capacity: writes smpc_kernel_time_slots() entries -- size the arrays with that call, or use the _n form */
 int smpc_get_kernel_times(smpc_handle * h, double * ms, long * calls);
