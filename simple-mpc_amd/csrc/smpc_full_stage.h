@@ -243,24 +243,28 @@ namespace smpc
   // C (M x N) = init(i, j) + sum_k a(i, k) b(k, j) on the FP64 matrix cores, one wave; a / b read their operand entries (LDS, or device memory: the
   // fetch of K-step k + 1 is in flight during step k), store(i, j, v) receives every entry once after the last K-step (so C may overwrite an
   // operand).  K-steps of 4, 16 x 16 tiles.  `init` makes a read-modify-write pass one product: all its reads are issued before the first K-step.
-  template <int M, int N, int K, class FA, class FB, class FI, class FS_>
+  // PF = K-steps the operand fetch runs ahead (1: an LDS round trip is shorter than a K-step's matrix instructions; 2: operands in device memory --
+  // a K-step of 10 instructions is 640 cycles, an L2 round trip more).
+  template <int M, int N, int K, int PF = 1, class FA, class FB, class FI, class FS_>
   SMPC_DEV void fwave_gemm(FA a, FB b, FI init, FS_ store);
-  template <int M, int N, int K, class FA, class FB, class FS_>
+  template <int M, int N, int K, int PF = 1, class FA, class FB, class FS_>
   SMPC_DEV void fwave_gemm(FA a, FB b, FS_ store)
   {
-    fwave_gemm<M, N, K>(a, b, [](int, int) { return 0.0; }, store);
+    fwave_gemm<M, N, K, PF>(a, b, [](int, int) { return 0.0; }, store);
   }
-  template <int M, int N, int K, class FA, class FB, class FI, class FS_>
+  template <int M, int N, int K, int PF, class FA, class FB, class FI, class FS_>
   SMPC_DEV void fwave_gemm(FA a, FB b, FI init, FS_ store)
   {
+    static_assert(PF == 1 || PF == 2, "operand sets");
+    constexpr int NS = PF + 1;
     constexpr int NT = 64, TI = (M + 15) / 16, TJ = (N + 15) / 16, KS = (K + 3) / 4;
     SMPC_ACC(acc, NT, TI * TJ);
     // two operand sets: the LDS reads of K-step k + 1 are issued before the matrix instructions of step k, so that with one
     // resident wave per SIMD the matrix pipe does not idle through every LDS round trip
-    SMPC_PLA(double, av, NT, 2 * TI);
-    SMPC_PLA(double, bv, NT, 2 * TJ);
+    SMPC_PLA(double, av, NT, NS * TI);
+    SMPC_PLA(double, bv, NT, NS * TJ);
     auto fetch = [&](int ks) {
-      const int ob = ks & 1;
+      const int ob = ks % NS;
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
@@ -302,12 +306,14 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
     fetch(0);
+    if (PF == 2 && KS > 1)
+      fetch(1);
 #pragma unroll
     for (int ks = 0; ks < KS; ks++)
     {
-      if (ks + 1 < KS)
-        fetch(ks + 1);
-      const int ob = ks & 1;
+      if (ks + PF < KS)
+        fetch(ks + PF);
+      const int ob = ks % NS;
 #pragma unroll
       for (int I = 0; I < TI; I++)
 #pragma unroll
@@ -1749,19 +1755,19 @@ namespace smpc
     ftick(fp, 11);
     // ---- [M -J^T; J mu] [da; dlam] = -[r1; r2]:  Mr = M^-1 R1 ; rhs = J Mr - r2 ; dlam = G^-1 rhs ; da = -Mr + M^-1 J^T dlam ----
     // Mr = M^-1 R1 (in place)
-    fwave_gemm<NV, NCOL, NV>(
+    fwave_gemm<NV, NCOL, NV, D::WIDE_DEV ? 2 : 1>(
       [&](int i, int k) { return sc.M[k * NV + i]; }, [&](int k, int j) { return sw.R1[k * NCOL + j]; },
       [&](int i, int j, double v) { sw.R1[i * NCOL + j] = v; });
     // rhs = J Mr - r2 (in place on the force rows of JT)
-    fwave_gemm<NCM, NCOL, NV>(
+    fwave_gemm<NCM, NCOL, NV, D::WIDE_DEV ? 2 : 1>(
       [&](int i, int k) { return sc.J[i * NV + k]; }, [&](int k, int j) { return sw.R1[k * NCOL + j]; },
       [&](int i, int j) { return -sw.JT[i * NCOL + j]; }, [&](int i, int j, double v) { sw.JT[i * NCOL + j] = v; });
     // dlam = G^-1 rhs (in place)
-    fwave_gemm<NCM, NCOL, NCM>(
+    fwave_gemm<NCM, NCOL, NCM, D::WIDE_DEV ? 2 : 1>(
       [&](int i, int k) { return sc.Gi[k * NCM + i]; }, [&](int k, int j) { return sw.JT[k * NCOL + j]; },
       [&](int i, int j, double v) { sw.JT[i * NCOL + j] = v; });
     // da = -Mr + M^-1 J^T dlam (in place on R1)
-    fwave_gemm<NV, NCOL, NCM>(
+    fwave_gemm<NV, NCOL, NCM, D::WIDE_DEV ? 2 : 1>(
       [&](int i, int k) { return sc.W[i * NR + 1 + k]; }, [&](int k, int j) { return sw.JT[k * NCOL + j]; },
       [&](int i, int j) { return -sw.R1[i * NCOL + j]; }, [&](int i, int j, double v) { sw.R1[i * NCOL + j] = v; });
     full_gn_rows<D>(sc, sd, false);
@@ -2107,8 +2113,19 @@ namespace smpc
       else if (!term)
         g = sc.Wru[k - NDX];
       // (terminal node: only the momentum rows exist)
-      for (int r = term ? NCM : 0; r < (term ? NCM + 6 : NGN); r++)
-        g += (r < NCM ? sw.JT[r * NCOL + k] : sc.jt2_()[(r - NCM) * NCOL + k]) * sd.dual_()[r];
+      // (the force rows may lie in device memory: the column's entries are read together, not one per pass of the sum)
+      double jtc[NCM];
+#pragma unroll
+      for (int r = 0; r < NCM; r++)
+        jtc[r] = term ? 0.0 : sw.JT[r * NCOL + k];
+      if (!term)
+      {
+#pragma unroll
+        for (int r = 0; r < NCM; r++)
+          g += jtc[r] * sd.dual_()[r];
+      }
+      for (int r = NCM; r < (term ? NCM + 6 : NGN); r++)
+        g += sc.jt2_()[(r - NCM) * NCOL + k] * sd.dual_()[r];
       if (k < NDX)
         sd.gx_()[k] = g;
       else
@@ -2129,8 +2146,11 @@ namespace smpc
       }
       else if constexpr (D::NCONE > 0)
         if (!term)
+        {
+#pragma unroll
           for (int r = 0; r < NCM; r++)
-            cqv += sw.JT[r * NCOL + k] * sd.yc_()[r];
+            cqv += jtc[r] * sd.yc_()[r];
+        }
       if constexpr (D::NLAND > 0)
         if (land != 0u && k < NDX) // land rows: C_x^T nu (rows of the state only)
           for (int f = 0; f < NF; f++)

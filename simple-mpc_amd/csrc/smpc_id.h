@@ -1175,7 +1175,7 @@ namespace smpc
         s.xl[lane] = lane < N ? SMPC_PLV(rb) : 0.0;
       }
       SMPC_LANES_END_WAVE
-      fwave_gemm<N, N, DR>(
+      fwave_gemm<N, N, DR, 2>( // (operands from the assembled QP in device memory: fetched two K-steps ahead)
         [&](int i, int k) { return s.rd[k] * Cg[drow(k) * NP + i]; }, [&](int k, int j) { return Cg[drow(k) * NP + j]; },
         [&](int i, int j, double v) {
           double kk = Hg[i * NP + j] + (i == j ? sigma + s.xl[i] : 0.0);
