@@ -308,7 +308,10 @@ namespace smpc
           {
             v = i == j ? preg : 0.0;
             if (i >= 3 && i / 3 == j / 3)
-              v += (i < 6 ? md.w_lm : md.w_am)[(i % 3) * 3 + j % 3];
+            {
+              const double * W = i < 6 ? md.w_lm : md.w_am; // (pointer first: g++ 11 with -fsanitize=shift miscompiles the indexed conditional of two arrays)
+              v += W[(i % 3) * 3 + j % 3];
+            }
           }
           QN[idx] = v;
         }
@@ -519,7 +522,10 @@ namespace smpc
         {
           q = i == j ? preg : 0.0;
           if (i / 3 == j / 3)
-            q += (i < 3 ? md.w_com : (i < 6 ? md.w_lm : md.w_am))[(i % 3) * 3 + j % 3];
+          {
+            const double * W = i < 3 ? md.w_com : (i < 6 ? md.w_lm : md.w_am);
+            q += W[(i % 3) * 3 + j % 3];
+          }
           for (int r = 0; r < 6; r++)
             q += s.J[r * NXU + i] * s.WJ[r * NXU + j];
         }
@@ -649,7 +655,7 @@ namespace smpc
     SMPC_PLA(double, zr, NT, 10);  // lane < NC: Z row (9) | z
     SMPC_PLA(double, ab, NT, 9 + D::NU); // lane < 9: A row | B row
     SMPC_PLA(double, pr, NT, 9);   // lane < 9: P~ row
-    SMPC_PLA(double, sv, NT, 8);   // lu_i | d_r, vpd_r | f_i, pn_i, lx_i, lpd_i
+    SMPC_PLA(double, sv, NT, 8);   // lu_i | d_r, vpd_r | f_i, pn_i, lx_i, lpd_i | act_r
     auto fetch = [&](int t) {
       const double * lq = ka.sb.lq + (inst * H + t) * DD::LQ_STRIDE;
       const double * g = ka.sb.gains + (inst * H + t) * DD::G_STRIDE;
@@ -676,6 +682,7 @@ namespace smpc
         SMPC_PLV(sv)[4] = g[DD::G_pn + x];
         SMPC_PLV(sv)[5] = lq[DD::O_lx + x];
         SMPC_PLV(sv)[6] = lq[DD::O_lpd + x];
+        SMPC_PLV(sv)[7] = lq[DD::O_act + NU + r];
       }
       SMPC_LANES_END_WAVE
     };
@@ -703,7 +710,7 @@ namespace smpc
         for (int j = 0; j < 9; j++)
           SMPC_PLV(cp)[j] = SMPC_PLV(pr)[j];
 #pragma unroll
-        for (int j = 0; j < 7; j++)
+        for (int j = 0; j < 8; j++)
           SMPC_PLV(cs)[j] = SMPC_PLV(sv)[j];
       }
       SMPC_LANES_END_WAVE
@@ -725,11 +732,13 @@ namespace smpc
       {
         if (lane < NC)
         {
+          const double d = SMPC_PLV(cs)[1];
           double dnu = SMPC_PLV(cz)[9];
 #pragma unroll
           for (int j = 0; j < 9; j++)
             dnu += SMPC_PLV(cz)[j] * dx[j];
-          const double d = SMPC_PLV(cs)[1];
+          if (SMPC_PLV(cs)[7] == 0.0)
+            dnu = d / mu; // inactive row: Z = 0, z = d / mu -- the sweep writes no [Z z] for it in the stages of the light grid (what was read is stale)
           b.dvs[lt * NC + lane] = dnu;
           part[lane] += SMPC_PLV(cs)[2] * (mu * dnu - d) - d * dnu;
         }

@@ -466,7 +466,10 @@ namespace smpc
           const int i = idx / 9, j = idx % 9;
           double v = i == j ? preg : 0.0;
           if (i >= 3 && i / 3 == j / 3)
-            v += (i < 6 ? md.w_lm : md.w_am)[(i % 3) * 3 + j % 3];
+          {
+            const double * W = i < 6 ? md.w_lm : md.w_am;
+            v += W[(i % 3) * 3 + j % 3];
+          }
           s.P[idx] = v;
         }
         if (lane < 9)

@@ -377,7 +377,8 @@ namespace smpc
               double v = i == j ? preg : 0.0;
               if (i >= 3 && i / 3 == j / 3)
               {
-                const double w = (i < 6 ? md.w_lm : md.w_am)[(i % 3) * 3 + j % 3];
+                const double * W = i < 6 ? md.w_lm : md.w_am; // (pointer first: g++ 11 with -fsanitize=shift miscompiles the indexed conditional of two arrays)
+                const double w = W[(i % 3) * 3 + j % 3];
                 v += w;
                 g += w * xH[j];
               }

@@ -238,11 +238,15 @@ namespace smpc
         // dense rows (wrench cones): dnu = Z dx + z from the explicitly pivoted multipliers
         for (int r = NU + NA + lane; r < NU + NA + D::NCD; r += NT)
         {
-          const double * Zr = g + D::G_Z + (r - NU - NA) * (NDX + 1);
-          double dnu = Zr[NDX];
-          for (int j = 0; j < NDX; j++)
-            dnu += Zr[j] * dx[j];
           const double d = lq[D::O_d + r];
+          double dnu = d / mu; // inactive row: Z = 0, z = d / mu (riccati_dense_body writes no [Z z] for it in the stages of the light grid)
+          if (lq[D::O_act + r] != 0.0)
+          {
+            const double * Zr = g + D::G_Z + (r - NU - NA) * (NDX + 1);
+            dnu = Zr[NDX];
+            for (int j = 0; j < NDX; j++)
+              dnu += Zr[j] * dx[j];
+          }
           b.dvs[lt * NC + r] = dnu;
           part[lane] += lq[D::O_vpd + r] * (mu * dnu - d) - d * dnu;
         }
