@@ -2518,8 +2518,8 @@ namespace smpc
     for (int m = slot; m < count; m += stride)
     {
       const int inst = ka.slots > 0 ? ka.b.und_list[m] : m;
-      if (ka.slots == 0 && ka.b.ls_sel[inst] >= 0)
-        break;
+      if (ka.b.ls_sel[inst] >= 0) // decided (list mode: by an earlier batch of backtracking candidates -- the list is the one compacted before the first)
+        continue;
       for (int jj = 0; jj < ka.nj; jj++)
         fdyn_trial_one<D>(ka, inst, t, ka.j0 + jj);
     }

@@ -465,9 +465,30 @@ namespace smpc
         if (ka.j0 == 0)
         {
           double phi = 0.0, cost = 0.0, prim = 0.0, dual = 0.0;
-          for (int t = 0; t <= H; t++)
+          // (eight stages' partials are read together, then added in stage order: the sums are those of the plain loop, the chain of dependent
+          //  round trips to memory is an eighth as long -- a lane owns an instance here, its reads are strided)
+          const double * p0 = b.parts0 + (size_t)inst * (H + 1) * 4;
+          int t = 0;
+          for (; t + 8 <= H + 1; t += 8)
           {
-            const double * p = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
+            double v[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+              for (int c = 0; c < 4; c++)
+                v[k][c] = p0[(t + k) * 4 + c];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+              phi += v[k][0];
+              cost += v[k][1];
+              prim = fmax(prim, v[k][2]);
+              dual = fmax(dual, v[k][3]);
+            }
+          }
+          for (; t <= H; t++)
+          {
+            const double * p = p0 + t * 4;
             phi += p[0];
             cost += p[1];
             prim = fmax(prim, p[2]);
@@ -499,11 +520,28 @@ namespace smpc
           {
             const int j = ka.j0 + jj;
             double phi = 0.0, prim = 0.0;
-            for (int t = 0; t <= H; t++)
+            const double * pT = b.partsT + ((size_t)inst * D::LS_N + j) * (H + 1) * 2;
+            int t = 0;
+            for (; t + 8 <= H + 1; t += 8)
             {
-              const double * p = b.partsT + (((size_t)inst * D::LS_N + j) * (H + 1) + t) * 2;
-              phi += p[0];
-              prim = fmax(prim, p[1]);
+              double v[8][2];
+#pragma unroll
+              for (int k = 0; k < 8; k++)
+              {
+                v[k][0] = pT[(t + k) * 2];
+                v[k][1] = pT[(t + k) * 2 + 1];
+              }
+#pragma unroll
+              for (int k = 0; k < 8; k++)
+              {
+                phi += v[k][0];
+                prim = fmax(prim, v[k][1]);
+              }
+            }
+            for (; t <= H; t++)
+            {
+              phi += pT[t * 2];
+              prim = fmax(prim, pT[t * 2 + 1]);
             }
             const bool ok = phi <= phi0 + ka.armijo_c1 * alpha * dphi0;
             const bool last = j == D::LS_N - 1;
@@ -658,100 +696,49 @@ namespace smpc
     }
     SMPC_LANES(NT)
     {
-      constexpr int NL = NX - 7; // linear entries of a state: joints (q[7:]) and velocities
-      for (int idx = lane; idx < (H + 1) * NL; idx += NT)
-      {
-        const int t = idx / NL, k = idx % NL; // k-th linear entry: x[7 + k] <-> dx[6 + k]
-        const size_t o = (ib + ring_slot(ka.head, t, R)) * NX + 7 + k;
-        if (restore)
-          b.xs[o] = b.xs_b[o];
-        else
+      // flat streams over the instance's ring: entry i of node t of `dst` (n entries per node behind offset `doff`, `dn` doubles per ring slot)
+      // += alpha * entry `soff + i` of node t of `step` (`sn` doubles per node, `nodes_s` nodes per instance).  Four entries per lane are read
+      // before the first is written: a store and the next entry's loads are the same arrays as far as the compiler knows, and taken one by one
+      // every entry waited for the round trip of the one before it (0.16 ms per launch for 4096 quadrupeds, 0.34 ms for 1024 bipeds)
+      auto stream = [&](double * dst, double * bak, const double * step, int n, int nodes, int dn, int doff, int sn, int soff, int nodes_s) {
+        const int total = nodes * n;
+        for (int idx0 = lane; idx0 < total; idx0 += 4 * NT)
         {
-          const double v = b.xs[o];
-          if (tent)
-            b.xs_b[o] = v;
-          b.xs[o] = v + alpha * b.dxs[((size_t)inst * (H + 1) + t) * NDX + 6 + k];
-        }
-      }
-      // controls and multipliers: ring slot of node t, flat over (t, i)
-      for (int idx = lane; idx < H * NU; idx += NT)
-      {
-        const int t = idx / NU, i = idx % NU;
-        const size_t o = (ib + ring_slot(ka.head, t, R)) * NU + i;
-        if (restore)
-          b.us[o] = b.us_b[o];
-        else
-        {
-          const double v = b.us[o];
-          if (tent)
-            b.us_b[o] = v;
-          b.us[o] = v + alpha * b.dus[((size_t)inst * H + t) * NU + i];
-        }
-      }
-      for (int idx = lane; idx < H * NC; idx += NT)
-      {
-        const int t = idx / NC, i = idx % NC;
-        const size_t o = (ib + ring_slot(ka.head, t, R)) * NC + i;
-        if (restore)
-          b.vs[o] = b.vs_b[o];
-        else
-        {
-          const double v = b.vs[o];
-          if (tent)
-            b.vs_b[o] = v;
-          b.vs[o] = v + alpha * b.dvs[((size_t)inst * H + t) * NC + i];
-        }
-      }
-      for (int idx = lane; idx < H * NDX; idx += NT)
-      {
-        const int t = idx / NDX, i = idx % NDX;
-        const size_t o = (ib + ring_slot(ka.head, t, R)) * NDX + i;
-        if (restore)
-          b.lams[o] = b.lams_b[o];
-        else
-        {
-          const double v = b.lams[o];
-          if (tent)
-            b.lams_b[o] = v;
-          b.lams[o] = v + alpha * b.dlams[((size_t)inst * H + t) * NDX + i];
-        }
-      }
-      if (b.es != nullptr)
-      { // multipliers of the friction-cone rows
-        constexpr int NE = 2 * D::NF;
-        for (int idx = lane; idx < H * NE; idx += NT)
-        {
-          const int t = idx / NE, i = idx % NE;
-          const size_t o = (ib + ring_slot(ka.head, t, R)) * NE + i;
-          if (restore)
-            b.es[o] = b.es_b[o];
-          else
+          size_t o[4];
+          double v[4], d[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
           {
-            const double v = b.es[o];
-            if (tent)
-              b.es_b[o] = v;
-            b.es[o] = v + alpha * b.des[((size_t)inst * H + t) * NE + i];
+            const int idx = idx0 + k * NT;
+            const bool ok = idx < total;
+            const int t = ok ? idx / n : 0, i = ok ? idx % n : 0;
+            o[k] = (ib + ring_slot(ka.head, t, R)) * dn + doff + i;
+            v[k] = restore ? bak[o[k]] : dst[o[k]];
+            d[k] = restore ? 0.0 : step[((size_t)inst * nodes_s + t) * sn + soff + i];
           }
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (idx0 + k * NT < total)
+            {
+              if (restore)
+                dst[o[k]] = v[k];
+              else
+              {
+                if (tent)
+                  bak[o[k]] = v[k];
+                dst[o[k]] = v[k] + alpha * d[k];
+              }
+            }
         }
-      }
-      if (b.ls != nullptr)
-      { // multipliers of the land_cstr rows
-        constexpr int NL = D::NF;
-        for (int idx = lane; idx < H * NL; idx += NT)
-        {
-          const int t = idx / NL, i = idx % NL;
-          const size_t o = (ib + ring_slot(ka.head, t, R)) * NL + i;
-          if (restore)
-            b.ls[o] = b.ls_b[o];
-          else
-          {
-            const double v = b.ls[o];
-            if (tent)
-              b.ls_b[o] = v;
-            b.ls[o] = v + alpha * b.dls[((size_t)inst * H + t) * NL + i];
-          }
-        }
-      }
+      };
+      stream(b.xs, b.xs_b, b.dxs, NX - 7, H + 1, NX, 7, NDX, 6, H + 1); // linear entries of a state: x[7 + k] <-> dx[6 + k]
+      stream(b.us, b.us_b, b.dus, NU, H, NU, 0, NU, 0, H);               // controls and multipliers: ring slot of node t
+      stream(b.vs, b.vs_b, b.dvs, NC, H, NC, 0, NC, 0, H);
+      stream(b.lams, b.lams_b, b.dlams, NDX, H, NDX, 0, NDX, 0, H);
+      if (b.es != nullptr) // multipliers of the friction-cone rows
+        stream(b.es, b.es_b, b.des, 2 * D::NF, H, 2 * D::NF, 0, 2 * D::NF, 0, H);
+      if (b.ls != nullptr) // multipliers of the land_cstr rows
+        stream(b.ls, b.ls_b, b.dls, D::NF, H, D::NF, 0, D::NF, 0, H);
       if (b.CN != nullptr && lane < 3)
       { // multipliers of the terminal constraint
         const size_t o = (size_t)inst * 3 + lane;
