@@ -564,11 +564,25 @@ namespace smpc
             sc[SC_LS_INDEX] = (double)sel;
             const double preg = sc[SC_PREG];
             sc[SC_PREG] = sc[SC_LS_FAILED] != 0.0 ? fmin(preg * ka.reg_inc, ka.reg_max) : fmax(preg * ka.reg_dec, ka.reg_min);
-            for (int i = 0; i < 4 * D::NV; i++)
-              b.xdot01[(size_t)inst * 4 * D::NV + i] = b.xdotT[((size_t)inst * D::LS_N + sel) * 4 * D::NV + i];
+            // (copies of the accepted candidate's outputs: eight entries are read before the first is written, as above)
+            auto copy = [](double * dst, const double * src, int n) {
+              int i = 0;
+              for (; i + 8 <= n; i += 8)
+              {
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                  v[k] = src[i + k];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                  dst[i + k] = v[k];
+              }
+              for (; i < n; i++)
+                dst[i] = src[i];
+            };
+            copy(b.xdot01 + (size_t)inst * 4 * D::NV, b.xdotT + ((size_t)inst * D::LS_N + sel) * 4 * D::NV, 4 * D::NV);
             if (b.forcesT != nullptr)
-              for (int i = 0; i < H * b.nforce; i++)
-                b.forces[(size_t)inst * H * b.nforce + i] = b.forcesT[((size_t)inst * D::LS_N + sel) * H * b.nforce + i];
+              copy(b.forces + (size_t)inst * H * b.nforce, b.forcesT + ((size_t)inst * D::LS_N + sel) * H * b.nforce, H * b.nforce);
           }
         }
       }
