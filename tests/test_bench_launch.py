@@ -16,7 +16,10 @@ def _run(args):
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
-    return json.loads(lines[0])
+    # the driver parses the LAST stdout line: it must be that object, and short (round 5 printed 24 KB and was not parsed)
+    last = p.stdout.rstrip("\n").splitlines()[-1]
+    assert last == lines[0] and len(last) < 4096, len(last)
+    return json.loads(last)
 
 
 def test_gpus_flag_starts_that_many_ranks(built):
@@ -38,3 +41,27 @@ def test_default_batch_is_the_baseline_configuration():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "8192 if args.gpus >= 8 else 4096" in src  # 8 x 8192 = 65536 (BASELINE configs[4]); 4096 on one GPU (configs[2])
     assert 'default=100' in src and 'default=20' in src  # >= 100 timed steps after 20 warm-up steps
+
+
+def test_the_printed_line_stays_compact():
+    """compact_line on the largest line this repo has produced (round 5's 24 KB object): under the limit, every contract key kept, the
+    dominant kernel's roofline flat, the cpu_baseline present."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05g_bench.json")))
+    text = bench.compact_line(full)
+    assert len(text) < bench.LINE_LIMIT <= 3072 and "\n" not in text
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "kernel_ms", "cfg2_centroidal_steps_per_s", "cfg4_talos_fulldynamics_steps_per_s"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    rl = line["roofline"]
+    assert set(rl) <= {"bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "kernel", "traffic", "traffic_source", "peak_measured"}
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-4 and not any(isinstance(v, dict) for v in rl.values())
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    # a line that would not fit sheds its optional blocks, never the contract keys
+    fat = dict(full, kernel_ms={("k%d" % i): 1.0 for i in range(400)})
+    slim = json.loads(bench.compact_line(fat))
+    assert "kernel_ms" not in slim and "roofline" in slim and "cpu_baseline" in slim
