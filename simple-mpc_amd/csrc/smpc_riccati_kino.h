@@ -315,11 +315,14 @@ namespace smpc
     static constexpr int SCR_1 = 2 * SWP, SCR_2 = NG * NXU, SCR_3 = NG * NDX + 2 * 4 * 64;
     static constexpr int SCR = SCR_1 > SCR_2 ? (SCR_1 > SCR_3 ? SCR_1 : SCR_3) : (SCR_2 > SCR_3 ? SCR_2 : SCR_3);
     static_assert(NU * (NDX + 1) <= SCR_3, "the [K | k] staging block takes over Cc and the sweep operands");
-    double P[NDX * NDX]; // P_{t+1} -> P~ (-> E^T P~ E in place) -> P_t
+    // rows 0 .. NDX-1: P_{t+1} -> P~ (-> E^T P~ E in place) -> P_t, full symmetric image, row stride NDX.
+    // row NDX: c = p_{t+1} - f / mu, row NDX+1: p_{t+1} -> p_t -- the vector column of the bordered matrix of the first sweep is read through
+    // the same (column, row) addresses as the matrix entries: element (R, C) of a tile comes from P[C' * NDX + R'] with C' = NDX, NDX + 1 for it
+    double P[(NDX + 2) * NDX];
     // scratch, by phase:  sweep operands (2 x 4 x 80)  ->  NAB (NG x NXU)
     //                     ->  [Cc (NG x NDX) | sweep operands (2 x 4 x 64)]  ->  staging of [K | k] (NU x (NDX+1))
     double scr[SCR];
-    double p[NDX], pt0[NDX], pt[NDX], qh[NDX], rh[NU], f[NDX];
+    double pt[NDX], qh[NDX], rh[NU];
     double dc[NG], boxd[D::NA], boxact[D::NA];
     double cone[8 * D::NF]; // friction-cone rows of the stage (force_cone): active Jacobian rows (2 NF x 3) | d (2 NF)
     float sink[64]; // destination of the line touches (never read)
@@ -355,8 +358,13 @@ namespace smpc
       for (int i = lane; i < NDX * NDX; i += NT)
         s.P[i] = b.QN[(size_t)inst * NDX * NDX + i];
       for (int i = lane; i < NDX; i += NT)
-        s.p[i] = b.qN[(size_t)inst * NDX + i];
+        s.P[(NDX + 1) * NDX + i] = b.qN[(size_t)inst * NDX + i];
     }
+    SMPC_LANES_END_WAVE
+    // f of the stage, one double per lane, fetched one stage ahead
+    SMPC_PL(double, f_pf, NT);
+    SMPC_LANES(NT)
+    SMPC_PLV(f_pf) = b.lq[((size_t)inst * H + (H - 1)) * D::LQ_STRIDE + D::O_f + (lane < NDX ? lane : 0)];
     SMPC_LANES_END_WAVE
 
     double * prof = (b.dbg != nullptr && block == 0) ? b.dbg : nullptr; // optional phase timers (block 0 only)
@@ -375,25 +383,16 @@ namespace smpc
       constexpr int NAB_PL = (NG * NXU + NT - 1) / NT, CC_PL = (NG * NDX + NT - 1) / NT;
       SMPC_PLA(double, nab_pf, NT, NAB_PL);
       SMPC_PL(double, vq_pf, NT);                   // q / r of the stage (one double per lane)
-      // ---- (1) f ; save p_{t+1} ; pt0 = p + P f ----
+      // ---- (1) save p_{t+1} ; vector column of the pivot rows c = p - f / mu (see (2)) ----
       SMPC_LANES(NT)
       if (lane < NDX)
       {
-        s.f[lane] = lq[D::O_f + lane];
-        g[GK::G_pn + lane] = s.p[lane];
+        const double pv = s.P[(NDX + 1) * NDX + lane];
+        g[GK::G_pn + lane] = pv;
+        s.P[NDX * NDX + lane] = pv - imu * SMPC_PLV(f_pf);
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 0, tprev);
-      SMPC_LANES(NT)
-      if (lane < NDX)
-      {
-        double acc = s.p[lane];
-#pragma unroll 4
-        for (int j = 0; j < NDX; j++)
-          acc += s.P[j * NDX + lane] * s.f[j]; // (P is symmetric: along the row of j the lanes read consecutive addresses -- conflict-free)
-        s.pt0[lane] = acc;
-      }
-      SMPC_LANES_END_WAVE
       prof_tick(prof, 1, tprev);
       // ---- (2b) register prefetch of the dense rows of [A|B]: the latency overlaps with the P~ sweep.  (The contact rows
       //           of C and the stage vectors are fetched after the sweep, once the [A|B] registers are free again: held
@@ -411,56 +410,96 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 2, tprev);
-      // ---- (2) P~ and p~ as the Schur complement of the bordered matrix
-      //              [ I + mu P      sqrt(mu) P   sqrt(mu) pt0 ]
-      //              [ sqrt(mu) P    P            pt0          ]      (pivots: the first NDX rows, 9 panels of 4)
-      //          = P - mu P (I + mu P)^-1 P = (I + mu P)^-1 P   and   pt0 - mu P (I + mu P)^-1 pt0 = p~ ----
+      // ---- (2) P~ and p~ as the Schur complement of the bordered matrix (pivots: the first NDX rows, 9 panels of 4)
+      //              [ P + I / mu    P    c ]       c = p - f / mu
+      //              [ P             P    p ]
+      //          = P - P (P + I/mu)^-1 P = (I + mu P)^-1 P = P~   and   p - mu P~ c = p + P~ (f - mu p) = (I - mu P~)(p + P f) = p~.
+      //          (The same elimination as on [[I + mu P, sqrt(mu) P], [., P]] -- rows and columns of the pivot block scaled by 1 / sqrt(mu) --
+      //          with nothing to scale: every entry is an entry of the LDS image, at a compile-time offset from one of four per-lane bases.) ----
       {
         SMPC_ACC(t1, NT, 15);
+        static_assert(NDX == 36 && NDX % 4 == 0, "tile geometry of the bordered matrix: blocks start at 36 = 2 * 16 + 4");
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
+          // element (R, C) <- P[C' * NDX + R'],  R' = R - NDX [R >= NDX],  C' = C - NDX [C >= NDX]  (C' = NDX: the vector column)
+          const int bA = lc * NDX + lr;                                     // tile columns 0, 1, 3: C' = lc + const
+          const int bW = (lc < 4 ? lc + 32 : lc - 4) * NDX + lr;            // tile column 2: C = 32 + lc wraps at NDX
+          const int b4p = (lc < 9 ? 28 + lc : NDX + 1) * NDX + lr;          // tile column 4, pivot rows: P columns 28 .. 35, c, (padding: p)
+          const int b4s = (lc < 8 ? 28 + lc : NDX + 1) * NDX + lr;          // tile column 4, other rows: P columns 28 .. 35, p, (padding: p)
 #pragma unroll
           for (int tt = 0; tt < 15; tt++)
 #pragma unroll
             for (int v = 0; v < 4; v++)
             {
-              const int row = 16 * T5I[tt] + lr + 4 * v, col = 16 * T5J[tt] + lc;
-              const int r = row < col ? row : col, c = row < col ? col : row;
-              const int ri = r < NDX ? r : r - NDX, ci = c < NDX ? c : c - NDX; // indices into P / pt0
-              const bool isv = c == 2 * NDX && r < 2 * NDX, ism = c < 2 * NDX;
-              const double pv = s.P[(ism ? ri * NDX + ci : 0)];
-              const double tv = s.pt0[isv ? ri : 0];
-              double val = ism ? pv : (isv ? tv : 0.0);
-              const double scale = c < NDX ? mu : ((r < NDX && (ism || isv)) ? smu : 1.0);
-              val = val * scale + ((c < NDX && r == c) ? 1.0 : 0.0);
+              const int I = T5I[tt], J = T5J[tt], R0 = 16 * I + 4 * v; // (compile-time: NDX is a multiple of 4)
+              double val = 0.0;
+              if (R0 < 2 * NDX) // (rows beyond the vector row: padding)
+              {
+                const bool piv = R0 < NDX;
+                const int Rp = piv ? R0 : R0 - NDX;
+                const int base = J <= 1 ? bA + 16 * J * NDX : (J == 2 ? bW : (J == 3 ? bA + (48 - NDX) * NDX : (piv ? b4p : b4s)));
+                val = s.P[base + Rp];
+                if (piv && I == J && lc == lr + 4 * v)
+                  val += imu;
+              }
               SMPC_ACCV(t1, tt, v) = val;
             }
         }
         SMPC_LANES_END_WAVE
         prof_tick(prof, 3, tprev);
 wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 + RiccatiKinoLds<D>::SWP, prof, tprev);
+        // P~ (rows / columns NDX .. 2 NDX of the grid) -> LDS image, both halves, and -> the gains block (upper triangle packed row by row), from
+        // the registers; p~ -> pt.  One execution mask per group of stores (a predicate per store costs four scalar instructions and a branch);
+        // of a diagonal tile the upper entries only (its two halves are rounded differently: the image stays exactly symmetric).
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
+          const int bR = lr * NDX + lc, bT = lc * NDX + lr; // (row, column) and mirrored
+          const int gl = lc - lr * (lr - 1) / 2;            // packed offset of (Rp + lr, Cp + lc): const(Rp, Cp) + lr (NDX - 1 - Rp) + gl
+          auto put = [&](int tt, int v) SMPC_LAMBDA_INLINE {
+            const int I = T5I[tt], J = T5J[tt];
+            const int Rp = 16 * I + 4 * v - NDX, Cp = 16 * J - NDX; // row lr + Rp, column lc + Cp of P~
+            const double val = SMPC_ACCV(t1, tt, v);
+            s.P[bR + Rp * NDX + Cp] = val;
+            s.P[bT + Cp * NDX + Rp] = val;
+            g[GK::G_Pt + Rp * (NDX - 1) - Rp * (Rp - 1) / 2 + Cp + lr * (NDX - 1 - Rp) + gl] = val;
+          };
+          constexpr int t22 = tix<5>(2, 2), t23 = tix<5>(2, 3), t24 = tix<5>(2, 4), t33 = tix<5>(3, 3), t34 = tix<5>(3, 4), t44 = tix<5>(4, 4);
 #pragma unroll
-          for (int tt = 9; tt < 15; tt++) // tile rows >= 2 hold the Schur block (rows NDX .. 2 NDX)
+          for (int v = 0; v < 4; v++)
+            if (lc >= lr + 4 * v)
+            {
+              if (v >= 1)
+                put(t22, v); // (rows NDX + 4 (v - 1) ..: columns lc >= 4 follow from the mask)
+              put(t33, v);
+              if (v < 2 && lc < 8)
+                put(t44, v);
+            }
+#pragma unroll
+          for (int v = 1; v < 4; v++)
+            put(t23, v);
+          if (lc < 8)
+          {
+#pragma unroll
+            for (int v = 1; v < 4; v++)
+              put(t24, v);
 #pragma unroll
             for (int v = 0; v < 4; v++)
-            {
-              const int row = 16 * T5I[tt] + lr + 4 * v, col = 16 * T5J[tt] + lc;
-              const double val = SMPC_ACCV(t1, tt, v);
-              if (row >= NDX && row < 2 * NDX && col >= row)
-              {
-                if (col < 2 * NDX)
-                {
-                  s.P[(row - NDX) * NDX + col - NDX] = val;
-                  s.P[(col - NDX) * NDX + row - NDX] = val;
-                }
-                else if (col == 2 * NDX)
-                  s.pt[row - NDX] = val;
-              }
-            }
+              put(t34, v);
+          }
+          if (lc == 8)
+          {
+#pragma unroll
+            for (int v = 1; v < 4; v++)
+              s.pt[4 * v - 4 + lr] = SMPC_ACCV(t1, t24, v);
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+              s.pt[12 + 4 * v + lr] = SMPC_ACCV(t1, t34, v);
+#pragma unroll
+            for (int v = 0; v < 2; v++)
+              s.pt[28 + 4 * v + lr] = SMPC_ACCV(t1, t44, v);
+          }
         }
         SMPC_LANES_END_WAVE
       }
@@ -482,28 +521,9 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
           }
       }
       SMPC_LANES_END_WAVE
-      // stream P~ out ; load the dense rows of [A|B]
+      // commit the dense rows of [A|B]
       SMPC_LANES(NT)
       {
-        // packed upper triangle, row by row: lane = column (no index arithmetic in the stage loop; each row is one
-        // contiguous run of the gains block)
-        static_assert(NDX <= NT, "one column per lane");
-        // (LDS reads of a chunk of rows first, unconditionally, then the masked stores: a read-wait-store chain per row
-        //  would expose the LDS latency 36 times)
-        static_assert(NDX % 9 == 0, "row chunks of 9");
-        const int pcol = lane < NDX ? lane : 0;
-#pragma unroll
-        for (int c = 0; c < NDX / 9; c++)
-        {
-          double pv[9];
-#pragma unroll
-          for (int r = 0; r < 9; r++)
-            pv[r] = s.P[(9 * c + r) * NDX + pcol];
-#pragma unroll
-          for (int r = 0; r < 9; r++)
-            if (lane >= 9 * c + r && lane < NDX)
-              g[GK::pt_off(9 * c + r, 9 * c + r) + lane - (9 * c + r)] = pv[r];
-        }
 #pragma unroll
         for (int n = 0; n < NAB_PL; n++)
         {
@@ -682,6 +702,8 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
         const double vbd = lq[D::O_d + (pl < NA ? pl : 0)];
         const double * ekp = (EXT && b.es != nullptr) ? b.ek + ((size_t)inst * H + t) * 12 * NF : lq; // (cone rows: [D | d] are contiguous)
         const double vce = ekp[pl < 8 * NF ? pl : 0];
+        if (t > 0)
+          SMPC_PLV(f_pf) = lq[-(int)D::LQ_STRIDE + D::O_f + (pl < NDX ? pl : 0)]; // f of the next stage of the sweep
 #pragma unroll
         for (int n = 0; n < CC_PL; n++)
         {
@@ -832,34 +854,81 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
       //          (u, vector) entries -> R^^-1 r^ = -k ----
       wave_block_sweep<NT, 4, true, NDX, NU / 4, false, SMPC_KINO_RCP1>(hacc, sw2, sw2 + 4 * 64, prof, tprev);
       prof_tick(prof, 10, tprev);
+      // P_t -> LDS image (both halves; of a diagonal tile the upper entries), p_t -> its row NDX + 1, [K | k] -> staging; grouped by mask
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
+        const int bR = lr * NDX + lc, bT = lc * NDX + lr;
+        const int bK = lc * (NDX + 1) + lr; // K[u][x] of tile entry (x = R0 + lr, u = U0 + lc)
+        auto putP = [&](int tt, int v) SMPC_LAMBDA_INLINE {
+          const int R0 = 16 * T4I[tt] + 4 * v, C0 = 16 * T4J[tt];
+          const double val = SMPC_ACCV(hacc, tt, v);
+          s.P[bR + R0 * NDX + C0] = val;
+          s.P[bT + C0 * NDX + R0] = val;
+        };
+        auto putK = [&](int tt, int v) SMPC_LAMBDA_INLINE {
+          const int R0 = 16 * T4I[tt] + 4 * v, U0 = 16 * T4J[tt] - NDX;
+          Wm[bK + U0 * (NDX + 1) + R0] = -SMPC_ACCV(hacc, tt, v);
+        };
+        constexpr int h00 = tix<4>(0, 0), h01 = tix<4>(0, 1), h02 = tix<4>(0, 2), h03 = tix<4>(0, 3), h11 = tix<4>(1, 1), h12 = tix<4>(1, 2),
+                      h13 = tix<4>(1, 3), h22 = tix<4>(2, 2), h23 = tix<4>(2, 3), h33 = tix<4>(3, 3);
 #pragma unroll
-        for (int tt = 0; tt < 10; tt++)
+        for (int v = 0; v < 4; v++)
+          if (lc >= lr + 4 * v)
+          {
+            putP(h00, v);
+            putP(h11, v);
+            if (v == 0 && lc < 4)
+              putP(h22, 0);
+          }
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+          putP(h01, v);
+        if (lc < 4)
+        {
 #pragma unroll
           for (int v = 0; v < 4; v++)
           {
-            const int row = 16 * T4I[tt] + lr + 4 * v, col = 16 * T4J[tt] + lc;
-            const double val = SMPC_ACCV(hacc, tt, v);
-            if (row < NDX)
-            {
-              if (col < NDX)
-              {
-                if (row <= col)
-                {
-                  s.P[row * NDX + col] = val;
-                  s.P[col * NDX + row] = val;
-                }
-              }
-              else if (col < NXU)
-                Wm[(col - NDX) * (NDX + 1) + row] = -val; // K
-              else if (col == NXU)
-                s.p[row] = val; // p_t
-            }
-            else if (row < NXU && col == NXU)
-              Wm[(row - NDX) * (NDX + 1) + NDX] = -val; // k
+            putP(h02, v);
+            putP(h12, v);
           }
+        }
+        else
+        {
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            putK(h02, v);
+            putK(h12, v);
+          }
+          putK(h22, 0);
+        }
+        if (lc < 12)
+        {
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            putK(h03, v);
+            putK(h13, v);
+          }
+          putK(h23, 0);
+        }
+        else if (lc == 12)
+        {
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+          {
+            s.P[(NDX + 1) * NDX + 4 * v + lr] = SMPC_ACCV(hacc, h03, v); // p_t
+            s.P[(NDX + 1) * NDX + 16 + 4 * v + lr] = SMPC_ACCV(hacc, h13, v);
+          }
+          s.P[(NDX + 1) * NDX + 32 + lr] = SMPC_ACCV(hacc, h23, 0);
+#pragma unroll
+          for (int v = 1; v < 4; v++)
+            Wm[(4 * v - 4 + lr) * (NDX + 1) + NDX] = -SMPC_ACCV(hacc, h23, v); // k
+#pragma unroll
+          for (int v = 0; v < 3; v++)
+            Wm[(12 + 4 * v + lr) * (NDX + 1) + NDX] = -SMPC_ACCV(hacc, h33, v);
+        }
       }
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
