@@ -388,6 +388,7 @@ namespace smpc
         if (t == 0)
           q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
         lq[D::O_q + k] = q;
+        lq[D::t_off(k, D::NXU)] = q; // (column NXU of the tile grid: the vector column of the structured sweep, loaded with its tiles)
         lq[D::O_lx + k] = g;
         lq[D::O_f + k] = mu * (sc.lamp[k] - sc.lam_next[k]);
         lq[D::O_lpd + k] = 2.0 * sc.lamp[k] - sc.lam_next[k];
@@ -418,6 +419,7 @@ namespace smpc
             r += j0[k % 3] * cs[6 * NF + 2 * f] + j1[k % 3] * cs[6 * NF + 2 * f + 1];
         }
         lq[D::O_r + k] = r;
+        lq[D::t_off(NDX + k, D::NXU)] = r;
         lq[D::O_lu + k] = g;
         sc.ru[k] = fabs(r);
       }

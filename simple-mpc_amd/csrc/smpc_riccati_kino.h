@@ -315,16 +315,16 @@ namespace smpc
     static constexpr int SCR_1 = 2 * SWP, SCR_2 = NG * NXU, SCR_3 = NG * NDX + 2 * 4 * 64;
     static constexpr int SCR = SCR_1 > SCR_2 ? (SCR_1 > SCR_3 ? SCR_1 : SCR_3) : (SCR_2 > SCR_3 ? SCR_2 : SCR_3);
     static_assert(NU * (NDX + 1) <= SCR_3, "the [K | k] staging block takes over Cc and the sweep operands");
-    // rows 0 .. NDX-1: P_{t+1} -> P~ (-> E^T P~ E in place) -> P_t, full symmetric image, row stride NDX.
-    // row NDX: c = p_{t+1} - f / mu, row NDX+1: p_{t+1} -> p_t -- the vector column of the bordered matrix of the first sweep is read through
-    // the same (column, row) addresses as the matrix entries: element (R, C) of a tile comes from P[C' * NDX + R'] with C' = NDX, NDX + 1 for it
-    double P[(NDX + 2) * NDX];
-    // scratch, by phase:  sweep operands (2 x 4 x 80)  ->  NAB (NG x NXU)
-    //                     ->  [Cc (NG x NDX) | sweep operands (2 x 4 x 64)]  ->  staging of [K | k] (NU x (NDX+1))
-    double scr[SCR];
-    double pt[NDX], qh[NDX], rh[NU];
-    double dc[NG], boxd[D::NA], boxact[D::NA];
-    double cone[8 * D::NF]; // friction-cone rows of the stage (force_cone): active Jacobian rows (2 NF x 3) | d (2 NF)
+    // One array, offsets by name (entries of different blocks are reached from one per-lane base with compile-time offsets).
+    // P: rows 0 .. NDX-1: P_{t+1} -> P~ (-> E^T P~ E in place) -> P_t, full symmetric image, row stride NDX;
+    //    row NDX: c = p_{t+1} - f / mu -> p~ (-> E^T p~), row NDX+1: p_{t+1} -> p_t -- the vector column of the bordered matrix of the first sweep is
+    //    read through the same (column, row) addresses as the matrix entries: element (R, C) of a tile comes from P[C' * NDX + R'], C' = NDX, NDX + 1 for it
+    // Z: two zeros: where the masked lanes of a gather read (an address select instead of a predicated load)
+    // scr, by phase:  sweep operands (2 x 4 x 80)  ->  dense rows of A (NG x NDX) | of B (NG x NU)
+    //                 ->  [Cc (NG x NDX) | sweep operands (2 x 4 x 64)]  ->  staging of [K | k] (NU x (NDX+1))
+    static constexpr int O_P = 0, O_Z = O_P + (NDX + 2) * NDX, O_SCR = O_Z + 2, O_qh = O_SCR + SCR, O_rh = O_qh + NDX, O_dc = O_rh + NU, O_boxd = O_dc + NG,
+                         O_boxact = O_boxd + D::NA, O_cone = O_boxact + D::NA, N_W = O_cone + 8 * D::NF;
+    double w[N_W]; // (cone: friction-cone rows of the stage (force_cone): active Jacobian rows (2 NF x 3) | d (2 NF))
     float sink[64]; // destination of the line touches (never read)
   };
 
@@ -347,18 +347,29 @@ namespace smpc
     const double mu = SMPC_UNIFORM_F64(b.model->mu), imu = SMPC_UNIFORM_F64(1.0 / mu), dt = SMPC_UNIFORM_F64(b.model->dt), smu = SMPC_UNIFORM_F64(sqrt(mu));
     SMPC_LDS(RiccatiKinoLds<D>, lds, 1);
     RiccatiKinoLds<D> & s = lds[0];
-    double * NAB = s.scr;                      // [NG][NXU]  dense rows of [A | B]           phase 4
-    double * Cc = s.scr;                       // [NG][NDX]  contact rows                     phase 5-6
-    double * Wm = s.scr;                       // [NU][NDX+1] staging of [K | k]              epilogue
-    double * sw1 = s.scr;                      // sweep operands of the first (5x5 tiles) sweep: 2 x 4 x 80
-    double * sw2 = s.scr + NG * NDX;           // ... of the second (4x4 tiles): 2 x 4 x 64
+    typedef RiccatiKinoLds<D> LD;
+    double * const sP = s.w + LD::O_P;         // image of P (+ vector rows); sP[LD::O_Z] = 0
+    double * const scr = s.w + LD::O_SCR;
+    double * const NAl = scr;                  // [NG][NDX]  dense rows of A                  phase 4
+    double * const NBl = scr + NG * NDX;       // [NG][NU]   dense rows of B                  phase 4
+    double * const Cc = scr;                   // [NG][NDX]  contact rows                     phase 5-6
+    double * const Wm = scr;                   // [NU][NDX+1] staging of [K | k]              epilogue
+    double * const sw1 = scr;                  // sweep operands of the first (5x5 tiles) sweep: 2 x 4 x 80
+    double * const sw2 = scr + NG * NDX;       // ... of the second (4x4 tiles): 2 x 4 x 64
+    double * const qh = s.w + LD::O_qh, * const rh = s.w + LD::O_rh, * const dcv = s.w + LD::O_dc, * const boxd = s.w + LD::O_boxd,
+           * const boxact = s.w + LD::O_boxact, * const cone = s.w + LD::O_cone;
+    constexpr int ZP = LD::O_Z - LD::O_P; // the zero slot, as an index into sP
 
     SMPC_LANES(NT)
     {
       for (int i = lane; i < NDX * NDX; i += NT)
-        s.P[i] = b.QN[(size_t)inst * NDX * NDX + i];
+        sP[i] = b.QN[(size_t)inst * NDX * NDX + i];
       for (int i = lane; i < NDX; i += NT)
-        s.P[(NDX + 1) * NDX + i] = b.qN[(size_t)inst * NDX + i];
+        sP[(NDX + 1) * NDX + i] = b.qN[(size_t)inst * NDX + i];
+      if (lane < 2)
+        sP[ZP + lane] = 0.0;
+      if (lane < NU)
+        rh[lane] = 0.0; // (written by the stages of problems with friction-cone rows only)
     }
     SMPC_LANES_END_WAVE
     // f of the stage, one double per lane, fetched one stage ahead
@@ -380,16 +391,18 @@ namespace smpc
       constexpr int QT[6] = {0, 1, 2, 4, 5, 7}; // the T4 tiles that hold Q^ (rows, cols < NDX)
       // per-lane registers that live across phases
       SMPC_ACC(hacc, NT, 10); // H^ = [Q S; S^T R] + [A|B]^T P~ [A|B], upper tiles; swept in place
-      constexpr int NAB_PL = (NG * NXU + NT - 1) / NT, CC_PL = (NG * NDX + NT - 1) / NT;
+      static_assert(NDX == 36 && NV == 18 && NU == 24 && 3 * NF == 12 && NA == 12,
+                    "lane maps of the stage body: x = [qb(6) qj(12) vb(6) vj(12)] on 36 = 2 * 16 + 4, u = [forces(12) accelerations(12)]");
+      constexpr int NAQ = NG * NDX, NBQ = NG * NU, NA_PL = (NAQ + NT - 1) / NT, NB_PL = (NBQ + NT - 1) / NT, NAB_PL = NA_PL + NB_PL;
+      constexpr int CC_PL = (NG * NDX + NT - 1) / NT;
       SMPC_PLA(double, nab_pf, NT, NAB_PL);
-      SMPC_PL(double, vq_pf, NT);                   // q / r of the stage (one double per lane)
       // ---- (1) save p_{t+1} ; vector column of the pivot rows c = p - f / mu (see (2)) ----
       SMPC_LANES(NT)
       if (lane < NDX)
       {
-        const double pv = s.P[(NDX + 1) * NDX + lane];
+        const double pv = sP[(NDX + 1) * NDX + lane];
         g[GK::G_pn + lane] = pv;
-        s.P[NDX * NDX + lane] = pv - imu * SMPC_PLV(f_pf);
+        sP[NDX * NDX + lane] = pv - imu * SMPC_PLV(f_pf);
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 0, tprev);
@@ -399,13 +412,20 @@ namespace smpc
       //           across the sweep's 15 accumulator tiles they were spilled right after the load, i.e. waited for) ----
       SMPC_LANES(NT)
       {
+        // rows G = {0 .. 5, NV .. NV + 5} of A and of B are two contiguous runs each: flat copies, one address select where a load straddles them
 #pragma unroll
-        for (int n = 0; n < NAB_PL; n++)
+        for (int n = 0; n < NA_PL; n++)
         {
-          const int idx = lane + n * NT;
-          const int gi = idx < NG * NXU ? idx / NXU : 0, j = idx % NXU;
-          // (address selects, one load each: a select on a loaded VALUE would make the wave wait for it here)
-          SMPC_PLV(nab_pf)[n] = lq[j < NDX ? D::O_A + IX::G(gi) * NDX + j : D::O_B + IX::G(gi) * NU + j - NDX];
+          const int lo = n * NT, hi = lo + NT - 1, idx = lo + lane;
+          const int off = hi < 6 * NDX ? idx : ((lo >= 6 * NDX && hi < NAQ) ? idx + (NV - 6) * NDX : (idx < 6 * NDX ? idx : (idx < NAQ ? idx + (NV - 6) * NDX : 0)));
+          SMPC_PLV(nab_pf)[n] = lq[D::O_A + off];
+        }
+#pragma unroll
+        for (int n = 0; n < NB_PL; n++)
+        {
+          const int lo = n * NT, hi = lo + NT - 1, idx = lo + lane;
+          const int off = hi < 6 * NU ? idx : ((lo >= 6 * NU && hi < NBQ) ? idx + (NV - 6) * NU : (idx < 6 * NU ? idx : (idx < NBQ ? idx + (NV - 6) * NU : 0)));
+          SMPC_PLV(nab_pf)[NA_PL + n] = lq[D::O_B + off];
         }
       }
       SMPC_LANES_END_WAVE
@@ -439,7 +459,7 @@ namespace smpc
                 const bool piv = R0 < NDX;
                 const int Rp = piv ? R0 : R0 - NDX;
                 const int base = J <= 1 ? bA + 16 * J * NDX : (J == 2 ? bW : (J == 3 ? bA + (48 - NDX) * NDX : (piv ? b4p : b4s)));
-                val = s.P[base + Rp];
+                val = sP[base + Rp];
                 if (piv && I == J && lc == lr + 4 * v)
                   val += imu;
               }
@@ -448,9 +468,9 @@ namespace smpc
         }
         SMPC_LANES_END_WAVE
         prof_tick(prof, 3, tprev);
-wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 + RiccatiKinoLds<D>::SWP, prof, tprev);
+wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 + LD::SWP, prof, tprev);
         // P~ (rows / columns NDX .. 2 NDX of the grid) -> LDS image, both halves, and -> the gains block (upper triangle packed row by row), from
-        // the registers; p~ -> pt.  One execution mask per group of stores (a predicate per store costs four scalar instructions and a branch);
+        // the registers; p~ -> row NDX of the image (c is dead).  One execution mask per group of stores (a predicate per store costs four scalar instructions and a branch);
         // of a diagonal tile the upper entries only (its two halves are rounded differently: the image stays exactly symmetric).
         SMPC_LANES(NT)
         {
@@ -461,8 +481,8 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
             const int I = T5I[tt], J = T5J[tt];
             const int Rp = 16 * I + 4 * v - NDX, Cp = 16 * J - NDX; // row lr + Rp, column lc + Cp of P~
             const double val = SMPC_ACCV(t1, tt, v);
-            s.P[bR + Rp * NDX + Cp] = val;
-            s.P[bT + Cp * NDX + Rp] = val;
+            sP[bR + Rp * NDX + Cp] = val;
+            sP[bT + Cp * NDX + Rp] = val;
             g[GK::G_Pt + Rp * (NDX - 1) - Rp * (Rp - 1) / 2 + Cp + lr * (NDX - 1 - Rp) + gl] = val;
           };
           constexpr int t22 = tix<5>(2, 2), t23 = tix<5>(2, 3), t24 = tix<5>(2, 4), t33 = tix<5>(3, 3), t34 = tix<5>(3, 4), t44 = tix<5>(4, 4);
@@ -492,13 +512,13 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
           {
 #pragma unroll
             for (int v = 1; v < 4; v++)
-              s.pt[4 * v - 4 + lr] = SMPC_ACCV(t1, t24, v);
+              sP[NDX * NDX + 4 * v - 4 + lr] = SMPC_ACCV(t1, t24, v);
 #pragma unroll
             for (int v = 0; v < 4; v++)
-              s.pt[12 + 4 * v + lr] = SMPC_ACCV(t1, t34, v);
+              sP[NDX * NDX + 12 + 4 * v + lr] = SMPC_ACCV(t1, t34, v);
 #pragma unroll
             for (int v = 0; v < 2; v++)
-              s.pt[28 + 4 * v + lr] = SMPC_ACCV(t1, t44, v);
+              sP[NDX * NDX + 28 + 4 * v + lr] = SMPC_ACCV(t1, t44, v);
           }
         }
         SMPC_LANES_END_WAVE
@@ -506,10 +526,10 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
       prof_tick(prof, 4, tprev);
       // ---- (3b) register prefetch of [Q S; S^T R] in accumulator-tile layout (element (row, col) of tile (I, J):
       //           row = 16 I + (lane >> 4) + 4 v, col = 16 J + (lane & 15)); the HBM/L2 latency overlaps with the
-      //           P~ E passes and the TG product below ----
+      //           P~ E passes and the TG product below.  Column NXU of the grid is the vector column of the second sweep: the derivative pass
+      //           stores q / r there as well (smpc_kino_kernels.h) ----
       SMPC_LANES(NT)
       {
-        const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
         for (int tt = 0; tt < 10; tt++)
 #pragma unroll
@@ -525,12 +545,13 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
       SMPC_LANES(NT)
       {
 #pragma unroll
-        for (int n = 0; n < NAB_PL; n++)
-        {
-          const int idx = lane + n * NT;
-          if (idx < NG * NXU)
-            NAB[idx] = SMPC_PLV(nab_pf)[n];
-        }
+        for (int n = 0; n < NA_PL; n++)
+          if (n * NT + NT <= NAQ || lane + n * NT < NAQ)
+            NAl[lane + n * NT] = SMPC_PLV(nab_pf)[n];
+#pragma unroll
+        for (int n = 0; n < NB_PL; n++)
+          if (n * NT + NT <= NBQ || lane + n * NT < NBQ)
+            NBl[lane + n * NT] = SMPC_PLV(nab_pf)[NA_PL + n];
         // The contact rows of C, d and the box selectors are consumed after the products.  Eleven prefetch registers per lane
         // do not survive the products' accumulator tiles (the compiler spilled them right after the load, i.e. waited for
         // every one of them), so the lines are only TOUCHED here -- one 4-byte load per 64-byte line into an LDS sink, no
@@ -538,19 +559,18 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
         static_assert(NG * NDX <= 54 * 8 && NA + NG <= 24 && NA <= NT, "line touches: 54 lines of C, 3 of d, one per box row");
         SMPC_TOUCH(lq + (lane < 54 ? D::O_C + NA * NDX + lane * 8 : D::O_d + (lane < 57 ? (lane - 54) * 8 : 0)), s.sink);
         SMPC_TOUCH(lq + D::O_C + (lane < NA ? lane * NDX + 6 + lane : 0), s.sink);
-        SMPC_PLV(vq_pf) = lq[lane < NDX ? D::O_q + lane : (lane < NXU ? D::O_r + lane - NDX : D::O_q)];
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 5, tprev);
-      // ---- (4a) column pass, in place:  P[:, vj] += dt P[:, qj]   (P now holds P~ E on its J columns) ----
+      // ---- (4a) column pass, in place:  P[:, vj] += dt P[:, qj]   (P now holds P~ E on its J columns; row NDX: p~ -> E^T p~) ----
       // E_b = dt * E[:, vj], so every product with E_b is a scaled slice of the same matrix.
       SMPC_LANES(NT)
       {
         // lane -> (row group, column): NA columns x 5 row groups, no index division in the loop
         const int jp = lane % NA, ib = lane / NA;
         if (ib < 5)
-          for (int i = ib; i < NDX; i += 5)
-            s.P[i * NDX + NV + 6 + jp] += dt * s.P[i * NDX + 6 + jp];
+          for (int i = ib; i < NDX + 1; i += 5)
+            sP[i * NDX + NV + 6 + jp] += dt * sP[i * NDX + 6 + jp];
       }
       SMPC_LANES_END_WAVE
       static_assert(5 * NA <= NT, "lane map of the column pass");
@@ -558,7 +578,8 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
       // ---- (4b, 4c) PEG = [(P~ E)[G,:] | (P~ E_b)[G,:]] (zero in the G / force columns), gathered from P straight
       //      into accumulator layout;  TG = P~[G,G] * NAB + PEG on the matrix cores (M = NG -> 16, N = NXU -> 64, K = NG).
       //      Both stay in registers: in accumulator layout a lane holds rows lr, lr + 4, lr + 8 of its column, which
-      //      are exactly the rows 4 ks + lr it must supply as an MFMA operand at K-step ks of the next product. ----
+      //      are exactly the rows 4 ks + lr it must supply as an MFMA operand at K-step ks of the next product.
+      //      Gathers: per-lane bases + compile-time offsets; the lanes of the masked columns read the zero slot (address select). ----
       constexpr int KS = NG / 4;
       SMPC_ACC(tacc, NT, 4);
       SMPC_PLA(double, pegv, NT, 4 * KS);
@@ -568,32 +589,37 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
+          // dense row index G(4 v + lr), v = 0, 1, 2
+          const int gq1 = lr < 2 ? lr + 4 : lr + NV - 2;
+          const int rb[3] = {lr * NDX, gq1 * NDX, (lr + NV + 2) * NDX};
+          // columns of [x | u] with a structured entry, by tile column: x not in G ; accelerations -> their vj column
+          const bool cm[4] = {lc >= 6, lc < 2 || lc >= 8, lc < 4, lc < NA};
+          const int pc[4] = {lc, 16 + lc, 32 + lc, NV + 6 + lc};
 #pragma unroll
           for (int J = 0; J < 4; J++)
 #pragma unroll
             for (int v = 0; v < 4; v++)
             {
-              const int row = lr + 4 * v, col = 16 * J + lc;
-              const int ac = col - NDX - 3 * NF; // joint-acceleration column if >= 0
-              const int pc = col < NDX ? col : (ac >= 0 && col < NXU ? NV + 6 + ac : 0);
-              const double scale = col < NDX ? (IX::isG(col) ? 0.0 : 1.0) : (ac >= 0 && col < NXU ? dt : 0.0);
-              const double pv = v < KS ? scale * s.P[IX::G(row < NG ? row : 0) * NDX + pc] : 0.0;
-              SMPC_ACCV(tacc, J, v) = pv;
+              double pv = 0.0;
               if (v < KS)
+              {
+                pv = sP[cm[J] ? rb[v] + pc[J] : ZP];
+                if (J == 3)
+                  pv *= dt;
                 SMPC_PLV(pegv)[J * KS + v] = pv;
+              }
+              SMPC_ACCV(tacc, J, v) = pv;
             }
+          const int gcol = lc < 6 ? lc : lc + NV - 6; // G(lc), lc < NG
+          const int na = lr * NDX + lc, nb = lr * NU + lc;
 #pragma unroll
           for (int ks = 0; ks < KS; ks++)
           {
-            const double pv = s.P[IX::G(lc < NG ? lc : 0) * NDX + IX::G(4 * ks + lr)];
-            SMPC_PLV(pgv)[ks] = lc < NG ? pv : 0.0;
-#pragma unroll
-            for (int J = 0; J < 4; J++)
-            {
-              const int col = 16 * J + lc;
-              const double nv = NAB[(4 * ks + lr) * NXU + (col < NXU ? col : 0)];
-              SMPC_PLV(nbv)[ks * 4 + J] = col < NXU ? nv : 0.0;
-            }
+            SMPC_PLV(pgv)[ks] = sP[lc < NG ? rb[ks] + gcol : ZP];
+            SMPC_PLV(nbv)[ks * 4 + 0] = NAl[na + 4 * ks * NDX];
+            SMPC_PLV(nbv)[ks * 4 + 1] = NAl[na + 4 * ks * NDX + 16];
+            SMPC_PLV(nbv)[ks * 4 + 2] = scr[lc < 4 ? na + 4 * ks * NDX + 32 : NAQ + nb + 4 * ks * NU - 4];
+            SMPC_PLV(nbv)[ks * 4 + 3] = lc < NU - 12 ? NBl[nb + 4 * ks * NU + 12] : 0.0;
           }
         }
         SMPC_LANES_END_WAVE
@@ -606,67 +632,77 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
         SMPC_LANES(NT)
         if (lane < NDX)
           for (int ip = 0; ip < NA; ip++)
-            s.P[(NV + 6 + ip) * NDX + lane] += dt * s.P[(6 + ip) * NDX + lane];
+            sP[(NV + 6 + ip) * NDX + lane] += dt * sP[(6 + ip) * NDX + lane];
         SMPC_LANES_END_WAVE
       }
       prof_tick(prof, 7, tprev);
-      // ---- (4d) H^ += E^T P~ [E|E_b] (structured) + NAB^T TG + PEG^T NAB  (matrix cores, K = 2 NG) ; q^ , r^ ----
+      // ---- (4d) H^ += E^T P~ [E|E_b] (structured) + NAB^T TG + PEG^T NAB  (matrix cores, K = 2 NG).  The vector column rides along:
+      //      column NXU of TG := p~[G] gives NAB^T p~[G] by the first product, row NDX of the image (E^T p~) the structured part ----
       {
         SMPC_PLA(double, nav, NT, KS * 4);
         SMPC_PLA(double, tgv, NT, KS * 4);
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
+          const int gq[3] = {lr, lr < 2 ? lr + 4 : lr + NV - 2, lr + NV + 2};
+          const int na = lr * NDX + lc, nb = lr * NU + lc;
 #pragma unroll
           for (int ks = 0; ks < KS; ks++)
+          {
+            SMPC_PLV(nav)[ks * 4 + 0] = NAl[na + 4 * ks * NDX];
+            SMPC_PLV(nav)[ks * 4 + 1] = NAl[na + 4 * ks * NDX + 16];
+            SMPC_PLV(nav)[ks * 4 + 2] = scr[lc < 4 ? na + 4 * ks * NDX + 32 : NAQ + nb + 4 * ks * NU - 4];
+            SMPC_PLV(nav)[ks * 4 + 3] = lc < NU - 12 ? NBl[nb + 4 * ks * NU + 12] : 0.0;
 #pragma unroll
-            for (int J = 0; J < 4; J++)
-            {
-              const int col = 16 * J + lc;
-              const double a0 = NAB[(4 * ks + lr) * NXU + (col < NXU ? col : 0)];
-              SMPC_PLV(nav)[ks * 4 + J] = col < NXU ? a0 : 0.0;
-              SMPC_PLV(tgv)[ks * 4 + J] = col < NXU ? SMPC_ACCV(tacc, J, ks) : 0.0;
-            }
-          // structured term: index m of [x | u] -> (column of P, scale): x: (m, 0 on G rows else 1); u: joint accelerations
-          // map to the vj columns with scale dt, forces to nothing
+            for (int J = 0; J < 3; J++)
+              SMPC_PLV(tgv)[ks * 4 + J] = SMPC_ACCV(tacc, J, ks);
+            // (TG is zero in the padding columns: its lanes lc >= NU - 12 of tile column 3 hold 0 + 0)
+            SMPC_PLV(tgv)[ks * 4 + 3] = SMPC_ACCV(tacc, 3, ks) + sP[lc == NXU % 16 ? NDX * NDX + gq[ks] : ZP];
+          }
+          // structured term: entry (r, c) of [x | u] x [x | u] -> image entry (pr, pc) x scale: x: itself unless in G (nothing) ;
+          // joint accelerations: their vj row / column x dt ; forces: nothing.  Rows by register (compile-time), columns by lane (masks).
+          const int bR = lr * NDX + lc;
+          const bool cm[4] = {lc >= 6, lc < 2 || lc >= 8, lc < 4, lc < NA};
+          const bool rm2 = lr >= 2;
 #pragma unroll
           for (int tt = 0; tt < 10; tt++)
 #pragma unroll
             for (int v = 0; v < 4; v++)
             {
-              const int row = 16 * T4I[tt] + lr + 4 * v, col = 16 * T4J[tt] + lc;
-              const int r = row < col ? row : col, c = row < col ? col : row;
-              const int ar = r - NDX - 3 * NF, ac = c - NDX - 3 * NF;
-              const int pr = r < NDX ? r : (ar >= 0 && r < NXU ? NV + 6 + ar : 0);
-              const int pc = c < NDX ? c : (ac >= 0 && c < NXU ? NV + 6 + ac : 0);
-              const double sr = r < NDX ? (IX::isG(r) ? 0.0 : 1.0) : (ar >= 0 && r < NXU ? dt : 0.0);
-              const double sc = c < NDX ? (IX::isG(c) ? 0.0 : 1.0) : (ac >= 0 && c < NXU ? dt : 0.0);
-              SMPC_ACCV(hacc, tt, v) += sr * sc * s.P[pr * NDX + pc];
+              const int I = T4I[tt], J = T4J[tt], R0 = 16 * I + 4 * v;
+              // rows: 0..3 G | 4,5 G, 6,7 | 8..15 | 16,17, 18,19 G | 20..23 G | 24..35 | forces | 48..59 accelerations | padding
+              const bool rnone = R0 < 4 || (R0 >= 20 && R0 < 24) || (R0 >= NDX && R0 < NDX + 12) || R0 >= NXU;
+              if (rnone)
+                continue;
+              const bool racc = R0 >= NDX + 12;
+              const int pr0 = racc ? R0 - NDX - 12 + NV + 6 : R0, pc0 = J == 3 ? NV + 6 : 16 * J;
+              const bool m = cm[J] && (R0 == 4 ? rm2 : (R0 == 16 ? !rm2 : true));
+              const double pv = sP[m ? bR + pr0 * NDX + pc0 : ZP];
+              if (racc && J == 3)
+                SMPC_ACCV(hacc, tt, v) += dt * dt * pv;
+              else if (racc || J == 3)
+                SMPC_ACCV(hacc, tt, v) += dt * pv;
+              else
+                SMPC_ACCV(hacc, tt, v) += pv;
             }
-          // q^ = q + A^T p~ ; r^ = r + B^T p~
-          if (lane < NXU)
+          // ... of the vector column: E^T p~ (row NDX of the image)
+          if (lc == NXU % 16)
           {
-            const int j = lane;
-            double acc = SMPC_PLV(vq_pf);
-            if (j < NDX)
-            {
-              if (IX::isQj(j))
-                acc += s.pt[j];
-              else if (IX::isVj(j))
-                acc += dt * s.pt[j - NV] + s.pt[j];
-            }
-            else if (j - NDX >= 3 * NF)
-            {
-              const int ip = j - NDX - 3 * NF;
-              acc += dt * dt * s.pt[6 + ip] + dt * s.pt[NV + 6 + ip];
-            }
 #pragma unroll
-            for (int k = 0; k < NG; k++)
-              acc += NAB[k * NXU + j] * s.pt[IX::G(k)];
-            if (j < NDX)
-              s.qh[j] = acc;
-            else
-              s.rh[j - NDX] = acc;
+            for (int I = 0; I < 4; I++)
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+              {
+                const int R0 = 16 * I + 4 * v;
+                const bool rnone = R0 < 4 || (R0 >= 20 && R0 < 24) || (R0 >= NDX && R0 < NDX + 12) || R0 >= NXU;
+                if (rnone)
+                  continue;
+                const bool racc = R0 >= NDX + 12;
+                const int pr0 = racc ? R0 - NDX - 12 + NV + 6 : R0;
+                const bool m = R0 == 4 ? rm2 : (R0 == 16 ? !rm2 : true);
+                const double pv = sP[m ? NDX * NDX + pr0 + lr : ZP];
+                SMPC_ACCV(hacc, tix<4>(I, 3), v) += racc ? dt * pv : pv;
+              }
           }
         }
         SMPC_LANES_END_WAVE
@@ -712,15 +748,15 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
             Cc[idx] = ccv[n];
         }
         if (lane < NG)
-          s.dc[lane] = vdc;
+          dcv[lane] = vdc;
         if (lane < NA)
         {
-          s.boxact[lane] = vba;
-          s.boxd[lane] = vbd;
+          boxact[lane] = vba;
+          boxd[lane] = vbd;
         }
         if constexpr (EXT)
           if (lane < 8 * NF)
-            s.cone[lane] = b.es != nullptr ? vce : 0.0;
+            cone[lane] = b.es != nullptr ? vce : 0.0;
       }
       SMPC_LANES_END_WAVE
       {
@@ -747,10 +783,10 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
             double cd = 0.0;
 #pragma unroll 4
             for (int r = 0; r < NG; r++)
-              cd += Cc[r * NDX + i] * s.dc[r];
+              cd += Cc[r * NDX + i] * dcv[r];
             if (IX::isQj(i))
-              cd += s.boxact[i - 6] * s.boxd[i - 6];
-            s.qh[i] += imu * cd;
+              cd += boxact[i - 6] * boxd[i - 6];
+            qh[i] = imu * cd; // (this phase's part of the vector column; added to it below)
           }
           if (landrows != 0u && lane < NV)
           { // q^ += c^T d / mu of the land rows (rows on q only)
@@ -759,12 +795,12 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
             for (int f = 0; f < NF; f++)
               if ((landrows >> f) & 1u)
                 acc += lkp[f * NV + lane] * lkp[NF * NV + f];
-            s.qh[lane] += imu * acc;
+            qh[lane] += imu * acc;
           }
           else if ((EXT && b.es != nullptr) && lane >= NDX && lane < NDX + 3 * NF)
           { // r^ += D^T d / mu of the friction-cone rows
             const int k = lane - NDX, f = k / 3;
-            s.rh[k] += imu * (s.cone[(2 * f) * 3 + k % 3] * s.cone[6 * NF + 2 * f] + s.cone[(2 * f + 1) * 3 + k % 3] * s.cone[6 * NF + 2 * f + 1]);
+            rh[k] = imu * (cone[(2 * f) * 3 + k % 3] * cone[6 * NF + 2 * f] + cone[(2 * f + 1) * 3 + k % 3] * cone[6 * NF + 2 * f + 1]);
           }
         }
         SMPC_LANES_END_WAVE
@@ -784,7 +820,7 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
             {
               const int row = 16 * I + lr + 4 * v;
               if (lc == lr + 4 * v && IX::isQj(row))
-                SMPC_ACCV(hacc, tix<4>(I, I), v) += imu * s.boxact[row - 6];
+                SMPC_ACCV(hacc, tix<4>(I, I), v) += imu * boxact[row - 6];
             }
           // land rows: Q^[q, q] += c^T c / mu (rank one per landing foot; at most a few stages of a horizon have any)
           if (landrows != 0u)
@@ -824,22 +860,24 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
               if (row >= 0 && row < 3 * NF && col >= 0 && col < 3 * NF && row / 3 == col / 3)
               {
                 const int f = row / 3;
-                const double * d0 = &s.cone[(2 * f) * 3], * d1 = d0 + 3;
+                const double * d0 = &cone[(2 * f) * 3], * d1 = d0 + 3;
                 SMPC_ACCV(hacc, tix<4>(2, 2), v) += imu * (d0[row % 3] * d0[col % 3] + d1[row % 3] * d1[col % 3]);
               }
             }
           }
-          // vector column NXU (lanes with lc == NXU % 16 of the last tile column)
+          // vector column NXU (lanes with lc == NXU % 16 of the last tile column): += C^T d / mu (+ the force part of the cone rows)
           if (lc == NXU % 16)
           {
 #pragma unroll
-            for (int I = 0; I < 4; I++)
+            for (int I = 0; I < 3; I++)
 #pragma unroll
               for (int v = 0; v < 4; v++)
               {
-                const int row = 16 * I + lr + 4 * v;
-                const double val = row < NDX ? s.qh[row] : s.rh[row < NXU ? row - NDX : 0];
-                SMPC_ACCV(hacc, tix<4>(I, 3), v) = row < NXU ? val : 0.0;
+                const int R0 = 16 * I + 4 * v;
+                if (R0 < NDX)
+                  SMPC_ACCV(hacc, tix<4>(I, 3), v) += qh[R0 + lr];
+                else if (EXT && R0 < NDX + 3 * NF)
+                  SMPC_ACCV(hacc, tix<4>(I, 3), v) += rh[R0 - NDX + lr];
               }
           }
         }
@@ -863,8 +901,8 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
         auto putP = [&](int tt, int v) SMPC_LAMBDA_INLINE {
           const int R0 = 16 * T4I[tt] + 4 * v, C0 = 16 * T4J[tt];
           const double val = SMPC_ACCV(hacc, tt, v);
-          s.P[bR + R0 * NDX + C0] = val;
-          s.P[bT + C0 * NDX + R0] = val;
+          sP[bR + R0 * NDX + C0] = val;
+          sP[bT + C0 * NDX + R0] = val;
         };
         auto putK = [&](int tt, int v) SMPC_LAMBDA_INLINE {
           const int R0 = 16 * T4I[tt] + 4 * v, U0 = 16 * T4J[tt] - NDX;
@@ -918,10 +956,10 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
 #pragma unroll
           for (int v = 0; v < 4; v++)
           {
-            s.P[(NDX + 1) * NDX + 4 * v + lr] = SMPC_ACCV(hacc, h03, v); // p_t
-            s.P[(NDX + 1) * NDX + 16 + 4 * v + lr] = SMPC_ACCV(hacc, h13, v);
+            sP[(NDX + 1) * NDX + 4 * v + lr] = SMPC_ACCV(hacc, h03, v); // p_t
+            sP[(NDX + 1) * NDX + 16 + 4 * v + lr] = SMPC_ACCV(hacc, h13, v);
           }
-          s.P[(NDX + 1) * NDX + 32 + lr] = SMPC_ACCV(hacc, h23, 0);
+          sP[(NDX + 1) * NDX + 32 + lr] = SMPC_ACCV(hacc, h23, 0);
 #pragma unroll
           for (int v = 1; v < 4; v++)
             Wm[(4 * v - 4 + lr) * (NDX + 1) + NDX] = -SMPC_ACCV(hacc, h23, v); // k
