@@ -91,6 +91,11 @@
 // fire-and-forget touch of one cache line per lane: a 4-byte load that lands in an LDS sink nobody reads -- no destination
 // register, hence nothing to wait for and nothing to spill; the line is in L2 when the real load comes
 #define SMPC_TOUCH(gptr, lds_sink) ::smpc::touch_line((gptr), (lds_sink))
+// asynchronous copy global -> LDS without registers (global_load_lds_dwordx4, gfx950): lane l moves the 16 bytes at its `gptr` (16-byte aligned)
+// to lds_dst + 16 l.  All LDS reads issued before it have completed (the destination may be a block the wave has just read); the data is
+// there after SMPC_COPY_TO_LDS_WAIT() (it drains the wave's outstanding global loads, the copy among them).
+#define SMPC_COPY16_TO_LDS(gptr, lds_dst) ::smpc::global_to_lds_b128((gptr), (lds_dst))
+#define SMPC_COPY_TO_LDS_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps (full FP64 accuracy, no division)
 #define SMPC_RSQRT(x) ::smpc::rsqrt_nr(x)
 // 1/x: hardware estimate (v_rcp_f64) + two Newton steps (a full IEEE division is ~3x the dependent latency)
@@ -129,6 +134,11 @@ namespace smpc
     // LDS destination of lane l: M0 + 4 l (the sink is 256 bytes)
     const unsigned lds_off = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds_sink;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(gptr), "s"(lds_off) : "memory", "m0");
+  }
+  __device__ __forceinline__ void global_to_lds_b128(const void * gptr, void * lds_dst)
+  {
+    const unsigned lds_off = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds_dst;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_off) : "memory", "m0");
   }
   typedef double d4 __attribute__((ext_vector_type(4)));
   __device__ __forceinline__ double readlane_f64(double v, int src)

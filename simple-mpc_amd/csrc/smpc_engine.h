@@ -1396,6 +1396,7 @@ namespace smpc
       pa.R = R;
       pa.g_off = structured_riccati ? GainsK<D>::G_W : D::G_K;
       pa.g_str = structured_riccati ? GainsK<D>::STRIDE : D::G_STRIDE;
+      pa.g_tr = structured_riccati ? 1 : 0;
       pa.row = row_doubles;
       pa.out = out_dev;
       launch<PackOutArgs<D>, pack_outputs_body<D>, 64>(B, stream, pa);

@@ -29,7 +29,8 @@ namespace smpc
   struct GainsK
   {
     static constexpr int NDX = D::NDX, NU = D::NU;
-    static constexpr int G_W = 0;                     // [K | k] = -R^^-1 [S^^T | r^]   NU x (NDX+1)
+    static constexpr int G_W = 0;                     // [K | k]^T = -[S^^T | r^]^T R^^-1, (NDX+1) x NU: K(u, x) at G_W + x NU + u, k(u) at G_W + NDX NU + u
+                                                      // (the sweep stores its accumulator rows -- x -- as runs of u; the forward sweep reads columns)
     static constexpr int G_Pt = G_W + NU * (NDX + 1);       // P~, upper triangle packed row by row (the forward sweep is
     static constexpr int G_pn = G_Pt + NDX * (NDX + 1) / 2; //     HBM bound: half of P~ is 18 % of what it reads); p_{t+1}
     static constexpr int STRIDE = ((G_pn + NDX + 7) / 8) * 8;
@@ -314,14 +315,13 @@ namespace smpc
     static constexpr int SWP = 4 * 16 * 5; // one operand block of the widest sweep (4 x 80)
     static constexpr int SCR_1 = 2 * SWP, SCR_2 = NG * NXU, SCR_3 = NG * NDX + 2 * 4 * 64;
     static constexpr int SCR = SCR_1 > SCR_2 ? (SCR_1 > SCR_3 ? SCR_1 : SCR_3) : (SCR_2 > SCR_3 ? SCR_2 : SCR_3);
-    static_assert(NU * (NDX + 1) <= SCR_3, "the [K | k] staging block takes over Cc and the sweep operands");
     // One array, offsets by name (entries of different blocks are reached from one per-lane base with compile-time offsets).
     // P: rows 0 .. NDX-1: P_{t+1} -> P~ (-> E^T P~ E in place) -> P_t, full symmetric image, row stride NDX;
     //    row NDX: c = p_{t+1} - f / mu -> p~ (-> E^T p~), row NDX+1: p_{t+1} -> p_t -- the vector column of the bordered matrix of the first sweep is
     //    read through the same (column, row) addresses as the matrix entries: element (R, C) of a tile comes from P[C' * NDX + R'], C' = NDX, NDX + 1 for it
     // Z: two zeros: where the masked lanes of a gather read (an address select instead of a predicated load)
     // scr, by phase:  sweep operands (2 x 4 x 80)  ->  dense rows of A (NG x NDX) | of B (NG x NU)
-    //                 ->  [Cc (NG x NDX) | sweep operands (2 x 4 x 64)]  ->  staging of [K | k] (NU x (NDX+1))
+    //                 ->  [Cc (NG x NDX) | sweep operands (2 x 4 x 64)]
     static constexpr int O_P = 0, O_Z = O_P + (NDX + 2) * NDX, O_SCR = O_Z + 2, O_qh = O_SCR + SCR, O_rh = O_qh + NDX, O_dc = O_rh + NU, O_boxd = O_dc + NG,
                          O_boxact = O_boxd + D::NA, O_cone = O_boxact + D::NA, N_W = O_cone + 8 * D::NF;
     double w[N_W]; // (cone: friction-cone rows of the stage (force_cone): active Jacobian rows (2 NF x 3) | d (2 NF))
@@ -353,7 +353,6 @@ namespace smpc
     double * const NAl = scr;                  // [NG][NDX]  dense rows of A                  phase 4
     double * const NBl = scr + NG * NDX;       // [NG][NU]   dense rows of B                  phase 4
     double * const Cc = scr;                   // [NG][NDX]  contact rows                     phase 5-6
-    double * const Wm = scr;                   // [NU][NDX+1] staging of [K | k]              epilogue
     double * const sw1 = scr;                  // sweep operands of the first (5x5 tiles) sweep: 2 x 4 x 80
     double * const sw2 = scr + NG * NDX;       // ... of the second (4x4 tiles): 2 x 4 x 64
     double * const qh = s.w + LD::O_qh, * const rh = s.w + LD::O_rh, * const dcv = s.w + LD::O_dc, * const boxd = s.w + LD::O_boxd,
@@ -394,8 +393,10 @@ namespace smpc
       static_assert(NDX == 36 && NV == 18 && NU == 24 && 3 * NF == 12 && NA == 12,
                     "lane maps of the stage body: x = [qb(6) qj(12) vb(6) vj(12)] on 36 = 2 * 16 + 4, u = [forces(12) accelerations(12)]");
       constexpr int NAQ = NG * NDX, NBQ = NG * NU, NA_PL = (NAQ + NT - 1) / NT, NB_PL = (NBQ + NT - 1) / NT, NAB_PL = NA_PL + NB_PL;
-      constexpr int CC_PL = (NG * NDX + NT - 1) / NT;
       SMPC_PLA(double, nab_pf, NT, NAB_PL);
+      SMPC_PL(double, pf_dc, NT); // d of the contact rows, box selectors and their d: fetched before the products of (4d), used in (5)
+      SMPC_PL(double, pf_ba, NT);
+      SMPC_PL(double, pf_bd, NT);
       // ---- (1) save p_{t+1} ; vector column of the pivot rows c = p - f / mu (see (2)) ----
       SMPC_LANES(NT)
       if (lane < NDX)
@@ -579,7 +580,7 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
       //      into accumulator layout;  TG = P~[G,G] * NAB + PEG on the matrix cores (M = NG -> 16, N = NXU -> 64, K = NG).
       //      Both stay in registers: in accumulator layout a lane holds rows lr, lr + 4, lr + 8 of its column, which
       //      are exactly the rows 4 ks + lr it must supply as an MFMA operand at K-step ks of the next product.
-      //      Gathers: per-lane bases + compile-time offsets; the lanes of the masked columns read the zero slot (address select). ----
+      //      Gathers: per-lane bases + compile-time offsets. ----
       constexpr int KS = NG / 4;
       SMPC_ACC(tacc, NT, 4);
       SMPC_PLA(double, pegv, NT, 4 * KS);
@@ -592,8 +593,9 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
           // dense row index G(4 v + lr), v = 0, 1, 2
           const int gq1 = lr < 2 ? lr + 4 : lr + NV - 2;
           const int rb[3] = {lr * NDX, gq1 * NDX, (lr + NV + 2) * NDX};
-          // columns of [x | u] with a structured entry, by tile column: x not in G ; accelerations -> their vj column
-          const bool cm[4] = {lc >= 6, lc < 2 || lc >= 8, lc < 4, lc < NA};
+          // columns of [x | u] with a structured entry, by tile column: x not in G ; accelerations -> their vj column (x dt).  The lanes of the
+          // other columns read a finite entry of the image and multiply it by zero (a scale per lane instead of an address select per entry)
+          const double cs[4] = {lc >= 6 ? 1.0 : 0.0, (lc < 2 || lc >= 8) ? 1.0 : 0.0, lc < 4 ? 1.0 : 0.0, lc < NA ? dt : 0.0};
           const int pc[4] = {lc, 16 + lc, 32 + lc, NV + 6 + lc};
 #pragma unroll
           for (int J = 0; J < 4; J++)
@@ -603,9 +605,7 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
               double pv = 0.0;
               if (v < KS)
               {
-                pv = sP[cm[J] ? rb[v] + pc[J] : ZP];
-                if (J == 3)
-                  pv *= dt;
+                pv = sP[rb[v] + pc[J]] * cs[J];
                 SMPC_PLV(pegv)[J * KS + v] = pv;
               }
               SMPC_ACCV(tacc, J, v) = pv;
@@ -615,7 +615,7 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
 #pragma unroll
           for (int ks = 0; ks < KS; ks++)
           {
-            SMPC_PLV(pgv)[ks] = sP[lc < NG ? rb[ks] + gcol : ZP];
+            SMPC_PLV(pgv)[ks] = sP[rb[ks] + gcol] * (lc < NG ? 1.0 : 0.0);
             SMPC_PLV(nbv)[ks * 4 + 0] = NAl[na + 4 * ks * NDX];
             SMPC_PLV(nbv)[ks * 4 + 1] = NAl[na + 4 * ks * NDX + 16];
             SMPC_PLV(nbv)[ks * 4 + 2] = scr[lc < 4 ? na + 4 * ks * NDX + 32 : NAQ + nb + 4 * ks * NU - 4];
@@ -662,8 +662,16 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
           // structured term: entry (r, c) of [x | u] x [x | u] -> image entry (pr, pc) x scale: x: itself unless in G (nothing) ;
           // joint accelerations: their vj row / column x dt ; forces: nothing.  Rows by register (compile-time), columns by lane (masks).
           const int bR = lr * NDX + lc;
-          const bool cm[4] = {lc >= 6, lc < 2 || lc >= 8, lc < 4, lc < NA};
           const bool rm2 = lr >= 2;
+          const double cs[4] = {lc >= 6 ? 1.0 : 0.0, (lc < 2 || lc >= 8) ? 1.0 : 0.0, lc < 4 ? 1.0 : 0.0, lc < NA ? dt : 0.0}; // column scale / mask
+          double csa[4], csb[4]; // ... x row mask of the two registers whose four rows are partly in G
+#pragma unroll
+          for (int J = 0; J < 4; J++)
+          {
+            csa[J] = rm2 ? cs[J] : 0.0;
+            csb[J] = rm2 ? 0.0 : cs[J];
+          }
+          const double csd = cs[3] * dt;
 #pragma unroll
           for (int tt = 0; tt < 10; tt++)
 #pragma unroll
@@ -674,16 +682,10 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
               const bool rnone = R0 < 4 || (R0 >= 20 && R0 < 24) || (R0 >= NDX && R0 < NDX + 12) || R0 >= NXU;
               if (rnone)
                 continue;
-              const bool racc = R0 >= NDX + 12;
+              const bool racc = R0 >= NDX + 12; // (tile (3, 3) only)
               const int pr0 = racc ? R0 - NDX - 12 + NV + 6 : R0, pc0 = J == 3 ? NV + 6 : 16 * J;
-              const bool m = cm[J] && (R0 == 4 ? rm2 : (R0 == 16 ? !rm2 : true));
-              const double pv = sP[m ? bR + pr0 * NDX + pc0 : ZP];
-              if (racc && J == 3)
-                SMPC_ACCV(hacc, tt, v) += dt * dt * pv;
-              else if (racc || J == 3)
-                SMPC_ACCV(hacc, tt, v) += dt * pv;
-              else
-                SMPC_ACCV(hacc, tt, v) += pv;
+              const double sc = racc ? csd : (R0 == 4 ? csa[J] : (R0 == 16 ? csb[J] : cs[J]));
+              SMPC_ACCV(hacc, tt, v) += sc * sP[bR + pr0 * NDX + pc0];
             }
           // ... of the vector column: E^T p~ (row NDX of the image)
           if (lc == NXU % 16)
@@ -706,6 +708,21 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
           }
         }
         SMPC_LANES_END_WAVE
+        // the dense rows of [A|B] are in registers: their block takes the contact rows of C (one contiguous run of the knot, 16 bytes per lane and
+        // copy, no registers), the small vectors of (5) go to registers -- all of it lands while the products run
+        SMPC_LANES(NT)
+        {
+          static_assert(4 * 2 * NT >= NG * NDX && 4 * 2 * NT <= LD::SCR && D::O_C + NA * NDX + 4 * 2 * NT <= D::LQ_STRIDE, "four copies of 64 x 16 bytes");
+#pragma unroll
+          for (int n = 0; n < 4; n++)
+            SMPC_COPY16_TO_LDS(lq + D::O_C + NA * NDX + 2 * (lane + NT * n), Cc + 2 * NT * n);
+          SMPC_PLV(pf_dc) = lq[D::O_d + NA + (lane < NG ? lane : 0)];
+          SMPC_PLV(pf_ba) = lq[D::O_C + (lane < NA ? lane * NDX + 6 + lane : 0)]; // 1 if the box row is active
+          SMPC_PLV(pf_bd) = lq[D::O_d + (lane < NA ? lane : 0)];
+          if (t > 0)
+            SMPC_PLV(f_pf) = lq[-(int)D::LQ_STRIDE + D::O_f + (lane < NDX ? lane : 0)]; // f of the next stage of the sweep
+        }
+        SMPC_LANES_END_WAVE
 #pragma unroll
         for (int ks = 0; ks < KS; ks++)
 #pragma unroll
@@ -718,35 +735,15 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
       prof_tick(prof, 8, tprev);
       // land_cstr rows present at this stage (wave-uniform: the stage descriptors are shared by the batch)
       const unsigned landrows = (EXT && b.ls != nullptr) ? (b.stages[t].land & b.stages[t].mask) : 0u;
-      // ---- (5) contact rows of C into LDS ; then  Q^ += C^T C / mu + box  (matrix cores, K = NG), the vector column
-      //          [q^ + C^T d / mu ; r^] goes into column NXU of the H^ grid ----
+      // ---- (5) Q^ += C^T C / mu + box  (matrix cores, K = NG), the vector column += C^T d / mu ----
+      SMPC_COPY_TO_LDS_WAIT();
       SMPC_LANES(NT)
       {
-        // (all loads first -- index clamped, values of out-of-range lanes unused --, then the LDS commits)
-        double ccv[CC_PL];
-        const int pl = SMPC_PIN(lane); // (keeps these loads here: hoisted above the products they are spilled)
-        static_assert(NT * CC_PL >= NG * NDX && NT * (CC_PL - 1) < NG * NDX, "the contact rows of C: CC_PL per lane");
-#pragma unroll
-        for (int n = 0; n < CC_PL; n++)
-        {
-          // the contact rows are one contiguous run of C
-          const int idx = pl + n * NT;
-          ccv[n] = lq[D::O_C + NA * NDX + (idx < NG * NDX ? idx : 0)];
-        }
-        const double vdc = lq[D::O_d + NA + (pl < NG ? pl : 0)];
-        const double vba = lq[D::O_C + (pl < NA ? pl * NDX + 6 + pl : 0)]; // 1 if the box row is active
-        const double vbd = lq[D::O_d + (pl < NA ? pl : 0)];
+        // (the contact rows are in Cc: asynchronous copy issued before the products of (4d))
+        const int pl = SMPC_PIN(lane);
         const double * ekp = (EXT && b.es != nullptr) ? b.ek + ((size_t)inst * H + t) * 12 * NF : lq; // (cone rows: [D | d] are contiguous)
         const double vce = ekp[pl < 8 * NF ? pl : 0];
-        if (t > 0)
-          SMPC_PLV(f_pf) = lq[-(int)D::LQ_STRIDE + D::O_f + (pl < NDX ? pl : 0)]; // f of the next stage of the sweep
-#pragma unroll
-        for (int n = 0; n < CC_PL; n++)
-        {
-          const int idx = lane + n * NT;
-          if (idx < NG * NDX)
-            Cc[idx] = ccv[n];
-        }
+        const double vdc = SMPC_PLV(pf_dc), vba = SMPC_PLV(pf_ba), vbd = SMPC_PLV(pf_bd);
         if (lane < NG)
           dcv[lane] = vdc;
         if (lane < NA)
@@ -892,12 +889,13 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
       //          (u, vector) entries -> R^^-1 r^ = -k ----
       wave_block_sweep<NT, 4, true, NDX, NU / 4, false, SMPC_KINO_RCP1>(hacc, sw2, sw2 + 4 * 64, prof, tprev);
       prof_tick(prof, 10, tprev);
-      // P_t -> LDS image (both halves; of a diagonal tile the upper entries), p_t -> its row NDX + 1, [K | k] -> staging; grouped by mask
+      // P_t -> LDS image (both halves; of a diagonal tile the upper entries), p_t -> its row NDX + 1, [K | k]^T -> gains block, from the registers
+      // (a 16-lane row of a tile = 12 consecutive u of one x); grouped by mask
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
         const int bR = lr * NDX + lc, bT = lc * NDX + lr;
-        const int bK = lc * (NDX + 1) + lr; // K[u][x] of tile entry (x = R0 + lr, u = U0 + lc)
+        const int bK = lr * NU + lc; // K^T[x][u] of tile entry (x = R0 + lr, u = U0 + lc)
         auto putP = [&](int tt, int v) SMPC_LAMBDA_INLINE {
           const int R0 = 16 * T4I[tt] + 4 * v, C0 = 16 * T4J[tt];
           const double val = SMPC_ACCV(hacc, tt, v);
@@ -906,7 +904,7 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
         };
         auto putK = [&](int tt, int v) SMPC_LAMBDA_INLINE {
           const int R0 = 16 * T4I[tt] + 4 * v, U0 = 16 * T4J[tt] - NDX;
-          Wm[bK + U0 * (NDX + 1) + R0] = -SMPC_ACCV(hacc, tt, v);
+          g[GK::G_W + bK + R0 * NU + U0] = -SMPC_ACCV(hacc, tt, v);
         };
         constexpr int h00 = tix<4>(0, 0), h01 = tix<4>(0, 1), h02 = tix<4>(0, 2), h03 = tix<4>(0, 3), h11 = tix<4>(1, 1), h12 = tix<4>(1, 2),
                       h13 = tix<4>(1, 3), h22 = tix<4>(2, 2), h23 = tix<4>(2, 3), h33 = tix<4>(3, 3);
@@ -962,25 +960,11 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
           sP[(NDX + 1) * NDX + 32 + lr] = SMPC_ACCV(hacc, h23, 0);
 #pragma unroll
           for (int v = 1; v < 4; v++)
-            Wm[(4 * v - 4 + lr) * (NDX + 1) + NDX] = -SMPC_ACCV(hacc, h23, v); // k
+            g[GK::G_W + NDX * NU + 4 * v - 4 + lr] = -SMPC_ACCV(hacc, h23, v); // k
 #pragma unroll
           for (int v = 0; v < 3; v++)
-            Wm[(12 + 4 * v + lr) * (NDX + 1) + NDX] = -SMPC_ACCV(hacc, h33, v);
+            g[GK::G_W + NDX * NU + 12 + 4 * v + lr] = -SMPC_ACCV(hacc, h33, v);
         }
-      }
-      SMPC_LANES_END_WAVE
-      SMPC_LANES(NT)
-      {
-        // [K | k] out: all LDS reads first, then the stores (a read-wait-store chain per row of 64 exposes the LDS latency 14 times)
-        constexpr int NW = (NU * (NDX + 1) + NT - 1) / NT;
-        double wv[NW];
-#pragma unroll
-        for (int n = 0; n < NW; n++)
-          wv[n] = Wm[lane + n * NT < NU * (NDX + 1) ? lane + n * NT : 0];
-#pragma unroll
-        for (int n = 0; n < NW; n++)
-          if (lane + n * NT < NU * (NDX + 1))
-            g[GK::G_W + lane + n * NT] = wv[n];
       }
       SMPC_LANES_END_WAVE
       prof_tick(prof, 13, tprev);
@@ -1149,11 +1133,11 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
         }
         if (lane < NU)
         {
-          const double * Wr = &W[lane * (NDX + 1)];
-          double acc = Wr[NDX];
+          const double * Wc = &W[lane]; // column `lane` of [K | k]^T
+          double acc = Wc[NDX * NU];
 #pragma unroll 4
           for (int j = 0; j < NDX; j++)
-            acc += Wr[j] * s.dx[j];
+            acc += Wc[j * NU] * s.dx[j];
           s.du[lane] = acc;
           b.dus[lt * NU + lane] = acc;
           s.part[lane] += vlu[lane] * acc;
@@ -1354,7 +1338,7 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
     {
 #pragma unroll 4
       for (int i = 0; i < NU; i++)
-        out[i * NDX + lane] = g[GK::G_W + i * (NDX + 1) + lane];
+        out[i * NDX + lane] = g[GK::G_W + lane * NU + i];
     }
     SMPC_LANES_END_WAVE
   }
@@ -1367,7 +1351,8 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
     Buffers<D> b;
     int s1, s0;        // ring slots of xs[1], us[0]
     int R;             // ring length
-    int g_off, g_str;  // [K k] rows (NDX + 1 apart) of stage 0 inside an instance's gains; doubles per (instance, stage)
+    int g_off, g_str;  // [K k] of stage 0 inside an instance's gains; doubles per (instance, stage)
+    int g_tr;          // 0: rows of NDX + 1 (K(u, x) at u (NDX + 1) + x) ; 1: the structured sweep's transposed block (x NU + u)
     size_t row;
     double * out;
   };
@@ -1388,7 +1373,7 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
       for (int i = lane; i < NU; i += NT)
         out[NX + i] = u[i];
       for (int i = lane; i < NU * NDX; i += NT)
-        out[NX + NU + i] = g[(i / NDX) * (NDX + 1) + i % NDX];
+        out[NX + NU + i] = pa.g_tr ? g[(i % NDX) * NU + i / NDX] : g[(i / NDX) * (NDX + 1) + i % NDX];
     }
     SMPC_LANES_END_WAVE
   }

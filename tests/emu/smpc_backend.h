@@ -55,6 +55,8 @@
 #define SMPC_UNIFORM_F64(x) (x)
 #define SMPC_PIN(x) (x)
 #define SMPC_TOUCH(gptr, lds_sink) ((void)(gptr), (void)(lds_sink))
+#define SMPC_COPY16_TO_LDS(gptr, lds_dst) std::memcpy((char *)(lds_dst) + 16 * lane, (const void *)(gptr), 16)
+#define SMPC_COPY_TO_LDS_WAIT() ((void)0)
 #define SMPC_RSQRT(x) (1.0 / std::sqrt(x))
 #define SMPC_RCP(x) (1.0 / (x))
 #define SMPC_RCP1(x) (1.0 / (x))
