@@ -377,7 +377,12 @@ namespace smpc
     SMPC_PLV(f_pf) = b.lq[((size_t)inst * H + (H - 1)) * D::LQ_STRIDE + D::O_f + (lane < NDX ? lane : 0)];
     SMPC_LANES_END_WAVE
 
+#ifdef SMPC_KINO_RICCATI_PROF
     double * prof = (b.dbg != nullptr && block == 0) ? b.dbg : nullptr; // optional phase timers (block 0 only)
+#else
+    // (phase timers: an experiment build, tools/variant_build.sh <name> -DSMPC_KINO_RICCATI_PROF -- their 63 uniform branches per stage cost 1 %)
+    double * prof = nullptr;
+#endif
     long long tprev = SMPC_CLOCK();
     for (int t = H - 1; t >= 0; t--)
     {
@@ -777,12 +782,17 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
           if (lane < NDX)
           {
             const int i = lane;
-            double cd = 0.0;
-#pragma unroll 4
+            // (all reads first: a rolled loop waits for the LDS once per trip)
+            double cc[NG];
+#pragma unroll
             for (int r = 0; r < NG; r++)
-              cd += Cc[r * NDX + i] * dcv[r];
-            if (IX::isQj(i))
-              cd += boxact[i - 6] * boxd[i - 6];
+              cc[r] = Cc[r * NDX + i];
+            const bool bx = IX::isQj(i);
+            const double bb = boxact[bx ? i - 6 : 0] * boxd[bx ? i - 6 : 0];
+            double cd = bx ? bb : 0.0;
+#pragma unroll
+            for (int r = 0; r < NG; r++)
+              cd += cc[r] * dcv[r];
             qh[i] = imu * cd; // (this phase's part of the vector column; added to it below)
           }
           if (landrows != 0u && lane < NV)
@@ -809,16 +819,21 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
-          // box rows: unit selectors -> diagonal contribution on the qj entries
+          // box rows: unit selectors -> diagonal contribution on the qj entries (rows 6 .. NV - 1: registers (0, 0) v = 1, 2, 3 and (1, 1) v = 0);
+          // all reads first, no predicated read-wait-add per register
+          {
+            double ba[4];
 #pragma unroll
-          for (int I = 0; I < 3; I++)
-#pragma unroll
-            for (int v = 0; v < 4; v++)
+            for (int n = 0; n < 4; n++)
             {
-              const int row = 16 * I + lr + 4 * v;
-              if (lc == lr + 4 * v && IX::isQj(row))
-                SMPC_ACCV(hacc, tix<4>(I, I), v) += imu * boxact[row - 6];
+              const int R0 = n < 3 ? 4 * (n + 1) : 16, v = n < 3 ? n + 1 : 0;
+              const bool m = lc == lr + 4 * v && R0 + lr >= 6 && R0 + lr < NV;
+              ba[n] = boxact[m ? R0 + lr - 6 : 0] * (m ? imu : 0.0);
             }
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+              SMPC_ACCV(hacc, tix<4>(n < 3 ? 0 : 1, n < 3 ? 0 : 1), n < 3 ? n + 1 : 0) += ba[n];
+          }
           // land rows: Q^[q, q] += c^T c / mu (rank one per landing foot; at most a few stages of a horizon have any)
           if (landrows != 0u)
           {

@@ -20,7 +20,7 @@ kt = gm.kernel_times()
 print('NT=%s B=%d k=%d: %.1f ms/step  %.0f steps/s |' % (os.environ.get('SMPC_RICCATI_NT','256'), B, iters, dt*1e3, B/dt), ' '.join('%s %.2f' % (k, v[0]/max(1,v[1])) for k,v in kt.items()), '| finite', bool(np.isfinite(gm.info).all()))
 if os.environ.get('SMPC_PHASE_PROFILE'):
     out = np.zeros(64); gm._lib.check(gm._lib.L.smpc_debug_get_phase_cycles(gm._h, out))
-    names = ['loadM','pt0','chol36','subst36','Ptilde','ptilde+io','PEG','TG','products','writeback','chol24','subst24','loadC','Pt']
+    names = ['c','-','AB_prefetch','build','Ptilde_out','Hprefetch','colpass','TG','products','Cphase','-','-','-','Pt_out']  # riccati_kino_body slots (a -DSMPC_KINO_RICCATI_PROF build)
     n = (steps+1)*iters*gm.H
     print('phase cycles per stage (block 0):', ' '.join('%s %.0f' % (nm, out[i]/n) for i,nm in enumerate(names)), '| total %.0f' % (out[:14].sum()/n))
     print('  sweep parts per stage (15 panels): gather %.0f  invert+U %.0f  operands+mfma %.0f  fixup %.0f' % tuple(out[36:40]/n))
