@@ -247,7 +247,7 @@ extern "C"
     const HostMpcSettings ms = host_mpc(mpc);
     return guarded([&] {
       std::unique_ptr<smpc_handle> h(new smpc_handle());
-#if !defined(SMPC_KINO_ONLY)
+#if !defined(SMPC_KINO_ONLY) || defined(SMPC_XCHECK_SUBSET) // (the cross-check HIP build: Go2 kinodynamics + both centroidal engines)
       if (quad)
         h->cent.reset(new CentEngine<FullTalos, CentTalos>(robot, cs, ms, batch, gravity_arg, device_id));
       else

@@ -246,18 +246,18 @@ namespace smpc
         x6.parts0 = dalloc((size_t)B * (H + 1) * 4);
         x6.partsT = dalloc((size_t)B * DC::LS_N * (H + 1) * 2);
         x6.xdotT = dalloc((size_t)B * DC::LS_N * 18);
-        ls_passes = (std::getenv("SMPC_CENT6_LS_PASSES") && std::getenv("SMPC_CENT6_LS_PASSES")[0] == '2' && DC::LS_N > 1) ? 2 : 1;
+        ls_passes = (xcheck_env("SMPC_CENT6_LS_PASSES") && xcheck_env("SMPC_CENT6_LS_PASSES")[0] == '2' && DC::LS_N > 1) ? 2 : 1;
       }
       if constexpr (DC::FS == 3)
       {
-        fused = std::getenv("SMPC_CENT_FUSED") != nullptr && std::getenv("SMPC_CENT_FUSED")[0] == '1';
+        fused = xcheck_env("SMPC_CENT_FUSED") != nullptr && xcheck_env("SMPC_CENT_FUSED")[0] == '1';
         if (!fused)
         {
           if (BH * CentRec<DC>::STRIDE >= ((size_t)1 << 32))
             throw std::runtime_error("centroidal OCP: batch x horizon too large for the 32-bit record offsets");
           sbuf.rec = dalloc(BH * CentRec<DC>::STRIDE);
           sbuf.term = dalloc((size_t)B * CentRec<DC>::T_STRIDE);
-          const char * le = std::getenv("SMPC_CENT_LS");
+          const char * le = xcheck_env("SMPC_CENT_LS");
           ls_direct = le != nullptr && le[0] == 'd';
           const char * pe = std::getenv("SMPC_CENT_PARTS");
           nparts = pe ? std::atoi(pe) : (B >= 1024 ? 2 : 1);
@@ -482,7 +482,10 @@ namespace smpc
         }
       }
       else if (fused)
-        timed_launch<CentStepArgs<DC>, cent_step_body<DC>, 64, 2>(CKID_STEP, B, a, aux);
+      {
+        if constexpr (kCrossCheck) // (the one-kernel form: SMPC_CENT_FUSED=1 of a cross-check build)
+          timed_launch<CentStepArgs<DC>, cent_step_body<DC>, 64, 2>(CKID_STEP, B, a, aux);
+      }
       else
         launch_split_part(a, aux, 0, B, nullptr, nullptr, nullptr, nullptr);
     }

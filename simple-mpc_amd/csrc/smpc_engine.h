@@ -359,14 +359,14 @@ namespace smpc
     double * stage_out = nullptr; // staging for linearised outputs
     size_t stage_out_bytes = 0;
     int cold_iters = 0;
-    int riccati_nt = std::getenv("SMPC_RICCATI_NT") ? std::atoi(std::getenv("SMPC_RICCATI_NT")) : 128; // dense sweep: lanes per instance
+    int riccati_nt = xcheck_env("SMPC_RICCATI_NT") ? std::atoi(xcheck_env("SMPC_RICCATI_NT")) : 128; // dense sweep: lanes per instance
     // SMPC_RICCATI=dense selects the model-independent sweep (A/B comparison and cross-check in the tests)
-    bool structured_riccati = !(std::getenv("SMPC_RICCATI") && std::string(std::getenv("SMPC_RICCATI")) == "dense");
+    bool structured_riccati = !(xcheck_env("SMPC_RICCATI") && std::string(xcheck_env("SMPC_RICCATI")) == "dense");
     std::vector<double> cold_trace; // [n][4] phi0, prim, dual, alpha
     // profiling
     bool profiling = false;
     static constexpr int LS_SLOTS = 64; // instance slots of the list-mode (backtracking) launches: 64 x (H+1) blocks when the list is empty
-    bool speculative_ls = std::getenv("SMPC_NO_SPECULATIVE_LS") == nullptr; // tentative full steps (run_iterations)
+    bool speculative_ls = xcheck_env("SMPC_NO_SPECULATIVE_LS") == nullptr; // tentative full steps (run_iterations)
     bool early_exit_on_tol = false; // smpc_set_early_exit_on_tol: iterate() stops an instance's iterations once it is converged to TOL
     bool aux_launches = false; // true during the cold start: every launch uses the auxiliary kernel symbols
     // lane-per-problem stage evaluation (smpc_kino_lane.h) for problems without optional constraint blocks; SMPC_LANE_EVAL=0: the
@@ -374,10 +374,10 @@ namespace smpc
     int lane_slots = 1;
     // The derivative pass starts from the lane-per-problem evaluation too (lane_tree_body + deriv2_body: 0.27 + 3.1 ms per launch at
     // B = 4096 against 4.3 - 4.7 ms for the one-kernel path); SMPC_LANE_DERIV=0: the one-kernel path (A/B comparison)
-    bool lane_deriv = !(std::getenv("SMPC_LANE_DERIV") && std::atoi(std::getenv("SMPC_LANE_DERIV")) == 0);
+    bool lane_deriv = !(xcheck_env("SMPC_LANE_DERIV") && std::atoi(xcheck_env("SMPC_LANE_DERIV")) == 0);
     size_t handover_bytes = 0; // device memory of the lane hand-over (tiles + stream)
-    bool lane_eval = !(std::getenv("SMPC_LANE_EVAL") && std::atoi(std::getenv("SMPC_LANE_EVAL")) == 0);
-    bool lane_stream = !(std::getenv("SMPC_LANE_STREAM") && std::atoi(std::getenv("SMPC_LANE_STREAM")) == 0);
+    bool lane_eval = !(xcheck_env("SMPC_LANE_EVAL") && std::atoi(xcheck_env("SMPC_LANE_EVAL")) == 0);
+    bool lane_stream = !(xcheck_env("SMPC_LANE_STREAM") && std::atoi(xcheck_env("SMPC_LANE_STREAM")) == 0);
     bool stream_order_recorded = false;
     int foot_joint_h[D::NF] = {0}; // (host copy for deriv2_commit_code)
     double kernel_ms[KID_N] = {0};
@@ -452,7 +452,7 @@ namespace smpc
         for (int j = 0; j < D::NU; j++)
           if (i != j && m.w_u[i * D::NU + j] != 0.0)
             m.w_diag = 0;
-      if (std::getenv("SMPC_FORCE_DENSE_WEIGHTS"))
+      if (xcheck_env("SMPC_FORCE_DENSE_WEIGHTS"))
         m.w_diag = 0; // test hook: exercise the general path with diagonal data
       for (int i = 0; i < D::NDX; i++)
         m.wxd[i] = m.w_x[i * D::NDX + i];
@@ -761,9 +761,9 @@ namespace smpc
         else
           timed_launch<StageKernelArgs<D>, deriv2_body<D, false>, 64, SMPC_DERIV2_MINW>(kid, xcd_grid(n, H), stage_args(b, slots), slots > 0);
       }
-      else if (has_ext(b))
+      else if (has_ext(b) || !kCrossCheck) // (without the lane hand-over -- allocation refused -- the shipped library runs the instantiation it has)
         timed_launch<StageKernelArgs<D>, deriv_body<D, true>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
-      else
+      else if constexpr (kCrossCheck)
         timed_launch<StageKernelArgs<D>, deriv_body<D, false>, 64, 2>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
     }
     // line-search evaluation of the candidates sk.j0 .. sk.j0 + sk.nj - 1 (sk.slots > 0: for the compacted list of undecided instances)
@@ -786,9 +786,9 @@ namespace smpc
           timed_launch<LaneKernelArgs<D>, lane_tree_body<D, 2>, 64, SMPC_LANE_MINW>(kid_tree, (H + 1) * ((n + 63) / 64), la, aux);
         timed_launch<StageKernelArgs<D>, trial_rows_body<D>, 64>(kid, xcd_grid(n, H), sk, aux);
       }
-      else if (has_ext(b))
+      else if (has_ext(b) || !kCrossCheck)
         timed_launch<StageKernelArgs<D>, trial_body<D, true>, 64, TRIAL_MINW>(kid, (sk.slots > 0 ? sk.slots : b.B) * (H + 1), sk, aux);
-      else
+      else if constexpr (kCrossCheck)
         timed_launch<StageKernelArgs<D>, trial_body<D, false>, 64, TRIAL_MINW>(kid, (sk.slots > 0 ? sk.slots : b.B) * (H + 1), sk, aux);
     }
     // backward + forward sweep: Newton step and merit directional derivative
@@ -808,9 +808,9 @@ namespace smpc
           timed_launch<SolverArgs<D>, forward_kino_body<D, false>, 64>(KID_FORWARD, b.B, solver_args(b));
         }
       }
-      else
+      else if constexpr (kCrossCheck)
       {
-        // dense, model-independent sweep (kept for models without the semi-implicit row structure)
+        // dense, model-independent sweep (cross-check of the structured one: SMPC_RICCATI=dense)
         switch (riccati_nt)
         {
         case 64:

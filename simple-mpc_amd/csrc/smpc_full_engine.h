@@ -98,8 +98,8 @@ namespace smpc
     double * X_dev = nullptr;
     double * stage_out = nullptr;
     size_t stage_out_bytes = 0;
-    bool valu_riccati = std::getenv("SMPC_RICCATI") && std::string(std::getenv("SMPC_RICCATI")) == "valu";
-    bool speculative_ls = std::getenv("SMPC_NO_SPECULATIVE_LS") == nullptr;
+    bool valu_riccati = xcheck_env("SMPC_RICCATI") && std::string(xcheck_env("SMPC_RICCATI")) == "valu";
+    bool speculative_ls = xcheck_env("SMPC_NO_SPECULATIVE_LS") == nullptr;
     bool early_exit_on_tol = false; // smpc_set_early_exit_on_tol
     void set_early_exit(bool on) override { early_exit_on_tol = on; }
     bool aux_launches = false;
@@ -164,7 +164,7 @@ namespace smpc
         for (int j = 0; j < D::NU; j++)
           if (i != j && m.w_u[i * D::NU + j] != 0.0)
             m.w_diag = 0;
-      if (std::getenv("SMPC_FORCE_DENSE_WEIGHTS"))
+      if (xcheck_env("SMPC_FORCE_DENSE_WEIGHTS"))
         m.w_diag = 0;
       for (int i = 0; i < D::NDX; i++)
         m.wxd[i] = m.w_x[i * D::NDX + i];
@@ -391,7 +391,7 @@ namespace smpc
     }
     void launch_sweeps(const Buffers<D> & b)
     {
-      if constexpr (D::NCD == 0)
+      if constexpr (D::NCD == 0 && kCrossCheck)
       {
         if (valu_riccati)
         {

@@ -205,6 +205,16 @@ namespace smpc
   };
 
   // optional in-kernel phase timer: accumulates shader cycles since the previous tick into dbg[slot]
+  // Cross-check builds (-DSMPC_CROSSCHECK: the sequential-lane test build, and libsmpc_hip_xcheck.so of the GPU tests) carry the alternative
+  // paths of the engines -- the dense / VALU sweeps, the one-kernel stage and centroidal forms, the sequential line search -- and the environment
+  // switches that select them.  The shipped library has neither: xcheck_env() is nullptr there and the launches sit under `if constexpr`.
+#ifdef SMPC_CROSSCHECK
+  constexpr bool kCrossCheck = true;
+  inline const char * xcheck_env(const char * name) { return std::getenv(name); }
+#else
+  constexpr bool kCrossCheck = false;
+  inline const char * xcheck_env(const char *) { return nullptr; }
+#endif
   SMPC_DEV void prof_tick(double * dbg, int slot, long long & tprev)
   {
     if (!dbg)

@@ -15,6 +15,9 @@
 #include <string>
 
 #define SMPC_CPU_EMU_BUILD 1
+#ifndef SMPC_CROSSCHECK
+#define SMPC_CROSSCHECK 1 // the alternative paths of the engines and their environment switches (smpc_model.h)
+#endif
 #define SMPC_HD inline
 #define SMPC_DEV inline
 #define SMPC_DEV_NOINLINE inline

@@ -33,6 +33,21 @@ def emu_lib():
     return _emu
 
 
+_xcheck = None
+
+
+def xcheck_lib():
+    """The -DSMPC_CROSSCHECK HIP build (alternative engine paths + their environment switches; test infrastructure of the GPU tier)."""
+    global _xcheck
+    if _xcheck is None:
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+
+        g.build_hip(with_xcheck=True)
+        _xcheck = SmpcLib(g.XCHECK_LIB)
+    return _xcheck
+
+
 def make_product(batch, max_iters=1, lib=None, horizon=50, settings_override=None, mpc_override=None, device_id=0):
     rb = O.Robot("go2_like")
     s = O.go2_kino_settings(rb)

@@ -85,7 +85,7 @@ def test_emu_long_horizon_uses_the_reevaluating_line_search(lib):
 # ------------------------------------------------------------------------------------------------ GPU tier
 @pytest.mark.gpu
 def test_hip_pipeline_equals_its_alternatives():
-    _cases(None, 1e-9)
+    _cases(S.xcheck_lib(), 1e-9)  # (SMPC_CENT_FUSED / SMPC_CENT_LS exist in the cross-check build only)
 
 
 @pytest.mark.gpu

@@ -52,7 +52,7 @@ def test_lane_derivative_path_matches_oracle_emulated(monkeypatch):
 
 @pytest.mark.gpu
 def test_lane_paths_match_the_one_kernel_path_gpu(monkeypatch):
-    _check(None, monkeypatch, 1e-8)
+    _check(S.xcheck_lib(), monkeypatch, 1e-8)  # (the one-kernel path of a cone-free problem lives in the cross-check build)
 
 
 def _stream_pair(monkeypatch, lib, bitwise, **kw):
@@ -79,4 +79,4 @@ def test_stream_handover_is_the_tile_handover_gpu(monkeypatch, batch):
     #  running along; the random states make some instances backtrack: list-mode launches with a few entries.  The two forms of the tree
     #  kernel are separate template instantiations: the compiler contracts a few multiply-adds differently in them, so single instances
     #  differ in the last bit after some steps -- 1e-16 .. 4e-14 observed, tools/stream_cmp.py; the CPU build of the kernels is bit-identical)
-    _stream_pair(monkeypatch, None, False, steps=6, batch=batch, max_iters=3, horizon=20)
+    _stream_pair(monkeypatch, S.xcheck_lib(), False, steps=6, batch=batch, max_iters=3, horizon=20)

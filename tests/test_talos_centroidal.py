@@ -167,7 +167,7 @@ def test_emulated_kernels_two_pass_line_search(built):
 
 @pytest.mark.gpu
 def test_hip_two_pass_line_search(built):
-    _two_pass_line_search(None, 8)
+    _two_pass_line_search(S.xcheck_lib(), 8)  # (SMPC_CENT6_LS_PASSES: a switch of the cross-check build)
 
 
 @pytest.mark.gpu
