@@ -30,7 +30,10 @@ def main():
            "git_commit": os.environ.get("SMPC_PROFILE_COMMIT", ""), "kernels": res}
     status = 0
     if len(sys.argv) > 3:
-        line = json.loads([ln for ln in open(sys.argv[3]).read().splitlines() if ln.startswith('{"metric"')][-1])
+        # (the full object of the run: bench.py prints it to stderr as "bench.py full line: {...}"; its last stdout line is the compact one)
+        lines = open(sys.argv[3]).read().splitlines()
+        full = [ln[len("bench.py full line: "):] for ln in lines if ln.startswith("bench.py full line: ")]
+        line = json.loads(full[-1] if full else [ln for ln in lines if ln.startswith('{"metric"')][-1])
         checks = {}
         rl = dict(line.get("roofline_other", {}))
         if "roofline" in line and "avg_launch_ms" in line["roofline"]:

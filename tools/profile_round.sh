@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/<tag>_* is made from, in one call on the GPU box:
 #   gpurun --timeout 2400 -- "bash tools/profile_round.sh r03a $(git rev-parse --short HEAD)"
-# Writes gpurun_out/<tag>_{bench,bench_centroidal}.json, <tag>_kernel_stats.csv (all workloads), <tag>_kernel_stats_headline.csv and
+# Writes gpurun_out/<tag>_{bench,bench_full,bench_side,bench_centroidal}.json, <tag>_kernel_stats.csv (all workloads), <tag>_kernel_stats_headline.csv and
 # <tag>_kernel_durations.json (the headline workload alone under the profiler: full-batch launches only, checked against the HIP-event
 # averages of that same run's bench line), <tag>_kernel_durations_all.json (every workload's full-batch launches), <tag>_pmc_hbm_traffic.json, <tag>_pmc_sq.json, <tag>_fp64_peak.json;
 # copy them into profiles/ afterwards.  The PMC passes are separate rocprofv3 runs with --kernel-trace only (no other trace
@@ -19,6 +19,8 @@ BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 [ -x tools/micro/fp64_peak.bin ] && ./tools/micro/fp64_peak.bin 1.0 > "$OUT/${TAG}_fp64_peak.json"
 python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err" || echo "bench failed"
 tail -1 "$OUT/${TAG}_bench.json" | cut -c1-300
+cp bench_full.json "$OUT/${TAG}_bench_full.json" 2> /dev/null # (everything the run measured; the printed line is the compact object)
+cp bench_side.json "$OUT/${TAG}_bench_side.json" 2> /dev/null
 python3 bench.py --workload centroidal > "$OUT/${TAG}_bench_centroidal.json" 2>> "$OUT/${TAG}_bench.err" || echo "centroidal bench failed"
 
 run_prof() { # name, rocprofv3 options...
