@@ -560,6 +560,15 @@ extern "C"
     mat_to(o.Cx, Cx);
     mat_to(o.Cu, Cu);
   }
+  // terminal cost of the full-dynamics OCP (state + 10 x centroidal, orc_fulldyn.hpp: term_eval) -- what tests/test_oracle_vs_scipy.py adds to
+  // the stage costs on the side of the independent solver
+  double orc_full_term(void * h, const double * x_tgt, const double * x)
+  {
+    FullModel * md = (FullModel *)h;
+    Rigid R(md->M);
+    Vec xt(x_tgt, x_tgt + md->nx);
+    return md->term_eval(R, xt, x);
+  }
   // ProxDDP on an H-stage problem with the same references at every stage (masks per stage), from the constant guess
   // (x0, u0): up to max_iter iterations with the stopping rules of the cold solve (orc_mpc.hpp).  trace: [iter][6] =
   // prim_infeas, dual_infeas, cost, phi0, alpha, ls_failed.  Returns the iteration count.

@@ -89,6 +89,8 @@ def lib():
     L.orc_full_set_land_cstr.argtypes = [vp, C.c_int]
     L.orc_kino_term.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
     L.orc_kino_term_cstr.argtypes = [vp, _dp, _dp, C.c_double, _dp, _dp]
+    L.orc_full_term.argtypes = [vp, _dp, _dp]
+    L.orc_full_term.restype = C.c_double
     L.orc_centroidal.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_full_forward_dynamics.argtypes = [vp, _dp, _dp, C.c_uint, C.c_int, _dp, _dp] + [_dp] * 7
     L.orc_full_forward_dynamics.restype = C.c_int
@@ -494,6 +496,10 @@ class Full:
         k, lo, hi = np.zeros(self.nc, np.int32), np.zeros(self.nc), np.zeros(self.nc)
         lib().orc_full_row_kinds(self.h, int(mask), k, lo, hi)
         return k, lo, hi
+
+    def term(self, x_tgt, x):
+        """Terminal cost (state + 10 x centroidal)."""
+        return float(lib().orc_full_term(self.h, np.ascontiguousarray(x_tgt, float), np.ascontiguousarray(x, float)))
 
     def solve(self, masks, u_ref, x_tgt, foot_ref, x0, u0, max_iter=50, tol=1e-4, mu=1e-8):
         c = lambda a: np.ascontiguousarray(a, float)
