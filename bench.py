@@ -184,12 +184,14 @@ def main():
     if args.workload != "kinodynamics":
         if world > 1 or dry:
             raise SystemExit("--workload %s is a single-GPU line" % args.workload)
+        import bench_side
+
         measure_fp64_peak()
         if args.workload == "centroidal":
-            line = centroidal_line(B, args.iters, args.steps, args.warmup, local_rank, not args.no_cpu_baseline)
+            line = bench_side.centroidal_line(B, args.iters, args.steps, args.warmup, local_rank, not args.no_cpu_baseline)
         else:
-            line = fulldynamics_line(B, args.iters, args.steps, args.warmup, local_rank, not args.no_cpu_baseline,
-                                     robot="talos" if args.workload == "talos" else "go2")
+            line = bench_side.fulldynamics_line(B, args.iters, args.steps, args.warmup, local_rank, not args.no_cpu_baseline,
+                                                robot="talos" if args.workload == "talos" else "go2")
         line.update({"n_gpus": 1, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
         print(json.dumps(line))
         return

@@ -244,32 +244,6 @@ class Robot:
         self.mass = float(m[0])
         self.x_ref = np.concatenate([self.q_ref, np.zeros(self.nv)])
 
-    @classmethod
-    def with_centred_com(cls, name="talos_like"):
-        """A copy of the built-in table whose centre of mass, in the reference configuration, lies over the centre of the feet (the mass
-        centre of the base body is moved; every other entry is the table's).  The synthetic talos_like table carries its CoM 6.6 mm behind the
-        centre of its soles -- a standing simulation without ground is an inverted pendulum, and that lever arm, not the controller, is what
-        makes the reference's contactQuad tests drift at their own force weight (tests/test_inverse_dynamics_quad.py)."""
-        import ctypes
-
-        sys_path_added = os.path.join(ROOT, "simple-mpc_amd", "python")
-        if sys_path_added not in sys.path:
-            sys.path.insert(0, sys_path_added)
-        from simple_mpc._capi import RobotModelC
-
-        base = cls(name)
-        var = RobotModelC.from_buffer_copy(ctypes.cast(base.ptr, ctypes.POINTER(RobotModelC)).contents)
-        c = base.centroidal(base.x_ref)
-        off = np.asarray(c["com"])[:2] - np.asarray(c["feet"]).reshape(base.nf, 3).mean(0)[:2]
-        assert np.allclose(base.x_ref[3:7], [0, 0, 0, 1])  # (base frame = world frame in the reference configuration)
-        for i in range(2):
-            var.com[0][i] -= off[i] * var.total_mass / var.mass[0]
-        r = cls.__new__(cls)
-        r._table = var  # (keeps the copy alive)
-        r.ptr = ctypes.addressof(var)
-        r._init_from_ptr()
-        return r
-
     def integrate(self, x, dx):
         out = np.zeros(self.nx)
         lib().orc_x_integrate(self.ptr, np.ascontiguousarray(x, float), np.ascontiguousarray(dx, float), out)

@@ -151,7 +151,7 @@ def talos_like():
     parameters are Talos-like values entered by hand (the URDF is not available here); total mass about 91 kg."""
     r = Robot("talos_like")
     b = lambda m, c, d: (m, c, inertia_mat(d[0], 0, 0, d[1], 0, d[2]))
-    r.add_joint(-1, 0, [0, 0, 0], (15.0, [-0.05, 0.0, -0.02], inertia_mat(0.2, 0.0, 0.01, 0.1, 0.0, 0.2)))
+    r.add_joint(-1, 0, [0, 0, 0], (15.0, [-0.00978, 0.0, -0.02], inertia_mat(0.2, 0.0, 0.01, 0.1, 0.0, 0.2)))  # (mass centre placed so that the robot's CoM at half_sitting is over the centre of its soles)
     for nm, sy in (("left", 1), ("right", -1)):
         j1 = r.add_joint(0, 3, [-0.02, 0.085 * sy, -0.27], b(1.9, [0.02, 0.0, 0.03], (0.004, 0.006, 0.004)), -0.35, 1.57)
         j2 = r.add_joint(j1, 1, [0, 0, 0], b(2.0, [-0.01, 0.0, 0.0], (0.004, 0.004, 0.003)), -0.52, 0.52)
