@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include "smpc_alloc_scope.h"
 
 #define SMPC_HD __host__ __device__ __forceinline__
 #define SMPC_DEV __device__ __forceinline__
@@ -214,13 +215,17 @@ namespace smpc
       (void)hipFree(p); // (a caller that handles the failure -- the hand-over fall-backs -- must not leak the block)
       hip_check(e, "zero-fill of a fresh allocation", __FILE__, __LINE__);
     }
+    AllocScope::note_alloc(p); // (released again if the constructor that asked for it throws: smpc_alloc_scope.h)
     return p;
   }
   inline void dev_clear_error() { (void)hipGetLastError(); } // after a failed allocation that the caller handles
   inline void dev_free(void * p)
   {
     if (p)
+    {
+      AllocScope::note_free(p);
       (void)hipFree(p);
+    }
   }
   inline void h2d(void * dst, const void * src, size_t bytes, stream_t s)
   {

@@ -154,6 +154,7 @@ namespace smpc
     CentEngine(const smpc_robot_model * rm, const HostCentSettings & cs, const HostMpcSettings & ms_, int batch, double gravity_arg, int device)
     : ms(ms_)
     {
+      AllocScope ctor_scope; // (a throw below releases what was allocated so far: smpc_alloc_scope.h)
       if (batch <= 0)
         throw std::runtime_error("batch must be positive");
       if (cs.force_size != DC::FS)
@@ -296,6 +297,7 @@ namespace smpc
       horizon.assign(H, def);
       standing = def;
       cold_solve(def);
+      ctor_scope.commit();
     }
     ~CentEngine()
     {

@@ -390,6 +390,7 @@ namespace smpc
     KinoEngine(const smpc_robot_model * rm, const HostKinoSettings & ks, const HostMpcSettings & ms_, int batch, double gravity_arg, int device)
     : ms(ms_)
     {
+      AllocScope ctor_scope; // (a throw below releases what was allocated so far: smpc_alloc_scope.h)
       if (rm->njoints != D::NJ || rm->nfeet != D::NF)
         throw std::runtime_error("robot shape (njoints, nfeet) does not match this kernel instantiation");
       if (batch <= 0)
@@ -606,6 +607,7 @@ namespace smpc
       cold_solve(def);
       for (int f = 0; f < D::NF; f++)
         buf.land_z[f] = ref_foot_pos[f][2]; // contact poses of the cycle stages: the feet at the reference state (src/mpc.cpp:162)
+      ctor_scope.commit();
     }
     bool land_cstr = false;
     ~KinoEngine()

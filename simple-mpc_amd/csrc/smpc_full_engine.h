@@ -116,6 +116,7 @@ namespace smpc
     FullEngine(const smpc_robot_model * rm, const HostFullSettings & fs, const HostMpcSettings & ms_, int batch, double gravity_arg, int device)
     : ms(ms_)
     {
+      AllocScope ctor_scope; // (a throw below releases what was allocated so far: smpc_alloc_scope.h)
       if (rm->njoints != D::NJ || rm->nfeet != D::NF)
         throw std::runtime_error("robot shape (njoints, nfeet) does not match this kernel instantiation");
       if (fs.force_size != D::FS)
@@ -290,6 +291,7 @@ namespace smpc
       horizon.assign(H, def);
       standing = def;
       cold_solve(def, m);
+      ctor_scope.commit();
     }
     ~FullEngine()
     {

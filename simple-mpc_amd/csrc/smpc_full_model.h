@@ -83,6 +83,9 @@ namespace smpc
     // gains block per (instance, stage)
     static constexpr int G_K = 0;                          // [K k]  NU x (NDX+1)
     static constexpr int G_Z = G_K + NU * (NDX + 1);       // [Z z]  NCD x (NDX+1)  (multiplier feedback of the dense rows)
+    // INVARIANT of G_Z: rows of INACTIVE dense constraint rows are not written by the light grid of riccati_dense_body (stale values of an
+    // earlier iteration / stage stay there); every reader -- forward_full_body, cent6_forward_body -- forms d / mu itself for a row whose
+    // activity flag lq[O_act + ...] is 0 and never reads [Z z] of it.  A new reader of G_Z must test the same flag.
     static constexpr int G_Pt = G_Z + NCD * (NDX + 1);     // P~ (NDX x NDX)
     static constexpr int G_pn = G_Pt + NDX * NDX;          // p_{t+1}
     static constexpr int G_STRIDE = ((G_pn + NDX + 7) / 8) * 8;

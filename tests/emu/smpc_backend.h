@@ -13,6 +13,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include "smpc_alloc_scope.h"
 
 #define SMPC_CPU_EMU_BUILD 1
 #ifndef SMPC_CROSSCHECK
@@ -95,10 +96,16 @@ namespace smpc
     void * p = std::calloc(bytes ? bytes : 8, 1);
     if (!p)
       throw std::runtime_error("emu: out of memory");
+    AllocScope::note_alloc(p);
     return p;
   }
   inline void dev_clear_error() {}
-  inline void dev_free(void * p) { std::free(p); }
+  inline void dev_free(void * p)
+  {
+    if (p)
+      AllocScope::note_free(p);
+    std::free(p);
+  }
   inline void h2d(void * dst, const void * src, size_t bytes, stream_t) { std::memcpy(dst, src, bytes); }
   inline void d2h(void * dst, const void * src, size_t bytes, stream_t) { std::memcpy(dst, src, bytes); }
   inline void d2h_2d(void * dst, size_t dpitch, const void * src, size_t spitch, size_t width, size_t height, stream_t)
