@@ -1483,7 +1483,6 @@ namespace smpc
     bool mask_all_valid = false; // (the per-robot setters invalidate it)
     IdEngine(const smpc_robot_model * rm, const HostIdSettings & hs, int batch, int device)
     {
-      AllocScope ctor_scope; // (a throw below releases what was allocated so far: smpc_alloc_scope.h)
       if (rm->njoints != D::NJ || rm->nfeet != D::NF)
         throw std::runtime_error("robot shape (njoints, nfeet) does not match this kernel instantiation");
       if (batch <= 0)
@@ -1615,7 +1614,6 @@ namespace smpc
           st3(&fp[3 * k], ld3(q.data()) + R0 * ld3(rm->foot_ref_p[k]));
         set_target_centroidal(-1, com, z.data(), fp.data(), zf.data(), (1u << nf) - 1u, f.data());
       }
-      ctor_scope.commit();
     }
     ~IdEngine()
     {
