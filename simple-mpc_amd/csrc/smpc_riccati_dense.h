@@ -57,11 +57,13 @@ namespace smpc
     static constexpr int NDX = D::NDX, NU = D::NU;
     static constexpr int SWP = 4 * 16 * GM::NTM;
     static constexpr int N_SCR = 2 * SWP;
-    double P[NDX * NDX];      // P_{t+1} -> P~ -> P_t
+    // rows 0 .. NDX-1: P_{t+1} -> P~ -> P_t (full symmetric image); row NDX: c = p_{t+1} - f / mu; row NDX+1: p_{t+1} -> p_t -- the vector column of
+    // the first sweep's bordered matrix is read through the same (column, row) addresses as the matrix entries (smpc_riccati_kino.h, round 6)
+    double P[(NDX + 2) * NDX];
     double scr[N_SCR];        // sweep operands (2 x 4 x 16 NT)
     // ([A | B] is not staged: its 16 x 4 operand slices are read from the knot twice, coalesced along the rows, one K-step ahead
     //  of the products that consume them -- 36 KB of LDS per wave are worth more as resident waves)
-    double p[NDX], pt0[NDX], pt[NDX], f[NDX];
+    double pt[NDX];
     double boxa[D::NU + D::NA], boxd[D::NU + D::NA + GM::NCD]; // activity of the box rows ; d = mu (nu+ - nu) of all rows
     double cact[GM::NCP > 0 ? GM::NCP : 1];                    // activity of the dense rows (padded to whole panels)
   };
@@ -86,8 +88,13 @@ namespace smpc
       for (int i = lane; i < NDX * NDX; i += NT)
         s.P[i] = b.QN[(size_t)inst * NDX * NDX + i];
       for (int i = lane; i < NDX; i += NT)
-        s.p[i] = b.qN[(size_t)inst * NDX + i];
+        s.P[(NDX + 1) * NDX + i] = b.qN[(size_t)inst * NDX + i];
     }
+    SMPC_LANES_END_WAVE
+    static_assert(NDX <= NT, "one entry of f / p per lane");
+    SMPC_PL(double, f_pf, NT); // f of the stage, fetched one stage ahead
+    SMPC_LANES(NT)
+    SMPC_PLV(f_pf) = b.lq[((size_t)inst * H + (H - 1)) * D::LQ_STRIDE + D::O_f + (lane < NDX ? lane : 0)];
     SMPC_LANES_END_WAVE
     double * prof = (b.dbg != nullptr && block == 0) ? b.dbg : nullptr; // optional phase timers (block 0 only): slots 40 .. 46
     long long tprev = prof ? SMPC_CLOCK() : 0;
@@ -99,14 +106,17 @@ namespace smpc
       // nothing, so its panel is left out of the sweep and z = d / mu is written directly.  (The flags are fetched by the lanes of
       // phase (1) with their other loads; the mask is formed from LDS afterwards.)
       unsigned skip = 0u;
-      // ---- (1) f ; box rows ; save p_{t+1} ; pt0 = p + P f ----
+      // ---- (1) box rows ; save p_{t+1} ; c = p - f / mu (the vector column of the pivot rows of (2)) ; f of the next stage ----
       SMPC_LANES(NT)
       {
-        for (int i = lane; i < NDX; i += NT)
+        if (lane < NDX)
         {
-          s.f[i] = lq[D::O_f + i];
-          g[D::G_pn + i] = s.p[i];
+          const double pv = s.P[(NDX + 1) * NDX + lane];
+          g[D::G_pn + lane] = pv;
+          s.P[NDX * NDX + lane] = pv - imu * SMPC_PLV(f_pf);
         }
+        if (t > 0)
+          SMPC_PLV(f_pf) = lq[-(int)D::LQ_STRIDE + D::O_f + (lane < NDX ? lane : 0)];
         for (int i = lane; i < NU + NA; i += NT)
           s.boxa[i] = lq[D::O_act + i];
         for (int i = lane; i < NU + NA + NCD; i += NT)
@@ -130,23 +140,23 @@ namespace smpc
         SMPC_LANES_END_WAVE
         skip = m;
       }
-      SMPC_LANES(NT)
-      for (int i = lane; i < NDX; i += NT)
-      {
-        double acc = s.p[i];
-#pragma unroll 4
-        for (int j = 0; j < NDX; j++)
-          acc += s.P[j * NDX + i] * s.f[j];
-        s.pt0[i] = acc;
-      }
-      SMPC_LANES_END_WAVE
       prof_tick(prof, 40, tprev);
-      // ---- (2) P~ and p~: Schur complement of the bordered matrix (pivots: the first NDX rows) ----
+      // ---- (2) P~ and p~: Schur complement of the leading NDX pivots of  [[P + I / mu, P, c], [P, P, p]],  c = p - f / mu:
+      //          P - P (P + I/mu)^-1 P = (I + mu P)^-1 P = P~,   p - mu P~ c = p + P~ (f - mu p) = p~   (the same elimination as on
+      //          [[I + mu P, sqrt(mu) P], [., P]] with the pivot rows / columns scaled by 1 / sqrt(mu); no scaling, no P f product).
+      //          Element (R, C) of a tile <- image[C' * NDX + R']: compile-time offsets from four per-lane bases (smpc_riccati_kino.h) ----
       {
         SMPC_ACC(t1, NT, NT1 * (NT1 + 1) / 2);
+        constexpr int JW = NDX / 16, LW = NDX % 16;             // tile column holding column NDX, its first lane there
+        constexpr int JV = (2 * NDX) / 16, LV = (2 * NDX) % 16; // tile column / lane of the vector column
+        static_assert(JV < NT1 && (LW == 0 || JW != JV), "geometry of the bordered matrix");
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
+          const int bA = lc * NDX + lr;
+          const int bW = (lc < LW ? 16 * JW + lc : lc - LW) * NDX + lr;                       // tile column JW: C = 16 JW + lc wraps at NDX
+          const int bVp = (lc < LV ? 16 * JV - NDX + lc : (lc == LV ? NDX : NDX + 1)) * NDX + lr; // tile column JV, pivot rows: ..., c, (padding: p)
+          const int bVs = (lc < LV ? 16 * JV - NDX + lc : NDX + 1) * NDX + lr;                  // tile column JV, other rows: ..., p, (padding: p)
 #pragma unroll
           for (int I = 0; I < NT1; I++)
 #pragma unroll
@@ -154,43 +164,85 @@ namespace smpc
 #pragma unroll
               for (int v = 0; v < 4; v++)
               {
-                const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
-                const int r = row < col ? row : col, c = row < col ? col : row;
-                const int ri = r < NDX ? r : r - NDX, ci = c < NDX ? c : c - NDX;
-                const bool isv = c == 2 * NDX && r < 2 * NDX, ism = c < 2 * NDX;
-                const double pv = s.P[(ism ? ri * NDX + ci : 0)];
-                const double tv = s.pt0[isv ? ri : 0];
-                double val = ism ? pv : (isv ? tv : 0.0);
-                const double scale = c < NDX ? mu : ((r < NDX && (ism || isv)) ? smu : 1.0);
-                val = val * scale + ((c < NDX && r == c) ? 1.0 : 0.0);
+                const int R0 = 16 * I + 4 * v; // (compile-time: NDX is a multiple of 4)
+                double val = 0.0;
+                if (R0 < 2 * NDX)
+                {
+                  const bool piv = R0 < NDX;
+                  const int Rp = piv ? R0 : R0 - NDX;
+                  const int base = J == JV ? (piv ? bVp : bVs) : ((LW != 0 && J == JW) ? bW : (16 * J + 15 < NDX ? bA + 16 * J * NDX : bA + (16 * J - NDX) * NDX));
+                  val = s.P[base + Rp];
+                  if (piv && I == J && lc == lr + 4 * v)
+                    val += imu;
+                }
                 SMPC_ACCV(t1, tix<NT1>(I, J), v) = val;
               }
         }
         SMPC_LANES_END_WAVE
         wave_block_sweep<NT, NT1, false, 0, NDX / 4>(t1, sw, sw + LDS::SWP, prof, tprev);
+        // P~ (rows / columns NDX .. 2 NDX of the grid) -> LDS image, both halves, upper entries of a diagonal tile only; p~ -> pt.  Stores grouped
+        // by execution mask (a predicate per store costs four scalar instructions and a branch)
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
+          const int bR = lr * NDX + lc, bT = lc * NDX + lr;
+          auto put = [&](int I, int J, int v) SMPC_LAMBDA_INLINE {
+            const int Rp = 16 * I + 4 * v - NDX, Cp = 16 * J - NDX;
+            const double val = SMPC_ACCV(t1, tix<NT1>(I, J), v);
+            s.P[bR + Rp * NDX + Cp] = val;
+            s.P[bT + Cp * NDX + Rp] = val;
+          };
+          auto rows = [](int I, int v) { return 16 * I + 4 * v >= NDX && 16 * I + 4 * v < 2 * NDX; };
+          // diagonal tiles: lanes lc >= lr + 4 v (and inside the block's columns)
 #pragma unroll
-          for (int I = NDX / 16; I < NT1; I++) // tile rows that reach into the Schur block (rows NDX .. 2 NDX)
+          for (int v = 0; v < 4; v++)
+            if (lc >= lr + 4 * v)
+            {
 #pragma unroll
-            for (int J = I; J < NT1; J++)
+              for (int I = JW; I <= JV; I++)
+                if (rows(I, v))
+                {
+                  if (I == JV)
+                  {
+                    if (lc < LV)
+                      put(I, I, v);
+                  }
+                  else if (I == JW && LW != 0)
+                  {
+                    if (lc >= LW)
+                      put(I, I, v);
+                  }
+                  else
+                    put(I, I, v);
+                }
+            }
+          // off-diagonal tiles: all lanes, but for the tile column of the vector column
+#pragma unroll
+          for (int I = JW; I < JV; I++)
+#pragma unroll
+            for (int J = I + 1; J < JV; J++)
 #pragma unroll
               for (int v = 0; v < 4; v++)
-              {
-                const int row = 16 * I + lr + 4 * v, col = 16 * J + lc;
-                const double val = SMPC_ACCV(t1, tix<NT1>(I, J), v);
-                if (row >= NDX && row < 2 * NDX && col >= row)
-                {
-                  if (col < 2 * NDX)
-                  {
-                    s.P[(row - NDX) * NDX + col - NDX] = val;
-                    s.P[(col - NDX) * NDX + row - NDX] = val;
-                  }
-                  else if (col == 2 * NDX)
-                    s.pt[row - NDX] = val;
-                }
-              }
+                if (rows(I, v))
+                  put(I, J, v);
+          if (lc < LV)
+          {
+#pragma unroll
+            for (int I = JW; I < JV; I++)
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+                if (rows(I, v))
+                  put(I, JV, v);
+          }
+          if (lc == LV)
+          {
+#pragma unroll
+            for (int I = JW; I <= JV; I++)
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+                if (rows(I, v))
+                  s.pt[16 * I + 4 * v - NDX + lr] = SMPC_ACCV(t1, tix<NT1>(I, JV), v);
+          }
         }
         SMPC_LANES_END_WAVE
       }
@@ -414,7 +466,7 @@ namespace smpc
                   else if (drowx(col) >= 0)
                     g[D::G_Z + drowx(col) * (NDX + 1) + row] = -val; // Z: multiplier feedback of the dense rows
                   else if (col == VCX)
-                    s.p[row] = val; // p_t
+                    s.P[(NDX + 1) * NDX + row] = val; // p_t
                 }
                 else if (row < NXU && col == VCX)
                   g[D::G_K + (row - NDX) * (NDX + 1) + NDX] = -val; // k
