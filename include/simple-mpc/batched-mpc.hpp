@@ -270,6 +270,23 @@ namespace simple_mpc
       check(smpc_get_reference_pose(h_, (int)t, foot(ee_name), 0, p.data()));
       return p;
     }
+    // ... with the rotation of the SE3 (row-major 3 x 3): kept and returned (reference tests/problem.cpp:157-160) until the next iterate, which
+    // rewrites every stage's pose with the identity rotation (src/mpc.cpp:303-309)
+    struct Placement
+    {
+      double translation[3];
+      double rotation[9];
+    };
+    void setReferencePose(std::size_t t, const std::string & ee_name, const Placement & M)
+    {
+      check(smpc_set_reference_pose_se3(h_, (int)t, foot(ee_name), M.translation, M.rotation));
+    }
+    Placement getReferencePlacement(std::size_t t, const std::string & ee_name)
+    {
+      Placement M;
+      check(smpc_get_reference_pose_se3(h_, (int)t, foot(ee_name), 0, M.translation, M.rotation));
+      return M;
+    }
     std::vector<bool> getContactState(std::size_t t)
     {
       std::vector<uint8_t> c(ee_names_.size());

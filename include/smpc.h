@@ -190,6 +190,13 @@ int smpc_get_stage_reference(smpc_handle * h, int t, int what, double * v, int n
 /* setReferencePose / getReferencePose (translation; src/kinodynamics.cpp:154-169, src/centroidal-dynamics.cpp:151-188) */
 int smpc_set_reference_pose(smpc_handle * h, int t, int foot, const double * p3);
 int smpc_get_reference_pose(smpc_handle * h, int t, int foot, int instance, double * p3);
+/* ... with the rotation of the SE3 (R9: row-major 3 x 3; src/kinodynamics.cpp:154-170, reference tests/problem.cpp:157-160: what was set is
+ * what is returned).  MPC::iterate overwrites every stage's pose with (identity rotation, Bezier position) before it solves
+ * (src/mpc.cpp:303-309): so does smpc_iterate -- no solve behind this boundary ever evaluates another rotation (the stage kernels use
+ * M_ref = (I, p)); a rotation set here lives until the next control step, exactly as in the reference.  smpc_set_reference_pose (translation
+ * only) sets the identity rotation. */
+int smpc_set_reference_pose_se3(smpc_handle * h, int t, int foot, const double * p3, const double * R9);
+int smpc_get_reference_pose_se3(smpc_handle * h, int t, int foot, int instance, double * p3, double * R9);
 /* getContactState(t): contact flag per foot (src/kinodynamics.cpp:343-349); getContactSupport = their sum */
 int smpc_get_contact_state(smpc_handle * h, int t, uint8_t * out_nfeet);
 /* MPC::getCyclingContactState(t, ee_name) for every foot: entry t of the (rotating) contact sequence the cycle horizon was generated

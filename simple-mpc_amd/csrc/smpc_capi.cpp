@@ -462,6 +462,32 @@ extern "C"
       return guarded([&] { h->cent->get_reference_pose(t, foot, instance, p3); });
     return guarded([&] { h->eng->get_reference_pose(t, foot, instance, p3); });
   }
+  int smpc_set_reference_pose_se3(smpc_handle * h, int t, int foot, const double * p3, const double * R9)
+  {
+    if (!h || !p3 || !R9)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    const int rc = smpc_set_reference_pose(h, t, foot, p3);
+    if (rc != SMPC_OK)
+      return rc;
+    if (h->full)
+      return guarded([&] { h->full->set_reference_rotation(t, foot, R9); });
+    if (h->cent)
+      return guarded([&] { h->cent->set_reference_rotation(t, foot, R9); });
+    return guarded([&] { h->eng->set_reference_rotation(t, foot, R9); });
+  }
+  int smpc_get_reference_pose_se3(smpc_handle * h, int t, int foot, int instance, double * p3, double * R9)
+  {
+    if (!h || !p3 || !R9)
+      return fail(SMPC_ERR_INVALID, "null argument");
+    const int rc = smpc_get_reference_pose(h, t, foot, instance, p3);
+    if (rc != SMPC_OK)
+      return rc;
+    if (h->full)
+      return guarded([&] { h->full->get_reference_rotation(t, foot, R9); });
+    if (h->cent)
+      return guarded([&] { h->cent->get_reference_rotation(t, foot, R9); });
+    return guarded([&] { h->eng->get_reference_rotation(t, foot, R9); });
+  }
   int smpc_get_contact_state(smpc_handle * h, int t, uint8_t * out)
   {
     if (!h || !out)

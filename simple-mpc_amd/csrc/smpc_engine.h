@@ -607,6 +607,7 @@ namespace smpc
       cold_solve(def);
       for (int f = 0; f < D::NF; f++)
         buf.land_z[f] = ref_foot_pos[f][2]; // contact poses of the cycle stages: the feet at the reference state (src/mpc.cpp:162)
+      ref_rot.init(H, D::NF);
       ctor_scope.commit();
     }
     bool land_cstr = false;
@@ -1107,6 +1108,7 @@ namespace smpc
     // One control step for the whole batch; Xd: device pointer [B][NX]
     void iterate_device(const double * Xd)
     {
+      ref_rot.reset(); // (every control step rewrites every stage's reference pose with the identity rotation: src/mpc.cpp:303-309)
       if (cycle.empty())
         throw std::runtime_error("generateCycleHorizon must be called before iterate");
       // ---- recedeWithCycle (host, shared by the batch) ----
@@ -1278,6 +1280,7 @@ namespace smpc
       check_stage(t);
       if (foot < 0 || foot >= D::NF)
         throw std::runtime_error("unknown end effector");
+      ref_rot.set(t, foot, nullptr); // (a translation: identity rotation)
       fill_strided(buf.foot_ref + ((size_t)t * D::NF + foot) * 3, (size_t)H * D::NF * 3, B, p3, 3);
     }
     void get_reference_pose(int t, int foot, int inst, double * p3)
@@ -1286,6 +1289,21 @@ namespace smpc
       if (foot < 0 || foot >= D::NF || inst < 0 || inst >= B)
         throw std::runtime_error("unknown end effector or instance");
       get_linear(buf.foot_ref + (((size_t)inst * H + t) * D::NF + foot) * 3, 3, p3);
+    }
+    RefRotations ref_rot; // rotations of the foot reference placements: API state (smpc_model.h)
+    void set_reference_rotation(int t, int foot, const double * R9)
+    {
+      check_stage(t);
+      if (foot < 0 || foot >= D::NF)
+        throw std::runtime_error("unknown end effector");
+      ref_rot.set(t, foot, R9);
+    }
+    void get_reference_rotation(int t, int foot, double * R9)
+    {
+      check_stage(t);
+      if (foot < 0 || foot >= D::NF)
+        throw std::runtime_error("unknown end effector");
+      ref_rot.get(t, foot, R9);
     }
     unsigned contact_mask(int t) const
     {

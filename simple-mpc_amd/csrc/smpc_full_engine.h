@@ -52,6 +52,8 @@ namespace smpc
     virtual void get_stage_reference(int t, int what, double * v, int n) = 0;
     virtual void set_reference_pose(int t, int foot, const double * p3) = 0;
     virtual void get_reference_pose(int t, int foot, int inst, double * p3) = 0;
+    virtual void set_reference_rotation(int t, int foot, const double * R9) = 0;
+    virtual void get_reference_rotation(int t, int foot, double * R9) = 0;
     virtual unsigned contact_mask(int t) const = 0;
     virtual void update_internal_data(const double * X, double * feet, double * com, double * hg, double * cstate) = 0;
     virtual void full_forward_dynamics(int n, const double * X, const double * tau, const unsigned * mask, const double * Kp, const double * Kd,
@@ -291,6 +293,7 @@ namespace smpc
       horizon.assign(H, def);
       standing = def;
       cold_solve(def, m);
+      ref_rot.init(H, D::NF);
       ctor_scope.commit();
     }
     ~FullEngine()
@@ -658,6 +661,7 @@ namespace smpc
 
     void iterate_device(const double * Xd) override
     {
+      ref_rot.reset(); // (every control step rewrites every stage's reference pose with the identity rotation: src/mpc.cpp:303-309)
       if (cycle.empty())
         throw std::runtime_error("generateCycleHorizon must be called before iterate");
       int last_support = 0;
@@ -835,6 +839,7 @@ namespace smpc
       check_stage(t);
       if (foot < 0 || foot >= D::NF)
         throw std::runtime_error("unknown end effector");
+      ref_rot.set(t, foot, nullptr); // (a translation: identity rotation)
       fill_strided(buf.foot_ref + ((size_t)t * D::NF + foot) * 3, (size_t)H * D::NF * 3, B, p3, 3);
     }
     void get_reference_pose(int t, int foot, int inst, double * p3) override
@@ -843,6 +848,21 @@ namespace smpc
       if (foot < 0 || foot >= D::NF || inst < 0 || inst >= B)
         throw std::runtime_error("unknown end effector or instance");
       get_linear(buf.foot_ref + (((size_t)inst * H + t) * D::NF + foot) * 3, 3, p3);
+    }
+    RefRotations ref_rot; // rotations of the foot reference placements: API state (smpc_model.h)
+    void set_reference_rotation(int t, int foot, const double * R9) override
+    {
+      check_stage(t);
+      if (foot < 0 || foot >= D::NF)
+        throw std::runtime_error("unknown end effector");
+      ref_rot.set(t, foot, R9);
+    }
+    void get_reference_rotation(int t, int foot, double * R9) override
+    {
+      check_stage(t);
+      if (foot < 0 || foot >= D::NF)
+        throw std::runtime_error("unknown end effector");
+      ref_rot.get(t, foot, R9);
     }
     unsigned contact_mask(int t) const override
     {

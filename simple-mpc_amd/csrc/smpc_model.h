@@ -7,6 +7,7 @@
 // slot(t) = (head + t) % R: receding the horizon (reference: replaceStageCircular + cycleProblem,
 // src/mpc.cpp:225-226) is a head increment, not a memmove.
 #pragma once
+#include <vector>
 #include "../../include/smpc_robot.h"
 #include <smpc_backend.h>
 
@@ -205,6 +206,52 @@ namespace smpc
   };
 
   // optional in-kernel phase timer: accumulates shader cycles since the previous tick into dbg[slot]
+  // Rotations of the foot reference placements, [H][nf] row-major 3 x 3 (host side).  OCPHandler::setReferencePose takes a full SE3 and
+  // getReferencePose returns it (reference src/kinodynamics.cpp:154-170, tests/problem.cpp:157-160); MPC::iterate overwrites every stage's
+  // pose with (identity rotation, Bezier position) before it solves (src/mpc.cpp:303-309), so no solve of this boundary ever sees another
+  // rotation: the stage kernels evaluate M_ref = (I, p), this table carries what was set until the next iterate resets it -- as the reference does.
+  struct RefRotations
+  {
+    std::vector<double> R;
+    int H = 0, nf = 0;
+    bool any = false; // some entry is not the identity
+    void init(int H_, int nf_)
+    {
+      H = H_;
+      nf = nf_;
+      R.assign((size_t)H * nf * 9, 0.0);
+      for (size_t i = 0; i < (size_t)H * nf; i++)
+        R[i * 9] = R[i * 9 + 4] = R[i * 9 + 8] = 1.0;
+      any = false;
+    }
+    void set(int t, int f, const double * R9)
+    {
+      double * r = &R[((size_t)t * nf + f) * 9];
+      if (R9 == nullptr)
+      {
+        for (int i = 0; i < 9; i++)
+          r[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        return;
+      }
+      for (int i = 0; i < 9; i++)
+      {
+        r[i] = R9[i];
+        if (R9[i] != ((i % 4 == 0) ? 1.0 : 0.0))
+          any = true;
+      }
+    }
+    void get(int t, int f, double * R9) const
+    {
+      const double * r = &R[((size_t)t * nf + f) * 9];
+      for (int i = 0; i < 9; i++)
+        R9[i] = r[i];
+    }
+    void reset() // (every control step: src/mpc.cpp:303-309)
+    {
+      if (any)
+        init(H, nf);
+    }
+  };
   // Cross-check builds (-DSMPC_CROSSCHECK: the sequential-lane test build, and libsmpc_hip_xcheck.so of the GPU tests) carry the alternative
   // paths of the engines -- the dense / VALU sweeps, the one-kernel stage and centroidal forms, the sequential line search -- and the environment
   // switches that select them.  The shipped library has neither: xcheck_env() is nullptr there and the launches sit under `if constexpr`.

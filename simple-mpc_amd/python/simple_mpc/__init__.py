@@ -260,10 +260,12 @@ class _StageReferences:
 
     # foot references (reference src/kinodynamics.cpp:154-228, src/centroidal-dynamics.cpp:120-188)
     def setReferencePose(self, t, ee_name, pose_ref):
+        """pose_ref: an SE3-like object (`.translation`, `.rotation`), a 4 x 4 homogeneous matrix or a translation.  The rotation is kept and
+        returned by getReferencePose (reference tests/problem.cpp:157-160); like the reference's, it lives until the next MPC.iterate, which
+        rewrites every stage's pose with the identity rotation before it solves (src/mpc.cpp:303-309)."""
         m = self._handle()
-        _require_identity_rotation(pose_ref, self)
-        p = np.ascontiguousarray(getattr(pose_ref, "translation", pose_ref), float).reshape(3)
-        m._lib.check(m._lib.L.smpc_set_reference_pose(m._h, int(t), self._foot(ee_name), p))
+        p, R = _pose_parts(pose_ref)
+        m._lib.check(m._lib.L.smpc_set_reference_pose_se3(m._h, int(t), self._foot(ee_name), p, R))
 
     def setReferencePoses(self, t, pose_refs):
         if len(pose_refs) != self.model_handler.getFeetNb():
@@ -272,10 +274,12 @@ class _StageReferences:
             self.setReferencePose(t, name, pose_refs[name])
 
     def getReferencePose(self, t, ee_name):
+        """The reference placement of the foot at stage t: a `Pose` -- a 3-vector (the translation, as before) that also carries `.translation`,
+        `.rotation` and `.homogeneous` (the SE3 of the reference)."""
         m = self._handle()
-        p = np.zeros(3)
-        m._lib.check(m._lib.L.smpc_get_reference_pose(m._h, int(t), self._foot(ee_name), 0, p))
-        return p
+        p, R = np.zeros(3), np.zeros(9)
+        m._lib.check(m._lib.L.smpc_get_reference_pose_se3(m._h, int(t), self._foot(ee_name), 0, p, R))
+        return Pose(p, R.reshape(3, 3))
 
     # state target and its segments
     def setReferenceState(self, t, x_ref):
@@ -1305,11 +1309,55 @@ class KinodynamicsID:
         return out
 
 
+class Pose(np.ndarray):
+    """Reference placement of a foot: the translation as a 3-vector (what earlier versions of getReferencePose returned), with the SE3's parts as
+    attributes: `.translation`, `.rotation` (3 x 3), `.homogeneous` (4 x 4)."""
+
+    def __new__(cls, translation, rotation=None):
+        obj = np.asarray(translation, dtype=np.float64).reshape(3).copy().view(cls)
+        obj.rotation = np.eye(3) if rotation is None else np.asarray(rotation, dtype=np.float64).reshape(3, 3).copy()
+        return obj
+
+    def __array_finalize__(self, obj):
+        if obj is not None:
+            self.rotation = getattr(obj, "rotation", np.eye(3))
+
+    @property
+    def translation(self):
+        return np.asarray(self)
+
+    @property
+    def homogeneous(self):
+        M = np.eye(4)
+        M[:3, :3] = self.rotation
+        M[:3, 3] = np.asarray(self)
+        return M
+
+    def __eq__(self, other):
+        if hasattr(other, "rotation") and hasattr(other, "translation"):
+            return bool(np.array_equal(np.asarray(self), np.asarray(other.translation).reshape(3)) and np.array_equal(self.rotation, np.asarray(other.rotation).reshape(3, 3)))
+        return np.ndarray.__eq__(self, other)
+
+    __hash__ = None
+
+
+def _pose_parts(pose_ref):
+    """(translation [3], rotation [9]) of an SE3-like object, a 4 x 4 homogeneous matrix or a translation."""
+    if hasattr(pose_ref, "translation"):
+        p = np.ascontiguousarray(pose_ref.translation, float).reshape(3)
+        R = np.ascontiguousarray(getattr(pose_ref, "rotation", np.eye(3)), float).reshape(9)
+        return p, R
+    a = np.asarray(pose_ref, float)
+    if a.shape == (4, 4):
+        return np.ascontiguousarray(a[:3, 3]), np.ascontiguousarray(a[:3, :3]).reshape(9)
+    return np.ascontiguousarray(a, float).reshape(3), np.eye(3).reshape(9)
+
+
 def _require_identity_rotation(pose_ref, ocp=None):
-    """The foot references of this build carry a translation only: the 6-D placement residual of flat feet (reference
-    src/kinodynamics.cpp:66-72,154-170, FramePlacementResidual with a full SE3 reference; CentroidalID's TaskSE3Equality, src/inverse-dynamics/
-    centroidal-id.cpp:109-113) is evaluated against (identity rotation, p) -- level soles.  A reference with another rotation must not be
-    replaced by the identity silently: it is refused.  (Point feet and the centroidal OCP use the translation only, as the reference does.)"""
+    """Targets of the inverse-dynamics controllers (CentroidalID's TaskSE3Equality, src/inverse-dynamics/centroidal-id.cpp:109-113) are tracked as
+    (identity rotation, p) -- level soles: a target with another rotation is refused, not dropped.  (The OCP handlers KEEP the rotation of a
+    reference pose and return it -- setReferencePose / getReferencePose -- although no solve uses it: MPC.iterate rewrites every pose with the
+    identity rotation first, as the reference's does.)"""
     rot = getattr(pose_ref, "rotation", None)
     if rot is None:
         return

@@ -150,7 +150,7 @@ class RobotModelC(C.Structure):
 SYMBOLS = [
     "smpc_builtin_robot", "smpc_last_error", "smpc_device_count", "smpc_create", "smpc_create_centroidal", "smpc_create_fulldynamics", "smpc_get_contact_forces", "smpc_destroy", "smpc_get_dims",
     "smpc_generate_cycle_horizon", "smpc_switch_to_walk", "smpc_switch_to_stand", "smpc_set_velocity_base_batched", "smpc_set_stage_reference", "smpc_get_stage_reference", "smpc_set_reference_pose",
-    "smpc_get_reference_pose", "smpc_get_contact_state", "smpc_get_cycling_contact_state", "smpc_debug_get_extra_multipliers", "smpc_set_x_reference",
+    "smpc_get_reference_pose", "smpc_set_reference_pose_se3", "smpc_get_reference_pose_se3", "smpc_get_contact_state", "smpc_get_cycling_contact_state", "smpc_debug_get_extra_multipliers", "smpc_set_x_reference",
     "smpc_state_size", "smpc_save_state", "smpc_load_state", "smpc_iterate", "smpc_iterate_device", "smpc_wait", "smpc_get_stream", "smpc_get_x_device", "smpc_get_xs", "smpc_get_us", "smpc_get_K0", "smpc_get_Ks",
     "smpc_get_vs", "smpc_get_lams", "smpc_get_state_derivative01", "smpc_get_reference_poses",
     "smpc_set_early_exit_on_tol", "smpc_iterate_async", "smpc_gather_outputs", "smpc_gather_outputs_device", "smpc_gather_outputs_peer", "smpc_get_foot_timing", "smpc_get_info", "smpc_get_status", "smpc_get_cold_trace", "smpc_lq_size", "smpc_debug_get_lq",
@@ -214,6 +214,8 @@ class SmpcLib:
         L.smpc_get_stage_reference.argtypes = [vp, C.c_int, C.c_int, _dp, C.c_int]
         L.smpc_set_reference_pose.argtypes = [vp, C.c_int, C.c_int, _dp]
         L.smpc_get_reference_pose.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp]
+        L.smpc_set_reference_pose_se3.argtypes = [vp, C.c_int, C.c_int, _dp, _dp]
+        L.smpc_get_reference_pose_se3.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp, _dp]
         L.smpc_get_contact_state.argtypes = [vp, C.c_int, _bp]
         L.smpc_get_cycling_contact_state.argtypes = [vp, C.c_int, C.c_void_p]
         L.smpc_id_create.argtypes = [vp, C.POINTER(IdSettingsC), C.c_int, C.c_int, C.POINTER(vp)]
