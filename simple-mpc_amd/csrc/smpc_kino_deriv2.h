@@ -194,16 +194,18 @@ namespace smpc
         {
           const int h = (SMPC_PLV(oi)[n] >> 16) - 1; // (commit code: deriv2_commit_code)
           const double v = SMPC_PLV(vb)[n];
-          if (h >= 0)
-          {
-            rs.head[h] = v;
-            if (h >= L::H_footp && h < L::H_footp + 3 * NF)
-              sc.footp[h - L::H_footp] = v;
-            if (h >= L::H_hg && h < L::H_hg + 6)
-              sc.hg[h - L::H_hg] = v;
-            if (h >= L::H_hd && h < L::H_hd + 6)
-              sc.hd[h - L::H_hd] = v;
-          }
+          // two unconditional stores per element, the destinations by address select (a predicate per store costs a compare, two scalar
+          // mask instructions and a branch: 44 of them per block): elements that are no head fields go to a dump slot (red[3], unused)
+          static_assert(L::H_hg == L::H_footp + 3 * NF && L::H_hd == L::H_hg + 6 && L::HEAD == L::H_hd + 6, "footp | hg | hd end the head");
+          double * const scb0 = reinterpret_cast<double *>(&sc);
+          const int o_dump = (int)(&sc.red[3] - scb0), o_head = (int)(rs.head - scb0);
+          const int o_fp = (int)(sc.footp - scb0) - L::H_footp, o_hg = (int)(sc.hg - scb0) - L::H_hg, o_hd = (int)(sc.hd - scb0) - L::H_hd;
+          const int d1 = h >= 0 ? o_head + h : o_dump;
+          int d2 = h >= L::H_footp ? h + o_fp : o_dump;
+          d2 = h >= L::H_hg ? h + o_hg : d2;
+          d2 = h >= L::H_hd ? h + o_hd : d2;
+          scb0[d1] = v;
+          scb0[d2] = v;
         }
       }
       else
