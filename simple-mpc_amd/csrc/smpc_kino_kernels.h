@@ -284,29 +284,18 @@ namespace smpc
       const bool isA = lane < NDX;
       const int k = isA ? lane : lane - NDX;
       const double lam_prev_v = b.lams[(ib + sprev) * NDX + (isA ? k : 0)]; // lambda_t (used at the end of the phase)
-      // top block source column: Dtop[m] (m<6) = d(dx_q)[m]/d(col)
+      // top block source column: Dtop[m] (m<6) = d(dx_q)[m]/d(col).  Branch-free: the three sources (d/dq, d/dv, d/du blocks) by a per-lane pointer
+      // and stride, the lane-dependent extra terms by selects -- all LDS reads of the phase are issued unconditionally, side by side
       double Dtop[6], Dbot[6];
+      const bool isAv = isA && k >= NV; // a velocity column of A
+      const int kk = isAv ? k - NV : k;
+      const double * const dsrc = isA ? (isAv ? sc.ab_dv() + kk : sc.ab_dq() + k) : sc.ab_du() + k;
+      const int dstride = isA ? NV : NU;
+#pragma unroll
       for (int m = 0; m < 6; m++)
       {
-        if (isA)
-        {
-          if (k < NV)
-          {
-            Dbot[m] = dt * sc.ab_dq()[m * NV + k];
-            Dtop[m] = dt * Dbot[m];
-          }
-          else
-          {
-            const int kk = k - NV;
-            Dbot[m] = dt * sc.ab_dv()[m * NV + kk];
-            Dtop[m] = dt * Dbot[m] + (m == kk ? dt : 0.0);
-          }
-        }
-        else
-        {
-          Dbot[m] = dt * sc.ab_du()[m * NU + k];
-          Dtop[m] = dt * Dbot[m];
-        }
+        Dbot[m] = dt * dsrc[m * dstride];
+        Dtop[m] = dt * Dbot[m] + ((isAv && m == kk) ? dt : 0.0);
       }
       double acc = 0.0; // (A^T lam_next)[k] or (B^T lam_next)[k]
       double * dst = lq + (isA ? D::O_A : D::O_B);
@@ -314,17 +303,18 @@ namespace smpc
       // only the 12 rows G = qb u vb are state dependent; rows qj / vj are the constant integrator pattern
       // (e_i + dt e_{v(i)} | dt^2 e_a and e_i | dt e_a), written once by lq_init_body
       // (the multiplier products are accumulated in row order, like a dense A^T lam)
+      const double jq_on = (isA && k < 6) ? 1.0 : 0.0;
+      const int jq_k = (isA && k < 6) ? k : 0;
 #pragma unroll
       for (int gi = 0; gi < 12; gi++)
       {
         const int i = gi < 6 ? gi : NV + gi - 6;
         if (gi == 6)
         {
-          // rows qj
-          if (isA)
-            acc += (k >= 6 && k < NV) ? sc.lam_next[k] : (k >= NV + 6 ? dt * sc.lam_next[k - NV] : 0.0);
-          else
-            acc += k >= 3 * NF ? dt * dt * sc.lam_next[6 + k - 3 * NF] : 0.0;
+          // rows qj: lam_next[k] (A, k in qj), dt lam_next[k - NV] (A, k in vj), dt^2 lam_next[6 + k - 3 NF] (B, accelerations)
+          const int li = isA ? kk : (k >= 3 * NF ? 6 + k - 3 * NF : 0);
+          const double ls = isA ? ((k >= 6 && k < NV) ? 1.0 : (k >= NV + 6 ? dt : 0.0)) : (k >= 3 * NF ? dt * dt : 0.0);
+          acc += ls * sc.lam_next[li];
         }
         double v;
         if (gi < 6)
@@ -335,15 +325,10 @@ namespace smpc
                 + sc.JeQ[i * 3 + 1] * Dtop[4] + sc.JeQ[i * 3 + 2] * Dtop[5];
           else
             v = sc.Je3[(i - 3) * 3 + 0] * Dtop[3] + sc.Je3[(i - 3) * 3 + 1] * Dtop[4] + sc.Je3[(i - 3) * 3 + 2] * Dtop[5];
-          if (isA && k < 6)
-            v += sc.Jq[i * 6 + k];
+          v += jq_on * sc.Jq[i * 6 + jq_k];
         }
         else
-        {
-          v = Dbot[i - NV];
-          if (isA && k == i)
-            v += 1.0;
-        }
+          v = Dbot[i - NV] + ((isA && k == i) ? 1.0 : 0.0);
         dst[i * ld + k] = v;
         acc += v * sc.lam_next[i];
       }
