@@ -145,7 +145,7 @@ extern "C"
       const HostMpcSettings ms6 = host_mpc(mpc);
       return guarded([&] {
         std::unique_ptr<smpc_handle> h(new smpc_handle());
-#ifndef SMPC_KINO_ONLY
+#if !defined(SMPC_KINO_ONLY) || defined(SMPC_TALOS_TOO) // (experiment builds: -DSMPC_KINO_ONLY -DSMPC_TALOS_TOO = Go2 kinodynamics + the biped's two dense engines)
         h->full.reset(new FullEngine<KinoTalos>(robot, s, ms6, batch, gravity_arg, device_id));
 #else
         throw std::runtime_error("SMPC_KINO_ONLY experiment build");
@@ -316,7 +316,12 @@ extern "C"
     const HostMpcSettings ms = host_mpc(mpc);
     return guarded([&] {
       std::unique_ptr<smpc_handle> h(new smpc_handle());
-#ifdef SMPC_KINO_ONLY
+#if defined(SMPC_KINO_ONLY) && defined(SMPC_TALOS_TOO)
+      if (robot->njoints == FullTalos::NJ && robot->nfeet == FullTalos::NF && fs == FullTalos::FS && !s.land_cstr)
+        h->full.reset(new FullEngine<FullTalos>(robot, s, ms, batch, gravity_arg, device_id));
+      else
+        throw std::runtime_error("SMPC_KINO_ONLY experiment build");
+#elif defined(SMPC_KINO_ONLY)
       throw std::runtime_error("SMPC_KINO_ONLY experiment build");
 #else
       if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS && s.land_cstr && s.force_cone)
