@@ -34,48 +34,6 @@ namespace smpc
       prof_tick(fp.prof, slot, fp.tprev);
   }
 
-  template <class D, bool DERIV>
-  struct FullScratch
-  {
-    static constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX, NX = D::NX, NC = D::NC;
-    static constexpr int NR = NCM + 1;           // columns of W = [M^-1 b | M^-1 J^T]
-    static constexpr int NCOL = 2 * NV + NU;     // derivative columns (q | v | tau)
-    static constexpr int NGN = 6 + D::PF * NF + NCM; // rows of the stacked Gauss-Newton Jacobian: forces | momentum | foot poses
-    FullHead<D> h;
-    // block inputs
-    double x[NX], u[NU], xn1[NX], x_tgt[NX], u_ref[NU], f_ref[NCM], foot_ref[NF * 3];
-    double lam_next[NDX], nu[NC];
-    // kinematics
-    double oR[NJ * 9], op[NJ * 3], S[NV * 6], vel[NJ * 6], acc[NJ * 6], I[NJ * 10], Ic[NJ * 10], hc[NJ * 6], Fc[NJ * 6];
-    double footp[NF * 3], com[3], hg[6];
-    // constrained dynamics
-    // (one contiguous block: dead after the derivative solves, it then takes the momentum / foot-pose rows of the stacked
-    //  Gauss-Newton Jacobian, see jt2_())
-    double M[NV * NV];    // joint-space inertia -> its inverse
-    double J[NCM * NV];   // contact Jacobian (rows of absent contacts zero)
-    double W[NV * NR];    // [M^-1 (S tau - nle) | M^-1 J^T]
-    double Gi[NCM * NCM]; // damped Delassus matrix -> its inverse
-    double IcS[NV * 6];
-    static constexpr int DYN_DOUBLES = NV * NV + NCM * NV + NV * NR + NCM * NCM + NV * 6;
-    static_assert(DYN_DOUBLES >= (NGN - NCM) * NCOL, "the momentum / pose rows of the Gauss-Newton Jacobian fit the dead dynamics block");
-    SMPC_HD double * jt2_() { return M; } // rows NCM .. NGN-1 of the stacked Jacobian, [NGN - NCM][NCOL]
-    double gam[NCM], JMb[NCM], lam[NCM], rhs[NCM], dl[NCM];
-    double rotl[D::FS == 6 ? NF * 3 : 1]; // log3 of the foot rotations (6-D contacts: angular part of the corrector)
-    static constexpr int NVP = ((NV + 3) / 4) * 4, NCP = ((NCM + 3) / 4) * 4;
-    static constexpr int NTM = (2 * NVP + 15) / 16, NTG = (2 * NCP + 15) / 16; // tile grids of the two bordered inverses
-    static constexpr int SWP_DOUBLES = 2 * 4 * 16 * (NTM > NTG ? NTM : NTG);     // sweep operands
-    double a[NV];
-    // ---- "late block": written only after the dynamics phases (integration, residuals, multipliers, reductions); until then its
-    //      head serves as the operand scratch of the two bordered inverses, see swp_() ----
-    double xnext[NX], e[NDX];
-    // costs / constraints / multipliers
-    double rx[NDX], Wrx[NDX], ru[NU], Wru[NU], Whg[6], rf[NF * D::PF], Wrf[NF * D::PF], rl[NCM], Wrl[NCM];
-    double cval[NC], vplus[NC], lamp[NDX];
-    int act[NC + NC % 2];
-    double part[64], part8[16], red[4];
-    int iters_[2];
-    SMPC_HD double * swp_() { return xnext; } // (size checked where the inverses are called)
-  };
   // The two widest derivative blocks of a stage -- R1 (NV x NCOL) and the force rows JT (NCM x NCOL) of the Gauss-Newton Jacobian.  They are
   // operands / results of the column-wise solve chain.  Where D::WIDE_DEV says so they live in a per-block slice of DEVICE MEMORY instead of LDS
   // (round 5): LDS, not registers, decides the occupancy of this kernel (one wavefront per block), and for the biped these 24.4 KB are the
@@ -98,10 +56,26 @@ namespace smpc
       else
         return R1[i * NCOL + cc];
     }
-    double JT[NCM * NCOL];      // force rows of the stacked Gauss-Newton Jacobian: [r2q | r2v | 0] -> [dlam_dq | dlam_dv | dlam_dtau]
-                                // (the momentum / foot-pose rows live in the dead dynamics block of the evaluation scratch)
-                                // kinodynamics variant: rows 0 .. 5 = Jacobian of the centroidal_derivative residual hdot(u, q), the rest zero
-    double Cv[D::KINO ? D::NVEL * D::NDX : 1]; // kinodynamics variant: the frame-velocity rows (NVEL x NDX) of the feet in contact
+    // force rows of the stacked Gauss-Newton Jacobian: [r2q | r2v | 0] -> [dlam_dq | dlam_dv | dlam_dtau]
+    // kinodynamics variant: rows 0 .. 5 = Jacobian of the centroidal_derivative residual hdot(u, q), the rest zero
+    // In LDS (WIDE_DEV = false) the momentum / foot-pose rows live in the dead dynamics block of the evaluation scratch (FullScratch::jt2_());
+    // in the device slice they follow the force rows (round 6: the dynamics block of such a block is no longer its own LDS, see FullScratch).
+    static constexpr int NGN = 6 + D::PF * D::NF + NCM;
+    static constexpr int JTROWS = D::WIDE_DEV ? NGN : NCM;
+    double JT[JTROWS * NCOL];
+    // Round 6, WIDE_DEV: the factorised dynamics block [M^-1 | J | W | G^-1] of the stage, copied out of LDS once the accelerations and forces
+    // are solved -- its only readers afterwards are operand fetches of the derivative solve chain (latency-tolerant, two K-steps ahead), and
+    // its LDS then holds the derivative scratch: 53.0 -> 40.0 KB per block, four resident blocks per CU instead of three.
+    // Full dynamics: what goes out is the TRANSPOSE of the (NV + NCM)^2 inverse of the contact KKT matrix (full_kkt_inv; the operand fetch of the
+    // solve then reads 16 consecutive entries per K index); kinodynamics variant: the block as it lies ([M | J | W | Gi], its six base rows are used).
+    static constexpr int DYN4 = NV * NV + NCM * NV + NV * (NCM + 1) + NCM * NCM, NK = NV + NCM;
+    static constexpr int DYN_OUT_DOUBLES = D::KINO ? DYN4 : NK * NK;
+    double dyn[D::WIDE_DEV ? DYN_OUT_DOUBLES : 2];
+    double Cv[D::KINO ? D::NVEL * D::NDX : 2]; // kinodynamics variant: the frame-velocity rows (NVEL x NDX) of the feet in contact
+    SMPC_HD const double * Mi_() const { return dyn; }
+    SMPC_HD const double * J_() const { return dyn + NV * NV; }
+    SMPC_HD const double * W_() const { return dyn + NV * NV + NCM * NV; }
+    SMPC_HD const double * Gi_() const { return dyn + NV * NV + NCM * NV + NV * (NCM + 1); }
   };
   // LDS part of the wide blocks: the blocks themselves (WIDE_DEV = false), or the per-dof vectors of the R1 fill, which otherwise borrow the
   // force rows of JT (strided per-lane accesses: not for device memory)
@@ -138,6 +112,55 @@ namespace smpc
     SMPC_HD double * yc_() const { return cq_() + NDX + NU; }
     SMPC_HD double * dual_() const { return yc_() + NCM + 1; }
     static_assert(NDX * 6 + 36 + NDX + NU + NDX + NU + NCM + 1 + NGN <= NJ * 36, "assembly tables fit the dead Bc block");
+  };
+
+  template <class D, bool DERIV>
+  struct FullScratch
+  {
+    static constexpr int NV = D::NV, NJ = D::NJ, NF = D::NF, NCM = D::NCM, NU = D::NU, NDX = D::NDX, NX = D::NX, NC = D::NC;
+    static constexpr int NR = NCM + 1;           // columns of W = [M^-1 b | M^-1 J^T]
+    static constexpr int NCOL = 2 * NV + NU;     // derivative columns (q | v | tau)
+    static constexpr int NGN = 6 + D::PF * NF + NCM; // rows of the stacked Gauss-Newton Jacobian: forces | momentum | foot poses
+    FullHead<D> h;
+    // block inputs
+    double x[NX], u[NU], xn1[NX], x_tgt[NX], u_ref[NU], f_ref[NCM], foot_ref[NF * 3];
+    double lam_next[NDX], nu[NC];
+    // kinematics
+    double oR[NJ * 9], op[NJ * 3], S[NV * 6], vel[NJ * 6], acc[NJ * 6], I[NJ * 10], Ic[NJ * 10], hc[NJ * 6], Fc[NJ * 6];
+    double footp[NF * 3], com[3], hg[6];
+    double IcS[NV * 6];
+    double gam[NCM], JMb[NCM], lam[NCM], rhs[NCM], dl[NCM];
+    double rotl[D::FS == 6 ? NF * 3 : 1]; // log3 of the foot rotations (6-D contacts: angular part of the corrector)
+    static constexpr int NVP = ((NV + 3) / 4) * 4, NCP = ((NCM + 3) / 4) * 4;
+    static constexpr int NTM = (2 * NVP + 15) / 16, NTG = (2 * NCP + 15) / 16; // tile grids of the two bordered inverses
+    static constexpr int SWP_DOUBLES = 2 * 4 * 16 * (NTM > NTG ? NTM : NTG);     // sweep operands
+    double a[NV];
+    // ---- "late block": written only after the dynamics phases (integration, residuals, multipliers, reductions); until then its
+    //      head serves as the operand scratch of the two bordered inverses, see swp_() ----
+    double xnext[NX], e[NDX];
+    // costs / constraints / multipliers
+    double rx[NDX], Wrx[NDX], ru[NU], Wru[NU], Whg[6], rf[NF * D::PF], Wrf[NF * D::PF], rl[NCM], Wrl[NCM];
+    double cval[NC], vplus[NC], lamp[NDX];
+    int act[NC + NC % 2];
+    double part[64], part8[16], red[4];
+    int iters_[2];
+    SMPC_HD double * swp_() { return xnext; } // (size checked where the inverses are called)
+    // ---- constrained dynamics: one contiguous block at the END of the scratch ----
+    // WIDE_DEV = false: dead after the derivative solves, it then takes the momentum / foot-pose rows of the stacked Gauss-Newton Jacobian
+    // (jt2_()).  Derivative kernel with WIDE_DEV (round 6, DYN_OUT): once a and lam are solved the block is copied to the device slice
+    // (FullDerivWide::dyn) and its LDS becomes the derivative scratch (FullScratchDeriv + the per-dof vectors of the R1 fill: dyn_overlay_()),
+    // which is why the composite velocity-product matrices Bc of such a block are formed after the dynamics phases, not with the other composites.
+    static constexpr bool DYN_OUT = DERIV && D::WIDE_DEV;
+    static constexpr int DYN_DOUBLES = NV * NV + NCM * NV + NV * NR + NCM * NCM;
+    static constexpr int OVL_DOUBLES = (int)((sizeof(FullScratchDeriv<D>) + sizeof(FullDerivWideLds<D, true>)) / sizeof(double));
+    static constexpr int DYN_PAD = (DYN_OUT && OVL_DOUBLES > DYN_DOUBLES) ? OVL_DOUBLES - DYN_DOUBLES : 0;
+    static_assert(DYN_OUT || DYN_DOUBLES >= (NGN - NCM) * NCOL, "the momentum / pose rows of the Gauss-Newton Jacobian fit the dead dynamics block");
+    double M[NV * NV];    // joint-space inertia -> its inverse
+    double J[NCM * NV];   // contact Jacobian (rows of absent contacts zero)
+    double W[NV * NR];    // [M^-1 (S tau - nle) | M^-1 J^T]
+    double Gi[NCM * NCM + DYN_PAD]; // damped Delassus matrix -> its inverse (+ what the overlay needs beyond the block)
+    SMPC_HD double * jt2_() { return M; } // (not DYN_OUT) rows NCM .. NGN-1 of the stacked Jacobian, [NGN - NCM][NCOL]
+    SMPC_HD double * dyn_overlay_() { return M; }
   };
 
   // copy the head of the device model into LDS (all loads in flight before the first store)
@@ -255,7 +278,7 @@ namespace smpc
   template <int M, int N, int K, int PF, class FA, class FB, class FI, class FS_>
   SMPC_DEV void fwave_gemm(FA a, FB b, FI init, FS_ store)
   {
-    static_assert(PF == 1 || PF == 2, "operand sets");
+    static_assert(PF >= 1 && PF <= (K + 3) / 4, "operand sets");
     constexpr int NS = PF + 1;
     constexpr int NT = 64, TI = (M + 15) / 16, TJ = (N + 15) / 16, KS = (K + 3) / 4;
     SMPC_ACC(acc, NT, TI * TJ);
@@ -275,7 +298,7 @@ namespace smpc
           const int i = 16 * I + lc;
           const bool ok = i < M && k < K;
           const double x = a(ok ? i : 0, ok ? k : 0);
-          SMPC_PLV(av)[ob * TI + I] = ok ? x : 0.0;
+          SMPC_PLV(av)[ob * TI + I] = (PF > 1 || ok) ? x : 0.0; // (PF > 1: masked at use, see mask())
         }
 #pragma unroll
         for (int J = 0; J < TJ; J++)
@@ -283,8 +306,27 @@ namespace smpc
           const int j = 16 * J + lc;
           const bool ok = j < N && k < K;
           const double x = b(ok ? k : 0, ok ? j : 0);
-          SMPC_PLV(bv)[ob * TJ + J] = ok ? x : 0.0;
+          SMPC_PLV(bv)[ob * TJ + J] = (PF > 1 || ok) ? x : 0.0;
         }
+      }
+      SMPC_LANES_END_WAVE
+    };
+    // operands in device memory: the entries outside the matrices are zeroed when the K-step USES them, not when it fetches them -- a select on
+    // a loaded value is a wait for the load
+    auto mask = [&](int ks) {
+      const int ob = ks % NS;
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+        const int k = 4 * ks + lr;
+#pragma unroll
+        for (int I = 0; I < TI; I++)
+          if (16 * I + 16 > M || 4 * ks + 4 > K)
+            SMPC_PLV(av)[ob * TI + I] = (16 * I + lc < M && k < K) ? SMPC_PLV(av)[ob * TI + I] : 0.0;
+#pragma unroll
+        for (int J = 0; J < TJ; J++)
+          if (16 * J + 16 > N || 4 * ks + 4 > K)
+            SMPC_PLV(bv)[ob * TJ + J] = (16 * J + lc < N && k < K) ? SMPC_PLV(bv)[ob * TJ + J] : 0.0;
       }
       SMPC_LANES_END_WAVE
     };
@@ -305,20 +347,29 @@ namespace smpc
           }
     }
     SMPC_LANES_END_WAVE
-    fetch(0);
-    if (PF == 2 && KS > 1)
-      fetch(1);
+#pragma unroll
+    for (int p = 0; p < PF && p < KS; p++)
+      fetch(p);
 #pragma unroll
     for (int ks = 0; ks < KS; ks++)
     {
       if (ks + PF < KS)
         fetch(ks + PF);
+      // (the scheduler otherwise sinks the loads of the fetch below the matrix instructions, next to their use: the operands of the biped's
+      //  blocks lie in device memory and every K-step then waited for its own loads)
+      if constexpr (PF > 1)
+      {
+        SMPC_SCHED_FENCE();
+        mask(ks);
+      }
       const int ob = ks % NS;
 #pragma unroll
       for (int I = 0; I < TI; I++)
 #pragma unroll
         for (int J = 0; J < TJ; J++)
           SMPC_MFMA(acc, I * TJ + J, av, ob * TI + I, bv, ob * TJ + J);
+      if constexpr (PF > 1)
+        SMPC_SCHED_FENCE();
     }
     SMPC_LANES(NT)
     {
@@ -344,6 +395,51 @@ namespace smpc
   // Kinematics, composites, joint-space inertia, contact rows, factorisations, proximal iteration, accelerations.
   // dyn = false: kinematics / momentum only (terminal node).
   // -------------------------------------------------------------------------------------------------------------
+  // per-body velocity-product matrices  B_l y = v_l x* (I_l y) - I_l (v_l x y)  (lane = (body, column)); in: world inertias I (NOT yet the
+  // composite forces the derivative phases put in their block), body velocities
+  template <class D, class SC, class SD>
+  SMPC_DEV void full_bc_bodies(SC & sc, SD & sd)
+  {
+    constexpr int NT = 64, NJ = D::NJ;
+    SMPC_LANES(NT)
+    for (int idx = lane; idx < NJ * 6; idx += NT)
+    {
+      const int l = idx / 6, m = idx % 6;
+      const SI Il = ldsi(&sc.I[l * 10]);
+      const SV vl = ldsv(&sc.vel[l * 6]);
+      const V3 e = mk3(m % 3 == 0, m % 3 == 1, m % 3 == 2), z = mk3(0, 0, 0);
+      const SV y = m < 3 ? SV{e, z} : SV{z, e};
+      const SV col = crf(vl, Il * y) - Il * crm(vl, y);
+      double * dst = &sd.Bc[l * 36 + m];
+      dst[0] = col.l.x;
+      dst[6] = col.l.y;
+      dst[12] = col.l.z;
+      dst[18] = col.a.x;
+      dst[24] = col.a.y;
+      dst[30] = col.a.z;
+    }
+    SMPC_LANES_END_WAVE
+  }
+  // the same and their composites (leaf -> root), as a pass of its own: blocks whose dynamics block is staged out (FullScratch::DYN_OUT)
+  template <class D, class SC, class SD>
+  SMPC_DEV void full_bc_composites(SC & sc, SD & sd)
+  {
+    constexpr int NT = 64, NJ = D::NJ;
+    full_bc_bodies<D>(sc, sd);
+    SMPC_LANES(NT)
+    if (lane < 36)
+    {
+      int par[NJ];
+#pragma unroll
+      for (int j = 1; j < NJ; j++)
+        par[j] = sc.h.parent[j];
+#pragma unroll
+      for (int j = NJ - 1; j >= 1; j--)
+        sd.Bc[par[j] * 36 + lane] += sd.Bc[j * 36 + lane];
+    }
+    SMPC_LANES_END_WAVE
+  }
+
   template <class D, bool DERIV, class SC, class SD>
   SMPC_DEV void full_dynamics_phases(SC & sc, SD * sd, const DevModel<D> & mg, unsigned mask, bool dyn, FullProf & fp, bool rows_only = false)
   {
@@ -354,11 +450,21 @@ namespace smpc
     const int nlev = h.nlevels;
     const double * vq = &sc.x[NQ];
     SMPC_PLA(double, rl, NT, 9);
+    // what a joint's lane needs in its pass of the level loop, read once (the loop then waits for its parent's entries only)
+    SMPC_PLA(double, jc, NT, 4); // offset from the parent (3), joint velocity
+    SMPC_PLA(int, ji, NT, 3);    // level, parent, axis
     // ---- joint-local transforms (all joints at once) ----
     SMPC_LANES(NT)
     if (lane < NJ)
     {
       const int j = lane;
+      SMPC_PLV(ji)[0] = j > 0 ? h.level[j] : 0;
+      SMPC_PLV(ji)[1] = j > 0 ? h.parent[j] : 0;
+      SMPC_PLV(ji)[2] = j > 0 ? h.jtype[j] - 1 : 0;
+      SMPC_PLV(jc)[0] = mg.jpp[j][0];
+      SMPC_PLV(jc)[1] = mg.jpp[j][1];
+      SMPC_PLV(jc)[2] = mg.jpp[j][2];
+      SMPC_PLV(jc)[3] = j > 0 ? vq[j + 5] : 0.0;
       if (j == 0)
       {
         const M3 R = quat_to_R(Quat{sc.x[3], sc.x[4], sc.x[5], sc.x[6]});
@@ -391,17 +497,17 @@ namespace smpc
     for (int lvl = 1; lvl < nlev; lvl++)
     {
       SMPC_LANES(NT)
-      if (lane > 0 && lane < NJ && h.level[lane] == lvl)
+      if (lane > 0 && lane < NJ && SMPC_PLV(ji)[0] == lvl)
       {
-        const int j = lane, par = h.parent[j];
+        const int j = lane, par = SMPC_PLV(ji)[1];
         const M3 Rp = ldm3(&sc.oR[par * 9]);
         const M3 R = Rp * ldm3(SMPC_PLV(rl));
-        const V3 p = ld3(&sc.op[par * 3]) + Rp * ld3(mg.jpp[j]);
-        const int col = h.jtype[j] - 1;
+        const V3 p = ld3(&sc.op[par * 3]) + Rp * mk3(SMPC_PLV(jc)[0], SMPC_PLV(jc)[1], SMPC_PLV(jc)[2]);
+        const int col = SMPC_PLV(ji)[2];
         const V3 ax = col == 0 ? mk3(R.a00, R.a10, R.a20) : (col == 1 ? mk3(R.a01, R.a11, R.a21) : mk3(R.a02, R.a12, R.a22));
         const SV sk = SV{cross(p, ax), ax};
         const SV vp = ldsv(&sc.vel[par * 6]);
-        const double qd = vq[j + 5];
+        const double qd = SMPC_PLV(jc)[3];
         stm3(&sc.oR[j * 9], R);
         st3(&sc.op[j * 3], p);
         stsv(&sc.S[(j + 5) * 6], sk);
@@ -447,40 +553,25 @@ namespace smpc
     SMPC_LANES_END_WAVE
     static_assert(NF <= 32 && NJ <= 32, "lane map of the inertia / foot phase");
     ftick(fp, 1);
-    if constexpr (DERIV)
-    {
-      // per-body velocity-product matrices  B_l y = v_l x* (I_l y) - I_l (v_l x y)  (lane = (body, column))
-      SMPC_LANES(NT)
-      for (int idx = lane; idx < NJ * 6; idx += NT)
-      {
-        const int l = idx / 6, m = idx % 6;
-        const SI Il = ldsi(&sc.I[l * 10]);
-        const SV vl = ldsv(&sc.vel[l * 6]);
-        const V3 e = mk3(m % 3 == 0, m % 3 == 1, m % 3 == 2), z = mk3(0, 0, 0);
-        const SV y = m < 3 ? SV{e, z} : SV{z, e};
-        const SV col = crf(vl, Il * y) - Il * crm(vl, y);
-        double * dst = &sd->Bc[l * 36 + m];
-        dst[0] = col.l.x;
-        dst[6] = col.l.y;
-        dst[12] = col.l.z;
-        dst[18] = col.a.x;
-        dst[24] = col.a.y;
-        dst[30] = col.a.z;
-      }
-      SMPC_LANES_END_WAVE
-    }
+    // (a block whose dynamics block is staged out forms Bc afterwards, in the LDS the block leaves: full_bc_composites)
+    constexpr bool BC_HERE = DERIV && !SC::DYN_OUT;
+    if constexpr (BC_HERE)
+      full_bc_bodies<D>(sc, *sd);
     // ---- composites, leaf -> root: lane = one scalar of (Ic | hc | Fc | Bc) ----
     SMPC_LANES(NT)
-    if (lane < 22 + (DERIV ? 36 : 0))
+    if (lane < 22 + (BC_HERE ? 36 : 0))
     {
-      double * base = lane < 10 ? sc.Ic : (lane < 16 ? sc.hc : (lane < 22 ? sc.Fc : (DERIV ? sd->Bc : sc.Fc)));
+      double * base = lane < 10 ? sc.Ic : (lane < 16 ? sc.hc : (lane < 22 ? sc.Fc : (BC_HERE ? sd->Bc : sc.Fc)));
       const int stride = lane < 10 ? 10 : (lane < 22 ? 6 : 36);
       const int e = lane < 10 ? lane : (lane < 16 ? lane - 10 : (lane < 22 ? lane - 16 : lane - 22));
+      // (the parents first: each step of the chain then waits for one LDS round trip, not two)
+      int par[NJ];
+#pragma unroll
+      for (int j = 1; j < NJ; j++)
+        par[j] = h.parent[j];
+#pragma unroll
       for (int j = NJ - 1; j >= 1; j--)
-      {
-        const int par = h.parent[j];
-        base[par * stride + e] += base[j * stride + e];
-      }
+        base[par[j] * stride + e] += base[j * stride + e];
     }
     SMPC_LANES_END_WAVE
     // ---- CoM, centroidal momentum; centroidal map columns (derivative pass) ----
@@ -648,7 +739,7 @@ namespace smpc
           sc.Gi[idx] = sc.M[(idx / 6) * NV + idx % 6];
       }
       SMPC_LANES_END_WAVE
-      static_assert(sizeof(SC) - offsetof(SC, xnext) >= 2 * 4 * 16 * sizeof(double), "the sweep scratch fits the late block");
+      static_assert(offsetof(SC, M) - offsetof(SC, xnext) >= 2 * 4 * 16 * sizeof(double), "the sweep scratch fits the late block");
       fwave_spd_inverse<6>(sc.Gi, sc.swp_());
       SMPC_LANES(NT)
       if (lane < 6)
@@ -680,7 +771,7 @@ namespace smpc
       return;
     }
     // ---- M <- M^-1 (bordered symmetric sweep) ; W = M^-1 [S tau - nle | J^T] on the matrix cores ----
-    static_assert(sizeof(SC) - offsetof(SC, xnext) >= SC::SWP_DOUBLES * sizeof(double), "the sweep scratch fits the late block");
+    static_assert(offsetof(SC, M) - offsetof(SC, xnext) >= SC::SWP_DOUBLES * sizeof(double), "the sweep scratch fits the late block");
     fwave_spd_inverse<NV>(sc.M, sc.swp_());
     fwave_gemm<NV, NR, NV>(
       [&](int i, int k) { return sc.M[k * NV + i]; },                                     // symmetric: read along the row of k
@@ -744,7 +835,29 @@ namespace smpc
         sc.iters_[0] = iters;
     }
     SMPC_LANES_END_WAVE
+    if constexpr (DERIV)
+    {
+      // ---- blocks of the inverse of the contact KKT matrix [M -J^T ; J mu] for the derivative solve (full_kkt_inv): the solve is then ONE
+      //      product over the (NV + NCM) x NCOL right-hand sides instead of a chain of four whose results go through memory.
+      //      T = G^-1 J M^-1 (into J, dead from here) ;  A = M^-1 - M^-1 J^T T (into M) ----
+      fwave_gemm<NCM, NV, NCM>(
+        [&](int i, int k) { return sc.Gi[k * NCM + i]; }, [&](int k, int j) { return sc.W[j * NR + 1 + k]; },
+        [&](int i, int j, double v) { sc.J[i * NV + j] = v; });
+      fwave_gemm<NV, NV, NCM>(
+        [&](int i, int k) { return sc.W[i * NR + 1 + k]; }, [&](int k, int j) { return -sc.J[k * NV + j]; },
+        [&](int i, int j) { return sc.M[i * NV + j]; }, [&](int i, int j, double v) { sc.M[i * NV + j] = v; });
+    }
     ftick(fp, 6);
+  }
+  // entry (i, k) of  [da ; dlam] = Kinv [r1 ; r2]:  Kinv = [-A  -T^T ; T  -G^-1]  from the blocks full_dynamics_phases<D, true> leaves in the
+  // dynamics block (A in M, T in J, G^-1 in Gi):  [M -J^T ; J mu] [da ; dlam] = -[r1 ; r2]
+  template <class D, class SC>
+  SMPC_DEV double full_kkt_inv(const SC & sc, int i, int k)
+  {
+    constexpr int NV = D::NV, NCM = D::NCM;
+    const bool iu = i < NV, ku = k < NV;
+    const double * src = iu ? (ku ? &sc.M[k * NV + i] : &sc.J[(k - NV) * NV + i]) : (ku ? &sc.J[(i - NV) * NV + k] : &sc.Gi[(k - NV) * NCM + (i - NV)]);
+    return ((!iu && ku) ? 1.0 : -1.0) * *src;
   }
 
   // entry (i, j) of the 17 x 6 wrench-cone matrix of a rectangular sole (half length L, half width W, friction mu) acting on the
@@ -1280,8 +1393,18 @@ namespace smpc
 {
   // Momentum and foot-pose rows of the stacked Gauss-Newton Jacobian (rows NCM .. NGN-1): written into the dynamics block of the
   // evaluation scratch (M | J | W | Gi | IcS), which is dead once the derivative solves are done (terminal node: never used).
+  // row r >= NCM (momentum, foot poses) of the stacked Gauss-Newton Jacobian: behind the force rows in the device slice, or in the dead
+  // dynamics block of the LDS scratch
+  template <class D, class SC>
+  SMPC_DEV double * full_gn_row(SC & sc, FullDerivWide<D> & sw, int r)
+  {
+    if constexpr (D::WIDE_DEV)
+      return &sw.JT[r * SC::NCOL];
+    else
+      return sc.jt2_() + (r - D::NCM) * SC::NCOL;
+  }
   template <class D, class SC, class SD>
-  SMPC_DEV void full_gn_rows(SC & sc, SD & sd, bool term)
+  SMPC_DEV void full_gn_rows(SC & sc, SD & sd, FullDerivWide<D> & sw, bool term)
   {
     constexpr int NT = 64;
     constexpr int NV = D::NV, NF = D::NF, NU = D::NU, NCOL = SC::NCOL, FS = D::FS;
@@ -1299,7 +1422,7 @@ namespace smpc
       const V3 jc = (1.0 / h.total_mass) * (Ici * s).l;
       const SV h0 = ldsv(&sc.hc[0]);
       const V3 dha = dh.a - cross(com, dh.l) - cross(jc, h0.l);
-      double * jc6 = sc.jt2_();
+      double * jc6 = full_gn_row<D>(sc, sw, D::NCM);
       jc6[0 * NCOL + k] = dh.l.x;
       jc6[1 * NCOL + k] = dh.l.y;
       jc6[2 * NCOL + k] = dh.l.z;
@@ -1318,7 +1441,7 @@ namespace smpc
             jc6[r * NCOL + 2 * NV + c] = 0.0;
         }
       }
-      double * jf = sc.jt2_() + 6 * NCOL;
+      double * jf = full_gn_row<D>(sc, sw, D::NCM + 6);
       constexpr int PF = D::PF;
       for (int f = 0; f < NF; f++)
       {
@@ -1414,8 +1537,15 @@ namespace smpc
       SMPC_LANES_END_WAVE
       SMPC_LANES(NT)
       if (lane < 6)
+      {
+        int par[NJ];
+#pragma unroll
+        for (int j = 1; j < NJ; j++)
+          par[j] = h.parent[j];
+#pragma unroll
         for (int j = NJ - 1; j >= 1; j--)
-          sc.Fc[h.parent[j] * 6 + lane] += sc.Fc[j * 6 + lane];
+          sc.Fc[par[j] * 6 + lane] += sc.Fc[j * 6 + lane];
+      }
       SMPC_LANES_END_WAVE
       // composite force below joint i minus the contact wrenches applied below it
       SMPC_LANES(NT)
@@ -1452,7 +1582,7 @@ namespace smpc
     ftick(fp, 9);
     if (term)
     {
-      full_gn_rows<D>(sc, sd, true);
+      full_gn_rows<D>(sc, sd, sw, true);
       return;
     }
     // ---- partial derivatives of RNEA(q, v, a) - J^T lam at the solution: R1 = [r1q | r1v | -S], as masked small GEMMs ----
@@ -1585,6 +1715,7 @@ namespace smpc
     {
       // ---- kinodynamics variant: the base rows  M_bb da_b = -(r1q | r1v) dq,dv + (J^T)_b d lam - M_bj d a_j ; the joint accelerations are
       //      controls (r1()).  Right-hand sides in place on the six rows of R1, then R1 <- M_bb^-1 R1 (lane = column) ----
+      const double * const kM = SC::DYN_OUT ? sw.Mi_() : sc.M, * const kJ = SC::DYN_OUT ? sw.J_() : sc.J, * const kGi = SC::DYN_OUT ? sw.Gi_() : sc.Gi;
       SMPC_LANES(NT)
       for (int idx = lane; idx < 6 * NCOL; idx += NT)
       {
@@ -1596,11 +1727,11 @@ namespace smpc
         {
           const int f = (c - 2 * NV) / FS, j = (c - 2 * NV) % FS;
           const int cc = __builtin_popcount(mask & ((1u << f) - 1u));
-          const double jv = sc.J[(FS * (((mask >> f) & 1u) ? cc : 0) + j) * NV + b];
+          const double jv = kJ[(FS * (((mask >> f) & 1u) ? cc : 0) + j) * NV + b];
           v = ((mask >> f) & 1u) ? jv : 0.0;
         }
         else
-          v = -sc.M[b * NV + 6 + (c - 2 * NV - NCM)];
+          v = -kM[b * NV + 6 + (c - 2 * NV - NCM)];
         sw.R1[idx] = v;
       }
       SMPC_LANES_END_WAVE
@@ -1614,7 +1745,7 @@ namespace smpc
         {
           double acc = 0.0;
           for (int d = 0; d < 6; d++)
-            acc += sc.Gi[b * 6 + d] * t[d];
+            acc += kGi[b * 6 + d] * t[d];
           o[b] = acc;
         }
         for (int b = 0; b < 6; b++)
@@ -1667,7 +1798,7 @@ namespace smpc
         }
       }
       SMPC_LANES_END_WAVE
-      full_gn_rows<D>(sc, sd, false);
+      full_gn_rows<D>(sc, sd, sw, false);
       ftick(fp, 12);
       return;
     }
@@ -1753,25 +1884,28 @@ namespace smpc
     SMPC_LANES_END_WAVE
     }
     ftick(fp, 11);
-    // ---- [M -J^T; J mu] [da; dlam] = -[r1; r2]:  Mr = M^-1 R1 ; rhs = J Mr - r2 ; dlam = G^-1 rhs ; da = -Mr + M^-1 J^T dlam ----
-    // Mr = M^-1 R1 (in place)
-    fwave_gemm<NV, NCOL, NV, D::WIDE_DEV ? 2 : 1>(
-      [&](int i, int k) { return sc.M[k * NV + i]; }, [&](int k, int j) { return sw.R1[k * NCOL + j]; },
-      [&](int i, int j, double v) { sw.R1[i * NCOL + j] = v; });
-    // rhs = J Mr - r2 (in place on the force rows of JT)
-    fwave_gemm<NCM, NCOL, NV, D::WIDE_DEV ? 2 : 1>(
-      [&](int i, int k) { return sc.J[i * NV + k]; }, [&](int k, int j) { return sw.R1[k * NCOL + j]; },
-      [&](int i, int j) { return -sw.JT[i * NCOL + j]; }, [&](int i, int j, double v) { sw.JT[i * NCOL + j] = v; });
-    // dlam = G^-1 rhs (in place)
-    fwave_gemm<NCM, NCOL, NCM, D::WIDE_DEV ? 2 : 1>(
-      [&](int i, int k) { return sc.Gi[k * NCM + i]; }, [&](int k, int j) { return sw.JT[k * NCOL + j]; },
-      [&](int i, int j, double v) { sw.JT[i * NCOL + j] = v; });
-    // da = -Mr + M^-1 J^T dlam (in place on R1)
-    fwave_gemm<NV, NCOL, NCM, D::WIDE_DEV ? 2 : 1>(
-      [&](int i, int k) { return sc.W[i * NR + 1 + k]; }, [&](int k, int j) { return sw.JT[k * NCOL + j]; },
-      [&](int i, int j) { return -sw.R1[i * NCOL + j]; }, [&](int i, int j, double v) { sw.R1[i * NCOL + j] = v; });
-    full_gn_rows<D>(sc, sd, false);
+    // ---- [M -J^T; J mu] [da; dlam] = -[r1; r2] ----
+    // One product with the inverse of the contact KKT matrix (blocks formed by full_dynamics_phases<D, true>; DYN_OUT: its transpose lies in the
+    // device slice, the LDS of the dynamics block is the derivative scratch by now), in place on [R1 ; force rows of JT]: every operand entry is
+    // fetched before the first result is stored.
+    {
+      constexpr int NK = NV + NCM;
+#ifndef SMPC_KKT_PF
+#define SMPC_KKT_PF 2
+#endif
+      fwave_gemm<NK, NCOL, NK, D::WIDE_DEV ? SMPC_KKT_PF : 1>(
+        [&](int i, int k) {
+          if constexpr (SC::DYN_OUT)
+            return sw.dyn[k * NK + i];
+          else
+            return full_kkt_inv<D>(sc, i, k);
+        },
+        [&](int k, int j) { return *(k < NV ? &sw.R1[k * NCOL + j] : &sw.JT[(k - NV) * NCOL + j]); },
+        [&](int i, int j, double v) { *(i < NV ? &sw.R1[i * NCOL + j] : &sw.JT[(i - NV) * NCOL + j]) = v; });
+    }
     ftick(fp, 12);
+    full_gn_rows<D>(sc, sd, sw, false);
+    ftick(fp, 19);
     (void)NGN;
   }
 
@@ -1850,7 +1984,7 @@ namespace smpc
   // B-operand layout of K-step 4 R + v of the second product, so the weighted Jacobian never leaves the registers.  Upper 16 x 16
   // tiles of the (x, u) grid are written: Q (upper tiles; mirrored when `mirror`), S, R (readers take (min, max) indices).
   template <class D, class SC, class SD>
-  SMPC_DEV void full_hessian_mfma(SC & sc, SD & sd, FullDerivWide<D> & sw, const DevModel<D> & mg, bool term, double preg, double * Qd, double * Sd, double * Rd, bool mirror, bool tcs = false)
+  SMPC_DEV void full_hessian_mfma(SC & sc, SD & sd, FullDerivWide<D> & sw, const DevModel<D> & mg, bool term, double preg, double * Qd, double * Sd, double * Rd, bool mirror, bool tcs = false, FullProf * fpp = nullptr)
   {
     constexpr int NT = 64;
     constexpr int NDX = D::NDX, NU = D::NU, NXU = D::NXU, NCOL = SC::NCOL, NGN0 = SC::NGN;
@@ -1890,6 +2024,31 @@ namespace smpc
           }
     }
     SMPC_LANES_END_WAVE
+    // The biped's full-dynamics blocks (rows of the Jacobian in the device slice, both passes below read every row): all entries of a lane are
+    // fetched at once, before the first K-step -- one memory round trip for the two products instead of one per K-step and pass; entries outside
+    // the rows are zeroed where a K-step uses them (a select on a loaded value is a wait for the load).
+    if (fpp)
+      ftick(*fpp, 21);
+    constexpr bool PRE = D::WIDE_DEV && !D::KINO;
+    SMPC_PLA(double, jta, NT, PRE ? KS * NTC : 1);
+    if constexpr (PRE)
+    {
+      SMPC_LANES(NT)
+      {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+          for (int J = 0; J < NTC; J++)
+          {
+            const int r = 4 * ks + lr, c = 16 * J + lc;
+            SMPC_PLV(jta)[ks * NTC + J] = sw.JT[(r < NGN ? r : 0) * NCOL + (c < NCOL ? c : 0)];
+          }
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_SCHED_FENCE();
+    }
+#pragma unroll(PRE ? KS : 1)
     for (int ks = 0; ks < KS; ks++)
     {
       SMPC_LANES(NT)
@@ -1902,10 +2061,15 @@ namespace smpc
           const int c = 16 * J + lc;
           const bool velr = D::KINO && r >= NGN0;
           const bool ok = r < NGN && (velr ? (c < NDX && !term) : c < NCOL) && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3)); // terminal node: momentum (+ constraint) rows only
+          if constexpr (PRE)
+            SMPC_PLV(jtv)[J] = ok ? SMPC_PLV(jta)[ks * NTC + J] : 0.0;
+          else
+          {
           const double * row = (ok && velr) ? &sw.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
-                                            : ((ok && r < D::NCM) ? &sw.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL);
+                                            : ((ok && r < D::NCM) ? &sw.JT[r * NCOL] : full_gn_row<D>(sc, sw, ok ? r : D::NCM));
           const double v = row[(c < NCOL && ok) ? c : 0];
           SMPC_PLV(jtv)[J] = ok ? v : 0.0;
+          }
         }
 #pragma unroll
         for (int R = 0; R < NTR; R++)
@@ -1918,6 +2082,8 @@ namespace smpc
         for (int J = 0; J < NTC; J++)
           SMPC_MFMA(wj, R * NTC + J, wop, R, jtv, J);
     }
+    if (fpp)
+      ftick(*fpp, 22);
     SMPC_PLA(double, bv, NT, NTC);
 #pragma unroll
     for (int R = 0; R < NTR; R++)
@@ -1936,10 +2102,15 @@ namespace smpc
             const int c = 16 * J + lc;
             const bool velr = D::KINO && r >= NGN0;
             const bool ok = r < NGN && (velr ? (c < NDX && !term) : c < NCOL) && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3));
+            if constexpr (PRE)
+              SMPC_PLV(jtv)[J] = ok ? SMPC_PLV(jta)[(4 * R + v) * NTC + J] : 0.0;
+            else
+            {
             const double * row = (ok && velr) ? &sw.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
-                                              : ((ok && r < D::NCM) ? &sw.JT[r * NCOL] : sc.jt2_() + ((ok ? r : D::NCM) - D::NCM) * NCOL);
+                                              : ((ok && r < D::NCM) ? &sw.JT[r * NCOL] : full_gn_row<D>(sc, sw, ok ? r : D::NCM));
             const double x = row[(c < NCOL && ok) ? c : 0];
             SMPC_PLV(jtv)[J] = ok ? x : 0.0;
+            }
             SMPC_PLV(bv)[J] = SMPC_ACCV(wj, R * NTC + J, v);
           }
         }
@@ -1950,6 +2121,8 @@ namespace smpc
           for (int J = I; J < NTC; J++)
             SMPC_MFMA(qa, tix<NTC>(I, J), jtv, I, bv, J);
       }
+    if (fpp)
+      ftick(*fpp, 23);
     SMPC_LANES(NT)
     {
       const int lr = lane >> 4, lc = lane & 15;
@@ -2001,7 +2174,6 @@ namespace smpc
     const bool term = t == H;
     const DevModel<D> & mg = *b.model;
     SMPC_LDS(SC, scs, 1);
-    SMPC_LDS(SD, sds, 1);
     // LDS decides the resident blocks per CU here (160 KB / block size, one wave per SIMD at most): the quadruped with neither cone nor
     // land rows must stay under 40 KB -- four blocks; at 41.2 KB it ran three and the launch took 15.2 ms instead of 11.9
     static_assert(!(D::NJ == 13 && D::FS == 3 && D::NCONE == 0 && D::NLAND == 0 && !D::KINO) || sizeof(SC) + sizeof(SD) + sizeof(FullDerivWideLds<D>) <= 40960,
@@ -2012,14 +2184,28 @@ namespace smpc
       padlds[ka.b.H] = 1.0;
 #endif
     SC & sc = scs[0];
-    SD & sd = sds[0];
-    SMPC_LDS(FullDerivWideLds<D>, swls, 1);
-    FullDerivWideLds<D> & swl = swls[0];
+    // derivative scratch, per-dof vectors of the R1 fill, the wide blocks: LDS objects of their own, or (WIDE_DEV) an overlay of the
+    // dynamics block at the end of the evaluation scratch + a slice of device memory
+    SD * sdp;
+    double * wtmp;
     FullDerivWide<D> * swp;
     if constexpr (D::WIDE_DEV)
+    {
+      static_assert(SC::DYN_OUT && sizeof(SC) - offsetof(SC, M) >= sizeof(SD) + sizeof(FullDerivWideLds<D>), "derivative scratch fits the dynamics block");
+      sdp = reinterpret_cast<SD *>(sc.dyn_overlay_());
+      wtmp = sc.dyn_overlay_() + sizeof(SD) / sizeof(double);
       swp = reinterpret_cast<FullDerivWide<D> *>(ka.wide) + block; // (one slice per BLOCK of the launch: smpc_full_engine.h)
+      static_assert(sizeof(SC) <= 40960, "fdyn_deriv_body with its wide blocks in device memory: 4 resident blocks per CU");
+    }
     else
-      swp = &swl.w;
+    {
+      SMPC_LDS(SD, sds, 1);
+      SMPC_LDS(FullDerivWideLds<D>, swls, 1);
+      sdp = &sds[0];
+      swp = &swls[0].w;
+      wtmp = swls[0].tmp_(*swp);
+    }
+    SD & sd = *sdp;
     FullDerivWide<D> & sw = *swp;
     const FullHead<D> & h = sc.h;
     const int st = ring_slot(ka.head, t, R);
@@ -2060,9 +2246,70 @@ namespace smpc
     fp.tprev = SMPC_CLOCK();
     ftick(fp, 0);
     full_dynamics_phases<D, true>(sc, &sd, mg, mask, !term, fp);
+    if constexpr (SC::DYN_OUT)
+    {
+      // a and lam are solved: the factorised block goes to the device slice (every load before the first store), the derivative scratch
+      // takes its place, starting with the composite velocity-product matrices
+      if (!term)
+      {
+        if constexpr (!D::KINO)
+        {
+          constexpr int NK = FullDerivWide<D>::NK, PERK = (NK * NK + NT - 1) / NT;
+          SMPC_LANES(NT)
+          {
+            double v[PERK];
+#pragma unroll
+            for (int i = 0; i < PERK; i++)
+            {
+              const int idx = lane + i * NT < NK * NK ? lane + i * NT : NK * NK - 1;
+              v[i] = full_kkt_inv<D>(sc, idx % NK, idx / NK);
+            }
+#pragma unroll
+            for (int i = 0; i < PERK; i++)
+            {
+              const int idx = lane + i * NT < NK * NK ? lane + i * NT : NK * NK - 1;
+              sw.dyn[idx] = v[i];
+            }
+          }
+          SMPC_LANES_END_WAVE
+        }
+        else
+        {
+        constexpr int N = FullDerivWide<D>::DYN4, PER = (N / 2 + NT - 1) / NT;
+        static_assert(N == SC::DYN_DOUBLES && N % 2 == 0 && sizeof(FullDerivWide<D>) % 16 == 0 && offsetof(FullDerivWide<D>, dyn) % 16 == 0 && offsetof(SC, M) % 16 == 0, "16-byte copies");
+        SMPC_LANES(NT)
+        {
+          struct alignas(16) Pair
+          {
+            double a, b;
+          };
+          const Pair * src = reinterpret_cast<const Pair *>(sc.M);
+          Pair * dst = reinterpret_cast<Pair *>(sw.dyn);
+          Pair v[PER];
+          // (indices clamped, not predicated: the last pass stores a few pairs twice)
+#pragma unroll
+          for (int i = 0; i < PER; i++)
+          {
+            const int idx = lane + i * NT < N / 2 ? lane + i * NT : N / 2 - 1;
+            v[i] = src[idx];
+          }
+#pragma unroll
+          for (int i = 0; i < PER; i++)
+          {
+            const int idx = lane + i * NT < N / 2 ? lane + i * NT : N / 2 - 1;
+            dst[idx] = v[i];
+          }
+        }
+        SMPC_LANES_END_WAVE
+        }
+        ftick(fp, 18);
+        full_bc_composites<D>(sc, sd);
+      }
+      ftick(fp, 17);
+    }
     full_eval_tail<D, true>(sc, &sd, mg, mask, land, term, b.lams_e + (ib + st) * NDX, b.vs_e + (ib + st) * NC, &fp);
     ftick(fp, 7);
-    full_deriv_phases<D>(sc, sd, sw, swl.tmp_(sw), mg, mask, term, fp);
+    full_deriv_phases<D>(sc, sd, sw, wtmp, mg, mask, term, fp);
     ftick(fp, 13);
     full_state_tables<D>(sc, sd, mg);
     double * parts = b.parts0 + ((size_t)inst * (H + 1) + t) * 4;
@@ -2124,8 +2371,20 @@ namespace smpc
         for (int r = 0; r < NCM; r++)
           g += jtc[r] * sd.dual_()[r];
       }
-      for (int r = NCM; r < (term ? NCM + 6 : NGN); r++)
-        g += sc.jt2_()[(r - NCM) * NCOL + k] * sd.dual_()[r];
+      if constexpr (D::WIDE_DEV)
+      {
+        // (momentum / pose rows in the device slice too: again all entries of the column before the sums)
+        double jt2c[NGN - NCM];
+#pragma unroll
+        for (int r = NCM; r < NGN; r++)
+          jt2c[r - NCM] = (term && r >= NCM + 6) ? 0.0 : sw.JT[r * NCOL + k];
+#pragma unroll
+        for (int r = NCM; r < NGN; r++)
+          g += (term && r >= NCM + 6) ? 0.0 : jt2c[r - NCM] * sd.dual_()[r];
+      }
+      else
+        for (int r = NCM; r < (term ? NCM + 6 : NGN); r++)
+          g += full_gn_row<D>(sc, sw, r)[k] * sd.dual_()[r];
       if (k < NDX)
         sd.gx_()[k] = g;
       else
@@ -2176,7 +2435,7 @@ namespace smpc
         SMPC_LANES(NT)
         {
           const double im = 1.0 / h.total_mass, tau = b.dcm_tau;
-          const double * hrow = sc.jt2_(); // momentum rows [dh/dq | Ag | 0]
+          const double * hrow = full_gn_row<D>(sc, sw, NCM); // momentum rows [dh/dq | Ag | 0]
           for (int idx = lane; idx < 3 * NCOL; idx += NT)
           {
             const int r = idx / NCOL, k = idx % NCOL;
@@ -2326,7 +2585,7 @@ namespace smpc
     SMPC_LANES_END_WAVE
     ftick(fp, 15);
     // ---- [Q S; S^T R] = H_0 + JT^T (W~ JT) + preg I on the matrix cores ----
-    full_hessian_mfma<D>(sc, sd, sw, mg, false, preg, lq + D::O_Q, lq + D::O_S, lq + D::O_R, false);
+    full_hessian_mfma<D>(sc, sd, sw, mg, false, preg, lq + D::O_Q, lq + D::O_S, lq + D::O_R, false, false, &fp);
     SMPC_LANES(NT)
     {
       for (int i = lane; i < NC; i += NT)
@@ -2341,32 +2600,70 @@ namespace smpc
     if constexpr (D::NCONE > 0)
     {
       // dense cone rows of the knot: A_cone d lam / d(x, u) for the active rows, zero otherwise
-      SMPC_LANES(NT)
-      for (int idx = lane; idx < D::NCONE * NXU; idx += NT)
+      if constexpr (D::KINO)
       {
-        const int i = idx / NXU, k = idx % NXU;
-        const int f = i / D::NCONE1, r = i % D::NCONE1;
-        double acc = 0.0;
-        if (sc.act[NU + NA + i])
+        // CentroidalWrenchConeResidual: constant rows on the wrench of foot f
+        SMPC_LANES(NT)
+        for (int idx = lane; idx < D::NCONE * NXU; idx += NT)
         {
-          if constexpr (D::KINO)
-          { // CentroidalWrenchConeResidual: constant rows on the wrench of foot f
+          const int i = idx / NXU, k = idx % NXU;
+          const int f = i / D::NCONE1, r = i % D::NCONE1;
+          double acc = 0.0;
+          if (sc.act[NU + NA + i])
             if (k >= NDX + D::FS * f && k < NDX + D::FS * (f + 1))
               acc = wrench_cone_entry(r, k - NDX - D::FS * f, h.fric_mu, h.Lfoot, h.Wfoot);
-          }
+          if (k < NDX)
+            lq[D::O_C + i * NDX + k] = acc;
           else
+            lq[D::O_D + i * NU + k - NDX] = acc;
+        }
+        SMPC_LANES_END_WAVE
+      }
+      else
+      {
+        // lane = column k of (x, u): its NCM entries of d lam / d(x, u) are read once (the rows may lie in device memory), then every cone row of
+        // every foot is a short sum with wave-uniform coefficients; a row's lanes store consecutive addresses
+        SMPC_LANES(NT)
+        for (int k = lane; k < NXU; k += NT)
+        {
+          double jt[NCM];
+#pragma unroll
+          for (int r = 0; r < NCM; r++)
+            jt[r] = sw.JT[r * NCOL + k];
+#pragma unroll
+          for (int f = 0; f < NF; f++)
           {
-            const int c = __builtin_popcount(mask & ((1u << f) - 1u));
+            const bool on = (mask >> f) & 1u;
+            const int c = on ? __builtin_popcount(mask & ((1u << f) - 1u)) : 0;
+            double lf[D::FS];
+#pragma unroll
             for (int j = 0; j < D::FS; j++)
-              acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * sw.JT[(D::FS * c + j) * NCOL + k];
+            {
+              // (the contact index c is wave-uniform; a select chain over the NF possible values keeps jt in registers)
+              double v = jt[j];
+#pragma unroll
+              for (int cc = 1; cc < NF; cc++)
+                v = c == cc ? jt[D::FS * cc + j] : v;
+              lf[j] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < D::NCONE1; r++)
+            {
+              const int i = D::NCONE1 * f + r;
+              double acc = 0.0;
+#pragma unroll
+              for (int j = 0; j < D::FS; j++)
+                acc += wrench_cone_entry(r, j, h.fric_mu, h.Lfoot, h.Wfoot) * lf[j];
+              acc = sc.act[NU + NA + i] ? acc : 0.0;
+              if (k < NDX)
+                lq[D::O_C + i * NDX + k] = acc;
+              else
+                lq[D::O_D + i * NU + k - NDX] = acc;
+            }
           }
         }
-        if (k < NDX)
-          lq[D::O_C + i * NDX + k] = acc;
-        else
-          lq[D::O_D + i * NU + k - NDX] = acc;
+        SMPC_LANES_END_WAVE
       }
-      SMPC_LANES_END_WAVE
     }
     if constexpr (D::KINO)
     {
@@ -2392,13 +2689,30 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
     }
+    ftick(fp, 24);
+    // (the maximum over the lanes' partial values in two levels: eight lanes over eight values each, then one lane over eight -- max is exact in any order)
+    SMPC_LANES(NT)
+    if (lane < 8)
+    {
+      double d8[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        d8[i] = sc.part[lane * 8 + i];
+      double dual = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        dual = fmax(dual, d8[i]);
+      sc.part8[lane] = dual;
+    }
+    SMPC_LANES_END_WAVE
     SMPC_LANES(NT)
     {
       if (lane == 0)
       {
         double dual = 0.0;
-        for (int k = 0; k < NT; k++)
-          dual = fmax(dual, sc.part[k]);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          dual = fmax(dual, sc.part8[k]);
         parts[0] = sc.red[0] + sc.red[1];
         parts[1] = sc.red[0];
         parts[2] = sc.red[2];
@@ -2406,6 +2720,7 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
+    ftick(fp, 20);
   }
 
   template <class D>
