@@ -1716,38 +1716,36 @@ namespace smpc
       // ---- kinodynamics variant: the base rows  M_bb da_b = -(r1q | r1v) dq,dv + (J^T)_b d lam - M_bj d a_j ; the joint accelerations are
       //      controls (r1()).  Right-hand sides in place on the six rows of R1, then R1 <- M_bb^-1 R1 (lane = column) ----
       const double * const kM = SC::DYN_OUT ? sw.Mi_() : sc.M, * const kJ = SC::DYN_OUT ? sw.J_() : sc.J, * const kGi = SC::DYN_OUT ? sw.Gi_() : sc.Gi;
-      SMPC_LANES(NT)
-      for (int idx = lane; idx < 6 * NCOL; idx += NT)
-      {
-        const int b = idx / NCOL, c = idx % NCOL;
-        double v;
-        if (c < 2 * NV)
-          v = -sw.R1[idx];
-        else if (c < 2 * NV + NCM)
-        {
-          const int f = (c - 2 * NV) / FS, j = (c - 2 * NV) % FS;
-          const int cc = __builtin_popcount(mask & ((1u << f) - 1u));
-          const double jv = kJ[(FS * (((mask >> f) & 1u) ? cc : 0) + j) * NV + b];
-          v = ((mask >> f) & 1u) ? jv : 0.0;
-        }
-        else
-          v = -kM[b * NV + 6 + (c - 2 * NV - NCM)];
-        sw.R1[idx] = v;
-      }
-      SMPC_LANES_END_WAVE
+      // (lane = column: the six right-hand-side entries of a column come from one source -- a column of R1, a row of J, a row of M_bj -- through
+      //  one pointer and stride per lane, read together; the product with M_bb^-1 follows in the same lane)
       SMPC_LANES(NT)
       for (int c = lane; c < NCOL; c += NT)
       {
+        const bool isx = c < 2 * NV, isf = !isx && c < 2 * NV + NCM;
+        const int cf = isf ? c - 2 * NV : 0, f = cf / FS, j = cf % FS;
+        const bool on = (mask >> f) & 1u;
+        const int cc = on ? __builtin_popcount(mask & ((1u << f) - 1u)) : 0;
+        const int ca = (!isx && !isf) ? c - 2 * NV - NCM : 0;
+        const double * const src = isx ? &sw.R1[c] : (isf ? &kJ[(FS * cc + j) * NV] : &kM[6 + ca]);
+        const int stride = isx ? NCOL : (isf ? 1 : NV);
+        const double sg = isf ? (on ? 1.0 : 0.0) : -1.0;
         double t[6], o[6];
+#pragma unroll
         for (int b = 0; b < 6; b++)
-          t[b] = sw.R1[b * NCOL + c];
+          t[b] = src[b * stride];
+#pragma unroll
+        for (int b = 0; b < 6; b++)
+          t[b] *= sg;
+#pragma unroll
         for (int b = 0; b < 6; b++)
         {
           double acc = 0.0;
+#pragma unroll
           for (int d = 0; d < 6; d++)
             acc += kGi[b * 6 + d] * t[d];
           o[b] = acc;
         }
+#pragma unroll
         for (int b = 0; b < 6; b++)
           sw.R1[b * NCOL + c] = o[b];
       }
@@ -1791,10 +1789,26 @@ namespace smpc
           }
           sw.JT[r * NCOL + 2 * NV + c] = v;
         }
-        for (int idx = lane; idx < D::NVEL * D::NDX; idx += NT)
+        if constexpr (D::NVEL > 0)
         {
-          const int row = idx / D::NDX, k = idx % D::NDX, f = row / FS, r = row % FS;
-          sw.Cv[idx] = ((mask >> f) & 1u) ? kino_vel_entry<D>(sc, sd, f, r, k) : 0.0;
+          // (one task = the three entries of a (foot, linear | angular) row triple in column k: they share everything but the component)
+          static_assert(D::NVEL == 0 || FS == 6, "frame-velocity rows of 6-D feet");
+          for (int idx = lane; idx < NF * 2 * D::NDX; idx += NT)
+          {
+            const int f = idx / (2 * D::NDX), half = (idx / D::NDX) % 2, k = idx % D::NDX;
+            const int jf = h.foot_joint[f], kk = k < NV ? k : k - NV;
+            V3 o = mk3(0, 0, 0);
+            if (((mask >> f) & 1u) && ((h.anc[jf] >> jof(kk)) & 1u))
+            {
+              const V3 p = ld3(&sc.footp[f * 3]);
+              const SV m = k >= NV ? ldsv(&sc.S[kk * 6]) : ldsv(&sd.dk[kk * 6]);
+              o = tmul(ldm3(&sc.oR[jf * 9]), half == 0 ? m.l + cross(m.a, p) : m.a);
+            }
+            double * dst = &sw.Cv[(FS * f + 3 * half) * D::NDX + k];
+            dst[0] = o.x;
+            dst[D::NDX] = o.y;
+            dst[2 * D::NDX] = o.z;
+          }
         }
       }
       SMPC_LANES_END_WAVE
@@ -2024,28 +2038,37 @@ namespace smpc
           }
     }
     SMPC_LANES_END_WAVE
-    // The biped's full-dynamics blocks (rows of the Jacobian in the device slice, both passes below read every row): all entries of a lane are
-    // fetched at once, before the first K-step -- one memory round trip for the two products instead of one per K-step and pass; entries outside
-    // the rows are zeroed where a K-step uses them (a select on a loaded value is a wait for the load).
+    // Blocks with the rows of the Jacobian in the device slice: a lane's entries of WIN K-steps are in flight ahead of the matrix instructions
+    // (the biped's full dynamics: all of them, fetched once for the two products; its kinodynamics variant: four K-steps, each product fetches);
+    // entries outside the rows are zeroed where a K-step uses them (a select on a loaded value is a wait for the load).
     if (fpp)
       ftick(*fpp, 21);
-    constexpr bool PRE = D::WIDE_DEV && !D::KINO;
-    SMPC_PLA(double, jta, NT, PRE ? KS * NTC : 1);
-    if constexpr (PRE)
-    {
+    constexpr int WIN = !D::WIDE_DEV ? 0 : (D::KINO ? (KS < 4 ? KS : 4) : KS);
+    constexpr bool PRE = WIN > 0;
+    SMPC_PLA(double, jta, NT, PRE ? WIN * NTC : 1);
+    // raw entries of K-step ks (rows 4 ks .. 4 ks + 3) into their slot of the window
+    auto prefetch = [&](int ks) {
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
+        const int r = 4 * ks + lr;
+        const bool velr = D::KINO && r >= NGN0;
+        const double * row = velr ? &sw.Cv[((r < NGN ? r : NGN0) - NGN0) * (D::KINO ? NDX : 0)] : &sw.JT[(r < NGN0 ? r : 0) * NCOL];
+        const int cmax = velr ? NDX : NCOL;
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-          for (int J = 0; J < NTC; J++)
-          {
-            const int r = 4 * ks + lr, c = 16 * J + lc;
-            SMPC_PLV(jta)[ks * NTC + J] = sw.JT[(r < NGN ? r : 0) * NCOL + (c < NCOL ? c : 0)];
-          }
+        for (int J = 0; J < NTC; J++)
+        {
+          const int c = 16 * J + lc;
+          SMPC_PLV(jta)[(ks % (PRE ? WIN : 1)) * NTC + J] = row[c < cmax ? c : 0];
+        }
       }
       SMPC_LANES_END_WAVE
+    };
+    if constexpr (PRE)
+    {
+#pragma unroll
+      for (int ks = 0; ks < WIN; ks++)
+        prefetch(ks);
       SMPC_SCHED_FENCE();
     }
 #pragma unroll(PRE ? KS : 1)
@@ -2062,7 +2085,7 @@ namespace smpc
           const bool velr = D::KINO && r >= NGN0;
           const bool ok = r < NGN && (velr ? (c < NDX && !term) : c < NCOL) && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3)); // terminal node: momentum (+ constraint) rows only
           if constexpr (PRE)
-            SMPC_PLV(jtv)[J] = ok ? SMPC_PLV(jta)[ks * NTC + J] : 0.0;
+            SMPC_PLV(jtv)[J] = ok ? SMPC_PLV(jta)[(ks % WIN) * NTC + J] : 0.0;
           else
           {
           const double * row = (ok && velr) ? &sw.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
@@ -2076,14 +2099,30 @@ namespace smpc
           SMPC_PLV(wop)[R] = full_wtilde<D, SC>(h, 16 * R + lc, r, term, tcs);
       }
       SMPC_LANES_END_WAVE
+      if constexpr (PRE && WIN < KS)
+      {
+        // the slot is free: the next K-step of the window
+        if (ks + WIN < KS)
+          prefetch(ks + WIN);
+        SMPC_SCHED_FENCE();
+      }
 #pragma unroll
       for (int R = 0; R < NTR; R++)
 #pragma unroll
         for (int J = 0; J < NTC; J++)
           SMPC_MFMA(wj, R * NTC + J, wop, R, jtv, J);
+      if constexpr (PRE && WIN < KS)
+        SMPC_SCHED_FENCE();
     }
     if (fpp)
       ftick(*fpp, 22);
+    if constexpr (PRE && WIN < KS)
+    {
+#pragma unroll
+      for (int ks = 0; ks < WIN; ks++)
+        prefetch(ks);
+      SMPC_SCHED_FENCE();
+    }
     SMPC_PLA(double, bv, NT, NTC);
 #pragma unroll
     for (int R = 0; R < NTR; R++)
@@ -2103,7 +2142,7 @@ namespace smpc
             const bool velr = D::KINO && r >= NGN0;
             const bool ok = r < NGN && (velr ? (c < NDX && !term) : c < NCOL) && (!term || (r >= D::NCM && r < D::NCM + 6) || (tcs && r < 3));
             if constexpr (PRE)
-              SMPC_PLV(jtv)[J] = ok ? SMPC_PLV(jta)[(4 * R + v) * NTC + J] : 0.0;
+              SMPC_PLV(jtv)[J] = ok ? SMPC_PLV(jta)[((4 * R + v) % WIN) * NTC + J] : 0.0;
             else
             {
             const double * row = (ok && velr) ? &sw.Cv[(r - NGN0) * (D::KINO ? NDX : 0)]
@@ -2115,11 +2154,19 @@ namespace smpc
           }
         }
         SMPC_LANES_END_WAVE
+        if constexpr (PRE && WIN < KS)
+        {
+          if (4 * R + v + WIN < KS)
+            prefetch(4 * R + v + WIN);
+          SMPC_SCHED_FENCE();
+        }
 #pragma unroll
         for (int I = 0; I < NTC; I++)
 #pragma unroll
           for (int J = I; J < NTC; J++)
             SMPC_MFMA(qa, tix<NTC>(I, J), jtv, I, bv, J);
+        if constexpr (PRE && WIN < KS)
+          SMPC_SCHED_FENCE();
       }
     if (fpp)
       ftick(*fpp, 23);
@@ -2602,20 +2649,28 @@ namespace smpc
       // dense cone rows of the knot: A_cone d lam / d(x, u) for the active rows, zero otherwise
       if constexpr (D::KINO)
       {
-        // CentroidalWrenchConeResidual: constant rows on the wrench of foot f
+        // CentroidalWrenchConeResidual: constant rows on the wrench of foot f (lane = column: a row's lanes store consecutive addresses, the
+        // row index is a compile-time constant of the unrolled loops)
         SMPC_LANES(NT)
-        for (int idx = lane; idx < D::NCONE * NXU; idx += NT)
+        for (int k = lane; k < NXU; k += NT)
         {
-          const int i = idx / NXU, k = idx % NXU;
-          const int f = i / D::NCONE1, r = i % D::NCONE1;
-          double acc = 0.0;
-          if (sc.act[NU + NA + i])
-            if (k >= NDX + D::FS * f && k < NDX + D::FS * (f + 1))
-              acc = wrench_cone_entry(r, k - NDX - D::FS * f, h.fric_mu, h.Lfoot, h.Wfoot);
-          if (k < NDX)
-            lq[D::O_C + i * NDX + k] = acc;
-          else
-            lq[D::O_D + i * NU + k - NDX] = acc;
+#pragma unroll
+          for (int f = 0; f < NF; f++)
+          {
+            const int j = k - NDX - D::FS * f;
+            const bool mine = j >= 0 && j < D::FS;
+#pragma unroll
+            for (int r = 0; r < D::NCONE1; r++)
+            {
+              const int i = D::NCONE1 * f + r;
+              const double e = wrench_cone_entry(r, mine ? j : 0, h.fric_mu, h.Lfoot, h.Wfoot);
+              const double acc = (mine && sc.act[NU + NA + i]) ? e : 0.0;
+              if (k < NDX)
+                lq[D::O_C + i * NDX + k] = acc;
+              else
+                lq[D::O_D + i * NU + k - NDX] = acc;
+            }
+          }
         }
         SMPC_LANES_END_WAVE
       }
