@@ -321,6 +321,11 @@ extern "C"
         h->full.reset(new FullEngine<FullTalos>(robot, s, ms, batch, gravity_arg, device_id));
       else
         throw std::runtime_error("SMPC_KINO_ONLY experiment build");
+#elif defined(SMPC_KINO_ONLY) && defined(SMPC_GO2FULL_TOO)
+      if (robot->njoints == FullGo2::NJ && robot->nfeet == FullGo2::NF && fs == FullGo2::FS && !s.land_cstr && !s.force_cone)
+        h->full.reset(new FullEngine<FullGo2>(robot, s, ms, batch, gravity_arg, device_id));
+      else
+        throw std::runtime_error("SMPC_KINO_ONLY experiment build");
 #elif defined(SMPC_KINO_ONLY)
       throw std::runtime_error("SMPC_KINO_ONLY experiment build");
 #else

@@ -835,7 +835,7 @@ namespace smpc
         sc.iters_[0] = iters;
     }
     SMPC_LANES_END_WAVE
-    if constexpr (DERIV)
+    if constexpr (DERIV && D::WIDE_DEV)
     {
       // ---- blocks of the inverse of the contact KKT matrix [M -J^T ; J mu] for the derivative solve (full_kkt_inv): the solve is then ONE
       //      product over the (NV + NCM) x NCOL right-hand sides instead of a chain of four whose results go through memory.
@@ -1899,21 +1899,31 @@ namespace smpc
     }
     ftick(fp, 11);
     // ---- [M -J^T; J mu] [da; dlam] = -[r1; r2] ----
-    // One product with the inverse of the contact KKT matrix (blocks formed by full_dynamics_phases<D, true>; DYN_OUT: its transpose lies in the
+    if constexpr (!D::WIDE_DEV)
+    {
+      // everything in LDS (the quadruped): Mr = M^-1 R1 ; rhs = J Mr - r2 ; dlam = G^-1 rhs ; da = -Mr + M^-1 J^T dlam, each in place -- four short
+      // products whose operands are an LDS round trip away (the one-product form below measured 3 % slower here: 11.7 -> 12.0 ms per launch)
+      fwave_gemm<NV, NCOL, NV>(
+        [&](int i, int k) { return sc.M[k * NV + i]; }, [&](int k, int j) { return sw.R1[k * NCOL + j]; },
+        [&](int i, int j, double v) { sw.R1[i * NCOL + j] = v; });
+      fwave_gemm<NCM, NCOL, NV>(
+        [&](int i, int k) { return sc.J[i * NV + k]; }, [&](int k, int j) { return sw.R1[k * NCOL + j]; },
+        [&](int i, int j) { return -sw.JT[i * NCOL + j]; }, [&](int i, int j, double v) { sw.JT[i * NCOL + j] = v; });
+      fwave_gemm<NCM, NCOL, NCM>(
+        [&](int i, int k) { return sc.Gi[k * NCM + i]; }, [&](int k, int j) { return sw.JT[k * NCOL + j]; },
+        [&](int i, int j, double v) { sw.JT[i * NCOL + j] = v; });
+      fwave_gemm<NV, NCOL, NCM>(
+        [&](int i, int k) { return sc.W[i * NR + 1 + k]; }, [&](int k, int j) { return sw.JT[k * NCOL + j]; },
+        [&](int i, int j) { return -sw.R1[i * NCOL + j]; }, [&](int i, int j, double v) { sw.R1[i * NCOL + j] = v; });
+    }
+    else
+    {
+    // One product with the inverse of the contact KKT matrix (blocks formed by full_dynamics_phases<D, true>; its transpose lies in the
     // device slice, the LDS of the dynamics block is the derivative scratch by now), in place on [R1 ; force rows of JT]: every operand entry is
     // fetched before the first result is stored.
-    {
       constexpr int NK = NV + NCM;
-#ifndef SMPC_KKT_PF
-#define SMPC_KKT_PF 2
-#endif
-      fwave_gemm<NK, NCOL, NK, D::WIDE_DEV ? SMPC_KKT_PF : 1>(
-        [&](int i, int k) {
-          if constexpr (SC::DYN_OUT)
-            return sw.dyn[k * NK + i];
-          else
-            return full_kkt_inv<D>(sc, i, k);
-        },
+      fwave_gemm<NK, NCOL, NK, 2>(
+        [&](int i, int k) { return sw.dyn[k * NK + i]; },
         [&](int k, int j) { return *(k < NV ? &sw.R1[k * NCOL + j] : &sw.JT[(k - NV) * NCOL + j]); },
         [&](int i, int j, double v) { *(i < NV ? &sw.R1[i * NCOL + j] : &sw.JT[(i - NV) * NCOL + j]) = v; });
     }
@@ -2042,7 +2052,7 @@ namespace smpc
     // (the biped's full dynamics: all of them, fetched once for the two products; its kinodynamics variant: four K-steps, each product fetches);
     // entries outside the rows are zeroed where a K-step uses them (a select on a loaded value is a wait for the load).
     if (fpp)
-      ftick(*fpp, 21);
+      ftick(*fpp, 26);
     constexpr int WIN = !D::WIDE_DEV ? 0 : (D::KINO ? (KS < 4 ? KS : 4) : KS);
     constexpr bool PRE = WIN > 0;
     SMPC_PLA(double, jta, NT, PRE ? WIN * NTC : 1);
@@ -2071,7 +2081,7 @@ namespace smpc
         prefetch(ks);
       SMPC_SCHED_FENCE();
     }
-#pragma unroll(PRE ? KS : 1)
+#pragma unroll
     for (int ks = 0; ks < KS; ks++)
     {
       SMPC_LANES(NT)
@@ -2115,7 +2125,7 @@ namespace smpc
         SMPC_SCHED_FENCE();
     }
     if (fpp)
-      ftick(*fpp, 22);
+      ftick(*fpp, 27);
     if constexpr (PRE && WIN < KS)
     {
 #pragma unroll
@@ -2169,7 +2179,7 @@ namespace smpc
           SMPC_SCHED_FENCE();
       }
     if (fpp)
-      ftick(*fpp, 23);
+      ftick(*fpp, 28);
     SMPC_LANES(NT)
     {
       const int lr = lane >> 4, lc = lane & 15;
@@ -2744,7 +2754,7 @@ namespace smpc
       }
       SMPC_LANES_END_WAVE
     }
-    ftick(fp, 24);
+    ftick(fp, 30);
     // (the maximum over the lanes' partial values in two levels: eight lanes over eight values each, then one lane over eight -- max is exact in any order)
     SMPC_LANES(NT)
     if (lane < 8)
@@ -2775,7 +2785,7 @@ namespace smpc
       }
     }
     SMPC_LANES_END_WAVE
-    ftick(fp, 20);
+    ftick(fp, 29);
   }
 
   template <class D>

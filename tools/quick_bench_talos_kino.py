@@ -14,6 +14,7 @@ print(' '.join('%s %.2f' % (k, v[0]/max(1,v[1])) for k,v in kt.items()))
 if not os.environ.get('SMPC_PHASE_PROFILE'):
     sys.exit(0)
 out = np.zeros(64); gm._lib.check(gm._lib.L.smpc_debug_get_phase_cycles(gm._h, out))
-names = ['load','kin','composite','M/J','cholM/W','G/Gi','prox/a','eval-tail','forces','dk/Ak/Jc','R1','R2','solves','WJ','tables/grad','AB','QSR','Bc','stage-out','GN rows','tail','H0','WJ','JtWJ','knot rows']
+names = ['load','kin','composite','M/J','cholM/W','G/Gi','prox/a','eval-tail','forces','dk/Ak/Jc','R1','R2','solve','-','tables/grad','AB','Hessian stores','Bc','stage-out','GN rows']
+extra = [(26, 'H0'), (27, 'W JT'), (28, 'JT^T W JT'), (30, 'knot rows'), (29, 'dual max / end')]
 nd = 4*3
-print('deriv phase cycles:', ' '.join('%s %.0f' % (nm, out[i]/nd) for i,nm in enumerate(names)), '| total %.0f' % (out[:25].sum()/nd))
+print('deriv phase cycles:', ' '.join('%s %.0f' % (nm, out[i]/nd) for i,nm in enumerate(names)), ' '.join('%s %.0f' % (nm, out[i]/nd) for i,nm in extra), '| total %.0f' % ((out[:20].sum() + sum(out[i] for i,_ in extra))/nd))
