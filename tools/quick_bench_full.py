@@ -21,7 +21,8 @@ kt = gm.kernel_times()
 print('FULL B=%d H=%d k=%d: %.1f ms/step  %.0f steps/s |' % (B, H, iters, dt*1e3, B/dt), ' '.join('%s %.2f' % (k, v[0]/max(1,v[1])) for k,v in kt.items()), '| finite', bool(np.isfinite(gm.info).all()))
 if os.environ.get('SMPC_PHASE_PROFILE'):
     out = np.zeros(64); gm._lib.check(gm._lib.L.smpc_debug_get_phase_cycles(gm._h, out))
-    names = ['load','kin','composite','M/J','cholM/W','G/Gi','prox/a','eval-tail','forces','dk/Ak/Jc','R1','R2','solves','WJ','tables/grad','AB','QSR']
+    names = ['load','kin','composite','M/J','cholM/W','G/Gi','prox/a','eval-tail','forces','dk/Ak/Jc','R1','R2','solve','-','tables/grad','AB','Hessian stores','Bc','stage-out','GN rows']
+    extra = [(26, 'H0'), (27, 'W JT'), (28, 'JT^T W JT'), (30, 'knot rows'), (29, 'dual max / end')]
     nd = (steps+1)*iters
     print('eval-tail parts:', ' '.join('%s %.0f' % (nm, out[20+i]/nd) for i,nm in enumerate(['se3','defect','resid','weighted','cost'])))
-    print('deriv phase cycles (inst 0, stage 17):', ' '.join('%s %.0f' % (nm, out[i]/nd) for i,nm in enumerate(names)), '| total %.0f' % (out[:17].sum()/nd))
+    print('deriv phase cycles (inst 0, stage 17):', ' '.join('%s %.0f' % (nm, out[i]/nd) for i,nm in enumerate(names)), ' '.join('%s %.0f' % (nm, out[i]/nd) for i,nm in extra), '| total %.0f' % ((out[:20].sum() + sum(out[i] for i,_ in extra))/nd))
