@@ -259,6 +259,13 @@ namespace smpc
   }
   inline void stream_destroy(stream_t s) { (void)hipStreamDestroy(s); }
   inline void set_device(int id) { SMPC_HIP(hipSetDevice(id)); }
+  // compute units of a device (grids of kernels whose blocks own a slice of device scratch for their lifetime are sized by it)
+  inline int dev_cu_count(int id)
+  {
+    int n = 0;
+    SMPC_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, id));
+    return n > 0 ? n : 256;
+  }
   inline int device_count()
   {
     int n = 0;

@@ -80,6 +80,7 @@ namespace smpc
   public:
     Buffers<D> buf;
     double * deriv_wide = nullptr; // D::WIDE_DEV: R1 / JT slices of the derivative kernel's blocks (FullDerivWide, smpc_full_stage.h)
+    int n_res = 0;                 // blocks of its persistent grid (compute units x resident blocks per unit)
     // The batch as parts on streams of their own (round 5; SMPC_FULL_PARTS=n, default 1): one wavefront per instance is all the sweeps have, so
     // at B = 1024 riccati_dense_body runs one wave per SIMD for its whole duration; with two parts the sweep of one could run beside the stage
     // kernel of the other.  Measured on the biped (B = 1024, H = 100): 10.77 k control-steps/s with 1 part, 10.29 k with 2, 10.43 k with 3 --
@@ -253,13 +254,18 @@ namespace smpc
       buf.stages = (StageShared<D> *)dev_alloc((size_t)H * sizeof(StageShared<D>));
       buf.model = (DevModel<D> *)dev_alloc(sizeof(DevModel<D>));
       X_dev = dalloc((size_t)B * D::NX);
-      if constexpr (D::WIDE_DEV)
-        deriv_wide = (double *)dev_alloc((size_t)B * (H + 1) * sizeof(FullDerivWide<D>)); // (largest grid of fdyn_deriv_body)
       {
         const char * pe = std::getenv("SMPC_FULL_PARTS");
         n_parts = pe ? std::atoi(pe) : 1;
         if (n_parts < 1 || n_parts > MAX_PARTS || B < 64 * n_parts)
           n_parts = 1;
+        if constexpr (D::WIDE_DEV)
+        {
+          // one slice per RESIDENT block of fdyn_deriv_body (its grid is persistent: smpc_full_stage.h), per part of the batch: LDS decides how
+          // many blocks a CU holds
+          n_res = dev_cu_count(device_id) * (int)(160 * 1024 / sizeof(FullScratch<D, true>));
+          deriv_wide = (double *)dev_alloc((size_t)n_res * n_parts * sizeof(FullDerivWide<D>));
+        }
         if (n_parts > 1)
         {
           ev_fork = event_create();
@@ -386,13 +392,23 @@ namespace smpc
       sk.j0 = 0;
       sk.nj = 0;
       sk.slots = slots;
-      // (a view of a part of the batch: its blocks index the slices behind those of the instances before it)
-      sk.wide = deriv_wide ? deriv_wide + (size_t)(b.xs - buf.xs) / ((size_t)R * D::NX) * (H + 1) * (sizeof(FullDerivWide<D>) / sizeof(double)) : nullptr;
+      // (a view of a part of the batch: the slices of its blocks lie behind those of the parts before it)
+      const long long i0 = (long long)((size_t)(b.xs - buf.xs) / ((size_t)R * D::NX));
+      const int part = (int)((i0 * n_parts + B - 1) / B);
+      sk.wide = deriv_wide ? deriv_wide + (size_t)part * n_res * (sizeof(FullDerivWide<D>) / sizeof(double)) : nullptr;
       return sk;
     }
     void launch_deriv(const Buffers<D> & b, int slots = 0)
     {
-      timed_launch<StageKernelArgs<D>, fdyn_deriv_body<D>, 64, DERIV_MINW>(slots > 0 ? KID_SELECT : KID_DERIV, (slots > 0 ? slots : b.B) * (H + 1), stage_args(b, slots), slots > 0);
+      StageKernelArgs<D> sk = stage_args(b, slots);
+      int grid = (slots > 0 ? slots : b.B) * (H + 1);
+      if constexpr (D::WIDE_DEV)
+      {
+        sk.nwork = grid;
+        sk.nres = grid < n_res ? grid : n_res;
+        grid = sk.nres;
+      }
+      timed_launch<StageKernelArgs<D>, fdyn_deriv_body<D>, 64, DERIV_MINW>(slots > 0 ? KID_SELECT : KID_DERIV, grid, sk, slots > 0);
     }
     void launch_sweeps(const Buffers<D> & b)
     {

@@ -2251,7 +2251,7 @@ namespace smpc
       static_assert(SC::DYN_OUT && sizeof(SC) - offsetof(SC, M) >= sizeof(SD) + sizeof(FullDerivWideLds<D>), "derivative scratch fits the dynamics block");
       sdp = reinterpret_cast<SD *>(sc.dyn_overlay_());
       wtmp = sc.dyn_overlay_() + sizeof(SD) / sizeof(double);
-      swp = reinterpret_cast<FullDerivWide<D> *>(ka.wide) + block; // (one slice per BLOCK of the launch: smpc_full_engine.h)
+      swp = reinterpret_cast<FullDerivWide<D> *>(ka.wide) + block; // (one slice per block of the persistent GRID: fdyn_deriv_body, smpc_full_engine.h)
       static_assert(sizeof(SC) <= 40960, "fdyn_deriv_body with its wide blocks in device memory: 4 resident blocks per CU");
     }
     else
@@ -2791,12 +2791,19 @@ namespace smpc
   template <class D>
   SMPC_DEV void fdyn_deriv_body(const StageKernelArgs<D> & ka, int block)
   {
+    // A block whose wide blocks lie in device memory owns slice `block` for its lifetime: the grid is as many blocks as stay resident
+    // (ka.nres), each walks the work items block, block + nres, .. -- the slices are 50 MB that live in the caches instead of one slice per
+    // item of the launch (5 GB at B = 1024, H = 100, every line of it written back once), and no slice is ever touched from two CUs.
     const int H = ka.b.H;
-    const int slot = block / (H + 1), t = block % (H + 1);
-    const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : slot + 1;
-    const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
-    for (int m = slot; m < count; m += stride)
-      fdyn_deriv_one<D>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t, block);
+    const int nwork = ka.nwork > 0 ? ka.nwork : block + 1, nres = ka.nwork > 0 ? ka.nres : 1;
+    for (int w = block; w < nwork; w += nres)
+    {
+      const int slot = w / (H + 1), t = w % (H + 1);
+      const int count = ka.slots > 0 ? ka.b.und_list[ka.b.B] : slot + 1;
+      const int stride = ka.slots > 0 ? ka.slots : ka.b.B;
+      for (int m = slot; m < count; m += stride)
+        fdyn_deriv_one<D>(ka, ka.slots > 0 ? ka.b.und_list[m] : m, t, block);
+    }
   }
 
   // =============================================================================================

@@ -15,7 +15,8 @@ namespace smpc
     int head;
     int j0, nj; // trial kernel: candidate range
     int slots;  // trial kernel: 0 = block per (instance, stage); > 0 = `slots` instance slots walking und_list
-    double * wide = nullptr; // full-dynamics derivative kernel (D::WIDE_DEV): device scratch, one FullDerivWide slice per block (smpc_full_stage.h)
+    double * wide = nullptr; // full-dynamics derivative kernel (D::WIDE_DEV): device scratch, one FullDerivWide slice per block OF THE GRID (smpc_full_stage.h)
+    int nwork = 0, nres = 0; // the same kernel: nwork (instance-slot, stage) items on a grid of nres persistent blocks (0: one item per block)
   };
 
   // x (+) alpha*dx into dst (NX); SE3 part by `se3lane`, vector part by lanes

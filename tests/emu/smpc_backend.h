@@ -120,6 +120,7 @@ namespace smpc
   inline stream_t stream_create() { return 0; }
   inline void stream_destroy(stream_t) {}
   inline void set_device(int) {}
+  inline int dev_cu_count(int) { return 2; } // (small on purpose: the persistent grids of the dense engines loop over many work items per block here)
   inline int device_count() { return 1; }
   struct event_t
   {
