@@ -92,8 +92,26 @@ namespace smpc
   // SKIPPABLE: bit p of `skip` set = panel p is left out (its 4 pivots couple to nothing: the caller deals with their rows).
   // RCP1: one Newton step on the pivot reciprocals instead of two (2e-15 instead of 1e-16 relative, tools/micro/rcp_accuracy.hip): two dependent
   // FMAs less per pivot, 8 per panel
+  // Per-lane address bases of a sweep's LDS staging, formed ONCE by a kernel that sweeps in a loop (the lane index is re-materialised in every
+  // lane phase, so the phases cannot share them otherwise: five integer instructions per base and phase, ~ 270 per stage of the kinodynamics
+  // sweep): rc = (lane >> 4) * LDW + (lane & 15), cr = (lane & 15) * LDW + (lane >> 4).
+  struct SweepBases
+  {
+    SMPC_PL(int, rc, 64);
+    SMPC_PL(int, cr, 64);
+  };
+  template <int LDW>
+  SMPC_DEV void sweep_bases_init(SweepBases & sb)
+  {
+    SMPC_LANES(64)
+    {
+      SMPC_PLV(sb.rc) = (lane >> 4) * LDW + (lane & 15);
+      SMPC_PLV(sb.cr) = (lane & 15) * LDW + (lane >> 4);
+    }
+    SMPC_LANES_END_WAVE
+  }
   template <int NT, int NTI, bool ALL, int PIV0, int NP, bool SKIPPABLE = false, bool RCP1 = false, class Acc>
-  SMPC_DEV void wave_block_sweep(Acc & acc, double * prow, double * urow, double * prof, long long & tprev, unsigned skip = 0u)
+  SMPC_DEV void wave_block_sweep(Acc & acc, double * prow, double * urow, double * prof, long long & tprev, unsigned skip = 0u, const SweepBases * sb = nullptr)
   {
     constexpr int LDW = 16 * NTI;
     static_assert(NT == 64 && PIV0 % 4 == 0 && PIV0 + 4 * NP <= LDW && LDW <= 2 * NT, "sweep geometry");
@@ -114,16 +132,17 @@ namespace smpc
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
+        const int brc = sb ? SMPC_PLV(sb->rc) : lr * LDW + lc, bcr = sb ? SMPC_PLV(sb->cr) : lc * LDW + lr;
 #pragma unroll
         for (int J = Ip; J < NTI; J++)
-          prow[lr * LDW + 16 * J + lc] = SMPC_ACCV(acc, tix<NTI>(Ip, J), vp);
+          prow[brc + 16 * J] = SMPC_ACCV(acc, tix<NTI>(Ip, J), vp);
         if (ALL && lc >= c0 && lc < c0 + 4)
         {
 #pragma unroll
           for (int I = 0; I < Ip; I++)
 #pragma unroll
             for (int v = 0; v < 4; v++)
-              prow[(lc - c0) * LDW + 16 * I + lr + 4 * v] = SMPC_ACCV(acc, tix<NTI>(I, Ip), v);
+              prow[bcr - c0 * LDW + 16 * I + 4 * v] = SMPC_ACCV(acc, tix<NTI>(I, Ip), v);
         }
       }
       SMPC_LANES_END_WAVE
@@ -211,12 +230,12 @@ namespace smpc
         continue;
       SMPC_LANES(NT)
       {
-        const int lr = lane >> 4, lc = lane & 15;
+        const int brc = sb ? SMPC_PLV(sb->rc) : (lane >> 4) * LDW + (lane & 15);
 #pragma unroll
         for (int I = 0; I < NTI; I++)
         {
-          SMPC_PLV(aop)[ob + I] = -urow[lr * LDW + 16 * I + lc];
-          SMPC_PLV(bop)[ob + I] = prow[lr * LDW + 16 * I + lc];
+          SMPC_PLV(aop)[ob + I] = -urow[brc + 16 * I];
+          SMPC_PLV(bop)[ob + I] = prow[brc + 16 * I];
         }
       }
       SMPC_LANES_END_WAVE
@@ -233,9 +252,10 @@ namespace smpc
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
+          const int brc = sb ? SMPC_PLV(sb->rc) : lr * LDW + lc, bcr = sb ? SMPC_PLV(sb->cr) : lc * LDW + lr;
 #pragma unroll
           for (int J = Ip; J < NTI; J++)
-            SMPC_ACCV(acc, tix<NTI>(Ip, J), vp) = urow[lr * LDW + 16 * J + lc];
+            SMPC_ACCV(acc, tix<NTI>(Ip, J), vp) = urow[brc + 16 * J];
           if (lc >= c0 && lc < c0 + 4)
           {
 #pragma unroll
@@ -243,7 +263,7 @@ namespace smpc
 #pragma unroll
               for (int v = 0; v < 4; v++)
                 if (I < Ip || v != vp)
-                  SMPC_ACCV(acc, tix<NTI>(I, Ip), v) = urow[(lc - c0) * LDW + 16 * I + lr + 4 * v];
+                  SMPC_ACCV(acc, tix<NTI>(I, Ip), v) = urow[bcr - c0 * LDW + 16 * I + 4 * v];
           }
         }
         SMPC_LANES_END_WAVE
@@ -384,6 +404,10 @@ namespace smpc
     double * prof = nullptr;
 #endif
     long long tprev = SMPC_CLOCK();
+    // address bases of the two sweeps' LDS staging (80- and 64-wide operand rows), formed once for the 50 stages
+    SweepBases sb5, sb4;
+    sweep_bases_init<80>(sb5);
+    sweep_bases_init<64>(sb4);
     for (int t = H - 1; t >= 0; t--)
     {
       const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
@@ -474,7 +498,7 @@ namespace smpc
         }
         SMPC_LANES_END_WAVE
         prof_tick(prof, 3, tprev);
-wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 + LD::SWP, prof, tprev);
+wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 + LD::SWP, prof, tprev, 0u, &sb5);
         // P~ (rows / columns NDX .. 2 NDX of the grid) -> LDS image, both halves, and -> the gains block (upper triangle packed row by row), from
         // the registers; p~ -> row NDX of the image (c is dead).  One execution mask per group of stores (a predicate per store costs four scalar instructions and a branch);
         // of a diagonal tile the upper entries only (its two halves are rounded differently: the image stays exactly symmetric).
@@ -902,7 +926,7 @@ wave_block_sweep<NT, 5, false, 0, NDX / 4, false, SMPC_KINO_RCP1>(t1, sw1, sw1 +
       //              [ S^^T            R^    r^            ]
       //          in place:  x-x block -> P_t,  x-vector -> p_t,  stored (x, u) entries -> R^^-1 S^^T = -K,
       //          (u, vector) entries -> R^^-1 r^ = -k ----
-      wave_block_sweep<NT, 4, true, NDX, NU / 4, false, SMPC_KINO_RCP1>(hacc, sw2, sw2 + 4 * 64, prof, tprev);
+      wave_block_sweep<NT, 4, true, NDX, NU / 4, false, SMPC_KINO_RCP1>(hacc, sw2, sw2 + 4 * 64, prof, tprev, 0u, &sb4);
       prof_tick(prof, 10, tprev);
       // P_t -> LDS image (both halves; of a diagonal tile the upper entries), p_t -> its row NDX + 1, [K | k]^T -> gains block, from the registers
       // (a 16-lane row of a tile = 12 consecutive u of one x); grouped by mask
