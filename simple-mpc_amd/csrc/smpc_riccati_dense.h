@@ -98,6 +98,10 @@ namespace smpc
     SMPC_LANES_END_WAVE
     double * prof = (b.dbg != nullptr && block == 0) ? b.dbg : nullptr; // optional phase timers (block 0 only): slots 40 .. 46
     long long tprev = prof ? SMPC_CLOCK() : 0;
+    // address bases of the first sweep's LDS staging, formed once for all stages (wave_block_sweep; the second sweep has two grid widths and the
+    // biped's instantiation no registers to spare: it computes its own)
+    SweepBases sb1;
+    sweep_bases_init<16 * NT1>(sb1);
     for (int t = H - 1; t >= 0; t--)
     {
       const double * lq = b.lq + ((size_t)inst * H + t) * D::LQ_STRIDE;
@@ -179,7 +183,7 @@ namespace smpc
               }
         }
         SMPC_LANES_END_WAVE
-        wave_block_sweep<NT, NT1, false, 0, NDX / 4>(t1, sw, sw + LDS::SWP, prof, tprev);
+        wave_block_sweep<NT, NT1, false, 0, NDX / 4>(t1, sw, sw + LDS::SWP, prof, tprev, 0u, &sb1);
         // P~ (rows / columns NDX .. 2 NDX of the grid) -> LDS image, both halves, upper entries of a diagonal tile only; p~ -> pt.  Stores grouped
         // by execution mask (a predicate per store costs four scalar instructions and a branch)
         SMPC_LANES(NT)
