@@ -415,9 +415,9 @@ namespace smpc
         if (it == 0 && after_first_pre)
           event_record(*after_first_pre, on ? *on : stream);
         if (buf.dbg != nullptr)
-          timed_launch<CentSplitArgs<DC>, cent_bwd_body<DC, true>, 64, 2>(CKID_RICCATI, count, c, aux, on);
+          timed_launch<CentSplitArgs<DC>, cent_bwd_body<DC, true>, 64, 4>(CKID_RICCATI, count, c, aux, on);
         else
-          timed_launch<CentSplitArgs<DC>, cent_bwd_body<DC, false>, 64, 2>(CKID_RICCATI, count, c, aux, on);
+          timed_launch<CentSplitArgs<DC>, cent_bwd_body<DC, false>, 64, 4>(CKID_RICCATI, count, c, aux, on);
         timed_launch<CentSplitArgs<DC>, cent_fwd_body<DC>, 64, 4>(CKID_FORWARD, count, c, aux, on);
         // (line search: the polynomial form needs one lane per stage and the terminal node; longer horizons re-evaluate per candidate)
         if (H + 1 <= 64 && !ls_direct)

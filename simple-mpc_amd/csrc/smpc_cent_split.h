@@ -718,7 +718,7 @@ namespace smpc
   // a plan: Plan::NP panels of 4 pivots starting at Plan::kb(p); Plan::cls(p, I, J) = 0 tile not maintained any more, 1 update before the
   // next panel's gather, 2 update deferred into the next panel's gather / inverse phases.
   template <int NT, int NTI, bool ALL, class Plan, bool PROF = true, class Acc>
-  SMPC_DEV void wave_block_sweep_plan(Acc & acc, double * prow, double * urow, double * prof, long long & tprev)
+  SMPC_DEV void wave_block_sweep_plan(Acc & acc, double * prow, double * urow, double * prof, long long & tprev, const SweepBases * sb = nullptr)
   {
     constexpr int LDW = 16 * NTI, NP = Plan::NP;
     static_assert(NT == 64 && LDW <= NT, "sweep geometry");
@@ -733,16 +733,18 @@ namespace smpc
       SMPC_LANES(NT)
       {
         const int lr = lane >> 4, lc = lane & 15;
+        // (address bases formed once per kernel where the caller sweeps in a loop: SweepBases, smpc_riccati_kino.h)
+        const int brc = sb ? SMPC_PLV(sb->rc) : lr * LDW + lc, bcr = sb ? SMPC_PLV(sb->cr) : lc * LDW + lr;
 #pragma unroll
         for (int J = Ip; J < NTI; J++)
-          prow[lr * LDW + 16 * J + lc] = SMPC_ACCV(acc, tix<NTI>(Ip, J), vp);
+          prow[brc + 16 * J] = SMPC_ACCV(acc, tix<NTI>(Ip, J), vp);
         if (ALL && lc >= c0 && lc < c0 + 4)
         {
 #pragma unroll
           for (int I = 0; I < Ip; I++)
 #pragma unroll
             for (int v = 0; v < 4; v++)
-              prow[(lc - c0) * LDW + 16 * I + lr + 4 * v] = SMPC_ACCV(acc, tix<NTI>(I, Ip), v);
+              prow[bcr - c0 * LDW + 16 * I + 4 * v] = SMPC_ACCV(acc, tix<NTI>(I, Ip), v);
         }
       }
       SMPC_LANES_END_WAVE
@@ -816,12 +818,12 @@ namespace smpc
       // (c) operands of this panel's rank-4 updates ; the updates the next panel depends on
       SMPC_LANES(NT)
       {
-        const int lr = lane >> 4, lc = lane & 15;
+        const int brc = sb ? SMPC_PLV(sb->rc) : (lane >> 4) * LDW + (lane & 15);
 #pragma unroll
         for (int I = ALL ? 0 : Ip; I < NTI; I++)
         {
-          SMPC_PLV(aop)[ob + I] = -urow[lr * LDW + 16 * I + lc];
-          SMPC_PLV(bop)[ob + I] = prow[lr * LDW + 16 * I + lc];
+          SMPC_PLV(aop)[ob + I] = -urow[brc + 16 * I];
+          SMPC_PLV(bop)[ob + I] = prow[brc + 16 * I];
         }
       }
       SMPC_LANES_END_WAVE
@@ -839,9 +841,10 @@ namespace smpc
         SMPC_LANES(NT)
         {
           const int lr = lane >> 4, lc = lane & 15;
+          const int brc = sb ? SMPC_PLV(sb->rc) : lr * LDW + lc, bcr = sb ? SMPC_PLV(sb->cr) : lc * LDW + lr;
 #pragma unroll
           for (int J = Ip; J < NTI; J++)
-            SMPC_ACCV(acc, tix<NTI>(Ip, J), vp) = urow[lr * LDW + 16 * J + lc];
+            SMPC_ACCV(acc, tix<NTI>(Ip, J), vp) = urow[brc + 16 * J];
           if (lc >= c0 && lc < c0 + 4)
           {
 #pragma unroll
@@ -849,7 +852,7 @@ namespace smpc
 #pragma unroll
               for (int v = 0; v < 4; v++)
                 if (I < Ip || v != vp)
-                  SMPC_ACCV(acc, tix<NTI>(I, Ip), v) = urow[(lc - c0) * LDW + 16 * I + lr + 4 * v];
+                  SMPC_ACCV(acc, tix<NTI>(I, Ip), v) = urow[bcr - c0 * LDW + 16 * I + 4 * v];
           }
         }
         SMPC_LANES_END_WAVE
@@ -979,6 +982,9 @@ namespace smpc
     }
     SMPC_LANES_END_WAVE
 
+    // address bases of the sweeps' LDS staging (32-wide operand rows, both sweeps), formed once for the H stages
+    SweepBases sb2;
+    sweep_bases_init<32>(sb2);
     for (int t = H - 1; t >= 0; t--)
     {
       double * g = b.gains + (inst * H + t) * D::G_STRIDE;
@@ -1011,7 +1017,7 @@ namespace smpc
       SMPC_LANES_END_WAVE
       if constexpr (PROF)
         CENT_FINE_TICK(5);
-      wave_block_sweep_plan<NT, 2, false, CentPlan1, PROF>(m1, prow, urow, CENT_FINE_DBG, tprev);
+      wave_block_sweep_plan<NT, 2, false, CentPlan1, PROF>(m1, prow, urow, CENT_FINE_DBG, tprev, &sb2);
       // ---- P~ (tile (1, 1)): out for the forward sweep; operand of the products.  p~ = p + P~ (f - mu p) ----
       SMPC_LANES(NT)
       {
@@ -1075,9 +1081,9 @@ namespace smpc
       // ---- sweep 2: pivots u, then the multipliers of the active cone rows (quasi-definite KKT matrix: explicit pivots) ----
       const bool anyact = SMPC_UNIFORM_U32(stg[RC::O_ANY] != 0.0 ? 1u : 0u) != 0u;
       if (anyact)
-        wave_block_sweep_plan<NT, 2, true, CentPlan2<true>, PROF>(m2, prow, urow, CENT_FINE_DBG, tprev);
+        wave_block_sweep_plan<NT, 2, true, CentPlan2<true>, PROF>(m2, prow, urow, CENT_FINE_DBG, tprev, &sb2);
       else
-        wave_block_sweep_plan<NT, 2, true, CentPlan2<false>, PROF>(m2, prow, urow, CENT_FINE_DBG, tprev);
+        wave_block_sweep_plan<NT, 2, true, CentPlan2<false>, PROF>(m2, prow, urow, CENT_FINE_DBG, tprev, &sb2);
       // ---- gains out ; P_t, p_t stay in the accumulators ----
       SMPC_LANES(NT)
       {
