@@ -20,11 +20,12 @@ KEYS = {
     "riccati_dense_body_go2": ("riccati_dense_body", "FullDimsILi13E", 4096 * 64),
     "forward_full_body_go2": ("forward_full_body", "FullDimsILi13E", 4096 * 64),
     # Talos full dynamics = FullDims<23,2,6,0,0,0>; the kinodynamics OCP with 6-D feet runs the same kernels as FullDims<23,2,6,0,0,1>
-    "fdyn_deriv_body_talos": ("fdyn_deriv_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi0E", 1024 * 101 * 64),
+    # (round 6: the biped's derivative kernel runs a persistent grid of compute units x 4 blocks; its full-batch launches are the TAG = 0 ones)
+    "fdyn_deriv_body_talos": ("fdyn_deriv_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi0E", 1024 * 64),
     "fdyn_trial_body_talos": ("fdyn_trial_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi0E", 1024 * 101 * 64),
     "riccati_dense_body_talos": ("riccati_dense_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi0E", 1024 * 64),
     "forward_full_body_talos": ("forward_full_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi0E", 1024 * 64),
-    "fdyn_deriv_body_taloskino": ("fdyn_deriv_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi1E", 1024 * 101 * 64),
+    "fdyn_deriv_body_taloskino": ("fdyn_deriv_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi1E", 1024 * 64),
     "fdyn_trial_body_taloskino": ("fdyn_trial_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi1E", 1024 * 101 * 64),
     "riccati_dense_body_taloskino": ("riccati_dense_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi1E", 1024 * 64),
     "forward_full_body_taloskino": ("forward_full_body", "FullDimsILi23ELi2ELi6ELi0ELi0ELi1E", 1024 * 64),
@@ -44,7 +45,9 @@ KEYS = {
 
 def kernel_key(name, grid_size):
     """Key of a full-batch main-symbol launch (TAG = 0), or None."""
-    if "ELi0EEE" not in name:
+    # TAG is the last template argument of kernel_entry: the symbol ends "...ELi<NT>ELi<MINW>ELi<TAG>EEEvS5_" (a robot shape that ends in
+    # zeros carries the same characters in the middle of the symbol: look at the end only)
+    if "ELi0EEEv" not in name.strip()[-24:]:
         return None
     for key, (sub, tag, grid) in KEYS.items():
         if sub in name and tag in name and int(grid_size) >= grid:
