@@ -56,11 +56,14 @@ def test_oracle_closed_loop_meets_the_terminal_constraint():
     assert np.abs(v).max() > 1.0 and np.all(np.isfinite(om.xs))
 
 
-def _loop(om, gm, X, n, tol):
-    for _ in range(n):
+def _loop(om, gm, X, n, tol, tol_later=None):
+    """tol_later: the gate of the steps after the first where the first step alone needs a wider one (a random state thrown onto a plan that
+    ends in 1 / mu-weighted rows amplifies rounding once; a regression of the solves would show in every step)"""
+    for i in range(n):
         om.iterate(X)
         gm.iterate(X)
-        assert S.rel_err(om.xs, gm.xs) < tol and S.rel_err(om.us, gm.us) < 1e3 * tol
+        t = tol if (i == 0 or tol_later is None) else tol_later
+        assert S.rel_err(om.xs, gm.xs) < t and S.rel_err(om.us, gm.us) < 1e3 * t, (i, S.rel_err(om.xs, gm.xs), S.rel_err(om.us, gm.us))
         assert S.alphas_agree(om, gm, rtol=1e-8)
         X = om.xs[:, 1, :].copy()
 
@@ -119,7 +122,7 @@ def test_centroidal_problem_accepts_the_flag_like_the_reference(built):
 @pytest.mark.parametrize("iters", [1, 3])
 def test_hip_kinodynamics_terminal_constraint(built, iters):
     om, gm, rb = S.make_pair(3, max_iters=iters, mpc_override=TC)
-    _loop(om, gm, S.random_states(rb, 3), 15, 1e-7)
+    _loop(om, gm, S.random_states(rb, 3), 15, 1e-7, tol_later=1e-8)
 
 
 @pytest.mark.gpu
@@ -127,7 +130,7 @@ def test_hip_go2_fulldynamics_terminal_constraint(built):
     om, gm, rb = S.make_full_pair(2, max_iters=2, mpc_override=TC)
     # (1e-7: the first step, from a random state onto a plan that ends in the 1 / mu-weighted terminal rows, amplifies rounding to 3e-8 -- the order
     # in which the derivative solves accumulate decides the last digits; from the second step on the two sides agree to 1e-11)
-    _loop(om, gm, S.random_states(rb, 2), 12, 1e-7)
+    _loop(om, gm, S.random_states(rb, 2), 12, 1e-7, tol_later=1e-8)
 
 
 @pytest.mark.gpu
