@@ -2273,29 +2273,69 @@ namespace smpc
     const unsigned mask = term ? 0u : (b.stages[t].mask & ((1u << NF) - 1u));
     const unsigned land = (D::NLAND > 0 && !term && mg.land_cstr) ? (b.stages[t].land & mask) : 0u; // feet with land_cstr rows at this stage
     // ---- block inputs ----
+    // Every global load of the block's inputs is issued before the first value is committed to LDS (indices clamped, sources chosen by address;
+    // written as one loop per array, each a load followed by its LDS store, this phase was a chain of ten memory round trips per block).
+    // The stage-shared inputs of the terminal node are read from stage 0 and not used.
     SMPC_LANES(NT)
     {
-      full_load_head<D, NT>(sc.h, &mg, lane);
-      for (int i = lane; i < NX; i += NT)
+      constexpr int PX = (NX + NT - 1) / NT, PU = (NU + NT - 1) / NT, PD = (NDX + NT - 1) / NT, PC = (NC + NT - 1) / NT;
+      static_assert(NCM <= NT && NF * 3 <= NT, "one entry per lane");
+      const int ts = term ? 0 : t;
+      double vx[PX], vxn[PX], vxt[PX], vu[PU], vur[PU], vl[PD], vn[PC];
+#pragma unroll
+      for (int n = 0; n < PX; n++)
       {
-        sc.x[i] = b.xs[(ib + st) * NX + i];
-        sc.xn1[i] = b.xs[(ib + snext) * NX + i];
+        const int i = lane + n * NT < NX ? lane + n * NT : NX - 1;
+        vx[n] = b.xs[(ib + st) * NX + i];
+        vxn[n] = b.xs[(ib + snext) * NX + i];
         // state_cost target: shared pose part, per-instance base-velocity part
-        sc.x_tgt[i] = term ? mg.x_term[i] : ((i >= NQ && i < NQ + 6) ? b.vref[(ib + st) * 6 + (i - NQ)] : b.stages[t].x_tgt[i]);
+        const double * pt = term ? &mg.x_term[i] : ((i >= NQ && i < NQ + 6) ? &b.vref[(ib + st) * 6 + (i - NQ)] : &b.stages[ts].x_tgt[i]);
+        vxt[n] = *pt;
       }
-      for (int i = lane; i < NU; i += NT)
+#pragma unroll
+      for (int n = 0; n < PU; n++)
       {
-        sc.u[i] = term ? 0.0 : b.us[(ib + st) * NU + i];
-        sc.u_ref[i] = term ? 0.0 : b.stages[t].u_ref[i];
+        const int i = lane + n * NT < NU ? lane + n * NT : NU - 1;
+        vu[n] = b.us[(ib + st) * NU + i];
+        vur[n] = b.stages[ts].u_ref[i];
       }
-      for (int i = lane; i < NCM; i += NT)
-        sc.f_ref[i] = term ? 0.0 : b.stages[t].f_ref[i];
-      for (int i = lane; i < NF * 3; i += NT)
-        sc.foot_ref[i] = term ? 0.0 : b.foot_ref[((size_t)inst * H + t) * NF * 3 + i];
-      for (int i = lane; i < NDX; i += NT)
-        sc.lam_next[i] = term ? 0.0 : b.lams[(ib + st) * NDX + i];
-      for (int i = lane; i < NC; i += NT)
-        sc.nu[i] = term ? 0.0 : b.vs[(ib + st) * NC + i];
+      const double vfr = b.stages[ts].f_ref[lane < NCM ? lane : NCM - 1];
+      const double vfo = b.foot_ref[((size_t)inst * H + ts) * NF * 3 + (lane < NF * 3 ? lane : NF * 3 - 1)];
+#pragma unroll
+      for (int n = 0; n < PD; n++)
+        vl[n] = b.lams[(ib + st) * NDX + (lane + n * NT < NDX ? lane + n * NT : NDX - 1)];
+#pragma unroll
+      for (int n = 0; n < PC; n++)
+        vn[n] = b.vs[(ib + st) * NC + (lane + n * NT < NC ? lane + n * NT : NC - 1)];
+      SMPC_SCHED_FENCE();
+      full_load_head<D, NT>(sc.h, &mg, lane);
+#pragma unroll
+      for (int n = 0; n < PX; n++)
+        if (lane + n * NT < NX)
+        {
+          sc.x[lane + n * NT] = vx[n];
+          sc.xn1[lane + n * NT] = vxn[n];
+          sc.x_tgt[lane + n * NT] = vxt[n];
+        }
+#pragma unroll
+      for (int n = 0; n < PU; n++)
+        if (lane + n * NT < NU)
+        {
+          sc.u[lane + n * NT] = term ? 0.0 : vu[n];
+          sc.u_ref[lane + n * NT] = term ? 0.0 : vur[n];
+        }
+      if (lane < NCM)
+        sc.f_ref[lane] = term ? 0.0 : vfr;
+      if (lane < NF * 3)
+        sc.foot_ref[lane] = term ? 0.0 : vfo;
+#pragma unroll
+      for (int n = 0; n < PD; n++)
+        if (lane + n * NT < NDX)
+          sc.lam_next[lane + n * NT] = term ? 0.0 : vl[n];
+#pragma unroll
+      for (int n = 0; n < PC; n++)
+        if (lane + n * NT < NC)
+          sc.nu[lane + n * NT] = term ? 0.0 : vn[n];
     }
     SMPC_LANES_END_WAVE
     FullProf fp;
@@ -2831,27 +2871,91 @@ namespace smpc
     const unsigned land = (D::NLAND > 0 && !term && mg.land_cstr) ? (b.stages[t].land & mask) : 0u; // feet with land_cstr rows at this stage
     const double * dx = b.dxs + ((size_t)inst * (H + 1) + t) * NDX;
     const size_t lt = (size_t)inst * H + (term ? 0 : t);
+    // Every global load of the block's inputs before the first commit to LDS (see fdyn_deriv_one); the two states and their steps go to a
+    // staging area in the late block (unused until the dynamics phases are through), the trial points are formed from there.
+    double * const sx = sc.swp_(), * const sdx = sx + NX, * const sxn = sdx + NDX, * const sdxn = sxn + NX;
+    static_assert(2 * (NX + NDX) <= SC::SWP_DOUBLES, "staging of the trial points fits the sweep scratch");
     SMPC_LANES(NT)
     {
-      full_load_head<D, NT>(sc.h, &mg, lane);
-      for (int i = lane; i < NX; i += NT)
-        sc.x_tgt[i] = term ? mg.x_term[i] : ((i >= NQ && i < NQ + 6) ? b.vref[(ib + st) * 6 + (i - NQ)] : b.stages[t].x_tgt[i]);
-      for (int i = lane; i < NU; i += NT)
+      constexpr int PX = (NX + NT - 1) / NT, PU = (NU + NT - 1) / NT, PD = (NDX + NT - 1) / NT, PC = (NC + NT - 1) / NT;
+      static_assert(NCM <= NT && NF * 3 <= NT, "one entry per lane");
+      const int ts = term ? 0 : t;
+      double vx[PX], vxn[PX], vxt[PX], vu[PU], vdu[PU], vur[PU], vl[PD], vdl[PD], vdx[PD], vdxn[PD], vn[PC], vdn[PC];
+#pragma unroll
+      for (int n = 0; n < PX; n++)
       {
-        sc.u[i] = term ? 0.0 : b.us[(ib + st) * NU + i] + alpha * b.dus[lt * NU + i];
-        sc.u_ref[i] = term ? 0.0 : b.stages[t].u_ref[i];
+        const int i = lane + n * NT < NX ? lane + n * NT : NX - 1;
+        vx[n] = b.xs[(ib + st) * NX + i];
+        vxn[n] = b.xs[(ib + sn) * NX + i];
+        const double * pt = term ? &mg.x_term[i] : ((i >= NQ && i < NQ + 6) ? &b.vref[(ib + st) * 6 + (i - NQ)] : &b.stages[ts].x_tgt[i]);
+        vxt[n] = *pt;
       }
-      for (int i = lane; i < NCM; i += NT)
-        sc.f_ref[i] = term ? 0.0 : b.stages[t].f_ref[i];
-      for (int i = lane; i < NF * 3; i += NT)
-        sc.foot_ref[i] = term ? 0.0 : b.foot_ref[((size_t)inst * H + t) * NF * 3 + i];
-      for (int i = lane; i < NDX; i += NT)
-        sc.lam_next[i] = term ? 0.0 : b.lams[(ib + st) * NDX + i] + alpha * b.dlams[lt * NDX + i];
-      for (int i = lane; i < NC; i += NT)
-        sc.nu[i] = term ? 0.0 : b.vs[(ib + st) * NC + i] + alpha * b.dvs[lt * NC + i];
-      // trial points x_t (+) alpha dx_t and x_{t+1} (+) alpha dx_{t+1}
-      lanes_integrate<D>(b.xs + (ib + st) * NX, dx, alpha, sc.x, lane, 0);
-      lanes_integrate<D>(b.xs + (ib + sn) * NX, dx + (term ? 0 : NDX), alpha, sc.xn1, lane, 1);
+#pragma unroll
+      for (int n = 0; n < PU; n++)
+      {
+        const int i = lane + n * NT < NU ? lane + n * NT : NU - 1;
+        vu[n] = b.us[(ib + st) * NU + i];
+        vdu[n] = b.dus[lt * NU + i];
+        vur[n] = b.stages[ts].u_ref[i];
+      }
+      const double vfr = b.stages[ts].f_ref[lane < NCM ? lane : NCM - 1];
+      const double vfo = b.foot_ref[((size_t)inst * H + ts) * NF * 3 + (lane < NF * 3 ? lane : NF * 3 - 1)];
+#pragma unroll
+      for (int n = 0; n < PD; n++)
+      {
+        const int i = lane + n * NT < NDX ? lane + n * NT : NDX - 1;
+        vl[n] = b.lams[(ib + st) * NDX + i];
+        vdl[n] = b.dlams[lt * NDX + i];
+        vdx[n] = dx[i];
+        vdxn[n] = dx[(term ? 0 : NDX) + i];
+      }
+#pragma unroll
+      for (int n = 0; n < PC; n++)
+      {
+        const int i = lane + n * NT < NC ? lane + n * NT : NC - 1;
+        vn[n] = b.vs[(ib + st) * NC + i];
+        vdn[n] = b.dvs[lt * NC + i];
+      }
+      SMPC_SCHED_FENCE();
+      full_load_head<D, NT>(sc.h, &mg, lane);
+#pragma unroll
+      for (int n = 0; n < PX; n++)
+        if (lane + n * NT < NX)
+        {
+          sx[lane + n * NT] = vx[n];
+          sxn[lane + n * NT] = vxn[n];
+          sc.x_tgt[lane + n * NT] = vxt[n];
+        }
+#pragma unroll
+      for (int n = 0; n < PU; n++)
+        if (lane + n * NT < NU)
+        {
+          sc.u[lane + n * NT] = term ? 0.0 : vu[n] + alpha * vdu[n];
+          sc.u_ref[lane + n * NT] = term ? 0.0 : vur[n];
+        }
+      if (lane < NCM)
+        sc.f_ref[lane] = term ? 0.0 : vfr;
+      if (lane < NF * 3)
+        sc.foot_ref[lane] = term ? 0.0 : vfo;
+#pragma unroll
+      for (int n = 0; n < PD; n++)
+        if (lane + n * NT < NDX)
+        {
+          sc.lam_next[lane + n * NT] = term ? 0.0 : vl[n] + alpha * vdl[n];
+          sdx[lane + n * NT] = vdx[n];
+          sdxn[lane + n * NT] = vdxn[n];
+        }
+#pragma unroll
+      for (int n = 0; n < PC; n++)
+        if (lane + n * NT < NC)
+          sc.nu[lane + n * NT] = term ? 0.0 : vn[n] + alpha * vdn[n];
+    }
+    SMPC_LANES_END_WAVE
+    // trial points x_t (+) alpha dx_t and x_{t+1} (+) alpha dx_{t+1}
+    SMPC_LANES(NT)
+    {
+      lanes_integrate<D>(sx, sdx, alpha, sc.x, lane, 0);
+      lanes_integrate<D>(sxn, sdxn, alpha, sc.xn1, lane, 1);
     }
     SMPC_LANES_END_WAVE
     FullProf fp;
