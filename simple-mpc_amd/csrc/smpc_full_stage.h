@@ -1060,6 +1060,21 @@ namespace smpc
     const FullHead<D> & h = sc.h;
     const double dt = h.dt, mu = h.mu;
     const double * vq = &sc.x[NQ];
+    // the centres of the augmented Lagrangian (device memory) are what the multiplier phase below waits for: their loads are issued here, a
+    // whole SE(3) pair ahead of their use
+    constexpr int PDE = (NDX + NT - 1) / NT, PCE = (NC + NT - 1) / NT;
+    SMPC_PLA(double, lame_r, NT, PDE);
+    SMPC_PLA(double, nue_r, NT, PCE);
+    SMPC_LANES(NT)
+    {
+#pragma unroll
+      for (int n = 0; n < PDE; n++)
+        SMPC_PLV(lame_r)[n] = lam_e[lane + n * NT < NDX ? lane + n * NT : NDX - 1];
+#pragma unroll
+      for (int n = 0; n < PCE; n++)
+        SMPC_PLV(nue_r)[n] = nu_e[lane + n * NT < NC ? lane + n * NT : NC - 1];
+    }
+    SMPC_LANES_END_WAVE
     // ---- x+ = x (+) [dt (v + dt a); dt a] ; base block of the state residual ----
     SMPC_LANES(NT)
     {
@@ -1310,16 +1325,24 @@ namespace smpc
     SMPC_LANES(NT)
     {
       double pen = 0.0, prim = 0.0;
-      for (int i = lane; i < NDX; i += NT)
+#pragma unroll
+      for (int n = 0; n < PDE; n++)
       {
-        const double lp = lam_e[i] + sc.e[i] / mu;
+        const int i = lane + n * NT;
+        if (i >= NDX)
+          break;
+        const double lp = SMPC_PLV(lame_r)[n] + sc.e[i] / mu;
         sc.lamp[i] = lp;
         const double dl = lp - sc.lam_next[i];
         pen += 0.5 * mu * (lp * lp + dl * dl);
         prim = fmax(prim, fabs(sc.e[i]));
       }
-      for (int i = lane; i < NC; i += NT)
+#pragma unroll
+      for (int n = 0; n < PCE; n++)
       {
+        const int i = lane + n * NT;
+        if (i >= NC)
+          break;
         // rows: torque box | joint box | wrench-cone rows of the feet in contact (negative orthant) | rows of the landing feet (equality)
         // (kinodynamics variant: | frame-velocity rows of the feet in contact (equality), behind the dense rows)
         const bool box = i < NU + NA, eq = i >= NU + NA + D::NCONE, vel = i >= NU + NA + D::NCD;
@@ -1333,7 +1356,7 @@ namespace smpc
         if (present)
         {
           const double lo = i < NU ? h.umin[i] : (box ? h.qmin[i - NU] : -1e300), hi = i < NU ? h.umax[i] : (box ? h.qmax[i - NU] : 0.0);
-          const double z = sc.cval[i] + mu * nu_e[i];
+          const double z = sc.cval[i] + mu * SMPC_PLV(nue_r)[n];
           const double proj = box ? fmin(fmax(z, lo), hi) : (eq ? 0.0 : fmin(z, 0.0));
           vp = (z - proj) / mu;
           act = eq || z != proj;
@@ -2609,6 +2632,9 @@ namespace smpc
     SMPC_LANES(NT)
     {
       double dual = 0.0;
+      // (the previous stage's dynamics multiplier -- device memory -- is asked for before the column is assembled, not at the end of it)
+      static_assert(NDX <= NT, "the state columns are one pass of the lanes");
+      const double lam_prev = b.lams[(ib + sprev) * NDX + (lane < NDX ? lane : 0)];
       for (int col = lane; col < NXU; col += NT)
       {
         const bool isA = col < NDX;
@@ -2655,7 +2681,7 @@ namespace smpc
           double cn = 0.0;
           if (h.kinematics_limits && k >= 6 && k < NV)
             cn = sc.nu[NU + k - 6];
-          double q = sd.gx_()[k] + acc + cn + sd.cq_()[k] - (t > 0 ? b.lams[(ib + sprev) * NDX + k] : 0.0);
+          double q = sd.gx_()[k] + acc + cn + sd.cq_()[k] - (t > 0 ? lam_prev : 0.0);
           if (t == 0)
             q = 0.0; // x_0 is pinned (force_initial_condition_, reference src/mpc.cpp:53)
           double qf = q;
