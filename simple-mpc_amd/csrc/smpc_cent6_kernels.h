@@ -258,36 +258,54 @@ namespace smpc
     const unsigned mask = term ? 0u : b.stages[t].mask;
     const double preg = b.scal[inst * SC_N + SC_PREG];
     double * parts = ka.parts0 + (inst * (H + 1) + t) * 4;
+    // every global load of the block's inputs before the first commit to LDS (indices clamped, the terminal node reads stage 0's shared
+    // entries and does not use them): written as one loop per array the phase was a chain of memory round trips per block
     SMPC_LANES(NT)
     {
-      constexpr int N = (int)(sizeof(CentDevModel<D>) / sizeof(double));
+      constexpr int N = (int)(sizeof(CentDevModel<D>) / sizeof(double)), PM = (N + NT - 1) / NT;
+      static_assert(NU <= NT && NC <= NT && 3 * NF <= NT, "one entry per lane");
       const alias_double * src = reinterpret_cast<const alias_double *>(b.model);
       alias_double * dst = reinterpret_cast<alias_double *>(&s.md);
-      for (int i = lane; i < N; i += NT)
-        dst[i] = src[i];
+      const int ts = term ? 0 : t, l9 = lane < 9 ? lane : 8;
+      double vm[PM];
+#pragma unroll
+      for (int n = 0; n < PM; n++)
+        vm[n] = src[lane + n * NT < N ? lane + n * NT : N - 1];
+      const double vx = b.xs[(ib + st) * 9 + l9], vxn = b.xs[(ib + st1) * 9 + l9];
+      const double vl1 = b.lams[(ib + st) * 9 + l9], vl1e = b.lams_e[(ib + st) * 9 + l9], vl0 = b.lams[(ib + stm) * 9 + l9];
+      const double vxt = *(l9 < 3 ? &b.stages[ts].x_tgt[l9] : &b.vref[(ib + st) * 6 + l9 - 3]);
+      const int lu = lane < NU ? lane : NU - 1, lc = lane < NC ? lane : NC - 1, lf = lane < 3 * NF ? lane : 3 * NF - 1;
+      const double vu = b.us[(ib + st) * NU + lu], vur = b.stages[ts].u_ref[lu];
+      const double vv = b.vs[(ib + st) * NC + lc], vve = b.vs_e[(ib + st) * NC + lc];
+      const double vpp = b.foot[(inst * H + ts) * (3 * NF) + lf];
+      SMPC_SCHED_FENCE();
+#pragma unroll
+      for (int n = 0; n < PM; n++)
+        if (lane + n * NT < N)
+          dst[lane + n * NT] = vm[n];
       if (lane < 9)
       {
-        s.x[lane] = b.xs[(ib + st) * 9 + lane];
-        s.xn[lane] = b.xs[(ib + st1) * 9 + lane];
-        s.l1[lane] = term ? 0.0 : b.lams[(ib + st) * 9 + lane];
-        s.l1e[lane] = term ? 0.0 : b.lams_e[(ib + st) * 9 + lane];
-        s.l0[lane] = t > 0 ? b.lams[(ib + stm) * 9 + lane] : 0.0;
-        s.xt[lane] = term ? 0.0 : (lane < 3 ? b.stages[t].x_tgt[lane] : b.vref[(ib + st) * 6 + lane - 3]);
+        s.x[lane] = vx;
+        s.xn[lane] = vxn;
+        s.l1[lane] = term ? 0.0 : vl1;
+        s.l1e[lane] = term ? 0.0 : vl1e;
+        s.l0[lane] = t > 0 ? vl0 : 0.0;
+        s.xt[lane] = term ? 0.0 : vxt;
       }
       if (!term)
       {
-        for (int i = lane; i < NU; i += NT)
+        if (lane < NU)
         {
-          s.u[i] = b.us[(ib + st) * NU + i];
-          s.uref[i] = b.stages[t].u_ref[i];
+          s.u[lane] = vu;
+          s.uref[lane] = vur;
         }
-        for (int i = lane; i < NC; i += NT)
+        if (lane < NC)
         {
-          s.v[i] = b.vs[(ib + st) * NC + i];
-          s.ve[i] = b.vs_e[(ib + st) * NC + i];
+          s.v[lane] = vv;
+          s.ve[lane] = vve;
         }
-        for (int i = lane; i < 3 * NF; i += NT)
-          s.pp[i] = b.foot[(inst * H + t) * (3 * NF) + i];
+        if (lane < 3 * NF)
+          s.pp[lane] = vpp;
       }
     }
     SMPC_LANES_END_WAVE
@@ -834,35 +852,47 @@ namespace smpc
     Cent6TrialLds<D> & s = ldsv[0];
     const int st = ring_slot(head, t, R), st1 = ring_slot(head, term ? t : t + 1, R);
     const unsigned mask = term ? 0u : b.stages[t].mask;
+    // (every global load before the first commit to LDS, as in cent6_deriv_body)
     SMPC_LANES(NT)
     {
+      static_assert(NU <= NT && NC <= NT && 3 * NF <= NT, "one entry per lane");
+      const int ts = term ? 0 : t, l9 = lane < 9 ? lane : 8;
+      const double vx = b.xs[(ib + st) * 9 + l9], vdx = b.dxs[(inst * (H + 1) + t) * 9 + l9];
+      const double vxn = b.xs[(ib + st1) * 9 + l9], vdxn = b.dxs[(inst * (H + 1) + (term ? t : t + 1)) * 9 + l9];
+      const double vl1 = b.lams[(ib + st) * 9 + l9], vdl = b.dlams[(inst * H + ts) * 9 + l9], vl1e = b.lams_e[(ib + st) * 9 + l9];
+      const double vxt = *(l9 < 3 ? &b.stages[ts].x_tgt[l9] : &b.vref[(ib + st) * 6 + l9 - 3]);
+      const int lu = lane < NU ? lane : NU - 1, lc = lane < NC ? lane : NC - 1, lf = lane < 3 * NF ? lane : 3 * NF - 1;
+      const double vu = b.us[(ib + st) * NU + lu], vdu = b.dus[(inst * H + ts) * NU + lu], vur = b.stages[ts].u_ref[lu];
+      const double vv = b.vs[(ib + st) * NC + lc], vdv = b.dvs[(inst * H + ts) * NC + lc], vve = b.vs_e[(ib + st) * NC + lc];
+      const double vpp = b.foot[(inst * H + ts) * (3 * NF) + lf];
+      SMPC_SCHED_FENCE();
       if (lane < 9)
       {
-        s.x[lane] = b.xs[(ib + st) * 9 + lane];
-        s.dx[lane] = b.dxs[(inst * (H + 1) + t) * 9 + lane];
-        s.xn[lane] = b.xs[(ib + st1) * 9 + lane];
-        s.dxn[lane] = term ? 0.0 : b.dxs[(inst * (H + 1) + t + 1) * 9 + lane];
-        s.l1[lane] = term ? 0.0 : b.lams[(ib + st) * 9 + lane];
-        s.dl[lane] = term ? 0.0 : b.dlams[(inst * H + t) * 9 + lane];
-        s.l1e[lane] = term ? 0.0 : b.lams_e[(ib + st) * 9 + lane];
-        s.xt[lane] = term ? 0.0 : (lane < 3 ? b.stages[t].x_tgt[lane] : b.vref[(ib + st) * 6 + lane - 3]);
+        s.x[lane] = vx;
+        s.dx[lane] = vdx;
+        s.xn[lane] = vxn;
+        s.dxn[lane] = term ? 0.0 : vdxn;
+        s.l1[lane] = term ? 0.0 : vl1;
+        s.dl[lane] = term ? 0.0 : vdl;
+        s.l1e[lane] = term ? 0.0 : vl1e;
+        s.xt[lane] = term ? 0.0 : vxt;
       }
       if (!term)
       {
-        for (int i = lane; i < NU; i += NT)
+        if (lane < NU)
         {
-          s.u[i] = b.us[(ib + st) * NU + i];
-          s.du[i] = b.dus[(inst * H + t) * NU + i];
-          s.uref[i] = b.stages[t].u_ref[i];
+          s.u[lane] = vu;
+          s.du[lane] = vdu;
+          s.uref[lane] = vur;
         }
-        for (int i = lane; i < NC; i += NT)
+        if (lane < NC)
         {
-          s.v[i] = b.vs[(ib + st) * NC + i];
-          s.dv[i] = b.dvs[(inst * H + t) * NC + i];
-          s.ve[i] = b.vs_e[(ib + st) * NC + i];
+          s.v[lane] = vv;
+          s.dv[lane] = vdv;
+          s.ve[lane] = vve;
         }
-        for (int i = lane; i < 3 * NF; i += NT)
-          s.pp[i] = b.foot[(inst * H + t) * (3 * NF) + i];
+        if (lane < 3 * NF)
+          s.pp[lane] = vpp;
       }
     }
     SMPC_LANES_END_WAVE

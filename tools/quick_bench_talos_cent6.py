@@ -7,7 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "simple-mpc_amd", "python"))
-import bench  # noqa: E402
+import bench_side as bench  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
