@@ -2861,6 +2861,15 @@ namespace smpc
     // (ka.nres), each walks the work items block, block + nres, .. -- the slices are 50 MB that live in the caches instead of one slice per
     // item of the launch (5 GB at B = 1024, H = 100, every line of it written back once), and no slice is ever touched from two CUs.
     const int H = ka.b.H;
+    if (ka.nwork > 0 && ka.slots > 0)
+    {
+      // list mode on the persistent grid: the (list entry, stage) pairs themselves are dealt round-robin (the slot walk below gives a block the
+      // entries slot, slot + slots, ..: one or two per item, uneven once the list is longer than the slots)
+      const int total = ka.b.und_list[ka.b.B] * (H + 1);
+      for (int w = block; w < total; w += ka.nres)
+        fdyn_deriv_one<D>(ka, ka.b.und_list[w / (H + 1)], w % (H + 1), block);
+      return;
+    }
     const int nwork = ka.nwork > 0 ? ka.nwork : block + 1, nres = ka.nwork > 0 ? ka.nres : 1;
     for (int w = block; w < nwork; w += nres)
     {
