@@ -51,6 +51,7 @@ namespace smpc
     static constexpr int LQ_STRIDE = ((O_act + NC + 7) / 8) * 8;
     static constexpr int G_K = 0;
     static constexpr int G_Z = G_K + NU * (NDX + 1);
+    static constexpr bool PT_PACKED = false; // (P~ as a full NDX x NDX image: cent6_forward_body reads rows of it)
     static constexpr int G_Pt = G_Z + NCD * (NDX + 1);
     static constexpr int G_pn = G_Pt + NDX * NDX;
     static constexpr int G_STRIDE = ((G_pn + NDX + 7) / 8) * 8;

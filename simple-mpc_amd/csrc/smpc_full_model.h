@@ -86,8 +86,12 @@ namespace smpc
     // INVARIANT of G_Z: rows of INACTIVE dense constraint rows are not written by the light grid of riccati_dense_body (stale values of an
     // earlier iteration / stage stay there); every reader -- forward_full_body, cent6_forward_body -- forms d / mu itself for a row whose
     // activity flag lq[O_act + ...] is 0 and never reads [Z z] of it.  A new reader of G_Z must test the same flag.
-    static constexpr int G_Pt = G_Z + NCD * (NDX + 1);     // P~ (NDX x NDX)
-    static constexpr int G_pn = G_Pt + NDX * NDX;          // p_{t+1}
+    // P~: upper triangle packed row by row (round 6; the forward sweep is bound by the bytes it reads, half of P~ is 18 % of them): entry
+    // (i, j), i <= j, at pt_off(i, j); the sweeps that write it and forward_full_body go through pt_row
+    static constexpr bool PT_PACKED = true;
+    static constexpr int G_Pt = G_Z + NCD * (NDX + 1);
+    SMPC_HD static constexpr int pt_row(int i) { return G_Pt + i * NDX - i * (i - 1) / 2 - i; } // + j = entry (i, j), j >= i
+    static constexpr int G_pn = G_Pt + NDX * (NDX + 1) / 2; // p_{t+1}
     static constexpr int G_STRIDE = ((G_pn + NDX + 7) / 8) * 8;
     static constexpr int LS_N = 10;
     static_assert(NJ_ <= 32, "ancestor bit sets");

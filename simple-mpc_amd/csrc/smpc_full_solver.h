@@ -109,8 +109,25 @@ namespace smpc
       SMPC_LANES_END
       SMPC_LANES(NT)
       {
-        for (int idx = lane; idx < NDX * NDX; idx += NT)
-          g[D::G_Pt + idx] = s.P[idx];
+        if constexpr (D::PT_PACKED)
+        {
+          // upper triangle: row i (NDX - i entries from the diagonal on) and row NDX - 1 - i (i + 1 entries) share a pass of the lanes
+          // (NDX + 1 <= 64 entries): half as many stores as one row per pass
+          static_assert(NDX + 1 <= NT && NDX % 2 == 0, "two rows of P~ per pass of the lanes");
+#pragma unroll
+          for (int i = 0; i < NDX / 2; i++)
+          {
+            const int i2 = NDX - 1 - i, n1 = NDX - i;
+            const bool first = lane < n1;
+            const int src = first ? i * NDX + i + lane : i2 * NDX + i2 + (lane - n1);
+            const int dst = first ? D::pt_row(i) + i + lane : D::pt_row(i2) + i2 + (lane - n1);
+            if (lane < NDX + 1)
+              g[dst] = s.P[src];
+          }
+        }
+        else
+          for (int idx = lane; idx < NDX * NDX; idx += NT)
+            g[D::G_Pt + idx] = s.P[idx];
         mm_tn<NDX, NXU, NDX, TL, TL, NT>(
           s.P, NDX, s.AB, NXU, lane, [](int, int) { return 0.0; }, [&](int i, int j, double v) { s.MT[i * NXU + j] = v; });
       }
@@ -283,10 +300,15 @@ namespace smpc
       SMPC_LANES(NT)
       for (int i = lane; i < NDX; i += NT)
       {
-        const double * Pr = g + D::G_Pt + i * NDX;
+        // row i of the packed upper triangle: (j, i) for j < i -- the lanes of a wave read consecutive addresses --, (i, j) from the diagonal on
+        static_assert(D::PT_PACKED, "forward_full_body reads the packed P~ of the FullDims sweeps");
         double w = 0.0;
+#pragma unroll
         for (int j = 0; j < NDX; j++)
-          w += Pr[j] * y[j];
+        {
+          const double * src = j < i ? g + D::pt_row(j) + i : g + D::pt_row(i) + j;
+          w += *src * y[j];
+        }
         const double dxn = y[i] - mu * w;
         const double dl = w + g[D::G_pn + i];
         b.dxs[((size_t)inst * (H + 1) + t + 1) * NDX + i] = dxn;

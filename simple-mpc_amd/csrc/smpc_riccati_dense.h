@@ -285,8 +285,25 @@ namespace smpc
                   off = r0 < NDX ? D::O_q + r0 : D::O_r + r0 - NDX;
                 SMPC_ACCV(hacc, tix<NT2X>(I, J), v) = lq[off];
               }
-          for (int idx = lane; idx < NDX * NDX; idx += NT)
-            g[D::G_Pt + idx] = s.P[idx];
+          if constexpr (D::PT_PACKED)
+          {
+            // upper triangle: row i (NDX - i entries from the diagonal on) and row NDX - 1 - i (i + 1 entries) share a pass of the lanes
+            // (NDX + 1 <= 64 entries): half as many stores as one row per pass
+            static_assert(NDX + 1 <= NT && NDX % 2 == 0, "two rows of P~ per pass of the lanes");
+#pragma unroll
+            for (int i = 0; i < NDX / 2; i++)
+            {
+              const int i2 = NDX - 1 - i, n1 = NDX - i;
+              const bool first = lane < n1;
+              const int src = first ? i * NDX + i + lane : i2 * NDX + i2 + (lane - n1);
+              const int dst = first ? D::pt_row(i) + i + lane : D::pt_row(i2) + i2 + (lane - n1);
+              if (lane < NDX + 1)
+                g[dst] = s.P[src];
+            }
+          }
+          else
+            for (int idx = lane; idx < NDX * NDX; idx += NT)
+              g[D::G_Pt + idx] = s.P[idx];
         }
         SMPC_LANES_END_WAVE
         prof_tick(prof, 42, tprev);
