@@ -206,10 +206,12 @@ namespace smpc
     const Buffers<D> & b = ka.b;
     const int H = b.H, R = b.R;
     const int inst = block;
-    const double mu = b.model->mu;
+    const double mu = b.model->mu, dt = b.model->dt;
+    constexpr int NV = D::NV;
     SMPC_LDS(double, dx, D::NDX);
     SMPC_LDS(double, du, D::NU);
     SMPC_LDS(double, y, D::NDX);
+    SMPC_LDS(double, ab, D::NDX);
     SMPC_LDS(double, part, 64);
     SMPC_LDS(double, lpd_prev, D::NDX);
     SMPC_LANES(NT)
@@ -281,8 +283,13 @@ namespace smpc
             b.dvs[lt * NC + row] = dnu;
             part[lane] += lq[D::O_vpd + row] * (mu * dnu - d) - d * dnu;
           }
+        // Rows of [A B]: the joint-position rows are e_i + dt x (the joint-velocity row of the same joint) -- q_i+ = q_i + dt v_i+ (semi-implicit
+        // Euler; assembled exactly so by fdyn_deriv_body) --, so only the base rows and the velocity rows are read: 34 of the biped's 56 rows,
+        // a quarter fewer of the bytes that bound this kernel.  (A dx + B du)_i of the other rows follows from the velocity rows below.
         for (int i = lane; i < NDX; i += NT)
         {
+          if (i >= 6 && i < NV)
+            continue;
           const double * Ar = lq + D::O_A + i * NDX;
           const double * Br = lq + D::O_B + i * NU;
           double acc = 0.0;
@@ -290,10 +297,17 @@ namespace smpc
             acc += Ar[j] * dx[j];
           for (int j = 0; j < NU; j++)
             acc += Br[j] * du[j];
-          const double fi = lq[D::O_f + i], pn = g[D::G_pn + i];
-          part[lane] += (lq[D::O_lx + i] - lpd_prev[i]) * dx[i] + lq[D::O_lpd + i] * acc;
-          y[i] = acc + fi - mu * pn;
+          ab[i] = acc;
         }
+      }
+      SMPC_LANES_END_WAVE
+      SMPC_LANES(NT)
+      for (int i = lane; i < NDX; i += NT)
+      {
+        const double acc = (i >= 6 && i < NV) ? dx[i] + dt * ab[NV + i] : ab[i];
+        const double fi = lq[D::O_f + i], pn = g[D::G_pn + i];
+        part[lane] += (lq[D::O_lx + i] - lpd_prev[i]) * dx[i] + lq[D::O_lpd + i] * acc;
+        y[i] = acc + fi - mu * pn;
       }
       SMPC_LANES_END_WAVE
       // w = P~ y ; dx+ = y - mu w ; dlam+ = w + p_{t+1}
