@@ -285,11 +285,18 @@ namespace smpc
           }
         // Rows of [A B]: the joint-position rows are e_i + dt x (the joint-velocity row of the same joint) -- q_i+ = q_i + dt v_i+ (semi-implicit
         // Euler; assembled exactly so by fdyn_deriv_body) --, so only the base rows and the velocity rows are read: 34 of the biped's 56 rows,
-        // a quarter fewer of the bytes that bound this kernel.  (A dx + B du)_i of the other rows follows from the velocity rows below.
+        // a quarter fewer of the bytes that bound this kernel (the kinodynamics variant: the 12 base rows).  (A dx + B du)_i of the other rows follows from the velocity rows below.
         for (int i = lane; i < NDX; i += NT)
         {
           if (i >= 6 && i < NV)
             continue;
+          if constexpr (D::KINO)
+            if (i >= NV + 6)
+            {
+              // kinodynamics variant: the joint accelerations are controls, v_i+ = v_i + dt u_i: a unit entry and one dt (fdyn_deriv_body, r1())
+              ab[i] = dx[i] + dt * du[D::NCM + (i - NV) - 6];
+              continue;
+            }
           const double * Ar = lq + D::O_A + i * NDX;
           const double * Br = lq + D::O_B + i * NU;
           double acc = 0.0;
