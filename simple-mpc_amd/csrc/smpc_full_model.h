@@ -79,7 +79,10 @@ namespace smpc
     static constexpr int O_lpd = O_lu + NU;
     static constexpr int O_vpd = O_lpd + NDX;       // active ? 2 nu+ - nu : 0, all NC rows
     static constexpr int O_act = O_vpd + NC;        // 1.0 / 0.0 activity of all NC rows (box rows, then the dense cone rows)
-    static constexpr int LQ_STRIDE = ((O_act + NC + 7) / 8) * 8;
+    // 1.0 while the dense cone rows [Cd | Dd] of this block hold a nonzero row (fdyn_deriv_body: a stage without an active cone row writes its rows --
+    // zeros -- only over a block that is not zero already; fresh allocations are zero-filled)
+    static constexpr int O_cdirty = O_act + NC;
+    static constexpr int LQ_STRIDE = ((O_cdirty + 1 + 7) / 8) * 8;
     // gains block per (instance, stage)
     static constexpr int G_K = 0;                          // [K k]  NU x (NDX+1)
     static constexpr int G_Z = G_K + NU * (NDX + 1);       // [Z z]  NCD x (NDX+1)  (multiplier feedback of the dense rows)
