@@ -2294,7 +2294,7 @@ namespace smpc
     const int snext = ring_slot(ka.head, term ? t : t + 1, R);
     const double preg = b.scal[(size_t)inst * SC_N + SC_PREG];
     // (flag of the knot's dense cone rows, asked for here -- a scalar load -- and used at the end of the block)
-    const bool cone_block_dirty = (D::NCONE > 0 && !D::KINO && !term) ? b.lq[((size_t)inst * H + t) * D::LQ_STRIDE + D::O_cdirty] != 0.0 : false;
+    const bool cone_block_dirty = (D::NCONE > 0 && !term) ? b.lq[((size_t)inst * H + t) * D::LQ_STRIDE + D::O_cdirty] != 0.0 : false;
     const unsigned mask = term ? 0u : (b.stages[t].mask & ((1u << NF) - 1u));
     const unsigned land = (D::NLAND > 0 && !term && mg.land_cstr) ? (b.stages[t].land & mask) : 0u; // feet with land_cstr rows at this stage
     // ---- block inputs ----
@@ -2725,11 +2725,10 @@ namespace smpc
     if constexpr (D::NCONE > 0)
     {
       // dense cone rows of the knot: A_cone d lam / d(x, u) for the active rows, zero otherwise
-      // (full dynamics: a stage without an active row -- the common case: soles flat on the ground -- would write 34 x 78 zeros over zeros; the
+      // (a stage without an active row -- the common case: soles flat on the ground -- would write 34 x 78 zeros over zeros; the
       //  block's flag says whether it holds anything else, and the phase is skipped when neither it nor this stage does.  The block's content
       //  is what the unconditional form leaves; the sweep's light grid never reads it in such a stage.)
       bool cone_rows = true;
-      if constexpr (!D::KINO)
       {
         unsigned any = 0u;
         for (int i = 0; i < D::NCONE; i++) // (wave-uniform: every lane reads the same flags)
