@@ -48,7 +48,8 @@ namespace smpc
     static constexpr int O_lpd = O_lu + NU;
     static constexpr int O_vpd = O_lpd + NDX;
     static constexpr int O_act = O_vpd + NC;
-    static constexpr int LQ_STRIDE = ((O_act + NC + 7) / 8) * 8;
+    static constexpr int O_cdirty = O_act + NC;    // 1.0 while the dense rows [C | D] of this block hold a nonzero entry (cent6_deriv_body; allocations are zero-filled)
+    static constexpr int LQ_STRIDE = ((O_cdirty + 1 + 7) / 8) * 8;
     static constexpr int G_K = 0;
     static constexpr int G_Z = G_K + NU * (NDX + 1);
     static constexpr bool PT_PACKED = false; // (P~ as a full NDX x NDX image: cent6_forward_body reads rows of it)
@@ -258,6 +259,8 @@ namespace smpc
     const int st = ring_slot(head, t, R), st1 = ring_slot(head, term ? t : t + 1, R), stm = ring_slot(head, t > 0 ? t - 1 : 0, R);
     const unsigned mask = term ? 0u : b.stages[t].mask;
     const double preg = b.scal[inst * SC_N + SC_PREG];
+    // (flag of the knot's dense rows: a scalar load here, used where the knot is written)
+    const bool dense_dirty = term ? false : ka.sb.lq[(inst * H + t) * DD::LQ_STRIDE + DD::O_cdirty] != 0.0;
     double * parts = ka.parts0 + (inst * (H + 1) + t) * 4;
     // every global load of the block's inputs before the first commit to LDS (indices clamped, the terminal node reads stage 0's shared
     // entries and does not use them): written as one loop per array the phase was a chain of memory round trips per block
@@ -568,14 +571,26 @@ namespace smpc
           rv += s.J[r * NXU + 9 + i] * s.WJ[r * NXU + 9 + k];
         lq[DD::O_R + idx] = rv;
       }
-      // dense rows: C = 0, D = A_cone on the wrench of the foot for the active rows
-      for (int idx = lane; idx < NC * NP; idx += NT)
-        lq[DD::O_C + idx] = 0.0;
-      for (int idx = lane; idx < NC * NU; idx += NT)
+      // dense rows: C = 0, D = A_cone on the wrench of the foot for the active rows.  A stage without an active row (soles flat on the ground:
+      // most of them) would write 34 x 24 zeros over a block that is zero already: the block's flag says whether it holds anything else, and
+      // the rows are written only if it or this stage does -- the content is what the unconditional form leaves (45 % of the knot's doubles;
+      // the sweep's light grid never reads them in such a stage)
+      double anya = 0.0;
+      for (int row = 0; row < NC; row++) // (every lane reads the same flags)
+        anya += s.act[row];
+      const bool any_dense = anya != 0.0;
+      if (any_dense || dense_dirty)
       {
-        const int row = idx / NU, k = idx % NU, f = row / 17, r = row % 17;
-        lq[DD::O_D + idx] = (s.act[row] != 0.0 && k / 6 == f) ? wrench_cone_entry(r, k % 6, md.mu_fric, md.Lfoot, md.Wfoot) : 0.0;
+        for (int idx = lane; idx < NC * NP; idx += NT)
+          lq[DD::O_C + idx] = 0.0;
+        for (int idx = lane; idx < NC * NU; idx += NT)
+        {
+          const int row = idx / NU, k = idx % NU, f = row / 17, r = row % 17;
+          lq[DD::O_D + idx] = (s.act[row] != 0.0 && k / 6 == f) ? wrench_cone_entry(r, k % 6, md.mu_fric, md.Lfoot, md.Wfoot) : 0.0;
+        }
       }
+      if (any_dense != dense_dirty && lane == 0)
+        lq[DD::O_cdirty] = any_dense ? 1.0 : 0.0;
       // vectors
       if (lane < NP)
       {
